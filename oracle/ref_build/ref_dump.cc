@@ -1,0 +1,328 @@
+// ref_dump -- golden-vector generator.  TEST INFRASTRUCTURE ONLY.
+//
+// Our own harness (no reference code in it) that links against the compiled
+// reference objects (oracle/ref_build/Makefile) and drives the reference's
+// public Aln2 surface (aln.h:348-357) and its SimdAln2s1 engine class
+// (fwd2s1_simd.h:65-349) on one (genomic window, query) pair, then writes
+//   * the complete read-only DP context the engines consumed (codes, splice
+//     signals, substitution matrix, gap / intron parameters, band), and
+//   * what the reference produced (raw engine scores, SKL corner lists, UDH
+//     cpos rows, rescored totals)
+// as a flat little-endian "SPDG" container that tests/ read with numpy.
+//
+// It runs only in the build container (needs /root/reference); the fixtures it
+// writes are committed under tests/golden/ together with the driver script.
+//
+// usage: ref_dump [opts] genome.fa query.fa out.spdg
+//   -l N     alprm.ls (2 affine, 3 double affine)      -w N   band shoulder alprm.sh
+//   -L       local (-LS)                               -g ab  exg flags: 4 chars 0/1
+//                                                              a.exgl a.exgr b.exgl b.exgr
+//   -U N     forced #intermediates for UDH (alprm.ubh) -V N   MaxVmfSpace bytes
+//   -q N     IntronPrm.nquant override                 -T dir species table (AlnParam not parsed)
+//   -u list  extra explicit UDH runs with these n_im (comma separated)
+
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include "aln.h"
+#include "utilseq.h"
+#include "wln.h"
+#include "vmf.h"
+#include "gsinfo.h"
+#include "fwd2s1_simd.h"
+
+extern	int	MaxVmfSpace;
+
+// ---------------------------------------------------------------- container
+struct Writer {
+	FILE*	fd;
+	explicit Writer(const char* fn) {
+	    fd = fopen(fn, "wb");
+	    if (!fd) { perror(fn); exit(1); }
+	    fwrite("SPDG1\0\0\0", 1, 8, fd);
+	}
+	~Writer() { fclose(fd); }
+	// dtype: 1 u8, 2 i16, 3 i32, 4 i8
+	void put(const char* name, unsigned dtype, const void* p, size_t cnt) {
+	    static const int esz[5] = {0, 1, 2, 4, 1};
+	    char	nm[32];
+	    memset(nm, 0, sizeof(nm));
+	    strncpy(nm, name, 31);
+	    fwrite(nm, 1, 32, fd);
+	    unsigned	hd[2] = {dtype, (unsigned) cnt};
+	    fwrite(hd, 4, 2, fd);
+	    size_t	nb = cnt * esz[dtype];
+	    if (nb) fwrite(p, 1, nb, fd);
+	    static const char zero[8] = {0};
+	    if (nb % 8) fwrite(zero, 1, 8 - nb % 8, fd);
+	}
+	void put_i32(const char* name, const std::vector<int>& v) {
+	    put(name, 3, v.data(), v.size());
+	}
+	void put_int(const char* name, int x) { put(name, 3, &x, 1); }
+};
+
+static void set_default_params()	// same calls, same order as the CLI default set-up (spaln.cc:1471-1494)
+{
+	algmode.lcl = 15;
+	alprm.ls = 2;
+	algmode.lsg = 1;
+	algmode.qck = 3;
+	algmode.mlt = 0;
+	algmode.mns = 3;
+	algmode.thr = 1;
+	setalgmode(4, 0);
+	setNpam(4, -6);
+	setpam(100, 0);			// intra-species PAM (spaln.cc:49)
+	setpam(150, 1);			// cross-species PAM (spaln.cc:50)
+	setpam(50, WlnPamNo);		// HSP-search PAM (spaln.cc:51)
+	setorf(75, 2);			// default ORF length (spaln.cc:52)
+	OutPrm.MaxOut = 1;
+	OutPrm.SkipLongGap = 1;
+	OutPrm.fastanno = 1;
+	alprm.scale = 10;
+}
+
+static std::vector<int> skl2vec(const SKL* skl)
+{
+	std::vector<int>	v;
+	if (!skl) return v;
+	v.push_back(skl->m);		// flags
+	v.push_back(skl->n);		// #corners
+	for (int i = 1; i <= skl->n; ++i) {
+	    v.push_back(skl[i].m);
+	    v.push_back(skl[i].n);
+	}
+	return v;
+}
+
+int main(int argc, const char** argv)
+{
+	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0;
+	long	vmfspace = 0;
+const	char*	exg = 0;
+	std::vector<int>	udh_list;
+	int	ai = 1;
+	for ( ; ai < argc && argv[ai][0] == '-'; ++ai) {
+	    switch (argv[ai][1]) {
+		case 'l': ls = atoi(argv[++ai]); break;
+		case 'w': sh = atoi(argv[++ai]); break;
+		case 'L': local = 1; break;
+		case 'g': exg = argv[++ai]; break;
+		case 'U': ubh = atoi(argv[++ai]); break;
+		case 'V': vmfspace = atol(argv[++ai]); break;
+		case 'q': nquant = atoi(argv[++ai]); break;
+		case 'u': {
+		    const char* p = argv[++ai];
+		    while (*p) {
+			udh_list.push_back(atoi(p));
+			while (*p && *p != ',') ++p;
+			if (*p == ',') ++p;
+		    }
+		    break;
+		}
+		default: fprintf(stderr, "bad option %s\n", argv[ai]); return 1;
+	    }
+	}
+	if (argc - ai < 3) {
+	    fprintf(stderr, "usage: ref_dump [opts] genome.fa query.fa out.spdg\n");
+	    return 1;
+	}
+const	char*	files[2] = {argv[ai], argv[ai + 1]};
+const	char*	outfn = argv[ai + 2];
+
+	set_default_params();
+	optimize(GLOBAL, MAXIMUM);
+	algmode.qck = 0;		// -Q0: whole window through lspS_ng
+	algmode.blk = 0;
+	alprm.ls = ls;
+	alprm.sh = sh;
+	alprm.ubh = ubh;
+	if (local) algmode.lcl |= 16;
+	if (vmfspace) MaxVmfSpace = (int) vmfspace;
+	if (nquant) IntronPrm.nquant = nquant;
+	OutPrm.all_out = 1;
+
+	Seq*	seqs[4];
+	initseq(seqs, 4);
+	Seq*&	a = seqs[0];
+	Seq*&	b = seqs[1];
+	SeqServer	svr(2, files, IM_SNGL, 0, UNKNOWN, UNKNOWN);
+	if (svr.nextseq(b, 1) == IS_END) { fprintf(stderr, "no genome\n"); return 1; }
+	if (svr.nextseq(a, 0) != IS_OK) { fprintf(stderr, "no query\n"); return 1; }
+	b->inex.intr = algmode.lsg;
+	makeWlprms(prePwd((const Seq**) seqs));
+	algmode.alg = 2;		// IntronPenalty builds the quantile table qm only when alg > 1 (codepot.cc:162)
+	PwdB*	pwd = new PwdB((const Seq**) seqs);
+	makeStdSig53();
+	a->inex.intr = 0;
+	a->inex.ori = 1;
+	if (algmode.lcl & 16) {
+	    a->exg_seq(1, 1);
+	    b->exg_seq(1, 1);
+	} else {
+	    a->exg_seq(algmode.lcl & 4, algmode.lcl & 8);
+	    b->exg_seq(algmode.lcl & 1, algmode.lcl & 2);
+	}
+	if (exg) {
+	    a->exg_seq(exg[0] == '1', exg[1] == '1');
+	    b->exg_seq(exg[2] == '1', exg[3] == '1');
+	}
+	b->exin = new Exinon(b, pwd, false);
+
+	Writer	w(outfn);
+// ---- inputs
+	w.put("a_codes", 1, a->at(0), a->len);
+	w.put("b_codes", 1, b->at(0), b->len);
+	{
+	    std::vector<short>	s5(b->len + 1, 0), s3(b->len + 1, 0);
+	    std::vector<signed char> p5(b->len + 1, -2), p3(b->len + 1, -2);
+	    std::vector<unsigned char> c5(b->len + 1, 0), c3(b->len + 1, 0);
+	    for (int n = b->left; n <= b->right; ++n) {
+		const SGPT2* sg = b->exin->score_n(n);
+		s5[n] = sg->sig5; s3[n] = sg->sig3;
+		p5[n] = sg->phs5; p3[n] = sg->phs3;
+		c5[n] = b->exin->isDonor(n);
+		c3[n] = b->exin->isAccpt(n);
+	    }
+	    w.put("sig5", 2, s5.data(), s5.size());
+	    w.put("sig3", 2, s3.data(), s3.size());
+	    w.put("phs5", 4, p5.data(), p5.size());
+	    w.put("phs3", 4, p3.data(), p3.size());
+	    w.put("cano5", 1, c5.data(), c5.size());
+	    w.put("cano3", 1, c3.data(), c3.size());
+	}
+	{
+	    const Simmtx* sm = pwd->simmtx;
+	    std::vector<int>	mtx(sm->dim * sm->dim);
+	    for (int i = 0; i < sm->dim; ++i)
+		for (int j = 0; j < sm->dim; ++j) mtx[i * sm->dim + j] = sm->mtx[i][j];
+	    w.put_int("mtx_dim", sm->dim);
+	    w.put_i32("mtx", mtx);
+	    w.put_int("avmch", (int) sm->AvTrc());
+	}
+	{
+	    std::vector<int> prm = {
+		(int) pwd->BasicGOP, (int) pwd->BasicGEP, (int) pwd->LongGOP, (int) pwd->LongGEP,
+		pwd->Noll, (int) pwd->Vthr, (int) pwd->Vab, pwd->codonk1,
+		IntronPrm.llmt, IntronPrm.minl, IntronPrm.rlmt, IntronPrm.mu,
+		IntronPrm.maxl, IntronPrm.nquant, (int) IntronPrm.hard_minl, (int) IntronPrm.hard_maxl,
+		(int) pwd->IntPen->Penalty(), alprm.sh, (int) (algmode.lcl & 16),
+		(int) a->inex.exgl, (int) a->inex.exgr, (int) b->inex.exgl, (int) b->inex.exgr,
+		a->left, a->right, b->left, b->right, MaxVmfSpace, alprm.ubh,
+		(int) b->inex.intr};
+	    w.put_i32("params", prm);
+	    std::vector<int>	ql, qp;
+	    for (int j = 0; j < IntronPrm.nquant; ++j) {
+		ql.push_back(pwd->IntPen->qm[j].len);
+		qp.push_back(pwd->IntPen->qm[j].pen);
+	    }
+	    w.put_i32("qm_len", ql);
+	    w.put_i32("qm_pen", qp);
+	    // exact intron-length penalty materialised for every length that can occur
+	    std::vector<int>	ip(b->len + 2);
+	    for (int l = 0; l < (int) ip.size(); ++l)
+		ip[l] = (l <= IntronPrm.mu)? SHRT_MIN: pwd->IntPen->Penalty(l);
+	    w.put_i32("intpen", ip);
+	}
+
+// ---- reference results
+const	RANGE	ra = {a->left, a->right};
+const	RANGE	rb = {b->left, b->right};
+const	INEX	ia = a->inex, ib = b->inex;
+const	int	nq0 = IntronPrm.nquant;
+	auto restore = [&]() {
+	    a->left = ra.left; a->right = ra.right;
+	    b->left = rb.left; b->right = rb.right;
+	    a->inex = ia; b->inex = ib;
+	};
+	char	nm[48];
+
+// (1) engine-level goldens straight from SimdAln2s1, the _wip engines
+//     (fwd2s1_wip_simd.h:42,233,476).  tag qn: nquant as configured (what -A2
+//     runs), tag q1: nquant = 1 (what -A3 runs, fwd2s1.cc:125).
+	for (int pass = 0; pass < 2; ++pass) {
+	    IntronPrm.nquant = pass? 1: nq0;
+const	    char*	tag = pass? "q1": "qn";
+	    SpJunc	spjcs(b, pwd);
+	    WINDOW	wdw;
+	    restore();
+	    stripe((const Seq**) seqs, &wdw, alprm.sh);
+	    if (pass == 0) {
+		std::vector<int> wv = {wdw.lw, wdw.up, wdw.width};
+		w.put_i32("wdw", wv);
+	    }
+	    {	// score only (mode 1 as HomScoreS_ng passes for simd > 1, fwd2s1.cc:2709)
+		SimdAln2s1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, 1);
+		VTYPE	s = eng.scoreonlyS1_wip();
+		snprintf(nm, sizeof nm, "wip_%s_score", tag);
+		w.put_int(nm, (int) s);
+	    }
+	    {	// forward + bitmap traceback (mode 1, trcbkalignS_ng fwd2s1.cc:1682-1684)
+		restore();
+		Mfile	mfd(sizeof(SKL));
+		SimdAln2s1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, 1, 0);
+		VTYPE	s = eng.forwardS1_wip(&mfd);
+		snprintf(nm, sizeof nm, "wip_%s_fwd_scr", tag);
+		w.put_int(nm, (int) s);
+		int	nrec = (int) mfd.size();
+		SKL*	rec = (SKL*) mfd.flush();
+		std::vector<int> v;
+		for (int i = 0; i < nrec; ++i) { v.push_back(rec[i].m); v.push_back(rec[i].n); }
+		snprintf(nm, sizeof nm, "wip_%s_fwd_skl", tag);
+		w.put_i32(nm, v);
+		delete[] rec;
+	    }
+	    for (size_t u = 0; u < udh_list.size(); ++u) {	// UDH with explicit n_im
+const		int	n_im = udh_list[u];
+		restore();
+		stripe((const Seq**) seqs, &wdw, alprm.sh);
+const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4;	// fwd2s1.cc:1867
+		Dim10*	cpos = new Dim10[n_im + 1];
+		for (int i = 0; i <= n_im; ++i) {
+		    for (int c = 0; c < 10; ++c) cpos[i][c] = 0;
+		    cpos[i][0] = cpos[i][2] = end_of_ulk;
+		}
+		SimdAln2s1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, mode);
+		VTYPE	s = eng.hirschbergS1_wip(cpos, n_im);
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_scr", tag, n_im);
+		w.put_int(nm, (int) s);
+		std::vector<int> v;
+		for (int i = 0; i <= n_im; ++i)
+		    for (int c = 0; c < 10; ++c) v.push_back(cpos[i][c]);
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_cpos", tag, n_im);
+		w.put_i32(nm, v);
+		std::vector<int> rngs = {a->left, a->right, b->left, b->right, mode};
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_rng", tag, n_im);
+		w.put_i32(nm, rngs);
+		delete[] cpos;
+	    }
+	}
+	IntronPrm.nquant = nq0;
+
+// (2) the Aln2 surface per engine selector -A0..3 (algmode.alg & 3, fwd2s1.cc:112).
+//     -A3 goes last: its Aln2s1 ctor sets IntronPrm.nquant = 1 for good.
+	for (int alg = 0; alg < 4; ++alg) {
+	    algmode.alg = alg;
+	    restore();
+	    VTYPE	hs = HomScoreS_ng((const Seq**) seqs, pwd);
+	    snprintf(nm, sizeof nm, "hom_scr_A%d", alg);
+	    w.put_int(nm, (int) hs);
+	    restore();
+	    Gsinfo	gsi;
+	    gsi.skl = alignS_ng(seqs, pwd, &gsi, 1);
+	    snprintf(nm, sizeof nm, "aln_scr_A%d", alg);
+	    w.put_int(nm, (int) gsi.scr);
+	    snprintf(nm, sizeof nm, "aln_skl_A%d", alg);
+	    w.put_i32(nm, skl2vec(gsi.skl));
+	    if (gsi.skl && gsi.skl->n) {
+		restore();
+		VTYPE	rs = skl_rngS_ng((const Seq**) seqs, &gsi, pwd);
+		snprintf(nm, sizeof nm, "rng_scr_A%d", alg);
+		w.put_int(nm, (int) rs);
+	    }
+	}
+	return 0;
+}

@@ -1,0 +1,146 @@
+/* spdp.h -- C ABI of the MI355X spliced-alignment DP engine (libspdp_hip.so).
+ *
+ * Drop-in boundary for the fine-alignment path of ogotoh/spaln v3.0.7.  The
+ * reference has no FFI layer; the surface a binding replaces is
+ *   - the free functions declared in src/aln.h:348-357
+ *       VTYPE HomScoreS_ng(const Seq* seqs[], const PwdB* pwd)      src/fwd2s1.cc:2696
+ *       SKL*  alignS_ng(Seq* seqs[], const PwdB*, Gsinfo*, int ori) src/fwd2s1.cc:2746
+ *   - the engine object they construct:  SimdAln2s1(seqs, pwd, wdw, spjcs, cip, mode, vmf)
+ *       src/fwd2s1_simd.h:191, with methods
+ *       scoreonlyS1_wip()            src/fwd2s1_wip_simd.h:42
+ *       forwardS1_wip(Mfile*)        src/fwd2s1_wip_simd.h:233
+ *       hirschbergS1_wip(cpos, n_im) src/fwd2s1_wip_simd.h:476
+ *   - the dispatch between them: Aln2s1::lspS_ng / trcbkalignS_ng / mimd_postwork
+ *       src/fwd2s1.cc:1801 / 1667 / 1714.
+ * Every pointer below is plain host memory unless the name says "_dev".
+ * Plain C types only; no C++/torch types cross this boundary.
+ *
+ * A "problem" is everything one DP call of the reference reads (SURVEY.md §8a
+ * row a18): residue codes of both sequences, the active sub-ranges, the
+ * per-genome-position splice signals, substitution matrix, gap and intron
+ * parameters, band and end-gap flags.  Positions are absolute (the reference's
+ * Seq::left/right convention): DP row m in (a_left, a_right] is residue
+ * a[m-1]; DP column n in (b_left, b_right] is b[n-1]; sig5/sig3 are indexed by
+ * n in [b_left, b_right].
+ */
+#ifndef SPDP_H_
+#define SPDP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPDP_MAX_QUANT   8
+#define SPDP_NEVSEL      (INT32_MIN / 16 * 7)   /* "no alignment", src/cmn.h:79 NEVSEL   */
+#define SPDP_END_OF_ULK  (INT32_MAX - 2)        /* src/aln.h:49 end_of_ulk              */
+#define SPDP_REF_NELEM   16                     /* int16 lanes of the AVX2 reference build */
+
+/* scoring bundle shared by many problems: the PwdB / IntronPenalty / Simmtx
+ * subset the _wip engines read (src/aln.h:235-308, src/codepot.h:223-257). */
+typedef struct SpdpScoring {
+    int32_t mtx_dim;                 /* Simmtx::dim (17 = NSIMD for DNA)                 */
+    int32_t mtx[32 * 32];            /* row-major mtx[a * mtx_dim + b]                   */
+    int32_t gop, gep;                /* PwdB::BasicGOP, BasicGEP (both <= 0)             */
+    int32_t lgop, lgep;              /* PwdB::LongGOP, LongGEP                           */
+    int32_t noll;                    /* PwdB::Noll: 2 affine, 3 double affine            */
+    int32_t spj;                     /* b->inex.intr: splice-aware                       */
+    int32_t llmt;                    /* IntronPrm.llmt: introns need hil > llmt          */
+    int32_t ipen;                    /* IntronPenalty::Penalty() = GapWI, added to sig5  */
+    int32_t nquant;                  /* IntronPrm.nquant (1 = flat, the -A3 model)       */
+    int32_t qm_len[SPDP_MAX_QUANT];  /* IntronPenalty::qm[j].len                         */
+    int32_t qm_pen[SPDP_MAX_QUANT];  /* IntronPenalty::qm[j].pen                         */
+    int32_t local;                   /* algmode.lcl & 16                                 */
+    int32_t sh;                      /* alprm.sh band shoulder used by stripe()          */
+    int32_t max_vmf_space;           /* MaxVmfSpace (src/vmf.h:27), traceback/UDH switch */
+    int32_t ubh;                     /* alprm.ubh: forced #intermediates, 0 = automatic  */
+    int32_t ref_nelem;               /* stripe height of the reference build to reproduce */
+} SpdpScoring;
+
+typedef struct SpdpProblem {
+    const uint8_t* a;  int32_t a_len;      /* query codes, a[0 .. a_len)                 */
+    const uint8_t* b;  int32_t b_len;      /* genomic codes                              */
+    const int16_t* sig5;                   /* SGPT2::sig5 per position, index 0 .. b_len */
+    const int16_t* sig3;                   /* SGPT2::sig3                                */
+    int32_t a_left, a_right;               /* active ranges (Seq::left / right)          */
+    int32_t b_left, b_right;
+    uint8_t a_exgl, a_exgr, b_exgl, b_exgr;/* Seq::inex.exgl / exgr (free end gaps)      */
+} SpdpProblem;
+
+typedef struct SpdpWindow { int32_t lw, up, width; } SpdpWindow;   /* WINDOW, src/cmn.h:133 */
+typedef struct SpdpSkl { int32_t m, n; } SpdpSkl;                  /* SKL,    src/cmn.h:130 */
+
+/* result of an alignment call: corner list in the reference's SKL format
+ * (skl[0].n = number of corners, skl[0].m = flags, corners follow start->end) */
+typedef struct SpdpAlignment {
+    int32_t  score;            /* gsi->scr: raw engine score, SPDP_NEVSEL on failure      */
+    int32_t  n_skl;            /* entries in skl[] including the header record, 0 = none */
+    SpdpSkl* skl;              /* owned by the library until spdp_free_alignments        */
+} SpdpAlignment;
+
+typedef struct SpdpContext SpdpContext;
+
+/* ---- lifetime -------------------------------------------------------- */
+/* Creates a context bound to HIP device `device` (fails, returning NULL, when
+ * no HIP device is available -- there is no CPU fallback). */
+SpdpContext* spdp_create(int device);
+void         spdp_destroy(SpdpContext* ctx);
+const char*  spdp_last_error(const SpdpContext* ctx);
+int          spdp_device_name(const SpdpContext* ctx, char* buf, int buflen);
+
+/* band of one problem: stripe(seqs, &wdw, sh), src/aln2.cc:156-176 */
+void spdp_stripe(const SpdpProblem* p, int sh, SpdpWindow* wdw);
+/* DP cells the reference loops visit for one call (SURVEY.md §8d, fwd2s1.cc:249-256) */
+int64_t spdp_cells(const SpdpProblem* p, const SpdpWindow* wdw);
+
+/* ---- engine level (SimdAln2s1 methods), batched ----------------------- */
+/* scoreonlyS1_wip over each problem with its own stripe() band.  scores[i]
+ * receives what the reference method returns. */
+int spdp_wip_scoreonly(SpdpContext* ctx, const SpdpScoring* sc,
+                       const SpdpProblem* probs, int n_probs, int32_t* scores);
+
+/* forwardS1_wip: score + the raw corner records the reference writes to its
+ * Mfile (end -> start order, before stdskl/trimskl).  out[i].skl holds the
+ * records without header; out[i].n_skl their count. */
+int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc,
+                     const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+
+/* hirschbergS1_wip with n_im intermediate rows: cpos[i] points at
+ * (n_im + 1) * 10 ints (Dim10 rows, src/udh_intermediate.h:90); ranges[i*4..]
+ * receives the written-back a_left, a_right, b_left, b_right. */
+int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc,
+                 const SpdpProblem* probs, int n_probs, int n_im,
+                 int32_t* scores, int32_t* cpos, int32_t* ranges);
+
+/* ---- Aln2 surface, batched --------------------------------------------- */
+/* HomScoreS_ng for -A2/-A3 (simd > 1): stripe() then scoreonlyS1_wip. */
+int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc,
+                    const SpdpProblem* probs, int n_probs, int32_t* scores);
+
+/* alignS_ng with a fixed orientation (ori = 1) and seeding off (-Q0/-Q4):
+ * stripe() -> lspS_ng decision ladder -> traceback or multi-intermediate UDH
+ * + per-slab traceback -> stdskl -> trimskl. */
+int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc,
+                 const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+void spdp_free_alignments(SpdpAlignment* out, int n);
+
+/* ---- resident batches (benchmarking / pipelines) ------------------------ */
+/* Uploads a batch once; the run calls below then work on HBM-resident inputs
+ * (timed region excludes PCIe).  Returns NULL on failure. */
+typedef struct SpdpBatch SpdpBatch;
+SpdpBatch* spdp_batch_upload(SpdpContext* ctx, const SpdpScoring* sc,
+                             const SpdpProblem* probs, int n_probs);
+void       spdp_batch_free(SpdpBatch* bt);
+int64_t    spdp_batch_cells(const SpdpBatch* bt);
+/* one pass of HomScoreS_ng over the resident batch; scores copied out only if
+ * scores != NULL.  kernel_ms (optional) = HIP-event time of the DP kernel on
+ * the stream it was launched on. */
+int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms);
+int spdp_batch_align(SpdpBatch* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPDP_H_ */

@@ -1,0 +1,78 @@
+"""ctypes wrapper of liboracle.so (oracle/spdp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (spaln_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from spaln_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "spdp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _SO, src])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_cells.restype = C.c_int64
+    return _lib
+
+
+def stripe(p: abi.Problem, sh: int) -> abi.Window:
+    w = abi.Window()
+    lib().orc_stripe(C.byref(p), C.c_int(sh), C.byref(w))
+    return w
+
+
+def cells(p: abi.Problem, w: abi.Window) -> int:
+    return int(lib().orc_cells(C.byref(p), C.byref(w)))
+
+
+def wip_scoreonly(sc: abi.Scoring, p: abi.Problem, w: abi.Window | None = None) -> int:
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    rc = lib().orc_wip_scoreonly(C.byref(sc), C.byref(p), C.byref(w), C.byref(s))
+    if rc:
+        raise RuntimeError(f"orc_wip_scoreonly rc={rc}")
+    return s.value
+
+
+def wip_forward(sc, p, w=None):
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_wip_forward(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_wip_forward rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    C.CDLL(None).free(skl)
+    return s.value, out
+
+
+def wip_udh(sc, p, n_im: int, w=None):
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.zeros((n_im + 1, 10), dtype=np.int32)
+    cpos[:, 0] = abi.END_OF_ULK
+    cpos[:, 2] = abi.END_OF_ULK
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_wip_udh(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.byref(s),
+                           cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"orc_wip_udh rc={rc}")
+    return s.value, cpos, rng

@@ -19,6 +19,7 @@
 //                                                              a.exgl a.exgr b.exgl b.exgr
 //   -U N     forced #intermediates for UDH (alprm.ubh) -V N   MaxVmfSpace bytes
 //   -q N     IntronPrm.nquant override                 -T dir species table (AlnParam not parsed)
+//   -r al,ar,bl,br  restrict the active ranges (Seq::left/right) before the tables are built
 //   -u list  extra explicit UDH runs with these n_im (comma separated)
 
 #include <vector>
@@ -104,6 +105,7 @@ int main(int argc, const char** argv)
 	long	vmfspace = 0;
 const	char*	exg = 0;
 	std::vector<int>	udh_list;
+	int	rng4[4] = {-1, -1, -1, -1};
 	int	ai = 1;
 	for ( ; ai < argc && argv[ai][0] == '-'; ++ai) {
 	    switch (argv[ai][1]) {
@@ -114,6 +116,7 @@ const	char*	exg = 0;
 		case 'U': ubh = atoi(argv[++ai]); break;
 		case 'V': vmfspace = atol(argv[++ai]); break;
 		case 'q': nquant = atoi(argv[++ai]); break;
+		case 'r': sscanf(argv[++ai], "%d,%d,%d,%d", rng4, rng4 + 1, rng4 + 2, rng4 + 3); break;
 		case 'u': {
 		    const char* p = argv[++ai];
 		    while (*p) {
@@ -152,6 +155,7 @@ const	char*	outfn = argv[ai + 2];
 	SeqServer	svr(2, files, IM_SNGL, 0, UNKNOWN, UNKNOWN);
 	if (svr.nextseq(b, 1) == IS_END) { fprintf(stderr, "no genome\n"); return 1; }
 	if (svr.nextseq(a, 0) != IS_OK) { fprintf(stderr, "no query\n"); return 1; }
+	if (rng4[0] >= 0) { a->left = rng4[0]; a->right = rng4[1]; b->left = rng4[2]; b->right = rng4[3]; }
 	b->inex.intr = algmode.lsg;
 	makeWlprms(prePwd((const Seq**) seqs));
 	algmode.alg = 2;		// IntronPenalty builds the quantile table qm only when alg > 1 (codepot.cc:162)
@@ -222,10 +226,10 @@ const	char*	outfn = argv[ai + 2];
 	    w.put_i32("qm_len", ql);
 	    w.put_i32("qm_pen", qp);
 	    // exact intron-length penalty materialised for every length that can occur
-	    std::vector<int>	ip(b->len + 2);
+	    std::vector<short>	ip(b->len + 2);
 	    for (int l = 0; l < (int) ip.size(); ++l)
 		ip[l] = (l <= IntronPrm.mu)? SHRT_MIN: pwd->IntPen->Penalty(l);
-	    w.put_i32("intpen", ip);
+	    w.put("intpen", 2, ip.data(), ip.size());
 	}
 
 // ---- reference results

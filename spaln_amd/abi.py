@@ -1,0 +1,117 @@
+"""ctypes mirror of include/spdp.h (the C ABI of libspdp_hip.so).
+
+Pure declarations: structure layouts and helpers that fill them from numpy
+arrays.  Used by the host-side binding (spaln_amd/engine.py) and, for the
+struct layouts only, by the oracle's Python wrapper under oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+MAX_QUANT = 8
+NEVSEL = -(2 ** 31) // 16 * 7            # INT_MIN / 16 * 7 (C truncation: INT_MIN is divisible by 16)
+END_OF_ULK = 2 ** 31 - 1 - 2
+REF_NELEM = 16
+
+
+class Scoring(C.Structure):
+    _fields_ = [
+        ("mtx_dim", C.c_int32),
+        ("mtx", C.c_int32 * (32 * 32)),
+        ("gop", C.c_int32), ("gep", C.c_int32),
+        ("lgop", C.c_int32), ("lgep", C.c_int32),
+        ("noll", C.c_int32),
+        ("spj", C.c_int32),
+        ("llmt", C.c_int32),
+        ("ipen", C.c_int32),
+        ("nquant", C.c_int32),
+        ("qm_len", C.c_int32 * MAX_QUANT),
+        ("qm_pen", C.c_int32 * MAX_QUANT),
+        ("local", C.c_int32),
+        ("sh", C.c_int32),
+        ("max_vmf_space", C.c_int32),
+        ("ubh", C.c_int32),
+        ("ref_nelem", C.c_int32),
+    ]
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("a_len", C.c_int32),
+        ("b", C.c_void_p), ("b_len", C.c_int32),
+        ("sig5", C.c_void_p),
+        ("sig3", C.c_void_p),
+        ("a_left", C.c_int32), ("a_right", C.c_int32),
+        ("b_left", C.c_int32), ("b_right", C.c_int32),
+        ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
+        ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
+    ]
+
+
+class Window(C.Structure):
+    _fields_ = [("lw", C.c_int32), ("up", C.c_int32), ("width", C.c_int32)]
+
+
+class Skl(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("score", C.c_int32), ("n_skl", C.c_int32), ("skl", C.POINTER(Skl))]
+
+
+def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
+                 ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
+                 max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM) -> Scoring:
+    sc = Scoring()
+    sc.mtx_dim = int(mtx_dim)
+    flat = np.asarray(mtx, dtype=np.int32).ravel()
+    assert flat.size == mtx_dim * mtx_dim and mtx_dim <= 32
+    for i, v in enumerate(flat):
+        sc.mtx[i] = int(v)
+    sc.gop, sc.gep, sc.lgop, sc.lgep = int(gop), int(gep), int(lgop), int(lgep)
+    sc.noll, sc.spj, sc.llmt, sc.ipen = int(noll), int(spj), int(llmt), int(ipen)
+    nq = len(qm_len) if nquant is None else int(nquant)
+    assert 1 <= nq <= MAX_QUANT
+    sc.nquant = nq
+    for j in range(min(len(qm_len), MAX_QUANT)):
+        sc.qm_len[j] = int(qm_len[j])
+        sc.qm_pen[j] = int(qm_pen[j])
+    sc.local, sc.sh = int(local), int(sh)
+    sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
+    return sc
+
+
+class ProblemSet:
+    """Owns the numpy buffers a ctypes Problem array points into."""
+
+    def __init__(self):
+        self._keep = []
+        self.items = []
+
+    def add(self, a, b, sig5, sig3, a_left=0, a_right=None, b_left=0, b_right=None,
+            exg=(1, 1, 1, 1)):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        sig5 = np.ascontiguousarray(sig5, dtype=np.int16)
+        sig3 = np.ascontiguousarray(sig3, dtype=np.int16)
+        assert sig5.size >= b.size + 1 and sig3.size >= b.size + 1
+        self._keep += [a, b, sig5, sig3]
+        p = Problem()
+        p.a, p.a_len = a.ctypes.data, a.size
+        p.b, p.b_len = b.ctypes.data, b.size
+        p.sig5, p.sig3 = sig5.ctypes.data, sig3.ctypes.data
+        p.a_left, p.a_right = int(a_left), int(a.size if a_right is None else a_right)
+        p.b_left, p.b_right = int(b_left), int(b.size if b_right is None else b_right)
+        p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr = (int(x) for x in exg)
+        self.items.append(p)
+        return p
+
+    def __len__(self):
+        return len(self.items)
+
+    def array(self):
+        arr = (Problem * len(self.items))(*self.items)
+        self._keep.append(arr)
+        return arr

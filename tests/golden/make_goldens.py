@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container: it needs oracle/_ref/ref_dump (built by
+`make -C oracle/ref_build`, which compiles /root/reference in place) and the
+reference's parameter tables (ALN_TAB).  Each case is a deterministic synthetic
+(window, query) pair from spaln_amd.synth; the harness writes the DP inputs the
+reference engines consumed and everything they produced.  The .spdg files are
+data only (inputs + expected outputs) -- no reference source travels.
+
+    python tests/golden/make_goldens.py            # regenerate all
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from spaln_amd import synth  # noqa: E402
+
+REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+ALN_TAB = os.environ.get("ALN_TAB", "/tmp/spaln_ref_build/table")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def gene(seed, **kw):
+    rng = np.random.default_rng(synth.SEED + seed)
+    return synth.make_gene(rng, **kw)
+
+
+def random_pair(seed, m, n):
+    rng = np.random.default_rng(synth.SEED + seed)
+    return synth.random_dna(rng, n), synth.random_dna(rng, m)
+
+
+def cut(g, lo, hi):
+    """window cut through the gene: [lo, hi) of the original window"""
+    return g.window[lo:hi], g.query
+
+
+# name -> (window, query, harness options)
+def cases():
+    c = {}
+    g = gene(1, n_exons=5, mrna_len=600, flank=300, intron_hi=1500)
+    c["s1_basic"] = (g.window, g.query, ["-u", "1,2,3,5"])
+    g = gene(2, n_exons=8, mrna_len=1400, flank=500, intron_hi=1200)
+    c["s1_1400nt"] = (g.window, g.query, ["-u", "1,4,8", "-V", "4000000"])
+    g = gene(3, n_exons=1, mrna_len=300, flank=200)
+    c["s1_single_exon"] = (g.window, g.query, ["-u", "1,2"])
+    g = gene(4, n_exons=4, mrna_len=500, flank=250, intron_hi=900, sub=0.18, indel=0.02)
+    c["s1_divergent"] = (g.window, g.query, ["-u", "1,3", "-V", "500000"])
+    g = gene(5, n_exons=6, mrna_len=900, flank=400, intron_hi=800, sub=0.03, indel=0.01)
+    c["s1_indels"] = (g.window, g.query, ["-u", "2,6", "-V", "1000000"])
+    # window cut inside the gene: query overhangs the window on the left / right / both
+    g = gene(6, n_exons=5, mrna_len=700, flank=300, intron_hi=700)
+    e = g.exons
+    c["s1_cut_left"] = (*cut(g, e[1][0] + 40, len(g.window)), ["-u", "1,2,4"])
+    c["s1_cut_right"] = (*cut(g, 0, e[3][1] - 35), ["-u", "1,2,4"])
+    c["s1_cut_both"] = (*cut(g, e[0][1] - 23, e[4][0] + 57), ["-u", "1,3"])
+    # narrow band shoulder: the path runs along the band edges
+    g = gene(7, n_exons=3, mrna_len=400, flank=150, intron_hi=300)
+    c["s1_narrow_band"] = (g.window, g.query, ["-w", "8", "-u", "1,2"])
+    c["s1_narrow_cut"] = (*cut(g, g.exons[0][0] + 70, g.exons[2][1] - 50), ["-w", "12", "-u", "1,2"])
+    # end-gap flag combinations (a.exgl a.exgr b.exgl b.exgr)
+    g = gene(8, n_exons=3, mrna_len=300, flank=100, intron_hi=250)
+    for flags in ("0000", "1100", "0011", "1001", "0110"):
+        c[f"s1_exg_{flags}"] = (g.window, g.query, ["-g", flags, "-u", "1,2"])
+    c["s1_exg_0000_cut"] = (*cut(g, g.exons[0][0] + 20, g.exons[2][1] - 30), ["-g", "0000", "-u", "1,2"])
+    # local alignment (-LS)
+    g = gene(9, n_exons=4, mrna_len=500, flank=200, intron_hi=400, sub=0.05)
+    c["s1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
+    c["s1_local_cut"] = (*cut(g, g.exons[1][0] + 30, g.exons[3][1] - 40), ["-L", "-u", "1,3"])
+    # unrelated sequences, and tiny queries
+    w, q = random_pair(10, 250, 1800)
+    c["s1_random"] = (w, q, ["-u", "1,2"])
+    for m in (1, 3, 7, 8, 15, 16, 17, 33):
+        g = gene(20 + m, n_exons=1, mrna_len=max(m, 30), flank=60)
+        c[f"s1_tiny_m{m}"] = (g.window, g.query[:m], ["-u", "1"] if m > 2 else [])
+    # active sub-ranges of longer sequences (what UDH slabs look like)
+    g = gene(11, n_exons=5, mrna_len=800, flank=300, intron_hi=600)
+    e = g.exons
+    c["s1_subrange"] = (g.window, g.query,
+                        ["-r", f"120,640,{e[0][0] + 100},{e[4][0] + 20}", "-u", "1,2"])
+    c["s1_subrange_global"] = (g.window, g.query,
+                               ["-r", f"150,600,{e[1][0] - 10},{e[3][1] + 10}", "-g", "0000", "-u", "1,2,3"])
+    # flat intron penalty requested from the start, and forced UDH through the Aln2 surface
+    g = gene(12, n_exons=7, mrna_len=1000, flank=300, intron_hi=1000)
+    c["s1_forced_udh3"] = (g.window, g.query, ["-U", "3", "-V", "100000", "-u", "3"])
+    c["s1_auto_udh"] = (g.window, g.query, ["-V", "300000", "-u", "2"])
+    g = gene(13, n_exons=9, mrna_len=1450, flank=600, intron_hi=2500)
+    c["s1_1450nt_auto"] = (g.window, g.query, ["-V", "2000000", "-u", "5"])
+    return c
+
+
+def main():
+    if not os.path.exists(REF_DUMP):
+        sys.exit(f"{REF_DUMP} missing: run `make -C oracle/ref_build` first")
+    env = dict(os.environ, ALN_TAB=ALN_TAB)
+    only = set(sys.argv[1:])
+    with tempfile.TemporaryDirectory() as td:
+        for name, (window, query, opts) in cases().items():
+            if only and name not in only:
+                continue
+            gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
+            synth.write_fasta(gf, "win", window)
+            synth.write_fasta(qf, "qry", query)
+            out = os.path.join(OUT, name + ".spdg")
+            r = subprocess.run([REF_DUMP, *opts, gf, qf, out], env=env, capture_output=True, text=True)
+            status = "ok" if r.returncode == 0 else f"FAILED rc={r.returncode} {r.stderr[-300:]}"
+            print(f"{name:24s} m={len(query):5d} n={len(window):6d} {status}")
+            if r.returncode != 0 and os.path.exists(out):
+                os.remove(out)
+
+
+if __name__ == "__main__":
+    main()

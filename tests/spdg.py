@@ -1,0 +1,49 @@
+"""Reader for the SPDG golden-fixture container written by oracle/ref_build/ref_dump.cc."""
+from __future__ import annotations
+
+import struct
+import numpy as np
+
+from spaln_amd import abi
+
+_DT = {1: np.uint8, 2: np.int16, 3: np.int32, 4: np.int8}
+PARAM_NAMES = ["gop", "gep", "lgop", "lgep", "noll", "vthr", "vab", "codonk1",
+               "llmt", "minl", "rlmt", "mu", "maxl", "nquant", "hard_minl", "hard_maxl",
+               "ipen", "sh", "local", "a_exgl", "a_exgr", "b_exgl", "b_exgr",
+               "a_left", "a_right", "b_left", "b_right", "max_vmf_space", "ubh", "b_intr"]
+
+
+def load(path: str) -> dict:
+    raw = open(path, "rb").read()
+    assert raw[:5] == b"SPDG1", path
+    off, out = 8, {}
+    while off < len(raw):
+        name = raw[off:off + 32].split(b"\0")[0].decode()
+        off += 32
+        dt, cnt = struct.unpack("<II", raw[off:off + 8])
+        off += 8
+        nb = cnt * np.dtype(_DT[dt]).itemsize
+        out[name] = np.frombuffer(raw[off:off + nb], dtype=_DT[dt]).copy()
+        off += (nb + 7) // 8 * 8
+    out["prm"] = dict(zip(PARAM_NAMES, (int(x) for x in out["params"])))
+    return out
+
+
+def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
+    q = fx["prm"]
+    kw = dict(mtx=fx["mtx"], mtx_dim=int(fx["mtx_dim"][0]), gop=q["gop"], gep=q["gep"],
+              lgop=q["lgop"], lgep=q["lgep"], noll=q["noll"], spj=q["b_intr"], llmt=q["llmt"],
+              ipen=q["ipen"], qm_len=fx["qm_len"], qm_pen=fx["qm_pen"],
+              nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
+              sh=q["sh"], max_vmf_space=q["max_vmf_space"], ubh=q["ubh"])
+    kw.update(over)
+    return abi.make_scoring(**kw)
+
+
+def problem(fx: dict, ps: abi.ProblemSet | None = None):
+    q = fx["prm"]
+    ps = ps or abi.ProblemSet()
+    p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"],
+               q["a_left"], q["a_right"], q["b_left"], q["b_right"],
+               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]))
+    return ps, p

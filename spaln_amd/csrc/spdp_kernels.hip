@@ -1,0 +1,625 @@
+// spdp_kernels.hip -- CDNA4 (gfx950) kernels for the spliced-alignment DP of
+// ogotoh/spaln's `_wip` engines (reference: src/fwd2s1_wip_simd.h:42 / 233 / 476,
+// boundary set-up src/fwd2s1_simd.cc:163-262).  Written for wave64 / DPP rows;
+// no CUDA idiom, no MFMA (integer recurrence).
+//
+// Mapping.  The reference sweeps stripes of 16 query rows (AVX2 int16 lanes),
+// lane k of a stripe holding cell (m = ml+1+k, n-k) at sweep step n, and chains
+// stripes through per-diagonal arrays hv/fv.  A DPP row is exactly 16 lanes, so
+// one wave64 runs FOUR consecutive stripes of one problem at once: row g of
+// the wave is stripe 4*pass+g, started SPDP_GROUP_LAG blocks (64 columns) after
+// row g-1, so that every boundary value it needs has already been produced.
+// The up / up-left neighbour exchange is a single `row_shr:1` DPP move per
+// value; lane 0 of each row is fed from a 16-entry register chunk of the
+// boundary array by `row_shl:j`; the bottom lane's results are collected in a
+// register shift chain (`row_ror:1` + `row_shr:1`) and written back coalesced
+// every 16 steps.  Stripes keep the reference's exact geometry (band staircase,
+// out-of-window lanes, first-column rule), so results are those of the AVX2
+// build bit for bit -- with int32 scores instead of re-based int16 ones (adds
+// saturate at SHRT_MIN as _mm256_adds_epi16 does on the low side).
+//
+// One wave = one problem at a time; waves pull problems from an atomic queue.
+// HBM traffic per 64 rows x 1 column: 8 B column record (+3 L2 re-reads),
+// 8/16 B boundary read + 8/16 B boundary write; forward adds 1 B / cell of
+// traceback codes.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spdp_dev.h"
+#include "spdp_internal.h"
+
+enum { FL_SCORE = 0, FL_FORWARD = 1, FL_UDH = 2 };
+
+// TraceBackCode values (src/rhomb_coord.h:36-61)
+enum { TB_DIAG = 1, TB_HORI = 2, TB_VERT = 8, TB_ACCR = 14, TB_NHOR = 16, TB_NVER = 32, TB_DONR = 128 };
+
+#define END_OF_ULK (INT32_MAX - 2)
+
+#define DPP_ROW_SL(n) (0x100 + (n))
+#define DPP_ROW_SR(n) (0x110 + (n))
+#define DPP_ROW_RR(n) (0x120 + (n))
+
+// lane i of every 16-lane row <- lane i-1; lane 0 of the row keeps `old`
+__device__ __forceinline__ int row_shr1(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, DPP_ROW_SR(1), 0xf, 0xf, false);
+}
+// lane 0 of every row <- lane J of that row (other lanes: don't care)
+template <int J>
+__device__ __forceinline__ int row_pick(int src)
+{
+    if constexpr (J == 0) return src;
+    else return __builtin_amdgcn_update_dpp(0, src, DPP_ROW_SL(J), 0xf, 0xf, false);
+}
+// lane 0 of every row <- lane 15 of that row
+__device__ __forceinline__ int row_ror1(int src)
+{
+    return __builtin_amdgcn_update_dpp(0, src, DPP_ROW_RR(1), 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int sadd16(int a, int b) { return max(a + b, SPDP_FLOOR16); }
+
+
+// ---------------------------------------------------------------------------
+template <int FL, bool LOCAL>
+__global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
+{
+    constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
+    __shared__ int s_mtx[32 * 32];
+
+    const DevScoring* __restrict__ sc = A.sc;
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4;                    // DPP row = stripe slot of the pass
+    const int k = lane & 15;                    // lane within the stripe
+    const int ge = sc->gep, gn = sc->gep + sc->gop;
+    const int spj = sc->spj, llmt = sc->llmt, nquant = sc->nquant;
+    const int q0 = sc->qm_len[0], q1 = sc->qm_len[1], q2 = sc->qm_len[2], q3 = sc->qm_len[3],
+              q4 = sc->qm_len[4], q5 = sc->qm_len[5], q6 = sc->qm_len[6];
+    const int p0 = sc->qm_pen[0], p1 = sc->qm_pen[1], p2 = sc->qm_pen[2], p3 = sc->qm_pen[3],
+              p4 = sc->qm_pen[4], p5 = sc->qm_pen[5], p6 = sc->qm_pen[6], p7 = sc->qm_pen[7];
+
+    for (;;) {
+        int pi = 0;
+        if (lane == 0) pi = atomicAdd(A.queue, 1);
+        pi = __builtin_amdgcn_readfirstlane(pi);
+        if (pi >= A.n_probs) break;
+        const DevProblem P = A.probs[pi];
+        const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
+        const int lw = P.lw, up = P.up, width = P.width;
+        const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
+        const bool LocalL = LOCAL && a_exgl && b_exgl;
+        const bool LocalR = LOCAL && a_exgr && b_exgr;
+        int* __restrict__ bnd = A.bnd + P.bnd_off * BW;
+        const int2* __restrict__ cols = A.cols + P.col_off;
+        const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
+        const int n_ent = P.buf_size + SPDP_BND_PAD;
+#define BIDX(r) ((r) - lw + 1)
+
+        // ---- fhinitS1 (src/fwd2s1_simd.cc:163-239): boundary values by diagonal
+        {
+            const int rl = b_left - a_left;
+            int rr = min(b_right - a_left, up);
+            int rr_g = rr;                                   // global: ramp stops where it reaches nevsel
+            if (!a_exgl && ge) rr_g = min(rr, (SPDP_NEV16 - sc->gop) / ge + rl);
+            const int ru = up + 2 * SPDP_NELEM;
+            for (int e = lane; e < n_ent; e += 64) {
+                const int r = e + lw - 1;
+                int h = SPDP_NEV16;
+                if (b_exgl && r >= lw && r < rl) h = 0;
+                if (a_exgl) { if (r >= rl && r <= rr) h = 0; }
+                else {
+                    if (r == rl) h = 0;
+                    else if (r == rl + 1) h = sc->gop + ge;
+                    else if (ge) { if (r > rl + 1 && r < rr_g) h = sc->gop + ge + (r - rl - 1) * ge; }
+                    else if (r > rl + 1 && r < rr) h = sc->gop;
+                }
+                if constexpr (FL == FL_UDH) {
+                    int c;                                   // link = diagonal where the path starts
+                    if (r >= rl) c = a_exgl ? ((r < ru) ? r : 0) : rl;
+                    else         c = b_exgl ? r : rl;
+                    if (r > ru) c = 0;
+                    reinterpret_cast<int4*>(bnd)[e] = make_int4(h, SPDP_NEV16, c, c);
+                } else {
+                    reinterpret_cast<int2*>(bnd)[e] = make_int2(h, SPDP_NEV16);
+                }
+            }
+            if constexpr (FL == FL_UDH) {
+                int* imd = A.imd + P.imd_off;
+                const int tot = P.n_im * 4 * width;
+                for (int e = lane; e < tot; e += 64) imd[e] = END_OF_ULK;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+
+        // UDH: intermediate rows (src/fwd2s1_wip_simd.h:503-508)
+        const int n_im = (FL == FL_UDH) ? P.n_im : 0;
+        const int imd_step = (FL == FL_UDH) ? (a_right - a_left + n_im) / (n_im + 1) : 0;
+        int imd_cur = 0;
+
+        // running maximum for local right ends: value, then first (stripe, step, lane)
+        int best_val = SPDP_NEV16, best_mr = a_right, best_nr = b_right, best_ml = a_left, best_ulk = END_OF_ULK;
+        unsigned long long best_key = ~0ull;
+
+        int64_t tb_base = P.tb_off;                         // forward: byte offset of the pass' first stripe
+        const int n_stripes = (a_right - a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+        for (int s0 = 0; s0 < n_stripes; s0 += 4) {
+            // ---- geometry of my stripe (row g of the wave)
+            const int s = s0 + g;
+            const int ml = a_left + s * SPDP_NELEM;
+            const bool has = s < n_stripes;
+            const int j9 = has ? min(SPDP_NELEM, a_right - ml) : 0;
+            const int j8 = j9 - 1;
+            const int n_start = max(b_left, lw + ml);
+            const int n9 = min(b_right, up + (ml + j9) + 1) + j9;
+            const int n_end = (FL == FL_FORWARD) ? n9 + 1 : n9;
+            const int len = has ? max(0, n_end - n_start) : 0;
+            const int nb = (len + 15) >> 4;
+            // blocks this pass runs: row g is active for blocks [LAG*g, LAG*g + nb)
+            int tot = SPDP_GROUP_LAG * g + nb;
+            tot = max(tot, __shfl_xor(tot, 16));
+            tot = max(tot, __shfl_xor(tot, 32));
+            // traceback offsets of the 4 stripes of this pass
+            int64_t my_tb = 0;
+            if constexpr (FL == FL_FORWARD) {
+                const int nb0 = __shfl(nb, 0), nb1 = __shfl(nb, 16), nb2 = __shfl(nb, 32), nb3 = __shfl(nb, 48);
+                my_tb = tb_base + 256ll * ((g > 0 ? nb0 : 0) + (g > 1 ? nb1 : 0) + (g > 2 ? nb2 : 0));
+                tb_base += 256ll * (nb0 + nb1 + nb2 + nb3);
+            }
+            // UDH: the reference walks its intermediates in order and tests, per stripe, only the
+            // current one (src/fwd2s1_wip_simd.h:527,806-811): replay that pointer over my 4 stripes
+            int imd_i = -1, k8 = -1;
+            if constexpr (FL == FL_UDH) {
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int ml_gg = a_left + (s0 + gg) * SPDP_NELEM;
+                    if (imd_cur < n_im && ml_gg < a_right) {
+                        const int cand = a_left + (imd_cur + 1) * imd_step;
+                        const int mm = a_left + (cand - a_left - 1) / SPDP_NELEM * SPDP_NELEM;
+                        if (mm == ml_gg) {
+                            if (gg == g) { imd_i = imd_cur; k8 = cand - mm - 1; }
+                            ++imd_cur;
+                        }
+                    }
+                }
+            }
+            const bool imd_row = (FL == FL_UDH) && imd_i >= 0;
+            int* imd_p = nullptr;
+            if constexpr (FL == FL_UDH) if (imd_row) imd_p = A.imd + P.imd_off + (int64_t) imd_i * 4 * width;
+
+            // my residue row of the substitution matrix (byte address in LDS)
+            const int acode = (k < j9) ? acod[ml + k] : 0;
+            const int* mrow = s_mtx + acode * 32;
+
+            // per-lane DP state
+            int Hs = SPDP_NEV16, Fs = SPDP_NEV16, E = SPDP_NEV16, Hd = SPDP_NEV16;
+            int hv2 = SPDP_NEV16, hil = 0, sigp = 0, basep = 0;
+            int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
+            int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
+            int pv_stale = 0; bool stale_on = false;                   // UDH Local first-column quirk (unused)
+            int outH = 0, outF = 0, outC = 0, outFC = 0;
+            (void) pv_stale; (void) stale_on;
+
+            for (int blk = 0; blk < tot; ++blk) {
+                const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
+                if (lb >= 0 && lb < nb) {
+                    const int n0 = n_start + lb * 16;                   // sweep step of j = 0
+                    if (lb == 0) {
+                        // stripe start: pipes are empty except the base pipe, and lane 0's
+                        // up-left neighbour comes from the boundary array
+                        const int c = n_start - 1 - k;                 // column lane k "had" one step before
+                        basep = (c > b_left && c <= b_right) ? cols[c - b_left].y : 0;
+                        const int r = n_start - (ml + 1);
+                        donor_r = r;
+                        if (k == 0) {
+                            Hd = bnd[(int64_t) BIDX(r) * BW];
+                            if constexpr (FL == FL_UDH) Cd = bnd[(int64_t) BIDX(r) * BW + 2];
+                        }
+                    }
+                    // ---- chunk loads: 16 boundary entries and 16 column records per stripe
+                    int chH, chF, chC = 0, chFC = 0;
+                    {
+                        const int r1 = n0 + k - ml;                     // r + 1 of step j = k
+                        if constexpr (FL == FL_UDH) {
+                            const int4 v = reinterpret_cast<const int4*>(bnd)[BIDX(r1)];
+                            chH = v.x; chF = v.y; chC = v.z; chFC = v.w;
+                        } else {
+                            const int2 v = reinterpret_cast<const int2*>(bnd)[BIDX(r1)];
+                            chH = v.x; chF = v.y;
+                        }
+                    }
+                    const int2 crec = cols[n0 + k - b_left];
+                    const int chS = spj ? crec.x : 0, chB = crec.y;
+                    uint32_t code4[4] = {0, 0, 0, 0};
+
+#define STEP(J)                                                                                  \
+                    {                                                                                        \
+                        const int n = n0 + J;                                                                \
+                        /* neighbour exchange */                                                             \
+                        const int upH = row_shr1(row_pick<J>(chH), Hs);                                      \
+                        const int upF = row_shr1(row_pick<J>(chF), Fs);                                      \
+                        sigp  = row_shr1(row_pick<J>(chS), sigp);                                            \
+                        basep = row_shr1(row_pick<J>(chB), basep);                                           \
+                        int upC = 0, upFC = 0;                                                               \
+                        if constexpr (FL == FL_UDH) {                                                        \
+                            upC  = row_shr1(row_pick<J>(chC), Cs);                                           \
+                            upFC = row_shr1(row_pick<J>(chFC), FCs);                                         \
+                        }                                                                                    \
+                        const int pv = mrow[basep];                                                          \
+                        int h, f, hc = 0, fc = 0;                                                            \
+                        unsigned code = 0; int pb3 = 0;                                                      \
+                        if constexpr (FL == FL_SCORE) {                                                      \
+                            E = max3i(E + ge, Hs + gn, SPDP_FLOOR16);                                        \
+                            f = max3i(upF + ge, upH + gn, SPDP_FLOOR16);                                     \
+                            h = max3i(Hd + pv, f, E);                                                        \
+                        } else {                                                                             \
+                            const int eo = sadd16(Hs, gn), ee = sadd16(E, ge);                               \
+                            const bool ext = ee > eo;                                                        \
+                            E = ext ? ee : eo;                                                               \
+                            if (!ext) { code |= TB_NHOR; ec = Cs; }                                          \
+                            const int fo = sadd16(upH, gn), fe = sadd16(upF, ge);                            \
+                            const bool fext = fe > fo;                                                       \
+                            f = fext ? fe : fo;                                                              \
+                            fc = fext ? upFC : upC;                                                          \
+                            if (!fext) code |= TB_NVER;                                                      \
+                            h = sadd16(Hd, pv); hc = Cd;                                                     \
+                            unsigned dir = TB_DIAG;                                                          \
+                            if (f > h) { h = f; hc = fc; dir = TB_VERT; pb3 = 2; }                           \
+                            if (E > h) { h = E; hc = ec; dir = TB_HORI; pb3 = 1; }                           \
+                            code |= dir;                                                                     \
+                        }                                                                                    \
+                        bool is_acc = false, is_don = false;                                                 \
+                        if (spj) {                                                                           \
+                            const int s3 = sigp >> 16;                                                       \
+                            const int s5 = (int) (short) sigp;                                               \
+                            int pen = p0;                                                                    \
+                            if (nquant > 1) {                                                                \
+                                pen = (hil > q0) ? p1 : pen;                                                 \
+                                if (nquant > 2) pen = (hil > q1) ? p2 : pen;                                 \
+                                if (nquant > 3) pen = (hil > q2) ? p3 : pen;                                 \
+                                if (nquant > 4) pen = (hil > q3) ? p4 : pen;                                 \
+                                if (nquant > 5) pen = (hil > q4) ? p5 : pen;                                 \
+                                if (nquant > 6) pen = (hil > q5) ? p6 : pen;                                 \
+                                if (nquant > 7) pen = (hil > q6) ? p7 : pen;                                 \
+                            }                                                                                \
+                            int x = sadd16(sadd16(hv2, s3), pen);                                            \
+                            x = (hil > llmt) ? x : SPDP_NEV16;                                               \
+                            if (x > h) {                                                                     \
+                                h = x; is_acc = true;                                                        \
+                                if constexpr (FL != FL_SCORE) { hc = hc2; code = (code & ~15u) | TB_ACCR; }  \
+                            }                                                                                \
+                            if (LOCAL && LocalL && h < 0) { h = 0; if constexpr (FL == FL_FORWARD) code &= 15u; } \
+                            int qd = sadd16(h, s5);                                                          \
+                            if constexpr (FL == FL_FORWARD) qd = is_acc ? SPDP_NEV16 : qd;                   \
+                            is_don = qd > hv2;                                                               \
+                            hv2 = is_don ? qd : hv2;                                                         \
+                            if constexpr (FL == FL_UDH) hc2 = is_don ? hc : hc2;                             \
+                            hil = min((is_don ? 0 : hil) + 1, 32767);                                        \
+                            if constexpr (FL == FL_FORWARD) code |= is_don ? TB_DONR : 0u;                   \
+                        } else if (LOCAL && LocalL && h < 0) {                                               \
+                            h = 0; if constexpr (FL == FL_FORWARD) code &= 15u;                              \
+                        }                                                                                    \
+                        Hd = upH; Hs = h; Fs = f;                                                            \
+                        if constexpr (FL == FL_UDH) { Cd = upC; Cs = hc; FCs = fc; }                         \
+                        if constexpr (FL == FL_FORWARD) {                                                    \
+                            if (k >= j9) code = 0;                                                           \
+                            code4[J >> 2] |= (code & 0xffu) << (8 * (J & 3));                                \
+                        }                                                                                    \
+                        if constexpr (FL == FL_UDH) {                                                        \
+                            /* scalar bookkeeping of the intermediate row (lane k8 of its stripe) */         \
+                            const int rj = n - (ml + 1) - 2 * k;            /* my cell's diagonal */         \
+                            if (imd_row && k == k8 && rj >= lw && rj <= up && n < n_end) {                   \
+                                int* hl0 = imd_p + BIDX(rj);                                                 \
+                                if (spj && is_acc) { hl0[0] = donor_r; hl0[width] = donor_r + width; rlst = rj; } \
+                                if (spj && is_don) donor_r = rj;                                             \
+                                if (pb3 == 0) rlst = rj;                                                     \
+                                if (pb3 == 1) hl0[0] = rlst;                                                 \
+                                hl0[2 * width] = Cs;  Cs = rj;                                               \
+                                hl0[3 * width] = FCs; FCs = rj + width;                                      \
+                            }                                                                                \
+                        }                                                                                    \
+                        if (LOCAL && LocalR) {                                                               \
+                            if (k < j9 && n < n_end && h >= best_val) {                                      \
+                                const unsigned long long key =                                               \
+                                    ((unsigned long long) s << 40) | ((unsigned long long) (n - n_start) << 8) | k; \
+                                if (h > best_val || key < best_key) {                                        \
+                                    best_val = h; best_key = key; best_mr = ml + k + 1; best_nr = n - k;     \
+                                    if constexpr (FL == FL_UDH) { best_ulk = Cs; }                           \
+                                }                                                                            \
+                            }                                                                                \
+                        }                                                                                    \
+                        /* bottom lane of the stripe -> output shift chain */                                \
+                        int bh = Hs, bf = Fs, bc = Cs, bfc = FCs;                                            \
+                        if (j9 < SPDP_NELEM && j9 > 0) {                                                     \
+                            const int src = (lane & 48) + j8;                                                \
+                            bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                      \
+                            if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); }    \
+                        }                                                                                    \
+                        outH = row_shr1(row_ror1(bh), outH);                                                 \
+                        outF = row_shr1(row_ror1(bf), outF);                                                 \
+                        if constexpr (FL == FL_UDH) {                                                        \
+                            outC  = row_shr1(row_ror1(bc), outC);                                            \
+                            outFC = row_shr1(row_ror1(bfc), outFC);                                          \
+                        }                                                                                    \
+                    }
+                    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
+                    STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
+#undef STEP
+                    // ---- flush: lane i holds the bottom-row result of step j = 15 - i
+                    {
+                        const int j = 15 - k;
+                        const int n = n0 + j;
+                        const int r0 = n - (ml + 1) - 2 * j8;
+                        if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
+                            if constexpr (FL == FL_UDH)
+                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] = make_int4(outH, outF, outC, outFC);
+                            else
+                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] = make_int2(outH, outF);
+                        }
+                    }
+                    if constexpr (FL == FL_FORWARD) {
+                        uint4* dst = reinterpret_cast<uint4*>(A.tb + my_tb + 256ll * lb + 16 * k);
+                        *dst = make_uint4(code4[0], code4[1], code4[2], code4[3]);
+                    }
+                }
+                // the next block's boundary loads must see this block's stores (same CU, same L1)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+
+        // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
+        DevResult R;
+        R.score = SPDP_NEV16; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = END_OF_ULK; R.maxr = 0;
+        R.pad[0] = R.pad[1] = 0;
+        if (LOCAL && LocalR) {
+            // reduce (value desc, key asc) over the wave
+            for (int off = 32; off; off >>= 1) {
+                const int ov = __shfl_xor(best_val, off);
+                const unsigned long long ok = __shfl_xor(best_key, off);
+                const int omr = __shfl_xor(best_mr, off), onr = __shfl_xor(best_nr, off);
+                const int oml = __shfl_xor(best_ml, off), oul = __shfl_xor(best_ulk, off);
+                if (ov > best_val || (ov == best_val && ok < best_key)) {
+                    best_val = ov; best_key = ok; best_mr = omr; best_nr = onr; best_ml = oml; best_ulk = oul;
+                }
+            }
+            R.score = best_val; R.mr = best_mr; R.nr = best_nr; R.ml = best_ml; R.ulk = best_ulk;
+        } else {
+            const int rr = b_right - a_right;
+            // first maximum over [lo, hi): returns index (lo if the range is empty)
+            auto argmax_first = [&](int lo, int hi) {
+                int bv = INT32_MIN, bi = INT32_MAX;
+                for (int r = lo + lane; r < hi; r += 64) {
+                    const int v = bnd[(int64_t) BIDX(r) * BW];
+                    if (v > bv) { bv = v; bi = r; }
+                }
+                for (int off = 32; off; off >>= 1) {
+                    const int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                return (bi == INT32_MAX) ? lo : bi;
+            };
+            int maxr = rr;
+            if (a_exgr) maxr = argmax_first(max(lw, b_left - a_right), rr);
+            if (b_exgr) {
+                const int r2 = min(up - 1, b_right - a_left);
+                int mv = argmax_first(rr, r2);
+                if (r2 - rr < 1) mv = rr;
+                if (bnd[(int64_t) BIDX(mv) * BW] > bnd[(int64_t) BIDX(maxr) * BW]) maxr = mv;
+            }
+            R.score = bnd[(int64_t) BIDX(maxr) * BW];
+            if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
+            if constexpr (FL == FL_UDH) R.ulk = bnd[(int64_t) BIDX(maxr) * BW + 2];
+            R.maxr = maxr;
+        }
+        if (lane == 0) A.res[pi] = R;
+#undef BIDX
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers (used by spdp_api.cpp)
+extern "C" hipError_t spdp_launch_sweep(int flavour, int local, const SweepArgs* args,
+                                        int grid, hipStream_t stream)
+{
+    SweepArgs A = *args;
+    dim3 blk(256), grd(grid);
+    switch (flavour * 2 + (local ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((spdp_sweep<FL_SCORE, false>), grd, blk, 0, stream, A); break;
+    case 1: hipLaunchKernelGGL((spdp_sweep<FL_SCORE, true>), grd, blk, 0, stream, A); break;
+    case 2: hipLaunchKernelGGL((spdp_sweep<FL_FORWARD, false>), grd, blk, 0, stream, A); break;
+    case 3: hipLaunchKernelGGL((spdp_sweep<FL_FORWARD, true>), grd, blk, 0, stream, A); break;
+    case 4: hipLaunchKernelGGL((spdp_sweep<FL_UDH, false>), grd, blk, 0, stream, A); break;
+    case 5: hipLaunchKernelGGL((spdp_sweep<FL_UDH, true>), grd, blk, 0, stream, A); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Traceback walk over the code buffer written by spdp_sweep<FL_FORWARD>:
+// Anti_rhomb_coord<CHAR>::traceback / go_back (src/rhomb_coord.h:141-235) on
+// our own layout -- per stripe, per 16-step block, 16 lanes x 16 codes.  One
+// thread per problem; emits the reference's Mfile records (end -> start).
+
+struct TbView {
+    const uint8_t* tb; int64_t tb_off;
+    int a_left, a_right, b_left, b_right, lw, up;
+    bool a_exgl;
+    // cached stripe
+    int cs; int64_t cbase; int c_nstart, c_n9;
+    __device__ void stripe_geom(int s, int& n_start, int& n9, int& nb) const {
+        const int ml = a_left + s * SPDP_NELEM;
+        const int j9 = min(SPDP_NELEM, a_right - ml);
+        n_start = max(b_left, lw + ml);
+        n9 = min(b_right, up + (ml + j9) + 1) + j9;
+        const int len = max(0, n9 + 1 - n_start);
+        nb = (len + 15) >> 4;
+    }
+    __device__ void seek(int s) {
+        if (s == cs) return;
+        int ns, n9, nb;
+        if (cs >= 0 && s == cs - 1) {
+            stripe_geom(s, ns, n9, nb);
+            cbase -= 256ll * nb;
+        } else {
+            int64_t base = tb_off;
+            for (int t = 0; t < s; ++t) { stripe_geom(t, ns, n9, nb); base += 256ll * nb; }
+            stripe_geom(s, ns, n9, nb);
+            cbase = base;
+        }
+        cs = s; c_nstart = ns; c_n9 = n9;
+    }
+    // code of window-relative cell (mp, np), mp >= 0, np >= 0
+    __device__ unsigned at(int mp, int np) {
+        if (mp == 0) return (!a_exgl && np >= 1) ? (unsigned) TB_HORI : 0u;
+        const int s = (mp - 1) >> 4, k = (mp - 1) & 15;
+        seek(s);
+        const int n = np + b_left + k;               // sweep step that produced the cell
+        if (n < c_nstart || n > c_n9) return 0u;
+        const int tau = n - c_nstart;
+        return tb[cbase + 256ll * (tau >> 4) + 16 * k + (tau & 15)];
+    }
+};
+
+__global__ void spdp_walk(WalkArgs A)
+{
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= A.n_probs) return;
+    const DevProblem P = A.probs[pi];
+    TbView V;
+    V.tb = A.tb; V.tb_off = P.tb_off;
+    V.a_left = P.a_left; V.a_right = P.a_right; V.b_left = P.b_left; V.b_right = P.b_right;
+    V.lw = P.lw; V.up = P.up; V.a_exgl = P.flags & 1; V.cs = -1; V.cbase = 0; V.c_nstart = V.c_n9 = 0;
+    int2* out = A.skl + (int64_t) pi * A.skl_cap;
+    int cnt = 0, status = 0;
+    int m = A.res[pi].mr - P.a_left, n = A.res[pi].nr - P.b_left;   // window-relative
+    auto emit = [&]() {
+        if (cnt < A.skl_cap) out[cnt] = make_int2(m + P.a_left, n + P.b_left);
+        else status = -1;
+        ++cnt;
+    };
+    // to_left / to_upper of Anti_rhomb_coord (cur_m, cur_n track m, n)
+    auto to_left = [&](int s) -> unsigned {
+        n -= s;
+        if (n < 0) { n = 0; return 0u; }
+        return V.at(m, n);
+    };
+    auto to_upper = [&](int s) -> unsigned {
+        --m; n -= s;
+        if (m < 0) { m = 0; n += s; return 0u; }
+        if (n < 0) { if (s > 0) m -= n / s; n = 0; return 0u; }
+        return V.at(m, n);
+    };
+    unsigned code = (m >= 0 && n >= 0) ? V.at(m, n) : 0u;
+    long guard = 4l * ((long) (P.a_right - P.a_left) + (P.b_right - P.b_left)) + 64;
+    while (code && guard-- > 0) {
+        emit();
+        switch (code & 15u) {
+        case TB_DIAG:
+            do { code = to_upper(1); } while (code && (code & 15u) == TB_DIAG);
+            break;
+        case TB_HORI: {
+            bool dead = false;
+            while (!(code & TB_NHOR)) { code = to_left(1); if (!code) { dead = true; break; } }
+            if (!dead) code = to_left(1);
+            break;
+        }
+        case TB_VERT: {
+            bool dead = false;
+            while (!(code & TB_NVER)) { code = to_upper(0); if (!code) { dead = true; break; } }
+            if (!dead) code = to_upper(0);
+            break;
+        }
+        case TB_ACCR:
+            do { code = to_left(1); } while (code && !(code & TB_DONR));
+            break;
+        default:
+            status = -2; code = 0;
+            break;
+        }
+    }
+    emit();
+    A.n_skl[pi] = status ? status : cnt;
+}
+
+// ---------------------------------------------------------------------------
+// Back-walk over the UDH links: tail of hirschbergS1_wip, src/fwd2s1_wip_simd.h:814-863
+// (non-local ends).  One thread per problem.
+
+__global__ void spdp_udh_cpos(CposArgs A)
+{
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= A.n_probs) return;
+    const DevProblem P = A.probs[pi];
+    const DevResult R = A.res[pi];
+    const int n_im = P.n_im, lw = P.lw, up = P.up, width = P.width;
+    const int step = (P.a_right - P.a_left + n_im) / (n_im + 1);
+    const int* imd0 = A.imd + P.imd_off;
+    int* cpos = A.cpos + (int64_t) pi * A.cpos_stride;
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+#define MI(i) (P.a_left + ((i) + 1) * step)
+#define LNK(i, which, d, r) imd0[((int64_t) (i) * 4 + (which) * 2 + (d)) * width + ((r) - lw + 1)]
+    for (int i = 0; i <= n_im; ++i) {
+        for (int c = 0; c < 10; ++c) CPOS(i, c) = 0;
+        CPOS(i, 0) = END_OF_ULK; CPOS(i, 2) = END_OF_ULK;
+    }
+    int a_left = P.a_left, b_left = P.b_left;
+    const int a_right = R.mr, b_right = R.nr;
+    const int max_ml = P.a_left;                       // non-local
+    int val = R.score;
+    int i = n_im;
+    while (--i >= 0 && MI(i) > a_right) ;
+    if (i < 0 && MI(0) > a_right) CPOS(0, 2) = b_right;
+    int r = R.ulk;
+    for ( ; i >= 0 && MI(i) > max_ml; --i) {
+        int c = 0, d = 0;
+        for ( ; r >= up; r -= width) ++d;
+        const int vl = LNK(i, 1, d, r);
+        if (lw < vl && vl < up) {
+            CPOS(i, c++) = MI(i);
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            for (int rp = LNK(i, 0, d, r); lw <= rp && rp < up && r != rp; rp = LNK(i, 0, d, r = rp)) {
+                if (c < 8) CPOS(i, c++) = r + MI(i); else ++c;
+            }
+            if (c < 9) { CPOS(i, c++) = r + MI(i); CPOS(i, c) = END_OF_ULK; }
+            r = LNK(i, 1, d, r);
+            if (r == END_OF_ULK) break;
+        } else
+            CPOS(i, 0) = END_OF_ULK;
+    }
+    for ( ; r > up; r -= width) ;
+    {
+        const int rl = b_left - a_left;
+        const bool a_exgl = P.flags & 1, b_exgl = P.flags & 4;
+        if (b_exgl && rl > r) {
+            a_left = b_left - r;
+            for (int j = 0; j < n_im && MI(j) < a_left; ++j) CPOS(j, 0) = END_OF_ULK;
+        }
+        if (a_exgl && rl < r) b_left = a_left + r;
+    }
+    ++i;
+    if ((i < n_im && MI(i) < a_left) || CPOS(i, 2) < b_left) val = INT32_MIN / 16 * 7;
+    A.scores[pi] = val;
+    int* rg = A.ranges + 4 * pi;
+    rg[0] = a_left; rg[1] = a_right; rg[2] = b_left; rg[3] = b_right;
+#undef CPOS
+#undef MI
+#undef LNK
+}
+
+extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t stream)
+{
+    WalkArgs A = *a;
+    hipLaunchKernelGGL(spdp_walk, dim3((A.n_probs + 63) / 64), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}
+extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t stream)
+{
+    CposArgs A = *a;
+    hipLaunchKernelGGL(spdp_udh_cpos, dim3((A.n_probs + 63) / 64), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}

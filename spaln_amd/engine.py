@@ -1,0 +1,153 @@
+"""Host-side binding of libspdp_hip.so (include/spdp.h) -- the product path.
+
+Mirrors the reference's Aln2 surface for the cDNA x genome path
+(src/aln.h:348-357): `homscore_s` ~ HomScoreS_ng, `align_s` ~ alignS_ng, plus
+the three SimdAln2s1 `_wip` engine methods.  Everything computes on the GPU;
+if the HIP library is missing or no device is present this module raises --
+there is deliberately no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
+
+EXPORTS = [
+    "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
+    "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
+    "spdp_align_s", "spdp_free_alignments", "spdp_batch_upload", "spdp_batch_free",
+    "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align",
+]
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `make -C spaln_amd/csrc` (or __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH)
+    lib.spdp_create.restype = C.c_void_p
+    lib.spdp_create.argtypes = [C.c_int]
+    lib.spdp_destroy.argtypes = [C.c_void_p]
+    lib.spdp_last_error.restype = C.c_char_p
+    lib.spdp_last_error.argtypes = [C.c_void_p]
+    lib.spdp_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.spdp_cells.restype = C.c_int64
+    lib.spdp_batch_upload.restype = C.c_void_p
+    lib.spdp_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.spdp_batch_free.argtypes = [C.c_void_p]
+    lib.spdp_batch_cells.restype = C.c_int64
+    lib.spdp_batch_cells.argtypes = [C.c_void_p]
+    lib.spdp_batch_homscore.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in ("spdp_wip_scoreonly", "spdp_homscore_s"):
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_wip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_align_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_wip_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_free_alignments.argtypes = [C.c_void_p, C.c_int]
+    return lib
+
+
+class Engine:
+    """One SpdpContext on one GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.ctx = self.lib.spdp_create(device)
+        if not self.ctx:
+            raise RuntimeError("spdp_create failed: no usable HIP device (there is no CPU path)")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.spdp_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.spdp_last_error(self.ctx).decode()}")
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self.lib.spdp_device_name(self.ctx, buf, 256)
+        return buf.value.decode()
+
+    # ---- SimdAln2s1 `_wip` engines ------------------------------------------------
+    def wip_scoreonly(self, sc: abi.Scoring, ps: abi.ProblemSet) -> np.ndarray:
+        out = np.zeros(len(ps), dtype=np.int32)
+        self._check(self.lib.spdp_wip_scoreonly(self.ctx, C.byref(sc), ps.array(), len(ps),
+                                                out.ctypes.data), "spdp_wip_scoreonly")
+        return out
+
+    def homscore_s(self, sc, ps) -> np.ndarray:
+        out = np.zeros(len(ps), dtype=np.int32)
+        self._check(self.lib.spdp_homscore_s(self.ctx, C.byref(sc), ps.array(), len(ps),
+                                             out.ctypes.data), "spdp_homscore_s")
+        return out
+
+    def _alignments(self, fn, sc, ps, what):
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        self._check(fn(self.ctx, C.byref(sc), ps.array(), n, arr), what)
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)],
+                           dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
+
+    def wip_forward(self, sc, ps):
+        return self._alignments(self.lib.spdp_wip_forward, sc, ps, "spdp_wip_forward")
+
+    def align_s(self, sc, ps):
+        return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s")
+
+    def wip_udh(self, sc, ps, n_im: int):
+        n = len(ps)
+        scores = np.zeros(n, dtype=np.int32)
+        cpos = np.zeros((n, n_im + 1, 10), dtype=np.int32)
+        ranges = np.zeros((n, 4), dtype=np.int32)
+        self._check(self.lib.spdp_wip_udh(self.ctx, C.byref(sc), ps.array(), n, n_im,
+                                          scores.ctypes.data, cpos.ctypes.data, ranges.ctypes.data),
+                    "spdp_wip_udh")
+        return scores, cpos, ranges
+
+    # ---- resident batches ------------------------------------------------------------
+    def upload(self, sc, ps):
+        h = self.lib.spdp_batch_upload(self.ctx, C.byref(sc), ps.array(), len(ps))
+        if not h:
+            raise RuntimeError("spdp_batch_upload: " + self.lib.spdp_last_error(self.ctx).decode())
+        return Batch(self, h, len(ps))
+
+
+class Batch:
+    def __init__(self, eng: Engine, handle, n: int):
+        self.eng, self.h, self.n = eng, handle, n
+
+    def cells(self) -> int:
+        return int(self.eng.lib.spdp_batch_cells(self.h))
+
+    def homscore(self, want_scores: bool = True):
+        ms = C.c_float()
+        out = np.zeros(self.n, dtype=np.int32) if want_scores else None
+        rc = self.eng.lib.spdp_batch_homscore(self.h, out.ctypes.data if want_scores else None, C.byref(ms))
+        self.eng._check(rc, "spdp_batch_homscore")
+        return out, ms.value
+
+    def free(self):
+        if self.h:
+            self.eng.lib.spdp_batch_free(self.h)
+            self.h = None

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/spdp.h"
 #include "spdp_dev.h"
@@ -230,6 +231,14 @@ int DevBatch::run(float* kernel_ms)
     A.sc = (const DevScoring*) d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n_probs;
     A.a_codes = (const uint8_t*) d_a; A.cols = (const int2*) d_cols; A.bnd = (int*) d_bnd;
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.queue = (int*) d_queue;
+    A.dbg = nullptr;
+    static int* dbg_host = nullptr;
+    if (getenv("SPDP_DEBUG")) {
+        if (!dbg_host) { hipHostMalloc((void**) &dbg_host, 64 * sizeof(int), hipHostMallocMapped); }
+        memset(dbg_host, 0, 64 * sizeof(int));
+        int* dp = nullptr; hipHostGetDevicePointer((void**) &dp, dbg_host, 0);
+        A.dbg = dp;
+    }
     HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(int), ctx->stream));
     const int grid = std::max(1, std::min((n_probs + 3) / 4, ctx->n_cu * 8));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -247,6 +256,17 @@ int DevBatch::run(float* kernel_ms)
         C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
         C.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(spdp_launch_cpos(&C, ctx->stream));
+    }
+    if (A.dbg) {
+        for (int it = 0; it < 100; ++it) {
+            if (hipStreamQuery(ctx->stream) == hipSuccess) break;
+            usleep(100000);
+            if (it % 10 == 9) {
+                fprintf(stderr, "[spdp dbg] t=%.1fs:", 0.1 * (it + 1));
+                for (int q = 0; q < 32; ++q) fprintf(stderr, " %d", dbg_host[q]);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));

@@ -20,6 +20,7 @@ struct SweepArgs {
     int*              imd;        // udh: hlnk0, hlnk1, vlnk0, vlnk1 per intermediate
     DevResult*        res;
     int*              queue;      // atomic problem counter
+    volatile int*     dbg;        // optional host-pinned progress markers (debugging)
 };
 
 struct WalkArgs {

@@ -28,13 +28,16 @@ def main():
             line = [name, tag]
             try:
                 s = int(eng.wip_scoreonly(sc, ps)[0])
-                line.append(f"score {'OK' if s == int(fx[f'wip_{tag}_score'][0]) else f'BAD {s}!={int(fx[f'wip_{tag}_score'][0])}'}")
+                w = int(fx["wip_%s_score" % tag][0])
+                line.append("score OK" if s == w else "score BAD %d != %d" % (s, w))
             except Exception as e:
                 line.append(f"score EXC {e}")
             try:
                 (s, skl), = eng.wip_forward(sc, ps)
-                ok = s == int(fx[f"wip_{tag}_fwd_scr"][0]) and skl.ravel().tolist() == fx[f"wip_{tag}_fwd_skl"].tolist()
-                line.append("fwd OK" if ok else f"fwd BAD scr {s} vs {int(fx[f'wip_{tag}_fwd_scr'][0])} skl {skl.ravel().tolist()[:12]} vs {fx[f'wip_{tag}_fwd_skl'].tolist()[:12]}")
+                ws = int(fx["wip_%s_fwd_scr" % tag][0])
+                wk = fx["wip_%s_fwd_skl" % tag].tolist()
+                ok = s == ws and skl.ravel().tolist() == wk
+                line.append("fwd OK" if ok else "fwd BAD scr %d vs %d skl %s vs %s" % (s, ws, skl.ravel().tolist()[:12], wk[:12]))
             except Exception as e:
                 line.append(f"fwd EXC {e}")
             if not sc.local:
@@ -43,9 +46,12 @@ def main():
                     try:
                         scores, cpos, rng = eng.wip_udh(sc, ps, n_im)
                         want = fx[f"wip_{tag}_udh{n_im}_cpos"].reshape(-1, 10)
-                        ok = int(scores[0]) == int(fx[k][0]) and rng[0].tolist() == fx[f"wip_{tag}_udh{n_im}_rng"][:4].tolist()
-                        okc = all((cpos[0][i][:4] == want[i][:4]).all() or want[i][0] > 2**30 for i in range(n_im + 1))
-                        line.append(f"udh{n_im} {'OK' if ok and okc else f'BAD scr {int(scores[0])} vs {int(fx[k][0])} rng {rng[0].tolist()} cpos {cpos[0][:, :4].tolist()} want {want[:, :4].tolist()}'}")
+                        wr = fx["wip_%s_udh%d_rng" % (tag, n_im)][:4].tolist()
+                        ok = int(scores[0]) == int(fx[k][0]) and rng[0].tolist() == wr
+                        okc = all((cpos[0][i][:4] == want[i][:4]).all() or (want[i][0] > 2**30 and cpos[0][i][0] > 2**30)
+                                  for i in range(n_im + 1))
+                        line.append("udh%d OK" % n_im if ok and okc else "udh%d BAD scr %d vs %d rng %s vs %s cpos %s want %s" % (
+                            n_im, int(scores[0]), int(fx[k][0]), rng[0].tolist(), wr, cpos[0][:, :4].tolist(), want[:, :4].tolist()))
                     except Exception as e:
                         line.append(f"udh{n_im} EXC {e}")
             print(" | ".join(line), file=out, flush=True)

@@ -1,0 +1,60 @@
+"""Default scoring bundle of the cDNA x genome path, as the reference CLI sets it up
+(setdefparam, src/spaln.cc:1471-1494; PwdB, src/aln2.cc:99-137; IntronPenalty,
+src/codepot.cc:126-233 with the generic table/ parameter set).  These are DATA
+read back from a reference run (the same values every tests/golden/*.spdg
+fixture carries in its `params`, `mtx`, `qm_*` records), not code.
+"""
+import numpy as np
+
+from . import abi
+
+# residue codes of the reference's nucleotide alphabet (src/cmn.h:114): A=2 C=3 G=5 T=9, N=16
+CODE_OF = {ord("A"): 2, ord("C"): 3, ord("G"): 5, ord("T"): 9, ord("N"): 16}
+NSIMD = 17
+
+# Simmtx::Nmtx for setNpam(4, -6), alprm.scale = 10: match +20, mismatch -60, gap column -20
+NMTX = np.array([
+    [   0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0,    0],
+    [   0,    0,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20,  -20],
+    [   0,  -20,   20,  -60,    0,  -60,    0,  -60,  -30,  -60,    0,  -60,  -30,  -60,  -30,  -60,  -30],
+    [   0,  -20,  -60,   20,    0,  -60,  -60,    0,  -30,  -60,  -60,    0,  -30,  -60,  -60,  -30,  -30],
+    [   0,  -20,    0,    0,    0,  -60,  -30,  -30,  -30,  -60,  -30,  -30,  -30,  -60,  -60,  -60,  -30],
+    [   0,  -20,  -60,  -60,  -60,   20,    0,    0,  -30,  -60,  -60,  -60,  -60,    0,  -30,  -30,  -30],
+    [   0,  -20,    0,  -60,  -30,    0,    0,  -30,  -30,  -60,  -30,  -60,  -60,  -30,  -30,  -60,  -30],
+    [   0,  -20,  -60,    0,  -30,    0,  -30,    0,  -30,  -60,  -60,  -30,  -60,  -30,  -60,  -30,  -30],
+    [   0,  -20,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -60,  -60,  -60,  -30,  -60,  -30,  -30,  -30],
+    [   0,  -20,  -60,  -60,  -60,  -60,  -60,  -60,  -60,   20,    0,    0,  -30,    0,  -30,  -30,  -30],
+    [   0,  -20,    0,  -60,  -30,  -60,  -30,  -60,  -60,    0,    0,  -30,  -30,  -30,  -30,  -60,  -30],
+    [   0,  -20,  -60,    0,  -30,  -60,  -60,  -30,  -60,    0,  -30,    0,  -30,  -30,  -60,  -30,  -30],
+    [   0,  -20,  -30,  -30,  -30,  -60,  -60,  -60,  -30,  -30,  -30,  -30,  -30,  -60,  -30,  -30,  -30],
+    [   0,  -20,  -60,  -60,  -60,    0,  -30,  -30,  -60,    0,  -30,  -30,  -60,    0,  -30,  -30,  -30],
+    [   0,  -20,  -30,  -60,  -60,  -30,  -30,  -60,  -30,  -30,  -30,  -60,  -30,  -30,  -30,  -30,  -30],
+    [   0,  -20,  -60,  -30,  -60,  -30,  -60,  -30,  -30,  -30,  -60,  -30,  -30,  -30,  -30,  -30,  -30],
+    [   0,  -20,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30,  -30]
+], dtype=np.int32)
+
+GOP, GEP = -60, -20              # PwdB::BasicGOP / BasicGEP  (v = 6, u = 2, Vab = 10)
+LGOP, LGEP = -158, -6
+LLMT = 20                       # IntronPrm.llmt
+IPEN = -245                     # IntronPenalty::Penalty() = GapWI
+QM_LEN = [73, 136, 317, 959, 1523]    # IntronPenalty::qm[].len (5 equi-probable quantiles)
+QM_PEN = [-230, -229, -251, -273, -323]
+SH = 100                        # alprm.sh band shoulder
+MAX_VMF_SPACE = 32 * 1024 * 1024
+
+
+def scoring(nquant=None, **over) -> abi.Scoring:
+    kw = dict(mtx=NMTX, mtx_dim=NSIMD, gop=GOP, gep=GEP, lgop=LGOP, lgep=LGEP, noll=2, spj=1,
+              llmt=LLMT, ipen=IPEN, qm_len=QM_LEN, qm_pen=QM_PEN, nquant=nquant, local=0, sh=SH,
+              max_vmf_space=MAX_VMF_SPACE, ubh=0)
+    kw.update(over)
+    return abi.make_scoring(**kw)
+
+
+def encode(seq_ascii: np.ndarray) -> np.ndarray:
+    """ASCII nucleotides -> reference residue codes."""
+    lut = np.full(256, 16, dtype=np.uint8)
+    for k, v in CODE_OF.items():
+        lut[k] = v
+        lut[k + 32] = v
+    return lut[np.asarray(seq_ascii, dtype=np.uint8)]

@@ -50,24 +50,31 @@ class Gene:
 
 
 def mutate(rng, seq: np.ndarray, sub: float, indel: float) -> np.ndarray:
-    out = []
-    i = 0
+    """Substitutions at rate `sub`, 1-3 nt insertions / deletions at rate `indel` (vectorised)."""
     n = len(seq)
+    out = seq.copy()
     r = rng.random(n)
-    pick = rng.integers(0, 3, size=n)
-    while i < n:
-        if r[i] < indel / 2:                       # deletion of 1-3 nt
-            i += int(rng.integers(1, 4))
+    hit = r > 1 - sub
+    if hit.any():
+        idx = np.nonzero(hit)[0]
+        cur = np.searchsorted(_ACGT, out[idx])          # A C G T -> 0..3 (ACGT is sorted)
+        out[idx] = _ACGT[(cur + rng.integers(1, 4, size=idx.size)) % 4]
+    ev = np.nonzero(r < indel)[0]
+    if ev.size == 0:
+        return out
+    pieces, pos = [], 0
+    for i in ev:
+        if i < pos:
             continue
-        if r[i] < indel:                           # insertion of 1-3 nt
-            out.extend(random_dna(rng, int(rng.integers(1, 4))).tolist())
-        c = seq[i]
-        if r[i] > 1 - sub:
-            others = [x for x in b"ACGT" if x != c]
-            c = others[pick[i]]
-        out.append(int(c))
-        i += 1
-    return np.array(out, dtype=np.uint8)
+        pieces.append(out[pos:i])
+        k = int(rng.integers(1, 4))
+        if r[i] < indel / 2:
+            pos = min(n, i + k)                          # deletion
+        else:
+            pieces.append(random_dna(rng, k))            # insertion
+            pos = i
+    pieces.append(out[pos:])
+    return np.concatenate(pieces)
 
 
 def make_gene(rng, n_exons: int = 8, mrna_len: int = 2000, flank: int = 1000,
@@ -104,3 +111,52 @@ def write_fasta(path: str, name: str, seq: np.ndarray, width: int = 60) -> None:
         s = seq.tobytes().decode()
         for i in range(0, len(s), width):
             fh.write(s[i:i + width] + "\n")
+
+
+# ---------------------------------------------------------------------------
+# Synthetic splice-signal tables.  In the reference these are Exinon::data_n
+# (sig5 / sig3 per genomic position, src/codepot.h:27-54), computed by a PSSM
+# scan on the host (SURVEY.md §8f row 1 -- a "next" row, not built yet).  For
+# benchmarks without the reference we synthesise tables of the same shape and
+# value range (read off the golden fixtures: canonical sites +15..+80, all other
+# positions -460..-65, median -350): donor GT at b[n], b[n+1] scores sig5[n],
+# acceptor AG at b[n-2], b[n-1] scores sig3[n].
+def splice_signals(window_ascii: np.ndarray):
+    w = np.asarray(window_ascii, dtype=np.uint8)
+    n = w.size
+    G, T, A, C = ord("G"), ord("T"), ord("A"), ord("C")
+    pad = np.concatenate([np.full(16, ord("N"), np.uint8), w, np.full(16, ord("N"), np.uint8)])
+
+    def at(off):                                   # base at string index i + off, i = 0 .. n
+        return pad[16 + off: 16 + off + n + 1]
+    h = (np.arange(n + 1, dtype=np.uint32) * np.uint32(2654435761)) ^ (at(0).astype(np.uint32) * np.uint32(40503))
+    h ^= at(-1).astype(np.uint32) * np.uint32(97) + at(1).astype(np.uint32) * np.uint32(193)
+    noise = ((h >> 7) % 381).astype(np.int32)      # 0 .. 380
+    base = -455 + np.minimum(noise, 380 - noise) * 2 + (noise % 7)
+    sig5 = base.copy()
+    is_gt = (at(0) == G) & (at(1) == T)
+    cons5 = (at(2) == A).astype(np.int32) + (at(3) == A) + (at(4) == G) + (at(5) == T) + (at(-1) == G)
+    sig5[is_gt] = 15 + 13 * cons5[is_gt]
+    sig3 = np.roll(base, 3).copy()
+    is_ag = (at(-2) == A) & (at(-1) == G)
+    py = np.zeros(n + 1, dtype=np.int32)
+    for off in range(-13, -3):
+        b = at(off)
+        py += ((b == C) | (b == T))
+    sig3[is_ag] = 10 + 5 * py[is_ag] + 6 * (at(-3)[is_ag] == C)
+    return sig5.astype(np.int16), sig3.astype(np.int16)
+
+
+def make_batch(n_queries: int, seed: int = SEED, *, n_exons: int = 8, mrna_len: int = 2000,
+               flank: int = 1000, sub: float = 0.02, indel: float = 0.002,
+               intron_lo: int = 60, intron_hi: int = 20000):
+    """C2-style batch: list of (window_codes, query_codes, sig5, sig3, exons)."""
+    from . import defaults
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_queries):
+        g = make_gene(rng, n_exons=n_exons, mrna_len=mrna_len, flank=flank, sub=sub, indel=indel,
+                      intron_lo=intron_lo, intron_hi=intron_hi)
+        s5, s3 = splice_signals(g.window)
+        out.append((defaults.encode(g.window), defaults.encode(g.query), s5, s3, g.exons))
+    return out

@@ -1,0 +1,225 @@
+"""Oracle-side restatement of the reference's dispatch around the `_wip` engines.
+TEST INFRASTRUCTURE ONLY (see oracle/spdp_oracle.c header).
+
+Plain Python over the C oracle engines, one query at a time, written from the
+reference semantics independently of spaln_amd/csrc/spdp_host.cpp:
+  alignS_ng (ori = 1, -Q0)      src/fwd2s1.cc:2746-2760
+  globalS_ng                    src/fwd2s1.cc:2674-2694
+  lspS_ng                       src/fwd2s1.cc:1801-1897
+  trcbkalignS_ng                src/fwd2s1.cc:1667-1710  (m >= 8: forwardS1_wip)
+  mimd_postwork / rcsv_postwork src/fwd2s1.cc:1714-1799
+  diagonalS_ng                  src/fwd2s1.cc:1629-1665
+  stdskl / trimskl              src/gaps.cc:140-180, 254-273
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+
+import numpy as np
+
+from spaln_amd import abi
+from . import oracle
+
+END = abi.END_OF_ULK
+NELEM = 16
+
+
+class NeedsScalarEngine(Exception):
+    """trcbkalignS_ng with m < 8 uses the scalar exact-ILD engine (not restated yet)."""
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+def _sub(p: abi.Problem, al, ar, bl, br, flags) -> abi.Problem:
+    q = abi.Problem()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(abi.Problem))
+    q.a_left, q.a_right, q.b_left, q.b_right = al, ar, bl, br
+    q.a_exgl, q.a_exgr, q.b_exgl, q.b_exgr = flags
+    return q
+
+
+def _codes(ptr, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,))
+
+
+def diagonal(sc, p, rec):
+    local = bool(sc.local)
+    LL = local and p.a_exgl and p.b_exgl
+    LR = local and p.a_exgr and p.b_exgr
+    dlt = 0 if local else (p.b_right - p.b_left) - (p.a_right - p.a_left)
+    a = _codes(p.a, p.a_len)
+    b = _codes(p.b, p.b_len)
+    al, ar, bl = p.a_left, p.a_right, p.b_left
+    if dlt < 0:
+        a, b = b, a
+        al, ar, bl = p.b_left, p.b_right, p.a_left
+    mL, mR, scr, maxh = al, ar, 0, abi.NEVSEL
+    dim = sc.mtx_dim
+    for m in range(al + 1, ar + 1):
+        x, y = int(a[m - 1]), int(b[bl + m - 1 - al])
+        scr += sc.mtx[y * dim + x] if dlt < 0 else sc.mtx[x * dim + y]
+        if LL and scr < 0:
+            scr, mL = 0, m
+        if LR and scr > maxh:
+            maxh, mR = scr, m
+    r = bl - al
+    if dlt < 0:
+        r -= dlt
+    rec.append((mL, mL + r))
+    rec.append((mR, mR + r))
+    return maxh if LR else scr
+
+
+def trcbk(sc, p, w, rec):
+    if w.width < 0:
+        return abi.NEVSEL
+    if p.a_right - p.a_left < 8:
+        raise NeedsScalarEngine()
+    s, skl = oracle.wip_forward(sc, p, w)
+    rec.extend((int(m), int(n)) for m, n in skl)
+    return s
+
+
+def lsp(sc, p, w, rec):
+    m, n = p.a_right - p.a_left, p.b_right - p.b_left
+    if not m and not n:
+        return 0
+    if not m or not n:
+        rec.append((p.a_left, p.b_left))
+        rec.append((p.a_right, p.b_right))
+        if m:
+            return sc.gep if (p.a_exgl or p.a_exgr) else sc.gop + m * sc.gep
+        return sc.gep if (p.b_exgl or p.b_exgr) else n * sc.gep
+    if w.up == w.lw:
+        return diagonal(sc, p, rec)
+    if abs(n - m) < 8 or m == 1 or n == 1:
+        return trcbk(sc, p, w, rec)
+    coef_B, coef_C = 2.0, float((sc.noll + 1) * 4)
+    cvol = _f32(_f32(m) * _f32(n + m))
+    if _f32(coef_B * cvol) < sc.max_vmf_space:
+        return trcbk(sc, p, w, rec)
+    recursive = False
+    n_imd = 1
+    z = 2.0 * m * coef_B / coef_C
+    imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
+    spc = _f32(_f32(_f32(coef_C * n) * imd1) + _f32(_f32(_f32(coef_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
+    if spc > sc.max_vmf_space:
+        recursive = True
+    else:
+        imd3 = m // NELEM
+        n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
+        intvl = (m + n_imd) // (n_imd + 1)
+        if intvl * n_imd == m:
+            n_imd -= 1
+        if n_imd == 0:
+            return trcbk(sc, p, w, rec)
+    scr, cpos, rng = oracle.wip_udh(sc, p, n_imd, w)
+    if scr > abi.NEVSEL:
+        cur = _sub(p, int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]),
+                   (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr))
+        if cpos[0][0] == END:
+            rec.append((cur.a_left, cur.b_left))
+            rec.append((cur.a_right, cur.b_right))
+        elif recursive:
+            rcsv(sc, cur, cpos, rec)
+        else:
+            mimd(sc, cur, cpos, n_imd, rec)
+    return scr
+
+
+def mimd(sc, cur, cpos, n_imd, rec):
+    aleft, bleft = cur.a_left, cur.b_left
+    cur = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
+    i = n_imd - 1
+    while i >= 0 and cpos[i][0] == END:
+        i -= 1
+    while i >= 0 and cpos[i][0] != END:
+        cur.a_left = int(cpos[i][0])
+        cur.b_exgl = 1 if cpos[i][1] else 0
+        cur.b_left = int(cpos[i][2])
+        if cur.b_left < 0 or cur.b_left > cur.b_right:
+            break
+        c = 3
+        while c < 10 and cpos[i][c] < END:
+            rec.append((cur.a_left, int(cpos[i][c])))
+            c += 1
+        trcbk(sc, cur, oracle.stripe(cur, sc.sh), rec)
+        cur.a_right = cur.a_left
+        cur.b_right = int(cpos[i][c - 1])
+        i -= 1
+    if (i < 0 and cpos[0][0] != END) or cpos[0][2] != END:
+        cur.a_left, cur.b_left = aleft, bleft
+        trcbk(sc, cur, oracle.stripe(cur, sc.sh), rec)
+
+
+def rcsv(sc, cur, cpos, rec):
+    base = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
+    row = cpos[0]
+    if row[0] < END:
+        c = 2
+        while c < 10 and row[c] < END:
+            rec.append((int(row[0]), int(row[c])))
+            c += 1
+        first = _sub(base, base.a_left, int(row[0]), base.b_left, int(row[c - 1]), (0, 0, 0, 0))
+        lsp(sc, first, oracle.stripe(first, sc.sh), rec)
+        second = _sub(base, int(row[0]), base.a_right, int(row[2]), base.b_right,
+                      (0, 0, 1 if row[1] else 0, 0))
+        lsp(sc, second, oracle.stripe(second, sc.sh), rec)
+    elif sc.local:
+        trcbk(sc, base, oracle.stripe(base, sc.sh), rec)
+
+
+def std_skl(rec):
+    if len(rec) < 2:
+        return list(rec)
+    org = sorted(rec)
+    out, pr, prv = [], 2, org[0]
+    for o in org[1:]:
+        dm, dn = o[0] - prv[0], o[1] - prv[1]
+        if not dm and not dn:
+            continue
+        if dm < 0 or dn < 0:
+            continue
+        dd = min(dm, dn)
+        df = dn - dm
+        if df:
+            df = 1 if df > 0 else -1
+        if dd and df:
+            if pr:
+                out.append(prv)
+            out.append((prv[0] + dd, prv[1] + dd))
+        elif df != pr or not dm:
+            out.append(prv)
+        pr, prv = df, o
+    out.append(prv)
+    return out
+
+
+def trim_skl(s, p):
+    s = list(s)
+    if len(s) >= 2:
+        i, j = s[1][0] - s[0][0], s[1][1] - s[0][1]
+        if (p.a_exgl and not i) or (p.b_exgl and not j):
+            s.pop(0)
+    if len(s) >= 2:
+        i, j = s[-1][0] - s[-2][0], s[-1][1] - s[-2][1]
+        if (p.a_exgr and not i) or (p.b_exgr and not j):
+            s.pop()
+    return s
+
+
+def align_s(sc, p):
+    """alignS_ng(ori=1) with seeding off.  Returns (score, skl) with skl = [flags, n, m1, n1, ...] or None."""
+    rec = []
+    scr = lsp(sc, p, oracle.stripe(p, sc.sh), rec)
+    if len(rec) < 2:
+        return scr, None
+    s = trim_skl(std_skl(rec), p)
+    flat = [1, len(s)]
+    for m, n in s:
+        flat += [m, n]
+    return scr, flat

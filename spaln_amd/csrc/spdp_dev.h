@@ -2,12 +2,13 @@
 //
 // HBM layout of one batch (all offsets in elements of the named array):
 //   a_codes  uint8   concatenated query residues, problem p at [a_off, a_off + a_len)
-//   cols     int2    per-genome-column records {sigpack, base}; problem p, column n is
-//                    cols[col_off + (n - b_left)], n in [b_left, b_right + COL_PAD);
-//                    sigpack = (uint16)(sig5[n] + ipen) | sig3[n] << 16, zero for
-//                    n > b_right (the reference feeds 0 beyond the window,
-//                    fwd2s1_wip_simd.h:159,194); base = b[n-1] for b_left < n <= b_right
-//                    else 0 (mtx row/column 0 is all zero, simmtx.cc:160-164)
+//   cols     int2    per-genome-position records {sigpack, base} of a whole parent sequence:
+//                    position n is cols[col_off + n], n in [0, b_len + COL_PAD);
+//                    sigpack = (uint16)(sig5[n] + ipen) | sig3[n] << 16, base = b[n-1].
+//                    The kernel applies the window itself: records beyond b_right read as
+//                    zero (the reference feeds 0 there, fwd2s1_wip_simd.h:159,194) and the
+//                    residue at n <= b_left is code 0 (mtx row/column 0 is all zero,
+//                    simmtx.cc:160-164) -- so sub-problems (UDH slabs) reuse the arrays
 //   bnd      int2/4  stripe-boundary rows by diagonal: entry (r - lw + 1) holds
 //                    {H, F} (score / forward) or {H, F, Hlink, Flink} (UDH) of the
 //                    reference's hv/fv(/hc/fc) arrays (fwd2s1_simd.h:129-132), in place

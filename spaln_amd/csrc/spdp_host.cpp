@@ -1,11 +1,437 @@
-// spdp_host.cpp -- the reference's dispatch around the DP engines, host side:
-// Aln2s1::lspS_ng / trcbkalignS_ng / mimd_postwork (src/fwd2s1.cc:1667-1897),
-// globalS_ng + stdskl / trimskl (src/fwd2s1.cc:2674-2694, src/gaps.cc:140-273).
+// spdp_host.cpp -- the reference's dispatch around the DP engines, host side.
+//
+// What it mirrors (ogotoh/spaln v3.0.7):
+//   alignS_ng (ori = 1, seeding off)        src/fwd2s1.cc:2746-2760
+//   Aln2s1::globalS_ng                      src/fwd2s1.cc:2674-2694
+//   Aln2s1::lspS_ng   (decision ladder)     src/fwd2s1.cc:1801-1897
+//   Aln2s1::trcbkalignS_ng                  src/fwd2s1.cc:1667-1710
+//   Aln2s1::mimd_postwork / rcsv_postwork   src/fwd2s1.cc:1714-1799
+//   Aln2s1::diagonalS_ng                    src/fwd2s1.cc:1629-1665
+//   stdskl / trimskl                        src/gaps.cc:140-180, 254-273
+//
+// The reference runs this ladder synchronously per query, deep inside its
+// worker threads.  Here the same decisions are taken for a whole batch in
+// rounds: every pending sub-problem is classified, all UDH sweeps of the round
+// go to the GPU in one launch, their cpos rows are turned into slabs (or, in
+// recursive mode, into two half problems for the next round), and finally all
+// traceback sub-problems of all queries run in one forward launch + one walk.
+// Sub-problems are descriptors into the resident inputs (no re-upload).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "spdp_internal.h"
 
-int spdp_align_s(SpdpContext* ctx, const SpdpScoring*, const SpdpProblem*, int, SpdpAlignment*)
+namespace {
+
+const int kEndOfUlk = SPDP_END_OF_ULK;
+const float kCoefB = 2.0f;                  // sizeof(short), src/fwd2s1.cc:58
+const int kScalarRows = 8;                  // trcbkalignS_ng: m < 8 goes to the scalar engine
+
+struct Rng { int al, ar, bl, br; uint8_t a_exgl, a_exgr, b_exgl, b_exgr; };
+
+struct Job {                                // one query through alignS_ng
+    int score = SPDP_NEVSEL;
+    bool score_set = false;
+    bool failed = false;
+    std::vector<SpdpSkl> rec;               // Mfile records after the dummy one
+};
+
+struct LspItem { int job; Rng r; SpdpWindow w; bool top; };
+struct TbItem  { int job; Rng r; SpdpWindow w; bool top; };     // trcbkalignS_ng call
+struct UdhItem { int job; Rng r; SpdpWindow w; bool top; int n_imd; bool recursive; };
+
+void stripe_of(const Rng& r, int sh, SpdpWindow* w)
 {
-    if (ctx) ctx->err = "spdp_align_s: not implemented yet";
-    return -1;
+    SpdpProblem p;
+    memset(&p, 0, sizeof p);
+    p.a_left = r.al; p.a_right = r.ar; p.b_left = r.bl; p.b_right = r.br;
+    spdp_stripe(&p, sh, w);
 }
-int spdp_batch_align(SpdpBatch*, SpdpAlignment*, float*, int64_t*) { return -1; }
+
+RunItem run_item(int parent, const Rng& r, const SpdpWindow& w, int n_im)
+{
+    RunItem it;
+    it.parent = parent;
+    it.a_left = r.al; it.a_right = r.ar; it.b_left = r.bl; it.b_right = r.br;
+    it.a_exgl = r.a_exgl; it.a_exgr = r.a_exgr; it.b_exgl = r.b_exgl; it.b_exgr = r.b_exgr;
+    it.w = w; it.n_im = n_im;
+    return it;
+}
+
+// PwdB::GapPenalty / GapExtPen / UnpPenalty with codonk1 = LARGEN (Noll = 2), src/aln.h:275-287
+int gap_penalty(const SpdpScoring& sc, int i) { return i == 0 ? 0 : sc.gop + i * sc.gep; }
+int gap_ext_pen(const SpdpScoring& sc, int) { return sc.gep; }
+int unp_penalty(const SpdpScoring& sc, int d) { return d * sc.gep; }
+
+// Aln2s1::diagonalS_ng (non-local and local), src/fwd2s1.cc:1629-1665
+int diagonal_s(const SpdpScoring& sc, const SpdpProblem& p, const Rng& r, std::vector<SpdpSkl>& rec)
+{
+    const bool Local = sc.local;
+    const bool LocalL = Local && r.a_exgl && r.b_exgl;
+    const bool LocalR = Local && r.a_exgr && r.b_exgr;
+    const int dlt = Local ? 0 : ((r.br - r.bl) - (r.ar - r.al));
+    // if dlt < 0 the roles of a and b are swapped for the walk
+    const uint8_t* as = dlt < 0 ? p.b : p.a;
+    const uint8_t* bs = dlt < 0 ? p.a : p.b;
+    const int al = dlt < 0 ? r.bl : r.al, ar = dlt < 0 ? r.br : r.ar;
+    const int bl = dlt < 0 ? r.al : r.bl;
+    int mL = al, mR = ar;
+    int scr = 0, maxh = SPDP_NEVSEL;
+    for (int m = al; m++ < ar; ) {
+        const int x = as[m - 1], y = bs[bl + (m - 1 - al)];
+        scr += dlt < 0 ? sc.mtx[y * sc.mtx_dim + x] : sc.mtx[x * sc.mtx_dim + y];
+        if (LocalL && scr < 0) { scr = 0; mL = m; }
+        if (LocalR && scr > maxh) { maxh = scr; mR = m; }
+    }
+    int rr = bl - al;
+    if (dlt < 0) rr -= dlt;
+    // NB: the reference writes (m, n) of the *swapped* pair; reproduce literally
+    rec.push_back({mL, mL + rr});
+    rec.push_back({mR, mR + rr});
+    return LocalR ? maxh : scr;
+}
+
+// stdskl, src/gaps.cc:140-180: sort by (m, n), drop repeats / inconsistent steps, insert the
+// corner of every diagonal-then-gap step.  In/out: records without header.
+std::vector<SpdpSkl> std_skl(std::vector<SpdpSkl> org)
+{
+    const int num = (int) org.size();
+    if (num < 2) return org;
+    std::sort(org.begin(), org.end(), [](const SpdpSkl& a, const SpdpSkl& b) {
+        return a.m != b.m ? a.m < b.m : a.n < b.n;
+    });
+    std::vector<SpdpSkl> out;
+    out.reserve(2 * num + 1);
+    int pr = 2;
+    const SpdpSkl* prv = &org[0];
+    for (int i = 1; i < num; ++i) {
+        const SpdpSkl* o = &org[i];
+        const int dm = o->m - prv->m, dn = o->n - prv->n;
+        if (!dm && !dn) continue;
+        if (dm < 0 || dn < 0) continue;
+        const int dd = std::min(dm, dn);
+        int df = dn - dm;
+        if (df) df = df > 0 ? 1 : -1;
+        if (dd && df) {
+            if (pr) out.push_back(*prv);
+            out.push_back({prv->m + dd, prv->n + dd});
+        } else if (df != pr || !dm)
+            out.push_back(*prv);
+        pr = df;
+        prv = o;
+    }
+    out.push_back(*prv);
+    return out;
+}
+
+// trimskl, src/gaps.cc:254-273: delete terminal gaps at free ends
+void trim_skl(std::vector<SpdpSkl>& s, const SpdpProblem& p)
+{
+    if (s.size() >= 2) {
+        const int i = s[1].m - s[0].m, j = s[1].n - s[0].n;
+        if ((p.a_exgl && !i) || (p.b_exgl && !j)) s.erase(s.begin());
+    }
+    if (s.size() >= 2) {
+        const size_t k = s.size() - 1;
+        const int i = s[k].m - s[k - 1].m, j = s[k].n - s[k - 1].n;
+        if ((p.a_exgr && !i) || (p.b_exgr && !j)) s.pop_back();
+    }
+}
+
+struct Aligner {
+    SpdpContext* ctx;
+    const DevStore* st;
+    const SpdpProblem* probs;
+    int n;
+    std::vector<Job> jobs;
+    std::vector<LspItem> pending;
+    std::vector<TbItem> tbs;
+    float kernel_ms = 0.f;
+    int64_t kernel_cells = 0;
+    int unsupported = 0;
+
+    void set_score(int job, bool top, int scr) { if (top) { jobs[job].score = scr; jobs[job].score_set = true; } }
+
+    // Aln2s1::trcbkalignS_ng
+    void trcbk(int job, const Rng& r, const SpdpWindow& w, bool top)
+    {
+        if (w.width < 0) { set_score(job, top, SPDP_NEVSEL); return; }
+        if (r.ar - r.al < kScalarRows) {        // scalar forwardS_ng: not on the GPU yet
+            ++unsupported; jobs[job].failed = true; return;
+        }
+        tbs.push_back({job, r, w, top});
+    }
+
+    // Aln2s1::lspS_ng up to the point where an engine is needed
+    bool classify(const LspItem& it, std::vector<UdhItem>& udh)
+    {
+        const SpdpScoring& sc = st->sc;
+        const Rng& r = it.r;
+        Job& J = jobs[it.job];
+        const int m = r.ar - r.al, n = r.br - r.bl;
+        if (!m && !n) { set_score(it.job, it.top, 0); return true; }
+        if (!m || !n) {
+            J.rec.push_back({r.al, r.bl});
+            J.rec.push_back({r.ar, r.br});
+            int scr;
+            if (m) scr = (r.a_exgl || r.a_exgr) ? gap_ext_pen(sc, m) : gap_penalty(sc, m);
+            else   scr = (r.b_exgl || r.b_exgr) ? gap_ext_pen(sc, n) : unp_penalty(sc, n);
+            set_score(it.job, it.top, scr);
+            return true;
+        }
+        if (it.w.up == it.w.lw) {
+            set_score(it.job, it.top, diagonal_s(sc, probs[it.job], r, J.rec));
+            return true;
+        }
+        if (abs(n - m) < 8 || m == 1 || n == 1) { trcbk(it.job, r, it.w, it.top); return true; }
+        int n_imd = 1;
+        bool recursive = false;                 // algmode.alg & 4 (-A4..7) not offered
+        float cvol = float(m) * (n + m);        // rhombic, simd >= 2
+        if (kCoefB * cvol < sc.max_vmf_space) { trcbk(it.job, r, it.w, it.top); return true; }
+        {
+            const float coef_C = (sc.noll + 1) * sizeof(int);
+            const double z = 2. * m * kCoefB / coef_C;
+            const int imd1 = int(pow(z, 1. / 3) + 0.5) - 1;
+            const float spc = coef_C * n * imd1 + kCoefB * cvol / (imd1 + 1) / (imd1 + 1);
+            if (spc > sc.max_vmf_space) recursive = true;
+            else {
+                const int imd3 = m / SPDP_NELEM;
+                n_imd = sc.ubh ? sc.ubh : std::min(imd1, imd3);
+                const int imd_intvl = (m + n_imd) / (n_imd + 1);
+                if (imd_intvl * n_imd == m) --n_imd;
+                if (n_imd == 0) { trcbk(it.job, r, it.w, it.top); return true; }
+            }
+        }
+        udh.push_back({it.job, r, it.w, it.top, n_imd, recursive});
+        return true;
+    }
+
+    // Aln2s1::mimd_postwork on the written-back ranges
+    void mimd(const UdhItem& u, const int32_t* cpos, Rng cur)
+    {
+        Job& J = jobs[u.job];
+        const int sh = st->sc.sh;
+        const int aleft = cur.al, bleft = cur.bl;
+        cur.a_exgl = cur.a_exgr = cur.b_exgl = cur.b_exgr = 0;
+#define CP(i, c) cpos[(i) * 10 + (c)]
+        int i = u.n_imd;
+        while (--i >= 0 && CP(i, 0) == kEndOfUlk) ;
+        for ( ; i >= 0 && CP(i, 0) != kEndOfUlk; --i) {
+            int c = 0;
+            cur.al = CP(i, c);
+            cur.b_exgl = CP(i, ++c) ? 1 : 0;
+            cur.bl = CP(i, ++c);
+            if (cur.bl < 0 || cur.bl > cur.br) break;
+            while (c < 9 && CP(i, ++c) < kEndOfUlk) J.rec.push_back({cur.al, CP(i, c)});
+            SpdpWindow vw;
+            stripe_of(cur, sh, &vw);
+            trcbk(u.job, cur, vw, false);
+            cur.ar = cur.al;
+            cur.br = CP(i, c - 1);
+        }
+        if ((i < 0 && CP(0, 0) != kEndOfUlk) || CP(0, 2) != kEndOfUlk) {
+            cur.al = aleft; cur.bl = bleft;
+            SpdpWindow vw;
+            stripe_of(cur, sh, &vw);
+            trcbk(u.job, cur, vw, false);
+        }
+#undef CP
+    }
+
+    // Aln2s1::rcsv_postwork: two half problems for the next round
+    void rcsv(const UdhItem& u, const int32_t* cpos, Rng cur)
+    {
+        Job& J = jobs[u.job];
+        const int sh = st->sc.sh;
+        cur.a_exgl = cur.a_exgr = cur.b_exgl = cur.b_exgr = 0;
+        int c = 0;
+        if (cpos[c++] < kEndOfUlk) {
+            while (c < 9 && cpos[++c] < kEndOfUlk) J.rec.push_back({cpos[0], cpos[c]});
+            Rng first = cur;
+            first.ar = cpos[0]; first.br = cpos[c - 1];
+            SpdpWindow w;
+            stripe_of(first, sh, &w);
+            pending.push_back({u.job, first, w, false});
+            Rng second = cur;
+            second.al = cpos[0]; second.b_exgl = cpos[1] ? 1 : 0; second.bl = cpos[2];
+            stripe_of(second, sh, &w);
+            pending.push_back({u.job, second, w, false});
+        } else if (st->sc.local) {
+            SpdpWindow w;
+            stripe_of(cur, sh, &w);
+            trcbk(u.job, cur, w, false);
+        }
+    }
+
+    int run()
+    {
+        const SpdpScoring& sc = st->sc;
+        jobs.assign(n, Job());
+        for (int i = 0; i < n; ++i) {           // alignS_ng: stripe(alprm.sh), globalS_ng -> lspS_ng
+            const SpdpProblem& p = probs[i];
+            Rng r{p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
+            SpdpWindow w;
+            stripe_of(r, sc.sh, &w);
+            pending.push_back({i, r, w, true});
+        }
+        while (!pending.empty()) {
+            std::vector<LspItem> cur;
+            cur.swap(pending);
+            std::vector<UdhItem> udh;
+            for (const LspItem& it : cur) classify(it, udh);
+            if (udh.empty()) continue;
+            std::vector<RunItem> items;
+            for (const UdhItem& u : udh) items.push_back(run_item(u.job, u.r, u.w, u.n_imd));
+            DevRun run;
+            if (run.build(st, items, 2) || run.launch() || run.sync()) return -1;
+            kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+            std::vector<int32_t> scores, cpos, ranges;
+            if (run.fetch_udh(scores, cpos, ranges)) return -1;
+            const int stride = 10 * (run.max_n_im + 1);
+            for (size_t k = 0; k < udh.size(); ++k) {
+                const UdhItem& u = udh[k];
+                const int scr = scores[k];
+                set_score(u.job, u.top, scr);
+                if (scr <= SPDP_NEVSEL) continue;
+                Rng curr = u.r;                 // ranges as written back by the engine
+                curr.al = ranges[4 * k]; curr.ar = ranges[4 * k + 1];
+                curr.bl = ranges[4 * k + 2]; curr.br = ranges[4 * k + 3];
+                const int32_t* cp = cpos.data() + k * stride;
+                if (cp[0] == kEndOfUlk) {
+                    jobs[u.job].rec.push_back({curr.al, curr.bl});
+                    jobs[u.job].rec.push_back({curr.ar, curr.br});
+                } else if (u.recursive) rcsv(u, cp, curr);
+                else mimd(u, cp, curr);
+            }
+        }
+        // all trcbkalignS_ng calls of all queries: one forward sweep + one walk
+        if (!tbs.empty()) {
+            std::vector<RunItem> items;
+            for (const TbItem& t : tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            DevRun run;
+            if (run.build(st, items, 1) || run.launch() || run.sync()) return -1;
+            kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+            std::vector<DevResult> res;
+            std::vector<int> nskl;
+            std::vector<SpdpSkl> skl;
+            if (run.fetch_results(res) || run.fetch_skl(nskl, skl)) return -1;
+            for (size_t k = 0; k < tbs.size(); ++k) {
+                const TbItem& t = tbs[k];
+                if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
+                set_score(t.job, t.top, res[k].score);
+                const SpdpSkl* s = skl.data() + k * run.max_skl;
+                jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
+            }
+        }
+        return 0;
+    }
+
+    // globalS_ng tail: header, stdskl, trimskl
+    void finish(int i, SpdpAlignment* out) const
+    {
+        const Job& J = jobs[i];
+        out->score = J.score_set ? J.score : SPDP_NEVSEL;
+        out->n_skl = 0; out->skl = nullptr;
+        if (J.failed || (int) J.rec.size() < 2) return;
+        std::vector<SpdpSkl> s = std_skl(J.rec);
+        trim_skl(s, probs[i]);
+        out->n_skl = (int) s.size() + 1;
+        out->skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * out->n_skl);
+        out->skl[0].m = 1;                      // AlgnTrb
+        out->skl[0].n = (int) s.size();
+        memcpy(out->skl + 1, s.data(), sizeof(SpdpSkl) * s.size());
+    }
+};
+
+}   // namespace
+
+// ---- resident batches -----------------------------------------------------------------------
+struct SpdpBatch {
+    SpdpContext* ctx = nullptr;
+    DevStore store;
+    std::vector<SpdpProblem> probs;
+    DevRun score;                                // HomScoreS_ng leg, built once
+    bool score_built = false;
+};
+
+SpdpBatch* spdp_batch_upload(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n)
+{
+    if (!ctx || n <= 0) return nullptr;
+    SpdpBatch* b = new SpdpBatch();
+    b->ctx = ctx;
+    b->probs.assign(probs, probs + n);
+    if (b->store.upload(ctx, sc, probs, n)) { delete b; return nullptr; }
+    return b;
+}
+
+void spdp_batch_free(SpdpBatch* bt) { delete bt; }
+
+int64_t spdp_batch_cells(const SpdpBatch* bt)
+{
+    if (!bt) return 0;
+    int64_t c = 0;
+    for (const SpdpProblem& p : bt->probs) {
+        SpdpWindow w;
+        spdp_stripe(&p, bt->store.sc.sh, &w);
+        c += spdp_cells(&p, &w);
+    }
+    return c;
+}
+
+int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms)
+{
+    if (!bt) return -1;
+    if (!bt->score_built) {
+        std::vector<RunItem> items;
+        for (size_t i = 0; i < bt->probs.size(); ++i)
+            items.push_back(spdp_item_of(bt->probs[i], (int) i, bt->store.sc.sh));
+        if (bt->score.build(&bt->store, items, 0)) return -1;
+        bt->score_built = true;
+    }
+    if (bt->score.launch() || bt->score.sync()) return -1;
+    if (kernel_ms) *kernel_ms = bt->score.kernel_ms;
+    if (scores) {
+        std::vector<DevResult> r;
+        if (bt->score.fetch_results(r)) return -1;
+        for (size_t i = 0; i < r.size(); ++i) scores[i] = r[i].score;
+    }
+    return 0;
+}
+
+static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n,
+                          SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells)
+{
+    Aligner al;
+    al.ctx = ctx; al.st = st; al.probs = probs; al.n = n;
+    if (al.run()) return -1;
+    if (out) for (int i = 0; i < n; ++i) al.finish(i, out + i);
+    if (kernel_ms) *kernel_ms = al.kernel_ms;
+    if (kernel_cells) *kernel_cells = al.kernel_cells;
+    if (al.unsupported) {
+        ctx->err = "sub-problems with fewer than 8 query rows need the scalar engine (not implemented)";
+        return 1;                               // partial: those queries are returned without alignment
+    }
+    return 0;
+}
+
+int spdp_batch_align(SpdpBatch* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells)
+{
+    if (!bt) return -1;
+    return align_on_store(bt->ctx, &bt->store, bt->probs.data(), (int) bt->probs.size(), out,
+                          kernel_ms, kernel_cells);
+}
+
+int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
+                 SpdpAlignment* out)
+{
+    if (!ctx) return -1;
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    if (n_probs <= 0) return 0;
+    DevStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    return align_on_store(ctx, &st, probs, n_probs, out, nullptr, nullptr);
+}

@@ -20,7 +20,6 @@ struct SweepArgs {
     int*              imd;        // udh: hlnk0, hlnk1, vlnk0, vlnk1 per intermediate
     DevResult*        res;
     int*              queue;      // atomic problem counter
-    volatile int*     dbg;        // optional host-pinned progress markers (debugging)
 };
 
 struct WalkArgs {
@@ -57,31 +56,58 @@ struct SpdpContext {
     std::string err;
 };
 
-// one packed, HBM-resident batch of problems for one sweep flavour (0 score, 1 forward, 2 udh)
-struct DevBatch {
+// Resident inputs of a set of parent problems: residues, per-position column
+// records and the scoring bundle.  Sub-problems (UDH slabs, engine calls on
+// sub-ranges) are descriptors pointing into these arrays -- no re-upload.
+struct DevStore {
     SpdpContext* ctx = nullptr;
-    int flavour = 0, n_probs = 0, local = 0;
-    int max_n_im = 0, max_skl = 0;
-    int64_t total_cells = 0, tb_bytes = 0;
-    std::vector<DevProblem> h_probs;
-    void *d_sc = nullptr, *d_probs = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_bnd = nullptr,
-         *d_tb = nullptr, *d_imd = nullptr, *d_res = nullptr, *d_queue = nullptr, *d_skl = nullptr,
-         *d_nskl = nullptr, *d_cpos = nullptr, *d_ranges = nullptr, *d_scores = nullptr;
-    DevBatch() = default;
-    DevBatch(const DevBatch&) = delete;
-    DevBatch& operator=(const DevBatch&) = delete;
-    ~DevBatch() { release(); }
-    int build(SpdpContext* c, const SpdpScoring* sc, const SpdpProblem* probs, int n,
-              const SpdpWindow* wdws, const int* n_im, int flav);
-    int run(float* kernel_ms);
-    int fetch_results(std::vector<DevResult>& out);
+    SpdpScoring sc;
+    int n_parents = 0;
+    std::vector<int64_t> a_off, col_off;
+    std::vector<int32_t> a_len, b_len;
+    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr;
+    DevStore() = default;
+    DevStore(const DevStore&) = delete;
+    DevStore& operator=(const DevStore&) = delete;
+    ~DevStore() { release(); }
+    int upload(SpdpContext* c, const SpdpScoring* sc, const SpdpProblem* probs, int n);
     void release();
 };
 
-// engine entry points with explicit bands (used by the dispatch layer)
-int spdp_wip_forward_w(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
-                       const SpdpWindow* wdws, int n_probs, SpdpAlignment* out);
-int spdp_wip_udh_w(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
-                   const SpdpWindow* wdws, int n_probs, const int* n_im, int cpos_rows,
-                   int32_t* scores, int32_t* cpos, int32_t* ranges);
+// one DP call on (a sub-range of) a parent problem
+struct RunItem {
+    int parent;
+    int a_left, a_right, b_left, b_right;
+    uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
+    SpdpWindow w;
+    int n_im;          // UDH only
+};
+
+// descriptors + work buffers of one sweep flavour (0 score, 1 forward, 2 udh) over a DevStore
+struct DevRun {
+    SpdpContext* ctx = nullptr;
+    const DevStore* store = nullptr;
+    int flavour = 0, n = 0;
+    int max_n_im = 0, max_skl = 0;
+    int64_t total_cells = 0, tb_bytes = 0;
+    std::vector<DevProblem> h_probs;
+    void *d_probs = nullptr, *d_bnd = nullptr, *d_tb = nullptr, *d_imd = nullptr, *d_res = nullptr,
+         *d_queue = nullptr, *d_skl = nullptr, *d_nskl = nullptr, *d_cpos = nullptr,
+         *d_ranges = nullptr, *d_scores = nullptr;
+    float kernel_ms = 0.f;
+    DevRun() = default;
+    DevRun(const DevRun&) = delete;
+    DevRun& operator=(const DevRun&) = delete;
+    ~DevRun() { release(); }
+    int build(const DevStore* st, const std::vector<RunItem>& items, int flav);
+    int launch();                       // async on ctx->stream: sweep (+ walk / cpos)
+    int sync();                         // waits, fills kernel_ms
+    int fetch_results(std::vector<DevResult>& out);
+    int fetch_skl(std::vector<int>& n_skl, std::vector<SpdpSkl>& skl);       // forward
+    int fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges);
+    void release();
+};
+
+RunItem spdp_item_of(const SpdpProblem& p, int parent, int sh);
+int64_t spdp_cells_w(int a_left, int a_right, int b_left, int b_right, const SpdpWindow& w);
 #endif

@@ -62,11 +62,9 @@ __device__ __forceinline__ int sadd16(int a, int b) { return max(a + b, SPDP_FLO
 
 
 // ---------------------------------------------------------------------------
-#define DBG(slot, val) do { if (A.dbg && (threadIdx.x & 63) == 0) { A.dbg[(slot)] = (val); __threadfence_system(); } } while (0)
 template <int FL, bool LOCAL>
 __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 {
-    DBG(0 + 8 * (threadIdx.x >> 6), 1);
     constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
     __shared__ int s_mtx[32 * 32];
 
@@ -88,7 +86,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         int pi = 0;
         if (lane == 0) pi = atomicAdd(A.queue, 1);
         pi = __builtin_amdgcn_readfirstlane(pi);
-        DBG(1 + 8 * (threadIdx.x >> 6), pi + 100);
         if (pi >= A.n_probs) break;
         const DevProblem P = A.probs[pi];
         const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
@@ -138,8 +135,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-
-        DBG(2, 2);
         // UDH: intermediate rows (src/fwd2s1_wip_simd.h:503-508)
         const int n_im = (FL == FL_UDH) ? P.n_im : 0;
         const int imd_step = (FL == FL_UDH) ? (a_right - a_left + n_im) / (n_im + 1) : 0;
@@ -206,10 +201,7 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
             int pv_stale = 0; bool stale_on = false;                   // UDH Local first-column quirk (unused)
             int outH = 0, outF = 0, outC = 0, outFC = 0;
             (void) pv_stale; (void) stale_on;
-
-            DBG(3, tot);
             for (int blk = 0; blk < tot; ++blk) {
-                DBG(4, blk);
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
                 if (lb >= 0 && lb < nb) {
                     const int n0 = n_start + lb * 16;                   // sweep step of j = 0
@@ -217,7 +209,7 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                         // stripe start: pipes are empty except the base pipe, and lane 0's
                         // up-left neighbour comes from the boundary array
                         const int c = n_start - 1 - k;                 // column lane k "had" one step before
-                        basep = (c > b_left && c <= b_right) ? cols[c - b_left].y : 0;
+                        basep = (c > b_left && c <= b_right) ? cols[c].y : 0;
                         const int r = n_start - (ml + 1);
                         donor_r = r;
                         if (k == 0) {
@@ -237,8 +229,12 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                             chH = v.x; chF = v.y;
                         }
                     }
-                    const int2 crec = cols[n0 + k - b_left];
-                    const int chS = spj ? crec.x : 0, chB = crec.y;
+                    // column records are stored per absolute position of the parent sequence; the
+                    // window edges are applied here: nothing beyond b_right, no residue at b_left
+                    const int cn = n0 + k;
+                    int2 crec = make_int2(0, 0);
+                    if (cn <= b_right) crec = cols[cn];
+                    const int chS = spj ? crec.x : 0, chB = (cn > b_left) ? crec.y : 0;
                     uint32_t code4[4] = {0, 0, 0, 0};
 
 #define STEP(J)                                                                                  \
@@ -376,8 +372,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
         }
-
-        DBG(5, 5);
         // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
         DevResult R;
         R.score = SPDP_NEV16; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = END_OF_ULK; R.maxr = 0;
@@ -423,7 +417,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
             R.maxr = maxr;
         }
         if (lane == 0) A.res[pi] = R;
-        DBG(6, 6);
 #undef BIDX
     }
 }

@@ -147,6 +147,24 @@ class Batch:
         self.eng._check(rc, "spdp_batch_homscore")
         return out, ms.value
 
+    def align(self, want: bool = True):
+        """alignS_ng (ori = 1, -Q0) over the resident batch.  Returns (alignments, kernel_ms, kernel_cells)."""
+        ms = C.c_float()
+        cells = C.c_int64()
+        arr = (abi.Alignment * self.n)() if want else None
+        rc = self.eng.lib.spdp_batch_align(self.h, arr, C.byref(ms), C.byref(cells))
+        self.eng._check(rc, "spdp_batch_align")
+        res = None
+        if want:
+            res = []
+            for i in range(self.n):
+                k = arr[i].n_skl
+                skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)],
+                               dtype=np.int32).reshape(-1, 2)
+                res.append((int(arr[i].score), skl))
+            self.eng.lib.spdp_free_alignments(arr, self.n)
+        return res, ms.value, cells.value
+
     def free(self):
         if self.h:
             self.eng.lib.spdp_batch_free(self.h)

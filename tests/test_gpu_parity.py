@@ -98,3 +98,17 @@ def test_batch_vs_oracle(eng):
         got = eng.wip_scoreonly(sc, ps)
         want = [oracle.wip_scoreonly(sc, p) for p in ps.items]
         assert got.tolist() == want
+
+
+@pytest.mark.parametrize("alg", [2, 3])
+def test_align_s_vs_reference(eng, fx, alg):
+    """alignS_ng(ori=1, -Q0) through the C ABI: dispatch ladder + UDH + slab tracebacks + stdskl/trimskl."""
+    sc = spdg.scoring(fx, nquant=(1 if alg == 3 else None))
+    ps, p = spdg.problem(fx)
+    if sc.local and fx["prm"]["max_vmf_space"] < 32 * 1024 * 1024:
+        pytest.skip("local UDH not implemented on the GPU")
+    if p.a_right - p.a_left < 8:
+        pytest.skip("m < 8 uses the scalar engine (not implemented on the GPU)")
+    (score, skl), = eng.align_s(sc, ps)
+    assert score == int(fx[f"aln_scr_A{alg}"][0])
+    assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()

@@ -273,7 +273,7 @@ int DevRun::launch()
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.queue = (int*) d_queue;
     HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(int), ctx->stream));
-    const int grid = std::max(1, std::min((n + 3) / 4, ctx->n_cu * 8));
+    const int grid = (n + 3) / 4;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, &A, grid, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

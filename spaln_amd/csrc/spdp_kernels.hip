@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     const int p0 = sc->qm_pen[0], p1 = sc->qm_pen[1], p2 = sc->qm_pen[2], p3 = sc->qm_pen[3],
               p4 = sc->qm_pen[4], p5 = sc->qm_pen[5], p6 = sc->qm_pen[6], p7 = sc->qm_pen[7];
 
-    for (;;) {
-        int pi = 0;
-        if (lane == 0) pi = atomicAdd(A.queue, 1);
-        pi = __builtin_amdgcn_readfirstlane(pi);
-        if (pi >= A.n_probs) break;
+    // one wave = one problem; the hardware dispatcher balances the load (blocks are
+    // launched as CUs free up), so no software queue is needed
+    {
+        const int pi = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+        if (pi >= A.n_probs) return;
         const DevProblem P = A.probs[pi];
         const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
         const int lw = P.lw, up = P.up, width = P.width;

@@ -139,6 +139,12 @@ int64_t    spdp_batch_cells(const SpdpBatch* bt);
  * the stream it was launched on. */
 int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms);
 int spdp_batch_align(SpdpBatch* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells);
+/* per-kernel figures of the last spdp_batch_align call:
+ *  [0] UDH sweep ms (HIP events)  [1] UDH cells  [2] UDH problems
+ *  [3] forward sweep ms           [4] forward cells  [5] forward problems (direct + slabs)
+ *  [6] UDH rounds                 [7] traceback bytes written */
+#define SPDP_N_STATS 8
+int spdp_batch_stats(const SpdpBatch* bt, double* out, int n);
 
 #ifdef __cplusplus
 }

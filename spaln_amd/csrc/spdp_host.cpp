@@ -153,6 +153,7 @@ struct Aligner {
     float kernel_ms = 0.f;
     int64_t kernel_cells = 0;
     int unsupported = 0;
+    double stats[SPDP_N_STATS] = {0};           // see include/spdp.h
 
     void set_score(int job, bool top, int scr) { if (top) { jobs[job].score = scr; jobs[job].score_set = true; } }
 
@@ -289,6 +290,8 @@ struct Aligner {
             DevRun run;
             if (run.build(st, items, 2) || run.launch() || run.sync()) return -1;
             kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+            stats[0] += run.kernel_ms; stats[1] += (double) run.total_cells; stats[2] += (double) items.size();
+            stats[6] += 1;
             std::vector<int32_t> scores, cpos, ranges;
             if (run.fetch_udh(scores, cpos, ranges)) return -1;
             const int stride = 10 * (run.max_n_im + 1);
@@ -315,6 +318,8 @@ struct Aligner {
             DevRun run;
             if (run.build(st, items, 1) || run.launch() || run.sync()) return -1;
             kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+            stats[3] += run.kernel_ms; stats[4] += (double) run.total_cells; stats[5] += (double) items.size();
+            stats[7] += (double) run.tb_bytes;
             std::vector<DevResult> res;
             std::vector<int> nskl;
             std::vector<SpdpSkl> skl;
@@ -356,6 +361,7 @@ struct SpdpBatch {
     std::vector<SpdpProblem> probs;
     DevRun score;                                // HomScoreS_ng leg, built once
     bool score_built = false;
+    double stats[SPDP_N_STATS] = {0};
 };
 
 SpdpBatch* spdp_batch_upload(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n)
@@ -403,7 +409,8 @@ int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms)
 }
 
 static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n,
-                          SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells)
+                          SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells,
+                          double* stats = nullptr)
 {
     Aligner al;
     al.ctx = ctx; al.st = st; al.probs = probs; al.n = n;
@@ -411,6 +418,7 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     if (out) for (int i = 0; i < n; ++i) al.finish(i, out + i);
     if (kernel_ms) *kernel_ms = al.kernel_ms;
     if (kernel_cells) *kernel_cells = al.kernel_cells;
+    if (stats) memcpy(stats, al.stats, sizeof al.stats);
     if (al.unsupported) {
         ctx->err = "sub-problems with fewer than 8 query rows need the scalar engine (not implemented)";
         return 1;                               // partial: those queries are returned without alignment
@@ -422,7 +430,14 @@ int spdp_batch_align(SpdpBatch* bt, SpdpAlignment* out, float* kernel_ms, int64_
 {
     if (!bt) return -1;
     return align_on_store(bt->ctx, &bt->store, bt->probs.data(), (int) bt->probs.size(), out,
-                          kernel_ms, kernel_cells);
+                          kernel_ms, kernel_cells, bt->stats);
+}
+
+int spdp_batch_stats(const SpdpBatch* bt, double* out, int n)
+{
+    if (!bt || !out) return -1;
+    for (int i = 0; i < n && i < SPDP_N_STATS; ++i) out[i] = bt->stats[i];
+    return 0;
 }
 
 int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,

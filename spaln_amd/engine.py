@@ -22,7 +22,7 @@ EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
     "spdp_align_s", "spdp_free_alignments", "spdp_batch_upload", "spdp_batch_free",
-    "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align",
+    "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
 ]
 
 
@@ -44,6 +44,7 @@ def load_library() -> C.CDLL:
     lib.spdp_batch_cells.argtypes = [C.c_void_p]
     lib.spdp_batch_homscore.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     for f in ("spdp_wip_scoreonly", "spdp_homscore_s"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -164,6 +165,13 @@ class Batch:
                 res.append((int(arr[i].score), skl))
             self.eng.lib.spdp_free_alignments(arr, self.n)
         return res, ms.value, cells.value
+
+    def stats(self) -> dict:
+        v = (C.c_double * 8)()
+        self.eng.lib.spdp_batch_stats(self.h, v, 8)
+        keys = ["udh_ms", "udh_cells", "udh_problems", "fwd_ms", "fwd_cells", "fwd_problems",
+                "udh_rounds", "tb_bytes"]
+        return dict(zip(keys, (float(x) for x in v)))
 
     def free(self):
         if self.h:

@@ -102,10 +102,31 @@ SpdpContext* spdp_create(int device)
     return ctx;
 }
 
+void* DevPool::get(int slot, size_t bytes)
+{
+    if (bytes < 256) bytes = 256;
+    if (cap[slot] >= bytes) return ptr[slot];
+    if (ptr[slot]) (void) hipFree(ptr[slot]);
+    ptr[slot] = nullptr; cap[slot] = 0;
+    size_t want = bytes + bytes / 8;                    // head-room: batches of one run vary a little
+    if (hipMalloc(&ptr[slot], want) != hipSuccess) {
+        if (hipMalloc(&ptr[slot], bytes) != hipSuccess) return nullptr;
+        want = bytes;
+    }
+    cap[slot] = want;
+    return ptr[slot];
+}
+
+void DevPool::release()
+{
+    for (int i = 0; i < N_SLOTS; ++i) { if (ptr[i]) (void) hipFree(ptr[i]); ptr[i] = nullptr; cap[i] = 0; }
+}
+
 void spdp_destroy(SpdpContext* ctx)
 {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
+    for (DevPool& p : ctx->pool) p.release();
     (void) hipEventDestroy(ctx->ev0);
     (void) hipEventDestroy(ctx->ev1);
     (void) hipStreamDestroy(ctx->stream);
@@ -198,14 +219,13 @@ static int stripe_blocks(const DevProblem& P, int s, bool forward)
     return (len + 15) >> 4;
 }
 
-void DevRun::release()
-{
-    if (!ctx) return;
-    (void) hipSetDevice(ctx->device);
-    void* ptrs[] = {d_probs, d_bnd, d_tb, d_imd, d_res, d_queue, d_skl, d_nskl, d_cpos, d_ranges, d_scores};
-    for (void* p : ptrs) if (p) (void) hipFree(p);
-    d_probs = d_bnd = d_tb = d_imd = d_res = d_queue = d_skl = d_nskl = d_cpos = d_ranges = d_scores = nullptr;
-}
+void DevRun::release() {}       // buffers belong to ctx->pool[flavour]
+
+#define POOLGET(dst, slot, bytes)                                                        \
+    do {                                                                                 \
+        (dst) = ctx->pool[flav].get((slot), (size_t) (bytes));                           \
+        if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
+    } while (0)
 
 int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int flav)
 {
@@ -245,20 +265,20 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     tb_bytes = tb_tot;
     const int bw = (flav == 2) ? 4 : 2;
     const int nn = std::max(n, 1);
-    HIPCHK(hipMalloc(&d_probs, sizeof(DevProblem) * nn));
-    HIPCHK(hipMalloc(&d_bnd, sizeof(int32_t) * bw * std::max<int64_t>(bnd_tot, 1)));
-    HIPCHK(hipMalloc(&d_res, sizeof(DevResult) * nn));
-    HIPCHK(hipMalloc(&d_queue, sizeof(int)));
+    skl_cap = std::min(std::max(max_skl, 1), 1024);     // typical lists are short; overflow is re-walked
+    POOLGET(d_probs, POOL_PROBS, sizeof(DevProblem) * nn);
+    POOLGET(d_bnd, POOL_BND, sizeof(int32_t) * bw * std::max<int64_t>(bnd_tot, 1));
+    POOLGET(d_res, POOL_RES, sizeof(DevResult) * nn);
     if (flav == 1) {
-        HIPCHK(hipMalloc(&d_tb, std::max<int64_t>(tb_tot, 16)));
-        HIPCHK(hipMalloc(&d_skl, sizeof(int2) * (int64_t) std::max(max_skl, 1) * nn));
-        HIPCHK(hipMalloc(&d_nskl, sizeof(int) * nn));
+        POOLGET(d_tb, POOL_TB, std::max<int64_t>(tb_tot, 16));
+        POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
+        POOLGET(d_nskl, POOL_NSKL, sizeof(int) * nn);
     }
     if (flav == 2) {
-        HIPCHK(hipMalloc(&d_imd, sizeof(int32_t) * std::max<int64_t>(imd_tot, 1)));
-        HIPCHK(hipMalloc(&d_cpos, sizeof(int32_t) * 10 * (max_n_im + 1) * nn));
-        HIPCHK(hipMalloc(&d_ranges, sizeof(int32_t) * 4 * nn));
-        HIPCHK(hipMalloc(&d_scores, sizeof(int32_t) * nn));
+        POOLGET(d_imd, POOL_IMD, sizeof(int32_t) * std::max<int64_t>(imd_tot, 1));
+        POOLGET(d_cpos, POOL_CPOS, sizeof(int32_t) * 10 * (max_n_im + 1) * nn);
+        POOLGET(d_ranges, POOL_RANGES, sizeof(int32_t) * 4 * nn);
+        POOLGET(d_scores, POOL_SCORES, sizeof(int32_t) * nn);
     }
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
     return 0;
@@ -271,8 +291,7 @@ int DevRun::launch()
     SweepArgs A;
     A.sc = (const DevScoring*) store->d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n;
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
-    A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.queue = (int*) d_queue;
-    HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(int), ctx->stream));
+    A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res;
     const int grid = (n + 3) / 4;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, &A, grid, ctx->stream));
@@ -280,7 +299,7 @@ int DevRun::launch()
     if (flavour == 1) {
         WalkArgs W;
         W.probs = A.probs; W.n_probs = n; W.tb = (const uint8_t*) d_tb; W.res = (const DevResult*) d_res;
-        W.skl = (int2*) d_skl; W.n_skl = (int*) d_nskl; W.skl_cap = max_skl;
+        W.skl = (int2*) d_skl; W.n_skl = (int*) d_nskl; W.skl_cap = skl_cap;
         HIPCHK(spdp_launch_walk(&W, ctx->stream));
     }
     if (flavour == 2) {
@@ -308,14 +327,26 @@ int DevRun::fetch_results(std::vector<DevResult>& out)
     return 0;
 }
 
-int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<SpdpSkl>& skl)
+int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::vector<SpdpSkl>& skl)
 {
-    n_skl.resize(n);
-    skl.resize((size_t) n * max_skl);
-    if (n) {
-        HIPCHK(hipMemcpy(n_skl.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(skl.data(), d_skl, sizeof(SpdpSkl) * skl.size(), hipMemcpyDeviceToHost));
+    const int flav = 1;
+    n_skl.resize(n); off.assign(n + 1, 0);
+    if (!n) { skl.clear(); return 0; }
+    HIPCHK(hipMemcpy(n_skl.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        if (n_skl[i] > skl_cap) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
+        off[i + 1] = off[i] + std::max(n_skl[i], 0);
     }
+    skl.resize(off[n]);
+    if (!off[n]) return 0;
+    void *d_off, *d_pack;
+    POOLGET(d_off, POOL_SKLOFF, sizeof(int64_t) * (n + 1));
+    POOLGET(d_pack, POOL_SKLPACK, sizeof(int2) * off[n]);
+    HIPCHK(hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(spdp_launch_pack((const int2*) d_skl, skl_cap, (const int*) d_nskl, (const int64_t*) d_off,
+                            (int2*) d_pack, n, ctx->stream));
+    HIPCHK(hipMemcpyAsync(skl.data(), d_pack, sizeof(SpdpSkl) * off[n], hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -369,14 +400,15 @@ int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem*
     if (run.build(&st, items_of(sc, probs, n_probs), 1) || run.launch() || run.sync()) return -1;
     std::vector<DevResult> r;
     std::vector<int> nskl;
+    std::vector<int64_t> off;
     std::vector<SpdpSkl> skl;
-    if (run.fetch_results(r) || run.fetch_skl(nskl, skl)) return -1;
+    if (run.fetch_results(r) || run.fetch_skl(nskl, off, skl)) return -1;
     for (int i = 0; i < n_probs; ++i) {
         out[i].score = r[i].score;
         if (nskl[i] < 0) { ctx->err = "traceback walk failed"; return -1; }
         out[i].n_skl = nskl[i];
         out[i].skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * std::max(1, nskl[i]));
-        memcpy(out[i].skl, skl.data() + (size_t) i * run.max_skl, sizeof(SpdpSkl) * nskl[i]);
+        memcpy(out[i].skl, skl.data() + off[i], sizeof(SpdpSkl) * nskl[i]);
     }
     return 0;
 }

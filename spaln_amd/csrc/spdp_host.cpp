@@ -322,13 +322,14 @@ struct Aligner {
             stats[7] += (double) run.tb_bytes;
             std::vector<DevResult> res;
             std::vector<int> nskl;
+            std::vector<int64_t> off;
             std::vector<SpdpSkl> skl;
-            if (run.fetch_results(res) || run.fetch_skl(nskl, skl)) return -1;
+            if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
             for (size_t k = 0; k < tbs.size(); ++k) {
                 const TbItem& t = tbs[k];
                 if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
                 set_score(t.job, t.top, res[k].score);
-                const SpdpSkl* s = skl.data() + k * run.max_skl;
+                const SpdpSkl* s = skl.data() + off[k];
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
             }
         }
@@ -391,12 +392,11 @@ int64_t spdp_batch_cells(const SpdpBatch* bt)
 int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms)
 {
     if (!bt) return -1;
-    if (!bt->score_built) {
+    {   // descriptors are rebuilt per call: work buffers live in the context's pool
         std::vector<RunItem> items;
         for (size_t i = 0; i < bt->probs.size(); ++i)
             items.push_back(spdp_item_of(bt->probs[i], (int) i, bt->store.sc.sh));
         if (bt->score.build(&bt->store, items, 0)) return -1;
-        bt->score_built = true;
     }
     if (bt->score.launch() || bt->score.sync()) return -1;
     if (kernel_ms) *kernel_ms = bt->score.kernel_ms;

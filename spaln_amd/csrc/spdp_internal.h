@@ -19,7 +19,6 @@ struct SweepArgs {
     uint8_t*          tb;         // forward: traceback codes
     int*              imd;        // udh: hlnk0, hlnk1, vlnk0, vlnk1 per intermediate
     DevResult*        res;
-    int*              queue;      // atomic problem counter
 };
 
 struct WalkArgs {
@@ -46,8 +45,23 @@ struct CposArgs {
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, const SweepArgs* args, int grid, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
+extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
+                                       int2* packed, int n_probs, hipStream_t s);
+
+// grow-only device allocations reused across launches (hipMalloc / hipFree of multi-GB
+// work buffers per batch costs seconds)
+struct DevPool {
+    enum { N_SLOTS = 16 };
+    void*  ptr[N_SLOTS] = {nullptr};
+    size_t cap[N_SLOTS] = {0};
+    void*  get(int slot, size_t bytes);
+    void   release();
+};
+enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSKL, POOL_CPOS,
+       POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
+    DevPool pool[3];                 // one pool per sweep flavour (they coexist in a pipeline)
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -92,8 +106,9 @@ struct DevRun {
     int64_t total_cells = 0, tb_bytes = 0;
     std::vector<DevProblem> h_probs;
     void *d_probs = nullptr, *d_bnd = nullptr, *d_tb = nullptr, *d_imd = nullptr, *d_res = nullptr,
-         *d_queue = nullptr, *d_skl = nullptr, *d_nskl = nullptr, *d_cpos = nullptr,
-         *d_ranges = nullptr, *d_scores = nullptr;
+         *d_skl = nullptr, *d_nskl = nullptr, *d_cpos = nullptr,
+         *d_ranges = nullptr, *d_scores = nullptr;         // all owned by ctx->pool[flavour]
+    int skl_cap = 0;
     float kernel_ms = 0.f;
     DevRun() = default;
     DevRun(const DevRun&) = delete;
@@ -103,7 +118,8 @@ struct DevRun {
     int launch();                       // async on ctx->stream: sweep (+ walk / cpos)
     int sync();                         // waits, fills kernel_ms
     int fetch_results(std::vector<DevResult>& out);
-    int fetch_skl(std::vector<int>& n_skl, std::vector<SpdpSkl>& skl);       // forward
+    // forward: records of problem i are skl[off[i] .. off[i] + n_skl[i])
+    int fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::vector<SpdpSkl>& skl);
     int fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges);
     void release();
 };

@@ -18,7 +18,8 @@
 // build bit for bit -- with int32 scores instead of re-based int16 ones (adds
 // saturate at SHRT_MIN as _mm256_adds_epi16 does on the low side).
 //
-// One wave = one problem at a time; waves pull problems from an atomic queue.
+// One wave = one problem (four problems per 256-thread block); the hardware dispatcher
+// balances the load.
 // HBM traffic per 64 rows x 1 column: 8 B column record (+3 L2 re-reads),
 // 8/16 B boundary read + 8/16 B boundary write; forward adds 1 B / cell of
 // traceback codes.
@@ -622,5 +623,23 @@ extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t stream)
 {
     CposArgs A = *a;
     hipLaunchKernelGGL(spdp_udh_cpos, dim3((A.n_probs + 63) / 64), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}
+
+// gathers the per-problem record slots of spdp_walk into one contiguous array
+__global__ void spdp_pack_skl(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
+                              int2* packed, int n_probs)
+{
+    const int pi = blockIdx.x;
+    if (pi >= n_probs) return;
+    const int cnt = n_skl[pi];
+    const int2* src = skl + (int64_t) pi * skl_cap;
+    int2* dst = packed + off[pi];
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+}
+extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
+                                       int2* packed, int n_probs, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spdp_pack_skl, dim3(n_probs), dim3(64), 0, stream, skl, skl_cap, n_skl, off, packed, n_probs);
     return hipGetLastError();
 }

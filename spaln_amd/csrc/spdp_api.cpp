@@ -294,7 +294,9 @@ int DevRun::launch()
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res;
     const int grid = (n + 3) / 4;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, &A, grid, ctx->stream));
+    const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
+    const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;
+    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (flavour == 1) {
         WalkArgs W;

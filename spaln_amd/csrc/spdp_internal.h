@@ -42,7 +42,8 @@ struct CposArgs {
     int               cpos_stride;
 };
 
-extern "C" hipError_t spdp_launch_sweep(int flavour, int local, const SweepArgs* args, int grid, hipStream_t s);
+extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
+                                        int grid, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,

@@ -50,158 +50,175 @@ template <int J>
 __device__ __forceinline__ int row_pick(int src)
 {
     if constexpr (J == 0) return src;
-    else return __builtin_amdgcn_update_dpp(0, src, DPP_ROW_SL(J), 0xf, 0xf, false);
+    else return __builtin_amdgcn_mov_dpp(src, DPP_ROW_SL(J), 0xf, 0xf, true);
 }
 // lane 0 of every row <- lane 15 of that row
 __device__ __forceinline__ int row_ror1(int src)
 {
-    return __builtin_amdgcn_update_dpp(0, src, DPP_ROW_RR(1), 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(src, DPP_ROW_RR(1), 0xf, 0xf, true);
 }
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int sadd16(int a, int b) { return max(a + b, SPDP_FLOOR16); }
 
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
+// intron-length penalty modes: flat (nquant == 1, the -A3 model), LDS table, select chain
+enum { NQ_FLAT = 0, NQ_TABLE = 1, NQ_CHAIN = 2 };
+#define SPDP_PEN_TAB 4096
 
 // ---------------------------------------------------------------------------
-template <int FL, bool LOCAL>
+template <int FL, bool LOCAL, int NQM>
 __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 {
     constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
     __shared__ int s_mtx[32 * 32];
+    __shared__ short s_pen[NQM == NQ_TABLE ? SPDP_PEN_TAB : 2];
 
     const DevScoring* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
+    const int nquant = sc->nquant;
+    const int pen_cap = (NQM == NQ_TABLE) ? sc->qm_len[nquant - 2] + 1 : 0;
+    if constexpr (NQM == NQ_TABLE) {
+        // pen(hil) = qm_pen[j] for the last j with hil > qm_len[j-1]  (fwd2s1_wip_simd.h:163-167)
+        for (int h = threadIdx.x; h <= pen_cap; h += blockDim.x) {
+            int pv = sc->qm_pen[0];
+            for (int j = 1; j < nquant; ++j) if (h > sc->qm_len[j - 1]) pv = sc->qm_pen[j];
+            s_pen[h] = (short) pv;
+        }
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;                    // DPP row = stripe slot of the pass
     const int k = lane & 15;                    // lane within the stripe
     const int ge = sc->gep, gn = sc->gep + sc->gop;
-    const int spj = sc->spj, llmt = sc->llmt, nquant = sc->nquant;
-    const int q0 = sc->qm_len[0], q1 = sc->qm_len[1], q2 = sc->qm_len[2], q3 = sc->qm_len[3],
-              q4 = sc->qm_len[4], q5 = sc->qm_len[5], q6 = sc->qm_len[6];
-    const int p0 = sc->qm_pen[0], p1 = sc->qm_pen[1], p2 = sc->qm_pen[2], p3 = sc->qm_pen[3],
-              p4 = sc->qm_pen[4], p5 = sc->qm_pen[5], p6 = sc->qm_pen[6], p7 = sc->qm_pen[7];
+    const int spj = sc->spj, llmt = sc->llmt;
+    const int p0 = sc->qm_pen[0];
 
     // one wave = one problem; the hardware dispatcher balances the load (blocks are
     // launched as CUs free up), so no software queue is needed
-    {
-        const int pi = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-        if (pi >= A.n_probs) return;
-        const DevProblem P = A.probs[pi];
-        const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
-        const int lw = P.lw, up = P.up, width = P.width;
-        const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
-        const bool LocalL = LOCAL && a_exgl && b_exgl;
-        const bool LocalR = LOCAL && a_exgr && b_exgr;
-        int* __restrict__ bnd = A.bnd + P.bnd_off * BW;
-        const int2* __restrict__ cols = A.cols + P.col_off;
-        const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
-        const int n_ent = P.buf_size + SPDP_BND_PAD;
+    const int pi = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (pi >= A.n_probs) return;
+    const DevProblem P = A.probs[pi];
+    const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
+    const int lw = P.lw, up = P.up, width = P.width;
+    const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
+    const bool LocalL = LOCAL && a_exgl && b_exgl;
+    const bool LocalR = LOCAL && a_exgr && b_exgr;
+    int* __restrict__ bnd = A.bnd + P.bnd_off * BW;
+    const int2* __restrict__ cols = A.cols + P.col_off;
+    const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
+    const int n_ent = P.buf_size + SPDP_BND_PAD;
 #define BIDX(r) ((r) - lw + 1)
 
-        // ---- fhinitS1 (src/fwd2s1_simd.cc:163-239): boundary values by diagonal
-        {
-            const int rl = b_left - a_left;
-            int rr = min(b_right - a_left, up);
-            int rr_g = rr;                                   // global: ramp stops where it reaches nevsel
-            if (!a_exgl && ge) rr_g = min(rr, (SPDP_NEV16 - sc->gop) / ge + rl);
-            const int ru = up + 2 * SPDP_NELEM;
-            for (int e = lane; e < n_ent; e += 64) {
-                const int r = e + lw - 1;
-                int h = SPDP_NEV16;
-                if (b_exgl && r >= lw && r < rl) h = 0;
-                if (a_exgl) { if (r >= rl && r <= rr) h = 0; }
-                else {
-                    if (r == rl) h = 0;
-                    else if (r == rl + 1) h = sc->gop + ge;
-                    else if (ge) { if (r > rl + 1 && r < rr_g) h = sc->gop + ge + (r - rl - 1) * ge; }
-                    else if (r > rl + 1 && r < rr) h = sc->gop;
-                }
-                if constexpr (FL == FL_UDH) {
-                    int c;                                   // link = diagonal where the path starts
-                    if (r >= rl) c = a_exgl ? ((r < ru) ? r : 0) : rl;
-                    else         c = b_exgl ? r : rl;
-                    if (r > ru) c = 0;
-                    reinterpret_cast<int4*>(bnd)[e] = make_int4(h, SPDP_NEV16, c, c);
-                } else {
-                    reinterpret_cast<int2*>(bnd)[e] = make_int2(h, SPDP_NEV16);
-                }
+    // ---- fhinitS1 (src/fwd2s1_simd.cc:163-239): boundary values by diagonal
+    {
+        const int rl = b_left - a_left;
+        int rr = min(b_right - a_left, up);
+        int rr_g = rr;                                   // global: ramp stops where it reaches nevsel
+        if (!a_exgl && ge) rr_g = min(rr, (SPDP_NEV16 - sc->gop) / ge + rl);
+        const int ru = up + 2 * SPDP_NELEM;
+        for (int e = lane; e < n_ent; e += 64) {
+            const int r = e + lw - 1;
+            int h = SPDP_NEV16;
+            if (b_exgl && r >= lw && r < rl) h = 0;
+            if (a_exgl) { if (r >= rl && r <= rr) h = 0; }
+            else {
+                if (r == rl) h = 0;
+                else if (r == rl + 1) h = sc->gop + ge;
+                else if (ge) { if (r > rl + 1 && r < rr_g) h = sc->gop + ge + (r - rl - 1) * ge; }
+                else if (r > rl + 1 && r < rr) h = sc->gop;
             }
             if constexpr (FL == FL_UDH) {
-                int* imd = A.imd + P.imd_off;
-                const int tot = P.n_im * 4 * width;
-                for (int e = lane; e < tot; e += 64) imd[e] = END_OF_ULK;
+                int c;                                   // link = diagonal where the path starts
+                if (r >= rl) c = a_exgl ? ((r < ru) ? r : 0) : rl;
+                else         c = b_exgl ? r : rl;
+                if (r > ru) c = 0;
+                reinterpret_cast<int4*>(bnd)[e] = make_int4(h, SPDP_NEV16, c, c);
+            } else {
+                reinterpret_cast<int2*>(bnd)[e] = make_int2(h, SPDP_NEV16);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // UDH: intermediate rows (src/fwd2s1_wip_simd.h:503-508)
-        const int n_im = (FL == FL_UDH) ? P.n_im : 0;
-        const int imd_step = (FL == FL_UDH) ? (a_right - a_left + n_im) / (n_im + 1) : 0;
-        int imd_cur = 0;
+        if constexpr (FL == FL_UDH) {
+            int* imd = A.imd + P.imd_off;
+            const int tot = P.n_im * 4 * width;
+            for (int e = lane; e < tot; e += 64) imd[e] = END_OF_ULK;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 
-        // running maximum for local right ends: value, then first (stripe, step, lane)
-        int best_val = SPDP_NEV16, best_mr = a_right, best_nr = b_right, best_ml = a_left, best_ulk = END_OF_ULK;
-        unsigned long long best_key = ~0ull;
+    // UDH: intermediate rows (src/fwd2s1_wip_simd.h:503-508)
+    const int n_im = (FL == FL_UDH) ? P.n_im : 0;
+    const int imd_step = (FL == FL_UDH) ? (a_right - a_left + n_im) / (n_im + 1) : 0;
+    int imd_cur = 0;
 
-        int64_t tb_base = P.tb_off;                         // forward: byte offset of the pass' first stripe
-        const int n_stripes = (a_right - a_left + SPDP_NELEM - 1) / SPDP_NELEM;
-        for (int s0 = 0; s0 < n_stripes; s0 += 4) {
-            // ---- geometry of my stripe (row g of the wave)
-            const int s = s0 + g;
-            const int ml = a_left + s * SPDP_NELEM;
-            const bool has = s < n_stripes;
-            const int j9 = has ? min(SPDP_NELEM, a_right - ml) : 0;
-            const int j8 = j9 - 1;
-            const int n_start = max(b_left, lw + ml);
-            const int n9 = min(b_right, up + (ml + j9) + 1) + j9;
-            const int n_end = (FL == FL_FORWARD) ? n9 + 1 : n9;
-            const int len = has ? max(0, n_end - n_start) : 0;
-            const int nb = (len + 15) >> 4;
-            // blocks this pass runs: row g is active for blocks [LAG*g, LAG*g + nb)
-            int tot = SPDP_GROUP_LAG * g + nb;
-            tot = max(tot, __shfl_xor(tot, 16));
-            tot = max(tot, __shfl_xor(tot, 32));
-            // traceback offsets of the 4 stripes of this pass
-            int64_t my_tb = 0;
-            if constexpr (FL == FL_FORWARD) {
-                const int nb0 = __shfl(nb, 0), nb1 = __shfl(nb, 16), nb2 = __shfl(nb, 32), nb3 = __shfl(nb, 48);
-                my_tb = tb_base + 256ll * ((g > 0 ? nb0 : 0) + (g > 1 ? nb1 : 0) + (g > 2 ? nb2 : 0));
-                tb_base += 256ll * (nb0 + nb1 + nb2 + nb3);
-            }
-            // UDH: the reference walks its intermediates in order and tests, per stripe, only the
-            // current one (src/fwd2s1_wip_simd.h:527,806-811): replay that pointer over my 4 stripes
-            int imd_i = -1, k8 = -1;
-            if constexpr (FL == FL_UDH) {
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int ml_gg = a_left + (s0 + gg) * SPDP_NELEM;
-                    if (imd_cur < n_im && ml_gg < a_right) {
-                        const int cand = a_left + (imd_cur + 1) * imd_step;
-                        const int mm = a_left + (cand - a_left - 1) / SPDP_NELEM * SPDP_NELEM;
-                        if (mm == ml_gg) {
-                            if (gg == g) { imd_i = imd_cur; k8 = cand - mm - 1; }
-                            ++imd_cur;
-                        }
+    // running maximum for local right ends: value, then first (stripe, step, lane)
+    int best_val = SPDP_NEV16, best_mr = a_right, best_nr = b_right, best_ml = a_left, best_ulk = END_OF_ULK;
+    unsigned long long best_key = ~0ull;
+
+    int64_t tb_base = P.tb_off;                         // forward: byte offset of the pass' first stripe
+    const int n_stripes = (a_right - a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+    for (int s0 = 0; s0 < n_stripes; s0 += 4) {
+        // ---- geometry of my stripe (row g of the wave)
+        const int s = s0 + g;
+        const int ml = a_left + s * SPDP_NELEM;
+        const bool has = s < n_stripes;
+        const int j9 = has ? min(SPDP_NELEM, a_right - ml) : 0;
+        const int j8 = j9 - 1;
+        const int n_start = max(b_left, lw + ml);
+        const int n9 = min(b_right, up + (ml + j9) + 1) + j9;
+        const int n_end = (FL == FL_FORWARD) ? n9 + 1 : n9;
+        const int len = has ? max(0, n_end - n_start) : 0;
+        const int nb = (len + 15) >> 4;
+        // blocks this pass runs: row g is active for blocks [LAG*g, LAG*g + nb)
+        const int nb0 = __builtin_amdgcn_readlane(nb, 0), nb1 = __builtin_amdgcn_readlane(nb, 16),
+                  nb2 = __builtin_amdgcn_readlane(nb, 32), nb3 = __builtin_amdgcn_readlane(nb, 48);
+        const int tot = max(max(nb0, SPDP_GROUP_LAG + nb1),
+                            max(2 * SPDP_GROUP_LAG + nb2, 3 * SPDP_GROUP_LAG + nb3));
+        int64_t my_tb = 0;
+        if constexpr (FL == FL_FORWARD) {
+            my_tb = tb_base + 256ll * ((g > 0 ? nb0 : 0) + (g > 1 ? nb1 : 0) + (g > 2 ? nb2 : 0));
+            tb_base += 256ll * (nb0 + nb1 + nb2 + nb3);
+        }
+        // UDH: the reference walks its intermediates in order and tests, per stripe, only the
+        // current one (src/fwd2s1_wip_simd.h:527,806-811): replay that pointer over my 4 stripes
+        int imd_i = -1, k8 = -1;
+        bool pass_imd = false;
+        if constexpr (FL == FL_UDH) {
+            for (int gg = 0; gg < 4; ++gg) {
+                const int ml_gg = a_left + (s0 + gg) * SPDP_NELEM;
+                if (imd_cur < n_im && ml_gg < a_right) {
+                    const int cand = a_left + (imd_cur + 1) * imd_step;
+                    const int mm = a_left + (cand - a_left - 1) / SPDP_NELEM * SPDP_NELEM;
+                    if (mm == ml_gg) {
+                        if (gg == g) { imd_i = imd_cur; k8 = cand - mm - 1; }
+                        ++imd_cur; pass_imd = true;
                     }
                 }
             }
-            const bool imd_row = (FL == FL_UDH) && imd_i >= 0;
-            int* imd_p = nullptr;
-            if constexpr (FL == FL_UDH) if (imd_row) imd_p = A.imd + P.imd_off + (int64_t) imd_i * 4 * width;
+        }
+        const bool imd_row = (FL == FL_UDH) && imd_i >= 0;
+        int* imd_p = nullptr;
+        if constexpr (FL == FL_UDH) if (imd_row) imd_p = A.imd + P.imd_off + (int64_t) imd_i * 4 * width;
+        // only the last stripe of a problem can be partial (fewer than 16 rows)
+        const bool pass_partial = (s0 + 4 >= n_stripes) && ((a_right - a_left) & 15);
 
-            // my residue row of the substitution matrix (byte address in LDS)
-            const int acode = (k < j9) ? acod[ml + k] : 0;
-            const int* mrow = s_mtx + acode * 32;
+        // my residue row of the substitution matrix
+        const int acode = (k < j9) ? acod[ml + k] : 0;
+        const int* mrow = s_mtx + acode * 32;
 
-            // per-lane DP state
-            int Hs = SPDP_NEV16, Fs = SPDP_NEV16, E = SPDP_NEV16, Hd = SPDP_NEV16;
-            int hv2 = SPDP_NEV16, hil = 0, sigp = 0, basep = 0;
-            int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
-            int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
-            int pv_stale = 0; bool stale_on = false;                   // UDH Local first-column quirk (unused)
-            int outH = 0, outF = 0, outC = 0, outFC = 0;
-            (void) pv_stale; (void) stale_on;
+        // per-lane DP state
+        int Hs = SPDP_NEV16, Fs = SPDP_NEV16, E = SPDP_NEV16, Hd = SPDP_NEV16;
+        int hv2 = SPDP_NEV16, hil = 0, sigp = 0, basep = 0;
+        int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
+        int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
+        int outH = 0, outF = 0, outC = 0, outFC = 0;
+
+        auto run_pass = [&](auto partial_tag, auto imd_tag) {
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            constexpr bool IMD = decltype(imd_tag)::value;
             for (int blk = 0; blk < tot; ++blk) {
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
                 if (lb >= 0 && lb < nb) {
@@ -240,7 +257,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 
 #define STEP(J)                                                                                  \
                     {                                                                                        \
-                        const int n = n0 + J;                                                                \
                         /* neighbour exchange */                                                             \
                         const int upH = row_shr1(row_pick<J>(chH), Hs);                                      \
                         const int upF = row_shr1(row_pick<J>(chF), Fs);                                      \
@@ -259,15 +275,15 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                             f = max3i(upF + ge, upH + gn, SPDP_FLOOR16);                                     \
                             h = max3i(Hd + pv, f, E);                                                        \
                         } else {                                                                             \
-                            const int eo = sadd16(Hs, gn), ee = sadd16(E, ge);                               \
-                            const bool ext = ee > eo;                                                        \
+                            const int eo = sadd16(Hs, gn), ee = E + ge;                                      \
+                            const bool ext = ee > eo;            /* == sadd16(E, ge) > eo */                 \
                             E = ext ? ee : eo;                                                               \
-                            if (!ext) { code |= TB_NHOR; ec = Cs; }                                          \
-                            const int fo = sadd16(upH, gn), fe = sadd16(upF, ge);                            \
+                            if constexpr (FL == FL_UDH) ec = ext ? ec : Cs;                                  \
+                            const int fo = sadd16(upH, gn), fe = upF + ge;                                   \
                             const bool fext = fe > fo;                                                       \
                             f = fext ? fe : fo;                                                              \
-                            fc = fext ? upFC : upC;                                                          \
-                            if (!fext) code |= TB_NVER;                                                      \
+                            if constexpr (FL == FL_UDH) fc = fext ? upFC : upC;                              \
+                            if constexpr (FL == FL_FORWARD) code = (ext ? 0u : (unsigned) TB_NHOR) | (fext ? 0u : (unsigned) TB_NVER); \
                             h = sadd16(Hd, pv); hc = Cd;                                                     \
                             unsigned dir = TB_DIAG;                                                          \
                             if (f > h) { h = f; hc = fc; dir = TB_VERT; pb3 = 2; }                           \
@@ -279,28 +295,25 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                             const int s3 = sigp >> 16;                                                       \
                             const int s5 = (int) (short) sigp;                                               \
                             int pen = p0;                                                                    \
-                            if (nquant > 1) {                                                                \
-                                pen = (hil > q0) ? p1 : pen;                                                 \
-                                if (nquant > 2) pen = (hil > q1) ? p2 : pen;                                 \
-                                if (nquant > 3) pen = (hil > q2) ? p3 : pen;                                 \
-                                if (nquant > 4) pen = (hil > q3) ? p4 : pen;                                 \
-                                if (nquant > 5) pen = (hil > q4) ? p5 : pen;                                 \
-                                if (nquant > 6) pen = (hil > q5) ? p6 : pen;                                 \
-                                if (nquant > 7) pen = (hil > q6) ? p7 : pen;                                 \
+                            if constexpr (NQM == NQ_TABLE) pen = s_pen[min(hil, pen_cap)];                   \
+                            if constexpr (NQM == NQ_CHAIN) {                                                 \
+                                for (int jq = 1; jq < nquant; ++jq)                                          \
+                                    pen = (hil > sc->qm_len[jq - 1]) ? sc->qm_pen[jq] : pen;                 \
                             }                                                                                \
-                            int x = sadd16(sadd16(hv2, s3), pen);                                            \
+                            int x = sadd16(hv2, s3) + pen;                                                   \
                             x = (hil > llmt) ? x : SPDP_NEV16;                                               \
-                            if (x > h) {                                                                     \
-                                h = x; is_acc = true;                                                        \
-                                if constexpr (FL != FL_SCORE) { hc = hc2; code = (code & ~15u) | TB_ACCR; }  \
+                            if constexpr (FL == FL_SCORE) { h = max(h, x); }                                 \
+                            else if (x > h) {                                                                \
+                                h = x; is_acc = true; hc = hc2;                                              \
+                                if constexpr (FL == FL_FORWARD) code = (code & ~15u) | TB_ACCR;              \
                             }                                                                                \
                             if (LOCAL && LocalL && h < 0) { h = 0; if constexpr (FL == FL_FORWARD) code &= 15u; } \
-                            int qd = sadd16(h, s5);                                                          \
+                            int qd = h + s5;                                                                 \
                             if constexpr (FL == FL_FORWARD) qd = is_acc ? SPDP_NEV16 : qd;                   \
                             is_don = qd > hv2;                                                               \
                             hv2 = is_don ? qd : hv2;                                                         \
                             if constexpr (FL == FL_UDH) hc2 = is_don ? hc : hc2;                             \
-                            hil = min((is_don ? 0 : hil) + 1, 32767);                                        \
+                            hil = is_don ? 1 : hil + 1;                                                      \
                             if constexpr (FL == FL_FORWARD) code |= is_don ? TB_DONR : 0u;                   \
                         } else if (LOCAL && LocalL && h < 0) {                                               \
                             h = 0; if constexpr (FL == FL_FORWARD) code &= 15u;                              \
@@ -308,11 +321,12 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                         Hd = upH; Hs = h; Fs = f;                                                            \
                         if constexpr (FL == FL_UDH) { Cd = upC; Cs = hc; FCs = fc; }                         \
                         if constexpr (FL == FL_FORWARD) {                                                    \
-                            if (k >= j9) code = 0;                                                           \
+                            if constexpr (PARTIAL) { if (k >= j9) code = 0; }                                \
                             code4[J >> 2] |= (code & 0xffu) << (8 * (J & 3));                                \
                         }                                                                                    \
-                        if constexpr (FL == FL_UDH) {                                                        \
+                        if constexpr (FL == FL_UDH && IMD) {                                                 \
                             /* scalar bookkeeping of the intermediate row (lane k8 of its stripe) */         \
+                            const int n = n0 + J;                                                            \
                             const int rj = n - (ml + 1) - 2 * k;            /* my cell's diagonal */         \
                             if (imd_row && k == k8 && rj >= lw && rj <= up && n < n_end) {                   \
                                 int* hl0 = imd_p + BIDX(rj);                                                 \
@@ -325,6 +339,7 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                             }                                                                                \
                         }                                                                                    \
                         if (LOCAL && LocalR) {                                                               \
+                            const int n = n0 + J;                                                            \
                             if (k < j9 && n < n_end && h >= best_val) {                                      \
                                 const unsigned long long key =                                               \
                                     ((unsigned long long) s << 40) | ((unsigned long long) (n - n_start) << 8) | k; \
@@ -336,10 +351,12 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                         }                                                                                    \
                         /* bottom lane of the stripe -> output shift chain */                                \
                         int bh = Hs, bf = Fs, bc = Cs, bfc = FCs;                                            \
-                        if (j9 < SPDP_NELEM && j9 > 0) {                                                     \
-                            const int src = (lane & 48) + j8;                                                \
-                            bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                      \
-                            if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); }    \
+                        if constexpr (PARTIAL) {                                                             \
+                            if (j9 < SPDP_NELEM && j9 > 0) {                                                 \
+                                const int src = (lane & 48) + j8;                                            \
+                                bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                  \
+                                if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); } \
+                            }                                                                                \
                         }                                                                                    \
                         outH = row_shr1(row_ror1(bh), outH);                                                 \
                         outF = row_shr1(row_ror1(bf), outF);                                                 \
@@ -372,70 +389,89 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-        }
-        // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
-        DevResult R;
-        R.score = SPDP_NEV16; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = END_OF_ULK; R.maxr = 0;
-        R.pad[0] = R.pad[1] = 0;
-        if (LOCAL && LocalR) {
-            // reduce (value desc, key asc) over the wave
-            for (int off = 32; off; off >>= 1) {
-                const int ov = __shfl_xor(best_val, off);
-                const unsigned long long ok = __shfl_xor(best_key, off);
-                const int omr = __shfl_xor(best_mr, off), onr = __shfl_xor(best_nr, off);
-                const int oml = __shfl_xor(best_ml, off), oul = __shfl_xor(best_ulk, off);
-                if (ov > best_val || (ov == best_val && ok < best_key)) {
-                    best_val = ov; best_key = ok; best_mr = omr; best_nr = onr; best_ml = oml; best_ulk = oul;
-                }
-            }
-            R.score = best_val; R.mr = best_mr; R.nr = best_nr; R.ml = best_ml; R.ulk = best_ulk;
+        };
+        if (pass_partial) {
+            if (pass_imd) run_pass(BoolTag<true>{}, BoolTag<true>{});
+            else          run_pass(BoolTag<true>{}, BoolTag<false>{});
         } else {
-            const int rr = b_right - a_right;
-            // first maximum over [lo, hi): returns index (lo if the range is empty)
-            auto argmax_first = [&](int lo, int hi) {
-                int bv = INT32_MIN, bi = INT32_MAX;
-                for (int r = lo + lane; r < hi; r += 64) {
-                    const int v = bnd[(int64_t) BIDX(r) * BW];
-                    if (v > bv) { bv = v; bi = r; }
-                }
-                for (int off = 32; off; off >>= 1) {
-                    const int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                return (bi == INT32_MAX) ? lo : bi;
-            };
-            int maxr = rr;
-            if (a_exgr) maxr = argmax_first(max(lw, b_left - a_right), rr);
-            if (b_exgr) {
-                const int r2 = min(up - 1, b_right - a_left);
-                int mv = argmax_first(rr, r2);
-                if (r2 - rr < 1) mv = rr;
-                if (bnd[(int64_t) BIDX(mv) * BW] > bnd[(int64_t) BIDX(maxr) * BW]) maxr = mv;
-            }
-            R.score = bnd[(int64_t) BIDX(maxr) * BW];
-            if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
-            if constexpr (FL == FL_UDH) R.ulk = bnd[(int64_t) BIDX(maxr) * BW + 2];
-            R.maxr = maxr;
+            if (pass_imd) run_pass(BoolTag<false>{}, BoolTag<true>{});
+            else          run_pass(BoolTag<false>{}, BoolTag<false>{});
         }
-        if (lane == 0) A.res[pi] = R;
-#undef BIDX
     }
+
+    // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
+    DevResult R;
+    R.score = SPDP_NEV16; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = END_OF_ULK; R.maxr = 0;
+    R.pad[0] = R.pad[1] = 0;
+    if (LOCAL && LocalR) {
+        // reduce (value desc, key asc) over the wave
+        for (int off = 32; off; off >>= 1) {
+            const int ov = __shfl_xor(best_val, off);
+            const unsigned long long ok = __shfl_xor(best_key, off);
+            const int omr = __shfl_xor(best_mr, off), onr = __shfl_xor(best_nr, off);
+            const int oml = __shfl_xor(best_ml, off), oul = __shfl_xor(best_ulk, off);
+            if (ov > best_val || (ov == best_val && ok < best_key)) {
+                best_val = ov; best_key = ok; best_mr = omr; best_nr = onr; best_ml = oml; best_ulk = oul;
+            }
+        }
+        R.score = best_val; R.mr = best_mr; R.nr = best_nr; R.ml = best_ml; R.ulk = best_ulk;
+    } else {
+        const int rr = b_right - a_right;
+        // first maximum over [lo, hi): returns index (lo if the range is empty)
+        auto argmax_first = [&](int lo, int hi) {
+            int bv = INT32_MIN, bi = INT32_MAX;
+            for (int r = lo + lane; r < hi; r += 64) {
+                const int v = bnd[(int64_t) BIDX(r) * BW];
+                if (v > bv) { bv = v; bi = r; }
+            }
+            for (int off = 32; off; off >>= 1) {
+                const int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            return (bi == INT32_MAX) ? lo : bi;
+        };
+        int maxr = rr;
+        if (a_exgr) maxr = argmax_first(max(lw, b_left - a_right), rr);
+        if (b_exgr) {
+            const int r2 = min(up - 1, b_right - a_left);
+            int mv = argmax_first(rr, r2);
+            if (r2 - rr < 1) mv = rr;
+            if (bnd[(int64_t) BIDX(mv) * BW] > bnd[(int64_t) BIDX(maxr) * BW]) maxr = mv;
+        }
+        R.score = bnd[(int64_t) BIDX(maxr) * BW];
+        if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
+        if constexpr (FL == FL_UDH) R.ulk = bnd[(int64_t) BIDX(maxr) * BW + 2];
+        R.maxr = maxr;
+    }
+    if (lane == 0) A.res[pi] = R;
+#undef BIDX
 }
 
 // ---------------------------------------------------------------------------
 // host-callable launchers (used by spdp_api.cpp)
-extern "C" hipError_t spdp_launch_sweep(int flavour, int local, const SweepArgs* args,
+template <int FL, bool LOCAL>
+static void launch_nq(int nqm, dim3 grd, dim3 blk, hipStream_t stream, const SweepArgs& A)
+{
+    switch (nqm) {
+    case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT>), grd, blk, 0, stream, A); break;
+    case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE>), grd, blk, 0, stream, A); break;
+    default:       hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_CHAIN>), grd, blk, 0, stream, A); break;
+    }
+}
+
+extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
                                         int grid, hipStream_t stream)
 {
     SweepArgs A = *args;
     dim3 blk(256), grd(grid);
+    const int nqm = nquant <= 1 ? NQ_FLAT : (pen_cap < SPDP_PEN_TAB ? NQ_TABLE : NQ_CHAIN);
     switch (flavour * 2 + (local ? 1 : 0)) {
-    case 0: hipLaunchKernelGGL((spdp_sweep<FL_SCORE, false>), grd, blk, 0, stream, A); break;
-    case 1: hipLaunchKernelGGL((spdp_sweep<FL_SCORE, true>), grd, blk, 0, stream, A); break;
-    case 2: hipLaunchKernelGGL((spdp_sweep<FL_FORWARD, false>), grd, blk, 0, stream, A); break;
-    case 3: hipLaunchKernelGGL((spdp_sweep<FL_FORWARD, true>), grd, blk, 0, stream, A); break;
-    case 4: hipLaunchKernelGGL((spdp_sweep<FL_UDH, false>), grd, blk, 0, stream, A); break;
-    case 5: hipLaunchKernelGGL((spdp_sweep<FL_UDH, true>), grd, blk, 0, stream, A); break;
+    case 0: launch_nq<FL_SCORE, false>(nqm, grd, blk, stream, A); break;
+    case 1: launch_nq<FL_SCORE, true>(nqm, grd, blk, stream, A); break;
+    case 2: launch_nq<FL_FORWARD, false>(nqm, grd, blk, stream, A); break;
+    case 3: launch_nq<FL_FORWARD, true>(nqm, grd, blk, stream, A); break;
+    case 4: launch_nq<FL_UDH, false>(nqm, grd, blk, stream, A); break;
+    case 5: launch_nq<FL_UDH, true>(nqm, grd, blk, stream, A); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -61,11 +61,25 @@ __device__ __forceinline__ int row_ror1(int src)
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int sadd16(int a, int b) { return max(a + b, SPDP_FLOOR16); }
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+// L1-bypassing loads for data another row of this wave stored a few blocks ago
+__device__ __forceinline__ int4 ld_nt4(const int* p)
+{
+    const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int2 ld_nt2(const int* p)
+{
+    const v2i_t v = __builtin_nontemporal_load(reinterpret_cast<const v2i_t*>(p));
+    return make_int2(v.x, v.y);
+}
+
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // intron-length penalty modes: flat (nquant == 1, the -A3 model), LDS table, select chain
 enum { NQ_FLAT = 0, NQ_TABLE = 1, NQ_CHAIN = 2 };
-#define SPDP_PEN_TAB 4096
+#define SPDP_PEN_TAB 2048
 
 // ---------------------------------------------------------------------------
 template <int FL, bool LOCAL, int NQM>
@@ -74,6 +88,11 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
     __shared__ int s_mtx[32 * 32];
     __shared__ short s_pen[NQM == NQ_TABLE ? SPDP_PEN_TAB : 2];
+    // per wave, per DPP row: a 2 x 48-entry ring of column records (every record is written
+    // twice, 48 slots apart, so that any 31-column window is contiguous) and the 16 boundary
+    // entries of the current block
+    __shared__ int2 s_col[4][4][96];
+    __shared__ int  s_feed[4][4][16 * BW];
 
     const DevScoring* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
@@ -110,6 +129,8 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     const int2* __restrict__ cols = A.cols + P.col_off;
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int n_ent = P.buf_size + SPDP_BND_PAD;
+    int* __restrict__ stage = bnd + (int64_t) n_ent * BW;      // 4 rows x 16 steps of bottom-lane results
+    const int wv = threadIdx.x >> 6;
 #define BIDX(r) ((r) - lw + 1)
 
     // ---- fhinitS1 (src/fwd2s1_simd.cc:163-239): boundary values by diagonal
@@ -211,10 +232,13 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 
         // per-lane DP state
         int Hs = SPDP_NEV16, Fs = SPDP_NEV16, E = SPDP_NEV16, Hd = SPDP_NEV16;
-        int hv2 = SPDP_NEV16, hil = 0, sigp = 0, basep = 0;
+        int hv2 = SPDP_NEV16, hil = 0;
         int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
         int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
-        int outH = 0, outF = 0, outC = 0, outFC = 0;
+        const bool is_bottom = has && k == j8;                     // lane that owns the stripe's last row
+        int2* const colring = &s_col[wv][g][0];
+        int*  const feed = &s_feed[wv][g][0];
+        int*  const my_stage = stage + (g * 16) * BW;
 
         auto run_pass = [&](auto partial_tag, auto imd_tag) {
             constexpr bool PARTIAL = decltype(partial_tag)::value;
@@ -224,50 +248,62 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                 if (lb >= 0 && lb < nb) {
                     const int n0 = n_start + lb * 16;                   // sweep step of j = 0
                     if (lb == 0) {
-                        // stripe start: pipes are empty except the base pipe, and lane 0's
-                        // up-left neighbour comes from the boundary array
-                        const int c = n_start - 1 - k;                 // column lane k "had" one step before
-                        basep = (c > b_left && c <= b_right) ? cols[c].y : 0;
+                        // stripe start: the signal pipes are empty (zero), the residue pipe holds
+                        // what in-window lanes need, and lane 0's up-left neighbour comes from the
+                        // boundary array
+                        const int c = n_start - 1 - k;
+                        const int2 rec0 = make_int2(0, (c > b_left && c <= b_right) ? cols[c].y : 0);
+                        colring[15 - k] = rec0; colring[15 - k + 48] = rec0;
                         const int r = n_start - (ml + 1);
                         donor_r = r;
                         if (k == 0) {
-                            Hd = bnd[(int64_t) BIDX(r) * BW];
-                            if constexpr (FL == FL_UDH) Cd = bnd[(int64_t) BIDX(r) * BW + 2];
+                            Hd = __builtin_nontemporal_load(&bnd[(int64_t) BIDX(r) * BW]);
+                            if constexpr (FL == FL_UDH) Cd = __builtin_nontemporal_load(&bnd[(int64_t) BIDX(r) * BW + 2]);
                         }
                     }
                     // ---- chunk loads: 16 boundary entries and 16 column records per stripe
-                    int chH, chF, chC = 0, chFC = 0;
                     {
                         const int r1 = n0 + k - ml;                     // r + 1 of step j = k
                         if constexpr (FL == FL_UDH) {
-                            const int4 v = reinterpret_cast<const int4*>(bnd)[BIDX(r1)];
-                            chH = v.x; chF = v.y; chC = v.z; chFC = v.w;
+                            const int4 v = ld_nt4(bnd + (int64_t) BIDX(r1) * 4);
+                            reinterpret_cast<int4*>(feed)[k] = v;
                         } else {
-                            const int2 v = reinterpret_cast<const int2*>(bnd)[BIDX(r1)];
-                            chH = v.x; chF = v.y;
+                            const int2 v = ld_nt2(bnd + (int64_t) BIDX(r1) * 2);
+                            reinterpret_cast<int2*>(feed)[k] = v;
                         }
                     }
-                    // column records are stored per absolute position of the parent sequence; the
-                    // window edges are applied here: nothing beyond b_right, no residue at b_left
-                    const int cn = n0 + k;
-                    int2 crec = make_int2(0, 0);
-                    if (cn <= b_right) crec = cols[cn];
-                    const int chS = spj ? crec.x : 0, chB = (cn > b_left) ? crec.y : 0;
+                    {
+                        // column records are stored per absolute position of the parent sequence; the
+                        // window edges are applied here: nothing beyond b_right, no residue at b_left
+                        const int cn = n0 + k;
+                        int2 crec = make_int2(0, 0);
+                        if (cn <= b_right) crec = cols[cn];
+                        if (!spj) crec.x = 0;
+                        if (cn <= b_left) crec.y = 0;
+                        const int slot = (lb * 16 + k + 16) % 48;
+                        colring[slot] = crec; colring[slot + 48] = crec;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // lane k reads column n0 + J - k at step J: one contiguous run of 16 ring slots
+                    const int2* const mycol = colring + ((lb * 16 - k + 16 + 48) % 48);
                     uint32_t code4[4] = {0, 0, 0, 0};
 
 #define STEP(J)                                                                                  \
                     {                                                                                        \
-                        /* neighbour exchange */                                                             \
-                        const int upH = row_shr1(row_pick<J>(chH), Hs);                                      \
-                        const int upF = row_shr1(row_pick<J>(chF), Fs);                                      \
-                        sigp  = row_shr1(row_pick<J>(chS), sigp);                                            \
-                        basep = row_shr1(row_pick<J>(chB), basep);                                           \
-                        int upC = 0, upFC = 0;                                                               \
+                        /* neighbour exchange: lane 0 of the row takes the boundary entry of this step */    \
+                        int upH, upF, upC = 0, upFC = 0;                                                     \
                         if constexpr (FL == FL_UDH) {                                                        \
-                            upC  = row_shr1(row_pick<J>(chC), Cs);                                           \
-                            upFC = row_shr1(row_pick<J>(chFC), FCs);                                         \
+                            const int4 fd = reinterpret_cast<const int4*>(feed)[J];                          \
+                            upH = row_shr1(fd.x, Hs); upF = row_shr1(fd.y, Fs);                              \
+                            upC = row_shr1(fd.z, Cs); upFC = row_shr1(fd.w, FCs);                            \
+                        } else {                                                                             \
+                            const int2 fd = reinterpret_cast<const int2*>(feed)[J];                          \
+                            upH = row_shr1(fd.x, Hs); upF = row_shr1(fd.y, Fs);                              \
                         }                                                                                    \
-                        const int pv = mrow[basep];                                                          \
+                        const int2 cr = mycol[J];                                                            \
+                        const int sigp = cr.x;                                                               \
+                        const int pv = mrow[cr.y];                                                           \
                         int h, f, hc = 0, fc = 0;                                                            \
                         unsigned code = 0; int pb3 = 0;                                                      \
                         if constexpr (FL == FL_SCORE) {                                                      \
@@ -349,35 +385,31 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                                 }                                                                            \
                             }                                                                                \
                         }                                                                                    \
-                        /* bottom lane of the stripe -> output shift chain */                                \
-                        int bh = Hs, bf = Fs, bc = Cs, bfc = FCs;                                            \
-                        if constexpr (PARTIAL) {                                                             \
-                            if (j9 < SPDP_NELEM && j9 > 0) {                                                 \
-                                const int src = (lane & 48) + j8;                                            \
-                                bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                  \
-                                if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); } \
-                            }                                                                                \
-                        }                                                                                    \
-                        outH = row_shr1(row_ror1(bh), outH);                                                 \
-                        outF = row_shr1(row_ror1(bf), outF);                                                 \
-                        if constexpr (FL == FL_UDH) {                                                        \
-                            outC  = row_shr1(row_ror1(bc), outC);                                            \
-                            outFC = row_shr1(row_ror1(bfc), outFC);                                          \
+                        /* bottom row of the stripe -> staging slot of this step */                          \
+                        if (is_bottom) {                                                                     \
+                            if constexpr (FL == FL_UDH)                                                      \
+                                reinterpret_cast<int4*>(my_stage)[J] = make_int4(Hs, Fs, Cs, FCs);           \
+                            else                                                                             \
+                                reinterpret_cast<int2*>(my_stage)[J] = make_int2(Hs, Fs);                    \
                         }                                                                                    \
                     }
                     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
                     STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
 #undef STEP
-                    // ---- flush: lane i holds the bottom-row result of step j = 15 - i
+                    // ---- flush: lane k moves the bottom-row result of step j = k into the boundary
+                    // array under the reference's write condition (fwd2s1_wip_simd.h:205-209)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     {
-                        const int j = 15 - k;
-                        const int n = n0 + j;
+                        const int n = n0 + k;
                         const int r0 = n - (ml + 1) - 2 * j8;
                         if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
                             if constexpr (FL == FL_UDH)
-                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] = make_int4(outH, outF, outC, outFC);
+                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] =
+                                    ld_nt4(my_stage + 4 * k);
                             else
-                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] = make_int2(outH, outF);
+                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] =
+                                    ld_nt2(my_stage + 2 * k);
                         }
                     }
                     if constexpr (FL == FL_FORWARD) {

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--cpu-sample", type=int, default=12, help="problems timed on the CPU oracle")
+    ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
     args = ap.parse_args()
 
     import torch
@@ -52,7 +53,7 @@ def main():
     from spaln_amd import abi, defaults, engine, synth
     eng = engine.Engine(local_rank)
     sc = defaults.scoring()
-    batch = synth.make_batch(args.queries, seed=synth.SEED + 1000 * rank)
+    batch = synth.make_batch(args.queries, seed=synth.SEED + 1000 * rank, intron_hi=args.intron_hi)
     ps = abi.ProblemSet()
     for w, q, s5, s3, _ in batch:
         ps.add(q, w, s5, s3)

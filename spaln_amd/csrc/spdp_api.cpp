@@ -250,7 +250,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.n_im = (flav == 2) ? it.n_im : 0;
         P.a_off = st->a_off[it.parent];
         P.col_off = st->col_off[it.parent];
-        P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD + 64;    // + staging: 4 rows x 16 steps
+        P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
         if (flav == 1) {
             const int ns = (it.a_right - it.a_left + SPDP_NELEM - 1) / SPDP_NELEM;

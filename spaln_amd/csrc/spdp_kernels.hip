@@ -129,7 +129,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     const int2* __restrict__ cols = A.cols + P.col_off;
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int n_ent = P.buf_size + SPDP_BND_PAD;
-    int* __restrict__ stage = bnd + (int64_t) n_ent * BW;      // 4 rows x 16 steps of bottom-lane results
     const int wv = threadIdx.x >> 6;
 #define BIDX(r) ((r) - lw + 1)
 
@@ -235,16 +234,32 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         int hv2 = SPDP_NEV16, hil = 0;
         int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
         int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
-        const bool is_bottom = has && k == j8;                     // lane that owns the stripe's last row
+        int outH = 0, outF = 0, outC = 0, outFC = 0;               // bottom-row results of the block
         int2* const colring = &s_col[wv][g][0];
         int*  const feed = &s_feed[wv][g][0];
-        int*  const my_stage = stage + (g * 16) * BW;
 
         auto run_pass = [&](auto partial_tag, auto imd_tag) {
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             constexpr bool IMD = decltype(imd_tag)::value;
+            // registers holding the NEXT block's boundary entry / column record of this lane
+            int4 nx_b = make_int4(0, 0, 0, 0);
+            int2 nx_c = make_int2(0, 0);
+            auto prefetch = [&](int lbn) {
+                const int nn = n_start + lbn * 16 + k;                  // sweep step this lane loads for
+                if constexpr (FL == FL_UDH) nx_b = ld_nt4(bnd + (int64_t) BIDX(nn - ml) * 4);
+                else { const int2 v = ld_nt2(bnd + (int64_t) BIDX(nn - ml) * 2); nx_b.x = v.x; nx_b.y = v.y; }
+                // column records are stored per absolute position of the parent sequence; the window
+                // edges are applied here: nothing beyond b_right, no residue at b_left
+                int2 crec = make_int2(0, 0);
+                if (nn <= b_right) crec = cols[nn];
+                if (!spj) crec.x = 0;
+                if (nn <= b_left) crec.y = 0;
+                nx_c = crec;
+            };
+            if (g == 0 && nb > 0) prefetch(0);
             for (int blk = 0; blk < tot; ++blk) {
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
+                if (lb == -1 && nb > 0) prefetch(0);                    // one block ahead of first use
                 if (lb >= 0 && lb < nb) {
                     const int n0 = n_start + lb * 16;                   // sweep step of j = 0
                     if (lb == 0) {
@@ -261,28 +276,15 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                             if constexpr (FL == FL_UDH) Cd = __builtin_nontemporal_load(&bnd[(int64_t) BIDX(r) * BW + 2]);
                         }
                     }
-                    // ---- chunk loads: 16 boundary entries and 16 column records per stripe
+                    // ---- this block's chunk (prefetched one block ago) goes to LDS ...
+                    if constexpr (FL == FL_UDH) reinterpret_cast<int4*>(feed)[k] = nx_b;
+                    else reinterpret_cast<int2*>(feed)[k] = make_int2(nx_b.x, nx_b.y);
                     {
-                        const int r1 = n0 + k - ml;                     // r + 1 of step j = k
-                        if constexpr (FL == FL_UDH) {
-                            const int4 v = ld_nt4(bnd + (int64_t) BIDX(r1) * 4);
-                            reinterpret_cast<int4*>(feed)[k] = v;
-                        } else {
-                            const int2 v = ld_nt2(bnd + (int64_t) BIDX(r1) * 2);
-                            reinterpret_cast<int2*>(feed)[k] = v;
-                        }
-                    }
-                    {
-                        // column records are stored per absolute position of the parent sequence; the
-                        // window edges are applied here: nothing beyond b_right, no residue at b_left
-                        const int cn = n0 + k;
-                        int2 crec = make_int2(0, 0);
-                        if (cn <= b_right) crec = cols[cn];
-                        if (!spj) crec.x = 0;
-                        if (cn <= b_left) crec.y = 0;
                         const int slot = (lb * 16 + k + 16) % 48;
-                        colring[slot] = crec; colring[slot + 48] = crec;
+                        colring[slot] = nx_c; colring[slot + 48] = nx_c;
                     }
+                    // ---- ... and the next block's loads are issued now, to land while this one computes
+                    if (lb + 1 < nb) prefetch(lb + 1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // lane k reads column n0 + J - k at step J: one contiguous run of 16 ring slots
@@ -385,31 +387,36 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                                 }                                                                            \
                             }                                                                                \
                         }                                                                                    \
-                        /* bottom row of the stripe -> staging slot of this step */                          \
-                        if (is_bottom) {                                                                     \
-                            if constexpr (FL == FL_UDH)                                                      \
-                                reinterpret_cast<int4*>(my_stage)[J] = make_int4(Hs, Fs, Cs, FCs);           \
-                            else                                                                             \
-                                reinterpret_cast<int2*>(my_stage)[J] = make_int2(Hs, Fs);                    \
+                        /* bottom lane of the stripe -> output shift chain */                                \
+                        int bh = Hs, bf = Fs, bc = Cs, bfc = FCs;                                            \
+                        if constexpr (PARTIAL) {                                                             \
+                            if (j9 < SPDP_NELEM && j9 > 0) {                                                 \
+                                const int src = (lane & 48) + j8;                                            \
+                                bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                  \
+                                if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); } \
+                            }                                                                                \
+                        }                                                                                    \
+                        outH = row_shr1(row_ror1(bh), outH);                                                 \
+                        outF = row_shr1(row_ror1(bf), outF);                                                 \
+                        if constexpr (FL == FL_UDH) {                                                        \
+                            outC  = row_shr1(row_ror1(bc), outC);                                            \
+                            outFC = row_shr1(row_ror1(bfc), outFC);                                          \
                         }                                                                                    \
                     }
                     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
                     STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
 #undef STEP
-                    // ---- flush: lane k moves the bottom-row result of step j = k into the boundary
-                    // array under the reference's write condition (fwd2s1_wip_simd.h:205-209)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    // ---- flush: lane i holds the bottom-row result of step j = 15 - i; it goes to the
+                    // boundary array under the reference's write condition (fwd2s1_wip_simd.h:205-209)
                     {
-                        const int n = n0 + k;
+                        const int j = 15 - k;
+                        const int n = n0 + j;
                         const int r0 = n - (ml + 1) - 2 * j8;
                         if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
                             if constexpr (FL == FL_UDH)
-                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] =
-                                    ld_nt4(my_stage + 4 * k);
+                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] = make_int4(outH, outF, outC, outFC);
                             else
-                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] =
-                                    ld_nt2(my_stage + 2 * k);
+                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] = make_int2(outH, outF);
                         }
                     }
                     if constexpr (FL == FL_FORWARD) {
@@ -417,9 +424,11 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                         *dst = make_uint4(code4[0], code4[1], code4[2], code4[3]);
                     }
                 }
-                // the next block's boundary loads must see this block's stores (same CU, same L1)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // boundary entries are exchanged between the rows of this wave through memory: a
+                // load issued after a store of the same wave to the same address observes it (in-order
+                // vector memory path, loads bypass L1), so only the compiler needs a fence here
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         };
         if (pass_partial) {

@@ -112,3 +112,39 @@ def test_align_s_vs_reference(eng, fx, alg):
     (score, skl), = eng.align_s(sc, ps)
     assert score == int(fx[f"aln_scr_A{alg}"][0])
     assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
+
+
+def test_many_problems_vs_oracle(eng):
+    """A loaded GPU (hundreds of concurrent waves, ragged sizes): all three engines + the
+    full alignS_ng ladder against the oracle, bit for bit.  Guards the in-wave
+    store->load exchange of the boundary rows against ordering / caching hazards."""
+    import numpy as np
+    from oracle import oracle, host_logic
+    from spaln_amd import abi, defaults, synth
+    sc = defaults.scoring()
+    rng = np.random.default_rng(4242)
+    ps = abi.ProblemSet()
+    for i in range(160):
+        g = synth.make_gene(rng, n_exons=int(rng.integers(1, 7)), mrna_len=int(rng.integers(40, 900)),
+                            flank=int(rng.integers(20, 400)), intron_hi=int(rng.integers(100, 2500)),
+                            sub=float(rng.uniform(0, 0.1)), indel=float(rng.uniform(0, 0.02)))
+        s5, s3 = synth.splice_signals(g.window)
+        ps.add(defaults.encode(g.query), defaults.encode(g.window), s5, s3)
+    got = eng.wip_scoreonly(sc, ps)
+    want = [oracle.wip_scoreonly(sc, p) for p in ps.items]
+    assert got.tolist() == want
+    fwd = eng.wip_forward(sc, ps)
+    for (s, skl), p in zip(fwd, ps.items):
+        ws, wskl = oracle.wip_forward(sc, p)
+        assert s == ws and np.array_equal(skl, wskl)
+    us, ucpos, urng = eng.wip_udh(sc, ps, 4)
+    for i, p in enumerate(ps.items):
+        ws, wcpos, wrng = oracle.wip_udh(sc, p, 4)
+        assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist()
+        for r in range(5):
+            assert _row(ucpos[i][r]) == _row(wcpos[r])
+    sc2 = defaults.scoring(max_vmf_space=400000)          # forces UDH + slabs on these sizes
+    al = eng.align_s(sc2, ps)
+    for (s, skl), p in zip(al, ps.items):
+        ws, wskl = host_logic.align_s(sc2, p)
+        assert s == ws and skl.ravel().tolist() == (wskl or [])

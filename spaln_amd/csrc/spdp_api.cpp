@@ -280,6 +280,14 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         POOLGET(d_ranges, POOL_RANGES, sizeof(int32_t) * 4 * nn);
         POOLGET(d_scores, POOL_SCORES, sizeof(int32_t) * nn);
     }
+    // dispatch order = largest problems first (longest-processing-time rule): one wave owns one
+    // problem, so the big ones must not start last.  order[j] = caller index of dispatch slot j.
+    order.resize(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return h_probs[x].cells > h_probs[y].cells; });
+    std::vector<DevProblem> sorted(n);
+    for (int j = 0; j < n; ++j) sorted[j] = h_probs[order[j]];
+    h_probs.swap(sorted);
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
@@ -325,40 +333,59 @@ int DevRun::sync()
 int DevRun::fetch_results(std::vector<DevResult>& out)
 {
     out.resize(n);
-    if (n) HIPCHK(hipMemcpy(out.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost));
+    std::vector<DevResult> tmp(n);
+    if (n) HIPCHK(hipMemcpy(tmp.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost));
+    for (int j = 0; j < n; ++j) out[order[j]] = tmp[j];
     return 0;
 }
 
 int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::vector<SpdpSkl>& skl)
 {
     const int flav = 1;
-    n_skl.resize(n); off.assign(n + 1, 0);
+    n_skl.assign(n, 0); off.assign(n + 1, 0);
     if (!n) { skl.clear(); return 0; }
-    HIPCHK(hipMemcpy(n_skl.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) {
-        if (n_skl[i] > skl_cap) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
-        off[i + 1] = off[i] + std::max(n_skl[i], 0);
+    std::vector<int> cnt(n);                            // dispatch order
+    HIPCHK(hipMemcpy(cnt.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    std::vector<int64_t> doff(n + 1, 0);
+    for (int j = 0; j < n; ++j) {
+        if (cnt[j] > skl_cap) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
+        doff[j + 1] = doff[j] + std::max(cnt[j], 0);
+        n_skl[order[j]] = cnt[j];
     }
+    std::vector<SpdpSkl> packed(doff[n]);
+    if (doff[n]) {
+        void *d_off, *d_pack;
+        POOLGET(d_off, POOL_SKLOFF, sizeof(int64_t) * (n + 1));
+        POOLGET(d_pack, POOL_SKLPACK, sizeof(int2) * doff[n]);
+        HIPCHK(hipMemcpyAsync(d_off, doff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(spdp_launch_pack((const int2*) d_skl, skl_cap, (const int*) d_nskl, (const int64_t*) d_off,
+                                (int2*) d_pack, n, ctx->stream));
+        HIPCHK(hipMemcpyAsync(packed.data(), d_pack, sizeof(SpdpSkl) * doff[n], hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    // back to the caller's order
+    for (int i = 0; i < n; ++i) off[i + 1] = off[i] + std::max(n_skl[i], 0);
     skl.resize(off[n]);
-    if (!off[n]) return 0;
-    void *d_off, *d_pack;
-    POOLGET(d_off, POOL_SKLOFF, sizeof(int64_t) * (n + 1));
-    POOLGET(d_pack, POOL_SKLPACK, sizeof(int2) * off[n]);
-    HIPCHK(hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(spdp_launch_pack((const int2*) d_skl, skl_cap, (const int*) d_nskl, (const int64_t*) d_off,
-                            (int2*) d_pack, n, ctx->stream));
-    HIPCHK(hipMemcpyAsync(skl.data(), d_pack, sizeof(SpdpSkl) * off[n], hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n; ++j)
+        if (cnt[j] > 0) memcpy(skl.data() + off[order[j]], packed.data() + doff[j], sizeof(SpdpSkl) * cnt[j]);
     return 0;
 }
 
 int DevRun::fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges)
 {
-    scores.resize(n); ranges.resize((size_t) 4 * n); cpos.resize((size_t) 10 * (max_n_im + 1) * n);
+    const size_t st = (size_t) 10 * (max_n_im + 1);
+    scores.resize(n); ranges.resize((size_t) 4 * n); cpos.resize(st * n);
     if (n) {
-        HIPCHK(hipMemcpy(scores.data(), d_scores, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(ranges.data(), d_ranges, sizeof(int32_t) * 4 * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(cpos.data(), d_cpos, sizeof(int32_t) * cpos.size(), hipMemcpyDeviceToHost));
+        std::vector<int32_t> ts(n), tr((size_t) 4 * n), tc(st * n);
+        HIPCHK(hipMemcpy(ts.data(), d_scores, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tr.data(), d_ranges, sizeof(int32_t) * 4 * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tc.data(), d_cpos, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost));
+        for (int j = 0; j < n; ++j) {
+            const int i = order[j];
+            scores[i] = ts[j];
+            memcpy(&ranges[(size_t) 4 * i], &tr[(size_t) 4 * j], sizeof(int32_t) * 4);
+            memcpy(&cpos[st * i], &tc[st * j], sizeof(int32_t) * st);
+        }
     }
     return 0;
 }

@@ -105,7 +105,8 @@ struct DevRun {
     int flavour = 0, n = 0;
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;
-    std::vector<DevProblem> h_probs;
+    std::vector<DevProblem> h_probs;        // in dispatch order
+    std::vector<int> order;                 // dispatch slot -> caller index
     void *d_probs = nullptr, *d_bnd = nullptr, *d_tb = nullptr, *d_imd = nullptr, *d_res = nullptr,
          *d_skl = nullptr, *d_nskl = nullptr, *d_cpos = nullptr,
          *d_ranges = nullptr, *d_scores = nullptr;         // all owned by ctx->pool[flavour]

@@ -57,6 +57,11 @@ typedef struct SpdpScoring {
     int32_t max_vmf_space;           /* MaxVmfSpace (src/vmf.h:27), traceback/UDH switch */
     int32_t ubh;                     /* alprm.ubh: forced #intermediates, 0 = automatic  */
     int32_t ref_nelem;               /* stripe height of the reference build to reproduce */
+    /* ---- exact intron-length model (scalar engines, -A0): optional, may be NULL / 0 ---- */
+    const int16_t* intpen;           /* IntronPenalty::Penalty(len) for len in [0, intpen_len)  */
+    int32_t intpen_len;              /*   (src/codepot.h:242-247); must cover the longest window */
+    int16_t t53[256];                /* Exinon::sig53(m, n, IE53) - sig3[n], by 16*dinc5[m]+dinc3[n]
+                                        (src/codepot.cc:411-415)                              */
 } SpdpScoring;
 
 typedef struct SpdpProblem {
@@ -67,6 +72,10 @@ typedef struct SpdpProblem {
     int32_t a_left, a_right;               /* active ranges (Seq::left / right)          */
     int32_t b_left, b_right;
     uint8_t a_exgl, a_exgr, b_exgl, b_exgr;/* Seq::inex.exgl / exgr (free end gaps)      */
+    /* ---- exact model only (NULL for the _wip engines): per position, index 0 .. b_len --------- */
+    const uint8_t* cano5;                  /* Exinon::isDonor(n)  (src/codepot.h:106)            */
+    const uint8_t* cano3;                  /* Exinon::isAccpt(n)                                 */
+    const uint8_t* dinc;                   /* INT53::dinc5 << 4 | INT53::dinc3 (src/codepot.h:49) */
 } SpdpProblem;
 
 typedef struct SpdpWindow { int32_t lw, up, width; } SpdpWindow;   /* WINDOW, src/cmn.h:133 */
@@ -113,6 +122,14 @@ int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc,
 int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc,
                  const SpdpProblem* probs, int n_probs, int n_im,
                  int32_t* scores, int32_t* cpos, int32_t* ranges);
+
+/* scalar exact-intron-length engines (-A0; also what trcbkalignS_ng uses below 8 query rows):
+ * Aln2s1::forwardS_ng via trcbkalignS_ng (src/fwd2s1.cc:217, 1667) and scorealoneS_ng (:1163).
+ * Need SpdpScoring.intpen / t53 and SpdpProblem.cano5 / cano3 / dinc. */
+int spdp_scalar_forward(SpdpContext* ctx, const SpdpScoring* sc,
+                        const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+int spdp_scalar_scorealone(SpdpContext* ctx, const SpdpScoring* sc,
+                           const SpdpProblem* probs, int n_probs, int32_t* scores);
 
 /* ---- Aln2 surface, batched --------------------------------------------- */
 /* HomScoreS_ng for -A2/-A3 (simd > 1): stripe() then scoreonlyS1_wip. */

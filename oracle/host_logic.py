@@ -77,8 +77,12 @@ def diagonal(sc, p, rec):
 def trcbk(sc, p, w, rec):
     if w.width < 0:
         return abi.NEVSEL
-    if p.a_right - p.a_left < 8:
-        raise NeedsScalarEngine()
+    if p.a_right - p.a_left < 8:          # scalar forwardS_ng (src/fwd2s1.cc:1677)
+        if not sc.intpen or not p.cano5:
+            raise NeedsScalarEngine()
+        s, skl = oracle.scalar_forward(sc, p, w)
+        rec.extend((int(m), int(n)) for m, n in skl)
+        return s
     s, skl = oracle.wip_forward(sc, p, w)
     rec.extend((int(m), int(n)) for m, n in skl)
     return s

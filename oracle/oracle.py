@@ -18,9 +18,11 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "spdp_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _SO, src])
+    srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c")]
+    hdr = os.path.join(_HERE, "..", "include", "spdp.h")
+    newest = max(os.path.getmtime(f) for f in srcs + [hdr])
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _SO] + srcs)
     return _SO
 
 
@@ -76,3 +78,28 @@ def wip_udh(sc, p, n_im: int, w=None):
     if rc:
         raise RuntimeError(f"orc_wip_udh rc={rc}")
     return s.value, cpos, rng
+
+
+def scalar_scorealone(sc, p, w=None) -> int:
+    """Aln2s1::scorealoneS_ng (the -A0 HomScoreS_ng engine)."""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    rc = lib().orc_scalar_scorealone(C.byref(sc), C.byref(p), C.byref(w), C.byref(s))
+    if rc:
+        raise RuntimeError(f"orc_scalar_scorealone rc={rc}")
+    return s.value
+
+
+def scalar_forward(sc, p, w=None):
+    """Aln2s1::forwardS_ng + the record hand-over of trcbkalignS_ng."""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_scalar_forward(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_scalar_forward rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out

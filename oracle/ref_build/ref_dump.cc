@@ -197,6 +197,39 @@ const	char*	outfn = argv[ai + 2];
 	    w.put("phs3", 4, p3.data(), p3.size());
 	    w.put("cano5", 1, c5.data(), c5.size());
 	    w.put("cano3", 1, c3.data(), c3.size());
+	    // dinucleotide classes exactly as Exinon::intron53_c assigns them (codepot.cc:435-448),
+	    // and the junction table behind Exinon::sig53(m, n, IE53) (codepot.cc:411-415):
+	    //   sig53(m, n, IE53) = sig3[n] + T53[16 * dinc5[m] + dinc3[n]]
+	    std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
+	    int	nc = 1;
+	    for (int i = b->left; i < b->right; ++i) {
+		int c = ncredctab[*b->at(i)];
+		if (c >= 4) c = 1;
+		nc = ((nc << 2) + c) & 0xf;
+		if (i - 1 >= 0) d5[i - 1] = nc;
+		d3[i + 1] = nc;
+	    }
+	    w.put("dinc5", 1, d5.data(), b->len + 1);
+	    w.put("dinc3", 1, d3.data(), b->len + 1);
+	    std::vector<int> t53(256, 0), mrep(16, -1), nrep(16, -1);
+	    for (int n = b->left; n <= b->right; ++n) {
+		if (n >= b->left && n < b->right - 1 && mrep[d5[n]] < 0 && n >= b->left) mrep[d5[n]] = n;
+		if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	    }
+	    for (int u = 0; u < 16; ++u)
+		for (int v = 0; v < 16; ++v)
+		    if (mrep[u] >= 0 && nrep[v] >= 0)
+			t53[16 * u + v] = b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_n(nrep[v])->sig3;
+	    w.put_i32("t53", t53);
+	    int	bad = 0;
+	    for (int t = 0; t < 400; ++t) {		// self-check of the restated classes
+		int m = b->left + (t * 7919) % std::max(1, b->right - b->left - 2);
+		int n = b->left + 2 + (t * 104729) % std::max(1, b->right - b->left - 2);
+		int want = b->exin->sig53(m, n, IE53);
+		int got = b->exin->score_n(n)->sig3 + t53[16 * d5[m] + d3[n]];
+		if (want != got) ++bad;
+	    }
+	    if (bad) fprintf(stderr, "ref_dump: %d sig53 self-check mismatches\n", bad);
 	}
 	{
 	    const Simmtx* sm = pwd->simmtx;
@@ -228,7 +261,7 @@ const	char*	outfn = argv[ai + 2];
 	    // exact intron-length penalty materialised for every length that can occur
 	    std::vector<short>	ip(b->len + 2);
 	    for (int l = 0; l < (int) ip.size(); ++l)
-		ip[l] = (l <= IntronPrm.mu)? SHRT_MIN: pwd->IntPen->Penalty(l);
+		ip[l] = pwd->IntPen->Penalty(l);
 	    w.put("intpen", 2, ip.data(), ip.size());
 	}
 

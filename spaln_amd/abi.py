@@ -33,6 +33,9 @@ class Scoring(C.Structure):
         ("max_vmf_space", C.c_int32),
         ("ubh", C.c_int32),
         ("ref_nelem", C.c_int32),
+        ("intpen", C.c_void_p),
+        ("intpen_len", C.c_int32),
+        ("t53", C.c_int16 * 256),
     ]
 
 
@@ -46,6 +49,7 @@ class Problem(C.Structure):
         ("b_left", C.c_int32), ("b_right", C.c_int32),
         ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
+        ("cano5", C.c_void_p), ("cano3", C.c_void_p), ("dinc", C.c_void_p),
     ]
 
 
@@ -63,7 +67,8 @@ class Alignment(C.Structure):
 
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
-                 max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM) -> Scoring:
+                 max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,
+                 intpen=None, t53=None) -> Scoring:
     sc = Scoring()
     sc.mtx_dim = int(mtx_dim)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -80,6 +85,13 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
         sc.qm_pen[j] = int(qm_pen[j])
     sc.local, sc.sh = int(local), int(sh)
     sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
+    if intpen is not None:
+        ip = np.ascontiguousarray(intpen, dtype=np.int16)
+        sc._keep_intpen = ip                      # keep the buffer alive with the struct
+        sc.intpen, sc.intpen_len = ip.ctypes.data, ip.size
+    if t53 is not None:
+        for i, v in enumerate(np.asarray(t53).ravel()[:256]):
+            sc.t53[i] = int(v)
     return sc
 
 
@@ -91,7 +103,7 @@ class ProblemSet:
         self.items = []
 
     def add(self, a, b, sig5, sig3, a_left=0, a_right=None, b_left=0, b_right=None,
-            exg=(1, 1, 1, 1)):
+            exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)
         sig5 = np.ascontiguousarray(sig5, dtype=np.int16)
@@ -105,6 +117,13 @@ class ProblemSet:
         p.a_left, p.a_right = int(a_left), int(a.size if a_right is None else a_right)
         p.b_left, p.b_right = int(b_left), int(b.size if b_right is None else b_right)
         p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr = (int(x) for x in exg)
+        if cano5 is not None:
+            c5 = np.ascontiguousarray(cano5, dtype=np.uint8)
+            c3 = np.ascontiguousarray(cano3, dtype=np.uint8)
+            dc = np.ascontiguousarray(dinc, dtype=np.uint8)
+            assert min(c5.size, c3.size, dc.size) >= b.size + 1
+            self._keep += [c5, c3, dc]
+            p.cano5, p.cano3, p.dinc = c5.ctypes.data, c3.ctypes.data, dc.ctypes.data
         self.items.append(p)
         return p
 

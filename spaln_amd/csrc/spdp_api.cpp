@@ -164,7 +164,9 @@ void DevStore::release()
     if (d_sc) (void) hipFree(d_sc);
     if (d_a) (void) hipFree(d_a);
     if (d_cols) (void) hipFree(d_cols);
-    d_sc = d_a = d_cols = nullptr;
+    if (d_aux) (void) hipFree(d_aux);
+    if (d_intpen) (void) hipFree(d_intpen);
+    d_sc = d_a = d_cols = d_aux = d_intpen = nullptr;
 }
 
 int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* probs, int n)
@@ -185,8 +187,19 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     }
     std::vector<uint8_t> ha(std::max<int64_t>(a_tot, 16), 0);
     std::vector<int32_t> hc(2 * std::max<int64_t>(col_tot, 1), 0);
+    has_exact = sc.intpen && sc.intpen_len > 0;
+    for (int i = 0; i < n && has_exact; ++i)
+        if (!probs[i].cano5 || !probs[i].cano3 || !probs[i].dinc) has_exact = false;
+    std::vector<uint8_t> hx(has_exact ? 2 * std::max<int64_t>(col_tot, 1) : 0, 0);
     for (int i = 0; i < n; ++i) {
         const SpdpProblem& p = probs[i];
+        if (has_exact) {
+            uint8_t* x = hx.data() + 2 * col_off[i];
+            for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
+                x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
+                x[1] = p.dinc[nn];
+            }
+        }
         memcpy(ha.data() + a_off[i], p.a, p.a_len);
         int32_t* cr = hc.data() + 2 * col_off[i];
         for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
@@ -204,6 +217,12 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     HIPCHK(hipMemcpyAsync(d_sc, &hsc, sizeof hsc, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_a, ha.data(), ha.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_cols, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (has_exact) {
+        HIPCHK(hipMalloc(&d_aux, hx.size()));
+        HIPCHK(hipMalloc(&d_intpen, sizeof(int16_t) * sc.intpen_len));
+        HIPCHK(hipMemcpyAsync(d_aux, hx.data(), hx.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, sizeof(int16_t) * sc.intpen_len, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -232,6 +251,10 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     store = st; ctx = st->ctx; flavour = flav; n = (int) items.size();
     (void) hipSetDevice(ctx->device);
     if (flav == 2 && st->sc.local) { ctx->err = "local UDH is not implemented"; return -1; }
+    if (flav >= 3 && !st->has_exact) {
+        ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
+        return -1;
+    }
     h_probs.assign(n, DevProblem());
     int64_t bnd_tot = 0, tb_tot = 0, imd_tot = 0;
     total_cells = 0; max_n_im = 0; max_skl = 0;
@@ -252,23 +275,36 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.col_off = st->col_off[it.parent];
         P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
+        if (flav >= 3) {        // scalar: work = 4 * width ints + width dir bytes; Vmf records
+            P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
+            bnd_tot = P.bnd_off + 4ll * it.w.width + (it.w.width + 3) / 4 + 8;
+            const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
+            const int64_t cap = (flav == 3) ? 2 * cells + 64 : 0;
+            P.imd_off = cap;
+            tb_tot += cap;
+        }
         if (flav == 1) {
             const int ns = (it.a_right - it.a_left + SPDP_NELEM - 1) / SPDP_NELEM;
             for (int s = 0; s < ns; ++s) tb_tot += 256ll * stripe_blocks(P, s, true);
         }
-        P.imd_off = imd_tot; imd_tot += (int64_t) P.n_im * 4 * it.w.width;
+        if (flav < 3) { P.imd_off = imd_tot; imd_tot += (int64_t) P.n_im * 4 * it.w.width; }
         P.cells = spdp_cells_w(it.a_left, it.a_right, it.b_left, it.b_right, it.w);
         total_cells += P.cells;
         max_n_im = std::max(max_n_im, P.n_im);
         max_skl = std::max(max_skl, (it.a_right - it.a_left) + (it.b_right - it.b_left) + 8);
     }
     tb_bytes = tb_tot;
-    const int bw = (flav == 2) ? 4 : 2;
+    const int bw = (flav == 2) ? 4 : (flav >= 3 ? 1 : 2);
     const int nn = std::max(n, 1);
     skl_cap = std::min(std::max(max_skl, 1), 1024);     // typical lists are short; overflow is re-walked
     POOLGET(d_probs, POOL_PROBS, sizeof(DevProblem) * nn);
     POOLGET(d_bnd, POOL_BND, sizeof(int32_t) * bw * std::max<int64_t>(bnd_tot, 1));
     POOLGET(d_res, POOL_RES, sizeof(DevResult) * nn);
+    if (flav == 3) {
+        POOLGET(d_tb, POOL_TB, sizeof(int3) * std::max<int64_t>(tb_tot, 16));
+        POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
+        POOLGET(d_nskl, POOL_NSKL, sizeof(int) * nn);
+    }
     if (flav == 1) {
         POOLGET(d_tb, POOL_TB, std::max<int64_t>(tb_tot, 16));
         POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
@@ -296,6 +332,20 @@ int DevRun::launch()
 {
     (void) hipSetDevice(ctx->device);
     if (n == 0) return 0;
+    if (flavour >= 3) {
+        ScalarArgs S;
+        S.sc = (const DevScoring*) store->d_sc; S.probs = (const DevProblem*) d_probs; S.n_probs = n;
+        S.a_codes = (const uint8_t*) store->d_a; S.cols = (const int2*) store->d_cols;
+        S.aux = (const uint8_t*) store->d_aux; S.intpen = (const int16_t*) store->d_intpen;
+        S.intpen_len = store->sc.intpen_len; S.ipen = store->sc.ipen;
+        memcpy(S.t53, store->sc.t53, sizeof S.t53);
+        S.work = (int*) d_bnd; S.vmf = (int3*) d_tb; S.res = (DevResult*) d_res;
+        S.skl = (int2*) d_skl; S.n_skl = (int*) d_nskl; S.skl_cap = skl_cap;
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        return 0;
+    }
     SweepArgs A;
     A.sc = (const DevScoring*) store->d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n;
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
@@ -341,7 +391,7 @@ int DevRun::fetch_results(std::vector<DevResult>& out)
 
 int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::vector<SpdpSkl>& skl)
 {
-    const int flav = 1;
+    const int flav = flavour;
     n_skl.assign(n, 0); off.assign(n + 1, 0);
     if (!n) { skl.clear(); return 0; }
     std::vector<int> cnt(n);                            // dispatch order
@@ -349,6 +399,7 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     std::vector<int64_t> doff(n + 1, 0);
     for (int j = 0; j < n; ++j) {
         if (cnt[j] > skl_cap) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
+        if (cnt[j] == -3) { ctx->err = "scalar engine: Vmf record buffer overflow"; return -1; }
         doff[j + 1] = doff[j] + std::max(cnt[j], 0);
         n_skl[order[j]] = cnt[j];
     }
@@ -419,28 +470,7 @@ int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* 
 }
 
 int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
-                     int n_probs, SpdpAlignment* out)
-{
-    if (!ctx) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
-    if (n_probs <= 0) return 0;
-    DevStore st; DevRun run;
-    if (st.upload(ctx, sc, probs, n_probs)) return -1;
-    if (run.build(&st, items_of(sc, probs, n_probs), 1) || run.launch() || run.sync()) return -1;
-    std::vector<DevResult> r;
-    std::vector<int> nskl;
-    std::vector<int64_t> off;
-    std::vector<SpdpSkl> skl;
-    if (run.fetch_results(r) || run.fetch_skl(nskl, off, skl)) return -1;
-    for (int i = 0; i < n_probs; ++i) {
-        out[i].score = r[i].score;
-        if (nskl[i] < 0) { ctx->err = "traceback walk failed"; return -1; }
-        out[i].n_skl = nskl[i];
-        out[i].skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * std::max(1, nskl[i]));
-        memcpy(out[i].skl, skl.data() + off[i], sizeof(SpdpSkl) * nskl[i]);
-    }
-    return 0;
-}
+                     int n_probs, SpdpAlignment* out);
 
 int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
                  int n_im, int32_t* scores, int32_t* cpos, int32_t* ranges)
@@ -458,6 +488,56 @@ int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
     memcpy(ranges, r.data(), sizeof(int32_t) * 4 * n_probs);
     memcpy(cpos, c.data(), sizeof(int32_t) * c.size());
     return 0;
+}
+
+static int forward_like(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
+                        SpdpAlignment* out, int flav)
+{
+    if (!ctx) return -1;
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    if (n_probs <= 0) return 0;
+    DevStore st; DevRun run;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    if (run.build(&st, items_of(sc, probs, n_probs), flav) || run.launch() || run.sync()) return -1;
+    std::vector<DevResult> r;
+    std::vector<int> nskl;
+    std::vector<int64_t> off;
+    std::vector<SpdpSkl> skl;
+    if (run.fetch_results(r) || run.fetch_skl(nskl, off, skl)) return -1;
+    for (int i = 0; i < n_probs; ++i) {
+        out[i].score = r[i].score;
+        if (nskl[i] < 0) { ctx->err = "traceback failed"; return -1; }
+        out[i].n_skl = nskl[i];
+        out[i].skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * std::max(1, nskl[i]));
+        memcpy(out[i].skl, skl.data() + off[i], sizeof(SpdpSkl) * nskl[i]);
+    }
+    return 0;
+}
+
+int spdp_scalar_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
+                        int n_probs, SpdpAlignment* out)
+{   // Aln2s1::forwardS_ng through trcbkalignS_ng (scalar exact engine)
+    return forward_like(ctx, sc, probs, n_probs, out, 3);
+}
+
+int spdp_scalar_scorealone(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
+                           int n_probs, int32_t* scores)
+{   // Aln2s1::scorealoneS_ng = HomScoreS_ng under -A0
+    if (!ctx) return -1;
+    if (n_probs <= 0) return 0;
+    DevStore st; DevRun run;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    if (run.build(&st, items_of(sc, probs, n_probs), 4) || run.launch() || run.sync()) return -1;
+    std::vector<DevResult> r;
+    if (run.fetch_results(r)) return -1;
+    for (int i = 0; i < n_probs; ++i) scores[i] = r[i].score;
+    return 0;
+}
+
+int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
+                     int n_probs, SpdpAlignment* out)
+{
+    return forward_like(ctx, sc, probs, n_probs, out, 1);
 }
 
 void spdp_free_alignments(SpdpAlignment* out, int n)

@@ -149,7 +149,8 @@ struct Aligner {
     int n;
     std::vector<Job> jobs;
     std::vector<LspItem> pending;
-    std::vector<TbItem> tbs;
+    std::vector<TbItem> tbs;                    // forwardS1_wip calls
+    std::vector<TbItem> stbs;                   // scalar forwardS_ng calls (< 8 rows)
     float kernel_ms = 0.f;
     int64_t kernel_cells = 0;
     int unsupported = 0;
@@ -161,8 +162,10 @@ struct Aligner {
     void trcbk(int job, const Rng& r, const SpdpWindow& w, bool top)
     {
         if (w.width < 0) { set_score(job, top, SPDP_NEVSEL); return; }
-        if (r.ar - r.al < kScalarRows) {        // scalar forwardS_ng: not on the GPU yet
-            ++unsupported; jobs[job].failed = true; return;
+        if (r.ar - r.al < kScalarRows) {        // fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
+            if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
+            stbs.push_back({job, r, w, top});
+            return;
         }
         tbs.push_back({job, r, w, top});
     }
@@ -311,6 +314,25 @@ struct Aligner {
                 else mimd(u, cp, curr);
             }
         }
+        // the few sub-problems below 8 rows: scalar exact engine, one thread each
+        if (!stbs.empty()) {
+            std::vector<RunItem> items;
+            for (const TbItem& t : stbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            DevRun run;
+            if (run.build(st, items, 3) || run.launch() || run.sync()) return -1;
+            std::vector<DevResult> res;
+            std::vector<int> nskl;
+            std::vector<int64_t> off;
+            std::vector<SpdpSkl> skl;
+            if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
+            for (size_t k = 0; k < stbs.size(); ++k) {
+                const TbItem& t = stbs[k];
+                if (nskl[k] < 0) { ctx->err = "scalar traceback failed"; return -1; }
+                set_score(t.job, t.top, res[k].score);
+                const SpdpSkl* s = skl.data() + off[k];
+                jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
+            }
+        }
         // all trcbkalignS_ng calls of all queries: one forward sweep + one walk
         if (!tbs.empty()) {
             std::vector<RunItem> items;
@@ -420,7 +442,8 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     if (kernel_cells) *kernel_cells = al.kernel_cells;
     if (stats) memcpy(stats, al.stats, sizeof al.stats);
     if (al.unsupported) {
-        ctx->err = "sub-problems with fewer than 8 query rows need the scalar engine (not implemented)";
+        ctx->err = "sub-problems with fewer than 8 query rows need the scalar exact engine: supply "
+                   "SpdpScoring.intpen / t53 and SpdpProblem.cano5 / cano3 / dinc";
         return 1;                               // partial: those queries are returned without alignment
     }
     return 0;

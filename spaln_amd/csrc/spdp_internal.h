@@ -46,6 +46,26 @@ extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int 
                                         int grid, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
+// scalar exact engines (spdp_scalar.hip): one thread per problem
+struct ScalarArgs {
+    const DevScoring* sc;
+    const DevProblem* probs;      // bnd_off = work offset (ints), tb_off = Vmf offset (records), imd_off = Vmf capacity
+    int               n_probs;
+    const uint8_t*    a_codes;
+    const int2*       cols;
+    const uint8_t*    aux;        // per position: {bit0 isDonor | bit1 isAccpt, dinc5 << 4 | dinc3}
+    const int16_t*    intpen;
+    int               intpen_len;
+    int               ipen;
+    int16_t           t53[256];
+    int*              work;
+    int3*             vmf;
+    DevResult*        res;
+    int2*             skl;
+    int*              n_skl;
+    int               skl_cap;
+};
+extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
@@ -62,7 +82,7 @@ enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSK
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
-    DevPool pool[3];                 // one pool per sweep flavour (they coexist in a pipeline)
+    DevPool pool[5];                 // one pool per engine flavour (they coexist in a pipeline)
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -80,7 +100,8 @@ struct DevStore {
     int n_parents = 0;
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> a_len, b_len;
-    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr;
+    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    bool has_exact = false;                 // exact-model inputs (cano / dinc / intpen) were supplied
     DevStore() = default;
     DevStore(const DevStore&) = delete;
     DevStore& operator=(const DevStore&) = delete;
@@ -98,7 +119,8 @@ struct RunItem {
     int n_im;          // UDH only
 };
 
-// descriptors + work buffers of one sweep flavour (0 score, 1 forward, 2 udh) over a DevStore
+// descriptors + work buffers of one engine flavour over a DevStore:
+// 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score
 struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
 EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
-    "spdp_align_s", "spdp_free_alignments", "spdp_batch_upload", "spdp_batch_free",
+    "spdp_align_s", "spdp_free_alignments", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
 ]
 
@@ -45,10 +45,11 @@ def load_library() -> C.CDLL:
     lib.spdp_batch_homscore.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    for f in ("spdp_wip_scoreonly", "spdp_homscore_s"):
+    for f in ("spdp_wip_scoreonly", "spdp_homscore_s", "spdp_scalar_scorealone"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_align_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_scalar_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_free_alignments.argtypes = [C.c_void_p, C.c_int]
@@ -112,6 +113,16 @@ class Engine:
 
     def wip_forward(self, sc, ps):
         return self._alignments(self.lib.spdp_wip_forward, sc, ps, "spdp_wip_forward")
+
+    def scalar_forward(self, sc, ps):
+        """Aln2s1::forwardS_ng via trcbkalignS_ng (scalar exact engine, -A0)."""
+        return self._alignments(self.lib.spdp_scalar_forward, sc, ps, "spdp_scalar_forward")
+
+    def scalar_scorealone(self, sc, ps) -> np.ndarray:
+        out = np.zeros(len(ps), dtype=np.int32)
+        self._check(self.lib.spdp_scalar_scorealone(self.ctx, C.byref(sc), ps.array(), len(ps),
+                                                    out.ctypes.data), "spdp_scalar_scorealone")
+        return out
 
     def align_s(self, sc, ps):
         return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s")

@@ -35,7 +35,8 @@ def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
               lgop=q["lgop"], lgep=q["lgep"], noll=q["noll"], spj=q["b_intr"], llmt=q["llmt"],
               ipen=q["ipen"], qm_len=fx["qm_len"], qm_pen=fx["qm_pen"],
               nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
-              sh=q["sh"], max_vmf_space=q["max_vmf_space"], ubh=q["ubh"])
+              sh=q["sh"], max_vmf_space=q["max_vmf_space"], ubh=q["ubh"],
+              intpen=fx.get("intpen"), t53=fx.get("t53"))
     kw.update(over)
     return abi.make_scoring(**kw)
 
@@ -43,7 +44,11 @@ def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
 def problem(fx: dict, ps: abi.ProblemSet | None = None):
     q = fx["prm"]
     ps = ps or abi.ProblemSet()
+    extra = {}
+    if "dinc5" in fx:
+        extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                     dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"],
                q["a_left"], q["a_right"], q["b_left"], q["b_right"],
-               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]))
+               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), **extra)
     return ps, p

@@ -107,8 +107,6 @@ def test_align_s_vs_reference(eng, fx, alg):
     ps, p = spdg.problem(fx)
     if sc.local and fx["prm"]["max_vmf_space"] < 32 * 1024 * 1024:
         pytest.skip("local UDH not implemented on the GPU")
-    if p.a_right - p.a_left < 8:
-        pytest.skip("m < 8 uses the scalar engine (not implemented on the GPU)")
     (score, skl), = eng.align_s(sc, ps)
     assert score == int(fx[f"aln_scr_A{alg}"][0])
     assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
@@ -148,3 +146,21 @@ def test_many_problems_vs_oracle(eng):
     for (s, skl), p in zip(al, ps.items):
         ws, wskl = host_logic.align_s(sc2, p)
         assert s == ws and skl.ravel().tolist() == (wskl or [])
+
+
+def test_scalar_engines_vs_reference(eng, fx):
+    """Scalar exact-ILD engines on the GPU (-A0: scorealoneS_ng, forwardS_ng) vs the reference."""
+    from oracle import oracle, host_logic
+    from tests.test_oracle_scalar import direct_under_a0
+    sc = spdg.scoring(fx)
+    ps, p = spdg.problem(fx)
+    assert int(eng.scalar_scorealone(sc, ps)[0]) == int(fx["hom_scr_A0"][0])
+    (scr, skl), = eng.scalar_forward(sc, ps)
+    oscr, oskl = oracle.scalar_forward(sc, p)
+    assert scr == oscr and skl.tolist() == oskl.tolist()
+    if direct_under_a0(fx, p, oracle.stripe(p, sc.sh)):
+        assert scr == int(fx["aln_scr_A0"][0])
+        rec = [(int(a), int(b)) for a, b in skl]
+        fin = host_logic.trim_skl(host_logic.std_skl(rec), p) if len(rec) >= 2 else []
+        flat = ([1, len(fin)] + [x for mn in fin for x in mn]) if fin else []
+        assert flat == fx["aln_skl_A0"].tolist()

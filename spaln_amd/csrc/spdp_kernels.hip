@@ -560,8 +560,18 @@ struct TbView {
         const int n = np + b_left + k;               // sweep step that produced the cell
         if (n < c_nstart || n > c_n9) return 0u;
         const int tau = n - c_nstart;
-        return tb[cbase + 256ll * (tau >> 4) + 16 * k + (tau & 15)];
+        // a lane's 16 codes of one block are contiguous: keep the last 16-byte group in registers,
+        // so walks along a row (introns, gaps) cost one load per 16 cells
+        const int64_t grp = cbase + 256ll * (tau >> 4) + 16 * k;
+        if (grp != c_grp) {
+            c_w = *reinterpret_cast<const uint4*>(tb + grp);
+            c_grp = grp;
+        }
+        const int j = tau & 15;
+        const unsigned w = (j < 8) ? ((j < 4) ? c_w.x : c_w.y) : ((j < 12) ? c_w.z : c_w.w);
+        return (w >> (8 * (j & 3))) & 0xffu;
     }
+    int64_t c_grp; uint4 c_w;
 };
 
 __global__ void spdp_walk(WalkArgs A)
@@ -573,6 +583,7 @@ __global__ void spdp_walk(WalkArgs A)
     V.tb = A.tb; V.tb_off = P.tb_off;
     V.a_left = P.a_left; V.a_right = P.a_right; V.b_left = P.b_left; V.b_right = P.b_right;
     V.lw = P.lw; V.up = P.up; V.a_exgl = P.flags & 1; V.cs = -1; V.cbase = 0; V.c_nstart = V.c_n9 = 0;
+    V.c_grp = -1; V.c_w = make_uint4(0, 0, 0, 0);
     int2* out = A.skl + (int64_t) pi * A.skl_cap;
     int cnt = 0, status = 0;
     int m = A.res[pi].mr - P.a_left, n = A.res[pi].nr - P.b_left;   // window-relative

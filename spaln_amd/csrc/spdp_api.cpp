@@ -50,12 +50,38 @@ void spdp_stripe(const SpdpProblem* p, int sh, SpdpWindow* w)
 }
 
 int64_t spdp_cells_w(int a_left, int a_right, int b_left, int b_right, const SpdpWindow& w)
-{   // cells visited by the reference loops, src/fwd2s1.cc:249-256
+{   // cells visited by the reference loops, src/fwd2s1.cc:249-256:
+    //   sum over m in (a_left, a_right] of max(0, min(m + up + 1, b_right) - max(m + lw, b_left)),
+    // evaluated piecewise (both clamps switch once along m)
+    auto seg = [&](int64_t m0, int64_t m1, bool hi_clamped, bool lo_clamped) -> int64_t {
+        if (m1 < m0) return 0;                           // rows m0 .. m1 inclusive
+        const int64_t cnt = m1 - m0 + 1, sm = (m0 + m1) * cnt / 2;
+        // width(m) = (hi_clamped ? b_right : m + up + 1) - (lo_clamped ? b_left : m + lw)
+        int64_t tot = 0;
+        tot += hi_clamped ? (int64_t) b_right * cnt : sm + (int64_t) (w.up + 1) * cnt;
+        tot -= lo_clamped ? (int64_t) b_left * cnt : sm + (int64_t) w.lw * cnt;
+        return tot;
+    };
+    const int64_t mh = (int64_t) b_right - w.up - 1;     // m >= mh: upper end clamped to b_right
+    const int64_t ml = (int64_t) b_left - w.lw;          // m <= ml: lower end clamped to b_left
     int64_t c = 0;
-    for (int m = a_left + 1; m <= a_right; ++m) {
-        int n1 = std::max(m + w.lw, b_left);
-        int n9 = std::min(m + w.up + 1, b_right);
-        if (n9 > n1) c += n9 - n1;
+    int64_t cuts[4] = {a_left + 1, std::min<int64_t>(std::max<int64_t>(mh, a_left + 1), a_right + 1),
+                       std::min<int64_t>(std::max<int64_t>(ml + 1, a_left + 1), a_right + 1), a_right + 1};
+    std::sort(cuts, cuts + 4);
+    for (int i = 0; i < 3; ++i) {
+        const int64_t m0 = cuts[i], m1 = cuts[i + 1] - 1;
+        if (m1 < m0) continue;
+        const bool hi = m0 >= mh, lo = m1 <= ml;
+        // within a segment both flags are constant; widths are linear, so a negative width can only
+        // occur over a whole prefix/suffix -- fall back to the exact loop in that rare case
+        const int64_t w0 = (hi ? b_right : m0 + w.up + 1) - (lo ? b_left : m0 + w.lw);
+        const int64_t w1 = (hi ? b_right : m1 + w.up + 1) - (lo ? b_left : m1 + w.lw);
+        if (w0 >= 0 && w1 >= 0) c += seg(m0, m1, hi, lo);
+        else
+            for (int64_t m = m0; m <= m1; ++m) {
+                const int64_t n1 = std::max<int64_t>(m + w.lw, b_left), n9 = std::min<int64_t>(m + w.up + 1, b_right);
+                if (n9 > n1) c += n9 - n1;
+            }
     }
     return c;
 }

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <cstdio>
 
 #include "spdp_internal.h"
 
@@ -271,9 +273,21 @@ struct Aligner {
         }
     }
 
+    double t_mark = 0;
+    bool timing = getenv("SPDP_TIMING") != nullptr;
+    void lap(const char* what)
+    {
+        if (!timing) return;
+        const double now = std::chrono::duration<double, std::milli>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (t_mark > 0) fprintf(stderr, "[spdp timing] %-28s %8.2f ms\n", what, now - t_mark);
+        t_mark = now;
+    }
+
     int run()
     {
         const SpdpScoring& sc = st->sc;
+        lap("start");
         jobs.assign(n, Job());
         for (int i = 0; i < n; ++i) {           // alignS_ng: stripe(alprm.sh), globalS_ng -> lspS_ng
             const SpdpProblem& p = probs[i];
@@ -287,16 +301,21 @@ struct Aligner {
             cur.swap(pending);
             std::vector<UdhItem> udh;
             for (const LspItem& it : cur) classify(it, udh);
+            lap("classify");
             if (udh.empty()) continue;
             std::vector<RunItem> items;
             for (const UdhItem& u : udh) items.push_back(run_item(u.job, u.r, u.w, u.n_imd));
             DevRun run;
-            if (run.build(st, items, 2) || run.launch() || run.sync()) return -1;
+            if (run.build(st, items, 2)) return -1;
+            lap("udh build");
+            if (run.launch() || run.sync()) return -1;
+            lap("udh launch+sync");
             kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
             stats[0] += run.kernel_ms; stats[1] += (double) run.total_cells; stats[2] += (double) items.size();
             stats[6] += 1;
             std::vector<int32_t> scores, cpos, ranges;
             if (run.fetch_udh(scores, cpos, ranges)) return -1;
+            lap("udh fetch");
             const int stride = 10 * (run.max_n_im + 1);
             for (size_t k = 0; k < udh.size(); ++k) {
                 const UdhItem& u = udh[k];
@@ -314,6 +333,7 @@ struct Aligner {
                 else mimd(u, cp, curr);
             }
         }
+        lap("postwork (slab lists)");
         // the few sub-problems below 8 rows: scalar exact engine, one thread each
         if (!stbs.empty()) {
             std::vector<RunItem> items;
@@ -338,7 +358,10 @@ struct Aligner {
             std::vector<RunItem> items;
             for (const TbItem& t : tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
             DevRun run;
-            if (run.build(st, items, 1) || run.launch() || run.sync()) return -1;
+            if (run.build(st, items, 1)) return -1;
+            lap("fwd build");
+            if (run.launch() || run.sync()) return -1;
+            lap("fwd launch+sync (+walk)");
             kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
             stats[3] += run.kernel_ms; stats[4] += (double) run.total_cells; stats[5] += (double) items.size();
             stats[7] += (double) run.tb_bytes;
@@ -347,6 +370,7 @@ struct Aligner {
             std::vector<int64_t> off;
             std::vector<SpdpSkl> skl;
             if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
+            lap("fwd fetch");
             for (size_t k = 0; k < tbs.size(); ++k) {
                 const TbItem& t = tbs[k];
                 if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
@@ -355,6 +379,7 @@ struct Aligner {
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
             }
         }
+        lap("assemble records");
         return 0;
     }
 

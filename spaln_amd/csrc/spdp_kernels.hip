@@ -574,10 +574,14 @@ struct TbView {
     int64_t c_grp; uint4 c_w;
 };
 
+// One WAVE per problem: all 64 lanes run the same walk on the same addresses (the loads
+// broadcast), so a long intron scan of one problem never stalls 63 others the way
+// one-thread-per-problem did in a divergent wave.
 __global__ void spdp_walk(WalkArgs A)
 {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pi >= A.n_probs) return;
+    const bool writer = (threadIdx.x & 63) == 0;
     const DevProblem P = A.probs[pi];
     TbView V;
     V.tb = A.tb; V.tb_off = P.tb_off;
@@ -588,7 +592,7 @@ __global__ void spdp_walk(WalkArgs A)
     int cnt = 0, status = 0;
     int m = A.res[pi].mr - P.a_left, n = A.res[pi].nr - P.b_left;   // window-relative
     auto emit = [&]() {
-        if (cnt < A.skl_cap) out[cnt] = make_int2(m + P.a_left, n + P.b_left);
+        if (cnt < A.skl_cap) { if (writer) out[cnt] = make_int2(m + P.a_left, n + P.b_left); }
         else status = -1;
         ++cnt;
     };
@@ -633,7 +637,7 @@ __global__ void spdp_walk(WalkArgs A)
         }
     }
     emit();
-    A.n_skl[pi] = status ? status : cnt;
+    if (writer) A.n_skl[pi] = status ? status : cnt;
 }
 
 // ---------------------------------------------------------------------------
@@ -704,7 +708,7 @@ __global__ void spdp_udh_cpos(CposArgs A)
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t stream)
 {
     WalkArgs A = *a;
-    hipLaunchKernelGGL(spdp_walk, dim3((A.n_probs + 63) / 64), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(spdp_walk, dim3((A.n_probs + 3) / 4), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t stream)

@@ -350,6 +350,18 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     std::vector<DevProblem> sorted(n);
     for (int j = 0; j < n; ++j) sorted[j] = h_probs[order[j]];
     h_probs.swap(sorted);
+    // Big problems of an under-filled launch are spread over the 4 waves of a block (pipelined
+    // passes); with plenty of problems one wave each is more efficient (no pipeline fill).
+    n_multi = 0;
+    if (flav <= 2 && !st->sc.local) {
+        const char* force = getenv("SPDP_MULTI");
+        const bool underfilled = n < 4 * 4 * ctx->n_cu;
+        if (force ? atoi(force) != 0 : underfilled)
+            for (int j = 0; j < n; ++j) {
+                const int stripes = (h_probs[j].a_right - h_probs[j].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+                if (stripes >= 16) n_multi = j + 1; else break;          // sorted by size: a prefix
+            }
+    }
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
@@ -375,8 +387,8 @@ int DevRun::launch()
     SweepArgs A;
     A.sc = (const DevScoring*) store->d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n;
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
-    A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res;
-    const int grid = (n + 3) / 4;
+    A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.n_multi = n_multi;
+    const int grid = n_multi + (n - n_multi + 3) / 4;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;

@@ -19,6 +19,7 @@ struct SweepArgs {
     uint8_t*          tb;         // forward: traceback codes
     int*              imd;        // udh: hlnk0, hlnk1, vlnk0, vlnk1 per intermediate
     DevResult*        res;
+    int               n_multi;    // the first n_multi problems get a whole 4-wave block each
 };
 
 struct WalkArgs {
@@ -125,6 +126,7 @@ struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;
     int flavour = 0, n = 0;
+    int n_multi = 0;                        // leading problems run as 4-wave pipelines
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;
     std::vector<DevProblem> h_probs;        // in dispatch order

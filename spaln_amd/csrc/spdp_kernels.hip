@@ -115,10 +115,21 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     const int spj = sc->spj, llmt = sc->llmt;
     const int p0 = sc->qm_pen[0];
 
-    // one wave = one problem; the hardware dispatcher balances the load (blocks are
-    // launched as CUs free up), so no software queue is needed
-    const int pi = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (pi >= A.n_probs) return;
+    // Work mapping.  The first n_multi problems (the largest) own a whole 4-wave block each: wave w
+    // runs passes w, w+4, w+8, .. (a pass = 4 stripes = 64 query rows) behind wave w-1, which it
+    // follows at a distance through progress words in LDS -- a wavefront pipeline inside the CU.
+    // All other problems take one wave each (4 per block).  The hardware dispatcher balances the
+    // load (blocks are launched as CUs free up), so no software queue is needed.
+    __shared__ int s_prog[4];
+    const int wv = threadIdx.x >> 6;
+    const bool multi = (int) blockIdx.x < A.n_multi;
+    const int W = multi ? 4 : 1;                    // waves cooperating on my problem
+    const int w = multi ? wv : 0;                   // my position among them
+    int pi = multi ? (int) blockIdx.x : A.n_multi + ((int) blockIdx.x - A.n_multi) * 4 + wv;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const bool active = pi < A.n_probs;
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
+    if (!active) pi = A.n_probs - 1;                // keep the addressing valid until the barrier
     const DevProblem P = A.probs[pi];
     const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width;
@@ -129,7 +140,6 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     const int2* __restrict__ cols = A.cols + P.col_off;
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int n_ent = P.buf_size + SPDP_BND_PAD;
-    const int wv = threadIdx.x >> 6;
 #define BIDX(r) ((r) - lw + 1)
 
     // ---- fhinitS1 (src/fwd2s1_simd.cc:163-239): boundary values by diagonal
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         int rr_g = rr;                                   // global: ramp stops where it reaches nevsel
         if (!a_exgl && ge) rr_g = min(rr, (SPDP_NEV16 - sc->gop) / ge + rl);
         const int ru = up + 2 * SPDP_NELEM;
-        for (int e = lane; e < n_ent; e += 64) {
+        for (int e = lane + 64 * w; e < n_ent && active; e += 64 * W) {
             const int r = e + lw - 1;
             int h = SPDP_NEV16;
             if (b_exgl && r >= lw && r < rl) h = 0;
@@ -163,11 +173,13 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         if constexpr (FL == FL_UDH) {
             int* imd = A.imd + P.imd_off;
             const int tot = P.n_im * 4 * width;
-            for (int e = lane; e < tot; e += 64) imd[e] = END_OF_ULK;
+            for (int e = lane + 64 * w; e < tot && active; e += 64 * W) imd[e] = END_OF_ULK;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();                                // the only block-wide barrier (all waves reach it)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (!active) return;
 
     // UDH: intermediate rows (src/fwd2s1_wip_simd.h:503-508)
     const int n_im = (FL == FL_UDH) ? P.n_im : 0;
@@ -180,7 +192,12 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 
     int64_t tb_base = P.tb_off;                         // forward: byte offset of the pass' first stripe
     const int n_stripes = (a_right - a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+    const int n_passes = (n_stripes + 3) >> 2;
+    constexpr int BIGB = 1 << 20;                       // progress word = pass * BIGB + blocks done
+    const int prod = (w + W - 1) % W;                   // wave running the pass before mine
     for (int s0 = 0; s0 < n_stripes; s0 += 4) {
+        const int pass = s0 >> 2;
+        const bool mine = (pass % W) == w;
         // ---- geometry of my stripe (row g of the wave)
         const int s = s0 + g;
         const int ml = a_left + s * SPDP_NELEM;
@@ -222,6 +239,7 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         const bool imd_row = (FL == FL_UDH) && imd_i >= 0;
         int* imd_p = nullptr;
         if constexpr (FL == FL_UDH) if (imd_row) imd_p = A.imd + P.imd_off + (int64_t) imd_i * 4 * width;
+        if (!mine) continue;                            // bookkeeping above ran; the sweep is another wave's
         // only the last stripe of a problem can be partial (fewer than 16 rows)
         const bool pass_partial = (s0 + 4 >= n_stripes) && ((a_right - a_left) & 15);
 
@@ -256,8 +274,19 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                 if (nn <= b_left) crec.y = 0;
                 nx_c = crec;
             };
+            // multi-wave: row 0 reads boundary entries of the previous pass, produced by wave `prod`;
+            // local block lbn of row 0 needs its absolute blocks <= lbn + 15 flushed (3 rows x LAG + 3)
+            auto wait_for = [&](int lbn) {
+                if (W == 1 || pass == 0) return;
+                const int need = (pass - 1) * BIGB + lbn + 16;
+                while (__hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                    __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            };
+            wait_for(0);
             if (g == 0 && nb > 0) prefetch(0);
             for (int blk = 0; blk < tot; ++blk) {
+                if (blk + 1 < nb0) wait_for(blk + 1);
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
                 if (lb == -1 && nb > 0) prefetch(0);                    // one block ahead of first use
                 if (lb >= 0 && lb < nb) {
@@ -429,6 +458,16 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
                 // vector memory path, loads bypass L1), so only the compiler needs a fence here
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (W > 1) {                                            // publish: this block's stores are done
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0)
+                        __hip_atomic_store(&s_prog[w], pass * BIGB + blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (W > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&s_prog[w], (pass + 1) * BIGB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
         if (pass_partial) {
@@ -440,6 +479,17 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
         }
     }
 
+    if (W > 1) {
+        if ((n_passes - 1) % W != w) return;            // the wave of the last pass finishes the problem
+        for (int x = 0; x < W; ++x) {
+            if (x == w) continue;
+            const int last_own = ((n_passes - 1 - x) / W) * W + x;      // last pass of wave x (< 0: none)
+            if (n_passes - 1 - x < 0) continue;
+            while (__hip_atomic_load(&s_prog[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (last_own + 1) * BIGB)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
     DevResult R;
     R.score = SPDP_NEV16; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = END_OF_ULK; R.maxr = 0;

@@ -22,48 +22,9 @@
 //   -r al,ar,bl,br  restrict the active ranges (Seq::left/right) before the tables are built
 //   -u list  extra explicit UDH runs with these n_im (comma separated)
 
-#include <vector>
-#include <string>
-#include <cstdio>
-#include <cstring>
-#include <cstdlib>
-#include "aln.h"
-#include "utilseq.h"
-#include "wln.h"
-#include "vmf.h"
-#include "gsinfo.h"
+#include "ref_dump_common.h"
 #include "fwd2s1_simd.h"
 
-extern	int	MaxVmfSpace;
-
-// ---------------------------------------------------------------- container
-struct Writer {
-	FILE*	fd;
-	explicit Writer(const char* fn) {
-	    fd = fopen(fn, "wb");
-	    if (!fd) { perror(fn); exit(1); }
-	    fwrite("SPDG1\0\0\0", 1, 8, fd);
-	}
-	~Writer() { fclose(fd); }
-	// dtype: 1 u8, 2 i16, 3 i32, 4 i8
-	void put(const char* name, unsigned dtype, const void* p, size_t cnt) {
-	    static const int esz[5] = {0, 1, 2, 4, 1};
-	    char	nm[32];
-	    memset(nm, 0, sizeof(nm));
-	    strncpy(nm, name, 31);
-	    fwrite(nm, 1, 32, fd);
-	    unsigned	hd[2] = {dtype, (unsigned) cnt};
-	    fwrite(hd, 4, 2, fd);
-	    size_t	nb = cnt * esz[dtype];
-	    if (nb) fwrite(p, 1, nb, fd);
-	    static const char zero[8] = {0};
-	    if (nb % 8) fwrite(zero, 1, 8 - nb % 8, fd);
-	}
-	void put_i32(const char* name, const std::vector<int>& v) {
-	    put(name, 3, v.data(), v.size());
-	}
-	void put_int(const char* name, int x) { put(name, 3, &x, 1); }
-};
 
 static void set_default_params()	// same calls, same order as the CLI default set-up (spaln.cc:1471-1494)
 {
@@ -86,18 +47,6 @@ static void set_default_params()	// same calls, same order as the CLI default se
 	alprm.scale = 10;
 }
 
-static std::vector<int> skl2vec(const SKL* skl)
-{
-	std::vector<int>	v;
-	if (!skl) return v;
-	v.push_back(skl->m);		// flags
-	v.push_back(skl->n);		// #corners
-	for (int i = 1; i <= skl->n; ++i) {
-	    v.push_back(skl[i].m);
-	    v.push_back(skl[i].n);
-	}
-	return v;
-}
 
 int main(int argc, const char** argv)
 {
@@ -156,6 +105,7 @@ const	char*	outfn = argv[ai + 2];
 	if (svr.nextseq(b, 1) == IS_END) { fprintf(stderr, "no genome\n"); return 1; }
 	if (svr.nextseq(a, 0) != IS_OK) { fprintf(stderr, "no query\n"); return 1; }
 	if (rng4[0] >= 0) { a->left = rng4[0]; a->right = rng4[1]; b->left = rng4[2]; b->right = rng4[3]; }
+	if (a->isprotein()) return dump_protein(seqs, exg, udh_list, outfn);
 	b->inex.intr = algmode.lsg;
 	makeWlprms(prePwd((const Seq**) seqs));
 	algmode.alg = 2;		// IntronPenalty builds the quantile table qm only when alg > 1 (codepot.cc:162)

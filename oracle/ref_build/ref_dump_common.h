@@ -1,0 +1,62 @@
+// ref_dump_common.h -- shared by the two translation units of the golden harness
+// (TEST INFRASTRUCTURE ONLY; see ref_dump.cc).
+#ifndef REF_DUMP_COMMON_H_
+#define REF_DUMP_COMMON_H_
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include "aln.h"
+#include "utilseq.h"
+#include "wln.h"
+#include "vmf.h"
+#include "gsinfo.h"
+
+extern	int	MaxVmfSpace;
+
+// ---------------------------------------------------------------- container
+struct Writer {
+	FILE*	fd;
+	explicit Writer(const char* fn) {
+	    fd = fopen(fn, "wb");
+	    if (!fd) { perror(fn); exit(1); }
+	    fwrite("SPDG1\0\0\0", 1, 8, fd);
+	}
+	~Writer() { fclose(fd); }
+	// dtype: 1 u8, 2 i16, 3 i32, 4 i8
+	void put(const char* name, unsigned dtype, const void* p, size_t cnt) {
+	    static const int esz[5] = {0, 1, 2, 4, 1};
+	    char	nm[32];
+	    memset(nm, 0, sizeof(nm));
+	    strncpy(nm, name, 31);
+	    fwrite(nm, 1, 32, fd);
+	    unsigned	hd[2] = {dtype, (unsigned) cnt};
+	    fwrite(hd, 4, 2, fd);
+	    size_t	nb = cnt * esz[dtype];
+	    if (nb) fwrite(p, 1, nb, fd);
+	    static const char zero[8] = {0};
+	    if (nb % 8) fwrite(zero, 1, 8 - nb % 8, fd);
+	}
+	void put_i32(const char* name, const std::vector<int>& v) {
+	    put(name, 3, v.data(), v.size());
+	}
+	void put_int(const char* name, int x) { put(name, 3, &x, 1); }
+};
+
+
+inline std::vector<int> skl2vec(const SKL* skl)
+{
+	std::vector<int>	v;
+	if (!skl) return v;
+	v.push_back(skl->m);		// flags
+	v.push_back(skl->n);		// #corners
+	for (int i = 1; i <= skl->n; ++i) {
+	    v.push_back(skl[i].m);
+	    v.push_back(skl[i].n);
+	}
+	return v;
+}
+
+int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn);
+#endif

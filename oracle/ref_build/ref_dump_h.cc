@@ -1,0 +1,174 @@
+// ref_dump_h.cc -- protein x genome half of the golden harness (TEST INFRASTRUCTURE ONLY).
+// Separate translation unit: fwd2s1_simd.h and fwd2h1_simd.h cannot share one.
+#include "ref_dump_common.h"
+#include "fwd2h1_simd.h"
+
+// ---------------------------------------------------------------- protein x genome (Fwd2h1)
+// Same idea for the aa x 3-frame path: SimdAln2h1 (fwd2h1_simd.h:69-382) and the
+// HomScoreH_ng / alignH_ng surface (fwd2h1.cc:3288, 3310).  Set-up order as in match_2
+// (spaln.cc:742-765): nuc2tron, Exinon, then exg_seq.
+int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn)
+{
+	Seq*&	a = seqs[0];
+	Seq*&	b = seqs[1];
+	b->inex.intr = algmode.lsg;
+	makeWlprms(prePwd((const Seq**) seqs));
+	algmode.alg = 2;
+	PwdB*	pwd = new PwdB((const Seq**) seqs);
+	makeStdSig53();
+	a->inex.intr = 0;
+	b->nuc2tron();
+	b->exin = new Exinon(b, pwd, false);
+	if (algmode.lcl & 16) {
+	    a->exg_seq(1, 1);
+	    b->exg_seq(1, 1);
+	} else {
+	    a->exg_seq(algmode.lcl & 4, algmode.lcl & 8);
+	    b->exg_seq(algmode.lcl & 1, algmode.lcl & 2);
+	}
+	if (exg) {
+	    a->exg_seq(exg[0] == '1', exg[1] == '1');
+	    b->exg_seq(exg[2] == '1', exg[3] == '1');
+	}
+	Writer	w(outfn);
+	w.put_int("is_protein", 1);
+	w.put("a_codes", 1, a->at(0), a->len);
+	w.put("b_codes", 1, b->at(0), b->len);
+	{
+	    const int N = b->len + 3;
+	    std::vector<short> v[6];
+	    for (int f = 0; f < 6; ++f) v[f].assign(N, 0);
+	    std::vector<signed char> p5(N, -2), p3(N, -2);
+	    std::vector<unsigned char> good(N, 0);
+	    for (int n = std::max(0, b->left - 1); n <= b->right + 1 && n < N; ++n) {
+		const SGPT6* sg = b->exin->score_p(n);
+		v[0][n] = sg->sig5; v[1][n] = sg->sig3; v[2][n] = sg->sigS;
+		v[3][n] = sg->sigT; v[4][n] = sg->sigE; v[5][n] = sg->sigI;
+		p5[n] = sg->phs5; p3[n] = sg->phs3;
+		good[n] = b->exin->good(sg);
+	    }
+	    const char* nm[6] = {"sig5", "sig3", "sigS", "sigT", "sigE", "sigI"};
+	    for (int f = 0; f < 6; ++f) w.put(nm[f], 2, v[f].data(), N);
+	    w.put("phs5", 4, p5.data(), N);
+	    w.put("phs3", 4, p3.data(), N);
+	    w.put("good", 1, good.data(), N);
+	}
+	{
+	    const Simmtx* sm = pwd->simmtx;
+	    std::vector<int> dims = {sm->dim, sm->rows, sm->cols};
+	    w.put_i32("mtx_dims", dims);
+	    const int R = sm->rows? sm->rows: sm->dim, Cc = sm->cols? sm->cols: sm->dim;
+	    std::vector<int>	mtx(R * Cc);
+	    for (int i = 0; i < R; ++i)
+		for (int j = 0; j < Cc; ++j) mtx[i * Cc + j] = sm->mtx[i][j];
+	    w.put_i32("mtx", mtx);
+	    w.put_int("avmch", (int) sm->AvTrc());
+	}
+	{
+	    std::vector<int> prm = {
+		(int) pwd->BasicGOP, (int) pwd->BasicGEP, (int) pwd->LongGOP, (int) pwd->LongGEP,
+		pwd->Noll, (int) pwd->Vthr, (int) pwd->Vab, pwd->codonk1,
+		IntronPrm.llmt, IntronPrm.minl, IntronPrm.rlmt, IntronPrm.mu,
+		IntronPrm.maxl, IntronPrm.nquant, (int) IntronPrm.hard_minl, (int) IntronPrm.hard_maxl,
+		(int) pwd->IntPen->Penalty(), alprm.sh, (int) (algmode.lcl & 16),
+		(int) a->inex.exgl, (int) a->inex.exgr, (int) b->inex.exgl, (int) b->inex.exgr,
+		a->left, a->right, b->left, b->right, MaxVmfSpace, alprm.ubh,
+		(int) b->inex.intr};
+	    w.put_i32("params", prm);
+	    std::vector<int> hp = {(int) pwd->GapW1, (int) pwd->GapW2, (int) pwd->GapW3, (int) pwd->GapW3L,
+		(int) pwd->GapE1, (int) pwd->GapE2, (int) pwd->ExtraGOP, alprm.k1, alprm2.termk1,
+		(int) algmode.lcl, pwd->DvsP};
+	    w.put_i32("hparams", hp);
+	    std::vector<int>	ql, qp;
+	    for (int j = 0; j < IntronPrm.nquant; ++j) {
+		ql.push_back(pwd->IntPen->qm[j].len);
+		qp.push_back(pwd->IntPen->qm[j].pen);
+	    }
+	    w.put_i32("qm_len", ql);
+	    w.put_i32("qm_pen", qp);
+	}
+const	RANGE	ra = {a->left, a->right};
+const	RANGE	rb = {b->left, b->right};
+const	INEX	ia = a->inex, ib = b->inex;
+const	int	nq0 = IntronPrm.nquant;
+	auto restore = [&]() {
+	    a->left = ra.left; a->right = ra.right;
+	    b->left = rb.left; b->right = rb.right;
+	    a->inex = ia; b->inex = ib;
+	};
+	char	nm[48];
+	for (int pass = 0; pass < 2; ++pass) {
+	    IntronPrm.nquant = pass? 1: nq0;
+const	    char*	tag = pass? "q1": "qn";
+	    SpJunc	spjcs(b, pwd);
+	    WINDOW	wdw;
+	    restore();
+	    stripe31((const Seq**) seqs, &wdw, alprm.sh);
+	    if (pass == 0) {
+		std::vector<int> wv = {wdw.lw, wdw.up, wdw.width};
+		w.put_i32("wdw", wv);
+	    }
+	    {
+		SimdAln2h1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, 1);
+		VTYPE	s = eng.forwardH1_wip();
+		snprintf(nm, sizeof nm, "wip_%s_score", tag);
+		w.put_int(nm, (int) s);
+	    }
+	    {
+		restore();
+		Mfile	mfd(sizeof(SKL));
+		SimdAln2h1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, 1, 0);
+		VTYPE	s = eng.forwardH1_wip(&mfd);
+		snprintf(nm, sizeof nm, "wip_%s_fwd_scr", tag);
+		w.put_int(nm, (int) s);
+		int	nrec = (int) mfd.size();
+		SKL*	rec = (SKL*) mfd.flush();
+		std::vector<int> v;
+		for (int i = 0; i < nrec; ++i) { v.push_back(rec[i].m); v.push_back(rec[i].n); }
+		snprintf(nm, sizeof nm, "wip_%s_fwd_skl", tag);
+		w.put_i32(nm, v);
+		delete[] rec;
+	    }
+	    for (size_t u = 0; u < udh_list.size(); ++u) {
+const		int	n_im = udh_list[u];
+		restore();
+		stripe31((const Seq**) seqs, &wdw, alprm.sh);
+const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4;
+		Dim10*	cpos = new Dim10[n_im + 1];
+		for (int i = 0; i <= n_im; ++i)
+		    for (int c = 0; c < 10; ++c) cpos[i][c] = end_of_ulk;
+		SimdAln2h1 eng((const Seq**) seqs, pwd, wdw, &spjcs, 0, mode);
+		VTYPE	s = eng.hirschbergH1_wip(cpos, n_im);
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_scr", tag, n_im);
+		w.put_int(nm, (int) s);
+		std::vector<int> v;
+		for (int i = 0; i <= n_im; ++i)
+		    for (int c = 0; c < 10; ++c) v.push_back(cpos[i][c]);
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_cpos", tag, n_im);
+		w.put_i32(nm, v);
+		std::vector<int> rngs = {a->left, a->right, b->left, b->right, mode};
+		snprintf(nm, sizeof nm, "wip_%s_udh%d_rng", tag, n_im);
+		w.put_i32(nm, rngs);
+		delete[] cpos;
+	    }
+	}
+	IntronPrm.nquant = nq0;
+	for (int alg = 0; alg < 4; ++alg) {
+	    if (alg == 1) continue;	// -A1 (forwardH1 / exact SIMD) is not part of these fixtures
+	    algmode.alg = alg;
+	    restore();
+	    fprintf(stderr, "[hom %d]\n", alg);
+	    VTYPE	hs = HomScoreH_ng((const Seq**) seqs, pwd);
+	    snprintf(nm, sizeof nm, "hom_scr_A%d", alg);
+	    w.put_int(nm, (int) hs);
+	    restore();
+	    Gsinfo	gsi;
+	    fprintf(stderr, "[aln %d]\n", alg);
+	    gsi.skl = alignH_ng((const Seq**) seqs, pwd, &gsi);
+	    snprintf(nm, sizeof nm, "aln_scr_A%d", alg);
+	    w.put_int(nm, (int) gsi.scr);
+	    snprintf(nm, sizeof nm, "aln_skl_A%d", alg);
+	    w.put_i32(nm, skl2vec(gsi.skl));
+	}
+	return 0;
+}

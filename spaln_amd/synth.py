@@ -160,3 +160,63 @@ def make_batch(n_queries: int, seed: int = SEED, *, n_exons: int = 8, mrna_len: 
         s5, s3 = splice_signals(g.window)
         out.append((defaults.encode(g.window), defaults.encode(g.query), s5, s3, g.exons))
     return out
+
+
+# ---------------------------------------------------------------------------
+# protein x genome (BASELINE config C3): an ORF split into coding exons
+_CODON_AA = {}
+_BASES = "TCAG"
+_AAS = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+for _i, _a in enumerate(_BASES):
+    for _j, _b in enumerate(_BASES):
+        for _k, _c in enumerate(_BASES):
+            _CODON_AA[_a + _b + _c] = _AAS[16 * _i + 4 * _j + _k]
+_AA_LETTERS = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+
+def translate(dna_ascii: np.ndarray) -> np.ndarray:
+    s = dna_ascii.tobytes().decode()
+    return np.frombuffer("".join(_CODON_AA[s[i:i + 3]] for i in range(0, len(s) - 2, 3)).encode(), dtype=np.uint8)
+
+
+@dataclasses.dataclass
+class ProteinGene:
+    window: np.ndarray          # genomic window, ASCII
+    protein: np.ndarray         # error-free translation, ASCII amino acids
+    query: np.ndarray           # mutated protein (the query)
+    exons: list                 # [(start, end)] of the coding exons in window coordinates
+
+
+def make_protein_gene(rng, n_exons: int = 4, aa_len: int = 400, flank: int = 500,
+                      sub: float = 0.10, intron_lo: int = 60, intron_hi: int = 3000) -> ProteinGene:
+    """ATG ... stop ORF of `aa_len` codons (no internal stop), cut into exons at arbitrary phases."""
+    orf = random_dna(rng, 3 * aa_len)
+    s = bytearray(orf.tobytes())
+    for i in range(0, len(s), 3):                       # remove stop codons
+        while _CODON_AA[s[i:i + 3].decode()] == "*":
+            s[i:i + 3] = random_dna(rng, 3).tobytes()
+    s[0:3] = b"ATG"
+    orf = np.frombuffer(bytes(s), dtype=np.uint8)
+    cds = np.concatenate([orf, np.frombuffer(b"TAA", dtype=np.uint8)])
+    w = rng.lognormal(mean=0.0, sigma=0.5, size=n_exons)
+    lens = np.maximum(20, (w / w.sum() * len(cds)).astype(int))
+    lens[-1] = max(20, len(cds) - int(lens[:-1].sum()))
+    parts, exons, pos, off = [random_dna(rng, flank)], [], flank, 0
+    for k, L in enumerate(lens):
+        L = int(min(L, len(cds) - off))
+        if L <= 0:
+            break
+        parts.append(cds[off:off + L])
+        exons.append((pos, pos + L))
+        pos += L
+        off += L
+        if off < len(cds) and k + 1 < n_exons:
+            il = _intron_len(rng, intron_lo, intron_hi)
+            parts.append(_intron(rng, il))
+            pos += il
+    parts.append(random_dna(rng, flank))
+    prot = translate(orf)
+    q = prot.copy()
+    hit = rng.random(q.size) < sub
+    q[hit] = _AA_LETTERS[rng.integers(0, 20, size=int(hit.sum()))]
+    return ProteinGene(np.concatenate(parts), prot, q, exons)

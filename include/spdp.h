@@ -163,6 +163,72 @@ int spdp_batch_align(SpdpBatch* bt, SpdpAlignment* out, float* kernel_ms, int64_
 #define SPDP_N_STATS 8
 int spdp_batch_stats(const SpdpBatch* bt, double* out, int n);
 
+
+/* ======================================================================== */
+/* protein x genome (aa x 3-frame "tron" codes): the Fwd2h1 `_wip` path      */
+/*   VTYPE HomScoreH_ng(const Seq* seqs[], const PwdB* pwd)   src/fwd2h1.cc:3288 */
+/*   SKL*  alignH_ng(const Seq* seqs[], const PwdB*, Gsinfo*) src/fwd2h1.cc:3310 */
+/*   SimdAln2h1(seqs, pwd, wdw, spjcs, cip, mode = 1)         src/fwd2h1_simd.h:198 */
+/*     forwardH1_wip(Mfile*)                                  src/fwd2h1_wip_simd.h:50 */
+/* DP row m in (a_left, a_right] is residue a[m-1]; DP column n is the       */
+/* nucleotide position, the codon ending at n is b[n-2] (tron code, after    */
+/* Seq::nuc2tron); diagonals are r = n - 3m.                                 */
+/* ======================================================================== */
+
+/* PwdB / IntronPenalty / Simmtx subset read by SimdAln2h1 (src/aln.h:235-308) */
+typedef struct SpdpScoringH {
+    int32_t mtx_rows, mtx_cols;      /* Simmtx::rows (aa, 23), Simmtx::dim (tron, 26)       */
+    int32_t mtx[32 * 32];            /* row-major mtx[aa * mtx_cols + tron]                 */
+    int32_t gop, gep;                /* PwdB::BasicGOP, BasicGEP (per codon)                */
+    int32_t lgep, codonk1;           /* GapExtPen3(i) = i > codonk1 ? LongGEP : BasicGEP    */
+    int32_t gapw1, gapw2, gapw3;     /* PwdB::GapW1 / GapW2 (frame shifts), GapW3 (codon gap open) */
+    int32_t spj;                     /* b->inex.intr                                        */
+    int32_t llmt, ipen;              /* IntronPrm.llmt, IntronPenalty::Penalty()            */
+    int32_t nquant;
+    int32_t qm_len[SPDP_MAX_QUANT];
+    int32_t qm_pen[SPDP_MAX_QUANT];
+    int32_t local;                   /* algmode.lcl & 16                                    */
+    int32_t term_codon;              /* algmode.lcl & 2: termination codon as a right end (fwd2h1_simd.h:720) */
+    int32_t sh;                      /* alprm.sh (codons), stripe31()                       */
+    int32_t max_vmf_space;           /* MaxVmfSpace                                         */
+    int32_t ubh;                     /* alprm.ubh                                           */
+    int32_t ref_nelem;               /* 16                                                  */
+} SpdpScoringH;
+
+typedef struct SpdpProblemH {
+    const uint8_t* a;  int32_t a_len;      /* amino-acid codes a[0 .. a_len)                      */
+    const uint8_t* b;  int32_t b_len;      /* tron codes b[0 .. b_len]: b_len + 1 readable entries
+                                              (the engine reads the terminator, fwd2h1_wip_simd.h:188) */
+    /* SGPT6 fields per genomic position (src/codepot.h:34-43), index 0 .. b_len + 2; the reference
+     * holds them for [exin_left - 1, exin_right + 1] (Exinon ctor, src/codepot.cc:357-366) */
+    const int16_t* sig5;  const int16_t* sig3;
+    const int16_t* sigS;  const int16_t* sigT;  const int16_t* sigE;
+    const int8_t*  phs5;  const int8_t*  phs3;
+    int32_t exin_left, exin_right;         /* Seq::left / right when the Exinon was built: good(n)
+                                              <=> exin_left - 1 <= n < exin_right (codepot.h:120-123) */
+    int32_t a_left, a_right, b_left, b_right;
+    uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
+} SpdpProblemH;
+
+/* stripe31(seqs, &wdw, sh), src/aln2.cc:178-198 */
+void spdp_stripe31(const SpdpProblemH* p, int sh, SpdpWindow* wdw);
+/* (aa, nt) cells inside the band: rows m, columns max(b_left, lw + 3m) < n <= min(b_right, up + 3m) */
+int64_t spdp_cells_h(const SpdpProblemH* p, const SpdpWindow* wdw);
+
+/* forwardH1_wip(mfd): returned score (the reference returns its `nevsel` here unless a local
+ * right end was tracked: fhlastH1 never sets maxh.val, fwd2h1_simd.h:692-785) + raw Mfile
+ * records end -> start.  n_skl = -1 flags the reference's fatal "Unexpected dir". */
+int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc,
+                       const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+/* HomScoreH_ng for -A2/-A3: stripe31() then forwardH1_wip() */
+int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
+                    const SpdpProblemH* probs, int n_probs, int32_t* scores);
+/* alignH_ng with seeding off (-Q0/-Q4): stripe31 -> lspH_ng -> trcbkalignH_ng -> stdskl3.
+ * Problems whose volume exceeds MaxVmfSpace need hirschbergH1_wip, which is not built yet:
+ * they are reported through the return value 1 and come back with n_skl = 0. */
+int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
+                 const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c", "spdp_oracle_h.c")]
     hdr = os.path.join(_HERE, "..", "include", "spdp.h")
     newest = max(os.path.getmtime(f) for f in srcs + [hdr])
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
@@ -31,6 +31,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.orc_cells.restype = C.c_int64
+        _lib.orc_cells_h.restype = C.c_int64
     return _lib
 
 
@@ -103,3 +104,29 @@ def scalar_forward(sc, p, w=None):
     if n.value:
         C.CDLL(None).free(skl)
     return s.value, out
+
+
+# ---- protein x genome ------------------------------------------------------------------
+def stripe31(p: abi.ProblemH, sh: int) -> abi.Window:
+    w = abi.Window()
+    lib().orc_stripe31(C.byref(p), C.c_int(sh), C.byref(w))
+    return w
+
+
+def cells_h(p: abi.ProblemH, w: abi.Window) -> int:
+    return int(lib().orc_cells_h(C.byref(p), C.byref(w)))
+
+
+def wip_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None):
+    """SimdAln2h1::forwardH1_wip(mfd): (score, records end -> start, flag); flag 0 ok, -2 the
+    reference's fatal "Unexpected dir", -3 its traceback starts outside the bitmap (undefined)."""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_wip_forward_h(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    if rc not in (0, -2, -3):
+        raise RuntimeError(f"orc_wip_forward_h rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    C.CDLL(None).free(skl)
+    return s.value, out, rc

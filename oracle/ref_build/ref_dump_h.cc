@@ -33,7 +33,7 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	Writer	w(outfn);
 	w.put_int("is_protein", 1);
 	w.put("a_codes", 1, a->at(0), a->len);
-	w.put("b_codes", 1, b->at(0), b->len);
+	w.put("b_codes", 1, b->at(0), b->len + 1);	// + the terminator the engine reads (sm_a at n = right + 2)
 	{
 	    const int N = b->len + 3;
 	    std::vector<short> v[6];
@@ -157,13 +157,11 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	    if (alg == 1) continue;	// -A1 (forwardH1 / exact SIMD) is not part of these fixtures
 	    algmode.alg = alg;
 	    restore();
-	    fprintf(stderr, "[hom %d]\n", alg);
 	    VTYPE	hs = HomScoreH_ng((const Seq**) seqs, pwd);
 	    snprintf(nm, sizeof nm, "hom_scr_A%d", alg);
 	    w.put_int(nm, (int) hs);
 	    restore();
 	    Gsinfo	gsi;
-	    fprintf(stderr, "[aln %d]\n", alg);
 	    gsi.skl = alignH_ng((const Seq**) seqs, pwd, &gsi);
 	    snprintf(nm, sizeof nm, "aln_scr_A%d", alg);
 	    w.put_int(nm, (int) gsi.scr);

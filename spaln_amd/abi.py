@@ -134,3 +134,101 @@ class ProblemSet:
         arr = (Problem * len(self.items))(*self.items)
         self._keep.append(arr)
         return arr
+
+
+# ---- protein x genome (Fwd2h1 `_wip`) ------------------------------------------------------
+class ScoringH(C.Structure):
+    _fields_ = [
+        ("mtx_rows", C.c_int32), ("mtx_cols", C.c_int32),
+        ("mtx", C.c_int32 * (32 * 32)),
+        ("gop", C.c_int32), ("gep", C.c_int32),
+        ("lgep", C.c_int32), ("codonk1", C.c_int32),
+        ("gapw1", C.c_int32), ("gapw2", C.c_int32), ("gapw3", C.c_int32),
+        ("spj", C.c_int32),
+        ("llmt", C.c_int32), ("ipen", C.c_int32),
+        ("nquant", C.c_int32),
+        ("qm_len", C.c_int32 * MAX_QUANT),
+        ("qm_pen", C.c_int32 * MAX_QUANT),
+        ("local", C.c_int32),
+        ("term_codon", C.c_int32),
+        ("sh", C.c_int32),
+        ("max_vmf_space", C.c_int32),
+        ("ubh", C.c_int32),
+        ("ref_nelem", C.c_int32),
+    ]
+
+
+class ProblemH(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("a_len", C.c_int32),
+        ("b", C.c_void_p), ("b_len", C.c_int32),
+        ("sig5", C.c_void_p), ("sig3", C.c_void_p),
+        ("sigS", C.c_void_p), ("sigT", C.c_void_p), ("sigE", C.c_void_p),
+        ("phs5", C.c_void_p), ("phs3", C.c_void_p),
+        ("exin_left", C.c_int32), ("exin_right", C.c_int32),
+        ("a_left", C.c_int32), ("a_right", C.c_int32),
+        ("b_left", C.c_int32), ("b_right", C.c_int32),
+        ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
+        ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
+    ]
+
+
+def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, gapw2, gapw3,
+                   spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
+                   term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
+                   ref_nelem=REF_NELEM) -> ScoringH:
+    sc = ScoringH()
+    sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
+    flat = np.asarray(mtx, dtype=np.int32).ravel()
+    assert flat.size == mtx_rows * mtx_cols <= 32 * 32
+    for i, v in enumerate(flat):
+        sc.mtx[i] = int(v)
+    sc.gop, sc.gep, sc.lgep, sc.codonk1 = int(gop), int(gep), int(lgep), int(codonk1)
+    sc.gapw1, sc.gapw2, sc.gapw3 = int(gapw1), int(gapw2), int(gapw3)
+    sc.spj, sc.llmt, sc.ipen = int(spj), int(llmt), int(ipen)
+    nq = len(qm_len) if nquant is None else int(nquant)
+    assert 1 <= nq <= MAX_QUANT
+    sc.nquant = nq
+    for j in range(min(len(qm_len), MAX_QUANT)):
+        sc.qm_len[j] = int(qm_len[j])
+        sc.qm_pen[j] = int(qm_pen[j])
+    sc.local, sc.term_codon, sc.sh = int(local), int(term_codon), int(sh)
+    sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
+    return sc
+
+
+class ProblemSetH:
+    """Owns the numpy buffers a ctypes ProblemH array points into."""
+
+    def __init__(self):
+        self._keep = []
+        self.items = []
+
+    def add(self, a, b, sig5, sig3, sigS, sigT, sigE, phs5, phs3, a_left=0, a_right=None,
+            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)          # b_len + 1 entries
+        b_len = b.size - 1
+        sg = [np.ascontiguousarray(x, dtype=np.int16) for x in (sig5, sig3, sigS, sigT, sigE)]
+        ph = [np.ascontiguousarray(x, dtype=np.int8) for x in (phs5, phs3)]
+        assert min(x.size for x in sg + ph) >= b_len + 3
+        self._keep += [a, b] + sg + ph
+        p = ProblemH()
+        p.a, p.a_len = a.ctypes.data, a.size
+        p.b, p.b_len = b.ctypes.data, b_len
+        p.sig5, p.sig3, p.sigS, p.sigT, p.sigE = (x.ctypes.data for x in sg)
+        p.phs5, p.phs3 = (x.ctypes.data for x in ph)
+        p.a_left, p.a_right = int(a_left), int(a.size if a_right is None else a_right)
+        p.b_left, p.b_right = int(b_left), int(b_len if b_right is None else b_right)
+        p.exin_left, p.exin_right = (p.b_left, p.b_right) if exin is None else (int(exin[0]), int(exin[1]))
+        p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr = (int(x) for x in exg)
+        self.items.append(p)
+        return p
+
+    def __len__(self):
+        return len(self.items)
+
+    def array(self):
+        arr = (ProblemH * len(self.items))(*self.items)
+        self._keep.append(arr)
+        return arr

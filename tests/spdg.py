@@ -52,3 +52,35 @@ def problem(fx: dict, ps: abi.ProblemSet | None = None):
                q["a_left"], q["a_right"], q["b_left"], q["b_right"],
                (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), **extra)
     return ps, p
+
+
+HPARAM_NAMES = ["gapw1", "gapw2", "gapw3", "gapw3l", "gape1", "gape2", "extragop", "k1", "termk1",
+                "lcl", "dvsp"]
+
+
+def scoring_h(fx: dict, nquant: int | None = None, **over) -> abi.ScoringH:
+    q = fx["prm"]
+    h = dict(zip(HPARAM_NAMES, (int(x) for x in fx["hparams"])))
+    dim, rows, cols = (int(x) for x in fx["mtx_dims"])
+    rows, cols = rows or dim, cols or dim
+    kw = dict(mtx=fx["mtx"], mtx_rows=rows, mtx_cols=cols, gop=q["gop"], gep=q["gep"], lgep=q["lgep"],
+              codonk1=q["codonk1"], gapw1=h["gapw1"], gapw2=h["gapw2"], gapw3=h["gapw3"],
+              spj=q["b_intr"], llmt=q["llmt"], ipen=q["ipen"], qm_len=fx["qm_len"], qm_pen=fx["qm_pen"],
+              nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
+              term_codon=1 if h["lcl"] & 2 else 0, sh=q["sh"], max_vmf_space=q["max_vmf_space"],
+              ubh=q["ubh"])
+    kw.update(over)
+    return abi.make_scoring_h(**kw)
+
+
+def problem_h(fx: dict, ps: abi.ProblemSetH | None = None):
+    q = fx["prm"]
+    ps = ps or abi.ProblemSetH()
+    good = fx["good"]
+    # the harness builds the Exinon on the active range: good(n) <=> b_left - 1 <= n < b_right
+    idx = np.nonzero(good)[0]
+    assert idx[0] == max(0, q["b_left"] - 1) and idx[-1] == q["b_right"] - 1
+    p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+               fx["phs5"], fx["phs3"], q["a_left"], q["a_right"], q["b_left"], q["b_right"],
+               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]))
+    return ps, p

@@ -1,0 +1,60 @@
+"""The aa x genome oracle (oracle/spdp_oracle_h.c, oracle/host_logic_h.py) against the reference's
+own outputs (tests/golden/h1_*.spdg, written by oracle/ref_build/ref_dump_h.cc)."""
+import numpy as np
+import pytest
+
+from tests import spdg
+from tests.conftest import golden_files
+from oracle import oracle, host_logic_h as hh
+
+H_FILES = golden_files("h1_")
+# the reference starts its traceback outside its bitmap on this one (out-of-bounds read)
+UNDEFINED = {"h1_cut_right", "h1_random"}
+
+
+def _name(f):
+    return f.split("/")[-1][:-5]
+
+
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_stripe31(path):
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx)
+    _, p = spdg.problem_h(fx)
+    w = oracle.stripe31(p, sc.sh)
+    assert [w.lw, w.up, w.width] == [int(x) for x in fx["wdw"]]
+    assert oracle.cells_h(p, w) > 0
+
+
+@pytest.mark.parametrize("tag", ["qn", "q1"])
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_forward_h1_wip(path, tag):
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx, nquant=None if tag == "qn" else 1)
+    _, p = spdg.problem_h(fx)
+    s, skl, flag = oracle.wip_forward_h(sc, p)
+    assert s == int(fx[f"wip_{tag}_fwd_scr"][0]) == int(fx[f"wip_{tag}_score"][0])
+    assert skl.ravel().tolist() == fx[f"wip_{tag}_fwd_skl"].tolist()
+    assert flag == (-3 if _name(path) in UNDEFINED else 0)
+
+
+@pytest.mark.parametrize("alg", [2, 3])
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_align_h(path, alg):
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx, nquant=None if alg == 2 else 1)
+    _, p = spdg.problem_h(fx)
+    assert hh.homscore_h(sc, p) == int(fx[f"hom_scr_A{alg}"][0])
+    if _name(path) in UNDEFINED:
+        with pytest.raises(hh.ReferenceUndefined):
+            hh.align_h(sc, p)
+        return
+    scr, skl = hh.align_h(sc, p)
+    assert scr == int(fx[f"aln_scr_A{alg}"][0])
+    assert (skl or []) == fx[f"aln_skl_A{alg}"].tolist()
+
+
+def test_exon_structure_agrees_with_exact_engine():
+    """on clean inputs the `_wip` model and the scalar exact model (-A0) find the same corners"""
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    assert fx["aln_skl_A2"].tolist() == fx["aln_skl_A0"].tolist()

@@ -217,7 +217,9 @@ int64_t spdp_cells_h(const SpdpProblemH* p, const SpdpWindow* wdw);
 
 /* forwardH1_wip(mfd): returned score (the reference returns its `nevsel` here unless a local
  * right end was tracked: fhlastH1 never sets maxh.val, fwd2h1_simd.h:692-785) + raw Mfile
- * records end -> start.  n_skl = -1 flags the reference's fatal "Unexpected dir". */
+ * records end -> start.  n_skl = -1 flags the reference's fatal "Unexpected dir"; n_skl = -2 says
+ * its traceback would start outside its bitmap (a winning genomic end gap moves the end cell
+ * beyond b_right, fwd2h1_simd.h:756-766, 780: an out-of-bounds read there, undefined result). */
 int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc,
                        const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 /* HomScoreH_ng for -A2/-A3: stripe31() then forwardH1_wip() */
@@ -228,6 +230,16 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
  * they are reported through the return value 1 and come back with n_skl = 0. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+
+/* resident batch (benchmarking / pipelines); one live batch of this kind per context */
+typedef struct SpdpBatchH SpdpBatchH;
+SpdpBatchH* spdp_batch_upload_h(SpdpContext* ctx, const SpdpScoringH* sc,
+                                const SpdpProblemH* probs, int n_probs);
+void        spdp_batch_free_h(SpdpBatchH* bt);
+int64_t     spdp_batch_cells_h(const SpdpBatchH* bt);
+/* one pass of alignH_ng over the resident batch; out may be NULL.  kernel_ms = HIP-event time of the
+ * DP sweep kernel on the stream it was launched on. */
+int spdp_batch_align_h(SpdpBatchH* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,33 @@
+// spdp_h_internal.h -- kernel argument blocks of the aa x genome path (spdp_h_kernels.hip / spdp_h_api.cpp)
+#ifndef SPDP_H_INTERNAL_H_
+#define SPDP_H_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spdp_h_dev.h"
+
+struct HSweepArgs {
+    const DevScoringH* sc;
+    const DevProblemH* probs;
+    int                n_probs;
+    const uint8_t*     a_codes;
+    const int4*        cols;
+    const short4*      aux;
+    int2*              bnd;
+    uint16_t*          tb;
+    DevResultH*        res;
+};
+
+struct HWalkArgs {
+    const DevProblemH* probs;
+    int                n_probs;
+    const uint16_t*    tb;
+    const DevResultH*  res;
+    int2*              skl;       // per problem: skl_cap records
+    int*               n_skl;     // records; -1 overflow, -2 "Unexpected dir", -3 start outside the bitmap
+    int                skl_cap;
+};
+
+extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, hipStream_t s);
+extern "C" hipError_t spdh_launch_walk(const HWalkArgs* a, hipStream_t s);
+#endif

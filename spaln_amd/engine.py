@@ -23,6 +23,8 @@ EXPORTS = [
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
     "spdp_align_s", "spdp_free_alignments", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
+    "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h",
+    "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
 ]
 
 
@@ -53,6 +55,15 @@ def load_library() -> C.CDLL:
     lib.spdp_wip_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_free_alignments.argtypes = [C.c_void_p, C.c_int]
+    lib.spdp_cells_h.restype = C.c_int64
+    for f in ("spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h"):
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_batch_upload_h.restype = C.c_void_p
+    lib.spdp_batch_upload_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.spdp_batch_free_h.argtypes = [C.c_void_p]
+    lib.spdp_batch_cells_h.restype = C.c_int64
+    lib.spdp_batch_cells_h.argtypes = [C.c_void_p]
+    lib.spdp_batch_align_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -137,6 +148,46 @@ class Engine:
                     "spdp_wip_udh")
         return scores, cpos, ranges
 
+    # ---- aa x genome (SimdAln2h1 `_wip`) ------------------------------------------------
+    def _alignments_h(self, fn, sc, ps, what):
+        """[(score, records, flag)]: flag 0 ok, -1 the reference's fatal "Unexpected dir", -2 its
+        traceback starts outside its bitmap, 1 the problem needs an engine that is not built."""
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        rc = fn(self.ctx, C.byref(sc), ps.array(), n, arr)
+        if rc not in (0, 1):
+            self._check(rc, what)
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(max(k, 0))],
+                           dtype=np.int32).reshape(-1, 2)
+            flag = k if k < 0 else (1 if (rc == 1 and arr[i].score == abi.NEVSEL and k == 0) else 0)
+            res.append((int(arr[i].score), skl, flag))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
+
+    def wip_forward_h(self, sc: abi.ScoringH, ps: abi.ProblemSetH):
+        """SimdAln2h1::forwardH1_wip(mfd) with the stripe31() band: raw records end -> start."""
+        return self._alignments_h(self.lib.spdp_wip_forward_h, sc, ps, "spdp_wip_forward_h")
+
+    def align_h(self, sc, ps):
+        """alignH_ng (-Q0): [flags, n, corners...] as rows of (m, n) after the header row."""
+        return self._alignments_h(self.lib.spdp_align_h, sc, ps, "spdp_align_h")
+
+    def homscore_h(self, sc, ps) -> np.ndarray:
+        out = np.zeros(len(ps), dtype=np.int32)
+        rc = self.lib.spdp_homscore_h(self.ctx, C.byref(sc), ps.array(), len(ps), out.ctypes.data)
+        if rc not in (0, 1):
+            self._check(rc, "spdp_homscore_h")
+        return out
+
+    def upload_h(self, sc, ps):
+        h = self.lib.spdp_batch_upload_h(self.ctx, C.byref(sc), ps.array(), len(ps))
+        if not h:
+            raise RuntimeError("spdp_batch_upload_h: " + self.lib.spdp_last_error(self.ctx).decode())
+        return BatchH(self, h, len(ps))
+
     # ---- resident batches ------------------------------------------------------------
     def upload(self, sc, ps):
         h = self.lib.spdp_batch_upload(self.ctx, C.byref(sc), ps.array(), len(ps))
@@ -187,4 +238,38 @@ class Batch:
     def free(self):
         if self.h:
             self.eng.lib.spdp_batch_free(self.h)
+            self.h = None
+
+
+class BatchH:
+    """resident aa x genome batch (one live batch of this kind per Engine)"""
+
+    def __init__(self, eng: Engine, handle, n: int):
+        self.eng, self.h, self.n = eng, handle, n
+
+    def cells(self) -> int:
+        return int(self.eng.lib.spdp_batch_cells_h(self.h))
+
+    def align(self, want: bool = True):
+        """alignH_ng over the resident batch.  Returns (alignments, sweep_kernel_ms, cells)."""
+        ms = C.c_float()
+        cells = C.c_int64()
+        arr = (abi.Alignment * self.n)() if want else None
+        rc = self.eng.lib.spdp_batch_align_h(self.h, arr, C.byref(ms), C.byref(cells))
+        if rc not in (0, 1):
+            self.eng._check(rc, "spdp_batch_align_h")
+        res = None
+        if want:
+            res = []
+            for i in range(self.n):
+                k = arr[i].n_skl
+                skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(max(k, 0))],
+                               dtype=np.int32).reshape(-1, 2)
+                res.append((int(arr[i].score), skl, min(k, 0)))
+            self.eng.lib.spdp_free_alignments(arr, self.n)
+        return res, ms.value, cells.value
+
+    def free(self):
+        if self.h:
+            self.eng.lib.spdp_batch_free_h(self.h)
             self.h = None

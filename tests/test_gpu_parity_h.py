@@ -1,0 +1,116 @@
+"""GPU parity of the aa x genome path (libspdp_hip.so through its C ABI) against the reference's
+goldens (tests/golden/h1_*.spdg) and, on seeded synthetic loci, against the oracle."""
+import numpy as np
+import pytest
+
+from tests import spdg
+from tests.conftest import golden_files
+from spaln_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+H_FILES = golden_files("h1_")
+UNDEFINED = {"h1_cut_right", "h1_random"}     # the reference starts its traceback outside its bitmap
+LOCAL = {"h1_local"}                          # -LS: not built on the GPU yet (rejected loudly)
+
+
+def _name(f):
+    return f.split("/")[-1][:-5]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from spaln_amd import engine
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def _cases(tag):
+    out = []
+    for f in H_FILES:
+        if _name(f) in LOCAL:
+            continue
+        fx = spdg.load(f)
+        out.append((_name(f), fx))
+    return out
+
+
+@pytest.mark.parametrize("tag", ["qn", "q1"])
+def test_forward_h1_wip_goldens(eng, tag):
+    """all fixtures in one batch per intron model: raw score + raw corner records"""
+    cases = _cases(tag)
+    sc = spdg.scoring_h(cases[0][1], nquant=None if tag == "qn" else 1)
+    ps = abi.ProblemSetH()
+    for _, fx in cases:
+        spdg.problem_h(fx, ps)
+    res = eng.wip_forward_h(sc, ps)
+    bad = []
+    for (name, fx), (score, skl, flag) in zip(cases, res):
+        ok = score == int(fx[f"wip_{tag}_fwd_scr"][0])
+        if name in UNDEFINED:
+            ok = ok and flag == -2
+        else:
+            ok = ok and flag == 0 and skl.ravel().tolist() == fx[f"wip_{tag}_fwd_skl"].tolist()
+        if not ok:
+            bad.append((name, score, flag, skl.ravel().tolist()[:12], fx[f"wip_{tag}_fwd_skl"].tolist()[:12]))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("alg", [2, 3])
+def test_align_h_goldens(eng, alg):
+    cases = _cases(alg)
+    sc = spdg.scoring_h(cases[0][1], nquant=None if alg == 2 else 1)
+    ps = abi.ProblemSetH()
+    for _, fx in cases:
+        spdg.problem_h(fx, ps)
+    res = eng.align_h(sc, ps)
+    hom = eng.homscore_h(sc, ps)
+    bad = []
+    for (name, fx), (score, skl, flag), hs in zip(cases, res, hom):
+        ok = score == int(fx[f"aln_scr_A{alg}"][0]) and int(hs) == int(fx[f"hom_scr_A{alg}"][0])
+        if name in UNDEFINED:
+            ok = ok and flag == -2
+        else:
+            ok = ok and flag == 0 and skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
+        if not ok:
+            bad.append((name, score, flag, skl.ravel().tolist()[:14], fx[f"aln_skl_A{alg}"].tolist()[:14]))
+    assert not bad, bad
+
+
+def test_local_mode_is_rejected_loudly(eng):
+    fx = spdg.load([f for f in H_FILES if _name(f) in LOCAL][0])
+    sc = spdg.scoring_h(fx)
+    ps, _ = spdg.problem_h(fx)
+    with pytest.raises(RuntimeError, match="local"):
+        eng.wip_forward_h(sc, ps)
+
+
+def test_loaded_gpu_against_oracle(eng):
+    """many waves per CU at once: goldens' signals re-used on windows cut at many offsets"""
+    from oracle import oracle
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    sc = spdg.scoring_h(fx)
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 77)
+    ps = abi.ProblemSetH()
+    for i in range(96):
+        al = int(rng.integers(0, 120))
+        ar = int(rng.integers(al + 40, q["a_right"] + 1))
+        bl = int(rng.integers(0, 900))
+        br = int(rng.integers(max(bl + 3 * (ar - al) // 2, bl + 300), q["b_right"] + 1))
+        exg = tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+               fx["phs5"], fx["phs3"], al, ar, bl, br, exg, exin=(q["b_left"], q["b_right"]))
+    res = eng.wip_forward_h(sc, ps)
+    bad = []
+    for i, (p, (score, skl, flag)) in enumerate(zip(ps.items, res)):
+        s, oskl, oflag = oracle.wip_forward_h(sc, p)
+        want_flag = {0: 0, -2: -1, -3: -2}[oflag]
+        ok = score == s and flag == want_flag
+        if oflag == 0:
+            ok = ok and skl.tolist() == oskl.tolist()
+        if not ok:
+            bad.append((i, (p.a_left, p.a_right, p.b_left, p.b_right), score, s, flag, oflag,
+                        skl.ravel().tolist()[:10], oskl.ravel().tolist()[:10]))
+    assert not bad, bad[:4]

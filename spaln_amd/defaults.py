@@ -58,3 +58,24 @@ def encode(seq_ascii: np.ndarray) -> np.ndarray:
         lut[k] = v
         lut[k + 32] = v
     return lut[np.asarray(seq_ascii, dtype=np.uint8)]
+
+
+# ---- aa x genome path (protein query vs genomic DNA): PwdB set-up for DvsP = 1 -------------------
+# values read back from a reference run (tests/golden/h1_*.spdg carry the same numbers); the
+# 23 x 26 amino-acid x tron matrix (Simmtx of mdm_mtx, PAM level 150) is data/aa_tron_mtx.npy
+H_GOP, H_GEP, H_LGEP = -90, -20, -6
+H_CODONK1 = 1610612733                      # effectively "never": GapExtPen3 = BasicGEP
+H_GAPW1, H_GAPW2, H_GAPW3 = -410, -430, -110
+H_IPEN = -401
+H_QM_PEN = [-367, -370, -413, -456, -557]
+
+
+def scoring_h(nquant=None, **over) -> abi.ScoringH:
+    import os
+    mtx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "aa_tron_mtx.npy"))
+    kw = dict(mtx=mtx.astype(np.int32), mtx_rows=mtx.shape[0], mtx_cols=mtx.shape[1], gop=H_GOP, gep=H_GEP,
+              lgep=H_LGEP, codonk1=H_CODONK1, gapw1=H_GAPW1, gapw2=H_GAPW2, gapw3=H_GAPW3, spj=1,
+              llmt=LLMT, ipen=H_IPEN, qm_len=QM_LEN, qm_pen=H_QM_PEN, nquant=nquant, local=0,
+              term_codon=1, sh=SH, max_vmf_space=MAX_VMF_SPACE, ubh=0)
+    kw.update(over)
+    return abi.make_scoring_h(**kw)

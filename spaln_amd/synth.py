@@ -220,3 +220,73 @@ def make_protein_gene(rng, n_exons: int = 4, aa_len: int = 400, flank: int = 500
     hit = rng.random(q.size) < sub
     q[hit] = _AA_LETTERS[rng.integers(0, 20, size=int(hit.sum()))]
     return ProteinGene(np.concatenate(parts), prot, q, exons)
+
+
+# ---- aa x genome inputs (synthetic stand-ins for Seq::nuc2tron + Exinon::intron53_p) ----------
+# tron / amino-acid alphabet of the reference (A = 3 ... V = 22, the AGY serines 23, TGA 24, TAA / TAG 25)
+_AA_CODE = {"A": 3, "R": 4, "N": 5, "D": 6, "C": 7, "Q": 8, "E": 9, "G": 10, "H": 11, "I": 12, "L": 13,
+            "K": 14, "M": 15, "F": 16, "P": 17, "S": 18, "T": 19, "W": 20, "Y": 21, "V": 22}
+
+
+def encode_protein(aa_ascii: np.ndarray) -> np.ndarray:
+    lut = np.zeros(256, dtype=np.uint8)
+    for k, v in _AA_CODE.items():
+        lut[ord(k)] = v
+    return lut[aa_ascii]
+
+
+def protein_signals(window: np.ndarray, rng) -> dict:
+    """Per-position inputs of the aa x genome DP for a genomic window (ASCII): tron codes
+    (b_len + 1 entries) and the SGPT6 fields, index 0 .. b_len + 2.  Position conventions follow
+    the reference's (a codon's fields sit at the 0-based index of its middle base; a GT donor at
+    the count of bases before it, an AG acceptor at the count of bases through it); the values are
+    synthetic: canonical GT / AG sites only, flat coding potential."""
+    s = window.tobytes().decode()
+    L = len(s)
+    N = L + 3
+    tron = np.zeros(L + 1, dtype=np.uint8)
+    sig5 = (-700 + rng.integers(-150, 150, size=N)).astype(np.int16)
+    sig3 = (-700 + rng.integers(-150, 150, size=N)).astype(np.int16)
+    sigS = np.full(N, -700, dtype=np.int16)
+    sigT = np.full(N, -1360, dtype=np.int16)
+    sigE = rng.integers(-8, 8, size=N).astype(np.int16)
+    phs5 = np.full(N, -2, dtype=np.int8)
+    phs3 = np.full(N, -2, dtype=np.int8)
+    for i in range(L - 2):
+        cod = s[i:i + 3]
+        aa = _CODON_AA[cod]
+        if aa == "*":
+            tron[i + 1] = 24 if cod == "TGA" else 25
+            sigT[i + 1] = 336
+            sigE[i + 1] = -475
+        elif aa == "S" and cod[0] == "A":
+            tron[i + 1] = 23
+        else:
+            tron[i + 1] = _AA_CODE[aa]
+        if cod == "ATG":
+            sigS[i + 1] = 650
+    for n in range(1, L - 1):
+        if s[n:n + 2] == "GT":
+            sig5[n] = int(rng.integers(-200, 120))
+            if phs5[n] == -2:
+                phs5[n] = 0
+                phs5[n + 1] = 1
+                phs5[n - 1] = 2 if phs5[n - 1] == 1 else -1
+        if n >= 2 and s[n - 2:n] == "AG":
+            sig3[n] = int(rng.integers(-200, 150))
+            if phs3[n] == -2:
+                phs3[n] = 0
+                phs3[n + 1] = 1
+                phs3[n - 1] = 2 if phs3[n - 1] == 1 else -1
+    return dict(b=tron, sig5=sig5, sig3=sig3, sigS=sigS, sigT=sigT, sigE=sigE, phs5=phs5, phs3=phs3)
+
+
+def make_protein_batch(n: int, seed: int = SEED, aa_len: int = 400, n_exons: int = 6, flank: int = 1000,
+                       intron_hi: int = 5000, sub: float = 0.10):
+    """C3-style work: `n` (window, protein) pairs, each a planted `aa_len`-codon ORF +- `flank` nt."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        g = make_protein_gene(rng, n_exons=n_exons, aa_len=aa_len, flank=flank, sub=sub, intron_hi=intron_hi)
+        out.append((g, protein_signals(g.window, rng)))
+    return out

@@ -241,44 +241,55 @@ def protein_signals(window: np.ndarray, rng) -> dict:
     the reference's (a codon's fields sit at the 0-based index of its middle base; a GT donor at
     the count of bases before it, an AG acceptor at the count of bases through it); the values are
     synthetic: canonical GT / AG sites only, flat coding potential."""
-    s = window.tobytes().decode()
-    L = len(s)
+    w = np.asarray(window, dtype=np.uint8)
+    L = w.size
     N = L + 3
+    base = np.zeros(256, dtype=np.int64)
+    for i, c in enumerate(b"TCAG"):
+        base[c] = i
+    idx = base[w]
+    cod = 16 * idx[:-2] + 4 * idx[1:-1] + idx[2:]                 # codon starting at i, order TCAG
+    tl = np.zeros(64, dtype=np.uint8)
+    bases = "TCAG"
+    for c in range(64):
+        s3 = bases[c >> 4] + bases[(c >> 2) & 3] + bases[c & 3]
+        aa = _CODON_AA[s3]
+        tl[c] = (24 if s3 == "TGA" else 25) if aa == "*" else (23 if (aa == "S" and s3[0] == "A") else _AA_CODE[aa])
     tron = np.zeros(L + 1, dtype=np.uint8)
+    tron[1:L - 1] = tl[cod]
     sig5 = (-700 + rng.integers(-150, 150, size=N)).astype(np.int16)
     sig3 = (-700 + rng.integers(-150, 150, size=N)).astype(np.int16)
     sigS = np.full(N, -700, dtype=np.int16)
     sigT = np.full(N, -1360, dtype=np.int16)
     sigE = rng.integers(-8, 8, size=N).astype(np.int16)
-    phs5 = np.full(N, -2, dtype=np.int8)
-    phs3 = np.full(N, -2, dtype=np.int8)
-    for i in range(L - 2):
-        cod = s[i:i + 3]
-        aa = _CODON_AA[cod]
-        if aa == "*":
-            tron[i + 1] = 24 if cod == "TGA" else 25
-            sigT[i + 1] = 336
-            sigE[i + 1] = -475
-        elif aa == "S" and cod[0] == "A":
-            tron[i + 1] = 23
-        else:
-            tron[i + 1] = _AA_CODE[aa]
-        if cod == "ATG":
-            sigS[i + 1] = 650
-    for n in range(1, L - 1):
-        if s[n:n + 2] == "GT":
-            sig5[n] = int(rng.integers(-200, 120))
-            if phs5[n] == -2:
-                phs5[n] = 0
-                phs5[n + 1] = 1
-                phs5[n - 1] = 2 if phs5[n - 1] == 1 else -1
-        if n >= 2 and s[n - 2:n] == "AG":
-            sig3[n] = int(rng.integers(-200, 150))
-            if phs3[n] == -2:
-                phs3[n] = 0
-                phs3[n + 1] = 1
-                phs3[n - 1] = 2 if phs3[n - 1] == 1 else -1
-    return dict(b=tron, sig5=sig5, sig3=sig3, sigS=sigS, sigT=sigT, sigE=sigE, phs5=phs5, phs3=phs3)
+    stop = np.zeros(N, dtype=bool)
+    stop[1:L - 1] = tron[1:L - 1] >= 24
+    sigT[stop] = 336
+    sigE[stop] = -475
+    atg = np.zeros(N, dtype=bool)
+    atg[1:L - 1] = cod == (16 * 2 + 4 * 0 + 3)
+    sigS[atg] = 650
+    gt = np.zeros(N, dtype=bool)
+    ag = np.zeros(N, dtype=bool)
+    gt[1:L - 1] = (w[1:L - 1] == ord("G")) & (w[2:L] == ord("T"))
+    ag[2:L - 1] = (w[0:L - 3] == ord("A")) & (w[1:L - 2] == ord("G"))
+    nd, na = int(gt.sum()), int(ag.sum())
+    sig5[gt] = rng.integers(-200, 120, size=nd).astype(np.int16)
+    sig3[ag] = rng.integers(-200, 150, size=na).astype(np.int16)
+
+    def phases(site):
+        # the reference's left-to-right rule (src/codepot.cc:599-606) for canonical sites: a site at n
+        # sets phs[n] = 0 (unless already set), phs[n+1] = 1, phs[n-1] = 2 if that was 1 else -1.
+        # canonical dinucleotides cannot sit at adjacent positions, so the rule has a closed form
+        ph = np.full(N, -2, dtype=np.int8)
+        pos = np.nonzero(site)[0]
+        ph[pos + 1] = 1
+        prev1 = ph[pos - 1] == 1
+        ph[pos - 1] = np.where(prev1, 2, -1).astype(np.int8)
+        ph[pos] = 0
+        return ph
+
+    return dict(b=tron, sig5=sig5, sig3=sig3, sigS=sigS, sigT=sigT, sigE=sigE, phs5=phases(gt), phs3=phases(ag))
 
 
 def make_protein_batch(n: int, seed: int = SEED, aa_len: int = 400, n_exons: int = 6, flank: int = 1000,

@@ -142,13 +142,23 @@ static int batch_build(SpdpBatchH* bt, SpdpContext* ctx, const SpdpScoringH* sc,
     std::vector<short4> aux;
     int64_t bnd_ent = 0, tb_el = 0;
     bt->h_probs.clear(); bt->run_idx.clear(); bt->cells = 0;
+    // dispatch order: largest problems first (the hardware hands blocks out in index order, so the
+    // long ones start early and the short ones fill the tail)
+    std::vector<std::pair<int64_t, int>> todo;
     for (int i = 0; i < n; ++i) {
         const SpdpProblemH& p = probs[i];
         if (validate(ctx, sc, &p, i)) return -1;
         SpdpWindow w;
         stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sc->sh, &w);
         bt->cls[i] = classify(sc, &p, w, ladder);
-        if (bt->cls[i]) continue;
+        if (!bt->cls[i]) todo.emplace_back(-spdp_cells_h(&p, &w), i);
+    }
+    std::stable_sort(todo.begin(), todo.end());
+    for (const auto& td : todo) {
+        const int i = td.second;
+        const SpdpProblemH& p = probs[i];
+        SpdpWindow w;
+        stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sc->sh, &w);
         DevProblemH d;
         memset(&d, 0, sizeof d);
         d.a_left = p.a_left; d.a_right = p.a_right; d.b_left = p.b_left; d.b_right = p.b_right;
@@ -248,7 +258,8 @@ static int batch_run(SpdpBatchH* bt, bool walk, std::vector<DevResultH>& res, st
     A.a_codes = (const uint8_t*) bt->d_a; A.cols = (const int4*) bt->d_cols; A.aux = (const short4*) bt->d_aux;
     A.bnd = (int2*) bt->d_bnd; A.tb = (uint16_t*) bt->d_tb; A.res = (DevResultH*) bt->d_res;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(spdh_launch_sweep(&A, ctx->stream));
+    const int pen_cap = bt->sc.nquant > 1 ? bt->sc.qm_len[bt->sc.nquant - 2] + 1 : 0;
+    HIPCHK(spdh_launch_sweep(&A, bt->sc.spj, pen_cap, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (walk) {
         HWalkArgs W;

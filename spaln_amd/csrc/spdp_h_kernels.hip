@@ -58,15 +58,21 @@ __device__ __forceinline__ unsigned ld_nt_u16(const uint16_t* p) { return __buil
 #define SPDH_PEN_TAB 2048
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
+// SPJ: splice-aware (b->inex.intr); TAB: the intron-length penalty steps fit the LDS table
+template <bool SPJ, bool TAB>
+__global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
 {
     __shared__ int   s_mtx[32 * 32];
     __shared__ short s_pen[SPDH_PEN_TAB];
+    __shared__ int   s_qlen[8], s_qpen[8];
     __shared__ int4  s_ring[4][4][64];
     __shared__ int2  s_feed[4][4][16];
 
     const DevScoringH* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
+    if (threadIdx.x < 8) { s_qlen[threadIdx.x] = sc->qm_len[threadIdx.x]; s_qpen[threadIdx.x] = sc->qm_pen[threadIdx.x]; }
     const int nquant = sc->nquant;
     const int pen_cap = (nquant > 1) ? min(sc->qm_len[nquant - 2] + 1, SPDH_PEN_TAB - 1) : 0;
     // pen(hil) = qm_pen[j] for the last j with hil > qm_len[j-1]  (fwd2h1_wip_simd.h:229-233)
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
     const int m_width = P.m_width, n_width = P.n_width;
     const s16 ge = (s16) sc->gep, g1 = (s16) sc->g1, g2 = (s16) sc->g2, g3 = (s16) sc->g3;
     const int gop = sc->gop, gep = sc->gep;
-    const int spj = sc->spj, llmt = sc->llmt;
+    const int llmt = sc->llmt;
     int2* __restrict__ bnd = A.bnd + P.bnd_off;
     const int4* __restrict__ cols = A.cols + P.col_off;
     const short4* __restrict__ aux = A.aux + P.col_off;
@@ -193,11 +199,10 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
     const int n_stripes = (a_right - a_left + SPDH_NELEM - 1) / SPDH_NELEM;
     int4* const ring = &s_ring[wv][g][0];
     int2* const feed = &s_feed[wv][g][0];
-    const bool use_tab = (nquant <= 1) || (sc->qm_len[nquant - 2] + 1 < SPDH_PEN_TAB);
     auto pen_of = [&](int hil) -> s16 {
-        if (use_tab) return (s16) s_pen[min(hil, pen_cap)];
-        int pv = sc->qm_pen[0];
-        for (int jq = 1; jq < nquant; ++jq) pv = (hil > sc->qm_len[jq - 1]) ? sc->qm_pen[jq] : pv;
+        if constexpr (TAB) return (s16) s_pen[min(hil, pen_cap)];
+        int pv = s_qpen[0];
+        for (int jq = 1; jq < nquant; ++jq) pv = (hil > s_qlen[jq - 1]) ? s_qpen[jq] : pv;
         return (s16) pv;
     };
 
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
         auto load_col = [&](int c) -> int4 {
             int4 rec = make_int4(0, 0, 0, 0);
             if (c >= 0 && c < col_len) rec = cols[c];
-            if (c >= b_right || !spj) rec.x &= 0x00ffffff;                  // nothing splices at n >= b_right
+            if (c >= b_right) rec.x &= 0x00ffffff;                          // nothing splices at n >= b_right
             if (c < b_left + 3 || c > b_right + 2) rec.x = (rec.x & (int) 0xff00ffffu) | (SPDH_ZCODE << 16);
             return rec;
         };
@@ -249,6 +254,8 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
             nx_b = ld_nt2(bnd + e);
             nx_c = load_col(nn);
         };
+        auto run_pass = [&](auto partial_tag) __attribute__((always_inline)) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
         if (g == 0 && nb > 0) prefetch(0);
         for (int blk = 0; blk < tot; ++blk) {
             const int lb = blk - SPDH_LAG * g;                       // my local block number
@@ -325,12 +332,16 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
                     h = m ? ee : h;
                     pb = m ? eb : pb;
                     bool ab = false;
-                    if (spj) {
+                    if constexpr (SPJ) {
                         // ---- intron 3' boundary: candidate 0 (phase -1 / 0 / +1), candidate 1 (phase +1)
                         const unsigned c0 = fl & 3u;
                         const s16 s3_0 = (s16) rec.y, s3_1 = (s16) (rec.y >> 16);
-                        const s16 shiv = (c0 == 1u) ? hiv0 : ((c0 == 2u) ? hiv1 : hiv2);
-                        const int shil = (c0 == 1u) ? hil0 : ((c0 == 2u) ? hil1 : hil2);
+                        // (selects on copies: a ?: on the captured variables themselves would select
+                        //  between their addresses and pin all of them to memory)
+                        const s16 cv0 = hiv0, cv1 = hiv1, cv2 = hiv2;
+                        const int cl0 = hil0, cl1 = hil1, cl2 = hil2;
+                        const s16 shiv = (c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2);
+                        const int shil = (c0 == 1u) ? cl0 : ((c0 == 2u) ? cl1 : cl2);
                         s16 x = sadd(sadd(shiv, s3_0), pen_of(shil));
                         m = (c0 != 0u) && (shil > llmt) && (x > h);
                         h = m ? x : h;
@@ -355,7 +366,9 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
                         hiv2 = m ? pvD : hiv2; hil2 = m ? 0 : hil2; hb |= m ? C_DONP : 0;
                         m = (fl & 32u) && (pvD1 > hiv2);
                         hiv2 = m ? pvD1 : hiv2; hil2 = m ? 0 : hil2; hb |= m ? C_DONP : 0;
-                        hil0 = min(hil0 + 1, 32767); hil1 = min(hil1 + 1, 32767); hil2 = min(hil2 + 1, 32767);
+                        // (the reference's int16 counters saturate at 32767; every threshold they are
+                        //  compared with is far below, so plain increments decide identically)
+                        ++hil0; ++hil1; ++hil2;
                     }
                     // ---- rotate the histories
                     h3 = h2; h2 = h1; h1 = h;
@@ -367,12 +380,16 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
                     tb_off += m_width;
                     // ---- bottom lane of the stripe -> output shift chain
                     int bh = (int) h, bf = (int) ff;
-                    if (partial && j9 > 0) {
-                        const int src = (lane & 48) + j8;
-                        bh = __shfl(bh, src); bf = __shfl(bf, src);
+                    if constexpr (PARTIAL) {
+                        if (partial && j9 > 0) {
+                            const int src = (lane & 48) + j8;
+                            bh = __shfl(bh, src); bf = __shfl(bf, src);
+                        }
                     }
                     outH = row_shr1(row_ror1(bh), outH);
                     outF = row_shr1(row_ror1(bf), outF);
+                    // keep the unrolled steps apart: interleaving them only inflates register pressure
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- flush: lane i holds the bottom-row result of step j = 15 - i; it becomes the
                 // boundary entry of its diagonal under the reference's condition (:301-305)
@@ -390,6 +407,10 @@ __global__ __launch_bounds__(256) void spdh_sweep(HSweepArgs A)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        };
+        // only the last stripe of a problem can be partial (fewer than 16 rows)
+        if ((s0 + 4 >= n_stripes) && ((a_right - a_left) & 15)) run_pass(BoolTag<true>{});
+        else run_pass(BoolTag<false>{});
     }
 
     // =====================================================================================
@@ -578,10 +599,15 @@ __global__ void spdh_walk(HWalkArgs A)
     if (writer && status == -3) A.n_skl[pi] = -3;
 }
 
-extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, hipStream_t stream)
+extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, hipStream_t stream)
 {
     HSweepArgs A = *a;
-    hipLaunchKernelGGL(spdh_sweep, dim3((A.n_probs + 3) / 4), dim3(256), 0, stream, A);
+    const dim3 grd((A.n_probs + 3) / 4), blk(256);
+    const bool tab = pen_cap < SPDH_PEN_TAB;
+    if (spj) {
+        if (tab) hipLaunchKernelGGL((spdh_sweep<true, true>), grd, blk, 0, stream, A);
+        else     hipLaunchKernelGGL((spdh_sweep<true, false>), grd, blk, 0, stream, A);
+    } else       hipLaunchKernelGGL((spdh_sweep<false, true>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }
 extern "C" hipError_t spdh_launch_walk(const HWalkArgs* a, hipStream_t stream)

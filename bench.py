@@ -169,12 +169,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path)")
-    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000 for c2, 2000 for c3)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = 2 per host core)")
     ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
     args = ap.parse_args()
     if not args.queries:
-        args.queries = 10000 if args.workload == "c2" else 2000
+        args.queries = 10000
     if args.workload == "c3":
         return main_c3(args)
 

@@ -29,6 +29,8 @@ BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64
 HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
 PMC_TRAFFIC_BYTES = int((81013809 + 193130163) * 1024)
+# same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
+PMC_TRAFFIC_BYTES_H = int((39397482 + 147294407) * 1024)
 
 
 def _cpu_align_one(item):
@@ -149,7 +151,9 @@ def main_c3(args):
                        "queries_per_s": round(args.queries * world * args.steps / dt, 1),
                        "sweep_ms": round(k_ms, 3), "sweep_gcups": round(cells / k_ms / 1e6, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1) else None,
+                         "traffic_source": "profiles/r01_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
                          "note": "integer-VALU bound recurrence (int16 saturating lanes); HBM fraction reported as asked"},
             "cpu_baseline": {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "port",

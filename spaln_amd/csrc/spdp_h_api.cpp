@@ -92,7 +92,6 @@ static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
         ctx->err = buf;
         return -1;
     };
-    if (sc->local) return fail("local mode (algmode.lcl & 16) is not built for this path yet");
     if (sc->mtx_rows <= 0 || sc->mtx_rows > 31 || sc->mtx_cols <= 0 || sc->mtx_cols > 31) return fail("matrix larger than 31 x 31");
     if (sc->nquant < 1 || sc->nquant > SPDP_MAX_QUANT) return fail("bad nquant");
     if (!p->a || !p->b || !p->sig5 || !p->sig3 || !p->sigS || !p->sigT || !p->sigE || !p->phs5 || !p->phs3)
@@ -259,7 +258,7 @@ static int batch_run(SpdpBatchH* bt, bool walk, std::vector<DevResultH>& res, st
     A.bnd = (int2*) bt->d_bnd; A.tb = (uint16_t*) bt->d_tb; A.res = (DevResultH*) bt->d_res;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int pen_cap = bt->sc.nquant > 1 ? bt->sc.qm_len[bt->sc.nquant - 2] + 1 : 0;
-    HIPCHK(spdh_launch_sweep(&A, bt->sc.spj, pen_cap, ctx->stream));
+    HIPCHK(spdh_launch_sweep(&A, bt->sc.spj, pen_cap, bt->sc.local, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (walk) {
         HWalkArgs W;

@@ -28,6 +28,6 @@ struct HWalkArgs {
     int                skl_cap;
 };
 
-extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, hipStream_t s);
+extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t s);
 extern "C" hipError_t spdh_launch_walk(const HWalkArgs* a, hipStream_t s);
 #endif

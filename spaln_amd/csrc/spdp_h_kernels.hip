@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned ld_nt_u16(const uint16_t* p) { return __buil
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // SPJ: splice-aware (b->inex.intr); TAB: the intron-length penalty steps fit the LDS table
-template <bool SPJ, bool TAB>
+template <bool SPJ, bool TAB, bool LOCAL>
 __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
 {
     __shared__ int   s_mtx[32 * 32];
@@ -197,6 +197,11 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
     // the sweep (src/fwd2h1_wip_simd.h:101-331)
     // =====================================================================================
     const int n_stripes = (a_right - a_left + SPDH_NELEM - 1) / SPDH_NELEM;
+    const bool LocalL = LOCAL && a_exgl && b_exgl;
+    const bool LocalR = LOCAL && a_exgr && b_exgr;
+    // running maximum for local right ends: value, then the first (stripe, step, lane) holding it
+    int best_val = SPDH_NEV, best_mr = a_right, best_nr = b_right;
+    unsigned long long best_key = ~0ull;
     int4* const ring = &s_ring[wv][g][0];
     int2* const feed = &s_feed[wv][g][0];
     auto pen_of = [&](int hil) -> s16 {
@@ -352,6 +357,19 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                         h = m ? x : h;
                         pb = m ? C_ACCP : pb;
                         ab = ab || m;
+                    }
+                    if constexpr (LOCAL) {
+                        // local left end (:243-247; accscr stays 0 without re-basing), right end (:250-258)
+                        if (LocalL && h < 0) { h = 0; hb = 0; }
+                        if (LocalR && k < j9 && n <= n9 && (int) h >= best_val) {
+                            const unsigned long long key =
+                                ((unsigned long long) s << 40) | ((unsigned long long) (n - n_start) << 8) | (unsigned) k;
+                            if ((int) h > best_val || key < best_key) {
+                                best_val = h; best_key = key; best_mr = ml + k + 1; best_nr = n - 3 * k;
+                            }
+                        }
+                    }
+                    if constexpr (SPJ) {
                         // ---- intron 5' boundary
                         const unsigned d0 = (fl >> 3) & 3u;
                         const s16 s5_0 = (s16) rec.z, s5_1 = (s16) (rec.z >> 16);
@@ -419,7 +437,23 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
     DevResultH R;
     R.score = SPDH_NEV; R.mr = a_right; R.nr = b_right; R.maxt = 0; R.maxr = 0;
     R.pad[0] = R.pad[1] = R.pad[2] = 0;
-    {
+    bool run_last = true;
+    if constexpr (LOCAL) {
+        if (LocalR) {
+            // reduce (value desc, key asc) over the wave
+            for (int off = 32; off; off >>= 1) {
+                const int ov = __shfl_xor(best_val, off);
+                const unsigned long long ok = __shfl_xor(best_key, off);
+                const int omr = __shfl_xor(best_mr, off), onr = __shfl_xor(best_nr, off);
+                if (ov > best_val || (ov == best_val && ok < best_key)) {
+                    best_val = ov; best_key = ok; best_mr = omr; best_nr = onr;
+                }
+            }
+            R.score = best_val; R.mr = best_mr; R.nr = best_nr;
+            run_last = best_mr == a_right;             // `if (!LocalR || maxh.mr == a->right)`, :330
+        }
+    }
+    if (run_last) {
         const int m3 = 3 * a_right;
         const int rw = max(lw, b_left - m3);
         const int rr = b_right - m3;
@@ -433,12 +467,13 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
             for (int i0 = 0; rw + i0 <= rr; i0 += 64) {
                 const int hj = rw + i0 + lane;
                 const int bb = hj + m3;                     // genomic position of the cell
-                int vH = 0, vE = 0, vT = 0, vC = 0;
+                int vH = 0, vE = 0, vT = 0, vC = 0, v5 = 0;
                 const bool in = hj <= rr;
                 const int64_t cidx = rowbase + (int64_t) (bb - b_left) * m_width;
                 if (in) {
                     vH = (s16) ld_nt1(&bnd[BIDX(hj)].x);
                     if (bb - 2 >= 0) { const short4 ax = aux[bb - 2]; vE = ax.z; vT = ax.y; }
+                    if constexpr (LOCAL) v5 = aux[bb].w;
                     vC = ld_nt_u16(&tb[cidx]);
                 }
                 int mycode = vC; bool changed = false;
@@ -457,10 +492,13 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                         if (sc->term_codon) cand2 = hq3 + sT;
                     }
                     if (i >= 3) tc0 = tc0 || sT > 0;
-                    int kk = 0, best = cand0;
+                    int s5l = 0;
+                    if constexpr (LOCAL) { s5l = __builtin_amdgcn_readlane(v5, j); s5l = s5l > 0 ? s5l : 0; }
+                    int kk = 0, best = cand0 + s5l;
+                    cand1 += s5l;
                     if (cand1 > best) { kk = 1; best = cand1; }
                     if (cand2 > best) { kk = 2; best = cand2; }
-                    const int newh = (kk == 0) ? cand0 : (int) (s16) best;
+                    const int newh = (kk == 0) ? cand0 : (int) (s16) (kk == 1 ? best - s5l : best);
                     if (kk == 0) { gl0 = 0; tc0 = false; }
                     if (hd == mx) mxval = newh;
                     else if (newh > mxval) { mx = hd; mxval = newh; maxr = hd - (kk == 2 ? 3 : 0); }
@@ -599,15 +637,20 @@ __global__ void spdh_walk(HWalkArgs A)
     if (writer && status == -3) A.n_skl[pi] = -3;
 }
 
-extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, hipStream_t stream)
+extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t stream)
 {
     HSweepArgs A = *a;
     const dim3 grd((A.n_probs + 3) / 4), blk(256);
     const bool tab = pen_cap < SPDH_PEN_TAB;
-    if (spj) {
-        if (tab) hipLaunchKernelGGL((spdh_sweep<true, true>), grd, blk, 0, stream, A);
-        else     hipLaunchKernelGGL((spdh_sweep<true, false>), grd, blk, 0, stream, A);
-    } else       hipLaunchKernelGGL((spdh_sweep<false, true>), grd, blk, 0, stream, A);
+    if (local) {
+        if (!spj)     hipLaunchKernelGGL((spdh_sweep<false, true, true>), grd, blk, 0, stream, A);
+        else if (tab) hipLaunchKernelGGL((spdh_sweep<true, true, true>), grd, blk, 0, stream, A);
+        else          hipLaunchKernelGGL((spdh_sweep<true, false, true>), grd, blk, 0, stream, A);
+    } else {
+        if (!spj)     hipLaunchKernelGGL((spdh_sweep<false, true, false>), grd, blk, 0, stream, A);
+        else if (tab) hipLaunchKernelGGL((spdh_sweep<true, true, false>), grd, blk, 0, stream, A);
+        else          hipLaunchKernelGGL((spdh_sweep<true, false, false>), grd, blk, 0, stream, A);
+    }
     return hipGetLastError();
 }
 extern "C" hipError_t spdh_launch_walk(const HWalkArgs* a, hipStream_t stream)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 H_FILES = golden_files("h1_")
 UNDEFINED = {"h1_cut_right", "h1_random"}     # the reference starts its traceback outside its bitmap
-LOCAL = {"h1_local"}                          # -LS: not built on the GPU yet (rejected loudly)
+LOCAL = {"h1_local"}                          # -LS: its own kernel variant, run separately
 
 
 def _name(f):
@@ -78,12 +78,48 @@ def test_align_h_goldens(eng, alg):
     assert not bad, bad
 
 
-def test_local_mode_is_rejected_loudly(eng):
+@pytest.mark.parametrize("tag", ["qn", "q1"])
+def test_local_mode_golden(eng, tag):
     fx = spdg.load([f for f in H_FILES if _name(f) in LOCAL][0])
-    sc = spdg.scoring_h(fx)
+    sc = spdg.scoring_h(fx, nquant=None if tag == "qn" else 1)
     ps, _ = spdg.problem_h(fx)
-    with pytest.raises(RuntimeError, match="local"):
-        eng.wip_forward_h(sc, ps)
+    (score, skl, flag), = eng.wip_forward_h(sc, ps)
+    assert flag == 0 and score == int(fx[f"wip_{tag}_fwd_scr"][0])
+    assert skl.ravel().tolist() == fx[f"wip_{tag}_fwd_skl"].tolist()
+    alg = 2 if tag == "qn" else 3
+    (score, skl, flag), = eng.align_h(sc, ps)
+    assert flag == 0 and score == int(fx[f"aln_scr_A{alg}"][0])
+    assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
+    assert int(eng.homscore_h(sc, ps)[0]) == int(fx[f"hom_scr_A{alg}"][0])
+
+
+def test_local_mode_against_oracle(eng):
+    """local ends on sub-ranges (LocalL / LocalR only hold when both sequences are free on that side)"""
+    from oracle import oracle
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    sc = spdg.scoring_h(fx, local=1)
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 78)
+    ps = abi.ProblemSetH()
+    for i in range(48):
+        al = int(rng.integers(0, 150))
+        ar = int(rng.integers(al + 30, q["a_right"] + 1))
+        bl = int(rng.integers(0, 1200))
+        br = int(rng.integers(max(bl + 3 * (ar - al) // 2, bl + 300), q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 3 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+               fx["phs5"], fx["phs3"], al, ar, bl, br, exg, exin=(q["b_left"], q["b_right"]))
+    res = eng.wip_forward_h(sc, ps)
+    bad = []
+    for i, (p, (score, skl, flag)) in enumerate(zip(ps.items, res)):
+        s, oskl, oflag = oracle.wip_forward_h(sc, p)
+        ok = score == s and flag == {0: 0, -2: -1, -3: -2}[oflag]
+        if oflag == 0:
+            ok = ok and skl.tolist() == oskl.tolist()
+        if not ok:
+            bad.append((i, (p.a_left, p.a_right, p.b_left, p.b_right), score, s, flag, oflag,
+                        skl.ravel().tolist()[:10], oskl.ravel().tolist()[:10]))
+    assert not bad, bad[:4]
 
 
 def test_loaded_gpu_against_oracle(eng):

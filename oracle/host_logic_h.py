@@ -3,11 +3,15 @@ TEST INFRASTRUCTURE ONLY (see oracle/spdp_oracle.c header).
 
   HomScoreH_ng (-A2/-A3)        src/fwd2h1.cc:3288-3308
   alignH_ng / globalH_ng (-Q0)  src/fwd2h1.cc:3310-3316, 3267-3286
-  lspH_ng                       src/fwd2h1.cc:2140-2231   (traceback branch; UDH not restated)
+  lspH_ng                       src/fwd2h1.cc:2140-2231
   trcbkalignH_ng                src/fwd2h1.cc:1997-2041   (m >= 8: forwardH1_wip)
+  mimd_postwork / rcsv_postwork src/fwd2h1.cc:2045-2138
   stdskl3                       src/gaps.cc:178-227       (UNITE_INDEL_FS = 0)
 """
 from __future__ import annotations
+
+import ctypes as C
+import math
 
 import numpy as np
 
@@ -16,6 +20,20 @@ from . import oracle
 
 NELEM = 16
 COEF_B = 2.0                     # sizeof(short), fwd2h1.cc:60
+COEF_C = 12.0                    # (Noll + 1) * sizeof(int), fwd2h1.cc:119
+END = abi.END_OF_ULK
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+def _sub(p: abi.ProblemH, al, ar, bl, br, flags) -> abi.ProblemH:
+    q = abi.ProblemH()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(abi.ProblemH))
+    q.a_left, q.a_right, q.b_left, q.b_right = al, ar, bl, br
+    q.a_exgl, q.a_exgr, q.b_exgl, q.b_exgr = flags
+    return q
 
 
 class NotRestated(Exception):
@@ -62,10 +80,79 @@ def lsp_h(sc, p, w, rec):
         raise NotRestated("diagonalH_ng")
     if abs(n - m) < NELEM or m == 1 or n <= 3:
         return trcbk_h(sc, p, w, rec)
-    cvol = float(np.float32(m) * np.float32(n + 3 * m))
-    if COEF_B * cvol < sc.max_vmf_space:
+    cvol = _f32(_f32(m) * _f32(n + 3 * m))
+    if _f32(COEF_B * cvol) < sc.max_vmf_space:
         return trcbk_h(sc, p, w, rec)
-    raise NotRestated("hirschbergH1_wip")
+    recursive = False
+    n_imd = 1
+    z = 2.0 * m * COEF_B / COEF_C
+    imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
+    spc = _f32(_f32(_f32(COEF_C * n) * imd1) + _f32(_f32(_f32(COEF_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
+    if spc > sc.max_vmf_space:
+        recursive = True
+    else:
+        imd3 = m // NELEM
+        n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
+        intvl = (m + n_imd) // (n_imd + 1)
+        if intvl * n_imd == m:
+            n_imd -= 1
+        if n_imd == 0:
+            return trcbk_h(sc, p, w, rec)
+    scr, cpos, rng = oracle.wip_udh_h(sc, p, n_imd, w)
+    if scr > abi.NEVSEL:
+        cur = _sub(p, int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]),
+                   (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr))
+        if cpos[0][0] == END:
+            rec.append((cur.a_left, cur.b_left))
+            rec.append((cur.a_right, cur.b_right))
+        elif recursive:
+            rcsv_h(sc, cur, cpos, rec)
+        else:
+            mimd_h(sc, cur, cpos, n_imd, rec)
+    return scr
+
+
+def mimd_h(sc, cur, cpos, n_imd, rec):
+    aleft, bleft = cur.a_left, cur.b_left
+    cur = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
+    i = n_imd - 1
+    while i >= 0 and cpos[i][0] == END:
+        i -= 1
+    while i >= 0 and cpos[i][0] != END:
+        cur.a_left = int(cpos[i][0])
+        cur.b_exgl = int(cpos[i][1])
+        cur.b_left = int(cpos[i][2])
+        if cur.a_right > cur.a_len or cur.b_right > cur.b_len or cur.a_left < 0 or cur.b_left < 0:
+            return
+        if cur.b_left < 0 or cur.b_left > cur.b_right:
+            break
+        c = 3
+        while c < 10 and cpos[i][c] < END:
+            rec.append((cur.a_left, int(cpos[i][c])))
+            c += 1
+        trcbk_h(sc, cur, oracle.stripe31(cur, sc.sh), rec)
+        cur.a_right = cur.a_left
+        cur.b_right = int(cpos[i][c - 1])
+        i -= 1
+    if (i < 0 and cpos[0][0] != END) or cpos[0][2] != END:
+        cur.a_left, cur.b_left = aleft, bleft
+        trcbk_h(sc, cur, oracle.stripe31(cur, sc.sh), rec)
+
+
+def rcsv_h(sc, cur, cpos, rec):
+    base = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
+    row = cpos[0]
+    if row[0] < END:
+        c = 2
+        while c < 10 and row[c] < END:
+            rec.append((int(row[0]), int(row[c])))
+            c += 1
+        first = _sub(base, base.a_left, int(row[0]), base.b_left, int(row[c - 1]), (0, 0, 0, 0))
+        lsp_h(sc, first, oracle.stripe31(first, sc.sh), rec)
+        second = _sub(base, int(row[0]), base.a_right, int(row[2]), base.b_right, (0, 0, int(row[1]), 0))
+        lsp_h(sc, second, oracle.stripe31(second, sc.sh), rec)
+    elif sc.local:
+        trcbk_h(sc, base, oracle.stripe31(base, sc.sh), rec)
 
 
 def std_skl3(rec):

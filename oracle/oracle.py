@@ -130,3 +130,16 @@ def wip_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None):
     out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
     C.CDLL(None).free(skl)
     return s.value, out, rc
+
+
+def wip_udh_h(sc, p, n_im: int, w=None):
+    """SimdAln2h1::hirschbergH1_wip: (score, cpos rows, written-back ranges)"""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.full((n_im + 1, 10), abi.END_OF_ULK, dtype=np.int32)
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_wip_udh_h(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.byref(s),
+                             cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"orc_wip_udh_h rc={rc}")
+    return s.value, cpos, rng

@@ -107,44 +107,50 @@ def protein_cases():
     """aa x genome (Fwd2h1 `_wip`) cases: query = protein, window = its planted locus"""
     c = {}
     g = pgene(1, n_exons=3, aa_len=120, flank=200, intron_hi=600)
-    c["h1_basic"] = (g.window, g.query, [])
+    c["h1_basic"] = (g.window, g.query, ["-u", "1,2,3"])
     g = pgene(2, n_exons=5, aa_len=400, flank=400, intron_hi=1200)
-    c["h1_400aa"] = (g.window, g.query, [])
+    c["h1_400aa"] = (g.window, g.query, ["-u", "1,4,7"])
     g = pgene(3, n_exons=1, aa_len=100, flank=150)
-    c["h1_single_exon"] = (g.window, g.query, [])
+    c["h1_single_exon"] = (g.window, g.query, ["-u", "1,2"])
     g = pgene(4, n_exons=4, aa_len=200, flank=250, intron_hi=800, sub=0.35)
-    c["h1_divergent"] = (g.window, g.query, [])
+    c["h1_divergent"] = (g.window, g.query, ["-u", "1,3"])
     g = pgene(5, n_exons=4, aa_len=180, flank=200, intron_hi=500)
     e = g.exons
-    c["h1_cut_left"] = (g.window[e[1][0] + 31:], g.query, [])
-    c["h1_cut_right"] = (g.window[:e[2][1] - 29], g.query, [])
+    c["h1_cut_left"] = (g.window[e[1][0] + 31:], g.query, ["-u", "1,2"])
+    c["h1_cut_right"] = (g.window[:e[2][1] - 29], g.query, ["-u", "1,2"])
     # frame shifts: delete one / insert two nucleotides inside exons of the window
     w = g.window
     w = np.concatenate([w[:e[0][0] + 40], w[e[0][0] + 41:e[2][0] + 25],
                         np.frombuffer(b"AC", dtype=np.uint8), w[e[2][0] + 25:]])
-    c["h1_frameshift"] = (w, g.query, [])
+    c["h1_frameshift"] = (w, g.query, ["-u", "1,3"])
     # missing / extra residues in the query
     q = np.concatenate([g.query[:50], g.query[57:110], g.query[100:]])
-    c["h1_query_indel"] = (g.window, q, [])
+    c["h1_query_indel"] = (g.window, q, ["-u", "2,4"])
     g = pgene(6, n_exons=3, aa_len=150, flank=120, intron_hi=300)
-    c["h1_narrow_band"] = (g.window, g.query, ["-w", "6"])
+    c["h1_narrow_band"] = (g.window, g.query, ["-w", "6", "-u", "1,2"])
     g = pgene(7, n_exons=3, aa_len=100, flank=100, intron_hi=250)
     for flags in ("0000", "1100", "0011", "1001"):
-        c[f"h1_exg_{flags}"] = (g.window, g.query, ["-g", flags])
+        c[f"h1_exg_{flags}"] = (g.window, g.query, ["-g", flags, "-u", "1,2"])
     g = pgene(8, n_exons=4, aa_len=160, flank=200, intron_hi=400, sub=0.15)
-    c["h1_local"] = (g.window, g.query, ["-L"])
+    c["h1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
     rng = np.random.default_rng(synth.SEED + 590)
     c["h1_random"] = (synth.random_dna(rng, 1500),
-                      synth._AA_LETTERS[rng.integers(0, 20, size=90)], [])
+                      synth._AA_LETTERS[rng.integers(0, 20, size=90)], ["-u", "1"])
     for m in (8, 15, 16, 17, 33, 48):
         g = pgene(20 + m, n_exons=1, aa_len=max(m, 20), flank=60)
-        c[f"h1_tiny_m{m}"] = (g.window, g.query[:m], [])
+        c[f"h1_tiny_m{m}"] = (g.window, g.query[:m], ["-u", "1"] if m >= 17 else [])
     g = pgene(9, n_exons=5, aa_len=300, flank=300, intron_hi=700)
     e = g.exons
     # (semi-global sub-ranges such as -r 40,260,e0+90,e4+30 make the reference itself stop with
     #  "Unexpected dir": no fixture can be taken from them)
     c["h1_subrange_global"] = (g.window, g.query,
-                               ["-r", f"50,250,{e[1][0] - 12},{e[3][1] + 9}", "-g", "0000"])
+                               ["-r", f"50,250,{e[1][0] - 12},{e[3][1] + 9}", "-g", "0000", "-u", "1,2"])
+    # the Aln2h1 surface forced into the linear-space branch (small MaxVmfSpace)
+    g = pgene(10, n_exons=5, aa_len=320, flank=300, intron_hi=900)
+    c["h1_auto_udh"] = (g.window, g.query, ["-V", "400000", "-u", "2"])
+    c["h1_forced_udh3"] = (g.window, g.query, ["-V", "200000", "-U", "3", "-u", "3"])
+    g = pgene(11, n_exons=6, aa_len=450, flank=400, intron_hi=1500, sub=0.2)
+    c["h1_450aa_auto"] = (g.window, g.query, ["-V", "1500000", "-u", "5"])
     return c
 
 

@@ -58,3 +58,27 @@ def test_exon_structure_agrees_with_exact_engine():
     """on clean inputs the `_wip` model and the scalar exact model (-A0) find the same corners"""
     fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
     assert fx["aln_skl_A2"].tolist() == fx["aln_skl_A0"].tolist()
+
+
+def _udh_cases():
+    import re
+    out = []
+    for f in H_FILES:
+        fx = spdg.load(f)
+        for k in fx:
+            m = re.match(r"wip_(qn|q1)_udh(\d+)_scr", k)
+            if m:
+                out.append((f, m.group(1), int(m.group(2))))
+    return out
+
+
+@pytest.mark.parametrize("path,tag,n_im", _udh_cases(), ids=lambda v: _name(v) if isinstance(v, str) and "/" in v else str(v))
+def test_hirschberg_h1_wip(path, tag, n_im):
+    """score, cpos rows and written-back ranges of SimdAln2h1::hirschbergH1_wip"""
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx, nquant=None if tag == "qn" else 1)
+    _, p = spdg.problem_h(fx)
+    s, cpos, rng = oracle.wip_udh_h(sc, p, n_im)
+    assert s == int(fx[f"wip_{tag}_udh{n_im}_scr"][0])
+    assert cpos.ravel().tolist() == fx[f"wip_{tag}_udh{n_im}_cpos"].tolist()
+    assert rng.tolist() == fx[f"wip_{tag}_udh{n_im}_rng"][:4].tolist()

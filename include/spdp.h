@@ -222,12 +222,19 @@ int64_t spdp_cells_h(const SpdpProblemH* p, const SpdpWindow* wdw);
  * beyond b_right, fwd2h1_simd.h:756-766, 780: an out-of-bounds read there, undefined result). */
 int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc,
                        const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+/* hirschbergH1_wip with n_im intermediate rows (src/fwd2h1_wip_simd.h:338): cpos[i] points at
+ * (n_im + 1) * 10 ints, ranges[i*4..] receives the written-back a_left, a_right, b_left, b_right.
+ * Non-local ends only. */
+int spdp_wip_udh_h(SpdpContext* ctx, const SpdpScoringH* sc,
+                   const SpdpProblemH* probs, int n_probs, int n_im,
+                   int32_t* scores, int32_t* cpos, int32_t* ranges);
 /* HomScoreH_ng for -A2/-A3: stripe31() then forwardH1_wip() */
 int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
                     const SpdpProblemH* probs, int n_probs, int32_t* scores);
-/* alignH_ng with seeding off (-Q0/-Q4): stripe31 -> lspH_ng -> trcbkalignH_ng -> stdskl3.
- * Problems whose volume exceeds MaxVmfSpace need hirschbergH1_wip, which is not built yet:
- * they are reported through the return value 1 and come back with n_skl = 0. */
+/* alignH_ng with seeding off (-Q0/-Q4): stripe31 -> lspH_ng decision ladder -> forwardH1_wip, or
+ * hirschbergH1_wip + per-slab forwardH1_wip (mimd_postwork / rcsv_postwork) -> stdskl3.
+ * Return value 1: some problem needs an engine that is not built (scalar forwardH_ng for < 8 query
+ * rows, diagonalH_ng, the local linear-space engine); those come back with n_skl = 0, score NEVSEL. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 

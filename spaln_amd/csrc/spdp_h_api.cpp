@@ -29,8 +29,9 @@
         }                                                                                \
     } while (0)
 
-enum { H_POOL = 5 };                         // ctx->pool[] slot group of this path
+enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs + traceback runs / linear-space runs
 enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF };
+enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES };
 static const int H_SKL_CAP = 1024;
 
 // ---- geometry --------------------------------------------------------------------------
@@ -68,20 +69,26 @@ int64_t spdp_cells_h(const SpdpProblemH* p, const SpdpWindow* w)
     return c;
 }
 
-// ---- resident inputs + work buffers of one set of problems -------------------------------
-struct SpdpBatchH {
+// ---- resident inputs of a set of parent problems ------------------------------------------
+struct HStore {
     SpdpContext* ctx = nullptr;
     SpdpScoringH sc;
     int n = 0;
-    std::vector<SpdpProblemH> probs;            // ranges / flags only are used after upload
-    std::vector<DevProblemH> h_probs;
-    std::vector<int> cls;                        // per problem: 0 run, 1 needs an engine not built, 2 bad input
-    std::vector<int> run_idx;                    // dispatch slot -> caller index
-    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_probs = nullptr,
-         *d_bnd = nullptr, *d_tb = nullptr, *d_res = nullptr, *d_skl = nullptr, *d_nskl = nullptr;
-    int64_t cells = 0, tb_elems = 0;
-    float sweep_ms = 0.f, walk_ms = 0.f;
-    std::string err;
+    std::vector<SpdpProblemH> probs;            // ranges / flags / lengths are used after upload
+    std::vector<int64_t> a_off, col_off;
+    std::vector<int32_t> col_len;
+    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr;
+    int upload(SpdpContext* c, const SpdpScoringH* sc, const SpdpProblemH* probs, int n);
+};
+
+// one engine call on (a sub-range of) a parent problem
+struct HItem {
+    int top;                                    // caller index the records belong to
+    int a_left, a_right, b_left, b_right;
+    int a_exgl, a_exgr, b_exgl, b_exgr;
+    SpdpWindow w;
+    int n_im = 0;
+    bool recursive = false, first = false;      // first: this call's return value is gsi->scr
 };
 
 static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* p, int i)
@@ -102,88 +109,39 @@ static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
     return 0;
 }
 
-// the reference's decision ladder up to the engine call (lspH_ng, src/fwd2h1.cc:2140-2175)
-static int classify(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow& w, bool ladder)
+int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* pr, int cnt)
 {
-    const int m = p->a_right - p->a_left, n = p->b_right - p->b_left;
-    if (!m || !n) return 2;                                  // empty range: GapPenalty paths, not built
-    if (w.width < 0) return 2;
-    if (m < 8) return 1;                                     // scalar forwardH_ng
-    if (!ladder) return 0;
-    if (w.up == w.lw) return 1;                              // diagonalH_ng
-    if (std::abs(n - m) < 16 || m == 1 || n <= 3) return 0;
-    const float cvol = float(m) * float(n + 3 * m);
-    if (2.f * cvol < (float) sc->max_vmf_space) return 0;    // coef_B = sizeof(short)
-    return 1;                                                // hirschbergH1_wip
-}
-
-static int batch_build(SpdpBatchH* bt, SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n,
-                       bool ladder)
-{
-    bt->ctx = ctx; bt->sc = *sc; bt->n = n;
-    bt->probs.assign(probs, probs + n);
-    bt->cls.assign(n, 0);
+    ctx = c; sc = *scp; n = cnt;
+    probs.assign(pr, pr + cnt);
     DevPool& pool = ctx->pool[H_POOL];
-    // ---- scoring
     DevScoringH ds;
     memset(&ds, 0, sizeof ds);
-    ds.gop = sc->gop; ds.gep = sc->gep; ds.lgep = sc->lgep; ds.codonk1 = sc->codonk1;
-    ds.g1 = sc->gapw1; ds.g2 = sc->gapw2; ds.g3 = sc->gapw3;
-    ds.spj = sc->spj; ds.llmt = sc->llmt; ds.nquant = sc->nquant; ds.local = sc->local;
-    ds.term_codon = sc->term_codon;
-    for (int j = 0; j < 8; ++j) { ds.qm_len[j] = sc->qm_len[j]; ds.qm_pen[j] = sc->qm_pen[j]; }
-    for (int i = 0; i < sc->mtx_rows; ++i)
-        for (int j = 0; j < sc->mtx_cols; ++j) ds.mtx[i * 32 + j] = sc->mtx[i * sc->mtx_cols + j];
-    const int ipen = sc->spj ? sc->ipen : SPDH_NEV;
-    // ---- problems
+    ds.gop = sc.gop; ds.gep = sc.gep; ds.lgep = sc.lgep; ds.codonk1 = sc.codonk1;
+    ds.g1 = sc.gapw1; ds.g2 = sc.gapw2; ds.g3 = sc.gapw3;
+    ds.spj = sc.spj; ds.llmt = sc.llmt; ds.nquant = sc.nquant; ds.local = sc.local;
+    ds.term_codon = sc.term_codon;
+    for (int j = 0; j < 8; ++j) { ds.qm_len[j] = sc.qm_len[j]; ds.qm_pen[j] = sc.qm_pen[j]; }
+    for (int i = 0; i < sc.mtx_rows; ++i)
+        for (int j = 0; j < sc.mtx_cols; ++j) ds.mtx[i * 32 + j] = sc.mtx[i * sc.mtx_cols + j];
+    const int ipen = sc.spj ? sc.ipen : SPDH_NEV;
     std::vector<uint8_t> a_all;
     std::vector<int4> cols;
     std::vector<short4> aux;
-    int64_t bnd_ent = 0, tb_el = 0;
-    bt->h_probs.clear(); bt->run_idx.clear(); bt->cells = 0;
-    // dispatch order: largest problems first (the hardware hands blocks out in index order, so the
-    // long ones start early and the short ones fill the tail)
-    std::vector<std::pair<int64_t, int>> todo;
+    a_off.resize(n); col_off.resize(n); col_len.resize(n);
     for (int i = 0; i < n; ++i) {
         const SpdpProblemH& p = probs[i];
-        if (validate(ctx, sc, &p, i)) return -1;
-        SpdpWindow w;
-        stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sc->sh, &w);
-        bt->cls[i] = classify(sc, &p, w, ladder);
-        if (!bt->cls[i]) todo.emplace_back(-spdp_cells_h(&p, &w), i);
-    }
-    std::stable_sort(todo.begin(), todo.end());
-    for (const auto& td : todo) {
-        const int i = td.second;
-        const SpdpProblemH& p = probs[i];
-        SpdpWindow w;
-        stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sc->sh, &w);
-        DevProblemH d;
-        memset(&d, 0, sizeof d);
-        d.a_left = p.a_left; d.a_right = p.a_right; d.b_left = p.b_left; d.b_right = p.b_right;
-        d.lw = w.lw; d.up = w.up; d.width = w.width; d.buf_size = w.width + 6 * SPDH_NELEM;
-        d.a_exgl = p.a_exgl; d.a_exgr = p.a_exgr; d.b_exgl = p.b_exgl; d.b_exgr = p.b_exgr;
-        d.m_width = p.a_right - p.a_left + 1;
-        d.n_width = p.b_right - p.b_left + 1 + 3 * d.m_width;
-        d.tb_size = (int64_t) d.m_width * d.n_width + 32;
-        if (d.tb_size + 64 >= (int64_t) 1 << 31) { ctx->err = "traceback bitmap of one problem exceeds 2^31 cells"; return -1; }
-        d.col_len = p.b_len + 3 + SPDH_COL_PAD;
-        d.a_off = (int64_t) a_all.size();
-        d.col_off = (int64_t) cols.size();
-        d.bnd_off = bnd_ent;
-        d.tb_off = tb_el;
-        d.cells = spdp_cells_h(&p, &w);
-        bnd_ent += d.buf_size + SPDH_BND_PAD;
-        tb_el += (d.tb_size + 64 + 7) / 8 * 8;
-        bt->cells += d.cells;
+        if (validate(ctx, &sc, &p, i)) return -1;
+        a_off[i] = (int64_t) a_all.size();
+        col_off[i] = (int64_t) cols.size();
+        col_len[i] = p.b_len + 3 + SPDH_COL_PAD;
         a_all.insert(a_all.end(), p.a, p.a + p.a_len);
         // column records (layout: spdp_h_dev.h); positions beyond the inputs read as zero
         const int N = p.b_len + 3;
         auto good = [&](int x) { return p.exin_left - 1 <= x && x < p.exin_right; };
         auto s16at = [&](const int16_t* v, int x) -> int { return (x >= 0 && x < N) ? v[x] : 0; };
         const size_t c0 = cols.size();
-        cols.resize(c0 + d.col_len, make_int4(0, 0, 0, 0));
-        aux.resize(c0 + d.col_len, make_short4(0, 0, 0, 0));
+        cols.resize(c0 + col_len[i], make_int4(0, 0, 0, 0));
+        aux.resize(c0 + col_len[i], make_short4(0, 0, 0, 0));
         for (int x = 0; x < N; ++x) {
             const int cp = (x - 2 >= 0 && good(x - 2)) ? p.sigE[x - 2] : 0;
             const int tron = (x - 2 >= 0 && x - 2 <= p.b_len) ? p.b[x - 2] : 0;
@@ -211,92 +169,381 @@ static int batch_build(SpdpBatchH* bt, SpdpContext* ctx, const SpdpScoringH* sc,
             cols[c0 + x] = rec;
             aux[c0 + x] = make_short4(p.sigS[x], p.sigT[x], p.sigE[x], p.sig5[x]);
         }
-        bt->h_probs.push_back(d);
-        bt->run_idx.push_back(i);
     }
-    const int nr = (int) bt->h_probs.size();
-    bt->tb_elems = tb_el;
-    if (!nr) return 0;
-    // ---- upload
-    bt->d_sc = pool.get(HP_SC, sizeof ds);
-    bt->d_a = pool.get(HP_A, a_all.size() + 16);
-    bt->d_cols = pool.get(HP_COLS, cols.size() * sizeof(int4));
-    bt->d_aux = pool.get(HP_AUX, aux.size() * sizeof(short4));
-    bt->d_probs = pool.get(HP_PROBS, nr * sizeof(DevProblemH));
-    bt->d_bnd = pool.get(HP_BND, (size_t) bnd_ent * sizeof(int2));
-    bt->d_tb = pool.get(HP_TB, (size_t) tb_el * sizeof(uint16_t));
-    bt->d_res = pool.get(HP_RES, nr * sizeof(DevResultH));
-    bt->d_skl = pool.get(HP_SKL, (size_t) nr * H_SKL_CAP * sizeof(int2));
-    bt->d_nskl = pool.get(HP_NSKL, nr * sizeof(int));
-    if (!bt->d_sc || !bt->d_a || !bt->d_cols || !bt->d_aux || !bt->d_probs || !bt->d_bnd || !bt->d_tb ||
-        !bt->d_res || !bt->d_skl || !bt->d_nskl) {
-        ctx->err = "device allocation failed (aa x genome batch; traceback bitmaps need " +
-                   std::to_string((size_t) tb_el * 2 >> 20) + " MiB)";
-        return -1;
-    }
-    HIPCHK(hipMemcpyAsync(bt->d_sc, &ds, sizeof ds, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bt->d_a, a_all.data(), a_all.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bt->d_cols, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bt->d_aux, aux.data(), aux.size() * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bt->d_probs, bt->h_probs.data(), nr * sizeof(DevProblemH), hipMemcpyHostToDevice, ctx->stream));
+    if (!n) return 0;
+    d_sc = pool.get(HP_SC, sizeof ds);
+    d_a = pool.get(HP_A, a_all.size() + 16);
+    d_cols = pool.get(HP_COLS, cols.size() * sizeof(int4));
+    d_aux = pool.get(HP_AUX, aux.size() * sizeof(short4));
+    if (!d_sc || !d_a || !d_cols || !d_aux) { ctx->err = "device allocation failed (aa x genome inputs)"; return -1; }
+    HIPCHK(hipMemcpyAsync(d_sc, &ds, sizeof ds, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_a, a_all.data(), a_all.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
-// one pass: sweep (+ walk); results to host
-static int batch_run(SpdpBatchH* bt, bool walk, std::vector<DevResultH>& res, std::vector<int>& n_skl,
-                     std::vector<SpdpSkl>& skl)
+static HItem item_of(const SpdpProblemH& p, int top, int sh)
 {
-    SpdpContext* ctx = bt->ctx;
-    const int nr = (int) bt->h_probs.size();
-    res.clear(); n_skl.clear(); skl.clear();
-    bt->sweep_ms = bt->walk_ms = 0.f;
+    HItem it;
+    it.top = top;
+    it.a_left = p.a_left; it.a_right = p.a_right; it.b_left = p.b_left; it.b_right = p.b_right;
+    it.a_exgl = p.a_exgl; it.a_exgr = p.a_exgr; it.b_exgl = p.b_exgl; it.b_exgr = p.b_exgr;
+    stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sh, &it.w);
+    return it;
+}
+
+static int64_t cells_of(const HItem& it)
+{
+    SpdpProblemH q;
+    memset(&q, 0, sizeof q);
+    q.a_left = it.a_left; q.a_right = it.a_right; q.b_left = it.b_left; q.b_right = it.b_right;
+    return spdp_cells_h(&q, &it.w);
+}
+
+// descriptors shared by both engines
+static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
+{
+    memset(&d, 0, sizeof d);
+    d.a_left = it.a_left; d.a_right = it.a_right; d.b_left = it.b_left; d.b_right = it.b_right;
+    d.lw = it.w.lw; d.up = it.w.up; d.width = it.w.width; d.buf_size = it.w.width + 6 * SPDH_NELEM;
+    d.a_exgl = it.a_exgl; d.a_exgr = it.a_exgr; d.b_exgl = it.b_exgl; d.b_exgr = it.b_exgr;
+    d.m_width = it.a_right - it.a_left + 1;
+    d.n_width = it.b_right - it.b_left + 1 + 3 * d.m_width;
+    d.tb_size = (int64_t) d.m_width * d.n_width + 32;
+    d.col_len = st.col_len[it.top];
+    d.a_off = st.a_off[it.top];
+    d.col_off = st.col_off[it.top];
+    d.n_im = it.n_im;
+    d.cells = cells_of(it);
+}
+
+// ---- forwardH1_wip over a list of items -----------------------------------------------------
+struct HFwdOut {
+    std::vector<DevResultH> res;                // in item order
+    std::vector<int> n_skl;                     // records; -2 "Unexpected dir", -3 start outside the bitmap
+    std::vector<int64_t> off;
+    std::vector<SpdpSkl> skl;
+    float sweep_ms = 0.f;
+    int64_t cells = 0, tb_elems = 0;
+};
+
+static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, HFwdOut& out)
+{
+    SpdpContext* ctx = st.ctx;
+    DevPool& pool = ctx->pool[H_POOL];
+    const int nr = (int) items.size();
+    out = HFwdOut();
     if (!nr) return 0;
+    // dispatch order: largest problems first (the hardware hands blocks out in index order, so the
+    // long ones start early and the short ones fill the tail)
+    std::vector<std::pair<int64_t, int>> order(nr);
+    std::vector<DevProblemH> descs(nr);
+    for (int i = 0; i < nr; ++i) { fill_desc(st, items[i], descs[i]); order[i] = {-descs[i].cells, i}; }
+    std::stable_sort(order.begin(), order.end());
+    std::vector<DevProblemH> h_probs(nr);
+    int64_t bnd_ent = 0, tb_el = 0;
+    for (int s = 0; s < nr; ++s) {
+        DevProblemH d = descs[order[s].second];
+        if (d.tb_size + 64 >= (int64_t) 1 << 31) { ctx->err = "traceback bitmap of one problem exceeds 2^31 cells"; return -1; }
+        d.bnd_off = bnd_ent;
+        d.tb_off = tb_el;
+        bnd_ent += d.buf_size + SPDH_BND_PAD;
+        tb_el += (d.tb_size + 64 + 7) / 8 * 8;
+        out.cells += d.cells;
+        h_probs[s] = d;
+    }
+    out.tb_elems = tb_el;
+    void* d_probs = pool.get(HP_PROBS, nr * sizeof(DevProblemH));
+    void* d_bnd = pool.get(HP_BND, (size_t) bnd_ent * sizeof(int2));
+    void* d_tb = pool.get(HP_TB, (size_t) tb_el * sizeof(uint16_t));
+    void* d_res = pool.get(HP_RES, nr * sizeof(DevResultH));
+    void* d_skl = pool.get(HP_SKL, (size_t) nr * H_SKL_CAP * sizeof(int2));
+    void* d_nskl = pool.get(HP_NSKL, nr * sizeof(int));
+    if (!d_probs || !d_bnd || !d_tb || !d_res || !d_skl || !d_nskl) {
+        ctx->err = "device allocation failed (aa x genome traceback run: bitmaps need " +
+                   std::to_string((size_t) tb_el * 2 >> 20) + " MiB)";
+        return -1;
+    }
+    HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), nr * sizeof(DevProblemH), hipMemcpyHostToDevice, ctx->stream));
     HSweepArgs A;
-    A.sc = (const DevScoringH*) bt->d_sc; A.probs = (const DevProblemH*) bt->d_probs; A.n_probs = nr;
-    A.a_codes = (const uint8_t*) bt->d_a; A.cols = (const int4*) bt->d_cols; A.aux = (const short4*) bt->d_aux;
-    A.bnd = (int2*) bt->d_bnd; A.tb = (uint16_t*) bt->d_tb; A.res = (DevResultH*) bt->d_res;
+    A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
+    A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
+    A.bnd = (int2*) d_bnd; A.tb = (uint16_t*) d_tb; A.res = (DevResultH*) d_res;
+    const int pen_cap = st.sc.nquant > 1 ? st.sc.qm_len[st.sc.nquant - 2] + 1 : 0;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    const int pen_cap = bt->sc.nquant > 1 ? bt->sc.qm_len[bt->sc.nquant - 2] + 1 : 0;
-    HIPCHK(spdh_launch_sweep(&A, bt->sc.spj, pen_cap, bt->sc.local, ctx->stream));
+    HIPCHK(spdh_launch_sweep(&A, st.sc.spj, pen_cap, st.sc.local, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (walk) {
         HWalkArgs W;
         W.probs = A.probs; W.n_probs = nr; W.tb = A.tb; W.res = A.res;
-        W.skl = (int2*) bt->d_skl; W.n_skl = (int*) bt->d_nskl; W.skl_cap = H_SKL_CAP;
+        W.skl = (int2*) d_skl; W.n_skl = (int*) d_nskl; W.skl_cap = H_SKL_CAP;
         HIPCHK(spdh_launch_walk(&W, ctx->stream));
     }
-    res.resize(nr);
-    HIPCHK(hipMemcpyAsync(res.data(), bt->d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
-    if (walk) {
-        n_skl.resize(nr);
-        HIPCHK(hipMemcpyAsync(n_skl.data(), bt->d_nskl, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    std::vector<DevResultH> res(nr);
+    std::vector<int> n_skl(nr, 0);
+    HIPCHK(hipMemcpyAsync(res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
+    if (walk) HIPCHK(hipMemcpyAsync(n_skl.data(), d_nskl, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipEventElapsedTime(&bt->sweep_ms, ctx->ev0, ctx->ev1));
+    HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    std::vector<int64_t> off(nr + 1, 0);
+    std::vector<SpdpSkl> skl;
     if (walk) {
-        // compact copy of the records actually written
-        DevPool& pool = ctx->pool[H_POOL];
-        std::vector<int64_t> off(nr + 1, 0);
-        for (int i = 0; i < nr; ++i) {
-            int c = n_skl[i];
+        for (int s = 0; s < nr; ++s) {
+            int c = n_skl[s];
+            if (c == -1) { ctx->err = "traceback record buffer overflow"; return -1; }
             if (c == -3) c = 1;                              // the single start record
             if (c < 0) c = 0;
-            off[i + 1] = off[i] + c;
+            off[s + 1] = off[s] + c;
         }
         skl.resize(off[nr]);
         if (off[nr]) {
             void* d_off = pool.get(HP_OFF, (nr + 1) * sizeof(int64_t));
             void* d_pack = pool.get(HP_PACK, off[nr] * sizeof(int2));
             std::vector<int> cnt(nr);
-            for (int i = 0; i < nr; ++i) cnt[i] = (int) (off[i + 1] - off[i]);
+            for (int s = 0; s < nr; ++s) cnt[s] = (int) (off[s + 1] - off[s]);
             HIPCHK(hipMemcpyAsync(d_off, off.data(), (nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-            // n_skl on the device still holds the status codes: hand the counts over instead
-            HIPCHK(hipMemcpyAsync(bt->d_nskl, cnt.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(spdp_launch_pack((const int2*) bt->d_skl, H_SKL_CAP, (const int*) bt->d_nskl, (const int64_t*) d_off,
+            HIPCHK(hipMemcpyAsync(d_nskl, cnt.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(spdp_launch_pack((const int2*) d_skl, H_SKL_CAP, (const int*) d_nskl, (const int64_t*) d_off,
                                     (int2*) d_pack, nr, ctx->stream));
             HIPCHK(hipMemcpyAsync(skl.data(), d_pack, off[nr] * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    // back to item order
+    out.res.resize(nr); out.n_skl.resize(nr); out.off.assign(nr + 1, 0);
+    std::vector<int> slot_of(nr);
+    for (int s = 0; s < nr; ++s) slot_of[order[s].second] = s;
+    for (int i = 0; i < nr; ++i) {
+        const int s = slot_of[i];
+        out.res[i] = res[s]; out.n_skl[i] = n_skl[s];
+        out.off[i + 1] = out.off[i] + (off[s + 1] - off[s]);
+    }
+    out.skl.resize(out.off[nr]);
+    for (int i = 0; i < nr; ++i) {
+        const int s = slot_of[i];
+        std::copy(skl.begin() + off[s], skl.begin() + off[s + 1], out.skl.begin() + out.off[i]);
+    }
+    return 0;
+}
+
+// ---- hirschbergH1_wip over a list of items ------------------------------------------------------
+struct HUdhOut {
+    std::vector<int32_t> scores, cpos, ranges;  // in item order; cpos stride = stride ints per item
+    int stride = 0;
+    float sweep_ms = 0.f;
+    int64_t cells = 0;
+};
+
+static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
+{
+    SpdpContext* ctx = st.ctx;
+    DevPool& pool = ctx->pool[HU_POOL];
+    const int nr = (int) items.size();
+    out = HUdhOut();
+    if (!nr) return 0;
+    int max_im = 1;
+    for (const HItem& it : items) max_im = std::max(max_im, it.n_im);
+    out.stride = (max_im + 1) * 10;
+    std::vector<DevProblemH> h_probs(nr);
+    int64_t bnd_ent = 0, imd_int = 0;
+    for (int i = 0; i < nr; ++i) {
+        DevProblemH& d = h_probs[i];
+        fill_desc(st, items[i], d);
+        d.bnd_off = bnd_ent;
+        d.imd_off = imd_int;
+        bnd_ent += d.buf_size + SPDH_BND_PAD;
+        imd_int += (int64_t) d.n_im * 5 * d.width;
+        out.cells += d.cells;
+    }
+    void* d_probs = pool.get(HU_PROBS, nr * sizeof(DevProblemH));
+    void* d_bnd = pool.get(HU_BND, (size_t) bnd_ent * sizeof(int4));
+    void* d_imd = pool.get(HU_IMD, (size_t) std::max<int64_t>(imd_int, 1) * sizeof(int));
+    void* d_res = pool.get(HU_RES, nr * sizeof(DevResultH));
+    void* d_cpos = pool.get(HU_CPOS, (size_t) nr * out.stride * sizeof(int));
+    void* d_ranges = pool.get(HU_RANGES, (size_t) nr * 4 * sizeof(int));
+    void* d_scores = pool.get(HU_SCORES, (size_t) nr * sizeof(int));
+    if (!d_probs || !d_bnd || !d_imd || !d_res || !d_cpos || !d_ranges || !d_scores) {
+        ctx->err = "device allocation failed (aa x genome linear-space run)";
+        return -1;
+    }
+    HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), nr * sizeof(DevProblemH), hipMemcpyHostToDevice, ctx->stream));
+    HUdhArgs A;
+    A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
+    A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
+    A.bnd = (int4*) d_bnd; A.imd = (int*) d_imd; A.res = (DevResultH*) d_res;
+    const int pen_cap = st.sc.nquant > 1 ? st.sc.qm_len[st.sc.nquant - 2] + 1 : 0;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(spdh_launch_udh(&A, st.sc.spj, pen_cap, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HCposArgs Cc;
+    Cc.probs = A.probs; Cc.n_probs = nr; Cc.imd = A.imd; Cc.res = A.res;
+    Cc.cpos = (int*) d_cpos; Cc.ranges = (int*) d_ranges; Cc.scores = (int*) d_scores; Cc.cpos_stride = out.stride;
+    HIPCHK(spdh_launch_cpos(&Cc, ctx->stream));
+    out.scores.resize(nr); out.cpos.resize((size_t) nr * out.stride); out.ranges.resize((size_t) nr * 4);
+    HIPCHK(hipMemcpyAsync(out.scores.data(), d_scores, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out.cpos.data(), d_cpos, (size_t) nr * out.stride * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out.ranges.data(), d_ranges, (size_t) nr * 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+// ---- the reference's dispatch (lspH_ng & co.) over a batch, in rounds ---------------------------
+struct HTop {
+    int cls = 0;                                // 0 ok, 1 needs an engine that is not built, 2 bad input
+    int flag = 0;                               // -1 "Unexpected dir", -2 traceback start outside the bitmap
+    int score = SPDP_NEVSEL;
+    std::vector<SpdpSkl> rec;
+};
+
+struct HStats { float fwd_ms = 0.f, udh_ms = 0.f; int64_t fwd_cells = 0, udh_cells = 0; int rounds = 0; };
+
+static const int END_ULK = SPDP_END_OF_ULK;
+
+static void push_rec(HTop& t, int m, int n) { SpdpSkl s; s.m = m; s.n = n; t.rec.push_back(s); }
+
+// trcbkalignH_ng's engine choice (src/fwd2h1.cc:1997-2014): returns false when the item cannot run here
+static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, HTop& t)
+{
+    if (it.w.width < 0) return true;                         // NEVSEL, no records
+    if (it.a_right - it.a_left < 8) { t.cls = 1; return false; }   // scalar forwardH_ng
+    fwd.push_back(it);
+    return true;
+}
+
+// lspH_ng (src/fwd2h1.cc:2140-2180) up to the engine call
+static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd, std::vector<HItem>& udh, HTop& t)
+{
+    const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
+    if (!m && !n) { if (it.first) t.score = 0; return; }
+    if (!m || !n) { t.cls = 2; return; }                     // terminal-gap-only ranges: GapPenalty paths, not built
+    if (it.w.up == it.w.lw) { t.cls = 1; return; }           // diagonalH_ng
+    if (std::abs(n - m) < 16 || m == 1 || n <= 3) { queue_trcbk(it, fwd, t); return; }
+    const float coef_B = 2.f, coef_C = 12.f;                 // sizeof(short); (Noll + 1) * sizeof(int)
+    const float cvol = float(m) * (n + 3 * m);
+    if (coef_B * cvol < sc.max_vmf_space) { queue_trcbk(it, fwd, t); return; }
+    bool recursive = false;
+    int n_imd = 1;
+    {
+        const double z = 2. * m * coef_B / coef_C;
+        const int imd1 = int(pow(z, 1. / 3) + 0.5) - 1;
+        const float spc = coef_C * n * imd1 + coef_B * cvol / (imd1 + 1) / (imd1 + 1);
+        if (spc > sc.max_vmf_space) recursive = true;
+        else {
+            const int imd3 = m / 16;
+            n_imd = sc.ubh ? sc.ubh : std::min(imd1, imd3);
+            const int intvl = (m + n_imd) / (n_imd + 1);
+            if (intvl * n_imd == m) --n_imd;
+            if (n_imd == 0) { queue_trcbk(it, fwd, t); return; }
+        }
+    }
+    if (sc.local) { t.cls = 1; return; }                     // local linear-space engine: not built
+    it.n_im = n_imd; it.recursive = recursive;
+    udh.push_back(it);
+}
+
+static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& hs)
+{
+    const SpdpScoringH& sc = st.sc;
+    tops.assign(st.n, HTop());
+    std::vector<HItem> pending, fwd, udh;
+    for (int i = 0; i < st.n; ++i) {
+        HItem it = item_of(st.probs[i], i, sc.sh);
+        it.first = true;
+        if (ladder) pending.push_back(it);
+        else {                                               // engine level: forwardH1_wip on the stripe31 band
+            const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
+            if (!m || !n || it.w.width < 0) tops[i].cls = 2;
+            else if (m < 8) tops[i].cls = 1;
+            else fwd.push_back(it);
+        }
+    }
+    while (!pending.empty() || !fwd.empty()) {
+        ++hs.rounds;
+        udh.clear();
+        for (const HItem& it : pending) if (!tops[it.top].cls) queue_lsp(sc, it, fwd, udh, tops[it.top]);
+        pending.clear();
+        // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)
+        if (!udh.empty()) {
+            HUdhOut uo;
+            if (run_udh(st, udh, uo)) return -1;
+            hs.udh_ms += uo.sweep_ms; hs.udh_cells += uo.cells;
+            for (size_t u = 0; u < udh.size(); ++u) {
+                const HItem& it = udh[u];
+                HTop& t = tops[it.top];
+                if (t.cls) continue;
+                const int scr = uo.scores[u];
+                if (it.first) t.score = scr;
+                if (scr <= SPDP_NEVSEL) continue;
+                const int32_t* cpos = &uo.cpos[u * uo.stride];
+                const int32_t* rg = &uo.ranges[u * 4];
+                HItem cur = it;
+                cur.first = false; cur.n_im = 0; cur.recursive = false;
+                cur.a_left = rg[0]; cur.a_right = rg[1]; cur.b_left = rg[2]; cur.b_right = rg[3];
+#define CP(i, c) cpos[(i) * 10 + (c)]
+                if (CP(0, 0) == END_ULK) {                   // does not cross an intermediate row
+                    push_rec(t, cur.a_left, cur.b_left);
+                    push_rec(t, cur.a_right, cur.b_right);
+                } else if (it.recursive) {                   // rcsv_postwork, src/fwd2h1.cc:2091-2138
+                    cur.a_exgl = cur.a_exgr = cur.b_exgl = cur.b_exgr = 0;
+                    int c = 1;
+                    while (c < 9 && CP(0, c + 1) < END_ULK) { ++c; push_rec(t, CP(0, 0), CP(0, c)); }
+                    HItem h1 = cur, h2 = cur;
+                    h1.a_right = CP(0, 0); h1.b_right = CP(0, c);
+                    stripe31_rng(h1.a_left, h1.a_right, h1.b_left, h1.b_right, sc.sh, &h1.w);
+                    h2.a_left = CP(0, 0); h2.b_exgl = CP(0, 1); h2.b_left = CP(0, 2);
+                    stripe31_rng(h2.a_left, h2.a_right, h2.b_left, h2.b_right, sc.sh, &h2.w);
+                    pending.push_back(h1);
+                    pending.push_back(h2);
+                } else {                                     // mimd_postwork, src/fwd2h1.cc:2045-2089
+                    const int aleft = cur.a_left, bleft = cur.b_left;
+                    const int a_len = st.probs[it.top].a_len, b_len = st.probs[it.top].b_len;
+                    cur.a_exgl = cur.a_exgr = cur.b_exgl = cur.b_exgr = 0;
+                    int i = it.n_im;
+                    bool bad = false;
+                    while (--i >= 0 && CP(i, 0) == END_ULK) ;
+                    for ( ; i >= 0 && CP(i, 0) != END_ULK; --i) {
+                        int c = 0;
+                        cur.a_left = CP(i, c);
+                        cur.b_exgl = CP(i, ++c);
+                        cur.b_left = CP(i, ++c);
+                        if (cur.a_right > a_len || cur.b_right > b_len || cur.a_left < 0 || cur.b_left < 0) { bad = true; break; }
+                        if (cur.b_left < 0 || cur.b_left > cur.b_right) break;
+                        while (c < 9 && CP(i, c + 1) < END_ULK) { ++c; push_rec(t, cur.a_left, CP(i, c)); }
+                        ++c;
+                        stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
+                        if (!queue_trcbk(cur, fwd, t)) break;
+                        cur.a_right = cur.a_left;
+                        cur.b_right = CP(i, c - 1);
+                    }
+                    if (!bad && !t.cls && ((i < 0 && CP(0, 0) != END_ULK) || CP(0, 2) != END_ULK)) {
+                        cur.a_left = aleft; cur.b_left = bleft;
+                        stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
+                        queue_trcbk(cur, fwd, t);
+                    }
+                }
+#undef CP
+            }
+        }
+        // ---- traceback round
+        if (!fwd.empty()) {
+            std::vector<HItem> run;
+            for (const HItem& it : fwd) if (!tops[it.top].cls) run.push_back(it);
+            fwd.clear();
+            HFwdOut fo;
+            if (run_forward(st, run, true, fo)) return -1;
+            hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells;
+            for (size_t f = 0; f < run.size(); ++f) {
+                HTop& t = tops[run[f].top];
+                if (run[f].first) t.score = fo.res[f].score;
+                const int stt = fo.n_skl[f];
+                if (stt == -2) { if (!t.flag) t.flag = -1; }
+                else if (stt == -3) { if (!t.flag) t.flag = -2; }
+                if (stt == -2) continue;
+                t.rec.insert(t.rec.end(), fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
+            }
         }
     }
     return 0;
@@ -346,46 +593,32 @@ static SpdpSkl* dup_skl(const std::vector<SpdpSkl>& v)
 }
 
 // level 0: raw engine output; level 1: alignH_ng (header + stdskl3)
-static int batch_deliver(SpdpBatchH* bt, int level, SpdpAlignment* out)
+static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
 {
-    std::vector<DevResultH> res;
-    std::vector<int> n_skl;
-    std::vector<SpdpSkl> skl;
-    if (batch_run(bt, true, res, n_skl, skl)) return -1;
+    std::vector<HTop> tops;
+    if (run_ladder(st, level == 1, tops, hs)) return -1;
     int rc = 0;
-    for (int i = 0; i < bt->n; ++i) {
-        if (out) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
-        if (bt->cls[i]) rc = 1;
-    }
-    int64_t off = 0;
-    std::vector<SpdpSkl> rec, stdv, full;
-    for (size_t s = 0; s < bt->run_idx.size(); ++s) {
-        const int i = bt->run_idx[s];
-        const int st = n_skl[s];
-        const int cnt = st == -3 ? 1 : (st < 0 ? 0 : st);
-        if (st == -1) { bt->ctx->err = "traceback record buffer overflow"; return -1; }
-        if (out) {
-            out[i].score = res[s].score;
-            if (st == -2) out[i].n_skl = -1;                 // the reference's fatal "Unexpected dir"
-            else if (st == -3) out[i].n_skl = -2;            // its traceback starts outside the bitmap
-            else if (level == 0) {
-                rec.assign(skl.begin() + off, skl.begin() + off + cnt);
-                out[i].n_skl = cnt;
-                out[i].skl = dup_skl(rec);
-            } else {
-                rec.assign(skl.begin() + off, skl.begin() + off + cnt);
-                if (cnt >= 2) {                              // globalH_ng: fewer than 2 records = no alignment
-                    std_skl3(rec, stdv);
-                    full.clear();
-                    SpdpSkl hd; hd.m = 1; hd.n = (int) stdv.size();
-                    full.push_back(hd);
-                    full.insert(full.end(), stdv.begin(), stdv.end());
-                    out[i].n_skl = (int) full.size();
-                    out[i].skl = dup_skl(full);
-                }
-            }
+    std::vector<SpdpSkl> stdv, full;
+    for (int i = 0; i < st.n; ++i) {
+        HTop& t = tops[i];
+        if (t.cls) rc = 1;
+        if (!out) continue;
+        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr;
+        if (t.cls) continue;
+        out[i].score = t.score;
+        if (t.flag) { out[i].n_skl = t.flag; continue; }
+        if (level == 0) {
+            out[i].n_skl = (int) t.rec.size();
+            out[i].skl = dup_skl(t.rec);
+        } else if (t.rec.size() >= 2) {                      // globalH_ng: fewer than 2 records = no alignment
+            std_skl3(t.rec, stdv);
+            full.clear();
+            SpdpSkl hd; hd.m = 1; hd.n = (int) stdv.size();
+            full.push_back(hd);
+            full.insert(full.end(), stdv.begin(), stdv.end());
+            out[i].n_skl = (int) full.size();
+            out[i].skl = dup_skl(full);
         }
-        off += cnt;
     }
     return rc;
 }
@@ -395,24 +628,55 @@ int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProbl
                        SpdpAlignment* out)
 {
     if (!ctx || !sc || !probs || n_probs < 0 || !out) return -1;
-    SpdpBatchH bt;
-    if (batch_build(&bt, ctx, sc, probs, n_probs, false)) return -1;
-    return batch_deliver(&bt, 0, out);
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    HStats hs;
+    return deliver(st, 0, out, hs);
+}
+
+int spdp_wip_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs, int n_im,
+                   int32_t* scores, int32_t* cpos, int32_t* ranges)
+{
+    if (!ctx || !sc || !probs || n_probs < 0 || n_im < 1 || !scores || !cpos || !ranges) return -1;
+    if (sc->local) { ctx->err = "hirschbergH1_wip in local mode is not built"; return -1; }
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    std::vector<HItem> items;
+    for (int i = 0; i < n_probs; ++i) {
+        HItem it = item_of(probs[i], i, sc->sh);
+        it.n_im = n_im;
+        if (it.a_right - it.a_left < 16 * 1 || it.w.width < 0) { ctx->err = "hirschbergH1_wip: problem too small"; return -1; }
+        items.push_back(it);
+    }
+    HUdhOut uo;
+    if (run_udh(st, items, uo)) return -1;
+    for (int i = 0; i < n_probs; ++i) {
+        scores[i] = uo.scores[i];
+        memcpy(cpos + (size_t) i * (n_im + 1) * 10, &uo.cpos[(size_t) i * uo.stride], (size_t) (n_im + 1) * 10 * sizeof(int32_t));
+        memcpy(ranges + 4 * i, &uo.ranges[4 * i], 4 * sizeof(int32_t));
+    }
+    return 0;
 }
 
 int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
                     int32_t* scores)
 {
     if (!ctx || !sc || !probs || n_probs < 0 || !scores) return -1;
-    SpdpBatchH bt;
-    if (batch_build(&bt, ctx, sc, probs, n_probs, false)) return -1;
-    std::vector<DevResultH> res;
-    std::vector<int> n_skl;
-    std::vector<SpdpSkl> skl;
-    if (batch_run(&bt, false, res, n_skl, skl)) return -1;
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    std::vector<HItem> items;
+    std::vector<int> idx;
     int rc = 0;
-    for (int i = 0; i < n_probs; ++i) { scores[i] = SPDP_NEVSEL; if (bt.cls[i]) rc = 1; }
-    for (size_t s = 0; s < bt.run_idx.size(); ++s) scores[bt.run_idx[s]] = res[s].score;
+    for (int i = 0; i < n_probs; ++i) {
+        scores[i] = SPDP_NEVSEL;
+        HItem it = item_of(probs[i], i, sc->sh);
+        const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
+        if (m < 8 || !n || it.w.width < 0) { rc = 1; continue; }     // scalar forwardH_ng
+        items.push_back(it); idx.push_back(i);
+    }
+    HFwdOut fo;
+    if (run_forward(st, items, false, fo)) return -1;
+    for (size_t f = 0; f < items.size(); ++f) scores[idx[f]] = fo.res[f].score;
     return rc;
 }
 
@@ -420,16 +684,28 @@ int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* p
                  SpdpAlignment* out)
 {
     if (!ctx || !sc || !probs || n_probs < 0 || !out) return -1;
-    SpdpBatchH bt;
-    if (batch_build(&bt, ctx, sc, probs, n_probs, true)) return -1;
-    return batch_deliver(&bt, 1, out);
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    HStats hs;
+    return deliver(st, 1, out, hs);
 }
+
+struct SpdpBatchH {
+    HStore st;
+    HStats last;
+    int64_t cells = 0;
+};
 
 SpdpBatchH* spdp_batch_upload_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs)
 {
     if (!ctx || !sc || !probs || n_probs < 0) return nullptr;
     SpdpBatchH* bt = new SpdpBatchH();
-    if (batch_build(bt, ctx, sc, probs, n_probs, true)) { delete bt; return nullptr; }
+    if (bt->st.upload(ctx, sc, probs, n_probs)) { delete bt; return nullptr; }
+    for (int i = 0; i < n_probs; ++i) {
+        SpdpWindow w;
+        spdp_stripe31(&probs[i], sc->sh, &w);
+        bt->cells += spdp_cells_h(&probs[i], &w);
+    }
     return bt;
 }
 void spdp_batch_free_h(SpdpBatchH* bt) { delete bt; }
@@ -438,8 +714,9 @@ int64_t spdp_batch_cells_h(const SpdpBatchH* bt) { return bt ? bt->cells : 0; }
 int spdp_batch_align_h(SpdpBatchH* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells)
 {
     if (!bt) return -1;
-    const int rc = batch_deliver(bt, 1, out);
-    if (kernel_ms) *kernel_ms = bt->sweep_ms;
-    if (kernel_cells) *kernel_cells = bt->cells;
+    bt->last = HStats();
+    const int rc = deliver(bt->st, 1, out, bt->last);
+    if (kernel_ms) *kernel_ms = bt->last.fwd_ms + bt->last.udh_ms;
+    if (kernel_cells) *kernel_cells = bt->last.fwd_cells + bt->last.udh_cells;
     return rc;
 }

@@ -15,6 +15,7 @@
 //                    substitution score outside [b_left + 3, b_right + 2]).
 //   aux      short4  {sigS, sigT, sigE, sig5} raw per position: boundary set-up / end selection
 //   bnd      int2    {H, F} by diagonal r = n - 3m: entry r - lw + 3 (hv / fv of fwd2h1_simd.h:335-338)
+//   bnd (linear-space engine) int4 {H, F, Hlink, Flink}
 //   tb       uint16  traceback codes in the reference's own Anti_rhomb_coord<SHORT> layout, step 3:
 //                    cell (m, n) at ((3 (m - a_left) + n - b_left) * m_width + m - a_left)
 #ifndef SPDP_H_DEV_H_
@@ -46,11 +47,14 @@ struct DevProblemH {
     int32_t a_exgl, a_exgr, b_exgl, b_exgr;
     int32_t m_width, n_width;
     int32_t col_len;
+    int32_t n_im;                  // linear-space engine: number of intermediate rows
     int64_t a_off;
     int64_t col_off;               // into cols / aux
     int64_t bnd_off;               // into bnd (entries)
     int64_t tb_off;                // into tb (uint16 elements)
     int64_t tb_size;               // m_width * n_width + 32, the reference's allocation
+    int64_t imd_off;               // linear-space engine: into imd (ints), 5 * width per intermediate row:
+                                   //   hlnk[2][width], vlnk[2][width], event[width], index r - lw + 1
     int64_t cells;
 };
 
@@ -58,7 +62,7 @@ struct DevResultH {
     int32_t score;                 // what forwardH1_wip returns (nevsel unless a local end was tracked)
     int32_t mr, nr;                // start cell of the traceback
     int32_t maxt, maxr;            // fhlastH1's choice
-    int32_t pad[3];
+    int32_t pad[3];                // pad[0]: linear-space engine: link of the end cell (maxh.ulk)
 };
 
 #endif

@@ -28,6 +28,31 @@ struct HWalkArgs {
     int                skl_cap;
 };
 
+struct HUdhArgs {
+    const DevScoringH* sc;
+    const DevProblemH* probs;
+    int                n_probs;
+    const uint8_t*     a_codes;
+    const int4*        cols;
+    const short4*      aux;
+    int4*              bnd;
+    int*               imd;
+    DevResultH*        res;
+};
+
+struct HCposArgs {
+    const DevProblemH* probs;
+    int                n_probs;
+    int*               imd;
+    const DevResultH*  res;
+    int*               cpos;       // per problem cpos_stride ints ((n_im_max + 1) Dim10 rows)
+    int*               ranges;     // per problem 4 ints
+    int*               scores;
+    int                cpos_stride;
+};
+
+extern "C" hipError_t spdh_launch_udh(const HUdhArgs* a, int spj, int pen_cap, hipStream_t s);
+extern "C" hipError_t spdh_launch_cpos(const HCposArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t s);
 extern "C" hipError_t spdh_launch_walk(const HWalkArgs* a, hipStream_t s);
 #endif

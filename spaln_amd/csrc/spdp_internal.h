@@ -83,7 +83,7 @@ enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSK
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
-    DevPool pool[6];                 // one pool per engine flavour (they coexist in a pipeline); [5] = aa x genome path
+    DevPool pool[7];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;

@@ -23,7 +23,7 @@ EXPORTS = [
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
     "spdp_align_s", "spdp_free_alignments", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
-    "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h",
+    "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
 ]
 
@@ -58,6 +58,8 @@ def load_library() -> C.CDLL:
     lib.spdp_cells_h.restype = C.c_int64
     for f in ("spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_wip_udh_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_batch_upload_h.restype = C.c_void_p
     lib.spdp_batch_upload_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.spdp_batch_free_h.argtypes = [C.c_void_p]
@@ -174,6 +176,17 @@ class Engine:
     def align_h(self, sc, ps):
         """alignH_ng (-Q0): [flags, n, corners...] as rows of (m, n) after the header row."""
         return self._alignments_h(self.lib.spdp_align_h, sc, ps, "spdp_align_h")
+
+    def wip_udh_h(self, sc, ps, n_im: int):
+        """SimdAln2h1::hirschbergH1_wip: (scores, cpos rows, written-back ranges)"""
+        n = len(ps)
+        scores = np.zeros(n, dtype=np.int32)
+        cpos = np.zeros((n, n_im + 1, 10), dtype=np.int32)
+        ranges = np.zeros((n, 4), dtype=np.int32)
+        self._check(self.lib.spdp_wip_udh_h(self.ctx, C.byref(sc), ps.array(), n, n_im,
+                                            scores.ctypes.data, cpos.ctypes.data, ranges.ctypes.data),
+                    "spdp_wip_udh_h")
+        return scores, cpos, ranges
 
     def homscore_h(self, sc, ps) -> np.ndarray:
         out = np.zeros(len(ps), dtype=np.int32)

@@ -150,3 +150,76 @@ def test_loaded_gpu_against_oracle(eng):
             bad.append((i, (p.a_left, p.a_right, p.b_left, p.b_right), score, s, flag, oflag,
                         skl.ravel().tolist()[:10], oskl.ravel().tolist()[:10]))
     assert not bad, bad[:4]
+
+
+def _udh_cases():
+    import re
+    out = []
+    for f in H_FILES:
+        if _name(f) in LOCAL:
+            continue
+        fx = spdg.load(f)
+        for k in fx:
+            m = re.match(r"wip_(qn|q1)_udh(\d+)_scr", k)
+            if m:
+                out.append((f, m.group(1), int(m.group(2))))
+    return out
+
+
+def test_hirschberg_h1_wip_goldens(eng):
+    """score, cpos rows and written-back ranges of hirschbergH1_wip, every (case, model, n_im)"""
+    bad = []
+    for path, tag, n_im in _udh_cases():
+        fx = spdg.load(path)
+        sc = spdg.scoring_h(fx, nquant=None if tag == "qn" else 1)
+        ps, _ = spdg.problem_h(fx)
+        scores, cpos, ranges = eng.wip_udh_h(sc, ps, n_im)
+        ok = (int(scores[0]) == int(fx[f"wip_{tag}_udh{n_im}_scr"][0])
+              and cpos[0].ravel().tolist() == fx[f"wip_{tag}_udh{n_im}_cpos"].tolist()
+              and ranges[0].tolist() == fx[f"wip_{tag}_udh{n_im}_rng"][:4].tolist())
+        if not ok:
+            bad.append((_name(path), tag, n_im, int(scores[0]), ranges[0].tolist(), cpos[0][:2].tolist(),
+                        fx[f"wip_{tag}_udh{n_im}_cpos"][:20].tolist()))
+    assert not bad, bad[:3]
+
+
+def test_udh_ladder_against_oracle(eng):
+    """alignH_ng forced into the linear-space branch (small MaxVmfSpace) on sub-ranges, vs the oracle ladder"""
+    from oracle import oracle, host_logic_h as hh
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_450aa_auto.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 79)
+    for vmf, ubh in ((1500000, 0), (600000, 0), (300000, 3), (150000, 0)):
+        sc = spdg.scoring_h(fx, max_vmf_space=vmf, ubh=ubh)
+        ps = abi.ProblemSetH()
+        for i in range(24):
+            al = int(rng.integers(0, 100))
+            ar = int(rng.integers(al + 200, q["a_right"] + 1))
+            bl = int(rng.integers(0, 500))
+            br = int(rng.integers(max(bl + 3 * (ar - al), q["b_right"] - 1500), q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 2 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, ar, bl, br, exg, exin=(q["b_left"], q["b_right"]))
+        res = eng.align_h(sc, ps)
+        bad = []
+        n_udh = sum(2.0 * (p.a_right - p.a_left) * (p.b_right - p.b_left + 3 * (p.a_right - p.a_left)) >= vmf
+                    for p in ps.items)
+        assert n_udh >= 20                                   # the linear-space branch is what runs
+        assert sum(f == 0 for _, _, f in res) >= 16
+        for i, (p, (score, skl, flag)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = hh.align_h(sc, p)
+                wflag = 0
+            except hh.ReferenceUndefined:
+                ws, wskl, wflag = None, None, -2
+            except hh.ReferenceFatal:
+                ws, wskl, wflag = None, None, -1
+            except hh.NotRestated:
+                ws, wskl, wflag = None, None, 1
+            ok = flag == wflag
+            if wflag == 0:
+                ok = ok and score == ws and skl.ravel().tolist() == (wskl or [])
+            if not ok:
+                bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, wflag, score, ws,
+                            skl.ravel().tolist()[:12], (wskl or [])[:12]))
+        assert not bad, bad[:3]

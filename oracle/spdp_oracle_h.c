@@ -465,9 +465,10 @@ static void h_sweep(HEng* e)
                     const int pk = 2 * f3 + k2;
                     S3[pk][0] = phase < 2 ? p->sig3[n - phase] : MIN_SSV;
                     P3[pk][0] = accpr_code[phase + 1];
-                    int ss[NELEM], ph[NELEM];
-                    for (int k = 0; k < NELEM; ++k) { ss[k] = S3[pk][k]; ph[k] = P3[pk][k]; }
+                    int ss[NELEM], ph[NELEM], any = 0;
+                    for (int k = 0; k < NELEM; ++k) { ss[k] = S3[pk][k]; ph[k] = P3[pk][k]; any |= ph[k]; }
                     for (int k = 0; k < NELEM; ++k) { S3[pk][k + 1] = ss[k]; P3[pk][k + 1] = ph[k]; }
+                    if (!any) continue;                                 /* AllZero(ph_v), :224 */
                     for (int f = k2 ? 2 : 0; f < 3; ++f)
                         for (int k = 0; k < NELEM; ++k) {
                             int x = sadd(hiv[f][k], ss[k]);

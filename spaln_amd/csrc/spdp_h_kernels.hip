@@ -347,16 +347,41 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                         const int cl0 = hil0, cl1 = hil1, cl2 = hil2;
                         const s16 shiv = (c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2);
                         const int shil = (c0 == 1u) ? cl0 : ((c0 == 2u) ? cl1 : cl2);
-                        s16 x = sadd(sadd(shiv, s3_0), pen_of(shil));
-                        m = (c0 != 0u) && (shil > llmt) && (x > h);
-                        h = m ? x : h;
-                        pb = m ? (int) (12u + c0) : pb;
-                        ab = m;
-                        x = sadd(sadd(hiv2, s3_1), pen_of(hil2));
-                        m = (fl & 4u) && (hil2 > llmt) && (x > h);
-                        h = m ? x : h;
-                        pb = m ? C_ACCP : pb;
-                        ab = ab || m;
+                        const s16 x0 = sadd(sadd(shiv, s3_0), pen_of(shil));
+                        const s16 x1 = sadd(sadd(cv2, s3_1), pen_of(cl2));
+                        // A score already below `nevsel` is LIFTED to it by the reference's non-matching
+                        // blends (`Blend(qv, ninf, ..)` then `Cmp_gt(qv, hv)`, :237-243) whenever the pipe
+                        // is not skipped as a whole (`AllZero(ph_v)`, :224).  Only dead cells can be that
+                        // low, so the three-blend form runs only when the wave holds one.
+                        if (__builtin_amdgcn_ballot_w64(h < (s16) SPDH_NEV) == 0ull) {
+                            m = (c0 != 0u) && (shil > llmt) && (x0 > h);
+                            h = m ? x0 : h;
+                            pb = m ? (int) (12u + c0) : pb;
+                            ab = m;
+                            m = (fl & 4u) && (cl2 > llmt) && (x1 > h);
+                            h = m ? x1 : h;
+                            pb = m ? C_ACCP : pb;
+                            ab = ab || m;
+                        } else {
+                            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(c0 != 0u);
+                            const unsigned long long b1 = __builtin_amdgcn_ballot_w64((fl & 4u) != 0u);
+                            const unsigned long long rowm = 0xffffull << (16 * g);
+                            const bool any0 = (b0 & rowm) != 0ull, any1 = (b1 & rowm) != 0ull;
+#pragma unroll
+                            for (int f = 0; f < 3; ++f) {
+                                const int lf = f == 0 ? cl0 : (f == 1 ? cl1 : cl2);
+                                const s16 cand = (c0 == (unsigned) (f + 1) && lf > llmt) ? x0 : (s16) SPDH_NEV;
+                                m = any0 && cand > h;
+                                h = m ? cand : h;
+                                pb = m ? (C_ACCM + f) : pb;
+                                ab = ab || (m && c0 != 0u);
+                            }
+                            const s16 cand = ((fl & 4u) && cl2 > llmt) ? x1 : (s16) SPDH_NEV;
+                            m = any1 && cand > h;
+                            h = m ? cand : h;
+                            pb = m ? C_ACCP : pb;
+                            ab = ab || (m && (fl & 4u));
+                        }
                     }
                     if constexpr (LOCAL) {
                         // local left end (:243-247; accscr stays 0 without re-basing), right end (:250-258)

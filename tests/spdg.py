@@ -43,7 +43,7 @@ def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
 
 def problem(fx: dict, ps: abi.ProblemSet | None = None):
     q = fx["prm"]
-    ps = ps or abi.ProblemSet()
+    ps = abi.ProblemSet() if ps is None else ps
     extra = {}
     if "dinc5" in fx:
         extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
@@ -75,7 +75,7 @@ def scoring_h(fx: dict, nquant: int | None = None, **over) -> abi.ScoringH:
 
 def problem_h(fx: dict, ps: abi.ProblemSetH | None = None):
     q = fx["prm"]
-    ps = ps or abi.ProblemSetH()
+    ps = abi.ProblemSetH() if ps is None else ps
     good = fx["good"]
     # the harness builds the Exinon on the active range: good(n) <=> b_left - 1 <= n < b_right
     idx = np.nonzero(good)[0]

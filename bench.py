@@ -62,6 +62,48 @@ def _cpu_align_one(item):
     return cells[0]
 
 
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "spaln")
+REF_TAB = os.path.join(ROOT, "oracle", "_ref", "table")
+
+
+def _ref_available():
+    return os.path.exists(REF_BIN) and os.path.exists(os.path.join(REF_TAB, "mdm_mtx"))
+
+
+def _ref_cli_one(item):
+    """cpu_baseline worker, kind "reference": the compiled reference itself (oracle/_ref/spaln, built by
+    oracle/ref_build/Makefile from the sources where they lie) on one (window, query) pair:
+    -Q0 (block search off: the whole window goes through the DP ladder), -A2 (the `_wip` engines)."""
+    import subprocess
+    import tempfile
+    from spaln_amd import synth
+    window_ascii, query_ascii, protein = item
+    with tempfile.TemporaryDirectory() as td:
+        gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
+        synth.write_fasta(gf, "win", window_ascii)
+        synth.write_fasta(qf, "qry", query_ascii)
+        cmd = [REF_BIN, "-Q0", "-A2", "-pw", "-O4", "-t1"] + ([] if protein else ["-S1"]) + [gf, qf]
+        r = subprocess.run(cmd, env=dict(os.environ, ALN_TAB=REF_TAB), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+    return r.returncode
+
+
+def _ref_baseline(pairs, protein, band_cells, cell_ratio):
+    """times the reference CLI on `pairs` with one process per host core; cells = band cells of the
+    sample x (engine cells / band cells) of the GPU run (the reference runs the same ladder)"""
+    import multiprocessing as mp
+    ncores = max(1, os.cpu_count() or 1)
+    used = min(ncores, len(pairs))
+    tc = time.perf_counter()
+    with mp.Pool(used) as pool:
+        rcs = pool.map(_ref_cli_one, [(w, q, protein) for w, q in pairs])
+    cdt = time.perf_counter() - tc
+    ok = sum(1 for r in rcs if r == 0)
+    return {"value": round(band_cells * cell_ratio / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "reference",
+            "sample": f"first {len(pairs)} queries through the compiled reference (oracle/_ref/spaln -Q0 -A2 -t1, AVX2 build), "
+                      f"one process per query on {used} cores, {ok} ok; wall {cdt:.1f} s incl. process start-up"}
+
+
 def _cpu_align_h_one(item):
     """cpu_baseline worker of the aa x genome workload: one query through the oracle's alignH_ng"""
     from spaln_amd import abi, defaults, synth
@@ -133,12 +175,22 @@ def main_c3(args):
         achieved = cells * bpc / (k_ms * 1e-3) / 1e9
         import multiprocessing as mp
         ncores = max(1, os.cpu_count() or 1)
-        ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else ncores, len(batch)))
-        tc = time.perf_counter()
-        with mp.Pool(min(ncores, ns)) as pool:
-            ccells = sum(pool.map(_cpu_align_h_one, [(batch[i][0].query, batch[i][1]) for i in range(ns)]))
-        cdt = time.perf_counter() - tc
-        used = min(ncores, ns)
+        ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
+        if _ref_available() and not args.cpu_port:
+            from oracle import oracle
+            band = 0
+            for i in range(ns):
+                band += oracle.cells_h(ps.items[i], oracle.stripe31(ps.items[i], sc.sh))
+            cpu_base = _ref_baseline([(batch[i][0].window, batch[i][0].query) for i in range(ns)], True, band,
+                                     cells / max(1, bt.cells()))
+        else:
+            tc = time.perf_counter()
+            with mp.Pool(min(ncores, ns)) as pool:
+                ccells = sum(pool.map(_cpu_align_h_one, [(batch[i][0].query, batch[i][1]) for i in range(ns)]))
+            cdt = time.perf_counter() - tc
+            used = min(ncores, ns)
+            cpu_base = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "port",
+                        "sample": f"first {ns} queries, oracle alignH_ng restatement, one query per process on {used} cores"}
         out = {
             "metric": "GCUPS (DP cell updates/s), protein->genome spliced DP", "value": round(total_cells * args.steps / dt / 1e9, 3),
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,8 +208,7 @@ def main_c3(args):
                          "traffic_source": "profiles/r01_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
                          "note": "integer-VALU bound recurrence (int16 saturating lanes); HBM fraction reported as asked"},
-            "cpu_baseline": {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "port",
-                             "sample": f"first {ns} queries, oracle alignH_ng restatement, one query per process on {used} cores"},
+            "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)
     bt.free()
@@ -176,6 +227,8 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = 2 per host core)")
     ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
+    ap.add_argument("--cpu-port", action="store_true",
+                    help="time the oracle port as the CPU baseline even when oracle/_ref/spaln is present")
     args = ap.parse_args()
     if not args.queries:
         args.queries = 10000
@@ -247,11 +300,25 @@ def main():
         import multiprocessing as mp
         ncores = max(1, os.cpu_count() or 1)
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
-        tc = time.perf_counter()
-        with mp.Pool(min(ncores, ns)) as pool:
-            ccells = sum(pool.map(_cpu_align_one, [batch[i][:4] for i in range(ns)]))
-        cdt = time.perf_counter() - tc
-        used = min(ncores, ns)
+        if _ref_available() and not args.cpu_port:
+            from oracle import oracle
+            dec = np.zeros(32, dtype=np.uint8)
+            for ch, code in defaults.CODE_OF.items():
+                dec[code] = ch
+            band = 0
+            for i in range(ns):
+                band += oracle.cells(ps.items[i], oracle.stripe(ps.items[i], sc.sh))
+            cpu_base = _ref_baseline([(dec[batch[i][0]], dec[batch[i][1]]) for i in range(ns)], False, band,
+                                     cells / max(1, bt.cells()))
+        else:
+            tc = time.perf_counter()
+            with mp.Pool(min(ncores, ns)) as pool:
+                ccells = sum(pool.map(_cpu_align_one, [batch[i][:4] for i in range(ns)]))
+            cdt = time.perf_counter() - tc
+            used = min(ncores, ns)
+            cpu_base = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "port",
+                        "sample": f"first {ns} queries of the batch, oracle alignS_ng restatement "
+                                  f"(UDH + slab tracebacks), one query per process on {used} cores"}
         out = {
             "metric": "GCUPS (DP cell updates/s), cDNA->genome spliced DP",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -272,10 +339,7 @@ def main():
                          "traffic_source": "profiles/r01_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdp_sweep<FL_UDH>", "kernel_ms": round(k_ms, 3),
                          "note": "integer-VALU bound recurrence; HBM fraction reported as asked"},
-            "cpu_baseline": {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used,
-                             "kind": "port",
-                             "sample": f"first {ns} queries of the batch, oracle alignS_ng restatement "
-                                       f"(UDH + slab tracebacks), one query per process on {used} cores"},
+            "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)
     bt.free()

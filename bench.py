@@ -66,6 +66,19 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "spaln")
 REF_TAB = os.path.join(ROOT, "oracle", "_ref", "table")
 
 
+def _host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but grant the container 16 CPUs worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _ref_available():
     return os.path.exists(REF_BIN) and os.path.exists(os.path.join(REF_TAB, "mdm_mtx"))
 
@@ -99,7 +112,7 @@ def _ref_baseline(pairs, protein, band_cells, cell_ratio):
     and FASTA writing excluded, the CLI's own start-up included); cells = band cells of the sample x
     (engine cells / band cells) of the GPU run (the reference runs the same ladder)"""
     import multiprocessing as mp
-    ncores = max(1, os.cpu_count() or 1)
+    ncores = _host_cores()
     used = min(ncores, len(pairs))
     chunks = [[(w, q, protein) for w, q in pairs[c::used]] for c in range(used)]
     with mp.Pool(used) as pool:
@@ -182,7 +195,7 @@ def main_c3(args):
         bpc = 32.0 / 64.0 + 2.0            # 16 B record + 8 B boundary read + 8 B write per 64 rows x 1 nt; 2 B code / cell
         achieved = cells * bpc / (k_ms * 1e-3) / 1e9
         import multiprocessing as mp
-        ncores = max(1, os.cpu_count() or 1)
+        ncores = _host_cores()
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if _ref_available() and not args.cpu_port:
             from oracle import oracle
@@ -307,7 +320,7 @@ def main():
         # CPU baseline: the oracle's alignS_ng restatement (int32, one query per process) on all
         # host cores of this box, bounded sample
         import multiprocessing as mp
-        ncores = max(1, os.cpu_count() or 1)
+        ncores = _host_cores()
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if _ref_available() and not args.cpu_port:
             from oracle import oracle

@@ -199,7 +199,7 @@ def main_c3(args):
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if _ref_available() and not args.cpu_port:
             from oracle import oracle
-            ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 16 * ncores, len(batch)))
+            ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 64 * ncores, len(batch)))
             band = 0
             for i in range(ns):
                 band += oracle.cells_h(ps.items[i], oracle.stripe31(ps.items[i], sc.sh))
@@ -324,7 +324,7 @@ def main():
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if _ref_available() and not args.cpu_port:
             from oracle import oracle
-            ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 8 * ncores, len(batch)))
+            ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 32 * ncores, len(batch)))
             dec = np.zeros(32, dtype=np.uint8)
             for ch, code in defaults.CODE_OF.items():
                 dec[code] = ch

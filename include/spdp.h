@@ -143,6 +143,41 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc,
                  const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
 void spdp_free_alignments(SpdpAlignment* out, int n);
 
+/* ---- rescoring: skl_rngS_ng (src/fwd2s1.cc:446) ---------------------------------------------- */
+/* The score the CLI prints and the per-exon records come from a walk over the finished corner
+ * list, not from the DP engines.  Needs the exact-model inputs (SpdpScoring.intpen / t53,
+ * SpdpProblem.dinc).  Cigar / Vulgar / SAM strings are not produced. */
+typedef struct SpdpExon {            /* EISCR, src/gsinfo.h:262-284; all scores raw ints */
+    int32_t left, right;             /* genomic range of the exon                                  */
+    int32_t rleft, rright;           /* query range                                                */
+    int32_t mch, mmc, gap, unp;      /* matches, mismatches, gaps, unpaired residues in the exon   */
+    int32_t mch5, mmc5, gap5, unp5;  /* ... within jneibr positions after its 5' end               */
+    int32_t mch3, mmc3, gap3, unp3;  /* ... within jneibr positions before its 3' end              */
+    int32_t phs;
+    int32_t escr, iscr;              /* exon score, score of the intron that follows               */
+    int32_t sig3, sig5;              /* acceptor signal at the exon start, donor signal at its end */
+} SpdpExon;
+
+typedef struct SpdpRescoreParams {
+    int32_t codonk1;                 /* PwdB::codonk1: GapPenalty switches to LongGOP/LongGEP above it (src/aln.h:275) */
+    int32_t minl;                    /* IntronPrm.minl: shorter deletions are never introns         */
+    int32_t jneibr;                  /* alprm2.jneibr: junction neighbourhood (<= 32)               */
+    int32_t lsg;                     /* algmode.lsg: splice-aware                                   */
+} SpdpRescoreParams;
+
+typedef struct SpdpRescored {
+    int32_t   score;                 /* return value of skl_rngS_ng (gsi->scr of the CLI)           */
+    int32_t   mch, mmc, gap, unp, val;   /* Gsinfo::fstat                                           */
+    int32_t   n_exons;               /* records in exons[], including the reference's end marker    */
+    SpdpExon* exons;                 /* Eijnc records; owned by the library until spdp_free_rescored */
+} SpdpRescored;
+
+/* aln[i] is an alignment as spdp_align_s returns it (header record + corners); problems without an
+ * alignment (n_skl < 3) come back with n_exons = 0. */
+int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
+                   const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
+void spdp_free_rescored(SpdpRescored* out, int n);
+
 /* ---- resident batches (benchmarking / pipelines) ------------------------ */
 /* Uploads a batch once; the run calls below then work on HBM-resident inputs
  * (timed region excludes PCIe).  Returns NULL on failure. */

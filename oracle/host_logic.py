@@ -227,3 +227,177 @@ def align_s(sc, p):
     for m, n in s:
         flat += [m, n]
     return scr, flat
+
+
+# ---- skl_rngS_ng (src/fwd2s1.cc:446-693): rescoring of a finished alignment -----------------------
+# The value the CLI prints ("S:") and the per-exon records come from here, not from the engines.
+# Restated without the output-format side channels (Cigar / Vulgar / SAM) and without the query's
+# intron-position profile (`PfqItr`: empty unless the query carries one).
+EIJ_FIELDS = ["left", "right", "rleft", "rright", "mch", "mmc", "gap", "unp", "mch5", "mmc5", "gap5", "unp5",
+              "mch3", "mmc3", "gap3", "unp3", "phs", "escr", "iscr", "sig3", "sig5"]
+ENDRNG = 2 ** 31 - 1
+
+
+def skl_rng_s(sc, p, skl, *, codonk1, minl, jneibr, lsg=1):
+    """skl = [flags, n, m1, n1, ...] as align_s returns it.  Returns (h, fstat[5], [21-int records])."""
+    a = _codes(p.a, p.a_len)
+    b = _codes(p.b, p.b_len)
+    sig5 = np.ctypeslib.as_array(C.cast(p.sig5, C.POINTER(C.c_int16)), shape=(p.b_len + 1,))
+    sig3 = np.ctypeslib.as_array(C.cast(p.sig3, C.POINTER(C.c_int16)), shape=(p.b_len + 1,))
+    dinc = _codes(p.dinc, p.b_len + 1)
+    intpen = np.ctypeslib.as_array(C.cast(sc.intpen, C.POINTER(C.c_int16)), shape=(sc.intpen_len,))
+    mtx = np.array(sc.mtx[:sc.mtx_dim * sc.mtx_dim]).reshape(sc.mtx_dim, sc.mtx_dim)
+
+    def gap_penalty(i):                                  # PwdB::GapPenalty, src/aln.h:275
+        if i == 0:
+            return 0
+        return sc.lgop + i * sc.lgep if i > codonk1 else sc.gop + i * sc.gep
+
+    def spjscr(n5, n3):                                  # SpJunc::spjscr = IntPen(len) + sig53(IE53)
+        return int(intpen[n3 - n5]) + int(sig3[n3]) + int(sc.t53[16 * (dinc[n5] >> 4) + (dinc[n3] & 15)])
+
+    corners = [(skl[2 + 2 * i], skl[3 + 2 * i]) for i in range(skl[1])]
+    num = len(corners)
+    w = 0
+    h = ha = hb = 0
+    s5 = s3 = 0
+    insert = deletn = intlen = preint = 0
+    fst = dict(mch=0, mmc=0, gap=0, unp=0, val=0)
+    pst = dict(fst)
+    psp = 0
+    rbuf = dict.fromkeys(EIJ_FIELDS, 0)
+    recs = []
+    que = [dict(fst) for _ in range(jneibr)]            # Eijnc(true): ring of the last jneibr statistics
+    qpos = [0]
+
+    def shift(near):                                     # Eijnc::shift, src/gsinfo.cc:1255
+        if near:
+            for k in ("mch", "mmc", "unp", "gap"):
+                rbuf[k + "5"] = fst[k] - que[qpos[0]][k]
+        que[qpos[0]] = dict(fst)
+        qpos[0] = (qpos[0] + 1) % jneibr
+
+    def store(prv, near):                                # Eijnc::store, :1237
+        for k in ("mch", "mmc", "gap", "unp"):
+            rbuf[k] = fst[k] - prv[k]
+        if near:
+            for k in ("mch", "mmc", "gap", "unp"):
+                rbuf[k + "5"] = rbuf[k]
+        for k in ("mch", "mmc", "unp", "gap"):
+            rbuf[k + "3"] = fst[k] - que[qpos[0]][k]
+
+    def push():
+        recs.append([int(rbuf[k]) for k in EIJ_FIELDS])
+
+    if num >= 2 and corners[1][1] == corners[0][1] and p.b_exgl:
+        w += 1
+        num -= 1
+    m, n = corners[w]
+    ai, bi = m, n                                        # as = a->at(m), bs = b->at(n)
+    rbuf["left"], rbuf["rleft"], rbuf["iscr"], rbuf["sig3"] = n, m, abi.NEVSEL, 0
+    left = num
+    while left > 1:
+        left -= 1
+        w += 1
+        wm, wn = corners[w]
+        mi = wm - m
+        if mi and insert:
+            j = p.a_exgl and m == p.a_left
+            x = 0 if j else gap_penalty(insert)
+            xi = abi.NEVSEL
+            if intlen:
+                insert -= intlen
+                xi = rbuf["iscr"] + gap_penalty(insert)
+            if xi >= x:                                  # intron
+                hb = ha
+                if rbuf["right"] - rbuf["left"] > 0:
+                    push()
+                rbuf["left"] = rbuf["right"] + intlen
+                rbuf["rleft"] = m
+                rbuf["sig3"] = s3
+                rbuf["iscr"] = abi.NEVSEL
+                h += xi
+                insert -= preint
+            else:
+                h += x
+            if insert:
+                insert = intlen = preint = 0
+        ni = wn - n
+        if ni and deletn:
+            if not (p.b_exgl and n == p.b_left):
+                h += gap_penalty(deletn)
+                fst["gap"] += 1
+            ai += deletn
+            deletn = 0
+        i = mi - ni
+        d = ni if i >= 0 else mi
+        if d:
+            m += d
+            x = 0
+            for _ in range(d):
+                shift(psp == jneibr)
+                psp += 1
+                x += int(mtx[a[ai], b[bi]])
+                if a[ai] == b[bi]:
+                    fst["mch"] += 1
+                else:
+                    fst["mmc"] += 1
+                ai += 1
+                bi += 1
+                n += 1
+            h += x
+            fst["val"] += x
+        if i > 0:
+            deletn += i
+            for _ in range(i):
+                shift(psp == jneibr)
+                psp += 1
+                fst["unp"] += 1
+        elif i < 0:
+            i = -i
+            n3 = n + i
+            if lsg and i > minl:
+                s5 = int(sig5[n])
+                s3 = int(sig3[n3])
+                xi = s5 + spjscr(n, n3)
+            else:
+                xi = abi.NEVSEL
+            if xi > gap_penalty(i) and xi > rbuf["iscr"]:
+                preint = insert                         # intron
+                intlen = i
+                rbuf["right"], rbuf["rright"], rbuf["iscr"] = n, m, xi
+                rbuf["escr"] = h + s5 - hb
+                rbuf["sig5"] = s5
+                ha = h + xi - s3
+                store(pst, psp < jneibr)
+                pst = dict(fst)
+                psp = 0
+            elif not p.a_exgl or m != p.a_left:
+                if not insert:
+                    fst["gap"] += 1
+                for _ in range(i):
+                    shift(psp == jneibr)
+                    psp += 1
+                    fst["unp"] += 1
+                    n += 1
+            bi += i
+            insert += i
+        m, n = wm, wn
+    if insert and not (p.a_exgr and m == p.a_right):
+        h += gap_penalty(insert)
+        fst["gap"] += 1
+        fst["unp"] += insert
+    if deletn and not (p.b_exgr and n == p.b_right):
+        h += gap_penalty(deletn)
+        fst["gap"] += 1
+        fst["unp"] += deletn
+    rbuf["escr"] = h - hb
+    rbuf["iscr"] = 0
+    rbuf["sig5"] = 0
+    rbuf["right"], rbuf["rright"] = n, m
+    store(pst, n - rbuf["left"] <= jneibr)
+    push()
+    rbuf["left"] = rbuf["right"] = ENDRNG
+    push()
+    fst["val"] += sc.gop * fst["gap"] + sc.gep * fst["unp"]
+    return h, [fst[k] for k in ("mch", "mmc", "gap", "unp", "val")], recs

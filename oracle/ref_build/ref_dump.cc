@@ -309,6 +309,23 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		VTYPE	rs = skl_rngS_ng((const Seq**) seqs, &gsi, pwd);
 		snprintf(nm, sizeof nm, "rng_scr_A%d", alg);
 		w.put_int(nm, (int) rs);
+		// what the rescoring leaves in Gsinfo: alignment statistics and the per-exon records
+		std::vector<int> fs = {(int) gsi.fstat.mch, (int) gsi.fstat.mmc, (int) gsi.fstat.gap,
+		    (int) gsi.fstat.unp, (int) gsi.fstat.val, gsi.noeij, alprm2.jneibr, (int) algmode.lsg};
+		snprintf(nm, sizeof nm, "rng_fstat_A%d", alg);
+		w.put_i32(nm, fs);
+		std::vector<int> ej;
+		if (gsi.eijnc) {
+		    const EISCR* e = gsi.eijnc->begin();
+		    for (int i = 0; i < gsi.eijnc->size(); ++i, ++e) {
+			const int rec[21] = {e->left, e->right, e->rleft, e->rright, e->mch, e->mmc, e->gap, e->unp,
+			    e->mch5, e->mmc5, e->gap5, e->unp5, e->mch3, e->mmc3, e->gap3, e->unp3, e->phs,
+			    (int) e->escr, (int) e->iscr, (int) e->sig3, (int) e->sig5};
+			ej.insert(ej.end(), rec, rec + 21);
+		    }
+		}
+		snprintf(nm, sizeof nm, "rng_eij_A%d", alg);
+		w.put_i32(nm, ej);
 	    }
 	}
 	return 0;

@@ -65,6 +65,21 @@ class Alignment(C.Structure):
     _fields_ = [("score", C.c_int32), ("n_skl", C.c_int32), ("skl", C.POINTER(Skl))]
 
 
+class Exon(C.Structure):                 # SpdpExon / EISCR
+    _fields_ = [(k, C.c_int32) for k in
+                ("left", "right", "rleft", "rright", "mch", "mmc", "gap", "unp", "mch5", "mmc5", "gap5", "unp5",
+                 "mch3", "mmc3", "gap3", "unp3", "phs", "escr", "iscr", "sig3", "sig5")]
+
+
+class RescoreParams(C.Structure):
+    _fields_ = [("codonk1", C.c_int32), ("minl", C.c_int32), ("jneibr", C.c_int32), ("lsg", C.c_int32)]
+
+
+class Rescored(C.Structure):
+    _fields_ = [("score", C.c_int32), ("mch", C.c_int32), ("mmc", C.c_int32), ("gap", C.c_int32),
+                ("unp", C.c_int32), ("val", C.c_int32), ("n_exons", C.c_int32), ("exons", C.POINTER(Exon))]
+
+
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,

@@ -70,6 +70,27 @@ extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipSt
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
+// skl_rngS_ng on the device (spdp_rescore.hip): one thread per query
+struct RescoreArgs {
+    const DevScoring* sc;
+    const DevProblem* probs;
+    int               n_probs;
+    const uint8_t*    a_codes;
+    const int2*       cols;
+    const uint8_t*    aux;
+    const int16_t*    intpen;
+    int               intpen_len;
+    const int2*       skl;        // corner lists without header, query i at skl_off[i], skl_cnt[i] corners
+    const int64_t*    skl_off;
+    const int*        skl_cnt;
+    const int64_t*    rec_off;    // first exon record of query i (21 ints each)
+    int*              out_hdr;    // per query 8 ints: h, mch, mmc, gap, unp, val, n_records, 0
+    int*              out_rec;
+    int               gop, gep, lgop, lgep, codonk1, minl, jneibr, lsg, ipen;
+    int16_t           t53[256];
+};
+extern "C" hipError_t spdp_launch_rescore(const RescoreArgs* a, hipStream_t s);
+
 // grow-only device allocations reused across launches (hipMalloc / hipFree of multi-GB
 // work buffers per batch costs seconds)
 struct DevPool {
@@ -83,7 +104,7 @@ enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSK
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
-    DevPool pool[7];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path
+    DevPool pool[8];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path, [7] = rescoring
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;

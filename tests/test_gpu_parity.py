@@ -164,3 +164,46 @@ def test_scalar_engines_vs_reference(eng, fx):
         fin = host_logic.trim_skl(host_logic.std_skl(rec), p) if len(rec) >= 2 else []
         flat = ([1, len(fin)] + [x for mn in fin for x in mn]) if fin else []
         assert flat == fx["aln_skl_A0"].tolist()
+
+
+def test_skl_rng_s_goldens(eng):
+    """spdp_skl_rng_s (skl_rngS_ng on the device) on the reference's own corner lists: total score,
+    alignment statistics and every per-exon record, for all four engine selectors' alignments"""
+    bad = []
+    n_checked = 0
+    for f in golden_files():
+        fx = spdg.load(f)
+        for alg in (0, 1, 2, 3):
+            if f"rng_eij_A{alg}" not in fx:
+                continue
+            sc = spdg.scoring(fx, nquant=(1 if alg == 3 else None))
+            ps, p = spdg.problem(fx)
+            fs = fx[f"rng_fstat_A{alg}"]
+            (score, fst, ex), = eng.skl_rng_s(sc, ps, [fx[f"aln_skl_A{alg}"].reshape(-1, 2)],
+                                               codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"],
+                                               jneibr=int(fs[6]), lsg=int(fs[7]))
+            ok = (score == int(fx[f"rng_scr_A{alg}"][0]) and fst == [int(x) for x in fs[:5]]
+                  and ex.tolist() == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist())
+            n_checked += 1
+            if not ok:
+                bad.append((f.split("/")[-1], alg, score, int(fx[f"rng_scr_A{alg}"][0]), fst, fs[:5].tolist()))
+    assert n_checked >= 100 and not bad, bad[:4]
+
+
+def test_align_then_rescore_batch(eng):
+    """the product pipeline: spdp_align_s then spdp_skl_rng_s on its output, a whole batch per call"""
+    fxs = [spdg.load(f) for f in golden_files() if "local" not in f and "tiny" not in f and "exg" not in f
+           and "narrow" not in f]
+    fxs = [fx for fx in fxs if "rng_eij_A2" in fx and fx["prm"]["sh"] == 100]
+    sc = spdg.scoring(fxs[0])
+    ps = abi.ProblemSet()
+    for fx in fxs:
+        spdg.problem(fx, ps)
+    aln = eng.align_s(sc, ps)
+    fs = fxs[0]["rng_fstat_A2"]
+    res = eng.skl_rng_s(sc, ps, [skl for _, skl in aln], codonk1=fxs[0]["prm"]["codonk1"],
+                        minl=fxs[0]["prm"]["minl"], jneibr=int(fs[6]), lsg=int(fs[7]))
+    assert len(res) == len(fxs) >= 8
+    for fx, (score, fst, ex) in zip(fxs, res):
+        assert score == int(fx["rng_scr_A2"][0])
+        assert ex.tolist() == fx["rng_eij_A2"].reshape(-1, 21).tolist()

@@ -24,3 +24,22 @@ def test_align_s(fx, alg):
     want = fx[f"aln_skl_A{alg}"].tolist()
     assert scr == int(fx[f"aln_scr_A{alg}"][0])
     assert (skl or []) == want
+
+
+
+@pytest.mark.parametrize("alg", [0, 1, 2, 3])
+def test_skl_rng_s_vs_reference(fx, alg):
+    """skl_rngS_ng restated: total score, alignment statistics and per-exon records from the
+    reference's own corner lists (every engine selector leaves the same kind of list)"""
+    from oracle import host_logic
+    if f"rng_eij_A{alg}" not in fx:
+        pytest.skip("no alignment under this selector")
+    sc = spdg.scoring(fx, nquant=(1 if alg == 3 else None))
+    ps, p = spdg.problem(fx)
+    fs = fx[f"rng_fstat_A{alg}"]
+    h, fst, recs = host_logic.skl_rng_s(sc, p, [int(x) for x in fx[f"aln_skl_A{alg}"]],
+                                        codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"],
+                                        jneibr=int(fs[6]), lsg=int(fs[7]))
+    assert h == int(fx[f"rng_scr_A{alg}"][0])
+    assert fst == [int(x) for x in fs[:5]]
+    assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()

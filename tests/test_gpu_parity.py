@@ -192,6 +192,7 @@ def test_skl_rng_s_goldens(eng):
 
 def test_align_then_rescore_batch(eng):
     """the product pipeline: spdp_align_s then spdp_skl_rng_s on its output, a whole batch per call"""
+    from spaln_amd import abi
     fxs = [spdg.load(f) for f in golden_files() if "local" not in f and "tiny" not in f and "exg" not in f
            and "narrow" not in f]
     fxs = [fx for fx in fxs if "rng_eij_A2" in fx and fx["prm"]["sh"] == 100]

@@ -196,7 +196,7 @@ def test_align_then_rescore_batch(eng):
     fxs = [spdg.load(f) for f in golden_files() if "local" not in f and "tiny" not in f and "exg" not in f
            and "narrow" not in f]
     fxs = [fx for fx in fxs if "rng_eij_A2" in fx and fx["prm"]["sh"] == 100]
-    sc = spdg.scoring(fxs[0])
+    sc = spdg.scoring(max(fxs, key=lambda fx: len(fx["intpen"])))     # the table must cover the longest window
     ps = abi.ProblemSet()
     for fx in fxs:
         spdg.problem(fx, ps)

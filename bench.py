@@ -92,6 +92,10 @@ def _ref_cli_chunk(chunk):
     import tempfile
     from spaln_amd import synth
     busy, ok = 0.0, 0
+    # a profiler wrapped around bench.py (rocprofv3) must not instrument the CPU baseline's processes
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
+    env["ALN_TAB"] = REF_TAB
     with tempfile.TemporaryDirectory() as td:
         for window_ascii, query_ascii, protein in chunk:
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
@@ -99,8 +103,7 @@ def _ref_cli_chunk(chunk):
             synth.write_fasta(qf, "qry", query_ascii)
             cmd = [REF_BIN, "-Q0", "-A2", "-pw", "-O4", "-t1"] + ([] if protein else ["-S1"]) + [gf, qf]
             t0 = time.perf_counter()
-            r = subprocess.run(cmd, env=dict(os.environ, ALN_TAB=REF_TAB), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             busy += time.perf_counter() - t0
             ok += r.returncode == 0
     return busy, ok

@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
 PMC_TRAFFIC_BYTES = int((81013809 + 193130163) * 1024)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((39397482 + 147294407) * 1024)
+PMC_TRAFFIC_BYTES_H = int((37826839 + 146710905) * 1024)
 
 
 def _cpu_align_one(item):

@@ -200,7 +200,9 @@ def main_c3(args):
         import multiprocessing as mp
         ncores = _host_cores()
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
-        if _ref_available() and not args.cpu_port:
+        if world > 1:
+            cpu_base = None                                   # timed at N = 1 only
+        elif _ref_available() and not args.cpu_port:
             from oracle import oracle
             ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 64 * ncores, len(batch)))
             band = 0
@@ -325,7 +327,9 @@ def main():
         import multiprocessing as mp
         ncores = _host_cores()
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
-        if _ref_available() and not args.cpu_port:
+        if world > 1:
+            cpu_base = None                                   # timed at N = 1 only
+        elif _ref_available() and not args.cpu_port:
             from oracle import oracle
             ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 32 * ncores, len(batch)))
             dec = np.zeros(32, dtype=np.uint8)

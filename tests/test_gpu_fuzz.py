@@ -1,0 +1,137 @@
+"""Randomised parity: GPU engines vs the oracle on small problems whose EVERYTHING is random --
+sequences, signals, gap / intron parameters, quantile tables, band shoulder, end-gap flags,
+sub-ranges.  The goldens pin the oracle to the reference under its default parameters; this keeps
+the kernels honest everywhere else in the input space."""
+import numpy as np
+import pytest
+
+from spaln_amd import abi, defaults, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from spaln_amd import engine
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def _rand_scoring_s(rng, local=0):
+    nq = int(rng.integers(1, 6))
+    qlen = np.sort(rng.choice(np.arange(30, 1500), size=5, replace=False))
+    qpen = -rng.integers(150, 400, size=5)
+    return defaults.scoring(gop=-int(rng.integers(20, 120)), gep=-int(rng.integers(5, 40)),
+                            ipen=-int(rng.integers(100, 400)), llmt=int(rng.integers(5, 40)),
+                            qm_len=[int(x) for x in qlen], qm_pen=[int(x) for x in qpen], nquant=nq,
+                            sh=int(rng.choice([10, 30, 100])), local=local)
+
+
+def _rand_problem_s(rng, ps):
+    m = int(rng.integers(9, 120))
+    n = int(rng.integers(m + 20, 900))
+    g = synth.make_gene(rng, n_exons=int(rng.integers(1, 4)), mrna_len=max(m, 40), flank=int(rng.integers(10, 80)),
+                        intron_hi=int(rng.integers(80, 400)), sub=float(rng.uniform(0, 0.3)))
+    w, q = defaults.encode(g.window), defaults.encode(g.query)
+    N = w.size + 1
+    s5 = rng.integers(-900, 150, size=N).astype(np.int16)
+    s3 = rng.integers(-900, 150, size=N).astype(np.int16)
+    al = int(rng.integers(0, max(1, q.size // 4)))
+    ar = int(rng.integers(max(al + 9, q.size // 2), q.size + 1))
+    bl = int(rng.integers(0, max(1, w.size // 5)))
+    br = int(rng.integers(max(bl + (ar - al) + 5, w.size // 2), w.size + 1))
+    exg = tuple(int(x) for x in rng.integers(0, 2, size=4))
+    return ps.add(q, w, s5, s3, al, ar, bl, br, exg)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_cdna_engines(eng, seed):
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9000 + seed)
+    for rnd in range(4):
+        sc = _rand_scoring_s(rng)
+        ps = abi.ProblemSet()
+        for _ in range(40):
+            _rand_problem_s(rng, ps)
+        got = eng.wip_scoreonly(sc, ps)
+        assert got.tolist() == [oracle.wip_scoreonly(sc, p) for p in ps.items]
+        for (s, skl), p in zip(eng.wip_forward(sc, ps), ps.items):
+            ws, wskl = oracle.wip_forward(sc, p)
+            assert s == ws and skl.tolist() == wskl.tolist()
+        big = abi.ProblemSet()
+        for p in ps.items:
+            if p.a_right - p.a_left >= 40:
+                big.items.append(p)
+        big._keep = ps._keep
+        if len(big):
+            n_im = int(rng.integers(1, 3))
+            us, ucpos, urng = eng.wip_udh(sc, big, n_im)
+            for i, p in enumerate(big.items):
+                ws, wcpos, wrng = oracle.wip_udh(sc, p, n_im)
+                assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist() and ucpos[i].tolist() == wcpos.tolist()
+
+
+def _rand_scoring_h(rng, local=0):
+    nq = int(rng.integers(1, 6))
+    qlen = np.sort(rng.choice(np.arange(30, 1500), size=5, replace=False))
+    qpen = -rng.integers(250, 600, size=5)
+    return defaults.scoring_h(gop=-int(rng.integers(40, 150)), gep=-int(rng.integers(8, 40)),
+                              gapw1=-int(rng.integers(200, 500)), gapw2=-int(rng.integers(200, 500)),
+                              gapw3=-int(rng.integers(60, 200)), ipen=-int(rng.integers(200, 500)),
+                              llmt=int(rng.integers(5, 40)), qm_len=[int(x) for x in qlen],
+                              qm_pen=[int(x) for x in qpen], nquant=nq, sh=int(rng.choice([5, 20, 100])),
+                              term_codon=int(rng.integers(0, 2)), local=local)
+
+
+def _rand_problem_h(rng, ps):
+    aa = int(rng.integers(10, 90))
+    g = synth.make_protein_gene(rng, n_exons=int(rng.integers(1, 4)), aa_len=aa, flank=int(rng.integers(10, 120)),
+                                sub=float(rng.uniform(0, 0.4)), intron_hi=int(rng.integers(80, 400)))
+    sg = synth.protein_signals(g.window, rng)
+    q = synth.encode_protein(g.query)
+    L = g.window.size
+    al = int(rng.integers(0, max(1, q.size // 4)))
+    ar = int(rng.integers(max(al + 9, q.size // 2), q.size + 1))
+    bl = int(rng.integers(0, max(1, L // 5)))
+    br = int(rng.integers(max(bl + 3 * (ar - al) // 2, L // 2), L + 1))
+    exg = tuple(int(x) for x in rng.integers(0, 2, size=4))
+    return ps.add(q, sg["b"], sg["sig5"], sg["sig3"], sg["sigS"], sg["sigT"], sg["sigE"], sg["phs5"], sg["phs3"],
+                  al, ar, bl, br, exg, exin=(0, L))
+
+
+@pytest.mark.parametrize("local", [0, 1])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_protein_forward(eng, seed, local):
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9100 + seed + 10 * local)
+    flagmap = {0: 0, -2: -1, -3: -2}
+    for rnd in range(4):
+        sc = _rand_scoring_h(rng, local)
+        ps = abi.ProblemSetH()
+        for _ in range(40):
+            _rand_problem_h(rng, ps)
+        for i, ((s, skl, flag), p) in enumerate(zip(eng.wip_forward_h(sc, ps), ps.items)):
+            ws, wskl, wflag = oracle.wip_forward_h(sc, p)
+            assert s == ws and flag == flagmap[wflag], (seed, rnd, i)
+            if wflag == 0:
+                assert skl.tolist() == wskl.tolist(), (seed, rnd, i)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_protein_udh(eng, seed):
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9200 + seed)
+    for rnd in range(4):
+        sc = _rand_scoring_h(rng)
+        ps = abi.ProblemSetH()
+        while len(ps) < 24:
+            p = _rand_problem_h(rng, ps)
+            if p.a_right - p.a_left < 34:
+                ps.items.pop()
+        n_im = int(rng.integers(1, 3))
+        us, ucpos, urng = eng.wip_udh_h(sc, ps, n_im)
+        for i, p in enumerate(ps.items):
+            ws, wcpos, wrng = oracle.wip_udh_h(sc, p, n_im)
+            assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist() and ucpos[i].tolist() == wcpos.tolist(), \
+                (seed, rnd, i)

@@ -69,7 +69,12 @@ def test_fuzz_cdna_engines(eng, seed):
             us, ucpos, urng = eng.wip_udh(sc, big, n_im)
             for i, p in enumerate(big.items):
                 ws, wcpos, wrng = oracle.wip_udh(sc, p, n_im)
-                assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist() and ucpos[i].tolist() == wcpos.tolist()
+                assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist()
+                # an EMPTY optimum (all of it free end gaps: written-back range of zero length) leaves
+                # the reference's cpos rows to link lanes it never initialises per stripe
+                # (src/fwd2s1_wip_simd.h:524 clears only the hb block); see DESIGN.md section 2
+                if wrng[0] < wrng[1] and wrng[2] < wrng[3]:
+                    assert ucpos[i].tolist() == wcpos.tolist()
 
 
 def _rand_scoring_h(rng, local=0):
@@ -133,5 +138,6 @@ def test_fuzz_protein_udh(eng, seed):
         us, ucpos, urng = eng.wip_udh_h(sc, ps, n_im)
         for i, p in enumerate(ps.items):
             ws, wcpos, wrng = oracle.wip_udh_h(sc, p, n_im)
-            assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist() and ucpos[i].tolist() == wcpos.tolist(), \
-                (seed, rnd, i)
+            assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist(), (seed, rnd, i)
+            if wrng[0] < wrng[1] and wrng[2] < wrng[3]:          # see the cDNA case above
+                assert ucpos[i].tolist() == wcpos.tolist(), (seed, rnd, i)

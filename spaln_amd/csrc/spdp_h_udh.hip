@@ -590,7 +590,7 @@ __global__ void spdh_udh_cpos(HCposArgs A)
                 if (c < 8) CPOS(i, c++) = r + mm3; else ++c;
             }
             if (c < 9) { CPOS(i, c++) = r + mm3; CPOS(i, c) = END_OF_ULK; }
-            r = vl;
+            r = LNK(i, 2 + d, r);                      // re-read: the horizontal walk moved r to the run's start
             if (r == END_OF_ULK) break;
         } else
             CPOS(i, 0) = END_OF_ULK;

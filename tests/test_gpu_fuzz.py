@@ -111,6 +111,22 @@ def test_fuzz_cdna_engines(eng, seed):
                 n_full += 1
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_cdna_local(eng, seed):
+    """-LS: Kadane reset at the left end, running maximum at the right end (score-only and traceback)"""
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9050 + seed)
+    for rnd in range(3):
+        sc = _rand_scoring_s(rng, local=1)
+        ps = abi.ProblemSet()
+        for _ in range(40):
+            _rand_problem_s(rng, ps)
+        assert eng.wip_scoreonly(sc, ps).tolist() == [oracle.wip_scoreonly(sc, p) for p in ps.items]
+        for (s, skl), p in zip(eng.wip_forward(sc, ps), ps.items):
+            ws, wskl = oracle.wip_forward(sc, p)
+            assert s == ws and skl.tolist() == wskl.tolist()
+
+
 def _rand_scoring_h(rng, local=0):
     nq = int(rng.integers(1, 6))
     qlen = np.sort(rng.choice(np.arange(30, 1500), size=5, replace=False))

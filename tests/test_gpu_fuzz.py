@@ -197,3 +197,52 @@ def test_fuzz_protein_udh(eng, seed):
             assert int(us[i]) == ws and urng[i].tolist() == wrng.tolist(), (seed, rnd, i)
             assert ucpos[i].tolist() == wcpos.tolist(), (seed, rnd, i)
     assert n_full > n_empty
+
+
+def _ladder_udh_n_im(sc, m, n, step):
+    """n_imd lspS_ng / lspH_ng would pick (0: traceback branch, -1: recursive)"""
+    import math
+    coef_b, coef_c = 2.0, 12.0
+    cvol = float(m) * (n + step * m)
+    if abs(n - m) < (8 if step == 1 else 16) or coef_b * cvol < sc.max_vmf_space:
+        return 0
+    imd1 = int(math.pow(2.0 * m * coef_b / coef_c, 1.0 / 3) + 0.5) - 1
+    if coef_c * n * imd1 + coef_b * cvol / (imd1 + 1) / (imd1 + 1) > sc.max_vmf_space:
+        return -1
+    n_imd = sc.ubh if sc.ubh else min(imd1, m // 16)
+    if ((m + n_imd) // (n_imd + 1)) * n_imd == m:
+        n_imd -= 1
+    return n_imd
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_cdna_ladder(eng, seed):
+    """alignS_ng with a small MaxVmfSpace (linear-space branch, slabs, recursion) under random
+    parameters: GPU ladder == oracle ladder wherever the top-level linear-space call is well defined"""
+    from oracle import oracle, host_logic
+    rng = np.random.default_rng(synth.SEED + 9300 + seed)
+    n_cmp = n_skip = 0
+    for rnd in range(3):
+        sc = _rand_scoring_s(rng)
+        sc.max_vmf_space = int(rng.choice([3000, 8000, 20000, 60000]))
+        ps = abi.ProblemSet()
+        for _ in range(40):
+            _rand_problem_s(rng, ps)
+        res = eng.align_s(sc, ps) if all(p.a_right - p.a_left >= 9 for p in ps.items) else None
+        assert res is not None
+        for p, (score, skl) in zip(ps.items, res):
+            m, n = p.a_right - p.a_left, p.b_right - p.b_left
+            k = _ladder_udh_n_im(sc, m, n, 1)
+            if k != 0:
+                ws, wcpos, wrng = oracle.wip_udh(sc, p, max(k, 1))
+                if not _well_defined(wrng, wcpos, oracle.wip_forward(sc, p)[1], 1):
+                    n_skip += 1
+                    continue
+            try:
+                wscr, wskl = host_logic.align_s(sc, p)
+            except host_logic.NeedsScalarEngine:
+                n_skip += 1
+                continue
+            n_cmp += 1
+            assert score == wscr and skl.ravel().tolist() == (wskl or [])
+    assert n_cmp > n_skip

@@ -113,10 +113,12 @@ class Engine:
                                              out.ctypes.data), "spdp_homscore_s")
         return out
 
-    def _alignments(self, fn, sc, ps, what):
+    def _alignments(self, fn, sc, ps, what, allow_partial=False):
         n = len(ps)
         arr = (abi.Alignment * n)()
-        self._check(fn(self.ctx, C.byref(sc), ps.array(), n, arr), what)
+        rc = fn(self.ctx, C.byref(sc), ps.array(), n, arr)
+        if not (allow_partial and rc == 1):
+            self._check(rc, what)
         res = []
         for i in range(n):
             k = arr[i].n_skl
@@ -139,8 +141,11 @@ class Engine:
                                                     out.ctypes.data), "spdp_scalar_scorealone")
         return out
 
-    def align_s(self, sc, ps):
-        return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s")
+    def align_s(self, sc, ps, allow_partial=False):
+        """alignS_ng (ori = 1, -Q0).  allow_partial: accept return value 1 (some problem needed the
+        scalar engine for a < 8-row slab and the exact-model inputs were not supplied; those come
+        back without an alignment) instead of raising."""
+        return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s", allow_partial)
 
     def skl_rng_s(self, sc, ps, alignments, *, codonk1, minl, jneibr, lsg=1):
         """skl_rngS_ng over finished alignments (rows of (m, n) with the header row first, as align_s

@@ -228,8 +228,7 @@ def test_fuzz_cdna_ladder(eng, seed):
         ps = abi.ProblemSet()
         for _ in range(40):
             _rand_problem_s(rng, ps)
-        res = eng.align_s(sc, ps) if all(p.a_right - p.a_left >= 9 for p in ps.items) else None
-        assert res is not None
+        res = eng.align_s(sc, ps, allow_partial=True)
         for p, (score, skl) in zip(ps.items, res):
             m, n = p.a_right - p.a_left, p.b_right - p.b_left
             k = _ladder_udh_n_im(sc, m, n, 1)

@@ -161,9 +161,17 @@ struct Aligner {
     void set_score(int job, bool top, int scr) { if (top) { jobs[job].score = scr; jobs[job].score_set = true; } }
 
     // Aln2s1::trcbkalignS_ng
+    // a sub-range the links produced that does not lie inside the sequences: the reference would run
+    // its engine on it anyway (out-of-bounds reads); here the query is reported as not aligned
+    bool bad_range(int job, const Rng& r) const
+    {
+        return r.al < 0 || r.bl < 0 || r.ar > probs[job].a_len || r.br > probs[job].b_len || r.ar < r.al || r.br < r.bl;
+    }
+
     void trcbk(int job, const Rng& r, const SpdpWindow& w, bool top)
     {
         if (w.width < 0) { set_score(job, top, SPDP_NEVSEL); return; }
+        if (bad_range(job, r) || w.width < 3) { ++unsupported; jobs[job].failed = true; return; }
         if (r.ar - r.al < kScalarRows) {        // fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
             if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
             stbs.push_back({job, r, w, top});
@@ -212,6 +220,7 @@ struct Aligner {
                 if (n_imd == 0) { trcbk(it.job, r, it.w, it.top); return true; }
             }
         }
+        if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
         udh.push_back({it.job, r, it.w, it.top, n_imd, recursive});
         return true;
     }

@@ -405,6 +405,14 @@ static const int END_ULK = SPDP_END_OF_ULK;
 static void push_rec(HTop& t, int m, int n) { SpdpSkl s; s.m = m; s.n = n; t.rec.push_back(s); }
 
 // trcbkalignH_ng's engine choice (src/fwd2h1.cc:1997-2014): returns false when the item cannot run here
+// a sub-range the links produced that does not lie inside the sequences: the reference would run its
+// engine on it anyway (out-of-bounds reads); here the query is reported as not computed
+static bool bad_range(const HItem& it, const SpdpProblemH& p)
+{
+    return it.a_left < 0 || it.b_left < 0 || it.a_right > p.a_len || it.b_right > p.b_len ||
+           it.a_right < it.a_left || it.b_right < it.b_left || it.b_left < p.exin_left || it.b_right > p.exin_right;
+}
+
 static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, HTop& t)
 {
     if (it.w.width < 0) return true;                         // NEVSEL, no records
@@ -463,7 +471,11 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
     while (!pending.empty() || !fwd.empty()) {
         ++hs.rounds;
         udh.clear();
-        for (const HItem& it : pending) if (!tops[it.top].cls) queue_lsp(sc, it, fwd, udh, tops[it.top]);
+        for (const HItem& it : pending) {
+            if (tops[it.top].cls) continue;
+            if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
+            queue_lsp(sc, it, fwd, udh, tops[it.top]);
+        }
         pending.clear();
         // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)
         if (!udh.empty()) {
@@ -530,7 +542,11 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         // ---- traceback round
         if (!fwd.empty()) {
             std::vector<HItem> run;
-            for (const HItem& it : fwd) if (!tops[it.top].cls) run.push_back(it);
+            for (const HItem& it : fwd) {
+                if (tops[it.top].cls) continue;
+                if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
+                run.push_back(it);
+            }
             fwd.clear();
             HFwdOut fo;
             if (run_forward(st, run, true, fo)) return -1;

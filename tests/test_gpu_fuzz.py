@@ -245,3 +245,41 @@ def test_fuzz_cdna_ladder(eng, seed):
             n_cmp += 1
             assert score == wscr and skl.ravel().tolist() == (wskl or [])
     assert n_cmp > n_skip
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_protein_ladder(eng, seed):
+    """alignH_ng with a small MaxVmfSpace under random parameters, as test_fuzz_cdna_ladder"""
+    from oracle import oracle, host_logic_h as hh
+    rng = np.random.default_rng(synth.SEED + 9400 + seed)
+    n_cmp = n_skip = 0
+    for rnd in range(3):
+        sc = _rand_scoring_h(rng)
+        sc.max_vmf_space = int(rng.choice([20000, 60000, 200000]))
+        ps = abi.ProblemSetH()
+        for _ in range(32):
+            _rand_problem_h(rng, ps)
+        res = eng.align_h(sc, ps)
+        for p, (score, skl, flag) in zip(ps.items, res):
+            m, n = p.a_right - p.a_left, p.b_right - p.b_left
+            k = _ladder_udh_n_im(sc, m, n, 3)
+            if k != 0 and m >= 17:
+                ws, wcpos, wrng = oracle.wip_udh_h(sc, p, max(k, 1))
+                fs, fskl, fflag = oracle.wip_forward_h(sc, p)
+                if fflag != 0 or not _well_defined(wrng, wcpos, fskl, 3):
+                    n_skip += 1
+                    continue
+            try:
+                wscr, wskl = hh.align_h(sc, p)
+                wflag = 0
+            except hh.ReferenceUndefined:
+                wflag = -2
+            except hh.ReferenceFatal:
+                wflag = -1
+            except hh.NotRestated:
+                wflag = 1
+            n_cmp += 1
+            assert flag == wflag
+            if wflag == 0:
+                assert score == wscr and skl.ravel().tolist() == (wskl or [])
+    assert n_cmp > n_skip

@@ -352,7 +352,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     h_probs.swap(sorted);
     // Big problems of an under-filled launch are spread over the 4 waves of a block (pipelined
     // passes); with plenty of problems one wave each is more efficient (no pipeline fill).
-    n_multi = 0;
+    n_multi = 0; wpb = 4;
     if (flav <= 2 && !st->sc.local) {
         const char* force = getenv("SPDP_MULTI");
         const bool underfilled = n < 4 * 4 * ctx->n_cu;
@@ -361,6 +361,13 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
                 const int stripes = (h_probs[j].a_right - h_probs[j].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
                 if (stripes >= 16) n_multi = j + 1; else break;          // sorted by size: a prefix
             }
+        // a launch of a few huge problems only (top levels of the recursion on a long cDNA): one
+        // 16-wave block, i.e. a whole CU, per problem
+        if (n_multi == n && n <= 2 * ctx->n_cu) {
+            const int smallest = (h_probs[n - 1].a_right - h_probs[n - 1].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+            const char* w16 = getenv("SPDP_WPB16");
+            if (w16 ? atoi(w16) != 0 : smallest >= 4 * 32) wpb = 16;     // >= 32 passes each
+        }
     }
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
     return 0;
@@ -388,11 +395,11 @@ int DevRun::launch()
     A.sc = (const DevScoring*) store->d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n;
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.n_multi = n_multi;
-    const int grid = n_multi + (n - n_multi + 3) / 4;
+    const int grid = n_multi + (n - n_multi + wpb - 1) / wpb;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;
-    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, ctx->stream));
+    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, wpb, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (flavour == 1) {
         WalkArgs W;

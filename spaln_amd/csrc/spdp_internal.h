@@ -44,7 +44,7 @@ struct CposArgs {
 };
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
-                                        int grid, hipStream_t s);
+                                        int grid, int wpb, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // scalar exact engines (spdp_scalar.hip): one thread per problem
@@ -147,7 +147,8 @@ struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;
     int flavour = 0, n = 0;
-    int n_multi = 0;                        // leading problems run as 4-wave pipelines
+    int n_multi = 0;                        // leading problems run as multi-wave pipelines
+    int wpb = 4;                            // waves per block of the sweep launch (16: one huge problem per CU)
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;
     std::vector<DevProblem> h_probs;        // in dispatch order

@@ -82,8 +82,10 @@ enum { NQ_FLAT = 0, NQ_TABLE = 1, NQ_CHAIN = 2 };
 #define SPDP_PEN_TAB 2048
 
 // ---------------------------------------------------------------------------
-template <int FL, bool LOCAL, int NQM>
-__global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
+// WPB: waves per block.  4 by default; 16 when a launch holds only a few huge problems, each of which
+// then owns a whole CU (a 16-wave pass pipeline instead of a 4-wave one).
+template <int FL, bool LOCAL, int NQM, int WPB>
+__global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
 {
     constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
     __shared__ int s_mtx[32 * 32];
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     // per wave, per DPP row: a 2 x 48-entry ring of column records (every record is written
     // twice, 48 slots apart, so that any 31-column window is contiguous) and the 16 boundary
     // entries of the current block
-    __shared__ int2 s_col[4][4][96];
-    __shared__ int  s_feed[4][4][16 * BW];
+    __shared__ int2 s_col[WPB][4][96];
+    __shared__ int  s_feed[WPB][4][16 * BW];
 
     const DevScoring* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
@@ -120,15 +122,15 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
     // follows at a distance through progress words in LDS -- a wavefront pipeline inside the CU.
     // All other problems take one wave each (4 per block).  The hardware dispatcher balances the
     // load (blocks are launched as CUs free up), so no software queue is needed.
-    __shared__ int s_prog[4];
+    __shared__ int s_prog[WPB];
     const int wv = threadIdx.x >> 6;
     const bool multi = (int) blockIdx.x < A.n_multi;
-    const int W = multi ? 4 : 1;                    // waves cooperating on my problem
+    const int W = multi ? WPB : 1;                  // waves cooperating on my problem
     const int w = multi ? wv : 0;                   // my position among them
-    int pi = multi ? (int) blockIdx.x : A.n_multi + ((int) blockIdx.x - A.n_multi) * 4 + wv;
+    int pi = multi ? (int) blockIdx.x : A.n_multi + ((int) blockIdx.x - A.n_multi) * WPB + wv;
     pi = __builtin_amdgcn_readfirstlane(pi);
     const bool active = pi < A.n_probs;
-    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < WPB) s_prog[threadIdx.x] = 0;
     if (!active) pi = A.n_probs - 1;                // keep the addressing valid until the barrier
     const DevProblem P = A.probs[pi];
     const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
@@ -541,20 +543,33 @@ __global__ __launch_bounds__(256) void spdp_sweep(SweepArgs A)
 // ---------------------------------------------------------------------------
 // host-callable launchers (used by spdp_api.cpp)
 template <int FL, bool LOCAL>
-static void launch_nq(int nqm, dim3 grd, dim3 blk, hipStream_t stream, const SweepArgs& A)
+static void launch_nq(int nqm, dim3 grd, int wpb, hipStream_t stream, const SweepArgs& A)
 {
+    if constexpr (!LOCAL) {
+        if (wpb == 16) {
+            const dim3 blk(1024);
+            switch (nqm) {
+            case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT, 16>), grd, blk, 0, stream, A); break;
+            case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE, 16>), grd, blk, 0, stream, A); break;
+            default:       hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_CHAIN, 16>), grd, blk, 0, stream, A); break;
+            }
+            return;
+        }
+    }
+    const dim3 blk(256);
     switch (nqm) {
-    case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT>), grd, blk, 0, stream, A); break;
-    case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE>), grd, blk, 0, stream, A); break;
-    default:       hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_CHAIN>), grd, blk, 0, stream, A); break;
+    case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT, 4>), grd, blk, 0, stream, A); break;
+    case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE, 4>), grd, blk, 0, stream, A); break;
+    default:       hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_CHAIN, 4>), grd, blk, 0, stream, A); break;
     }
 }
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
-                                        int grid, hipStream_t stream)
+                                        int grid, int wpb, hipStream_t stream)
 {
     SweepArgs A = *args;
-    dim3 blk(256), grd(grid);
+    dim3 grd(grid);
+    const int blk = (wpb == 16 && !local) ? 16 : 4;
     const int nqm = nquant <= 1 ? NQ_FLAT : (pen_cap < SPDP_PEN_TAB ? NQ_TABLE : NQ_CHAIN);
     switch (flavour * 2 + (local ? 1 : 0)) {
     case 0: launch_nq<FL_SCORE, false>(nqm, grd, blk, stream, A); break;

@@ -58,5 +58,29 @@ inline std::vector<int> skl2vec(const SKL* skl)
 	return v;
 }
 
+// same calls, same order as the CLI default set-up (spaln.cc:1471-1494)
+inline void set_default_params()	// same calls, same order as the CLI default set-up (spaln.cc:1471-1494)
+{
+	algmode.lcl = 15;
+	alprm.ls = 2;
+	algmode.lsg = 1;
+	algmode.qck = 3;
+	algmode.mlt = 0;
+	algmode.mns = 3;
+	algmode.thr = 1;
+	setalgmode(4, 0);
+	setNpam(4, -6);
+	setpam(100, 0);			// intra-species PAM (spaln.cc:49)
+	setpam(150, 1);			// cross-species PAM (spaln.cc:50)
+	setpam(50, WlnPamNo);		// HSP-search PAM (spaln.cc:51)
+	setorf(75, 2);			// default ORF length (spaln.cc:52)
+	OutPrm.MaxOut = 1;
+	OutPrm.SkipLongGap = 1;
+	OutPrm.fastanno = 1;
+	alprm.scale = 10;
+}
+
+
+
 int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn);
 #endif

@@ -1,0 +1,47 @@
+"""The reference-side binding end to end: oracle/_ref/shim_check is that shim compiled
+against the reference's own headers and linked with libspdp_hip.so.  It sets a pair up the way the
+reference does, runs HomScoreS_ng / alignS_ng (alignH_ng) of the compiled reference AND the *_gpu
+replacements in the same process, and exits 0 only when scores and SKL corner lists are identical."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from spaln_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "shim_check")
+TAB = os.path.join(ROOT, "oracle", "_ref", "table")
+
+
+def _run(tmp_path, window_ascii, query_ascii):
+    gf, qf = str(tmp_path / "g.fa"), str(tmp_path / "q.fa")
+    synth.write_fasta(gf, "win", window_ascii)
+    synth.write_fasta(qf, "qry", query_ascii)
+    r = subprocess.run([BIN, gf, qf], env=dict(os.environ, ALN_TAB=TAB), capture_output=True, text=True, timeout=300)
+    return r.returncode, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed,kw", [(1, dict(n_exons=5, mrna_len=700, flank=300, intron_hi=1500)),
+                                     (2, dict(n_exons=8, mrna_len=1400, flank=600, intron_hi=2500)),
+                                     (3, dict(n_exons=3, mrna_len=400, flank=200, intron_hi=600, sub=0.1, indel=0.01))])
+def test_cdna_through_the_reference_side_shim(tmp_path, seed, kw):
+    rng = np.random.default_rng(synth.SEED + 7000 + seed)
+    g = synth.make_gene(rng, **kw)
+    rc, out = _run(tmp_path, g.window, g.query)
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed,kw", [(1, dict(n_exons=3, aa_len=150, flank=200, intron_hi=600)),
+                                     (2, dict(n_exons=5, aa_len=400, flank=500, intron_hi=1500)),
+                                     (3, dict(n_exons=4, aa_len=220, flank=300, intron_hi=900, sub=0.3))])
+def test_protein_through_the_reference_side_shim(tmp_path, seed, kw):
+    rng = np.random.default_rng(synth.SEED + 7100 + seed)
+    g = synth.make_protein_gene(rng, **kw)
+    rc, out = _run(tmp_path, g.window, g.query)
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]

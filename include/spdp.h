@@ -228,6 +228,13 @@ typedef struct SpdpScoringH {
     int32_t max_vmf_space;           /* MaxVmfSpace                                         */
     int32_t ubh;                     /* alprm.ubh                                           */
     int32_t ref_nelem;               /* 16                                                  */
+    /* ---- rescoring only (spdp_skl_rng_h); zero / NULL otherwise ------------------------------- */
+    int32_t lgop;                    /* PwdB::LongGOP                                       */
+    int32_t gape1, gape2, extragop;  /* PwdB::GapE1, GapE2, ExtraGOP (frame-shift terms)    */
+    int32_t diffu, k1;               /* PwdB::diffu, alprm.k1 (UnpPenalty3, src/aln.h:290)  */
+    const int16_t* intpen;           /* IntronPenalty::Penalty(len), len in [0, intpen_len) */
+    int32_t intpen_len;
+    int16_t t53[256];                /* sig53(m, n, IE53) - sig3[n] by 16 * dinc5[m] + dinc3[n] */
 } SpdpScoringH;
 
 typedef struct SpdpProblemH {
@@ -243,6 +250,7 @@ typedef struct SpdpProblemH {
                                               <=> exin_left - 1 <= n < exin_right (codepot.h:120-123) */
     int32_t a_left, a_right, b_left, b_right;
     uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
+    const uint8_t* dinc;                   /* rescoring only: INT53::dinc5 << 4 | dinc3 per position, or NULL */
 } SpdpProblemH;
 
 /* stripe31(seqs, &wdw, sh), src/aln2.cc:178-198 */
@@ -272,6 +280,19 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
  * rows, diagonalH_ng, the local linear-space engine); those come back with n_skl = 0, score NEVSEL. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+
+/* skl_rngH_ng (src/fwd2h1.cc:635): the same for protein alignments (codon-split introns, frame
+ * shifts, start / stop signals).  Needs SpdpScoringH.intpen / t53 / lgop ... and SpdpProblemH.dinc.
+ * The standard genetic code is assumed for codons split by an intron, as the reference's static
+ * spj_tron_tab does (src/codepot.h:130). */
+typedef struct SpdpRescoreParamsH {
+    int32_t minl;                    /* IntronPrm.minl                                              */
+    int32_t jneibr;                  /* alprm2.jneibr (<= 32)                                       */
+    int32_t lcl;                     /* algmode.lcl: which ends may take start / stop / splice signals */
+    int32_t sup_tcodon;              /* OutPrm.supTcodon                                            */
+} SpdpRescoreParamsH;
+int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                   const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 
 /* resident batch (benchmarking / pipelines); one live batch of this kind per context */
 typedef struct SpdpBatchH SpdpBatchH;

@@ -206,3 +206,346 @@ def align_h(sc, p):
     for m, n in s:
         flat += [m, n]
     return scr, flat
+
+
+# ---- skl_rngH_ng (src/fwd2h1.cc:635-940): rescoring of a finished protein alignment ----------------
+# Restated without the Cigar / Vulgar side channels, the frame-shift warning prompt and the query's
+# intron-position profile (PfqItr: empty unless the query carries one).
+EIJ_FIELDS = ["left", "right", "rleft", "rright", "mch", "mmc", "gap", "unp", "mch5", "mmc5", "gap5", "unp5",
+              "mch3", "mmc3", "gap3", "unp3", "phs", "escr", "iscr", "sig3", "sig5"]
+ENDRNG = 2 ** 31 - 1
+SER, SER2, TRM2, TRM, AMB = 18, 23, 24, 25, 2
+
+# second base of the codons a tron code stands for, reduced A C G T = 0 1 2 3 (what the reference
+# keeps as tnredctab / aa2nuc: a tron code pins the middle base of its codon), and the two tron codes
+# a 4-base word spells (spj_tron_tab): derived from the genetic code, not copied
+_BASES = "ACGT"
+_CODON_AA = {a + b + c: aa for (a, b, c), aa in zip(
+    [(x, y, z) for x in "TCAG" for y in "TCAG" for z in "TCAG"],
+    "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG")}
+_AA_CODE = {"A": 3, "R": 4, "N": 5, "D": 6, "C": 7, "Q": 8, "E": 9, "G": 10, "H": 11, "I": 12, "L": 13,
+            "K": 14, "M": 15, "F": 16, "P": 17, "S": 18, "T": 19, "W": 20, "Y": 21, "V": 22}
+
+
+def _tron_of(codon):
+    aa = _CODON_AA[codon]
+    if aa == "*":
+        return TRM2 if codon == "TGA" else TRM
+    if aa == "S" and codon[0] == "A":
+        return SER2
+    return _AA_CODE[aa]
+
+
+_MID = {}
+for _c in _CODON_AA:
+    _MID.setdefault(_tron_of(_c), set()).add(_BASES.index(_c[1]))
+assert all(len(v) == 1 for v in _MID.values())
+_MID = {k: next(iter(v)) for k, v in _MID.items()}
+
+
+def _spjseq(b, b_left, b_right, n5, n3):
+    """SpJunc::spjseq (src/codepot.cc:79-107): the codon(s) an intron splits, as tron codes"""
+    if n5 < b_left or n3 >= b_right:
+        return (AMB, AMB)
+    word = []
+    for idx in (n5 - 2, n5 - 1, n3, n3 + 1):
+        c = _MID.get(int(b[idx]))
+        if c is None:
+            return (AMB, AMB)            # ambiguous bases: not produced by the synthetic inputs
+        word.append(_BASES[c])
+    return (_tron_of("".join(word[0:3])), _tron_of("".join(word[1:4])))
+
+
+def skl_rng_h(sc, p, skl, *, intpen, t53, dinc, lgop, diffu, k1, gape1, gape2, extragop, minl, jneibr,
+              lcl=15, lsg=1, sup_tcodon=0, many=1):
+    """Returns (h, fstat[5], [21-int records]); skl = [flags, n, m1, n1, ...] as align_h returns it."""
+    import ctypes as C
+    N = p.b_len + 3
+
+    class _Safe:
+        """positions outside what the Exinon holds read as `fill` (the reference reads its heap there)"""
+        def __init__(self, arr, fill=0):
+            self.a, self.fill = arr, fill
+
+        def __getitem__(self, i):
+            return int(self.a[i]) if 0 <= i < self.a.size else self.fill
+
+    a = _Safe(np.ctypeslib.as_array(C.cast(p.a, C.POINTER(C.c_uint8)), shape=(p.a_len,)), AMB)
+    b = _Safe(np.ctypeslib.as_array(C.cast(p.b, C.POINTER(C.c_uint8)), shape=(p.b_len + 1,)), AMB)
+
+    def arr16(ptr):
+        return _Safe(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(N,)))
+    sig5a, sig3a, sigS, sigT, sigE = (arr16(x) for x in (p.sig5, p.sig3, p.sigS, p.sigT, p.sigE))
+    phs5 = _Safe(np.ctypeslib.as_array(C.cast(p.phs5, C.POINTER(C.c_int8)), shape=(N,)), -2)
+    phs3 = _Safe(np.ctypeslib.as_array(C.cast(p.phs3, C.POINTER(C.c_int8)), shape=(N,)), -2)
+    mtx = np.array(sc.mtx[:sc.mtx_rows * sc.mtx_cols]).reshape(sc.mtx_rows, sc.mtx_cols)
+    gop, gep, lgep, codonk1 = sc.gop, sc.gep, sc.lgep, sc.codonk1
+
+    def cdiv(x, y):
+        q = abs(x) // abs(y)
+        return q if (x >= 0) == (y >= 0) else -q
+
+    def gap_penalty3(i, bgop=None):                      # PwdB::GapPenalty3, src/aln2.cc:41-52
+        bgop = gop if bgop is None else bgop
+        if i == 0:
+            return 0
+        d = i // 3
+        x = (0, gape1, gape2)[i % 3]
+        return x + (cdiv(lgop * bgop, gop) + d * lgep if i > codonk1 else bgop + d * gep)
+
+    def unp_penalty3(i):                                 # src/aln.h:290-301
+        d = i // 3
+        unp = d * gep
+        egop = (0, gape1, gape2)[i % 3]
+        return unp + egop if i <= codonk1 else unp - diffu * (d - k1) + egop
+
+    def sig53_ie53(n5, n3):
+        return int(sig3a[n3]) + int(t53[16 * int(dinc[n5] >> 4) + int(dinc[n3] & 15)])
+
+    def spjscr(n5, n3):
+        return int(intpen[n3 - n5]) + sig53_ie53(n5, n3)
+
+    def avst_equal(ar, br):                              # PxT, src/aln.h:266-272
+        return ar == br or (br == SER2 and ar == SER)
+
+    def is_term(x):
+        return x == TRM or x == TRM2
+
+    corners = [[skl[2 + 2 * i], skl[3 + 2 * i]] for i in range(skl[1])]
+    num = len(corners)
+    h, hi, ha, hb, hvl = 0, abi.NEVSEL, 0, 0, 0
+    ivl = False
+    ngop = 0                                             # `gop` counter of the reference
+    s5 = s3 = 0
+    insert = deletn = intlen = preint = phs = psp = 0
+    fst = dict(mch=0, mmc=0, gap=0, unp=0, val=0)
+    pst = dict(fst)
+    rbuf = dict.fromkeys(EIJ_FIELDS, 0)
+    recs = []
+    que = [dict(fst) for _ in range(jneibr)]
+    qpos = [0]
+
+    def shift(near):
+        if near:
+            for k in ("mch", "mmc", "unp", "gap"):
+                rbuf[k + "5"] = fst[k] - que[qpos[0]][k]
+        que[qpos[0]] = dict(fst)
+        qpos[0] = (qpos[0] + 1) % jneibr
+
+    def store(prv, near):
+        for k in ("mch", "mmc", "gap", "unp"):
+            rbuf[k] = fst[k] - prv[k]
+        if near:
+            for k in ("mch", "mmc", "gap", "unp"):
+                rbuf[k + "5"] = rbuf[k]
+        for k in ("mch", "mmc", "unp", "gap"):
+            rbuf[k + "3"] = fst[k] - que[qpos[0]][k]
+
+    def push():
+        recs.append([int(rbuf[k]) for k in EIJ_FIELDS])
+
+    termcodon = 0
+    if sup_tcodon:
+        cs0 = int(b[corners[num - 1][1] - 2])
+        termcodon = is_term(cs0)
+        if termcodon:
+            corners[num - 1][1] -= 3
+    w = 0
+    if num >= 2 and corners[1][1] == corners[0][1] and p.b_exgl:
+        w += 1
+        num -= 1
+    m, n = corners[w]
+    ai, bi, bbn = m, n, n                                # as, bs, bb
+    cs = None
+    if (lcl & 17) and sigS[bbn + 1] > h:
+        h = int(sigS[bbn + 1])
+    if (lcl & 20) and sig3a[bbn] > h:
+        h = int(sig3a[bbn])
+    rbuf["left"], rbuf["rleft"], rbuf["iscr"], rbuf["sig3"] = n, m, abi.NEVSEL, h
+    while True:
+        num -= 1
+        if not (num > 0 or hi > abi.NEVSEL):
+            break
+        if num > 0:
+            w += 1
+        wm, wn = corners[w]
+        term = num == 1
+        mi = (wm - m) * 3
+        if insert and (mi or (h > abi.NEVSEL and hi > abi.NEVSEL) or term):
+            termgap = (p.a_exgl and m == p.a_left) or (p.a_exgr and m == p.a_right)
+            h += unp_penalty3(insert) if termgap else gap_penalty3(insert)
+            if hi > abi.NEVSEL and insert > intlen:
+                hi += gap_penalty3(insert - intlen)
+            if hi > abi.NEVSEL and hi >= h:              # intron
+                hb = ha
+                if rbuf["right"] - rbuf["left"] > 1:
+                    push()
+                rbuf["left"] = rbuf["right"] + intlen
+                rbuf["rleft"] = m
+                rbuf["sig3"] = s3
+                h = hi
+                insert -= preint + intlen
+            hi = abi.NEVSEL
+            if insert:                                   # post-intron gap
+                if term and is_term(int(b[bi - 1])):
+                    insert -= 3
+                phs = insert % 3
+                insert -= phs
+                if not ((p.a_exgl and m == p.a_left) or (p.a_exgr and m == p.a_right)):
+                    fst["gap"] += ngop
+                j = 0
+                while j < insert:
+                    shift(psp // 3 == jneibr)
+                    fst["unp"] += 3
+                    j += 3
+                    psp += 3
+                if phs:                                  # insertion frame shift
+                    rbuf["right"], rbuf["rright"], rbuf["iscr"] = n - phs, m, abi.NEVSEL
+                    push()
+                    rbuf["left"], rbuf["rleft"] = n, m
+                    h += gape1 if phs == 1 else gape2
+                    fst["val"] += gape1 if phs == 1 else gape2
+                ngop = insert = intlen = preint = 0
+        ni = wn - n
+        if ni and deletn:
+            if not (p.b_exgl and n == p.b_left):
+                h += gap_penalty3(deletn)
+                fst["gap"] += 1
+            ai += deletn // 3
+            phs = deletn % 3
+            if phs:                                      # deletion frame shift
+                rbuf["right"], rbuf["rright"], rbuf["iscr"] = n + phs, m, abi.NEVSEL
+                push()
+                rbuf["left"], rbuf["rleft"] = n, m
+                h += extragop
+                fst["val"] += extragop
+                ai += 1
+                deletn -= phs
+                phs = 3 - phs
+                bi += phs
+                bbn += phs
+            deletn = 0
+        i = mi - ni
+        d = ni if i >= 0 else mi
+        if d:
+            n += d
+            m += d // 3
+            while d > 2:
+                shift(psp // 3 == jneibr)
+                gs = cs[1] if cs else int(b[bi + 1])     # *((cs ? cs : bs) + 1)
+                hvl = int(mtx[a[ai], gs])
+                fst["val"] += hvl
+                hvl += 0 if cs else int(sigE[bbn + 1])
+                h += hvl
+                ivl = avst_equal(int(a[ai]), gs)
+                if ivl:
+                    fst["mch"] += 1
+                else:
+                    fst["mmc"] += 1
+                cs = None
+                d -= 3
+                ai += 1
+                bi += 3
+                bbn += 3
+                psp += 3
+        if i > 0:
+            cs = None
+            deletn += i
+            j = 0
+            while j < i:
+                shift(psp // 3 == jneibr)
+                fst["unp"] += 3
+                j += 3
+                psp += 3
+        elif i < 0:
+            i = -i
+            b3n = bbn + i
+            if hi <= abi.NEVSEL and i >= minl and wn < p.b_right:       # intron?
+                cm = None
+                sig5m = 0
+                ph5 = int(phs3[b3n]) if phs5[bbn] == 2 else int(phs5[bbn])
+                ph3 = int(phs5[bbn]) if phs3[b3n] == 2 else int(phs3[b3n])
+                xm = xi = abi.NEVSEL
+                if ph3 == 2 and ph5 == 2:                # GTGT....AGAG
+                    nb = n + 1
+                    n3 = nb + i
+                    sig5m = int(sig5a[nb])
+                    xm = sig5m + spjscr(nb, n3)
+                    cm = _spjseq(b, p.b_left, p.b_right, nb, n3)
+                    ph3 = ph5 = 1
+                nb = n - ph3
+                n3 = nb + i
+                if ph5 == ph3 and ph5 > -2:              # isJunct
+                    s5 = int(sig5a[nb])
+                    s3 = sig53_ie53(nb, n3)
+                    xi = s5 + spjscr(nb, n3)
+                    cs = _spjseq(b, p.b_left, p.b_right, nb, n3)
+                    preint = insert
+                    if ph3 == 0:
+                        cs = None
+                    if insert == 0 and ph3 == 1:
+                        hdlt = int(mtx[a[ai - 1], cs[0]]) - hvl
+                        xi += hdlt
+                        fst["val"] += hdlt
+                        match = avst_equal(int(a[ai - 1]), cs[0])
+                        if match and not ivl:
+                            fst["mch"] += 1
+                            fst["mmc"] -= 1
+                        elif not match and ivl:
+                            fst["mch"] -= 1
+                            fst["mmc"] += 1
+                if xm > xi:
+                    xi = xm
+                    ph3 = -1
+                    nb = n - ph3
+                    n3 = nb + i
+                    s5 = sig5m
+                    s3 = sig53_ie53(nb, n3)
+                    cs = cm
+                if xi > abi.NEVSEL:
+                    if ph3 != -1:
+                        cs = None
+                    hi = h + xi
+                    intlen = i
+                    rbuf["right"], rbuf["rright"], rbuf["phs"] = nb, m, ph3
+                    rbuf["iscr"], rbuf["sig5"] = xi, s5
+                    rbuf["escr"] = h + gap_penalty3(insert)
+                    ha = rbuf["escr"] + xi - s3
+                    rbuf["escr"] += s5 - hb
+                    store(pst, psp < jneibr)
+                    pst = dict(fst)
+                    psp = 0
+            elif not (term and is_term(int(b[bi + 1]))):
+                y, k = 0, i                              # SumCodePot(bb, i, 0, pwd)
+                pos = bbn + 1
+                while k > 0:
+                    y += int(sigE[pos])
+                    pos += 3
+                    k -= 3
+                h += y
+                if hi <= abi.NEVSEL:
+                    ngop += 1
+            bbn = b3n
+            bi += i
+            insert += i
+        m, n = wm, wn
+    s5 = 0
+    if n > 1:
+        if (lcl & 18) and sigT[bbn - 2] > 0:
+            s5 = int(sigT[bbn - 2])
+        if (lcl & 24) and sig5a[bbn] > 0 and sig5a[bbn] > sigT[bbn - 2]:
+            s5 = int(sig5a[bbn])
+        h += s5
+    rbuf["escr"] = h - hb
+    rbuf["iscr"] = 0
+    rbuf["sig5"] = s5
+    rbuf["right"], rbuf["rright"] = n, m
+    store(pst, n - rbuf["left"] <= jneibr)
+    push()
+    rbuf["left"] = rbuf["right"] = ENDRNG
+    push()
+    fst["mch"] = cdiv(fst["mch"], many)
+    fst["mmc"] = cdiv(fst["mmc"], many)
+    fst["unp"] = cdiv(fst["unp"], 3)
+    fst["val"] += gop * fst["gap"] + gep * fst["unp"]
+    return h, [fst[k] for k in ("mch", "mmc", "gap", "unp", "val")], recs

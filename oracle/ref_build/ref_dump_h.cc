@@ -52,6 +52,42 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	    w.put("phs5", 4, p5.data(), N);
 	    w.put("phs3", 4, p3.data(), N);
 	    w.put("good", 1, good.data(), N);
+	    // exact-model inputs of the rescoring walk (skl_rngH_ng): dinucleotide classes as
+	    // Exinon::intron53_c assigns them on a tron sequence (codepot.cc:437-450), the junction table
+	    // behind sig53(m, n, IE53) (codepot.cc:411-415) and the intron-length penalty by length
+	    std::vector<unsigned char> d5(N, 0), d3(N, 0);
+	    int	nc = 1;
+	    for (int i = b->left; i < b->right; ++i) {
+		int c = tnredctab[*b->at(i)];
+		if (c >= 4) c = 1;
+		nc = ((nc << 2) + c) & 0xf;
+		if (i - 1 >= 0) d5[i - 1] = nc;
+		d3[i + 1] = nc;
+	    }
+	    w.put("dinc5", 1, d5.data(), b->len + 1);
+	    w.put("dinc3", 1, d3.data(), b->len + 1);
+	    std::vector<int> t53(256, 0), mrep(16, -1), nrep(16, -1);
+	    for (int n = b->left; n <= b->right; ++n) {
+		if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
+		if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	    }
+	    for (int u = 0; u < 16; ++u)
+		for (int v2 = 0; v2 < 16; ++v2)
+		    if (mrep[u] >= 0 && nrep[v2] >= 0)
+			t53[16 * u + v2] = b->exin->sig53(mrep[u], nrep[v2], IE53) - b->exin->score_p(nrep[v2])->sig3;
+	    w.put_i32("t53", t53);
+	    int	bad = 0;
+	    for (int t = 0; t < 400; ++t) {		// self-check of the restated classes
+		int m = b->left + (t * 7919) % std::max(1, b->right - b->left - 2);
+		int n = b->left + 2 + (t * 104729) % std::max(1, b->right - b->left - 2);
+		int want = b->exin->sig53(m, n, IE53);
+		int got = b->exin->score_p(n)->sig3 + t53[16 * d5[m] + d3[n]];
+		if (want != got) ++bad;
+	    }
+	    if (bad) fprintf(stderr, "ref_dump: %d sig53 self-check mismatches (protein)\n", bad);
+	    std::vector<short> ip(b->len + 2, 0);
+	    for (int l = 0; l <= b->len + 1; ++l) ip[l] = (short) pwd->IntPen->Penalty(l);
+	    w.put("intpen", 2, ip.data(), ip.size());
 	}
 	{
 	    const Simmtx* sm = pwd->simmtx;
@@ -79,6 +115,9 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 		(int) pwd->GapE1, (int) pwd->GapE2, (int) pwd->ExtraGOP, alprm.k1, alprm2.termk1,
 		(int) algmode.lcl, pwd->DvsP};
 	    w.put_i32("hparams", hp);
+	    std::vector<int> rp = {(int) pwd->diffu, (int) OutPrm.supTcodon, (int) (alprm2.Z * 1000), a->many,
+		alprm2.jneibr, (int) algmode.lsg, (int) (alprm2.o * 1000)};
+	    w.put_i32("rparams", rp);
 	    std::vector<int>	ql, qp;
 	    for (int j = 0; j < IntronPrm.nquant; ++j) {
 		ql.push_back(pwd->IntPen->qm[j].len);
@@ -167,6 +206,28 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	    w.put_int(nm, (int) gsi.scr);
 	    snprintf(nm, sizeof nm, "aln_skl_A%d", alg);
 	    w.put_i32(nm, skl2vec(gsi.skl));
+	    if (gsi.skl && gsi.skl->n) {
+		restore();
+		VTYPE	rs = skl_rngH_ng((const Seq**) seqs, &gsi, pwd);
+		snprintf(nm, sizeof nm, "rng_scr_A%d", alg);
+		w.put_int(nm, (int) rs);
+		std::vector<int> fs = {(int) gsi.fstat.mch, (int) gsi.fstat.mmc, (int) gsi.fstat.gap,
+		    (int) gsi.fstat.unp, (int) gsi.fstat.val, gsi.noeij, alprm2.jneibr, (int) algmode.lsg};
+		snprintf(nm, sizeof nm, "rng_fstat_A%d", alg);
+		w.put_i32(nm, fs);
+		std::vector<int> ej;
+		if (gsi.eijnc) {
+		    const EISCR* e = gsi.eijnc->begin();
+		    for (int i = 0; i < gsi.eijnc->size(); ++i, ++e) {
+			const int rec[21] = {e->left, e->right, e->rleft, e->rright, e->mch, e->mmc, e->gap, e->unp,
+			    e->mch5, e->mmc5, e->gap5, e->unp5, e->mch3, e->mmc3, e->gap3, e->unp3, e->phs,
+			    (int) e->escr, (int) e->iscr, (int) e->sig3, (int) e->sig5};
+			ej.insert(ej.end(), rec, rec + 21);
+		    }
+		}
+		snprintf(nm, sizeof nm, "rng_eij_A%d", alg);
+		w.put_i32(nm, ej);
+	    }
 	}
 	return 0;
 }

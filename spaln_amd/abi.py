@@ -170,7 +170,17 @@ class ScoringH(C.Structure):
         ("max_vmf_space", C.c_int32),
         ("ubh", C.c_int32),
         ("ref_nelem", C.c_int32),
+        ("lgop", C.c_int32),
+        ("gape1", C.c_int32), ("gape2", C.c_int32), ("extragop", C.c_int32),
+        ("diffu", C.c_int32), ("k1", C.c_int32),
+        ("intpen", C.c_void_p),
+        ("intpen_len", C.c_int32),
+        ("t53", C.c_int16 * 256),
     ]
+
+
+class RescoreParamsH(C.Structure):
+    _fields_ = [("minl", C.c_int32), ("jneibr", C.c_int32), ("lcl", C.c_int32), ("sup_tcodon", C.c_int32)]
 
 
 class ProblemH(C.Structure):
@@ -185,13 +195,15 @@ class ProblemH(C.Structure):
         ("b_left", C.c_int32), ("b_right", C.c_int32),
         ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
+        ("dinc", C.c_void_p),
     ]
 
 
 def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, gapw2, gapw3,
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
-                   ref_nelem=REF_NELEM) -> ScoringH:
+                   ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
+                   intpen=None, t53=None) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -209,6 +221,15 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
         sc.qm_pen[j] = int(qm_pen[j])
     sc.local, sc.term_codon, sc.sh = int(local), int(term_codon), int(sh)
     sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
+    sc.lgop, sc.gape1, sc.gape2, sc.extragop = int(lgop), int(gape1), int(gape2), int(extragop)
+    sc.diffu, sc.k1 = int(diffu), int(k1)
+    if intpen is not None:
+        ip = np.ascontiguousarray(intpen, dtype=np.int16)
+        sc._keep_intpen = ip
+        sc.intpen, sc.intpen_len = ip.ctypes.data, ip.size
+    if t53 is not None:
+        for i, v in enumerate(np.asarray(t53).ravel()[:256]):
+            sc.t53[i] = int(v)
     return sc
 
 
@@ -220,7 +241,7 @@ class ProblemSetH:
         self.items = []
 
     def add(self, a, b, sig5, sig3, sigS, sigT, sigE, phs5, phs3, a_left=0, a_right=None,
-            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None):
+            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None, dinc=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)          # b_len + 1 entries
         b_len = b.size - 1
@@ -237,6 +258,11 @@ class ProblemSetH:
         p.b_left, p.b_right = int(b_left), int(b_len if b_right is None else b_right)
         p.exin_left, p.exin_right = (p.b_left, p.b_right) if exin is None else (int(exin[0]), int(exin[1]))
         p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr = (int(x) for x in exg)
+        if dinc is not None:
+            dc = np.ascontiguousarray(dinc, dtype=np.uint8)
+            assert dc.size >= b_len + 1
+            self._keep.append(dc)
+            p.dinc = dc.ctypes.data
         self.items.append(p)
         return p
 

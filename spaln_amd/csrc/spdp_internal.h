@@ -91,6 +91,38 @@ struct RescoreArgs {
 };
 extern "C" hipError_t spdp_launch_rescore(const RescoreArgs* a, hipStream_t s);
 
+// skl_rngH_ng on the device
+struct HRescoreProb {
+    int32_t a_left, a_right, b_left, b_right;
+    int32_t a_len, b_len;
+    int32_t a_exgl, a_exgr, b_exgl, b_exgr;
+    int64_t a_off, b_off, col_off;
+};
+struct HRescoreArgs {
+    const int*        mtx;        // stride 32: mtx[aa * 32 + tron]
+    int               n_probs;
+    const HRescoreProb* probs;
+    const uint8_t*    a_codes;
+    const uint8_t*    b_codes;    // tron codes, b_len + 1 per problem
+    const short*      sig;        // per position 5 shorts: sig5, sig3, sigS, sigT, sigE
+    const int8_t*     phs;        // per position 2: phs5, phs3
+    const uint8_t*    dinc;
+    const int16_t*    intpen;
+    int               intpen_len;
+    const int2*       skl;
+    const int64_t*    skl_off;
+    const int*        skl_cnt;
+    const int64_t*    rec_off;
+    int*              out_hdr;
+    int*              out_rec;
+    int               gop, gep, lgop, lgep, codonk1, gape1, gape2, extragop, diffu, k1;
+    int               minl, jneibr, lcl, sup_tcodon;
+    int16_t           t53[256];
+    uint8_t           mid[32];    // tron code -> its codon's middle base (0..3), 4 = ambiguous
+    uint8_t           tron_of[64];// codon (A C G T order) -> tron code
+};
+extern "C" hipError_t spdh_launch_rescore(const void* args, hipStream_t s);
+
 // grow-only device allocations reused across launches (hipMalloc / hipFree of multi-GB
 // work buffers per batch costs seconds)
 struct DevPool {

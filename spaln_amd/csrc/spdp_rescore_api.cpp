@@ -2,6 +2,7 @@
 // spdp_rescore_s (spdp_rescore.hip) and hands the records back through the C ABI.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -101,4 +102,128 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
 void spdp_free_rescored(SpdpRescored* out, int n)
 {
     for (int i = 0; i < n; ++i) { free(out[i].exons); out[i].exons = nullptr; out[i].n_exons = 0; }
+}
+
+// ---- protein alignments: skl_rngH_ng ---------------------------------------------------------
+enum { RH_MTX = 8, RH_PROBS, RH_A, RH_B, RH_SIG, RH_PHS, RH_DINC, RH_INTPEN };   // pool slots after the cDNA ones
+
+// the standard genetic code in the reference's tron alphabet (A = 3 ... V = 22, AGY serines 23, TGA 24,
+// TAA / TAG 25), as its static spj_tron_tab / tnredctab assume (src/codepot.h:130, src/seq.cc:41)
+static void genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64])
+{
+    static const char* aas = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";   // TCAG order
+    static const char* order = "ARNDCQEGHILKMFPSTWYV";
+    const int tcag2acgt[4] = {3, 1, 0, 2};
+    memset(mid, 4, 32);
+    for (int c = 0; c < 64; ++c) {
+        const int b1 = tcag2acgt[c >> 4], b2 = tcag2acgt[(c >> 2) & 3], b3 = tcag2acgt[c & 3];
+        const char aa = aas[c];
+        int code;
+        if (aa == '*') code = (b1 == 3 && b2 == 2 && b3 == 0) ? 24 : 25;        // TGA : TAA / TAG
+        else if (aa == 'S' && b1 == 0) code = 23;                                // AGY
+        else code = 3 + (int) (strchr(order, aa) - order);
+        tron_of[16 * b1 + 4 * b2 + b3] = (uint8_t) code;
+        mid[code] = (uint8_t) b2;
+    }
+}
+
+int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                   const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out)
+{
+    if (!ctx || !sc || !rp || !probs || n_probs < 0 || !aln || !out) return -1;
+    if (rp->jneibr < 1 || rp->jneibr > 32) { ctx->err = "jneibr out of range (1 .. 32)"; return -1; }
+    for (int i = 0; i < n_probs; ++i) { memset(&out[i], 0, sizeof out[i]); out[i].score = SPDP_NEVSEL; }
+    if (!n_probs) return 0;
+    if (!sc->intpen || sc->intpen_len <= 0) { ctx->err = "rescoring needs SpdpScoringH.intpen / t53"; return -1; }
+    if (sc->mtx_rows > 32 || sc->mtx_cols > 32) { ctx->err = "matrix larger than 32 x 32"; return -1; }
+    std::vector<int> idx;
+    std::vector<HRescoreProb> descs;
+    std::vector<uint8_t> a_all, b_all, dinc;
+    std::vector<short> sig;
+    std::vector<int8_t> phs;
+    std::vector<SpdpSkl> skl;
+    std::vector<int64_t> soff, roff;
+    std::vector<int> scnt;
+    int64_t rtot = 0;
+    for (int i = 0; i < n_probs; ++i) {
+        const SpdpProblemH& p = probs[i];
+        const int cnt = aln[i].n_skl - 1;
+        if (cnt < 2 || !aln[i].skl) continue;
+        if (!p.dinc) { ctx->err = "rescoring needs SpdpProblemH.dinc"; return -1; }
+        if (p.b_len + 2 > sc->intpen_len) { ctx->err = "intpen table shorter than the window"; return -1; }
+        HRescoreProb d;
+        memset(&d, 0, sizeof d);
+        d.a_left = p.a_left; d.a_right = p.a_right; d.b_left = p.b_left; d.b_right = p.b_right;
+        d.a_len = p.a_len; d.b_len = p.b_len;
+        d.a_exgl = p.a_exgl; d.a_exgr = p.a_exgr; d.b_exgl = p.b_exgl; d.b_exgr = p.b_exgr;
+        d.a_off = (int64_t) a_all.size(); d.b_off = (int64_t) b_all.size(); d.col_off = (int64_t) phs.size() / 2;
+        a_all.insert(a_all.end(), p.a, p.a + p.a_len);
+        b_all.insert(b_all.end(), p.b, p.b + p.b_len + 1);
+        const int N = p.b_len + 3;
+        for (int x = 0; x < N; ++x) {
+            const short v[5] = {p.sig5[x], p.sig3[x], p.sigS[x], p.sigT[x], p.sigE[x]};
+            sig.insert(sig.end(), v, v + 5);
+            phs.push_back(p.phs5[x]); phs.push_back(p.phs3[x]);
+            dinc.push_back(x <= p.b_len ? p.dinc[x] : 0);
+        }
+        idx.push_back(i); descs.push_back(d);
+        soff.push_back((int64_t) skl.size()); scnt.push_back(cnt);
+        skl.insert(skl.end(), aln[i].skl + 1, aln[i].skl + 1 + cnt);
+        roff.push_back(rtot);
+        rtot += cnt + 3;                                    // exons, frame-shift records, end marker
+    }
+    const int nr = (int) idx.size();
+    if (!nr) return 0;
+    std::vector<int> mtx(32 * 32, 0);
+    for (int i = 0; i < sc->mtx_rows; ++i)
+        for (int j = 0; j < sc->mtx_cols; ++j) mtx[i * 32 + j] = sc->mtx[i * sc->mtx_cols + j];
+    DevPool& pool = ctx->pool[R_POOL];
+    void* d_mtx = pool.get(RH_MTX, mtx.size() * sizeof(int));
+    void* d_probs = pool.get(RH_PROBS, nr * sizeof(HRescoreProb));
+    void* d_a = pool.get(RH_A, a_all.size() + 16);
+    void* d_b = pool.get(RH_B, b_all.size() + 16);
+    void* d_sig = pool.get(RH_SIG, sig.size() * sizeof(short));
+    void* d_phs = pool.get(RH_PHS, phs.size());
+    void* d_dinc = pool.get(RH_DINC, dinc.size());
+    void* d_intpen = pool.get(RH_INTPEN, sizeof(int16_t) * sc->intpen_len);
+    void* d_skl = pool.get(RP_SKL, skl.size() * sizeof(SpdpSkl));
+    void* d_soff = pool.get(RP_SOFF, nr * sizeof(int64_t));
+    void* d_scnt = pool.get(RP_SCNT, nr * sizeof(int));
+    void* d_roff = pool.get(RP_ROFF, nr * sizeof(int64_t));
+    void* d_hdr = pool.get(RP_HDR, (size_t) nr * 8 * sizeof(int));
+    void* d_rec = pool.get(RP_REC, (size_t) rtot * 21 * sizeof(int));
+    if (!d_mtx || !d_probs || !d_a || !d_b || !d_sig || !d_phs || !d_dinc || !d_intpen || !d_skl || !d_soff ||
+        !d_scnt || !d_roff || !d_hdr || !d_rec) { ctx->err = "out of device memory"; return -1; }
+#define UP(dst, vec) HIPCHK(hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, ctx->stream))
+    UP(d_mtx, mtx); UP(d_probs, descs); UP(d_a, a_all); UP(d_b, b_all); UP(d_sig, sig); UP(d_phs, phs); UP(d_dinc, dinc);
+    UP(d_skl, skl); UP(d_soff, soff); UP(d_scnt, scnt); UP(d_roff, roff);
+#undef UP
+    HIPCHK(hipMemcpyAsync(d_intpen, sc->intpen, sizeof(int16_t) * sc->intpen_len, hipMemcpyHostToDevice, ctx->stream));
+    HRescoreArgs A;
+    memset(&A, 0, sizeof A);
+    A.mtx = (const int*) d_mtx; A.n_probs = nr; A.probs = (const HRescoreProb*) d_probs;
+    A.a_codes = (const uint8_t*) d_a; A.b_codes = (const uint8_t*) d_b; A.sig = (const short*) d_sig;
+    A.phs = (const int8_t*) d_phs; A.dinc = (const uint8_t*) d_dinc;
+    A.intpen = (const int16_t*) d_intpen; A.intpen_len = sc->intpen_len;
+    A.skl = (const int2*) d_skl; A.skl_off = (const int64_t*) d_soff; A.skl_cnt = (const int*) d_scnt;
+    A.rec_off = (const int64_t*) d_roff; A.out_hdr = (int*) d_hdr; A.out_rec = (int*) d_rec;
+    A.gop = sc->gop; A.gep = sc->gep; A.lgop = sc->lgop; A.lgep = sc->lgep; A.codonk1 = sc->codonk1;
+    A.gape1 = sc->gape1; A.gape2 = sc->gape2; A.extragop = sc->extragop; A.diffu = sc->diffu; A.k1 = sc->k1;
+    A.minl = rp->minl; A.jneibr = rp->jneibr; A.lcl = rp->lcl; A.sup_tcodon = rp->sup_tcodon;
+    memcpy(A.t53, sc->t53, sizeof A.t53);
+    genetic_code_tables(A.mid, A.tron_of);
+    HIPCHK(spdh_launch_rescore(&A, ctx->stream));
+    std::vector<int> hdr((size_t) nr * 8), rec((size_t) rtot * 21);
+    HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < nr; ++s) {
+        SpdpRescored& o = out[idx[s]];
+        const int* h = &hdr[(size_t) s * 8];
+        o.score = h[0]; o.mch = h[1]; o.mmc = h[2]; o.gap = h[3]; o.unp = h[4]; o.val = h[5];
+        o.n_exons = h[6];
+        o.exons = (SpdpExon*) malloc(sizeof(SpdpExon) * (size_t) std::max(1, o.n_exons));
+        memcpy(o.exons, &rec[(size_t) roff[s] * 21], sizeof(SpdpExon) * (size_t) o.n_exons);
+    }
+    return 0;
 }

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
 EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
-    "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
+    "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
@@ -56,6 +56,7 @@ def load_library() -> C.CDLL:
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_free_alignments.argtypes = [C.c_void_p, C.c_int]
     lib.spdp_skl_rng_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.spdp_skl_rng_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.spdp_free_rescored.argtypes = [C.c_void_p, C.c_int]
     lib.spdp_cells_h.restype = C.c_int64
     for f in ("spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h"):
@@ -161,6 +162,28 @@ class Engine:
         rp = abi.RescoreParams(int(codonk1), int(minl), int(jneibr), int(lsg))
         out = (abi.Rescored * n)()
         self._check(self.lib.spdp_skl_rng_s(self.ctx, C.byref(sc), C.byref(rp), ps.array(), n, arr, out), "spdp_skl_rng_s")
+        res = []
+        for i in range(n):
+            k = out[i].n_exons
+            ex = np.ctypeslib.as_array(C.cast(out[i].exons, C.POINTER(C.c_int32)), shape=(k, 21)).copy() if k else \
+                np.zeros((0, 21), dtype=np.int32)
+            res.append((int(out[i].score), [out[i].mch, out[i].mmc, out[i].gap, out[i].unp, out[i].val], ex))
+        self.lib.spdp_free_rescored(out, n)
+        return res
+
+    def skl_rng_h(self, sc, ps, alignments, *, minl, jneibr, lcl=15, sup_tcodon=0):
+        """skl_rngH_ng over finished protein alignments; returns as skl_rng_s does"""
+        n = len(ps)
+        keep = []
+        arr = (abi.Alignment * n)()
+        for i, skl in enumerate(alignments):
+            skl = np.ascontiguousarray(skl, dtype=np.int32).reshape(-1, 2)
+            keep.append(skl)
+            arr[i].score, arr[i].n_skl = 0, skl.shape[0]
+            arr[i].skl = C.cast(skl.ctypes.data, C.POINTER(abi.Skl))
+        rp = abi.RescoreParamsH(int(minl), int(jneibr), int(lcl), int(sup_tcodon))
+        out = (abi.Rescored * n)()
+        self._check(self.lib.spdp_skl_rng_h(self.ctx, C.byref(sc), C.byref(rp), ps.array(), n, arr, out), "spdp_skl_rng_h")
         res = []
         for i in range(n):
             k = out[i].n_exons

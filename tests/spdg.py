@@ -69,6 +69,9 @@ def scoring_h(fx: dict, nquant: int | None = None, **over) -> abi.ScoringH:
               nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
               term_codon=1 if h["lcl"] & 2 else 0, sh=q["sh"], max_vmf_space=q["max_vmf_space"],
               ubh=q["ubh"])
+    if "rparams" in fx:                                  # exact-model inputs of the rescoring walk
+        kw.update(lgop=q["lgop"], gape1=h["gape1"], gape2=h["gape2"], extragop=h["extragop"],
+                  diffu=int(fx["rparams"][0]), k1=h["k1"], intpen=fx["intpen"], t53=fx["t53"])
     kw.update(over)
     return abi.make_scoring_h(**kw)
 
@@ -80,7 +83,10 @@ def problem_h(fx: dict, ps: abi.ProblemSetH | None = None):
     # the harness builds the Exinon on the active range: good(n) <=> b_left - 1 <= n < b_right
     idx = np.nonzero(good)[0]
     assert idx[0] == max(0, q["b_left"] - 1) and idx[-1] == q["b_right"] - 1
+    dinc = None
+    if "dinc5" in fx:
+        dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
                fx["phs5"], fx["phs3"], q["a_left"], q["a_right"], q["b_left"], q["b_right"],
-               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]))
+               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), dinc=dinc)
     return ps, p

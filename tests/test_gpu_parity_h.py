@@ -223,3 +223,27 @@ def test_udh_ladder_against_oracle(eng):
                 bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, wflag, score, ws,
                             skl.ravel().tolist()[:12], (wskl or [])[:12]))
         assert not bad, bad[:3]
+
+
+def test_skl_rng_h_goldens(eng):
+    """spdp_skl_rng_h (skl_rngH_ng on the device) on the reference's own corner lists"""
+    bad, n_checked = [], 0
+    for f in H_FILES:
+        if _name(f) == "h1_cut_right":
+            continue                                  # alignment beyond the window: reference reads its heap
+        fx = spdg.load(f)
+        h = dict(zip(spdg.HPARAM_NAMES, (int(x) for x in fx["hparams"])))
+        rp = [int(x) for x in fx["rparams"]]
+        for alg in (0, 2, 3):
+            if f"rng_eij_A{alg}" not in fx:
+                continue
+            sc = spdg.scoring_h(fx, nquant=None if alg != 3 else 1)
+            ps, _ = spdg.problem_h(fx)
+            (score, fst, ex), = eng.skl_rng_h(sc, ps, [fx[f"aln_skl_A{alg}"].reshape(-1, 2)], minl=fx["prm"]["minl"],
+                                               jneibr=rp[4], lcl=h["lcl"], sup_tcodon=rp[1])
+            ok = (score == int(fx[f"rng_scr_A{alg}"][0]) and fst == [int(x) for x in fx[f"rng_fstat_A{alg}"][:5]]
+                  and ex.tolist() == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist())
+            n_checked += 1
+            if not ok:
+                bad.append((_name(f), alg, score, int(fx[f"rng_scr_A{alg}"][0]), fst, fx[f"rng_fstat_A{alg}"][:5].tolist()))
+    assert n_checked >= 60 and not bad, bad[:4]

@@ -82,3 +82,31 @@ def test_hirschberg_h1_wip(path, tag, n_im):
     assert s == int(fx[f"wip_{tag}_udh{n_im}_scr"][0])
     assert cpos.ravel().tolist() == fx[f"wip_{tag}_udh{n_im}_cpos"].tolist()
     assert rng.tolist() == fx[f"wip_{tag}_udh{n_im}_rng"][:4].tolist()
+
+
+
+def _rescore_kw(fx):
+    h = dict(zip(spdg.HPARAM_NAMES, (int(x) for x in fx["hparams"])))
+    rp = [int(x) for x in fx["rparams"]]
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    return dict(intpen=fx["intpen"], t53=fx["t53"], dinc=dinc, lgop=fx["prm"]["lgop"], diffu=rp[0], k1=h["k1"],
+                gape1=h["gape1"], gape2=h["gape2"], extragop=h["extragop"], minl=fx["prm"]["minl"],
+                jneibr=rp[4], lcl=h["lcl"], lsg=rp[5], sup_tcodon=rp[1], many=rp[3])
+
+
+@pytest.mark.parametrize("alg", [0, 2, 3])
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_skl_rng_h_vs_reference(path, alg):
+    """skl_rngH_ng restated: total score, statistics and per-exon / frame-shift records from the
+    reference's own corner lists"""
+    fx = spdg.load(path)
+    if f"rng_eij_A{alg}" not in fx:
+        pytest.skip("no alignment under this selector")
+    if _name(path) == "h1_cut_right":
+        pytest.skip("alignment lies beyond the window: the reference reads its heap (undefined)")
+    sc = spdg.scoring_h(fx, nquant=None if alg != 3 else 1)
+    _, p = spdg.problem_h(fx)
+    h, fst, recs = hh.skl_rng_h(sc, p, [int(x) for x in fx[f"aln_skl_A{alg}"]], **_rescore_kw(fx))
+    assert h == int(fx[f"rng_scr_A{alg}"][0])
+    assert fst == [int(x) for x in fx[f"rng_fstat_A{alg}"][:5]]
+    assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()

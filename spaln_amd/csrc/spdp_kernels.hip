@@ -77,6 +77,13 @@ __device__ __forceinline__ int2 ld_nt2(const int* p)
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
+// Ordering inside ONE wave needs no hardware fence: a wave's LDS instructions execute in order, and so
+// do its vector-memory instructions (a load issued after a store of the same wave to the same address
+// observes it; the rows of a pass are >= SPDP_GROUP_LAG blocks apart anyway).  Only the compiler must
+// not move accesses across these points.  (A wavefront-scope __builtin_amdgcn_fence would do, but it
+// makes the compiler emit s_waitcnt vmcnt(0) right after the prefetch loads -- no prefetch left.)
+#define WAVE_ORDER() asm volatile("" ::: "memory")
+
 // intron-length penalty modes: flat (nquant == 1, the -A3 model), LDS table, select chain
 enum { NQ_FLAT = 0, NQ_TABLE = 1, NQ_CHAIN = 2 };
 #define SPDP_PEN_TAB 2048
@@ -268,13 +275,9 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 const int nn = n_start + lbn * 16 + k;                  // sweep step this lane loads for
                 if constexpr (FL == FL_UDH) nx_b = ld_nt4(bnd + (int64_t) BIDX(nn - ml) * 4);
                 else { const int2 v = ld_nt2(bnd + (int64_t) BIDX(nn - ml) * 2); nx_b.x = v.x; nx_b.y = v.y; }
-                // column records are stored per absolute position of the parent sequence; the window
-                // edges are applied here: nothing beyond b_right, no residue at b_left
-                int2 crec = make_int2(0, 0);
-                if (nn <= b_right) crec = cols[nn];
-                if (!spj) crec.x = 0;
-                if (nn <= b_left) crec.y = 0;
-                nx_c = crec;
+                // raw record: nothing may depend on the loaded value here, or the compiler has to wait
+                // for the load on the spot and the prefetch is gone (nn < b_len + SPDP_COL_PAD always)
+                nx_c = cols[nn];
             };
             // multi-wave: row 0 reads boundary entries of the previous pass, produced by wave `prod`;
             // local block lbn of row 0 needs its absolute blocks <= lbn + 15 flushed (3 rows x LAG + 3)
@@ -311,13 +314,19 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                     if constexpr (FL == FL_UDH) reinterpret_cast<int4*>(feed)[k] = nx_b;
                     else reinterpret_cast<int2*>(feed)[k] = make_int2(nx_b.x, nx_b.y);
                     {
+                        // column records are stored per absolute position of the parent sequence; the
+                        // window edges are applied here: nothing beyond b_right, no residue at b_left
+                        const int nn = n0 + k;
+                        int2 crec = nx_c;
+                        if (nn > b_right) crec = make_int2(0, 0);
+                        if (!spj) crec.x = 0;
+                        if (nn <= b_left) crec.y = 0;
                         const int slot = (lb * 16 + k + 16) % 48;
-                        colring[slot] = nx_c; colring[slot + 48] = nx_c;
+                        colring[slot] = crec; colring[slot + 48] = crec;
                     }
                     // ---- ... and the next block's loads are issued now, to land while this one computes
                     if (lb + 1 < nb) prefetch(lb + 1);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    WAVE_ORDER();
                     // lane k reads column n0 + J - k at step J: one contiguous run of 16 ring slots
                     const int2* const mycol = colring + ((lb * 16 - k + 16 + 48) % 48);
                     uint32_t code4[4] = {0, 0, 0, 0};
@@ -458,8 +467,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 // boundary entries are exchanged between the rows of this wave through memory: a
                 // load issued after a store of the same wave to the same address observes it (in-order
                 // vector memory path, loads bypass L1), so only the compiler needs a fence here
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                WAVE_ORDER();
                 if (W > 1) {                                            // publish: this block's stores are done
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0)

@@ -22,3 +22,7 @@ for rep in range(2):
     t = time.perf_counter()
     eng.wip_scoreonly(sc, ps)
     print("score", round(time.perf_counter() - t, 3), "s wall")
+for rep in range(2):
+    t = time.perf_counter()
+    eng.wip_udh(sc, ps, 8)
+    print("udh8", round(time.perf_counter() - t, 3), "s wall")

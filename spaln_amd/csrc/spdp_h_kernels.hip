@@ -246,18 +246,21 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
         int2 nx_b = make_int2(0, 0);
         int4 nx_c = make_int4(0, 0, 0, 0);
         // column record as lanes see it: window edges applied
-        auto load_col = [&](int c) -> int4 {
-            int4 rec = make_int4(0, 0, 0, 0);
-            if (c >= 0 && c < col_len) rec = cols[c];
+        // column record as lanes see it: window edges applied
+        auto mask_col = [&](int4 rec, int c) -> int4 {
+            if (c < 0 || c >= col_len) rec = make_int4(0, 0, 0, 0);
             if (c >= b_right) rec.x &= 0x00ffffff;                          // nothing splices at n >= b_right
             if (c < b_left + 3 || c > b_right + 2) rec.x = (rec.x & (int) 0xff00ffffu) | (SPDH_ZCODE << 16);
             return rec;
         };
+        auto load_col = [&](int c) -> int4 { return mask_col(cols[min(max(c, 0), col_len - 1)], c); };
         auto prefetch = [&](int lbn) {
             const int nn = n_start + lbn * 16 + k;                  // sweep step this lane loads for
             const int e = min(nn + e_base, n_ent - 1);
             nx_b = ld_nt2(bnd + e);
-            nx_c = load_col(nn);
+            // raw record (masks are applied when it is consumed: nothing may depend on the loaded value
+            // here, or the compiler waits for the load on the spot and the prefetch is gone)
+            nx_c = cols[min(max(nn, 0), col_len - 1)];
         };
         auto run_pass = [&](auto partial_tag) __attribute__((always_inline)) {
         constexpr bool PARTIAL = decltype(partial_tag)::value;
@@ -284,10 +287,9 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     }
                 }
                 feed[k] = nx_b;
-                ring[(n0 + k) & 63] = nx_c;
+                ring[(n0 + k) & 63] = mask_col(nx_c, n0 + k);
                 if (lb + 1 < nb) prefetch(lb + 1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                asm volatile("" ::: "memory");      // wave-internal ordering: see spdp_kernels.hip WAVE_ORDER
 
 #pragma unroll
                 for (int J = 0; J < 16; ++J) {
@@ -447,8 +449,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
             // boundary entries are exchanged between the rows of this wave through memory: a load
             // issued after a store of the same wave to the same address observes it (in-order vector
             // memory path, loads bypass L1), so only the compiler needs a fence here
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
         }
         };
         // only the last stripe of a problem can be partial (fewer than 16 rows)

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64.0 + 1.0}
 HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
-PMC_TRAFFIC_BYTES = int((81013809 + 193130163) * 1024)
+PMC_TRAFFIC_BYTES = int((70322106 + 207443561) * 1024)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
 PMC_TRAFFIC_BYTES_H = int((37826839 + 146710905) * 1024)
 

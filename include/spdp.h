@@ -228,13 +228,14 @@ typedef struct SpdpScoringH {
     int32_t max_vmf_space;           /* MaxVmfSpace                                         */
     int32_t ubh;                     /* alprm.ubh                                           */
     int32_t ref_nelem;               /* 16                                                  */
-    /* ---- rescoring only (spdp_skl_rng_h); zero / NULL otherwise ------------------------------- */
+    /* ---- rescoring (spdp_skl_rng_h) and the scalar engine (forwardH_ng) only; zero / NULL otherwise */
     int32_t lgop;                    /* PwdB::LongGOP                                       */
     int32_t gape1, gape2, extragop;  /* PwdB::GapE1, GapE2, ExtraGOP (frame-shift terms)    */
     int32_t diffu, k1;               /* PwdB::diffu, alprm.k1 (UnpPenalty3, src/aln.h:290)  */
     const int16_t* intpen;           /* IntronPenalty::Penalty(len), len in [0, intpen_len) */
     int32_t intpen_len;
     int16_t t53[256];                /* sig53(m, n, IE53) - sig3[n] by 16 * dinc5[m] + dinc3[n] */
+    int32_t minl;                    /* IntronPrm.minl (scalar engine: shortest intron; 0 = llmt)   */
 } SpdpScoringH;
 
 typedef struct SpdpProblemH {

@@ -48,18 +48,21 @@ class ReferenceUndefined(Exception):
     """the reference starts its traceback outside the bitmap (out-of-bounds read) on this input"""
 
 
-def homscore_h(sc: abi.ScoringH, p: abi.ProblemH) -> int:
-    if p.a_right - p.a_left < 8:
-        raise NotRestated("forwardH_ng (m < 8)")
+def homscore_h(sc: abi.ScoringH, p: abi.ProblemH, simd: int = 2) -> int:
+    """simd = algmode.alg & 3: 0 runs the scalar forwardH_ng (as does any problem below 8 rows)"""
+    if simd == 0 or p.a_right - p.a_left < 8:
+        return oracle.scalar_forward_h(sc, p, oracle.stripe31(p, sc.sh), traceback=False)[0]
     s, _, _ = oracle.wip_forward_h(sc, p, oracle.stripe31(p, sc.sh))
     return s
 
 
-def trcbk_h(sc, p, w, rec):
+def trcbk_h(sc, p, w, rec, simd=2):
     if w.width < 0:
         return abi.NEVSEL
-    if p.a_right - p.a_left < 8:
-        raise NotRestated("forwardH_ng (m < 8)")
+    if simd == 0 or p.a_right - p.a_left < 8:             # forwardH_ng + Vmf::traceback
+        s, skl = oracle.scalar_forward_h(sc, p, w)
+        rec.extend((int(m), int(n)) for m, n in skl)
+        return s
     s, skl, bad = oracle.wip_forward_h(sc, p, w)
     if bad == -2:
         raise ReferenceFatal("Unexpected dir")
@@ -69,7 +72,7 @@ def trcbk_h(sc, p, w, rec):
     return s
 
 
-def lsp_h(sc, p, w, rec):
+def lsp_h(sc, p, w, rec, simd=2):
     m = p.a_right - p.a_left
     n = p.b_right - p.b_left
     if not m and not n:
@@ -79,10 +82,15 @@ def lsp_h(sc, p, w, rec):
     if w.up == w.lw:
         raise NotRestated("diagonalH_ng")
     if abs(n - m) < NELEM or m == 1 or n <= 3:
-        return trcbk_h(sc, p, w, rec)
-    cvol = _f32(_f32(m) * _f32(n + 3 * m))
+        return trcbk_h(sc, p, w, rec, simd)
+    if simd < 2:                                          # hexagonal
+        k = _f32(w.lw - p.b_left + 3 * p.a_right)
+        q = _f32(p.b_right - 3 * p.a_left - w.up)
+        cvol = _f32(_f32(_f32(m) * _f32(n)) - _f32(_f32(_f32(k * k) + _f32(q * q)) / 6))
+    else:                                                 # rhombic
+        cvol = _f32(_f32(m) * _f32(n + 3 * m))
     if _f32(COEF_B * cvol) < sc.max_vmf_space:
-        return trcbk_h(sc, p, w, rec)
+        return trcbk_h(sc, p, w, rec, simd)
     recursive = False
     n_imd = 1
     z = 2.0 * m * COEF_B / COEF_C
@@ -97,7 +105,9 @@ def lsp_h(sc, p, w, rec):
         if intvl * n_imd == m:
             n_imd -= 1
         if n_imd == 0:
-            return trcbk_h(sc, p, w, rec)
+            return trcbk_h(sc, p, w, rec, simd)
+    if simd < 2:
+        raise NotRestated("hirschbergH_ng / hirschbergH1 (linear space under -A0 / -A1)")
     scr, cpos, rng = oracle.wip_udh_h(sc, p, n_imd, w)
     if scr > abi.NEVSEL:
         cur = _sub(p, int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]),
@@ -195,10 +205,10 @@ def _cmod(a, b):
     return a - _cdiv(a, b) * b
 
 
-def align_h(sc, p):
+def align_h(sc, p, simd=2):
     """alignH_ng with seeding off.  Returns (score, [flags, n, m1, n1, ...] or None)."""
     rec = []
-    scr = lsp_h(sc, p, oracle.stripe31(p, sc.sh), rec)
+    scr = lsp_h(sc, p, oracle.stripe31(p, sc.sh), rec, simd)
     if len(rec) < 2:
         return scr, None
     s = std_skl3(rec)

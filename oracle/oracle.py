@@ -18,7 +18,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c", "spdp_oracle_h.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c", "spdp_oracle_h.c",
+                                                "spdp_oracle_h_scalar.c")]
     hdr = os.path.join(_HERE, "..", "include", "spdp.h")
     newest = max(os.path.getmtime(f) for f in srcs + [hdr])
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
@@ -143,3 +144,22 @@ def wip_udh_h(sc, p, n_im: int, w=None):
     if rc:
         raise RuntimeError(f"orc_wip_udh_h rc={rc}")
     return s.value, cpos, rng
+
+
+def scalar_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None, traceback=True):
+    """Aln2h1::forwardH_ng (+ the record hand-over of trcbkalignH_ng when traceback): the -A0 engine,
+    also the -A2/-A3 fallback below 8 query rows.  Returns (score, records end -> start)."""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    if traceback:
+        rc = lib().orc_scalar_forward_h(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    else:
+        rc = lib().orc_scalar_forward_h(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), None, None)
+    if rc:
+        raise RuntimeError(f"orc_scalar_forward_h rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out

@@ -1,0 +1,460 @@
+/* spdp_oracle_h_scalar.c -- CPU restatement of the reference's SCALAR protein x genome engine.
+ *
+ * TEST INFRASTRUCTURE ONLY (same rules as spdp_oracle.c): tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may use it as the checker; the product never links or calls it.
+ *
+ * Restates (ogotoh/spaln v3.0.7):
+ *   orc_scalar_forward_h   Aln2h1::forwardH_ng                        src/fwd2h1.cc:294-617
+ *                          + initH_ng / lastH_ng                      src/fwd2h1.cc:143-208 / 210-292
+ *                          + Vmf::traceback                           src/vmf.cc:125-140
+ *                          + the record fix-up of trcbkalignH_ng      src/fwd2h1.cc:2019-2036
+ * This is the -A0 engine (int32, row by row, exact intron-length penalty with the top-NCAND donor
+ * list per row and codon phase) -- also what the -A2/-A3 dispatch falls back to for sub-problems
+ * with fewer than 8 query rows (trcbkalignH_ng src/fwd2h1.cc:2005, HomScoreH_ng :3297).
+ * Affine gaps (Noll = 2), no cip, no cut range.  Junction terms:
+ *   spjscr(jnc, n) = IntPen(n - jnc) + sig3[n] + T53[16 * dinc5[jnc] + dinc3[n]]
+ *     (SpJunc::spjscr src/codepot.cc:74-77, Exinon::sig53 IE53 src/codepot.cc:411-415)
+ *   spjseq(jnc, n): the two codons the four bases around an intron spell (src/codepot.cc:79-107),
+ *     rebuilt here from the standard genetic code; a word with an ambiguous base reads as (AMB, AMB).
+ * Positions outside the sequences read the Seq padding (amb_code, Seq::fillpad src/seq.cc:491-496).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include "../include/spdp.h"
+
+#define NCAND 4
+#define NOD 3                                   /* 2 * Noll - 1 for Noll = 2: DIAG, HORI, VERT */
+#define NQUE 3
+#define AMB 2
+
+/* TraceBackDir, src/aln.h:30-35 */
+enum { DEAD, RSRV, DIAG, NEWD, VERT, SLA1, SLA2, VERL, HORI, HOR1, HOR2, HORL, NEWV, NEWH, SPIN = 16 };
+static const int dir2nod[16] = {-1, -1, 0, 0, 2, 2, 2, 4, 1, 1, 1, 3, 2, 1, -1, -1};    /* src/aln.h:50 */
+static const int nod2dir[5] = {DIAG, HORI, VERT, HORL, VERL};
+static const char is_diag[16] = {0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      /* src/aln.h:67-69 */
+static const char is_vert[16] = {0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 0, 0, 0};
+static const char is_hori[16] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 0};
+
+typedef struct { int val, ptr, dir; } Rvpd;
+typedef struct { int val, ptr, dir, jnc; } Rvpdj;
+typedef struct { int m, n, p; } Sklp;
+typedef struct { Sklp* rec; int n, cap, on; } Vmf;
+
+static int vmf_add(Vmf* v, int m, int n, int p)
+{
+    if (!v->on) return 0;
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->rec = (Sklp*) realloc(v->rec, v->cap * sizeof(Sklp)); }
+    v->rec[v->n].m = m; v->rec[v->n].n = n; v->rec[v->n].p = p;
+    return v->n++;
+}
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+/* genetic code -> tron codes (aa codes 3.. in the order ARNDCQEGHILKMFPSTWYV; AGY serine 23, TGA 24,
+ * TAA / TAG 25) and the middle base (A C G T = 0..3) each tron code pins */
+static uint8_t g_tron_of[64];                   /* index 16 * b1 + 4 * b2 + b3, bases A C G T */
+static uint8_t g_mid[32];
+static int g_tabs = 0;
+static void code_tables(void)
+{
+    if (g_tabs) return;
+    static const char* aas = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";   /* T C A G order */
+    static const char* order = "ARNDCQEGHILKMFPSTWYV";
+    static const int tcag[4] = {3, 1, 0, 2};    /* T C A G as A C G T indices */
+    memset(g_mid, 4, sizeof g_mid);
+    for (int c = 0; c < 64; ++c) {
+        const int b1 = tcag[c >> 4], b2 = tcag[(c >> 2) & 3], b3 = tcag[c & 3];
+        const char aa = aas[c];
+        int code;
+        if (aa == '*') code = (b1 == 3 && b2 == 2 && b3 == 0) ? 24 : 25;
+        else if (aa == 'S' && b1 == 0) code = 23;
+        else code = 3 + (int) (strchr(order, aa) - order);
+        g_tron_of[16 * b1 + 4 * b2 + b3] = (uint8_t) code;
+        g_mid[code] = (uint8_t) b2;
+    }
+    g_tabs = 1;
+}
+
+typedef struct {
+    const SpdpScoringH* sc;
+    const SpdpProblemH* p;
+    int minl;
+} Ctx;
+
+static inline int a_code(const Ctx* c, int i) { return (i < 0 || i >= c->p->a_len) ? AMB : c->p->a[i]; }
+static inline int b_code(const Ctx* c, int i) { return (i < 0 || i > c->p->b_len) ? AMB : c->p->b[i]; }
+static inline int mtx_at(const Ctx* c, int aa, int tron) { return c->sc->mtx[aa * c->sc->mtx_cols + tron]; }
+static inline int gap_ext3(const SpdpScoringH* sc, int i) { return i > sc->codonk1 ? sc->lgep : sc->gep; }
+static inline int intpen(const SpdpScoringH* sc, int len)
+{
+    if (len < 0) return SHRT_MIN;
+    if (len >= sc->intpen_len) len = sc->intpen_len - 1;
+    return sc->intpen[len];
+}
+static inline int spjscr(const Ctx* c, int jnc, int n)
+{
+    const SpdpProblemH* p = c->p;
+    return intpen(c->sc, n - jnc) + p->sig3[n] + c->sc->t53[16 * (p->dinc[jnc] >> 4) + (p->dinc[n] & 15)];
+}
+static void spjseq(const Ctx* c, int n5, int n3, int cs[2])
+{
+    const SpdpProblemH* p = c->p;
+    cs[0] = cs[1] = AMB;
+    if (n5 < p->b_left || n3 >= p->b_right) return;
+    const int idx[4] = {n5 - 2, n5 - 1, n3, n3 + 1};
+    int w[4];
+    for (int i = 0; i < 4; ++i) {
+        const int t = b_code(c, idx[i]);
+        if (t >= 32 || g_mid[t] > 3) return;
+        w[i] = g_mid[t];
+    }
+    cs[0] = g_tron_of[16 * w[0] + 4 * w[1] + w[2]];
+    cs[1] = g_tron_of[16 * w[1] + 4 * w[2] + w[3]];
+}
+
+/* rc 0 ok; -1 unsupported parameters.  skl / n_skl may be NULL (score only: no Vmf, as HomScoreH_ng
+ * runs it).  With a traceback the records come back end -> start as trcbkalignH_ng writes them. */
+int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w,
+                         int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    if (skl) { *skl = 0; *n_skl = 0; }
+    if (!sc->intpen || !p->dinc) return -1;
+    if (w->width < 0) { *score = SPDP_NEVSEL; return 0; }
+    code_tables();
+    const int minl = sc->minl ? sc->minl : sc->llmt;
+    Ctx cx = {sc, p, minl};
+    const int NEV = SPDP_NEVSEL;
+    const Rvpd black = {NEV, 0, 0};
+    const Rvpdj blackj = {NEV, 0, 0, 0};
+    const int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
+    const int Local = sc->local;
+    const int LocalL = Local && p->a_exgl && p->b_exgl;
+    const int LocalR = Local && p->a_exgr && p->b_exgr;
+    const int spj = sc->spj;
+    const int lw = w->lw, up = w->up, width = w->width;
+    const int GOP[2] = {0, sc->gop};
+    const size_t bufsiz = (size_t) 2 * width;
+    Rvpd* buf = (Rvpd*) malloc((bufsiz + 8) * sizeof(Rvpd));
+    for (size_t i = 0; i < bufsiz + 8; ++i) buf[i] = black;
+    Rvpd* hh0 = buf - lw + 3;
+    Rvpd* hh1 = hh0 + width;
+    Vmf vmf = {0, 0, 0, skl != 0};
+    vmf_add(&vmf, 0, 0, 0);                     /* skip 0-th record */
+
+    /* ---- initH_ng ---- */
+    {
+        int n = bl;
+        int r = bl - 3 * al;
+        int rr = br - 3 * al;
+        const int dir = p->a_exgl ? DEAD : DIAG;
+        int jnc[3] = {n, 0, 0};
+        int bb = n + 1;
+        Rvpd* h = hh0 + r;
+        h->val = (p->a_exgl && p->sigS[bb] > 0) ? p->sigS[bb] : 0;
+        h->dir = dir;
+        h->ptr = vmf_add(&vmf, al, n, 0);
+        if (p->a_exgl) {
+            if (up < rr) rr = up;
+            for (int i = 1; ++r <= rr; ++i) {
+                ++h; ++bb; ++n;
+                if (i < 3) {
+                    h->val = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+                    h->dir = dir;
+                    h->ptr = vmf_add(&vmf, al, n, 0);
+                    jnc[i] = n;
+                } else {
+                    *h = h[-3];
+                    const int k = n - jnc[i % 3];
+                    if (k == 3 && !(p->a_exgl & 1)) h->val += sc->gop;
+                    if (!(p->a_exgl & 2)) h->val += gap_ext3(sc, k);
+                    h->val += p->sigE[bb - 3];
+                    h->dir = HORI;
+                    int x = h[-1].val + sc->gapw1;
+                    if (x > h->val) { *h = h[-1]; h->val = x; h->dir = HOR1; }
+                    x = h[-2].val + sc->gapw2;
+                    if (x > h->val) { *h = h[-2]; h->val = x; h->dir = HOR2; }
+                }
+                const int x = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+                if (h->val < x) {
+                    h->val = x;
+                    h->dir = DEAD;
+                    h->ptr = vmf_add(&vmf, al, n, 0);
+                    jnc[i % 3] = n;
+                }
+            }
+        }
+        r = bl - 3 * al;
+        rr = bl - 3 * ar;
+        h = hh0 + r - 1;
+        if (lw > rr) rr = lw;
+        for (int i = 1; --r >= rr; ++i, --h) {
+            if (p->b_exgl == 1) { h->val = 0; h->dir = DEAD; h->ptr = 0; }
+            else if (i <= 3) {
+                *h = h[i];
+                if (!(p->b_exgl & 2)) h->val += sc->gep;
+                if (!(p->b_exgl & 1)) h->val += sc->gop;
+                if (i < 3) h->val += sc->extragop;
+                h->dir = VERT;
+            } else {
+                *h = h[3];
+                if (!(p->b_exgl & 2)) h->val += gap_ext3(sc, i);
+            }
+        }
+    }
+
+    int maxh_val = NEV, maxh_m = al, maxh_n = bl, maxh_p = 0;
+    int m = al;
+    if (!p->a_exgl) --m;
+    int n1 = 3 * m + lw - 1;
+    int n2 = 3 * m + up;
+    for ( ; ++m <= ar; ) {
+        n1 += 3; n2 += 3;
+        const int n0 = imax(n1, bl);
+        const int n9 = imin(n2, br);
+        int n = n0;
+        int r = n - 3 * m;
+        Rvpd e1[NQUE] = {black, black, black};
+        if (!p->b_exgl && m == al) { e1[2] = hh0[r]; e1[2].val = sc->gapw3; }
+        Rvpd* h = hh0 + r;
+        Rvpd* f = hh1 + r;
+        Rvpd* hf[NOD] = {h, 0, f};
+        const int aa0 = a_code(&cx, m - 1), aa1 = a_code(&cx, m);
+        Rvpdj hl[3][NCAND + 1];
+        int nx[3][NCAND + 1];
+        for (int ph = 0; ph < 3; ++ph)
+            for (int l = 0; l <= NCAND; ++l) { hl[ph][l] = blackj; nx[ph][l] = l; }
+        int ncand[3] = {-1, -1, -1};
+        for (int q = 0; n <= n9; ++n, ++h, ++f) {
+            int x, y;
+            hf[0] = h; hf[2] = f;
+            const int sigE = (n > bl) ? p->sigE[n - 2] : 0;
+            Rvpd* const eq1 = hf[1] = e1 + q;
+            const Rvpd hq = *h;                 /* previous state */
+            Rvpd* from = h;
+            Rvpd* mx = h;
+            if (m != al) {
+                /* diagonal match */
+                if (n < bl + 3) *h = black;
+                else {
+                    h->val += mtx_at(&cx, aa0, b_code(&cx, n - 2)) + sigE;
+                    h->dir = is_diag[from->dir & 15] ? DIAG : NEWD;
+                }
+                /* vertical gap extension, 1 / 2 nt deletions, codon deletion */
+                y = f[3].val + sc->gep;
+                ++from;
+                x = from->val + (is_vert[from->dir & 15] ? sc->gape1 : sc->gapw1);
+                if (x > y) { f->val = x; f->dir = SLA2; f->ptr = from->ptr; }
+                else f->val = y;
+                ++from;
+                x = from->val + (is_vert[from->dir & 15] ? sc->gape2 : sc->gapw2);
+                if (x > f->val) { f->val = x; f->dir = SLA1; f->ptr = from->ptr; }
+                x = (++from)->val + sc->gapw3;
+                if (x >= f->val) { f->val = x; f->dir = VERT; f->ptr = from->ptr; }
+                else if (y >= f->val) { f->val = y; f->dir = VERT; f->ptr = f[3].ptr; }
+                if (f->val > mx->val) mx = f;
+            }
+            /* insertions of a codon, 2 nt, 1 nt */
+            if (n > n0 + 2) {
+                from = h - 3;
+                x = from->val + sc->gapw3;
+                y = eq1->val += sc->gep;
+                if (x > y) { *eq1 = *from; eq1->val = x; }
+                eq1->val += sigE;
+                eq1->dir = (eq1->dir & SPIN) + HORI;
+            }
+            if (n > n0 + 1) {
+                from = h - 2;
+                x = from->val + sc->gapw2;
+                if (x > eq1->val) { *eq1 = *from; eq1->val = x; eq1->dir = (eq1->dir & SPIN) + HOR2; }
+            }
+            from = h - 1;
+            x = from->val + sc->gapw1;
+            if (x > eq1->val) { *eq1 = *from; eq1->val = x; eq1->dir = (eq1->dir & SPIN) + HOR1; }
+            if (eq1->val > mx->val) mx = eq1;
+            if (++q == NQUE) q = 0;
+
+            /* intron 3' boundary */
+            if (spj && p->phs3[n] > -2) {
+                int phs = (p->phs3[n] == 2) ? -1 : p->phs3[n];
+                for (;;) {
+                    const int nb = n - phs;
+                    const int* pnx = nx[phs + 1];
+                    const Rvpdj* maxphl[NOD] = {0, 0, 0};
+                    for (int l = 0; l <= ncand[phs + 1]; ++l) {
+                        const Rvpdj* phl = hl[phs + 1] + pnx[l];
+                        if (phs == 1 && phl->dir == 2) continue;
+                        if (nb - phl->jnc < minl) continue;
+                        x = phl->val + spjscr(&cx, phl->jnc, nb);
+                        if (phl->dir == 0 && phs) {
+                            int cs[2];
+                            spjseq(&cx, phl->jnc, nb, cs);
+                            if (phs == 1) x += mtx_at(&cx, aa0, cs[0]);
+                            else x += mtx_at(&cx, aa1, cs[1]) - mtx_at(&cx, aa1, b_code(&cx, n + 1)) - p->sigE[n + 1];
+                        }
+                        from = hf[phl->dir];
+                        if (x > from->val) { from->val = x; maxphl[phl->dir] = phl; }
+                    }
+                    for (int d = 0; d < NOD; ++d) {
+                        const Rvpdj* phl = maxphl[d];
+                        if (!phl) continue;
+                        from = hf[d];
+                        if (vmf.on) {
+                            const int inner = vmf_add(&vmf, m, phl->jnc + phs, phl->ptr);
+                            from->ptr = vmf_add(&vmf, m, n, inner);
+                        }
+                        from->dir = nod2dir[phl->dir] | SPIN;
+                        if (from->val > mx->val) mx = from;
+                    }
+                    if (p->phs3[n] - phs == 3) { phs = 1; continue; }   /* AGAG */
+                    break;
+                }
+            }
+
+            /* optimal path */
+            y = h->val;
+            if (h != mx) *h = *mx;
+            else if (Local && y > hq.val) {
+                if (LocalL && hq.dir == 0 && !(h->dir & SPIN)) h->ptr = vmf_add(&vmf, m - 1, n - 3, 0);
+                else if (LocalR && y > maxh_val) { maxh_val = y; maxh_p = h->ptr; maxh_m = m; maxh_n = n; }
+            }
+            if (LocalL && h->val <= 0) h->val = h->dir = 0;
+            else if (vmf.on && h->dir == NEWD) h->ptr = vmf_add(&vmf, m - 1, n - 3, h->ptr);
+
+            /* intron 5' boundary */
+            if (spj && p->phs5[n] > -2) {
+                int phs = (p->phs5[n] == 2) ? -1 : p->phs5[n];
+                for (;;) {
+                    const int nb = n - phs;
+                    const int sigJ = p->sig5[nb];
+                    const int hd = dir2nod[mx->dir & 15];
+                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < NOD; ++k) {
+                        const int crossspj = phs == 1 && k == 0;
+                        const Rvpd* src = crossspj ? &hq : hf[k];
+                        if (!src->dir || (src->dir & SPIN)) continue;        /* no orphan exon */
+                        if (!crossspj && k != hd && hd >= 0) {
+                            y = mx->val;
+                            if (hd == 0 || (k - hd) % 2) y += GOP[k / 2];
+                            if (src->val <= y) continue;                     /* prune */
+                        }
+                        x = src->val + sigJ;
+                        Rvpdj* phl = hl[phs + 1];
+                        int* pnx = nx[phs + 1];
+                        int* nc = &ncand[phs + 1];
+                        int l = *nc < NCAND ? ++*nc : NCAND;
+                        while (--l >= 0) {
+                            if (x >= phl[pnx[l]].val) { const int t = pnx[l]; pnx[l] = pnx[l + 1]; pnx[l + 1] = t; }
+                            else break;
+                        }
+                        if (++l < NCAND) {
+                            phl += pnx[l];
+                            phl->val = x; phl->jnc = nb; phl->dir = k; phl->ptr = src->ptr;
+                        } else --*nc;
+                    }
+                    if (p->phs5[n] - phs == 3) { phs = 1; continue; }   /* GTGT */
+                    break;
+                }
+            }
+        }
+    }
+
+    int ptr = 0, scr;
+    if (!LocalR || maxh_m == ar) {              /* ---- lastH_ng ---- */
+        static const int next_p[3] = {1, 2, 0};
+        int glen[3] = {0, 0, 0};
+        int rw = lw;
+        const int m3 = 3 * ar;
+        int rf = bl - m3;
+        if (rf > rw) rw = rf; else rf = rw;
+        Rvpd* h = hh0 + rw;
+        Rvpd* h9 = hh0 + br - m3;
+        Rvpd* mx = h9;
+        int bb = rw + m3;
+        int done = 0;
+        if (p->a_exgr) {
+            for (int ph = 0; h <= h9; ++h, ++bb, ++rf, ph = next_p[ph]) {
+                glen[ph] += 3;
+                int cand[3] = {h->val, NEV, NEV};
+                if (rf - rw >= 3 && h[-3].dir != DEAD) {
+                    cand[1] = h[-3].val + p->sigE[bb - 2];
+                    if (!(p->a_exgr & 2)) cand[1] += gap_ext3(sc, glen[ph]);
+                    if (!(p->a_exgr & 1) && glen[ph] == 3) cand[1] += sc->gop;
+                    if (p->sigT[bb - 2] > 0 && !(h->dir & SPIN)) cand[2] = h[-3].val + p->sigT[bb - 2];
+                }
+                const int sig5 = (Local && p->sig5[bb] > 0) ? p->sig5[bb] : 0;
+                cand[0] += sig5;
+                cand[1] += sig5;
+                int k = 0;
+                if (cand[1] > cand[k]) k = 1;
+                if (cand[2] > cand[k]) k = 2;
+                if (k == 0) { if (!is_hori[h->dir & 15]) glen[ph] = 0; }
+                else if (k == 1) { *h = h[-3]; h->dir = HORI; h->val = cand[k] - sig5; }
+                else {
+                    *h = h[-3];
+                    h->dir = DEAD;
+                    h->val = cand[k];
+                    if (h->val > mx->val && vmf.on) h->ptr = vmf_add(&vmf, ar, rf + m3 - 3, h->ptr);
+                }
+                if (h->val > mx->val) mx = h;
+            }
+        } else {
+            bb += (int) (h9 - h);
+            const int y = h9[-3].val + p->sigT[bb - 2];
+            if (y > h9->val) { *h9 = h9[-3]; h9->val = y; h9->dir = HORI; }
+        }
+        if (p->b_exgr == 1) {
+            rw = imin(up, br - 3 * al);
+            int g[3] = {NEV, NEV, NEV};
+            h = hh0 + rw - 3;
+            for (int ph = 0; h >= h9; --h) {
+                int x = h[3].val;
+                if (!(p->b_exgr & 1)) x += sc->gop;
+                if (x > g[ph]) g[ph] = x;
+                if (!(p->b_exgr & 2)) g[ph] += sc->gep;
+                if (h->val > g[ph]) g[ph] = NEV;
+                else if (g[ph] > mx->val) { mx = h; mx->val = g[ph]; }
+                if (++ph == 3) ph = 0;
+            }
+        } else if (p->b_exgr == 2) {
+            mx = hh1 + br - m3;
+            mx->ptr = vmf_add(&vmf, ar, br, mx->ptr);
+            done = 1;
+        }
+        if (!done) {
+            int pp = (int) (mx - h9);
+            rf = ar;
+            rw = br;
+            if (pp > 0) { rf -= (pp + 2) / 3; if (pp %= 3) rw -= (3 - pp); }
+            else if (pp < 0) rw += pp;
+            mx->ptr = vmf_add(&vmf, rf, rw, mx->ptr);
+        }
+        scr = mx->val;
+        ptr = mx->ptr;
+    } else {
+        scr = maxh_val;
+        ptr = vmf_add(&vmf, maxh_m, maxh_n, maxh_p);
+    }
+
+    /* trcbkalignH_ng: Vmf::traceback(ptr) -> records, plus the boundary fix-up */
+    if (skl && ptr) {
+        int cap = 64, cnt = 0;
+        SpdpSkl* out = (SpdpSkl*) malloc(cap * sizeof(SpdpSkl));
+        Sklp sv = vmf.rec[ptr];
+        for (;;) {
+            if (cnt + 2 > cap) { cap *= 2; out = (SpdpSkl*) realloc(out, cap * sizeof(SpdpSkl)); }
+            out[cnt].m = sv.m; out[cnt].n = sv.n; ++cnt;
+            if (!sv.p) break;
+            sv = vmf.rec[sv.p];
+        }
+        const int r = out[cnt - 1].n - 3 * out[cnt - 1].m;
+        const int rd = Local ? 0 : (r - bl + 3 * al);
+        if (rd > 0) { out[cnt].m = al; out[cnt].n = bl + rd; ++cnt; }
+        else if (rd < 0) { out[cnt].m = al - rd / 3; out[cnt].n = bl; ++cnt; }
+        *skl = out; *n_skl = cnt;
+    }
+    free(buf); free(vmf.rec);
+    *score = scr;
+    return 0;
+}

@@ -176,6 +176,7 @@ class ScoringH(C.Structure):
         ("intpen", C.c_void_p),
         ("intpen_len", C.c_int32),
         ("t53", C.c_int16 * 256),
+        ("minl", C.c_int32),
     ]
 
 
@@ -203,7 +204,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
                    ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
-                   intpen=None, t53=None) -> ScoringH:
+                   intpen=None, t53=None, minl=0) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -223,6 +224,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
     sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
     sc.lgop, sc.gape1, sc.gape2, sc.extragop = int(lgop), int(gape1), int(gape2), int(extragop)
     sc.diffu, sc.k1 = int(diffu), int(k1)
+    sc.minl = int(minl)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip

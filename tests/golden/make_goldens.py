@@ -136,7 +136,8 @@ def protein_cases():
     rng = np.random.default_rng(synth.SEED + 590)
     c["h1_random"] = (synth.random_dna(rng, 1500),
                       synth._AA_LETTERS[rng.integers(0, 20, size=90)], ["-u", "1"])
-    for m in (8, 15, 16, 17, 33, 48):
+    # below 8 residues every -A mode runs the scalar forwardH_ng (src/fwd2h1.cc:2005, 3297)
+    for m in (3, 5, 7, 8, 15, 16, 17, 33, 48):
         g = pgene(20 + m, n_exons=1, aa_len=max(m, 20), flank=60)
         c[f"h1_tiny_m{m}"] = (g.window, g.query[:m], ["-u", "1"] if m >= 17 else [])
     g = pgene(9, n_exons=5, aa_len=300, flank=300, intron_hi=700)

@@ -71,7 +71,8 @@ def scoring_h(fx: dict, nquant: int | None = None, **over) -> abi.ScoringH:
               ubh=q["ubh"])
     if "rparams" in fx:                                  # exact-model inputs of the rescoring walk
         kw.update(lgop=q["lgop"], gape1=h["gape1"], gape2=h["gape2"], extragop=h["extragop"],
-                  diffu=int(fx["rparams"][0]), k1=h["k1"], intpen=fx["intpen"], t53=fx["t53"])
+                  diffu=int(fx["rparams"][0]), k1=h["k1"], intpen=fx["intpen"], t53=fx["t53"],
+                  minl=q["minl"])
     kw.update(over)
     return abi.make_scoring_h(**kw)
 

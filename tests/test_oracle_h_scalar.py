@@ -1,0 +1,52 @@
+"""The scalar aa x genome engine of the oracle (oracle/spdp_oracle_h_scalar.c: forwardH_ng + initH_ng /
+lastH_ng + Vmf traceback) against the reference's -A0 outputs in tests/golden/h1_*.spdg, and the
+below-8-rows fallback of the -A2 / -A3 dispatch."""
+import pytest
+
+from tests import spdg
+from tests.conftest import golden_files
+from oracle import oracle, host_logic_h as hh
+
+H_FILES = golden_files("h1_")
+
+
+def _name(f):
+    return f.split("/")[-1][:-5]
+
+
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_homscore_a0(path):
+    """HomScoreH_ng under -A0 = forwardH_ng without a Vmf (src/fwd2h1.cc:3297)"""
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx)
+    _, p = spdg.problem_h(fx)
+    assert hh.homscore_h(sc, p, simd=0) == int(fx["hom_scr_A0"][0])
+
+
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_align_a0(path):
+    """alignH_ng under -A0 where lspH_ng takes the traceback branch (forwardH_ng + Vmf::traceback +
+    stdskl3); the linear-space branch would need hirschbergH_ng, which is not restated"""
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx)
+    _, p = spdg.problem_h(fx)
+    try:
+        scr, flat = hh.align_h(sc, p, simd=0)
+    except hh.NotRestated:
+        pytest.skip("linear-space branch under -A0")
+    assert scr == int(fx["aln_scr_A0"][0])
+    assert (flat or []) == fx["aln_skl_A0"].tolist()
+
+
+@pytest.mark.parametrize("alg", [2, 3])
+@pytest.mark.parametrize("m", [3, 5, 7])
+def test_below_8_rows_default_modes(m, alg):
+    """-A2 / -A3 run the scalar engine below 8 query rows (src/fwd2h1.cc:2005, 3297)"""
+    path = [f for f in H_FILES if _name(f) == f"h1_tiny_m{m}"][0]
+    fx = spdg.load(path)
+    sc = spdg.scoring_h(fx, nquant=1 if alg == 3 else None)
+    _, p = spdg.problem_h(fx)
+    assert hh.homscore_h(sc, p, simd=alg) == int(fx[f"hom_scr_A{alg}"][0])
+    scr, flat = hh.align_h(sc, p, simd=alg)
+    assert scr == int(fx[f"aln_scr_A{alg}"][0])
+    assert flat == fx[f"aln_skl_A{alg}"].tolist()

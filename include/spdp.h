@@ -277,10 +277,22 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
                     const SpdpProblemH* probs, int n_probs, int32_t* scores);
 /* alignH_ng with seeding off (-Q0/-Q4): stripe31 -> lspH_ng decision ladder -> forwardH1_wip, or
  * hirschbergH1_wip + per-slab forwardH1_wip (mimd_postwork / rcsv_postwork) -> stdskl3.
- * Return value 1: some problem needs an engine that is not built (scalar forwardH_ng for < 8 query
- * rows, diagonalH_ng, the local linear-space engine); those come back with n_skl = 0, score NEVSEL. */
+ * Sub-problems below 8 query rows run the scalar forwardH_ng (needs the scalar engine's inputs, see
+ * spdp_scalar_forward_h).  Return value 1: some problem needs an engine that is not built (diagonalH_ng,
+ * the local linear-space engine) or the scalar inputs are missing; those come back with n_skl = 0,
+ * score NEVSEL. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+
+/* Aln2h1::forwardH_ng (src/fwd2h1.cc:294-617, with initH_ng / lastH_ng): the scalar -A0 engine -- int32,
+ * exact intron-length penalty, top-4 donor list per row and codon phase -- on the stripe31() band.
+ * traceback != 0: the Mfile records trcbkalignH_ng (src/fwd2h1.cc:1997-2041) writes, end -> start (Vmf
+ * traceback + boundary fix-up); traceback == 0: score only, as HomScoreH_ng runs it under -A0 (:3297).
+ * Needs SpdpScoringH.intpen / t53 / gape1 / gape2 / extragop / minl and SpdpProblemH.dinc.  One GPU
+ * thread per problem: meant for the sub-problems below 8 query rows that the -A2 / -A3 dispatch hands
+ * to this engine (spdp_align_h and spdp_homscore_h do that themselves), correct at any size. */
+int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
+                          int traceback, SpdpAlignment* out);
 
 /* skl_rngH_ng (src/fwd2h1.cc:635): the same for protein alignments (codon-split introns, frame
  * shifts, start / stop signals).  Needs SpdpScoringH.intpen / t53 / lgop ... and SpdpProblemH.dinc.

@@ -230,7 +230,7 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
         for (int q = 0; n <= n9; ++n, ++h, ++f) {
             int x, y;
             hf[0] = h; hf[2] = f;
-            const int sigE = (n > bl) ? p->sigE[n - 2] : 0;
+            const int sigE = (n > bl && n >= 2) ? p->sigE[n - 2] : 0;       /* position -1 is not in the arrays */
             Rvpd* const eq1 = hf[1] = e1 + q;
             const Rvpd hq = *h;                 /* previous state */
             Rvpd* from = h;

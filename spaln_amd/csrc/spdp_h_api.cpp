@@ -30,7 +30,8 @@
     } while (0)
 
 enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs + traceback runs / linear-space runs
-enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF };
+enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN };
+void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64]);       // spdp_rescore_api.cpp
 enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES };
 static const int H_SKL_CAP = 1024;
 
@@ -77,7 +78,8 @@ struct HStore {
     std::vector<SpdpProblemH> probs;            // ranges / flags / lengths are used after upload
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> col_len;
-    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr;
+    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    bool scalar_ok = false;                     // inputs of the scalar engine present (intpen / t53, dinc)
     int upload(SpdpContext* c, const SpdpScoringH* sc, const SpdpProblemH* probs, int n);
 };
 
@@ -165,12 +167,19 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
             rec.x = (int) ((unsigned) (uint16_t) (int16_t) cp | ((unsigned) (tron > 31 ? SPDH_ZCODE : tron) << 16) | (fl << 24));
             rec.y = (int) ((unsigned) (uint16_t) (int16_t) s3_0 | ((unsigned) (uint16_t) (int16_t) s3_1 << 16));
             rec.z = (int) ((unsigned) (uint16_t) (int16_t) s5_0 | ((unsigned) (uint16_t) (int16_t) s5_1 << 16));
-            rec.w = 0;
+            rec.w = (p.dinc && x <= p.b_len) ? (int) p.dinc[x] : 0;     // b_len + 1 entries
             cols[c0 + x] = rec;
             aux[c0 + x] = make_short4(p.sigS[x], p.sigT[x], p.sigE[x], p.sig5[x]);
         }
     }
+    scalar_ok = sc.intpen && sc.intpen_len > 0;
+    for (int i = 0; i < n; ++i) if (!probs[i].dinc) scalar_ok = false;
     if (!n) return 0;
+    if (scalar_ok) {
+        d_intpen = pool.get(HP_INTPEN, (size_t) sc.intpen_len * sizeof(int16_t));
+        if (!d_intpen) { ctx->err = "device allocation failed (intron penalty table)"; return -1; }
+        HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, (size_t) sc.intpen_len * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+    }
     d_sc = pool.get(HP_SC, sizeof ds);
     d_a = pool.get(HP_A, a_all.size() + 16);
     d_cols = pool.get(HP_COLS, cols.size() * sizeof(int4));
@@ -216,6 +225,7 @@ static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
     d.a_off = st.a_off[it.top];
     d.col_off = st.col_off[it.top];
     d.n_im = it.n_im;
+    d.a_len = st.probs[it.top].a_len; d.b_len = st.probs[it.top].b_len;
     d.cells = cells_of(it);
 }
 
@@ -328,6 +338,84 @@ static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, H
     return 0;
 }
 
+// ---- scalar forwardH_ng over a list of items (spdp_h_scalar.hip) ------------------------------
+static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out)
+{
+    SpdpContext* ctx = st.ctx;
+    DevPool& pool = ctx->pool[H_POOL];
+    const int nr = (int) items.size();
+    out = HFwdOut();
+    if (!nr) return 0;
+    if (!st.scalar_ok) { ctx->err = "the scalar engine needs SpdpScoringH.intpen / t53 and SpdpProblemH.dinc"; return -1; }
+    std::vector<DevProblemH> h_probs(nr);
+    int64_t work_int = 0, vmf_rec = 0;
+    int skl_cap = 64;
+    for (int i = 0; i < nr; ++i) {
+        DevProblemH& d = h_probs[i];
+        fill_desc(st, items[i], d);
+        d.bnd_off = work_int;
+        work_int += 3ll * (2 * (int64_t) d.width + 8);
+        d.tb_off = vmf_rec;
+        // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
+        // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
+        const int64_t cap = forward ? 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64 : 0;
+        if (cap >= (int64_t) 1 << 31) { ctx->err = "scalar engine: problem too large for its record store"; return -1; }
+        d.imd_off = cap;
+        vmf_rec += cap;
+        out.cells += d.cells;
+        skl_cap = std::max(skl_cap, std::min(H_SKL_CAP, (d.a_right - d.a_left) + (d.b_right - d.b_left) + 8));
+    }
+    void* d_probs = pool.get(HP_PROBS, nr * sizeof(DevProblemH));
+    void* d_work = pool.get(HP_BND, (size_t) work_int * sizeof(int));
+    void* d_vmf = pool.get(HP_TB, (size_t) std::max<int64_t>(vmf_rec, 1) * sizeof(int3));
+    void* d_res = pool.get(HP_RES, nr * sizeof(DevResultH));
+    void* d_skl = pool.get(HP_SKL, (size_t) nr * skl_cap * sizeof(int2));
+    void* d_nskl = pool.get(HP_NSKL, nr * sizeof(int));
+    if (!d_probs || !d_work || !d_vmf || !d_res || !d_skl || !d_nskl) {
+        ctx->err = "device allocation failed (scalar aa x genome run: records need " +
+                   std::to_string((size_t) vmf_rec * 12 >> 20) + " MiB)";
+        return -1;
+    }
+    HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), nr * sizeof(DevProblemH), hipMemcpyHostToDevice, ctx->stream));
+    HScalarArgs A;
+    memset(&A, 0, sizeof A);
+    A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
+    A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
+    A.intpen = (const int16_t*) st.d_intpen; A.intpen_len = st.sc.intpen_len;
+    A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
+    A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
+    memcpy(A.t53, st.sc.t53, sizeof A.t53);
+    spdp_genetic_code_tables(A.mid, A.tron_of);
+    A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
+    A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    out.res.resize(nr); out.n_skl.assign(nr, 0); out.off.assign(nr + 1, 0);
+    HIPCHK(hipMemcpyAsync(out.res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int2> skl;
+    if (forward) {
+        skl.resize((size_t) nr * skl_cap);
+        HIPCHK(hipMemcpyAsync(out.n_skl.data(), d_nskl, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(skl.data(), d_skl, skl.size() * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    for (int i = 0; i < nr; ++i) {
+        const int c = out.n_skl[i];
+        if (c == -1) { ctx->err = "traceback record buffer overflow (scalar engine)"; return -1; }
+        if (c == -3) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
+        out.off[i + 1] = out.off[i] + std::max(c, 0);
+    }
+    out.skl.resize(out.off[nr]);
+    for (int i = 0; i < nr; ++i)
+        for (int k = 0; k < out.n_skl[i]; ++k) {
+            SpdpSkl s; s.m = skl[(size_t) i * skl_cap + k].x; s.n = skl[(size_t) i * skl_cap + k].y;
+            out.skl[out.off[i] + k] = s;
+        }
+    return 0;
+}
+
 // ---- hirschbergH1_wip over a list of items ------------------------------------------------------
 struct HUdhOut {
     std::vector<int32_t> scores, cpos, ranges;  // in item order; cpos stride = stride ints per item
@@ -413,25 +501,30 @@ static bool bad_range(const HItem& it, const SpdpProblemH& p)
            it.a_right < it.a_left || it.b_right < it.b_left || it.b_left < p.exin_left || it.b_right > p.exin_right;
 }
 
-static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, HTop& t)
+static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok, HTop& t)
 {
     if (it.w.width < 0) return true;                         // NEVSEL, no records
-    if (it.a_right - it.a_left < 8) { t.cls = 1; return false; }   // scalar forwardH_ng
+    if (it.a_right - it.a_left < 8) {                        // scalar forwardH_ng
+        if (!scalar_ok) { t.cls = 1; return false; }
+        scl.push_back(it);
+        return true;
+    }
     fwd.push_back(it);
     return true;
 }
 
 // lspH_ng (src/fwd2h1.cc:2140-2180) up to the engine call
-static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd, std::vector<HItem>& udh, HTop& t)
+static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok,
+                      std::vector<HItem>& udh, HTop& t)
 {
     const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
     if (!m && !n) { if (it.first) t.score = 0; return; }
     if (!m || !n) { t.cls = 2; return; }                     // terminal-gap-only ranges: GapPenalty paths, not built
     if (it.w.up == it.w.lw) { t.cls = 1; return; }           // diagonalH_ng
-    if (std::abs(n - m) < 16 || m == 1 || n <= 3) { queue_trcbk(it, fwd, t); return; }
+    if (std::abs(n - m) < 16 || m == 1 || n <= 3) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
     const float coef_B = 2.f, coef_C = 12.f;                 // sizeof(short); (Noll + 1) * sizeof(int)
     const float cvol = float(m) * (n + 3 * m);
-    if (coef_B * cvol < sc.max_vmf_space) { queue_trcbk(it, fwd, t); return; }
+    if (coef_B * cvol < sc.max_vmf_space) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
     bool recursive = false;
     int n_imd = 1;
     {
@@ -444,7 +537,7 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
             n_imd = sc.ubh ? sc.ubh : std::min(imd1, imd3);
             const int intvl = (m + n_imd) / (n_imd + 1);
             if (intvl * n_imd == m) --n_imd;
-            if (n_imd == 0) { queue_trcbk(it, fwd, t); return; }
+            if (n_imd == 0) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
         }
     }
     if (sc.local) { t.cls = 1; return; }                     // local linear-space engine: not built
@@ -456,7 +549,7 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
 {
     const SpdpScoringH& sc = st.sc;
     tops.assign(st.n, HTop());
-    std::vector<HItem> pending, fwd, udh;
+    std::vector<HItem> pending, fwd, udh, scl;
     for (int i = 0; i < st.n; ++i) {
         HItem it = item_of(st.probs[i], i, sc.sh);
         it.first = true;
@@ -468,13 +561,13 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
             else fwd.push_back(it);
         }
     }
-    while (!pending.empty() || !fwd.empty()) {
+    while (!pending.empty() || !fwd.empty() || !scl.empty()) {
         ++hs.rounds;
         udh.clear();
         for (const HItem& it : pending) {
             if (tops[it.top].cls) continue;
             if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
-            queue_lsp(sc, it, fwd, udh, tops[it.top]);
+            queue_lsp(sc, it, fwd, scl, st.scalar_ok, udh, tops[it.top]);
         }
         pending.clear();
         // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)
@@ -526,31 +619,33 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
                         while (c < 9 && CP(i, c + 1) < END_ULK) { ++c; push_rec(t, cur.a_left, CP(i, c)); }
                         ++c;
                         stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
-                        if (!queue_trcbk(cur, fwd, t)) break;
+                        if (!queue_trcbk(cur, fwd, scl, st.scalar_ok, t)) break;
                         cur.a_right = cur.a_left;
                         cur.b_right = CP(i, c - 1);
                     }
                     if (!bad && !t.cls && ((i < 0 && CP(0, 0) != END_ULK) || CP(0, 2) != END_ULK)) {
                         cur.a_left = aleft; cur.b_left = bleft;
                         stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
-                        queue_trcbk(cur, fwd, t);
+                        queue_trcbk(cur, fwd, scl, st.scalar_ok, t);
                     }
                 }
 #undef CP
             }
         }
-        // ---- traceback round
-        if (!fwd.empty()) {
+        // ---- traceback round; sub-problems below 8 rows go through the scalar engine
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<HItem>& list = pass ? scl : fwd;
+            if (list.empty()) continue;
             std::vector<HItem> run;
-            for (const HItem& it : fwd) {
+            for (const HItem& it : list) {
                 if (tops[it.top].cls) continue;
                 if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
                 run.push_back(it);
             }
-            fwd.clear();
+            list.clear();
             HFwdOut fo;
-            if (run_forward(st, run, true, fo)) return -1;
-            hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells;
+            if (pass ? run_scalar(st, run, true, fo) : run_forward(st, run, true, fo)) return -1;
+            if (!pass) { hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells; }
             for (size_t f = 0; f < run.size(); ++f) {
                 HTop& t = tops[run[f].top];
                 if (run[f].first) t.score = fo.res[f].score;
@@ -680,20 +775,54 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
     if (!ctx || !sc || !probs || n_probs < 0 || !scores) return -1;
     HStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
-    std::vector<HItem> items;
-    std::vector<int> idx;
+    std::vector<HItem> items, sitems;
+    std::vector<int> idx, sidx;
     int rc = 0;
     for (int i = 0; i < n_probs; ++i) {
         scores[i] = SPDP_NEVSEL;
         HItem it = item_of(probs[i], i, sc->sh);
         const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
-        if (m < 8 || !n || it.w.width < 0) { rc = 1; continue; }     // scalar forwardH_ng
+        if (!n || !m || it.w.width < 0) { rc = 1; continue; }
+        if (m < 8) {                                                  // scalar forwardH_ng (src/fwd2h1.cc:3297)
+            if (!st.scalar_ok) { rc = 1; continue; }
+            sitems.push_back(it); sidx.push_back(i);
+            continue;
+        }
         items.push_back(it); idx.push_back(i);
     }
     HFwdOut fo;
     if (run_forward(st, items, false, fo)) return -1;
     for (size_t f = 0; f < items.size(); ++f) scores[idx[f]] = fo.res[f].score;
+    if (run_scalar(st, sitems, false, fo)) return -1;
+    for (size_t f = 0; f < sitems.size(); ++f) scores[sidx[f]] = fo.res[f].score;
     return rc;
+}
+
+int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
+                          int traceback, SpdpAlignment* out)
+{
+    if (!ctx || !sc || !probs || n_probs < 0 || !out) return -1;
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    std::vector<HItem> items;
+    std::vector<int> idx;
+    for (int i = 0; i < n_probs; ++i) {
+        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr;
+        HItem it = item_of(probs[i], i, sc->sh);
+        if (it.w.width < 0) continue;                                 // trcbkalignH_ng returns NEVSEL
+        items.push_back(it); idx.push_back(i);
+    }
+    HFwdOut fo;
+    if (run_scalar(st, items, traceback != 0, fo)) return -1;
+    for (size_t f = 0; f < items.size(); ++f) {
+        SpdpAlignment& o = out[idx[f]];
+        o.score = fo.res[f].score;
+        if (!traceback) continue;
+        std::vector<SpdpSkl> rec(fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
+        o.n_skl = (int) rec.size();
+        o.skl = dup_skl(rec);
+    }
+    return 0;
 }
 
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,

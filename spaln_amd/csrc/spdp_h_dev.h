@@ -10,7 +10,7 @@
 //                                    | don0 << 3 (2 bits, DONM/DONZ/DONP) | don1 << 5
 //                      y = (uint16) s3_0 | s3_1 << 16      acceptor signals of the 2 candidates (:214-222)
 //                      z = (uint16) s5_0 | s5_1 << 16      donor signals + ipen           (:262-270)
-//                      w = 0
+//                      w = dinc5 << 4 | dinc3 of the position (scalar engine / rescoring; 0 if not given)
 //                    The kernel applies the window itself (nothing splices at n >= b_right, no
 //                    substitution score outside [b_left + 3, b_right + 2]).
 //   aux      short4  {sigS, sigT, sigE, sig5} raw per position: boundary set-up / end selection
@@ -48,6 +48,7 @@ struct DevProblemH {
     int32_t m_width, n_width;
     int32_t col_len;
     int32_t n_im;                  // linear-space engine: number of intermediate rows
+    int32_t a_len, b_len;          // parent sequence lengths (scalar engine: positions beyond read as padding)
     int64_t a_off;
     int64_t col_off;               // into cols / aux
     int64_t bnd_off;               // into bnd (entries)

@@ -51,6 +51,30 @@ struct HCposArgs {
     int                cpos_stride;
 };
 
+// scalar forwardH_ng (spdp_h_scalar.hip): one thread per problem
+struct HScalarArgs {
+    const DevScoringH* sc;
+    const DevProblemH* probs;      // bnd_off: into work (ints), tb_off: into vmf (records), imd_off: record capacity
+    int                n_probs;
+    const uint8_t*     a_codes;
+    const int4*        cols;
+    const short4*      aux;
+    const int16_t*     intpen;     // IntronPenalty::Penalty(len)
+    int                intpen_len;
+    int                minl;       // IntronPrm.minl
+    int                gape1, gape2, extragop;
+    int16_t            t53[256];
+    uint8_t            mid[32];    // middle base a tron code pins (4: none)
+    uint8_t            tron_of[64];
+    int*               work;       // per problem 3 * (2 * width + 8) ints: two rows of {val, ptr, dir}
+    int3*              vmf;        // Vmf records {m, n, prev}
+    DevResultH*        res;
+    int2*              skl;        // per problem skl_cap records
+    int*               n_skl;      // records; -1 skl overflow, -3 Vmf capacity exceeded
+    int                skl_cap;
+};
+
+extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_udh(const HUdhArgs* a, int spj, int pen_cap, hipStream_t s);
 extern "C" hipError_t spdh_launch_cpos(const HCposArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t s);

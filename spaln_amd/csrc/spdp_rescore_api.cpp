@@ -109,7 +109,7 @@ enum { RH_MTX = 8, RH_PROBS, RH_A, RH_B, RH_SIG, RH_PHS, RH_DINC, RH_INTPEN };  
 
 // the standard genetic code in the reference's tron alphabet (A = 3 ... V = 22, AGY serines 23, TGA 24,
 // TAA / TAG 25), as its static spj_tron_tab / tnredctab assume (src/codepot.h:130, src/seq.cc:41)
-static void genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64])
+void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64])
 {
     static const char* aas = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";   // TCAG order
     static const char* order = "ARNDCQEGHILKMFPSTWYV";
@@ -211,7 +211,7 @@ int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescorePa
     A.gape1 = sc->gape1; A.gape2 = sc->gape2; A.extragop = sc->extragop; A.diffu = sc->diffu; A.k1 = sc->k1;
     A.minl = rp->minl; A.jneibr = rp->jneibr; A.lcl = rp->lcl; A.sup_tcodon = rp->sup_tcodon;
     memcpy(A.t53, sc->t53, sizeof A.t53);
-    genetic_code_tables(A.mid, A.tron_of);
+    spdp_genetic_code_tables(A.mid, A.tron_of);
     HIPCHK(spdh_launch_rescore(&A, ctx->stream));
     std::vector<int> hdr((size_t) nr * 8), rec((size_t) rtot * 21);
     HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -24,6 +24,7 @@ EXPORTS = [
     "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
+    "spdp_scalar_forward_h",
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
 ]
 
@@ -63,6 +64,7 @@ def load_library() -> C.CDLL:
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_udh_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_scalar_forward_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.spdp_batch_upload_h.restype = C.c_void_p
     lib.spdp_batch_upload_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.spdp_batch_free_h.argtypes = [C.c_void_p]
@@ -225,6 +227,21 @@ class Engine:
     def wip_forward_h(self, sc: abi.ScoringH, ps: abi.ProblemSetH):
         """SimdAln2h1::forwardH1_wip(mfd) with the stripe31() band: raw records end -> start."""
         return self._alignments_h(self.lib.spdp_wip_forward_h, sc, ps, "spdp_wip_forward_h")
+
+    def scalar_forward_h(self, sc: abi.ScoringH, ps: abi.ProblemSetH, traceback: bool = True):
+        """Aln2h1::forwardH_ng on the stripe31() band: [(score, records end -> start)]"""
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        self._check(self.lib.spdp_scalar_forward_h(self.ctx, C.byref(sc), ps.array(), n, 1 if traceback else 0, arr),
+                    "spdp_scalar_forward_h")
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(max(k, 0))],
+                           dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
 
     def align_h(self, sc, ps):
         """alignH_ng (-Q0): [flags, n, corners...] as rows of (m, n) after the header row."""

@@ -26,6 +26,10 @@ END = abi.END_OF_ULK
 NELEM = 16
 
 
+class ReferenceUndefined(Exception):
+    """the reference reads or writes outside its arrays on this input"""
+
+
 class NeedsScalarEngine(Exception):
     """trcbkalignS_ng with m < 8 uses the scalar exact-ILD engine (not restated yet)."""
 
@@ -74,10 +78,10 @@ def diagonal(sc, p, rec):
     return maxh if LR else scr
 
 
-def trcbk(sc, p, w, rec):
+def trcbk(sc, p, w, rec, simd=2):
     if w.width < 0:
         return abi.NEVSEL
-    if p.a_right - p.a_left < 8:          # scalar forwardS_ng (src/fwd2s1.cc:1677)
+    if simd == 0 or p.a_right - p.a_left < 8:          # scalar forwardS_ng (src/fwd2s1.cc:1677)
         if not sc.intpen or not p.cano5:
             raise NeedsScalarEngine()
         s, skl = oracle.scalar_forward(sc, p, w)
@@ -88,7 +92,7 @@ def trcbk(sc, p, w, rec):
     return s
 
 
-def lsp(sc, p, w, rec):
+def lsp(sc, p, w, rec, simd=2):
     m, n = p.a_right - p.a_left, p.b_right - p.b_left
     if not m and not n:
         return 0
@@ -101,13 +105,19 @@ def lsp(sc, p, w, rec):
     if w.up == w.lw:
         return diagonal(sc, p, rec)
     if abs(n - m) < 8 or m == 1 or n == 1:
-        return trcbk(sc, p, w, rec)
+        return trcbk(sc, p, w, rec, simd)
     coef_B, coef_C = 2.0, float((sc.noll + 1) * 4)
-    cvol = _f32(_f32(m) * _f32(n + m))
+    if simd < 2:                                          # hexagonal
+        k = _f32(w.lw - p.b_left + p.a_right)
+        q = _f32(p.b_right - p.a_left - w.up)
+        cvol = _f32(_f32(_f32(m) * _f32(n)) - _f32(_f32(_f32(k * k) + _f32(q * q)) / 2))
+    else:                                                 # rhombic
+        cvol = _f32(_f32(m) * _f32(n + m))
     if _f32(coef_B * cvol) < sc.max_vmf_space:
-        return trcbk(sc, p, w, rec)
+        return trcbk(sc, p, w, rec, simd)
     recursive = False
     n_imd = 1
+    imd_intvl = (m + 1) // 2
     z = 2.0 * m * coef_B / coef_C
     imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
     spc = _f32(_f32(_f32(coef_C * n) * imd1) + _f32(_f32(_f32(coef_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
@@ -116,12 +126,19 @@ def lsp(sc, p, w, rec):
     else:
         imd3 = m // NELEM
         n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
-        intvl = (m + n_imd) // (n_imd + 1)
+        intvl = imd_intvl = (m + n_imd) // (n_imd + 1)
         if intvl * n_imd == m:
             n_imd -= 1
         if n_imd == 0:
-            return trcbk(sc, p, w, rec)
-    scr, cpos, rng = oracle.wip_udh(sc, p, n_imd, w)
+            return trcbk(sc, p, w, rec, simd)
+    if simd == 0:
+        scr, cpos, rng, flag = oracle.scalar_udh(sc, p, n_imd, imd_intvl, w)
+        if flag:
+            raise ReferenceUndefined("hirschbergS_ng outside its arrays")
+    elif simd == 1:
+        raise NeedsScalarEngine("hirschbergS1 (-A1) is not restated")
+    else:
+        scr, cpos, rng = oracle.wip_udh(sc, p, n_imd, w)
     if scr > abi.NEVSEL:
         cur = _sub(p, int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]),
                    (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr))
@@ -129,13 +146,23 @@ def lsp(sc, p, w, rec):
             rec.append((cur.a_left, cur.b_left))
             rec.append((cur.a_right, cur.b_right))
         elif recursive:
-            rcsv(sc, cur, cpos, rec)
+            rcsv(sc, cur, cpos, rec, simd)
         else:
-            mimd(sc, cur, cpos, n_imd, rec)
+            mimd(sc, cur, cpos, n_imd, rec, simd)
     return scr
 
 
-def mimd(sc, cur, cpos, n_imd, rec):
+def _slab_window(sc, cur, row, simd):
+    """mimd_postwork / rcsv_postwork: stripe() under SIMD, the recorded diagonal bounds under -A0"""
+    if simd:
+        return oracle.stripe(cur, sc.sh)
+    w = abi.Window()
+    w.lw, w.up = int(row[8]), int(row[9])
+    w.width = w.up - w.lw + 3
+    return w
+
+
+def mimd(sc, cur, cpos, n_imd, rec, simd=2):
     aleft, bleft = cur.a_left, cur.b_left
     cur = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
     i = n_imd - 1
@@ -151,16 +178,16 @@ def mimd(sc, cur, cpos, n_imd, rec):
         while c < 10 and cpos[i][c] < END:
             rec.append((cur.a_left, int(cpos[i][c])))
             c += 1
-        trcbk(sc, cur, oracle.stripe(cur, sc.sh), rec)
+        trcbk(sc, cur, _slab_window(sc, cur, cpos[i + 1], simd), rec, simd)
         cur.a_right = cur.a_left
         cur.b_right = int(cpos[i][c - 1])
         i -= 1
     if (i < 0 and cpos[0][0] != END) or cpos[0][2] != END:
         cur.a_left, cur.b_left = aleft, bleft
-        trcbk(sc, cur, oracle.stripe(cur, sc.sh), rec)
+        trcbk(sc, cur, _slab_window(sc, cur, cpos[0], simd), rec, simd)
 
 
-def rcsv(sc, cur, cpos, rec):
+def rcsv(sc, cur, cpos, rec, simd=2):
     base = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
     row = cpos[0]
     if row[0] < END:
@@ -169,12 +196,12 @@ def rcsv(sc, cur, cpos, rec):
             rec.append((int(row[0]), int(row[c])))
             c += 1
         first = _sub(base, base.a_left, int(row[0]), base.b_left, int(row[c - 1]), (0, 0, 0, 0))
-        lsp(sc, first, oracle.stripe(first, sc.sh), rec)
+        lsp(sc, first, _slab_window(sc, first, cpos[0], simd), rec, simd)
         second = _sub(base, int(row[0]), base.a_right, int(row[2]), base.b_right,
                       (0, 0, 1 if row[1] else 0, 0))
-        lsp(sc, second, oracle.stripe(second, sc.sh), rec)
+        lsp(sc, second, _slab_window(sc, second, cpos[1], simd), rec, simd)
     elif sc.local:
-        trcbk(sc, base, oracle.stripe(base, sc.sh), rec)
+        trcbk(sc, base, oracle.stripe(base, sc.sh), rec, simd)
 
 
 def std_skl(rec):
@@ -216,10 +243,11 @@ def trim_skl(s, p):
     return s
 
 
-def align_s(sc, p):
-    """alignS_ng(ori=1) with seeding off.  Returns (score, skl) with skl = [flags, n, m1, n1, ...] or None."""
+def align_s(sc, p, simd=2):
+    """alignS_ng(ori=1) with seeding off.  Returns (score, skl) with skl = [flags, n, m1, n1, ...] or None.
+    simd = algmode.alg & 3: 0 runs the scalar engines (forwardS_ng, hirschbergS_ng) throughout."""
     rec = []
-    scr = lsp(sc, p, oracle.stripe(p, sc.sh), rec)
+    scr = lsp(sc, p, oracle.stripe(p, sc.sh), rec, simd)
     if len(rec) < 2:
         return scr, None
     s = trim_skl(std_skl(rec), p)

@@ -107,6 +107,20 @@ def scalar_forward(sc, p, w=None):
     return s.value, out
 
 
+def scalar_udh(sc, p, n_im: int, imd_intvl: int, w=None):
+    """Aln2s1::hirschbergS_ng: (score, cpos rows, written-back ranges, flag); flag -3: the reference
+    reads / writes outside its arrays on this input (undefined)."""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.full((n_im + 1, 10), abi.END_OF_ULK, dtype=np.int32)
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_scalar_udh(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.c_int(imd_intvl), C.byref(s),
+                              cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc not in (0, -3):
+        raise RuntimeError(f"orc_scalar_udh rc={rc}")
+    return s.value, cpos, rng, rc
+
+
 # ---- protein x genome ------------------------------------------------------------------
 def stripe31(p: abi.ProblemH, sh: int) -> abi.Window:
     w = abi.Window()

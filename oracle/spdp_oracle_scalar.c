@@ -370,3 +370,294 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
     *score = scr;
     return 0;
 }
+
+/* ---- unidirectional Hirschberg, scalar ------------------------------------------------------
+ * orc_scalar_udh   Aln2s1::hirschbergS_ng + hinitS_ng / hlastS_ng        src/fwd2s1.cc:762-1104, 701-760
+ *                  with UdhIntermediate (lub = true)                      src/udh_intermediate.h:29-66
+ * The -A0 linear-space engine: forwardS_ng's recurrence with every state carrying the diagonal
+ * range it has visited since the last intermediate row (upr / lwr), the row it started on (ml) and a
+ * link (ulk) to where its path crossed the previous intermediate row.  cpos[i] comes back as
+ * lspS_ng reads it: [0] = mi, [1] = entered in a gap, [2..] = n coordinates of the horizontal run on
+ * row mi, terminated by end_of_ulk, [8] / [9] = diagonal bounds of the slab below.  Entries the
+ * reference leaves uninitialised (it allocates cpos with new[]) are end_of_ulk here.
+ * rc -3: the reference would dereference udhimds[n_im] (a null pointer) at :1093. */
+typedef struct { int val, upr, lwr, ml, ulk; } Rvwml;
+typedef struct { int val, dir, upr, lwr, ml, ulk, jnc; } Rvdwmlj;
+typedef struct { int mi; int* buf; int *hlnk[2], *vlnk[2], *lwrb[2], *uprb[2]; } UImd;
+
+int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w, int n_im, int imd_intvl,
+                   int32_t* score, int32_t* cpos, int32_t* ranges)
+{
+    if (sc->noll != 2 || !sc->intpen || !p->cano5 || n_im < 1) return -1;
+    const int NEV = SPDP_NEVSEL, EOU = SPDP_END_OF_ULK;
+    int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
+    const int Local = sc->local;
+    const int LocalL = Local && p->a_exgl && p->b_exgl;
+    const int LocalR = Local && p->a_exgr && p->b_exgr;
+    const int dim = sc->mtx_dim;
+    const int lw = w->lw, up = w->up, width = w->width;
+    const int GOP[2] = {0, sc->gop};
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+    for (int i = 0; i <= n_im; ++i) for (int c = 0; c < 10; ++c) CPOS(i, c) = EOU;
+    const size_t bufsiz = (size_t) 2 * width;
+    Rvwml* wbuf = (Rvwml*) malloc((bufsiz + 4) * sizeof(Rvwml));
+    int r = bl - ar;
+    const Rvwml black = {NEV, r, r, 0, EOU};
+    for (size_t i = 0; i < bufsiz + 4; ++i) wbuf[i] = black;
+    Rvwml* hh0 = wbuf - lw + 1;
+    Rvwml* hh1 = hh0 + width;
+    /* hinitS_ng */
+    {
+        int rr = br - al;
+        const int r0 = bl - al;
+        r = r0;
+        Rvwml* h = hh0 + r;
+        h->val = 0; h->lwr = h->upr = h->ulk = r; h->ml = al;
+        if (p->a_exgl) {
+            if (up < rr) rr = up;
+            while (++r <= rr) { ++h; h->val = 0; h->lwr = h->upr = h->ulk = r; h->ml = al; }
+        }
+        r = r0;
+        rr = bl - ar;
+        if (lw > rr) rr = lw;
+        h = hh0 + r - 1;
+        for (int i = 1; --r >= rr; ++i, --h) {
+            if (p->b_exgl) { h->val = 0; h->lwr = h->upr = h->ulk = r; h->ml = h[1].ml + 1; }
+            else {
+                *h = h[1];
+                ++h->ml;
+                h->val += (i == 1) ? sc->gop + sc->gep : sc->gep;   /* GapPenalty(1) / GapExtPen(i) */
+                h->lwr = r;
+                h->ulk = r0;
+            }
+        }
+    }
+    /* Udh_Imds(n_im, a->left, imd_intvl, wdw, Noll, lub = true) */
+    UImd* imds = (UImd*) calloc(n_im, sizeof(UImd));
+    {
+        int mi = al;
+        const size_t us = (size_t) 2 * width;
+        for (int i = 0; i < n_im; ++i) {
+            UImd* d = imds + i;
+            d->mi = (mi += imd_intvl);
+            d->buf = (int*) malloc(4 * us * sizeof(int));
+            for (size_t k = 0; k < 2 * us; ++k) d->buf[k] = EOU;
+            for (size_t k = 0; k < us; ++k) { d->buf[2 * us + k] = INT_MAX; d->buf[3 * us + k] = INT_MIN; }
+            d->hlnk[0] = d->buf - lw + 1;  d->vlnk[0] = d->hlnk[0] + us;
+            d->lwrb[0] = d->vlnk[0] + us;  d->uprb[0] = d->lwrb[0] + us;
+            d->hlnk[1] = d->hlnk[0] + width; d->vlnk[1] = d->vlnk[0] + width;
+            d->lwrb[1] = d->lwrb[0] + width; d->uprb[1] = d->uprb[0] + width;
+        }
+    }
+    UImd* imd = imds;
+    int mm = imd->mi;
+    int rlst = INT_MAX;
+    int maxh_val = NEV, maxh_upr = 0, maxh_lwr = 0, maxh_ml = al, maxh_ulk = 0, maxh_mr = ar, maxh_nr = br;
+    int m = al;
+    if (!p->a_exgl) --m;
+    int n1 = m + lw, n2 = m + up + 1;
+    for (int i = 0; ++m <= ar; ++n1, ++n2) {
+        int n = imax(n1, bl);
+        const int n9 = imin(n2, br);
+        const int is_imd = m == mm;
+        unsigned psp = 0;
+        r = n - m;
+        Rvwml *h = hh0 + r, *f = hh1 + r;
+        Rvwml e1 = black;
+        Rvwml* hf[NOD] = {0, &e1, 0};
+        Rvdwmlj rcd[NCAND + 1];
+        int idx[NCAND + 1];
+        for (int l = 0; l <= NCAND; ++l) {
+            rcd[l].val = NEV; rcd[l].dir = 0; rcd[l].upr = INT_MIN; rcd[l].lwr = INT_MAX;
+            rcd[l].ml = 0; rcd[l].ulk = EOU; rcd[l].jnc = 0;
+            idx[l] = l;
+        }
+        int ncand = -1;
+        const int32_t* qprof = (m >= 1) ? sc->mtx + (size_t) p->a[m - 1] * dim : sc->mtx;
+        for ( ; ++n <= n9; ) {
+            int x;
+            ++r; ++h; ++f;
+            hf[0] = h; hf[2] = f;
+            Rvwml* from = h;
+            Rvwml* mx = h;
+            if (m != al) {
+                h->val += qprof[p->b[n - 1]];
+                x = (++from)->val + sc->gop;
+                if (x >= f[1].val) { *f = *from; f->val = x; }
+                else *f = f[1];
+                f->val += sc->gep;
+                if (f->val >= mx->val) mx = f;
+            }
+            x = h[-1].val + sc->gop;
+            if (x >= e1.val) { e1 = h[-1]; e1.val = x; psp = psp ? E1_PSP : 0; }
+            else psp &= 3;                                  /* e_psp = e1_psp + e2_psp */
+            e1.val += sc->gep;
+            if (e1.val >= mx->val) mx = &e1;
+            int spj3 = 0;
+            if (p->cano3[n]) {
+                const Rvdwmlj* maxphl[NOD] = {0, 0, 0};
+                for (int l = 0; l <= ncand; ++l) {
+                    const Rvdwmlj* prd = rcd + idx[l];
+                    if (n - prd->jnc < sc->llmt) continue;
+                    from = hf[prd->dir];
+                    x = prd->val + spjscr(sc, p, prd->jnc, n);
+                    if (x > from->val) { from->val = x; maxphl[prd->dir] = prd; }
+                }
+                int maxk = NOD;
+                for (int k = 0; k < NOD; ++k) {
+                    const Rvdwmlj* prd = maxphl[k];
+                    if (!prd) continue;
+                    psp |= psp_bit[k];
+                    if (!k) spj3 = 1;
+                    from = hf[k];
+                    from->upr = imax(prd->upr, r);
+                    from->lwr = imin(prd->lwr, r);
+                    from->ml = prd->ml;
+                    from->ulk = prd->ulk;
+                    if (from->val > mx->val) { maxk = k; mx = from; }
+                }
+                if (is_imd && maxk < NOD) {
+                    const Rvdwmlj* phl = maxphl[maxk];
+                    imd->hlnk[0][r] = phl->ulk;
+                    mx->ulk = rlst = r;
+                    if (maxk == 0) {
+                        if ((phl = maxphl[1]) && hf[1]->val > mx->val + GOP[1]) {
+                            hf[1]->ulk = r + width;
+                            imd->hlnk[1][r] = phl->ulk;
+                        }
+                        if (maxphl[2] && hf[2]->val > mx->val + GOP[1]) hf[2]->ulk = r + width;
+                    }
+                }
+            }
+            int hd = 0;
+            if (h == mx) {
+                if (LocalR && h->val > maxh_val) {
+                    maxh_val = h->val; maxh_upr = h->upr; maxh_lwr = h->lwr; maxh_ml = h->ml; maxh_ulk = h->ulk;
+                    maxh_mr = m; maxh_nr = n;
+                }
+            } else {
+                while (mx != hf[++hd]) ;
+                *h = *mx;
+                if (h->upr < r) h->upr = r;
+                if (h->lwr > r) h->lwr = r;
+            }
+            if (LocalL && h->val <= 0) { h->val = 0; h->ml = m; h->ulk = h->upr = h->lwr = r; }
+            if (p->cano5[n]) {
+                const int sigJ = p->sig5[n];
+                for (int k = (mx == h) ? 0 : 1; k < NOD; ++k) {
+                    from = hf[k];
+                    if (psp & psp_bit[k]) continue;
+                    if (k != hd) {
+                        int y = mx->val;
+                        if (hd == 0 || (k - hd) % 2) y += GOP[k / 2];
+                        if (from->val <= y) continue;
+                    }
+                    x = from->val + sigJ;
+                    int l = ncand < NCAND ? ++ncand : NCAND;
+                    while (--l >= 0) {
+                        if (x > rcd[idx[l]].val) { int t = idx[l]; idx[l] = idx[l + 1]; idx[l + 1] = t; }
+                        else break;
+                    }
+                    if (++l < NCAND) {
+                        Rvdwmlj* prd = rcd + idx[l];
+                        prd->val = x; prd->jnc = n; prd->dir = k;
+                        prd->upr = from->upr; prd->lwr = from->lwr; prd->ml = from->ml;
+                        if (is_imd) {
+                            if (k == 1) imd->hlnk[0][r] = rlst;
+                            prd->ulk = r;
+                        } else prd->ulk = from->ulk;
+                    } else --ncand;
+                }
+            }
+            if (is_imd) {
+                if (hd == 0) rlst = r;
+                else if (!spj3 && hd % 2) imd->hlnk[0][r] = rlst;
+                for (int k = 0; k < 2; ++k) {
+                    Rvwml* g = hf[2 * k];
+                    imd->vlnk[k][r] = g->ulk;
+                    imd->lwrb[k][r] = imin(r, g->lwr);
+                    imd->uprb[k][r] = imax(r, g->upr);
+                    g->lwr = g->upr = r;
+                    g->ulk = r + k * width;
+                }
+            }
+        }
+        if (is_imd && ++i < n_im) { imd = imds + i; mm = imd->mi; }
+    }
+
+    int rc = 0;
+    const int rr = br - ar;
+    if (LocalR) {
+        int i = n_im;
+        while (--i >= 0 && imds[i].mi > ar) ;
+        ar = maxh_mr; br = maxh_nr;
+        if (i < 0) i = 0;
+        CPOS(i, 8) = maxh_lwr;
+        CPOS(i, 9) = maxh_upr;
+    } else {    /* hlastS_ng */
+        Rvwml* h9 = hh0 + br - ar;
+        Rvwml* mx = h9;
+        if (p->b_exgr) { const int rw = imin(up, br - al); for (Rvwml* h = hh0 + rw; h > h9; --h) if (h->val > mx->val) mx = h; }
+        if (p->a_exgr) { const int rw = imax(lw, bl - ar); for (Rvwml* h = hh0 + rw; h < h9; ++h) if (h->val > mx->val) mx = h; }
+        maxh_val = mx->val; maxh_lwr = mx->lwr; maxh_upr = mx->upr; maxh_ulk = mx->ulk; maxh_ml = mx->ml;
+        r = (int) (mx - hh0);
+        if (p->b_exgr && rr < r) ar = br - r;
+        if (p->a_exgr && rr > r) br = ar + r;
+    }
+    int i = n_im;
+    while (--i >= 0 && imds[i].mi > ar) ;
+    if (i < 0 && imds[0].mi > ar) CPOS(0, 2) = br;
+    r = br - ar;
+    CPOS(i + 1, 8) = imin(maxh_lwr, r);
+    CPOS(i + 1, 9) = imax(maxh_upr, r);
+    r = maxh_ulk;
+    int d = 0;
+    for ( ; i >= 0 && (imd = imds + i)->mi > maxh_ml; --i) {
+        int c = 0;
+        for (d = 0; r > up; r -= width) ++d;
+        if (d > 1 || r < lw - 1) { rc = -3; break; }         /* outside the link arrays */
+        if (imd->vlnk[d][r] < EOU) {
+            CPOS(i, c++) = imd->mi;
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            for (int rp = imd->hlnk[d][r]; lw <= rp && rp < up && r != rp; rp = imd->hlnk[0][r = rp]) {
+                if (c >= 6) { rc = -3; break; }              /* the terminator would land on [8] */
+                CPOS(i, c++) = r + imd->mi;
+            }
+            if (rc) break;
+            CPOS(i, c++) = r + imd->mi;
+            CPOS(i, c) = EOU;
+            CPOS(i, 8) = imd->lwrb[d][r];
+            CPOS(i, 9) = imd->uprb[d][r];
+            r = imd->vlnk[d][r];
+            if (r == EOU) break;
+        } else
+            CPOS(i, 0) = EOU;
+    }
+    if (!rc) {
+        for ( ; r > up; r -= width) ;
+        if (LocalL) { al = maxh_ml; bl = r + maxh_ml; }
+        else {
+            const int rl = bl - al;
+            if (p->b_exgl && rl > r) {
+                al = bl - r;
+                for (int j = 0; j < n_im && imds[j].mi < al; ++j) CPOS(j, 0) = EOU;
+            }
+            if (p->a_exgl && rl < r) bl = al + r;
+        }
+        ++i;
+        if (i >= n_im) rc = -3;
+        else if (imds[i].mi < al || CPOS(i, 2) < bl) maxh_val = NEV;
+        else if (CPOS(i, 8) == EOU || CPOS(i, 9) == EOU) rc = -3;   /* bounds the reference never set */
+        else {
+            const int rl = bl - al;
+            CPOS(i, 8) = imin(rl, CPOS(i, 8));
+            CPOS(i, 9) = imax(rl, CPOS(i, 9));
+        }
+    }
+#undef CPOS
+    *score = maxh_val;
+    ranges[0] = al; ranges[1] = ar; ranges[2] = bl; ranges[3] = br;
+    for (int j = 0; j < n_im; ++j) free(imds[j].buf);
+    free(imds); free(wbuf);
+    return rc;
+}

@@ -46,3 +46,33 @@ def test_forward(fx):
     flat = ([1, len(fin)] + [x for mn in fin for x in mn]) if fin else []
     assert scr == int(fx["aln_scr_A0"][0])
     assert flat == fx["aln_skl_A0"].tolist()
+
+
+def test_align_a0_ladder(fx):
+    """alignS_ng under -A0 end to end: lspS_ng with the hexagonal volume estimate, hirschbergS_ng with its
+    recorded diagonal bounds as slab windows (mimd_postwork / rcsv_postwork), forwardS_ng per slab"""
+    sc = spdg.scoring(fx)
+    ps, p = spdg.problem(fx)
+    scr, flat = host_logic.align_s(sc, p, simd=0)
+    assert scr == int(fx["aln_scr_A0"][0])
+    assert (flat or []) == fx["aln_skl_A0"].tolist()
+
+
+def test_hirschberg_s_ng_is_exercised():
+    """the fixtures above do reach the scalar linear-space engine, in recurrent and recursive mode"""
+    seen = []
+    orig = oracle.scalar_udh
+
+    def spy(sc, p, n_im, intvl, w=None):
+        seen.append(n_im)
+        return orig(sc, p, n_im, intvl, w)
+    oracle.scalar_udh = spy
+    try:
+        for name in ("s1_1400nt", "s1_forced_udh3"):
+            fx = spdg.load([f for f in golden_files() if f.endswith(name + ".spdg")][0])
+            sc = spdg.scoring(fx)
+            _, p = spdg.problem(fx)
+            host_logic.align_s(sc, p, simd=0)
+    finally:
+        oracle.scalar_udh = orig
+    assert 7 in seen and seen.count(1) >= 3

@@ -62,6 +62,9 @@ typedef struct SpdpScoring {
     int32_t intpen_len;              /*   (src/codepot.h:242-247); must cover the longest window */
     int16_t t53[256];                /* Exinon::sig53(m, n, IE53) - sig3[n], by 16*dinc5[m]+dinc3[n]
                                         (src/codepot.cc:411-415)                              */
+    int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3, the default of the reference);
+                                        1: algmode.alg == 0 (-A0): spdp_align_s runs forwardS_ng /
+                                        hirschbergS_ng throughout, spdp_homscore_s scorealoneS_ng */
 } SpdpScoring;
 
 typedef struct SpdpProblem {
@@ -130,6 +133,15 @@ int spdp_scalar_forward(SpdpContext* ctx, const SpdpScoring* sc,
                         const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
 int spdp_scalar_scorealone(SpdpContext* ctx, const SpdpScoring* sc,
                            const SpdpProblem* probs, int n_probs, int32_t* scores);
+/* Aln2s1::hirschbergS_ng (src/fwd2s1.cc:762-1104), the scalar linear-space engine, with n_im
+ * intermediate rows imd_intvl rows apart (Aln2s1::imd_intvl as lspS_ng sets it, :1839 / :1850): cpos,
+ * ranges as for spdp_wip_udh; cpos[..][8], [9] carry the diagonal bounds of each slab (what
+ * mimd_postwork / rcsv_postwork use as its window under -A0); entries the reference leaves
+ * uninitialised read end_of_ulk.  flags[i] = -3: the reference reads or writes outside its arrays on
+ * this input (undefined there), 0 otherwise. */
+int spdp_scalar_udh(SpdpContext* ctx, const SpdpScoring* sc,
+                    const SpdpProblem* probs, int n_probs, int n_im, int imd_intvl,
+                    int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags);
 
 /* ---- Aln2 surface, batched --------------------------------------------- */
 /* HomScoreS_ng for -A2/-A3 (simd > 1): stripe() then scoreonlyS1_wip. */

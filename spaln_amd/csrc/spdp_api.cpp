@@ -268,7 +268,7 @@ void DevRun::release() {}       // buffers belong to ctx->pool[flavour]
 
 #define POOLGET(dst, slot, bytes)                                                        \
     do {                                                                                 \
-        (dst) = ctx->pool[flav].get((slot), (size_t) (bytes));                           \
+        (dst) = ctx->pool[flav == 5 ? 4 : flav].get((slot), (size_t) (bytes));           \
         if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
     } while (0)
 
@@ -296,12 +296,18 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.lw = it.w.lw; P.up = it.w.up; P.width = it.w.width;
         P.buf_size = it.w.width + 2 * SPDP_NELEM;
         P.flags = (it.a_exgl ? 1 : 0) | (it.a_exgr ? 2 : 0) | (it.b_exgl ? 4 : 0) | (it.b_exgr ? 8 : 0);
-        P.n_im = (flav == 2) ? it.n_im : 0;
+        P.n_im = (flav == 2 || flav == 5) ? it.n_im : 0;
+        P.imd_intvl = it.imd_intvl;
         P.a_off = st->a_off[it.parent];
         P.col_off = st->col_off[it.parent];
         P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
-        if (flav >= 3) {        // scalar: work = 4 * width ints + width dir bytes; Vmf records
+        if (flav == 5) {        // scalar UDH: 2 * width + 4 states of 5 ints; 8 link / bound rows per intermediate
+            P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
+            bnd_tot = P.bnd_off + 5ll * (2 * it.w.width + 4);
+            P.imd_off = imd_tot;
+            imd_tot += (int64_t) P.n_im * 8 * it.w.width;
+        } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + 4ll * it.w.width + (it.w.width + 3) / 4 + 8;
             const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
@@ -336,7 +342,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
         POOLGET(d_nskl, POOL_NSKL, sizeof(int) * nn);
     }
-    if (flav == 2) {
+    if (flav == 2 || flav == 5) {
         POOLGET(d_imd, POOL_IMD, sizeof(int32_t) * std::max<int64_t>(imd_tot, 1));
         POOLGET(d_cpos, POOL_CPOS, sizeof(int32_t) * 10 * (max_n_im + 1) * nn);
         POOLGET(d_ranges, POOL_RANGES, sizeof(int32_t) * 4 * nn);
@@ -396,8 +402,11 @@ int DevRun::launch()
         memcpy(S.t53, store->sc.t53, sizeof S.t53);
         S.work = (int*) d_bnd; S.vmf = (int3*) d_tb; S.res = (DevResult*) d_res;
         S.skl = (int2*) d_skl; S.n_skl = (int*) d_nskl; S.skl_cap = skl_cap;
+        S.imd = (int*) d_imd; S.cpos = (int*) d_cpos; S.ranges = (int*) d_ranges; S.scores = (int*) d_scores;
+        S.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-        HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
+        if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
+        else HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         return 0;
     }
@@ -520,7 +529,9 @@ int spdp_wip_scoreonly(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProble
 
 int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
                     int n_probs, int32_t* scores)
-{   // HomScoreS_ng for simd > 1: stripe(alprm.sh) + scoreonlyS1_wip, src/fwd2s1.cc:2696-2712
+{   // HomScoreS_ng for simd > 1: stripe(alprm.sh) + scoreonlyS1_wip, src/fwd2s1.cc:2696-2712;
+    // simd == 0: scorealoneS_ng
+    if (sc && sc->scalar_engines) return spdp_scalar_scorealone(ctx, sc, probs, n_probs, scores);
     return spdp_wip_scoreonly(ctx, sc, probs, n_probs, scores);
 }
 
@@ -542,6 +553,29 @@ int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
     memcpy(scores, s.data(), sizeof(int32_t) * n_probs);
     memcpy(ranges, r.data(), sizeof(int32_t) * 4 * n_probs);
     memcpy(cpos, c.data(), sizeof(int32_t) * c.size());
+    return 0;
+}
+
+int spdp_scalar_udh(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
+                    int n_im, int imd_intvl, int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags)
+{
+    if (!ctx || !sc || !probs || !scores || !cpos || !ranges || !flags || n_im < 1 || imd_intvl < 1) return -1;
+    if (n_probs <= 0) return 0;
+    DevStore st; DevRun run;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    std::vector<RunItem> items = items_of(sc, probs, n_probs);
+    for (auto& it : items) {
+        it.n_im = n_im; it.imd_intvl = imd_intvl;
+        if (it.a_left + (int64_t) n_im * imd_intvl > it.a_right + imd_intvl) { ctx->err = "intermediate rows beyond the query range"; return -1; }
+    }
+    if (run.build(&st, items, 5) || run.launch() || run.sync()) return -1;
+    std::vector<int32_t> s, c, r;
+    std::vector<DevResult> res;
+    if (run.fetch_udh(s, c, r) || run.fetch_results(res)) return -1;
+    memcpy(scores, s.data(), sizeof(int32_t) * n_probs);
+    memcpy(ranges, r.data(), sizeof(int32_t) * 4 * n_probs);
+    memcpy(cpos, c.data(), sizeof(int32_t) * c.size());
+    for (int i = 0; i < n_probs; ++i) flags[i] = res[i].pad[0];
     return 0;
 }
 

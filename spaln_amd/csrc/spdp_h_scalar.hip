@@ -415,7 +415,9 @@ __global__ void spdh_scalar(HScalarArgs A)
 extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;
-    const dim3 grd((A.n_probs + 63) / 64), blk(64);
+    // few problems: one per wave (a wave of divergent one-thread problems runs them one after another)
+    const int per = A.n_probs <= 8192 ? 1 : 64;
+    const dim3 grd((A.n_probs + per - 1) / per), blk(per);
     if (forward) hipLaunchKernelGGL(spdh_scalar<true>, grd, blk, 0, stream, A);
     else hipLaunchKernelGGL(spdh_scalar<false>, grd, blk, 0, stream, A);
     return hipGetLastError();

@@ -44,7 +44,7 @@ struct Job {                                // one query through alignS_ng
 
 struct LspItem { int job; Rng r; SpdpWindow w; bool top; };
 struct TbItem  { int job; Rng r; SpdpWindow w; bool top; };     // trcbkalignS_ng call
-struct UdhItem { int job; Rng r; SpdpWindow w; bool top; int n_imd; bool recursive; };
+struct UdhItem { int job; Rng r; SpdpWindow w; bool top; int n_imd; bool recursive; int imd_intvl; };
 
 void stripe_of(const Rng& r, int sh, SpdpWindow* w)
 {
@@ -172,7 +172,7 @@ struct Aligner {
     {
         if (w.width < 0) { set_score(job, top, SPDP_NEVSEL); return; }
         if (bad_range(job, r) || w.width < 3) { ++unsupported; jobs[job].failed = true; return; }
-        if (r.ar - r.al < kScalarRows) {        // fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
+        if (st->sc.scalar_engines || r.ar - r.al < kScalarRows) {   // -A0, or fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
             if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
             stbs.push_back({job, r, w, top});
             return;
@@ -205,7 +205,13 @@ struct Aligner {
         int n_imd = 1;
         bool recursive = false;                 // algmode.alg & 4 (-A4..7) not offered
         float cvol = float(m) * (n + m);        // rhombic, simd >= 2
+        if (sc.scalar_engines) {                // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
+            const float k = it.w.lw - r.bl + r.ar;
+            const float q = r.br - r.al - it.w.up;
+            cvol = float(m) * n - (k * k + q * q) / 2;
+        }
         if (kCoefB * cvol < sc.max_vmf_space) { trcbk(it.job, r, it.w, it.top); return true; }
+        int intvl = (m + 1) / 2;
         {
             const float coef_C = (sc.noll + 1) * sizeof(int);
             const double z = 2. * m * kCoefB / coef_C;
@@ -215,14 +221,24 @@ struct Aligner {
             else {
                 const int imd3 = m / SPDP_NELEM;
                 n_imd = sc.ubh ? sc.ubh : std::min(imd1, imd3);
-                const int imd_intvl = (m + n_imd) / (n_imd + 1);
+                const int imd_intvl = intvl = (m + n_imd) / (n_imd + 1);
                 if (imd_intvl * n_imd == m) --n_imd;
                 if (n_imd == 0) { trcbk(it.job, r, it.w, it.top); return true; }
             }
         }
         if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
-        udh.push_back({it.job, r, it.w, it.top, n_imd, recursive});
+        if (sc.scalar_engines && !st->has_exact) { ++unsupported; J.failed = true; return true; }
+        udh.push_back({it.job, r, it.w, it.top, n_imd, recursive, intvl});
         return true;
+    }
+
+    // window of a slab: stripe() under SIMD; under -A0 the diagonal bounds hirschbergS_ng recorded in
+    // the cpos row (src/fwd2s1.cc:1735-1740, 1778-1797)
+    void slab_window(const Rng& r, int sh, const int32_t* row, SpdpWindow* w) const
+    {
+        if (!st->sc.scalar_engines) { stripe_of(r, sh, w); return; }
+        w->lw = row[8]; w->up = row[9];
+        w->width = w->up - w->lw + 3;
     }
 
     // Aln2s1::mimd_postwork on the written-back ranges
@@ -243,7 +259,7 @@ struct Aligner {
             if (cur.bl < 0 || cur.bl > cur.br) break;
             while (c < 9 && CP(i, ++c) < kEndOfUlk) J.rec.push_back({cur.al, CP(i, c)});
             SpdpWindow vw;
-            stripe_of(cur, sh, &vw);
+            slab_window(cur, sh, &CP(i + 1, 0), &vw);
             trcbk(u.job, cur, vw, false);
             cur.ar = cur.al;
             cur.br = CP(i, c - 1);
@@ -251,7 +267,7 @@ struct Aligner {
         if ((i < 0 && CP(0, 0) != kEndOfUlk) || CP(0, 2) != kEndOfUlk) {
             cur.al = aleft; cur.bl = bleft;
             SpdpWindow vw;
-            stripe_of(cur, sh, &vw);
+            slab_window(cur, sh, &CP(0, 0), &vw);
             trcbk(u.job, cur, vw, false);
         }
 #undef CP
@@ -269,11 +285,11 @@ struct Aligner {
             Rng first = cur;
             first.ar = cpos[0]; first.br = cpos[c - 1];
             SpdpWindow w;
-            stripe_of(first, sh, &w);
+            slab_window(first, sh, cpos, &w);
             pending.push_back({u.job, first, w, false});
             Rng second = cur;
             second.al = cpos[0]; second.b_exgl = cpos[1] ? 1 : 0; second.bl = cpos[2];
-            stripe_of(second, sh, &w);
+            slab_window(second, sh, cpos + 10, &w);
             pending.push_back({u.job, second, w, false});
         } else if (st->sc.local) {
             SpdpWindow w;
@@ -313,9 +329,13 @@ struct Aligner {
             lap("classify");
             if (udh.empty()) continue;
             std::vector<RunItem> items;
-            for (const UdhItem& u : udh) items.push_back(run_item(u.job, u.r, u.w, u.n_imd));
+            for (const UdhItem& u : udh) {
+                items.push_back(run_item(u.job, u.r, u.w, u.n_imd));
+                items.back().imd_intvl = u.imd_intvl;
+            }
             DevRun run;
-            if (run.build(st, items, 2)) return -1;
+            const bool a0 = sc.scalar_engines != 0;
+            if (run.build(st, items, a0 ? 5 : 2)) return -1;
             lap("udh build");
             if (run.launch() || run.sync()) return -1;
             lap("udh launch+sync");
@@ -324,11 +344,14 @@ struct Aligner {
             stats[6] += 1;
             std::vector<int32_t> scores, cpos, ranges;
             if (run.fetch_udh(scores, cpos, ranges)) return -1;
+            std::vector<DevResult> ures;
+            if (a0 && run.fetch_results(ures)) return -1;
             lap("udh fetch");
             const int stride = 10 * (run.max_n_im + 1);
             for (size_t k = 0; k < udh.size(); ++k) {
                 const UdhItem& u = udh[k];
                 const int scr = scores[k];
+                if (a0 && ures[k].pad[0]) { ++unsupported; jobs[u.job].failed = true; continue; }   // undefined in the reference
                 set_score(u.job, u.top, scr);
                 if (scr <= SPDP_NEVSEL) continue;
                 Rng curr = u.r;                 // ranges as written back by the engine

@@ -65,8 +65,15 @@ struct ScalarArgs {
     int2*             skl;
     int*              n_skl;
     int               skl_cap;
+    // scalar UDH (hirschbergS_ng) only
+    int*              imd;        // per problem n_im * 8 * width ints at DevProblem::imd_off
+    int*              cpos;       // per problem cpos_stride ints
+    int*              ranges;     // per problem 4 ints
+    int*              scores;
+    int               cpos_stride;
 };
 extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
+extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
@@ -171,10 +178,12 @@ struct RunItem {
     uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
     SpdpWindow w;
     int n_im;          // UDH only
+    int imd_intvl = 0; // scalar UDH only: Aln2s1::imd_intvl as lspS_ng set it
 };
 
 // descriptors + work buffers of one engine flavour over a DevStore:
-// 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score
+// 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score,
+// 5 scalar udh (shares pool 4 with the scalar score run: the two never coexist)
 struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;

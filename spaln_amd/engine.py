@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
 EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
-    "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_batch_upload", "spdp_batch_free",
+    "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_scalar_udh", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
     "spdp_scalar_forward_h",
@@ -55,6 +55,8 @@ def load_library() -> C.CDLL:
     lib.spdp_scalar_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_scalar_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_free_alignments.argtypes = [C.c_void_p, C.c_int]
     lib.spdp_skl_rng_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.spdp_skl_rng_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -143,6 +145,18 @@ class Engine:
         self._check(self.lib.spdp_scalar_scorealone(self.ctx, C.byref(sc), ps.array(), len(ps),
                                                     out.ctypes.data), "spdp_scalar_scorealone")
         return out
+
+    def scalar_udh(self, sc, ps, n_im: int, imd_intvl: int):
+        """Aln2s1::hirschbergS_ng: (scores, cpos rows, written-back ranges, flags)"""
+        n = len(ps)
+        scores = np.zeros(n, dtype=np.int32)
+        cpos = np.zeros((n, n_im + 1, 10), dtype=np.int32)
+        ranges = np.zeros((n, 4), dtype=np.int32)
+        flags = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.spdp_scalar_udh(self.ctx, C.byref(sc), ps.array(), n, n_im, imd_intvl,
+                                             scores.ctypes.data, cpos.ctypes.data, ranges.ctypes.data,
+                                             flags.ctypes.data), "spdp_scalar_udh")
+        return scores, cpos, ranges, flags
 
     def align_s(self, sc, ps, allow_partial=False):
         """alignS_ng (ori = 1, -Q0).  allow_partial: accept return value 1 (some problem needed the

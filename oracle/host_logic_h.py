@@ -93,6 +93,7 @@ def lsp_h(sc, p, w, rec, simd=2):
         return trcbk_h(sc, p, w, rec, simd)
     recursive = False
     n_imd = 1
+    imd_intvl = (m + 1) // 2
     z = 2.0 * m * COEF_B / COEF_C
     imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
     spc = _f32(_f32(_f32(COEF_C * n) * imd1) + _f32(_f32(_f32(COEF_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
@@ -101,14 +102,19 @@ def lsp_h(sc, p, w, rec, simd=2):
     else:
         imd3 = m // NELEM
         n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
-        intvl = (m + n_imd) // (n_imd + 1)
+        intvl = imd_intvl = (m + n_imd) // (n_imd + 1)
         if intvl * n_imd == m:
             n_imd -= 1
         if n_imd == 0:
             return trcbk_h(sc, p, w, rec, simd)
-    if simd < 2:
-        raise NotRestated("hirschbergH_ng / hirschbergH1 (linear space under -A0 / -A1)")
-    scr, cpos, rng = oracle.wip_udh_h(sc, p, n_imd, w)
+    if simd == 1:
+        raise NotRestated("hirschbergH1 (linear space under -A1)")
+    if simd == 0:
+        scr, cpos, rng, flag = oracle.scalar_udh_h(sc, p, n_imd, imd_intvl, w)
+        if flag:
+            raise ReferenceUndefined("hirschbergH_ng outside its arrays")
+    else:
+        scr, cpos, rng = oracle.wip_udh_h(sc, p, n_imd, w)
     if scr > abi.NEVSEL:
         cur = _sub(p, int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]),
                    (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr))
@@ -116,13 +122,23 @@ def lsp_h(sc, p, w, rec, simd=2):
             rec.append((cur.a_left, cur.b_left))
             rec.append((cur.a_right, cur.b_right))
         elif recursive:
-            rcsv_h(sc, cur, cpos, rec)
+            rcsv_h(sc, cur, cpos, rec, simd)
         else:
-            mimd_h(sc, cur, cpos, n_imd, rec)
+            mimd_h(sc, cur, cpos, n_imd, rec, simd)
     return scr
 
 
-def mimd_h(sc, cur, cpos, n_imd, rec):
+def _slab_window_h(sc, cur, row, simd):
+    """mimd_postwork / rcsv_postwork: stripe31() under SIMD, the recorded diagonal bounds under -A0"""
+    if simd:
+        return oracle.stripe31(cur, sc.sh)
+    w = abi.Window()
+    w.lw, w.up = int(row[8]), int(row[9])
+    w.width = w.up - w.lw + 7
+    return w
+
+
+def mimd_h(sc, cur, cpos, n_imd, rec, simd=2):
     aleft, bleft = cur.a_left, cur.b_left
     cur = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
     i = n_imd - 1
@@ -140,16 +156,16 @@ def mimd_h(sc, cur, cpos, n_imd, rec):
         while c < 10 and cpos[i][c] < END:
             rec.append((cur.a_left, int(cpos[i][c])))
             c += 1
-        trcbk_h(sc, cur, oracle.stripe31(cur, sc.sh), rec)
+        trcbk_h(sc, cur, _slab_window_h(sc, cur, cpos[i + 1], simd), rec, simd)
         cur.a_right = cur.a_left
         cur.b_right = int(cpos[i][c - 1])
         i -= 1
     if (i < 0 and cpos[0][0] != END) or cpos[0][2] != END:
         cur.a_left, cur.b_left = aleft, bleft
-        trcbk_h(sc, cur, oracle.stripe31(cur, sc.sh), rec)
+        trcbk_h(sc, cur, _slab_window_h(sc, cur, cpos[0], simd), rec, simd)
 
 
-def rcsv_h(sc, cur, cpos, rec):
+def rcsv_h(sc, cur, cpos, rec, simd=2):
     base = _sub(cur, cur.a_left, cur.a_right, cur.b_left, cur.b_right, (0, 0, 0, 0))
     row = cpos[0]
     if row[0] < END:
@@ -158,11 +174,11 @@ def rcsv_h(sc, cur, cpos, rec):
             rec.append((int(row[0]), int(row[c])))
             c += 1
         first = _sub(base, base.a_left, int(row[0]), base.b_left, int(row[c - 1]), (0, 0, 0, 0))
-        lsp_h(sc, first, oracle.stripe31(first, sc.sh), rec)
+        lsp_h(sc, first, _slab_window_h(sc, first, cpos[0], simd), rec, simd)
         second = _sub(base, int(row[0]), base.a_right, int(row[2]), base.b_right, (0, 0, int(row[1]), 0))
-        lsp_h(sc, second, oracle.stripe31(second, sc.sh), rec)
+        lsp_h(sc, second, _slab_window_h(sc, second, cpos[1], simd), rec, simd)
     elif sc.local:
-        trcbk_h(sc, base, oracle.stripe31(base, sc.sh), rec)
+        trcbk_h(sc, base, oracle.stripe31(base, sc.sh), rec, simd)
 
 
 def std_skl3(rec):

@@ -177,3 +177,17 @@ def scalar_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None, traceback=True):
     if n.value:
         C.CDLL(None).free(skl)
     return s.value, out
+
+
+def scalar_udh_h(sc, p, n_im: int, imd_intvl: int, w=None):
+    """Aln2h1::hirschbergH_ng: (score, cpos rows, written-back ranges, flag); flag -3: the reference
+    indexes outside its arrays on this input (undefined)."""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.full((n_im + 1, 10), abi.END_OF_ULK, dtype=np.int32)
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_scalar_udh_h(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.c_int(imd_intvl), C.byref(s),
+                                cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc not in (0, -3):
+        raise RuntimeError(f"orc_scalar_udh_h rc={rc}")
+    return s.value, cpos, rng, rc

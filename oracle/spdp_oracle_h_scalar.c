@@ -458,3 +458,436 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
     *score = scr;
     return 0;
 }
+
+/* ---- unidirectional Hirschberg, scalar -------------------------------------------------------
+ * orc_scalar_udh_h   Aln2h1::hirschbergH_ng + hinitH_ng / hlastH_ng     src/fwd2h1.cc:1085-1520, 941-1083
+ *                    with UdhIntermediate (lub = true)                   src/udh_intermediate.h:29-66
+ * forwardH_ng's recurrence with every state carrying the diagonal range visited since the last
+ * intermediate row (upr / lwr), its start row (ml) and a link (ulk) to where it crossed the previous
+ * intermediate.  Not the same boundary rules as forwardH_ng: one `jnc` for all frames in the leading
+ * gap, termination codons gated by algmode.lcl & 2, `(dir & DIAG)` as the diagonal-continuation test,
+ * `>=` where the forward engine has `>` -- all as in the reference.  cpos rows as lspH_ng reads them;
+ * entries the reference leaves uninitialised are end_of_ulk.  rc -3: the reference indexes outside
+ * its arrays on this input. */
+typedef struct { int val, dir, upr, lwr, ml, ulk; } Rvdwml;
+typedef struct { int val, dir, upr, lwr, ml, ulk, jnc; } Rvdwmlj;
+typedef struct { int mi; int* buf; int *hlnk[2], *vlnk[2], *lwrb[2], *uprb[2]; } HUImd;
+
+int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int n_im, int imd_intvl,
+                     int32_t* score, int32_t* cpos, int32_t* ranges)
+{
+    if (!sc->intpen || !p->dinc || n_im < 1) return -1;
+    code_tables();
+    const int minl = sc->minl ? sc->minl : sc->llmt;
+    Ctx cx = {sc, p, minl};
+    const int NEV = SPDP_NEVSEL, EOU = SPDP_END_OF_ULK;
+    int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
+    const int Local = sc->local;
+    const int LocalL = Local && p->a_exgl && p->b_exgl;
+    const int LocalR = Local && p->a_exgr && p->b_exgr;
+    const int spj = sc->spj;
+    const int lw = w->lw, up = w->up, width = w->width;
+    const int GOP[2] = {0, sc->gop};
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+    for (int i = 0; i <= n_im; ++i) for (int c = 0; c < 10; ++c) CPOS(i, c) = EOU;
+    const size_t bufsiz = (size_t) 2 * width;
+    Rvdwml* wbuf = (Rvdwml*) malloc((bufsiz + 8) * sizeof(Rvdwml));
+    int r = bl - 3 * ar;
+    const Rvdwml black = {NEV, 0, r, r, 0, EOU};
+    const Rvdwmlj blackj = {NEV, 0, INT_MIN, INT_MAX, 0, EOU, 0};
+    for (size_t i = 0; i < bufsiz + 8; ++i) wbuf[i] = black;
+    Rvdwml* hh0 = wbuf - lw + 3;
+    Rvdwml* hh1 = hh0 + width;
+
+    /* ---- hinitH_ng ---- */
+    {
+        int n = bl;
+        r = bl - 3 * al;
+        const int r0 = r;
+        int rr = br - 3 * al;
+        const int dir = p->a_exgl ? DEAD : DIAG;
+        int bb = n + 1;
+        Rvdwml* h = hh0 + r;
+        h->val = (p->a_exgl && p->sigS[bb] > 0) ? p->sigS[bb] : 0;
+        h->dir = dir;
+        h->lwr = h->upr = h->ulk = r0;
+        h->ml = al;
+        if (p->a_exgl) {
+            if (up < rr) rr = up;
+            int jnc = n;
+            for (int i = 1; ++r <= rr; ++i) {
+                ++h; ++bb; ++n;
+                if (i < 3) {
+                    h->val = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+                    h->dir = dir;
+                    h->lwr = h->ulk = r;
+                    h->ml = al;
+                } else {
+                    *h = h[-3];
+                    const int d = n - jnc;
+                    if (!(p->a_exgl & 1) && d == 3) h->val += sc->gop;
+                    if (!(p->a_exgl & 2)) h->val += gap_ext3(sc, d);
+                    h->val += p->sigE[bb - 3];
+                    h->dir = HORI;
+                    int x = h[-1].val + sc->gapw1;
+                    if (x > h->val) { *h = h[-1]; h->val = x; h->dir = HOR1; }
+                    x = h[-2].val + sc->gapw2;
+                    if (x > h->val) { *h = h[-2]; h->val = x; h->dir = HOR2; }
+                }
+                const int x = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+                if (h->val < x) { h->val = x; h->dir = DEAD; jnc = n; h->lwr = h->ulk = r; }
+                h->upr = r;
+            }
+        }
+        r = r0;
+        rr = bl - 3 * ar;
+        if (lw > rr) rr = lw;
+        h = hh0 + r - 1;
+        for (int i = 1; --r >= rr; ++i, --h) {
+            if (p->b_exgl == 1) {
+                h->val = 0; h->dir = DEAD;
+                h->upr = h->lwr = h->ulk = r;
+                h->ml = al + i / 3;
+            } else if (i <= 3) {
+                *h = h[i];
+                if (!(p->b_exgl & 2)) h->val += sc->gep;
+                if (!(p->b_exgl & 1)) h->val += sc->gop;
+                if (i < 3) h->val += sc->extragop;
+                h->dir = VERT;
+                h->ml += i / 3;
+                h->lwr = h->ulk = r;
+            } else {
+                *h = h[3];
+                if (!(p->b_exgl & 2)) h->val += gap_ext3(sc, i);
+                h->lwr = h->ulk = r;
+                ++h->ml;
+            }
+        }
+    }
+    HUImd* imds = (HUImd*) calloc(n_im, sizeof(HUImd));
+    {
+        int mi = al;
+        const size_t us = (size_t) 2 * width;
+        for (int i = 0; i < n_im; ++i) {
+            HUImd* d = imds + i;
+            d->mi = (mi += imd_intvl);
+            d->buf = (int*) malloc(4 * us * sizeof(int));
+            for (size_t k = 0; k < 2 * us; ++k) d->buf[k] = EOU;
+            for (size_t k = 0; k < us; ++k) { d->buf[2 * us + k] = INT_MAX; d->buf[3 * us + k] = INT_MIN; }
+            d->hlnk[0] = d->buf - lw + 1;  d->vlnk[0] = d->hlnk[0] + us;
+            d->lwrb[0] = d->vlnk[0] + us;  d->uprb[0] = d->lwrb[0] + us;
+            d->hlnk[1] = d->hlnk[0] + width; d->vlnk[1] = d->vlnk[0] + width;
+            d->lwrb[1] = d->lwrb[0] + width; d->uprb[1] = d->uprb[0] + width;
+        }
+    }
+    HUImd* imd = imds;
+    int mm = imd->mi;
+    int rlst[3] = {INT_MAX, INT_MAX, INT_MAX};
+    int maxh_val = NEV, maxh_upr = 0, maxh_lwr = 0, maxh_ml = al, maxh_ulk = 0, maxh_mr = ar, maxh_nr = br;
+    int m = al;
+    if (!p->a_exgl) --m;
+    int n1 = 3 * m + lw - 1;
+    int n2 = 3 * m + up;
+    for (int i = 0; ++m <= ar; ) {
+        n1 += 3; n2 += 3;
+        const int n0 = imax(n1, bl);
+        const int n9 = imin(n2, br);
+        const int is_imd = m == mm;
+        int n = n0;
+        r = n - 3 * m;
+        Rvdwml e1[NQUE] = {black, black, black};
+        if (!p->b_exgl && m == al) { e1[2] = hh0[r]; e1[2].val += sc->gapw3; }
+        Rvdwml* h = hh0 + r;
+        Rvdwml* f = hh1 + r;
+        Rvdwml* hf[NOD] = {h, 0, f};
+        const int aa0 = a_code(&cx, m - 1), aa1 = a_code(&cx, m);
+        Rvdwmlj hl[3][NCAND + 1];
+        int nx[3][NCAND + 1];
+        for (int ph = 0; ph < 3; ++ph)
+            for (int l = 0; l <= NCAND; ++l) { hl[ph][l] = blackj; nx[ph][l] = l; }
+        int ncand[3] = {-1, -1, -1};
+        int q = 0;
+        for ( ; n <= n9; ++n, ++r, ++h, ++f) {
+            int x, y;
+            hf[0] = h; hf[2] = f;
+            const int sigE = (n > bl && n >= 2) ? p->sigE[n - 2] : 0;
+            Rvdwml* const eq1 = hf[1] = e1 + q;
+            const Rvdwml hq = *h;
+            Rvdwml* from = h;
+            Rvdwml* mx = h;
+            if (m != al) {
+                if (n < bl + 3) *h = black;
+                else {
+                    h->val += mtx_at(&cx, aa0, b_code(&cx, n - 2)) + sigE;
+                    h->dir = (from->dir & DIAG) ? DIAG : NEWD;
+                }
+                y = f[3].val + sc->gep;
+                ++from;
+                x = from->val + (is_vert[from->dir & 15] ? sc->gape1 : sc->gapw1);
+                if (x > y) { *f = *from; f->val = x; f->dir = SLA2; }
+                else f->val = y;
+                ++from;
+                x = from->val + (is_vert[from->dir & 15] ? sc->gape2 : sc->gapw2);
+                if (x > f->val) { *f = *from; f->val = x; f->dir = SLA1; }
+                x = (++from)->val + sc->gapw3;
+                if (x >= f->val) { *f = *from; f->val = x; f->dir = VERT; }
+                else if (y >= f->val) { *f = f[3]; f->val = y; f->dir = VERT; }
+                if (f->val >= mx->val) mx = f;
+            }
+            if (n > n0 + 2) {
+                from = h - 3;
+                x = from->val + sc->gapw3;
+                y = eq1->val += sc->gep;
+                if (x > y) { *eq1 = *from; eq1->val = x; }
+                eq1->val += sigE;
+                eq1->dir = (eq1->dir & SPIN) + HORI;
+            }
+            if (n > n0 + 1) {
+                from = h - 2;
+                x = from->val + sc->gapw2;
+                if (x > eq1->val) { *eq1 = *from; eq1->val = x; eq1->dir = HOR2; }
+            }
+            from = h - 1;
+            x = from->val + sc->gapw1;
+            if (x > eq1->val) { *eq1 = *from; eq1->val = x; eq1->dir = HOR1; }
+            if (eq1->val > mx->val) mx = eq1;
+            if (++q == NQUE) q = 0;
+
+            int spj3 = 0;
+            if (spj && p->phs3[n] > -2) {
+                int phs = (p->phs3[n] == 2) ? -1 : p->phs3[n];
+                for (;;) {
+                    const int nb = n - phs;
+                    const int* pnx = nx[phs + 1];
+                    const Rvdwmlj* maxphl[NOD] = {0, 0, 0};
+                    for (int l = 0; l <= ncand[phs + 1]; ++l) {
+                        const Rvdwmlj* phl = hl[phs + 1] + pnx[l];
+                        if (phs == 1 && phl->dir == 2) continue;
+                        if (nb - phl->jnc < minl) continue;
+                        x = phl->val + spjscr(&cx, phl->jnc, nb);
+                        if (phl->dir == 0 && phs) {
+                            int cs[2];
+                            spjseq(&cx, phl->jnc, nb, cs);
+                            if (phs == 1) x += mtx_at(&cx, aa0, cs[0]);
+                            else x += mtx_at(&cx, aa1, cs[1]) - mtx_at(&cx, aa1, b_code(&cx, n + 1)) - p->sigE[n + 1];
+                        }
+                        from = hf[phl->dir];
+                        if (x > from->val) { from->val = x; maxphl[phl->dir] = phl; }
+                    }
+                    int maxk = NOD;
+                    for (int k = 0; k < NOD; ++k) {
+                        const Rvdwmlj* phl = maxphl[k];
+                        if (!phl) continue;
+                        from = hf[k];
+                        from->dir = nod2dir[phl->dir] | SPIN;
+                        from->upr = imax(phl->upr, r);
+                        from->lwr = imin(phl->lwr, r);
+                        from->ml = phl->ml;
+                        from->ulk = phl->ulk;
+                        if (from->val >= mx->val) { maxk = k; mx = from; }
+                    }
+                    if (is_imd && maxk < NOD) {
+                        const Rvdwmlj* phl = maxphl[maxk];
+                        imd->hlnk[0][r] = phl->ulk;
+                        mx->ulk = rlst[q] = r;
+                        spj3 = 1;
+                        if (maxk == 0) {
+                            if ((phl = maxphl[1]) && hf[1]->val > mx->val + GOP[1]) {
+                                hf[1]->ulk = r + width;
+                                imd->hlnk[1][r] = phl->ulk;
+                            }
+                            if (maxphl[2] && hf[2]->val > mx->val + GOP[1]) hf[2]->ulk = r + width;
+                        }
+                    }
+                    if (p->phs3[n] - phs == 3) { phs = 1; continue; }
+                    break;
+                }
+            }
+
+            y = h->val;
+            if (h == mx) {
+                if (LocalR && y > maxh_val) {
+                    maxh_val = h->val; maxh_upr = h->upr; maxh_lwr = h->lwr; maxh_ml = h->ml; maxh_ulk = h->ulk;
+                    maxh_mr = m; maxh_nr = n;
+                }
+            } else {
+                if (mx->upr < r) mx->upr = r;
+                if (mx->lwr > r) mx->lwr = r;
+                *h = *mx;
+            }
+            if (LocalL && h->val <= 0) {
+                h->val = h->dir = 0;
+                h->ml = m;
+                h->ulk = h->upr = h->lwr = r;
+            }
+
+            const int hd = dir2nod[mx->dir & 15];
+            if (spj && p->phs5[n] > -2) {
+                int phs = (p->phs5[n] == 2) ? -1 : p->phs5[n];
+                for (;;) {
+                    const int nb = n - phs;
+                    const int sigJ = p->sig5[nb];
+                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < NOD; ++k) {
+                        const int crossspj = phs == 1 && k == 0;
+                        const Rvdwml* src = crossspj ? &hq : hf[k];
+                        if (!src->dir || (src->dir & SPIN)) continue;
+                        if (k != hd && !crossspj && hd >= 0) {
+                            y = mx->val;
+                            if (hd == 0 || (k - hd) % 2) y += GOP[k / 2];
+                            if (src->val <= y) continue;
+                        }
+                        x = src->val + sigJ;
+                        Rvdwmlj* phl = hl[phs + 1];
+                        int* pnx = nx[phs + 1];
+                        int* nc = &ncand[phs + 1];
+                        int l = *nc < NCAND ? ++*nc : NCAND;
+                        while (--l >= 0) {
+                            if (x >= phl[pnx[l]].val) { const int t = pnx[l]; pnx[l] = pnx[l + 1]; pnx[l + 1] = t; }
+                            else break;
+                        }
+                        if (++l < NCAND) {
+                            phl += pnx[l];
+                            phl->val = x; phl->jnc = nb; phl->dir = k;
+                            phl->upr = src->upr; phl->lwr = src->lwr; phl->ml = src->ml;
+                            if (is_imd) {
+                                if (k == 1) imd->hlnk[0][r] = rlst[q];
+                                phl->ulk = r;
+                            } else phl->ulk = src->ulk;
+                        } else --*nc;
+                    }
+                    if (p->phs5[n] - phs == 3) { phs = 1; continue; }
+                    break;
+                }
+            }
+
+            if (is_imd) {
+                if (hd == 0) rlst[q] = r;
+                else if (!spj3 && hd % 2) imd->hlnk[0][r] = rlst[q];
+                for (int k = 0; k < 2; ++k) {
+                    Rvdwml* g = hf[2 * k];
+                    imd->vlnk[k][r] = g->ulk;
+                    imd->lwrb[k][r] = imin(r, g->lwr);
+                    imd->uprb[k][r] = imax(r, g->upr);
+                    g->lwr = g->upr = r;
+                    g->ulk = r + k * width;
+                }
+            }
+        }
+        if (is_imd && ++i < n_im) { imd = imds + i; mm = imd->mi; }
+    }
+
+    int rc = 0;
+    const int rr = br - 3 * ar;
+    if (LocalR) {
+        int i = n_im;
+        while (--i >= 0 && imds[i].mi > ar) ;
+        ar = maxh_mr; br = maxh_nr;
+        if (i < 0) i = 0;
+        CPOS(i, 8) = maxh_lwr;
+        CPOS(i, 9) = maxh_upr;
+    } else {        /* ---- hlastH_ng ---- */
+        static const int next_p[3] = {1, 2, 0};
+        int glen[3] = {0, 0, 0};
+        const int m3 = 3 * ar;
+        int rw = lw;
+        int rf = bl - m3;
+        if (rf > rw) rw = rf; else rf = rw;
+        Rvdwml* h = hh0 + rw;
+        Rvdwml* h9 = hh0 + br - m3;
+        Rvdwml* mx = h9;
+        int bb = rw + m3;
+        if (p->a_exgr) {
+            for (int ph = 0; h <= h9; ++h, ++bb, ++rf, ph = next_p[ph]) {
+                glen[ph] += 3;
+                int cand[3] = {h->val, NEV, NEV};
+                if (rf - rw >= 3 && h[-3].dir != DEAD) {
+                    cand[1] = h[-3].val + p->sigE[bb - 2];
+                    if (!(p->a_exgr & 2)) cand[1] += gap_ext3(sc, glen[ph]);
+                    if (glen[ph] == 3 && !(p->a_exgr & 1)) cand[1] += sc->gop;
+                    if (sc->term_codon && !(h->dir & SPIN)) cand[2] = h[-3].val + p->sigT[bb - 2];
+                }
+                const int sig5 = (Local && p->sig5[bb] > 0) ? p->sig5[bb] : 0;
+                cand[0] += sig5;
+                cand[1] += sig5;
+                int k = 0;
+                if (cand[1] > cand[k]) k = 1;
+                if (cand[2] > cand[k]) k = 2;
+                if (k == 0) { if (!is_hori[h->dir & 15]) glen[ph] = 0; }
+                else if (k == 1) { *h = h[-3]; h->dir = HORI; h->val = cand[k] - sig5; }
+                else { *h = h[-3]; h->dir = DEAD; h->val = cand[k]; h->upr = imax(rf, h->upr); }
+                if (h->val > mx->val) mx = h;
+            }
+        } else {
+            bb += (int) (h9 - h);
+            const int y = h9[-3].val + p->sigT[bb - 2];
+            if (y > h9->val) { *h9 = h9[-3]; h9->val = y; h9->dir = HORI; h9->upr = imax(br - m3, h9->upr); }
+        }
+        if (p->b_exgr == 1) {
+            rw = imin(up, br - 3 * al);
+            for (h = hh0 + rw; h > h9; --h, --rw) {
+                const int x = h->val + ((rw % 3) ? sc->extragop : 0);
+                if (x > mx->val) { mx = h; mx->val = x; }
+            }
+        } else if (p->b_exgr == 2)
+            mx = hh1 + br - m3;
+        maxh_val = mx->val; maxh_lwr = mx->lwr; maxh_upr = mx->upr; maxh_ulk = mx->ulk; maxh_ml = mx->ml;
+        r = (int) (mx - hh0);
+        if (p->b_exgr && rr < r) ar = (br - r) / 3;
+        if (p->a_exgr && rr > r) br = 3 * ar + r;
+    }
+    int i = n_im;
+    while (--i >= 0 && imds[i].mi > ar) ;
+    if (i < 0 && imds[0].mi > ar) CPOS(0, 2) = br;
+    r = br - 3 * ar;
+    CPOS(i + 1, 8) = imin(maxh_lwr, r);
+    CPOS(i + 1, 9) = imax(maxh_upr, r);
+    r = maxh_ulk;
+    for ( ; i >= 0 && (imd = imds + i)->mi > maxh_ml; --i) {
+        int c = 0, d = 0;
+        for ( ; r > up; r -= width) ++d;
+        if (d > 1 || r < lw - 1) { rc = -3; break; }
+        if (imd->vlnk[d][r] < EOU) {
+            CPOS(i, c++) = imd->mi;
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            const int mm3 = 3 * imd->mi;
+            for (int rp = imd->hlnk[d][r]; lw <= rp && rp < up && r != rp; rp = imd->hlnk[0][r = rp]) {
+                if (c >= 6) { rc = -3; break; }
+                CPOS(i, c++) = r + mm3;
+            }
+            if (rc) break;
+            CPOS(i, c++) = r + mm3;
+            CPOS(i, c) = EOU;
+            CPOS(i, 8) = imd->lwrb[d][r];
+            CPOS(i, 9) = imd->uprb[d][r];
+            r = imd->vlnk[d][r];
+            if (r == EOU) break;
+        } else
+            CPOS(i, 0) = EOU;
+    }
+    if (!rc) {
+        for ( ; r > up; r -= width) ;
+        if (LocalL) { al = maxh_ml; bl = r + 3 * maxh_ml; }
+        else {
+            const int rl = bl - 3 * al;
+            if (p->b_exgl && rl > r) {
+                al = (bl - r) / 3;
+                for (int j = 0; j < n_im && imds[j].mi < al; ++j) CPOS(j, 0) = EOU;
+            }
+            if (p->a_exgl && rl < r) bl = 3 * al + r;
+        }
+        ++i;
+        if ((i < n_im && imds[i].mi < al) || CPOS(i, 2) < bl) maxh_val = NEV;
+        else if (CPOS(i, 8) == EOU || CPOS(i, 9) == EOU) rc = -3;
+        else {
+            r = bl - 3 * al;
+            CPOS(i, 8) = imin(r, CPOS(i, 8));
+            CPOS(i, 9) = imax(r, CPOS(i, 9));
+        }
+    }
+#undef CPOS
+    *score = maxh_val;
+    ranges[0] = al; ranges[1] = ar; ranges[2] = bl; ranges[3] = br;
+    for (int j = 0; j < n_im; ++j) free(imds[j].buf);
+    free(imds); free(wbuf);
+    return rc;
+}

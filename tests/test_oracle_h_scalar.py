@@ -25,15 +25,12 @@ def test_homscore_a0(path):
 
 @pytest.mark.parametrize("path", H_FILES, ids=_name)
 def test_align_a0(path):
-    """alignH_ng under -A0 where lspH_ng takes the traceback branch (forwardH_ng + Vmf::traceback +
-    stdskl3); the linear-space branch would need hirschbergH_ng, which is not restated"""
+    """alignH_ng under -A0 end to end: forwardH_ng + Vmf::traceback in the traceback branch, hirschbergH_ng
+    with its recorded diagonal bounds as slab windows in the linear-space branch, stdskl3"""
     fx = spdg.load(path)
     sc = spdg.scoring_h(fx)
     _, p = spdg.problem_h(fx)
-    try:
-        scr, flat = hh.align_h(sc, p, simd=0)
-    except hh.NotRestated:
-        pytest.skip("linear-space branch under -A0")
+    scr, flat = hh.align_h(sc, p, simd=0)
     assert scr == int(fx["aln_scr_A0"][0])
     assert (flat or []) == fx["aln_skl_A0"].tolist()
 
@@ -50,3 +47,22 @@ def test_below_8_rows_default_modes(m, alg):
     scr, flat = hh.align_h(sc, p, simd=alg)
     assert scr == int(fx[f"aln_scr_A{alg}"][0])
     assert flat == fx[f"aln_skl_A{alg}"].tolist()
+
+
+def test_hirschberg_h_ng_is_exercised():
+    seen = []
+    orig = oracle.scalar_udh_h
+
+    def spy(sc, p, n_im, intvl, w=None):
+        seen.append(n_im)
+        return orig(sc, p, n_im, intvl, w)
+    oracle.scalar_udh_h = spy
+    try:
+        for name in ("h1_450aa_auto", "h1_forced_udh3", "h1_auto_udh"):
+            fx = spdg.load([f for f in H_FILES if _name(f) == name][0])
+            sc = spdg.scoring_h(fx)
+            _, p = spdg.problem_h(fx)
+            hh.align_h(sc, p, simd=0)
+    finally:
+        oracle.scalar_udh_h = orig
+    assert len(seen) >= 3 and max(seen) >= 2

@@ -248,6 +248,8 @@ typedef struct SpdpScoringH {
     int32_t intpen_len;
     int16_t t53[256];                /* sig53(m, n, IE53) - sig3[n] by 16 * dinc5[m] + dinc3[n] */
     int32_t minl;                    /* IntronPrm.minl (scalar engine: shortest intron; 0 = llmt)   */
+    int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3); 1: algmode.alg == 0 (-A0):
+                                        spdp_align_h / spdp_homscore_h run forwardH_ng / hirschbergH_ng */
 } SpdpScoringH;
 
 typedef struct SpdpProblemH {
@@ -305,6 +307,14 @@ int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
  * to this engine (spdp_align_h and spdp_homscore_h do that themselves), correct at any size. */
 int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
                           int traceback, SpdpAlignment* out);
+
+/* Aln2h1::hirschbergH_ng (src/fwd2h1.cc:1085-1520), the scalar linear-space engine, with n_im
+ * intermediate rows imd_intvl rows apart (Aln2h1::imd_intvl as lspH_ng sets it): cpos, ranges as for
+ * spdp_wip_udh_h; cpos[..][8], [9] carry the diagonal bounds of each slab (its window under -A0);
+ * entries the reference leaves uninitialised read end_of_ulk.  flags[i] = -3: the reference indexes
+ * outside its arrays on this input (undefined there), 0 otherwise. */
+int spdp_scalar_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
+                      int n_im, int imd_intvl, int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags);
 
 /* skl_rngH_ng (src/fwd2h1.cc:635): the same for protein alignments (codon-split introns, frame
  * shifts, start / stop signals).  Needs SpdpScoringH.intpen / t53 / lgop ... and SpdpProblemH.dinc.

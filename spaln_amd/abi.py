@@ -179,6 +179,7 @@ class ScoringH(C.Structure):
         ("intpen_len", C.c_int32),
         ("t53", C.c_int16 * 256),
         ("minl", C.c_int32),
+        ("scalar_engines", C.c_int32),
     ]
 
 
@@ -206,7 +207,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
                    ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
-                   intpen=None, t53=None, minl=0) -> ScoringH:
+                   intpen=None, t53=None, minl=0, scalar_engines=0) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -227,6 +228,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
     sc.lgop, sc.gape1, sc.gape2, sc.extragop = int(lgop), int(gape1), int(gape2), int(extragop)
     sc.diffu, sc.k1 = int(diffu), int(k1)
     sc.minl = int(minl)
+    sc.scalar_engines = int(scalar_engines)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip

@@ -89,7 +89,7 @@ struct HItem {
     int a_left, a_right, b_left, b_right;
     int a_exgl, a_exgr, b_exgl, b_exgr;
     SpdpWindow w;
-    int n_im = 0;
+    int n_im = 0, imd_intvl = 0;
     bool recursive = false, first = false;      // first: this call's return value is gsi->scr
 };
 
@@ -224,7 +224,7 @@ static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
     d.col_len = st.col_len[it.top];
     d.a_off = st.a_off[it.top];
     d.col_off = st.col_off[it.top];
-    d.n_im = it.n_im;
+    d.n_im = it.n_im; d.imd_intvl = it.imd_intvl;
     d.a_len = st.probs[it.top].a_len; d.b_len = st.probs[it.top].b_len;
     d.cells = cells_of(it);
 }
@@ -416,6 +416,10 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     return 0;
 }
 
+// ---- scalar hirschbergH_ng over a list of items (spdp_h_scalar.hip) ----------------------------
+struct HUdhOut;
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags);
+
 // ---- hirschbergH1_wip over a list of items ------------------------------------------------------
 struct HUdhOut {
     std::vector<int32_t> scores, cpos, ranges;  // in item order; cpos stride = stride ints per item
@@ -478,6 +482,68 @@ static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
     return 0;
 }
 
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags)
+{
+    SpdpContext* ctx = st.ctx;
+    DevPool& pool = ctx->pool[HU_POOL];
+    const int nr = (int) items.size();
+    out = HUdhOut();
+    flags.assign(nr, 0);
+    if (!nr) return 0;
+    if (!st.scalar_ok) { ctx->err = "the scalar engine needs SpdpScoringH.intpen / t53 and SpdpProblemH.dinc"; return -1; }
+    int max_im = 1;
+    for (const HItem& it : items) max_im = std::max(max_im, it.n_im);
+    out.stride = (max_im + 1) * 10;
+    std::vector<DevProblemH> h_probs(nr);
+    int64_t work_int = 0, imd_int = 0;
+    for (int i = 0; i < nr; ++i) {
+        DevProblemH& d = h_probs[i];
+        fill_desc(st, items[i], d);
+        d.bnd_off = work_int;
+        work_int += 6ll * (2 * (int64_t) d.width + 8);
+        d.imd_off = imd_int;
+        imd_int += (int64_t) d.n_im * 8 * d.width;
+        out.cells += d.cells;
+    }
+    void* d_probs = pool.get(HU_PROBS, nr * sizeof(DevProblemH));
+    void* d_work = pool.get(HU_BND, (size_t) work_int * sizeof(int));
+    void* d_imd = pool.get(HU_IMD, (size_t) std::max<int64_t>(imd_int, 1) * sizeof(int));
+    void* d_res = pool.get(HU_RES, nr * sizeof(DevResultH));
+    void* d_cpos = pool.get(HU_CPOS, (size_t) nr * out.stride * sizeof(int));
+    void* d_ranges = pool.get(HU_RANGES, (size_t) nr * 4 * sizeof(int));
+    void* d_scores = pool.get(HU_SCORES, (size_t) nr * sizeof(int));
+    if (!d_probs || !d_work || !d_imd || !d_res || !d_cpos || !d_ranges || !d_scores) {
+        ctx->err = "device allocation failed (scalar aa x genome linear-space run)";
+        return -1;
+    }
+    HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), nr * sizeof(DevProblemH), hipMemcpyHostToDevice, ctx->stream));
+    HScalarArgs A;
+    memset(&A, 0, sizeof A);
+    A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
+    A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
+    A.intpen = (const int16_t*) st.d_intpen; A.intpen_len = st.sc.intpen_len;
+    A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
+    A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
+    memcpy(A.t53, st.sc.t53, sizeof A.t53);
+    spdp_genetic_code_tables(A.mid, A.tron_of);
+    A.work = (int*) d_work; A.res = (DevResultH*) d_res;
+    A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
+    A.cpos_stride = out.stride;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    out.scores.resize(nr); out.cpos.resize((size_t) nr * out.stride); out.ranges.resize((size_t) nr * 4);
+    std::vector<DevResultH> res(nr);
+    HIPCHK(hipMemcpyAsync(out.scores.data(), d_scores, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out.cpos.data(), d_cpos, (size_t) nr * out.stride * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out.ranges.data(), d_ranges, (size_t) nr * 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    for (int i = 0; i < nr; ++i) flags[i] = res[i].pad[0];
+    return 0;
+}
+
 // ---- the reference's dispatch (lspH_ng & co.) over a batch, in rounds ---------------------------
 struct HTop {
     int cls = 0;                                // 0 ok, 1 needs an engine that is not built, 2 bad input
@@ -501,10 +567,12 @@ static bool bad_range(const HItem& it, const SpdpProblemH& p)
            it.a_right < it.a_left || it.b_right < it.b_left || it.b_left < p.exin_left || it.b_right > p.exin_right;
 }
 
+static thread_local bool a0_mode = false;        // SpdpScoringH.scalar_engines of the running ladder
+
 static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok, HTop& t)
 {
     if (it.w.width < 0) return true;                         // NEVSEL, no records
-    if (it.a_right - it.a_left < 8) {                        // scalar forwardH_ng
+    if (a0_mode || it.a_right - it.a_left < 8) {             // -A0, or below 8 rows: scalar forwardH_ng
         if (!scalar_ok) { t.cls = 1; return false; }
         scl.push_back(it);
         return true;
@@ -523,10 +591,16 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
     if (it.w.up == it.w.lw) { t.cls = 1; return; }           // diagonalH_ng
     if (std::abs(n - m) < 16 || m == 1 || n <= 3) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
     const float coef_B = 2.f, coef_C = 12.f;                 // sizeof(short); (Noll + 1) * sizeof(int)
-    const float cvol = float(m) * (n + 3 * m);
+    float cvol = float(m) * (n + 3 * m);                     // rhombic, simd >= 2
+    if (a0_mode) {                                           // hexagonal, simd < 2 (src/fwd2h1.cc:2166-2169)
+        const float k = it.w.lw - it.b_left + 3 * it.a_right;
+        const float q = it.b_right - 3 * it.a_left - it.w.up;
+        cvol = float(m) * n - (k * k + q * q) / 6;
+    }
     if (coef_B * cvol < sc.max_vmf_space) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
     bool recursive = false;
     int n_imd = 1;
+    it.imd_intvl = (m + 1) / 2;
     {
         const double z = 2. * m * coef_B / coef_C;
         const int imd1 = int(pow(z, 1. / 3) + 0.5) - 1;
@@ -535,19 +609,30 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
         else {
             const int imd3 = m / 16;
             n_imd = sc.ubh ? sc.ubh : std::min(imd1, imd3);
-            const int intvl = (m + n_imd) / (n_imd + 1);
+            const int intvl = it.imd_intvl = (m + n_imd) / (n_imd + 1);
             if (intvl * n_imd == m) --n_imd;
             if (n_imd == 0) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
         }
     }
-    if (sc.local) { t.cls = 1; return; }                     // local linear-space engine: not built
+    if (sc.local && !a0_mode) { t.cls = 1; return; }         // local linear-space `_wip` engine: not built
+    if (a0_mode && !scalar_ok) { t.cls = 1; return; }
     it.n_im = n_imd; it.recursive = recursive;
     udh.push_back(it);
+}
+
+// window of a slab: stripe31() under SIMD; under -A0 the diagonal bounds hirschbergH_ng recorded in the
+// cpos row (src/fwd2h1.cc:2068-2073, 2108-2128)
+static void slab_window(HItem& it, int sh, const int32_t* row)
+{
+    if (!a0_mode) { stripe31_rng(it.a_left, it.a_right, it.b_left, it.b_right, sh, &it.w); return; }
+    it.w.lw = row[8]; it.w.up = row[9];
+    it.w.width = it.w.up - it.w.lw + 7;
 }
 
 static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& hs)
 {
     const SpdpScoringH& sc = st.sc;
+    a0_mode = ladder && sc.scalar_engines != 0;
     tops.assign(st.n, HTop());
     std::vector<HItem> pending, fwd, udh, scl;
     for (int i = 0; i < st.n; ++i) {
@@ -573,13 +658,15 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)
         if (!udh.empty()) {
             HUdhOut uo;
-            if (run_udh(st, udh, uo)) return -1;
+            std::vector<int> uflags(udh.size(), 0);
+            if (a0_mode ? run_scalar_udh(st, udh, uo, uflags) : run_udh(st, udh, uo)) return -1;
             hs.udh_ms += uo.sweep_ms; hs.udh_cells += uo.cells;
             for (size_t u = 0; u < udh.size(); ++u) {
                 const HItem& it = udh[u];
                 HTop& t = tops[it.top];
                 if (t.cls) continue;
                 const int scr = uo.scores[u];
+                if (uflags[u]) { t.cls = 1; continue; }      // undefined in the reference
                 if (it.first) t.score = scr;
                 if (scr <= SPDP_NEVSEL) continue;
                 const int32_t* cpos = &uo.cpos[u * uo.stride];
@@ -597,9 +684,9 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
                     while (c < 9 && CP(0, c + 1) < END_ULK) { ++c; push_rec(t, CP(0, 0), CP(0, c)); }
                     HItem h1 = cur, h2 = cur;
                     h1.a_right = CP(0, 0); h1.b_right = CP(0, c);
-                    stripe31_rng(h1.a_left, h1.a_right, h1.b_left, h1.b_right, sc.sh, &h1.w);
+                    slab_window(h1, sc.sh, &CP(0, 0));
                     h2.a_left = CP(0, 0); h2.b_exgl = CP(0, 1); h2.b_left = CP(0, 2);
-                    stripe31_rng(h2.a_left, h2.a_right, h2.b_left, h2.b_right, sc.sh, &h2.w);
+                    slab_window(h2, sc.sh, &CP(1, 0));
                     pending.push_back(h1);
                     pending.push_back(h2);
                 } else {                                     // mimd_postwork, src/fwd2h1.cc:2045-2089
@@ -618,14 +705,14 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
                         if (cur.b_left < 0 || cur.b_left > cur.b_right) break;
                         while (c < 9 && CP(i, c + 1) < END_ULK) { ++c; push_rec(t, cur.a_left, CP(i, c)); }
                         ++c;
-                        stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
+                        slab_window(cur, sc.sh, &CP(i + 1, 0));
                         if (!queue_trcbk(cur, fwd, scl, st.scalar_ok, t)) break;
                         cur.a_right = cur.a_left;
                         cur.b_right = CP(i, c - 1);
                     }
                     if (!bad && !t.cls && ((i < 0 && CP(0, 0) != END_ULK) || CP(0, 2) != END_ULK)) {
                         cur.a_left = aleft; cur.b_left = bleft;
-                        stripe31_rng(cur.a_left, cur.a_right, cur.b_left, cur.b_right, sc.sh, &cur.w);
+                        slab_window(cur, sc.sh, &CP(0, 0));
                         queue_trcbk(cur, fwd, scl, st.scalar_ok, t);
                     }
                 }
@@ -783,7 +870,7 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
         HItem it = item_of(probs[i], i, sc->sh);
         const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
         if (!n || !m || it.w.width < 0) { rc = 1; continue; }
-        if (m < 8) {                                                  // scalar forwardH_ng (src/fwd2h1.cc:3297)
+        if (sc->scalar_engines || m < 8) {                            // scalar forwardH_ng (src/fwd2h1.cc:3297)
             if (!st.scalar_ok) { rc = 1; continue; }
             sitems.push_back(it); sidx.push_back(i);
             continue;
@@ -821,6 +908,33 @@ int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpPr
         std::vector<SpdpSkl> rec(fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
         o.n_skl = (int) rec.size();
         o.skl = dup_skl(rec);
+    }
+    return 0;
+}
+
+int spdp_scalar_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
+                      int n_im, int imd_intvl, int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags)
+{
+    if (!ctx || !sc || !probs || n_probs < 0 || n_im < 1 || imd_intvl < 1 || !scores || !cpos || !ranges || !flags) return -1;
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    std::vector<HItem> items;
+    for (int i = 0; i < n_probs; ++i) {
+        HItem it = item_of(probs[i], i, sc->sh);
+        it.n_im = n_im; it.imd_intvl = imd_intvl;
+        if (it.w.width < 0 || it.a_left + (int64_t) n_im * imd_intvl > it.a_right + imd_intvl) {
+            ctx->err = "hirschbergH_ng: intermediate rows beyond the query range"; return -1;
+        }
+        items.push_back(it);
+    }
+    HUdhOut uo;
+    std::vector<int> fl;
+    if (run_scalar_udh(st, items, uo, fl)) return -1;
+    for (int i = 0; i < n_probs; ++i) {
+        scores[i] = uo.scores[i];
+        flags[i] = fl[i];
+        memcpy(cpos + (size_t) i * (n_im + 1) * 10, &uo.cpos[(size_t) i * uo.stride], (size_t) (n_im + 1) * 10 * sizeof(int32_t));
+        memcpy(ranges + 4 * i, &uo.ranges[4 * i], 4 * sizeof(int32_t));
     }
     return 0;
 }

@@ -49,6 +49,7 @@ struct DevProblemH {
     int32_t col_len;
     int32_t n_im;                  // linear-space engine: number of intermediate rows
     int32_t a_len, b_len;          // parent sequence lengths (scalar engine: positions beyond read as padding)
+    int32_t imd_intvl, pad0;       // scalar linear-space engine: rows between intermediates (Aln2h1::imd_intvl)
     int64_t a_off;
     int64_t col_off;               // into cols / aux
     int64_t bnd_off;               // into bnd (entries)

@@ -72,9 +72,16 @@ struct HScalarArgs {
     int2*              skl;        // per problem skl_cap records
     int*               n_skl;      // records; -1 skl overflow, -3 Vmf capacity exceeded
     int                skl_cap;
+    // hirschbergH_ng only
+    int*               imd;        // per problem n_im * 8 * width ints at DevProblemH::imd_off
+    int*               cpos;       // per problem cpos_stride ints
+    int*               ranges;     // per problem 4 ints
+    int*               scores;
+    int                cpos_stride;
 };
 
 extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t s);
+extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_udh(const HUdhArgs* a, int spj, int pen_cap, hipStream_t s);
 extern "C" hipError_t spdh_launch_cpos(const HCposArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t s);

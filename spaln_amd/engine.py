@@ -24,7 +24,7 @@ EXPORTS = [
     "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_scalar_udh", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
-    "spdp_scalar_forward_h",
+    "spdp_scalar_forward_h", "spdp_scalar_udh_h",
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
 ]
 
@@ -66,6 +66,8 @@ def load_library() -> C.CDLL:
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_udh_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_scalar_udh_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_scalar_forward_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.spdp_batch_upload_h.restype = C.c_void_p
     lib.spdp_batch_upload_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -256,6 +258,18 @@ class Engine:
             res.append((int(arr[i].score), skl))
         self.lib.spdp_free_alignments(arr, n)
         return res
+
+    def scalar_udh_h(self, sc, ps, n_im: int, imd_intvl: int):
+        """Aln2h1::hirschbergH_ng: (scores, cpos rows, written-back ranges, flags)"""
+        n = len(ps)
+        scores = np.zeros(n, dtype=np.int32)
+        cpos = np.zeros((n, n_im + 1, 10), dtype=np.int32)
+        ranges = np.zeros((n, 4), dtype=np.int32)
+        flags = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.spdp_scalar_udh_h(self.ctx, C.byref(sc), ps.array(), n, n_im, imd_intvl,
+                                               scores.ctypes.data, cpos.ctypes.data, ranges.ctypes.data,
+                                               flags.ctypes.data), "spdp_scalar_udh_h")
+        return scores, cpos, ranges, flags
 
     def align_h(self, sc, ps):
         """alignH_ng (-Q0): [flags, n, corners...] as rows of (m, n) after the header row."""

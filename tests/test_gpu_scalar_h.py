@@ -113,3 +113,94 @@ def test_small_subranges_against_oracle(eng):
             bad.append((i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, score, ws,
                         skl.ravel().tolist()[:12], (wskl or [])[:12]))
     assert n_ok >= 100 and not bad, bad[:4]
+
+
+# ---- -A0 mode: hirschbergH_ng and the scalar ladder ---------------------------------------------
+def test_align_a0_goldens(eng):
+    """alignH_ng / HomScoreH_ng with SpdpScoringH.scalar_engines = 1 against the reference's -A0 output.
+    (One GPU thread per problem: the 400 / 450 aa fixtures take minutes and stay with the CPU suite.)"""
+    for local in (False, True):
+        cases = [(_name(f), spdg.load(f)) for f in H_FILES if (_name(f) == "h1_local") == local]
+        cases = [(n, fx) for n, fx in cases if fx["prm"]["a_right"] - fx["prm"]["a_left"] <= 330]
+        ref = max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size)
+        key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
+        for vmf, ubh, sh in sorted({key(fx) for _, fx in cases}):
+            sub = [(n, fx) for n, fx in cases if key(fx) == (vmf, ubh, sh)]
+            sc = spdg.scoring_h(ref, scalar_engines=1, max_vmf_space=vmf, ubh=ubh, sh=sh)
+            ps = abi.ProblemSetH()
+            for _, fx in sub:
+                spdg.problem_h(fx, ps)
+            res = eng.align_h(sc, ps)
+            hom = eng.homscore_h(sc, ps)
+            bad = []
+            for (name, fx), (score, skl, flag), hs in zip(sub, res, hom):
+                if (flag != 0 or score != int(fx["aln_scr_A0"][0]) or skl.ravel().tolist() != fx["aln_skl_A0"].tolist()
+                        or int(hs) != int(fx["hom_scr_A0"][0])):
+                    bad.append((name, flag, score, int(fx["aln_scr_A0"][0]), skl.ravel().tolist()[:14],
+                                fx["aln_skl_A0"].tolist()[:14]))
+            assert not bad, bad[:3]
+
+
+def test_hirschberg_h_ng_against_oracle(eng):
+    """cpos rows (incl. the diagonal bounds), ranges and score of spdp_scalar_udh_h on sub-ranges"""
+    from oracle import oracle
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 93)
+    sc = spdg.scoring_h(fx, scalar_engines=1)
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    for n_im in (1, 3):
+        ps = abi.ProblemSetH()
+        m = 120 + 10 * n_im
+        intvl = (m + n_im) // (n_im + 1)
+        for i in range(16):
+            al = int(rng.integers(0, q["a_right"] - m))
+            bl = int(rng.integers(1, 800))
+            br = int(rng.integers(max(bl + 3 * m + 300, q["b_right"] - 2500), q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 2 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, al + m, bl, br, exg, exin=(q["b_left"], q["b_right"]), dinc=dinc)
+        scores, cpos, ranges, flags = eng.scalar_udh_h(sc, ps, n_im, intvl)
+        bad = []
+        for i, p in enumerate(ps.items):
+            ws, wcpos, wrng, wflag = oracle.scalar_udh_h(sc, p, n_im, intvl)
+            ok = int(flags[i]) == wflag
+            if wflag == 0:
+                ok = ok and int(scores[i]) == ws and ranges[i].tolist() == wrng.tolist() and cpos[i].tolist() == wcpos.tolist()
+            if not ok:
+                bad.append((n_im, i, int(scores[i]), ws, int(flags[i]), wflag, ranges[i].tolist(), wrng.tolist(),
+                            cpos[i][:2].tolist(), wcpos[:2].tolist()))
+        assert not bad, bad[:3]
+
+
+def test_a0_ladder_against_oracle(eng):
+    """alignH_ng under -A0 pushed into the linear-space branches (small MaxVmfSpace) on sub-ranges"""
+    from oracle import host_logic_h as hh
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_auto_udh.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 94)
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    for vmf, ubh in ((200000, 0), (60000, 3), (20000, 0)):
+        sc = spdg.scoring_h(fx, scalar_engines=1, max_vmf_space=vmf, ubh=ubh)
+        ps = abi.ProblemSetH()
+        for i in range(10):
+            al = int(rng.integers(0, 120))
+            ar = int(rng.integers(al + 100, min(al + 200, q["a_right"]) + 1))
+            bl = int(rng.integers(1, 500))
+            br = int(rng.integers(q["b_right"] - 1500, q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 2 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, ar, bl, br, exg, exin=(q["b_left"], q["b_right"]), dinc=dinc)
+        res = eng.align_h(sc, ps)
+        bad, n_ok = [], 0
+        for i, (p, (score, skl, flag)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = hh.align_h(sc, p, simd=0)
+            except (hh.ReferenceUndefined, hh.NotRestated):
+                assert flag == 1, i
+                continue
+            n_ok += 1
+            if flag != 0 or score != ws or skl.ravel().tolist() != (wskl or []):
+                bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, score, ws,
+                            skl.ravel().tolist()[:12], (wskl or [])[:12]))
+        assert n_ok >= 7 and not bad, bad[:3]

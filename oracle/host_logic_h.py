@@ -51,6 +51,8 @@ class ReferenceUndefined(Exception):
 def homscore_h(sc: abi.ScoringH, p: abi.ProblemH, simd: int = 2) -> int:
     """simd = algmode.alg & 3: 0 runs the scalar forwardH_ng (as does any problem below 8 rows)"""
     if simd == 0 or p.a_right - p.a_left < 8:
+        if not sc.intpen or not p.dinc:
+            raise NotRestated("forwardH_ng without its inputs (intpen / t53 / dinc)")
         return oracle.scalar_forward_h(sc, p, oracle.stripe31(p, sc.sh), traceback=False)[0]
     s, _, _ = oracle.wip_forward_h(sc, p, oracle.stripe31(p, sc.sh))
     return s
@@ -60,6 +62,8 @@ def trcbk_h(sc, p, w, rec, simd=2):
     if w.width < 0:
         return abi.NEVSEL
     if simd == 0 or p.a_right - p.a_left < 8:             # forwardH_ng + Vmf::traceback
+        if not sc.intpen or not p.dinc:
+            raise NotRestated("forwardH_ng without its inputs (intpen / t53 / dinc)")
         s, skl = oracle.scalar_forward_h(sc, p, w)
         rec.extend((int(m), int(n)) for m, n in skl)
         return s

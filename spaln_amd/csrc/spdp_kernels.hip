@@ -25,6 +25,7 @@
 // traceback codes.
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "spdp_dev.h"
 #include "spdp_internal.h"
@@ -116,6 +117,14 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
         }
     }
     __syncthreads();
+    // select-chain form of pen(hil): thresholds and penalties in scalar registers, unused steps never fire
+    int ql[7], qp[7];
+    #pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const bool on = (NQM == NQ_CHAIN) && j + 1 < nquant;
+        ql[j] = on ? sc->qm_len[j] : 0x7fffffff;
+        qp[j] = on ? sc->qm_pen[j + 1] : 0;
+    }
 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;                    // DPP row = stripe slot of the pass
@@ -375,8 +384,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                             int pen = p0;                                                                    \
                             if constexpr (NQM == NQ_TABLE) pen = s_pen[min(hil, pen_cap)];                   \
                             if constexpr (NQM == NQ_CHAIN) {                                                 \
-                                for (int jq = 1; jq < nquant; ++jq)                                          \
-                                    pen = (hil > sc->qm_len[jq - 1]) ? sc->qm_pen[jq] : pen;                 \
+                                _Pragma("unroll")                                                            \
+                                for (int jq = 0; jq < 7; ++jq) pen = (hil > ql[jq]) ? qp[jq] : pen;          \
                             }                                                                                \
                             int x = sadd16(hv2, s3) + pen;                                                   \
                             x = (hil > llmt) ? x : SPDP_NEV16;                                               \
@@ -578,7 +587,8 @@ extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int 
     SweepArgs A = *args;
     dim3 grd(grid);
     const int blk = (wpb == 16 && !local) ? 16 : 4;
-    const int nqm = nquant <= 1 ? NQ_FLAT : (pen_cap < SPDP_PEN_TAB ? NQ_TABLE : NQ_CHAIN);
+    int nqm = nquant <= 1 ? NQ_FLAT : (pen_cap < SPDP_PEN_TAB ? NQ_TABLE : NQ_CHAIN);
+    if (const char* e = getenv("SPDP_NQM")) { if (nqm != NQ_FLAT && atoi(e) == NQ_CHAIN) nqm = NQ_CHAIN; }
     switch (flavour * 2 + (local ? 1 : 0)) {
     case 0: launch_nq<FL_SCORE, false>(nqm, grd, blk, stream, A); break;
     case 1: launch_nq<FL_SCORE, true>(nqm, grd, blk, stream, A); break;

@@ -144,7 +144,9 @@ int spdp_scalar_udh(SpdpContext* ctx, const SpdpScoring* sc,
                     int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags);
 
 /* ---- Aln2 surface, batched --------------------------------------------- */
-/* HomScoreS_ng for -A2/-A3 (simd > 1): stripe() then scoreonlyS1_wip. */
+/* HomScoreS_ng: stripe() then scoreonlyS1_wip (-A2 / -A3); scorealoneS_ng under -A0
+ * (SpdpScoring.scalar_engines) and for query ranges below 4 rows (src/fwd2s1.cc:2705), which needs the
+ * exact-model inputs -- without them such problems come back SPDP_NEVSEL and the call returns 1. */
 int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc,
                     const SpdpProblem* probs, int n_probs, int32_t* scores);
 
@@ -153,6 +155,14 @@ int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc,
  * + per-slab traceback -> stdskl -> trimskl. */
 int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc,
                  const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+
+/* alignS_ng(seqs, pwd, gsi, ori = 3) with seeding off (src/fwd2s1.cc:2746-2760): infer_orientation
+ * (:2718-2730) = HomScoreS_ng on the query as given (fwd[i]) and on its reverse complement against the
+ * opposite genomic strand (rev[i]: comrev(a) + antiseq(b), with that strand's own signals), the reverse
+ * wins only with a strictly higher score; then one alignment.  orient[i] = 0 / 1 says which problem
+ * out[i] refers to. */
+int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* fwd, const SpdpProblem* rev,
+                      int n_probs, SpdpAlignment* out, int32_t* orient);
 void spdp_free_alignments(SpdpAlignment* out, int n);
 
 /* ---- rescoring: skl_rngS_ng (src/fwd2s1.cc:446) ---------------------------------------------- */

@@ -243,6 +243,22 @@ def trim_skl(s, p):
     return s
 
 
+def homscore_s(sc, p, simd=2):
+    """HomScoreS_ng (src/fwd2s1.cc:2696-2716): scalar below 4 rows or under -A0, else scoreonlyS1_wip"""
+    w = oracle.stripe(p, sc.sh)
+    if simd == 0 or p.a_right - p.a_left < 4:
+        if not sc.intpen or not p.cano5:
+            raise NeedsScalarEngine()
+        return oracle.scalar_scorealone(sc, p, w)
+    return oracle.wip_scoreonly(sc, p, w)
+
+
+def align_s_ori3(sc, p_fwd, p_rev, simd=2):
+    """alignS_ng(ori = 3) with seeding off: infer_orientation (src/fwd2s1.cc:2718-2730) + one alignment"""
+    ori = 1 if homscore_s(sc, p_rev, simd) > homscore_s(sc, p_fwd, simd) else 0
+    return align_s(sc, p_rev if ori else p_fwd, simd), ori
+
+
 def align_s(sc, p, simd=2):
     """alignS_ng(ori=1) with seeding off.  Returns (score, skl) with skl = [flags, n, m1, n1, ...] or None.
     simd = algmode.alg & 3: 0 runs the scalar engines (forwardS_ng, hirschbergS_ng) throughout."""

@@ -527,12 +527,47 @@ int spdp_wip_scoreonly(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProble
     return 0;
 }
 
+// HomScoreS_ng on an uploaded store (src/fwd2s1.cc:2696-2716): scoreonlyS1_wip on the stripe() band for
+// simd > 1; scorealoneS_ng when simd == 0 or the query range has fewer than 4 rows.  Returns 1 when a
+// problem needs the scalar engine and its inputs are missing (score NEVSEL).
+static int homscore_on_store(SpdpContext* ctx, const DevStore& st, const SpdpProblem* probs, int n_probs, int32_t* scores)
+{
+    const SpdpScoring* sc = &st.sc;
+    std::vector<RunItem> vec, sca;
+    std::vector<int> vi, si;
+    int rc = 0;
+    for (int i = 0; i < n_probs; ++i) {
+        scores[i] = SPDP_NEVSEL;
+        RunItem it = spdp_item_of(probs[i], i, sc->sh);
+        const int m = it.a_right - it.a_left;
+        if (it.w.width < 3) { rc = 1; continue; }
+        if (sc->scalar_engines || m < 4) {
+            if (!st.has_exact) { rc = 1; continue; }
+            sca.push_back(it); si.push_back(i);
+        } else { vec.push_back(it); vi.push_back(i); }
+    }
+    std::vector<DevResult> r;
+    if (!vec.empty()) {
+        DevRun run;
+        if (run.build(&st, vec, 0) || run.launch() || run.sync() || run.fetch_results(r)) return -1;
+        for (size_t k = 0; k < vec.size(); ++k) scores[vi[k]] = r[k].score;
+    }
+    if (!sca.empty()) {
+        DevRun run;
+        if (run.build(&st, sca, 4) || run.launch() || run.sync() || run.fetch_results(r)) return -1;
+        for (size_t k = 0; k < sca.size(); ++k) scores[si[k]] = r[k].score;
+    }
+    return rc;
+}
+
 int spdp_homscore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,
                     int n_probs, int32_t* scores)
-{   // HomScoreS_ng for simd > 1: stripe(alprm.sh) + scoreonlyS1_wip, src/fwd2s1.cc:2696-2712;
-    // simd == 0: scorealoneS_ng
-    if (sc && sc->scalar_engines) return spdp_scalar_scorealone(ctx, sc, probs, n_probs, scores);
-    return spdp_wip_scoreonly(ctx, sc, probs, n_probs, scores);
+{
+    if (!ctx || !sc || !probs || !scores) return -1;
+    if (n_probs <= 0) return 0;
+    DevStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    return homscore_on_store(ctx, st, probs, n_probs, scores);
 }
 
 int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs,

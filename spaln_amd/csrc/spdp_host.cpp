@@ -530,3 +530,25 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
     return align_on_store(ctx, &st, probs, n_probs, out, nullptr, nullptr);
 }
+
+// alignS_ng(seqs, pwd, gsi, ori = 3) with seeding off (src/fwd2s1.cc:2746-2760): infer_orientation
+// (:2718-2730) scores the query as given and its reverse complement against the opposite strand with
+// HomScoreS_ng, keeps the reverse only if it scores strictly higher, then aligns once.
+int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* fwd, const SpdpProblem* rev,
+                      int n_probs, SpdpAlignment* out, int32_t* orient)
+{
+    if (!ctx || !sc || !fwd || !rev || !out || !orient) return -1;
+    if (n_probs <= 0) return 0;
+    std::vector<int32_t> s1(n_probs), s2(n_probs);
+    const int r1 = spdp_homscore_s(ctx, sc, fwd, n_probs, s1.data());
+    if (r1 < 0) return -1;
+    const int r2 = spdp_homscore_s(ctx, sc, rev, n_probs, s2.data());
+    if (r2 < 0) return -1;
+    std::vector<SpdpProblem> pick(n_probs);
+    for (int i = 0; i < n_probs; ++i) {
+        orient[i] = s2[i] > s1[i] ? 1 : 0;
+        pick[i] = orient[i] ? rev[i] : fwd[i];
+    }
+    const int r3 = spdp_align_s(ctx, sc, pick.data(), n_probs, out);
+    return r3 < 0 ? -1 : (r1 | r2 | r3);
+}

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
 EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",
     "spdp_cells", "spdp_wip_scoreonly", "spdp_wip_forward", "spdp_wip_udh", "spdp_homscore_s",
-    "spdp_align_s", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_scalar_udh", "spdp_batch_upload", "spdp_batch_free",
+    "spdp_align_s", "spdp_align_s_ori3", "spdp_free_alignments", "spdp_skl_rng_s", "spdp_skl_rng_h", "spdp_free_rescored", "spdp_scalar_forward", "spdp_scalar_scorealone", "spdp_scalar_udh", "spdp_batch_upload", "spdp_batch_free",
     "spdp_batch_cells", "spdp_batch_homscore", "spdp_batch_align", "spdp_batch_stats",
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
     "spdp_scalar_forward_h", "spdp_scalar_udh_h",
@@ -52,6 +52,7 @@ def load_library() -> C.CDLL:
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_align_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_align_s_ori3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.spdp_scalar_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_wip_udh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
@@ -114,11 +115,28 @@ class Engine:
                                                 out.ctypes.data), "spdp_wip_scoreonly")
         return out
 
-    def homscore_s(self, sc, ps) -> np.ndarray:
+    def homscore_s(self, sc, ps, allow_partial=False) -> np.ndarray:
         out = np.zeros(len(ps), dtype=np.int32)
-        self._check(self.lib.spdp_homscore_s(self.ctx, C.byref(sc), ps.array(), len(ps),
-                                             out.ctypes.data), "spdp_homscore_s")
+        rc = self.lib.spdp_homscore_s(self.ctx, C.byref(sc), ps.array(), len(ps), out.ctypes.data)
+        if not (allow_partial and rc == 1):
+            self._check(rc, "spdp_homscore_s")
         return out
+
+    def align_s_ori3(self, sc, ps_fwd, ps_rev):
+        """alignS_ng(ori = 3), -Q0: ([(score, skl)], orientation 0 / 1 per query)"""
+        n = len(ps_fwd)
+        assert len(ps_rev) == n
+        arr = (abi.Alignment * n)()
+        orient = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.spdp_align_s_ori3(self.ctx, C.byref(sc), ps_fwd.array(), ps_rev.array(), n, arr,
+                                               orient.ctypes.data), "spdp_align_s_ori3")
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res, orient
 
     def _alignments(self, fn, sc, ps, what, allow_partial=False):
         n = len(ps)

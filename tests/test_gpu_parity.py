@@ -213,3 +213,44 @@ def test_align_then_rescore_batch(eng):
         wh, wfst, wrecs = host_logic.skl_rng_s(sc, p, wskl, codonk1=fxs[0]["prm"]["codonk1"],
                                                minl=fxs[0]["prm"]["minl"], jneibr=int(fs[6]), lsg=int(fs[7]))
         assert score == wh and fst == wfst and ex.tolist() == wrecs
+
+
+def test_homscore_s_ng_goldens(eng):
+    from spaln_amd import abi
+    """spdp_homscore_s = HomScoreS_ng (-A2 / -A3), every fixture in one batch per intron model: the vector
+    engine, and scorealoneS_ng for the query ranges below 4 rows"""
+    from tests.conftest import golden_files
+    for alg in (2, 3):
+        cases = [spdg.load(f) for f in golden_files("s1_") if "local" not in f]
+        ref = max(cases, key=lambda fx: fx["intpen"].size)
+        for sh in sorted({fx["prm"]["sh"] for fx in cases}):
+            sub = [fx for fx in cases if fx["prm"]["sh"] == sh]
+            sc = spdg.scoring(ref, nquant=1 if alg == 3 else None, sh=sh)
+            ps = abi.ProblemSet()
+            for fx in sub:
+                spdg.problem(fx, ps)
+            got = eng.homscore_s(sc, ps)
+            assert got.tolist() == [int(fx[f"hom_scr_A{alg}"][0]) for fx in sub]
+
+
+def test_align_s_ori3_against_oracle(eng):
+    from spaln_amd import abi
+    """alignS_ng(ori = 3), -Q0: infer_orientation + one alignment; the 'reverse' problems here are other
+    fixtures' windows, so that either orientation wins for some queries"""
+    from oracle import host_logic
+    from tests.conftest import golden_files
+    names = ["s1_basic", "s1_single_exon", "s1_divergent", "s1_random", "s1_tiny_m3", "s1_cut_left"]
+    fxs = [spdg.load([f for f in golden_files("s1_") if f.endswith(n + ".spdg")][0]) for n in names]
+    sc = spdg.scoring(max(fxs, key=lambda fx: fx["intpen"].size))
+    fwd, rev = abi.ProblemSet(), abi.ProblemSet()
+    for i, fx in enumerate(fxs):
+        spdg.problem(fx, fwd)
+        spdg.problem(fxs[(i + 1) % len(fxs)] if i % 2 else fxs[i], rev)      # odd: another locus, even: identical
+    res, orient = eng.align_s_ori3(sc, fwd, rev)
+    picked = []
+    for i, (pf, pr) in enumerate(zip(fwd.items, rev.items)):
+        (ws, wskl), wori = host_logic.align_s_ori3(sc, pf, pr)
+        assert int(orient[i]) == wori
+        assert res[i][0] == ws and res[i][1].ravel().tolist() == (wskl or [])
+        picked.append(wori)
+    assert picked[0] == 0 and picked[2] == 0                   # ties keep the query as given

@@ -43,3 +43,17 @@ def test_skl_rng_s_vs_reference(fx, alg):
     assert h == int(fx[f"rng_scr_A{alg}"][0])
     assert fst == [int(x) for x in fs[:5]]
     assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()
+
+
+@pytest.mark.parametrize("alg", [0, 2, 3])
+def test_homscore_s_ng_goldens(alg):
+    """HomScoreS_ng as the reference returns it under -A0 / -A2 / -A3, incl. the scalar branch below 4 rows"""
+    from tests.conftest import golden_files
+    n = 0
+    for f in golden_files("s1_"):
+        fx = spdg.load(f)
+        sc = spdg.scoring(fx, nquant=1 if alg == 3 else None)
+        _, p = spdg.problem(fx)
+        assert host_logic.homscore_s(sc, p, simd=alg) == int(fx[f"hom_scr_A{alg}"][0]), f
+        n += 1
+    assert n >= 30

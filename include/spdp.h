@@ -200,6 +200,26 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
                    const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 void spdp_free_rescored(SpdpRescored* out, int n);
 
+/* ---- submit / wait ------------------------------------------------------ */
+/* Asynchronous form of the batched calls: a worker thread runs the call and owns `ctx` until
+ * spdp_wait() returns (one ticket in flight per context; inputs and `out` must stay valid until
+ * then).  spdp_wait returns what the synchronous call would have returned and frees the ticket;
+ * spdp_poll says whether it would return at once.  Use several contexts -- one per GPU, or more than
+ * one per GPU -- to keep batches in flight from a single host thread. */
+typedef struct SpdpTicket SpdpTicket;
+struct SpdpScoringH;
+struct SpdpProblemH;
+SpdpTicket* spdp_submit_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
+                                SpdpAlignment* out);
+SpdpTicket* spdp_submit_homscore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs,
+                                   int32_t* scores);
+SpdpTicket* spdp_submit_align_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs,
+                                int n_probs, SpdpAlignment* out);
+SpdpTicket* spdp_submit_homscore_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs,
+                                   int n_probs, int32_t* scores);
+int spdp_poll(const SpdpTicket* t);
+int spdp_wait(SpdpTicket* t);
+
 /* ---- resident batches (benchmarking / pipelines) ------------------------ */
 /* Uploads a batch once; the run calls below then work on HBM-resident inputs
  * (timed region excludes PCIe).  Returns NULL on failure. */

@@ -26,6 +26,8 @@ EXPORTS = [
     "spdp_stripe31", "spdp_cells_h", "spdp_wip_forward_h", "spdp_wip_udh_h", "spdp_homscore_h", "spdp_align_h",
     "spdp_scalar_forward_h", "spdp_scalar_udh_h",
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
+    "spdp_submit_align_s", "spdp_submit_homscore_s", "spdp_submit_align_h", "spdp_submit_homscore_h",
+    "spdp_poll", "spdp_wait",
 ]
 
 
@@ -76,6 +78,11 @@ def load_library() -> C.CDLL:
     lib.spdp_batch_cells_h.restype = C.c_int64
     lib.spdp_batch_cells_h.argtypes = [C.c_void_p]
     lib.spdp_batch_align_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in ("spdp_submit_align_s", "spdp_submit_homscore_s", "spdp_submit_align_h", "spdp_submit_homscore_h"):
+        getattr(lib, f).restype = C.c_void_p
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_poll.argtypes = [C.c_void_p]
+    lib.spdp_wait.argtypes = [C.c_void_p]
     return lib
 
 
@@ -177,6 +184,31 @@ class Engine:
                                              scores.ctypes.data, cpos.ctypes.data, ranges.ctypes.data,
                                              flags.ctypes.data), "spdp_scalar_udh")
         return scores, cpos, ranges, flags
+
+    def submit_align_s(self, sc, ps):
+        """spdp_submit_align_s: returns a callable that waits and yields [(score, skl)]"""
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        parr = ps.array()
+        t = self.lib.spdp_submit_align_s(self.ctx, C.byref(sc), parr, n, arr)
+        if not t:
+            raise RuntimeError("spdp_submit_align_s failed")
+
+        def wait():
+            rc = self.lib.spdp_wait(t)
+            wait.done = True                     # the ticket is gone
+            self._check(rc, "spdp_submit_align_s")
+            res = []
+            for i in range(n):
+                k = arr[i].n_skl
+                skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+                res.append((int(arr[i].score), skl))
+            self.lib.spdp_free_alignments(arr, n)
+            return res
+        wait.poll = lambda: True if wait.done else bool(self.lib.spdp_poll(t))
+        wait.done = False
+        wait.keep = (parr, ps, sc)               # inputs stay alive until waited
+        return wait
 
     def align_s(self, sc, ps, allow_partial=False):
         """alignS_ng (ori = 1, -Q0).  allow_partial: accept return value 1 (some problem needed the

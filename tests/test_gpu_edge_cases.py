@@ -119,3 +119,26 @@ def test_mixed_cdna_batch_sizes(eng):
     for i, f in enumerate(files):
         ps, _ = spdg.problem(spdg.load(f))
         assert int(eng.wip_scoreonly(sc, ps)[0]) == int(res_all[i])
+
+
+def test_submit_wait_two_contexts(eng):
+    """spdp_submit_align_s / spdp_wait: two contexts on one GPU with batches in flight at the same time,
+    same results as the synchronous call"""
+    from spaln_amd import engine, synth
+    sc = defaults.scoring()
+    sets = []
+    for seed in (3, 4):
+        ps = abi.ProblemSet()
+        for w, q, s5, s3, _ in synth.make_batch(24, seed=seed, n_exons=4, mrna_len=600, flank=300, intron_hi=1500):
+            ps.add(q, w, s5, s3)
+        sets.append(ps)
+    want = [eng.align_s(sc, ps) for ps in sets]
+    e2 = engine.Engine(0)
+    try:
+        waits = [eng.submit_align_s(sc, sets[0]), e2.submit_align_s(sc, sets[1])]
+        got = [w() for w in waits]
+        assert all(w.poll() for w in waits)
+    finally:
+        e2.close()
+    for g, w in zip(got, want):
+        assert [(s, k.tolist()) for s, k in g] == [(s, k.tolist()) for s, k in w]

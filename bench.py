@@ -147,16 +147,7 @@ def _cpu_align_h_one(item):
 def main_c3(args):
     """BASELINE configs[2] ("C3"), scaled to one GPU's memory: protein queries (400 aa) against their
     planted 6-exon loci +-1 kb, Fwd2h1 `_wip` path: alignH_ng = forwardH1_wip + traceback + stdskl3."""
-    import torch
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-    torch.cuda.set_device(local_rank)
+    torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
     from spaln_amd import abi, defaults, engine, synth
     eng = engine.Engine(local_rank)
     sc = defaults.scoring_h()
@@ -185,10 +176,10 @@ def main_c3(args):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(cells)], device="cuda", dtype=torch.float64)
+        c = torch.tensor([float(cells)], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = float(c.item())
     else:
@@ -244,6 +235,28 @@ def main_c3(args):
         dist.destroy_process_group()
 
 
+def _dist_setup():
+    """(torch, dist or None, rank, world, local device index, device for collectives).
+    BENCH_SHARE_GPU=1 is a test hook: all ranks use GPU 0 and talk over gloo, so that the multi-rank
+    path can be exercised on a one-GPU box."""
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    dist = None
+    coll_dev = "cuda"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if (torch.cuda.is_available() and not share) else "gloo"
+        dist.init_process_group(backend=backend)
+        coll_dev = "cuda" if backend == "nccl" else "cpu"
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
+    return torch, dist, rank, world, dev, coll_dev
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,16 +275,7 @@ def main():
     if args.workload == "c3":
         return main_c3(args)
 
-    import torch
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-    torch.cuda.set_device(local_rank)
+    torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
 
     from spaln_amd import abi, defaults, engine, synth
     eng = engine.Engine(local_rank)
@@ -305,10 +309,10 @@ def main():
     dt = time.perf_counter() - t0
     cells = step_cells                       # DP cells of all engine calls of one step
     if dist is not None:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(cells)], device="cuda", dtype=torch.float64)
+        c = torch.tensor([float(cells)], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = float(c.item())
     else:

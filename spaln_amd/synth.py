@@ -162,6 +162,30 @@ def make_batch(n_queries: int, seed: int = SEED, *, n_exons: int = 8, mrna_len: 
     return out
 
 
+def make_est_batch(n_queries: int, seed: int = SEED, *, frag_len: int = 500, margin: int = 1000):
+    """C4-style batch: `frag_len`-nt fragments of C2-style transcripts with 1 % error, each against the
+    genomic span of its fragment +- `margin`.  Same tuple layout as make_batch (exons = None)."""
+    rng = np.random.default_rng(seed + 404)
+    out = []
+    for w, q, s5, s3, exons in make_batch(n_queries, seed=seed, sub=0.01, indel=0.001):
+        a0 = int(rng.integers(0, max(1, len(q) - frag_len)))
+        frag = q[a0:a0 + frag_len]
+        pos, lo, hi = 0, None, None
+        for e0, e1 in exons:
+            L = e1 - e0
+            if lo is None and a0 < pos + L:
+                lo = e0 + (a0 - pos)
+            if a0 + frag_len <= pos + L:
+                hi = e0 + (a0 + frag_len - pos)
+                break
+            pos += L
+        lo = exons[0][0] if lo is None else lo
+        hi = exons[-1][1] if hi is None else hi
+        b0, b1 = max(0, lo - margin), min(len(w), hi + margin)
+        out.append((w[b0:b1], frag, s5[b0:b1 + 1], s3[b0:b1 + 1], None))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # protein x genome (BASELINE config C3): an ORF split into coding exons
 _CODON_AA = {}

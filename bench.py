@@ -28,9 +28,9 @@ sys.path.insert(0, ROOT)
 BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64.0 + 1.0}
 HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
-PMC_TRAFFIC_BYTES = int((70322106 + 207443561) * 1024)
+PMC_TRAFFIC_BYTES = int((70312554 + 207449824) * 1024)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((37826839 + 146710905) * 1024)
+PMC_TRAFFIC_BYTES_H = int((38104022 + 146635754) * 1024)
 
 
 def _cpu_align_one(item):

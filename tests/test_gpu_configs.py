@@ -94,3 +94,29 @@ def test_c5_long_cdna():
     assert hits >= 40                                     # 48 exon boundaries planted
     ws, wskl = _oracle_align((w, q, s5, s3, kw))
     assert score == ws and skl.ravel().tolist() == wskl
+
+
+def test_c5_full_size_properties():
+    """C5 at BASELINE size -- one 50 kb cDNA with 25 exons against its ~190 kb locus, default parameters:
+    the recursive linear-space branch all the way down (16-wave blocks at the top levels).  Far beyond
+    what the CPU oracle finishes in test time, so size-independent properties: a monotone corner list
+    covering the whole query, every planted exon boundary among the corners, the same result twice."""
+    from spaln_amd import abi, defaults, engine, synth
+    rng = np.random.default_rng(synth.SEED + 55)
+    g = synth.make_gene(rng, n_exons=25, mrna_len=50000, flank=1000, intron_lo=1000, intron_hi=10000)
+    w, q = defaults.encode(g.window), defaults.encode(g.query)
+    s5, s3 = synth.splice_signals(g.window)
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    ps.add(q, w, s5, s3)
+    eng = engine.Engine(0)
+    (score, skl), = eng.align_s(sc, ps)
+    (score2, skl2), = eng.align_s(sc, ps)
+    eng.close()
+    c = _check_corners(skl, q, w)
+    assert c[0, 0] == 0 and c[-1, 0] == len(q)
+    cols = set(int(x) for x in c[:, 1])
+    hits = sum((e0 in cols) + (e1 in cols) for e0, e1 in g.exons)
+    assert hits == 50
+    assert score == score2 and skl.tolist() == skl2.tolist()
+    assert score > 150000                                  # ~4 per matched base at 2 % divergence

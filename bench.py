@@ -27,6 +27,11 @@ sys.path.insert(0, ROOT)
 # sweep streams one 8 B column record and reads + writes one 8 B {H,F} boundary entry
 BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64.0 + 1.0}
 HBM_PEAK_GBS = 8000.0
+# int32 VALU ceiling of one MI355X measured with tools/ubench/valu_rate.hip (profiles/r01_valu_ubench.txt):
+# 0.62 G wave-instructions/s per SIMD x 1024 SIMDs; VALU wave-instructions per DP cell from SQ_INSTS_VALU
+# (profiles/r01_sq_counters.txt): UDH sweep 59.6 / 64, forward sweep 69.6 / 64, protein sweep 151.5 / 64
+VALU_PEAK_WINST_S = 0.62e9 * 1024
+VALU_PER_CELL = {"udh": 1.9475e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3136e10 / 3.0943e10}
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
 PMC_TRAFFIC_BYTES = int((70312554 + 207449824) * 1024)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
@@ -225,6 +230,7 @@ def main_c3(args):
                          "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1) else None,
                          "traffic_source": "profiles/r01_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
+                         "valu": _valu_roofline(cells, "h", k_ms),
                          "note": "integer-VALU bound recurrence (int16 saturating lanes); HBM fraction reported as asked"},
             "cpu_baseline": cpu_base,
         }
@@ -233,6 +239,18 @@ def main_c3(args):
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _valu_roofline(cells, kind, k_ms):
+    """the bound that actually binds: VALU wave-instructions issued per second against the measured ceiling"""
+    if not k_ms:
+        return None
+    ach = cells * VALU_PER_CELL[kind] / (k_ms * 1e-3)
+    return {"achieved": round(ach / 1e9, 1), "peak": round(VALU_PEAK_WINST_S / 1e9, 1), "unit": "G wave-instr/s",
+            "frac": round(ach / VALU_PEAK_WINST_S, 3),
+            "source": "SQ_INSTS_VALU per cell (profiles/r01_sq_counters.txt) x cells / kernel time; peak from "
+                      "tools/ubench/valu_rate.hip (profiles/r01_valu_ubench.txt); above 1 when the count includes "
+                      "instructions skipped under an empty EXEC mask"}
 
 
 def _dist_setup():
@@ -381,6 +399,7 @@ def main():
                          "traffic": PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4) else None,
                          "traffic_source": "profiles/r01_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep<FL_UDH>", "kernel_ms": round(k_ms, 3),
+                         "valu": _valu_roofline(k_cells, k_name, k_ms),
                          "note": "integer-VALU bound recurrence; HBM fraction reported as asked"},
             "cpu_baseline": cpu_base,
         }

@@ -384,6 +384,27 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             const int smallest = (h_probs[n - 1].a_right - h_probs[n - 1].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
             if (smallest >= 4 * 32) wpb = 16;                            // >= 32 passes each
         }
+        // fewer huge problems than a quarter of the CUs (the top levels of the recursion on one long
+        // cDNA): spread each over several CUs -- cross-CU pass pipelines, all blocks resident
+        cross_g = 0;
+        const char* cg = getenv("SPDP_CROSS");
+        if (flav == 2 && wpb == 16 && n_multi == n && n > 0 && (!cg || atoi(cg) != 0)) {
+            int max_passes = 0, min_passes = 1 << 30;
+            for (int j = 0; j < n; ++j) {
+                const int stripes = (h_probs[j].a_right - h_probs[j].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
+                max_passes = std::max(max_passes, (stripes + 3) / 4);
+                min_passes = std::min(min_passes, (stripes + 3) / 4);
+            }
+            const int room = ctx->n_cu / n;                              // blocks per problem that stay resident
+            int g = std::min(room, (max_passes + 15) / 16);
+            if (cg && atoi(cg) > 1) g = std::min(room, atoi(cg));
+            if (g >= 2 && min_passes >= 32) cross_g = g;
+        }
+    }
+    if (cross_g > 0) {
+        const size_t words = (size_t) n * (cross_g * 16 + 2);
+        POOLGET(d_gprog, POOL_GPROG, sizeof(int) * words);
+        HIPCHK(hipMemsetAsync(d_gprog, 0, sizeof(int) * words, ctx->stream));
     }
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
     return 0;
@@ -414,7 +435,8 @@ int DevRun::launch()
     A.sc = (const DevScoring*) store->d_sc; A.probs = (const DevProblem*) d_probs; A.n_probs = n;
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.n_multi = n_multi;
-    const int grid = n_multi + (n - n_multi + wpb - 1) / wpb;
+    A.cross_g = cross_g; A.gprog = (int*) d_gprog;
+    const int grid = cross_g > 0 ? n * cross_g : n_multi + (n - n_multi + wpb - 1) / wpb;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;

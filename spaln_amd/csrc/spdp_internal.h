@@ -20,6 +20,9 @@ struct SweepArgs {
     int*              imd;        // udh: hlnk0, hlnk1, vlnk0, vlnk1 per intermediate
     DevResult*        res;
     int               n_multi;    // the first n_multi problems get a whole 4-wave block each
+    // cross-CU pass pipelines (CROSS kernels): every problem is spread over cross_g blocks
+    int               cross_g;    // blocks per problem (0: off)
+    int*              gprog;      // per problem: cross_g * WPB progress words, then 2 barrier words; zeroed per launch
 };
 
 struct WalkArgs {
@@ -140,7 +143,7 @@ struct DevPool {
     void   release();
 };
 enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSKL, POOL_CPOS,
-       POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_FLAV_STRIDE = 0 };
+       POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_GPROG, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
     DevPool pool[8];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path, [7] = rescoring
@@ -190,6 +193,8 @@ struct DevRun {
     int flavour = 0, n = 0;
     int n_multi = 0;                        // leading problems run as multi-wave pipelines
     int wpb = 4;                            // waves per block of the sweep launch (16: one huge problem per CU)
+    int cross_g = 0;                        // > 0: every problem spread over this many 16-wave blocks (CUs)
+    void* d_gprog = nullptr;                // progress / barrier words of the cross-CU pipelines
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;
     std::vector<DevProblem> h_probs;        // in dispatch order

@@ -76,6 +76,41 @@ __device__ __forceinline__ int2 ld_nt2(const int* p)
     return make_int2(v.x, v.y);
 }
 
+// Boundary entries that cross CUs (CROSS kernels): the per-XCD L2s are not coherent with each other, so every
+// access to the boundary array goes to the memory side -- agent-scope relaxed atomics compile to sc1
+// loads / stores (write-through, no allocation of stale lines); a flag published after the stores have
+// drained (s_waitcnt vmcnt(0)) orders them for the consumer.
+template <bool X> __device__ __forceinline__ int ld_b1(const int* p)
+{
+    if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __builtin_nontemporal_load(p);
+}
+template <bool X> __device__ __forceinline__ int4 ld_b4(const int* p)
+{
+    if constexpr (X) return make_int4(ld_b1<true>(p), ld_b1<true>(p + 1), ld_b1<true>(p + 2), ld_b1<true>(p + 3));
+    else return ld_nt4(p);
+}
+template <bool X> __device__ __forceinline__ int2 ld_b2(const int* p)
+{
+    if constexpr (X) return make_int2(ld_b1<true>(p), ld_b1<true>(p + 1));
+    else return ld_nt2(p);
+}
+template <bool X> __device__ __forceinline__ void st_b1(int* p, int v)
+{
+    if constexpr (X) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool X> __device__ __forceinline__ void st_b4(int* p, int4 v)
+{
+    if constexpr (X) { st_b1<true>(p, v.x); st_b1<true>(p + 1, v.y); st_b1<true>(p + 2, v.z); st_b1<true>(p + 3, v.w); }
+    else *reinterpret_cast<int4*>(p) = v;
+}
+template <bool X> __device__ __forceinline__ void st_b2(int* p, int2 v)
+{
+    if constexpr (X) { st_b1<true>(p, v.x); st_b1<true>(p + 1, v.y); }
+    else *reinterpret_cast<int2*>(p) = v;
+}
+
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // Ordering inside ONE wave needs no hardware fence: a wave's LDS instructions execute in order, and so
@@ -92,7 +127,11 @@ enum { NQ_FLAT = 0, NQ_TABLE = 1, NQ_CHAIN = 2 };
 // ---------------------------------------------------------------------------
 // WPB: waves per block.  4 by default; 16 when a launch holds only a few huge problems, each of which
 // then owns a whole CU (a 16-wave pass pipeline instead of a 4-wave one).
-template <int FL, bool LOCAL, int NQM, int WPB>
+// CROSS: one problem is spread over A.cross_g blocks (CUs): global wave c * WPB + wv runs passes
+// c * WPB + wv, + cross_g * WPB, ..; progress words live in global memory and the boundary array is
+// accessed with memory-side coherent loads / stores.  All blocks of the launch must be resident (grid
+// <= number of CUs; 16-wave blocks take a whole CU each).
+template <int FL, bool LOCAL, int NQM, int WPB, bool CROSS = false>
 __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
 {
     constexpr int BW = (FL == FL_UDH) ? 4 : 2;          // ints per boundary entry
@@ -138,15 +177,20 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
     // follows at a distance through progress words in LDS -- a wavefront pipeline inside the CU.
     // All other problems take one wave each (4 per block).  The hardware dispatcher balances the
     // load (blocks are launched as CUs free up), so no software queue is needed.
-    __shared__ int s_prog[WPB];
+    __shared__ int s_prog_lds[WPB];
     const int wv = threadIdx.x >> 6;
-    const bool multi = (int) blockIdx.x < A.n_multi;
-    const int W = multi ? WPB : 1;                  // waves cooperating on my problem
-    const int w = multi ? wv : 0;                   // my position among them
-    int pi = multi ? (int) blockIdx.x : A.n_multi + ((int) blockIdx.x - A.n_multi) * WPB + wv;
+    const int G = CROSS ? A.cross_g : 1;            // blocks cooperating on my problem
+    const bool multi = CROSS || (int) blockIdx.x < A.n_multi;
+    const int W = multi ? WPB * G : 1;              // waves cooperating on my problem
+    const int w = multi ? (CROSS ? ((int) blockIdx.x % G) * WPB + wv : wv) : 0;     // my position among them
+    int pi = CROSS ? (int) blockIdx.x / G
+                   : (multi ? (int) blockIdx.x : A.n_multi + ((int) blockIdx.x - A.n_multi) * WPB + wv);
     pi = __builtin_amdgcn_readfirstlane(pi);
     const bool active = pi < A.n_probs;
-    if (threadIdx.x < WPB) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < WPB) s_prog_lds[threadIdx.x] = 0;
+    // progress words: LDS inside one block, global memory (zeroed by the host) across blocks
+    int* const s_prog = CROSS ? A.gprog + (int64_t) pi * (G * WPB + 2) : s_prog_lds;
+    constexpr auto PSCOPE = CROSS ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
     if (!active) pi = A.n_probs - 1;                // keep the addressing valid until the barrier
     const DevProblem P = A.probs[pi];
     const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
@@ -183,19 +227,38 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 if (r >= rl) c = a_exgl ? ((r < ru) ? r : 0) : rl;
                 else         c = b_exgl ? r : rl;
                 if (r > ru) c = 0;
-                reinterpret_cast<int4*>(bnd)[e] = make_int4(h, SPDP_NEV16, c, c);
+                st_b4<CROSS>(bnd + (int64_t) e * 4, make_int4(h, SPDP_NEV16, c, c));
             } else {
-                reinterpret_cast<int2*>(bnd)[e] = make_int2(h, SPDP_NEV16);
+                st_b2<CROSS>(bnd + (int64_t) e * 2, make_int2(h, SPDP_NEV16));
             }
         }
         if constexpr (FL == FL_UDH) {
             int* imd = A.imd + P.imd_off;
             const int tot = P.n_im * 4 * width;
-            for (int e = lane + 64 * w; e < tot && active; e += 64 * W) imd[e] = END_OF_ULK;
+            // (CROSS: memory-side stores -- a dirty line left in one XCD's L2 would later overwrite the links
+            //  another XCD's wave stores into the same line)
+            for (int e = lane + 64 * w; e < tot && active; e += 64 * W) st_b1<CROSS>(imd + e, END_OF_ULK);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();                                // the only block-wide barrier (all waves reach it)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (CROSS) {
+            // all blocks of the problem have initialised their share before any pass starts
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int* bar = s_prog + G * WPB;
+                __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long spins = 0;
+                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1l << 24)) __builtin_trap();         // a block of the group is not resident
+                }
+            }
+            __syncthreads();
+            WAVE_ORDER();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                            // the only block-wide barrier (all waves reach it)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
     }
     if (!active) return;
 
@@ -282,8 +345,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             int2 nx_c = make_int2(0, 0);
             auto prefetch = [&](int lbn) {
                 const int nn = n_start + lbn * 16 + k;                  // sweep step this lane loads for
-                if constexpr (FL == FL_UDH) nx_b = ld_nt4(bnd + (int64_t) BIDX(nn - ml) * 4);
-                else { const int2 v = ld_nt2(bnd + (int64_t) BIDX(nn - ml) * 2); nx_b.x = v.x; nx_b.y = v.y; }
+                if constexpr (FL == FL_UDH) nx_b = ld_b4<CROSS>(bnd + (int64_t) BIDX(nn - ml) * 4);
+                else { const int2 v = ld_b2<CROSS>(bnd + (int64_t) BIDX(nn - ml) * 2); nx_b.x = v.x; nx_b.y = v.y; }
                 // raw record: nothing may depend on the loaded value here, or the compiler has to wait
                 // for the load on the spot and the prefetch is gone (nn < b_len + SPDP_COL_PAD always)
                 nx_c = cols[nn];
@@ -293,9 +356,13 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             auto wait_for = [&](int lbn) {
                 if (W == 1 || pass == 0) return;
                 const int need = (pass - 1) * BIGB + lbn + 16;
-                while (__hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                long spins = 0;
+                while (__hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, PSCOPE) < need) {
                     __builtin_amdgcn_s_sleep(4);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if constexpr (CROSS) { if (++spins > (1l << 26)) __builtin_trap(); }
+                }
+                if constexpr (CROSS) WAVE_ORDER();      // the entries are read with memory-side loads
+                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             };
             wait_for(0);
             if (g == 0 && nb > 0) prefetch(0);
@@ -315,8 +382,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                         const int r = n_start - (ml + 1);
                         donor_r = r;
                         if (k == 0) {
-                            Hd = __builtin_nontemporal_load(&bnd[(int64_t) BIDX(r) * BW]);
-                            if constexpr (FL == FL_UDH) Cd = __builtin_nontemporal_load(&bnd[(int64_t) BIDX(r) * BW + 2]);
+                            Hd = ld_b1<CROSS>(&bnd[(int64_t) BIDX(r) * BW]);
+                            if constexpr (FL == FL_UDH) Cd = ld_b1<CROSS>(&bnd[(int64_t) BIDX(r) * BW + 2]);
                         }
                     }
                     // ---- this block's chunk (prefetched one block ago) goes to LDS ...
@@ -417,12 +484,12 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                             const int rj = n - (ml + 1) - 2 * k;            /* my cell's diagonal */         \
                             if (imd_row && k == k8 && rj >= lw && rj <= up && n < n_end) {                   \
                                 int* hl0 = imd_p + BIDX(rj);                                                 \
-                                if (spj && is_acc) { hl0[0] = donor_r; hl0[width] = donor_r + width; rlst = rj; } \
+                                if (spj && is_acc) { st_b1<CROSS>(hl0, donor_r); st_b1<CROSS>(hl0 + width, donor_r + width); rlst = rj; } \
                                 if (spj && is_don) donor_r = rj;                                             \
                                 if (pb3 == 0) rlst = rj;                                                     \
-                                if (pb3 == 1) hl0[0] = rlst;                                                 \
-                                hl0[2 * width] = Cs;  Cs = rj;                                               \
-                                hl0[3 * width] = FCs; FCs = rj + width;                                      \
+                                if (pb3 == 1) st_b1<CROSS>(hl0, rlst);                                       \
+                                st_b1<CROSS>(hl0 + 2 * width, Cs);  Cs = rj;                                 \
+                                st_b1<CROSS>(hl0 + 3 * width, FCs); FCs = rj + width;                        \
                             }                                                                                \
                         }                                                                                    \
                         if (LOCAL && LocalR) {                                                               \
@@ -463,9 +530,9 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                         const int r0 = n - (ml + 1) - 2 * j8;
                         if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
                             if constexpr (FL == FL_UDH)
-                                reinterpret_cast<int4*>(bnd)[BIDX(r0)] = make_int4(outH, outF, outC, outFC);
+                                st_b4<CROSS>(bnd + (int64_t) BIDX(r0) * 4, make_int4(outH, outF, outC, outFC));
                             else
-                                reinterpret_cast<int2*>(bnd)[BIDX(r0)] = make_int2(outH, outF);
+                                st_b2<CROSS>(bnd + (int64_t) BIDX(r0) * 2, make_int2(outH, outF));
                         }
                     }
                     if constexpr (FL == FL_FORWARD) {
@@ -478,15 +545,17 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 // vector memory path, loads bypass L1), so only the compiler needs a fence here
                 WAVE_ORDER();
                 if (W > 1) {                                            // publish: this block's stores are done
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if constexpr (CROSS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0)
-                        __hip_atomic_store(&s_prog[w], pass * BIGB + blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&s_prog[w], pass * BIGB + blk + 1, __ATOMIC_RELAXED, PSCOPE);
                 }
             }
             if (W > 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if constexpr (CROSS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0)
-                    __hip_atomic_store(&s_prog[w], (pass + 1) * BIGB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&s_prog[w], (pass + 1) * BIGB, __ATOMIC_RELAXED, PSCOPE);
             }
         };
         if (pass_partial) {
@@ -504,10 +573,14 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             if (x == w) continue;
             const int last_own = ((n_passes - 1 - x) / W) * W + x;      // last pass of wave x (< 0: none)
             if (n_passes - 1 - x < 0) continue;
-            while (__hip_atomic_load(&s_prog[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (last_own + 1) * BIGB)
+            long spins = 0;
+            while (__hip_atomic_load(&s_prog[x], __ATOMIC_RELAXED, PSCOPE) < (last_own + 1) * BIGB) {
                 __builtin_amdgcn_s_sleep(4);
+                if constexpr (CROSS) { if (++spins > (1l << 26)) __builtin_trap(); }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (CROSS) WAVE_ORDER();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     // ---- fhlastS1 (src/fwd2s1_simd.cc:241-262) unless a local right end was tracked
     DevResult R;
@@ -531,7 +604,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
         auto argmax_first = [&](int lo, int hi) {
             int bv = INT32_MIN, bi = INT32_MAX;
             for (int r = lo + lane; r < hi; r += 64) {
-                const int v = bnd[(int64_t) BIDX(r) * BW];
+                const int v = ld_b1<CROSS>(&bnd[(int64_t) BIDX(r) * BW]);
                 if (v > bv) { bv = v; bi = r; }
             }
             for (int off = 32; off; off >>= 1) {
@@ -546,11 +619,11 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             const int r2 = min(up - 1, b_right - a_left);
             int mv = argmax_first(rr, r2);
             if (r2 - rr < 1) mv = rr;
-            if (bnd[(int64_t) BIDX(mv) * BW] > bnd[(int64_t) BIDX(maxr) * BW]) maxr = mv;
+            if (ld_b1<CROSS>(&bnd[(int64_t) BIDX(mv) * BW]) > ld_b1<CROSS>(&bnd[(int64_t) BIDX(maxr) * BW])) maxr = mv;
         }
-        R.score = bnd[(int64_t) BIDX(maxr) * BW];
+        R.score = ld_b1<CROSS>(&bnd[(int64_t) BIDX(maxr) * BW]);
         if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
-        if constexpr (FL == FL_UDH) R.ulk = bnd[(int64_t) BIDX(maxr) * BW + 2];
+        if constexpr (FL == FL_UDH) R.ulk = ld_b1<CROSS>(&bnd[(int64_t) BIDX(maxr) * BW + 2]);
         R.maxr = maxr;
     }
     if (lane == 0) A.res[pi] = R;
@@ -565,6 +638,18 @@ static void launch_nq(int nqm, dim3 grd, int wpb, hipStream_t stream, const Swee
     if constexpr (!LOCAL) {
         if (wpb == 16) {
             const dim3 blk(1024);
+            if constexpr (FL == FL_UDH) {
+                if (A.cross_g > 0) {                    // one problem over several CUs: every block must be
+                    // resident, so this is a cooperative launch (the runtime checks the grid against residency)
+                    SweepArgs Ac = A;
+                    void* kargs[] = {&Ac};
+                    const void* fn = nqm == NQ_FLAT  ? (const void*) spdp_sweep<FL, LOCAL, NQ_FLAT, 16, true>
+                                   : nqm == NQ_TABLE ? (const void*) spdp_sweep<FL, LOCAL, NQ_TABLE, 16, true>
+                                                     : (const void*) spdp_sweep<FL, LOCAL, NQ_CHAIN, 16, true>;
+                    (void) hipLaunchCooperativeKernel(fn, grd, blk, kargs, 0, stream);
+                    return;
+                }
+            }
             switch (nqm) {
             case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT, 16>), grd, blk, 0, stream, A); break;
             case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE, 16>), grd, blk, 0, stream, A); break;

@@ -120,3 +120,39 @@ def test_c5_full_size_properties():
     assert hits == 50
     assert score == score2 and skl.tolist() == skl2.tolist()
     assert score > 150000                                  # ~4 per matched base at 2 % divergence
+
+
+def test_cross_cu_pipelines_equal_one_cu():
+    """a launch of a few huge problems spreads each over several CUs (progress words in global memory,
+    memory-side coherent boundary entries): bit-identical to the one-CU pipelines, run after run"""
+    from spaln_amd import abi, defaults, engine, synth
+    rng = np.random.default_rng(synth.SEED + 77)
+    g = synth.make_gene(rng, n_exons=20, mrna_len=20000, flank=1000, intron_lo=800, intron_hi=6000)
+    w, q = defaults.encode(g.window), defaults.encode(g.query)
+    s5, s3 = synth.splice_signals(g.window)
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    ps.add(q, w, s5, s3)
+    old = os.environ.get("SPDP_CROSS")
+    try:
+        os.environ["SPDP_CROSS"] = "0"
+        eng = engine.Engine(0)
+        (ws, wskl), = eng.align_s(sc, ps)
+        us0 = eng.wip_udh(sc, ps, 3)
+        eng.close()
+        os.environ["SPDP_CROSS"] = "1"
+        eng = engine.Engine(0)
+        for _ in range(4):
+            (s, skl), = eng.align_s(sc, ps)
+            assert s == ws and skl.tolist() == wskl.tolist()
+            us1 = eng.wip_udh(sc, ps, 3)
+            assert all(np.array_equal(a, b) for a, b in zip(us0, us1))
+        eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("SPDP_CROSS", None)
+        else:
+            os.environ["SPDP_CROSS"] = old
+    c = _check_corners(wskl, q, w)
+    cols = set(int(x) for x in c[:, 1])
+    assert sum((e0 in cols) + (e1 in cols) for e0, e1 in g.exons) == 40

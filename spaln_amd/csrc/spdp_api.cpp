@@ -395,14 +395,18 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
                 max_passes = std::max(max_passes, (stripes + 3) / 4);
                 min_passes = std::min(min_passes, (stripes + 3) / 4);
             }
-            const int room = ctx->n_cu / n;                              // blocks per problem that stay resident
+            const int room = ctx->n_cu / n;                              // blocks per problem, one block per CU
             int g = std::min(room, (max_passes + 15) / 16);
+            // with CUs to spare a wave gets a SIMD to itself: 4-wave blocks, one pass per wave
+            const char* c4 = getenv("SPDP_CROSS_WPB");
+            if (c4 ? atoi(c4) == 4 : (max_passes + 3) / 4 <= room) { wpb = 4; g = std::min(room, (max_passes + 3) / 4); }
             if (cg && atoi(cg) > 1) g = std::min(room, atoi(cg));
             if (g >= 2 && min_passes >= 32) cross_g = g;
+            else wpb = 16;
         }
     }
     if (cross_g > 0) {
-        const size_t words = (size_t) n * (cross_g * 16 + 2);
+        const size_t words = (size_t) n * (cross_g * wpb + 2);
         POOLGET(d_gprog, POOL_GPROG, sizeof(int) * words);
         HIPCHK(hipMemsetAsync(d_gprog, 0, sizeof(int) * words, ctx->stream));
     }

@@ -635,21 +635,28 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
 template <int FL, bool LOCAL>
 static void launch_nq(int nqm, dim3 grd, int wpb, hipStream_t stream, const SweepArgs& A)
 {
+    if constexpr (!LOCAL && FL == FL_UDH) {
+        if (A.cross_g > 0) {
+            // one problem over several CUs: every block must be resident, so this is a cooperative launch
+            // (the runtime checks the grid against residency)
+            SweepArgs Ac = A;
+            void* kargs[] = {&Ac};
+            const void* fn;
+            if (wpb == 16)
+                fn = nqm == NQ_FLAT  ? (const void*) spdp_sweep<FL, LOCAL, NQ_FLAT, 16, true>
+                   : nqm == NQ_TABLE ? (const void*) spdp_sweep<FL, LOCAL, NQ_TABLE, 16, true>
+                                     : (const void*) spdp_sweep<FL, LOCAL, NQ_CHAIN, 16, true>;
+            else
+                fn = nqm == NQ_FLAT  ? (const void*) spdp_sweep<FL, LOCAL, NQ_FLAT, 4, true>
+                   : nqm == NQ_TABLE ? (const void*) spdp_sweep<FL, LOCAL, NQ_TABLE, 4, true>
+                                     : (const void*) spdp_sweep<FL, LOCAL, NQ_CHAIN, 4, true>;
+            (void) hipLaunchCooperativeKernel(fn, grd, dim3(wpb == 16 ? 1024 : 256), kargs, 0, stream);
+            return;
+        }
+    }
     if constexpr (!LOCAL) {
         if (wpb == 16) {
             const dim3 blk(1024);
-            if constexpr (FL == FL_UDH) {
-                if (A.cross_g > 0) {                    // one problem over several CUs: every block must be
-                    // resident, so this is a cooperative launch (the runtime checks the grid against residency)
-                    SweepArgs Ac = A;
-                    void* kargs[] = {&Ac};
-                    const void* fn = nqm == NQ_FLAT  ? (const void*) spdp_sweep<FL, LOCAL, NQ_FLAT, 16, true>
-                                   : nqm == NQ_TABLE ? (const void*) spdp_sweep<FL, LOCAL, NQ_TABLE, 16, true>
-                                                     : (const void*) spdp_sweep<FL, LOCAL, NQ_CHAIN, 16, true>;
-                    (void) hipLaunchCooperativeKernel(fn, grd, blk, kargs, 0, stream);
-                    return;
-                }
-            }
             switch (nqm) {
             case NQ_FLAT:  hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_FLAT, 16>), grd, blk, 0, stream, A); break;
             case NQ_TABLE: hipLaunchKernelGGL((spdp_sweep<FL, LOCAL, NQ_TABLE, 16>), grd, blk, 0, stream, A); break;

@@ -440,7 +440,8 @@ int DevRun::launch()
     A.a_codes = (const uint8_t*) store->d_a; A.cols = (const int2*) store->d_cols; A.bnd = (int*) d_bnd;
     A.tb = (uint8_t*) d_tb; A.imd = (int*) d_imd; A.res = (DevResult*) d_res; A.n_multi = n_multi;
     A.cross_g = cross_g; A.gprog = (int*) d_gprog;
-    const int grid = cross_g > 0 ? n * cross_g : n_multi + (n - n_multi + wpb - 1) / wpb;
+    int grid = cross_g > 0 ? n * cross_g : n_multi + (n - n_multi + wpb - 1) / wpb;
+    if (cross_g > 0 && getenv("SPDP_CROSS_TEST_SHORT")) --grid;    // test hook: one block never arrives -> the fallback runs
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;
@@ -465,6 +466,20 @@ int DevRun::launch()
 int DevRun::sync()
 {
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (cross_g > 0) {
+        // cross-CU pipelines need every block resident; on a shared GPU the start-up barrier can time out, the
+        // blocks then leave a mark (second barrier word of their problem) and the launch is repeated without them
+        const size_t per = (size_t) cross_g * wpb + 2;
+        std::vector<int> words(per * n);
+        HIPCHK(hipMemcpy(words.data(), d_gprog, sizeof(int) * words.size(), hipMemcpyDeviceToHost));
+        bool gave_up = false;
+        for (int j = 0; j < n; ++j) gave_up = gave_up || words[per * j + per - 1] != 0;
+        if (gave_up) {
+            cross_g = 0; wpb = 16;
+            if (launch()) return -1;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+    }
     kernel_ms = 0.f;
     if (n) HIPCHK(hipEventElapsedTime(&kernel_ms, ctx->ev0, ctx->ev1));
     return 0;

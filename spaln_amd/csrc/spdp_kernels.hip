@@ -247,12 +247,18 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 int* bar = s_prog + G * WPB;
                 __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 long spins = 0;
+                s_prog_lds[0] = 0;
                 while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1l << 24)) __builtin_trap();         // a block of the group is not resident
+                    if (++spins > (1l << 22)) {         // a block of the group is not resident (the GPU is shared):
+                        s_prog_lds[0] = 1;              // give up -- the host re-runs the launch on one CU per problem
+                        __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
             __syncthreads();
+            if (s_prog_lds[0]) return;
             WAVE_ORDER();
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -156,3 +156,25 @@ def test_cross_cu_pipelines_equal_one_cu():
     c = _check_corners(wskl, q, w)
     cols = set(int(x) for x in c[:, 1])
     assert sum((e0 in cols) + (e1 in cols) for e0, e1 in g.exons) == 40
+
+
+def test_cross_cu_fallback_when_a_block_is_missing():
+    """the start-up barrier of the cross-CU pipelines times out when a block of the group is not resident
+    (here: never launched); the blocks then give up and the host repeats the launch on one CU per problem"""
+    from spaln_amd import abi, defaults, engine, synth
+    rng = np.random.default_rng(synth.SEED + 505)
+    g = synth.make_gene(rng, n_exons=24, mrna_len=6000, flank=1000, intron_lo=500, intron_hi=3000)
+    w, q = defaults.encode(g.window), defaults.encode(g.query)
+    s5, s3 = synth.splice_signals(g.window)
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    ps.add(q, w, s5, s3)
+    eng = engine.Engine(0)
+    want = eng.wip_udh(sc, ps, 3)
+    os.environ["SPDP_CROSS_TEST_SHORT"] = "1"
+    try:
+        got = eng.wip_udh(sc, ps, 3)
+    finally:
+        os.environ.pop("SPDP_CROSS_TEST_SHORT", None)
+        eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))

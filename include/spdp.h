@@ -65,6 +65,7 @@ typedef struct SpdpScoring {
     int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3, the default of the reference);
                                         1: algmode.alg == 0 (-A0): spdp_align_s runs forwardS_ng /
                                         hirschbergS_ng throughout, spdp_homscore_s scorealoneS_ng */
+    int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
 } SpdpScoring;
 
 typedef struct SpdpProblem {

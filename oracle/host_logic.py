@@ -250,6 +250,10 @@ def homscore_s(sc, p, simd=2):
         if not sc.intpen or not p.cano5:
             raise NeedsScalarEngine()
         return oracle.scalar_scorealone(sc, p, w)
+    if simd == 1:                                         # -A1: scoreonlyS1 (mode 3 / 5 do not change the score)
+        if not sc.intpen or not p.cano5:
+            raise NeedsScalarEngine()
+        return oracle.exact_scoreonly(sc, p, w)
     return oracle.wip_scoreonly(sc, p, w)
 
 

@@ -121,6 +121,16 @@ def scalar_udh(sc, p, n_im: int, imd_intvl: int, w=None):
     return s.value, cpos, rng, rc
 
 
+def exact_scoreonly(sc, p, w=None) -> int:
+    """SimdAln2s1::scoreonlyS1 (the -A1 HomScoreS_ng engine: vector H / E / F with exact intron lists)."""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    rc = lib().orc_exact_scoreonly(C.byref(sc), C.byref(p), C.byref(w), C.byref(s))
+    if rc:
+        raise RuntimeError(f"orc_exact_scoreonly rc={rc}")
+    return s.value
+
+
 # ---- protein x genome ------------------------------------------------------------------
 def stripe31(p: abi.ProblemH, sh: int) -> abi.Window:
     w = abi.Window()

@@ -37,6 +37,7 @@ class Scoring(C.Structure):
         ("intpen_len", C.c_int32),
         ("t53", C.c_int16 * 256),
         ("scalar_engines", C.c_int32),
+        ("minl", C.c_int32),
     ]
 
 
@@ -84,7 +85,7 @@ class Rescored(C.Structure):
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,
-                 intpen=None, t53=None, scalar_engines=0) -> Scoring:
+                 intpen=None, t53=None, scalar_engines=0, minl=0) -> Scoring:
     sc = Scoring()
     sc.mtx_dim = int(mtx_dim)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -102,6 +103,7 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
     sc.local, sc.sh = int(local), int(sh)
     sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
     sc.scalar_engines = int(scalar_engines)
+    sc.minl = int(minl)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip                      # keep the buffer alive with the struct

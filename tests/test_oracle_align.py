@@ -45,9 +45,10 @@ def test_skl_rng_s_vs_reference(fx, alg):
     assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()
 
 
-@pytest.mark.parametrize("alg", [0, 2, 3])
+@pytest.mark.parametrize("alg", [0, 1, 2, 3])
 def test_homscore_s_ng_goldens(alg):
-    """HomScoreS_ng as the reference returns it under -A0 / -A2 / -A3, incl. the scalar branch below 4 rows"""
+    """HomScoreS_ng as the reference returns it under -A0 / -A1 / -A2 / -A3, incl. the scalar branch below 4
+    rows; -A1 is scoreonlyS1 (vector H / E / F with exact per-lane intron lists)"""
     from tests.conftest import golden_files
     n = 0
     for f in golden_files("s1_"):

@@ -268,7 +268,7 @@ void DevRun::release() {}       // buffers belong to ctx->pool[flavour]
 
 #define POOLGET(dst, slot, bytes)                                                        \
     do {                                                                                 \
-        (dst) = ctx->pool[flav == 5 ? 4 : flav].get((slot), (size_t) (bytes));           \
+        (dst) = ctx->pool[flav >= 5 ? 4 : flav].get((slot), (size_t) (bytes));           \
         if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
     } while (0)
 
@@ -302,7 +302,10 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.col_off = st->col_off[it.parent];
         P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
-        if (flav == 5) {        // scalar UDH: 2 * width + 4 states of 5 ints; 8 link / bound rows per intermediate
+        if (flav == 6) {        // -A1 score-only: hv / fv by diagonal, buf_size ints each
+            P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
+            bnd_tot = P.bnd_off + 2ll * P.buf_size + 8;
+        } else if (flav == 5) { // scalar UDH: 2 * width + 4 states of 5 ints; 8 link / bound rows per intermediate
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + 5ll * (2 * it.w.width + 4);
             P.imd_off = imd_tot;
@@ -430,7 +433,9 @@ int DevRun::launch()
         S.imd = (int*) d_imd; S.cpos = (int*) d_cpos; S.ranges = (int*) d_ranges; S.scores = (int*) d_scores;
         S.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-        if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
+        S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
+        if (flavour == 6) HIPCHK(spdp_launch_exact_score(&S, ctx->stream));
+        else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
         else HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         return 0;
@@ -574,17 +579,20 @@ int spdp_wip_scoreonly(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProble
 static int homscore_on_store(SpdpContext* ctx, const DevStore& st, const SpdpProblem* probs, int n_probs, int32_t* scores)
 {
     const SpdpScoring* sc = &st.sc;
-    std::vector<RunItem> vec, sca;
-    std::vector<int> vi, si;
+    std::vector<RunItem> vec, sca, exa;
+    std::vector<int> vi, si, ei;
     int rc = 0;
     for (int i = 0; i < n_probs; ++i) {
         scores[i] = SPDP_NEVSEL;
         RunItem it = spdp_item_of(probs[i], i, sc->sh);
         const int m = it.a_right - it.a_left;
         if (it.w.width < 3) { rc = 1; continue; }
-        if (sc->scalar_engines || m < 4) {
+        if (sc->scalar_engines == 1 || m < 4) {
             if (!st.has_exact) { rc = 1; continue; }
             sca.push_back(it); si.push_back(i);
+        } else if (sc->scalar_engines == 2) {           // -A1: scoreonlyS1
+            if (!st.has_exact) { rc = 1; continue; }
+            exa.push_back(it); ei.push_back(i);
         } else { vec.push_back(it); vi.push_back(i); }
     }
     std::vector<DevResult> r;
@@ -597,6 +605,11 @@ static int homscore_on_store(SpdpContext* ctx, const DevStore& st, const SpdpPro
         DevRun run;
         if (run.build(&st, sca, 4) || run.launch() || run.sync() || run.fetch_results(r)) return -1;
         for (size_t k = 0; k < sca.size(); ++k) scores[si[k]] = r[k].score;
+    }
+    if (!exa.empty()) {
+        DevRun run;
+        if (run.build(&st, exa, 6) || run.launch() || run.sync() || run.fetch_results(r)) return -1;
+        for (size_t k = 0; k < exa.size(); ++k) scores[ei[k]] = r[k].score;
     }
     return rc;
 }

@@ -172,7 +172,7 @@ struct Aligner {
     {
         if (w.width < 0) { set_score(job, top, SPDP_NEVSEL); return; }
         if (bad_range(job, r) || w.width < 3) { ++unsupported; jobs[job].failed = true; return; }
-        if (st->sc.scalar_engines || r.ar - r.al < kScalarRows) {   // -A0, or fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
+        if (st->sc.scalar_engines == 1 || r.ar - r.al < kScalarRows) {   // -A0, or fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
             if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
             stbs.push_back({job, r, w, top});
             return;
@@ -205,7 +205,7 @@ struct Aligner {
         int n_imd = 1;
         bool recursive = false;                 // algmode.alg & 4 (-A4..7) not offered
         float cvol = float(m) * (n + m);        // rhombic, simd >= 2
-        if (sc.scalar_engines) {                // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
+        if (sc.scalar_engines == 1) {           // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
             const float k = it.w.lw - r.bl + r.ar;
             const float q = r.br - r.al - it.w.up;
             cvol = float(m) * n - (k * k + q * q) / 2;
@@ -227,7 +227,7 @@ struct Aligner {
             }
         }
         if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
-        if (sc.scalar_engines && !st->has_exact) { ++unsupported; J.failed = true; return true; }
+        if (sc.scalar_engines == 1 && !st->has_exact) { ++unsupported; J.failed = true; return true; }
         udh.push_back({it.job, r, it.w, it.top, n_imd, recursive, intvl});
         return true;
     }
@@ -236,7 +236,7 @@ struct Aligner {
     // the cpos row (src/fwd2s1.cc:1735-1740, 1778-1797)
     void slab_window(const Rng& r, int sh, const int32_t* row, SpdpWindow* w) const
     {
-        if (!st->sc.scalar_engines) { stripe_of(r, sh, w); return; }
+        if (st->sc.scalar_engines != 1) { stripe_of(r, sh, w); return; }
         w->lw = row[8]; w->up = row[9];
         w->width = w->up - w->lw + 3;
     }
@@ -312,6 +312,7 @@ struct Aligner {
     int run()
     {
         const SpdpScoring& sc = st->sc;
+        if (sc.scalar_engines == 2) { ctx->err = "alignS_ng under -A1 (forwardS1 / hirschbergS1) is not built"; return -1; }
         lap("start");
         jobs.assign(n, Job());
         for (int i = 0; i < n; ++i) {           // alignS_ng: stripe(alprm.sh), globalS_ng -> lspS_ng
@@ -334,7 +335,7 @@ struct Aligner {
                 items.back().imd_intvl = u.imd_intvl;
             }
             DevRun run;
-            const bool a0 = sc.scalar_engines != 0;
+            const bool a0 = sc.scalar_engines == 1;
             if (run.build(st, items, a0 ? 5 : 2)) return -1;
             lap("udh build");
             if (run.launch() || run.sync()) return -1;

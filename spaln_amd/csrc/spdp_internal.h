@@ -61,6 +61,7 @@ struct ScalarArgs {
     const int16_t*    intpen;
     int               intpen_len;
     int               ipen;
+    int               minl;       // IntronPrm.minl (-A1 engines)
     int16_t           t53[256];
     int*              work;
     int3*             vmf;
@@ -77,6 +78,7 @@ struct ScalarArgs {
 };
 extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
+extern "C" hipError_t spdp_launch_exact_score(const ScalarArgs* a, hipStream_t s);    // spdp_exact.hip
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
@@ -186,7 +188,7 @@ struct RunItem {
 
 // descriptors + work buffers of one engine flavour over a DevStore:
 // 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score,
-// 5 scalar udh (shares pool 4 with the scalar score run: the two never coexist)
+// 5 scalar udh, 6 -A1 score-only (both share pool 4 with the scalar score run: they never coexist)
 struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;

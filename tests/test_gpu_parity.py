@@ -217,20 +217,21 @@ def test_align_then_rescore_batch(eng):
 
 def test_homscore_s_ng_goldens(eng):
     from spaln_amd import abi
-    """spdp_homscore_s = HomScoreS_ng (-A2 / -A3), every fixture in one batch per intron model: the vector
-    engine, and scorealoneS_ng for the query ranges below 4 rows"""
+    """spdp_homscore_s = HomScoreS_ng (-A2 / -A3 / -A1), every fixture in one batch per intron model: the
+    `_wip` engine, scoreonlyS1 under -A1 (SpdpScoring.scalar_engines = 2), and scorealoneS_ng for the query
+    ranges below 4 rows"""
     from tests.conftest import golden_files
-    for alg in (2, 3):
+    for alg in (2, 3, 1):
         cases = [spdg.load(f) for f in golden_files("s1_") if "local" not in f]
         ref = max(cases, key=lambda fx: fx["intpen"].size)
         for sh in sorted({fx["prm"]["sh"] for fx in cases}):
             sub = [fx for fx in cases if fx["prm"]["sh"] == sh]
-            sc = spdg.scoring(ref, nquant=1 if alg == 3 else None, sh=sh)
+            sc = spdg.scoring(ref, nquant=1 if alg == 3 else None, sh=sh, scalar_engines=2 if alg == 1 else 0)
             ps = abi.ProblemSet()
             for fx in sub:
                 spdg.problem(fx, ps)
             got = eng.homscore_s(sc, ps)
-            assert got.tolist() == [int(fx[f"hom_scr_A{alg}"][0]) for fx in sub]
+            assert got.tolist() == [int(fx[f"hom_scr_A{alg}"][0]) for fx in sub], alg
 
 
 def test_align_s_ori3_against_oracle(eng):
@@ -254,3 +255,34 @@ def test_align_s_ori3_against_oracle(eng):
         assert res[i][0] == ws and res[i][1].ravel().tolist() == (wskl or [])
         picked.append(wori)
     assert picked[0] == 0 and picked[2] == 0                   # ties keep the query as given
+
+
+def test_homscore_a1_local_and_subranges(eng):
+    """scoreonlyS1 in local mode (goldens) and on random sub-ranges / end-gap flags against the oracle"""
+    from spaln_amd import abi, synth
+    from oracle import oracle
+    from tests.conftest import golden_files
+    for name in ("s1_local", "s1_local_cut"):
+        fx = spdg.load([f for f in golden_files("s1_") if f.endswith(name + ".spdg")][0])
+        sc = spdg.scoring(fx, scalar_engines=2)
+        ps, _ = spdg.problem(fx)
+        assert int(eng.homscore_s(sc, ps)[0]) == int(fx["hom_scr_A1"][0])
+    fx = spdg.load([f for f in golden_files("s1_") if f.endswith("s1_indels.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 97)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    for local in (0, 1):
+        sc = spdg.scoring(fx, scalar_engines=2, local=local)
+        ps = abi.ProblemSet()
+        for i in range(96):
+            al = int(rng.integers(0, q["a_right"] - 40))
+            ar = int(rng.integers(al + 4, min(al + 400, q["a_right"]) + 1))
+            bl = int(rng.integers(0, q["b_right"] - 600))
+            br = int(rng.integers(bl + (ar - al) // 2 + 20, min(bl + 3000, q["b_right"]) + 1))
+            exg = tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, ar, bl, br, exg, **extra)
+        got = eng.homscore_s(sc, ps)
+        want = [oracle.exact_scoreonly(sc, p) for p in ps.items]
+        bad = [(i, int(g), w) for i, (g, w) in enumerate(zip(got, want)) if int(g) != w]
+        assert not bad, (local, bad[:5])

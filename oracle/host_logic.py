@@ -87,6 +87,14 @@ def trcbk(sc, p, w, rec, simd=2):
         s, skl = oracle.scalar_forward(sc, p, w)
         rec.extend((int(m), int(n)) for m, n in skl)
         return s
+    if simd == 1:                                         # forwardS1 (mode 3 / 5) + Vmf::traceback
+        if not sc.intpen or not p.cano5:
+            raise NeedsScalarEngine()
+        s, skl, flag = oracle.exact_forward(sc, p, w)
+        if flag:
+            raise ReferenceUndefined("forwardS1: mode 3 pointer beyond int16")
+        rec.extend((int(m), int(n)) for m, n in skl)
+        return s
     s, skl = oracle.wip_forward(sc, p, w)
     rec.extend((int(m), int(n)) for m, n in skl)
     return s

@@ -131,6 +131,22 @@ def exact_scoreonly(sc, p, w=None) -> int:
     return s.value
 
 
+def exact_forward(sc, p, w=None):
+    """SimdAln2s1::forwardS1 + Vmf traceback + the record hand-over of trcbkalignS_ng (-A1):
+    (score, records end -> start, flag); flag -3: mode 3 pointer overflow in the reference (undefined)."""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_exact_forward(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    if rc not in (0, -3):
+        raise RuntimeError(f"orc_exact_forward rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out, rc
+
+
 # ---- protein x genome ------------------------------------------------------------------
 def stripe31(p: abi.ProblemH, sh: int) -> abi.Window:
     w = abi.Window()

@@ -58,3 +58,24 @@ def test_homscore_s_ng_goldens(alg):
         assert host_logic.homscore_s(sc, p, simd=alg) == int(fx[f"hom_scr_A{alg}"][0]), f
         n += 1
     assert n >= 30
+
+
+def test_align_a1_traceback_branch():
+    """alignS_ng under -A1 wherever lspS_ng takes the traceback branch: forwardS1 (vector H / E / F, exact
+    per-lane intron lists, Vmf pointers riding on the states) + Vmf::traceback + stdskl / trimskl, against
+    the reference's -A1 output; the linear-space branch would need hirschbergS1 (not restated)"""
+    from tests.conftest import golden_files
+    n_ok = n_skip = 0
+    for f in golden_files("s1_"):
+        fx = spdg.load(f)
+        sc = spdg.scoring(fx)
+        _, p = spdg.problem(fx)
+        try:
+            scr, flat = host_logic.align_s(sc, p, simd=1)
+        except host_logic.NeedsScalarEngine:
+            n_skip += 1
+            continue
+        assert scr == int(fx["aln_scr_A1"][0]), f
+        assert (flat or []) == fx["aln_skl_A1"].tolist(), f
+        n_ok += 1
+    assert n_ok >= 26 and n_skip <= 6

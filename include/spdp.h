@@ -65,8 +65,9 @@ typedef struct SpdpScoring {
     int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3, the default of the reference);
                                         1: algmode.alg == 0 (-A0): spdp_align_s runs forwardS_ng /
                                         hirschbergS_ng throughout, spdp_homscore_s scorealoneS_ng;
-                                        2: algmode.alg == 1 (-A1): spdp_homscore_s runs scoreonlyS1
-                                        (spdp_align_s: forwardS1 / hirschbergS1 are not built) */
+                                        2: algmode.alg == 1 (-A1): spdp_homscore_s runs scoreonlyS1,
+                                        spdp_align_s forwardS1 (hirschbergS1 is not built: queries whose
+                                        ladder goes linear-space come back without an alignment) */
     int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
 } SpdpScoring;
 

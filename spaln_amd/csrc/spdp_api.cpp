@@ -268,7 +268,7 @@ void DevRun::release() {}       // buffers belong to ctx->pool[flavour]
 
 #define POOLGET(dst, slot, bytes)                                                        \
     do {                                                                                 \
-        (dst) = ctx->pool[flav >= 5 ? 4 : flav].get((slot), (size_t) (bytes));           \
+        (dst) = ctx->pool[flav == 7 ? 3 : (flav >= 5 ? 4 : flav)].get((slot), (size_t) (bytes)); \
         if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
     } while (0)
 
@@ -302,9 +302,15 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.col_off = st->col_off[it.parent];
         P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
-        if (flav == 6) {        // -A1 score-only: hv / fv by diagonal, buf_size ints each
+        if (flav == 6 || flav == 7) {   // -A1 engines: hv / fv (/ hb / hc / fc) by diagonal, buf_size ints each, a counter
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + 2ll * P.buf_size + 8;
+            bnd_tot = P.bnd_off + 5ll * P.buf_size + 8;
+            if (flav == 7) {
+                const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
+                const int64_t cap = 2 * cells + 64;
+                P.imd_off = cap;
+                tb_tot += cap;
+            }
         } else if (flav == 5) { // scalar UDH: 2 * width + 4 states of 5 ints; 8 link / bound rows per intermediate
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + 5ll * (2 * it.w.width + 4);
@@ -335,7 +341,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     POOLGET(d_probs, POOL_PROBS, sizeof(DevProblem) * nn);
     POOLGET(d_bnd, POOL_BND, sizeof(int32_t) * bw * std::max<int64_t>(bnd_tot, 1));
     POOLGET(d_res, POOL_RES, sizeof(DevResult) * nn);
-    if (flav == 3) {
+    if (flav == 3 || flav == 7) {
         POOLGET(d_tb, POOL_TB, sizeof(int3) * std::max<int64_t>(tb_tot, 16));
         POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
         POOLGET(d_nskl, POOL_NSKL, sizeof(int) * nn);
@@ -434,7 +440,7 @@ int DevRun::launch()
         S.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
-        if (flavour == 6) HIPCHK(spdp_launch_exact_score(&S, ctx->stream));
+        if (flavour == 6 || flavour == 7) HIPCHK(spdp_launch_exact(flavour == 7, &S, ctx->stream));
         else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
         else HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

@@ -27,7 +27,13 @@ __device__ static const unsigned char x_psp_bit[3] = {4, 1, 8};
 __device__ __forceinline__ int x_sadd(int a, int b) { return max(a + b, SPDP_FLOOR16); }
 __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      // lane k <- lane k - 1 of its group
 
-__global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
+// FORWARD: forwardS1 (src/fwd2s1_simd.cc:481-773) -- the same sweep with a Vmf pointer riding on H / E / F (one
+// int here; modes 3 / 5 of the reference split it over int16 lanes), a diagonal flag per cell, a record at
+// the start of every diagonal run and two per accepted intron (appended through a per-problem atomic
+// counter: record numbers differ from the reference's, the chains do not), then Vmf::traceback and the
+// fix-up of trcbkalignS_ng by lane 0.
+template <bool FORWARD>
+__global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 {
     const int k = threadIdx.x & 15;
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 4);
@@ -47,6 +53,17 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
     const uint8_t* aux = A.aux + 2 * P.col_off;  // {bit0 donor | bit1 acceptor, dinc5 << 4 | dinc3}
     int* hv = A.work + P.bnd_off - lw + 1;       // by diagonal, in place like the reference's hv / fv
     int* fv = hv + P.buf_size;
+    int* hb = fv + P.buf_size;                   // forward: diagonal flag, pointers of H and F
+    int* hc = hb + P.buf_size;
+    int* fc = hc + P.buf_size;
+    int* vcount = A.work + P.bnd_off + 5 * (int64_t) P.buf_size;          // forward: records appended so far
+    int3* vrec = A.vmf + P.tb_off;
+    const int vcap = (int) P.imd_off;
+    auto vadd = [&](int mm, int nn, int pp) -> int {
+        const int i = atomicAdd(vcount, 1);
+        if (i < vcap) vrec[i] = make_int3(mm, nn, pp);
+        return i;
+    };
     const int n_ent = P.buf_size;
 
     // ---- fhinitS1
@@ -67,11 +84,22 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
                 else if (r > rl + 1 && r < rr) h = gop;
             }
             hv[r] = h; fv[r] = XNEV;
+            if constexpr (FORWARD) {                 // the Vmf part of fhinitS1 (:185-205): records 0 (dummy) and 1 (start)
+                const int ru = up + 2 * XN;
+                int c = 0;
+                if (r == rl) c = 1;
+                else if (r > rl && r <= ru) c = a_exgl ? 0 : 1;
+                else if (r < rl) c = b_exgl ? 0 : 1;
+                hb[r] = 0; hc[r] = c; fc[r] = c;
+            }
+        }
+        if constexpr (FORWARD) {
+            if (k == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(a_left, b_left, 0); *vcount = 2; }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-    int maxh = XNEV;
+    int maxh = XNEV, max_ulk = 0, max_mr = a_right, max_nr = b_right;
     for (int ml = a_left; ml < a_right; ml += XN) {
         const int j9 = min(XN, a_right - ml);
         const int j8 = j9 - 1;
@@ -81,9 +109,10 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
         int r = n - (ml + 1);
         // per-lane state: H of the last two steps, F, E, flags, the candidate list of my row
         int H1 = XNEV, H2 = XNEV, F1 = XNEV, E = XNEV, ps = 0;
-        int c_val[5], c_jnc[5], c_dir[5], idx[5], ncand = -1;
+        int B1 = 0, B2 = 0, C1 = 0, C2 = 0, FC1 = 0, EC = 0, EB = 0, FB = 0;    // forward: flags / pointers of H (two steps), F, E
+        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], idx[5], ncand = -1;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = 0; idx[i] = i; }
+        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = 0; idx[i] = i; }
         const int m = ml + 1 + k;                             // my row
         const int* mrow = sc->mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
         for ( ; n < n9; ++n, ++r) {
@@ -91,23 +120,33 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
             const int ke = min(j9, n - b_left);
             const int nj = n - k;                             // my column
             // boundary feeds of lane 0 (previous stripe's bottom row, by diagonal)
-            int bH1 = 0, bF1 = 0, bH2 = 0;
+            int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0;
             if (k == 0) {
                 bH1 = __builtin_nontemporal_load(&hv[r + 1]);
                 bF1 = __builtin_nontemporal_load(&fv[r + 1]);
                 bH2 = __builtin_nontemporal_load(&hv[r]);
+                if constexpr (FORWARD) {
+                    bC1 = __builtin_nontemporal_load(&hc[r + 1]); bFC1 = __builtin_nontemporal_load(&fc[r + 1]);
+                    bB2 = __builtin_nontemporal_load(&hb[r]); bC2 = __builtin_nontemporal_load(&hc[r]);
+                }
             }
             int upH1 = x_up(H1), upF1 = x_up(F1), upH2 = x_up(H2);
-            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; }
+            int upC1 = 0, upFC1 = 0, upB2 = 0, upC2 = 0;
+            if constexpr (FORWARD) { upC1 = x_up(C1); upFC1 = x_up(FC1); upB2 = x_up(B2); upC2 = x_up(C2); }
+            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; }
             // insertion, deletion, diagonal
             {
                 const int open = x_sadd(H1, gn), ext = x_sadd(E, ge);
-                E = ext > open ? ext : open;
+                const bool m_ = ext > open;
+                E = m_ ? ext : open;
+                if constexpr (FORWARD) EC = m_ ? EC : C1;
             }
-            int F;
+            int F, FC = 0;
             {
                 const int open = x_sadd(upH1, gn), ext = x_sadd(upF1, ge);
-                F = ext > open ? ext : open;
+                const bool m_ = ext > open;
+                F = m_ ? ext : open;
+                if constexpr (FORWARD) FC = m_ ? upFC1 : upC1;
             }
             int pv = 0;
             const bool incell = nj <= b_right && nj > b_left && k < j9;     // kb <= k < ke
@@ -115,16 +154,30 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
             if (nj >= 0 && nj <= b_right + 1) col = cols[nj];
             if (incell) pv = mrow[col.y];
             int H = x_sadd(pv, upH2);
-            int hb = 0;
-            if (F > H) { H = F; hb = 2; }
-            if (E > H) { H = E; hb = 1; }
-            if (spj) ps &= hb;
+            int HC = upC2;
+            int code = 0;                                     // diag: 0, hori: 1, vert: 2 (pv_a)
+            if (F > H) { H = F; HC = FC; code = 2; }
+            if (E > H) { H = E; HC = EC; code = 1; }
+            const int hb_pv = code;
+            if (spj) ps &= code;
             if (!local) { if (!(H > XNEV)) H = XNEV; }
-            else if (LocalL) { if (0 > H) H = 0; }
+            else if (LocalL) { if (0 > H) { H = 0; code = 1; HC = 0; } }
+            int HB = 0;
+            if constexpr (FORWARD) {
+                HB = code == 0;                               // diag: 1, others: 0
+                if (HB && !(upB2 & 1) && incell) HC = vadd(ml + k, n - 1 - k, HC);   // a diagonal run starts here
+            }
             if (LocalR) {
                 int mx = (k < j9) ? H : INT32_MIN;
-                for (int off = 8; off; off >>= 1) mx = max(mx, __shfl_xor(mx, off, XN));
-                maxh = max(maxh, mx);
+                int mk = k;                                   // first maximum over the lanes (vmax)
+                for (int off = 8; off; off >>= 1) {
+                    const int ov = __shfl_xor(mx, off, XN), ok = __shfl_xor(mk, off, XN);
+                    if (ov > mx || (ov == mx && ok < mk)) { mx = ov; mk = ok; }
+                }
+                if (mx > maxh) {
+                    maxh = mx;
+                    if constexpr (FORWARD) { max_ulk = __shfl(HC, mk, XN); max_mr = ml + mk + 1; max_nr = n - mk; }
+                }
             }
             // the exact intron lists: only columns that were queued (pushed at step n_j of THIS stripe, n_j <= b_right)
             const bool queued = spj && k < j9 && nj >= n_first && nj <= b_right;
@@ -146,12 +199,19 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
                         cur = (int) (short) x;
                         if (d == 0) H = cur; else if (d == 1) E = cur; else F = cur;
                         ps |= x_psp_bit[d];
+                        if constexpr (FORWARD) {
+                            const int inner = vadd(m, don, c_ulk[ci]);
+                            const int ptr = vadd(m, nj, inner);
+                            const int bml = c_ml[ci];
+                            if (d == 0) { HB = bml; HC = ptr; } else if (d == 1) { EB = bml; EC = ptr; } else { FB = bml; FC = ptr; }
+                            if (d && cur > H) { HB = bml; HC = ptr; }
+                        }
                         if (d && cur > H) H = cur;
                     }
                 }
                 if (fl & 1) {                                 // donor: Sjsites::put
                     const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
-                    for (int kk = hb ? 1 : 0; kk < 3; ++kk) {
+                    for (int kk = hb_pv ? 1 : 0; kk < 3; ++kk) {
                         if (ps & x_psp_bit[kk]) continue;
                         const int from = kk == 0 ? H : (kk == 1 ? E : F);
                         if (kk && from <= H + gop) continue;
@@ -162,22 +222,35 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
                             if (x >= c_val[idx[l]]) { const int t = idx[l]; idx[l] = idx[l + 1]; idx[l + 1] = t; }
                             else break;
                         }
-                        if (++l < 4) { const int ci = idx[l]; c_val[ci] = (int) (short) x; c_jnc[ci] = nj; c_dir[ci] = kk; }
+                        if (++l < 4) {
+                            const int ci = idx[l];
+                            c_val[ci] = (int) (short) x; c_jnc[ci] = nj; c_dir[ci] = kk;
+                            if constexpr (FORWARD) {
+                                c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
+                                c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                            }
+                        }
                         else --ncand;
                     }
                 }
             }
             // bottom row of the stripe -> boundary arrays
-            if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) { hv[r0] = H; fv[r0] = F; }
+            if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) {
+                hv[r0] = H; fv[r0] = F;
+                if constexpr (FORWARD) { hb[r0] = HB; hc[r0] = HC; fc[r0] = FC; }
+            }
             H2 = H1; H1 = H; F1 = F;
+            if constexpr (FORWARD) { B2 = B1; B1 = HB; C2 = C1; C1 = HC; FC1 = FC; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    // ---- fhlastS1 unless a local right end was tracked
+    // ---- fhlastS1 unless a local right end was tracked; forward: the end record, Vmf::traceback, fix-up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (k == 0) {
         DevResult R;
         R.score = XNEV; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = 0; R.maxr = 0; R.pad[0] = R.pad[1] = 0;
-        if (LocalR) R.score = maxh;
+        int end_ulk = max_ulk;
+        if (LocalR) { R.score = maxh; R.mr = max_mr; R.nr = max_nr; }
         else {
             const int rr = b_right - a_right;
             int maxr = rr;
@@ -195,14 +268,44 @@ __global__ void __launch_bounds__(64) spdp_exact_score(ScalarArgs A)
             }
             R.score = __builtin_nontemporal_load(&hv[maxr]);
             R.maxr = maxr;
+            if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
+            if constexpr (FORWARD) end_ulk = __builtin_nontemporal_load(&hc[maxr]);
+        }
+        if constexpr (FORWARD) {
+            const int ptr = vadd(R.mr, R.nr, end_ulk);
+            const int used = __builtin_nontemporal_load(vcount);
+            int2* out = A.skl + (int64_t) pi * A.skl_cap;
+            int cnt = 0, status = used > vcap ? -3 : 0;
+            if (!status) {
+                const int* vr = reinterpret_cast<const int*>(vrec);
+                int cur = ptr, lm = 0, ln = 0;
+                for (;;) {
+                    const int sm = __builtin_nontemporal_load(vr + 3 * (int64_t) cur);
+                    const int sn = __builtin_nontemporal_load(vr + 3 * (int64_t) cur + 1);
+                    const int sp = __builtin_nontemporal_load(vr + 3 * (int64_t) cur + 2);
+                    if (cnt < A.skl_cap) out[cnt] = make_int2(sm, sn); else status = -1;
+                    lm = sm; ln = sn; ++cnt;
+                    if (!sp) break;
+                    cur = sp;
+                }
+                const int rd = local ? 0 : ((ln - lm) - b_left + a_left);
+                if (rd) {
+                    const int2 rec = rd > 0 ? make_int2(a_left, b_left + rd) : make_int2(a_left - rd, b_left);
+                    if (cnt < A.skl_cap) out[cnt] = rec; else status = -1;
+                    ++cnt;
+                }
+            }
+            A.n_skl[pi] = status ? status : cnt;
         }
         A.res[pi] = R;
     }
 }
 
-extern "C" hipError_t spdp_launch_exact_score(const ScalarArgs* a, hipStream_t stream)
+extern "C" hipError_t spdp_launch_exact(int forward, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    hipLaunchKernelGGL(spdp_exact_score, dim3((A.n_probs + 3) / 4), dim3(64), 0, stream, A);
+    const dim3 grd((A.n_probs + 3) / 4), blk(64);
+    if (forward) hipLaunchKernelGGL(spdp_exact<true>, grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL(spdp_exact<false>, grd, blk, 0, stream, A);
     return hipGetLastError();
 }

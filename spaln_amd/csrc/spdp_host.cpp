@@ -153,6 +153,7 @@ struct Aligner {
     std::vector<LspItem> pending;
     std::vector<TbItem> tbs;                    // forwardS1_wip calls
     std::vector<TbItem> stbs;                   // scalar forwardS_ng calls (< 8 rows)
+    std::vector<TbItem> xtbs;                   // -A1: forwardS1 calls
     float kernel_ms = 0.f;
     int64_t kernel_cells = 0;
     int unsupported = 0;
@@ -175,6 +176,11 @@ struct Aligner {
         if (st->sc.scalar_engines == 1 || r.ar - r.al < kScalarRows) {   // -A0, or fewer than 8 rows: scalar forwardS_ng (src/fwd2s1.cc:1677)
             if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
             stbs.push_back({job, r, w, top});
+            return;
+        }
+        if (st->sc.scalar_engines == 2) {       // -A1: forwardS1 (mode 3 / 5) + Vmf::traceback
+            if (!st->has_exact) { ++unsupported; jobs[job].failed = true; return; }
+            xtbs.push_back({job, r, w, top});
             return;
         }
         tbs.push_back({job, r, w, top});
@@ -205,7 +211,7 @@ struct Aligner {
         int n_imd = 1;
         bool recursive = false;                 // algmode.alg & 4 (-A4..7) not offered
         float cvol = float(m) * (n + m);        // rhombic, simd >= 2
-        if (sc.scalar_engines == 1) {           // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
+        if (sc.scalar_engines >= 1) {           // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
             const float k = it.w.lw - r.bl + r.ar;
             const float q = r.br - r.al - it.w.up;
             cvol = float(m) * n - (k * k + q * q) / 2;
@@ -228,6 +234,7 @@ struct Aligner {
         }
         if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
         if (sc.scalar_engines == 1 && !st->has_exact) { ++unsupported; J.failed = true; return true; }
+        if (sc.scalar_engines == 2) { ++unsupported; J.failed = true; return true; }     // hirschbergS1: not built
         udh.push_back({it.job, r, it.w, it.top, n_imd, recursive, intvl});
         return true;
     }
@@ -312,7 +319,6 @@ struct Aligner {
     int run()
     {
         const SpdpScoring& sc = st->sc;
-        if (sc.scalar_engines == 2) { ctx->err = "alignS_ng under -A1 (forwardS1 / hirschbergS1) is not built"; return -1; }
         lap("start");
         jobs.assign(n, Job());
         for (int i = 0; i < n; ++i) {           // alignS_ng: stripe(alprm.sh), globalS_ng -> lspS_ng
@@ -384,6 +390,25 @@ struct Aligner {
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* s = skl.data() + off[k];
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
+            }
+        }
+        // -A1 traceback calls: forwardS1
+        if (!xtbs.empty()) {
+            std::vector<RunItem> items;
+            for (const TbItem& t : xtbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            DevRun run;
+            if (run.build(st, items, 7) || run.launch() || run.sync()) return -1;
+            std::vector<DevResult> res;
+            std::vector<int> nskl;
+            std::vector<int64_t> off;
+            std::vector<SpdpSkl> skl;
+            if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
+            for (size_t k = 0; k < xtbs.size(); ++k) {
+                const TbItem& t = xtbs[k];
+                if (nskl[k] < 0) { ctx->err = "forwardS1 traceback failed"; return -1; }
+                set_score(t.job, t.top, res[k].score);
+                const SpdpSkl* sk = skl.data() + off[k];
+                jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
             }
         }
         // all trcbkalignS_ng calls of all queries: one forward sweep + one walk

@@ -78,7 +78,7 @@ struct ScalarArgs {
 };
 extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
-extern "C" hipError_t spdp_launch_exact_score(const ScalarArgs* a, hipStream_t s);    // spdp_exact.hip
+extern "C" hipError_t spdp_launch_exact(int forward, const ScalarArgs* a, hipStream_t s);    // spdp_exact.hip
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
@@ -188,7 +188,8 @@ struct RunItem {
 
 // descriptors + work buffers of one engine flavour over a DevStore:
 // 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score,
-// 5 scalar udh, 6 -A1 score-only (both share pool 4 with the scalar score run: they never coexist)
+// 5 scalar udh, 6 -A1 score-only (both share pool 4 with the scalar score run: they never coexist),
+// 7 -A1 forward (shares pool 3 with the scalar forward run)
 struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;

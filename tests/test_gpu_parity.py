@@ -286,3 +286,69 @@ def test_homscore_a1_local_and_subranges(eng):
         want = [oracle.exact_scoreonly(sc, p) for p in ps.items]
         bad = [(i, int(g), w) for i, (g, w) in enumerate(zip(got, want)) if int(g) != w]
         assert not bad, (local, bad[:5])
+
+
+def test_align_a1_goldens(eng):
+    """alignS_ng under -A1 (SpdpScoring.scalar_engines = 2): forwardS1 on the GPU + the ladder, against the
+    reference's -A1 alignments wherever lspS_ng takes the traceback branch; the others (hirschbergS1) come
+    back without an alignment"""
+    from spaln_amd import abi
+    from oracle import host_logic
+    from tests.conftest import golden_files
+    n_ok = n_ls = 0
+    for local in (False, True):
+        cases = [spdg.load(f) for f in golden_files("s1_") if ("local" in f) == local]
+        ref = max(cases, key=lambda fx: fx["intpen"].size)
+        key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
+        for vmf, ubh, sh in sorted({key(fx) for fx in cases}):
+            sub = [fx for fx in cases if key(fx) == (vmf, ubh, sh)]
+            sc = spdg.scoring(ref, scalar_engines=2, max_vmf_space=vmf, ubh=ubh, sh=sh, local=1 if local else 0)
+            ps = abi.ProblemSet()
+            for fx in sub:
+                spdg.problem(fx, ps)
+            res = eng.align_s(sc, ps, allow_partial=True)
+            for fx, p, (score, skl) in zip(sub, ps.items, res):
+                try:
+                    host_logic.align_s(sc, p, simd=1)
+                except host_logic.NeedsScalarEngine:
+                    assert len(skl) == 0
+                    n_ls += 1
+                    continue
+                assert score == int(fx["aln_scr_A1"][0])
+                assert skl.ravel().tolist() == fx["aln_skl_A1"].tolist()
+                n_ok += 1
+    assert n_ok >= 26 and n_ls <= 6
+
+
+def test_forward_s1_subranges_against_oracle(eng):
+    """forwardS1 through the -A1 ladder on random sub-ranges / end-gap flags, global and local"""
+    from spaln_amd import abi, synth
+    from oracle import host_logic
+    from tests.conftest import golden_files
+    fx = spdg.load([f for f in golden_files("s1_") if f.endswith("s1_basic.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 98)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    for local in (0, 1):
+        sc = spdg.scoring(fx, scalar_engines=2, local=local)
+        ps = abi.ProblemSet()
+        for i in range(64):
+            al = int(rng.integers(0, q["a_right"] - 40))
+            ar = int(rng.integers(al + 8, min(al + 300, q["a_right"]) + 1))
+            bl = int(rng.integers(0, q["b_right"] - 500))
+            br = int(rng.integers(bl + (ar - al) // 2 + 20, min(bl + 2500, q["b_right"]) + 1))
+            exg = tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, ar, bl, br, exg, **extra)
+        res = eng.align_s(sc, ps, allow_partial=True)
+        bad, n_ok = [], 0
+        for i, (p, (score, skl)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = host_logic.align_s(sc, p, simd=1)
+            except (host_logic.NeedsScalarEngine, host_logic.ReferenceUndefined):
+                continue
+            n_ok += 1
+            if score != ws or skl.ravel().tolist() != (wskl or []):
+                bad.append((local, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws,
+                            skl.ravel().tolist()[:12], (wskl or [])[:12]))
+        assert n_ok >= 40 and not bad, bad[:3]

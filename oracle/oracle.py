@@ -147,6 +147,21 @@ def exact_forward(sc, p, w=None):
     return s.value, out, rc
 
 
+def exact_udh(sc, p, n_im: int, w=None):
+    """SimdAln2s1::hirschbergS1 (-A1, non-local): (score, cpos rows, written-back ranges)"""
+    w = w or stripe(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.zeros((n_im + 1, 10), dtype=np.int32)
+    cpos[:, 0] = abi.END_OF_ULK
+    cpos[:, 2] = abi.END_OF_ULK
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_exact_udh(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.byref(s),
+                             cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"orc_exact_udh rc={rc}")
+    return s.value, cpos, rng
+
+
 # ---- protein x genome ------------------------------------------------------------------
 def stripe31(p: abi.ProblemH, sh: int) -> abi.Window:
     w = abi.Window()

@@ -66,8 +66,7 @@ typedef struct SpdpScoring {
                                         1: algmode.alg == 0 (-A0): spdp_align_s runs forwardS_ng /
                                         hirschbergS_ng throughout, spdp_homscore_s scorealoneS_ng;
                                         2: algmode.alg == 1 (-A1): spdp_homscore_s runs scoreonlyS1,
-                                        spdp_align_s forwardS1 (hirschbergS1 is not built: queries whose
-                                        ladder goes linear-space come back without an alignment) */
+                                        spdp_align_s forwardS1 / hirschbergS1 (non-local ends) */
     int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
 } SpdpScoring;
 

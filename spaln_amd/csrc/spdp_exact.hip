@@ -32,9 +32,15 @@ __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      
 // the start of every diagonal run and two per accepted intron (appended through a per-problem atomic
 // counter: record numbers differ from the reference's, the chains do not), then Vmf::traceback and the
 // fix-up of trcbkalignS_ng by lane 0.
-template <bool FORWARD>
+// MODE 2: hirschbergS1 (src/fwd2s1_simd.cc:775-1150, non-local) -- the pointer lanes carry links (the diagonal at
+// which the path crossed the previous intermediate row); the lane holding an intermediate row stores and
+// restarts them; spdp_udh_cpos (strict form) walks them back afterwards.
+template <int MODE>
 __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 {
+    constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
+    constexpr bool UDH = MODE == 2;             // links, intermediate rows
+    constexpr bool PTR = MODE != 0;             // a pointer / link rides on H, E, F
     const int k = threadIdx.x & 15;
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (pi >= A.n_probs) return;                 // a whole 16-lane group leaves together
@@ -53,6 +59,11 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     const uint8_t* aux = A.aux + 2 * P.col_off;  // {bit0 donor | bit1 acceptor, dinc5 << 4 | dinc3}
     int* hv = A.work + P.bnd_off - lw + 1;       // by diagonal, in place like the reference's hv / fv
     int* fv = hv + P.buf_size;
+    const int width = P.width;
+    int* imd0 = A.imd + (UDH ? P.imd_off : 0);   // udh: hlnk[2], vlnk[2] per intermediate, `width` ints each
+    auto LNK = [&](int i, int which, int d, int r) -> int& { return imd0[((int64_t) i * 4 + which * 2 + d) * width + (r - lw + 1)]; };
+    const int n_im = UDH ? P.n_im : 0;
+    const int imd_step = UDH ? (a_right - a_left + n_im) / (n_im + 1) : 0;
     int* hb = fv + P.buf_size;                   // forward: diagonal flag, pointers of H and F
     int* hc = hb + P.buf_size;
     int* fc = hc + P.buf_size;
@@ -92,6 +103,16 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 else if (r < rl) c = b_exgl ? 0 : 1;
                 hb[r] = 0; hc[r] = c; fc[r] = c;
             }
+            if constexpr (UDH) {                     // the Hirschberg part (:206-227): link = diagonal where the path starts
+                const int ru = up + 2 * XN;
+                int c = 0;
+                if (r >= rl) { if (a_exgl) c = (r < ru) ? r : 0; else c = (r <= ru) ? rl : 0; }
+                else c = b_exgl ? r : rl;
+                hc[r] = c; fc[r] = c;
+            }
+        }
+        if constexpr (UDH) {
+            for (int e = k; e < n_im * 4 * width; e += XN) imd0[e] = 0x7fffffff - 2;    // end_of_ulk
         }
         if constexpr (FORWARD) {
             if (k == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(a_left, b_left, 0); *vcount = 2; }
@@ -100,6 +121,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     int maxh = XNEV, max_ulk = 0, max_mr = a_right, max_nr = b_right;
+    int imd_i = 0, rlst = 0x7fffffff;            // udh: current intermediate, hs1.rlst
     for (int ml = a_left; ml < a_right; ml += XN) {
         const int j9 = min(XN, a_right - ml);
         const int j8 = j9 - 1;
@@ -114,6 +136,19 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 #pragma unroll
         for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = 0; idx[i] = i; }
         const int m = ml + 1 + k;                             // my row
+        // udh: is the current intermediate row in this stripe, and on which lane
+        int mm_ = 0, k9 = 0, k8 = -1;
+        bool is_imd_ = false;
+        if constexpr (UDH) {
+            if (imd_i < n_im) {
+                const int mi = a_left + (imd_i + 1) * imd_step;
+                mm_ = a_left + (mi - a_left - 1) / XN * XN;
+                k9 = mi - mm_; k8 = k9 - 1;
+                is_imd_ = ml == mm_;
+            }
+        }
+        const bool imd_here = UDH && is_imd_ && k == k8;     // my row is the intermediate row (m == imd->mi)
+        (void) k9;
         const int* mrow = sc->mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
         for ( ; n < n9; ++n, ++r) {
             const int r0 = r - 2 * j8;
@@ -125,28 +160,30 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 bH1 = __builtin_nontemporal_load(&hv[r + 1]);
                 bF1 = __builtin_nontemporal_load(&fv[r + 1]);
                 bH2 = __builtin_nontemporal_load(&hv[r]);
-                if constexpr (FORWARD) {
+                if constexpr (PTR) {
                     bC1 = __builtin_nontemporal_load(&hc[r + 1]); bFC1 = __builtin_nontemporal_load(&fc[r + 1]);
-                    bB2 = __builtin_nontemporal_load(&hb[r]); bC2 = __builtin_nontemporal_load(&hc[r]);
+                    bC2 = __builtin_nontemporal_load(&hc[r]);
                 }
+                if constexpr (FORWARD) bB2 = __builtin_nontemporal_load(&hb[r]);
             }
             int upH1 = x_up(H1), upF1 = x_up(F1), upH2 = x_up(H2);
             int upC1 = 0, upFC1 = 0, upB2 = 0, upC2 = 0;
-            if constexpr (FORWARD) { upC1 = x_up(C1); upFC1 = x_up(FC1); upB2 = x_up(B2); upC2 = x_up(C2); }
+            if constexpr (PTR) { upC1 = x_up(C1); upFC1 = x_up(FC1); upC2 = x_up(C2); }
+            if constexpr (FORWARD) upB2 = x_up(B2);
             if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; }
             // insertion, deletion, diagonal
             {
                 const int open = x_sadd(H1, gn), ext = x_sadd(E, ge);
                 const bool m_ = ext > open;
                 E = m_ ? ext : open;
-                if constexpr (FORWARD) EC = m_ ? EC : C1;
+                if constexpr (PTR) EC = m_ ? EC : C1;
             }
             int F, FC = 0;
             {
                 const int open = x_sadd(upH1, gn), ext = x_sadd(upF1, ge);
                 const bool m_ = ext > open;
                 F = m_ ? ext : open;
-                if constexpr (FORWARD) FC = m_ ? upFC1 : upC1;
+                if constexpr (PTR) FC = m_ ? upFC1 : upC1;
             }
             int pv = 0;
             const bool incell = nj <= b_right && nj > b_left && k < j9;     // kb <= k < ke
@@ -158,7 +195,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             int code = 0;                                     // diag: 0, hori: 1, vert: 2 (pv_a)
             if (F > H) { H = F; HC = FC; code = 2; }
             if (E > H) { H = E; HC = EC; code = 1; }
-            const int hb_pv = code;
+            int hb_pv = code;
             if (spj) ps &= code;
             if (!local) { if (!(H > XNEV)) H = XNEV; }
             else if (LocalL) { if (0 > H) { H = 0; code = 1; HC = 0; } }
@@ -187,6 +224,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 if (fl & 2) {                                 // acceptor: Sjsites::get
                     const int s3 = col.x >> 16;
                     const int d3 = aux[2 * nj + 1] & 15;
+                    int mx_ci[3] = {-1, -1, -1}, br_ci = -1;  // udh: maxprd[d], brd (as candidate slots)
                     for (int l = 0; l <= ncand; ++l) {
                         const int ci = idx[l];
                         const int d = c_dir[ci], don = c_jnc[ci];
@@ -206,7 +244,30 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                             if (d == 0) { HB = bml; HC = ptr; } else if (d == 1) { EB = bml; EC = ptr; } else { FB = bml; FC = ptr; }
                             if (d && cur > H) { HB = bml; HC = ptr; }
                         }
+                        if constexpr (UDH) {
+                            if (mx_ci[d] < 0 || x > c_val[mx_ci[d]]) {
+                                mx_ci[d] = ci;
+                                if (br_ci < 0 || x > c_val[br_ci]) br_ci = ci;
+                            }
+                            const int lk = c_ulk[ci];
+                            if (d == 0) HC = lk; else if (d == 1) EC = lk; else FC = lk;
+                            if (d && cur > H) HC = lk;
+                        }
                         if (d && cur > H) H = cur;
+                    }
+                    if constexpr (UDH) {
+                        if (imd_here && br_ci >= 0) {             // the acceptor sits on the intermediate row (:91-110)
+                            const int maxd = c_dir[br_ci];
+                            const int lk = c_ulk[mx_ci[maxd]];
+                            LNK(imd_i, 0, 0, rj) = lk; rlst = rj;
+                            if (maxd == 0) HC = rj; else if (maxd == 1) EC = rj; else FC = rj;
+                            hb_pv = maxd;
+                            if (maxd != 0) HC = rj;
+                            else {
+                                if (mx_ci[1] >= 0 && E > H + gop) EC = rj + width;
+                                if (mx_ci[2] >= 0 && F > H + gop) { LNK(imd_i, 0, 1, rj) = lk; FC = rj + width; }
+                            }
+                        }
                     }
                 }
                 if (fl & 1) {                                 // donor: Sjsites::put
@@ -229,18 +290,36 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                                 c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
                                 c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
                             }
+                            if constexpr (UDH) {
+                                if (imd_here) { if (kk & 1) LNK(imd_i, 0, 0, rj) = rlst; c_ulk[ci] = rj; }
+                                else c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                            }
                         }
                         else --ncand;
                     }
                 }
             }
+            if constexpr (UDH) {                              // intermediate row: lane k8 of its stripe (:1043-1052)
+                const int rq = r - 2 * k8;
+                if (is_imd_ && k == k8 && rq >= lw && rq <= up) {
+                    if (hb_pv == 0) rlst = rq;
+                    if (hb_pv == 1) LNK(imd_i, 0, 0, rq) = rlst;
+                    LNK(imd_i, 1, 0, rq) = HC; HC = rq;
+                    LNK(imd_i, 1, 1, rq) = FC; FC = rq + width;
+                }
+            }
             // bottom row of the stripe -> boundary arrays
             if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) {
                 hv[r0] = H; fv[r0] = F;
-                if constexpr (FORWARD) { hb[r0] = HB; hc[r0] = HC; fc[r0] = FC; }
+                if constexpr (FORWARD) hb[r0] = HB;
+                if constexpr (PTR) { hc[r0] = HC; fc[r0] = FC; }
             }
             H2 = H1; H1 = H; F1 = F;
-            if constexpr (FORWARD) { B2 = B1; B1 = HB; C2 = C1; C1 = HC; FC1 = FC; }
+            if constexpr (FORWARD) { B2 = B1; B1 = HB; }
+            if constexpr (PTR) { C2 = C1; C1 = HC; FC1 = FC; }
+        }
+        if constexpr (UDH) {
+            if (is_imd_) { rlst = __shfl(rlst, k8, XN); ++imd_i; }       // hs1.rlst is one variable for all lanes
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
@@ -269,7 +348,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             R.score = __builtin_nontemporal_load(&hv[maxr]);
             R.maxr = maxr;
             if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
-            if constexpr (FORWARD) end_ulk = __builtin_nontemporal_load(&hc[maxr]);
+            if constexpr (PTR) end_ulk = __builtin_nontemporal_load(&hc[maxr]);
         }
         if constexpr (FORWARD) {
             const int ptr = vadd(R.mr, R.nr, end_ulk);
@@ -297,15 +376,17 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             }
             A.n_skl[pi] = status ? status : cnt;
         }
+        if constexpr (UDH) R.ulk = end_ulk;
         A.res[pi] = R;
     }
 }
 
-extern "C" hipError_t spdp_launch_exact(int forward, const ScalarArgs* a, hipStream_t stream)
+extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
     const dim3 grd((A.n_probs + 3) / 4), blk(64);
-    if (forward) hipLaunchKernelGGL(spdp_exact<true>, grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL(spdp_exact<false>, grd, blk, 0, stream, A);
+    if (mode == 2) hipLaunchKernelGGL(spdp_exact<2>, grd, blk, 0, stream, A);
+    else if (mode == 1) hipLaunchKernelGGL(spdp_exact<1>, grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL(spdp_exact<0>, grd, blk, 0, stream, A);
     return hipGetLastError();
 }

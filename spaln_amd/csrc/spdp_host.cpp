@@ -234,7 +234,7 @@ struct Aligner {
         }
         if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
         if (sc.scalar_engines == 1 && !st->has_exact) { ++unsupported; J.failed = true; return true; }
-        if (sc.scalar_engines == 2) { ++unsupported; J.failed = true; return true; }     // hirschbergS1: not built
+        if (sc.scalar_engines == 2 && (!st->has_exact || sc.local)) { ++unsupported; J.failed = true; return true; }
         udh.push_back({it.job, r, it.w, it.top, n_imd, recursive, intvl});
         return true;
     }
@@ -342,7 +342,7 @@ struct Aligner {
             }
             DevRun run;
             const bool a0 = sc.scalar_engines == 1;
-            if (run.build(st, items, a0 ? 5 : 2)) return -1;
+            if (run.build(st, items, a0 ? 5 : (sc.scalar_engines == 2 ? 8 : 2))) return -1;
             lap("udh build");
             if (run.launch() || run.sync()) return -1;
             lap("udh launch+sync");

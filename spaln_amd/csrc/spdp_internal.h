@@ -44,6 +44,7 @@ struct CposArgs {
     int*              ranges;     // per problem 4 ints
     int*              scores;
     int               cpos_stride;
+    int               strict;     // 1: the -A1 form of the walk (hirschbergS1: r > up, lw <= vlnk)
 };
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
@@ -78,7 +79,7 @@ struct ScalarArgs {
 };
 extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
-extern "C" hipError_t spdp_launch_exact(int forward, const ScalarArgs* a, hipStream_t s);    // spdp_exact.hip
+extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t s);   // spdp_exact.hip: 0 score, 1 forward, 2 udh
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
@@ -189,7 +190,7 @@ struct RunItem {
 // descriptors + work buffers of one engine flavour over a DevStore:
 // 0 score, 1 forward, 2 udh (the _wip sweeps); 3 scalar exact forward, 4 scalar exact score,
 // 5 scalar udh, 6 -A1 score-only (both share pool 4 with the scalar score run: they never coexist),
-// 7 -A1 forward (shares pool 3 with the scalar forward run)
+// 7 -A1 forward (shares pool 3 with the scalar forward run), 8 -A1 udh (pool 4)
 struct DevRun {
     SpdpContext* ctx = nullptr;
     const DevStore* store = nullptr;

@@ -852,9 +852,10 @@ __global__ void spdp_udh_cpos(CposArgs A)
     int r = R.ulk;
     for ( ; i >= 0 && MI(i) > max_ml; --i) {
         int c = 0, d = 0;
-        for ( ; r >= up; r -= width) ++d;
+        if (A.strict) { for ( ; r > up; r -= width) ++d; }
+        else { for ( ; r >= up; r -= width) ++d; }
         const int vl = LNK(i, 1, d, r);
-        if (lw < vl && vl < up) {
+        if ((A.strict ? lw <= vl : lw < vl) && vl < up) {
             CPOS(i, c++) = MI(i);
             CPOS(i, c++) = (d > 0) ? 1 : 0;
             for (int rp = LNK(i, 0, d, r); lw <= rp && rp < up && r != rp; rp = LNK(i, 0, d, r = rp)) {

@@ -289,9 +289,8 @@ def test_homscore_a1_local_and_subranges(eng):
 
 
 def test_align_a1_goldens(eng):
-    """alignS_ng under -A1 (SpdpScoring.scalar_engines = 2): forwardS1 on the GPU + the ladder, against the
-    reference's -A1 alignments wherever lspS_ng takes the traceback branch; the others (hirschbergS1) come
-    back without an alignment"""
+    """alignS_ng under -A1 (SpdpScoring.scalar_engines = 2): forwardS1 / hirschbergS1 on the GPU + the ladder,
+    against the reference's -A1 alignments (all fixtures: traceback and linear-space branches)"""
     from spaln_amd import abi
     from oracle import host_logic
     from tests.conftest import golden_files
@@ -317,7 +316,7 @@ def test_align_a1_goldens(eng):
                 assert score == int(fx["aln_scr_A1"][0])
                 assert skl.ravel().tolist() == fx["aln_skl_A1"].tolist()
                 n_ok += 1
-    assert n_ok >= 26 and n_ls <= 6
+    assert n_ok == 32 and n_ls == 0
 
 
 def test_forward_s1_subranges_against_oracle(eng):
@@ -352,3 +351,38 @@ def test_forward_s1_subranges_against_oracle(eng):
                 bad.append((local, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws,
                             skl.ravel().tolist()[:12], (wskl or [])[:12]))
         assert n_ok >= 40 and not bad, bad[:3]
+
+
+def test_a1_ladder_linear_space_against_oracle(eng):
+    """alignS_ng under -A1 pushed into the linear-space branches (small MaxVmfSpace: recurrent and recursive)
+    on sub-ranges, vs the oracle ladder (hirschbergS1 + forwardS1 per slab)"""
+    from spaln_amd import abi, synth
+    from oracle import host_logic
+    from tests.conftest import golden_files
+    fx = spdg.load([f for f in golden_files("s1_") if f.endswith("s1_auto_udh.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 99)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    for vmf, ubh in ((600000, 0), (100000, 3), (40000, 0)):
+        sc = spdg.scoring(fx, scalar_engines=2, max_vmf_space=vmf, ubh=ubh)
+        ps = abi.ProblemSet()
+        for i in range(16):
+            al = int(rng.integers(0, 400))
+            ar = int(rng.integers(al + 300, min(al + 600, q["a_right"]) + 1))
+            bl = int(rng.integers(0, 500))
+            br = int(rng.integers(q["b_right"] - 1500, q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 2 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, ar, bl, br, exg, **extra)
+        res = eng.align_s(sc, ps, allow_partial=True)
+        bad, n_ok = [], 0
+        for i, (p, (score, skl)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = host_logic.align_s(sc, p, simd=1)
+            except (host_logic.NeedsScalarEngine, host_logic.ReferenceUndefined):
+                continue
+            n_ok += 1
+            if score != ws or skl.ravel().tolist() != (wskl or []):
+                bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws,
+                            skl.ravel().tolist()[:12], (wskl or [])[:12]))
+        assert n_ok >= 12 and not bad, bad[:3]

@@ -61,9 +61,9 @@ def test_homscore_s_ng_goldens(alg):
 
 
 def test_align_a1_traceback_branch():
-    """alignS_ng under -A1 wherever lspS_ng takes the traceback branch: forwardS1 (vector H / E / F, exact
-    per-lane intron lists, Vmf pointers riding on the states) + Vmf::traceback + stdskl / trimskl, against
-    the reference's -A1 output; the linear-space branch would need hirschbergS1 (not restated)"""
+    """alignS_ng under -A1 end to end: forwardS1 (vector H / E / F, exact per-lane intron lists, Vmf pointers
+    riding on the states) + Vmf::traceback in the traceback branch, hirschbergS1 + per-slab forwardS1 in the
+    linear-space branches, stdskl / trimskl -- against the reference's -A1 output on every fixture"""
     from tests.conftest import golden_files
     n_ok = n_skip = 0
     for f in golden_files("s1_"):
@@ -78,4 +78,4 @@ def test_align_a1_traceback_branch():
         assert scr == int(fx["aln_scr_A1"][0]), f
         assert (flat or []) == fx["aln_skl_A1"].tolist(), f
         n_ok += 1
-    assert n_ok >= 26 and n_skip <= 6
+    assert n_ok == 32 and n_skip == 0

@@ -33,9 +33,9 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_WINST_S = 0.62e9 * 1024
 VALU_PER_CELL = {"udh": 1.9475e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3136e10 / 3.0943e10}
 # FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
-PMC_TRAFFIC_BYTES = int((70312554 + 207449824) * 1024)
+PMC_TRAFFIC_BYTES = int((69879445 + 206684966) * 1024)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((38104022 + 146635754) * 1024)
+PMC_TRAFFIC_BYTES_H = int((37931084 + 146762151) * 1024)
 
 
 def _cpu_align_one(item):

@@ -68,6 +68,8 @@ typedef struct SpdpScoring {
                                         2: algmode.alg == 1 (-A1): spdp_homscore_s runs scoreonlyS1,
                                         spdp_align_s forwardS1 / hirschbergS1 (non-local ends) */
     int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
+    int32_t recursive;               /* algmode.alg & 4 (-A4 .. -A7): lspS_ng always takes the recursive
+                                        linear-space branch (one intermediate row, halves of halves)   */
 } SpdpScoring;
 
 typedef struct SpdpProblem {
@@ -283,6 +285,7 @@ typedef struct SpdpScoringH {
     int32_t minl;                    /* IntronPrm.minl (scalar engine: shortest intron; 0 = llmt)   */
     int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3); 1: algmode.alg == 0 (-A0):
                                         spdp_align_h / spdp_homscore_h run forwardH_ng / hirschbergH_ng */
+    int32_t recursive;               /* algmode.alg & 4: lspH_ng always takes the recursive branch    */
 } SpdpScoringH;
 
 typedef struct SpdpProblemH {

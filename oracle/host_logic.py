@@ -123,22 +123,23 @@ def lsp(sc, p, w, rec, simd=2):
         cvol = _f32(_f32(m) * _f32(n + m))
     if _f32(coef_B * cvol) < sc.max_vmf_space:
         return trcbk(sc, p, w, rec, simd)
-    recursive = False
+    recursive = bool(sc.recursive)                      # algmode.alg & 4 (-A4 .. -A7)
     n_imd = 1
     imd_intvl = (m + 1) // 2
-    z = 2.0 * m * coef_B / coef_C
-    imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
-    spc = _f32(_f32(_f32(coef_C * n) * imd1) + _f32(_f32(_f32(coef_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
-    if spc > sc.max_vmf_space:
-        recursive = True
-    else:
-        imd3 = m // NELEM
-        n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
-        intvl = imd_intvl = (m + n_imd) // (n_imd + 1)
-        if intvl * n_imd == m:
-            n_imd -= 1
-        if n_imd == 0:
-            return trcbk(sc, p, w, rec, simd)
+    if not recursive:
+        z = 2.0 * m * coef_B / coef_C
+        imd1 = int(math.pow(z, 1.0 / 3) + 0.5) - 1
+        spc = _f32(_f32(_f32(coef_C * n) * imd1) + _f32(_f32(_f32(coef_B * cvol) / (imd1 + 1)) / (imd1 + 1)))
+        if spc > sc.max_vmf_space:
+            recursive = True
+        else:
+            imd3 = m // NELEM
+            n_imd = sc.ubh if sc.ubh else min(imd1, imd3)
+            intvl = imd_intvl = (m + n_imd) // (n_imd + 1)
+            if intvl * n_imd == m:
+                n_imd -= 1
+            if n_imd == 0:
+                return trcbk(sc, p, w, rec, simd)
     if simd == 0:
         scr, cpos, rng, flag = oracle.scalar_udh(sc, p, n_imd, imd_intvl, w)
         if flag:

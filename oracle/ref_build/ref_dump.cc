@@ -269,7 +269,8 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 
 // (2) the Aln2 surface per engine selector -A0..3 (algmode.alg & 3, fwd2s1.cc:112).
 //     -A3 goes last: its Aln2s1 ctor sets IntronPrm.nquant = 1 for good.
-	for (int alg = 0; alg < 4; ++alg) {
+	for (int alg = 0; alg < 7; ++alg) {
+	    if (alg == 4 || alg == 5) continue;	// 6 = -A2 with the recursive switch (algmode.alg & 4)
 	    algmode.alg = alg;
 	    restore();
 	    VTYPE	hs = HomScoreS_ng((const Seq**) seqs, pwd);

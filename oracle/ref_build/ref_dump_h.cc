@@ -192,7 +192,8 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	    }
 	}
 	IntronPrm.nquant = nq0;
-	for (int alg = 0; alg < 4; ++alg) {
+	for (int alg = 0; alg < 7; ++alg) {
+	    if (alg == 4 || alg == 5) continue;	// 6 = -A2 with the recursive switch (algmode.alg & 4)
 	    if (alg == 1) continue;	// -A1 (forwardH1 / exact SIMD) is not part of these fixtures
 	    algmode.alg = alg;
 	    restore();

@@ -38,6 +38,7 @@ class Scoring(C.Structure):
         ("t53", C.c_int16 * 256),
         ("scalar_engines", C.c_int32),
         ("minl", C.c_int32),
+        ("recursive", C.c_int32),
     ]
 
 
@@ -85,7 +86,7 @@ class Rescored(C.Structure):
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,
-                 intpen=None, t53=None, scalar_engines=0, minl=0) -> Scoring:
+                 intpen=None, t53=None, scalar_engines=0, minl=0, recursive=0) -> Scoring:
     sc = Scoring()
     sc.mtx_dim = int(mtx_dim)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -104,6 +105,7 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
     sc.max_vmf_space, sc.ubh, sc.ref_nelem = int(max_vmf_space), int(ubh), int(ref_nelem)
     sc.scalar_engines = int(scalar_engines)
     sc.minl = int(minl)
+    sc.recursive = int(recursive)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip                      # keep the buffer alive with the struct
@@ -182,6 +184,7 @@ class ScoringH(C.Structure):
         ("t53", C.c_int16 * 256),
         ("minl", C.c_int32),
         ("scalar_engines", C.c_int32),
+        ("recursive", C.c_int32),
     ]
 
 
@@ -209,7 +212,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
                    ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
-                   intpen=None, t53=None, minl=0, scalar_engines=0) -> ScoringH:
+                   intpen=None, t53=None, minl=0, scalar_engines=0, recursive=0) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -231,6 +234,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
     sc.diffu, sc.k1 = int(diffu), int(k1)
     sc.minl = int(minl)
     sc.scalar_engines = int(scalar_engines)
+    sc.recursive = int(recursive)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip

@@ -598,10 +598,10 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
         cvol = float(m) * n - (k * k + q * q) / 6;
     }
     if (coef_B * cvol < sc.max_vmf_space) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
-    bool recursive = false;
+    bool recursive = sc.recursive != 0;                      // algmode.alg & 4
     int n_imd = 1;
     it.imd_intvl = (m + 1) / 2;
-    {
+    if (!recursive) {
         const double z = 2. * m * coef_B / coef_C;
         const int imd1 = int(pow(z, 1. / 3) + 0.5) - 1;
         const float spc = coef_C * n * imd1 + coef_B * cvol / (imd1 + 1) / (imd1 + 1);

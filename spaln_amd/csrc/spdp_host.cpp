@@ -209,7 +209,7 @@ struct Aligner {
         }
         if (abs(n - m) < 8 || m == 1 || n == 1) { trcbk(it.job, r, it.w, it.top); return true; }
         int n_imd = 1;
-        bool recursive = false;                 // algmode.alg & 4 (-A4..7) not offered
+        bool recursive = sc.recursive != 0;     // algmode.alg & 4 (-A4 .. -A7)
         float cvol = float(m) * (n + m);        // rhombic, simd >= 2
         if (sc.scalar_engines >= 1) {           // hexagonal, simd < 2 (src/fwd2s1.cc:1830-1833)
             const float k = it.w.lw - r.bl + r.ar;
@@ -218,7 +218,7 @@ struct Aligner {
         }
         if (kCoefB * cvol < sc.max_vmf_space) { trcbk(it.job, r, it.w, it.top); return true; }
         int intvl = (m + 1) / 2;
-        {
+        if (!recursive) {
             const float coef_C = (sc.noll + 1) * sizeof(int);
             const double z = 2. * m * kCoefB / coef_C;
             const int imd1 = int(pow(z, 1. / 3) + 0.5) - 1;

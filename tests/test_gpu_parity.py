@@ -386,3 +386,24 @@ def test_a1_ladder_linear_space_against_oracle(eng):
                 bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws,
                             skl.ravel().tolist()[:12], (wskl or [])[:12]))
         assert n_ok >= 12 and not bad, bad[:3]
+
+
+def test_align_a6_recursive_switch(eng):
+    """-A6 (algmode.alg & 4 with the `_wip` engines): SpdpScoring.recursive sends lspS_ng down the recursive
+    linear-space branch; against the reference's -A6 output (flat penalty model, see the CPU test)"""
+    from spaln_amd import abi
+    from tests.conftest import golden_files
+    for local in (False, True):
+        cases = [spdg.load(f) for f in golden_files("s1_") if ("local" in f) == local]
+        ref = max(cases, key=lambda fx: fx["intpen"].size)
+        key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
+        for vmf, ubh, sh in sorted({key(fx) for fx in cases}):
+            sub = [fx for fx in cases if key(fx) == (vmf, ubh, sh)]
+            sc = spdg.scoring(ref, nquant=1, recursive=1, max_vmf_space=vmf, ubh=ubh, sh=sh, local=1 if local else 0)
+            ps = abi.ProblemSet()
+            for fx in sub:
+                spdg.problem(fx, ps)
+            res = eng.align_s(sc, ps)
+            for fx, (score, skl) in zip(sub, res):
+                assert score == int(fx["aln_scr_A6"][0])
+                assert skl.ravel().tolist() == fx["aln_skl_A6"].tolist()

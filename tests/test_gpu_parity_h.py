@@ -248,3 +248,20 @@ def test_skl_rng_h_goldens(eng):
             if not ok:
                 bad.append((_name(f), alg, score, int(fx[f"rng_scr_A{alg}"][0]), fst, fx[f"rng_fstat_A{alg}"][:5].tolist()))
     assert n_checked >= 60 and not bad, bad[:4]
+
+
+def test_align_h_a6_recursive_switch(eng):
+    """SpdpScoringH.recursive (algmode.alg & 4): lspH_ng's recursive branch, against the reference's -A6 output"""
+    cases = [(n, fx) for n, fx in _cases(3) if n not in UNDEFINED]
+    key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
+    for vmf, ubh, sh in sorted({key(fx) for _, fx in cases}):
+        sub = [(n, fx) for n, fx in cases if key(fx) == (vmf, ubh, sh)]
+        sc = spdg.scoring_h(max((fx for _, fx in sub), key=lambda fx: fx["intpen"].size), nquant=1, recursive=1,
+                            max_vmf_space=vmf, ubh=ubh, sh=sh)
+        ps = abi.ProblemSetH()
+        for _, fx in sub:
+            spdg.problem_h(fx, ps)
+        res = eng.align_h(sc, ps)
+        for (name, fx), (score, skl, flag) in zip(sub, res):
+            assert flag == 0 and score == int(fx["aln_scr_A6"][0]), name
+            assert skl.ravel().tolist() == fx["aln_skl_A6"].tolist(), name

@@ -79,3 +79,26 @@ def test_align_a1_traceback_branch():
         assert (flat or []) == fx["aln_skl_A1"].tolist(), f
         n_ok += 1
     assert n_ok == 32 and n_skip == 0
+
+
+def test_align_a6_recursive_switch():
+    """-A6 = the `_wip` engines with algmode.alg & 4: lspS_ng / lspH_ng always take the recursive
+    linear-space branch once the traceback does not fit (SpdpScoring[H].recursive).  The harness runs it
+    after -A3, whose engine constructor leaves IntronPrm.nquant = 1 behind (src/fwd2s1.cc:130), so the
+    fixtures hold the flat-penalty model with the recursive ladder."""
+    from tests.conftest import golden_files
+    from oracle import host_logic_h
+    for f in golden_files("s1_"):
+        fx = spdg.load(f)
+        sc = spdg.scoring(fx, nquant=1, recursive=1)
+        _, p = spdg.problem(fx)
+        scr, flat = host_logic.align_s(sc, p)
+        assert scr == int(fx["aln_scr_A6"][0]) and (flat or []) == fx["aln_skl_A6"].tolist(), f
+    for f in golden_files("h1_"):
+        fx = spdg.load(f)
+        if f.endswith("h1_cut_right.spdg") or f.endswith("h1_random.spdg"):
+            continue                                   # undefined in the reference (see test_oracle_h_golden)
+        sc = spdg.scoring_h(fx, nquant=1, recursive=1)
+        _, p = spdg.problem_h(fx)
+        scr, flat = host_logic_h.align_h(sc, p)
+        assert scr == int(fx["aln_scr_A6"][0]) and (flat or []) == fx["aln_skl_A6"].tolist(), f

@@ -194,12 +194,16 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	IntronPrm.nquant = nq0;
 	for (int alg = 0; alg < 7; ++alg) {
 	    if (alg == 4 || alg == 5) continue;	// 6 = -A2 with the recursive switch (algmode.alg & 4)
-	    if (alg == 1) continue;	// -A1 (forwardH1 / exact SIMD) is not part of these fixtures
+
 	    algmode.alg = alg;
 	    restore();
-	    VTYPE	hs = HomScoreH_ng((const Seq**) seqs, pwd);
-	    snprintf(nm, sizeof nm, "hom_scr_A%d", alg);
-	    w.put_int(nm, (int) hs);
+	    // HomScoreH_ng under -A1 (forwardH1 without a Vmf) stops with SIGSEGV in the reference itself; the CLI
+	    // never takes that path for proteins, so only the alignment is recorded for that mode
+	    if (alg != 1) {
+		VTYPE	hs = HomScoreH_ng((const Seq**) seqs, pwd);
+		snprintf(nm, sizeof nm, "hom_scr_A%d", alg);
+		w.put_int(nm, (int) hs);
+	    }
 	    restore();
 	    Gsinfo	gsi;
 	    gsi.skl = alignH_ng((const Seq**) seqs, pwd, &gsi);

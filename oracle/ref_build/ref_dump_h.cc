@@ -192,8 +192,9 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	    }
 	}
 	IntronPrm.nquant = nq0;
-	for (int alg = 0; alg < 7; ++alg) {
-	    if (alg == 4 || alg == 5) continue;	// 6 = -A2 with the recursive switch (algmode.alg & 4)
+	static const int alg_order[] = {0, 2, 3, 6, 1};	// 6 = -A2 with the recursive switch (algmode.alg & 4);
+	for (int ai = 0; ai < 5; ++ai) {		// -A1 last: it leaves state behind that changes later runs
+	    const int alg = alg_order[ai];
 
 	    algmode.alg = alg;
 	    restore();

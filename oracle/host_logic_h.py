@@ -67,6 +67,14 @@ def trcbk_h(sc, p, w, rec, simd=2):
         s, skl = oracle.scalar_forward_h(sc, p, w)
         rec.extend((int(m), int(n)) for m, n in skl)
         return s
+    if simd == 1:                                         # forwardH1 (modes 3 / 5) + Vmf::traceback
+        if not sc.intpen or not p.dinc:
+            raise NotRestated("forwardH1 without its inputs (intpen / t53 / dinc)")
+        s, skl, bad = oracle.exact_forward_h(sc, p, w)
+        if bad == -3:
+            raise ReferenceUndefined("Vmf pointer beyond an int16 lane")
+        rec.extend((int(m), int(n)) for m, n in skl)
+        return s
     s, skl, bad = oracle.wip_forward_h(sc, p, w)
     if bad == -2:
         raise ReferenceFatal("Unexpected dir")
@@ -113,8 +121,10 @@ def lsp_h(sc, p, w, rec, simd=2):
             if n_imd == 0:
                 return trcbk_h(sc, p, w, rec, simd)
     if simd == 1:
-        raise NotRestated("hirschbergH1 (linear space under -A1)")
-    if simd == 0:
+        if not sc.intpen or not p.dinc:
+            raise NotRestated("hirschbergH1 without its inputs (intpen / t53 / dinc)")
+        scr, cpos, rng = oracle.exact_udh_h(sc, p, n_imd, w)
+    elif simd == 0:
         scr, cpos, rng, flag = oracle.scalar_udh_h(sc, p, n_imd, imd_intvl, w)
         if flag:
             raise ReferenceUndefined("hirschbergH_ng outside its arrays")

@@ -201,6 +201,35 @@ def wip_udh_h(sc, p, n_im: int, w=None):
     return s.value, cpos, rng
 
 
+def exact_forward_h(sc, p, w=None):
+    """SimdAln2h1::forwardH1 + Vmf traceback + the record hand-over of trcbkalignH_ng (-A1):
+    (score, records end -> start, flag); flag -3: mode 3 pointer overflow in the reference (undefined)."""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_exact_forward_h(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
+    if rc not in (0, -3):
+        raise RuntimeError(f"orc_exact_forward_h rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out, rc
+
+
+def exact_udh_h(sc, p, n_im: int, w=None):
+    """SimdAln2h1::hirschbergH1 (-A1): (score, cpos rows, written-back ranges)"""
+    w = w or stripe31(p, sc.sh)
+    s = C.c_int32()
+    cpos = np.full((n_im + 1, 10), abi.END_OF_ULK, dtype=np.int32)
+    rng = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_exact_udh_h(C.byref(sc), C.byref(p), C.byref(w), C.c_int(n_im), C.byref(s),
+                               cpos.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"orc_exact_udh_h rc={rc}")
+    return s.value, cpos, rng
+
+
 def scalar_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None, traceback=True):
     """Aln2h1::forwardH_ng (+ the record hand-over of trcbkalignH_ng when traceback): the -A0 engine,
     also the -A2/-A3 fallback below 8 query rows.  Returns (score, records end -> start)."""

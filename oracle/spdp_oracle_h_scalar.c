@@ -891,3 +891,698 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
     free(imds); free(wbuf);
     return rc;
 }
+
+/* ======================================================================================== */
+/* The -A1 ("full-precision intron-length distribution") SIMD engines of the protein path.   */
+/*   orc_exact_forward_h  SimdAln2h1::forwardH1 (modes 3 / 5)     src/fwd2h1_simd.h:820-1096  */
+/*                        + fhinitH1 / fhlastH1 with a Vmf        src/fwd2h1_simd.h:546-791   */
+/*                        + Sjsites::get / put, from_spj / to_spj src/fwd2h1_simd.h:388-543, 793-815 */
+/*                        + the record fix-up of trcbkalignH_ng   src/fwd2h1.cc:2019-2036     */
+/*   orc_exact_udh_h      SimdAln2h1::hirschbergH1 (modes 2 / 4)  src/fwd2h1_simd.h:1100-1470 */
+/* 16 int16 lanes, six codon-phase planes (H, F by n mod 6; E and the per-frame side lanes by */
+/* n mod 3) as in the `_wip` engines; the intron model is the scalar engines': each lane keeps */
+/* the top-4 donor candidates (value, junction, state, phase) of its row, an acceptor column   */
+/* re-scores them with the exact IntPen(len) + pair signal and the codon the junction spells.  */
+/* The reference keeps its lane planes from one stripe to the next without clearing the link   */
+/* planes; they are kept alive across stripes here as well.  No cip, no checkpoint re-basing   */
+/* (the score planes of a 16-bit run are not re-based below 0.9 * SHRT_MAX / AvTrc rows).      */
+/* ======================================================================================== */
+#define XN    16
+#define XN1   17
+#define XNEV  (SHRT_MIN + 1024)
+static inline int xsat(int x) { return x < SHRT_MIN ? SHRT_MIN : (x > SHRT_MAX ? SHRT_MAX : x); }
+static inline int xadd(int x, int y) { return xsat(x + y); }
+static inline int xw16(int x) { return (int16_t) x; }
+static inline int xmod6(int x) { x %= 6; return x < 0 ? x + 6 : x; }
+static inline int xgood(const SpdpProblemH* p, int n) { return p->exin_left - 1 <= n && n < p->exin_right; }
+
+typedef struct { int val, ulk, jnc, ml, dir, phs; } XhCand;
+typedef struct { XhCand rcd[5]; int idx[5]; int ncand; } XhSites;
+typedef struct { int q[XN]; int ne, qs, qe; } XhQueue;              /* Queue2<int>(nelem), src/clib.h:397-441 */
+static void xq_clear(XhQueue* q) { memset(q, 0, sizeof *q); }
+static void xq_push(XhQueue* q, int v)
+{
+    q->q[q->qe] = v;
+    if (++q->qe == XN) q->qe = 0;
+    if (q->ne < XN) ++q->ne;
+    else if (++q->qs == XN) q->qs = 0;
+}
+static void xq_pull(XhQueue* q) { if (++q->qs == XN) q->qs = 0; if (q->ne > 0) --q->ne; }
+
+typedef struct { int mi; int *hlnk[2], *vlnk[2]; int* buf; } XhImd;
+
+typedef struct {
+    Ctx cx;
+    const SpdpScoringH* sc;
+    const SpdpProblemH* p;
+    int lw, up, width, buf_size;
+    int a_left, a_right, b_left, b_right;
+    int *hv, *fv, *hb, *fb, *hc, *fc;           /* boundary rows by diagonal */
+    int *mem;
+    int HV[6][XN1], FV[6][XN1], EV[3][XN], QV[3][XN], PS[3][XN], PV[3][XN], CP[3][XN1], SM[XN1];
+    int HB[6][XN1], FB[6][XN1], EB[3][XN], QB[3][XN];
+    int HC[6][XN1], FC[6][XN1], EC[3][XN], QC[3][XN];
+    XhSites sites[XN];
+    XhQueue dq[3], aq[3];
+    Vmf* vmf;                                   /* forward (modes 3 / 5) */
+    XhImd* imd; int mm3; int rlst[3];           /* linear space (modes 2 / 4) */
+    int mode, LocalL, LocalR;
+    int max_val, max_ulk, max_ml, max_mr, max_nr;
+} XhEng;
+
+static int* xh_slot(XhEng* e, int plane, int qq, int j, int d)
+{   /* hfesv / hfesb / hfesc [qq][j][d], d = 0 H, 1 E, 2 F, 3 the diagonal predecessor (fwd2h1_simd.h:301-325) */
+    const int f3 = qq % 3;
+    if (plane == 0) return d == 0 ? &e->HV[qq][j + 1] : d == 1 ? &e->EV[f3][j] : d == 2 ? &e->FV[qq][j + 1] : &e->QV[f3][j];
+    if (plane == 1) return d == 0 ? &e->HB[qq][j + 1] : d == 1 ? &e->EB[f3][j] : d == 2 ? &e->FB[qq][j + 1] : &e->QB[f3][j];
+    return d == 0 ? &e->HC[qq][j + 1] : d == 1 ? &e->EC[f3][j] : d == 2 ? &e->FC[qq][j + 1] : &e->QC[f3][j];
+}
+
+static void xs_reset_h(XhSites* s)
+{
+    s->ncand = -1;
+    for (int i = 0; i <= 4; ++i) {
+        s->rcd[i].val = XNEV; s->rcd[i].ulk = s->rcd[i].jnc = s->rcd[i].ml = s->rcd[i].dir = 0; s->rcd[i].phs = -2;
+        s->idx[i] = i;
+    }
+}
+
+/* Sjsites::get, src/fwd2h1_simd.h:388-494 */
+static void xh_get(XhEng* e, XhSites* s, int j, int m, int n, int q)
+{
+    static const int psp_bit[3] = {4, 1, 8};
+    const SpdpProblemH* p = e->p;
+    const int acc = n - 1;
+    const int r = acc - 3 * (m + 1);
+    const XhCand* maxprd[3] = {0, 0, 0};
+    const XhCand* brd = 0;
+    const int is_imd = e->imd && (m + 1) == e->imd->mi;
+    for (int l = 0; l <= s->ncand; ++l) {
+        const XhCand* prd = s->rcd + s->idx[l];
+        const int rr = r + prd->phs;
+        if (rr < e->lw || rr >= e->up) continue;
+        const int d = prd->dir, don = prd->jnc;
+        if (d == 2 && prd->phs == 1) continue;
+        if (acc - don < e->cx.minl) continue;
+        int x = prd->val + spjscr(&e->cx, don, acc);
+        if (d == 0 && prd->phs) {
+            int cs[2];
+            spjseq(&e->cx, don, acc, cs);
+            if (prd->phs == 1) x += mtx_at(&e->cx, a_code(&e->cx, m), cs[0]);
+            else x += mtx_at(&e->cx, a_code(&e->cx, m + 1), cs[1]) - mtx_at(&e->cx, a_code(&e->cx, m + 1), b_code(&e->cx, acc))
+                      - p->sigE[acc];
+        }
+        const int qq = xmod6(q + prd->phs);
+        int* v[3] = {xh_slot(e, 0, qq, j, 0), xh_slot(e, 0, qq, j, 1), xh_slot(e, 0, qq, j, 2)};
+        if (x <= *v[d]) continue;
+        if (!maxprd[d] || x > maxprd[d]->val) {
+            maxprd[d] = prd;
+            if (!brd || x > brd->val) brd = prd;
+        }
+        *v[d] = xw16(x);
+        e->PS[qq % 3][j] |= psp_bit[d];
+        int* b[3] = {xh_slot(e, 1, qq, j, 0), xh_slot(e, 1, qq, j, 1), xh_slot(e, 1, qq, j, 2)};
+        int* c[3] = {xh_slot(e, 2, qq, j, 0), xh_slot(e, 2, qq, j, 1), xh_slot(e, 2, qq, j, 2)};
+        *b[d] = prd->ml;
+        if (e->vmf) {
+            const int inner = vmf_add(e->vmf, m + 1, don + prd->phs, prd->ulk);
+            *c[d] = vmf_add(e->vmf, m + 1, acc + prd->phs, inner);
+        } else
+            *c[d] = prd->ulk;
+        if (d && *v[d] > *v[0]) { *v[0] = *v[d]; *b[0] = *b[d]; *c[0] = *c[d]; }
+        if (j + 1 == XN) {
+            e->hv[rr] = *v[0];
+            if (is_imd) e->imd->hlnk[0][rr] = prd->ulk;
+            else { e->hb[rr] = *b[0]; e->hc[rr] = *c[0]; }
+            if (d == 2) {
+                e->fv[rr] = *v[d];
+                if (is_imd) e->imd->hlnk[1][rr] = prd->ulk;
+                else { e->fb[rr] = *b[d]; e->fc[rr] = *c[d]; }
+            }
+        }
+    }
+    if (is_imd && brd) {
+        const int maxd = brd->dir;
+        const XhCand* prd = maxprd[maxd];
+        const int qq = xmod6(q + prd->phs);
+        const int lstr = e->rlst[qq % 3] = acc + prd->phs - e->mm3;
+        e->imd->hlnk[0][lstr] = prd->ulk;
+        int* v[3] = {xh_slot(e, 0, qq, j, 0), xh_slot(e, 0, qq, j, 1), xh_slot(e, 0, qq, j, 2)};
+        int* c[3] = {xh_slot(e, 2, qq, j, 0), xh_slot(e, 2, qq, j, 1), xh_slot(e, 2, qq, j, 2)};
+        *c[maxd] = lstr;
+        e->PV[qq % 3][j] = maxd;
+        if (maxd) { *c[0] = *c[maxd]; return; }
+        if ((prd = maxprd[1]) && *v[1] > *v[0] + e->sc->gop) {
+            e->imd->hlnk[1][lstr] = prd->ulk;
+            *c[1] = lstr + e->width;
+        }
+        if (maxprd[2] && *v[2] > *v[0] + e->sc->gop) *c[2] = lstr + e->width;
+    }
+}
+
+/* Sjsites::put, src/fwd2h1_simd.h:496-543 */
+static void xh_put(XhEng* e, XhSites* s, int j, int m, int n, int q)
+{
+    static const int psp_bit[3] = {4, 1, 8};
+    const SpdpProblemH* p = e->p;
+    const int don = n - 1;
+    const int sigJ = p->sig5[don];
+    const int is_imd = e->imd && (m + 1) == e->imd->mi;
+    for (int phs = 1; phs > -2; --n, --phs, q = xmod6(q - 1)) {
+        const int rr = don - 3 * (m + 1) + phs;
+        if (rr < e->lw || rr >= e->up) continue;
+        const int f3 = q % 3;
+        const int h = e->PV[f3][j];
+        const int thrscr = *xh_slot(e, 0, q, j, 0) + e->sc->gop;
+        for (int k = (h && phs < 1) ? 1 : 0; k < 3; ++k) {
+            if (e->PS[f3][j] & psp_bit[k]) continue;
+            const int cross = (phs == 1 && k == 0) ? 3 : k;
+            const int from = *xh_slot(e, 0, q, j, cross);
+            if (k && from <= thrscr) continue;
+            const int x = from + sigJ;
+            if (x <= XNEV) continue;
+            int l = s->ncand < 4 ? ++s->ncand : 4;
+            while (--l >= 0) {
+                if (x >= s->rcd[s->idx[l]].val) { const int t = s->idx[l]; s->idx[l] = s->idx[l + 1]; s->idx[l + 1] = t; }
+                else break;
+            }
+            if (++l < 4) {
+                XhCand* prd = s->rcd + s->idx[l];
+                prd->val = xw16(x);
+                prd->ml = *xh_slot(e, 1, q, j, k);
+                const int r = n - e->mm3;
+                const int rl = *xh_slot(e, 2, q, j, cross);
+                if (is_imd) {
+                    if (k == 1) e->imd->hlnk[0][r] = e->rlst[f3];
+                    prd->ulk = r;
+                } else
+                    prd->ulk = rl;
+                prd->jnc = don; prd->dir = k; prd->phs = phs;
+            } else --s->ncand;
+        }
+    }
+}
+
+static void xh_from_spj(XhEng* e, XhQueue* l, int m, int n, int q)
+{
+    for (int ns = 0; ns < l->ne; ++ns) {
+        const int nj = l->q[(l->qs + ns) % XN];
+        const int j = (n - nj) / 3, mj = m + j;
+        if (mj + 1 < e->a_right) xh_get(e, e->sites + j, j, mj, nj, q - 1);
+    }
+}
+static void xh_to_spj(XhEng* e, XhQueue* l, int m, int n, int q)
+{
+    for (int ns = 0; ns < l->ne; ++ns) {
+        const int nj = l->q[(l->qs + ns) % XN];
+        const int j = (n - nj) / 3, mj = m + j;
+        if (mj + 1 < e->a_right) xh_put(e, e->sites + j, j, mj, nj, q);
+    }
+}
+
+static int xh_open(XhEng* e, const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int mode, Vmf* vmf)
+{
+    memset(e, 0, sizeof *e);
+    code_tables();
+    e->sc = sc; e->p = p;
+    e->cx.sc = sc; e->cx.p = p; e->cx.minl = sc->minl ? sc->minl : sc->llmt;
+    e->lw = w->lw; e->up = w->up; e->width = w->width;
+    e->buf_size = w->width + 6 * XN;
+    e->a_left = p->a_left; e->a_right = p->a_right; e->b_left = p->b_left; e->b_right = p->b_right;
+    e->mem = (int*) calloc((size_t) 6 * e->buf_size, sizeof(int));
+    if (!e->mem) return -1;
+    e->hv = e->mem - w->lw + 3;       e->fv = e->hv + e->buf_size;
+    e->hb = e->fv + e->buf_size;      e->fb = e->hb + e->buf_size;
+    e->hc = e->fb + e->buf_size;      e->fc = e->hc + e->buf_size;
+    e->mode = mode; e->vmf = vmf;
+    e->LocalL = sc->local && p->a_exgl && p->b_exgl;
+    e->LocalR = sc->local && p->a_exgr && p->b_exgr;
+    e->max_val = XNEV; e->max_ulk = SPDP_END_OF_ULK;
+    e->max_ml = p->a_left; e->max_mr = p->a_right; e->max_nr = p->b_right;
+    e->rlst[0] = e->rlst[1] = e->rlst[2] = INT_MAX;
+    return 0;
+}
+
+/* fhinitH1 without a traceback bitmap, src/fwd2h1_simd.h:546-689 */
+static void xh_init(XhEng* e)
+{
+    const SpdpScoringH* sc = e->sc;
+    const SpdpProblemH* p = e->p;
+    const int lw = e->lw, up = e->up;
+    int *hv = e->hv, *fv = e->fv, *hb = e->hb, *hc = e->hc, *fc = e->fc;
+    const int B = e->buf_size;
+    for (int i = 0; i < 2 * B; ++i) (hv + lw - 3)[i] = XNEV;
+    const int rl = e->b_left - 3 * e->a_left;
+    Vmf* vmf = e->vmf;
+    if (vmf) {
+        for (int i = 0; i < 2 * B; ++i) (hb + lw - 3)[i] = 0;
+        int ptr = vmf_add(vmf, 0, 0, 0);
+        if (!(p->a_exgl && p->b_exgl)) ptr = vmf_add(vmf, e->a_left, e->b_left, ptr);
+        for (int r = rl; r < up; ++r) hc[r] = p->a_exgl ? 0 : ptr;
+        for (int r = lw; r < rl; ++r) hc[r] = p->b_exgl ? 0 : ptr;
+        if (p->b_exgl == 2) fc[rl] = ptr;
+    } else {
+        for (int i = 0; i < 2 * B; ++i) (hb + lw - 3)[i] = e->a_left;
+        const int re = p->a_exgl ? rl : up;
+        for (int r = lw; r < re; ++r) hc[r] = r;
+        for (int i = 0, r = rl; r >= lw; --r) hb[r] = e->a_left + (i++ / 3);
+    }
+    if (p->b_exgl == 1) { for (int r = lw; r < rl; ++r) hv[r] = 0; }
+    else if (p->b_exgl == 2) { fv[rl] = 0; fc[rl] = rl; }
+
+    int rr = e->b_right - 3 * e->a_left;
+    if (up < rr) rr = up;
+    int r = rl;
+    if (!p->a_exgl) {
+        if (p->b_exgl) { fv[r] = 0; fc[r] = hc[r]; }
+        hv[r++] = 0;
+        hv[r++] = xw16(sc->gapw1);
+        hv[r++] = xw16(sc->gapw2);
+        hv[r++] = xw16(sc->gapw3);
+        if (sc->gep) {
+            int x = (XNEV - sc->gapw3) / sc->gep + r;
+            if (x < rr) rr = x;
+            for ( ; r < rr; ++r) hv[r] = xw16(hv[r - 3] + sc->gep);
+        } else if (rr > r)
+            for (int v = hv[r - 1]; r < rr; ++r) hv[r] = v;
+        return;
+    }
+    int n = e->b_left;
+    int lend[3] = {r, r + 1, r + 2};
+    int bb = n + 1;
+    for (int f = 0; f < 3; ++f, ++r, ++n, ++bb) {
+        hv[r] = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+        if (vmf) { hc[r] = vmf_add(vmf, e->a_left, n, 0); hb[r] = 1; }
+        else hc[r] = r;
+    }
+    for (int f = 0; r < rr; ++r, ++n, ++bb, f = (f + 1) % 3) {
+        int h = hv[r - 3];
+        hc[r] = hc[r - 3];
+        const int gl = r - lend[f];
+        if (!(p->a_exgl & 1) && gl == 3) h = xw16(h + sc->gop);
+        if (!(p->a_exgl & 2)) h = xw16(h + gap_ext3(sc, gl));
+        h = xw16(h + p->sigE[bb - 3]);
+        hv[r] = h;
+        if (h < XNEV) break;
+        int x = xw16(hv[r - 1] + sc->gapw1);
+        if (x > h) { hv[r] = h = x; hc[r] = hc[r - 1]; }
+        x = xw16(hv[r - 2] + sc->gapw2);
+        if (x > h) { hv[r] = h = x; hc[r] = hc[r - 2]; }
+        x = p->sigS[bb] > 0 ? p->sigS[bb] : 0;
+        if (x > h) {
+            hv[r] = x; lend[f] = r;
+            if (vmf) { hc[r] = vmf_add(vmf, e->a_left, n, 0); hb[r] = 1; }
+            else hc[r] = r;
+        }
+    }
+}
+
+/* fhlastH1, src/fwd2h1_simd.h:691-791; returns the diagonal of the end cell */
+static int xh_last(XhEng* e)
+{
+    const SpdpScoringH* sc = e->sc;
+    const SpdpProblemH* p = e->p;
+    const int lw = e->lw, up = e->up;
+    int* hv = e->hv;
+    int glen[3] = {0, 0, 0}, tcdn[3] = {0, 0, 0};
+    const int m3 = 3 * e->a_right;
+    int rw = lw;
+    int rf = e->b_left - m3;
+    if (rf > rw) rw = rf; else rf = rw;
+    const int rr = e->b_right - m3;
+    int maxr = rr, mx = rr;
+    int bb = rw + m3;
+    if (p->a_exgr) {
+        int f = 0;
+        for (int h = rw; h <= rr; ++h, ++rf, ++bb, f = (f + 1) % 3) {
+            glen[f] += 3;
+            int cand[3] = {hv[h], XNEV, XNEV};
+            if (rf - rw >= 3 && !tcdn[f]) {
+                cand[1] = hv[h - 3] + p->sigE[bb - 2];
+                if (!(p->a_exgr & 2)) cand[1] += gap_ext3(sc, glen[f]);
+                if (!(p->a_exgr & 1) && glen[f] == 3) cand[1] += sc->gop;
+                if (sc->term_codon) cand[2] = hv[h - 3] + p->sigT[bb - 2];
+            }
+            if (rf - rw >= 3) tcdn[f] = tcdn[f] || p->sigT[bb - 2] > 0;
+            const int s5 = (sc->local && p->sig5[bb] > 0) ? p->sig5[bb] : 0;
+            cand[0] += s5; cand[1] += s5;
+            int k = 0;
+            if (cand[1] > cand[k]) k = 1;
+            if (cand[2] > cand[k]) k = 2;
+            if (k == 0) { glen[f] = 0; tcdn[f] = 0; }
+            else if (k == 1) hv[h] = xw16(cand[1] - s5);
+            else hv[h] = xw16(cand[2]);
+            if (hv[h] > hv[mx]) { mx = h; maxr = rf - (k == 2 ? 3 : 0); }
+        }
+    } else {
+        const int y = xw16(hv[rr - 3] + p->sigT[bb + (rr - rw)]);
+        if (y > hv[rr]) { hv[rr] = y; maxr = rr - 3; }
+    }
+    if (p->b_exgr) {
+        rw = imin(up - 1, e->b_right - 3 * e->a_left);
+        int g[3] = {XNEV, XNEV, XNEV};
+        int f = 0;
+        for (int h = rw - 3; h > rr; --h, f = (f + 1) % 3) {
+            int x = hv[h + 3];
+            if (!(p->b_exgr & 1)) x = xw16(x + sc->gop);
+            if (x > g[f]) g[f] = x;
+            if (!(p->b_exgr & 2)) g[f] = xw16(g[f] + sc->gep);
+            if (hv[h] > g[f]) g[f] = XNEV;
+            else if (g[f] > hv[mx]) { mx = h; hv[h] = g[f]; }
+        }
+    }
+    const int maxt = mx;
+    if (e->mode == 2 || e->mode == 4) e->hb[maxt] = e->hb[maxr];
+    e->max_ulk = e->hc[maxr];
+    int q = maxr - rr;
+    if (e->vmf) {
+        int m9 = e->a_right, n9 = e->b_right;
+        if (q > 0) { m9 -= (q + 2) / 3; if (q %= 3) n9 -= 3 - q; }
+        else if (q < 0) n9 += q;
+        e->max_ulk = vmf_add(e->vmf, m9, n9, e->max_ulk);
+        if (maxr != maxt) e->max_ulk = vmf_add(e->vmf, e->a_right, maxt + m3, e->max_ulk);
+    } else {
+        if (q > 0) e->max_mr = (e->b_right - maxr) / 3;
+        else       e->max_nr = maxt + m3;
+    }
+    return maxt;
+}
+
+/* one anti-diagonal step of forwardH1 / hirschbergH1 up to the splice phases (src/fwd2h1_simd.h:864-1047,
+ * 1157-1358): `udh` carries the left-end row in the B planes instead of the diagonal flag */
+static void xh_step(XhEng* e, int ml, int j9, int n, int r, int q, int udh)
+{
+    const SpdpScoringH* sc = e->sc;
+    const SpdpProblemH* p = e->p;
+    const int ge = sc->gep, g1 = sc->gapw1, g2 = sc->gapw2, g3 = sc->gapw3;
+    const int f3 = q % 3;
+    const int nb = imax(0, n - e->b_right + 1);
+    const int kb = (nb - 1) / 3;
+    const int ke = imin(j9, (n - e->b_left) / 3);
+    const int LL = e->LocalL;
+    if (sc->spj && !nb) {
+        if (p->phs5[n] > 0) xq_push(&e->dq[f3], n);
+        if (p->phs3[n] > 0) xq_push(&e->aq[f3], n);
+        e->CP[f3][0] = xgood(p, n - 2) ? p->sigE[n - 2] : 0;
+    }
+    int cv[XN];
+    for (int k = 0; k < XN; ++k) cv[k] = e->CP[f3][k];
+    for (int k = 0; k < XN; ++k) e->CP[f3][k + 1] = cv[k];
+    const int q1 = xmod6(q - 1), q2 = xmod6(q - 2), q3 = xmod6(q - 3), q4 = xmod6(q - 4), q5 = xmod6(q - 5);
+    int ev[XN], eb[XN], ec[XN], fvv[XN], fbv[XN], fcv[XN];
+    for (int k = 0; k < XN; ++k) {                              /* insertion */
+        int h = xadd(e->HV[q1][k + 1], g1), hb = e->HB[q1][k + 1], hc = e->HC[q1][k + 1];
+        int x = xadd(e->HV[q2][k + 1], g2);
+        int m = h > x;
+        h = m ? h : x; hb = m ? hb : e->HB[q2][k + 1]; hc = m ? hc : e->HC[q2][k + 1];
+        x = xadd(xadd(e->HV[q3][k + 1], g3), cv[k]);
+        m = h > x;
+        h = m ? h : x; hb = m ? hb : e->HB[q3][k + 1]; hc = m ? hc : e->HC[q3][k + 1];
+        x = xadd(xadd(e->EV[f3][k], ge), cv[k]);
+        m = x > h;
+        ev[k] = m ? x : h; eb[k] = m ? e->EB[f3][k] : hb; ec[k] = m ? e->EC[f3][k] : hc;
+    }
+    for (int k = 0; k < XN; ++k) { e->EV[f3][k] = ev[k]; e->EC[f3][k] = ec[k]; if (udh && LL) e->EB[f3][k] = eb[k]; }
+    e->FV[q3][0] = e->fv[r + 3]; e->FC[q3][0] = e->fc[r + 3];     /* deletion */
+    e->HV[q3][0] = e->hv[r + 3]; e->HC[q3][0] = e->hc[r + 3];
+    e->HV[q4][0] = e->hv[r + 2]; e->HC[q4][0] = e->hc[r + 2];
+    e->HV[q5][0] = e->hv[r + 1]; e->HC[q5][0] = e->hc[r + 1];
+    if (udh && LL) {
+        e->FB[q3][0] = e->fb[r + 3]; e->HB[q3][0] = e->hb[r + 3];
+        e->HB[q4][0] = e->hb[r + 2]; e->HB[q5][0] = e->hb[r + 1];
+    }
+    for (int k = 0; k < XN; ++k) {
+        int f = xadd(e->FV[q3][k], ge), fb = e->FB[q3][k], fc = e->FC[q3][k];
+        int x = xadd(e->HV[q3][k], g3);
+        int m = f > x;
+        f = m ? f : x; fb = m ? fb : e->HB[q3][k]; fc = m ? fc : e->HC[q3][k];
+        x = xadd(e->HV[q4][k], g2);
+        m = f > x;
+        f = m ? f : x; fb = m ? fb : e->HB[q4][k]; fc = m ? fc : e->HC[q4][k];
+        x = xadd(e->HV[q5][k], g1);
+        m = f > x;
+        f = m ? f : x; fb = m ? fb : e->HB[q5][k]; fc = m ? fc : e->HC[q5][k];
+        fvv[k] = f; fbv[k] = fb; fcv[k] = fc;
+    }
+    for (int k = 0; k < XN; ++k) { e->FV[q][k + 1] = fvv[k]; e->FC[q][k + 1] = fcv[k]; if (udh && LL) e->FB[q][k + 1] = fbv[k]; }
+    if (nb) for (int k = 0; k < XN; ++k) e->SM[k] = 0;           /* diagonal */
+    for (int k = kb; k < ke; ++k)
+        e->SM[k] = xw16(sc->mtx[p->a[ml + k] * sc->mtx_cols + p->b[n - 3 * k - 2]]);
+    e->HV[q][0] = e->hv[r]; e->HC[q][0] = e->hc[r];
+    if (!udh || LL) e->HB[q][0] = e->hb[r];
+    int hx[XN], hbx[XN], hcx[XN], qb[XN];
+    for (int k = 0; k < XN; ++k) {
+        const int qv = e->HV[q][k], qc = e->HC[q][k], qbb = e->HB[q][k];
+        int h = xadd(xadd(e->SM[k], qv), cv[k]);
+        e->QV[f3][k] = qv; e->QC[f3][k] = qc;
+        if (udh && LL) e->QB[f3][k] = qbb;
+        int m = fvv[k] > h;
+        h = m ? fvv[k] : h;
+        int hc = m ? fcv[k] : qc, hb = m ? fbv[k] : qbb, code = m ? 2 : 0;
+        m = ev[k] > h;
+        h = m ? ev[k] : h; hc = m ? ec[k] : hc; hb = m ? eb[k] : hb; code = m ? 1 : code;
+        e->PV[f3][k] = code;
+        e->PS[f3][k] &= code;
+        if (!sc->local) { if (!(h > XNEV)) h = XNEV; }
+        else if (LL) {
+            if (0 > h) { h = 0; if (!udh) { code = 1; hc = 0; } }
+        }
+        if (!udh) {
+            const int diag = code == 0;
+            qb[k] = diag & ~qbb & 1;
+            hb = diag;
+            e->QB[f3][k] = qb[k];
+        }
+        hx[k] = h; hbx[k] = hb; hcx[k] = hc;
+    }
+    for (int k = 0; k < XN; ++k) {
+        e->HV[q][k + 1] = hx[k]; e->HC[q][k + 1] = hcx[k];
+        if (!udh || LL) e->HB[q][k + 1] = hbx[k];
+    }
+    if (udh && LL)
+        for (int k = kb; k < ke; ++k)
+            if (e->HV[q][k + 1] == 0) { e->HB[q][k + 1] = ml + k; e->HC[q][k + 1] = r - 6 * k; }
+    if (e->LocalR) {
+        int bk = 1;
+        for (int k = 2; k <= j9; ++k) if (e->HV[q][k] > e->HV[q][bk]) bk = k;
+        if (e->HV[q][bk] > e->max_val) {
+            e->max_val = e->HV[q][bk]; e->max_ulk = e->HC[q][bk];
+            if (udh) { e->max_ml = e->HB[q][bk]; e->max_mr = ml + bk + 1; e->max_nr = n - 3 * bk; }   /* sic, :1355-1356 */
+            else     { e->max_mr = ml + bk; e->max_nr = n - 3 * bk + 3; }
+        }
+    }
+    if (!udh)
+        for (int k = kb; k < ke; ++k)
+            if (qb[k]) e->HC[q][k + 1] = vmf_add(e->vmf, ml + k, n - 3 * (k + 1), e->HC[q][k + 1]);
+}
+
+static void xh_stripe_reset(XhEng* e, int j9)
+{
+    for (int i = 0; i < 6; ++i) for (int k = 0; k < XN1; ++k) { e->HV[i][k] = e->FV[i][k] = XNEV; e->HB[i][k] = e->FB[i][k] = 0; }
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < XN; ++k) { e->EV[i][k] = XNEV; e->EB[i][k] = 0; e->PS[i][k] = e->PV[i][k] = 0; }
+        for (int k = 0; k < XN1; ++k) e->CP[i][k] = 0;
+    }
+    for (int k = 0; k < XN1; ++k) e->SM[k] = 0;
+    if (e->sc->spj) {
+        for (int j = 0; j < j9; ++j) xs_reset_h(e->sites + j);
+        for (int i = 0; i < 3; ++i) { xq_clear(&e->dq[i]); xq_clear(&e->aq[i]); }
+    }
+}
+
+static void xh_splice(XhEng* e, int ml, int n, int n0, int q)
+{
+    const int f3 = q % 3;
+    if (!e->sc->spj) return;
+    if (e->aq[f3].ne) {
+        if (e->aq[f3].q[e->aq[f3].qs] < n0) xq_pull(&e->aq[f3]);
+        if (e->aq[f3].ne) xh_from_spj(e, &e->aq[f3], ml, n, q);
+    }
+    if (e->dq[f3].ne) {
+        if (e->dq[f3].q[e->dq[f3].qs] < n0) xq_pull(&e->dq[f3]);
+        if (e->dq[f3].ne) xh_to_spj(e, &e->dq[f3], ml, n, q);
+    }
+}
+
+/* rc 0 ok, -1 unsupported parameters, -3 the reference keeps the record pointer in one int16 lane (mode 3)
+ * and this run needs more than 32767 records (undefined there).  Records come back end -> start. */
+int orc_exact_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w,
+                        int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    *skl = 0; *n_skl = 0;
+    if (!sc->intpen || !p->dinc) return -1;
+    if (w->width < 0) { *score = SPDP_NEVSEL; return 0; }
+    Vmf vmf = {0, 0, 0, 1};
+    XhEng* e = (XhEng*) malloc(sizeof(XhEng));
+    if (xh_open(e, sc, p, w, 3, &vmf)) { free(e); return -1; }
+    xh_init(e);
+    for (int ml = e->a_left; ml < e->a_right; ml += XN) {
+        const int j9 = imin(XN, e->a_right - ml);
+        const int j8 = j9 - 1;
+        int n = imax(e->b_left, e->lw + 3 * ml);
+        const int n9 = imin(e->b_right, e->up + 3 * (ml + j9) + 1) + 3 * j9;
+        int n0 = n - 3 * j8;
+        int q = (n + 3 * (ml + 1)) % 6;
+        int r = n - 3 * (ml + 1);
+        xh_stripe_reset(e, j9);
+        for ( ; n < n9; ++n, ++n0, ++r, q = xmod6(q + 1)) {
+            const int ke = imin(j9, (n - e->b_left) / 3);
+            xh_step(e, ml, j9, n, r, q, 0);
+            xh_splice(e, ml, n, n0, q);
+            const int r0 = r - 6 * j8;
+            if (j9 == ke && e->lw <= r0 && r0 <= e->up) {
+                e->hv[r0] = e->HV[q][j9]; e->hb[r0] = e->HB[q][j9]; e->hc[r0] = e->HC[q][j9];
+                e->fv[r0] = e->FV[q][j9]; e->fc[r0] = e->FC[q][j9];
+            }
+        }
+    }
+    int ptr, val = e->max_val;
+    if (!e->LocalR || e->max_mr == e->a_right) { xh_last(e); ptr = e->max_ulk; }
+    else ptr = vmf_add(&vmf, e->max_mr, e->max_nr, e->max_ulk);
+    int rc = 0;
+    {
+        const int m = e->a_right - e->a_left;
+        float cvol = (float) (w->lw - e->b_left + 3 * e->a_right);
+        cvol = (float) m * (float) (e->b_right - e->b_left) - cvol * cvol / 3;
+        if (cvol < 65535.f && vmf.n > 32767) rc = -3;
+    }
+    if (ptr) {
+        int cap = 64, cnt = 0;
+        SpdpSkl* out = (SpdpSkl*) malloc(cap * sizeof(SpdpSkl));
+        Sklp sv = vmf.rec[ptr];
+        for (;;) {
+            if (cnt + 2 > cap) { cap *= 2; out = (SpdpSkl*) realloc(out, cap * sizeof(SpdpSkl)); }
+            out[cnt].m = sv.m; out[cnt].n = sv.n; ++cnt;
+            if (!sv.p) break;
+            sv = vmf.rec[sv.p];
+        }
+        const int rdiag = out[cnt - 1].n - 3 * out[cnt - 1].m;
+        const int rd = sc->local ? 0 : (rdiag - e->b_left + 3 * e->a_left);
+        if (rd > 0) { out[cnt].m = e->a_left; out[cnt].n = e->b_left + rd; ++cnt; }
+        else if (rd < 0) { out[cnt].m = e->a_left - rd / 3; out[cnt].n = e->b_left; ++cnt; }
+        *skl = out; *n_skl = cnt;
+    }
+    *score = val;
+    free(vmf.rec); free(e->mem); free(e);
+    return rc;
+}
+
+/* hirschbergH1: cpos rows of 10, ranges = {a_left, a_right, b_left, b_right} as the reference writes
+ * them back into the Seq objects */
+int orc_exact_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int n_im,
+                    int32_t* score, int32_t* cpos, int32_t* ranges)
+{
+    if (!sc->intpen || !p->dinc || n_im < 1) return -1;
+    XhEng* e = (XhEng*) malloc(sizeof(XhEng));
+    if (xh_open(e, sc, p, w, 2, 0)) { free(e); return -1; }
+    xh_init(e);
+    const int step = (e->a_right - e->a_left + n_im) / (n_im + 1);
+    XhImd* imds = (XhImd*) calloc(n_im, sizeof(XhImd));
+    for (int i = 0; i < n_im; ++i) {
+        imds[i].mi = e->a_left + (i + 1) * step;
+        imds[i].buf = (int*) malloc(sizeof(int) * 4 * w->width);
+        for (int j = 0; j < 4 * w->width; ++j) imds[i].buf[j] = SPDP_END_OF_ULK;
+        imds[i].hlnk[0] = imds[i].buf - w->lw + 1;
+        imds[i].hlnk[1] = imds[i].hlnk[0] + w->width;
+        imds[i].vlnk[0] = imds[i].hlnk[0] + 2 * w->width;
+        imds[i].vlnk[1] = imds[i].vlnk[0] + w->width;
+    }
+    e->imd = imds;
+    int mm = e->a_left + (e->imd->mi - e->a_left - 1) / XN * XN;
+    e->mm3 = 3 * e->imd->mi;
+    int k9 = e->imd->mi - mm, k8 = k9 - 1;
+    for (int ml = e->a_left, i = 0; ml < e->a_right; ml += XN) {
+        const int j9 = imin(XN, e->a_right - ml);
+        const int j8 = j9 - 1;
+        int n = imax(e->b_left, e->lw + 3 * ml);
+        const int n9 = imin(e->b_right, e->up + 3 * (ml + j9) + 1) + 3 * j9;
+        int n0 = n - 3 * j8;
+        int q = xmod6(n + 3 * (ml + 1));
+        int r = n - 3 * (ml + 1);
+        xh_stripe_reset(e, j9);
+        const int is_imd_ = ml == mm;
+        for ( ; n < n9; ++n, ++n0, ++r, q = xmod6(q + 1)) {
+            const int rj = r - 6 * k8;
+            const int f3 = q % 3;
+            const int ke = imin(j9, (n - e->b_left) / 3);
+            const int is_imd = is_imd_ && rj >= e->lw && rj <= e->up;
+            xh_step(e, ml, j9, n, r, q, 1);
+            xh_splice(e, ml, n, n0, q);
+            if (is_imd) {
+                if (e->PV[f3][k8] == 0) e->rlst[f3] = rj;
+                if (e->PV[f3][k8] == 1) e->imd->hlnk[0][rj] = e->rlst[f3];
+                e->imd->vlnk[0][rj] = e->HC[q][k9];
+                e->HC[q][k9] = rj;
+                e->imd->vlnk[1][rj] = e->FC[q][k9];
+                e->FC[q][k9] = rj + e->width;
+            }
+            const int r0 = r - 6 * j8;
+            if (j9 == ke && e->lw <= r0 && r0 < e->up) {
+                e->hv[r0] = e->HV[q][j9]; e->hc[r0] = e->HC[q][j9];
+                e->fv[r0] = e->FV[q][j9]; e->fc[r0] = e->FC[q][j9];
+                if (e->LocalL) { e->hb[r0] = e->HB[q][j9]; e->fb[r0] = e->FB[q][j9]; }
+            }
+        }
+        if (is_imd_ && ++i < n_im) {
+            e->imd = imds + i;
+            e->mm3 = 3 * e->imd->mi;
+            mm = e->a_left + (e->imd->mi - e->a_left - 1) / XN * XN;
+            k9 = e->imd->mi - mm; k8 = k9 - 1;
+        }
+    }
+
+    int a_left = e->a_left, a_right = e->a_right, b_left = e->b_left, b_right = e->b_right;
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+    if (e->LocalR && e->max_mr < a_right) {
+        a_right = e->max_mr; b_right = e->max_nr;
+    } else {
+        const int rt = xh_last(e);
+        e->max_ml = e->LocalL ? e->hb[rt] : a_left;
+        a_right = e->max_mr; b_right = e->max_nr;
+    }
+    int val = e->max_val;
+    int i = n_im;
+    while (--i >= 0 && imds[i].mi > a_right) ;
+    if (i < 0 && imds[0].mi > a_right) CPOS(0, 2) = b_right;
+    int r = e->max_ulk;
+    XhImd* imd;
+    for ( ; i >= 0 && (imd = imds + i)->mi > e->max_ml; --i) {
+        int c = 0, d = 0;
+        for ( ; r > w->up; r -= w->width) ++d;
+        if (imd->vlnk[d][r] < SPDP_END_OF_ULK) {
+            CPOS(i, c++) = imd->mi;
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            const int mm3 = 3 * imd->mi;
+            for (int rp = imd->hlnk[d][r];
+                 w->lw <= rp && rp < w->up && r != rp;
+                 rp = imd->hlnk[d][r = rp])
+                CPOS(i, c++) = r + mm3;
+            CPOS(i, c++) = r + mm3;
+            CPOS(i, c) = SPDP_END_OF_ULK;
+            r = imd->vlnk[d][r];
+            if (r == SPDP_END_OF_ULK) break;
+        } else
+            CPOS(i, 0) = SPDP_END_OF_ULK;
+    }
+    for ( ; r > w->up; r -= w->width) ;
+    if (e->LocalL) {
+        a_left = e->max_ml;
+        b_left = r + 3 * a_left;
+    } else {
+        const int rl = b_left - 3 * a_left;
+        if (p->b_exgl && rl > r) {
+            a_left = (b_left - r) / 3;
+            for (int j = 0; j < n_im && imds[j].mi < a_left; ++j) CPOS(j, 0) = SPDP_END_OF_ULK;
+        }
+        if (p->a_exgl && rl < r) b_left = 3 * a_left + r;
+    }
+    ++i;
+    if ((i >= 0 && i < n_im && imds[i].mi < a_left) || CPOS(i, 2) < b_left) val = SPDP_NEVSEL;
+#undef CPOS
+    *score = val;
+    ranges[0] = a_left; ranges[1] = a_right; ranges[2] = b_left; ranges[3] = b_right;
+    for (int j = 0; j < n_im; ++j) free(imds[j].buf);
+    free(imds);
+    free(e->mem); free(e);
+    return 0;
+}

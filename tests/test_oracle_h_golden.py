@@ -110,3 +110,17 @@ def test_skl_rng_h_vs_reference(path, alg):
     assert h == int(fx[f"rng_scr_A{alg}"][0])
     assert fst == [int(x) for x in fx[f"rng_fstat_A{alg}"][:5]]
     assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()
+
+
+@pytest.mark.parametrize("path", H_FILES, ids=_name)
+def test_align_h_a1(path):
+    """-A1: alignH_ng over forwardH1 / hirschbergH1 (full-precision intron lengths, 16-bit lanes) against the
+    reference's own -A1 run (differs from both -A0 and -A2 on a third of the fixtures)"""
+    fx = spdg.load(path)
+    if "aln_skl_A1" not in fx:
+        pytest.skip("no -A1 record")
+    sc = spdg.scoring_h(fx)
+    _, p = spdg.problem_h(fx)
+    scr, skl = hh.align_h(sc, p, simd=1)
+    assert scr == int(fx["aln_scr_A1"][0])
+    assert (skl or []) == fx["aln_skl_A1"].tolist()

@@ -284,7 +284,11 @@ typedef struct SpdpScoringH {
     int16_t t53[256];                /* sig53(m, n, IE53) - sig3[n] by 16 * dinc5[m] + dinc3[n] */
     int32_t minl;                    /* IntronPrm.minl (scalar engine: shortest intron; 0 = llmt)   */
     int32_t scalar_engines;          /* 0: the `_wip` engines (-A2 / -A3); 1: algmode.alg == 0 (-A0):
-                                        spdp_align_h / spdp_homscore_h run forwardH_ng / hirschbergH_ng */
+                                        spdp_align_h / spdp_homscore_h run forwardH_ng / hirschbergH_ng;
+                                        2: algmode.alg == 1 (-A1): spdp_align_h runs forwardH1 / hirschbergH1
+                                        (src/fwd2h1_simd.h:820, 1100) with the -A0 ladder geometry; HomScoreH_ng
+                                        above 7 rows stops with SIGSEGV in the reference under -A1 (forwardH1
+                                        without a Vmf) and comes back here as "not computed" (return value 1) */
     int32_t recursive;               /* algmode.alg & 4: lspH_ng always takes the recursive branch    */
 } SpdpScoringH;
 
@@ -340,7 +344,10 @@ int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
  * traceback + boundary fix-up); traceback == 0: score only, as HomScoreH_ng runs it under -A0 (:3297).
  * Needs SpdpScoringH.intpen / t53 / gape1 / gape2 / extragop / minl and SpdpProblemH.dinc.  One GPU
  * thread per problem: meant for the sub-problems below 8 query rows that the -A2 / -A3 dispatch hands
- * to this engine (spdp_align_h and spdp_homscore_h do that themselves), correct at any size. */
+ * to this engine (spdp_align_h and spdp_homscore_h do that themselves), correct at any size.
+ * With SpdpScoringH.scalar_engines = 2 this entry runs SimdAln2h1::forwardH1 instead (the -A1 engine, modes
+ * 3 / 5, src/fwd2h1_simd.h:820-1096; 16 lanes per problem; traceback form only); n_skl = -3 marks a run
+ * whose record pointers leave the int16 lane the reference keeps them in under mode 3 (undefined there). */
 int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
                           int traceback, SpdpAlignment* out);
 
@@ -348,7 +355,9 @@ int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpPr
  * intermediate rows imd_intvl rows apart (Aln2h1::imd_intvl as lspH_ng sets it): cpos, ranges as for
  * spdp_wip_udh_h; cpos[..][8], [9] carry the diagonal bounds of each slab (its window under -A0);
  * entries the reference leaves uninitialised read end_of_ulk.  flags[i] = -3: the reference indexes
- * outside its arrays on this input (undefined there), 0 otherwise. */
+ * outside its arrays on this input (undefined there), 0 otherwise.
+ * With SpdpScoringH.scalar_engines = 2 this entry runs SimdAln2h1::hirschbergH1 (src/fwd2h1_simd.h:1100-1470,
+ * non-local ends): cpos / ranges as for spdp_wip_udh_h, imd_intvl unused, flags 0. */
 int spdp_scalar_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs,
                       int n_im, int imd_intvl, int32_t* scores, int32_t* cpos, int32_t* ranges, int32_t* flags);
 

@@ -8,6 +8,11 @@
  *                          + initH_ng / lastH_ng                      src/fwd2h1.cc:143-208 / 210-292
  *                          + Vmf::traceback                           src/vmf.cc:125-140
  *                          + the record fix-up of trcbkalignH_ng      src/fwd2h1.cc:2019-2036
+ *   orc_scalar_udh_h       Aln2h1::hirschbergH_ng                     src/fwd2h1.cc:1085-1520
+ *   orc_exact_forward_h    SimdAln2h1::forwardH1   (-A1)              src/fwd2h1_simd.h:820-1096   } second half
+ *   orc_exact_udh_h        SimdAln2h1::hirschbergH1 (-A1)             src/fwd2h1_simd.h:1100-1470  } of this file
+ * Pinned: alignH_ng over these engines equals the compiled reference's -A0 / -A1 records on every protein
+ * fixture (tests/test_oracle_h_golden.py, tests/test_oracle_h_scalar.py).
  * This is the -A0 engine (int32, row by row, exact intron-length penalty with the top-NCAND donor
  * list per row and codon phase) -- also what the -A2/-A3 dispatch falls back to for sub-problems
  * with fewer than 8 query rows (trcbkalignH_ng src/fwd2h1.cc:2005, HomScoreH_ng :3297).

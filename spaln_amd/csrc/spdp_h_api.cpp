@@ -91,6 +91,7 @@ struct HItem {
     SpdpWindow w;
     int n_im = 0, imd_intvl = 0;
     bool recursive = false, first = false;      // first: this call's return value is gsi->scr
+    bool exact = false;                         // traceback by the -A1 engine (forwardH1)
 };
 
 static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* p, int i)
@@ -339,7 +340,7 @@ static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, H
 }
 
 // ---- scalar forwardH_ng over a list of items (spdp_h_scalar.hip) ------------------------------
-static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out)
+static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
 {
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[H_POOL];
@@ -354,7 +355,8 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
         DevProblemH& d = h_probs[i];
         fill_desc(st, items[i], d);
         d.bnd_off = work_int;
-        work_int += 3ll * (2 * (int64_t) d.width + 8);
+        // scalar: two rows of {val, ptr, dir}; -A1 (forwardH1): six boundary rows by diagonal + the record counter
+        work_int += exact ? 6ll * d.buf_size + 8 : 3ll * (2 * (int64_t) d.width + 8);
         d.tb_off = vmf_rec;
         // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
         // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
@@ -389,7 +391,8 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
+    if (exact) HIPCHK(spdh_launch_exact(0, &A, ctx->stream));
+    else HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     out.res.resize(nr); out.n_skl.assign(nr, 0); out.off.assign(nr + 1, 0);
     HIPCHK(hipMemcpyAsync(out.res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
@@ -405,6 +408,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
         const int c = out.n_skl[i];
         if (c == -1) { ctx->err = "traceback record buffer overflow (scalar engine)"; return -1; }
         if (c == -3) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
+        if (c == -4) { out.n_skl[i] = -3; out.off[i + 1] = out.off[i]; continue; }   // -A1, mode 3: record pointer beyond an int16 lane (undefined)
         out.off[i + 1] = out.off[i] + std::max(c, 0);
     }
     out.skl.resize(out.off[nr]);
@@ -418,7 +422,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
 
 // ---- scalar hirschbergH_ng over a list of items (spdp_h_scalar.hip) ----------------------------
 struct HUdhOut;
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags);
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, bool exact = false);
 
 // ---- hirschbergH1_wip over a list of items ------------------------------------------------------
 struct HUdhOut {
@@ -482,7 +486,7 @@ static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
     return 0;
 }
 
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags)
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, bool exact)
 {
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[HU_POOL];
@@ -500,7 +504,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
         DevProblemH& d = h_probs[i];
         fill_desc(st, items[i], d);
         d.bnd_off = work_int;
-        work_int += 6ll * (2 * (int64_t) d.width + 8);
+        work_int += exact ? 6ll * d.buf_size + 8 : 6ll * (2 * (int64_t) d.width + 8);
         d.imd_off = imd_int;
         imd_int += (int64_t) d.n_im * 8 * d.width;
         out.cells += d.cells;
@@ -530,7 +534,8 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
     A.cpos_stride = out.stride;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
+    if (exact) HIPCHK(spdh_launch_exact(1, &A, ctx->stream));
+    else HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     out.scores.resize(nr); out.cpos.resize((size_t) nr * out.stride); out.ranges.resize((size_t) nr * 4);
     std::vector<DevResultH> res(nr);
@@ -540,7 +545,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     HIPCHK(hipMemcpyAsync(res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
-    for (int i = 0; i < nr; ++i) flags[i] = res[i].pad[0];
+    for (int i = 0; i < nr; ++i) flags[i] = exact ? 0 : res[i].pad[0];
     return 0;
 }
 
@@ -567,14 +572,20 @@ static bool bad_range(const HItem& it, const SpdpProblemH& p)
            it.a_right < it.a_left || it.b_right < it.b_left || it.b_left < p.exin_left || it.b_right > p.exin_right;
 }
 
-static thread_local bool a0_mode = false;        // SpdpScoringH.scalar_engines of the running ladder
+static thread_local int a0_mode = 0;             // SpdpScoringH.scalar_engines of the running ladder: 1 -A0, 2 -A1
 
 static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok, HTop& t)
 {
     if (it.w.width < 0) return true;                         // NEVSEL, no records
-    if (a0_mode || it.a_right - it.a_left < 8) {             // -A0, or below 8 rows: scalar forwardH_ng
+    if (a0_mode == 1 || it.a_right - it.a_left < 8) {        // -A0, or below 8 rows: scalar forwardH_ng
         if (!scalar_ok) { t.cls = 1; return false; }
         scl.push_back(it);
+        return true;
+    }
+    if (a0_mode == 2) {                                      // -A1: forwardH1 (modes 3 / 5)
+        if (!scalar_ok) { t.cls = 1; return false; }
+        scl.push_back(it);
+        scl.back().exact = true;
         return true;
     }
     fwd.push_back(it);
@@ -614,7 +625,7 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
             if (n_imd == 0) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
         }
     }
-    if (sc.local && !a0_mode) { t.cls = 1; return; }         // local linear-space `_wip` engine: not built
+    if (sc.local && a0_mode != 1) { t.cls = 1; return; }     // local linear-space SIMD engines: not built / not pinned
     if (a0_mode && !scalar_ok) { t.cls = 1; return; }
     it.n_im = n_imd; it.recursive = recursive;
     udh.push_back(it);
@@ -624,7 +635,7 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
 // cpos row (src/fwd2h1.cc:2068-2073, 2108-2128)
 static void slab_window(HItem& it, int sh, const int32_t* row)
 {
-    if (!a0_mode) { stripe31_rng(it.a_left, it.a_right, it.b_left, it.b_right, sh, &it.w); return; }
+    if (a0_mode != 1) { stripe31_rng(it.a_left, it.a_right, it.b_left, it.b_right, sh, &it.w); return; }
     it.w.lw = row[8]; it.w.up = row[9];
     it.w.width = it.w.up - it.w.lw + 7;
 }
@@ -632,7 +643,7 @@ static void slab_window(HItem& it, int sh, const int32_t* row)
 static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& hs)
 {
     const SpdpScoringH& sc = st.sc;
-    a0_mode = ladder && sc.scalar_engines != 0;
+    a0_mode = ladder ? sc.scalar_engines : 0;
     tops.assign(st.n, HTop());
     std::vector<HItem> pending, fwd, udh, scl;
     for (int i = 0; i < st.n; ++i) {
@@ -659,7 +670,7 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         if (!udh.empty()) {
             HUdhOut uo;
             std::vector<int> uflags(udh.size(), 0);
-            if (a0_mode ? run_scalar_udh(st, udh, uo, uflags) : run_udh(st, udh, uo)) return -1;
+            if (a0_mode ? run_scalar_udh(st, udh, uo, uflags, a0_mode == 2) : run_udh(st, udh, uo)) return -1;
             hs.udh_ms += uo.sweep_ms; hs.udh_cells += uo.cells;
             for (size_t u = 0; u < udh.size(); ++u) {
                 const HItem& it = udh[u];
@@ -720,18 +731,20 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
             }
         }
         // ---- traceback round; sub-problems below 8 rows go through the scalar engine
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < 3; ++pass) {                // `_wip` forward, scalar forwardH_ng, -A1 forwardH1
             std::vector<HItem>& list = pass ? scl : fwd;
             if (list.empty()) continue;
             std::vector<HItem> run;
             for (const HItem& it : list) {
+                if (pass && it.exact != (pass == 2)) continue;
                 if (tops[it.top].cls) continue;
                 if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
                 run.push_back(it);
             }
-            list.clear();
+            if (pass != 1) list.clear();
+            if (run.empty()) continue;
             HFwdOut fo;
-            if (pass ? run_scalar(st, run, true, fo) : run_forward(st, run, true, fo)) return -1;
+            if (pass ? run_scalar(st, run, true, fo, pass == 2) : run_forward(st, run, true, fo)) return -1;
             if (!pass) { hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells; }
             for (size_t f = 0; f < run.size(); ++f) {
                 HTop& t = tops[run[f].top];
@@ -870,6 +883,9 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
         HItem it = item_of(probs[i], i, sc->sh);
         const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
         if (!n || !m || it.w.width < 0) { rc = 1; continue; }
+        // -A1 above 7 rows: the reference runs forwardH1 without a Vmf here and stops with SIGSEGV (Sjsites::get
+        // dereferences it, src/fwd2h1_simd.h:431-434 reached through hfesmc of a mode-1 object): not computed
+        if (sc->scalar_engines == 2 && m >= 8) { rc = 1; continue; }
         if (sc->scalar_engines || m < 8) {                            // scalar forwardH_ng (src/fwd2h1.cc:3297)
             if (!st.scalar_ok) { rc = 1; continue; }
             sitems.push_back(it); sidx.push_back(i);
@@ -900,11 +916,14 @@ int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpPr
         items.push_back(it); idx.push_back(i);
     }
     HFwdOut fo;
-    if (run_scalar(st, items, traceback != 0, fo)) return -1;
+    const bool exact = sc->scalar_engines == 2;                       // forwardH1 (-A1): traceback form only
+    if (exact && !traceback) { ctx->err = "forwardH1 (-A1) has no score-only form (the reference's stops)"; return -1; }
+    if (run_scalar(st, items, traceback != 0, fo, exact)) return -1;
     for (size_t f = 0; f < items.size(); ++f) {
         SpdpAlignment& o = out[idx[f]];
         o.score = fo.res[f].score;
         if (!traceback) continue;
+        if (fo.n_skl[f] < 0) { o.n_skl = fo.n_skl[f]; continue; }    // -3: undefined in the reference (mode 3 pointer lanes)
         std::vector<SpdpSkl> rec(fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
         o.n_skl = (int) rec.size();
         o.skl = dup_skl(rec);
@@ -929,7 +948,7 @@ int spdp_scalar_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProble
     }
     HUdhOut uo;
     std::vector<int> fl;
-    if (run_scalar_udh(st, items, uo, fl)) return -1;
+    if (run_scalar_udh(st, items, uo, fl, sc->scalar_engines == 2)) return -1;  // 2: hirschbergH1 (imd_intvl unused)
     for (int i = 0; i < n_probs; ++i) {
         scores[i] = uo.scores[i];
         flags[i] = fl[i];

@@ -276,11 +276,12 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
 {
     store = st; ctx = st->ctx; flavour = flav; n = (int) items.size();
     (void) hipSetDevice(ctx->device);
-    if (flav == 2 && st->sc.local) { ctx->err = "local UDH is not implemented"; return -1; }
     if (flav >= 3 && !st->has_exact) {
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
         return -1;
     }
+    // hirschbergS1_wip with local ends (-LS): its own kernel (spdp_local_udh.hip), flavour 9
+    if (flav == 2 && st->sc.local) flav = flavour = 9;
     h_probs.assign(n, DevProblem());
     int64_t bnd_tot = 0, tb_tot = 0, imd_tot = 0;
     total_cells = 0; max_n_im = 0; max_skl = 0;
@@ -296,7 +297,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.lw = it.w.lw; P.up = it.w.up; P.width = it.w.width;
         P.buf_size = it.w.width + 2 * SPDP_NELEM;
         P.flags = (it.a_exgl ? 1 : 0) | (it.a_exgr ? 2 : 0) | (it.b_exgl ? 4 : 0) | (it.b_exgr ? 8 : 0);
-        P.n_im = (flav == 2 || flav == 5 || flav == 8) ? it.n_im : 0;
+        P.n_im = (flav == 2 || flav == 5 || flav == 8 || flav == 9) ? it.n_im : 0;
         P.imd_intvl = it.imd_intvl;
         P.a_off = st->a_off[it.parent];
         P.col_off = st->col_off[it.parent];
@@ -304,8 +305,8 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.tb_off = tb_tot;
         if (flav >= 6) {                // -A1 engines: hv / fv (/ hb / hc / fc) by diagonal, buf_size ints each, a counter
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + 5ll * P.buf_size + 8;
-            if (flav == 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
+            bnd_tot = P.bnd_off + (flav == 9 ? 6ll : 5ll) * P.buf_size + 8;
+            if (flav >= 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
             if (flav == 7) {
                 const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
                 const int64_t cap = 2 * cells + 64;
@@ -352,7 +353,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         POOLGET(d_skl, POOL_SKL, sizeof(int2) * (int64_t) skl_cap * nn);
         POOLGET(d_nskl, POOL_NSKL, sizeof(int) * nn);
     }
-    if (flav == 2 || flav == 5 || flav == 8) {
+    if (flav == 2 || flav == 5 || flav == 8 || flav == 9) {
         POOLGET(d_imd, POOL_IMD, sizeof(int32_t) * std::max<int64_t>(imd_tot, 1));
         POOLGET(d_cpos, POOL_CPOS, sizeof(int32_t) * 10 * (max_n_im + 1) * nn);
         POOLGET(d_ranges, POOL_RANGES, sizeof(int32_t) * 4 * nn);
@@ -441,15 +442,16 @@ int DevRun::launch()
         S.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
-        if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, ctx->stream));
+        if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, ctx->stream));
+        else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, ctx->stream));
         else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
         else HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-        if (flavour == 8) {                 // hirschbergS1's link walk
+        if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk
             CposArgs C;
             C.probs = S.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
             C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
-            C.cpos_stride = 10 * (max_n_im + 1); C.strict = 1;
+            C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = flavour == 9;
             HIPCHK(spdp_launch_cpos(&C, ctx->stream));
         }
         return 0;
@@ -476,7 +478,7 @@ int DevRun::launch()
         CposArgs C;
         C.probs = A.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
         C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
-        C.cpos_stride = 10 * (max_n_im + 1); C.strict = 0;
+        C.cpos_stride = 10 * (max_n_im + 1); C.strict = 0; C.local = 0;
         HIPCHK(spdp_launch_cpos(&C, ctx->stream));
     }
     return 0;

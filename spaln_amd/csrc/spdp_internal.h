@@ -45,6 +45,7 @@ struct CposArgs {
     int*              scores;
     int               cpos_stride;
     int               strict;     // 1: the -A1 form of the walk (hirschbergS1: r > up, lw <= vlnk)
+    int               local;      // 1: local ends (DevResult::ml is the left-end row of the path)
 };
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
@@ -79,6 +80,7 @@ struct ScalarArgs {
 };
 extern "C" hipError_t spdp_launch_scalar(int forward, const ScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
+extern "C" hipError_t spdp_launch_local_udh(const ScalarArgs* a, hipStream_t s);          // spdp_local_udh.hip: hirschbergS1_wip, -LS
 extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t s);   // spdp_exact.hip: 0 score, 1 forward, 2 udh
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);

@@ -844,7 +844,7 @@ __global__ void spdp_udh_cpos(CposArgs A)
     }
     int a_left = P.a_left, b_left = P.b_left;
     const int a_right = R.mr, b_right = R.nr;
-    const int max_ml = P.a_left;                       // non-local
+    const int max_ml = A.local ? R.ml : P.a_left;
     int val = R.score;
     int i = n_im;
     while (--i >= 0 && MI(i) > a_right) ;
@@ -868,7 +868,10 @@ __global__ void spdp_udh_cpos(CposArgs A)
             CPOS(i, 0) = END_OF_ULK;
     }
     for ( ; r > up; r -= width) ;
-    {
+    if (A.local && (P.flags & 1) && (P.flags & 4)) {    // LocalL: the path's own left end
+        a_left = max_ml;
+        b_left = r + a_left;
+    } else {
         const int rl = b_left - a_left;
         const bool a_exgl = P.flags & 1, b_exgl = P.flags & 4;
         if (b_exgl && rl > r) {

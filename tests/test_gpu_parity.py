@@ -3,7 +3,7 @@ C ABI, against (a) the committed reference goldens and (b) the CPU oracle on
 the same inputs.  Integer work: every comparison is bit-exact.
 
 Known, documented deviation (DESIGN.md "Local-mode corner"): none of the
-non-local cases; local UDH is not implemented on the GPU yet.
+all cases; hirschbergS1_wip with local ends runs in its own kernel (spdp_local_udh.hip).
 """
 import re
 
@@ -66,8 +66,6 @@ def test_forward_vs_reference(eng, fx, tag):
 @pytest.mark.parametrize("tag", ["qn", "q1"])
 def test_udh_vs_reference(eng, fx, tag):
     sc, ps, p = _setup(fx, tag)
-    if sc.local:
-        pytest.skip("local UDH not implemented on the GPU")
     for k in [k for k in fx if re.fullmatch(rf"wip_{tag}_udh\d+_scr", k)]:
         n_im = int(re.search(r"udh(\d+)", k).group(1))
         scores, cpos, rng = eng.wip_udh(sc, ps, n_im)
@@ -105,8 +103,6 @@ def test_align_s_vs_reference(eng, fx, alg):
     """alignS_ng(ori=1, -Q0) through the C ABI: dispatch ladder + UDH + slab tracebacks + stdskl/trimskl."""
     sc = spdg.scoring(fx, nquant=(1 if alg == 3 else None))
     ps, p = spdg.problem(fx)
-    if sc.local and fx["prm"]["max_vmf_space"] < 32 * 1024 * 1024:
-        pytest.skip("local UDH not implemented on the GPU")
     (score, skl), = eng.align_s(sc, ps)
     assert score == int(fx[f"aln_scr_A{alg}"][0])
     assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
@@ -407,3 +403,48 @@ def test_align_a6_recursive_switch(eng):
             for fx, (score, skl) in zip(sub, res):
                 assert score == int(fx["aln_scr_A6"][0])
                 assert skl.ravel().tolist() == fx["aln_skl_A6"].tolist()
+
+
+def test_local_udh_against_oracle(eng):
+    """hirschbergS1_wip with local ends (-LS, spdp_local_udh.hip) on random sub-ranges: cpos rows, ranges and
+    score against the oracle (which reproduces the reference's stale lanes, pinned by s1_local_cut), and
+    alignS_ng pushed into the linear-space branches in local mode"""
+    from spaln_amd import abi, synth
+    from oracle import oracle, host_logic
+    from tests.conftest import golden_files
+    fx = spdg.load([f for f in golden_files("s1_") if f.endswith("s1_local.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 98)
+    sc = spdg.scoring(fx)
+    assert sc.local
+    for n_im in (1, 3):
+        ps = abi.ProblemSet()
+        for i in range(24):
+            m = int(rng.integers(100, 400))
+            al = int(rng.integers(0, q["a_right"] - m))
+            bl = int(rng.integers(0, 300))
+            br = int(rng.integers(max(bl + m + 200, q["b_right"] - 600), q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 3 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg)
+        scores, cpos, rngs = eng.wip_udh(sc, ps, n_im)
+        bad = []
+        for i, p in enumerate(ps.items):
+            ws, wcpos, wrng = oracle.wip_udh(sc, p, n_im)
+            if int(scores[i]) != ws or rngs[i].tolist() != wrng.tolist() or \
+                    [_row(x) for x in cpos[i]] != [_row(x) for x in wcpos]:
+                bad.append((n_im, i, int(scores[i]), ws, rngs[i].tolist(), wrng.tolist(), cpos[i][:2].tolist(), wcpos[:2].tolist()))
+        assert not bad, bad[:3]
+    for vmf in (400000, 100000):
+        sc2 = spdg.scoring(fx, max_vmf_space=vmf)
+        ps = abi.ProblemSet()
+        for i in range(12):
+            m = int(rng.integers(250, q["a_right"]))
+            al = int(rng.integers(0, q["a_right"] - m + 1))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, 0, q["b_right"], (1, 1, 1, 1))
+        res = eng.align_s(sc2, ps)
+        bad = []
+        for i, p in enumerate(ps.items):
+            ws, wskl = host_logic.align_s(sc2, p)
+            if res[i][0] != ws or res[i][1].ravel().tolist() != (wskl or []):
+                bad.append((vmf, i, res[i][0], ws, res[i][1].ravel().tolist()[:12], (wskl or [])[:12]))
+        assert not bad, bad[:3]

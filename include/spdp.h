@@ -322,7 +322,8 @@ int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc,
                        const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 /* hirschbergH1_wip with n_im intermediate rows (src/fwd2h1_wip_simd.h:338): cpos[i] points at
  * (n_im + 1) * 10 ints, ranges[i*4..] receives the written-back a_left, a_right, b_left, b_right.
- * Non-local ends only. */
+ * With SpdpScoringH.local the local-ends form runs (its own kernel; a_right may come back one row beyond the
+ * query when the path ends on the last row, as in the reference, :652-653). */
 int spdp_wip_udh_h(SpdpContext* ctx, const SpdpScoringH* sc,
                    const SpdpProblemH* probs, int n_probs, int n_im,
                    int32_t* scores, int32_t* cpos, int32_t* ranges);

@@ -87,6 +87,10 @@ def trcbk_h(sc, p, w, rec, simd=2):
 def lsp_h(sc, p, w, rec, simd=2):
     m = p.a_right - p.a_left
     n = p.b_right - p.b_left
+    if p.a_left < 0 or p.b_left < 0 or p.a_right > p.a_len or p.b_right > p.b_len:
+        # e.g. the right end hirschbergH1_wip reports for a local path that ends on the last row lies one row
+        # beyond the query (src/fwd2h1_wip_simd.h:652-653): the reference then reads past its sequences
+        raise ReferenceUndefined("sub-range outside the sequences")
     if not m and not n:
         return 0
     if not m or not n:

@@ -422,7 +422,8 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
 
 // ---- scalar hirschbergH_ng over a list of items (spdp_h_scalar.hip) ----------------------------
 struct HUdhOut;
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, bool exact = false);
+// engine: 0 hirschbergH_ng (scalar), 1 hirschbergH1 (-A1), 2 hirschbergH1_wip with local ends (-LS)
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine = 0);
 
 // ---- hirschbergH1_wip over a list of items ------------------------------------------------------
 struct HUdhOut {
@@ -486,15 +487,16 @@ static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
     return 0;
 }
 
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, bool exact)
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine)
 {
+    const bool exact = engine != 0;
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[HU_POOL];
     const int nr = (int) items.size();
     out = HUdhOut();
     flags.assign(nr, 0);
     if (!nr) return 0;
-    if (!st.scalar_ok) { ctx->err = "the scalar engine needs SpdpScoringH.intpen / t53 and SpdpProblemH.dinc"; return -1; }
+    if (engine != 2 && !st.scalar_ok) { ctx->err = "the scalar engine needs SpdpScoringH.intpen / t53 and SpdpProblemH.dinc"; return -1; }
     int max_im = 1;
     for (const HItem& it : items) max_im = std::max(max_im, it.n_im);
     out.stride = (max_im + 1) * 10;
@@ -534,7 +536,8 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
     A.cpos_stride = out.stride;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (exact) HIPCHK(spdh_launch_exact(1, &A, ctx->stream));
+    if (engine == 2) HIPCHK(spdh_launch_local_udh(&A, ctx->stream));
+    else if (exact) HIPCHK(spdh_launch_exact(1, &A, ctx->stream));
     else HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     out.scores.resize(nr); out.cpos.resize((size_t) nr * out.stride); out.ranges.resize((size_t) nr * 4);
@@ -625,7 +628,7 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
             if (n_imd == 0) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
         }
     }
-    if (sc.local && a0_mode != 1) { t.cls = 1; return; }     // local linear-space SIMD engines: not built / not pinned
+    if (sc.local && a0_mode == 2) { t.cls = 1; return; }     // hirschbergH1 (-A1) with local ends: not pinned
     if (a0_mode && !scalar_ok) { t.cls = 1; return; }
     it.n_im = n_imd; it.recursive = recursive;
     udh.push_back(it);
@@ -670,7 +673,8 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         if (!udh.empty()) {
             HUdhOut uo;
             std::vector<int> uflags(udh.size(), 0);
-            if (a0_mode ? run_scalar_udh(st, udh, uo, uflags, a0_mode == 2) : run_udh(st, udh, uo)) return -1;
+            if (a0_mode ? run_scalar_udh(st, udh, uo, uflags, a0_mode == 2 ? 1 : 0)
+                        : sc.local ? run_scalar_udh(st, udh, uo, uflags, 2) : run_udh(st, udh, uo)) return -1;
             hs.udh_ms += uo.sweep_ms; hs.udh_cells += uo.cells;
             for (size_t u = 0; u < udh.size(); ++u) {
                 const HItem& it = udh[u];
@@ -849,7 +853,6 @@ int spdp_wip_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH*
                    int32_t* scores, int32_t* cpos, int32_t* ranges)
 {
     if (!ctx || !sc || !probs || n_probs < 0 || n_im < 1 || !scores || !cpos || !ranges) return -1;
-    if (sc->local) { ctx->err = "hirschbergH1_wip in local mode is not built"; return -1; }
     HStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
     std::vector<HItem> items;
@@ -860,7 +863,8 @@ int spdp_wip_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH*
         items.push_back(it);
     }
     HUdhOut uo;
-    if (run_udh(st, items, uo)) return -1;
+    std::vector<int> lfl;
+    if (sc->local ? run_scalar_udh(st, items, uo, lfl, 2) : run_udh(st, items, uo)) return -1;   // -LS: spdh_local_udh
     for (int i = 0; i < n_probs; ++i) {
         scores[i] = uo.scores[i];
         memcpy(cpos + (size_t) i * (n_im + 1) * 10, &uo.cpos[(size_t) i * uo.stride], (size_t) (n_im + 1) * 10 * sizeof(int32_t));
@@ -948,7 +952,7 @@ int spdp_scalar_udh_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProble
     }
     HUdhOut uo;
     std::vector<int> fl;
-    if (run_scalar_udh(st, items, uo, fl, sc->scalar_engines == 2)) return -1;  // 2: hirschbergH1 (imd_intvl unused)
+    if (run_scalar_udh(st, items, uo, fl, sc->scalar_engines == 2 ? 1 : 0)) return -1;  // 2: hirschbergH1 (imd_intvl unused)
     for (int i = 0; i < n_probs; ++i) {
         scores[i] = uo.scores[i];
         flags[i] = fl[i];

@@ -627,6 +627,435 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
 #undef LV
 }
 
+// ---- hirschbergH1_wip with local ends (-LS), src/fwd2h1_wip_simd.h:338-773 ---------------------------
+// The production linear-space sweep (spdh_udh, spdp_h_udh.hip) covers the non-local form.  With local ends the
+// reference carries the left-end row on H / E / F and the three phase donors as well, restarts paths at zero
+// and tracks the best cell -- and, as in the cDNA engine, reads lane state it does not re-initialise: the link
+// planes survive from stripe to stripe, and on stripes that hold an intermediate row the substitution lane is
+// overwritten with flag vectors (`Store(sm_a, ..)`, :601 / :676 / :707) that out-of-range lanes then add as
+// scores.  Same literal 16-lanes-per-problem form as spdh_exact above (planes in the lane's LDS column).
+enum { W_HV = 0, W_FV = 6, W_HB = 12, W_FB = 18, W_HC = 24, W_FC = 30, W_EV = 36, W_EB = 39, W_EC = 42, W_CP = 45,
+       W_S3 = 48, W_P3 = 54, W_S5 = 60, W_P5 = 66, W_IV = 72, W_IL = 75, W_IC = 78, W_IB = 81, W_END = 84 };
+
+__global__ void __launch_bounds__(64) spdh_local_udh(HScalarArgs A)
+{
+    __shared__ int L[W_END][64];
+    const int t = threadIdx.x;
+    const int k = t & 15;
+    const int grp = t >> 4;
+    const int pi = blockIdx.x * 4 + grp;
+    if (pi >= A.n_probs) return;
+    const DevProblemH P = A.probs[pi];
+    const DevScoringH* sc = A.sc;
+    const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
+    const int lw = P.lw, up = P.up, width = P.width, B = P.buf_size;
+    const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
+    const bool local = sc->local;
+    const bool LocalL = local && a_exgl && b_exgl, LocalR = local && a_exgr && b_exgr;
+    const bool spj = sc->spj;
+    const int gop = sc->gop, gep = sc->gep, lgep = sc->lgep, codonk1 = sc->codonk1;
+    const int g1 = sc->g1, g2 = sc->g2, g3 = sc->g3;
+    const int llmt = sc->llmt, nquant = sc->nquant;
+    const uint8_t* acod = A.a_codes + P.a_off;
+    const int4* cols = A.cols + P.col_off;
+    const short4* aux = A.aux + P.col_off;
+    int* hv = A.work + P.bnd_off - lw + 3;
+    int* fv = hv + B;
+    int* hb = fv + B;
+    int* fb = hb + B;
+    int* hc = fb + B;
+    int* fc = hc + B;
+    int* imd0 = A.imd + P.imd_off;
+    auto LNK = [&](int i, int which, int d, int r) -> int& { return imd0[((int64_t) i * 4 + which * 2 + d) * width + (r - lw + 1)]; };
+    const int n_im = P.n_im;
+    const int imd_step = (a_right - a_left + n_im) / (n_im + 1);
+    auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
+    auto qpen = [&](int hil) -> int {
+        int pv = sc->qm_pen[0];
+        for (int j = 1; j < nquant; ++j) if (hil > sc->qm_len[j - 1]) pv = sc->qm_pen[j];
+        return pv;
+    };
+#define LV(slot) L[(slot)][t]
+    const int rl = b_left - 3 * a_left;
+    for (int e = k; e < 2 * B; e += XN) {
+        (hv + lw - 3)[e] = XNEV;
+        (hb + lw - 3)[e] = a_left;
+        (hc + lw - 3)[e] = 0;
+    }
+    for (int e = k; e < n_im * 4 * width; e += XN) imd0[e] = X_EOU;
+    for (int s = 0; s < W_END; ++s) LV(s) = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (k == 0) {                                        // fhinitH1, Hirschberg form (:588-689)
+        const int re = a_exgl ? rl : up;
+        for (int r = lw; r < re; ++r) hc[r] = r;
+        for (int i = 0, r = rl; r >= lw; --r) hb[r] = a_left + (i++ / 3);
+        if (b_exgl == 1) { for (int r = lw; r < rl; ++r) hv[r] = 0; }
+        else if (b_exgl == 2) { fv[rl] = 0; fc[rl] = rl; }
+        int rr = b_right - 3 * a_left;
+        if (up < rr) rr = up;
+        int r = rl;
+        if (!a_exgl) {
+            if (b_exgl) { fv[r] = 0; fc[r] = hc[r]; }
+            hv[r++] = 0;
+            hv[r++] = xh_w16(g1);
+            hv[r++] = xh_w16(g2);
+            hv[r++] = xh_w16(g3);
+            if (gep) {
+                const int x = (XNEV - g3) / gep + r;
+                if (x < rr) rr = x;
+                for ( ; r < rr; ++r) hv[r] = xh_w16(hv[r - 3] + gep);
+            } else if (rr > r)
+                for (const int v = hv[r - 1]; r < rr; ++r) hv[r] = v;
+        } else {
+            int lend[3] = {r, r + 1, r + 2};
+            int bb = b_left + 1;
+            for (int f = 0; f < 3; ++f, ++r, ++bb) { hv[r] = aux[bb].x > 0 ? aux[bb].x : 0; hc[r] = r; }
+            for (int f = 0; r < rr; ++r, ++bb, f = (f + 1) % 3) {
+                int h = hv[r - 3];
+                hc[r] = hc[r - 3];
+                const int gl = r - lend[f];
+                if (!(a_exgl & 1) && gl == 3) h = xh_w16(h + gop);
+                if (!(a_exgl & 2)) h = xh_w16(h + gext3(gl));
+                h = xh_w16(h + aux[bb - 3].z);
+                hv[r] = h;
+                if (h < XNEV) break;
+                int x = xh_w16(hv[r - 1] + g1);
+                if (x > h) { hv[r] = h = x; hc[r] = hc[r - 1]; }
+                x = xh_w16(hv[r - 2] + g2);
+                if (x > h) { hv[r] = h = x; hc[r] = hc[r - 2]; }
+                x = aux[bb].x > 0 ? aux[bb].x : 0;
+                if (x > h) { hv[r] = x; lend[f] = r; hc[r] = r; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    int max_val = XNEV, max_ulk = X_EOU, max_ml = a_left, max_mr = a_right, max_nr = b_right;
+    int rlst[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int imd_i = 0;
+    int sm = 0;                                          // sm_a: kept across stripes except for the per-stripe clear
+    for (int ml = a_left; ml < a_right; ml += XN) {
+        const int j9 = min(XN, a_right - ml);
+        const int j8 = j9 - 1;
+        int n = max(b_left, lw + 3 * ml);
+        const int n9 = min(b_right, up + 3 * (ml + j9) + 1) + 3 * j9;
+        int q = xh_mod6(n + 3 * (ml + 1));
+        int r = n - 3 * (ml + 1);
+        int donor_r[3] = {r, r, r};
+        for (int i = 0; i < 6; ++i) {
+            LV(W_HV + i) = XNEV; LV(W_FV + i) = XNEV; LV(W_HB + i) = 0; LV(W_FB + i) = 0;
+            LV(W_S3 + i) = 0; LV(W_P3 + i) = 0; LV(W_S5 + i) = 0; LV(W_P5 + i) = 0;
+        }
+        for (int i = 0; i < 3; ++i) {
+            LV(W_EV + i) = XNEV; LV(W_EB + i) = 0; LV(W_CP + i) = 0;
+            LV(W_IV + i) = XNEV; LV(W_IL + i) = 0; LV(W_IC + i) = 0; LV(W_IB + i) = 0;
+        }
+        sm = 0;
+        int mm_ = 0, k9 = 0, k8 = -1;
+        bool is_imd_ = false;
+        if (imd_i < n_im) {
+            const int mi = a_left + (imd_i + 1) * imd_step;
+            mm_ = a_left + (mi - a_left - 1) / XN * XN;
+            k9 = mi - mm_; k8 = k9 - 1;
+            is_imd_ = ml == mm_;
+        }
+        (void) k9;
+        const int* mrow = sc->mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
+        for ( ; n < n9; ++n, ++r, q = xh_mod6(q + 1)) {
+            const int f3 = q % 3;
+            const int rj = r - 6 * k8;
+            const int nb = max(0, n - b_right + 1);
+            const int kb = (nb - 1) / 3;
+            const int ke = min(j9, (n - b_left) / 3);
+            const bool is_imd = is_imd_ && rj >= lw && rj <= up;
+            const int q1 = xh_mod6(q - 1), q2 = xh_mod6(q - 2), q3 = xh_mod6(q - 3), q4 = xh_mod6(q - 4), q5 = xh_mod6(q - 5);
+            const int c = n - 3 * k;
+            int4 col0 = make_int4(0, 0, 0, 0);           // the column record of this step (lane 0 feeds the pipes)
+            if (n < P.col_len) col0 = cols[n];
+            const unsigned fl0 = nb ? 0u : ((unsigned) col0.x >> 24);
+            // coding potential pipe (unconditional here, :121-125)
+            if (k == 0) LV(W_CP + f3) = (int) (short) (col0.x & 0xffff);
+            const int cv = LV(W_CP + f3);
+            { const int u = xh_up(cv); if (k) LV(W_CP + f3) = u; }
+            int uH3 = xh_up(LV(W_HV + q3)), uF3 = xh_up(LV(W_FV + q3)), uH4 = xh_up(LV(W_HV + q4)), uH5 = xh_up(LV(W_HV + q5));
+            int uC3 = xh_up(LV(W_HC + q3)), uFC3 = xh_up(LV(W_FC + q3)), uC4 = xh_up(LV(W_HC + q4)), uC5 = xh_up(LV(W_HC + q5));
+            int uB3 = xh_up(LV(W_HB + q3)), uFB3 = xh_up(LV(W_FB + q3)), uB4 = xh_up(LV(W_HB + q4)), uB5 = xh_up(LV(W_HB + q5));
+            int uH0 = xh_up(LV(W_HV + q)), uC0 = xh_up(LV(W_HC + q)), uB0 = xh_up(LV(W_HB + q));
+            if (k == 0) {
+                uF3 = fv[r + 3]; uFC3 = fc[r + 3]; uH3 = hv[r + 3]; uC3 = hc[r + 3];
+                uH4 = hv[r + 2]; uC4 = hc[r + 2]; uH5 = hv[r + 1]; uC5 = hc[r + 1];
+                uH0 = hv[r]; uC0 = hc[r];
+                // the `ml` feeds exist only with local left ends; entry 0 otherwise keeps the per-stripe zero
+                if (LocalL) { uFB3 = fb[r + 3]; uB3 = hb[r + 3]; uB4 = hb[r + 2]; uB5 = hb[r + 1]; uB0 = hb[r]; }
+                else { uFB3 = uB3 = uB4 = uB5 = uB0 = 0; }
+            }
+            // insertion
+            int ev, eb, ec;
+            {
+                int h = xh_add(LV(W_HV + q1), g1), cc = LV(W_HC + q1), bb2 = LV(W_HB + q1);
+                int x = xh_add(LV(W_HV + q2), g2);
+                bool mk = h > x;
+                h = mk ? h : x; cc = mk ? cc : LV(W_HC + q2); bb2 = mk ? bb2 : LV(W_HB + q2);
+                x = xh_add(xh_add(LV(W_HV + q3), g3), cv);
+                mk = h > x;
+                h = mk ? h : x; cc = mk ? cc : LV(W_HC + q3); bb2 = mk ? bb2 : LV(W_HB + q3);
+                x = xh_add(xh_add(LV(W_EV + f3), gep), cv);
+                mk = x > h;
+                ev = mk ? x : h; ec = mk ? LV(W_EC + f3) : cc; eb = mk ? LV(W_EB + f3) : bb2;
+            }
+            LV(W_EV + f3) = ev; LV(W_EC + f3) = ec;
+            if (LocalL) LV(W_EB + f3) = eb;
+            // deletion
+            int fvv, fcc, fbb;
+            {
+                int h = xh_add(uF3, gep), cc = uFC3, bb2 = uFB3;
+                int x = xh_add(uH3, g3);
+                bool mk = h > x;
+                h = mk ? h : x; cc = mk ? cc : uC3; bb2 = mk ? bb2 : uB3;
+                x = xh_add(uH4, g2);
+                mk = h > x;
+                h = mk ? h : x; cc = mk ? cc : uC4; bb2 = mk ? bb2 : uB4;
+                x = xh_add(uH5, g1);
+                mk = h > x;
+                fvv = mk ? h : x; fcc = mk ? cc : uC5; fbb = mk ? bb2 : uB5;
+            }
+            LV(W_FV + q) = fvv; LV(W_FC + q) = fcc;
+            if (LocalL) LV(W_FB + q) = fbb;
+            // diagonal, best of three
+            if (nb) sm = 0;
+            if (k >= kb && k < ke) sm = xh_w16(mrow[(cols[c].x >> 16) & 0xff]);
+            const int dv = uH0;
+            int hx, hcx, hbx, pb, ab = 0;
+            {
+                int h = xh_add(xh_add(sm, dv), cv);
+                int cc = uC0, bb2 = uB0;
+                bool mk = fvv > h;
+                h = mk ? fvv : h; cc = mk ? fcc : cc; bb2 = mk ? fbb : bb2;
+                pb = mk ? 2 : 0;
+                mk = ev > h;
+                h = mk ? ev : h; cc = mk ? ec : cc; bb2 = mk ? eb : bb2;
+                pb = mk ? 1 : pb;
+                hx = h; hcx = cc; hbx = bb2;
+            }
+            const int pv_k8 = __shfl(pb, max(k8, 0), XN);    // PV[f3][k8] of this step
+            // intron 3' boundary: two legs (phase of the site, and +1 when both phases are sites)
+            if (spj) {
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int pk = 2 * f3 + k2;
+                    int f_s = SPDH_MIN_SSV, f_p = 0;
+                    const unsigned a3 = fl0 & 7u;            // (phase + 2) | 4 when phs3 == 2
+                    if (!k2) { if (a3 & 3u) { f_s = (int) (short) (col0.y & 0xffff); f_p = (int) (a3 & 3u); } }
+                    else if (a3 & 4u) { f_s = (int) (short) ((unsigned) col0.y >> 16); f_p = 3; }
+                    if (k == 0) { LV(W_S3 + pk) = f_s; LV(W_P3 + pk) = f_p; }
+                    const int ss = LV(W_S3 + pk), ph = LV(W_P3 + pk);
+                    { const int us = xh_up(ss), upp = xh_up(ph); if (k) { LV(W_S3 + pk) = us; LV(W_P3 + pk) = upp; } }
+                    const unsigned long long bal = __ballot(ph != 0);
+                    if (!((bal >> (grp * 16)) & 0xffffull)) continue;
+                    for (int f = 0; f < 3; ++f) {
+                        int x = xh_add(LV(W_IV + f), ss);
+                        x = xh_add(x, qpen(LV(W_IL + f)));
+                        x = (ph == f + 1) ? x : XNEV;
+                        x = (LV(W_IL + f) > llmt) ? x : XNEV;
+                        const bool mk = x > hx;
+                        hx = mk ? x : hx;
+                        hcx = mk ? LV(W_IC + f) : hcx;
+                        if (LocalL) hbx = mk ? LV(W_IB + f) : hbx;
+                        ab |= mk ? 1 : 0;
+                        if (is_imd) {
+                            sm = mk ? 1 : 0;                 // Store(sm_a, qv_v)
+                            if (k == k8 && mk) {
+                                LNK(imd_i, 0, 0, rj) = donor_r[f];
+                                LNK(imd_i, 0, 1, rj) = donor_r[f] + width;
+                                rlst[f3] = rj;
+                            }
+                        }
+                    }
+                }
+            }
+            if (LocalL && 0 > hx) hx = 0;
+            LV(W_HV + q) = hx; LV(W_HC + q) = hcx;
+            if (LocalL) LV(W_HB + q) = hbx;
+            if (LocalL && k >= kb && k < ke && hx == 0) { LV(W_HB + q) = xh_w16(ml + k); LV(W_HC + q) = r - 6 * k; }
+            if (LocalR) {
+                int bv = (k < j9) ? LV(W_HV + q) : -0x7fffffff, bk = k;
+                for (int o = 1; o < XN; o <<= 1) {
+                    const int ov = __shfl_xor(bv, o, XN), ok = __shfl_xor(bk, o, XN);
+                    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+                }
+                if (bv > max_val) {
+                    max_val = bv;
+                    max_ml = __shfl(LV(W_HB + q), bk, XN); max_ulk = __shfl(LV(W_HC + q), bk, XN);
+                    max_mr = ml + bk + 2; max_nr = n - 3 * (bk + 1);
+                }
+            }
+            // intron 5' boundary
+            if (spj) {
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int pk = 2 * f3 + k2;
+                    int f_s = SPDH_MIN_SSV, f_p = 0;
+                    const unsigned a5 = (fl0 >> 3) & 7u;
+                    if (!k2) { if (a5 & 3u) { f_s = (int) (short) (col0.z & 0xffff); f_p = (int) (a5 & 3u); } }
+                    else if (a5 & 4u) { f_s = (int) (short) ((unsigned) col0.z >> 16); f_p = 3; }
+                    if (k == 0) { LV(W_S5 + pk) = f_s; LV(W_P5 + pk) = f_p; }
+                    const int ss = LV(W_S5 + pk), ph = LV(W_P5 + pk);
+                    { const int us = xh_up(ss), upp = xh_up(ph); if (k) { LV(W_S5 + pk) = us; LV(W_P5 + pk) = upp; } }
+                    const unsigned long long bal = __ballot(ph != 0);
+                    if (!((bal >> (grp * 16)) & 0xffffull)) continue;
+                    for (int f = k2 ? 2 : 0; f < 3; ++f) {
+                        int x = (f == 2) ? xh_add(dv, ss) : xh_add(hx, ss);
+                        x = (ab == 0) ? x : XNEV;
+                        x = (ph == f + 1) ? x : XNEV;
+                        const bool mk = x > LV(W_IV + f);
+                        LV(W_IV + f) = mk ? x : LV(W_IV + f);
+                        LV(W_IL + f) = xh_add(mk ? 0 : LV(W_IL + f), 1);
+                        LV(W_IC + f) = mk ? hcx : LV(W_IC + f);
+                        if (LocalL) LV(W_IB + f) = mk ? hbx : LV(W_IB + f);
+                        if (is_imd) {
+                            sm = mk ? 1 : 0;                 // Store(sm_a, pv_v)
+                            if (k == k8 && mk) donor_r[f] = rj;
+                        }
+                    }
+                }
+            }
+            if (is_imd) {
+                sm = ab;
+                if (k == k8) {
+                    if (pv_k8 == 0) rlst[f3] = rj;
+                    if (!ab && pv_k8 == 1) LNK(imd_i, 0, 0, rj) = rlst[f3];
+                    LNK(imd_i, 1, 0, rj) = LV(W_HC + q); LV(W_HC + q) = rj;
+                    LNK(imd_i, 1, 1, rj) = LV(W_FC + q); LV(W_FC + q) = rj + width;
+                }
+            }
+            const int r0 = r - 6 * j8;
+            if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) {
+                hv[r0] = LV(W_HV + q); hc[r0] = LV(W_HC + q);
+                fv[r0] = LV(W_FV + q); fc[r0] = LV(W_FC + q);
+                if (LocalL) { hb[r0] = LV(W_HB + q); fb[r0] = LV(W_FB + q); }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (is_imd_) {
+            for (int i = 0; i < 3; ++i) rlst[i] = __shfl(rlst[i], k8, XN);
+            ++imd_i;
+        }
+    }
+    if (k) return;
+
+    // ---- fhlastH1 (unless a local right end inside the matrix was tracked), then the link walk (:735-773)
+    int maxt = 0;
+    const bool by_last = !(LocalR && max_mr < a_right);
+    if (by_last) {
+        int glen[3] = {0, 0, 0};
+        bool tcdn[3] = {false, false, false};
+        const int m3 = 3 * a_right;
+        int rw = lw;
+        int rf = b_left - m3;
+        if (rf > rw) rw = rf; else rf = rw;
+        const int rr = b_right - m3;
+        int maxr = rr, mx = rr;
+        int bb = rw + m3;
+        if (a_exgr) {
+            int f = 0;
+            for (int h = rw; h <= rr; ++h, ++rf, ++bb, f = (f + 1) % 3) {
+                glen[f] += 3;
+                int cand[3] = {hv[h], XNEV, XNEV};
+                if (rf - rw >= 3 && !tcdn[f]) {
+                    cand[1] = hv[h - 3] + aux[bb - 2].z;
+                    if (!(a_exgr & 2)) cand[1] += gext3(glen[f]);
+                    if (!(a_exgr & 1) && glen[f] == 3) cand[1] += gop;
+                    if (sc->term_codon) cand[2] = hv[h - 3] + aux[bb - 2].y;
+                }
+                if (rf - rw >= 3) tcdn[f] = tcdn[f] || aux[bb - 2].y > 0;
+                const int s5 = (local && aux[bb].w > 0) ? aux[bb].w : 0;
+                cand[0] += s5; cand[1] += s5;
+                int kk = 0;
+                if (cand[1] > cand[kk]) kk = 1;
+                if (cand[2] > cand[kk]) kk = 2;
+                if (kk == 0) { glen[f] = 0; tcdn[f] = false; }
+                else if (kk == 1) hv[h] = xh_w16(cand[1] - s5);
+                else hv[h] = xh_w16(cand[2]);
+                if (hv[h] > hv[mx]) { mx = h; maxr = rf - (kk == 2 ? 3 : 0); }
+            }
+        } else {
+            const int y = xh_w16(hv[rr - 3] + aux[bb + (rr - rw)].y);
+            if (y > hv[rr]) { hv[rr] = y; maxr = rr - 3; }
+        }
+        if (b_exgr) {
+            rw = min(up - 1, b_right - 3 * a_left);
+            int g[3] = {XNEV, XNEV, XNEV};
+            int f = 0;
+            for (int h = rw - 3; h > rr; --h, f = (f + 1) % 3) {
+                int x = hv[h + 3];
+                if (!(b_exgr & 1)) x = xh_w16(x + gop);
+                if (x > g[f]) g[f] = x;
+                if (!(b_exgr & 2)) g[f] = xh_w16(g[f] + gep);
+                if (hv[h] > g[f]) g[f] = XNEV;
+                else if (g[f] > hv[mx]) { mx = h; hv[h] = g[f]; }
+            }
+        }
+        maxt = mx;
+        hb[maxt] = hb[maxr];
+        max_ulk = hc[maxr];
+        const int qd = maxr - rr;
+        if (qd > 0) max_mr = (b_right - maxr) / 3;
+        else        max_nr = maxt + m3;
+        max_ml = LocalL ? hb[maxt] : a_left;
+    }
+    {
+        int* cpos = A.cpos + (int64_t) pi * A.cpos_stride;
+        for (int i = 0; i < A.cpos_stride; ++i) cpos[i] = X_EOU;
+        auto mi_of = [&](int i) { return a_left + (i + 1) * imd_step; };
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+        int al = a_left, bl = b_left;
+        const int ar = max_mr, br = max_nr;
+        int val = max_val;
+        int i = n_im;
+        while (--i >= 0 && mi_of(i) > ar) ;
+        if (i < 0 && mi_of(0) > ar) CPOS(0, 2) = br;
+        int r = max_ulk;
+        for ( ; i >= 0 && mi_of(i) > max_ml; --i) {
+            int c = 0, d = 0;
+            for ( ; r > up; r -= width) ++d;
+            if (LNK(i, 1, d, r) < X_EOU) {
+                CPOS(i, c++) = mi_of(i);
+                CPOS(i, c++) = (d > 0) ? 1 : 0;
+                const int m3 = 3 * mi_of(i);
+                for (int rp = LNK(i, 0, d, r); lw <= rp && rp < up && r != rp && c < 8; rp = LNK(i, 0, d, r = rp))
+                    CPOS(i, c++) = r + m3;
+                CPOS(i, c++) = r + m3;
+                CPOS(i, c) = X_EOU;
+                r = LNK(i, 1, d, r);
+                if (r == X_EOU) break;
+            } else
+                CPOS(i, 0) = X_EOU;
+        }
+        for ( ; r > up; r -= width) ;
+        if (LocalL) { al = max_ml; bl = r + 3 * al; }
+        else {
+            const int rl2 = bl - 3 * al;
+            if (b_exgl && rl2 > r) {
+                al = (bl - r) / 3;
+                for (int j = 0; j < n_im && mi_of(j) < al; ++j) CPOS(j, 0) = X_EOU;
+            }
+            if (a_exgl && rl2 < r) bl = 3 * al + r;
+        }
+        ++i;
+        if ((i >= 0 && i < n_im && mi_of(i) < al) || CPOS(i, 2) < bl) val = INT32_MIN / 16 * 7;
+#undef CPOS
+        A.scores[pi] = val;
+        int* rg = A.ranges + 4 * (int64_t) pi;
+        rg[0] = al; rg[1] = ar; rg[2] = bl; rg[3] = br;
+    }
+#undef LV
+}
+
+extern "C" hipError_t spdh_launch_local_udh(const HScalarArgs* a, hipStream_t stream)
+{
+    HScalarArgs A = *a;
+    hipLaunchKernelGGL(spdh_local_udh, dim3((A.n_probs + 3) / 4), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t spdh_launch_exact(int udh, const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;

@@ -83,6 +83,7 @@ struct HScalarArgs {
 extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_exact(int udh, const HScalarArgs* a, hipStream_t s);   // -A1: forwardH1 / hirschbergH1
+extern "C" hipError_t spdh_launch_local_udh(const HScalarArgs* a, hipStream_t s);        // hirschbergH1_wip, -LS
 extern "C" hipError_t spdh_launch_udh(const HUdhArgs* a, int spj, int pen_cap, hipStream_t s);
 extern "C" hipError_t spdh_launch_cpos(const HCposArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_sweep(const HSweepArgs* a, int spj, int pen_cap, int local, hipStream_t s);

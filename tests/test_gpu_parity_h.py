@@ -157,9 +157,7 @@ def _udh_cases():
     import re
     out = []
     for f in H_FILES:
-        if _name(f) in LOCAL:
-            continue
-        fx = spdg.load(f)
+        fx = spdg.load(f)                       # h1_local too: hirschbergH1_wip with local ends (spdh_local_udh)
         for k in fx:
             m = re.match(r"wip_(qn|q1)_udh(\d+)_scr", k)
             if m:
@@ -265,3 +263,53 @@ def test_align_h_a6_recursive_switch(eng):
         for (name, fx), (score, skl, flag) in zip(sub, res):
             assert flag == 0 and score == int(fx["aln_scr_A6"][0]), name
             assert skl.ravel().tolist() == fx["aln_skl_A6"].tolist(), name
+
+
+def test_local_udh_against_oracle(eng):
+    """hirschbergH1_wip with local ends (-LS, spdh_local_udh) on random sub-ranges against the oracle (pinned by
+    the h1_local records), and alignH_ng in local mode pushed into the linear-space branches"""
+    from oracle import oracle, host_logic_h as hh
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_local.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 99)
+    sc = spdg.scoring_h(fx)
+    assert sc.local
+    for n_im in (1, 3):
+        ps = abi.ProblemSetH()
+        for i in range(24):
+            m = int(rng.integers(40, 150))
+            al = int(rng.integers(0, q["a_right"] - m + 1))
+            bl = int(rng.integers(1, 300))
+            br = int(rng.integers(max(bl + 3 * m + 100, q["b_right"] - 500), q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 3 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, al + m, bl, br, exg, exin=(q["b_left"], q["b_right"]))
+        scores, cpos, ranges = eng.wip_udh_h(sc, ps, n_im)
+        bad = []
+        for i, p in enumerate(ps.items):
+            ws, wcpos, wrng = oracle.wip_udh_h(sc, p, n_im)
+            if int(scores[i]) != ws or ranges[i].tolist() != wrng.tolist() or cpos[i].tolist() != wcpos.tolist():
+                bad.append((n_im, i, int(scores[i]), ws, ranges[i].tolist(), wrng.tolist(), cpos[i][:2].tolist(), wcpos[:2].tolist()))
+        assert not bad, bad[:3]
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    for vmf in (100000, 30000):
+        sc2 = spdg.scoring_h(fx, max_vmf_space=vmf)
+        ps = abi.ProblemSetH()
+        for i in range(10):
+            m = int(rng.integers(80, q["a_right"] + 1))
+            al = int(rng.integers(0, q["a_right"] - m + 1))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, al + m, q["b_left"], q["b_right"], (1, 1, 1, 1),
+                   exin=(q["b_left"], q["b_right"]), dinc=dinc)
+        res = eng.align_h(sc2, ps)
+        bad, n_ok = [], 0
+        for i, (p, (score, skl, flag)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = hh.align_h(sc2, p)
+            except (hh.ReferenceUndefined, hh.NotRestated, hh.ReferenceFatal):
+                assert flag != 0, i
+                continue
+            n_ok += 1
+            if flag != 0 or score != ws or skl.ravel().tolist() != (wskl or []):
+                bad.append((vmf, i, flag, score, ws, skl.ravel().tolist()[:12], (wskl or [])[:12]))
+        assert n_ok >= 6 and not bad, bad[:3]

@@ -126,7 +126,8 @@ int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc,
 
 /* hirschbergS1_wip with n_im intermediate rows: cpos[i] points at
  * (n_im + 1) * 10 ints (Dim10 rows, src/udh_intermediate.h:90); ranges[i*4..]
- * receives the written-back a_left, a_right, b_left, b_right. */
+ * receives the written-back a_left, a_right, b_left, b_right.  With SpdpScoring.local the
+ * local-ends form runs (spdp_local_udh.hip). */
 int spdp_wip_udh(SpdpContext* ctx, const SpdpScoring* sc,
                  const SpdpProblem* probs, int n_probs, int n_im,
                  int32_t* scores, int32_t* cpos, int32_t* ranges);
@@ -334,8 +335,8 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
  * hirschbergH1_wip + per-slab forwardH1_wip (mimd_postwork / rcsv_postwork) -> stdskl3.
  * Sub-problems below 8 query rows run the scalar forwardH_ng (needs the scalar engine's inputs, see
  * spdp_scalar_forward_h).  Return value 1: some problem needs an engine that is not built (diagonalH_ng,
- * the local linear-space engine) or the scalar inputs are missing; those come back with n_skl = 0,
- * score NEVSEL. */
+ * the -A1 linear-space engine with local ends), the links lead outside the sequences (undefined in the
+ * reference) or the scalar inputs are missing; those come back with n_skl = 0, score NEVSEL. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 

@@ -87,9 +87,11 @@ def trcbk_h(sc, p, w, rec, simd=2):
 def lsp_h(sc, p, w, rec, simd=2):
     m = p.a_right - p.a_left
     n = p.b_right - p.b_left
-    if p.a_left < 0 or p.b_left < 0 or p.a_right > p.a_len or p.b_right > p.b_len:
-        # e.g. the right end hirschbergH1_wip reports for a local path that ends on the last row lies one row
-        # beyond the query (src/fwd2h1_wip_simd.h:652-653): the reference then reads past its sequences
+    # the right end hirschbergH1[_wip] reports for a local path that ends on the last row lies one row beyond the
+    # query (src/fwd2h1_wip_simd.h:652-653, fwd2h1_simd.h:1355): the reference goes on with it and reads the
+    # byte behind the sequence (0 in its process, measured through the fixture harness), which the engines
+    # reproduce; anything further out is outside its arrays
+    if p.a_left < 0 or p.b_left < 0 or p.a_right > p.a_len + 1 or p.b_right > p.b_len:
         raise ReferenceUndefined("sub-range outside the sequences")
     if not m and not n:
         return 0

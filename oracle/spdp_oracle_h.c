@@ -442,7 +442,7 @@ static void h_sweep(HEng* e)
             /* diagonal */
             if (nb) for (int k = 0; k < NELEM; ++k) SM[k] = 0;
             for (int k = kb; k < ke; ++k)
-                SM[k] = w16(sc->mtx[p->a[ml + k] * sc->mtx_cols + p->b[n - 3 * k - 2]]);
+                SM[k] = w16(sc->mtx[(ml + k < p->a_len ? p->a[ml + k] : 0 /* the byte behind the query: 0 in the reference process */) * sc->mtx_cols + p->b[n - 3 * k - 2]]);
             H[q][0] = hv[r];
             for (int k = 0; k < NELEM; ++k) {
                 dv[k] = H[q][k];
@@ -704,7 +704,7 @@ static int h_sweep_udh(HEng* e, int n_im, HImd* imds)
             /* diagonal */
             if (nb) for (int k = 0; k < NELEM; ++k) SM[k] = 0;
             for (int k = kb; k < ke; ++k)
-                SM[k] = w16(sc->mtx[p->a[ml + k] * sc->mtx_cols + p->b[n - 3 * k - 2]]);
+                SM[k] = w16(sc->mtx[(ml + k < p->a_len ? p->a[ml + k] : 0 /* the byte behind the query: 0 in the reference process */) * sc->mtx_cols + p->b[n - 3 * k - 2]]);
             H[q][0] = hv[r]; HC[q][0] = hc[r]; if (LocalL) HB[q][0] = hb[r];
             for (int k = 0; k < NELEM; ++k) {
                 dv[k] = H[q][k];

@@ -1332,7 +1332,7 @@ static void xh_step(XhEng* e, int ml, int j9, int n, int r, int q, int udh)
     for (int k = 0; k < XN; ++k) { e->FV[q][k + 1] = fvv[k]; e->FC[q][k + 1] = fcv[k]; if (udh && LL) e->FB[q][k + 1] = fbv[k]; }
     if (nb) for (int k = 0; k < XN; ++k) e->SM[k] = 0;           /* diagonal */
     for (int k = kb; k < ke; ++k)
-        e->SM[k] = xw16(sc->mtx[p->a[ml + k] * sc->mtx_cols + p->b[n - 3 * k - 2]]);
+        e->SM[k] = xw16(sc->mtx[(ml + k < p->a_len ? p->a[ml + k] : 0 /* the byte behind the query: 0 in the reference process */) * sc->mtx_cols + p->b[n - 3 * k - 2]]);
     e->HV[q][0] = e->hv[r]; e->HC[q][0] = e->hc[r];
     if (!udh || LL) e->HB[q][0] = e->hb[r];
     int hx[XN], hbx[XN], hcx[XN], qb[XN];

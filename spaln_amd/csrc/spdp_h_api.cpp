@@ -138,6 +138,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         col_off[i] = (int64_t) cols.size();
         col_len[i] = p.b_len + 3 + SPDH_COL_PAD;
         a_all.insert(a_all.end(), p.a, p.a + p.a_len);
+        a_all.push_back(0);                     // the byte behind the query reads 0 in the reference process (row a_len, see bad_range)
         // column records (layout: spdp_h_dev.h); positions beyond the inputs read as zero
         const int N = p.b_len + 3;
         auto good = [&](int x) { return p.exin_left - 1 <= x && x < p.exin_right; };
@@ -571,7 +572,9 @@ static void push_rec(HTop& t, int m, int n) { SpdpSkl s; s.m = m; s.n = n; t.rec
 // engine on it anyway (out-of-bounds reads); here the query is reported as not computed
 static bool bad_range(const HItem& it, const SpdpProblemH& p)
 {
-    return it.a_left < 0 || it.b_left < 0 || it.a_right > p.a_len || it.b_right > p.b_len ||
+    // a_len + 1: the right end the local linear-space engines report for a path that ends on the last row
+    // (src/fwd2h1_wip_simd.h:652-653); the reference goes on with it and reads the padding residue
+    return it.a_left < 0 || it.b_left < 0 || it.a_right > p.a_len + 1 || it.b_right > p.b_len ||
            it.a_right < it.a_left || it.b_right < it.b_left || it.b_left < p.exin_left || it.b_right > p.exin_right;
 }
 
@@ -628,7 +631,6 @@ static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd,
             if (n_imd == 0) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
         }
     }
-    if (sc.local && a0_mode == 2) { t.cls = 1; return; }     // hirschbergH1 (-A1) with local ends: not pinned
     if (a0_mode && !scalar_ok) { t.cls = 1; return; }
     it.n_im = n_imd; it.recursive = recursive;
     udh.push_back(it);

@@ -75,6 +75,8 @@ def cases():
     g = gene(9, n_exons=4, mrna_len=500, flank=200, intron_hi=400, sub=0.05)
     c["s1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
     c["s1_local_cut"] = (*cut(g, g.exons[1][0] + 30, g.exons[3][1] - 40), ["-L", "-u", "1,3"])
+    # local ends with the ladder forced into its linear-space branches (small MaxVmfSpace)
+    c["s1_local_udh"] = (g.window, g.query, ["-L", "-V", "300000", "-u", "2"])
     # unrelated sequences, and tiny queries
     w, q = random_pair(10, 250, 1800)
     c["s1_random"] = (w, q, ["-u", "1,2"])
@@ -133,6 +135,7 @@ def protein_cases():
         c[f"h1_exg_{flags}"] = (g.window, g.query, ["-g", flags, "-u", "1,2"])
     g = pgene(8, n_exons=4, aa_len=160, flank=200, intron_hi=400, sub=0.15)
     c["h1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
+    c["h1_local_udh"] = (g.window, g.query, ["-L", "-V", "100000", "-u", "3"])
     rng = np.random.default_rng(synth.SEED + 590)
     c["h1_random"] = (synth.random_dna(rng, 1500),
                       synth._AA_LETTERS[rng.integers(0, 20, size=90)], ["-u", "1"])

@@ -26,7 +26,7 @@ def eng():
 
 
 def _batch(local):
-    cases = [(_name(f), spdg.load(f)) for f in H_FILES if (_name(f) == "h1_local") == local]
+    cases = [(_name(f), spdg.load(f)) for f in H_FILES if bool(spdg.load(f)["prm"]["local"]) == local]
     sc = spdg.scoring_h(max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size))
     ps = abi.ProblemSetH()
     for _, fx in cases:
@@ -120,7 +120,7 @@ def test_align_a0_goldens(eng):
     """alignH_ng / HomScoreH_ng with SpdpScoringH.scalar_engines = 1 against the reference's -A0 output.
     (One GPU thread per problem: the 400 / 450 aa fixtures take minutes and stay with the CPU suite.)"""
     for local in (False, True):
-        cases = [(_name(f), spdg.load(f)) for f in H_FILES if (_name(f) == "h1_local") == local]
+        cases = [(_name(f), spdg.load(f)) for f in H_FILES if bool(spdg.load(f)["prm"]["local"]) == local]
         cases = [(n, fx) for n, fx in cases if fx["prm"]["a_right"] - fx["prm"]["a_left"] <= 330]
         ref = max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size)
         key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])

@@ -104,6 +104,9 @@ def test_skl_rng_h_vs_reference(path, alg):
         pytest.skip("no alignment under this selector")
     if _name(path) == "h1_cut_right":
         pytest.skip("alignment lies beyond the window: the reference reads its heap (undefined)")
+    if _name(path) == "h1_local_udh" and alg in (2, 3):
+        pytest.skip("the -LS linear-space engine ends this alignment one row beyond the query (a reference quirk, "
+                    "fwd2h1_wip_simd.h:652): the rescoring reads whatever lies behind the sequence")
     sc = spdg.scoring_h(fx, nquant=None if alg != 3 else 1)
     _, p = spdg.problem_h(fx)
     h, fst, recs = hh.skl_rng_h(sc, p, [int(x) for x in fx[f"aln_skl_A{alg}"]], **_rescore_kw(fx))

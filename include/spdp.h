@@ -66,7 +66,7 @@ typedef struct SpdpScoring {
                                         1: algmode.alg == 0 (-A0): spdp_align_s runs forwardS_ng /
                                         hirschbergS_ng throughout, spdp_homscore_s scorealoneS_ng;
                                         2: algmode.alg == 1 (-A1): spdp_homscore_s runs scoreonlyS1,
-                                        spdp_align_s forwardS1 / hirschbergS1 (non-local ends) */
+                                        spdp_align_s forwardS1 / hirschbergS1 */
     int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
     int32_t recursive;               /* algmode.alg & 4 (-A4 .. -A7): lspS_ng always takes the recursive
                                         linear-space branch (one intermediate row, halves of halves)   */

@@ -145,8 +145,8 @@ def lsp(sc, p, w, rec, simd=2):
         if flag:
             raise ReferenceUndefined("hirschbergS_ng outside its arrays")
     elif simd == 1:
-        if sc.local or not sc.intpen or not p.cano5:
-            raise NeedsScalarEngine("hirschbergS1 in local mode / without its inputs")
+        if not sc.intpen or not p.cano5:
+            raise NeedsScalarEngine("hirschbergS1 without its inputs")
         scr, cpos, rng = oracle.exact_udh(sc, p, n_imd, w)
     else:
         scr, cpos, rng = oracle.wip_udh(sc, p, n_imd, w)

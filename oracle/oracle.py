@@ -148,7 +148,7 @@ def exact_forward(sc, p, w=None):
 
 
 def exact_udh(sc, p, n_im: int, w=None):
-    """SimdAln2s1::hirschbergS1 (-A1, non-local): (score, cpos rows, written-back ranges)"""
+    """SimdAln2s1::hirschbergS1 (-A1): (score, cpos rows, written-back ranges)"""
     w = w or stripe(p, sc.sh)
     s = C.c_int32()
     cpos = np.zeros((n_im + 1, 10), dtype=np.int32)

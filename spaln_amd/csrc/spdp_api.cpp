@@ -305,7 +305,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.tb_off = tb_tot;
         if (flav >= 6) {                // -A1 engines: hv / fv (/ hb / hc / fc) by diagonal, buf_size ints each, a counter
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + (flav == 9 ? 6ll : 5ll) * P.buf_size + 8;
+            bnd_tot = P.bnd_off + (flav >= 8 ? 6ll : 5ll) * P.buf_size + 8;   // udh forms: + the `ml` row of F
             if (flav >= 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
             if (flav == 7) {
                 const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
@@ -451,7 +451,7 @@ int DevRun::launch()
             CposArgs C;
             C.probs = S.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
             C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
-            C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = flavour == 9;
+            C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = store->sc.local ? 1 : 0;
             HIPCHK(spdp_launch_cpos(&C, ctx->stream));
         }
         return 0;

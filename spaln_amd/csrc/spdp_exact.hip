@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     int* hc = hb + P.buf_size;
     int* fc = hc + P.buf_size;
     int* vcount = A.work + P.bnd_off + 5 * (int64_t) P.buf_size;          // forward: records appended so far
+    int* fb = fc + P.buf_size;                   // udh with local left ends: left-end row (`ml`) of F (hb: of H)
     int3* vrec = A.vmf + P.tb_off;
     const int vcap = (int) P.imd_off;
     auto vadd = [&](int mm, int nn, int pp) -> int {
@@ -109,6 +110,9 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 if (r >= rl) { if (a_exgl) c = (r < ru) ? r : 0; else c = (r <= ru) ? rl : 0; }
                 else c = b_exgl ? r : rl;
                 hc[r] = c; fc[r] = c;
+                int bm = a_left;                     // bbuf = a_left; the free left column counts rows upwards (:209-224)
+                if (b_exgl && r <= rl && r >= lw) bm = a_left + (rl - r);
+                hb[r] = bm; fb[r] = a_left;
             }
         }
         if constexpr (UDH) {
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-    int maxh = XNEV, max_ulk = 0, max_mr = a_right, max_nr = b_right;
+    int maxh = XNEV, max_ulk = 0, max_mr = a_right, max_nr = b_right, max_ml = a_left;
     int imd_i = 0, rlst = 0x7fffffff;            // udh: current intermediate, hs1.rlst
     for (int ml = a_left; ml < a_right; ml += XN) {
         const int j9 = min(XN, a_right - ml);
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             const int ke = min(j9, n - b_left);
             const int nj = n - k;                             // my column
             // boundary feeds of lane 0 (previous stripe's bottom row, by diagonal)
-            int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0;
+            int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0, bB1 = 0, bFB1 = 0;
             if (k == 0) {
                 bH1 = __builtin_nontemporal_load(&hv[r + 1]);
                 bF1 = __builtin_nontemporal_load(&fv[r + 1]);
@@ -165,18 +169,25 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                     bC2 = __builtin_nontemporal_load(&hc[r]);
                 }
                 if constexpr (FORWARD) bB2 = __builtin_nontemporal_load(&hb[r]);
+                if constexpr (UDH) {
+                    if (LocalL) { bB2 = __builtin_nontemporal_load(&hb[r]); bB1 = __builtin_nontemporal_load(&hb[r + 1]);
+                                  bFB1 = __builtin_nontemporal_load(&fb[r + 1]); }
+                }
             }
             int upH1 = x_up(H1), upF1 = x_up(F1), upH2 = x_up(H2);
             int upC1 = 0, upFC1 = 0, upB2 = 0, upC2 = 0;
             if constexpr (PTR) { upC1 = x_up(C1); upFC1 = x_up(FC1); upC2 = x_up(C2); }
             if constexpr (FORWARD) upB2 = x_up(B2);
-            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; }
+            int upB1 = 0, upFB1 = 0;                          // udh, local left ends: `ml` of the lane above
+            if constexpr (UDH) { if (LocalL) { upB2 = x_up(B2); upB1 = x_up(B1); upFB1 = x_up(FB); } }
+            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; upB1 = bB1; upFB1 = bFB1; }
             // insertion, deletion, diagonal
             {
                 const int open = x_sadd(H1, gn), ext = x_sadd(E, ge);
                 const bool m_ = ext > open;
                 E = m_ ? ext : open;
                 if constexpr (PTR) EC = m_ ? EC : C1;
+                if constexpr (UDH) { if (LocalL) EB = m_ ? EB : B1; }
             }
             int F, FC = 0;
             {
@@ -184,6 +195,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 const bool m_ = ext > open;
                 F = m_ ? ext : open;
                 if constexpr (PTR) FC = m_ ? upFC1 : upC1;
+                if constexpr (UDH) { if (LocalL) FB = m_ ? upFB1 : upB1; }
             }
             int pv = 0;
             const bool incell = nj <= b_right && nj > b_left && k < j9;     // kb <= k < ke
@@ -193,13 +205,20 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             int H = x_sadd(pv, upH2);
             int HC = upC2;
             int code = 0;                                     // diag: 0, hori: 1, vert: 2 (pv_a)
-            if (F > H) { H = F; HC = FC; code = 2; }
-            if (E > H) { H = E; HC = EC; code = 1; }
+            int HBu = upB2;                                   // udh, local left ends: `ml` of H
+            if (F > H) { H = F; HC = FC; HBu = FB; code = 2; }
+            if (E > H) { H = E; HC = EC; HBu = EB; code = 1; }
             int hb_pv = code;
             if (spj) ps &= code;
             if (!local) { if (!(H > XNEV)) H = XNEV; }
-            else if (LocalL) { if (0 > H) { H = 0; code = 1; HC = 0; } }
+            else if (LocalL) { if (0 > H) { H = 0; if constexpr (FORWARD) { code = 1; HC = 0; } } }
             int HB = 0;
+            if constexpr (UDH) {
+                if (LocalL) {
+                    HB = HBu;
+                    if (incell && H == 0) { HB = (int) (short) (ml + k + 1); HC = r - 2 * k; }   // left end of a local path
+                }
+            }
             if constexpr (FORWARD) {
                 HB = code == 0;                               // diag: 1, others: 0
                 if (HB && !(upB2 & 1) && incell) HC = vadd(ml + k, n - 1 - k, HC);   // a diagonal run starts here
@@ -214,6 +233,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 if (mx > maxh) {
                     maxh = mx;
                     if constexpr (FORWARD) { max_ulk = __shfl(HC, mk, XN); max_mr = ml + mk + 1; max_nr = n - mk; }
+                    if constexpr (UDH) { max_ulk = __shfl(HC, mk, XN); max_ml = __shfl(HB, mk, XN); max_mr = ml + mk + 1; max_nr = n - mk; }
                 }
             }
             // the exact intron lists: only columns that were queued (pushed at step n_j of THIS stripe, n_j <= b_right)
@@ -249,9 +269,9 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                                 mx_ci[d] = ci;
                                 if (br_ci < 0 || x > c_val[br_ci]) br_ci = ci;
                             }
-                            const int lk = c_ulk[ci];
-                            if (d == 0) HC = lk; else if (d == 1) EC = lk; else FC = lk;
-                            if (d && cur > H) HC = lk;
+                            const int lk = c_ulk[ci], bml = c_ml[ci];
+                            if (d == 0) { HC = lk; HB = bml; } else if (d == 1) { EC = lk; EB = bml; } else { FC = lk; FB = bml; }
+                            if (d && cur > H) { HC = lk; HB = bml; }
                         }
                         if (d && cur > H) H = cur;
                     }
@@ -293,6 +313,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                             if constexpr (UDH) {
                                 if (imd_here) { if (kk & 1) LNK(imd_i, 0, 0, rj) = rlst; c_ulk[ci] = rj; }
                                 else c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                                c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
                             }
                         }
                         else --ncand;
@@ -313,9 +334,10 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 hv[r0] = H; fv[r0] = F;
                 if constexpr (FORWARD) hb[r0] = HB;
                 if constexpr (PTR) { hc[r0] = HC; fc[r0] = FC; }
+                if constexpr (UDH) { if (LocalL) { hb[r0] = HB; fb[r0] = FB; } }
             }
             H2 = H1; H1 = H; F1 = F;
-            if constexpr (FORWARD) { B2 = B1; B1 = HB; }
+            if constexpr (FORWARD || UDH) { B2 = B1; B1 = HB; }
             if constexpr (PTR) { C2 = C1; C1 = HC; FC1 = FC; }
         }
         if constexpr (UDH) {
@@ -329,7 +351,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         DevResult R;
         R.score = XNEV; R.mr = a_right; R.nr = b_right; R.ml = a_left; R.ulk = 0; R.maxr = 0; R.pad[0] = R.pad[1] = 0;
         int end_ulk = max_ulk;
-        if (LocalR) { R.score = maxh; R.mr = max_mr; R.nr = max_nr; }
+        if (LocalR) { R.score = maxh; R.mr = max_mr; R.nr = max_nr; if constexpr (UDH) R.ml = max_ml; }
         else {
             const int rr = b_right - a_right;
             int maxr = rr;
@@ -349,6 +371,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             R.maxr = maxr;
             if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
             if constexpr (PTR) end_ulk = __builtin_nontemporal_load(&hc[maxr]);
+            if constexpr (UDH) { if (LocalL) R.ml = __builtin_nontemporal_load(&hb[maxr]); }
         }
         if constexpr (FORWARD) {
             const int ptr = vadd(R.mr, R.nr, end_ulk);

@@ -234,7 +234,7 @@ struct Aligner {
         }
         if (bad_range(it.job, r) || it.w.width < 3) { ++unsupported; J.failed = true; return true; }
         if (sc.scalar_engines == 1 && !st->has_exact) { ++unsupported; J.failed = true; return true; }
-        if (sc.scalar_engines == 2 && (!st->has_exact || sc.local)) { ++unsupported; J.failed = true; return true; }
+        if (sc.scalar_engines == 2 && !st->has_exact) { ++unsupported; J.failed = true; return true; }
         udh.push_back({it.job, r, it.w, it.top, n_imd, recursive, intvl});
         return true;
     }

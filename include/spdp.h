@@ -334,9 +334,9 @@ int spdp_homscore_h(SpdpContext* ctx, const SpdpScoringH* sc,
 /* alignH_ng with seeding off (-Q0/-Q4): stripe31 -> lspH_ng decision ladder -> forwardH1_wip, or
  * hirschbergH1_wip + per-slab forwardH1_wip (mimd_postwork / rcsv_postwork) -> stdskl3.
  * Sub-problems below 8 query rows run the scalar forwardH_ng (needs the scalar engine's inputs, see
- * spdp_scalar_forward_h).  Return value 1: some problem needs an engine that is not built (diagonalH_ng,
- * the -A1 linear-space engine with local ends), the links lead outside the sequences (undefined in the
- * reference) or the scalar inputs are missing; those come back with n_skl = 0, score NEVSEL. */
+ * spdp_scalar_forward_h).  A window without width (up == lw) takes diagonalH_ng.  Return value 1: for some
+ * problem the links lead outside the sequences (undefined in the reference) or the scalar inputs are
+ * missing; those come back with n_skl = 0, score NEVSEL. */
 int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc,
                  const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 

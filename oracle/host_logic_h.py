@@ -84,6 +84,27 @@ def trcbk_h(sc, p, w, rec, simd=2):
     return s
 
 
+def diagonal_h(sc, p, rec):
+    """Aln2h1::diagonalH_ng (src/fwd2h1.cc:1963-1995): the one diagonal of a window without width"""
+    local = bool(sc.local)
+    ll = local and p.a_exgl and p.b_exgl
+    lr = local and p.a_exgr and p.b_exgr
+    scr, maxh, m_l, m_r = 0, abi.NEVSEL, p.a_left, p.a_right
+    a = np.ctypeslib.as_array(C.cast(p.a, C.POINTER(C.c_uint8)), (p.a_len,))
+    b = np.ctypeslib.as_array(C.cast(p.b, C.POINTER(C.c_uint8)), (p.b_len + 1,))
+    sig_e = np.ctypeslib.as_array(C.cast(p.sigE, C.POINTER(C.c_int16)), (p.b_len + 3,))
+    for m in range(p.a_left, p.a_right):
+        n = p.b_left + 1 + 3 * (m - p.a_left)
+        scr += sc.mtx[int(a[m]) * sc.mtx_cols + int(b[n])] + int(sig_e[n])
+        if ll and scr < 0:
+            scr, m_l = 0, m + 1
+        if lr and scr > maxh:
+            maxh, m_r = scr, m + 1
+    rec.append((m_l, 3 * (m_l - p.a_left) + p.b_left))
+    rec.append((m_r, 3 * (m_r - p.a_left) + p.b_left))
+    return maxh if lr else scr
+
+
 def lsp_h(sc, p, w, rec, simd=2):
     m = p.a_right - p.a_left
     n = p.b_right - p.b_left
@@ -98,7 +119,7 @@ def lsp_h(sc, p, w, rec, simd=2):
     if not m or not n:
         raise NotRestated("empty range")
     if w.up == w.lw:
-        raise NotRestated("diagonalH_ng")
+        return diagonal_h(sc, p, rec)
     if abs(n - m) < NELEM or m == 1 or n <= 3:
         return trcbk_h(sc, p, w, rec, simd)
     if simd < 2:                                          # hexagonal

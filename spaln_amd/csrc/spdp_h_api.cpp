@@ -599,13 +599,28 @@ static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, std::vector<HI
 }
 
 // lspH_ng (src/fwd2h1.cc:2140-2180) up to the engine call
-static void queue_lsp(const SpdpScoringH& sc, HItem it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok,
-                      std::vector<HItem>& udh, HTop& t)
+static void queue_lsp(const SpdpScoringH& sc, const SpdpProblemH& p, HItem it, std::vector<HItem>& fwd, std::vector<HItem>& scl,
+                      bool scalar_ok, std::vector<HItem>& udh, HTop& t)
 {
     const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
     if (!m && !n) { if (it.first) t.score = 0; return; }
     if (!m || !n) { t.cls = 2; return; }                     // terminal-gap-only ranges: GapPenalty paths, not built
-    if (it.w.up == it.w.lw) { t.cls = 1; return; }           // diagonalH_ng
+    if (it.w.up == it.w.lw) {                                // diagonalH_ng (src/fwd2h1.cc:1963-1995): one O(m) walk,
+        const bool LocalL = sc.local && it.a_exgl && it.b_exgl;  // host side in the reference's ladder as well
+        const bool LocalR = sc.local && it.a_exgr && it.b_exgr;
+        int scr = 0, maxh = SPDP_NEVSEL, mL = it.a_left, mR = it.a_right;
+        for (int mm = it.a_left; mm < it.a_right; ++mm) {
+            const int nn = it.b_left + 1 + 3 * (mm - it.a_left);
+            if (mm >= p.a_len || nn > p.b_len) break;
+            scr += sc.mtx[p.a[mm] * sc.mtx_cols + p.b[nn]] + p.sigE[nn];
+            if (LocalL && scr < 0) { scr = 0; mL = mm + 1; }
+            if (LocalR && scr > maxh) { maxh = scr; mR = mm + 1; }
+        }
+        push_rec(t, mL, 3 * (mL - it.a_left) + it.b_left);
+        push_rec(t, mR, 3 * (mR - it.a_left) + it.b_left);
+        if (it.first) t.score = LocalR ? maxh : scr;
+        return;
+    }
     if (std::abs(n - m) < 16 || m == 1 || n <= 3) { queue_trcbk(it, fwd, scl, scalar_ok, t); return; }
     const float coef_B = 2.f, coef_C = 12.f;                 // sizeof(short); (Noll + 1) * sizeof(int)
     float cvol = float(m) * (n + 3 * m);                     // rhombic, simd >= 2
@@ -668,7 +683,7 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         for (const HItem& it : pending) {
             if (tops[it.top].cls) continue;
             if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
-            queue_lsp(sc, it, fwd, scl, st.scalar_ok, udh, tops[it.top]);
+            queue_lsp(sc, st.probs[it.top], it, fwd, scl, st.scalar_ok, udh, tops[it.top]);
         }
         pending.clear();
         // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)

@@ -75,6 +75,9 @@ def cases():
     g = gene(9, n_exons=4, mrna_len=500, flank=200, intron_hi=400, sub=0.05)
     c["s1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
     c["s1_local_cut"] = (*cut(g, g.exons[1][0] + 30, g.exons[3][1] - 40), ["-L", "-u", "1,3"])
+    # window = query, no shoulder: stripe() gives up == lw and lspS_ng takes diagonalS_ng
+    g2 = gene(31, n_exons=1, mrna_len=120, flank=0, sub=0.1)
+    c["s1_diagonal"] = (g2.window[:len(g2.query)], g2.query, ["-w", "0"])
     # local ends with the ladder forced into its linear-space branches (small MaxVmfSpace)
     c["s1_local_udh"] = (g.window, g.query, ["-L", "-V", "300000", "-u", "2"])
     # unrelated sequences, and tiny queries
@@ -136,6 +139,9 @@ def protein_cases():
     g = pgene(8, n_exons=4, aa_len=160, flank=200, intron_hi=400, sub=0.15)
     c["h1_local"] = (g.window, g.query, ["-L", "-u", "1,2"])
     c["h1_local_udh"] = (g.window, g.query, ["-L", "-V", "100000", "-u", "3"])
+    # window = the coding sequence, no shoulder: stripe31() gives up == lw and lspH_ng takes diagonalH_ng
+    g2 = pgene(31, n_exons=1, aa_len=60, flank=0, sub=0.1)
+    c["h1_diagonal"] = (g2.window[:3 * len(g2.query)], g2.query, ["-w", "0"])
     rng = np.random.default_rng(synth.SEED + 590)
     c["h1_random"] = (synth.random_dna(rng, 1500),
                       synth._AA_LETTERS[rng.integers(0, 20, size=90)], ["-u", "1"])

@@ -312,7 +312,7 @@ def test_align_a1_goldens(eng):
                 assert score == int(fx["aln_scr_A1"][0])
                 assert skl.ravel().tolist() == fx["aln_skl_A1"].tolist()
                 n_ok += 1
-    assert n_ok == 33 and n_ls == 0
+    assert n_ok == len(golden_files("s1_")) >= 34 and n_ls == 0
 
 
 def test_forward_s1_subranges_against_oracle(eng):

@@ -78,7 +78,7 @@ def test_align_a1_traceback_branch():
         assert scr == int(fx["aln_scr_A1"][0]), f
         assert (flat or []) == fx["aln_skl_A1"].tolist(), f
         n_ok += 1
-    assert n_ok == 33 and n_skip == 0
+    assert n_ok == len(golden_files("s1_")) >= 34 and n_skip == 0
 
 
 def test_align_a6_recursive_switch():

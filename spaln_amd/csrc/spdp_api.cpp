@@ -394,6 +394,9 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         else if (n_multi == n && n <= 2 * ctx->n_cu) {
             const int smallest = (h_probs[n - 1].a_right - h_probs[n - 1].a_left + SPDP_NELEM - 1) / SPDP_NELEM;
             if (smallest >= 4 * 32) wpb = 16;                            // >= 32 passes each
+            // a handful of mid-sized problems (the stragglers of an EST batch that need the linear-space
+            // engine): the launch is latency-bound, more passes in flight shorten it
+            else if (n <= ctx->n_cu / 2 && smallest > 4 * 4) wpb = 16;
         }
         // fewer huge problems than a quarter of the CUs (the top levels of the recursion on one long
         // cDNA): spread each over several CUs -- cross-CU pass pipelines, all blocks resident

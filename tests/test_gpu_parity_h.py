@@ -60,22 +60,25 @@ def test_forward_h1_wip_goldens(eng, tag):
 
 @pytest.mark.parametrize("alg", [2, 3])
 def test_align_h_goldens(eng, alg):
-    cases = _cases(alg)
-    sc = spdg.scoring_h(cases[0][1], nquant=None if alg == 2 else 1)
-    ps = abi.ProblemSetH()
-    for _, fx in cases:
-        spdg.problem_h(fx, ps)
-    res = eng.align_h(sc, ps)
-    hom = eng.homscore_h(sc, ps)
+    all_cases = _cases(alg)
+    key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
     bad = []
-    for (name, fx), (score, skl, flag), hs in zip(cases, res, hom):
-        ok = score == int(fx[f"aln_scr_A{alg}"][0]) and int(hs) == int(fx[f"hom_scr_A{alg}"][0])
-        if name in UNDEFINED:
-            ok = ok and flag == -2
-        else:
-            ok = ok and flag == 0 and skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
-        if not ok:
-            bad.append((name, score, flag, skl.ravel().tolist()[:14], fx[f"aln_skl_A{alg}"].tolist()[:14]))
+    for vmf, ubh, sh in sorted({key(fx) for _, fx in all_cases}):       # one batch per ladder setting
+        cases = [(n, fx) for n, fx in all_cases if key(fx) == (vmf, ubh, sh)]
+        sc = spdg.scoring_h(all_cases[0][1], nquant=None if alg == 2 else 1, max_vmf_space=vmf, ubh=ubh, sh=sh)
+        ps = abi.ProblemSetH()
+        for _, fx in cases:
+            spdg.problem_h(fx, ps)
+        res = eng.align_h(sc, ps)
+        hom = eng.homscore_h(sc, ps)
+        for (name, fx), (score, skl, flag), hs in zip(cases, res, hom):
+            ok = score == int(fx[f"aln_scr_A{alg}"][0]) and int(hs) == int(fx[f"hom_scr_A{alg}"][0])
+            if name in UNDEFINED:
+                ok = ok and flag == -2
+            else:
+                ok = ok and flag == 0 and skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist()
+            if not ok:
+                bad.append((name, score, flag, skl.ravel().tolist()[:14], fx[f"aln_skl_A{alg}"].tolist()[:14]))
     assert not bad, bad
 
 

@@ -125,6 +125,9 @@ SpdpContext* spdp_create(int device)
     if (ctx->n_cu <= 0) ctx->n_cu = 256;
     (void) hipEventCreate(&ctx->ev0);
     (void) hipEventCreate(&ctx->ev1);
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    (void) hipEventCreate(&ctx->ev2);
+    (void) hipEventCreate(&ctx->ev3);
     return ctx;
 }
 
@@ -155,6 +158,9 @@ void spdp_destroy(SpdpContext* ctx)
     for (DevPool& p : ctx->pool) p.release();
     (void) hipEventDestroy(ctx->ev0);
     (void) hipEventDestroy(ctx->ev1);
+    (void) hipEventDestroy(ctx->ev2);
+    (void) hipEventDestroy(ctx->ev3);
+    if (ctx->stream2) (void) hipStreamDestroy(ctx->stream2);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -422,9 +428,9 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     if (cross_g > 0) {
         const size_t words = (size_t) n * (cross_g * wpb + 2);
         POOLGET(d_gprog, POOL_GPROG, sizeof(int) * words);
-        HIPCHK(hipMemsetAsync(d_gprog, 0, sizeof(int) * words, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_gprog, 0, sizeof(int) * words, strm()));
     }
-    if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, strm()));
     return 0;
 }
 
@@ -443,19 +449,19 @@ int DevRun::launch()
         S.skl = (int2*) d_skl; S.n_skl = (int*) d_nskl; S.skl_cap = skl_cap;
         S.imd = (int*) d_imd; S.cpos = (int*) d_cpos; S.ranges = (int*) d_ranges; S.scores = (int*) d_scores;
         S.cpos_stride = 10 * (max_n_im + 1);
-        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        HIPCHK(hipEventRecord(evb(), strm()));
         S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
-        if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, ctx->stream));
-        else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, ctx->stream));
-        else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, ctx->stream));
-        else HIPCHK(spdp_launch_scalar(flavour == 3, &S, ctx->stream));
-        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, strm()));
+        else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, strm()));
+        else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, strm()));
+        else HIPCHK(spdp_launch_scalar(flavour == 3, &S, strm()));
+        HIPCHK(hipEventRecord(eve(), strm()));
         if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk
             CposArgs C;
             C.probs = S.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
             C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
             C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = store->sc.local ? 1 : 0;
-            HIPCHK(spdp_launch_cpos(&C, ctx->stream));
+            HIPCHK(spdp_launch_cpos(&C, strm()));
         }
         return 0;
     }
@@ -466,30 +472,30 @@ int DevRun::launch()
     A.cross_g = cross_g; A.gprog = (int*) d_gprog;
     int grid = cross_g > 0 ? n * cross_g : n_multi + (n - n_multi + wpb - 1) / wpb;
     if (cross_g > 0 && getenv("SPDP_CROSS_TEST_SHORT")) --grid;    // test hook: one block never arrives -> the fallback runs
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipEventRecord(evb(), strm()));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;
-    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, wpb, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, wpb, strm()));
+    HIPCHK(hipEventRecord(eve(), strm()));
     if (flavour == 1) {
         WalkArgs W;
         W.probs = A.probs; W.n_probs = n; W.tb = (const uint8_t*) d_tb; W.res = (const DevResult*) d_res;
         W.skl = (int2*) d_skl; W.n_skl = (int*) d_nskl; W.skl_cap = skl_cap;
-        HIPCHK(spdp_launch_walk(&W, ctx->stream));
+        HIPCHK(spdp_launch_walk(&W, strm()));
     }
     if (flavour == 2) {
         CposArgs C;
         C.probs = A.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
         C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
         C.cpos_stride = 10 * (max_n_im + 1); C.strict = 0; C.local = 0;
-        HIPCHK(spdp_launch_cpos(&C, ctx->stream));
+        HIPCHK(spdp_launch_cpos(&C, strm()));
     }
     return 0;
 }
 
 int DevRun::sync()
 {
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(strm()));
     if (cross_g > 0) {
         // cross-CU pipelines need every block resident; on a shared GPU the start-up barrier can time out, the
         // blocks then leave a mark (second barrier word of their problem) and the launch is repeated without them
@@ -501,11 +507,11 @@ int DevRun::sync()
         if (gave_up) {
             cross_g = 0; wpb = 16;
             if (launch()) return -1;
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipStreamSynchronize(strm()));
         }
     }
     kernel_ms = 0.f;
-    if (n) HIPCHK(hipEventElapsedTime(&kernel_ms, ctx->ev0, ctx->ev1));
+    if (n) HIPCHK(hipEventElapsedTime(&kernel_ms, evb(), eve()));
     return 0;
 }
 
@@ -537,11 +543,11 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
         void *d_off, *d_pack;
         POOLGET(d_off, POOL_SKLOFF, sizeof(int64_t) * (n + 1));
         POOLGET(d_pack, POOL_SKLPACK, sizeof(int2) * doff[n]);
-        HIPCHK(hipMemcpyAsync(d_off, doff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_off, doff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, strm()));
         HIPCHK(spdp_launch_pack((const int2*) d_skl, skl_cap, (const int*) d_nskl, (const int64_t*) d_off,
-                                (int2*) d_pack, n, ctx->stream));
-        HIPCHK(hipMemcpyAsync(packed.data(), d_pack, sizeof(SpdpSkl) * doff[n], hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+                                (int2*) d_pack, n, strm()));
+        HIPCHK(hipMemcpyAsync(packed.data(), d_pack, sizeof(SpdpSkl) * doff[n], hipMemcpyDeviceToHost, strm()));
+        HIPCHK(hipStreamSynchronize(strm()));
     }
     // back to the caller's order
     for (int i = 0; i < n; ++i) off[i + 1] = off[i] + std::max(n_skl[i], 0);

@@ -328,12 +328,29 @@ struct Aligner {
             stripe_of(r, sc.sh, &w);
             pending.push_back({i, r, w, true});
         }
+        // Queries that go straight to the traceback do not wait for the linear-space rounds of the others: their
+        // forward sweep starts on the side stream as soon as the first classification is done (an EST batch
+        // has a handful of stragglers in the linear-space engine; that launch is latency-bound and would
+        // otherwise hold up everything).  SPDP_OVERLAP=0 restores the single-stream order.
+        DevRun side;
+        std::vector<TbItem> side_tbs;
+        const char* ov = getenv("SPDP_OVERLAP");
+        bool may_overlap = ctx->stream2 != nullptr && !(ov && atoi(ov) == 0);
         while (!pending.empty()) {
             std::vector<LspItem> cur;
             cur.swap(pending);
             std::vector<UdhItem> udh;
             for (const LspItem& it : cur) classify(it, udh);
             lap("classify");
+            if (may_overlap && !udh.empty() && tbs.size() >= 64) {
+                side_tbs.swap(tbs);
+                std::vector<RunItem> items;
+                for (const TbItem& t : side_tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+                side.side = true;
+                if (side.build(st, items, 1) || side.launch()) return -1;
+                lap("side fwd build+launch");
+            }
+            may_overlap = false;                        // first round only
             if (udh.empty()) continue;
             std::vector<RunItem> items;
             for (const UdhItem& u : udh) {
@@ -411,7 +428,26 @@ struct Aligner {
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
             }
         }
-        // all trcbkalignS_ng calls of all queries: one forward sweep + one walk
+        if (!side_tbs.empty()) {                        // collect the side run before its pool is used again
+            if (side.sync()) return -1;
+            lap("side fwd sync");
+            kernel_ms += side.kernel_ms; kernel_cells += side.total_cells;
+            stats[3] += side.kernel_ms; stats[4] += (double) side.total_cells; stats[5] += (double) side_tbs.size();
+            stats[7] += (double) side.tb_bytes;
+            std::vector<DevResult> res;
+            std::vector<int> nskl;
+            std::vector<int64_t> off;
+            std::vector<SpdpSkl> skl;
+            if (side.fetch_results(res) || side.fetch_skl(nskl, off, skl)) return -1;
+            for (size_t k = 0; k < side_tbs.size(); ++k) {
+                const TbItem& t = side_tbs[k];
+                if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
+                set_score(t.job, t.top, res[k].score);
+                const SpdpSkl* sk = skl.data() + off[k];
+                jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
+            }
+        }
+        // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk
         if (!tbs.empty()) {
             std::vector<RunItem> items;
             for (const TbItem& t : tbs) items.push_back(run_item(t.job, t.r, t.w, 0));

@@ -156,6 +156,8 @@ struct SpdpContext {
     int n_cu = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream (non-blocking): a forward run beside the linear-space rounds
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
     std::string name;
     std::string err;
 };
@@ -210,6 +212,10 @@ struct DevRun {
          *d_ranges = nullptr, *d_scores = nullptr;         // all owned by ctx->pool[flavour]
     int skl_cap = 0;
     float kernel_ms = 0.f;
+    bool side = false;                      // run on ctx->stream2 (set before build)
+    hipStream_t strm() const { return side ? ctx->stream2 : ctx->stream; }
+    hipEvent_t evb() const { return side ? ctx->ev2 : ctx->ev0; }
+    hipEvent_t eve() const { return side ? ctx->ev3 : ctx->ev1; }
     DevRun() = default;
     DevRun(const DevRun&) = delete;
     DevRun& operator=(const DevRun&) = delete;

@@ -113,7 +113,12 @@ SpdpContext* spdp_create(int device)
     if (device < 0 || device >= ndev) return nullptr;
     SpdpContext* ctx = new SpdpContext();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+    // the main stream carries the latency-bound launches (linear-space rounds, slab tracebacks): highest priority;
+    // the side stream (a big forward sweep beside them) the lowest
+    int prio_lo = 0, prio_hi = 0;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return nullptr; }
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, prio_hi) != hipSuccess) {
         delete ctx;
         return nullptr;
     }
@@ -125,7 +130,7 @@ SpdpContext* spdp_create(int device)
     if (ctx->n_cu <= 0) ctx->n_cu = 256;
     (void) hipEventCreate(&ctx->ev0);
     (void) hipEventCreate(&ctx->ev1);
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) ctx->stream2 = nullptr;
     (void) hipEventCreate(&ctx->ev2);
     (void) hipEventCreate(&ctx->ev3);
     return ctx;
@@ -270,11 +275,13 @@ static int stripe_blocks(const DevProblem& P, int s, bool forward)
     return (len + 15) >> 4;
 }
 
-void DevRun::release() {}       // buffers belong to ctx->pool[flavour]
+// buffers belong to ctx->pool[..]; a run abandoned in flight (an error elsewhere in the batch) is waited for so
+// that its pool can be reused
+void DevRun::release() { if (in_flight && ctx) { (void) hipStreamSynchronize(strm()); in_flight = false; } }
 
 #define POOLGET(dst, slot, bytes)                                                        \
     do {                                                                                 \
-        (dst) = ctx->pool[flav == 7 ? 3 : (flav >= 5 ? 4 : flav)].get((slot), (size_t) (bytes)); \
+        (dst) = ctx->pool[side ? 8 : (flav == 7 ? 3 : (flav >= 5 ? 4 : flav))].get((slot), (size_t) (bytes)); \
         if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
     } while (0)
 
@@ -402,7 +409,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             if (smallest >= 4 * 32) wpb = 16;                            // >= 32 passes each
             // a handful of mid-sized problems (the stragglers of an EST batch that need the linear-space
             // engine): the launch is latency-bound, more passes in flight shorten it
-            else if (n <= ctx->n_cu / 2 && smallest > 4 * 4) wpb = 16;
+            else if (!beside && n <= ctx->n_cu / 2 && smallest > 4 * 4) wpb = 16;
         }
         // fewer huge problems than a quarter of the CUs (the top levels of the recursion on one long
         // cDNA): spread each over several CUs -- cross-CU pass pipelines, all blocks resident
@@ -438,6 +445,7 @@ int DevRun::launch()
 {
     (void) hipSetDevice(ctx->device);
     if (n == 0) return 0;
+    in_flight = true;
     if (flavour >= 3) {
         ScalarArgs S;
         S.sc = (const DevScoring*) store->d_sc; S.probs = (const DevProblem*) d_probs; S.n_probs = n;
@@ -496,6 +504,7 @@ int DevRun::launch()
 int DevRun::sync()
 {
     HIPCHK(hipStreamSynchronize(strm()));
+    in_flight = false;
     if (cross_g > 0) {
         // cross-CU pipelines need every block resident; on a shared GPU the start-up barrier can time out, the
         // blocks then leave a mark (second barrier word of their problem) and the launch is repeated without them

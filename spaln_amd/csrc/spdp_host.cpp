@@ -358,6 +358,7 @@ struct Aligner {
                 items.back().imd_intvl = u.imd_intvl;
             }
             DevRun run;
+            run.beside = !side_tbs.empty();
             const bool a0 = sc.scalar_engines == 1;
             if (run.build(st, items, a0 ? 5 : (sc.scalar_engines == 2 ? 8 : 2))) return -1;
             lap("udh build");
@@ -428,26 +429,7 @@ struct Aligner {
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
             }
         }
-        if (!side_tbs.empty()) {                        // collect the side run before its pool is used again
-            if (side.sync()) return -1;
-            lap("side fwd sync");
-            kernel_ms += side.kernel_ms; kernel_cells += side.total_cells;
-            stats[3] += side.kernel_ms; stats[4] += (double) side.total_cells; stats[5] += (double) side_tbs.size();
-            stats[7] += (double) side.tb_bytes;
-            std::vector<DevResult> res;
-            std::vector<int> nskl;
-            std::vector<int64_t> off;
-            std::vector<SpdpSkl> skl;
-            if (side.fetch_results(res) || side.fetch_skl(nskl, off, skl)) return -1;
-            for (size_t k = 0; k < side_tbs.size(); ++k) {
-                const TbItem& t = side_tbs[k];
-                if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
-                set_score(t.job, t.top, res[k].score);
-                const SpdpSkl* sk = skl.data() + off[k];
-                jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
-            }
-        }
-        // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk
+        // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk (beside the side run, if any)
         if (!tbs.empty()) {
             std::vector<RunItem> items;
             for (const TbItem& t : tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
@@ -471,6 +453,25 @@ struct Aligner {
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* s = skl.data() + off[k];
                 jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
+            }
+        }
+        if (!side_tbs.empty()) {                        // collect the side run (its own pool: the runs above went on beside it)
+            if (side.sync()) return -1;
+            lap("side fwd sync");
+            kernel_ms += side.kernel_ms; kernel_cells += side.total_cells;
+            stats[3] += side.kernel_ms; stats[4] += (double) side.total_cells; stats[5] += (double) side_tbs.size();
+            stats[7] += (double) side.tb_bytes;
+            std::vector<DevResult> res;
+            std::vector<int> nskl;
+            std::vector<int64_t> off;
+            std::vector<SpdpSkl> skl;
+            if (side.fetch_results(res) || side.fetch_skl(nskl, off, skl)) return -1;
+            for (size_t k = 0; k < side_tbs.size(); ++k) {
+                const TbItem& t = side_tbs[k];
+                if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
+                set_score(t.job, t.top, res[k].score);
+                const SpdpSkl* sk = skl.data() + off[k];
+                jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
             }
         }
         lap("assemble records");

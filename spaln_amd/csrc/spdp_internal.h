@@ -151,7 +151,8 @@ enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSK
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_GPROG, POOL_FLAV_STRIDE = 0 };
 
 struct SpdpContext {
-    DevPool pool[8];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path, [7] = rescoring
+    DevPool pool[9];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path, [7] = rescoring,
+                                     // [8] = the forward run on the side stream (coexists with a regular forward run)
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -213,6 +214,9 @@ struct DevRun {
     int skl_cap = 0;
     float kernel_ms = 0.f;
     bool side = false;                      // run on ctx->stream2 (set before build)
+    bool in_flight = false;                 // launched, not yet waited for
+    bool beside = false;                    // another kernel fills the GPU meanwhile: keep to 4-wave blocks (a 16-wave
+                                            // block finds no CU with room while small blocks keep refilling them)
     hipStream_t strm() const { return side ? ctx->stream2 : ctx->stream; }
     hipEvent_t evb() const { return side ? ctx->ev2 : ctx->ev0; }
     hipEvent_t eve() const { return side ? ctx->ev3 : ctx->ev1; }

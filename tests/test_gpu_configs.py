@@ -58,7 +58,20 @@ def test_c4_est_batch():
         ps.add(frag, w[b0:b1], s5[b0:b1 + 1], s3[b0:b1 + 1])
     eng = engine.Engine(0)
     res = eng.align_s(sc, ps)
+    # the same batch with the stragglers' linear-space rounds in front of the big forward sweep instead of
+    # beside it (two streams) and with a small MaxVmfSpace (a third of the batch in those rounds)
+    os.environ["SPDP_OVERLAP"] = "0"
+    try:
+        res1 = eng.align_s(sc, ps)
+        sc_small = defaults.scoring(max_vmf_space=6 * 1024 * 1024)
+        res_small1 = eng.align_s(sc_small, ps)
+    finally:
+        del os.environ["SPDP_OVERLAP"]
+    res_small = eng.align_s(sc_small, ps)
     eng.close()
+    for x, y in ((res, res1), (res_small, res_small1)):
+        for i, ((s0, k0), (s1, k1)) in enumerate(zip(x, y)):
+            assert s0 == s1 and k0.tolist() == k1.tolist(), i
     n_full = 0
     for (score, skl), (w, q, _, _) in zip(res, items):
         assert skl.shape[0] >= 3

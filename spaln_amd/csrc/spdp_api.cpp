@@ -489,6 +489,7 @@ int DevRun::launch()
         WalkArgs W;
         W.probs = A.probs; W.n_probs = n; W.tb = (const uint8_t*) d_tb; W.res = (const DevResult*) d_res;
         W.skl = (int2*) d_skl; W.n_skl = (int*) d_nskl; W.skl_cap = skl_cap;
+        { const char* sw = getenv("SPDP_WALK_SEQ"); W.seq = (sw && atoi(sw) != 0) ? 1 : 0; }
         HIPCHK(spdp_launch_walk(&W, strm()));
     }
     if (flavour == 2) {

@@ -33,6 +33,7 @@ struct WalkArgs {
     int2*             skl;        // per problem: skl_cap records
     int*              n_skl;      // per problem: number of records, -1 on overflow, -2 on bad code
     int               skl_cap;
+    int               seq;        // 1: one diagonal step per load (SPDP_WALK_SEQ=1, for A/B runs)
 };
 
 struct CposArgs {

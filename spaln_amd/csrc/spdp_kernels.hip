@@ -763,6 +763,7 @@ __global__ void spdp_walk(WalkArgs A)
     const int pi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pi >= A.n_probs) return;
     const bool writer = (threadIdx.x & 63) == 0;
+    const bool seq_walk = A.seq != 0;
     const DevProblem P = A.probs[pi];
     TbView V;
     V.tb = A.tb; V.tb_off = P.tb_off;
@@ -795,7 +796,28 @@ __global__ void spdp_walk(WalkArgs A)
         emit();
         switch (code & 15u) {
         case TB_DIAG:
-            do { code = to_upper(1); } while (code && (code & 15u) == TB_DIAG);
+            // a diagonal run: one step changes row and column, so every step is a load of its own.  Inside a stripe
+            // the next steps are known in advance (row k - j, sweep step n_step - 2 j): 16 lanes fetch them at once
+            // and the first one that ends the run is taken; stripe changes and the matrix edges stay with the
+            // one-step form.
+            do {
+                const int kk = (m - 1) & 15;
+                const int cnt = (m >= 1 && !seq_walk) ? min(kk, n) : 0;      // steps that stay in my stripe and inside n >= 0
+                if (cnt >= 2) {
+                    V.seek((m - 1) >> 4);
+                    const int j = (int) (threadIdx.x & 15);
+                    const int tau = n - (j + 1) + V.b_left + (kk - (j + 1)) - V.c_nstart;
+                    unsigned cj = 0u;
+                    if (j < cnt && tau >= 0 && tau <= V.c_n9 - V.c_nstart)
+                        cj = V.tb[V.cbase + 256ll * (tau >> 4) + 16 * (kk - (j + 1)) + (tau & 15)];
+                    const bool stop = j < cnt && (cj == 0u || (cj & 15u) != TB_DIAG);
+                    const unsigned hit = (unsigned) (__ballot(stop) & 0xffffull);
+                    const int js = hit ? __builtin_ctz(hit) : cnt - 1;
+                    m -= js + 1; n -= js + 1;
+                    code = (unsigned) __shfl((int) cj, js, 16);
+                } else
+                    code = to_upper(1);
+            } while (code && (code & 15u) == TB_DIAG);
             break;
         case TB_HORI: {
             bool dead = false;

@@ -79,6 +79,27 @@ for n_im in (1, 2, 5):
         same = [[int(x) for x in r] for r in cpos[i]] == [[int(x) for x in r] for r in wc]
         if int(scores[i]) != ws or rngs[i].tolist() != wr.tolist() or (not same and wc[0][0] != abi.END_OF_ULK):
             bad += 1; print("hirschbergS1_wip -LS", n_im, i, (p.a_left, p.a_right, p.b_left, p.b_right), int(scores[i]), ws)
+# alignS_ng under -A1 with local ends pushed into the linear-space branches (hirschbergS1 -LS through the ladder)
+from oracle import host_logic
+extra = dict(cano5=fx["cano5"], cano3=fx["cano3"], dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+for vmf in (300000, 120000):
+    sc1 = spdg.scoring(fx, scalar_engines=2, max_vmf_space=vmf)
+    ps = abi.ProblemSet()
+    for i in range(max(8, N // 8)):
+        m = int(rng.integers(200, q["a_right"] + 1))
+        al = int(rng.integers(0, q["a_right"] - m + 1))
+        bl = int(rng.integers(0, 200))
+        br = int(rng.integers(q["b_right"] - 300, q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 2 == 0 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg, **extra)
+    res = eng.align_s(sc1, ps, allow_partial=True)
+    for i, (p, (score, skl)) in enumerate(zip(ps.items, res)):
+        try:
+            ws, wskl = host_logic.align_s(sc1, p, simd=1)
+        except (host_logic.NeedsScalarEngine, host_logic.ReferenceUndefined):
+            continue
+        if score != ws or skl.ravel().tolist() != (wskl or []):
+            bad += 1; print("alignS_ng -A1 -LS", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws)
 eng.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

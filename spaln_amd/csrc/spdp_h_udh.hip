@@ -596,7 +596,7 @@ __global__ void spdh_udh_cpos(HCposArgs A)
         } else
             CPOS(i, 0) = END_OF_ULK;
     }
-    for ( ; r > up; r -= width) ;
+    while (r > up) r -= width;
     {
         const int rl = b_left - 3 * a_left;
         if (P.b_exgl && rl > r) {

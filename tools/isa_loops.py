@@ -28,5 +28,5 @@ for f in funcs:
                           cnt('s_waitcnt'), cnt('s_nop'), t, labels[t], i))
     print(name)
     print("   (total, valu, salu, lds, vmem, waitcnt, nop, label, first, last)")
-    for L in sorted(loops, key=lambda x: -x[0])[:10]:
+    for L in sorted(loops, key=lambda x: -x[0])[:40]:
         print("  ", L)

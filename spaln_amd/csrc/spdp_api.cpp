@@ -228,6 +228,7 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     for (int i = 0; i < n && has_exact; ++i)
         if (!probs[i].cano5 || !probs[i].cano3 || !probs[i].dinc) has_exact = false;
     std::vector<uint8_t> hx(has_exact ? 2 * std::max<int64_t>(col_tot, 1) : 0, 0);
+    int max_s5 = INT32_MIN, max_s3 = INT32_MIN;
     for (int i = 0; i < n; ++i) {
         const SpdpProblem& p = probs[i];
         if (has_exact) {
@@ -243,8 +244,17 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
             const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
             const uint16_t s3 = (uint16_t) p.sig3[nn];
             cr[0] = sc.spj ? (int32_t) ((uint32_t) s5 | ((uint32_t) s3 << 16)) : 0;
+            max_s5 = std::max(max_s5, (int) (int16_t) s5); max_s3 = std::max(max_s3, (int) (int16_t) s3);
             cr[1] = nn > 0 ? p.b[nn - 1] : 0;
         }
+    }
+    // bounds for the fp32 sweeps (DevRun::build): best substitution score, best net gain of one intron
+    fp_maxpos = 1;
+    for (int i = 0; i < sc.mtx_dim * sc.mtx_dim; ++i) fp_maxpos = std::max(fp_maxpos, (int) sc.mtx[i]);
+    {
+        int max_pen = INT32_MIN;
+        for (int j = 0; j < std::max(1, std::min(sc.nquant, SPDP_MAX_QUANT)); ++j) max_pen = std::max(max_pen, (int) sc.qm_pen[j]);
+        fp_gain = (sc.spj && max_s5 > INT32_MIN) ? std::max(0, max_s5 + max_s3 + max_pen) : 0;
     }
     DevScoring hsc;
     to_dev_scoring(&sc, &hsc);
@@ -350,6 +360,19 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         max_skl = std::max(max_skl, (it.a_right - it.a_left) + (it.b_right - it.b_left) + 8);
     }
     tb_bytes = tb_tot;
+    // fp32 sweeps: every score must stay an exactly representable integer below 2^22 - 2^16 (the penalty table
+    // pushes a candidate down by 2^22 to disable it).  Upper bound of a score: matches on every row, plus
+    // whatever an intron can gain where the signals outweigh its penalties (never, with real parameters).
+    {
+        int64_t rows = 0, cols_span = 0;
+        for (int i = 0; i < n; ++i) {
+            rows = std::max<int64_t>(rows, items[i].a_right - items[i].a_left);
+            cols_span = std::max<int64_t>(cols_span, items[i].b_right - items[i].b_left);
+        }
+        const char* e = getenv("SPDP_FP");
+        const int64_t ub = (rows + 1) * st->fp_maxpos + (st->fp_gain > 0 ? (cols_span + 1) * st->fp_gain : 0) + 65536;
+        fp_ok = (!e || atoi(e) != 0) && ub < (1ll << 22) - 65536;
+    }
     const int bw = (flav == 2) ? 4 : (flav >= 3 ? 1 : 2);
     const int nn = std::max(n, 1);
     skl_cap = std::min(std::max(max_skl, 1), 1024);     // typical lists are short; overflow is re-walked
@@ -483,7 +506,15 @@ int DevRun::launch()
     HIPCHK(hipEventRecord(evb(), strm()));
     const int nq = std::max(1, std::min(store->sc.nquant, SPDP_MAX_QUANT));
     const int pen_cap = nq > 1 ? store->sc.qm_len[nq - 2] + 1 : 0;
-    HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, wpb, strm()));
+    // the fp32-issue form of the sweep (spdp_sweep_fp.hip) where it applies: non-local score-only / linear-space runs
+    // whose scores stay inside the exact fp32 integer range; SPDP_FP=0 keeps everything on spdp_kernels.hip
+    bool done = false;
+    if (fp_ok && flavour != 1 && !store->sc.local) {
+        const hipError_t e = spdp_launch_sweep_fp(flavour, 0, store->sc.spj ? 1 : 0, nq, pen_cap, store->sc.llmt, &A, grid, wpb, strm());
+        if (e == hipSuccess) done = true;
+        else if (e != hipErrorNotSupported) HIPCHK(e);
+    }
+    if (!done) HIPCHK(spdp_launch_sweep(flavour, store->sc.local ? 1 : 0, nq, pen_cap, &A, grid, wpb, strm()));
     HIPCHK(hipEventRecord(eve(), strm()));
     if (flavour == 1) {
         WalkArgs W;

@@ -51,6 +51,9 @@ struct CposArgs {
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
                                         int grid, int wpb, hipStream_t s);
+// spdp_sweep_fp.hip: the fp32-issue form of the score-only / linear-space sweeps; hipErrorNotSupported = use spdp_launch_sweep
+extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int nquant, int pen_cap, int llmt,
+                                           const SweepArgs* args, int grid, int wpb, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // scalar exact engines (spdp_scalar.hip): one thread per problem
@@ -175,6 +178,7 @@ struct DevStore {
     std::vector<int32_t> a_len, b_len;
     void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
     bool has_exact = false;                 // exact-model inputs (cano / dinc / intpen) were supplied
+    int fp_maxpos = 1, fp_gain = 0;         // largest substitution score; best net score of one intron (>= 0)
     DevStore() = default;
     DevStore(const DevStore&) = delete;
     DevStore& operator=(const DevStore&) = delete;
@@ -204,6 +208,7 @@ struct DevRun {
     int n_multi = 0;                        // leading problems run as multi-wave pipelines
     int wpb = 4;                            // waves per block of the sweep launch (16: one huge problem per CU)
     int cross_g = 0;                        // > 0: every problem spread over this many 16-wave blocks (CUs)
+    bool fp_ok = false;                     // scores stay inside the exact fp32 range: spdp_sweep_fp.hip may run it
     void* d_gprog = nullptr;                // progress / barrier words of the cross-CU pipelines
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;

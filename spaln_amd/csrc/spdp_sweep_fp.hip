@@ -652,8 +652,10 @@ static hipError_t launch_fp(dim3 grd, int wpb, hipStream_t stream, const SweepAr
             return hipLaunchCooperativeKernel(fn, grd, dim3(wpb == 16 ? 1024 : 256), kargs, 0, stream);
         }
     }
+    // SPDP_LDS_PAD=<bytes>: extra dynamic LDS per block, i.e. fewer resident blocks per CU (occupancy experiments)
+    static const int lds_pad = getenv("SPDP_LDS_PAD") ? atoi(getenv("SPDP_LDS_PAD")) : 0;
     if (wpb == 16) hipLaunchKernelGGL((spdp_sweep_fp<FL, 16, false, SPJ>), grd, dim3(1024), 0, stream, A);
-    else           hipLaunchKernelGGL((spdp_sweep_fp<FL, 4, false, SPJ>), grd, dim3(256), 0, stream, A);
+    else           hipLaunchKernelGGL((spdp_sweep_fp<FL, 4, false, SPJ>), grd, dim3(256), lds_pad, stream, A);
     return hipGetLastError();
 }
 

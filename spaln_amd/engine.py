@@ -16,7 +16,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspdp_hip.so")
+LIB_PATH = os.environ.get("SPDP_LIB") or os.path.join(_HERE, "libspdp_hip.so")     # SPDP_LIB: A/B builds (tools/ab_variants.sh)
 
 EXPORTS = [
     "spdp_create", "spdp_destroy", "spdp_last_error", "spdp_device_name", "spdp_stripe",

@@ -17,15 +17,6 @@
 #include "spdp_dev.h"
 #include "spdp_internal.h"
 
-#define HIPCHK(call)                                                                     \
-    do {                                                                                 \
-        hipError_t e_ = (call);                                                          \
-        if (e_ != hipSuccess) {                                                          \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
-            return -1;                                                                   \
-        }                                                                                \
-    } while (0)
-
 // ---- small helpers --------------------------------------------------------------
 static void stripe_rng(int a_left, int a_right, int b_left, int b_right, int sh, SpdpWindow* w)
 {   // stripe(), src/aln2.cc:156-176 (cmode 3)
@@ -156,9 +147,24 @@ void DevPool::release()
     for (int i = 0; i < N_SLOTS; ++i) { if (ptr[i]) (void) hipFree(ptr[i]); ptr[i] = nullptr; cap[i] = 0; }
 }
 
+// lane i of a context: lane 0 is the context itself, the others are contexts of their own (streams, events, pools)
+// on the same device, created on first use and owned by the parent
+SpdpContext* spdp_lane(SpdpContext* ctx, int i)
+{
+    if (i <= 0) return ctx;
+    while ((int) ctx->lanes.size() < i) {
+        SpdpContext* l = spdp_create(ctx->device);
+        if (!l) return nullptr;
+        ctx->lanes.push_back(l);
+    }
+    return ctx->lanes[i - 1];
+}
+
 void spdp_destroy(SpdpContext* ctx)
 {
     if (!ctx) return;
+    for (SpdpContext* l : ctx->lanes) spdp_destroy(l);
+    ctx->lanes.clear();
     (void) hipSetDevice(ctx->device);
     for (DevPool& p : ctx->pool) p.release();
     (void) hipEventDestroy(ctx->ev0);
@@ -297,7 +303,7 @@ void DevRun::release() { if (in_flight && ctx) { (void) hipStreamSynchronize(str
 
 int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int flav)
 {
-    store = st; ctx = st->ctx; flavour = flav; n = (int) items.size();
+    store = st; ctx = use_ctx ? use_ctx : st->ctx; flavour = flav; n = (int) items.size();
     (void) hipSetDevice(ctx->device);
     if (flav >= 3 && !st->has_exact) {
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";

@@ -23,7 +23,10 @@
 #include <cstring>
 #include <vector>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 
 #include "spdp_internal.h"
 
@@ -144,11 +147,27 @@ void trim_skl(std::vector<SpdpSkl>& s, const SpdpProblem& p)
     }
 }
 
+// Chunks of one batch run as a software pipeline on lanes of the context (own streams and pools): chunk c starts
+// its first linear-space sweep when that of chunk c - 1 has finished, so the host work, the slab tracebacks and the
+// walk of one chunk run beside the big sweep of the next instead of leaving the GPU idle between launches.
+struct ChunkGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;                              // 0: not there yet, 1: event recorded, 2: nothing to wait for
+    hipEvent_t ev = nullptr;
+    void open(int st_) { { std::lock_guard<std::mutex> g(m); if (state == 0) state = st_; } cv.notify_all(); }
+    int wait() { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return state != 0; }); return state; }
+};
+
 struct Aligner {
-    SpdpContext* ctx;
+    SpdpContext* ctx;                           // the lane this chunk runs on
     const DevStore* st;
-    const SpdpProblem* probs;
+    const SpdpProblem* probs;                   // first problem of the chunk
     int n;
+    int base = 0;                               // its index in the store (parent of job j = base + j)
+    ChunkGate* gate_in = nullptr;               // the chunk before mine / mine
+    ChunkGate* gate_out = nullptr;
+    SpdpAlignment* out = nullptr;               // where the chunk's alignments go (may be null)
     std::vector<Job> jobs;
     std::vector<LspItem> pending;
     std::vector<TbItem> tbs;                    // forwardS1_wip calls
@@ -318,6 +337,14 @@ struct Aligner {
 
     int run()
     {
+        const int rc = run_chunk();
+        if (gate_out) gate_out->open(2);        // no linear-space round (or an error): the next chunk need not wait
+        if (!rc && out) for (int i = 0; i < n; ++i) finish(i, out + i);     // stdskl / trimskl, beside the other chunks
+        return rc;
+    }
+
+    int run_chunk()
+    {
         const SpdpScoring& sc = st->sc;
         lap("start");
         jobs.assign(n, Job());
@@ -333,9 +360,11 @@ struct Aligner {
         // has a handful of stragglers in the linear-space engine; that launch is latency-bound and would
         // otherwise hold up everything).  SPDP_OVERLAP=0 restores the single-stream order.
         DevRun side;
+        side.use_ctx = ctx;
         std::vector<TbItem> side_tbs;
         const char* ov = getenv("SPDP_OVERLAP");
         bool may_overlap = ctx->stream2 != nullptr && !(ov && atoi(ov) == 0);
+        bool first_round = true;
         while (!pending.empty()) {
             std::vector<LspItem> cur;
             cur.swap(pending);
@@ -345,7 +374,7 @@ struct Aligner {
             if (may_overlap && !udh.empty() && tbs.size() >= 64) {
                 side_tbs.swap(tbs);
                 std::vector<RunItem> items;
-                for (const TbItem& t : side_tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+                for (const TbItem& t : side_tbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
                 side.side = true;
                 if (side.build(st, items, 1) || side.launch()) return -1;
                 lap("side fwd build+launch");
@@ -354,15 +383,23 @@ struct Aligner {
             if (udh.empty()) continue;
             std::vector<RunItem> items;
             for (const UdhItem& u : udh) {
-                items.push_back(run_item(u.job, u.r, u.w, u.n_imd));
+                items.push_back(run_item(base + u.job, u.r, u.w, u.n_imd));
                 items.back().imd_intvl = u.imd_intvl;
             }
             DevRun run;
+            run.use_ctx = ctx;
             run.beside = !side_tbs.empty();
             const bool a0 = sc.scalar_engines == 1;
             if (run.build(st, items, a0 ? 5 : (sc.scalar_engines == 2 ? 8 : 2))) return -1;
             lap("udh build");
-            if (run.launch() || run.sync()) return -1;
+            if (first_round && gate_in && gate_in->wait() == 1) HIPCHK(hipStreamWaitEvent(run.strm(), gate_in->ev, 0));
+            if (run.launch()) return -1;
+            if (first_round && gate_out) {
+                HIPCHK(hipEventRecord(gate_out->ev, run.strm()));
+                gate_out->open(1);
+            }
+            first_round = false;
+            if (run.sync()) return -1;
             lap("udh launch+sync");
             kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
             stats[0] += run.kernel_ms; stats[1] += (double) run.total_cells; stats[2] += (double) items.size();
@@ -394,8 +431,9 @@ struct Aligner {
         // the few sub-problems below 8 rows: scalar exact engine, one thread each
         if (!stbs.empty()) {
             std::vector<RunItem> items;
-            for (const TbItem& t : stbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            for (const TbItem& t : stbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
             DevRun run;
+            run.use_ctx = ctx;
             if (run.build(st, items, 3) || run.launch() || run.sync()) return -1;
             std::vector<DevResult> res;
             std::vector<int> nskl;
@@ -413,8 +451,9 @@ struct Aligner {
         // -A1 traceback calls: forwardS1
         if (!xtbs.empty()) {
             std::vector<RunItem> items;
-            for (const TbItem& t : xtbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            for (const TbItem& t : xtbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
             DevRun run;
+            run.use_ctx = ctx;
             if (run.build(st, items, 7) || run.launch() || run.sync()) return -1;
             std::vector<DevResult> res;
             std::vector<int> nskl;
@@ -432,8 +471,9 @@ struct Aligner {
         // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk (beside the side run, if any)
         if (!tbs.empty()) {
             std::vector<RunItem> items;
-            for (const TbItem& t : tbs) items.push_back(run_item(t.job, t.r, t.w, 0));
+            for (const TbItem& t : tbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
             DevRun run;
+            run.use_ctx = ctx;
             if (run.build(st, items, 1)) return -1;
             lap("fwd build");
             if (run.launch() || run.sync()) return -1;
@@ -554,14 +594,46 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
                           SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells,
                           double* stats = nullptr)
 {
-    Aligner al;
-    al.ctx = ctx; al.st = st; al.probs = probs; al.n = n;
-    if (al.run()) return -1;
-    if (out) for (int i = 0; i < n; ++i) al.finish(i, out + i);
-    if (kernel_ms) *kernel_ms = al.kernel_ms;
-    if (kernel_cells) *kernel_cells = al.kernel_cells;
-    if (stats) memcpy(stats, al.stats, sizeof al.stats);
-    if (al.unsupported) {
+    // big batches run as chunks on lanes of the context, a software pipeline (ChunkGate); SPDP_CHUNKS=1 turns it off
+    int n_chunks = n >= 4096 ? 2 : 1;
+    if (const char* e = getenv("SPDP_CHUNKS")) n_chunks = std::max(1, std::min(atoi(e), 8));
+    n_chunks = std::min(n_chunks, std::max(1, n / 64));
+    std::vector<Aligner> al(n_chunks);
+    std::vector<ChunkGate> gates(n_chunks);
+    std::vector<int> rc(n_chunks, 0);
+    for (int c = 0; c < n_chunks; ++c) {
+        Aligner& a = al[c];
+        a.ctx = spdp_lane(ctx, c);
+        if (!a.ctx) { ctx->err = "cannot create a lane context"; return -1; }
+        a.st = st;
+        a.base = (int) ((int64_t) n * c / n_chunks);
+        a.n = (int) ((int64_t) n * (c + 1) / n_chunks) - a.base;
+        a.probs = probs + a.base;
+        a.out = out ? out + a.base : nullptr;
+        if (n_chunks > 1) {
+            if (hipEventCreateWithFlags(&gates[c].ev, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate"; return -1; }
+            a.gate_out = &gates[c];
+            a.gate_in = c > 0 ? &gates[c - 1] : nullptr;
+        }
+    }
+    std::vector<std::thread> workers;
+    for (int c = 1; c < n_chunks; ++c)
+        workers.emplace_back([&, c]() { (void) hipSetDevice(ctx->device); rc[c] = al[c].run(); });
+    rc[0] = al[0].run();
+    for (std::thread& t : workers) t.join();
+    for (int c = 0; c < n_chunks; ++c) if (gates[c].ev) (void) hipEventDestroy(gates[c].ev);
+    int unsupported = 0;
+    float kms = 0.f; int64_t kc = 0;
+    double st_sum[SPDP_N_STATS] = {0};
+    for (int c = 0; c < n_chunks; ++c) {
+        if (rc[c]) { if (c > 0) ctx->err = al[c].ctx->err; return -1; }
+        kms += al[c].kernel_ms; kc += al[c].kernel_cells; unsupported += al[c].unsupported;
+        for (int k = 0; k < SPDP_N_STATS; ++k) st_sum[k] += al[c].stats[k];
+    }
+    if (kernel_ms) *kernel_ms = kms;
+    if (kernel_cells) *kernel_cells = kc;
+    if (stats) memcpy(stats, st_sum, sizeof st_sum);
+    if (unsupported) {
         ctx->err = "sub-problems with fewer than 8 query rows need the scalar exact engine: supply "
                    "SpdpScoring.intpen / t53 and SpdpProblem.cano5 / cano3 / dinc";
         return 1;                               // partial: those queries are returned without alignment

@@ -25,6 +25,15 @@ struct SweepArgs {
     int*              gprog;      // per problem: cross_g * WPB progress words, then 2 barrier words; zeroed per launch
 };
 
+#define HIPCHK(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return -1;                                                                   \
+        }                                                                                \
+    } while (0)
+
 struct WalkArgs {
     const DevProblem* probs;
     int               n_probs;
@@ -165,7 +174,9 @@ struct SpdpContext {
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     std::string name;
     std::string err;
+    std::vector<SpdpContext*> lanes;  // further lanes of this context (spdp_lane): chunks of a batch run side by side
 };
+SpdpContext* spdp_lane(SpdpContext* ctx, int i);
 
 // Resident inputs of a set of parent problems: residues, per-position column
 // records and the scoring bundle.  Sub-problems (UDH slabs, engine calls on
@@ -203,6 +214,7 @@ struct RunItem {
 // 7 -A1 forward (shares pool 3 with the scalar forward run), 8 -A1 udh (pool 4)
 struct DevRun {
     SpdpContext* ctx = nullptr;
+    SpdpContext* use_ctx = nullptr;         // set before build: the lane to run on (default: the store's context)
     const DevStore* store = nullptr;
     int flavour = 0, n = 0;
     int n_multi = 0;                        // leading problems run as multi-wave pipelines

@@ -371,15 +371,21 @@ class Batch:
         self.eng._check(rc, "spdp_batch_homscore")
         return out, ms.value
 
-    def align(self, want: bool = True):
-        """alignS_ng (ori = 1, -Q0) over the resident batch.  Returns (alignments, kernel_ms, kernel_cells)."""
+    def align(self, want: bool = True, convert: bool = True):
+        """alignS_ng (ori = 1, -Q0) over the resident batch.  Returns (alignments, kernel_ms, kernel_cells).
+        want: the library produces the final SKL arrays in host memory (stdskl / trimskl / allocation);
+        convert=False leaves them as the C arrays they are (freed again) instead of building numpy rows --
+        what bench.py times: the whole product path, no Python per-record work."""
         ms = C.c_float()
         cells = C.c_int64()
         arr = (abi.Alignment * self.n)() if want else None
         rc = self.eng.lib.spdp_batch_align(self.h, arr, C.byref(ms), C.byref(cells))
         self.eng._check(rc, "spdp_batch_align")
         res = None
-        if want:
+        if want and not convert:
+            res = sum(arr[i].n_skl for i in range(0, self.n, max(1, self.n // 64)))      # touch a few
+            self.eng.lib.spdp_free_alignments(arr, self.n)
+        elif want:
             res = []
             for i in range(self.n):
                 k = arr[i].n_skl
@@ -411,8 +417,9 @@ class BatchH:
     def cells(self) -> int:
         return int(self.eng.lib.spdp_batch_cells_h(self.h))
 
-    def align(self, want: bool = True):
-        """alignH_ng over the resident batch.  Returns (alignments, sweep_kernel_ms, cells)."""
+    def align(self, want: bool = True, convert: bool = True):
+        """alignH_ng over the resident batch.  Returns (alignments, sweep_kernel_ms, cells); want / convert as in
+        Batch.align."""
         ms = C.c_float()
         cells = C.c_int64()
         arr = (abi.Alignment * self.n)() if want else None
@@ -420,7 +427,10 @@ class BatchH:
         if rc not in (0, 1):
             self.eng._check(rc, "spdp_batch_align_h")
         res = None
-        if want:
+        if want and not convert:
+            res = sum(max(arr[i].n_skl, 0) for i in range(0, self.n, max(1, self.n // 64)))
+            self.eng.lib.spdp_free_alignments(arr, self.n)
+        elif want:
             res = []
             for i in range(self.n):
                 k = arr[i].n_skl

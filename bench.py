@@ -7,10 +7,14 @@ default band (alprm.sh = 100), Fwd2s1 `_wip` engine.  One "step" = one pass of
 the hot path over the whole batch, inputs resident in HBM.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            (spawns its N ranks itself, one process per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  N > 1: queries are sharded across ranks, no
-data-path collective (weak scaling: every rank aligns its own 10k queries).
+Prints ONE JSON line (rank 0).  N > 1: queries are sharded across ranks with no data-path collective
+(SURVEY.md 8e); the ranks only meet at the timing barriers and the reduction of the timer, over gloo --
+the path needs no RCCL.  Reported value: weak scaling (every rank aligns its own 10k queries); the same
+line also carries the strong-scaling figure (ONE fixed 10k batch sharded with shard.shard_range) under
+config.strong_scaling (--scaling strong swaps the two).
 """
 import argparse
 import json
@@ -253,26 +257,45 @@ def _valu_roofline(cells, kind, k_ms):
                       "instructions skipped under an empty EXEC mask"}
 
 
+def _self_spawn(argv, n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks here, one process per GPU, and wait."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
+
+
 def _dist_setup():
     """(torch, dist or None, rank, world, local device index, device for collectives).
-    BENCH_SHARE_GPU=1 is a test hook: all ranks use GPU 0 and talk over gloo, so that the multi-rank
-    path can be exercised on a one-GPU box."""
+    The ranks exchange nothing but a barrier and two scalars, so the process group is gloo on the host.
+    BENCH_SHARE_GPU=1 is a test hook: all ranks use GPU 0, so that the multi-rank path can be exercised on a
+    one-GPU box."""
     import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     share = os.environ.get("BENCH_SHARE_GPU") == "1"
     dist = None
-    coll_dev = "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if (torch.cuda.is_available() and not share) else "gloo"
-        dist.init_process_group(backend=backend)
-        coll_dev = "cuda" if backend == "nccl" else "cpu"
+        dist.init_process_group(backend="gloo")
     dev = 0 if share else local_rank
+    if dev >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: GPU {dev} not present ({torch.cuda.device_count()} visible); "
+                         "BENCH_SHARE_GPU=1 runs all ranks on GPU 0")
     torch.cuda.set_device(dev)
-    return torch, dist, rank, world, dev, coll_dev
+    return torch, dist, rank, world, dev, "cpu"
 
 
 def main():
@@ -288,25 +311,22 @@ def main():
     ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
     ap.add_argument("--cpu-port", action="store_true",
                     help="time the oracle port as the CPU baseline even when oracle/_ref/spaln is present")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank its own batch of --queries (the reported value), strong = one "
+                         "batch of --queries sharded over the ranks; the other one is reported under config")
     args = ap.parse_args()
     if not args.queries:
         args.queries = 10000
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_spawn(sys.argv[1:], args.gpus)
     if args.workload == "c3":
         return main_c3(args)
 
     torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
 
-    from spaln_amd import abi, defaults, engine, synth
+    from spaln_amd import abi, defaults, engine, shard, synth
     eng = engine.Engine(local_rank)
     sc = defaults.scoring()
-    if args.workload == "c4":
-        batch = synth.make_est_batch(args.queries, seed=synth.SEED + 1000 * rank)
-    else:
-        batch = synth.make_batch(args.queries, seed=synth.SEED + 1000 * rank, intron_hi=args.intron_hi)
-    ps = abi.ProblemSet()
-    for w, q, s5, s3, _ in batch:
-        ps.add(q, w, s5, s3)
-    bt = eng.upload(sc, ps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -314,32 +334,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one step = alignS_ng (ori = 1, seeding off) for every query of the batch: dispatch ladder,
-    # UDH sweep, cpos back-walk, slab list, forward sweep + traceback walk, stdskl / trimskl.
-    # Alignments are produced in host memory every step: D2H of the records, stdskl / trimskl and the SKL arrays are
-    # inside the clock (want=True); convert=False only skips turning them into numpy rows in Python.
-    for _ in range(args.warmup):
-        bt.align(want=True, convert=False)
-    barrier()
-    t0 = time.perf_counter()
-    stats = []
-    step_cells = 0
-    for _ in range(args.steps):
-        _, ms, kc = bt.align(want=True, convert=False)
-        stats.append(bt.stats())
-        step_cells = kc
-    barrier()
-    dt = time.perf_counter() - t0
-    cells = step_cells                       # DP cells of all engine calls of one step
-    if dist is not None:
-        t = torch.tensor([dt], device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([float(cells)], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
-    else:
-        total_cells = float(cells)
+    def make(seed, n):
+        if args.workload == "c4":
+            return synth.make_est_batch(n, seed=seed)
+        return synth.make_batch(n, seed=seed, intron_hi=args.intron_hi)
+
+    def measure(mode):
+        """K timed steps of one scaling mode; returns the figures of the whole job and this rank's batch.
+        weak: every rank aligns its own --queries queries; strong: one batch of --queries, rank r takes
+        shard.shard_range(queries, r, world) of it.  One step = alignS_ng (ori = 1, seeding off) for every query
+        of the rank's batch: dispatch ladder, UDH sweep, cpos back-walk, slab list, forward sweep + traceback
+        walk, stdskl / trimskl.  Alignments are produced in host memory every step: D2H of the records,
+        stdskl / trimskl and the SKL arrays are inside the clock (want=True); convert=False only skips
+        turning them into numpy rows in Python."""
+        if mode == "weak" or world == 1:
+            batch = make(synth.SEED + 1000 * rank, args.queries)
+        else:
+            full = make(synth.SEED, args.queries)                  # the same batch on every rank
+            batch = [full[i] for i in shard.shard_range(len(full), rank, world)]
+        ps = abi.ProblemSet()
+        for w, q, s5, s3, _ in batch:
+            ps.add(q, w, s5, s3)
+        bt = eng.upload(sc, ps)
+        for _ in range(args.warmup):
+            bt.align(want=True, convert=False)
+        barrier()
+        t0 = time.perf_counter()
+        stats = []
+        step_cells = 0
+        for _ in range(args.steps):
+            _, ms, kc = bt.align(want=True, convert=False)
+            stats.append(bt.stats())
+            step_cells = kc
+        barrier()
+        dt = time.perf_counter() - t0
+        tot_cells, tot_q = float(step_cells), float(len(batch))
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            c = torch.tensor([tot_cells, tot_q], dtype=torch.float64)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            tot_cells, tot_q = float(c[0].item()), float(c[1].item())
+        band_cells = bt.cells()
+        bt.free()
+        return {"dt": dt, "total_cells": tot_cells, "total_queries": tot_q, "cells": step_cells, "stats": stats,
+                "batch": batch, "ps": ps, "band_cells": band_cells}
+
+    prim = measure(args.scaling)
+    other = None
+    if world > 1:
+        om = "strong" if args.scaling == "weak" else "weak"
+        o = measure(om)
+        other = {"scaling": om, "value": round(o["total_cells"] * args.steps / o["dt"] / 1e9, 3), "unit": "GCUPS",
+                 "queries_total": int(o["total_queries"]), "queries_per_s": round(o["total_queries"] * args.steps / o["dt"], 1),
+                 "ms_per_step": round(o["dt"] / args.steps * 1e3, 3)}
+    dt, total_cells, cells, stats, batch, ps = (prim["dt"], prim["total_cells"], prim["cells"], prim["stats"],
+                                                prim["batch"], prim["ps"])
 
     if rank == 0:
         gcups = total_cells * args.steps / dt / 1e9
@@ -368,7 +419,7 @@ def main():
             for i in range(ns):
                 band += oracle.cells(ps.items[i], oracle.stripe(ps.items[i], sc.sh))
             cpu_base = _ref_baseline([(dec[batch[i][0]], dec[batch[i][1]]) for i in range(ns)], False, band,
-                                     cells / max(1, bt.cells()))
+                                     cells / max(1, prim["band_cells"]))
         else:
             tc = time.perf_counter()
             with mp.Pool(min(ncores, ns)) as pool:
@@ -382,7 +433,7 @@ def main():
             "metric": "GCUPS (DP cell updates/s), cDNA->genome spliced DP",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (exact integers) / int32",
             "data": "synthetic",
             "config": {"workload": ("C4 shape (batch scaled to the run): 500-nt ESTs, 1 % error, vs the locus of "
                                     "the fragment +-1 kb (windows 2-10 kb), default band, Fwd2s1 _wip path: "
@@ -390,8 +441,11 @@ def main():
                                    ("C2: 10k x 2 kb cDNA vs planted loci +-1 kb (windows ~12 kb), "
                                     "default band, Fwd2s1 _wip path: alignS_ng(ori=1, -Q0) = UDH sweep + "
                                     "slab tracebacks, SKL out"),
-                       "queries_per_gpu": args.queries, "cells_per_gpu_per_step": int(cells),
-                       "queries_per_s": round(args.queries * world * args.steps / dt, 1),
+                       "queries_per_gpu": len(batch), "queries_total": int(prim["total_queries"]),
+                       "cells_per_gpu_per_step": int(cells),
+                       "queries_per_s": round(prim["total_queries"] * args.steps / dt, 1),
+                       "parallelism": f"{world} rank(s), one per GPU, queries sharded, no collective on the data path",
+                       **({"strong_scaling" if other["scaling"] == "strong" else "weak_scaling": other} if other else {}),
                        "udh_ms": round(udh_ms, 3), "udh_gcups": round(udh_cells / udh_ms / 1e6, 2) if udh_ms else None,
                        "fwd_ms": round(fwd_ms, 3), "fwd_gcups": round(fwd_cells / fwd_ms / 1e6, 2) if fwd_ms else None,
                        "fwd_problems": int(stats[-1]["fwd_problems"]), "tb_bytes": int(stats[-1]["tb_bytes"])},
@@ -405,7 +459,6 @@ def main():
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)
-    bt.free()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -206,6 +206,26 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
                    const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 void spdp_free_rescored(SpdpRescored* out, int n);
 
+/* ---- device groups: every GPU of the node behind one handle -------------- */
+/* The reference is one process with worker threads (spaln -t N, src/spaln.cc:1389-1468: a master hands
+ * whole queries to the workers).  A group owns one context per listed HIP device (a device may be listed more
+ * than once); the calls below shard the problem list into contiguous ranges, one per member, run them
+ * concurrently -- problems are independent, nothing is exchanged between devices -- and fill scores / out in
+ * the caller's order.  Return values as for the single-device calls (the worst of the members). */
+typedef struct SpdpGroup SpdpGroup;
+SpdpGroup*  spdp_group_create(const int* devices, int n_devices);
+void        spdp_group_destroy(SpdpGroup* g);
+int         spdp_group_size(const SpdpGroup* g);
+const char* spdp_group_last_error(const SpdpGroup* g);
+int spdp_group_homscore_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, int32_t* scores);
+int spdp_group_align_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+struct SpdpScoringH;
+struct SpdpProblemH;
+int spdp_group_homscore_h(SpdpGroup* g, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs, int n_probs,
+                          int32_t* scores);
+int spdp_group_align_h(SpdpGroup* g, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs, int n_probs,
+                       SpdpAlignment* out);
+
 /* ---- submit / wait ------------------------------------------------------ */
 /* Asynchronous form of the batched calls: a worker thread runs the call and owns `ctx` until
  * spdp_wait() returns (one ticket in flight per context; inputs and `out` must stay valid until

@@ -28,6 +28,8 @@ EXPORTS = [
     "spdp_batch_upload_h", "spdp_batch_free_h", "spdp_batch_cells_h", "spdp_batch_align_h",
     "spdp_submit_align_s", "spdp_submit_homscore_s", "spdp_submit_align_h", "spdp_submit_homscore_h",
     "spdp_poll", "spdp_wait",
+    "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
+    "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
 ]
 
 
@@ -83,7 +85,53 @@ def load_library() -> C.CDLL:
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_poll.argtypes = [C.c_void_p]
     lib.spdp_wait.argtypes = [C.c_void_p]
+    lib.spdp_group_create.restype = C.c_void_p
+    lib.spdp_group_create.argtypes = [C.c_void_p, C.c_int]
+    lib.spdp_group_destroy.argtypes = [C.c_void_p]
+    lib.spdp_group_size.argtypes = [C.c_void_p]
+    lib.spdp_group_last_error.restype = C.c_char_p
+    lib.spdp_group_last_error.argtypes = [C.c_void_p]
+    for f in ("spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h"):
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return lib
+
+
+class Group:
+    """Several GPUs behind one handle (spdp_group_*): the batched calls shard the query list over the members."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        self.h = self.lib.spdp_group_create(arr, len(devices))
+        if not self.h:
+            raise RuntimeError("spdp_group_create failed: no usable HIP device (there is no CPU path)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.spdp_group_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.spdp_group_last_error(self.h).decode()}")
+
+    def homscore_s(self, sc, ps) -> np.ndarray:
+        out = np.zeros(len(ps), dtype=np.int32)
+        self._check(self.lib.spdp_group_homscore_s(self.h, C.byref(sc), ps.array(), len(ps), out.ctypes.data),
+                    "spdp_group_homscore_s")
+        return out
+
+    def align_s(self, sc, ps):
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        self._check(self.lib.spdp_group_align_s(self.h, C.byref(sc), ps.array(), n, arr), "spdp_group_align_s")
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
 
 
 class Engine:

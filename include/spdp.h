@@ -166,7 +166,8 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc,
  * (:2718-2730) = HomScoreS_ng on the query as given (fwd[i]) and on its reverse complement against the
  * opposite genomic strand (rev[i]: comrev(a) + antiseq(b), with that strand's own signals), the reverse
  * wins only with a strictly higher score; then one alignment.  orient[i] = 0 / 1 says which problem
- * out[i] refers to. */
+ * out[i] refers to; an alignment of the flipped pair carries A_RevCom (0x10) in its header record, as
+ * globalS_ng sets it (src/fwd2s1.cc:2691-2692). */
 int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* fwd, const SpdpProblem* rev,
                       int n_probs, SpdpAlignment* out, int32_t* orient);
 void spdp_free_alignments(SpdpAlignment* out, int n);

@@ -271,7 +271,10 @@ def homscore_s(sc, p, simd=2):
 def align_s_ori3(sc, p_fwd, p_rev, simd=2):
     """alignS_ng(ori = 3) with seeding off: infer_orientation (src/fwd2s1.cc:2718-2730) + one alignment"""
     ori = 1 if homscore_s(sc, p_rev, simd) > homscore_s(sc, p_fwd, simd) else 0
-    return align_s(sc, p_rev if ori else p_fwd, simd), ori
+    scr, flat = align_s(sc, p_rev if ori else p_fwd, simd)
+    if ori and flat:
+        flat[0] |= 0x10                                   # A_RevCom: a->inex.sens after comrev (src/fwd2s1.cc:2692)
+    return (scr, flat), ori
 
 
 def align_s(sc, p, simd=2):

@@ -116,8 +116,18 @@ def lsp_h(sc, p, w, rec, simd=2):
         raise ReferenceUndefined("sub-range outside the sequences")
     if not m and not n:
         return 0
-    if not m or not n:
-        raise NotRestated("empty range")
+    if not m or not n:                                    # src/fwd2h1.cc:2148-2159, PwdB penalties src/aln.h:275-304
+        rec.append((p.a_left, p.b_left))
+        rec.append((p.a_right, p.b_right))
+        if m:
+            if p.a_exgl or p.a_exgr:
+                return sc.lgep if m > sc.codonk1 else sc.gep
+            return sc.lgop + m * sc.lgep if m > sc.codonk1 else sc.gop + m * sc.gep
+        if p.b_exgl or p.b_exgr:
+            return sc.lgep if n > sc.codonk1 else sc.gep
+        d = n // 3
+        egop = sc.gape1 if n % 3 == 1 else (sc.gape2 if n % 3 == 2 else 0)
+        return d * sc.gep + egop if n <= sc.codonk1 else d * sc.gep - sc.diffu * (d - sc.k1) + egop
     if w.up == w.lw:
         return diagonal_h(sc, p, rec)
     if abs(n - m) < NELEM or m == 1 or n <= 3:

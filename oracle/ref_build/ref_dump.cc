@@ -21,6 +21,8 @@
 //   -q N     IntronPrm.nquant override                 -T dir species table (AlnParam not parsed)
 //   -r al,ar,bl,br  restrict the active ranges (Seq::left/right) before the tables are built
 //   -u list  extra explicit UDH runs with these n_im (comma separated)
+//   -O       alignS_ng(ori = 3) fixture: both strands prepared as spaln.cc:1137-1152 does (genomicseq, ori = 3),
+//            the reverse-strand problem dumped under r_*, the result of alignS_ng(seqs, pwd, gsi, 3) under ori3_*
 
 #include "ref_dump_common.h"
 #include "fwd2s1_simd.h"
@@ -28,7 +30,7 @@
 
 int main(int argc, const char** argv)
 {
-	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0;
+	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0, ori3 = 0;
 	long	vmfspace = 0;
 const	char*	exg = 0;
 	std::vector<int>	udh_list;
@@ -39,6 +41,7 @@ const	char*	exg = 0;
 		case 'l': ls = atoi(argv[++ai]); break;
 		case 'w': sh = atoi(argv[++ai]); break;
 		case 'L': local = 1; break;
+		case 'O': ori3 = 1; break;
 		case 'g': exg = argv[++ai]; break;
 		case 'U': ubh = atoi(argv[++ai]); break;
 		case 'V': vmfspace = atol(argv[++ai]); break;
@@ -105,26 +108,33 @@ const	char*	outfn = argv[ai + 2];
 	b->exin = new Exinon(b, pwd, false);
 
 	Writer	w(outfn);
-// ---- inputs
-	w.put("a_codes", 1, a->at(0), a->len);
-	w.put("b_codes", 1, b->at(0), b->len);
+// ---- inputs: everything the engines read from one strand's (query, genome) pair; `pre` = "" for the
+//      pair as given, "r_" for the reverse strand (comrev(a) + antiseq(b))
+	auto dump_strand = [&](const char* pre) {
+	    char	pnb[40];
+	    auto pn = [&](const char* nm_) { snprintf(pnb, sizeof pnb, "%s%s", pre, nm_); return (const char*) pnb; };
+	w.put(pn("a_codes"), 1, a->at(0), a->len);
+	w.put(pn("b_codes"), 1, b->at(0), b->len);
 	{
 	    std::vector<short>	s5(b->len + 1, 0), s3(b->len + 1, 0);
 	    std::vector<signed char> p5(b->len + 1, -2), p3(b->len + 1, -2);
 	    std::vector<unsigned char> c5(b->len + 1, 0), c3(b->len + 1, 0);
-	    for (int n = b->left; n <= b->right; ++n) {
+	    // column b->left is the boundary column of the DP, not a cell: Exinon never defines its record (the
+	    // first one it writes is begin_n() + 1, codepot.cc:497) and what sits there differs from run to run.
+	    // It is dumped as zero, so that regenerating the fixtures reproduces them byte for byte.
+	    for (int n = b->left + 1; n <= b->right; ++n) {
 		const SGPT2* sg = b->exin->score_n(n);
 		s5[n] = sg->sig5; s3[n] = sg->sig3;
 		p5[n] = sg->phs5; p3[n] = sg->phs3;
 		c5[n] = b->exin->isDonor(n);
 		c3[n] = b->exin->isAccpt(n);
 	    }
-	    w.put("sig5", 2, s5.data(), s5.size());
-	    w.put("sig3", 2, s3.data(), s3.size());
-	    w.put("phs5", 4, p5.data(), p5.size());
-	    w.put("phs3", 4, p3.data(), p3.size());
-	    w.put("cano5", 1, c5.data(), c5.size());
-	    w.put("cano3", 1, c3.data(), c3.size());
+	    w.put(pn("sig5"), 2, s5.data(), s5.size());
+	    w.put(pn("sig3"), 2, s3.data(), s3.size());
+	    w.put(pn("phs5"), 4, p5.data(), p5.size());
+	    w.put(pn("phs3"), 4, p3.data(), p3.size());
+	    w.put(pn("cano5"), 1, c5.data(), c5.size());
+	    w.put(pn("cano3"), 1, c3.data(), c3.size());
 	    // dinucleotide classes exactly as Exinon::intron53_c assigns them (codepot.cc:435-448),
 	    // and the junction table behind Exinon::sig53(m, n, IE53) (codepot.cc:411-415):
 	    //   sig53(m, n, IE53) = sig3[n] + T53[16 * dinc5[m] + dinc3[n]]
@@ -137,8 +147,8 @@ const	char*	outfn = argv[ai + 2];
 		if (i - 1 >= 0) d5[i - 1] = nc;
 		d3[i + 1] = nc;
 	    }
-	    w.put("dinc5", 1, d5.data(), b->len + 1);
-	    w.put("dinc3", 1, d3.data(), b->len + 1);
+	    w.put(pn("dinc5"), 1, d5.data(), b->len + 1);
+	    w.put(pn("dinc3"), 1, d3.data(), b->len + 1);
 	    std::vector<int> t53(256, 0), mrep(16, -1), nrep(16, -1);
 	    for (int n = b->left; n <= b->right; ++n) {
 		if (n >= b->left && n < b->right - 1 && mrep[d5[n]] < 0 && n >= b->left) mrep[d5[n]] = n;
@@ -148,7 +158,7 @@ const	char*	outfn = argv[ai + 2];
 		for (int v = 0; v < 16; ++v)
 		    if (mrep[u] >= 0 && nrep[v] >= 0)
 			t53[16 * u + v] = b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_n(nrep[v])->sig3;
-	    w.put_i32("t53", t53);
+	    w.put_i32(pn("t53"), t53);
 	    int	bad = 0;
 	    for (int t = 0; t < 400; ++t) {		// self-check of the restated classes
 		int m = b->left + (t * 7919) % std::max(1, b->right - b->left - 2);
@@ -158,6 +168,26 @@ const	char*	outfn = argv[ai + 2];
 		if (want != got) ++bad;
 	    }
 	    if (bad) fprintf(stderr, "ref_dump: %d sig53 self-check mismatches\n", bad);
+	}
+	    std::vector<int> rg = {a->left, a->right, b->left, b->right,
+		(int) a->inex.exgl, (int) a->inex.exgr, (int) b->inex.exgl, (int) b->inex.exgr, (int) a->inex.sens};
+	    w.put_i32(pn("ranges"), rg);
+	};
+	if (ori3) {
+	    // both strands as the caller of alignS_ng prepares them (genomicseq with ori = 3, spaln.cc:1137-1152)
+	    delete b->exin;
+	    b->exin = new Exinon(b, pwd, true);
+	    b->comrev(seqs + 2);
+	    seqs[2]->setanti(seqs + 1);
+	    seqs[2]->exin = new Exinon(seqs[2], pwd, true);
+	}
+	dump_strand("");
+	if (ori3) {
+	    a->comrev();
+	    antiseq(seqs + 1);
+	    dump_strand("r_");
+	    a->comrev();
+	    antiseq(seqs + 1);
 	}
 	{
 	    const Simmtx* sm = pwd->simmtx;
@@ -204,6 +234,25 @@ const	int	nq0 = IntronPrm.nquant;
 	    a->inex = ia; b->inex = ib;
 	};
 	char	nm[48];
+
+	if (ori3) {
+	    // alignS_ng with the default orientation handling (src/fwd2s1.cc:2746-2778 -> infer_orientation :2718)
+	    for (int alg = 2; alg >= 0; alg -= 2) {	// -A2 (the _wip engines), then -A0
+		algmode.alg = alg;
+		restore();
+		Gsinfo	gsi;
+		gsi.skl = alignS_ng(seqs, pwd, &gsi, 3);
+const		int	rev = a->inex.sens? 1: 0;
+		snprintf(nm, sizeof nm, "ori3_rev_A%d", alg);
+		w.put_int(nm, rev);
+		snprintf(nm, sizeof nm, "ori3_scr_A%d", alg);
+		w.put_int(nm, (int) gsi.scr);
+		snprintf(nm, sizeof nm, "ori3_skl_A%d", alg);
+		w.put_i32(nm, skl2vec(gsi.skl));
+		if (rev) { a->comrev(); antiseq(seqs + 1); }	// back to the strand as given
+	    }
+	    return 0;
+	}
 
 // (1) engine-level goldens straight from SimdAln2s1, the _wip engines
 //     (fwd2s1_wip_simd.h:42,233,476).  tag qn: nquant as configured (what -A2

@@ -604,7 +604,21 @@ static void queue_lsp(const SpdpScoringH& sc, const SpdpProblemH& p, HItem it, s
 {
     const int m = it.a_right - it.a_left, n = it.b_right - it.b_left;
     if (!m && !n) { if (it.first) t.score = 0; return; }
-    if (!m || !n) { t.cls = 2; return; }                     // terminal-gap-only ranges: GapPenalty paths, not built
+    if (!m || !n) {                                          // one sequence only: the two end records and the gap's
+        push_rec(t, it.a_left, it.b_left);                   // price (src/fwd2h1.cc:2148-2159; PwdB::GapPenalty /
+        push_rec(t, it.a_right, it.b_right);                 // GapExtPen / UnpPenalty3 / GapExtPen3, src/aln.h:275-304)
+        if (it.first) {
+            if (m) t.score = (it.a_exgl || it.a_exgr) ? (m > sc.codonk1 ? sc.lgep : sc.gep)
+                                                      : (m > sc.codonk1 ? sc.lgop + m * sc.lgep : sc.gop + m * sc.gep);
+            else if (it.b_exgl || it.b_exgr) t.score = n > sc.codonk1 ? sc.lgep : sc.gep;
+            else {
+                const int d = n / 3;
+                const int egop = n % 3 == 1 ? sc.gape1 : (n % 3 == 2 ? sc.gape2 : 0);
+                t.score = n <= sc.codonk1 ? d * sc.gep + egop : d * sc.gep - sc.diffu * (d - sc.k1) + egop;
+            }
+        }
+        return;
+    }
     if (it.w.up == it.w.lw) {                                // diagonalH_ng (src/fwd2h1.cc:1963-1995): one O(m) walk,
         const bool LocalL = sc.local && it.a_exgl && it.b_exgl;  // host side in the reference's ladder as well
         const bool LocalR = sc.local && it.a_exgr && it.b_exgr;

@@ -685,5 +685,10 @@ int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem
         pick[i] = orient[i] ? rev[i] : fwd[i];
     }
     const int r3 = spdp_align_s(ctx, sc, pick.data(), n_probs, out);
-    return r3 < 0 ? -1 : (r1 | r2 | r3);
+    if (r3 < 0) return -1;
+    // globalS_ng marks an alignment of the flipped pair: skl->m |= A_RevCom when a->inex.sens is set, which
+    // comrev() does (src/fwd2s1.cc:2691-2692, src/aln.h:89)
+    for (int i = 0; i < n_probs; ++i)
+        if (orient[i] && out[i].skl && out[i].n_skl > 0) out[i].skl[0].m |= 0x10;
+    return r1 | r2 | r3;
 }

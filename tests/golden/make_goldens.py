@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from spaln_amd import synth  # noqa: E402
 
 REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
-ALN_TAB = os.environ.get("ALN_TAB", "/tmp/spaln_ref_build/table")
+ALN_TAB = os.environ.get("ALN_TAB", os.path.join(ROOT, "oracle", "_ref", "table"))
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -99,8 +99,27 @@ def cases():
     c["s1_auto_udh"] = (g.window, g.query, ["-V", "300000", "-u", "2"])
     g = gene(13, n_exons=9, mrna_len=1450, flank=600, intron_hi=2500)
     c["s1_1450nt_auto"] = (g.window, g.query, ["-V", "2000000", "-u", "5"])
+    # alignS_ng with its default orientation handling (ori = 3, -Q0).  Flipping both sequences keeps the match and
+    # turns the transcript's direction around: "minus" = query and window both reverse-complemented, i.e. the pair
+    # matches as given but its introns read CT..AC; infer_orientation has to pick the flipped view.  Once with a
+    # query long enough for the linear-space branch
+    g = gene(14, n_exons=5, mrna_len=700, flank=300, intron_hi=900)
+    c["o3_plus"] = (g.window, g.query, ["-O"])
+    c["o3_minus"] = (revcomp(g.window), revcomp(g.query), ["-O"])
+    g = gene(15, n_exons=7, mrna_len=1100, flank=400, intron_hi=1500, sub=0.06, indel=0.01)
+    c["o3_minus_udh"] = (revcomp(g.window), revcomp(g.query), ["-O", "-V", "600000"])
+    c["o3_plus_udh"] = (g.window, g.query, ["-O", "-V", "600000"])
+    w, q = random_pair(16, 300, 2500)
+    c["o3_random"] = (w, q, ["-O"])
     c.update(protein_cases())
     return c
+
+
+def revcomp(ascii_seq):
+    comp = np.zeros(256, dtype=np.uint8)
+    for x, y in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+        comp[x] = y
+    return comp[np.asarray(ascii_seq, dtype=np.uint8)][::-1].copy()
 
 
 def pgene(seed, **kw):

@@ -54,6 +54,20 @@ def problem(fx: dict, ps: abi.ProblemSet | None = None):
     return ps, p
 
 
+def problem_rev(fx: dict, ps: abi.ProblemSet | None = None):
+    """the reverse-strand problem of an ori = 3 fixture (ref_dump -O): comrev(a) + antiseq(b), with that
+    strand's own signals and its own ranges / end flags (r_ranges)"""
+    ps = abi.ProblemSet() if ps is None else ps
+    r = [int(x) for x in fx["r_ranges"]]
+    extra = {}
+    if "r_dinc5" in fx:
+        extra = dict(cano5=fx["r_cano5"], cano3=fx["r_cano3"],
+                     dinc=(fx["r_dinc5"].astype("uint8") << 4) | fx["r_dinc3"].astype("uint8"))
+    p = ps.add(fx["r_a_codes"], fx["r_b_codes"], fx["r_sig5"], fx["r_sig3"], r[0], r[1], r[2], r[3],
+               (r[4], r[5], r[6], r[7]), **extra)
+    return ps, p
+
+
 HPARAM_NAMES = ["gapw1", "gapw2", "gapw3", "gapw3l", "gape1", "gape2", "extragop", "k1", "termk1",
                 "lcl", "dvsp"]
 

@@ -102,3 +102,28 @@ def test_align_a6_recursive_switch():
         _, p = spdg.problem_h(fx)
         scr, flat = host_logic_h.align_h(sc, p)
         assert scr == int(fx["aln_scr_A6"][0]) and (flat or []) == fx["aln_skl_A6"].tolist(), f
+
+
+# ---- alignS_ng with its default orientation handling (ori = 3), pinned to the reference ----------------
+O3 = golden_files("o3_")
+
+
+@pytest.mark.parametrize("path", O3, ids=golden_ids("o3_"))
+@pytest.mark.parametrize("alg", [2, 0])
+def test_align_s_ori3_vs_reference(path, alg):
+    """infer_orientation (src/fwd2s1.cc:2718-2730) + one alignment: which strand view wins, gsi->scr and the SKL
+    (with A_RevCom in its header when the flipped pair was aligned), under -A2 and -A0; the reverse-strand problem is
+    the reference's own comrev(a) / antiseq(b) with that strand's Exinon (ref_dump -O)"""
+    fx = spdg.load(path)
+    sc = spdg.scoring(fx)
+    _, pf = spdg.problem(fx)
+    _, pr = spdg.problem_rev(fx)
+    (scr, skl), ori = host_logic.align_s_ori3(sc, pf, pr, simd=alg)
+    assert ori == int(fx[f"ori3_rev_A{alg}"][0])
+    assert scr == int(fx[f"ori3_scr_A{alg}"][0])
+    assert (skl or []) == fx[f"ori3_skl_A{alg}"].tolist()
+
+
+def test_ori3_fixtures_cover_both_outcomes():
+    seen = {int(spdg.load(f)["ori3_rev_A2"][0]) for f in O3}
+    assert seen == {0, 1} and len(O3) >= 5

@@ -119,10 +119,13 @@ const	char*	outfn = argv[ai + 2];
 	    std::vector<short>	s5(b->len + 1, 0), s3(b->len + 1, 0);
 	    std::vector<signed char> p5(b->len + 1, -2), p3(b->len + 1, -2);
 	    std::vector<unsigned char> c5(b->len + 1, 0), c3(b->len + 1, 0);
-	    // column b->left is the boundary column of the DP, not a cell: Exinon never defines its record (the
-	    // first one it writes is begin_n() + 1, codepot.cc:497) and what sits there differs from run to run.
-	    // It is dumped as zero, so that regenerating the fixtures reproduces them byte for byte.
-	    for (int n = b->left + 1; n <= b->right; ++n) {
+	    // NB: the acceptor signal of the boundary column (n = b->left when the window starts at 0) comes out of
+	    // the pattern scan's reach in front of the sequence (PatMat::calcPatMat from sd->left - 1 on,
+	    // codepot.cc:481-486): indeterminate memory in the reference, a few units different from run to run.
+	    // The engines READ it (s1_cut_left changes its alignment if it is forced to 0), so it is dumped as this
+	    // run saw it: inputs and outputs of a fixture belong to one run; regenerating a fixture may change
+	    // this one input element (and nothing else).
+	    for (int n = b->left; n <= b->right; ++n) {
 		const SGPT2* sg = b->exin->score_n(n);
 		s5[n] = sg->sig5; s3[n] = sg->sig3;
 		p5[n] = sg->phs5; p3[n] = sg->phs3;

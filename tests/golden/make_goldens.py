@@ -7,6 +7,7 @@ reference's parameter tables (ALN_TAB).  Each case is a deterministic synthetic
 (window, query) pair from spaln_amd.synth; the harness writes the DP inputs the
 reference engines consumed and everything they produced.  The .spdg files are
 data only (inputs + expected outputs) -- no reference source travels.
+Regenerating is idempotent: see same_but_boundary_signal().
 
     python tests/golden/make_goldens.py            # regenerate all
 """
@@ -196,11 +197,39 @@ def main():
             synth.write_fasta(gf, "win", window)
             synth.write_fasta(qf, "qry", query)
             out = os.path.join(OUT, name + ".spdg")
-            r = subprocess.run([REF_DUMP, *opts, gf, qf, out], env=env, capture_output=True, text=True)
+            tmp = os.path.join(td, name + ".spdg")
+            r = subprocess.run([REF_DUMP, *opts, gf, qf, tmp], env=env, capture_output=True, text=True)
             status = "ok" if r.returncode == 0 else f"FAILED rc={r.returncode} {r.stderr[-300:]}"
+            if r.returncode == 0:
+                if os.path.exists(out) and same_but_boundary_signal(out, tmp):
+                    status += " (unchanged)"
+                else:
+                    os.replace(tmp, out)
+                    status += " (written)"
             print(f"{name:24s} m={len(query):5d} n={len(window):6d} {status}")
-            if r.returncode != 0 and os.path.exists(out):
-                os.remove(out)
+
+
+def same_but_boundary_signal(old, new):
+    """One input element of a fixture is not a function of the sequences: the acceptor signal of the boundary
+    column of a window that starts at position 0 comes out of memory in front of the sequence (ref_dump.cc) and
+    moves by a few units from run to run; the reference's outputs in the fixtures do not move with it.  A
+    regenerated fixture that differs from the committed one in that element only is the same fixture: the
+    committed file (inputs and outputs of ONE real run) is kept, so that regenerating is idempotent."""
+    sys.path.insert(0, ROOT)
+    from tests import spdg
+    a, b = spdg.load(old), spdg.load(new)
+    if set(a) != set(b):
+        return False
+    for k in a:
+        if k == "prm":
+            continue
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        if x.shape != y.shape:
+            return False
+        bad = np.nonzero(x != y)[0]
+        if bad.size and not (k in ("sig3", "r_sig3") and bad.tolist() == [0]):
+            return False
+    return True
 
 
 if __name__ == "__main__":

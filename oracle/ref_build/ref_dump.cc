@@ -21,10 +21,13 @@
 //   -q N     IntronPrm.nquant override                 -T dir species table (AlnParam not parsed)
 //   -r al,ar,bl,br  restrict the active ranges (Seq::left/right) before the tables are built
 //   -u list  extra explicit UDH runs with these n_im (comma separated)
+//   -A list  only these engine selectors in the Aln2-surface section, and no engine-level section: fixtures beyond
+//            1472 nt, where the reference's int16 engines (-A1..3) are erratic and -A0 is the truth
 //   -O       alignS_ng(ori = 3) fixture: both strands prepared as spaln.cc:1137-1152 does (genomicseq, ori = 3),
 //            the reverse-strand problem dumped under r_*, the result of alignS_ng(seqs, pwd, gsi, 3) under ori3_*
 
 #include "ref_dump_common.h"
+#include <algorithm>
 #include "fwd2s1_simd.h"
 
 
@@ -33,7 +36,7 @@ int main(int argc, const char** argv)
 	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0, ori3 = 0;
 	long	vmfspace = 0;
 const	char*	exg = 0;
-	std::vector<int>	udh_list;
+	std::vector<int>	udh_list, alg_list;
 	int	rng4[4] = {-1, -1, -1, -1};
 	int	ai = 1;
 	for ( ; ai < argc && argv[ai][0] == '-'; ++ai) {
@@ -42,6 +45,15 @@ const	char*	exg = 0;
 		case 'w': sh = atoi(argv[++ai]); break;
 		case 'L': local = 1; break;
 		case 'O': ori3 = 1; break;
+		case 'A': {
+		    const char* p = argv[++ai];
+		    while (*p) {
+			alg_list.push_back(atoi(p));
+			while (*p && *p != ',') ++p;
+			if (*p == ',') ++p;
+		    }
+		    break;
+		}
 		case 'g': exg = argv[++ai]; break;
 		case 'U': ubh = atoi(argv[++ai]); break;
 		case 'V': vmfspace = atol(argv[++ai]); break;
@@ -260,7 +272,7 @@ const		int	rev = a->inex.sens? 1: 0;
 // (1) engine-level goldens straight from SimdAln2s1, the _wip engines
 //     (fwd2s1_wip_simd.h:42,233,476).  tag qn: nquant as configured (what -A2
 //     runs), tag q1: nquant = 1 (what -A3 runs, fwd2s1.cc:125).
-	for (int pass = 0; pass < 2; ++pass) {
+	for (int pass = 0; pass < 2 && alg_list.empty(); ++pass) {
 	    IntronPrm.nquant = pass? 1: nq0;
 const	    char*	tag = pass? "q1": "qn";
 	    SpJunc	spjcs(b, pwd);
@@ -323,6 +335,7 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 //     -A3 goes last: its Aln2s1 ctor sets IntronPrm.nquant = 1 for good.
 	for (int alg = 0; alg < 7; ++alg) {
 	    if (alg == 4 || alg == 5) continue;	// 6 = -A2 with the recursive switch (algmode.alg & 4)
+	    if (!alg_list.empty() && std::find(alg_list.begin(), alg_list.end(), alg) == alg_list.end()) continue;
 	    algmode.alg = alg;
 	    restore();
 	    VTYPE	hs = HomScoreS_ng((const Seq**) seqs, pwd);

@@ -112,6 +112,13 @@ def cases():
     c["o3_plus_udh"] = (g.window, g.query, ["-O", "-V", "600000"])
     w, q = random_pair(16, 300, 2500)
     c["o3_random"] = (w, q, ["-O"])
+    # BASELINE's headline size (C2: 2 kb cDNA, 8 exons, locus +-1 kb) and a C5-scaled long cDNA, -A0 only: the
+    # reference's int16 engines are erratic beyond 1472 nt, its scalar engines are the truth
+    for k in range(4):
+        g = synth.make_gene(np.random.default_rng(synth.SEED + 7000 + k))           # make_batch()'s defaults
+        c[f"c2_seed{k}"] = (g.window, g.query, ["-A", "0"])
+    g = gene(7100, n_exons=24, mrna_len=6000, flank=1000, intron_hi=2500)
+    c["c5_6kb"] = (g.window, g.query, ["-A", "0"])
     c.update(protein_cases())
     return c
 

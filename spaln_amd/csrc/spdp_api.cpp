@@ -381,7 +381,8 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     }
     const int bw = (flav == 2) ? 4 : (flav >= 3 ? 1 : 2);
     const int nn = std::max(n, 1);
-    skl_cap = std::min(std::max(max_skl, 1), 1024);     // typical lists are short; overflow is re-walked
+    skl_cap = std::min(std::max(max_skl, 1), 1024);     // typical lists are short; DevRun::fetch_skl walks the rest again
+    if (const char* e = getenv("SPDP_SKL_CAP")) skl_cap = std::max(4, std::min(skl_cap, atoi(e)));   // test hook: tiny slots
     POOLGET(d_probs, POOL_PROBS, sizeof(DevProblem) * nn);
     POOLGET(d_bnd, POOL_BND, sizeof(int32_t) * bw * std::max<int64_t>(bnd_tot, 1));
     POOLGET(d_res, POOL_RES, sizeof(DevResult) * nn);
@@ -578,9 +579,50 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     if (!n) { skl.clear(); return 0; }
     std::vector<int> cnt(n);                            // dispatch order
     HIPCHK(hipMemcpy(cnt.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    // Lists that did not fit their slot (skl_cap is sized for typical lists; an indel-rich slab can need more): the
+    // walk is repeated for those few with slots of the longest list their problem can produce.  Only the `_wip`
+    // walk (flavour 1) can be repeated on its own; the scalar / -A1 engines walk inside their sweep kernel and
+    // report the overflow (-1) to the caller, who gives up that one query, not the batch.
+    std::vector<int> over;
+    for (int j = 0; j < n; ++j) if (cnt[j] == -1) over.push_back(j);
+    std::vector<std::vector<SpdpSkl>> redo(over.size());
+    if (!over.empty() && flav == 1) {
+        const int m = (int) over.size();
+        std::vector<DevResult> all_res(n), sub_res(m);
+        std::vector<DevProblem> sub_probs(m);
+        HIPCHK(hipMemcpy(all_res.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost));
+        int cap2 = 1;
+        for (int k = 0; k < m; ++k) {
+            const DevProblem& P = h_probs[over[k]];
+            sub_probs[k] = P; sub_res[k] = all_res[over[k]];
+            cap2 = std::max(cap2, (P.a_right - P.a_left) + (P.b_right - P.b_left) + 8);
+        }
+        void *dp = nullptr, *dr = nullptr, *ds = nullptr, *dn = nullptr;
+        HIPCHK(hipMalloc(&dp, sizeof(DevProblem) * m));
+        HIPCHK(hipMalloc(&dr, sizeof(DevResult) * m));
+        HIPCHK(hipMalloc(&ds, sizeof(int2) * (size_t) cap2 * m));
+        HIPCHK(hipMalloc(&dn, sizeof(int) * m));
+        HIPCHK(hipMemcpy(dp, sub_probs.data(), sizeof(DevProblem) * m, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dr, sub_res.data(), sizeof(DevResult) * m, hipMemcpyHostToDevice));
+        WalkArgs W;
+        W.probs = (const DevProblem*) dp; W.n_probs = m; W.tb = (const uint8_t*) d_tb; W.res = (const DevResult*) dr;
+        W.skl = (int2*) ds; W.n_skl = (int*) dn; W.skl_cap = cap2; W.seq = 0;
+        HIPCHK(spdp_launch_walk(&W, strm()));
+        HIPCHK(hipStreamSynchronize(strm()));
+        std::vector<int> c2(m);
+        HIPCHK(hipMemcpy(c2.data(), dn, sizeof(int) * m, hipMemcpyDeviceToHost));
+        for (int k = 0; k < m; ++k) {
+            cnt[over[k]] = c2[k];
+            if (c2[k] > 0) {
+                redo[k].resize(c2[k]);
+                HIPCHK(hipMemcpy(redo[k].data(), (const int2*) ds + (size_t) k * cap2, sizeof(SpdpSkl) * c2[k], hipMemcpyDeviceToHost));
+            }
+        }
+        (void) hipFree(dp); (void) hipFree(dr); (void) hipFree(ds); (void) hipFree(dn);
+    }
     std::vector<int64_t> doff(n + 1, 0);
     for (int j = 0; j < n; ++j) {
-        if (cnt[j] > skl_cap) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
+        if (cnt[j] > skl_cap && redo.empty()) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
         if (cnt[j] == -3) { ctx->err = "scalar engine: Vmf record buffer overflow"; return -1; }
         doff[j + 1] = doff[j] + std::max(cnt[j], 0);
         n_skl[order[j]] = cnt[j];
@@ -601,6 +643,8 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     skl.resize(off[n]);
     for (int j = 0; j < n; ++j)
         if (cnt[j] > 0) memcpy(skl.data() + off[order[j]], packed.data() + doff[j], sizeof(SpdpSkl) * cnt[j]);
+    for (size_t k = 0; k < over.size(); ++k)            // the lists of the second walk (the pack kernel skipped them)
+        if (!redo[k].empty()) memcpy(skl.data() + off[order[over[k]]], redo[k].data(), sizeof(SpdpSkl) * redo[k].size());
     return 0;
 }
 

@@ -33,7 +33,8 @@ enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs +
 enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN };
 void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64]);       // spdp_rescore_api.cpp
 enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES };
-static const int H_SKL_CAP = 1024;
+static const int H_SKL_CAP = 4096;       // slot of one traceback record list; a list is at most ~4 records per query row (diagonal / gap corners and
+                                           // two per intron), and the slot is min(this, rows + columns + 8): protein queries stay far below
 
 // ---- geometry --------------------------------------------------------------------------
 static void stripe31_rng(int a_left, int a_right, int b_left, int b_right, int sh, SpdpWindow* w)

@@ -176,6 +176,7 @@ struct Aligner {
     float kernel_ms = 0.f;
     int64_t kernel_cells = 0;
     int unsupported = 0;
+    int overflowed = 0;                         // queries given up because a record list did not fit (scalar / -A1 walkers)
     double stats[SPDP_N_STATS] = {0};           // see include/spdp.h
 
     void set_score(int job, bool top, int scr) { if (top) { jobs[job].score = scr; jobs[job].score_set = true; } }
@@ -442,6 +443,7 @@ struct Aligner {
             if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
             for (size_t k = 0; k < stbs.size(); ++k) {
                 const TbItem& t = stbs[k];
+                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
                 if (nskl[k] < 0) { ctx->err = "scalar traceback failed"; return -1; }
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* s = skl.data() + off[k];
@@ -462,6 +464,7 @@ struct Aligner {
             if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
             for (size_t k = 0; k < xtbs.size(); ++k) {
                 const TbItem& t = xtbs[k];
+                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
                 if (nskl[k] < 0) { ctx->err = "forwardS1 traceback failed"; return -1; }
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* sk = skl.data() + off[k];
@@ -489,6 +492,7 @@ struct Aligner {
             lap("fwd fetch");
             for (size_t k = 0; k < tbs.size(); ++k) {
                 const TbItem& t = tbs[k];
+                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
                 if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* s = skl.data() + off[k];
@@ -508,6 +512,7 @@ struct Aligner {
             if (side.fetch_results(res) || side.fetch_skl(nskl, off, skl)) return -1;
             for (size_t k = 0; k < side_tbs.size(); ++k) {
                 const TbItem& t = side_tbs[k];
+                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
                 if (nskl[k] < 0) { ctx->err = "traceback walk failed"; return -1; }
                 set_score(t.job, t.top, res[k].score);
                 const SpdpSkl* sk = skl.data() + off[k];
@@ -622,12 +627,12 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     rc[0] = al[0].run();
     for (std::thread& t : workers) t.join();
     for (int c = 0; c < n_chunks; ++c) if (gates[c].ev) (void) hipEventDestroy(gates[c].ev);
-    int unsupported = 0;
+    int unsupported = 0, overflowed = 0;
     float kms = 0.f; int64_t kc = 0;
     double st_sum[SPDP_N_STATS] = {0};
     for (int c = 0; c < n_chunks; ++c) {
         if (rc[c]) { if (c > 0) ctx->err = al[c].ctx->err; return -1; }
-        kms += al[c].kernel_ms; kc += al[c].kernel_cells; unsupported += al[c].unsupported;
+        kms += al[c].kernel_ms; kc += al[c].kernel_cells; unsupported += al[c].unsupported; overflowed += al[c].overflowed;
         for (int k = 0; k < SPDP_N_STATS; ++k) st_sum[k] += al[c].stats[k];
     }
     if (kernel_ms) *kernel_ms = kms;
@@ -637,6 +642,10 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
         ctx->err = "sub-problems with fewer than 8 query rows need the scalar exact engine: supply "
                    "SpdpScoring.intpen / t53 and SpdpProblem.cano5 / cano3 / dinc";
         return 1;                               // partial: those queries are returned without alignment
+    }
+    if (overflowed) {
+        ctx->err = "traceback record list of a scalar / -A1 engine call exceeds its slot; those queries come back without an alignment";
+        return 1;
     }
     return 0;
 }

@@ -244,18 +244,25 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
+                // One word decides: arrivals count in the low bits; a block that waited too long sets GIVEUP and leaves,
+                // and so does every block that sees the bit on arrival or while waiting (one that got through just
+                // before ends at the bounded wait for its producer); the host then repeats the launch with one CU
+                // per problem (DevRun::sync).
+                constexpr int GIVEUP = 1 << 30;
                 int* bar = s_prog + G * WPB;
-                __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int seen = __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
                 long spins = 0;
-                s_prog_lds[0] = 0;
-                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+                while (!(seen & GIVEUP) && (seen & (GIVEUP - 1)) < G) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1l << 22)) {         // a block of the group is not resident (the GPU is shared):
-                        s_prog_lds[0] = 1;              // give up -- the host re-runs the launch on one CU per problem
-                        __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1l << 22)) {         // a block of the group is not resident (the GPU is shared)
+                        seen = __hip_atomic_fetch_or(bar, GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | GIVEUP;
                         break;
                     }
+                    seen = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                const bool quit = (seen & GIVEUP) != 0;
+                if (quit) __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prog_lds[0] = quit ? 1 : 0;
             }
             __syncthreads();
             if (s_prog_lds[0]) return;
@@ -282,7 +289,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
     const int n_passes = (n_stripes + 3) >> 2;
     constexpr int BIGB = 1 << 20;                       // progress word = pass * BIGB + blocks done
     const int prod = (w + W - 1) % W;                   // wave running the pass before mine
-    for (int s0 = 0; s0 < n_stripes; s0 += 4) {
+    bool dead = false;                                  // CROSS: a producer never showed up
+    for (int s0 = 0; s0 < n_stripes && !dead; s0 += 4) {
         const int pass = s0 >> 2;
         const bool mine = (pass % W) == w;
         // ---- geometry of my stripe (row g of the wave)
@@ -365,14 +373,20 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                 long spins = 0;
                 while (__hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, PSCOPE) < need) {
                     __builtin_amdgcn_s_sleep(4);
-                    if constexpr (CROSS) { if (++spins > (1l << 26)) __builtin_trap(); }
+                    if constexpr (CROSS) {
+                        // a producer that never comes (it left at the barrier): mark the problem, the host re-runs it
+                        if (++spins > (1l << 24)) {
+                            __hip_atomic_store(s_prog + G * WPB + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dead = true; return;
+                        }
+                    }
                 }
                 if constexpr (CROSS) WAVE_ORDER();      // the entries are read with memory-side loads
                 else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             };
             wait_for(0);
             if (g == 0 && nb > 0) prefetch(0);
-            for (int blk = 0; blk < tot; ++blk) {
+            for (int blk = 0; blk < tot && !dead; ++blk) {
                 if (blk + 1 < nb0) wait_for(blk + 1);
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
                 if (lb == -1 && nb > 0) prefetch(0);                    // one block ahead of first use
@@ -573,6 +587,11 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
         }
     }
 
+    if (dead) {
+        // keep the waves behind me from waiting for the full time-out each
+        if (lane == 0) __hip_atomic_store(&s_prog[w], INT32_MAX, __ATOMIC_RELAXED, PSCOPE);
+        return;
+    }
     if (W > 1) {
         if ((n_passes - 1) % W != w) return;            // the wave of the last pass finishes the problem
         for (int x = 0; x < W; ++x) {
@@ -582,7 +601,12 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
             long spins = 0;
             while (__hip_atomic_load(&s_prog[x], __ATOMIC_RELAXED, PSCOPE) < (last_own + 1) * BIGB) {
                 __builtin_amdgcn_s_sleep(4);
-                if constexpr (CROSS) { if (++spins > (1l << 26)) __builtin_trap(); }
+                if constexpr (CROSS) {
+                    if (++spins > (1l << 24)) {
+                        __hip_atomic_store(s_prog + G * WPB + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                }
             }
         }
         if constexpr (CROSS) WAVE_ORDER();

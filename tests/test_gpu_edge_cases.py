@@ -142,3 +142,22 @@ def test_submit_wait_two_contexts(eng):
         e2.close()
     for g, w in zip(got, want):
         assert [(s, k.tolist()) for s, k in g] == [(s, k.tolist()) for s, k in w]
+
+
+def test_skl_slot_overflow_is_walked_again(monkeypatch):
+    """traceback record lists longer than their device slot (SPDP_SKL_CAP shrinks the slots to 6 records): the walk is
+    repeated for those problems with full-size slots and the batch comes back complete and unchanged"""
+    from spaln_amd import abi, defaults, engine, synth
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    for w, q, s5, s3, _ in synth.make_batch(12, seed=77, mrna_len=600, n_exons=5, flank=200, intron_hi=900, indel=0.02):
+        ps.add(q, w, s5, s3)
+    eng = engine.Engine(0)
+    want = [(s, skl.tolist()) for s, skl in eng.align_s(sc, ps)]
+    want_f = [(s, skl.tolist()) for s, skl in eng.wip_forward(sc, ps)]
+    assert max(len(skl) for _, skl in want_f) > 8
+    monkeypatch.setenv("SPDP_SKL_CAP", "6")
+    got = [(s, skl.tolist()) for s, skl in eng.align_s(sc, ps)]
+    got_f = [(s, skl.tolist()) for s, skl in eng.wip_forward(sc, ps)]
+    eng.close()
+    assert got == want and got_f == want_f

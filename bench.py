@@ -31,15 +31,20 @@ sys.path.insert(0, ROOT)
 # sweep streams one 8 B column record and reads + writes one 8 B {H,F} boundary entry
 BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64.0 + 1.0}
 HBM_PEAK_GBS = 8000.0
-# int32 VALU ceiling of one MI355X measured with tools/ubench/valu_rate.hip (profiles/r01_valu_ubench.txt):
-# 0.62 G wave-instructions/s per SIMD x 1024 SIMDs; VALU wave-instructions per DP cell from SQ_INSTS_VALU
-# (profiles/r01_sq_counters.txt): UDH sweep 59.6 / 64, forward sweep 69.6 / 64, protein sweep 151.5 / 64
-VALU_PEAK_WINST_S = 0.62e9 * 1024
-VALU_PER_CELL = {"udh": 1.9475e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3136e10 / 3.0943e10}
-# FETCH_SIZE + WRITE_SIZE of one spdp_sweep<FL_UDH> launch on the default workload (KiB -> bytes)
-PMC_TRAFFIC_BYTES = int((69879445 + 206684966) * 1024)
-# same for one spdh_sweep launch of the default c3 workload (profiles/r01_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((37931084 + 146762151) * 1024)
+# VALU issue ceiling of one MI355X, measured with tools/ubench (profiles/r02_valu_ubench.txt): a SIMD issues at most one
+# VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
+# fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
+# profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
+# same profiles: fp32-issue UDH sweep 51.2 / 64 (round 1: 59.6), forward sweep 69.6 / 64, protein sweep 151.5 / 64.
+VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
+VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3136e10 / 3.0943e10}
+# HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
+# chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes (profiles/r02_hbm_traffic_pmc.txt).  FETCH_SIZE
+# counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
+# the figure an upper bound for the 8-byte column-record reads.
+PMC_TRAFFIC_BYTES = int((2 * 49828262 + 178326372) * 1024 / 2)
+# same for one spdh_sweep launch of the default c3 workload (profiles/r02_h_hbm_traffic_pmc.txt)
+PMC_TRAFFIC_BYTES_H = int((2 * 37825292 + 146769521) * 1024)
 
 
 def _cpu_align_one(item):
@@ -232,7 +237,7 @@ def main_c3(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1) else None,
-                         "traffic_source": "profiles/r01_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
+                         "traffic_source": "profiles/r02_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
                          "valu": _valu_roofline(cells, "h", k_ms),
                          "note": "integer-VALU bound recurrence (int16 saturating lanes); HBM fraction reported as asked"},
@@ -252,9 +257,9 @@ def _valu_roofline(cells, kind, k_ms):
     ach = cells * VALU_PER_CELL[kind] / (k_ms * 1e-3)
     return {"achieved": round(ach / 1e9, 1), "peak": round(VALU_PEAK_WINST_S / 1e9, 1), "unit": "G wave-instr/s",
             "frac": round(ach / VALU_PEAK_WINST_S, 3),
-            "source": "SQ_INSTS_VALU per cell (profiles/r01_sq_counters.txt) x cells / kernel time; peak from "
-                      "tools/ubench/valu_rate.hip (profiles/r01_valu_ubench.txt); above 1 when the count includes "
-                      "instructions skipped under an empty EXEC mask"}
+            "source": "SQ_INSTS_VALU per cell (profiles/r02_sq_counters.txt) x cells / kernel time; peak = one VALU "
+                      "wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, profiles/r02_valu_ubench.txt); "
+                      "the instruction mix of the step, priced by class, explains 0.71 of the measured time"}
 
 
 def _self_spawn(argv, n):
@@ -452,10 +457,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4) else None,
-                         "traffic_source": "profiles/r01_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
-                         "kernel": "spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep<FL_UDH>", "kernel_ms": round(k_ms, 3),
+                         "traffic_source": "profiles/r02_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
+                         "kernel": "spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>", "kernel_ms": round(k_ms, 3),
                          "valu": _valu_roofline(k_cells, k_name, k_ms),
-                         "note": "integer-VALU bound recurrence; HBM fraction reported as asked"},
+                         "note": "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)

@@ -349,7 +349,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             imd_tot += (int64_t) P.n_im * 8 * it.w.width;
         } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + 4ll * it.w.width + (it.w.width + 3) / 4 + 8;
+            bnd_tot = P.bnd_off + 5ll * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal
             const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
             const int64_t cap = (flav == 3) ? 2 * cells + 64 : 0;
             P.imd_off = cap;
@@ -492,7 +492,7 @@ int DevRun::launch()
         if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, strm()));
         else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, strm()));
         else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, strm()));
-        else HIPCHK(spdp_launch_scalar(flavour == 3, &S, strm()));
+        else HIPCHK(spdp_launch_rowwave(flavour == 3, &S, strm()));
         HIPCHK(hipEventRecord(eve(), strm()));
         if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk
             CposArgs C;

@@ -1,0 +1,404 @@
+// spdp_rowwave.hip -- the exact-intron-length ("-A0") cDNA engines as wavefront kernels.
+//
+// What they compute (ogotoh/spaln v3.0.7; restated for the checker in oracle/spdp_oracle_scalar.c):
+//   MODE 0  Aln2s1::scorealoneS_ng + sinitS_ng / slastS_ng                 src/fwd2s1.cc:1163-1336, 1112-1161
+//   MODE 1  Aln2s1::forwardS_ng + initS_ng / lastS_ng, Vmf::traceback and the record fix-up of
+//           trcbkalignS_ng                                                 src/fwd2s1.cc:217-444, 142-215, 1690-1707
+// int32 scores, affine gaps, a sorted list of the best donor candidates per query row, acceptors priced with the
+// exact IntPen(length) + the junction table, "orphan exon" flags.  The reference walks the matrix row by row
+// with its state in arrays indexed by DIAGONAL (H, F, and in mode 1 a Vmf pointer per state and a direction
+// byte); results depend on what those arrays hold at the band edges, so the arrays are kept as they are.
+//
+// Mapping (ours).  One wave per problem.  Lane k of the wave owns query row m0 + k of a tile of 64 rows and
+// all per-row state (the horizontal gap, the orphan-exon flags, the candidate list) lives in its registers.  The
+// wave sweeps anti-diagonals: at step S lane k is at column S - m, i.e. on array entry r = S - 2m; it reads
+// entries r - 1 (its own left neighbour), r (the cell above-left) and r + 1 (the cell above) and writes r.  Every
+// entry a lane reads was written one or two steps earlier by the lane above it -- the order the reference's
+// row-by-row loop guarantees as well -- so the arrays can be shared through an LDS window of 256 diagonals that
+// slides with the sweep: 64 entries at a time stream in from / out to the arrays in global memory (coalesced),
+// which carry the state from one tile of rows to the next.  Vmf records are appended through a counter that is
+// uniform in the wave (ballot + prefix count: no atomics); record numbers differ from the reference's, the
+// chains do not.  Lane 0 walks the chain back at the end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spdp_dev.h"
+#include "spdp_internal.h"
+
+namespace {
+
+constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
+constexpr int RING = 256;                               // diagonals resident in LDS
+constexpr int CHUNK = 32;                               // steps between two refills of the window
+constexpr int NC = 5;                                   // NCAND + 1 slots of the candidate list
+
+// the three states a candidate can splice from / into: the cell's diagonal value, the horizontal and the vertical gap
+enum { K_H = 0, K_E = 1, K_F = 2 };
+__device__ __forceinline__ int psp_bit(int k) { return k == 0 ? 4 : (k == 1 ? 1 : 8); }    // src/aln.h:56
+
+struct Lds {
+    int hv[RING], fv[RING];
+    int hp[RING], fp[RING], dr[RING];                   // forward only
+    int mtx[32 * 32];
+};
+
+}   // namespace
+
+template <int MODE>
+__global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
+{
+    constexpr bool FWD = MODE == 1;
+    __shared__ Lds L;
+    const int lane = threadIdx.x;
+    const int pi = blockIdx.x;
+    if (pi >= A.n_probs) return;
+    const DevProblem P = A.probs[pi];
+    const DevScoring* sc = A.sc;
+    const int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
+    const int lw = P.lw, up = P.up, width = P.width;
+    const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
+    const bool Local = sc->local;
+    const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
+    const int gop = sc->gop, gep = sc->gep, spj = sc->spj, llmt = sc->llmt, ipen = A.ipen;
+    const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
+    const int2* __restrict__ cols = A.cols + P.col_off;            // {(sig5 + ipen) | sig3 << 16, base}
+    const uint8_t* __restrict__ aux = A.aux + 2 * P.col_off;        // {bit0 donor | bit1 acceptor, dinc5 << 4 | dinc3}
+    // the reference's arrays, by entry e = r - (lw - 1), 0 <= e < width
+    int* __restrict__ gHv = A.work + P.bnd_off;
+    int* __restrict__ gFv = gHv + width;
+    int* __restrict__ gHp = gFv + width;
+    int* __restrict__ gFp = gHp + width;
+    int* __restrict__ gDr = gFp + width;
+    int3* __restrict__ vrec = A.vmf + P.tb_off;
+    const int vcap = (int) P.imd_off;
+    int vcount = 2;                                     // wave-uniform; records 0 (dummy) and 1 (start) below
+    bool vover = false;
+    // appends one record for every lane that asks; returns its number (garbage for the others)
+    auto vadd = [&](bool need, int mm, int nn, int pp) -> int {
+        const unsigned long long mask = __ballot(need);
+        if (!mask) return 0;
+        const int my = vcount + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0));
+        vcount += __popcll(mask);
+        if (need) { if (my < vcap) vrec[my] = make_int3(mm, nn, pp); else vover = true; }
+        return my;
+    };
+
+    for (int i = lane; i < 32 * 32; i += 64) L.mtx[i] = sc->mtx[i];
+    // ---- the arrays as vset / initS_ng (sinitS_ng) leave them
+    {
+        const int r0 = bl - al;
+        const int r_hi = a_exgl ? min(up, br - al) : r0;            // free start columns of the first row
+        const int r_lo = max(lw, bl - ar);                          // first column, rows below the first
+        for (int e = lane; e < width; e += 64) {
+            const int r = e + lw - 1;
+            int hv = NEV, hp = 0, fv = NEV, dr = 0;
+            if (r == r0) { hv = 0; hp = 1; }
+            else if (r > r0 && r <= r_hi) { hv = 0; dr = 1; }
+            else if (r < r0 && r >= r_lo) {
+                dr = 2;
+                if (b_exgl) hv = 0;
+                else { hv = gop + (r0 - r) * gep; hp = 1; if (!FWD) fv = hv; }
+            }
+            gHv[e] = hv; gFv[e] = fv;
+            if (FWD) { gHp[e] = hp; gFp[e] = 0; gDr[e] = dr; }
+        }
+        if (FWD && lane == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(al, bl, 0); }
+    }
+    __syncthreads();
+
+    // running maximum of a local right end: first maximum in row-major order
+    int best_v = NEV, best_m = al, best_n = bl, best_p = 0;
+
+    const int R0 = al + (a_exgl ? 1 : 0);                          // first row the reference's loop visits
+    for (int m0 = R0; m0 <= ar; m0 += 64) {
+        // what the previous tile wrote back must be what this one reads
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const int m = m0 + lane;
+        const bool row = m <= ar;
+        const int n_first = max(m - 1 + lw, bl) + 1, n_last = min(m + up, br);
+        const bool any = row && n_first <= n_last;
+        // anti-diagonals this tile sweeps
+        int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? n_last + m : INT32_MIN;
+        for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
+        if (s_lo > s_hi) continue;
+        const int acode = (row && m >= 1) ? acod[m - 1] : 0;
+        const int* qprof = L.mtx + acode * 32;
+        const bool internal = FWD ? (spj && (!a_exgr || m < ar)) : true;
+
+        // per-row state
+        int e1v = NEV, e1p = 0;
+        unsigned psp = 0;
+        int cv[NC], cj[NC], cd[NC], cp[NC], cx[NC];                 // candidates: value, donor column, state, pointer, dinc5
+#pragma unroll
+        for (int l = 0; l < NC; ++l) { cv[l] = NEV; cj[l] = 0; cd[l] = 0; cp[l] = 0; cx[l] = 0; }
+        int ncand = -1;
+
+        // window of entries resident in LDS: [res_lo, res_hi)
+        auto need_lo = [&](int S) { return S - 2 * (m0 + 63) - 1 - (lw - 1); };
+        auto need_hi = [&](int S) { return S - 2 * m0 + 1 - (lw - 1); };
+        int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
+        auto refill = [&](int S) {
+            // entries no lane will touch again go back to memory, those of the next CHUNK steps come in
+            const int dead = min(max(0, need_lo(S)), width);
+            for (int e = res_lo + lane; e < dead; e += 64) {
+                const int q = e & (RING - 1);
+                gHv[e] = L.hv[q]; gFv[e] = L.fv[q];
+                if (FWD) { gHp[e] = L.hp[q]; gFp[e] = L.fp[q]; gDr[e] = L.dr[q]; }
+            }
+            res_lo = max(res_lo, dead);
+            const int want = min(width, need_hi(S + CHUNK - 1) + 1);
+            for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
+                const int q = e & (RING - 1);
+                L.hv[q] = __builtin_nontemporal_load(gHv + e); L.fv[q] = __builtin_nontemporal_load(gFv + e);
+                if (FWD) { L.hp[q] = __builtin_nontemporal_load(gHp + e); L.fp[q] = __builtin_nontemporal_load(gFp + e);
+                           L.dr[q] = __builtin_nontemporal_load(gDr + e); }
+            }
+            res_hi = max(res_hi, want);
+            __syncthreads();
+        };
+
+        for (int S = s_lo; S <= s_hi; ++S) {
+            if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
+            const int n = S - m;
+            const bool on = any && n >= n_first && n <= n_last;
+            if (__ballot(on) == 0) continue;
+            const int r = n - m;
+            const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
+            // the cell's inputs
+            int2 col = make_int2(0, 0); int ax = 0, adn = 0;
+            if (on) { col = cols[n]; ax = aux[2 * n]; adn = aux[2 * n + 1]; }
+            int hv = L.hv[q], hp = FWD ? L.hp[q] : 0, dir = FWD ? L.dr[q] : 0;     // entry r: the cell above-left
+            const int uhv = L.hv[qu], uhp = FWD ? L.hp[qu] : 0;                    // entry r + 1: H of the cell above
+            const int ufv = L.fv[qu], ufp = FWD ? L.fp[qu] : 0;                    //              F of the cell above
+            const int lhv = L.hv[ql], lhp = FWD ? L.hp[ql] : 0;                    // entry r - 1: my left neighbour
+            int fv = L.fv[q], fp = FWD ? L.fp[q] : 0;
+            const int diag = hv;
+            int mxk = K_H;                                          // which state holds the running maximum
+            if (m != al) {                                          // (the row of a global left end has no cell above)
+                hv += qprof[col.y];
+                if (FWD) dir = (dir % 3) ? 3 : 0;                   // a diagonal step that follows a non-diagonal one: NEWD
+                const int x = uhv + gop;
+                if (FWD ? (x >= ufv) : (x > ufv)) { fv = x; fp = uhp; } else { fv = ufv; fp = ufp; }
+                fv += gep;
+                if (fv > hv) mxk = K_F;
+            }
+            {
+                const int x = lhv + gop;
+                if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; e1p = lhp; psp = psp ? 1u : 0u; } else psp &= 1u;
+                e1v += gep;
+                const int cur = mxk == K_H ? hv : fv;
+                if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E;
+            }
+            // ---- acceptor: every candidate of my row may raise the state it left from
+            const bool acc = on && internal && (ax & 2);
+            if (__ballot(acc)) {
+                int sel_h = -1, sel_e = -1, sel_f = -1;
+                const int s3 = col.x >> 16, dn3 = adn & 15;
+#pragma unroll
+                for (int l = 0; l < NC; ++l) {
+                    const int len = n - cj[l];
+                    if (acc && l <= ncand && len >= llmt) {
+                        const int ip = len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
+                        const int x = cv[l] + ip + s3 + A.t53[16 * cx[l] + dn3];
+                        if (cd[l] == K_H) { if (FWD ? (x >= hv) : (x > hv)) { hv = x; sel_h = l; } }
+                        else if (cd[l] == K_E) { if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; sel_e = l; } }
+                        else { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
+                    }
+                }
+                auto pick = [&](int sel, int* arr) { int v = 0; _Pragma("unroll") for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l]; return v; };
+                // K_H, K_E, K_F in this order, as the reference's loop over its states
+                if (__ballot(sel_h >= 0)) {
+                    const bool t = sel_h >= 0;
+                    if (t) psp |= psp_bit(K_H);
+                    if (FWD) { const int p1 = vadd(t, m, pick(sel_h, cj), pick(sel_h, cp)); const int p2 = vadd(t, m, n, p1); if (t) hp = p2; }
+                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (hv >= cur) : (hv > cur)) mxk = K_H; }
+                }
+                if (__ballot(sel_e >= 0)) {
+                    const bool t = sel_e >= 0;
+                    if (t) psp |= psp_bit(K_E);
+                    if (FWD) { const int p1 = vadd(t, m, pick(sel_e, cj), pick(sel_e, cp)); const int p2 = vadd(t, m, n, p1); if (t) e1p = p2; }
+                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E; }
+                }
+                if (__ballot(sel_f >= 0)) {
+                    const bool t = sel_f >= 0;
+                    if (t) psp |= psp_bit(K_F);
+                    if (FWD) { const int p1 = vadd(t, m, pick(sel_f, cj), pick(sel_f, cp)); const int p2 = vadd(t, m, n, p1); if (t) fp = p2; }
+                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (fv >= cur) : (fv > cur)) mxk = K_F; }
+                }
+            }
+            // ---- the cell's value: the best state
+            const int hd = mxk;
+            const int mxv = mxk == K_H ? hv : (mxk == K_E ? e1v : fv);       // *mx
+            const int mxp = mxk == K_H ? hp : (mxk == K_E ? e1p : fp);
+            int hval_raw = hv;                                      // the diagonal state's own value (candidate source K_H)
+            int hptr_raw = hp;
+            if (FWD) {
+                bool newrec = false; int nr_p = 0;
+                if (hd != K_H) { hv = mxv; hp = mxp; dir = hd; }
+                else if (Local && hv > diag) {
+                    if (LocalL && diag == 0) { newrec = true; nr_p = 0; }
+                    else if (LocalR && on && hv > best_v) { best_v = hv; best_p = hp; best_m = m; best_n = n; }
+                }
+                const int p_local = vadd(on && newrec, m - 1, n - 1, nr_p);
+                if (on && newrec) hp = p_local;
+                if (LocalL && hv <= 0) { hv = 0; dir = 1; }
+                else {
+                    const bool t = on && dir == 3 && !(psp & psp_bit(K_H));
+                    const int pn = vadd(t, m - 1, n - 1, hp);
+                    if (t) hp = pn;
+                }
+                hval_raw = hv; hptr_raw = hp;                       // (the reference's donor loop reads *h after these updates)
+            } else {
+                const int y = hv;
+                if (hd != K_H) hv = mxv;
+                else if (LocalR && on && y > best_v) best_v = y;
+                if (LocalL && hv < 0) hv = 0;
+                hval_raw = hv;
+            }
+            // ---- donor: the states of this cell enter my row's candidate list
+            const bool don = on && internal && (ax & 1);
+            if (__ballot(don)) {
+                const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
+                const int dn5 = adn >> 4;
+                const int mx_now = hd == K_H ? hval_raw : (hd == K_E ? e1v : fv);     // *mx as it stands now
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int sv = k == K_H ? hval_raw : (k == K_E ? e1v : fv);
+                    const int sp = k == K_H ? hptr_raw : (k == K_E ? e1p : fp);
+                    bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
+                    if (t && k != hd) {
+                        int z = mx_now;
+                        if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;      // GOP[k / 2]
+                        if (sv <= z) t = false;                     // cannot become the better path
+                    }
+                    if (__ballot(t)) {
+                        const int x = sv + sigJ;
+                        // the free slot starts below the list and moves up past every entry x beats
+                        int pos = ncand < NC - 1 ? ncand + 1 : NC - 1;
+                        const bool grew = t && ncand < NC - 1;
+                        if (grew) ++ncand;
+#pragma unroll
+                        for (int l = NC - 1; l >= 1; --l) {
+                            const bool mv = t && pos == l && (FWD ? (x > cv[l - 1]) : (x >= cv[l - 1]));
+                            if (mv) { cv[l] = cv[l - 1]; cj[l] = cj[l - 1]; cd[l] = cd[l - 1]; cp[l] = cp[l - 1]; cx[l] = cx[l - 1]; pos = l - 1; }
+                        }
+                        if (t) {
+                            if (pos < NC - 1) {
+#pragma unroll
+                                for (int l = 0; l < NC - 1; ++l)
+                                    if (l == pos) { cv[l] = x; cj[l] = n; cd[l] = k; cp[l] = sp; cx[l] = dn5; }
+                            } else --ncand;
+                        }
+                    }
+                }
+            }
+            // ---- entry r takes the cell
+            if (on) {
+                L.hv[q] = hv; L.fv[q] = fv;
+                if (FWD) { L.hp[q] = hp; L.fp[q] = fp; L.dr[q] = dir; }
+            }
+        }
+        // everything still resident goes back
+        {
+            __syncthreads();
+            for (int e = res_lo + lane; e < res_hi; e += 64) {
+                const int q = e & (RING - 1);
+                gHv[e] = L.hv[q]; gFv[e] = L.fv[q];
+                if (FWD) { gHp[e] = L.hp[q]; gFp[e] = L.fp[q]; gDr[e] = L.dr[q]; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+
+    DevResult R;
+    R.score = NEV; R.mr = ar; R.nr = br; R.ml = al; R.ulk = 0; R.maxr = 0; R.pad[0] = R.pad[1] = 0;
+    auto GH = [&](int r) { return __builtin_nontemporal_load(gHv + (r - (lw - 1))); };
+    // first maximum of H over [lo, hi] walked upwards (dir = +1) or downwards (dir = -1), only where it beats `start`
+    auto scan_best = [&](int lo, int hi, int step, int start_r, int start_v) {
+        // candidates strictly greater than the running maximum take over in walk order: the result is the first position
+        // (in walk order) that holds the range's maximum, provided that maximum beats start_v
+        int bv = start_v, bk = INT32_MAX;                           // bk: position in walk order
+        const int cnt = hi - lo + 1;
+        for (int i = lane; i < cnt; i += 64) {
+            const int r = step > 0 ? lo + i : hi - i;
+            const int v = GH(r);
+            if (v > bv) { bv = v; bk = i; }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const int ov = __shfl_xor(bv, off), ok = __shfl_xor(bk, off);
+            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        if (bk == INT32_MAX) return start_r;
+        return step > 0 ? lo + bk : hi - bk;
+    };
+    if (!FWD) {
+        if (LocalR) {
+            for (int off = 32; off; off >>= 1) best_v = max(best_v, __shfl_xor(best_v, off));
+            R.score = best_v;
+        } else {                                                    // slastS_ng: the best end value
+            const int r9 = br - ar;
+            int mx = GH(r9);
+            if (b_exgr) { const int rw = min(up, br - al); if (rw > r9) mx = max(mx, GH(scan_best(r9 + 1, rw, -1, r9, mx))); }
+            if (a_exgr) { const int rw = max(lw, bl - ar); if (rw < r9) mx = max(mx, GH(scan_best(rw, r9 - 1, +1, r9, mx))); }
+            R.score = mx;
+        }
+        if (lane == 0) A.res[pi] = R;
+        return;
+    }
+    int ptr = 0;
+    if (LocalR) {
+        // first maximum in row-major order over all lanes
+        for (int off = 32; off; off >>= 1) {
+            const int ov = __shfl_xor(best_v, off), om = __shfl_xor(best_m, off), on_ = __shfl_xor(best_n, off), op = __shfl_xor(best_p, off);
+            if (ov > best_v || (ov == best_v && (om < best_m || (om == best_m && on_ < best_n)))) { best_v = ov; best_m = om; best_n = on_; best_p = op; }
+        }
+        ptr = vadd(lane == 0, best_m, best_n, best_p);
+        ptr = __shfl(ptr, 0);
+        R.score = best_v;
+    } else {                                                        // lastS_ng
+        const int r9 = br - ar;
+        int mx = r9;
+        if (a_exgr) { const int rw = max(lw, bl - ar); if (rw <= r9) mx = scan_best(rw, r9, +1, mx, GH(mx)); }
+        if (b_exgr) { const int rw = min(up, br - al); if (rw > r9) mx = scan_best(r9 + 1, rw, -1, mx, GH(mx)); }
+        const int i = mx - r9;
+        int m9 = ar, n9 = br;
+        if (i > 0) m9 -= i;
+        if (i < 0) n9 += i;
+        const int e = mx - (lw - 1);
+        ptr = vadd(lane == 0, m9, n9, __builtin_nontemporal_load(gHp + e));
+        ptr = __shfl(ptr, 0);
+        R.score = GH(mx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    const bool over_any = __any(vover);
+    // Vmf::traceback(ptr) + the boundary record of trcbkalignS_ng, by one lane
+    if (lane == 0) {
+        int2* out = A.skl + (int64_t) pi * A.skl_cap;
+        int cnt = 0, status = over_any ? -3 : 0;
+        if (ptr && !status) {
+            int3 sv = vrec[ptr];
+            int lm = 0, ln = 0;
+            for (;;) {
+                if (cnt < A.skl_cap) out[cnt] = make_int2(sv.x, sv.y); else status = -1;
+                lm = sv.x; ln = sv.y; ++cnt;
+                if (!sv.z) break;
+                sv = vrec[sv.z];
+            }
+            const int rd = Local ? 0 : ((ln - lm) - bl + al);
+            if (rd) {
+                const int2 rec = rd > 0 ? make_int2(al, bl + rd) : make_int2(al - rd, bl);
+                if (cnt < A.skl_cap) out[cnt] = rec; else status = -1;
+                ++cnt;
+            }
+        }
+        A.n_skl[pi] = status ? status : cnt;
+        A.res[pi] = R;
+    }
+}
+
+extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t stream)
+{
+    ScalarArgs A = *a;
+    if (forward) hipLaunchKernelGGL(spdp_rowwave<1>, dim3(A.n_probs), dim3(64), 0, stream, A);
+    else hipLaunchKernelGGL(spdp_rowwave<0>, dim3(A.n_probs), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}

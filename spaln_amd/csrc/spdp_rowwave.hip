@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
                 fv += gep;
                 if (fv > hv) mxk = K_F;
             }
-            {
+            if (on) {                                               // (row state: only cells of the row may touch it)
                 const int x = lhv + gop;
                 if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; e1p = lhp; psp = psp ? 1u : 0u; } else psp &= 1u;
                 e1v += gep;
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
                 }
                 const int p_local = vadd(on && newrec, m - 1, n - 1, nr_p);
                 if (on && newrec) hp = p_local;
-                if (LocalL && hv <= 0) { hv = 0; dir = 1; }
-                else {
-                    const bool t = on && dir == 3 && !(psp & psp_bit(K_H));
-                    const int pn = vadd(t, m - 1, n - 1, hp);
-                    if (t) hp = pn;
-                }
+                // (vadd keeps a counter every lane must advance: it is never called under a per-lane condition)
+                const bool reset = LocalL && hv <= 0;
+                if (reset) { hv = 0; dir = 1; }
+                const bool t = on && !reset && dir == 3 && !(psp & psp_bit(K_H));
+                const int pn = vadd(t, m - 1, n - 1, hp);
+                if (t) hp = pn;
                 hval_raw = hv; hptr_raw = hp;                       // (the reference's donor loop reads *h after these updates)
             } else {
                 const int y = hv;
@@ -374,13 +374,14 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
     if (lane == 0) {
         int2* out = A.skl + (int64_t) pi * A.skl_cap;
         int cnt = 0, status = over_any ? -3 : 0;
-        if (ptr && !status) {
+        if (ptr > 0 && ptr < vcount && !status) {
             int3 sv = vrec[ptr];
             int lm = 0, ln = 0;
             for (;;) {
                 if (cnt < A.skl_cap) out[cnt] = make_int2(sv.x, sv.y); else status = -1;
                 lm = sv.x; ln = sv.y; ++cnt;
                 if (!sv.z) break;
+                if (sv.z < 0 || sv.z >= vcount || cnt > vcount) { status = -2; break; }     // not a chain: never follow it
                 sv = vrec[sv.z];
             }
             const int rd = Local ? 0 : ((ln - lm) - bl + al);

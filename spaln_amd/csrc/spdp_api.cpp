@@ -491,7 +491,7 @@ int DevRun::launch()
         S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
         if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, strm()));
         else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, strm()));
-        else if (flavour == 5) HIPCHK(spdp_launch_scalar_udh(&S, strm()));
+        else if (flavour == 5) HIPCHK(spdp_launch_rowwave_udh(&S, strm()));
         else HIPCHK(spdp_launch_rowwave(flavour == 3, &S, strm()));
         HIPCHK(hipEventRecord(eve(), strm()));
         if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk

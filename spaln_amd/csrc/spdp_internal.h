@@ -92,7 +92,7 @@ struct ScalarArgs {
     int               cpos_stride;
 };
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t s);    // spdp_rowwave.hip: -A0 forward / score-only
-extern "C" hipError_t spdp_launch_scalar_udh(const ScalarArgs* a, hipStream_t s);
+extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t s);            // spdp_rowwave.hip: -A0 linear space
 extern "C" hipError_t spdp_launch_local_udh(const ScalarArgs* a, hipStream_t s);          // spdp_local_udh.hip: hirschbergS1_wip, -LS
 extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t s);   // spdp_exact.hip: 0 score, 1 forward, 2 udh
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,

@@ -396,6 +396,389 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MODE 2: Aln2s1::hirschbergS_ng + hinitS_ng / hlastS_ng with UdhIntermediate(lub = true)
+//         src/fwd2s1.cc:762-1104, 701-760; src/udh_intermediate.h:29-66
+// The -A0 linear-space engine: the recurrence above with every state carrying the range of diagonals it has
+// visited since the last intermediate row (upr, lwr), the row its path started on (ml) and a link (ulk) to where
+// it crossed the previous intermediate row.  Same mapping: lane = row, entries {val, upr, lwr, ml, ulk} of H and F
+// by diagonal in the sliding LDS window.  The lane that holds an intermediate row writes that row's link / bound
+// arrays (global memory) and keeps `rlst`, the one value the reference carries from one intermediate row to the
+// next: a tile is never taller than the distance between intermediates, so it holds at most one and `rlst` goes
+// from tile to tile by broadcast.  Lane 0 walks the links back into the cpos rows lspS_ng reads.
+namespace {
+constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
+struct LdsU {
+    int hv[RING], hu[RING], hl[RING], hm[RING], hk[RING];
+    int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
+    int mtx[32 * 32];
+};
+struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
+}   // namespace
+
+__global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
+{
+    __shared__ LdsU L;
+    const int lane = threadIdx.x;
+    const int pi = blockIdx.x;
+    if (pi >= A.n_probs) return;
+    const DevProblem P = A.probs[pi];
+    const DevScoring* sc = A.sc;
+    int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
+    const int lw = P.lw, up = P.up, width = P.width, n_im = P.n_im, intvl = P.imd_intvl;
+    const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
+    const bool Local = sc->local;
+    const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
+    const int gop = sc->gop, gep = sc->gep, llmt = sc->llmt, ipen = A.ipen;
+    const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
+    const int2* __restrict__ cols = A.cols + P.col_off;
+    const uint8_t* __restrict__ aux = A.aux + 2 * P.col_off;
+    int* const g0 = A.work + P.bnd_off;                             // ten arrays of `width` entries
+    auto G = [&](int arr) { return g0 + (int64_t) arr * width; };  // 0..4 H {v,u,l,m,k}, 5..9 F
+    // intermediate i: hlnk[2], vlnk[2], lwrb[2], uprb[2], `width` ints each, entry r - lw + 1
+    int* const imd_base = A.imd + P.imd_off;
+    const int64_t us = 2 * (int64_t) width;
+    enum { HLNK = 0, VLNK = 1, LWRB = 2, UPRB = 3 };
+    auto IM = [&](int i, int arr, int k, int r) -> int* { return imd_base + (int64_t) i * 4 * us + arr * us + (int64_t) k * width + (r - lw + 1); };
+    auto mi_of = [&](int i) { return P.a_left + (i + 1) * intvl; };
+    int* cpos = A.cpos + (int64_t) pi * A.cpos_stride;
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+
+    for (int i = lane; i < 32 * 32; i += 64) L.mtx[i] = sc->mtx[i];
+    for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
+    // ---- the arrays as hinitS_ng leaves them; the link / bound arrays of the intermediates
+    {
+        const int r0 = bl - al, rb = bl - ar;
+        const int r_hi = a_exgl ? min(up, br - al) : r0;
+        const int r_lo = max(lw, bl - ar);
+        for (int e = lane; e < width; e += 64) {
+            const int r = e + lw - 1;
+            St h = {NEV, rb, rb, 0, EOU};
+            if (r >= r0 && r <= r_hi) h = {0, r, r, al, r};
+            else if (r < r0 && r >= r_lo) {
+                if (b_exgl) h = {0, r, r, al + (r0 - r), r};
+                else h = {gop + (r0 - r) * gep, r0, r, al + (r0 - r), r0};
+            }
+            G(0)[e] = h.v; G(1)[e] = h.u; G(2)[e] = h.l; G(3)[e] = h.m; G(4)[e] = h.k;
+            G(5)[e] = NEV; G(6)[e] = rb; G(7)[e] = rb; G(8)[e] = 0; G(9)[e] = EOU;
+        }
+        for (int i = 0; i < n_im; ++i)
+            for (int64_t q = lane; q < us; q += 64) {
+                int* b = imd_base + (int64_t) i * 4 * us;
+                b[q] = EOU; b[us + q] = EOU; b[2 * us + q] = 0x7fffffff; b[3 * us + q] = (int) 0x80000000;
+            }
+    }
+    __syncthreads();
+
+    // local right end: first maximum in row-major order
+    St best = {NEV, 0, 0, al, 0}; int best_mr = ar, best_nr = br;
+    int rlst = 0x7fffffff;
+    const int R0 = al + (a_exgl ? 1 : 0);
+    const int TH = max(1, min(64, intvl));                          // tile height: at most one intermediate row per tile
+    for (int m0 = R0; m0 <= ar; m0 += TH) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const int m = m0 + lane;
+        const bool row = lane < TH && m <= ar;
+        const int n_first = max(m - 1 + lw, bl) + 1, n_last = min(m + up, br);
+        const bool any = row && n_first <= n_last;
+        int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? n_last + m : INT32_MIN;
+        for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
+        // is my row an intermediate row, and which
+        const int iq = (m - P.a_left) / max(1, intvl) - 1;
+        const bool is_imd = row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
+        const unsigned long long imd_mask = __ballot(is_imd);
+        if (s_lo <= s_hi) {
+            const int acode = (row && m >= 1) ? acod[m - 1] : 0;
+            const int* qprof = L.mtx + acode * 32;
+            St E = {NEV, bl - ar, bl - ar, 0, EOU};
+            unsigned psp = 0;
+            int cv[NC], cj[NC], cd[NC], cu[NC], cl[NC], cm[NC], ck[NC], cx[NC];
+#pragma unroll
+            for (int l = 0; l < NC; ++l) { cv[l] = NEV; cj[l] = 0; cd[l] = 0; cu[l] = (int) 0x80000000; cl[l] = 0x7fffffff; cm[l] = 0; ck[l] = EOU; cx[l] = 0; }
+            int ncand = -1;
+            auto need_lo = [&](int S) { return S - 2 * (m0 + 63) - 1 - (lw - 1); };
+            auto need_hi = [&](int S) { return S - 2 * m0 + 1 - (lw - 1); };
+            int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
+            int* const lds[10] = {L.hv, L.hu, L.hl, L.hm, L.hk, L.fv, L.fu, L.fl, L.fm, L.fk};
+            auto refill = [&](int S) {
+                const int dead = min(max(0, need_lo(S)), width);
+                for (int e = res_lo + lane; e < dead; e += 64) {
+                    const int q = e & (RING - 1);
+#pragma unroll
+                    for (int a = 0; a < 10; ++a) G(a)[e] = lds[a][q];
+                }
+                res_lo = max(res_lo, dead);
+                const int want = min(width, need_hi(S + CHUNK - 1) + 1);
+                for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
+                    const int q = e & (RING - 1);
+#pragma unroll
+                    for (int a = 0; a < 10; ++a) lds[a][q] = __builtin_nontemporal_load(G(a) + e);
+                }
+                res_hi = max(res_hi, want);
+                __syncthreads();
+            };
+            for (int S = s_lo; S <= s_hi; ++S) {
+                if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
+                const int n = S - m;
+                const bool on = any && n >= n_first && n <= n_last;
+                if (__ballot(on) == 0) continue;
+                const int r = n - m;
+                const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
+                int2 col = make_int2(0, 0); int ax = 0, adn = 0;
+                if (on) { col = cols[n]; ax = aux[2 * n]; adn = aux[2 * n + 1]; }
+                St H = {L.hv[q], L.hu[q], L.hl[q], L.hm[q], L.hk[q]};
+                St F = {L.fv[q], L.fu[q], L.fl[q], L.fm[q], L.fk[q]};
+                const St uH = {L.hv[qu], L.hu[qu], L.hl[qu], L.hm[qu], L.hk[qu]};
+                const St uF = {L.fv[qu], L.fu[qu], L.fl[qu], L.fm[qu], L.fk[qu]};
+                const St lH = {L.hv[ql], L.hu[ql], L.hl[ql], L.hm[ql], L.hk[ql]};
+                int mxk = K_H;
+                if (m != P.a_left) {
+                    H.v += qprof[col.y];
+                    const int x = uH.v + gop;
+                    if (x >= uF.v) { F = uH; F.v = x; } else F = uF;
+                    F.v += gep;
+                    if (F.v >= H.v) mxk = K_F;
+                }
+                if (on) {
+                    const int x = lH.v + gop;
+                    if (x >= E.v) { E = lH; E.v = x; psp = psp ? 1u : 0u; } else psp &= 3u;
+                    E.v += gep;
+                    const int cur = mxk == K_H ? H.v : F.v;
+                    if (E.v >= cur) mxk = K_E;
+                }
+                auto val_of = [&](int k) { return k == K_H ? H.v : (k == K_E ? E.v : F.v); };
+                // ---- acceptor
+                bool spj3 = false;
+                const bool acc = on && (ax & 2);
+                if (__ballot(acc)) {
+                    int sel_h = -1, sel_e = -1, sel_f = -1;
+                    const int s3 = col.x >> 16, dn3 = adn & 15;
+#pragma unroll
+                    for (int l = 0; l < NC; ++l) {
+                        const int len = n - cj[l];
+                        if (acc && l <= ncand && len >= llmt) {
+                            const int ip = len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
+                            const int x = cv[l] + ip + s3 + A.t53[16 * cx[l] + dn3];
+                            if (cd[l] == K_H) { if (x > H.v) { H.v = x; sel_h = l; } }
+                            else if (cd[l] == K_E) { if (x > E.v) { E.v = x; sel_e = l; } }
+                            else { if (x > F.v) { F.v = x; sel_f = l; } }
+                        }
+                    }
+                    auto pick = [&](int sel, const int* arr) { int v = 0; _Pragma("unroll") for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l]; return v; };
+                    int maxk = 3;
+                    if (sel_h >= 0) {
+                        psp |= psp_bit(K_H); spj3 = true;
+                        H.u = max(pick(sel_h, cu), r); H.l = min(pick(sel_h, cl), r); H.m = pick(sel_h, cm); H.k = pick(sel_h, ck);
+                        if (H.v > val_of(mxk)) { maxk = K_H; mxk = K_H; }
+                    }
+                    if (sel_e >= 0) {
+                        psp |= psp_bit(K_E);
+                        E.u = max(pick(sel_e, cu), r); E.l = min(pick(sel_e, cl), r); E.m = pick(sel_e, cm); E.k = pick(sel_e, ck);
+                        if (E.v > val_of(mxk)) { maxk = K_E; mxk = K_E; }
+                    }
+                    if (sel_f >= 0) {
+                        psp |= psp_bit(K_F);
+                        F.u = max(pick(sel_f, cu), r); F.l = min(pick(sel_f, cl), r); F.m = pick(sel_f, cm); F.k = pick(sel_f, ck);
+                        if (F.v > val_of(mxk)) { maxk = K_F; mxk = K_F; }
+                    }
+                    if (is_imd && acc && maxk < 3) {
+                        const int sel = maxk == K_H ? sel_h : (maxk == K_E ? sel_e : sel_f);
+                        *IM(iq, HLNK, 0, r) = pick(sel, ck);
+                        rlst = r;
+                        if (maxk == K_H) H.k = r; else if (maxk == K_E) E.k = r; else F.k = r;
+                        if (maxk == K_H) {
+                            if (sel_e >= 0 && E.v > H.v + gop) { E.k = r + width; *IM(iq, HLNK, 1, r) = pick(sel_e, ck); }
+                            if (sel_f >= 0 && F.v > H.v + gop) F.k = r + width;
+                        }
+                    }
+                }
+                // ---- the cell takes the best state
+                const int hd = mxk;
+                const St MX = mxk == K_H ? H : (mxk == K_E ? E : F);         // *mx
+                if (hd == K_H) {
+                    if (LocalR && on && H.v > best.v) { best = H; best_mr = m; best_nr = n; }
+                } else {
+                    H = MX;
+                    if (H.u < r) H.u = r;
+                    if (H.l > r) H.l = r;
+                }
+                if (LocalL && H.v <= 0) { H.v = 0; H.m = m; H.k = H.u = H.l = r; }
+                // ---- donor
+                const bool don = on && (ax & 1);
+                if (__ballot(don)) {
+                    const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
+                    const int dn5 = adn >> 4;
+                    const int mx_now = hd == K_H ? H.v : MX.v;      // *mx: E / F keep their own value when they won
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const St src = k == K_H ? H : (k == K_E ? E : F);
+                        bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
+                        if (t && k != hd) {
+                            int z = mx_now;
+                            if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;
+                            if (src.v <= z) t = false;
+                        }
+                        if (__ballot(t)) {
+                            const int x = src.v + sigJ;
+                            int pos = ncand < NC - 1 ? ncand + 1 : NC - 1;
+                            if (t && ncand < NC - 1) ++ncand;
+#pragma unroll
+                            for (int l = NC - 1; l >= 1; --l) {
+                                const bool mv = t && pos == l && x > cv[l - 1];
+                                if (mv) { cv[l] = cv[l - 1]; cj[l] = cj[l - 1]; cd[l] = cd[l - 1]; cu[l] = cu[l - 1]; cl[l] = cl[l - 1];
+                                          cm[l] = cm[l - 1]; ck[l] = ck[l - 1]; cx[l] = cx[l - 1]; pos = l - 1; }
+                            }
+                            if (t) {
+                                if (pos < NC - 1) {
+#pragma unroll
+                                    for (int l = 0; l < NC - 1; ++l)
+                                        if (l == pos) { cv[l] = x; cj[l] = n; cd[l] = k; cu[l] = src.u; cl[l] = src.l; cm[l] = src.m;
+                                                        ck[l] = is_imd ? r : src.k; cx[l] = dn5; }
+                                    if (is_imd && k == K_E) *IM(iq, HLNK, 0, r) = rlst;
+                                } else --ncand;
+                            }
+                        }
+                    }
+                }
+                // ---- an intermediate row records where the paths cross it and restarts ranges and links
+                if (is_imd && on) {
+                    if (hd == K_H) rlst = r;
+                    else if (!spj3 && (hd % 2)) *IM(iq, HLNK, 0, r) = rlst;
+                    *IM(iq, VLNK, 0, r) = H.k; *IM(iq, LWRB, 0, r) = min(r, H.l); *IM(iq, UPRB, 0, r) = max(r, H.u);
+                    H.l = H.u = r; H.k = r;
+                    *IM(iq, VLNK, 1, r) = F.k; *IM(iq, LWRB, 1, r) = min(r, F.l); *IM(iq, UPRB, 1, r) = max(r, F.u);
+                    F.l = F.u = r; F.k = r + width;
+                }
+                if (on) {
+                    L.hv[q] = H.v; L.hu[q] = H.u; L.hl[q] = H.l; L.hm[q] = H.m; L.hk[q] = H.k;
+                    L.fv[q] = F.v; L.fu[q] = F.u; L.fl[q] = F.l; L.fm[q] = F.m; L.fk[q] = F.k;
+                }
+            }
+            __syncthreads();
+            for (int e = res_lo + lane; e < res_hi; e += 64) {
+                const int q = e & (RING - 1);
+#pragma unroll
+                for (int a = 0; a < 10; ++a) G(a)[e] = lds[a][q];
+            }
+        }
+        // `rlst` of this tile's intermediate row is what the next one starts from
+        if (imd_mask) rlst = __shfl(rlst, __ffsll((long long) imd_mask) - 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+
+    // ---- the end cell (hlastS_ng) or the tracked local maximum
+    auto GL = [&](int arr, int r) { return __builtin_nontemporal_load(G(arr) + (r - (lw - 1))); };
+    auto scan_best = [&](int lo, int hi, int step, int start_r, int start_v) {
+        int bv = start_v, bk = INT32_MAX;
+        const int cnt = hi - lo + 1;
+        for (int i = lane; i < cnt; i += 64) {
+            const int r = step > 0 ? lo + i : hi - i;
+            const int v = GL(0, r);
+            if (v > bv) { bv = v; bk = i; }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const int ov = __shfl_xor(bv, off), ok = __shfl_xor(bk, off);
+            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        if (bk == INT32_MAX) return start_r;
+        return step > 0 ? lo + bk : hi - bk;
+    };
+    St mxs = best;
+    int flag = 0;
+    const int rr = br - ar;
+    if (LocalR) {
+        for (int off = 32; off; off >>= 1) {
+            St o; o.v = __shfl_xor(best.v, off); o.u = __shfl_xor(best.u, off); o.l = __shfl_xor(best.l, off);
+            o.m = __shfl_xor(best.m, off); o.k = __shfl_xor(best.k, off);
+            const int om = __shfl_xor(best_mr, off), on_ = __shfl_xor(best_nr, off);
+            if (o.v > best.v || (o.v == best.v && (om < best_mr || (om == best_mr && on_ < best_nr)))) { best = o; best_mr = om; best_nr = on_; }
+        }
+        mxs = best;
+    } else {
+        const int r9 = br - ar;
+        int mxr = r9;
+        if (b_exgr) { const int rw = min(up, br - al); if (rw > r9) mxr = scan_best(r9 + 1, rw, -1, mxr, GL(0, mxr)); }
+        if (a_exgr) { const int rw = max(lw, bl - ar); if (rw < r9) mxr = scan_best(rw, r9 - 1, +1, mxr, GL(0, mxr)); }
+        mxs = {GL(0, mxr), GL(1, mxr), GL(2, mxr), GL(3, mxr), GL(4, mxr)};
+        if (b_exgr && rr < mxr) ar = br - mxr;
+        if (a_exgr && rr > mxr) br = ar + mxr;
+    }
+    if (lane != 0) return;
+    int score = mxs.v;
+    if (LocalR) {
+        int i = n_im;
+        while (--i >= 0 && mi_of(i) > ar) ;
+        ar = best_mr; br = best_nr;
+        if (i < 0) i = 0;
+        CPOS(i, 8) = mxs.l;
+        CPOS(i, 9) = mxs.u;
+    }
+    // ---- walk the links back: one cpos row per intermediate the path crosses
+    int i = n_im;
+    while (--i >= 0 && mi_of(i) > ar) ;
+    if (i < 0 && mi_of(0) > ar) CPOS(0, 2) = br;
+    int r = br - ar;
+    CPOS(i + 1, 8) = min(mxs.l, r);
+    CPOS(i + 1, 9) = max(mxs.u, r);
+    r = mxs.k;
+    for ( ; i >= 0 && mi_of(i) > mxs.m; --i) {
+        int c = 0, d = 0;
+        for ( ; r > up; r -= width) ++d;
+        if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
+        const int mi = mi_of(i);
+        if (*IM(i, VLNK, d, r) < EOU) {
+            CPOS(i, c++) = mi;
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            for (int rp = *IM(i, HLNK, d, r); lw <= rp && rp < up && r != rp; rp = *IM(i, HLNK, 0, r = rp)) {
+                if (c >= 6) { flag = -3; break; }                   // the terminator would land on [8]
+                CPOS(i, c++) = r + mi;
+            }
+            if (flag) break;
+            CPOS(i, c++) = r + mi;
+            CPOS(i, c) = EOU;
+            CPOS(i, 8) = *IM(i, LWRB, d, r);
+            CPOS(i, 9) = *IM(i, UPRB, d, r);
+            r = *IM(i, VLNK, d, r);
+            if (r == EOU) break;
+        } else
+            CPOS(i, 0) = EOU;
+    }
+    if (!flag) {
+        for ( ; r > up; r -= width) ;
+        if (LocalL) { al = mxs.m; bl = r + mxs.m; }
+        else {
+            const int rl = bl - al;
+            if (b_exgl && rl > r) {
+                al = bl - r;
+                for (int j = 0; j < n_im && mi_of(j) < al; ++j) CPOS(j, 0) = EOU;
+            }
+            if (a_exgl && rl < r) bl = al + r;
+        }
+        ++i;
+        if (i >= n_im) flag = -3;                                   // the reference dereferences udhimds[n_im]
+        else if (mi_of(i) < al || CPOS(i, 2) < bl) score = NEV;
+        else if (CPOS(i, 8) == EOU || CPOS(i, 9) == EOU) flag = -3; // bounds the reference never set
+        else {
+            const int rl = bl - al;
+            CPOS(i, 8) = min(rl, CPOS(i, 8));
+            CPOS(i, 9) = max(rl, CPOS(i, 9));
+        }
+    }
+#undef CPOS
+    A.scores[pi] = score;
+    A.ranges[4 * pi] = al; A.ranges[4 * pi + 1] = ar; A.ranges[4 * pi + 2] = bl; A.ranges[4 * pi + 3] = br;
+    DevResult R;
+    R.score = score; R.mr = ar; R.nr = br; R.ml = al; R.ulk = 0; R.maxr = 0; R.pad[0] = flag; R.pad[1] = 0;
+    A.res[pi] = R;
+}
+
+extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t stream)
+{
+    ScalarArgs A = *a;
+    hipLaunchKernelGGL(spdp_rowwave_udh, dim3(A.n_probs), dim3(64), 0, stream, A);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;

@@ -65,7 +65,7 @@ extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int 
                                            const SweepArgs* args, int grid, int wpb, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
-// scalar exact engines (spdp_scalar.hip): one thread per problem
+// exact-intron-length (-A0) engines (spdp_rowwave.hip: one wave per problem, lane = row) and the -A1 engines
 struct ScalarArgs {
     const DevScoring* sc;
     const DevProblem* probs;      // bnd_off = work offset (ints), tb_off = Vmf offset (records), imd_off = Vmf capacity

@@ -43,6 +43,15 @@ SH = 100                        # alprm.sh band shoulder
 MAX_VMF_SPACE = 32 * 1024 * 1024
 
 
+def exact_tables():
+    """IntPen(length) of the default intron-length distribution, materialised up to 29 450 nt (longer introns
+    price like the last entry), and the junction table behind Exinon::sig53(.., IE53): both read back from a
+    reference run (the c5_6kb fixture).  What SpdpScoring.intpen / t53 carry for the -A0 / -A1 engines."""
+    import os
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "exact_tables.npz"))
+    return t["intpen"], t["t53"]
+
+
 def scoring(nquant=None, **over) -> abi.Scoring:
     kw = dict(mtx=NMTX, mtx_dim=NSIMD, gop=GOP, gep=GEP, lgop=LGOP, lgep=LGEP, noll=2, spj=1,
               llmt=LLMT, ipen=IPEN, qm_len=QM_LEN, qm_pen=QM_PEN, nquant=nquant, local=0, sh=SH,

@@ -325,3 +325,29 @@ def make_protein_batch(n: int, seed: int = SEED, aa_len: int = 400, n_exons: int
         g = make_protein_gene(rng, n_exons=n_exons, aa_len=aa_len, flank=flank, sub=sub, intron_hi=intron_hi)
         out.append((g, protein_signals(g.window, rng)))
     return out
+
+
+# ---- exact-model inputs (what the -A0 / -A1 engines read besides the signals) ----------------------------
+def exact_inputs(window_codes: np.ndarray) -> dict:
+    """cano5 / cano3 / dinc of a genomic window as Exinon::intron53_c assigns them with the default
+    `algmode.any = 0` (src/codepot.cc:435-476: donor after AT / GC / GT, acceptor after AC / AG; dinucleotide class
+    = the two reduced codes, 'N' counted as C) -- checked against the reference's own arrays in the fixtures
+    (tests/test_synth_exact.py).  Returned arrays have len(window) + 1 entries, indexed by position n."""
+    b = np.asarray(window_codes, dtype=np.uint8)
+    n = b.size
+    red = np.full(256, 1, dtype=np.int64)
+    for code, c in ((2, 0), (3, 1), (5, 2), (9, 3)):
+        red[code] = c
+    c = red[b]
+    prev = np.concatenate([[1], c[:-1]])                     # the reference starts from the reduced code of 'C'
+    nc = ((prev << 2) + c) & 0xf                             # class of the dinucleotide ending at base i
+    d5 = np.zeros(n + 2, dtype=np.uint8); d3 = np.zeros(n + 2, dtype=np.uint8)
+    d5[:n - 1] = nc[1:]                                      # dinc5[i - 1] = class at base i
+    d3[1:n + 1] = nc                                         # dinc3[i + 1] = class at base i
+    k5 = np.where(nc == 3, 2, np.where((nc == 9) | (nc == 11), 3, 0)).astype(np.uint8)     # AT, GC, GT
+    k3 = np.where(nc == 1, 2, np.where(nc == 2, 3, 0)).astype(np.uint8)                    # AC, AG
+    c5 = np.zeros(n + 2, dtype=np.uint8); c3 = np.zeros(n + 2, dtype=np.uint8)
+    c5[:n - 1] = k5[1:]
+    c3[1:n + 1] = k3
+    return dict(cano5=(c5[:n + 1] > 0).astype(np.uint8), cano3=(c3[:n + 1] > 0).astype(np.uint8),
+                dinc=((d5[:n + 1] << 4) | d3[:n + 1]).astype(np.uint8))

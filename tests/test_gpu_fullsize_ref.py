@@ -39,3 +39,27 @@ def test_wip_ladder_vs_reference_A0_records():
             n_same += 1
     eng.close()
     assert n_same >= 1
+
+
+def test_A0_ladder_equals_reference_at_full_size():
+    """-A0 (scalar_engines = 1: scorealoneS_ng, hirschbergS_ng rounds, forwardS_ng slabs -- spdp_rowwave.hip) against the
+    reference's own -A0 records at 2 kb and 6 kb: HomScoreS_ng, gsi->scr, the SKL, skl_rngS_ng's score and exon table"""
+    import time
+    from spaln_amd import engine
+    eng = engine.Engine(0)
+    for path in BIG:
+        fx = spdg.load(path)
+        sc = spdg.scoring(fx, scalar_engines=1)
+        ps, p = spdg.problem(fx)
+        assert int(eng.homscore_s(sc, ps)[0]) == int(fx["hom_scr_A0"][0]), path
+        t0 = time.perf_counter()
+        (scr, skl), = eng.align_s(sc, ps)
+        dt = time.perf_counter() - t0
+        skl = skl.ravel().tolist()
+        assert scr == int(fx["aln_scr_A0"][0]), path
+        assert skl == fx["aln_skl_A0"].tolist(), path
+        fs = fx["rng_fstat_A0"]
+        (h, fst, recs), = eng.skl_rng_s(sc, ps, [skl], codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"], jneibr=int(fs[6]), lsg=int(fs[7]))
+        assert h == int(fx["rng_scr_A0"][0]) and recs.tolist() == fx["rng_eij_A0"].reshape(-1, 21).tolist(), path
+        assert dt < 60, (path, dt)                    # one wave per problem: a 2 kb query well under a second
+    eng.close()

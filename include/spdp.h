@@ -70,7 +70,26 @@ typedef struct SpdpScoring {
     int32_t minl;                    /* IntronPrm.minl: shortest intron of the -A1 engines (0 = llmt) */
     int32_t recursive;               /* algmode.alg & 4 (-A4 .. -A7): lspS_ng always takes the recursive
                                         linear-space branch (one intermediate row, halves of halves)   */
+    const struct SpdpSignalModel* sigmodel;   /* optional: with it, problems whose sig5 / sig3 are NULL get their
+                                        signals (and cano5 / cano3 / dinc) computed on the device from b[] alone */
 } SpdpScoring;
+
+/* the splice-site model behind SGPT2::sig5 / sig3 (Exinon::intron53_n, src/codepot.cc:479-520): the two
+ * second-order Markov position weight matrices (PatMat, src/utilseq.h:64-88, as read from the species'
+ * parameter tables), the per-dinucleotide terms sig53tab[0 / 1][class] and the scale fs = fS * alprm2.sss. */
+typedef struct SpdpSignalModel {
+    int32_t rows;                    /* PatMat::rows = 84 (4 + 16 + 64 terms per column), order 2, 4 letters */
+    int32_t cols5, off5;             /* pattern5: PatMat::cols, PatMat::offset                               */
+    int32_t cols3, off3;             /* pattern3                                                             */
+    float   fs;
+    float   tonic5, min5;            /* PatMat::tonic, PatMat::min_elem                                      */
+    float   tonic3, min3;
+    const float* mtx5;               /* PatMat::mtx, cols5 * rows floats                                     */
+    const float* mtx3;
+    int16_t tab5[16], tab3[16];      /* sig53tab[0][dinc5], sig53tab[1][dinc3]                               */
+    int32_t any;                     /* algmode.any (canonical-site levels, codepot.cc:438-475)              */
+    int32_t both_ori;                /* Exinon::both_ori (ori == 3 callers)                                  */
+} SpdpSignalModel;
 
 typedef struct SpdpProblem {
     const uint8_t* a;  int32_t a_len;      /* query codes, a[0 .. a_len)                 */
@@ -115,6 +134,14 @@ int64_t spdp_cells(const SpdpProblem* p, const SpdpWindow* wdw);
 /* ---- engine level (SimdAln2s1 methods), batched ----------------------- */
 /* scoreonlyS1_wip over each problem with its own stripe() band.  scores[i]
  * receives what the reference method returns. */
+/* Exinon::intron53_c + intron53_n for one genomic window on the device: arrays of b_len + 1 entries indexed by
+ * position, computed for the range [left, right) and zero outside it like the reference's (any output may be NULL).
+ * The two cells the reference itself leaves to stale memory (sig5 / cano5 of right - 1, sig3 / cano3 of left) are
+ * computed from class 0 here. */
+int spdp_splice_signals(SpdpContext* ctx, const SpdpSignalModel* model, const uint8_t* b, int32_t b_len,
+                        int32_t left, int32_t right, int16_t* sig5, int16_t* sig3,
+                        uint8_t* cano5, uint8_t* cano3, uint8_t* dinc);
+
 int spdp_wip_scoreonly(SpdpContext* ctx, const SpdpScoring* sc,
                        const SpdpProblem* probs, int n_probs, int32_t* scores);
 

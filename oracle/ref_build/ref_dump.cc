@@ -28,6 +28,7 @@
 
 #include "ref_dump_common.h"
 #include <algorithm>
+#include <climits>
 #include "fwd2s1_simd.h"
 
 
@@ -197,6 +198,59 @@ const	char*	outfn = argv[ai + 2];
 	    seqs[2]->exin = new Exinon(seqs[2], pwd, true);
 	}
 	dump_strand("");
+	{
+	    // the splice-signal model behind sig5 / sig3 (Exinon::intron53_n, codepot.cc:479-520): the two position weight
+	    // matrices (PatMat, utilseq.h:64-88) as loaded from the parameter tables, the per-dinucleotide terms and the
+	    // scale, so that the signal arrays above can be recomputed from b_codes
+	    auto dump_pm = [&](const char* tag, const PatMat* pm) {
+		char nmb[40];
+		if (!pm) return;
+		std::vector<int> hd = {pm->rows, pm->cols, pm->offset, pm->order(), pm->nalpha};
+		snprintf(nmb, sizeof nmb, "%s_hdr", tag); w.put_i32(nmb, hd);
+		std::vector<int> fl(2 + pm->rows * pm->cols);
+		memcpy(&fl[0], &pm->tonic, 4); memcpy(&fl[1], &pm->min_elem, 4);
+		memcpy(&fl[2], pm->mtx, sizeof(float) * pm->rows * pm->cols);
+		snprintf(nmb, sizeof nmb, "%s_f32", tag); w.put_i32(nmb, fl);	// float bit patterns: tonic, min_elem, mtx
+	    };
+	    dump_pm("pm5", pwd->eijpat->pattern5);
+	    dump_pm("pm3", pwd->eijpat->pattern3);
+	    const float fs = (float) b->exin->fS * alprm2.sss;		// intron53_n: fs = fS * alprm2.sss (codepot.cc:496)
+	    std::vector<int> sm(4);
+	    memcpy(&sm[0], &fs, 4);
+	    sm[1] = (int) algmode.any; sm[2] = (int) b->many;
+	    sm[3] = ori3 ? 1 : 0;					// the both_ori argument Exinon was built with above
+	    // the per-dinucleotide terms sig53tab[0 / 1][class] (private to Exinon): what is left of a signal after the
+	    // scaled matrix score, which the reference's own PatMat::calcPatMat reproduces (same call, same range as
+	    // intron53_n: codepot.cc:481-486)
+	    std::vector<int> tab(32, INT_MIN);
+	    if (pwd->eijpat->pattern5 && pwd->eijpat->pattern3) {
+		--b->left; ++b->right;
+		float* p5 = pwd->eijpat->pattern5->calcPatMat(b);
+		float* p3 = pwd->eijpat->pattern3->calcPatMat(b);
+		++b->left; --b->right;
+		std::vector<unsigned char> e5(b->len + 3, 0), e3(b->len + 3, 0);
+		int	nc2 = 1;
+		for (int i = b->left; i < b->right; ++i) {
+		    int c = ncredctab[*b->at(i)];
+		    if (c >= 4) c = 1;
+		    nc2 = ((nc2 << 2) + c) & 0xf;
+		    if (i - 1 >= 0) e5[i - 1] = nc2;
+		    e3[i + 1] = nc2;
+		}
+		int	clash = 0;
+		for (int n = b->left + 2; n < b->right - 1; ++n) {
+		    const SGPT2* sg = b->exin->score_n(n);
+		    const int t5 = sg->sig5 - (STYPE) (fs * p5[n - b->left + 1]);
+		    const int t3 = sg->sig3 - (STYPE) (fs * p3[n - b->left + 1]);
+		    if (tab[e5[n]] == INT_MIN) tab[e5[n]] = t5; else if (tab[e5[n]] != t5) ++clash;
+		    if (tab[16 + e3[n]] == INT_MIN) tab[16 + e3[n]] = t3; else if (tab[16 + e3[n]] != t3) ++clash;
+		}
+		if (clash) fprintf(stderr, "ref_dump: %d signal-table clashes\n", clash);
+		delete[] p5; delete[] p3;
+	    }
+	    w.put_i32("sig53tab01", tab);
+	    w.put_i32("sigmodel", sm);
+	}
 	if (ori3) {
 	    a->comrev();
 	    antiseq(seqs + 1);

@@ -39,7 +39,50 @@ class Scoring(C.Structure):
         ("scalar_engines", C.c_int32),
         ("minl", C.c_int32),
         ("recursive", C.c_int32),
+        ("sigmodel", C.c_void_p),
     ]
+
+
+class SignalModel(C.Structure):          # SpdpSignalModel
+    _fields_ = [
+        ("rows", C.c_int32),
+        ("cols5", C.c_int32), ("off5", C.c_int32),
+        ("cols3", C.c_int32), ("off3", C.c_int32),
+        ("fs", C.c_float),
+        ("tonic5", C.c_float), ("min5", C.c_float),
+        ("tonic3", C.c_float), ("min3", C.c_float),
+        ("mtx5", C.c_void_p), ("mtx3", C.c_void_p),
+        ("tab5", C.c_int16 * 16), ("tab3", C.c_int16 * 16),
+        ("any", C.c_int32), ("both_ori", C.c_int32),
+    ]
+
+
+def make_signal_model(*, rows, cols5, off5, mtx5, tonic5, min5, cols3, off3, mtx3, tonic3, min3, fs, tab5, tab3,
+                      any=0, both_ori=0) -> SignalModel:
+    m = SignalModel()
+    m.rows, m.cols5, m.off5, m.cols3, m.off3 = int(rows), int(cols5), int(off5), int(cols3), int(off3)
+    m.fs, m.tonic5, m.min5, m.tonic3, m.min3 = float(fs), float(tonic5), float(min5), float(tonic3), float(min3)
+    m5 = np.ascontiguousarray(mtx5, dtype=np.float32).ravel()
+    m3 = np.ascontiguousarray(mtx3, dtype=np.float32).ravel()
+    assert m5.size == rows * cols5 and m3.size == rows * cols3
+    m._keep = (m5, m3)
+    m.mtx5, m.mtx3 = m5.ctypes.data, m3.ctypes.data
+    for i in range(16):
+        m.tab5[i] = int(tab5[i]); m.tab3[i] = int(tab3[i])
+    m.any, m.both_ori = int(any), int(both_ori)
+    return m
+
+
+def signal_model_from_fixture(fx: dict) -> SignalModel:
+    """the model a reference dump carries (tests/golden/*.spdg: pm5_* / pm3_* / sig53tab01 / sigmodel)"""
+    h5, h3 = fx["pm5_hdr"], fx["pm3_hdr"]
+    f5 = np.asarray(fx["pm5_f32"], dtype=np.int32).view(np.float32)
+    f3 = np.asarray(fx["pm3_f32"], dtype=np.int32).view(np.float32)
+    sm = np.asarray(fx["sigmodel"], dtype=np.int32)
+    return make_signal_model(rows=h5[0], cols5=h5[1], off5=h5[2], mtx5=f5[2:], tonic5=f5[0], min5=f5[1],
+                             cols3=h3[1], off3=h3[2], mtx3=f3[2:], tonic3=f3[0], min3=f3[1],
+                             fs=sm[:1].view(np.float32)[0], tab5=fx["sig53tab01"][:16], tab3=fx["sig53tab01"][16:],
+                             any=sm[1], both_ori=sm[3] if sm.size > 3 else 0)
 
 
 class Problem(C.Structure):
@@ -86,7 +129,7 @@ class Rescored(C.Structure):
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,
-                 intpen=None, t53=None, scalar_engines=0, minl=0, recursive=0) -> Scoring:
+                 intpen=None, t53=None, scalar_engines=0, minl=0, recursive=0, sigmodel=None) -> Scoring:
     sc = Scoring()
     sc.mtx_dim = int(mtx_dim)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -106,6 +149,9 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
     sc.scalar_engines = int(scalar_engines)
     sc.minl = int(minl)
     sc.recursive = int(recursive)
+    if sigmodel is not None:
+        sc._keep_sigmodel = sigmodel
+        sc.sigmodel = C.addressof(sigmodel)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip                      # keep the buffer alive with the struct
@@ -127,14 +173,16 @@ class ProblemSet:
             exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)
-        sig5 = np.ascontiguousarray(sig5, dtype=np.int16)
-        sig3 = np.ascontiguousarray(sig3, dtype=np.int16)
-        assert sig5.size >= b.size + 1 and sig3.size >= b.size + 1
-        self._keep += [a, b, sig5, sig3]
         p = Problem()
         p.a, p.a_len = a.ctypes.data, a.size
         p.b, p.b_len = b.ctypes.data, b.size
-        p.sig5, p.sig3 = sig5.ctypes.data, sig3.ctypes.data
+        self._keep += [a, b]
+        if sig5 is not None:                          # None: Scoring.sigmodel computes them on the device
+            sig5 = np.ascontiguousarray(sig5, dtype=np.int16)
+            sig3 = np.ascontiguousarray(sig3, dtype=np.int16)
+            assert sig5.size >= b.size + 1 and sig3.size >= b.size + 1
+            self._keep += [sig5, sig3]
+            p.sig5, p.sig3 = sig5.ctypes.data, sig3.ctypes.data
         p.a_left, p.a_right = int(a_left), int(a.size if a_right is None else a_right)
         p.b_left, p.b_right = int(b_left), int(b.size if b_right is None else b_right)
         p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr = (int(x) for x in exg)

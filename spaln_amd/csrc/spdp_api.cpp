@@ -229,31 +229,76 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         col_off[i] = col_tot; col_tot += (int64_t) p.b_len + 1 + SPDP_COL_PAD;
     }
     std::vector<uint8_t> ha(std::max<int64_t>(a_tot, 16), 0);
-    std::vector<int32_t> hc(2 * std::max<int64_t>(col_tot, 1), 0);
+    // signals: either every problem brings sig5 / sig3 (then also cano5 / cano3 / dinc for the exact engines), or none
+    // does and SpdpScoring::sigmodel says how to compute them from the codes -- on the device (spdp_signals.hip)
+    int n_sig = 0;
+    for (int i = 0; i < n; ++i) n_sig += (probs[i].sig5 && probs[i].sig3) ? 1 : 0;
+    const bool dev_sig = n > 0 && n_sig == 0 && sc.sigmodel;
+    if (n_sig != n && !dev_sig) {
+        ctx->err = n_sig ? "sig5 / sig3 missing for part of the batch" : "sig5 / sig3 missing and no SpdpScoring::sigmodel";
+        return -1;
+    }
     has_exact = sc.intpen && sc.intpen_len > 0;
-    for (int i = 0; i < n && has_exact; ++i)
+    for (int i = 0; i < n && has_exact && !dev_sig; ++i)
         if (!probs[i].cano5 || !probs[i].cano3 || !probs[i].dinc) has_exact = false;
-    std::vector<uint8_t> hx(has_exact ? 2 * std::max<int64_t>(col_tot, 1) : 0, 0);
     int max_s5 = INT32_MIN, max_s3 = INT32_MIN;
-    for (int i = 0; i < n; ++i) {
-        const SpdpProblem& p = probs[i];
-        if (has_exact) {
-            uint8_t* x = hx.data() + 2 * col_off[i];
-            for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
-                x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
-                x[1] = p.dinc[nn];
+    for (int i = 0; i < n; ++i) memcpy(ha.data() + a_off[i], probs[i].a, probs[i].a_len);
+    HIPCHK(hipMalloc(&d_cols, 2 * std::max<int64_t>(col_tot, 1) * sizeof(int32_t)));
+    if (has_exact) HIPCHK(hipMalloc(&d_aux, 2 * std::max<int64_t>(col_tot, 1)));
+    if (dev_sig) {
+        // codes only over PCIe (1 B per position instead of 8 + 2): base i of problem p at hb[col_off + i]
+        std::vector<uint8_t> hb(std::max<int64_t>(col_tot, 16), 0);
+        std::vector<SigJob> jobs(n);
+        for (int i = 0; i < n; ++i) {
+            memcpy(hb.data() + col_off[i], probs[i].b, probs[i].b_len);
+            SigJob& J = jobs[i];
+            J.b_off = J.col_off = col_off[i]; J.out_off = 0; J.pad = 0;
+            J.b_len = probs[i].b_len; J.left = probs[i].b_left; J.right = probs[i].b_right;
+        }
+        void* d_b = nullptr;
+        HIPCHK(hipMalloc(&d_b, hb.size()));
+        hipError_t e = hipMemcpyAsync(d_b, hb.data(), hb.size(), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cols, 0, 2 * std::max<int64_t>(col_tot, 1) * sizeof(int32_t), ctx->stream);
+        if (e == hipSuccess && has_exact) e = hipMemsetAsync(d_aux, 0, 2 * std::max<int64_t>(col_tot, 1), ctx->stream);
+        int rc = -1;
+        if (e == hipSuccess) {
+            SignalArgs A;
+            memset(&A, 0, sizeof A);
+            A.codes = (const uint8_t*) d_b;
+            A.cols = (int2*) d_cols; A.aux = has_exact ? (uchar2*) d_aux : nullptr;
+            A.ipen = sc.ipen; A.spj = sc.spj;
+            rc = spdp_signals_run(ctx, sc.sigmodel, jobs, A, &max_s5, &max_s3);
+        } else {
+            ctx->err = std::string("signal upload: ") + hipGetErrorString(e);
+        }
+        (void) hipFree(d_b);
+        if (rc) return -1;
+    } else {
+        std::vector<int32_t> hc(2 * std::max<int64_t>(col_tot, 1), 0);
+        std::vector<uint8_t> hx(has_exact ? 2 * std::max<int64_t>(col_tot, 1) : 0, 0);
+        for (int i = 0; i < n; ++i) {
+            const SpdpProblem& p = probs[i];
+            if (has_exact) {
+                uint8_t* x = hx.data() + 2 * col_off[i];
+                for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
+                    x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
+                    x[1] = p.dinc[nn];
+                }
+            }
+            int32_t* cr = hc.data() + 2 * col_off[i];
+            for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
+                const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
+                const uint16_t s3 = (uint16_t) p.sig3[nn];
+                cr[0] = sc.spj ? (int32_t) ((uint32_t) s5 | ((uint32_t) s3 << 16)) : 0;
+                max_s5 = std::max(max_s5, (int) (int16_t) s5); max_s3 = std::max(max_s3, (int) (int16_t) s3);
+                cr[1] = nn > 0 ? p.b[nn - 1] : 0;
             }
         }
-        memcpy(ha.data() + a_off[i], p.a, p.a_len);
-        int32_t* cr = hc.data() + 2 * col_off[i];
-        for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
-            const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
-            const uint16_t s3 = (uint16_t) p.sig3[nn];
-            cr[0] = sc.spj ? (int32_t) ((uint32_t) s5 | ((uint32_t) s3 << 16)) : 0;
-            max_s5 = std::max(max_s5, (int) (int16_t) s5); max_s3 = std::max(max_s3, (int) (int16_t) s3);
-            cr[1] = nn > 0 ? p.b[nn - 1] : 0;
-        }
+        HIPCHK(hipMemcpyAsync(d_cols, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (has_exact) HIPCHK(hipMemcpyAsync(d_aux, hx.data(), hx.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));          // hc / hx go out of scope
     }
+    sc.sigmodel = nullptr;                                   // the caller's model is not ours to keep
     // bounds for the fp32 sweeps (DevRun::build): best substitution score, best net gain of one intron
     fp_maxpos = 1;
     for (int i = 0; i < sc.mtx_dim * sc.mtx_dim; ++i) fp_maxpos = std::max(fp_maxpos, (int) sc.mtx[i]);
@@ -266,14 +311,10 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     to_dev_scoring(&sc, &hsc);
     HIPCHK(hipMalloc(&d_sc, sizeof(DevScoring)));
     HIPCHK(hipMalloc(&d_a, ha.size()));
-    HIPCHK(hipMalloc(&d_cols, hc.size() * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(d_sc, &hsc, sizeof hsc, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_a, ha.data(), ha.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_cols, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (has_exact) {
-        HIPCHK(hipMalloc(&d_aux, hx.size()));
         HIPCHK(hipMalloc(&d_intpen, sizeof(int16_t) * sc.intpen_len));
-        HIPCHK(hipMemcpyAsync(d_aux, hx.data(), hx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, sizeof(int16_t) * sc.intpen_len, hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));

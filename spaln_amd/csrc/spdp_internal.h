@@ -98,6 +98,38 @@ extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream
 extern "C" hipError_t spdp_launch_pack(const int2* skl, int skl_cap, const int* n_skl, const int64_t* off,
                                        int2* packed, int n_probs, hipStream_t s);
 
+// splice-signal precompute (spdp_signals.hip): Exinon::intron53_c / intron53_n per position of a genomic window
+struct SigModelDev {
+    int32_t rows, cols5, off5, cols3, off3, any, both_ori;
+    float   fs, tonic5, min5, tonic3, min3;
+    int16_t tab5[16], tab3[16];
+};
+struct SigJob {
+    int64_t b_off;                // first base of the window in `codes`
+    int64_t col_off;              // its column records (DevStore layout)
+    int64_t out_off;              // its plain output arrays
+    int32_t b_len, left, right, pad;
+};
+struct SignalArgs {
+    const SigModelDev* model;
+    const float*       mtx5;      // cols5 x rows
+    const float*       mtx3;
+    const SigJob*      jobs;
+    const uint8_t*     codes;
+    int16_t*           sig5;      // plain arrays, b_len + 1 entries per job at out_off (or null)
+    int16_t*           sig3;
+    uint8_t*           cano5;
+    uint8_t*           cano3;
+    uint8_t*           dinc;
+    int2*              cols;      // column records / aux of the sweeps (or null)
+    uchar2*            aux;
+    int*               maxes;     // {max(sig5 + ipen), max sig3} over everything written (or null)
+    int32_t            ipen, spj;
+};
+int spdp_signals_run(SpdpContext* ctx, const SpdpSignalModel* m, const std::vector<SigJob>& jobs, SignalArgs args,
+                     int* max_s5, int* max_s3);          // spdp_signals_api.cpp
+extern "C" hipError_t spdp_launch_signals(const SignalArgs* a, int n_jobs, int max_len, int lds_floats, hipStream_t s);
+
 // skl_rngS_ng on the device (spdp_rescore.hip): one thread per query
 struct RescoreArgs {
     const DevScoring* sc;

@@ -44,6 +44,8 @@ def load_library() -> C.CDLL:
     lib.spdp_last_error.argtypes = [C.c_void_p]
     lib.spdp_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.spdp_cells.restype = C.c_int64
+    lib.spdp_splice_signals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_batch_upload.restype = C.c_void_p
     lib.spdp_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.spdp_batch_free.argtypes = [C.c_void_p]
@@ -164,6 +166,18 @@ class Engine:
         return buf.value.decode()
 
     # ---- SimdAln2s1 `_wip` engines ------------------------------------------------
+    def splice_signals(self, model: abi.SignalModel, b_codes, left: int = 0, right=None) -> dict:
+        """Exinon::intron53_c / intron53_n of one window on the device: sig5, sig3, cano5, cano3, dinc by position"""
+        b = np.ascontiguousarray(b_codes, dtype=np.uint8)
+        n1 = b.size + 1
+        out = dict(sig5=np.zeros(n1, np.int16), sig3=np.zeros(n1, np.int16), cano5=np.zeros(n1, np.uint8),
+                   cano3=np.zeros(n1, np.uint8), dinc=np.zeros(n1, np.uint8))
+        self._check(self.lib.spdp_splice_signals(self.ctx, C.addressof(model), b.ctypes.data, b.size, int(left),
+                                                 int(b.size if right is None else right),
+                                                 *(out[k].ctypes.data for k in ("sig5", "sig3", "cano5", "cano3", "dinc"))),
+                    "spdp_splice_signals")
+        return out
+
     def wip_scoreonly(self, sc: abi.Scoring, ps: abi.ProblemSet) -> np.ndarray:
         out = np.zeros(len(ps), dtype=np.int32)
         self._check(self.lib.spdp_wip_scoreonly(self.ctx, C.byref(sc), ps.array(), len(ps),

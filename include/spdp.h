@@ -199,6 +199,10 @@ int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem
                       int n_probs, SpdpAlignment* out, int32_t* orient);
 void spdp_free_alignments(SpdpAlignment* out, int n);
 
+/* stdskl (m_unit 1) / stdskl3 (m_unit 3), src/gaps.cc:140-227: corner list of n path records in any order;
+ * out[] needs 2 n + 1 entries, returns the number written.  Host only (no device work). */
+int spdp_corner_list(const SpdpSkl* recs, int n, int m_unit, SpdpSkl* out);
+
 /* ---- rescoring: skl_rngS_ng (src/fwd2s1.cc:446) ---------------------------------------------- */
 /* The score the CLI prints and the per-exon records come from a walk over the finished corner
  * list, not from the DP engines.  Needs the exact-model inputs (SpdpScoring.intpen / t53,

@@ -796,41 +796,6 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
     return 0;
 }
 
-// stdskl3, src/gaps.cc:178-227 (UNITE_INDEL_FS = 0): records in any order -> corner list start -> end
-static void std_skl3(std::vector<SpdpSkl>& rec, std::vector<SpdpSkl>& out)
-{
-    out.clear();
-    if (rec.size() < 2) { out = rec; return; }
-    std::sort(rec.begin(), rec.end(), [](const SpdpSkl& x, const SpdpSkl& y) {
-        return x.m != y.m ? x.m < y.m : x.n < y.n;
-    });
-    int pr = -2;
-    const SpdpSkl* prv = &rec[0];
-    for (size_t i = 1; i < rec.size(); ++i) {
-        const SpdpSkl* org = &rec[i];
-        const int dm = (org->m - prv->m) * 3;
-        const int dn = org->n - prv->n;
-        if (!dm && !dn) continue;
-        if (dn < 0) continue;
-        int dd = std::min(dm, dn);
-        const int df = dn - dm;
-        const int dr = df ? (df > 0 ? 1 : -1) : 0;
-        if (dd && df) {
-            if (pr) out.push_back(*prv);
-            SpdpSkl b;
-            b.n = prv->n + dd;
-            if (df < 0 && df % 3) dd += 2;
-            b.m = prv->m + dd / 3;
-            out.push_back(b);
-            if (df > 0 && df % 3) { b.n += df % 3; out.push_back(b); }
-        } else if (dr != pr || !dm)
-            out.push_back(*prv);
-        pr = dr;
-        prv = org;
-    }
-    out.push_back(*prv);
-}
-
 static SpdpSkl* dup_skl(const std::vector<SpdpSkl>& v)
 {
     if (v.empty()) return nullptr;
@@ -858,7 +823,7 @@ static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
             out[i].n_skl = (int) t.rec.size();
             out[i].skl = dup_skl(t.rec);
         } else if (t.rec.size() >= 2) {                      // globalH_ng: fewer than 2 records = no alignment
-            std_skl3(t.rec, stdv);
+            stdv = corner_list<3>(t.rec);                   // stdskl3 with UNITE_INDEL_FS = 0
             full.clear();
             SpdpSkl hd; hd.m = 1; hd.n = (int) stdv.size();
             full.push_back(hd);

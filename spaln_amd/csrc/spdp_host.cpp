@@ -100,38 +100,58 @@ int diagonal_s(const SpdpScoring& sc, const SpdpProblem& p, const Rng& r, std::v
     return LocalR ? maxh : scr;
 }
 
-// stdskl, src/gaps.cc:140-180: sort by (m, n), drop repeats / inconsistent steps, insert the
-// corner of every diagonal-then-gap step.  In/out: records without header.
-std::vector<SpdpSkl> std_skl(std::vector<SpdpSkl> org)
+}   // namespace
+
+// Corner list of a set of path records (what stdskl / stdskl3, src/gaps.cc:140-227, return; in / out without header).
+// The records, sorted by (m, n), are the vertices of a monotone polyline.  Every step between two of them is a
+// diagonal leg (when it advances in both sequences) followed by a gap leg (when the advances differ); a vertex is
+// a corner when the leg leaving it does not continue the leg arriving -- plus, as in the reference, every vertex
+// that starts a step without progress in m.  M_UNIT = 3 for protein rows against nucleotide columns: a gap leg that
+// is not a whole number of codons rounds the row of its corner up (row gaps) or splits off the frame shift (column gaps).
+template <int M_UNIT>
+std::vector<SpdpSkl> corner_list(std::vector<SpdpSkl> pts)
 {
-    const int num = (int) org.size();
-    if (num < 2) return org;
-    std::sort(org.begin(), org.end(), [](const SpdpSkl& a, const SpdpSkl& b) {
-        return a.m != b.m ? a.m < b.m : a.n < b.n;
-    });
-    std::vector<SpdpSkl> out;
-    out.reserve(2 * num + 1);
-    int pr = 2;
-    const SpdpSkl* prv = &org[0];
-    for (int i = 1; i < num; ++i) {
-        const SpdpSkl* o = &org[i];
-        const int dm = o->m - prv->m, dn = o->n - prv->n;
-        if (!dm && !dn) continue;
-        if (dm < 0 || dn < 0) continue;
-        const int dd = std::min(dm, dn);
-        int df = dn - dm;
-        if (df) df = df > 0 ? 1 : -1;
-        if (dd && df) {
-            if (pr) out.push_back(*prv);
-            out.push_back({prv->m + dd, prv->n + dd});
-        } else if (df != pr || !dm)
-            out.push_back(*prv);
-        pr = df;
-        prv = o;
+    if (pts.size() < 2) return pts;
+    std::sort(pts.begin(), pts.end(), [](const SpdpSkl& x, const SpdpSkl& y) { return x.m != y.m ? x.m < y.m : x.n < y.n; });
+    std::vector<SpdpSkl> corners;
+    corners.reserve(2 * pts.size() + 1);
+    enum { DIAG = 0, NONE = 2 };                     // headings: 0 diagonal, +1 gap along n, -1 gap along m
+    int heading = NONE;
+    size_t at = 0;
+    for (size_t nxt = 1; nxt < pts.size(); ++nxt) {
+        const int adv_m = (pts[nxt].m - pts[at].m) * M_UNIT, adv_n = pts[nxt].n - pts[at].n;
+        if (adv_n < 0 || (!adv_m && !adv_n)) continue;           // a step back or a repeat: not a vertex
+        const int diag = std::min(adv_m, adv_n), slack = adv_n - adv_m;
+        const int gap = (slack > 0) - (slack < 0);
+        const bool two_legs = diag && gap;
+        if ((two_legs ? (int) DIAG : gap) != heading || !adv_m) corners.push_back(pts[at]);
+        if (two_legs) {
+            SpdpSkl c;
+            c.n = pts[at].n + diag;
+            c.m = pts[at].m + (diag + ((M_UNIT > 1 && slack < 0 && slack % M_UNIT) ? M_UNIT - 1 : 0)) / M_UNIT;
+            corners.push_back(c);
+            if (M_UNIT > 1 && slack > 0 && slack % M_UNIT) { c.n += slack % M_UNIT; corners.push_back(c); }
+        }
+        heading = gap;
+        at = nxt;
     }
-    out.push_back(*prv);
-    return out;
+    corners.push_back(pts[at]);
+    return corners;
 }
+template std::vector<SpdpSkl> corner_list<1>(std::vector<SpdpSkl>);
+template std::vector<SpdpSkl> corner_list<3>(std::vector<SpdpSkl>);
+
+// host-only entry (no device work): the corner list of n records, out[] has room for 2 n + 1; returns the count
+extern "C" int spdp_corner_list(const SpdpSkl* recs, int n, int m_unit, SpdpSkl* out)
+{
+    if (!recs || !out || n < 0 || (m_unit != 1 && m_unit != 3)) return -1;
+    std::vector<SpdpSkl> v(recs, recs + n);
+    v = m_unit == 1 ? corner_list<1>(std::move(v)) : corner_list<3>(std::move(v));
+    std::copy(v.begin(), v.end(), out);
+    return (int) v.size();
+}
+
+namespace {
 
 // trimskl, src/gaps.cc:254-273: delete terminal gaps at free ends
 void trim_skl(std::vector<SpdpSkl>& s, const SpdpProblem& p)
@@ -526,7 +546,7 @@ struct Aligner {
         out->score = J.score_set ? J.score : SPDP_NEVSEL;
         out->n_skl = 0; out->skl = nullptr;
         if (J.failed || (int) J.rec.size() < 2) return;
-        std::vector<SpdpSkl> s = std_skl(J.rec);
+        std::vector<SpdpSkl> s = corner_list<1>(J.rec);
         trim_skl(s, probs[i]);
         out->n_skl = (int) s.size() + 1;
         out->skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * out->n_skl);

@@ -286,4 +286,7 @@ struct DevRun {
 
 RunItem spdp_item_of(const SpdpProblem& p, int parent, int sh);
 int64_t spdp_cells_w(int a_left, int a_right, int b_left, int b_right, const SpdpWindow& w);
+// corner list of path records (spdp_host.cpp): M_UNIT = 1 nucleotide rows, 3 protein rows
+template <int M_UNIT> std::vector<SpdpSkl> corner_list(std::vector<SpdpSkl> pts);
+
 #endif

@@ -57,6 +57,7 @@ const	char*	exg = 0;
 		}
 		case 'g': exg = argv[++ai]; break;
 		case 'U': ubh = atoi(argv[++ai]); break;
+		case 'T': ftable.setpath(argv[++ai], gnm2tab); break;	// species-specific tables, as spaln -T (spaln.cc:484-487)
 		case 'V': vmfspace = atol(argv[++ai]); break;
 		case 'q': nquant = atoi(argv[++ai]); break;
 		case 'r': sscanf(argv[++ai], "%d,%d,%d,%d", rng4, rng4 + 1, rng4 + 2, rng4 + 3); break;

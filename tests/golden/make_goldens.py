@@ -191,13 +191,71 @@ def protein_cases():
     return c
 
 
+_SYN = None
+
+
+def _synonymous():
+    """amino acid -> its codons (standard code), from synth's own codon table"""
+    global _SYN
+    if _SYN is None:
+        _SYN = {}
+        for codon, aa in synth._CODON_AA.items():
+            _SYN.setdefault(aa, []).append(codon)
+    return _SYN
+
+
+def dictdisc_cases(n=6):
+    """BASELINE config 1 (dictdisc.faa vs the Dictyostelium genome, -Tdictdisc): the sample genome is absent
+    upstream, so the stand-in SURVEY App. B probed: proteins of the reference's own seqdb/dictdisc.faa.gz,
+    back-translated with random synonymous codons (A/T-rich third positions, as in Dictyostelium), 1-3 planted
+    GTAAGT...(T)10..CAG introns, A/T-rich flanks; the reference runs with its species tables (-T dictdisc)."""
+    import gzip
+    path = os.path.join(os.environ.get("SPALN_REF", "/root/reference"), "seqdb", "dictdisc.faa.gz")
+    recs, name, buf = [], None, []
+    with gzip.open(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name:
+                    recs.append((name, "".join(buf)))
+                name, buf = line[1:].split()[0], []
+            else:
+                buf.append(line.strip())
+    recs.append((name, "".join(buf)))
+    rng = np.random.default_rng(synth.SEED + 9001)
+    ok = [(nm, aa) for nm, aa in recs if 120 <= len(aa) <= 330 and set(aa) <= set("ACDEFGHIKLMNPQRSTVWY")]
+    pick = [ok[i] for i in sorted(rng.choice(len(ok), size=n, replace=False))]
+    syn = _synonymous()
+    c = {}
+    for k, (nm, aa) in enumerate(pick):
+        cds = []
+        for ch in aa:
+            opts = syn[ch]
+            w = np.array([3.0 if o[2] in "AT" else 1.0 for o in opts])
+            cds.append(opts[int(rng.choice(len(opts), p=w / w.sum()))])
+        cds = "".join(cds) + "TAA"
+        n_int = int(rng.integers(1, 4))
+        cuts = sorted(int(x) for x in rng.choice(np.arange(30, len(cds) - 30), size=n_int, replace=False))
+        parts, prev = [], 0
+        at = lambda L: "".join("AT"[int(x)] if y < 0.85 else "GC"[int(x)] for x, y in zip(rng.integers(0, 2, L), rng.random(L)))
+        for cpos in cuts:
+            parts.append(cds[prev:cpos])
+            parts.append("GTAAGT" + at(int(rng.integers(60, 400))) + "T" * 10 + at(6) + "CAG")
+            prev = cpos
+        parts.append(cds[prev:])
+        window = at(300) + "".join(parts) + at(300)
+        w = np.frombuffer(window.encode(), dtype=np.uint8)
+        q = np.frombuffer(aa.encode(), dtype=np.uint8)
+        c[f"c1_{nm.split('_')[0].lower()}"] = (w, q, ["-T", "dictdisc", "-u", "1,2"])
+    return c
+
+
 def main():
     if not os.path.exists(REF_DUMP):
         sys.exit(f"{REF_DUMP} missing: run `make -C oracle/ref_build` first")
     env = dict(os.environ, ALN_TAB=ALN_TAB)
     only = set(sys.argv[1:])
     with tempfile.TemporaryDirectory() as td:
-        for name, (window, query, opts) in cases().items():
+        for name, (window, query, opts) in {**cases(), **dictdisc_cases()}.items():
             if only and name not in only:
                 continue
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")

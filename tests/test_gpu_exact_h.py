@@ -9,7 +9,7 @@ from spaln_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
 
-H_FILES = golden_files("h1_")
+H_FILES = golden_files("h1_") + golden_files("c1_")      # c1_: dictdisc proteins, species tables (BASELINE config 1)
 
 
 def _name(f):

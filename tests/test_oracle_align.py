@@ -94,7 +94,7 @@ def test_align_a6_recursive_switch():
         _, p = spdg.problem(fx)
         scr, flat = host_logic.align_s(sc, p)
         assert scr == int(fx["aln_scr_A6"][0]) and (flat or []) == fx["aln_skl_A6"].tolist(), f
-    for f in golden_files("h1_"):
+    for f in golden_files("h1_") + golden_files("c1_"):
         fx = spdg.load(f)
         if f.endswith("h1_cut_right.spdg") or f.endswith("h1_random.spdg"):
             continue                                   # undefined in the reference (see test_oracle_h_golden)

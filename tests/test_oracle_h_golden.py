@@ -7,7 +7,7 @@ from tests import spdg
 from tests.conftest import golden_files
 from oracle import oracle, host_logic_h as hh
 
-H_FILES = golden_files("h1_")
+H_FILES = golden_files("h1_") + golden_files("c1_")      # c1_: dictdisc proteins, species tables (BASELINE config 1)
 # the reference starts its traceback outside its bitmap on this one (out-of-bounds read)
 UNDEFINED = {"h1_cut_right", "h1_random"}
 

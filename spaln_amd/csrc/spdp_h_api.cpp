@@ -341,7 +341,7 @@ static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, H
     return 0;
 }
 
-// ---- scalar forwardH_ng over a list of items (spdp_h_scalar.hip) ------------------------------
+// ---- scalar forwardH_ng over a list of items (spdp_h_rowwave.hip) ------------------------------
 static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
 {
     SpdpContext* ctx = st.ctx;
@@ -422,7 +422,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     return 0;
 }
 
-// ---- scalar hirschbergH_ng over a list of items (spdp_h_scalar.hip) ----------------------------
+// ---- scalar hirschbergH_ng over a list of items (spdp_h_rowwave.hip) ----------------------------
 struct HUdhOut;
 // engine: 0 hirschbergH_ng (scalar), 1 hirschbergH1 (-A1), 2 hirschbergH1_wip with local ends (-LS)
 static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine = 0);

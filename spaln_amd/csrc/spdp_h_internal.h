@@ -51,7 +51,7 @@ struct HCposArgs {
     int                cpos_stride;
 };
 
-// scalar forwardH_ng (spdp_h_scalar.hip): one thread per problem
+// the -A0 engines forwardH_ng / hirschbergH_ng (spdp_h_rowwave.hip): one wave per problem, lane = row
 struct HScalarArgs {
     const DevScoringH* sc;
     const DevProblemH* probs;      // bnd_off: into work (ints), tb_off: into vmf (records), imd_off: record capacity

@@ -1,0 +1,882 @@
+// spdp_h_rowwave.hip -- the exact-intron-length ("-A0") protein x genome engines as wavefront kernels.
+//
+// What they compute (ogotoh/spaln v3.0.7; restated for the checker in oracle/spdp_oracle_h_scalar.c):
+//   MODE 0  Aln2h1::forwardH_ng without a Vmf (HomScoreH_ng)                  src/fwd2h1.cc:294-617, 143-292
+//   MODE 1  forwardH_ng + initH_ng / lastH_ng, Vmf::traceback and the record fix-up of trcbkalignH_ng
+//                                                                             src/vmf.cc:125, src/fwd2h1.cc:2019-2036
+//   MODE 2  Aln2h1::hirschbergH_ng + hinitH_ng / hlastH_ng with UdhIntermediate(lub = true)
+//                                                                             src/fwd2h1.cc:1085-1520, 941-1083
+// int32 scores; a cell (m, n) pairs residue m with the codon ending at n; three gap states (match H, insertion E in
+// a queue of three codon phases, deletion F) with 1- and 2-nt frame shifts; a sorted list of the best donor
+// candidates per row AND codon phase; acceptors priced with IntPen(length) + the junction table, and a codon
+// split by the intron re-scored from the four bases around it.  The -A2 / -A3 dispatch runs this engine on
+// sub-problems below 8 query rows, -A0 runs it on everything.
+//
+// The reference walks the matrix row by row over arrays indexed by DIAGONAL r = n - 3m that it updates in place; what
+// a cell sees at the band edges is whatever those arrays hold, so the arrays stay as they are.  Mapping (ours): one
+// wave per problem, lane k owns row m0 + k of a tile of up to 64 rows with all per-row state (the insertion queue,
+// three candidate lists) in its registers; at step S it is on column S - m, i.e. on array entry S - 4m: it reads
+// entries r - 3 .. r + 3 -- its own last three cells and the four cells of the row above that the lane above wrote one
+// to four steps earlier -- and writes r.  The arrays are shared through an LDS window of 512 diagonals sliding with
+// the sweep, streamed from / to global memory 64 entries at a time between tiles.  Every state carries riders:
+// a Vmf record number (MODE 1) or the diagonal range, start row and intermediate-row link of its path (MODE 2).
+// Vmf records are appended through a wave-uniform counter (ballot + prefix count).  The sequential boundary rules
+// (leading / trailing gap relaxation along the first and last row) run on one lane over LDS-staged chunks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spdp_h_dev.h"
+#include "spdp_h_internal.h"
+
+namespace {
+
+constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
+constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
+constexpr int RING = 512;                               // diagonals resident in LDS
+constexpr int CHUNK = 32;                               // steps between two refills of the window
+constexpr int NC = 5;                                   // NCAND + 1 slots per candidate list
+constexpr int WPB = 4;                                  // waves (= problems) per block
+constexpr int IPEN_LDS = 4096;
+constexpr int AMB = 2;                                  // the ambiguity code of both alphabets
+
+// TraceBackDir (src/aln.h:30-35): what a state remembers about its last step
+enum : int { T_DEAD = 0, T_DIAG = 2, T_NEWD = 3, T_VERT = 4, T_SLA1 = 5, T_SLA2 = 6, T_VERL = 7, T_HORI = 8, T_HOR1 = 9,
+             T_HOR2 = 10, T_HORL = 11, T_NEWV = 12, T_NEWH = 13, T_SPIN = 16 };
+constexpr unsigned M_DIAG = 1u << T_DIAG | 1u << T_NEWD;
+constexpr unsigned M_VERT = 1u << T_VERT | 1u << T_SLA1 | 1u << T_SLA2 | 1u << T_VERL | 1u << T_NEWV;
+constexpr unsigned M_HORI = 1u << T_HORI | 1u << T_HOR1 | 1u << T_HOR2 | 1u << T_HORL | 1u << T_NEWH;
+__device__ __forceinline__ bool is_kind(int d, unsigned mask) { return (mask >> (d & 15)) & 1u; }
+// which of the three states a direction belongs to (dir2nod, src/aln.h:50-56): 0 H, 1 E, 2 F, 3 / 4 the long-gap forms
+__device__ __forceinline__ int node_of(int d)
+{
+    d &= 15;
+    if (is_kind(d, M_DIAG)) return 0;
+    if (d == T_VERL) return 4;
+    if (d == T_HORL) return 3;
+    if (is_kind(d, M_VERT)) return 2;
+    if (is_kind(d, M_HORI)) return 1;
+    return -1;
+}
+
+struct Tables {
+    int mtx[32 * 32];
+    short ipen[IPEN_LDS];
+    short t53[256];
+    uint8_t mid[32];
+    uint8_t tron_of[64];
+};
+__device__ __forceinline__ void load_tables(Tables& T, const HScalarArgs& A, const DevScoringH* sc)
+{
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = sc->mtx[i];
+    for (int i = threadIdx.x; i < IPEN_LDS; i += blockDim.x) T.ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
+    if (threadIdx.x < 32) T.mid[threadIdx.x] = A.mid[threadIdx.x];
+    if (threadIdx.x < 64) T.tron_of[threadIdx.x] = A.tron_of[threadIdx.x];
+    __syncthreads();                                    // the only block-wide barrier
+}
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// a DP state: value, direction, riders (MODE 1: a = Vmf record; MODE 2: a = upr, b = lwr, c = ml, e = ulk)
+struct St { int v, d, a, b, c, e; };
+template <int MODE> struct Shape { static constexpr int NF = MODE == 0 ? 2 : (MODE == 1 ? 3 : 6); };
+__device__ __forceinline__ int& fld(St& s, int i) { return i == 0 ? s.v : i == 1 ? s.d : i == 2 ? s.a : i == 3 ? s.b : i == 4 ? s.c : s.e; }
+
+// donor candidates of one codon phase, best first
+template <int MODE> struct Cands {
+    int v[NC], j[NC], x[NC];                            // value, donor position, packed {state, dinc5, the two bases before the donor}
+    int a[NC], b[NC], c[NC], e[NC];                     // riders of the state it left from
+    int n;                                              // index of the last one, -1: none
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int l = 0; l < NC; ++l) { v[l] = NEV; j[l] = 0; x[l] = 0; a[l] = MODE == 2 ? INT32_MIN : 0; b[l] = INT32_MAX; c[l] = 0; e[l] = EOU; }
+        n = -1;
+    }
+    // the free slot starts below the list and moves up past every entry the newcomer ties or beats; a full list
+    // drops its last entry, and a newcomer that beats nobody in a full list takes that entry with it
+    __device__ __forceinline__ bool insert(bool t, int val, int pos_n, int packed, const St& src, int ulk)
+    {
+        int pos = n < NC - 1 ? n + 1 : NC - 1;
+        if (t && n < NC - 1) ++n;
+#pragma unroll
+        for (int l = NC - 1; l >= 1; --l) {
+            const bool mv = t && pos == l && val >= v[l - 1];
+            if (mv) { v[l] = v[l - 1]; j[l] = j[l - 1]; x[l] = x[l - 1]; a[l] = a[l - 1];
+                      if (MODE == 2) { b[l] = b[l - 1]; c[l] = c[l - 1]; e[l] = e[l - 1]; }
+                      pos = l - 1; }
+        }
+        if (!t) return false;
+        if (pos < NC - 1) {
+#pragma unroll
+            for (int l = 0; l < NC - 1; ++l)
+                if (l == pos) { v[l] = val; j[l] = pos_n; x[l] = packed; a[l] = src.a;
+                                if (MODE == 2) { b[l] = src.b; c[l] = src.c; e[l] = ulk; } }
+            return true;
+        }
+        --n;
+        return false;
+    }
+};
+template <class A> __device__ __forceinline__ int pick(int sel, const A& arr)
+{
+    int v = 0;
+#pragma unroll
+    for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l];
+    return v;
+}
+
+}   // namespace
+
+template <int MODE>
+__global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
+{
+    constexpr bool FWD = MODE == 1, UDH = MODE == 2;
+    constexpr int NF = Shape<MODE>::NF;
+    __shared__ int Lw[WPB][2 * NF][RING];
+    __shared__ Tables T;
+    const DevScoringH* sc = A.sc;
+    load_tables(T, A, sc);
+    int (*L)[RING] = Lw[threadIdx.x >> 6];              // L[f] = field f of H, L[NF + f] = field f of F
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (pi >= A.n_probs) return;
+    const DevProblemH P = A.probs[pi];
+    int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
+    const int lw = P.lw, up = P.up, width = P.width, n_im = UDH ? P.n_im : 0, intvl = P.imd_intvl;
+    const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
+    const bool Local = sc->local;
+    const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
+    const int gop = sc->gop, gep = sc->gep, lgep = sc->lgep, codonk1 = sc->codonk1;
+    const int gw1 = sc->g1, gw2 = sc->g2, gw3 = sc->g3, ge1 = A.gape1, ge2 = A.gape2;
+    const bool spj = sc->spj;
+    const int minl = A.minl;
+    const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
+    const int4* __restrict__ cols = A.cols + P.col_off;             // .x: codon ending at n | flags, .y: sig3 x 2, .w: dinc
+    const short4* __restrict__ aux = A.aux + P.col_off;             // {sigS, sigT, sigE, sig5}
+    const int W = width + 4;                                        // 2 NF arrays of W ints: entry e = r - lw + 3
+    int* const g0 = A.work + P.bnd_off;
+    auto G = [&](int arr) { return g0 + (int64_t) arr * W; };
+    auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
+    auto tron_at = [&](int i) -> int { return (i < 0 || i > P.b_len) ? AMB : ((cols[i + 2].x >> 16) & 0xff); };   // the codon starting at i
+    auto intpen_of = [&](int len) -> int {
+        if (len < 0) return -32768;
+        if (len < IPEN_LDS) return T.ipen[len];
+        return A.intpen[min(len, A.intpen_len - 1)];
+    };
+
+    // ---- Vmf (MODE 1): record 0 is never used
+    int3* __restrict__ vrec = A.vmf + P.tb_off;
+    const int vcap = (int) P.imd_off;
+    int vcount = 1;
+    bool vover = false;
+    auto vadd = [&](bool need, int mm, int nn, int pp) -> int {
+        if (!FWD) return 0;
+        const unsigned long long mask = __ballot(need);
+        if (!mask) return 0;
+        const int my = vcount + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0));
+        vcount += __popcll(mask);
+        if (need) { if (my < vcap) vrec[my] = make_int3(mm, nn, pp); else vover = true; }
+        return my;
+    };
+    // ---- intermediate rows (MODE 2): hlnk[2], vlnk[2], lwrb[2], uprb[2], `width` ints each, entry r - lw + 1
+    int* const imd_base = UDH ? A.imd + P.imd_off : nullptr;
+    const int64_t us = 2 * (int64_t) width;
+    enum { HLNK = 0, VLNK = 1, LWRB = 2, UPRB = 3 };
+    auto IM = [&](int i, int arr, int k, int r) -> int* { return imd_base + (int64_t) i * 4 * us + arr * us + (int64_t) k * width + (r - lw + 1); };
+    auto mi_of = [&](int i) { return P.a_left + (i + 1) * intvl; };
+    int* cpos = UDH ? A.cpos + (int64_t) pi * A.cpos_stride : nullptr;
+#define CPOS(i, c) cpos[(i) * 10 + (c)]
+
+    const int r_corner = bl - 3 * al;                               // the diagonal of the start cell
+    const int r_floor = bl - 3 * ar;
+    const St black = UDH ? St{NEV, 0, r_floor, r_floor, 0, EOU} : St{NEV, 0, 0, 0, 0, 0};
+    auto put = [&](int e, int isF, const St& s) {                  // one entry to global memory
+        St t = s;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) G(isF * NF + f)[e] = fld(t, f);
+    };
+
+    // ---- the arrays as initH_ng / hinitH_ng leave them
+    {
+        if (UDH) {
+            for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
+            for (int i = 0; i < n_im; ++i)
+                for (int64_t q = lane; q < us; q += 64) {
+                    int* b = imd_base + (int64_t) i * 4 * us;
+                    b[q] = EOU; b[us + q] = EOU; b[2 * us + q] = INT32_MAX; b[3 * us + q] = INT32_MIN;
+                }
+        }
+        // the start cell, and below it the first column (leading gap of the query side): closed form per entry
+        const int first_dir = a_exgl ? T_DEAD : T_DIAG;
+        const int sS0 = aux[bl + 1].x;
+        St corner = black;
+        corner.v = (a_exgl && sS0 > 0) ? sS0 : 0;
+        corner.d = first_dir;
+        const int p0 = vadd(lane == 0, al, bl, 0);
+        if (FWD) corner.a = __shfl(p0, 0);
+        if (UDH) { corner.a = corner.b = corner.e = r_corner; corner.c = al; }
+        const int r_low = max(lw, r_floor);
+        for (int e = lane; e < W; e += 64) {
+            const int r = e + lw - 3;
+            St h = black;
+            if (r == r_corner) h = corner;
+            else if (r < r_corner && r >= r_low) {
+                const int i = r_corner - r;                         // nucleotides of the gap
+                if (b_exgl == 1) {
+                    h.v = 0; h.d = T_DEAD;
+                    if (FWD) h.a = 0;
+                    if (UDH) { h.a = h.b = h.e = r; h.c = al + i / 3; }
+                } else {
+                    const int base = (i - 1) % 3 + 1, steps = (i - base) / 3;       // i = base + 3 steps: whole codons after a 1-, 2- or 3-nt start
+                    h = corner;
+                    h.d = T_VERT;
+                    if (!(b_exgl & 2)) h.v += gep;
+                    if (!(b_exgl & 1)) h.v += gop;
+                    if (base < 3) h.v += A.extragop;
+                    if (!(b_exgl & 2)) {
+                        const int cheap = min(steps, max(0, (codonk1 - base) / 3));         // codons still inside the short-gap regime
+                        h.v += cheap * gep + (steps - cheap) * lgep;
+                    }
+                    if (UDH) { h.b = h.e = r; h.c = al + i / 3; }
+                }
+            }
+            put(e, 0, h);
+            put(e, 1, black);
+        }
+        // the first row: a leading gap on the genomic side may restart wherever a start codon signal beats it --
+        // a running maximum with restarts, one lane, history in registers
+        if (a_exgl) {
+            const int r_top = min(up, br - 3 * al);
+            St h1 = corner, h2 = black, h3 = black;                 // the entries 1, 2, 3 below the current one
+            int since[3] = {bl, 0, 0};                              // where the gap of each frame (MODE 2: of all frames) started
+            for (int r = r_corner + 1; r <= r_top; ++r) {
+                const int i = r - r_corner, n = bl + i;
+                const int sS = max(0, (int) aux[n + 1].x);
+                St h;
+                bool fresh = false;
+                if (i < 3) { h = corner; h.v = sS; h.d = first_dir; fresh = true; if (!UDH) since[i] = n; }
+                else {
+                    h = h3;
+                    const int k = n - since[UDH ? 0 : i % 3];
+                    if (k == 3 && !(a_exgl & 1)) h.v += gop;
+                    if (!(a_exgl & 2)) h.v += gext3(k);
+                    h.v += aux[n - 2].z;
+                    h.d = T_HORI;
+                    if (h1.v + gw1 > h.v) { h = h1; h.v += gw1; h.d = T_HOR1; }
+                    if (h2.v + gw2 > h.v) { h = h2; h.v += gw2; h.d = T_HOR2; }
+                }
+                if (h.v < sS) { h.v = sS; h.d = T_DEAD; fresh = true; since[UDH ? 0 : i % 3] = n; }
+                const int p = vadd(lane == 0 && fresh, al, n, 0);
+                if (FWD && fresh) h.a = p;
+                if (UDH) { if (fresh) { h.b = h.e = r; if (i < 3) h.c = al; } h.a = r; }
+                if (lane == 0) put(r - lw + 3, 0, h);
+                h3 = h2; h2 = h1; h1 = h;
+            }
+        }
+    }
+
+    // running maximum of a local right end: first maximum in row-major order
+    St best = black; int best_m = UDH ? ar : al, best_n = UDH ? br : bl;
+    best.v = NEV; best.c = al;
+    int rl0 = INT32_MAX, rl1 = INT32_MAX, rl2 = INT32_MAX;         // MODE 2: `rlst` per queue slot, carried from one intermediate row to the next
+
+    const int R0 = al + (a_exgl ? 1 : 0);
+    const int TH = UDH ? max(1, min(64, intvl)) : 64;              // a tile holds at most one intermediate row
+    for (int m0 = R0; m0 <= ar; m0 += TH) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const int m = m0 + lane;
+        const bool row = lane < TH && m <= ar;
+        const int n0 = max(3 * m + lw - 1, bl), n9 = min(3 * m + up, br);
+        const bool any = row && n0 <= n9;
+        int s_lo = any ? n0 + m : INT32_MAX, s_hi = any ? n9 + m : INT32_MIN;
+        for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
+        const int iq = UDH ? (m - P.a_left) / max(1, intvl) - 1 : -1;
+        const bool is_imd = UDH && row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
+        const unsigned long long imd_mask = __ballot(is_imd);
+        if (s_lo <= s_hi) {
+            const int aa0 = (row && m >= 1 && m - 1 < P.a_len) ? acod[m - 1] : AMB;       // the residue of my row, and the next one
+            const int aa1 = (row && m < P.a_len) ? acod[m] : AMB;
+            const int* prof0 = T.mtx + aa0 * 32;
+            const int* prof1 = T.mtx + aa1 * 32;
+            // the insertion queue: ea is the slot of the current column's frame
+            St ea = black, eb = black, ec = black;
+            Cands<MODE> cl[3];
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) cl[ph].clear();
+            bool seeded = false;                                    // a global query start: the corner seeds the third slot
+
+            auto need_lo = [&](int S) { return S - 4 * (m0 + 63) - 3 - lw + 3; };
+            auto need_hi = [&](int S) { return S - 4 * m0 + 3 - lw + 3; };
+            int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
+            auto refill = [&](int S) {
+                const int dead = min(max(0, need_lo(S)), W);
+                for (int e = res_lo + lane; e < dead; e += 64) {
+                    const int q = e & (RING - 1);
+#pragma unroll
+                    for (int a = 0; a < 2 * NF; ++a) G(a)[e] = L[a][q];
+                }
+                res_lo = max(res_lo, dead);
+                const int want = min(W, need_hi(S + CHUNK - 1) + 1);
+                for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
+                    const int q = e & (RING - 1);
+#pragma unroll
+                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = __builtin_nontemporal_load(G(a) + e);
+                }
+                res_hi = max(res_hi, want);
+                WAVE_SYNC();
+            };
+            auto lds_get = [&](int e, int isF) {
+                const int q = e & (RING - 1);
+                St s = black;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fld(s, f) = L[isF * NF + f][q];
+                return s;
+            };
+            auto lds_put = [&](int e, int isF, St s) {
+                const int q = e & (RING - 1);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) L[isF * NF + f][q] = fld(s, f);
+            };
+            // the column record and the codon-end signal of my next two cells are on their way when a step starts
+            auto ld_col = [&](int nn, int4& c, int& se) {
+                if (any && nn >= n0 && nn <= n9) { c = cols[nn]; se = (nn > bl && nn >= 2) ? (int) aux[nn - 2].z : 0; }
+            };
+            int4 col1 = make_int4(0, 0, 0, 0), col2 = col1; int se1 = 0, se2 = 0;
+            ld_col(s_lo - m, col1, se1);
+            ld_col(s_lo + 1 - m, col2, se2);
+
+            for (int S = s_lo; S <= s_hi; ++S) {
+                if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
+                const int n = S - m;
+                const bool on = any && n >= n0 && n <= n9;
+                const int4 col = col1; const int sigE = se1;
+                col1 = col2; se1 = se2;
+                ld_col(n + 2, col2, se2);
+                if (__ballot(on) == 0) continue;
+                const int r = n - 3 * m, e = r - lw + 3;
+                St h = lds_get(e, 0), f = lds_get(e, 1);
+                const St hq = h;                                    // the entry as the cell found it
+                const St u1 = lds_get(e + 1, 0), u2 = lds_get(e + 2, 0), u3 = lds_get(e + 3, 0), fu = lds_get(e + 3, 1);
+                const St l1 = lds_get(e - 1, 0), l2 = lds_get(e - 2, 0), l3 = lds_get(e - 3, 0);
+                if (on && !seeded && !b_exgl && m == al) {          // (the queue slot of column n0 + 2)
+                    ec = hq;
+                    if (UDH) ec.v += gw3; else ec.v = gw3;
+                }
+                seeded = seeded || on;
+                int mxk = 0;                                        // which state holds the running maximum: 0 H, 1 E, 2 F
+                auto val_of = [&](int k) { return k == 0 ? h.v : (k == 1 ? ea.v : f.v); };
+                if (m != al) {
+                    // match: the codon ending here against my residue
+                    if (n < bl + 3) h = black;
+                    else {
+                        h.v += prof0[(col.x >> 16) & 0xff] + sigE;
+                        h.d = (UDH ? (hq.d & T_DIAG) != 0 : is_kind(hq.d, M_DIAG)) ? T_DIAG : T_NEWD;
+                    }
+                    // deletion: extend, or open after a frame shift of 2 / 1 nt or after a whole codon
+                    const int stay = fu.v + gep;
+                    const int x2 = u1.v + (is_kind(u1.d, M_VERT) ? ge1 : gw1);
+                    const int x1 = u2.v + (is_kind(u2.d, M_VERT) ? ge2 : gw2);
+                    const int x0 = u3.v + gw3;
+                    St nf = fu; nf.v = stay; nf.d = T_VERT;
+                    if (x2 > nf.v) { nf = u1; nf.v = x2; nf.d = T_SLA2; }
+                    if (x1 > nf.v) { nf = u2; nf.v = x1; nf.d = T_SLA1; }
+                    if (x0 >= nf.v) { nf = u3; nf.v = x0; nf.d = T_VERT; }
+                    f = nf;
+                    if (UDH ? (f.v >= h.v) : (f.v > h.v)) mxk = 2;
+                }
+                if (on) {
+                    // insertion: a whole codon (extend or open), 2 nt, 1 nt
+                    if (n > n0 + 2) {
+                        const int x = l3.v + gw3;
+                        ea.v += gep;
+                        if (x > ea.v) { ea = l3; ea.v = x; }
+                        ea.v += sigE;
+                        ea.d = (ea.d & T_SPIN) + T_HORI;
+                    }
+                    if (n > n0 + 1) {
+                        const int x = l2.v + gw2;
+                        if (x > ea.v) { ea = l2; ea.v = x; ea.d = UDH ? T_HOR2 : (ea.d & T_SPIN) + T_HOR2; }
+                    }
+                    const int x = l1.v + gw1;
+                    if (x > ea.v) { ea = l1; ea.v = x; ea.d = UDH ? T_HOR1 : (ea.d & T_SPIN) + T_HOR1; }
+                    if (ea.v > val_of(mxk)) mxk = 1;
+                }
+                const unsigned fl = (unsigned) col.x >> 24;
+                // MODE 2 reads `rlst` of the NEXT queue slot
+                const int qslot = on ? (n - n0 + 1) % 3 : 0;
+                auto rl_get = [&]() { return qslot == 0 ? rl0 : (qslot == 1 ? rl1 : rl2); };
+                auto rl_set = [&](int v) { if (qslot == 0) rl0 = v; else if (qslot == 1) rl1 = v; else rl2 = v; };
+
+                // ---- acceptor: the candidates of this column's phase(s) may raise the state they left from
+                bool spj3 = false;
+                const bool acc = on && spj && (fl & 3);
+                if (__ballot(acc)) {
+#pragma unroll 1
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int ph0 = (int) (fl & 3) - 2;
+                        const bool t = acc && (pass == 0 || ((fl & 4) && ph0 == -1));
+                        if (!__ballot(t)) break;
+                        const int phs = pass == 0 ? ph0 : 1;
+                        const int s3 = pass == 0 ? (int) (short) (col.y & 0xffff) : (int) (short) ((unsigned) col.y >> 16);
+                        const int nb = n - phs;
+                        int dn3 = 0, w2 = 7, w3 = 7, fix = 0;
+                        if (t) {
+                            dn3 = cols[nb].w & 15;
+                            if (phs) {                              // the two bases after the acceptor, for a codon the intron splits
+                                const int t2 = tron_at(nb), t3 = tron_at(nb + 1);
+                                w2 = t2 < 32 ? T.mid[t2] : 7; w3 = t3 < 32 ? T.mid[t3] : 7;
+                                if (nb >= br) w2 = 7;
+                                if (phs == -1) fix = prof1[tron_at(n + 1)] + aux[n + 1].z;     // what the next row's match will add anyway
+                            }
+                        }
+                        int sel[3] = {-1, -1, -1};
+#pragma unroll
+                        for (int ph = 0; ph < 3; ++ph) {
+                            const bool tt = t && phs + 1 == ph;
+                            if (!__ballot(tt)) continue;
+                            const Cands<MODE>& C = cl[ph];
+#pragma unroll
+                            for (int l = 0; l < NC; ++l) {
+                                if (!(tt && l <= C.n)) continue;
+                                const int cd = C.x[l] & 3;
+                                if (phs == 1 && cd == 2) continue;
+                                if (nb - C.j[l] < minl) continue;
+                                int x = C.v[l] + intpen_of(nb - C.j[l]) + s3 + T.t53[16 * ((C.x[l] >> 2) & 15) + dn3];
+                                if (cd == 0 && phs) {
+                                    const int w0 = (C.x[l] >> 6) & 7, w1 = (C.x[l] >> 9) & 7;
+                                    const bool ok = w0 < 4 && w1 < 4 && w2 < 4 && w3 < 4;
+                                    if (phs == 1) x += prof0[ok ? T.tron_of[16 * w0 + 4 * w1 + w2] : AMB];
+                                    else x += prof1[ok ? T.tron_of[16 * w1 + 4 * w2 + w3] : AMB] - fix;
+                                }
+                                if (cd == 0) { if (x > h.v) { h.v = x; sel[0] = l; } }
+                                else if (cd == 1) { if (x > ea.v) { ea.v = x; sel[1] = l; } }
+                                else { if (x > f.v) { f.v = x; sel[2] = l; } }
+                            }
+                        }
+                        // the winners, in the order H, E, F
+                        int maxk = 3;
+                        int lnk[3] = {EOU, EOU, EOU};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const bool w = sel[k] >= 0;
+                            if (!__ballot(w)) continue;
+                            int cj = 0, ca = 0, cb = 0, cc = 0, ce = 0;
+#pragma unroll
+                            for (int ph = 0; ph < 3; ++ph)
+                                if (phs + 1 == ph) { cj = pick(sel[k], cl[ph].j); ca = pick(sel[k], cl[ph].a);
+                                                     if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
+                            St& to = k == 0 ? h : (k == 1 ? ea : f);
+                            const int p1 = vadd(w, m, cj + phs, ca);
+                            const int p2 = vadd(w, m, n, p1);
+                            if (w) {
+                                to.d = (k == 0 ? T_DIAG : (k == 1 ? T_HORI : T_VERT)) | T_SPIN;
+                                if (FWD) to.a = p2;
+                                if (UDH) { to.a = max(ca, r); to.b = min(cb, r); to.c = cc; to.e = ce; lnk[k] = ce; }
+                                if (UDH ? (to.v >= val_of(mxk)) : (to.v > val_of(mxk))) { mxk = k; maxk = k; }
+                            }
+                        }
+                        if (UDH && is_imd && t && maxk < 3) {
+                            *IM(iq, HLNK, 0, r) = lnk[maxk];
+                            rl_set(r);
+                            St& mxs = maxk == 0 ? h : (maxk == 1 ? ea : f);
+                            mxs.e = r;
+                            spj3 = true;
+                            if (maxk == 0) {
+                                if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; *IM(iq, HLNK, 1, r) = lnk[1]; }
+                                if (sel[2] >= 0 && f.v > h.v + gop) f.e = r + width;
+                            }
+                        }
+                    }
+                }
+
+                // ---- the cell takes the best state
+                const int y = h.v;
+                St mxs = mxk == 0 ? h : (mxk == 1 ? ea : f);
+                if (FWD || MODE == 0) {
+                    bool opened = false;
+                    if (mxk != 0) h = mxs;
+                    else if (Local && y > hq.v) {
+                        if (LocalL && hq.d == 0 && !(h.d & T_SPIN)) opened = true;
+                        else if (LocalR && on && y > best.v) { best = h; best_m = m; best_n = n; }
+                    }
+                    const int p_open = vadd(on && opened, m - 1, n - 3, 0);
+                    if (FWD && on && opened) h.a = p_open;
+                    const bool reset = LocalL && h.v <= 0;
+                    if (reset) { h.v = 0; h.d = 0; }
+                    const bool turn = on && !reset && h.d == T_NEWD;
+                    const int p_turn = vadd(turn, m - 1, n - 3, h.a);
+                    if (FWD && turn) h.a = p_turn;
+                } else {
+                    if (mxk == 0) {
+                        if (LocalR && on && y > best.v) { best = h; best_m = m; best_n = n; }
+                    } else {
+                        if (mxs.a < r) mxs.a = r;
+                        if (mxs.b > r) mxs.b = r;
+                        if (mxk == 1) ea = mxs; else f = mxs;
+                        h = mxs;
+                    }
+                    if (LocalL && h.v <= 0) { h.v = 0; h.d = 0; h.c = m; h.e = h.a = h.b = r; }
+                }
+                if (mxk == 0) mxs = h;                              // (`mx` is the entry itself: it sees the resets)
+
+                // ---- donor: the states of this cell enter the candidate list(s) of the phase(s) this column can start
+                const int hd = node_of(mxs.d);
+                const bool don = on && spj && ((fl >> 3) & 3);
+                if (__ballot(don)) {
+#pragma unroll 1
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int ph0 = (int) ((fl >> 3) & 3) - 2;
+                        const bool t = don && (pass == 0 || ((fl & 32) && ph0 == -1));
+                        if (!__ballot(t)) break;
+                        const int phs = pass == 0 ? ph0 : 1;
+                        const int nb = n - phs;
+                        int sigJ = 0, packed = 0;
+                        if (t) {
+                            sigJ = aux[nb].w;
+                            const int t0 = tron_at(nb - 2), t1 = tron_at(nb - 1);
+                            int w0 = t0 < 32 ? T.mid[t0] : 7, w1 = t1 < 32 ? T.mid[t1] : 7;
+                            if (nb < P.b_left) w0 = 7;
+                            packed = ((cols[nb].w >> 4) & 15) << 2 | (w0 & 7) << 6 | (w1 & 7) << 9;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const bool cross = phs == 1 && k == 0;          // the intron cuts the codon of the cell above-left
+                            const St& src = cross ? hq : (k == 0 ? h : (k == 1 ? ea : f));
+                            bool tk = t && k >= ((hd == 0 || phs == 1) ? 0 : 1) && src.d && !(src.d & T_SPIN);    // (no orphan exon)
+                            if (tk && !cross && k != hd && hd >= 0) {
+                                int z = mxs.v;
+                                if (hd == 0 || ((k - hd) & 1)) z += (k == 2) ? gop : 0;
+                                if (src.v <= z) tk = false;         // cannot become the better path
+                            }
+                            if (!__ballot(tk)) continue;
+#pragma unroll
+                            for (int ph = 0; ph < 3; ++ph) {
+                                const bool tt = tk && phs + 1 == ph;
+                                if (!__ballot(tt)) continue;
+                                const bool kept = cl[ph].insert(tt, src.v + sigJ, nb, packed | k, src, is_imd ? r : src.e);
+                                // an intermediate row links an insertion that splices out to the last match of its frame
+                                if (UDH && is_imd && kept && k == 1) *IM(iq, HLNK, 0, r) = rl_get();
+                            }
+                        }
+                    }
+                }
+
+                // ---- an intermediate row records where the paths cross it and restarts ranges and links
+                if (UDH && is_imd && on) {
+                    if (hd == 0) rl_set(r);
+                    else if (!spj3 && (hd & 1)) *IM(iq, HLNK, 0, r) = rl_get();
+                    *IM(iq, VLNK, 0, r) = h.e; *IM(iq, LWRB, 0, r) = min(r, h.b); *IM(iq, UPRB, 0, r) = max(r, h.a);
+                    h.b = h.a = r; h.e = r;
+                    *IM(iq, VLNK, 1, r) = f.e; *IM(iq, LWRB, 1, r) = min(r, f.b); *IM(iq, UPRB, 1, r) = max(r, f.a);
+                    f.b = f.a = r; f.e = r + width;
+                }
+                if (on) {
+                    lds_put(e, 0, h);
+                    lds_put(e, 1, f);
+                    const St t = ea; ea = eb; eb = ec; ec = t;      // the next column is the next frame
+                }
+            }
+            WAVE_SYNC();
+            for (int e = res_lo + lane; e < res_hi; e += 64) {
+                const int q = e & (RING - 1);
+#pragma unroll
+                for (int a = 0; a < 2 * NF; ++a) G(a)[e] = L[a][q];
+            }
+        }
+        if (UDH && imd_mask) {
+            const int src = __ffsll((long long) imd_mask) - 1;
+            rl0 = __shfl(rl0, src); rl1 = __shfl(rl1, src); rl2 = __shfl(rl2, src);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+
+    // ---- the end of the alignment: the tracked local maximum, or lastH_ng / hlastH_ng on the last row
+    // staging for the sequential relaxations: entries [e0, e0 + cnt) of H through the LDS arrays, cnt <= RING
+    auto stage_in = [&](int e0, int cnt) {
+        for (int i = lane; i < cnt; i += 64)
+#pragma unroll
+            for (int a = 0; a < NF; ++a) L[a][i] = __builtin_nontemporal_load(G(a) + e0 + i);
+        WAVE_SYNC();
+    };
+    auto stage_out = [&](int e0, int from, int cnt) {
+        WAVE_SYNC();
+        for (int i = from + lane; i < cnt; i += 64)
+#pragma unroll
+            for (int a = 0; a < NF; ++a) G(a)[e0 + i] = L[a][i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    };
+    auto at = [&](int i) { St s = black;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) fld(s, a) = L[a][i];
+        return s; };
+    auto set = [&](int i, St s) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a) L[a][i] = fld(s, a); };
+    auto gload = [&](int r, int isF) { St s = black;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) fld(s, a) = __builtin_nontemporal_load(G(isF * NF + a) + (r - lw + 3));
+        return s; };
+
+    St fin = black;                                                 // the state the alignment ends in
+    int fin_r = br - 3 * ar;
+    int ptr = 0;
+    if (LocalR) {
+        for (int off = 32; off; off >>= 1) {
+            St o;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) fld(o, a) = __shfl_xor(fld(best, a), off);
+            const int om = __shfl_xor(best_m, off), on_ = __shfl_xor(best_n, off);
+            if (o.v > best.v || (o.v == best.v && (om < best_m || (om == best_m && on_ < best_n)))) { best = o; best_m = om; best_n = on_; }
+        }
+    }
+    const bool by_last_row = UDH ? !LocalR : (!LocalR || best_m == ar);
+    if (by_last_row) {
+        const int m3 = 3 * ar, r9 = br - m3;
+        const int r_in = max(lw, bl - m3);                          // first entry of the last row
+        int mx_r = r9, mx_v = gload(r9, 0).v;
+        if (a_exgr) {
+            // trailing gap on the genomic side: per frame, every entry may be reached from the one a codon below it --
+            // sequential (each entry sees its predecessor as already relaxed), one lane over staged chunks
+            int glen0 = 0, glen1 = 0, glen2 = 0;
+            constexpr int CH = RING - 3;
+            for (int c0 = r_in; c0 <= r9; c0 += CH) {
+                const int cnt = min(CH, r9 - c0 + 1);
+                const int back = c0 - r_in >= 3 ? 3 : 0;            // relaxed entries below the chunk come along
+                stage_in(c0 - back - lw + 3, cnt + back);
+                for (int i = 0; i < cnt; ++i) {
+                    const int r = c0 + i, t = r - r_in, ph = t % 3, n = r + m3;
+                    bool rec = false; int rec_p = 0;
+                    if (lane == 0) {
+                        int& glen = ph == 0 ? glen0 : (ph == 1 ? glen1 : glen2);
+                        glen += 3;
+                        St h = at(i + back);
+                        int c1 = NEV, c2 = NEV;
+                        St below = black;
+                        if (t >= 3) {
+                            below = at(i + back - 3);
+                            if (below.d != T_DEAD) {
+                                c1 = below.v + aux[n - 2].z;
+                                if (!(a_exgr & 2)) c1 += gext3(glen);
+                                if (!(a_exgr & 1) && glen == 3) c1 += gop;
+                                const bool stop_ok = UDH ? sc->term_codon != 0 : aux[n - 2].y > 0;
+                                if (stop_ok && !(h.d & T_SPIN)) c2 = below.v + aux[n - 2].y;
+                            }
+                        }
+                        const int s5 = (Local && aux[n].w > 0) ? aux[n].w : 0;
+                        const int c0v = h.v + s5;
+                        c1 += s5;
+                        if (c2 > c0v && c2 > c1) {                  // a stop codon ends the alignment here
+                            h = below; h.d = T_DEAD; h.v = c2;
+                            if (UDH) h.a = max(r, h.a);
+                            if (FWD && r != mx_r && h.v > mx_v) { rec = true; rec_p = h.a; }
+                        } else if (c1 > c0v) { h = below; h.d = T_HORI; h.v = c1 - s5; }
+                        else if (!is_kind(h.d, M_HORI)) glen = 0;
+                        set(i + back, h);
+                    }
+                    const int p = vadd(rec, ar, r + m3 - 3, rec_p);
+                    if (lane == 0) {
+                        St h = at(i + back);
+                        if (rec) { h.a = p; set(i + back, h); }
+                        if (r == mx_r) mx_v = h.v;
+                        else if (h.v > mx_v) { mx_r = r; mx_v = h.v; }
+                    }
+                }
+                stage_out(c0 - back - lw + 3, back, cnt + back);
+            }
+        } else {
+            // a global genomic end: only a stop codon may follow the last residue
+            if (lane == 0) {
+                const St below = gload(r9 - 3, 0);
+                St h9 = gload(r9, 0);
+                const int y = below.v + aux[br - 2].y;
+                if (y > h9.v) {
+                    h9 = below; h9.v = y; h9.d = T_HORI;
+                    if (UDH) h9.a = max(r9, h9.a);
+                    put(r9 - lw + 3, 0, h9);
+                    mx_v = y;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        }
+        mx_r = __shfl(mx_r, 0); mx_v = __shfl(mx_v, 0);
+        bool from_f = false;
+        if (b_exgr == 1) {
+            const int r_top = min(up, br - 3 * al);
+            if (UDH) {
+                // trailing gap on the query side, MODE 2: a frame-shifted end pays once -- the first best in descending order
+                int bv = mx_v, bk = INT32_MAX;
+                for (int i = lane; i < r_top - r9; i += 64) {
+                    const int r = r_top - i;
+                    const int x = gload(r, 0).v + ((r % 3) ? A.extragop : 0);
+                    if (x > bv) { bv = x; bk = i; }
+                }
+                for (int off = 32; off; off >>= 1) {
+                    const int ov = __shfl_xor(bv, off), ok = __shfl_xor(bk, off);
+                    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+                }
+                if (bk != INT32_MAX) { mx_r = r_top - bk; mx_v = bv; }
+            } else {
+                // MODE 0 / 1: per frame a running gap from the entries above, closed wherever an entry beats it;
+                // sequential downwards (it rewrites the values it later reads), one lane over staged chunks
+                int g0v = NEV, g1v = NEV, g2v = NEV;
+                constexpr int CH = RING - 3;
+                for (int c1 = r_top - 3; c1 >= r9; c1 -= CH) {
+                    const int cnt = min(CH, c1 - r9 + 1);
+                    const int c0 = c1 - cnt + 1;
+                    stage_in(c0 - lw + 3, cnt + 3);
+                    if (lane == 0) {
+                        for (int i = cnt - 1; i >= 0; --i) {
+                            const int r = c0 + i, ph = (r_top - 3 - r) % 3;
+                            int& g = ph == 0 ? g0v : (ph == 1 ? g1v : g2v);
+                            int x = L[0][i + 3];
+                            if (!(b_exgr & 1)) x += gop;
+                            if (x > g) g = x;
+                            if (!(b_exgr & 2)) g += gep;
+                            if (L[0][i] > g) g = NEV;
+                            else if (g > mx_v) { mx_r = r; mx_v = g; L[0][i] = g; }
+                        }
+                    }
+                    stage_out(c0 - lw + 3, 0, cnt);
+                }
+                mx_r = __shfl(mx_r, 0); mx_v = __shfl(mx_v, 0);
+            }
+        } else if (b_exgr == 2) {
+            from_f = true; mx_r = r9;
+        }
+        fin = gload(mx_r, from_f ? 1 : 0);
+        if (!from_f) fin.v = mx_v;
+        fin_r = from_f ? mx_r + width : mx_r;                        // (the reference measures an F entry from the H array)
+        if (FWD) {
+            int rf = ar, rw = br;
+            if (!from_f) {
+                int pp = mx_r - r9;
+                if (pp > 0) { rf -= (pp + 2) / 3; if (pp %= 3) rw -= 3 - pp; }
+                else if (pp < 0) rw += pp;
+            }
+            ptr = __shfl(vadd(lane == 0, rf, rw, fin.a), 0);
+        }
+    } else {
+        fin = best;
+        if (FWD) ptr = __shfl(vadd(lane == 0, best_m, best_n, best.a), 0);
+    }
+
+    if (!UDH) {
+        DevResultH R;
+        R.score = fin.v; R.mr = ar; R.nr = br; R.maxt = 0; R.maxr = 0; R.pad[0] = R.pad[1] = R.pad[2] = 0;
+        if (!FWD) { if (lane == 0) A.res[pi] = R; return; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const bool over_any = __any(vover);
+        if (lane == 0) {
+            // Vmf::traceback(ptr) + the boundary record of trcbkalignH_ng
+            int2* out = A.skl + (int64_t) pi * A.skl_cap;
+            int cnt = 0, status = over_any ? -3 : 0;
+            if (ptr > 0 && ptr < vcount && !status) {
+                int3 sv = vrec[ptr];
+                int lm = 0, ln = 0;
+                for (;;) {
+                    if (cnt < A.skl_cap) out[cnt] = make_int2(sv.x, sv.y); else status = -1;
+                    lm = sv.x; ln = sv.y; ++cnt;
+                    if (!sv.z) break;
+                    if (sv.z < 0 || sv.z >= vcount || cnt > vcount) { status = -2; break; }
+                    sv = vrec[sv.z];
+                }
+                const int rd = Local ? 0 : ((ln - 3 * lm) - bl + 3 * al);
+                if (rd) {
+                    const int2 rec = rd > 0 ? make_int2(al, bl + rd) : make_int2(al - rd / 3, bl);
+                    if (cnt < A.skl_cap) out[cnt] = rec; else status = -1;
+                    ++cnt;
+                }
+            }
+            A.n_skl[pi] = status ? status : cnt;
+            A.res[pi] = R;
+        }
+        return;
+    }
+
+    // ---- MODE 2: the end cell, then the links back through the intermediate rows (one cpos row each)
+    if (lane != 0) return;
+    int flag = 0, score = fin.v;
+    if (LocalR) {
+        int i = n_im;
+        while (--i >= 0 && mi_of(i) > ar) ;
+        ar = best_m; br = best_n;
+        if (i < 0) i = 0;
+        CPOS(i, 8) = fin.b;
+        CPOS(i, 9) = fin.a;
+    } else {
+        const int rr = br - 3 * ar;
+        if (b_exgr && rr < fin_r) ar = (br - fin_r) / 3;
+        if (a_exgr && rr > fin_r) br = 3 * ar + fin_r;
+    }
+    int i = n_im;
+    while (--i >= 0 && mi_of(i) > ar) ;
+    if (i < 0 && mi_of(0) > ar) CPOS(0, 2) = br;
+    int r = br - 3 * ar;
+    CPOS(i + 1, 8) = min(fin.b, r);
+    CPOS(i + 1, 9) = max(fin.a, r);
+    r = fin.e;
+    for ( ; i >= 0 && mi_of(i) > fin.c; --i) {
+        int c = 0, d = 0;
+        for ( ; r > up; r -= width) ++d;                            // links into the F array carry + width
+        if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
+        const int mi = mi_of(i);
+        if (*IM(i, VLNK, d, r) < EOU) {
+            CPOS(i, c++) = mi;
+            CPOS(i, c++) = (d > 0) ? 1 : 0;
+            const int mm3 = 3 * mi;
+            for (int rp = *IM(i, HLNK, d, r); lw <= rp && rp < up && r != rp; rp = *IM(i, HLNK, 0, r = rp)) {
+                if (c >= 6) { flag = -3; break; }
+                CPOS(i, c++) = r + mm3;
+            }
+            if (flag) break;
+            CPOS(i, c++) = r + mm3;
+            CPOS(i, c) = EOU;
+            CPOS(i, 8) = *IM(i, LWRB, d, r);
+            CPOS(i, 9) = *IM(i, UPRB, d, r);
+            r = *IM(i, VLNK, d, r);
+            if (r == EOU) break;
+        } else
+            CPOS(i, 0) = EOU;
+    }
+    if (!flag) {
+        for ( ; r > up; r -= width) ;
+        if (LocalL) { al = fin.c; bl = r + 3 * fin.c; }
+        else {
+            const int rl = bl - 3 * al;
+            if (b_exgl && rl > r) {
+                al = (bl - r) / 3;
+                for (int j = 0; j < n_im && mi_of(j) < al; ++j) CPOS(j, 0) = EOU;
+            }
+            if (a_exgl && rl < r) bl = 3 * al + r;
+        }
+        ++i;
+        if ((i < n_im && mi_of(i) < al) || CPOS(i, 2) < bl) score = NEV;
+        else if (CPOS(i, 8) == EOU || CPOS(i, 9) == EOU) flag = -3;
+        else {
+            r = bl - 3 * al;
+            CPOS(i, 8) = min(r, CPOS(i, 8));
+            CPOS(i, 9) = max(r, CPOS(i, 9));
+        }
+    }
+#undef CPOS
+    A.scores[pi] = score;
+    A.ranges[4 * pi] = al; A.ranges[4 * pi + 1] = ar; A.ranges[4 * pi + 2] = bl; A.ranges[4 * pi + 3] = br;
+    DevResultH R;
+    R.score = score; R.mr = ar; R.nr = br; R.maxt = 0; R.maxr = 0; R.pad[0] = flag; R.pad[1] = R.pad[2] = 0;
+    A.res[pi] = R;
+}
+
+extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t stream)
+{
+    HScalarArgs A = *a;
+    const dim3 grd((A.n_probs + WPB - 1) / WPB), blk(64 * WPB);
+    if (forward) hipLaunchKernelGGL(spdh_rowwave<1>, grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL(spdh_rowwave<0>, grd, blk, 0, stream, A);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t stream)
+{
+    HScalarArgs A = *a;
+    hipLaunchKernelGGL(spdh_rowwave<2>, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    return hipGetLastError();
+}

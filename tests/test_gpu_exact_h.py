@@ -27,8 +27,10 @@ def eng():
 def test_align_a1_goldens(eng):
     """alignH_ng with scalar_engines = 2 against the reference's -A1 run on every protein fixture (a third of
     them differ from both the -A0 and the -A2 result)"""
-    for local in (False, True):
-        cases = [(_name(f), spdg.load(f)) for f in H_FILES if bool(spdg.load(f)["prm"]["local"]) == local]
+    for local, fam in ((lo, fa) for lo in (False, True) for fa in (golden_files("h1_"), golden_files("c1_"))):
+        cases = [(_name(f), spdg.load(f)) for f in fam if bool(spdg.load(f)["prm"]["local"]) == local]
+        if not cases:
+            continue
         ref = max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size)
         key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
         for vmf, ubh, sh in sorted({key(fx) for _, fx in cases}):

@@ -9,7 +9,7 @@ from spaln_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
 
-H_FILES = golden_files("h1_") + golden_files("c1_")      # c1_: dictdisc proteins, species tables (BASELINE config 1)
+H_FILES = golden_files("h1_")
 UNDEFINED = {"h1_cut_right", "h1_random"}     # the reference starts its traceback outside its bitmap
 LOCAL = {"h1_local", "h1_local_udh"}          # -LS: its own kernel variants, run separately
 BELOW_8 = {"h1_tiny_m3", "h1_tiny_m5", "h1_tiny_m7"}   # every dispatch sends these to the scalar engine

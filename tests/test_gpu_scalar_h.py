@@ -1,5 +1,5 @@
 """GPU parity of the scalar aa x genome engine (spdp_scalar_forward_h = forwardH_ng + trcbkalignH_ng's
-record hand-over, spdp_h_scalar.hip) and of the below-8-rows branch of the dispatch, against the
+record hand-over, spdp_h_rowwave.hip) and of the below-8-rows branch of the dispatch, against the
 reference's -A0 goldens and the oracle."""
 import numpy as np
 import pytest
@@ -11,6 +11,7 @@ from spaln_amd import abi, synth
 pytestmark = pytest.mark.gpu
 
 H_FILES = golden_files("h1_") + golden_files("c1_")      # c1_: dictdisc proteins, species tables (BASELINE config 1)
+FAMILIES = [golden_files("h1_"), golden_files("c1_")]    # one parameter set (scoring) per family
 
 
 def _name(f):
@@ -25,37 +26,40 @@ def eng():
     e.close()
 
 
-def _batch(local):
-    cases = [(_name(f), spdg.load(f)) for f in H_FILES if bool(spdg.load(f)["prm"]["local"]) == local]
-    sc = spdg.scoring_h(max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size))
-    ps = abi.ProblemSetH()
-    for _, fx in cases:
-        spdg.problem_h(fx, ps)
-    return cases, sc, ps
+def _batches(local):
+    for fam in FAMILIES:
+        cases = [(_name(f), spdg.load(f)) for f in fam if bool(spdg.load(f)["prm"]["local"]) == local]
+        if not cases:
+            continue
+        sc = spdg.scoring_h(max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size))
+        ps = abi.ProblemSetH()
+        for _, fx in cases:
+            spdg.problem_h(fx, ps)
+        yield cases, sc, ps
 
 
 @pytest.mark.parametrize("local", [False, True])
 def test_scores_against_reference_a0(eng, local):
     """HomScoreH_ng under -A0 = forwardH_ng without a Vmf: every fixture, one batch"""
-    cases, sc, ps = _batch(local)
-    res = eng.scalar_forward_h(sc, ps, traceback=False)
-    bad = [(name, s, int(fx["hom_scr_A0"][0])) for (name, fx), (s, _) in zip(cases, res)
-           if s != int(fx["hom_scr_A0"][0])]
-    assert not bad, bad
+    for cases, sc, ps in _batches(local):
+        res = eng.scalar_forward_h(sc, ps, traceback=False)
+        bad = [(name, s, int(fx["hom_scr_A0"][0])) for (name, fx), (s, _) in zip(cases, res)
+               if s != int(fx["hom_scr_A0"][0])]
+        assert not bad, bad
 
 
 @pytest.mark.parametrize("local", [False, True])
 def test_records_against_oracle(eng, local):
     """raw Mfile records of trcbkalignH_ng's scalar branch (the oracle is pinned on the -A0 alignments)"""
     from oracle import oracle
-    cases, sc, ps = _batch(local)
-    res = eng.scalar_forward_h(sc, ps)
-    bad = []
-    for (name, fx), p, (s, skl) in zip(cases, ps.items, res):
-        ws, wskl = oracle.scalar_forward_h(sc, p)
-        if s != ws or skl.tolist() != wskl.tolist():
-            bad.append((name, s, ws, skl.ravel().tolist()[:12], wskl.ravel().tolist()[:12]))
-    assert not bad, bad[:4]
+    for cases, sc, ps in _batches(local):
+        res = eng.scalar_forward_h(sc, ps)
+        bad = []
+        for (name, fx), p, (s, skl) in zip(cases, ps.items, res):
+            ws, wskl = oracle.scalar_forward_h(sc, p)
+            if s != ws or skl.tolist() != wskl.tolist():
+                bad.append((name, s, ws, skl.ravel().tolist()[:12], wskl.ravel().tolist()[:12]))
+        assert not bad, bad[:4]
 
 
 @pytest.mark.parametrize("alg", [2, 3])
@@ -117,11 +121,11 @@ def test_small_subranges_against_oracle(eng):
 
 # ---- -A0 mode: hirschbergH_ng and the scalar ladder ---------------------------------------------
 def test_align_a0_goldens(eng):
-    """alignH_ng / HomScoreH_ng with SpdpScoringH.scalar_engines = 1 against the reference's -A0 output.
-    (One GPU thread per problem: the 400 / 450 aa fixtures take minutes and stay with the CPU suite.)"""
-    for local in (False, True):
-        cases = [(_name(f), spdg.load(f)) for f in H_FILES if bool(spdg.load(f)["prm"]["local"]) == local]
-        cases = [(n, fx) for n, fx in cases if fx["prm"]["a_right"] - fx["prm"]["a_left"] <= 330]
+    """alignH_ng / HomScoreH_ng with SpdpScoringH.scalar_engines = 1 against the reference's -A0 output"""
+    for local, fam in ((lo, fa) for lo in (False, True) for fa in FAMILIES):
+        cases = [(_name(f), spdg.load(f)) for f in fam if bool(spdg.load(f)["prm"]["local"]) == local]
+        if not cases:
+            continue
         ref = max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size)
         key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
         for vmf, ubh, sh in sorted({key(fx) for _, fx in cases}):

@@ -199,6 +199,24 @@ int spdp_align_s_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem
                       int n_probs, SpdpAlignment* out, int32_t* orient);
 void spdp_free_alignments(SpdpAlignment* out, int n);
 
+/* Aln2s1::lspS_ng (src/fwd2s1.cc:1817-1880) for a caller that keeps the record file itself -- the seeded path's
+ * interpolateS (:2497-2514): the ladder below spdp_align_s, but out[i].skl holds the Mfile records as written (n_skl of
+ * them, no header record, in no particular order: globalS_ng's stdskl sorts) and nothing is trimmed. */
+int spdp_lsp_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
+
+/* ---- batching of single-problem calls from many host threads ----------------------------------
+ * The reference's seeded path walks one query per CPU thread and calls lspS_ng synchronously for the gaps between
+ * HSPs; its thread pool runs many walks at once.  A collector owns `ctx` (do not use it elsewhere meanwhile) and one
+ * scoring bundle; spdp_collector_align_s blocks the calling thread until the batch its problem joined has run:
+ * a batch closes at max_batch problems or max_wait_us after its first arrival.  raw_records = 1: spdp_lsp_s results,
+ * 0: spdp_align_s results.  Returns 0, 1 (this query came back without an alignment, see spdp_align_s) or -1. */
+typedef struct SpdpCollector SpdpCollector;
+SpdpCollector* spdp_collector_create(SpdpContext* ctx, const SpdpScoring* sc, int max_batch, int max_wait_us, int raw_records);
+void spdp_collector_destroy(SpdpCollector* c);
+int spdp_collector_align_s(SpdpCollector* c, const SpdpProblem* p, SpdpAlignment* out);
+const char* spdp_collector_last_error(const SpdpCollector* c);
+int spdp_collector_stats(SpdpCollector* c, int64_t* n_requests, int64_t* n_batches, int64_t* largest_batch);
+
 /* stdskl (m_unit 1) / stdskl3 (m_unit 3), src/gaps.cc:140-227: corner list of n path records in any order;
  * out[] needs 2 n + 1 entries, returns the number written.  Host only (no device work). */
 int spdp_corner_list(const SpdpSkl* recs, int n, int m_unit, SpdpSkl* out);

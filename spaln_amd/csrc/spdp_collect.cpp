@@ -1,0 +1,111 @@
+// spdp_collect.cpp -- SpdpCollector: turns the one-problem-at-a-time calls of many host threads into device batches.
+//
+// The reference's seeded path (seededS_ng -> interpolateS, src/fwd2s1.cc:2405-2672) walks the HSPs of ONE query on ONE
+// CPU thread and calls lspS_ng / trcbkalignS_ng synchronously for every gap it cannot close by other means; spaln's
+// thread pool (-t, src/spaln.cc:1560-1640) runs many such walks at once.  A shim that replaces lspS_ng by a device call
+// would therefore issue thousands of single-problem launches.  The collector is the piece in between: every worker
+// thread calls spdp_collector_align_s() with its one problem and blocks; a dispatcher thread gathers what has arrived
+// (up to max_batch problems, or whatever is there max_wait_us after the first arrival), runs ONE batch through the
+// ladder on the context it owns, hands each caller its result and wakes it.  Problems only borrow the caller's buffers
+// for the duration of its call.
+#include "spdp_internal.h"
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct SpdpCollector {
+    SpdpContext* ctx = nullptr;
+    SpdpScoring sc;
+    std::vector<int16_t> intpen;                // own copy of the length-penalty table
+    int max_batch = 256, max_wait_us = 200, raw = 0;
+    struct Req { const SpdpProblem* p; SpdpAlignment* out; int rc = 0; bool done = false; };
+    std::mutex mu;
+    std::condition_variable cv_req, cv_done;
+    std::deque<Req*> queue;
+    std::chrono::steady_clock::time_point first_arrival;
+    bool stop = false;
+    std::thread worker;
+    std::string err;
+    int64_t n_requests = 0, n_batches = 0, largest = 0;
+
+    void loop()
+    {
+        (void) hipSetDevice(ctx->device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_req.wait(lk, [&] { return stop || !queue.empty(); });
+            if (queue.empty()) { if (stop) return; continue; }
+            // a batch closes when it is full, when its first request has waited long enough, or at shutdown
+            const auto deadline = first_arrival + std::chrono::microseconds(max_wait_us);
+            cv_req.wait_until(lk, deadline, [&] { return stop || (int) queue.size() >= max_batch; });
+            std::vector<Req*> take;
+            while (!queue.empty() && (int) take.size() < max_batch) { take.push_back(queue.front()); queue.pop_front(); }
+            if (!queue.empty()) first_arrival = std::chrono::steady_clock::now();
+            lk.unlock();
+            std::vector<SpdpProblem> probs(take.size());
+            std::vector<SpdpAlignment> outs(take.size());
+            for (size_t i = 0; i < take.size(); ++i) probs[i] = *take[i]->p;
+            const int rc = raw ? spdp_lsp_s(ctx, &sc, probs.data(), (int) probs.size(), outs.data())
+                               : spdp_align_s(ctx, &sc, probs.data(), (int) probs.size(), outs.data());
+            lk.lock();
+            if (rc) err = ctx->err;
+            ++n_batches; n_requests += (int64_t) take.size(); largest = std::max<int64_t>(largest, (int64_t) take.size());
+            for (size_t i = 0; i < take.size(); ++i) {
+                *take[i]->out = outs[i];        // ownership of skl passes to the caller (spdp_free_alignments)
+                // rc 1 = some queries of the batch came back without an alignment: only those report it
+                take[i]->rc = rc < 0 ? -1 : ((rc == 1 && !outs[i].skl) ? 1 : 0);
+                take[i]->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" SpdpCollector* spdp_collector_create(SpdpContext* ctx, const SpdpScoring* sc, int max_batch, int max_wait_us, int raw_records)
+{
+    if (!ctx || !sc) return nullptr;
+    SpdpCollector* c = new SpdpCollector;
+    c->ctx = ctx; c->sc = *sc;
+    if (sc->intpen && sc->intpen_len > 0) { c->intpen.assign(sc->intpen, sc->intpen + sc->intpen_len); c->sc.intpen = c->intpen.data(); }
+    c->max_batch = std::max(1, max_batch); c->max_wait_us = std::max(0, max_wait_us); c->raw = raw_records ? 1 : 0;
+    c->worker = std::thread([c] { c->loop(); });
+    return c;
+}
+
+extern "C" void spdp_collector_destroy(SpdpCollector* c)
+{
+    if (!c) return;
+    { std::lock_guard<std::mutex> g(c->mu); c->stop = true; }
+    c->cv_req.notify_all();
+    if (c->worker.joinable()) c->worker.join();
+    delete c;
+}
+
+extern "C" int spdp_collector_align_s(SpdpCollector* c, const SpdpProblem* p, SpdpAlignment* out)
+{
+    if (!c || !p || !out) return -1;
+    SpdpCollector::Req r;
+    r.p = p; r.out = out;
+    std::unique_lock<std::mutex> lk(c->mu);
+    if (c->stop) return -1;
+    if (c->queue.empty()) c->first_arrival = std::chrono::steady_clock::now();
+    c->queue.push_back(&r);
+    c->cv_req.notify_all();
+    c->cv_done.wait(lk, [&] { return r.done; });
+    return r.rc;
+}
+
+extern "C" const char* spdp_collector_last_error(const SpdpCollector* c) { return c ? c->err.c_str() : "null collector"; }
+
+extern "C" int spdp_collector_stats(SpdpCollector* c, int64_t* n_requests, int64_t* n_batches, int64_t* largest_batch)
+{
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_requests) *n_requests = c->n_requests;
+    if (n_batches) *n_batches = c->n_batches;
+    if (largest_batch) *largest_batch = c->largest;
+    return 0;
+}

@@ -188,6 +188,7 @@ struct Aligner {
     ChunkGate* gate_in = nullptr;               // the chunk before mine / mine
     ChunkGate* gate_out = nullptr;
     SpdpAlignment* out = nullptr;               // where the chunk's alignments go (may be null)
+    bool raw = false;                           // lspS_ng level: hand the Mfile records over as they are
     std::vector<Job> jobs;
     std::vector<LspItem> pending;
     std::vector<TbItem> tbs;                    // forwardS1_wip calls
@@ -545,6 +546,13 @@ struct Aligner {
         const Job& J = jobs[i];
         out->score = J.score_set ? J.score : SPDP_NEVSEL;
         out->n_skl = 0; out->skl = nullptr;
+        if (raw) {                              // what lspS_ng appended to the caller's Mfile (no header, any order)
+            if (J.failed || J.rec.empty()) return;
+            out->n_skl = (int) J.rec.size();
+            out->skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * J.rec.size());
+            memcpy(out->skl, J.rec.data(), sizeof(SpdpSkl) * J.rec.size());
+            return;
+        }
         if (J.failed || (int) J.rec.size() < 2) return;
         std::vector<SpdpSkl> s = corner_list<1>(J.rec);
         trim_skl(s, probs[i]);
@@ -613,7 +621,7 @@ int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms)
 
 static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n,
                           SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells,
-                          double* stats = nullptr)
+                          double* stats = nullptr, bool raw = false)
 {
     // big batches run as chunks on lanes of the context, a software pipeline (ChunkGate); SPDP_CHUNKS=1 turns it off
     int n_chunks = n >= 4096 ? 2 : 1;
@@ -631,6 +639,7 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
         a.n = (int) ((int64_t) n * (c + 1) / n_chunks) - a.base;
         a.probs = probs + a.base;
         a.out = out ? out + a.base : nullptr;
+        a.raw = raw;
         if (n_chunks > 1) {
             if (hipEventCreateWithFlags(&gates[c].ev, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate"; return -1; }
             a.gate_out = &gates[c];
@@ -689,6 +698,18 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
     return align_on_store(ctx, &st, probs, n_probs, out, nullptr, nullptr);
+}
+
+// Aln2s1::lspS_ng (src/fwd2s1.cc:1817-1880) for a caller that keeps the record file itself (seededS_ng / interpolateS):
+// the whole ladder below it, records as written (out[i].skl has no header record; globalS_ng's stdskl sorts them)
+int spdp_lsp_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, SpdpAlignment* out)
+{
+    if (!ctx || !sc || !out) return -1;
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    if (n_probs <= 0) return 0;
+    DevStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    return align_on_store(ctx, &st, probs, n_probs, out, nullptr, nullptr, nullptr, true);
 }
 
 // alignS_ng(seqs, pwd, gsi, ori = 3) with seeding off (src/fwd2s1.cc:2746-2760): infer_orientation

@@ -87,6 +87,14 @@ def load_library() -> C.CDLL:
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_poll.argtypes = [C.c_void_p]
     lib.spdp_wait.argtypes = [C.c_void_p]
+    lib.spdp_lsp_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_collector_create.restype = C.c_void_p
+    lib.spdp_collector_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.spdp_collector_destroy.argtypes = [C.c_void_p]
+    lib.spdp_collector_align_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_collector_last_error.restype = C.c_char_p
+    lib.spdp_collector_last_error.argtypes = [C.c_void_p]
+    lib.spdp_collector_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.spdp_group_create.restype = C.c_void_p
     lib.spdp_group_create.argtypes = [C.c_void_p, C.c_int]
     lib.spdp_group_destroy.argtypes = [C.c_void_p]
@@ -96,6 +104,37 @@ def load_library() -> C.CDLL:
     for f in ("spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return lib
+
+
+class Collector:
+    """SpdpCollector: single-problem calls from many host threads, run as device batches.
+    Owns the engine's context while it lives; align_s() may be called from any number of threads."""
+
+    def __init__(self, eng: "Engine", sc: abi.Scoring, max_batch: int = 256, max_wait_us: int = 200, raw: bool = False):
+        self.eng, self.lib, self._sc = eng, eng.lib, sc
+        self.h = self.lib.spdp_collector_create(eng.ctx, C.byref(sc), int(max_batch), int(max_wait_us), 1 if raw else 0)
+        if not self.h:
+            raise RuntimeError("spdp_collector_create failed")
+        self.raw = raw
+
+    def align_s(self, p: abi.Problem):
+        out = abi.Alignment()
+        rc = self.lib.spdp_collector_align_s(self.h, C.byref(p), C.byref(out))
+        if rc < 0:
+            raise RuntimeError("spdp_collector_align_s: " + self.lib.spdp_collector_last_error(self.h).decode())
+        skl = np.array([(out.skl[i].m, out.skl[i].n) for i in range(out.n_skl)], dtype=np.int32).reshape(-1, 2)
+        self.lib.spdp_free_alignments(C.byref(out), 1)
+        return int(out.score), skl
+
+    def stats(self) -> dict:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.spdp_collector_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(requests=a.value, batches=b.value, largest=c.value)
+
+    def close(self):
+        if self.h:
+            self.lib.spdp_collector_destroy(self.h)
+            self.h = None
 
 
 class Group:
@@ -219,6 +258,16 @@ class Engine:
             skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)],
                            dtype=np.int32).reshape(-1, 2)
             res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
+
+    def lsp_s(self, sc, ps):
+        """lspS_ng level: (score, raw Mfile records) per problem"""
+        n = len(ps)
+        arr = (abi.Alignment * n)()
+        self._check(self.lib.spdp_lsp_s(self.ctx, C.byref(sc), ps.array(), n, arr), "spdp_lsp_s")
+        res = [(int(a.score), np.array([(a.skl[i].m, a.skl[i].n) for i in range(a.n_skl)], dtype=np.int32).reshape(-1, 2))
+               for a in arr]
         self.lib.spdp_free_alignments(arr, n)
         return res
 

@@ -242,7 +242,7 @@ struct HFwdOut {
     int64_t cells = 0, tb_elems = 0;
 };
 
-static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, HFwdOut& out)
+static int run_forward_group(HStore& st, const std::vector<HItem>& items, bool walk, HFwdOut& out)
 {
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[H_POOL];
@@ -337,6 +337,41 @@ static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, H
     for (int i = 0; i < nr; ++i) {
         const int s = slot_of[i];
         std::copy(skl.begin() + off[s], skl.begin() + off[s + 1], out.skl.begin() + out.off[i]);
+    }
+    return 0;
+}
+
+// the traceback bitmaps (2 B per cell of the reference's skewed layout, ~9 MB for a 400 aa query on a 12 kb window) bound
+// how many problems one launch can hold: a list whose bitmaps exceed the budget (SPDP_H_TB_GB, default 160 GiB of the
+// 288) runs as consecutive groups, each a full sweep + walk; results come back in item order either way
+static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, HFwdOut& out)
+{
+    double gb = 160.0;
+    if (const char* e = getenv("SPDP_H_TB_GB")) gb = std::max(0.001, atof(e));
+    const int64_t budget = (int64_t) (gb * 1073741824.0 / 2.0);             // elements
+    const int nr = (int) items.size();
+    std::vector<int> cut(1, 0);
+    int64_t acc = 0;
+    for (int i = 0; i < nr; ++i) {
+        const int64_t mw = items[i].a_right - items[i].a_left + 1;
+        const int64_t el = mw * ((int64_t) items[i].b_right - items[i].b_left + 1 + 3 * mw) + 104;
+        if (acc && acc + el > budget) { cut.push_back(i); acc = 0; }
+        acc += el;
+    }
+    cut.push_back(nr);
+    if (cut.size() == 2) return run_forward_group(st, items, walk, out);
+    out = HFwdOut();
+    out.off.assign(1, 0);
+    for (size_t g = 0; g + 1 < cut.size(); ++g) {
+        std::vector<HItem> part(items.begin() + cut[g], items.begin() + cut[g + 1]);
+        HFwdOut po;
+        if (run_forward_group(st, part, walk, po)) return -1;
+        out.res.insert(out.res.end(), po.res.begin(), po.res.end());
+        out.n_skl.insert(out.n_skl.end(), po.n_skl.begin(), po.n_skl.end());
+        const int64_t base = out.off.back();
+        for (size_t i = 1; i < po.off.size(); ++i) out.off.push_back(base + po.off[i]);
+        out.skl.insert(out.skl.end(), po.skl.begin(), po.skl.end());
+        out.sweep_ms += po.sweep_ms; out.cells += po.cells; out.tb_elems = std::max(out.tb_elems, po.tb_elems);
     }
     return 0;
 }

@@ -23,7 +23,9 @@ def build(force: bool = False) -> str:
     hdr = os.path.join(_HERE, "..", "include", "spdp.h")
     newest = max(os.path.getmtime(f) for f in srcs + [hdr])
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _SO] + srcs)
+        tmp = f"{_SO}.{os.getpid()}.tmp"          # several test processes may get here at once: build aside, swap in
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp] + srcs)
+        os.replace(tmp, _SO)
     return _SO
 
 

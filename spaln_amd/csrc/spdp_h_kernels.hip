@@ -10,7 +10,8 @@
 // keeps its own last three H / F / E values (the reference's six rotating phase buffers hold
 // exactly that) and pulls the upper row's value of three steps ago with one `row_shr:1` DPP move.
 // Per-column inputs come from an LDS ring of packed records; lane k reads the record of its own
-// column n - 3k.  All score arithmetic is int16 with `v_add_i16 ... clamp`, i.e. exactly the
+// column n - 3k.  All score arithmetic is int16-saturating (the value sits in the upper half of a 32-bit register and
+// `v_add_i32 ... clamp` saturates it where `v_add_i16 ... clamp` would), i.e. exactly the
 // reference's _mm256_adds_epi16 lanes -- including what the lanes outside the DP matrix compute,
 // which the reference's end-cell selection can observe.
 //
@@ -30,6 +31,13 @@ enum { C_DIAG = 1, C_HORI = 2, C_HORL = 3, C_HOR1 = 4, C_HOR2 = 5, C_VERT = 8, C
 typedef short s16;
 __device__ __forceinline__ s16 sadd(s16 a, s16 b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ s16 smax(s16 a, s16 b) { return a > b ? a : b; }
+// the sweep keeps its int16 scores in the UPPER half of 32-bit registers (value * 65536): `v_add_i32 ... clamp` then
+// saturates exactly where `v_add_i16 ... clamp` does, at less than half the issue cost (profiles/r02_valu_ubench.txt:
+// 7.7 cycles per wave-instruction for the 16-bit VOP3 form, 4 for the 32-bit one), and order comparisons are unchanged
+typedef int q16;
+#define Q16(x) ((q16) ((unsigned) (x) << 16))
+__device__ __forceinline__ q16 qadd(q16 a, q16 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ q16 qmax(q16 a, q16 b) { return a > b ? a : b; }
 
 #define DPP_ROW_SR(n) (0x110 + (n))
 #define DPP_ROW_RR(n) (0x120 + (n))
@@ -62,16 +70,19 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // SPJ: splice-aware (b->inex.intr); TAB: the intron-length penalty steps fit the LDS table
 template <bool SPJ, bool TAB, bool LOCAL>
-__global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
+#ifndef SPDH_MINBLK
+#define SPDH_MINBLK 5          // blocks per CU the register budget is set for (A/B: -DSPDH_MINBLK=4)
+#endif
+__global__ __launch_bounds__(256, SPDH_MINBLK) void spdh_sweep(HSweepArgs A)
 {
     __shared__ int   s_mtx[32 * 32];
-    __shared__ short s_pen[SPDH_PEN_TAB];
+    __shared__ int   s_pen[SPDH_PEN_TAB];          // q16
     __shared__ int   s_qlen[8], s_qpen[8];
     __shared__ int4  s_ring[4][4][64];
     __shared__ int2  s_feed[4][4][16];
 
     const DevScoringH* __restrict__ sc = A.sc;
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = Q16(sc->mtx[i]);      // q16
     if (threadIdx.x < 8) { s_qlen[threadIdx.x] = sc->qm_len[threadIdx.x]; s_qpen[threadIdx.x] = sc->qm_pen[threadIdx.x]; }
     const int nquant = sc->nquant;
     const int pen_cap = (nquant > 1) ? min(sc->qm_len[nquant - 2] + 1, SPDH_PEN_TAB - 1) : 0;
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
     for (int h = threadIdx.x; h <= pen_cap; h += blockDim.x) {
         int pv = sc->qm_pen[0];
         for (int j = 1; j < nquant; ++j) if (h > sc->qm_len[j - 1]) pv = sc->qm_pen[j];
-        s_pen[h] = (short) pv;
+        s_pen[h] = Q16(pv);
     }
     __syncthreads();
 
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
     const int lw = P.lw, up = P.up;
     const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
     const int m_width = P.m_width, n_width = P.n_width;
-    const s16 ge = (s16) sc->gep, g1 = (s16) sc->g1, g2 = (s16) sc->g2, g3 = (s16) sc->g3;
+    const q16 ge = Q16(sc->gep), g1 = Q16(sc->g1), g2 = Q16(sc->g2), g3 = Q16(sc->g3);
     const int gop = sc->gop, gep = sc->gep;
     const int llmt = sc->llmt;
     int2* __restrict__ bnd = A.bnd + P.bnd_off;
@@ -200,15 +211,15 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
     const bool LocalL = LOCAL && a_exgl && b_exgl;
     const bool LocalR = LOCAL && a_exgr && b_exgr;
     // running maximum for local right ends: value, then the first (stripe, step, lane) holding it
-    int best_val = SPDH_NEV, best_mr = a_right, best_nr = b_right;
+    q16 best_val = Q16(SPDH_NEV); int best_mr = a_right, best_nr = b_right;       // (q16 until the reduction below)
     unsigned long long best_key = ~0ull;
     int4* const ring = &s_ring[wv][g][0];
     int2* const feed = &s_feed[wv][g][0];
-    auto pen_of = [&](int hil) -> s16 {
-        if constexpr (TAB) return (s16) s_pen[min(hil, pen_cap)];
+    auto pen_of = [&](int hil) -> q16 {
+        if constexpr (TAB) return s_pen[min(hil, pen_cap)];
         int pv = s_qpen[0];
         for (int jq = 1; jq < nquant; ++jq) pv = (hil > s_qlen[jq - 1]) ? s_qpen[jq] : pv;
-        return (s16) pv;
+        return Q16(pv);
     };
 
     for (int s0 = 0; s0 < n_stripes; s0 += 4) {
@@ -232,12 +243,12 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
         const int acode = (k < j9) ? acod[ml + k] : SPDH_ZCODE;
         const int* mrow = s_mtx + acode * 32;
 
-        // per-lane DP state (s16 values kept in 32-bit registers)
-        s16 h1 = SPDH_NEV, h2 = SPDH_NEV, h3 = SPDH_NEV;          // my H one, two, three steps ago
-        s16 f1 = SPDH_NEV, f2 = SPDH_NEV, f3 = SPDH_NEV;          // my F
-        s16 e1 = SPDH_NEV, e2 = SPDH_NEV, e3 = SPDH_NEV;          // my E, by frame
-        s16 u4 = SPDH_NEV, u5 = SPDH_NEV, u6 = SPDH_NEV;          // upper row's H four, five, six steps ago
-        s16 hiv0 = SPDH_NEV, hiv1 = SPDH_NEV, hiv2 = SPDH_NEV;    // best donor so far, by phase
+        // per-lane DP state (q16: the int16 value in the upper half of the register)
+        q16 h1 = Q16(SPDH_NEV), h2 = Q16(SPDH_NEV), h3 = Q16(SPDH_NEV);          // my H one, two, three steps ago
+        q16 f1 = Q16(SPDH_NEV), f2 = Q16(SPDH_NEV), f3 = Q16(SPDH_NEV);          // my F
+        q16 e1 = Q16(SPDH_NEV), e2 = Q16(SPDH_NEV), e3 = Q16(SPDH_NEV);          // my E, by frame
+        q16 u4 = Q16(SPDH_NEV), u5 = Q16(SPDH_NEV), u6 = Q16(SPDH_NEV);          // upper row's H four, five, six steps ago
+        q16 hiv0 = Q16(SPDH_NEV), hiv1 = Q16(SPDH_NEV), hiv2 = Q16(SPDH_NEV);    // best donor so far, by phase
         int hil0 = 0, hil1 = 0, hil2 = 0;                          // columns since that donor
         int outH = 0, outF = 0;                                    // bottom-row results of the block
         // bitmap offset of my cell at step n_start (advances by m_width per step)
@@ -281,12 +292,12 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     }
                     if (k == 0) {
                         const int e = n_start + e_base;
-                        u4 = (s16) ld_nt1(&bnd[e - 1].x);
-                        u5 = (s16) ld_nt1(&bnd[e - 2].x);
-                        u6 = (s16) ld_nt1(&bnd[e - 3].x);
+                        u4 = Q16(ld_nt1(&bnd[e - 1].x));
+                        u5 = Q16(ld_nt1(&bnd[e - 2].x));
+                        u6 = Q16(ld_nt1(&bnd[e - 3].x));
                     }
                 }
-                feed[k] = nx_b;
+                feed[k] = make_int2(Q16(nx_b.x), Q16(nx_b.y));
                 ring[(n0 + k) & 63] = mask_col(nx_c, n0 + k);
                 if (lb + 1 < nb) prefetch(lb + 1);
                 asm volatile("" ::: "memory");      // wave-internal ordering: see spdp_kernels.hip WAVE_ORDER
@@ -295,45 +306,45 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                 for (int J = 0; J < 16; ++J) {
                     const int n = n0 + J;
                     const int4 rec = ring[(n - 3 * k) & 63];
-                    const s16 cv = (s16) rec.x;
+                    const q16 cv = Q16(rec.x);
                     const int tron = (rec.x >> 16) & 0xff;
                     const unsigned fl = (unsigned) rec.x >> 24;
                     // ---- horizontal: 1-nt / 2-nt frame shift, new codon insertion, extension
-                    const s16 a1 = sadd(h1, g1), a2 = sadd(h2, g2);
+                    const q16 a1 = qadd(h1, g1), a2 = qadd(h2, g2);
                     bool m = a1 > a2;
-                    s16 eh = smax(a1, a2);
+                    q16 eh = qmax(a1, a2);
                     int eb = m ? C_HOR1 : C_HOR2;
-                    const s16 a3 = sadd(sadd(h3, g3), cv);
+                    const q16 a3 = qadd(qadd(h3, g3), cv);
                     m = eh > a3;
-                    eh = smax(eh, a3);
+                    eh = qmax(eh, a3);
                     eb = m ? eb : C_HORI;
-                    s16 ee = sadd(sadd(e3, ge), cv);
+                    q16 ee = qadd(qadd(e3, ge), cv);
                     m = ee > eh;
-                    ee = smax(ee, eh);
+                    ee = qmax(ee, eh);
                     int hb = m ? 0 : C_NHOR;
                     eb = m ? C_HORI : eb;
                     // ---- vertical: extension, codon deletion, 2-nt / 1-nt frame shift
                     const int2 fd = feed[J];
-                    const s16 u3 = (s16) row_shr1(fd.x, (int) h3);
-                    const s16 uf = (s16) row_shr1(fd.y, (int) f3);
-                    s16 ff = sadd(uf, ge);
-                    const s16 b3 = sadd(u3, g3), b2 = sadd(u4, g2);
+                    const q16 u3 = row_shr1(fd.x, h3);
+                    const q16 uf = row_shr1(fd.y, f3);
+                    q16 ff = qadd(uf, ge);
+                    const q16 b3 = qadd(u3, g3), b2 = qadd(u4, g2);
                     m = b3 > b2;
-                    s16 fh = smax(b3, b2);
+                    q16 fh = qmax(b3, b2);
                     int pb = m ? C_VERT : C_VER1;
-                    const s16 b1 = sadd(u5, g1);
+                    const q16 b1 = qadd(u5, g1);
                     m = fh > b1;
-                    fh = smax(fh, b1);
+                    fh = qmax(fh, b1);
                     pb = m ? pb : C_VER2;
                     m = ff > fh;
-                    ff = smax(ff, fh);
+                    ff = qmax(ff, fh);
                     hb |= m ? 0 : C_NVER;
                     pb = m ? C_VERT : pb;
                     // ---- diagonal
-                    const s16 sm = (s16) mrow[tron];
-                    const s16 dg = sadd(sadd(sm, u6), cv);
+                    const q16 sm = mrow[tron];
+                    const q16 dg = qadd(qadd(sm, u6), cv);
                     m = ff > dg;
-                    s16 h = m ? ff : dg;
+                    q16 h = m ? ff : dg;
                     pb = m ? pb : C_DIAG;
                     m = ee > h;
                     h = m ? ee : h;
@@ -342,20 +353,20 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     if constexpr (SPJ) {
                         // ---- intron 3' boundary: candidate 0 (phase -1 / 0 / +1), candidate 1 (phase +1)
                         const unsigned c0 = fl & 3u;
-                        const s16 s3_0 = (s16) rec.y, s3_1 = (s16) (rec.y >> 16);
+                        const q16 s3_0 = Q16(rec.y), s3_1 = (q16) ((unsigned) rec.y & 0xffff0000u);
                         // (selects on copies: a ?: on the captured variables themselves would select
                         //  between their addresses and pin all of them to memory)
-                        const s16 cv0 = hiv0, cv1 = hiv1, cv2 = hiv2;
+                        const q16 cv0 = hiv0, cv1 = hiv1, cv2 = hiv2;
                         const int cl0 = hil0, cl1 = hil1, cl2 = hil2;
-                        const s16 shiv = (c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2);
+                        const q16 shiv = (c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2);
                         const int shil = (c0 == 1u) ? cl0 : ((c0 == 2u) ? cl1 : cl2);
-                        const s16 x0 = sadd(sadd(shiv, s3_0), pen_of(shil));
-                        const s16 x1 = sadd(sadd(cv2, s3_1), pen_of(cl2));
+                        const q16 x0 = qadd(qadd(shiv, s3_0), pen_of(shil));
+                        const q16 x1 = qadd(qadd(cv2, s3_1), pen_of(cl2));
                         // A score already below `nevsel` is LIFTED to it by the reference's non-matching
                         // blends (`Blend(qv, ninf, ..)` then `Cmp_gt(qv, hv)`, :237-243) whenever the pipe
                         // is not skipped as a whole (`AllZero(ph_v)`, :224).  Only dead cells can be that
                         // low, so the three-blend form runs only when the wave holds one.
-                        if (__builtin_amdgcn_ballot_w64(h < (s16) SPDH_NEV) == 0ull) {
+                        if (__builtin_amdgcn_ballot_w64(h < Q16(SPDH_NEV)) == 0ull) {
                             m = (c0 != 0u) && (shil > llmt) && (x0 > h);
                             h = m ? x0 : h;
                             pb = m ? (int) (12u + c0) : pb;
@@ -372,13 +383,13 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
 #pragma unroll
                             for (int f = 0; f < 3; ++f) {
                                 const int lf = f == 0 ? cl0 : (f == 1 ? cl1 : cl2);
-                                const s16 cand = (c0 == (unsigned) (f + 1) && lf > llmt) ? x0 : (s16) SPDH_NEV;
+                                const q16 cand = (c0 == (unsigned) (f + 1) && lf > llmt) ? x0 : Q16(SPDH_NEV);
                                 m = any0 && cand > h;
                                 h = m ? cand : h;
                                 pb = m ? (C_ACCM + f) : pb;
                                 ab = ab || (m && c0 != 0u);
                             }
-                            const s16 cand = ((fl & 4u) && cl2 > llmt) ? x1 : (s16) SPDH_NEV;
+                            const q16 cand = ((fl & 4u) && cl2 > llmt) ? x1 : Q16(SPDH_NEV);
                             m = any1 && cand > h;
                             h = m ? cand : h;
                             pb = m ? C_ACCP : pb;
@@ -388,10 +399,10 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     if constexpr (LOCAL) {
                         // local left end (:243-247; accscr stays 0 without re-basing), right end (:250-258)
                         if (LocalL && h < 0) { h = 0; hb = 0; }
-                        if (LocalR && k < j9 && n <= n9 && (int) h >= best_val) {
+                        if (LocalR && k < j9 && n <= n9 && h >= best_val) {
                             const unsigned long long key =
                                 ((unsigned long long) s << 40) | ((unsigned long long) (n - n_start) << 8) | (unsigned) k;
-                            if ((int) h > best_val || key < best_key) {
+                            if (h > best_val || key < best_key) {
                                 best_val = h; best_key = key; best_mr = ml + k + 1; best_nr = n - 3 * k;
                             }
                         }
@@ -399,10 +410,10 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     if constexpr (SPJ) {
                         // ---- intron 5' boundary
                         const unsigned d0 = (fl >> 3) & 3u;
-                        const s16 s5_0 = (s16) rec.z, s5_1 = (s16) (rec.z >> 16);
-                        const s16 pvH = ab ? (s16) SPDH_NEV : sadd(h, s5_0);
-                        const s16 pvD = ab ? (s16) SPDH_NEV : sadd(u6, s5_0);
-                        const s16 pvD1 = ab ? (s16) SPDH_NEV : sadd(u6, s5_1);
+                        const q16 s5_0 = Q16(rec.z), s5_1 = (q16) ((unsigned) rec.z & 0xffff0000u);
+                        const q16 pvH = ab ? Q16(SPDH_NEV) : qadd(h, s5_0);
+                        const q16 pvD = ab ? Q16(SPDH_NEV) : qadd(u6, s5_0);
+                        const q16 pvD1 = ab ? Q16(SPDH_NEV) : qadd(u6, s5_1);
                         m = (d0 == 1u) && (pvH > hiv0);
                         hiv0 = m ? pvH : hiv0; hil0 = m ? 0 : hil0; hb |= m ? C_DONM : 0;
                         m = (d0 == 2u) && (pvH > hiv1);
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     if (k < j9 && n <= n9) tb[tb_off] = (uint16_t) (hb | pb);
                     tb_off += m_width;
                     // ---- bottom lane of the stripe -> output shift chain
-                    int bh = (int) h, bf = (int) ff;
+                    int bh = h, bf = ff;
                     if constexpr (PARTIAL) {
                         if (partial && j9 > 0) {
                             const int src = (lane & 48) + j8;
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     const int n = n0 + j;
                     const int r0 = n - 3 * mp1 - 6 * j8;
                     if (n <= n9 && n - b_left >= 3 * j9 && r0 >= lw && r0 <= up && j9 > 0)
-                        bnd[BIDX(r0)] = make_int2(outH, outF);
+                        bnd[BIDX(r0)] = make_int2(outH >> 16, outF >> 16);
                 }
             }
             // boundary entries are exchanged between the rows of this wave through memory: a load
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(256, 5) void spdh_sweep(HSweepArgs A)
                     best_val = ov; best_key = ok; best_mr = omr; best_nr = onr;
                 }
             }
-            R.score = best_val; R.mr = best_mr; R.nr = best_nr;
+            R.score = best_val >> 16; R.mr = best_mr; R.nr = best_nr;
             run_last = best_mr == a_right;             // `if (!LocalR || maxh.mr == a->right)`, :330
         }
     }

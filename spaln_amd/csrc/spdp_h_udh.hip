@@ -22,6 +22,11 @@
 #include "spdp_h_internal.h"
 
 typedef short s16;
+// int16 scores in the upper half of 32-bit registers: see spdp_h_kernels.hip
+typedef int q16;
+#define Q16(x) ((q16) ((unsigned) (x) << 16))
+__device__ __forceinline__ q16 qadd(q16 a, q16 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ q16 qmax(q16 a, q16 b) { return a > b ? a : b; }
 __device__ __forceinline__ s16 sadd(s16 a, s16 b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ s16 smax(s16 a, s16 b) { return a > b ? a : b; }
 
@@ -52,20 +57,20 @@ template <bool SPJ, bool TAB>
 __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
 {
     __shared__ int   s_mtx[32 * 32];
-    __shared__ short s_pen[SPDH_PEN_TAB];
+    __shared__ int   s_pen[SPDH_PEN_TAB];          // q16
     __shared__ int   s_qlen[8], s_qpen[8];
     __shared__ int4  s_ring[4][4][64];
     __shared__ int4  s_feed[4][4][16];
 
     const DevScoringH* __restrict__ sc = A.sc;
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = Q16(sc->mtx[i]);      // q16
     if (threadIdx.x < 8) { s_qlen[threadIdx.x] = sc->qm_len[threadIdx.x]; s_qpen[threadIdx.x] = sc->qm_pen[threadIdx.x]; }
     const int nquant = sc->nquant;
     const int pen_cap = (nquant > 1) ? min(sc->qm_len[nquant - 2] + 1, SPDH_PEN_TAB - 1) : 0;
     for (int h = threadIdx.x; h <= pen_cap; h += blockDim.x) {
         int pv = sc->qm_pen[0];
         for (int j = 1; j < nquant; ++j) if (h > sc->qm_len[j - 1]) pv = sc->qm_pen[j];
-        s_pen[h] = (short) pv;
+        s_pen[h] = Q16(pv);
     }
     __syncthreads();
 
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
     const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width;
     const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
-    const s16 ge = (s16) sc->gep, g1 = (s16) sc->g1, g2 = (s16) sc->g2, g3 = (s16) sc->g3;
+    const q16 ge = Q16(sc->gep), g1 = Q16(sc->g1), g2 = Q16(sc->g2), g3 = Q16(sc->g3);
     const int gop = sc->gop, gep = sc->gep;
     const int llmt = sc->llmt;
     int4* __restrict__ bnd = A.bnd + P.bnd_off;
@@ -184,11 +189,11 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
     int imd_cur = 0;
     int4* const ring = &s_ring[wv][g][0];
     int4* const feed = &s_feed[wv][g][0];
-    auto pen_of = [&](int hil) -> s16 {
-        if constexpr (TAB) return (s16) s_pen[min(hil, pen_cap)];
+    auto pen_of = [&](int hil) -> q16 {
+        if constexpr (TAB) return s_pen[min(hil, pen_cap)];
         int pv = s_qpen[0];
         for (int jq = 1; jq < nquant; ++jq) pv = (hil > s_qlen[jq - 1]) ? s_qpen[jq] : pv;
-        return (s16) pv;
+        return Q16(pv);
     };
     // "does any lane of my 16-lane row ..." from a wave ballot
     const int row_sh = 16 * (g & 1);
@@ -236,13 +241,13 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
         const int acode = (k < j9) ? acod[ml + k] : SPDH_ZCODE;
         const int* mrow = s_mtx + acode * 32;
 
-        s16 h1 = SPDH_NEV, h2 = SPDH_NEV, h3 = SPDH_NEV;
-        s16 f1 = SPDH_NEV, f2 = SPDH_NEV, f3 = SPDH_NEV;
-        s16 e1 = SPDH_NEV, e2 = SPDH_NEV, e3 = SPDH_NEV;
-        s16 u4 = SPDH_NEV, u5 = SPDH_NEV, u6 = SPDH_NEV;
+        q16 h1 = Q16(SPDH_NEV), h2 = Q16(SPDH_NEV), h3 = Q16(SPDH_NEV);
+        q16 f1 = Q16(SPDH_NEV), f2 = Q16(SPDH_NEV), f3 = Q16(SPDH_NEV);
+        q16 e1 = Q16(SPDH_NEV), e2 = Q16(SPDH_NEV), e3 = Q16(SPDH_NEV);
+        q16 u4 = Q16(SPDH_NEV), u5 = Q16(SPDH_NEV), u6 = Q16(SPDH_NEV);
         int c1 = 0, c2 = 0, c3 = 0, fc1 = 0, fc2 = 0, fc3 = 0, ec1 = 0, ec2 = 0, ec3 = 0;   // their links
         int uc4 = 0, uc5 = 0, uc6 = 0;
-        s16 hiv0 = SPDH_NEV, hiv1 = SPDH_NEV, hiv2 = SPDH_NEV;
+        q16 hiv0 = Q16(SPDH_NEV), hiv1 = Q16(SPDH_NEV), hiv2 = Q16(SPDH_NEV);
         int hil0 = 0, hil1 = 0, hil2 = 0, hic0 = 0, hic1 = 0, hic2 = 0;
         int dr0 = n_start - 3 * mp1, dr1 = dr0, dr2 = dr0;                  // donor_r[], lane k8 only
         int outH = 0, outF = 0, outC = 0, outFC = 0;
@@ -284,12 +289,12 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     if (k == 0) {
                         const int e = n_start + e_base;
                         const int4 t1 = ld_nt4(bnd + e - 1), t2 = ld_nt4(bnd + e - 2), t3 = ld_nt4(bnd + e - 3);
-                        u4 = (s16) t1.x; uc4 = t1.z;
-                        u5 = (s16) t2.x; uc5 = t2.z;
-                        u6 = (s16) t3.x; uc6 = t3.z;
+                        u4 = Q16(t1.x); uc4 = t1.z;
+                        u5 = Q16(t2.x); uc5 = t2.z;
+                        u6 = Q16(t3.x); uc6 = t3.z;
                     }
                 }
-                feed[k] = nx_b;
+                feed[k] = make_int4(Q16(nx_b.x), Q16(nx_b.y), nx_b.z, nx_b.w);
                 ring[(n0 + k) & 63] = mask_col(nx_c, n0 + k);
                 if (lb + 1 < nb) prefetch(lb + 1);
                 asm volatile("" ::: "memory");      // wave-internal ordering: see spdp_kernels.hip WAVE_ORDER
@@ -298,41 +303,41 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                 for (int J = 0; J < 16; ++J) {
                     const int n = n0 + J;
                     const int4 rec = ring[(n - 3 * k) & 63];
-                    const s16 cv = (s16) rec.x;
+                    const q16 cv = Q16(rec.x);
                     const int tron = (rec.x >> 16) & 0xff;
                     const unsigned fl = (unsigned) rec.x >> 24;
                     // ---- insertion (E)
-                    const s16 a1 = sadd(h1, g1), a2 = sadd(h2, g2);
+                    const q16 a1 = qadd(h1, g1), a2 = qadd(h2, g2);
                     bool m = a1 > a2;
-                    s16 eh = smax(a1, a2);
+                    q16 eh = qmax(a1, a2);
                     int ehc = m ? c1 : c2;
-                    const s16 a3 = sadd(sadd(h3, g3), cv);
+                    const q16 a3 = qadd(qadd(h3, g3), cv);
                     m = eh > a3;
-                    eh = smax(eh, a3);
+                    eh = qmax(eh, a3);
                     ehc = m ? ehc : c3;
-                    s16 ee = sadd(sadd(e3, ge), cv);
+                    q16 ee = qadd(qadd(e3, ge), cv);
                     m = ee > eh;
-                    ee = smax(ee, eh);
+                    ee = qmax(ee, eh);
                     const int eec = m ? ec3 : ehc;
                     // ---- deletion (F): extension first, then the three opens (:465-521)
                     const int4 fd = feed[J];
-                    const s16 u3 = (s16) row_shr1(fd.x, (int) h3);
-                    const s16 uf = (s16) row_shr1(fd.y, (int) f3);
+                    const q16 u3 = row_shr1(fd.x, h3);
+                    const q16 uf = row_shr1(fd.y, f3);
                     const int uc3 = row_shr1(fd.z, c3);
                     const int ufc = row_shr1(fd.w, fc3);
-                    s16 ff = sadd(uf, ge);
+                    q16 ff = qadd(uf, ge);
                     int ffc = ufc;
-                    const s16 b3 = sadd(u3, g3);
-                    m = ff > b3; ff = smax(ff, b3); ffc = m ? ffc : uc3;
-                    const s16 b2 = sadd(u4, g2);
-                    m = ff > b2; ff = smax(ff, b2); ffc = m ? ffc : uc4;
-                    const s16 b1 = sadd(u5, g1);
-                    m = ff > b1; ff = smax(ff, b1); ffc = m ? ffc : uc5;
+                    const q16 b3 = qadd(u3, g3);
+                    m = ff > b3; ff = qmax(ff, b3); ffc = m ? ffc : uc3;
+                    const q16 b2 = qadd(u4, g2);
+                    m = ff > b2; ff = qmax(ff, b2); ffc = m ? ffc : uc4;
+                    const q16 b1 = qadd(u5, g1);
+                    m = ff > b1; ff = qmax(ff, b1); ffc = m ? ffc : uc5;
                     // ---- diagonal
-                    const s16 sm = (s16) mrow[tron];
-                    const s16 dg = sadd(sadd(sm, u6), cv);
+                    const q16 sm = mrow[tron];
+                    const q16 dg = qadd(qadd(sm, u6), cv);
                     m = ff > dg;
-                    s16 h = m ? ff : dg;
+                    q16 h = m ? ff : dg;
                     int hc = m ? ffc : uc6;
                     int pv = m ? 2 : 0;
                     m = ee > h;
@@ -343,23 +348,23 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     int acc_dr = 0; bool acc_hit = false;          // lane k8: donor_r of the last acceptor taken
                     if constexpr (SPJ) {
                         const unsigned c0 = fl & 3u;
-                        const s16 s3_0 = (s16) rec.y, s3_1 = (s16) (rec.y >> 16);
-                        const s16 cv0 = hiv0, cv1 = hiv1, cv2 = hiv2;
+                        const q16 s3_0 = Q16(rec.y), s3_1 = (q16) ((unsigned) rec.y & 0xffff0000u);
+                        const q16 cv0 = hiv0, cv1 = hiv1, cv2 = hiv2;
                         const int cl0 = hil0, cl1 = hil1, cl2 = hil2;
                         const int cc0 = hic0, cc1 = hic1, cc2 = hic2;
                         const int cd0 = dr0, cd1 = dr1, cd2 = dr2;
                         // the three blends of each pipe in the reference's order; a pipe whose 16 lanes
                         // hold no candidate is skipped as a whole (:569)
                         const bool any0 = row_any(c0 != 0u), any1 = row_any((fl & 4u) != 0u);
-                        const s16 x0 = sadd(sadd((c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2), s3_0),
+                        const q16 x0 = qadd(qadd((c0 == 1u) ? cv0 : ((c0 == 2u) ? cv1 : cv2), s3_0),
                                             pen_of((c0 == 1u) ? cl0 : ((c0 == 2u) ? cl1 : cl2)));
-                        const s16 x1 = sadd(sadd(cv2, s3_1), pen_of(cl2));
+                        const q16 x1 = qadd(qadd(cv2, s3_1), pen_of(cl2));
 #pragma unroll
                         for (int f = 0; f < 3; ++f) {
                             const int lf = f == 0 ? cl0 : (f == 1 ? cl1 : cl2);
                             const int lc = f == 0 ? cc0 : (f == 1 ? cc1 : cc2);
                             const int ld = f == 0 ? cd0 : (f == 1 ? cd1 : cd2);
-                            const s16 cand = (c0 == (unsigned) (f + 1) && lf > llmt) ? x0 : (s16) SPDH_NEV;
+                            const q16 cand = (c0 == (unsigned) (f + 1) && lf > llmt) ? x0 : Q16(SPDH_NEV);
                             m = any0 && cand > h;
                             h = m ? cand : h; hc = m ? lc : hc; ab = ab || m;
                             if constexpr (IMD) { acc_dr = m ? ld : acc_dr; acc_hit = acc_hit || m; }
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                             const int lf = f == 0 ? cl0 : (f == 1 ? cl1 : cl2);
                             const int lc = f == 0 ? cc0 : (f == 1 ? cc1 : cc2);
                             const int ld = f == 0 ? cd0 : (f == 1 ? cd1 : cd2);
-                            const s16 cand = (f == 2 && (fl & 4u) && lf > llmt) ? x1 : (s16) SPDH_NEV;
+                            const q16 cand = (f == 2 && (fl & 4u) && lf > llmt) ? x1 : Q16(SPDH_NEV);
                             m = any1 && cand > h;
                             h = m ? cand : h; hc = m ? lc : hc; ab = ab || m;
                             if constexpr (IMD) { acc_dr = m ? ld : acc_dr; acc_hit = acc_hit || m; }
@@ -380,11 +385,11 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     if constexpr (SPJ) {
                         // ---- intron 5' boundary; the length counters advance only with a busy pipe
                         const unsigned d0 = (fl >> 3) & 3u;
-                        const s16 s5_0 = (s16) rec.z, s5_1 = (s16) (rec.z >> 16);
+                        const q16 s5_0 = Q16(rec.z), s5_1 = (q16) ((unsigned) rec.z & 0xffff0000u);
                         const bool dny0 = row_any(d0 != 0u), dny1 = row_any((fl & 32u) != 0u);
-                        const s16 pvH = ab ? (s16) SPDH_NEV : sadd(h, s5_0);
-                        const s16 pvD = ab ? (s16) SPDH_NEV : sadd(u6, s5_0);
-                        const s16 pvD1 = ab ? (s16) SPDH_NEV : sadd(u6, s5_1);
+                        const q16 pvH = ab ? Q16(SPDH_NEV) : qadd(h, s5_0);
+                        const q16 pvD = ab ? Q16(SPDH_NEV) : qadd(u6, s5_0);
+                        const q16 pvD1 = ab ? Q16(SPDH_NEV) : qadd(u6, s5_1);
                         m = dny0 && (d0 == 1u) && (pvH > hiv0);
                         hiv0 = m ? pvH : hiv0; hic0 = m ? hc : hic0; hil0 = m ? 0 : hil0; hil0 += dny0 ? 1 : 0;
                         if constexpr (IMD) dr0 = (m && on_imd) ? rj : dr0;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     e3 = e2; e2 = e1; e1 = ee;    ec3 = ec2; ec2 = ec1; ec1 = eec;
                     u6 = u5; u5 = u4; u4 = u3;    uc6 = uc5; uc5 = uc4; uc4 = uc3;
                     // ---- bottom lane of the stripe -> output shift chain
-                    int bh = (int) h, bf = (int) ff, bc = hc, bfc = ffc;
+                    int bh = h, bf = ff, bc = hc, bfc = ffc;
                     if constexpr (PARTIAL) {
                         if (partial && j9 > 0) {
                             const int src = (lane & 48) + j8;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     const int n = n0 + j;
                     const int r0 = n - 3 * mp1 - 6 * j8;
                     if (n < n9 && n - b_left >= 3 * j9 && r0 >= lw && r0 <= up && j9 > 0)
-                        bnd[BIDX(r0)] = make_int4(outH, outF, outC, outFC);
+                        bnd[BIDX(r0)] = make_int4(outH >> 16, outF >> 16, outC, outFC);
                 }
             }
             asm volatile("" ::: "memory");

@@ -111,11 +111,11 @@ def _ref_cli_chunk(chunk):
            if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
     env["ALN_TAB"] = REF_TAB
     with tempfile.TemporaryDirectory() as td:
-        for window_ascii, query_ascii, protein in chunk:
+        for window_ascii, query_ascii, protein, alg in chunk:
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
             synth.write_fasta(gf, "win", window_ascii)
             synth.write_fasta(qf, "qry", query_ascii)
-            cmd = [REF_BIN, "-Q0", "-A2", "-pw", "-O4", "-t1"] + ([] if protein else ["-S1"]) + [gf, qf]
+            cmd = [REF_BIN, "-Q0", f"-A{alg}", "-pw", "-O4", "-t1"] + ([] if protein else ["-S1"]) + [gf, qf]
             t0 = time.perf_counter()
             r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             busy += time.perf_counter() - t0
@@ -123,7 +123,7 @@ def _ref_cli_chunk(chunk):
     return busy, ok
 
 
-def _ref_baseline(pairs, protein, band_cells, cell_ratio):
+def _ref_baseline(pairs, protein, band_cells, cell_ratio, alg=2):
     """times the reference CLI on `pairs`, one worker per host core, each running its share of the
     pairs back to back; elapsed = the busiest worker's time inside the reference runs (pool start-up
     and FASTA writing excluded, the CLI's own start-up included); cells = band cells of the sample x
@@ -131,13 +131,13 @@ def _ref_baseline(pairs, protein, band_cells, cell_ratio):
     import multiprocessing as mp
     ncores = _host_cores()
     used = min(ncores, len(pairs))
-    chunks = [[(w, q, protein) for w, q in pairs[c::used]] for c in range(used)]
+    chunks = [[(w, q, protein, alg) for w, q in pairs[c::used]] for c in range(used)]
     with mp.Pool(used) as pool:
         res = pool.map(_ref_cli_chunk, chunks)
     cdt = max(b for b, _ in res)
     ok = sum(k for _, k in res)
     return {"value": round(band_cells * cell_ratio / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "reference",
-            "sample": f"first {len(pairs)} queries through the compiled reference (oracle/_ref/spaln -Q0 -A2 -t1, AVX2 build), "
+            "sample": f"first {len(pairs)} queries through the compiled reference (oracle/_ref/spaln -Q0 -A{alg} -t1, AVX2 build), "
                       f"{used} workers x {len(chunks[0])} runs back to back, {ok} ok; busiest worker {cdt:.2f} s, "
                       f"{sum(b for b, _ in res):.0f} core-seconds in total"}
 
@@ -207,6 +207,8 @@ def main_c3(args):
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if world > 1:
             cpu_base = None                                   # timed at N = 1 only
+        elif exact and not _ref_available():
+            cpu_base = None                                   # (the port's ladder is the -A2 one)
         elif _ref_available() and not args.cpu_port:
             from oracle import oracle
             ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 64 * ncores, len(batch)))
@@ -311,7 +313,10 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "
                          "c4: 500-nt ESTs (traceback branch of the ladder only)")
-    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000)")
+    ap.add_argument("--engines", choices=["wip", "a0", "a1"], default="wip",
+                    help="c2 / c4 only: wip = the -A2 `_wip` engines (the headline); a0 = the exact-intron-length engines "
+                         "(algmode.alg 0: forwardS_ng / hirschbergS_ng, spdp_rowwave.hip); a1 = the -A1 engines (spdp_exact.hip)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000; 1000 with --engines a0 / a1)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = 2 per host core)")
     ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
     ap.add_argument("--cpu-port", action="store_true",
@@ -321,7 +326,7 @@ def main():
                          "batch of --queries sharded over the ranks; the other one is reported under config")
     args = ap.parse_args()
     if not args.queries:
-        args.queries = 10000
+        args.queries = 10000 if args.engines == "wip" else 1000
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_spawn(sys.argv[1:], args.gpus)
     if args.workload == "c3":
@@ -331,7 +336,12 @@ def main():
 
     from spaln_amd import abi, defaults, engine, shard, synth
     eng = engine.Engine(local_rank)
-    sc = defaults.scoring()
+    exact = args.engines != "wip"
+    if exact:
+        intpen, t53 = defaults.exact_tables()
+        sc = defaults.scoring(scalar_engines=1 if args.engines == "a0" else 2, intpen=intpen, t53=t53)
+    else:
+        sc = defaults.scoring()
 
     def barrier():
         torch.cuda.synchronize()
@@ -359,7 +369,7 @@ def main():
             batch = [full[i] for i in shard.shard_range(len(full), rank, world)]
         ps = abi.ProblemSet()
         for w, q, s5, s3, _ in batch:
-            ps.add(q, w, s5, s3)
+            ps.add(q, w, s5, s3, **(synth.exact_inputs(w) if exact else {}))
         bt = eng.upload(sc, ps)
         for _ in range(args.warmup):
             bt.align(want=True, convert=False)
@@ -414,6 +424,8 @@ def main():
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if world > 1:
             cpu_base = None                                   # timed at N = 1 only
+        elif exact and not _ref_available():
+            cpu_base = None                                   # (the port's ladder is the -A2 one)
         elif _ref_available() and not args.cpu_port:
             from oracle import oracle
             ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 32 * ncores, len(batch)))
@@ -423,8 +435,10 @@ def main():
             band = 0
             for i in range(ns):
                 band += oracle.cells(ps.items[i], oracle.stripe(ps.items[i], sc.sh))
+            if exact:
+                ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 4 * ncores, len(batch)))
             cpu_base = _ref_baseline([(dec[batch[i][0]], dec[batch[i][1]]) for i in range(ns)], False, band,
-                                     cells / max(1, prim["band_cells"]))
+                                     cells / max(1, prim["band_cells"]), {"wip": 2, "a0": 0, "a1": 1}[args.engines])
         else:
             tc = time.perf_counter()
             with mp.Pool(min(ncores, ns)) as pool:
@@ -434,6 +448,9 @@ def main():
             cpu_base = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "port",
                         "sample": f"first {ns} queries of the batch, oracle alignS_ng restatement "
                                   f"(UDH + slab tracebacks), one query per process on {used} cores"}
+        if exact:
+            eng_name = {"a0": "-A0: forwardS_ng / hirschbergS_ng / scorealoneS_ng as wavefront kernels (spdp_rowwave.hip)",
+                        "a1": "-A1: forwardS1 / hirschbergS1 (spdp_exact.hip)"}[args.engines]
         out = {
             "metric": "GCUPS (DP cell updates/s), cDNA->genome spliced DP",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -445,7 +462,9 @@ def main():
                                     "alignS_ng(ori=1, -Q0) = forward sweep + traceback walk, SKL out") if c4 else
                                    ("C2: 10k x 2 kb cDNA vs planted loci +-1 kb (windows ~12 kb), "
                                     "default band, Fwd2s1 _wip path: alignS_ng(ori=1, -Q0) = UDH sweep + "
-                                    "slab tracebacks, SKL out"),
+                                    "slab tracebacks, SKL out") if not exact else
+                                   (f"C2 shape, {len(batch)} x 2 kb cDNA vs planted loci +-1 kb, alignS_ng(ori=1, -Q0) with the "
+                                    f"exact-model engines ({eng_name})"),
                        "queries_per_gpu": len(batch), "queries_total": int(prim["total_queries"]),
                        "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(prim["total_queries"] * args.steps / dt, 1),
@@ -456,10 +475,11 @@ def main():
                        "fwd_problems": int(stats[-1]["fwd_problems"]), "tb_bytes": int(stats[-1]["tb_bytes"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4) else None,
+                         "traffic": PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4 and not exact) else None,
                          "traffic_source": "profiles/r02_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
-                         "kernel": "spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>", "kernel_ms": round(k_ms, 3),
-                         "valu": _valu_roofline(k_cells, k_name, k_ms),
+                         "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
+                                   ("spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
+                         "valu": None if exact else _valu_roofline(k_cells, k_name, k_ms),
                          "note": "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
             "cpu_baseline": cpu_base,
         }

@@ -35,16 +35,17 @@ HBM_PEAK_GBS = 8000.0
 # VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
 # fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
 # profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
-# same profiles: fp32-issue UDH sweep 51.2 / 64 (round 1: 59.6), forward sweep 69.6 / 64, protein sweep 151.5 / 64.
+# same profiles: fp32-issue UDH sweep 51.2 / 64 (round 1: 59.6), forward sweep 69.6 / 64, protein sweep 152.3 / 64
+# (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3136e10 / 3.0943e10}
+VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10}
 # HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
 # chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes (profiles/r02_hbm_traffic_pmc.txt).  FETCH_SIZE
 # counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
 # the figure an upper bound for the 8-byte column-record reads.
 PMC_TRAFFIC_BYTES = int((2 * 49828262 + 178326372) * 1024 / 2)
 # same for one spdh_sweep launch of the default c3 workload (profiles/r02_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((2 * 37825292 + 146769521) * 1024)
+PMC_TRAFFIC_BYTES_H = int((2 * 38323706 + 146477017) * 1024)
 
 
 def _cpu_align_one(item):
@@ -242,7 +243,7 @@ def main_c3(args):
                          "traffic_source": "profiles/r02_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
                          "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
                          "valu": _valu_roofline(cells, "h", k_ms),
-                         "note": "integer-VALU bound recurrence (int16 saturating lanes); HBM fraction reported as asked"},
+                         "note": "integer-VALU bound recurrence (int16 saturating lanes carried in the upper half of 32-bit registers); HBM fraction reported as asked"},
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)

@@ -41,8 +41,19 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
     constexpr bool UDH = MODE == 2;             // links, intermediate rows
     constexpr bool PTR = MODE != 0;             // a pointer / link rides on H, E, F
+    // what a step needs from memory is staged through LDS a block of 16 steps ahead (per 16-lane group): the column
+    // records and class bytes of the block's columns, and the boundary entries lane 0 feeds from (the previous stripe's
+    // bottom row, by diagonal) -- a step used to wait for its own loads
+    __shared__ int s_mtx[32 * 32];
+    __shared__ int2 s_col[4][64];
+    __shared__ unsigned short s_ax[4][64];
+    enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_N };
+    __shared__ int s_fd[4][FD_N][20];
+    for (int i = threadIdx.x; i < 32 * 32; i += 64) s_mtx[i] = A.sc->mtx[i];
+    __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
-    const int pi = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const int grp = threadIdx.x >> 4;
+    const int pi = blockIdx.x * 4 + grp;
     if (pi >= A.n_probs) return;                 // a whole 16-lane group leaves together
     const DevProblem P = A.probs[pi];
     const DevScoring* sc = A.sc;
@@ -136,9 +147,9 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         // per-lane state: H of the last two steps, F, E, flags, the candidate list of my row
         int H1 = XNEV, H2 = XNEV, F1 = XNEV, E = XNEV, ps = 0;
         int B1 = 0, B2 = 0, C1 = 0, C2 = 0, FC1 = 0, EC = 0, EB = 0, FB = 0;    // forward: flags / pointers of H (two steps), F, E
-        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], idx[5], ncand = -1;
+        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], c_dn5[5], idx[5], ncand = -1;      // c_dn5: dinc5 of the donor column
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = 0; idx[i] = i; }
+        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; idx[i] = i; }
         const int m = ml + 1 + k;                             // my row
         // udh: is the current intermediate row in this stripe, and on which lane
         int mm_ = 0, k9 = 0, k8 = -1;
@@ -153,26 +164,70 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         }
         const bool imd_here = UDH && is_imd_ && k == k8;     // my row is the intermediate row (m == imd->mi)
         (void) k9;
-        const int* mrow = sc->mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
+        const int* mrow = s_mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
+        // ---- staging (see the top of the kernel): registers hold the NEXT block's loads while a block runs
+        int2* const ring = s_col[grp];
+        unsigned short* const ringx = s_ax[grp];
+        int (*const fd)[20] = s_fd[grp];
+        const int e_last = lw - 1 + P.buf_size - 1;                       // last entry of the boundary arrays
+        auto ld_col = [&](int c, int2& cc, unsigned& ax) {
+            const bool in = c >= 0 && c <= b_right + 1;
+            cc = in ? cols[c] : make_int2(0, 0);
+            ax = in ? reinterpret_cast<const unsigned short*>(aux)[c] : 0u;
+        };
+        int2 pc = make_int2(0, 0); unsigned pax = 0; int pfd[FD_N] = {0, 0, 0, 0, 0, 0};
+        auto prefetch = [&](int nb_, int rb_) {                           // block starting at step nb_, diagonal rb_
+            ld_col(nb_ + k, pc, pax);
+            const int e = min(rb_ + 1 + k, e_last);
+            pfd[FD_HV] = __builtin_nontemporal_load(&hv[e]); pfd[FD_FV] = __builtin_nontemporal_load(&fv[e]);
+            if constexpr (PTR) { pfd[FD_HC] = __builtin_nontemporal_load(&hc[e]); pfd[FD_FC] = __builtin_nontemporal_load(&fc[e]); }
+            if constexpr (FORWARD) pfd[FD_HB] = __builtin_nontemporal_load(&hb[e]);
+            if constexpr (UDH) { if (LocalL) { pfd[FD_HB] = __builtin_nontemporal_load(&hb[e]); pfd[FD_FB] = __builtin_nontemporal_load(&fb[e]); } }
+        };
+        auto commit = [&](int nb_) {                                      // the staged block becomes the current one
+            ring[(nb_ + k) & 63] = pc; ringx[(nb_ + k) & 63] = (unsigned short) pax;
+#pragma unroll
+            for (int a = 0; a < FD_N; ++a) {
+                const int carry = fd[a][16];                              // entry rb of the new block = entry rb + 16 of the old one
+                fd[a][k + 1] = pfd[a];
+                if (k == 0) fd[a][0] = carry;
+            }
+        };
+        {
+            // the 16 columns left of the first step (lane k of step n_first looks at n_first - k), then block 0
+            int2 c0; unsigned a0;
+            ld_col(n_first - 16 + k, c0, a0);
+            ring[(n_first - 16 + k) & 63] = c0; ringx[(n_first - 16 + k) & 63] = (unsigned short) a0;
+            if (k == 0) {
+                const int e = min(r, e_last);
+                fd[FD_HV][16] = __builtin_nontemporal_load(&hv[e]); fd[FD_FV][16] = __builtin_nontemporal_load(&fv[e]);
+                if constexpr (PTR) { fd[FD_HC][16] = __builtin_nontemporal_load(&hc[e]); fd[FD_FC][16] = __builtin_nontemporal_load(&fc[e]); }
+                if constexpr (FORWARD) fd[FD_HB][16] = __builtin_nontemporal_load(&hb[e]);
+                if constexpr (UDH) { if (LocalL) { fd[FD_HB][16] = __builtin_nontemporal_load(&hb[e]); fd[FD_FB][16] = __builtin_nontemporal_load(&fb[e]); } }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            prefetch(n, r);
+        }
+        int jb = 16;                                                      // step within the block; 16 = a new block starts
         for ( ; n < n9; ++n, ++r) {
+            if (jb == 16) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's reads of the old block are done)
+                commit(n);
+                prefetch(n + 16, r + 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                jb = 0;
+            }
+            const int j = jb++;
             const int r0 = r - 2 * j8;
             const int ke = min(j9, n - b_left);
             const int nj = n - k;                             // my column
-            // boundary feeds of lane 0 (previous stripe's bottom row, by diagonal)
+            // boundary feeds of lane 0 (previous stripe's bottom row, by diagonal): entry r is fd[..][j], r + 1 is fd[..][j + 1]
             int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0, bB1 = 0, bFB1 = 0;
             if (k == 0) {
-                bH1 = __builtin_nontemporal_load(&hv[r + 1]);
-                bF1 = __builtin_nontemporal_load(&fv[r + 1]);
-                bH2 = __builtin_nontemporal_load(&hv[r]);
-                if constexpr (PTR) {
-                    bC1 = __builtin_nontemporal_load(&hc[r + 1]); bFC1 = __builtin_nontemporal_load(&fc[r + 1]);
-                    bC2 = __builtin_nontemporal_load(&hc[r]);
-                }
-                if constexpr (FORWARD) bB2 = __builtin_nontemporal_load(&hb[r]);
-                if constexpr (UDH) {
-                    if (LocalL) { bB2 = __builtin_nontemporal_load(&hb[r]); bB1 = __builtin_nontemporal_load(&hb[r + 1]);
-                                  bFB1 = __builtin_nontemporal_load(&fb[r + 1]); }
-                }
+                bH1 = fd[FD_HV][j + 1]; bF1 = fd[FD_FV][j + 1]; bH2 = fd[FD_HV][j];
+                if constexpr (PTR) { bC1 = fd[FD_HC][j + 1]; bFC1 = fd[FD_FC][j + 1]; bC2 = fd[FD_HC][j]; }
+                if constexpr (FORWARD) bB2 = fd[FD_HB][j];
+                if constexpr (UDH) { if (LocalL) { bB2 = fd[FD_HB][j]; bB1 = fd[FD_HB][j + 1]; bFB1 = fd[FD_FB][j + 1]; } }
             }
             int upH1 = x_up(H1), upF1 = x_up(F1), upH2 = x_up(H2);
             int upC1 = 0, upFC1 = 0, upB2 = 0, upC2 = 0;
@@ -199,8 +254,8 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             }
             int pv = 0;
             const bool incell = nj <= b_right && nj > b_left && k < j9;     // kb <= k < ke
-            int2 col = make_int2(0, 0);
-            if (nj >= 0 && nj <= b_right + 1) col = cols[nj];
+            const int2 col = ring[nj & 63];
+            const unsigned axj = ringx[nj & 63];
             if (incell) pv = mrow[col.y];
             int H = x_sadd(pv, upH2);
             int HC = upC2;
@@ -240,10 +295,10 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             const bool queued = spj && k < j9 && nj >= n_first && nj <= b_right;
             const int rj = nj - m;
             if (queued && rj >= lw && rj < up) {
-                const unsigned fl = aux[2 * nj];
+                const unsigned fl = axj & 0xffu;
                 if (fl & 2) {                                 // acceptor: Sjsites::get
                     const int s3 = col.x >> 16;
-                    const int d3 = aux[2 * nj + 1] & 15;
+                    const int d3 = (axj >> 8) & 15;
                     int mx_ci[3] = {-1, -1, -1}, br_ci = -1;  // udh: maxprd[d], brd (as candidate slots)
                     for (int l = 0; l <= ncand; ++l) {
                         const int ci = idx[l];
@@ -251,7 +306,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         if (nj - don < minl) continue;
                         int len = nj - don;
                         if (len >= A.intpen_len) len = A.intpen_len - 1;
-                        const int x = c_val[ci] + A.intpen[len] + s3 + A.t53[16 * (aux[2 * don + 1] >> 4) + d3];
+                        const int x = c_val[ci] + A.intpen[len] + s3 + A.t53[16 * c_dn5[ci] + d3];
                         int cur = d == 0 ? H : (d == 1 ? E : F);
                         if (x <= cur) continue;
                         cur = (int) (short) x;
@@ -305,7 +360,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         }
                         if (++l < 4) {
                             const int ci = idx[l];
-                            c_val[ci] = (int) (short) x; c_jnc[ci] = nj; c_dir[ci] = kk;
+                            c_val[ci] = (int) (short) x; c_jnc[ci] = nj; c_dir[ci] = kk; c_dn5[ci] = (int) (axj >> 12) & 15;
                             if constexpr (FORWARD) {
                                 c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
                                 c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);

@@ -342,6 +342,18 @@ void DevRun::release() { if (in_flight && ctx) { (void) hipStreamSynchronize(str
         if (!(dst)) { ctx->err = "out of device memory"; return -1; }                    \
     } while (0)
 
+// Vmf record budget of one forwardS_ng / forwardS1 call.  A record is written where a diagonal run starts and twice per
+// accepted intron: on real alignments a few per row.  The budget is one record per two band cells (the band, not the
+// bounding rectangle), at least 64 per row; a call that outgrows it reports so (n_skl = -3) and is run again with
+// vmf_scale x 8 by the ladder -- the old "two per cell of the rectangle" made batches of slabs run in dozens of groups.
+static int64_t vmf_capacity(const RunItem& it)
+{
+    const int64_t rows = it.a_right - it.a_left + 1, cols = it.b_right - it.b_left + 1;
+    const int64_t band = rows * std::min<int64_t>(cols, (int64_t) it.w.width);
+    const int64_t full = 2 * rows * cols + 64;
+    return std::min(full, std::max(band / 2, 64 * rows) * (int64_t) it.vmf_scale + 64);
+}
+
 int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int flav)
 {
     store = st; ctx = use_ctx ? use_ctx : st->ctx; flavour = flav; n = (int) items.size();
@@ -378,8 +390,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             bnd_tot = P.bnd_off + (flav >= 8 ? 6ll : 5ll) * P.buf_size + 8;   // udh forms: + the `ml` row of F
             if (flav >= 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
             if (flav == 7) {
-                const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
-                const int64_t cap = 2 * cells + 64;
+                const int64_t cap = vmf_capacity(it);
                 P.imd_off = cap;
                 tb_tot += cap;
             }
@@ -391,8 +402,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + 5ll * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal
-            const int64_t cells = (int64_t) (it.a_right - it.a_left + 1) * (it.b_right - it.b_left + 1);
-            const int64_t cap = (flav == 3) ? 2 * cells + 64 : 0;
+            const int64_t cap = (flav == 3) ? vmf_capacity(it) : 0;
             P.imd_off = cap;
             tb_tot += cap;
         }
@@ -664,7 +674,7 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     std::vector<int64_t> doff(n + 1, 0);
     for (int j = 0; j < n; ++j) {
         if (cnt[j] > skl_cap && redo.empty()) { ctx->err = "traceback record list exceeds the per-problem slot"; return -1; }
-        if (cnt[j] == -3) { ctx->err = "scalar engine: Vmf record buffer overflow"; return -1; }
+        // (cnt = -3: the call outgrew its Vmf record budget; the ladder runs it again with a larger one)
         doff[j + 1] = doff[j] + std::max(cnt[j], 0);
         n_skl[order[j]] = cnt[j];
     }
@@ -833,7 +843,9 @@ static int forward_like(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProbl
     if (n_probs <= 0) return 0;
     DevStore st; DevRun run;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
-    if (run.build(&st, items_of(sc, probs, n_probs), flav) || run.launch() || run.sync()) return -1;
+    std::vector<RunItem> items = items_of(sc, probs, n_probs);
+    for (RunItem& it : items) it.vmf_scale = 1 << 20;           // engine-level call: the full record budget at once
+    if (run.build(&st, items, flav) || run.launch() || run.sync()) return -1;
     std::vector<DevResult> r;
     std::vector<int> nskl;
     std::vector<int64_t> off;

@@ -49,7 +49,13 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     __shared__ unsigned short s_ax[4][64];
     enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_N };
     __shared__ int s_fd[4][FD_N][20];
+    // the tables an acceptor prices its candidates with: a read from memory inside that loop stalled the whole wave
+    // (some lane of 64 sits on an acceptor column at almost every step)
+    __shared__ short s_ipen[4096];
+    __shared__ short s_t53[256];
     for (int i = threadIdx.x; i < 32 * 32; i += 64) s_mtx[i] = A.sc->mtx[i];
+    for (int i = threadIdx.x; i < 4096; i += 64) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
+    for (int i = threadIdx.x; i < 256; i += 64) s_t53[i] = A.t53[i];
     __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
@@ -305,8 +311,8 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         const int d = c_dir[ci], don = c_jnc[ci];
                         if (nj - don < minl) continue;
                         int len = nj - don;
-                        if (len >= A.intpen_len) len = A.intpen_len - 1;
-                        const int x = c_val[ci] + A.intpen[len] + s3 + A.t53[16 * c_dn5[ci] + d3];
+                        const int pen = len < 4096 ? (int) s_ipen[len] : (int) A.intpen[min(len, A.intpen_len - 1)];
+                        const int x = c_val[ci] + pen + s3 + s_t53[16 * c_dn5[ci] + d3];
                         int cur = d == 0 ? H : (d == 1 ? E : F);
                         if (x <= cur) continue;
                         cur = (int) (short) x;

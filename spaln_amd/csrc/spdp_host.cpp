@@ -396,7 +396,7 @@ struct Aligner {
             if (may_overlap && !udh.empty() && tbs.size() >= 64) {
                 side_tbs.swap(tbs);
                 std::vector<RunItem> items;
-                for (const TbItem& t : side_tbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
+                for (const TbItem& t : side_tbs) { items.push_back(run_item(base + t.job, t.r, t.w, 0)); items.back().vmf_scale = 1 << 20; }   // (a few rows each)
                 side.side = true;
                 if (side.build(st, items, 1) || side.launch()) return -1;
                 lap("side fwd build+launch");
@@ -456,33 +456,47 @@ struct Aligner {
         auto run_vmf = [&](std::vector<TbItem>& list, int flav, const char* what) -> int {
             size_t limit = (size_t) 32 << 30;
             if (const char* e = getenv("SPDP_VMF_GB")) limit = (size_t) std::max(1, atoi(e)) << 30;
-            auto bytes_of = [](const TbItem& t) {
-                return ((size_t) 2 * (t.r.ar - t.r.al + 1) * (size_t) (t.r.br - t.r.bl + 1) + 64) * sizeof(int3);
+            auto recs_of = [](const TbItem& t, int scale) {
+                const size_t rows = t.r.ar - t.r.al + 1, cols = t.r.br - t.r.bl + 1;
+                const size_t band = rows * std::min<size_t>(cols, (size_t) t.w.width);
+                return std::min(2 * rows * cols + 64, std::max(band / 2, 64 * rows) * (size_t) scale + 64);
             };
-            for (size_t lo = 0; lo < list.size(); ) {
-                size_t hi = lo, sum = 0;
-                while (hi < list.size() && (hi == lo || sum + bytes_of(list[hi]) <= limit)) sum += bytes_of(list[hi++]);
-                std::vector<RunItem> items;
-                for (size_t k = lo; k < hi; ++k) items.push_back(run_item(base + list[k].job, list[k].r, list[k].w, 0));
-                DevRun run;
-                run.use_ctx = ctx;
-                if (run.build(st, items, flav) || run.launch() || run.sync()) return -1;
-                kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
-                std::vector<DevResult> res;
-                std::vector<int> nskl;
-                std::vector<int64_t> off;
-                std::vector<SpdpSkl> skl;
-                if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
-                for (size_t k = lo; k < hi; ++k) {
-                    const TbItem& t = list[k];
-                    const int c = nskl[k - lo];
-                    if (c == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
-                    if (c < 0) { ctx->err = what; return -1; }
-                    set_score(t.job, t.top, res[k - lo].score);
-                    const SpdpSkl* sk = skl.data() + off[k - lo];
-                    jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + c);
+            std::vector<size_t> todo(list.size());
+            for (size_t k = 0; k < list.size(); ++k) todo[k] = k;
+            for (int scale = 1; !todo.empty(); scale *= 8) {
+                std::vector<size_t> again;
+                for (size_t lo = 0; lo < todo.size(); ) {
+                    size_t hi = lo, sum = 0;
+                    while (hi < todo.size() && (hi == lo || sum + recs_of(list[todo[hi]], scale) * sizeof(int3) <= limit))
+                        sum += recs_of(list[todo[hi++]], scale) * sizeof(int3);
+                    std::vector<RunItem> items;
+                    for (size_t k = lo; k < hi; ++k) {
+                        const TbItem& t = list[todo[k]];
+                        items.push_back(run_item(base + t.job, t.r, t.w, 0));
+                        items.back().vmf_scale = scale;
+                    }
+                    DevRun run;
+                    run.use_ctx = ctx;
+                    if (run.build(st, items, flav) || run.launch() || run.sync()) return -1;
+                    kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+                    std::vector<DevResult> res;
+                    std::vector<int> nskl;
+                    std::vector<int64_t> off;
+                    std::vector<SpdpSkl> skl;
+                    if (run.fetch_results(res) || run.fetch_skl(nskl, off, skl)) return -1;
+                    for (size_t k = lo; k < hi; ++k) {
+                        const TbItem& t = list[todo[k]];
+                        const int c = nskl[k - lo];
+                        if (c == -3 && scale < 4096) { again.push_back(todo[k]); continue; }     // outgrew its record budget: once more, larger
+                        if (c == -1) { jobs[t.job].failed = true; ++overflowed; continue; }    // record list beyond its slot: this query only
+                        if (c < 0) { ctx->err = what; return -1; }
+                        set_score(t.job, t.top, res[k - lo].score);
+                        const SpdpSkl* sk = skl.data() + off[k - lo];
+                        jobs[t.job].rec.insert(jobs[t.job].rec.end(), sk, sk + c);
+                    }
+                    lo = hi;
                 }
-                lo = hi;
+                todo.swap(again);
             }
             return 0;
         };

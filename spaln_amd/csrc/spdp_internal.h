@@ -238,6 +238,7 @@ struct RunItem {
     SpdpWindow w;
     int n_im;          // UDH only
     int imd_intvl = 0; // scalar UDH only: Aln2s1::imd_intvl as lspS_ng set it
+    int vmf_scale = 1; // Vmf-backed forward runs: 1 = the usual record budget, larger on the retry after an overflow
 };
 
 // descriptors + work buffers of one engine flavour over a DevStore:

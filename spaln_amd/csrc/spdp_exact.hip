@@ -22,7 +22,8 @@
 
 #define XN 16                                    // rows per stripe (SPDP_NELEM)
 #define XNEV SPDP_NEV16
-__device__ static const unsigned char x_psp_bit[3] = {4, 1, 8};
+// post-splice flag of a state (src/aln.h:56): H 4, E 1, F 8 -- arithmetic, not a table in memory
+__device__ __forceinline__ int x_psp_bit_of(int d) { return d == 0 ? 4 : (d == 1 ? 1 : 8); }
 
 __device__ __forceinline__ int x_sadd(int a, int b) { return max(a + b, SPDP_FLOOR16); }
 __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      // lane k <- lane k - 1 of its group
@@ -153,9 +154,12 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         // per-lane state: H of the last two steps, F, E, flags, the candidate list of my row
         int H1 = XNEV, H2 = XNEV, F1 = XNEV, E = XNEV, ps = 0;
         int B1 = 0, B2 = 0, C1 = 0, C2 = 0, FC1 = 0, EC = 0, EB = 0, FB = 0;    // forward: flags / pointers of H (two steps), F, E
-        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], c_dn5[5], idx[5], ncand = -1;      // c_dn5: dinc5 of the donor column
+        // the donor candidates of my row, best first, in registers: slots are moved, never indexed by a variable (a
+        // run-time index into five register arrays costs a select chain per access, and the wave pays for it at every step
+        // on which ANY of its 64 lanes sits on a donor or acceptor column)
+        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], c_dn5[5], ncand = -1;      // c_dn5: dinc5 of the donor column
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; idx[i] = i; }
+        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; }
         const int m = ml + 1 + k;                             // my row
         // udh: is the current intermediate row in this stripe, and on which lane
         int mm_ = 0, k9 = 0, k8 = -1;
@@ -305,9 +309,12 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 if (fl & 2) {                                 // acceptor: Sjsites::get
                     const int s3 = col.x >> 16;
                     const int d3 = (axj >> 8) & 15;
-                    int mx_ci[3] = {-1, -1, -1}, br_ci = -1;  // udh: maxprd[d], brd (as candidate slots)
-                    for (int l = 0; l <= ncand; ++l) {
-                        const int ci = idx[l];
+                    // udh: maxprd[d], brd -- the best candidate per state and overall: its value and link (and state)
+                    bool mx_on[3] = {false, false, false}; int mx_v[3] = {0, 0, 0}, mx_lk[3] = {0, 0, 0};
+                    bool br_on = false; int br_v = 0, br_d = 0;
+#pragma unroll
+                    for (int ci = 0; ci < 5; ++ci) {
+                        if (ci > ncand) continue;
                         const int d = c_dir[ci], don = c_jnc[ci];
                         if (nj - don < minl) continue;
                         int len = nj - don;
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         if (x <= cur) continue;
                         cur = (int) (short) x;
                         if (d == 0) H = cur; else if (d == 1) E = cur; else F = cur;
-                        ps |= x_psp_bit[d];
+                        ps |= x_psp_bit_of(d);
                         if constexpr (FORWARD) {
                             const int inner = vadd(m, don, c_ulk[ci]);
                             const int ptr = vadd(m, nj, inner);
@@ -326,10 +333,13 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                             if (d && cur > H) { HB = bml; HC = ptr; }
                         }
                         if constexpr (UDH) {
-                            if (mx_ci[d] < 0 || x > c_val[mx_ci[d]]) {
-                                mx_ci[d] = ci;
-                                if (br_ci < 0 || x > c_val[br_ci]) br_ci = ci;
-                            }
+#pragma unroll
+                            for (int dd = 0; dd < 3; ++dd)
+                                if (dd == d && (!mx_on[dd] || x > mx_v[dd])) {
+                                    // NB the reference compares x with the stored candidate's own VALUE (prd->val), as here
+                                    mx_on[dd] = true; mx_v[dd] = c_val[ci]; mx_lk[dd] = c_ulk[ci];
+                                    if (!br_on || x > br_v) { br_on = true; br_v = c_val[ci]; br_d = d; }
+                                }
                             const int lk = c_ulk[ci], bml = c_ml[ci];
                             if (d == 0) { HC = lk; HB = bml; } else if (d == 1) { EC = lk; EB = bml; } else { FC = lk; FB = bml; }
                             if (d && cur > H) { HC = lk; HB = bml; }
@@ -337,16 +347,16 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         if (d && cur > H) H = cur;
                     }
                     if constexpr (UDH) {
-                        if (imd_here && br_ci >= 0) {             // the acceptor sits on the intermediate row (:91-110)
-                            const int maxd = c_dir[br_ci];
-                            const int lk = c_ulk[mx_ci[maxd]];
+                        if (imd_here && br_on) {                  // the acceptor sits on the intermediate row (:91-110)
+                            const int maxd = br_d;
+                            const int lk = maxd == 0 ? mx_lk[0] : (maxd == 1 ? mx_lk[1] : mx_lk[2]);
                             LNK(imd_i, 0, 0, rj) = lk; rlst = rj;
                             if (maxd == 0) HC = rj; else if (maxd == 1) EC = rj; else FC = rj;
                             hb_pv = maxd;
                             if (maxd != 0) HC = rj;
                             else {
-                                if (mx_ci[1] >= 0 && E > H + gop) EC = rj + width;
-                                if (mx_ci[2] >= 0 && F > H + gop) { LNK(imd_i, 0, 1, rj) = lk; FC = rj + width; }
+                                if (mx_on[1] && E > H + gop) EC = rj + width;
+                                if (mx_on[2] && F > H + gop) { LNK(imd_i, 0, 1, rj) = lk; FC = rj + width; }
                             }
                         }
                     }
@@ -354,28 +364,38 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 if (fl & 1) {                                 // donor: Sjsites::put
                     const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
                     for (int kk = hb_pv ? 1 : 0; kk < 3; ++kk) {
-                        if (ps & x_psp_bit[kk]) continue;
+                        if (ps & x_psp_bit_of(kk)) continue;
                         const int from = kk == 0 ? H : (kk == 1 ? E : F);
                         if (kk && from <= H + gop) continue;
                         const int x = from + sigJ;
                         if (x <= XNEV) continue;
-                        int l = ncand < 4 ? ++ncand : 4;
-                        while (--l >= 0) {
-                            if (x >= c_val[idx[l]]) { const int t = idx[l]; idx[l] = idx[l + 1]; idx[l + 1] = t; }
-                            else break;
-                        }
-                        if (++l < 4) {
-                            const int ci = idx[l];
-                            c_val[ci] = (int) (short) x; c_jnc[ci] = nj; c_dir[ci] = kk; c_dn5[ci] = (int) (axj >> 12) & 15;
+                        // the free slot starts below the list and moves up past every entry x ties or beats
+                        int pos = ncand < 4 ? ncand + 1 : 4;
+                        if (ncand < 4) ++ncand;
+#pragma unroll
+                        for (int l = 4; l >= 1; --l)
+                            if (pos == l && x >= c_val[l - 1]) {
+                                c_val[l] = c_val[l - 1]; c_jnc[l] = c_jnc[l - 1]; c_dir[l] = c_dir[l - 1]; c_dn5[l] = c_dn5[l - 1];
+                                c_ml[l] = c_ml[l - 1]; c_ulk[l] = c_ulk[l - 1];
+                                pos = l - 1;
+                            }
+                        if (pos < 4) {
+                            int n_ml = 0, n_ulk = 0;
                             if constexpr (FORWARD) {
-                                c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
-                                c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                                n_ml = kk == 0 ? HB : (kk == 1 ? EB : FB);
+                                n_ulk = kk == 0 ? HC : (kk == 1 ? EC : FC);
                             }
                             if constexpr (UDH) {
-                                if (imd_here) { if (kk & 1) LNK(imd_i, 0, 0, rj) = rlst; c_ulk[ci] = rj; }
-                                else c_ulk[ci] = kk == 0 ? HC : (kk == 1 ? EC : FC);
-                                c_ml[ci] = kk == 0 ? HB : (kk == 1 ? EB : FB);
+                                if (imd_here) { if (kk & 1) LNK(imd_i, 0, 0, rj) = rlst; n_ulk = rj; }
+                                else n_ulk = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                                n_ml = kk == 0 ? HB : (kk == 1 ? EB : FB);
                             }
+#pragma unroll
+                            for (int l = 0; l < 4; ++l)
+                                if (l == pos) {
+                                    c_val[l] = (int) (short) x; c_jnc[l] = nj; c_dir[l] = kk; c_dn5[l] = (int) (axj >> 12) & 15;
+                                    c_ml[l] = n_ml; c_ulk[l] = n_ulk;
+                                }
                         }
                         else --ncand;
                     }

@@ -11,11 +11,13 @@ sys.path.insert(0, '.')
 from spaln_amd import abi, defaults, engine, synth
 intpen, t53 = defaults.exact_tables()
 eng = engine.Engine(0)
-sc = defaults.scoring(scalar_engines=2, intpen=intpen, t53=t53)
+import os
+sc = defaults.scoring(scalar_engines=int(os.environ.get("ENG", "2")), intpen=intpen, t53=t53)
 ps = abi.ProblemSet()
 for w, q, s5, s3, _ in synth.make_batch(64, seed=7, mrna_len=500, n_exons=3, flank=300, intron_hi=1500):
     ps.add(q, w, s5, s3, **synth.exact_inputs(w))
 print(eng.homscore_s(sc, ps)[:4])
+if os.environ.get("ALIGN"): print(len(eng.align_s(sc, ps)))
 print(sum((p.a_right - p.a_left) * (p.b_right - p.b_left) for p in ps.items) / 64)
 eng.close()
 PY

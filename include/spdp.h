@@ -388,7 +388,9 @@ int64_t spdp_cells_h(const SpdpProblemH* p, const SpdpWindow* wdw);
  * right end was tracked: fhlastH1 never sets maxh.val, fwd2h1_simd.h:692-785) + raw Mfile
  * records end -> start.  n_skl = -1 flags the reference's fatal "Unexpected dir"; n_skl = -2 says
  * its traceback would start outside its bitmap (a winning genomic end gap moves the end cell
- * beyond b_right, fwd2h1_simd.h:756-766, 780: an out-of-bounds read there, undefined result). */
+ * beyond b_right, fwd2h1_simd.h:756-766, 780: an out-of-bounds read there, undefined result);
+ * n_skl = -4: the record list of this query outgrew its slot (4096 records per traceback call): this query only comes
+ * back without records, the rest of the batch is unaffected. */
 int spdp_wip_forward_h(SpdpContext* ctx, const SpdpScoringH* sc,
                        const SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
 /* hirschbergH1_wip with n_im intermediate rows (src/fwd2h1_wip_simd.h:338): cpos[i] points at

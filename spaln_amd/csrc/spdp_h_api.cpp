@@ -305,7 +305,7 @@ static int run_forward_group(HStore& st, const std::vector<HItem>& items, bool w
     if (walk) {
         for (int s = 0; s < nr; ++s) {
             int c = n_skl[s];
-            if (c == -1) { ctx->err = "traceback record buffer overflow"; return -1; }
+            if (c == -1) { n_skl[s] = -5; c = 0; }           // record list beyond its slot: this query only (flag -4 at the ABI)
             if (c == -3) c = 1;                              // the single start record
             if (c < 0) c = 0;
             off[s + 1] = off[s] + c;
@@ -823,7 +823,8 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
                 const int stt = fo.n_skl[f];
                 if (stt == -2) { if (!t.flag) t.flag = -1; }
                 else if (stt == -3) { if (!t.flag) t.flag = -2; }
-                if (stt == -2) continue;
+                else if (stt == -5) { if (!t.flag) t.flag = -4; }
+                if (stt == -2 || stt == -5) continue;
                 t.rec.insert(t.rec.end(), fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
             }
         }
@@ -959,7 +960,7 @@ int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpPr
         SpdpAlignment& o = out[idx[f]];
         o.score = fo.res[f].score;
         if (!traceback) continue;
-        if (fo.n_skl[f] < 0) { o.n_skl = fo.n_skl[f]; continue; }    // -3: undefined in the reference (mode 3 pointer lanes)
+        if (fo.n_skl[f] < 0) { o.n_skl = fo.n_skl[f] == -5 ? -4 : fo.n_skl[f]; continue; }    // -3: undefined in the reference (mode 3 pointer lanes)
         std::vector<SpdpSkl> rec(fo.skl.begin() + fo.off[f], fo.skl.begin() + fo.off[f + 1]);
         o.n_skl = (int) rec.size();
         o.skl = dup_skl(rec);

@@ -208,8 +208,6 @@ def main_c3(args):
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
         if world > 1:
             cpu_base = None                                   # timed at N = 1 only
-        elif exact and not _ref_available():
-            cpu_base = None                                   # (the port's ladder is the -A2 one)
         elif _ref_available() and not args.cpu_port:
             from oracle import oracle
             ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 64 * ncores, len(batch)))

@@ -103,6 +103,10 @@ typedef struct SpdpProblem {
     const uint8_t* cano5;                  /* Exinon::isDonor(n)  (src/codepot.h:106)            */
     const uint8_t* cano3;                  /* Exinon::isAccpt(n)                                 */
     const uint8_t* dinc;                   /* INT53::dinc5 << 4 | INT53::dinc3 (src/codepot.h:49) */
+    /* ---- optional, the -A0 / -A1 engines only (the `_wip` engines do not read it, as in the reference) ---------- */
+    const int32_t* cip;                    /* Cip_score::cip_score(m) for query row m = 0 .. a_len (src/gsinfo.h:128-140,
+                                              src/fwd2s1.cc:254, src/fwd2s1_simd.cc:50): the bonus every intron accepted
+                                              in row m earns when the query carries conserved intron positions; NULL = none */
 } SpdpProblem;
 
 typedef struct SpdpWindow { int32_t lw, up, width; } SpdpWindow;   /* WINDOW, src/cmn.h:133 */

@@ -115,7 +115,7 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
                     const Cand* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
                     from = hf[prd->dir];
-                    x = prd->val + spjscr(sc, p, prd->jnc, n);
+                    x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     if (x > *from) { *from = x; maxphl[prd->dir] = prd; }
                 }
                 for (int k = 0; k < NOD; ++k) {
@@ -279,7 +279,7 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
                 for (int l = 0; l <= ncand; ++l) {
                     const Cand* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
-                    x = prd->val + spjscr(sc, p, prd->jnc, n);
+                    x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     from = hf[prd->dir];
                     if (x >= from->val) { from->val = x; maxphl[prd->dir] = prd; }
                 }
@@ -500,7 +500,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                     const Rvdwmlj* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
                     from = hf[prd->dir];
-                    x = prd->val + spjscr(sc, p, prd->jnc, n);
+                    x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     if (x > from->val) { from->val = x; maxphl[prd->dir] = prd; }
                 }
                 int maxk = NOD;

@@ -96,6 +96,7 @@ class Problem(C.Structure):
         ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
         ("cano5", C.c_void_p), ("cano3", C.c_void_p), ("dinc", C.c_void_p),
+        ("cip", C.c_void_p),
     ]
 
 
@@ -170,7 +171,7 @@ class ProblemSet:
         self.items = []
 
     def add(self, a, b, sig5, sig3, a_left=0, a_right=None, b_left=0, b_right=None,
-            exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None):
+            exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None, cip=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)
         p = Problem()
@@ -193,6 +194,11 @@ class ProblemSet:
             assert min(c5.size, c3.size, dc.size) >= b.size + 1
             self._keep += [c5, c3, dc]
             p.cano5, p.cano3, p.dinc = c5.ctypes.data, c3.ctypes.data, dc.ctypes.data
+        if cip is not None:
+            cp = np.ascontiguousarray(cip, dtype=np.int32)
+            assert cp.size >= a.size + 1
+            self._keep.append(cp)
+            p.cip = cp.ctypes.data
         self.items.append(p)
         return p
 

@@ -209,7 +209,8 @@ void DevStore::release()
     if (d_cols) (void) hipFree(d_cols);
     if (d_aux) (void) hipFree(d_aux);
     if (d_intpen) (void) hipFree(d_intpen);
-    d_sc = d_a = d_cols = d_aux = d_intpen = nullptr;
+    if (d_cip) (void) hipFree(d_cip);
+    d_sc = d_a = d_cols = d_aux = d_intpen = d_cip = nullptr;
 }
 
 int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* probs, int n)
@@ -307,6 +308,20 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         for (int j = 0; j < std::max(1, std::min(sc.nquant, SPDP_MAX_QUANT)); ++j) max_pen = std::max(max_pen, (int) sc.qm_pen[j]);
         fp_gain = (sc.spj && max_s5 > INT32_MIN) ? std::max(0, max_s5 + max_s3 + max_pen) : 0;
     }
+    // conserved-intron bonuses of the queries that carry them (SpdpProblem::cip), one row of a_len + 1 ints each
+    cip_off.assign(n, -1);
+    {
+        std::vector<int32_t> hcip;
+        for (int i = 0; i < n; ++i)
+            if (probs[i].cip) {
+                cip_off[i] = (int32_t) hcip.size();
+                hcip.insert(hcip.end(), probs[i].cip, probs[i].cip + probs[i].a_len + 1);
+            }
+        if (!hcip.empty()) {
+            HIPCHK(hipMalloc(&d_cip, hcip.size() * sizeof(int32_t)));
+            HIPCHK(hipMemcpy(d_cip, hcip.data(), hcip.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
     DevScoring hsc;
     to_dev_scoring(&sc, &hsc);
     HIPCHK(hipMalloc(&d_sc, sizeof(DevScoring)));
@@ -383,6 +398,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.imd_intvl = it.imd_intvl;
         P.a_off = st->a_off[it.parent];
         P.col_off = st->col_off[it.parent];
+        P.cip_off = st->cip_off.empty() ? -1 : st->cip_off[it.parent];
         P.bnd_off = bnd_tot; bnd_tot += (int64_t) P.buf_size + SPDP_BND_PAD;
         P.tb_off = tb_tot;
         if (flav >= 6) {                // -A1 engines: hv / fv (/ hb / hc / fc) by diagonal, buf_size ints each, a counter
@@ -532,6 +548,7 @@ int DevRun::launch()
         S.sc = (const DevScoring*) store->d_sc; S.probs = (const DevProblem*) d_probs; S.n_probs = n;
         S.a_codes = (const uint8_t*) store->d_a; S.cols = (const int2*) store->d_cols;
         S.aux = (const uint8_t*) store->d_aux; S.intpen = (const int16_t*) store->d_intpen;
+        S.cip = (const int*) store->d_cip;
         S.intpen_len = store->sc.intpen_len; S.ipen = store->sc.ipen;
         memcpy(S.t53, store->sc.t53, sizeof S.t53);
         S.work = (int*) d_bnd; S.vmf = (int3*) d_tb; S.res = (DevResult*) d_res;

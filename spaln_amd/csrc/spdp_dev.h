@@ -38,7 +38,8 @@ struct DevProblem {
     int32_t lw, up, width, buf_size;
     int32_t flags;                 // bit0 a_exgl, bit1 a_exgr, bit2 b_exgl, bit3 b_exgr
     int32_t n_im;                  // UDH: number of intermediate rows
-    int32_t imd_intvl, pad0;       // scalar UDH: rows between intermediates (Aln2s1::imd_intvl)
+    int32_t imd_intvl;             // scalar UDH: rows between intermediates (Aln2s1::imd_intvl)
+    int32_t cip_off;               // exact engines: first entry of the query's cip row in ScalarArgs::cip, -1 = none
     int64_t a_off;                 // into a_codes; residue of row m is a_codes[a_off + m - 1]
     int64_t col_off;               // into cols
     int64_t bnd_off;               // into bnd (entries)

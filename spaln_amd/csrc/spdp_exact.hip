@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 #pragma unroll
         for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; }
         const int m = ml + 1 + k;                             // my row
+        const int sigJ_cip = (A.cip && P.cip_off >= 0 && m <= P.a_right) ? A.cip[P.cip_off + m] : 0;     // Cip_score::cip_score(m), fwd2s1_simd.cc:50
         // udh: is the current intermediate row in this stripe, and on which lane
         int mm_ = 0, k9 = 0, k8 = -1;
         bool is_imd_ = false;
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         if (nj - don < minl) continue;
                         int len = nj - don;
                         const int pen = len < 4096 ? (int) s_ipen[len] : (int) A.intpen[min(len, A.intpen_len - 1)];
-                        const int x = c_val[ci] + pen + s3 + s_t53[16 * c_dn5[ci] + d3];
+                        const int x = c_val[ci] + sigJ_cip + pen + s3 + s_t53[16 * c_dn5[ci] + d3];
                         int cur = d == 0 ? H : (d == 1 ? E : F);
                         if (x <= cur) continue;
                         cur = (int) (short) x;

@@ -73,6 +73,7 @@ struct ScalarArgs {
     const uint8_t*    a_codes;
     const int2*       cols;
     const uint8_t*    aux;        // per position: {bit0 isDonor | bit1 isAccpt, dinc5 << 4 | dinc3}
+    const int*        cip;        // Cip_score::cip_score(m) rows of the queries that have one (DevProblem::cip_off), or null
     const int16_t*    intpen;
     int               intpen_len;
     int               ipen;
@@ -219,7 +220,8 @@ struct DevStore {
     int n_parents = 0;
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> a_len, b_len;
-    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr, *d_cip = nullptr;
+    std::vector<int32_t> cip_off;           // per parent: first entry of its cip row in d_cip, -1 = none
     bool has_exact = false;                 // exact-model inputs (cano / dinc / intpen) were supplied
     int fp_maxpos = 1, fp_gain = 0;         // largest substitution score; best net score of one intron (>= 0)
     DevStore() = default;

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
         const int* qprof = T.mtx + acode * 32;
         const bool internal = FWD ? (spj && (!a_exgr || m < ar)) : true;
+        const int sigB = (row && A.cip && P.cip_off >= 0) ? A.cip[P.cip_off + m] : 0;      // Cip_score::cip_score(m)
 
         // per-row state
         int e1v = NEV, e1p = 0;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
                 for (int l = 0; l < NC; ++l) {
                     const int len = n - cj[l];
                     if (acc && l <= ncand && len >= llmt) {
-                        const int x = cv[l] + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
+                        const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                         if (cd[l] == K_H) { if (FWD ? (x >= hv) : (x > hv)) { hv = x; sel_h = l; } }
                         else if (cd[l] == K_E) { if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; sel_e = l; } }
                         else { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
         if (s_lo <= s_hi) {
             const int acode = (row && m >= 1) ? acod[m - 1] : 0;
             const int* qprof = T.mtx + acode * 32;
+            const int sigB = (row && A.cip && P.cip_off >= 0) ? A.cip[P.cip_off + m] : 0;  // Cip_score::cip_score(m)
             St E = {NEV, bl - ar, bl - ar, 0, EOU};
             unsigned psp = 0;
             int cv[NC], cj[NC], cd[NC], cu[NC], cl[NC], cm[NC], ck[NC], cx[NC];
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                     for (int l = 0; l < NC; ++l) {
                         const int len = n - cj[l];
                         if (acc && l <= ncand && len >= llmt) {
-                            const int x = cv[l] + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
+                            const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                             if (cd[l] == K_H) { if (x > H.v) { H.v = x; sel_h = l; } }
                             else if (cd[l] == K_E) { if (x > E.v) { E.v = x; sel_e = l; } }
                             else { if (x > F.v) { F.v = x; sel_f = l; } }

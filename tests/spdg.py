@@ -51,6 +51,7 @@ def problem(fx: dict, ps: abi.ProblemSet | None = None):
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"],
                q["a_left"], q["a_right"], q["b_left"], q["b_right"],
                (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), **extra)
+    p._owner = ps            # the set owns buffers made on the fly (dinc): callers that drop the set keep them alive through p
     return ps, p
 
 
@@ -65,6 +66,7 @@ def problem_rev(fx: dict, ps: abi.ProblemSet | None = None):
                      dinc=(fx["r_dinc5"].astype("uint8") << 4) | fx["r_dinc3"].astype("uint8"))
     p = ps.add(fx["r_a_codes"], fx["r_b_codes"], fx["r_sig5"], fx["r_sig3"], r[0], r[1], r[2], r[3],
                (r[4], r[5], r[6], r[7]), **extra)
+    p._owner = ps
     return ps, p
 
 
@@ -104,4 +106,5 @@ def problem_h(fx: dict, ps: abi.ProblemSetH | None = None):
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
                fx["phs5"], fx["phs3"], q["a_left"], q["a_right"], q["b_left"], q["b_right"],
                (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), dinc=dinc)
+    p._owner = ps
     return ps, p

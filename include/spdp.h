@@ -260,6 +260,25 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
                    const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 void spdp_free_rescored(SpdpRescored* out, int n);
 
+/* The edit records skl_rngS_ng collects for the Cigar / Vulgar / SAM writers (Cigar::push / Vulgar::push / Samfmt,
+ * src/gsinfo.h:286-375; pushed at src/fwd2s1.cc:492-689), as raw records in the order the reference writes them -- one
+ * format per call, as algmode.nsa selects one there.  CIGAR and SAM: {op, len} in {op, alen}, blen = 0; VULGAR:
+ * {op, alen, blen}.  The records are the reference's as they are: SAM carries the running '=' / 'X' stretch once per
+ * aligned base, and a gap whose intron candidate lost can come out with a non-positive length (:509-538).  The SAM header
+ * fields are those of a forward-strand hit (b->inex.sens == 0). */
+#define SPDP_FMT_CIGAR  1
+#define SPDP_FMT_VULGAR 2
+#define SPDP_FMT_SAM    3
+typedef struct SpdpEdit { int32_t op, alen, blen; } SpdpEdit;
+typedef struct SpdpEdits {
+    int32_t   n;
+    SpdpEdit* rec;                   /* owned by the library until spdp_free_edits */
+    int32_t   sam_flag, sam_pos, sam_mapq, sam_left, sam_right;   /* Samfmt::flag, pos, mapq, left, right (SAM only) */
+} SpdpEdits;
+int spdp_skl_edits_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
+                     const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, int format, SpdpEdits* out);
+void spdp_free_edits(SpdpEdits* out, int n);
+
 /* ---- device groups: every GPU of the node behind one handle -------------- */
 /* The reference is one process with worker threads (spaln -t N, src/spaln.cc:1389-1468: a master hands
  * whole queries to the workers).  A group owns one context per listed HIP device (a device may be listed more

@@ -425,6 +425,37 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		}
 		snprintf(nm, sizeof nm, "rng_eij_A%d", alg);
 		w.put_i32(nm, ej);
+		// the edit records skl_rngS_ng builds for the Cigar / Vulgar / SAM writers (fwd2s1.cc:469-475, 509-689),
+		// one run per format (algmode.nsa selects which record file exists); -A2 and -A0 only
+		if (alg == 2 || alg == 0) {
+		    const int keep_nsa = algmode.nsa;
+		    const int fmts[3] = {CIG_FORM, VLG_FORM, SAM_FORM};
+		    const char* tag[3] = {"cigar", "vulgar", "sam"};
+		    for (int f = 0; f < 3; ++f) {
+			algmode.nsa = fmts[f];
+			restore();
+			Gsinfo	g2;
+			g2.skl = gsi.skl;
+			(void) skl_rngS_ng((const Seq**) seqs, &g2, pwd);
+			std::vector<int> ops;
+			if (f == 0 && g2.cigar)
+			    for (int i = 0; i < g2.cigar->size(); ++i) { ops.push_back(g2.cigar->rec[i].ope); ops.push_back(g2.cigar->rec[i].len); }
+			if (f == 1 && g2.vlgar)
+			    for (int i = 0; i < g2.vlgar->size(); ++i) {
+				ops.push_back(g2.vlgar->rec[i].ope); ops.push_back(g2.vlgar->rec[i].alen); ops.push_back(g2.vlgar->rec[i].blen);
+			    }
+			if (f == 2 && g2.samfm) {
+			    for (int i = 0; i < g2.samfm->size(); ++i) { ops.push_back(g2.samfm->rec[i].ope); ops.push_back(g2.samfm->rec[i].len); }
+			    std::vector<int> hd = {g2.samfm->flag, g2.samfm->pos, g2.samfm->mapq, g2.samfm->left, g2.samfm->right};
+			    snprintf(nm, sizeof nm, "rng_samhdr_A%d", alg);
+			    w.put_i32(nm, hd);
+			}
+			snprintf(nm, sizeof nm, "rng_%s_A%d", tag[f], alg);
+			w.put_i32(nm, ops);
+			g2.skl = 0;				// (owned by gsi)
+		    }
+		    algmode.nsa = keep_nsa;
+		}
 	    }
 	}
 	return 0;

@@ -127,6 +127,18 @@ class Rescored(C.Structure):
                 ("unp", C.c_int32), ("val", C.c_int32), ("n_exons", C.c_int32), ("exons", C.POINTER(Exon))]
 
 
+class Edit(C.Structure):                 # SpdpEdit
+    _fields_ = [("op", C.c_int32), ("alen", C.c_int32), ("blen", C.c_int32)]
+
+
+class Edits(C.Structure):                # SpdpEdits
+    _fields_ = [("n", C.c_int32), ("rec", C.POINTER(Edit)), ("sam_flag", C.c_int32), ("sam_pos", C.c_int32),
+                ("sam_mapq", C.c_int32), ("sam_left", C.c_int32), ("sam_right", C.c_int32)]
+
+
+FMT_CIGAR, FMT_VULGAR, FMT_SAM = 1, 2, 3
+
+
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,

@@ -149,6 +149,12 @@ struct RescoreArgs {
     int*              out_rec;
     int               gop, gep, lgop, lgep, codonk1, minl, jneibr, lsg, ipen;
     int16_t           t53[256];
+    // edit records for the Cigar / Vulgar / SAM writers (0: none)
+    int               ops_format; // 1 Cigar, 2 Vulgar, 3 SAM
+    int3*             ops;        // query i: records at ops_off[i] .. ops_off[i + 1]
+    const int64_t*    ops_off;
+    int*              ops_cnt;    // records the walk produced (may exceed the slot: then the slot is full and the rest lost)
+    const int*        a_len;      // SAM: query lengths
 };
 extern "C" hipError_t spdp_launch_rescore(const RescoreArgs* a, hipStream_t s);
 

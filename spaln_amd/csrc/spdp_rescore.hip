@@ -3,8 +3,9 @@
 // the per-exon records (EISCR: boundaries, exon / intron scores, splice signals, match / mismatch /
 // gap counts in the exon and within `jneibr` positions of its junctions).  One thread per query: the
 // work is O(alignment length) and the inputs (residues, per-position signals) are already resident.
-// The output-format side channels of the reference (Cigar / Vulgar / SAM strings) are not produced,
-// and queries carrying an intron-position profile (PfqItr) are not supported.
+// With RescoreArgs::ops_format set, the walk also writes the edit records the reference collects for its Cigar /
+// Vulgar / SAM writers (Cigar::push, Vulgar::push, Samfmt, src/fwd2s1.cc:469-475, 509-689) -- one format per launch, as
+// algmode.nsa selects one in the reference.  Queries carrying an intron-position profile (PfqItr) are not supported.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,10 +66,17 @@ __global__ void spdp_rescore_s(RescoreArgs A)
         rb[UNP3] = fst.unp - que[qp].unp; rb[GAP3] = fst.gap - que[qp].gap;
     };
     auto push = [&]() { for (int i = 0; i < 21; ++i) rec_out[21 * n_rec + i] = rb[i]; ++n_rec; };
+    // edit records: format 1 Cigar {ope, len}, 2 Vulgar {ope, alen, blen}, 3 SAM {ope, len}
+    const int fmt = A.ops_format;
+    int3* ops = fmt ? A.ops + A.ops_off[qi] : nullptr;
+    const int ops_cap = fmt ? (int) (A.ops_off[qi + 1] - A.ops_off[qi]) : 0;
+    int n_ops = 0;
+    auto op = [&](int f, int ope, int x, int y) { if (fmt == f) { if (n_ops < ops_cap) ops[n_ops] = make_int3(ope, x, y); ++n_ops; } };
 
     int w = 0;
     if (num >= 2 && skl[1].y == skl[0].y && b_exgl) { ++w; --num; }
     int m = skl[w].x, n = skl[w].y;
+    if (m) op(3, 'H', m, 0);                                      // SAM: local alignment, clipped query start
     int ai = m, bi = n;
     int h = 0, ha = 0, hb = 0, s5 = 0, s3 = 0;
     int insert = 0, deletn = 0, intlen = 0, preint = 0, psp = 0;
@@ -83,6 +91,9 @@ __global__ void spdp_rescore_s(RescoreArgs A)
             int xi = NEVSEL_I;
             if (intlen) { insert -= intlen; xi = rb[ISCR] + gap_penalty(insert); }
             if (xi >= x) {                                        // intron
+                if (preint) { op(1, 'D', preint, 0); op(3, 'D', preint, 0); op(2, 'G', 0, preint); }
+                op(1, 'N', intlen, 0); op(3, 'N', intlen, 0);
+                op(2, '5', 0, 2); op(2, 'I', 0, intlen - 4); op(2, '3', 0, 2);
                 hb = ha;
                 if (rb[RIGHT] - rb[LEFT] > 0) push();
                 rb[LEFT] = rb[RIGHT] + intlen;
@@ -92,7 +103,10 @@ __global__ void spdp_rescore_s(RescoreArgs A)
                 h += xi;
                 insert -= preint;
             } else h += x;
-            if (insert) insert = intlen = preint = 0;
+            if (insert) {
+                op(1, 'D', insert, 0); op(3, 'D', insert, 0); op(2, 'G', 0, insert);
+                insert = intlen = preint = 0;
+            }
         }
         const int ni = wn - n;
         if (ni && deletn) {
@@ -104,18 +118,22 @@ __global__ void spdp_rescore_s(RescoreArgs A)
         int d = (i >= 0) ? ni : mi;
         if (d) {
             m += d;
-            int x = 0;
+            op(1, 'M', d, 0); op(2, 'M', d, d);
+            int x = 0, run = 0;                                   // SAM: the running '=' / 'X' stretch is pushed at every base
             for ( ; d; --d, ++ai, ++bi, ++n) {
                 shift(psp++ == jn);
                 const int ac = a[ai], bc = cols[bi + 1].y;
                 x += sc->mtx[ac * 32 + bc];
-                if (ac == bc) ++fst.mch; else ++fst.mmc;
+                if (ac == bc) { if (run < 0) { op(3, 'X', -run, 0); run = 0; } ++fst.mch; ++run; }
+                else { if (run > 0) { op(3, '=', run, 0); run = 0; } ++fst.mmc; --run; }
+                if (run > 0) op(3, '=', run, 0); else if (run < 0) op(3, 'X', -run, 0);
             }
             h += x;
             fval += x;
         }
         if (i > 0) {
             deletn += i;
+            op(1, 'I', i, 0); op(3, 'I', i, 0); op(2, 'G', i, 0);
             for (int j = 0; j < i; ++j) { shift(psp++ == jn); ++fst.unp; }
         } else if (i < 0) {
             i = -i;
@@ -145,8 +163,16 @@ __global__ void spdp_rescore_s(RescoreArgs A)
         }
         m = wm; n = wn;
     }
-    if (insert && !(a_exgr && m == P.a_right)) { h += gap_penalty(insert); fst.gap += 1; fst.unp += insert; }
-    if (deletn && !(b_exgr && n == P.b_right)) { h += gap_penalty(deletn); fst.gap += 1; fst.unp += deletn; }
+    if (insert && !(a_exgr && m == P.a_right)) {
+        h += gap_penalty(insert); fst.gap += 1; fst.unp += insert;
+        op(1, 'D', insert, 0); op(3, 'D', insert, 0); op(2, 'G', 0, insert);
+    }
+    if (deletn && !(b_exgr && n == P.b_right)) {
+        h += gap_penalty(deletn); fst.gap += 1; fst.unp += deletn;
+        op(1, 'I', deletn, 0); op(3, 'I', deletn, 0); op(2, 'G', deletn, 0);
+    }
+    if (fmt == 3 && m < A.a_len[qi]) op(3, 'H', A.a_len[qi] - m, 0);     // clipped query end
+    if (fmt) A.ops_cnt[qi] = n_ops;
     rb[ESCR] = h - hb; rb[ISCR] = 0; rb[SIG5] = 0; rb[RIGHT] = n; rb[RRIGHT] = m;
     store(pst, n - rb[LEFT] <= jn);
     push();

@@ -24,12 +24,18 @@
 enum { R_POOL = 7 };
 enum { RP_PROBS = 0, RP_SKL, RP_SOFF, RP_SCNT, RP_ROFF, RP_HDR, RP_REC };
 
-int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
-                   const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out)
+// the rescoring walk over a batch; `out` (records of spdp_skl_rng_s) and `edits` (format != 0: spdp_skl_edits_s) may each be null
+static int rescore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
+                     const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out,
+                     int format, SpdpEdits* edits)
 {
-    if (!ctx || !sc || !rp || !probs || n_probs < 0 || !aln || !out) return -1;
+    if (!ctx || !sc || !rp || !probs || n_probs < 0 || !aln || (!out && !edits)) return -1;
     if (rp->jneibr < 1 || rp->jneibr > 32) { ctx->err = "jneibr out of range (1 .. 32)"; return -1; }
-    for (int i = 0; i < n_probs; ++i) { memset(&out[i], 0, sizeof out[i]); out[i].score = SPDP_NEVSEL; }
+    if (edits && (format < SPDP_FMT_CIGAR || format > SPDP_FMT_SAM)) { ctx->err = "edit records: unknown format"; return -1; }
+    for (int i = 0; i < n_probs; ++i) {
+        if (out) { memset(&out[i], 0, sizeof out[i]); out[i].score = SPDP_NEVSEL; }
+        if (edits) memset(&edits[i], 0, sizeof edits[i]);
+    }
     if (!n_probs) return 0;
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
@@ -83,12 +89,31 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
     A.codonk1 = rp->codonk1; A.minl = rp->minl; A.jneibr = rp->jneibr; A.lsg = rp->lsg; A.ipen = sc->spj ? sc->ipen : 0;
     memcpy(A.t53, sc->t53, sizeof A.t53);
     if (!sc->spj && rp->lsg) { ctx->err = "splice-aware rescoring of a problem set uploaded without splice signals"; return -1; }
+    // edit records: Cigar / Vulgar need at most 7 per corner, SAM up to two per aligned base on top of that
+    std::vector<int64_t> ooff(nr + 1, 0);
+    std::vector<int> alen(nr);
+    void *d_ops = nullptr, *d_ooff = nullptr, *d_ocnt = nullptr, *d_alen = nullptr;
+    struct Freer { void** p[4]; ~Freer() { for (void** q : p) if (*q) (void) hipFree(*q); } } freer{{&d_ops, &d_ooff, &d_ocnt, &d_alen}};
+    if (edits) {
+        for (int s = 0; s < nr; ++s) {
+            alen[s] = probs[idx[s]].a_len;
+            ooff[s + 1] = ooff[s] + 8ll * scnt[s] + 16 + (format == SPDP_FMT_SAM ? 2ll * alen[s] + 16 : 0);
+        }
+        HIPCHK(hipMalloc(&d_ops, (size_t) ooff[nr] * sizeof(int3)));
+        HIPCHK(hipMalloc(&d_ooff, (nr + 1) * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&d_ocnt, nr * sizeof(int)));
+        HIPCHK(hipMalloc(&d_alen, nr * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(d_ooff, ooff.data(), (nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_alen, alen.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        A.ops_format = format; A.ops = (int3*) d_ops; A.ops_off = (const int64_t*) d_ooff; A.ops_cnt = (int*) d_ocnt;
+        A.a_len = (const int*) d_alen;
+    }
     HIPCHK(spdp_launch_rescore(&A, ctx->stream));
     std::vector<int> hdr((size_t) nr * 8), rec((size_t) rtot * 21);
     HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int s = 0; s < nr; ++s) {
+    for (int s = 0; s < nr && out; ++s) {
         SpdpRescored& o = out[idx[s]];
         const int* h = &hdr[(size_t) s * 8];
         o.score = h[0]; o.mch = h[1]; o.mmc = h[2]; o.gap = h[3]; o.unp = h[4]; o.val = h[5];
@@ -96,7 +121,52 @@ int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescorePar
         o.exons = (SpdpExon*) malloc(sizeof(SpdpExon) * (size_t) std::max(1, o.n_exons));
         memcpy(o.exons, &rec[(size_t) roff[s] * 21], sizeof(SpdpExon) * (size_t) o.n_exons);
     }
+    if (edits) {
+        std::vector<int3> ops((size_t) ooff[nr]);
+        std::vector<int> ocnt(nr);
+        HIPCHK(hipMemcpy(ops.data(), d_ops, ops.size() * sizeof(int3), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ocnt.data(), d_ocnt, nr * sizeof(int), hipMemcpyDeviceToHost));
+        for (int s = 0; s < nr; ++s) {
+            SpdpEdits& e = edits[idx[s]];
+            if (ocnt[s] > ooff[s + 1] - ooff[s]) { ctx->err = "edit records: slot too small"; return -1; }
+            e.n = ocnt[s];
+            e.rec = (SpdpEdit*) malloc(sizeof(SpdpEdit) * (size_t) std::max(1, e.n));
+            for (int k = 0; k < e.n; ++k) { const int3 o = ops[(size_t) ooff[s] + k]; e.rec[k].op = o.x; e.rec[k].alen = o.y; e.rec[k].blen = o.z; }
+            if (format == SPDP_FMT_SAM) {
+                // Samfmt's header fields for a forward-strand hit (b->inex.sens == 0; src/fwd2s1.cc:492-495, 678-687)
+                const SpdpAlignment& al = aln[idx[s]];
+                const SpdpProblem& p = probs[idx[s]];
+                int first = 1;
+                if (al.n_skl > 2 && al.skl[2].n == al.skl[1].n && p.b_exgl) first = 2;
+                const int* h = &hdr[(size_t) s * 8];
+                e.sam_flag = 0;
+                e.sam_pos = al.skl[first].n;
+                e.sam_left = al.skl[first].m;
+                e.sam_right = al.skl[al.n_skl - 1].m;
+                e.sam_mapq = 30 + (int) (100ll * (h[2] + h[4]) / std::max(1, p.a_len));
+            }
+        }
+    }
     return 0;
+}
+
+int spdp_skl_rng_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
+                   const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out)
+{
+    if (!out) return -1;
+    return rescore_s(ctx, sc, rp, probs, n_probs, aln, out, 0, nullptr);
+}
+
+int spdp_skl_edits_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreParams* rp,
+                     const SpdpProblem* probs, int n_probs, const SpdpAlignment* aln, int format, SpdpEdits* out)
+{
+    if (!out) return -1;
+    return rescore_s(ctx, sc, rp, probs, n_probs, aln, nullptr, format, out);
+}
+
+void spdp_free_edits(SpdpEdits* out, int n)
+{
+    for (int i = 0; i < n; ++i) { free(out[i].rec); out[i].rec = nullptr; out[i].n = 0; }
 }
 
 void spdp_free_rescored(SpdpRescored* out, int n)

@@ -448,3 +448,33 @@ def test_local_udh_against_oracle(eng):
             if res[i][0] != ws or res[i][1].ravel().tolist() != (wskl or []):
                 bad.append((vmf, i, res[i][0], ws, res[i][1].ravel().tolist()[:12], (wskl or [])[:12]))
         assert not bad, bad[:3]
+
+
+def test_skl_edits_s_goldens(eng):
+    """spdp_skl_edits_s: the edit records skl_rngS_ng collects for its Cigar / Vulgar / SAM writers, on the reference's
+    own corner lists (-A2 and -A0 alignments of every fixture), record for record; SAM header fields included"""
+    from spaln_amd import abi
+    bad, n_checked, n_introns = [], 0, 0
+    for f in golden_files() + golden_files("c2_") + golden_files("o3_"):
+        fx = spdg.load(f)
+        for alg in (0, 2):
+            if f"rng_cigar_A{alg}" not in fx:
+                continue
+            sc = spdg.scoring(fx)
+            ps, p = spdg.problem(fx)
+            fs = fx[f"rng_fstat_A{alg}"]
+            kw = dict(codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"], jneibr=int(fs[6]), lsg=int(fs[7]))
+            skl = [fx[f"aln_skl_A{alg}"].reshape(-1, 2)]
+            (cig, _), = eng.skl_edits_s(sc, ps, skl, abi.FMT_CIGAR, **kw)
+            (vul, _), = eng.skl_edits_s(sc, ps, skl, abi.FMT_VULGAR, **kw)
+            (sam, hdr), = eng.skl_edits_s(sc, ps, skl, abi.FMT_SAM, **kw)
+            ok = (cig[:, :2].ravel().tolist() == fx[f"rng_cigar_A{alg}"].tolist()
+                  and vul.ravel().tolist() == fx[f"rng_vulgar_A{alg}"].tolist()
+                  and sam[:, :2].ravel().tolist() == fx[f"rng_sam_A{alg}"].tolist()
+                  and hdr == fx[f"rng_samhdr_A{alg}"].tolist())
+            n_checked += 1
+            n_introns += int((cig[:, 0] == ord("N")).sum())
+            if not ok:
+                bad.append((f.split("/")[-1], alg, cig[:6].tolist(), fx[f"rng_cigar_A{alg}"][:12].tolist(), hdr,
+                            fx[f"rng_samhdr_A{alg}"].tolist()))
+    assert n_checked >= 60 and n_introns >= 100 and not bad, bad[:3]

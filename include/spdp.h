@@ -472,6 +472,11 @@ int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescorePa
                    const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 
 /* resident batch (benchmarking / pipelines); one live batch of this kind per context */
+/* the protein-side edit records (skl_rngH_ng, src/fwd2h1.cc:663-667, 695-924): SPDP_FMT_CIGAR or SPDP_FMT_VULGAR (the
+ * latter after Vulgar::postproc, as the reference keeps them; no SAM form exists there) */
+int spdp_skl_edits_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                     const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, int format, SpdpEdits* out);
+
 typedef struct SpdpBatchH SpdpBatchH;
 SpdpBatchH* spdp_batch_upload_h(SpdpContext* ctx, const SpdpScoringH* sc,
                                 const SpdpProblemH* probs, int n_probs);

@@ -233,6 +233,28 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		}
 		snprintf(nm, sizeof nm, "rng_eij_A%d", alg);
 		w.put_i32(nm, ej);
+		// the edit records behind the Cigar / Vulgar writers (fwd2h1.cc:663-667, 695-924; Vulgar after postproc)
+		if (alg == 2 || alg == 0) {
+		    const int keep_nsa = algmode.nsa;
+		    for (int f = 0; f < 2; ++f) {
+			algmode.nsa = f ? VLG_FORM : CIG_FORM;
+			restore();
+			Gsinfo	g2;
+			g2.skl = gsi.skl;
+			(void) skl_rngH_ng((const Seq**) seqs, &g2, pwd);
+			std::vector<int> ops;
+			if (!f && g2.cigar)
+			    for (int i = 0; i < g2.cigar->size(); ++i) { ops.push_back(g2.cigar->rec[i].ope); ops.push_back(g2.cigar->rec[i].len); }
+			if (f && g2.vlgar)
+			    for (int i = 0; i < g2.vlgar->size(); ++i) {
+				ops.push_back(g2.vlgar->rec[i].ope); ops.push_back(g2.vlgar->rec[i].alen); ops.push_back(g2.vlgar->rec[i].blen);
+			    }
+			snprintf(nm, sizeof nm, "rng_%s_A%d", f ? "vulgar" : "cigar", alg);
+			w.put_i32(nm, ops);
+			g2.skl = 0;
+		    }
+		    algmode.nsa = keep_nsa;
+		}
 	    }
 	}
 	return 0;

@@ -187,6 +187,11 @@ struct HRescoreArgs {
     int16_t           t53[256];
     uint8_t           mid[32];    // tron code -> its codon's middle base (0..3), 4 = ambiguous
     uint8_t           tron_of[64];// codon (A C G T order) -> tron code
+    // edit records for the Cigar / Vulgar writers (0: none; 1 Cigar, 2 Vulgar), as RescoreArgs
+    int               ops_format;
+    int3*             ops;
+    const int64_t*    ops_off;
+    int*              ops_cnt;
 };
 extern "C" hipError_t spdh_launch_rescore(const void* args, hipStream_t s);
 

@@ -272,6 +272,12 @@ __global__ void spdh_rescore(HRescoreArgs A)
         rb[UNP3] = fst.unp - que[qp].unp; rb[GAP3] = fst.gap - que[qp].gap;
     };
     auto push = [&]() { for (int i = 0; i < 21; ++i) rec_out[21 * n_rec + i] = rb[i]; ++n_rec; };
+    // edit records (Cigar::push / Vulgar::push, src/fwd2h1.cc:695-924): format 1 Cigar {ope, len}, 2 Vulgar {ope, alen, blen}
+    const int fmt = A.ops_format;
+    int3* ops = fmt ? A.ops + A.ops_off[qi] : nullptr;
+    const int ops_cap = fmt ? (int) (A.ops_off[qi + 1] - A.ops_off[qi]) : 0;
+    int n_ops = 0;
+    auto op = [&](int f, int ope, int x, int y) { if (fmt == f) { if (n_ops < ops_cap) ops[n_ops] = make_int3(ope, x, y); ++n_ops; } };
 
     if (A.sup_tcodon) {
         const int cs0 = bat(skl[num - 1].y - 2);
@@ -289,6 +295,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
     if ((A.lcl & 17) && sgat(bbn + 1, 2) > h) h = sgat(bbn + 1, 2);
     if ((A.lcl & 20) && sgat(bbn, 1) > h) h = sgat(bbn, 1);
     rb[LEFT] = n; rb[RLEFT] = m; rb[ISCR] = NEVSEL_I; rb[SIG3] = h;
+    if (m) op(1, 'H', m, 0);                                       // local alignment
     for (;;) {
         --num;
         if (!(num > 0 || hi > NEVSEL_I)) break;
@@ -301,6 +308,12 @@ __global__ void spdh_rescore(HRescoreArgs A)
             h += termgap ? unp_penalty3(insert) : gap_penalty3(insert);
             if (hi > NEVSEL_I && insert > intlen) hi += gap_penalty3(insert - intlen);
             if (hi > NEVSEL_I && hi >= h) {              // intron
+                if (preint) { op(1, 'D', preint, 0); op(2, 'G', 0, preint); }
+                op(1, 'N', intlen, 0);
+                // (`phs` is what the last frame shift left in it, not the intron's phase: as in the reference)
+                if (phs == -1) op(2, 'S', 0, 1); else if (phs == 1) op(2, 'S', 0, 2);
+                op(2, '5', 0, 2); op(2, 'I', 0, intlen - 4); op(2, '3', 0, 2);
+                if (phs == -1) op(2, 'S', 1, 2); else if (phs == 1) op(2, 'S', 1, 1);
                 hb = ha;
                 if (rb[RIGHT] - rb[LEFT] > 1) push();
                 rb[LEFT] = rb[RIGHT] + intlen;
@@ -312,6 +325,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
             hi = NEVSEL_I;
             if (insert) {                               // post-intron gap
                 if (term && is_term(bat(bi - 1))) insert -= 3;
+                op(1, 'D', insert, 0);
                 phs = insert % 3;
                 insert -= phs;
                 if (!((P.a_exgl && m == P.a_left) || (P.a_exgr && m == P.a_right))) fst.gap += ngop;
@@ -319,10 +333,12 @@ __global__ void spdh_rescore(HRescoreArgs A)
                 if (phs) {                              // insertion frame shift
                     rb[RIGHT] = n - phs; rb[RRIGHT] = m; rb[ISCR] = NEVSEL_I;
                     push();
+                    op(2, 'F', 0, phs);
                     rb[LEFT] = n; rb[RLEFT] = m;
                     h += (phs == 1) ? A.gape1 : A.gape2;
                     fval += (phs == 1) ? A.gape1 : A.gape2;
                 }
+                if (insert) op(2, 'G', 0, insert);
                 ngop = insert = intlen = preint = 0;
             }
         }
@@ -333,6 +349,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
             if ((phs = deletn % 3)) {                   // deletion frame shift
                 rb[RIGHT] = n + phs; rb[RRIGHT] = m; rb[ISCR] = NEVSEL_I;
                 push();
+                op(2, 'F', phs, 0);
                 rb[LEFT] = n; rb[RLEFT] = m;
                 h += A.extragop;
                 fval += A.extragop;
@@ -342,11 +359,13 @@ __global__ void spdh_rescore(HRescoreArgs A)
                 bi += phs;
                 bbn += phs;
             }
+            if (deletn > 2) op(2, 'G', deletn / 3, 0);
             deletn = 0;
         }
         int i = mi - ni;
         int d = (i >= 0) ? ni : mi;
         if (d) {
+            op(1, 'M', d, 0); op(2, 'M', d / 3, d);
             n += d;
             m += d / 3;
             for ( ; d > 2; d -= 3, ++ai, bi += 3, bbn += 3, psp += 3) {
@@ -364,6 +383,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
         if (i > 0) {
             cs = -1;
             deletn += i;
+            op(1, 'I', i, 0);
             for (int j = 0; j < i; j += 3, psp += 3) { shift(psp / 3 == jn); fst.unp += 3; }
         } else if (i < 0) {
             i = -i;
@@ -447,6 +467,22 @@ __global__ void spdh_rescore(HRescoreArgs A)
     fval += A.gop * fst.gap + A.gep * unp3;
     hdr[0] = h; hdr[1] = fst.mch; hdr[2] = fst.mmc; hdr[3] = fst.gap; hdr[4] = unp3; hdr[5] = fval;
     hdr[6] = n_rec; hdr[7] = 0;
+    if (fmt == 2) {
+        // Vulgar::postproc (src/gsinfo.cc:1206-1226) over the records before the trailing dummy: match lengths next to
+        // split codons and frame shifts
+        const int cnt = min(n_ops, ops_cap);
+        for (int k = 0; k < cnt; ++k) {
+            const int o = ops[k].x;
+            if (o == 'M' || o == 'D') {
+                const bool split = (k + 1 < cnt) ? (ops[k + 1].x == 'S' && ops[k + 1].z == 2) : false;      // (the dummy 'E' follows the last one)
+                if (split) { --ops[k].y; ops[k].z -= 3; }
+            } else if (o == 'F' && k > 0) {
+                if (ops[k].y == 1) { ops[k - 1].z -= 2; ops[k].z += 2; }
+                else if (ops[k].y == 2) { ops[k - 1].z -= 1; ops[k].z += 1; ops[k].y = 1; }
+            }
+        }
+    }
+    if (fmt) A.ops_cnt[qi] = n_ops;
 }
 
 extern "C" hipError_t spdh_launch_rescore(const void* args, hipStream_t stream)

@@ -197,12 +197,17 @@ void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64])
     }
 }
 
-int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
-                   const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out)
+static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                     const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out,
+                     int format, SpdpEdits* edits)
 {
-    if (!ctx || !sc || !rp || !probs || n_probs < 0 || !aln || !out) return -1;
+    if (!ctx || !sc || !rp || !probs || n_probs < 0 || !aln || (!out && !edits)) return -1;
     if (rp->jneibr < 1 || rp->jneibr > 32) { ctx->err = "jneibr out of range (1 .. 32)"; return -1; }
-    for (int i = 0; i < n_probs; ++i) { memset(&out[i], 0, sizeof out[i]); out[i].score = SPDP_NEVSEL; }
+    if (edits && format != SPDP_FMT_CIGAR && format != SPDP_FMT_VULGAR) { ctx->err = "edit records (protein): Cigar or Vulgar"; return -1; }
+    for (int i = 0; i < n_probs; ++i) {
+        if (out) { memset(&out[i], 0, sizeof out[i]); out[i].score = SPDP_NEVSEL; }
+        if (edits) memset(&edits[i], 0, sizeof edits[i]);
+    }
     if (!n_probs) return 0;
     if (!sc->intpen || sc->intpen_len <= 0) { ctx->err = "rescoring needs SpdpScoringH.intpen / t53"; return -1; }
     if (sc->mtx_rows > 32 || sc->mtx_cols > 32) { ctx->err = "matrix larger than 32 x 32"; return -1; }
@@ -282,12 +287,23 @@ int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescorePa
     A.minl = rp->minl; A.jneibr = rp->jneibr; A.lcl = rp->lcl; A.sup_tcodon = rp->sup_tcodon;
     memcpy(A.t53, sc->t53, sizeof A.t53);
     spdp_genetic_code_tables(A.mid, A.tron_of);
+    std::vector<int64_t> ooff(nr + 1, 0);
+    void *d_ops = nullptr, *d_ooff = nullptr, *d_ocnt = nullptr;
+    struct Freer { void** p[3]; ~Freer() { for (void** q : p) if (*q) (void) hipFree(*q); } } freer{{&d_ops, &d_ooff, &d_ocnt}};
+    if (edits) {
+        for (int s = 0; s < nr; ++s) ooff[s + 1] = ooff[s] + 12ll * scnt[s] + 16;       // an accepted intron pushes up to 8 Vulgar records
+        HIPCHK(hipMalloc(&d_ops, (size_t) ooff[nr] * sizeof(int3)));
+        HIPCHK(hipMalloc(&d_ooff, (nr + 1) * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&d_ocnt, nr * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(d_ooff, ooff.data(), (nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        A.ops_format = format; A.ops = (int3*) d_ops; A.ops_off = (const int64_t*) d_ooff; A.ops_cnt = (int*) d_ocnt;
+    }
     HIPCHK(spdh_launch_rescore(&A, ctx->stream));
     std::vector<int> hdr((size_t) nr * 8), rec((size_t) rtot * 21);
     HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int s = 0; s < nr; ++s) {
+    for (int s = 0; s < nr && out; ++s) {
         SpdpRescored& o = out[idx[s]];
         const int* h = &hdr[(size_t) s * 8];
         o.score = h[0]; o.mch = h[1]; o.mmc = h[2]; o.gap = h[3]; o.unp = h[4]; o.val = h[5];
@@ -295,5 +311,32 @@ int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescorePa
         o.exons = (SpdpExon*) malloc(sizeof(SpdpExon) * (size_t) std::max(1, o.n_exons));
         memcpy(o.exons, &rec[(size_t) roff[s] * 21], sizeof(SpdpExon) * (size_t) o.n_exons);
     }
+    if (edits) {
+        std::vector<int3> ops((size_t) ooff[nr]);
+        std::vector<int> ocnt(nr);
+        HIPCHK(hipMemcpy(ops.data(), d_ops, ops.size() * sizeof(int3), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ocnt.data(), d_ocnt, nr * sizeof(int), hipMemcpyDeviceToHost));
+        for (int s = 0; s < nr; ++s) {
+            SpdpEdits& e = edits[idx[s]];
+            if (ocnt[s] > ooff[s + 1] - ooff[s]) { ctx->err = "edit records: slot too small"; return -1; }
+            e.n = ocnt[s];
+            e.rec = (SpdpEdit*) malloc(sizeof(SpdpEdit) * (size_t) std::max(1, e.n));
+            for (int k = 0; k < e.n; ++k) { const int3 o = ops[(size_t) ooff[s] + k]; e.rec[k].op = o.x; e.rec[k].alen = o.y; e.rec[k].blen = o.z; }
+        }
+    }
     return 0;
+}
+
+int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                   const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out)
+{
+    if (!out) return -1;
+    return rescore_h(ctx, sc, rp, probs, n_probs, aln, out, 0, nullptr);
+}
+
+int spdp_skl_edits_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                     const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, int format, SpdpEdits* out)
+{
+    if (!out) return -1;
+    return rescore_h(ctx, sc, rp, probs, n_probs, aln, nullptr, format, out);
 }

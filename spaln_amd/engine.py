@@ -70,6 +70,7 @@ def load_library() -> C.CDLL:
     lib.spdp_free_rescored.argtypes = [C.c_void_p, C.c_int]
     lib.spdp_skl_edits_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_free_edits.argtypes = [C.c_void_p, C.c_int]
+    lib.spdp_skl_edits_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_cells_h.restype = C.c_int64
     for f in ("spdp_wip_forward_h", "spdp_homscore_h", "spdp_align_h"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -373,6 +374,28 @@ class Engine:
             rec = np.ctypeslib.as_array(C.cast(out[i].rec, C.POINTER(C.c_int32)), shape=(k, 3)).copy() if k else \
                 np.zeros((0, 3), dtype=np.int32)
             res.append((rec, [out[i].sam_flag, out[i].sam_pos, out[i].sam_mapq, out[i].sam_left, out[i].sam_right]))
+        self.lib.spdp_free_edits(out, n)
+        return res
+
+    def skl_edits_h(self, sc, ps, alignments, fmt, *, minl, jneibr, lcl=15, sup_tcodon=0):
+        """the edit records skl_rngH_ng collects for the Cigar / Vulgar writers: per query records (k x 3: op, alen, blen)"""
+        n = len(ps)
+        keep = []
+        arr = (abi.Alignment * n)()
+        for i, skl in enumerate(alignments):
+            skl = np.ascontiguousarray(skl, dtype=np.int32).reshape(-1, 2)
+            keep.append(skl)
+            arr[i].score, arr[i].n_skl = 0, skl.shape[0]
+            arr[i].skl = C.cast(skl.ctypes.data, C.POINTER(abi.Skl))
+        rp = abi.RescoreParamsH(int(minl), int(jneibr), int(lcl), int(sup_tcodon))
+        out = (abi.Edits * n)()
+        self._check(self.lib.spdp_skl_edits_h(self.ctx, C.byref(sc), C.byref(rp), ps.array(), n, arr, int(fmt), out),
+                    "spdp_skl_edits_h")
+        res = []
+        for i in range(n):
+            k = out[i].n
+            res.append(np.ctypeslib.as_array(C.cast(out[i].rec, C.POINTER(C.c_int32)), shape=(k, 3)).copy() if k else
+                       np.zeros((0, 3), dtype=np.int32))
         self.lib.spdp_free_edits(out, n)
         return res
 

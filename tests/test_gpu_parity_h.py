@@ -256,6 +256,39 @@ def test_skl_rng_h_goldens(eng):
     assert n_checked >= 60 and not bad, bad[:4]
 
 
+def test_skl_edits_h_goldens(eng):
+    """spdp_skl_edits_h: the Cigar and (post-processed) Vulgar edit records of skl_rngH_ng on the reference's own
+    corner lists, record for record -- h1_* and the dictdisc c1_* fixtures, -A2 and -A0 alignments"""
+    from spaln_amd import abi as _abi
+    from tests.conftest import golden_files as _gf
+    bad, n_checked, n_introns = [], 0, 0
+    for f in H_FILES + _gf("c1_"):
+        if _name(f) == "h1_cut_right":
+            continue
+        fx = spdg.load(f)
+        h = dict(zip(spdg.HPARAM_NAMES, (int(x) for x in fx["hparams"])))
+        rp = [int(x) for x in fx["rparams"]]
+        for alg in (0, 2):
+            if f"rng_cigar_A{alg}" not in fx:
+                continue
+            if _name(f) == "h1_local_udh" and alg == 2:
+                continue
+            sc = spdg.scoring_h(fx)
+            ps, _ = spdg.problem_h(fx)
+            kw = dict(minl=fx["prm"]["minl"], jneibr=rp[4], lcl=h["lcl"], sup_tcodon=rp[1])
+            skl = [fx[f"aln_skl_A{alg}"].reshape(-1, 2)]
+            cig, = eng.skl_edits_h(sc, ps, skl, _abi.FMT_CIGAR, **kw)
+            vul, = eng.skl_edits_h(sc, ps, skl, _abi.FMT_VULGAR, **kw)
+            ok = (cig[:, :2].ravel().tolist() == fx[f"rng_cigar_A{alg}"].tolist()
+                  and vul.ravel().tolist() == fx[f"rng_vulgar_A{alg}"].tolist())
+            n_checked += 1
+            n_introns += int((cig[:, 0] == ord("N")).sum())
+            if not ok:
+                bad.append((_name(f), alg, cig[:8, :2].ravel().tolist(), fx[f"rng_cigar_A{alg}"][:16].tolist(),
+                            vul[:6].ravel().tolist(), fx[f"rng_vulgar_A{alg}"][:18].tolist()))
+    assert n_checked >= 50 and n_introns >= 60 and not bad, bad[:3]
+
+
 def test_align_h_a6_recursive_switch(eng):
     """SpdpScoringH.recursive (algmode.alg & 4): lspH_ng's recursive branch, against the reference's -A6 output"""
     cases = [(n, fx) for n, fx in _cases(3) if n not in UNDEFINED]

@@ -472,6 +472,44 @@ int spdp_skl_rng_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescorePa
                    const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
 
 /* resident batch (benchmarking / pipelines); one live batch of this kind per context */
+/* ---- result records ----------------------------------------------------------------------------
+ * What Gsinfo::ExonForm (src/sqpr.cc:820-996) makes of an alignment's EISCR records: the ExonRecord / GeneRecord
+ * payload of the -O12 `.erd` / `.grd` files (same layout as src/seq.h:1212-1255, so a caller can fwrite them as they
+ * are) and the text lines of -O4.  Host only.  `eij` = SpdpRescored::exons of spdp_skl_rng_s / _h (end marker
+ * included or not). */
+typedef struct SpdpSiteMap { int32_t site0, step; } SpdpSiteMap;    /* Seq::SiteNo(n) = site0 + n * step (step -1 on the reverse strand) */
+typedef struct SpdpExonRecord {      /* ExonRecord */
+    int32_t Elen, Nmmc, Nunp, Rleft, Rright, Gleft, Gright, Ilen, Bmmc, Bunp, miss, phase;
+    float   Pmatch, Escore, Iscore, Sig3, Sig5;
+    char    Iends[4];
+} SpdpExonRecord;
+typedef struct SpdpGeneRecord {      /* GeneRecord */
+    int32_t  Cid, Gstart, Gend;
+    uint32_t Nrecord, nexn;
+    int32_t  Rid, Rlen, Rstart, Rend, mmc, unp, bmmc, bunp, ng;
+    float    Gscore, Pmatch, Pcover;
+    int16_t  Csense, Rsense;
+} SpdpGeneRecord;
+typedef struct SpdpExonFormIn {
+    const SpdpExon* eij;  int32_t n_eij;
+    int32_t scr;                     /* Gsinfo::scr (the alignment's score, raw) */
+    const uint8_t* gene_codes;       /* residue codes of the genomic sequence (nucleotide or tron), whole sequence */
+    int32_t gene_is_tron;            /* 1: tron genome (protein queries): intron ends print through `ncodon` */
+    int32_t qry_is_protein;
+    int32_t q_left, q_right, q_len, q_many, q_sens;      /* qry->left, right, len, many, inex.sens */
+    SpdpSiteMap gmap, qmap;
+    float   scale;                   /* alprm.scale * (gene->exin->fact, when set) */
+    float   aln_scale;               /* alprm.scale */
+    int32_t hsp_len;                 /* sum of gene->jxt[].jlen ("HC:" of the @ line), 0 without seeding */
+    int32_t gene_id, qry_id;         /* GeneRecord::Cid (gene->did), Rid (running query index of the .qrd file) */
+    int32_t first_exon_record;       /* GeneRecord::Nrecord: exon records written before this gene */
+} SpdpExonFormIn;
+/* returns the number of exon records written (<= cap), -1 on bad input */
+int spdp_exon_form(const SpdpExonFormIn* in, SpdpExonRecord* exons, int cap, SpdpGeneRecord* gene);
+/* the -O4 lines (header != 0: with the column header the reference prints once per run); returns the length written,
+ * or -(needed + 1) when buf is too small */
+int spdp_exon_form_text(const SpdpExonFormIn* in, const char* qname, const char* gname, int header, char* buf, int cap);
+
 /* the protein-side edit records (skl_rngH_ng, src/fwd2h1.cc:663-667, 695-924): SPDP_FMT_CIGAR or SPDP_FMT_VULGAR (the
  * latter after Vulgar::postproc, as the reference keeps them; no SAM form exists there) */
 int spdp_skl_edits_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,

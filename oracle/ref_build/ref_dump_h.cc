@@ -233,6 +233,34 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		}
 		snprintf(nm, sizeof nm, "rng_eij_A%d", alg);
 		w.put_i32(nm, ej);
+		// the exon-form report of this alignment (Gsinfo::ExonForm, sqpr.cc:820-996: the -O4 lines, the same numbers
+		// the -O12 ExonRecord / GeneRecord files carry), and the few values of the run it reads besides the records
+		if (alg == 2 || alg == 0) {
+		    FILE* tf = tmpfile();
+		    if (tf) {
+			static bool out_ready = false;
+			if (!out_ready) { (void) setup_output(EXN_FORM, 0, false); out_ready = true; }	// sets the printer's out_form (sqpr.cc:95-118)
+			gsi.printgene(seqs, EXN_FORM, tf);
+			const long len = ftell(tf);
+			std::vector<unsigned char> txt(len > 0 ? len : 0);
+			rewind(tf);
+			if (len > 0 && fread(txt.data(), 1, len, tf) != (size_t) len) txt.clear();
+			fclose(tf);
+			snprintf(nm, sizeof nm, "rng_exn_A%d", alg);
+			w.put(nm, 1, txt.data(), (int) txt.size());
+			const Seq* gene = seqs[1];
+			const Seq* qry = seqs[0];
+			float scale = alprm.scale;
+			if (gene->exin && gene->exin->fact) scale *= gene->exin->fact;
+			int sbits; memcpy(&sbits, &scale, 4);
+			int abits; { float as = alprm.scale; memcpy(&abits, &as, 4); }
+			std::vector<int> ep = {sbits, abits, gene->SiteNo(0), gene->SiteNo(1), gene->len, (int) gene->inex.sens,
+			    qry->SiteNo(0), qry->SiteNo(1), qry->len, (int) qry->inex.sens, qry->many, (int) gsi.scr,
+			    qry->left, qry->right};
+			snprintf(nm, sizeof nm, "rng_exnprm_A%d", alg);
+			w.put_i32(nm, ep);
+		    }
+		}
 		// the edit records behind the Cigar / Vulgar writers (fwd2h1.cc:663-667, 695-924; Vulgar after postproc)
 		if (alg == 2 || alg == 0) {
 		    const int keep_nsa = algmode.nsa;

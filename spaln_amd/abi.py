@@ -139,6 +139,32 @@ class Edits(C.Structure):                # SpdpEdits
 FMT_CIGAR, FMT_VULGAR, FMT_SAM = 1, 2, 3
 
 
+class SiteMap(C.Structure):              # SpdpSiteMap
+    _fields_ = [("site0", C.c_int32), ("step", C.c_int32)]
+
+
+class ExonRecord(C.Structure):           # SpdpExonRecord = ExonRecord, src/seq.h:1212
+    _fields_ = [(k, C.c_int32) for k in ("Elen", "Nmmc", "Nunp", "Rleft", "Rright", "Gleft", "Gright", "Ilen", "Bmmc",
+                                          "Bunp", "miss", "phase")] + \
+               [(k, C.c_float) for k in ("Pmatch", "Escore", "Iscore", "Sig3", "Sig5")] + [("Iends", C.c_char * 4)]
+
+
+class GeneRecord(C.Structure):           # SpdpGeneRecord = GeneRecord, src/seq.h:1235
+    _fields_ = [("Cid", C.c_int32), ("Gstart", C.c_int32), ("Gend", C.c_int32), ("Nrecord", C.c_uint32),
+                ("nexn", C.c_uint32)] + \
+               [(k, C.c_int32) for k in ("Rid", "Rlen", "Rstart", "Rend", "mmc", "unp", "bmmc", "bunp", "ng")] + \
+               [(k, C.c_float) for k in ("Gscore", "Pmatch", "Pcover")] + [("Csense", C.c_int16), ("Rsense", C.c_int16)]
+
+
+class ExonFormIn(C.Structure):           # SpdpExonFormIn
+    _fields_ = [("eij", C.c_void_p), ("n_eij", C.c_int32), ("scr", C.c_int32), ("gene_codes", C.c_void_p),
+                ("gene_is_tron", C.c_int32), ("qry_is_protein", C.c_int32),
+                ("q_left", C.c_int32), ("q_right", C.c_int32), ("q_len", C.c_int32), ("q_many", C.c_int32),
+                ("q_sens", C.c_int32), ("gmap", SiteMap), ("qmap", SiteMap), ("scale", C.c_float),
+                ("aln_scale", C.c_float), ("hsp_len", C.c_int32), ("gene_id", C.c_int32), ("qry_id", C.c_int32),
+                ("first_exon_record", C.c_int32)]
+
+
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,

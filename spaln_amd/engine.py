@@ -109,6 +109,32 @@ def load_library() -> C.CDLL:
     return lib
 
 
+def exon_form(lib, eij, *, scr, gene_codes, protein, q_left, q_right, q_len, gmap, qmap, scale, aln_scale,
+              q_many=1, q_sens=0, hsp_len=0, qname="qry", gname="win", header=False):
+    """Gsinfo::ExonForm from EISCR records (k x 21 ints, as skl_rng_s / _h return them): (exon records, gene record,
+    the -O4 text).  Host only: works without a GPU."""
+    eij = np.ascontiguousarray(eij, dtype=np.int32).reshape(-1, 21)
+    codes = np.ascontiguousarray(gene_codes, dtype=np.uint8)
+    a = abi.ExonFormIn()
+    a.eij, a.n_eij, a.scr = eij.ctypes.data, eij.shape[0], int(scr)
+    a.gene_codes, a.gene_is_tron, a.qry_is_protein = codes.ctypes.data, int(bool(protein)), int(bool(protein))
+    a.q_left, a.q_right, a.q_len, a.q_many, a.q_sens = int(q_left), int(q_right), int(q_len), int(q_many), int(q_sens)
+    a.gmap = abi.SiteMap(int(gmap[0]), int(gmap[1])); a.qmap = abi.SiteMap(int(qmap[0]), int(qmap[1]))
+    a.scale, a.aln_scale, a.hsp_len = float(scale), float(aln_scale), int(hsp_len)
+    lib.spdp_exon_form.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_exon_form_text.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    ex = (abi.ExonRecord * max(1, eij.shape[0]))()
+    g = abi.GeneRecord()
+    n = lib.spdp_exon_form(C.byref(a), ex, eij.shape[0], C.byref(g))
+    if n < 0:
+        raise RuntimeError("spdp_exon_form failed")
+    buf = C.create_string_buffer(256 * (eij.shape[0] + 4))
+    k = lib.spdp_exon_form_text(C.byref(a), qname.encode(), gname.encode(), int(header), buf, len(buf))
+    if k < 0:
+        raise RuntimeError("spdp_exon_form_text failed")
+    return [ex[i] for i in range(n)], g, buf.raw[:k]
+
+
 class Collector:
     """SpdpCollector: single-problem calls from many host threads, run as device batches.
     Owns the engine's context while it lives; align_s() may be called from any number of threads."""

@@ -478,3 +478,29 @@ def test_skl_edits_s_goldens(eng):
                 bad.append((f.split("/")[-1], alg, cig[:6].tolist(), fx[f"rng_cigar_A{alg}"][:12].tolist(), hdr,
                             fx[f"rng_samhdr_A{alg}"].tolist()))
     assert n_checked >= 60 and n_introns >= 100 and not bad, bad[:3]
+
+
+def test_exon_form_from_device_records(eng):
+    """the reporting pipeline end to end: spdp_skl_rng_s on the device, then spdp_exon_form_text on its records, equals the
+    reference's -O4 lines for its own alignment (tests/test_exon_form.py does the same from the reference's records)"""
+    from spaln_amd import engine as _engine
+    from tests.test_exon_form import _text      # noqa: F401  (same parameter decoding)
+    n = 0
+    for f in golden_files() + golden_files("c2_"):
+        fx = spdg.load(f)
+        for alg in (0, 2):
+            if f"rng_exn_A{alg}" not in fx:
+                continue
+            sc = spdg.scoring(fx)
+            ps, p = spdg.problem(fx)
+            fs = fx[f"rng_fstat_A{alg}"]
+            (score, fst, ex), = eng.skl_rng_s(sc, ps, [fx[f"aln_skl_A{alg}"].reshape(-1, 2)],
+                                               codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"],
+                                               jneibr=int(fs[6]), lsg=int(fs[7]))
+            fx2 = dict(fx)
+            fx2[f"rng_eij_A{alg}"] = ex
+            want = bytes(fx[f"rng_exn_A{alg}"])
+            _, _, got = _text(fx2, alg, False, eng.lib, header=want.startswith(b"#"))
+            assert got == want, (f, alg)
+            n += 1
+    assert n >= 60

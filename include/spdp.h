@@ -400,6 +400,10 @@ typedef struct SpdpProblemH {
     int32_t a_left, a_right, b_left, b_right;
     uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
     const uint8_t* dinc;                   /* rescoring only: INT53::dinc5 << 4 | dinc3 per position, or NULL */
+    const int32_t* cip;                    /* optional, the -A0 / -A1 engines only: Cip_score::cip_score(c) for coding
+                                              position c = 0 .. 3 a_len + 1 (an intron accepted in row m at phase phs
+                                              earns cip[3 m - phs], src/fwd2h1.cc:352-354, 483; fwd2h1_simd.h:407);
+                                              NULL = none */
 } SpdpProblemH;
 
 /* stripe31(seqs, &wdw, sh), src/aln2.cc:178-198 */

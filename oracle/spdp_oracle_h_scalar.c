@@ -292,7 +292,7 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
                         const Rvpdj* phl = hl[phs + 1] + pnx[l];
                         if (phs == 1 && phl->dir == 2) continue;
                         if (nb - phl->jnc < minl) continue;
-                        x = phl->val + spjscr(&cx, phl->jnc, nb);
+                        x = phl->val + (p->cip ? p->cip[3 * m - phs] : 0) + spjscr(&cx, phl->jnc, nb);   /* sigB[phs] = cip_score(3 m - phs) */
                         if (phl->dir == 0 && phs) {
                             int cs[2];
                             spjseq(&cx, phl->jnc, nb, cs);
@@ -669,7 +669,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                         const Rvdwmlj* phl = hl[phs + 1] + pnx[l];
                         if (phs == 1 && phl->dir == 2) continue;
                         if (nb - phl->jnc < minl) continue;
-                        x = phl->val + spjscr(&cx, phl->jnc, nb);
+                        x = phl->val + (p->cip ? p->cip[3 * m - phs] : 0) + spjscr(&cx, phl->jnc, nb);   /* sigB[phs] = cip_score(3 m - phs) */
                         if (phl->dir == 0 && phs) {
                             int cs[2];
                             spjseq(&cx, phl->jnc, nb, cs);
@@ -989,7 +989,7 @@ static void xh_get(XhEng* e, XhSites* s, int j, int m, int n, int q)
         const int d = prd->dir, don = prd->jnc;
         if (d == 2 && prd->phs == 1) continue;
         if (acc - don < e->cx.minl) continue;
-        int x = prd->val + spjscr(&e->cx, don, acc);
+        int x = prd->val + (p->cip ? p->cip[3 * (m + 1) - prd->phs] : 0) + spjscr(&e->cx, don, acc);
         if (d == 0 && prd->phs) {
             int cs[2];
             spjseq(&e->cx, don, acc, cs);

@@ -297,6 +297,7 @@ class ProblemH(C.Structure):
         ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
         ("dinc", C.c_void_p),
+        ("cip", C.c_void_p),
     ]
 
 
@@ -345,7 +346,7 @@ class ProblemSetH:
         self.items = []
 
     def add(self, a, b, sig5, sig3, sigS, sigT, sigE, phs5, phs3, a_left=0, a_right=None,
-            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None, dinc=None):
+            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None, dinc=None, cip=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)          # b_len + 1 entries
         b_len = b.size - 1
@@ -367,6 +368,11 @@ class ProblemSetH:
             assert dc.size >= b_len + 1
             self._keep.append(dc)
             p.dinc = dc.ctypes.data
+        if cip is not None:
+            cp = np.ascontiguousarray(cip, dtype=np.int32)
+            assert cp.size >= 3 * a.size + 2
+            self._keep.append(cp)
+            p.cip = cp.ctypes.data
         self.items.append(p)
         return p
 

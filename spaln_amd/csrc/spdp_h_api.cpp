@@ -80,6 +80,9 @@ struct HStore {
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> col_len;
     void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    void* d_cip = nullptr;                      // owned (hipMalloc): conserved-intron bonuses, SpdpProblemH::cip
+    std::vector<int32_t> cip_off;               // per problem: first entry of its row in d_cip, -1 = none
+    ~HStore() { if (d_cip) (void) hipFree(d_cip); }
     bool scalar_ok = false;                     // inputs of the scalar engine present (intpen / t53, dinc)
     int upload(SpdpContext* c, const SpdpScoringH* sc, const SpdpProblemH* probs, int n);
 };
@@ -183,6 +186,19 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         if (!d_intpen) { ctx->err = "device allocation failed (intron penalty table)"; return -1; }
         HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, (size_t) sc.intpen_len * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
     }
+    cip_off.assign(n, -1);
+    {
+        std::vector<int32_t> hcip;
+        for (int i = 0; i < n; ++i)
+            if (probs[i].cip) {
+                cip_off[i] = (int32_t) hcip.size();
+                hcip.insert(hcip.end(), probs[i].cip, probs[i].cip + 3 * probs[i].a_len + 2);
+            }
+        if (!hcip.empty()) {
+            HIPCHK(hipMalloc(&d_cip, hcip.size() * sizeof(int32_t)));
+            HIPCHK(hipMemcpy(d_cip, hcip.data(), hcip.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
     d_sc = pool.get(HP_SC, sizeof ds);
     d_a = pool.get(HP_A, a_all.size() + 16);
     d_cols = pool.get(HP_COLS, cols.size() * sizeof(int4));
@@ -229,6 +245,7 @@ static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
     d.col_off = st.col_off[it.top];
     d.n_im = it.n_im; d.imd_intvl = it.imd_intvl;
     d.a_len = st.probs[it.top].a_len; d.b_len = st.probs[it.top].b_len;
+    d.cip_off = st.cip_off.empty() ? -1 : st.cip_off[it.top];
     d.cells = cells_of(it);
 }
 
@@ -425,6 +442,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);
     spdp_genetic_code_tables(A.mid, A.tron_of);
+    A.cip = (const int*) st.d_cip;
     A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -569,6 +587,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);
     spdp_genetic_code_tables(A.mid, A.tron_of);
+    A.cip = (const int*) st.d_cip;
     A.work = (int*) d_work; A.res = (DevResultH*) d_res;
     A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
     A.cpos_stride = out.stride;

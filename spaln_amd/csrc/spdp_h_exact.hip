@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
                     if (d == 2 && phs == 1) continue;
                     if (acc - don < minl) continue;
                     int x = LV(S_CVAL + ci) + spjscr(don, acc);
+                    if (A.cip && P.cip_off >= 0) x += A.cip[P.cip_off + 3 * (m + 1) - phs];      // Cip_score::cip_score, fwd2h1_simd.h:407
                     if (d == 0 && phs) {
                         int c0, c1;
                         spjseq(don, acc, c0, c1);

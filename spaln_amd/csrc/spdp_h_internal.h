@@ -60,6 +60,7 @@ struct HScalarArgs {
     const int4*        cols;
     const short4*      aux;
     const int16_t*     intpen;     // IntronPenalty::Penalty(len)
+    const int*         cip;        // Cip_score::cip_score(c) rows (3 a_len + 2 ints) of the queries that have one, or null
     int                intpen_len;
     int                minl;       // IntronPrm.minl
     int                gape1, gape2, extragop;

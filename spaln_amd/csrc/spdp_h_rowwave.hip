@@ -297,6 +297,10 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
             const int aa1 = (row && m < P.a_len) ? acod[m] : AMB;
             const int* prof0 = T.mtx + aa0 * 32;
             const int* prof1 = T.mtx + aa1 * 32;
+            // Cip_score::cip_score(3 m - phs) for the three phases (sigB[phs], src/fwd2h1.cc:352-354)
+            const bool has_cip = row && A.cip && P.cip_off >= 0;
+            const int cipm = has_cip ? A.cip[P.cip_off + 3 * m + 1] : 0, cip0 = has_cip ? A.cip[P.cip_off + 3 * m] : 0,
+                      cipp = has_cip ? A.cip[P.cip_off + 3 * m - 1] : 0;
             // the insertion queue: ea is the slot of the current column's frame
             St ea = black, eb = black, ec = black;
             Cands<MODE> cl[3];
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                                 const int cd = C.x[l] & 3;
                                 if (phs == 1 && cd == 2) continue;
                                 if (nb - C.j[l] < minl) continue;
-                                int x = C.v[l] + intpen_of(nb - C.j[l]) + s3 + T.t53[16 * ((C.x[l] >> 2) & 15) + dn3];
+                                int x = C.v[l] + (phs < 0 ? cipm : (phs == 0 ? cip0 : cipp)) + intpen_of(nb - C.j[l]) + s3 + T.t53[16 * ((C.x[l] >> 2) & 15) + dn3];
                                 if (cd == 0 && phs) {
                                     const int w0 = (C.x[l] >> 6) & 7, w1 = (C.x[l] >> 9) & 7;
                                     const bool ok = w0 < 4 && w1 < 4 && w2 < 4 && w3 < 4;

@@ -35,6 +35,76 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	w.put("a_codes", 1, a->at(0), a->len);
 	w.put("b_codes", 1, b->at(0), b->len + 1);	// + the terminator the engine reads (sm_a at n = right + 2)
 	{
+	    // the signal model behind the SGPT6 arrays (Exinon::intron53_p, codepot.cc:524-611): the position weight
+	    // matrices (splice sites, start / stop context, branch point), the coding / intron potential tables (ExinPot,
+	    // utilseq.h:90-168) and the scale factors, so that the arrays can be recomputed from b_codes
+	    auto dump_pm = [&](const char* tag, const PatMat* pm) {
+		char nmb[40];
+		std::vector<int> hd = {pm ? pm->rows : 0, pm ? pm->cols : 0, pm ? pm->offset : 0, pm ? pm->order() : 0, pm ? pm->nalpha : 0};
+		snprintf(nmb, sizeof nmb, "%s_hdr", tag); w.put_i32(nmb, hd);
+		std::vector<int> fl(pm ? 2 + pm->rows * pm->cols : 0);
+		if (pm) { memcpy(&fl[0], &pm->tonic, 4); memcpy(&fl[1], &pm->min_elem, 4); memcpy(&fl[2], pm->mtx, sizeof(float) * pm->rows * pm->cols); }
+		snprintf(nmb, sizeof nmb, "%s_f32", tag); w.put_i32(nmb, fl);
+	    };
+	    dump_pm("pm5", pwd->eijpat->pattern5);
+	    dump_pm("pm3", pwd->eijpat->pattern3);
+	    dump_pm("pmI", pwd->eijpat->patternI);
+	    dump_pm("pmT", pwd->eijpat->patternT);
+	    dump_pm("pmB", pwd->eijpat->patternB);
+	    auto dump_pot = [&](const char* tag, const ExinPot* ep) {
+		char nmb[40];
+		const int nd = ep ? ep->size() : 0, tot = ep ? (int) (ep->end() - ep->begin()) : 0;
+		std::vector<int> hd = {nd, nd ? tot / nd : 0};
+		snprintf(nmb, sizeof nmb, "%s_hdr", tag); w.put_i32(nmb, hd);
+		std::vector<int> fl(tot);
+		if (tot) memcpy(fl.data(), ep->begin(), sizeof(float) * tot);
+		snprintf(nmb, sizeof nmb, "%s_f32", tag); w.put_i32(nmb, fl);
+	    };
+	    dump_pot("potC", pwd->codepot);
+	    dump_pot("potI", pwd->intnpot);
+	    dump_pot("potX", pwd->exonpot);
+	    const float fact = (float) b->exin->fact, fS = (float) b->exin->fS;
+	    const float f[10] = {(float) (alprm2.z * b->exin->fact), (float) (alprm2.Z * b->exin->fact), (float) (alprm2.bti * b->exin->fact),
+		(float) (bpprm.factor * b->exin->fact), (float) (-alprm2.o * b->exin->fact), fS, (float) (b->exin->fS * alprm2.sss),
+		pwd->eijpat->tonic3, pwd->eijpat->tonic5, pwd->eijpat->tonicB};
+	    std::vector<int> fb(10);
+	    memcpy(fb.data(), f, sizeof f);
+	    w.put_i32("sigmodel_f32", fb);		// fE, fI, fT, fB, fO, fS, fs, tonic3, tonic5, tonicB
+	    std::vector<int> im = {(int) algmode.any, (int) pwd->DvsP, (int) bpprm.maxb3d, (int) b->many, (int) sizeof(FTYPE), (int) TRM, (int) TRM2};
+	    w.put_i32("sigmodel_i32", im);		// any, DvsP, maxb3d, many, sizeof(FTYPE), TRM, TRM2
+	    (void) fact;
+	    // the per-dinucleotide terms sig53tab[0 / 1][class] (private to Exinon): what is left of a signal after the scaled
+	    // matrix score, which the reference's own PatMat::calcPatMat reproduces (same call and range as intron53_p)
+	    std::vector<int> tab(32, INT_MIN);
+	    if (pwd->eijpat->pattern5 && pwd->eijpat->pattern3 && !pwd->eijpat->patternB) {
+		const float fs = f[6];
+		--b->left; ++b->right;
+		float* p5 = pwd->eijpat->pattern5->calcPatMat(b);
+		float* p3 = pwd->eijpat->pattern3->calcPatMat(b);
+		++b->left; --b->right;
+		std::vector<unsigned char> e5(b->len + 3, 0), e3(b->len + 3, 0);
+		int	nc2 = 1;
+		for (int i = b->left; i < b->right; ++i) {
+		    int c = tnredctab[*b->at(i)];
+		    if (c >= 4) c = 1;
+		    nc2 = ((nc2 << 2) + c) & 0xf;
+		    if (i - 1 >= 0) e5[i - 1] = nc2;
+		    e3[i + 1] = nc2;
+		}
+		int	clash = 0;
+		for (int n = b->left + 2; n < b->right - 1; ++n) {
+		    const SGPT6* sg = b->exin->score_p(n);
+		    const int t5 = sg->sig5 - (STYPE) (fs * p5[n - b->left + 1]);
+		    const int t3 = sg->sig3 - (STYPE) (fs * p3[n - b->left + 1]);
+		    if (tab[e5[n]] == INT_MIN) tab[e5[n]] = t5; else if (tab[e5[n]] != t5) ++clash;
+		    if (tab[16 + e3[n]] == INT_MIN) tab[16 + e3[n]] = t3; else if (tab[16 + e3[n]] != t3) ++clash;
+		}
+		if (clash) fprintf(stderr, "ref_dump: %d signal-table clashes\n", clash);
+		delete[] p5; delete[] p3;
+	    }
+	    w.put_i32("sig53tab01", tab);
+	}
+	{
 	    const int N = b->len + 3;
 	    std::vector<short> v[6];
 	    for (int f = 0; f < 6; ++f) v[f].assign(N, 0);

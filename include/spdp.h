@@ -384,7 +384,36 @@ typedef struct SpdpScoringH {
                                         above 7 rows stops with SIGSEGV in the reference under -A1 (forwardH1
                                         without a Vmf) and comes back here as "not computed" (return value 1) */
     int32_t recursive;               /* algmode.alg & 4: lspH_ng always takes the recursive branch    */
+    const struct SpdpSignalModelH* sigmodel;  /* optional: with it, problems whose signal arrays are all NULL get them (and
+                                        dinc) computed on the device from the tron codes (spdp_signals_h.hip) */
 } SpdpScoringH;
+
+/* the model behind the SGPT6 arrays (Exinon::intron53_p, src/codepot.cc:524-611): position weight matrices of the splice
+ * sites (order 2), the start-codon context (order <= 1) and the stop-codon context (order 2) -- PatMat, src/utilseq.h:64-88,
+ * rows = 4 + 16 (+ 64) terms per column --, the 5th-order three-phase coding potential (ExinPot, utilseq.h:90-168:
+ * 3 * ndata floats), the scale factors and the per-dinucleotide terms.  A model with a branch-point matrix
+ * (EijPat::patternB) or an intron potential (alprm2.Z > 0) is not supported. */
+typedef struct SpdpPatMat {
+    int32_t rows, cols, offset, order;          /* rows = 0: matrix absent                                  */
+    float   tonic, min_elem;
+    const float* mtx;                           /* cols * rows                                              */
+} SpdpPatMat;
+typedef struct SpdpSignalModelH {
+    SpdpPatMat pm5, pm3, pmI, pmT;              /* EijPat::pattern5, pattern3, patternI, patternT           */
+    int32_t pot_ndata;  const float* pot;       /* PwdB::codepot: size(), begin() (0 / NULL: none)          */
+    float   fE, fT, fO;                         /* alprm2.z * fact, alprm2.bti * fact, -alprm2.o * fact     */
+    float   fS, fs;                             /* Exinon::fS, fS * alprm2.sss                              */
+    float   tonic5, tonic3;                     /* EijPat::tonic5, tonic3                                   */
+    int16_t tab5[16], tab3[16];                 /* sig53tab[0][dinc5], sig53tab[1][dinc3]                   */
+    int32_t any;                                /* algmode.any                                              */
+    int32_t dvsp;                               /* PwdB::DvsP != 3: start / stop contexts are scored        */
+    int32_t trm, trm2;                          /* the two termination tron codes (TRM, TRM2)               */
+} SpdpSignalModelH;
+/* the SGPT6 arrays of one tron window on the device: b_len + 3 entries each, computed for [left, right) (any output may be
+ * NULL); b holds b_len + 1 codes */
+int spdp_splice_signals_h(SpdpContext* ctx, const SpdpSignalModelH* model, const uint8_t* b, int32_t b_len,
+                          int32_t left, int32_t right, int16_t* sig5, int16_t* sig3, int16_t* sigS, int16_t* sigT,
+                          int16_t* sigE, int8_t* phs5, int8_t* phs3, uint8_t* dinc);
 
 typedef struct SpdpProblemH {
     const uint8_t* a;  int32_t a_len;      /* amino-acid codes a[0 .. a_len)                      */

@@ -277,7 +277,48 @@ class ScoringH(C.Structure):
         ("minl", C.c_int32),
         ("scalar_engines", C.c_int32),
         ("recursive", C.c_int32),
+        ("sigmodel", C.c_void_p),
     ]
+
+
+class PatMatC(C.Structure):              # SpdpPatMat
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("offset", C.c_int32), ("order", C.c_int32),
+                ("tonic", C.c_float), ("min_elem", C.c_float), ("mtx", C.c_void_p)]
+
+
+class SignalModelH(C.Structure):         # SpdpSignalModelH
+    _fields_ = [("pm5", PatMatC), ("pm3", PatMatC), ("pmI", PatMatC), ("pmT", PatMatC),
+                ("pot_ndata", C.c_int32), ("pot", C.c_void_p),
+                ("fE", C.c_float), ("fT", C.c_float), ("fO", C.c_float), ("fS", C.c_float), ("fs", C.c_float),
+                ("tonic5", C.c_float), ("tonic3", C.c_float),
+                ("tab5", C.c_int16 * 16), ("tab3", C.c_int16 * 16),
+                ("any", C.c_int32), ("dvsp", C.c_int32), ("trm", C.c_int32), ("trm2", C.c_int32)]
+
+
+def signal_model_h_from_fixture(fx: dict) -> SignalModelH:
+    """the protein-side model a reference dump carries (pm*_hdr / pm*_f32, potC_*, sigmodel_f32 / _i32, sig53tab01)"""
+    m = SignalModelH()
+    keep = []
+    for tag, dst in (("pm5", m.pm5), ("pm3", m.pm3), ("pmI", m.pmI), ("pmT", m.pmT)):
+        hd = [int(v) for v in fx[tag + "_hdr"]]
+        if not hd[0]:
+            continue
+        f = np.asarray(fx[tag + "_f32"], dtype=np.int32).view(np.float32)
+        mtx = np.ascontiguousarray(f[2:], dtype=np.float32)
+        keep.append(mtx)
+        dst.rows, dst.cols, dst.offset, dst.order = hd[0], hd[1], hd[2], hd[3]
+        dst.tonic, dst.min_elem, dst.mtx = float(f[0]), float(f[1]), mtx.ctypes.data
+    pot = np.ascontiguousarray(np.asarray(fx["potC_f32"], dtype=np.int32).view(np.float32))
+    keep.append(pot)
+    m.pot_ndata, m.pot = int(fx["potC_hdr"][0]), (pot.ctypes.data if pot.size else None)
+    f = np.asarray(fx["sigmodel_f32"], dtype=np.int32).view(np.float32)
+    i = [int(v) for v in fx["sigmodel_i32"]]
+    m.fE, m.fT, m.fO, m.fS, m.fs, m.tonic3, m.tonic5 = (float(f[k]) for k in (0, 2, 4, 5, 6, 7, 8))
+    for k in range(16):
+        m.tab5[k] = int(fx["sig53tab01"][k]); m.tab3[k] = int(fx["sig53tab01"][16 + k])
+    m.any, m.dvsp, m.trm, m.trm2 = i[0], int(i[1] != 3), i[5], i[6]
+    m._keep = keep
+    return m
 
 
 class RescoreParamsH(C.Structure):
@@ -305,7 +346,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
                    ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
-                   intpen=None, t53=None, minl=0, scalar_engines=0, recursive=0) -> ScoringH:
+                   intpen=None, t53=None, minl=0, scalar_engines=0, recursive=0, sigmodel=None) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -328,6 +369,9 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
     sc.minl = int(minl)
     sc.scalar_engines = int(scalar_engines)
     sc.recursive = int(recursive)
+    if sigmodel is not None:
+        sc._keep_sigmodel = sigmodel
+        sc.sigmodel = C.addressof(sigmodel)
     if intpen is not None:
         ip = np.ascontiguousarray(intpen, dtype=np.int16)
         sc._keep_intpen = ip

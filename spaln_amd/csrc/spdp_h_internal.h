@@ -81,6 +81,36 @@ struct HScalarArgs {
     int                cpos_stride;
 };
 
+// protein-side signal precompute (spdp_signals_h.hip): Exinon::intron53_c / intron53_p for tron windows
+struct SigPatMatDev { int32_t rows, cols, offset, order; float tonic, min_elem; };
+struct SigModelHDev {
+    SigPatMatDev pm5, pm3, pmI, pmT;
+    int32_t pot_ndata, any, dvsp, trm, trm2;
+    float   fE, fT, fO, fS, fs, tonic5, tonic3;
+    int16_t tab5[16], tab3[16];
+};
+struct SigJobH {
+    int64_t b_off;                 // first tron code of the window in `codes`
+    int64_t out_off;               // its plain arrays (b_len + 3 entries each)
+    int64_t col_off;               // its column records (HStore layout)
+    int32_t b_len, left, right, pad;
+};
+struct SignalArgsH {
+    const SigModelHDev* model;
+    const float*        mtx;       // pm5, pm3, pmI, pmT matrices back to back
+    const float*        pot;       // coding potential, 3 * pot_ndata floats
+    const SigJobH*      jobs;
+    const uint8_t*      codes;
+    int16_t*            sig5;  int16_t* sig3;  int16_t* sigS;  int16_t* sigT;  int16_t* sigE;
+    int8_t*             phs5;  int8_t*  phs3;
+    uint8_t*            cano;      // cano5 | cano3 << 4 (levels)
+    uint8_t*            dinc;      // dinc5 << 4 | dinc3
+    int4*               cols;      // packed records (pack != 0)
+    short4*             aux;
+    int32_t             ipen;      // IntronPenalty::Penalty() or SPDH_NEV when splicing is off (as HStore::upload)
+};
+extern "C" hipError_t spdh_launch_signals(const SignalArgsH* a, int n_jobs, int max_len, int lds_floats, int pack, hipStream_t s);
+
 extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t s);
 extern "C" hipError_t spdh_launch_exact(int udh, const HScalarArgs* a, hipStream_t s);   // -A1: forwardH1 / hirschbergH1

@@ -96,3 +96,95 @@ extern "C" int spdp_splice_signals(SpdpContext* ctx, const SpdpSignalModel* mode
     if (dinc) HIPCHK(hipMemcpy(dinc, d_dc.p, n1, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ---- protein side (spdp_signals_h.hip) ---------------------------------------------------------------------------
+#include "spdp_h_internal.h"
+
+static const char* check_model_h(const SpdpSignalModelH* m)
+{
+    if (!m || !m->pm5.mtx || !m->pm3.mtx) return "signal model: splice-site matrices missing";
+    const SpdpPatMat* pm[4] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT};
+    for (int i = 0; i < 4; ++i) {
+        const SpdpPatMat& q = *pm[i];
+        if (i >= 2 && (!q.rows || !q.mtx)) continue;
+        if ((q.order == 2 && q.rows != 84) || (q.order == 1 && q.rows != 20) || (q.order == 0 && q.rows != 4) || q.order < 0 || q.order > 2)
+            return "signal model: matrix rows do not match its Markov order";
+        if (q.cols < 1 || q.cols > 48 || q.offset < 0 || q.offset > 60 || q.cols - q.offset + 2 > 60) return "signal model: matrix shape out of range";
+    }
+    if (m->pot_ndata && (!m->pot || m->pot_ndata != 4096)) return "signal model: coding potential must be the 5th-order table (4096 x 3)";
+    return nullptr;
+}
+
+// model -> device; jobs (host) -> device; the three kernels; `args` carries the device pointers of codes and outputs
+int spdh_signals_run(SpdpContext* ctx, const SpdpSignalModelH* m, const std::vector<SigJobH>& jobs, SignalArgsH args, int pack)
+{
+    if (const char* e = check_model_h(m)) { ctx->err = e; return -1; }
+    (void) hipSetDevice(ctx->device);
+    SigModelHDev hm;
+    memset(&hm, 0, sizeof hm);
+    const SpdpPatMat* pm[4] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT};
+    SigPatMatDev* dm[4] = {&hm.pm5, &hm.pm3, &hm.pmI, &hm.pmT};
+    size_t tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        const bool on = pm[i]->rows && pm[i]->mtx;
+        if (on) { dm[i]->rows = pm[i]->rows; dm[i]->cols = pm[i]->cols; dm[i]->offset = pm[i]->offset; dm[i]->order = pm[i]->order;
+                  dm[i]->tonic = pm[i]->tonic; dm[i]->min_elem = pm[i]->min_elem; tot += (size_t) pm[i]->rows * pm[i]->cols; }
+    }
+    hm.pot_ndata = m->pot ? m->pot_ndata : 0; hm.any = m->any; hm.dvsp = m->dvsp ? 1 : 0; hm.trm = m->trm; hm.trm2 = m->trm2;
+    hm.fE = m->fE; hm.fT = m->fT; hm.fO = m->fO; hm.fS = m->fS; hm.fs = m->fs; hm.tonic5 = m->tonic5; hm.tonic3 = m->tonic3;
+    memcpy(hm.tab5, m->tab5, sizeof hm.tab5); memcpy(hm.tab3, m->tab3, sizeof hm.tab3);
+    std::vector<float> hmtx;
+    hmtx.reserve(tot);
+    for (int i = 0; i < 4; ++i) if (dm[i]->rows) hmtx.insert(hmtx.end(), pm[i]->mtx, pm[i]->mtx + (size_t) dm[i]->rows * dm[i]->cols);
+    DevBuf d_model, d_mtx, d_pot, d_jobs;
+    HIPCHK(d_model.get(sizeof hm));
+    HIPCHK(d_mtx.get(hmtx.size() * sizeof(float)));
+    HIPCHK(d_pot.get(hm.pot_ndata ? 3 * (size_t) hm.pot_ndata * sizeof(float) : 16));
+    HIPCHK(d_jobs.get(jobs.size() * sizeof(SigJobH)));
+    HIPCHK(hipMemcpyAsync(d_model.p, &hm, sizeof hm, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_mtx.p, hmtx.data(), hmtx.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (hm.pot_ndata) HIPCHK(hipMemcpyAsync(d_pot.p, m->pot, 3 * (size_t) hm.pot_ndata * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(SigJobH), hipMemcpyHostToDevice, ctx->stream));
+    args.model = d_model.as<SigModelHDev>(); args.mtx = d_mtx.as<float>(); args.pot = d_pot.as<float>();
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += 65535) {
+        const int nj = (int) std::min<size_t>(65535, jobs.size() - j0);
+        int max_len = 0;
+        for (int j = 0; j < nj; ++j) max_len = std::max(max_len, jobs[j0 + j].b_len);
+        args.jobs = d_jobs.as<SigJobH>() + j0;
+        HIPCHK(spdh_launch_signals(&args, nj, max_len, (int) hmtx.size(), pack, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int spdp_splice_signals_h(SpdpContext* ctx, const SpdpSignalModelH* model, const uint8_t* b, int32_t b_len,
+                                     int32_t left, int32_t right, int16_t* sig5, int16_t* sig3, int16_t* sigS, int16_t* sigT,
+                                     int16_t* sigE, int8_t* phs5, int8_t* phs3, uint8_t* dinc)
+{
+    if (!ctx) return -1;
+    if (!b || b_len < 0 || left < 0 || right > b_len || right < left) { ctx->err = "spdp_splice_signals_h: bad window"; return -1; }
+    (void) hipSetDevice(ctx->device);
+    const size_t N = (size_t) b_len + 3;
+    DevBuf d_b, d_s[5], d_p[2], d_c, d_d;
+    HIPCHK(d_b.get(b_len + 1));
+    for (DevBuf& x : d_s) HIPCHK(x.get(2 * N));
+    for (DevBuf& x : d_p) HIPCHK(x.get(N));
+    HIPCHK(d_c.get(N)); HIPCHK(d_d.get(N));
+    HIPCHK(hipMemcpyAsync(d_b.p, b, b_len + 1, hipMemcpyHostToDevice, ctx->stream));
+    SigJobH J;
+    memset(&J, 0, sizeof J);
+    J.b_len = b_len; J.left = left; J.right = right;
+    SignalArgsH A;
+    memset(&A, 0, sizeof A);
+    A.codes = d_b.as<uint8_t>();
+    A.sig5 = d_s[0].as<int16_t>(); A.sig3 = d_s[1].as<int16_t>(); A.sigS = d_s[2].as<int16_t>(); A.sigT = d_s[3].as<int16_t>();
+    A.sigE = d_s[4].as<int16_t>(); A.phs5 = d_p[0].as<int8_t>(); A.phs3 = d_p[1].as<int8_t>();
+    A.cano = d_c.as<uint8_t>(); A.dinc = d_d.as<uint8_t>();
+    if (spdh_signals_run(ctx, model, std::vector<SigJobH>(1, J), A, 0)) return -1;
+    int16_t* outs[5] = {sig5, sig3, sigS, sigT, sigE};
+    for (int i = 0; i < 5; ++i) if (outs[i]) HIPCHK(hipMemcpy(outs[i], d_s[i].p, 2 * N, hipMemcpyDeviceToHost));
+    if (phs5) HIPCHK(hipMemcpy(phs5, d_p[0].p, N, hipMemcpyDeviceToHost));
+    if (phs3) HIPCHK(hipMemcpy(phs3, d_p[1].p, N, hipMemcpyDeviceToHost));
+    if (dinc) HIPCHK(hipMemcpy(dinc, d_d.p, N, hipMemcpyDeviceToHost));
+    return 0;
+}

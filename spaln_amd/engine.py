@@ -46,6 +46,7 @@ def load_library() -> C.CDLL:
     lib.spdp_cells.restype = C.c_int64
     lib.spdp_splice_signals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.spdp_splice_signals_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
     lib.spdp_batch_upload.restype = C.c_void_p
     lib.spdp_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.spdp_batch_free.argtypes = [C.c_void_p]
@@ -244,6 +245,20 @@ class Engine:
                                                  int(b.size if right is None else right),
                                                  *(out[k].ctypes.data for k in ("sig5", "sig3", "cano5", "cano3", "dinc"))),
                     "spdp_splice_signals")
+        return out
+
+    def splice_signals_h(self, model: abi.SignalModelH, b_codes, left: int = 0, right=None) -> dict:
+        """Exinon::intron53_c / intron53_p of one tron window on the device (b_codes: b_len + 1 codes)"""
+        b = np.ascontiguousarray(b_codes, dtype=np.uint8)
+        b_len = b.size - 1
+        n = b_len + 3
+        out = {k: np.zeros(n, np.int16) for k in ("sig5", "sig3", "sigS", "sigT", "sigE")}
+        out.update(phs5=np.zeros(n, np.int8), phs3=np.zeros(n, np.int8), dinc=np.zeros(n, np.uint8))
+        self._check(self.lib.spdp_splice_signals_h(self.ctx, C.addressof(model), b.ctypes.data, b_len, int(left),
+                                                   int(b_len if right is None else right),
+                                                   *(out[k].ctypes.data for k in ("sig5", "sig3", "sigS", "sigT", "sigE",
+                                                                                  "phs5", "phs3", "dinc"))),
+                    "spdp_splice_signals_h")
         return out
 
     def wip_scoreonly(self, sc: abi.Scoring, ps: abi.ProblemSet) -> np.ndarray:

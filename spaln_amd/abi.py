@@ -394,15 +394,17 @@ class ProblemSetH:
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)          # b_len + 1 entries
         b_len = b.size - 1
-        sg = [np.ascontiguousarray(x, dtype=np.int16) for x in (sig5, sig3, sigS, sigT, sigE)]
-        ph = [np.ascontiguousarray(x, dtype=np.int8) for x in (phs5, phs3)]
-        assert min(x.size for x in sg + ph) >= b_len + 3
-        self._keep += [a, b] + sg + ph
         p = ProblemH()
         p.a, p.a_len = a.ctypes.data, a.size
         p.b, p.b_len = b.ctypes.data, b_len
-        p.sig5, p.sig3, p.sigS, p.sigT, p.sigE = (x.ctypes.data for x in sg)
-        p.phs5, p.phs3 = (x.ctypes.data for x in ph)
+        self._keep += [a, b]
+        if sig5 is not None:                          # None (all seven): ScoringH.sigmodel computes them on the device
+            sg = [np.ascontiguousarray(x, dtype=np.int16) for x in (sig5, sig3, sigS, sigT, sigE)]
+            ph = [np.ascontiguousarray(x, dtype=np.int8) for x in (phs5, phs3)]
+            assert min(x.size for x in sg + ph) >= b_len + 3
+            self._keep += sg + ph
+            p.sig5, p.sig3, p.sigS, p.sigT, p.sigE = (x.ctypes.data for x in sg)
+            p.phs5, p.phs3 = (x.ctypes.data for x in ph)
         p.a_left, p.a_right = int(a_left), int(a.size if a_right is None else a_right)
         p.b_left, p.b_right = int(b_left), int(b_len if b_right is None else b_right)
         p.exin_left, p.exin_right = (p.b_left, p.b_right) if exin is None else (int(exin[0]), int(exin[1]))

@@ -32,6 +32,7 @@
 enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs + traceback runs / linear-space runs
 enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN };
 void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64]);       // spdp_rescore_api.cpp
+int spdh_signals_run(SpdpContext* ctx, const SpdpSignalModelH* m, const std::vector<SigJobH>& jobs, SignalArgsH args, int pack);   // spdp_signals_api.cpp
 enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES };
 static const int H_SKL_CAP = 4096;       // slot of one traceback record list; a list is at most ~4 records per query row (diagonal / gap corners and
                                            // two per intron), and the slot is min(this, rows + columns + 8): protein queries stay far below
@@ -80,6 +81,7 @@ struct HStore {
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> col_len;
     void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    std::vector<std::vector<int16_t>> own_sigE; // device-made signals: the host ladder still reads sigE (diagonalH_ng)
     void* d_cip = nullptr;                      // owned (hipMalloc): conserved-intron bonuses, SpdpProblemH::cip
     std::vector<int32_t> cip_off;               // per problem: first entry of its row in d_cip, -1 = none
     ~HStore() { if (d_cip) (void) hipFree(d_cip); }
@@ -108,8 +110,10 @@ static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH
     };
     if (sc->mtx_rows <= 0 || sc->mtx_rows > 31 || sc->mtx_cols <= 0 || sc->mtx_cols > 31) return fail("matrix larger than 31 x 31");
     if (sc->nquant < 1 || sc->nquant > SPDP_MAX_QUANT) return fail("bad nquant");
-    if (!p->a || !p->b || !p->sig5 || !p->sig3 || !p->sigS || !p->sigT || !p->sigE || !p->phs5 || !p->phs3)
-        return fail("null input array");
+    const int n_arr = (p->sig5 ? 1 : 0) + (p->sig3 ? 1 : 0) + (p->sigS ? 1 : 0) + (p->sigT ? 1 : 0) + (p->sigE ? 1 : 0) +
+                      (p->phs5 ? 1 : 0) + (p->phs3 ? 1 : 0);
+    if (!p->a || !p->b || (n_arr != 7 && !(n_arr == 0 && sc->sigmodel)))
+        return fail("null input array (all seven signal arrays, or none of them together with SpdpScoringH::sigmodel)");
     if (p->a_left < 0 || p->a_right > p->a_len || p->a_left > p->a_right) return fail("bad query range");
     if (p->b_left < 0 || p->b_right > p->b_len || p->b_left > p->b_right) return fail("bad genomic range");
     if (p->b_left < p->exin_left || p->b_right > p->exin_right) return fail("active range outside the Exinon range");
@@ -135,9 +139,15 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     std::vector<int4> cols;
     std::vector<short4> aux;
     a_off.resize(n); col_off.resize(n); col_len.resize(n);
+    int n_dev = 0;
+    for (int i = 0; i < n; ++i) {
+        if (validate(ctx, &sc, &probs[i], i)) return -1;
+        n_dev += probs[i].sig5 ? 0 : 1;
+    }
+    if (n_dev && n_dev != n) { ctx->err = "signal arrays missing for part of the batch"; return -1; }
+    const bool dev_sig = n_dev > 0;
     for (int i = 0; i < n; ++i) {
         const SpdpProblemH& p = probs[i];
-        if (validate(ctx, &sc, &p, i)) return -1;
         a_off[i] = (int64_t) a_all.size();
         col_off[i] = (int64_t) cols.size();
         col_len[i] = p.b_len + 3 + SPDH_COL_PAD;
@@ -150,7 +160,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         const size_t c0 = cols.size();
         cols.resize(c0 + col_len[i], make_int4(0, 0, 0, 0));
         aux.resize(c0 + col_len[i], make_short4(0, 0, 0, 0));
-        for (int x = 0; x < N; ++x) {
+        for (int x = 0; x < N && !dev_sig; ++x) {
             const int cp = (x - 2 >= 0 && good(x - 2)) ? p.sigE[x - 2] : 0;
             const int tron = (x - 2 >= 0 && x - 2 <= p.b_len) ? p.b[x - 2] : 0;
             unsigned fl = 0;
@@ -179,7 +189,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         }
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;
-    for (int i = 0; i < n; ++i) if (!probs[i].dinc) scalar_ok = false;
+    for (int i = 0; i < n && !dev_sig; ++i) if (!probs[i].dinc) scalar_ok = false;      // (device-made signals bring dinc along)
     if (!n) return 0;
     if (scalar_ok) {
         d_intpen = pool.get(HP_INTPEN, (size_t) sc.intpen_len * sizeof(int16_t));
@@ -206,9 +216,48 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     if (!d_sc || !d_a || !d_cols || !d_aux) { ctx->err = "device allocation failed (aa x genome inputs)"; return -1; }
     HIPCHK(hipMemcpyAsync(d_sc, &ds, sizeof ds, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_a, a_all.data(), a_all.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
+    if (dev_sig) {                              // (made on the device below: only zeros for the padding now)
+        HIPCHK(hipMemsetAsync(d_cols, 0, cols.size() * sizeof(int4), ctx->stream));
+        HIPCHK(hipMemsetAsync(d_aux, 0, aux.size() * sizeof(short4), ctx->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (dev_sig) {
+        // only the tron codes crossed PCIe (1 B per position instead of 24): spdp_signals_h.hip writes the column records
+        const size_t tot = cols.size();
+        std::vector<uint8_t> hb(tot + 16, 0);
+        std::vector<SigJobH> jobs(n);
+        for (int i = 0; i < n; ++i) {
+            memcpy(hb.data() + col_off[i], probs[i].b, (size_t) probs[i].b_len + 1);
+            SigJobH& J = jobs[i];
+            J.b_off = J.out_off = J.col_off = col_off[i]; J.pad = 0;
+            J.b_len = probs[i].b_len; J.left = probs[i].exin_left; J.right = probs[i].exin_right;
+        }
+        void* tmp[10] = {nullptr};
+        const size_t bytes[10] = {tot + 16, 2 * tot, 2 * tot, 2 * tot, 2 * tot, 2 * tot, tot, tot, tot, tot};
+        struct Freer { void** p; ~Freer() { for (int k = 0; k < 10; ++k) if (p[k]) (void) hipFree(p[k]); } } freer{tmp};
+        for (int k = 0; k < 10; ++k) HIPCHK(hipMalloc(&tmp[k], std::max<size_t>(bytes[k], 16)));
+        HIPCHK(hipMemcpy(tmp[0], hb.data(), tot + 16, hipMemcpyHostToDevice));
+        SignalArgsH A;
+        memset(&A, 0, sizeof A);
+        A.codes = (const uint8_t*) tmp[0];
+        A.sig5 = (int16_t*) tmp[1]; A.sig3 = (int16_t*) tmp[2]; A.sigS = (int16_t*) tmp[3]; A.sigT = (int16_t*) tmp[4];
+        A.sigE = (int16_t*) tmp[5]; A.phs5 = (int8_t*) tmp[6]; A.phs3 = (int8_t*) tmp[7];
+        A.cano = (uint8_t*) tmp[8]; A.dinc = (uint8_t*) tmp[9];
+        A.cols = (int4*) d_cols; A.aux = (short4*) d_aux; A.ipen = ipen;
+        if (spdh_signals_run(ctx, sc.sigmodel, jobs, A, 1)) return -1;
+        // the host ladder scores pure diagonals itself (diagonalH_ng) and reads sigE for that: bring it back
+        std::vector<int16_t> all(tot);
+        HIPCHK(hipMemcpy(all.data(), tmp[5], 2 * tot, hipMemcpyDeviceToHost));
+        own_sigE.resize(n);
+        for (int i = 0; i < n; ++i) {
+            own_sigE[i].assign(all.begin() + col_off[i], all.begin() + col_off[i] + probs[i].b_len + 3);
+            probs[i].sigE = own_sigE[i].data();
+        }
+    }
+    sc.sigmodel = nullptr;                      // the caller's model is not ours to keep
     return 0;
 }
 

@@ -543,6 +543,14 @@ int spdp_exon_form(const SpdpExonFormIn* in, SpdpExonRecord* exons, int cap, Spd
  * or -(needed + 1) when buf is too small */
 int spdp_exon_form_text(const SpdpExonFormIn* in, const char* qname, const char* gname, int header, char* buf, int cap);
 
+/* the -O12 record files sortgrcd reads (src/sqpr.cc:853-885, 960-985): <prefix>.grd (GeneRecord[]), <prefix>.erd
+ * (ExonRecord[]), <prefix>.qrd (database name, then one query name per gene, NUL-terminated).  spdp_o12_write numbers the
+ * records itself (GeneRecord::Nrecord, ::Rid). */
+typedef struct SpdpO12 SpdpO12;
+SpdpO12* spdp_o12_open(const char* prefix, const char* db_name);
+int spdp_o12_write(SpdpO12* h, const SpdpExonRecord* exons, int n_exons, const SpdpGeneRecord* gene, const char* qname);
+int spdp_o12_close(SpdpO12* h);
+
 /* the protein-side edit records (skl_rngH_ng, src/fwd2h1.cc:663-667, 695-924): SPDP_FMT_CIGAR or SPDP_FMT_VULGAR (the
  * latter after Vulgar::postproc, as the reference keeps them; no SAM form exists there) */
 int spdp_skl_edits_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,

@@ -140,3 +140,51 @@ extern "C" int spdp_exon_form_text(const SpdpExonFormIn* in, const char* qname, 
     memcpy(buf, out.c_str(), out.size() + 1);
     return (int) out.size();
 }
+
+// ---- the -O12 record files (src/sqpr.cc:853-885, 960-985): <prefix>.grd = GeneRecord[], <prefix>.erd = ExonRecord[],
+//      <prefix>.qrd = the database name, then one query name per gene record, each NUL-terminated.  GeneRecord::Nrecord
+//      (exon records written before this gene) and ::Rid (index into .qrd; entry 0 is the database name) are kept here.
+struct SpdpO12 {
+    FILE* fg = nullptr; FILE* fe = nullptr; FILE* fq = nullptr;
+    uint32_t n_exons = 0;
+    int32_t n_genes = 0;
+};
+
+extern "C" SpdpO12* spdp_o12_open(const char* prefix, const char* db_name)
+{
+    if (!prefix || !db_name) return nullptr;
+    SpdpO12* h = new SpdpO12;
+    const std::string p(prefix);
+    h->fg = fopen((p + ".grd").c_str(), "wb");
+    h->fe = fopen((p + ".erd").c_str(), "wb");
+    h->fq = fopen((p + ".qrd").c_str(), "wb");
+    if (!h->fg || !h->fe || !h->fq || fputs(db_name, h->fq) == EOF || fputc('\0', h->fq) == EOF) {
+        if (h->fg) fclose(h->fg);
+        if (h->fe) fclose(h->fe);
+        if (h->fq) fclose(h->fq);
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" int spdp_o12_write(SpdpO12* h, const SpdpExonRecord* exons, int n_exons, const SpdpGeneRecord* gene, const char* qname)
+{
+    if (!h || !gene || !qname || n_exons < 0 || (n_exons && !exons)) return -1;
+    SpdpGeneRecord g = *gene;
+    g.Nrecord = h->n_exons;
+    g.Rid = ++h->n_genes;                       // entry 0 of the .qrd file is the database name
+    if (n_exons && fwrite(exons, sizeof(SpdpExonRecord), (size_t) n_exons, h->fe) != (size_t) n_exons) return -1;
+    if (fwrite(&g, sizeof g, 1, h->fg) != 1) return -1;
+    if (fputs(qname, h->fq) == EOF || fputc('\0', h->fq) == EOF) return -1;
+    h->n_exons += (uint32_t) n_exons;
+    return 0;
+}
+
+extern "C" int spdp_o12_close(SpdpO12* h)
+{
+    if (!h) return -1;
+    const int rc = (fclose(h->fg) | fclose(h->fe) | fclose(h->fq)) ? -1 : 0;
+    delete h;
+    return rc;
+}

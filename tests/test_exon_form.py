@@ -45,3 +45,30 @@ def test_exon_form_text_equals_reference(path):
         n += 1
     if not n:
         pytest.skip("no alignment in this fixture")
+
+
+def test_o12_files(tmp_path):
+    """spdp_o12_*: the three record files -O12 writes (layout of src/sqpr.cc:853-985): record counts, the running exon
+    index in GeneRecord::Nrecord, the query index, NUL-separated names"""
+    lib = engine.load_library()
+    lib.spdp_o12_open.restype = C.c_void_p
+    lib.spdp_o12_open.argtypes = [C.c_char_p, C.c_char_p]
+    lib.spdp_o12_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
+    lib.spdp_o12_close.argtypes = [C.c_void_p]
+    prefix = str(tmp_path / "out")
+    h = lib.spdp_o12_open(prefix.encode(), b"genome_db")
+    assert h
+    counts = []
+    for k, name in enumerate(("s1_basic", "s1_indels", "s1_1400nt")):
+        fx = spdg.load([f for f in FILES if f.endswith(name + ".spdg")][0])
+        ex, g, _ = _text(fx, 2, False, lib, header=False)
+        arr = (abi.ExonRecord * len(ex))(*ex)
+        assert lib.spdp_o12_write(h, arr, len(ex), C.byref(g), f"q{k}".encode()) == 0
+        counts.append(len(ex))
+    assert lib.spdp_o12_close(h) == 0
+    grd = open(prefix + ".grd", "rb").read(); erd = open(prefix + ".erd", "rb").read(); qrd = open(prefix + ".qrd", "rb").read()
+    assert len(grd) == 3 * 72 and len(erd) == sum(counts) * 72
+    assert qrd == b"genome_db\0q0\0q1\0q2\0"
+    genes = (abi.GeneRecord * 3).from_buffer_copy(grd)
+    assert [g.Nrecord for g in genes] == [0, counts[0], counts[0] + counts[1]]
+    assert [g.Rid for g in genes] == [1, 2, 3] and [g.nexn for g in genes] == counts

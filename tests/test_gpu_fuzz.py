@@ -283,3 +283,131 @@ def test_fuzz_protein_ladder(eng, seed):
             if wflag == 0:
                 assert score == wscr and skl.ravel().tolist() == (wskl or [])
     assert n_cmp > n_skip
+
+
+# ---- the -A0 wavefront kernels (spdp_rowwave.hip / spdp_h_rowwave.hip) under fully random inputs -------------------
+def _rand_exact_s(rng):
+    """random length-penalty table, junction table and per-position classes on top of _rand_scoring_s"""
+    sc0 = _rand_scoring_s(rng)
+    intpen = (-rng.integers(100, 500, size=1200)).astype(np.int16)
+    intpen[:int(rng.integers(5, 60))] = -32768 + 1024
+    t53 = rng.integers(-80, 40, size=256).astype(np.int16)
+    kw = dict(gop=sc0.gop, gep=sc0.gep, ipen=sc0.ipen, llmt=sc0.llmt, qm_len=list(sc0.qm_len)[:5], qm_pen=list(sc0.qm_pen)[:5],
+              nquant=sc0.nquant, sh=sc0.sh, intpen=intpen, t53=t53, scalar_engines=1)
+    return defaults.scoring(**kw)
+
+
+def _with_classes(rng, ps):
+    out = abi.ProblemSet()
+    for p in ps.items:
+        n = p.b_len + 1
+        c5 = (rng.random(n) < 0.08).astype(np.uint8); c3 = (rng.random(n) < 0.08).astype(np.uint8)
+        dinc = rng.integers(0, 256, size=n).astype(np.uint8)
+        a = np.ctypeslib.as_array(C_cast_u8(p.a), shape=(p.a_len,)).copy()
+        b = np.ctypeslib.as_array(C_cast_u8(p.b), shape=(p.b_len,)).copy()
+        s5 = np.ctypeslib.as_array(C_cast_i16(p.sig5), shape=(n,)).copy()
+        s3 = np.ctypeslib.as_array(C_cast_i16(p.sig3), shape=(n,)).copy()
+        out.add(a, b, s5, s3, p.a_left, p.a_right, p.b_left, p.b_right, (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr),
+                cano5=c5, cano3=c3, dinc=dinc)
+    return out
+
+
+def C_cast_u8(ptr):
+    import ctypes as C
+    return C.cast(ptr, C.POINTER(C.c_uint8))
+
+
+def C_cast_i16(ptr):
+    import ctypes as C
+    return C.cast(ptr, C.POINTER(C.c_int16))
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_cdna_a0_engines(eng, seed):
+    """scorealoneS_ng, forwardS_ng (records) and hirschbergS_ng (cpos rows) as wavefront kernels against the oracle:
+    random gap / intron parameters, signals, donor / acceptor sites, classes, length penalties, sub-ranges, end flags"""
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9500 + seed)
+    n_udh = 0
+    for rnd in range(3):
+        sc = _rand_exact_s(rng)
+        base = abi.ProblemSet()
+        for _ in range(32):
+            _rand_problem_s(rng, base)
+        ps = _with_classes(rng, base)
+        assert eng.scalar_scorealone(sc, ps).tolist() == [oracle.scalar_scorealone(sc, p) for p in ps.items]
+        for (s, skl), p in zip(eng.scalar_forward(sc, ps), ps.items):
+            ws, wskl = oracle.scalar_forward(sc, p)
+            assert s == ws and skl.tolist() == wskl.tolist()
+        for n_im in (1, 2):
+            big = abi.ProblemSet()
+            big._keep = ps._keep
+            m = 40 + 6 * n_im
+            for p in ps.items:
+                if p.a_right - p.a_left >= m:
+                    q = abi.Problem.from_buffer_copy(p)
+                    q.a_right = q.a_left + m                   # one imd_intvl for the batch
+                    big.items.append(q)
+            if not len(big):
+                continue
+            intvl = (m + n_im) // (n_im + 1)
+            scores, cpos, ranges, flags = eng.scalar_udh(sc, big, n_im, intvl)
+            for i, p in enumerate(big.items):
+                ws, wcpos, wrng, wflag = oracle.scalar_udh(sc, p, n_im, intvl)
+                assert int(flags[i]) == wflag, (seed, rnd, n_im, i)
+                if wflag == 0:
+                    assert int(scores[i]) == ws and ranges[i].tolist() == wrng.tolist() and cpos[i].tolist() == wcpos.tolist(), \
+                        (seed, rnd, n_im, i)
+                    n_udh += 1
+    assert n_udh >= 30
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_protein_a0_engines(eng, seed):
+    """forwardH_ng (score-only and records) and hirschbergH_ng as wavefront kernels against the oracle under random
+    parameters, signals, phases, tables and sub-ranges"""
+    from oracle import oracle
+    rng = np.random.default_rng(synth.SEED + 9600 + seed)
+    n_udh = 0
+    for rnd in range(3):
+        sc0 = _rand_scoring_h(rng)
+        intpen = (-rng.integers(100, 500, size=1500)).astype(np.int16)
+        t53 = rng.integers(-80, 40, size=256).astype(np.int16)
+        sc = defaults.scoring_h(gop=sc0.gop, gep=sc0.gep, gapw1=sc0.gapw1, gapw2=sc0.gapw2, gapw3=sc0.gapw3, ipen=sc0.ipen,
+                                llmt=sc0.llmt, qm_len=list(sc0.qm_len)[:5], qm_pen=list(sc0.qm_pen)[:5], nquant=sc0.nquant,
+                                sh=sc0.sh, term_codon=sc0.term_codon, intpen=intpen, t53=t53, scalar_engines=1,
+                                minl=int(rng.integers(20, 60)), gape1=-int(rng.integers(100, 400)),
+                                gape2=-int(rng.integers(100, 400)), extragop=-int(rng.integers(0, 200)))
+        ps = abi.ProblemSetH()
+        for _ in range(24):
+            p = _rand_problem_h(rng, ps)
+            dc = rng.integers(0, 256, size=p.b_len + 3).astype(np.uint8)
+            ps._keep.append(dc)
+            p.dinc = dc.ctypes.data
+            ps.items[-1] = p
+        for tb in (False, True):
+            res = eng.scalar_forward_h(sc, ps, traceback=tb)
+            for (s, skl), p in zip(res, ps.items):
+                ws, wskl = oracle.scalar_forward_h(sc, p, traceback=tb)
+                assert s == ws, (seed, rnd, tb)
+                if tb:
+                    assert skl.tolist() == wskl.tolist(), (seed, rnd)
+        n_im, m = 1, 36
+        big = abi.ProblemSetH()
+        big._keep = ps._keep
+        for p in ps.items:
+            if p.a_right - p.a_left >= m:
+                q = abi.ProblemH.from_buffer_copy(p)
+                q.a_right = q.a_left + m
+                big.items.append(q)
+        if len(big):
+            intvl = (m + n_im) // (n_im + 1)
+            scores, cpos, ranges, flags = eng.scalar_udh_h(sc, big, n_im, intvl)
+            for i, p in enumerate(big.items):
+                ws, wcpos, wrng, wflag = oracle.scalar_udh_h(sc, p, n_im, intvl)
+                assert int(flags[i]) == wflag, (seed, rnd, i)
+                if wflag == 0:
+                    assert int(scores[i]) == ws and ranges[i].tolist() == wrng.tolist() and cpos[i].tolist() == wcpos.tolist(), \
+                        (seed, rnd, i)
+                    n_udh += 1
+    assert n_udh >= 12

@@ -418,7 +418,8 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + 5ll * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal
-            const int64_t cap = (flav == 3) ? vmf_capacity(it) : 0;
+            // (+ what the waves of a pipelined problem may leave unused of the chunks of numbers they reserve)
+            const int64_t cap = (flav == 3) ? vmf_capacity(it) + (int64_t) SPDP_VMF_CHUNK * ((it.a_right - it.a_left) / 64 + 2) : 0;
             P.imd_off = cap;
             tb_tot += cap;
         }
@@ -534,6 +535,27 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         POOLGET(d_gprog, POOL_GPROG, sizeof(int) * words);
         HIPCHK(hipMemsetAsync(d_gprog, 0, sizeof(int) * words, strm()));
     }
+    // forwardS_ng / scorealoneS_ng: a problem's 64-row tiles as a pipeline of waves (SPDP_A0_PIPE=0: one wave each)
+    pipe_on = false;
+    if ((flav == 3 || flav == 4 || flav == 5) && n > 0) {
+        const char* e = getenv("SPDP_A0_PIPE");
+        int mt = 1;
+        h_items.clear();
+        for (int j = 0; j < n; ++j) {
+            const DevProblem& P = h_probs[j];
+            const int r0 = P.a_left + (P.flags & 1);
+            const int th = flav == 5 ? std::max(1, std::min(64, P.imd_intvl)) : 64;
+            const int nt = std::max(1, (P.a_right - r0 + th) / th);          // as the kernel counts them
+            mt = std::max(mt, nt);
+            for (int t = 0; t < nt; ++t) { h_items.push_back(j); h_items.push_back(t); }
+        }
+        if ((!e || atoi(e) != 0) && mt >= 2) {
+            pipe_on = true; pipe_tiles = mt;
+            pipe_stride = flav == 5 ? 2 + 9 * mt + max_n_im : 2 + 5 * mt;
+            pipe_words = ((size_t) n * pipe_stride + 2 + 1) & ~(size_t) 1;
+            POOLGET(d_gprog, POOL_GPROG, sizeof(int) * (pipe_words + h_items.size()));
+        }
+    }
     if (n) HIPCHK(hipMemcpyAsync(d_probs, h_probs.data(), sizeof(DevProblem) * n, hipMemcpyHostToDevice, strm()));
     return 0;
 }
@@ -544,7 +566,14 @@ int DevRun::launch()
     if (n == 0) return 0;
     in_flight = true;
     if (flavour >= 3) {
-        ScalarArgs S;
+        ScalarArgs S{};
+        if (pipe_on) {
+            int* w = (int*) d_gprog;
+            HIPCHK(hipMemsetAsync(w, 0, sizeof(int) * pipe_words, strm()));
+            HIPCHK(hipMemcpyAsync(w + pipe_words, h_items.data(), sizeof(int) * h_items.size(), hipMemcpyHostToDevice, strm()));
+            S.pipe = w; S.pipe_stride = pipe_stride; S.pipe_ticket = n * S.pipe_stride; S.max_tiles = pipe_tiles;
+            S.items = (const int2*) (w + pipe_words); S.n_items = (int) (h_items.size() / 2);
+        }
         S.sc = (const DevScoring*) store->d_sc; S.probs = (const DevProblem*) d_probs; S.n_probs = n;
         S.a_codes = (const uint8_t*) store->d_a; S.cols = (const int2*) store->d_cols;
         S.aux = (const uint8_t*) store->d_aux; S.intpen = (const int16_t*) store->d_intpen;
@@ -626,8 +655,28 @@ int DevRun::sync()
             HIPCHK(hipStreamSynchronize(strm()));
         }
     }
+    if (pipe_on) {
+        // a wave that waited in vain for the tile above it leaves a mark: the launch is repeated with one wave per problem
+        int mark[2] = {0, 0};
+        HIPCHK(hipMemcpy(mark, (int*) d_gprog + (size_t) n * pipe_stride, sizeof mark, hipMemcpyDeviceToHost));
+        if (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) {
+            pipe_on = false;
+            if (launch()) return -1;
+            HIPCHK(hipStreamSynchronize(strm()));
+        }
+    }
     kernel_ms = 0.f;
     if (n) HIPCHK(hipEventElapsedTime(&kernel_ms, evb(), eve()));
+    if (n && getenv("SPDP_TRACE_RUNS")) {
+        int mr = 0, mc = 0; int64_t mcell = 0;
+        for (int j = 0; j < n; ++j) {
+            mr = std::max(mr, h_probs[j].a_right - h_probs[j].a_left); mc = std::max(mc, h_probs[j].width);
+            mcell = std::max<int64_t>(mcell, h_probs[j].cells);
+        }
+        fprintf(stderr, "[spdp run] flavour %d n %d cells %.3g (largest %.3g, rows <= %d, width <= %d) pipe %d items %zu  %.2f ms  %.1f GCUPS\n",
+                flavour, n, (double) total_cells, (double) mcell, mr, mc, (int) pipe_on, h_items.size() / 2, kernel_ms,
+                total_cells / (kernel_ms * 1e6));
+    }
     return 0;
 }
 

@@ -66,6 +66,7 @@ extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int 
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // exact-intron-length (-A0) engines (spdp_rowwave.hip: one wave per problem, lane = row) and the -A1 engines
+#define SPDP_VMF_CHUNK 512          // Vmf record numbers a wave of a pipelined forwardS_ng problem reserves at a time
 struct ScalarArgs {
     const DevScoring* sc;
     const DevProblem* probs;      // bnd_off = work offset (ints), tb_off = Vmf offset (records), imd_off = Vmf capacity
@@ -91,6 +92,11 @@ struct ScalarArgs {
     int*              ranges;     // per problem 4 ints
     int*              scores;
     int               cpos_stride;
+    // tiles of a problem as separate waves (spdp_rowwave<., true>): null = one wave per problem
+    int*              pipe;       // per problem pipe_stride ints {records, overflow, prog[max_tiles], best[max_tiles][4]}; then {ticket, stalled}
+    int               pipe_stride, pipe_ticket, max_tiles;
+    const int2*       items;      // (problem, tile) in dispatch order
+    int               n_items;
 };
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t s);    // spdp_rowwave.hip: -A0 forward / score-only
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t s);            // spdp_rowwave.hip: -A0 linear space
@@ -268,6 +274,12 @@ struct DevRun {
     int cross_g = 0;                        // > 0: every problem spread over this many 16-wave blocks (CUs)
     bool fp_ok = false;                     // scores stay inside the exact fp32 range: spdp_sweep_fp.hip may run it
     void* d_gprog = nullptr;                // progress / barrier words of the cross-CU pipelines
+    // -A0 wavefront engines with the tiles of a problem as separate waves (spdp_rowwave<., true>): shares d_gprog
+    bool pipe_on = false;
+    int pipe_tiles = 0;                     // most tiles of one problem
+    int pipe_stride = 0;                    // sync words per problem
+    size_t pipe_words = 0;                  // sync words ahead of the item list
+    std::vector<int> h_items;               // (problem, tile) pairs in dispatch order
     int max_n_im = 0, max_skl = 0;
     int64_t total_cells = 0, tb_bytes = 0;
     std::vector<DevProblem> h_probs;        // in dispatch order

@@ -65,7 +65,24 @@ struct Lds {
 
 }   // namespace
 
-template <int MODE>
+// PIPE: the tiles of one problem run as separate waves, each a few dozen anti-diagonals behind the tile above it
+// (ScalarArgs::items lists (problem, tile) in dispatch order; a wave draws the next one from a ticket counter, so a
+// tile's predecessor is always resident or done).  The arrays then cross CUs: their accesses go to the memory side
+// (agent-scope atomics, the per-XCD L2s are not coherent with each other) and a tile publishes, after its stores have
+// drained, the anti-diagonal up to which it has handed its entries back (prog[tile], +1; INT_MAX = finished).
+template <bool X> __device__ __forceinline__ int gld(const int* p)
+{
+    if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __builtin_nontemporal_load(p);
+}
+template <bool X> __device__ __forceinline__ void gst(int* p, int v)
+{
+    if constexpr (X) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+#define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int MODE, bool PIPE>
 __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
 {
     constexpr bool FWD = MODE == 1;
@@ -75,7 +92,16 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
     load_tables(T, A, sc);
     Lds& L = Lw[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
+    if (PIPE) {
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= A.n_items) return;
+        const int2 it = A.items[tk];
+        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+    }
     if (pi >= A.n_probs) return;
     const DevProblem P = A.probs[pi];
     const int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
@@ -94,21 +120,56 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
     int* __restrict__ gFp = gHp + width;
     int* __restrict__ gDr = gFp + width;
     int3* __restrict__ vrec = A.vmf + P.tb_off;
+    int* __restrict__ vraw = reinterpret_cast<int*>(vrec);
     const int vcap = (int) P.imd_off;
+    // PIPE: what the tiles of the problem share: {records appended, overflow}, prog[max_tiles], best[max_tiles][4]
+    int* __restrict__ sy = PIPE ? A.pipe + (size_t) pi * A.pipe_stride : nullptr;
+    int* __restrict__ prog = PIPE ? sy + 2 : nullptr;
+    int* __restrict__ tbest = PIPE ? sy + 2 + A.max_tiles : nullptr;
     int vcount = 2;                                     // wave-uniform; records 0 (dummy) and 1 (start) below
+    int vleft = 0;                                      // PIPE: numbers left of the chunk this wave holds
     bool vover = false;
     // appends one record for every lane that asks; returns its number (garbage for the others)
     auto vadd = [&](bool need, int mm, int nn, int pp) -> int {
         const unsigned long long mask = __ballot(need);
         if (!mask) return 0;
+        const int cnt = __popcll(mask);
+        if (PIPE && cnt > vleft) {                      // numbers come from the problem's counter SPDP_VMF_CHUNK at a time:
+            int b = 0;                                  // they differ from the one-wave order, the chains do not
+            if (lane == 0) b = __hip_atomic_fetch_add(sy, SPDP_VMF_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vcount = 2 + __builtin_amdgcn_readfirstlane(b);
+            vleft = SPDP_VMF_CHUNK;
+        }
         const int my = vcount + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0));
-        vcount += __popcll(mask);
-        if (need) { if (my < vcap) vrec[my] = make_int3(mm, nn, pp); else vover = true; }
+        vcount += cnt; vleft -= cnt;
+        if (need) {
+            if (my < vcap) {
+                if (PIPE) { gst<true>(vraw + 3 * my, mm); gst<true>(vraw + 3 * my + 1, nn); gst<true>(vraw + 3 * my + 2, pp); }
+                else vrec[my] = make_int3(mm, nn, pp);
+            } else vover = true;
+        }
         return my;
+    };
+    // PIPE: waits until tile `t` has published at least `req`; false when it never does (a wave of the problem is not
+    // resident: cannot happen with the ticket order, kept as a bound on every spin)
+    auto wait_for = [&](int t, int req) -> bool {
+        long spins = 0;
+        while (__hip_atomic_load(prog + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < req) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1l << 22)) {
+                if (lane == 0) __hip_atomic_store(A.pipe + A.pipe_ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        return true;
+    };
+    auto publish = [&](int t, int v) {
+        STORES_DRAINED();
+        if (lane == 0) __hip_atomic_store(prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // ---- the arrays as vset / initS_ng (sinitS_ng) leave them
-    {
+    if (t_lo == 0) {
         const int r0 = bl - al;
         const int r_hi = a_exgl ? min(up, br - al) : r0;            // free start columns of the first row
         const int r_lo = max(lw, bl - ar);                          // first column, rows below the first
@@ -122,19 +183,26 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
                 if (b_exgl) hv = 0;
                 else { hv = gop + (r0 - r) * gep; hp = 1; if (!FWD) fv = hv; }
             }
-            gHv[e] = hv; gFv[e] = fv;
-            if (FWD) { gHp[e] = hp; gFp[e] = 0; gDr[e] = dr; }
+            gst<PIPE>(gHv + e, hv); gst<PIPE>(gFv + e, fv);
+            if (FWD) { gst<PIPE>(gHp + e, hp); gst<PIPE>(gFp + e, 0); gst<PIPE>(gDr + e, dr); }
         }
-        if (FWD && lane == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(al, bl, 0); }
+        if (FWD && lane == 0) {
+            gst<PIPE>(vraw + 0, 0); gst<PIPE>(vraw + 1, 0); gst<PIPE>(vraw + 2, 0);
+            gst<PIPE>(vraw + 3, al); gst<PIPE>(vraw + 4, bl); gst<PIPE>(vraw + 5, 0);
+        }
     }
 
     // running maximum of a local right end: first maximum in row-major order
     int best_v = NEV, best_m = al, best_n = bl, best_p = 0;
 
     const int R0 = al + (a_exgl ? 1 : 0);                          // first row the reference's loop visits
-    for (int m0 = R0; m0 <= ar; m0 += 64) {
+    const int n_tiles = max(1, (ar - R0 + 64) / 64);               // (DevRun::prepare lists the same count)
+    bool stalled = false;
+    for (int ti = t_lo; ti < t_hi; ++ti) {
+        const int m0 = R0 + 64 * ti;
+        if (m0 > ar) break;
         // what the previous tile wrote back must be what this one reads
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const int m = m0 + lane;
         const bool row = m <= ar;
         const int n_first = max(m - 1 + lw, bl) + 1, n_last = min(m + up, br);
@@ -142,7 +210,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
         // anti-diagonals this tile sweeps
         int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? n_last + m : INT32_MIN;
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
-        if (s_lo > s_hi) continue;
+        if (s_lo > s_hi) continue;                                  // (PIPE: published as finished below)
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
         const int* qprof = T.mtx + acode * 32;
         const bool internal = FWD ? (spj && (!a_exgr || m < ar)) : true;
@@ -165,16 +233,21 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
             const int dead = min(max(0, need_lo(S)), width);
             for (int e = res_lo + lane; e < dead; e += 64) {
                 const int q = e & (RING - 1);
-                gHv[e] = L.hv[q]; gFv[e] = L.fv[q];
-                if (FWD) { gHp[e] = L.hp[q]; gFp[e] = L.fp[q]; gDr[e] = L.dr[q]; }
+                gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
+                if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
             }
             res_lo = max(res_lo, dead);
             const int want = min(width, need_hi(S + CHUNK - 1) + 1);
+            if (PIPE) {
+                // the tile below may read everything under `dead`; what I am about to read, the tile above must have
+                // handed back: its need_lo(S') >= want, S' published as S' + 1
+                if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, want + 2 * (m0 - 1) + 1 + (lw - 1) + 1);
+                publish(ti, S + 1);
+            }
             for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                 const int q = e & (RING - 1);
-                L.hv[q] = __builtin_nontemporal_load(gHv + e); L.fv[q] = __builtin_nontemporal_load(gFv + e);
-                if (FWD) { L.hp[q] = __builtin_nontemporal_load(gHp + e); L.fp[q] = __builtin_nontemporal_load(gFp + e);
-                           L.dr[q] = __builtin_nontemporal_load(gDr + e); }
+                L.hv[q] = gld<PIPE>(gHv + e); L.fv[q] = gld<PIPE>(gFv + e);
+                if (FWD) { L.hp[q] = gld<PIPE>(gHp + e); L.fp[q] = gld<PIPE>(gFp + e); L.dr[q] = gld<PIPE>(gDr + e); }
             }
             res_hi = max(res_hi, want);
             WAVE_SYNC();
@@ -332,16 +405,42 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
             WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
-                gHv[e] = L.hv[q]; gFv[e] = L.fv[q];
-                if (FWD) { gHp[e] = L.hp[q]; gFp[e] = L.fp[q]; gDr[e] = L.dr[q]; }
+                gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
+                if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (PIPE) {
+        // finished = every entry holds what the tiles up to this one leave: the tile above must be finished too
+        const int ti = t_lo;
+        if (LocalR) {
+            // first maximum in row-major order over the tile's lanes, handed to the wave of the last tile
+            for (int off = 32; off; off >>= 1) {
+                const int ov = __shfl_xor(best_v, off), om = __shfl_xor(best_m, off), on_ = __shfl_xor(best_n, off), op = __shfl_xor(best_p, off);
+                if (ov > best_v || (ov == best_v && (om < best_m || (om == best_m && on_ < best_n)))) { best_v = ov; best_m = om; best_n = on_; best_p = op; }
+            }
+            if (lane == 0) { gst<true>(tbest + 4 * ti, best_v); gst<true>(tbest + 4 * ti + 1, best_m);
+                             gst<true>(tbest + 4 * ti + 2, best_n); gst<true>(tbest + 4 * ti + 3, best_p); }
+        }
+        if (__any(vover) && lane == 0) gst<true>(sy + 1, 1);
+        if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, INT32_MAX);
+        publish(ti, INT32_MAX);
+        if (ti != n_tiles - 1) return;
+        // the wave of the last tile ends the problem
+        vover = __hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (LocalR) {
+            best_v = NEV; best_m = al; best_n = bl; best_p = 0;
+            for (int t = lane; t < n_tiles; t += 64) {              // tiles in row order: the first maximum wins
+                const int ov = gld<true>(tbest + 4 * t), om = gld<true>(tbest + 4 * t + 1);
+                const int on_ = gld<true>(tbest + 4 * t + 2), op = gld<true>(tbest + 4 * t + 3);
+                if (ov > best_v) { best_v = ov; best_m = om; best_n = on_; best_p = op; }
+            }
+        }
+    } else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 
     DevResult R;
     R.score = NEV; R.mr = ar; R.nr = br; R.ml = al; R.ulk = 0; R.maxr = 0; R.pad[0] = R.pad[1] = 0;
-    auto GH = [&](int r) { return __builtin_nontemporal_load(gHv + (r - (lw - 1))); };
+    auto GH = [&](int r) { return gld<PIPE>(gHv + (r - (lw - 1))); };
     // first maximum of H over [lo, hi] walked upwards (dir = +1) or downwards (dir = -1), only where it beats `start`
     auto scan_best = [&](int lo, int hi, int step, int start_r, int start_v) {
         // candidates strictly greater than the running maximum take over in walk order: the result is the first position
@@ -394,25 +493,31 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
         if (i > 0) m9 -= i;
         if (i < 0) n9 += i;
         const int e = mx - (lw - 1);
-        ptr = vadd(lane == 0, m9, n9, __builtin_nontemporal_load(gHp + e));
+        ptr = vadd(lane == 0, m9, n9, gld<PIPE>(gHp + e));
         ptr = __shfl(ptr, 0);
         R.score = GH(mx);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    int vtotal = vcount;                                            // numbers handed out
+    if (PIPE) { STORES_DRAINED(); vtotal = 2 + __hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     const bool over_any = __any(vover);
     // Vmf::traceback(ptr) + the boundary record of trcbkalignS_ng, by one lane
     if (lane == 0) {
         int2* out = A.skl + (int64_t) pi * A.skl_cap;
         int cnt = 0, status = over_any ? -3 : 0;
-        if (ptr > 0 && ptr < vcount && !status) {
-            int3 sv = vrec[ptr];
+        auto rec = [&](int i) {
+            if (PIPE) return make_int3(gld<true>(vraw + 3 * i), gld<true>(vraw + 3 * i + 1), gld<true>(vraw + 3 * i + 2));
+            return vrec[i];
+        };
+        if (ptr > 0 && ptr < vtotal && !status) {
+            int3 sv = rec(ptr);
             int lm = 0, ln = 0;
             for (;;) {
                 if (cnt < A.skl_cap) out[cnt] = make_int2(sv.x, sv.y); else status = -1;
                 lm = sv.x; ln = sv.y; ++cnt;
                 if (!sv.z) break;
-                if (sv.z < 0 || sv.z >= vcount || cnt > vcount) { status = -2; break; }     // not a chain: never follow it
-                sv = vrec[sv.z];
+                if (sv.z < 0 || sv.z >= vtotal || cnt > vtotal) { status = -2; break; }     // not a chain: never follow it
+                sv = rec(sv.z);
             }
             const int rd = Local ? 0 : ((ln - lm) - bl + al);
             if (rd) {
@@ -438,6 +543,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
 // from tile to tile by broadcast.  Lane 0 walks the links back into the cpos rows lspS_ng reads.
 namespace {
 constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
+constexpr int INH = 0x7ffffff0;                         // PIPE: "the rlst the row above me ends with", resolved by the link walk
 struct LdsU {
     int hv[RING], hu[RING], hl[RING], hm[RING], hk[RING];
     int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
@@ -445,6 +551,10 @@ struct LdsU {
 struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
 }   // namespace
 
+// PIPE as above.  `rlst` is the one value that would tie a tile to the END of the intermediate row above it; it is only
+// ever stored (into HLNK), so a tile starts from the marker INH, every intermediate row leaves the value it ends
+// with in rlf[], and the link walk replaces the marker by what the rows above left.
+template <bool PIPE>
 __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
 {
     __shared__ LdsU Lw[WPB];
@@ -453,7 +563,16 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
     load_tables(T, A, sc);
     LdsU& L = Lw[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int t_lo = 0, t_hi = INT32_MAX;
+    if (PIPE) {
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= A.n_items) return;
+        const int2 it = A.items[tk];
+        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+    }
     if (pi >= A.n_probs) return;
     const DevProblem P = A.probs[pi];
     int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
@@ -475,10 +594,35 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
     auto mi_of = [&](int i) { return P.a_left + (i + 1) * intvl; };
     int* cpos = A.cpos + (int64_t) pi * A.cpos_stride;
 #define CPOS(i, c) cpos[(i) * 10 + (c)]
+    // PIPE: what the tiles of the problem share: prog[max_tiles], best[max_tiles][8], rlf[n_im]
+    int* __restrict__ sy = PIPE ? A.pipe + (size_t) pi * A.pipe_stride : nullptr;
+    int* __restrict__ prog = PIPE ? sy + 2 : nullptr;
+    int* __restrict__ tbest = PIPE ? sy + 2 + A.max_tiles : nullptr;
+    int* __restrict__ rlf = PIPE ? sy + 2 + 9 * A.max_tiles : nullptr;
+    auto wait_for = [&](int t, int req) -> bool {
+        long spins = 0;
+        while (__hip_atomic_load(prog + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < req) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1l << 22)) {
+                if (lane == 0) __hip_atomic_store(A.pipe + A.pipe_ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        return true;
+    };
+    auto publish = [&](int t, int v) {
+        STORES_DRAINED();
+        if (lane == 0) __hip_atomic_store(prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto imd_init = [&](int i) {
+        int* b = imd_base + (int64_t) i * 4 * us;
+        for (int64_t q = lane; q < us; q += 64) {
+            gst<PIPE>(b + q, EOU); gst<PIPE>(b + us + q, EOU); gst<PIPE>(b + 2 * us + q, 0x7fffffff); gst<PIPE>(b + 3 * us + q, (int) 0x80000000);
+        }
+    };
 
-    for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
     // ---- the arrays as hinitS_ng leaves them; the link / bound arrays of the intermediates
-    {
+    if (t_lo == 0) {
         const int r0 = bl - al, rb = bl - ar;
         const int r_hi = a_exgl ? min(up, br - al) : r0;
         const int r_lo = max(lw, bl - ar);
@@ -490,14 +634,10 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                 if (b_exgl) h = {0, r, r, al + (r0 - r), r};
                 else h = {gop + (r0 - r) * gep, r0, r, al + (r0 - r), r0};
             }
-            G(0)[e] = h.v; G(1)[e] = h.u; G(2)[e] = h.l; G(3)[e] = h.m; G(4)[e] = h.k;
-            G(5)[e] = NEV; G(6)[e] = rb; G(7)[e] = rb; G(8)[e] = 0; G(9)[e] = EOU;
+            gst<PIPE>(G(0) + e, h.v); gst<PIPE>(G(1) + e, h.u); gst<PIPE>(G(2) + e, h.l); gst<PIPE>(G(3) + e, h.m); gst<PIPE>(G(4) + e, h.k);
+            gst<PIPE>(G(5) + e, NEV); gst<PIPE>(G(6) + e, rb); gst<PIPE>(G(7) + e, rb); gst<PIPE>(G(8) + e, 0); gst<PIPE>(G(9) + e, EOU);
         }
-        for (int i = 0; i < n_im; ++i)
-            for (int64_t q = lane; q < us; q += 64) {
-                int* b = imd_base + (int64_t) i * 4 * us;
-                b[q] = EOU; b[us + q] = EOU; b[2 * us + q] = 0x7fffffff; b[3 * us + q] = (int) 0x80000000;
-            }
+        if (!PIPE) for (int i = 0; i < n_im; ++i) imd_init(i);      // (PIPE: by the tile that holds the row)
     }
 
     // local right end: first maximum in row-major order
@@ -505,8 +645,12 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
     int rlst = 0x7fffffff;
     const int R0 = al + (a_exgl ? 1 : 0);
     const int TH = max(1, min(64, intvl));                          // tile height: at most one intermediate row per tile
-    for (int m0 = R0; m0 <= ar; m0 += TH) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    const int n_tiles = max(1, (ar - R0 + TH) / TH);               // (DevRun::prepare lists the same count)
+    bool stalled = false;
+    for (int ti = t_lo; ti < t_hi; ++ti) {
+        const int m0 = R0 + TH * ti;
+        if (m0 > ar) break;
+        if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const int m = m0 + lane;
         const bool row = lane < TH && m <= ar;
         const int n_first = max(m - 1 + lw, bl) + 1, n_last = min(m + up, br);
@@ -517,6 +661,11 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
         const int iq = (m - P.a_left) / max(1, intvl) - 1;
         const bool is_imd = row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
         const unsigned long long imd_mask = __ballot(is_imd);
+        if (PIPE && imd_mask) {
+            const int i0 = __shfl(iq, __ffsll((long long) imd_mask) - 1);
+            imd_init(i0);
+            rlst = i0 == 0 ? 0x7fffffff : INH;
+        }
         if (s_lo <= s_hi) {
             const int acode = (row && m >= 1) ? acod[m - 1] : 0;
             const int* qprof = T.mtx + acode * 32;
@@ -536,14 +685,18 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                 for (int e = res_lo + lane; e < dead; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 10; ++a) G(a)[e] = lds[a][q];
+                    for (int a = 0; a < 10; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
                 }
                 res_lo = max(res_lo, dead);
                 const int want = min(width, need_hi(S + CHUNK - 1) + 1);
+                if (PIPE) {
+                    if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, want + 2 * (m0 - TH + 63) + 1 + (lw - 1) + 1);
+                    publish(ti, S + 1);
+                }
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 10; ++a) lds[a][q] = __builtin_nontemporal_load(G(a) + e);
+                    for (int a = 0; a < 10; ++a) lds[a][q] = gld<PIPE>(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
                 WAVE_SYNC();
@@ -620,11 +773,11 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                     }
                     if (is_imd && acc && maxk < 3) {
                         const int sel = maxk == K_H ? sel_h : (maxk == K_E ? sel_e : sel_f);
-                        *IM(iq, HLNK, 0, r) = pick(sel, ck);
+                        gst<PIPE>(IM(iq, HLNK, 0, r), pick(sel, ck));
                         rlst = r;
                         if (maxk == K_H) H.k = r; else if (maxk == K_E) E.k = r; else F.k = r;
                         if (maxk == K_H) {
-                            if (sel_e >= 0 && E.v > H.v + gop) { E.k = r + width; *IM(iq, HLNK, 1, r) = pick(sel_e, ck); }
+                            if (sel_e >= 0 && E.v > H.v + gop) { E.k = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), pick(sel_e, ck)); }
                             if (sel_f >= 0 && F.v > H.v + gop) F.k = r + width;
                         }
                     }
@@ -671,7 +824,7 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                                     for (int l = 0; l < NC - 1; ++l)
                                         if (l == pos) { cv[l] = x; cj[l] = n; cd[l] = k; cu[l] = src.u; cl[l] = src.l; cm[l] = src.m;
                                                         ck[l] = is_imd ? r : src.k; cx[l] = dn5; }
-                                    if (is_imd && k == K_E) *IM(iq, HLNK, 0, r) = rlst;
+                                    if (is_imd && k == K_E) gst<PIPE>(IM(iq, HLNK, 0, r), rlst);
                                 } else --ncand;
                             }
                         }
@@ -680,10 +833,10 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
                 // ---- an intermediate row records where the paths cross it and restarts ranges and links
                 if (is_imd && on) {
                     if (hd == K_H) rlst = r;
-                    else if (!spj3 && (hd % 2)) *IM(iq, HLNK, 0, r) = rlst;
-                    *IM(iq, VLNK, 0, r) = H.k; *IM(iq, LWRB, 0, r) = min(r, H.l); *IM(iq, UPRB, 0, r) = max(r, H.u);
+                    else if (!spj3 && (hd % 2)) gst<PIPE>(IM(iq, HLNK, 0, r), rlst);
+                    gst<PIPE>(IM(iq, VLNK, 0, r), H.k); gst<PIPE>(IM(iq, LWRB, 0, r), min(r, H.l)); gst<PIPE>(IM(iq, UPRB, 0, r), max(r, H.u));
                     H.l = H.u = r; H.k = r;
-                    *IM(iq, VLNK, 1, r) = F.k; *IM(iq, LWRB, 1, r) = min(r, F.l); *IM(iq, UPRB, 1, r) = max(r, F.u);
+                    gst<PIPE>(IM(iq, VLNK, 1, r), F.k); gst<PIPE>(IM(iq, LWRB, 1, r), min(r, F.l)); gst<PIPE>(IM(iq, UPRB, 1, r), max(r, F.u));
                     F.l = F.u = r; F.k = r + width;
                 }
                 if (on) {
@@ -695,16 +848,46 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
 #pragma unroll
-                for (int a = 0; a < 10; ++a) G(a)[e] = lds[a][q];
+                for (int a = 0; a < 10; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
             }
         }
         // `rlst` of this tile's intermediate row is what the next one starts from
-        if (imd_mask) rlst = __shfl(rlst, __ffsll((long long) imd_mask) - 1);
+        if (PIPE) { if (is_imd) gst<true>(rlf + iq, rlst); }
+        else if (imd_mask) rlst = __shfl(rlst, __ffsll((long long) imd_mask) - 1);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (PIPE) {
+        const int ti = t_lo;
+        if (LocalR) {
+            for (int off = 32; off; off >>= 1) {
+                St o; o.v = __shfl_xor(best.v, off); o.u = __shfl_xor(best.u, off); o.l = __shfl_xor(best.l, off);
+                o.m = __shfl_xor(best.m, off); o.k = __shfl_xor(best.k, off);
+                const int om = __shfl_xor(best_mr, off), on_ = __shfl_xor(best_nr, off);
+                if (o.v > best.v || (o.v == best.v && (om < best_mr || (om == best_mr && on_ < best_nr)))) { best = o; best_mr = om; best_nr = on_; }
+            }
+            if (lane == 0) {
+                int* b = tbest + 8 * ti;
+                gst<true>(b, best.v); gst<true>(b + 1, best.u); gst<true>(b + 2, best.l); gst<true>(b + 3, best.m);
+                gst<true>(b + 4, best.k); gst<true>(b + 5, best_mr); gst<true>(b + 6, best_nr);
+            }
+        }
+        if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, INT32_MAX);
+        publish(ti, INT32_MAX);
+        if (ti != n_tiles - 1) return;
+        if (LocalR) {                                               // tiles in row order: the first maximum wins
+            best = {NEV, 0, 0, al, 0}; best_mr = ar; best_nr = br;
+            for (int t = lane; t < n_tiles; t += 64) {
+                const int* b = tbest + 8 * t;
+                const int ov = gld<true>(b);
+                if (ov > best.v) { best = {ov, gld<true>(b + 1), gld<true>(b + 2), gld<true>(b + 3), gld<true>(b + 4)};
+                                   best_mr = gld<true>(b + 5); best_nr = gld<true>(b + 6); }
+            }
+        }
+    } else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
+    STORES_DRAINED();
 
     // ---- the end cell (hlastS_ng) or the tracked local maximum
-    auto GL = [&](int arr, int r) { return __builtin_nontemporal_load(G(arr) + (r - (lw - 1))); };
+    auto GL = [&](int arr, int r) { return gld<PIPE>(G(arr) + (r - (lw - 1))); };
     auto scan_best = [&](int lo, int hi, int step, int start_r, int start_v) {
         int bv = start_v, bk = INT32_MAX;
         const int cnt = hi - lo + 1;
@@ -751,6 +934,15 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
         CPOS(i, 9) = mxs.u;
     }
     // ---- walk the links back: one cpos row per intermediate the path crosses
+    // a link that stands for "rlst as the intermediate rows above left it"
+    auto hlnk = [&](int ii, int d, int rr_) {
+        int v = gld<PIPE>(IM(ii, HLNK, d, rr_));
+        if (PIPE && v == INH) {
+            v = 0x7fffffff;
+            for (int j = ii - 1; j >= 0; --j) { const int w = gld<true>(rlf + j); if (w != INH) { v = w; break; } }
+        }
+        return v;
+    };
     int i = n_im;
     while (--i >= 0 && mi_of(i) > ar) ;
     if (i < 0 && mi_of(0) > ar) CPOS(0, 2) = br;
@@ -763,19 +955,19 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
         for ( ; r > up; r -= width) ++d;
         if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
         const int mi = mi_of(i);
-        if (*IM(i, VLNK, d, r) < EOU) {
+        if (gld<PIPE>(IM(i, VLNK, d, r)) < EOU) {
             CPOS(i, c++) = mi;
             CPOS(i, c++) = (d > 0) ? 1 : 0;
-            for (int rp = *IM(i, HLNK, d, r); lw <= rp && rp < up && r != rp; rp = *IM(i, HLNK, 0, r = rp)) {
+            for (int rp = hlnk(i, d, r); lw <= rp && rp < up && r != rp; rp = hlnk(i, 0, r = rp)) {
                 if (c >= 6) { flag = -3; break; }                   // the terminator would land on [8]
                 CPOS(i, c++) = r + mi;
             }
             if (flag) break;
             CPOS(i, c++) = r + mi;
             CPOS(i, c) = EOU;
-            CPOS(i, 8) = *IM(i, LWRB, d, r);
-            CPOS(i, 9) = *IM(i, UPRB, d, r);
-            r = *IM(i, VLNK, d, r);
+            CPOS(i, 8) = gld<PIPE>(IM(i, LWRB, d, r));
+            CPOS(i, 9) = gld<PIPE>(IM(i, UPRB, d, r));
+            r = gld<PIPE>(IM(i, VLNK, d, r));
             if (r == EOU) break;
         } else
             CPOS(i, 0) = EOU;
@@ -812,15 +1004,23 @@ __global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    hipLaunchKernelGGL(spdp_rowwave_udh, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    if (A.pipe) hipLaunchKernelGGL(spdp_rowwave_udh<true>, dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    else hipLaunchKernelGGL(spdp_rowwave_udh<false>, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    const dim3 grd((A.n_probs + WPB - 1) / WPB), blk(64 * WPB);
-    if (forward) hipLaunchKernelGGL(spdp_rowwave<1>, grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL(spdp_rowwave<0>, grd, blk, 0, stream, A);
+    const dim3 blk(64 * WPB);
+    if (A.pipe) {                                       // one wave per (problem, tile)
+        const dim3 grd((A.n_items + WPB - 1) / WPB);
+        if (forward) hipLaunchKernelGGL((spdp_rowwave<1, true>), grd, blk, 0, stream, A);
+        else hipLaunchKernelGGL((spdp_rowwave<0, true>), grd, blk, 0, stream, A);
+        return hipGetLastError();
+    }
+    const dim3 grd((A.n_probs + WPB - 1) / WPB);
+    if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false>), grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL((spdp_rowwave<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }

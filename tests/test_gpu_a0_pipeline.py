@@ -1,0 +1,102 @@
+"""The -A0 wavefront kernels with the 64-row tiles of a problem running as a pipeline of waves
+(spdp_rowwave<., true> / spdp_rowwave_udh<true>, the default whenever a problem has two tiles or more):
+same records, cpos rows and scores as one wave per problem (SPDP_A0_PIPE=0), as the oracle, and as the
+relaunch that follows a wave giving up its wait (test hook SPDP_A0_PIPE_TEST_STALL)."""
+import numpy as np
+import pytest
+
+from tests import spdg
+from tests.conftest import golden_files
+from spaln_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+S_FILES = golden_files("s1_")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from spaln_amd import engine
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def _subranges(fx, n, seed, rows=(70, 1400)):
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + seed)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    ps = abi.ProblemSet()
+    for i in range(n):
+        m = int(rng.integers(rows[0], min(rows[1], q["a_right"]) + 1))
+        al = int(rng.integers(0, q["a_right"] - m + 1))
+        bl = int(rng.integers(0, min(800, q["b_right"] - m - 350)))
+        br = int(rng.integers(max(bl + m + 300, q["b_right"] - 1500), q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 3 == 0 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg, **extra)
+    return ps
+
+
+def _run_all(eng, sc, ps, n_im, intvl):
+    fwd = [(s, skl.tolist()) for s, skl in eng.scalar_forward(sc, ps)]
+    sco = eng.scalar_scorealone(sc, ps).tolist()
+    scores, cpos, ranges, flags = eng.scalar_udh(sc, ps, n_im, intvl)
+    return fwd, sco, scores.tolist(), cpos.tolist(), ranges.tolist(), flags.tolist()
+
+
+@pytest.mark.parametrize("name,m", [("s1_1400nt", 700), ("s1_local", 400)])
+def test_pipelined_equals_one_wave(eng, monkeypatch, name, m):
+    f = [f for f in S_FILES if f.endswith(name + ".spdg")]
+    if not f:
+        pytest.skip("fixture not present")
+    fx = spdg.load(f[0])
+    sc = spdg.scoring(fx, scalar_engines=1)
+    n_im = 4
+    intvl = (m + n_im) // (n_im + 1)
+    # hirschbergS_ng wants one interval for the batch: fixed height for the linear-space leg
+    ps = _subranges(fx, 24, 301, rows=(m, m))
+    monkeypatch.setenv("SPDP_A0_PIPE", "0")
+    want = _run_all(eng, sc, ps, n_im, intvl)
+    monkeypatch.delenv("SPDP_A0_PIPE")
+    got = _run_all(eng, sc, ps, n_im, intvl)
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert w == g, k
+    monkeypatch.setenv("SPDP_A0_PIPE_TEST_STALL", "1")       # every pipelined launch is repeated one wave per problem
+    again = _run_all(eng, sc, ps, n_im, intvl)
+    monkeypatch.delenv("SPDP_A0_PIPE_TEST_STALL")
+    for k, (w, g) in enumerate(zip(want, again)):
+        assert w == g, k
+    # ragged heights (1 .. 22 tiles) through the two engines that take them
+    ps = _subranges(fx, 48, 302, rows=(70, 2 * m))
+    monkeypatch.setenv("SPDP_A0_PIPE", "0")
+    want = [(s, skl.tolist()) for s, skl in eng.scalar_forward(sc, ps)], eng.scalar_scorealone(sc, ps).tolist()
+    monkeypatch.delenv("SPDP_A0_PIPE")
+    got = [(s, skl.tolist()) for s, skl in eng.scalar_forward(sc, ps)], eng.scalar_scorealone(sc, ps).tolist()
+    assert want == got
+
+
+def test_pipelined_against_oracle(eng):
+    """tall sub-ranges (up to 22 tiles): records, scores and cpos rows against the oracle"""
+    from oracle import oracle
+    fx = spdg.load([f for f in S_FILES if f.endswith("s1_1400nt.spdg")][0])
+    sc = spdg.scoring(fx, scalar_engines=1)
+    ps = _subranges(fx, 10, 303, rows=(900, 1400))
+    bad = []
+    for i, (p, (s, skl)) in enumerate(zip(ps.items, eng.scalar_forward(sc, ps))):
+        ws, wskl = oracle.scalar_forward(sc, p)
+        if s != ws or skl.tolist() != wskl.tolist():
+            bad.append((i, s, ws, skl.tolist()[:6], wskl.tolist()[:6]))
+    assert not bad, bad[:3]
+    m, n_im = 1100, 9
+    intvl = (m + n_im) // (n_im + 1)
+    ps = _subranges(fx, 8, 304, rows=(m, m))
+    scores, cpos, ranges, flags = eng.scalar_udh(sc, ps, n_im, intvl)
+    for i, p in enumerate(ps.items):
+        ws, wcpos, wrng, wflag = oracle.scalar_udh(sc, p, n_im, intvl)
+        ok = int(flags[i]) == wflag
+        if wflag == 0:
+            ok = ok and int(scores[i]) == ws and ranges[i].tolist() == wrng.tolist() and cpos[i].tolist() == wcpos.tolist()
+        if not ok:
+            bad.append((i, int(scores[i]), ws, int(flags[i]), wflag))
+    assert not bad, bad[:3]

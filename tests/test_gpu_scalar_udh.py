@@ -29,9 +29,6 @@ def test_align_a0_goldens(eng):
     """every cDNA fixture, one batch per mode: score + final corner list as the reference prints under -A0"""
     for local in (False, True):
         cases = [(_name(f), spdg.load(f)) for f in S_FILES if ("local" in _name(f)) == local]
-        # one GPU thread per problem: the two 1.4 kb fixtures take minutes (the CPU suite checks the
-        # oracle on them, tests/test_oracle_scalar.py)
-        cases = [(n, fx) for n, fx in cases if fx["prm"]["a_right"] - fx["prm"]["a_left"] <= 1000]
         sc = spdg.scoring(max((fx for _, fx in cases), key=lambda fx: fx["intpen"].size), scalar_engines=1)
         key = lambda fx: (fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
         for vmf, ubh, sh in sorted({key(fx) for _, fx in cases}):

@@ -83,7 +83,7 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 #define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int MODE, bool PIPE>
-__global__ __launch_bounds__(64 * WPB) void spdp_rowwave(ScalarArgs A)
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void spdp_rowwave(ScalarArgs A)
 {
     constexpr bool FWD = MODE == 1;
     __shared__ Lds Lw[WPB];
@@ -555,7 +555,7 @@ struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, 
 // ever stored (into HLNK), so a tile starts from the marker INH, every intermediate row leaves the value it ends
 // with in rlf[], and the link walk replaces the marker by what the rows above left.
 template <bool PIPE>
-__global__ __launch_bounds__(64 * WPB) void spdp_rowwave_udh(ScalarArgs A)
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void spdp_rowwave_udh(ScalarArgs A)
 {
     __shared__ LdsU Lw[WPB];
     __shared__ Tables T;

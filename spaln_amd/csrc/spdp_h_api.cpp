@@ -30,10 +30,10 @@
     } while (0)
 
 enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs + traceback runs / linear-space runs
-enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN };
+enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN, HP_PIPE };
 void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64]);       // spdp_rescore_api.cpp
 int spdh_signals_run(SpdpContext* ctx, const SpdpSignalModelH* m, const std::vector<SigJobH>& jobs, SignalArgsH args, int pack);   // spdp_signals_api.cpp
-enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES };
+enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES, HU_PIPE };
 static const int H_SKL_CAP = 4096;       // slot of one traceback record list; a list is at most ~4 records per query row (diagonal / gap corners and
                                            // two per intron), and the slot is min(this, rows + columns + 8): protein queries stay far below
 
@@ -442,6 +442,60 @@ static int run_forward(HStore& st, const std::vector<HItem>& items, bool walk, H
     return 0;
 }
 
+// ---- the -A0 wavefront kernels with the tiles of a problem as a pipeline of waves (spdh_rowwave<., true>) ----
+// The work list (problem, tile) in dispatch order behind the sync words of the problems; on whenever a problem has
+// two tiles or more (SPDP_A0_PIPE=0: one wave per problem).  A wave that waited in vain for the tile above it
+// leaves a mark and the caller repeats the launch without the pipeline.
+struct HPipe {
+    std::vector<int> items;
+    int max_tiles = 1, stride = 0;
+    size_t words = 0;
+    int* d = nullptr;
+    bool on = false;
+};
+static int pipe_setup(SpdpContext* ctx, DevPool& pool, int slot, const std::vector<DevProblemH>& probs, bool udh, int max_im, HPipe& pp)
+{
+    pp = HPipe();
+    const char* e = getenv("SPDP_A0_PIPE");
+    for (size_t j = 0; j < probs.size(); ++j) {
+        const DevProblemH& P = probs[j];
+        const int r0 = P.a_left + (P.a_exgl ? 1 : 0);
+        const int th = udh ? std::max(1, std::min(64, P.imd_intvl)) : 64;
+        const int nt = std::max(1, (P.a_right - r0 + th) / th);              // as the kernel counts them
+        pp.max_tiles = std::max(pp.max_tiles, nt);
+        for (int t = 0; t < nt; ++t) { pp.items.push_back((int) j); pp.items.push_back(t); }
+    }
+    if ((e && atoi(e) == 0) || pp.max_tiles < 2) return 0;
+    // These kernels run one or two waves per SIMD: once every SIMD has a problem of its own the pipeline only adds
+    // memory-side traffic (measured on 400-residue queries: 256 problems 283 -> 137 ms, 2048 problems 714 -> 926 ms).
+    // SPDP_A0_PIPE=1 forces it.
+    if (!e && (int) probs.size() >= 4 * ctx->n_cu) return 0;
+    pp.stride = 2 + 9 * pp.max_tiles + 3 * max_im;
+    pp.words = (probs.size() * (size_t) pp.stride + 2 + 1) & ~(size_t) 1;
+    pp.d = (int*) pool.get(slot, sizeof(int) * (pp.words + pp.items.size()));
+    if (!pp.d) { ctx->err = "device allocation failed (tile pipeline of the scalar aa x genome engines)"; return -1; }
+    pp.on = true;
+    return 0;
+}
+static int pipe_arm(SpdpContext* ctx, const HPipe& pp, int n_probs, HScalarArgs& A)
+{
+    A.pipe = nullptr;
+    if (!pp.on) return 0;
+    HIPCHK(hipMemsetAsync(pp.d, 0, sizeof(int) * pp.words, ctx->stream));
+    HIPCHK(hipMemcpyAsync(pp.d + pp.words, pp.items.data(), sizeof(int) * pp.items.size(), hipMemcpyHostToDevice, ctx->stream));
+    A.pipe = pp.d; A.pipe_stride = pp.stride; A.pipe_ticket = n_probs * pp.stride; A.max_tiles = pp.max_tiles;
+    A.items = (const int2*) (pp.d + pp.words); A.n_items = (int) (pp.items.size() / 2);
+    return 0;
+}
+// after the launch has finished: 1 = a wave gave up (repeat without the pipeline), 0 = fine
+static int pipe_stalled(SpdpContext* ctx, const HPipe& pp, int n_probs)
+{
+    if (!pp.on) return 0;
+    int mark[2] = {0, 0};
+    HIPCHK(hipMemcpy(mark, pp.d + (size_t) n_probs * pp.stride, sizeof mark, hipMemcpyDeviceToHost));
+    return (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) ? 1 : 0;
+}
+
 // ---- scalar forwardH_ng over a list of items (spdp_h_rowwave.hip) ------------------------------
 static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
 {
@@ -463,7 +517,9 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
         d.tb_off = vmf_rec;
         // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
         // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
-        const int64_t cap = forward ? 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64 : 0;
+        // (+ what the waves of a pipelined problem may leave unused of the chunks of numbers they reserve)
+        const int64_t cap = forward ? 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64
+                                      + (int64_t) SPDP_VMF_CHUNK * ((d.a_right - d.a_left) / 64 + 2) : 0;
         if (cap >= (int64_t) 1 << 31) { ctx->err = "scalar engine: problem too large for its record store"; return -1; }
         d.imd_off = cap;
         vmf_rec += cap;
@@ -494,10 +550,21 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     A.cip = (const int*) st.d_cip;
     A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (exact) HIPCHK(spdh_launch_exact(0, &A, ctx->stream));
-    else HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HPipe pp;
+    if (!exact && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (pipe_arm(ctx, pp, nr, A)) return -1;
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        if (exact) HIPCHK(spdh_launch_exact(0, &A, ctx->stream));
+        else HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        if (!pp.on) break;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const int st_ = pipe_stalled(ctx, pp, nr);
+        if (st_ < 0) return -1;
+        if (!st_) break;
+        pp.on = false;
+    }
     out.res.resize(nr); out.n_skl.assign(nr, 0); out.off.assign(nr + 1, 0);
     HIPCHK(hipMemcpyAsync(out.res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<int2> skl;
@@ -640,11 +707,22 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.work = (int*) d_work; A.res = (DevResultH*) d_res;
     A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
     A.cpos_stride = out.stride;
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (engine == 2) HIPCHK(spdh_launch_local_udh(&A, ctx->stream));
-    else if (exact) HIPCHK(spdh_launch_exact(1, &A, ctx->stream));
-    else HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HPipe pp;
+    if (engine == 0 && pipe_setup(ctx, pool, HU_PIPE, h_probs, true, max_im, pp)) return -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (pipe_arm(ctx, pp, nr, A)) return -1;
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        if (engine == 2) HIPCHK(spdh_launch_local_udh(&A, ctx->stream));
+        else if (exact) HIPCHK(spdh_launch_exact(1, &A, ctx->stream));
+        else HIPCHK(spdh_launch_scalar_udh(&A, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        if (!pp.on) break;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const int st_ = pipe_stalled(ctx, pp, nr);
+        if (st_ < 0) return -1;
+        if (!st_) break;
+        pp.on = false;
+    }
     out.scores.resize(nr); out.cpos.resize((size_t) nr * out.stride); out.ranges.resize((size_t) nr * 4);
     std::vector<DevResultH> res(nr);
     HIPCHK(hipMemcpyAsync(out.scores.data(), d_scores, nr * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

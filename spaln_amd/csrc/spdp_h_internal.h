@@ -51,6 +51,9 @@ struct HCposArgs {
     int                cpos_stride;
 };
 
+#ifndef SPDP_VMF_CHUNK
+#define SPDP_VMF_CHUNK 512          // Vmf record numbers a wave of a pipelined forward problem reserves at a time
+#endif
 // the -A0 engines forwardH_ng / hirschbergH_ng (spdp_h_rowwave.hip): one wave per problem, lane = row
 struct HScalarArgs {
     const DevScoringH* sc;
@@ -79,6 +82,11 @@ struct HScalarArgs {
     int*               ranges;     // per problem 4 ints
     int*               scores;
     int                cpos_stride;
+    // tiles of a problem as separate waves (spdh_rowwave<., true>): null = one wave per problem
+    int*               pipe;       // per problem pipe_stride ints {records, overflow, prog[max_tiles], best[max_tiles][8], rlf[n_im][3]}; then {ticket, stalled}
+    int                pipe_stride, pipe_ticket, max_tiles;
+    const int2*        items;      // (problem, tile) in dispatch order
+    int                n_items;
 };
 
 // protein-side signal precompute (spdp_signals_h.hip): Exinon::intron53_c / intron53_p for tron windows

@@ -126,7 +126,29 @@ template <class A> __device__ __forceinline__ int pick(int sel, const A& arr)
 
 }   // namespace
 
-template <int MODE>
+// PIPE (as spdp_rowwave.hip): the tiles of one problem run as separate waves, each a few dozen anti-diagonals behind
+// the tile above it.  HScalarArgs::items lists (problem, tile) in dispatch order and a wave draws the next one from a
+// ticket counter, so a tile's predecessor is always resident or done.  The arrays then cross CUs: their accesses
+// go to the memory side (agent-scope atomics; the per-XCD L2s are not coherent with each other) and a tile
+// publishes, once its stores have drained, the anti-diagonal up to which it has handed its entries back
+// (prog[tile], + 1; INT_MAX = finished).  Vmf numbers are reserved SPDP_VMF_CHUNK at a time from the problem's counter.
+// MODE 2: `rlst`, which would tie a tile to the END of the intermediate row above it, is only ever stored (into
+// HLNK): a tile starts from the marker INH + slot, every intermediate row leaves what it ends with in rlf[], and
+// the link walk replaces the marker by what the rows above left.
+constexpr int INH = 0x7ffffff0;
+template <bool X> __device__ __forceinline__ int gld(const int* p)
+{
+    if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __builtin_nontemporal_load(p);
+}
+template <bool X> __device__ __forceinline__ void gst(int* p, int v)
+{
+    if constexpr (X) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+#define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int MODE, bool PIPE>
 __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 {
     constexpr bool FWD = MODE == 1, UDH = MODE == 2;
@@ -137,7 +159,16 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     load_tables(T, A, sc);
     int (*L)[RING] = Lw[threadIdx.x >> 6];              // L[f] = field f of H, L[NF + f] = field f of F
     const int lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
+    if (PIPE) {
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= A.n_items) return;
+        const int2 it = A.items[tk];
+        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+    }
     if (pi >= A.n_probs) return;
     const DevProblemH P = A.probs[pi];
     int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
@@ -165,17 +196,52 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 
     // ---- Vmf (MODE 1): record 0 is never used
     int3* __restrict__ vrec = A.vmf + P.tb_off;
+    int* __restrict__ vraw = reinterpret_cast<int*>(vrec);
     const int vcap = (int) P.imd_off;
+    // PIPE: what the tiles of the problem share: {record numbers handed out, overflow}, prog[max_tiles],
+    // best[max_tiles][8], rlf[n_im][3]
+    int* __restrict__ sy = PIPE ? A.pipe + (size_t) pi * A.pipe_stride : nullptr;
+    int* __restrict__ prog = PIPE ? sy + 2 : nullptr;
+    int* __restrict__ tbest = PIPE ? sy + 2 + A.max_tiles : nullptr;
+    int* __restrict__ rlf = PIPE ? sy + 2 + 9 * A.max_tiles : nullptr;
     int vcount = 1;
+    int vleft = 0;                                      // PIPE: numbers left of the chunk this wave holds
     bool vover = false;
     auto vadd = [&](bool need, int mm, int nn, int pp) -> int {
         if (!FWD) return 0;
         const unsigned long long mask = __ballot(need);
         if (!mask) return 0;
+        const int cnt = __popcll(mask);
+        if (PIPE && cnt > vleft) {
+            int b = 0;
+            if (lane == 0) b = __hip_atomic_fetch_add(sy, SPDP_VMF_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vcount = 1 + __builtin_amdgcn_readfirstlane(b);
+            vleft = SPDP_VMF_CHUNK;
+        }
         const int my = vcount + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0));
-        vcount += __popcll(mask);
-        if (need) { if (my < vcap) vrec[my] = make_int3(mm, nn, pp); else vover = true; }
+        vcount += cnt; vleft -= cnt;
+        if (need) {
+            if (my < vcap) {
+                if (PIPE) { gst<true>(vraw + 3 * my, mm); gst<true>(vraw + 3 * my + 1, nn); gst<true>(vraw + 3 * my + 2, pp); }
+                else vrec[my] = make_int3(mm, nn, pp);
+            } else vover = true;
+        }
         return my;
+    };
+    auto wait_for = [&](int t, int req) -> bool {
+        long spins = 0;
+        while (__hip_atomic_load(prog + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < req) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1l << 22)) {                 // (cannot happen with the ticket order; bounds every spin)
+                if (lane == 0) __hip_atomic_store(A.pipe + A.pipe_ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        return true;
+    };
+    auto publish = [&](int t, int v) {
+        STORES_DRAINED();
+        if (lane == 0) __hip_atomic_store(prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // ---- intermediate rows (MODE 2): hlnk[2], vlnk[2], lwrb[2], uprb[2], `width` ints each, entry r - lw + 1
     int* const imd_base = UDH ? A.imd + P.imd_off : nullptr;
@@ -192,19 +258,18 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     auto put = [&](int e, int isF, const St& s) {                  // one entry to global memory
         St t = s;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) G(isF * NF + f)[e] = fld(t, f);
+        for (int f = 0; f < NF; ++f) gst<PIPE>(G(isF * NF + f) + e, fld(t, f));
+    };
+    auto imd_init = [&](int i) {
+        int* b = imd_base + (int64_t) i * 4 * us;
+        for (int64_t q = lane; q < us; q += 64) {
+            gst<PIPE>(b + q, EOU); gst<PIPE>(b + us + q, EOU); gst<PIPE>(b + 2 * us + q, INT32_MAX); gst<PIPE>(b + 3 * us + q, INT32_MIN);
+        }
     };
 
     // ---- the arrays as initH_ng / hinitH_ng leave them
-    {
-        if (UDH) {
-            for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU;
-            for (int i = 0; i < n_im; ++i)
-                for (int64_t q = lane; q < us; q += 64) {
-                    int* b = imd_base + (int64_t) i * 4 * us;
-                    b[q] = EOU; b[us + q] = EOU; b[2 * us + q] = INT32_MAX; b[3 * us + q] = INT32_MIN;
-                }
-        }
+    if (t_lo == 0) {
+        if (UDH && !PIPE) for (int i = 0; i < n_im; ++i) imd_init(i);       // (PIPE: by the tile that holds the row)
         // the start cell, and below it the first column (leading gap of the query side): closed form per entry
         const int first_dir = a_exgl ? T_DEAD : T_DIAG;
         const int sS0 = aux[bl + 1].x;
@@ -281,8 +346,12 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 
     const int R0 = al + (a_exgl ? 1 : 0);
     const int TH = UDH ? max(1, min(64, intvl)) : 64;              // a tile holds at most one intermediate row
-    for (int m0 = R0; m0 <= ar; m0 += TH) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    const int n_tiles = max(1, (ar - R0 + TH) / TH);               // (the host lists the same count)
+    bool stalled = false;
+    for (int ti = t_lo; ti < t_hi; ++ti) {
+        const int m0 = R0 + TH * ti;
+        if (m0 > ar) break;
+        if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const int m = m0 + lane;
         const bool row = lane < TH && m <= ar;
         const int n0 = max(3 * m + lw - 1, bl), n9 = min(3 * m + up, br);
@@ -292,6 +361,11 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         const int iq = UDH ? (m - P.a_left) / max(1, intvl) - 1 : -1;
         const bool is_imd = UDH && row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
         const unsigned long long imd_mask = __ballot(is_imd);
+        if (UDH && PIPE && imd_mask) {
+            const int i0 = __shfl(iq, __ffsll((long long) imd_mask) - 1);
+            imd_init(i0);
+            rl0 = i0 == 0 ? INT32_MAX : INH; rl1 = i0 == 0 ? INT32_MAX : INH + 1; rl2 = i0 == 0 ? INT32_MAX : INH + 2;
+        }
         if (s_lo <= s_hi) {
             const int aa0 = (row && m >= 1 && m - 1 < P.a_len) ? acod[m - 1] : AMB;       // the residue of my row, and the next one
             const int aa1 = (row && m < P.a_len) ? acod[m] : AMB;
@@ -316,14 +390,19 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                 for (int e = res_lo + lane; e < dead; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) G(a)[e] = L[a][q];
+                    for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
                 }
                 res_lo = max(res_lo, dead);
                 const int want = min(W, need_hi(S + CHUNK - 1) + 1);
+                if (PIPE) {
+                    // what I am about to read, the tile above must have handed back: its need_lo(S') >= want
+                    if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, want + 4 * (m0 - TH + 63) + lw + 1);
+                    publish(ti, S + 1);
+                }
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = __builtin_nontemporal_load(G(a) + e);
+                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = gld<PIPE>(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
                 WAVE_SYNC();
@@ -479,13 +558,13 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                             }
                         }
                         if (UDH && is_imd && t && maxk < 3) {
-                            *IM(iq, HLNK, 0, r) = lnk[maxk];
+                            gst<PIPE>(IM(iq, HLNK, 0, r), lnk[maxk]);
                             rl_set(r);
                             St& mxs = maxk == 0 ? h : (maxk == 1 ? ea : f);
                             mxs.e = r;
                             spj3 = true;
                             if (maxk == 0) {
-                                if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; *IM(iq, HLNK, 1, r) = lnk[1]; }
+                                if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), lnk[1]); }
                                 if (sel[2] >= 0 && f.v > h.v + gop) f.e = r + width;
                             }
                         }
@@ -558,7 +637,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                                 if (!__ballot(tt)) continue;
                                 const bool kept = cl[ph].insert(tt, src.v + sigJ, nb, packed | k, src, is_imd ? r : src.e);
                                 // an intermediate row links an insertion that splices out to the last match of its frame
-                                if (UDH && is_imd && kept && k == 1) *IM(iq, HLNK, 0, r) = rl_get();
+                                if (UDH && is_imd && kept && k == 1) gst<PIPE>(IM(iq, HLNK, 0, r), rl_get());
                             }
                         }
                     }
@@ -567,10 +646,10 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                 // ---- an intermediate row records where the paths cross it and restarts ranges and links
                 if (UDH && is_imd && on) {
                     if (hd == 0) rl_set(r);
-                    else if (!spj3 && (hd & 1)) *IM(iq, HLNK, 0, r) = rl_get();
-                    *IM(iq, VLNK, 0, r) = h.e; *IM(iq, LWRB, 0, r) = min(r, h.b); *IM(iq, UPRB, 0, r) = max(r, h.a);
+                    else if (!spj3 && (hd & 1)) gst<PIPE>(IM(iq, HLNK, 0, r), rl_get());
+                    gst<PIPE>(IM(iq, VLNK, 0, r), h.e); gst<PIPE>(IM(iq, LWRB, 0, r), min(r, h.b)); gst<PIPE>(IM(iq, UPRB, 0, r), max(r, h.a));
                     h.b = h.a = r; h.e = r;
-                    *IM(iq, VLNK, 1, r) = f.e; *IM(iq, LWRB, 1, r) = min(r, f.b); *IM(iq, UPRB, 1, r) = max(r, f.a);
+                    gst<PIPE>(IM(iq, VLNK, 1, r), f.e); gst<PIPE>(IM(iq, LWRB, 1, r), min(r, f.b)); gst<PIPE>(IM(iq, UPRB, 1, r), max(r, f.a));
                     f.b = f.a = r; f.e = r + width;
                 }
                 if (on) {
@@ -583,30 +662,73 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
 #pragma unroll
-                for (int a = 0; a < 2 * NF; ++a) G(a)[e] = L[a][q];
+                for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
             }
         }
-        if (UDH && imd_mask) {
+        if (UDH && PIPE) {
+            if (is_imd) { gst<true>(rlf + 3 * iq, rl0); gst<true>(rlf + 3 * iq + 1, rl1); gst<true>(rlf + 3 * iq + 2, rl2); }
+        } else if (UDH && imd_mask) {
             const int src = __ffsll((long long) imd_mask) - 1;
             rl0 = __shfl(rl0, src); rl1 = __shfl(rl1, src); rl2 = __shfl(rl2, src);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    auto reduce_best = [&]() {                                      // first maximum in row-major order over the lanes
+        for (int off = 32; off; off >>= 1) {
+            St o;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) fld(o, a) = __shfl_xor(fld(best, a), off);
+            const int om = __shfl_xor(best_m, off), on_ = __shfl_xor(best_n, off);
+            if (o.v > best.v || (o.v == best.v && (om < best_m || (om == best_m && on_ < best_n)))) { best = o; best_m = om; best_n = on_; }
+        }
+    };
+    if (PIPE) {
+        // finished = every entry holds what the tiles up to this one leave: the tile above must be finished too
+        const int ti = t_lo;
+        if (LocalR) {
+            reduce_best();
+            if (lane == 0) {
+                int* b = tbest + 8 * ti;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) gst<true>(b + a, fld(best, a));
+                gst<true>(b + 6, best_m); gst<true>(b + 7, best_n);
+            }
+        }
+        if (FWD && __any(vover) && lane == 0) gst<true>(sy + 1, 1);
+        if (ti > 0 && !stalled) stalled = !wait_for(ti - 1, INT32_MAX);
+        publish(ti, INT32_MAX);
+        if (ti != n_tiles - 1) return;
+        // the wave of the last tile ends the problem
+        if (FWD) vover = __hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (LocalR) {                                               // tiles in row order: the first maximum wins
+            St bb = black; bb.v = NEV; bb.c = al;
+            int bm = UDH ? ar : al, bn = UDH ? br : bl;
+            for (int t = lane; t < n_tiles; t += 64) {
+                const int* b = tbest + 8 * t;
+                if (gld<true>(b) > bb.v) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) fld(bb, a) = gld<true>(b + a);
+                    bm = gld<true>(b + 6); bn = gld<true>(b + 7);
+                }
+            }
+            best = bb; best_m = bm; best_n = bn;
+        }
+    } else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (UDH) { for (int i = lane; i < 10 * (n_im + 1); i += 64) cpos[i] = EOU; STORES_DRAINED(); }
 
     // ---- the end of the alignment: the tracked local maximum, or lastH_ng / hlastH_ng on the last row
     // staging for the sequential relaxations: entries [e0, e0 + cnt) of H through the LDS arrays, cnt <= RING
     auto stage_in = [&](int e0, int cnt) {
         for (int i = lane; i < cnt; i += 64)
 #pragma unroll
-            for (int a = 0; a < NF; ++a) L[a][i] = __builtin_nontemporal_load(G(a) + e0 + i);
+            for (int a = 0; a < NF; ++a) L[a][i] = gld<PIPE>(G(a) + e0 + i);
         WAVE_SYNC();
     };
     auto stage_out = [&](int e0, int from, int cnt) {
         WAVE_SYNC();
         for (int i = from + lane; i < cnt; i += 64)
 #pragma unroll
-            for (int a = 0; a < NF; ++a) G(a)[e0 + i] = L[a][i];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            for (int a = 0; a < NF; ++a) gst<PIPE>(G(a) + e0 + i, L[a][i]);
+        if (PIPE) STORES_DRAINED(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     };
     auto at = [&](int i) { St s = black;
 #pragma unroll
@@ -617,21 +739,13 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         for (int a = 0; a < NF; ++a) L[a][i] = fld(s, a); };
     auto gload = [&](int r, int isF) { St s = black;
 #pragma unroll
-        for (int a = 0; a < NF; ++a) fld(s, a) = __builtin_nontemporal_load(G(isF * NF + a) + (r - lw + 3));
+        for (int a = 0; a < NF; ++a) fld(s, a) = gld<PIPE>(G(isF * NF + a) + (r - lw + 3));
         return s; };
 
     St fin = black;                                                 // the state the alignment ends in
     int fin_r = br - 3 * ar;
     int ptr = 0;
-    if (LocalR) {
-        for (int off = 32; off; off >>= 1) {
-            St o;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) fld(o, a) = __shfl_xor(fld(best, a), off);
-            const int om = __shfl_xor(best_m, off), on_ = __shfl_xor(best_n, off);
-            if (o.v > best.v || (o.v == best.v && (om < best_m || (om == best_m && on_ < best_n)))) { best = o; best_m = om; best_n = on_; }
-        }
-    }
+    if (LocalR) reduce_best();
     const bool by_last_row = UDH ? !LocalR : (!LocalR || best_m == ar);
     if (by_last_row) {
         const int m3 = 3 * ar, r9 = br - m3;
@@ -699,7 +813,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                     mx_v = y;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            if (PIPE) STORES_DRAINED(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         }
         mx_r = __shfl(mx_r, 0); mx_v = __shfl(mx_v, 0);
         bool from_f = false;
@@ -767,21 +881,27 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         DevResultH R;
         R.score = fin.v; R.mr = ar; R.nr = br; R.maxt = 0; R.maxr = 0; R.pad[0] = R.pad[1] = R.pad[2] = 0;
         if (!FWD) { if (lane == 0) A.res[pi] = R; return; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        int vtotal = vcount;                                        // numbers handed out
+        if (PIPE) { STORES_DRAINED(); vtotal = 1 + __hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const bool over_any = __any(vover);
         if (lane == 0) {
             // Vmf::traceback(ptr) + the boundary record of trcbkalignH_ng
             int2* out = A.skl + (int64_t) pi * A.skl_cap;
             int cnt = 0, status = over_any ? -3 : 0;
-            if (ptr > 0 && ptr < vcount && !status) {
-                int3 sv = vrec[ptr];
+            auto rec = [&](int i) {
+                if (PIPE) return make_int3(gld<true>(vraw + 3 * i), gld<true>(vraw + 3 * i + 1), gld<true>(vraw + 3 * i + 2));
+                return vrec[i];
+            };
+            if (ptr > 0 && ptr < vtotal && !status) {
+                int3 sv = rec(ptr);
                 int lm = 0, ln = 0;
                 for (;;) {
                     if (cnt < A.skl_cap) out[cnt] = make_int2(sv.x, sv.y); else status = -1;
                     lm = sv.x; ln = sv.y; ++cnt;
                     if (!sv.z) break;
-                    if (sv.z < 0 || sv.z >= vcount || cnt > vcount) { status = -2; break; }
-                    sv = vrec[sv.z];
+                    if (sv.z < 0 || sv.z >= vtotal || cnt > vtotal) { status = -2; break; }
+                    sv = rec(sv.z);
                 }
                 const int rd = Local ? 0 : ((ln - 3 * lm) - bl + 3 * al);
                 if (rd) {
@@ -811,6 +931,16 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         if (b_exgr && rr < fin_r) ar = (br - fin_r) / 3;
         if (a_exgr && rr > fin_r) br = 3 * ar + fin_r;
     }
+    // a link that stands for "rlst of this queue slot as the intermediate rows above left it"
+    auto hlnk = [&](int ii, int d, int rr_) {
+        int v = gld<PIPE>(IM(ii, HLNK, d, rr_));
+        if (PIPE && v >= INH && v < INH + 3) {
+            const int slot = v - INH;
+            v = INT32_MAX;
+            for (int j = ii - 1; j >= 0; --j) { const int w = gld<true>(rlf + 3 * j + slot); if (w != INH + slot) { v = w; break; } }
+        }
+        return v;
+    };
     int i = n_im;
     while (--i >= 0 && mi_of(i) > ar) ;
     if (i < 0 && mi_of(0) > ar) CPOS(0, 2) = br;
@@ -823,20 +953,20 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         for ( ; r > up; r -= width) ++d;                            // links into the F array carry + width
         if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
         const int mi = mi_of(i);
-        if (*IM(i, VLNK, d, r) < EOU) {
+        if (gld<PIPE>(IM(i, VLNK, d, r)) < EOU) {
             CPOS(i, c++) = mi;
             CPOS(i, c++) = (d > 0) ? 1 : 0;
             const int mm3 = 3 * mi;
-            for (int rp = *IM(i, HLNK, d, r); lw <= rp && rp < up && r != rp; rp = *IM(i, HLNK, 0, r = rp)) {
+            for (int rp = hlnk(i, d, r); lw <= rp && rp < up && r != rp; rp = hlnk(i, 0, r = rp)) {
                 if (c >= 6) { flag = -3; break; }
                 CPOS(i, c++) = r + mm3;
             }
             if (flag) break;
             CPOS(i, c++) = r + mm3;
             CPOS(i, c) = EOU;
-            CPOS(i, 8) = *IM(i, LWRB, d, r);
-            CPOS(i, 9) = *IM(i, UPRB, d, r);
-            r = *IM(i, VLNK, d, r);
+            CPOS(i, 8) = gld<PIPE>(IM(i, LWRB, d, r));
+            CPOS(i, 9) = gld<PIPE>(IM(i, UPRB, d, r));
+            r = gld<PIPE>(IM(i, VLNK, d, r));
             if (r == EOU) break;
         } else
             CPOS(i, 0) = EOU;
@@ -872,15 +1002,23 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;
-    const dim3 grd((A.n_probs + WPB - 1) / WPB), blk(64 * WPB);
-    if (forward) hipLaunchKernelGGL(spdh_rowwave<1>, grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL(spdh_rowwave<0>, grd, blk, 0, stream, A);
+    const dim3 blk(64 * WPB);
+    if (A.pipe) {                                       // one wave per (problem, tile)
+        const dim3 grd((A.n_items + WPB - 1) / WPB);
+        if (forward) hipLaunchKernelGGL((spdh_rowwave<1, true>), grd, blk, 0, stream, A);
+        else hipLaunchKernelGGL((spdh_rowwave<0, true>), grd, blk, 0, stream, A);
+        return hipGetLastError();
+    }
+    const dim3 grd((A.n_probs + WPB - 1) / WPB);
+    if (forward) hipLaunchKernelGGL((spdh_rowwave<1, false>), grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL((spdh_rowwave<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;
-    hipLaunchKernelGGL(spdh_rowwave<2>, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    if (A.pipe) hipLaunchKernelGGL((spdh_rowwave<2, true>), dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    else hipLaunchKernelGGL((spdh_rowwave<2, false>), dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     return hipGetLastError();
 }

@@ -66,7 +66,9 @@ extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int 
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // exact-intron-length (-A0) engines (spdp_rowwave.hip: one wave per problem, lane = row) and the -A1 engines
+#ifndef SPDP_VMF_CHUNK
 #define SPDP_VMF_CHUNK 512          // Vmf record numbers a wave of a pipelined forwardS_ng problem reserves at a time
+#endif
 struct ScalarArgs {
     const DevScoring* sc;
     const DevProblem* probs;      // bnd_off = work offset (ints), tb_off = Vmf offset (records), imd_off = Vmf capacity

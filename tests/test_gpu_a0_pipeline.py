@@ -100,3 +100,62 @@ def test_pipelined_against_oracle(eng):
         if not ok:
             bad.append((i, int(scores[i]), ws, int(flags[i]), wflag))
     assert not bad, bad[:3]
+
+
+# ---- aa x genome: spdh_rowwave<., true> ------------------------------------------------------------
+def _subranges_h(fx, n, seed, rows):
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + seed)
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    ps = abi.ProblemSetH()
+    for i in range(n):
+        m = int(rng.integers(rows[0], min(rows[1], q["a_right"]) + 1))
+        al = int(rng.integers(0, q["a_right"] - m + 1))
+        bl = int(rng.integers(1, 500))
+        br = int(rng.integers(max(bl + 3 * m + 300, q["b_right"] - 1200), q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 3 == 0 else tuple(int(x) for x in rng.integers(0, 3 if i % 4 == 1 else 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+               fx["phs5"], fx["phs3"], al, al + m, bl, br, exg, exin=(q["b_left"], q["b_right"]), dinc=dinc)
+    return ps
+
+
+def _run_all_h(eng, sc, ps, n_im, intvl):
+    fwd = [(s, skl.tolist()) for s, skl in eng.scalar_forward_h(sc, ps)]
+    sco = [s for s, _ in eng.scalar_forward_h(sc, ps, traceback=False)]
+    out = [fwd, sco]
+    if n_im:
+        scores, cpos, ranges, flags = eng.scalar_udh_h(sc, ps, n_im, intvl)
+        out += [flags.tolist(), [(int(s), c.tolist(), r.tolist()) for s, c, r, f in zip(scores, cpos, ranges, flags) if f == 0]]
+    return out
+
+
+@pytest.mark.parametrize("name,local", [("h1_400aa", False), ("h1_local", True)])
+def test_pipelined_equals_one_wave_h(eng, monkeypatch, name, local):
+    f = [f for f in golden_files("h1_") if f.endswith(name + ".spdg")]
+    if not f:
+        pytest.skip("fixture not present")
+    fx = spdg.load(f[0])
+    assert bool(fx["prm"]["local"]) == local
+    sc = spdg.scoring_h(fx, scalar_engines=1)
+    m = min(300, fx["prm"]["a_right"])
+    n_im = 3
+    intvl = (m + n_im) // (n_im + 1)
+    ps = _subranges_h(fx, 20, 311, rows=(m, m))
+    monkeypatch.setenv("SPDP_A0_PIPE", "0")
+    want = _run_all_h(eng, sc, ps, n_im, intvl)
+    monkeypatch.setenv("SPDP_A0_PIPE", "1")
+    got = _run_all_h(eng, sc, ps, n_im, intvl)
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert w == g, k
+    monkeypatch.setenv("SPDP_A0_PIPE_TEST_STALL", "1")
+    again = _run_all_h(eng, sc, ps, n_im, intvl)
+    monkeypatch.delenv("SPDP_A0_PIPE_TEST_STALL")
+    for k, (w, g) in enumerate(zip(want, again)):
+        assert w == g, k
+    # ragged heights
+    ps = _subranges_h(fx, 40, 312, rows=(66, 400))
+    monkeypatch.setenv("SPDP_A0_PIPE", "0")
+    want = _run_all_h(eng, sc, ps, 0, 0)
+    monkeypatch.setenv("SPDP_A0_PIPE", "1")
+    got = _run_all_h(eng, sc, ps, 0, 0)
+    assert want == got

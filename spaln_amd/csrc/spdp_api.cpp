@@ -209,6 +209,8 @@ void DevStore::release()
     if (d_cols) (void) hipFree(d_cols);
     if (d_aux) (void) hipFree(d_aux);
     if (d_intpen) (void) hipFree(d_intpen);
+    if (d_ipen_runs) (void) hipFree(d_ipen_runs);
+    d_ipen_runs = nullptr;
     if (d_cip) (void) hipFree(d_cip);
     d_sc = d_a = d_cols = d_aux = d_intpen = d_cip = nullptr;
 }
@@ -331,6 +333,11 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     if (has_exact) {
         HIPCHK(hipMalloc(&d_intpen, sizeof(int16_t) * sc.intpen_len));
         HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, sizeof(int16_t) * sc.intpen_len, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int16_t> runs(SPDP_IPR_WORDS);
+        if (spdp_intpen_runs(sc.intpen, sc.intpen_len, runs.data())) {
+            HIPCHK(hipMalloc(&d_ipen_runs, sizeof(int16_t) * runs.size()));
+            HIPCHK(hipMemcpy(d_ipen_runs, runs.data(), sizeof(int16_t) * runs.size(), hipMemcpyHostToDevice));
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -361,6 +368,39 @@ void DevRun::release() { if (in_flight && ctx) { (void) hipStreamSynchronize(str
 // accepted intron: on real alignments a few per row.  The budget is one record per two band cells (the band, not the
 // bounding rectangle), at least 64 per row; a call that outgrows it reports so (n_skl = -3) and is run again with
 // vmf_scale x 8 by the ladder -- the old "two per cell of the rectangle" made batches of slabs run in dozens of groups.
+bool spdp_intpen_runs(const int16_t* intpen, int len, int16_t* out)
+{
+    if (len <= SPDP_IPR_BASE) {                         // nothing beyond the LDS table: one run
+        if (len <= 0) return false;
+        memset(out, 0, sizeof(int16_t) * SPDP_IPR_WORDS);
+        uint16_t* st = (uint16_t*) out;
+        st[0] = SPDP_IPR_BASE; st[1] = 65535;
+        out[SPDP_IPR_RUNS + 1] = intpen[len - 1];
+        return true;
+    }
+    if (len > 65536) return false;
+    uint16_t* start = (uint16_t*) out;
+    int16_t* val = out + SPDP_IPR_RUNS + 1;
+    uint8_t* span = (uint8_t*) (out + SPDP_IPR_RUNS + 1 + SPDP_IPR_RUNS);
+    int nr = 0;
+    start[0] = SPDP_IPR_BASE; val[0] = intpen[SPDP_IPR_BASE];
+    for (int i = SPDP_IPR_BASE + 1; i < len; ++i)
+        if (intpen[i] != intpen[i - 1]) {
+            if (++nr >= SPDP_IPR_RUNS) return false;
+            start[nr] = (uint16_t) i; val[nr] = intpen[i];
+        }
+    for (int j = nr + 1; j <= SPDP_IPR_RUNS; ++j) start[j] = 65535;
+    for (int j = nr + 1; j < SPDP_IPR_RUNS; ++j) val[j] = val[nr];
+    int j = 0;
+    for (int b = 0; b < SPDP_IPR_SPANS; ++b) {
+        const int lo = SPDP_IPR_BASE + 64 * b, hi = lo + 63;
+        while (j < nr && (int) start[j + 1] <= lo) ++j;
+        span[b] = (uint8_t) j;
+        if (j + 2 <= nr && (int) start[j + 2] <= hi) return false;      // two steps inside one span
+    }
+    return true;
+}
+
 static int64_t vmf_capacity(const RunItem& it)
 {
     const int64_t rows = it.a_right - it.a_left + 1, cols = it.b_right - it.b_left + 1;
@@ -577,6 +617,7 @@ int DevRun::launch()
         S.sc = (const DevScoring*) store->d_sc; S.probs = (const DevProblem*) d_probs; S.n_probs = n;
         S.a_codes = (const uint8_t*) store->d_a; S.cols = (const int2*) store->d_cols;
         S.aux = (const uint8_t*) store->d_aux; S.intpen = (const int16_t*) store->d_intpen;
+        S.ipen_runs = (const int16_t*) store->d_ipen_runs;
         S.cip = (const int*) store->d_cip;
         S.intpen_len = store->sc.intpen_len; S.ipen = store->sc.ipen;
         memcpy(S.t53, store->sc.t53, sizeof S.t53);

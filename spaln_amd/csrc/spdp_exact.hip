@@ -53,9 +53,11 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     // the tables an acceptor prices its candidates with: a read from memory inside that loop stalled the whole wave
     // (some lane of 64 sits on an acceptor column at almost every step)
     __shared__ short s_ipen[4096];
+    __shared__ IpenRuns s_runs;                 // IntPen beyond s_ipen (spdp_ipen_runs.h)
     __shared__ short s_t53[256];
     for (int i = threadIdx.x; i < 32 * 32; i += 64) s_mtx[i] = A.sc->mtx[i];
     for (int i = threadIdx.x; i < 4096; i += 64) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
+    ipen_runs_load(s_runs, A.ipen_runs);
     for (int i = threadIdx.x; i < 256; i += 64) s_t53[i] = A.t53[i];
     __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
@@ -319,7 +321,8 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         const int d = c_dir[ci], don = c_jnc[ci];
                         if (nj - don < minl) continue;
                         int len = nj - don;
-                        const int pen = len < 4096 ? (int) s_ipen[len] : (int) A.intpen[min(len, A.intpen_len - 1)];
+                        const int pen = len < 4096 ? (int) s_ipen[len]
+                                      : (A.ipen_runs ? ipen_runs_get(s_runs, len, A.intpen_len) : (int) A.intpen[min(len, A.intpen_len - 1)]);
                         const int x = c_val[ci] + sigJ_cip + pen + s3 + s_t53[16 * c_dn5[ci] + d3];
                         int cur = d == 0 ? H : (d == 1 ? E : F);
                         if (x <= cur) continue;

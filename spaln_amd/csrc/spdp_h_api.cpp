@@ -81,6 +81,7 @@ struct HStore {
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> col_len;
     void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr;
+    bool ipen_runs_ok = false;
     std::vector<std::vector<int16_t>> own_sigE; // device-made signals: the host ladder still reads sigE (diagonalH_ng)
     void* d_cip = nullptr;                      // owned (hipMalloc): conserved-intron bonuses, SpdpProblemH::cip
     std::vector<int32_t> cip_off;               // per problem: first entry of its row in d_cip, -1 = none
@@ -192,9 +193,14 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     for (int i = 0; i < n && !dev_sig; ++i) if (!probs[i].dinc) scalar_ok = false;      // (device-made signals bring dinc along)
     if (!n) return 0;
     if (scalar_ok) {
-        d_intpen = pool.get(HP_INTPEN, (size_t) sc.intpen_len * sizeof(int16_t));
+        // the table, and behind it its steps beyond the part the kernels keep in LDS (spdp_ipen_runs.h)
+        d_intpen = pool.get(HP_INTPEN, ((size_t) sc.intpen_len + SPDP_IPR_WORDS) * sizeof(int16_t));
         if (!d_intpen) { ctx->err = "device allocation failed (intron penalty table)"; return -1; }
         HIPCHK(hipMemcpyAsync(d_intpen, sc.intpen, (size_t) sc.intpen_len * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int16_t> runs(SPDP_IPR_WORDS);
+        ipen_runs_ok = spdp_intpen_runs(sc.intpen, sc.intpen_len, runs.data());
+        if (ipen_runs_ok)
+            HIPCHK(hipMemcpy((int16_t*) d_intpen + sc.intpen_len, runs.data(), runs.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     }
     cip_off.assign(n, -1);
     {
@@ -543,6 +549,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
     A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
     A.intpen = (const int16_t*) st.d_intpen; A.intpen_len = st.sc.intpen_len;
+    A.ipen_runs = st.ipen_runs_ok ? (const int16_t*) st.d_intpen + st.sc.intpen_len : nullptr;
     A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);
@@ -699,6 +706,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.sc = (const DevScoringH*) st.d_sc; A.probs = (const DevProblemH*) d_probs; A.n_probs = nr;
     A.a_codes = (const uint8_t*) st.d_a; A.cols = (const int4*) st.d_cols; A.aux = (const short4*) st.d_aux;
     A.intpen = (const int16_t*) st.d_intpen; A.intpen_len = st.sc.intpen_len;
+    A.ipen_runs = st.ipen_runs_ok ? (const int16_t*) st.d_intpen + st.sc.intpen_len : nullptr;
     A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "spdp_h_dev.h"
+#include "spdp_ipen_runs.h"
 
 struct HSweepArgs {
     const DevScoringH* sc;
@@ -64,6 +65,7 @@ struct HScalarArgs {
     const short4*      aux;
     const int16_t*     intpen;     // IntronPenalty::Penalty(len)
     const int*         cip;        // Cip_score::cip_score(c) rows (3 a_len + 2 ints) of the queries that have one, or null
+    const int16_t*     ipen_runs;  // SPDP_IPR_WORDS words (spdp_intpen_runs), or null: long introns read `intpen`
     int                intpen_len;
     int                minl;       // IntronPrm.minl
     int                gape1, gape2, extragop;

@@ -63,6 +63,7 @@ struct Tables {
     short t53[256];
     uint8_t mid[32];
     uint8_t tron_of[64];
+    IpenRuns runs;                                      // IntPen beyond the table above (spdp_ipen_runs.h)
 };
 __device__ __forceinline__ void load_tables(Tables& T, const HScalarArgs& A, const DevScoringH* sc)
 {
@@ -71,6 +72,7 @@ __device__ __forceinline__ void load_tables(Tables& T, const HScalarArgs& A, con
     for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
     if (threadIdx.x < 32) T.mid[threadIdx.x] = A.mid[threadIdx.x];
     if (threadIdx.x < 64) T.tron_of[threadIdx.x] = A.tron_of[threadIdx.x];
+    ipen_runs_load(T.runs, A.ipen_runs);
     __syncthreads();                                    // the only block-wide barrier
 }
 #define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     auto intpen_of = [&](int len) -> int {
         if (len < 0) return -32768;
         if (len < IPEN_LDS) return T.ipen[len];
+        if (A.ipen_runs) return ipen_runs_get(T.runs, len, A.intpen_len);      // (kernel-uniform)
         return A.intpen[min(len, A.intpen_len - 1)];
     };
 

@@ -66,6 +66,8 @@ extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int 
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);
 extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // exact-intron-length (-A0) engines (spdp_rowwave.hip: one wave per problem, lane = row) and the -A1 engines
+#include "spdp_ipen_runs.h"
+
 #ifndef SPDP_VMF_CHUNK
 #define SPDP_VMF_CHUNK 512          // Vmf record numbers a wave of a pipelined forwardS_ng problem reserves at a time
 #endif
@@ -80,6 +82,7 @@ struct ScalarArgs {
     const int16_t*    intpen;
     int               intpen_len;
     int               ipen;
+    const int16_t*    ipen_runs;  // SPDP_IPR_WORDS words (spdp_intpen_runs), or null: long introns read `intpen`
     int               minl;       // IntronPrm.minl (-A1 engines)
     int16_t           t53[256];
     int*              work;
@@ -240,6 +243,7 @@ struct DevStore {
     std::vector<int64_t> a_off, col_off;
     std::vector<int32_t> a_len, b_len;
     void *d_sc = nullptr, *d_a = nullptr, *d_cols = nullptr, *d_aux = nullptr, *d_intpen = nullptr, *d_cip = nullptr;
+    void* d_ipen_runs = nullptr;            // spdp_intpen_runs() of the table, when it has that shape
     std::vector<int32_t> cip_off;           // per parent: first entry of its cip row in d_cip, -1 = none
     bool has_exact = false;                 // exact-model inputs (cano / dinc / intpen) were supplied
     int fp_maxpos = 1, fp_gain = 0;         // largest substitution score; best net score of one intron (>= 0)

@@ -31,24 +31,27 @@ constexpr int RING = 256;                               // diagonals resident in
 constexpr int CHUNK = 32;                               // steps between two refills of the window
 constexpr int NC = 5;                                   // NCAND + 1 slots of the candidate list
 constexpr int WPB = 4;                                  // waves (= problems) per block: they share the tables below
-constexpr int IPEN_LDS = 4096;                          // IntPen(len) for len < this lives in LDS, longer ones in memory
+constexpr int IPEN_LDS = SPDP_IPR_BASE;                 // IntPen(len) for len < this lives in LDS as it is, longer ones as runs
 
 // read-only tables every wave of a block uses
 struct Tables {
-    int mtx[32 * 32];
+    short mtx[32 * 32];
     short ipen[IPEN_LDS];
     short t53[256];
+    IpenRuns runs;                                      // IntPen beyond the table above (spdp_ipen_runs.h)
 };
 __device__ __forceinline__ void load_tables(Tables& T, const ScalarArgs& A, const DevScoring* sc)
 {
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = sc->mtx[i];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = (short) sc->mtx[i];
     for (int i = threadIdx.x; i < IPEN_LDS; i += blockDim.x) T.ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
+    ipen_runs_load(T.runs, A.ipen_runs);
     __syncthreads();                                    // the only block-wide barrier: every wave reaches it
 }
 __device__ __forceinline__ int intpen_of(const Tables& T, const ScalarArgs& A, int len)
 {
     if (len < IPEN_LDS) return T.ipen[len];
+    if (A.ipen_runs) return ipen_runs_get(T.runs, len, A.intpen_len);          // (kernel-uniform)
     return len >= A.intpen_len ? A.intpen[A.intpen_len - 1] : A.intpen[len];
 }
 // LDS traffic inside ONE wave needs no barrier (its DS instructions execute in order); the compiler must keep it so
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
         if (s_lo > s_hi) continue;                                  // (PIPE: published as finished below)
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
-        const int* qprof = T.mtx + acode * 32;
+        const short* qprof = T.mtx + acode * 32;
         const bool internal = FWD ? (spj && (!a_exgr || m < ar)) : true;
         const int sigB = (row && A.cip && P.cip_off >= 0) ? A.cip[P.cip_off + m] : 0;      // Cip_score::cip_score(m)
 
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         if (s_lo <= s_hi) {
             const int acode = (row && m >= 1) ? acod[m - 1] : 0;
-            const int* qprof = T.mtx + acode * 32;
+            const short* qprof = T.mtx + acode * 32;
             const int sigB = (row && A.cip && P.cip_off >= 0) ? A.cip[P.cip_off + m] : 0;  // Cip_score::cip_score(m)
             St E = {NEV, bl - ar, bl - ar, 0, EOU};
             unsigned psp = 0;

@@ -38,7 +38,8 @@ HBM_PEAK_GBS = 8000.0
 # same profiles: fp32-issue UDH sweep 51.2 / 64 (round 1: 59.6), forward sweep 69.6 / 64, protein sweep 152.3 / 64
 # (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10}
+VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
+                 "a0_udh": 1.2802e10 / 2.05e9}      # (--engines a0: profiles/r02_a0_sq_counters.txt)
 # HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
 # chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes (profiles/r02_hbm_traffic_pmc.txt).  FETCH_SIZE
 # counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
@@ -253,14 +254,18 @@ def main_c3(args):
 
 def _valu_roofline(cells, kind, k_ms):
     """the bound that actually binds: VALU wave-instructions issued per second against the measured ceiling"""
-    if not k_ms:
+    if not k_ms or not cells:
         return None
     ach = cells * VALU_PER_CELL[kind] / (k_ms * 1e-3)
+    src = ("SQ_INSTS_VALU per cell (profiles/r02_sq_counters.txt) x cells / kernel time; peak = one VALU "
+           "wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, profiles/r02_valu_ubench.txt); "
+           "the instruction mix of the step, priced by class, explains 0.71 of the measured time")
+    if kind == "a0_udh":
+        src = ("SQ_INSTS_VALU per cell of spdp_rowwave_udh<true> (profiles/r02_a0_sq_counters.txt: 400 per 64-cell step, + 278 "
+               "scalar) x cells / kernel time against the same measured VALU ceiling; the kernel is latency-bound, not "
+               "issue-bound: its waves wait 62 % of their resident cycles (same file)")
     return {"achieved": round(ach / 1e9, 1), "peak": round(VALU_PEAK_WINST_S / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(ach / VALU_PEAK_WINST_S, 3),
-            "source": "SQ_INSTS_VALU per cell (profiles/r02_sq_counters.txt) x cells / kernel time; peak = one VALU "
-                      "wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, profiles/r02_valu_ubench.txt); "
-                      "the instruction mix of the step, priced by class, explains 0.71 of the measured time"}
+            "frac": round(ach / VALU_PEAK_WINST_S, 3), "source": src}
 
 
 def _self_spawn(argv, n):
@@ -454,7 +459,7 @@ def main():
             "metric": "GCUPS (DP cell updates/s), cDNA->genome spliced DP",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (exact integers) / int32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32" if exact else "f32 (exact integers) / int32",
             "data": "synthetic",
             "config": {"workload": ("C4 shape (batch scaled to the run): 500-nt ESTs, 1 % error, vs the locus of "
                                     "the fragment +-1 kb (windows 2-10 kb), default band, Fwd2s1 _wip path: "
@@ -478,8 +483,12 @@ def main():
                          "traffic_source": "profiles/r02_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
                          "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
                                    ("spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
-                         "valu": None if exact else _valu_roofline(k_cells, k_name, k_ms),
-                         "note": "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
+                         "valu": (_valu_roofline(udh_cells, "a0_udh", k_ms) if args.engines == "a0" else None) if exact
+                                 else _valu_roofline(k_cells, k_name, k_ms),
+                         "note": ("exact-model engines: int32 scores, per-row donor lists; latency-bound chains of exec-masked regions, the tiles of a "
+                                  "problem pipelined over waves; HBM fraction reported as asked; kernel_ms = mean duration per step summed "
+                                  "over the step's launches of this kernel") if exact else
+                                 "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)

@@ -9,7 +9,9 @@
 // with its state in arrays indexed by DIAGONAL (H, F, and in mode 1 a Vmf pointer per state and a direction
 // byte); results depend on what those arrays hold at the band edges, so the arrays are kept as they are.
 //
-// Mapping (ours).  One wave per problem (four problems per block share the read-only tables in LDS).  Lane k of the wave owns query row m0 + k of a tile of 64 rows and
+// Mapping (ours).  One wave per 64-row tile of a problem (the four waves of a block share the read-only tables in
+// LDS): the tiles of a problem run as a pipeline of waves, or -- <., false> -- one after the other in one wave.
+// Lane k of the wave owns query row m0 + k of the tile and
 // all per-row state (the horizontal gap, the orphan-exon flags, the candidate list) lives in its registers.  The
 // wave sweeps anti-diagonals: at step S lane k is at column S - m, i.e. on array entry r = S - 2m; it reads
 // entries r - 1 (its own left neighbour), r (the cell above-left) and r + 1 (the cell above) and writes r.  Every
@@ -17,8 +19,9 @@
 // row-by-row loop guarantees as well -- so the arrays can be shared through an LDS window of 256 diagonals that
 // slides with the sweep: 64 entries at a time stream in from / out to the arrays in global memory (coalesced),
 // which carry the state from one tile of rows to the next.  Vmf records are appended through a counter that is
-// uniform in the wave (ballot + prefix count: no atomics); record numbers differ from the reference's, the
-// chains do not.  Lane 0 walks the chain back at the end.
+// uniform in the wave (ballot + prefix count; pipelined tiles reserve their numbers 512 at a time from the
+// problem's counter); record numbers differ from the reference's, the chains do not.  Lane 0 of the last tile's
+// wave walks the chain back at the end.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "spdp_dev.h"

@@ -446,7 +446,9 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             bnd_tot = P.bnd_off + (flav >= 8 ? 6ll : 5ll) * P.buf_size + 8;   // udh forms: + the `ml` row of F
             if (flav >= 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
             if (flav == 7) {
-                const int64_t cap = vmf_capacity(it);
+                // (+ what the lanes may leave unused of the chunks of numbers they reserve, per stripe when pipelined)
+                const int64_t cap = vmf_capacity(it)
+                                    + (int64_t) SPDP_VMF_LANE_CHUNK * SPDP_NELEM * ((it.a_right - it.a_left) / SPDP_NELEM + 2);
                 P.imd_off = cap;
                 tb_tot += cap;
             }
@@ -577,6 +579,25 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
     }
     // forwardS_ng / scorealoneS_ng: a problem's 64-row tiles as a pipeline of waves (SPDP_A0_PIPE=0: one wave each)
     pipe_on = false;
+    if (flav >= 6 && flav <= 8 && n > 0) {
+        // -A1 engines: work item = (four problems, 16-row stripe), spdp_exact<., true>
+        const char* e = getenv("SPDP_A1_PIPE");
+        int mt = 1;
+        h_items.clear();
+        for (int q = 0; 4 * q < n; ++q) {
+            int ns = 1;
+            for (int j = 4 * q; j < std::min(n, 4 * q + 4); ++j)
+                ns = std::max(ns, (h_probs[j].a_right - h_probs[j].a_left + SPDP_NELEM - 1) / SPDP_NELEM);
+            mt = std::max(mt, ns);
+            for (int t = 0; t < ns; ++t) { h_items.push_back(q); h_items.push_back(t); }
+        }
+        if ((!e || atoi(e) != 0) && mt >= 2) {
+            pipe_on = true; pipe_tiles = mt;
+            pipe_stride = 2 + 7 * mt + max_n_im;
+            pipe_words = ((size_t) n * pipe_stride + 2 + 1) & ~(size_t) 1;
+            POOLGET(d_gprog, POOL_GPROG, sizeof(int) * (pipe_words + h_items.size()));
+        }
+    }
     if ((flav == 3 || flav == 4 || flav == 5) && n > 0) {
         const char* e = getenv("SPDP_A0_PIPE");
         int mt = 1;
@@ -633,10 +654,12 @@ int DevRun::launch()
         else HIPCHK(spdp_launch_rowwave(flavour == 3, &S, strm()));
         HIPCHK(hipEventRecord(eve(), strm()));
         if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk
-            CposArgs C;
+            CposArgs C{};
             C.probs = S.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
             C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
             C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = store->sc.local ? 1 : 0;
+            C.pipe = (flavour == 8 && pipe_on) ? (const int*) d_gprog : nullptr;
+            C.pipe_stride = pipe_stride; C.rlf_off = 2 + 7 * pipe_tiles;
             HIPCHK(spdp_launch_cpos(&C, strm()));
         }
         return 0;
@@ -669,7 +692,7 @@ int DevRun::launch()
         HIPCHK(spdp_launch_walk(&W, strm()));
     }
     if (flavour == 2) {
-        CposArgs C;
+        CposArgs C{};
         C.probs = A.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
         C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
         C.cpos_stride = 10 * (max_n_im + 1); C.strict = 0; C.local = 0;

@@ -36,7 +36,30 @@ __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      
 // MODE 2: hirschbergS1 (src/fwd2s1_simd.cc:775-1150, non-local) -- the pointer lanes carry links (the diagonal at
 // which the path crossed the previous intermediate row); the lane holding an intermediate row stores and
 // restarts them; spdp_udh_cpos (strict form) walks them back afterwards.
-template <int MODE>
+// PIPE: the stripes of a problem run as a pipeline.  A work item is (four problems, stripe): group g of the wave
+// sweeps that stripe of problem 4 q + g, the wave of the next item follows ~50 steps behind.  Items are drawn from
+// a ticket counter in dispatch order, so a stripe's predecessor is always resident or done.  The boundary arrays
+// cross CUs (agent-scope accesses, memory side); a stripe publishes, once its stores have drained, the diagonal
+// up to which its bottom row is out (prog[stripe], + 2^20; INT_MAX = finished), and reads its predecessor's word
+// before every block of 16 steps it stages.  What the one-wave form carries from stripe to stripe in registers goes
+// through memory: the local maximum (per stripe, first maximum in stripe order), the intermediate-row counter
+// (recomputed), and hs1.rlst -- only ever stored, so a stripe starts from a marker (XINH) and the link walk
+// (spdp_udh_cpos) replaces it by what the intermediate rows above left (rlf[]).
+#define XINH SPDP_RLST_INHERITED
+#define XPROG0 (1 << 28)
+#define XVCH SPDP_VMF_LANE_CHUNK
+template <bool X> __device__ __forceinline__ int x_ld(const int* p)
+{
+    if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __builtin_nontemporal_load(p);
+}
+template <bool X> __device__ __forceinline__ void x_st(int* p, int v)
+{
+    if constexpr (X) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <int MODE, bool PIPE>
 __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 {
     constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
@@ -62,7 +85,16 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
-    const int pi = blockIdx.x * 4 + grp;
+    int pi = blockIdx.x * 4 + grp;
+    int my_stripe = -1;                          // PIPE: the one stripe this group sweeps
+    if (PIPE) {
+        int tk = 0;
+        if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= A.n_items) return;
+        const int2 it = A.items[tk];
+        pi = it.x * 4 + grp; my_stripe = it.y;
+    }
     if (pi >= A.n_probs) return;                 // a whole 16-lane group leaves together
     const DevProblem P = A.probs[pi];
     const DevScoring* sc = A.sc;
@@ -90,16 +122,48 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     int* vcount = A.work + P.bnd_off + 5 * (int64_t) P.buf_size;          // forward: records appended so far
     int* fb = fc + P.buf_size;                   // udh with local left ends: left-end row (`ml`) of F (hb: of H)
     int3* vrec = A.vmf + P.tb_off;
+    int* vraw = reinterpret_cast<int*>(vrec);
     const int vcap = (int) P.imd_off;
+    // every lane takes its record numbers XVCH at a time from the problem's counter (an atomic per record made the
+    // forward sweep wait for memory at every diagonal run it started)
+    int v_next = 0, v_left = 0;
     auto vadd = [&](int mm, int nn, int pp) -> int {
-        const int i = atomicAdd(vcount, 1);
-        if (i < vcap) vrec[i] = make_int3(mm, nn, pp);
+        if (v_left == 0) { v_next = atomicAdd(vcount, XVCH); v_left = XVCH; }
+        const int i = v_next++;
+        --v_left;
+        if (i < vcap) {
+            if (PIPE) { x_st<true>(vraw + 3 * i, mm); x_st<true>(vraw + 3 * i + 1, nn); x_st<true>(vraw + 3 * i + 2, pp); }
+            else vrec[i] = make_int3(mm, nn, pp);
+        }
         return i;
     };
     const int n_ent = P.buf_size;
+    const int n_stripes = max(1, (a_right - a_left + XN - 1) / XN);     // (DevRun::build lists the same count)
+    if (PIPE && my_stripe >= n_stripes) return;  // (a shorter problem of the four)
+    // PIPE: what the stripes of the problem share: prog[max_tiles], best[max_tiles][6], rlf[n_im]
+    int* sy = PIPE ? A.pipe + (size_t) pi * A.pipe_stride : nullptr;
+    int* prog = PIPE ? sy + 2 : nullptr;
+    int* tbest = PIPE ? sy + 2 + A.max_tiles : nullptr;
+    int* rlf = PIPE ? sy + 2 + 7 * A.max_tiles : nullptr;
+    bool stalled = false;
+    // waits until stripe t has published at least `req` (per lane: a group waits for its own problem)
+    auto wait_for = [&](int t, int req) {
+        long spins = 0;
+        while (!stalled && __hip_atomic_load(prog + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < req) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1l << 22)) {              // (cannot happen with the ticket order; bounds every spin)
+                __hip_atomic_store(A.pipe + A.pipe_ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stalled = true;
+            }
+        }
+    };
+    auto publish = [&](int t, int v) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (k == 0) __hip_atomic_store(prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
 
     // ---- fhinitS1
-    {
+    if (!PIPE || my_stripe == 0) {
         const int rl = b_left - a_left;
         const int rr = min(b_right - a_left, up);
         int rr_g = rr;
@@ -115,38 +179,51 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 else if (ge) { if (r > rl + 1 && r < rr_g) h = gop + ge + (r - rl - 1) * ge; }
                 else if (r > rl + 1 && r < rr) h = gop;
             }
-            hv[r] = h; fv[r] = XNEV;
+            x_st<PIPE>(&hv[r], h); x_st<PIPE>(&fv[r], XNEV);
             if constexpr (FORWARD) {                 // the Vmf part of fhinitS1 (:185-205): records 0 (dummy) and 1 (start)
                 const int ru = up + 2 * XN;
                 int c = 0;
                 if (r == rl) c = 1;
                 else if (r > rl && r <= ru) c = a_exgl ? 0 : 1;
                 else if (r < rl) c = b_exgl ? 0 : 1;
-                hb[r] = 0; hc[r] = c; fc[r] = c;
+                x_st<PIPE>(&hb[r], 0); x_st<PIPE>(&hc[r], c); x_st<PIPE>(&fc[r], c);
             }
             if constexpr (UDH) {                     // the Hirschberg part (:206-227): link = diagonal where the path starts
                 const int ru = up + 2 * XN;
                 int c = 0;
                 if (r >= rl) { if (a_exgl) c = (r < ru) ? r : 0; else c = (r <= ru) ? rl : 0; }
                 else c = b_exgl ? r : rl;
-                hc[r] = c; fc[r] = c;
+                x_st<PIPE>(&hc[r], c); x_st<PIPE>(&fc[r], c);
                 int bm = a_left;                     // bbuf = a_left; the free left column counts rows upwards (:209-224)
                 if (b_exgl && r <= rl && r >= lw) bm = a_left + (rl - r);
-                hb[r] = bm; fb[r] = a_left;
+                x_st<PIPE>(&hb[r], bm); x_st<PIPE>(&fb[r], a_left);
             }
         }
         if constexpr (UDH) {
-            for (int e = k; e < n_im * 4 * width; e += XN) imd0[e] = 0x7fffffff - 2;    // end_of_ulk
+            if (!PIPE) for (int e = k; e < n_im * 4 * width; e += XN) imd0[e] = 0x7fffffff - 2;    // end_of_ulk
         }
         if constexpr (FORWARD) {
-            if (k == 0) { vrec[0] = make_int3(0, 0, 0); vrec[1] = make_int3(a_left, b_left, 0); *vcount = 2; }
+            if (k == 0) {
+                x_st<PIPE>(vraw, 0); x_st<PIPE>(vraw + 1, 0); x_st<PIPE>(vraw + 2, 0);
+                x_st<PIPE>(vraw + 3, a_left); x_st<PIPE>(vraw + 4, b_left); x_st<PIPE>(vraw + 5, 0);
+                x_st<PIPE>(vcount, 2);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     int maxh = XNEV, max_ulk = 0, max_mr = a_right, max_nr = b_right, max_ml = a_left;
     int imd_i = 0, rlst = 0x7fffffff;            // udh: current intermediate, hs1.rlst
-    for (int ml = a_left; ml < a_right; ml += XN) {
+    const int ml_first = PIPE ? a_left + XN * my_stripe : a_left;
+    const int ml_end = PIPE ? min(a_right, ml_first + XN) : a_right;
+    if (PIPE && UDH) {
+        // the counter as the stripes above would have left it: one step per stripe that held the then current row
+        for (int mq = a_left; mq < ml_first && imd_i < n_im; mq += XN) {
+            const int mi = a_left + (imd_i + 1) * imd_step;
+            if (mq == a_left + (mi - a_left - 1) / XN * XN) ++imd_i;
+        }
+    }
+    for (int ml = ml_first; ml < ml_end; ml += XN) {
         const int j9 = min(XN, a_right - ml);
         const int j8 = j9 - 1;
         int n = max(b_left, lw + ml);
@@ -177,6 +254,13 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         }
         const bool imd_here = UDH && is_imd_ && k == k8;     // my row is the intermediate row (m == imd->mi)
         (void) k9;
+        if (PIPE && UDH && is_imd_) {
+            for (int e = k; e < 4 * width; e += XN) x_st<true>(imd0 + (int64_t) imd_i * 4 * width + e, 0x7fffffff - 2);
+            rlst = imd_i == 0 ? 0x7fffffff : XINH;
+        }
+        const int st = PIPE ? my_stripe : 0;
+        // PIPE: entries up to diagonal `rq` of the stripe above must be out before they are staged
+        auto ready = [&](int rq) { if (PIPE && st > 0) wait_for(st - 1, rq + XPROG0); };
         const int* mrow = s_mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
         // ---- staging (see the top of the kernel): registers hold the NEXT block's loads while a block runs
         int2* const ring = s_col[grp];
@@ -192,10 +276,10 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         auto prefetch = [&](int nb_, int rb_) {                           // block starting at step nb_, diagonal rb_
             ld_col(nb_ + k, pc, pax);
             const int e = min(rb_ + 1 + k, e_last);
-            pfd[FD_HV] = __builtin_nontemporal_load(&hv[e]); pfd[FD_FV] = __builtin_nontemporal_load(&fv[e]);
-            if constexpr (PTR) { pfd[FD_HC] = __builtin_nontemporal_load(&hc[e]); pfd[FD_FC] = __builtin_nontemporal_load(&fc[e]); }
-            if constexpr (FORWARD) pfd[FD_HB] = __builtin_nontemporal_load(&hb[e]);
-            if constexpr (UDH) { if (LocalL) { pfd[FD_HB] = __builtin_nontemporal_load(&hb[e]); pfd[FD_FB] = __builtin_nontemporal_load(&fb[e]); } }
+            pfd[FD_HV] = x_ld<PIPE>(&hv[e]); pfd[FD_FV] = x_ld<PIPE>(&fv[e]);
+            if constexpr (PTR) { pfd[FD_HC] = x_ld<PIPE>(&hc[e]); pfd[FD_FC] = x_ld<PIPE>(&fc[e]); }
+            if constexpr (FORWARD) pfd[FD_HB] = x_ld<PIPE>(&hb[e]);
+            if constexpr (UDH) { if (LocalL) { pfd[FD_HB] = x_ld<PIPE>(&hb[e]); pfd[FD_FB] = x_ld<PIPE>(&fb[e]); } }
         };
         auto commit = [&](int nb_) {                                      // the staged block becomes the current one
             ring[(nb_ + k) & 63] = pc; ringx[(nb_ + k) & 63] = (unsigned short) pax;
@@ -209,14 +293,15 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         {
             // the 16 columns left of the first step (lane k of step n_first looks at n_first - k), then block 0
             int2 c0; unsigned a0;
+            ready(r + 16);
             ld_col(n_first - 16 + k, c0, a0);
             ring[(n_first - 16 + k) & 63] = c0; ringx[(n_first - 16 + k) & 63] = (unsigned short) a0;
             if (k == 0) {
                 const int e = min(r, e_last);
-                fd[FD_HV][16] = __builtin_nontemporal_load(&hv[e]); fd[FD_FV][16] = __builtin_nontemporal_load(&fv[e]);
-                if constexpr (PTR) { fd[FD_HC][16] = __builtin_nontemporal_load(&hc[e]); fd[FD_FC][16] = __builtin_nontemporal_load(&fc[e]); }
-                if constexpr (FORWARD) fd[FD_HB][16] = __builtin_nontemporal_load(&hb[e]);
-                if constexpr (UDH) { if (LocalL) { fd[FD_HB][16] = __builtin_nontemporal_load(&hb[e]); fd[FD_FB][16] = __builtin_nontemporal_load(&fb[e]); } }
+                fd[FD_HV][16] = x_ld<PIPE>(&hv[e]); fd[FD_FV][16] = x_ld<PIPE>(&fv[e]);
+                if constexpr (PTR) { fd[FD_HC][16] = x_ld<PIPE>(&hc[e]); fd[FD_FC][16] = x_ld<PIPE>(&fc[e]); }
+                if constexpr (FORWARD) fd[FD_HB][16] = x_ld<PIPE>(&hb[e]);
+                if constexpr (UDH) { if (LocalL) { fd[FD_HB][16] = x_ld<PIPE>(&hb[e]); fd[FD_FB][16] = x_ld<PIPE>(&fb[e]); } }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             prefetch(n, r);
@@ -226,6 +311,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             if (jb == 16) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's reads of the old block are done)
                 commit(n);
+                if (PIPE) { publish(st, r - 1 - 2 * j8 + XPROG0); ready(r + 32); }
                 prefetch(n + 16, r + 16);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 jb = 0;
@@ -354,13 +440,13 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                         if (imd_here && br_on) {                  // the acceptor sits on the intermediate row (:91-110)
                             const int maxd = br_d;
                             const int lk = maxd == 0 ? mx_lk[0] : (maxd == 1 ? mx_lk[1] : mx_lk[2]);
-                            LNK(imd_i, 0, 0, rj) = lk; rlst = rj;
+                            x_st<PIPE>(&LNK(imd_i, 0, 0, rj), lk); rlst = rj;
                             if (maxd == 0) HC = rj; else if (maxd == 1) EC = rj; else FC = rj;
                             hb_pv = maxd;
                             if (maxd != 0) HC = rj;
                             else {
                                 if (mx_on[1] && E > H + gop) EC = rj + width;
-                                if (mx_on[2] && F > H + gop) { LNK(imd_i, 0, 1, rj) = lk; FC = rj + width; }
+                                if (mx_on[2] && F > H + gop) { x_st<PIPE>(&LNK(imd_i, 0, 1, rj), lk); FC = rj + width; }
                             }
                         }
                     }
@@ -390,7 +476,7 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                                 n_ulk = kk == 0 ? HC : (kk == 1 ? EC : FC);
                             }
                             if constexpr (UDH) {
-                                if (imd_here) { if (kk & 1) LNK(imd_i, 0, 0, rj) = rlst; n_ulk = rj; }
+                                if (imd_here) { if (kk & 1) x_st<PIPE>(&LNK(imd_i, 0, 0, rj), rlst); n_ulk = rj; }
                                 else n_ulk = kk == 0 ? HC : (kk == 1 ? EC : FC);
                                 n_ml = kk == 0 ? HB : (kk == 1 ? EB : FB);
                             }
@@ -409,26 +495,49 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
                 const int rq = r - 2 * k8;
                 if (is_imd_ && k == k8 && rq >= lw && rq <= up) {
                     if (hb_pv == 0) rlst = rq;
-                    if (hb_pv == 1) LNK(imd_i, 0, 0, rq) = rlst;
-                    LNK(imd_i, 1, 0, rq) = HC; HC = rq;
-                    LNK(imd_i, 1, 1, rq) = FC; FC = rq + width;
+                    if (hb_pv == 1) x_st<PIPE>(&LNK(imd_i, 0, 0, rq), rlst);
+                    x_st<PIPE>(&LNK(imd_i, 1, 0, rq), HC); HC = rq;
+                    x_st<PIPE>(&LNK(imd_i, 1, 1, rq), FC); FC = rq + width;
                 }
             }
             // bottom row of the stripe -> boundary arrays
             if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) {
-                hv[r0] = H; fv[r0] = F;
-                if constexpr (FORWARD) hb[r0] = HB;
-                if constexpr (PTR) { hc[r0] = HC; fc[r0] = FC; }
-                if constexpr (UDH) { if (LocalL) { hb[r0] = HB; fb[r0] = FB; } }
+                x_st<PIPE>(&hv[r0], H); x_st<PIPE>(&fv[r0], F);
+                if constexpr (FORWARD) x_st<PIPE>(&hb[r0], HB);
+                if constexpr (PTR) { x_st<PIPE>(&hc[r0], HC); x_st<PIPE>(&fc[r0], FC); }
+                if constexpr (UDH) { if (LocalL) { x_st<PIPE>(&hb[r0], HB); x_st<PIPE>(&fb[r0], FB); } }
             }
             H2 = H1; H1 = H; F1 = F;
             if constexpr (FORWARD || UDH) { B2 = B1; B1 = HB; }
             if constexpr (PTR) { C2 = C1; C1 = HC; FC1 = FC; }
         }
         if constexpr (UDH) {
-            if (is_imd_) { rlst = __shfl(rlst, k8, XN); ++imd_i; }       // hs1.rlst is one variable for all lanes
+            if (is_imd_) {
+                rlst = __shfl(rlst, k8, XN);                              // hs1.rlst is one variable for all lanes
+                if (PIPE && k == 0) x_st<true>(rlf + imd_i, rlst);
+                ++imd_i;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (PIPE) {
+        // finished = every entry holds what the stripes up to this one leave: the stripe above must be finished too
+        const int st = my_stripe;
+        if (LocalR && k == 0) {
+            int* b = tbest + 6 * st;
+            x_st<true>(b, maxh); x_st<true>(b + 1, max_ulk); x_st<true>(b + 2, max_mr); x_st<true>(b + 3, max_nr); x_st<true>(b + 4, max_ml);
+        }
+        if (st > 0) wait_for(st - 1, INT32_MAX);
+        publish(st, INT32_MAX);
+        if (st != n_stripes - 1) return;
+        if (LocalR) {                                                     // stripes in order: the first maximum wins
+            maxh = XNEV; max_ulk = 0; max_mr = a_right; max_nr = b_right; max_ml = a_left;
+            for (int t = 0; t < n_stripes; ++t) {
+                const int* b = tbest + 6 * t;
+                const int v = x_ld<true>(b);
+                if (v > maxh) { maxh = v; max_ulk = x_ld<true>(b + 1); max_mr = x_ld<true>(b + 2); max_nr = x_ld<true>(b + 3); max_ml = x_ld<true>(b + 4); }
+            }
+        }
     }
     // ---- fhlastS1 unless a local right end was tracked; forward: the end record, Vmf::traceback, fix-up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -443,33 +552,34 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
             if (a_exgr) {
                 const int r1 = max(lw, b_left - a_right);
                 int best = r1;
-                for (int i = r1 + 1; i < rr; ++i) if (__builtin_nontemporal_load(&hv[i]) > __builtin_nontemporal_load(&hv[best])) best = i;
+                for (int i = r1 + 1; i < rr; ++i) if (x_ld<PIPE>(&hv[i]) > x_ld<PIPE>(&hv[best])) best = i;
                 maxr = best;
             }
             if (b_exgr) {
                 const int r2 = min(up - 1, b_right - a_left);
                 int best = rr;
-                for (int i = rr + 1; i < r2; ++i) if (__builtin_nontemporal_load(&hv[i]) > __builtin_nontemporal_load(&hv[best])) best = i;
-                if (__builtin_nontemporal_load(&hv[best]) > __builtin_nontemporal_load(&hv[maxr])) maxr = best;
+                for (int i = rr + 1; i < r2; ++i) if (x_ld<PIPE>(&hv[i]) > x_ld<PIPE>(&hv[best])) best = i;
+                if (x_ld<PIPE>(&hv[best]) > x_ld<PIPE>(&hv[maxr])) maxr = best;
             }
-            R.score = __builtin_nontemporal_load(&hv[maxr]);
+            R.score = x_ld<PIPE>(&hv[maxr]);
             R.maxr = maxr;
             if (maxr > rr) R.mr = b_right - maxr; else R.nr = a_right + maxr;
-            if constexpr (PTR) end_ulk = __builtin_nontemporal_load(&hc[maxr]);
-            if constexpr (UDH) { if (LocalL) R.ml = __builtin_nontemporal_load(&hb[maxr]); }
+            if constexpr (PTR) end_ulk = x_ld<PIPE>(&hc[maxr]);
+            if constexpr (UDH) { if (LocalL) R.ml = x_ld<PIPE>(&hb[maxr]); }
         }
         if constexpr (FORWARD) {
             const int ptr = vadd(R.mr, R.nr, end_ulk);
-            const int used = __builtin_nontemporal_load(vcount);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int used = x_ld<PIPE>(vcount);
             int2* out = A.skl + (int64_t) pi * A.skl_cap;
             int cnt = 0, status = used > vcap ? -3 : 0;
             if (!status) {
                 const int* vr = reinterpret_cast<const int*>(vrec);
                 int cur = ptr, lm = 0, ln = 0;
                 for (;;) {
-                    const int sm = __builtin_nontemporal_load(vr + 3 * (int64_t) cur);
-                    const int sn = __builtin_nontemporal_load(vr + 3 * (int64_t) cur + 1);
-                    const int sp = __builtin_nontemporal_load(vr + 3 * (int64_t) cur + 2);
+                    const int sm = x_ld<PIPE>(vr + 3 * (int64_t) cur);
+                    const int sn = x_ld<PIPE>(vr + 3 * (int64_t) cur + 1);
+                    const int sp = x_ld<PIPE>(vr + 3 * (int64_t) cur + 2);
                     if (cnt < A.skl_cap) out[cnt] = make_int2(sm, sn); else status = -1;
                     lm = sm; ln = sn; ++cnt;
                     if (!sp) break;
@@ -492,9 +602,17 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    const dim3 grd((A.n_probs + 3) / 4), blk(64);
-    if (mode == 2) hipLaunchKernelGGL(spdp_exact<2>, grd, blk, 0, stream, A);
-    else if (mode == 1) hipLaunchKernelGGL(spdp_exact<1>, grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL(spdp_exact<0>, grd, blk, 0, stream, A);
+    const dim3 blk(64);
+    if (A.pipe) {                                // one wave per (four problems, stripe)
+        const dim3 grd(A.n_items);
+        if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, true>), grd, blk, 0, stream, A);
+        else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, true>), grd, blk, 0, stream, A);
+        else hipLaunchKernelGGL((spdp_exact<0, true>), grd, blk, 0, stream, A);
+        return hipGetLastError();
+    }
+    const dim3 grd((A.n_probs + 3) / 4);
+    if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, false>), grd, blk, 0, stream, A);
+    else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, false>), grd, blk, 0, stream, A);
+    else hipLaunchKernelGGL((spdp_exact<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }

@@ -45,6 +45,7 @@ struct WalkArgs {
     int               seq;        // 1: one diagonal step per load (SPDP_WALK_SEQ=1, for A/B runs)
 };
 
+#define SPDP_RLST_INHERITED 0x7ffffff0   // pipelined linear-space engines: "rlst as the intermediate rows above left it" (an HLNK value)
 struct CposArgs {
     const DevProblem* probs;
     int               n_probs;
@@ -56,6 +57,8 @@ struct CposArgs {
     int               cpos_stride;
     int               strict;     // 1: the -A1 form of the walk (hirschbergS1: r > up, lw <= vlnk)
     int               local;      // 1: local ends (DevResult::ml is the left-end row of the path)
+    const int*        pipe;       // pipelined spdp_exact<2>: the sync words of the launch (rlf[] resolves SPDP_RLST_INHERITED), or null
+    int               pipe_stride, rlf_off;
 };
 
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
@@ -68,6 +71,7 @@ extern "C" hipError_t spdp_launch_cpos(const CposArgs* a, hipStream_t s);
 // exact-intron-length (-A0) engines (spdp_rowwave.hip: one wave per problem, lane = row) and the -A1 engines
 #include "spdp_ipen_runs.h"
 
+#define SPDP_VMF_LANE_CHUNK 32      // Vmf record numbers a lane of forwardS1 (spdp_exact<1>) reserves at a time
 #ifndef SPDP_VMF_CHUNK
 #define SPDP_VMF_CHUNK 512          // Vmf record numbers a wave of a pipelined forwardS_ng problem reserves at a time
 #endif

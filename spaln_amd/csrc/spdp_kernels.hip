@@ -904,7 +904,17 @@ __global__ void spdp_udh_cpos(CposArgs A)
         if ((A.strict ? lw <= vl : lw < vl) && vl < up) {
             CPOS(i, c++) = MI(i);
             CPOS(i, c++) = (d > 0) ? 1 : 0;
-            for (int rp = LNK(i, 0, d, r); lw <= rp && rp < up && r != rp; rp = LNK(i, 0, d, r = rp)) {
+            // (a pipelined sweep leaves a marker where it stored hs1.rlst of the rows above: what they ended with)
+            auto hl = [&](int ii, int dd, int rr) {
+                int v = LNK(ii, 0, dd, rr);
+                if (A.pipe && v == SPDP_RLST_INHERITED) {
+                    const int* rlf = A.pipe + (size_t) pi * A.pipe_stride + A.rlf_off;
+                    v = 0x7fffffff;
+                    for (int j = ii - 1; j >= 0; --j) if (rlf[j] != SPDP_RLST_INHERITED) { v = rlf[j]; break; }
+                }
+                return v;
+            };
+            for (int rp = hl(i, d, r); lw <= rp && rp < up && r != rp; rp = hl(i, d, r = rp)) {
                 if (c < 8) CPOS(i, c++) = r + MI(i); else ++c;
             }
             if (c < 9) { CPOS(i, c++) = r + MI(i); CPOS(i, c) = END_OF_ULK; }

@@ -159,3 +159,37 @@ def test_pipelined_equals_one_wave_h(eng, monkeypatch, name, local):
     monkeypatch.setenv("SPDP_A0_PIPE", "1")
     got = _run_all_h(eng, sc, ps, 0, 0)
     assert want == got
+
+
+# ---- -A1: spdp_exact<., true>, the 16-row stripes of a problem as a pipeline ---------------------------------
+def test_a1_pipelined_equals_one_group(eng, monkeypatch):
+    """alignS_ng / HomScoreS_ng under -A1 (scalar_engines = 2) on every taller cDNA fixture with its own ladder
+    parameters (traceback, linear-space and local branches): pipelined stripes = one group per problem = the relaunch
+    after a wave gave up its wait; the default (pipelined) run is what tests/test_gpu_parity.py pins to the goldens"""
+    cases = [(f.split("/")[-1][:-5], spdg.load(f)) for f in S_FILES]
+    cases = [(n, fx) for n, fx in cases if fx["prm"]["a_right"] - fx["prm"]["a_left"] >= 100]
+    assert len(cases) >= 10
+    key = lambda fx: (bool(fx["prm"]["local"]), fx["prm"]["max_vmf_space"], fx["prm"]["ubh"], fx["prm"]["sh"])
+    n_batches = 0
+    for kk in sorted({key(fx) for _, fx in cases}):
+        sub = [(n, fx) for n, fx in cases if key(fx) == kk]
+        ref = max((fx for _, fx in sub), key=lambda fx: fx["intpen"].size)
+        sc = spdg.scoring(ref, scalar_engines=2, max_vmf_space=kk[1], ubh=kk[2], sh=kk[3])
+        ps = abi.ProblemSet()
+        for _, fx in sub:
+            spdg.problem(fx, ps)
+
+        def run():
+            al = [(s, skl.ravel().tolist()) for s, skl in eng.align_s(sc, ps, allow_partial=True)]
+            return al, [int(x) for x in eng.homscore_s(sc, ps)]
+        monkeypatch.setenv("SPDP_A1_PIPE", "0")
+        want = run()
+        monkeypatch.delenv("SPDP_A1_PIPE")
+        got = run()
+        assert want == got, kk
+        monkeypatch.setenv("SPDP_A0_PIPE_TEST_STALL", "1")
+        again = run()
+        monkeypatch.delenv("SPDP_A0_PIPE_TEST_STALL")
+        assert want == again, kk
+        n_batches += 1
+    assert n_batches >= 3

@@ -100,6 +100,34 @@ for vmf in (300000, 120000):
             continue
         if score != ws or skl.ravel().tolist() != (wskl or []):
             bad += 1; print("alignS_ng -A1 -LS", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws)
+# alignS_ng under -A0 and -A1 on a global fixture, tall sub-ranges (the tiles / stripes of a problem run as pipelines
+# of waves), traceback and linear-space branches
+fx = spdg.load(S["s1_1400nt"])
+q = fx["prm"]
+extra = dict(cano5=fx["cano5"], cano3=fx["cano3"], dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+for eng_sel, simd in ((1, 0), (2, 1)):
+    for vmf in (1 << 30, 600000, 150000):
+        sc1 = spdg.scoring(fx, scalar_engines=eng_sel, max_vmf_space=vmf)
+        ps = abi.ProblemSet()
+        for i in range(max(8, N // 8)):
+            m = int(rng.integers(100, q["a_right"] + 1))
+            al = int(rng.integers(0, q["a_right"] - m + 1))
+            bl = int(rng.integers(0, 600))
+            br = int(rng.integers(max(bl + m + 300, q["b_right"] - 1500), q["b_right"] + 1))
+            exg = (1, 1, 1, 1) if i % 2 == 0 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg, **extra)
+        res = eng.align_s(sc1, ps, allow_partial=True)
+        hom = eng.homscore_s(sc1, ps)
+        n_cmp = 0
+        for i, (p, (score, skl)) in enumerate(zip(ps.items, res)):
+            try:
+                ws, wskl = host_logic.align_s(sc1, p, simd=simd)
+            except (host_logic.NeedsScalarEngine, host_logic.ReferenceUndefined):
+                continue
+            n_cmp += 1
+            if score != ws or skl.ravel().tolist() != (wskl or []):
+                bad += 1; print("alignS_ng", "-A0" if simd == 0 else "-A1", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws)
+        print("alignS_ng", "-A0" if simd == 0 else "-A1", "MaxVmfSpace", vmf, ":", n_cmp, "compared", flush=True)
 eng.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -48,6 +48,7 @@ __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      
 #define XINH SPDP_RLST_INHERITED
 #define XPROG0 (1 << 28)
 #define XVCH SPDP_VMF_LANE_CHUNK
+#define XWPB 4                                   // waves per block: they share the read-only tables in LDS
 template <bool X> __device__ __forceinline__ int x_ld(const int* p)
 {
     if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -60,7 +61,7 @@ template <bool X> __device__ __forceinline__ void x_st(int* p, int v)
 }
 
 template <int MODE, bool PIPE>
-__global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
+__global__ void __launch_bounds__(64 * XWPB) spdp_exact(ScalarArgs A)
 {
     constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
     constexpr bool UDH = MODE == 2;             // links, intermediate rows
@@ -69,27 +70,28 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
     // records and class bytes of the block's columns, and the boundary entries lane 0 feeds from (the previous stripe's
     // bottom row, by diagonal) -- a step used to wait for its own loads
     __shared__ int s_mtx[32 * 32];
-    __shared__ int2 s_col[4][64];
-    __shared__ unsigned short s_ax[4][64];
+    __shared__ int2 s_col[4 * XWPB][64];
+    __shared__ unsigned short s_ax[4 * XWPB][64];
     enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_N };
-    __shared__ int s_fd[4][FD_N][20];
+    __shared__ int s_fd[4 * XWPB][FD_N][20];
     // the tables an acceptor prices its candidates with: a read from memory inside that loop stalled the whole wave
     // (some lane of 64 sits on an acceptor column at almost every step)
     __shared__ short s_ipen[4096];
     __shared__ IpenRuns s_runs;                 // IntPen beyond s_ipen (spdp_ipen_runs.h)
     __shared__ short s_t53[256];
-    for (int i = threadIdx.x; i < 32 * 32; i += 64) s_mtx[i] = A.sc->mtx[i];
-    for (int i = threadIdx.x; i < 4096; i += 64) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
+    for (int i = threadIdx.x; i < 32 * 32; i += 64 * XWPB) s_mtx[i] = A.sc->mtx[i];
+    for (int i = threadIdx.x; i < 4096; i += 64 * XWPB) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     ipen_runs_load(s_runs, A.ipen_runs);
-    for (int i = threadIdx.x; i < 256; i += 64) s_t53[i] = A.t53[i];
+    for (int i = threadIdx.x; i < 256; i += 64 * XWPB) s_t53[i] = A.t53[i];
     __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;
-    int pi = blockIdx.x * 4 + grp;
+    const int grp = (threadIdx.x & 63) >> 4;     // my 16-lane group in the wave
+    const int g16 = threadIdx.x >> 4;            // ... in the block (its staging rings)
+    int pi = (blockIdx.x * XWPB + (threadIdx.x >> 6)) * 4 + grp;
     int my_stripe = -1;                          // PIPE: the one stripe this group sweeps
     if (PIPE) {
         int tk = 0;
-        if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((threadIdx.x & 63) == 0) tk = __hip_atomic_fetch_add(A.pipe + A.pipe_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= A.n_items) return;
         const int2 it = A.items[tk];
@@ -263,9 +265,9 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
         auto ready = [&](int rq) { if (PIPE && st > 0) wait_for(st - 1, rq + XPROG0); };
         const int* mrow = s_mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
         // ---- staging (see the top of the kernel): registers hold the NEXT block's loads while a block runs
-        int2* const ring = s_col[grp];
-        unsigned short* const ringx = s_ax[grp];
-        int (*const fd)[20] = s_fd[grp];
+        int2* const ring = s_col[g16];
+        unsigned short* const ringx = s_ax[g16];
+        int (*const fd)[20] = s_fd[g16];
         const int e_last = lw - 1 + P.buf_size - 1;                       // last entry of the boundary arrays
         auto ld_col = [&](int c, int2& cc, unsigned& ax) {
             const bool in = c >= 0 && c <= b_right + 1;
@@ -602,15 +604,15 @@ __global__ void __launch_bounds__(64) spdp_exact(ScalarArgs A)
 extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    const dim3 blk(64);
+    const dim3 blk(64 * XWPB);
     if (A.pipe) {                                // one wave per (four problems, stripe)
-        const dim3 grd(A.n_items);
+        const dim3 grd((A.n_items + XWPB - 1) / XWPB);
         if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, true>), grd, blk, 0, stream, A);
         else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, true>), grd, blk, 0, stream, A);
         else hipLaunchKernelGGL((spdp_exact<0, true>), grd, blk, 0, stream, A);
         return hipGetLastError();
     }
-    const dim3 grd((A.n_probs + 3) / 4);
+    const dim3 grd((A.n_probs + 4 * XWPB - 1) / (4 * XWPB));
     if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, false>), grd, blk, 0, stream, A);
     else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, false>), grd, blk, 0, stream, A);
     else hipLaunchKernelGGL((spdp_exact<0, false>), grd, blk, 0, stream, A);

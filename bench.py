@@ -166,12 +166,22 @@ def main_c3(args):
     torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
     from spaln_amd import abi, defaults, engine, synth
     eng = engine.Engine(local_rank)
-    sc = defaults.scoring_h()
+    exact = args.engines != "wip"
+    if exact:
+        # -A0 / -A1: the reference's protein parameter set as its harness dumped it (intron penalty table, junction table,
+        # frame-shift penalties: tests/golden/h1_400aa.spdg), forwardH_ng / hirschbergH_ng (spdp_h_rowwave.hip) or
+        # forwardH1 / hirschbergH1 (spdp_h_exact.hip) instead of the `_wip` pair
+        from tests import spdg
+        fx = spdg.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "h1_400aa.spdg"))
+        sc = spdg.scoring_h(fx, scalar_engines=1 if args.engines == "a0" else 2)
+    else:
+        sc = defaults.scoring_h()
     batch = synth.make_protein_batch(args.queries, seed=synth.SEED + 3000 + 1000 * rank)
     ps = abi.ProblemSetH()
     for g, sg in batch:
+        kw = dict(dinc=synth.exact_inputs(defaults.encode(g.window))["dinc"]) if exact else {}
         ps.add(synth.encode_protein(g.query), sg["b"], sg["sig5"], sg["sig3"], sg["sigS"], sg["sigT"], sg["sigE"],
-               sg["phs5"], sg["phs3"])
+               sg["phs5"], sg["phs3"], **kw)
     bt = eng.upload_h(sc, ps)
 
     def barrier():
@@ -189,6 +199,8 @@ def main_c3(args):
     for _ in range(args.steps):
         _, ms, cells = bt.align(want=True, convert=False)
         kms.append(ms)
+    if not cells:
+        cells = bt.cells()          # (the exact-model ladder does not report the cells of its launches: band cells)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -203,7 +215,7 @@ def main_c3(args):
     if rank == 0:
         k_ms = float(np.mean(kms))
         bpc = 32.0 / 64.0 + 2.0            # 16 B record + 8 B boundary read + 8 B write per 64 rows x 1 nt; 2 B code / cell
-        achieved = cells * bpc / (k_ms * 1e-3) / 1e9
+        achieved = cells * bpc / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         import multiprocessing as mp
         ncores = _host_cores()
         ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 2 * ncores, len(batch)))
@@ -215,8 +227,10 @@ def main_c3(args):
             band = 0
             for i in range(ns):
                 band += oracle.cells_h(ps.items[i], oracle.stripe31(ps.items[i], sc.sh))
+            if exact:
+                ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 8 * ncores, len(batch)))
             cpu_base = _ref_baseline([(batch[i][0].window, batch[i][0].query) for i in range(ns)], True, band,
-                                     cells / max(1, bt.cells()))
+                                     cells / max(1, bt.cells()), {"wip": 2, "a0": 0, "a1": 1}[args.engines])
         else:
             tc = time.perf_counter()
             with mp.Pool(min(ncores, ns)) as pool:
@@ -229,20 +243,25 @@ def main_c3(args):
             "metric": "GCUPS (DP cell updates/s), protein->genome spliced DP", "value": round(total_cells * args.steps / dt / 1e9, 3),
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "C3 (per-GPU batch scaled to HBM): 400 aa proteins vs planted 6-exon loci +-1 kb "
-                                   "(windows ~5-15 kb), Fwd2h1 _wip path: alignH_ng(-Q0) = forwardH1_wip + "
-                                   "traceback walk + stdskl3, SKL out",
+            "vs_baseline": None, "dtype": "int32" if args.engines == "a0" else "int16", "data": "synthetic",
+            "config": {"workload": ("C3 (per-GPU batch scaled to HBM): 400 aa proteins vs planted 6-exon loci +-1 kb "
+                                    "(windows ~5-15 kb), Fwd2h1 _wip path: alignH_ng(-Q0) = forwardH1_wip + "
+                                    "traceback walk + stdskl3, SKL out") if not exact else
+                                   (f"C3 shape, {args.queries} x 400 aa proteins vs planted 6-exon loci +-1 kb, alignH_ng(-Q0) with the "
+                                    "exact-model engines (" + ("-A0: forwardH_ng / hirschbergH_ng as wavefront kernels, spdp_h_rowwave.hip"
+                                                               if args.engines == "a0" else "-A1: forwardH1 / hirschbergH1, spdp_h_exact.hip") + ")"),
                        "queries_per_gpu": args.queries, "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(args.queries * world * args.steps / dt, 1),
-                       "sweep_ms": round(k_ms, 3), "sweep_gcups": round(cells / k_ms / 1e6, 2)},
+                       "sweep_ms": round(k_ms, 3), "sweep_gcups": round(cells / k_ms / 1e6, 2) if k_ms > 0 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1) else None,
+                         "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1 and not exact) else None,
                          "traffic_source": "profiles/r02_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
-                         "kernel": "spdh_sweep", "kernel_ms": round(k_ms, 3),
-                         "valu": _valu_roofline(cells, "h", k_ms),
-                         "note": "integer-VALU bound recurrence (int16 saturating lanes carried in the upper half of 32-bit registers); HBM fraction reported as asked"},
+                         "kernel": ("spdh_rowwave" if args.engines == "a0" else "spdh_exact") if exact else "spdh_sweep",
+                         "kernel_ms": round(k_ms, 3),
+                         "valu": None if exact else _valu_roofline(cells, "h", k_ms),
+                         "note": "exact-model engines: latency-bound chains, see DESIGN.md; HBM fraction reported as asked" if exact else
+                                 "integer-VALU bound recurrence (int16 saturating lanes carried in the upper half of 32-bit registers); HBM fraction reported as asked"},
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(out), flush=True)
@@ -318,7 +337,7 @@ def main():
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "
                          "c4: 500-nt ESTs (traceback branch of the ladder only)")
     ap.add_argument("--engines", choices=["wip", "a0", "a1"], default="wip",
-                    help="c2 / c4 only: wip = the -A2 `_wip` engines (the headline); a0 = the exact-intron-length engines "
+                    help="wip = the -A2 `_wip` engines (the headline); a0 = the exact-intron-length engines "
                          "(algmode.alg 0: forwardS_ng / hirschbergS_ng, spdp_rowwave.hip); a1 = the -A1 engines (spdp_exact.hip)")
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default 10000; 1000 with --engines a0 / a1)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the CPU oracle (0 = 2 per host core)")

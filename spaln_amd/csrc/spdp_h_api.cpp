@@ -582,6 +582,10 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    if (getenv("SPDP_TRACE_RUNS"))
+        fprintf(stderr, "[spdp run] aa x genome %s forward=%d n %d cells %.3g pipe %d items %zu  %.2f ms  %.2f GCUPS\n",
+                exact ? "-A1" : "-A0", (int) forward, nr, (double) out.cells, (int) pp.on, pp.items.size() / 2, out.sweep_ms,
+                out.cells / (out.sweep_ms * 1e6));
     for (int i = 0; i < nr; ++i) {
         const int c = out.n_skl[i];
         if (c == -1) { ctx->err = "traceback record buffer overflow (scalar engine)"; return -1; }
@@ -739,6 +743,9 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     HIPCHK(hipMemcpyAsync(res.data(), d_res, nr * sizeof(DevResultH), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipEventElapsedTime(&out.sweep_ms, ctx->ev0, ctx->ev1));
+    if (getenv("SPDP_TRACE_RUNS"))
+        fprintf(stderr, "[spdp run] aa x genome linear space engine %d n %d cells %.3g pipe %d items %zu  %.2f ms  %.2f GCUPS\n",
+                engine, nr, (double) out.cells, (int) pp.on, pp.items.size() / 2, out.sweep_ms, out.cells / (out.sweep_ms * 1e6));
     for (int i = 0; i < nr; ++i) flags[i] = exact ? 0 : res[i].pad[0];
     return 0;
 }

@@ -32,6 +32,7 @@ namespace {
 constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
 constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
 constexpr int RING = 512;                               // diagonals resident in LDS
+constexpr int CRING = 128;                              // columns resident in LDS
 constexpr int CHUNK = 32;                               // steps between two refills of the window
 constexpr int NC = 5;                                   // NCAND + 1 slots per candidate list
 constexpr int WPB = 4;                                  // waves (= problems) per block
@@ -156,10 +157,18 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     constexpr bool FWD = MODE == 1, UDH = MODE == 2;
     constexpr int NF = Shape<MODE>::NF;
     __shared__ int Lw[WPB][2 * NF][RING];
+    // the column records and signal quadruples of the columns the wave is on (its 64 rows sit on 64 + 31 consecutive
+    // columns during a chunk of steps, and a cell looks 2 back and 4 ahead): staged 32 columns at a time, coalesced --
+    // an acceptor or donor used to wait for four or five dependent reads from memory, and some lane is on one at
+    // almost every step
+    __shared__ int4 Ccol[WPB][CRING];
+    __shared__ short4 Caux[WPB][CRING];
     __shared__ Tables T;
     const DevScoringH* sc = A.sc;
     load_tables(T, A, sc);
     int (*L)[RING] = Lw[threadIdx.x >> 6];              // L[f] = field f of H, L[NF + f] = field f of F
+    int4* const Cc = Ccol[threadIdx.x >> 6];
+    short4* const Ca = Caux[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
     int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
@@ -388,6 +397,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
             auto need_lo = [&](int S) { return S - 4 * (m0 + 63) - 3 - lw + 3; };
             auto need_hi = [&](int S) { return S - 4 * m0 + 3 - lw + 3; };
             int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
+            int cres = INT32_MIN;                                   // columns below this one are staged
             auto refill = [&](int S) {
                 const int dead = min(max(0, need_lo(S)), W);
                 for (int e = res_lo + lane; e < dead; e += 64) {
@@ -408,8 +418,19 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                     for (int a = 0; a < 2 * NF; ++a) L[a][q] = gld<PIPE>(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
+                // columns [S - (m0 + 63) - 3, S + CHUNK - 1 - m0 + 5] of the next CHUNK steps
+                const int c_hi = S + CHUNK - 1 - m0 + 5;
+                for (int c = max(cres, S - (m0 + 63) - 3) + lane; c <= c_hi; c += 64) {
+                    const bool in = c >= 0 && c <= P.b_len + 2;
+                    Cc[c & (CRING - 1)] = in ? cols[c] : make_int4(0, 0, 0, 0);
+                    Ca[c & (CRING - 1)] = in ? aux[c] : make_short4(0, 0, 0, 0);
+                }
+                cres = c_hi + 1;
                 WAVE_SYNC();
             };
+            auto COL = [&](int c) -> int4 { return Cc[c & (CRING - 1)]; };
+            auto AUX = [&](int c) -> short4 { return Ca[c & (CRING - 1)]; };
+            auto tron_l = [&](int i) -> int { return (i < 0 || i > P.b_len) ? AMB : ((COL(i + 2).x >> 16) & 0xff); };   // tron_at from the staged columns
             auto lds_get = [&](int e, int isF) {
                 const int q = e & (RING - 1);
                 St s = black;
@@ -422,22 +443,14 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) L[isF * NF + f][q] = fld(s, f);
             };
-            // the column record and the codon-end signal of my next two cells are on their way when a step starts
-            auto ld_col = [&](int nn, int4& c, int& se) {
-                if (any && nn >= n0 && nn <= n9) { c = cols[nn]; se = (nn > bl && nn >= 2) ? (int) aux[nn - 2].z : 0; }
-            };
-            int4 col1 = make_int4(0, 0, 0, 0), col2 = col1; int se1 = 0, se2 = 0;
-            ld_col(s_lo - m, col1, se1);
-            ld_col(s_lo + 1 - m, col2, se2);
 
             for (int S = s_lo; S <= s_hi; ++S) {
                 if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
                 const int n = S - m;
                 const bool on = any && n >= n0 && n <= n9;
-                const int4 col = col1; const int sigE = se1;
-                col1 = col2; se1 = se2;
-                ld_col(n + 2, col2, se2);
                 if (__ballot(on) == 0) continue;
+                const int4 col = on ? COL(n) : make_int4(0, 0, 0, 0);
+                const int sigE = (on && n > bl && n >= 2) ? (int) AUX(n - 2).z : 0;
                 const int r = n - 3 * m, e = r - lw + 3;
                 St h = lds_get(e, 0), f = lds_get(e, 1);
                 const St hq = h;                                    // the entry as the cell found it
@@ -506,12 +519,12 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                         const int nb = n - phs;
                         int dn3 = 0, w2 = 7, w3 = 7, fix = 0;
                         if (t) {
-                            dn3 = cols[nb].w & 15;
+                            dn3 = COL(nb).w & 15;
                             if (phs) {                              // the two bases after the acceptor, for a codon the intron splits
-                                const int t2 = tron_at(nb), t3 = tron_at(nb + 1);
+                                const int t2 = tron_l(nb), t3 = tron_l(nb + 1);
                                 w2 = t2 < 32 ? T.mid[t2] : 7; w3 = t3 < 32 ? T.mid[t3] : 7;
                                 if (nb >= br) w2 = 7;
-                                if (phs == -1) fix = prof1[tron_at(n + 1)] + aux[n + 1].z;     // what the next row's match will add anyway
+                                if (phs == -1) fix = prof1[tron_l(n + 1)] + AUX(n + 1).z;     // what the next row's match will add anyway
                             }
                         }
                         int sel[3] = {-1, -1, -1};
@@ -617,11 +630,11 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                         const int nb = n - phs;
                         int sigJ = 0, packed = 0;
                         if (t) {
-                            sigJ = aux[nb].w;
-                            const int t0 = tron_at(nb - 2), t1 = tron_at(nb - 1);
+                            sigJ = AUX(nb).w;
+                            const int t0 = tron_l(nb - 2), t1 = tron_l(nb - 1);
                             int w0 = t0 < 32 ? T.mid[t0] : 7, w1 = t1 < 32 ? T.mid[t1] : 7;
                             if (nb < P.b_left) w0 = 7;
-                            packed = ((cols[nb].w >> 4) & 15) << 2 | (w0 & 7) << 6 | (w1 & 7) << 9;
+                            packed = ((COL(nb).w >> 4) & 15) << 2 | (w0 & 7) << 6 | (w1 & 7) << 9;
                         }
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {

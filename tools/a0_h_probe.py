@@ -1,8 +1,10 @@
-"""scratch probe run on the GPU box (not a test): -A0 aa x genome engines, tiles pipelined or one wave per problem"""
+"""-A0 aa x genome engines on sub-ranges of a fixture, tiles pipelined or one wave per problem (GPU box:
+python tools/a0_h_probe.py [n])"""
 import os
 import sys
 import time
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import spdg
 from tests.conftest import golden_files
 from spaln_amd import abi, engine, synth

@@ -954,7 +954,10 @@ int spdp_scalar_udh(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* 
         it.n_im = n_im; it.imd_intvl = imd_intvl;
         if (it.a_left + (int64_t) n_im * imd_intvl > it.a_right + imd_intvl) { ctx->err = "intermediate rows beyond the query range"; return -1; }
     }
-    if (run.build(&st, items, 5) || run.launch() || run.sync()) return -1;
+    // test hook: the same call on hirschbergS1 (the -A1 linear-space engine, spdp_exact<2> + spdp_udh_cpos), which the ABI
+    // otherwise reaches through alignS_ng only; imd_intvl is then the engine's own (a_right - a_left + n_im) / (n_im + 1)
+    const int flav = getenv("SPDP_UDH_ENGINE_A1") ? 8 : 5;
+    if (run.build(&st, items, flav) || run.launch() || run.sync()) return -1;
     std::vector<int32_t> s, c, r;
     std::vector<DevResult> res;
     if (run.fetch_udh(s, c, r) || run.fetch_results(res)) return -1;

@@ -193,3 +193,34 @@ def test_a1_pipelined_equals_one_group(eng, monkeypatch):
         assert want == again, kk
         n_batches += 1
     assert n_batches >= 3
+
+
+def test_a1_linear_space_engine_against_oracle(eng, monkeypatch):
+    """hirschbergS1 + its link walk on their own (test hook SPDP_UDH_ENGINE_A1 on spdp_scalar_udh), stripes pipelined and
+    one group per problem, against the oracle's exact_udh: score, written-back ranges, cpos rows -- wherever the reference's
+    walk is complete (a path down the window's left edge leaves rows of stale link lanes: DESIGN.md section 2)"""
+    from oracle import oracle
+    monkeypatch.setenv("SPDP_UDH_ENGINE_A1", "1")
+    fx = spdg.load([f for f in S_FILES if f.endswith("s1_1400nt.spdg")][0])
+    sc = spdg.scoring(fx, scalar_engines=2)
+    n_cmp = n_skip = 0
+    bad = []
+    for n_im, m in ((1, 300), (4, 700), (7, 1100)):
+        ps = _subranges(fx, 16, 320 + n_im, rows=(m, m))
+        intvl = (m + n_im) // (n_im + 1)
+        want = [oracle.exact_udh(sc, p, n_im) for p in ps.items]
+        for pipe in ("0", "1"):
+            monkeypatch.setenv("SPDP_A1_PIPE", pipe)
+            scores, cpos, ranges, flags = eng.scalar_udh(sc, ps, n_im, intvl)
+            for i, (ws, wc, wr) in enumerate(want):
+                rows = [int(r[0]) for r in wc[:n_im]]
+                if ws <= abi.NEVSEL or any(r == abi.END_OF_ULK for r in rows):
+                    n_skip += 1
+                    continue
+                n_cmp += 1
+                g = [[int(x) for x in r[:8]] for r in cpos[i][:n_im + 1]]
+                w = [[int(x) for x in r[:8]] for r in wc[:n_im + 1]]
+                if int(scores[i]) != ws or ranges[i].tolist() != [int(x) for x in wr] or g != w:
+                    bad.append((n_im, pipe, i, int(scores[i]), ws, ranges[i].tolist(), [int(x) for x in wr], g[:2], w[:2]))
+    assert not bad, bad[:3]
+    assert n_cmp > 3 * n_skip and n_cmp >= 60

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Larger randomised runs of the exactness kernels against the oracle than the test suite affords
 (GPU box: python tools/fuzz_exact.py [n [seed]]).  Protein -A1 forward / linear-space engines and the local-ends
-linear-space kernels of both paths on random sub-ranges with random end-gap flags."""
+linear-space kernels of both paths on random sub-ranges with random end-gap flags.  The last section runs whole -A0 / -A1
+ladders; a mismatch there is looked into with tools/ladder_case.py (the four engine / MaxVmfSpace combinations),
+tools/ladder_subproblems.py (which linear-space call differs) and tools/a1_udh_case.py (that call's cpos rows): so far every
+one was a path down the window's left edge or an empty optimum, where the reference's own link walk reads stale lanes
+(2 of 2400 ladders with seed 99173)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -126,7 +130,8 @@ for eng_sel, simd in ((1, 0), (2, 1)):
                 continue
             n_cmp += 1
             if score != ws or skl.ravel().tolist() != (wskl or []):
-                bad += 1; print("alignS_ng", "-A0" if simd == 0 else "-A1", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), score, ws)
+                bad += 1; print("alignS_ng", "-A0" if simd == 0 else "-A1", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right),
+                                "exg", (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr), score, ws, skl.ravel().tolist()[:12], (wskl or [])[:12])
         print("alignS_ng", "-A0" if simd == 0 else "-A1", "MaxVmfSpace", vmf, ":", n_cmp, "compared", flush=True)
 eng.close()
 print("mismatches:", bad)

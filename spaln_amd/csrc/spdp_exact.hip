@@ -308,6 +308,18 @@ __global__ void __launch_bounds__(64 * XWPB) spdp_exact(ScalarArgs A)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             prefetch(n, r);
         }
+        // PIPE: a stripe is finished the moment its last step is done, not when the wave leaves the loop -- the other
+        // groups of the wave sweep other problems and may go on for thousands of steps, and the stripes below this one
+        // wait for the word (tools/ladder_case.py: two problems in one launch ran as slowly as unpipelined before)
+        auto finish_stripe = [&]() {
+            if (LocalR && k == 0) {
+                int* b = tbest + 6 * st;
+                x_st<true>(b, maxh); x_st<true>(b + 1, max_ulk); x_st<true>(b + 2, max_mr); x_st<true>(b + 3, max_nr); x_st<true>(b + 4, max_ml);
+            }
+            if (st > 0) wait_for(st - 1, INT32_MAX);                      // finished = all stripes up to this one are
+            publish(st, INT32_MAX);
+        };
+        if (PIPE && n >= n9) finish_stripe();
         int jb = 16;                                                      // step within the block; 16 = a new block starts
         for ( ; n < n9; ++n, ++r) {
             if (jb == 16) {
@@ -512,6 +524,7 @@ __global__ void __launch_bounds__(64 * XWPB) spdp_exact(ScalarArgs A)
             H2 = H1; H1 = H; F1 = F;
             if constexpr (FORWARD || UDH) { B2 = B1; B1 = HB; }
             if constexpr (PTR) { C2 = C1; C1 = HC; FC1 = FC; }
+            if (PIPE && n == n9 - 1) finish_stripe();
         }
         if constexpr (UDH) {
             if (is_imd_) {
@@ -525,12 +538,10 @@ __global__ void __launch_bounds__(64 * XWPB) spdp_exact(ScalarArgs A)
     if (PIPE) {
         // finished = every entry holds what the stripes up to this one leave: the stripe above must be finished too
         const int st = my_stripe;
-        if (LocalR && k == 0) {
-            int* b = tbest + 6 * st;
-            x_st<true>(b, maxh); x_st<true>(b + 1, max_ulk); x_st<true>(b + 2, max_mr); x_st<true>(b + 3, max_nr); x_st<true>(b + 4, max_ml);
+        if (ml_first >= ml_end) {                                         // (a problem without rows: no stripe loop ran)
+            if (st > 0) wait_for(st - 1, INT32_MAX);
+            publish(st, INT32_MAX);
         }
-        if (st > 0) wait_for(st - 1, INT32_MAX);
-        publish(st, INT32_MAX);
         if (st != n_stripes - 1) return;
         if (LocalR) {                                                     // stripes in order: the first maximum wins
             maxh = XNEV; max_ulk = 0; max_mr = a_right; max_nr = b_right; max_ml = a_left;

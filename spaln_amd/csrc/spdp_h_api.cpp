@@ -503,7 +503,18 @@ static int pipe_stalled(SpdpContext* ctx, const HPipe& pp, int n_probs)
 }
 
 // ---- scalar forwardH_ng over a list of items (spdp_h_rowwave.hip) ------------------------------
-static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
+// Vmf record budget of one forwardH_ng / forwardH1 call: a record is written where a diagonal run starts, twice per
+// accepted intron and per first-row restart -- far fewer than cells on real inputs.  One per two cells (at least 64 per
+// row) to start with; a problem that outgrows it reports -3 and is run again with eight times as much, up to the
+// four per cell nothing can exceed (as the cDNA path does, DevRun / run_vmf).
+static int64_t vmf_budget_h(const DevProblemH& d, int scale)
+{
+    const int64_t rows = d.a_right - d.a_left + 1;
+    const int64_t full = 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64;
+    return std::min<int64_t>(full, std::max<int64_t>(d.cells / 2, 64 * rows) * scale + 3ll * (d.b_right - d.b_left + 8) + 64);
+}
+
+static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale)
 {
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[H_POOL];
@@ -524,8 +535,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
         // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
         // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
         // (+ what the waves of a pipelined problem may leave unused of the chunks of numbers they reserve)
-        const int64_t cap = forward ? 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64
-                                      + (int64_t) SPDP_VMF_CHUNK * ((d.a_right - d.a_left) / 64 + 2) : 0;
+        const int64_t cap = forward ? vmf_budget_h(d, scale) + (int64_t) SPDP_VMF_CHUNK * ((d.a_right - d.a_left) / 64 + 2) : 0;
         if (cap >= (int64_t) 1 << 31) { ctx->err = "scalar engine: problem too large for its record store"; return -1; }
         d.imd_off = cap;
         vmf_rec += cap;
@@ -589,7 +599,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     for (int i = 0; i < nr; ++i) {
         const int c = out.n_skl[i];
         if (c == -1) { ctx->err = "traceback record buffer overflow (scalar engine)"; return -1; }
-        if (c == -3) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
+        if (c == -3) { out.off[i + 1] = out.off[i]; continue; }             // outgrew its record budget: the caller runs it again, larger
         if (c == -4) { out.n_skl[i] = -3; out.off[i + 1] = out.off[i]; continue; }   // -A1, mode 3: record pointer beyond an int16 lane (undefined)
         out.off[i + 1] = out.off[i] + std::max(c, 0);
     }
@@ -599,6 +609,56 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
             SpdpSkl s; s.m = skl[(size_t) i * skl_cap + k].x; s.n = skl[(size_t) i * skl_cap + k].y;
             out.skl[out.off[i] + k] = s;
         }
+    return 0;
+}
+
+// the same over any number of items: launches whose record space stays below SPDP_VMF_GB (default 32) gigabytes, and
+// another round with a larger budget for the problems that outgrew theirs
+static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
+{
+    SpdpContext* ctx = st.ctx;
+    const int nr = (int) items.size();
+    out = HFwdOut();
+    if (!nr) return 0;
+    if (!forward) return run_scalar_group(st, items, false, out, exact, 1);
+    size_t limit = (size_t) 32 << 30;
+    if (const char* e = getenv("SPDP_VMF_GB")) limit = (size_t) std::max(1, atoi(e)) << 30;
+    std::vector<DevResultH> res(nr);
+    std::vector<int> n_skl(nr, 0);
+    std::vector<std::vector<SpdpSkl>> lists(nr);
+    std::vector<int> todo(nr);
+    for (int i = 0; i < nr; ++i) todo[i] = i;
+    for (int scale = 1; !todo.empty(); scale *= 8) {
+        if (scale > 32768) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
+        std::vector<int> again;
+        for (size_t lo = 0; lo < todo.size(); ) {
+            size_t hi = lo, sum = 0;
+            std::vector<HItem> part;
+            while (hi < todo.size()) {
+                DevProblemH d;
+                fill_desc(st, items[todo[hi]], d);
+                const size_t bytes = (size_t) vmf_budget_h(d, scale) * sizeof(int3);
+                if (hi > lo && sum + bytes > limit) break;
+                sum += bytes; part.push_back(items[todo[hi++]]);
+            }
+            HFwdOut po;
+            if (run_scalar_group(st, part, true, po, exact, scale)) return -1;
+            out.sweep_ms += po.sweep_ms; out.cells += po.cells;
+            for (size_t k = lo; k < hi; ++k) {
+                const int i = todo[k], c = po.n_skl[k - lo];
+                if (c == -3) { again.push_back(i); continue; }
+                res[i] = po.res[k - lo]; n_skl[i] = c;
+                if (c > 0) lists[i].assign(po.skl.begin() + po.off[k - lo], po.skl.begin() + po.off[k - lo] + c);
+            }
+            lo = hi;
+        }
+        todo.swap(again);
+    }
+    out.res.swap(res); out.n_skl.swap(n_skl);
+    out.off.assign(nr + 1, 0);
+    for (int i = 0; i < nr; ++i) out.off[i + 1] = out.off[i] + (int64_t) lists[i].size();
+    out.skl.resize(out.off[nr]);
+    for (int i = 0; i < nr; ++i) std::copy(lists[i].begin(), lists[i].end(), out.skl.begin() + out.off[i]);
     return 0;
 }
 

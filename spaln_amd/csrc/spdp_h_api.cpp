@@ -511,6 +511,7 @@ static int64_t vmf_budget_h(const DevProblemH& d, int scale)
 {
     const int64_t rows = d.a_right - d.a_left + 1;
     const int64_t full = 4 * d.cells + 3ll * (d.b_right - d.b_left + 8) + 64;
+    if (scale == 1 && getenv("SPDP_VMF_TEST_TINY")) return 96;      // test hook: every problem outgrows its first budget
     return std::min<int64_t>(full, std::max<int64_t>(d.cells / 2, 64 * rows) * scale + 3ll * (d.b_right - d.b_left + 8) + 64);
 }
 

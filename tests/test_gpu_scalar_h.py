@@ -208,3 +208,31 @@ def test_a0_ladder_against_oracle(eng):
                 bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, score, ws,
                             skl.ravel().tolist()[:12], (wskl or [])[:12]))
         assert n_ok >= 7 and not bad, bad[:3]
+
+
+def test_record_budget_retry_and_groups(eng, monkeypatch):
+    """forwardH_ng / forwardH1 with Vmf records: a problem that outgrows its record budget is run again with a larger one
+    (test hook SPDP_VMF_TEST_TINY: every first budget is 96 records), and a batch is cut into launches by record memory"""
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + 97)
+    dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+    for sel in (1, 2):
+        sc = spdg.scoring_h(fx, scalar_engines=sel)
+        ps = abi.ProblemSetH()
+        for i in range(24):
+            m = int(rng.integers(40, 200))
+            al = int(rng.integers(0, q["a_right"] - m))
+            bl = int(rng.integers(1, 600))
+            br = int(rng.integers(max(bl + 3 * m + 200, q["b_right"] - 1500), q["b_right"] + 1))
+            ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
+                   fx["phs5"], fx["phs3"], al, al + m, bl, br, (1, 1, 1, 1), exin=(q["b_left"], q["b_right"]), dinc=dinc)
+        want = [(s, skl.tolist(), f) for s, skl, f in eng.align_h(sc, ps)]
+        monkeypatch.setenv("SPDP_VMF_TEST_TINY", "1")
+        got = [(s, skl.tolist(), f) for s, skl, f in eng.align_h(sc, ps)]
+        monkeypatch.delenv("SPDP_VMF_TEST_TINY")
+        assert want == got, sel
+        monkeypatch.setenv("SPDP_VMF_GB", "1")          # (1 GiB: several launches for the -A0 ladder's slabs is not guaranteed; the path runs)
+        again = [(s, skl.tolist(), f) for s, skl, f in eng.align_h(sc, ps)]
+        monkeypatch.delenv("SPDP_VMF_GB")
+        assert want == again, sel

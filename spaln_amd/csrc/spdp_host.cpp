@@ -479,6 +479,7 @@ struct Aligner {
                     run.use_ctx = ctx;
                     if (run.build(st, items, flav) || run.launch() || run.sync()) return -1;
                     kernel_ms += run.kernel_ms; kernel_cells += run.total_cells;
+                    stats[3] += run.kernel_ms; stats[4] += (double) run.total_cells; stats[5] += (double) items.size();
                     std::vector<DevResult> res;
                     std::vector<int> nskl;
                     std::vector<int64_t> off;

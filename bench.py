@@ -45,6 +45,8 @@ VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10,
 # counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
 # the figure an upper bound for the 8-byte column-record reads.
 PMC_TRAFFIC_BYTES = int((2 * 49828262 + 178326372) * 1024 / 2)
+# one spdp_rowwave_udh<true> launch of the default --engines a0 workload (profiles/r02_a0_hbm_traffic_pmc.txt)
+PMC_TRAFFIC_BYTES_A0 = (2 * 10706788 + 37364177) * 1024
 # same for one spdh_sweep launch of the default c3 workload (profiles/r02_h_hbm_traffic_pmc.txt)
 PMC_TRAFFIC_BYTES_H = int((2 * 38323706 + 146477017) * 1024)
 
@@ -498,8 +500,10 @@ def main():
                        "fwd_problems": int(stats[-1]["fwd_problems"]), "tb_bytes": int(stats[-1]["tb_bytes"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4 and not exact) else None,
-                         "traffic_source": "profiles/r02_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
+                         "traffic": (PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4 and not exact) else
+                                     PMC_TRAFFIC_BYTES_A0 if (args.engines == "a0" and args.queries == 1000 and world == 1 and not c4) else None),
+                         "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r02_hbm_traffic_pmc.txt") +
+                                           " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
                          "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
                                    ("spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
                          "valu": (_valu_roofline(udh_cells, "a0_udh", k_ms) if args.engines == "a0" else None) if exact

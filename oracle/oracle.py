@@ -26,7 +26,23 @@ def build(force: bool = False) -> str:
         tmp = f"{_SO}.{os.getpid()}.tmp"          # several test processes may get here at once: build aside, swap in
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp] + srcs)
         os.replace(tmp, _SO)
+    build_walk_check(force)
     return _SO
+
+
+_WALK_SO = os.path.join(_HERE, "libwalkcheck.so")
+
+
+def build_walk_check(force: bool = False) -> str:
+    """the seeded walk's CPU checker: the product's host walk (a header) compiled with callbacks in place of the device"""
+    srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk.h"),
+            os.path.join(_HERE, "..", "include", "spdp.h")]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    if force or not os.path.exists(_WALK_SO) or os.path.getmtime(_WALK_SO) < newest:
+        tmp = f"{_WALK_SO}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, _WALK_SO)
+    return _WALK_SO
 
 
 def lib():
@@ -103,6 +119,21 @@ def scalar_forward(sc, p, w=None):
     rc = lib().orc_scalar_forward(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), C.byref(skl), C.byref(n))
     if rc:
         raise RuntimeError(f"orc_scalar_forward rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out
+
+
+def scalar_forward_cut(sc, p, w, cut_l: int, cut_r: int):
+    """trcbkalignS_ng(wdw, spj, mc): forwardS_ng jumping over the genomic range (cut_l, cut_r] (shortcutS_ng)."""
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_scalar_forward_cut(C.byref(sc), C.byref(p), C.byref(w), C.c_int(cut_l), C.c_int(cut_r),
+                                      C.byref(s), C.byref(skl), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_scalar_forward_cut rc={rc}")
     out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
     if n.value:
         C.CDLL(None).free(skl)

@@ -23,6 +23,10 @@
 //   -u list  extra explicit UDH runs with these n_im (comma separated)
 //   -A list  only these engine selectors in the Aln2-surface section, and no engine-level section: fixtures beyond
 //            1472 nt, where the reference's int16 engines (-A1..3) are erratic and -A0 is the truth
+//   -X n     algmode.crs (-yX)                        -C     -LC (local, LocalC)
+//   -Q n     seeded path (algmode.qck = n, 1..3): the HSPs of geneorient() as match_2 obtains them (spaln.cc:773-776) are
+//            dumped as inputs, alignS_ng(seqs, pwd, gsi, 1) runs with seeding on, and every Wilip the walk constructs on a
+//            sub-range (seededS_ng at the higher levels, fwd2s1.cc:2609) is recorded through the tap below
 //   -O       alignS_ng(ori = 3) fixture: both strands prepared as spaln.cc:1137-1152 does (genomicseq, ori = 3),
 //            the reverse-strand problem dumped under r_*, the result of alignS_ng(seqs, pwd, gsi, 3) under ori3_*
 
@@ -31,10 +35,37 @@
 #include <climits>
 #include "fwd2s1_simd.h"
 
+// ---- Wilip tap.  The Makefile links ref_dump against a copy of the reference's wln.o in which objcopy has renamed the
+// two symbols of Wilip::Wilip(const Seq**, const PwdB*, int) (complete / base object constructor) -- the object code is
+// the reference's, untouched.  The definition below takes the original name, calls the renamed original and, while the
+// tap is on, records what the constructor produced: that is how a fixture carries the HSP units the reference's own
+// seeded walk saw at its recursion levels.
+extern "C" void ref_wilip_ctor(Wilip* self, const Seq** seqs, const PwdB* pwd, int level);
+static bool		wilip_tap_on = false;
+static std::vector<int>	wilip_tap_log;
+Wilip::Wilip(const Seq* seqs[], const PwdB* pwd, const int level)
+{
+	ref_wilip_ctor(this, seqs, pwd, level);
+	if (!wilip_tap_on) return;
+	std::vector<int>& L = wilip_tap_log;
+	const int hd[6] = {level, seqs[0]->left, seqs[0]->right, seqs[1]->left, seqs[1]->right, wlu? nwlu: 0};
+	L.insert(L.end(), hd, hd + 6);
+	for (int u = 0; wlu && u < nwlu; ++u) {
+	    const WLUNIT& x = wlu[u];
+	    const int uh[6] = {x.num, x.nid, x.tlen, x.llmt, x.ulmt, (int) x.scr};
+	    L.insert(L.end(), uh, uh + 6);
+	    for (int j = 0; j <= x.num; ++j) {		// num HSPs + the slot behind them that seededS_ng overwrites
+		const JUXT& t = x.jxt[j];
+		const int jr[5] = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		L.insert(L.end(), jr, jr + 5);
+	    }
+	}
+}
+
 
 int main(int argc, const char** argv)
 {
-	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0, ori3 = 0;
+	int	ls = 2, sh = 100, local = 0, ubh = 0, nquant = 0, ori3 = 0, seeded_q = 0, crs = -1;
 	long	vmfspace = 0;
 const	char*	exg = 0;
 	std::vector<int>	udh_list, alg_list;
@@ -46,6 +77,9 @@ const	char*	exg = 0;
 		case 'w': sh = atoi(argv[++ai]); break;
 		case 'L': local = 1; break;
 		case 'O': ori3 = 1; break;
+		case 'Q': seeded_q = atoi(argv[++ai]) & 3; break;
+		case 'X': crs = atoi(argv[++ai]); break;	// algmode.crs as -yX sets it (simmtx.cc:704): 0 = same species
+		case 'C': local = 3; break;			// -LC: local with LocalC (algmode.lcl & 32)
 		case 'A': {
 		    const char* p = argv[++ai];
 		    while (*p) {
@@ -88,6 +122,8 @@ const	char*	outfn = argv[ai + 2];
 	alprm.sh = sh;
 	alprm.ubh = ubh;
 	if (local) algmode.lcl |= 16;
+	if (local == 3) algmode.lcl |= 32;
+	if (crs >= 0) algmode.crs = crs;
 	if (vmfspace) MaxVmfSpace = (int) vmfspace;
 	if (nquant) IntronPrm.nquant = nquant;
 	OutPrm.all_out = 1;
@@ -120,6 +156,17 @@ const	char*	outfn = argv[ai + 2];
 	    b->exg_seq(exg[2] == '1', exg[3] == '1');
 	}
 	b->exin = new Exinon(b, pwd, false);
+	if (seeded_q) {
+	    // the two-sequence set-up of match_2 (spaln.cc:742-776): the reverse strand beside the forward one, HSPs of
+	    // the lowest level that finds any from geneorient()
+	    algmode.qck = seeded_q;
+	    Seq* const	b0 = b;
+	    b->comrev(seqs + 2);
+	    seqs[2]->exin = new Exinon(seqs[2], pwd, false);
+	    const int np = geneorient(seqs, pwd);
+	    if (b != b0) { fprintf(stderr, "ref_dump -Q: the reverse strand won geneorient(); not a fixture\n"); return 3; }
+	    if (np == 0) fprintf(stderr, "ref_dump -Q: no HSP at any level\n");
+	}
 
 	Writer	w(outfn);
 // ---- inputs: everything the engines read from one strand's (query, genome) pair; `pre` = "" for the
@@ -304,6 +351,57 @@ const	int	nq0 = IntronPrm.nquant;
 	    a->inex = ia; b->inex = ib;
 	};
 	char	nm[48];
+
+	if (seeded_q) {
+	    // alignS_ng with seeding on (fwd2s1.cc:2746 -> globalS_ng :2674 -> seededS_ng :2587 -> interpolateS :2405)
+	    std::vector<int> jx;
+	    for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {
+		const JUXT& t = b->jxt[j];
+		const int jr[5] = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		jx.insert(jx.end(), jr, jr + 5);
+	    }
+	    w.put_i32("seed_jxt", jx);		// CdsNo HSPs + the slot behind them
+	    float smn4 = getsmn(4), w2 = alprm2.w, maxsp = alprm.maxsp;
+	    int smn4b, w2b, maxspb;
+	    memcpy(&smn4b, &smn4, 4); memcpy(&w2b, &w2, 4); memcpy(&maxspb, &maxsp, 4);
+	    std::vector<int> sp = {(int) algmode.qck, b->wllvl, b->jxt? b->CdsNo: 0,
+		(int) setwlprm(0)->width, (int) setwlprm(1)->width, (int) setwlprm(2)->width, (int) setwlprm(3)->width,
+		IntronPrm.elmt, IntronPrm.minl, IntronPrm.tlmt, (int) pwd->Vthr, alprm2.desert, maxspb, (int) algmode.crs,
+		smn4b, w2b, (int) b->exin->gc_sig5, (int) algmode.lcl, (int) a->inex.ori, (int) b->exin->at_sig5};
+	    w.put_i32("seed_params", sp);
+	    // the walk edits its inputs (phs5 / phs3 of the junctions indelfreespjS accepts, :2055-2059; the HSP list's last
+	    // slot, :2633, 2667): every run starts from the same state
+	    std::vector<SGPT2> sg0(b->right - b->left + 1);
+	    for (int n = b->left; n <= b->right; ++n) sg0[n - b->left] = *b->exin->score_n(n);
+	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
+	    if (alg_list.empty()) { alg_list.push_back(0); alg_list.push_back(2); }
+	    for (size_t k = 0; k < alg_list.size(); ++k) {
+const		int	alg = alg_list[k];
+		algmode.alg = alg;
+		restore();
+		for (int n = b->left; n <= b->right; ++n) *b->exin->score_n(n) = sg0[n - b->left];
+		if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
+		wilip_tap_log.clear();
+		wilip_tap_on = true;
+		Gsinfo	gsi;
+		gsi.skl = alignS_ng(seqs, pwd, &gsi, 1);
+		wilip_tap_on = false;
+		snprintf(nm, sizeof nm, "seed_scr_A%d", alg);
+		w.put_int(nm, (int) gsi.scr);
+		snprintf(nm, sizeof nm, "seed_skl_A%d", alg);
+		w.put_i32(nm, skl2vec(gsi.skl));
+		snprintf(nm, sizeof nm, "seed_wilip_A%d", alg);
+		w.put_i32(nm, wilip_tap_log);
+		if (gsi.skl && gsi.skl->n) {
+		    restore();
+		    for (int n = b->left; n <= b->right; ++n) *b->exin->score_n(n) = sg0[n - b->left];
+		    VTYPE	rs = skl_rngS_ng((const Seq**) seqs, &gsi, pwd);
+		    snprintf(nm, sizeof nm, "seed_rng_scr_A%d", alg);
+		    w.put_int(nm, (int) rs);
+		}
+	    }
+	    return 0;
+	}
 
 	if (ori3) {
 	    // alignS_ng with the default orientation handling (src/fwd2s1.cc:2746-2778 -> infer_orientation :2718)

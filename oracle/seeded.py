@@ -1,0 +1,115 @@
+"""The seeded path (alignS_ng with algmode.qck > 0) on the CPU, for the tests.  TEST INFRASTRUCTURE ONLY.
+
+The walk itself (seededS_ng / interpolateS and the closed-form joins, src/fwd2s1.cc:1899-2672) is the product's host
+code, spaln_amd/csrc/spdp_seeded_walk.h, compiled into oracle/libwalkcheck.so with callbacks where the product has the
+device.  Here those callbacks are bound to the oracle: lspS_ng and trcbkalignS_ng to host_logic.lsp / trcbk over the C
+engines, a trcbkalignS_ng with a cut range to the scalar forward sweep with that range, Wilip to a reply table (what a
+`ref_dump -Q` fixture recorded from the reference's own walk).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from spaln_amd import abi
+from . import oracle, host_logic
+
+_lib = None
+_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)),
+                  C.POINTER(C.c_int32))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(oracle.build_walk_check())
+    return _lib
+
+
+def parse_wilip_log(log) -> dict:
+    """seed_wilip_A* of a fixture -> {(level, a_left, a_right, b_left, b_right): flat unit record}"""
+    log = [int(x) for x in log]
+    out, at = {}, 0
+    while at < len(log):
+        key = tuple(log[at:at + 5])
+        n_units = log[at + 5]
+        at += 6
+        flat = [n_units]
+        for _ in range(n_units):
+            num = log[at]
+            flat += log[at:at + 6 + 5 * (num + 1)]
+            at += 6 + 5 * (num + 1)
+        out.setdefault(key, flat)
+    return out
+
+
+def hsps_of(fx: dict):
+    j = np.asarray(fx["seed_jxt"], dtype=np.int32).reshape(-1, 5)
+    n = int(fx["seed_params"][2])
+    assert j.shape[0] == (n + 1 if n else 0) or (n == 0 and j.shape[0] <= 1)
+    return j, n
+
+
+JOINS = ["abut", "diagonal", "head_cont", "head_short", "head_nogenome", "head_extend", "head_exon", "tail_short",
+         "tail_nogenome", "tail_extend", "tail_exon", "junction", "micro_exon", "shortcut", "backforth", "small_dp",
+         "recurse", "dp", "giveup_localc", "giveup_head", "giveup_tail", "giveup_inner", "pick_unit"]
+
+
+def align_s_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict, simd: int = 2, trace=None, joins=None):
+    """alignS_ng(ori = 1) with seeding on: (gsi->scr, flat SKL [flags, n, m0, n0, ...] or None, status)"""
+    keep = []
+
+    def cb(_user, kind, args, out, n_out):
+        a = [args[i] for i in range(15)]
+        try:
+            if kind == 2:
+                key = (a[14], a[0], a[1], a[2], a[3])
+                if key not in wilip:
+                    raise KeyError(f"no recorded Wilip reply for {key}")
+                data = wilip[key]
+            else:
+                q = host_logic._sub(p, a[0], a[1], a[2], a[3], tuple(a[4:8]))
+                w = abi.Window()
+                w.lw, w.up, w.width = a[8], a[9], a[10]
+                rec = []
+                if kind == 0:
+                    scr = host_logic.lsp(sc, q, w, rec, simd)
+                elif a[11]:
+                    scr, skl = oracle.scalar_forward_cut(sc, q, w, a[12], a[13])
+                    rec = [(int(m), int(n)) for m, n in skl]
+                else:
+                    scr = host_logic.trcbk(sc, q, w, rec, simd)
+                data = [int(scr)] + [int(x) for mn in rec for x in mn]
+            if trace is not None:
+                trace.append((kind, a, list(data)))
+        except Exception as e:                                   # noqa: BLE001 -- reported through the return code
+            keep.append(e)
+            return 1
+        arr = np.asarray(data, dtype=np.int32)
+        keep.append(arr)
+        out[0] = arr.ctypes.data_as(C.POINTER(C.c_int32))
+        n_out[0] = arr.size
+        return 0
+
+    fn = _FN(cb)
+    jx = np.ascontiguousarray(hsps, dtype=np.int32)
+    cap = 1 << 16
+    rec = (abi.Skl * cap)()
+    score, n_rec = C.c_int32(), C.c_int()
+    jn = (C.c_int32 * lib().walk_check_n_joins())()
+    rc = lib().walk_check_run(C.byref(sc), C.byref(sp), C.byref(p), jx.ctypes.data_as(C.c_void_p), C.c_int(n_hsps),
+                              C.c_int(lowest_level), fn, None, C.byref(score), rec, C.c_int(cap), C.byref(n_rec), jn)
+    if joins is not None:
+        for k, v in enumerate(jn):
+            joins[JOINS[k]] = joins.get(JOINS[k], 0) + int(v)
+    errs = [e for e in keep if isinstance(e, Exception)]
+    if errs:
+        raise errs[0]
+    if rc < 0:
+        raise RuntimeError(f"walk_check_run rc={rc}")
+    recs = [(rec[i].m, rec[i].n) for i in range(1, n_rec.value)]      # [0] is globalS_ng's dummy record
+    if len(recs) < 2:
+        return score.value, None, rc
+    fin = host_logic.trim_skl(host_logic.std_skl(recs), p)
+    return score.value, [1, len(fin)] + [x for mn in fin for x in mn], rc

@@ -187,10 +187,15 @@ typedef struct { int val, ptr; } Rvp;
 enum { DIAG = 2, NEWD = 3 };    /* TraceBackDir, src/aln.h:30-35: DEAD, RSRV, DIAG, NEWD, ... */
 
 /* returns the records trcbkalignS_ng hands to the Mfile (end -> start); caller frees *skl */
-int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w,
+/* cut_l < cut_r: forwardS_ng's cut range (`cutrng`, src/fwd2s1.cc:217, 423-430; initS_ng :157-161, lastS_ng :191-204):
+ * after column cut_l of a row the sweep charges the horizontal gap for the cut_r - cut_l columns it jumps over and goes on
+ * behind them; the diagonal arrays are narrower by that much and simply keep counting (shortcutS_ng, :1899-1930) */
+static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w, int cut_l, int cut_r,
                        int32_t* score, SpdpSkl** skl, int32_t* n_skl)
 {
     *skl = 0; *n_skl = 0;
+    const int has_cut = cut_r > cut_l || (cut_l | cut_r) != 0;
+    const int cutlen = has_cut ? cut_r - cut_l : 0;
     if (sc->noll != 2 || !sc->intpen || !p->cano5) return -1;
     if (w->width < 0) { *score = SPDP_NEVSEL; return 0; }
     const int NEV = SPDP_NEVSEL;
@@ -200,7 +205,8 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
     const int LocalR = Local && p->a_exgr && p->b_exgr;
     const int spj = sc->spj;
     const int dim = sc->mtx_dim;
-    const int width = w->width;
+    const int width = w->width - cutlen;
+    if (width < 3) { *score = NEV; return -1; }
     const size_t bufsiz = (size_t) 2 * width;
     Rvp* jbuf = (Rvp*) malloc(bufsiz * sizeof(Rvp));
     for (size_t i = 0; i < bufsiz; ++i) { jbuf[i].val = NEV; jbuf[i].ptr = 0; }
@@ -219,7 +225,10 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
         h->ptr = vmf_add(&vmf, al, n, 0);
         if (p->a_exgl) {
             if (w->up < rr) rr = w->up;
-            while (++r <= rr) { ++h; h->val = 0; *++hd = 1; h->ptr = 0; }
+            while (++r <= rr) {
+                if (has_cut && n == cut_l) { n += cutlen; r += cutlen; continue; }
+                ++h; h->val = 0; *++hd = 1; h->ptr = 0;
+            }
         }
         r = bl - al; rr = bl - ar;
         h = hh0 + r; hd = hdir + r;
@@ -326,20 +335,26 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
                     } else --ncand;
                 }
             }
+            if (has_cut && n == cut_l) {                /* shortcut: the gap runs on over the cut */
+                e1.val += sc->gep * cutlen;
+                *h = e1;
+                f->val = NEV; f->ptr = 0;
+                n += cutlen;
+            }
         }
     }
     int ptr = 0, scr;
     if (LocalR) { ptr = vmf_add(&vmf, maxh_m, maxh_n, maxh_p); scr = maxh_val; }
     else {      /* lastS_ng */
         int rw = w->lw;
-        int rf = bl - ar;
+        int rf = (has_cut ? cut_l : bl) - ar;
         if (rf > rw) rw = rf;
-        Rvp* h = hh0 + rw;
-        Rvp* h9 = hh0 + br - ar;
+        Rvp* h = hh0 + rw - cutlen;
+        Rvp* h9 = hh0 + br - ar - cutlen;
         Rvp* mx = h9;
         if (p->a_exgr) for ( ; h <= h9; ++h) if (h->val > mx->val) mx = h;
         if (p->b_exgr) {
-            rw = imin(w->up, br - al);
+            rw = imin(w->up, br - al) - cutlen;
             for (Rvp* hq = hh0 + rw; hq > h9; --hq) if (hq->val > mx->val) mx = hq;
         }
         const int i = (int) (mx - h9);
@@ -369,6 +384,19 @@ int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWi
     free(jbuf); free(dbuf); free(vmf.rec);
     *score = scr;
     return 0;
+}
+
+int orc_scalar_forward(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w,
+                       int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    return scalar_forward_impl(sc, p, w, 0, 0, score, skl, n_skl);
+}
+
+/* trcbkalignS_ng(wdw, spj, mc) with a cut range: always the scalar engine (src/fwd2s1.cc:1674-1678) */
+int orc_scalar_forward_cut(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w, int cut_l, int cut_r,
+                           int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    return scalar_forward_impl(sc, p, w, cut_l, cut_r, score, skl, n_skl);
 }
 
 /* ---- unidirectional Hirschberg, scalar ------------------------------------------------------

@@ -1,0 +1,71 @@
+// walk_check.cpp -- CPU checker for the seeded walk.  TEST INFRASTRUCTURE ONLY (same rules as spdp_oracle.c: only
+// tests/ load this library; the product never does).
+//
+// The product's host walk (spaln_amd/csrc/spdp_seeded_walk.h: seededS_ng / interpolateS and the closed-form joins,
+// src/fwd2s1.cc:1899-2672) is a header shared by the product library, where its DP calls go to the device, and by this
+// library, where they go to callbacks -- the tests bind those to the oracle's ladder (oracle/host_logic.py: lsp, trcbk)
+// and to the Wilip replies a `ref_dump -Q` fixture recorded.  That way the walk's decisions are checked against the
+// reference's seeded alignments without a GPU, and the -m gpu tests check the same source with the device behind it.
+#include <cstring>
+#include <vector>
+
+#include "../spaln_amd/csrc/spdp_seeded_walk.h"
+
+extern "C" {
+// kind 0: lspS_ng, 1: trcbkalignS_ng, 2: Wilip.  args: a_left, a_right, b_left, b_right, a_exgl, a_exgr, b_exgl, b_exgr,
+// lw, up, width, has_cut, cut_left, cut_right, level.  The callee returns 0 and points *out at int32 data it keeps alive
+// until its next call: kinds 0 / 1: score, then (m, n) pairs; kind 2: the flat unit record of SpdpHspSource.
+typedef int (*WalkCheckFn)(void* user, int kind, const int32_t* args, const int32_t** out, int32_t* n_out);
+}
+
+namespace {
+using namespace spdp_seed;
+
+struct CallbackBackend : DpBackend {
+    WalkCheckFn fn; void* user; bool failed = false;
+    int call(int kind, const Span& s, const SpdpWindow* w, const int* cut, int level, const int32_t** out, int32_t* n)
+    {
+        int32_t args[15] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr, w ? w->lw : 0, w ? w->up : 0,
+                            w ? w->width : 0, cut ? 1 : 0, cut ? cut[0] : 0, cut ? cut[1] : 0, level};
+        return fn(user, kind, args, out, n);
+    }
+    int dp(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
+    {
+        const int32_t* out = nullptr; int32_t n = 0;
+        if (call(kind, s, &w, cut, 0, &out, &n) || n < 1) { failed = true; return SPDP_NEVSEL; }
+        for (int i = 1; i + 1 < n; i += 2) rec.push_back({out[i], out[i + 1]});
+        return out[0];
+    }
+    int lsp(const Span& s, const SpdpWindow& w, std::vector<SpdpSkl>& rec) override { return dp(0, s, w, nullptr, rec); }
+    int trcbk(const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec) override { return dp(1, s, w, cut, rec); }
+    bool wilip(int level, const Span& s, std::vector<Unit>& units) override
+    {
+        const int32_t* out = nullptr; int32_t n = 0;
+        if (call(2, s, nullptr, nullptr, level, &out, &n) || n < 1) { failed = true; return false; }
+        return spdp_seed::parse_units(out, n, units);
+    }
+};
+}   // namespace
+
+extern "C" int walk_check_n_joins() { return SeedWalk::J_COUNT; }
+
+// one query through globalS_ng with seeding on; rec receives the record file (dummy record first), *n_rec its size
+// (cap entries available).  Returns 0, 1 when the walk met a state it does not serve, -1 on a callback failure.
+extern "C" int walk_check_run(const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpProblem* p,
+                              const SpdpJuxt* hsps, int n_hsps, int lowest_level, WalkCheckFn fn, void* user,
+                              int32_t* score, SpdpSkl* rec, int cap, int* n_rec, int32_t* joins /* J_COUNT or null */)
+{
+    CallbackBackend be;
+    be.fn = fn; be.user = user;
+    SeedWalk w;
+    if (!spdp_seed::bind_problem(w, sc, sp, p, hsps, n_hsps, lowest_level)) return -1;
+    w.dp = &be;
+    const Span whole = {p->a_left, p->a_right, p->b_left, p->b_right, p->a_exgl, p->a_exgr, p->b_exgl, p->b_exgr};
+    *score = w.run(whole);
+    *n_rec = (int) w.rec.size();
+    if (joins) for (int k = 0; k < SeedWalk::J_COUNT; ++k) joins[k] = w.joins[k];
+    if ((int) w.rec.size() > cap) return -1;
+    if (!w.rec.empty()) memcpy(rec, w.rec.data(), sizeof(SpdpSkl) * w.rec.size());
+    if (be.failed) return -1;
+    return w.unsupported ? 1 : 0;
+}

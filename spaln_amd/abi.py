@@ -97,7 +97,47 @@ class Problem(C.Structure):
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
         ("cano5", C.c_void_p), ("cano3", C.c_void_p), ("dinc", C.c_void_p),
         ("cip", C.c_void_p),
+        ("phs5", C.c_void_p), ("phs3", C.c_void_p),
     ]
+
+
+class Juxt(C.Structure):                 # SpdpJuxt / JUXT
+    _fields_ = [(k, C.c_int32) for k in ("jx", "jy", "jlen", "nid", "jscr")]
+
+
+class SeedParams(C.Structure):           # SpdpSeedParams
+    _fields_ = [("qck", C.c_int32), ("wl_width", C.c_int32 * 4), ("elmt", C.c_int32), ("minl", C.c_int32),
+                ("vthr", C.c_int32), ("desert", C.c_int32), ("maxsp", C.c_float), ("crs", C.c_int32),
+                ("smn4", C.c_float), ("w2", C.c_float), ("gc_sig5", C.c_int32), ("lcl", C.c_int32),
+                ("codonk1", C.c_int32), ("any", C.c_int32), ("both_ori", C.c_int32)]
+
+
+HSP_UNITS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32))
+HSP_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int32))
+
+
+class HspSource(C.Structure):            # SpdpHspSource
+    _fields_ = [("user", C.c_void_p), ("units", HSP_UNITS_FN), ("release", HSP_RELEASE_FN)]
+
+
+def seed_params_from_fixture(fx: dict) -> SeedParams:
+    """SpdpSeedParams of a `ref_dump -Q` fixture (tests/golden/q*_*.spdg: seed_params + params)"""
+    v = np.asarray(fx["seed_params"], dtype=np.int32)
+    sp = SeedParams()
+    sp.qck = int(v[0])
+    for k in range(4):
+        sp.wl_width[k] = int(v[3 + k])
+    sp.elmt, sp.minl, sp.vthr, sp.desert = int(v[7]), int(v[8]), int(v[10]), int(v[11])
+    sp.maxsp = float(v[12:13].view(np.float32)[0])
+    sp.crs = int(v[13])
+    sp.smn4 = float(v[14:15].view(np.float32)[0])
+    sp.w2 = float(v[15:16].view(np.float32)[0])
+    sp.gc_sig5, sp.lcl = int(v[16]), int(v[17])
+    sp.codonk1 = int(fx["params"][7])
+    sm = np.asarray(fx["sigmodel"], dtype=np.int32)
+    sp.any, sp.both_ori = int(sm[1]), int(sm[3]) if sm.size > 3 else 0
+    return sp
 
 
 class Window(C.Structure):
@@ -209,7 +249,7 @@ class ProblemSet:
         self.items = []
 
     def add(self, a, b, sig5, sig3, a_left=0, a_right=None, b_left=0, b_right=None,
-            exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None, cip=None):
+            exg=(1, 1, 1, 1), cano5=None, cano3=None, dinc=None, cip=None, phs5=None, phs3=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)
         p = Problem()
@@ -237,6 +277,12 @@ class ProblemSet:
             assert cp.size >= a.size + 1
             self._keep.append(cp)
             p.cip = cp.ctypes.data
+        if phs5 is not None:
+            h5 = np.ascontiguousarray(phs5, dtype=np.int8)
+            h3 = np.ascontiguousarray(phs3, dtype=np.int8)
+            assert min(h5.size, h3.size) >= b.size + 1
+            self._keep += [h5, h3]
+            p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
         self.items.append(p)
         return p
 
@@ -419,6 +465,12 @@ class ProblemSetH:
             assert cp.size >= 3 * a.size + 2
             self._keep.append(cp)
             p.cip = cp.ctypes.data
+        if phs5 is not None:
+            h5 = np.ascontiguousarray(phs5, dtype=np.int8)
+            h3 = np.ascontiguousarray(phs3, dtype=np.int8)
+            assert min(h5.size, h3.size) >= b.size + 1
+            self._keep += [h5, h3]
+            p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
         self.items.append(p)
         return p
 

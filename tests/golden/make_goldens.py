@@ -255,7 +255,8 @@ def main():
     env = dict(os.environ, ALN_TAB=ALN_TAB)
     only = set(sys.argv[1:])
     with tempfile.TemporaryDirectory() as td:
-        for name, (window, query, opts) in {**cases(), **dictdisc_cases()}.items():
+        from tests.golden import seed_cases
+        for name, (window, query, opts) in {**cases(), **dictdisc_cases(), **seed_cases.cases()}.items():
             if only and name not in only:
                 continue
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")

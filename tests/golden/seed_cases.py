@@ -1,0 +1,117 @@
+"""Synthetic (window, query) pairs for the seeded-path fixtures (`ref_dump -Q`): a seeded family of genes with
+the kinds of damage that send Aln2s1::interpolateS (src/fwd2s1.cc:2405-2539) down its different joins, and a few
+hand-made pairs for joins the random family rarely reaches.  Used by make_goldens.py (the committed q_* fixtures)
+and by tools/seed_fuzz.py (the same comparison over thousands of seeds, build container only)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from spaln_amd import synth  # noqa: E402
+
+# seeds of the random family that are committed as fixtures: between them they reach every join at least three times
+FIXTURE_SEEDS = [65, 92, 170, 262, 302, 320, 389, 513, 545, 687, 745, 763, 819, 820, 832, 902, 1057, 1287, 1309, 1332,
+                 1362, 1386, 1454, 1572, 1576]
+
+
+def make_case(seed):
+    """(window, query, harness options, description)"""
+    rng = np.random.default_rng(synth.SEED + 40000 + seed)
+    kind = seed % 10
+    n_exons = int(rng.integers(2, 9))
+    mrna = int(rng.integers(200, 1400))
+    sub = float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.15, 0.2]))
+    indel = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
+    exon_min = int(rng.choice([5, 12, 30]))
+    g = synth.make_gene(rng, n_exons=n_exons, mrna_len=mrna, flank=int(rng.integers(100, 1200)),
+                        intron_hi=int(rng.choice([300, 1500, 6000])), sub=sub, indel=indel, exon_min=exon_min)
+    w, q = g.window, g.query
+    opts = ["-Q", str(int(rng.integers(1, 4)))]
+    if rng.random() < 0.4:
+        opts += ["-X", "0"]
+    if rng.random() < 0.1:
+        opts += ["-C"]
+    desc = f"ex{n_exons} m{mrna} sub{sub} indel{indel} emin{exon_min}"
+    if kind == 1:                                   # poly-A tail and junk head on the query
+        q = np.concatenate([synth.random_dna(rng, int(rng.integers(3, 40))), q, np.frombuffer(b"A" * int(rng.integers(5, 40)), dtype=np.uint8)])
+        desc += " junk+polyA"
+    elif kind == 2:                                 # window cut inside the gene: the query overhangs
+        e = g.exons
+        lo = e[0][0] + int(rng.integers(5, max(6, e[0][1] - e[0][0] - 5))) if rng.random() < 0.7 else 0
+        hi = e[-1][1] - int(rng.integers(5, max(6, e[-1][1] - e[-1][0] - 5))) if rng.random() < 0.7 else len(w)
+        w = w[lo:hi]
+        desc += " cut"
+    elif kind == 3:
+        opts.append("-L")
+        desc += " local"
+    elif kind == 4:                                 # a block of the query replaced by noise (HSP desert)
+        a0 = int(rng.integers(0, max(1, len(q) - 60)))
+        ln = int(rng.integers(20, min(400, len(q) - a0)))
+        q = q.copy()
+        q[a0:a0 + ln] = synth.random_dna(rng, ln)
+        desc += f" noise{ln}"
+    elif kind == 5:                                 # an exon missing from the query / duplicated piece
+        k = int(rng.integers(0, n_exons))
+        lens = [b - a for a, b in g.exons]
+        off = sum(lens[:k])
+        q = np.concatenate([g.transcript[:off], g.transcript[off + lens[k]:]])
+        q = synth.mutate(rng, q, sub, indel)
+        desc += f" skip_exon{k}"
+    elif kind == 6:                                 # genomic insertion / deletion inside an exon of the window
+        k = int(rng.integers(0, n_exons))
+        a, b = g.exons[k]
+        at = a + (b - a) // 2
+        if rng.random() < 0.5:
+            w = np.concatenate([w[:at], synth.random_dna(rng, int(rng.integers(1, 30))), w[at:]])
+        else:
+            w = np.concatenate([w[:at], w[at + int(rng.integers(1, min(30, b - at))):]])
+        desc += " exon_indel"
+    elif kind == 7:                                 # small MaxVmfSpace: DP calls take the linear-space branch
+        opts += ["-V", str(int(rng.choice([20000, 100000, 400000])))]
+        desc += " smallV"
+    elif kind == 8:                                 # unrelated pair
+        q = synth.random_dna(rng, int(rng.integers(60, 400)))
+        desc += " random"
+    elif kind == 9:                                 # a tandem copy of the locus: several HSP units
+        w = np.concatenate([w, w[len(w) // 3:]])
+        desc += " tandem"
+    return w, q, opts, desc
+
+
+
+
+def special_cases():
+    """name -> (window, query, options)"""
+    c = {}
+    # the window is the gene exactly, error-free query: the walk closes on an HSP that ends where both sequences end
+    rng = np.random.default_rng(synth.SEED + 49001)
+    g = synth.make_gene(rng, n_exons=4, mrna_len=500, flank=0, intron_hi=400, sub=0.0, indel=0.0)
+    c["q_exact_ends"] = (g.window, g.query, ["-Q", "1"])
+    # short terminal exons, error-free: too short for an HSP, found by first_exon / last_exon's exact search
+    for k, (qck, crs) in enumerate(((1, 1), (3, 0), (2, 1))):
+        rng = np.random.default_rng(synth.SEED + 49010 + k)
+        g = synth.make_gene(rng, n_exons=5, mrna_len=600, flank=400, intron_hi=500, sub=0.0, indel=0.0, exon_min=30)
+        e = g.exons
+        # shrink the first and the last exon to 9-16 nt: window and transcript both lose the outer part
+        cut5 = (e[0][1] - e[0][0]) - int(rng.integers(9, 17))
+        cut3 = (e[-1][1] - e[-1][0]) - int(rng.integers(9, 17))
+        w = np.concatenate([g.window[:e[0][0]], g.window[e[0][0] + cut5:e[-1][1] - cut3], g.window[e[-1][1]:]])
+        q = g.transcript[cut5:len(g.transcript) - cut3]
+        c[f"q_short_ends{k}"] = (w, q, ["-Q", str(qck), "-X", str(crs)])
+    # BASELINE's headline size under -Q7: the DP calls between HSPs stay far below the 1472 rows at which the
+    # reference's int16 engines start re-basing, so its -A2 output IS a witness at 2 kb here
+    for k in range(2):
+        g = synth.make_gene(np.random.default_rng(synth.SEED + 7000 + k), sub=0.06, indel=0.006)
+        c[f"q_c2_seed{k}"] = (g.window, g.query, ["-Q", "3"])
+    return c
+
+
+def cases():
+    c = {}
+    for s in FIXTURE_SEEDS:
+        w, q, opts, _ = make_case(s)
+        c[f"q_{s:04d}"] = (w, q, opts)
+    c.update(special_cases())
+    return c

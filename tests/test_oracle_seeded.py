@@ -1,0 +1,63 @@
+"""The seeded path (alignS_ng with algmode.qck = 1 .. 3, -Q5 .. -Q7) against the reference, on the CPU.
+
+The q_* fixtures are `ref_dump -Q` runs of the compiled reference: the HSPs geneorient() found, every Wilip reply
+its own seeded walk received at the recursion levels, and score + SKL of alignS_ng under -A0 and -A2.  The walk under
+test is the product's host source (spaln_amd/csrc/spdp_seeded_walk.h) compiled into oracle/libwalkcheck.so with the
+oracle's DP ladder where the product has the device; tests/test_gpu_seeded.py runs the same source with the GPU behind it."""
+import numpy as np
+import pytest
+
+from spaln_amd import abi
+from tests import spdg
+from tests.conftest import golden_files, golden_ids
+from oracle import seeded
+
+
+def seeded_inputs(fx, alg):
+    sc = spdg.scoring(fx)
+    ps = abi.ProblemSet()
+    _, p = spdg.problem(fx, ps)
+    h5, h3 = np.ascontiguousarray(fx["phs5"]), np.ascontiguousarray(fx["phs3"])
+    p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
+    p._phs = (h5, h3)
+    sp = abi.seed_params_from_fixture(fx)
+    hsps, n = seeded.hsps_of(fx)
+    return sc, sp, p, hsps, n, int(fx["seed_params"][1]), seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"])
+
+
+@pytest.fixture(scope="module", params=golden_files("q_"), ids=golden_ids("q_"))
+def fx(request):
+    return spdg.load(request.param)
+
+
+@pytest.mark.parametrize("alg,simd", [(0, 0), (2, 2)])
+def test_seeded_alignment_equals_reference(fx, alg, simd):
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, alg)
+    scr, flat, rc = seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, simd)
+    assert rc == 0
+    assert scr == int(fx[f"seed_scr_A{alg}"][0])
+    assert (flat or []) == fx[f"seed_skl_A{alg}"].tolist()
+
+
+def test_fixtures_reach_every_join():
+    """every branch of interpolateS (and bestwlu) is taken by some fixture, most by several"""
+    joins = {}
+    for f in golden_files("q_"):
+        fx = spdg.load(f)
+        sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 2)
+        seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2, joins=joins)
+    missing = [k for k in seeded.JOINS if not joins.get(k)]
+    assert not missing, (missing, joins)
+
+
+def test_dp_calls_are_made():
+    """the walk does hand gaps between HSPs to the DP engines (lspS_ng, trcbkalignS_ng with and without a cut range)"""
+    kinds = set()
+    for name in ("q_0687", "q_0745", "q_c2_seed0"):
+        fx = spdg.load([f for f in golden_files("q_") if f.endswith(name + ".spdg")][0])
+        sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 2)
+        tr = []
+        seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2, trace=tr)
+        for kind, a, _ in tr:
+            kinds.add((kind, bool(a[11])))
+    assert {(0, False), (1, False), (1, True), (2, False)} <= kinds

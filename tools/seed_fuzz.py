@@ -24,68 +24,7 @@ REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
 ENV = dict(os.environ, ALN_TAB=os.path.join(ROOT, "oracle", "_ref", "table"))
 
 
-def make_case(seed):
-    """(window, query, harness options, description)"""
-    rng = np.random.default_rng(synth.SEED + 40000 + seed)
-    kind = seed % 10
-    n_exons = int(rng.integers(2, 9))
-    mrna = int(rng.integers(200, 1400))
-    sub = float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.15, 0.2]))
-    indel = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
-    exon_min = int(rng.choice([5, 12, 30]))
-    g = synth.make_gene(rng, n_exons=n_exons, mrna_len=mrna, flank=int(rng.integers(100, 1200)),
-                        intron_hi=int(rng.choice([300, 1500, 6000])), sub=sub, indel=indel, exon_min=exon_min)
-    w, q = g.window, g.query
-    opts = ["-Q", str(int(rng.integers(1, 4)))]
-    if rng.random() < 0.4:
-        opts += ["-X", "0"]
-    if rng.random() < 0.1:
-        opts += ["-C"]
-    desc = f"ex{n_exons} m{mrna} sub{sub} indel{indel} emin{exon_min}"
-    if kind == 1:                                   # poly-A tail and junk head on the query
-        q = np.concatenate([synth.random_dna(rng, int(rng.integers(3, 40))), q, np.frombuffer(b"A" * int(rng.integers(5, 40)), dtype=np.uint8)])
-        desc += " junk+polyA"
-    elif kind == 2:                                 # window cut inside the gene: the query overhangs
-        e = g.exons
-        lo = e[0][0] + int(rng.integers(5, max(6, e[0][1] - e[0][0] - 5))) if rng.random() < 0.7 else 0
-        hi = e[-1][1] - int(rng.integers(5, max(6, e[-1][1] - e[-1][0] - 5))) if rng.random() < 0.7 else len(w)
-        w = w[lo:hi]
-        desc += " cut"
-    elif kind == 3:
-        opts.append("-L")
-        desc += " local"
-    elif kind == 4:                                 # a block of the query replaced by noise (HSP desert)
-        a0 = int(rng.integers(0, max(1, len(q) - 60)))
-        ln = int(rng.integers(20, min(400, len(q) - a0)))
-        q = q.copy()
-        q[a0:a0 + ln] = synth.random_dna(rng, ln)
-        desc += f" noise{ln}"
-    elif kind == 5:                                 # an exon missing from the query / duplicated piece
-        k = int(rng.integers(0, n_exons))
-        lens = [b - a for a, b in g.exons]
-        off = sum(lens[:k])
-        q = np.concatenate([g.transcript[:off], g.transcript[off + lens[k]:]])
-        q = synth.mutate(rng, q, sub, indel)
-        desc += f" skip_exon{k}"
-    elif kind == 6:                                 # genomic insertion / deletion inside an exon of the window
-        k = int(rng.integers(0, n_exons))
-        a, b = g.exons[k]
-        at = a + (b - a) // 2
-        if rng.random() < 0.5:
-            w = np.concatenate([w[:at], synth.random_dna(rng, int(rng.integers(1, 30))), w[at:]])
-        else:
-            w = np.concatenate([w[:at], w[at + int(rng.integers(1, min(30, b - at))):]])
-        desc += " exon_indel"
-    elif kind == 7:                                 # small MaxVmfSpace: DP calls take the linear-space branch
-        opts += ["-V", str(int(rng.choice([20000, 100000, 400000])))]
-        desc += " smallV"
-    elif kind == 8:                                 # unrelated pair
-        q = synth.random_dna(rng, int(rng.integers(60, 400)))
-        desc += " random"
-    elif kind == 9:                                 # a tandem copy of the locus: several HSP units
-        w = np.concatenate([w, w[len(w) // 3:]])
-        desc += " tandem"
-    return w, q, opts, desc
+from tests.golden.seed_cases import make_case  # noqa: E402
 
 
 def run_case(seed, td, verbose=False, joins=None):

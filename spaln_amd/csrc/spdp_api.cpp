@@ -412,6 +412,7 @@ static int64_t vmf_capacity(const RunItem& it)
 int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int flav)
 {
     store = st; ctx = use_ctx ? use_ctx : st->ctx; flavour = flav; n = (int) items.size();
+    cut = false;
     (void) hipSetDevice(ctx->device);
     if (flav >= 3 && !st->has_exact) {
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
@@ -432,6 +433,14 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         }
         P.a_left = it.a_left; P.a_right = it.a_right; P.b_left = it.b_left; P.b_right = it.b_right;
         P.lw = it.w.lw; P.up = it.w.up; P.width = it.w.width;
+        P.cut_l = P.cut_len = 0;
+        if (it.cut_r > it.cut_l) {              // forwardS_ng over a cut range: its arrays are narrower by the cut (src/fwd2s1.cc:234)
+            if (flav != 3 || it.a_exgl || it.w.width - (it.cut_r - it.cut_l) < 3 || it.cut_l < it.b_left || it.cut_r > it.b_right ||
+                (i > 0 && !cut)) { ctx->err = "bad cut range"; return -1; }
+            cut = true;
+            P.cut_l = it.cut_l; P.cut_len = it.cut_r - it.cut_l;
+            P.width = it.w.width - P.cut_len;
+        } else if (cut) { ctx->err = "bad cut range"; return -1; }
         P.buf_size = it.w.width + 2 * SPDP_NELEM;
         P.flags = (it.a_exgl ? 1 : 0) | (it.a_exgr ? 2 : 0) | (it.b_exgl ? 4 : 0) | (it.b_exgr ? 8 : 0);
         P.n_im = (flav == 2 || flav == 5 || flav == 8 || flav == 9) ? it.n_im : 0;
@@ -610,7 +619,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             mt = std::max(mt, nt);
             for (int t = 0; t < nt; ++t) { h_items.push_back(j); h_items.push_back(t); }
         }
-        if ((!e || atoi(e) != 0) && mt >= 2) {
+        if ((!e || atoi(e) != 0) && mt >= 2 && !cut) {
             pipe_on = true; pipe_tiles = mt;
             pipe_stride = flav == 5 ? 2 + 9 * mt + max_n_im : 2 + 5 * mt;
             pipe_words = ((size_t) n * pipe_stride + 2 + 1) & ~(size_t) 1;
@@ -651,7 +660,7 @@ int DevRun::launch()
         if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, strm()));
         else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, strm()));
         else if (flavour == 5) HIPCHK(spdp_launch_rowwave_udh(&S, strm()));
-        else HIPCHK(spdp_launch_rowwave(flavour == 3, &S, strm()));
+        else HIPCHK(spdp_launch_rowwave(flavour == 3 ? (cut ? 2 : 1) : 0, &S, strm()));
         HIPCHK(hipEventRecord(eve(), strm()));
         if (flavour >= 8) {                 // hirschbergS1's / the local hirschbergS1_wip's link walk
             CposArgs C{};

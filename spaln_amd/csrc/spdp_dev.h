@@ -40,6 +40,7 @@ struct DevProblem {
     int32_t n_im;                  // UDH: number of intermediate rows
     int32_t imd_intvl;             // scalar UDH: rows between intermediates (Aln2s1::imd_intvl)
     int32_t cip_off;               // exact engines: first entry of the query's cip row in ScalarArgs::cip, -1 = none
+    int32_t cut_l, cut_len;        // forwardS_ng with a cut range: the sweep jumps from column cut_l over cut_len columns
     int64_t a_off;                 // into a_codes; residue of row m is a_codes[a_off + m - 1]
     int64_t col_off;               // into cols
     int64_t bnd_off;               // into bnd (entries)

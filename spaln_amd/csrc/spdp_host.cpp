@@ -46,7 +46,7 @@ struct Job {                                // one query through alignS_ng
 };
 
 struct LspItem { int job; Rng r; SpdpWindow w; bool top; };
-struct TbItem  { int job; Rng r; SpdpWindow w; bool top; };     // trcbkalignS_ng call
+struct TbItem  { int job; Rng r; SpdpWindow w; bool top; int cut_l = 0, cut_r = 0; };     // trcbkalignS_ng call (cut_r > cut_l: with a cut range)
 struct UdhItem { int job; Rng r; SpdpWindow w; bool top; int n_imd; bool recursive; int imd_intvl; };
 
 void stripe_of(const Rng& r, int sh, SpdpWindow* w)
@@ -167,6 +167,10 @@ void trim_skl(std::vector<SpdpSkl>& s, const SpdpProblem& p)
     }
 }
 
+}   // namespace
+void trim_skl_of(std::vector<SpdpSkl>& s, const SpdpProblem& p) { trim_skl(s, p); }
+namespace {
+
 // Chunks of one batch run as a software pipeline on lanes of the context (own streams and pools): chunk c starts
 // its first linear-space sweep when that of chunk c - 1 has finished, so the host work, the slab tracebacks and the
 // walk of one chunk run beside the big sweep of the next instead of leaving the GPU idle between launches.
@@ -189,6 +193,9 @@ struct Aligner {
     ChunkGate* gate_out = nullptr;
     SpdpAlignment* out = nullptr;               // where the chunk's alignments go (may be null)
     bool raw = false;                           // lspS_ng level: hand the Mfile records over as they are
+    const SpdpRequests* req = nullptr;          // explicit engine calls on sub-ranges of store entries (the seeded path)
+    int parent(int job) const { return req ? req->parents[base + job] : base + job; }
+    std::vector<TbItem> ctbs;                   // forwardS_ng calls with a cut range
     std::vector<Job> jobs;
     std::vector<LspItem> pending;
     std::vector<TbItem> tbs;                    // forwardS1_wip calls
@@ -375,6 +382,19 @@ struct Aligner {
             Rng r{p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
             SpdpWindow w;
             stripe_of(r, sc.sh, &w);
+            if (req) {                          // a caller that made the reference's decisions up to the engine call itself
+                w = req->windows[base + i];
+                const int kind = req->kinds[base + i];
+                if (kind == 1) { trcbk(i, r, w, true); continue; }
+                if (kind == 2) {                // trcbkalignS_ng(wdw, spj, mc): always the scalar engine (src/fwd2s1.cc:1674-1678)
+                    if (w.width < 0) { set_score(i, true, SPDP_NEVSEL); continue; }
+                    if (bad_range(i, r) || !st->has_exact) { ++unsupported; jobs[i].failed = true; continue; }
+                    TbItem t{i, r, w, true};
+                    t.cut_l = req->cuts[2 * (base + i)]; t.cut_r = req->cuts[2 * (base + i) + 1];
+                    ctbs.push_back(t);
+                    continue;
+                }
+            }
             pending.push_back({i, r, w, true});
         }
         // Queries that go straight to the traceback do not wait for the linear-space rounds of the others: their
@@ -396,7 +416,7 @@ struct Aligner {
             if (may_overlap && !udh.empty() && tbs.size() >= 64) {
                 side_tbs.swap(tbs);
                 std::vector<RunItem> items;
-                for (const TbItem& t : side_tbs) { items.push_back(run_item(base + t.job, t.r, t.w, 0)); items.back().vmf_scale = 1 << 20; }   // (a few rows each)
+                for (const TbItem& t : side_tbs) { items.push_back(run_item(parent(t.job), t.r, t.w, 0)); items.back().vmf_scale = 1 << 20; }   // (a few rows each)
                 side.side = true;
                 if (side.build(st, items, 1) || side.launch()) return -1;
                 lap("side fwd build+launch");
@@ -405,7 +425,7 @@ struct Aligner {
             if (udh.empty()) continue;
             std::vector<RunItem> items;
             for (const UdhItem& u : udh) {
-                items.push_back(run_item(base + u.job, u.r, u.w, u.n_imd));
+                items.push_back(run_item(parent(u.job), u.r, u.w, u.n_imd));
                 items.back().imd_intvl = u.imd_intvl;
             }
             DevRun run;
@@ -472,8 +492,9 @@ struct Aligner {
                     std::vector<RunItem> items;
                     for (size_t k = lo; k < hi; ++k) {
                         const TbItem& t = list[todo[k]];
-                        items.push_back(run_item(base + t.job, t.r, t.w, 0));
+                        items.push_back(run_item(parent(t.job), t.r, t.w, 0));
                         items.back().vmf_scale = scale;
+                        items.back().cut_l = t.cut_l; items.back().cut_r = t.cut_r;
                     }
                     DevRun run;
                     run.use_ctx = ctx;
@@ -502,11 +523,12 @@ struct Aligner {
             return 0;
         };
         if (!stbs.empty() && run_vmf(stbs, 3, "forwardS_ng traceback failed")) return -1;
+        if (!ctbs.empty() && run_vmf(ctbs, 3, "forwardS_ng (cut range) traceback failed")) return -1;
         if (!xtbs.empty() && run_vmf(xtbs, 7, "forwardS1 traceback failed")) return -1;
         // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk (beside the side run, if any)
         if (!tbs.empty()) {
             std::vector<RunItem> items;
-            for (const TbItem& t : tbs) items.push_back(run_item(base + t.job, t.r, t.w, 0));
+            for (const TbItem& t : tbs) items.push_back(run_item(parent(t.job), t.r, t.w, 0));
             DevRun run;
             run.use_ctx = ctx;
             if (run.build(st, items, 1)) return -1;
@@ -562,6 +584,7 @@ struct Aligner {
         out->score = J.score_set ? J.score : SPDP_NEVSEL;
         out->n_skl = 0; out->skl = nullptr;
         if (raw) {                              // what lspS_ng appended to the caller's Mfile (no header, any order)
+            if (J.failed && req) { out->n_skl = -1; return; }   // (explicit requests: the caller must tell "no records" from "not served")
             if (J.failed || J.rec.empty()) return;
             out->n_skl = (int) J.rec.size();
             out->skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * J.rec.size());
@@ -636,7 +659,7 @@ int spdp_batch_homscore(SpdpBatch* bt, int32_t* scores, float* kernel_ms)
 
 static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n,
                           SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells,
-                          double* stats = nullptr, bool raw = false)
+                          double* stats = nullptr, bool raw = false, const SpdpRequests* req = nullptr)
 {
     // big batches run as chunks on lanes of the context, a software pipeline (ChunkGate); SPDP_CHUNKS=1 turns it off
     int n_chunks = n >= 4096 ? 2 : 1;
@@ -655,8 +678,12 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
         a.probs = probs + a.base;
         a.out = out ? out + a.base : nullptr;
         a.raw = raw;
+        a.req = req;
         if (n_chunks > 1) {
-            if (hipEventCreateWithFlags(&gates[c].ev, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate"; return -1; }
+            if (hipEventCreateWithFlags(&gates[c].ev, hipEventDisableTiming) != hipSuccess) {
+                for (int k = 0; k < c; ++k) if (gates[k].ev) (void) hipEventDestroy(gates[k].ev);
+                ctx->err = "hipEventCreate"; return -1;
+            }
             a.gate_out = &gates[c];
             a.gate_in = c > 0 ? &gates[c - 1] : nullptr;
         }
@@ -671,7 +698,11 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     float kms = 0.f; int64_t kc = 0;
     double st_sum[SPDP_N_STATS] = {0};
     for (int c = 0; c < n_chunks; ++c) {
-        if (rc[c]) { if (c > 0) ctx->err = al[c].ctx->err; return -1; }
+        if (rc[c]) {                            // alignments other chunks have already handed over do not outlive the failed call
+            if (c > 0) ctx->err = al[c].ctx->err;
+            if (out) spdp_free_alignments(out, n);
+            return -1;
+        }
         kms += al[c].kernel_ms; kc += al[c].kernel_cells; unsupported += al[c].unsupported; overflowed += al[c].overflowed;
         for (int k = 0; k < SPDP_N_STATS; ++k) st_sum[k] += al[c].stats[k];
     }
@@ -725,6 +756,17 @@ int spdp_lsp_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
     return align_on_store(ctx, &st, probs, n_probs, out, nullptr, nullptr, nullptr, true);
+}
+
+// engine calls a caller has already dispatched itself (the seeded walk, spdp_seeded.cpp): request k runs lspS_ng (kind 0)
+// or trcbkalignS_ng (kind 1; kind 2 with a cut range) on probs[k]'s ranges with windows[k], on the resident inputs of
+// store entry parents[k]; out[k]: score + records as written, n_skl = -1 where the request could not be served
+int spdp_run_requests(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n, const SpdpRequests* req,
+                      SpdpAlignment* out)
+{
+    for (int i = 0; i < n; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    if (n <= 0) return 0;
+    return align_on_store(ctx, st, probs, n, out, nullptr, nullptr, nullptr, true, req);
 }
 
 // alignS_ng(seqs, pwd, gsi, ori = 3) with seeding off (src/fwd2s1.cc:2746-2760): infer_orientation

@@ -234,6 +234,7 @@ struct SpdpContext {
     std::string name;
     std::string err;
     std::vector<SpdpContext*> lanes;  // further lanes of this context (spdp_lane): chunks of a batch run side by side
+    int64_t seed_stats[6] = {0};      // spdp_seeded_stats
 };
 SpdpContext* spdp_lane(SpdpContext* ctx, int i);
 
@@ -268,6 +269,7 @@ struct RunItem {
     int n_im;          // UDH only
     int imd_intvl = 0; // scalar UDH only: Aln2s1::imd_intvl as lspS_ng set it
     int vmf_scale = 1; // Vmf-backed forward runs: 1 = the usual record budget, larger on the retry after an overflow
+    int cut_l = 0, cut_r = 0;   // scalar forward only: forwardS_ng's cut range (cut_r > cut_l), see spdp_rowwave<1, false, true>
 };
 
 // descriptors + work buffers of one engine flavour over a DevStore:
@@ -285,6 +287,7 @@ struct DevRun {
     bool fp_ok = false;                     // scores stay inside the exact fp32 range: spdp_sweep_fp.hip may run it
     void* d_gprog = nullptr;                // progress / barrier words of the cross-CU pipelines
     // -A0 wavefront engines with the tiles of a problem as separate waves (spdp_rowwave<., true>): shares d_gprog
+ bool cut = false;                       // flavour 3 with cut ranges on every item (set by build)
     bool pipe_on = false;
     int pipe_tiles = 0;                     // most tiles of one problem
     int pipe_stride = 0;                    // sync words per problem
@@ -321,6 +324,16 @@ struct DevRun {
 };
 
 RunItem spdp_item_of(const SpdpProblem& p, int parent, int sh);
+// explicit engine calls on sub-ranges of store entries (spdp_host.cpp: spdp_run_requests); all arrays indexed by request
+struct SpdpRequests {
+    const int* parents;            // store entry
+    const SpdpWindow* windows;
+    const uint8_t* kinds;          // 0 lspS_ng, 1 trcbkalignS_ng, 2 trcbkalignS_ng with a cut range
+    const int* cuts;               // 2 per request: cut_l, cut_r (kind 2)
+};
+int spdp_run_requests(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n, const SpdpRequests* req,
+                      SpdpAlignment* out);
+void trim_skl_of(std::vector<SpdpSkl>& s, const SpdpProblem& p);     // trimskl, src/gaps.cc:254-273
 int64_t spdp_cells_w(int a_left, int a_right, int b_left, int b_right, const SpdpWindow& w);
 // corner list of path records (spdp_host.cpp): M_UNIT = 1 nucleotide rows, 3 protein rows
 template <int M_UNIT> std::vector<SpdpSkl> corner_list(std::vector<SpdpSkl> pts);

@@ -88,10 +88,17 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 }
 #define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <int MODE, bool PIPE>
+// CUT: forwardS_ng with a cut range (`cutrng`, src/fwd2s1.cc:217, 423-430; shortcutS_ng :1899-1930): a row that reaches
+// genomic column cut_l charges its horizontal gap for the cut_len columns behind it, leaves {that gap, nothing} in the
+// diagonal arrays and goes on behind the cut -- while the arrays simply keep counting, so a lane's array entry follows
+// its "virtual" column v (the one it would be on without the jump) and everything that names a genomic position
+// (column records, intron lengths, path records) its real column n = v + cut_len once it is past the cut.  Rows that
+// start behind cut_l never jump, as in the reference.  One wave per problem.
+template <int MODE, bool PIPE, bool CUT = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void spdp_rowwave(ScalarArgs A)
 {
     constexpr bool FWD = MODE == 1;
+    static_assert(!CUT || (FWD && !PIPE), "the cut range exists for the forward engine only");
     __shared__ Lds Lw[WPB];
     __shared__ Tables T;
     const DevScoring* sc = A.sc;
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const DevProblem P = A.probs[pi];
     const int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width;
+    const int cut_l = CUT ? P.cut_l : 0, cut_len = CUT ? P.cut_len : 0;
     const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
     const bool Local = sc->local;
     const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
@@ -213,8 +221,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         const bool row = m <= ar;
         const int n_first = max(m - 1 + lw, bl) + 1, n_last = min(m + up, br);
         const bool any = row && n_first <= n_last;
+        // CUT: does my row reach column cut_l, and the last virtual column it visits
+        const bool jumps = CUT && n_first <= cut_l && cut_l <= n_last;
+        const int v_last = jumps ? max(cut_l, n_last - cut_len) : n_last;
+        auto real_col = [&](int v) { return (CUT && jumps && v > cut_l) ? v + cut_len : v; };
         // anti-diagonals this tile sweeps
-        int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? n_last + m : INT32_MIN;
+        int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? v_last + m : INT32_MIN;
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
         if (s_lo > s_hi) continue;                                  // (PIPE: published as finished below)
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
@@ -259,8 +271,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             WAVE_SYNC();
         };
         // the column records of my next two cells are already on their way when a step starts
-        auto ld_col = [&](int nn, int2& c, int& a2) {
-            if (any && nn >= n_first && nn <= n_last) { c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
+        auto ld_col = [&](int vv, int2& c, int& a2) {
+            if (any && vv >= n_first && vv <= v_last) { const int nn = real_col(vv); c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
         };
         int2 col1 = make_int2(0, 0), col2 = make_int2(0, 0); int aux1 = 0, aux2 = 0;
         ld_col(s_lo - m, col1, aux1);
@@ -268,13 +280,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 
         for (int S = s_lo; S <= s_hi; ++S) {
             if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
-            const int n = S - m;
-            const bool on = any && n >= n_first && n <= n_last;
+            const int v = S - m;                                    // the column without the jump: array entry r = v - m
+            const int n = real_col(v);
+            const bool on = any && v >= n_first && v <= v_last;
             const int2 col = col1; const int ax = aux1 & 0xff, adn = aux1 >> 8;
             col1 = col2; aux1 = aux2;
-            ld_col(n + 2, col2, aux2);
+            ld_col(v + 2, col2, aux2);
             if (__ballot(on) == 0) continue;
-            const int r = n - m;
+            const int r = v - m;
             const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
             int hv = L.hv[q], hp = FWD ? L.hp[q] : 0, dir = FWD ? L.dr[q] : 0;     // entry r: the cell above-left
             const int uhv = L.hv[qu], uhp = FWD ? L.hp[qu] : 0;                    // entry r + 1: H of the cell above
@@ -400,6 +413,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     }
                 }
             }
+            if (CUT && on && jumps && v == cut_l) {                  // the gap runs on over the cut: {gap, nothing} stay behind
+                e1v += gep * cut_len;
+                hv = e1v; hp = e1p; fv = NEV; fp = 0;
+            }
             // ---- entry r takes the cell
             if (on) {
                 L.hv[q] = hv; L.fv[q] = fv;
@@ -489,11 +506,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         ptr = vadd(lane == 0, best_m, best_n, best_p);
         ptr = __shfl(ptr, 0);
         R.score = best_v;
-    } else {                                                        // lastS_ng
-        const int r9 = br - ar;
+    } else {                                                        // lastS_ng (entries behind the cut sit cut_len lower)
+        const int r9 = br - ar - cut_len;
         int mx = r9;
-        if (a_exgr) { const int rw = max(lw, bl - ar); if (rw <= r9) mx = scan_best(rw, r9, +1, mx, GH(mx)); }
-        if (b_exgr) { const int rw = min(up, br - al); if (rw > r9) mx = scan_best(r9 + 1, rw, -1, mx, GH(mx)); }
+        if (a_exgr) { const int rw = max(lw, (CUT ? cut_l : bl) - ar) - cut_len; if (rw <= r9) mx = scan_best(rw, r9, +1, mx, GH(mx)); }
+        if (b_exgr) { const int rw = min(up, br - al) - cut_len; if (rw > r9) mx = scan_best(r9 + 1, rw, -1, mx, GH(mx)); }
         const int i = mx - r9;
         int m9 = ar, n9 = br;
         if (i > 0) m9 -= i;
@@ -1026,7 +1043,8 @@ extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipS
         return hipGetLastError();
     }
     const dim3 grd((A.n_probs + WPB - 1) / WPB);
-    if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false>), grd, blk, 0, stream, A);
+    if (forward == 2) hipLaunchKernelGGL((spdp_rowwave<1, false, true>), grd, blk, 0, stream, A);      // every problem with a cut range
+    else if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false>), grd, blk, 0, stream, A);
     else hipLaunchKernelGGL((spdp_rowwave<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }

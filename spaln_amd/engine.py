@@ -30,6 +30,7 @@ EXPORTS = [
     "spdp_poll", "spdp_wait",
     "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
     "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
+    "spdp_align_s_seeded", "spdp_seeded_stats",
 ]
 
 
@@ -304,6 +305,62 @@ class Engine:
             res.append((int(arr[i].score), skl))
         self.lib.spdp_free_alignments(arr, n)
         return res
+
+    def align_s_seeded(self, sc, sp: abi.SeedParams, ps, hsps, lowest_levels, wilip_tables=None, allow_partial=False):
+        """alignS_ng (ori = 1) with seeding on (-Q5 .. -Q7): hsps[i] = (n_i + 1, 5) int32 array (b->jxt with its free slot) or
+        None, lowest_levels[i] = b->wllvl; wilip_tables[i] = {(level, a_left, a_right, b_left, b_right): flat unit record}
+        serves the Wilip calls of the recursion levels (a replay of what a reference run recorded, in the tests; the
+        reference's own wln.cc in an integration).  Returns [(score, skl)] like align_s."""
+        n = len(ps)
+        keep = []
+        jx = (C.c_void_p * n)()
+        nh = (C.c_int32 * n)()
+        lv = (C.c_int32 * n)(*[int(x) for x in lowest_levels])
+        for i, h in enumerate(hsps):
+            if h is None or len(h) < 2:
+                continue
+            a = np.ascontiguousarray(h, dtype=np.int32)
+            keep.append(a)
+            jx[i] = a.ctypes.data
+            nh[i] = a.shape[0] - 1
+        missing = []
+
+        def units(_user, query, level, span, flat, n_flat):
+            key = (level, span[0], span[1], span[2], span[3])
+            tab = wilip_tables[query] if wilip_tables else None
+            if not tab or key not in tab:
+                missing.append((query,) + key)
+                return 1
+            a = np.asarray(tab[key], dtype=np.int32)
+            keep.append(a)                                   # (appends are atomic; the arrays live until the call returns)
+            flat[0] = a.ctypes.data_as(C.POINTER(C.c_int32))
+            n_flat[0] = a.size
+            return 0
+
+        src = abi.HspSource()
+        src.user = None
+        src.units = abi.HSP_UNITS_FN(units)
+        src.release = abi.HSP_RELEASE_FN(lambda _u, _q, _f: None)
+        arr = (abi.Alignment * n)()
+        self.lib.spdp_align_s_seeded.argtypes = [C.c_void_p] * 10
+        rc = self.lib.spdp_align_s_seeded(self.ctx, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
+        if missing:
+            raise KeyError(f"no Wilip reply for {missing[:3]}")
+        if not (allow_partial and rc == 1):
+            self._check(rc, "spdp_align_s_seeded")
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res
+
+    def seeded_stats(self) -> dict:
+        v = (C.c_int64 * 6)()
+        self.lib.spdp_seeded_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.spdp_seeded_stats(self.ctx, v, 6)
+        return dict(zip(("batches", "lsp", "trcbk", "trcbk_cut", "wilip", "walks"), (int(x) for x in v)))
 
     def lsp_s(self, sc, ps):
         """lspS_ng level: (score, raw Mfile records) per problem"""

@@ -110,6 +110,11 @@ typedef struct SpdpProblem {
     /* ---- optional, the seeded path only (spdp_align_s_seeded): per position, index 0 .. b_len ------------------- */
     const int8_t* phs5;                    /* SGPT2::phs5 / phs3 (src/codepot.h:27-32) as Exinon::intron53_n leaves them        */
     const int8_t* phs3;                    /*   (src/codepot.cc:504-518); NULL: derived from cano5 / cano3 by the same rule     */
+    /* ---- optional, with SpdpScoring.sigmodel only ---------------------------------------------------------------- */
+    int32_t exin_left, exin_right;         /* Seq::left / right when the reference built its Exinon (the whole gene window): the
+                                              device computes the signals over [exin_left, exin_right), so that a problem on a
+                                              sub-range (an lspS_ng call between two HSPs) reads what the reference's engines
+                                              read there; both 0: the problem's own b_left / b_right */
 } SpdpProblem;
 
 typedef struct SpdpWindow { int32_t lw, up, width; } SpdpWindow;   /* WINDOW, src/cmn.h:133 */

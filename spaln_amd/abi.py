@@ -98,6 +98,7 @@ class Problem(C.Structure):
         ("cano5", C.c_void_p), ("cano3", C.c_void_p), ("dinc", C.c_void_p),
         ("cip", C.c_void_p),
         ("phs5", C.c_void_p), ("phs3", C.c_void_p),
+        ("exin_left", C.c_int32), ("exin_right", C.c_int32),
     ]
 
 

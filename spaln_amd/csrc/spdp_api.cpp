@@ -257,6 +257,11 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
             SigJob& J = jobs[i];
             J.b_off = J.col_off = col_off[i]; J.out_off = 0; J.pad = 0;
             J.b_len = probs[i].b_len; J.left = probs[i].b_left; J.right = probs[i].b_right;
+            if (probs[i].exin_left || probs[i].exin_right) {      // the range the reference's Exinon covers, not the call's sub-range
+                if (probs[i].exin_left < 0 || probs[i].exin_right > probs[i].b_len || probs[i].exin_left > probs[i].b_left ||
+                    probs[i].exin_right < probs[i].b_right) { ctx->err = "exin_left / exin_right must enclose b_left / b_right"; return -1; }
+                J.left = probs[i].exin_left; J.right = probs[i].exin_right;
+            }
         }
         void* d_b = nullptr;
         HIPCHK(hipMalloc(&d_b, hb.size()));

@@ -20,8 +20,15 @@ struct SpdpCollector {
     SpdpContext* ctx = nullptr;
     SpdpScoring sc;
     std::vector<int16_t> intpen;                // own copy of the length-penalty table
+    SpdpSignalModel model;                      // ... and of the signal model with its two matrices (SpdpScoring::sigmodel)
+    std::vector<float> mtx5, mtx3;
+    int in_flight = 0;                          // callers inside spdp_collector_align_s
     int max_batch = 256, max_wait_us = 200, raw = 0;
     struct Req { const SpdpProblem* p; SpdpAlignment* out; int rc = 0; bool done = false; };
+    int run(const SpdpProblem* probs, int n, SpdpAlignment* outs)
+    {
+        return raw ? spdp_lsp_s(ctx, &sc, probs, n, outs) : spdp_align_s(ctx, &sc, probs, n, outs);
+    }
     std::mutex mu;
     std::condition_variable cv_req, cv_done;
     std::deque<Req*> queue;
@@ -48,15 +55,24 @@ struct SpdpCollector {
             std::vector<SpdpProblem> probs(take.size());
             std::vector<SpdpAlignment> outs(take.size());
             for (size_t i = 0; i < take.size(); ++i) probs[i] = *take[i]->p;
-            const int rc = raw ? spdp_lsp_s(ctx, &sc, probs.data(), (int) probs.size(), outs.data())
-                               : spdp_align_s(ctx, &sc, probs.data(), (int) probs.size(), outs.data());
+            const int rc = run(probs.data(), (int) probs.size(), outs.data());
+            std::vector<int> each(take.size(), rc);
+            std::string why = rc ? ctx->err : std::string();
+            if (rc < 0 && take.size() > 1) {
+                // one caller's malformed problem must not fail the callers that happened to share its batch: once more, one by one
+                for (size_t i = 0; i < take.size(); ++i) {
+                    outs[i].score = SPDP_NEVSEL; outs[i].n_skl = 0; outs[i].skl = nullptr;
+                    each[i] = run(&probs[i], 1, &outs[i]);
+                    if (each[i]) why = ctx->err;
+                }
+            }
             lk.lock();
-            if (rc) err = ctx->err;
+            if (!why.empty()) err = why;
             ++n_batches; n_requests += (int64_t) take.size(); largest = std::max<int64_t>(largest, (int64_t) take.size());
             for (size_t i = 0; i < take.size(); ++i) {
                 *take[i]->out = outs[i];        // ownership of skl passes to the caller (spdp_free_alignments)
                 // rc 1 = some queries of the batch came back without an alignment: only those report it
-                take[i]->rc = rc < 0 ? -1 : ((rc == 1 && !outs[i].skl) ? 1 : 0);
+                take[i]->rc = each[i] < 0 ? -1 : ((each[i] == 1 && !outs[i].skl) ? 1 : 0);
                 take[i]->done = true;
             }
             cv_done.notify_all();
@@ -70,6 +86,12 @@ extern "C" SpdpCollector* spdp_collector_create(SpdpContext* ctx, const SpdpScor
     SpdpCollector* c = new SpdpCollector;
     c->ctx = ctx; c->sc = *sc;
     if (sc->intpen && sc->intpen_len > 0) { c->intpen.assign(sc->intpen, sc->intpen + sc->intpen_len); c->sc.intpen = c->intpen.data(); }
+    if (sc->sigmodel) {                         // the caller may free its model once the collector exists
+        c->model = *sc->sigmodel;
+        if (sc->sigmodel->mtx5) { c->mtx5.assign(sc->sigmodel->mtx5, sc->sigmodel->mtx5 + (size_t) c->model.cols5 * c->model.rows); c->model.mtx5 = c->mtx5.data(); }
+        if (sc->sigmodel->mtx3) { c->mtx3.assign(sc->sigmodel->mtx3, sc->sigmodel->mtx3 + (size_t) c->model.cols3 * c->model.rows); c->model.mtx3 = c->mtx3.data(); }
+        c->sc.sigmodel = &c->model;
+    }
     c->max_batch = std::max(1, max_batch); c->max_wait_us = std::max(0, max_wait_us); c->raw = raw_records ? 1 : 0;
     c->worker = std::thread([c] { c->loop(); });
     return c;
@@ -81,6 +103,10 @@ extern "C" void spdp_collector_destroy(SpdpCollector* c)
     { std::lock_guard<std::mutex> g(c->mu); c->stop = true; }
     c->cv_req.notify_all();
     if (c->worker.joinable()) c->worker.join();
+    {   // callers the last batch woke are still on their way out of cv_done.wait: the mutex must outlive them
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv_done.wait(lk, [&] { return c->in_flight == 0; });
+    }
     delete c;
 }
 
@@ -91,10 +117,12 @@ extern "C" int spdp_collector_align_s(SpdpCollector* c, const SpdpProblem* p, Sp
     r.p = p; r.out = out;
     std::unique_lock<std::mutex> lk(c->mu);
     if (c->stop) return -1;
+    ++c->in_flight;
     if (c->queue.empty()) c->first_arrival = std::chrono::steady_clock::now();
     c->queue.push_back(&r);
     c->cv_req.notify_all();
     c->cv_done.wait(lk, [&] { return r.done; });
+    if (--c->in_flight == 0) c->cv_done.notify_all();       // (spdp_collector_destroy may be waiting for the last caller)
     return r.rc;
 }
 

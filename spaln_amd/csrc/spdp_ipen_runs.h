@@ -35,7 +35,7 @@ __device__ __forceinline__ int ipen_runs_get(const IpenRuns& R, int len, int int
     const int l = max(min(len, intpen_len - 1), SPDP_IPR_BASE);
     int j = R.span[(l - SPDP_IPR_BASE) >> 6];
     j += l >= (int) R.start[j + 1];
-    return R.val[j];
+    return R.val[min(j, SPDP_IPR_RUNS - 1)];        // (a table with 255 steps that ends at 65535: the sentinel is not a run)
 }
 #endif
 #endif

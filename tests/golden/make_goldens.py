@@ -249,11 +249,19 @@ def dictdisc_cases(n=6):
     return c
 
 
+# cases whose outcome in the reference depends on what its heap holds: h1_cut_right makes forwardH1_wip start its
+# traceback outside its own bitmap (an out-of-bounds read, src/fwd2h1_simd.h:756-766, 780); a freshly built reference
+# may stop there with "Unexpected dir".  The committed file is one run's record; the tests treat the case as UNDEFINED
+# (tests/test_gpu_parity_h.py), and a failed regeneration of it is not an error.
+RUN_DEPENDENT = {"h1_cut_right"}
+
+
 def main():
     if not os.path.exists(REF_DUMP):
         sys.exit(f"{REF_DUMP} missing: run `make -C oracle/ref_build` first")
     env = dict(os.environ, ALN_TAB=ALN_TAB)
     only = set(sys.argv[1:])
+    failed = []
     with tempfile.TemporaryDirectory() as td:
         from tests.golden import seed_cases
         for name, (window, query, opts) in {**cases(), **dictdisc_cases(), **seed_cases.cases()}.items():
@@ -266,6 +274,11 @@ def main():
             tmp = os.path.join(td, name + ".spdg")
             r = subprocess.run([REF_DUMP, *opts, gf, qf, tmp], env=env, capture_output=True, text=True)
             status = "ok" if r.returncode == 0 else f"FAILED rc={r.returncode} {r.stderr[-300:]}"
+            if r.returncode != 0:
+                if name in RUN_DEPENDENT:
+                    status = f"run-dependent case, reference stopped (rc={r.returncode}): committed file kept"
+                else:
+                    failed.append(name)
             if r.returncode == 0:
                 if os.path.exists(out) and same_but_boundary_signal(out, tmp):
                     status += " (unchanged)"
@@ -273,6 +286,8 @@ def main():
                     os.replace(tmp, out)
                     status += " (written)"
             print(f"{name:24s} m={len(query):5d} n={len(window):6d} {status}")
+    if failed:
+        sys.exit(f"reference harness failed on: {' '.join(failed)}")
 
 
 def same_but_boundary_signal(old, new):

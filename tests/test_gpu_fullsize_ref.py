@@ -1,12 +1,12 @@
 """The GPU path at BASELINE's headline size against the reference's own output (fixtures c2_seed*, c5_6kb =
 ref_dump -A 0; see tests/test_oracle_fullsize.py for why only -A0 records exist at that size): the `_wip` ladder the
-product runs by default finds the reference's -A0 gene (exon boundaries counted and thresholded, rescored total where
+product runs by default finds the reference's -A0 gene (every exon boundary of it: exact counts per fixture; rescored total where
 the corner lists coincide) and equals the oracle's int32 `_wip` ladder bit for bit."""
 import pytest
 
 from tests import spdg
 from tests.conftest import golden_files
-from tests.test_oracle_fullsize import exon_bounds
+from tests.test_oracle_fullsize import exon_bounds, WIP_VS_A0
 
 pytestmark = pytest.mark.gpu
 BIG = golden_files("c2_") + golden_files("c5_")
@@ -30,7 +30,8 @@ def test_wip_ladder_vs_reference_A0_records():
         ex_g, ex_r = exon_bounds(skl, minl), exon_bounds(ref, minl)
         ends_g = {x for e in ex_g for x in e}
         ends_r = [x for e in ex_r for x in e]
-        assert sum(x in ends_g for x in ends_r) >= 0.85 * len(ends_r), path
+        name = path.split("/")[-1][:-5]
+        assert (sum(x in ends_g for x in ends_r), len(ends_r), skl == ref) == WIP_VS_A0[name], path     # exact counts
         fs = fx["rng_fstat_A0"]
         (h, fst, recs), = eng.skl_rng_s(sc, ps, [skl], codonk1=fx["prm"]["codonk1"], minl=minl, jneibr=int(fs[6]), lsg=int(fs[7]))
         if skl == ref:                                              # same traceback -> the CLI's score and exon table
@@ -38,7 +39,7 @@ def test_wip_ladder_vs_reference_A0_records():
             assert recs.tolist() == fx["rng_eij_A0"].reshape(-1, 21).tolist(), path
             n_same += 1
     eng.close()
-    assert n_same >= 1
+    assert n_same == 3
 
 
 def test_A0_ladder_equals_reference_at_full_size():

@@ -24,6 +24,7 @@
 //   -A list  only these engine selectors in the Aln2-surface section, and no engine-level section: fixtures beyond
 //            1472 nt, where the reference's int16 engines (-A1..3) are erratic and -A0 is the truth
 //   -X n     algmode.crs (-yX)                        -C     -LC (local, LocalC)
+//   -B       the -O12 record files of the -A0 and -A2 alignments instead of their -O4 text (keys o12_grd / o12_erd / o12_qrd)
 //   -Q n     seeded path (algmode.qck = n, 1..3): the HSPs of geneorient() as match_2 obtains them (spaln.cc:773-776) are
 //            dumped as inputs, alignS_ng(seqs, pwd, gsi, 1) runs with seeding on, and every Wilip the walk constructs on a
 //            sub-range (seededS_ng at the higher levels, fwd2s1.cc:2609) is recorded through the tap below
@@ -41,6 +42,8 @@
 // tap is on, records what the constructor produced: that is how a fixture carries the HSP units the reference's own
 // seeded walk saw at its recursion levels.
 extern "C" void ref_wilip_ctor(Wilip* self, const Seq** seqs, const PwdB* pwd, int level);
+bool	g_o12_mode = false;
+char	g_o12_prefix[256];
 static bool		wilip_tap_on = false;
 static std::vector<int>	wilip_tap_log;
 Wilip::Wilip(const Seq* seqs[], const PwdB* pwd, const int level)
@@ -78,6 +81,7 @@ const	char*	exg = 0;
 		case 'L': local = 1; break;
 		case 'O': ori3 = 1; break;
 		case 'Q': seeded_q = atoi(argv[++ai]) & 3; break;
+		case 'B': g_o12_mode = true; break;
 		case 'X': crs = atoi(argv[++ai]); break;	// algmode.crs as -yX sets it (simmtx.cc:704): 0 = same species
 		case 'C': local = 3; break;			// -LC: local with LocalC (algmode.lcl & 32)
 		case 'A': {
@@ -136,6 +140,7 @@ const	char*	outfn = argv[ai + 2];
 	if (svr.nextseq(b, 1) == IS_END) { fprintf(stderr, "no genome\n"); return 1; }
 	if (svr.nextseq(a, 0) != IS_OK) { fprintf(stderr, "no query\n"); return 1; }
 	if (rng4[0] >= 0) { a->left = rng4[0]; a->right = rng4[1]; b->left = rng4[2]; b->right = rng4[3]; }
+	if (g_o12_mode) o12_begin();
 	if (a->isprotein()) return dump_protein(seqs, exg, udh_list, outfn);
 	b->inex.intr = algmode.lsg;
 	makeWlprms(prePwd((const Seq**) seqs));
@@ -530,7 +535,8 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		    if (tf) {
 			static bool out_ready = false;
 			if (!out_ready) { (void) setup_output(EXN_FORM, 0, false); out_ready = true; }	// sets the printer's out_form (sqpr.cc:95-118)
-			gsi.printgene(seqs, EXN_FORM, tf);
+			if (g_o12_mode) o12_write(gsi, seqs);
+			else gsi.printgene(seqs, EXN_FORM, tf);
 			const long len = ftell(tf);
 			std::vector<unsigned char> txt(len > 0 ? len : 0);
 			rewind(tf);
@@ -584,5 +590,6 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		}
 	    }
 	}
+	if (g_o12_mode) o12_collect(w, seqs[1]);
 	return 0;
 }

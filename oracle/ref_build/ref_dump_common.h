@@ -83,4 +83,40 @@ inline void set_default_params()	// same calls, same order as the CLI default se
 
 
 int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn);
+
+// -B: the reference writes its -O12 record files (<prefix>.grd / .erd / .qrd, Gsinfo::ExonForm with BIN_FORM,
+// sqpr.cc:853-985) for the -A0 and the -A2 alignment of the case instead of the -O4 text; the three files end up in the
+// fixture byte for byte.  (One process can do one or the other: ExonForm opens its files on its first call only.)
+extern bool	g_o12_mode;
+extern char	g_o12_prefix[256];
+inline void o12_begin()
+{
+	snprintf(g_o12_prefix, sizeof g_o12_prefix, "/tmp/ref_dump_o12_%d", (int) getpid());
+	if (!dbs_dt[0]) dbs_dt[0] = new DbsDt('f');
+	dbs_dt[0]->dbsid = "fixture_db";		// ExonForm starts the .qrd file with the database name (sqpr.cc:886)
+}
+inline void o12_write(Gsinfo& gsi, Seq** seqs)
+{
+	gsi.setprefix(g_o12_prefix);
+	gsi.printgene(seqs, BIN_FORM, 0);
+}
+inline void o12_collect(Writer& w, const Seq* gene)
+{
+	closeGeneRecord();
+const	char*	ext[3] = {".grd", ".erd", ".qrd"};
+const	char*	key[3] = {"o12_grd", "o12_erd", "o12_qrd"};
+	for (int k = 0; k < 3; ++k) {
+	    std::string fn = std::string(g_o12_prefix) + ext[k];
+	    std::vector<unsigned char> buf;
+	    if (FILE* f = fopen(fn.c_str(), "rb")) {
+		int c;
+		while ((c = fgetc(f)) != EOF) buf.push_back((unsigned char) c);
+		fclose(f);
+		remove(fn.c_str());
+	    }
+	    w.put(key[k], 1, buf.data(), buf.size());
+	}
+	std::vector<int> meta = {gene->did};
+	w.put_i32("o12_meta", meta);
+}
 #endif

@@ -310,7 +310,8 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		    if (tf) {
 			static bool out_ready = false;
 			if (!out_ready) { (void) setup_output(EXN_FORM, 0, false); out_ready = true; }	// sets the printer's out_form (sqpr.cc:95-118)
-			gsi.printgene(seqs, EXN_FORM, tf);
+			if (g_o12_mode) o12_write(gsi, seqs);
+			else gsi.printgene(seqs, EXN_FORM, tf);
 			const long len = ftell(tf);
 			std::vector<unsigned char> txt(len > 0 ? len : 0);
 			rewind(tf);
@@ -355,5 +356,6 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 		}
 	    }
 	}
+	if (g_o12_mode) o12_collect(w, seqs[1]);
 	return 0;
 }

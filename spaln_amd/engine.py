@@ -112,7 +112,7 @@ def load_library() -> C.CDLL:
 
 
 def exon_form(lib, eij, *, scr, gene_codes, protein, q_left, q_right, q_len, gmap, qmap, scale, aln_scale,
-              q_many=1, q_sens=0, hsp_len=0, qname="qry", gname="win", header=False):
+              q_many=1, q_sens=0, hsp_len=0, qname="qry", gname="win", header=False, gene_id=0):
     """Gsinfo::ExonForm from EISCR records (k x 21 ints, as skl_rng_s / _h return them): (exon records, gene record,
     the -O4 text).  Host only: works without a GPU."""
     eij = np.ascontiguousarray(eij, dtype=np.int32).reshape(-1, 21)
@@ -123,6 +123,7 @@ def exon_form(lib, eij, *, scr, gene_codes, protein, q_left, q_right, q_len, gma
     a.q_left, a.q_right, a.q_len, a.q_many, a.q_sens = int(q_left), int(q_right), int(q_len), int(q_many), int(q_sens)
     a.gmap = abi.SiteMap(int(gmap[0]), int(gmap[1])); a.qmap = abi.SiteMap(int(qmap[0]), int(qmap[1]))
     a.scale, a.aln_scale, a.hsp_len = float(scale), float(aln_scale), int(hsp_len)
+    a.gene_id = int(gene_id)
     lib.spdp_exon_form.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.spdp_exon_form_text.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     ex = (abi.ExonRecord * max(1, eij.shape[0]))()

@@ -256,6 +256,12 @@ def dictdisc_cases(n=6):
 RUN_DEPENDENT = {"h1_cut_right"}
 
 
+# -O12 record files (ref_dump -B): the same cases once more, the fixture trimmed to what the record writers read
+O12_CASES = ["s1_basic", "s1_indels", "s1_1400nt", "s1_local", "c2_seed0", "h1_basic", "h1_frameshift", "h1_400aa", "h1_query_indel"]
+O12_KEEP = ("b_codes", "params", "rng_eij_A0", "rng_eij_A2", "rng_exnprm_A0", "rng_exnprm_A2", "o12_grd", "o12_erd",
+            "o12_qrd", "o12_meta")
+
+
 def main():
     if not os.path.exists(REF_DUMP):
         sys.exit(f"{REF_DUMP} missing: run `make -C oracle/ref_build` first")
@@ -264,7 +270,9 @@ def main():
     failed = []
     with tempfile.TemporaryDirectory() as td:
         from tests.golden import seed_cases
-        for name, (window, query, opts) in {**cases(), **dictdisc_cases(), **seed_cases.cases()}.items():
+        base = {**cases(), **dictdisc_cases()}
+        o12 = {"o12_" + k: (base[k][0], base[k][1], ["-B"] + base[k][2]) for k in O12_CASES}
+        for name, (window, query, opts) in {**base, **seed_cases.cases(), **o12}.items():
             if only and name not in only:
                 continue
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
@@ -279,6 +287,10 @@ def main():
                     status = f"run-dependent case, reference stopped (rc={r.returncode}): committed file kept"
                 else:
                     failed.append(name)
+            if r.returncode == 0 and name.startswith("o12_"):
+                from tests import spdg
+                fx = spdg.load(tmp)
+                spdg.save(tmp, {k: fx[k] for k in O12_KEEP if k in fx})
             if r.returncode == 0:
                 if os.path.exists(out) and same_but_boundary_signal(out, tmp):
                     status += " (unchanged)"

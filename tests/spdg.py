@@ -29,6 +29,19 @@ def load(path: str) -> dict:
     return out
 
 
+def save(path: str, arrays: dict) -> None:
+    """the container format of ref_dump's Writer (make_goldens.py trims the -B fixtures with it)"""
+    code = {np.dtype(v): k for k, v in _DT.items()}
+    with open(path, "wb") as f:
+        f.write(b"SPDG1\0\0\0")
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            f.write(name.encode().ljust(32, b"\0")[:32])
+            f.write(struct.pack("<II", code[a.dtype], a.size))
+            raw = a.tobytes()
+            f.write(raw + b"\0" * (-len(raw) % 8))
+
+
 def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
     q = fx["prm"]
     kw = dict(mtx=fx["mtx"], mtx_dim=int(fx["mtx_dim"][0]), gop=q["gop"], gep=q["gep"],

@@ -15,14 +15,14 @@ from tests.conftest import golden_files
 FILES = [f for pre in ("s1_", "c2_", "o3_", "h1_", "c1_") for f in golden_files(pre)]
 
 
-def _text(fx, alg, protein, lib, header):
+def _text(fx, alg, protein, lib, header, gene_id=0):
     prm = [int(x) for x in fx[f"rng_exnprm_A{alg}"]]
     scale = np.array(prm[0], dtype=np.int32).view(np.float32)
     aln_scale = np.array(prm[1], dtype=np.int32).view(np.float32)
     gmap, qmap = (prm[2], prm[3] - prm[2]), (prm[6], prm[7] - prm[6])
     return engine.exon_form(lib, fx[f"rng_eij_A{alg}"], scr=prm[11], gene_codes=fx["b_codes"], protein=protein,
                             q_left=prm[12], q_right=prm[13], q_len=prm[8], q_many=prm[10], q_sens=prm[9],
-                            gmap=gmap, qmap=qmap, scale=float(scale), aln_scale=float(aln_scale), header=header)
+                            gmap=gmap, qmap=qmap, scale=float(scale), aln_scale=float(aln_scale), header=header, gene_id=gene_id)
 
 
 def test_record_layouts():
@@ -72,3 +72,36 @@ def test_o12_files(tmp_path):
     genes = (abi.GeneRecord * 3).from_buffer_copy(grd)
     assert [g.Nrecord for g in genes] == [0, counts[0], counts[0] + counts[1]]
     assert [g.Rid for g in genes] == [1, 2, 3] and [g.nexn for g in genes] == counts
+
+
+O12 = golden_files("o12_")
+
+
+@pytest.mark.parametrize("path", O12, ids=[f.split("/")[-1][:-5] for f in O12])
+def test_o12_files_equal_the_references_bytes(path, tmp_path):
+    """the reference's own -O12 output (ref_dump -B: Gsinfo::ExonForm with BIN_FORM writes <prefix>.grd / .erd / .qrd for the
+    -A0 and then the -A2 alignment of the case, src/sqpr.cc:853-985) against spdp_exon_form + spdp_o12_* fed the same EISCR
+    records: all three files byte for byte -- struct layouts, float arithmetic, running Nrecord / Rid, padding bytes"""
+    fx = spdg.load(path)
+    lib = engine.load_library()
+    lib.spdp_o12_open.restype = C.c_void_p
+    lib.spdp_o12_open.argtypes = [C.c_char_p, C.c_char_p]
+    lib.spdp_o12_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
+    lib.spdp_o12_close.argtypes = [C.c_void_p]
+    protein = "_h1_" in path
+    prefix = str(tmp_path / "out")
+    h = lib.spdp_o12_open(prefix.encode(), b"fixture_db")
+    assert h
+    n = 0
+    for alg in (0, 2):                                   # the order the harness wrote them in
+        if f"rng_eij_A{alg}" not in fx or not len(fx[f"rng_eij_A{alg}"]):
+            continue
+        ex, g, _ = _text(fx, alg, protein, lib, header=False, gene_id=int(fx["o12_meta"][0]))
+        arr = (abi.ExonRecord * max(1, len(ex)))(*ex)
+        assert lib.spdp_o12_write(h, arr, len(ex), C.byref(g), b"qry") == 0
+        n += 1
+    assert lib.spdp_o12_close(h) == 0 and n >= 1
+    for ext in ("grd", "erd", "qrd"):
+        got = open(f"{prefix}.{ext}", "rb").read()
+        want = bytes(fx[f"o12_{ext}"])
+        assert got == want, (ext, len(got), len(want))

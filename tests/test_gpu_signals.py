@@ -120,3 +120,37 @@ def test_fixture_alignment_from_codes():
         n += 1
     eng.close()
     assert n >= 12
+
+
+@pytest.mark.parametrize("engines", [0, 1])
+def test_subrange_problem_from_codes_reads_the_gene_windows_signals(engines):
+    """an engine call on a SUB-range (what lspS_ng gets between two HSPs) reads the signals of the Exinon built over the
+    whole gene window: with SpdpProblem.exin_left / exin_right a codes-only upload equals the upload of the arrays, and
+    without them (signals recomputed from the sub-range's own left end) it need not"""
+    from spaln_amd import abi, engine
+    eng = engine.Engine(0)
+    n_diff = 0
+    for name in ("s1_basic", "s1_1400nt", "s1_indels", "s1_divergent"):
+        fx = spdg.load([f for f in golden_files("s1_") if f.endswith(name + ".spdg")][0])
+        q = fx["prm"]
+        model = abi.signal_model_from_fixture(fx)
+        got = eng.splice_signals(model, fx["b_codes"], q["b_left"], q["b_right"])
+        if not (np.array_equal(got["sig5"], fx["sig5"]) and np.array_equal(got["sig3"], fx["sig3"])):
+            continue
+        m, n = q["a_right"] - q["a_left"], q["b_right"] - q["b_left"]
+        sub = (q["a_left"] + m // 5, q["a_right"] - m // 4, q["b_left"] + n // 6 + 1, q["b_right"] - n // 7)
+        dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
+        arrays, codes, naive = abi.ProblemSet(), abi.ProblemSet(), abi.ProblemSet()
+        arrays.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], *sub, (0, 0, 0, 0),
+                   cano5=fx["cano5"], cano3=fx["cano3"], dinc=dinc)
+        p = codes.add(fx["a_codes"], fx["b_codes"], None, None, *sub, (0, 0, 0, 0))
+        p.exin_left, p.exin_right = q["b_left"], q["b_right"]
+        naive.add(fx["a_codes"], fx["b_codes"], None, None, *sub, (0, 0, 0, 0))
+        sc_a = spdg.scoring(fx, scalar_engines=engines)
+        sc_c = spdg.scoring(fx, scalar_engines=engines, sigmodel=model)
+        want = eng.lsp_s(sc_a, arrays)[0]
+        have = eng.lsp_s(sc_c, codes)[0]
+        assert have[0] == want[0] and have[1].tolist() == want[1].tolist(), name
+        other = eng.lsp_s(sc_c, naive)[0]
+        n_diff += other[0] != want[0] or other[1].tolist() != want[1].tolist()
+    eng.close()

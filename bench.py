@@ -17,6 +17,7 @@ line also carries the strong-scaling figure (ONE fixed 10k batch sharded with sh
 config.strong_scaling (--scaling strong swaps the two).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -127,7 +128,48 @@ def _ref_cli_chunk(chunk):
     return busy, ok
 
 
+REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+
+
+def _ref_bench_baseline(pairs, band_cells, cell_ratio, alg):
+    """the compiled reference's engines over `pairs` in ONE process (oracle/_ref/ref_bench: parameter tables loaded once,
+    one worker thread per host core taking pairs from a shared counter, per pair what `spaln -Q0 -A<alg>` runs); elapsed =
+    the wall time of its parallel section"""
+    import subprocess
+    import tempfile
+    from spaln_amd import synth
+    ncores = _host_cores()
+    used = min(ncores, len(pairs))
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
+    env["ALN_TAB"] = REF_TAB
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "list.txt"), "w") as lf:
+            for i, (w, q) in enumerate(pairs):
+                gf, qf = os.path.join(td, f"g{i}.fa"), os.path.join(td, f"q{i}.fa")
+                synth.write_fasta(gf, "win", w)
+                synth.write_fasta(qf, "qry", q)
+                lf.write(f"{gf} {qf}\n")
+        r = subprocess.run([REF_BENCH, "-A", str(alg), "-t", str(used), os.path.join(td, "list.txt")], env=env,
+                           capture_output=True, text=True)
+    if r.returncode != 0 or len(r.stdout.split()) != 3:
+        return None
+    done, ok, cdt = int(r.stdout.split()[0]), int(r.stdout.split()[1]), float(r.stdout.split()[2])
+    return {"value": round(band_cells * cell_ratio / cdt / 1e9, 5), "unit": "GCUPS", "cores": used, "kind": "reference",
+            "sample": f"first {len(pairs)} queries through the compiled reference's own engines in one process "
+                      f"(oracle/_ref/ref_bench -A{alg} -t{used}: tables loaded once, per pair what spaln -Q0 runs -- Exinon, "
+                      f"alignS_ng / alignH_ng, skl_rng*_ng; AVX2 build), {done} done, {ok} aligned, {cdt:.2f} s wall"}
+
+
 def _ref_baseline(pairs, protein, band_cells, cell_ratio, alg=2):
+    if os.path.exists(REF_BENCH):
+        rb = _ref_bench_baseline(pairs, band_cells, cell_ratio, alg)
+        if rb:
+            return rb
+    return _ref_cli_baseline(pairs, protein, band_cells, cell_ratio, alg)
+
+
+def _ref_cli_baseline(pairs, protein, band_cells, cell_ratio, alg=2):
     """times the reference CLI on `pairs`, one worker per host core, each running its share of the
     pairs back to back; elapsed = the busiest worker's time inside the reference runs (pool start-up
     and FASTA writing excluded, the CLI's own start-up included); cells = band cells of the sample x
@@ -390,11 +432,37 @@ def main():
         if mode == "weak" or world == 1:
             batch = make(synth.SEED + 1000 * rank, args.queries)
         else:
-            full = make(synth.SEED, args.queries)                  # the same batch on every rank
-            batch = [full[i] for i in shard.shard_range(len(full), rank, world)]
+            # one batch, the same on every rank, sharded by DP cells (longest-processing-time rule): windows differ by a
+            # factor of two and more, equal counts would leave the slowest rank with more cells than the rest
+            full = make(synth.SEED, args.queries)
+            fps = abi.ProblemSet()
+            for w, q, s5, s3, _ in full:
+                fps.add(q, w, s5, s3)
+            costs = []
+            for p in fps.items:
+                win = abi.Window()
+                eng.lib.spdp_stripe(C.byref(p), sc.sh, C.byref(win))
+                costs.append(int(eng.lib.spdp_cells(C.byref(p), C.byref(win))))
+            batch = [full[i] for i in shard.balanced_shards(costs, world)[rank]]
         ps = abi.ProblemSet()
         for w, q, s5, s3, _ in batch:
             ps.add(q, w, s5, s3, **(synth.exact_inputs(w) if exact else {}))
+        h2d = None
+        if mode == args.scaling:
+            # the same step with the batch coming over PCIe first (upload + align): reported beside the headline, which
+            # counts inputs resident in HBM (the bench contract); full column records, ~95 B per genomic position
+            tb0 = time.perf_counter()
+            b0 = eng.upload(sc, ps)
+            b0.align(want=True, convert=False)
+            b0.free()
+            torch.cuda.synchronize()
+            tb1 = time.perf_counter()
+            b0 = eng.upload(sc, ps)
+            tu = time.perf_counter()
+            b0.align(want=True, convert=False)
+            b0.free()
+            h2d = {"upload_ms": round((tu - tb1) * 1e3, 2), "step_ms_incl_upload": round((time.perf_counter() - tb1) * 1e3, 2)}
+            del tb0
         bt = eng.upload(sc, ps)
         for _ in range(args.warmup):
             bt.align(want=True, convert=False)
@@ -406,9 +474,16 @@ def main():
             _, ms, kc = bt.align(want=True, convert=False)
             stats.append(bt.stats())
             step_cells = kc
+        torch.cuda.synchronize()
+        busy = time.perf_counter() - t0                              # this rank's own time, before it waits for the others
         barrier()
         dt = time.perf_counter() - t0
         tot_cells, tot_q = float(step_cells), float(len(batch))
+        rank_busy, rank_cells = [busy], [float(step_cells)]
+        if dist is not None:
+            gb = [None] * world
+            dist.all_gather_object(gb, (busy, float(step_cells)))
+            rank_busy, rank_cells = [x[0] for x in gb], [x[1] for x in gb]
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,7 +494,8 @@ def main():
         band_cells = bt.cells()
         bt.free()
         return {"dt": dt, "total_cells": tot_cells, "total_queries": tot_q, "cells": step_cells, "stats": stats,
-                "batch": batch, "ps": ps, "band_cells": band_cells}
+                "batch": batch, "ps": ps, "band_cells": band_cells, "h2d": h2d,
+                "rank_busy_ms": [round(b / args.steps * 1e3, 2) for b in rank_busy], "rank_cells": [int(c) for c in rank_cells]}
 
     prim = measure(args.scaling)
     other = None
@@ -428,7 +504,9 @@ def main():
         o = measure(om)
         other = {"scaling": om, "value": round(o["total_cells"] * args.steps / o["dt"] / 1e9, 3), "unit": "GCUPS",
                  "queries_total": int(o["total_queries"]), "queries_per_s": round(o["total_queries"] * args.steps / o["dt"], 1),
-                 "ms_per_step": round(o["dt"] / args.steps * 1e3, 3)}
+                 "ms_per_step": round(o["dt"] / args.steps * 1e3, 3),
+                 "rank_busy_ms": o["rank_busy_ms"], "rank_cells": o["rank_cells"],
+                 "sharding": "by DP cells (longest-processing-time rule, shard.balanced_shards)" if om == "strong" else "every rank its own batch"}
     dt, total_cells, cells, stats, batch, ps = (prim["dt"], prim["total_cells"], prim["cells"], prim["stats"],
                                                 prim["batch"], prim["ps"])
 
@@ -493,6 +571,10 @@ def main():
                        "queries_per_gpu": len(batch), "queries_total": int(prim["total_queries"]),
                        "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(prim["total_queries"] * args.steps / dt, 1),
+                       **({"with_h2d": {**prim["h2d"], "queries_per_s": round(len(batch) / (prim["h2d"]["step_ms_incl_upload"] * 1e-3), 1),
+                                        "note": "one step with the batch uploaded first (host arrays -> column records -> HBM), this rank; "
+                                                "the headline counts inputs resident in HBM"}} if prim.get("h2d") else {}),
+                       "rank_busy_ms": prim["rank_busy_ms"],
                        "parallelism": f"{world} rank(s), one per GPU, queries sharded, no collective on the data path",
                        **({"strong_scaling" if other["scaling"] == "strong" else "weak_scaling": other} if other else {}),
                        "udh_ms": round(udh_ms, 3), "udh_gcups": round(udh_cells / udh_ms / 1e6, 2) if udh_ms else None,

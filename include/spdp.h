@@ -339,7 +339,7 @@ void spdp_free_edits(SpdpEdits* out, int n);
 /* ---- device groups: every GPU of the node behind one handle -------------- */
 /* The reference is one process with worker threads (spaln -t N, src/spaln.cc:1389-1468: a master hands
  * whole queries to the workers).  A group owns one context per listed HIP device (a device may be listed more
- * than once); the calls below shard the problem list into contiguous ranges, one per member, run them
+ * than once); the calls below shard the problem list by DP cells, one shard per member, run them
  * concurrently -- problems are independent, nothing is exchanged between devices -- and fill scores / out in
  * the caller's order.  Return values as for the single-device calls (the worst of the members). */
 typedef struct SpdpGroup SpdpGroup;
@@ -347,6 +347,9 @@ SpdpGroup*  spdp_group_create(const int* devices, int n_devices);
 void        spdp_group_destroy(SpdpGroup* g);
 int         spdp_group_size(const SpdpGroup* g);
 const char* spdp_group_last_error(const SpdpGroup* g);
+/* member[i] = the group member that ran problem i in the last call (shards are balanced by DP cells -- spdp_cells /
+ * spdp_cells_h per problem, longest first to the least loaded member --, not by count); returns the number of problems */
+int spdp_group_last_shards(const SpdpGroup* g, int32_t* member, int n);
 int spdp_group_homscore_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, int32_t* scores);
 int spdp_group_align_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, SpdpAlignment* out);
 struct SpdpScoringH;

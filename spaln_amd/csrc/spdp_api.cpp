@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spdp.h"
@@ -167,6 +169,7 @@ void spdp_destroy(SpdpContext* ctx)
     ctx->lanes.clear();
     (void) hipSetDevice(ctx->device);
     for (DevPool& p : ctx->pool) p.release();
+    for (int k = 0; k < 2; ++k) if (ctx->stage_ptr[k]) (void) hipHostFree(ctx->stage_ptr[k]);
     (void) hipEventDestroy(ctx->ev0);
     (void) hipEventDestroy(ctx->ev1);
     (void) hipEventDestroy(ctx->ev2);
@@ -174,6 +177,17 @@ void spdp_destroy(SpdpContext* ctx)
     if (ctx->stream2) (void) hipStreamDestroy(ctx->stream2);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+void* SpdpContext::staging(int k, size_t bytes)
+{
+    if (bytes <= stage_cap[k]) return stage_ptr[k];
+    if (stage_ptr[k]) (void) hipHostFree(stage_ptr[k]);
+    stage_ptr[k] = nullptr; stage_cap[k] = 0;
+    const size_t want = bytes + bytes / 8;
+    if (hipHostMalloc(&stage_ptr[k], want, hipHostMallocDefault) != hipSuccess) { stage_ptr[k] = nullptr; return nullptr; }
+    stage_cap[k] = want;
+    return stage_ptr[k];
 }
 
 const char* spdp_last_error(const SpdpContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -282,29 +296,53 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         (void) hipFree(d_b);
         if (rc) return -1;
     } else {
-        std::vector<int32_t> hc(2 * std::max<int64_t>(col_tot, 1), 0);
-        std::vector<uint8_t> hx(has_exact ? 2 * std::max<int64_t>(col_tot, 1) : 0, 0);
-        for (int i = 0; i < n; ++i) {
-            const SpdpProblem& p = probs[i];
-            if (has_exact) {
-                uint8_t* x = hx.data() + 2 * col_off[i];
-                for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
-                    x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
-                    x[1] = p.dinc[nn];
+        // column records (8 B per genomic position) and class bytes, packed by all host cores into pinned staging
+        // memory the context keeps (a 10 k batch is ~1 GB: one thread and pageable memory took 430 ms, 40 % of a step)
+        const size_t nc = 2 * (size_t) std::max<int64_t>(col_tot, 1);
+        int32_t* hc = (int32_t*) ctx->staging(0, nc * sizeof(int32_t));
+        uint8_t* hx = has_exact ? (uint8_t*) ctx->staging(1, nc) : nullptr;
+        if (!hc || (has_exact && !hx)) { ctx->err = "out of pinned host memory"; return -1; }
+        int n_thr = (int) std::thread::hardware_concurrency();
+        if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
+        n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
+        std::vector<int> t_s5(n_thr, INT32_MIN), t_s3(n_thr, INT32_MIN);
+        std::atomic<int> next_prob{0};
+        auto pack = [&](int t) {
+            int m5 = INT32_MIN, m3 = INT32_MIN;
+            for (;;) {
+                const int i = next_prob.fetch_add(1);
+                if (i >= n) break;
+                const SpdpProblem& p = probs[i];
+                if (has_exact) {
+                    uint8_t* x = hx + 2 * col_off[i];
+                    for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
+                        x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
+                        x[1] = p.dinc[nn];
+                    }
+                    memset(x, 0, 2 * SPDP_COL_PAD);
                 }
+                int32_t* cr = hc + 2 * col_off[i];
+                for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
+                    const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
+                    const uint16_t s3 = (uint16_t) p.sig3[nn];
+                    cr[0] = sc.spj ? (int32_t) ((uint32_t) s5 | ((uint32_t) s3 << 16)) : 0;
+                    m5 = std::max(m5, (int) (int16_t) s5); m3 = std::max(m3, (int) (int16_t) s3);
+                    cr[1] = nn > 0 ? p.b[nn - 1] : 0;
+                }
+                memset(cr, 0, 2 * SPDP_COL_PAD * sizeof(int32_t));
             }
-            int32_t* cr = hc.data() + 2 * col_off[i];
-            for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
-                const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
-                const uint16_t s3 = (uint16_t) p.sig3[nn];
-                cr[0] = sc.spj ? (int32_t) ((uint32_t) s5 | ((uint32_t) s3 << 16)) : 0;
-                max_s5 = std::max(max_s5, (int) (int16_t) s5); max_s3 = std::max(max_s3, (int) (int16_t) s3);
-                cr[1] = nn > 0 ? p.b[nn - 1] : 0;
-            }
+            t_s5[t] = m5; t_s3[t] = m3;
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < n_thr; ++t) th.emplace_back(pack, t);
+            pack(0);
+            for (std::thread& t : th) t.join();
         }
-        HIPCHK(hipMemcpyAsync(d_cols, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (has_exact) HIPCHK(hipMemcpyAsync(d_aux, hx.data(), hx.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));          // hc / hx go out of scope
+        for (int t = 0; t < n_thr; ++t) { max_s5 = std::max(max_s5, t_s5[t]); max_s3 = std::max(max_s3, t_s3[t]); }
+        HIPCHK(hipMemcpyAsync(d_cols, hc, nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (has_exact) HIPCHK(hipMemcpyAsync(d_aux, hx, nc, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));          // the staging buffers are the context's: one upload at a time
     }
     sc.sigmodel = nullptr;                                   // the caller's model is not ours to keep
     // bounds for the fp32 sweeps (DevRun::build): best substitution score, best net gain of one intron

@@ -235,6 +235,9 @@ struct SpdpContext {
     std::string err;
     std::vector<SpdpContext*> lanes;  // further lanes of this context (spdp_lane): chunks of a batch run side by side
     int64_t seed_stats[6] = {0};      // spdp_seeded_stats
+    void*  stage_ptr[2] = {nullptr, nullptr};   // pinned host staging of DevStore::upload (grow-only)
+    size_t stage_cap[2] = {0, 0};
+    void*  staging(int k, size_t bytes);
 };
 SpdpContext* spdp_lane(SpdpContext* ctx, int i);
 

@@ -106,6 +106,9 @@ def load_library() -> C.CDLL:
     lib.spdp_group_size.argtypes = [C.c_void_p]
     lib.spdp_group_last_error.restype = C.c_char_p
     lib.spdp_group_last_error.argtypes = [C.c_void_p]
+    lib.spdp_group_last_shards.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.spdp_stripe.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.spdp_cells.argtypes = [C.c_void_p, C.c_void_p]
     for f in ("spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h"):
         getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return lib

@@ -28,6 +28,20 @@ def test_device_group_equals_single_context():
         assert grp.lib.spdp_group_size(grp.h) == len(members)
         assert grp.homscore_s(sc, ps).tolist() == want_s
         assert [(s, skl.tolist()) for s, skl in grp.align_s(sc, ps)] == want_a
+        # the shards are balanced by DP cells (longest first to the least loaded member), not by count
+        import ctypes as C
+        from spaln_amd import shard
+        member = (C.c_int32 * len(ps))()
+        assert grp.lib.spdp_group_last_shards(grp.h, member, len(ps)) == len(ps)
+        costs = []
+        for p in ps.items:
+            w = abi.Window()
+            grp.lib.spdp_stripe(C.byref(p), sc.sh, C.byref(w))
+            costs.append(int(grp.lib.spdp_cells(C.byref(p), C.byref(w))))
+        want_sh = shard.balanced_shards(costs, len(members))
+        assert [[i for i in range(len(ps)) if member[i] == r] for r in range(len(members))] == want_sh
+        loads = [sum(costs[i] for i in s) for s in want_sh]
+        assert max(loads) - min(loads) <= max(costs)
         grp.close()
 
 
@@ -46,4 +60,6 @@ def test_bench_two_ranks_on_one_card():
     assert rec["config"]["queries_total"] == 1200
     strong = rec["config"]["strong_scaling"]
     assert strong["queries_total"] == 600 and strong["value"] > 0
+    assert len(strong["rank_busy_ms"]) == 2 and len(strong["rank_cells"]) == 2
+    assert max(strong["rank_cells"]) - min(strong["rank_cells"]) < 0.02 * sum(strong["rank_cells"])   # cell-balanced shards
     assert rec["cpu_baseline"] is None                 # timed at N = 1 only

@@ -24,6 +24,23 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_balanced_shards_partition_and_balance():
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 500):
+        costs = rng.integers(6_000_000, 33_000_000, size=n).tolist()     # 2 kb x 3-16 kb windows
+        for w in (1, 2, 3, 8):
+            sh = shard.balanced_shards(costs, w)
+            assert sorted(i for s in sh for i in s) == list(range(n)) and all(s == sorted(s) for s in sh)
+            if n >= 100:
+                loads = [sum(costs[i] for i in s) for s in sh]
+                by_count = [sum(costs[i] for i in shard.shard_range(n, r, w)) for r in range(w)]
+                assert max(loads) - min(loads) <= max(costs)                # LPT: within one item of each other
+                assert max(loads) <= max(by_count)
+            parts = [[("r", i) for i in s] for s in sh]
+            assert shard.scatter_in_order(n, sh, parts) == [("r", i) for i in range(n)]
+
+
 WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
@@ -35,13 +52,20 @@ WORKER = textwrap.dedent("""
     rank, world = dist.get_rank(), dist.get_world_size()
     sc = defaults.scoring()
     batch = synth.make_batch(9, seed=99, n_exons=3, mrna_len=200, flank=80, intron_hi=300)
-    mine = shard.shard_range(len(batch), rank, world)
+    costs = []
+    for w, q, s5, s3, _ in batch:
+        ps = abi.ProblemSet(); p = ps.add(q, w, s5, s3)
+        costs.append(oracle.cells(p, oracle.stripe(p, sc.sh)))
+    shards = shard.balanced_shards(costs, world)          # by DP cells, the same list on every rank
+    mine = shards[rank]
     local = []
     for i in mine:
         w, q, s5, s3, _ = batch[i]
         ps = abi.ProblemSet(); p = ps.add(q, w, s5, s3)
         local.append((i, oracle.wip_scoreonly(sc, p)))
-    full = shard.gather_in_order(local, dist)
+    parts = [None] * world
+    dist.all_gather_object(parts, local)
+    full = shard.scatter_in_order(len(batch), shards, parts)
     if rank == 0:
         print("RESULT " + json.dumps(full))
     dist.barrier()

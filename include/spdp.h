@@ -274,6 +274,15 @@ typedef struct SpdpHspSource {
 int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
                         const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
                         const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out);
+/* alignS_ng(seqs, pwd, gsi, ori = 3) with seeding on (src/fwd2s1.cc:2762-2777): the walk on the pair as given (fwd[i]) and on
+ * the reverse-complemented query against the other genomic strand (rev[i]: comrev(a) + antiseq(b), that strand's own signals),
+ * whose HSP list is the given one turned around as Seq::revjxt does; the reverse result is taken only if it scores strictly
+ * higher and then carries A_RevCom (0x10) in its header record; orient[i] = 0 / 1 says which.  The HSP source sees the
+ * reverse walk of query i as query n_probs + i. */
+int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
+                             const SpdpProblem* fwd, const SpdpProblem* rev, int n_probs,
+                             const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                             const SpdpHspSource* src, SpdpAlignment* out, int32_t* orient);
 /* counters of the last spdp_align_s_seeded call on this context: [0] device batches, [1] lspS_ng requests,
  * [2] trcbkalignS_ng requests, [3] of those with a cut range, [4] Wilip calls, [5] walks */
 int spdp_seeded_stats(const SpdpContext* ctx, int64_t* out, int n);

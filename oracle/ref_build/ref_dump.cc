@@ -51,7 +51,8 @@ Wilip::Wilip(const Seq* seqs[], const PwdB* pwd, const int level)
 	ref_wilip_ctor(this, seqs, pwd, level);
 	if (!wilip_tap_on) return;
 	std::vector<int>& L = wilip_tap_log;
-	const int hd[6] = {level, seqs[0]->left, seqs[0]->right, seqs[1]->left, seqs[1]->right, wlu? nwlu: 0};
+	// (+ 16 on the reverse-strand pass of alignS_ng(.., 3): the query has been reverse-complemented there)
+	const int hd[6] = {level + (seqs[0]->inex.sens? 16: 0), seqs[0]->left, seqs[0]->right, seqs[1]->left, seqs[1]->right, wlu? nwlu: 0};
 	L.insert(L.end(), hd, hd + 6);
 	for (int u = 0; wlu && u < nwlu; ++u) {
 	    const WLUNIT& x = wlu[u];
@@ -166,8 +167,14 @@ const	char*	outfn = argv[ai + 2];
 	    // the lowest level that finds any from geneorient()
 	    algmode.qck = seeded_q;
 	    Seq* const	b0 = b;
+	    if (ori3) {			// both strands as genomicseq prepares them for ori = 3 (spaln.cc:1137-1152)
+		a->inex.ori = 3;
+		delete b->exin;
+		b->exin = new Exinon(b, pwd, true);
+	    }
 	    b->comrev(seqs + 2);
-	    seqs[2]->exin = new Exinon(seqs[2], pwd, false);
+	    if (ori3) seqs[2]->setanti(seqs + 1);
+	    seqs[2]->exin = new Exinon(seqs[2], pwd, ori3 != 0);
 	    const int np = geneorient(seqs, pwd);
 	    if (b != b0) { fprintf(stderr, "ref_dump -Q: the reverse strand won geneorient(); not a fixture\n"); return 3; }
 	    if (np == 0) fprintf(stderr, "ref_dump -Q: no HSP at any level\n");
@@ -242,7 +249,7 @@ const	char*	outfn = argv[ai + 2];
 		(int) a->inex.exgl, (int) a->inex.exgr, (int) b->inex.exgl, (int) b->inex.exgr, (int) a->inex.sens};
 	    w.put_i32(pn("ranges"), rg);
 	};
-	if (ori3) {
+	if (ori3 && !seeded_q) {
 	    // both strands as the caller of alignS_ng prepares them (genomicseq with ori = 3, spaln.cc:1137-1152)
 	    delete b->exin;
 	    b->exin = new Exinon(b, pwd, true);
@@ -310,6 +317,7 @@ const	char*	outfn = argv[ai + 2];
 	    dump_strand("r_");
 	    a->comrev();
 	    antiseq(seqs + 1);
+	    a->inex.sens = 0;			// (comrev toggles it; the pair is back as given)
 	}
 	{
 	    const Simmtx* sm = pwd->simmtx;
@@ -379,6 +387,9 @@ const	int	nq0 = IntronPrm.nquant;
 	    std::vector<SGPT2> sg0(b->right - b->left + 1);
 	    for (int n = b->left; n <= b->right; ++n) sg0[n - b->left] = *b->exin->score_n(n);
 	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
+	    std::vector<SGPT2> sgr0;
+	    if (ori3)
+		for (int n = seqs[2]->left; n <= seqs[2]->right; ++n) sgr0.push_back(*seqs[2]->exin->score_n(n));
 	    if (alg_list.empty()) { alg_list.push_back(0); alg_list.push_back(2); }
 	    for (size_t k = 0; k < alg_list.size(); ++k) {
 const		int	alg = alg_list[k];
@@ -389,15 +400,23 @@ const		int	alg = alg_list[k];
 		wilip_tap_log.clear();
 		wilip_tap_on = true;
 		Gsinfo	gsi;
-		gsi.skl = alignS_ng(seqs, pwd, &gsi, 1);
+		if (ori3)			// the reverse strand's phase marks start clean as well
+		    for (int n = seqs[2]->left; n <= seqs[2]->right; ++n) *seqs[2]->exin->score_n(n) = sgr0[n - seqs[2]->left];
+		gsi.skl = alignS_ng(seqs, pwd, &gsi, ori3? 3: 1);
 		wilip_tap_on = false;
+		if (ori3) {
+const		    int	rev = a->inex.sens? 1: 0;
+		    snprintf(nm, sizeof nm, "seed_rev_A%d", alg);
+		    w.put_int(nm, rev);
+		    if (rev) { a->comrev(); antiseq(seqs + 1); }	// back to the strand as given
+		}
 		snprintf(nm, sizeof nm, "seed_scr_A%d", alg);
 		w.put_int(nm, (int) gsi.scr);
 		snprintf(nm, sizeof nm, "seed_skl_A%d", alg);
 		w.put_i32(nm, skl2vec(gsi.skl));
 		snprintf(nm, sizeof nm, "seed_wilip_A%d", alg);
 		w.put_i32(nm, wilip_tap_log);
-		if (gsi.skl && gsi.skl->n) {
+		if (gsi.skl && gsi.skl->n && !ori3) {
 		    restore();
 		    for (int n = b->left; n <= b->right; ++n) *b->exin->score_n(n) = sg0[n - b->left];
 		    VTYPE	rs = skl_rngS_ng((const Seq**) seqs, &gsi, pwd);

@@ -27,12 +27,14 @@ def lib():
     return _lib
 
 
-def parse_wilip_log(log) -> dict:
-    """seed_wilip_A* of a fixture -> {(level, a_left, a_right, b_left, b_right): flat unit record}"""
+def parse_wilip_log(log, strand: int = 0) -> dict:
+    """seed_wilip_A* of a fixture -> {(level, a_left, a_right, b_left, b_right): flat unit record} for the walk on the pair
+    as given (strand 0) or on the reverse-complemented pair of an ori = 3 run (strand 1: the harness adds 16 to the level)"""
     log = [int(x) for x in log]
     out, at = {}, 0
     while at < len(log):
-        key = tuple(log[at:at + 5])
+        key = (log[at] & 15,) + tuple(log[at + 1:at + 5])
+        mine = (log[at] >> 4) == strand
         n_units = log[at + 5]
         at += 6
         flat = [n_units]
@@ -40,8 +42,31 @@ def parse_wilip_log(log) -> dict:
             num = log[at]
             flat += log[at:at + 6 + 5 * (num + 1)]
             at += 6 + 5 * (num + 1)
-        out.setdefault(key, flat)
+        if mine:
+            out.setdefault(key, flat)
     return out
+
+
+def turned_hsps(hsps, n_hsps: int, a_len: int, b_len: int):
+    """Seq::revjxt (src/seq.cc:745-755) on a list whose free slot holds {a->len, b->len}, as the forward walk leaves it"""
+    j = np.array(hsps, dtype=np.int32).reshape(-1, 5).copy()
+    if n_hsps:
+        j[:n_hsps, 0] = a_len - j[:n_hsps, 0] - j[:n_hsps, 2]
+        j[:n_hsps, 1] = b_len - j[:n_hsps, 1] - j[:n_hsps, 2]
+        j[:n_hsps] = j[:n_hsps][::-1]
+    return j
+
+
+def align_s_seeded_ori3(sc, sp, p_fwd, p_rev, hsps, n_hsps, lowest_level, wilip_fwd, wilip_rev, simd=2):
+    """alignS_ng(seqs, pwd, gsi, 3) with seeding on (src/fwd2s1.cc:2762-2777): (score, flat SKL, reverse taken)"""
+    sf, ff, _ = align_s_seeded(sc, sp, p_fwd, hsps, n_hsps, lowest_level, wilip_fwd, simd)
+    sr, fr, _ = align_s_seeded(sc, sp, p_rev, turned_hsps(hsps, n_hsps, p_fwd.a_len, p_fwd.b_len), n_hsps, lowest_level,
+                               wilip_rev, simd)
+    if sf >= sr:
+        return sf, ff, 0
+    if fr:
+        fr = [fr[0] | 0x10] + fr[1:]
+    return sr, fr, 1
 
 
 def hsps_of(fx: dict):

@@ -75,14 +75,14 @@ struct DeviceBackend : DpBackend {
 };
 }   // namespace
 
-extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
-                                   const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
-                                   const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out)
+// the walks of `n_probs` (query, strand) pairs: scores[i] = what globalS_ng's seededS_ng returns, recs[i] = its record file
+// (dummy record first), status[i] = 0, or 1 / 2 for a walk that was not served
+static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
+                       const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
+                       const int32_t* lowest_level, const SpdpHspSource* src,
+                       std::vector<int>& scores, std::vector<std::vector<SpdpSkl>>& recs, std::vector<uint8_t>& status)
 {
-    if (!ctx || !sc || !sp || !probs || !out) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
     memset(ctx->seed_stats, 0, sizeof ctx->seed_stats);
-    if (n_probs <= 0) return 0;
     if (sp->qck < 1 || sp->qck > 3) { ctx->err = "SpdpSeedParams.qck must be 1 .. 3"; return -1; }
     if (!sc->intpen || sc->intpen_len <= 0) { ctx->err = "the seeded path needs SpdpScoring.intpen / t53"; return -1; }
     for (int i = 0; i < n_probs; ++i)
@@ -96,9 +96,9 @@ extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, cons
     Rendezvous rv;
     std::atomic<int> next{0};
     std::atomic<int64_t> n_wilip{0};
-    std::vector<int> scores(n_probs, SPDP_NEVSEL);
-    std::vector<std::vector<SpdpSkl>> recs(n_probs);
-    std::vector<uint8_t> status(n_probs, 0);            // 1: the walk met a state it does not serve, 2: a request failed
+    scores.assign(n_probs, SPDP_NEVSEL);
+    recs.assign(n_probs, std::vector<SpdpSkl>());
+    status.assign(n_probs, 0);                          // 1: the walk met a state it does not serve, 2: a request failed
     int n_threads = 256;
     if (const char* e = getenv("SPDP_SEED_WALKS")) n_threads = std::max(1, atoi(e));
     n_threads = std::min(n_threads, n_probs);
@@ -175,23 +175,92 @@ extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, cons
     for (std::thread& t : pool) t.join();
     ctx->seed_stats[0] = n_batches; ctx->seed_stats[1] = n_kind[0]; ctx->seed_stats[2] = n_kind[1] + n_kind[2];
     ctx->seed_stats[3] = n_kind[2]; ctx->seed_stats[4] = n_wilip.load(); ctx->seed_stats[5] = n_probs;
-    if (rc < 0) return -1;
-    // globalS_ng's tail: the file without its dummy record -> header, stdskl, trimskl (src/fwd2s1.cc:2684-2693)
+    return rc < 0 ? -1 : 0;
+}
+
+namespace {
+// globalS_ng's tail: the file without its dummy record -> header, stdskl, trimskl (src/fwd2s1.cc:2684-2693)
+void finish_walk(const SpdpProblem& p, int score, const std::vector<SpdpSkl>& rec, bool rev, SpdpAlignment* out)
+{
+    out->score = score;
+    if (rec.size() < 3) return;                         // fewer than two records behind the dummy: no alignment
+    std::vector<SpdpSkl> s = corner_list<1>(std::vector<SpdpSkl>(rec.begin() + 1, rec.end()));
+    trim_skl_of(s, p);
+    out->n_skl = (int) s.size() + 1;
+    out->skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * out->n_skl);
+    out->skl[0].m = 1 | (rev ? 0x10 : 0);               // AlgnTrb (| A_RevCom: a->inex.sens after comrev)
+    out->skl[0].n = (int) s.size();
+    memcpy(out->skl + 1, s.data(), sizeof(SpdpSkl) * s.size());
+}
+const char* kPartial = "some walks met a state the seeded path does not serve (no HSP source for a recursion level, "
+                       "or an engine call outside the sequences); those queries come back without an alignment";
+}   // namespace
+
+extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
+                                   const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
+                                   const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out)
+{
+    if (!ctx || !sc || !sp || !probs || !out) return -1;
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    if (n_probs <= 0) return 0;
+    std::vector<int> scores;
+    std::vector<std::vector<SpdpSkl>> recs;
+    std::vector<uint8_t> status;
+    if (seeded_core(ctx, sc, sp, probs, n_probs, hsps, n_hsps, lowest_level, src, scores, recs, status) < 0) return -1;
     int partial = 0;
     for (int i = 0; i < n_probs; ++i) {
         if (status[i]) { ++partial; continue; }
-        out[i].score = scores[i];
-        if (recs[i].size() < 3) continue;               // fewer than two records behind the dummy: no alignment
-        std::vector<SpdpSkl> s = corner_list<1>(std::vector<SpdpSkl>(recs[i].begin() + 1, recs[i].end()));
-        trim_skl_of(s, probs[i]);
-        out[i].n_skl = (int) s.size() + 1;
-        out[i].skl = (SpdpSkl*) malloc(sizeof(SpdpSkl) * out[i].n_skl);
-        out[i].skl[0].m = 1;                            // AlgnTrb
-        out[i].skl[0].n = (int) s.size();
-        memcpy(out[i].skl + 1, s.data(), sizeof(SpdpSkl) * s.size());
+        finish_walk(probs[i], scores[i], recs[i], false, out + i);
     }
-    if (partial) { ctx->err = "some walks met a state the seeded path does not serve (no HSP source for a recursion level, "
-                              "or an engine call outside the sequences); those queries come back without an alignment"; return 1; }
+    if (partial) { ctx->err = kPartial; return 1; }
+    return 0;
+}
+
+// alignS_ng(seqs, pwd, gsi, ori = 3) with seeding on (src/fwd2s1.cc:2762-2777): the walk on the pair as given, then on the
+// reverse-complemented query against the other genomic strand with the HSP list turned around (reverse_copy_jxt ->
+// Seq::revjxt, src/seq.cc:745-755: jx' = a_len - jx - jlen, jy' = b_len - jy - jlen, order reversed); the forward result
+// stays unless the reverse one scores strictly higher.  Both walks of every query run in the same device batches.
+extern "C" int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
+                                        const SpdpProblem* fwd, const SpdpProblem* rev, int n_probs,
+                                        const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                                        const SpdpHspSource* src, SpdpAlignment* out, int32_t* orient)
+{
+    if (!ctx || !sc || !sp || !fwd || !rev || !out || !orient) return -1;
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; orient[i] = 0; }
+    if (n_probs <= 0) return 0;
+    const int n2 = 2 * n_probs;
+    std::vector<SpdpProblem> both(fwd, fwd + n_probs);
+    both.insert(both.end(), rev, rev + n_probs);
+    std::vector<std::vector<SpdpJuxt>> turned(n_probs);
+    std::vector<const SpdpJuxt*> lists(n2, nullptr);
+    std::vector<int32_t> counts(n2, 0), levels(n2, 0);
+    for (int i = 0; i < n_probs; ++i) {
+        const int nh = (hsps && n_hsps && hsps[i]) ? n_hsps[i] : 0;
+        levels[i] = levels[n_probs + i] = lowest_level ? lowest_level[i] : 0;
+        if (!nh) continue;
+        lists[i] = hsps[i]; counts[i] = nh;
+        std::vector<SpdpJuxt>& t = turned[i];
+        t.assign(hsps[i], hsps[i] + nh + 1);
+        for (int j = 0; j < nh; ++j) {                  // (the forward walk has left {a->len, b->len} in the slot behind the list)
+            t[j].jx = fwd[i].a_len - t[j].jx - t[j].jlen;
+            t[j].jy = fwd[i].b_len - t[j].jy - t[j].jlen;
+        }
+        std::reverse(t.begin(), t.begin() + nh);
+        lists[n_probs + i] = t.data(); counts[n_probs + i] = nh;
+    }
+    std::vector<int> scores;
+    std::vector<std::vector<SpdpSkl>> recs;
+    std::vector<uint8_t> status;
+    if (seeded_core(ctx, sc, sp, both.data(), n2, lists.data(), counts.data(), levels.data(), src, scores, recs, status) < 0) return -1;
+    int partial = 0;
+    for (int i = 0; i < n_probs; ++i) {
+        if (status[i] || status[n_probs + i]) { ++partial; continue; }
+        const int r = n_probs + i;
+        orient[i] = scores[i] >= scores[r] ? 0 : 1;
+        if (orient[i]) finish_walk(rev[i], scores[r], recs[r], true, out + i);
+        else finish_walk(fwd[i], scores[i], recs[i], false, out + i);
+    }
+    if (partial) { ctx->err = kPartial; return 1; }
     return 0;
 }
 

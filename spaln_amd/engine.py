@@ -30,7 +30,7 @@ EXPORTS = [
     "spdp_poll", "spdp_wait",
     "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
     "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
-    "spdp_align_s_seeded", "spdp_seeded_stats",
+    "spdp_align_s_seeded", "spdp_align_s_seeded_ori3", "spdp_seeded_stats",
 ]
 
 
@@ -359,6 +359,55 @@ class Engine:
             res.append((int(arr[i].score), skl))
         self.lib.spdp_free_alignments(arr, n)
         return res
+
+    def align_s_seeded_ori3(self, sc, sp, ps_fwd, ps_rev, hsps, lowest_levels, wilip_tables):
+        """alignS_ng(ori = 3) with seeding on: wilip_tables has 2 n entries (the reverse walk of query i is query n + i).
+        Returns ([(score, skl)], orient)."""
+        n = len(ps_fwd)
+        keep = []
+        jx = (C.c_void_p * n)()
+        nh = (C.c_int32 * n)()
+        lv = (C.c_int32 * n)(*[int(x) for x in lowest_levels])
+        for i, h in enumerate(hsps):
+            if h is None or len(h) < 2:
+                continue
+            a = np.ascontiguousarray(h, dtype=np.int32)
+            keep.append(a)
+            jx[i] = a.ctypes.data
+            nh[i] = a.shape[0] - 1
+        missing = []
+
+        def units(_user, query, level, span, flat, n_flat):
+            key = (level, span[0], span[1], span[2], span[3])
+            tab = wilip_tables[query]
+            if not tab or key not in tab:
+                missing.append((query,) + key)
+                return 1
+            a = np.asarray(tab[key], dtype=np.int32)
+            keep.append(a)
+            flat[0] = a.ctypes.data_as(C.POINTER(C.c_int32))
+            n_flat[0] = a.size
+            return 0
+
+        src = abi.HspSource()
+        src.user = None
+        src.units = abi.HSP_UNITS_FN(units)
+        src.release = abi.HSP_RELEASE_FN(lambda _u, _q, _f: None)
+        arr = (abi.Alignment * n)()
+        orient = (C.c_int32 * n)()
+        self.lib.spdp_align_s_seeded_ori3.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6
+        rc = self.lib.spdp_align_s_seeded_ori3(self.ctx, C.byref(sc), C.byref(sp), ps_fwd.array(), ps_rev.array(), n, jx, nh, lv,
+                                               C.byref(src), arr, orient)
+        if missing:
+            raise KeyError(f"no Wilip reply for {missing[:3]}")
+        self._check(rc, "spdp_align_s_seeded_ori3")
+        res = []
+        for i in range(n):
+            k = arr[i].n_skl
+            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+            res.append((int(arr[i].score), skl))
+        self.lib.spdp_free_alignments(arr, n)
+        return res, [int(x) for x in orient]
 
     def seeded_stats(self) -> dict:
         v = (C.c_int64 * 6)()

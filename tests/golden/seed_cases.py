@@ -100,6 +100,14 @@ def special_cases():
         w = np.concatenate([g.window[:e[0][0]], g.window[e[0][0] + cut5:e[-1][1] - cut3], g.window[e[-1][1]:]])
         q = g.transcript[cut5:len(g.transcript) - cut3]
         c[f"q_short_ends{k}"] = (w, q, ["-Q", str(qck), "-X", str(crs)])
+    # alignS_ng's default orientation handling with seeding on (ori = 3: both strands walked, the better one kept); "minus"
+    # = query and window both reverse-complemented, i.e. the pair matches as given but its introns read CT..AC
+    from tests.golden.make_goldens import revcomp
+    for k, (qck, sub) in enumerate(((1, 0.03), (3, 0.1), (2, 0.06))):
+        rng = np.random.default_rng(synth.SEED + 49030 + k)
+        g = synth.make_gene(rng, n_exons=5, mrna_len=700, flank=500, intron_hi=1200, sub=sub, indel=0.01)
+        c[f"q_o3_plus{k}"] = (g.window, g.query, ["-Q", str(qck), "-O"])
+        c[f"q_o3_minus{k}"] = (revcomp(g.window), revcomp(g.query), ["-Q", str(qck), "-O"])
     # BASELINE's headline size under -Q7: the DP calls between HSPs stay far below the 1472 rows at which the
     # reference's int16 engines start re-basing, so its -A2 output IS a witness at 2 kb here
     for k in range(2):

@@ -8,7 +8,7 @@ import pytest
 from spaln_amd import abi, engine
 from tests import spdg
 from tests.conftest import golden_files, golden_ids
-from tests.test_oracle_seeded import seeded_inputs
+from tests.test_oracle_seeded import seeded_inputs, Q_FILES, O3
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def _flat(res):
 
 
 @pytest.mark.parametrize("alg,eng_sel", [(0, 1), (2, 0)])
-@pytest.mark.parametrize("path", golden_files("q_"), ids=golden_ids("q_"))
+@pytest.mark.parametrize("path", Q_FILES, ids=[f.split("/")[-1][:-5] for f in Q_FILES])
 def test_seeded_alignment_equals_reference(eng, path, alg, eng_sel):
     fx = spdg.load(path)
     sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, alg)
@@ -42,7 +42,7 @@ def test_seeded_alignment_equals_reference(eng, path, alg, eng_sel):
 def test_whole_fixture_set_as_one_batch(eng, alg, eng_sel):
     """queries with one parameter set in ONE call: their DP requests share device batches, results stay per query"""
     groups = {}
-    for f in golden_files("q_"):
+    for f in Q_FILES:
         fx = spdg.load(f)
         seedp = [int(x) for x in fx["seed_params"]]
         key = (seedp[0], tuple(seedp[3:]), tuple(int(x) for x in fx["params"][:19]),     # ([1], [2]: per query: wllvl, #HSPs)
@@ -89,3 +89,38 @@ def test_missing_hsp_source_is_reported(eng):
     sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 2)
     with pytest.raises(KeyError):
         eng.align_s_seeded(sc, sp, p._owner, [hsps], [lowest], [{}], allow_partial=True)
+
+
+@pytest.mark.parametrize("alg,eng_sel", [(0, 1), (2, 0)])
+def test_seeded_ori3_equals_reference(eng, alg, eng_sel):
+    """alignS_ng(seqs, pwd, gsi, 3) with seeding on, all ori = 3 fixtures of one parameter set in one call: 2 n walks share
+    the device batches; orientation, score, SKL and the A_RevCom bit as the reference returns them"""
+    from oracle import seeded
+    groups = {}
+    for f in O3:
+        fx = spdg.load(f)
+        groups.setdefault(int(fx["seed_params"][0]), []).append(fx)
+    for fxs in groups.values():
+        psf, psr = abi.ProblemSet(), abi.ProblemSet()
+        hs, lv, wf, wr, keep = [], [], [], [], []
+        for fx in fxs:
+            spdg.problem(fx, psf)
+            spdg.problem_rev(fx, psr)
+            for p, pre in ((psf.items[-1], ""), (psr.items[-1], "r_")):
+                h5, h3 = np.ascontiguousarray(fx[pre + "phs5"]), np.ascontiguousarray(fx[pre + "phs3"])
+                keep += [h5, h3]
+                p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
+            j, n = seeded.hsps_of(fx)
+            hs.append(j if n else None)
+            lv.append(int(fx["seed_params"][1]))
+            wf.append(seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"], 0))
+            wr.append(seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"], 1))
+        sc = spdg.scoring(max(fxs, key=lambda f: len(f["intpen"])))
+        sc.scalar_engines = eng_sel
+        sp = abi.seed_params_from_fixture(fxs[0])
+        res, orient = eng.align_s_seeded_ori3(sc, sp, psf, psr, hs, lv, wf + wr)
+        for fx, r, o in zip(fxs, res, orient):
+            scr, flat = _flat(r)
+            assert o == int(fx[f"seed_rev_A{alg}"][0])
+            assert scr == int(fx[f"seed_scr_A{alg}"][0])
+            assert flat == fx[f"seed_skl_A{alg}"].tolist()

@@ -25,7 +25,10 @@ def seeded_inputs(fx, alg):
     return sc, sp, p, hsps, n, int(fx["seed_params"][1]), seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"])
 
 
-@pytest.fixture(scope="module", params=golden_files("q_"), ids=golden_ids("q_"))
+Q_FILES = [f for f in golden_files("q_") if "/q_o3_" not in f]         # (q_o3_*: ori = 3 runs, tested on their own below)
+
+
+@pytest.fixture(scope="module", params=Q_FILES, ids=[f.split("/")[-1][:-5] for f in Q_FILES])
 def fx(request):
     return spdg.load(request.param)
 
@@ -42,7 +45,7 @@ def test_seeded_alignment_equals_reference(fx, alg, simd):
 def test_fixtures_reach_every_join():
     """every branch of interpolateS (and bestwlu) is taken by some fixture, most by several"""
     joins = {}
-    for f in golden_files("q_"):
+    for f in Q_FILES:
         fx = spdg.load(f)
         sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 2)
         seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2, joins=joins)
@@ -61,3 +64,27 @@ def test_dp_calls_are_made():
         for kind, a, _ in tr:
             kinds.add((kind, bool(a[11])))
     assert {(0, False), (1, False), (1, True), (2, False)} <= kinds
+
+
+O3 = [f for f in golden_files("q_o3_")]
+
+
+@pytest.mark.parametrize("path", O3, ids=[f.split("/")[-1][:-5] for f in O3])
+@pytest.mark.parametrize("alg,simd", [(0, 0), (2, 2)])
+def test_seeded_ori3_equals_reference(path, alg, simd):
+    """alignS_ng(seqs, pwd, gsi, 3) with seeding on: both strands walked (the reverse one with the HSP list turned around),
+    the reverse kept only if strictly better, A_RevCom in its header"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl_f = seeded_inputs(fx, alg)
+    _, pr = spdg.problem_rev(fx)
+    h5, h3 = np.ascontiguousarray(fx["r_phs5"]), np.ascontiguousarray(fx["r_phs3"])
+    pr.phs5, pr.phs3 = h5.ctypes.data, h3.ctypes.data
+    wl_r = seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"], strand=1)
+    scr, flat, rev = seeded.align_s_seeded_ori3(sc, sp, p, pr, hsps, n, lowest, wl_f, wl_r, simd)
+    assert rev == int(fx[f"seed_rev_A{alg}"][0])
+    assert scr == int(fx[f"seed_scr_A{alg}"][0])
+    assert (flat or []) == fx[f"seed_skl_A{alg}"].tolist()
+
+
+def test_ori3_fixtures_take_both_orientations():
+    assert sorted({int(spdg.load(f)["seed_rev_A2"][0]) for f in O3}) == [0, 1]

@@ -126,7 +126,15 @@ typedef struct SpdpAlignment {
     int32_t  score;            /* gsi->scr: raw engine score, SPDP_NEVSEL on failure      */
     int32_t  n_skl;            /* entries in skl[] including the header record, 0 = none */
     SpdpSkl* skl;              /* owned by the library until spdp_free_alignments        */
+    int32_t  flags;            /* SPDP_ALN_* below                                       */
+    int32_t  reserved;
 } SpdpAlignment;
+/* a linear-space (hirschbergS1[_wip]) call of this query found its path on the free left edge of its window -- a crossing of
+ * an intermediate row on or left of the first genomic column, or an empty optimum.  There the reference records link
+ * lanes it never initialised (src/fwd2s1_wip_simd.h:524: what the previous stripe left behind, heap contents in the first
+ * stripe), so its own result is run-dependent; the device starts those lanes from zero and may differ.
+ * Planted-gene inputs with the default semi-global ends never set it. */
+#define SPDP_ALN_LEFT_EDGE 1
 
 typedef struct SpdpContext SpdpContext;
 

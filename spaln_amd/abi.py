@@ -150,7 +150,11 @@ class Skl(C.Structure):
 
 
 class Alignment(C.Structure):
-    _fields_ = [("score", C.c_int32), ("n_skl", C.c_int32), ("skl", C.POINTER(Skl))]
+    _fields_ = [("score", C.c_int32), ("n_skl", C.c_int32), ("skl", C.POINTER(Skl)), ("flags", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+ALN_LEFT_EDGE = 1                       # SPDP_ALN_LEFT_EDGE
 
 
 class Exon(C.Structure):                 # SpdpExon / EISCR

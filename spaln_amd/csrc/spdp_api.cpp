@@ -562,7 +562,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         POOLGET(d_imd, POOL_IMD, sizeof(int32_t) * std::max<int64_t>(imd_tot, 1));
         POOLGET(d_cpos, POOL_CPOS, sizeof(int32_t) * 10 * (max_n_im + 1) * nn);
         POOLGET(d_ranges, POOL_RANGES, sizeof(int32_t) * 4 * nn);
-        POOLGET(d_scores, POOL_SCORES, sizeof(int32_t) * nn);
+        POOLGET(d_scores, POOL_SCORES, sizeof(int32_t) * 2 * nn);          // scores, then the left-edge marks of spdp_udh_cpos
     }
     // dispatch order = largest problems first (longest-processing-time rule): one wave owns one
     // problem, so the big ones must not start last.  order[j] = caller index of dispatch slot j.
@@ -710,6 +710,7 @@ int DevRun::launch()
             C.probs = S.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
             C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
             C.cpos_stride = 10 * (max_n_im + 1); C.strict = flavour == 8; C.local = store->sc.local ? 1 : 0;
+            C.edge = (int*) d_scores + n;
             C.pipe = (flavour == 8 && pipe_on) ? (const int*) d_gprog : nullptr;
             C.pipe_stride = pipe_stride; C.rlf_off = 2 + 7 * pipe_tiles;
             HIPCHK(spdp_launch_cpos(&C, strm()));
@@ -748,6 +749,7 @@ int DevRun::launch()
         C.probs = A.probs; C.n_probs = n; C.imd = (const int*) d_imd; C.res = (const DevResult*) d_res;
         C.cpos = (int*) d_cpos; C.ranges = (int*) d_ranges; C.scores = (int*) d_scores;
         C.cpos_stride = 10 * (max_n_im + 1); C.strict = 0; C.local = 0;
+        C.edge = (int*) d_scores + n;
         HIPCHK(spdp_launch_cpos(&C, strm()));
     }
     return 0;
@@ -881,13 +883,20 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     return 0;
 }
 
-int DevRun::fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges)
+int DevRun::fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges,
+                      std::vector<int32_t>* edge)
 {
     const size_t st = (size_t) 10 * (max_n_im + 1);
     scores.resize(n); ranges.resize((size_t) 4 * n); cpos.resize(st * n);
+    if (edge) edge->assign(n, 0);
     if (n) {
         std::vector<int32_t> ts(n), tr((size_t) 4 * n), tc(st * n);
         HIPCHK(hipMemcpy(ts.data(), d_scores, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        if (edge && (flavour == 2 || flavour >= 8)) {
+            std::vector<int32_t> te(n);
+            HIPCHK(hipMemcpy(te.data(), (int32_t*) d_scores + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            for (int j = 0; j < n; ++j) (*edge)[order[j]] = te[j];
+        }
         HIPCHK(hipMemcpy(tr.data(), d_ranges, sizeof(int32_t) * 4 * n, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tc.data(), d_cpos, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost));
         for (int j = 0; j < n; ++j) {
@@ -1024,7 +1033,7 @@ static int forward_like(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProbl
                         SpdpAlignment* out, int flav)
 {
     if (!ctx) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n_probs <= 0) return 0;
     DevStore st; DevRun run;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
@@ -1074,5 +1083,5 @@ int spdp_wip_forward(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem*
 
 void spdp_free_alignments(SpdpAlignment* out, int n)
 {
-    for (int i = 0; i < n; ++i) { free(out[i].skl); out[i].skl = nullptr; out[i].n_skl = 0; }
+    for (int i = 0; i < n; ++i) { free(out[i].skl); out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; out[i].n_skl = 0; }
 }

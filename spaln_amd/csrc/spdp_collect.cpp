@@ -61,7 +61,7 @@ struct SpdpCollector {
             if (rc < 0 && take.size() > 1) {
                 // one caller's malformed problem must not fail the callers that happened to share its batch: once more, one by one
                 for (size_t i = 0; i < take.size(); ++i) {
-                    outs[i].score = SPDP_NEVSEL; outs[i].n_skl = 0; outs[i].skl = nullptr;
+                    outs[i].score = SPDP_NEVSEL; outs[i].n_skl = 0; outs[i].skl = nullptr; outs[i].flags = 0; outs[i].reserved = 0;
                     each[i] = run(&probs[i], 1, &outs[i]);
                     if (each[i]) why = ctx->err;
                 }

@@ -1073,7 +1073,7 @@ static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
         HTop& t = tops[i];
         if (t.cls) rc = 1;
         if (!out) continue;
-        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr;
+        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0;
         if (t.cls) continue;
         out[i].score = t.score;
         if (t.flag) { out[i].n_skl = t.flag; continue; }
@@ -1169,7 +1169,7 @@ int spdp_scalar_forward_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpPr
     std::vector<HItem> items;
     std::vector<int> idx;
     for (int i = 0; i < n_probs; ++i) {
-        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr;
+        out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0;
         HItem it = item_of(probs[i], i, sc->sh);
         if (it.w.width < 0) continue;                                 // trcbkalignH_ng returns NEVSEL
         items.push_back(it); idx.push_back(i);

@@ -42,6 +42,7 @@ struct Job {                                // one query through alignS_ng
     int score = SPDP_NEVSEL;
     bool score_set = false;
     bool failed = false;
+    bool edge = false;                      // a linear-space call of this query ran along the free left edge (SPDP_ALN_LEFT_EDGE)
     std::vector<SpdpSkl> rec;               // Mfile records after the dummy one
 };
 
@@ -447,7 +448,8 @@ struct Aligner {
             stats[0] += run.kernel_ms; stats[1] += (double) run.total_cells; stats[2] += (double) items.size();
             stats[6] += 1;
             std::vector<int32_t> scores, cpos, ranges;
-            if (run.fetch_udh(scores, cpos, ranges)) return -1;
+            std::vector<int32_t> edge;
+            if (run.fetch_udh(scores, cpos, ranges, &edge)) return -1;
             std::vector<DevResult> ures;
             if (a0 && run.fetch_results(ures)) return -1;
             lap("udh fetch");
@@ -457,6 +459,7 @@ struct Aligner {
                 const int scr = scores[k];
                 if (a0 && ures[k].pad[0]) { ++unsupported; jobs[u.job].failed = true; continue; }   // undefined in the reference
                 set_score(u.job, u.top, scr);
+                if (edge[k]) jobs[u.job].edge = true;
                 if (scr <= SPDP_NEVSEL) continue;
                 Rng curr = u.r;                 // ranges as written back by the engine
                 curr.al = ranges[4 * k]; curr.ar = ranges[4 * k + 1];
@@ -583,6 +586,7 @@ struct Aligner {
         const Job& J = jobs[i];
         out->score = J.score_set ? J.score : SPDP_NEVSEL;
         out->n_skl = 0; out->skl = nullptr;
+        out->flags = J.edge ? SPDP_ALN_LEFT_EDGE : 0;
         if (raw) {                              // what lspS_ng appended to the caller's Mfile (no header, any order)
             if (J.failed && req) { out->n_skl = -1; return; }   // (explicit requests: the caller must tell "no records" from "not served")
             if (J.failed || J.rec.empty()) return;
@@ -739,7 +743,7 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
                  SpdpAlignment* out)
 {
     if (!ctx) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n_probs <= 0) return 0;
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
@@ -751,7 +755,7 @@ int spdp_align_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* pro
 int spdp_lsp_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs, int n_probs, SpdpAlignment* out)
 {
     if (!ctx || !sc || !out) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n_probs <= 0) return 0;
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
@@ -764,7 +768,7 @@ int spdp_lsp_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpProblem* probs
 int spdp_run_requests(SpdpContext* ctx, const DevStore* st, const SpdpProblem* probs, int n, const SpdpRequests* req,
                       SpdpAlignment* out)
 {
-    for (int i = 0; i < n; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    for (int i = 0; i < n; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n <= 0) return 0;
     return align_on_store(ctx, st, probs, n, out, nullptr, nullptr, nullptr, true, req);
 }

@@ -57,6 +57,9 @@ struct CposArgs {
     int               cpos_stride;
     int               strict;     // 1: the -A1 form of the walk (hirschbergS1: r > up, lw <= vlnk)
     int               local;      // 1: local ends (DevResult::ml is the left-end row of the path)
+    int*              edge;       // per problem: 1 = the path crosses an intermediate row on or left of the first column, or is
+                                  // empty: the one class where the reference's own linear-space result depends on what a previous
+                                  // stripe left in its link lanes -- reported, not imitated; may be null
     const int*        pipe;       // pipelined spdp_exact<2>: the sync words of the launch (rlf[] resolves SPDP_RLST_INHERITED), or null
     int               pipe_stride, rlf_off;
 };
@@ -322,7 +325,8 @@ struct DevRun {
     int fetch_results(std::vector<DevResult>& out);
     // forward: records of problem i are skl[off[i] .. off[i] + n_skl[i])
     int fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::vector<SpdpSkl>& skl);
-    int fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges);
+    int fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, std::vector<int32_t>& ranges,
+                  std::vector<int32_t>* edge = nullptr);     // edge: CposArgs::edge per problem (flavours 2, 8, 9), zeros otherwise
     void release();
 };
 

@@ -896,11 +896,13 @@ __global__ void spdp_udh_cpos(CposArgs A)
     while (--i >= 0 && MI(i) > a_right) ;
     if (i < 0 && MI(0) > a_right) CPOS(0, 2) = b_right;
     int r = R.ulk;
+    int edge = 0;
     for ( ; i >= 0 && MI(i) > max_ml; --i) {
         int c = 0, d = 0;
         if (A.strict) { for ( ; r > up; r -= width) ++d; }
         else { for ( ; r >= up; r -= width) ++d; }
         const int vl = LNK(i, 1, d, r);
+        if (r + MI(i) <= P.b_left) edge = 1;            // the crossing lies on the boundary column or left of it
         if ((A.strict ? lw <= vl : lw < vl) && vl < up) {
             CPOS(i, c++) = MI(i);
             CPOS(i, c++) = (d > 0) ? 1 : 0;
@@ -938,6 +940,8 @@ __global__ void spdp_udh_cpos(CposArgs A)
     }
     ++i;
     if ((i < n_im && MI(i) < a_left) || CPOS(i, 2) < b_left) val = INT32_MIN / 16 * 7;
+    if (a_left >= a_right || b_left >= b_right) edge = 1;      // an empty optimum
+    if (A.edge) A.edge[pi] = edge;
     A.scores[pi] = val;
     int* rg = A.ranges + 4 * pi;
     rg[0] = a_left; rg[1] = a_right; rg[2] = b_left; rg[3] = b_right;

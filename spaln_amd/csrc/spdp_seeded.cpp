@@ -27,6 +27,7 @@ struct Parked {
     int score = SPDP_NEVSEL;
     std::vector<SpdpSkl> rec;
     bool done = false, failed = false;
+    int flags = 0;                              // SpdpAlignment::flags of the request
 };
 
 struct Rendezvous {
@@ -39,6 +40,7 @@ struct Rendezvous {
 struct DeviceBackend : DpBackend {
     Rendezvous* rv; int query; const SpdpHspSource* src;
     bool failed = false;
+    int flags = 0;                              // of all DP calls of the walk
     std::atomic<int64_t>* n_wilip;
     int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
     {
@@ -53,6 +55,7 @@ struct DeviceBackend : DpBackend {
             rv->cv_walk.wait(lk, [&] { return p.done; });       // (the dispatcher counts me as running again before it wakes me)
         }
         if (p.failed) { failed = true; return SPDP_NEVSEL; }
+        flags |= p.flags;
         rec.insert(rec.end(), p.rec.begin(), p.rec.end());
         return p.score;
     }
@@ -118,6 +121,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
             scores[q] = w.run(whole);
             recs[q].swap(w.rec);
             status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+            if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
         }
         std::lock_guard<std::mutex> g(rv.mu);
         --rv.running;
@@ -162,7 +166,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
                 Parked& q = *take[k];
                 if (brc < 0 || res[k].n_skl < 0) q.failed = true;
                 else {
-                    q.score = res[k].score;
+                    q.score = res[k].score; q.flags = res[k].flags;
                     if (res[k].n_skl > 0) q.rec.assign(res[k].skl, res[k].skl + res[k].n_skl);
                 }
                 q.done = true;
@@ -201,7 +205,7 @@ extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, cons
                                    const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out)
 {
     if (!ctx || !sc || !sp || !probs || !out) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; }
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n_probs <= 0) return 0;
     std::vector<int> scores;
     std::vector<std::vector<SpdpSkl>> recs;
@@ -209,8 +213,9 @@ extern "C" int spdp_align_s_seeded(SpdpContext* ctx, const SpdpScoring* sc, cons
     if (seeded_core(ctx, sc, sp, probs, n_probs, hsps, n_hsps, lowest_level, src, scores, recs, status) < 0) return -1;
     int partial = 0;
     for (int i = 0; i < n_probs; ++i) {
-        if (status[i]) { ++partial; continue; }
+        if (status[i] & 15) { ++partial; continue; }
         finish_walk(probs[i], scores[i], recs[i], false, out + i);
+        if (status[i] & 16) out[i].flags |= SPDP_ALN_LEFT_EDGE;
     }
     if (partial) { ctx->err = kPartial; return 1; }
     return 0;
@@ -226,7 +231,7 @@ extern "C" int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc,
                                         const SpdpHspSource* src, SpdpAlignment* out, int32_t* orient)
 {
     if (!ctx || !sc || !sp || !fwd || !rev || !out || !orient) return -1;
-    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; orient[i] = 0; }
+    for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; orient[i] = 0; }
     if (n_probs <= 0) return 0;
     const int n2 = 2 * n_probs;
     std::vector<SpdpProblem> both(fwd, fwd + n_probs);
@@ -254,11 +259,12 @@ extern "C" int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc,
     if (seeded_core(ctx, sc, sp, both.data(), n2, lists.data(), counts.data(), levels.data(), src, scores, recs, status) < 0) return -1;
     int partial = 0;
     for (int i = 0; i < n_probs; ++i) {
-        if (status[i] || status[n_probs + i]) { ++partial; continue; }
+        if ((status[i] | status[n_probs + i]) & 15) { ++partial; continue; }
         const int r = n_probs + i;
         orient[i] = scores[i] >= scores[r] ? 0 : 1;
         if (orient[i]) finish_walk(rev[i], scores[r], recs[r], true, out + i);
         else finish_walk(fwd[i], scores[i], recs[i], false, out + i);
+        if (status[orient[i] ? r : i] & 16) out[i].flags |= SPDP_ALN_LEFT_EDGE;
     }
     if (partial) { ctx->err = kPartial; return 1; }
     return 0;

@@ -295,7 +295,7 @@ class Engine:
         self.lib.spdp_free_alignments(arr, n)
         return res, orient
 
-    def _alignments(self, fn, sc, ps, what, allow_partial=False):
+    def _alignments(self, fn, sc, ps, what, allow_partial=False, with_flags=False):
         n = len(ps)
         arr = (abi.Alignment * n)()
         rc = fn(self.ctx, C.byref(sc), ps.array(), n, arr)
@@ -306,7 +306,7 @@ class Engine:
             k = arr[i].n_skl
             skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)],
                            dtype=np.int32).reshape(-1, 2)
-            res.append((int(arr[i].score), skl))
+            res.append((int(arr[i].score), skl, int(arr[i].flags)) if with_flags else (int(arr[i].score), skl))
         self.lib.spdp_free_alignments(arr, n)
         return res
 
@@ -475,11 +475,11 @@ class Engine:
         wait.keep = (parr, ps, sc)               # inputs stay alive until waited
         return wait
 
-    def align_s(self, sc, ps, allow_partial=False):
+    def align_s(self, sc, ps, allow_partial=False, with_flags=False):
         """alignS_ng (ori = 1, -Q0).  allow_partial: accept return value 1 (some problem needed the
         scalar engine for a < 8-row slab and the exact-model inputs were not supplied; those come
-        back without an alignment) instead of raising."""
-        return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s", allow_partial)
+        back without an alignment) instead of raising.  with_flags: (score, skl, SpdpAlignment.flags)."""
+        return self._alignments(self.lib.spdp_align_s, sc, ps, "spdp_align_s", allow_partial, with_flags)
 
     def skl_rng_s(self, sc, ps, alignments, *, codonk1, minl, jneibr, lsg=1):
         """skl_rngS_ng over finished alignments (rows of (m, n) with the header row first, as align_s

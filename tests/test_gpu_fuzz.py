@@ -217,34 +217,34 @@ def _ladder_udh_n_im(sc, m, n, step):
 
 @pytest.mark.parametrize("seed", [1, 2])
 def test_fuzz_cdna_ladder(eng, seed):
-    """alignS_ng with a small MaxVmfSpace (linear-space branch, slabs, recursion) under random
-    parameters: GPU ladder == oracle ladder wherever the top-level linear-space call is well defined"""
+    """alignS_ng with a small MaxVmfSpace (linear-space branch, slabs, recursion) under random parameters: GPU ladder ==
+    oracle ladder for EVERY query the library does not mark itself (SpdpAlignment.flags & SPDP_ALN_LEFT_EDGE: the path of
+    a linear-space call ran along the free left edge, where the reference reads link lanes it never initialised);
+    nothing is skipped on the oracle's say-so"""
     from oracle import oracle, host_logic
     rng = np.random.default_rng(synth.SEED + 9300 + seed)
-    n_cmp = n_skip = 0
+    n_cmp = n_marked = 0
     for rnd in range(3):
         sc = _rand_scoring_s(rng)
         sc.max_vmf_space = int(rng.choice([3000, 8000, 20000, 60000]))
         ps = abi.ProblemSet()
         for _ in range(40):
             _rand_problem_s(rng, ps)
-        res = eng.align_s(sc, ps, allow_partial=True)
-        for p, (score, skl) in zip(ps.items, res):
+        res = eng.align_s(sc, ps, allow_partial=True, with_flags=True)
+        for p, (score, skl, flags) in zip(ps.items, res):
             m, n = p.a_right - p.a_left, p.b_right - p.b_left
             k = _ladder_udh_n_im(sc, m, n, 1)
-            if k != 0:
-                ws, wcpos, wrng = oracle.wip_udh(sc, p, max(k, 1))
-                if not _well_defined(wrng, wcpos, oracle.wip_forward(sc, p)[1], 1):
-                    n_skip += 1
-                    continue
+            marked = bool(flags & abi.ALN_LEFT_EDGE)
+            if marked:
+                n_marked += 1
+                continue
             try:
                 wscr, wskl = host_logic.align_s(sc, p)
             except host_logic.NeedsScalarEngine:
-                n_skip += 1
                 continue
             n_cmp += 1
             assert score == wscr and skl.ravel().tolist() == (wskl or [])
-    assert n_cmp > n_skip
+    assert n_cmp > 2 * n_marked and n_cmp >= 60
 
 
 @pytest.mark.parametrize("seed", [1, 2])

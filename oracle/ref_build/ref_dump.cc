@@ -24,6 +24,9 @@
 //   -A list  only these engine selectors in the Aln2-surface section, and no engine-level section: fixtures beyond
 //            1472 nt, where the reference's int16 engines (-A1..3) are erratic and -A0 is the truth
 //   -X n     algmode.crs (-yX)                        -C     -LC (local, LocalC)
+//   -I list  the query carries conserved intron positions (a SigII as a database entry with gene structure has it,
+//            src/dbs.cc:780): Cip_score::cip_score(m) (src/gsinfo.cc:65-79) then gives every intron accepted in row m a
+//            bonus under -A0 / -A1; -J w = alprm2.spb (the weight, as -yJ).  The bonus row is dumped as `cip`.
 //   -B       the -O12 record files of the -A0 and -A2 alignments instead of their -O4 text (keys o12_grd / o12_erd / o12_qrd)
 //   -Q n     seeded path (algmode.qck = n, 1..3): the HSPs of geneorient() as match_2 obtains them (spaln.cc:773-776) are
 //            dumped as inputs, alignS_ng(seqs, pwd, gsi, 1) runs with seeding on, and every Wilip the walk constructs on a
@@ -74,6 +77,8 @@ int main(int argc, const char** argv)
 const	char*	exg = 0;
 	std::vector<int>	udh_list, alg_list;
 	int	rng4[4] = {-1, -1, -1, -1};
+	std::vector<int>	intron_pos;
+	float	spb = 0;
 	int	ai = 1;
 	for ( ; ai < argc && argv[ai][0] == '-'; ++ai) {
 	    switch (argv[ai][1]) {
@@ -83,6 +88,16 @@ const	char*	exg = 0;
 		case 'O': ori3 = 1; break;
 		case 'Q': seeded_q = atoi(argv[++ai]) & 3; break;
 		case 'B': g_o12_mode = true; break;
+		case 'I': {			// query positions that carry a conserved intron (SigII of the query), -J weight
+		    const char* p = argv[++ai];
+		    while (*p) {
+			intron_pos.push_back(atoi(p));
+			while (*p && *p != ',') ++p;
+			if (*p == ',') ++p;
+		    }
+		    break;
+		}
+		case 'J': spb = atof(argv[++ai]); break;
 		case 'X': crs = atoi(argv[++ai]); break;	// algmode.crs as -yX sets it (simmtx.cc:704): 0 = same species
 		case 'C': local = 3; break;			// -LC: local with LocalC (algmode.lcl & 32)
 		case 'A': {
@@ -162,6 +177,11 @@ const	char*	outfn = argv[ai + 2];
 	    b->exg_seq(exg[2] == '1', exg[3] == '1');
 	}
 	b->exin = new Exinon(b, pwd, false);
+	if (!intron_pos.empty()) {
+	    if (spb > 0) alprm2.spb = spb;
+	    (void) spb_fact();
+	    a->sigII = new SigII(intron_pos.data(), (int) intron_pos.size(), 1);
+	}
 	if (seeded_q) {
 	    // the two-sequence set-up of match_2 (spaln.cc:742-776): the reverse strand beside the forward one, HSPs of
 	    // the lowest level that finds any from geneorient()
@@ -351,6 +371,12 @@ const	char*	outfn = argv[ai + 2];
 	    for (int l = 0; l < (int) ip.size(); ++l)
 		ip[l] = pwd->IntPen->Penalty(l);
 	    w.put("intpen", 2, ip.data(), ip.size());
+	    if (a->sigII) {
+		Cip_score	cs(a);
+		std::vector<int>	cv(a->len + 1);
+		for (int m = 0; m <= a->len; ++m) cv[m] = (int) cs.cip_score(m);
+		w.put_i32("cip", cv);
+	    }
 	}
 
 // ---- reference results

@@ -120,6 +120,20 @@ def cases():
     g = gene(7100, n_exons=24, mrna_len=6000, flank=1000, intron_hi=2500)
     c["c5_6kb"] = (g.window, g.query, ["-A", "0"])
     c.update(protein_cases())
+    c.update(cip_cases())
+    return c
+
+
+def cip_cases():
+    """queries that carry conserved intron positions (ref_dump -I: a SigII on the query, Cip_score::cip_score(m) per row):
+    at the true junctions, displaced by a few residues with a weight that outbids the splice signals, and with the ladder in
+    its linear-space branch"""
+    c = {}
+    for k, (shift, w, extra) in enumerate(((0, 8, []), (3, 40, []), (-2, 25, ["-V", "150000"]), (0, 12, ["-V", "60000", "-U", "2"]))):
+        g = gene(60 + k, n_exons=6, mrna_len=800, flank=400, intron_hi=900, sub=0.12, indel=0.0)
+        cum = np.cumsum([b - a for a, b in g.exons])[:-1]
+        pos = sorted(set(int(x) + shift for x in cum) | {int(cum[0]) + 37, int(cum[2]) - 41})
+        c[f"cp_shift{shift}_w{w}" + ("_udh" if extra else "")] = (g.window, g.query, ["-I", ",".join(map(str, pos)), "-J", str(w)] + extra)
     return c
 
 

@@ -1,8 +1,8 @@
 """SpdpProblem.cip (Cip_score::cip_score(m), src/gsinfo.h:128-140): the per-row bonus every intron accepted in that row
 earns under the -A0 engines (src/fwd2s1.cc:254, 338) and the -A1 engines (src/fwd2s1_simd.cc:50).  GPU against the
 oracle's restatement with random sparse bonuses; the bonus must matter (alignments change), and a NULL list must
-equal an all-zero one.  (Parity with the reference itself is not pinned: a Cip_score needs a query with conserved
-intron positions, which the fixtures' plain FASTA queries do not carry.)"""
+equal an all-zero one.  Parity with the reference itself: test_cip_pinned_to_reference_runs (the cp_* fixtures, `ref_dump -I`:
+the query carries a SigII as a database entry with gene structure would)."""
 import numpy as np
 import pytest
 
@@ -61,3 +61,24 @@ def test_cip_against_oracle(engines):
             changed += r_bonus[i][0] != r_plain[i][0]
     eng.close()
     assert changed >= 6                                      # the bonus is priced in
+
+
+@pytest.mark.parametrize("alg,engines", [(0, 1), (1, 2), (2, 0)])
+def test_cip_pinned_to_reference_runs(alg, engines):
+    """the cp_* fixtures: the reference itself run on a query that carries conserved intron positions (ref_dump -I / -J);
+    HomScoreS_ng and alignS_ng under -A0 / -A1 (which read the bonus) and -A2 (which does not) through the ABI"""
+    from spaln_amd import engine
+    from tests.test_oracle_cip import cip_problem
+    eng = engine.Engine(0)
+    n = 0
+    for path in golden_files("cp_"):
+        fx = spdg.load(path)
+        sc = spdg.scoring(fx, scalar_engines=engines)
+        ps, p = cip_problem(fx)
+        assert int(eng.homscore_s(sc, ps)[0]) == int(fx[f"hom_scr_A{alg}"][0]), path
+        (scr, skl), = eng.align_s(sc, ps)
+        assert scr == int(fx[f"aln_scr_A{alg}"][0]), path
+        assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist(), path
+        n += 1
+    eng.close()
+    assert n == 4

@@ -512,6 +512,16 @@ typedef struct SpdpProblemH {
                                               NULL = none */
 } SpdpProblemH;
 
+/* Aln2h1::lspH_ng (src/fwd2h1.cc:2134-2230) for a caller that keeps the record file itself -- the protein side of the
+ * seeded path (interpolateH, src/fwd2h1.cc:3106-3120): the ladder below spdp_align_h, out[i].skl = the Mfile records as
+ * written (n_skl of them, no header, any order: globalH_ng's stdskl3 sorts), flags as spdp_align_h. */
+int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+/* the protein entry of the collector: spdp_collector_create_h owns `ctx` and one SpdpScoringH (its intpen table is copied; a
+ * signal model, if any, must outlive the collector); spdp_collector_align_h is spdp_collector_align_s for one SpdpProblemH
+ * (raw_records = 1: spdp_lsp_h results, 0: spdp_align_h results).  Destroy, error and stats calls are shared. */
+SpdpCollector* spdp_collector_create_h(SpdpContext* ctx, const struct SpdpScoringH* sc, int max_batch, int max_wait_us, int raw_records);
+int spdp_collector_align_h(SpdpCollector* c, const struct SpdpProblemH* p, SpdpAlignment* out);
+
 /* stripe31(seqs, &wdw, sh), src/aln2.cc:178-198 */
 void spdp_stripe31(const SpdpProblemH* p, int sh, SpdpWindow* wdw);
 /* (aa, nt) cells inside the band: rows m, columns max(b_left, lw + 3m) < n <= min(b_right, up + 3m) */

@@ -24,10 +24,32 @@ struct SpdpCollector {
     std::vector<float> mtx5, mtx3;
     int in_flight = 0;                          // callers inside spdp_collector_align_s
     int max_batch = 256, max_wait_us = 200, raw = 0;
-    struct Req { const SpdpProblem* p; SpdpAlignment* out; int rc = 0; bool done = false; };
+    bool protein = false;                       // spdp_collector_create_h: requests are SpdpProblemH, sch is the bundle
+    SpdpScoringH sch;
+    struct Req { const void* p; SpdpAlignment* out; int rc = 0; bool done = false; };
     int run(const SpdpProblem* probs, int n, SpdpAlignment* outs)
     {
         return raw ? spdp_lsp_s(ctx, &sc, probs, n, outs) : spdp_align_s(ctx, &sc, probs, n, outs);
+    }
+    int run(const SpdpProblemH* probs, int n, SpdpAlignment* outs)
+    {
+        return raw ? spdp_lsp_h(ctx, &sch, probs, n, outs) : spdp_align_h(ctx, &sch, probs, n, outs);
+    }
+    template <typename P> void serve(std::vector<Req*>& take, std::vector<SpdpAlignment>& outs, std::vector<int>& each, std::string& why)
+    {
+        std::vector<P> probs(take.size());
+        for (size_t i = 0; i < take.size(); ++i) probs[i] = *static_cast<const P*>(take[i]->p);
+        const int rc = run(probs.data(), (int) probs.size(), outs.data());
+        each.assign(take.size(), rc);
+        why = rc ? ctx->err : std::string();
+        if (rc < 0 && take.size() > 1) {
+            // one caller's malformed problem must not fail the callers that happened to share its batch: once more, one by one
+            for (size_t i = 0; i < take.size(); ++i) {
+                outs[i].score = SPDP_NEVSEL; outs[i].n_skl = 0; outs[i].skl = nullptr; outs[i].flags = 0; outs[i].reserved = 0;
+                each[i] = run(&probs[i], 1, &outs[i]);
+                if (each[i]) why = ctx->err;
+            }
+        }
     }
     std::mutex mu;
     std::condition_variable cv_req, cv_done;
@@ -52,20 +74,11 @@ struct SpdpCollector {
             while (!queue.empty() && (int) take.size() < max_batch) { take.push_back(queue.front()); queue.pop_front(); }
             if (!queue.empty()) first_arrival = std::chrono::steady_clock::now();
             lk.unlock();
-            std::vector<SpdpProblem> probs(take.size());
             std::vector<SpdpAlignment> outs(take.size());
-            for (size_t i = 0; i < take.size(); ++i) probs[i] = *take[i]->p;
-            const int rc = run(probs.data(), (int) probs.size(), outs.data());
-            std::vector<int> each(take.size(), rc);
-            std::string why = rc ? ctx->err : std::string();
-            if (rc < 0 && take.size() > 1) {
-                // one caller's malformed problem must not fail the callers that happened to share its batch: once more, one by one
-                for (size_t i = 0; i < take.size(); ++i) {
-                    outs[i].score = SPDP_NEVSEL; outs[i].n_skl = 0; outs[i].skl = nullptr; outs[i].flags = 0; outs[i].reserved = 0;
-                    each[i] = run(&probs[i], 1, &outs[i]);
-                    if (each[i]) why = ctx->err;
-                }
-            }
+            std::vector<int> each;
+            std::string why;
+            if (protein) serve<SpdpProblemH>(take, outs, each, why);
+            else serve<SpdpProblem>(take, outs, each, why);
             lk.lock();
             if (!why.empty()) err = why;
             ++n_batches; n_requests += (int64_t) take.size(); largest = std::max<int64_t>(largest, (int64_t) take.size());
@@ -97,6 +110,17 @@ extern "C" SpdpCollector* spdp_collector_create(SpdpContext* ctx, const SpdpScor
     return c;
 }
 
+extern "C" SpdpCollector* spdp_collector_create_h(SpdpContext* ctx, const SpdpScoringH* sc, int max_batch, int max_wait_us, int raw_records)
+{
+    if (!ctx || !sc) return nullptr;
+    SpdpCollector* c = new SpdpCollector;
+    c->ctx = ctx; c->protein = true; c->sch = *sc;
+    if (sc->intpen && sc->intpen_len > 0) { c->intpen.assign(sc->intpen, sc->intpen + sc->intpen_len); c->sch.intpen = c->intpen.data(); }
+    c->max_batch = std::max(1, max_batch); c->max_wait_us = std::max(0, max_wait_us); c->raw = raw_records ? 1 : 0;
+    c->worker = std::thread([c] { c->loop(); });
+    return c;
+}
+
 extern "C" void spdp_collector_destroy(SpdpCollector* c)
 {
     if (!c) return;
@@ -110,7 +134,18 @@ extern "C" void spdp_collector_destroy(SpdpCollector* c)
     delete c;
 }
 
+static int collector_call(SpdpCollector* c, const void* p, SpdpAlignment* out);
 extern "C" int spdp_collector_align_s(SpdpCollector* c, const SpdpProblem* p, SpdpAlignment* out)
+{
+    if (!c || c->protein) return -1;
+    return collector_call(c, p, out);
+}
+extern "C" int spdp_collector_align_h(SpdpCollector* c, const SpdpProblemH* p, SpdpAlignment* out)
+{
+    if (!c || !c->protein) return -1;
+    return collector_call(c, p, out);
+}
+static int collector_call(SpdpCollector* c, const void* p, SpdpAlignment* out)
 {
     if (!c || !p || !out) return -1;
     SpdpCollector::Req r;

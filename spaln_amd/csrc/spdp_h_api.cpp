@@ -1062,11 +1062,11 @@ static SpdpSkl* dup_skl(const std::vector<SpdpSkl>& v)
     return p;
 }
 
-// level 0: raw engine output; level 1: alignH_ng (header + stdskl3)
+// level 0: raw engine output; level 1: alignH_ng (header + stdskl3); level 2: lspH_ng (the ladder, records as written)
 static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
 {
     std::vector<HTop> tops;
-    if (run_ladder(st, level == 1, tops, hs)) return -1;
+    if (run_ladder(st, level >= 1, tops, hs)) return -1;
     int rc = 0;
     std::vector<SpdpSkl> stdv, full;
     for (int i = 0; i < st.n; ++i) {
@@ -1077,7 +1077,7 @@ static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
         if (t.cls) continue;
         out[i].score = t.score;
         if (t.flag) { out[i].n_skl = t.flag; continue; }
-        if (level == 0) {
+        if (level == 0 || level == 2) {
             out[i].n_skl = (int) t.rec.size();
             out[i].skl = dup_skl(t.rec);
         } else if (t.rec.size() >= 2) {                      // globalH_ng: fewer than 2 records = no alignment
@@ -1225,6 +1225,17 @@ int spdp_align_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* p
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
     HStats hs;
     return deliver(st, 1, out, hs);
+}
+
+// Aln2h1::lspH_ng (src/fwd2h1.cc:2134-2230) for a caller that keeps the record file itself -- the seeded path's
+// interpolateH (:3106-3120): the ladder below spdp_align_h, records as written (no header, no stdskl3)
+int spdp_lsp_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n_probs, SpdpAlignment* out)
+{
+    if (!ctx || !sc || !probs || n_probs < 0 || !out) return -1;
+    HStore st;
+    if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    HStats hs;
+    return deliver(st, 2, out, hs);
 }
 
 struct SpdpBatchH {

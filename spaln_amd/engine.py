@@ -145,12 +145,28 @@ class Collector:
     """SpdpCollector: single-problem calls from many host threads, run as device batches.
     Owns the engine's context while it lives; align_s() may be called from any number of threads."""
 
-    def __init__(self, eng: "Engine", sc: abi.Scoring, max_batch: int = 256, max_wait_us: int = 200, raw: bool = False):
+    def __init__(self, eng: "Engine", sc, max_batch: int = 256, max_wait_us: int = 200, raw: bool = False):
         self.eng, self.lib, self._sc = eng, eng.lib, sc
-        self.h = self.lib.spdp_collector_create(eng.ctx, C.byref(sc), int(max_batch), int(max_wait_us), 1 if raw else 0)
+        self.lib.spdp_collector_create.restype = C.c_void_p
+        self.lib.spdp_collector_create_h.restype = C.c_void_p
+        self.lib.spdp_collector_create.argtypes = self.lib.spdp_collector_create_h.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.lib.spdp_collector_align_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.protein = isinstance(sc, abi.ScoringH)
+        make = self.lib.spdp_collector_create_h if self.protein else self.lib.spdp_collector_create
+        self.h = make(eng.ctx, C.byref(sc), int(max_batch), int(max_wait_us), 1 if raw else 0)
         if not self.h:
             raise RuntimeError("spdp_collector_create failed")
         self.raw = raw
+
+    def align_h(self, p: abi.ProblemH):
+        out = abi.Alignment()
+        rc = self.lib.spdp_collector_align_h(self.h, C.byref(p), C.byref(out))
+        if rc < 0:
+            raise RuntimeError("spdp_collector_align_h: " + self.lib.spdp_collector_last_error(self.h).decode())
+        skl = np.array([(out.skl[i].m, out.skl[i].n) for i in range(max(out.n_skl, 0))], dtype=np.int32).reshape(-1, 2)
+        res = int(out.score), skl, (out.n_skl if out.n_skl < 0 else 0)
+        self.lib.spdp_free_alignments(C.byref(out), 1)
+        return res
 
     def align_s(self, p: abi.Problem):
         out = abi.Alignment()
@@ -635,6 +651,11 @@ class Engine:
     def align_h(self, sc, ps):
         """alignH_ng (-Q0): [flags, n, corners...] as rows of (m, n) after the header row."""
         return self._alignments_h(self.lib.spdp_align_h, sc, ps, "spdp_align_h")
+
+    def lsp_h(self, sc, ps):
+        """lspH_ng level: (score, raw Mfile records, flag) per problem"""
+        self.lib.spdp_lsp_h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        return self._alignments_h(self.lib.spdp_lsp_h, sc, ps, "spdp_lsp_h")
 
     def wip_udh_h(self, sc, ps, n_im: int):
         """SimdAln2h1::hirschbergH1_wip: (scores, cpos rows, written-back ranges)"""

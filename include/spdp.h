@@ -264,6 +264,7 @@ typedef struct SpdpSeedParams {
     int32_t codonk1;                 /* PwdB::codonk1 (GapPenalty, src/aln.h:275)                                         */
     int32_t any, both_ori;           /* algmode.any, Exinon::both_ori: Exinon::isCanon's site levels follow from them and
                                         the dinucleotide classes (src/codepot.cc:435-475, src/codepot.h:108-113)          */
+    int32_t ip_maxl, ip_mode;        /* IntronPrm.maxl, IntronPrm.mode (protein walk: first_exon_wmm / last_exon_wmm)      */
 } SpdpSeedParams;
 /* Wilip(seqs, pwd, level) (src/wln.cc:980) for the recursion levels above the one the caller's HSPs come from: the HSP
  * search stays with the caller (the reference's wln.cc in an integration).  units() is called from the walks' threads
@@ -505,6 +506,12 @@ typedef struct SpdpProblemH {
                                               <=> exin_left - 1 <= n < exin_right (codepot.h:120-123) */
     int32_t a_left, a_right, b_left, b_right;
     uint8_t a_exgl, a_exgr, b_exgl, b_exgr;
+    uint8_t a_pad;                         /* the code the reference's Seq holds behind the query, a->at(a->len)[0]: the
+                                              -A0 / -A1 engines price a phase -1 acceptor of the last row with the profile
+                                              of the "next" residue (qprof[1], src/fwd2h1.cc:368-370, 489).  Seq::exg_seq
+                                              (src/seq.cc:926-938) leaves nil_code = 0 there when the query's end gaps are
+                                              free or under the default tgapf, so 0 is the usual value */
+    uint8_t reserved_[3];
     const uint8_t* dinc;                   /* rescoring only: INT53::dinc5 << 4 | dinc3 per position, or NULL */
     const int32_t* cip;                    /* optional, the -A0 / -A1 engines only: Cip_score::cip_score(c) for coding
                                               position c = 0 .. 3 a_len + 1 (an intron accepted in row m at phase phs

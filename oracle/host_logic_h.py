@@ -58,9 +58,20 @@ def homscore_h(sc: abi.ScoringH, p: abi.ProblemH, simd: int = 2) -> int:
     return s
 
 
-def trcbk_h(sc, p, w, rec, simd=2):
+def trcbk_h(sc, p, w, rec, simd=2, cut=None, spj=True):
+    """trcbkalignH_ng(wdw, spj, mc): only the scalar engine listens to spj = false (src/fwd2h1.cc:2004-2018)"""
     if w.width < 0:
         return abi.NEVSEL
+    if not spj and sc.spj and (simd == 0 or p.a_right - p.a_left < 8 or cut is not None):
+        flat = abi.ScoringH.from_buffer_copy(sc)
+        flat.spj = 0
+        return trcbk_h(flat, p, w, rec, simd, cut)
+    if cut is not None:                                   # a cut range always takes the scalar engine (:2004-2008)
+        if not sc.intpen or not p.dinc:
+            raise NotRestated("forwardH_ng without its inputs (intpen / t53 / dinc)")
+        s, skl = oracle.scalar_forward_h_cut(sc, p, w, cut)
+        rec.extend((int(m), int(n)) for m, n in skl)
+        return s
     if simd == 0 or p.a_right - p.a_left < 8:             # forwardH_ng + Vmf::traceback
         if not sc.intpen or not p.dinc:
             raise NotRestated("forwardH_ng without its inputs (intpen / t53 / dinc)")

@@ -36,7 +36,8 @@ _WALK_SO = os.path.join(_HERE, "libwalkcheck.so")
 def build_walk_check(force: bool = False) -> str:
     """the seeded walk's CPU checker: the product's host walk (a header) compiled with callbacks in place of the device"""
     srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk.h"),
-            os.path.join(_HERE, "..", "include", "spdp.h")]
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk_h.h"),
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_gencode.h"), os.path.join(_HERE, "..", "include", "spdp.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_WALK_SO) or os.path.getmtime(_WALK_SO) < newest:
         tmp = f"{_WALK_SO}.{os.getpid()}.tmp"
@@ -276,6 +277,21 @@ def scalar_forward_h(sc: abi.ScoringH, p: abi.ProblemH, w=None, traceback=True):
         rc = lib().orc_scalar_forward_h(C.byref(sc), C.byref(p), C.byref(w), C.byref(s), None, None)
     if rc:
         raise RuntimeError(f"orc_scalar_forward_h rc={rc}")
+    out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
+    if n.value:
+        C.CDLL(None).free(skl)
+    return s.value, out
+
+
+def scalar_forward_h_cut(sc: abi.ScoringH, p: abi.ProblemH, w, cut):
+    """forwardH_ng with a cut range (shortcutH_ng): the sweep jumps over genomic columns (cut[0], cut[1]]"""
+    s = C.c_int32()
+    n = C.c_int32()
+    skl = C.POINTER(abi.Skl)()
+    rc = lib().orc_scalar_forward_h_cut(C.byref(sc), C.byref(p), C.byref(w), C.c_int(cut[0]), C.c_int(cut[1]),
+                                        C.byref(s), C.byref(skl), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_scalar_forward_h_cut rc={rc}")
     out = np.array([(skl[i].m, skl[i].n) for i in range(n.value)], dtype=np.int32).reshape(-1, 2)
     if n.value:
         C.CDLL(None).free(skl)

@@ -47,8 +47,9 @@
 extern "C" void ref_wilip_ctor(Wilip* self, const Seq** seqs, const PwdB* pwd, int level);
 bool	g_o12_mode = false;
 char	g_o12_prefix[256];
-static bool		wilip_tap_on = false;
-static std::vector<int>	wilip_tap_log;
+int	g_seeded_q = 0;
+bool		wilip_tap_on = false;
+std::vector<int>	wilip_tap_log;
 Wilip::Wilip(const Seq* seqs[], const PwdB* pwd, const int level)
 {
 	ref_wilip_ctor(this, seqs, pwd, level);
@@ -157,6 +158,7 @@ const	char*	outfn = argv[ai + 2];
 	if (svr.nextseq(a, 0) != IS_OK) { fprintf(stderr, "no query\n"); return 1; }
 	if (rng4[0] >= 0) { a->left = rng4[0]; a->right = rng4[1]; b->left = rng4[2]; b->right = rng4[3]; }
 	if (g_o12_mode) o12_begin();
+	g_seeded_q = seeded_q;
 	if (a->isprotein()) return dump_protein(seqs, exg, udh_list, outfn);
 	b->inex.intr = algmode.lsg;
 	makeWlprms(prePwd((const Seq**) seqs));

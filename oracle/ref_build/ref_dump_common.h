@@ -87,6 +87,9 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 // -B: the reference writes its -O12 record files (<prefix>.grd / .erd / .qrd, Gsinfo::ExonForm with BIN_FORM,
 // sqpr.cc:853-985) for the -A0 and the -A2 alignment of the case instead of the -O4 text; the three files end up in the
 // fixture byte for byte.  (One process can do one or the other: ExonForm opens its files on its first call only.)
+extern int	g_seeded_q;			// -Q n: the seeded path (algmode.qck)
+extern bool	wilip_tap_on;			// the Wilip tap of ref_dump.cc
+extern std::vector<int>	wilip_tap_log;
 extern bool	g_o12_mode;
 extern char	g_o12_prefix[256];
 inline void o12_begin()

@@ -17,8 +17,13 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	PwdB*	pwd = new PwdB((const Seq**) seqs);
 	makeStdSig53();
 	a->inex.intr = 0;
+	if (g_seeded_q) b->comrev(seqs + 2);		// (match_2, spaln.cc:748-756: the other strand first, then both to tron codes)
 	b->nuc2tron();
 	b->exin = new Exinon(b, pwd, false);
+	if (g_seeded_q) {
+	    seqs[2]->nuc2tron();
+	    seqs[2]->exin = new Exinon(seqs[2], pwd, false);
+	}
 	if (algmode.lcl & 16) {
 	    a->exg_seq(1, 1);
 	    b->exg_seq(1, 1);
@@ -30,9 +35,18 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	    a->exg_seq(exg[0] == '1', exg[1] == '1');
 	    b->exg_seq(exg[2] == '1', exg[3] == '1');
 	}
+	if (g_seeded_q) {
+	    // HSPs of the lowest level that finds any, as match_2 obtains them (spaln.cc:773-776)
+	    algmode.qck = g_seeded_q;
+	    Seq* const	b0 = b;
+	    const int np = geneorient(seqs, pwd);
+	    if (b != b0) { fprintf(stderr, "ref_dump -Q: the reverse strand won geneorient(); not a fixture\n"); return 3; }
+	    if (np == 0) fprintf(stderr, "ref_dump -Q: no HSP at any level\n");
+	}
 	Writer	w(outfn);
 	w.put_int("is_protein", 1);
 	w.put("a_codes", 1, a->at(0), a->len);
+	w.put_int("a_pad", *a->at(a->len));		// what exg_seq left behind the query (SpdpProblemH::a_pad)
 	w.put("b_codes", 1, b->at(0), b->len + 1);	// + the terminator the engine reads (sm_a at n = right + 2)
 	{
 	    // the signal model behind the SGPT6 arrays (Exinon::intron53_p, codepot.cc:524-611): the position weight
@@ -206,6 +220,48 @@ const	int	nq0 = IntronPrm.nquant;
 	    a->inex = ia; b->inex = ib;
 	};
 	char	nm[48];
+	if (g_seeded_q) {
+	    // alignH_ng with seeding on (fwd2h1.cc:3310 -> globalH_ng :3267 -> seededH_ng :3180 -> interpolateH :3022)
+	    std::vector<int> jx;
+	    for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {
+		const JUXT& t = b->jxt[j];
+		const int jr[5] = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		jx.insert(jx.end(), jr, jr + 5);
+	    }
+	    w.put_i32("seed_jxt", jx);		// CdsNo HSPs + the slot behind them, scores before addsigEjxt (:2397)
+	    float smn4 = getsmn(4), w2 = alprm2.w, maxsp = alprm.maxsp;
+	    int smn4b, w2b, maxspb;
+	    memcpy(&smn4b, &smn4, 4); memcpy(&w2b, &w2, 4); memcpy(&maxspb, &maxsp, 4);
+	    std::vector<int> sp = {(int) algmode.qck, b->wllvl, b->jxt? b->CdsNo: 0,
+		(int) setwlprm(0)->width, (int) setwlprm(1)->width, (int) setwlprm(2)->width, (int) setwlprm(3)->width,
+		IntronPrm.elmt, IntronPrm.minl, IntronPrm.tlmt, (int) pwd->Vthr, alprm2.desert, maxspb, (int) algmode.crs,
+		smn4b, w2b, (int) b->exin->gc_sig5, (int) algmode.lcl, (int) a->inex.ori, (int) b->exin->at_sig5,
+		IntronPrm.maxl, IntronPrm.mode};
+	    w.put_i32("seed_params", sp);
+	    std::vector<SGPT6> sg0;
+	    for (int n = std::max(0, b->left - 1); n <= b->right + 1; ++n) sg0.push_back(*b->exin->score_p(n));
+	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
+	    static const int algs[2] = {0, 2};
+	    for (int k = 0; k < 2; ++k) {
+const		int	alg = algs[k];
+		algmode.alg = alg;
+		restore();
+		for (int n = std::max(0, b->left - 1), i = 0; n <= b->right + 1; ++n, ++i) *b->exin->score_p(n) = sg0[i];
+		if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
+		wilip_tap_log.clear();
+		wilip_tap_on = true;
+		Gsinfo	gsi;
+		gsi.skl = alignH_ng((const Seq**) seqs, pwd, &gsi);
+		wilip_tap_on = false;
+		snprintf(nm, sizeof nm, "seed_scr_A%d", alg);
+		w.put_int(nm, (int) gsi.scr);
+		snprintf(nm, sizeof nm, "seed_skl_A%d", alg);
+		w.put_i32(nm, skl2vec(gsi.skl));
+		snprintf(nm, sizeof nm, "seed_wilip_A%d", alg);
+		w.put_i32(nm, wilip_tap_log);
+	    }
+	    return 0;
+	}
 	for (int pass = 0; pass < 2; ++pass) {
 	    IntronPrm.nquant = pass? 1: nq0;
 const	    char*	tag = pass? "q1": "qn";

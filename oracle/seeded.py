@@ -138,3 +138,66 @@ def align_s_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict,
         return score.value, None, rc
     fin = host_logic.trim_skl(host_logic.std_skl(recs), p)
     return score.value, [1, len(fin)] + [x for mn in fin for x in mn], rc
+
+
+JOINS_H = ["diagonal", "head_nogenome", "head_cds", "head_exon", "tail_nogenome", "tail_cds", "tail_exon", "junction",
+           "micro_exon", "shortcut", "backforth", "small_dp", "recurse", "dp", "giveup_head", "giveup_tail", "giveup_inner",
+           "pick_unit"]
+
+
+def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict, simd: int = 2, trace=None, joins=None):
+    """alignH_ng with seeding on (the product's protein walk, spdp_seeded_walk_h.h, over the oracle's ladder):
+    (gsi->scr, flat SKL or None, status); status 1 = the walk met a join it does not serve"""
+    from . import host_logic_h as hh
+    keep = []
+
+    def cb(_user, kind, args, out, n_out):
+        a = [args[i] for i in range(15)]
+        try:
+            if kind == 2:
+                key = (a[14], a[0], a[1], a[2], a[3])
+                if key not in wilip:
+                    raise KeyError(f"no recorded Wilip reply for {key}")
+                data = wilip[key]
+            else:
+                q = hh._sub(p, a[0], a[1], a[2], a[3], tuple(a[4:8]))
+                w = abi.Window()
+                w.lw, w.up, w.width = a[8], a[9], a[10]
+                rec = []
+                cut = (a[12], a[13]) if a[11] else None
+                scr = hh.lsp_h(sc, q, w, rec, simd) if kind == 0 else hh.trcbk_h(sc, q, w, rec, simd, cut, spj=kind == 1)
+                data = [int(scr)] + [int(x) for mn in rec for x in mn]
+            if trace is not None:
+                trace.append((kind, a, list(data)))
+        except Exception as e:                                   # noqa: BLE001
+            keep.append(e)
+            return 1
+        arr = np.asarray(data, dtype=np.int32)
+        keep.append(arr)
+        out[0] = arr.ctypes.data_as(C.POINTER(C.c_int32))
+        n_out[0] = arr.size
+        return 0
+
+    fn = _FN(cb)
+    jx = np.ascontiguousarray(hsps, dtype=np.int32)
+    cap = 1 << 16
+    rec = (abi.Skl * cap)()
+    score, n_rec = C.c_int32(), C.c_int()
+    jn = (C.c_int32 * lib().walk_check_n_joins_h())()
+    rc = lib().walk_check_run_h(C.byref(sc), C.byref(sp), C.byref(p), jx.ctypes.data_as(C.c_void_p), C.c_int(n_hsps),
+                                C.c_int(lowest_level), fn, None, C.byref(score), rec, C.c_int(cap), C.byref(n_rec), jn)
+    if joins is not None:
+        for k, v in enumerate(jn):
+            joins[JOINS_H[k]] = joins.get(JOINS_H[k], 0) + int(v)
+    errs = [e for e in keep if isinstance(e, Exception)]
+    if errs:
+        raise errs[0]
+    if rc < 0:
+        raise RuntimeError(f"walk_check_run_h rc={rc}")
+    if rc == 1:
+        return score.value, None, 1
+    recs = [(rec[i].m, rec[i].n) for i in range(1, n_rec.value)]
+    if len(recs) < 2:
+        return score.value, None, rc
+    fin = hh.std_skl3(recs)
+    return score.value, [1, len(fin)] + [x for mn in fin for x in mn], rc

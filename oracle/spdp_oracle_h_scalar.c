@@ -89,7 +89,7 @@ typedef struct {
     int minl;
 } Ctx;
 
-static inline int a_code(const Ctx* c, int i) { return (i < 0 || i >= c->p->a_len) ? AMB : c->p->a[i]; }
+static inline int a_code(const Ctx* c, int i) { return i < 0 ? AMB : (i >= c->p->a_len ? c->p->a_pad : c->p->a[i]); }
 static inline int b_code(const Ctx* c, int i) { return (i < 0 || i > c->p->b_len) ? AMB : c->p->b[i]; }
 static inline int mtx_at(const Ctx* c, int aa, int tron) { return c->sc->mtx[aa * c->sc->mtx_cols + tron]; }
 static inline int gap_ext3(const SpdpScoringH* sc, int i) { return i > sc->codonk1 ? sc->lgep : sc->gep; }
@@ -122,10 +122,15 @@ static void spjseq(const Ctx* c, int n5, int n3, int cs[2])
 
 /* rc 0 ok; -1 unsupported parameters.  skl / n_skl may be NULL (score only: no Vmf, as HomScoreH_ng
  * runs it).  With a traceback the records come back end -> start as trcbkalignH_ng writes them. */
-int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w,
+/* cut_r > cut_l: forwardH_ng's cut range (`cutrng`, src/fwd2h1.cc:294-312, 589-603; lastH_ng :210-281): after column cut_l
+ * the three insertion states, charged for the codons of the cut, replace the last three entries of the diagonal arrays
+ * and the sweep goes on behind the cut (shortcutH_ng, :2232-2260) */
+static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int cut_l, int cut_r,
                          int32_t* score, SpdpSkl** skl, int32_t* n_skl)
 {
     if (skl) { *skl = 0; *n_skl = 0; }
+    const int has_cut = cut_r > cut_l;
+    const int cutlen = has_cut ? cut_r - cut_l : 0;
     if (!sc->intpen || !p->dinc) return -1;
     if (w->width < 0) { *score = SPDP_NEVSEL; return 0; }
     code_tables();
@@ -139,7 +144,8 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
     const int LocalL = Local && p->a_exgl && p->b_exgl;
     const int LocalR = Local && p->a_exgr && p->b_exgr;
     const int spj = sc->spj;
-    const int lw = w->lw, up = w->up, width = w->width;
+    const int lw = w->lw, up = w->up, width = w->width - cutlen;
+    if (width < 7) { *score = SPDP_NEVSEL; return -1; }
     const int GOP[2] = {0, sc->gop};
     const size_t bufsiz = (size_t) 2 * width;
     Rvpd* buf = (Rvpd*) malloc((bufsiz + 8) * sizeof(Rvpd));
@@ -362,6 +368,16 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
                     break;
                 }
             }
+            if (has_cut && n == cut_l) {                /* shortcut: the insertion states run on over the cut */
+                h -= 3; f -= 3;
+                for (int pp = 0; pp < 3; ++pp) {
+                    if (++q == 3) q = 0;
+                    e1[q].val += sc->gep * cutlen / 3;
+                    *++h = e1[q];
+                    *++f = black;
+                }
+                n += cutlen;
+            }
         }
     }
 
@@ -371,10 +387,10 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
         int glen[3] = {0, 0, 0};
         int rw = lw;
         const int m3 = 3 * ar;
-        int rf = bl - m3;
+        int rf = (has_cut ? cut_l : bl) - m3;
         if (rf > rw) rw = rf; else rf = rw;
-        Rvpd* h = hh0 + rw;
-        Rvpd* h9 = hh0 + br - m3;
+        Rvpd* h = hh0 + rw - cutlen;
+        Rvpd* h9 = hh0 + br - m3 - cutlen;
         Rvpd* mx = h9;
         int bb = rw + m3;
         int done = 0;
@@ -410,7 +426,7 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
             if (y > h9->val) { *h9 = h9[-3]; h9->val = y; h9->dir = HORI; }
         }
         if (p->b_exgr == 1) {
-            rw = imin(up, br - 3 * al);
+            rw = imin(up, br - 3 * al) - cutlen;
             int g[3] = {NEV, NEV, NEV};
             h = hh0 + rw - 3;
             for (int ph = 0; h >= h9; --h) {
@@ -423,7 +439,7 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
                 if (++ph == 3) ph = 0;
             }
         } else if (p->b_exgr == 2) {
-            mx = hh1 + br - m3;
+            mx = hh1 + br - m3 - cutlen;
             mx->ptr = vmf_add(&vmf, ar, br, mx->ptr);
             done = 1;
         }
@@ -462,6 +478,17 @@ int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const Sp
     free(buf); free(vmf.rec);
     *score = scr;
     return 0;
+}
+
+int orc_scalar_forward_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w,
+                         int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    return scalar_forward_h_impl(sc, p, w, 0, 0, score, skl, n_skl);
+}
+int orc_scalar_forward_h_cut(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int cut_l, int cut_r,
+                             int32_t* score, SpdpSkl** skl, int32_t* n_skl)
+{
+    return scalar_forward_h_impl(sc, p, w, cut_l, cut_r, score, skl, n_skl);
 }
 
 /* ---- unidirectional Hirschberg, scalar -------------------------------------------------------

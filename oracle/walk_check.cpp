@@ -69,3 +69,54 @@ extern "C" int walk_check_run(const SpdpScoring* sc, const SpdpSeedParams* sp, c
     if (be.failed) return -1;
     return w.unsupported ? 1 : 0;
 }
+
+// ---- the protein walk (spdp_seeded_walk_h.h), same scheme: kind 0 lspH_ng, 1 trcbkalignH_ng, 2 Wilip, 3 trcbkalignH_ng
+// without introns (spj = false)
+#include "../spaln_amd/csrc/spdp_seeded_walk_h.h"
+namespace {
+struct CallbackBackendH : DpBackendH {
+    WalkCheckFn fn; void* user; bool failed = false;
+    int call(int kind, const Span& s, const SpdpWindow* w, const int* cut, int level, const int32_t** out, int32_t* n)
+    {
+        int32_t args[15] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr, w ? w->lw : 0, w ? w->up : 0,
+                            w ? w->width : 0, cut ? 1 : 0, cut ? cut[0] : 0, cut ? cut[1] : 0, level};
+        return fn(user, kind, args, out, n);
+    }
+    int dp(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
+    {
+        const int32_t* out = nullptr; int32_t n = 0;
+        if (call(kind, s, &w, cut, 0, &out, &n) || n < 1) { failed = true; return SPDP_NEVSEL; }
+        for (int i = 1; i + 1 < n; i += 2) rec.push_back({out[i], out[i + 1]});
+        return out[0];
+    }
+    int lsp(const Span& s, const SpdpWindow& w, std::vector<SpdpSkl>& rec) override { return dp(0, s, w, nullptr, rec); }
+    int trcbk(const Span& s, const SpdpWindow& w, bool spj, const int* cut, std::vector<SpdpSkl>& rec) override { return dp(spj ? 1 : 3, s, w, cut, rec); }
+    bool wilip(int level, const Span& s, std::vector<Unit>& units) override
+    {
+        const int32_t* out = nullptr; int32_t n = 0;
+        if (call(2, s, nullptr, nullptr, level, &out, &n) || n < 1) { failed = true; return false; }
+        return spdp_seed::parse_units(out, n, units);
+    }
+};
+}   // namespace
+
+extern "C" int walk_check_n_joins_h() { return SeedWalkH::J_COUNT; }
+
+extern "C" int walk_check_run_h(const SpdpScoringH* sc, const SpdpSeedParams* sp, const SpdpProblemH* p,
+                                const SpdpJuxt* hsps, int n_hsps, int lowest_level, WalkCheckFn fn, void* user,
+                                int32_t* score, SpdpSkl* rec, int cap, int* n_rec, int32_t* joins)
+{
+    CallbackBackendH be;
+    be.fn = fn; be.user = user;
+    SeedWalkH w;
+    if (!spdp_seed::bind_problem_h(w, sc, sp, p, hsps, n_hsps, lowest_level)) return -1;
+    w.dp = &be;
+    const Span whole = {p->a_left, p->a_right, p->b_left, p->b_right, p->a_exgl, p->a_exgr, p->b_exgl, p->b_exgr};
+    *score = w.run(whole);
+    *n_rec = (int) w.rec.size();
+    if (joins) for (int k = 0; k < SeedWalkH::J_COUNT; ++k) joins[k] = w.joins[k];
+    if ((int) w.rec.size() > cap) return -1;
+    if (!w.rec.empty()) memcpy(rec, w.rec.data(), sizeof(SpdpSkl) * w.rec.size());
+    if (be.failed) return -1;
+    return w.unsupported ? 1 : 0;
+}

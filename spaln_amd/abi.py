@@ -110,7 +110,8 @@ class SeedParams(C.Structure):           # SpdpSeedParams
     _fields_ = [("qck", C.c_int32), ("wl_width", C.c_int32 * 4), ("elmt", C.c_int32), ("minl", C.c_int32),
                 ("vthr", C.c_int32), ("desert", C.c_int32), ("maxsp", C.c_float), ("crs", C.c_int32),
                 ("smn4", C.c_float), ("w2", C.c_float), ("gc_sig5", C.c_int32), ("lcl", C.c_int32),
-                ("codonk1", C.c_int32), ("any", C.c_int32), ("both_ori", C.c_int32)]
+                ("codonk1", C.c_int32), ("any", C.c_int32), ("both_ori", C.c_int32), ("ip_maxl", C.c_int32),
+                ("ip_mode", C.c_int32)]
 
 
 HSP_UNITS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -136,8 +137,13 @@ def seed_params_from_fixture(fx: dict) -> SeedParams:
     sp.w2 = float(v[15:16].view(np.float32)[0])
     sp.gc_sig5, sp.lcl = int(v[16]), int(v[17])
     sp.codonk1 = int(fx["params"][7])
-    sm = np.asarray(fx["sigmodel"], dtype=np.int32)
-    sp.any, sp.both_ori = int(sm[1]), int(sm[3]) if sm.size > 3 else 0
+    if "sigmodel" in fx:
+        sm = np.asarray(fx["sigmodel"], dtype=np.int32)
+        sp.any, sp.both_ori = int(sm[1]), int(sm[3]) if sm.size > 3 else 0
+    else:                                                # protein fixtures: sigmodel_i32 = any, DvsP, ...
+        sp.any, sp.both_ori = int(fx["sigmodel_i32"][0]), 0
+    if v.size > 21:
+        sp.ip_maxl, sp.ip_mode = int(v[20]), int(v[21])
     return sp
 
 
@@ -388,6 +394,7 @@ class ProblemH(C.Structure):
         ("b_left", C.c_int32), ("b_right", C.c_int32),
         ("a_exgl", C.c_uint8), ("a_exgr", C.c_uint8),
         ("b_exgl", C.c_uint8), ("b_exgr", C.c_uint8),
+        ("a_pad", C.c_uint8), ("reserved_", C.c_uint8 * 3),
         ("dinc", C.c_void_p),
         ("cip", C.c_void_p),
     ]
@@ -441,11 +448,12 @@ class ProblemSetH:
         self.items = []
 
     def add(self, a, b, sig5, sig3, sigS, sigT, sigE, phs5, phs3, a_left=0, a_right=None,
-            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None, dinc=None, cip=None):
+            b_left=0, b_right=None, exg=(1, 1, 1, 1), exin=None, dinc=None, cip=None, a_pad=0):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         b = np.ascontiguousarray(b, dtype=np.uint8)          # b_len + 1 entries
         b_len = b.size - 1
         p = ProblemH()
+        p.a_pad = int(a_pad)
         p.a, p.a_len = a.ctypes.data, a.size
         p.b, p.b_len = b.ctypes.data, b_len
         self._keep += [a, b]

@@ -31,7 +31,7 @@
 
 enum { H_POOL = 5, HU_POOL = 6 };           // ctx->pool[] slot groups: inputs + traceback runs / linear-space runs
 enum { HP_SC = 0, HP_A, HP_COLS, HP_AUX, HP_PROBS, HP_BND, HP_TB, HP_RES, HP_SKL, HP_NSKL, HP_PACK, HP_OFF, HP_INTPEN, HP_PIPE };
-void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64]);       // spdp_rescore_api.cpp
+#include "spdp_gencode.h"
 int spdh_signals_run(SpdpContext* ctx, const SpdpSignalModelH* m, const std::vector<SigJobH>& jobs, SignalArgsH args, int pack);   // spdp_signals_api.cpp
 enum { HU_PROBS = 0, HU_BND, HU_IMD, HU_RES, HU_CPOS, HU_RANGES, HU_SCORES, HU_PIPE };
 static const int H_SKL_CAP = 4096;       // slot of one traceback record list; a list is at most ~4 records per query row (diagonal / gap corners and
@@ -301,6 +301,7 @@ static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
     d.n_im = it.n_im; d.imd_intvl = it.imd_intvl;
     d.a_len = st.probs[it.top].a_len; d.b_len = st.probs[it.top].b_len;
     d.cip_off = st.cip_off.empty() ? -1 : st.cip_off[it.top];
+    d.a_pad = st.probs[it.top].a_pad;
     d.cells = cells_of(it);
 }
 

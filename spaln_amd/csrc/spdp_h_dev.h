@@ -51,6 +51,7 @@ struct DevProblemH {
     int32_t a_len, b_len;          // parent sequence lengths (scalar engine: positions beyond read as padding)
     int32_t imd_intvl;             // scalar linear-space engine: rows between intermediates (Aln2h1::imd_intvl)
     int32_t cip_off;               // -A0 / -A1 engines: first entry of the query's cip row in HScalarArgs::cip, -1 = none
+    int32_t a_pad;                 // SpdpProblemH::a_pad
     int64_t a_off;
     int64_t col_off;               // into cols / aux
     int64_t bnd_off;               // into bnd (entries)

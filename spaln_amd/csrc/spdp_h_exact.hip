@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
     const int n_im = UDH ? P.n_im : 0;
     const int imd_step = UDH ? (a_right - a_left + n_im) / (n_im + 1) : 0;
     auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
-    auto acode = [&](int i) -> int { return (i < 0 || i >= P.a_len) ? 2 : acod[i]; };
+    auto acode = [&](int i) -> int { return i < 0 ? 2 : (i >= P.a_len ? P.a_pad : acod[i]); };      // a_pad: SpdpProblemH
     auto bcode = [&](int i) -> int { return (i < 0 || i > P.b_len) ? 2 : ((cols[i + 2].x >> 16) & 0xff); };
     auto mtx = [&](int aa, int tron) -> int { return sc->mtx[aa * 32 + tron]; };
     auto ipen = [&](int len) -> int {

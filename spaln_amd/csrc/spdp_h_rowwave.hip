@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         }
         if (s_lo <= s_hi) {
             const int aa0 = (row && m >= 1 && m - 1 < P.a_len) ? acod[m - 1] : AMB;       // the residue of my row, and the next one
-            const int aa1 = (row && m < P.a_len) ? acod[m] : AMB;
+            const int aa1 = row ? (m < P.a_len ? acod[m] : P.a_pad) : AMB;                  // a_pad: what the Seq holds behind the query
             const int* prof0 = T.mtx + aa0 * 32;
             const int* prof1 = T.mtx + aa1 * 32;
             // Cip_score::cip_score(3 m - phs) for the three phases (sigB[phs], src/fwd2h1.cc:352-354)

@@ -11,6 +11,7 @@
 #include "../../include/spdp.h"
 #include "spdp_dev.h"
 #include "spdp_internal.h"
+#include "spdp_gencode.h"
 
 #define HIPCHK(call)                                                                     \
     do {                                                                                 \
@@ -176,26 +177,6 @@ void spdp_free_rescored(SpdpRescored* out, int n)
 
 // ---- protein alignments: skl_rngH_ng ---------------------------------------------------------
 enum { RH_MTX = 8, RH_PROBS, RH_A, RH_B, RH_SIG, RH_PHS, RH_DINC, RH_INTPEN };   // pool slots after the cDNA ones
-
-// the standard genetic code in the reference's tron alphabet (A = 3 ... V = 22, AGY serines 23, TGA 24,
-// TAA / TAG 25), as its static spj_tron_tab / tnredctab assume (src/codepot.h:130, src/seq.cc:41)
-void spdp_genetic_code_tables(uint8_t mid[32], uint8_t tron_of[64])
-{
-    static const char* aas = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";   // TCAG order
-    static const char* order = "ARNDCQEGHILKMFPSTWYV";
-    const int tcag2acgt[4] = {3, 1, 0, 2};
-    memset(mid, 4, 32);
-    for (int c = 0; c < 64; ++c) {
-        const int b1 = tcag2acgt[c >> 4], b2 = tcag2acgt[(c >> 2) & 3], b3 = tcag2acgt[c & 3];
-        const char aa = aas[c];
-        int code;
-        if (aa == '*') code = (b1 == 3 && b2 == 2 && b3 == 0) ? 24 : 25;        // TGA : TAA / TAG
-        else if (aa == 'S' && b1 == 0) code = 23;                                // AGY
-        else code = 3 + (int) (strchr(order, aa) - order);
-        tron_of[16 * b1 + 4 * b2 + b3] = (uint8_t) code;
-        mid[code] = (uint8_t) b2;
-    }
-}
 
 static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
                      const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out,

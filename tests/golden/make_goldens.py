@@ -286,7 +286,7 @@ def main():
         from tests.golden import seed_cases
         base = {**cases(), **dictdisc_cases()}
         o12 = {"o12_" + k: (base[k][0], base[k][1], ["-B"] + base[k][2]) for k in O12_CASES}
-        for name, (window, query, opts) in {**base, **seed_cases.cases(), **o12}.items():
+        for name, (window, query, opts) in {**base, **seed_cases.cases(), **seed_cases.cases_h(), **o12}.items():
             if only and name not in only:
                 continue
             gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
@@ -305,6 +305,10 @@ def main():
                 from tests import spdg
                 fx = spdg.load(tmp)
                 spdg.save(tmp, {k: fx[k] for k in O12_KEEP if k in fx})
+            if r.returncode == 0 and name.startswith("qh_"):        # the walk does not read the signal model's tables
+                from tests import spdg
+                fx = spdg.load(tmp)
+                spdg.save(tmp, {k: v for k, v in fx.items() if k != "prm" and not (k.endswith("_f32") and k[:2] in ("po", "pm"))})
             if r.returncode == 0:
                 if os.path.exists(out) and same_but_boundary_signal(out, tmp):
                     status += " (unchanged)"

@@ -82,6 +82,60 @@ def make_case(seed):
 
 
 
+def make_case_h(seed):
+    """protein twin of make_case: (window, protein query, harness options, description)"""
+    rng = np.random.default_rng(synth.SEED + 60000 + seed)
+    kind = seed % 8
+    n_exons = int(rng.integers(2, 7))
+    aa = int(rng.integers(80, 420))
+    sub = float(rng.choice([0.0, 0.05, 0.15, 0.3, 0.45]))
+    g = synth.make_protein_gene(rng, n_exons=n_exons, aa_len=aa, flank=int(rng.integers(100, 900)),
+                                sub=sub, intron_hi=int(rng.choice([300, 1200, 4000])))
+    w, q = g.window, g.query
+    opts = ["-Q", str(int(rng.integers(1, 4)))]
+    if rng.random() < 0.4:
+        opts += ["-X", "0"]
+    desc = f"ex{n_exons} aa{aa} sub{sub}"
+    if kind == 1:                                   # junk residues at both ends of the protein
+        aas = synth._AA_LETTERS
+        q = np.concatenate([aas[rng.integers(0, 20, size=int(rng.integers(2, 25)))], q,
+                            aas[rng.integers(0, 20, size=int(rng.integers(2, 25)))]])
+        desc += " junk_ends"
+    elif kind == 2:                                 # window cut inside the gene
+        e = g.exons
+        lo = e[0][0] + int(rng.integers(5, max(6, e[0][1] - e[0][0] - 5))) if rng.random() < 0.7 else 0
+        hi = e[-1][1] - int(rng.integers(5, max(6, e[-1][1] - e[-1][0] - 5))) if rng.random() < 0.7 else len(w)
+        w = w[lo:hi]
+        desc += " cut"
+    elif kind == 3:                                 # a stretch of the protein replaced by noise
+        a0 = int(rng.integers(0, max(1, len(q) - 30)))
+        ln = int(rng.integers(8, min(120, len(q) - a0)))
+        q = q.copy()
+        q[a0:a0 + ln] = synth._AA_LETTERS[rng.integers(0, 20, size=ln)]
+        desc += f" noise{ln}"
+    elif kind == 4:                                 # residues missing from / inserted into the query
+        a0 = int(rng.integers(5, max(6, len(q) - 40)))
+        if rng.random() < 0.5:
+            q = np.concatenate([q[:a0], q[a0 + int(rng.integers(1, 30)):]])
+        else:
+            q = np.concatenate([q[:a0], synth._AA_LETTERS[rng.integers(0, 20, size=int(rng.integers(1, 20)))], q[a0:]])
+        desc += " query_indel"
+    elif kind == 5:                                 # a frame shift in an exon of the window
+        k = int(rng.integers(0, n_exons))
+        a_, b_ = g.exons[k]
+        at = a_ + (b_ - a_) // 2
+        w = np.concatenate([w[:at], w[at + int(rng.integers(1, 3)):]]) if rng.random() < 0.5 else \
+            np.concatenate([w[:at], synth.random_dna(rng, int(rng.integers(1, 3))), w[at:]])
+        desc += " frameshift"
+    elif kind == 6:
+        opts += ["-V", str(int(rng.choice([60000, 200000, 600000])))]
+        desc += " smallV"
+    elif kind == 7:                                 # unrelated pair
+        q = synth._AA_LETTERS[rng.integers(0, 20, size=int(rng.integers(30, 200)))]
+        desc += " random"
+    return w, q, opts, desc
+
+
 def special_cases():
     """name -> (window, query, options)"""
     c = {}
@@ -113,6 +167,21 @@ def special_cases():
     for k in range(2):
         g = synth.make_gene(np.random.default_rng(synth.SEED + 7000 + k), sub=0.06, indel=0.006)
         c[f"q_c2_seed{k}"] = (g.window, g.query, ["-Q", "3"])
+    return c
+
+
+# the protein walk (seededH_ng / interpolateH): seeds of make_case_h picked with tools/seed_fuzz_h.py so that every join
+# the walk serves is reached (diagonal, CDS ends, first / last exon, indel-free junction, micro exon, shortcut with its
+# cut range, back-and-forth, small DP without introns, recursion, DP, the three give-ups), all three -Q levels, both
+# -X settings; 65 has no HSP at any level and an optimum that hangs on the code behind the query (SpdpProblemH::a_pad)
+FIXTURE_SEEDS_H = [116, 45, 13, 82, 85, 89, 123, 0, 3, 5, 6, 14, 24, 32, 38, 65, 98]
+
+
+def cases_h():
+    c = {}
+    for s in FIXTURE_SEEDS_H:
+        w, q, opts, _ = make_case_h(s)
+        c[f"qh_{s:04d}"] = (w, q, opts)
     return c
 
 

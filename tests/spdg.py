@@ -118,6 +118,7 @@ def problem_h(fx: dict, ps: abi.ProblemSetH | None = None):
         dinc = (fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8")
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], fx["sigS"], fx["sigT"], fx["sigE"],
                fx["phs5"], fx["phs3"], q["a_left"], q["a_right"], q["b_left"], q["b_right"],
-               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), dinc=dinc)
+               (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), dinc=dinc,
+               a_pad=int(fx["a_pad"][0]) if "a_pad" in fx else 0)     # the harness' exg_seq calls leave nil_code there
     p._owner = ps
     return ps, p

@@ -1,0 +1,70 @@
+"""The protein seeded path (alignH_ng with algmode.qck = 1 .. 3: seededH_ng / interpolateH) against the reference, on the CPU.
+
+The qh_* fixtures are `ref_dump -Q` runs of the compiled reference on aa x genome cases: HSPs of geneorient(), every
+Wilip reply the reference's own walk received, score + SKL of alignH_ng under -A0 and -A2.  The walk under test is the
+product's host source (spaln_amd/csrc/spdp_seeded_walk_h.h) compiled into oracle/libwalkcheck.so over the oracle's
+protein ladder (lspH_ng, trcbkalignH_ng with / without introns and with a cut range)."""
+import pytest
+
+from spaln_amd import abi
+from tests import spdg
+from tests.conftest import golden_files
+from oracle import seeded
+from oracle import host_logic_h as hh
+
+QH = golden_files("qh_")
+# the reference's own -A2 traceback starts outside its bitmap on the tail of this case (an out-of-bounds read,
+# SpdpAlignment n_skl = -2 in the product): its recorded output is not a function of the inputs
+UNDEFINED = {("qh_0098", 2)}
+
+
+def seeded_inputs_h(fx, alg):
+    sc = spdg.scoring_h(fx)
+    _, p = spdg.problem_h(fx)
+    sp = abi.seed_params_from_fixture(fx)
+    hsps, n = seeded.hsps_of(fx)
+    return sc, sp, p, hsps, n, int(fx["seed_params"][1]), seeded.parse_wilip_log(fx[f"seed_wilip_A{alg}"])
+
+
+@pytest.fixture(scope="module", params=QH, ids=[f.split("/")[-1][:-5] for f in QH])
+def fx(request):
+    f = spdg.load(request.param)
+    f["_name"] = request.param.split("/")[-1][:-5]
+    return f
+
+
+@pytest.mark.parametrize("alg,simd", [(0, 0), (2, 2)])
+def test_seeded_alignment_equals_reference(fx, alg, simd):
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, alg)
+    if (fx["_name"], alg) in UNDEFINED:
+        with pytest.raises(hh.ReferenceUndefined):
+            seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, simd)
+        return
+    scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, simd)
+    assert rc == 0
+    assert scr == int(fx[f"seed_scr_A{alg}"][0])
+    assert (flat or []) == fx[f"seed_skl_A{alg}"].tolist()
+
+
+def test_fixtures_reach_every_join():
+    """every branch of interpolateH the walk serves is taken by some fixture (pick_unit -- bestwlu among several units
+    -- needs paralogous HSP chains and is not reached by synthetic single-gene windows)"""
+    joins = {}
+    for f in QH:
+        fx = spdg.load(f)
+        sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 0)
+        seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 0, joins=joins)
+    missing = [k for k in seeded.JOINS_H if not joins.get(k) and k not in ("pick_unit", "head_nogenome")]
+    assert not missing, (missing, joins)
+
+
+def test_dp_calls_are_made():
+    """lspH_ng, trcbkalignH_ng with a cut range (shortcutH_ng) and without introns (the small-gap DP) all occur"""
+    kinds = set()
+    for f in QH:
+        fx = spdg.load(f)
+        sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 0)
+        tr = []
+        seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 0, trace=tr)
+        kinds |= {(kind, bool(a[11])) for kind, a, _ in tr}
+    assert {(0, False), (1, True), (2, False), (3, False)} <= kinds

@@ -523,6 +523,14 @@ typedef struct SpdpProblemH {
  * seeded path (interpolateH, src/fwd2h1.cc:3106-3120): the ladder below spdp_align_h, out[i].skl = the Mfile records as
  * written (n_skl of them, no header, any order: globalH_ng's stdskl3 sorts), flags as spdp_align_h. */
 int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs, int n_probs, SpdpAlignment* out);
+/* alignH_ng with seeding on (algmode.qck = 1 .. 3; Aln2h1::globalH_ng -> seededH_ng -> interpolateH, src/fwd2h1.cc:3267-3286,
+ * 3177-3265, 3023-3131): arguments as spdp_align_s_seeded (jy of an HSP is a nucleotide position of the tron sequence).
+ * The problems need all seven signal arrays and dinc on the host, sc->intpen / t53.  Return value and out[] as
+ * spdp_align_h; a walk that needs the exact three-frame search of the same-species mode (algmode.crs = 0 with a terminal
+ * stretch the HSPs leave open) or meets ambiguous bases at a junction is reported as not served (return 1, no alignment). */
+int spdp_align_h_seeded(SpdpContext* ctx, const struct SpdpScoringH* sc, const SpdpSeedParams* sp,
+                        const struct SpdpProblemH* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
+                        const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out);
 /* the protein entry of the collector: spdp_collector_create_h owns `ctx` and one SpdpScoringH (its intpen table is copied; a
  * signal model, if any, must outlive the collector); spdp_collector_align_h is spdp_collector_align_s for one SpdpProblemH
  * (raw_records = 1: spdp_lsp_h results, 0: spdp_align_h results).  Destroy, error and stats calls are shared. */

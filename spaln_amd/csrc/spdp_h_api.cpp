@@ -19,6 +19,7 @@
 #include "spdp_internal.h"
 #include "spdp_h_dev.h"
 #include "spdp_h_internal.h"
+#include "spdp_h_requests.h"
 
 #define HIPCHK(call)                                                                     \
     do {                                                                                 \
@@ -99,6 +100,9 @@ struct HItem {
     int n_im = 0, imd_intvl = 0;
     bool recursive = false, first = false;      // first: this call's return value is gsi->scr
     bool exact = false;                         // traceback by the -A1 engine (forwardH1)
+    int slot = -1;                              // result slot (the caller's problem, or the request)
+    bool nospj = false;                         // trcbkalignH_ng(wdw, spj = false): the scalar engine runs without introns
+    int cut_l = 0, cut_r = 0;                   // cut_r > cut_l: forwardH_ng jumps over genomic columns (cut_l, cut_r]
 };
 
 static int validate(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* p, int i)
@@ -270,7 +274,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
 static HItem item_of(const SpdpProblemH& p, int top, int sh)
 {
     HItem it;
-    it.top = top;
+    it.top = it.slot = top;
     it.a_left = p.a_left; it.a_right = p.a_right; it.b_left = p.b_left; it.b_right = p.b_right;
     it.a_exgl = p.a_exgl; it.a_exgr = p.a_exgr; it.b_exgl = p.b_exgl; it.b_exgr = p.b_exgr;
     stripe31_rng(p.a_left, p.a_right, p.b_left, p.b_right, sh, &it.w);
@@ -290,7 +294,8 @@ static void fill_desc(const HStore& st, const HItem& it, DevProblemH& d)
 {
     memset(&d, 0, sizeof d);
     d.a_left = it.a_left; d.a_right = it.a_right; d.b_left = it.b_left; d.b_right = it.b_right;
-    d.lw = it.w.lw; d.up = it.w.up; d.width = it.w.width; d.buf_size = it.w.width + 6 * SPDH_NELEM;
+    d.cut_l = it.cut_l; d.cut_len = std::max(0, it.cut_r - it.cut_l); d.nospj = it.nospj ? 1 : 0;
+    d.lw = it.w.lw; d.up = it.w.up; d.width = it.w.width - d.cut_len; d.buf_size = it.w.width + 6 * SPDH_NELEM;
     d.a_exgl = it.a_exgl; d.a_exgr = it.a_exgr; d.b_exgl = it.b_exgl; d.b_exgr = it.b_exgr;
     d.m_width = it.a_right - it.a_left + 1;
     d.n_width = it.b_right - it.b_left + 1 + 3 * d.m_width;
@@ -516,7 +521,7 @@ static int64_t vmf_budget_h(const DevProblemH& d, int scale)
     return std::min<int64_t>(full, std::max<int64_t>(d.cells / 2, 64 * rows) * scale + 3ll * (d.b_right - d.b_left + 8) + 64);
 }
 
-static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale)
+static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale, bool cut = false)
 {
     SpdpContext* ctx = st.ctx;
     DevPool& pool = ctx->pool[H_POOL];
@@ -570,12 +575,12 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
     A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
     HPipe pp;
-    if (!exact && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;
+    if (!exact && !cut && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;     // (the cut-range variant runs one wave per problem)
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pipe_arm(ctx, pp, nr, A)) return -1;
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         if (exact) HIPCHK(spdh_launch_exact(0, &A, ctx->stream));
-        else HIPCHK(spdh_launch_scalar(forward ? 1 : 0, &A, ctx->stream));
+        else HIPCHK(spdh_launch_scalar(cut ? 2 : (forward ? 1 : 0), &A, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         if (!pp.on) break;
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -616,7 +621,7 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
 
 // the same over any number of items: launches whose record space stays below SPDP_VMF_GB (default 32) gigabytes, and
 // another round with a larger budget for the problems that outgrew theirs
-static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false)
+static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false, bool cut = false)
 {
     SpdpContext* ctx = st.ctx;
     const int nr = (int) items.size();
@@ -644,7 +649,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
                 sum += bytes; part.push_back(items[todo[hi++]]);
             }
             HFwdOut po;
-            if (run_scalar_group(st, part, true, po, exact, scale)) return -1;
+            if (run_scalar_group(st, part, true, po, exact, scale, cut)) return -1;
             out.sweep_ms += po.sweep_ms; out.cells += po.cells;
             for (size_t k = lo; k < hi; ++k) {
                 const int i = todo[k], c = po.n_skl[k - lo];
@@ -842,6 +847,15 @@ static thread_local int a0_mode = 0;             // SpdpScoringH.scalar_engines 
 static bool queue_trcbk(const HItem& it, std::vector<HItem>& fwd, std::vector<HItem>& scl, bool scalar_ok, HTop& t)
 {
     if (it.w.width < 0) return true;                         // NEVSEL, no records
+    if (it.cut_r > it.cut_l) {                               // a cut range: always the scalar engine (:2004-2008)
+        // what the kernel serves: both ends global (shortcutH_ng clears all four flags), every row starts before the
+        // cut, room for the seven entries a row needs
+        const int cl = it.cut_r - it.cut_l;
+        if (!scalar_ok || it.a_exgl || it.a_exgr || it.b_exgl || it.b_exgr || it.w.width - cl < 7 ||
+            it.cut_l < it.b_left || it.cut_r > it.b_right || 3 * it.a_right + it.w.lw - 1 > it.cut_l) { t.cls = 1; return false; }
+        scl.push_back(it);
+        return true;
+    }
     if (a0_mode == 1 || it.a_right - it.a_left < 8) {        // -A0, or below 8 rows: scalar forwardH_ng
         if (!scalar_ok) { t.cls = 1; return false; }
         scl.push_back(it);
@@ -933,13 +947,28 @@ static void slab_window(HItem& it, int sh, const int32_t* row)
     it.w.width = it.w.up - it.w.lw + 7;
 }
 
-static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& hs)
+static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& hs, const SpdhRequest* reqs = nullptr, int n_reqs = 0)
 {
     const SpdpScoringH& sc = st.sc;
     a0_mode = ladder ? sc.scalar_engines : 0;
-    tops.assign(st.n, HTop());
+    tops.assign(reqs ? n_reqs : st.n, HTop());
     std::vector<HItem> pending, fwd, udh, scl;
-    for (int i = 0; i < st.n; ++i) {
+    // explicit requests (the seeded walk, spdp_seeded_h.cpp): a sub-range of a resident parent with its own flags and
+    // window; kind 0 enters the ladder as lspH_ng(wdw), 1 / 3 go straight to trcbkalignH_ng's engine choice
+    for (int k = 0; reqs && k < n_reqs; ++k) {
+        const SpdhRequest& q = reqs[k];
+        HItem it;
+        it.top = q.parent; it.slot = k; it.first = true;
+        it.a_left = q.al; it.a_right = q.ar; it.b_left = q.bl; it.b_right = q.br;
+        it.a_exgl = q.exg[0]; it.a_exgr = q.exg[1]; it.b_exgl = q.exg[2]; it.b_exgr = q.exg[3];
+        it.w = q.w;
+        if (q.parent < 0 || q.parent >= st.n) { tops[k].cls = 2; continue; }
+        if (q.kind == 0) { pending.push_back(it); continue; }
+        it.nospj = q.kind == 3; it.cut_l = q.cut_l; it.cut_r = q.cut_r;
+        if (bad_range(it, st.probs[it.top])) { tops[k].cls = 1; continue; }
+        queue_trcbk(it, fwd, scl, st.scalar_ok, tops[k]);
+    }
+    for (int i = 0; !reqs && i < st.n; ++i) {
         HItem it = item_of(st.probs[i], i, sc.sh);
         it.first = true;
         if (ladder) pending.push_back(it);
@@ -954,9 +983,9 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
         ++hs.rounds;
         udh.clear();
         for (const HItem& it : pending) {
-            if (tops[it.top].cls) continue;
-            if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
-            queue_lsp(sc, st.probs[it.top], it, fwd, scl, st.scalar_ok, udh, tops[it.top]);
+            if (tops[it.slot].cls) continue;
+            if (bad_range(it, st.probs[it.top])) { tops[it.slot].cls = 1; continue; }
+            queue_lsp(sc, st.probs[it.top], it, fwd, scl, st.scalar_ok, udh, tops[it.slot]);
         }
         pending.clear();
         // ---- linear-space round: cpos rows -> slabs (mimd_postwork) or halves (rcsv_postwork)
@@ -968,7 +997,7 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
             hs.udh_ms += uo.sweep_ms; hs.udh_cells += uo.cells;
             for (size_t u = 0; u < udh.size(); ++u) {
                 const HItem& it = udh[u];
-                HTop& t = tops[it.top];
+                HTop& t = tops[it.slot];
                 if (t.cls) continue;
                 const int scr = uo.scores[u];
                 if (uflags[u]) { t.cls = 1; continue; }      // undefined in the reference
@@ -1025,23 +1054,24 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
             }
         }
         // ---- traceback round; sub-problems below 8 rows go through the scalar engine
-        for (int pass = 0; pass < 3; ++pass) {                // `_wip` forward, scalar forwardH_ng, -A1 forwardH1
+        for (int pass = 0; pass < 4; ++pass) {                // `_wip` forward, scalar forwardH_ng, -A1 forwardH1, scalar with a cut range
             std::vector<HItem>& list = pass ? scl : fwd;
             if (list.empty()) continue;
             std::vector<HItem> run;
             for (const HItem& it : list) {
-                if (pass && it.exact != (pass == 2)) continue;
-                if (tops[it.top].cls) continue;
-                if (bad_range(it, st.probs[it.top])) { tops[it.top].cls = 1; continue; }
+                const int kind = it.cut_r > it.cut_l ? 3 : (it.exact ? 2 : 1);
+                if (pass && kind != pass) continue;
+                if (tops[it.slot].cls) continue;
+                if (bad_range(it, st.probs[it.top])) { tops[it.slot].cls = 1; continue; }
                 run.push_back(it);
             }
-            if (pass != 1) list.clear();
+            if (pass == 0 || pass == 3) list.clear();
             if (run.empty()) continue;
             HFwdOut fo;
-            if (pass ? run_scalar(st, run, true, fo, pass == 2) : run_forward(st, run, true, fo)) return -1;
+            if (pass ? run_scalar(st, run, true, fo, pass == 2, pass == 3) : run_forward(st, run, true, fo)) return -1;
             if (!pass) { hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells; }
             for (size_t f = 0; f < run.size(); ++f) {
-                HTop& t = tops[run[f].top];
+                HTop& t = tops[run[f].slot];
                 if (run[f].first) t.score = fo.res[f].score;
                 const int stt = fo.n_skl[f];
                 if (stt == -2) { if (!t.flag) t.flag = -1; }
@@ -1092,6 +1122,35 @@ static int deliver(HStore& st, int level, SpdpAlignment* out, HStats& hs)
         }
     }
     return rc;
+}
+
+// ---- requests against a resident store (spdp_h_requests.h) --------------------------------
+HStore* spdh_store_open(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n)
+{
+    HStore* st = new HStore();
+    if (st->upload(ctx, sc, probs, n)) { delete st; return nullptr; }
+    return st;
+}
+void spdh_store_close(HStore* st) { delete st; }
+
+// out[k]: what the call returns + the Mfile records it writes, as written; n_skl < 0: not served here (an engine that is
+// not built, a range outside the sequences) or undefined in the reference (spdp_align_h's flags)
+int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out)
+{
+    std::vector<HTop> tops;
+    HStats hs;
+    for (int k = 0; k < n; ++k) { out[k].score = SPDP_NEVSEL; out[k].n_skl = 0; out[k].skl = nullptr; out[k].flags = 0; out[k].reserved = 0; }
+    if (n <= 0) return 0;
+    if (run_ladder(*st, true, tops, hs, reqs, n)) return -1;
+    for (int k = 0; k < n; ++k) {
+        const HTop& t = tops[k];
+        if (t.cls) { out[k].n_skl = -1; continue; }
+        out[k].score = t.score;
+        if (t.flag) { out[k].n_skl = t.flag; continue; }
+        out[k].n_skl = (int) t.rec.size();
+        out[k].skl = dup_skl(t.rec);
+    }
+    return 0;
 }
 
 // ---- C ABI ------------------------------------------------------------------------------

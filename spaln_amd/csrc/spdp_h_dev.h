@@ -52,6 +52,9 @@ struct DevProblemH {
     int32_t imd_intvl;             // scalar linear-space engine: rows between intermediates (Aln2h1::imd_intvl)
     int32_t cip_off;               // -A0 / -A1 engines: first entry of the query's cip row in HScalarArgs::cip, -1 = none
     int32_t a_pad;                 // SpdpProblemH::a_pad
+    int32_t nospj;                 // scalar engine: no introns (trcbkalignH_ng(wdw, false))
+    int32_t cut_l, cut_len;        // scalar forward engine: the sweep jumps over columns (cut_l, cut_l + cut_len]; `width` is
+    int32_t pad_;                  //   the window's width minus cut_len (forwardH_ng's cutrng, src/fwd2h1.cc:308-312, 589-603)
     int64_t a_off;
     int64_t col_off;               // into cols / aux
     int64_t bnd_off;               // into bnd (entries)

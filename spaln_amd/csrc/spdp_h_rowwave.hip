@@ -151,9 +151,18 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 }
 #define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <int MODE, bool PIPE>
+// CUT (MODE 1, one wave per problem): forwardH_ng with a cut range (shortcutH_ng; src/fwd2h1.cc:308-312, 589-603, lastH_ng
+// :210-281).  After column cut_l of a row the three insertion states, charged for the codons of the cut, REPLACE the row's
+// last three entries (F: black) and the row goes on at column cut_l + cut_len + 1 on the next entry: a cell is addressed
+// by its virtual column v (= n up to cut_l, n - cut_len behind it), the data of a column by its real position.  The
+// reference finishes a row before it starts the next, so the next row's cells at cut_l - 2 .. cut_l already see the
+// replaced entries -- two columns ahead of what the one-column skew of the wave provides.  Hence three phases per tile:
+// the skewed sweep up to column cut_l - 3, the seam (cut_l - 2 .. cut_l and the replacement) row after row on one lane
+// at a time, and the skewed sweep again from cut_l + 1.
+template <int MODE, bool PIPE, bool CUT = false>
 __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
 {
+    static_assert(!CUT || (MODE == 1 && !PIPE), "the cut range: forward engine, one wave per problem");
     constexpr bool FWD = MODE == 1, UDH = MODE == 2;
     constexpr int NF = Shape<MODE>::NF;
     __shared__ int Lw[WPB][2 * NF][RING];
@@ -189,8 +198,13 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
     const int gop = sc->gop, gep = sc->gep, lgep = sc->lgep, codonk1 = sc->codonk1;
     const int gw1 = sc->g1, gw2 = sc->g2, gw3 = sc->g3, ge1 = A.gape1, ge2 = A.gape2;
-    const bool spj = sc->spj;
+    const bool spj = sc->spj && !P.nospj;
     const int minl = A.minl;
+    const int cutlen = CUT ? P.cut_len : 0, cut_l = CUT ? P.cut_l : INT32_MAX / 2;
+    const int xshift = CUT ? max(0, cutlen - 16) : 0;               // staged columns: the two sides of the cut 16 slots apart
+    auto XC = [&](int c) -> int { return (!CUT || c <= cut_l + 8) ? c : c - xshift; };     // real column -> staging index
+    auto CX = [&](int x) -> int { return (!CUT || x <= cut_l + 8) ? x : x + xshift; };
+    auto RV = [&](int v) -> int { return (!CUT || v <= cut_l) ? v : v + cutlen; };         // virtual -> real column
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int4* __restrict__ cols = A.cols + P.col_off;             // .x: codon ending at n | flags, .y: sig3 x 2, .w: dinc
     const short4* __restrict__ aux = A.aux + P.col_off;             // {sigS, sigT, sigE, sig5}
@@ -368,7 +382,8 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
         const bool row = lane < TH && m <= ar;
         const int n0 = max(3 * m + lw - 1, bl), n9 = min(3 * m + up, br);
         const bool any = row && n0 <= n9;
-        int s_lo = any ? n0 + m : INT32_MAX, s_hi = any ? n9 + m : INT32_MIN;
+        const int v0 = n0, v9 = !CUT ? n9 : (n9 <= cut_l ? n9 : (n9 > cut_l + cutlen ? n9 - cutlen : cut_l));    // (the host: n0 <= cut_l)
+        int s_lo = any ? v0 + m : INT32_MAX, s_hi = any ? v9 + m : INT32_MIN;
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
         const int iq = UDH ? (m - P.a_left) / max(1, intvl) - 1 : -1;
         const bool is_imd = UDH && row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
@@ -418,18 +433,20 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                     for (int a = 0; a < 2 * NF; ++a) L[a][q] = gld<PIPE>(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
-                // columns [S - (m0 + 63) - 3, S + CHUNK - 1 - m0 + 5] of the next CHUNK steps
-                const int c_hi = S + CHUNK - 1 - m0 + 5;
-                for (int c = max(cres, S - (m0 + 63) - 3) + lane; c <= c_hi; c += 64) {
+                // columns [S - (m0 + 63) - 3, S + CHUNK - 1 - m0 + 5] of the next CHUNK steps (CUT: their real positions,
+                // staged at XC(.): at most 16 slots more)
+                const int c_hi = XC(RV(S + CHUNK - 1 - m0) + 5);
+                for (int x = max(cres, XC(RV(S - (m0 + 63)) - 3)) + lane; x <= c_hi; x += 64) {
+                    const int c = CX(x);
                     const bool in = c >= 0 && c <= P.b_len + 2;
-                    Cc[c & (CRING - 1)] = in ? cols[c] : make_int4(0, 0, 0, 0);
-                    Ca[c & (CRING - 1)] = in ? aux[c] : make_short4(0, 0, 0, 0);
+                    Cc[x & (CRING - 1)] = in ? cols[c] : make_int4(0, 0, 0, 0);
+                    Ca[x & (CRING - 1)] = in ? aux[c] : make_short4(0, 0, 0, 0);
                 }
                 cres = c_hi + 1;
                 WAVE_SYNC();
             };
-            auto COL = [&](int c) -> int4 { return Cc[c & (CRING - 1)]; };
-            auto AUX = [&](int c) -> short4 { return Ca[c & (CRING - 1)]; };
+            auto COL = [&](int c) -> int4 { return Cc[XC(c) & (CRING - 1)]; };
+            auto AUX = [&](int c) -> short4 { return Ca[XC(c) & (CRING - 1)]; };
             auto tron_l = [&](int i) -> int { return (i < 0 || i > P.b_len) ? AMB : ((COL(i + 2).x >> 16) & 0xff); };   // tron_at from the staged columns
             auto lds_get = [&](int e, int isF) {
                 const int q = e & (RING - 1);
@@ -444,14 +461,48 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                 for (int f = 0; f < NF; ++f) L[isF * NF + f][q] = fld(s, f);
             };
 
-            for (int S = s_lo; S <= s_hi; ++S) {
-                if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
-                const int n = S - m;
-                const bool on = any && n >= n0 && n <= n9;
+            // CUT: steps up to SA_end sweep columns <= cut_l - 3; the next 3 TH steps are the seam (lane k / 3 on column
+            // cut_l - 2 + k % 3); from then on the wave is back on the schedule of a sweep that starts at column cut_l + 1
+            const int SA_end = CUT ? cut_l - 3 + m0 + TH - 1 : 0, seam = CUT ? 3 * TH : 0;
+            const int S_begin = CUT ? min(s_lo, SA_end + 1) : s_lo;
+            const int S2_begin = cut_l + 1 + m0, shiftB = CUT ? SA_end + seam + 1 - S2_begin : 0;
+            const int S_end = CUT ? max(s_hi + shiftB, SA_end + seam) : s_hi;
+            for (int S = S_begin; S <= S_end; ++S) {
+                int v = S - m;
+                bool act = true;
+                if constexpr (CUT) {
+                    if (S <= SA_end) {
+                        if (((S - S_begin) & (CHUNK - 1)) == 0) refill(S);
+                        act = v <= cut_l - 3;
+                    } else if (S <= SA_end + seam) {
+                        if (S == SA_end + 1) refill(SA_end);        // (covers what the seam reads: entries and columns of all rows around cut_l)
+                        const int k = S - SA_end - 1;
+                        v = cut_l - 2 + k % 3;
+                        act = lane == k / 3;
+                    } else {
+                        const int S2 = S - shiftB;
+                        if (S2 == S2_begin) {                       // hand the window back and take the one of the new schedule
+                            WAVE_SYNC();
+                            for (int e = res_lo + lane; e < res_hi; e += 64) {
+                                const int q = e & (RING - 1);
+#pragma unroll
+                                for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                            res_lo = res_hi = max(0, need_lo(S2));
+                            cres = INT32_MIN;
+                        }
+                        if (((S2 - S2_begin) & (CHUNK - 1)) == 0) refill(S2);
+                        v = S2 - m;
+                        act = v > cut_l;
+                    }
+                } else if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
+                const int n = RV(v);
+                const bool on = any && act && v >= v0 && v <= v9;
                 if (__ballot(on) == 0) continue;
                 const int4 col = on ? COL(n) : make_int4(0, 0, 0, 0);
                 const int sigE = (on && n > bl && n >= 2) ? (int) AUX(n - 2).z : 0;
-                const int r = n - 3 * m, e = r - lw + 3;
+                const int r = v - 3 * m, e = r - lw + 3;
                 St h = lds_get(e, 0), f = lds_get(e, 1);
                 const St hq = h;                                    // the entry as the cell found it
                 const St u1 = lds_get(e + 1, 0), u2 = lds_get(e + 2, 0), u3 = lds_get(e + 3, 0), fu = lds_get(e + 3, 1);
@@ -673,6 +724,14 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                     lds_put(e, 1, f);
                     const St t = ea; ea = eb; eb = ec; ec = t;      // the next column is the next frame
                 }
+                if constexpr (CUT) {
+                    if (on && v == cut_l) {                         // the insertion states run on over the cut (ea: the next column's frame)
+                        const int lg = gep * cutlen / 3;
+                        ea.v += lg; eb.v += lg; ec.v += lg;
+                        lds_put(e - 2, 0, eb); lds_put(e - 1, 0, ec); lds_put(e, 0, ea);
+                        lds_put(e - 2, 1, black); lds_put(e - 1, 1, black); lds_put(e, 1, black);
+                    }
+                }
             }
             WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
@@ -764,7 +823,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
     if (LocalR) reduce_best();
     const bool by_last_row = UDH ? !LocalR : (!LocalR || best_m == ar);
     if (by_last_row) {
-        const int m3 = 3 * ar, r9 = br - m3;
+        const int m3 = 3 * ar, r9 = br - cutlen - m3;               // (CUT: both ends global, only the entry of br matters)
         const int r_in = max(lw, bl - m3);                          // first entry of the last row
         int mx_r = r9, mx_v = gload(r9, 0).v;
         if (a_exgr) {
@@ -1026,7 +1085,8 @@ extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipS
         return hipGetLastError();
     }
     const dim3 grd((A.n_probs + WPB - 1) / WPB);
-    if (forward) hipLaunchKernelGGL((spdh_rowwave<1, false>), grd, blk, 0, stream, A);
+    if (forward == 2) hipLaunchKernelGGL((spdh_rowwave<1, false, true>), grd, blk, 0, stream, A);      // problems with a cut range
+    else if (forward) hipLaunchKernelGGL((spdh_rowwave<1, false>), grd, blk, 0, stream, A);
     else hipLaunchKernelGGL((spdh_rowwave<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();
 }

@@ -17,25 +17,10 @@
 
 #include "spdp_internal.h"
 #include "spdp_seeded_walk.h"
+#include "spdp_seeded_rv.h"
 
 namespace {
 using namespace spdp_seed;
-
-struct Parked {
-    int query = 0, kind = 0;
-    Span s{}; SpdpWindow w{}; int cut[2] = {0, 0};
-    int score = SPDP_NEVSEL;
-    std::vector<SpdpSkl> rec;
-    bool done = false, failed = false;
-    int flags = 0;                              // SpdpAlignment::flags of the request
-};
-
-struct Rendezvous {
-    std::mutex mu;
-    std::condition_variable cv_walk, cv_main;
-    std::vector<Parked*> parked;
-    int running = 0;                            // walker threads that are neither parked nor finished
-};
 
 struct DeviceBackend : DpBackend {
     Rendezvous* rv; int query; const SpdpHspSource* src;

@@ -331,6 +331,14 @@ class Engine:
         None, lowest_levels[i] = b->wllvl; wilip_tables[i] = {(level, a_left, a_right, b_left, b_right): flat unit record}
         serves the Wilip calls of the recursion levels (a replay of what a reference run recorded, in the tests; the
         reference's own wln.cc in an integration).  Returns [(score, skl)] like align_s."""
+        return self._align_seeded("spdp_align_s_seeded", sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
+
+    def align_h_seeded(self, sc, sp: abi.SeedParams, ps, hsps, lowest_levels, wilip_tables=None, allow_partial=False):
+        """alignH_ng with seeding on (the protein walk, spdp_align_h_seeded): arguments and result as align_s_seeded; with
+        allow_partial a query whose walk is not served comes back as (NEVSEL, empty)"""
+        return self._align_seeded("spdp_align_h_seeded", sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
+
+    def _align_seeded(self, name, sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial):
         n = len(ps)
         keep = []
         jx = (C.c_void_p * n)()
@@ -362,12 +370,13 @@ class Engine:
         src.units = abi.HSP_UNITS_FN(units)
         src.release = abi.HSP_RELEASE_FN(lambda _u, _q, _f: None)
         arr = (abi.Alignment * n)()
-        self.lib.spdp_align_s_seeded.argtypes = [C.c_void_p] * 10
-        rc = self.lib.spdp_align_s_seeded(self.ctx, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
+        fn = getattr(self.lib, name)
+        fn.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+        rc = fn(self.ctx, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
         if missing:
             raise KeyError(f"no Wilip reply for {missing[:3]}")
         if not (allow_partial and rc == 1):
-            self._check(rc, "spdp_align_s_seeded")
+            self._check(rc, name)
         res = []
         for i in range(n):
             k = arr[i].n_skl

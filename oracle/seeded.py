@@ -142,7 +142,7 @@ def align_s_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict,
 
 JOINS_H = ["diagonal", "head_nogenome", "head_cds", "head_exon", "tail_nogenome", "tail_cds", "tail_exon", "junction",
            "micro_exon", "shortcut", "backforth", "small_dp", "recurse", "dp", "giveup_head", "giveup_tail", "giveup_inner",
-           "pick_unit"]
+           "pick_unit", "exact_head", "exact_tail"]
 
 
 def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict, simd: int = 2, trace=None, joins=None):

@@ -172,9 +172,9 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         memcpy(out[i].skl + 1, s.data(), sizeof(SpdpSkl) * s.size());
     }
     if (partial) {
-        ctx->err = "some protein walks met a state the seeded path does not serve (the exact three-frame search of the same-"
-                   "species mode, ambiguous bases at a junction, no HSP source for a recursion level, or a DP call the "
-                   "reference itself leaves undefined); those queries come back without an alignment";
+        ctx->err = "some protein walks met a state the seeded path does not serve (ambiguous bases at a junction, no HSP "
+                   "source for a recursion level, or a DP call the reference itself leaves undefined); those queries "
+                   "come back without an alignment";
         return 1;
     }
     return 0;

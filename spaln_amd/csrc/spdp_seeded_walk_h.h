@@ -11,16 +11,16 @@
 //   Aln2h1::cds5end / cds3end                  :2331-2395      SeedWalkH::cds_end5 / cds_end3
 //   Aln2h1::nearest5ss / nearest3ss            :2524-2616      SeedWalkH::nearest_sites<5 / 3>
 //   Aln2h1::micro_exon                         :2620-2705      SeedWalkH::micro_exon
-//   Aln2h1::first_exon(_wmm) / last_exon(_wmm) :2709-3020      SeedWalkH::first_exon / last_exon (ungapped placements;
-//                                                              the three-frame exact search of the same-species mode
-//                                                              -- algmode.crs == 0 -- is reported as not served)
+//   Aln2h1::first_exon(_wmm) / last_exon(_wmm) :2709-3020      SeedWalkH::first_exon / last_exon: ungapped placements
+//                                                              (cross-species) or exact occurrences in three frames
+//   BoyerMoore(b, a, +-3) + nexthit3           src/boyer_moore.cc      ExactFinder3
 //   Aln2h1::openendH_ng + back2ward5endH_ng / for2ward3endH_ng  :2262-2291, 1522-1960   SeedWalkH::open_end, end_extension
 //   Aln2h1::diagonalH_ng                       :1963-1995      SeedWalkH::diagonal
 //   SpJunc::spjseq / spjscr                    src/codepot.cc:74-107   SeedWalkH::split_codon / junction_score
 //   Aln2h1::shortcutH_ng                       :2232-2260      SeedWalkH::shortcut (forwardH_ng with a cut range behind
 //                                                              DpBackendH::trcbk)
-// Not served (the walk marks itself and the query comes back without an alignment): the exact search named above, a
-// split codon with ambiguous bases.
+// Not served (the walk marks itself and the query comes back without an alignment): a split codon with ambiguous bases
+// (the reference's spj_amb_tron_tab / spj_tron_amb_tab).
 //
 // Same design as spdp_seeded_walk.h: the reference's decisions on the same mutable state, every DP call (lspH_ng,
 // trcbkalignH_ng) through DpBackendH, header only, compiled into the product (device behind the calls) and into the CPU
@@ -43,10 +43,104 @@ struct DpBackendH {
     virtual bool wilip(int level, const Span& s, std::vector<Unit>& units) = 0;
 };
 
+// Exact occurrences of an amino-acid pattern in a tron text, all three frames, in the order and with the skips of the
+// reference's search (BoyerMoore(b, a, +-3) + nexthit3, src/boyer_moore.cc:36-76, 114-153, 174-215): a text code
+// matches a pattern residue when equal, when the text holds the AGY serine and the pattern SER, or when the pattern
+// is AMB; the shift tables are built with "equal or either AMB".  Each call runs the three frames up to the bound
+// and hands the hits out nearest first (the reference's priority queue of three).
+class ExactFinder3 {
+    const uint8_t* text; int tlen, origin;
+    std::vector<uint8_t> pat; int plen;
+    std::vector<int> by_code, by_suffix;
+    int step, after_hit, idx[3];
+    std::vector<int> queue;                                      // hits not handed out yet, next one last
+    static bool src_eq(uint8_t t, uint8_t p) { return t == p || (t == 23 && p == 18) || p == 2; }
+    static bool tab_eq(uint8_t x, uint8_t y) { return x == y || x == 2 || y == 2; }
+    static int plus_k(int i, int k) { static const char t[3][3] = {{0, 1, 2}, {2, 0, 1}, {1, 2, 0}}; return i + t[i % 3][k]; }
+    static int minus_k(int i, int k) { static const char t[3][3] = {{0, 2, 1}, {1, 0, 2}, {2, 1, 0}}; return i - t[i % 3][k]; }
+public:
+    ExactFinder3(const uint8_t* b, int bl, int br, const uint8_t* a, int al, int ar, int direction)
+        : text(b + bl), tlen(br - bl), origin(bl), pat(a + al, a + ar), plen(ar - al), step(3 * direction)
+    {
+        pat.push_back(0);
+        if (step < 0) std::reverse(pat.begin(), pat.begin() + plen);
+        by_code.assign(256, plen);
+        for (int j = 0, skip = plen; j < plen; ++j) by_code[pat[j]] = --skip;
+        by_code[23] = by_code[18];                               // SER2 as SER
+        by_suffix.resize(std::max(plen, 1));
+        std::vector<int> link(std::max(plen, 1));
+        for (int j = 0, v = 2 * plen; j < plen; ++j) by_suffix[j] = --v;
+        int j = plen;
+        for (int k = plen; --k >= 0; ) {
+            link[k] = j;
+            pat[plen] = pat[k];                                  // sentinel
+            while (!tab_eq(pat[j], pat[k])) {
+                by_suffix[j] = std::min(by_suffix[j], plen - 1 - k);
+                j = link[j];
+            }
+            --j;
+        }
+        after_hit = std::max(j + 1, 2) * step;
+        for (int s = j, v = plen, q = 0; q < plen; ++q) {
+            by_suffix[q] = std::min(by_suffix[q], s + v--);
+            if (q >= s) s = s >= 0 ? link[s] : 0;
+        }
+        if (step < 0) {
+            std::reverse(pat.begin(), pat.begin() + plen);
+            std::reverse(by_suffix.begin(), by_suffix.begin() + plen);
+        }
+        for (int k = 0; k < 3; ++k) idx[k] = step > 0 ? k : minus_k(tlen, k);
+    }
+    bool finished() const
+    {
+        return step > 0 ? std::min(idx[0], std::min(idx[1], idx[2])) >= tlen : std::max(idx[0], std::max(idx[1], idx[2])) <= 0;
+    }
+    bool scanned(int n) const
+    {
+        if (!queue.empty()) return false;
+        n -= origin;
+        return step > 0 ? std::min(idx[0], std::min(idx[1], idx[2])) >= n : std::max(idx[0], std::max(idx[1], idx[2])) <= n;
+    }
+    // nexthit3(l, r): position in b of the first code of the next occurrence, or -1
+    int next(int l, int r)
+    {
+        if (!queue.empty()) { const int v = queue.back(); queue.pop_back(); return v + origin; }
+        if (l >= 0) l = std::max(l - origin, 0);
+        if (r >= 0) r = std::max(r - origin, 0);
+        for (int k = 0; k < 3; ++k) {
+            if (step > 0) {
+                int i = l >= 0 ? plus_k(l, k) : idx[k];
+                idx[k] = plus_k(r >= 0 ? r : tlen, k);
+                for (i += step * (plen - 1); i < r; ) {
+                    int j = plen - 1;
+                    while (j >= 0 && src_eq(text[i], pat[j])) { i -= step; --j; }
+                    if (j < 0) { queue.push_back(i + step); idx[k] = i + after_hit; break; }
+                    i += step * std::max(by_code[text[i]], by_suffix[j]);
+                }
+            } else {
+                int i = r >= 0 ? minus_k(r, k) : idx[k];
+                idx[k] = minus_k(l >= 0 ? l : 0, k);
+                for (i += step * (plen - 1); i >= l; ) {
+                    int j = 0;
+                    while (j < plen && src_eq(text[i], pat[j])) { i -= step; ++j; }
+                    if (j >= plen) { queue.push_back(i + step * plen); idx[k] = i + after_hit; break; }
+                    i += step * std::max(by_code[text[i]], by_suffix[j]);
+                }
+            }
+        }
+        if (queue.empty()) return -1;
+        // the reference's heap hands out the smallest first going right, the largest first going left
+        std::sort(queue.begin(), queue.end());
+        if (step > 0) std::reverse(queue.begin(), queue.end());
+        const int v = queue.back(); queue.pop_back();
+        return v + origin;
+    }
+};
+
 class SeedWalkH {
 public:
     // inputs (borrowed)
-    const uint8_t* a = nullptr; int a_len = 0;
+    const uint8_t* a = nullptr; int a_len = 0; int a_pad = 0;
     const uint8_t* b = nullptr; int b_len = 0;
     const int16_t *sig5 = nullptr, *sig3 = nullptr, *sigS = nullptr, *sigT = nullptr, *sigE = nullptr;
     const uint8_t* dinc = nullptr;
@@ -70,7 +164,7 @@ public:
 
     enum { J_DIAGONAL, J_HEAD_NOGENOME, J_HEAD_CDS, J_HEAD_EXON, J_TAIL_NOGENOME, J_TAIL_CDS, J_TAIL_EXON, J_JUNCTION,
            J_MICRO_EXON, J_SHORTCUT, J_BACKFORTH, J_SMALL_DP, J_RECURSE, J_DP, J_GIVEUP_HEAD, J_GIVEUP_TAIL, J_GIVEUP_INNER,
-           J_PICK_UNIT, J_COUNT };
+           J_PICK_UNIT, J_EXACT_HEAD, J_EXACT_TAIL, J_COUNT };     // (the last two: terminal exons the exact search found)
     int joins[J_COUNT] = {0};
 
     // TraceBackDir, src/aln.h:30-35
@@ -475,7 +569,39 @@ public:
                 const int f = first_exon_wmm(d3, scr, pm, nss);
                 if (unsupported) return NEV();
                 if (scr > maxscr) { maxscr = scr; maxf = f; nn = n; if (pm) break; }
-            } else { mark(__LINE__); return NEV(); }        // the exact three-frame search (same-species mode)
+            } else {                                        // same-species mode: exact occurrences of the terminal stretch
+                const int cds = 3 * cur.ar - d3;
+                if (d3 == 1) --cur.ar;
+                if (cur.ar - cur.al < 1) { mark(__LINE__); return NEV(); }
+                ExactFinder3 bm(b, cur.bl, cur.br, a, cur.al, cur.ar, -1);
+                int l = std::max(cur.bl, cur.br - sp->ip_maxl);
+                const int as = cur.ar;
+                while (!bm.finished()) {
+                    int f = bm.next(l, -1) - 1;
+                    if (f >= 0) {
+                        const int nd = f + cds;
+                        if (nd < 0 || nd > b_len || f + 1 > b_len + 2) { mark(__LINE__); return NEV(); }
+                        if (is_canon(nd, r)) {
+                            if (d3) {
+                                int cs[2];
+                                if (!split_codon(nd, r, cs)) return NEV();
+                                if (as >= a_len + 1) { mark(__LINE__); return NEV(); }
+                                if (!avst_equal(as < a_len ? a[as] : a_pad, d3 == -1 ? cs[1] : cs[0])) f = -1;
+                            }
+                            if (f >= 0) {
+                                const int scr = sigS[f + 1] + sig5[nd] + junction_score(nd, r);
+                                if (scr > maxscr) { maxscr = scr; maxf = f; }
+                            }
+                        }
+                    }
+                    if (bm.scanned(l)) {
+                        if (maxf < 0) l = std::max(cur.bl, l - sp->ip_maxl);
+                        else break;
+                    }
+                }
+                if (d3 == 1) ++cur.ar;
+                if (maxf >= 0) { ++joins[J_EXACT_HEAD]; nn = 1; break; }
+            }
         }
         if (maxf < 0) { cur.al = first.al; cur.ar = first.ar; cur.bl = first.bl; cur.br = first.br; return NEV(); }
         if (nn == 0) { cur.al = second.al; cur.ar = second.ar; cur.bl = second.bl; cur.br = second.br; }
@@ -557,7 +683,39 @@ public:
                 const int f = last_exon_wmm(d5, scr, pm, nss);
                 if (unsupported) return NEV();
                 if (scr > maxscr) { maxscr = scr; maxf = f; nn = n; if (pm) break; }
-            } else { mark(__LINE__); return NEV(); }
+            } else {                                        // same-species mode: exact occurrences of the terminal stretch
+                int as = cur.al;
+                if (d5 < 0) { ++cur.al; --alen; d5 += 3; }
+                if (cur.ar - cur.al < 1) { mark(__LINE__); return NEV(); }
+                ExactFinder3 bm(b, cur.bl, cur.br, a, cur.al, cur.ar, 1);
+                int r = std::min(cur.br, l + sp->ip_maxl);
+                if (d5 == 1) --as;
+                while (!bm.finished()) {
+                    int f = bm.next(-1, r) - 1;
+                    if (f >= 0) {
+                        const int na = f - d5;
+                        if (is_canon(l, na)) {
+                            if (d5) {
+                                int cs[2];
+                                if (!split_codon(l, na, cs)) return NEV();
+                                if (as < 0) { mark(__LINE__); return NEV(); }
+                                if (!avst_equal(a[as], d5 != 1 ? cs[1] : cs[0])) f = -1;
+                            }
+                            if (f >= 0) {
+                                const int t = f + 3 * alen + 1;
+                                if (t < 0 || t > b_len + 2) { mark(__LINE__); return NEV(); }
+                                if (sigT[t] > 0) { maxscr = sig5[l] + junction_score(l, na); maxf = f; break; }
+                            }
+                        }
+                    }
+                    if (bm.scanned(r)) {
+                        if (maxf < 0) r = std::min(cur.br, r + sp->ip_maxl);
+                        else break;
+                    }
+                }
+                if (d5 == 2) { --cur.al; ++alen; d5 -= 3; maxf -= 3; }
+                if (maxf >= 0) { ++joins[J_EXACT_TAIL]; nn = 1; break; }
+            }
         }
         if (maxf < 0) { cur.al = first.al; cur.ar = first.ar; cur.bl = first.bl; cur.br = first.br; return NEV(); }
         if (nn == 0) { cur.al = second.al; cur.ar = second.ar; cur.bl = second.bl; cur.br = second.br; alen = alen_0; }
@@ -996,7 +1154,7 @@ inline bool bind_problem_h(SeedWalkH& w, const SpdpScoringH* sc, const SpdpSeedP
 {
     if (!sc || !sp || !p || !p->a || !p->b || !p->sig5 || !p->sig3 || !p->sigS || !p->sigT || !p->sigE || !p->phs5 || !p->phs3 ||
         !p->dinc || !sc->intpen || sc->intpen_len <= 0 || sp->qck < 1 || sp->qck > 3) return false;
-    w.a = p->a; w.a_len = p->a_len; w.b = p->b; w.b_len = p->b_len;
+    w.a = p->a; w.a_len = p->a_len; w.a_pad = p->a_pad; w.b = p->b; w.b_len = p->b_len;
     w.sig5 = p->sig5; w.sig3 = p->sig3; w.sigS = p->sigS; w.sigT = p->sigT; w.sigE = p->sigE; w.dinc = p->dinc; w.cip = p->cip;
     w.sc = sc; w.sp = sp; w.lowest_level = lowest_level;
     const int N = p->b_len + 3;

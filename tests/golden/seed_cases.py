@@ -177,11 +177,30 @@ def special_cases():
 FIXTURE_SEEDS_H = [116, 45, 13, 82, 85, 89, 123, 0, 3, 5, 6, 14, 24, 32, 38, 65, 98]
 
 
+def special_cases_h():
+    """short terminal coding exons, error-free, same-species mode (-X 0): too short for an HSP, found by the exact
+    three-frame search of first_exon / last_exon (BoyerMoore::nexthit3, src/fwd2h1.cc:2803-2834, 2962-3000)"""
+    c = {}
+    for k, qck in ((3, 3), (5, 2), (12, 1), (13, 3)):          # (picked: both searches succeed, at all three -Q levels)
+        rng = np.random.default_rng(synth.SEED + 61010 + k)
+        g = synth.make_protein_gene(rng, n_exons=5, aa_len=260, flank=400, sub=0.0, intron_hi=500)
+        e = g.exons
+        # shrink the first and the last coding exon to 3 - 6 codons (+ up to two bases of a split codon): window and
+        # protein both lose the outer part; the stop codon stays where it is
+        cut5 = max(0, (e[0][1] - e[0][0]) - int(rng.integers(9, 19))) // 3 * 3
+        cut3 = max(0, (e[-1][1] - 3 - e[-1][0]) - int(rng.integers(9, 19))) // 3 * 3
+        w = np.concatenate([g.window[:e[0][0]], g.window[e[0][0] + cut5:e[-1][1] - 3 - cut3], g.window[e[-1][1] - 3:]])
+        q = g.query[cut5 // 3:len(g.query) - cut3 // 3]
+        c[f"qh_short_ends{k}"] = (w, q, ["-Q", str(qck), "-X", "0"])
+    return c
+
+
 def cases_h():
     c = {}
     for s in FIXTURE_SEEDS_H:
         w, q, opts, _ = make_case_h(s)
         c[f"qh_{s:04d}"] = (w, q, opts)
+    c.update(special_cases_h())
     return c
 
 

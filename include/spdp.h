@@ -526,8 +526,8 @@ int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct Spd
 /* alignH_ng with seeding on (algmode.qck = 1 .. 3; Aln2h1::globalH_ng -> seededH_ng -> interpolateH, src/fwd2h1.cc:3267-3286,
  * 3177-3265, 3023-3131): arguments as spdp_align_s_seeded (jy of an HSP is a nucleotide position of the tron sequence).
  * The problems need all seven signal arrays and dinc on the host, sc->intpen / t53.  Return value and out[] as
- * spdp_align_h; a walk that meets ambiguous bases at a junction it prices, or a DP call on which the reference itself is
- * undefined, is reported as not served (return 1, no alignment). */
+ * spdp_align_h; a walk with a DP call on which the reference itself is undefined is reported as not served (return 1, no
+ * alignment). */
 int spdp_align_h_seeded(SpdpContext* ctx, const struct SpdpScoringH* sc, const SpdpSeedParams* sp,
                         const struct SpdpProblemH* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
                         const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out);

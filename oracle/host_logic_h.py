@@ -336,13 +336,12 @@ def _spjseq(b, b_left, b_right, n5, n3):
     """SpJunc::spjseq (src/codepot.cc:79-107): the codon(s) an intron splits, as tron codes"""
     if n5 < b_left or n3 >= b_right:
         return (AMB, AMB)
-    word = []
-    for idx in (n5 - 2, n5 - 1, n3, n3 + 1):
-        c = _MID.get(int(b[idx]))
-        if c is None:
-            return (AMB, AMB)            # ambiguous bases: not produced by the synthetic inputs
-        word.append(_BASES[c])
-    return (_tron_of("".join(word[0:3])), _tron_of("".join(word[1:4])))
+    word = [_MID.get(int(b[idx])) for idx in (n5 - 2, n5 - 1, n3, n3 + 1)]
+    if word[1] is None or word[2] is None:                   # a codon is defined when its own three bases are
+        return (AMB, AMB)
+    base = [None if c is None else _BASES[c] for c in word]
+    return (AMB if base[0] is None else _tron_of("".join(base[0:3])),
+            AMB if base[3] is None else _tron_of("".join(base[1:4])))
 
 
 def skl_rng_h(sc, p, skl, *, intpen, t53, dinc, lgop, diffu, k1, gape1, gape2, extragop, minl, jneibr,

@@ -46,7 +46,27 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	Writer	w(outfn);
 	w.put_int("is_protein", 1);
 	w.put("a_codes", 1, a->at(0), a->len);
-	w.put_int("a_pad", *a->at(a->len));		// what exg_seq left behind the query (SpdpProblemH::a_pad)
+	w.put_int("a_pad", *a->at(a->len));
+	{
+	    // SpJunc::spjseq around every ambiguous position of the window: rows {n5, n3, codon of phase 1, codon of phase 2}
+	    SpJunc	spj(b, pwd);
+	    std::vector<int>	probe;
+	    int	n_amb = 0;
+	    for (int x = b->left; x < b->right && n_amb < 64; ++x) {
+		if (*b->at(x) != AMB) continue;
+		++n_amb;
+		for (int d = -3; d <= 4; ++d) {
+		    const int pr[2][2] = {{x + d, x + d + 61}, {x + d - 61, x + d}};
+		    for (int k = 0; k < 2; ++k) {
+			const int n5 = pr[k][0], n3 = pr[k][1];
+			if (n5 - 2 < 0 || n3 + 1 > b->len || n3 <= 0) continue;
+			const CHAR* cs = spj.spjseq(n5, n3);
+			probe.push_back(n5); probe.push_back(n3); probe.push_back(cs[0]); probe.push_back(cs[1]);
+		    }
+		}
+	    }
+	    if (!probe.empty()) w.put_i32("spj_probe", probe);
+	}		// what exg_seq left behind the query (SpdpProblemH::a_pad)
 	w.put("b_codes", 1, b->at(0), b->len + 1);	// + the terminator the engine reads (sm_a at n = right + 2)
 	{
 	    // the signal model behind the SGPT6 arrays (Exinon::intron53_p, codepot.cc:524-611): the position weight

@@ -113,11 +113,23 @@ static void spjseq(const Ctx* c, int n5, int n3, int cs[2])
     int w[4];
     for (int i = 0; i < 4; ++i) {
         const int t = b_code(c, idx[i]);
-        if (t >= 32 || g_mid[t] > 3) return;
-        w[i] = g_mid[t];
+        w[i] = (t >= 32) ? 4 : g_mid[t];
     }
-    cs[0] = g_tron_of[16 * w[0] + 4 * w[1] + w[2]];
-    cs[1] = g_tron_of[16 * w[1] + 4 * w[2] + w[3]];
+    /* an ambiguous second or third base: neither codon; an ambiguous first (last) one leaves the second (first)
+     * codon standing (spj_amb_tron_tab / spj_tron_amb_tab, src/codepot.cc:84-106) */
+    if (w[1] > 3 || w[2] > 3) return;
+    if (w[0] <= 3) cs[0] = g_tron_of[16 * w[0] + 4 * w[1] + w[2]];
+    if (w[3] <= 3) cs[1] = g_tron_of[16 * w[1] + 4 * w[2] + w[3]];
+}
+/* test hook: SpJunc::spjseq(n5, n3) as the engines of this file see it */
+void orc_spjseq_h(const SpdpProblemH* p, int n5, int n3, int32_t cs[2])
+{
+    Ctx cx; memset(&cx, 0, sizeof cx);
+    cx.p = p;
+    code_tables();
+    int c2[2];
+    spjseq(&cx, n5, n3, c2);
+    cs[0] = c2[0]; cs[1] = c2[1];
 }
 
 /* rc 0 ok; -1 unsupported parameters.  skl / n_skl may be NULL (score only: no Vmf, as HomScoreH_ng

@@ -120,3 +120,16 @@ extern "C" int walk_check_run_h(const SpdpScoringH* sc, const SpdpSeedParams* sp
     if (be.failed) return -1;
     return w.unsupported ? 1 : 0;
 }
+
+// SeedWalkH::split_codon on the whole active range of a problem (tests/test_oracle_spjseq.py)
+extern "C" int walk_check_split_codon_h(const SpdpProblemH* p, int n5, int n3, int32_t* cs)
+{
+    SeedWalkH w;
+    w.b = p->b; w.b_len = p->b_len;
+    spdp_genetic_code_tables(w.mid, w.tron_of);
+    w.cur = {p->a_left, p->a_right, p->b_left, p->b_right, 0, 0, 0, 0};
+    int c[2] = {0, 0};
+    const bool ok = w.split_codon(n5, n3, c);
+    cs[0] = c[0]; cs[1] = c[1];
+    return ok ? 0 : 1;
+}

@@ -100,9 +100,9 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
         const int t0 = bcode(n5 - 2), t1 = bcode(n5 - 1), t2 = bcode(n3), t3 = bcode(n3 + 1);
         if (t0 >= 32 || t1 >= 32 || t2 >= 32 || t3 >= 32) return;
         const int w0 = A.mid[t0], w1 = A.mid[t1], w2 = A.mid[t2], w3 = A.mid[t3];
-        if (w0 > 3 || w1 > 3 || w2 > 3 || w3 > 3) return;
-        c0 = A.tron_of[16 * w0 + 4 * w1 + w2];
-        c1 = A.tron_of[16 * w1 + 4 * w2 + w3];
+        if (w1 > 3 || w2 > 3) return;                   // a codon is defined when its own three bases are
+        if (w0 <= 3) c0 = A.tron_of[16 * w0 + 4 * w1 + w2];
+        if (w3 <= 3) c1 = A.tron_of[16 * w1 + 4 * w2 + w3];
     };
 #define LV(slot) L[(slot)][t]
     // slot of H / E / F / the diagonal predecessor (d = 0..3) in plane qq: hfesv / hfesb / hfesc (:301-325)

@@ -593,9 +593,10 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                                 int x = C.v[l] + (phs < 0 ? cipm : (phs == 0 ? cip0 : cipp)) + intpen_of(nb - C.j[l]) + s3 + T.t53[16 * ((C.x[l] >> 2) & 15) + dn3];
                                 if (cd == 0 && phs) {
                                     const int w0 = (C.x[l] >> 6) & 7, w1 = (C.x[l] >> 9) & 7;
-                                    const bool ok = w0 < 4 && w1 < 4 && w2 < 4 && w3 < 4;
-                                    if (phs == 1) x += prof0[ok ? T.tron_of[16 * w0 + 4 * w1 + w2] : AMB];
-                                    else x += prof1[ok ? T.tron_of[16 * w1 + 4 * w2 + w3] : AMB] - fix;
+                                    // a codon is defined when its own three bases are (spj_amb_tron_tab / spj_tron_amb_tab:
+                                    // an ambiguous first or last base of the four leaves the other codon standing)
+                                    if (phs == 1) x += prof0[(w0 < 4 && w1 < 4 && w2 < 4) ? T.tron_of[16 * w0 + 4 * w1 + w2] : AMB];
+                                    else x += prof1[(w1 < 4 && w2 < 4 && w3 < 4) ? T.tron_of[16 * w1 + 4 * w2 + w3] : AMB] - fix;
                                 }
                                 if (cd == 0) { if (x > h.v) { h.v = x; sel[0] = l; } }
                                 else if (cd == 1) { if (x > ea.v) { ea.v = x; sel[1] = l; } }
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
                             sigJ = AUX(nb).w;
                             const int t0 = tron_l(nb - 2), t1 = tron_l(nb - 1);
                             int w0 = t0 < 32 ? T.mid[t0] : 7, w1 = t1 < 32 ? T.mid[t1] : 7;
-                            if (nb < P.b_left) w0 = 7;
+                            if (nb < P.b_left) w0 = w1 = 7;            // (outside the range: neither codon)
                             packed = ((COL(nb).w >> 4) & 15) << 2 | (w0 & 7) << 6 | (w1 & 7) << 9;
                         }
 #pragma unroll

@@ -244,8 +244,8 @@ __global__ void spdh_rescore(HRescoreArgs A)
     auto spjseq = [&](int n5, int n3) -> int {
         if (n5 < P.b_left || n3 >= P.b_right) return AMBc | (AMBc << 8);
         const int c0 = A.mid[bat(n5 - 2) & 31], c1 = A.mid[bat(n5 - 1) & 31], c2 = A.mid[bat(n3) & 31], c3 = A.mid[bat(n3 + 1) & 31];
-        if ((c0 | c1 | c2 | c3) >= 4) return AMBc | (AMBc << 8);
-        return A.tron_of[16 * c0 + 4 * c1 + c2] | (A.tron_of[16 * c1 + 4 * c2 + c3] << 8);
+        if ((c1 | c2) >= 4) return AMBc | (AMBc << 8);         // a codon is defined when its own three bases are
+        return (c0 < 4 ? A.tron_of[16 * c0 + 4 * c1 + c2] : AMBc) | ((c3 < 4 ? A.tron_of[16 * c1 + 4 * c2 + c3] : AMBc) << 8);
     };
 
     int rb[21];

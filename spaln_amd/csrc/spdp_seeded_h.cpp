@@ -172,8 +172,8 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         memcpy(out[i].skl + 1, s.data(), sizeof(SpdpSkl) * s.size());
     }
     if (partial) {
-        ctx->err = "some protein walks met a state the seeded path does not serve (ambiguous bases at a junction, no HSP "
-                   "source for a recursion level, or a DP call the reference itself leaves undefined); those queries "
+        ctx->err = "some protein walks met a state the seeded path does not serve (no HSP source for a recursion "
+                   "level, or a DP call the reference itself leaves undefined); those queries "
                    "come back without an alignment";
         return 1;
     }

@@ -19,8 +19,8 @@
 //   SpJunc::spjseq / spjscr                    src/codepot.cc:74-107   SeedWalkH::split_codon / junction_score
 //   Aln2h1::shortcutH_ng                       :2232-2260      SeedWalkH::shortcut (forwardH_ng with a cut range behind
 //                                                              DpBackendH::trcbk)
-// Not served (the walk marks itself and the query comes back without an alignment): a split codon with ambiguous bases
-// (the reference's spj_amb_tron_tab / spj_tron_amb_tab).
+// Not served (the walk marks itself and the query comes back without an alignment): reads the reference would make
+// outside its sequences.
 //
 // Same design as spdp_seeded_walk.h: the reference's decisions on the same mutable state, every DP call (lspH_ng,
 // trcbkalignH_ng) through DpBackendH, header only, compiled into the product (device behind the calls) and into the CPU
@@ -204,20 +204,23 @@ public:
     void put(int m, int n) { rec.push_back({m, n}); }
     int end_margin() const { return (int) (sp->vthr / sc->gep); }
     int slmt() const { return sp->vthr / 2; }
-    // SpJunc::spjseq(n5, n3): the two codons an intron between n5 and n3 can split, as tron codes {phase 1, phase 2};
-    // false when a base around the junction is ambiguous (the reference has further tables for that)
+    // SpJunc::spjseq(n5, n3): the two codons an intron between n5 and n3 can split, as tron codes {phase 1, phase 2}.  A codon is
+    // defined when its own three bases are: an ambiguous second or third base of the four leaves neither, an ambiguous
+    // first (last) one the second (first) codon (spj_amb_tron_tab / spj_tron_amb_tab, src/codepot.cc:84-106)
     bool split_codon(int n5, int n3, int cs[2])
     {
-        if (n5 < cur.bl || n3 >= cur.br) { cs[0] = cs[1] = 2; return true; }         // spj_tron_tab[256]: {AMB, AMB}
+        cs[0] = cs[1] = 2;                                                              // spj_tron_tab[256]: {AMB, AMB}
+        if (n5 < cur.bl || n3 >= cur.br) return true;
         int w[4];
         const int at[4] = {n5 - 2, n5 - 1, n3, n3 + 1};
         for (int k = 0; k < 4; ++k) {
-            if (at[k] < 0 || at[k] > b_len) { mark(__LINE__); cs[0] = cs[1] = 0; return false; }
+            if (at[k] < 0 || at[k] > b_len) { mark(__LINE__); return false; }
             w[k] = mid[b[at[k]] & 31];
-            if (w[k] > 3) { if (getenv("SPDP_WALK_DEBUG")) fprintf(stderr, "split_codon n5 %d n3 %d k %d code %d\n", n5, n3, k, b[at[k]]); mark(__LINE__); cs[0] = cs[1] = 0; return false; }
         }
-        cs[0] = tron_of[16 * w[0] + 4 * w[1] + w[2]];
-        cs[1] = tron_of[16 * w[1] + 4 * w[2] + w[3]];
+        if (n3 == 0) w[2] = w[3] = 3;                                                   // (`pyrim`: PHE PHE stands in for position 0)
+        if (w[1] > 3 || w[2] > 3) return true;
+        if (w[0] <= 3) cs[0] = tron_of[16 * w[0] + 4 * w[1] + w[2]];
+        if (w[3] <= 3) cs[1] = tron_of[16 * w[1] + 4 * w[2] + w[3]];
         return true;
     }
     static bool avst_equal(int x, int y) { return x == y || (x == 18 && y == 23); }     // SER / SER2

@@ -202,6 +202,17 @@ def protein_cases():
     c["h1_forced_udh3"] = (g.window, g.query, ["-V", "200000", "-U", "3", "-u", "3"])
     g = pgene(11, n_exons=6, aa_len=450, flank=400, intron_hi=1500, sub=0.2)
     c["h1_450aa_auto"] = (g.window, g.query, ["-V", "1500000", "-u", "5"])
+    # ambiguous bases at junctions: an N two before a donor / one behind an acceptor leaves ONE of the two codons an
+    # intron can split defined (SpJunc::spjseq with spj_amb_tron_tab / spj_tron_amb_tab, src/codepot.cc:79-107)
+    for k in range(2):
+        g = pgene(40 + k, n_exons=6, aa_len=240, flank=200, intron_hi=400, sub=0.05)
+        w = g.window.copy()
+        for i, (lo, hi) in enumerate(g.exons):
+            if i + 1 < len(g.exons) and (i + k) % 2 == 0:
+                w[hi - 2] = ord("N")
+            if i > 0 and (i + k) % 2 == 1:
+                w[lo + 1] = ord("N")
+        c[f"h1_amb_junction{k}"] = (w, g.query, ["-u", "1,2"])
     return c
 
 

@@ -428,6 +428,20 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                     const int myslot = (lb * 16 - k + 16 + 48) % 48;
                     const float2* const mysig = sigring + myslot;
                     const int* const mybof = bofring + myslot;
+                    // intermediate row (lane k8 of its stripe): the steps of this block whose cell lies on it inside the band,
+                    // its diagonal at step 0, and the four link planes at that diagonal -- once per block, not per step
+                    int imd_jlo = 99, imd_jhi = -1, imd_r0 = 0, imd_r0w = 0;
+                    int *imd_h0 = nullptr, *imd_h1 = nullptr, *imd_v = nullptr, *imd_f = nullptr;
+                    if constexpr (UDH && IMD) {
+                        if (imd_row && k == k8) {
+                            imd_r0 = n0 - (ml + 1) - 2 * k;
+                            imd_r0w = imd_r0 + width;
+                            imd_jlo = max(0, lw - imd_r0);
+                            imd_jhi = min(15, min(up - imd_r0, n_end - n0 - 1));
+                            imd_h0 = imd_p + BIDX(imd_r0);
+                            imd_h1 = imd_h0 + width; imd_v = imd_h1 + width; imd_f = imd_v + width;
+                        }
+                    }
 
                     // LDS operands are read ahead of the step that uses them: the matrix column offset three steps, the
                     // substitution score two, signals, feed entry and penalty entry one
@@ -491,16 +505,14 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                         int fl = fcin;                                  /* link of my F */                   \
                         if constexpr (UDH && IMD) {                                                          \
                             /* scalar bookkeeping of the intermediate row (lane k8 of its stripe) */         \
-                            const int n = n0 + J;                                                            \
-                            const int rj = n - (ml + 1) - 2 * k;            /* my cell's diagonal */         \
-                            if (imd_row && k == k8 && rj >= lw && rj <= up && n < n_end) {                   \
-                                int* hl0 = imd_p + BIDX(rj);                                                 \
-                                if (SPJ && is_acc) { st_b1<CROSS>(hl0, donor_r); st_b1<CROSS>(hl0 + width, donor_r + width); rlst = rj; } \
-                                if (SPJ && is_don) donor_r = rj;                                             \
-                                if (pb3 == 0) rlst = rj;                                                     \
-                                if (pb3 == 1) st_b1<CROSS>(hl0, rlst);                                       \
-                                st_b1<CROSS>(hl0 + 2 * width, hc); hc = rj;                                  \
-                                st_b1<CROSS>(hl0 + 3 * width, fl); fl = rj + width;                          \
+                            if (J >= imd_jlo && J <= imd_jhi) {                                              \
+                                const int rj = imd_r0 + J;                      /* my cell's diagonal */     \
+                                if (SPJ && is_acc) { st_b1<CROSS>(imd_h0 + J, donor_r); st_b1<CROSS>(imd_h1 + J, donor_r + width); } \
+                                rlst = ((SPJ && is_acc) || pb3 == 0) ? rj : rlst;                            \
+                                if (SPJ) donor_r = is_don ? rj : donor_r;                                    \
+                                if (pb3 == 1) st_b1<CROSS>(imd_h0 + J, rlst);                                \
+                                st_b1<CROSS>(imd_v + J, hc); hc = rj;                                        \
+                                st_b1<CROSS>(imd_f + J, fl); fl = imd_r0w + J;                               \
                             }                                                                                \
                         }                                                                                    \
                         Hd = upH; Hs = h;                                                                    \

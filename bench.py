@@ -36,20 +36,22 @@ HBM_PEAK_GBS = 8000.0
 # VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
 # fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
 # profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
-# same profiles: fp32-issue UDH sweep 51.2 / 64 (round 1: 59.6), forward sweep 69.6 / 64, protein sweep 152.3 / 64
+# same kind of profile: fp32-issue UDH sweep 49.0 / 64 (profiles/r03_valu_pmc.txt: 4.807e11 over the six launches = three
+# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 69.6 / 64, protein sweep 152.3 / 64
 # (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 1.6736e11 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
+VALU_PER_CELL = {"udh": 4.80703e11 / 3 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
                  "a0_udh": 1.2802e10 / 2.05e9}      # (--engines a0: profiles/r02_a0_sq_counters.txt)
 # HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
-# chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes (profiles/r02_hbm_traffic_pmc.txt).  FETCH_SIZE
+# chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes, summed over the six launches of that run
+# (profiles/r03_hbm_traffic_pmc.txt; round 2: 2 x 24.9e6 + 89.2e6 KiB per launch, now 2 x 28.2e6 + 89.0e6).  FETCH_SIZE
 # counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
 # the figure an upper bound for the 8-byte column-record reads.
-PMC_TRAFFIC_BYTES = int((2 * 49828262 + 178326372) * 1024 / 2)
+PMC_TRAFFIC_BYTES = int((2 * 169079991 + 533981514) * 1024 / 6)
 # one spdp_rowwave_udh<true> launch of the default --engines a0 workload (profiles/r02_a0_hbm_traffic_pmc.txt)
 PMC_TRAFFIC_BYTES_A0 = (2 * 10706788 + 37364177) * 1024
-# same for one spdh_sweep launch of the default c3 workload (profiles/r02_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((2 * 38323706 + 146477017) * 1024)
+# same for one spdh_sweep launch of the default c3 workload (profiles/r03_h_hbm_traffic_pmc.txt)
+PMC_TRAFFIC_BYTES_H = int((2 * 38293411 + 146561684) * 1024)
 
 
 def _cpu_align_one(item):
@@ -300,7 +302,7 @@ def main_c3(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1 and not exact) else None,
-                         "traffic_source": "profiles/r02_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
+                         "traffic_source": "profiles/r03_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
                          "kernel": ("spdh_rowwave" if args.engines == "a0" else "spdh_exact") if exact else "spdh_sweep",
                          "kernel_ms": round(k_ms, 3),
                          "valu": None if exact else _valu_roofline(cells, "h", k_ms),
@@ -320,7 +322,7 @@ def _valu_roofline(cells, kind, k_ms):
     if not k_ms or not cells:
         return None
     ach = cells * VALU_PER_CELL[kind] / (k_ms * 1e-3)
-    src = ("SQ_INSTS_VALU per cell (profiles/r02_sq_counters.txt) x cells / kernel time; peak = one VALU "
+    src = ("SQ_INSTS_VALU per cell (profiles/r03_valu_pmc.txt) x cells / kernel time; peak = one VALU "
            "wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, profiles/r02_valu_ubench.txt); "
            "the instruction mix of the step, priced by class, explains 0.71 of the measured time")
     if kind == "a0_udh":
@@ -584,7 +586,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": (PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4 and not exact) else
                                      PMC_TRAFFIC_BYTES_A0 if (args.engines == "a0" and args.queries == 1000 and world == 1 and not c4) else None),
-                         "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r02_hbm_traffic_pmc.txt") +
+                         "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r03_hbm_traffic_pmc.txt") +
                                            " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
                          "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
                                    ("spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),

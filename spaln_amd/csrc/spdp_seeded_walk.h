@@ -131,6 +131,7 @@ public:
     const uint8_t* b = nullptr; int b_len = 0;
     const int16_t* sig5 = nullptr; const int16_t* sig3 = nullptr;
     const uint8_t* cano5 = nullptr; const uint8_t* cano3 = nullptr; const uint8_t* dinc = nullptr;
+    const int32_t* cip = nullptr;               // Cip_score::cip_score(m), m = 0 .. a_len, or null (SpdpProblem::cip)
     std::vector<int8_t> phs5, phs3;             // SGPT2::phs5 / phs3: the walk marks the junctions it accepts (:2055-2059)
     std::vector<uint8_t> lvl5, lvl3;            // INT53::cano5 / cano3 as levels 0 .. 3 (cano5 / cano3 above only say "a site")
     const SpdpScoring* sc = nullptr;
@@ -296,7 +297,11 @@ public:
             for (v = 0; n <= cur.bl; ++n, ++t, ++m) {
                 const int rc = is_canon(n, n + ilen);
                 if (retry || rc) {
-                    const int y = sig53_5p3(n, n + ilen) - v - bw[t];
+                    int x = sig53_5p3(n, n + ilen);
+                    // use_spb(): an annotated intron position of the query earns its bonus at a canonical junction
+                    // (PfqItr::match_score = Cip_score::cip_score of that position, src/gsinfo.h:226-229, gsinfo.cc:65-79)
+                    if (cip && m >= 0 && m <= a_len && cip[m] && rc > 3) x += cip[m];
+                    const int y = x - v - bw[t];
                     if (y > iscr) { k.n = n; k.m = m; iscr = y; }
                 }
                 v += sim(qa++, ++qb);
@@ -873,7 +878,7 @@ inline bool bind_problem(SeedWalk& w, const SpdpScoring* sc, const SpdpSeedParam
     if (!sc || !sp || !p || !p->a || !p->b || !p->sig5 || !p->sig3 || !p->cano5 || !p->cano3 || !p->dinc ||
         !sc->intpen || sc->intpen_len <= 0 || sp->qck < 1 || sp->qck > 3) return false;
     w.a = p->a; w.a_len = p->a_len; w.b = p->b; w.b_len = p->b_len;
-    w.sig5 = p->sig5; w.sig3 = p->sig3; w.cano5 = p->cano5; w.cano3 = p->cano3; w.dinc = p->dinc;
+    w.sig5 = p->sig5; w.sig3 = p->sig3; w.cano5 = p->cano5; w.cano3 = p->cano3; w.dinc = p->dinc; w.cip = p->cip;
     w.sc = sc; w.sp = sp;
     w.lowest_level = lowest_level;
     const int N = p->b_len + 1;

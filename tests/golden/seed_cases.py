@@ -162,6 +162,15 @@ def special_cases():
         g = synth.make_gene(rng, n_exons=5, mrna_len=700, flank=500, intron_hi=1200, sub=sub, indel=0.01)
         c[f"q_o3_plus{k}"] = (g.window, g.query, ["-Q", str(qck), "-O"])
         c[f"q_o3_minus{k}"] = (revcomp(g.window), revcomp(g.query), ["-Q", str(qck), "-O"])
+    # annotated intron positions on the query (ref_dump -I / -J; use_spb()): indelfreespjS adds the position's bonus at a
+    # canonical junction (src/fwd2s1.cc:2030-2037), the DP engines add it through Cip_score; positions at the true
+    # junctions and displaced by one / two residues, weights from modest to one that outbids the splice signals
+    for k, (qck, shift, wgt) in enumerate(((1, 0, 10), (3, 1, 60), (2, -2, 120), (1, 2, 300))):
+        rng = np.random.default_rng(synth.SEED + 49050 + k)
+        g = synth.make_gene(rng, n_exons=6, mrna_len=900, flank=400, intron_hi=900, sub=0.02, indel=0.0)
+        cum = np.cumsum([b - a for a, b in g.exons])[:-1]
+        pos = sorted(set(int(x) + shift for x in cum))
+        c[f"q_cip{k}"] = (g.window, g.query, ["-Q", str(qck), "-I", ",".join(map(str, pos)), "-J", str(wgt)])
     # BASELINE's headline size under -Q7: the DP calls between HSPs stay far below the 1472 rows at which the
     # reference's int16 engines start re-basing, so its -A2 output IS a witness at 2 kb here
     for k in range(2):

@@ -61,6 +61,8 @@ def problem(fx: dict, ps: abi.ProblemSet | None = None):
     if "dinc5" in fx:
         extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
                      dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    if "cip" in fx:                                      # ref_dump -I: conserved intron positions on the query
+        extra["cip"] = fx["cip"]
     p = ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"],
                q["a_left"], q["a_right"], q["b_left"], q["b_right"],
                (q["a_exgl"], q["a_exgr"], q["b_exgl"], q["b_exgr"]), **extra)

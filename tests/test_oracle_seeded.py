@@ -88,3 +88,13 @@ def test_seeded_ori3_equals_reference(path, alg, simd):
 
 def test_ori3_fixtures_take_both_orientations():
     assert sorted({int(spdg.load(f)["seed_rev_A2"][0]) for f in O3}) == [0, 1]
+
+
+def test_annotated_intron_positions_enter_the_junction_rule():
+    """use_spb(): q_cip0 carries the query's intron positions at the true junctions (ref_dump -I / -J); indelfreespjS adds
+    their bonus (src/fwd2s1.cc:2030-2037) -- without it the walk falls 5 x 100 short of the reference's score"""
+    fx = spdg.load([f for f in golden_files("q_cip") if f.endswith("q_cip0.spdg")][0])
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 2)
+    assert seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2)[0] == int(fx["seed_scr_A2"][0])
+    p.cip = None
+    assert seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2)[0] == int(fx["seed_scr_A2"][0]) - 500

@@ -422,6 +422,8 @@ def skl_rng_s(sc, p, skl, *, codonk1, minl, jneibr, lsg=1):
                 s5 = int(sig5[n])
                 s3 = int(sig3[n3])
                 xi = s5 + spjscr(n, n3)
+                if p.cip:                               # use_spb(): PfqItr::match_score(m) = Cip_score::cip_score(m) (:615)
+                    xi += int(C.cast(p.cip, C.POINTER(C.c_int32))[m]) if 0 <= m <= p.a_len else 0
             else:
                 xi = abi.NEVSEL
             if xi > gap_penalty(i) and xi > rbuf["iscr"]:

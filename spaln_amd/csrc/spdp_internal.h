@@ -173,6 +173,8 @@ struct RescoreArgs {
     const int64_t*    ops_off;
     int*              ops_cnt;    // records the walk produced (may exceed the slot: then the slot is full and the rest lost)
     const int*        a_len;      // SAM: query lengths
+    const int*        cip;        // Cip_score::cip_score(m) rows (DevProblem::cip_off), or null: the bonus of use_spb()
+    const int*        a_len_all;  // query lengths (always set when cip is)
 };
 extern "C" hipError_t spdp_launch_rescore(const RescoreArgs* a, hipStream_t s);
 

@@ -143,6 +143,8 @@ __global__ void spdp_rescore_s(RescoreArgs A)
                 s5 = sig5_at(n);
                 s3 = sig3_at(n3);
                 xi = s5 + spjscr(n, n3);
+                // use_spb(): an annotated intron position of the query (PfqItr::match_score(m) = Cip_score::cip_score(m))
+                if (A.cip && P.cip_off >= 0 && m >= 0 && m <= A.a_len_all[qi]) xi += A.cip[P.cip_off + m];
             }
             if (xi > gap_penalty(i) && xi > rb[ISCR]) {           // intron
                 preint = insert;

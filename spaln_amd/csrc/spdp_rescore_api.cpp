@@ -57,6 +57,7 @@ static int rescore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreP
         d.a_left = probs[i].a_left; d.a_right = probs[i].a_right; d.b_left = probs[i].b_left; d.b_right = probs[i].b_right;
         d.flags = (probs[i].a_exgl ? 1 : 0) | (probs[i].a_exgr ? 2 : 0) | (probs[i].b_exgl ? 4 : 0) | (probs[i].b_exgr ? 8 : 0);
         d.a_off = st.a_off[i]; d.col_off = st.col_off[i];
+        d.cip_off = st.cip_off.empty() ? -1 : st.cip_off[i];
         idx.push_back(i); descs.push_back(d);
         soff.push_back((int64_t) skl.size()); scnt.push_back(cnt);
         skl.insert(skl.end(), aln[i].skl + 1, aln[i].skl + 1 + cnt);
@@ -108,6 +109,16 @@ static int rescore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreP
         HIPCHK(hipMemcpyAsync(d_alen, alen.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         A.ops_format = format; A.ops = (int3*) d_ops; A.ops_off = (const int64_t*) d_ooff; A.ops_cnt = (int*) d_ocnt;
         A.a_len = (const int*) d_alen;
+    }
+    void* d_alen_all = nullptr;
+    struct Freer1 { void** p; ~Freer1() { if (*p) (void) hipFree(*p); } } freer1{&d_alen_all};
+    if (st.d_cip) {                                          // annotated intron positions (use_spb, src/fwd2s1.cc:615)
+        std::vector<int> la(nr);
+        for (int s = 0; s < nr; ++s) la[s] = probs[idx[s]].a_len;
+        HIPCHK(hipMalloc(&d_alen_all, nr * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(d_alen_all, la.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        A.cip = (const int*) st.d_cip; A.a_len_all = (const int*) d_alen_all;
     }
     HIPCHK(spdp_launch_rescore(&A, ctx->stream));
     std::vector<int> hdr((size_t) nr * 8), rec((size_t) rtot * 21);

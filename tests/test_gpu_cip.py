@@ -79,6 +79,12 @@ def test_cip_pinned_to_reference_runs(alg, engines):
         (scr, skl), = eng.align_s(sc, ps)
         assert scr == int(fx[f"aln_scr_A{alg}"][0]), path
         assert skl.ravel().tolist() == fx[f"aln_skl_A{alg}"].tolist(), path
+        # skl_rngS_ng with use_spb(): the intron score of a row with an annotated position carries its bonus (:615)
+        fs = fx[f"rng_fstat_A{alg}"]
+        (score, fst, ex), = eng.skl_rng_s(sc, ps, [skl], codonk1=fx["prm"]["codonk1"], minl=fx["prm"]["minl"],
+                                          jneibr=int(fs[6]), lsg=int(fs[7]))
+        assert score == int(fx[f"rng_scr_A{alg}"][0]), path
+        assert fst == [int(x) for x in fs[:5]] and ex.tolist() == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist(), path
         n += 1
     eng.close()
     assert n == 4

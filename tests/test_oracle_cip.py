@@ -44,3 +44,19 @@ def test_the_bonus_matters_in_the_fixtures():
         scr, skl = hl.align_s(sc, p, simd=0)
         n += scr != int(fx["aln_scr_A0"][0]) or (skl or []) != fx["aln_skl_A0"].tolist()
     assert n >= 2
+
+
+@pytest.mark.parametrize("path", golden_files("cp_"), ids=[f.split("/")[-1][:-5] for f in golden_files("cp_")])
+@pytest.mark.parametrize("alg", [0, 2])
+def test_rescoring_carries_the_bonus(path, alg):
+    """skl_rngS_ng with use_spb() (src/fwd2s1.cc:487, 615): total, statistics and exon records of the reference's run"""
+    from oracle import host_logic
+    fx = spdg.load(path)
+    sc = spdg.scoring(fx)
+    _, p = cip_problem(fx)
+    fs = fx[f"rng_fstat_A{alg}"]
+    h, fst, recs = host_logic.skl_rng_s(sc, p, [int(x) for x in fx[f"aln_skl_A{alg}"]], codonk1=fx["prm"]["codonk1"],
+                                        minl=fx["prm"]["minl"], jneibr=int(fs[6]), lsg=int(fs[7]))
+    assert h == int(fx[f"rng_scr_A{alg}"][0])
+    assert fst == [int(x) for x in fs[:5]]
+    assert recs == fx[f"rng_eij_A{alg}"].reshape(-1, 21).tolist()

@@ -486,6 +486,12 @@ typedef struct SpdpSignalModelH {
     int32_t any;                                /* algmode.any                                              */
     int32_t dvsp;                               /* PwdB::DvsP != 3: start / stop contexts are scored        */
     int32_t trm, trm2;                          /* the two termination tron codes (TRM, TRM2)               */
+    /* branch-point term of the acceptor signal (-yB; Exinon::intron53_p, src/codepot.cc:543, 586-597): an acceptor
+     * earns fB x the score of the last branch site stronger than tonicB at most maxb3d + 1 positions upstream.
+     * pmB.rows = 0 (a zeroed tail): off, as in the reference's default and all its species tables */
+    SpdpPatMat pmB;                             /* EijPat::patternB                                         */
+    float   fB, tonicB;                         /* bpprm.factor * fact, EijPat::tonicB                      */
+    int32_t maxb3d;                             /* bpprm.maxb3d                                             */
 } SpdpSignalModelH;
 /* the SGPT6 arrays of one tron window on the device: b_len + 3 entries each, computed for [left, right) (any output may be
  * NULL); b holds b_len + 1 codes */

@@ -100,6 +100,8 @@ const	char*	exg = 0;
 		}
 		case 'J': spb = atof(argv[++ai]); break;
 		case 'X': crs = atoi(argv[++ai]); break;	// algmode.crs as -yX sets it (simmtx.cc:704): 0 = same species
+		case 'b': bpprm.factor = atof(argv[++ai]); break;	// -yB: weight of the branch-point signal (simmtx.cc:671)
+		case 'D': bpprm.maxb3d = atoi(argv[++ai]); break;	// -yD: furthest branch point from its acceptor
 		case 'C': local = 3; break;			// -LC: local with LocalC (algmode.lcl & 32)
 		case 'A': {
 		    const char* p = argv[++ai];

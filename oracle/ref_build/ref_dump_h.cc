@@ -110,8 +110,12 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	    // the per-dinucleotide terms sig53tab[0 / 1][class] (private to Exinon): what is left of a signal after the scaled
 	    // matrix score, which the reference's own PatMat::calcPatMat reproduces (same call and range as intron53_p)
 	    std::vector<int> tab(32, INT_MIN);
-	    if (pwd->eijpat->pattern5 && pwd->eijpat->pattern3 && !pwd->eijpat->patternB) {
+	    if (pwd->eijpat->pattern5 && pwd->eijpat->pattern3) {
 		const float fs = f[6];
+		// (with the branch-point term on, sig3 carries it: the table is read off a second Exinon built without it)
+		PatMat* const	patB = pwd->eijpat->patternB;
+		Exinon*	exq = b->exin;
+		if (patB) { pwd->eijpat->patternB = 0; exq = new Exinon(b, pwd, false); pwd->eijpat->patternB = patB; }
 		--b->left; ++b->right;
 		float* p5 = pwd->eijpat->pattern5->calcPatMat(b);
 		float* p3 = pwd->eijpat->pattern3->calcPatMat(b);
@@ -127,13 +131,14 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 		}
 		int	clash = 0;
 		for (int n = b->left + 2; n < b->right - 1; ++n) {
-		    const SGPT6* sg = b->exin->score_p(n);
+		    const SGPT6* sg = exq->score_p(n);
 		    const int t5 = sg->sig5 - (STYPE) (fs * p5[n - b->left + 1]);
 		    const int t3 = sg->sig3 - (STYPE) (fs * p3[n - b->left + 1]);
 		    if (tab[e5[n]] == INT_MIN) tab[e5[n]] = t5; else if (tab[e5[n]] != t5) ++clash;
 		    if (tab[16 + e3[n]] == INT_MIN) tab[16 + e3[n]] = t3; else if (tab[16 + e3[n]] != t3) ++clash;
 		}
 		if (clash) fprintf(stderr, "ref_dump: %d signal-table clashes\n", clash);
+		if (exq != b->exin) delete exq;
 		delete[] p5; delete[] p3;
 	    }
 	    w.put_i32("sig53tab01", tab);

@@ -101,7 +101,7 @@ def model_of(fx: dict) -> dict:
                 pmB=PatMat(fx["pmB_hdr"], fx["pmB_f32"]),
                 pot=np.asarray(fx["potC_f32"], dtype=np.int32).view(np.float32), pot_ndata=int(fx["potC_hdr"][0]),
                 fE=F32(f[0]), fI=F32(f[1]), fT=F32(f[2]), fB=F32(f[3]), fO=F32(f[4]), fS=F32(f[5]), fs=F32(f[6]),
-                tonic3=F32(f[7]), tonic5=F32(f[8]), tonicB=F32(f[9]),
+                tonic3=F32(f[7]), tonic5=F32(f[8]), tonicB=F32(f[9]), maxb3d=i[2],
                 any=i[0], dvsp=i[1] != 3, trm=(i[5], i[6]), tab=np.asarray(fx["sig53tab01"], dtype=np.int64))
 
 
@@ -138,6 +138,10 @@ def splice_signals_h(md: dict, b: np.ndarray, b_len: int, left: int, right: int)
     pot0 = max(left - 1, 0)
     th5 = int(F32(md["fS"] * md["tonic5"])); th3 = int(F32(md["fS"] * md["tonic3"]))
     trm = md["trm"]
+    # the branch-point carry (-yB; src/codepot.cc:536, 567-568, 586-597)
+    use_b = md["pmB"].present
+    th_b = float(np.int16(int(md["tonicB"]))) if use_b else 0.0
+    sig_b, pos_b = 0, -1
     for pos in range(left, right):
         if md["dvsp"] and md["pmI"].present:
             out["sigS"][pos] = int(F32(md["fT"] * scan(md["pmI"], x, pos)))
@@ -152,6 +156,13 @@ def splice_signals_h(md: dict, b: np.ndarray, b_len: int, left: int, right: int)
             out["sigE"][pos] = int(e)
         s5 = int(F32(md["fs"] * scan(md["pm5"], x, pos))) + int(md["tab"][d5[pos]])
         s3 = int(F32(md["fs"] * scan(md["pm3"], x, pos))) + int(md["tab"][16 + d3[pos]])
+        if use_b:
+            s3 = int(np.int16(s3 + sig_b))
+            sb = scan(md["pmB"], x, pos)
+            if sb > th_b:
+                sig_b, pos_b = int(np.int16(int(F32(md["fB"] * sb)))), pos
+            if pos_b >= 0 and pos - pos_b > md["maxb3d"]:
+                sig_b, pos_b = 0, -1
         out["sig5"][pos] = s5
         out["sig3"][pos] = s3
         for sig, cano, ph, th in ((s5, c5, out["phs5"], th5), (s3, c3, out["phs3"], th3)):

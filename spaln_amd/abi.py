@@ -349,14 +349,15 @@ class SignalModelH(C.Structure):         # SpdpSignalModelH
                 ("fE", C.c_float), ("fT", C.c_float), ("fO", C.c_float), ("fS", C.c_float), ("fs", C.c_float),
                 ("tonic5", C.c_float), ("tonic3", C.c_float),
                 ("tab5", C.c_int16 * 16), ("tab3", C.c_int16 * 16),
-                ("any", C.c_int32), ("dvsp", C.c_int32), ("trm", C.c_int32), ("trm2", C.c_int32)]
+                ("any", C.c_int32), ("dvsp", C.c_int32), ("trm", C.c_int32), ("trm2", C.c_int32),
+                ("pmB", PatMatC), ("fB", C.c_float), ("tonicB", C.c_float), ("maxb3d", C.c_int32)]
 
 
 def signal_model_h_from_fixture(fx: dict) -> SignalModelH:
     """the protein-side model a reference dump carries (pm*_hdr / pm*_f32, potC_*, sigmodel_f32 / _i32, sig53tab01)"""
     m = SignalModelH()
     keep = []
-    for tag, dst in (("pm5", m.pm5), ("pm3", m.pm3), ("pmI", m.pmI), ("pmT", m.pmT)):
+    for tag, dst in (("pm5", m.pm5), ("pm3", m.pm3), ("pmI", m.pmI), ("pmT", m.pmT), ("pmB", m.pmB)):
         hd = [int(v) for v in fx[tag + "_hdr"]]
         if not hd[0]:
             continue
@@ -374,6 +375,7 @@ def signal_model_h_from_fixture(fx: dict) -> SignalModelH:
     for k in range(16):
         m.tab5[k] = int(fx["sig53tab01"][k]); m.tab3[k] = int(fx["sig53tab01"][16 + k])
     m.any, m.dvsp, m.trm, m.trm2 = i[0], int(i[1] != 3), i[5], i[6]
+    m.fB, m.tonicB, m.maxb3d = float(f[3]), float(f[9]), i[2]
     m._keep = keep
     return m
 

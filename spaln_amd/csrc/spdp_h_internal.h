@@ -94,9 +94,9 @@ struct HScalarArgs {
 // protein-side signal precompute (spdp_signals_h.hip): Exinon::intron53_c / intron53_p for tron windows
 struct SigPatMatDev { int32_t rows, cols, offset, order; float tonic, min_elem; };
 struct SigModelHDev {
-    SigPatMatDev pm5, pm3, pmI, pmT;
-    int32_t pot_ndata, any, dvsp, trm, trm2;
-    float   fE, fT, fO, fS, fs, tonic5, tonic3;
+    SigPatMatDev pm5, pm3, pmI, pmT, pmB;
+    int32_t pot_ndata, any, dvsp, trm, trm2, maxb3d;
+    float   fE, fT, fO, fS, fs, tonic5, tonic3, fB, thB;
     int16_t tab5[16], tab3[16];
 };
 struct SigJobH {
@@ -107,7 +107,9 @@ struct SigJobH {
 };
 struct SignalArgsH {
     const SigModelHDev* model;
-    const float*        mtx;       // pm5, pm3, pmI, pmT matrices back to back
+    const float*        mtx;       // pm5, pm3, pmI, pmT, pmB matrices back to back
+    int32_t*            sb;        // branch-point term on: per position (int16) (fB x score) of a site above the threshold,
+                                   // INT32_MIN elsewhere (spdh_signals writes it, spdh_signal_phases folds it into sig3)
     const float*        pot;       // coding potential, 3 * pot_ndata floats
     const SigJobH*      jobs;
     const uint8_t*      codes;

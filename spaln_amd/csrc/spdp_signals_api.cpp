@@ -103,8 +103,8 @@ extern "C" int spdp_splice_signals(SpdpContext* ctx, const SpdpSignalModel* mode
 static const char* check_model_h(const SpdpSignalModelH* m)
 {
     if (!m || !m->pm5.mtx || !m->pm3.mtx) return "signal model: splice-site matrices missing";
-    const SpdpPatMat* pm[4] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT};
-    for (int i = 0; i < 4; ++i) {
+    const SpdpPatMat* pm[5] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT, &m->pmB};
+    for (int i = 0; i < 5; ++i) {
         const SpdpPatMat& q = *pm[i];
         if (i >= 2 && (!q.rows || !q.mtx)) continue;
         if ((q.order == 2 && q.rows != 84) || (q.order == 1 && q.rows != 20) || (q.order == 0 && q.rows != 4) || q.order < 0 || q.order > 2)
@@ -122,21 +122,29 @@ int spdh_signals_run(SpdpContext* ctx, const SpdpSignalModelH* m, const std::vec
     (void) hipSetDevice(ctx->device);
     SigModelHDev hm;
     memset(&hm, 0, sizeof hm);
-    const SpdpPatMat* pm[4] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT};
-    SigPatMatDev* dm[4] = {&hm.pm5, &hm.pm3, &hm.pmI, &hm.pmT};
+    const SpdpPatMat* pm[5] = {&m->pm5, &m->pm3, &m->pmI, &m->pmT, &m->pmB};
+    SigPatMatDev* dm[5] = {&hm.pm5, &hm.pm3, &hm.pmI, &hm.pmT, &hm.pmB};
     size_t tot = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const bool on = pm[i]->rows && pm[i]->mtx;
         if (on) { dm[i]->rows = pm[i]->rows; dm[i]->cols = pm[i]->cols; dm[i]->offset = pm[i]->offset; dm[i]->order = pm[i]->order;
                   dm[i]->tonic = pm[i]->tonic; dm[i]->min_elem = pm[i]->min_elem; tot += (size_t) pm[i]->rows * pm[i]->cols; }
     }
     hm.pot_ndata = m->pot ? m->pot_ndata : 0; hm.any = m->any; hm.dvsp = m->dvsp ? 1 : 0; hm.trm = m->trm; hm.trm2 = m->trm2;
     hm.fE = m->fE; hm.fT = m->fT; hm.fO = m->fO; hm.fS = m->fS; hm.fs = m->fs; hm.tonic5 = m->tonic5; hm.tonic3 = m->tonic3;
+    hm.fB = m->fB; hm.thB = (float) (int16_t) (int) m->tonicB; hm.maxb3d = m->maxb3d;      // (STYPE thB, src/codepot.cc:536)
     memcpy(hm.tab5, m->tab5, sizeof hm.tab5); memcpy(hm.tab3, m->tab3, sizeof hm.tab3);
     std::vector<float> hmtx;
     hmtx.reserve(tot);
-    for (int i = 0; i < 4; ++i) if (dm[i]->rows) hmtx.insert(hmtx.end(), pm[i]->mtx, pm[i]->mtx + (size_t) dm[i]->rows * dm[i]->cols);
-    DevBuf d_model, d_mtx, d_pot, d_jobs;
+    for (int i = 0; i < 5; ++i) if (dm[i]->rows) hmtx.insert(hmtx.end(), pm[i]->mtx, pm[i]->mtx + (size_t) dm[i]->rows * dm[i]->cols);
+    DevBuf d_model, d_mtx, d_pot, d_jobs, d_sb;
+    args.sb = nullptr;
+    if (hm.pmB.rows) {                                       // the branch-point scores of all positions, between the two kernels
+        int64_t n_pos = 0;
+        for (const SigJobH& j : jobs) n_pos = std::max<int64_t>(n_pos, j.out_off + j.b_len + 3);
+        HIPCHK(d_sb.get((size_t) n_pos * sizeof(int32_t)));
+        args.sb = d_sb.as<int32_t>();
+    }
     HIPCHK(d_model.get(sizeof hm));
     HIPCHK(d_mtx.get(hmtx.size() * sizeof(float)));
     HIPCHK(d_pot.get(hm.pot_ndata ? 3 * (size_t) hm.pot_ndata * sizeof(float) : 16));

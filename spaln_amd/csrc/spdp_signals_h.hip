@@ -68,7 +68,7 @@ __device__ __forceinline__ float pm_scan(const SigPatMatDev& pm, const float* __
 __global__ __launch_bounds__(SGH_TPB)
 void spdh_signals(SignalArgsH A)
 {
-    extern __shared__ float s_mtx[];                     // pm5, pm3, pmI, pmT back to back
+    extern __shared__ float s_mtx[];                     // pm5, pm3, pmI, pmT, pmB back to back
     __shared__ uint8_t s_b[SGH_TPB + 2 * SGH_HALO];      // tron codes of positions p0 - HALO ..
     const SigJobH J = A.jobs[blockIdx.y];
     const int p0 = blockIdx.x * SGH_TPB;
@@ -76,7 +76,7 @@ void spdh_signals(SignalArgsH A)
     if (p0 >= N) return;
     const SigModelHDev& M = *A.model;
     const int o5 = 0, o3 = M.pm5.rows * M.pm5.cols, oI = o3 + M.pm3.rows * M.pm3.cols, oT = oI + M.pmI.rows * M.pmI.cols,
-              tot = oT + M.pmT.rows * M.pmT.cols;
+              oB = oT + M.pmT.rows * M.pmT.cols, tot = oB + M.pmB.rows * M.pmB.cols;
     for (int i = threadIdx.x; i < tot; i += SGH_TPB) s_mtx[i] = A.mtx[i];
     const uint8_t* __restrict__ codes = A.codes + J.b_off;
     for (int i = threadIdx.x; i < SGH_TPB + 2 * SGH_HALO; i += SGH_TPB) {
@@ -91,7 +91,7 @@ void spdh_signals(SignalArgsH A)
     auto xs = [&](int i) { return (int) sgh_tnred[tron(i) & 31]; };
     auto xc = [&](int i) { const int c = xs(i); return c > 3 ? 1 : c; };
     auto nc = [&](int i) { return (((i == J.left ? 1 : xc(i - 1)) << 2) + xc(i)) & 0xf; };
-    int v5 = 0, v3 = 0, vS = 0, vT = 0, vE = 0, d5 = 0, d3 = 0, c5 = 0, c3 = 0;
+    int v5 = 0, v3 = 0, vS = 0, vT = 0, vE = 0, d5 = 0, d3 = 0, c5 = 0, c3 = 0, vB = INT32_MIN;
     const int any = M.any & 3;
     const int jac[4] = {0, 2, 3, 1}, jgt[4] = {0, 0, 3, 1};
     const int ac = jac[any], gt = jgt[any], dflt = any == 3 ? 1 : 0;
@@ -131,6 +131,10 @@ void spdh_signals(SignalArgsH A)
             else if (pos + 3 < J.right && pos + 3 < len) { const int t3 = tron(pos + 3); if (t3 == M.trm || t3 == M.trm2) e = 0.f; }
             vE = (int16_t) (int) e;
         }
+        if (M.pmB.rows) {                                // a branch site stronger than the threshold (:588-591)
+            const float sb = pm_scan(M.pmB, s_mtx + oB, pos, len, xs);
+            if (sb > M.thB) vB = (int16_t) (int) (M.fB * sb);
+        }
         const float f5 = pm_scan(M.pm5, s_mtx + o5, pos, len, xs);
         const float f3 = pm_scan(M.pm3, s_mtx + o3, pos, len, xs);
         v5 = (int16_t) ((int16_t) (int) (M.fs * f5) + M.tab5[d5]);
@@ -138,6 +142,7 @@ void spdh_signals(SignalArgsH A)
     }
     const int64_t o = J.out_off + pos;
     A.sig5[o] = (int16_t) v5; A.sig3[o] = (int16_t) v3; A.sigS[o] = (int16_t) vS; A.sigT[o] = (int16_t) vT; A.sigE[o] = (int16_t) vE;
+    if (A.sb) A.sb[o] = vB;
     A.cano[o] = (uint8_t) (c5 | c3 << 4);
     A.dinc[o] = (uint8_t) (d5 << 4 | d3);
 }
@@ -152,12 +157,19 @@ __global__ void spdh_signal_phases(SignalArgsH A, int n_jobs)
     int8_t* p5 = A.phs5 + J.out_off;
     int8_t* p3 = A.phs3 + J.out_off;
     const int16_t* s5 = A.sig5 + J.out_off;
-    const int16_t* s3 = A.sig3 + J.out_off;
+    int16_t* s3 = A.sig3 + J.out_off;
     const uint8_t* cn = A.cano + J.out_off;
+    const int32_t* sb = A.sb ? A.sb + J.out_off : nullptr;
+    int sigB = 0, posB = -1;                             // the branch-point carry (src/codepot.cc:567-568, 586-597)
     for (int i = 0; i < N; ++i) { p5[i] = -2; p3[i] = -2; }
     const int th5 = (int16_t) (int) (M.fS * M.tonic5), th3 = (int16_t) (int) (M.fS * M.tonic3);
     for (int pos = J.left; pos < J.right; ++pos) {
         const int c5 = cn[pos] & 15, c3 = cn[pos] >> 4;
+        if (sb) {
+            s3[pos] = (int16_t) (s3[pos] + sigB);
+            if (sb[pos] != INT32_MIN) { sigB = sb[pos]; posB = pos; }
+            if (posB >= 0 && pos - posB > M.maxb3d) { sigB = 0; posB = -1; }
+        }
         if (p5[pos] == -2 && ((M.any == 2 && s5[pos] > th5) || c5)) {
             p5[pos] = 0;
             if (c5 > 1) { p5[pos + 1] = 1; if (pos >= 1) p5[pos - 1] = (p5[pos - 1] == 1) ? 2 : -1; }      // GTGT

@@ -38,3 +38,19 @@ def test_signals_h_equal_reference(path):
 
 def test_fixture_count():
     assert len(FILES) >= 34
+
+
+def test_branch_point_term_is_exercised():
+    """h1_branch*: `ref_dump -b` (-yB) switches the branch-point matrix on; the acceptor signal then differs from the plain one
+    at hundreds of positions, and the reach limit (-yD) matters"""
+    fa, fb = (spdg.load([f for f in golden_files("h1_branch") if f.endswith(n + ".spdg")][0]) for n in ("h1_branch", "h1_branch_d20"))
+    md = signals_h.model_of(fa)
+    assert md["pmB"].present and md["fB"] > 0
+    q = fa["prm"]
+    b_len = len(fa["b_codes"]) - 1
+    with_b = signals_h.splice_signals_h(md, fa["b_codes"], b_len, max(0, q["b_left"]), q["b_right"])["sig3"]
+    md0 = dict(md)
+    md0["pmB"] = signals_h.PatMat([0, 0, 0, 0, 0], fa["pmB_f32"][:2])
+    without = signals_h.splice_signals_h(md0, fa["b_codes"], b_len, max(0, q["b_left"]), q["b_right"])["sig3"]
+    assert int(np.count_nonzero(with_b != without)) > 200
+    assert int(np.count_nonzero(np.asarray(fa["sig3"]) != np.asarray(fb["sig3"]))) > 100

@@ -205,8 +205,8 @@ def protein_cases():
     # the branch-point term of the acceptor signal (-yB / -yD; Exinon::intron53_p, src/codepot.cc:586-597): the default
     # Branch matrix of the table directory, a weight that moves sig3 by tens of units, two reach limits
     g = pgene(12, n_exons=5, aa_len=260, flank=300, intron_hi=900)
-    c["h1_branch"] = (g.window, g.query, ["-b", "2.0", "-u", "1,2"])
-    c["h1_branch_d20"] = (g.window, g.query, ["-b", "5.0", "-D", "20", "-u", "1"])
+    c["hb_branch"] = (g.window, g.query, ["-b", "2.0", "-u", "1,2"])
+    c["hb_branch_d20"] = (g.window, g.query, ["-b", "5.0", "-D", "20", "-u", "1"])
     # ambiguous bases at junctions: an N two before a donor / one behind an acceptor leaves ONE of the two codons an
     # intron can split defined (SpJunc::spjseq with spj_amb_tron_tab / spj_tron_amb_tab, src/codepot.cc:79-107)
     for k in range(2):

@@ -236,3 +236,37 @@ def test_record_budget_retry_and_groups(eng, monkeypatch):
         again = [(s, skl.tolist(), f) for s, skl, f in eng.align_h(sc, ps)]
         monkeypatch.delenv("SPDP_VMF_GB")
         assert want == again, sel
+
+
+@pytest.mark.parametrize("engine_kind", ["a0", "a1"])
+def test_ambiguous_bases_against_oracle(eng, engine_kind):
+    """tron codes turned into AMB at random (1 - 3 % of the window; signals kept): the codon an intron splits is then
+    often half-defined, and the engines must price it as SpJunc::spjseq does -- a codon stands when its own three bases
+    do (the oracle's rule is pinned to the reference's function, tests/test_oracle_spjseq.py)"""
+    from oracle import oracle
+    rng = np.random.default_rng(4242)
+    names = ("h1_basic", "h1_400aa", "h1_divergent", "h1_frameshift", "h1_query_indel", "h1_amb_junction0")
+    cases = [spdg.load([f for f in H_FILES if _name(f) == n][0]) for n in names]
+    sc = spdg.scoring_h(max(cases, key=lambda fx: fx["intpen"].size))
+    ps = abi.ProblemSetH()
+    for fx in cases:
+        for frac in (0.01, 0.03):
+            fx2 = dict(fx)
+            b = np.array(fx["b_codes"], dtype=np.uint8)
+            hit = rng.random(b.size) < frac
+            b[hit] = 2                                            # AMB
+            fx2["b_codes"] = b
+            spdg.problem_h(fx2, ps)
+    sc.scalar_engines = 1 if engine_kind == "a0" else 2
+    got = eng.scalar_forward_h(sc, ps)
+    n_cmp = 0
+    for p, (s, skl) in zip(ps.items, got):
+        if engine_kind == "a0":
+            ws, wskl = oracle.scalar_forward_h(sc, p)
+        else:
+            ws, wskl, flag = oracle.exact_forward_h(sc, p)
+            if flag:
+                continue
+        assert s == ws and skl.ravel().tolist() == np.asarray(wskl).ravel().tolist()
+        n_cmp += 1
+    assert n_cmp >= 8

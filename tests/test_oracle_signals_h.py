@@ -20,7 +20,7 @@ def stale_mask(b_len, left, right):
     return ok
 
 
-FILES = [f for pre in ("h1_", "c1_") for f in golden_files(pre) if "pm5_hdr" in spdg.load(f)]
+FILES = [f for pre in ("h1_", "c1_", "hb_") for f in golden_files(pre) if "pm5_hdr" in spdg.load(f)]   # hb_: branch-point term on (own intron-penalty table: not batched with h1_)
 
 
 @pytest.mark.parametrize("path", FILES, ids=[f.split("/")[-1][:-5] for f in FILES])
@@ -41,9 +41,9 @@ def test_fixture_count():
 
 
 def test_branch_point_term_is_exercised():
-    """h1_branch*: `ref_dump -b` (-yB) switches the branch-point matrix on; the acceptor signal then differs from the plain one
+    """hb_branch*: `ref_dump -b` (-yB) switches the branch-point matrix on; the acceptor signal then differs from the plain one
     at hundreds of positions, and the reach limit (-yD) matters"""
-    fa, fb = (spdg.load([f for f in golden_files("h1_branch") if f.endswith(n + ".spdg")][0]) for n in ("h1_branch", "h1_branch_d20"))
+    fa, fb = (spdg.load([f for f in golden_files("hb_branch") if f.endswith(n + ".spdg")][0]) for n in ("hb_branch", "hb_branch_d20"))
     md = signals_h.model_of(fa)
     assert md["pmB"].present and md["fB"] > 0
     q = fa["prm"]

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, SPDH_MINBLK) void spdh_sweep(HSweepArgs A)
     __shared__ int   s_qlen[8], s_qpen[8];
     __shared__ int4  s_ring[4][4][64];
     __shared__ int2  s_feed[4][4][16];
+    __shared__ int2  s_out[4][4][17];           // bottom-row results of a block's steps (spdp_sweep_fp.hip: why not a DPP chain)
 
     const DevScoringH* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = Q16(sc->mtx[i]);      // q16
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(256, SPDH_MINBLK) void spdh_sweep(HSweepArgs A)
         q16 u4 = Q16(SPDH_NEV), u5 = Q16(SPDH_NEV), u6 = Q16(SPDH_NEV);          // upper row's H four, five, six steps ago
         q16 hiv0 = Q16(SPDH_NEV), hiv1 = Q16(SPDH_NEV), hiv2 = Q16(SPDH_NEV);    // best donor so far, by phase
         int hil0 = 0, hil1 = 0, hil2 = 0;                          // columns since that donor
-        int outH = 0, outF = 0;                                    // bottom-row results of the block
+        int2* const outb = &s_out[wv][g][0];
+        const bool is_bottom = k == ((j9 < SPDH_NELEM && j9 > 0) ? j8 : 15);     // (a partial last stripe: its last real row)
         // bitmap offset of my cell at step n_start (advances by m_width per step)
         int tb_off = (3 * (mp1 - a_left) + (n_start - b_left)) * m_width + (mp1 - a_left) + k;
 
@@ -434,16 +436,8 @@ __global__ __launch_bounds__(256, SPDH_MINBLK) void spdh_sweep(HSweepArgs A)
                     // ---- traceback code (the last stripe's lanes past a_right are masked, :308)
                     if (k < j9 && n <= n9) tb[tb_off] = (uint16_t) (hb | pb);
                     tb_off += m_width;
-                    // ---- bottom lane of the stripe -> output shift chain
-                    int bh = h, bf = ff;
-                    if constexpr (PARTIAL) {
-                        if (partial && j9 > 0) {
-                            const int src = (lane & 48) + j8;
-                            bh = __shfl(bh, src); bf = __shfl(bf, src);
-                        }
-                    }
-                    outH = row_shr1(row_ror1(bh), outH);
-                    outF = row_shr1(row_ror1(bf), outF);
+                    // ---- bottom lane of the stripe -> slot J of the row's output block (read back at the flush)
+                    if (is_bottom) outb[J] = make_int2(h, ff);
                     // keep the unrolled steps apart: interleaving them only inflates register pressure
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -454,7 +448,7 @@ __global__ __launch_bounds__(256, SPDH_MINBLK) void spdh_sweep(HSweepArgs A)
                     const int n = n0 + j;
                     const int r0 = n - 3 * mp1 - 6 * j8;
                     if (n <= n9 && n - b_left >= 3 * j9 && r0 >= lw && r0 <= up && j9 > 0)
-                        bnd[BIDX(r0)] = make_int2(outH >> 16, outF >> 16);
+                        { const int2 o = outb[j]; bnd[BIDX(r0)] = make_int2(o.x >> 16, o.y >> 16); }
                 }
             }
             // boundary entries are exchanged between the rows of this wave through memory: a load

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
     __shared__ int   s_qlen[8], s_qpen[8];
     __shared__ int4  s_ring[4][4][64];
     __shared__ int4  s_feed[4][4][16];
+    __shared__ int4  s_out[4][4][17];           // bottom-row results of a block's steps (spdp_sweep_fp.hip: why not a DPP chain)
 
     const DevScoringH* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = Q16(sc->mtx[i]);      // q16
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
         q16 hiv0 = Q16(SPDH_NEV), hiv1 = Q16(SPDH_NEV), hiv2 = Q16(SPDH_NEV);
         int hil0 = 0, hil1 = 0, hil2 = 0, hic0 = 0, hic1 = 0, hic2 = 0;
         int dr0 = n_start - 3 * mp1, dr1 = dr0, dr2 = dr0;                  // donor_r[], lane k8 only
-        int outH = 0, outF = 0, outC = 0, outFC = 0;
+        int4* const outb = &s_out[wv][g][0];
+        const bool is_bottom = k == ((j9 < SPDH_NELEM && j9 > 0) ? j8 : 15);     // (a partial last stripe: its last real row)
 
         int4 nx_b = make_int4(0, 0, 0, 0);
         int4 nx_c = make_int4(0, 0, 0, 0);
@@ -418,18 +420,8 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     f3 = f2; f2 = f1; f1 = ff;    fc3 = fc2; fc2 = fc1; fc1 = ffc;
                     e3 = e2; e2 = e1; e1 = ee;    ec3 = ec2; ec2 = ec1; ec1 = eec;
                     u6 = u5; u5 = u4; u4 = u3;    uc6 = uc5; uc5 = uc4; uc4 = uc3;
-                    // ---- bottom lane of the stripe -> output shift chain
-                    int bh = h, bf = ff, bc = hc, bfc = ffc;
-                    if constexpr (PARTIAL) {
-                        if (partial && j9 > 0) {
-                            const int src = (lane & 48) + j8;
-                            bh = __shfl(bh, src); bf = __shfl(bf, src); bc = __shfl(bc, src); bfc = __shfl(bfc, src);
-                        }
-                    }
-                    outH = row_shr1(row_ror1(bh), outH);
-                    outF = row_shr1(row_ror1(bf), outF);
-                    outC = row_shr1(row_ror1(bc), outC);
-                    outFC = row_shr1(row_ror1(bfc), outFC);
+                    // ---- bottom lane of the stripe -> slot J of the row's output block (read back at the flush)
+                    if (is_bottom) outb[J] = make_int4(h, ff, hc, ffc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 {
@@ -437,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void spdh_sweep_udh(HUdhArgs A)
                     const int n = n0 + j;
                     const int r0 = n - 3 * mp1 - 6 * j8;
                     if (n < n9 && n - b_left >= 3 * j9 && r0 >= lw && r0 <= up && j9 > 0)
-                        bnd[BIDX(r0)] = make_int4(outH >> 16, outF >> 16, outC, outFC);
+                        { const int4 o = outb[j]; bnd[BIDX(r0)] = make_int4(o.x >> 16, o.y >> 16, o.z, o.w); }
                 }
             }
             asm volatile("" ::: "memory");

@@ -142,6 +142,9 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
     // entries of the current block
     __shared__ int2 s_col[WPB][4][96];
     __shared__ int  s_feed[WPB][4][16 * BW];
+    // bottom-row results of a block's 16 steps: the bottom lane of a stripe writes slot J, lane 15 - j reads slot j at the
+    // flush (replaces a rotate + shift DPP pair per value and step: spdp_sweep_fp.hip has the measurements)
+    __shared__ int  s_out[WPB][4][16 * BW + BW];
 
     const DevScoring* __restrict__ sc = A.sc;
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) s_mtx[i] = sc->mtx[i];
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
         int hv2 = SPDP_NEV16, hil = 0;
         int Cs = 0, FCs = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
         int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
-        int outH = 0, outF = 0, outC = 0, outFC = 0;               // bottom-row results of the block
+        int* const outb = &s_out[threadIdx.x >> 6][g][0];
+        const bool is_bottom = k == max(j8, 0);                    // (a partial last stripe: its last real row)
         int2* const colring = &s_col[wv][g][0];
         int*  const feed = &s_feed[wv][g][0];
 
@@ -523,20 +527,10 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                                 }                                                                            \
                             }                                                                                \
                         }                                                                                    \
-                        /* bottom lane of the stripe -> output shift chain */                                \
-                        int bh = Hs, bf = Fs, bc = Cs, bfc = FCs;                                            \
-                        if constexpr (PARTIAL) {                                                             \
-                            if (j9 < SPDP_NELEM && j9 > 0) {                                                 \
-                                const int src = (lane & 48) + j8;                                            \
-                                bh = __shfl(Hs, src); bf = __shfl(Fs, src);                                  \
-                                if constexpr (FL == FL_UDH) { bc = __shfl(Cs, src); bfc = __shfl(FCs, src); } \
-                            }                                                                                \
-                        }                                                                                    \
-                        outH = row_shr1(row_ror1(bh), outH);                                                 \
-                        outF = row_shr1(row_ror1(bf), outF);                                                 \
-                        if constexpr (FL == FL_UDH) {                                                        \
-                            outC  = row_shr1(row_ror1(bc), outC);                                            \
-                            outFC = row_shr1(row_ror1(bfc), outFC);                                          \
+                        /* bottom lane of the stripe -> slot J of the row's output block */                  \
+                        if (is_bottom) {                                                                     \
+                            if constexpr (FL == FL_UDH) reinterpret_cast<int4*>(outb)[J] = make_int4(Hs, Fs, Cs, FCs); \
+                            else reinterpret_cast<int2*>(outb)[J] = make_int2(Hs, Fs);                       \
                         }                                                                                    \
                     }
                     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
@@ -550,9 +544,9 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep(SweepArgs A)
                         const int r0 = n - (ml + 1) - 2 * j8;
                         if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
                             if constexpr (FL == FL_UDH)
-                                st_b4<CROSS>(bnd + (int64_t) BIDX(r0) * 4, make_int4(outH, outF, outC, outFC));
+                                st_b4<CROSS>(bnd + (int64_t) BIDX(r0) * 4, reinterpret_cast<const int4*>(outb)[j]);
                             else
-                                st_b2<CROSS>(bnd + (int64_t) BIDX(r0) * 2, make_int2(outH, outF));
+                                st_b2<CROSS>(bnd + (int64_t) BIDX(r0) * 2, reinterpret_cast<const int2*>(outb)[j]);
                         }
                     }
                     if constexpr (FL == FL_FORWARD) {

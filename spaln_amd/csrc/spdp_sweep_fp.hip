@@ -152,6 +152,10 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
     __shared__ float2 s_sig[WPB][4][96];                // {sig5 + ipen, sig3}
     __shared__ int    s_bof[WPB][4][96];                // byte offset of the base's matrix column
     __shared__ int    s_feed[WPB][4][16 * BW + BW];
+    // bottom-row results of a block's 16 steps, written by the bottom lane of a stripe, read back by lane = step at the
+    // flush (a ds_write under a one-lane exec mask issues beside the VALU stream; the 64-bit DPP collectors it
+    // replaces were two of the six most expensive instructions of the step, and sixteen registers)
+    __shared__ int    s_out[WPB][4][16 * BW + BW];
     __shared__ int    s_prog_lds[WPB];
 
     const DevScoring* __restrict__ sc = A.sc;
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
         bool don_prev = false;
         int Cs = 0, FCm = 0, Cd = 0, ec = 0, hc2 = 0;              // UDH links
         int donor_r = 0, rlst = INT32_MAX;                         // UDH, lane k8 only
-        long long oa0 = 0, oa1 = 0, oa2 = 0, oa3 = 0;              // bottom-row {H, Fcand} of the block's steps
-        long long ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;              // ... {Hlink, Fcandlink}
+        int* const outb = &s_out[wv][g][0];
+        const bool is_bottom = k == max(j8, 0);                    // (a partial last stripe: its last real row)
         float2* const sigring = &s_sig[wv][g][0];
         int*    const bofring = &s_bof[wv][g][0];
         int*    const feed = &s_feed[wv][g][0];
@@ -358,11 +362,20 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
             // registers holding the NEXT block's boundary entry / column record of this lane
             int4 nx_b = make_int4(0, 0, 0, 0);
             int2 nx_c = make_int2(0, 0);
-            auto prefetch = [&](int lbn) {
-                const int nn = n_start + lbn * 16 + k;                  // sweep step this lane loads for
-                if constexpr (UDH) nx_b = ld_b4<CROSS>(bnd + (int64_t) BIDX(nn - ml) * 4);
-                else { const int2 v = ld_b2<CROSS>(bnd + (int64_t) BIDX(nn - ml) * 2); nx_b.x = v.x; nx_b.y = v.y; }
-                nx_c = cols[nn];                                        // raw record: no use here, the load must stay in flight
+            // a row's blocks are prefetched in order (block 0 once, then lb + 1 from block lb), so the two addresses and
+            // the flush address below are carried along, 16 entries per block, instead of being rebuilt from lb
+            const int* pf_b = bnd + (int64_t) BIDX(n_start + k - ml) * BW;    // sweep step n_start + 16 lbn + k of this lane
+            const int2* pf_c = cols + (n_start + k);
+            int* st_p = bnd + (int64_t) BIDX(n_start + k - (ml + 1) - 2 * j8) * BW;
+            // the reference's write condition (fwd2s1_wip_simd.h:205-209) as a range of the sweep step n0 + k
+            const int fl_lo = max(b_left + j9, lw + (ml + 1) + 2 * j8);
+            const int fl_hi = j9 > 0 ? min(up + (ml + 1) + 2 * j8 + 1, n_end) : INT32_MIN;
+            int lbm = 0;                                                // (16 lb) mod 48: where the block sits in the 48-slot rings
+            auto prefetch = [&](int) {
+                if constexpr (UDH) nx_b = ld_b4<CROSS>(pf_b);
+                else { const int2 v = ld_b2<CROSS>(pf_b); nx_b.x = v.x; nx_b.y = v.y; }
+                nx_c = *pf_c;                                           // raw record: no use here, the load must stay in flight
+                pf_b += 16 * BW; pf_c += 16;
             };
             // multi-wave: row 0 reads boundary entries of the previous pass, produced by wave `prod`;
             // local block lbn of row 0 needs its absolute blocks <= lbn + 15 flushed (3 rows x LAG + 3)
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                         if (nn <= b_left) bs = 0;
                         const float2 srec = make_float2((float) (short) sg, (float) (sg >> 16));
                         const int bof = s_perm[bs & 31] * 4;
-                        const int slot = (lb * 16 + k + 16) % 48;
+                        const int slot = lbm + k + 16 >= 48 ? lbm + k + 16 - 48 : lbm + k + 16;      // (16 lb + k + 16) mod 48
                         if constexpr (SPJ) { sigring[slot] = srec; sigring[slot + 48] = srec; }
                         bofring[slot] = bof; bofring[slot + 48] = bof;
                     }
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                     if (lb + 1 < nb) prefetch(lb + 1);
                     WAVE_ORDER();
                     // lane k reads column n0 + J - k at step J: one contiguous run of 16 ring slots
-                    const int myslot = (lb * 16 - k + 16 + 48) % 48;
+                    const int myslot = lbm - k + 16 == 48 ? 0 : lbm - k + 16;             // (16 lb - k + 16) mod 48
                     const float2* const mysig = sigring + myslot;
                     const int* const mybof = bofring + myslot;
                     // intermediate row (lane k8 of its stripe): the steps of this block whose cell lies on it inside the band,
@@ -522,45 +535,25 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                         const float fe = fin + gef;                                                          \
                         if constexpr (UDH) FCm = (fe > Hg) ? fl : hc;                                        \
                         Fm = fmaxf(fe, Hg);                                                                  \
-                        /* bottom lane of the stripe -> lanes of bank J / 4 of the collector J % 4 */        \
-                        {                                                                                    \
-                            long long pa = pack2(as_i(Hs), as_i(Fm)), pb = 0;                                \
-                            if constexpr (UDH) pb = pack2(Cs, FCm);                                          \
-                            if constexpr (PARTIAL) {                                                         \
-                                const int src = (lane & 48) + max(j8, 0);                                    \
-                                pa = pack2(__shfl(as_i(Hs), src), __shfl(as_i(Fm), src));                    \
-                                if constexpr (UDH) pb = pack2(__shfl(Cs, src), __shfl(FCm, src));            \
-                                if constexpr ((J & 3) == 0) { oa0 = bank_keep<(J >> 2)>(oa0, pa); if constexpr (UDH) ob0 = bank_keep<(J >> 2)>(ob0, pb); } \
-                                if constexpr ((J & 3) == 1) { oa1 = bank_keep<(J >> 2)>(oa1, pa); if constexpr (UDH) ob1 = bank_keep<(J >> 2)>(ob1, pb); } \
-                                if constexpr ((J & 3) == 2) { oa2 = bank_keep<(J >> 2)>(oa2, pa); if constexpr (UDH) ob2 = bank_keep<(J >> 2)>(ob2, pb); } \
-                                if constexpr ((J & 3) == 3) { oa3 = bank_keep<(J >> 2)>(oa3, pa); if constexpr (UDH) ob3 = bank_keep<(J >> 2)>(ob3, pb); } \
-                            } else {                                                                         \
-                                if constexpr ((J & 3) == 0) { oa0 = bank_from_15<(J >> 2)>(oa0, pa); if constexpr (UDH) ob0 = bank_from_15<(J >> 2)>(ob0, pb); } \
-                                if constexpr ((J & 3) == 1) { oa1 = bank_from_15<(J >> 2)>(oa1, pa); if constexpr (UDH) ob1 = bank_from_15<(J >> 2)>(ob1, pb); } \
-                                if constexpr ((J & 3) == 2) { oa2 = bank_from_15<(J >> 2)>(oa2, pa); if constexpr (UDH) ob2 = bank_from_15<(J >> 2)>(ob2, pb); } \
-                                if constexpr ((J & 3) == 3) { oa3 = bank_from_15<(J >> 2)>(oa3, pa); if constexpr (UDH) ob3 = bank_from_15<(J >> 2)>(ob3, pb); } \
-                            }                                                                                \
+                        /* bottom lane of the stripe -> slot J of the row's output block */                  \
+                        if (is_bottom) {                                                                     \
+                            if constexpr (UDH) reinterpret_cast<int4*>(outb)[J] = make_int4(as_i(Hs), as_i(Fm), Cs, FCm); \
+                            else reinterpret_cast<int2*>(outb)[J] = make_int2(as_i(Hs), as_i(Fm));           \
                         }                                                                                    \
                     }
                     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
                     STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
 #undef STEP
-                    // ---- flush: lane i holds the bottom-row result of step j = i in collector i % 4; it goes to the
-                    // boundary array under the reference's write condition (fwd2s1_wip_simd.h:205-209)
+                    // ---- flush: lane i takes the bottom-row result of step j = i; it goes to the boundary array under the
+                    // reference's write condition (fwd2s1_wip_simd.h:205-209)
                     {
-                        const int q = k & 3;
-                        const long long oa = (q == 0) ? oa0 : (q == 1) ? oa1 : (q == 2) ? oa2 : oa3;
-                        const int j = k;
-                        const int n = n0 + j;
-                        const int r0 = n - (ml + 1) - 2 * j8;
-                        if (n - b_left >= j9 && r0 >= lw && r0 <= up && n < n_end && j9 > 0) {
-                            if constexpr (UDH) {
-                                const long long ob = (q == 0) ? ob0 : (q == 1) ? ob1 : (q == 2) ? ob2 : ob3;
-                                st_b4<CROSS>(bnd + (int64_t) BIDX(r0) * 4,
-                                             make_int4((int) oa, (int) (oa >> 32), (int) ob, (int) (ob >> 32)));
-                            } else
-                                st_b2<CROSS>(bnd + (int64_t) BIDX(r0) * 2, make_int2((int) oa, (int) (oa >> 32)));
+                        const int n = n0 + k;
+                        if (n >= fl_lo && n < fl_hi) {
+                            if constexpr (UDH) st_b4<CROSS>(st_p, reinterpret_cast<const int4*>(outb)[k]);
+                            else st_b2<CROSS>(st_p, reinterpret_cast<const int2*>(outb)[k]);
                         }
+                        st_p += 16 * BW;
+                        lbm = lbm == 32 ? 0 : lbm + 16;
                     }
                 }
                 // boundary entries are exchanged between the rows of this wave through memory: a load issued after a

@@ -36,22 +36,23 @@ HBM_PEAK_GBS = 8000.0
 # VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
 # fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
 # profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
-# same kind of profile: fp32-issue UDH sweep 49.0 / 64 (profiles/r03_valu_pmc.txt: 4.807e11 over the six launches = three
-# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 69.6 / 64, protein sweep 152.3 / 64
+# same kind of profile: fp32-issue UDH sweep 45.0 / 64 (profiles/r03_valu_pmc.txt: 4.419e11 over the six launches = three
+# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 63.4 / 64 (7.406e10, same run; round 2: 69.6), protein sweep 152.3 / 64
 # (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 4.80703e11 / 3 / 2.0941e11, "forward": 2.7114e10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
+VALU_PER_CELL = {"udh": 4.41891e11 / 3 / 2.0941e11, "forward": 7.40618e10 / 3 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
                  "a0_udh": 1.2802e10 / 2.05e9}      # (--engines a0: profiles/r02_a0_sq_counters.txt)
 # HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
 # chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes, summed over the six launches of that run
-# (profiles/r03_hbm_traffic_pmc.txt; round 2: 2 x 24.9e6 + 89.2e6 KiB per launch, now 2 x 28.2e6 + 89.0e6).  FETCH_SIZE
+# (profiles/r03_hbm_traffic_pmc.txt; round 2: 2 x 24.9e6 + 89.2e6 KiB per launch, now 2 x 30.6e6 + 97.1e6; three profiles
+# of this round read 24.9 / 28.2 / 30.6 and 89.0 / 89.0 / 97.1 on unchanged traffic: L2 residency varies from box to box).  FETCH_SIZE
 # counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
 # the figure an upper bound for the 8-byte column-record reads.
-PMC_TRAFFIC_BYTES = int((2 * 169079991 + 533981514) * 1024 / 6)
+PMC_TRAFFIC_BYTES = int((2 * 183504024 + 582816383) * 1024 / 6)
 # one spdp_rowwave_udh<true> launch of the default --engines a0 workload (profiles/r02_a0_hbm_traffic_pmc.txt)
 PMC_TRAFFIC_BYTES_A0 = (2 * 10706788 + 37364177) * 1024
 # same for one spdh_sweep launch of the default c3 workload (profiles/r03_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((2 * 38293411 + 146561684) * 1024)
+PMC_TRAFFIC_BYTES_H = int((2 * 36231533 + 148415086) * 1024)
 
 
 def _cpu_align_one(item):

@@ -15,8 +15,9 @@
 //   * "no acceptor yet" (hil <= llmt) is folded into the intron-penalty table: an entry is {A, C} and
 //     the candidate is max(hv2 + sig3 + A, floor) + C with {A, C} = {-2^22, nevsel - floor} for the
 //     short lengths, which yields exactly `nevsel` there, as the reference's blend does;
-//   * the bottom row leaves the stripe through ONE 64-bit DPP per pair of values and step
-//     (row_newbcast:15 into the lanes of one bank), instead of a rotate + shift per value.
+//   * the bottom row leaves the stripe through LDS: its lane writes the step's {H, Fcand, links} into slot `step` of a
+//     16-entry block under a one-lane exec mask (a ds_write beside the VALU stream) and lane j reads slot j back at the
+//     flush (round 2 used one 64-bit row_newbcast DPP per pair of values and step; the int kernels a rotate + shift per value).
 //
 // Reference recurrence: src/fwd2s1_wip_simd.h:97-202 (score-only), :555-758 (linear space),
 // boundary set-up / end selection src/fwd2s1_simd.cc:163-262.  Geometry (16-row stripes = DPP rows, four
@@ -51,23 +52,6 @@ __device__ __forceinline__ int row_shr1(int old, int src)
     return __builtin_amdgcn_update_dpp(old, src, 0x111, 0xf, 0xf, false);
 }
 __device__ __forceinline__ float row_shr1(float old, float src) { return as_f(row_shr1(as_i(old), as_i(src))); }
-
-// the lanes of bank BANK (4 lanes) of every row <- lane 15 of that row; other lanes keep `old`
-template <int BANK>
-__device__ __forceinline__ long long bank_from_15(long long old, long long src)
-{
-    return __builtin_amdgcn_update_dpp(old, src, 0x15F, 0xf, 1 << BANK, false);
-}
-// the same with the value already in every lane (partial last stripe): identity quad_perm, bank-masked
-template <int BANK>
-__device__ __forceinline__ long long bank_keep(long long old, long long src)
-{
-    return __builtin_amdgcn_update_dpp(old, src, 0xE4, 0xf, 1 << BANK, false);
-}
-__device__ __forceinline__ long long pack2(int lo, int hi)
-{
-    return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
-}
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v2i_t __attribute__((ext_vector_type(2)));

@@ -48,6 +48,7 @@ extern "C" void ref_wilip_ctor(Wilip* self, const Seq** seqs, const PwdB* pwd, i
 bool	g_o12_mode = false;
 char	g_o12_prefix[256];
 int	g_seeded_q = 0;
+std::vector<int>	g_alg_list;
 bool		wilip_tap_on = false;
 std::vector<int>	wilip_tap_log;
 Wilip::Wilip(const Seq* seqs[], const PwdB* pwd, const int level)
@@ -161,6 +162,7 @@ const	char*	outfn = argv[ai + 2];
 	if (rng4[0] >= 0) { a->left = rng4[0]; a->right = rng4[1]; b->left = rng4[2]; b->right = rng4[3]; }
 	if (g_o12_mode) o12_begin();
 	g_seeded_q = seeded_q;
+	g_alg_list = alg_list;
 	if (a->isprotein()) return dump_protein(seqs, exg, udh_list, outfn);
 	b->inex.intr = algmode.lsg;
 	makeWlprms(prePwd((const Seq**) seqs));

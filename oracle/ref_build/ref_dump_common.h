@@ -88,6 +88,7 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 // sqpr.cc:853-985) for the -A0 and the -A2 alignment of the case instead of the -O4 text; the three files end up in the
 // fixture byte for byte.  (One process can do one or the other: ExonForm opens its files on its first call only.)
 extern int	g_seeded_q;			// -Q n: the seeded path (algmode.qck)
+extern std::vector<int>	g_alg_list;		// -A list: the engine selectors of the seeded runs (default 0, 2)
 extern bool	wilip_tap_on;			// the Wilip tap of ref_dump.cc
 extern std::vector<int>	wilip_tap_log;
 extern bool	g_o12_mode;

@@ -266,8 +266,9 @@ const	int	nq0 = IntronPrm.nquant;
 	    std::vector<SGPT6> sg0;
 	    for (int n = std::max(0, b->left - 1); n <= b->right + 1; ++n) sg0.push_back(*b->exin->score_p(n));
 	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
-	    static const int algs[2] = {0, 2};
-	    for (int k = 0; k < 2; ++k) {
+	    std::vector<int> algs = g_alg_list;
+	    if (algs.empty()) { algs.push_back(0); algs.push_back(2); }
+	    for (size_t k = 0; k < algs.size(); ++k) {
 const		int	alg = algs[k];
 		algmode.alg = alg;
 		restore();

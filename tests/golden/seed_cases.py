@@ -210,6 +210,20 @@ def cases_h():
         w, q, opts, _ = make_case_h(s)
         c[f"qh_{s:04d}"] = (w, q, opts)
     c.update(special_cases_h())
+    c.update({k: v for k, v in a1_cases().items() if k.startswith("qh_")})
+    return c
+
+
+def a1_cases():
+    """a few of the random cases once more with the -A1 engines (forwardS1 / hirschbergS1, forwardH1 / hirschbergH1)
+    behind the walk as well: ref_dump -A 0,1,2"""
+    c = {}
+    for s in FIXTURE_SEEDS[:5]:
+        w, q, opts, _ = make_case(s)
+        c[f"q_a1_{s:04d}"] = (w, q, opts + ["-A", "0,1,2"])
+    for s in FIXTURE_SEEDS_H[:5]:
+        w, q, opts, _ = make_case_h(s)
+        c[f"qh_a1_{s:04d}"] = (w, q, opts + ["-A", "0,1,2"])
     return c
 
 
@@ -219,4 +233,5 @@ def cases():
         w, q, opts, _ = make_case(s)
         c[f"q_{s:04d}"] = (w, q, opts)
     c.update(special_cases())
+    c.update({k: v for k, v in a1_cases().items() if k.startswith("q_")})
     return c

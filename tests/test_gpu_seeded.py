@@ -124,3 +124,15 @@ def test_seeded_ori3_equals_reference(eng, alg, eng_sel):
             assert o == int(fx[f"seed_rev_A{alg}"][0])
             assert scr == int(fx[f"seed_scr_A{alg}"][0])
             assert flat == fx[f"seed_skl_A{alg}"].tolist()
+
+
+@pytest.mark.parametrize("path", golden_files("q_a1_"), ids=[f.split("/")[-1][:-5] for f in golden_files("q_a1_")])
+def test_seeded_alignment_under_a1_equals_reference(eng, path):
+    """the -A1 engines (spdp_exact.hip) behind the walk: `ref_dump -Q -A 0,1,2` runs"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 1)
+    sc.scalar_engines = 2
+    res = eng.align_s_seeded(sc, sp, p._owner, [hsps if n else None], [lowest], [wl])
+    scr, flat = _flat(res[0])
+    assert scr == int(fx["seed_scr_A1"][0])
+    assert flat == fx["seed_skl_A1"].tolist()

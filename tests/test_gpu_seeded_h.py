@@ -7,6 +7,7 @@ import pytest
 from spaln_amd import abi, engine
 from tests import spdg
 from oracle import seeded
+from tests.conftest import golden_files
 from tests.test_oracle_seeded_h import seeded_inputs_h, QH, UNDEFINED
 
 pytestmark = pytest.mark.gpu
@@ -91,3 +92,15 @@ def test_fixtures_with_one_parameter_set_as_one_batch(eng, alg, eng_sel):
             scr, flat = _flat(r)
             assert scr == int(fx[f"seed_scr_A{alg}"][0])
             assert flat == fx[f"seed_skl_A{alg}"].tolist()
+
+
+@pytest.mark.parametrize("path", golden_files("qh_a1_"), ids=[f.split("/")[-1][:-5] for f in golden_files("qh_a1_")])
+def test_seeded_alignment_under_a1_equals_reference(eng, path):
+    """the protein -A1 engines (spdp_h_exact.hip) behind the walk: `ref_dump -Q -A 0,1,2` runs"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 1)
+    sc.scalar_engines = 2
+    res = eng.align_h_seeded(sc, sp, p._owner, [hsps if n else None], [lowest], [wl])
+    scr, flat = _flat(res[0])
+    assert scr == int(fx["seed_scr_A1"][0])
+    assert flat == fx["seed_skl_A1"].tolist()

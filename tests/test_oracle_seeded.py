@@ -98,3 +98,17 @@ def test_annotated_intron_positions_enter_the_junction_rule():
     assert seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2)[0] == int(fx["seed_scr_A2"][0])
     p.cip = None
     assert seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 2)[0] == int(fx["seed_scr_A2"][0]) - 500
+
+
+A1 = [f for f in golden_files("q_a1_")]
+
+
+@pytest.mark.parametrize("path", A1, ids=[f.split("/")[-1][:-5] for f in A1])
+def test_seeded_alignment_under_a1_equals_reference(path):
+    """the same walk with the -A1 engines (forwardS1 / hirschbergS1) behind its DP calls: `ref_dump -Q -A 0,1,2` runs"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 1)
+    scr, flat, rc = seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 1)
+    assert rc == 0
+    assert scr == int(fx["seed_scr_A1"][0])
+    assert (flat or []) == fx["seed_skl_A1"].tolist()

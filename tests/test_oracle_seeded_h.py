@@ -68,3 +68,20 @@ def test_dp_calls_are_made():
         seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 0, trace=tr)
         kinds |= {(kind, bool(a[11])) for kind, a, _ in tr}
     assert {(0, False), (1, True), (2, False), (3, False)} <= kinds
+
+
+QH_A1 = golden_files("qh_a1_")
+
+
+@pytest.mark.parametrize("path", QH_A1, ids=[f.split("/")[-1][:-5] for f in QH_A1])
+def test_seeded_alignment_under_a1_equals_reference(path):
+    """the protein walk with the -A1 engines (forwardH1 / hirschbergH1) behind its DP calls: `ref_dump -Q -A 0,1,2` runs"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 1)
+    try:
+        scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 1)
+    except hh.ReferenceUndefined:
+        pytest.skip("the reference's own -A1 traceback is undefined on a DP call of this case")
+    assert rc == 0
+    assert scr == int(fx["seed_scr_A1"][0])
+    assert (flat or []) == fx["seed_skl_A1"].tolist()

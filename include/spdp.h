@@ -268,12 +268,14 @@ typedef struct SpdpSeedParams {
 } SpdpSeedParams;
 /* Wilip(seqs, pwd, level) (src/wln.cc:980) for the recursion levels above the one the caller's HSPs come from: the HSP
  * search stays with the caller (the reference's wln.cc in an integration).  units() is called from the walks' threads
- * (concurrently for different queries) with the active sub-ranges {a_left, a_right, b_left, b_right}; it returns 0 and
+ * (concurrently for different queries) with span = {a_left, a_right, b_left, b_right, a_exgl, a_exgr, b_exgl, b_exgr}: the active
+ * sub-ranges AND the end flags the walk holds at that moment -- Wlp scores an HSP with an end bonus that depends on
+ * a->inex.exgl / exgr (src/wln.cc:378-382, 438-443), so a binding sets both before it constructs Wilip; it returns 0 and
  * a flat record in *flat: n_units, then per unit {num, nid, tlen, llmt, ulmt, scr} followed by num + 1 JUXT records of
  * five ints each (the slot behind the last HSP included, as WLUNIT::jxt has it).  release() hands the record back. */
 typedef struct SpdpHspSource {
     void* user;
-    int  (*units)(void* user, int32_t query, int32_t level, const int32_t span[4], const int32_t** flat, int32_t* n_flat);
+    int  (*units)(void* user, int32_t query, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat);
     void (*release)(void* user, int32_t query, const int32_t* flat);
 } SpdpHspSource;
 /* alignS_ng(seqs, pwd, gsi, ori = 1) with seeding on.  hsps[i] / n_hsps[i]: b->jxt / b->CdsNo of query i (hsps[i] holds

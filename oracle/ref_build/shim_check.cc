@@ -8,7 +8,9 @@
 // -A2, then the *_gpu replacements below -- which see nothing but the reference's objects -- and
 // compares scores and SKL corner lists.  Exit status 0 = identical.
 //
-// usage: shim_check genome.fa query.fa      (cDNA / EST or protein query; -Q0 semantics)
+// usage: shim_check [-Q n] genome.fa query.fa      (cDNA / EST or protein query; -Q0 semantics)
+//   -Q n (cDNA): algmode.qck = n -- the seeded path.  The reference's own geneorient() finds the HSPs and its own Wilip
+//   answers the recursion levels through SpdpHspSource; alignS_ng of the reference against spdp_align_s_seeded.
 
 #include "ref_dump_common.h"
 #include "spdp.h"
@@ -126,6 +128,175 @@ const	int rc = spdp_align_h(g_ctx, &sc, &p, 1, &al);
 	return skl;
 }
 
+// ---- the seeded path (-Q5 .. -Q7): globalS_ng with algmode.qck != 0 ------------------------------------------------
+// What a maintainer adds beside alignS_gpu: the exact-model inputs the walk prices its joins with, the parameters of
+// SpdpSeedParams from the globals they live in, b->jxt as the HSP list, and the reference's own Wilip behind the
+// SpdpHspSource callback (called from the walk's thread; one query here, so the shared Seq ranges are safe to move).
+struct SeedCols { std::vector<int16_t> s5, s3, ip; std::vector<uint8_t> c5, c3, dc; std::vector<int8_t> p5, p3; std::vector<int32_t> flat; };
+struct SeedSrc { Seq** seqs; const PwdB* pwd; SeedCols* cols; };
+
+static int wilip_units(void* user, int32_t, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
+{
+	SeedSrc* S = (SeedSrc*) user;
+	Seq*	a = S->seqs[0];
+	Seq*	b = S->seqs[1];
+const	RANGE	ra = {a->left, a->right}, rb = {b->left, b->right};
+const	INEX	ia = a->inex, ib = b->inex;
+	a->left = span[0]; a->right = span[1]; b->left = span[2]; b->right = span[3];
+	a->inex.exgl = span[4]; a->inex.exgr = span[5]; b->inex.exgl = span[6]; b->inex.exgr = span[7];	// (Wlp's end bonus reads them)
+	Wilip	wl((const Seq**) S->seqs, S->pwd, level);		// src/wln.cc:980
+	std::vector<int32_t>& L = S->cols->flat;
+	L.clear();
+const	WLUNIT*	wlu = wl.begin();
+const	int	nw = wlu? wl.size(): 0;
+	L.push_back(nw);
+	for (int u = 0; u < nw; ++u) {
+const	    WLUNIT& x = wlu[u];
+const	    int uh[6] = {x.num, x.nid, x.tlen, x.llmt, x.ulmt, (int) x.scr};
+	    L.insert(L.end(), uh, uh + 6);
+	    for (int j = 0; j <= x.num; ++j) {		// num HSPs + the slot behind them
+const		JUXT& t = x.jxt[j];
+const		int jr[5] = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		L.insert(L.end(), jr, jr + 5);
+	    }
+	}
+	a->left = ra.left; a->right = ra.right; b->left = rb.left; b->right = rb.right;
+	a->inex = ia; b->inex = ib;
+	*flat = L.data(); *n_flat = (int32_t) L.size();
+	return 0;
+}
+
+static SKL* alignS_seeded_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi) {	// == alignS_ng(.., ori = 1), -Q5 .. -Q7
+	Seq*	a = seqs[0];
+	Seq*	b = seqs[1];
+	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  SpdpAlignment al;  SeedCols c;
+	fill_scoring(sc, pwd, b);  fill_problem(p, a, b, s5, s3);
+	// exact intron-length penalties and the junction table (IntronPenalty::Penalty, Exinon::sig53(.., IE53))
+	c.ip.resize(b->len + 2);
+	for (int l = 0; l < (int) c.ip.size(); ++l) c.ip[l] = pwd->IntPen->Penalty(l);
+	sc.intpen = c.ip.data();  sc.intpen_len = (int) c.ip.size();
+	c.c5.assign(b->len + 3, 0); c.c3.assign(b->len + 3, 0); c.dc.assign(b->len + 3, 0);
+	c.p5.assign(b->len + 3, -2); c.p3.assign(b->len + 3, -2);
+	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
+	int	nc = 1;
+	for (int i = b->left; i < b->right; ++i) {		// the dinucleotide classes of Exinon::intron53_c
+	    int ch = ncredctab[*b->at(i)];
+	    if (ch >= 4) ch = 1;
+	    nc = ((nc << 2) + ch) & 0xf;
+	    if (i - 1 >= 0) d5[i - 1] = nc;
+	    d3[i + 1] = nc;
+	}
+	int	mrep[16], nrep[16];
+	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
+	for (int n = b->left; n <= b->right; ++n) {
+const	    SGPT2* g = b->exin->score_n(n);
+	    c.p5[n] = g->phs5; c.p3[n] = g->phs3;
+	    c.c5[n] = b->exin->isDonor(n); c.c3[n] = b->exin->isAccpt(n);
+	    c.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
+	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
+	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	}
+	for (int u = 0; u < 16; ++u)
+	    for (int v = 0; v < 16; ++v)
+		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
+		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_n(nrep[v])->sig3): 0;
+	p.cano5 = c.c5.data(); p.cano3 = c.c3.data(); p.dinc = c.dc.data(); p.phs5 = c.p5.data(); p.phs3 = c.p3.data();
+	p.exin_left = b->left; p.exin_right = b->right;
+	SpdpSeedParams sp;
+	memset(&sp, 0, sizeof sp);
+	sp.qck = algmode.qck;
+	for (int l = 0; l < 4; ++l) sp.wl_width[l] = setwlprm(l)->width;
+	sp.elmt = IntronPrm.elmt; sp.minl = IntronPrm.minl; sp.vthr = (int) pwd->Vthr; sp.desert = alprm2.desert;
+	sp.maxsp = alprm.maxsp; sp.crs = algmode.crs; sp.smn4 = getsmn(4); sp.w2 = alprm2.w;
+	sp.gc_sig5 = b->exin->gc_sig5; sp.lcl = algmode.lcl; sp.codonk1 = pwd->codonk1;
+	sp.any = algmode.any; sp.both_ori = 0;
+	std::vector<SpdpJuxt> jx;
+	for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {		// CdsNo HSPs + the free slot behind them
+const	    JUXT& t = b->jxt[j];
+	    SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+	    jx.push_back(q);
+	}
+const	SpdpJuxt* lists[1] = {jx.empty()? 0: jx.data()};
+const	int32_t	counts[1] = {b->jxt? b->CdsNo: 0};
+const	int32_t	lowest[1] = {b->wllvl};
+	SeedSrc	ss = {seqs, pwd, &c};
+	SpdpHspSource src = {&ss, wilip_units, 0};
+const	int rc = spdp_align_s_seeded(g_ctx, &sc, &sp, &p, 1, lists, counts, lowest, &src, &al);
+	if (rc != 0) fatal("spdp_align_s_seeded: %s\n", spdp_last_error(g_ctx));
+	gsi->scr = al.score;
+	if (!al.n_skl) return 0;
+	SKL* skl = new SKL[al.n_skl + 1];
+	memcpy(skl, al.skl, sizeof(SKL) * al.n_skl);
+	skl[al.n_skl].m = skl[al.n_skl].n = EOS;
+	spdp_free_alignments(&al, 1);
+	return skl;
+}
+
+static SKL* alignH_seeded_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int exin_left, int exin_right) {	// == alignH_ng, -Q5 .. -Q7
+	Seq*	a = seqs[0];
+	Seq*	b = seqs[1];
+	SpdpScoringH sc;  SpdpProblemH p;  HCols c;  SpdpAlignment al;  SeedCols sx;
+	fill_scoring_h(sc, pwd, b);  fill_problem_h(p, a, b, c, exin_left, exin_right);
+	p.a_pad = *a->at(a->len);			// what exg_seq left behind the query
+	// the exact-model inputs the walk prices its joins with (and the scalar engine behind its small DP calls)
+	sx.ip.resize(b->len + 2);
+	for (int l = 0; l < (int) sx.ip.size(); ++l) sx.ip[l] = pwd->IntPen->Penalty(l);
+	sc.intpen = sx.ip.data();  sc.intpen_len = (int) sx.ip.size();
+	sc.lgop = pwd->LongGOP; sc.gape1 = pwd->GapE1; sc.gape2 = pwd->GapE2; sc.extragop = pwd->ExtraGOP;
+	sc.diffu = pwd->diffu; sc.k1 = alprm.k1; sc.minl = IntronPrm.minl;
+	sx.dc.assign(b->len + 3, 0);
+	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
+	int	nc = 1;
+	for (int i = b->left; i < b->right; ++i) {		// intron53_c on the tron sequence
+	    int ch = tnredctab[*b->at(i)];
+	    if (ch >= 4) ch = 1;
+	    nc = ((nc << 2) + ch) & 0xf;
+	    if (i - 1 >= 0) d5[i - 1] = nc;
+	    d3[i + 1] = nc;
+	}
+	int	mrep[16], nrep[16];
+	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
+	for (int n = b->left; n <= b->right; ++n) {
+	    sx.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
+	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
+	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	}
+	for (int u = 0; u < 16; ++u)
+	    for (int v = 0; v < 16; ++v)
+		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
+		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_p(nrep[v])->sig3): 0;
+	p.dinc = sx.dc.data();
+	SpdpSeedParams sp;
+	memset(&sp, 0, sizeof sp);
+	sp.qck = algmode.qck;
+	for (int l = 0; l < 4; ++l) sp.wl_width[l] = setwlprm(l)->width;
+	sp.elmt = IntronPrm.elmt; sp.minl = IntronPrm.minl; sp.vthr = (int) pwd->Vthr; sp.desert = alprm2.desert;
+	sp.maxsp = alprm.maxsp; sp.crs = algmode.crs; sp.smn4 = getsmn(4); sp.w2 = alprm2.w;
+	sp.gc_sig5 = b->exin->gc_sig5; sp.lcl = algmode.lcl; sp.codonk1 = pwd->codonk1;
+	sp.any = algmode.any; sp.both_ori = 0; sp.ip_maxl = IntronPrm.maxl; sp.ip_mode = IntronPrm.mode;
+	std::vector<SpdpJuxt> jx;
+	for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {
+const	    JUXT& t = b->jxt[j];
+	    SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+	    jx.push_back(q);
+	}
+const	SpdpJuxt* lists[1] = {jx.empty()? 0: jx.data()};
+const	int32_t	counts[1] = {b->jxt? b->CdsNo: 0};
+const	int32_t	lowest[1] = {b->wllvl};
+	SeedSrc	ss = {seqs, pwd, &sx};
+	SpdpHspSource src = {&ss, wilip_units, 0};
+const	int rc = spdp_align_h_seeded(g_ctx, &sc, &sp, &p, 1, lists, counts, lowest, &src, &al);
+	if (rc < 0) fatal("spdp_align_h_seeded: %s\n", spdp_last_error(g_ctx));
+	if (rc == 1) return (SKL*) -1;			// a DP call the reference itself leaves undefined: not comparable
+	gsi->scr = al.score;
+	if (!al.n_skl) return 0;
+	SKL* skl = new SKL[al.n_skl + 1];
+	memcpy(skl, al.skl, sizeof(SKL) * al.n_skl);
+	skl[al.n_skl].m = skl[al.n_skl].n = EOS;
+	spdp_free_alignments(&al, 1);
+	return skl;
+}
+
 // ======================================================================================
 // driver: reference vs shim on one pair
 // ======================================================================================
@@ -148,7 +319,9 @@ static void print_skl(const char* tag, const SKL* s)
 
 int main(int argc, const char** argv)
 {
-	if (argc != 3) { fprintf(stderr, "usage: shim_check genome.fa query.fa\n"); return 2; }
+	int	seeded_q = 0;
+	if (argc == 5 && !strcmp(argv[1], "-Q")) { seeded_q = atoi(argv[2]) & 3; argv += 2; argc -= 2; }
+	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] genome.fa query.fa\n"); return 2; }
 	g_ctx = spdp_create(0);
 	if (!g_ctx) { fprintf(stderr, "shim_check: no HIP device\n"); return 3; }
 const	char*	files[2] = {argv[1], argv[2]};
@@ -173,9 +346,11 @@ const	bool	protein = a->isprotein();
 	makeStdSig53();
 	a->inex.intr = 0;
 	if (!protein) a->inex.ori = 1;
+	if (protein && seeded_q) b->comrev(seqs + 2);	// (match_2, spaln.cc:748-756: the other strand first, then both to tron codes)
 	if (protein) b->nuc2tron();
 const	int	exin_left = b->left, exin_right = b->right;
 	if (protein) b->exin = new Exinon(b, pwd, false);
+	if (protein && seeded_q) { seqs[2]->nuc2tron(); seqs[2]->exin = new Exinon(seqs[2], pwd, false); }
 	a->exg_seq(algmode.lcl & 4, algmode.lcl & 8);
 	b->exg_seq(algmode.lcl & 1, algmode.lcl & 2);
 	if (!protein) b->exin = new Exinon(b, pwd, false);
@@ -186,7 +361,34 @@ const	INEX	ia = a->inex, ib = b->inex;
 	    a->inex = ia; b->inex = ib;
 	};
 	bool	ok = true;
-	if (!protein) {
+	if (!protein && seeded_q) {
+	    // match_2's set-up for the seeded path (spaln.cc:742-776): the other strand beside this one, HSPs from geneorient()
+	    algmode.qck = seeded_q;
+	    Seq* const	b0 = b;
+	    b->comrev(seqs + 2);
+	    seqs[2]->exin = new Exinon(seqs[2], pwd, false);
+const	    int	np = geneorient(seqs, pwd);
+	    if (b != b0) { fprintf(stderr, "shim_check -Q: the reverse strand won geneorient()\n"); return 4; }
+	    // the walk edits the phase marks and the slot behind the HSP list: both runs start from the same state
+	    std::vector<SGPT2> sg0(b->right - b->left + 1);
+	    for (int n = b->left; n <= b->right; ++n) sg0[n - b->left] = *b->exin->score_n(n);
+	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
+	    Gsinfo	g_ref, g_gpu;
+	    g_ref.skl = alignS_ng(seqs, pwd, &g_ref, 1);
+	    restore();
+	    for (int n = b->left; n <= b->right; ++n) *b->exin->score_n(n) = sg0[n - b->left];
+	    if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
+	    g_gpu.skl = alignS_seeded_gpu(seqs, pwd, &g_gpu);
+	    ok = g_ref.scr == g_gpu.scr && same_skl(g_ref.skl, g_gpu.skl);
+	    int64_t st[6] = {0};
+	    spdp_seeded_stats(g_ctx, st, 6);
+	    printf("cDNA query %d nt, window %d nt, -Q%d: %d HSP(s) at level %d\nalignS score: reference %d, GPU %d\n"
+		   "device batches %d (lspS_ng calls %d, tracebacks %d), Wilip calls through the callback %d\n",
+		a->len, b->len, seeded_q + 4, np? b->CdsNo: 0, b->wllvl, (int) g_ref.scr, (int) g_gpu.scr,
+		(int) st[0], (int) st[1], (int) st[2], (int) st[4]);
+	    print_skl("reference SKL", g_ref.skl);
+	    print_skl("GPU       SKL", g_gpu.skl);
+	} else if (!protein) {
 	    VTYPE	h_ref = HomScoreS_ng((const Seq**) seqs, pwd);
 	    restore();
 	    VTYPE	h_gpu = HomScoreS_gpu((const Seq**) seqs, pwd);
@@ -198,6 +400,30 @@ const	INEX	ia = a->inex, ib = b->inex;
 	    ok = h_ref == h_gpu && g_ref.scr == g_gpu.scr && same_skl(g_ref.skl, g_gpu.skl);
 	    printf("cDNA query %d nt, window %d nt\nHomScoreS: reference %d, GPU %d\nalignS score: reference %d, GPU %d\n",
 		a->len, b->len, (int) h_ref, (int) h_gpu, (int) g_ref.scr, (int) g_gpu.scr);
+	    print_skl("reference SKL", g_ref.skl);
+	    print_skl("GPU       SKL", g_gpu.skl);
+	} else if (seeded_q) {
+	    algmode.qck = seeded_q;
+	    Seq* const	b0 = b;
+const	    int	np = geneorient(seqs, pwd);
+	    if (b != b0) { fprintf(stderr, "shim_check -Q: the reverse strand won geneorient()\n"); return 4; }
+	    std::vector<SGPT6> sg0;
+	    for (int n = std::max(0, b->left - 1); n <= b->right + 1; ++n) sg0.push_back(*b->exin->score_p(n));
+	    std::vector<JUXT> jx0(b->jxt, b->jxt + (b->jxt? b->CdsNo + 1: 0));
+	    Gsinfo	g_ref, g_gpu;
+	    g_ref.skl = alignH_ng((const Seq**) seqs, pwd, &g_ref);
+	    restore();
+	    for (int n = std::max(0, b->left - 1), i = 0; n <= b->right + 1; ++n, ++i) *b->exin->score_p(n) = sg0[i];
+	    if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
+	    g_gpu.skl = alignH_seeded_gpu(seqs, pwd, &g_gpu, exin_left, exin_right);
+	    if (g_gpu.skl == (SKL*) -1) { printf("a DP call of this case is undefined in the reference\n"); g_gpu.skl = 0; spdp_destroy(g_ctx); return 5; }
+	    ok = g_ref.scr == g_gpu.scr && same_skl(g_ref.skl, g_gpu.skl);
+	    int64_t st[6] = {0};
+	    spdp_seeded_stats(g_ctx, st, 6);
+	    printf("protein query %d aa, window %d nt, -Q%d: %d HSP(s) at level %d\nalignH score: reference %d, GPU %d\n"
+		   "device batches %d (lspH_ng calls %d, tracebacks %d, with a cut range %d), Wilip calls through the callback %d\n",
+		a->len, b->len, seeded_q + 4, np? b->CdsNo: 0, b->wllvl, (int) g_ref.scr, (int) g_gpu.scr,
+		(int) st[0], (int) st[1], (int) st[2], (int) st[3], (int) st[4]);
 	    print_skl("reference SKL", g_ref.skl);
 	    print_skl("GPU       SKL", g_gpu.skl);
 	} else {

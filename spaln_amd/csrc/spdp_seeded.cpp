@@ -52,7 +52,7 @@ struct DeviceBackend : DpBackend {
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
         if (!src || !src->units) return false;
-        const int32_t span[4] = {s.al, s.ar, s.bl, s.br};
+        const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
         const int32_t* flat = nullptr; int32_t n = 0;
         ++*n_wilip;
         if (src->units(src->user, query, level, span, &flat, &n) || !flat) return false;

@@ -17,11 +17,11 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "shim_check")
 TAB = os.path.join(ROOT, "oracle", "_ref", "table")
 
 
-def _run(tmp_path, window_ascii, query_ascii):
+def _run(tmp_path, window_ascii, query_ascii, opts=()):
     gf, qf = str(tmp_path / "g.fa"), str(tmp_path / "q.fa")
     synth.write_fasta(gf, "win", window_ascii)
     synth.write_fasta(qf, "qry", query_ascii)
-    r = subprocess.run([BIN, gf, qf], env=dict(os.environ, ALN_TAB=TAB), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([BIN, *opts, gf, qf], env=dict(os.environ, ALN_TAB=TAB), capture_output=True, text=True, timeout=300)
     return r.returncode, r.stdout + r.stderr
 
 
@@ -44,4 +44,37 @@ def test_protein_through_the_reference_side_shim(tmp_path, seed, kw):
     rng = np.random.default_rng(synth.SEED + 7100 + seed)
     g = synth.make_protein_gene(rng, **kw)
     rc, out = _run(tmp_path, g.window, g.query)
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("qck", [1, 2, 3])
+@pytest.mark.parametrize("seed,kw", [(11, dict(n_exons=5, mrna_len=900, flank=400, intron_hi=1500, sub=0.03, indel=0.005)),
+                                     (12, dict(n_exons=8, mrna_len=2000, flank=800, intron_hi=3000, sub=0.08, indel=0.01)),
+                                     (13, dict(n_exons=4, mrna_len=600, flank=300, intron_hi=800, sub=0.15, indel=0.02))])
+def test_seeded_path_through_the_reference_side_shim(tmp_path, seed, kw, qck):
+    """-Q5 .. -Q7 live: the reference's own geneorient() supplies the HSPs and its own Wilip answers the recursion levels
+    through SpdpHspSource; alignS_ng of the reference against spdp_align_s_seeded in one process"""
+    rng = np.random.default_rng(synth.SEED + 7200 + seed)
+    g = synth.make_gene(rng, **kw)
+    rc, out = _run(tmp_path, g.window, g.query, ("-Q", str(qck)))
+    if rc == 4:
+        pytest.skip("geneorient() preferred the reverse strand")
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("qck", [1, 2, 3])
+@pytest.mark.parametrize("seed,kw", [(21, dict(n_exons=4, aa_len=300, flank=400, intron_hi=900, sub=0.1)),
+                                     (22, dict(n_exons=6, aa_len=420, flank=500, intron_hi=1500, sub=0.25)),
+                                     (23, dict(n_exons=3, aa_len=180, flank=300, intron_hi=600, sub=0.05))])
+def test_protein_seeded_path_through_the_reference_side_shim(tmp_path, seed, kw, qck):
+    """the protein walk live: geneorient() and Wilip of the compiled reference behind spdp_align_h_seeded"""
+    rng = np.random.default_rng(synth.SEED + 7300 + seed)
+    g = synth.make_protein_gene(rng, **kw)
+    rc, out = _run(tmp_path, g.window, g.query, ("-Q", str(qck)))
+    if rc == 4:
+        pytest.skip("geneorient() preferred the reverse strand")
+    if rc == 5:
+        pytest.skip("a DP call of this case is undefined in the reference")
     assert rc == 0 and "IDENTICAL" in out, out[-1500:]

@@ -319,9 +319,20 @@ static void print_skl(const char* tag, const SKL* s)
 
 int main(int argc, const char** argv)
 {
-	int	seeded_q = 0;
-	if (argc == 5 && !strcmp(argv[1], "-Q")) { seeded_q = atoi(argv[2]) & 3; argv += 2; argc -= 2; }
-	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] genome.fa query.fa\n"); return 2; }
+	int	seeded_q = 0, crs = -1, local = 0;
+	long	vmfspace = 0;
+	while (argc > 3 && argv[1][0] == '-') {		// -Q n, -X crs, -L, -C, -V space: as ref_dump's options of the same name
+	    const char c = argv[1][1];
+	    if (c == 'L') { local = 1; ++argv; --argc; continue; }
+	    if (c == 'C') { local = 3; ++argv; --argc; continue; }
+	    if (argc < 5) break;
+	    if (c == 'Q') seeded_q = atoi(argv[2]) & 3;
+	    else if (c == 'X') crs = atoi(argv[2]);
+	    else if (c == 'V') vmfspace = atol(argv[2]);
+	    else break;
+	    argv += 2; argc -= 2;
+	}
+	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] [-X crs] [-L | -C] [-V space] genome.fa query.fa\n"); return 2; }
 	g_ctx = spdp_create(0);
 	if (!g_ctx) { fprintf(stderr, "shim_check: no HIP device\n"); return 3; }
 const	char*	files[2] = {argv[1], argv[2]};
@@ -330,6 +341,10 @@ const	char*	files[2] = {argv[1], argv[2]};
 	algmode.qck = 0;		// -Q0
 	algmode.blk = 0;
 	alprm.ls = 2;
+	if (local) algmode.lcl |= 16;
+	if (local == 3) algmode.lcl |= 32;
+	if (crs >= 0) algmode.crs = crs;
+	if (vmfspace) MaxVmfSpace = (int) vmfspace;
 	OutPrm.all_out = 1;
 	Seq*	seqs[4];
 	initseq(seqs, 4);
@@ -351,8 +366,11 @@ const	bool	protein = a->isprotein();
 const	int	exin_left = b->left, exin_right = b->right;
 	if (protein) b->exin = new Exinon(b, pwd, false);
 	if (protein && seeded_q) { seqs[2]->nuc2tron(); seqs[2]->exin = new Exinon(seqs[2], pwd, false); }
-	a->exg_seq(algmode.lcl & 4, algmode.lcl & 8);
-	b->exg_seq(algmode.lcl & 1, algmode.lcl & 2);
+	if (algmode.lcl & 16) { a->exg_seq(1, 1); b->exg_seq(1, 1); }
+	else {
+	    a->exg_seq(algmode.lcl & 4, algmode.lcl & 8);
+	    b->exg_seq(algmode.lcl & 1, algmode.lcl & 2);
+	}
 	if (!protein) b->exin = new Exinon(b, pwd, false);
 const	RANGE	ra = {a->left, a->right}, rb = {b->left, b->right};
 const	INEX	ia = a->inex, ib = b->inex;

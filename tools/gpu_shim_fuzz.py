@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""On an MI355X box: the seeded paths LIVE against the compiled reference, many random cases.
+
+oracle/_ref/shim_check -Q n runs the reference's geneorient() + alignS_ng / alignH_ng and, in the same process,
+spdp_align_s_seeded / spdp_align_h_seeded with the reference's own Wilip behind the HSP callback.
+No fixture in between: each case is one comparison of the product with the reference itself.
+
+    python tools/gpu_shim_fuzz.py 200 [first_seed] [h]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spaln_amd import synth  # noqa: E402
+from tests.golden.seed_cases import make_case, make_case_h  # noqa: E402
+
+BIN = os.path.join(ROOT, "oracle", "_ref", "shim_check")
+ENV = dict(os.environ, ALN_TAB=os.path.join(ROOT, "oracle", "_ref", "table"))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    protein = len(sys.argv) > 3 and sys.argv[3] == "h"
+    tally = {}
+    with tempfile.TemporaryDirectory() as td:
+        gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
+        for seed in range(first, first + n):
+            w, q, opts, desc = (make_case_h if protein else make_case)(seed)
+            keep, i = [], 0
+            while i < len(opts):                              # the options shim_check knows
+                if opts[i] in ("-Q", "-X", "-V"):
+                    keep += opts[i:i + 2]; i += 2
+                elif opts[i] in ("-L", "-C"):
+                    keep.append(opts[i]); i += 1
+                else:
+                    i += 2 if i + 1 < len(opts) and not opts[i + 1].startswith("-") else 1
+            synth.write_fasta(gf, "win", w)
+            synth.write_fasta(qf, "qry", q)
+            try:
+                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=120)
+                rc = r.returncode
+            except subprocess.TimeoutExpired:
+                rc = -9
+            key = {0: "identical", 1: "DIFFERENT", 4: "reverse strand", 5: "reference undefined", -9: "timeout"}.get(rc, f"rc {rc}")
+            if rc == 1 and "Unexpected dir" in r.stderr and "IDENTICAL" not in r.stdout and "DIFFERENT" not in r.stdout:
+                key = "reference fatal"                       # the reference's own fatal("Unexpected dir"), exit status 1
+            tally[key] = tally.get(key, 0) + 1
+            if key == "DIFFERENT" or key.startswith("rc"):
+                print(f"seed {seed}: {key} | {desc} {' '.join(keep)}\\n{(r.stdout + r.stderr)[-600:]}", flush=True)
+    print(tally)
+    return 1 if tally.get("DIFFERENT") else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -16,6 +16,7 @@
 #include "spdp.h"
 
 static SpdpContext* g_ctx = 0;
+static bool g_undefined = false;		// the library flagged the input as undefined in the reference (n_skl < 0)
 
 // ======================================================================================
 // The shim: ~80 lines a maintainer adds to sblib
@@ -56,16 +57,56 @@ const	    SGPT2* g = b->exin->score_n(n);
 	p.b_exgl = b->inex.exgl;  p.b_exgr = b->inex.exgr;
 }
 
+// the exact-model inputs (-A0 / -A1 engines, and the seeded walk's joins): IntronPenalty::Penalty(len) materialised, the
+// junction table behind Exinon::sig53(.., IE53), dinucleotide classes, site flags, splice-phase marks
+struct SeedCols { std::vector<int16_t> s5, s3, ip; std::vector<uint8_t> c5, c3, dc; std::vector<int8_t> p5, p3; std::vector<int32_t> flat; };
+static void fill_exact_s(SpdpScoring& sc, SpdpProblem& p, const Seq* b, const PwdB* pwd, SeedCols& c) {
+	c.ip.resize(b->len + 2);
+	for (int l = 0; l < (int) c.ip.size(); ++l) c.ip[l] = pwd->IntPen->Penalty(l);
+	sc.intpen = c.ip.data();  sc.intpen_len = (int) c.ip.size();
+	sc.minl = IntronPrm.minl;
+	sc.scalar_engines = algmode.alg == 0? 1: (algmode.alg == 1? 2: 0);
+	c.c5.assign(b->len + 3, 0); c.c3.assign(b->len + 3, 0); c.dc.assign(b->len + 3, 0);
+	c.p5.assign(b->len + 3, -2); c.p3.assign(b->len + 3, -2);
+	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
+	int	nc = 1;
+	for (int i = b->left; i < b->right; ++i) {		// the dinucleotide classes of Exinon::intron53_c
+	    int ch = ncredctab[*b->at(i)];
+	    if (ch >= 4) ch = 1;
+	    nc = ((nc << 2) + ch) & 0xf;
+	    if (i - 1 >= 0) d5[i - 1] = nc;
+	    d3[i + 1] = nc;
+	}
+	int	mrep[16], nrep[16];
+	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
+	for (int n = b->left; n <= b->right; ++n) {
+const	    SGPT2* g = b->exin->score_n(n);
+	    c.p5[n] = g->phs5; c.p3[n] = g->phs3;
+	    c.c5[n] = b->exin->isDonor(n); c.c3[n] = b->exin->isAccpt(n);
+	    c.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
+	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
+	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	}
+	for (int u = 0; u < 16; ++u)
+	    for (int v = 0; v < 16; ++v)
+		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
+		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_n(nrep[v])->sig3): 0;
+	p.cano5 = c.c5.data(); p.cano3 = c.c3.data(); p.dinc = c.dc.data(); p.phs5 = c.p5.data(); p.phs3 = c.p3.data();
+	p.exin_left = b->left; p.exin_right = b->right;
+}
+
 static VTYPE HomScoreS_gpu(const Seq* seqs[], const PwdB* pwd) {	// == HomScoreS_ng, -A2/-A3
-	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  int32_t scr;
+	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  int32_t scr;  SeedCols c;
 	fill_scoring(sc, pwd, seqs[1]);  fill_problem(p, seqs[0], seqs[1], s5, s3);
+	if (algmode.alg < 2) fill_exact_s(sc, p, seqs[1], pwd, c);	// -A0 / -A1: the exact intron-length engines
 	if (spdp_homscore_s(g_ctx, &sc, &p, 1, &scr)) fatal("%s\n", spdp_last_error(g_ctx));
 	return scr;
 }
 
 static SKL* alignS_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi) {	// == alignS_ng(.., ori = 1), -Q0/-Q4
-	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  SpdpAlignment al;
+	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  SpdpAlignment al;  SeedCols c;
 	fill_scoring(sc, pwd, seqs[1]);  fill_problem(p, seqs[0], seqs[1], s5, s3);
+	if (algmode.alg < 2) fill_exact_s(sc, p, seqs[1], pwd, c);
 	if (spdp_align_s(g_ctx, &sc, &p, 1, &al) < 0) fatal("%s\n", spdp_last_error(g_ctx));
 	gsi->scr = al.score;
 	if (!al.n_skl) return 0;			// "no alignment", as the reference
@@ -113,12 +154,49 @@ const	    SGPT6* g = b->exin->score_p(n);		// src/codepot.h:105
 	p.a_exgl = a->inex.exgl; p.a_exgr = a->inex.exgr; p.b_exgl = b->inex.exgl; p.b_exgr = b->inex.exgr;
 }
 
+static void fill_exact_h(SpdpScoringH& sc, SpdpProblemH& p, const Seq* b, const PwdB* pwd, SeedCols& sx) {
+	// the exact-model inputs the walk prices its joins with (and the scalar engine behind its small DP calls)
+	sx.ip.resize(b->len + 2);
+	for (int l = 0; l < (int) sx.ip.size(); ++l) sx.ip[l] = pwd->IntPen->Penalty(l);
+	sc.intpen = sx.ip.data();  sc.intpen_len = (int) sx.ip.size();
+	sc.lgop = pwd->LongGOP; sc.gape1 = pwd->GapE1; sc.gape2 = pwd->GapE2; sc.extragop = pwd->ExtraGOP;
+	sc.diffu = pwd->diffu; sc.k1 = alprm.k1; sc.minl = IntronPrm.minl;
+	sx.dc.assign(b->len + 3, 0);
+	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
+	int	nc = 1;
+	for (int i = b->left; i < b->right; ++i) {		// intron53_c on the tron sequence
+	    int ch = tnredctab[*b->at(i)];
+	    if (ch >= 4) ch = 1;
+	    nc = ((nc << 2) + ch) & 0xf;
+	    if (i - 1 >= 0) d5[i - 1] = nc;
+	    d3[i + 1] = nc;
+	}
+	int	mrep[16], nrep[16];
+	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
+	for (int n = b->left; n <= b->right; ++n) {
+	    sx.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
+	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
+	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
+	}
+	for (int u = 0; u < 16; ++u)
+	    for (int v = 0; v < 16; ++v)
+		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
+		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_p(nrep[v])->sig3): 0;
+	p.dinc = sx.dc.data();
+	sc.scalar_engines = algmode.alg == 0? 1: (algmode.alg == 1? 2: 0);
+}
+
 static SKL* alignH_gpu(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int exin_left, int exin_right) {	// == alignH_ng, -Q0/-Q4
-	SpdpScoringH sc;  SpdpProblemH p;  HCols c;  SpdpAlignment al;
+	SpdpScoringH sc;  SpdpProblemH p;  HCols c;  SpdpAlignment al;  SeedCols sx;
 	fill_scoring_h(sc, pwd, seqs[1]);  fill_problem_h(p, seqs[0], seqs[1], c, exin_left, exin_right);
+	p.a_pad = *seqs[0]->at(seqs[0]->len);
+	if (algmode.alg < 2) fill_exact_h(sc, p, seqs[1], pwd, sx);	// -A0 / -A1
 const	int rc = spdp_align_h(g_ctx, &sc, &p, 1, &al);
 	if (rc < 0) fatal("%s\n", spdp_last_error(g_ctx));
-	if (rc == 1 || al.n_skl < 0) return alignH_ng(seqs, pwd, gsi);	// engine not built / reference-undefined input
+	if (rc == 1 || al.n_skl < 0) {			// engine not built / reference-undefined input: a production shim falls
+	    g_undefined = true;				// back to the host here (the reference's result is garbage that differs
+	    return alignH_ng(seqs, pwd, gsi);		// from run to run on such inputs); the checker reports the case as such
+	}
 	gsi->scr = al.score;
 	if (!al.n_skl) return 0;
 	SKL* skl = new SKL[al.n_skl + 1];
@@ -132,7 +210,6 @@ const	int rc = spdp_align_h(g_ctx, &sc, &p, 1, &al);
 // What a maintainer adds beside alignS_gpu: the exact-model inputs the walk prices its joins with, the parameters of
 // SpdpSeedParams from the globals they live in, b->jxt as the HSP list, and the reference's own Wilip behind the
 // SpdpHspSource callback (called from the walk's thread; one query here, so the shared Seq ranges are safe to move).
-struct SeedCols { std::vector<int16_t> s5, s3, ip; std::vector<uint8_t> c5, c3, dc; std::vector<int8_t> p5, p3; std::vector<int32_t> flat; };
 struct SeedSrc { Seq** seqs; const PwdB* pwd; SeedCols* cols; };
 
 static int wilip_units(void* user, int32_t, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
@@ -171,37 +248,7 @@ static SKL* alignS_seeded_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi) {	// ==
 	Seq*	b = seqs[1];
 	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  SpdpAlignment al;  SeedCols c;
 	fill_scoring(sc, pwd, b);  fill_problem(p, a, b, s5, s3);
-	// exact intron-length penalties and the junction table (IntronPenalty::Penalty, Exinon::sig53(.., IE53))
-	c.ip.resize(b->len + 2);
-	for (int l = 0; l < (int) c.ip.size(); ++l) c.ip[l] = pwd->IntPen->Penalty(l);
-	sc.intpen = c.ip.data();  sc.intpen_len = (int) c.ip.size();
-	c.c5.assign(b->len + 3, 0); c.c3.assign(b->len + 3, 0); c.dc.assign(b->len + 3, 0);
-	c.p5.assign(b->len + 3, -2); c.p3.assign(b->len + 3, -2);
-	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
-	int	nc = 1;
-	for (int i = b->left; i < b->right; ++i) {		// the dinucleotide classes of Exinon::intron53_c
-	    int ch = ncredctab[*b->at(i)];
-	    if (ch >= 4) ch = 1;
-	    nc = ((nc << 2) + ch) & 0xf;
-	    if (i - 1 >= 0) d5[i - 1] = nc;
-	    d3[i + 1] = nc;
-	}
-	int	mrep[16], nrep[16];
-	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
-	for (int n = b->left; n <= b->right; ++n) {
-const	    SGPT2* g = b->exin->score_n(n);
-	    c.p5[n] = g->phs5; c.p3[n] = g->phs3;
-	    c.c5[n] = b->exin->isDonor(n); c.c3[n] = b->exin->isAccpt(n);
-	    c.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
-	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
-	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
-	}
-	for (int u = 0; u < 16; ++u)
-	    for (int v = 0; v < 16; ++v)
-		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
-		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_n(nrep[v])->sig3): 0;
-	p.cano5 = c.c5.data(); p.cano3 = c.c3.data(); p.dinc = c.dc.data(); p.phs5 = c.p5.data(); p.phs3 = c.p3.data();
-	p.exin_left = b->left; p.exin_right = b->right;
+	fill_exact_s(sc, p, b, pwd, c);
 	SpdpSeedParams sp;
 	memset(&sp, 0, sizeof sp);
 	sp.qck = algmode.qck;
@@ -238,34 +285,7 @@ static SKL* alignH_seeded_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int exi
 	SpdpScoringH sc;  SpdpProblemH p;  HCols c;  SpdpAlignment al;  SeedCols sx;
 	fill_scoring_h(sc, pwd, b);  fill_problem_h(p, a, b, c, exin_left, exin_right);
 	p.a_pad = *a->at(a->len);			// what exg_seq left behind the query
-	// the exact-model inputs the walk prices its joins with (and the scalar engine behind its small DP calls)
-	sx.ip.resize(b->len + 2);
-	for (int l = 0; l < (int) sx.ip.size(); ++l) sx.ip[l] = pwd->IntPen->Penalty(l);
-	sc.intpen = sx.ip.data();  sc.intpen_len = (int) sx.ip.size();
-	sc.lgop = pwd->LongGOP; sc.gape1 = pwd->GapE1; sc.gape2 = pwd->GapE2; sc.extragop = pwd->ExtraGOP;
-	sc.diffu = pwd->diffu; sc.k1 = alprm.k1; sc.minl = IntronPrm.minl;
-	sx.dc.assign(b->len + 3, 0);
-	std::vector<unsigned char> d5(b->len + 3, 0), d3(b->len + 3, 0);
-	int	nc = 1;
-	for (int i = b->left; i < b->right; ++i) {		// intron53_c on the tron sequence
-	    int ch = tnredctab[*b->at(i)];
-	    if (ch >= 4) ch = 1;
-	    nc = ((nc << 2) + ch) & 0xf;
-	    if (i - 1 >= 0) d5[i - 1] = nc;
-	    d3[i + 1] = nc;
-	}
-	int	mrep[16], nrep[16];
-	for (int u = 0; u < 16; ++u) mrep[u] = nrep[u] = -1;
-	for (int n = b->left; n <= b->right; ++n) {
-	    sx.dc[n] = (uint8_t) (d5[n] << 4 | d3[n]);
-	    if (n < b->right - 1 && mrep[d5[n]] < 0) mrep[d5[n]] = n;
-	    if (n >= b->left + 2 && nrep[d3[n]] < 0) nrep[d3[n]] = n;
-	}
-	for (int u = 0; u < 16; ++u)
-	    for (int v = 0; v < 16; ++v)
-		sc.t53[16 * u + v] = (mrep[u] >= 0 && nrep[v] >= 0)?
-		    (int16_t) (b->exin->sig53(mrep[u], nrep[v], IE53) - b->exin->score_p(nrep[v])->sig3): 0;
-	p.dinc = sx.dc.data();
+	fill_exact_h(sc, p, b, pwd, sx);
 	SpdpSeedParams sp;
 	memset(&sp, 0, sizeof sp);
 	sp.qck = algmode.qck;
@@ -319,7 +339,7 @@ static void print_skl(const char* tag, const SKL* s)
 
 int main(int argc, const char** argv)
 {
-	int	seeded_q = 0, crs = -1, local = 0;
+	int	seeded_q = 0, crs = -1, local = 0, alg = 2;
 	long	vmfspace = 0;
 	while (argc > 3 && argv[1][0] == '-') {		// -Q n, -X crs, -L, -C, -V space: as ref_dump's options of the same name
 	    const char c = argv[1][1];
@@ -329,10 +349,11 @@ int main(int argc, const char** argv)
 	    if (c == 'Q') seeded_q = atoi(argv[2]) & 3;
 	    else if (c == 'X') crs = atoi(argv[2]);
 	    else if (c == 'V') vmfspace = atol(argv[2]);
+	    else if (c == 'A') alg = atoi(argv[2]);
 	    else break;
 	    argv += 2; argc -= 2;
 	}
-	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] [-X crs] [-L | -C] [-V space] genome.fa query.fa\n"); return 2; }
+	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] [-A n] [-X crs] [-L | -C] [-V space] genome.fa query.fa\n"); return 2; }
 	g_ctx = spdp_create(0);
 	if (!g_ctx) { fprintf(stderr, "shim_check: no HIP device\n"); return 3; }
 const	char*	files[2] = {argv[1], argv[2]};
@@ -359,6 +380,8 @@ const	bool	protein = a->isprotein();
 	algmode.alg = 2;		// -A2: the `_wip` engines
 	PwdB*	pwd = new PwdB((const Seq**) seqs);
 	makeStdSig53();
+	algmode.alg = alg;		// -A0 / -A1 / -A2 / -A3 (the quantile table above needs alg > 1 at PwdB's construction)
+	if (alg == 3) IntronPrm.nquant = 1;
 	a->inex.intr = 0;
 	if (!protein) a->inex.ori = 1;
 	if (protein && seeded_q) b->comrev(seqs + 2);	// (match_2, spaln.cc:748-756: the other strand first, then both to tron codes)
@@ -449,6 +472,7 @@ const	    int	np = geneorient(seqs, pwd);
 	    g_ref.skl = alignH_ng((const Seq**) seqs, pwd, &g_ref);
 	    restore();
 	    g_gpu.skl = alignH_gpu((const Seq**) seqs, pwd, &g_gpu, exin_left, exin_right);
+	    if (g_undefined) { printf("the library reports this input as undefined in the reference\n"); spdp_destroy(g_ctx); return 5; }
 	    ok = g_ref.scr == g_gpu.scr && same_skl(g_ref.skl, g_gpu.skl);
 	    printf("protein query %d aa, window %d nt\nalignH score: reference %d, GPU %d\n",
 		a->len, b->len, (int) g_ref.scr, (int) g_gpu.scr);

@@ -5,7 +5,11 @@ oracle/_ref/shim_check -Q n runs the reference's geneorient() + alignS_ng / alig
 spdp_align_s_seeded / spdp_align_h_seeded with the reference's own Wilip behind the HSP callback.
 No fixture in between: each case is one comparison of the product with the reference itself.
 
-    python tools/gpu_shim_fuzz.py 200 [first_seed] [h]
+    python tools/gpu_shim_fuzz.py 200 [first_seed] [s | h | sp | hp]
+
+s / h: cDNA / protein queries through the seeded paths; sp / hp: the same cases without seeding (-Q0), the engine
+selector cycling through -A0 / -A1 / -A2 / -A3 -- HomScore*_ng and align*_ng of the reference against spdp_homscore_* /
+spdp_align_* for every engine family.
 """
 import os
 import subprocess
@@ -24,7 +28,8 @@ ENV = dict(os.environ, ALN_TAB=os.path.join(ROOT, "oracle", "_ref", "table"))
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    protein = len(sys.argv) > 3 and sys.argv[3] == "h"
+    mode = sys.argv[3] if len(sys.argv) > 3 else "s"
+    protein, plain = mode.startswith("h"), mode.endswith("p")
     tally = {}
     with tempfile.TemporaryDirectory() as td:
         gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
@@ -32,20 +37,25 @@ def main():
             w, q, opts, desc = (make_case_h if protein else make_case)(seed)
             keep, i = [], 0
             while i < len(opts):                              # the options shim_check knows
-                if opts[i] in ("-Q", "-X", "-V"):
+                if plain and opts[i] == "-Q":
+                    i += 2
+                elif opts[i] in ("-Q", "-X", "-V"):
                     keep += opts[i:i + 2]; i += 2
                 elif opts[i] in ("-L", "-C"):
                     keep.append(opts[i]); i += 1
                 else:
                     i += 2 if i + 1 < len(opts) and not opts[i + 1].startswith("-") else 1
+            if plain:
+                keep += ["-A", str(seed % 4)]
             synth.write_fasta(gf, "win", w)
             synth.write_fasta(qf, "qry", q)
             try:
-                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=120)
+                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=60)
                 rc = r.returncode
             except subprocess.TimeoutExpired:
                 rc = -9
-            key = {0: "identical", 1: "DIFFERENT", 4: "reverse strand", 5: "reference undefined", -9: "timeout"}.get(rc, f"rc {rc}")
+            key = {0: "identical", 1: "DIFFERENT", 4: "reverse strand", 5: "reference undefined", -9: "timeout (the reference loops on some inputs)",
+                   -11: "crash (the reference runs first; ref_dump alone crashes on the same input)"}.get(rc, f"rc {rc}")
             if rc == 1 and "Unexpected dir" in r.stderr and "IDENTICAL" not in r.stdout and "DIFFERENT" not in r.stdout:
                 key = "reference fatal"                       # the reference's own fatal("Unexpected dir"), exit status 1
             tally[key] = tally.get(key, 0) + 1

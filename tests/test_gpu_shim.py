@@ -78,3 +78,16 @@ def test_protein_seeded_path_through_the_reference_side_shim(tmp_path, seed, kw,
     if rc == 5:
         pytest.skip("a DP call of this case is undefined in the reference")
     assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed,opts", [(0, ("-A", "0")), (1, ("-Q", "3")), (2, ("-A", "0")), (3, ("-Q", "3"))])
+def test_headline_shape_live(tmp_path, seed, opts):
+    """BASELINE's C2 shape (2 kb cDNA, locus +- 1 kb) live against the compiled reference: its exact engines (-A0: HomScoreS_ng
+    and alignS_ng, reliable at this size) and the seeded path under -A2 (-Q7: the DP calls between HSPs stay below the rows
+    where the reference's int16 engines re-base)"""
+    g = synth.make_gene(np.random.default_rng(synth.SEED + 9000 + seed), sub=0.04 + 0.01 * (seed % 5), indel=0.005)
+    rc, out = _run(tmp_path, g.window, g.query, opts)
+    if rc == 4:
+        pytest.skip("geneorient() preferred the reverse strand")
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]

@@ -7,7 +7,9 @@ No fixture in between: each case is one comparison of the product with the refer
 
     python tools/gpu_shim_fuzz.py 200 [first_seed] [s | h | sp | hp]
 
-s / h: cDNA / protein queries through the seeded paths; sp / hp: the same cases without seeding (-Q0), the engine
+c2: BASELINE's headline shape (2 kb cDNA against its locus +- 1 kb), alternately -A0 without seeding (the reference's
+exact engines are reliable at that size, its int16 ones are not) and -Q7 under -A2 (the DP calls between HSPs stay below the
+rows where the int16 engines re-base).  s / h: cDNA / protein queries through the seeded paths; sp / hp: the same cases without seeding (-Q0), the engine
 selector cycling through -A0 / -A1 / -A2 / -A3 -- HomScore*_ng and align*_ng of the reference against spdp_homscore_* /
 spdp_align_* for every engine family.
 """
@@ -34,12 +36,18 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
         for seed in range(first, first + n):
-            w, q, opts, desc = (make_case_h if protein else make_case)(seed)
+            if mode == "c2":
+                import numpy as np
+                g = synth.make_gene(np.random.default_rng(synth.SEED + 9000 + seed), sub=0.04 + 0.01 * (seed % 5), indel=0.005)
+                w, q, desc = g.window, g.query, "C2 shape"
+                opts = ["-A", "0"] if seed % 2 == 0 else ["-Q", "3"]
+            else:
+                w, q, opts, desc = (make_case_h if protein else make_case)(seed)
             keep, i = [], 0
             while i < len(opts):                              # the options shim_check knows
                 if plain and opts[i] == "-Q":
                     i += 2
-                elif opts[i] in ("-Q", "-X", "-V"):
+                elif opts[i] in ("-Q", "-X", "-V", "-A"):
                     keep += opts[i:i + 2]; i += 2
                 elif opts[i] in ("-L", "-C"):
                     keep.append(opts[i]); i += 1
@@ -50,7 +58,7 @@ def main():
             synth.write_fasta(gf, "win", w)
             synth.write_fasta(qf, "qry", q)
             try:
-                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=60)
+                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=180 if mode == "c2" else 60)
                 rc = r.returncode
             except subprocess.TimeoutExpired:
                 rc = -9

@@ -91,3 +91,15 @@ def test_headline_shape_live(tmp_path, seed, opts):
     if rc == 4:
         pytest.skip("geneorient() preferred the reverse strand")
     assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/shim_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_wip_engines_at_headline_size_live(tmp_path, seed):
+    """the engines bench.py times (`_wip`: linear-space sweep + slab tracebacks) at BASELINE's 2 kb size against the
+    reference's OWN -A2 run: queries divergent enough (18 - 24 % substitutions) that its int16 scores never reach the
+    re-basing threshold above which its output stops being a function of the input (at 6 - 8 % the same
+    comparison fails on the reference's side)"""
+    g = synth.make_gene(np.random.default_rng(synth.SEED + 9500 + seed), sub=0.18 + 0.02 * (seed % 6), indel=0.01)
+    rc, out = _run(tmp_path, g.window, g.query, ("-A", "2"))
+    assert rc == 0 and "IDENTICAL" in out, out[-1500:]

@@ -36,7 +36,13 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         gf, qf = os.path.join(td, "g.fa"), os.path.join(td, "q.fa")
         for seed in range(first, first + n):
-            if mode == "c2":
+            if mode == "c2w":                                 # the `_wip` engines themselves at 2 kb: divergent enough that the
+                import numpy as np                            # reference's int16 scores never reach their re-basing threshold
+                base = float(os.environ.get("C2W_SUB", "0.18"))
+                g = synth.make_gene(np.random.default_rng(synth.SEED + 9500 + seed), sub=base + 0.02 * (seed % 6), indel=0.01)
+                w, q, desc = g.window, g.query, f"C2 shape, {100 * (base + 0.02 * (seed % 6)):.0f} % substitutions"
+                opts = ["-A", "2"]
+            elif mode == "c2":
                 import numpy as np
                 g = synth.make_gene(np.random.default_rng(synth.SEED + 9000 + seed), sub=0.04 + 0.01 * (seed % 5), indel=0.005)
                 w, q, desc = g.window, g.query, "C2 shape"
@@ -58,7 +64,7 @@ def main():
             synth.write_fasta(gf, "win", w)
             synth.write_fasta(qf, "qry", q)
             try:
-                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=180 if mode == "c2" else 60)
+                r = subprocess.run([BIN, *keep, gf, qf], env=ENV, capture_output=True, text=True, timeout=180 if mode.startswith("c2") else 60)
                 rc = r.returncode
             except subprocess.TimeoutExpired:
                 rc = -9

@@ -295,7 +295,8 @@ int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc, const Spdp
                              const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
                              const SpdpHspSource* src, SpdpAlignment* out, int32_t* orient);
 /* counters of the last spdp_align_s_seeded call on this context: [0] device batches, [1] lspS_ng requests,
- * [2] trcbkalignS_ng requests, [3] of those with a cut range, [4] Wilip calls, [5] walks */
+ * [2] trcbkalignS_ng requests, [3] of those with a cut range, [4] Wilip calls, [5] walks; microseconds: [6] upload of the
+ * inputs, [7] the walks' host code (device idle), [8] device batches (walks asleep), [9] handing results back, [10] the call */
 int spdp_seeded_stats(const SpdpContext* ctx, int64_t* out, int n);
 
 /* stdskl (m_unit 1) / stdskl3 (m_unit 3), src/gaps.cc:140-227: corner list of n path records in any order;

@@ -764,7 +764,7 @@ int DevRun::sync()
         // blocks then leave a mark (second barrier word of their problem) and the launch is repeated without them
         const size_t per = (size_t) cross_g * wpb + 2;
         std::vector<int> words(per * n);
-        HIPCHK(hipMemcpy(words.data(), d_gprog, sizeof(int) * words.size(), hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(words.data(), d_gprog, sizeof(int) * words.size(), hipMemcpyDeviceToHost, strm()));
         bool gave_up = false;
         for (int j = 0; j < n; ++j) gave_up = gave_up || words[per * j + per - 1] != 0;
         if (gave_up) {
@@ -776,7 +776,7 @@ int DevRun::sync()
     if (pipe_on) {
         // a wave that waited in vain for the tile above it leaves a mark: the launch is repeated with one wave per problem
         int mark[2] = {0, 0};
-        HIPCHK(hipMemcpy(mark, (int*) d_gprog + (size_t) n * pipe_stride, sizeof mark, hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(mark, (int*) d_gprog + (size_t) n * pipe_stride, sizeof mark, hipMemcpyDeviceToHost, strm()));
         if (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) {
             pipe_on = false;
             if (launch()) return -1;
@@ -802,7 +802,7 @@ int DevRun::fetch_results(std::vector<DevResult>& out)
 {
     out.resize(n);
     std::vector<DevResult> tmp(n);
-    if (n) HIPCHK(hipMemcpy(tmp.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost));
+    if (n) HIPCHK(spdp_copy_sync(tmp.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost, strm()));
     for (int j = 0; j < n; ++j) out[order[j]] = tmp[j];
     return 0;
 }
@@ -813,7 +813,7 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
     n_skl.assign(n, 0); off.assign(n + 1, 0);
     if (!n) { skl.clear(); return 0; }
     std::vector<int> cnt(n);                            // dispatch order
-    HIPCHK(hipMemcpy(cnt.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIPCHK(spdp_copy_sync(cnt.data(), d_nskl, sizeof(int) * n, hipMemcpyDeviceToHost, strm()));
     // Lists that did not fit their slot (skl_cap is sized for typical lists; an indel-rich slab can need more): the
     // walk is repeated for those few with slots of the longest list their problem can produce.  Only the `_wip`
     // walk (flavour 1) can be repeated on its own; the scalar / -A1 engines walk inside their sweep kernel and
@@ -825,7 +825,7 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
         const int m = (int) over.size();
         std::vector<DevResult> all_res(n), sub_res(m);
         std::vector<DevProblem> sub_probs(m);
-        HIPCHK(hipMemcpy(all_res.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(all_res.data(), d_res, sizeof(DevResult) * n, hipMemcpyDeviceToHost, strm()));
         int cap2 = 1;
         for (int k = 0; k < m; ++k) {
             const DevProblem& P = h_probs[over[k]];
@@ -837,20 +837,20 @@ int DevRun::fetch_skl(std::vector<int>& n_skl, std::vector<int64_t>& off, std::v
         HIPCHK(hipMalloc(&dr, sizeof(DevResult) * m));
         HIPCHK(hipMalloc(&ds, sizeof(int2) * (size_t) cap2 * m));
         HIPCHK(hipMalloc(&dn, sizeof(int) * m));
-        HIPCHK(hipMemcpy(dp, sub_probs.data(), sizeof(DevProblem) * m, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dr, sub_res.data(), sizeof(DevResult) * m, hipMemcpyHostToDevice));
+        HIPCHK(spdp_copy_sync(dp, sub_probs.data(), sizeof(DevProblem) * m, hipMemcpyHostToDevice, strm()));
+        HIPCHK(spdp_copy_sync(dr, sub_res.data(), sizeof(DevResult) * m, hipMemcpyHostToDevice, strm()));
         WalkArgs W;
         W.probs = (const DevProblem*) dp; W.n_probs = m; W.tb = (const uint8_t*) d_tb; W.res = (const DevResult*) dr;
         W.skl = (int2*) ds; W.n_skl = (int*) dn; W.skl_cap = cap2; W.seq = 0;
         HIPCHK(spdp_launch_walk(&W, strm()));
         HIPCHK(hipStreamSynchronize(strm()));
         std::vector<int> c2(m);
-        HIPCHK(hipMemcpy(c2.data(), dn, sizeof(int) * m, hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(c2.data(), dn, sizeof(int) * m, hipMemcpyDeviceToHost, strm()));
         for (int k = 0; k < m; ++k) {
             cnt[over[k]] = c2[k];
             if (c2[k] > 0) {
                 redo[k].resize(c2[k]);
-                HIPCHK(hipMemcpy(redo[k].data(), (const int2*) ds + (size_t) k * cap2, sizeof(SpdpSkl) * c2[k], hipMemcpyDeviceToHost));
+                HIPCHK(spdp_copy_sync(redo[k].data(), (const int2*) ds + (size_t) k * cap2, sizeof(SpdpSkl) * c2[k], hipMemcpyDeviceToHost, strm()));
             }
         }
         (void) hipFree(dp); (void) hipFree(dr); (void) hipFree(ds); (void) hipFree(dn);
@@ -891,14 +891,14 @@ int DevRun::fetch_udh(std::vector<int32_t>& scores, std::vector<int32_t>& cpos, 
     if (edge) edge->assign(n, 0);
     if (n) {
         std::vector<int32_t> ts(n), tr((size_t) 4 * n), tc(st * n);
-        HIPCHK(hipMemcpy(ts.data(), d_scores, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(ts.data(), d_scores, sizeof(int32_t) * n, hipMemcpyDeviceToHost, strm()));
         if (edge && (flavour == 2 || flavour >= 8)) {
             std::vector<int32_t> te(n);
-            HIPCHK(hipMemcpy(te.data(), (int32_t*) d_scores + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            HIPCHK(spdp_copy_sync(te.data(), (int32_t*) d_scores + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, strm()));
             for (int j = 0; j < n; ++j) (*edge)[order[j]] = te[j];
         }
-        HIPCHK(hipMemcpy(tr.data(), d_ranges, sizeof(int32_t) * 4 * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(tc.data(), d_cpos, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost));
+        HIPCHK(spdp_copy_sync(tr.data(), d_ranges, sizeof(int32_t) * 4 * n, hipMemcpyDeviceToHost, strm()));
+        HIPCHK(spdp_copy_sync(tc.data(), d_cpos, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost, strm()));
         for (int j = 0; j < n; ++j) {
             const int i = order[j];
             scores[i] = ts[j];

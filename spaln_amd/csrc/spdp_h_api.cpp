@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/spdp.h"
@@ -91,6 +93,11 @@ struct HStore {
     int upload(SpdpContext* c, const SpdpScoringH* sc, const SpdpProblemH* probs, int n);
 };
 
+// the context whose streams / pools / scratch a call on `st` uses: the one the inputs were uploaded through, or -- for
+// a request batch another dispatcher thread of the seeded path runs beside it (spdh_run_requests) -- that thread's lane
+static thread_local SpdpContext* t_lane = nullptr;
+static inline SpdpContext* lane_of(const HStore& st) { return t_lane ? t_lane : st.ctx; }
+
 // one engine call on (a sub-range of) a parent problem
 struct HItem {
     int top;                                    // caller index the records belong to
@@ -140,9 +147,6 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     for (int i = 0; i < sc.mtx_rows; ++i)
         for (int j = 0; j < sc.mtx_cols; ++j) ds.mtx[i * 32 + j] = sc.mtx[i * sc.mtx_cols + j];
     const int ipen = sc.spj ? sc.ipen : SPDH_NEV;
-    std::vector<uint8_t> a_all;
-    std::vector<int4> cols;
-    std::vector<short4> aux;
     a_off.resize(n); col_off.resize(n); col_len.resize(n);
     int n_dev = 0;
     for (int i = 0; i < n; ++i) {
@@ -151,21 +155,27 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     }
     if (n_dev && n_dev != n) { ctx->err = "signal arrays missing for part of the batch"; return -1; }
     const bool dev_sig = n_dev > 0;
+    int64_t a_tot = 0, c_tot = 0;
     for (int i = 0; i < n; ++i) {
+        a_off[i] = a_tot; a_tot += (int64_t) probs[i].a_len + 1;
+        col_off[i] = c_tot; col_len[i] = probs[i].b_len + 3 + SPDH_COL_PAD; c_tot += col_len[i];
+    }
+    std::vector<uint8_t> a_all((size_t) a_tot, 0);      // (the byte behind a query reads 0 in the reference process: row a_len, see bad_range)
+    // column records, packed by the host's cores into pinned staging memory the context keeps (one thread and pageable
+    // vectors took 0.18 ms per protein window -- longer than the reference takes to ALIGN the pair on its seeded path)
+    int4* cols = dev_sig ? nullptr : (int4*) ctx->staging(0, (size_t) std::max<int64_t>(c_tot, 1) * sizeof(int4));
+    short4* aux = dev_sig ? nullptr : (short4*) ctx->staging(1, (size_t) std::max<int64_t>(c_tot, 1) * sizeof(short4));
+    if (!dev_sig && (!cols || !aux)) { ctx->err = "out of pinned host memory"; return -1; }
+    auto pack_one = [&](int i) {
         const SpdpProblemH& p = probs[i];
-        a_off[i] = (int64_t) a_all.size();
-        col_off[i] = (int64_t) cols.size();
-        col_len[i] = p.b_len + 3 + SPDH_COL_PAD;
-        a_all.insert(a_all.end(), p.a, p.a + p.a_len);
-        a_all.push_back(0);                     // the byte behind the query reads 0 in the reference process (row a_len, see bad_range)
+        memcpy(a_all.data() + a_off[i], p.a, p.a_len);
+        if (dev_sig) return;
         // column records (layout: spdp_h_dev.h); positions beyond the inputs read as zero
         const int N = p.b_len + 3;
         auto good = [&](int x) { return p.exin_left - 1 <= x && x < p.exin_right; };
         auto s16at = [&](const int16_t* v, int x) -> int { return (x >= 0 && x < N) ? v[x] : 0; };
-        const size_t c0 = cols.size();
-        cols.resize(c0 + col_len[i], make_int4(0, 0, 0, 0));
-        aux.resize(c0 + col_len[i], make_short4(0, 0, 0, 0));
-        for (int x = 0; x < N && !dev_sig; ++x) {
+        const size_t c0 = (size_t) col_off[i];
+        for (int x = 0; x < N; ++x) {
             const int cp = (x - 2 >= 0 && good(x - 2)) ? p.sigE[x - 2] : 0;
             const int tron = (x - 2 >= 0 && x - 2 <= p.b_len) ? p.b[x - 2] : 0;
             unsigned fl = 0;
@@ -192,6 +202,18 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
             cols[c0 + x] = rec;
             aux[c0 + x] = make_short4(p.sigS[x], p.sigT[x], p.sigE[x], p.sig5[x]);
         }
+        for (int x = N; x < col_len[i]; ++x) { cols[c0 + x] = make_int4(0, 0, 0, 0); aux[c0 + x] = make_short4(0, 0, 0, 0); }
+    };
+    {
+        int n_thr = (int) std::thread::hardware_concurrency();
+        if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
+        n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
+        std::atomic<int> next_prob{0};
+        auto pack = [&]() { for (;;) { const int i = next_prob.fetch_add(1); if (i >= n) break; pack_one(i); } };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_thr; ++t) th.emplace_back(pack);
+        pack();
+        for (std::thread& t : th) t.join();
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;
     for (int i = 0; i < n && !dev_sig; ++i) if (!probs[i].dinc) scalar_ok = false;      // (device-made signals bring dinc along)
@@ -221,22 +243,22 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     }
     d_sc = pool.get(HP_SC, sizeof ds);
     d_a = pool.get(HP_A, a_all.size() + 16);
-    d_cols = pool.get(HP_COLS, cols.size() * sizeof(int4));
-    d_aux = pool.get(HP_AUX, aux.size() * sizeof(short4));
+    d_cols = pool.get(HP_COLS, (size_t) c_tot * sizeof(int4));
+    d_aux = pool.get(HP_AUX, (size_t) c_tot * sizeof(short4));
     if (!d_sc || !d_a || !d_cols || !d_aux) { ctx->err = "device allocation failed (aa x genome inputs)"; return -1; }
     HIPCHK(hipMemcpyAsync(d_sc, &ds, sizeof ds, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_a, a_all.data(), a_all.size(), hipMemcpyHostToDevice, ctx->stream));
     if (dev_sig) {                              // (made on the device below: only zeros for the padding now)
-        HIPCHK(hipMemsetAsync(d_cols, 0, cols.size() * sizeof(int4), ctx->stream));
-        HIPCHK(hipMemsetAsync(d_aux, 0, aux.size() * sizeof(short4), ctx->stream));
+        HIPCHK(hipMemsetAsync(d_cols, 0, (size_t) c_tot * sizeof(int4), ctx->stream));
+        HIPCHK(hipMemsetAsync(d_aux, 0, (size_t) c_tot * sizeof(short4), ctx->stream));
     } else {
-        HIPCHK(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_aux, aux.data(), aux.size() * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_cols, cols, (size_t) c_tot * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_aux, aux, (size_t) c_tot * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (dev_sig) {
         // only the tron codes crossed PCIe (1 B per position instead of 24): spdp_signals_h.hip writes the column records
-        const size_t tot = cols.size();
+        const size_t tot = (size_t) c_tot;
         std::vector<uint8_t> hb(tot + 16, 0);
         std::vector<SigJobH> jobs(n);
         for (int i = 0; i < n; ++i) {
@@ -322,7 +344,7 @@ struct HFwdOut {
 
 static int run_forward_group(HStore& st, const std::vector<HItem>& items, bool walk, HFwdOut& out)
 {
-    SpdpContext* ctx = st.ctx;
+    SpdpContext* ctx = lane_of(st);
     DevPool& pool = ctx->pool[H_POOL];
     const int nr = (int) items.size();
     out = HFwdOut();
@@ -504,7 +526,7 @@ static int pipe_stalled(SpdpContext* ctx, const HPipe& pp, int n_probs)
 {
     if (!pp.on) return 0;
     int mark[2] = {0, 0};
-    HIPCHK(hipMemcpy(mark, pp.d + (size_t) n_probs * pp.stride, sizeof mark, hipMemcpyDeviceToHost));
+    HIPCHK(spdp_copy_sync(mark, pp.d + (size_t) n_probs * pp.stride, sizeof mark, hipMemcpyDeviceToHost, ctx->stream));
     return (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) ? 1 : 0;
 }
 
@@ -523,7 +545,7 @@ static int64_t vmf_budget_h(const DevProblemH& d, int scale)
 
 static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale, bool cut = false)
 {
-    SpdpContext* ctx = st.ctx;
+    SpdpContext* ctx = lane_of(st);
     DevPool& pool = ctx->pool[H_POOL];
     const int nr = (int) items.size();
     out = HFwdOut();
@@ -623,7 +645,7 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
 // another round with a larger budget for the problems that outgrew theirs
 static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact = false, bool cut = false)
 {
-    SpdpContext* ctx = st.ctx;
+    SpdpContext* ctx = lane_of(st);
     const int nr = (int) items.size();
     out = HFwdOut();
     if (!nr) return 0;
@@ -684,7 +706,7 @@ struct HUdhOut {
 
 static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
 {
-    SpdpContext* ctx = st.ctx;
+    SpdpContext* ctx = lane_of(st);
     DevPool& pool = ctx->pool[HU_POOL];
     const int nr = (int) items.size();
     out = HUdhOut();
@@ -739,7 +761,7 @@ static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
 static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine)
 {
     const bool exact = engine != 0;
-    SpdpContext* ctx = st.ctx;
+    SpdpContext* ctx = lane_of(st);
     DevPool& pool = ctx->pool[HU_POOL];
     const int nr = (int) items.size();
     out = HUdhOut();
@@ -1135,8 +1157,9 @@ void spdh_store_close(HStore* st) { delete st; }
 
 // out[k]: what the call returns + the Mfile records it writes, as written; n_skl < 0: not served here (an engine that is
 // not built, a range outside the sequences) or undefined in the reference (spdp_align_h's flags)
-int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out)
+int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out, SpdpContext* lane)
 {
+    struct LaneScope { LaneScope(SpdpContext* l) { t_lane = l; } ~LaneScope() { t_lane = nullptr; } } scope(lane);
     std::vector<HTop> tops;
     HStats hs;
     for (int k = 0; k < n; ++k) { out[k].score = SPDP_NEVSEL; out[k].n_skl = 0; out[k].skl = nullptr; out[k].flags = 0; out[k].reserved = 0; }

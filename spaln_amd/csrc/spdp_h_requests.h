@@ -15,5 +15,6 @@ struct SpdhRequest {
 };
 HStore* spdh_store_open(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpProblemH* probs, int n);
 void spdh_store_close(HStore* st);
-int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out);
+// lane: the context whose streams and scratch the batch uses (null: the store's own); one batch per context at a time
+int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out, SpdpContext* lane = nullptr);
 #endif

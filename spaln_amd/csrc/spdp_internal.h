@@ -227,6 +227,15 @@ struct DevPool {
 enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSKL, POOL_CPOS,
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_GPROG, POOL_FLAV_STRIDE = 0 };
 
+// a blocking copy that waits for ONE stream.  hipMemcpy goes through the null stream, which first waits for every blocking
+// stream of the process -- with several contexts at work (lanes of a chunked batch, the dispatchers of the seeded path) a
+// 16-byte read-back then waits for another lane's multi-millisecond sweep
+static inline hipError_t spdp_copy_sync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 struct SpdpContext {
     DevPool pool[9];                 // one pool per engine flavour (they coexist in a pipeline); [5], [6] = aa x genome path, [7] = rescoring,
                                      // [8] = the forward run on the side stream (coexists with a regular forward run)
@@ -239,7 +248,7 @@ struct SpdpContext {
     std::string name;
     std::string err;
     std::vector<SpdpContext*> lanes;  // further lanes of this context (spdp_lane): chunks of a batch run side by side
-    int64_t seed_stats[6] = {0};      // spdp_seeded_stats
+    int64_t seed_stats[12] = {0};      // spdp_seeded_stats
     void*  stage_ptr[2] = {nullptr, nullptr};   // pinned host staging of DevStore::upload (grow-only)
     size_t stage_cap[2] = {0, 0};
     void*  staging(int k, size_t bytes);

@@ -9,7 +9,7 @@
 // the resident inputs of the batch (spdp_run_requests: the same rounds as spdp_align_s -- linear-space sweeps, slab
 // tracebacks, walks), hands the records back and wakes the walks.  No DP cell of a request is computed on the host.
 #include <atomic>
-#include <condition_variable>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -23,7 +23,7 @@ namespace {
 using namespace spdp_seed;
 
 struct DeviceBackend : DpBackend {
-    Rendezvous* rv; int query; const SpdpHspSource* src;
+    Fiber* fiber; int query; const SpdpHspSource* src;
     bool failed = false;
     int flags = 0;                              // of all DP calls of the walk
     std::atomic<int64_t>* n_wilip;
@@ -32,13 +32,7 @@ struct DeviceBackend : DpBackend {
         Parked p;
         p.query = query; p.kind = kind; p.s = s; p.w = w;
         if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
-        {
-            std::unique_lock<std::mutex> lk(rv->mu);
-            rv->parked.push_back(&p);
-            --rv->running;
-            rv->cv_main.notify_one();
-            rv->cv_walk.wait(lk, [&] { return p.done; });       // (the dispatcher counts me as running again before it wakes me)
-        }
+        fiber->park(&p);                        // back when the request has been served
         if (p.failed) { failed = true; return SPDP_NEVSEL; }
         flags |= p.flags;
         rec.insert(rec.end(), p.rec.begin(), p.rec.end());
@@ -78,53 +72,47 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
             ctx->err = "the seeded path needs sig5 / sig3 / cano5 / cano3 / dinc of every problem on the host";
             return -1;
         }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t) {
+        return (int64_t) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
     DevStore st;
     if (st.upload(ctx, sc, probs, n_probs)) return -1;
+    const int64_t us_upload = us_since(t_begin);
+    int64_t us_walks = 0, us_device = 0, us_hand = 0;
 
-    Rendezvous rv;
-    std::atomic<int> next{0};
     std::atomic<int64_t> n_wilip{0};
     scores.assign(n_probs, SPDP_NEVSEL);
     recs.assign(n_probs, std::vector<SpdpSkl>());
     status.assign(n_probs, 0);                          // 1: the walk met a state it does not serve, 2: a request failed
-    int n_threads = 256;
-    if (const char* e = getenv("SPDP_SEED_WALKS")) n_threads = std::max(1, atoi(e));
-    n_threads = std::min(n_threads, n_probs);
-    rv.running = n_threads;
-    auto walker = [&]() {
-        for (;;) {
-            const int q = next.fetch_add(1);
-            if (q >= n_probs) break;
-            DeviceBackend be;
-            be.rv = &rv; be.query = q; be.src = src; be.n_wilip = &n_wilip;
-            SeedWalk w;
-            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-            if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; continue; }
-            w.dp = &be;
-            const SpdpProblem& p = probs[q];
-            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-            scores[q] = w.run(whole);
-            recs[q].swap(w.rec);
-            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
-            if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
-        }
-        std::lock_guard<std::mutex> g(rv.mu);
-        --rv.running;
-        rv.cv_main.notify_one();
+    auto walk = [&](int q, Fiber& fb) {
+        DeviceBackend be;
+        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+        SeedWalk w;
+        const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+        if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
+        w.dp = &be;
+        const SpdpProblem& p = probs[q];
+        const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
+        scores[q] = w.run(whole);
+        recs[q].swap(w.rec);
+        status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+        if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; ++t) pool.emplace_back(walker);
 
-    int rc = 0;
+    std::atomic<int> rc{0};
     int64_t n_batches = 0, n_kind[3] = {0, 0, 0};
-    for (;;) {
-        std::vector<Parked*> take;
-        {
-            std::unique_lock<std::mutex> lk(rv.mu);
-            rv.cv_main.wait(lk, [&] { return rv.running == 0; });
-            if (rv.parked.empty()) break;               // every walk has ended
-            take.swap(rv.parked);
-        }
+    auto t_idle = std::chrono::steady_clock::now();
+    std::mutex stats_mu;
+    int n_lanes = 4;
+    if (const char* e = getenv("SPDP_SEED_LANES")) n_lanes = std::max(1, std::min(atoi(e), 16));
+    n_lanes = std::min(n_lanes, std::max(1, n_probs / 64));
+    if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) return -1;       // (created here, on one thread)
+    int busy_lanes = 0;
+    int64_t lane_n[16] = {0}, lane_us[16] = {0}, lane_req[16] = {0};
+    auto device = [&](std::vector<Parked*>& take, int lane) {
+        (void) hipSetDevice(ctx->device);
+        { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
+        auto t0 = std::chrono::steady_clock::now();
         // one device batch for everything parked
         const int m = (int) take.size();
         std::vector<SpdpProblem> rp(m);
@@ -138,32 +126,63 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
             rp[k].a_exgl = q.s.a_exgl; rp[k].a_exgr = q.s.a_exgr; rp[k].b_exgl = q.s.b_exgl; rp[k].b_exgr = q.s.b_exgr;
             parents[k] = q.query; wins[k] = q.w; kinds[k] = (uint8_t) q.kind;
             cuts[2 * k] = q.cut[0]; cuts[2 * k + 1] = q.cut[1];
-            ++n_kind[q.kind];
+        }
+        if (const char* df = getenv("SPDP_SEED_DUMP")) {      // request shapes of every batch, for tuning: batch kind rows cols lw up cut
+            std::lock_guard<std::mutex> g(stats_mu);
+            if (FILE* f = fopen(df, "a")) {
+                for (int k = 0; k < m; ++k) {
+                    const Parked& q = *take[k];
+                    fprintf(f, "%lld %d %d %d %d %d %d\n", (long long) n_batches, q.kind, q.s.ar - q.s.al, q.s.br - q.s.bl, q.w.lw, q.w.up, q.cut[1] - q.cut[0]);
+                }
+                fclose(f);
+            }
         }
         std::vector<SpdpAlignment> res(m);
         const SpdpRequests rq = {parents.data(), wins.data(), kinds.data(), cuts.data()};
-        int brc = rc < 0 ? -1 : spdp_run_requests(ctx, &st, rp.data(), m, &rq, res.data());
-        ++n_batches;
-        if (brc < 0) rc = -1;                           // the walks still have to be let go: every request fails from here on
-        {
-            std::lock_guard<std::mutex> g(rv.mu);
-            for (int k = 0; k < m; ++k) {
-                Parked& q = *take[k];
-                if (brc < 0 || res[k].n_skl < 0) q.failed = true;
-                else {
-                    q.score = res[k].score; q.flags = res[k].flags;
-                    if (res[k].n_skl > 0) q.rec.assign(res[k].skl, res[k].skl + res[k].n_skl);
-                }
-                q.done = true;
+        SpdpContext* lc = spdp_lane(ctx, lane);
+        int brc = rc < 0 ? -1 : spdp_run_requests(lc, &st, rp.data(), m, &rq, res.data());
+        const int64_t us_dev = us_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        if (brc < 0) { rc = -1; if (lc != ctx) ctx->err = lc->err; }    // the walks still have to be let go: every request fails from here on
+        for (int k = 0; k < m; ++k) {
+            Parked& q = *take[k];
+            if (brc < 0 || res[k].n_skl < 0) q.failed = true;
+            else {
+                q.score = res[k].score; q.flags = res[k].flags;
+                if (res[k].n_skl > 0) q.rec.assign(res[k].skl, res[k].skl + res[k].n_skl);
             }
-            rv.running += m;
         }
-        rv.cv_walk.notify_all();
         if (brc >= 0) spdp_free_alignments(res.data(), m);
-    }
-    for (std::thread& t : pool) t.join();
+        std::lock_guard<std::mutex> g(stats_mu);
+        ++n_batches;
+        lane_n[lane & 15] += 1; lane_us[lane & 15] += us_dev; lane_req[lane & 15] += m;
+        for (int k = 0; k < m; ++k) ++n_kind[take[k]->kind];
+        us_device += us_dev; us_hand += us_since(t0);
+        if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();
+    };
+    WalkScheduler ws;
+    // latency classes: a sweep walks its columns one step at a time, 64 query rows per pass (~0.13 us a step); the scalar
+    // engine (fewer than 8 rows, cut ranges) takes about eight times as long per step.  Two dispatchers for the short class:
+    // its batches are bound by launch and read-back latency, not by the device
+    std::vector<int> class_of_lane(n_lanes);
+    for (int l = 0; l < n_lanes; ++l) class_of_lane[l] = n_lanes >= 4 ? (l < n_lanes - 2 ? 0 : l - (n_lanes - 3)) : l;
+    const int n_cls = n_lanes >= 4 ? 3 : n_lanes;
+    auto cls = [n_cls](const Parked& q) {
+        const int rows = q.s.ar - q.s.al;
+        const int64_t cols = std::max<int64_t>(0, (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
+        const int64_t steps = (rows < 8 || q.kind == 2) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
+        return steps < 1500 ? 0 : (steps < 6000 ? std::min(1, n_cls - 1) : n_cls - 1);
+    };
+    if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
+    us_walks += us_since(t_idle);
+    if (getenv("SPDP_SEED_VERBOSE"))
+        for (int l = 0; l < n_lanes; ++l)
+            fprintf(stderr, "[seeded] lane %d: %lld batches, %.2f ms each, %.0f requests each\n", l, (long long) lane_n[l],
+                    lane_n[l] ? lane_us[l] / 1e3 / lane_n[l] : 0.0, lane_n[l] ? (double) lane_req[l] / lane_n[l] : 0.0);
     ctx->seed_stats[0] = n_batches; ctx->seed_stats[1] = n_kind[0]; ctx->seed_stats[2] = n_kind[1] + n_kind[2];
     ctx->seed_stats[3] = n_kind[2]; ctx->seed_stats[4] = n_wilip.load(); ctx->seed_stats[5] = n_probs;
+    ctx->seed_stats[6] = us_upload; ctx->seed_stats[7] = us_walks; ctx->seed_stats[8] = us_device; ctx->seed_stats[9] = us_hand;
+    ctx->seed_stats[10] = us_since(t_begin);
     return rc < 0 ? -1 : 0;
 }
 
@@ -258,6 +277,6 @@ extern "C" int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc,
 extern "C" int spdp_seeded_stats(const SpdpContext* ctx, int64_t* out, int n)
 {
     if (!ctx || !out) return -1;
-    for (int i = 0; i < n && i < 6; ++i) out[i] = ctx->seed_stats[i];
+    for (int i = 0; i < n && i < 12; ++i) out[i] = ctx->seed_stats[i];
     return 0;
 }

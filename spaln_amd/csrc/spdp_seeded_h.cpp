@@ -8,7 +8,9 @@
 // (spdh_run_requests, spdp_h_api.cpp: linear-space sweeps, slab tracebacks, the scalar engine with its cut-range and
 // no-intron variants).  No DP cell of a request is computed on the host.
 #include <atomic>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -21,7 +23,7 @@ namespace {
 using namespace spdp_seed;
 
 struct DeviceBackendH : DpBackendH {
-    Rendezvous* rv; int query; const SpdpHspSource* src;
+    Fiber* fiber; int query; const SpdpHspSource* src;
     bool failed = false;
     std::atomic<int64_t>* n_wilip;
     int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
@@ -29,13 +31,7 @@ struct DeviceBackendH : DpBackendH {
         Parked p;
         p.query = query; p.kind = kind; p.s = s; p.w = w;
         if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
-        {
-            std::unique_lock<std::mutex> lk(rv->mu);
-            rv->parked.push_back(&p);
-            --rv->running;
-            rv->cv_main.notify_one();
-            rv->cv_walk.wait(lk, [&] { return p.done; });
-        }
+        fiber->park(&p);                        // back when the request has been served
         if (p.failed) { failed = true; return SPDP_NEVSEL; }
         rec.insert(rec.end(), p.rec.begin(), p.rec.end());
         return p.score;
@@ -75,52 +71,45 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
             ctx->err = "the seeded path needs the seven signal arrays and dinc of every problem on the host";
             return -1;
         }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t) {
+        return (int64_t) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };
     HStore* st = spdh_store_open(ctx, sc, probs, n_probs);
     if (!st) return -1;
+    const int64_t us_upload = us_since(t_begin);
+    int64_t us_walks = 0, us_device = 0, us_hand = 0;
 
-    Rendezvous rv;
-    std::atomic<int> next{0};
     std::atomic<int64_t> n_wilip{0};
     std::vector<int> scores(n_probs, SPDP_NEVSEL);
     std::vector<std::vector<SpdpSkl>> recs(n_probs);
     std::vector<uint8_t> status(n_probs, 0);            // 1: the walk met a state it does not serve, 2: a request failed
-    int n_threads = 256;
-    if (const char* e = getenv("SPDP_SEED_WALKS")) n_threads = std::max(1, atoi(e));
-    n_threads = std::min(n_threads, n_probs);
-    rv.running = n_threads;
-    auto walker = [&]() {
-        for (;;) {
-            const int q = next.fetch_add(1);
-            if (q >= n_probs) break;
-            DeviceBackendH be;
-            be.rv = &rv; be.query = q; be.src = src; be.n_wilip = &n_wilip;
-            SeedWalkH w;
-            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-            if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; continue; }
-            w.dp = &be;
-            const SpdpProblemH& p = probs[q];
-            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-            scores[q] = w.run(whole);
-            recs[q].swap(w.rec);
-            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
-        }
-        std::lock_guard<std::mutex> g(rv.mu);
-        --rv.running;
-        rv.cv_main.notify_one();
+    auto walk = [&](int q, Fiber& fb) {
+        DeviceBackendH be;
+        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+        SeedWalkH w;
+        const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+        if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
+        w.dp = &be;
+        const SpdpProblemH& p = probs[q];
+        const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
+        scores[q] = w.run(whole);
+        recs[q].swap(w.rec);
+        status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; ++t) pool.emplace_back(walker);
 
-    int rc = 0;
+    std::atomic<int> rc{0};
     int64_t n_batches = 0, n_kind[4] = {0, 0, 0, 0}, n_cut = 0;
-    for (;;) {
-        std::vector<Parked*> take;
-        {
-            std::unique_lock<std::mutex> lk(rv.mu);
-            rv.cv_main.wait(lk, [&] { return rv.running == 0; });
-            if (rv.parked.empty()) break;               // every walk has ended
-            take.swap(rv.parked);
-        }
+    auto t_idle = std::chrono::steady_clock::now();
+    std::mutex stats_mu;
+    int n_lanes = 4;
+    if (const char* e = getenv("SPDP_SEED_LANES")) n_lanes = std::max(1, std::min(atoi(e), 16));
+    n_lanes = std::min(n_lanes, std::max(1, n_probs / 64));
+    if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) { spdh_store_close(st); return -1; }     // (created here, on one thread)
+    int busy_lanes = 0;
+    auto device = [&](std::vector<Parked*>& take, int lane) {
+        (void) hipSetDevice(ctx->device);
+        { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
+        auto t0 = std::chrono::steady_clock::now();
         const int m = (int) take.size();
         std::vector<SpdhRequest> rq(m);
         for (int k = 0; k < m; ++k) {
@@ -129,33 +118,48 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
             r.parent = q.query; r.al = q.s.al; r.ar = q.s.ar; r.bl = q.s.bl; r.br = q.s.br;
             r.exg[0] = q.s.a_exgl; r.exg[1] = q.s.a_exgr; r.exg[2] = q.s.b_exgl; r.exg[3] = q.s.b_exgr;
             r.w = q.w; r.kind = q.kind; r.cut_l = q.cut[0]; r.cut_r = q.cut[1];
-            ++n_kind[q.kind & 3];
-            if (q.cut[1] > q.cut[0]) ++n_cut;
         }
         std::vector<SpdpAlignment> res(m);
-        const int brc = rc < 0 ? -1 : spdh_run_requests(st, rq.data(), m, res.data());
-        ++n_batches;
-        if (brc < 0) rc = -1;                           // the walks still have to be let go: every request fails from here on
-        {
-            std::lock_guard<std::mutex> g(rv.mu);
-            for (int k = 0; k < m; ++k) {
-                Parked& q = *take[k];
-                if (brc < 0 || res[k].n_skl < 0) q.failed = true;
-                else {
-                    q.score = res[k].score;
-                    if (res[k].n_skl > 0) q.rec.assign(res[k].skl, res[k].skl + res[k].n_skl);
-                }
-                q.done = true;
+        SpdpContext* lc = spdp_lane(ctx, lane);
+        const int brc = rc < 0 ? -1 : spdh_run_requests(st, rq.data(), m, res.data(), lc);
+        const int64_t us_dev = us_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        if (brc < 0) { rc = -1; if (lc != ctx) ctx->err = lc->err; }                           // the walks still have to be let go: every request fails from here on
+        for (int k = 0; k < m; ++k) {
+            Parked& q = *take[k];
+            if (brc < 0 || res[k].n_skl < 0) q.failed = true;
+            else {
+                q.score = res[k].score;
+                if (res[k].n_skl > 0) q.rec.assign(res[k].skl, res[k].skl + res[k].n_skl);
             }
-            rv.running += m;
         }
-        rv.cv_walk.notify_all();
         if (brc >= 0) spdp_free_alignments(res.data(), m);
-    }
-    for (std::thread& t : pool) t.join();
+        std::lock_guard<std::mutex> g(stats_mu);
+        ++n_batches;
+        for (int k = 0; k < m; ++k) { ++n_kind[take[k]->kind & 3]; if (take[k]->cut[1] > take[k]->cut[0]) ++n_cut; }
+        us_device += us_dev; us_hand += us_since(t0);
+        if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();
+    };
+    WalkScheduler ws;
+    // latency classes: a sweep walks its columns one step at a time, 64 query rows per pass (~0.13 us a step); the scalar
+    // engine (fewer than 8 rows, cut ranges) takes about eight times as long per step.  Two dispatchers for the short class:
+    // its batches are bound by launch and read-back latency, not by the device
+    std::vector<int> class_of_lane(n_lanes);
+    for (int l = 0; l < n_lanes; ++l) class_of_lane[l] = n_lanes >= 4 ? (l < n_lanes - 2 ? 0 : l - (n_lanes - 3)) : l;
+    const int n_cls = n_lanes >= 4 ? 3 : n_lanes;
+    auto cls = [n_cls](const Parked& q) {
+        const int rows = q.s.ar - q.s.al;
+        const int64_t cols = std::max<int64_t>(0, 3 * (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + 3 * rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
+        const int64_t steps = (rows < 8 || q.kind != 0) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
+        return steps < 1500 ? 0 : (steps < 6000 ? std::min(1, n_cls - 1) : n_cls - 1);
+    };
+    if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
+    us_walks += us_since(t_idle);
     spdh_store_close(st);
     ctx->seed_stats[0] = n_batches; ctx->seed_stats[1] = n_kind[0]; ctx->seed_stats[2] = n_kind[1] + n_kind[3];
     ctx->seed_stats[3] = n_cut; ctx->seed_stats[4] = n_wilip.load(); ctx->seed_stats[5] = n_probs;
+    ctx->seed_stats[6] = us_upload; ctx->seed_stats[7] = us_walks; ctx->seed_stats[8] = us_device; ctx->seed_stats[9] = us_hand;
+    ctx->seed_stats[10] = us_since(t_begin);
     if (rc < 0) return -1;
 
     // globalH_ng's tail (src/fwd2h1.cc:3277-3285): the file without its dummy record -> header + stdskl3

@@ -1,28 +1,187 @@
 // spdp_seeded_rv.h -- where the walks of a seeded call (spdp_seeded.cpp, spdp_seeded_h.cpp) meet the thread that runs
-// the device: a walk parks a DP request and sleeps; when every walk in flight sleeps, all parked requests run as one batch
+// the device.
+//
+// A walk is deeply recursive host code that calls its DP engines synchronously from the inside (the reference runs one
+// per worker thread, src/spaln.cc:1389-1468).  The device wants the opposite: many requests at once -- a launch lasts as
+// long as its slowest problem, a few ms, whether it carries two hundred requests or two thousand.  So every walk runs
+// on a FIBER (ucontext, own small stack): thousands are in flight on a handful of worker threads; a walk that reaches
+// a DP call parks its request and switches back to its worker, which picks the next runnable walk.  A dispatcher (the
+// calling thread, and a few more beside it, each with a lane context of its own) takes whatever is parked as soon as it
+// is free (and either enough has gathered or no walk can run), runs it as one set of launches, and makes the owners
+// runnable again -- host code of some walks overlaps the device batches of others, and several batches share the device.
 #ifndef SPDP_SEEDED_RV_H_
 #define SPDP_SEEDED_RV_H_
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "spdp_seeded_walk.h"
 
 namespace spdp_seed {
 
+struct Fiber;
 struct Parked {
     int query = 0, kind = 0;
     Span s{}; SpdpWindow w{}; int cut[2] = {0, 0};
     int score = SPDP_NEVSEL;
     std::vector<SpdpSkl> rec;
-    bool done = false, failed = false;
+    bool failed = false;
     int flags = 0;                              // SpdpAlignment::flags of the request
+    Fiber* owner = nullptr;
 };
 
-struct Rendezvous {
+struct Fiber {
+    ucontext_t ctx{};
+    ucontext_t* back = nullptr;                 // the worker it runs on right now
+    void* stack = nullptr;
+    int query = -1;
+    Parked* want_park = nullptr;
+    bool finished = false;
+    struct WalkScheduler* sched = nullptr;
+    // called by a walk (DpBackend::lsp / trcbk): hand the request over and sleep until it has been served
+    void park(Parked* p)
+    {
+        p->owner = this;
+        want_park = p;
+        swapcontext(&ctx, back);                // (may come back on another worker thread)
+    }
+};
+
+struct WalkScheduler {
+    static constexpr size_t STACK = 512 << 10, GUARD = 4096;
     std::mutex mu;
-    std::condition_variable cv_walk, cv_main;
-    std::vector<Parked*> parked;
-    int running = 0;                            // walker threads that are neither parked nor finished
+    std::condition_variable cv_work, cv_main;
+    std::vector<Fiber*> ready, idle_fibers, all_fibers;
+    std::vector<std::vector<Parked*>> parked;           // per latency class (= dispatcher lane)
+    std::function<int(const Parked&)> classify;
+    int n_walks = 0, next = 0, done = 0, in_flight = 0, busy = 0;
+    int max_in_flight = 8192, n_threads = 16, batch_target = 512;
+    std::function<void(int, Fiber&)> body;
+    bool oom = false;
+
+    static void entry(unsigned lo, unsigned hi)
+    {
+        Fiber* f = (Fiber*) ((uintptr_t) lo | (uintptr_t) hi << 32);
+        f->sched->body(f->query, *f);
+        f->finished = true;
+        swapcontext(&f->ctx, f->back);          // never resumed
+    }
+    Fiber* fresh(int q)
+    {
+        Fiber* f;
+        if (!idle_fibers.empty()) { f = idle_fibers.back(); idle_fibers.pop_back(); }
+        else {
+            void* m = mmap(nullptr, STACK + GUARD, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (m == MAP_FAILED) return nullptr;
+            (void) mprotect(m, GUARD, PROT_NONE);       // a walk that outgrows its stack stops here, not in another walk's
+            f = new Fiber;
+            f->stack = m; f->sched = this;
+            all_fibers.push_back(f);
+        }
+        f->query = q; f->finished = false; f->want_park = nullptr;
+        getcontext(&f->ctx);
+        f->ctx.uc_stack.ss_sp = (char*) f->stack + GUARD;
+        f->ctx.uc_stack.ss_size = STACK;
+        f->ctx.uc_link = nullptr;
+        const uintptr_t p = (uintptr_t) f;
+        makecontext(&f->ctx, (void (*)()) entry, 2, (unsigned) (p & 0xffffffffu), (unsigned) (p >> 32));
+        return f;
+    }
+    void worker()
+    {
+        ucontext_t here;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            Fiber* f = nullptr;
+            for (;;) {
+                if (!ready.empty()) { f = ready.back(); ready.pop_back(); break; }
+                if (next < n_walks && in_flight < max_in_flight && !oom) {
+                    f = fresh(next);
+                    if (f) { ++next; ++in_flight; break; }
+                    oom = true;                         // no stack for another walk: go on with those in flight
+                    if (!in_flight) { done = n_walks; cv_main.notify_all(); cv_work.notify_all(); return; }
+                }
+                if (done >= n_walks) return;
+                cv_work.wait(lk);
+            }
+            ++busy;
+            lk.unlock();
+            f->back = &here;
+            swapcontext(&here, &f->ctx);
+            lk.lock();
+            --busy;
+            if (f->finished) {
+                idle_fibers.push_back(f);
+                --in_flight; ++done;
+                if (done >= n_walks) { cv_work.notify_all(); cv_main.notify_all(); }
+                else if (next < n_walks) cv_work.notify_one();
+            } else {
+                const int c = parked.size() > 1 ? std::max(0, std::min((int) parked.size() - 1, classify(*f->want_park))) : 0;
+                parked[c].push_back(f->want_park);
+                if ((int) parked[c].size() >= batch_target) cv_main.notify_all();
+            }
+            if (!busy) cv_main.notify_all();
+        }
+    }
+    // runs walks 0 .. n - 1 (body(q, fiber) on a fiber each).  A batch lasts as long as its slowest request, so requests
+    // are sorted into latency classes (cls(request), short to long) and every class has dispatchers of its own -- lane l
+    // serves class_of_lane[l]; lane 0 is this thread, the others are threads beside it: device(batch, lane) is called with the
+    // parked requests of one class and fills score / rec / failed of each; a walk whose requests are short does not wait for
+    // another walk's 20 kb intron.  Returns false when not every walk could be started.
+    bool run(int n, std::function<void(int, Fiber&)> walk_body,
+             const std::function<void(std::vector<Parked*>&, int)>& device, const std::vector<int>& class_of_lane,
+             std::function<int(const Parked&)> cls)
+    {
+        const int n_lanes = (int) class_of_lane.size();
+        parked.assign(*std::max_element(class_of_lane.begin(), class_of_lane.end()) + 1, std::vector<Parked*>());
+        classify = std::move(cls);
+        n_walks = n; body = std::move(walk_body);
+        if (const char* e = getenv("SPDP_SEED_WALKS")) max_in_flight = std::max(1, atoi(e));
+        if (const char* e = getenv("SPDP_SEED_BATCH")) batch_target = std::max(1, atoi(e));
+        n_threads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));     // (more only contend: measured 8 / 16 / 32 / 64)
+        if (const char* e = getenv("SPDP_SEED_THREADS")) n_threads = std::max(1, atoi(e));
+        n_threads = std::min(n_threads, n);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back([this] { worker(); });
+        auto dispatcher = [&](int lane) {
+            const int c = class_of_lane[lane];
+            for (;;) {
+                std::vector<Parked*> take;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_main.wait(lk, [&] {
+                        if (done >= n_walks) return true;
+                        if (parked[c].empty()) return false;
+                        // nobody can run (every worker waits: nothing ready, nothing new to start), or enough has gathered
+                        const bool startable = next < n_walks && in_flight < max_in_flight && !oom;
+                        return (int) parked[c].size() >= batch_target || (!busy && ready.empty() && !startable);
+                    });
+                    if (parked[c].empty()) { cv_main.notify_all(); break; }         // every walk has ended
+                    take.swap(parked[c]);
+                }
+                device(take, lane);
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    for (Parked* p : take) ready.push_back(p->owner);
+                }
+                cv_work.notify_all();
+            }
+        };
+        std::vector<std::thread> lanes;
+        for (int l = 1; l < n_lanes; ++l) lanes.emplace_back(dispatcher, l);
+        dispatcher(0);
+        for (std::thread& t : lanes) t.join();
+        for (std::thread& t : pool) t.join();
+        for (Fiber* f : all_fibers) { munmap(f->stack, STACK + GUARD); delete f; }
+        all_fibers.clear();
+        return !oom;
+    }
 };
 
 }   // namespace spdp_seed

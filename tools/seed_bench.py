@@ -41,7 +41,8 @@ def main():
                 synth.write_fasta(gf, "win", g.window)
                 synth.write_fasta(qf, "qry", g.query)
                 lf.write(f"{gf} {qf}\n")
-        r = subprocess.run([BIN, "-Q", str(q), "-t", str(threads), os.path.join(td, "list.txt")], env=ENV,
+        prefix = os.environ.get("SEED_BENCH_PREFIX", "").split()     # e.g. a profiler in front of the binary
+        r = subprocess.run(prefix + [BIN, "-Q", str(q), "-t", str(threads), os.path.join(td, "list.txt")], env=ENV,
                            capture_output=True, text=True)
     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     try:
@@ -54,7 +55,7 @@ def main():
     d["reference_pairs_per_s"] = round(d["walked"] / d["reference_s"], 1)
     d["library_pairs_per_s"] = round(d["walked"] / d["library_s"], 1)
     print(json.dumps(d))
-    if r.returncode not in (0, 1):
+    if r.returncode not in (0, 1) or os.environ.get("SPDP_SEED_VERBOSE"):
         print(r.stderr[-2000:])
     return r.returncode
 

@@ -201,14 +201,14 @@ const	double	t_fill0 = now_s();
 		fill_scoring_h(tsc, pwd, b);
 		fill_problem_h(ph[i], a, b, P.hc, P.exin_left, P.exin_right);
 		ph[i].a_pad = *a->at(a->len);
-		fill_exact_h(tsc, ph[i], b, pwd, P.c);
+		fill_exact_h(tsc, ph[i], b, pwd, P.c, false);
 		memcpy(loc, tsc.t53, sizeof loc);
 		if (i == 0) sch = tsc;
 	    } else {
 		SpdpScoring	tsc;
 		fill_scoring(tsc, pwd, b);
 		fill_problem(ps[i], a, b, P.s5, P.s3);
-		fill_exact_s(tsc, ps[i], b, pwd, P.c);
+		fill_exact_s(tsc, ps[i], b, pwd, P.c, false);
 		memcpy(loc, tsc.t53, sizeof loc);
 		if (i == 0) sc = tsc;
 	    }

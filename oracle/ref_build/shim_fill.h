@@ -45,10 +45,13 @@ const	    SGPT2* g = b->exin->score_n(n);
 // the exact-model inputs (-A0 / -A1 engines, and the seeded walk's joins): IntronPenalty::Penalty(len) materialised, the
 // junction table behind Exinon::sig53(.., IE53), dinucleotide classes, site flags, splice-phase marks
 struct SeedCols { std::vector<int16_t> s5, s3, ip; std::vector<uint8_t> c5, c3, dc; std::vector<int8_t> p5, p3; std::vector<int32_t> flat; };
-static void fill_exact_s(SpdpScoring& sc, SpdpProblem& p, const Seq* b, const PwdB* pwd, SeedCols& c) {
-	c.ip.resize(b->len + 2);
-	for (int l = 0; l < (int) c.ip.size(); ++l) c.ip[l] = pwd->IntPen->Penalty(l);
-	sc.intpen = c.ip.data();  sc.intpen_len = (int) c.ip.size();
+// (with_table = false: a batch shares one IntPen table, its caller fills sc.intpen once)
+static void fill_exact_s(SpdpScoring& sc, SpdpProblem& p, const Seq* b, const PwdB* pwd, SeedCols& c, bool with_table = true) {
+	if (with_table) {
+	    c.ip.resize(b->len + 2);
+	    for (int l = 0; l < (int) c.ip.size(); ++l) c.ip[l] = pwd->IntPen->Penalty(l);
+	    sc.intpen = c.ip.data();  sc.intpen_len = (int) c.ip.size();
+	}
 	sc.minl = IntronPrm.minl;
 	sc.scalar_engines = algmode.alg == 0? 1: (algmode.alg == 1? 2: 0);
 	c.c5.assign(b->len + 3, 0); c.c3.assign(b->len + 3, 0); c.dc.assign(b->len + 3, 0);
@@ -116,11 +119,13 @@ const	    SGPT6* g = b->exin->score_p(n);		// src/codepot.h:105
 	p.a_exgl = a->inex.exgl; p.a_exgr = a->inex.exgr; p.b_exgl = b->inex.exgl; p.b_exgr = b->inex.exgr;
 }
 
-static void fill_exact_h(SpdpScoringH& sc, SpdpProblemH& p, const Seq* b, const PwdB* pwd, SeedCols& sx) {
+static void fill_exact_h(SpdpScoringH& sc, SpdpProblemH& p, const Seq* b, const PwdB* pwd, SeedCols& sx, bool with_table = true) {
 	// the exact-model inputs the walk prices its joins with (and the scalar engine behind its small DP calls)
-	sx.ip.resize(b->len + 2);
-	for (int l = 0; l < (int) sx.ip.size(); ++l) sx.ip[l] = pwd->IntPen->Penalty(l);
-	sc.intpen = sx.ip.data();  sc.intpen_len = (int) sx.ip.size();
+	if (with_table) {
+	    sx.ip.resize(b->len + 2);
+	    for (int l = 0; l < (int) sx.ip.size(); ++l) sx.ip[l] = pwd->IntPen->Penalty(l);
+	    sc.intpen = sx.ip.data();  sc.intpen_len = (int) sx.ip.size();
+	}
 	sc.lgop = pwd->LongGOP; sc.gape1 = pwd->GapE1; sc.gape2 = pwd->GapE2; sc.extragop = pwd->ExtraGOP;
 	sc.diffu = pwd->diffu; sc.k1 = alprm.k1; sc.minl = IntronPrm.minl;
 	sx.dc.assign(b->len + 3, 0);

@@ -6,10 +6,12 @@
 // library, where they go to callbacks -- the tests bind those to the oracle's ladder (oracle/host_logic.py: lsp, trcbk)
 // and to the Wilip replies a `ref_dump -Q` fixture recorded.  That way the walk's decisions are checked against the
 // reference's seeded alignments without a GPU, and the -m gpu tests check the same source with the device behind it.
+#include <atomic>
 #include <cstring>
 #include <vector>
 
 #include "../spaln_amd/csrc/spdp_seeded_walk.h"
+#include "../spaln_amd/csrc/spdp_seeded_rv.h"
 
 extern "C" {
 // kind 0: lspS_ng, 1: trcbkalignS_ng, 2: Wilip.  args: a_left, a_right, b_left, b_right, a_exgl, a_exgr, b_exgl, b_exgr,
@@ -132,4 +134,49 @@ extern "C" int walk_check_split_codon_h(const SpdpProblemH* p, int n5, int n3, i
     const bool ok = w.split_codon(n5, n3, c);
     cs[0] = c[0]; cs[1] = c[1];
     return ok ? 0 : 1;
+}
+
+// ---- the fiber scheduler of the seeded drivers (spdp_seeded_rv.h) without a device ----------------------------------
+// n_walks toy walks: walk q makes 1 + (q * 7919) % max_parks requests in a row from `depth` frames down a recursion (each
+// frame keeps 1 KB on the fiber's stack), request k of walk q asks for f(q, k) = q * 131 + k * 17 and its latency class
+// is k % 3; the "device" (whatever dispatcher lane picks the batch up) answers.  out[q] = sum of the answers.  Returns the
+// number of batches, or -1 when the scheduler reports a failure.
+namespace {
+int toy_descend(spdp_seed::Fiber& fb, int q, int k, int depth)
+{
+    volatile char pad[1024];
+    pad[0] = (char) depth; pad[1023] = (char) q;
+    if (depth > 0) return toy_descend(fb, q, k, depth - 1) + (pad[0] - (char) depth) + (pad[1023] - (char) q);
+    spdp_seed::Parked p;
+    p.query = q; p.kind = k;
+    fb.park(&p);
+    return p.failed ? -1000000 : p.score;
+}
+}   // namespace
+
+extern "C" int walk_check_scheduler(int n_walks, int max_parks, int depth, int l0, int l1, int l2, int64_t* out)
+{
+    using namespace spdp_seed;
+    std::atomic<int> n_batches{0};
+    std::mutex mu;
+    bool bad_class = false;
+    const std::vector<int> class_of_lane = lanes_per_class(n_walks, l0, l1, l2);
+    const int n_cls = class_of_lane.back() + 1;
+    auto walk = [&](int q, Fiber& fb) {
+        const int parks = 1 + (int) (((int64_t) q * 7919) % max_parks);
+        int64_t sum = 0;
+        for (int k = 0; k < parks; ++k) sum += toy_descend(fb, q, k, depth);
+        out[q] = sum;
+    };
+    auto device = [&](std::vector<Parked*>& take, int lane) {
+        ++n_batches;
+        for (Parked* p : take) {
+            if (std::min(p->kind % 3, n_cls - 1) != class_of_lane[lane]) { std::lock_guard<std::mutex> g(mu); bad_class = true; }
+            p->score = p->query * 131 + p->kind * 17;
+        }
+    };
+    auto cls = [n_cls](const Parked& p) { return std::min(p.kind % 3, n_cls - 1); };
+    WalkScheduler ws;
+    if (!ws.run(n_walks, walk, device, class_of_lane, cls) || bad_class) return -1;
+    return n_batches.load();
 }

@@ -849,9 +849,55 @@ __global__ void spdp_walk(WalkArgs A)
             if (!dead) code = to_upper(0);
             break;
         }
-        case TB_ACCR:
-            do { code = to_left(1); } while (code && !(code & TB_DONR));
+        case TB_ACCR: {
+            // across an intron: left along row m to the first cell that carries the donor mark (or is dead).  One load
+            // per 16 cells of a 20 kb intron is a chain of 1250 dependent loads; the 64 lanes fetch the next 64 groups
+            // (1024 cells) at once instead and the nearest stop among them is taken.  Groups that reach beyond the
+            // stripe's first step or the window's first column stay with the one-step form below.
+            bool found = false;
+            while (!seq_walk && m >= 1) {
+                const int k = (m - 1) & 15;
+                V.seek((m - 1) >> 4);
+                const int t_here = n + V.b_left + k - V.c_nstart;
+                const int t_min = max(0, V.b_left + k - V.c_nstart);          // n >= 0 and inside the stripe
+                if (t_here > V.c_n9 - V.c_nstart + 1 || t_here - 1 < t_min + 16) break;
+                const int g0 = (t_here - 1) >> 4, jmax = (t_here - 1) & 15;
+                const int L = (int) (threadIdx.x & 63);
+                const int g = g0 - L;
+                const bool valid = g >= 0 && 16 * g >= t_min;
+                uint4 w4 = make_uint4(0, 0, 0, 0);
+                if (valid) w4 = *reinterpret_cast<const uint4*>(V.tb + V.cbase + 256ll * g + 16 * k);
+                int best = -1; unsigned bcode = 0;
+                const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const unsigned w = ws[wi];
+                    unsigned sb = (~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu)) | (w & 0x80808080u);   // byte == 0, or donor mark
+                    if (L == 0) {
+                        if (4 * wi > jmax) sb = 0u;
+                        else if (4 * wi + 3 > jmax) sb &= (1u << (8 * ((jmax & 3) + 1))) - 1u;
+                    }
+                    if (valid && sb) { const int bj = (31 - __builtin_clz(sb)) >> 3; best = 4 * wi + bj; bcode = (w >> (8 * bj)) & 0xffu; }
+                }
+                const unsigned long long stop_b = __ballot(best >= 0), inval_b = __ballot(!valid);
+                const int first_stop = stop_b ? __builtin_ctzll(stop_b) : 64;
+                const int first_inval = inval_b ? __builtin_ctzll(inval_b) : 64;
+                if (first_stop < first_inval) {
+                    const int bj = __shfl(best, first_stop, 64);
+                    code = (unsigned) __shfl((int) bcode, first_stop, 64);
+                    n = 16 * (g0 - first_stop) + bj - V.b_left - k + V.c_nstart;
+                    found = true;
+                    break;
+                }
+                // nothing in the valid groups: go to the leftmost cell looked at (alive, no mark) and look again from there
+                const int last = first_inval - 1;
+                if (last < 0) break;
+                n = 16 * (g0 - last) - V.b_left - k + V.c_nstart;
+            }
+            if (!found) do { code = to_left(1); } while (code && !(code & TB_DONR));
+            else { V.c_grp = -1; }
             break;
+        }
         default:
             status = -2; code = 0;
             break;

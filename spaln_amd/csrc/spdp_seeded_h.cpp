@@ -101,9 +101,10 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     int64_t n_batches = 0, n_kind[4] = {0, 0, 0, 0}, n_cut = 0;
     auto t_idle = std::chrono::steady_clock::now();
     std::mutex stats_mu;
-    int n_lanes = 4;
-    if (const char* e = getenv("SPDP_SEED_LANES")) n_lanes = std::max(1, std::min(atoi(e), 16));
-    n_lanes = std::min(n_lanes, std::max(1, n_probs / 64));
+    // (the long class here is the scalar engine on few-row calls with an intron inside, 10 - 30 ms each; more dispatchers
+    // for it were measured and cost time: 2,1,3 -> 0.50 s against 0.42 s for 20 k pairs)
+    const std::vector<int> class_of_lane = lanes_per_class(n_probs, 2, 1, 1);
+    const int n_lanes = (int) class_of_lane.size();
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) { spdh_store_close(st); return -1; }     // (created here, on one thread)
     int busy_lanes = 0;
     auto device = [&](std::vector<Parked*>& take, int lane) {
@@ -144,9 +145,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     // latency classes: a sweep walks its columns one step at a time, 64 query rows per pass (~0.13 us a step); the scalar
     // engine (fewer than 8 rows, cut ranges) takes about eight times as long per step.  Two dispatchers for the short class:
     // its batches are bound by launch and read-back latency, not by the device
-    std::vector<int> class_of_lane(n_lanes);
-    for (int l = 0; l < n_lanes; ++l) class_of_lane[l] = n_lanes >= 4 ? (l < n_lanes - 2 ? 0 : l - (n_lanes - 3)) : l;
-    const int n_cls = n_lanes >= 4 ? 3 : n_lanes;
+    const int n_cls = class_of_lane.back() + 1;
     auto cls = [n_cls](const Parked& q) {
         const int rows = q.s.ar - q.s.al;
         const int64_t cols = std::max<int64_t>(0, 3 * (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + 3 * rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));

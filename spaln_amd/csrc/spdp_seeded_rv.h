@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -53,6 +54,28 @@ struct Fiber {
     }
 };
 
+// dispatcher lanes per latency class (short, middle, long): "a,b,c" in SPDP_SEED_LANES overrides the defaults; a small call
+// gets one lane and one class
+inline std::vector<int> lanes_per_class(int n_walks, int d0, int d1, int d2)
+{
+    int k[3] = {d0, d1, d2};
+    if (const char* e = getenv("SPDP_SEED_LANES")) {
+        int a = 0, b = 0, c = 0;
+        const int got = sscanf(e, "%d,%d,%d", &a, &b, &c);
+        if (got == 3) { k[0] = a; k[1] = b; k[2] = c; }
+        else if (got == 1 && a == 1) { k[0] = 1; k[1] = k[2] = 0; }
+    }
+    if (n_walks < 256) { k[0] = 1; k[1] = k[2] = 0; }
+    std::vector<int> class_of_lane;
+    int cls = 0;
+    for (int c = 0; c < 3; ++c) {
+        const int m = std::max(c == 0 ? 1 : 0, std::min(k[c], 8));
+        for (int j = 0; j < m; ++j) class_of_lane.push_back(cls);
+        if (m) ++cls;
+    }
+    return class_of_lane;
+}
+
 struct WalkScheduler {
     static constexpr size_t STACK = 512 << 10, GUARD = 4096;
     std::mutex mu;
@@ -61,7 +84,7 @@ struct WalkScheduler {
     std::vector<std::vector<Parked*>> parked;           // per latency class (= dispatcher lane)
     std::function<int(const Parked&)> classify;
     int n_walks = 0, next = 0, done = 0, in_flight = 0, busy = 0;
-    int max_in_flight = 8192, n_threads = 16, batch_target = 512;
+    int max_in_flight = 8192, n_threads = 16, batch_target = 256;
     std::function<void(int, Fiber&)> body;
     bool oom = false;
 

@@ -164,6 +164,48 @@ def _ref_bench_baseline(pairs, band_cells, cell_ratio, alg):
                       f"alignS_ng / alignH_ng, skl_rng*_ng; AVX2 build), {done} done, {ok} aligned, {cdt:.2f} s wall"}
 
 
+SEED_BENCH = os.path.join(ROOT, "oracle", "_ref", "seed_bench")
+
+
+def _seeded_leg(n_pairs):
+    """SURVEY 8 row f2, measured: the seeded path (-Q7) of `n_pairs` C2-shaped pairs -- the reference's own alignS_ng on the
+    host cores against ONE spdp_align_s_seeded call (the reference's geneorient() finds the HSPs for both, its Wilip answers
+    the recursion levels through the callback), compared pair by pair.  oracle/_ref/seed_bench links the compiled
+    reference and the library (oracle/ref_build/seed_bench.cc); None where it has not been built."""
+    if not os.path.exists(SEED_BENCH):
+        return None
+    import subprocess
+    import tempfile
+    from spaln_amd import synth
+    used = _host_cores()
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
+    env["ALN_TAB"] = REF_TAB
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "list.txt"), "w") as lf:
+            for i in range(n_pairs):
+                g = synth.make_gene(np.random.default_rng(synth.SEED + 20000 + i), sub=0.04 + 0.01 * (i % 5), indel=0.005)
+                gf, qf = os.path.join(td, f"g{i}.fa"), os.path.join(td, f"q{i}.fa")
+                synth.write_fasta(gf, "win", g.window)
+                synth.write_fasta(qf, "qry", g.query)
+                lf.write(f"{gf} {qf}\n")
+        r = subprocess.run([SEED_BENCH, "-Q", "3", "-t", str(used), os.path.join(td, "list.txt")], env=env,
+                           capture_output=True, text=True)
+    try:
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return None
+    return {"pairs": d["walked"], "identical_to_reference": d["identical"], "compared": d["compared"],
+            "library_pairs_per_s": round(d["walked"] / d["library_s"], 1), "library_s": d["library_s"],
+            "library_first_call_s": d["library_cold_s"],
+            "reference_pairs_per_s": round(d["walked"] / d["reference_s"], 1), "reference_threads": d["threads"],
+            "marshalling_s": d["marshal_s"], "device_batches": d["batches"], "dp_requests": d["lsp"] + d["trcbk"],
+            "note": "spaln -Q7 semantics on C2-shaped pairs (oracle/_ref/seed_bench): HSPs from the reference's geneorient() for both "
+                    "sides (not timed); reference = its alignS_ng on the host cores; library = one spdp_align_s_seeded call, inputs "
+                    "uploaded inside the call, the second call on a warm context (first call beside it); marshalling = the "
+                    "reference-side shim turning Seq / Exinon into the plain arrays of include/spdp.h, outside both"}
+
+
 def _ref_baseline(pairs, protein, band_cells, cell_ratio, alg=2):
     if os.path.exists(REF_BENCH):
         rb = _ref_bench_baseline(pairs, band_cells, cell_ratio, alg)
@@ -380,6 +422,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seeded-pairs", type=int, default=6000,
+                    help="pairs of the seeded-path (-Q7) leg reported in config.seeded_q7 (c2, N = 1; 0: skip)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "
                          "c4: 500-nt ESTs (traceback branch of the ladder only)")
@@ -624,6 +668,10 @@ def main():
                                  "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
             "cpu_baseline": cpu_base,
         }
+        if world == 1 and not c4 and not exact and args.seeded_pairs > 0:
+            leg = _seeded_leg(args.seeded_pairs)
+            if leg:
+                out["config"]["seeded_q7"] = leg
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:

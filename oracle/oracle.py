@@ -37,7 +37,7 @@ def build_walk_check(force: bool = False) -> str:
     """the seeded walk's CPU checker: the product's host walk (a header) compiled with callbacks in place of the device"""
     srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk.h"),
             os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk_h.h"),
-            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_rv.h"),
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_rv.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_hostcpus.h"),
             os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_gencode.h"), os.path.join(_HERE, "..", "include", "spdp.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_WALK_SO) or os.path.getmtime(_WALK_SO) < newest:

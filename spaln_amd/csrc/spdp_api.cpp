@@ -302,7 +302,7 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         int32_t* hc = (int32_t*) ctx->staging(0, nc * sizeof(int32_t));
         uint8_t* hx = has_exact ? (uint8_t*) ctx->staging(1, nc) : nullptr;
         if (!hc || (has_exact && !hx)) { ctx->err = "out of pinned host memory"; return -1; }
-        int n_thr = (int) std::thread::hardware_concurrency();
+        int n_thr = spdp_host_cpus();
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
         std::vector<int> t_s5(n_thr, INT32_MIN), t_s3(n_thr, INT32_MIN);

@@ -205,7 +205,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         for (int x = N; x < col_len[i]; ++x) { cols[c0 + x] = make_int4(0, 0, 0, 0); aux[c0 + x] = make_short4(0, 0, 0, 0); }
     };
     {
-        int n_thr = (int) std::thread::hardware_concurrency();
+        int n_thr = spdp_host_cpus();
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
         std::atomic<int> next_prob{0};

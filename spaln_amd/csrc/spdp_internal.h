@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/spdp.h"
 #include "spdp_dev.h"
+#include "spdp_hostcpus.h"
 
 struct SweepArgs {
     const DevScoring* sc;

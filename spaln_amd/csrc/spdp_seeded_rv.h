@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 #include "spdp_seeded_walk.h"
+#include "spdp_hostcpus.h"
 
 namespace spdp_seed {
 
@@ -167,7 +168,7 @@ struct WalkScheduler {
         n_walks = n; body = std::move(walk_body);
         if (const char* e = getenv("SPDP_SEED_WALKS")) max_in_flight = std::max(1, atoi(e));
         if (const char* e = getenv("SPDP_SEED_BATCH")) batch_target = std::max(1, atoi(e));
-        n_threads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));     // (more only contend: measured 8 / 16 / 32 / 64)
+        n_threads = std::min(32, spdp_host_cpus());     // (threads beyond the CPUs granted only contend: 16 granted, measured 8 / 16 / 32 / 64)
         if (const char* e = getenv("SPDP_SEED_THREADS")) n_threads = std::max(1, atoi(e));
         n_threads = std::min(n_threads, n);
         std::vector<std::thread> pool;

@@ -103,3 +103,20 @@ def test_wip_engines_at_headline_size_live(tmp_path, seed):
     g = synth.make_gene(np.random.default_rng(synth.SEED + 9500 + seed), sub=0.18 + 0.02 * (seed % 6), indel=0.01)
     rc, out = _run(tmp_path, g.window, g.query, ("-A", "2"))
     assert rc == 0 and "IDENTICAL" in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n", [("c2", 600), ("c3", 600)])
+def test_seeded_batch_live(shape, n):
+    """a BATCH through the seeded path: the reference's alignS_ng / alignH_ng on host threads against one
+    spdp_align_*_seeded call (thousands of walks in flight on fibers, requests in latency classes), pair by pair"""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "seed_bench.py")
+    if not os.path.exists(os.path.join(os.path.dirname(tool), "..", "oracle", "_ref", "seed_bench")):
+        pytest.skip("oracle/_ref/seed_bench not built")
+    r = subprocess.run([sys.executable, tool, str(n), shape, "3", "8"], capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["walked"] >= n - n // 20                     # (pairs whose other strand wins geneorient() are left out)
+    assert d["compared"] == d["walked"] and d["identical"] == d["compared"], d

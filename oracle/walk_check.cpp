@@ -160,7 +160,7 @@ extern "C" int walk_check_scheduler(int n_walks, int max_parks, int depth, int l
     std::atomic<int> n_batches{0};
     std::mutex mu;
     bool bad_class = false;
-    const std::vector<int> class_of_lane = lanes_per_class(n_walks, l0, l1, l2);
+    const std::vector<int> class_of_lane = lanes_per_class(n_walks, {l0, l1, l2});
     const int n_cls = class_of_lane.back() + 1;
     auto walk = [&](int q, Fiber& fb) {
         const int parks = 1 + (int) (((int64_t) q * 7919) % max_parks);

@@ -103,7 +103,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     int64_t n_batches = 0, n_kind[3] = {0, 0, 0};
     auto t_idle = std::chrono::steady_clock::now();
     std::mutex stats_mu;
-    const std::vector<int> class_of_lane = lanes_per_class(n_probs, 2, 1, 1);
+    const std::vector<int> class_of_lane = lanes_per_class(n_probs, {2, 1, 1});
     const int n_lanes = (int) class_of_lane.size();
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) return -1;       // (created here, on one thread)
     int busy_lanes = 0;
@@ -168,7 +168,8 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         const int rows = q.s.ar - q.s.al;
         const int64_t cols = std::max<int64_t>(0, (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
         const int64_t steps = (rows < 8 || q.kind == 2) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
-        return steps < 1500 ? 0 : (steps < 6000 ? std::min(1, n_cls - 1) : n_cls - 1);
+        static const int64_t thr[] = {1500, 6000, 20000};            // (four classes measured: no gain over three; the defaults give lanes to the first three)
+        return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };
     if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
     us_walks += us_since(t_idle);

@@ -101,12 +101,11 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     int64_t n_batches = 0, n_kind[4] = {0, 0, 0, 0}, n_cut = 0;
     auto t_idle = std::chrono::steady_clock::now();
     std::mutex stats_mu;
-    // (the long class here is the scalar engine on few-row calls with an intron inside, 10 - 30 ms each; more dispatchers
-    // for it were measured and cost time: 2,1,3 -> 0.50 s against 0.42 s for 20 k pairs)
-    const std::vector<int> class_of_lane = lanes_per_class(n_probs, 2, 1, 1);
+    const std::vector<int> class_of_lane = lanes_per_class(n_probs, {2, 1, 1});
     const int n_lanes = (int) class_of_lane.size();
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) { spdh_store_close(st); return -1; }     // (created here, on one thread)
     int busy_lanes = 0;
+    int64_t lane_n[16] = {0}, lane_us[16] = {0}, lane_req[16] = {0};
     auto device = [&](std::vector<Parked*>& take, int lane) {
         (void) hipSetDevice(ctx->device);
         { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
@@ -137,6 +136,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         if (brc >= 0) spdp_free_alignments(res.data(), m);
         std::lock_guard<std::mutex> g(stats_mu);
         ++n_batches;
+        lane_n[lane & 15] += 1; lane_us[lane & 15] += us_dev; lane_req[lane & 15] += m;
         for (int k = 0; k < m; ++k) { ++n_kind[take[k]->kind & 3]; if (take[k]->cut[1] > take[k]->cut[0]) ++n_cut; }
         us_device += us_dev; us_hand += us_since(t0);
         if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();
@@ -150,10 +150,15 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         const int rows = q.s.ar - q.s.al;
         const int64_t cols = std::max<int64_t>(0, 3 * (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + 3 * rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
         const int64_t steps = (rows < 8 || q.kind != 0) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
-        return steps < 1500 ? 0 : (steps < 6000 ? std::min(1, n_cls - 1) : n_cls - 1);
+        static const int64_t thr[] = {1500, 6000, 18000, 45000};     // (five classes measured: no gain over three; the defaults give lanes to the first three)
+        return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };
     if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
     us_walks += us_since(t_idle);
+    if (getenv("SPDP_SEED_VERBOSE"))
+        for (int l = 0; l < n_lanes; ++l)
+            fprintf(stderr, "[seeded] lane %d (class %d): %lld batches, %.2f ms each, %.0f requests each\n", l, class_of_lane[l], (long long) lane_n[l],
+                    lane_n[l] ? lane_us[l] / 1e3 / lane_n[l] : 0.0, lane_n[l] ? (double) lane_req[l] / lane_n[l] : 0.0);
     spdh_store_close(st);
     ctx->seed_stats[0] = n_batches; ctx->seed_stats[1] = n_kind[0]; ctx->seed_stats[2] = n_kind[1] + n_kind[3];
     ctx->seed_stats[3] = n_cut; ctx->seed_stats[4] = n_wilip.load(); ctx->seed_stats[5] = n_probs;

@@ -55,26 +55,32 @@ struct Fiber {
     }
 };
 
-// dispatcher lanes per latency class (short, middle, long): "a,b,c" in SPDP_SEED_LANES overrides the defaults; a small call
-// gets one lane and one class
-inline std::vector<int> lanes_per_class(int n_walks, int d0, int d1, int d2)
+// dispatcher lanes per latency class, shortest class first: "a,b,c,.." in SPDP_SEED_LANES overrides the defaults (a 0 merges
+// that class into the one above it; "1" = one lane, no classes); a small call gets one lane and one class.
+// Returns the class each lane serves.
+inline std::vector<int> lanes_per_class(int n_walks, std::vector<int> k)
 {
-    int k[3] = {d0, d1, d2};
     if (const char* e = getenv("SPDP_SEED_LANES")) {
-        int a = 0, b = 0, c = 0;
-        const int got = sscanf(e, "%d,%d,%d", &a, &b, &c);
-        if (got == 3) { k[0] = a; k[1] = b; k[2] = c; }
-        else if (got == 1 && a == 1) { k[0] = 1; k[1] = k[2] = 0; }
+        std::vector<int> v;
+        for (const char* p = e; *p; ) { v.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        if (!v.empty()) k = v;
     }
-    if (n_walks < 256) { k[0] = 1; k[1] = k[2] = 0; }
+    if (n_walks < 256) k.assign(1, 1);
     std::vector<int> class_of_lane;
     int cls = 0;
-    for (int c = 0; c < 3; ++c) {
+    for (size_t c = 0; c < k.size(); ++c) {
         const int m = std::max(c == 0 ? 1 : 0, std::min(k[c], 8));
         for (int j = 0; j < m; ++j) class_of_lane.push_back(cls);
         if (m) ++cls;
     }
     return class_of_lane;
+}
+// class of a request whose sweep takes `steps`: how many of the thresholds it reaches, within the classes that have lanes
+inline int latency_class(int64_t steps, const int64_t* thr, int n_thr, int n_cls)
+{
+    int c = 0;
+    while (c < n_thr && steps >= thr[c]) ++c;
+    return std::min(c, n_cls - 1);
 }
 
 struct WalkScheduler {

@@ -84,7 +84,7 @@ inline int latency_class(int64_t steps, const int64_t* thr, int n_thr, int n_cls
 }
 
 struct WalkScheduler {
-    static constexpr size_t STACK = 512 << 10, GUARD = 4096;
+    static constexpr size_t STACK = 1 << 20, GUARD = 4096;     // (the HSP callback -- the reference's Wilip in an integration -- runs on it too)
     std::mutex mu;
     std::condition_variable cv_work, cv_main;
     std::vector<Fiber*> ready, idle_fibers, all_fibers;

@@ -38,7 +38,7 @@ def test_every_walk_gets_its_own_answers(lanes):
 
 
 def test_one_walk_one_thread_and_a_deep_recursion():
-    # 300 frames x 1 KB on a 512 KB fiber stack; a single walk never gathers a batch: the idle rule has to fire
+    # 300 frames x 1 KB on a 1 MB fiber stack; a single walk never gathers a batch: the idle rule has to fire
     nb, out, want = _run(1, 5, 300, (2, 1, 1), {"SPDP_SEED_THREADS": "1"})
     assert nb == int(1 + (0 * 7919) % 5) and np.array_equal(out, want)
 

@@ -3,11 +3,12 @@
 //
 // What it mirrors (ogotoh/spaln v3.0.7): Aln2s1::globalS_ng -> seededS_ng -> interpolateS (src/fwd2s1.cc:2587-2694,
 // 2405-2539); the walk itself is spdp_seeded_walk.h.  The reference runs one walk per worker thread and calls its DP
-// engines synchronously from deep inside it (spaln -t, src/spaln.cc:1389-1468).  Here a pool of host threads runs the
-// walks of a call side by side; a walk that reaches lspS_ng / trcbkalignS_ng parks its request and sleeps; when every
-// walk in flight sleeps (or has ended), the calling thread runs all parked requests as ONE set of device launches on
-// the resident inputs of the batch (spdp_run_requests: the same rounds as spdp_align_s -- linear-space sweeps, slab
-// tracebacks, walks), hands the records back and wakes the walks.  No DP cell of a request is computed on the host.
+// engines synchronously from deep inside it (spaln -t, src/spaln.cc:1389-1468).  Here every walk of a call runs on a
+// fiber, thousands in flight on the host's cores (spdp_seeded_rv.h); a walk that reaches lspS_ng / trcbkalignS_ng parks
+// its request and yields; the parked requests, sorted by how long their sweeps will take, run as sets of device launches
+// on the resident inputs of the batch (spdp_run_requests: the same rounds as spdp_align_s -- linear-space sweeps, slab
+// tracebacks, walks), one dispatcher lane per latency class, and their owners become runnable again.  No DP cell of a
+// request is computed on the host.
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -93,10 +94,12 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         w.dp = &be;
         const SpdpProblem& p = probs[q];
         const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-        scores[q] = w.run(whole);
-        recs[q].swap(w.rec);
-        status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
-        if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
+        try {
+            scores[q] = w.run(whole);
+            recs[q].swap(w.rec);
+            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+            if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
+        } catch (...) { status[q] = 2; }            // (out of memory inside one walk: that query comes back without an alignment)
     };
 
     std::atomic<int> rc{0};
@@ -142,7 +145,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         int brc = rc < 0 ? -1 : spdp_run_requests(lc, &st, rp.data(), m, &rq, res.data());
         const int64_t us_dev = us_since(t0);
         t0 = std::chrono::steady_clock::now();
-        if (brc < 0) { rc = -1; if (lc != ctx) ctx->err = lc->err; }    // the walks still have to be let go: every request fails from here on
+        if (brc < 0) { rc = -1; std::lock_guard<std::mutex> g(stats_mu); if (lc != ctx) ctx->err = lc->err; }    // the walks still have to be let go: every request fails from here on
         for (int k = 0; k < m; ++k) {
             Parked& q = *take[k];
             if (brc < 0 || res[k].n_skl < 0) q.failed = true;

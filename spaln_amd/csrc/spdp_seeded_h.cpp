@@ -2,11 +2,11 @@
 // HSPs, every DP call of every walk served by the device in common batches.
 //
 // What it mirrors (ogotoh/spaln v3.0.7): Aln2h1::globalH_ng -> seededH_ng -> interpolateH (src/fwd2h1.cc:3267-3286,
-// 3177-3265, 3023-3131); the walk itself is spdp_seeded_walk_h.h.  Same scheme as spdp_seeded.cpp: a pool of host threads
-// runs the walks; a walk that reaches lspH_ng / trcbkalignH_ng parks its request; when every walk in flight sleeps, the
-// calling thread runs all parked requests as one pass of the protein ladder on the resident inputs of the batch
-// (spdh_run_requests, spdp_h_api.cpp: linear-space sweeps, slab tracebacks, the scalar engine with its cut-range and
-// no-intron variants).  No DP cell of a request is computed on the host.
+// 3177-3265, 3023-3131); the walk itself is spdp_seeded_walk_h.h.  Same scheme as spdp_seeded.cpp: the walks run on
+// fibers (spdp_seeded_rv.h); a walk that reaches lspH_ng / trcbkalignH_ng parks its request; the parked requests of a
+// latency class run as one pass of the protein ladder on the resident inputs of the batch (spdh_run_requests,
+// spdp_h_api.cpp: linear-space sweeps, slab tracebacks, the scalar engine with its cut-range and no-intron variants) on
+// that class's dispatcher lane.  No DP cell of a request is computed on the host.
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -92,9 +92,11 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         w.dp = &be;
         const SpdpProblemH& p = probs[q];
         const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-        scores[q] = w.run(whole);
-        recs[q].swap(w.rec);
-        status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+        try {
+            scores[q] = w.run(whole);
+            recs[q].swap(w.rec);
+            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+        } catch (...) { status[q] = 2; }            // (out of memory inside one walk: that query comes back without an alignment)
     };
 
     std::atomic<int> rc{0};
@@ -124,7 +126,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         const int brc = rc < 0 ? -1 : spdh_run_requests(st, rq.data(), m, res.data(), lc);
         const int64_t us_dev = us_since(t0);
         t0 = std::chrono::steady_clock::now();
-        if (brc < 0) { rc = -1; if (lc != ctx) ctx->err = lc->err; }                           // the walks still have to be let go: every request fails from here on
+        if (brc < 0) { rc = -1; std::lock_guard<std::mutex> g(stats_mu); if (lc != ctx) ctx->err = lc->err; }                           // the walks still have to be let go: every request fails from here on
         for (int k = 0; k < m; ++k) {
             Parked& q = *take[k];
             if (brc < 0 || res[k].n_skl < 0) q.failed = true;

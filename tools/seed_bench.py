@@ -42,7 +42,8 @@ def main():
                 synth.write_fasta(qf, "qry", g.query)
                 lf.write(f"{gf} {qf}\n")
         prefix = os.environ.get("SEED_BENCH_PREFIX", "").split()     # e.g. a profiler in front of the binary
-        r = subprocess.run(prefix + [BIN, "-Q", str(q), "-t", str(threads), os.path.join(td, "list.txt")], env=ENV,
+        extra = os.environ.get("SEED_BENCH_OPTS", "").split()        # e.g. "-A 0" (engines behind the walk), "-X 1"
+        r = subprocess.run(prefix + [BIN, "-Q", str(q), "-t", str(threads)] + extra + [os.path.join(td, "list.txt")], env=ENV,
                            capture_output=True, text=True)
     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     try:

@@ -422,7 +422,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seeded-pairs", type=int, default=6000,
+    ap.add_argument("--seeded-pairs", type=int, default=10000,
                     help="pairs of the seeded-path (-Q7) leg reported in config.seeded_q7 (c2, N = 1; 0: skip)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "

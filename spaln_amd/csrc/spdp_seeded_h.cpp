@@ -7,6 +7,7 @@
 // latency class run as one pass of the protein ladder on the resident inputs of the batch (spdh_run_requests,
 // spdp_h_api.cpp: linear-space sweeps, slab tracebacks, the scalar engine with its cut-range and no-intron variants) on
 // that class's dispatcher lane.  No DP cell of a request is computed on the host.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -144,6 +145,11 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();
     };
     WalkScheduler ws;
+    // the walks of long windows first: their gaps hold the long introns, i.e. the slow requests, and a call ends with its last walk
+    ws.order.resize(n_probs);
+    for (int i = 0; i < n_probs; ++i) ws.order[i] = i;
+    std::stable_sort(ws.order.begin(), ws.order.end(), [&](int x, int y) {
+        return probs[x].b_right - probs[x].b_left > probs[y].b_right - probs[y].b_left; });
     // latency classes: a sweep walks its columns one step at a time, 64 query rows per pass (~0.13 us a step); the scalar
     // engine (fewer than 8 rows, cut ranges) takes about eight times as long per step.  Two dispatchers for the short class:
     // its batches are bound by launch and read-back latency, not by the device

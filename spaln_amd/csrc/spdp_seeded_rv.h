@@ -93,6 +93,7 @@ struct WalkScheduler {
     int n_walks = 0, next = 0, done = 0, in_flight = 0, busy = 0;
     int max_in_flight = 8192, n_threads = 16, batch_target = 256;
     std::function<void(int, Fiber&)> body;
+    std::vector<int> order;                             // walk started k-th (empty: k); longest first shortens the tail of a call
     bool oom = false;
 
     static void entry(unsigned lo, unsigned hi)
@@ -132,7 +133,7 @@ struct WalkScheduler {
             for (;;) {
                 if (!ready.empty()) { f = ready.back(); ready.pop_back(); break; }
                 if (next < n_walks && in_flight < max_in_flight && !oom) {
-                    f = fresh(next);
+                    f = fresh(order.empty() ? next : order[next]);
                     if (f) { ++next; ++in_flight; break; }
                     oom = true;                         // no stack for another walk: go on with those in flight
                     if (!in_flight) { done = n_walks; cv_main.notify_all(); cv_work.notify_all(); return; }

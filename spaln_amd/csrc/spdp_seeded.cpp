@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <ctime>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -29,6 +30,7 @@ struct DeviceBackend : DpBackend {
     bool failed = false;
     int flags = 0;                              // of all DP calls of the walk
     std::atomic<int64_t>* n_wilip;
+    std::atomic<int64_t>* ns_cb = nullptr;
     int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
     {
         Parked p;
@@ -51,7 +53,11 @@ struct DeviceBackend : DpBackend {
         const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
         const int32_t* flat = nullptr; int32_t n = 0;
         ++*n_wilip;
-        if (src->units(src->user, query, level, span, &flat, &n) || !flat) return false;
+        timespec t0, t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0);
+        const int urc = src->units(src->user, query, level, span, &flat, &n);
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
+        if (ns_cb) *ns_cb += (int64_t) (t1.tv_sec - t0.tv_sec) * 1000000000 + (t1.tv_nsec - t0.tv_nsec);
+        if (urc || !flat) return false;
         const bool ok = parse_units(flat, n, units);
         if (src->release) src->release(src->user, query, flat);
         return ok;
@@ -83,15 +89,19 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     int64_t us_walks = 0, us_device = 0, us_hand = 0;
 
     std::atomic<int64_t> n_wilip{0};
+    std::atomic<int64_t> ns_bind{0}, ns_run{0}, ns_cb{0};
+    auto cpu_ns = [] { timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return (int64_t) t.tv_sec * 1000000000 + t.tv_nsec; };
     scores.assign(n_probs, SPDP_NEVSEL);
     recs.assign(n_probs, std::vector<SpdpSkl>());
     status.assign(n_probs, 0);                          // 1: the walk met a state it does not serve, 2: a request failed
     auto walk = [&](int q, Fiber& fb) {
         DeviceBackend be;
-        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
         SeedWalk w;
         const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+        const int64_t tb0 = cpu_ns();
         if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
+        ns_bind += cpu_ns() - tb0;
         w.dp = &be;
         const SpdpProblem& p = probs[q];
         const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
@@ -182,6 +192,8 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     };
     if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
     us_walks += us_since(t_idle);
+    if (getenv("SPDP_SEED_VERBOSE"))
+        fprintf(stderr, "[seeded] host CPU: walks %.1f ms (bind %.1f, HSP callback %.1f), %d worker threads\n", ws.cpu_ns / 1e6, ns_bind.load() / 1e6, ns_cb.load() / 1e6, ws.n_threads);
     if (getenv("SPDP_SEED_VERBOSE"))
         for (int l = 0; l < n_lanes; ++l)
             fprintf(stderr, "[seeded] lane %d: %lld batches, %.2f ms each, %.0f requests each\n", l, (long long) lane_n[l],

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -95,6 +96,7 @@ struct WalkScheduler {
     std::function<void(int, Fiber&)> body;
     std::vector<int> order;                             // walk started k-th (empty: k); longest first shortens the tail of a call
     bool oom = false;
+    int64_t cpu_ns = 0;                                 // thread CPU time inside walks, all workers
 
     static void entry(unsigned lo, unsigned hi)
     {
@@ -144,8 +146,12 @@ struct WalkScheduler {
             ++busy;
             lk.unlock();
             f->back = &here;
+            timespec t0, t1;
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0);
             swapcontext(&here, &f->ctx);
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
             lk.lock();
+            cpu_ns += (int64_t) (t1.tv_sec - t0.tv_sec) * 1000000000 + (t1.tv_nsec - t0.tv_nsec);
             --busy;
             if (f->finished) {
                 idle_fibers.push_back(f);

@@ -124,6 +124,26 @@ public:
     }
 };
 
+// the phase marks of a window as one walk sees them: the caller's array plus the few marks the walk itself has set (a
+// private copy of the array per walk cost more than the rest of a walk's set-up)
+struct PhaseMarks {
+    const int8_t* base = nullptr;
+    std::vector<int8_t> own;                    // when the caller gave none: derived from the site flags
+    std::vector<std::pair<int, int8_t>> edits;
+    int8_t operator[](int n) const
+    {
+        for (size_t i = edits.size(); i-- > 0; ) if (edits[i].first == n) return edits[i].second;
+        return base[n];
+    }
+    void set(int n, int8_t v)
+    {
+        for (auto& e : edits) if (e.first == n) { e.second = v; return; }
+        edits.push_back({n, v});
+    }
+    void bind(const int8_t* b) { base = b; own.clear(); edits.clear(); }
+    void derive(int N) { own.assign(N, -2); base = own.data(); edits.clear(); }
+};
+
 class SeedWalk {
 public:
     // inputs (borrowed)
@@ -132,8 +152,10 @@ public:
     const int16_t* sig5 = nullptr; const int16_t* sig3 = nullptr;
     const uint8_t* cano5 = nullptr; const uint8_t* cano3 = nullptr; const uint8_t* dinc = nullptr;
     const int32_t* cip = nullptr;               // Cip_score::cip_score(m), m = 0 .. a_len, or null (SpdpProblem::cip)
-    std::vector<int8_t> phs5, phs3;             // SGPT2::phs5 / phs3: the walk marks the junctions it accepts (:2055-2059)
-    std::vector<uint8_t> lvl5, lvl3;            // INT53::cano5 / cano3 as levels 0 .. 3 (cano5 / cano3 above only say "a site")
+    PhaseMarks phs5, phs3;                      // SGPT2::phs5 / phs3: the walk marks the junctions it accepts (:2055-2059)
+    uint8_t f5[16] = {0}, f3[16] = {0};         // INT53::cano5 / cano3 as levels 0 .. 3 by dinucleotide class (cano5 / cano3 above only say "a site")
+    int lvl5(int n) const { return cano5[n] ? (f5[dinc[n] >> 4] ? f5[dinc[n] >> 4] : cano5[n]) : 0; }
+    int lvl3(int n) const { return cano3[n] ? (f3[dinc[n] & 15] ? f3[dinc[n] & 15] : cano3[n]) : 0; }
     const SpdpScoring* sc = nullptr;
     const SpdpSeedParams* sp = nullptr;
     DpBackend* dp = nullptr;
@@ -171,7 +193,7 @@ public:
     int sig53_5p3(int m, int n) const { return sig5[m] + sig3[n] + sc->t53[16 * (dinc[m] >> 4) + (dinc[n] & 15)]; }
     int is_canon(int d, int ac) const           // Exinon::isCanon, src/codepot.h:108-113
     {
-        const int c5 = lvl5[d], c3 = lvl3[ac];
+        const int c5 = lvl5(d), c3 = lvl3(ac);
         return ((c5 == 3 && c3 == 3) || (c5 == 2 && c3 == 2) || (c5 == 1 && c3) || (c5 && c3 == 1)) ? c5 + c3 : 0;
     }
     void put(int m, int n) { rec.push_back({m, n}); }
@@ -310,10 +332,10 @@ public:
         if (iscr <= NEV()) return false;
         if (write) {
             rec.push_back(k);
-            phs5[k.n] = 0;
+            phs5.set(k.n, 0);
             k.n += ilen;
             rec.push_back(k);
-            phs3[k.n] = 0;
+            phs3.set(k.n, 0);
             iscr += int_pen(ilen);
         }
         return true;
@@ -883,18 +905,19 @@ inline bool bind_problem(SeedWalk& w, const SpdpScoring* sc, const SpdpSeedParam
     w.lowest_level = lowest_level;
     const int N = p->b_len + 1;
     if (p->phs5 && p->phs3) {
-        w.phs5.assign(p->phs5, p->phs5 + N);
-        w.phs3.assign(p->phs3, p->phs3 + N);
+        w.phs5.bind(p->phs5); w.phs3.bind(p->phs3);
     } else {
-        w.phs5.assign(N, -2); w.phs3.assign(N, -2);
+        w.phs5.derive(N); w.phs3.derive(N);
+        std::vector<int8_t>& q5 = w.phs5.own;
+        std::vector<int8_t>& q3 = w.phs3.own;
         for (int n = std::max(1, p->b_left); n < std::min(N - 1, p->b_right + 1); ++n) {
-            if (w.phs5[n] == -2 && p->cano5[n]) {
-                w.phs5[n] = 0;
-                if (p->cano5[n] > 1) { w.phs5[n + 1] = 1; w.phs5[n - 1] = w.phs5[n - 1] == 1 ? 2 : -1; }
+            if (q5[n] == -2 && p->cano5[n]) {
+                q5[n] = 0;
+                if (p->cano5[n] > 1) { q5[n + 1] = 1; q5[n - 1] = q5[n - 1] == 1 ? 2 : -1; }
             }
-            if (w.phs3[n] == -2 && p->cano3[n]) {
-                w.phs3[n] = 0;
-                if (p->cano3[n] > 1) { w.phs3[n + 1] = 1; w.phs3[n - 1] = w.phs3[n - 1] == 1 ? 2 : -1; }
+            if (q3[n] == -2 && p->cano3[n]) {
+                q3[n] = 0;
+                if (p->cano3[n] > 1) { q3[n + 1] = 1; q3[n - 1] = q3[n - 1] == 1 ? 2 : -1; }
             }
         }
     }
@@ -904,7 +927,8 @@ inline bool bind_problem(SeedWalk& w, const SpdpScoring* sc, const SpdpSeedParam
         static const uint8_t lac[4] = {0, 2, 3, 1}, lgt[4] = {0, 0, 3, 1};
         const int any = sp->any & 3;
         const uint8_t base = any == 3 ? 1 : 0, gt = lgt[any], ac = lac[any], bo = sp->both_ori ? 1 : 0;
-        uint8_t f5[16], f3[16];
+        uint8_t* f5 = w.f5;
+        uint8_t* f3 = w.f3;
         for (int c = 0; c < 16; ++c) f5[c] = f3[c] = base;
         enum { AA, AC, AG, AT, CA, CC, CG, CT, GA, GC, GG, GT, TA, TC, TG, TT };
         f3[AA] = ac;
@@ -919,11 +943,6 @@ inline bool bind_problem(SeedWalk& w, const SpdpScoring* sc, const SpdpSeedParam
         f5[GT] = 3; if (bo) f3[GT] = 1;
         f3[TG] = gt;
         f5[TT] = gt;
-        w.lvl5.assign(N, 0); w.lvl3.assign(N, 0);
-        for (int n = 0; n < N; ++n) {
-            if (p->cano5[n]) w.lvl5[n] = f5[p->dinc[n] >> 4] ? f5[p->dinc[n] >> 4] : p->cano5[n];
-            if (p->cano3[n]) w.lvl3[n] = f3[p->dinc[n] & 15] ? f3[p->dinc[n] & 15] : p->cano3[n];
-        }
     }
     w.top_hsps.clear();
     if (hsps && n_hsps > 0)

@@ -145,8 +145,11 @@ public:
     const int16_t *sig5 = nullptr, *sig3 = nullptr, *sigS = nullptr, *sigT = nullptr, *sigE = nullptr;
     const uint8_t* dinc = nullptr;
     const int32_t* cip = nullptr;               // Cip_score::cip_score(c), c = 0 .. 3 a_len + 1, or null
-    std::vector<int8_t> phs5, phs3;             // SGPT6::phs5 / phs3: the walk marks the junctions it accepts (:2511-2516)
-    std::vector<uint8_t> lvl5, lvl3;            // INT53::cano5 / cano3 levels
+    PhaseMarks phs5, phs3;                      // SGPT6::phs5 / phs3: the walk marks the junctions it accepts (:2511-2516)
+    uint8_t f5[16] = {0}, f3[16] = {0};         // INT53::cano5 / cano3 levels by dinucleotide class; the classes exist for
+    int lv_left = 0, lv_right = 0;              // [exin_left, exin_right): dinc5 of position i - 1 and dinc3 of i + 1 come from base i
+    int lvl5(int n) const { return (n >= lv_left - 1 && n < lv_right - 1 && n >= 0 && n <= b_len) ? f5[dinc[n] >> 4] : 0; }
+    int lvl3(int n) const { return (n >= lv_left + 1 && n <= lv_right && n >= 0 && n <= b_len) ? f3[dinc[n] & 15] : 0; }
     const SpdpScoringH* sc = nullptr;
     const SpdpSeedParams* sp = nullptr;
     DpBackendH* dp = nullptr;
@@ -188,7 +191,7 @@ public:
     int junction_score(int n5, int n3) const { return int_pen(n3 - n5) + sig3[n3] + t53(n5, n3); }   // SpJunc::spjscr
     int is_canon(int d, int ac) const
     {
-        const int c5 = lvl5[d], c3 = lvl3[ac];
+        const int c5 = lvl5(d), c3 = lvl3(ac);
         return ((c5 == 3 && c3 == 3) || (c5 == 2 && c3 == 2) || (c5 == 1 && c3) || (c5 && c3 == 1)) ? c5 + c3 : 0;
     }
     // PwdB::GapPenalty3(i), src/aln2.cc:41-52
@@ -409,10 +412,10 @@ public:
         if (!all_mch || iscr <= NEV()) return false;
         if (write) {
             rec.push_back(k);
-            phs5[k.n] = (int8_t) phs53;
+            phs5.set(k.n, (int8_t) phs53);
             k.n += dgap;
             rec.push_back(k);
-            phs3[k.n] = (int8_t) phs53;
+            phs3.set(k.n, (int8_t) phs53);
             iscr += int_pen(dgap);
         }
         return true;
@@ -1161,25 +1164,21 @@ inline bool bind_problem_h(SeedWalkH& w, const SpdpScoringH* sc, const SpdpSeedP
     w.sig5 = p->sig5; w.sig3 = p->sig3; w.sigS = p->sigS; w.sigT = p->sigT; w.sigE = p->sigE; w.dinc = p->dinc; w.cip = p->cip;
     w.sc = sc; w.sp = sp; w.lowest_level = lowest_level;
     const int N = p->b_len + 3;
-    w.phs5.assign(p->phs5, p->phs5 + N);
-    w.phs3.assign(p->phs3, p->phs3 + N);
+    w.phs5.bind(p->phs5); w.phs3.bind(p->phs3);
+    (void) N;
     spdp_genetic_code_tables(w.mid, w.tron_of);
     {   // canonical-site levels by dinucleotide class (Exinon::intron53_c, src/codepot.cc:435-475), as in bind_problem
         static const uint8_t lac[4] = {0, 2, 3, 1}, lgt[4] = {0, 0, 3, 1};
         const int any = sp->any & 3;
         const uint8_t base = any == 3 ? 1 : 0, gt = lgt[any], ac = lac[any], bo = sp->both_ori ? 1 : 0;
-        uint8_t f5[16], f3[16];
+        uint8_t* f5 = w.f5;
+        uint8_t* f3 = w.f3;
         for (int c = 0; c < 16; ++c) f5[c] = f3[c] = base;
         enum { AA, AC, AG, AT, CA, CC, CG, CT, GA, GC, GG, GT, TA, TC, TG, TT };
         f3[AA] = ac; f3[AC] = 2; if (bo) f5[AC] = 1;
         f3[AG] = 3; f5[AT] = 2; f3[AT] = ac; f3[CG] = gt; f5[CT] = gt; if (bo) f3[CT] = 1;
         f5[GA] = gt; f5[GC] = 3; f5[GG] = gt; f3[GG] = gt; f5[GT] = 3; if (bo) f3[GT] = 1; f3[TG] = gt; f5[TT] = gt;
-        w.lvl5.assign(N, 0); w.lvl3.assign(N, 0);
-        // the classes exist for [b_left, b_right): dinc5 of position i - 1 and dinc3 of i + 1 come from base i
-        for (int n = 0; n <= p->b_len; ++n) {
-            if (n >= p->exin_left - 1 && n < p->exin_right - 1) w.lvl5[n] = f5[p->dinc[n] >> 4];
-            if (n >= p->exin_left + 1 && n <= p->exin_right) w.lvl3[n] = f3[p->dinc[n] & 15];
-        }
+        w.lv_left = p->exin_left; w.lv_right = p->exin_right;
     }
     w.top_hsps.clear();
     if (hsps && n_hsps > 0)

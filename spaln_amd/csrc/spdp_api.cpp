@@ -306,6 +306,19 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
         std::vector<int> t_s5(n_thr, INT32_MIN), t_s3(n_thr, INT32_MIN);
+        // the copy of a group of problems (~8 M positions) starts as soon as the group is packed, under the packing of the next ones
+        std::vector<int> grp_first, grp_of(n);
+        {
+            int64_t acc = 0;
+            for (int i = 0; i < n; ++i) {
+                if (i == 0 || acc >= (8 << 20)) { grp_first.push_back(i); acc = 0; }
+                grp_of[i] = (int) grp_first.size() - 1;
+                acc += (int64_t) probs[i].b_len + 1 + SPDP_COL_PAD;
+            }
+        }
+        const int n_grp = (int) grp_first.size();
+        std::vector<std::atomic<int>> grp_done(n_grp);
+        for (auto& g : grp_done) g.store(0);
         std::atomic<int> next_prob{0};
         auto pack = [&](int t) {
             int m5 = INT32_MIN, m3 = INT32_MIN;
@@ -330,18 +343,26 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
                     cr[1] = nn > 0 ? p.b[nn - 1] : 0;
                 }
                 memset(cr, 0, 2 * SPDP_COL_PAD * sizeof(int32_t));
+                grp_done[grp_of[i]].fetch_add(1, std::memory_order_release);
             }
             t_s5[t] = m5; t_s3[t] = m3;
         };
         {
             std::vector<std::thread> th;
-            for (int t = 1; t < n_thr; ++t) th.emplace_back(pack, t);
-            pack(0);
+            for (int t = 0; t < n_thr; ++t) th.emplace_back(pack, t);
+            hipError_t ce = hipSuccess;
+            for (int g = 0; g < n_grp && ce == hipSuccess; ++g) {
+                const int first = grp_first[g], last = g + 1 < n_grp ? grp_first[g + 1] : n;
+                while (grp_done[g].load(std::memory_order_acquire) < last - first) std::this_thread::yield();
+                const int64_t c0 = col_off[first], c1 = last < n ? col_off[last] : col_tot;
+                ce = hipMemcpyAsync((int32_t*) d_cols + 2 * c0, hc + 2 * c0, (size_t) (c1 - c0) * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+                if (ce == hipSuccess && has_exact)
+                    ce = hipMemcpyAsync((uint8_t*) d_aux + 2 * c0, hx + 2 * c0, (size_t) (c1 - c0) * 2, hipMemcpyHostToDevice, ctx->stream);
+            }
             for (std::thread& t : th) t.join();
+            HIPCHK(ce);
         }
         for (int t = 0; t < n_thr; ++t) { max_s5 = std::max(max_s5, t_s5[t]); max_s3 = std::max(max_s3, t_s3[t]); }
-        HIPCHK(hipMemcpyAsync(d_cols, hc, nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (has_exact) HIPCHK(hipMemcpyAsync(d_aux, hx, nc, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));          // the staging buffers are the context's: one upload at a time
     }
     sc.sigmodel = nullptr;                                   // the caller's model is not ours to keep

@@ -204,16 +204,50 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         }
         for (int x = N; x < col_len[i]; ++x) { cols[c0 + x] = make_int4(0, 0, 0, 0); aux[c0 + x] = make_short4(0, 0, 0, 0); }
     };
+    if (n && !dev_sig) {
+        d_cols = pool.get(HP_COLS, (size_t) c_tot * sizeof(int4));
+        d_aux = pool.get(HP_AUX, (size_t) c_tot * sizeof(short4));
+        if (!d_cols || !d_aux) { ctx->err = "device allocation failed (aa x genome inputs)"; return -1; }
+    }
     {
         int n_thr = spdp_host_cpus();
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
+        // the copy of a group of problems (~4 M positions) starts as soon as the group is packed, under the packing of the next ones
+        std::vector<int> grp_first, grp_of(n);
+        {
+            int64_t acc = 0;
+            for (int i = 0; i < n; ++i) {
+                if (i == 0 || acc >= (4 << 20)) { grp_first.push_back(i); acc = 0; }
+                grp_of[i] = (int) grp_first.size() - 1;
+                acc += col_len[i];
+            }
+        }
+        const int n_grp = (int) grp_first.size();
+        std::vector<std::atomic<int>> grp_done(std::max(1, n_grp));
+        for (auto& g : grp_done) g.store(0);
         std::atomic<int> next_prob{0};
-        auto pack = [&]() { for (;;) { const int i = next_prob.fetch_add(1); if (i >= n) break; pack_one(i); } };
+        auto pack = [&]() {
+            for (;;) {
+                const int i = next_prob.fetch_add(1);
+                if (i >= n) break;
+                pack_one(i);
+                grp_done[grp_of[i]].fetch_add(1, std::memory_order_release);
+            }
+        };
         std::vector<std::thread> th;
-        for (int t = 1; t < n_thr; ++t) th.emplace_back(pack);
-        pack();
+        for (int t = 0; t < n_thr; ++t) th.emplace_back(pack);
+        hipError_t ce = hipSuccess;
+        for (int g = 0; g < n_grp && !dev_sig && ce == hipSuccess; ++g) {
+            const int first = grp_first[g], last = g + 1 < n_grp ? grp_first[g + 1] : n;
+            while (grp_done[g].load(std::memory_order_acquire) < last - first) std::this_thread::yield();
+            const int64_t c0 = col_off[first], c1 = last < n ? col_off[last] : c_tot;
+            ce = hipMemcpyAsync((int4*) d_cols + c0, cols + c0, (size_t) (c1 - c0) * sizeof(int4), hipMemcpyHostToDevice, ctx->stream);
+            if (ce == hipSuccess)
+                ce = hipMemcpyAsync((short4*) d_aux + c0, aux + c0, (size_t) (c1 - c0) * sizeof(short4), hipMemcpyHostToDevice, ctx->stream);
+        }
         for (std::thread& t : th) t.join();
+        HIPCHK(ce);
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;
     for (int i = 0; i < n && !dev_sig; ++i) if (!probs[i].dinc) scalar_ok = false;      // (device-made signals bring dinc along)
@@ -243,18 +277,17 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     }
     d_sc = pool.get(HP_SC, sizeof ds);
     d_a = pool.get(HP_A, a_all.size() + 16);
-    d_cols = pool.get(HP_COLS, (size_t) c_tot * sizeof(int4));
-    d_aux = pool.get(HP_AUX, (size_t) c_tot * sizeof(short4));
+    if (dev_sig) {
+        d_cols = pool.get(HP_COLS, (size_t) c_tot * sizeof(int4));
+        d_aux = pool.get(HP_AUX, (size_t) c_tot * sizeof(short4));
+    }
     if (!d_sc || !d_a || !d_cols || !d_aux) { ctx->err = "device allocation failed (aa x genome inputs)"; return -1; }
     HIPCHK(hipMemcpyAsync(d_sc, &ds, sizeof ds, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_a, a_all.data(), a_all.size(), hipMemcpyHostToDevice, ctx->stream));
     if (dev_sig) {                              // (made on the device below: only zeros for the padding now)
         HIPCHK(hipMemsetAsync(d_cols, 0, (size_t) c_tot * sizeof(int4), ctx->stream));
         HIPCHK(hipMemsetAsync(d_aux, 0, (size_t) c_tot * sizeof(short4), ctx->stream));
-    } else {
-        HIPCHK(hipMemcpyAsync(d_cols, cols, (size_t) c_tot * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_aux, aux, (size_t) c_tot * sizeof(short4), hipMemcpyHostToDevice, ctx->stream));
-    }
+    }                                           // (else: copied group by group above)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (dev_sig) {
         // only the tron codes crossed PCIe (1 B per position instead of 24): spdp_signals_h.hip writes the column records

@@ -23,7 +23,7 @@ static bool g_undefined = false;		// the library flagged the input as undefined 
 static VTYPE HomScoreS_gpu(const Seq* seqs[], const PwdB* pwd) {	// == HomScoreS_ng, -A2/-A3
 	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  int32_t scr;  SeedCols c;
 	fill_scoring(sc, pwd, seqs[1]);  fill_problem(p, seqs[0], seqs[1], s5, s3);
-	if (algmode.alg < 2) fill_exact_s(sc, p, seqs[1], pwd, c);	// -A0 / -A1: the exact intron-length engines
+	fill_exact_s(sc, p, seqs[1], pwd, c);	// the exact intron-length engines: -A0 / -A1, and sub-problems below 8 query rows under every -A
 	if (spdp_homscore_s(g_ctx, &sc, &p, 1, &scr)) fatal("%s\n", spdp_last_error(g_ctx));
 	return scr;
 }
@@ -31,7 +31,7 @@ static VTYPE HomScoreS_gpu(const Seq* seqs[], const PwdB* pwd) {	// == HomScoreS
 static SKL* alignS_gpu(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi) {	// == alignS_ng(.., ori = 1), -Q0/-Q4
 	SpdpScoring sc;  SpdpProblem p;  std::vector<int16_t> s5, s3;  SpdpAlignment al;  SeedCols c;
 	fill_scoring(sc, pwd, seqs[1]);  fill_problem(p, seqs[0], seqs[1], s5, s3);
-	if (algmode.alg < 2) fill_exact_s(sc, p, seqs[1], pwd, c);
+	fill_exact_s(sc, p, seqs[1], pwd, c);		// (a ladder under -A2 / -A3 meets sub-problems below 8 rows too: small MaxVmfSpace, deep recursion)
 	if (spdp_align_s(g_ctx, &sc, &p, 1, &al) < 0) fatal("%s\n", spdp_last_error(g_ctx));
 	gsi->scr = al.score;
 	if (!al.n_skl) return 0;			// "no alignment", as the reference
@@ -47,7 +47,7 @@ static SKL* alignH_gpu(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int exin
 	SpdpScoringH sc;  SpdpProblemH p;  HCols c;  SpdpAlignment al;  SeedCols sx;
 	fill_scoring_h(sc, pwd, seqs[1]);  fill_problem_h(p, seqs[0], seqs[1], c, exin_left, exin_right);
 	p.a_pad = *seqs[0]->at(seqs[0]->len);
-	if (algmode.alg < 2) fill_exact_h(sc, p, seqs[1], pwd, sx);	// -A0 / -A1
+	fill_exact_h(sc, p, seqs[1], pwd, sx);		// -A0 / -A1, and sub-problems below 8 rows under every -A
 const	int rc = spdp_align_h(g_ctx, &sc, &p, 1, &al);
 	if (rc < 0) fatal("%s\n", spdp_last_error(g_ctx));
 	if (rc == 1 || al.n_skl < 0) {			// engine not built / reference-undefined input: a production shim falls

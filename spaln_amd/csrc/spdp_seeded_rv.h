@@ -96,6 +96,7 @@ struct WalkScheduler {
     std::function<void(int, Fiber&)> body;
     std::vector<int> order;                             // walk started k-th (empty: k); longest first shortens the tail of a call
     bool oom = false;
+    int stack_limit = -1;                               // SPDP_SEED_TEST_STACKS: pretend mmap fails beyond so many fibers
     int64_t cpu_ns = 0;                                 // thread CPU time inside walks, all workers
 
     static void entry(unsigned lo, unsigned hi)
@@ -110,6 +111,7 @@ struct WalkScheduler {
         Fiber* f;
         if (!idle_fibers.empty()) { f = idle_fibers.back(); idle_fibers.pop_back(); }
         else {
+            if (stack_limit >= 0 && (int) all_fibers.size() >= stack_limit) return nullptr;     // (test hook)
             void* m = mmap(nullptr, STACK + GUARD, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
             if (m == MAP_FAILED) return nullptr;
             (void) mprotect(m, GUARD, PROT_NONE);       // a walk that outgrows its stack stops here, not in another walk's
@@ -137,8 +139,10 @@ struct WalkScheduler {
                 if (next < n_walks && in_flight < max_in_flight && !oom) {
                     f = fresh(order.empty() ? next : order[next]);
                     if (f) { ++next; ++in_flight; break; }
-                    oom = true;                         // no stack for another walk: go on with those in flight
-                    if (!in_flight) { done = n_walks; cv_main.notify_all(); cv_work.notify_all(); return; }
+                    // no stack for another walk (address space, vm.max_map_count): those in flight are what there is, the
+                    // rest start as their fibers come free; not even one: the call fails
+                    if (in_flight > 0) max_in_flight = in_flight;
+                    else { oom = true; done = n_walks; next = n_walks; cv_main.notify_all(); cv_work.notify_all(); return; }
                 }
                 if (done >= n_walks) return;
                 cv_work.wait(lk);
@@ -187,6 +191,7 @@ struct WalkScheduler {
         if (const char* e = getenv("SPDP_SEED_BATCH")) batch_target = std::max(1, atoi(e));
         n_threads = std::min(32, spdp_host_cpus());     // (threads beyond the CPUs granted only contend: 16 granted, measured 8 / 16 / 32 / 64)
         if (const char* e = getenv("SPDP_SEED_THREADS")) n_threads = std::max(1, atoi(e));
+        if (const char* e = getenv("SPDP_SEED_TEST_STACKS")) stack_limit = atoi(e);
         n_threads = std::min(n_threads, n);
         std::vector<std::thread> pool;
         for (int t = 0; t < n_threads; ++t) pool.emplace_back([this] { worker(); });

@@ -46,3 +46,11 @@ def test_one_walk_one_thread_and_a_deep_recursion():
 def test_more_walks_than_fibers_in_flight():
     nb, out, want = _run(3000, 4, 5, (2, 1, 1), {"SPDP_SEED_THREADS": "4", "SPDP_SEED_WALKS": "7", "SPDP_SEED_BATCH": "1000"})
     assert np.array_equal(out, want)
+
+
+def test_out_of_stacks_caps_the_walks_in_flight():
+    # mmap "fails" after 5 fibers: the other walks start as those fibers come free; with none at all the call fails
+    nb, out, want = _run(400, 4, 5, (2, 1, 1), {"SPDP_SEED_THREADS": "4", "SPDP_SEED_TEST_STACKS": "5"})
+    assert nb > 0 and np.array_equal(out, want)
+    nb, out, want = _run(400, 4, 5, (2, 1, 1), {"SPDP_SEED_THREADS": "4", "SPDP_SEED_TEST_STACKS": "0"})
+    assert nb == -1

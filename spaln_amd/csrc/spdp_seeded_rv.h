@@ -57,7 +57,7 @@ struct Fiber {
 };
 
 // dispatcher lanes per latency class, shortest class first: "a,b,c,.." in SPDP_SEED_LANES overrides the defaults (a 0 merges
-// that class into the one above it; "1" = one lane, no classes); a small call gets one lane and one class.
+// that class into the one above it; "1" = one lane, no classes); a call of fewer than 64 walks gets one lane and one class.
 // Returns the class each lane serves.
 inline std::vector<int> lanes_per_class(int n_walks, std::vector<int> k)
 {
@@ -66,7 +66,7 @@ inline std::vector<int> lanes_per_class(int n_walks, std::vector<int> k)
         for (const char* p = e; *p; ) { v.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
         if (!v.empty()) k = v;
     }
-    if (n_walks < 256) k.assign(1, 1);
+    if (n_walks < 64) k.assign(1, 1);
     std::vector<int> class_of_lane;
     int cls = 0;
     for (size_t c = 0; c < k.size(); ++c) {

@@ -79,6 +79,13 @@ inline std::vector<int> lanes_per_class(int n_walks, std::vector<int> k)
 // class of a request whose sweep takes `steps`: how many of the thresholds it reaches, within the classes that have lanes
 inline int latency_class(int64_t steps, const int64_t* thr, int n_thr, int n_cls)
 {
+    static const std::vector<int64_t> env_thr = [] {            // SPDP_SEED_THR=a,b,..: other thresholds (tuning)
+        std::vector<int64_t> v;
+        if (const char* e = getenv("SPDP_SEED_THR"))
+            for (const char* p = e; *p; ) { v.push_back(atoll(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        return v;
+    }();
+    if (!env_thr.empty()) { thr = env_thr.data(); n_thr = (int) env_thr.size(); }
     int c = 0;
     while (c < n_thr && steps >= thr[c]) ++c;
     return std::min(c, n_cls - 1);

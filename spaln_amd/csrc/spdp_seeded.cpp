@@ -183,10 +183,12 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     // engine (fewer than 8 rows, cut ranges) takes about eight times as long per step.  Two dispatchers for the short class:
     // its batches are bound by launch and read-back latency, not by the device
     const int n_cls = class_of_lane.back() + 1;
-    auto cls = [n_cls](const Parked& q) {
+    int64_t scalar_w = 8;
+    if (const char* e = getenv("SPDP_SEED_SCALAR_W")) scalar_w = std::max(1, atoi(e));      // (tuning)
+    auto cls = [n_cls, scalar_w](const Parked& q) {
         const int rows = q.s.ar - q.s.al;
         const int64_t cols = std::max<int64_t>(0, (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
-        const int64_t steps = (rows < 8 || q.kind == 2) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
+        const int64_t steps = (rows < 8 || q.kind == 2) ? scalar_w * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
         static const int64_t thr[] = {1500, 6000, 20000};            // (four classes measured: no gain over three; the defaults give lanes to the first three)
         return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };

@@ -156,10 +156,12 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     // three times, as the three phases of a protein column suggest, a third of all requests landed in the long class and waited
     // for its 30 ms batches -- 20 000 pairs 0.39 s against 0.29 s.)
     const int n_cls = class_of_lane.back() + 1;
-    auto cls = [n_cls](const Parked& q) {
+    int64_t scalar_w = 8;
+    if (const char* e = getenv("SPDP_SEED_SCALAR_W")) scalar_w = std::max(1, atoi(e));      // (tuning)
+    auto cls = [n_cls, scalar_w](const Parked& q) {
         const int rows = q.s.ar - q.s.al;
         const int64_t cols = std::max<int64_t>(0, (int64_t) std::min(q.s.br - q.s.bl, q.w.up - q.w.lw + 3 * rows) - (q.cut[1] > q.cut[0] ? q.cut[1] - q.cut[0] : 0));
-        const int64_t steps = (rows < 8 || q.kind != 0) ? 8 * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
+        const int64_t steps = (rows < 8 || q.kind != 0) ? scalar_w * (cols + rows) : (int64_t) ((rows + 63) / 64) * cols;
         static const int64_t thr[] = {1500, 6000, 18000, 45000};     // (five classes measured: no gain over three; the defaults give lanes to the first three)
         return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };

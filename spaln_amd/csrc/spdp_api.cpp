@@ -149,6 +149,8 @@ void DevPool::release()
     for (int i = 0; i < N_SLOTS; ++i) { if (ptr[i]) (void) hipFree(ptr[i]); ptr[i] = nullptr; cap[i] = 0; }
 }
 
+thread_local bool t_lane_copies = false;         // spdp_internal.h, spdp_copy_sync
+
 // lane i of a context: lane 0 is the context itself, the others are contexts of their own (streams, events, pools)
 // on the same device, created on first use and owned by the parent
 SpdpContext* spdp_lane(SpdpContext* ctx, int i)

@@ -1193,6 +1193,7 @@ void spdh_store_close(HStore* st) { delete st; }
 int spdh_run_requests(HStore* st, const SpdhRequest* reqs, int n, SpdpAlignment* out, SpdpContext* lane)
 {
     struct LaneScope { LaneScope(SpdpContext* l) { t_lane = l; } ~LaneScope() { t_lane = nullptr; } } scope(lane);
+    LaneCopies own_stream;
     std::vector<HTop> tops;
     HStats hs;
     for (int k = 0; k < n; ++k) { out[k].score = SPDP_NEVSEL; out[k].n_skl = 0; out[k].skl = nullptr; out[k].flags = 0; out[k].reserved = 0; }

@@ -694,7 +694,7 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     }
     std::vector<std::thread> workers;
     for (int c = 1; c < n_chunks; ++c)
-        workers.emplace_back([&, c]() { (void) hipSetDevice(ctx->device); rc[c] = al[c].run(); });
+        workers.emplace_back([&, c, lane_copies = t_lane_copies]() { (void) hipSetDevice(ctx->device); t_lane_copies = lane_copies; rc[c] = al[c].run(); });
     rc[0] = al[0].run();
     for (std::thread& t : workers) t.join();
     for (int c = 0; c < n_chunks; ++c) if (gates[c].ev) (void) hipEventDestroy(gates[c].ev);
@@ -770,6 +770,7 @@ int spdp_run_requests(SpdpContext* ctx, const DevStore* st, const SpdpProblem* p
 {
     for (int i = 0; i < n; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n <= 0) return 0;
+    LaneCopies own_stream;                      // (request batches are small: one chunk, this thread)
     return align_on_store(ctx, st, probs, n, out, nullptr, nullptr, nullptr, true, req);
 }
 

@@ -228,11 +228,17 @@ struct DevPool {
 enum { POOL_PROBS = 0, POOL_BND, POOL_TB, POOL_IMD, POOL_RES, POOL_SKL, POOL_NSKL, POOL_CPOS,
        POOL_RANGES, POOL_SCORES, POOL_SKLPACK, POOL_SKLOFF, POOL_GPROG, POOL_FLAV_STRIDE = 0 };
 
-// a blocking copy that waits for ONE stream.  hipMemcpy goes through the null stream, which first waits for every blocking
-// stream of the process -- with several contexts at work (lanes of a chunked batch, the dispatchers of the seeded path) a
-// 16-byte read-back then waits for another lane's multi-millisecond sweep
+// a blocking copy.  hipMemcpy goes through the null stream, which first waits for every blocking stream of the process.  For the
+// request batches of the seeded path -- several dispatcher lanes at work, a 16-byte read-back of the short class would wait
+// for the long class's multi-millisecond sweep -- the copy waits for its OWN stream only (t_lane_copies, set by
+// spdp_run_requests / spdh_run_requests for the duration of the call).  Everywhere else the null-stream form stays: in the
+// chunked ladder of spdp_align_s it keeps one chunk's slab sweeps from starting under the other chunk's linear-space sweep,
+// which changes nothing end to end (290 ms a step either way) but is how the kernels of the headline step were profiled.
+extern thread_local bool t_lane_copies;
+struct LaneCopies { bool was; LaneCopies() : was(t_lane_copies) { t_lane_copies = true; } ~LaneCopies() { t_lane_copies = was; } };
 static inline hipError_t spdp_copy_sync(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s)
 {
+    if (!t_lane_copies) return hipMemcpy(dst, src, n, kind);
     const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s);
     return e != hipSuccess ? e : hipStreamSynchronize(s);
 }

@@ -480,12 +480,6 @@ class ProblemSetH:
             assert cp.size >= 3 * a.size + 2
             self._keep.append(cp)
             p.cip = cp.ctypes.data
-        if phs5 is not None:
-            h5 = np.ascontiguousarray(phs5, dtype=np.int8)
-            h3 = np.ascontiguousarray(phs3, dtype=np.int8)
-            assert min(h5.size, h3.size) >= b.size + 1
-            self._keep += [h5, h3]
-            p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
         self.items.append(p)
         return p
 

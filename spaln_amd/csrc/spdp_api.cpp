@@ -362,6 +362,7 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
                     ce = hipMemcpyAsync((uint8_t*) d_aux + 2 * c0, hx + 2 * c0, (size_t) (c1 - c0) * 2, hipMemcpyHostToDevice, ctx->stream);
             }
             for (std::thread& t : th) t.join();
+            if (ce != hipSuccess) (void) hipStreamSynchronize(ctx->stream);   // copies already issued still read the staging
             HIPCHK(ce);
         }
         for (int t = 0; t < n_thr; ++t) { max_s5 = std::max(max_s5, t_s5[t]); max_s3 = std::max(max_s3, t_s3[t]); }

@@ -247,6 +247,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
                 ce = hipMemcpyAsync((short4*) d_aux + c0, aux + c0, (size_t) (c1 - c0) * sizeof(short4), hipMemcpyHostToDevice, ctx->stream);
         }
         for (std::thread& t : th) t.join();
+        if (ce != hipSuccess) (void) hipStreamSynchronize(ctx->stream);       // copies already issued still read the staging
         HIPCHK(ce);
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;

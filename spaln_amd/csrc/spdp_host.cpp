@@ -669,6 +669,9 @@ static int align_on_store(SpdpContext* ctx, const DevStore* st, const SpdpProble
     int n_chunks = n >= 4096 ? 2 : 1;
     if (const char* e = getenv("SPDP_CHUNKS")) n_chunks = std::max(1, std::min(atoi(e), 8));
     n_chunks = std::min(n_chunks, std::max(1, n / 64));
+    // a request batch runs on the dispatcher lane that took it, as ONE chunk: chunk lanes are spdp_lane(ctx, c), and for
+    // the seeded dispatchers those are the contexts their sibling dispatchers run on from their own threads
+    if (req) n_chunks = 1;
     std::vector<Aligner> al(n_chunks);
     std::vector<ChunkGate> gates(n_chunks);
     std::vector<int> rc(n_chunks, 0);

@@ -95,17 +95,17 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     recs.assign(n_probs, std::vector<SpdpSkl>());
     status.assign(n_probs, 0);                          // 1: the walk met a state it does not serve, 2: a request failed
     auto walk = [&](int q, Fiber& fb) {
-        DeviceBackend be;
-        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
-        SeedWalk w;
-        const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-        const int64_t tb0 = cpu_ns();
-        if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
-        ns_bind += cpu_ns() - tb0;
-        w.dp = &be;
-        const SpdpProblem& p = probs[q];
-        const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-        try {
+        try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
+            DeviceBackend be;
+            be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
+            SeedWalk w;
+            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+            const int64_t tb0 = cpu_ns();
+            if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
+            ns_bind += cpu_ns() - tb0;
+            w.dp = &be;
+            const SpdpProblem& p = probs[q];
+            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
             scores[q] = w.run(whole);
             recs[q].swap(w.rec);
             status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
@@ -121,7 +121,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     const int n_lanes = (int) class_of_lane.size();
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) return -1;       // (created here, on one thread)
     int busy_lanes = 0;
-    int64_t lane_n[16] = {0}, lane_us[16] = {0}, lane_req[16] = {0};
+    std::vector<int64_t> lane_n(n_lanes, 0), lane_us(n_lanes, 0), lane_req(n_lanes, 0);
     auto device = [&](std::vector<Parked*>& take, int lane) {
         (void) hipSetDevice(ctx->device);
         { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
@@ -168,7 +168,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         if (brc >= 0) spdp_free_alignments(res.data(), m);
         std::lock_guard<std::mutex> g(stats_mu);
         ++n_batches;
-        lane_n[lane & 15] += 1; lane_us[lane & 15] += us_dev; lane_req[lane & 15] += m;
+        lane_n[lane] += 1; lane_us[lane] += us_dev; lane_req[lane] += m;
         for (int k = 0; k < m; ++k) ++n_kind[take[k]->kind];
         us_device += us_dev; us_hand += us_since(t0);
         if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();

@@ -85,15 +85,15 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     std::vector<std::vector<SpdpSkl>> recs(n_probs);
     std::vector<uint8_t> status(n_probs, 0);            // 1: the walk met a state it does not serve, 2: a request failed
     auto walk = [&](int q, Fiber& fb) {
-        DeviceBackendH be;
-        be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
-        SeedWalkH w;
-        const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-        if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
-        w.dp = &be;
-        const SpdpProblemH& p = probs[q];
-        const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-        try {
+        try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
+            DeviceBackendH be;
+            be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+            SeedWalkH w;
+            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+            if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
+            w.dp = &be;
+            const SpdpProblemH& p = probs[q];
+            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
             scores[q] = w.run(whole);
             recs[q].swap(w.rec);
             status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
@@ -108,7 +108,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     const int n_lanes = (int) class_of_lane.size();
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) { spdh_store_close(st); return -1; }     // (created here, on one thread)
     int busy_lanes = 0;
-    int64_t lane_n[16] = {0}, lane_us[16] = {0}, lane_req[16] = {0};
+    std::vector<int64_t> lane_n(n_lanes, 0), lane_us(n_lanes, 0), lane_req(n_lanes, 0);
     auto device = [&](std::vector<Parked*>& take, int lane) {
         (void) hipSetDevice(ctx->device);
         { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
@@ -139,7 +139,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         if (brc >= 0) spdp_free_alignments(res.data(), m);
         std::lock_guard<std::mutex> g(stats_mu);
         ++n_batches;
-        lane_n[lane & 15] += 1; lane_us[lane & 15] += us_dev; lane_req[lane & 15] += m;
+        lane_n[lane] += 1; lane_us[lane] += us_dev; lane_req[lane] += m;
         for (int k = 0; k < m; ++k) { ++n_kind[take[k]->kind & 3]; if (take[k]->cut[1] > take[k]->cut[0]) ++n_cut; }
         us_device += us_dev; us_hand += us_since(t0);
         if (!--busy_lanes) t_idle = std::chrono::steady_clock::now();

@@ -21,6 +21,7 @@
 // after the other.  This is the exactness engine, not a throughput path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "spdp_h_dev.h"
 #include "spdp_h_internal.h"
 
@@ -38,16 +39,22 @@ __device__ __forceinline__ int xh_w16(int x) { return (int) (short) x; }
 __device__ __forceinline__ int xh_up(int v) { return __shfl_up(v, 1, XN); }
 __device__ __forceinline__ int xh_mod6(int x) { x %= 6; return x < 0 ? x + 6 : x; }
 
-template <bool UDH>
-__global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
+// G = 16-lane groups (problems) per wave: a wave issues the same instructions for one group as for four, so a launch
+// with fewer problems than the chip has wave slots runs one problem per wave (four times the waves in flight)
+template <bool UDH, int G>
+__global__ void __launch_bounds__(16 * G) spdh_exact(HScalarArgs A)
 {
-    __shared__ int L[S_END][64];
+    __shared__ int L[S_END][16 * G];
+    __shared__ int Lmtx[32 * 32];                // the substitution matrix (aa x tron, row stride 32)
+    __shared__ int Lvcnt[G];                     // Vmf record counters: only this group appends to its problem's list
     const int t = threadIdx.x;
     const int k = t & 15;
-    const int pi = blockIdx.x * 4 + (t >> 4);
+    const int pi = blockIdx.x * G + (t >> 4);
+    const DevScoringH* sc = A.sc;
+    for (int e = t; e < 32 * 32; e += 16 * G) Lmtx[e] = sc->mtx[e];
+    __syncthreads();
     if (pi >= A.n_probs) return;                 // a whole 16-lane group leaves together
     const DevProblemH P = A.probs[pi];
-    const DevScoringH* sc = A.sc;
     const int a_left = P.a_left, a_right = P.a_right, b_left = P.b_left, b_right = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width, B = P.buf_size;
     const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
@@ -66,7 +73,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
     int* fb = hb + B;
     int* hc = fb + B;
     int* fc = hc + B;
-    int* vcount = A.work + P.bnd_off + 6 * (int64_t) B;
+    int* vcount = &Lvcnt[t >> 4];
     int3* vrec = A.vmf + (UDH ? 0 : P.tb_off);
     const int vcap = UDH ? 0 : (int) P.imd_off;
     auto vadd = [&](int mm, int nn, int pp) -> int {
@@ -81,7 +88,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
     auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
     auto acode = [&](int i) -> int { return i < 0 ? 2 : (i >= P.a_len ? P.a_pad : acod[i]); };      // a_pad: SpdpProblemH
     auto bcode = [&](int i) -> int { return (i < 0 || i > P.b_len) ? 2 : ((cols[i + 2].x >> 16) & 0xff); };
-    auto mtx = [&](int aa, int tron) -> int { return sc->mtx[aa * 32 + tron]; };
+    auto mtx = [&](int aa, int tron) -> int { return Lmtx[aa * 32 + tron]; };
     auto ipen = [&](int len) -> int {
         if (len < 0) return -32768;
         if (len >= A.intpen_len) len = A.intpen_len - 1;
@@ -219,7 +226,19 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
         const int mm3 = 3 * mi;
         const bool imd_lane = UDH && imd_i < n_im && (m + 1) == mi;      // Sjsites' is_imd for my row
         const bool site_lane = spj && k <= j8 && (m + 1) < a_right;
-        const int* mrow = sc->mtx + ((k < j9) ? acod[ml + k] : 0) * 32;
+        const int* mrow = Lmtx + ((k < j9) ? acod[ml + k] : 0) * 32;
+        // loads one step ahead of their use: my column's record, and (lane 0) the one new entry per boundary row that
+        // slides into the window hv / hc [r .. r + 3], fv / fc [r + 3], hb [r] -- this stripe writes those rows only
+        // behind lane 0's read position (r - 6 j8 and further back), so an entry read a step early is the entry
+        const int c_hi = P.b_len + 2;
+        int cx_next = cols[min(max(n - 3 * k, 0), c_hi)].x;
+        int wH0 = 0, wH1 = 0, wH2 = 0, wH3 = 0, wC0 = 0, wC1 = 0, wC2 = 0, wC3 = 0, wF = 0, wFC = 0, wB = 0;
+        if (k == 0) {
+            wH0 = hv[r]; wH1 = hv[r + 1]; wH2 = hv[r + 2]; wH3 = hv[r + 3];
+            wC0 = hc[r]; wC1 = hc[r + 1]; wC2 = hc[r + 2]; wC3 = hc[r + 3];
+            wF = fv[r + 3]; wFC = fc[r + 3];
+            if (!UDH || LocalL) wB = hb[r];
+        }
         for ( ; n < n9; ++n, ++r, q = xh_mod6(q + 1)) {
             const int f3 = q % 3;
             const int nb = max(0, n - b_right + 1);
@@ -227,8 +246,15 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
             const int ke = min(j9, (n - b_left) / 3);
             const int q1 = xh_mod6(q - 1), q2 = xh_mod6(q - 2), q3 = xh_mod6(q - 3), q4 = xh_mod6(q - 4), q5 = xh_mod6(q - 5);
             const int c = n - 3 * k;                          // my column
+            const int cx = cx_next;
+            cx_next = cols[min(max(c + 1, 0), c_hi)].x;
+            int pH = 0, pC = 0, pF = 0, pFC = 0, pB = 0;
+            if (k == 0 && n + 1 < n9) {
+                pH = hv[r + 4]; pC = hc[r + 4]; pF = fv[r + 4]; pFC = fc[r + 4];
+                if (!UDH || LocalL) pB = hb[r + 1];
+            }
             // coding-potential pipe (:870-877)
-            if (k == 0 && spj && !nb) LV(S_CP + f3) = (int) (short) (cols[n].x & 0xffff);
+            if (k == 0 && spj && !nb) LV(S_CP + f3) = (int) (short) (cx & 0xffff);
             const int cv = LV(S_CP + f3);
             {
                 const int upcv = xh_up(cv);
@@ -241,12 +267,12 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
             int uB3 = 0, uFB3 = 0, uB4 = 0, uB5 = 0;
             if (UDH && LocalL) { uB3 = xh_up(LV(S_HB + q3)); uFB3 = xh_up(LV(S_FB + q3)); uB4 = xh_up(LV(S_HB + q4)); uB5 = xh_up(LV(S_HB + q5)); }
             if (k == 0) {
-                uF3 = fv[r + 3]; uFC3 = fc[r + 3];
-                uH3 = hv[r + 3]; uC3 = hc[r + 3];
-                uH4 = hv[r + 2]; uC4 = hc[r + 2];
-                uH5 = hv[r + 1]; uC5 = hc[r + 1];
-                uH0 = hv[r]; uC0 = hc[r];
-                if (!UDH || LocalL) uB0 = hb[r];
+                uF3 = wF; uFC3 = wFC;
+                uH3 = wH3; uC3 = wC3;
+                uH4 = wH2; uC4 = wC2;
+                uH5 = wH1; uC5 = wC1;
+                uH0 = wH0; uC0 = wC0;
+                if (!UDH || LocalL) uB0 = wB;
                 if (UDH && LocalL) { uFB3 = fb[r + 3]; uB3 = hb[r + 3]; uB4 = hb[r + 2]; uB5 = hb[r + 1]; }
             }
             // insertion: frame shifts, codon insertion, extension (:879-915)
@@ -284,7 +310,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
             if (UDH && LocalL) LV(S_FB + q) = fbv;
             // diagonal (:967-1027)
             if (nb) sm = 0;
-            if (k >= kb && k < ke) sm = xh_w16(mrow[(cols[c].x >> 16) & 0xff]);
+            if (k >= kb && k < ke) sm = xh_w16(mrow[(cx >> 16) & 0xff]);
             int qb = 0;
             {
                 const int qv = uH0, qc = uC0, qbb = uB0;
@@ -331,7 +357,7 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
             // intron 3' boundary (:1049-1054, Sjsites::get :388-494): my column is a queued acceptor column
             const bool in_q = site_lane && c >= n_first && c < b_right;
             unsigned fl = 0;
-            if (in_q) fl = (unsigned) cols[c].x >> 24;
+            if (in_q) fl = (unsigned) cx >> 24;
             if (in_q && (((fl & 7) == 3) || (fl & 4))) {
                 const int acc = c - 1;
                 const int rr0 = acc - 3 * (m + 1);
@@ -465,6 +491,9 @@ __global__ void __launch_bounds__(64) spdh_exact(HScalarArgs A)
                 if constexpr (!UDH) hb[r0] = LV(S_HB + q);
                 else if (LocalL) { hb[r0] = LV(S_HB + q); fb[r0] = LV(S_FB + q); }
             }
+            wH0 = wH1; wH1 = wH2; wH2 = wH3; wH3 = pH;
+            wC0 = wC1; wC1 = wC2; wC2 = wC3; wC3 = pC;
+            wF = pF; wFC = pFC; wB = pB;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if constexpr (UDH) { if (is_imd_) ++imd_i; }
@@ -1060,8 +1089,13 @@ extern "C" hipError_t spdh_launch_local_udh(const HScalarArgs* a, hipStream_t st
 extern "C" hipError_t spdh_launch_exact(int udh, const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;
-    const dim3 grd((A.n_probs + 3) / 4), blk(64);
-    if (udh) hipLaunchKernelGGL(spdh_exact<true>, grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL(spdh_exact<false>, grd, blk, 0, stream, A);
+    // groups per wave: one while the launch has fewer problems than ~8 waves per CU would hold, then two, then four
+    int g = A.n_probs <= 8192 ? 1 : (A.n_probs <= 16384 ? 2 : 4);
+    if (const char* e = getenv("SPDP_HX_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) g = v; }
+    const dim3 grd((A.n_probs + g - 1) / g), blk(16 * g);
+#define SPDH_EXACT_GO(U, GG) hipLaunchKernelGGL((spdh_exact<U, GG>), grd, blk, 0, stream, A)
+    if (udh) { if (g == 1) SPDH_EXACT_GO(true, 1); else if (g == 2) SPDH_EXACT_GO(true, 2); else SPDH_EXACT_GO(true, 4); }
+    else     { if (g == 1) SPDH_EXACT_GO(false, 1); else if (g == 2) SPDH_EXACT_GO(false, 2); else SPDH_EXACT_GO(false, 4); }
+#undef SPDH_EXACT_GO
     return hipGetLastError();
 }

@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 # algorithmic HBM bytes per DP cell: per 64 query rows x 1 column the
 # sweep streams one 8 B column record and reads + writes one 8 B {H,F} boundary entry
 BYTES_PER_CELL = {"score": 24.0 / 64.0, "udh": 40.0 / 64.0, "forward": 24.0 / 64.0 + 1.0}
+# SURVEY.md 8(d)'s compulsory traffic, the figure roofline.achieved is computed from: per 64-row stripe one column costs
+# 6 B of window (base, two signals, flags) + 16 B of boundary rows read and written = 0.34 B/cell; a traceback byte per cell
+# on top for the forward flavour.  BYTES_PER_CELL above is what THIS layout moves at best (8 B column records, 16 B
+# linear-space entries) and is reported beside it as roofline.layout_*
+SURVEY_BYTES_PER_CELL = {"score": 22.0 / 64.0, "udh": 22.0 / 64.0, "forward": 22.0 / 64.0 + 1.0}
 HBM_PEAK_GBS = 8000.0
 # VALU issue ceiling of one MI355X, measured with tools/ubench (profiles/r02_valu_ubench.txt): a SIMD issues at most one
 # VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
@@ -265,7 +270,9 @@ def main_c3(args):
         sc = spdg.scoring_h(fx, scalar_engines=1 if args.engines == "a0" else 2)
     else:
         sc = defaults.scoring_h()
-    batch = synth.make_protein_batch(args.queries, seed=synth.SEED + 3000 + 1000 * rank)
+    bseed = synth.SEED + 3000 + 1000 * rank
+    batch = (synth.make_protein_batch(args.queries, seed=bseed) if args.queries <= 10000 else
+             synth.make_chunked("c3", args.queries, seed=bseed, procs=_host_cores()))
     ps = abi.ProblemSetH()
     for g, sg in batch:
         kw = dict(dinc=synth.exact_inputs(defaults.encode(g.window))["dinc"]) if exact else {}
@@ -341,6 +348,7 @@ def main_c3(args):
                                                                if args.engines == "a0" else "-A1: forwardH1 / hirschbergH1, spdp_h_exact.hip") + ")"),
                        "queries_per_gpu": args.queries, "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(args.queries * world * args.steps / dt, 1),
+                       "reference_parity": _parity_note(args),
                        "sweep_ms": round(k_ms, 3), "sweep_gcups": round(cells / k_ms / 1e6, 2) if k_ms > 0 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -417,6 +425,69 @@ def _dist_setup():
     return torch, dist, rank, world, dev, "cpu"
 
 
+# legs of the default line: name -> (arguments of this script, what the leg is)
+LEGS = {
+    "c3": (["--workload", "c3", "--queries", "50000", "--steps", "2", "--warmup", "1", "--cpu-sample", "512"],
+           "BASELINE configs[2] at its full 50 000 queries: the traceback bitmaps (2 B / cell, ~440 GB) run as groups, all inside the clock"),
+    "c4": (["--workload", "c4", "--queries", "20000", "--steps", "3", "--warmup", "1"],
+           "BASELINE configs[3]'s per-EST work on a 20 000-fragment batch (planted windows; the 3 Gb genome's block search is SURVEY 8 row f4)"),
+    "c5": (["--workload", "c5", "--queries", "32", "--steps", "2", "--warmup", "1", "--cpu-sample", "16"],
+           "BASELINE configs[4]: 32 cDNAs of 50 kb, 25 exons, against their ~190 kb loci"),
+    "a0": (["--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
+           "C2 shape under -A0 (forwardS_ng / hirschbergS_ng): the engines whose output is bit-identical to the reference's own -A0 records on 2 kb inputs"),
+    "a1": (["--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"], "C2 shape under -A1 (forwardS1 / hirschbergS1)"),
+    "c3_a0": (["--workload", "c3", "--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
+              "C3 shape under -A0 (forwardH_ng / hirschbergH_ng)"),
+    "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"],
+              "C3 shape under -A1 (forwardH1 / hirschbergH1)"),
+}
+
+
+def _run_leg(name):
+    """one leg = this script run on its own with the leg's arguments; returns the figures of its JSON line in short form"""
+    import subprocess
+    argv, what = LEGS[name]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--legs", "none", "--seeded-pairs", "0"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:                                       # noqa: BLE001 -- a leg must not cost the line
+        return {"what": what, "error": f"{type(e).__name__}: {str(e)[:160]}", "wall_s": round(time.perf_counter() - t0, 1)}
+    c, rf, cb = d["config"], d["roofline"], d.get("cpu_baseline") or {}
+    out = {"what": what, "args": " ".join(argv), "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+           "steps": d["steps"], "queries": c["queries_per_gpu"], "queries_per_s": c["queries_per_s"],
+           "cells_per_step": c["cells_per_gpu_per_step"], "dtype": d["dtype"],
+           "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "hbm_frac": rf["frac"],
+           "valu_frac": (rf.get("valu") or {}).get("frac"),
+           "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None,
+           "reference_parity": c.get("reference_parity"), "wall_s": round(time.perf_counter() - t0, 1)}
+    for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems"):
+        if c.get(k) is not None:
+            out[k] = c[k]
+    return out
+
+
+def _parity_note(args):
+    """which reference output the timed engines are bit-identical to (tests named)"""
+    if args.engines == "a0":
+        return ("-A0 engines: bit-identical to the compiled reference's own -A0 records (HomScore, gsi->scr, SKL, exon table) on all "
+                "fixtures incl. the 2 kb / 6 kb ones (tests/test_gpu_fullsize_ref.py, test_gpu_parity*.py)")
+    if args.engines == "a1":
+        return "-A1 engines: bit-identical to the compiled reference's -A1 output on all fixtures (tests/test_gpu_parity*.py, test_gpu_exact_h.py)"
+    if args.workload == "c3":
+        return ("`_wip` int16 engines: bit-identical to the compiled reference's -A2 output up to 512 aa (no re-basing below row 512; 400 aa "
+                "here), fixtures h1_* / c1_* and the live shim (tests/test_gpu_parity_h.py, test_gpu_shim.py)")
+    return ("`_wip` model (-A2) carried in int32 / exact fp32 WITHOUT the reference's int16 re-basing: bit-identical to the compiled reference's "
+            "-A2 output for queries <= 1472 nt (fixtures, C4's 500 nt included) and on 2 kb pairs of 18-28 % divergence (live shim, 36 / 36); "
+            "at this workload's own 2 kb / 2 % inputs the reference's -A2 re-bases and mis-aligns (SURVEY App. B), so there the timed engine is "
+            "bit-identical to the pinned int32 restatement (oracle) and agrees with the reference's -A0 records at exon-boundary level "
+            "(tests/test_gpu_fullsize_ref.py); the engines that ARE bit-identical to a reference output on these inputs are timed as config.a0")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,9 +495,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seeded-pairs", type=int, default=10000,
                     help="pairs of the seeded-path (-Q7) leg reported in config.seeded_q7 (c2, N = 1; 0: skip)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "
-                         "c4: 500-nt ESTs (traceback branch of the ladder only)")
+                         "c4: 500-nt ESTs (traceback branch of the ladder only); c5: 50 kb cDNAs with 25 exons "
+                         "(recursive linear-space branch all the way down)")
+    ap.add_argument("--legs", default="auto",
+                    help="the other BASELINE configs and engines as legs of the default line (config.c3 / c4 / c5 / a0 / a1 / "
+                         "c3_a0 / c3_a1), each a run of this script: auto = all of them with the default workload at N = 1, "
+                         "none, or a comma-separated subset")
     ap.add_argument("--engines", choices=["wip", "a0", "a1"], default="wip",
                     help="wip = the -A2 `_wip` engines (the headline); a0 = the exact-intron-length engines "
                          "(algmode.alg 0: forwardS_ng / hirschbergS_ng, spdp_rowwave.hip); a1 = the -A1 engines (spdp_exact.hip)")
@@ -440,7 +516,7 @@ def main():
                          "batch of --queries sharded over the ranks; the other one is reported under config")
     args = ap.parse_args()
     if not args.queries:
-        args.queries = 10000 if args.engines == "wip" else 1000
+        args.queries = (32 if args.workload == "c5" else 10000) if args.engines == "wip" else 1000
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_spawn(sys.argv[1:], args.gpus)
     if args.workload == "c3":
@@ -464,8 +540,10 @@ def main():
         torch.cuda.synchronize()
 
     def make(seed, n):
-        if args.workload == "c4":
-            return synth.make_est_batch(n, seed=seed)
+        if args.workload == "c4":       # (above the round-1 .. 3 size the batch is made in chunks by all host cores)
+            return synth.make_est_batch(n, seed=seed) if n <= 10000 else synth.make_chunked("c4", n, seed=seed, procs=_host_cores())
+        if args.workload == "c5":
+            return synth.make_batch(n, seed=seed + 55, n_exons=25, mrna_len=50000, flank=1000, intron_lo=1000, intron_hi=10000)
         return synth.make_batch(n, seed=seed, intron_hi=args.intron_hi)
 
     def measure(mode):
@@ -511,14 +589,20 @@ def main():
             h2d = {"upload_ms": round((tu - tb1) * 1e3, 2), "step_ms_incl_upload": round((time.perf_counter() - tb1) * 1e3, 2)}
             del tb0
             # ... and as a stream of batches: batch i + 1 is uploaded (host packing + H2D, on a second context of the same
-            # device) while batch i is aligned; three steps in steady state
+            # device) while batch i is aligned; steady state: the second context has uploaded (and aligned) once before the
+            # clock starts -- its first upload allocates the pinned staging and the pools, 2.5 - 3 x the time of any later
+            # one -- and six steps are averaged
             try:
                 import threading
                 eng2 = engine.Engine(local_rank)
+                w0 = eng2.upload(sc, ps)
+                w0.align(want=True, convert=False)
+                w0.free()
                 cur = eng.upload(sc, ps)
                 torch.cuda.synchronize()
+                n_str = 6
                 ts0 = time.perf_counter()
-                for i in range(3):
+                for i in range(n_str):
                     box = []
                     th = threading.Thread(target=lambda e=(eng2 if i % 2 == 0 else eng): box.append(e.upload(sc, ps)))
                     th.start()
@@ -527,7 +611,8 @@ def main():
                     cur.free()
                     cur = box[0]
                 torch.cuda.synchronize()
-                h2d["streamed_step_ms"] = round((time.perf_counter() - ts0) / 3 * 1e3, 2)
+                h2d["streamed_step_ms"] = round((time.perf_counter() - ts0) / n_str * 1e3, 2)
+                h2d["streamed_steps"] = n_str
                 cur.free()
                 eng2.close()
             except Exception as e:                                   # noqa: BLE001 -- the extra figure must not cost the line
@@ -589,7 +674,8 @@ def main():
         c4 = args.workload == "c4"
         k_ms = fwd_ms if c4 else udh_ms
         k_cells, k_name = (fwd_cells, "forward") if c4 else (udh_cells, "udh")
-        achieved = k_cells * BYTES_PER_CELL[k_name] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        achieved = k_cells * SURVEY_BYTES_PER_CELL[k_name] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        achieved_layout = k_cells * BYTES_PER_CELL[k_name] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # CPU baseline: the oracle's alignS_ng restatement (int32, one query per process) on all
         # host cores of this box, bounded sample
         import multiprocessing as mp
@@ -633,6 +719,9 @@ def main():
             "config": {"workload": ("C4 shape (batch scaled to the run): 500-nt ESTs, 1 % error, vs the locus of "
                                     "the fragment +-1 kb (windows 2-10 kb), default band, Fwd2s1 _wip path: "
                                     "alignS_ng(ori=1, -Q0) = forward sweep + traceback walk, SKL out") if c4 else
+                                   (f"C5: {len(batch)} cDNAs of 50 kb, 25 exons of ~2 kb, introns 1-10 kb, vs their loci +-1 kb (~190 kb), "
+                                    "default band, Fwd2s1 _wip path: alignS_ng(ori=1, -Q0) = recursive linear-space branch "
+                                    "(UDH sweeps over shrinking slabs) + slab tracebacks, SKL out") if args.workload == "c5" else
                                    ("C2: 10k x 2 kb cDNA vs planted loci +-1 kb (windows ~12 kb), "
                                     "default band, Fwd2s1 _wip path: alignS_ng(ori=1, -Q0) = UDH sweep + "
                                     "slab tracebacks, SKL out") if not exact else
@@ -641,6 +730,10 @@ def main():
                        "queries_per_gpu": len(batch), "queries_total": int(prim["total_queries"]),
                        "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(prim["total_queries"] * args.steps / dt, 1),
+                       **({"queries_per_s_incl_upload": round(len(batch) / ((prim["h2d"].get("streamed_step_ms") or
+                                                                            prim["h2d"]["step_ms_incl_upload"]) * 1e-3), 1)}
+                          if prim.get("h2d") else {}),
+                       "reference_parity": _parity_note(args),
                        **({"with_h2d": {**prim["h2d"], "queries_per_s": round(len(batch) / (prim["h2d"]["step_ms_incl_upload"] * 1e-3), 1),
                                         "note": "step_ms_incl_upload: one step with the batch uploaded first (host arrays -> column records "
                                                 "-> HBM), this rank; streamed_step_ms: steady state of a stream of batches, batch i + 1 uploaded "
@@ -654,7 +747,12 @@ def main():
                        "fwd_problems": int(stats[-1]["fwd_problems"]), "tb_bytes": int(stats[-1]["tb_bytes"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": (PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and not c4 and not exact) else
+                         "bytes_per_cell": round(SURVEY_BYTES_PER_CELL[k_name], 4),
+                         "bytes_per_cell_source": "SURVEY.md 8(d): (6 B window + 16 B boundary rows) / 64-row stripe"
+                                                  + (" + 1 B traceback code" if k_name == "forward" else ""),
+                         "layout_bytes_per_cell": round(BYTES_PER_CELL[k_name], 4),
+                         "layout_achieved": round(achieved_layout, 2), "layout_frac": round(achieved_layout / HBM_PEAK_GBS, 5),
+                         "traffic": (PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and args.workload == "c2" and not exact) else
                                      PMC_TRAFFIC_BYTES_A0 if (args.engines == "a0" and args.queries == 1000 and world == 1 and not c4) else None),
                          "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r03_hbm_traffic_pmc.txt") +
                                            " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
@@ -668,14 +766,25 @@ def main():
                                  "VALU-issue bound recurrence (integer scores carried as exact fp32); HBM fraction reported as asked; kernel_ms = mean duration per step summed over the step's launches of this kernel (one per pipelined chunk)"},
             "cpu_baseline": cpu_base,
         }
-        if world == 1 and not c4 and not exact and args.seeded_pairs > 0:
+        if world == 1 and args.workload == "c2" and not exact and args.seeded_pairs > 0:
             leg = _seeded_leg(args.seeded_pairs)
             if leg:
                 out["config"]["seeded_q7"] = leg
-        print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the other BASELINE configs and engines, each a run of this script on the now idle GPU (N = 1, default workload)
+        want = args.legs
+        if want == "auto":
+            want = ",".join(LEGS) if (world == 1 and args.workload == "c2" and not exact) else "none"
+        if want != "none":
+            t_legs = time.perf_counter()
+            for name in want.split(","):
+                if name in LEGS:
+                    out["config"][name] = _run_leg(name)
+            out["config"]["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

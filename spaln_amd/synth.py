@@ -351,3 +351,22 @@ def exact_inputs(window_codes: np.ndarray) -> dict:
     c3[1:n + 1] = k3
     return dict(cano5=(c5[:n + 1] > 0).astype(np.uint8), cano3=(c3[:n + 1] > 0).astype(np.uint8),
                 dinc=((d5[:n + 1] << 4) | d3[:n + 1]).astype(np.uint8))
+
+
+# ---- chunked, multi-process generation for the large bench batches ---------------------------------------
+def _chunk_job(job):
+    kind, n, seed, kw = job
+    return {"c2": make_batch, "c4": make_est_batch, "c3": make_protein_batch}[kind](n, seed=seed, **kw)
+
+
+def make_chunked(kind: str, n: int, seed: int = SEED, procs: int = 1, chunk: int = 500, **kw):
+    """`n` items of make_batch ("c2") / make_est_batch ("c4") / make_protein_batch ("c3") as chunks of `chunk`, chunk j
+    drawn from seed + 7919 j: the batch is a function of (n, seed, chunk) only, however many processes make it."""
+    jobs = [(kind, min(chunk, n - j), seed + 7919 * (j // chunk), kw) for j in range(0, n, chunk)]
+    if procs <= 1 or len(jobs) == 1:
+        parts = [_chunk_job(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
+            parts = pool.map(_chunk_job, jobs, chunksize=1)
+    return [x for part in parts for x in part]

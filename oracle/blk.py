@@ -1,0 +1,104 @@
+"""ctypes wrapper of the block-search restatement (oracle/spdp_oracle_blk.c).  TEST INFRASTRUCTURE ONLY.
+
+The index and parameter record come from a fixture written by the reference itself (oracle/ref_build/blk_tap.cc):
+`index_of(fx)` turns it into the BlkIndex the oracle reads; `parse_log(fx)` splits the recorder's query log."""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import oracle as _o
+
+
+class BlkIndex(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nalpha", "ktuple", "tabsize", "nshift", "blklen", "nbitpat", "convts", "n_chr", "avrscr", "maxblk",
+        "kk", "drna", "maxmmc", "nseg", "minsigpr", "ncand", "nascr", "maxblock", "extblock", "shortquery",
+        "hh_size1", "hh_size2", "hb_size1", "hb_size2", "ha_size1", "ha_size2", "phase1t", "gdb", "has_chrid", "pad0")] + [
+        ("rbscoef", C.c_float), ("rbscons", C.c_float),
+        ("bclw", C.c_double), ("bcup", C.c_double), ("bcce", C.c_double), ("cfact", C.c_double),
+        ("convtab", C.c_void_p), ("nblk", C.c_void_p), ("wscr", C.c_void_p), ("blkp", C.c_void_p), ("blkb", C.c_void_p),
+        ("rscrtab", C.c_void_p), ("chr", C.c_void_p), ("bitpat", C.c_void_p)]
+
+
+# positions in the recorder's blk_prm record (blk_tap.cc, dump_index)
+PRM = dict(nalpha=0, ktuple=1, bitpat2=2, tabsize=3, bitpat=4, nshift=5, blklen=6, maxgene=7, nbitpat=8, afact=9, convts=10,
+           wordno=11, n_chr=12, avrscr=13, maxblk=14, kk=15, drna=16, maxmmc=17, ptpl=18, nseg=19, bbt=20, min_agap=21,
+           minsigpr=22, ncand=23, nascr=24, maxblock=25, extblock=26, extblockl=27, shortquery=28, hh_size1=29, hh_size2=30,
+           hb_size1=31, hb_size2=32, ha_size1=33, ha_size2=34, phase1t=35, rbscoef=36, rbscons=37, gdb=38, maxout=39,
+           maxout2=40, has_chrid=41)
+
+
+def index_of(fx: dict):
+    """(BlkIndex, keep-alive list) from the arrays of a blk_*.spdg fixture"""
+    prm = np.asarray(fx["blk_prm"], dtype=np.int32)
+    ix = BlkIndex()
+    for name, _ in BlkIndex._fields_[:30]:
+        if name in PRM:
+            setattr(ix, name, int(prm[PRM[name]]))
+    ix.rbscoef = struct.unpack("<f", struct.pack("<i", int(prm[PRM["rbscoef"]])))[0]
+    ix.rbscons = struct.unpack("<f", struct.pack("<i", int(prm[PRM["rbscons"]])))[0]
+    ix.bclw, ix.bcup, ix.bcce = np.frombuffer(np.asarray(fx["blk_pb2c"], dtype=np.uint8).tobytes(), dtype=np.float64)
+    ix.cfact = float(np.frombuffer(np.asarray(fx["blk_cfact"], dtype=np.uint8).tobytes(), dtype=np.float64)[0])
+    keep = []
+    for field, key, dt in (("convtab", "blk_convtab", np.uint8), ("nblk", "blk_nblk", np.uint16), ("wscr", "blk_wscr", np.int16),
+                           ("blkp", "blk_blkp", np.int32), ("blkb", "blk_blkb", np.uint32), ("rscrtab", "blk_rscrtab", np.int32),
+                           ("chr", "blk_chr", np.int32), ("bitpat", "blk_bitpat", np.int32)):
+        a = np.ascontiguousarray(np.asarray(fx[key]).view(dt) if np.asarray(fx[key]).dtype.itemsize == np.dtype(dt).itemsize
+                                 else np.asarray(fx[key]).astype(dt))
+        keep.append(a)
+        setattr(ix, field, a.ctypes.data)
+    return ix, keep
+
+
+def parse_log(fx: dict):
+    """the recorder's query log -> [dict(left, right, codes, calls=[(vote record, pairs record or None)])]"""
+    L = np.asarray(fx["q_log"], dtype=np.int32)
+    ncand1 = int(fx["blk_prm"][PRM["ncand"]]) + 1
+    out, i = [], 0
+    while i < L.size:
+        assert L[i] == -1, (i, L[i])
+        left, right, n = int(L[i + 1]), int(L[i + 2]), int(L[i + 3])
+        q = dict(left=left, right=right, codes=L[i + 4:i + 4 + n].astype(np.uint8), calls=[])
+        i += 4 + n
+        while i < L.size and L[i] == -2:
+            j = i + 1 + 20
+            for _ in range(4):
+                for _ in range(4):              # prqueue_b, prqueue_a, bscr, ascr: count + pairs
+                    j += 1 + 2 * int(L[j])
+            vote = L[i:j].copy()
+            pairs = None
+            if j < L.size and L[j] == -3:
+                assert L[j + 1] == ncand1
+                pairs = L[j:j + 2 + 9 * ncand1].copy()
+                j += 2 + 9 * ncand1
+            q["calls"].append((vote, pairs))
+            i = j
+        out.append(q)
+    return out
+
+
+def vote(ix: BlkIndex, codes: np.ndarray, left: int, right: int, stop_at: int = 0):
+    """state at the stop_at-th TestOutput call + the block pairs built there: (vote record, pairs record) as int32 arrays in
+    the recorder's layout (pairs: -3, n, 9 ints per pair), or None if findblock ends before that call"""
+    lib = _o.lib()
+    q = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(64 + 16 * (4 * int(ix.nseg) + 64), dtype=np.int32)
+    lib.spdp_oracle_blk_vote.restype = C.c_int
+    n = lib.spdp_oracle_blk_vote(C.byref(ix), q.ctypes.data_as(C.c_void_p), C.c_int(q.size), C.c_int(left), C.c_int(right),
+                                 C.c_int(stop_at), out.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        raise RuntimeError("hash table overflow in the block vote (the reference resizes there)")
+    if n == 0:
+        return None
+    rec = out[:n]
+    k = int(np.nonzero(rec == -3)[0][-1])
+    # (a -3 can also occur as data only if a score is -3: scan from the structure instead)
+    j = 1 + 20
+    for _ in range(4):
+        for _ in range(4):
+            j += 1 + 2 * int(rec[j])
+    assert rec[j] == -3, (j, k)
+    return rec[:j].copy(), rec[j:].copy()

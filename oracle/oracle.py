@@ -19,12 +19,12 @@ _lib = None
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c", "spdp_oracle_h.c",
-                                                "spdp_oracle_h_scalar.c")]
+                                                "spdp_oracle_h_scalar.c", "spdp_oracle_blk.c")]
     hdr = os.path.join(_HERE, "..", "include", "spdp.h")
     newest = max(os.path.getmtime(f) for f in srcs + [hdr])
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         tmp = f"{_SO}.{os.getpid()}.tmp"          # several test processes may get here at once: build aside, swap in
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp] + srcs)
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp] + srcs + ["-lm"])
         os.replace(tmp, _SO)
     build_walk_check(force)
     return _SO

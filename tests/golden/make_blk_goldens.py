@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Fixtures of the block search from the REAL reference: tests/golden/blk_k1.spdg, blk_k3.spdg.
+
+Build container only (needs oracle/_ref/spaln and oracle/_ref/spaln_blktap, `make -C oracle/ref_build`).  A small synthetic
+genome (planted genes of spaln_amd.synth between random spacers) is formatted by the compiled reference itself
+(`spaln -W -KD`: its own .bkn index, once with the default contiguous k-mer, once with five spaced patterns, -XC5), then
+the reference's CLI with the recorder of oracle/ref_build/blk_tap.cc maps a mixed query set onto it (-Q7): transcripts,
+reverse complements, 500-nt fragments, short fragments, random sequences, chimeras, diverged copies.  The fixture holds
+the index arrays and parameters as the reference's SrchBlk object held them, every query as findblock saw it, the state of
+the vote at each TestOutput call and the block pairs handed to FindHsp.  Data only.
+
+    python tests/golden/make_blk_goldens.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from spaln_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+OUT = os.path.dirname(os.path.abspath(__file__))
+COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    COMP[a] = b
+
+
+def revcomp(s):
+    return COMP[np.asarray(s, dtype=np.uint8)[::-1]]
+
+
+def genome_and_queries(n_genes, n_chr, seed):
+    rng = np.random.default_rng(synth.SEED + seed)
+    genes = [synth.make_gene(np.random.default_rng(synth.SEED + seed + 1 + i), intron_hi=3000) for i in range(n_genes)]
+    per = n_genes // n_chr
+    chroms = []
+    for c in range(n_chr):
+        parts = []
+        for g in genes[c * per:(c + 1) * per]:
+            parts += [synth.random_dna(rng, int(rng.integers(500, 3000))), g.window]
+        chroms.append(np.concatenate(parts))
+    queries = []
+    for i, g in enumerate(genes):
+        s, m = g.query, i % 7
+        if m == 0:
+            queries.append(s)
+        elif m == 1:
+            queries.append(revcomp(s))
+        elif m == 2:
+            a = int(rng.integers(0, len(s) - 500))
+            queries.append(s[a:a + 500])
+        elif m == 3:
+            a = int(rng.integers(0, len(s) - 130))
+            queries.append(s[a:a + int(rng.integers(40, 120))])
+        elif m == 4:
+            queries.append(synth.random_dna(rng, int(rng.integers(200, 1200))))
+        elif m == 5:
+            o = genes[(i * 7 + 3) % n_genes].query
+            queries.append(np.concatenate([s[:700], revcomp(o)[:600]]))
+        else:
+            queries.append(synth.mutate(rng, s, 0.12, 0.01))
+    return chroms, queries
+
+
+def main():
+    env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
+    for name, fmt_opts, n_genes, seed in (("blk_k1", [], 42, 900), ("blk_k3", ["-XC5"], 28, 950)):
+        chroms, queries = genome_and_queries(n_genes, 2, seed)
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "gnm.mfa"), "w") as f:
+                for c, s in enumerate(chroms):
+                    f.write(f">chr{c + 1}\n")
+                    t = bytes(s).decode()
+                    f.writelines(t[i:i + 60] + "\n" for i in range(0, len(t), 60))
+            with open(os.path.join(td, "q.fa"), "w") as f:
+                for i, s in enumerate(queries):
+                    f.write(f">q{i}\n{bytes(s).decode()}\n")
+            e = dict(env, ALN_DBS=td)
+            subprocess.run([os.path.join(REF, "spaln"), "-W", "-KD"] + fmt_opts + ["gnm.mfa"], cwd=td, env=e, check=True,
+                           capture_output=True)
+            log = os.path.join(td, "log.spdg")
+            r = subprocess.run([os.path.join(REF, "spaln_blktap"), "-Q7", "-O4", "-t1", "-dgnm", "q.fa"], cwd=td,
+                               env=dict(e, SPDP_BLK_LOG=log), capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(log):
+                sys.exit(f"{name}: reference run failed: {r.stderr[-300:]}")
+            shutil.copyfile(log, os.path.join(OUT, name + ".spdg"))
+            print(f"{name}: genome {sum(len(c) for c in chroms)} nt, {len(queries)} queries, "
+                  f"{os.path.getsize(log) / 1e6:.2f} MB, {r.stdout.count(chr(10) + '@')} aligned")
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,8 @@ def load(path: str) -> dict:
         nb = cnt * np.dtype(_DT[dt]).itemsize
         out[name] = np.frombuffer(raw[off:off + nb], dtype=_DT[dt]).copy()
         off += (nb + 7) // 8 * 8
-    out["prm"] = dict(zip(PARAM_NAMES, (int(x) for x in out["params"])))
+    if "params" in out:                     # (the block-search fixtures, blk_*.spdg, carry their own parameter record)
+        out["prm"] = dict(zip(PARAM_NAMES, (int(x) for x in out["params"])))
     return out
 
 

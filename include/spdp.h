@@ -676,6 +676,59 @@ int64_t     spdp_batch_cells_h(const SpdpBatchH* bt);
  * DP sweep kernel on the stream it was launched on. */
 int spdp_batch_align_h(SpdpBatchH* bt, SpdpAlignment* out, float* kernel_ms, int64_t* kernel_cells);
 
+/* ---- block search: the vote of SrchBlk::findblock (first slice) -----------------------------------------
+ * Replaces, for cDNA / EST queries against a genome index, what the reference computes between the TestOutput calls of
+ * SrchBlk::findblock (src/blksrc.cc:2971-3087; Qwords :2819-2969, Bhit4 :2763-2817, Randbs :2047-2069) and the list of
+ * candidate block pairs TestOutput builds for FindHsp (extract_to_work :2547-2603, TestOutput :2620-2672).  FindHsp itself
+ * (Wilip on the candidate region, :2346) and the index file reader (:1697-1925) stay with the caller: an integration fills
+ * SpdpBlkIndexDesc from the SrchBlk object its own ReadBlkInfo produced.  One query per device lane; the
+ * index is resident in HBM.
+ *
+ * SpdpBlkIndexDesc = BlkWcPrm + ContBlk (src/blksrc.h:186-233) + the members / file statics of blksrc.cc the vote reads. */
+typedef struct SpdpBlkIndexDesc {
+    int32_t nalpha, tabsize, nshift, nbitpat;        /* wcp.Nalpha, TabSize, Nshift, Nbitpat */
+    int32_t convts, n_chr, maxblk;                   /* pbwc->ConvTS, ChrNo, MaxBlk */
+    int32_t kk, drna, maxmmc, nseg;                  /* SrchBlk::kk, DRNA, maxmmc, nseg */
+    int32_t minsigpr, ncand, nascr;                  /* MinSigpr, Ncand, Nascr (src/blksrc.cc:52-69, 2220) */
+    int32_t maxblock, extblock, shortquery;          /* MaxBlock, ExtBlock (:2213-2215), shortquery (src/wln.h:34, set :2219) */
+    int32_t hh_size, hh_step;                        /* geometry of Dhash<INT,int>(2 * MaxBlk, 0): size1, size2 (src/clib.h:257-267); */
+    int32_t hb_size, hb_step, ha_size, ha_step;      /*   of the position hashes of the Ncand / Nascr queues; 0 = derive (hh_step etc. = 8) */
+    int32_t gdb;                                     /* Randbs: log (genomic database) or sqrt transform beyond its table */
+    float   rbscoef, rbscons;                        /* Randbs::RbsCoef, RbsCons */
+    double  bclw, bcup, bcce;                        /* Block2Chr */
+    double  cfact;                                   /* app_c = Nbitpat ^ cfact (:2826) */
+    const uint8_t*  convtab;                         /* ConvTab[convts]: residue code -> reduced alphabet */
+    const uint16_t* nblk;                            /* pbwc->Nblk[tabsize] */
+    const int16_t*  wscr;                            /* pbwc->wscr[tabsize] */
+    const int32_t*  blkp;                            /* per word: offset of its posting list in blkb + 1, 0 = none (pbwc->blkp) */
+    const uint32_t* blkb;  int64_t n_words;          /* pbwc->blkb[WordNo] */
+    const int32_t*  rscrtab;                         /* Randbs::rscrtab[128] */
+    const int32_t*  chr;                             /* per chromosome 0 .. n_chr: (ChrID.spos, first block = chrblk(c)) */
+    const int32_t*  bitpat; int32_t n_bitpat;        /* per pattern k < kk: weight, width, wshift, exam[2 * weight] (Bitpat, src/bitpat.h:59-72) */
+} SpdpBlkIndexDesc;
+typedef struct SpdpBlkIndex SpdpBlkIndex;
+SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIndexDesc* desc);     /* uploads; NULL on error (spdp_last_error) */
+void          spdp_blk_index_destroy(SpdpBlkIndex* ix);
+/* n queries: codes of query i = codes[offs[i] .. offs[i + 1]), searched range [left[i], right[i]) (Seq::left / right);
+ * stop_at[i] (NULL = 0 for all) = which TestOutput call of findblock to stop at -- the earlier ones are taken to have
+ * answered "nothing found, go on" (a caller whose FindHsp rejects every pair of call k asks again with k + 1; most queries
+ * end at call 0).  out: n records of out_cap ints each: [0] ints used, [1] TestOutput calls met, [2] flags
+ * (SPDP_BLK_REACHED: the asked call was reached and the record follows; SPDP_BLK_CUT: out_cap too small; SPDP_BLK_TABLE:
+ * one of the reference-sized hash tables ran full, where the reference would grow it), then sign[4] mmct[4] nhit[4] maxs[4]
+ * testword[4] (Bhit4); per direction n, (block, score) x n: the significant blocks (prqueue_b, heap order); n_pairs and
+ * nine ints per candidate pair, best first (BPAIR: bscr chr lb rb ub db zl zr rvs); n_runs and (block | direction << 28,
+ * score) x n_runs: every block with a run score (Bhit4::bscr), unordered.  kernel_ms (may be NULL): HIP-event time. */
+#define SPDP_BLK_REACHED 1
+#define SPDP_BLK_CUT     2
+#define SPDP_BLK_TABLE   4
+int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* codes, const int64_t* offs,
+                  const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n,
+                  int32_t* out, int32_t out_cap, float* kernel_ms);
+/* the same with queries and records resident on the device (d_* are device pointers; the bench's timed region) */
+int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* d_codes, const int64_t* d_offs,
+                           const int32_t* d_left, const int32_t* d_right, const int32_t* d_stop_at, int32_t n,
+                           int32_t* d_out, int32_t out_cap, float* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

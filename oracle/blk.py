@@ -102,3 +102,71 @@ def vote(ix: BlkIndex, codes: np.ndarray, left: int, right: int, stop_at: int = 
             j += 1 + 2 * int(rec[j])
     assert rec[j] == -3, (j, k)
     return rec[:j].copy(), rec[j:].copy()
+
+
+def split_product_record(rec: np.ndarray):
+    """one query's record of the product (spdp_blk_core.h, blk_emit_and_reset) -> dict, or None when the asked call was not
+    reached"""
+    n, calls, flags = int(rec[0]), int(rec[1]), int(rec[2])
+    if not flags & 1:
+        return dict(reached=False, calls=calls, flags=flags)
+    r = rec[:n]
+    j = 3
+    head = r[j:j + 20].copy(); j += 20
+    qb = []
+    for _ in range(4):
+        k = int(r[j]); qb.append(r[j + 1:j + 1 + 2 * k].reshape(k, 2).copy()); j += 1 + 2 * k
+    npairs = int(r[j]); pairs = r[j + 1:j + 1 + 9 * npairs].reshape(npairs, 9).copy(); j += 1 + 9 * npairs
+    nruns = int(r[j]); runs = r[j + 1:j + 1 + 2 * nruns].reshape(nruns, 2).copy(); j += 1 + 2 * nruns
+    assert j == n, (j, n)
+    by_d = [[] for _ in range(4)]
+    for code, scr in runs:
+        by_d[int(code) >> 28].append((int(code) & 0xfffffff, int(scr)))
+    return dict(reached=True, calls=calls, flags=flags, head=head, qb=qb, pairs=pairs, runs=[sorted(x) for x in by_d])
+
+
+def split_recorded(vote_rec: np.ndarray, pairs_rec):
+    """the recorder's -2 / -3 records -> the same dict shape (word-hit counts and the all-hits queue are left out: the product
+    does not report them)"""
+    r = vote_rec
+    head = r[1:21].copy()
+    j = 21
+    qb, runs = [], []
+    for _ in range(4):
+        k = int(r[j]); qb.append(r[j + 1:j + 1 + 2 * k].reshape(k, 2).copy()); j += 1 + 2 * k
+        k = int(r[j]); j += 1 + 2 * k                                   # prqueue_a
+        k = int(r[j]); runs.append([(int(a), int(b)) for a, b in r[j + 1:j + 1 + 2 * k].reshape(k, 2)]); j += 1 + 2 * k
+        k = int(r[j]); j += 1 + 2 * k                                   # ascr
+    pairs = None if pairs_rec is None else pairs_rec[2:].reshape(-1, 9).copy()
+    return dict(head=head, qb=qb, runs=runs, pairs=pairs)
+
+
+def core_vote(ix: BlkIndex, codes, left, right, stop_at=0, cap=1 << 16, touched_cap=4096):
+    """the product's routine, host-compiled (oracle/blk_check.cpp)"""
+    lib = C.CDLL(_o.build_blk_check())
+    q = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(cap, dtype=np.int32)
+    n = lib.blk_check_vote(C.byref(ix), q.ctypes.data_as(C.c_void_p), C.c_int(q.size), C.c_int(left), C.c_int(right),
+                           C.c_int(stop_at), out.ctypes.data_as(C.c_void_p), C.c_int(cap), C.c_int(touched_cap))
+    assert n > -1000000, "a score slot was left dirty after the clean-up"
+    return split_product_record(out)
+
+
+def vote_carry(ix: BlkIndex, codes, left, right, stop_at, carry: np.ndarray):
+    """as vote(), with the memory the reference's worker thread keeps from query to query (see spdp_oracle_blk_vote_carry);
+    `carry` is updated in place.  Returns the raw record (vote + pairs) or None."""
+    lib = _o.lib()
+    q = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(64 + 16 * (4 * int(ix.nseg) + 64), dtype=np.int32)
+    n = lib.spdp_oracle_blk_vote_carry(C.byref(ix), q.ctypes.data_as(C.c_void_p), C.c_int(q.size), C.c_int(left), C.c_int(right),
+                                       C.c_int(stop_at), out.ctypes.data_as(C.c_void_p), carry.ctypes.data_as(C.c_void_p))
+    return None if n <= 0 else out[:n].copy()
+
+
+def new_carry(ix: BlkIndex) -> np.ndarray:
+    return np.zeros(8 * (int(ix.nascr) + 1) + 8, dtype=np.int32)
+
+
+def grows() -> int:
+    """how often a hash table of the oracle has grown so far (Dhash::resize)"""
+    return int(C.c_int.in_dll(_o.lib(), "spdp_oracle_blk_grows").value)

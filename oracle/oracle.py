@@ -27,7 +27,22 @@ def build(force: bool = False) -> str:
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp] + srcs + ["-lm"])
         os.replace(tmp, _SO)
     build_walk_check(force)
+    build_blk_check(force)
     return _SO
+
+
+_BLK_SO = os.path.join(_HERE, "libblkcheck.so")
+
+
+def build_blk_check(force: bool = False) -> str:
+    """the block vote's CPU checker: the text the device kernel is compiled from (spdp_blk_core.h), host-compiled"""
+    srcs = [os.path.join(_HERE, "blk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_core.h")]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    if force or not os.path.exists(_BLK_SO) or os.path.getmtime(_BLK_SO) < newest:
+        tmp = f"{_BLK_SO}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, _BLK_SO)
+    return _BLK_SO
 
 
 _WALK_SO = os.path.join(_HERE, "libwalkcheck.so")

@@ -10,7 +10,7 @@
  *   Qwords::init_mrglist / next_mrglist  :2938-2969         merge of the posting lists (incl. its k = 1 .. kk-1 loop over
  *                                                           elements 0 .. kk-2)
  *   Bhit4::update_a / update_b  :2804-2817                  PrQueue_wh<BlkScr> with its position hash (src/clib.h:570-688)
- *   Dhash<INT,int>::map / incr  src/clib.h:192-314          double hashing, literally: findblock writes the "undefined"
+ *   Dhash<INT,int>::map / incr / resize  src/clib.h:192-355 double hashing, literally (growth included): findblock writes the "undefined"
  *                                                           value 0 into live slots (h->val = 0), which cuts probe chains;
  *                                                           what a later lookup finds depends on the table geometry
  *   Randbs::randbs              :2064-2069
@@ -52,13 +52,42 @@ typedef struct { uint32_t key; int32_t val; } KV;
 typedef struct { KV* t; uint32_t size1, size2; int32_t undef; int overflow; } DH;
 
 static void dh_clear(DH* h) { for (uint32_t i = 0; i < h->size1; ++i) { h->t[i].key = 0; h->t[i].val = h->undef; } }
+static uint32_t next_prime(uint32_t n)          /* supprime(n), src/supprime.cc:375: the smallest prime >= n */
+{
+    if (n <= 3) return n;
+    if (n % 2 == 0) ++n;
+    for ( ; ; n += 2) {
+        int prime = 1;
+        for (uint32_t x = 3; x * x <= n; x += 2) if (n % x == 0) { prime = 0; break; }
+        if (prime) return n;
+    }
+}
+static KV* dh_map(DH* h, uint32_t key, int record);
+int spdp_oracle_blk_grows = 0;                  /* how often a table grew (tests: the fixtures must reach this path) */
+/* Dhash::resize() (src/clib.h:341-355): a table of the next prime >= twice the size, live entries re-entered in slot order */
+static void dh_grow(DH* h)
+{
+    KV* old = h->t;
+    const uint32_t n_old = h->size1;
+    if (n_old > (1u << 24)) { h->overflow = 1; return; }
+    ++spdp_oracle_blk_grows;
+    h->size1 = next_prime(2 * n_old);
+    h->t = (KV*) malloc(sizeof(KV) * h->size1);
+    dh_clear(h);
+    for (uint32_t i = 0; i < n_old; ++i)
+        if (old[i].val != h->undef) dh_map(h, old[i].key, 1)->val = old[i].val;
+    free(old);
+}
 static KV* dh_map(DH* h, uint32_t key, int record)
 {
     uint32_t v = key % h->size1, u = h->size2 - key % h->size2, v0 = v;
     KV* sh = h->t + v;
     while (sh->val != h->undef && sh->key != key) {
         v = (v + u) % h->size1;
-        if (v == v0) { h->overflow = 1; return record ? sh : 0; }     /* the reference resizes here: not restated */
+        if (v == v0) {                                  /* the probe came round: the reference grows the table and goes on */
+            dh_grow(h);                                 /* probing the NEW table from the OLD position with the old step */
+            if (h->overflow) return record ? sh : 0;
+        }
         sh = h->t + v;
     }
     if (sh->val == h->undef) { if (record) sh->key = key; else sh = 0; }
@@ -382,7 +411,20 @@ static int* emit_vote(const ST* s, int* o)
  * returned 0 ("nothing found yet, go on").  Writes the state at that call (record -2) and the block pairs it would
  * build (record -3 with the number of pairs first, nine ints each); returns the number of ints written, 0 if findblock
  * ends before that call is reached (the query too short, or the `notry` rule), -1 on a table overflow. */
+/* The reference keeps its queues' slot arrays from query to query (PrQueue_wh::reset only rewinds `front`), and the
+ * stand-in rule at the end of findblock reads the first Nascr slots of the all-hits queue whether or not this query
+ * filled them (src/blksrc.cc:3076-3082): what a query with fewer than Nascr hit blocks in some direction gets depends on
+ * the query the same thread searched before.  The queues' position hashes persist too: reset() clears them but a table
+ * that has grown (orphaned entries fill it: removing a key whose probe chain was cut leaves its live entry behind) stays
+ * grown, and its size decides where keys land.  `carry` = that memory (NULL = a fresh process): 4 x (nascr + 1) slots of the
+ * all-hits queues as key / score pairs, then the sizes of the eight position hashes (qa[0..3], qb[0..3]; 0 = initial);
+ * read at the start, written back at the end. */
+int spdp_oracle_blk_vote_carry(const BlkIndex* ix, const uint8_t* q, int q_len, int left, int right, int stop_at, int* out, int* carry);
 int spdp_oracle_blk_vote(const BlkIndex* ix, const uint8_t* q, int q_len, int left, int right, int stop_at, int* out)
+{
+    return spdp_oracle_blk_vote_carry(ix, q, q_len, left, right, stop_at, out, 0);
+}
+int spdp_oracle_blk_vote_carry(const BlkIndex* ix, const uint8_t* q, int q_len, int left, int right, int stop_at, int* out, int* carry)
 {
     ST s;
     memset(&s, 0, sizeof s);
@@ -400,11 +442,14 @@ int spdp_oracle_blk_vote(const BlkIndex* ix, const uint8_t* q, int q_len, int le
     s.ascr = (int*) calloc(4 * (size_t) nseg + 2, sizeof(int));
     for (int d = 0; d < 4; ++d) {
         s.qa[d].capacity = ix->nascr; s.qa[d].data = (BS*) calloc(ix->nascr + 1, sizeof(BS));
+        if (carry) memcpy(s.qa[d].data, carry + 2 * d * (ix->nascr + 1), sizeof(BS) * (ix->nascr + 1));
         s.qa[d].hpos.size1 = ix->ha_size1; s.qa[d].hpos.size2 = ix->ha_size2; s.qa[d].hpos.undef = -1;
-        s.qa[d].hpos.t = (KV*) malloc(sizeof(KV) * ix->ha_size1); dh_clear(&s.qa[d].hpos);
+        if (carry && carry[8 * (ix->nascr + 1) + d]) s.qa[d].hpos.size1 = carry[8 * (ix->nascr + 1) + d];
+        s.qa[d].hpos.t = (KV*) malloc(sizeof(KV) * s.qa[d].hpos.size1); dh_clear(&s.qa[d].hpos);
         s.qb[d].capacity = ix->ncand; s.qb[d].data = (BS*) calloc(ix->ncand + 1, sizeof(BS));
         s.qb[d].hpos.size1 = ix->hb_size1; s.qb[d].hpos.size2 = ix->hb_size2; s.qb[d].hpos.undef = -1;
-        s.qb[d].hpos.t = (KV*) malloc(sizeof(KV) * ix->hb_size1); dh_clear(&s.qb[d].hpos);
+        if (carry && carry[8 * (ix->nascr + 1) + 4 + d]) s.qb[d].hpos.size1 = carry[8 * (ix->nascr + 1) + 4 + d];
+        s.qb[d].hpos.t = (KV*) malloc(sizeof(KV) * s.qb[d].hpos.size1); dh_clear(&s.qb[d].hpos);
     }
     s.hh.size1 = ix->hh_size1; s.hh.size2 = ix->hh_size2; s.hh.undef = 0;
     s.hh.t = (KV*) malloc(sizeof(KV) * ix->hh_size1);
@@ -507,6 +552,11 @@ int spdp_oracle_blk_vote(const BlkIndex* ix, const uint8_t* q, int q_len, int le
 #undef SNAP
     int overflow = s.hh.overflow;
     for (int d = 0; d < 4; ++d) {
+        if (carry) {
+            memcpy(carry + 2 * d * (ix->nascr + 1), s.qa[d].data, sizeof(BS) * (ix->nascr + 1));
+            carry[8 * (ix->nascr + 1) + d] = (int) s.qa[d].hpos.size1;
+            carry[8 * (ix->nascr + 1) + 4 + d] = (int) s.qb[d].hpos.size1;
+        }
         overflow |= s.qa[d].hpos.overflow | s.qb[d].hpos.overflow;
         free(s.qa[d].data); free(s.qa[d].hpos.t); free(s.qb[d].data); free(s.qb[d].hpos.t);
     }

@@ -1,0 +1,125 @@
+"""Binding of the block search's vote (include/spdp.h, "block search") -- product path, device only.
+
+`desc_from_arrays` fills SpdpBlkIndexDesc from the arrays a reference-side dump of an index holds (the layout the tests'
+fixtures and the bench use: blk_prm, blk_nblk, ...); an integration fills the struct from its SrchBlk object instead
+(INTEGRATION.md)."""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+
+class BlkIndexDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nalpha", "tabsize", "nshift", "nbitpat", "convts", "n_chr", "maxblk", "kk", "drna", "maxmmc", "nseg",
+        "minsigpr", "ncand", "nascr", "maxblock", "extblock", "shortquery", "hh_size", "hh_step", "hb_size", "hb_step",
+        "ha_size", "ha_step", "gdb")] + [
+        ("rbscoef", C.c_float), ("rbscons", C.c_float),
+        ("bclw", C.c_double), ("bcup", C.c_double), ("bcce", C.c_double), ("cfact", C.c_double),
+        ("convtab", C.c_void_p), ("nblk", C.c_void_p), ("wscr", C.c_void_p), ("blkp", C.c_void_p),
+        ("blkb", C.c_void_p), ("n_words", C.c_int64), ("rscrtab", C.c_void_p), ("chr", C.c_void_p),
+        ("bitpat", C.c_void_p), ("n_bitpat", C.c_int32)]
+
+
+# positions in the parameter record of a reference-side index dump (oracle/ref_build/blk_tap.cc, dump_index)
+_PRM = dict(nalpha=0, tabsize=3, nshift=5, nbitpat=8, convts=10, n_chr=12, maxblk=14, kk=15, drna=16, maxmmc=17, nseg=19,
+            minsigpr=22, ncand=23, nascr=24, maxblock=25, extblock=26, shortquery=28, hh_size=29, hh_step=30, hb_size=31,
+            hb_step=32, ha_size=33, ha_step=34, gdb=38)
+REACHED, CUT, TABLE = 1, 2, 4
+
+
+def desc_from_arrays(fx: dict):
+    """(BlkIndexDesc, keep-alive list)"""
+    prm = np.asarray(fx["blk_prm"], dtype=np.int32)
+    d = BlkIndexDesc()
+    for name, pos in _PRM.items():
+        setattr(d, name, int(prm[pos]))
+    d.rbscoef = struct.unpack("<f", struct.pack("<i", int(prm[36])))[0]
+    d.rbscons = struct.unpack("<f", struct.pack("<i", int(prm[37])))[0]
+    d.bclw, d.bcup, d.bcce = (float(x) for x in np.frombuffer(np.asarray(fx["blk_pb2c"], dtype=np.uint8).tobytes(), dtype=np.float64))
+    d.cfact = float(np.frombuffer(np.asarray(fx["blk_cfact"], dtype=np.uint8).tobytes(), dtype=np.float64)[0])
+    keep = []
+    for field, key, dt in (("convtab", "blk_convtab", np.uint8), ("nblk", "blk_nblk", np.uint16), ("wscr", "blk_wscr", np.int16),
+                           ("blkp", "blk_blkp", np.int32), ("blkb", "blk_blkb", np.uint32), ("rscrtab", "blk_rscrtab", np.int32),
+                           ("chr", "blk_chr", np.int32), ("bitpat", "blk_bitpat", np.int32)):
+        a = np.asarray(fx[key])
+        a = np.ascontiguousarray(a.view(dt) if a.dtype.itemsize == np.dtype(dt).itemsize else a.astype(dt))
+        keep.append(a)
+        setattr(d, field, a.ctypes.data)
+    d.n_words = int(keep[4].size)
+    d.n_bitpat = int(keep[7].size)
+    return d, keep
+
+
+class BlockIndex:
+    """an index resident on the engine's device"""
+
+    def __init__(self, eng, fx: dict):
+        self.eng, self.lib = eng, eng.lib
+        self.lib.spdp_blk_index_create.restype = C.c_void_p
+        self.lib.spdp_blk_index_create.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.spdp_blk_index_destroy.argtypes = [C.c_void_p]
+        self.lib.spdp_blk_vote.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        self.lib.spdp_blk_vote_resident.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        self.desc, self._keep = desc_from_arrays(fx)
+        self.h = self.lib.spdp_blk_index_create(eng.ctx, C.byref(self.desc))
+        if not self.h:
+            raise RuntimeError("spdp_blk_index_create: " + self.lib.spdp_last_error(eng.ctx).decode())
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.spdp_blk_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def vote(self, queries, ranges=None, stop_at=None, out_cap: int = 4096):
+        """queries: list of uint8 code arrays; ranges: [(left, right)] (default whole query); stop_at: per query or None.
+        Returns (records as an (n, out_cap) int32 array, kernel ms)."""
+        n = len(queries)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(q) for q in queries])
+        codes = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in queries]) if n else np.zeros(0, np.uint8))
+        left = np.array([0 if ranges is None else ranges[i][0] for i in range(n)], dtype=np.int32)
+        right = np.array([len(queries[i]) if ranges is None else ranges[i][1] for i in range(n)], dtype=np.int32)
+        st = None if stop_at is None else np.ascontiguousarray(stop_at, dtype=np.int32)
+        out = np.zeros((n, out_cap), dtype=np.int32)
+        ms = C.c_float()
+        rc = self.lib.spdp_blk_vote(self.eng.ctx, self.h, codes.ctypes.data, offs.ctypes.data, left.ctypes.data, right.ctypes.data,
+                                    None if st is None else st.ctypes.data, n, out.ctypes.data, out_cap, C.byref(ms))
+        self.eng._check(rc, "spdp_blk_vote")
+        return out, ms.value
+
+    def vote_resident(self, d_codes, d_offs, d_left, d_right, d_stop_at, n, d_out, out_cap):
+        """device pointers in (ints), records written to d_out; returns kernel ms"""
+        ms = C.c_float()
+        rc = self.lib.spdp_blk_vote_resident(self.eng.ctx, self.h, d_codes, d_offs, d_left, d_right, d_stop_at, n, d_out, out_cap,
+                                             C.byref(ms))
+        self.eng._check(rc, "spdp_blk_vote_resident")
+        return ms.value
+
+
+def split_record(rec: np.ndarray):
+    """one query's record -> dict (see include/spdp.h, spdp_blk_vote)"""
+    n, calls, flags = int(rec[0]), int(rec[1]), int(rec[2])
+    if not flags & REACHED or flags & CUT:
+        return dict(reached=bool(flags & REACHED), calls=calls, flags=flags)
+    r = rec[:n]
+    j = 3
+    head = r[j:j + 20].copy(); j += 20
+    qb = []
+    for _ in range(4):
+        k = int(r[j]); qb.append(r[j + 1:j + 1 + 2 * k].reshape(k, 2).copy()); j += 1 + 2 * k
+    npairs = int(r[j]); pairs = r[j + 1:j + 1 + 9 * npairs].reshape(npairs, 9).copy(); j += 1 + 9 * npairs
+    nruns = int(r[j]); runs = r[j + 1:j + 1 + 2 * nruns].reshape(nruns, 2).copy(); j += 1 + 2 * nruns
+    assert j == n, (j, n)
+    by_d = [[] for _ in range(4)]
+    for code, scr in runs:
+        by_d[int(code) >> 28].append((int(code) & 0xfffffff, int(scr)))
+    return dict(reached=True, calls=calls, flags=flags, head=head, qb=qb, pairs=pairs, runs=[sorted(x) for x in by_d])

@@ -1,0 +1,197 @@
+// spdp_blk_api.cpp -- host side of the block search's vote (include/spdp.h, "block search"): the index goes to the device
+// once, a call uploads its queries, runs spdp_blk_vote_kernel over persistent lanes and brings the records back.
+#include "spdp_internal.h"
+#include "spdp_blk_core.h"
+#include "spdp_blk_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct SpdpBlkIndex {
+    SpdpContext* ctx = nullptr;
+    BlkDev dev;
+    std::vector<void*> bufs;                    // device copies of the index arrays
+    int32_t* slabs = nullptr; int32_t* scratch = nullptr;
+    size_t slab_ints = 0, scratch_ints = 0;
+    int n_lanes = 0, touched_cap = 0;
+    ~SpdpBlkIndex()
+    {
+        for (void* p : bufs) if (p) (void) hipFree(p);
+        if (slabs) (void) hipFree(slabs);
+        if (scratch) (void) hipFree(scratch);
+    }
+};
+
+namespace {
+
+template <class T>
+const T* to_device(SpdpBlkIndex* ix, const T* src, size_t n, hipError_t& e)
+{
+    void* d = nullptr;
+    if (e != hipSuccess) return nullptr;
+    e = hipMalloc(&d, std::max<size_t>(n * sizeof(T), 16));
+    if (e != hipSuccess) return nullptr;
+    ix->bufs.push_back(d);
+    e = hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice);
+    return (const T*) d;
+}
+
+// smallest prime-ish size the reference's Dhash(n, ..) picks is not restated here: the caller passes the geometry its own
+// containers have (SpdpBlkIndexDesc::hh_size ...); only the second step has a fixed default (SecondHS, src/clib.h:76)
+int or_default(int v, int d) { return v > 0 ? v : d; }
+
+// lanes of a launch: enough waves to cover the memory latency of every CU, as many slabs as fit the budget
+int pick_lanes(const SpdpContext* ctx, size_t slab_bytes)
+{
+    size_t budget = (size_t) 48 << 30;
+    if (const char* e = getenv("SPDP_BLK_SLAB_GB")) budget = (size_t) std::max(1, atoi(e)) << 30;
+    int waves_per_cu = 32;
+    if (const char* e = getenv("SPDP_BLK_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(atoi(e), 64));
+    size_t lanes = (size_t) std::max(1, ctx->n_cu) * waves_per_cu * 64;
+    lanes = std::min(lanes, std::max<size_t>(64, budget / std::max<size_t>(slab_bytes, 1)));
+    return (int) (lanes / 64 * 64);
+}
+
+}  // namespace
+
+extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIndexDesc* d)
+{
+    if (!ctx) return nullptr;
+    if (!d || !d->convtab || !d->nblk || !d->wscr || !d->blkp || !d->blkb || !d->rscrtab || !d->chr || !d->bitpat) {
+        ctx->err = "spdp_blk_index_create: index arrays missing"; return nullptr;
+    }
+    if (d->kk < 1 || d->kk > 3 || d->nshift < 1 || d->nshift > SPDP_BLK_MAX_SHIFT || d->tabsize < 1 || d->nseg < 2 ||
+        d->ncand < 1 || d->nascr < 1 || d->hh_size < 2 || d->hb_size < 2 || d->ha_size < 2 || d->maxmmc < 1 || d->n_chr < 1) {
+        ctx->err = "spdp_blk_index_create: parameter out of range (kk 1..3, Nshift <= 32, table geometries given)"; return nullptr;
+    }
+    if (!d->drna || d->nalpha != 4) {
+        ctx->err = "spdp_blk_index_create: only nucleotide queries against a nucleotide index (findblock) are implemented";
+        return nullptr;
+    }
+    (void) hipSetDevice(ctx->device);
+    SpdpBlkIndex* ix = new SpdpBlkIndex;
+    ix->ctx = ctx;
+    BlkDev& v = ix->dev;
+    memset(&v, 0, sizeof v);
+    v.nalpha = d->nalpha; v.tabsize = d->tabsize; v.nshift = d->nshift; v.nbitpat = d->nbitpat; v.convts = d->convts;
+    v.n_chr = d->n_chr; v.kk = d->kk; v.drna = d->drna; v.maxmmc = d->maxmmc; v.nseg = d->nseg; v.minsigpr = d->minsigpr;
+    v.ncand = d->ncand; v.nascr = d->nascr; v.maxblock = d->maxblock; v.extblock = d->extblock; v.shortquery = d->shortquery;
+    v.hh_size1 = d->hh_size; v.hh_size2 = or_default(d->hh_step, 8);
+    v.hb_size1 = d->hb_size; v.hb_size2 = or_default(d->hb_step, 8);
+    v.ha_size1 = d->ha_size; v.ha_size2 = or_default(d->ha_step, 8);
+    blk_fill_hash_levels(v);
+    v.gdb = d->gdb; v.rbscoef = d->rbscoef; v.rbscons = d->rbscons;
+    v.bclw = d->bclw; v.bcup = d->bcup; v.bcce = d->bcce;
+    v.app_c = d->kk > 1 ? pow((double) d->nbitpat, d->cfact) : 1.;
+    int at = 0;
+    for (int k = 0; k < d->kk; ++k) {
+        if (at + 3 > d->n_bitpat || d->bitpat[at] < 1 || at + 3 + 2 * d->bitpat[at] > d->n_bitpat) {
+            ctx->err = "spdp_blk_index_create: bit-pattern record too short"; delete ix; return nullptr;
+        }
+        v.pat_off[k] = at;
+        at += 3 + 2 * d->bitpat[at];
+    }
+    // posting lists must stay inside blkb: a malformed index would send lanes out of bounds
+    for (int64_t w = 0; w < d->tabsize; ++w)
+        if (d->blkp[w] && ((int64_t) d->blkp[w] - 1 + d->nblk[w] > d->n_words || d->blkp[w] < 0)) {
+            ctx->err = "spdp_blk_index_create: a posting list runs past blkb"; delete ix; return nullptr;
+        }
+    hipError_t e = hipSuccess;
+    v.convtab = to_device(ix, d->convtab, d->convts, e);
+    v.nblk = to_device(ix, d->nblk, d->tabsize, e);
+    v.wscr = to_device(ix, d->wscr, d->tabsize, e);
+    v.blkp = to_device(ix, d->blkp, d->tabsize, e);
+    v.blkb = to_device(ix, d->blkb, (size_t) d->n_words, e);
+    v.rscrtab = to_device(ix, d->rscrtab, 128, e);
+    v.chr = to_device(ix, d->chr, 2 * ((size_t) d->n_chr + 1), e);
+    v.bitpat = to_device(ix, d->bitpat, d->n_bitpat, e);
+    if (e != hipSuccess) { ctx->err = std::string("spdp_blk_index_create: ") + hipGetErrorString(e); delete ix; return nullptr; }
+    ix->touched_cap = 2048;
+    ix->slab_ints = blk_work_ints(v, ix->touched_cap);
+    ix->scratch_ints = ((sizeof(BlkPair) * ((size_t) v.ncand + 2) + sizeof(uint32_t) * (2 * (2 * (size_t) v.ncand + 2) + 2)) / 4 + 3) & ~(size_t) 3;
+    return ix;
+}
+
+extern "C" void spdp_blk_index_destroy(SpdpBlkIndex* ix)
+{
+    if (!ix) return;
+    (void) hipSetDevice(ix->ctx->device);
+    delete ix;
+}
+
+static int ensure_lanes(SpdpContext* ctx, SpdpBlkIndex* ix, int n)
+{
+    int want = pick_lanes(ctx, ix->slab_ints * 4);
+    want = std::min(want, std::max(64, (n + 63) / 64 * 64));
+    if (want <= ix->n_lanes) return 0;
+    if (ix->slabs) { (void) hipFree(ix->slabs); ix->slabs = nullptr; }
+    if (ix->scratch) { (void) hipFree(ix->scratch); ix->scratch = nullptr; }
+    ix->n_lanes = 0;
+    HIPCHK(hipMalloc((void**) &ix->slabs, (size_t) want * ix->slab_ints * 4));
+    HIPCHK(hipMalloc((void**) &ix->scratch, (size_t) want * ix->scratch_ints * 4));
+    HIPCHK(hipMemsetAsync(ix->slabs, 0, (size_t) want * ix->slab_ints * 4, ctx->stream));     // the kernel leaves every slab as it found it
+    ix->n_lanes = want;
+    return 0;
+}
+
+extern "C" int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* cix, const uint8_t* d_codes, const int64_t* d_offs,
+                                      const int32_t* d_left, const int32_t* d_right, const int32_t* d_stop_at, int32_t n,
+                                      int32_t* d_out, int32_t out_cap, float* kernel_ms)
+{
+    if (!ctx) return -1;
+    SpdpBlkIndex* ix = const_cast<SpdpBlkIndex*>(cix);
+    if (!ix || ix->ctx != ctx) { ctx->err = "spdp_blk_vote: the index belongs to another context"; return -1; }
+    if (n <= 0) return 0;
+    if (out_cap < 3) { ctx->err = "spdp_blk_vote: out_cap < 3"; return -1; }
+    (void) hipSetDevice(ctx->device);
+    if (ensure_lanes(ctx, ix, n)) return -1;
+    BlkArgs A;
+    A.ix = ix->dev;
+    A.codes = d_codes; A.offs = d_offs; A.left = d_left; A.right = d_right; A.stop_at = d_stop_at;
+    A.out = d_out; A.out_cap = out_cap; A.n = n;
+    A.slabs = ix->slabs; A.slab_ints = ix->slab_ints; A.scratch = ix->scratch; A.scratch_ints = ix->scratch_ints;
+    A.n_lanes = std::min(ix->n_lanes, (n + 63) / 64 * 64);
+    A.touched_cap = ix->touched_cap;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(spdp_blk_launch(&A, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+extern "C" int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* codes, const int64_t* offs,
+                             const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n,
+                             int32_t* out, int32_t out_cap, float* kernel_ms)
+{
+    if (!ctx) return -1;
+    if (n <= 0) return 0;
+    if (!codes || !offs || !left || !right || !out) { ctx->err = "spdp_blk_vote: null argument"; return -1; }
+    for (int i = 0; i < n; ++i) {
+        const int64_t len = offs[i + 1] - offs[i];
+        if (len < 0 || len > INT32_MAX || left[i] < 0 || right[i] > len || right[i] < left[i]) {
+            ctx->err = "spdp_blk_vote: bad query range"; return -1;
+        }
+    }
+    (void) hipSetDevice(ctx->device);
+    struct Dev { void* p = nullptr; ~Dev() { if (p) (void) hipFree(p); } } d_codes, d_offs, d_l, d_r, d_s, d_out;
+    const size_t nb = (size_t) (offs[n] - offs[0]);
+    HIPCHK(hipMalloc(&d_codes.p, std::max<size_t>(nb, 16)));
+    HIPCHK(hipMalloc(&d_offs.p, ((size_t) n + 1) * 8));
+    HIPCHK(hipMalloc(&d_l.p, (size_t) n * 4)); HIPCHK(hipMalloc(&d_r.p, (size_t) n * 4));
+    if (stop_at) HIPCHK(hipMalloc(&d_s.p, (size_t) n * 4));
+    HIPCHK(hipMalloc(&d_out.p, (size_t) n * out_cap * 4));
+    std::vector<int64_t> rel(n + 1);
+    for (int i = 0; i <= n; ++i) rel[i] = offs[i] - offs[0];
+    HIPCHK(hipMemcpyAsync(d_codes.p, codes + offs[0], nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_offs.p, rel.data(), ((size_t) n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_l.p, left, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_r.p, right, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (stop_at) HIPCHK(hipMemcpyAsync(d_s.p, stop_at, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // (rel is a local: the copies must have read it)
+    if (spdp_blk_vote_resident(ctx, ix, (const uint8_t*) d_codes.p, (const int64_t*) d_offs.p, (const int32_t*) d_l.p,
+                               (const int32_t*) d_r.p, (const int32_t*) d_s.p, n, (int32_t*) d_out.p, out_cap, kernel_ms)) return -1;
+    HIPCHK(hipMemcpy(out, d_out.p, (size_t) n * out_cap * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

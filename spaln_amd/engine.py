@@ -31,6 +31,7 @@ EXPORTS = [
     "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
     "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
     "spdp_align_s_seeded", "spdp_align_s_seeded_ori3", "spdp_seeded_stats",
+    "spdp_blk_index_create", "spdp_blk_index_destroy", "spdp_blk_vote", "spdp_blk_vote_resident",
 ]
 
 

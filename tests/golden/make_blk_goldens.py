@@ -88,9 +88,65 @@ def main():
                                env=dict(e, SPDP_BLK_LOG=log), capture_output=True, text=True)
             if r.returncode != 0 or not os.path.exists(log):
                 sys.exit(f"{name}: reference run failed: {r.stderr[-300:]}")
-            shutil.copyfile(log, os.path.join(OUT, name + ".spdg"))
+            # ConvTab[0], [1] (the nil / unknown codes, which no sequence position holds) are never written by the reference:
+            # whatever the heap held is replaced by "not a residue", so that regenerating gives the same file
+            from tests import spdg
+            fx = spdg.load(log)
+            fx["blk_convtab"][:2] = 255
+            spdg.save(os.path.join(OUT, name + ".spdg"), {k: v for k, v in fx.items() if k != "prm"})
             print(f"{name}: genome {sum(len(c) for c in chroms)} nt, {len(queries)} queries, "
                   f"{os.path.getsize(log) / 1e6:.2f} MB, {r.stdout.count(chr(10) + '@')} aligned")
+            if name == "blk_k3":
+                grow_fixture(td, e, os.path.join(OUT, name + ".spdg"))
+
+
+def grow_fixture(td, env, index_fixture):
+    """blk_k3_grow.spdg: queries on which a position hash of the reference's queues GROWS (Dhash::resize) -- found with the
+    oracle by random search (noisy fragments of the fixture's own queries; kept from the committed file when it exists) --
+    each run through the reference in a process of its own (q_log: what a fresh worker does) and all in one process
+    (q_log_batch: the grown tables persist from query to query there).  Index arrays: those of blk_k3.spdg."""
+    import ctypes as C
+    from oracle import blk, oracle
+    from tests import spdg
+    fx = spdg.load(index_fixture)
+    ix, _keep = blk.index_of(fx)
+    out = os.path.join(OUT, "blk_k3_grow.spdg")
+    if os.path.exists(out):
+        queries = [q["codes"] for q in blk.parse_log(dict(spdg.load(out), blk_prm=fx["blk_prm"]))]
+    else:
+        grows = C.c_int.in_dll(oracle.lib(), "spdp_oracle_blk_grows")
+        rng = np.random.default_rng(7)
+        pool = [q["codes"] for q in blk.parse_log(fx)]
+        queries = []
+        while len(queries) < 12:
+            a = pool[int(rng.integers(len(pool)))]
+            lo = int(rng.integers(0, max(1, len(a) - 40)))
+            b = a[lo:lo + int(rng.integers(200, 900))].copy()
+            hits = rng.random(b.size) < rng.choice([0.02, 0.2, 0.25])
+            b[hits] = rng.choice(np.array([2, 3, 5, 9], dtype=np.uint8), size=int(hits.sum()))
+            for stop in range(4):
+                g0 = grows.value
+                if blk.vote(ix, b, 0, len(b), stop) is None:
+                    break
+                if grows.value > g0:
+                    queries.append(b)
+                    break
+    dec = {2: "A", 3: "C", 5: "G", 9: "T", 16: "N"}
+    tap = [os.path.join(REF, "spaln_blktap"), "-Q7", "-O4", "-t1", "-dgnm"]
+    logs = []
+    for i, b in enumerate(queries):
+        with open(os.path.join(td, "one.fa"), "w") as f:
+            f.write(f">g{i}\n" + "".join(dec[int(x)] for x in b) + "\n")
+        log = os.path.join(td, f"one_{i}.spdg")
+        subprocess.run(tap + ["one.fa"], cwd=td, env=dict(env, SPDP_BLK_LOG=log), capture_output=True, check=True)
+        logs.append(np.asarray(spdg.load(log)["q_log"], dtype=np.int32))
+    with open(os.path.join(td, "all.fa"), "w") as f:
+        for i, b in enumerate(queries):
+            f.write(f">g{i}\n" + "".join(dec[int(x)] for x in b) + "\n")
+    log = os.path.join(td, "all.spdg")
+    subprocess.run(tap + ["all.fa"], cwd=td, env=dict(env, SPDP_BLK_LOG=log), capture_output=True, check=True)
+    spdg.save(out, {"q_log": np.concatenate(logs), "q_log_batch": np.asarray(spdg.load(log)["q_log"], dtype=np.int32)})
+    print(f"blk_k3_grow: {len(queries)} queries, {os.path.getsize(out) / 1e6:.2f} MB")
 
 
 if __name__ == "__main__":

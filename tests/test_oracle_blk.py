@@ -69,3 +69,49 @@ def test_findblock_ends_where_the_reference_ended(case):
     for q in qs:
         if len(q["calls"]) == ix.minsigpr + 1:
             assert blk.vote(ix, q["codes"], q["left"], q["right"], len(q["calls"])) is None
+
+
+# ---- Dhash::resize: a position hash of the queues grows -------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def grow_case():
+    base = spdg.load(os.path.join(HERE, "golden", "blk_k3.spdg"))
+    fx = spdg.load(os.path.join(HERE, "golden", "blk_k3_grow.spdg"))
+    ix, keep = blk.index_of(base)
+    single = blk.parse_log(dict(q_log=fx["q_log"], blk_prm=base["blk_prm"]))
+    batch = blk.parse_log(dict(q_log=fx["q_log_batch"], blk_prm=base["blk_prm"]))
+    return ix, keep, single, batch
+
+
+def test_growth_in_a_fresh_process(grow_case):
+    """each query run by the reference in a process of its own: the oracle equals every call, and tables do grow on the way"""
+    ix, _, single, _ = grow_case
+    g0 = blk.grows()
+    for qi, q in enumerate(single):
+        for ci, (want_vote, want_pairs) in enumerate(q["calls"]):
+            got = blk.vote(ix, q["codes"], q["left"], q["right"], ci)
+            assert got is not None and np.array_equal(got[0], want_vote), (qi, ci)
+            if want_pairs is not None:
+                k = int(got[1][1])
+                assert np.array_equal(got[1][2:2 + 9 * k], want_pairs[2:2 + 9 * k]), (qi, ci)
+    assert blk.grows() - g0 >= 3
+
+
+def test_grown_tables_persist_on_the_reference_worker(grow_case):
+    """the same queries in ONE reference process: later queries see the position hashes at the size earlier ones grew them to.
+    With that memory carried along the oracle equals the batch run as well; without it, it must differ somewhere (the
+    fixture would otherwise not witness the dependence)."""
+    ix, _, single, batch = grow_case
+    assert [q["codes"].tolist() for q in single] == [q["codes"].tolist() for q in batch]
+    carry = blk.new_carry(ix)
+    differs = 0
+    for qi, q in enumerate(batch):
+        last = len(q["calls"]) - 1
+        for ci, (want_vote, _) in enumerate(q["calls"]):
+            c2 = carry.copy()
+            rec = blk.vote_carry(ix, q["codes"], q["left"], q["right"], ci, c2)
+            assert rec is not None and np.array_equal(rec[:want_vote.size], want_vote), (qi, ci)
+            fresh = blk.vote(ix, q["codes"], q["left"], q["right"], ci)
+            differs += not np.array_equal(fresh[0], want_vote)
+            if ci == last:
+                carry = c2
+    assert differs > 0

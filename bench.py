@@ -368,6 +368,210 @@ def main_c3(args):
         dist.destroy_process_group()
 
 
+def _blk_oracle_chunk(job):
+    """cpu_baseline worker of the block-search leg: the oracle's vote (oracle/spdp_oracle_blk.c) on a chunk of queries"""
+    fx_path, queries = job
+    from oracle import blk
+    from tests import spdg
+    ix, _keep = blk.index_of(spdg.load(fx_path))
+    t0 = time.perf_counter()
+    for q in queries:
+        blk.vote(ix, q, 0, len(q), 0)
+    return time.perf_counter() - t0
+
+
+def main_blk(args):
+    """SURVEY 8 row f4, first slice, measured: the vote of the block search (SrchBlk::findblock up to its first TestOutput
+    call + the candidate block pairs) for a batch of 500-nt ESTs against the index of a synthetic 100 Mb genome.  The genome
+    is formatted by the compiled reference's own `spaln -W` where oracle/_ref is present -- the index is an INPUT, like the
+    genome -- and read back through the recorder build (spaln_blktap); one step = one spdp_blk_vote_resident call over all
+    ESTs, queries and records resident in HBM."""
+    import subprocess
+    import tempfile
+    torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
+    from spaln_amd import blocks, engine, synth
+    from tests import spdg
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref, "spaln_blktap")):
+        raise SystemExit("--workload blk needs the reference's formatter (oracle/_ref/spaln, spaln_blktap) to make its input index")
+    n_q = args.queries
+    rng = np.random.default_rng(synth.SEED + 4400 + rank)
+    t_in = time.perf_counter()
+    n_chr, chr_len, n_genes = 4, 25_000_000, 400
+    genes = [synth.make_gene(np.random.default_rng(synth.SEED + 4401 + i)) for i in range(n_genes)]
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    td = tempfile.mkdtemp(prefix="spdp_blk_")
+    where = []                                                   # (chromosome, offset) of every planted locus
+    with open(os.path.join(td, "gnm.mfa"), "wb") as f:
+        per = n_genes // n_chr
+        for c in range(n_chr):
+            s = synth.random_dna(rng, chr_len)
+            for k in range(per):
+                g = genes[c * per + k]
+                o = 100_000 + k * ((chr_len - 200_000) // per)
+                s[o:o + len(g.window)] = g.window
+                where.append((c, o))
+            f.write(f">chr{c + 1}\n".encode())
+            body = s[:chr_len // 60 * 60].reshape(-1, 60)
+            out = np.empty((body.shape[0], 61), dtype=np.uint8)
+            out[:, :60] = body
+            out[:, 60] = 10
+            f.write(out.tobytes())
+            f.write(s[chr_len // 60 * 60:].tobytes() + b"\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
+    env.update(ALN_TAB=REF_TAB, ALN_DBS=td)
+    subprocess.run([os.path.join(ref, "spaln"), "-W", "-KD", f"-t{_host_cores()}", "gnm.mfa"], cwd=td, env=env, check=True, capture_output=True)
+    with open(os.path.join(td, "q.fa"), "w") as f:
+        f.write(">q0\n" + bytes(genes[0].query).decode() + "\n")
+    fx_path = os.path.join(td, "index.spdg")
+    subprocess.run([os.path.join(ref, "spaln_blktap"), "-Q7", "-O4", "-t1", "-dgnm", "q.fa"], cwd=td,
+                   env=dict(env, SPDP_BLK_LOG=fx_path), check=True, capture_output=True)
+    fx = spdg.load(fx_path)
+    fx["blk_convtab"][:2] = 255
+    # the ESTs: 500-nt fragments of the planted transcripts, 1 % substitutions, every other one reverse-complemented
+    code_of = np.zeros(256, dtype=np.uint8)
+    for ch, code in zip(b"ACGTN", (2, 3, 5, 9, 16)):
+        code_of[ch] = code
+    frag = 500
+    gi = rng.integers(0, n_genes, size=n_q)
+    codes = np.empty((n_q, frag), dtype=np.uint8)
+    truth = np.empty((n_q, 2), dtype=np.int64)
+    for g_idx in range(n_genes):
+        sel = np.nonzero(gi == g_idx)[0]
+        if not sel.size:
+            continue
+        q = genes[g_idx].query
+        off = rng.integers(0, len(q) - frag, size=sel.size)
+        codes[sel] = q[off[:, None] + np.arange(frag)[None, :]]
+        truth[sel, 0], truth[sel, 1] = where[g_idx][0], where[g_idx][1]
+    sub = rng.random(codes.shape) < 0.01
+    codes[sub] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(sub.sum()))
+    rc = (np.arange(n_q) & 1).astype(bool)
+    codes[rc] = comp[codes[rc][:, ::-1]]
+    codes = code_of[codes]
+    input_s = time.perf_counter() - t_in
+
+    eng = engine.Engine(local_rank)
+    dix = blocks.BlockIndex(eng, fx)
+    out_cap = 768
+    dev = torch.device("cuda", local_rank)
+    d_codes = torch.from_numpy(codes.reshape(-1)).to(dev)
+    d_offs = torch.arange(0, (n_q + 1) * frag, frag, dtype=torch.int64, device=dev)
+    d_left = torch.zeros(n_q, dtype=torch.int32, device=dev)
+    d_right = torch.full((n_q,), frag, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((n_q, out_cap), dtype=torch.int32, device=dev)
+
+    def step():
+        return dix.vote_resident(d_codes.data_ptr(), d_offs.data_ptr(), d_left.data_ptr(), d_right.data_ptr(), None, n_q,
+                                 d_out.data_ptr(), out_cap)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kms = [step() for _ in range(args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        rec = d_out.cpu().numpy()
+        reached = (rec[:, 2] & blocks.REACHED) != 0
+        flagged = int(((rec[:, 2] & (blocks.CUT | blocks.TABLE)) != 0).sum())
+        # mapping accuracy: the best candidate pair covers the planted locus, on the right strand
+        prm = fx["blk_prm"]
+        blklen = int(prm[6])
+        chr_first = np.asarray(fx["blk_chr"]).reshape(-1, 2)[:, 1]
+        hit = hit_any = 0
+        sample = np.arange(0, n_q, max(1, n_q // 20000))
+        for i in sample:
+            r = blocks.split_record(rec[i])
+            if not r.get("reached") or "pairs" not in r or not len(r["pairs"]):
+                continue
+            bscr, c, lb, rb, ub, db, zl, zr, rvs = (int(x) for x in r["pairs"][0])
+            lo, hi = (lb - zl) * blklen if zl else 0, ((rb - zl if zl else 0) + 1) * blklen
+            covers = c == truth[i, 0] and lo <= truth[i, 1] + 60000 and truth[i, 1] <= hi
+            hit += covers and rvs == int(rc[i])
+            hit_any += covers
+        # parity on a sample against the oracle (the pinned restatement), in the same run
+        from oracle import blk as oblk
+        ix, _keep = oblk.index_of(fx)
+        same = 0
+        chk = sample[:300]
+        for i in chk:
+            want = oblk.vote(ix, codes[i], 0, frag, 0)
+            got = blocks.split_record(rec[i])
+            if want is None:
+                same += not got.get("reached")
+                continue
+            w = oblk.split_recorded(want[0], want[1])
+            same += bool(got.get("reached") and "head" in got and np.array_equal(got["head"], w["head"]) and
+                         np.array_equal(got["pairs"], want[1][2:].reshape(-1, 9)) and
+                         got["runs"] == [sorted(x) for x in oblk.runs_near_pairs(ix, w["runs"], got["pairs"])])
+        # CPU baseline: the oracle's vote, one process per host core
+        import multiprocessing as mp
+        ncores = _host_cores()
+        ns = min(n_q, args.cpu_sample if args.cpu_sample > 0 else 400 * ncores)
+        spdg.save(fx_path, {k: v for k, v in fx.items() if k != "prm"})
+        jobs = [(fx_path, [codes[i] for i in range(c, ns, ncores)]) for c in range(ncores)]
+        with mp.get_context("fork").Pool(ncores) as pool:
+            busy = pool.map(_blk_oracle_chunk, jobs)
+        cpu_qps = ns / max(busy)
+        k_ms = float(np.mean(kms))
+        words = int(prm[11])
+        # algorithmic bytes per query: its codes once, per looked-up word the two table entries (Nblk 2 B, wscr 2 B, blkp 4 B) and
+        # its posting list (4 B per listed block), per listed block one read-modify-write of two 4-byte score slots; the record out
+        tw = rec[reached, 3 + 16:3 + 20].sum(axis=1).mean() if reached.any() else 0.0
+        avg_list = words / max(1, int((np.asarray(fx["blk_blkp"]) != 0).sum()))
+        bytes_per_q = frag + tw * (8 + avg_list * (4 + 16)) + 4 * float(rec[:, 0].mean())
+        achieved = n_q * bytes_per_q / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "queries/s, block search vote (findblock) for 500-nt ESTs vs a 100 Mb genome index", "value": round(n_q * world * args.steps / dt, 1),
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 / int32", "data": "synthetic",
+            "config": {"workload": f"block search, first slice of SURVEY 8 f4: {n_q} ESTs of {frag} nt (1 % substitutions, half of them "
+                                   f"reverse strand) vs the index of a synthetic {n_chr * chr_len // 1000000} Mb genome ({n_genes} planted loci); "
+                                   "index made by the compiled reference's own formatter (spaln -W -KD), an input; one step = "
+                                   "spdp_blk_vote over all ESTs, queries and records resident in HBM",
+                       "queries_per_gpu": n_q, "queries_per_s": round(n_q * world * args.steps / dt, 1),
+                       "cells_per_gpu_per_step": 0,
+                       "index": {"ktuple": int(prm[1]), "tabsize": int(prm[3]), "nshift": int(prm[5]), "blklen": blklen, "nseg": int(prm[19]),
+                                 "words": words, "patterns": int(prm[8])},
+                       "reached_first_call": int(reached.sum()), "flagged": flagged,
+                       "best_pair_covers_planted_locus": f"{hit_any} / {len(sample)} ({hit} with the strand as planted)",
+                       "identical_to_oracle_on_sample": f"{same} / {len(chk)}",
+                       "words_looked_up_per_query": round(float(tw), 1),
+                       "input_generation_s": round(input_s, 1),
+                       "reference_parity": "the vote's state at every TestOutput call and the block pairs handed to FindHsp: bit-identical to the "
+                                           "compiled reference's recorded runs (tests/golden/blk_*.spdg: tests/test_gpu_blk.py); FindHsp itself "
+                                           "(Wilip on the candidate region) stays with the caller"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "bytes_per_query": round(float(bytes_per_q), 1), "traffic": None, "kernel": "spdp_blk_vote_kernel", "kernel_ms": round(k_ms, 3),
+                         "note": "one query per lane, random 4 .. 8-byte accesses into posting lists and the lane's private score slab: bound by "
+                                 "memory transactions in flight and by divergence, not by bytes; algorithmic bytes = codes + per word its table "
+                                 "entries and posting list + two score slots per listed block + the record"},
+            "cpu_baseline": {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
+                             "sample": f"first {ns} ESTs through the oracle's vote (oracle/spdp_oracle_blk.c), one process per host core"},
+        }
+        print(json.dumps(out), flush=True)
+    dix.free()
+    eng.close()
+    import shutil
+    shutil.rmtree(td, ignore_errors=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def _valu_roofline(cells, kind, k_ms):
     """the bound that actually binds: VALU wave-instructions issued per second against the measured ceiling"""
     if not k_ms or not cells:
@@ -433,6 +637,8 @@ LEGS = {
            "BASELINE configs[3]'s per-EST work on a 20 000-fragment batch (planted windows; the 3 Gb genome's block search is SURVEY 8 row f4)"),
     "c5": (["--workload", "c5", "--queries", "32", "--steps", "2", "--warmup", "1", "--cpu-sample", "16"],
            "BASELINE configs[4]: 32 cDNAs of 50 kb, 25 exons, against their ~190 kb loci"),
+    "blk": (["--workload", "blk", "--queries", "200000", "--steps", "3", "--warmup", "1"],
+            "SURVEY 8 row f4, first slice: the block search's vote for 200 000 ESTs against the index of a 100 Mb genome"),
     "a0": (["--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
            "C2 shape under -A0 (forwardS_ng / hirschbergS_ng): the engines whose output is bit-identical to the reference's own -A0 records on 2 kb inputs"),
     "a1": (["--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"], "C2 shape under -A1 (forwardS1 / hirschbergS1)"),
@@ -495,7 +701,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seeded-pairs", type=int, default=10000,
                     help="pairs of the seeded-path (-Q7) leg reported in config.seeded_q7 (c2, N = 1; 0: skip)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "blk"], default="c2",
                     help="c2: cDNA x genome (the headline); c3: protein x genome (Fwd2h1 path); "
                          "c4: 500-nt ESTs (traceback branch of the ladder only); c5: 50 kb cDNAs with 25 exons "
                          "(recursive linear-space branch all the way down)")
@@ -516,11 +722,13 @@ def main():
                          "batch of --queries sharded over the ranks; the other one is reported under config")
     args = ap.parse_args()
     if not args.queries:
-        args.queries = (32 if args.workload == "c5" else 10000) if args.engines == "wip" else 1000
+        args.queries = ({"c5": 32, "blk": 200000}.get(args.workload, 10000)) if args.engines == "wip" else 1000
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_spawn(sys.argv[1:], args.gpus)
     if args.workload == "c3":
         return main_c3(args)
+    if args.workload == "blk":
+        return main_blk(args)
 
     torch, dist, rank, world, local_rank, coll_dev = _dist_setup()
 

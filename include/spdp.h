@@ -690,7 +690,7 @@ typedef struct SpdpBlkIndexDesc {
     int32_t convts, n_chr, maxblk;                   /* pbwc->ConvTS, ChrNo, MaxBlk */
     int32_t kk, drna, maxmmc, nseg;                  /* SrchBlk::kk, DRNA, maxmmc, nseg */
     int32_t minsigpr, ncand, nascr;                  /* MinSigpr, Ncand, Nascr (src/blksrc.cc:52-69, 2220) */
-    int32_t maxblock, extblock, shortquery;          /* MaxBlock, ExtBlock (:2213-2215), shortquery (src/wln.h:34, set :2219) */
+    int32_t maxblock, extblock, extblockl, shortquery;   /* MaxBlock, ExtBlock, ExtBlockL (:2213-2216), shortquery (src/wln.h:34, set :2219) */
     int32_t hh_size, hh_step;                        /* geometry of Dhash<INT,int>(2 * MaxBlk, 0): size1, size2 (src/clib.h:257-267); */
     int32_t hb_size, hb_step, ha_size, ha_step;      /*   of the position hashes of the Ncand / Nascr queues; 0 = derive (hh_step etc. = 8) */
     int32_t gdb;                                     /* Randbs: log (genomic database) or sqrt transform beyond its table */
@@ -717,7 +717,8 @@ void          spdp_blk_index_destroy(SpdpBlkIndex* ix);
  * one of the reference-sized hash tables ran full, where the reference would grow it), then sign[4] mmct[4] nhit[4] maxs[4]
  * testword[4] (Bhit4); per direction n, (block, score) x n: the significant blocks (prqueue_b, heap order); n_pairs and
  * nine ints per candidate pair, best first (BPAIR: bscr chr lb rb ub db zl zr rvs); n_runs and (block | direction << 28,
- * score) x n_runs: every block with a run score (Bhit4::bscr), unordered.  kernel_ms (may be NULL): HIP-event time. */
+ * score) x n_runs: the run scores (Bhit4::bscr) FindHsp can look at -- within ExtBlockL blocks of a reported pair, inside its
+ * chromosome, on its strand -- unordered.  kernel_ms (may be NULL): HIP-event time. */
 #define SPDP_BLK_REACHED 1
 #define SPDP_BLK_CUT     2
 #define SPDP_BLK_TABLE   4

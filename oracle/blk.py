@@ -16,7 +16,7 @@ class BlkIndex(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nalpha", "ktuple", "tabsize", "nshift", "blklen", "nbitpat", "convts", "n_chr", "avrscr", "maxblk",
         "kk", "drna", "maxmmc", "nseg", "minsigpr", "ncand", "nascr", "maxblock", "extblock", "shortquery",
-        "hh_size1", "hh_size2", "hb_size1", "hb_size2", "ha_size1", "ha_size2", "phase1t", "gdb", "has_chrid", "pad0")] + [
+        "hh_size1", "hh_size2", "hb_size1", "hb_size2", "ha_size1", "ha_size2", "phase1t", "gdb", "has_chrid", "extblockl")] + [
         ("rbscoef", C.c_float), ("rbscons", C.c_float),
         ("bclw", C.c_double), ("bcup", C.c_double), ("bcce", C.c_double), ("cfact", C.c_double),
         ("convtab", C.c_void_p), ("nblk", C.c_void_p), ("wscr", C.c_void_p), ("blkp", C.c_void_p), ("blkb", C.c_void_p),
@@ -170,3 +170,19 @@ def new_carry(ix: BlkIndex) -> np.ndarray:
 def grows() -> int:
     """how often a hash table of the oracle has grown so far (Dhash::resize)"""
     return int(C.c_int.in_dll(_o.lib(), "spdp_oracle_blk_grows").value)
+
+
+def runs_near_pairs(ix: BlkIndex, runs, pairs):
+    """the part of the recorded run scores the product reports: blocks within ExtBlockL of a reported pair, inside its
+    chromosome, on its strand (runs: per direction [(block, score)], pairs: rows of nine ints)"""
+    e = int(ix.extblockl)
+    out = []
+    for d in range(4):
+        keep = []
+        for blk_, scr in runs[d]:
+            for bscr, c, lb, rb, ub, db, zl, zr, rvs in (tuple(int(x) for x in p) for p in pairs):
+                if rvs == d >> 1 and max(lb - e, zl, 0) <= blk_ <= min(rb + e, zr):
+                    keep.append((blk_, scr))
+                    break
+        out.append(keep)
+    return out

@@ -11,7 +11,7 @@ extern "C" {
 struct BlkIndexC {                       // = BlkIndex of oracle/spdp_oracle_blk.c (oracle/blk.py fills it)
     int32_t nalpha, ktuple, tabsize, nshift, blklen, nbitpat, convts, n_chr, avrscr, maxblk;
     int32_t kk, drna, maxmmc, nseg, minsigpr, ncand, nascr, maxblock, extblock, shortquery;
-    int32_t hh_size1, hh_size2, hb_size1, hb_size2, ha_size1, ha_size2, phase1t, gdb, has_chrid, pad0;
+    int32_t hh_size1, hh_size2, hb_size1, hb_size2, ha_size1, ha_size2, phase1t, gdb, has_chrid, extblockl;
     float rbscoef, rbscons;
     double bclw, bcup, bcce, cfact;
     const uint8_t* convtab; const uint16_t* nblk; const int16_t* wscr; const int32_t* blkp; const uint32_t* blkb;
@@ -25,7 +25,7 @@ int blk_check_vote(const BlkIndexC* c, const uint8_t* q, int q_len, int left, in
     memset(&ix, 0, sizeof ix);
     ix.nalpha = c->nalpha; ix.tabsize = c->tabsize; ix.nshift = c->nshift; ix.nbitpat = c->nbitpat; ix.convts = c->convts;
     ix.n_chr = c->n_chr; ix.kk = c->kk; ix.drna = c->drna; ix.maxmmc = c->maxmmc; ix.nseg = c->nseg; ix.minsigpr = c->minsigpr;
-    ix.ncand = c->ncand; ix.nascr = c->nascr; ix.maxblock = c->maxblock; ix.extblock = c->extblock; ix.shortquery = c->shortquery;
+    ix.ncand = c->ncand; ix.nascr = c->nascr; ix.maxblock = c->maxblock; ix.extblock = c->extblock; ix.extblockl = c->extblockl; ix.shortquery = c->shortquery;
     ix.hh_size1 = c->hh_size1; ix.hh_size2 = c->hh_size2; ix.hb_size1 = c->hb_size1; ix.hb_size2 = c->hb_size2;
     ix.ha_size1 = c->ha_size1; ix.ha_size2 = c->ha_size2; ix.gdb = c->gdb;
     ix.rbscoef = c->rbscoef; ix.rbscons = c->rbscons; ix.bclw = c->bclw; ix.bcup = c->bcup; ix.bcce = c->bcce;

@@ -14,7 +14,7 @@ import numpy as np
 class BlkIndexDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nalpha", "tabsize", "nshift", "nbitpat", "convts", "n_chr", "maxblk", "kk", "drna", "maxmmc", "nseg",
-        "minsigpr", "ncand", "nascr", "maxblock", "extblock", "shortquery", "hh_size", "hh_step", "hb_size", "hb_step",
+        "minsigpr", "ncand", "nascr", "maxblock", "extblock", "extblockl", "shortquery", "hh_size", "hh_step", "hb_size", "hb_step",
         "ha_size", "ha_step", "gdb")] + [
         ("rbscoef", C.c_float), ("rbscons", C.c_float),
         ("bclw", C.c_double), ("bcup", C.c_double), ("bcce", C.c_double), ("cfact", C.c_double),
@@ -25,7 +25,7 @@ class BlkIndexDesc(C.Structure):
 
 # positions in the parameter record of a reference-side index dump (oracle/ref_build/blk_tap.cc, dump_index)
 _PRM = dict(nalpha=0, tabsize=3, nshift=5, nbitpat=8, convts=10, n_chr=12, maxblk=14, kk=15, drna=16, maxmmc=17, nseg=19,
-            minsigpr=22, ncand=23, nascr=24, maxblock=25, extblock=26, shortquery=28, hh_size=29, hh_step=30, hb_size=31,
+            minsigpr=22, ncand=23, nascr=24, maxblock=25, extblock=26, extblockl=27, shortquery=28, hh_size=29, hh_step=30, hb_size=31,
             hb_step=32, ha_size=33, ha_step=34, gdb=38)
 REACHED, CUT, TABLE = 1, 2, 4
 

@@ -76,7 +76,7 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
     memset(&v, 0, sizeof v);
     v.nalpha = d->nalpha; v.tabsize = d->tabsize; v.nshift = d->nshift; v.nbitpat = d->nbitpat; v.convts = d->convts;
     v.n_chr = d->n_chr; v.kk = d->kk; v.drna = d->drna; v.maxmmc = d->maxmmc; v.nseg = d->nseg; v.minsigpr = d->minsigpr;
-    v.ncand = d->ncand; v.nascr = d->nascr; v.maxblock = d->maxblock; v.extblock = d->extblock; v.shortquery = d->shortquery;
+    v.ncand = d->ncand; v.nascr = d->nascr; v.maxblock = d->maxblock; v.extblock = d->extblock; v.extblockl = d->extblockl; v.shortquery = d->shortquery;
     v.hh_size1 = d->hh_size; v.hh_size2 = or_default(d->hh_step, 8);
     v.hb_size1 = d->hb_size; v.hb_size2 = or_default(d->hb_step, 8);
     v.ha_size1 = d->ha_size; v.ha_size2 = or_default(d->ha_step, 8);

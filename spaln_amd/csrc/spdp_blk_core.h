@@ -33,7 +33,7 @@
 
 struct BlkDev {                         // the index and the search parameters, device side (pointers into HBM)
     int32_t nalpha, tabsize, nshift, nbitpat, convts, n_chr, kk, drna, maxmmc, nseg, minsigpr, ncand, nascr;
-    int32_t maxblock, extblock, shortquery, hh_size1, hh_size2, hb_size1, hb_size2, ha_size1, ha_size2, gdb;
+    int32_t maxblock, extblock, extblockl, shortquery, hh_size1, hh_size2, hb_size1, hb_size2, ha_size1, ha_size2, gdb;
     int32_t hh_sizes[SPDP_BLK_HASH_LEVELS];  // hh_size1 and what Dhash::resize makes of it: the next prime >= twice the size, again and again
     int32_t hb_sizes[SPDP_BLK_HASH_LEVELS], ha_sizes[SPDP_BLK_HASH_LEVELS];      // the same for the queues' position hashes
     float rbscoef, rbscons;
@@ -572,16 +572,32 @@ SPDP_HD int blk_vote_run(const BlkDev& ix, BlkWork& w, BlkVote& v, const uint8_t
     return 0;
 }
 
+// the run scores a caller's FindHsp can ask for: it moves a pair's ends by up to ExtBlockL blocks inside the chromosome and
+// looks at the run scores of the pair's own strand on the way (src/blksrc.cc:2408-2460)
+SPDP_HD bool blk_near_a_pair(const BlkDev& ix, const BlkPair* bpair, int np, int d, uint32_t blk)
+{
+    for (int i = 0; i < np; ++i) {
+        const BlkPair& b = bpair[i];
+        if (b.rvs != (d >> 1)) continue;
+        const uint32_t e = (uint32_t) ix.extblockl;
+        uint32_t lo = b.lb > e ? b.lb - e : 0, hi = b.rb + e;
+        if (lo < b.zl) lo = b.zl;
+        if (hi > b.zr) hi = b.zr;
+        if (blk >= lo && blk <= hi) return true;
+    }
+    return false;
+}
+
 // One query's result record (int32): [0] ints written incl. this header, [1] TestOutput calls met, [2] flags
 // (1 reached the asked call, 2 record cut at the capacity, 4 a hash table of the reference's size ran full), then -- if
 // reached -- sign[4] mmct[4] nhit[4] maxs[4] testword[4]; per direction: n, (block, score) x n of the significant blocks in
 // the queue's own order; n_pairs, nine ints per candidate block pair (bscr chr lb rb ub db zl zr rvs), best first; n_runs,
-// (block | direction << 28, score) x n_runs of every block with a run score (unordered).  Also zeroes the score slots it walks.
+// (block | direction << 28, score) x n_runs: the run scores within ExtBlockL blocks of a reported pair, on its strand (unordered).  Also zeroes the score slots it walks.
 SPDP_HD int blk_emit_and_reset(const BlkDev& ix, BlkWork& w, const BlkVote& v, int reached, int calls, BlkPair* bpair, uint32_t* sw,
                                int32_t* out, int cap)
 {
     const int nseg = ix.nseg;
-    int n = 3, cut = 0;
+    int n = 3, cut = 0, np = 0;
 #define PUT(x) do { if (n < cap) out[n] = (x); else cut = 1; ++n; } while (0)
     if (reached) {
         for (int d = 0; d < 4; ++d) PUT(v.sign[d]);
@@ -593,7 +609,7 @@ SPDP_HD int blk_emit_and_reset(const BlkDev& ix, BlkWork& w, const BlkVote& v, i
             PUT(w.qb[d].front);
             for (int i = 0; i < w.qb[d].front; ++i) { PUT((int32_t) w.qb[d].data[i].key); PUT(w.qb[d].data[i].bscr); }
         }
-        const int np = blk_build_pairs(ix, w, v.sign, bpair, sw);
+        np = blk_build_pairs(ix, w, v.sign, bpair, sw);
         PUT(np);
         for (int i = 0; i < np; ++i) {
             const BlkPair& b = bpair[i];
@@ -611,8 +627,10 @@ SPDP_HD int blk_emit_and_reset(const BlkDev& ix, BlkWork& w, const BlkVote& v, i
             if (slot >= row) { w.ascr[slot - row] = 0; continue; }
             if (reached && w.bscr[slot]) {              // (a slot can be listed many times: it is reported at its first visit)
                 const int d = slot / nseg < 4 ? slot / nseg : 3;
-                if (at < cap) out[at] += 1;
-                PUT((slot - d * nseg) | (d << 28)); PUT(w.bscr[slot]);
+                if (blk_near_a_pair(ix, bpair, np, d, (uint32_t) (slot - d * nseg))) {
+                    if (at < cap) out[at] += 1;
+                    PUT((slot - d * nseg) | (d << 28)); PUT(w.bscr[slot]);
+                }
             }
             w.bscr[slot] = 0;
         }
@@ -620,7 +638,7 @@ SPDP_HD int blk_emit_and_reset(const BlkDev& ix, BlkWork& w, const BlkVote& v, i
         for (int d = 0; d < 4; ++d)
             for (int x = 0; x < nseg; ++x) {
                 const size_t s = (size_t) d * nseg + x;
-                if (reached && w.bscr[s]) { if (at < cap) out[at] += 1; PUT(x | (d << 28)); PUT(w.bscr[s]); }
+                if (reached && w.bscr[s] && blk_near_a_pair(ix, bpair, np, d, (uint32_t) x)) { if (at < cap) out[at] += 1; PUT(x | (d << 28)); PUT(w.bscr[s]); }
                 w.bscr[s] = 0; w.ascr[s] = 0;
             }
     }

@@ -74,7 +74,10 @@ struct BlkKV { uint32_t key; int32_t val; };
 struct BlkBS { uint32_t key; int32_t bscr; };
 
 // t = the live table; a table that can grow (the run hash of findblock) also has a second buffer and the sizes of its next levels
-struct BlkHash { BlkKV* t; uint32_t size1, size2; int32_t undef; BlkKV* spare; const int32_t* sizes; int level; };
+// epoch != 0: "cleared" is a matter of counting -- a slot belongs to the table as it is now only if the top byte of its key
+// holds the current epoch (keys are block numbers, < 2^24); clearing bumps the epoch and touches memory once in 255 times.
+// Every reader goes through blk_slot_val / blk_slot_key, so the table behaves exactly as one that is wiped each time.
+struct BlkHash { BlkKV* t; uint32_t size1, size2; int32_t undef; BlkKV* spare; const int32_t* sizes; int level; uint32_t epoch; };
 struct BlkQueue { BlkBS* data; int capacity, front; BlkHash hpos; };
 
 struct BlkWork {                        // one lane's slab
@@ -97,8 +100,9 @@ SPDP_HD size_t blk_work_ints(const BlkDev& ix, int touched_cap)
     n += (size_t) touched_cap;
     return (n + 3) & ~(size_t) 3;
 }
-SPDP_HD int32_t* blk_hash_bind(BlkHash& h, int32_t* p, const int32_t* sizes, int32_t step, int32_t undef)
+SPDP_HD int32_t* blk_hash_bind(BlkHash& h, int32_t* p, const int32_t* sizes, int32_t step, int32_t undef, bool epochs = false)
 {
+    h.epoch = epochs ? 255 : 0;                         // (255: the first clear wipes the buffer for real)
     const size_t top = (size_t) sizes[SPDP_BLK_HASH_LEVELS - 1];
     h.t = (BlkKV*) p; h.spare = (BlkKV*) (p + 2 * top);
     h.size1 = (uint32_t) sizes[0]; h.size2 = (uint32_t) step; h.undef = undef; h.sizes = sizes; h.level = 0;
@@ -109,7 +113,7 @@ SPDP_HD void blk_work_bind(BlkWork& w, const BlkDev& ix, int32_t* slab, int touc
     int32_t* p = slab;
     w.bscr = p; p += 4 * (size_t) ix.nseg + 2;
     w.ascr = p; p += 4 * (size_t) ix.nseg + 2;
-    p = blk_hash_bind(w.hh, p, ix.hh_sizes, ix.hh_size2, 0);
+    p = blk_hash_bind(w.hh, p, ix.hh_sizes, ix.hh_size2, 0, ix.nseg < (1 << 24));
     for (int d = 0; d < 4; ++d) {
         w.qa[d].data = (BlkBS*) p; p += 2 * ((size_t) ix.nascr + 1);
         w.qa[d].capacity = ix.nascr; w.qa[d].front = 0;
@@ -123,17 +127,27 @@ SPDP_HD void blk_work_bind(BlkWork& w, const BlkDev& ix, int32_t* slab, int touc
 }
 
 // ---- Dhash<key, int> ------------------------------------------------------------------------------------------------
-SPDP_HD void blk_hash_clear(BlkHash& h) { for (uint32_t i = 0; i < h.size1; ++i) { h.t[i].key = 0; h.t[i].val = h.undef; } }
+SPDP_HD void blk_hash_wipe(BlkHash& h) { for (uint32_t i = 0; i < h.size1; ++i) { h.t[i].key = 0; h.t[i].val = h.undef; } }
+SPDP_HD void blk_hash_clear(BlkHash& h)
+{
+    if (h.epoch && ++h.epoch < 256) return;
+    blk_hash_wipe(h);
+    if (h.epoch) h.epoch = 1;
+}
+SPDP_HD int32_t blk_slot_val(const BlkHash& h, const BlkKV* sh) { return (h.epoch && (sh->key >> 24) != h.epoch) ? h.undef : sh->val; }
+SPDP_HD uint32_t blk_slot_key(const BlkHash& h, const BlkKV* sh) { return h.epoch ? sh->key & 0xffffffu : sh->key; }
+SPDP_HD void blk_slot_claim(const BlkHash& h, BlkKV* sh, uint32_t key) { sh->key = h.epoch ? key | (h.epoch << 24) : key; sh->val = h.undef; }
 SPDP_HD void blk_hash_rewind(BlkHash& h)
 {
     if (h.level & 1) { BlkKV* t = h.t; h.t = h.spare; h.spare = t; }
+    if (h.level && h.epoch) h.epoch = 255;              // another buffer, another size: the next clear wipes it
     h.level = 0; h.size1 = (uint32_t) h.sizes[0];
 }
 // the probe of one key; returns the slot (a free one it may claim, or the key's own), or null when the probe came round
 SPDP_HD BlkKV* blk_hash_probe(BlkHash& h, uint32_t key, uint32_t& v, uint32_t u, uint32_t v0)
 {
     BlkKV* sh = h.t + v;
-    while (sh->val != h.undef && sh->key != key) {
+    while (blk_slot_val(h, sh) != h.undef && blk_slot_key(h, sh) != key) {
         v = (v + u) % h.size1;
         if (v == v0) return nullptr;
         sh = h.t + v;
@@ -148,14 +162,18 @@ SPDP_HD bool blk_hash_grow(BlkHash& h)
     const uint32_t n_old = h.size1;
     h.t = h.spare; h.spare = old;
     h.size1 = (uint32_t) h.sizes[++h.level];
-    blk_hash_clear(h);
-    for (uint32_t i = 0; i < n_old; ++i)
-        if (old[i].val != h.undef) {
-            uint32_t v = old[i].key % h.size1;
-            BlkKV* sh = blk_hash_probe(h, old[i].key, v, h.size2 - old[i].key % h.size2, v);
-            if (!sh) return false;
-            sh->key = old[i].key; sh->val = old[i].val;
-        }
+    const uint32_t was = h.epoch;
+    blk_hash_wipe(h);                                   // (the new buffer may hold anything: wiped for real, same epoch)
+    for (uint32_t i = 0; i < n_old; ++i) {
+        const bool live = (!was || (old[i].key >> 24) == was) && old[i].val != h.undef;
+        if (!live) continue;
+        const uint32_t key = was ? old[i].key & 0xffffffu : old[i].key;
+        uint32_t v = key % h.size1;
+        BlkKV* sh = blk_hash_probe(h, key, v, h.size2 - key % h.size2, v);
+        if (!sh) return false;
+        blk_slot_claim(h, sh, key);
+        sh->val = old[i].val;
+    }
     return true;
 }
 SPDP_HD BlkKV* blk_hash_map(BlkHash& h, uint32_t key, bool record, int& overflow)
@@ -168,9 +186,9 @@ SPDP_HD BlkKV* blk_hash_map(BlkHash& h, uint32_t key, bool record, int& overflow
         // the step it had in the old one
         if (!blk_hash_grow(h)) { overflow = 1; return record ? h.t + v : nullptr; }
         BlkKV* at = h.t + v;
-        if (!(at->val != h.undef && at->key != key)) { sh = at; break; }
+        if (!(blk_slot_val(h, at) != h.undef && blk_slot_key(h, at) != key)) { sh = at; break; }
     }
-    if (sh->val == h.undef) { if (record) sh->key = key; else sh = nullptr; }
+    if (blk_slot_val(h, sh) == h.undef) { if (record) blk_slot_claim(h, sh, key); else sh = nullptr; }
     return sh;
 }
 SPDP_HD BlkKV* blk_hash_incr(BlkHash& h, uint32_t key, int& overflow)

@@ -50,8 +50,7 @@ _WALK_SO = os.path.join(_HERE, "libwalkcheck.so")
 
 def build_walk_check(force: bool = False) -> str:
     """the seeded walk's CPU checker: the product's host walk (a header) compiled with callbacks in place of the device"""
-    srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk.h"),
-            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_walk_h.h"),
+    srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_walk.h"),
             os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_rv.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_hostcpus.h"),
             os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_gencode.h"), os.path.join(_HERE, "..", "include", "spdp.h")]
     newest = max(os.path.getmtime(f) for f in srcs)

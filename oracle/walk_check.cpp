@@ -1,7 +1,7 @@
 // walk_check.cpp -- CPU checker for the seeded walk.  TEST INFRASTRUCTURE ONLY (same rules as spdp_oracle.c: only
 // tests/ load this library; the product never does).
 //
-// The product's host walk (spaln_amd/csrc/spdp_seeded_walk.h: seededS_ng / interpolateS and the closed-form joins,
+// The product's host walk (spaln_amd/csrc/spdp_walk.h: seededS_ng / interpolateS and the closed-form joins,
 // src/fwd2s1.cc:1899-2672) is a header shared by the product library, where its DP calls go to the device, and by this
 // library, where they go to callbacks -- the tests bind those to the oracle's ladder (oracle/host_logic.py: lsp, trcbk)
 // and to the Wilip replies a `ref_dump -Q` fixture recorded.  That way the walk's decisions are checked against the
@@ -10,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../spaln_amd/csrc/spdp_seeded_walk.h"
+#include "../spaln_amd/csrc/spdp_walk.h"
 #include "../spaln_amd/csrc/spdp_seeded_rv.h"
 
 extern "C" {
@@ -39,7 +39,7 @@ struct CallbackBackend : DpBackend {
         return out[0];
     }
     int lsp(const Span& s, const SpdpWindow& w, std::vector<SpdpSkl>& rec) override { return dp(0, s, w, nullptr, rec); }
-    int trcbk(const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec) override { return dp(1, s, w, cut, rec); }
+    int trcbk(const Span& s, const SpdpWindow& w, bool, const int* cut, std::vector<SpdpSkl>& rec) override { return dp(1, s, w, cut, rec); }
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
         const int32_t* out = nullptr; int32_t n = 0;
@@ -72,11 +72,10 @@ extern "C" int walk_check_run(const SpdpScoring* sc, const SpdpSeedParams* sp, c
     return w.unsupported ? 1 : 0;
 }
 
-// ---- the protein walk (spdp_seeded_walk_h.h), same scheme: kind 0 lspH_ng, 1 trcbkalignH_ng, 2 Wilip, 3 trcbkalignH_ng
+// ---- the protein walk (Walk<ProteinPath>), same scheme: kind 0 lspH_ng, 1 trcbkalignH_ng, 2 Wilip, 3 trcbkalignH_ng
 // without introns (spj = false)
-#include "../spaln_amd/csrc/spdp_seeded_walk_h.h"
 namespace {
-struct CallbackBackendH : DpBackendH {
+struct CallbackBackendH : DpBackend {
     WalkCheckFn fn; void* user; bool failed = false;
     int call(int kind, const Span& s, const SpdpWindow* w, const int* cut, int level, const int32_t** out, int32_t* n)
     {

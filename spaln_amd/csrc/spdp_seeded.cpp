@@ -2,7 +2,7 @@
 // with every DP call of every walk served by the device in common batches.
 //
 // What it mirrors (ogotoh/spaln v3.0.7): Aln2s1::globalS_ng -> seededS_ng -> interpolateS (src/fwd2s1.cc:2587-2694,
-// 2405-2539); the walk itself is spdp_seeded_walk.h.  The reference runs one walk per worker thread and calls its DP
+// 2405-2539); the walk itself is spdp_walk.h (Walk<CdnaPath>).  The reference runs one walk per worker thread and calls its DP
 // engines synchronously from deep inside it (spaln -t, src/spaln.cc:1389-1468).  Here every walk of a call runs on a
 // fiber, thousands in flight on the host's cores (spdp_seeded_rv.h); a walk that reaches lspS_ng / trcbkalignS_ng parks
 // its request and yields; the parked requests, sorted by how long their sweeps will take, run as sets of device launches
@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "spdp_internal.h"
-#include "spdp_seeded_walk.h"
+#include "spdp_walk.h"
 #include "spdp_seeded_rv.h"
 
 namespace {
@@ -43,9 +43,9 @@ struct DeviceBackend : DpBackend {
         return p.score;
     }
     int lsp(const Span& s, const SpdpWindow& w, std::vector<SpdpSkl>& rec) override { return park(0, s, w, nullptr, rec); }
-    int trcbk(const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec) override
+    int trcbk(const Span& s, const SpdpWindow& w, bool, const int* cut, std::vector<SpdpSkl>& rec) override
     {
-        return park(cut ? 2 : 1, s, w, cut, rec);
+        return park(cut ? 2 : 1, s, w, cut, rec);      // (the cDNA engines have no intron switch)
     }
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {

@@ -2,7 +2,7 @@
 // HSPs, every DP call of every walk served by the device in common batches.
 //
 // What it mirrors (ogotoh/spaln v3.0.7): Aln2h1::globalH_ng -> seededH_ng -> interpolateH (src/fwd2h1.cc:3267-3286,
-// 3177-3265, 3023-3131); the walk itself is spdp_seeded_walk_h.h.  Same scheme as spdp_seeded.cpp: the walks run on
+// 3177-3265, 3023-3131); the walk itself is spdp_walk.h (Walk<ProteinPath>).  Same scheme as spdp_seeded.cpp: the walks run on
 // fibers (spdp_seeded_rv.h); a walk that reaches lspH_ng / trcbkalignH_ng parks its request; the parked requests of a
 // latency class run as one pass of the protein ladder on the resident inputs of the batch (spdh_run_requests,
 // spdp_h_api.cpp: linear-space sweeps, slab tracebacks, the scalar engine with its cut-range and no-intron variants) on
@@ -16,14 +16,14 @@
 #include <vector>
 
 #include "spdp_internal.h"
-#include "spdp_seeded_walk_h.h"
+#include "spdp_walk.h"
 #include "spdp_seeded_rv.h"
 #include "spdp_h_requests.h"
 
 namespace {
 using namespace spdp_seed;
 
-struct DeviceBackendH : DpBackendH {
+struct DeviceBackendH : DpBackend {
     Fiber* fiber; int query; const SpdpHspSource* src;
     bool failed = false;
     std::atomic<int64_t>* n_wilip;

@@ -23,7 +23,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
-#include "spdp_seeded_walk.h"
+#include "spdp_walk.h"
 #include "spdp_hostcpus.h"
 
 namespace spdp_seed {

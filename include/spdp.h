@@ -272,7 +272,11 @@ typedef struct SpdpSeedParams {
  * sub-ranges AND the end flags the walk holds at that moment -- Wlp scores an HSP with an end bonus that depends on
  * a->inex.exgl / exgr (src/wln.cc:378-382, 438-443), so a binding sets both before it constructs Wilip; it returns 0 and
  * a flat record in *flat: n_units, then per unit {num, nid, tlen, llmt, ulmt, scr} followed by num + 1 JUXT records of
- * five ints each (the slot behind the last HSP included, as WLUNIT::jxt has it).  release() hands the record back. */
+ * five ints each (the slot behind the last HSP included, as WLUNIT::jxt has it).  release() hands the record back.
+ * Threads: every walk runs on a user-level fiber of the library's worker threads; a walk never changes threads, so
+ * thread-local state of the callback (errno, allocator caches, thread_local objects) is safe -- but the fiber's stack is
+ * 1 MB, and many walks share one thread: the callback must not hold a lock across calls or rely on per-thread state of
+ * a single query. */
 typedef struct SpdpHspSource {
     void* user;
     int  (*units)(void* user, int32_t query, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat);

@@ -44,6 +44,7 @@ struct Fiber {
     ucontext_t* back = nullptr;                 // the worker it runs on right now
     void* stack = nullptr;
     int query = -1;
+    int home = -1;                              // the worker thread this walk runs on, from its first step to its last
     Parked* want_park = nullptr;
     bool finished = false;
     struct WalkScheduler* sched = nullptr;
@@ -52,7 +53,7 @@ struct Fiber {
     {
         p->owner = this;
         want_park = p;
-        swapcontext(&ctx, back);                // (may come back on another worker thread)
+        swapcontext(&ctx, back);                // (resumed by the same worker thread: see WalkScheduler::worker)
     }
 };
 
@@ -95,7 +96,12 @@ struct WalkScheduler {
     static constexpr size_t STACK = 1 << 20, GUARD = 4096;     // (the HSP callback -- the reference's Wilip in an integration -- runs on it too)
     std::mutex mu;
     std::condition_variable cv_work, cv_main;
-    std::vector<Fiber*> ready, idle_fibers, all_fibers;
+    // A walk never changes threads: compilers may keep thread-local addresses (errno, allocator caches, any thread_local
+    // of the HSP callback -- the integrator's code runs on the fiber too) across a context switch, so a served walk goes
+    // back to the queue of the worker that started it.
+    std::vector<std::vector<Fiber*>> ready_of;          // per worker thread
+    int n_ready = 0;
+    std::vector<Fiber*> idle_fibers, all_fibers;
     std::vector<std::vector<Parked*>> parked;           // per latency class (= dispatcher lane)
     std::function<int(const Parked&)> classify;
     int n_walks = 0, next = 0, done = 0, in_flight = 0, busy = 0;
@@ -135,17 +141,17 @@ struct WalkScheduler {
         makecontext(&f->ctx, (void (*)()) entry, 2, (unsigned) (p & 0xffffffffu), (unsigned) (p >> 32));
         return f;
     }
-    void worker()
+    void worker(int me)
     {
         ucontext_t here;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             Fiber* f = nullptr;
             for (;;) {
-                if (!ready.empty()) { f = ready.back(); ready.pop_back(); break; }
+                if (!ready_of[me].empty()) { f = ready_of[me].back(); ready_of[me].pop_back(); --n_ready; break; }
                 if (next < n_walks && in_flight < max_in_flight && !oom) {
                     f = fresh(order.empty() ? next : order[next]);
-                    if (f) { ++next; ++in_flight; break; }
+                    if (f) { f->home = me; ++next; ++in_flight; break; }
                     // no stack for another walk (address space, vm.max_map_count): those in flight are what there is, the
                     // rest start as their fibers come free; not even one: the call fails
                     if (in_flight > 0) max_in_flight = in_flight;
@@ -201,7 +207,9 @@ struct WalkScheduler {
         if (const char* e = getenv("SPDP_SEED_TEST_STACKS")) stack_limit = atoi(e);
         n_threads = std::min(n_threads, n);
         std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back([this] { worker(); });
+        ready_of.assign(n_threads, std::vector<Fiber*>());
+        n_ready = 0;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back([this, t] { worker(t); });
         auto dispatcher = [&](int lane) {
             const int c = class_of_lane[lane];
             for (;;) {
@@ -213,7 +221,7 @@ struct WalkScheduler {
                         if (parked[c].empty()) return false;
                         // nobody can run (every worker waits: nothing ready, nothing new to start), or enough has gathered
                         const bool startable = next < n_walks && in_flight < max_in_flight && !oom;
-                        return (int) parked[c].size() >= batch_target || (!busy && ready.empty() && !startable);
+                        return (int) parked[c].size() >= batch_target || (!busy && n_ready == 0 && !startable);
                     });
                     if (parked[c].empty()) { cv_main.notify_all(); break; }         // every walk has ended
                     take.swap(parked[c]);
@@ -221,7 +229,7 @@ struct WalkScheduler {
                 device(take, lane);
                 {
                     std::lock_guard<std::mutex> g(mu);
-                    for (Parked* p : take) ready.push_back(p->owner);
+                    for (Parked* p : take) { ready_of[p->owner->home].push_back(p->owner); ++n_ready; }
                 }
                 cv_work.notify_all();
             }

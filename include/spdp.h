@@ -698,6 +698,7 @@ typedef struct SpdpBlkIndexDesc {
     int32_t hh_size, hh_step;                        /* geometry of Dhash<INT,int>(2 * MaxBlk, 0): size1, size2 (src/clib.h:257-267); */
     int32_t hb_size, hb_step, ha_size, ha_step;      /*   of the position hashes of the Ncand / Nascr queues; 0 = derive (hh_step etc. = 8) */
     int32_t gdb;                                     /* Randbs: log (genomic database) or sqrt transform beyond its table */
+    int32_t blklen;                                  /* wcp.blklen: block b of a chromosome whose first block is z covers [(b - z) * blklen, ..) (SrchBlk::setgnmrng); not read by the vote */
     float   rbscoef, rbscons;                        /* Randbs::RbsCoef, RbsCons */
     double  bclw, bcup, bcce;                        /* Block2Chr */
     double  cfact;                                   /* app_c = Nbitpat ^ cfact (:2826) */
@@ -713,6 +714,26 @@ typedef struct SpdpBlkIndexDesc {
 typedef struct SpdpBlkIndex SpdpBlkIndex;
 SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIndexDesc* desc);     /* uploads; NULL on error (spdp_last_error) */
 void          spdp_blk_index_destroy(SpdpBlkIndex* ix);
+/* The reference's own index file (<db>.bkn of `spaln -W`, format version 26, nucleotide) read on the host, with the search
+ * parameters SrchBlk::initialize derives on opening one (src/blksrc.cc:1697-1858, 2179-2227).  What the file does not hold
+ * comes from SpdpBlkSearchOpts (defaults = the reference's: spdp_blk_search_opts_default); ExtBlock follows from the species'
+ * intron length distribution (max_intron_len(0.996), src/codepot.cc:648), which the caller supplies as max_intron_len or
+ * directly as ext_block. */
+typedef struct SpdpBlkSearchOpts {
+    int32_t max_out;                 /* OutPrm.MaxOut (Ncand = max_out + 10) */
+    int32_t max_mmc, min_sigpr, nascr;   /* MaxMmc (-Xm), MinSigpr (-Xn), Nascr (-Xd) */
+    int32_t ext_block, max_intron_len;   /* ExtBlock given (-XE), or max_intron_len(ild_up_quantile) to derive it from */
+    int32_t local;                   /* algmode.lcl & 16: no limit on recurrences */
+    int32_t genomic_db;              /* Randbs transform: 1 log (a genomic database), 0 sqrt */
+    float   rbs_fact, rbs_base;      /* RbsFact (-Xf), RbsBase (-Xe) */
+    double  cfact;                   /* -Xc */
+} SpdpBlkSearchOpts;
+typedef struct SpdpBlkIndexHost SpdpBlkIndexHost;
+void spdp_blk_search_opts_default(SpdpBlkSearchOpts* o);
+SpdpBlkIndexHost* spdp_blk_index_read(const char* path, const SpdpBlkSearchOpts* opts, char* err, int err_cap);   /* NULL + message on error */
+const SpdpBlkIndexDesc* spdp_blk_index_host_desc(const SpdpBlkIndexHost* h);      /* valid until spdp_blk_index_host_free */
+void spdp_blk_index_host_free(SpdpBlkIndexHost* h);
+
 /* n queries: codes of query i = codes[offs[i] .. offs[i + 1]), searched range [left[i], right[i]) (Seq::left / right);
  * stop_at[i] (NULL = 0 for all) = which TestOutput call of findblock to stop at -- the earlier ones are taken to have
  * answered "nothing found, go on" (a caller whose FindHsp rejects every pair of call k asks again with k + 1; most queries

@@ -15,7 +15,7 @@ class BlkIndexDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nalpha", "tabsize", "nshift", "nbitpat", "convts", "n_chr", "maxblk", "kk", "drna", "maxmmc", "nseg",
         "minsigpr", "ncand", "nascr", "maxblock", "extblock", "extblockl", "shortquery", "hh_size", "hh_step", "hb_size", "hb_step",
-        "ha_size", "ha_step", "gdb")] + [
+        "ha_size", "ha_step", "gdb", "blklen")] + [
         ("rbscoef", C.c_float), ("rbscons", C.c_float),
         ("bclw", C.c_double), ("bcup", C.c_double), ("bcce", C.c_double), ("cfact", C.c_double),
         ("convtab", C.c_void_p), ("nblk", C.c_void_p), ("wscr", C.c_void_p), ("blkp", C.c_void_p),
@@ -26,7 +26,7 @@ class BlkIndexDesc(C.Structure):
 # positions in the parameter record of a reference-side index dump (oracle/ref_build/blk_tap.cc, dump_index)
 _PRM = dict(nalpha=0, tabsize=3, nshift=5, nbitpat=8, convts=10, n_chr=12, maxblk=14, kk=15, drna=16, maxmmc=17, nseg=19,
             minsigpr=22, ncand=23, nascr=24, maxblock=25, extblock=26, extblockl=27, shortquery=28, hh_size=29, hh_step=30, hb_size=31,
-            hb_step=32, ha_size=33, ha_step=34, gdb=38)
+            hb_step=32, ha_size=33, ha_step=34, gdb=38, blklen=6)
 REACHED, CUT, TABLE = 1, 2, 4
 
 
@@ -123,3 +123,47 @@ def split_record(rec: np.ndarray):
     for code, scr in runs:
         by_d[int(code) >> 28].append((int(code) & 0xfffffff, int(scr)))
     return dict(reached=True, calls=calls, flags=flags, head=head, qb=qb, pairs=pairs, runs=[sorted(x) for x in by_d])
+
+
+class SearchOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("max_out", "max_mmc", "min_sigpr", "nascr", "ext_block", "max_intron_len", "local",
+                                          "genomic_db")] + [("rbs_fact", C.c_float), ("rbs_base", C.c_float), ("cfact", C.c_double)]
+
+
+def read_index_file(lib, path: str, **opts):
+    """the reference's <db>.bkn read by the library (host only): dict with the same keys a reference-side dump has
+    (blk_prm positions filled where the library knows them), for comparison and for BlockIndex"""
+    lib.spdp_blk_index_read.restype = C.c_void_p
+    lib.spdp_blk_index_read.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.spdp_blk_index_host_desc.restype = C.POINTER(BlkIndexDesc)
+    lib.spdp_blk_index_host_desc.argtypes = [C.c_void_p]
+    lib.spdp_blk_index_host_free.argtypes = [C.c_void_p]
+    o = SearchOpts()
+    lib.spdp_blk_search_opts_default(C.byref(o))
+    for k, v in opts.items():
+        setattr(o, k, v)
+    err = C.create_string_buffer(256)
+    h = lib.spdp_blk_index_read(path.encode(), C.byref(o), err, 256)
+    if not h:
+        raise RuntimeError(err.value.decode())
+    d = lib.spdp_blk_index_host_desc(h).contents
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+    out = {name: int(getattr(d, name)) for name, _ in BlkIndexDesc._fields_[:26]}
+    out.update(rbscoef=float(d.rbscoef), rbscons=float(d.rbscons), bclw=d.bclw, bcup=d.bcup, bcce=d.bcce, cfact=d.cfact,
+               blk_convtab=arr(d.convtab, d.convts, np.uint8), blk_nblk=arr(d.nblk, d.tabsize, np.uint16),
+               blk_wscr=arr(d.wscr, d.tabsize, np.int16), blk_blkp=arr(d.blkp, d.tabsize, np.int32),
+               blk_blkb=arr(d.blkb, d.n_words, np.uint32), blk_rscrtab=arr(d.rscrtab, 128, np.int32),
+               blk_chr=arr(d.chr, 2 * (d.n_chr + 1), np.int32), blk_bitpat=arr(d.bitpat, d.n_bitpat, np.int32))
+    lib.spdp_blk_index_host_free(h)
+    # ... and in the layout of a reference-side dump, so that the result can stand in for one (BlockIndex, the tests' oracle)
+    prm = np.zeros(42, dtype=np.int32)
+    for name, pos in _PRM.items():
+        prm[pos] = out[name]
+    prm[36] = struct.unpack("<i", struct.pack("<f", out["rbscoef"]))[0]
+    prm[37] = struct.unpack("<i", struct.pack("<f", out["rbscons"]))[0]
+    out["blk_prm"] = prm
+    out["blk_pb2c"] = np.frombuffer(np.array([out["bclw"], out["bcup"], out["bcce"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
+    out["blk_cfact"] = np.frombuffer(np.array([out["cfact"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
+    return out

@@ -94,6 +94,7 @@ def main():
             fx = spdg.load(log)
             fx["blk_convtab"][:2] = 255
             spdg.save(os.path.join(OUT, name + ".spdg"), {k: v for k, v in fx.items() if k != "prm"})
+            shutil.copyfile(os.path.join(td, "gnm.bkn"), os.path.join(OUT, name + ".bkn"))     # the reference's own index file: an input of the reader's test
             print(f"{name}: genome {sum(len(c) for c in chroms)} nt, {len(queries)} queries, "
                   f"{os.path.getsize(log) / 1e6:.2f} MB, {r.stdout.count(chr(10) + '@')} aligned")
             if name == "blk_k3":

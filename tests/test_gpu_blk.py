@@ -130,3 +130,25 @@ def test_device_grows_its_tables_like_a_fresh_reference_process(eng):
         got = blocks.split_record(out[i])
         assert not got["flags"] & blocks.TABLE and same(got, w), i
     dix.free()
+
+
+def test_index_read_from_the_reference_file_votes_like_the_recorded_one(eng):
+    """the whole of the slice end to end: the library reads the reference's own .bkn, uploads it, votes -- and equals the
+    reference's recorded runs"""
+    fx = spdg.load(os.path.join(HERE, "golden", "blk_k3.spdg"))
+    prm = np.asarray(fx["blk_prm"])
+    from_file = blocks.read_index_file(eng.lib, os.path.join(HERE, "golden", "blk_k3.bkn"), ext_block=int(prm[26]), max_out=int(prm[39]))
+    dix = blocks.BlockIndex(eng, from_file)
+    _IX[0] = oblk.index_of(fx)[0]
+    _keep = oblk.index_of(fx)
+    _IX[0] = _keep[0]
+    qs = oblk.parse_log(fx)
+    queries, ranges, stops, wants = [], [], [], []
+    for q in qs:
+        for ci, (vote, pairs) in enumerate(q["calls"]):
+            queries.append(q["codes"]); ranges.append((q["left"], q["right"])); stops.append(ci)
+            wants.append(oblk.split_recorded(vote, pairs))
+    out, _ = dix.vote(queries, ranges, stops, out_cap=1 << 14)
+    for i, w in enumerate(wants):
+        assert same(blocks.split_record(out[i]), w), i
+    dix.free()

@@ -392,8 +392,8 @@ def main_blk(args):
     from spaln_amd import blocks, engine, synth
     from tests import spdg
     ref = os.path.join(ROOT, "oracle", "_ref")
-    if not os.path.exists(os.path.join(ref, "spaln_blktap")):
-        raise SystemExit("--workload blk needs the reference's formatter (oracle/_ref/spaln, spaln_blktap) to make its input index")
+    if not os.path.exists(os.path.join(ref, "spaln")):
+        raise SystemExit("--workload blk needs the reference's formatter (oracle/_ref/spaln -W) to make its input index")
     n_q = args.queries
     rng = np.random.default_rng(synth.SEED + 4400 + rank)
     t_in = time.perf_counter()
@@ -423,13 +423,13 @@ def main_blk(args):
     env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
     env.update(ALN_TAB=REF_TAB, ALN_DBS=td)
     subprocess.run([os.path.join(ref, "spaln"), "-W", "-KD", f"-t{_host_cores()}", "gnm.mfa"], cwd=td, env=env, check=True, capture_output=True)
-    with open(os.path.join(td, "q.fa"), "w") as f:
-        f.write(">q0\n" + bytes(genes[0].query).decode() + "\n")
-    fx_path = os.path.join(td, "index.spdg")
-    subprocess.run([os.path.join(ref, "spaln_blktap"), "-Q7", "-O4", "-t1", "-dgnm", "q.fa"], cwd=td,
-                   env=dict(env, SPDP_BLK_LOG=fx_path), check=True, capture_output=True)
-    fx = spdg.load(fx_path)
+    # the library reads the reference's index file itself (spdp_blk_index_read); ExtBlock = max_intron_len(0.996) / blklen + 1
+    # with the reference's default intron length distribution (12 288 <= that quantile < 14 336: its own run on the
+    # fixtures' 2048-nt blocks gives ExtBlock = 7)
+    import ctypes as C
+    fx = blocks.read_index_file(C.CDLL(engine.LIB_PATH), os.path.join(td, "gnm.bkn"), max_intron_len=13000)
     fx["blk_convtab"][:2] = 255
+    fx_path = os.path.join(td, "index.spdg")
     # the ESTs: 500-nt fragments of the planted transcripts, 1 % substitutions, every other one reverse-complemented
     code_of = np.zeros(256, dtype=np.uint8)
     for ch, code in zip(b"ACGTN", (2, 3, 5, 9, 16)):
@@ -506,6 +506,7 @@ def main_blk(args):
         # parity on a sample against the oracle (the pinned restatement), in the same run
         from oracle import blk as oblk
         ix, _keep = oblk.index_of(fx)
+        ix.extblockl = int(prm[27])
         same = 0
         chk = sample[:300]
         for i in chk:
@@ -522,13 +523,14 @@ def main_blk(args):
         import multiprocessing as mp
         ncores = _host_cores()
         ns = min(n_q, args.cpu_sample if args.cpu_sample > 0 else 400 * ncores)
-        spdg.save(fx_path, {k: v for k, v in fx.items() if k != "prm"})
+        as_file = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}      # (the container knows the signed types)
+        spdg.save(fx_path, {k: np.asarray(v).view(as_file.get(np.asarray(v).dtype, np.asarray(v).dtype)) for k, v in fx.items() if k.startswith("blk_")})
         jobs = [(fx_path, [codes[i] for i in range(c, ns, ncores)]) for c in range(ncores)]
         with mp.get_context("fork").Pool(ncores) as pool:
             busy = pool.map(_blk_oracle_chunk, jobs)
         cpu_qps = ns / max(busy)
         k_ms = float(np.mean(kms))
-        words = int(prm[11])
+        words = int(np.asarray(fx["blk_blkb"]).size)
         # algorithmic bytes per query: its codes once, per looked-up word the two table entries (Nblk 2 B, wscr 2 B, blkp 4 B) and
         # its posting list (4 B per listed block), per listed block one read-modify-write of two 4-byte score slots; the record out
         tw = rec[reached, 3 + 16:3 + 20].sum(axis=1).mean() if reached.any() else 0.0
@@ -541,11 +543,11 @@ def main_blk(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 / int32", "data": "synthetic",
             "config": {"workload": f"block search, first slice of SURVEY 8 f4: {n_q} ESTs of {frag} nt (1 % substitutions, half of them "
                                    f"reverse strand) vs the index of a synthetic {n_chr * chr_len // 1000000} Mb genome ({n_genes} planted loci); "
-                                   "index made by the compiled reference's own formatter (spaln -W -KD), an input; one step = "
+                                   "index file made by the compiled reference's own formatter (spaln -W -KD), an input, read by spdp_blk_index_read; one step = "
                                    "spdp_blk_vote over all ESTs, queries and records resident in HBM",
                        "queries_per_gpu": n_q, "queries_per_s": round(n_q * world * args.steps / dt, 1),
                        "cells_per_gpu_per_step": 0,
-                       "index": {"ktuple": int(prm[1]), "tabsize": int(prm[3]), "nshift": int(prm[5]), "blklen": blklen, "nseg": int(prm[19]),
+                       "index": {"ktuple": int(prm[28]) // 8, "tabsize": int(prm[3]), "nshift": int(prm[5]), "blklen": blklen, "nseg": int(prm[19]),
                                  "words": words, "patterns": int(prm[8])},
                        "reached_first_call": int(reached.sum()), "flagged": flagged,
                        "best_pair_covers_planted_locus": f"{hit_any} / {len(sample)} ({hit} with the strand as planted)",

@@ -384,6 +384,7 @@ int spdp_group_homscore_h(SpdpGroup* g, const struct SpdpScoringH* sc, const str
 int spdp_group_align_h(SpdpGroup* g, const struct SpdpScoringH* sc, const struct SpdpProblemH* probs, int n_probs,
                        SpdpAlignment* out);
 
+
 /* ---- submit / wait ------------------------------------------------------ */
 /* Asynchronous form of the batched calls: a worker thread runs the call and owns `ctx` until
  * spdp_wait() returns (one ticket in flight per context; inputs and `out` must stay valid until
@@ -754,6 +755,24 @@ int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* codes
 int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* d_codes, const int64_t* d_offs,
                            const int32_t* d_left, const int32_t* d_right, const int32_t* d_stop_at, int32_t n,
                            int32_t* d_out, int32_t out_cap, float* kernel_ms);
+
+/* ---- device groups, continued ------------------------------------------------------------------------------------------ */
+/* the same sharding for the calls of the seeded path, rescoring and the block vote (rounds 3 / 4).  The HSP source of a
+ * seeded call is asked with the CALLER's query numbers, from the worker threads of every member.  spdp_group_blk_vote takes
+ * one index per member, created on that member's context (spdp_group_context(g, r)). */
+int spdp_group_align_s_seeded(SpdpGroup* g, const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpProblem* probs, int n_probs,
+                              const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                              const SpdpHspSource* src, SpdpAlignment* out);
+int spdp_group_align_h_seeded(SpdpGroup* g, const SpdpScoringH* sc, const SpdpSeedParams* sp, const SpdpProblemH* probs,
+                              int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                              const SpdpHspSource* src, SpdpAlignment* out);
+int spdp_group_skl_rng_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpRescoreParams* rp, const SpdpProblem* probs, int n_probs,
+                         const SpdpAlignment* aln, SpdpRescored* out);
+int spdp_group_skl_rng_h(SpdpGroup* g, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp,
+                         const SpdpProblemH* probs, int n_probs, const SpdpAlignment* aln, SpdpRescored* out);
+SpdpContext* spdp_group_context(SpdpGroup* g, int member);
+int spdp_group_blk_vote(SpdpGroup* g, const SpdpBlkIndex* const* ix, const uint8_t* codes, const int64_t* offs,
+                        const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n, int32_t* out, int32_t out_cap);
 
 #ifdef __cplusplus
 }

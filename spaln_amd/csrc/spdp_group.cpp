@@ -7,6 +7,7 @@
 // from its own host thread, and the results land in the caller's arrays in query order.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -135,6 +136,157 @@ int spdp_group_align_h(SpdpGroup* g, const SpdpScoringH* sc, const SpdpProblemH*
 {
     return fan_out(g, probs, n_probs, costs_h(sc, probs, n_probs), out, [=](SpdpContext* c, const SpdpProblemH* p, int cnt, SpdpAlignment* o) {
         return spdp_align_h(c, sc, p, cnt, o);
+    });
+}
+
+// ---- the calls round 3 / 4 added: seeded alignment, rescoring, the block vote -------------------------------------------
+extern "C++" {
+namespace {
+// a member's HSP source: the caller's, asked with the CALLER's query numbers
+struct RemapSource { const SpdpHspSource* src; const int* idx; };
+int remap_units(void* user, int32_t query, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
+{
+    const RemapSource* r = (const RemapSource*) user;
+    return r->src->units(r->src->user, r->idx[query], level, span, flat, n_flat);
+}
+void remap_release(void* user, int32_t query, const int32_t* flat)
+{
+    const RemapSource* r = (const RemapSource*) user;
+    if (r->src->release) r->src->release(r->src->user, r->idx[query], flat);
+}
+
+// member r runs call(ctx, its problem numbers in caller order); results are written by the call itself (it knows the layout)
+template <typename F>
+int fan_out_idx(SpdpGroup* g, int n, const std::vector<int64_t>& cost, F&& call)
+{
+    if (!g || g->ctx.empty()) return -1;
+    const int w = (int) g->ctx.size();
+    const std::vector<std::vector<int>> idx = balanced(cost, w);
+    g->shard_of.assign(n, 0);
+    std::vector<int> rc(w, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < w; ++r) {
+        if (idx[r].empty()) continue;
+        for (int i : idx[r]) g->shard_of[i] = r;
+        th.emplace_back([&, r]() { (void) hipSetDevice(g->ctx[r]->device); rc[r] = call(g->ctx[r], idx[r]); });
+    }
+    for (std::thread& t : th) t.join();
+    int worst = 0;
+    for (int r = 0; r < w; ++r) {
+        if (rc[r] < 0) { g->err = "device " + std::to_string(g->ctx[r]->device) + ": " + g->ctx[r]->err; return -1; }
+        worst |= rc[r];
+    }
+    return worst;
+}
+
+template <typename SC, typename P, typename CALL>
+int group_seeded(SpdpGroup* g, const SC* sc, const P* probs, int n, const std::vector<int64_t>& cost,
+                 const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level, const SpdpHspSource* src,
+                 SpdpAlignment* out, CALL&& call)
+{
+    return fan_out_idx(g, n, cost, [&](SpdpContext* c, const std::vector<int>& idx) {
+        const int cnt = (int) idx.size();
+        std::vector<P> mine(cnt);
+        std::vector<const SpdpJuxt*> h(cnt);
+        std::vector<int32_t> nh(cnt), ll(cnt);
+        std::vector<SpdpAlignment> o(cnt);
+        for (int k = 0; k < cnt; ++k) {
+            mine[k] = probs[idx[k]];
+            h[k] = hsps ? hsps[idx[k]] : nullptr;
+            nh[k] = n_hsps ? n_hsps[idx[k]] : 0;
+            ll[k] = lowest_level ? lowest_level[idx[k]] : 0;
+        }
+        RemapSource rs = {src, idx.data()};
+        SpdpHspSource local = {&rs, remap_units, remap_release};
+        const int rc = call(c, sc, mine.data(), cnt, hsps ? h.data() : nullptr, n_hsps ? nh.data() : nullptr,
+                            lowest_level ? ll.data() : nullptr, src ? &local : nullptr, o.data());
+        for (int k = 0; k < cnt; ++k) out[idx[k]] = o[k];
+        return rc;
+    });
+}
+}   // namespace
+}   // extern "C++"
+
+// alignS_ng / alignH_ng with seeding on for a batch, sharded over the group's devices by DP cells of the whole windows (the
+// reference's counterpart: the -t N master / worker loop, src/spaln.cc:1389-1468); every member runs its own fiber scheduler
+// and dispatcher lanes; the HSP source is asked with the caller's query numbers
+int spdp_group_align_s_seeded(SpdpGroup* g, const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpProblem* probs, int n_probs,
+                              const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                              const SpdpHspSource* src, SpdpAlignment* out)
+{
+    return group_seeded(g, sc, probs, n_probs, costs_s(sc, probs, n_probs), hsps, n_hsps, lowest_level, src, out,
+                        [=](SpdpContext* c, const SpdpScoring* s, const SpdpProblem* p, int cnt, const SpdpJuxt* const* h, const int32_t* nh,
+                            const int32_t* ll, const SpdpHspSource* so, SpdpAlignment* o) { return spdp_align_s_seeded(c, s, sp, p, cnt, h, nh, ll, so, o); });
+}
+int spdp_group_align_h_seeded(SpdpGroup* g, const SpdpScoringH* sc, const SpdpSeedParams* sp, const SpdpProblemH* probs, int n_probs,
+                              const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level,
+                              const SpdpHspSource* src, SpdpAlignment* out)
+{
+    return group_seeded(g, sc, probs, n_probs, costs_h(sc, probs, n_probs), hsps, n_hsps, lowest_level, src, out,
+                        [=](SpdpContext* c, const SpdpScoringH* s, const SpdpProblemH* p, int cnt, const SpdpJuxt* const* h, const int32_t* nh,
+                            const int32_t* ll, const SpdpHspSource* so, SpdpAlignment* o) { return spdp_align_h_seeded(c, s, sp, p, cnt, h, nh, ll, so, o); });
+}
+
+// skl_rngS_ng / skl_rngH_ng for a batch of alignments, sharded by alignment length (records)
+int spdp_group_skl_rng_s(SpdpGroup* g, const SpdpScoring* sc, const SpdpRescoreParams* rp, const SpdpProblem* probs, int n_probs,
+                         const SpdpAlignment* aln, SpdpRescored* out)
+{
+    std::vector<int64_t> cost(std::max(n_probs, 0));
+    for (int i = 0; i < n_probs; ++i) cost[i] = 1 + std::max(aln[i].n_skl, 0) + (probs[i].a_right - probs[i].a_left);
+    return fan_out_idx(g, n_probs, cost, [&](SpdpContext* c, const std::vector<int>& idx) {
+        const int cnt = (int) idx.size();
+        std::vector<SpdpProblem> mine(cnt);
+        std::vector<SpdpAlignment> al(cnt);
+        std::vector<SpdpRescored> o(cnt);
+        for (int k = 0; k < cnt; ++k) { mine[k] = probs[idx[k]]; al[k] = aln[idx[k]]; o[k] = out[idx[k]]; }
+        const int rc = spdp_skl_rng_s(c, sc, rp, mine.data(), cnt, al.data(), o.data());
+        for (int k = 0; k < cnt; ++k) out[idx[k]] = o[k];
+        return rc;
+    });
+}
+int spdp_group_skl_rng_h(SpdpGroup* g, const SpdpScoringH* sc, const SpdpRescoreParamsH* rp, const SpdpProblemH* probs, int n_probs,
+                         const SpdpAlignment* aln, SpdpRescored* out)
+{
+    std::vector<int64_t> cost(std::max(n_probs, 0));
+    for (int i = 0; i < n_probs; ++i) cost[i] = 1 + std::max(aln[i].n_skl, 0) + (probs[i].a_right - probs[i].a_left);
+    return fan_out_idx(g, n_probs, cost, [&](SpdpContext* c, const std::vector<int>& idx) {
+        const int cnt = (int) idx.size();
+        std::vector<SpdpProblemH> mine(cnt);
+        std::vector<SpdpAlignment> al(cnt);
+        std::vector<SpdpRescored> o(cnt);
+        for (int k = 0; k < cnt; ++k) { mine[k] = probs[idx[k]]; al[k] = aln[idx[k]]; o[k] = out[idx[k]]; }
+        const int rc = spdp_skl_rng_h(c, sc, rp, mine.data(), cnt, al.data(), o.data());
+        for (int k = 0; k < cnt; ++k) out[idx[k]] = o[k];
+        return rc;
+    });
+}
+
+// the block vote for a batch of queries: every member holds its own copy of the index (ix[r] created on the group's r-th
+// context: spdp_group_context), the queries are sharded by length
+SpdpContext* spdp_group_context(SpdpGroup* g, int member) { return (g && member >= 0 && member < (int) g->ctx.size()) ? g->ctx[member] : nullptr; }
+int spdp_group_blk_vote(SpdpGroup* g, const SpdpBlkIndex* const* ix, const uint8_t* codes, const int64_t* offs,
+                        const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n, int32_t* out, int32_t out_cap)
+{
+    if (!ix || !codes || !offs || !left || !right || !out) { if (g) g->err = "spdp_group_blk_vote: null argument"; return -1; }
+    std::vector<int64_t> cost(std::max(n, 0));
+    for (int i = 0; i < n; ++i) cost[i] = 1 + right[i] - left[i];
+    return fan_out_idx(g, n, cost, [&](SpdpContext* c, const std::vector<int>& idx) {
+        int member = 0;
+        while (g->ctx[member] != c) ++member;
+        const int cnt = (int) idx.size();
+        std::vector<int64_t> o2(cnt + 1, 0);
+        for (int k = 0; k < cnt; ++k) o2[k + 1] = o2[k] + (offs[idx[k] + 1] - offs[idx[k]]);
+        std::vector<uint8_t> cd((size_t) o2[cnt]);
+        std::vector<int32_t> l(cnt), r(cnt), st(cnt), rec((size_t) cnt * out_cap);
+        for (int k = 0; k < cnt; ++k) {
+            memcpy(cd.data() + o2[k], codes + offs[idx[k]], (size_t) (o2[k + 1] - o2[k]));
+            l[k] = left[idx[k]]; r[k] = right[idx[k]]; st[k] = stop_at ? stop_at[idx[k]] : 0;
+        }
+        const int rc = spdp_blk_vote(c, ix[member], cd.data(), o2.data(), l.data(), r.data(), stop_at ? st.data() : nullptr, cnt,
+                                     rec.data(), out_cap, nullptr);
+        if (rc == 0)
+            for (int k = 0; k < cnt; ++k) memcpy(out + (size_t) idx[k] * out_cap, rec.data() + (size_t) k * out_cap, (size_t) out_cap * 4);
+        return rc;
     });
 }
 

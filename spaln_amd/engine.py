@@ -30,6 +30,8 @@ EXPORTS = [
     "spdp_poll", "spdp_wait",
     "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
     "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
+    "spdp_group_align_s_seeded", "spdp_group_align_h_seeded", "spdp_group_skl_rng_s", "spdp_group_skl_rng_h",
+    "spdp_group_context", "spdp_group_blk_vote",
     "spdp_align_s_seeded", "spdp_align_s_seeded_ori3", "spdp_seeded_stats",
     "spdp_blk_index_create", "spdp_blk_index_destroy", "spdp_blk_vote", "spdp_blk_vote_resident",
     "spdp_blk_search_opts_default", "spdp_blk_index_read", "spdp_blk_index_host_desc", "spdp_blk_index_host_free",
@@ -190,6 +192,56 @@ class Collector:
             self.h = None
 
 
+def _seeded_call(lib, handle, check, name, sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial):
+    """one seeded batch call on a context or a group handle (the HSP source replays recorded Wilip replies)"""
+    n = len(ps)
+    keep = []
+    jx = (C.c_void_p * n)()
+    nh = (C.c_int32 * n)()
+    lv = (C.c_int32 * n)(*[int(x) for x in lowest_levels])
+    for i, h in enumerate(hsps):
+        if h is None or len(h) < 2:
+            continue
+        a = np.ascontiguousarray(h, dtype=np.int32)
+        keep.append(a)
+        jx[i] = a.ctypes.data
+        nh[i] = a.shape[0] - 1
+    missing = []
+
+    def units(_user, query, level, span, flat, n_flat):
+        key = (level, span[0], span[1], span[2], span[3])
+        tab = wilip_tables[query] if wilip_tables else None
+        if not tab or key not in tab:
+            missing.append((query,) + key)
+            return 1
+        a = np.asarray(tab[key], dtype=np.int32)
+        keep.append(a)                                   # (appends are atomic; the arrays live until the call returns)
+        flat[0] = a.ctypes.data_as(C.POINTER(C.c_int32))
+        n_flat[0] = a.size
+        return 0
+
+    src = abi.HspSource()
+    src.user = None
+    src.units = abi.HSP_UNITS_FN(units)
+    src.release = abi.HSP_RELEASE_FN(lambda _u, _q, _f: None)
+    arr = (abi.Alignment * n)()
+    fn = getattr(lib, name)
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+    rc = fn(handle, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
+    if missing:
+        raise KeyError(f"no Wilip reply for {missing[:3]}")
+    if not (allow_partial and rc == 1):
+        check(rc, name)
+    res = []
+    for i in range(n):
+        k = arr[i].n_skl
+        skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
+        res.append((int(arr[i].score), skl))
+    lib.spdp_free_alignments(arr, n)
+    return res
+
+
+
 class Group:
     """Several GPUs behind one handle (spdp_group_*): the batched calls shard the query list over the members."""
 
@@ -226,6 +278,17 @@ class Group:
             res.append((int(arr[i].score), skl))
         self.lib.spdp_free_alignments(arr, n)
         return res
+
+    def align_s_seeded(self, sc, sp, ps, hsps, lowest_levels, wilip_tables=None, allow_partial=False):
+        return _seeded_call(self.lib, self.h, self._check, "spdp_group_align_s_seeded", sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
+
+    def align_h_seeded(self, sc, sp, ps, hsps, lowest_levels, wilip_tables=None, allow_partial=False):
+        return _seeded_call(self.lib, self.h, self._check, "spdp_group_align_h_seeded", sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
+
+    def shards(self, n) -> np.ndarray:
+        member = np.zeros(n, dtype=np.int32)
+        self.lib.spdp_group_last_shards(self.h, member.ctypes.data_as(C.c_void_p), n)
+        return member
 
 
 class Engine:
@@ -341,51 +404,7 @@ class Engine:
         return self._align_seeded("spdp_align_h_seeded", sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
 
     def _align_seeded(self, name, sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial):
-        n = len(ps)
-        keep = []
-        jx = (C.c_void_p * n)()
-        nh = (C.c_int32 * n)()
-        lv = (C.c_int32 * n)(*[int(x) for x in lowest_levels])
-        for i, h in enumerate(hsps):
-            if h is None or len(h) < 2:
-                continue
-            a = np.ascontiguousarray(h, dtype=np.int32)
-            keep.append(a)
-            jx[i] = a.ctypes.data
-            nh[i] = a.shape[0] - 1
-        missing = []
-
-        def units(_user, query, level, span, flat, n_flat):
-            key = (level, span[0], span[1], span[2], span[3])
-            tab = wilip_tables[query] if wilip_tables else None
-            if not tab or key not in tab:
-                missing.append((query,) + key)
-                return 1
-            a = np.asarray(tab[key], dtype=np.int32)
-            keep.append(a)                                   # (appends are atomic; the arrays live until the call returns)
-            flat[0] = a.ctypes.data_as(C.POINTER(C.c_int32))
-            n_flat[0] = a.size
-            return 0
-
-        src = abi.HspSource()
-        src.user = None
-        src.units = abi.HSP_UNITS_FN(units)
-        src.release = abi.HSP_RELEASE_FN(lambda _u, _q, _f: None)
-        arr = (abi.Alignment * n)()
-        fn = getattr(self.lib, name)
-        fn.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
-        rc = fn(self.ctx, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
-        if missing:
-            raise KeyError(f"no Wilip reply for {missing[:3]}")
-        if not (allow_partial and rc == 1):
-            self._check(rc, name)
-        res = []
-        for i in range(n):
-            k = arr[i].n_skl
-            skl = np.array([(arr[i].skl[j].m, arr[i].skl[j].n) for j in range(k)], dtype=np.int32).reshape(-1, 2)
-            res.append((int(arr[i].score), skl))
-        self.lib.spdp_free_alignments(arr, n)
-        return res
+        return _seeded_call(self.lib, self.ctx, self._check, name, sc, sp, ps, hsps, lowest_levels, wilip_tables, allow_partial)
 
     def align_s_seeded_ori3(self, sc, sp, ps_fwd, ps_rev, hsps, lowest_levels, wilip_tables):
         """alignS_ng(ori = 3) with seeding on: wilip_tables has 2 n entries (the reverse walk of query i is query n + i).

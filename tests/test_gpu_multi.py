@@ -63,3 +63,123 @@ def test_bench_two_ranks_on_one_card():
     assert len(strong["rank_busy_ms"]) == 2 and len(strong["rank_cells"]) == 2
     assert max(strong["rank_cells"]) - min(strong["rank_cells"]) < 0.02 * sum(strong["rank_cells"])   # cell-balanced shards
     assert rec["cpu_baseline"] is None                 # timed at N = 1 only
+
+
+def test_eight_member_group_balances_cells_and_keeps_query_order():
+    """eight contexts on the one card stand in for the eight GPUs of a node: shards by DP cells within 2 %, results in
+    the caller's order"""
+    from spaln_amd import abi, defaults, engine, synth
+    import ctypes as C
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    for w, q, s5, s3, _ in synth.make_batch(400, seed=77, mrna_len=600, n_exons=4, flank=200, intron_hi=1500):
+        ps.add(q, w, s5, s3)
+    eng = engine.Engine(0)
+    want = eng.homscore_s(sc, ps).tolist()
+    eng.close()
+    grp = engine.Group([0] * 8)
+    assert grp.homscore_s(sc, ps).tolist() == want
+    member = grp.shards(len(ps))
+    costs = []
+    for p in ps.items:
+        w = abi.Window()
+        grp.lib.spdp_stripe(C.byref(p), sc.sh, C.byref(w))
+        costs.append(int(grp.lib.spdp_cells(C.byref(p), C.byref(w))))
+    loads = [sum(c for c, m in zip(costs, member) if m == r) for r in range(8)]
+    assert min(loads) > 0 and (max(loads) - min(loads)) / max(loads) < 0.02, loads
+    grp.close()
+
+
+def test_group_seeded_calls_equal_the_reference():
+    """spdp_group_align_s_seeded / _h_seeded: a fixture group with one parameter set through three members; the HSP source is
+    asked with the caller's query numbers (every query has its own recorded Wilip replies), results = the reference's"""
+    from spaln_amd import abi, engine
+    from oracle import seeded
+    from tests import spdg
+    from tests.test_oracle_seeded import Q_FILES
+    from tests.test_oracle_seeded_h import QH, seeded_inputs_h, UNDEFINED
+    grp = engine.Group([0, 0, 0])
+    groups = {}
+    for f in Q_FILES:
+        fx = spdg.load(f)
+        seedp = [int(x) for x in fx["seed_params"]]
+        key = (seedp[0], tuple(seedp[3:]), tuple(int(x) for x in fx["params"][:19]), int(fx["params"][27]), int(fx["params"][28]))
+        groups.setdefault(key, []).append(fx)
+    fxs = max(groups.values(), key=len)
+    assert len(fxs) >= 4
+    ps = abi.ProblemSet()
+    hs, lv, wls, keep = [], [], [], []
+    for fx in fxs:
+        spdg.problem(fx, ps)
+        p = ps.items[-1]
+        h5, h3 = np.ascontiguousarray(fx["phs5"]), np.ascontiguousarray(fx["phs3"])
+        keep += [h5, h3]
+        p.phs5, p.phs3 = h5.ctypes.data, h3.ctypes.data
+        sp = abi.seed_params_from_fixture(fx)
+        j, n = seeded.hsps_of(fx)
+        hs.append(j if n else None)
+        lv.append(int(fx["seed_params"][1]))
+        wls.append(seeded.parse_wilip_log(fx["seed_wilip_A2"]))
+    sc = spdg.scoring(max(fxs, key=lambda f: len(f["intpen"])))
+    res = grp.align_s_seeded(sc, sp, ps, hs, lv, wls)
+    assert len(set(grp.shards(len(fxs)).tolist())) > 1
+    for fx, (scr, skl) in zip(fxs, res):
+        assert scr == int(fx["seed_scr_A2"][0]) and [int(x) for x in skl.ravel()] == fx["seed_skl_A2"].tolist()
+    # protein: the fixtures one by one through the group entry (each its own parameter set)
+    n_ok = 0
+    for path in QH[:8]:
+        name = path.split("/")[-1][:-5]
+        if (name, 2) in UNDEFINED:
+            continue
+        fx = spdg.load(path)
+        sch, sph, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 2)
+        sch.scalar_engines = 0
+        (scr, skl), = grp.align_h_seeded(sch, sph, p._owner, [hsps if n else None], [lowest], [wl])
+        assert scr == int(fx["seed_scr_A2"][0]) and [int(x) for x in skl.ravel()] == fx["seed_skl_A2"].tolist()
+        n_ok += 1
+    assert n_ok >= 5
+    grp.close()
+
+
+def test_group_block_vote_equals_recorded_runs():
+    import ctypes as C
+    from spaln_amd import blocks, engine
+    from oracle import blk as oblk
+    from tests import spdg
+    from tests import test_gpu_blk as tb
+    fx = spdg.load(os.path.join(ROOT, "tests", "golden", "blk_k1.spdg"))
+    qs = oblk.parse_log(fx)
+    grp = engine.Group([0, 0, 0])
+    lib = grp.lib
+    lib.spdp_group_context.restype = C.c_void_p
+    lib.spdp_group_context.argtypes = [C.c_void_p, C.c_int]
+
+    class Member:                                   # what blocks.BlockIndex needs of an engine
+        def __init__(self, ctx):
+            self.lib, self.ctx = lib, ctx
+
+        def _check(self, rc, what):
+            assert rc == 0, what
+    idx = [blocks.BlockIndex(Member(lib.spdp_group_context(grp.h, r)), fx) for r in range(3)]
+    handles = (C.c_void_p * 3)(*[i.h for i in idx])
+    queries = [q["codes"] for q in qs]
+    offs = np.zeros(len(queries) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    codes = np.ascontiguousarray(np.concatenate(queries))
+    left = np.array([q["left"] for q in qs], dtype=np.int32)
+    right = np.array([q["right"] for q in qs], dtype=np.int32)
+    cap = 1 << 14
+    out = np.zeros((len(qs), cap), dtype=np.int32)
+    lib.spdp_group_blk_vote.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32]
+    rc = lib.spdp_group_blk_vote(grp.h, handles, codes.ctypes.data, offs.ctypes.data, left.ctypes.data, right.ctypes.data, None,
+                                 len(qs), out.ctypes.data, cap)
+    assert rc == 0, lib.spdp_group_last_error(grp.h)
+    tb._IX[0] = oblk.index_of(fx)[0]
+    _keep = oblk.index_of(fx)
+    tb._IX[0] = _keep[0]
+    for i, q in enumerate(qs):
+        assert tb.same(blocks.split_record(out[i]), oblk.split_recorded(*q["calls"][0])), i
+    assert len(set(grp.shards(len(qs)).tolist())) == 3
+    for i in idx:
+        i.free()
+    grp.close()

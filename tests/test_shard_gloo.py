@@ -74,12 +74,13 @@ WORKER = textwrap.dedent("""
 
 
 @pytest.mark.timeout(300)
-def test_two_process_gloo_matches_single(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])              # 8: the ranks of a full node (more ranks than some have work for)
+def test_gloo_ranks_match_single(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29641 + world), str(script)],
                          capture_output=True, text=True, env=env, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]

@@ -564,6 +564,36 @@ static int pipe_stalled(SpdpContext* ctx, const HPipe& pp, int n_probs)
     return (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) ? 1 : 0;
 }
 
+// the -A1 engines (spdh_exact): a pipelined work item is (G problems, stripe of 16 rows), one wave each; G = 4 once the
+// launch fills the chip that way, fewer before.  SPDP_HX_PIPE=0: the stripes of a problem one after the other in one
+// 16-lane group; SPDP_HX_GROUPS=1|2|4 forces G.
+static int pipe_setup_exact(SpdpContext* ctx, DevPool& pool, int slot, const std::vector<DevProblemH>& probs, int max_im, HPipe& pp, int& G, bool nopipe = false)
+{
+    pp = HPipe();
+    const int n = (int) probs.size();
+    int64_t stripes = 0;
+    for (const DevProblemH& P : probs) {
+        const int ns = std::max(1, (P.a_right - P.a_left + 15) / 16);
+        pp.max_tiles = std::max(pp.max_tiles, ns);
+        stripes += ns;
+    }
+    G = stripes >= 4 * 4096 ? 4 : (stripes >= 2 * 4096 ? 2 : 1);
+    if (const char* e = getenv("SPDP_HX_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) G = v; }
+    const char* e = getenv("SPDP_HX_PIPE");
+    if (nopipe || (e && atoi(e) == 0) || pp.max_tiles < 2) return 0;
+    for (int q = 0; q * G < n; ++q) {
+        int ns = 1;
+        for (int j = q * G; j < std::min(n, (q + 1) * G); ++j) ns = std::max(ns, std::max(1, (probs[j].a_right - probs[j].a_left + 15) / 16));
+        for (int t = 0; t < ns; ++t) { pp.items.push_back(q); pp.items.push_back(t); }
+    }
+    pp.stride = 2 + 7 * pp.max_tiles + 3 * max_im;
+    pp.words = ((size_t) n * pp.stride + 2 + 1) & ~(size_t) 1;
+    pp.d = (int*) pool.get(slot, sizeof(int) * (pp.words + pp.items.size()));
+    if (!pp.d) { ctx->err = "device allocation failed (stripe pipeline of the -A1 aa x genome engines)"; return -1; }
+    pp.on = true;
+    return 0;
+}
+
 // ---- scalar forwardH_ng over a list of items (spdp_h_rowwave.hip) ------------------------------
 // Vmf record budget of one forwardH_ng / forwardH1 call: a record is written where a diagonal run starts, twice per
 // accepted intron and per first-row restart -- far fewer than cells on real inputs.  One per two cells (at least 64 per
@@ -577,7 +607,7 @@ static int64_t vmf_budget_h(const DevProblemH& d, int scale)
     return std::min<int64_t>(full, std::max<int64_t>(d.cells / 2, 64 * rows) * scale + 3ll * (d.b_right - d.b_left + 8) + 64);
 }
 
-static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale, bool cut = false)
+static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool forward, HFwdOut& out, bool exact, int scale, bool cut = false, bool nopipe = false)
 {
     SpdpContext* ctx = lane_of(st);
     DevPool& pool = ctx->pool[H_POOL];
@@ -631,7 +661,8 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
     A.work = (int*) d_work; A.vmf = (int3*) d_vmf; A.res = (DevResultH*) d_res;
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
     HPipe pp;
-    if (!exact && !cut && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;     // (the cut-range variant runs one wave per problem)
+    if (exact) { if (pipe_setup_exact(ctx, pool, HP_PIPE, h_probs, 0, pp, A.item_probs, nopipe)) return -1; }
+    else if (!cut && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;     // (the cut-range variant runs one wave per problem)
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pipe_arm(ctx, pp, nr, A)) return -1;
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -659,6 +690,17 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
         fprintf(stderr, "[spdp run] aa x genome %s forward=%d n %d cells %.3g pipe %d items %zu  %.2f ms  %.2f GCUPS\n",
                 exact ? "-A1" : "-A0", (int) forward, nr, (double) out.cells, (int) pp.on, pp.items.size() / 2, out.sweep_ms,
                 out.cells / (out.sweep_ms * 1e6));
+    // -A1, pipelined: a result whose walk met a link word the reference leaves from stripe to stripe (spdp_h_exact.hip:
+    // HXPOISON) runs again, one 16-lane group per problem
+    std::vector<int> redo;
+    for (int i = 0; exact && pp.on && i < nr; ++i) if (out.res[i].pad[1]) redo.push_back(i);
+    HFwdOut ro;
+    if (!redo.empty()) {
+        std::vector<HItem> part;
+        for (int i : redo) part.push_back(items[i]);
+        if (run_scalar_group(st, part, forward, ro, exact, scale, cut, true)) return -1;
+        for (size_t k = 0; k < redo.size(); ++k) { out.res[redo[k]] = ro.res[k]; out.n_skl[redo[k]] = ro.n_skl[k]; }
+    }
     for (int i = 0; i < nr; ++i) {
         const int c = out.n_skl[i];
         if (c == -1) { ctx->err = "traceback record buffer overflow (scalar engine)"; return -1; }
@@ -672,6 +714,8 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
             SpdpSkl s; s.m = skl[(size_t) i * skl_cap + k].x; s.n = skl[(size_t) i * skl_cap + k].y;
             out.skl[out.off[i] + k] = s;
         }
+    for (size_t k = 0; k < redo.size(); ++k)
+        for (int j = 0; j < ro.n_skl[k]; ++j) out.skl[out.off[redo[k]] + j] = ro.skl[ro.off[k] + j];
     return 0;
 }
 
@@ -728,7 +772,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
 // ---- scalar hirschbergH_ng over a list of items (spdp_h_rowwave.hip) ----------------------------
 struct HUdhOut;
 // engine: 0 hirschbergH_ng (scalar), 1 hirschbergH1 (-A1), 2 hirschbergH1_wip with local ends (-LS)
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine = 0);
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine = 0, bool nopipe = false);
 
 // ---- hirschbergH1_wip over a list of items ------------------------------------------------------
 struct HUdhOut {
@@ -792,7 +836,7 @@ static int run_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out)
     return 0;
 }
 
-static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine)
+static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& out, std::vector<int>& flags, int engine, bool nopipe)
 {
     const bool exact = engine != 0;
     SpdpContext* ctx = lane_of(st);
@@ -843,7 +887,8 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.imd = (int*) d_imd; A.cpos = (int*) d_cpos; A.ranges = (int*) d_ranges; A.scores = (int*) d_scores;
     A.cpos_stride = out.stride;
     HPipe pp;
-    if (engine == 0 && pipe_setup(ctx, pool, HU_PIPE, h_probs, true, max_im, pp)) return -1;
+    if (engine == 1) { if (pipe_setup_exact(ctx, pool, HU_PIPE, h_probs, max_im, pp, A.item_probs, nopipe)) return -1; }
+    else if (engine == 0 && pipe_setup(ctx, pool, HU_PIPE, h_probs, true, max_im, pp)) return -1;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pipe_arm(ctx, pp, nr, A)) return -1;
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -870,6 +915,26 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
         fprintf(stderr, "[spdp run] aa x genome linear space engine %d n %d cells %.3g pipe %d items %zu  %.2f ms  %.2f GCUPS\n",
                 engine, nr, (double) out.cells, (int) pp.on, pp.items.size() / 2, out.sweep_ms, out.cells / (out.sweep_ms * 1e6));
     for (int i = 0; i < nr; ++i) flags[i] = exact ? 0 : res[i].pad[0];
+    // -A1, pipelined: dead results run again in the one-group form (see run_scalar_group)
+    std::vector<int> redo;
+    for (int i = 0; engine == 1 && pp.on && i < nr; ++i) if (res[i].pad[1]) redo.push_back(i);
+    if (getenv("SPDP_TRACE_RUNS") && engine == 1 && pp.on) {
+        fprintf(stderr, "[spdp run] -A1 linear space: %zu of %d results run again without the pipeline\n", redo.size(), nr);
+    }
+    if (!redo.empty()) {
+        std::vector<HItem> part;
+        for (int i : redo) part.push_back(items[i]);
+        HUdhOut ro;
+        std::vector<int> rf;
+        if (run_scalar_udh(st, part, ro, rf, engine, true)) return -1;
+        for (size_t k = 0; k < redo.size(); ++k) {
+            const int i = redo[k];
+            out.scores[i] = ro.scores[k];
+            for (int c = 0; c < 4; ++c) out.ranges[(size_t) i * 4 + c] = ro.ranges[k * 4 + c];
+            for (int c = 0; c < std::min(out.stride, ro.stride); ++c) out.cpos[(size_t) i * out.stride + c] = ro.cpos[k * ro.stride + c];
+            flags[i] = rf[k];
+        }
+    }
     return 0;
 }
 

@@ -89,6 +89,7 @@ struct HScalarArgs {
     int                pipe_stride, pipe_ticket, max_tiles;
     const int2*        items;      // (problem, tile) in dispatch order
     int                n_items;
+    int                item_probs; // spdh_exact: problems per wave (1, 2, 4); a pipelined item is (item_probs problems, stripe)
 };
 
 // protein-side signal precompute (spdp_signals_h.hip): Exinon::intron53_c / intron53_p for tron windows

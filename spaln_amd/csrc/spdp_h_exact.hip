@@ -87,7 +87,17 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
     __shared__ IpenRuns s_runs;                  // IntPen beyond s_ipen
     __shared__ short s_t53[256];
     __shared__ unsigned char s_mid[32], s_tron[64];
+    __shared__ int s_bnd[3];                     // max IntPen, max junction-pair score, max |mtx|: what a candidate can gain at most
     const int tid = threadIdx.x;
+    if (tid < 3) s_bnd[tid] = tid == 2 ? 0 : -0x7fffffff;
+    __syncthreads();
+    {
+        int pm = -0x7fffffff, tm = -0x7fffffff, mm = 0;
+        for (int i = tid; i < A.intpen_len; i += 64 * HXWPB) pm = max(pm, (int) A.intpen[i]);
+        for (int i = tid; i < 256; i += 64 * HXWPB) tm = max(tm, (int) A.t53[i]);
+        for (int i = tid; i < 32 * 32; i += 64 * HXWPB) mm = max(mm, abs(A.sc->mtx[i]));
+        atomicMax(&s_bnd[0], pm); atomicMax(&s_bnd[1], tm); atomicMax(&s_bnd[2], mm);
+    }
     for (int i = tid; i < 32 * 32; i += 64 * HXWPB) s_mtx[i] = A.sc->mtx[i];
     for (int i = tid; i < 4096; i += 64 * HXWPB) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     ipen_runs_load(s_runs, A.ipen_runs);
@@ -152,6 +162,9 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
     auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
     auto acode = [&](int i) -> int { return i < 0 ? 2 : (i >= P.a_len ? P.a_pad : acod[i]); };      // a_pad: SpdpProblemH
     const int c_hi = P.b_len + 2;
+    // no candidate of value v can reach more than v + sig3 + gain_max (+ |sigE| of the acceptor for a split codon)
+    const int gain_max = s_bnd[0] + s_bnd[1] + 2 * s_bnd[2];
+    const bool has_cip = A.cip && P.cip_off >= 0;
     const int n_stripes = max(1, (a_right - a_left + XN - 1) / XN);
     if (PIPE && my_stripe >= n_stripes) return;  // (a shorter problem of the four)
     // PIPE: what the stripes of the problem share: prog[max_tiles], best[max_tiles][6], rlf[n_im][3]
@@ -188,25 +201,34 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
         if (k == 0) xh_st<PIPE>(vcount, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (k == 0) {
-            if constexpr (!UDH) {
-                int ptr = vadd(0, 0, 0);
-                if (!(a_exgl && b_exgl)) ptr = vadd(a_left, b_left, ptr);
-                for (int r = rl; r < up; ++r) xh_st<PIPE>(hc + r, a_exgl ? 0 : ptr);
-                for (int r = lw; r < rl; ++r) xh_st<PIPE>(hc + r, b_exgl ? 0 : ptr);
-                if (b_exgl == 2) xh_st<PIPE>(fc + rl, ptr);
-            } else {
-                const int re = a_exgl ? rl : up;
-                for (int r = lw; r < re; ++r) xh_st<PIPE>(hc + r, r);
-                for (int i = 0, r = rl; r >= lw; --r) xh_st<PIPE>(hb + r, a_left + (i++ / 3));
+        int sc_on = 0, sc_r = 0, sc_n = 0, sc_bb = 0, sc_rr = 0;        // the first-row scan, where it stands (lane 0 -> group)
+        int sh1 = 0, sh2 = 0, sh3 = 0, sc1 = 0, sc2 = 0, sc3 = 0, sl0 = 0, sl1 = 0, sl2 = 0;
+        // the link / `ml` rows as fhinitH1 leaves them: by all lanes of the group
+        int ptr0 = 0;
+        if constexpr (!UDH) {
+            if (k == 0) {
+                ptr0 = vadd(0, 0, 0);
+                if (!(a_exgl && b_exgl)) ptr0 = vadd(a_left, b_left, ptr0);
             }
-            if (b_exgl == 1) { for (int r = lw; r < rl; ++r) xh_st<PIPE>(hv + r, 0); }
-            else if (b_exgl == 2) { xh_st<PIPE>(fv + rl, 0); xh_st<PIPE>(fc + rl, rl); }
+            ptr0 = __shfl(ptr0, 0, XN);
+            for (int r = rl + k; r < up; r += XN) xh_st<PIPE>(hc + r, a_exgl ? 0 : ptr0);
+            for (int r = lw + k; r < rl; r += XN) xh_st<PIPE>(hc + r, b_exgl ? 0 : ptr0);
+        } else {
+            const int re = a_exgl ? rl : up;
+            for (int r = lw + k; r < re; r += XN) xh_st<PIPE>(hc + r, r);
+            for (int i = k, r = rl - k; r >= lw; r -= XN, i += XN) xh_st<PIPE>(hb + r, a_left + i / 3);
+        }
+        if (b_exgl == 1) { for (int r = lw + k; r < rl; r += XN) xh_st<PIPE>(hv + r, 0); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (k == 0) {
+            if constexpr (!UDH) { if (b_exgl == 2) xh_st<PIPE>(fc + rl, ptr0); }
+            if (b_exgl == 2) { xh_st<PIPE>(fv + rl, 0); xh_st<PIPE>(fc + rl, rl); }
             int rr = b_right - 3 * a_left;
             if (up < rr) rr = up;
             int r = rl;
             if (!a_exgl) {
-                if (b_exgl) { xh_st<PIPE>(fv + r, 0); xh_st<PIPE>(fc + r, xh_ld<PIPE>(hc + r)); }
+                if (b_exgl) { xh_st<PIPE>(fv + r, 0); xh_st<PIPE>(fc + r, UDH ? rl : ptr0); }       // (= hc[rl] as set above)
                 xh_st<PIPE>(hv + r++, 0);
                 xh_st<PIPE>(hv + r++, xh_w16(g1));
                 xh_st<PIPE>(hv + r++, xh_w16(g2));
@@ -232,29 +254,55 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
                     xh_st<PIPE>(hv + r, h); xh_st<PIPE>(hc + r, c);
                     h3 = h2; h2 = h1; h1 = h; c3 = c2; c2 = c1; c1 = c;
                 }
-                for ( ; r < rr; ++r, ++n, ++bb) {
-                    int h = h3, c = c3;
-                    const int gl = r - le0;
-                    if (!(a_exgl & 1) && gl == 3) h = xh_w16(h + gop);
-                    if (!(a_exgl & 2)) h = xh_w16(h + gext3(gl));
-                    h = xh_w16(h + aux[bb - 3].z);
-                    if (h < XNEV) { xh_st<PIPE>(hv + r, h); xh_st<PIPE>(hc + r, c); break; }
-                    int x = xh_w16(h1 + g1);
-                    if (x > h) { h = x; c = c1; }
-                    x = xh_w16(h2 + g2);
-                    if (x > h) { h = x; c = c2; }
-                    const int s = aux[bb].x;
-                    x = s > 0 ? s : 0;
-                    if (x > h) {
-                        h = x; le0 = r;
-                        if constexpr (!UDH) { c = vadd(a_left, n, 0); xh_st<PIPE>(hb + r, 1); }
-                        else c = r;
-                    }
-                    xh_st<PIPE>(hv + r, h); xh_st<PIPE>(hc + r, c);
-                    h3 = h2; h2 = h1; h1 = h; c3 = c2; c2 = c1; c1 = c;
-                    const int t_ = le0; le0 = le1; le1 = le2; le2 = t_;
-                }
+                sc_on = 1; sc_r = r; sc_n = n; sc_bb = bb; sc_rr = rr;
+                sh1 = h1; sh2 = h2; sh3 = h3; sc1 = c1; sc2 = c2; sc3 = c3; sl0 = le0; sl1 = le1; sl2 = le2;
             }
+        }
+        // the max-plus scan over the free first row (:640-689): one entry after the other on lane 0, its signals staged
+        // through LDS by the whole group, 128 entries at a time (a load per entry from memory made this scan -- as long
+        // as the window -- the longest phase of the stripe that owns it)
+        sc_on = __shfl(sc_on, 0, XN); sc_r = __shfl(sc_r, 0, XN); sc_n = __shfl(sc_n, 0, XN); sc_bb = __shfl(sc_bb, 0, XN); sc_rr = __shfl(sc_rr, 0, XN);
+        {
+            int* const sI = reinterpret_cast<int*>(s_col[g16]);
+            while (sc_on && sc_r < sc_rr) {
+                const int cnt = min(128, sc_rr - sc_r);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = k; i < cnt + 3; i += XN) {
+                    const short4 a = aux[max(sc_bb - 3 + i, 0)];
+                    sI[i] = (int) ((unsigned) (unsigned short) a.x | ((unsigned) (unsigned short) a.z << 16));      // sigS | sigE << 16
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                int stop = 0;
+                if (k == 0) {
+                    int r = sc_r, n = sc_n;
+                    for (int i = 0; i < cnt; ++i, ++r, ++n) {
+                        int h = sh3, c = sc3;
+                        const int gl = r - sl0;
+                        if (!(a_exgl & 1) && gl == 3) h = xh_w16(h + gop);
+                        if (!(a_exgl & 2)) h = xh_w16(h + gext3(gl));
+                        h = xh_w16(h + (sI[i] >> 16));                        // aux[bb - 3].z
+                        if (h < XNEV) { xh_st<PIPE>(hv + r, h); xh_st<PIPE>(hc + r, c); stop = 1; break; }
+                        int x = xh_w16(sh1 + g1);
+                        if (x > h) { h = x; c = sc1; }
+                        x = xh_w16(sh2 + g2);
+                        if (x > h) { h = x; c = sc2; }
+                        const int sS = (int) (short) (sI[i + 3] & 0xffff);    // aux[bb].x
+                        x = sS > 0 ? sS : 0;
+                        if (x > h) {
+                            h = x; sl0 = r;
+                            if constexpr (!UDH) { c = vadd(a_left, n, 0); xh_st<PIPE>(hb + r, 1); }
+                            else c = r;
+                        }
+                        xh_st<PIPE>(hv + r, h); xh_st<PIPE>(hc + r, c);
+                        sh3 = sh2; sh2 = sh1; sh1 = h; sc3 = sc2; sc2 = sc1; sc1 = c;
+                        const int t_ = sl0; sl0 = sl1; sl1 = sl2; sl2 = t_;
+                    }
+                }
+                if (__shfl(stop, 0, XN)) break;
+                sc_r += cnt; sc_n += cnt; sc_bb += cnt;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -329,11 +377,11 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
         int uH[4] = {XNEV, XNEV, XNEV, XNEV}, uC[4] = {0, 0, 0, 0}, uB[4] = {0, 0, 0, 0};
         if (!PIPE) { uC[1] = xh_shr1(0, HC[4]); uC[2] = xh_shr1(0, HC[5]); uC[3] = xh_shr1(0, HC[6]); }
         else if (ml != a_left) uC[1] = uC[2] = uC[3] = HXPOISON;
-        // the donor candidates of my row, best first; c_pk = value << 16 | junction class << 8 | bases before the donor
-        // (w0 | w1 << 3, 7 = none) << 2 ... see the donor code; c_sp = state | (phase + 1) << 2
-        int c_val[5], c_jnc[5], c_sp[5], c_ml[5], c_ulk[5], c_dk[5], ncand = -1;
+        // the donor candidates of my row, best first: value, donor position, `ml` / link of the state it left, and what an
+        // acceptor needs of the donor's column (c_dk)
+        int c_val[5], c_jnc[5], c_ml[5], c_ulk[5], c_dk[5], ncand = -1;      // c_dk: bits 0-11 donor column pack, 12-13 state, 14-15 phase + 1
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = 0; c_sp[i] = 0; c_ml[i] = 0; c_ulk[i] = 0; c_dk[i] = 0; }
+        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = 0; c_ml[i] = 0; c_ulk[i] = 0; c_dk[i] = 0; }
         int sm = 0;
         const int m = ml + k;                                 // hb1's `mj`: my row is a[m]
         int mm_ = 0, k9 = 0, k8 = -1, mi = 0;
@@ -515,12 +563,20 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
 
             const bool in_q = site_lane && c >= n_first && c < b_right;
             const unsigned fl = in_q ? (unsigned) cx >> 24 : 0u;
-            const bool is_acc = ((fl & 7) == 3) || (fl & 4);
+            bool is_acc = (((fl & 7) == 3) || (fl & 4)) && ncand >= 0;
+            if (is_acc && !has_cip) {
+                // screen: the best candidate, priced as high as anything can be, against the lowest of the nine cells
+                // a candidate may raise (every update below is behind `x > cell`)
+                const int s3 = (fl & 4) ? (int) (short) ((unsigned) col.y >> 16) : (int) (short) (col.y & 0xffff);
+                const int sE = (int) (short) (ring[(c - 1) & (HXRING - 1)].w & 0xffff);
+                const int lo = min(min(min(HV[0], HV[1]), min(HV[2], EV[0])), min(min(EV[1], EV[2]), min(min(FV[0], FV[1]), FV[2])));
+                is_acc = c_val[0] + s3 + gain_max + abs(sE) > lo;
+            }
             const bool is_don = (((fl >> 3) & 7) == 3) || ((fl >> 3) & 4);
             if (is_acc || is_don) {
                 const int4 colm1 = ring[(c - 1) & (HXRING - 1)];          // the site itself: acc = don = c - 1
                 // intron 3' boundary (:1049-1054, Sjsites::get :388-494): my column is a queued acceptor column
-                if (is_acc && ncand >= 0) {
+                if (is_acc) {
                     const int acc = c - 1;
                     const int rr0 = acc - 3 * (m + 1);
                     const int s3 = (fl & 4) ? (int) (short) ((unsigned) col.y >> 16) : (int) (short) (col.y & 0xffff);     // sig3[acc]
@@ -531,13 +587,13 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
                     const int t3 = acc + 1 > P.b_len ? 2 : ((ring[(c + 2) & (HXRING - 1)].x >> 16) & 0xff);
                     const int w2 = t2 < 32 ? (int) s_mid[t2] : 7, w3 = t3 < 32 ? (int) s_mid[t3] : 7;
                     const bool acc_ok = acc < b_right && w2 <= 3 && w3 != 7;
-                    const int cip_base = (A.cip && P.cip_off >= 0) ? P.cip_off + 3 * (m + 1) : -1;
+                    const int cip_base = has_cip ? P.cip_off + 3 * (m + 1) : -1;
                     bool mx_on[3] = {false, false, false}; int mx_val[3] = {0, 0, 0}, mx_phs[3] = {0, 0, 0}, mx_ulk[3] = {0, 0, 0};
                     bool b_on = false; int b_val = 0, b_dir = 0;
 #pragma unroll
                     for (int l = 0; l < 5; ++l) {
                         if (l > ncand) continue;
-                        const int d = c_sp[l] & 3, phs = (c_sp[l] >> 2) - 1, don = c_jnc[l];
+                        const int d = (c_dk[l] >> 12) & 3, phs = ((c_dk[l] >> 14) & 3) - 1, don = c_jnc[l];
                         const int rr = rr0 + phs;
                         if (rr < lw || rr >= up) continue;
                         if (d == 2 && phs == 1) continue;
@@ -649,13 +705,15 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
                             if (kk && from <= thr) continue;
                             const int x = from + sigJ;
                             if (x <= XNEV) continue;
+                            // a full list whose fourth entry beats x: the free slot stays below it, and the list is four long after
+                            if (ncand >= 3 && c_val[3] > x) { ncand = 3; continue; }
                             // the free slot starts below the list and moves up past every entry x ties or beats
                             int pos = ncand < 4 ? ncand + 1 : 4;
                             if (ncand < 4) ++ncand;
 #pragma unroll
                             for (int l = 4; l >= 1; --l)
                                 if (pos == l && x >= c_val[l - 1]) {
-                                    c_val[l] = c_val[l - 1]; c_jnc[l] = c_jnc[l - 1]; c_sp[l] = c_sp[l - 1]; c_dk[l] = c_dk[l - 1];
+                                    c_val[l] = c_val[l - 1]; c_jnc[l] = c_jnc[l - 1]; c_dk[l] = c_dk[l - 1];
                                     c_ml[l] = c_ml[l - 1]; c_ulk[l] = c_ulk[l - 1];
                                     pos = l - 1;
                                 }
@@ -671,7 +729,7 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
 #pragma unroll
                                 for (int l = 0; l < 4; ++l)
                                     if (l == pos) {
-                                        c_val[l] = xh_w16(x); c_jnc[l] = don; c_sp[l] = kk | ((phs + 1) << 2); c_dk[l] = dk;
+                                        c_val[l] = xh_w16(x); c_jnc[l] = don; c_dk[l] = dk | (kk << 12) | ((phs + 1) << 14);
                                         c_ml[l] = n_ml; c_ulk[l] = n_ulk;
                                     }
                             } else --ncand;
@@ -743,54 +801,74 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
             }
         }
     }
-    if (k) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- fhlastH1 (:691-791) by lane 0
+    // ---- fhlastH1 (:691-791): the scans over the last row / the last column one entry after the other on lane 0,
+    // their inputs (boundary entries, signals) staged through LDS by the whole group, 128 entries at a time
     auto HVr = [&](int i) -> int { return xh_ld<PIPE>(hv + i); };
     int ptr = 0, maxt = 0;
     const bool by_last = UDH ? !(LocalR && max_mr < a_right) : (!LocalR || max_mr == a_right);
+    const int m3 = 3 * a_right;
+    const int rr = b_right - m3;
+    int maxr = rr, mx = rr, hmx = 0;
     if (by_last) {
+        int* const sH = reinterpret_cast<int*>(s_col[g16]);        // 512 ints: 128 entries, 130 x {sigT | sigE << 16}, 130 x sig5
+        int* const sYZ = sH + 128;
+        int* const sW = sH + 260;
         int gl0 = 0, gl1 = 0, gl2 = 0;                   // glen[f], tcdn[f], rotated with f
         bool tc0 = false, tc1 = false, tc2 = false;
-        const int m3 = 3 * a_right;
         int rw = lw;
         int rf = b_left - m3;
         if (rf > rw) rw = rf; else rf = rw;
-        const int rr = b_right - m3;
-        int maxr = rr, mx = rr;
-        int hmx = HVr(mx);                               // hv[mx]
+        const int rw0 = rw;
+        hmx = k == 0 ? HVr(mx) : 0;                      // hv[mx]
         int bb = rw + m3;
         if (a_exgr) {
             int p1 = 0, p2 = 0, p3 = 0;                  // hv[h - 1], [h - 2], [h - 3] as they stand (after this loop's writes)
-            for (int h = rw; h <= rr; ++h, ++rf, ++bb) {
-                gl0 += 3;
-                int hvh = HVr(h);
-                int c0 = hvh, c1 = XNEV, c2 = XNEV;
-                const short4 a2 = rf - rw >= 3 ? aux[bb - 2] : make_short4(0, 0, 0, 0);
-                if (rf - rw >= 3 && !tc0) {
-                    c1 = p3 + a2.z;
-                    if (!(a_exgr & 2)) c1 += gext3(gl0);
-                    if (!(a_exgr & 1) && gl0 == 3) c1 += gop;
-                    if (sc->term_codon) c2 = p3 + a2.y;
+            for (int h0 = rw; h0 <= rr; h0 += 128, bb += 128) {
+                const int cnt = min(128, rr - h0 + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = k; i < cnt; i += XN) sH[i] = HVr(h0 + i);
+                for (int i = k; i < cnt + 2; i += XN) {
+                    const short4 a = aux[max(bb - 2 + i, 0)];
+                    sYZ[i] = (int) ((unsigned) (unsigned short) a.y | ((unsigned) (unsigned short) a.z << 16));
+                    sW[i] = a.w;
                 }
-                if (rf - rw >= 3) tc0 = tc0 || a2.y > 0;
-                const int s5r = aux[bb].w;
-                const int s5 = (local && s5r > 0) ? s5r : 0;
-                c0 += s5; c1 += s5;
-                int kk = 0, cb = c0;
-                if (c1 > cb) { kk = 1; cb = c1; }
-                if (c2 > cb) { kk = 2; cb = c2; }
-                if (kk == 0) { gl0 = 0; tc0 = false; }
-                else if (kk == 1) { hvh = xh_w16(c1 - s5); xh_st<PIPE>(hv + h, hvh); }
-                else { hvh = xh_w16(c2); xh_st<PIPE>(hv + h, hvh); }
-                if (h == mx) hmx = hvh;
-                if (hvh > hmx) { mx = h; hmx = hvh; maxr = rf - (kk == 2 ? 3 : 0); }
-                p3 = p2; p2 = p1; p1 = hvh;
-                { const int t_ = gl0; gl0 = gl1; gl1 = gl2; gl2 = t_; }
-                { const bool t_ = tc0; tc0 = tc1; tc1 = tc2; tc2 = t_; }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (k == 0) {
+                    for (int i = 0; i < cnt; ++i, ++rf) {
+                        const int h = h0 + i;
+                        gl0 += 3;
+                        int hvh = sH[i];
+                        int c0 = hvh, c1 = XNEV, c2 = XNEV;
+                        const int yz = sYZ[i];                        // aux[bb - 2]: sigT, sigE
+                        const int a2y = (int) (short) (yz & 0xffff), a2z = yz >> 16;
+                        if (rf - rw0 >= 3 && !tc0) {
+                            c1 = p3 + a2z;
+                            if (!(a_exgr & 2)) c1 += gext3(gl0);
+                            if (!(a_exgr & 1) && gl0 == 3) c1 += gop;
+                            if (sc->term_codon) c2 = p3 + a2y;
+                        }
+                        if (rf - rw0 >= 3) tc0 = tc0 || a2y > 0;
+                        const int s5r = sW[i + 2];                    // aux[bb].w
+                        const int s5 = (local && s5r > 0) ? s5r : 0;
+                        c0 += s5; c1 += s5;
+                        int kk = 0, cb = c0;
+                        if (c1 > cb) { kk = 1; cb = c1; }
+                        if (c2 > cb) { kk = 2; cb = c2; }
+                        if (kk == 0) { gl0 = 0; tc0 = false; }
+                        else if (kk == 1) { hvh = xh_w16(c1 - s5); xh_st<PIPE>(hv + h, hvh); }
+                        else { hvh = xh_w16(c2); xh_st<PIPE>(hv + h, hvh); }
+                        if (h == mx) hmx = hvh;
+                        if (hvh > hmx) { mx = h; hmx = hvh; maxr = rf - (kk == 2 ? 3 : 0); }
+                        p3 = p2; p2 = p1; p1 = hvh;
+                        { const int t_ = gl0; gl0 = gl1; gl1 = gl2; gl2 = t_; }
+                        { const bool t_ = tc0; tc0 = tc1; tc1 = tc2; tc2 = t_; }
+                    }
+                }
             }
-        } else {
+        } else if (k == 0) {
             const int y = xh_w16(HVr(rr - 3) + aux[bb + (rr - rw)].y);
             if (y > HVr(rr)) { xh_st<PIPE>(hv + rr, y); maxr = rr - 3; if (mx == rr) hmx = y; }
         }
@@ -798,19 +876,33 @@ __global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
             rw = min(up - 1, b_right - 3 * a_left);
             int ga = XNEV, gb_ = XNEV, gc = XNEV;        // g[f], rotated with f
             int n3 = 0, n2 = 0, n1 = 0;                  // hv[h + 3], [h + 2], [h + 1] as they stand
-            if (rw - 3 > rr) { n3 = HVr(rw); n2 = HVr(rw - 1); n1 = HVr(rw - 2); }
-            for (int h = rw - 3; h > rr; --h) {
-                int x = n3;
-                if (!(b_exgr & 1)) x = xh_w16(x + gop);
-                if (x > ga) ga = x;
-                if (!(b_exgr & 2)) ga = xh_w16(ga + gep);
-                int hvh = HVr(h);
-                if (hvh > ga) ga = XNEV;
-                else if (ga > hmx) { mx = h; hvh = ga; hmx = ga; xh_st<PIPE>(hv + h, ga); }
-                n3 = n2; n2 = n1; n1 = hvh;
-                { const int t_ = ga; ga = gb_; gb_ = gc; gc = t_; }
+            if (k == 0 && rw - 3 > rr) { n3 = HVr(rw); n2 = HVr(rw - 1); n1 = HVr(rw - 2); }
+            for (int h0 = rw - 3; h0 > rr; h0 -= 256) {
+                const int cnt = min(256, h0 - rr);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = k; i < cnt; i += XN) sH[i] = HVr(h0 - i);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (k == 0) {
+                    for (int i = 0; i < cnt; ++i) {
+                        const int h = h0 - i;
+                        int x = n3;
+                        if (!(b_exgr & 1)) x = xh_w16(x + gop);
+                        if (x > ga) ga = x;
+                        if (!(b_exgr & 2)) ga = xh_w16(ga + gep);
+                        int hvh = sH[i];
+                        if (hvh > ga) ga = XNEV;
+                        else if (ga > hmx) { mx = h; hvh = ga; hmx = ga; xh_st<PIPE>(hv + h, ga); }
+                        n3 = n2; n2 = n1; n1 = hvh;
+                        { const int t_ = ga; ga = gb_; gb_ = gc; gc = t_; }
+                    }
+                }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (k) return;
+    if (by_last) {
         maxt = mx;
         if constexpr (UDH) xh_st<PIPE>(hb + maxt, xh_ld<PIPE>(hb + maxr));
         max_ulk = xh_ld<PIPE>(hc + maxr);

@@ -646,7 +646,7 @@ LEGS = {
     "a1": (["--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"], "C2 shape under -A1 (forwardS1 / hirschbergS1)"),
     "c3_a0": (["--workload", "c3", "--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
               "C3 shape under -A0 (forwardH_ng / hirschbergH_ng)"),
-    "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"],
+    "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "4000", "--steps", "2", "--warmup", "1"],
               "C3 shape under -A1 (forwardH1 / hirschbergH1)"),
 }
 

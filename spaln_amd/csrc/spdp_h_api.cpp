@@ -534,10 +534,10 @@ static int pipe_setup(SpdpContext* ctx, DevPool& pool, int slot, const std::vect
         for (int t = 0; t < nt; ++t) { pp.items.push_back((int) j); pp.items.push_back(t); }
     }
     if ((e && atoi(e) == 0) || pp.max_tiles < 2) return 0;
-    // These kernels run one or two waves per SIMD: once every SIMD has a problem of its own the pipeline only adds
-    // memory-side traffic (measured on 400-residue queries: 256 problems 283 -> 137 ms, 2048 problems 714 -> 926 ms).
-    // SPDP_A0_PIPE=1 forces it.
-    if (!e && (int) probs.size() >= 4 * ctx->n_cu) return 0;
+    // (Rounds 2 / 3 switched the pipeline off once every SIMD had a problem of its own: the kernels then ran ONE wave per
+    // SIMD -- 256 VGPRs and a handful of AGPRs -- and the pipeline only added memory-side traffic.  Held to 256 registers
+    // (amdgpu_waves_per_eu(2, 2), spdp_h_rowwave.hip) two waves share a SIMD and the pipeline pays at every size measured:
+    // 1000 x 400 aa 2.9 -> 5.1 GCUPS, 1827 problems 3.7 - 4.6 (one wave per problem) -> 5.7.)
     pp.stride = 2 + 9 * pp.max_tiles + 3 * max_im;
     pp.words = (probs.size() * (size_t) pp.stride + 2 + 1) & ~(size_t) 1;
     pp.d = (int*) pool.get(slot, sizeof(int) * (pp.words + pp.items.size()));

@@ -160,7 +160,7 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 // the skewed sweep up to column cut_l - 3, the seam (cut_l - 2 .. cut_l and the replacement) row after row on one lane
 // at a time, and the skewed sweep again from cut_l + 1.
 template <int MODE, bool PIPE, bool CUT = false>
-__global__ __launch_bounds__(64 * WPB) void spdh_rowwave(HScalarArgs A)
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void spdh_rowwave(HScalarArgs A)
 {
     static_assert(!CUT || (MODE == 1 && !PIPE), "the cut range: forward engine, one wave per problem");
     constexpr bool FWD = MODE == 1, UDH = MODE == 2;

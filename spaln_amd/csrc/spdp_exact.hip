@@ -61,7 +61,7 @@ template <bool X> __device__ __forceinline__ void x_st(int* p, int v)
 }
 
 template <int MODE, bool PIPE>
-__global__ void __launch_bounds__(64 * XWPB) spdp_exact(ScalarArgs A)
+__global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(3))) spdp_exact(ScalarArgs A)
 {
     constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
     constexpr bool UDH = MODE == 2;             // links, intermediate rows

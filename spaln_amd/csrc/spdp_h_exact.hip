@@ -78,7 +78,7 @@ template <bool X> __device__ __forceinline__ void xh_st(int* p, int v)
 enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_N };
 
 template <bool UDH, bool PIPE>
-__global__ void __launch_bounds__(64 * HXWPB) spdh_exact(HScalarArgs A)
+__global__ void __launch_bounds__(64 * HXWPB) __attribute__((amdgpu_waves_per_eu(2, 2))) spdh_exact(HScalarArgs A)
 {
     __shared__ int s_mtx[32 * 32];               // the substitution matrix (aa x tron, row stride 32)
     __shared__ int4 s_col[4 * HXWPB][HXRING];    // {cp | tron << 16 | flags << 24, sig3 candidates, dinc5 << 4 | dinc3, sigE | sig5 << 16}

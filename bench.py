@@ -648,6 +648,10 @@ LEGS = {
               "C3 shape under -A0 (forwardH_ng / hirschbergH_ng)"),
     "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "4000", "--steps", "2", "--warmup", "1"],
               "C3 shape under -A1 (forwardH1 / hirschbergH1)"),
+    "dropin": (["tools/dropin_demo.py", "--queries", "600", "--genes", "120", "--modes", "Q4,Q7", "--gpu-threads", "256"],
+               "the reference's own CLI (src/spaln.cc, -t workers, block search, output writers) with alignS_ng switched to the library "
+               "(oracle/_ref/spaln_gpu) against the unmodified build on a synthetic genome its own `spaln -W` formatted: -O4 records "
+               "compared, wall times of both; default engines (-A0)"),
 }
 
 
@@ -659,6 +663,16 @@ def _run_leg(name):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.perf_counter()
+    if name == "dropin":                                         # a program of its own (tools/dropin_demo.py): its JSON line as it is
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
+            return {"what": what, "error": "oracle/_ref/spaln_gpu is not built (needs the reference's sources at build time)"}
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], env=env, capture_output=True, text=True, timeout=900)
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:                                   # noqa: BLE001
+            return {"what": what, "error": f"{type(e).__name__}: {str(e)[:160]}", "wall_s": round(time.perf_counter() - t0, 1)}
+        d.update(what=what, args=" ".join(argv), wall_s=round(time.perf_counter() - t0, 1))
+        return d
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--legs", "none", "--seeded-pairs", "0"],
                            env=env, capture_output=True, text=True, timeout=900)

@@ -18,7 +18,7 @@ const	Simmtx* sm = pwd->simmtx;			// src/simmtx.h:35-63
 	sc.llmt = IntronPrm.llmt;			// src/codepot.h:207-214
 	sc.ipen = pwd->IntPen->Penalty();		// GapWI, src/codepot.h:241
 	sc.nquant = IntronPrm.nquant;			// 1 when -A3 (src/fwd2s1.cc:125)
-	for (int j = 0; j < sc.nquant; ++j) {
+	for (int j = 0; pwd->IntPen->qm && j < sc.nquant; ++j) {	// (the quantised table exists under -A2 / -A3 only, src/codepot.cc:161)
 	    sc.qm_len[j] = pwd->IntPen->qm[j].len;	// src/codepot.h:218-221,232
 	    sc.qm_pen[j] = pwd->IntPen->qm[j].pen;
 	}
@@ -94,7 +94,7 @@ const	Simmtx* sm = pwd->simmtx;			// aa x tron matrix: rows x dim
 	sc.gapw1 = pwd->GapW1;  sc.gapw2 = pwd->GapW2;  sc.gapw3 = pwd->GapW3;
 	sc.spj = b->inex.intr;  sc.llmt = IntronPrm.llmt;  sc.ipen = pwd->IntPen->Penalty();
 	sc.nquant = IntronPrm.nquant;			// 1 under -A3 (src/fwd2h1.cc:127)
-	for (int j = 0; j < sc.nquant; ++j) { sc.qm_len[j] = pwd->IntPen->qm[j].len; sc.qm_pen[j] = pwd->IntPen->qm[j].pen; }
+	for (int j = 0; pwd->IntPen->qm && j < sc.nquant; ++j) { sc.qm_len[j] = pwd->IntPen->qm[j].len; sc.qm_pen[j] = pwd->IntPen->qm[j].pen; }
 	sc.local = algmode.lcl & 16;  sc.term_codon = (algmode.lcl & 2) != 0;
 	sc.sh = alprm.sh;  sc.max_vmf_space = MaxVmfSpace;  sc.ubh = alprm.ubh;  sc.ref_nelem = 16;
 }

@@ -1,0 +1,223 @@
+// spaln_gpu_shim -- the reference's own command line program with its cDNA aligner call switched to libspdp_hip.so.
+// TEST INFRASTRUCTURE ONLY (built by oracle/ref_build/Makefile into oracle/_ref/spaln_gpu where /root/reference exists;
+// runs wherever a GPU is).
+//
+// What is linked: src/spaln.cc and every library object of the reference exactly as in oracle/_ref/spaln, except that
+// src/fwd2s1.cc is compiled once more with -DalignS_ng=alignS_ng_ref (the reference's function under another name,
+// nothing copied); this file supplies alignS_ng (src/aln.h:351, src/fwd2s1.cc:2746).  So spalign2 (src/spaln.cc:666-697),
+// called by the `-t N` worker threads of match_2 / blkaln, lands here; everything around it -- block search, Exinon,
+// skl_rngS_ng, the output writers -- is the reference's.
+//
+// The worker threads are the producers of a batch: a call parks its pair, and the first thread to find no batch running
+// becomes its leader -- it waits a moment for company, runs ONE library call over everything parked (spdp_align_s, or
+// spdp_align_s_seeded with the reference's own Wilip behind the HSP callback when algmode.qck != 0), hands the results
+// back and wakes the others.  What the library does not take (ori = 2, ori = 3 with seeding: they need the reference's
+// file-local reverse_copy_jxt) goes to alignS_ng_ref and is counted.  SPALN_GPU_BATCH / SPALN_GPU_WAIT_US size a batch;
+// the counts are printed to stderr at exit.
+#include "shim_fill.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+SKL* alignS_ng_ref(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori);	// src/fwd2s1.cc, compiled under this name
+
+namespace {
+
+struct Req {
+	Seq**	seqs;
+const	PwdB*	pwd;
+	int	kind;			// 0 alignS_ng(.., 1), 1 the same with seeding on, 2 HomScoreS_ng
+	SpdpProblem p;
+	std::vector<int16_t> s5, s3;
+	SeedCols c;
+	std::vector<SpdpJuxt> jx;
+	SKL*	skl = 0;
+	VTYPE	scr = 0;
+	bool	done = false;
+};
+
+std::mutex		g_m;
+std::condition_variable	g_cv;
+std::vector<Req*>	g_parked;
+bool			g_leader = false;
+SpdpContext*		g_ctx = 0;
+std::vector<int16_t>	g_ipen;			// IntronPenalty::Penalty(len), as long as the longest window so far
+std::atomic<long>	g_calls[4], g_batches, g_largest;
+int			g_max_batch = 256, g_wait_us = 300;
+
+// SPALN_GPU_DEBUG=1: a backtrace on SIGSEGV (the box has no debugger) and a line per stage
+bool g_dbg = false;
+void on_segv(int)
+{
+	void* bt[48];
+const	int n = backtrace(bt, 48);
+	backtrace_symbols_fd(bt, n, 2);
+	_exit(139);
+}
+struct DbgInit { DbgInit() { if (getenv("SPALN_GPU_DEBUG")) { g_dbg = true; signal(SIGSEGV, on_segv); fprintf(stderr, "[spaln_gpu] loaded\n"); } } } g_dbg_init;
+
+void report()
+{
+	fprintf(stderr, "[spaln_gpu] alignS_ng on the device: %ld plain, %ld seeded, %ld score-only; left to the reference: %ld; "
+		"%ld library calls, largest batch %ld\n", g_calls[0].load(), g_calls[1].load(), g_calls[2].load(), g_calls[3].load(),
+		g_batches.load(), g_largest.load());
+}
+
+int units_cb(void* user, int32_t q, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
+{
+	Req* r = ((Req**) user)[q];
+	wilip_flat(r->seqs, r->pwd, level, span, r->c.flat);
+	*flat = r->c.flat.data(); *n_flat = (int32_t) r->c.flat.size();
+	return 0;
+}
+
+SKL* to_skl(const SpdpAlignment& al, const Seq* a)
+{
+	if (!al.n_skl) return 0;
+	SKL* skl = new SKL[al.n_skl + 1];		// the caller (~Gsinfo) delete[]s it
+	memcpy(skl, al.skl, sizeof(SKL) * al.n_skl);
+	skl[al.n_skl].m = skl[al.n_skl].n = EOS;
+	if (a->inex.sens) skl->m |= A_RevCom;
+	return skl;
+}
+
+// one library call over the requests of one kind
+void run_kind(std::vector<Req*>& rq, int kind)
+{
+	if (rq.empty()) return;
+const	int n = (int) rq.size();
+	SpdpScoring sc;
+	fill_scoring(sc, rq[0]->pwd, rq[0]->seqs[1]);
+	int	longest = 0;
+	for (Req* r : rq) longest = std::max(longest, r->seqs[1]->len);
+	if ((int) g_ipen.size() < longest + 2) {
+const	    int from = (int) g_ipen.size();
+	    g_ipen.resize(longest + 2);
+	    for (int l = from; l < longest + 2; ++l) g_ipen[l] = rq[0]->pwd->IntPen->Penalty(l);
+	}
+	std::vector<SpdpProblem> probs(n);
+	for (int i = 0; i < n; ++i) {
+	    Req* r = rq[i];
+	    fill_problem(r->p, r->seqs[0], r->seqs[1], r->s5, r->s3);
+	    fill_exact_s(sc, r->p, r->seqs[1], r->pwd, r->c, false);
+	    probs[i] = r->p;
+	}
+	sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
+	std::vector<SpdpAlignment> al(n);
+	int rc = 0;
+	if (kind == 2) {
+	    std::vector<int32_t> scr(n);
+	    rc = spdp_homscore_s(g_ctx, &sc, probs.data(), n, scr.data());
+	    for (int i = 0; i < n; ++i) rq[i]->scr = scr[i];
+	} else if (kind == 0) {
+	    rc = spdp_align_s(g_ctx, &sc, probs.data(), n, al.data());
+	    if (rc > 0) rc = 0;
+	} else {
+	    SpdpSeedParams sp;
+	    fill_seed_params(sp, rq[0]->pwd, rq[0]->seqs[1]);
+	    std::vector<const SpdpJuxt*> lists(n);
+	    std::vector<int32_t> counts(n), lowest(n);
+	    for (int i = 0; i < n; ++i) {
+		Seq* b = rq[i]->seqs[1];
+		for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {		// CdsNo HSPs + the free slot behind them
+const		    JUXT& t = b->jxt[j];
+		    SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		    rq[i]->jx.push_back(q);
+		}
+		lists[i] = rq[i]->jx.empty()? 0: rq[i]->jx.data();
+		counts[i] = b->jxt? b->CdsNo: 0;
+		lowest[i] = b->wllvl;
+	    }
+	    SpdpHspSource src = {rq.data(), units_cb, 0};
+	    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), &src, al.data());
+	    if (rc > 0) rc = 0;
+	}
+	if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
+	if (kind != 2) {
+	    for (int i = 0; i < n; ++i) { rq[i]->scr = al[i].score; rq[i]->skl = to_skl(al[i], rq[i]->seqs[0]); }
+	    spdp_free_alignments(al.data(), n);
+	}
+	++g_batches;
+	if (n > g_largest) g_largest = n;
+}
+
+void submit(Req& r)
+{
+	std::unique_lock<std::mutex> lk(g_m);
+	g_parked.push_back(&r);
+	for (;;) {					// wait for my result, or for the leader's seat
+	    if (r.done) return;
+	    if (!g_leader) break;
+	    g_cv.wait(lk);
+	}
+	// no batch is being gathered: this thread gathers one (and goes on until its own request has run)
+	g_leader = true;
+	while (!r.done) {
+	    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(g_wait_us);
+	    while ((int) g_parked.size() < g_max_batch && std::chrono::steady_clock::now() < until) {
+		lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(20)); lk.lock();
+	    }
+	    std::vector<Req*> take;
+	    take.swap(g_parked);
+	    lk.unlock();
+	    for (int kind = 0; kind < 3; ++kind) {
+		std::vector<Req*> part;
+		for (Req* q : take) if (q->kind == kind) part.push_back(q);
+		run_kind(part, kind);
+	    }
+	    lk.lock();
+	    for (Req* q : take) q->done = true;
+	    g_cv.notify_all();
+	}
+	g_leader = false;
+	g_cv.notify_all();				// a parked thread takes over
+}
+
+bool device_up()
+{
+	static std::once_flag once;
+	std::call_once(once, [] {
+	    g_ctx = spdp_create(0);
+	    if (!g_ctx) fatal("spaln_gpu: no HIP device (there is no CPU path in the library)\n");
+	    if (const char* e = getenv("SPALN_GPU_BATCH")) g_max_batch = std::max(1, atoi(e));
+	    if (const char* e = getenv("SPALN_GPU_WAIT_US")) g_wait_us = std::max(0, atoi(e));
+	    atexit(report);
+	});
+	return g_ctx != 0;
+}
+
+VTYPE homscore(Seq* seqs[], const PwdB* pwd)
+{
+	Req r; r.seqs = seqs; r.pwd = pwd; r.kind = 2;
+	submit(r);
+	++g_calls[2];
+	return r.scr;
+}
+
+}	// namespace
+
+SKL* alignS_ng(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori)
+{
+	if (g_dbg) fprintf(stderr, "[spaln_gpu] alignS_ng ori %d qck %d\n", ori, (int) algmode.qck);
+	device_up();
+	if (g_dbg) fprintf(stderr, "[spaln_gpu] device up\n");
+	if (ori == 2 || (ori == 3 && algmode.qck)) { ++g_calls[3]; return alignS_ng_ref(seqs, pwd, gsi, ori); }
+	if (ori == 3) {				// infer_orientation (src/fwd2s1.cc:2716-2728), the two scores from the device
+	    Seq*& a = seqs[0];
+const	    VTYPE scr1 = homscore(seqs, pwd);
+	    a->comrev();
+	    antiseq(seqs + 1);
+const	    VTYPE scr2 = homscore(seqs, pwd);
+	    if (!(scr2 > scr1)) { a->comrev(); antiseq(seqs + 1); }
+	}
+	Req r; r.seqs = seqs; r.pwd = pwd; r.kind = algmode.qck? 1: 0;
+	submit(r);
+	++g_calls[r.kind];
+	gsi->scr = r.scr;
+	return r.skl;
+}

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""The drop-in under the reference's own calling pattern.  On an MI355X box:
+
+    python tools/dropin_demo.py [--queries 2000] [--genes 200] [--threads 16] [--gpu-threads 64] [--modes Q7,Q4]
+
+A synthetic genome (planted multi-exon genes between random spacers) is formatted by the compiled reference's own
+`spaln -W -KD`; cDNA queries (full transcripts of the planted genes, 2 % substitutions, 0.2 % indels) are mapped and
+aligned twice:
+
+  * oracle/_ref/spaln      -Q<n> -S1 -O4 -t<threads>      -dgnm q.fa   the reference, CPU
+  * oracle/_ref/spaln_gpu  -Q<n> -S1 -O4 -t<gpu-threads>  -dgnm q.fa   the SAME program with alignS_ng switched to
+                                                                       libspdp_hip.so (oracle/ref_build/spaln_gpu_shim.cc)
+
+and the two outputs are compared (records sorted: the order worker threads print in is theirs).  One JSON line with the
+md5s, wall times and what the shim counted goes to stdout.  TEST INFRASTRUCTURE: uses oracle/_ref (the prebuilt files)."""
+import argparse
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spaln_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def records(text):
+    """-O4 output as a sorted list of per-query blocks (the exon rows of a query, closed by its '@' line)"""
+    blocks, cur = [], []
+    for line in text.splitlines():
+        if line.startswith("#"):                       # the column header, printed once by whichever thread is first
+            continue
+        cur.append(line)
+        if line.startswith("@"):
+            blocks.append("\n".join(cur)); cur = []
+    if cur:
+        blocks.append("\n".join(cur))
+    return sorted(blocks)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=2000)
+    ap.add_argument("--genes", type=int, default=200)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--gpu-threads", type=int, default=64)
+    ap.add_argument("--modes", default="Q7,Q4")
+    ap.add_argument("--strand", default="-S1")
+    args = ap.parse_args()
+    rng = np.random.default_rng(synth.SEED + 8800)
+    genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
+    n_chr = 4
+    per = args.genes // n_chr
+    out = {"queries": args.queries, "genes": args.genes, "runs": []}
+    with tempfile.TemporaryDirectory(prefix="spdp_dropin_") as td:
+        tot = 0
+        with open(os.path.join(td, "gnm.mfa"), "w") as f:
+            for c in range(n_chr):
+                parts = []
+                for g in genes[c * per:(c + 1) * per]:
+                    parts += [synth.random_dna(rng, int(rng.integers(3000, 20000))), g.window]
+                s = bytes(np.concatenate(parts)).decode()
+                tot += len(s)
+                f.write(f">chr{c + 1}\n")
+                f.writelines(s[i:i + 60] + "\n" for i in range(0, len(s), 60))
+        with open(os.path.join(td, "q.fa"), "w") as f:
+            for i in range(args.queries):
+                g = genes[int(rng.integers(0, per * n_chr))]
+                q = synth.mutate(rng, g.query, 0.02, 0.002)
+                f.write(f">q{i}\n{bytes(q).decode()}\n")
+        out["genome_nt"] = tot
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
+        env.update(ALN_TAB=os.path.join(REF, "table"), ALN_DBS=td)
+        subprocess.run([os.path.join(REF, "spaln"), "-W", "-KD", f"-t{args.threads}", "gnm.mfa"], cwd=td, env=env, check=True,
+                       capture_output=True)
+        for mode in args.modes.split(","):
+            run = {"mode": "-" + mode}
+            res = {}
+            for name, exe, thr in (("reference", "spaln", args.threads), ("gpu", "spaln_gpu", args.gpu_threads)):
+                cmd = [os.path.join(REF, exe), "-" + mode, args.strand, "-O4", f"-t{thr}", "-dgnm", "q.fa"]
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, cwd=td, env=env, capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    run[name] = {"error": r.stderr[-400:], "rc": r.returncode, "stdout_tail": r.stdout[-200:]}
+                    continue
+                rec = records(r.stdout)
+                res[name] = rec
+                run[name] = {"wall_s": round(dt, 3), "threads": thr, "aligned": sum(1 for b in rec if "\n@" in "\n" + b),
+                             "md5_sorted_records": hashlib.md5("\n".join(rec).encode()).hexdigest(),
+                             "md5_raw": hashlib.md5(r.stdout.encode()).hexdigest()}
+                m = re.search(r"\[spaln_gpu\][^\n]*", r.stderr)
+                if m:
+                    run[name]["shim"] = m.group(0)
+            if "reference" in res and "gpu" in res:
+                a, b = res["reference"], res["gpu"]
+                run["identical"] = a == b
+                run["records_differing"] = len(set(a) ^ set(b)) // 2 if a != b else 0
+                if a != b:
+                    d = sorted(set(a) - set(b))[:1] + sorted(set(b) - set(a))[:1]
+                    run["first_difference"] = [x[:600] for x in d]
+                run["gpu_over_reference_wall"] = round(run["reference"]["wall_s"] / run["gpu"]["wall_s"], 3)
+            out["runs"].append(run)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

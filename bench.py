@@ -648,7 +648,7 @@ LEGS = {
               "C3 shape under -A0 (forwardH_ng / hirschbergH_ng)"),
     "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "4000", "--steps", "2", "--warmup", "1"],
               "C3 shape under -A1 (forwardH1 / hirschbergH1)"),
-    "dropin": (["tools/dropin_demo.py", "--queries", "600", "--genes", "120", "--modes", "Q4,Q7", "--gpu-threads", "256"],
+    "dropin": (["tools/dropin_demo.py", "--queries", "600", "--genes", "120", "--modes", "Q4,Q7", "--gpu-threads", "1000"],
                "the reference's own CLI (src/spaln.cc, -t workers, block search, output writers) with alignS_ng switched to the library "
                "(oracle/_ref/spaln_gpu) against the unmodified build on a synthetic genome its own `spaln -W` formatted: -O4 records "
                "compared, wall times of both; default engines (-A0)"),

@@ -738,6 +738,11 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     for (int scale = 1; !todo.empty(); scale *= 8) {
         if (scale > 32768) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
         std::vector<int> again;
+        // launches of about equal size (a last small one runs at a fraction of the rate of a full one)
+        size_t total = 0;
+        for (int i : todo) { DevProblemH d; fill_desc(st, items[i], d); total += (size_t) vmf_budget_h(d, scale) * sizeof(int3); }
+        const size_t n_launch = std::max<size_t>(1, (total + limit - 1) / limit);
+        const size_t even = std::min(limit, total / n_launch + total / n_launch / 16 + 1);
         for (size_t lo = 0; lo < todo.size(); ) {
             size_t hi = lo, sum = 0;
             std::vector<HItem> part;
@@ -745,7 +750,7 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
                 DevProblemH d;
                 fill_desc(st, items[todo[hi]], d);
                 const size_t bytes = (size_t) vmf_budget_h(d, scale) * sizeof(int3);
-                if (hi > lo && sum + bytes > limit) break;
+                if (hi > lo && sum + bytes > even) break;
                 sum += bytes; part.push_back(items[todo[hi++]]);
             }
             HFwdOut po;

@@ -132,3 +132,33 @@ def test_a1_ladder_against_oracle(eng):
                 bad.append((vmf, i, (p.a_left, p.a_right, p.b_left, p.b_right), flag, score, ws,
                             skl.ravel().tolist()[:12], (wskl or [])[:12]))
         assert n_ok >= 7 and not bad, bad[:3]
+
+
+def test_pipelined_stripes_equal_one_group(eng, monkeypatch):
+    """spdh_exact with the stripes of a problem as a pipeline of waves (the default; 1, 2 or 4 problems per wave) against the
+    same kernel with one 16-lane group per problem (SPDP_HX_PIPE=0, the form that carries the reference's stale link planes
+    from stripe to stripe): records, scores, cpos rows and ranges of random sub-ranges, the ones without a path included
+    (those meet a poisoned link in the pipelined form and are run again)"""
+    fx = spdg.load([f for f in H_FILES if f.endswith("h1_400aa.spdg")][0])
+    sc = spdg.scoring_h(fx, scalar_engines=2)
+    rng = np.random.default_rng(synth.SEED + 98)
+    ps = _subranges(fx, rng, 96, 20, 330)
+
+    def run():
+        fwd = [(s, k.ravel().tolist()) for s, k in eng.scalar_forward_h(sc, ps)]
+        udh = {}
+        for n_im in (1, 2):
+            sub = abi.ProblemSetH()
+            sub.items = [p for p in ps.items if p.a_right - p.a_left >= 64]
+            s, c, r, f = eng.scalar_udh_h(sc, sub, n_im, 40)
+            udh[n_im] = (s.tolist(), c.tolist(), r.tolist())
+        return fwd, udh
+
+    monkeypatch.setenv("SPDP_HX_PIPE", "0")
+    want = run()
+    monkeypatch.delenv("SPDP_HX_PIPE")
+    for groups in ("1", "2", "4"):
+        monkeypatch.setenv("SPDP_HX_GROUPS", groups)
+        got = run()
+        assert got[0] == want[0], groups
+        assert got[1] == want[1], groups

@@ -81,6 +81,16 @@ __device__ __forceinline__ void load_tables(Tables& T, const HScalarArgs& A, con
 // a DP state: value, direction, riders (MODE 1: a = Vmf record; MODE 2: a = upr, b = lwr, c = ml, e = ulk)
 struct St { int v, d, a, b, c, e; };
 template <int MODE> struct Shape { static constexpr int NF = MODE == 0 ? 2 : (MODE == 1 ? 3 : 6); };
+// picks one of two / three state records FIELD BY FIELD: `c ? a : b` on the records themselves is an lvalue -- a pointer is
+// selected and the record copied from memory, which parks every record it may name in scratch memory (round 4: h, ea
+// and f lived there and every access of the step waited for a round trip, 65 % of the wave cycles in SQ_WAIT_ANY)
+__device__ __forceinline__ St st_sel(bool c, const St& a, const St& b)
+{
+    St r;
+    r.v = c ? a.v : b.v; r.d = c ? a.d : b.d; r.a = c ? a.a : b.a; r.b = c ? a.b : b.b; r.c = c ? a.c : b.c; r.e = c ? a.e : b.e;
+    return r;
+}
+__device__ __forceinline__ St st_sel3(int k, const St& s0, const St& s1, const St& s2) { return st_sel(k == 0, s0, st_sel(k == 1, s1, s2)); }
 __device__ __forceinline__ int& fld(St& s, int i) { return i == 0 ? s.v : i == 1 ? s.d : i == 2 ? s.a : i == 3 ? s.b : i == 4 ? s.c : s.e; }
 
 // donor candidates of one codon phase, best first
@@ -615,21 +625,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int ph = 0; ph < 3; ++ph)
                                 if (phs + 1 == ph) { cj = pick(sel[k], cl[ph].j); ca = pick(sel[k], cl[ph].a);
                                                      if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
-                            St& to = k == 0 ? h : (k == 1 ? ea : f);
+                            St to = st_sel3(k, h, ea, f);
                             const int p1 = vadd(w, m, cj + phs, ca);
                             const int p2 = vadd(w, m, n, p1);
                             if (w) {
                                 to.d = (k == 0 ? T_DIAG : (k == 1 ? T_HORI : T_VERT)) | T_SPIN;
                                 if (FWD) to.a = p2;
                                 if (UDH) { to.a = max(ca, r); to.b = min(cb, r); to.c = cc; to.e = ce; lnk[k] = ce; }
+                                if (k == 0) h = to; else if (k == 1) ea = to; else f = to;
                                 if (UDH ? (to.v >= val_of(mxk)) : (to.v > val_of(mxk))) { mxk = k; maxk = k; }
                             }
                         }
                         if (UDH && is_imd && t && maxk < 3) {
                             gst<PIPE>(IM(iq, HLNK, 0, r), lnk[maxk]);
                             rl_set(r);
-                            St& mxs = maxk == 0 ? h : (maxk == 1 ? ea : f);
-                            mxs.e = r;
+                            if (maxk == 0) h.e = r; else if (maxk == 1) ea.e = r; else f.e = r;
                             spj3 = true;
                             if (maxk == 0) {
                                 if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), lnk[1]); }
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
 
                 // ---- the cell takes the best state
                 const int y = h.v;
-                St mxs = mxk == 0 ? h : (mxk == 1 ? ea : f);
+                St mxs = st_sel3(mxk, h, ea, f);
                 if (FWD || MODE == 0) {
                     bool opened = false;
                     if (mxk != 0) h = mxs;
@@ -691,7 +701,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             const bool cross = phs == 1 && k == 0;          // the intron cuts the codon of the cell above-left
-                            const St& src = cross ? hq : (k == 0 ? h : (k == 1 ? ea : f));
+                            const St own = st_sel3(k, h, ea, f);
+                            const St src = st_sel(cross, hq, own);
                             bool tk = t && k >= ((hd == 0 || phs == 1) ? 0 : 1) && src.d && !(src.d & T_SPIN);    // (no orphan exon)
                             if (tk && !cross && k != hd && hd >= 0) {
                                 int z = mxs.v;

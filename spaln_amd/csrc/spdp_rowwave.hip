@@ -572,6 +572,16 @@ struct LdsU {
     int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
 };
 struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
+// one of three state records, FIELD BY FIELD: `c ? a : b` on the records themselves is an lvalue -- a pointer is selected and
+// the record copied from memory, which parks H, E and F in scratch memory for the whole sweep (round 4)
+__device__ __forceinline__ St st_sel3(int k, const St& h, const St& e, const St& f)
+{
+    St r;
+    r.v = k == K_H ? h.v : (k == K_E ? e.v : f.v); r.u = k == K_H ? h.u : (k == K_E ? e.u : f.u);
+    r.l = k == K_H ? h.l : (k == K_E ? e.l : f.l); r.m = k == K_H ? h.m : (k == K_E ? e.m : f.m);
+    r.k = k == K_H ? h.k : (k == K_E ? e.k : f.k);
+    return r;
+}
 }   // namespace
 
 // PIPE as above.  `rlst` is the one value that would tie a tile to the END of the intermediate row above it; it is only
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                 }
                 // ---- the cell takes the best state
                 const int hd = mxk;
-                const St MX = mxk == K_H ? H : (mxk == K_E ? E : F);         // *mx
+                const St MX = st_sel3(mxk, H, E, F);                         // *mx
                 if (hd == K_H) {
                     if (LocalR && on && H.v > best.v) { best = H; best_mr = m; best_nr = n; }
                 } else {
@@ -824,7 +834,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                     const int mx_now = hd == K_H ? H.v : MX.v;      // *mx: E / F keep their own value when they won
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const St src = k == K_H ? H : (k == K_E ? E : F);
+                        const St src = st_sel3(k, H, E, F);
                         bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
                         if (t && k != hd) {
                             int z = mx_now;

@@ -65,9 +65,19 @@ struct Tables {
     uint8_t mid[32];
     uint8_t tron_of[64];
     IpenRuns runs;                                      // IntPen beyond the table above (spdp_ipen_runs.h)
+    int gain[3];                                        // max IntPen, max junction-pair score, max |mtx|: what an acceptor can add at most
 };
 __device__ __forceinline__ void load_tables(Tables& T, const HScalarArgs& A, const DevScoringH* sc)
 {
+    if (threadIdx.x < 3) T.gain[threadIdx.x] = threadIdx.x == 2 ? 0 : INT32_MIN;
+    __syncthreads();
+    {
+        int pm = INT32_MIN, tm = INT32_MIN, mm = 0;
+        for (int i = threadIdx.x; i < A.intpen_len; i += blockDim.x) pm = max(pm, (int) A.intpen[i]);
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) tm = max(tm, (int) A.t53[i]);
+        for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) mm = max(mm, abs(sc->mtx[i]));
+        atomicMax(&T.gain[0], pm); atomicMax(&T.gain[1], tm); atomicMax(&T.gain[2], mm);
+    }
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = sc->mtx[i];
     for (int i = threadIdx.x; i < IPEN_LDS; i += blockDim.x) T.ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
@@ -589,20 +599,32 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             }
                         }
                         int sel[3] = {-1, -1, -1};
+                        // the list of my column's phase, picked once (round 4: the candidate loop used to be written out three
+                        // times, once per phase, and a wave ran all three whenever its lanes sat on columns of different
+                        // phases -- the acceptor was 48 % of the step's cycles)
+                        const int phi = phs + 1;
+                        int tv[NC], tj[NC], tx[NC];
 #pragma unroll
-                        for (int ph = 0; ph < 3; ++ph) {
-                            const bool tt = t && phs + 1 == ph;
-                            if (!__ballot(tt)) continue;
-                            const Cands<MODE>& C = cl[ph];
+                        for (int l = 0; l < NC; ++l) {
+                            tv[l] = phi == 0 ? cl[0].v[l] : (phi == 1 ? cl[1].v[l] : cl[2].v[l]);
+                            tj[l] = phi == 0 ? cl[0].j[l] : (phi == 1 ? cl[1].j[l] : cl[2].j[l]);
+                            tx[l] = phi == 0 ? cl[0].x[l] : (phi == 1 ? cl[1].x[l] : cl[2].x[l]);
+                        }
+                        const int tn = phi == 0 ? cl[0].n : (phi == 1 ? cl[1].n : cl[2].n);
+                        const int cipv = phs < 0 ? cipm : (phs == 0 ? cip0 : cipp);
+                        // screen: the best candidate of the list, priced as high as anything can be, against the lowest of the
+                        // three states it may raise (every update below is behind `x > state`)
+                        const bool tq = t && tn >= 0 && tv[0] + cipv + s3 + T.gain[0] + T.gain[1] + T.gain[2] + abs(fix) > min(h.v, min(ea.v, f.v));
+                        if (__ballot(tq)) {
 #pragma unroll
                             for (int l = 0; l < NC; ++l) {
-                                if (!(tt && l <= C.n)) continue;
-                                const int cd = C.x[l] & 3;
+                                if (!(tq && l <= tn)) continue;
+                                const int cd = tx[l] & 3;
                                 if (phs == 1 && cd == 2) continue;
-                                if (nb - C.j[l] < minl) continue;
-                                int x = C.v[l] + (phs < 0 ? cipm : (phs == 0 ? cip0 : cipp)) + intpen_of(nb - C.j[l]) + s3 + T.t53[16 * ((C.x[l] >> 2) & 15) + dn3];
+                                if (nb - tj[l] < minl) continue;
+                                int x = tv[l] + cipv + intpen_of(nb - tj[l]) + s3 + T.t53[16 * ((tx[l] >> 2) & 15) + dn3];
                                 if (cd == 0 && phs) {
-                                    const int w0 = (C.x[l] >> 6) & 7, w1 = (C.x[l] >> 9) & 7;
+                                    const int w0 = (tx[l] >> 6) & 7, w1 = (tx[l] >> 9) & 7;
                                     // a codon is defined when its own three bases are (spj_amb_tron_tab / spj_tron_amb_tab:
                                     // an ambiguous first or last base of the four leaves the other codon standing)
                                     if (phs == 1) x += prof0[(w0 < 4 && w1 < 4 && w2 < 4) ? T.tron_of[16 * w0 + 4 * w1 + w2] : AMB];
@@ -620,11 +642,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int k = 0; k < 3; ++k) {
                             const bool w = sel[k] >= 0;
                             if (!__ballot(w)) continue;
-                            int cj = 0, ca = 0, cb = 0, cc = 0, ce = 0;
+                            int cj = pick(sel[k], tj), ca = 0, cb = 0, cc = 0, ce = 0;
 #pragma unroll
                             for (int ph = 0; ph < 3; ++ph)
-                                if (phs + 1 == ph) { cj = pick(sel[k], cl[ph].j); ca = pick(sel[k], cl[ph].a);
-                                                     if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
+                                if (phi == ph) { ca = pick(sel[k], cl[ph].a);
+                                                 if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
                             St to = st_sel3(k, h, ea, f);
                             const int p1 = vadd(w, m, cj + phs, ca);
                             const int p2 = vadd(w, m, n, p1);

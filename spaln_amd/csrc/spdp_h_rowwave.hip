@@ -33,7 +33,8 @@ constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
 constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
 constexpr int RING = 512;                               // diagonals resident in LDS
 constexpr int CRING = 128;                              // columns resident in LDS
-constexpr int CHUNK = 32;                               // steps between two refills of the window
+constexpr int CHUNK = 16;                               // steps between two refills of the window (32 until round 4: a tile that has caught up
+                                                        // with the one above waits for its next publish, half a chunk on average)
 constexpr int NC = 5;                                   // NCAND + 1 slots per candidate list
 constexpr int WPB = 4;                                  // waves (= problems) per block
 constexpr int IPEN_LDS = 4096;
@@ -730,6 +731,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 int z = mxs.v;
                                 if (hd == 0 || ((k - hd) & 1)) z += (k == 2) ? gop : 0;
                                 if (src.v <= z) tk = false;         // cannot become the better path
+                            }
+                            {   // a full list whose last kept entry beats the newcomer: the free slot stays below it and the list is
+                                // NC - 1 long afterwards (what Cands::insert does with it, without the insertion code)
+                                const int phi = phs + 1;
+                                const int ln = phi == 0 ? cl[0].n : (phi == 1 ? cl[1].n : cl[2].n);
+                                const int vl = phi == 0 ? cl[0].v[NC - 2] : (phi == 1 ? cl[1].v[NC - 2] : cl[2].v[NC - 2]);
+                                const bool weak = tk && ln >= NC - 2 && vl > src.v + sigJ;
+                                if (weak) { if (phi == 0) cl[0].n = NC - 2; else if (phi == 1) cl[1].n = NC - 2; else cl[2].n = NC - 2; }
+                                tk = tk && !weak;
                             }
                             if (!__ballot(tk)) continue;
 #pragma unroll

@@ -42,9 +42,18 @@ struct Tables {
     short ipen[IPEN_LDS];
     short t53[256];
     IpenRuns runs;                                      // IntPen beyond the table above (spdp_ipen_runs.h)
+    int gain[2];                                        // max IntPen, max junction-pair score: what an acceptor can add at most
 };
 __device__ __forceinline__ void load_tables(Tables& T, const ScalarArgs& A, const DevScoring* sc)
 {
+    if (threadIdx.x < 2) T.gain[threadIdx.x] = INT32_MIN;
+    __syncthreads();
+    {
+        int pm = INT32_MIN, tm = INT32_MIN;
+        for (int i = threadIdx.x; i < A.intpen_len; i += blockDim.x) pm = max(pm, (int) A.intpen[i]);
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) tm = max(tm, (int) A.t53[i]);
+        atomicMax(&T.gain[0], pm); atomicMax(&T.gain[1], tm);
+    }
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) T.mtx[i] = (short) sc->mtx[i];
     for (int i = threadIdx.x; i < IPEN_LDS; i += blockDim.x) T.ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) T.t53[i] = A.t53[i];
@@ -312,7 +321,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E;
             }
             // ---- acceptor: every candidate of my row may raise the state it left from
-            const bool acc = on && internal && (ax & 2);
+            // (screen: the best candidate, priced as high as anything can be, against the lowest of the three states it may
+            //  raise -- every update below is behind `x > state`, `>=` in the forward engine)
+            const bool acc = on && internal && (ax & 2) && ncand >= 0 &&
+                             cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >= min(hv, min(e1v, fv));
             if (__ballot(acc)) {
                 int sel_h = -1, sel_e = -1, sel_f = -1;
                 const int s3 = col.x >> 16, dn3 = adn & 15;
@@ -391,6 +403,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                         int z = mx_now;
                         if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;      // GOP[k / 2]
                         if (sv <= z) t = false;                     // cannot become the better path
+                    }
+                    {   // a full list whose last kept entry holds against the newcomer: the list is NC - 1 long afterwards
+                        const int x = sv + sigJ;
+                        const bool weak = t && ncand >= NC - 2 && !(FWD ? (x > cv[NC - 2]) : (x >= cv[NC - 2]));
+                        if (weak) ncand = NC - 2;
+                        t = t && !weak;
                     }
                     if (__ballot(t)) {
                         const int x = sv + sigJ;
@@ -773,7 +791,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                 auto val_of = [&](int k) { return k == K_H ? H.v : (k == K_E ? E.v : F.v); };
                 // ---- acceptor
                 bool spj3 = false;
-                const bool acc = on && (ax & 2);
+                const bool acc = on && (ax & 2) && ncand >= 0 &&
+                                 cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) > min(H.v, min(E.v, F.v));     // (screen, as above)
                 if (__ballot(acc)) {
                     int sel_h = -1, sel_e = -1, sel_f = -1;
                     const int s3 = col.x >> 16, dn3 = adn & 15;
@@ -840,6 +859,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                             int z = mx_now;
                             if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;
                             if (src.v <= z) t = false;
+                        }
+                        {
+                            const bool weak = t && ncand >= NC - 2 && !(src.v + sigJ > cv[NC - 2]);
+                            if (weak) ncand = NC - 2;
+                            t = t && !weak;
                         }
                         if (__ballot(t)) {
                             const int x = src.v + sigJ;

@@ -83,6 +83,15 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
     for (int i = threadIdx.x; i < 4096; i += 64 * XWPB) s_ipen[i] = A.intpen[min(i, A.intpen_len - 1)];
     ipen_runs_load(s_runs, A.ipen_runs);
     for (int i = threadIdx.x; i < 256; i += 64 * XWPB) s_t53[i] = A.t53[i];
+    __shared__ int s_gain[2];                   // max IntPen, max junction-pair score: what an acceptor can add at most
+    if (threadIdx.x < 2) s_gain[threadIdx.x] = INT32_MIN;
+    __syncthreads();
+    {
+        int pm = INT32_MIN, tm = INT32_MIN;
+        for (int i = threadIdx.x; i < A.intpen_len; i += 64 * XWPB) pm = max(pm, (int) A.intpen[i]);
+        for (int i = threadIdx.x; i < 256; i += 64 * XWPB) tm = max(tm, (int) A.t53[i]);
+        atomicMax(&s_gain[0], pm); atomicMax(&s_gain[1], tm);
+    }
     __syncthreads();                            // (before any group leaves)
     const int k = threadIdx.x & 15;
     const int grp = (threadIdx.x & 63) >> 4;     // my 16-lane group in the wave
@@ -409,7 +418,9 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             const int rj = nj - m;
             if (queued && rj >= lw && rj < up) {
                 const unsigned fl = axj & 0xffu;
-                if (fl & 2) {                                 // acceptor: Sjsites::get
+                // acceptor: Sjsites::get -- unless the best candidate, priced as high as anything can be, cannot beat the lowest of
+                // the three states it may raise (every update below is behind `x > state`)
+                if ((fl & 2) && ncand >= 0 && c_val[0] + sigJ_cip + s_gain[0] + s_gain[1] + (col.x >> 16) > min(H, min(E, F))) {
                     const int s3 = col.x >> 16;
                     const int d3 = (axj >> 8) & 15;
                     // udh: maxprd[d], brd -- the best candidate per state and overall: its value and link (and state)
@@ -473,6 +484,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                         if (kk && from <= H + gop) continue;
                         const int x = from + sigJ;
                         if (x <= XNEV) continue;
+                        if (ncand >= 3 && c_val[3] > x) { ncand = 3; continue; }      // a full list whose fourth entry beats x: it only gets shorter
                         // the free slot starts below the list and moves up past every entry x ties or beats
                         int pos = ncand < 4 ? ncand + 1 : 4;
                         if (ncand < 4) ++ncand;

@@ -524,7 +524,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             if (flav == 7) {
                 // (+ what the lanes may leave unused of the chunks of numbers they reserve, per stripe when pipelined)
                 const int64_t cap = vmf_capacity(it)
-                                    + (int64_t) SPDP_VMF_LANE_CHUNK * SPDP_NELEM * ((it.a_right - it.a_left) / SPDP_NELEM + 2);
+                                    + (int64_t) 2 * SPDP_VMF_LANE_CHUNK * SPDP_NELEM * ((it.a_right - it.a_left) / SPDP_NELEM + 2);
                 P.imd_off = cap;
                 tb_tot += cap;
             }

@@ -137,11 +137,18 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
     const int vcap = (int) P.imd_off;
     // every lane takes its record numbers XVCH at a time from the problem's counter (an atomic per record made the
     // forward sweep wait for memory at every diagonal run it started)
-    int v_next = 0, v_left = 0;
+    // (the next chunk is asked for while half of the current one is still there: the counter's round trip runs under the steps
+    //  in between)
+    int v_next = 0, v_left = 0, v_pend = 0;
+    bool v_asked = false;
     auto vadd = [&](int mm, int nn, int pp) -> int {
-        if (v_left == 0) { v_next = atomicAdd(vcount, XVCH); v_left = XVCH; }
+        if (v_left == 0) {
+            if (!v_asked) v_pend = atomicAdd(vcount, XVCH);
+            v_next = v_pend; v_left = XVCH; v_asked = false;
+        }
         const int i = v_next++;
         --v_left;
+        if (v_left == XVCH / 2 && !v_asked) { v_pend = atomicAdd(vcount, XVCH); v_asked = true; }
         if (i < vcap) {
             if (PIPE) { x_st<true>(vraw + 3 * i, mm); x_st<true>(vraw + 3 * i + 1, nn); x_st<true>(vraw + 3 * i + 2, pp); }
             else vrec[i] = make_int3(mm, nn, pp);

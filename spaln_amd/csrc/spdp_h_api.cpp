@@ -628,7 +628,8 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
         // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
         // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
         // (+ what the waves of a pipelined problem may leave unused of the chunks of numbers they reserve)
-        const int64_t cap = forward ? vmf_budget_h(d, scale) + (int64_t) SPDP_VMF_CHUNK * ((d.a_right - d.a_left) / 64 + 2) : 0;
+        // (-A1: every lane of a stripe may leave up to two chunks of 16 numbers unused: 32 per row)
+        const int64_t cap = forward ? vmf_budget_h(d, scale) + (int64_t) (exact ? 4 : 1) * SPDP_VMF_CHUNK * ((d.a_right - d.a_left) / 64 + 2) : 0;
         if (cap >= (int64_t) 1 << 31) { ctx->err = "scalar engine: problem too large for its record store"; return -1; }
         d.imd_off = cap;
         vmf_rec += cap;

@@ -51,7 +51,7 @@
 #define X_EOU (0x7fffffff - 2)                   // end_of_ulk
 #define HXWPB 4                                  // waves per block
 #define HXRING 128                               // column records per group in LDS
-#define HXVCH 8                                  // Vmf record numbers a lane reserves at a time
+#define HXVCH 16                                 // Vmf record numbers a lane reserves at a time (the next chunk is asked for at half)
 #define HXINH 0x7ffffff0                         // SPDP_RLST_INHERITED (spdp_internal.h) + frame: "rlst as the rows above left it"
 #define HXPROG0 (1 << 28)
 #define HXPOISON 0x7fffff00                      // pipelined form: a link word the reference would have inherited from the previous stripe
@@ -147,11 +147,19 @@ __global__ void __launch_bounds__(64 * HXWPB) __attribute__((amdgpu_waves_per_eu
     int3* vrec = A.vmf + (UDH ? 0 : P.tb_off);
     int* vraw = reinterpret_cast<int*>(vrec);
     const int vcap = UDH ? 0 : (int) P.imd_off;
-    int v_next = 0, v_left = 0;
+    // a lane's next chunk of numbers is asked for while half of the current one is still there: the counter's round trip
+    // (memory side, a microsecond) runs under the steps in between instead of stopping the wave at every eighth record of
+    // every lane
+    int v_next = 0, v_left = 0, v_pend = 0;
+    bool v_asked = false;
     auto vadd = [&](int mm, int nn, int pp) -> int {
-        if (v_left == 0) { v_next = __hip_atomic_fetch_add(vcount, HXVCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v_left = HXVCH; }
+        if (v_left == 0) {
+            if (!v_asked) v_pend = __hip_atomic_fetch_add(vcount, HXVCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v_next = v_pend; v_left = HXVCH; v_asked = false;
+        }
         const int i = v_next++;
         --v_left;
+        if (v_left == HXVCH / 2 && !v_asked) { v_pend = __hip_atomic_fetch_add(vcount, HXVCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v_asked = true; }
         if (i < vcap) { xh_st<PIPE>(vraw + 3 * i, mm); xh_st<PIPE>(vraw + 3 * i + 1, nn); xh_st<PIPE>(vraw + 3 * i + 2, pp); }
         return i;
     };

@@ -3,8 +3,9 @@
 // runs wherever a GPU is).
 //
 // What is linked: src/spaln.cc and every library object of the reference exactly as in oracle/_ref/spaln, except that
-// src/fwd2s1.cc is compiled once more with -DalignS_ng=alignS_ng_ref (the reference's function under another name,
-// nothing copied); this file supplies alignS_ng (src/aln.h:351, src/fwd2s1.cc:2746).  So spalign2 (src/spaln.cc:666-697),
+// src/fwd2s1.cc and src/fwd2h1.cc are compiled once more with -DalignS_ng=alignS_ng_ref / -DalignH_ng=alignH_ng_ref (the
+// reference's functions under other names, nothing copied); this file supplies alignS_ng and alignH_ng (src/aln.h:351-356,
+// src/fwd2s1.cc:2746, src/fwd2h1.cc:3310).  So spalign2 (src/spaln.cc:666-697),
 // called by the `-t N` worker threads of match_2 / blkaln, lands here; everything around it -- block search, Exinon,
 // skl_rngS_ng, the output writers -- is the reference's.
 //
@@ -25,14 +26,18 @@
 #include <unistd.h>
 
 SKL* alignS_ng_ref(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori);	// src/fwd2s1.cc, compiled under this name
+SKL* alignH_ng_ref(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi);		// src/fwd2h1.cc, likewise
 
 namespace {
 
 struct Req {
 	Seq**	seqs;
 const	PwdB*	pwd;
-	int	kind;			// 0 alignS_ng(.., 1), 1 the same with seeding on, 2 HomScoreS_ng
+	int	kind;			// 0 alignS_ng(.., 1), 1 the same with seeding on, 2 HomScoreS_ng, 3 alignH_ng, 4 alignH_ng with seeding on
 	SpdpProblem p;
+	SpdpProblemH ph;
+	HCols hc;
+	bool	undefined = false;	// protein: a DP call the reference itself leaves undefined (the caller falls back to it)
 	std::vector<int16_t> s5, s3;
 	SeedCols c;
 	std::vector<SpdpJuxt> jx;
@@ -47,7 +52,7 @@ std::vector<Req*>	g_parked;
 bool			g_leader = false;
 SpdpContext*		g_ctx = 0;
 std::vector<int16_t>	g_ipen;			// IntronPenalty::Penalty(len), as long as the longest window so far
-std::atomic<long>	g_calls[4], g_batches, g_largest;
+std::atomic<long>	g_calls[6], g_batches, g_largest;
 int			g_max_batch = 256, g_wait_us = 300;
 
 // SPALN_GPU_DEBUG=1: a backtrace on SIGSEGV (the box has no debugger) and a line per stage
@@ -63,9 +68,9 @@ struct DbgInit { DbgInit() { if (getenv("SPALN_GPU_DEBUG")) { g_dbg = true; sign
 
 void report()
 {
-	fprintf(stderr, "[spaln_gpu] alignS_ng on the device: %ld plain, %ld seeded, %ld score-only; left to the reference: %ld; "
-		"%ld library calls, largest batch %ld\n", g_calls[0].load(), g_calls[1].load(), g_calls[2].load(), g_calls[3].load(),
-		g_batches.load(), g_largest.load());
+	fprintf(stderr, "[spaln_gpu] alignS_ng on the device: %ld plain, %ld seeded, %ld score-only; alignH_ng: %ld plain, %ld seeded; "
+		"left to the reference: %ld; %ld library calls, largest batch %ld\n", g_calls[0].load(), g_calls[1].load(), g_calls[2].load(),
+		g_calls[4].load(), g_calls[5].load(), g_calls[3].load(), g_batches.load(), g_largest.load());
 }
 
 int units_cb(void* user, int32_t q, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
@@ -86,10 +91,70 @@ SKL* to_skl(const SpdpAlignment& al, const Seq* a)
 	return skl;
 }
 
+// one library call over the protein requests of one kind (3 plain, 4 seeded)
+void run_kind_h(std::vector<Req*>& rq, int kind)
+{
+const	int n = (int) rq.size();
+	SpdpScoringH sc;
+	fill_scoring_h(sc, rq[0]->pwd, rq[0]->seqs[1]);
+	int	longest = 0;
+	for (Req* r : rq) longest = std::max(longest, r->seqs[1]->len);
+	if ((int) g_ipen.size() < longest + 2) {
+const	    int from = (int) g_ipen.size();
+	    g_ipen.resize(longest + 2);
+	    for (int l = from; l < longest + 2; ++l) g_ipen[l] = rq[0]->pwd->IntPen->Penalty(l);
+	}
+	std::vector<SpdpProblemH> probs(n);
+	for (int i = 0; i < n; ++i) {
+	    Req* r = rq[i];
+	    Seq* a = r->seqs[0]; Seq* b = r->seqs[1];
+	    fill_problem_h(r->ph, a, b, r->hc, b->left, b->right);	// the Exinon was built for the range b holds at the call (src/spaln.cc:745-752)
+	    r->ph.a_pad = *a->at(a->len);			// what exg_seq left behind the query
+	    fill_exact_h(sc, r->ph, b, r->pwd, r->c, false);
+	    probs[i] = r->ph;
+	}
+	sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
+	std::vector<SpdpAlignment> al(n);
+	int rc;
+	if (kind == 3) rc = spdp_align_h(g_ctx, &sc, probs.data(), n, al.data());
+	else {
+	    SpdpSeedParams sp;
+	    fill_seed_params(sp, rq[0]->pwd, rq[0]->seqs[1]);
+	    std::vector<const SpdpJuxt*> lists(n);
+	    std::vector<int32_t> counts(n), lowest(n);
+	    for (int i = 0; i < n; ++i) {
+		Seq* b = rq[i]->seqs[1];
+		for (int j = 0; b->jxt && j <= b->CdsNo; ++j) {
+const		    JUXT& t = b->jxt[j];
+		    SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		    rq[i]->jx.push_back(q);
+		}
+		lists[i] = rq[i]->jx.empty()? 0: rq[i]->jx.data();
+		counts[i] = b->jxt? b->CdsNo: 0;
+		lowest[i] = b->wllvl;
+	    }
+	    SpdpHspSource src = {rq.data(), units_cb, 0};
+	    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), &src, al.data());
+	}
+	if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
+	for (int i = 0; i < n; ++i) {
+	    // undefined in the reference itself (spdp_align_h's return value 1: such a query comes back without records and with
+	    // NEVSEL; n_skl < 0: its traceback would start outside its bitmap / "Unexpected dir")
+	    rq[i]->undefined = al[i].n_skl < 0 || (rc == 1 && al[i].n_skl == 0 && al[i].score == SPDP_NEVSEL);
+	    rq[i]->scr = al[i].score;
+	    rq[i]->skl = al[i].n_skl > 0? to_skl(al[i], rq[i]->seqs[0]): 0;
+	    if (rq[i]->skl) rq[i]->skl->m = 1;			// globalH_ng: skl->m = 1 (no A_RevCom on this path)
+	}
+	spdp_free_alignments(al.data(), n);
+	++g_batches;
+	if (n > g_largest) g_largest = n;
+}
+
 // one library call over the requests of one kind
 void run_kind(std::vector<Req*>& rq, int kind)
 {
 	if (rq.empty()) return;
+	if (kind >= 3) { run_kind_h(rq, kind); return; }
 const	int n = (int) rq.size();
 	SpdpScoring sc;
 	fill_scoring(sc, rq[0]->pwd, rq[0]->seqs[1]);
@@ -165,7 +230,7 @@ void submit(Req& r)
 	    std::vector<Req*> take;
 	    take.swap(g_parked);
 	    lk.unlock();
-	    for (int kind = 0; kind < 3; ++kind) {
+	    for (int kind = 0; kind < 5; ++kind) {
 		std::vector<Req*> part;
 		for (Req* q : take) if (q->kind == kind) part.push_back(q);
 		run_kind(part, kind);
@@ -218,6 +283,20 @@ const	    VTYPE scr2 = homscore(seqs, pwd);
 	Req r; r.seqs = seqs; r.pwd = pwd; r.kind = algmode.qck? 1: 0;
 	submit(r);
 	++g_calls[r.kind];
+	gsi->scr = r.scr;
+	return r.skl;
+}
+
+SKL* alignH_ng(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi)
+{
+	device_up();
+	Req r; r.seqs = (Seq**) seqs; r.pwd = pwd; r.kind = algmode.qck? 4: 3;
+	submit(r);
+	if (r.undefined) {			// the reference's own result is undefined there (it reads outside its traceback bitmap / the sequences):
+	    ++g_calls[3];			// a production shim leaves the case to the host, as INTEGRATION.md says
+	    return alignH_ng_ref(seqs, pwd, gsi);
+	}
+	++g_calls[r.kind + 1];
 	gsi->scr = r.scr;
 	return r.skl;
 }

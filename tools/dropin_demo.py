@@ -54,12 +54,16 @@ def main():
     ap.add_argument("--gpu-threads", type=int, default=64)
     ap.add_argument("--modes", default="Q7,Q4")
     ap.add_argument("--strand", default="-S1")
+    ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")
     args = ap.parse_args()
     rng = np.random.default_rng(synth.SEED + 8800)
-    genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
+    if args.protein:
+        genes = [synth.make_protein_gene(np.random.default_rng(synth.SEED + 8801 + i), n_exons=6, flank=1000) for i in range(args.genes)]
+    else:
+        genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
     n_chr = 4
     per = args.genes // n_chr
-    out = {"queries": args.queries, "genes": args.genes, "runs": []}
+    out = {"queries": args.queries, "genes": args.genes, "query_type": "protein" if args.protein else "cDNA", "runs": []}
     with tempfile.TemporaryDirectory(prefix="spdp_dropin_") as td:
         tot = 0
         with open(os.path.join(td, "gnm.mfa"), "w") as f:
@@ -74,18 +78,23 @@ def main():
         with open(os.path.join(td, "q.fa"), "w") as f:
             for i in range(args.queries):
                 g = genes[int(rng.integers(0, per * n_chr))]
-                q = synth.mutate(rng, g.query, 0.02, 0.002)
+                if args.protein:                                  # the planted protein with another 5 % of its residues replaced
+                    q = g.query.copy()
+                    hit = rng.random(q.size) < 0.05
+                    q[hit] = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=int(hit.sum()))]
+                else:
+                    q = synth.mutate(rng, g.query, 0.02, 0.002)
                 f.write(f">q{i}\n{bytes(q).decode()}\n")
         out["genome_nt"] = tot
         env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
         env.update(ALN_TAB=os.path.join(REF, "table"), ALN_DBS=td)
-        subprocess.run([os.path.join(REF, "spaln"), "-W", "-KD", f"-t{args.threads}", "gnm.mfa"], cwd=td, env=env, check=True,
+        subprocess.run([os.path.join(REF, "spaln"), "-W", "-KP" if args.protein else "-KD", f"-t{args.threads}", "gnm.mfa"], cwd=td, env=env, check=True,
                        capture_output=True)
         for mode in args.modes.split(","):
             run = {"mode": "-" + mode}
             res = {}
             for name, exe, thr in (("reference", "spaln", args.threads), ("gpu", "spaln_gpu", args.gpu_threads)):
-                cmd = [os.path.join(REF, exe), "-" + mode, args.strand, "-O4", f"-t{thr}", "-dgnm", "q.fa"]
+                cmd = [os.path.join(REF, exe), "-" + mode] + ([] if args.protein else [args.strand]) + ["-O4", f"-t{thr}", "-dgnm", "q.fa"]
                 t0 = time.perf_counter()
                 r = subprocess.run(cmd, cwd=td, env=env, capture_output=True, text=True)
                 dt = time.perf_counter() - t0

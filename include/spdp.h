@@ -72,6 +72,8 @@ typedef struct SpdpScoring {
                                         linear-space branch (one intermediate row, halves of halves)   */
     const struct SpdpSignalModel* sigmodel;   /* optional: with it, problems whose sig5 / sig3 are NULL get their
                                         signals (and cano5 / cano3 / dinc) computed on the device from b[] alone */
+    int32_t codonk1;                 /* PwdB::codonk1 (src/aln2.cc:114), read when noll == 3 only: gaps longer than this
+                                        are priced with lgop / lgep by GapPenalty / GapExtPen (src/aln.h:275-282)     */
 } SpdpScoring;
 
 /* the splice-site model behind SGPT2::sig5 / sig3 (Exinon::intron53_n, src/codepot.cc:479-520): the two

@@ -13,7 +13,7 @@ const	Simmtx* sm = pwd->simmtx;			// src/simmtx.h:35-63
 	for (int i = 0; i < sm->dim; ++i)
 	    for (int j = 0; j < sm->dim; ++j) sc.mtx[i * sm->dim + j] = sm->mtx[i][j];
 	sc.gop = pwd->BasicGOP;  sc.gep = pwd->BasicGEP;	// src/aln.h:243-244
-	sc.lgop = pwd->LongGOP;  sc.lgep = pwd->LongGEP;  sc.noll = pwd->Noll;
+	sc.lgop = pwd->LongGOP;  sc.lgep = pwd->LongGEP;  sc.noll = pwd->Noll;  sc.codonk1 = pwd->codonk1;
 	sc.spj = b->inex.intr;
 	sc.llmt = IntronPrm.llmt;			// src/codepot.h:207-214
 	sc.ipen = pwd->IntPen->Penalty();		// GapWI, src/codepot.h:241

@@ -17,12 +17,18 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <limits.h>
 #include "../include/spdp.h"
 
 #define NCAND 4
-#define NOD 3                                   /* 2 * Noll - 1 for Noll = 2: DIAG, HORI, VERT */
+#define NOD 5                                   /* 2 * Noll - 1 states at most: DIAG, HORI, VERT, HORL, VERL (src/fwd2s1.cc:223); three when Noll = 2 */
+#define E2_PSP 2
+/* PwdB::GapPenalty / GapExtPen (src/aln.h:275-282): beyond codonk1 a gap is priced with the long pair (Noll = 3 only:
+ * codonk1 is LARGEN otherwise, src/aln2.cc:114) */
+static inline int gap_penalty(const SpdpScoring* sc, int i) { if (!i) return 0; return (sc->noll == 3 && i > sc->codonk1) ? sc->lgop + i * sc->lgep : sc->gop + i * sc->gep; }
+static inline int gap_ext_pen(const SpdpScoring* sc, int i) { return (sc->noll == 3 && i > sc->codonk1) ? sc->lgep : sc->gep; }
 static const unsigned char psp_bit[5] = {4, 1, 8, 2, 16};    /* src/aln.h:56 */
 #define E1_PSP 1
 
@@ -45,17 +51,21 @@ typedef struct { int val, dir, jnc, ptr; } Cand;
 /* ---- score only ------------------------------------------------------------------------ */
 int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w, int32_t* score)
 {
-    if (sc->noll != 2 || !sc->intpen || !p->cano5) return -1;
+    if ((sc->noll != 2 && sc->noll != 3) || !sc->intpen || !p->cano5) return -1;
+    const int dagp = sc->noll == 3, Nod = dagp ? 5 : 3;
+    const int GOP[3] = {0, sc->gop, sc->lgop};          /* PwdB::GOP, src/aln2.cc:111 */
     const int NEV = SPDP_NEVSEL;
     const int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
     const int LocalL = sc->local && p->a_exgl && p->b_exgl;
     const int LocalR = sc->local && p->a_exgr && p->b_exgr;
     const int dim = sc->mtx_dim;
-    const size_t bufsiz = (size_t) 2 * w->width;
+    const size_t bufsiz = (size_t) sc->noll * w->width;
     int* wbuf = (int*) malloc(bufsiz * sizeof(int));
     for (size_t i = 0; i < bufsiz; ++i) wbuf[i] = NEV;
     int* hh0 = wbuf - w->lw + 1;
     int* hh1 = hh0 + w->width;
+    int* hh2 = hh1 + w->width;                          /* F2, Noll = 3 */
+    int blackv = NEV;
     /* sinitS_ng */
     {
         int r = bl - al, rr = br - al;
@@ -70,8 +80,8 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
             for (int i = 1; --r >= rr; ++i) {
                 --h; --f;
                 *h = h[1];
-                if (i == 1) { *h += sc->gop + sc->gep; *f = *h; }
-                else { *f = f[1]; *h += sc->gep; *f += sc->gep; }
+                if (i == 1) { *h += gap_penalty(sc, 1); *f = *h; }
+                else { *f = f[1]; *h += gap_ext_pen(sc, i); *f += sc->gep; }
             }
         }
     }
@@ -84,9 +94,9 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
         const int n9 = imin(n2, br);
         unsigned psp = 0;
         int r = n - m;
-        int *h = hh0 + r, *f = hh1 + r;
-        int e1 = NEV;
-        int* hf[NOD] = {0, &e1, 0};
+        int *h = hh0 + r, *f = hh1 + r, *f2 = dagp ? hh2 + r : &blackv;
+        int e1 = NEV, e2 = NEV;
+        int* hf[NOD] = {0, &e1, 0, &e2, 0};
         Cand rcd[NCAND + 1];
         int idx[NCAND + 1];
         for (int l = 0; l <= NCAND; ++l) { rcd[l].val = NEV; rcd[l].dir = rcd[l].jnc = rcd[l].ptr = 0; idx[l] = l; }
@@ -94,8 +104,8 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
         const int32_t* qprof = (m >= 1) ? sc->mtx + (size_t) p->a[m - 1] * dim : sc->mtx;
         for ( ; ++n <= n9; ) {
             int x;
-            ++h; ++f;
-            hf[0] = h; hf[2] = f;
+            ++h; ++f; if (dagp) ++f2;
+            hf[0] = h; hf[2] = f; hf[4] = f2;
             int* from = h;
             int* mx = h;
             if (m != al) {
@@ -103,14 +113,27 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
                 x = *++from + sc->gop;
                 *f = imax(x, f[1]) + sc->gep;
                 if (*f > *mx) mx = f;
+                if (dagp) {                                 /* :1227-1231 */
+                    x = *from + sc->lgop;
+                    *f2 = imax(x, f2[1]) + sc->lgep;
+                    if (*f2 > *mx) mx = f2;
+                }
             }
             x = h[-1] + sc->gop;
+            const unsigned prev_psp = psp;
             if (x > e1) { e1 = x; psp = psp ? E1_PSP : 0; }
             else psp &= E1_PSP;
             e1 += sc->gep;
             if (e1 > *mx) mx = &e1;
+            if (dagp) {                                     /* :1245-1254 */
+                x = h[-1] + sc->lgop;
+                if (x > e2) { e2 = x; if (prev_psp) psp |= E2_PSP; }
+                else psp |= (prev_psp & E2_PSP);
+                e2 += sc->lgep;
+                if (e2 > *mx) mx = &e2;
+            }
             if (p->cano3[n]) {
-                const Cand* maxphl[NOD] = {0, 0, 0};
+                const Cand* maxphl[NOD] = {0, 0, 0, 0, 0};
                 for (int l = 0; l <= ncand; ++l) {
                     const Cand* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
@@ -118,7 +141,7 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
                     x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     if (x > *from) { *from = x; maxphl[prd->dir] = prd; }
                 }
-                for (int k = 0; k < NOD; ++k) {
+                for (int k = 0; k < Nod; ++k) {
                     if (!maxphl[k]) continue;
                     psp |= psp_bit[k];
                     from = hf[k];
@@ -133,12 +156,12 @@ int orc_scalar_scorealone(const SpdpScoring* sc, const SpdpProblem* p, const Spd
             for ( ; mx != hf[hd]; ++hd) ;
             if (p->cano5[n]) {
                 const int sigJ = p->sig5[n];
-                for (int k = hd == 0 ? 0 : 1; k < NOD; ++k) {
+                for (int k = hd == 0 ? 0 : 1; k < Nod; ++k) {
                     from = hf[k];
                     if (psp & psp_bit[k]) continue;
                     if (k != hd) {
                         y = *mx;
-                        if (hd == 0 || (k - hd) % 2) y += (k / 2 == 1) ? sc->gop : 0;   /* GOP[k/2] */
+                        if (hd == 0 || (k - hd) % 2) y += GOP[k / 2];
                         if (*from <= y) continue;
                     }
                     x = *from + sigJ;
@@ -184,7 +207,7 @@ static int vmf_add(Vmf* v, int m, int n, int p)
 }
 typedef struct { int val, ptr; } Rvp;
 
-enum { DIAG = 2, NEWD = 3 };    /* TraceBackDir, src/aln.h:30-35: DEAD, RSRV, DIAG, NEWD, ... */
+enum { NEWD = 8 };               /* the file-local Newd of src/fwd2s1.cc:48 (a direction byte holds the state that won, 0 .. 4, or Newd) */
 
 /* returns the records trcbkalignS_ng hands to the Mfile (end -> start); caller frees *skl */
 /* cut_l < cut_r: forwardS_ng's cut range (`cutrng`, src/fwd2s1.cc:217, 423-430; initS_ng :157-161, lastS_ng :191-204):
@@ -196,7 +219,9 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
     *skl = 0; *n_skl = 0;
     const int has_cut = cut_r > cut_l || (cut_l | cut_r) != 0;
     const int cutlen = has_cut ? cut_r - cut_l : 0;
-    if (sc->noll != 2 || !sc->intpen || !p->cano5) return -1;
+    if ((sc->noll != 2 && sc->noll != 3) || !sc->intpen || !p->cano5) return -1;
+    const int dagp = sc->noll == 3, Nod = dagp ? 5 : 3;
+    const int GOP[3] = {0, sc->gop, sc->lgop};
     if (w->width < 0) { *score = SPDP_NEVSEL; return 0; }
     const int NEV = SPDP_NEVSEL;
     const int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
@@ -207,11 +232,13 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
     const int dim = sc->mtx_dim;
     const int width = w->width - cutlen;
     if (width < 3) { *score = NEV; return -1; }
-    const size_t bufsiz = (size_t) 2 * width;
+    const size_t bufsiz = (size_t) sc->noll * width;
     Rvp* jbuf = (Rvp*) malloc(bufsiz * sizeof(Rvp));
     for (size_t i = 0; i < bufsiz; ++i) { jbuf[i].val = NEV; jbuf[i].ptr = 0; }
     Rvp* hh0 = jbuf - w->lw + 1;
     Rvp* hh1 = hh0 + width;
+    Rvp* hh2 = hh1 + width;                             /* F2, Noll = 3 */
+    Rvp blackvp = {NEV, 0};
     unsigned char* dbuf = (unsigned char*) calloc(width, 1);
     unsigned char* hdir = dbuf - w->lw + 1;
     Vmf vmf = {0, 0, 0};
@@ -238,8 +265,8 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
             if (p->b_exgl) { h->val = 0; h->ptr = 0; }
             else {
                 *h = h[1];
-                if (i == 1) h->val += sc->gop + sc->gep;
-                else h->val += sc->gep;             /* GapExtPen(i) */
+                if (i == 1) h->val += gap_penalty(sc, 1);
+                else h->val += gap_ext_pen(sc, i);
             }
         }
     }
@@ -252,11 +279,11 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
         int n = imax(n1, bl);
         const int n9 = imin(n2, br);
         int r = n - m;
-        Rvp *h = hh0 + r, *f = hh1 + r;
+        Rvp *h = hh0 + r, *f = hh1 + r, *f2 = dagp ? hh2 + r : &blackvp;
         unsigned char* dir = hdir + r;
         unsigned psp = 0;
-        Rvp e1 = {NEV, 0};
-        Rvp* hf[NOD] = {0, &e1, 0};
+        Rvp e1 = {NEV, 0}, e2 = {NEV, 0};
+        Rvp* hf[NOD] = {0, &e1, 0, &e2, 0};
         Cand rcd[NCAND + 1];
         int idx[NCAND + 1];
         for (int l = 0; l <= NCAND; ++l) { rcd[l].val = NEV; rcd[l].ptr = rcd[l].dir = rcd[l].jnc = 0; idx[l] = l; }
@@ -264,8 +291,8 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
         const int32_t* qprof = (m >= 1) ? sc->mtx + (size_t) p->a[m - 1] * dim : sc->mtx;
         for ( ; ++n <= n9; ) {
             int x;
-            ++dir; ++h; ++f;
-            hf[0] = h; hf[2] = f;
+            ++dir; ++h; ++f; if (dagp) ++f2;
+            hf[0] = h; hf[2] = f; hf[4] = f2;
             Rvp* from = h;
             Rvp* mx = h;
             const int diag = h->val;
@@ -277,14 +304,29 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
                 else *f = f[1];
                 f->val += sc->gep;
                 if (f->val > mx->val) mx = f;
+                if (dagp) {                                 /* :297-305 */
+                    x = from->val + sc->lgop;
+                    if (x >= f2[1].val) { f2->val = x; f2->ptr = from->ptr; }
+                    else *f2 = f2[1];
+                    f2->val += sc->lgep;
+                    if (f2->val > mx->val) mx = f2;
+                }
             }
             x = h[-1].val + sc->gop;
+            const unsigned prev_psp = psp;
             if (x >= e1.val) { e1.val = x; e1.ptr = h[-1].ptr; psp = psp ? E1_PSP : 0; }
             else psp &= E1_PSP;
             e1.val += sc->gep;
             if (e1.val >= mx->val) mx = &e1;
+            if (dagp) {                                     /* :320-330 */
+                x = h[-1].val + sc->lgop;
+                if (x >= e2.val) { e2.val = x; e2.ptr = h[-1].ptr; if (prev_psp) psp |= E2_PSP; }
+                else psp |= (prev_psp & E2_PSP);
+                e2.val += sc->lgep;
+                if (e2.val >= mx->val) mx = &e2;
+            }
             if (internal && p->cano3[n]) {
-                const Cand* maxphl[NOD] = {0, 0, 0};
+                const Cand* maxphl[NOD] = {0, 0, 0, 0, 0};
                 for (int l = 0; l <= ncand; ++l) {
                     const Cand* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
@@ -292,7 +334,7 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
                     from = hf[prd->dir];
                     if (x >= from->val) { from->val = x; maxphl[prd->dir] = prd; }
                 }
-                for (int k = 0; k < NOD; ++k) {
+                for (int k = 0; k < Nod; ++k) {
                     const Cand* prd = maxphl[k];
                     if (!prd) continue;
                     from = hf[k];
@@ -315,12 +357,12 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
                 h->ptr = vmf_add(&vmf, m - 1, n - 1, h->ptr);
             if (internal && p->cano5[n]) {
                 const int sigJ = p->sig5[n];
-                for (int k = hd == 0 ? 0 : 1; k < NOD; ++k) {
+                for (int k = hd == 0 ? 0 : 1; k < Nod; ++k) {
                     from = hf[k];
                     if (psp & psp_bit[k]) continue;
                     if (k != hd) {
                         int z = mx->val;
-                        if (hd == 0 || (k - hd) % 2) z += (k / 2 == 1) ? sc->gop : 0;    /* GOP[k/2] */
+                        if (hd == 0 || (k - hd) % 2) z += GOP[k / 2];
                         if (from->val <= z) continue;
                     }
                     x = from->val + sigJ;
@@ -337,7 +379,8 @@ static int scalar_forward_impl(const SpdpScoring* sc, const SpdpProblem* p, cons
             }
             if (has_cut && n == cut_l) {                /* shortcut: the gap runs on over the cut */
                 e1.val += sc->gep * cutlen;
-                *h = e1;
+                if (dagp) e2.val += sc->lgep * cutlen;
+                *h = dagp ? e2 : e1;
                 f->val = NEV; f->ptr = 0;
                 n += cutlen;
             }
@@ -409,6 +452,7 @@ int orc_scalar_forward_cut(const SpdpScoring* sc, const SpdpProblem* p, const Sp
  * row mi, terminated by end_of_ulk, [8] / [9] = diagonal bounds of the slab below.  Entries the
  * reference leaves uninitialised (it allocates cpos with new[]) are end_of_ulk here.
  * rc -3: the reference would dereference udhimds[n_im] (a null pointer) at :1093. */
+#define NOD_AFFINE 3                            /* the linear-space restatement below is the Noll = 2 form */
 typedef struct { int val, upr, lwr, ml, ulk; } Rvwml;
 typedef struct { int val, dir, upr, lwr, ml, ulk, jnc; } Rvdwmlj;
 typedef struct { int mi; int* buf; int *hlnk[2], *vlnk[2], *lwrb[2], *uprb[2]; } UImd;
@@ -492,7 +536,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
         r = n - m;
         Rvwml *h = hh0 + r, *f = hh1 + r;
         Rvwml e1 = black;
-        Rvwml* hf[NOD] = {0, &e1, 0};
+        Rvwml* hf[NOD_AFFINE] = {0, &e1, 0};
         Rvdwmlj rcd[NCAND + 1];
         int idx[NCAND + 1];
         for (int l = 0; l <= NCAND; ++l) {
@@ -523,7 +567,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             if (e1.val >= mx->val) mx = &e1;
             int spj3 = 0;
             if (p->cano3[n]) {
-                const Rvdwmlj* maxphl[NOD] = {0, 0, 0};
+                const Rvdwmlj* maxphl[NOD_AFFINE] = {0, 0, 0};
                 for (int l = 0; l <= ncand; ++l) {
                     const Rvdwmlj* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
@@ -531,8 +575,8 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                     x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     if (x > from->val) { from->val = x; maxphl[prd->dir] = prd; }
                 }
-                int maxk = NOD;
-                for (int k = 0; k < NOD; ++k) {
+                int maxk = NOD_AFFINE;
+                for (int k = 0; k < NOD_AFFINE; ++k) {
                     const Rvdwmlj* prd = maxphl[k];
                     if (!prd) continue;
                     psp |= psp_bit[k];
@@ -544,7 +588,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                     from->ulk = prd->ulk;
                     if (from->val > mx->val) { maxk = k; mx = from; }
                 }
-                if (is_imd && maxk < NOD) {
+                if (is_imd && maxk < NOD_AFFINE) {
                     const Rvdwmlj* phl = maxphl[maxk];
                     imd->hlnk[0][r] = phl->ulk;
                     mx->ulk = rlst = r;
@@ -572,7 +616,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             if (LocalL && h->val <= 0) { h->val = 0; h->ml = m; h->ulk = h->upr = h->lwr = r; }
             if (p->cano5[n]) {
                 const int sigJ = p->sig5[n];
-                for (int k = (mx == h) ? 0 : 1; k < NOD; ++k) {
+                for (int k = (mx == h) ? 0 : 1; k < NOD_AFFINE; ++k) {
                     from = hf[k];
                     if (psp & psp_bit[k]) continue;
                     if (k != hd) {

@@ -40,6 +40,7 @@ class Scoring(C.Structure):
         ("minl", C.c_int32),
         ("recursive", C.c_int32),
         ("sigmodel", C.c_void_p),
+        ("codonk1", C.c_int32),
     ]
 
 
@@ -219,7 +220,7 @@ class ExonFormIn(C.Structure):           # SpdpExonFormIn
 def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=20,
                  ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0, sh=100,
                  max_vmf_space=32 * 1024 * 1024, ubh=0, ref_nelem=REF_NELEM,
-                 intpen=None, t53=None, scalar_engines=0, minl=0, recursive=0, sigmodel=None) -> Scoring:
+                 intpen=None, t53=None, scalar_engines=0, minl=0, recursive=0, sigmodel=None, codonk1=0) -> Scoring:
     sc = Scoring()
     sc.mtx_dim = int(mtx_dim)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -239,6 +240,7 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
     sc.scalar_engines = int(scalar_engines)
     sc.minl = int(minl)
     sc.recursive = int(recursive)
+    sc.codonk1 = int(codonk1)
     if sigmodel is not None:
         sc._keep_sigmodel = sigmodel
         sc.sigmodel = C.addressof(sigmodel)

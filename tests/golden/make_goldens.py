@@ -112,6 +112,20 @@ def cases():
     c["o3_plus_udh"] = (g.window, g.query, ["-O", "-V", "600000"])
     w, q = random_pair(16, 300, 2500)
     c["o3_random"] = (w, q, ["-O"])
+    # double affine gaps (-yl3, PwdB::Noll = 3), -A0 only (forwardS_ng / scorealoneS_ng with their F2 / E2 states; traceback
+    # branch of the ladder): queries with a long deletion and a long insertion that only the second gap state carries, the
+    # same with global ends (initS_ng prices the leading gap with GapPenalty / GapExtPen beyond codonk1), a divergent one
+    g = gene(41, n_exons=4, mrna_len=500, flank=250, intron_hi=900, sub=0.03, indel=0.01)
+    ql = np.concatenate([g.query[:150], g.query[174:330], synth.random_dna(np.random.default_rng(5), 18), g.query[330:]])
+    c["l3_long_gaps"] = (g.window, ql, ["-l", "3", "-A", "0"])
+    c["l3_long_gaps_global"] = (*cut(g, g.exons[0][0] - 40, g.exons[3][1] + 30)[:1], ql, ["-l", "3", "-A", "0", "-g", "0000"])
+    g = gene(42, n_exons=5, mrna_len=700, flank=300, intron_hi=700, sub=0.12, indel=0.03)
+    c["l3_divergent"] = (g.window, g.query, ["-l", "3", "-A", "0"])
+    g = gene(43, n_exons=3, mrna_len=300, flank=120, intron_hi=300)
+    c["l3_local"] = (g.window, np.concatenate([g.query[:100], g.query[130:]]), ["-l", "3", "-A", "0", "-L"])
+    for m in (3, 9):
+        g = gene(60 + m, n_exons=1, mrna_len=40, flank=60)
+        c[f"l3_tiny_m{m}"] = (g.window, g.query[:m], ["-l", "3", "-A", "0"])
     # BASELINE's headline size (C2: 2 kb cDNA, 8 exons, locus +-1 kb) and a C5-scaled long cDNA, -A0 only: the
     # reference's int16 engines are erratic beyond 1472 nt, its scalar engines are the truth
     for k in range(4):

@@ -50,7 +50,7 @@ def scoring(fx: dict, nquant: int | None = None, **over) -> abi.Scoring:
               ipen=q["ipen"], qm_len=fx["qm_len"], qm_pen=fx["qm_pen"],
               nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
               sh=q["sh"], max_vmf_space=q["max_vmf_space"], ubh=q["ubh"],
-              intpen=fx.get("intpen"), t53=fx.get("t53"), minl=q.get("minl", 0))
+              intpen=fx.get("intpen"), t53=fx.get("t53"), minl=q.get("minl", 0), codonk1=q.get("codonk1", 0))
     kw.update(over)
     return abi.make_scoring(**kw)
 

@@ -76,3 +76,19 @@ def test_hirschberg_s_ng_is_exercised():
     finally:
         oracle.scalar_udh = orig
     assert 7 in seen and seen.count(1) >= 3
+
+
+# ---- double affine gaps (PwdB::Noll = 3, -yl3): forwardS_ng / scorealoneS_ng with their F2 / E2 states ------------------------
+L3 = golden_files("l3_")
+
+
+@pytest.mark.parametrize("path", L3, ids=golden_ids(L3))
+def test_noll3_oracle_equals_reference(path):
+    """HomScoreS_ng (scorealoneS_ng) and alignS_ng (forwardS_ng + traceback) of the reference under -yl3 -A0"""
+    fx = spdg.load(path)
+    assert fx["prm"]["noll"] == 3
+    sc = spdg.scoring(fx, scalar_engines=1)
+    _, p = spdg.problem(fx)
+    assert oracle.scalar_scorealone(sc, p) == int(fx["hom_scr_A0"][0])
+    scr, flat = host_logic.align_s(sc, p, simd=0)
+    assert scr == int(fx["aln_scr_A0"][0]) and list(flat) == fx["aln_skl_A0"].tolist()

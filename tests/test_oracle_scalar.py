@@ -82,7 +82,7 @@ def test_hirschberg_s_ng_is_exercised():
 L3 = golden_files("l3_")
 
 
-@pytest.mark.parametrize("path", L3, ids=golden_ids(L3))
+@pytest.mark.parametrize("path", L3, ids=golden_ids("l3_"))
 def test_noll3_oracle_equals_reference(path):
     """HomScoreS_ng (scorealoneS_ng) and alignS_ng (forwardS_ng + traceback) of the reference under -yl3 -A0"""
     fx = spdg.load(path)

@@ -235,7 +235,12 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
 {
     ctx = c; sc = *scp; n_parents = n;
     (void) hipSetDevice(ctx->device);
-    if (sc.noll != 2) { ctx->err = "only affine gaps (Noll = 2) are implemented"; return -1; }
+    // double affine gaps (Noll = 3, -yl3): forwardS_ng / scorealoneS_ng (the -A0 engines, spdp_rowwave<., ., ., DAGP>); the
+    // linear-space engine, the -A1 / -A2 / -A3 engines and the seeded walk's cut range refuse it (DevRun::prepare)
+    if (sc.noll != 2 && !(sc.noll == 3 && sc.scalar_engines == 1)) {
+        ctx->err = "double affine gaps (Noll = 3) are built for the -A0 engines only (SpdpScoring.scalar_engines = 1); Noll must be 2 or 3";
+        return -1;
+    }
     if (sc.mtx_dim < 1 || sc.mtx_dim > 32) { ctx->err = "mtx_dim out of range"; return -1; }
     a_off.resize(n); col_off.resize(n); a_len.resize(n); b_len.resize(n);
     int64_t a_tot = 0, col_tot = 0;
@@ -485,6 +490,11 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
         return -1;
     }
+    if (st->sc.noll == 3 && flav != 3 && flav != 4) {
+        ctx->err = "double affine gaps (Noll = 3): only forwardS_ng / scorealoneS_ng are built -- this problem needs the linear-space "
+                   "engine (raise SpdpScoring.max_vmf_space) or another engine family";
+        return -1;
+    }
     // hirschbergS1_wip with local ends (-LS): its own kernel (spdp_local_udh.hip), flavour 9
     if (flav == 2 && st->sc.local) flav = flavour = 9;
     h_probs.assign(n, DevProblem());
@@ -535,7 +545,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
             imd_tot += (int64_t) P.n_im * 8 * it.w.width;
         } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + 5ll * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal
+            bnd_tot = P.bnd_off + (st->sc.noll == 3 ? 7ll : 5ll) * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal (+ F2 with Noll = 3)
             // (+ what the waves of a pipelined problem may leave unused of the chunks of numbers they reserve)
             const int64_t cap = (flav == 3) ? vmf_capacity(it) + (int64_t) SPDP_VMF_CHUNK * ((it.a_right - it.a_left) / 64 + 2) : 0;
             P.imd_off = cap;
@@ -724,6 +734,7 @@ int DevRun::launch()
         S.cpos_stride = 10 * (max_n_im + 1);
         HIPCHK(hipEventRecord(evb(), strm()));
         S.minl = store->sc.minl ? store->sc.minl : store->sc.llmt;
+        S.noll = store->sc.noll; S.lgop = store->sc.lgop; S.lgep = store->sc.lgep; S.codonk1 = store->sc.codonk1;
         if (flavour == 9) HIPCHK(spdp_launch_local_udh(&S, strm()));
         else if (flavour >= 6) HIPCHK(spdp_launch_exact(flavour - 6, &S, strm()));
         else if (flavour == 5) HIPCHK(spdp_launch_rowwave_udh(&S, strm()));

@@ -110,6 +110,8 @@ struct ScalarArgs {
     int               pipe_stride, pipe_ticket, max_tiles;
     const int2*       items;      // (problem, tile) in dispatch order
     int               n_items;
+    // double affine gaps (spdp_rowwave<., ., ., DAGP>): PwdB::Noll, LongGOP, LongGEP, codonk1
+    int               noll, lgop, lgep, codonk1;
 };
 extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipStream_t s);    // spdp_rowwave.hip: -A0 forward / score-only
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t s);            // spdp_rowwave.hip: -A0 linear space

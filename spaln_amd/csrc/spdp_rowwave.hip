@@ -70,11 +70,12 @@ __device__ __forceinline__ int intpen_of(const Tables& T, const ScalarArgs& A, i
 #define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // the three states a candidate can splice from / into: the cell's diagonal value, the horizontal and the vertical gap
-enum { K_H = 0, K_E = 1, K_F = 2 };
-__device__ __forceinline__ int psp_bit(int k) { return k == 0 ? 4 : (k == 1 ? 1 : 8); }    // src/aln.h:56
+enum { K_H = 0, K_E = 1, K_F = 2, K_E2 = 3, K_F2 = 4 };   // hf[] of the reference: DIAG, HORI, VERT, HORL, VERL (the last two with Noll = 3)
+__device__ __forceinline__ int psp_bit(int k) { return k == 0 ? 4 : (k == 1 ? 1 : (k == 2 ? 8 : (k == 3 ? 2 : 16))); }    // src/aln.h:56
 
-struct Lds {
+template <bool DAGP> struct Lds {
     int hv[RING], fv[RING];
+    int f2v[DAGP ? RING : 1], f2p[DAGP ? RING : 1];     // the second vertical-gap state (Noll = 3)
     int hp[RING], fp[RING], dr[RING];                   // forward only
 };
 
@@ -103,16 +104,21 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 // its "virtual" column v (the one it would be on without the jump) and everything that names a genomic position
 // (column records, intron lengths, path records) its real column n = v + cut_len once it is past the cut.  Rows that
 // start behind cut_l never jump, as in the reference.  One wave per problem.
-template <int MODE, bool PIPE, bool CUT = false>
+// DAGP: double affine gaps (PwdB::Noll = 3, -yl3; src/fwd2s1.cc:219, 297-305, 320-330): a second vertical and a second
+// horizontal gap state priced with LongGOP / LongGEP, five states a candidate can leave from, a third array by diagonal.
+template <int MODE, bool PIPE, bool CUT = false, bool DAGP = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void spdp_rowwave(ScalarArgs A)
 {
     constexpr bool FWD = MODE == 1;
+    constexpr int NODK = DAGP ? 5 : 3;                  // states (Nod)
+    constexpr int NEWD = 8;                             // the file-local Newd of src/fwd2s1.cc:48 (a direction is a state number or this)
+    static_assert(!(CUT && DAGP), "the cut range with double affine gaps is not built");
     static_assert(!CUT || (FWD && !PIPE), "the cut range exists for the forward engine only");
-    __shared__ Lds Lw[WPB];
+    __shared__ Lds<DAGP> Lw[WPB];
     __shared__ Tables T;
     const DevScoring* sc = A.sc;
     load_tables(T, A, sc);
-    Lds& L = Lw[threadIdx.x >> 6];
+    Lds<DAGP>& L = Lw[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
     int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const bool Local = sc->local;
     const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
     const int gop = sc->gop, gep = sc->gep, spj = sc->spj, llmt = sc->llmt, ipen = A.ipen;
+    const int lgop = DAGP ? A.lgop : 0, lgep = DAGP ? A.lgep : 0, codonk1 = DAGP ? A.codonk1 : INT32_MAX;
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int2* __restrict__ cols = A.cols + P.col_off;            // {(sig5 + ipen) | sig3 << 16, base}
     const uint8_t* __restrict__ aux = A.aux + 2 * P.col_off;        // {bit0 donor | bit1 acceptor, dinc5 << 4 | dinc3}
@@ -142,6 +149,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     int* __restrict__ gHp = gFv + width;
     int* __restrict__ gFp = gHp + width;
     int* __restrict__ gDr = gFp + width;
+    int* __restrict__ gF2v = (FWD ? gDr : gFv) + width;              // Noll = 3: behind the arrays of the affine form
+    int* __restrict__ gF2p = gF2v + width;
     int3* __restrict__ vrec = A.vmf + P.tb_off;
     int* __restrict__ vraw = reinterpret_cast<int*>(vrec);
     const int vcap = (int) P.imd_off;
@@ -204,10 +213,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             else if (r < r0 && r >= r_lo) {
                 dr = 2;
                 if (b_exgl) hv = 0;
-                else { hv = gop + (r0 - r) * gep; hp = 1; if (!FWD) fv = hv; }
+                else {
+                    // GapPenalty(1) + GapExtPen(2) + .. + GapExtPen(i), i = r0 - r (src/aln.h:275-282; beyond codonk1 with LongGEP)
+                    const int i = r0 - r;
+                    hv = gop + (DAGP ? min(i, codonk1) * gep + max(0, i - codonk1) * lgep : i * gep); hp = 1;
+                    if (!FWD) fv = gop + i * gep;                   // (sinitS_ng: F runs on with BasicGEP)
+                }
             }
             gst<PIPE>(gHv + e, hv); gst<PIPE>(gFv + e, fv);
             if (FWD) { gst<PIPE>(gHp + e, hp); gst<PIPE>(gFp + e, 0); gst<PIPE>(gDr + e, dr); }
+            if (DAGP) { gst<PIPE>(gF2v + e, NEV); if (FWD) gst<PIPE>(gF2p + e, 0); }
         }
         if (FWD && lane == 0) {
             gst<PIPE>(vraw + 0, 0); gst<PIPE>(vraw + 1, 0); gst<PIPE>(vraw + 2, 0);
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 
         // per-row state
         int e1v = NEV, e1p = 0;
+        int e2v = NEV, e2p = 0;                                     // the second horizontal-gap state (Noll = 3)
         unsigned psp = 0;
         int cv[NC], cj[NC], cd[NC], cp[NC], cx[NC];                 // candidates: value, donor column, state, pointer, dinc5
 #pragma unroll
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
                 if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
+                if (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
             }
             res_lo = max(res_lo, dead);
             const int want = min(width, need_hi(S + CHUNK - 1) + 1);
@@ -275,6 +292,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 L.hv[q] = gld<PIPE>(gHv + e); L.fv[q] = gld<PIPE>(gFv + e);
                 if (FWD) { L.hp[q] = gld<PIPE>(gHp + e); L.fp[q] = gld<PIPE>(gFp + e); L.dr[q] = gld<PIPE>(gDr + e); }
+                if (DAGP) { L.f2v[q] = gld<PIPE>(gF2v + e); if (FWD) L.f2p[q] = gld<PIPE>(gF2p + e); }
             }
             res_hi = max(res_hi, want);
             WAVE_SYNC();
@@ -303,30 +321,55 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             const int ufv = L.fv[qu], ufp = FWD ? L.fp[qu] : 0;                    //              F of the cell above
             const int lhv = L.hv[ql], lhp = FWD ? L.hp[ql] : 0;                    // entry r - 1: my left neighbour
             int fv = L.fv[q], fp = FWD ? L.fp[q] : 0;
+            int f2v = DAGP ? L.f2v[q] : NEV, f2p = (DAGP && FWD) ? L.f2p[q] : 0;
+            const int uf2v = DAGP ? L.f2v[qu] : NEV, uf2p = (DAGP && FWD) ? L.f2p[qu] : 0;
             const int diag = hv;
             int mxk = K_H;                                          // which state holds the running maximum
+            // the value / pointer of state k (five-way once the long-gap states exist)
+            auto val_k = [&](int k) {
+                if constexpr (DAGP) return k == K_H ? hv : (k == K_E ? e1v : (k == K_F ? fv : (k == K_E2 ? e2v : f2v)));
+                else return k == K_H ? hv : (k == K_E ? e1v : fv);
+            };
+            auto ptr_k = [&](int k) {
+                if constexpr (DAGP) return k == K_H ? hp : (k == K_E ? e1p : (k == K_F ? fp : (k == K_E2 ? e2p : f2p)));
+                else return k == K_H ? hp : (k == K_E ? e1p : fp);
+            };
             if (m != al) {                                          // (the row of a global left end has no cell above)
                 hv += qprof[col.y];
-                if (FWD) dir = (dir % 3) ? 3 : 0;                   // a diagonal step that follows a non-diagonal one: NEWD
+                if (FWD) dir = (dir % NEWD) ? NEWD : 0;             // a diagonal step that follows a non-diagonal one: NEWD
                 const int x = uhv + gop;
                 if (FWD ? (x >= ufv) : (x > ufv)) { fv = x; fp = uhp; } else { fv = ufv; fp = ufp; }
                 fv += gep;
                 if (fv > hv) mxk = K_F;
+                if constexpr (DAGP) {                               // Vertical2 (:297-305 / :1227-1231)
+                    const int x2 = uhv + lgop;
+                    if (FWD ? (x2 >= uf2v) : (x2 > uf2v)) { f2v = x2; f2p = uhp; } else { f2v = uf2v; f2p = uf2p; }
+                    f2v += lgep;
+                    if (f2v > val_k(mxk)) mxk = K_F2;
+                }
             }
             if (on) {                                               // (row state: only cells of the row may touch it)
                 const int x = lhv + gop;
+                const unsigned prev_psp = psp;
                 if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; e1p = lhp; psp = psp ? 1u : 0u; } else psp &= 1u;
                 e1v += gep;
-                const int cur = mxk == K_H ? hv : fv;
+                const int cur = val_k(mxk);
                 if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E;
+                if constexpr (DAGP) {                               // Horizontal2 (:320-330 / :1245-1254)
+                    const int x2 = lhv + lgop;
+                    if (FWD ? (x2 >= e2v) : (x2 > e2v)) { e2v = x2; e2p = lhp; if (prev_psp) psp |= 2u; } else psp |= (prev_psp & 2u);
+                    e2v += lgep;
+                    const int cur2 = val_k(mxk);
+                    if (FWD ? (e2v >= cur2) : (e2v > cur2)) mxk = K_E2;
+                }
             }
             // ---- acceptor: every candidate of my row may raise the state it left from
             // (screen: the best candidate, priced as high as anything can be, against the lowest of the three states it may
             //  raise -- every update below is behind `x > state`, `>=` in the forward engine)
             const bool acc = on && internal && (ax & 2) && ncand >= 0 &&
-                             cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >= min(hv, min(e1v, fv));
+                             cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >= min(min(hv, min(e1v, fv)), DAGP ? min(e2v, f2v) : INT32_MAX);
             if (__ballot(acc)) {
-                int sel_h = -1, sel_e = -1, sel_f = -1;
+                int sel_h = -1, sel_e = -1, sel_f = -1, sel_e2 = -1, sel_f2 = -1;
                 const int s3 = col.x >> 16, dn3 = adn & 15;
 #pragma unroll
                 for (int l = 0; l < NC; ++l) {
@@ -335,7 +378,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                         const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                         if (cd[l] == K_H) { if (FWD ? (x >= hv) : (x > hv)) { hv = x; sel_h = l; } }
                         else if (cd[l] == K_E) { if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; sel_e = l; } }
-                        else { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
+                        else if (!DAGP || cd[l] == K_F) { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
+                        else if (cd[l] == K_E2) { if (FWD ? (x >= e2v) : (x > e2v)) { e2v = x; sel_e2 = l; } }
+                        else { if (FWD ? (x >= f2v) : (x > f2v)) { f2v = x; sel_f2 = l; } }
                     }
                 }
                 auto pick = [&](int sel, int* arr) { int v = 0; _Pragma("unroll") for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l]; return v; };
@@ -344,25 +389,39 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     const bool t = sel_h >= 0;
                     if (t) psp |= psp_bit(K_H);
                     if (FWD) { const int p1 = vadd(t, m, pick(sel_h, cj), pick(sel_h, cp)); const int p2 = vadd(t, m, n, p1); if (t) hp = p2; }
-                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (hv >= cur) : (hv > cur)) mxk = K_H; }
+                    if (t) { const int cur = val_k(mxk); if (FWD ? (hv >= cur) : (hv > cur)) mxk = K_H; }
                 }
                 if (__ballot(sel_e >= 0)) {
                     const bool t = sel_e >= 0;
                     if (t) psp |= psp_bit(K_E);
                     if (FWD) { const int p1 = vadd(t, m, pick(sel_e, cj), pick(sel_e, cp)); const int p2 = vadd(t, m, n, p1); if (t) e1p = p2; }
-                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E; }
+                    if (t) { const int cur = val_k(mxk); if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E; }
                 }
                 if (__ballot(sel_f >= 0)) {
                     const bool t = sel_f >= 0;
                     if (t) psp |= psp_bit(K_F);
                     if (FWD) { const int p1 = vadd(t, m, pick(sel_f, cj), pick(sel_f, cp)); const int p2 = vadd(t, m, n, p1); if (t) fp = p2; }
-                    if (t) { const int cur = mxk == K_H ? hv : (mxk == K_E ? e1v : fv); if (FWD ? (fv >= cur) : (fv > cur)) mxk = K_F; }
+                    if (t) { const int cur = val_k(mxk); if (FWD ? (fv >= cur) : (fv > cur)) mxk = K_F; }
+                }
+                if constexpr (DAGP) {
+                    if (__ballot(sel_e2 >= 0)) {
+                        const bool t = sel_e2 >= 0;
+                        if (t) psp |= psp_bit(K_E2);
+                        if (FWD) { const int p1 = vadd(t, m, pick(sel_e2, cj), pick(sel_e2, cp)); const int p2 = vadd(t, m, n, p1); if (t) e2p = p2; }
+                        if (t) { const int cur = val_k(mxk); if (FWD ? (e2v >= cur) : (e2v > cur)) mxk = K_E2; }
+                    }
+                    if (__ballot(sel_f2 >= 0)) {
+                        const bool t = sel_f2 >= 0;
+                        if (t) psp |= psp_bit(K_F2);
+                        if (FWD) { const int p1 = vadd(t, m, pick(sel_f2, cj), pick(sel_f2, cp)); const int p2 = vadd(t, m, n, p1); if (t) f2p = p2; }
+                        if (t) { const int cur = val_k(mxk); if (FWD ? (f2v >= cur) : (f2v > cur)) mxk = K_F2; }
+                    }
                 }
             }
             // ---- the cell's value: the best state
             const int hd = mxk;
-            const int mxv = mxk == K_H ? hv : (mxk == K_E ? e1v : fv);       // *mx
-            const int mxp = mxk == K_H ? hp : (mxk == K_E ? e1p : fp);
+            const int mxv = val_k(mxk);                                  // *mx
+            const int mxp = ptr_k(mxk);
             int hval_raw = hv;                                      // the diagonal state's own value (candidate source K_H)
             int hptr_raw = hp;
             if (FWD) {
@@ -377,7 +436,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 // (vadd keeps a counter every lane must advance: it is never called under a per-lane condition)
                 const bool reset = LocalL && hv <= 0;
                 if (reset) { hv = 0; dir = 1; }
-                const bool t = on && !reset && dir == 3 && !(psp & psp_bit(K_H));
+                const bool t = on && !reset && dir == NEWD && !(psp & psp_bit(K_H));
                 const int pn = vadd(t, m - 1, n - 1, hp);
                 if (t) hp = pn;
                 hval_raw = hv; hptr_raw = hp;                       // (the reference's donor loop reads *h after these updates)
@@ -393,15 +452,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (__ballot(don)) {
                 const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
                 const int dn5 = adn >> 4;
-                const int mx_now = hd == K_H ? hval_raw : (hd == K_E ? e1v : fv);     // *mx as it stands now
+                const int mx_now = hd == K_H ? hval_raw : val_k(hd);         // *mx as it stands now
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int sv = k == K_H ? hval_raw : (k == K_E ? e1v : fv);
-                    const int sp = k == K_H ? hptr_raw : (k == K_E ? e1p : fp);
+                for (int k = 0; k < NODK; ++k) {
+                    const int sv = k == K_H ? hval_raw : val_k(k);
+                    const int sp = k == K_H ? hptr_raw : ptr_k(k);
                     bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
                     if (t && k != hd) {
                         int z = mx_now;
-                        if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;      // GOP[k / 2]
+                        if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : (k / 2 == 2 ? lgop : 0);      // GOP[k / 2]
                         if (sv <= z) t = false;                     // cannot become the better path
                     }
                     {   // a full list whose last kept entry holds against the newcomer: the list is NC - 1 long afterwards
@@ -439,6 +498,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (on) {
                 L.hv[q] = hv; L.fv[q] = fv;
                 if (FWD) { L.hp[q] = hp; L.fp[q] = fp; L.dr[q] = dir; }
+                if (DAGP) { L.f2v[q] = f2v; if (FWD) L.f2p[q] = f2p; }
             }
         }
         // everything still resident goes back
@@ -448,6 +508,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
                 if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
+                if (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
             }
         }
     }
@@ -1070,14 +1131,22 @@ extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipS
 {
     ScalarArgs A = *a;
     const dim3 blk(64 * WPB);
+    const bool dagp = A.noll == 3;                      // double affine gaps: the F2 / E2 states (no cut-range form)
+    if (dagp && forward == 2) return hipErrorNotSupported;
     if (A.pipe) {                                       // one wave per (problem, tile)
         const dim3 grd((A.n_items + WPB - 1) / WPB);
-        if (forward) hipLaunchKernelGGL((spdp_rowwave<1, true>), grd, blk, 0, stream, A);
+        if (dagp) {
+            if (forward) hipLaunchKernelGGL((spdp_rowwave<1, true, false, true>), grd, blk, 0, stream, A);
+            else hipLaunchKernelGGL((spdp_rowwave<0, true, false, true>), grd, blk, 0, stream, A);
+        } else if (forward) hipLaunchKernelGGL((spdp_rowwave<1, true>), grd, blk, 0, stream, A);
         else hipLaunchKernelGGL((spdp_rowwave<0, true>), grd, blk, 0, stream, A);
         return hipGetLastError();
     }
     const dim3 grd((A.n_probs + WPB - 1) / WPB);
-    if (forward == 2) hipLaunchKernelGGL((spdp_rowwave<1, false, true>), grd, blk, 0, stream, A);      // every problem with a cut range
+    if (dagp) {
+        if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false, false, true>), grd, blk, 0, stream, A);
+        else hipLaunchKernelGGL((spdp_rowwave<0, false, false, true>), grd, blk, 0, stream, A);
+    } else if (forward == 2) hipLaunchKernelGGL((spdp_rowwave<1, false, true>), grd, blk, 0, stream, A);      // every problem with a cut range
     else if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false>), grd, blk, 0, stream, A);
     else hipLaunchKernelGGL((spdp_rowwave<0, false>), grd, blk, 0, stream, A);
     return hipGetLastError();

@@ -1,0 +1,80 @@
+"""Double affine gaps (Noll = 3, the reference's -yl3) in the -A0 engines: scorealoneS_ng and forwardS_ng as
+spdp_rowwave<., ., ., DAGP> (five states per cell: H, E1, F1, E2, F2; src/fwd2s1.cc:48, 350-640, 1050-1300).
+The reference's own HomScoreS_ng / alignS_ng under `-yl3 -A0` (tests/golden/l3_*.spdg), then sub-ranges of the same
+pairs, ragged in height, one wave per problem and as a pipeline of tiles, against the oracle."""
+import numpy as np
+import pytest
+
+from tests import spdg
+from tests.conftest import golden_files, golden_ids
+from spaln_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+L3_FILES = golden_files("l3_")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from spaln_amd import engine
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("path", L3_FILES, ids=golden_ids("l3_"))
+def test_noll3_equals_reference(eng, path):
+    fx = spdg.load(path)
+    assert fx["prm"]["noll"] == 3
+    sc = spdg.scoring(fx, scalar_engines=1)
+    ps, _ = spdg.problem(fx)
+    assert int(eng.scalar_scorealone(sc, ps)[0]) == int(fx["hom_scr_A0"][0])
+    assert int(eng.homscore_s(sc, ps)[0]) == int(fx["hom_scr_A0"][0])
+    (scr, skl), = eng.align_s(sc, ps)
+    assert scr == int(fx["aln_scr_A0"][0]) and skl.ravel().tolist() == fx["aln_skl_A0"].tolist()
+
+
+def _subranges(fx, n, seed):
+    q = fx["prm"]
+    rng = np.random.default_rng(synth.SEED + seed)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    ps = abi.ProblemSet()
+    for i in range(n):
+        m = int(rng.integers(min(40, q["a_right"]), q["a_right"] + 1))
+        al = int(rng.integers(0, q["a_right"] - m + 1))
+        bl = int(rng.integers(0, max(1, min(400, q["b_right"] - m - 200))))
+        br = int(rng.integers(max(bl + m + 100, q["b_right"] - 600), q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 3 == 0 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg, **extra)
+    return ps
+
+
+@pytest.mark.parametrize("name", ["l3_long_gaps", "l3_divergent", "l3_local"])
+def test_noll3_subranges_against_oracle(eng, monkeypatch, name):
+    from oracle import oracle
+    f = [f for f in L3_FILES if f.endswith(name + ".spdg")]
+    if not f:
+        pytest.skip("fixture not present")
+    fx = spdg.load(f[0])
+    sc = spdg.scoring(fx, scalar_engines=1)
+    ps = _subranges(fx, 12, 700 + len(name))
+    want_f = [oracle.scalar_forward(sc, p) for p in ps.items]
+    want_s = [oracle.scalar_scorealone(sc, p) for p in ps.items]
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("SPDP_A0_PIPE", pipe)
+        got = eng.scalar_forward(sc, ps)
+        bad = [(i, s, ws, skl.tolist()[:8], wskl.tolist()[:8]) for i, ((s, skl), (ws, wskl)) in enumerate(zip(got, want_f))
+               if s != ws or skl.tolist() != wskl.tolist()]
+        assert not bad, (pipe, bad[:3])
+        assert eng.scalar_scorealone(sc, ps).tolist() == want_s, pipe
+    monkeypatch.delenv("SPDP_A0_PIPE")
+
+
+def test_noll3_other_engines_refuse(eng):
+    """-A1 / -A2 / -A3 and the linear-space engine are not built for Noll = 3: the upload says so"""
+    fx = spdg.load([f for f in L3_FILES if f.endswith("l3_long_gaps.spdg")][0])
+    ps, _ = spdg.problem(fx)
+    for se in (0, 2):
+        with pytest.raises(Exception, match="Noll"):
+            eng.homscore_s(spdg.scoring(fx, scalar_engines=se), ps)

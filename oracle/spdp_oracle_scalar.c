@@ -452,15 +452,14 @@ int orc_scalar_forward_cut(const SpdpScoring* sc, const SpdpProblem* p, const Sp
  * row mi, terminated by end_of_ulk, [8] / [9] = diagonal bounds of the slab below.  Entries the
  * reference leaves uninitialised (it allocates cpos with new[]) are end_of_ulk here.
  * rc -3: the reference would dereference udhimds[n_im] (a null pointer) at :1093. */
-#define NOD_AFFINE 3                            /* the linear-space restatement below is the Noll = 2 form */
 typedef struct { int val, upr, lwr, ml, ulk; } Rvwml;
 typedef struct { int val, dir, upr, lwr, ml, ulk, jnc; } Rvdwmlj;
-typedef struct { int mi; int* buf; int *hlnk[2], *vlnk[2], *lwrb[2], *uprb[2]; } UImd;
+typedef struct { int mi; int* buf; int *hlnk[3], *vlnk[3], *lwrb[3], *uprb[3]; } UImd;    /* a plane per gap state: Noll of them */
 
 int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow* w, int n_im, int imd_intvl,
                    int32_t* score, int32_t* cpos, int32_t* ranges)
 {
-    if (sc->noll != 2 || !sc->intpen || !p->cano5 || n_im < 1) return -1;
+    if ((sc->noll != 2 && sc->noll != 3) || !sc->intpen || !p->cano5 || n_im < 1) return -1;
     const int NEV = SPDP_NEVSEL, EOU = SPDP_END_OF_ULK;
     int al = p->a_left, ar = p->a_right, bl = p->b_left, br = p->b_right;
     const int Local = sc->local;
@@ -468,16 +467,18 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
     const int LocalR = Local && p->a_exgr && p->b_exgr;
     const int dim = sc->mtx_dim;
     const int lw = w->lw, up = w->up, width = w->width;
-    const int GOP[2] = {0, sc->gop};
+    const int dagp = sc->noll == 3, Nol = sc->noll, Nod = 2 * Nol - 1;
+    const int GOP[3] = {0, sc->gop, sc->lgop};
 #define CPOS(i, c) cpos[(i) * 10 + (c)]
     for (int i = 0; i <= n_im; ++i) for (int c = 0; c < 10; ++c) CPOS(i, c) = EOU;
-    const size_t bufsiz = (size_t) 2 * width;
+    const size_t bufsiz = (size_t) Nol * width;
     Rvwml* wbuf = (Rvwml*) malloc((bufsiz + 4) * sizeof(Rvwml));
     int r = bl - ar;
     const Rvwml black = {NEV, r, r, 0, EOU};
     for (size_t i = 0; i < bufsiz + 4; ++i) wbuf[i] = black;
     Rvwml* hh0 = wbuf - lw + 1;
     Rvwml* hh1 = hh0 + width;
+    Rvwml* hh2 = hh1 + width;                           /* F2, Noll = 3 */
     /* hinitS_ng */
     {
         int rr = br - al;
@@ -498,7 +499,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             else {
                 *h = h[1];
                 ++h->ml;
-                h->val += (i == 1) ? sc->gop + sc->gep : sc->gep;   /* GapPenalty(1) / GapExtPen(i) */
+                h->val += (i == 1) ? gap_penalty(sc, 1) : gap_ext_pen(sc, i);
                 h->lwr = r;
                 h->ulk = r0;
             }
@@ -508,7 +509,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
     UImd* imds = (UImd*) calloc(n_im, sizeof(UImd));
     {
         int mi = al;
-        const size_t us = (size_t) 2 * width;
+        const size_t us = (size_t) Nol * width;
         for (int i = 0; i < n_im; ++i) {
             UImd* d = imds + i;
             d->mi = (mi += imd_intvl);
@@ -517,8 +518,10 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             for (size_t k = 0; k < us; ++k) { d->buf[2 * us + k] = INT_MAX; d->buf[3 * us + k] = INT_MIN; }
             d->hlnk[0] = d->buf - lw + 1;  d->vlnk[0] = d->hlnk[0] + us;
             d->lwrb[0] = d->vlnk[0] + us;  d->uprb[0] = d->lwrb[0] + us;
-            d->hlnk[1] = d->hlnk[0] + width; d->vlnk[1] = d->vlnk[0] + width;
-            d->lwrb[1] = d->lwrb[0] + width; d->uprb[1] = d->uprb[0] + width;
+            for (int k = 1; k < Nol; ++k) {
+                d->hlnk[k] = d->hlnk[k - 1] + width; d->vlnk[k] = d->vlnk[k - 1] + width;
+                d->lwrb[k] = d->lwrb[k - 1] + width; d->uprb[k] = d->uprb[k - 1] + width;
+            }
         }
     }
     UImd* imd = imds;
@@ -534,9 +537,9 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
         const int is_imd = m == mm;
         unsigned psp = 0;
         r = n - m;
-        Rvwml *h = hh0 + r, *f = hh1 + r;
-        Rvwml e1 = black;
-        Rvwml* hf[NOD_AFFINE] = {0, &e1, 0};
+        Rvwml *h = hh0 + r, *f = hh1 + r, *f2 = dagp ? hh2 + r : wbuf + bufsiz - 1;
+        Rvwml e1 = black, e2 = black;
+        Rvwml* hf[NOD] = {0, &e1, 0, &e2, 0};
         Rvdwmlj rcd[NCAND + 1];
         int idx[NCAND + 1];
         for (int l = 0; l <= NCAND; ++l) {
@@ -548,8 +551,8 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
         const int32_t* qprof = (m >= 1) ? sc->mtx + (size_t) p->a[m - 1] * dim : sc->mtx;
         for ( ; ++n <= n9; ) {
             int x;
-            ++r; ++h; ++f;
-            hf[0] = h; hf[2] = f;
+            ++r; ++h; ++f; if (dagp) ++f2;
+            hf[0] = h; hf[2] = f; hf[4] = f2;
             Rvwml* from = h;
             Rvwml* mx = h;
             if (m != al) {
@@ -559,15 +562,30 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                 else *f = f[1];
                 f->val += sc->gep;
                 if (f->val >= mx->val) mx = f;
+                if (dagp) {                                 /* Vertical2, :847-856 */
+                    x = from->val + sc->lgop;
+                    if (x >= f2[1].val) { *f2 = *from; f2->val = x; }
+                    else *f2 = f2[1];
+                    f2->val += sc->lgep;
+                    if (f2->val >= mx->val) mx = f2;
+                }
             }
             x = h[-1].val + sc->gop;
+            const unsigned prev_psp = psp;
             if (x >= e1.val) { e1 = h[-1]; e1.val = x; psp = psp ? E1_PSP : 0; }
             else psp &= 3;                                  /* e_psp = e1_psp + e2_psp */
             e1.val += sc->gep;
             if (e1.val >= mx->val) mx = &e1;
+            if (dagp) {                                     /* Horizontal2, :870-880 */
+                x = h[-1].val + sc->lgop;
+                if (x >= e2.val) { e2 = h[-1]; e2.val = x; if (prev_psp) psp |= E2_PSP; }
+                else psp |= (prev_psp & E2_PSP);
+                e2.val += sc->lgep;
+                if (e2.val >= mx->val) mx = &e2;
+            }
             int spj3 = 0;
             if (p->cano3[n]) {
-                const Rvdwmlj* maxphl[NOD_AFFINE] = {0, 0, 0};
+                const Rvdwmlj* maxphl[NOD] = {0, 0, 0, 0, 0};
                 for (int l = 0; l <= ncand; ++l) {
                     const Rvdwmlj* prd = rcd + idx[l];
                     if (n - prd->jnc < sc->llmt) continue;
@@ -575,8 +593,8 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                     x = prd->val + (p->cip ? p->cip[m] : 0) + spjscr(sc, p, prd->jnc, n);     /* sigB = cip_score(m) */
                     if (x > from->val) { from->val = x; maxphl[prd->dir] = prd; }
                 }
-                int maxk = NOD_AFFINE;
-                for (int k = 0; k < NOD_AFFINE; ++k) {
+                int maxk = Nod;
+                for (int k = 0; k < Nod; ++k) {
                     const Rvdwmlj* prd = maxphl[k];
                     if (!prd) continue;
                     psp |= psp_bit[k];
@@ -588,16 +606,18 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
                     from->ulk = prd->ulk;
                     if (from->val > mx->val) { maxk = k; mx = from; }
                 }
-                if (is_imd && maxk < NOD_AFFINE) {
+                if (is_imd && maxk < Nod) {
                     const Rvdwmlj* phl = maxphl[maxk];
                     imd->hlnk[0][r] = phl->ulk;
                     mx->ulk = rlst = r;
                     if (maxk == 0) {
-                        if ((phl = maxphl[1]) && hf[1]->val > mx->val + GOP[1]) {
-                            hf[1]->ulk = r + width;
-                            imd->hlnk[1][r] = phl->ulk;
+                        for (int c = 1, d = 1; c < Nol; ++c, d += 2) {
+                            if ((phl = maxphl[d]) && hf[d]->val > mx->val + GOP[c]) {
+                                hf[d]->ulk = r + c * width;
+                                imd->hlnk[c][r] = phl->ulk;
+                            }
+                            if (maxphl[d + 1] && hf[d + 1]->val > mx->val + GOP[c]) hf[d + 1]->ulk = r + c * width;
                         }
-                        if (maxphl[2] && hf[2]->val > mx->val + GOP[1]) hf[2]->ulk = r + width;
                     }
                 }
             }
@@ -616,7 +636,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             if (LocalL && h->val <= 0) { h->val = 0; h->ml = m; h->ulk = h->upr = h->lwr = r; }
             if (p->cano5[n]) {
                 const int sigJ = p->sig5[n];
-                for (int k = (mx == h) ? 0 : 1; k < NOD_AFFINE; ++k) {
+                for (int k = (mx == h) ? 0 : 1; k < Nod; ++k) {
                     from = hf[k];
                     if (psp & psp_bit[k]) continue;
                     if (k != hd) {
@@ -644,7 +664,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
             if (is_imd) {
                 if (hd == 0) rlst = r;
                 else if (!spj3 && hd % 2) imd->hlnk[0][r] = rlst;
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < Nol; ++k) {
                     Rvwml* g = hf[2 * k];
                     imd->vlnk[k][r] = g->ulk;
                     imd->lwrb[k][r] = imin(r, g->lwr);
@@ -687,7 +707,7 @@ int orc_scalar_udh(const SpdpScoring* sc, const SpdpProblem* p, const SpdpWindow
     for ( ; i >= 0 && (imd = imds + i)->mi > maxh_ml; --i) {
         int c = 0;
         for (d = 0; r > up; r -= width) ++d;
-        if (d > 1 || r < lw - 1) { rc = -3; break; }         /* outside the link arrays */
+        if (d > Nol - 1 || r < lw - 1) { rc = -3; break; }         /* outside the link arrays */
         if (imd->vlnk[d][r] < EOU) {
             CPOS(i, c++) = imd->mi;
             CPOS(i, c++) = (d > 0) ? 1 : 0;

@@ -126,6 +126,22 @@ def cases():
     for m in (3, 9):
         g = gene(60 + m, n_exons=1, mrna_len=40, flank=60)
         c[f"l3_tiny_m{m}"] = (g.window, g.query[:m], ["-l", "3", "-A", "0"])
+    # ... and through hirschbergS_ng (small MaxVmfSpace / forced intermediate rows): a third link plane per intermediate row.
+    # A 30-nt insertion in the query across an intermediate row (F2 crosses it), a 24-nt deletion on one (E2 runs along it)
+    g = gene(41, n_exons=4, mrna_len=500, flank=250, intron_hi=900, sub=0.03, indel=0.01)
+    qi = np.concatenate([g.query[:240], synth.random_dna(np.random.default_rng(6), 30), g.query[240:]])
+    c["l3_udh_f2_cross"] = (g.window, qi, ["-l", "3", "-A", "0", "-U", "3", "-V", "100000"])
+    c["l3_udh_f2_cross7"] = (g.window, qi, ["-l", "3", "-A", "0", "-U", "7", "-V", "100000"])
+    qd = np.concatenate([g.query[:238], g.query[262:]])
+    c["l3_udh_e2_on_row"] = (g.window, qd, ["-l", "3", "-A", "0", "-U", "3", "-V", "100000"])
+    c["l3_udh_long_gaps"] = (g.window, ql, ["-l", "3", "-A", "0", "-V", "150000"])
+    c["l3_udh_long_gaps_global"] = (*cut(g, g.exons[0][0] - 40, g.exons[3][1] + 30)[:1], ql, ["-l", "3", "-A", "0", "-g", "0000", "-V", "150000"])
+    g = gene(42, n_exons=5, mrna_len=700, flank=300, intron_hi=700, sub=0.12, indel=0.03)
+    c["l3_udh_divergent"] = (g.window, g.query, ["-l", "3", "-A", "0", "-V", "300000"])
+    g = gene(44, n_exons=6, mrna_len=900, flank=300, intron_hi=800, sub=0.04, indel=0.01)
+    ql2 = np.concatenate([g.query[:200], g.query[236:450], synth.random_dna(np.random.default_rng(7), 40), g.query[450:]])
+    c["l3_udh_local"] = (g.window, ql2, ["-l", "3", "-A", "0", "-L", "-V", "300000"])
+    c["l3_udh_900nt"] = (g.window, ql2, ["-l", "3", "-A", "0", "-V", "1000000"])
     # BASELINE's headline size (C2: 2 kb cDNA, 8 exons, locus +-1 kb) and a C5-scaled long cDNA, -A0 only: the
     # reference's int16 engines are erratic beyond 1472 nt, its scalar engines are the truth
     for k in range(4):

@@ -235,8 +235,8 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
 {
     ctx = c; sc = *scp; n_parents = n;
     (void) hipSetDevice(ctx->device);
-    // double affine gaps (Noll = 3, -yl3): forwardS_ng / scorealoneS_ng (the -A0 engines, spdp_rowwave<., ., ., DAGP>); the
-    // linear-space engine, the -A1 / -A2 / -A3 engines and the seeded walk's cut range refuse it (DevRun::prepare)
+    // double affine gaps (Noll = 3, -yl3): forwardS_ng / hirschbergS_ng / scorealoneS_ng (the -A0 engines, spdp_rowwave<., ., ., DAGP>,
+    // spdp_rowwave_udh<., DAGP>); the -A1 / -A2 / -A3 engines and the seeded walk's cut range refuse it (DevRun::prepare)
     if (sc.noll != 2 && !(sc.noll == 3 && sc.scalar_engines == 1)) {
         ctx->err = "double affine gaps (Noll = 3) are built for the -A0 engines only (SpdpScoring.scalar_engines = 1); Noll must be 2 or 3";
         return -1;
@@ -490,9 +490,8 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
         return -1;
     }
-    if (st->sc.noll == 3 && flav != 3 && flav != 4) {
-        ctx->err = "double affine gaps (Noll = 3): only forwardS_ng / scorealoneS_ng are built -- this problem needs the linear-space "
-                   "engine (raise SpdpScoring.max_vmf_space) or another engine family";
+    if (st->sc.noll == 3 && flav != 3 && flav != 4 && flav != 5) {
+        ctx->err = "double affine gaps (Noll = 3): only the -A0 engines (forwardS_ng / hirschbergS_ng / scorealoneS_ng) are built";
         return -1;
     }
     // hirschbergS1_wip with local ends (-LS): its own kernel (spdp_local_udh.hip), flavour 9
@@ -538,11 +537,11 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
                 P.imd_off = cap;
                 tb_tot += cap;
             }
-        } else if (flav == 5) { // scalar UDH: 2 * width + 4 states of 5 ints; 8 link / bound rows per intermediate
+        } else if (flav == 5) { // scalar UDH: Noll * width + 4 states of 5 ints; 4 * Noll link / bound rows per intermediate
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + 5ll * (2 * it.w.width + 4);
+            bnd_tot = P.bnd_off + 5ll * (st->sc.noll * it.w.width + 4);                  // H and Noll - 1 vertical-gap states
             P.imd_off = imd_tot;
-            imd_tot += (int64_t) P.n_im * 8 * it.w.width;
+            imd_tot += (int64_t) P.n_im * 4 * st->sc.noll * it.w.width;
         } else if (flav >= 3) { // scalar: work = 4 * width ints + width dir bytes; Vmf records
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
             bnd_tot = P.bnd_off + (st->sc.noll == 3 ? 7ll : 5ll) * it.w.width + 8;        // H, F (values, Vmf pointers) and the direction entries by diagonal (+ F2 with Noll = 3)

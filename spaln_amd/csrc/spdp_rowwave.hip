@@ -646,9 +646,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 namespace {
 constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
 constexpr int INH = 0x7ffffff0;                         // PIPE: "the rlst the row above me ends with", resolved by the link walk
-struct LdsU {
+template <bool DAGP> struct LdsU {
     int hv[RING], hu[RING], hl[RING], hm[RING], hk[RING];
     int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
+    static constexpr int R2 = DAGP ? RING : 1;          // the second vertical-gap state (Noll = 3)
+    int gv[R2], gu[R2], gl[R2], gm[R2], gk[R2];
 };
 struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
 // one of three state records, FIELD BY FIELD: `c ? a : b` on the records themselves is an lvalue -- a pointer is selected and
@@ -661,19 +663,31 @@ __device__ __forceinline__ St st_sel3(int k, const St& h, const St& e, const St&
     r.k = k == K_H ? h.k : (k == K_E ? e.k : f.k);
     return r;
 }
+// ... of five (Noll = 3: H, E1, F1, E2, F2)
+__device__ __forceinline__ St st_sel5(int k, const St& h, const St& e, const St& f, const St& e2, const St& f2)
+{
+    St r;
+#define SEL5(x) (k == K_H ? h.x : (k == K_E ? e.x : (k == K_F ? f.x : (k == K_E2 ? e2.x : f2.x))))
+    r.v = SEL5(v); r.u = SEL5(u); r.l = SEL5(l); r.m = SEL5(m); r.k = SEL5(k);
+#undef SEL5
+    return r;
+}
 }   // namespace
 
 // PIPE as above.  `rlst` is the one value that would tie a tile to the END of the intermediate row above it; it is only
 // ever stored (into HLNK), so a tile starts from the marker INH, every intermediate row leaves the value it ends
 // with in rlf[], and the link walk replaces the marker by what the rows above left.
-template <bool PIPE>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void spdp_rowwave_udh(ScalarArgs A)
+// DAGP: double affine gaps (Noll = 3): the states E2 / F2 (HORL / VERL), a third plane of entries by diagonal and a third
+// link plane per intermediate row (src/fwd2s1.cc:764, 847-880, 917-927, 1016-1023)
+template <bool PIPE, bool DAGP = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ? 2 : 3, DAGP ? 2 : 3))) void spdp_rowwave_udh(ScalarArgs A)
 {
-    __shared__ LdsU Lw[WPB];
+    constexpr int NOL = DAGP ? 3 : 2, NODK = 2 * NOL - 1, NA = 5 * NOL;
+    __shared__ LdsU<DAGP> Lw[WPB];
     __shared__ Tables T;
     const DevScoring* sc = A.sc;
     load_tables(T, A, sc);
-    LdsU& L = Lw[threadIdx.x >> 6];
+    LdsU<DAGP>& L = Lw[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
     int t_lo = 0, t_hi = INT32_MAX;
@@ -693,14 +707,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
     const bool Local = sc->local;
     const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
     const int gop = sc->gop, gep = sc->gep, llmt = sc->llmt, ipen = A.ipen;
+    const int lgop = A.lgop, lgep = A.lgep, codonk1 = A.codonk1;
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int2* __restrict__ cols = A.cols + P.col_off;
     const uint8_t* __restrict__ aux = A.aux + 2 * P.col_off;
-    int* const g0 = A.work + P.bnd_off;                             // ten arrays of `width` entries
-    auto G = [&](int arr) { return g0 + (int64_t) arr * width; };  // 0..4 H {v,u,l,m,k}, 5..9 F
-    // intermediate i: hlnk[2], vlnk[2], lwrb[2], uprb[2], `width` ints each, entry r - lw + 1
+    int* const g0 = A.work + P.bnd_off;                             // 5 * Noll arrays of `width` entries
+    auto G = [&](int arr) { return g0 + (int64_t) arr * width; };  // 0..4 H {v,u,l,m,k}, 5..9 F, 10..14 F2
+    // intermediate i: hlnk[Noll], vlnk[Noll], lwrb[Noll], uprb[Noll], `width` ints each, entry r - lw + 1
     int* const imd_base = A.imd + P.imd_off;
-    const int64_t us = 2 * (int64_t) width;
+    const int64_t us = NOL * (int64_t) width;
     enum { HLNK = 0, VLNK = 1, LWRB = 2, UPRB = 3 };
     auto IM = [&](int i, int arr, int k, int r) -> int* { return imd_base + (int64_t) i * 4 * us + arr * us + (int64_t) k * width + (r - lw + 1); };
     auto mi_of = [&](int i) { return P.a_left + (i + 1) * intvl; };
@@ -744,10 +759,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
             if (r >= r0 && r <= r_hi) h = {0, r, r, al, r};
             else if (r < r0 && r >= r_lo) {
                 if (b_exgl) h = {0, r, r, al + (r0 - r), r};
+                else if (DAGP) h = {gop + min(r0 - r, codonk1) * gep + max(0, r0 - r - codonk1) * lgep, r0, r, al + (r0 - r), r0};   // GapPenalty(1) + GapExtPen(2 ..)
                 else h = {gop + (r0 - r) * gep, r0, r, al + (r0 - r), r0};
             }
             gst<PIPE>(G(0) + e, h.v); gst<PIPE>(G(1) + e, h.u); gst<PIPE>(G(2) + e, h.l); gst<PIPE>(G(3) + e, h.m); gst<PIPE>(G(4) + e, h.k);
             gst<PIPE>(G(5) + e, NEV); gst<PIPE>(G(6) + e, rb); gst<PIPE>(G(7) + e, rb); gst<PIPE>(G(8) + e, 0); gst<PIPE>(G(9) + e, EOU);
+            if (DAGP) { gst<PIPE>(G(10) + e, NEV); gst<PIPE>(G(11) + e, rb); gst<PIPE>(G(12) + e, rb); gst<PIPE>(G(13) + e, 0); gst<PIPE>(G(14) + e, EOU); }
         }
         if (!PIPE) for (int i = 0; i < n_im; ++i) imd_init(i);      // (PIPE: by the tile that holds the row)
     }
@@ -783,6 +800,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
             const short* qprof = T.mtx + acode * 32;
             const int sigB = (row && A.cip && P.cip_off >= 0) ? A.cip[P.cip_off + m] : 0;  // Cip_score::cip_score(m)
             St E = {NEV, bl - ar, bl - ar, 0, EOU};
+            St E2 = E;
             unsigned psp = 0;
             int cv[NC], cj[NC], cd[NC], cu[NC], cl[NC], cm[NC], ck[NC], cx[NC];
 #pragma unroll
@@ -791,13 +809,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
             auto need_lo = [&](int S) { return S - 2 * (m0 + 63) - 1 - (lw - 1); };
             auto need_hi = [&](int S) { return S - 2 * m0 + 1 - (lw - 1); };
             int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
-            int* const lds[10] = {L.hv, L.hu, L.hl, L.hm, L.hk, L.fv, L.fu, L.fl, L.fm, L.fk};
+            int* const lds[15] = {L.hv, L.hu, L.hl, L.hm, L.hk, L.fv, L.fu, L.fl, L.fm, L.fk, L.gv, L.gu, L.gl, L.gm, L.gk};
             auto refill = [&](int S) {
                 const int dead = min(max(0, need_lo(S)), width);
                 for (int e = res_lo + lane; e < dead; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 10; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
+                    for (int a = 0; a < NA; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
                 }
                 res_lo = max(res_lo, dead);
                 const int want = min(width, need_hi(S + CHUNK - 1) + 1);
@@ -808,7 +826,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 10; ++a) lds[a][q] = gld<PIPE>(G(a) + e);
+                    for (int a = 0; a < NA; ++a) lds[a][q] = gld<PIPE>(G(a) + e);
                 }
                 res_hi = max(res_hi, want);
                 WAVE_SYNC();
@@ -834,6 +852,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                 const St uH = {L.hv[qu], L.hu[qu], L.hl[qu], L.hm[qu], L.hk[qu]};
                 const St uF = {L.fv[qu], L.fu[qu], L.fl[qu], L.fm[qu], L.fk[qu]};
                 const St lH = {L.hv[ql], L.hu[ql], L.hl[ql], L.hm[ql], L.hk[ql]};
+                St F2 = F, uF2 = F;
+                if (DAGP) {
+                    const int q2 = DAGP ? q : 0, qu2 = DAGP ? qu : 0;
+                    F2 = {L.gv[q2], L.gu[q2], L.gl[q2], L.gm[q2], L.gk[q2]};
+                    uF2 = {L.gv[qu2], L.gu[qu2], L.gl[qu2], L.gm[qu2], L.gk[qu2]};
+                }
+                auto val_of = [&](int k) {
+                    if (DAGP) return k == K_H ? H.v : (k == K_E ? E.v : (k == K_F ? F.v : (k == K_E2 ? E2.v : F2.v)));
+                    return k == K_H ? H.v : (k == K_E ? E.v : F.v);
+                };
                 int mxk = K_H;
                 if (m != P.a_left) {
                     H.v += qprof[col.y];
@@ -841,21 +869,33 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                     if (x >= uF.v) { F = uH; F.v = x; } else F = uF;
                     F.v += gep;
                     if (F.v >= H.v) mxk = K_F;
+                    if (DAGP) {                                     // Vertical2
+                        const int x2 = uH.v + lgop;
+                        if (x2 >= uF2.v) { F2 = uH; F2.v = x2; } else F2 = uF2;
+                        F2.v += lgep;
+                        if (F2.v >= val_of(mxk)) mxk = K_F2;
+                    }
                 }
                 if (on) {
+                    const unsigned prev_psp = psp;
                     const int x = lH.v + gop;
                     if (x >= E.v) { E = lH; E.v = x; psp = psp ? 1u : 0u; } else psp &= 3u;
                     E.v += gep;
-                    const int cur = mxk == K_H ? H.v : F.v;
-                    if (E.v >= cur) mxk = K_E;
+                    if (E.v >= val_of(mxk)) mxk = K_E;
+                    if (DAGP) {                                     // Horizontal2
+                        const int x2 = lH.v + lgop;
+                        if (x2 >= E2.v) { E2 = lH; E2.v = x2; if (prev_psp) psp |= 2u; } else psp |= (prev_psp & 2u);
+                        E2.v += lgep;
+                        if (E2.v >= val_of(mxk)) mxk = K_E2;
+                    }
                 }
-                auto val_of = [&](int k) { return k == K_H ? H.v : (k == K_E ? E.v : F.v); };
                 // ---- acceptor
                 bool spj3 = false;
                 const bool acc = on && (ax & 2) && ncand >= 0 &&
-                                 cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) > min(H.v, min(E.v, F.v));     // (screen, as above)
+                                 cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >
+                                     (DAGP ? min(min(H.v, min(E.v, F.v)), min(E2.v, F2.v)) : min(H.v, min(E.v, F.v)));     // (screen, as above)
                 if (__ballot(acc)) {
-                    int sel_h = -1, sel_e = -1, sel_f = -1;
+                    int sel_h = -1, sel_e = -1, sel_f = -1, sel_e2 = -1, sel_f2 = -1;
                     const int s3 = col.x >> 16, dn3 = adn & 15;
 #pragma unroll
                     for (int l = 0; l < NC; ++l) {
@@ -864,11 +904,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                             const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                             if (cd[l] == K_H) { if (x > H.v) { H.v = x; sel_h = l; } }
                             else if (cd[l] == K_E) { if (x > E.v) { E.v = x; sel_e = l; } }
-                            else { if (x > F.v) { F.v = x; sel_f = l; } }
+                            else if (!DAGP || cd[l] == K_F) { if (x > F.v) { F.v = x; sel_f = l; } }
+                            else if (cd[l] == K_E2) { if (x > E2.v) { E2.v = x; sel_e2 = l; } }
+                            else { if (x > F2.v) { F2.v = x; sel_f2 = l; } }
                         }
                     }
                     auto pick = [&](int sel, const int* arr) { int v = 0; _Pragma("unroll") for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l]; return v; };
-                    int maxk = 3;
+                    int maxk = NODK;
                     if (sel_h >= 0) {
                         psp |= psp_bit(K_H); spj3 = true;
                         H.u = max(pick(sel_h, cu), r); H.l = min(pick(sel_h, cl), r); H.m = pick(sel_h, cm); H.k = pick(sel_h, ck);
@@ -884,20 +926,36 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                         F.u = max(pick(sel_f, cu), r); F.l = min(pick(sel_f, cl), r); F.m = pick(sel_f, cm); F.k = pick(sel_f, ck);
                         if (F.v > val_of(mxk)) { maxk = K_F; mxk = K_F; }
                     }
-                    if (is_imd && acc && maxk < 3) {
-                        const int sel = maxk == K_H ? sel_h : (maxk == K_E ? sel_e : sel_f);
+                    if (DAGP && sel_e2 >= 0) {
+                        psp |= psp_bit(K_E2);
+                        E2.u = max(pick(sel_e2, cu), r); E2.l = min(pick(sel_e2, cl), r); E2.m = pick(sel_e2, cm); E2.k = pick(sel_e2, ck);
+                        if (E2.v > val_of(mxk)) { maxk = K_E2; mxk = K_E2; }
+                    }
+                    if (DAGP && sel_f2 >= 0) {
+                        psp |= psp_bit(K_F2);
+                        F2.u = max(pick(sel_f2, cu), r); F2.l = min(pick(sel_f2, cl), r); F2.m = pick(sel_f2, cm); F2.k = pick(sel_f2, ck);
+                        if (F2.v > val_of(mxk)) { maxk = K_F2; mxk = K_F2; }
+                    }
+                    if (is_imd && acc && maxk < NODK) {
+                        int sel = maxk == K_H ? sel_h : (maxk == K_E ? sel_e : sel_f);
+                        if (DAGP && maxk > K_F) sel = maxk == K_E2 ? sel_e2 : sel_f2;
                         gst<PIPE>(IM(iq, HLNK, 0, r), pick(sel, ck));
                         rlst = r;
-                        if (maxk == K_H) H.k = r; else if (maxk == K_E) E.k = r; else F.k = r;
+                        if (maxk == K_H) H.k = r; else if (maxk == K_E) E.k = r; else if (!DAGP || maxk == K_F) F.k = r;
+                        else if (maxk == K_E2) E2.k = r; else F2.k = r;
                         if (maxk == K_H) {
                             if (sel_e >= 0 && E.v > H.v + gop) { E.k = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), pick(sel_e, ck)); }
                             if (sel_f >= 0 && F.v > H.v + gop) F.k = r + width;
+                            if (DAGP) {
+                                if (sel_e2 >= 0 && E2.v > H.v + lgop) { E2.k = r + 2 * width; gst<PIPE>(IM(iq, HLNK, 2, r), pick(sel_e2, ck)); }
+                                if (sel_f2 >= 0 && F2.v > H.v + lgop) F2.k = r + 2 * width;
+                            }
                         }
                     }
                 }
                 // ---- the cell takes the best state
                 const int hd = mxk;
-                const St MX = st_sel3(mxk, H, E, F);                         // *mx
+                const St MX = DAGP ? st_sel5(mxk, H, E, F, E2, F2) : st_sel3(mxk, H, E, F);      // *mx
                 if (hd == K_H) {
                     if (LocalR && on && H.v > best.v) { best = H; best_mr = m; best_nr = n; }
                 } else {
@@ -913,12 +971,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                     const int dn5 = adn >> 4;
                     const int mx_now = hd == K_H ? H.v : MX.v;      // *mx: E / F keep their own value when they won
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const St src = st_sel3(k, H, E, F);
+                    for (int k = 0; k < NODK; ++k) {
+                        const St src = DAGP ? st_sel5(k, H, E, F, E2, F2) : st_sel3(k, H, E, F);
                         bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
                         if (t && k != hd) {
                             int z = mx_now;
-                            if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : 0;
+                            if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : ((k / 2 == 2) ? lgop : 0);
                             if (src.v <= z) t = false;
                         }
                         {
@@ -956,17 +1014,22 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
                     H.l = H.u = r; H.k = r;
                     gst<PIPE>(IM(iq, VLNK, 1, r), F.k); gst<PIPE>(IM(iq, LWRB, 1, r), min(r, F.l)); gst<PIPE>(IM(iq, UPRB, 1, r), max(r, F.u));
                     F.l = F.u = r; F.k = r + width;
+                    if (DAGP) {
+                        gst<PIPE>(IM(iq, VLNK, 2, r), F2.k); gst<PIPE>(IM(iq, LWRB, 2, r), min(r, F2.l)); gst<PIPE>(IM(iq, UPRB, 2, r), max(r, F2.u));
+                        F2.l = F2.u = r; F2.k = r + 2 * width;
+                    }
                 }
                 if (on) {
                     L.hv[q] = H.v; L.hu[q] = H.u; L.hl[q] = H.l; L.hm[q] = H.m; L.hk[q] = H.k;
                     L.fv[q] = F.v; L.fu[q] = F.u; L.fl[q] = F.l; L.fm[q] = F.m; L.fk[q] = F.k;
+                    if (DAGP) { const int q2 = DAGP ? q : 0; L.gv[q2] = F2.v; L.gu[q2] = F2.u; L.gl[q2] = F2.l; L.gm[q2] = F2.m; L.gk[q2] = F2.k; }
                 }
             }
             WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
 #pragma unroll
-                for (int a = 0; a < 10; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
+                for (int a = 0; a < NA; ++a) gst<PIPE>(G(a) + e, lds[a][q]);
             }
         }
         // `rlst` of this tile's intermediate row is what the next one starts from
@@ -1071,7 +1134,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
     for ( ; i >= 0 && mi_of(i) > mxs.m; --i) {
         int c = 0, d = 0;
         for ( ; r > up; r -= width) ++d;
-        if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
+        if (d > NOL - 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
         const int mi = mi_of(i);
         if (gld<PIPE>(IM(i, VLNK, d, r)) < EOU) {
             CPOS(i, c++) = mi;
@@ -1122,7 +1185,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
-    if (A.pipe) hipLaunchKernelGGL(spdp_rowwave_udh<true>, dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    if (A.noll == 3) {
+        if (A.pipe) hipLaunchKernelGGL((spdp_rowwave_udh<true, true>), dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+        else hipLaunchKernelGGL((spdp_rowwave_udh<false, true>), dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+    } else if (A.pipe) hipLaunchKernelGGL(spdp_rowwave_udh<true>, dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     else hipLaunchKernelGGL(spdp_rowwave_udh<false>, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     return hipGetLastError();
 }

@@ -1,7 +1,9 @@
 """Double affine gaps (Noll = 3, the reference's -yl3) in the -A0 engines: scorealoneS_ng and forwardS_ng as
-spdp_rowwave<., ., ., DAGP> (five states per cell: H, E1, F1, E2, F2; src/fwd2s1.cc:48, 350-640, 1050-1300).
-The reference's own HomScoreS_ng / alignS_ng under `-yl3 -A0` (tests/golden/l3_*.spdg), then sub-ranges of the same
-pairs, ragged in height, one wave per problem and as a pipeline of tiles, against the oracle."""
+spdp_rowwave<., ., ., DAGP> (five states per cell: H, E1, F1, E2, F2; src/fwd2s1.cc:48, 219-444, 1163-1336), hirschbergS_ng
+as spdp_rowwave_udh<., DAGP> (a third plane of entries and of links per intermediate row; src/fwd2s1.cc:762-1104).
+The reference's own HomScoreS_ng / alignS_ng under `-yl3 -A0` (tests/golden/l3_*.spdg; l3_udh_*: small MaxVmfSpace, the
+ladder goes through the linear-space engine), then sub-ranges of the same pairs, ragged in height, one wave per problem
+and as a pipeline of tiles, against the oracle."""
 import numpy as np
 import pytest
 
@@ -68,6 +70,42 @@ def test_noll3_subranges_against_oracle(eng, monkeypatch, name):
                if s != ws or skl.tolist() != wskl.tolist()]
         assert not bad, (pipe, bad[:3])
         assert eng.scalar_scorealone(sc, ps).tolist() == want_s, pipe
+    monkeypatch.delenv("SPDP_A0_PIPE")
+
+
+@pytest.mark.parametrize("name,m,n_im", [("l3_udh_f2_cross", 529, 3), ("l3_udh_f2_cross", 529, 7), ("l3_udh_e2_on_row", 475, 3),
+                                       ("l3_udh_900nt", 640, 5), ("l3_udh_local", 900, 4), ("l3_udh_divergent", 400, 2)])
+def test_noll3_hirschberg_against_oracle(eng, monkeypatch, name, m, n_im):
+    """hirschbergS_ng itself: scores, cpos rows, written-back ranges on sub-ranges of one height, against the oracle"""
+    from oracle import oracle
+    fx = spdg.load([f for f in L3_FILES if f.endswith(name + ".spdg")][0])
+    q = fx["prm"]
+    sc = spdg.scoring(fx, scalar_engines=1)
+    rng = np.random.default_rng(synth.SEED + 900 + m + n_im)
+    extra = dict(cano5=fx["cano5"], cano3=fx["cano3"],
+                 dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+    ps = abi.ProblemSet()
+    for i in range(10):
+        al = int(rng.integers(0, q["a_right"] - m + 1))
+        bl = int(rng.integers(0, 300))
+        br = int(rng.integers(q["b_right"] - 400, q["b_right"] + 1))
+        exg = (1, 1, 1, 1) if i % 3 == 0 else tuple(int(x) for x in rng.integers(0, 2, size=4))
+        ps.add(fx["a_codes"], fx["b_codes"], fx["sig5"], fx["sig3"], al, al + m, bl, br, exg, **extra)
+    intvl = (m + n_im) // (n_im + 1)
+    want = [oracle.scalar_udh(sc, p, n_im, intvl) for p in ps.items]
+    if name == "l3_udh_f2_cross":                        # the long insertion does cross an intermediate row in a gap state
+        assert any(int(c[1]) == 1 for w in want if w[3] == 0 for c in w[1][:-1])
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("SPDP_A0_PIPE", pipe)
+        scores, cpos, ranges, flags = eng.scalar_udh(sc, ps, n_im, intvl)
+        bad = []
+        for i, (ws, wcpos, wrng, wflag) in enumerate(want):
+            ok = int(flags[i]) == wflag
+            if wflag == 0:
+                ok = ok and int(scores[i]) == ws and ranges[i].tolist() == wrng.tolist() and cpos[i].tolist() == wcpos.tolist()
+            if not ok:
+                bad.append((i, int(scores[i]), ws, int(flags[i]), wflag))
+        assert not bad, (pipe, bad[:3])
     monkeypatch.delenv("SPDP_A0_PIPE")
 
 

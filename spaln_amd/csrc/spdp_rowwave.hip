@@ -112,7 +112,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     constexpr bool FWD = MODE == 1;
     constexpr int NODK = DAGP ? 5 : 3;                  // states (Nod)
     constexpr int NEWD = 8;                             // the file-local Newd of src/fwd2s1.cc:48 (a direction is a state number or this)
-    static_assert(!(CUT && DAGP), "the cut range with double affine gaps is not built");
     static_assert(!CUT || (FWD && !PIPE), "the cut range exists for the forward engine only");
     __shared__ Lds<DAGP> Lw[WPB];
     __shared__ Tables T;
@@ -492,7 +491,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
             if (CUT && on && jumps && v == cut_l) {                  // the gap runs on over the cut: {gap, nothing} stay behind
                 e1v += gep * cut_len;
-                hv = e1v; hp = e1p; fv = NEV; fp = 0;
+                if (DAGP) { e2v += lgep * cut_len; hv = e2v; hp = e2p; }            // (*h = dagp ? e2 : e1; F2 stays)
+                else { hv = e1v; hp = e1p; }
+                fv = NEV; fp = 0;
             }
             // ---- entry r takes the cell
             if (on) {
@@ -1197,8 +1198,7 @@ extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipS
 {
     ScalarArgs A = *a;
     const dim3 blk(64 * WPB);
-    const bool dagp = A.noll == 3;                      // double affine gaps: the F2 / E2 states (no cut-range form)
-    if (dagp && forward == 2) return hipErrorNotSupported;
+    const bool dagp = A.noll == 3;                      // double affine gaps: the F2 / E2 states
     if (A.pipe) {                                       // one wave per (problem, tile)
         const dim3 grd((A.n_items + WPB - 1) / WPB);
         if (dagp) {
@@ -1210,7 +1210,8 @@ extern "C" hipError_t spdp_launch_rowwave(int forward, const ScalarArgs* a, hipS
     }
     const dim3 grd((A.n_probs + WPB - 1) / WPB);
     if (dagp) {
-        if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false, false, true>), grd, blk, 0, stream, A);
+        if (forward == 2) hipLaunchKernelGGL((spdp_rowwave<1, false, true, true>), grd, blk, 0, stream, A);
+        else if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false, false, true>), grd, blk, 0, stream, A);
         else hipLaunchKernelGGL((spdp_rowwave<0, false, false, true>), grd, blk, 0, stream, A);
     } else if (forward == 2) hipLaunchKernelGGL((spdp_rowwave<1, false, true>), grd, blk, 0, stream, A);      // every problem with a cut range
     else if (forward) hipLaunchKernelGGL((spdp_rowwave<1, false>), grd, blk, 0, stream, A);

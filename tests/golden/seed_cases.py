@@ -227,11 +227,20 @@ def a1_cases():
     return c
 
 
+# the same family under double affine gaps (-yl3, Noll = 3; -A0 only: the reference's SIMD engines are not consistent with
+# themselves there): seeds that between them make every kind of DP call (lspS_ng, trcbkalignS_ng with and without a cut
+# range, the linear-space ladder) with long gaps in the pieces between HSPs
+FIXTURE_SEEDS_L3 = [36, 170, 302, 320, 389, 687, 745, 763, 902, 1454]
+
+
 def cases():
     c = {}
     for s in FIXTURE_SEEDS:
         w, q, opts, _ = make_case(s)
         c[f"q_{s:04d}"] = (w, q, opts)
+    for s in FIXTURE_SEEDS_L3:
+        w, q, opts, _ = make_case(s)
+        c[f"ql3_{s:04d}"] = (w, q, opts + ["-l", "3", "-A", "0"])
     c.update(special_cases())
     c.update({k: v for k, v in a1_cases().items() if k.startswith("q_")})
     return c

@@ -109,6 +109,26 @@ def test_noll3_hirschberg_against_oracle(eng, monkeypatch, name, m, n_im):
     monkeypatch.delenv("SPDP_A0_PIPE")
 
 
+QL3 = golden_files("ql3_")
+
+
+@pytest.mark.parametrize("path", QL3, ids=golden_ids("ql3_"))
+def test_noll3_seeded_equals_reference(eng, path):
+    """alignS_ng with seeding on (-Q5 .. -Q7) under -yl3: the walk's DP calls (lspS_ng through the ladder, trcbkalignS_ng
+    with and without shortcutS_ng's cut range: spdp_rowwave<1, false, CUT, DAGP>) against the reference's own runs"""
+    from tests.test_oracle_seeded import seeded_inputs
+    fx = spdg.load(path)
+    assert fx["prm"]["noll"] == 3
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 0)
+    sc.scalar_engines = 1
+    res = eng.align_s_seeded(sc, sp, p._owner, [hsps if n else None], [lowest], [wl])
+    scr, skl = res[0]
+    assert scr == int(fx["seed_scr_A0"][0])
+    assert ([int(x) for x in skl.ravel()] if len(skl) else []) == fx["seed_skl_A0"].tolist()
+    st = eng.seeded_stats()
+    assert st["walks"] == 1
+
+
 def test_noll3_other_engines_refuse(eng):
     """-A1 / -A2 / -A3 and the linear-space engine are not built for Noll = 3: the upload says so"""
     fx = spdg.load([f for f in L3_FILES if f.endswith("l3_long_gaps.spdg")][0])

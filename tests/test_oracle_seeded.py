@@ -42,6 +42,21 @@ def test_seeded_alignment_equals_reference(fx, alg, simd):
     assert (flat or []) == fx[f"seed_skl_A{alg}"].tolist()
 
 
+QL3 = golden_files("ql3_")
+
+
+@pytest.mark.parametrize("path", QL3, ids=golden_ids("ql3_"))
+def test_seeded_noll3_equals_reference(path):
+    """the seeded path under double affine gaps (-yl3; -A0 engines behind the walk): GapPenalty's switch to the long pair
+    beyond codonk1 in the closed-form joins, E2 / F2 in every DP call"""
+    fx = spdg.load(path)
+    assert fx["prm"]["noll"] == 3
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs(fx, 0)
+    scr, flat, rc = seeded.align_s_seeded(sc, sp, p, hsps, n, lowest, wl, 0)
+    assert rc == 0 and scr == int(fx["seed_scr_A0"][0])
+    assert (flat or []) == fx["seed_skl_A0"].tolist()
+
+
 def test_fixtures_reach_every_join():
     """every branch of interpolateS (and bestwlu) is taken by some fixture, most by several"""
     joins = {}

@@ -73,11 +73,14 @@ __device__ __forceinline__ int intpen_of(const Tables& T, const ScalarArgs& A, i
 enum { K_H = 0, K_E = 1, K_F = 2, K_E2 = 3, K_F2 = 4 };   // hf[] of the reference: DIAG, HORI, VERT, HORL, VERL (the last two with Noll = 3)
 __device__ __forceinline__ int psp_bit(int k) { return k == 0 ? 4 : (k == 1 ? 1 : (k == 2 ? 8 : (k == 3 ? 2 : 16))); }    // src/aln.h:56
 
-template <bool DAGP> struct Lds {
+struct Lds2 {
     int hv[RING], fv[RING];
-    int f2v[DAGP ? RING : 1], f2p[DAGP ? RING : 1];     // the second vertical-gap state (Noll = 3)
     int hp[RING], fp[RING], dr[RING];                   // forward only
 };
+struct Lds3 : Lds2 { int f2v[RING], f2p[RING]; };       // + the second vertical-gap state (Noll = 3)
+template <bool DAGP> struct Lds_of { using type = Lds2; };
+template <> struct Lds_of<true> { using type = Lds3; };
+template <bool DAGP> using Lds = typename Lds_of<DAGP>::type;
 
 }   // namespace
 
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
                 if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
-                if (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
+                if constexpr (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
             }
             res_lo = max(res_lo, dead);
             const int want = min(width, need_hi(S + CHUNK - 1) + 1);
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 L.hv[q] = gld<PIPE>(gHv + e); L.fv[q] = gld<PIPE>(gFv + e);
                 if (FWD) { L.hp[q] = gld<PIPE>(gHp + e); L.fp[q] = gld<PIPE>(gFp + e); L.dr[q] = gld<PIPE>(gDr + e); }
-                if (DAGP) { L.f2v[q] = gld<PIPE>(gF2v + e); if (FWD) L.f2p[q] = gld<PIPE>(gF2p + e); }
+                if constexpr (DAGP) { L.f2v[q] = gld<PIPE>(gF2v + e); if (FWD) L.f2p[q] = gld<PIPE>(gF2p + e); }
             }
             res_hi = max(res_hi, want);
             WAVE_SYNC();
@@ -320,8 +323,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             const int ufv = L.fv[qu], ufp = FWD ? L.fp[qu] : 0;                    //              F of the cell above
             const int lhv = L.hv[ql], lhp = FWD ? L.hp[ql] : 0;                    // entry r - 1: my left neighbour
             int fv = L.fv[q], fp = FWD ? L.fp[q] : 0;
-            int f2v = DAGP ? L.f2v[q] : NEV, f2p = (DAGP && FWD) ? L.f2p[q] : 0;
-            const int uf2v = DAGP ? L.f2v[qu] : NEV, uf2p = (DAGP && FWD) ? L.f2p[qu] : 0;
+            int f2v = NEV, f2p = 0, uf2v = NEV, uf2p = 0;
+            if constexpr (DAGP) { f2v = L.f2v[q]; uf2v = L.f2v[qu]; if (FWD) { f2p = L.f2p[q]; uf2p = L.f2p[qu]; } }
             const int diag = hv;
             int mxk = K_H;                                          // which state holds the running maximum
             // the value / pointer of state k (five-way once the long-gap states exist)
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const unsigned prev_psp = psp;
                 if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; e1p = lhp; psp = psp ? 1u : 0u; } else psp &= 1u;
                 e1v += gep;
-                const int cur = val_k(mxk);
+                const int cur = DAGP ? val_k(mxk) : (mxk == K_H ? hv : fv);
                 if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E;
                 if constexpr (DAGP) {                               // Horizontal2 (:320-330 / :1245-1254)
                     const int x2 = lhv + lgop;
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (on) {
                 L.hv[q] = hv; L.fv[q] = fv;
                 if (FWD) { L.hp[q] = hp; L.fp[q] = fp; L.dr[q] = dir; }
-                if (DAGP) { L.f2v[q] = f2v; if (FWD) L.f2p[q] = f2p; }
+                if constexpr (DAGP) { L.f2v[q] = f2v; if (FWD) L.f2p[q] = f2p; }
             }
         }
         // everything still resident goes back
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const int q = e & (RING - 1);
                 gst<PIPE>(gHv + e, L.hv[q]); gst<PIPE>(gFv + e, L.fv[q]);
                 if (FWD) { gst<PIPE>(gHp + e, L.hp[q]); gst<PIPE>(gFp + e, L.fp[q]); gst<PIPE>(gDr + e, L.dr[q]); }
-                if (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
+                if constexpr (DAGP) { gst<PIPE>(gF2v + e, L.f2v[q]); if (FWD) gst<PIPE>(gF2p + e, L.f2p[q]); }
             }
         }
     }
@@ -647,12 +650,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 namespace {
 constexpr int EOU = 0x7fffffff - 2;                     // end_of_ulk, src/aln.h:49
 constexpr int INH = 0x7ffffff0;                         // PIPE: "the rlst the row above me ends with", resolved by the link walk
-template <bool DAGP> struct LdsU {
+// (the affine form must not grow by a byte: three blocks of it fill the CU's LDS to within one allocation granule)
+struct LdsU2 {
     int hv[RING], hu[RING], hl[RING], hm[RING], hk[RING];
     int fv[RING], fu[RING], fl[RING], fm[RING], fk[RING];
-    static constexpr int R2 = DAGP ? RING : 1;          // the second vertical-gap state (Noll = 3)
-    int gv[R2], gu[R2], gl[R2], gm[R2], gk[R2];
 };
+struct LdsU3 : LdsU2 { int gv[RING], gu[RING], gl[RING], gm[RING], gk[RING]; };     // + the second vertical-gap state (Noll = 3)
+template <bool DAGP> struct LdsU_of { using type = LdsU2; };
+template <> struct LdsU_of<true> { using type = LdsU3; };
+template <bool DAGP> using LdsU = typename LdsU_of<DAGP>::type;
 struct St { int v, u, l, m, k; };                       // value, upr, lwr, ml, ulk
 // one of three state records, FIELD BY FIELD: `c ? a : b` on the records themselves is an lvalue -- a pointer is selected and
 // the record copied from memory, which parks H, E and F in scratch memory for the whole sweep (round 4)
@@ -810,7 +816,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
             auto need_lo = [&](int S) { return S - 2 * (m0 + 63) - 1 - (lw - 1); };
             auto need_hi = [&](int S) { return S - 2 * m0 + 1 - (lw - 1); };
             int res_lo = max(0, need_lo(s_lo)), res_hi = res_lo;
-            int* const lds[15] = {L.hv, L.hu, L.hl, L.hm, L.hk, L.fv, L.fu, L.fl, L.fm, L.fk, L.gv, L.gu, L.gl, L.gm, L.gk};
+            int* lds[NA] = {L.hv, L.hu, L.hl, L.hm, L.hk, L.fv, L.fu, L.fl, L.fm, L.fk};
+            if constexpr (DAGP) { lds[10] = L.gv; lds[11] = L.gu; lds[12] = L.gl; lds[13] = L.gm; lds[14] = L.gk; }
             auto refill = [&](int S) {
                 const int dead = min(max(0, need_lo(S)), width);
                 for (int e = res_lo + lane; e < dead; e += 64) {
@@ -854,10 +861,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                 const St uF = {L.fv[qu], L.fu[qu], L.fl[qu], L.fm[qu], L.fk[qu]};
                 const St lH = {L.hv[ql], L.hu[ql], L.hl[ql], L.hm[ql], L.hk[ql]};
                 St F2 = F, uF2 = F;
-                if (DAGP) {
-                    const int q2 = DAGP ? q : 0, qu2 = DAGP ? qu : 0;
-                    F2 = {L.gv[q2], L.gu[q2], L.gl[q2], L.gm[q2], L.gk[q2]};
-                    uF2 = {L.gv[qu2], L.gu[qu2], L.gl[qu2], L.gm[qu2], L.gk[qu2]};
+                if constexpr (DAGP) {
+                    F2 = {L.gv[q], L.gu[q], L.gl[q], L.gm[q], L.gk[q]};
+                    uF2 = {L.gv[qu], L.gu[qu], L.gl[qu], L.gm[qu], L.gk[qu]};
                 }
                 auto val_of = [&](int k) {
                     if (DAGP) return k == K_H ? H.v : (k == K_E ? E.v : (k == K_F ? F.v : (k == K_E2 ? E2.v : F2.v)));
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                     const int x = lH.v + gop;
                     if (x >= E.v) { E = lH; E.v = x; psp = psp ? 1u : 0u; } else psp &= 3u;
                     E.v += gep;
-                    if (E.v >= val_of(mxk)) mxk = K_E;
+                    if (E.v >= (DAGP ? val_of(mxk) : (mxk == K_H ? H.v : F.v))) mxk = K_E;
                     if (DAGP) {                                     // Horizontal2
                         const int x2 = lH.v + lgop;
                         if (x2 >= E2.v) { E2 = lH; E2.v = x2; if (prev_psp) psp |= 2u; } else psp |= (prev_psp & 2u);
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                 if (on) {
                     L.hv[q] = H.v; L.hu[q] = H.u; L.hl[q] = H.l; L.hm[q] = H.m; L.hk[q] = H.k;
                     L.fv[q] = F.v; L.fu[q] = F.u; L.fl[q] = F.l; L.fm[q] = F.m; L.fk[q] = F.k;
-                    if (DAGP) { const int q2 = DAGP ? q : 0; L.gv[q2] = F2.v; L.gu[q2] = F2.u; L.gl[q2] = F2.l; L.gm[q2] = F2.m; L.gk[q2] = F2.k; }
+                    if constexpr (DAGP) { L.gv[q] = F2.v; L.gu[q] = F2.u; L.gl[q] = F2.l; L.gm[q] = F2.m; L.gk[q] = F2.k; }
                 }
             }
             WAVE_SYNC();

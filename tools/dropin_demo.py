@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--gpu-threads", type=int, default=64)
     ap.add_argument("--modes", default="Q7,Q4")
     ap.add_argument("--strand", default="-S1")
+    ap.add_argument("--extra", default="", help="further options for both programs, e.g. -yl3 (double affine gaps)")
     ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")
     args = ap.parse_args()
     rng = np.random.default_rng(synth.SEED + 8800)
@@ -63,7 +64,7 @@ def main():
         genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
     n_chr = 4
     per = args.genes // n_chr
-    out = {"queries": args.queries, "genes": args.genes, "query_type": "protein" if args.protein else "cDNA", "runs": []}
+    out = {"queries": args.queries, "genes": args.genes, "query_type": "protein" if args.protein else "cDNA", "extra": args.extra, "runs": []}
     with tempfile.TemporaryDirectory(prefix="spdp_dropin_") as td:
         tot = 0
         with open(os.path.join(td, "gnm.mfa"), "w") as f:
@@ -94,7 +95,7 @@ def main():
             run = {"mode": "-" + mode}
             res = {}
             for name, exe, thr in (("reference", "spaln", args.threads), ("gpu", "spaln_gpu", args.gpu_threads)):
-                cmd = [os.path.join(REF, exe), "-" + mode] + ([] if args.protein else [args.strand]) + ["-O4", f"-t{thr}", "-dgnm", "q.fa"]
+                cmd = [os.path.join(REF, exe), "-" + mode] + ([] if args.protein else [args.strand]) + args.extra.split() + ["-O4", f"-t{thr}", "-dgnm", "q.fa"]
                 t0 = time.perf_counter()
                 r = subprocess.run(cmd, cwd=td, env=env, capture_output=True, text=True)
                 dt = time.perf_counter() - t0

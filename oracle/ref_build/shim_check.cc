@@ -161,7 +161,7 @@ static void print_skl(const char* tag, const SKL* s)
 
 int main(int argc, const char** argv)
 {
-	int	seeded_q = 0, crs = -1, local = 0, alg = 2;
+	int	seeded_q = 0, crs = -1, local = 0, alg = 2, ls = 2;
 	long	vmfspace = 0;
 	while (argc > 3 && argv[1][0] == '-') {		// -Q n, -X crs, -L, -C, -V space: as ref_dump's options of the same name
 	    const char c = argv[1][1];
@@ -172,10 +172,11 @@ int main(int argc, const char** argv)
 	    else if (c == 'X') crs = atoi(argv[2]);
 	    else if (c == 'V') vmfspace = atol(argv[2]);
 	    else if (c == 'A') alg = atoi(argv[2]);
+	    else if (c == 'l') ls = atoi(argv[2]);		// alprm.ls: 3 = double affine gaps (-yl3)
 	    else break;
 	    argv += 2; argc -= 2;
 	}
-	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] [-A n] [-X crs] [-L | -C] [-V space] genome.fa query.fa\n"); return 2; }
+	if (argc != 3) { fprintf(stderr, "usage: shim_check [-Q n] [-A n] [-l ls] [-X crs] [-L | -C] [-V space] genome.fa query.fa\n"); return 2; }
 	g_ctx = spdp_create(0);
 	if (!g_ctx) { fprintf(stderr, "shim_check: no HIP device\n"); return 3; }
 const	char*	files[2] = {argv[1], argv[2]};
@@ -183,7 +184,7 @@ const	char*	files[2] = {argv[1], argv[2]};
 	optimize(GLOBAL, MAXIMUM);
 	algmode.qck = 0;		// -Q0
 	algmode.blk = 0;
-	alprm.ls = 2;
+	alprm.ls = ls;
 	if (local) algmode.lcl |= 16;
 	if (local == 3) algmode.lcl |= 32;
 	if (crs >= 0) algmode.crs = crs;

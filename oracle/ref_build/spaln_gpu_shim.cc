@@ -52,7 +52,7 @@ std::vector<Req*>	g_parked;
 bool			g_leader = false;
 SpdpContext*		g_ctx = 0;
 std::vector<int16_t>	g_ipen;			// IntronPenalty::Penalty(len), as long as the longest window so far
-std::atomic<long>	g_calls[6], g_batches, g_largest;
+std::atomic<long>	g_calls[6], g_batches, g_largest, g_us[2], g_seed[11];
 int			g_max_batch = 256, g_wait_us = 300;
 
 // SPALN_GPU_DEBUG=1: a backtrace on SIGSEGV (the box has no debugger) and a line per stage
@@ -71,6 +71,12 @@ void report()
 	fprintf(stderr, "[spaln_gpu] alignS_ng on the device: %ld plain, %ld seeded, %ld score-only; alignH_ng: %ld plain, %ld seeded; "
 		"left to the reference: %ld; %ld library calls, largest batch %ld\n", g_calls[0].load(), g_calls[1].load(), g_calls[2].load(),
 		g_calls[4].load(), g_calls[5].load(), g_calls[3].load(), g_batches.load(), g_largest.load());
+	fprintf(stderr, "[spaln_gpu] cDNA batches: %.2f s turning Seq / Exinon into the arrays of include/spdp.h, %.2f s inside the library\n",
+		g_us[0].load() * 1e-6, g_us[1].load() * 1e-6);
+	if (g_seed[5].load())
+	    fprintf(stderr, "[spaln_gpu] seeded calls: upload %.2f s, walks alone %.2f s, device batches %.2f s (%ld batches, %ld lspS_ng, %ld tracebacks), "
+		"hand-back %.2f s, in all %.2f s; Wilip through the callback %ld\n", g_seed[6].load() * 1e-6, g_seed[7].load() * 1e-6, g_seed[8].load() * 1e-6,
+		g_seed[0].load(), g_seed[1].load(), g_seed[2].load(), g_seed[9].load() * 1e-6, g_seed[10].load() * 1e-6, g_seed[4].load());
 }
 
 int units_cb(void* user, int32_t q, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
@@ -156,6 +162,7 @@ void run_kind(std::vector<Req*>& rq, int kind)
 	if (rq.empty()) return;
 	if (kind >= 3) { run_kind_h(rq, kind); return; }
 const	int n = (int) rq.size();
+const	auto t0 = std::chrono::steady_clock::now();
 	SpdpScoring sc;
 	fill_scoring(sc, rq[0]->pwd, rq[0]->seqs[1]);
 	int	longest = 0;
@@ -175,6 +182,7 @@ const	    int from = (int) g_ipen.size();
 	sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
 	std::vector<SpdpAlignment> al(n);
 	int rc = 0;
+const	auto t1 = std::chrono::steady_clock::now();
 	if (kind == 2) {
 	    std::vector<int32_t> scr(n);
 	    rc = spdp_homscore_s(g_ctx, &sc, probs.data(), n, scr.data());
@@ -201,8 +209,14 @@ const		    JUXT& t = b->jxt[j];
 	    SpdpHspSource src = {rq.data(), units_cb, 0};
 	    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), &src, al.data());
 	    if (rc > 0) rc = 0;
+	    int64_t st[11] = {0};
+	    spdp_seeded_stats(g_ctx, st, 11);
+	    for (int k = 0; k < 11; ++k) g_seed[k] += st[k];
 	}
 	if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
+const	auto t2 = std::chrono::steady_clock::now();
+	g_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+	g_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
 	if (kind != 2) {
 	    for (int i = 0; i < n; ++i) { rq[i]->scr = al[i].score; rq[i]->skl = to_skl(al[i], rq[i]->seqs[0]); }
 	    spdp_free_alignments(al.data(), n);

@@ -99,6 +99,8 @@ def main():
                 t0 = time.perf_counter()
                 r = subprocess.run(cmd, cwd=td, env=env, capture_output=True, text=True)
                 dt = time.perf_counter() - t0
+                if name == "gpu" and os.environ.get("DROPIN_STDERR"):          # (tuning: what the library says under SPDP_SEED_VERBOSE)
+                    open(os.environ["DROPIN_STDERR"], "a").write(r.stderr)
                 if r.returncode != 0:
                     run[name] = {"error": r.stderr[-400:], "rc": r.returncode, "stdout_tail": r.stdout[-200:]}
                     continue
@@ -107,7 +109,7 @@ def main():
                 run[name] = {"wall_s": round(dt, 3), "threads": thr, "aligned": sum(1 for b in rec if "\n@" in "\n" + b),
                              "md5_sorted_records": hashlib.md5("\n".join(rec).encode()).hexdigest(),
                              "md5_raw": hashlib.md5(r.stdout.encode()).hexdigest()}
-                m = re.search(r"\[spaln_gpu\][^\n]*", r.stderr)
+                m = re.search(r"\[spaln_gpu\] alignS[^\n]*(\n\[spaln_gpu\] [^\n]*)*", r.stderr)
                 if m:
                     run[name]["shim"] = m.group(0)
             if "reference" in res and "gpu" in res:

@@ -5,7 +5,7 @@ oracle/_ref/shim_check -Q n runs the reference's geneorient() + alignS_ng / alig
 spdp_align_s_seeded / spdp_align_h_seeded with the reference's own Wilip behind the HSP callback.
 No fixture in between: each case is one comparison of the product with the reference itself.
 
-    python tools/gpu_shim_fuzz.py 200 [first_seed] [s | h | sp | hp]
+    python tools/gpu_shim_fuzz.py 200 [first_seed] [s | h | sp | hp | s3 | sp3 | c2 | c2w]
 
 c2: BASELINE's headline shape (2 kb cDNA against its locus +- 1 kb), alternately -A0 without seeding (the reference's
 exact engines are reliable at that size, its int16 ones are not) and -Q7 under -A2 (the DP calls between HSPs stay below the
@@ -31,6 +31,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     mode = sys.argv[3] if len(sys.argv) > 3 else "s"
+    dagp = mode.endswith("3") and not mode.startswith("c2")    # s3 / sp3: the same cases under -yl3 (double affine gaps), -A0 engines
+    if dagp:
+        mode = mode[:-1]
     protein, plain = mode.startswith("h"), mode.endswith("p")
     tally = {}
     with tempfile.TemporaryDirectory() as td:
@@ -60,7 +63,9 @@ def main():
                 else:
                     i += 2 if i + 1 < len(opts) and not opts[i + 1].startswith("-") else 1
             if plain:
-                keep += ["-A", str(seed % 4)]
+                keep += ["-A", "0" if dagp else str(seed % 4)]
+            if dagp:
+                keep += ["-l", "3"] + ([] if plain else ["-A", "0"])
             synth.write_fasta(gf, "win", w)
             synth.write_fasta(qf, "qry", q)
             try:

@@ -10,6 +10,9 @@ q = fx["prm"]
 sc = spdg.scoring(fx, scalar_engines=1)
 eng = engine.Engine(0)
 extra = dict(cano5=fx["cano5"], cano3=fx["cano3"], dinc=(fx["dinc5"].astype("uint8") << 4) | fx["dinc3"].astype("uint8"))
+import sys as _s
+if len(_s.argv) > 1 and _s.argv[1] == "nosites":            # no GT / AG anywhere: the step without donor / acceptor work
+    extra["cano5"] = np.zeros_like(fx["cano5"]); extra["cano3"] = np.zeros_like(fx["cano3"])
 for rows in (30, 100):
     for n in (1, 64):
         ps = abi.ProblemSet()
@@ -19,4 +22,8 @@ for rows in (30, 100):
         for what, f in (("forward", lambda: eng.scalar_forward(sc, ps)), ("scorealone", lambda: eng.scalar_scorealone(sc, ps))):
             f()
             t = time.perf_counter(); f(); f(); dt = (time.perf_counter() - t) / 2
+            if os.environ.get("SPDP_DBG_CNT"):                 # (a build with the event counters of DESIGN 6f; not in the shipped library)
+                import ctypes as C
+                c = (C.c_ulonglong * 8)(); eng.lib.spdp_dbg_counters(c, 1)
+                print("   steps, AG steps, AG+candidate, screen passed, raised, lanes in block, candidates in block:", list(c)[:7])
             print(f"rows {rows} x cols {q['b_right']}, {n} problem(s), {what}: {dt * 1e3:.1f} ms = {dt / q['b_right'] * 1e6:.2f} us per column")

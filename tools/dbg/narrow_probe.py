@@ -25,5 +25,5 @@ for rows in (30, 100):
             if os.environ.get("SPDP_DBG_CNT"):                 # (a build with the event counters of DESIGN 6f; not in the shipped library)
                 import ctypes as C
                 c = (C.c_ulonglong * 8)(); eng.lib.spdp_dbg_counters(c, 1)
-                print("   steps, AG steps, AG+candidate, screen passed, raised, lanes in block, candidates in block:", list(c)[:7])
+                print("   counters:", [int(x) >> 10 for x in list(c)[:7]])
             print(f"rows {rows} x cols {q['b_right']}, {n} problem(s), {what}: {dt * 1e3:.1f} ms = {dt / q['b_right'] * 1e6:.2f} us per column")

@@ -764,7 +764,8 @@ int DevRun::launch()
     // the fp32-issue form of the sweep (spdp_sweep_fp.hip) where it applies: non-local score-only / linear-space runs
     // whose scores stay inside the exact fp32 integer range; SPDP_FP=0 keeps everything on spdp_kernels.hip
     bool done = false;
-    if (fp_ok && flavour != 1 && !store->sc.local) {
+    const bool fp_fwd = !(getenv("SPDP_FP_FWD") && atoi(getenv("SPDP_FP_FWD")) == 0);       // SPDP_FP_FWD=0: the traceback sweep stays on spdp_kernels.hip
+    if (fp_ok && (flavour != 1 || fp_fwd) && !store->sc.local) {
         const hipError_t e = spdp_launch_sweep_fp(flavour, 0, store->sc.spj ? 1 : 0, nq, pen_cap, store->sc.llmt, &A, grid, wpb, strm());
         if (e == hipSuccess) done = true;
         else if (e != hipErrorNotSupported) HIPCHK(e);

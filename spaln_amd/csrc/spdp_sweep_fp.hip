@@ -115,8 +115,11 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int FL, int WPB, bool CROSS, bool SPJ>
 __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
 {
-    static_assert(FL == FL_SCORE || FL == FL_UDH, "traceback flavour: spdp_kernels.hip");
+    // FL_FORWARD (round 4): the traceback flavour -- one code byte per cell in the layout spdp_walk reads (spdp_kernels.hip:
+    // 256 bytes per block of 16 steps, 16 per lane) -- on this kernel's step; local ends stay with spdp_kernels.hip
     constexpr bool UDH = FL == FL_UDH;
+    constexpr bool FWD = FL == FL_FORWARD;
+    enum { TB_DIAG = 1, TB_HORI = 2, TB_VERT = 8, TB_ACCR = 14, TB_NHOR = 16, TB_NVER = 32, TB_DONR = 128 };      // as spdp_kernels.hip:36
     constexpr int BW = UDH ? 4 : 2;                     // dwords per boundary entry
     // LDS layout, bank by bank (64 banks of 4 B; ds_read_b32 sees 32): SQ_LDS_BANK_CONFLICT was 56 % of the LDS
     // cycles of the first version of this kernel, and the LDS array was busy 71 % of the time.
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
 
     const int n_stripes = (a_right - a_left + SPDP_NELEM - 1) / SPDP_NELEM;
     const int n_passes = (n_stripes + 3) >> 2;
+    int64_t tb_base = P.tb_off;                         // forward: byte offset of the pass' first stripe
     constexpr int BIGB = 1 << 20;                       // progress word = pass * BIGB + blocks done
     const int prod = (w + W - 1) % W;                   // wave running the pass before mine
     bool dead = false;                                  // CROSS: a producer never showed up
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
         const int j8 = j9 - 1;
         const int n_start = max(b_left, lw + ml);
         const int n9 = min(b_right, up + (ml + j9) + 1) + j9;
-        const int n_end = n9;
+        const int n_end = FWD ? n9 + 1 : n9;
         const int len = has ? max(0, n_end - n_start) : 0;
         const int nb = (len + 15) >> 4;
         // blocks this pass runs: row g is active for blocks [LAG*g, LAG*g + nb)
@@ -293,6 +297,11 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                   nb2 = __builtin_amdgcn_readlane(nb, 32), nb3 = __builtin_amdgcn_readlane(nb, 48);
         const int tot = max(max(nb0, SPDP_GROUP_LAG + nb1),
                             max(2 * SPDP_GROUP_LAG + nb2, 3 * SPDP_GROUP_LAG + nb3));
+        int64_t my_tb = 0;
+        if constexpr (FWD) {
+            my_tb = tb_base + 256ll * ((g > 0 ? nb0 : 0) + (g > 1 ? nb1 : 0) + (g > 2 ? nb2 : 0));
+            tb_base += 256ll * (nb0 + nb1 + nb2 + nb3);
+        }
         // UDH: the reference walks its intermediates in order and tests, per stripe, only the
         // current one (src/fwd2s1_wip_simd.h:527,806-811): replay that pointer over my 4 stripes
         int imd_i = -1, k8 = -1;
@@ -443,6 +452,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                     // LDS operands are read ahead of the step that uses them: the matrix column offset three steps, the
                     // substitution score two, signals, feed entry and penalty entry one
                     int bofv[16]; float pvv[16]; float2 sgv[16]; int4 fdv[16];
+                    uint32_t code4[4] = {0, 0, 0, 0};               // FWD: the 16 code bytes of my steps of this block
                     auto ld_feed = [&](int j) {
                         if constexpr (UDH) return reinterpret_cast<const int4*>(feed)[j];
                         else { const int2 v = reinterpret_cast<const int2*>(feed)[j]; return make_int4(v.x, v.y, 0, 0); }
@@ -473,9 +483,20 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                         /* horizontal gap: extend, or open from my H of the previous step */                 \
                         const float ee = E + gef;                                                            \
                         if constexpr (UDH) ec = (ee > Hg) ? ec : Cs;                                         \
+                        unsigned code = 0;                                                                   \
+                        if constexpr (FWD) code = (ee > Hg) ? 0u : (unsigned) TB_NHOR;                       \
                         E = fmaxf(ee, Hg);                                                                   \
                         float h; int hc = Cd, pb3 = 0;                                                       \
-                        if constexpr (UDH) {                                                                 \
+                        if constexpr (FWD) {                                                                 \
+                            /* my F was opened (not extended) iff it equals the gap opened from the H above */ \
+                            code |= (fin > fmaxf(upH + gnf, FLOORF)) ? 0u : (unsigned) TB_NVER;              \
+                            h = fmaxf(Hd + pv, FLOORF);                                                      \
+                            const bool c1 = fin > h;                                                         \
+                            h = fmaxf(h, fin);                                                               \
+                            const bool c2 = E > h;                                                           \
+                            h = fmaxf(h, E);                                                                 \
+                            code |= c2 ? (unsigned) TB_HORI : (c1 ? (unsigned) TB_VERT : (unsigned) TB_DIAG); \
+                        } else if constexpr (UDH) {                                                          \
                             h = fmaxf(Hd + pv, FLOORF);                                                      \
                             const bool c1 = fin > h;                                                         \
                             hc = c1 ? fcin : hc; h = fmaxf(h, fin);                                          \
@@ -491,13 +512,22 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                             float x = fmaxf(hv2 + sg2.y + ptc.x, FLOORF) + ptc.y;                            \
                             x = don_prev ? NEVF : x;                                                         \
                             if constexpr (UDH) { is_acc = x > h; hc = is_acc ? hc2 : hc; }                   \
+                            if constexpr (FWD) { is_acc = x > h; code = is_acc ? ((code & ~15u) | (unsigned) TB_ACCR) : code; } \
                             h = fmaxf(h, x);                                                                 \
-                            const float qd = h + sg2.x;                                                      \
+                            /* (forward flavour: a cell entered through an acceptor is no donor, spdp_kernels.hip) */ \
+                            const float qd = (FWD && is_acc) ? NEVF : h + sg2.x;                             \
                             is_don = qd > hv2;                                                               \
                             hv2 = fmaxf(hv2, qd);                                                            \
                             if constexpr (UDH) hc2 = is_don ? hc : hc2;                                      \
                             hil8 = is_don ? 8 : hil_n;                                                       \
                             ptc = pt_n; don_prev = is_don;                                                   \
+                            if constexpr (FWD) code |= is_don ? (unsigned) TB_DONR : 0u;                     \
+                        }                                                                                    \
+                        if constexpr (FWD) {                                                                 \
+                            if constexpr (PARTIAL) { if (k >= j9) code = 0; }                                \
+                            /* packed at once: left to the compiler the sixteen bytes are combined after the last step and */ \
+                            /* everything they depend on stays live till then (212 registers instead of 96) */ \
+                            asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(code4[J >> 2]) : "v"(code), "n"(8 * (J & 3))); \
                         }                                                                                    \
                         int fl = fcin;                                  /* link of my F */                   \
                         if constexpr (UDH && IMD) {                                                          \
@@ -538,6 +568,10 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                         }
                         st_p += 16 * BW;
                         lbm = lbm == 32 ? 0 : lbm + 16;
+                    }
+                    if constexpr (FWD) {
+                        uint4* dst = reinterpret_cast<uint4*>(A.tb + my_tb + 256ll * lb + 16 * k);
+                        *dst = make_uint4(code4[0], code4[1], code4[2], code4[3]);
                     }
                 }
                 // boundary entries are exchanged between the rows of this wave through memory: a load issued after a
@@ -652,12 +686,13 @@ static hipError_t launch_fp(dim3 grd, int wpb, hipStream_t stream, const SweepAr
 extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int nquant, int pen_cap, int llmt,
                                            const SweepArgs* args, int grid, int wpb, hipStream_t stream)
 {
-    if (local || flavour == FL_FORWARD) return hipErrorNotSupported;
+    if (local) return hipErrorNotSupported;
     const int cap = nquant > 1 ? pen_cap : 0;
     if (spj && (llmt < 1 || (cap > llmt + 1 ? cap : llmt + 1) >= SPDP_FPEN_TAB)) return hipErrorNotSupported;
     const int blk = wpb == 16 ? 16 : 4;
     const dim3 grd(grid);
     if (flavour == FL_SCORE) return spj ? launch_fp<FL_SCORE, true>(grd, blk, stream, *args) : launch_fp<FL_SCORE, false>(grd, blk, stream, *args);
     if (flavour == FL_UDH) return spj ? launch_fp<FL_UDH, true>(grd, blk, stream, *args) : launch_fp<FL_UDH, false>(grd, blk, stream, *args);
+    if (flavour == FL_FORWARD) return spj ? launch_fp<FL_FORWARD, true>(grd, blk, stream, *args) : launch_fp<FL_FORWARD, false>(grd, blk, stream, *args);
     return hipErrorInvalidValue;
 }

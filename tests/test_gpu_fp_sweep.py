@@ -47,7 +47,8 @@ def test_fp_sweep_equals_int_sweep_engines(shape):
         with _Env(SPDP_FP=fp):
             s = eng.wip_scoreonly(sc, ps)
             us, ucpos, urng = eng.wip_udh(sc, ps, 5)
-            out[fp] = (s.tolist(), us.tolist(), ucpos.tolist(), urng.tolist())
+            fw = [(int(r[0]), r[1].tolist()) for r in eng.wip_forward(sc, ps)]      # (the traceback flavour: round 4)
+            out[fp] = (s.tolist(), us.tolist(), ucpos.tolist(), urng.tolist(), fw)
     eng.close()
     assert out[0] == out[1]
 
@@ -72,7 +73,8 @@ def test_fp_sweep_equals_int_sweep_variants(variant):
         with _Env(SPDP_FP=fp):
             s = eng.wip_scoreonly(sc, ps)
             us, ucpos, urng = eng.wip_udh(sc, ps, 3)
-            out[fp] = (s.tolist(), us.tolist(), ucpos.tolist(), urng.tolist())
+            fw = [(int(r[0]), r[1].tolist()) for r in eng.wip_forward(sc, ps)]
+            out[fp] = (s.tolist(), us.tolist(), ucpos.tolist(), urng.tolist(), fw)
     eng.close()
     assert out[0] == out[1]
 
@@ -91,6 +93,11 @@ def test_fp_sweep_ladder_and_chunks():
     eng.close()
     assert res["int"] == res["fp"]
     assert res["fp"] == res["fp3"]
+    with _Env(SPDP_FP=1, SPDP_FP_FWD=0, SPDP_CHUNKS=1):                           # fp sweeps, the traceback sweep on spdp_kernels.hip
+        eng2 = engine.Engine(0)
+        mixed = [(s, skl.tolist()) for s, skl in eng2.align_s(sc, ps)]
+        eng2.close()
+    assert mixed == res["fp"]
     assert sum(1 for s, skl in res["fp"] if len(skl) > 3) > 360
 
 

@@ -42,10 +42,11 @@ HBM_PEAK_GBS = 8000.0
 # fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
 # profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
 # same kind of profile: fp32-issue UDH sweep 45.0 / 64 (profiles/r03_valu_pmc.txt: 4.419e11 over the six launches = three
-# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 63.4 / 64 (7.406e10, same run; round 2: 69.6), protein sweep 152.3 / 64
+# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 59.1 / 64 (round 4, on the fp32-issue kernel: profiles/r04_valu_pmc.txt, 2.3006e11 over the forty launches = ten
+# steps of that run; round 3, spdp_sweep<FL_FORWARD>: 63.4, round 2: 69.6), protein sweep 152.3 / 64
 # (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 4.41891e11 / 3 / 2.0941e11, "forward": 7.40618e10 / 3 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
+VALU_PER_CELL = {"udh": 4.41891e11 / 3 / 2.0941e11, "forward": 2.30060e11 / 10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
                  "a0_udh": 1.2802e10 / 2.05e9}      # (--engines a0: profiles/r02_a0_sq_counters.txt)
 # HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
 # chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes, summed over the six launches of that run
@@ -981,7 +982,7 @@ def main():
                          "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r03_hbm_traffic_pmc.txt") +
                                            " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
                          "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
-                                   ("spdp_sweep<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
+                                   ("spdp_sweep_fp<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
                          "valu": (_valu_roofline(udh_cells, "a0_udh", k_ms) if args.engines == "a0" else None) if exact
                                  else _valu_roofline(k_cells, k_name, k_ms),
                          "note": ("exact-model engines: int32 scores, per-row donor lists; latency-bound chains of exec-masked regions, the tiles of a "

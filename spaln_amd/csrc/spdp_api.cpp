@@ -640,7 +640,13 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         // cDNA): spread each over several CUs -- cross-CU pass pipelines, all blocks resident
         cross_g = 0;
         const char* cg = getenv("SPDP_CROSS");
-        if (flav == 2 && wpb == 16 && n_multi == n && n > 0 && (!cg || atoi(cg) != 0)) {
+        // (the traceback sweep too, where spdp_sweep_fp serves it: the tall slabs a long cDNA's recursion leaves, spdp_host.cpp)
+        bool fwd_cross = false;
+        if (flav == 1 && fp_ok && !(getenv("SPDP_FP_FWD") && atoi(getenv("SPDP_FP_FWD")) == 0)) {
+            const int nq = std::max(1, std::min(st->sc.nquant, SPDP_MAX_QUANT));
+            fwd_cross = spdp_sweep_fp_serves(st->sc.local ? 1 : 0, st->sc.spj ? 1 : 0, nq, nq > 1 ? st->sc.qm_len[nq - 2] + 1 : 0, st->sc.llmt) != 0;
+        }
+        if ((flav == 2 || fwd_cross) && wpb == 16 && n_multi == n && n > 0 && (!cg || atoi(cg) != 0)) {
             int max_passes = 0, min_passes = 1 << 30;
             for (int j = 0; j < n; ++j) {
                 const int stripes = (h_probs[j].a_right - h_probs[j].a_left + SPDP_NELEM - 1) / SPDP_NELEM;

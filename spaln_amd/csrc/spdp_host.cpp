@@ -529,11 +529,30 @@ struct Aligner {
         if (!ctbs.empty() && run_vmf(ctbs, 3, "forwardS_ng (cut range) traceback failed")) return -1;
         if (!xtbs.empty() && run_vmf(xtbs, 7, "forwardS1 traceback failed")) return -1;
         // all (remaining) trcbkalignS_ng calls of all queries: one forward sweep + one walk (beside the side run, if any)
+        // A few tall slabs among many short ones (the recursion on a long cDNA leaves slabs of thousands of rows whose band
+        // is narrow enough for the traceback): the launch would end with its tallest problem on the four waves of one
+        // block.  They go to the side stream as a launch of their own -- all of them tall, so each gets a 16-wave block
+        // (DevRun::build) -- beside the launch of the rest.  SPDP_SPLIT_FWD=0: one launch.
+        if (side_tbs.empty() && ctx->stream2 != nullptr && tbs.size() > 1 && !(getenv("SPDP_SPLIT_FWD") && atoi(getenv("SPDP_SPLIT_FWD")) == 0)) {
+            const int tall = 4 * 32 * SPDP_NELEM;               // >= 32 passes: DevRun::build's condition for 16-wave blocks
+            std::vector<TbItem> rest;
+            for (const TbItem& t : tbs) (t.r.ar - t.r.al >= tall ? side_tbs : rest).push_back(t);
+            if (side_tbs.empty() || rest.empty() || (int) side_tbs.size() > 2 * ctx->n_cu) side_tbs.clear();
+            else {
+                tbs.swap(rest);
+                std::vector<RunItem> items;
+                for (const TbItem& t : side_tbs) items.push_back(run_item(parent(t.job), t.r, t.w, 0));
+                side.side = true;
+                if (side.build(st, items, 1) || side.launch()) return -1;
+                lap("tall fwd build+launch");
+            }
+        }
         if (!tbs.empty()) {
             std::vector<RunItem> items;
             for (const TbItem& t : tbs) items.push_back(run_item(parent(t.job), t.r, t.w, 0));
             DevRun run;
             run.use_ctx = ctx;
+            run.beside = !side_tbs.empty();
             if (run.build(st, items, 1)) return -1;
             lap("fwd build");
             if (run.launch() || run.sync()) return -1;

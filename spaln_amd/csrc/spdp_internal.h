@@ -68,6 +68,7 @@ struct CposArgs {
 extern "C" hipError_t spdp_launch_sweep(int flavour, int local, int nquant, int pen_cap, const SweepArgs* args,
                                         int grid, int wpb, hipStream_t s);
 // spdp_sweep_fp.hip: the fp32-issue form of the score-only / linear-space sweeps; hipErrorNotSupported = use spdp_launch_sweep
+extern "C" int spdp_sweep_fp_serves(int local, int spj, int nquant, int pen_cap, int llmt);
 extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int nquant, int pen_cap, int llmt,
                                            const SweepArgs* args, int grid, int wpb, hipStream_t s);
 extern "C" hipError_t spdp_launch_walk(const WalkArgs* a, hipStream_t s);

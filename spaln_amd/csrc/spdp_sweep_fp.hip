@@ -666,7 +666,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
 template <int FL, bool SPJ>
 static hipError_t launch_fp(dim3 grd, int wpb, hipStream_t stream, const SweepArgs& A)
 {
-    if constexpr (FL == FL_UDH) {
+    if constexpr (FL == FL_UDH || FL == FL_FORWARD) {
         if (A.cross_g > 0) {
             // one problem over several CUs: every block must be resident, so this is a cooperative launch
             SweepArgs Ac = A;
@@ -682,13 +682,19 @@ static hipError_t launch_fp(dim3 grd, int wpb, hipStream_t stream, const SweepAr
     return hipGetLastError();
 }
 
+// does this kernel serve such a run (else it stays with spdp_kernels.hip)
+extern "C" int spdp_sweep_fp_serves(int local, int spj, int nquant, int pen_cap, int llmt)
+{
+    if (local) return 0;
+    const int cap = nquant > 1 ? pen_cap : 0;
+    return !(spj && (llmt < 1 || (cap > llmt + 1 ? cap : llmt + 1) >= SPDP_FPEN_TAB));
+}
+
 // returns hipErrorNotSupported when the launch has to stay with spdp_kernels.hip
 extern "C" hipError_t spdp_launch_sweep_fp(int flavour, int local, int spj, int nquant, int pen_cap, int llmt,
                                            const SweepArgs* args, int grid, int wpb, hipStream_t stream)
 {
-    if (local) return hipErrorNotSupported;
-    const int cap = nquant > 1 ? pen_cap : 0;
-    if (spj && (llmt < 1 || (cap > llmt + 1 ? cap : llmt + 1) >= SPDP_FPEN_TAB)) return hipErrorNotSupported;
+    if (!spdp_sweep_fp_serves(local, spj, nquant, pen_cap, llmt)) return hipErrorNotSupported;
     const int blk = wpb == 16 ? 16 : 4;
     const dim3 grd(grid);
     if (flavour == FL_SCORE) return spj ? launch_fp<FL_SCORE, true>(grd, blk, stream, *args) : launch_fp<FL_SCORE, false>(grd, blk, stream, *args);

@@ -117,3 +117,24 @@ def test_fp_sweep_long_query_cross_cu():
             res[fp].append((us.tolist(), ucpos.tolist(), urng.tolist()))
     eng.close()
     assert res[0] == res[1]
+
+
+def test_tall_slabs_on_the_side_stream_and_across_cus():
+    """two 50 kb cDNAs (BASELINE config 5): the recursion leaves traceback slabs of thousands of rows; they run as a launch of
+    their own beside the short ones, each as a cross-CU pass pipeline (spdp_sweep_fp<FL_FORWARD, ., CROSS>).  Same records as
+    one launch (SPDP_SPLIT_FWD=0), as 16-wave blocks (SPDP_CROSS=0), and as the int32 sweeps (SPDP_FP=0)"""
+    from spaln_amd import abi, defaults, engine, synth
+    sc = defaults.scoring()
+    ps = abi.ProblemSet()
+    # (the bench's own batch: two of its 32 queries leave a slab of 17 528 rows in a band of 13 361 diagonals)
+    for w, q, s5, s3, _ in synth.make_batch(32, seed=synth.SEED + 55, n_exons=25, mrna_len=50000, flank=1000, intron_lo=1000, intron_hi=10000):
+        ps.add(q, w, s5, s3)
+    res = {}
+    for name, env in (("default", {}), ("one_launch", dict(SPDP_SPLIT_FWD=0)), ("no_cross", dict(SPDP_CROSS=0)), ("int", dict(SPDP_FP=0))):
+        with _Env(**env):
+            eng = engine.Engine(0)
+            res[name] = [(s, skl.tolist()) for s, skl in eng.align_s(sc, ps)]
+            eng.close()
+    assert sum(1 for _, skl in res["default"] if len(skl) > 40) >= 30
+    for name in ("one_launch", "no_cross", "int"):
+        assert res[name] == res["default"], name

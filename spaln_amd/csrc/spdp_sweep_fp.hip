@@ -372,11 +372,23 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
             };
             // multi-wave: row 0 reads boundary entries of the previous pass, produced by wave `prod`;
             // local block lbn of row 0 needs its absolute blocks <= lbn + 15 flushed (3 rows x LAG + 3)
+            // CROSS: the word lives in memory, a look at it is a round trip the wave sits out.  The last value seen is kept, and
+            // a wave that has to look waits until the producer is SLACK blocks further than it needs: a look per SLACK + 1
+            // blocks instead of one per block (a pass trails its producer by up to that much more; the producer's last word,
+            // pass * BIGB, ends every wait)
+            // (only where the pipeline's skew, W x the lag between passes, is short against a pass: a launch of few tall narrow
+            // problems is bound by that chain and every block of lag counts)
+#ifndef SPDP_CROSS_SLACK
+#define SPDP_CROSS_SLACK 8
+#endif
+            const int SLACK = (CROSS && W * (16 + SPDP_CROSS_SLACK) <= nb0) ? SPDP_CROSS_SLACK : 0;
+            int seen = INT32_MIN;
             auto wait_for = [&](int lbn) {
                 if (W == 1 || pass == 0) return;
                 const int need = (pass - 1) * BIGB + lbn + 16;
+                if (CROSS && seen >= need) return;
                 long spins = 0;
-                while (__hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, PSCOPE) < need) {
+                while ((seen = __hip_atomic_load(&s_prog[prod], __ATOMIC_RELAXED, PSCOPE)) < need + SLACK) {
                     __builtin_amdgcn_s_sleep(4);
                     if constexpr (CROSS) {
                         // a producer that never comes (it left at the barrier): mark the problem, the host re-runs it
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
             for (int blk = 0; blk < tot && !dead; ++blk) {
                 if (blk + 1 < nb0) wait_for(blk + 1);
                 const int lb = blk - SPDP_GROUP_LAG * g;               // my local block number
+                uint32_t code4[4] = {0, 0, 0, 0};
                 if (lb == -1 && nb > 0) prefetch(0);                    // one block ahead of first use
                 if (lb >= 0 && lb < nb) {
                     const int n0 = n_start + lb * 16;                   // sweep step of j = 0
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                     // LDS operands are read ahead of the step that uses them: the matrix column offset three steps, the
                     // substitution score two, signals, feed entry and penalty entry one
                     int bofv[16]; float pvv[16]; float2 sgv[16]; int4 fdv[16];
-                    uint32_t code4[4] = {0, 0, 0, 0};               // FWD: the 16 code bytes of my steps of this block
+                    code4[0] = code4[1] = code4[2] = code4[3] = 0;  // FWD: the 16 code bytes of my steps of this block
                     auto ld_feed = [&](int j) {
                         if constexpr (UDH) return reinterpret_cast<const int4*>(feed)[j];
                         else { const int2 v = reinterpret_cast<const int2*>(feed)[j]; return make_int4(v.x, v.y, 0, 0); }
@@ -558,10 +571,22 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
                     STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
 #undef STEP
+                }
+                // CROSS: the progress word tells the waves of other CUs which blocks have LANDED in memory.  Waiting for this
+                // block's stores right after issuing them stalled the wave for a memory round trip per block (66 % of the
+                // resident cycles of C5's sweeps were SQ_WAIT_ANY); the word now runs one block behind: here, after the sixteen
+                // steps, the stores of the previous block have long landed and the wait is free
+                if constexpr (CROSS) {
+                    if (W > 1 && blk > 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(&s_prog[w], pass * BIGB + blk, __ATOMIC_RELAXED, PSCOPE);
+                    }
+                }
+                if (lb >= 0 && lb < nb) {
                     // ---- flush: lane i takes the bottom-row result of step j = i; it goes to the boundary array under the
                     // reference's write condition (fwd2s1_wip_simd.h:205-209)
                     {
-                        const int n = n0 + k;
+                        const int n = n_start + lb * 16 + k;
                         if (n >= fl_lo && n < fl_hi) {
                             if constexpr (UDH) st_b4<CROSS>(st_p, reinterpret_cast<const int4*>(outb)[k]);
                             else st_b2<CROSS>(st_p, reinterpret_cast<const int2*>(outb)[k]);
@@ -578,11 +603,12 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
                 // store of the same wave to the same address observes it (in-order vector memory path, loads bypass
                 // L1), so only the compiler needs a fence here
                 WAVE_ORDER();
-                if (W > 1) {                                            // publish: this block's stores are done
-                    if constexpr (CROSS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0)
-                        __hip_atomic_store(&s_prog[w], pass * BIGB + blk + 1, __ATOMIC_RELAXED, PSCOPE);
+                if constexpr (!CROSS) {
+                    if (W > 1) {                                        // publish: this block's stores are done
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0)
+                            __hip_atomic_store(&s_prog[w], pass * BIGB + blk + 1, __ATOMIC_RELAXED, PSCOPE);
+                    }
                 }
             }
             if (W > 1) {

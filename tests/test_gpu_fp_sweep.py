@@ -130,11 +130,12 @@ def test_tall_slabs_on_the_side_stream_and_across_cus():
     for w, q, s5, s3, _ in synth.make_batch(32, seed=synth.SEED + 55, n_exons=25, mrna_len=50000, flank=1000, intron_lo=1000, intron_hi=10000):
         ps.add(q, w, s5, s3)
     res = {}
-    for name, env in (("default", {}), ("one_launch", dict(SPDP_SPLIT_FWD=0)), ("no_cross", dict(SPDP_CROSS=0)), ("int", dict(SPDP_FP=0))):
+    for name, env in (("default", {}), ("one_launch", dict(SPDP_SPLIT_FWD=0)), ("no_cross", dict(SPDP_CROSS=0)), ("int", dict(SPDP_FP=0)),
+                      ("gave_up", dict(SPDP_CROSS_TEST_SHORT=1))):       # a block of every cross-CU launch never arrives: the launches are repeated
         with _Env(**env):
             eng = engine.Engine(0)
             res[name] = [(s, skl.tolist()) for s, skl in eng.align_s(sc, ps)]
             eng.close()
     assert sum(1 for _, skl in res["default"] if len(skl) > 40) >= 30
-    for name in ("one_launch", "no_cross", "int"):
+    for name in ("one_launch", "no_cross", "int", "gave_up"):
         assert res[name] == res["default"], name

@@ -304,6 +304,11 @@ int spdp_align_s_seeded_ori3(SpdpContext* ctx, const SpdpScoring* sc, const Spdp
  * [2] trcbkalignS_ng requests, [3] of those with a cut range, [4] Wilip calls, [5] walks; microseconds: [6] upload of the
  * inputs, [7] the walks' host code (device idle), [8] device batches (walks asleep), [9] handing results back, [10] the call */
 int spdp_seeded_stats(const SpdpContext* ctx, int64_t* out, int n);
+/* launches this context had to repeat since the last reset: out[0] a cross-CU pass group that did not find all its
+ * blocks resident (a cooperative launch beside another kernel), out[1] a tile pipeline of the -A0 / -A1 engines whose
+ * predecessor never arrived.  Results are unaffected (the launch runs again without the pipeline); a non-zero count is
+ * time lost. */
+void spdp_rerun_stats(SpdpContext* ctx, int64_t* out, int reset);
 
 /* stdskl (m_unit 1) / stdskl3 (m_unit 3), src/gaps.cc:140-227: corner list of n path records in any order;
  * out[] needs 2 n + 1 entries, returns the number written.  Host only (no device work). */

@@ -240,6 +240,8 @@ def make_scoring(*, mtx, mtx_dim, gop, gep, lgop=0, lgep=0, noll=2, spj=1, llmt=
     sc.scalar_engines = int(scalar_engines)
     sc.minl = int(minl)
     sc.recursive = int(recursive)
+    if int(noll) == 3 and int(codonk1) < 1:
+        raise ValueError("noll = 3 needs codonk1 >= 1 (alprm2.k1 of the reference): the first column's GapPenalty(1) depends on it")
     sc.codonk1 = int(codonk1)
     if sigmodel is not None:
         sc._keep_sigmodel = sigmodel

@@ -241,6 +241,9 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
         ctx->err = "double affine gaps (Noll = 3) are built for the -A0 engines only (SpdpScoring.scalar_engines = 1); Noll must be 2 or 3";
         return -1;
     }
+    // GapPenalty(1) of the first column is BasicGOP + BasicGEP only while codonk1 >= 1 (src/aln.h:275-282); a caller that leaves
+    // the field 0 would silently get scores that are not the reference's
+    if (sc.noll == 3 && sc.codonk1 < 1) { ctx->err = "Noll = 3 needs SpdpScoring.codonk1 >= 1 (alprm2.k1 of the reference)"; return -1; }
     if (sc.mtx_dim < 1 || sc.mtx_dim > 32) { ctx->err = "mtx_dim out of range"; return -1; }
     a_off.resize(n); col_off.resize(n); a_len.resize(n); b_len.resize(n);
     int64_t a_tot = 0, col_tot = 0;
@@ -796,6 +799,13 @@ int DevRun::launch()
     return 0;
 }
 
+extern "C" void spdp_rerun_stats(SpdpContext* ctx, int64_t* out, int reset)
+{
+    if (!ctx || !out) return;
+    out[0] = ctx->rerun_stats[0]; out[1] = ctx->rerun_stats[1];
+    if (reset) ctx->rerun_stats[0] = ctx->rerun_stats[1] = 0;
+}
+
 int DevRun::sync()
 {
     HIPCHK(hipStreamSynchronize(strm()));
@@ -809,6 +819,8 @@ int DevRun::sync()
         bool gave_up = false;
         for (int j = 0; j < n; ++j) gave_up = gave_up || words[per * j + per - 1] != 0;
         if (gave_up) {
+            ++ctx->rerun_stats[0];
+            if (getenv("SPDP_TRACE_RUNS")) fprintf(stderr, "[spdp run] a cross-CU group was not resident%s: launch repeated without the groups\n", side ? " (side stream, beside another launch)" : "");
             cross_g = 0; wpb = 16;
             if (launch()) return -1;
             HIPCHK(hipStreamSynchronize(strm()));
@@ -819,6 +831,7 @@ int DevRun::sync()
         int mark[2] = {0, 0};
         HIPCHK(spdp_copy_sync(mark, (int*) d_gprog + (size_t) n * pipe_stride, sizeof mark, hipMemcpyDeviceToHost, strm()));
         if (mark[1] != 0 || getenv("SPDP_A0_PIPE_TEST_STALL")) {
+            ++ctx->rerun_stats[1];
             pipe_on = false;
             if (launch()) return -1;
             HIPCHK(hipStreamSynchronize(strm()));

@@ -92,11 +92,39 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
         v.pat_off[k] = at;
         at += 3 + 2 * d->bitpat[at];
     }
-    // posting lists must stay inside blkb: a malformed index would send lanes out of bounds
+    // everything the kernel later uses as an INDEX is checked here, once, on the host: a mismatched or corrupt index would
+    // otherwise write into other lanes' score slabs without a sign
+    // posting lists must stay inside blkb
     for (int64_t w = 0; w < d->tabsize; ++w)
         if (d->blkp[w] && ((int64_t) d->blkp[w] - 1 + d->nblk[w] > d->n_words || d->blkp[w] < 0)) {
             ctx->err = "spdp_blk_index_create: a posting list runs past blkb"; delete ix; return nullptr;
         }
+    // block numbers index the per-lane slabs (acr[blk], rscr[blk])
+    for (int64_t i = 0; i < d->n_words; ++i)
+        if ((int64_t) d->blkb[i] >= (int64_t) d->nseg) {
+            ctx->err = "spdp_blk_index_create: a block number in blkb is not below nseg"; delete ix; return nullptr;
+        }
+    // words index blkp / wscr / nblk: the table must have nalpha ^ weight entries for every pattern; exam offsets stay inside the pattern
+    for (int k = 0; k < d->kk; ++k) {
+        const int32_t* bp = d->bitpat + v.pat_off[k];
+        const int weight = bp[0], width = bp[1];
+        int64_t words = 1;
+        for (int i = 0; i < weight && words <= (int64_t) d->tabsize; ++i) words *= d->nalpha;
+        if (words != (int64_t) d->tabsize || width < weight) {
+            ctx->err = "spdp_blk_index_create: tabsize is not nalpha ^ weight of a bit pattern"; delete ix; return nullptr;
+        }
+        for (int i = 0; i < 2 * weight; ++i)
+            if (bp[3 + i] < 0 || bp[3 + i] >= width) {
+                ctx->err = "spdp_blk_index_create: an exam offset of a bit pattern lies outside its width"; delete ix; return nullptr;
+            }
+    }
+    // the chromosome table is searched by block number: first blocks ascend and stay below nseg
+    for (int c = 0; c <= d->n_chr; ++c) {
+        const int64_t fb = d->chr[2 * c + 1];
+        if (fb < 0 || fb >= d->nseg + 1 || (c && fb < d->chr[2 * c - 1])) {
+            ctx->err = "spdp_blk_index_create: the chromosome table's first blocks do not ascend inside nseg"; delete ix; return nullptr;
+        }
+    }
     hipError_t e = hipSuccess;
     v.convtab = to_device(ix, d->convtab, d->convts, e);
     v.nblk = to_device(ix, d->nblk, d->tabsize, e);

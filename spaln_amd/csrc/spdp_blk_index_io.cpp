@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <new>
 #include <vector>
 
 namespace {
@@ -88,19 +89,34 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_read(const char* path, const SpdpBlk
     if (wc.BytBlk != 2 && wc.BytBlk != 4) { fclose(f); return fail("3-byte block numbers are not read"); }
     if (wcp.Nalpha != 4) { fclose(f); return fail("not a nucleotide index"); }
     if (wcp.TabSize == 0 || wcp.TabSize > (1u << 30) || wcp.Nshift == 0 || wcp.Nshift > SPDP_BLK_MAX_SHIFT || wcp.blklen == 0 ||
-        wc.ChrNo == 0 || wc.ChrNo > (1u << 24) || wc.WordNo > (1ull << 32) || wc.ConvTS == 0 || wc.ConvTS > 256) {
+        wc.ChrNo == 0 || wc.ChrNo > (1u << 24) || wc.WordNo > (1ull << 32) || wc.WordSz > (1ull << 33) || wc.ConvTS == 0 || wc.ConvTS > 256) {
         fclose(f); return fail("header values out of range");
     }
+    if (wc.WordNo > (uint64_t) INT32_MAX) { fclose(f); return fail("more postings than a 32-bit list offset (blkp) can address"); }
     if (wcp.Ktuple == wcp.BitPat) wcp.BitPat = (1u << wcp.BitPat) - 1;
-    std::vector<FileChromo> chrid(wc.ChrNo + 1);
-    h->nblk.resize(wcp.TabSize); h->blkp.resize(wcp.TabSize); h->wscr.resize(wcp.TabSize);
-    h->blkb.resize(wc.WordNo); h->convtab.resize(wc.ConvTS);
+    {   // the header's sizes against what the file really holds, BEFORE anything is sized from them
+        const long at = ftell(f);
+        if (at < 0 || fseek(f, 0, SEEK_END) != 0) { fclose(f); return fail("cannot seek"); }
+        const long end = ftell(f);
+        if (end < at || fseek(f, at, SEEK_SET) != 0) { fclose(f); return fail("cannot seek"); }
+        const uint64_t rest = (uint64_t) (end - at);
+        const uint64_t need = ((uint64_t) wc.ChrNo + 1) * sizeof(FileChromo) + (uint64_t) wcp.TabSize * (2 + 4 + 2) +
+                              (uint64_t) wc.WordSz * 2 + wc.ConvTS;
+        if (need > rest) { fclose(f); return fail("header sizes exceed the file"); }
+    }
+    std::vector<FileChromo> chrid;
+    try {
+        chrid.resize(wc.ChrNo + 1);
+        h->nblk.resize(wcp.TabSize); h->blkp.resize(wcp.TabSize); h->wscr.resize(wcp.TabSize);
+        h->blkb.resize(wc.WordNo); h->convtab.resize(wc.ConvTS);
+    } catch (const std::bad_alloc&) { fclose(f); return fail("out of memory for the index tables"); }
     bool ok = read_all(f, chrid.data(), chrid.size() * sizeof(FileChromo)) &&
               read_all(f, h->nblk.data(), (size_t) wcp.TabSize * 2) && read_all(f, h->blkp.data(), (size_t) wcp.TabSize * 4);
     if (ok && wc.BytBlk == 4) ok = wc.WordSz == 2 * wc.WordNo && read_all(f, h->blkb.data(), wc.WordNo * 4);
     else if (ok) {
-        std::vector<uint16_t> s(wc.WordSz);
-        ok = wc.WordSz == wc.WordNo && read_all(f, s.data(), s.size() * 2);
+        ok = wc.WordSz == wc.WordNo;
+        std::vector<uint16_t> s(ok ? wc.WordSz : 0);
+        ok = ok && read_all(f, s.data(), s.size() * 2);
         for (size_t i = 0; ok && i < s.size(); ++i) h->blkb[i] = s[i];
     }
     ok = ok && read_all(f, h->wscr.data(), (size_t) wcp.TabSize * 2) && read_all(f, h->convtab.data(), wc.ConvTS);

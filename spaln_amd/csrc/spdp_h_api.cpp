@@ -700,6 +700,7 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
         std::vector<HItem> part;
         for (int i : redo) part.push_back(items[i]);
         if (run_scalar_group(st, part, forward, ro, exact, scale, cut, true)) return -1;
+        out.sweep_ms += ro.sweep_ms;                    // (the second run is part of what the call cost)
         for (size_t k = 0; k < redo.size(); ++k) { out.res[redo[k]] = ro.res[k]; out.n_skl[redo[k]] = ro.n_skl[k]; }
     }
     for (int i = 0; i < nr; ++i) {
@@ -933,6 +934,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
         HUdhOut ro;
         std::vector<int> rf;
         if (run_scalar_udh(st, part, ro, rf, engine, true)) return -1;
+        out.sweep_ms += ro.sweep_ms;
         for (size_t k = 0; k < redo.size(); ++k) {
             const int i = redo[k];
             out.scores[i] = ro.scores[k];
@@ -1196,7 +1198,7 @@ static int run_ladder(HStore& st, bool ladder, std::vector<HTop>& tops, HStats& 
             if (run.empty()) continue;
             HFwdOut fo;
             if (pass ? run_scalar(st, run, true, fo, pass == 2, pass == 3) : run_forward(st, run, true, fo)) return -1;
-            if (!pass) { hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells; }
+            hs.fwd_ms += fo.sweep_ms; hs.fwd_cells += fo.cells;            // (every engine's launches: the exact-model passes too)
             for (size_t f = 0; f < run.size(); ++f) {
                 HTop& t = tops[run[f].slot];
                 if (run[f].first) t.score = fo.res[f].score;

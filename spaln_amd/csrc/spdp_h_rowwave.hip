@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "spdp_h_dev.h"
 #include "spdp_h_internal.h"
+#include "spdp_pipe.h"
 
 namespace {
 
@@ -196,11 +197,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ Tables T;
     const DevScoringH* sc = A.sc;
     load_tables(T, A, sc);
-    int (*L)[RING] = Lw[threadIdx.x >> 6];              // L[f] = field f of H, L[NF + f] = field f of F
-    int4* const Cc = Ccol[threadIdx.x >> 6];
-    short4* const Ca = Caux[threadIdx.x >> 6];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (scalar: the problem, its ranges and its arrays stay in SGPRs)
+    int (*L)[RING] = Lw[wv];                            // L[f] = field f of H, L[NF + f] = field f of F
+    int4* const Cc = Ccol[wv];
+    short4* const Ca = Caux[wv];
     const int lane = threadIdx.x & 63;
-    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + wv;
     int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
     if (PIPE) {
         int tk = 0;
@@ -208,10 +210,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= A.n_items) return;
         const int2 it = A.items[tk];
-        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+        pi = __builtin_amdgcn_readfirstlane(it.x); t_lo = __builtin_amdgcn_readfirstlane(it.y); t_hi = t_lo + 1;
     }
     if (pi >= A.n_probs) return;
-    const DevProblemH P = A.probs[pi];
+    const DevProblemH P = wave_uniform(A.probs[pi]);
     int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width, n_im = UDH ? P.n_im : 0, intvl = P.imd_intvl;
     const int a_exgl = P.a_exgl, a_exgr = P.a_exgr, b_exgl = P.b_exgl, b_exgr = P.b_exgr;
@@ -450,8 +452,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
+                    const int* src[2 * NF]; int val[2 * NF];               // (all planes in flight together: spdp_pipe.h)
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = gld<PIPE>(G(a) + e);
+                    for (int a = 0; a < 2 * NF; ++a) src[a] = G(a);
+                    gld_n<PIPE>(src, e, val);
+#pragma unroll
+                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = val[a];
                 }
                 res_hi = max(res_hi, want);
                 // columns [S - (m0 + 63) - 3, S + CHUNK - 1 - m0 + 5] of the next CHUNK steps (CUT: their real positions,

@@ -26,25 +26,29 @@
 #include <stdint.h>
 #include "spdp_dev.h"
 #include "spdp_internal.h"
+#include "spdp_sites.h"
+#include "spdp_pipe.h"
 
 namespace {
 
 constexpr int NEV = INT32_MIN / 16 * 7;                 // NEVSEL, src/cmn.h:79
 constexpr int RING = 256;                               // diagonals resident in LDS
 constexpr int CHUNK = 32;                               // steps between two refills of the window
-constexpr int NC = 5;                                   // NCAND + 1 slots of the candidate list
 constexpr int WPB = 4;                                  // waves (= problems) per block: they share the tables below
+using sites::NC; using sites::Tables; using sites::load_tables; using sites::DEADV;
+// the linear-space kernel keeps the tables as round 2 laid them out (IntPen beyond 4096 as runs, spdp_ipen_runs.h): with them
+// three four-wave blocks fill a CU's LDS to within one allocation granule; the span form of spdp_sites.h is 2 KB larger
 constexpr int IPEN_LDS = SPDP_IPR_BASE;                 // IntPen(len) for len < this lives in LDS as it is, longer ones as runs
 
 // read-only tables every wave of a block uses
-struct Tables {
+struct TablesU {
     short mtx[32 * 32];
     short ipen[IPEN_LDS];
     short t53[256];
     IpenRuns runs;                                      // IntPen beyond the table above (spdp_ipen_runs.h)
     int gain[2];                                        // max IntPen, max junction-pair score: what an acceptor can add at most
 };
-__device__ __forceinline__ void load_tables(Tables& T, const ScalarArgs& A, const DevScoring* sc)
+__device__ __forceinline__ void load_tables_u(TablesU& T, const ScalarArgs& A, const DevScoring* sc)
 {
     if (threadIdx.x < 2) T.gain[threadIdx.x] = INT32_MIN;
     __syncthreads();
@@ -60,7 +64,7 @@ __device__ __forceinline__ void load_tables(Tables& T, const ScalarArgs& A, cons
     ipen_runs_load(T.runs, A.ipen_runs);
     __syncthreads();                                    // the only block-wide barrier: every wave reaches it
 }
-__device__ __forceinline__ int intpen_of(const Tables& T, const ScalarArgs& A, int len)
+__device__ __forceinline__ int intpen_of_u(const TablesU& T, const ScalarArgs& A, int len)
 {
     if (len < IPEN_LDS) return T.ipen[len];
     if (A.ipen_runs) return ipen_runs_get(T.runs, len, A.intpen_len);          // (kernel-uniform)
@@ -101,6 +105,43 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 }
 #define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// ---- an experiment kept behind SPDP_COLFEED (default off: measured slower).  The column records.  A lane loaded the record of its own column (two steps ahead), but any wait for such a load is a
+//     wait for EVERYTHING the wave has in flight (one in-order counter for loads and stores on gfx9), and the compiler, with
+//     stores under branches in between, waits for zero outstanding: a step paid a full memory latency.  Now the records ride
+//     down the lanes: lane k is on column c0 - k, the column lane k - 1 was on a step earlier, so each step lane 0 takes the
+//     record of the column it enters -- ONE scalar load, issued a step ahead, out of the vector memory counter altogether --
+//     and every other lane takes what the lane above it held (two DPP wave shifts).
+#ifndef SPDP_COLFEED
+#define SPDP_COLFEED 0
+#endif
+struct ColFeed {
+    int x = 0, ya = 0;                                  // my column: cols[n].x, and cols[n].y & 0xff | aux[n] << 8
+    unsigned long long rc = 0; unsigned ra = 0; int sh = 0;
+    // the record of column c (wave-uniform) is asked for ...
+    __device__ __forceinline__ void issue(const int2* cols, const uint8_t* aux, int c)
+    {
+        auto uni = [](uintptr_t a) -> uintptr_t {              // (wave-uniform by construction; said so that it sits in SGPRs)
+            return (uintptr_t) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) a) |
+                   (uintptr_t) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (a >> 32)) << 32;
+        };
+        const uintptr_t pc = uni(reinterpret_cast<uintptr_t>(cols + c));
+        const uintptr_t pa = uni(reinterpret_cast<uintptr_t>(aux) + 2 * (intptr_t) c);
+        const uintptr_t pq = pa & ~(uintptr_t) 3;
+        sh = (int) (pa & 2) * 8;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(rc) : "s"(pc));
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(ra) : "s"(pq));
+    }
+    // ... has arrived (before anything looks at rc / ra: the compiler does not know these loads are asynchronous) ...
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rc), "+s"(ra)); }
+    // ... and enters at lane 0 while every record moves one lane down
+    __device__ __forceinline__ void shift()
+    {
+        const int nx = (int) (unsigned) rc;
+        const int ny = ((int) (rc >> 32) & 0xff) | (int) (((ra >> sh) & 0xffffu) << 8);
+        x = __builtin_amdgcn_update_dpp(nx, x, 0x138, 0xf, 0xf, false);          // wave_shr:1, lane 0 keeps `old` = the new record
+        ya = __builtin_amdgcn_update_dpp(ny, ya, 0x138, 0xf, 0xf, false);
+    }
+};
 // CUT: forwardS_ng with a cut range (`cutrng`, src/fwd2s1.cc:217, 423-430; shortcutS_ng :1899-1930): a row that reaches
 // genomic column cut_l charges its horizontal gap for the cut_len columns behind it, leaves {that gap, nothing} in the
 // diagonal arrays and goes on behind the cut -- while the arrays simply keep counting, so a lane's array entry follows
@@ -120,9 +161,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ Tables T;
     const DevScoring* sc = A.sc;
     load_tables(T, A, sc);
-    Lds<DAGP>& L = Lw[threadIdx.x >> 6];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (scalar: what follows from it -- the problem, its ranges, its arrays -- stays in SGPRs)
+    Lds<DAGP>& L = Lw[wv];
     const int lane = threadIdx.x & 63;
-    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + wv;
     int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
     if (PIPE) {
         int tk = 0;
@@ -130,10 +172,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= A.n_items) return;
         const int2 it = A.items[tk];
-        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+        pi = __builtin_amdgcn_readfirstlane(it.x); t_lo = __builtin_amdgcn_readfirstlane(it.y); t_hi = t_lo + 1;
     }
     if (pi >= A.n_probs) return;
-    const DevProblem P = A.probs[pi];
+    const DevProblem P = wave_uniform(A.probs[pi]);
     const int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width;
     const int cut_l = CUT ? P.cut_l : 0, cut_len = CUT ? P.cut_len : 0;
@@ -254,6 +296,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         // anti-diagonals this tile sweeps
         int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? v_last + m : INT32_MIN;
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
+        s_lo = __builtin_amdgcn_readfirstlane(s_lo); s_hi = __builtin_amdgcn_readfirstlane(s_hi);      // (the sweep's loop is scalar)
         if (s_lo > s_hi) continue;                                  // (PIPE: published as finished below)
         const int acode = (row && m >= 1) ? acod[m - 1] : 0;
         const short* qprof = T.mtx + acode * 32;
@@ -264,10 +307,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         int e1v = NEV, e1p = 0;
         int e2v = NEV, e2p = 0;                                     // the second horizontal-gap state (Noll = 3)
         unsigned psp = 0;
-        int cv[NC], cj[NC], cd[NC], cp[NC], cx[NC];                 // candidates: value, donor column, state, pointer, dinc5
-#pragma unroll
-        for (int l = 0; l < NC; ++l) { cv[l] = NEV; cj[l] = 0; cd[l] = 0; cp[l] = 0; cx[l] = 0; }
-        int ncand = -1;
+        sites::Cands<FWD ? 2 : 0, !FWD> C;                          // the row's donor candidates (spdp_sites.h); riders: column, Vmf pointer
+        C.clear();
 
         // window of entries resident in LDS: [res_lo, res_hi)
         auto need_lo = [&](int S) { return S - 2 * (m0 + 63) - 1 - (lw - 1); };
@@ -292,9 +333,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
             for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                 const int q = e & (RING - 1);
-                L.hv[q] = gld<PIPE>(gHv + e); L.fv[q] = gld<PIPE>(gFv + e);
-                if (FWD) { L.hp[q] = gld<PIPE>(gHp + e); L.fp[q] = gld<PIPE>(gFp + e); L.dr[q] = gld<PIPE>(gDr + e); }
-                if constexpr (DAGP) { L.f2v[q] = gld<PIPE>(gF2v + e); if (FWD) L.f2p[q] = gld<PIPE>(gF2p + e); }
+                constexpr int NP = (FWD ? 5 : 2) + (DAGP ? (FWD ? 2 : 1) : 0);
+                const int* src[NP]; int val[NP];
+                src[0] = gHv; src[1] = gFv;
+                if constexpr (FWD) { src[2] = gHp; src[3] = gFp; src[4] = gDr; }
+                if constexpr (DAGP) { src[FWD ? 5 : 2] = gF2v; if constexpr (FWD) src[6] = gF2p; }
+                gld_n<PIPE>(src, e, val);
+                L.hv[q] = val[0]; L.fv[q] = val[1];
+                if constexpr (FWD) { L.hp[q] = val[2]; L.fp[q] = val[3]; L.dr[q] = val[4]; }
+                if constexpr (DAGP) { L.f2v[q] = val[FWD ? 5 : 2]; if constexpr (FWD) L.f2p[q] = val[6]; }
             }
             res_hi = max(res_hi, want);
             WAVE_SYNC();
@@ -304,18 +351,29 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (any && vv >= n_first && vv <= v_last) { const int nn = real_col(vv); c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
         };
         int2 col1 = make_int2(0, 0), col2 = make_int2(0, 0); int aux1 = 0, aux2 = 0;
-        ld_col(s_lo - m, col1, aux1);
-        ld_col(s_lo + 1 - m, col2, aux2);
+        ColFeed feed;                                               // (without a cut range: the records ride down the lanes)
+        constexpr bool OWN = CUT || !SPDP_COLFEED;                  // every lane loads its own column's record
+        if constexpr (OWN) {
+            ld_col(s_lo - m, col1, aux1);
+            ld_col(s_lo + 1 - m, col2, aux2);
+        } else { feed.issue(cols, aux, s_lo - m0); feed.arrived(); }
 
         for (int S = s_lo; S <= s_hi; ++S) {
             if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
             const int v = S - m;                                    // the column without the jump: array entry r = v - m
             const int n = real_col(v);
             const bool on = any && v >= n_first && v <= v_last;
-            const int2 col = col1; const int ax = aux1 & 0xff, adn = aux1 >> 8;
-            col1 = col2; aux1 = aux2;
-            ld_col(v + 2, col2, aux2);
-            if (__ballot(on) == 0) continue;
+            int2 col; int ax, adn;
+            if constexpr (OWN) {
+                col = col1; ax = aux1 & 0xff; adn = aux1 >> 8;
+                col1 = col2; aux1 = aux2;
+                ld_col(v + 2, col2, aux2);
+            } else {
+                feed.shift();                                       // lane k now holds column (S - m0) - k = S - m
+                feed.issue(cols, aux, S + 1 - m0);                  // lane 0's next column: at most br + 63, inside the padded records
+                col = make_int2(feed.x, feed.ya & 0xff); ax = (feed.ya >> 8) & 0xff; adn = (feed.ya >> 16) & 0xff;
+            }
+            if (__ballot(on) == 0) { if constexpr (!OWN) feed.arrived(); continue; }
             const int r = v - m;
             const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
             int hv = L.hv[q], hp = FWD ? L.hp[q] : 0, dir = FWD ? L.dr[q] : 0;     // entry r: the cell above-left
@@ -365,61 +423,38 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (FWD ? (e2v >= cur2) : (e2v > cur2)) mxk = K_E2;
                 }
             }
-            // ---- acceptor: every candidate of my row may raise the state it left from
-            // (screen: the best candidate, priced as high as anything can be, against the lowest of the three states it may
-            //  raise -- every update below is behind `x > state`, `>=` in the forward engine)
-            const bool acc = on && internal && (ax & 2) && ncand >= 0 &&
-                             cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >= min(min(hv, min(e1v, fv)), DAGP ? min(e2v, f2v) : INT32_MAX);
+            __builtin_amdgcn_sched_barrier(0);                         // (the sections of a step stay apart: what one holds in registers the next need not)
+            // ---- acceptor: every candidate of my row may raise the state it left from (src/fwd2s1.cc:330-372 / :1256-1283)
+            const bool acc = on && internal && (ax & 2) && C.any();
             if (__ballot(acc)) {
-                int sel_h = -1, sel_e = -1, sel_f = -1, sel_e2 = -1, sel_f2 = -1;
-                const int s3 = col.x >> 16, dn3 = adn & 15;
+                int x[NC];
+                if (A.ipen_runs) sites::price<true>(C, T, A, acc, n, sigB + (col.x >> 16), adn & 15, llmt, x);
+                else sites::price<false>(C, T, A, acc, n, sigB + (col.x >> 16), adn & 15, llmt, x);
+                // who raised which state: the q word of the entry (FWD: the last one that reaches the value), -1 none
+                int wh = -1, we = -1, wf = -1, we2 = -1, wf2 = -1;
 #pragma unroll
                 for (int l = 0; l < NC; ++l) {
-                    const int len = n - cj[l];
-                    if (acc && l <= ncand && len >= llmt) {
-                        const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
-                        if (cd[l] == K_H) { if (FWD ? (x >= hv) : (x > hv)) { hv = x; sel_h = l; } }
-                        else if (cd[l] == K_E) { if (FWD ? (x >= e1v) : (x > e1v)) { e1v = x; sel_e = l; } }
-                        else if (!DAGP || cd[l] == K_F) { if (FWD ? (x >= fv) : (x > fv)) { fv = x; sel_f = l; } }
-                        else if (cd[l] == K_E2) { if (FWD ? (x >= e2v) : (x > e2v)) { e2v = x; sel_e2 = l; } }
-                        else { if (FWD ? (x >= f2v) : (x > f2v)) { f2v = x; sel_f2 = l; } }
-                    }
+                    const int cd = C.q[l] & 7;
+#define SPDP_TRY(K, S, W) { const bool b_ = cd == K && (FWD ? x[l] >= S : x[l] > S); S = b_ ? x[l] : S; W = b_ ? C.q[l] : W; }
+                    SPDP_TRY(K_H, hv, wh) SPDP_TRY(K_E, e1v, we)
+                    if constexpr (DAGP) { SPDP_TRY(K_F, fv, wf) SPDP_TRY(K_E2, e2v, we2) SPDP_TRY(K_F2, f2v, wf2) }
+                    else { const bool b_ = cd >= K_F && (FWD ? x[l] >= fv : x[l] > fv); fv = b_ ? x[l] : fv; wf = b_ ? C.q[l] : wf; }
+#undef SPDP_TRY
                 }
-                auto pick = [&](int sel, int* arr) { int v = 0; _Pragma("unroll") for (int l = 0; l < NC; ++l) if (l == sel) v = arr[l]; return v; };
-                // K_H, K_E, K_F in this order, as the reference's loop over its states
-                if (__ballot(sel_h >= 0)) {
-                    const bool t = sel_h >= 0;
-                    if (t) psp |= psp_bit(K_H);
-                    if (FWD) { const int p1 = vadd(t, m, pick(sel_h, cj), pick(sel_h, cp)); const int p2 = vadd(t, m, n, p1); if (t) hp = p2; }
-                    if (t) { const int cur = val_k(mxk); if (FWD ? (hv >= cur) : (hv > cur)) mxk = K_H; }
+                // K_H, K_E, K_F in this order, as the reference's loop over its states; the two path records of an accepted
+                // intron (donor side, acceptor side) are appended under one wave-uniform test per state
+#define SPDP_TAKE(K, W, P)                                                                                      \
+                if (__ballot(W >= 0)) {                                                                         \
+                    const bool t = W >= 0;                                                                      \
+                    if (t) psp |= psp_bit(K);                                                                   \
+                    if (FWD) { const int p1 = vadd(t, m, C.rider(0, W), C.rider(1, W)); const int p2 = vadd(t, m, n, p1); if (t) P = p2; } \
+                    if (t) { const int cur = val_k(mxk); if (FWD ? (val_k(K) >= cur) : (val_k(K) > cur)) mxk = K; }    \
                 }
-                if (__ballot(sel_e >= 0)) {
-                    const bool t = sel_e >= 0;
-                    if (t) psp |= psp_bit(K_E);
-                    if (FWD) { const int p1 = vadd(t, m, pick(sel_e, cj), pick(sel_e, cp)); const int p2 = vadd(t, m, n, p1); if (t) e1p = p2; }
-                    if (t) { const int cur = val_k(mxk); if (FWD ? (e1v >= cur) : (e1v > cur)) mxk = K_E; }
-                }
-                if (__ballot(sel_f >= 0)) {
-                    const bool t = sel_f >= 0;
-                    if (t) psp |= psp_bit(K_F);
-                    if (FWD) { const int p1 = vadd(t, m, pick(sel_f, cj), pick(sel_f, cp)); const int p2 = vadd(t, m, n, p1); if (t) fp = p2; }
-                    if (t) { const int cur = val_k(mxk); if (FWD ? (fv >= cur) : (fv > cur)) mxk = K_F; }
-                }
-                if constexpr (DAGP) {
-                    if (__ballot(sel_e2 >= 0)) {
-                        const bool t = sel_e2 >= 0;
-                        if (t) psp |= psp_bit(K_E2);
-                        if (FWD) { const int p1 = vadd(t, m, pick(sel_e2, cj), pick(sel_e2, cp)); const int p2 = vadd(t, m, n, p1); if (t) e2p = p2; }
-                        if (t) { const int cur = val_k(mxk); if (FWD ? (e2v >= cur) : (e2v > cur)) mxk = K_E2; }
-                    }
-                    if (__ballot(sel_f2 >= 0)) {
-                        const bool t = sel_f2 >= 0;
-                        if (t) psp |= psp_bit(K_F2);
-                        if (FWD) { const int p1 = vadd(t, m, pick(sel_f2, cj), pick(sel_f2, cp)); const int p2 = vadd(t, m, n, p1); if (t) f2p = p2; }
-                        if (t) { const int cur = val_k(mxk); if (FWD ? (f2v >= cur) : (f2v > cur)) mxk = K_F2; }
-                    }
-                }
+                SPDP_TAKE(K_H, wh, hp) SPDP_TAKE(K_E, we, e1p) SPDP_TAKE(K_F, wf, fp)
+                if constexpr (DAGP) { SPDP_TAKE(K_E2, we2, e2p) SPDP_TAKE(K_F2, wf2, f2p) }
+#undef SPDP_TAKE
             }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- the cell's value: the best state
             const int hd = mxk;
             const int mxv = val_k(mxk);                                  // *mx
@@ -449,47 +484,31 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 if (LocalL && hv < 0) hv = 0;
                 hval_raw = hv;
             }
-            // ---- donor: the states of this cell enter my row's candidate list
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- donor: the states of this cell enter my row's candidate list (src/fwd2s1.cc:386-421 / :1297-1329)
             const bool don = on && internal && (ax & 1);
             if (__ballot(don)) {
                 const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
                 const int dn5 = adn >> 4;
                 const int mx_now = hd == K_H ? hval_raw : val_k(hd);         // *mx as it stands now
+                unsigned pend = 0;                                  // the states that ask for a place, lowest first
 #pragma unroll
                 for (int k = 0; k < NODK; ++k) {
                     const int sv = k == K_H ? hval_raw : val_k(k);
-                    const int sp = k == K_H ? hptr_raw : ptr_k(k);
                     bool t = don && k >= (hd == K_H ? 0 : 1) && !(psp & psp_bit(k));
-                    if (t && k != hd) {
-                        int z = mx_now;
-                        if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : (k / 2 == 2 ? lgop : 0);      // GOP[k / 2]
-                        if (sv <= z) t = false;                     // cannot become the better path
-                    }
-                    {   // a full list whose last kept entry holds against the newcomer: the list is NC - 1 long afterwards
-                        const int x = sv + sigJ;
-                        const bool weak = t && ncand >= NC - 2 && !(FWD ? (x > cv[NC - 2]) : (x >= cv[NC - 2]));
-                        if (weak) ncand = NC - 2;
-                        t = t && !weak;
-                    }
-                    if (__ballot(t)) {
-                        const int x = sv + sigJ;
-                        // the free slot starts below the list and moves up past every entry x beats
-                        int pos = ncand < NC - 1 ? ncand + 1 : NC - 1;
-                        const bool grew = t && ncand < NC - 1;
-                        if (grew) ++ncand;
-#pragma unroll
-                        for (int l = NC - 1; l >= 1; --l) {
-                            const bool mv = t && pos == l && (FWD ? (x > cv[l - 1]) : (x >= cv[l - 1]));
-                            if (mv) { cv[l] = cv[l - 1]; cj[l] = cj[l - 1]; cd[l] = cd[l - 1]; cp[l] = cp[l - 1]; cx[l] = cx[l - 1]; pos = l - 1; }
-                        }
-                        if (t) {
-                            if (pos < NC - 1) {
-#pragma unroll
-                                for (int l = 0; l < NC - 1; ++l)
-                                    if (l == pos) { cv[l] = x; cj[l] = n; cd[l] = k; cp[l] = sp; cx[l] = dn5; }
-                            } else --ncand;
-                        }
-                    }
+                    int z = mx_now;
+                    if (hd == K_H || ((k - hd) % 2)) z += (k / 2 == 1) ? gop : (k / 2 == 2 ? lgop : 0);      // GOP[k / 2]
+                    if (k != hd && sv <= z) t = false;              // cannot become the better path
+                    pend |= t ? 1u << k : 0u;
+                }
+                while (__ballot(pend != 0)) {
+                    const bool t = pend != 0;
+                    const int k = __ffs(pend) - 1;
+                    pend &= pend - 1;
+                    const int sv = k <= K_H ? hval_raw : val_k(k);
+                    const int sp = k <= K_H ? hptr_raw : ptr_k(k);
+                    if constexpr (FWD) { const int rid[2] = {n, sp}; C.insert(t, sv + sigJ, n, k, dn5, rid); }
+                    else { const int rid[1] = {0}; C.insert(t, sv + sigJ, n, k, dn5, rid); }
                 }
             }
             if (CUT && on && jumps && v == cut_l) {                  // the gap runs on over the cut: {gap, nothing} stay behind
@@ -498,12 +517,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 else { hv = e1v; hp = e1p; }
                 fv = NEV; fp = 0;
             }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- entry r takes the cell
             if (on) {
                 L.hv[q] = hv; L.fv[q] = fv;
                 if (FWD) { L.hp[q] = hp; L.fp[q] = fp; L.dr[q] = dir; }
                 if constexpr (DAGP) { L.f2v[q] = f2v; if (FWD) L.f2p[q] = f2p; }
             }
+            if constexpr (!OWN) feed.arrived();
         }
         // everything still resident goes back
         {
@@ -686,17 +707,20 @@ __device__ __forceinline__ St st_sel5(int k, const St& h, const St& e, const St&
 // with in rlf[], and the link walk replaces the marker by what the rows above left.
 // DAGP: double affine gaps (Noll = 3): the states E2 / F2 (HORL / VERL), a third plane of entries by diagonal and a third
 // link plane per intermediate row (src/fwd2s1.cc:764, 847-880, 917-927, 1016-1023)
+template <bool DAGP> constexpr int WPBU = 4;
 template <bool PIPE, bool DAGP = false>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ? 2 : 3, DAGP ? 2 : 3))) void spdp_rowwave_udh(ScalarArgs A)
+__global__ __launch_bounds__(64 * WPBU<DAGP>) __attribute__((amdgpu_waves_per_eu(DAGP ? 2 : 3, DAGP ? 2 : 3))) void spdp_rowwave_udh(ScalarArgs A)
 {
+    constexpr int WPB = WPBU<DAGP>;
     constexpr int NOL = DAGP ? 3 : 2, NODK = 2 * NOL - 1, NA = 5 * NOL;
     __shared__ LdsU<DAGP> Lw[WPB];
-    __shared__ Tables T;
+    __shared__ TablesU T;
     const DevScoring* sc = A.sc;
-    load_tables(T, A, sc);
-    LdsU<DAGP>& L = Lw[threadIdx.x >> 6];
+    load_tables_u(T, A, sc);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LdsU<DAGP>& L = Lw[wv];
     const int lane = threadIdx.x & 63;
-    int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    int pi = blockIdx.x * WPB + wv;
     int t_lo = 0, t_hi = INT32_MAX;
     if (PIPE) {
         int tk = 0;
@@ -704,10 +728,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= A.n_items) return;
         const int2 it = A.items[tk];
-        pi = it.x; t_lo = it.y; t_hi = it.y + 1;
+        pi = __builtin_amdgcn_readfirstlane(it.x); t_lo = __builtin_amdgcn_readfirstlane(it.y); t_hi = t_lo + 1;
     }
     if (pi >= A.n_probs) return;
-    const DevProblem P = A.probs[pi];
+    const DevProblem P = wave_uniform(A.probs[pi]);
     int al = P.a_left, ar = P.a_right, bl = P.b_left, br = P.b_right;
     const int lw = P.lw, up = P.up, width = P.width, n_im = P.n_im, intvl = P.imd_intvl;
     const bool a_exgl = P.flags & 1, a_exgr = P.flags & 2, b_exgl = P.flags & 4, b_exgr = P.flags & 8;
@@ -793,6 +817,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
         const bool any = row && n_first <= n_last;
         int s_lo = any ? n_first + m : INT32_MAX, s_hi = any ? n_last + m : INT32_MIN;
         for (int off = 32; off; off >>= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, off)); s_hi = max(s_hi, __shfl_xor(s_hi, off)); }
+        s_lo = __builtin_amdgcn_readfirstlane(s_lo); s_hi = __builtin_amdgcn_readfirstlane(s_hi);
         // is my row an intermediate row, and which
         const int iq = (m - P.a_left) / max(1, intvl) - 1;
         const bool is_imd = row && intvl > 0 && (m - P.a_left) % intvl == 0 && iq >= 0 && iq < n_im;
@@ -833,8 +858,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                 }
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
+                    const int* src[NA]; int val[NA];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) lds[a][q] = gld<PIPE>(G(a) + e);
+                    for (int a = 0; a < NA; ++a) src[a] = G(a);
+                    gld_n<PIPE>(src, e, val);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) lds[a][q] = val[a];
                 }
                 res_hi = max(res_hi, want);
                 WAVE_SYNC();
@@ -843,16 +872,25 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                 if (any && nn >= n_first && nn <= n_last) { c = cols[nn]; a2 = reinterpret_cast<const unsigned short*>(aux)[nn]; }
             };
             int2 col1 = make_int2(0, 0), col2 = make_int2(0, 0); int aux1 = 0, aux2 = 0;
-            ld_col(s_lo - m, col1, aux1);
-            ld_col(s_lo + 1 - m, col2, aux2);
+            ColFeed feed;                                           // (SPDP_COLFEED: the column records ride down the lanes)
+            constexpr bool OWN = !SPDP_COLFEED;
+            if constexpr (OWN) { ld_col(s_lo - m, col1, aux1); ld_col(s_lo + 1 - m, col2, aux2); }
+            else { feed.issue(cols, aux, s_lo - m0); feed.arrived(); }
             for (int S = s_lo; S <= s_hi; ++S) {
                 if (((S - s_lo) & (CHUNK - 1)) == 0) refill(S);
                 const int n = S - m;
                 const bool on = any && n >= n_first && n <= n_last;
-                const int2 col = col1; const int ax = aux1 & 0xff, adn = aux1 >> 8;
-                col1 = col2; aux1 = aux2;
-                ld_col(n + 2, col2, aux2);
-                if (__ballot(on) == 0) continue;
+                int2 col; int ax, adn;
+                if constexpr (OWN) {
+                    col = col1; ax = aux1 & 0xff; adn = aux1 >> 8;
+                    col1 = col2; aux1 = aux2;
+                    ld_col(n + 2, col2, aux2);
+                } else {
+                    feed.shift();                                   // lane k now holds column (S - m0) - k = S - m
+                    feed.issue(cols, aux, S + 1 - m0);              // lane 0's next column: at most br + 63, inside the padded records
+                    col = make_int2(feed.x, feed.ya & 0xff); ax = (feed.ya >> 8) & 0xff; adn = (feed.ya >> 16) & 0xff;
+                }
+                if (__ballot(on) == 0) { if constexpr (!OWN) feed.arrived(); continue; }
                 const int r = n - m;
                 const int q = (r - (lw - 1)) & (RING - 1), ql = (q - 1) & (RING - 1), qu = (q + 1) & (RING - 1);
                 St H = {L.hv[q], L.hu[q], L.hl[q], L.hm[q], L.hk[q]};
@@ -898,9 +936,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                 }
                 // ---- acceptor
                 bool spj3 = false;
-                const bool acc = on && (ax & 2) && ncand >= 0 &&
-                                 cv[0] + sigB + T.gain[0] + T.gain[1] + (col.x >> 16) >
-                                     (DAGP ? min(min(H.v, min(E.v, F.v)), min(E2.v, F2.v)) : min(H.v, min(E.v, F.v)));     // (screen, as above)
+                const bool acc = on && (ax & 2) && ncand >= 0;
                 if (__ballot(acc)) {
                     int sel_h = -1, sel_e = -1, sel_f = -1, sel_e2 = -1, sel_f2 = -1;
                     const int s3 = col.x >> 16, dn3 = adn & 15;
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                     for (int l = 0; l < NC; ++l) {
                         const int len = n - cj[l];
                         if (acc && l <= ncand && len >= llmt) {
-                            const int x = cv[l] + sigB + intpen_of(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
+                            const int x = cv[l] + sigB + intpen_of_u(T, A, len) + s3 + T.t53[16 * cx[l] + dn3];
                             if (cd[l] == K_H) { if (x > H.v) { H.v = x; sel_h = l; } }
                             else if (cd[l] == K_E) { if (x > E.v) { E.v = x; sel_e = l; } }
                             else if (!DAGP || cd[l] == K_F) { if (x > F.v) { F.v = x; sel_f = l; } }
@@ -1031,6 +1067,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
                     L.fv[q] = F.v; L.fu[q] = F.u; L.fl[q] = F.l; L.fm[q] = F.m; L.fk[q] = F.k;
                     if constexpr (DAGP) { L.gv[q] = F2.v; L.gu[q] = F2.u; L.gl[q] = F2.l; L.gm[q] = F2.m; L.gk[q] = F2.k; }
                 }
+                if constexpr (!OWN) feed.arrived();
             }
             WAVE_SYNC();
             for (int e = res_lo + lane; e < res_hi; e += 64) {
@@ -1192,11 +1229,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(DAGP ?
 extern "C" hipError_t spdp_launch_rowwave_udh(const ScalarArgs* a, hipStream_t stream)
 {
     ScalarArgs A = *a;
+    const int units = A.pipe ? A.n_items : A.n_probs;
+    constexpr int W3 = WPBU<true>, W2 = WPBU<false>;
     if (A.noll == 3) {
-        if (A.pipe) hipLaunchKernelGGL((spdp_rowwave_udh<true, true>), dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
-        else hipLaunchKernelGGL((spdp_rowwave_udh<false, true>), dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
-    } else if (A.pipe) hipLaunchKernelGGL(spdp_rowwave_udh<true>, dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
-    else hipLaunchKernelGGL(spdp_rowwave_udh<false>, dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
+        if (A.pipe) hipLaunchKernelGGL((spdp_rowwave_udh<true, true>), dim3((units + W3 - 1) / W3), dim3(64 * W3), 0, stream, A);
+        else hipLaunchKernelGGL((spdp_rowwave_udh<false, true>), dim3((units + W3 - 1) / W3), dim3(64 * W3), 0, stream, A);
+    } else if (A.pipe) hipLaunchKernelGGL(spdp_rowwave_udh<true>, dim3((units + W2 - 1) / W2), dim3(64 * W2), 0, stream, A);
+    else hipLaunchKernelGGL(spdp_rowwave_udh<false>, dim3((units + W2 - 1) / W2), dim3(64 * W2), 0, stream, A);
     return hipGetLastError();
 }
 

@@ -40,25 +40,35 @@ HBM_PEAK_GBS = 8000.0
 # VALU issue ceiling of one MI355X, measured with tools/ubench (profiles/r02_valu_ubench.txt): a SIMD issues at most one
 # VALU wave-instruction per ~2.2 shader cycles (fp32 add / int add / logic / cndmask class, or a max / compare with an
 # fp32 add beside it; max / compare / DPP alone: one per 4), at the 2.3 GHz the sweeps sustain (GRBM_GUI_ACTIVE,
-# profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.  VALU wave-instructions per DP cell from SQ_INSTS_VALU of the
-# same kind of profile: fp32-issue UDH sweep 45.0 / 64 (profiles/r03_valu_pmc.txt: 4.419e11 over the six launches = three
-# steps of that run; round 2: 51.2, round 1: 59.6), forward sweep 59.1 / 64 (round 4, on the fp32-issue kernel: profiles/r04_valu_pmc.txt, 2.3006e11 over the forty launches = ten
-# steps of that run; round 3, spdp_sweep<FL_FORWARD>: 63.4, round 2: 69.6), protein sweep 152.3 / 64
-# (profiles/r02_h_sq_counters.txt: its mix is compare / select / saturating-add forms that issue one per 4 cycles).
+# profiles/r02_sq_counters.txt): 1024 SIMDs x 2.3e9 / 2.2.
 VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
-VALU_PER_CELL = {"udh": 4.41891e11 / 3 / 2.0941e11, "forward": 2.30060e11 / 10 / 2.4928e10, "h": 7.3635e10 / 3.0943e10,
-                 "a0_udh": 1.2802e10 / 2.05e9}      # (--engines a0: profiles/r02_a0_sq_counters.txt)
-# HBM-side traffic of ONE spdp_sweep_fp<FL_UDH> launch of the default workload (the step runs two, one per pipelined
-# chunk): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in KiB, separate passes, summed over the six launches of that run
-# (profiles/r03_hbm_traffic_pmc.txt; round 2: 2 x 24.9e6 + 89.2e6 KiB per launch, now 2 x 30.6e6 + 97.1e6; three profiles
-# of this round read 24.9 / 28.2 / 30.6 and 89.0 / 89.0 / 97.1 on unchanged traffic: L2 residency varies from box to box).  FETCH_SIZE
-# counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM): doubled for the 16-byte-per-lane boundary reads, which makes
-# the figure an upper bound for the 8-byte column-record reads.
-PMC_TRAFFIC_BYTES = int((2 * 183504024 + 582816383) * 1024 / 6)
-# one spdp_rowwave_udh<true> launch of the default --engines a0 workload (profiles/r02_a0_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_A0 = (2 * 10706788 + 37364177) * 1024
-# same for one spdh_sweep launch of the default c3 workload (profiles/r03_h_hbm_traffic_pmc.txt)
-PMC_TRAFFIC_BYTES_H = int((2 * 36231533 + 148415086) * 1024)
+# What the kernels issue and move per DP cell / per launch is NOT a constant of this file: it is read from the round's
+# counter profile (tools/profile_counters.py writes it on the GPU box: rocprofv3 --pmc SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE
+# in separate passes + --kernel-trace --stats, per workload).  Every entry carries the sha256 of its kernel's source file;
+# an entry whose kernel has changed since is reported as stale (roofline.*.profile_stale, and tests/test_profile_counters.py
+# fails) instead of pricing the new kernel with the old figures.
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_counters.json")
+
+
+def _counters(workload, key):
+    """the profile entry of kernel `key` in workload `workload`, or None; adds "stale": True when the kernel's source differs"""
+    try:
+        with open(COUNTERS_FILE) as f:
+            allc = json.load(f)
+        e = dict(allc[workload]["kernels"][key])
+    except (OSError, ValueError, KeyError):
+        return None
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, e["source"]), "rb") as f:
+            e["stale"] = hashlib.sha256(f.read()).hexdigest() != e.get("source_sha256")
+    except OSError:
+        e["stale"] = True
+    if e["stale"]:
+        sys.stderr.write(f"bench.py: {e['source']} has changed since {os.path.relpath(COUNTERS_FILE, ROOT)} was taken "
+                         f"({workload}/{key}): re-run tools/profile_counters.py\n")
+    e["file"] = os.path.relpath(COUNTERS_FILE, ROOT)
+    return e
 
 
 def _cpu_align_one(item):
@@ -296,8 +306,9 @@ def main_c3(args):
     for _ in range(args.steps):
         _, ms, cells = bt.align(want=True, convert=False)
         kms.append(ms)
-    if not cells:
-        cells = bt.cells()          # (the exact-model ladder does not report the cells of its launches: band cells)
+    kcells = cells                  # what the launches of the step processed (the exact-model ladders: linear-space passes + slabs)
+    if exact or not cells:
+        cells = bt.cells()          # the exact-model legs are quoted on BAND cells (m x window band, as round 4's), not on engine cells
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -311,6 +322,8 @@ def main_c3(args):
         total_cells = float(cells)
     if rank == 0:
         k_ms = float(np.mean(kms))
+        wl_key = {"wip": "c3", "a0": "c3_a0", "a1": "c3_a1"}[args.engines]              # entry of the round's counter profile
+        k_key = {"wip": "h", "a0": "h_a0_fwd", "a1": "h_a1"}[args.engines]
         bpc = 32.0 / 64.0 + 2.0            # 16 B record + 8 B boundary read + 8 B write per 64 rows x 1 nt; 2 B code / cell
         achieved = cells * bpc / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         import multiprocessing as mp
@@ -350,14 +363,15 @@ def main_c3(args):
                        "queries_per_gpu": args.queries, "cells_per_gpu_per_step": int(cells),
                        "queries_per_s": round(args.queries * world * args.steps / dt, 1),
                        "reference_parity": _parity_note(args),
-                       "sweep_ms": round(k_ms, 3), "sweep_gcups": round(cells / k_ms / 1e6, 2) if k_ms > 0 else None},
+                       "fwd_cells": int(kcells or cells), "udh_cells": 0,
+                       "sweep_ms": round(k_ms, 3), "sweep_gcups": round((kcells or cells) / k_ms / 1e6, 2) if k_ms > 0 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": PMC_TRAFFIC_BYTES_H if (args.queries == 10000 and world == 1 and not exact) else None,
-                         "traffic_source": "profiles/r03_h_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command)",
+                         "traffic": _traffic(wl_key, k_key, args.queries, world)[0],
+                         "traffic_source": _traffic(wl_key, k_key, args.queries, world)[1],
                          "kernel": ("spdh_rowwave" if args.engines == "a0" else "spdh_exact") if exact else "spdh_sweep",
                          "kernel_ms": round(k_ms, 3),
-                         "valu": None if exact else _valu_roofline(cells, "h", k_ms),
+                         "valu": _valu_roofline(kcells or cells, wl_key, k_key, k_ms),
                          "note": "exact-model engines: latency-bound chains, see DESIGN.md; HBM fraction reported as asked" if exact else
                                  "integer-VALU bound recurrence (int16 saturating lanes carried in the upper half of 32-bit registers); HBM fraction reported as asked"},
             "cpu_baseline": cpu_base,
@@ -559,7 +573,8 @@ def main_blk(args):
                                            "compiled reference's recorded runs (tests/golden/blk_*.spdg: tests/test_gpu_blk.py); FindHsp itself "
                                            "(Wilip on the candidate region) stays with the caller"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "bytes_per_query": round(float(bytes_per_q), 1), "traffic": None, "kernel": "spdp_blk_vote_kernel", "kernel_ms": round(k_ms, 3),
+                         "bytes_per_query": round(float(bytes_per_q), 1), "traffic": _traffic("blk", "blk", n_q, world)[0],
+                         "traffic_source": _traffic("blk", "blk", n_q, world)[1], "kernel": "spdp_blk_vote_kernel", "kernel_ms": round(k_ms, 3),
                          "note": "one query per lane, random 4 .. 8-byte accesses into posting lists and the lane's private score slab: bound by "
                                  "memory transactions in flight and by divergence, not by bytes; algorithmic bytes = codes + per word its table "
                                  "entries and posting list + two score slots per listed block + the record"},
@@ -575,20 +590,29 @@ def main_blk(args):
         dist.destroy_process_group()
 
 
-def _valu_roofline(cells, kind, k_ms):
-    """the bound that actually binds: VALU wave-instructions issued per second against the measured ceiling"""
-    if not k_ms or not cells:
+def _valu_roofline(cells, workload, key, k_ms):
+    """the bound that actually binds: VALU wave-instructions issued per second against the measured ceiling; instructions per
+    cell from the round's counter profile (COUNTERS_FILE), None where the profile has no entry for this kernel"""
+    e = _counters(workload, key)
+    if not k_ms or not cells or not e or not e.get("valu_per_cell"):
         return None
-    ach = cells * VALU_PER_CELL[kind] / (k_ms * 1e-3)
-    src = ("SQ_INSTS_VALU per cell (profiles/r03_valu_pmc.txt) x cells / kernel time; peak = one VALU "
-           "wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, profiles/r02_valu_ubench.txt); "
-           "the instruction mix of the step, priced by class, explains 0.71 of the measured time")
-    if kind == "a0_udh":
-        src = ("SQ_INSTS_VALU per cell of spdp_rowwave_udh<true> (profiles/r02_a0_sq_counters.txt: 400 per 64-cell step, + 278 "
-               "scalar) x cells / kernel time against the same measured VALU ceiling; the kernel is latency-bound, not "
-               "issue-bound: its waves wait 62 % of their resident cycles (same file)")
+    ach = cells * e["valu_per_cell"] / (k_ms * 1e-3)
     return {"achieved": round(ach / 1e9, 1), "peak": round(VALU_PEAK_WINST_S / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(ach / VALU_PEAK_WINST_S, 3), "source": src}
+            "frac": round(ach / VALU_PEAK_WINST_S, 3), "valu_per_64_cells": round(64 * e["valu_per_cell"], 1),
+            "profile_stale": bool(e["stale"]),
+            "source": f"SQ_INSTS_VALU per cell of {e['kernel']} ({e['file']}: {workload}/{key}, rocprofv3 --pmc, its own pass) x cells / "
+                      "kernel time; peak = one VALU wave-instruction per 2.2 cycles per SIMD at 2.3 GHz (tools/ubench, "
+                      "profiles/r02_valu_ubench.txt)"}
+
+
+def _traffic(workload, key, queries, world=1):
+    """HBM bytes per launch from the PMC passes of the round's profile (FETCH_SIZE x 2 + WRITE_SIZE), or None; only for the
+    batch size the profile was taken on (a launch's traffic scales with it)"""
+    e = _counters(workload, key)
+    if not e or not e.get("hbm_bytes_per_launch") or world != 1 or e.get("queries") != queries:
+        return None, None
+    return int(e["hbm_bytes_per_launch"]), (f"{e['file']}: {workload}/{key} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, "
+                                            f"{e['launches_per_step']:g} launches per step; per launch)" + (" -- STALE: kernel source changed" if e["stale"] else ""))
 
 
 def _self_spawn(argv, n):
@@ -686,6 +710,13 @@ def _run_leg(name):
            "cells_per_step": c["cells_per_gpu_per_step"], "dtype": d["dtype"],
            "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "hbm_frac": rf["frac"],
            "valu_frac": (rf.get("valu") or {}).get("frac"),
+           # kernel_ms sums the durations of the step's launches of this kernel; where they run side by side on two streams (c4)
+           # the sum exceeds the step: the kernel's share of the WALL is at most the step, and the fractions on that basis
+           **({"kernel_ms_is_sum_of_concurrent_launches": True,
+               "valu_frac_on_step_wall": round((rf.get("valu") or {}).get("frac", 0) * rf["kernel_ms"] / d["ms_per_step"], 3) if rf.get("valu") else None,
+               "hbm_frac_on_step_wall": round(rf["frac"] * rf["kernel_ms"] / d["ms_per_step"], 5)}
+              if rf["kernel_ms"] > d["ms_per_step"] else {}),
+           "profile_stale": (rf.get("valu") or {}).get("profile_stale"),
            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None,
            "reference_parity": c.get("reference_parity"), "wall_s": round(time.perf_counter() - t0, 1)}
     for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems"):
@@ -734,6 +765,9 @@ def main():
     ap.add_argument("--intron-hi", type=int, default=20000, help="upper clip of planted intron lengths")
     ap.add_argument("--cpu-port", action="store_true",
                     help="time the oracle port as the CPU baseline even when oracle/_ref/spaln is present")
+    ap.add_argument("--plain", action="store_true",
+                    help="nothing but --warmup + --steps aligns of the batch (no upload-inclusive / streamed figures): what "
+                         "tools/profile_counters.py runs under rocprofv3, so that counter totals divide by the number of steps")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every rank its own batch of --queries (the reported value), strong = one "
                          "batch of --queries sharded over the ranks; the other one is reported under config")
@@ -798,7 +832,7 @@ def main():
         for w, q, s5, s3, _ in batch:
             ps.add(q, w, s5, s3, **(synth.exact_inputs(w) if exact else {}))
         h2d = None
-        if mode == args.scaling:
+        if mode == args.scaling and not args.plain:
             # the same step with the batch coming over PCIe first (upload + align): reported beside the headline, which
             # counts inputs resident in HBM (the bench contract); full column records, ~95 B per genomic position
             tb0 = time.perf_counter()
@@ -899,6 +933,8 @@ def main():
         c4 = args.workload == "c4"
         k_ms = fwd_ms if c4 else udh_ms
         k_cells, k_name = (fwd_cells, "forward") if c4 else (udh_cells, "udh")
+        wl_key = args.workload if not exact else args.engines                            # entry of the round's counter profile
+        k_key = k_name if not exact else {"a0": "a0_udh", "a1": "a1_udh"}[args.engines]
         achieved = k_cells * SURVEY_BYTES_PER_CELL[k_name] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_layout = k_cells * BYTES_PER_CELL[k_name] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # CPU baseline: the oracle's alignS_ng restatement (int32, one query per process) on all
@@ -967,6 +1003,7 @@ def main():
                        "rank_busy_ms": prim["rank_busy_ms"],
                        "parallelism": f"{world} rank(s), one per GPU, queries sharded, no collective on the data path",
                        **({"strong_scaling" if other["scaling"] == "strong" else "weak_scaling": other} if other else {}),
+                       "udh_cells": int(udh_cells), "fwd_cells": int(fwd_cells),
                        "udh_ms": round(udh_ms, 3), "udh_gcups": round(udh_cells / udh_ms / 1e6, 2) if udh_ms else None,
                        "fwd_ms": round(fwd_ms, 3), "fwd_gcups": round(fwd_cells / fwd_ms / 1e6, 2) if fwd_ms else None,
                        "fwd_problems": int(stats[-1]["fwd_problems"]), "tb_bytes": int(stats[-1]["tb_bytes"])},
@@ -977,14 +1014,11 @@ def main():
                                                   + (" + 1 B traceback code" if k_name == "forward" else ""),
                          "layout_bytes_per_cell": round(BYTES_PER_CELL[k_name], 4),
                          "layout_achieved": round(achieved_layout, 2), "layout_frac": round(achieved_layout / HBM_PEAK_GBS, 5),
-                         "traffic": (PMC_TRAFFIC_BYTES if (args.queries == 10000 and world == 1 and args.workload == "c2" and not exact) else
-                                     PMC_TRAFFIC_BYTES_A0 if (args.engines == "a0" and args.queries == 1000 and world == 1 and not c4) else None),
-                         "traffic_source": ("profiles/r02_a0_hbm_traffic_pmc.txt" if args.engines == "a0" else "profiles/r03_hbm_traffic_pmc.txt") +
-                                           " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, same command; per launch)",
+                         "traffic": _traffic(wl_key, k_key, args.queries, world)[0],
+                         "traffic_source": _traffic(wl_key, k_key, args.queries, world)[1],
                          "kernel": ("spdp_rowwave_udh" if args.engines == "a0" else "spdp_exact<udh>") if exact else
                                    ("spdp_sweep_fp<FL_FORWARD>" if c4 else "spdp_sweep_fp<FL_UDH>"), "kernel_ms": round(k_ms, 3),
-                         "valu": (_valu_roofline(udh_cells, "a0_udh", k_ms) if args.engines == "a0" else None) if exact
-                                 else _valu_roofline(k_cells, k_name, k_ms),
+                         "valu": _valu_roofline(k_cells, wl_key, k_key, k_ms),
                          "note": ("exact-model engines: int32 scores, per-row donor lists; latency-bound chains of exec-masked regions, the tiles of a "
                                   "problem pipelined over waves; HBM fraction reported as asked; kernel_ms = mean duration per step summed "
                                   "over the step's launches of this kernel") if exact else

@@ -1,10 +1,22 @@
 // shim_fill.h -- the marshalling half of the reference-side binding: the reference's objects (Seq, PwdB,
-// Exinon, the parameter globals) -> the plain structs of include/spdp.h.  TEST INFRASTRUCTURE ONLY; shared by
-// shim_check.cc (one pair, reference vs library) and seed_bench.cc (a batch of pairs through the seeded path, timed).
+// Exinon, the parameter globals) -> the plain structs of include/spdp.h.  This is the code a maintainer of ogotoh/spaln
+// adds to the reference's tree (it compiles against the reference's headers, src/aln.h & co., and include/spdp.h; nothing
+// of the reference is in it).  Used by spaln_gpu_shim.cc (the reference's CLI on the library), and by the checkers
+// oracle/ref_build/shim_check.cc (one pair, reference vs library) and seed_bench.cc (a batch of pairs through the seeded path).
 #ifndef SHIM_FILL_H_
 #define SHIM_FILL_H_
-#include "ref_dump_common.h"
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include "aln.h"		// the reference's headers (src/)
+#include "utilseq.h"
+#include "wln.h"
+#include "vmf.h"
+#include "gsinfo.h"
 #include "spdp.h"
+extern	int	MaxVmfSpace;
 
 static void fill_scoring(SpdpScoring& sc, const PwdB* pwd, const Seq* b) {
 	memset(&sc, 0, sizeof sc);

@@ -1,6 +1,7 @@
-// spaln_gpu_shim -- the reference's own command line program with its cDNA aligner call switched to libspdp_hip.so.
-// TEST INFRASTRUCTURE ONLY (built by oracle/ref_build/Makefile into oracle/_ref/spaln_gpu where /root/reference exists;
-// runs wherever a GPU is).
+// spaln_gpu_shim -- the reference's own command line program with its aligner calls switched to libspdp_hip.so: the
+// reference-side binding of INTEGRATION.md ("the whole program"), i.e. what a maintainer of ogotoh/spaln links instead
+// of the bodies of alignS_ng / alignH_ng.  Built by oracle/ref_build/Makefile into oracle/_ref/spaln_gpu where the
+// reference's sources are (/root/reference); runs wherever a GPU is.
 //
 // What is linked: src/spaln.cc and every library object of the reference exactly as in oracle/_ref/spaln, except that
 // src/fwd2s1.cc and src/fwd2h1.cc are compiled once more with -DalignS_ng=alignS_ng_ref / -DalignH_ng=alignH_ng_ref (the
@@ -49,9 +50,12 @@ const	PwdB*	pwd;
 std::mutex		g_m;
 std::condition_variable	g_cv;
 std::vector<Req*>	g_parked;
-bool			g_leader = false;
-SpdpContext*		g_ctx = 0;
-std::vector<int16_t>	g_ipen;			// IntronPenalty::Penalty(len), as long as the longest window so far
+int			g_leaders = 0;			// batches being gathered / run right now (at most g_nctx)
+std::vector<SpdpContext*> g_ctxs;			// one library context per concurrent batch (SPALN_GPU_CONTEXTS, default 4): a seeded
+std::vector<int>	g_ctx_free;			// call is a chain of short dependent launches that leaves most of the device idle,
+int			g_nctx = 4;			// so several calls side by side multiply the throughput
+thread_local SpdpContext* g_ctx = 0;			// the context of the batch this thread leads
+thread_local std::vector<int16_t> g_ipen;			// IntronPenalty::Penalty(len), as long as the longest window so far
 std::atomic<long>	g_calls[6], g_batches, g_largest, g_us[2], g_seed[11];
 int			g_max_batch = 256, g_wait_us = 300;
 
@@ -229,20 +233,27 @@ void submit(Req& r)
 {
 	std::unique_lock<std::mutex> lk(g_m);
 	g_parked.push_back(&r);
-	for (;;) {					// wait for my result, or for the leader's seat
+	for (;;) {					// wait for my result, or for a leader's seat
 	    if (r.done) return;
-	    if (!g_leader) break;
+	    if (g_leaders < g_nctx && !g_parked.empty()) break;
 	    g_cv.wait(lk);
 	}
-	// no batch is being gathered: this thread gathers one (and goes on until its own request has run)
-	g_leader = true;
+	// a seat is free: this thread gathers a batch (and goes on until its own request has run)
+	++g_leaders;
+	const int slot = g_ctx_free.back(); g_ctx_free.pop_back();
+	g_ctx = g_ctxs[slot];
 	while (!r.done) {
 	    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(g_wait_us);
 	    while ((int) g_parked.size() < g_max_batch && std::chrono::steady_clock::now() < until) {
 		lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(20)); lk.lock();
 	    }
 	    std::vector<Req*> take;
-	    take.swap(g_parked);
+	    if ((int) g_parked.size() <= g_max_batch) take.swap(g_parked);
+	    else { take.assign(g_parked.begin(), g_parked.begin() + g_max_batch); g_parked.erase(g_parked.begin(), g_parked.begin() + g_max_batch); }
+	    if (take.empty()) {				// another leader took everything, mine included: wait for it
+		g_cv.wait(lk);
+		continue;
+	    }
 	    lk.unlock();
 	    for (int kind = 0; kind < 5; ++kind) {
 		std::vector<Req*> part;
@@ -253,7 +264,8 @@ void submit(Req& r)
 	    for (Req* q : take) q->done = true;
 	    g_cv.notify_all();
 	}
-	g_leader = false;
+	g_ctx_free.push_back(slot);
+	--g_leaders;
 	g_cv.notify_all();				// a parked thread takes over
 }
 
@@ -261,13 +273,17 @@ bool device_up()
 {
 	static std::once_flag once;
 	std::call_once(once, [] {
-	    g_ctx = spdp_create(0);
-	    if (!g_ctx) fatal("spaln_gpu: no HIP device (there is no CPU path in the library)\n");
+	    if (const char* e = getenv("SPALN_GPU_CONTEXTS")) g_nctx = std::max(1, std::min(16, atoi(e)));
+	    for (int i = 0; i < g_nctx; ++i) {
+		SpdpContext* c = spdp_create(0);
+		if (!c) fatal("spaln_gpu: no HIP device (there is no CPU path in the library)\n");
+		g_ctxs.push_back(c); g_ctx_free.push_back(i);
+	    }
 	    if (const char* e = getenv("SPALN_GPU_BATCH")) g_max_batch = std::max(1, atoi(e));
 	    if (const char* e = getenv("SPALN_GPU_WAIT_US")) g_wait_us = std::max(0, atoi(e));
 	    atexit(report);
 	});
-	return g_ctx != 0;
+	return !g_ctxs.empty();
 }
 
 VTYPE homscore(Seq* seqs[], const PwdB* pwd)
@@ -280,8 +296,34 @@ VTYPE homscore(Seq* seqs[], const PwdB* pwd)
 
 }	// namespace
 
+// SPALN_GPU_TIME_REF=1: no device at all -- every call goes to the reference's own aligner and the time inside it is added up
+// over the worker threads: what share of the program's worker time the call this library replaces is (Amdahl's bound on
+// what ANY faster aligner can do for the program; INTEGRATION.md, "where the time of -Q7 goes")
+std::atomic<long>	g_ref_us, g_ref_calls;
+std::chrono::steady_clock::time_point g_t_start = std::chrono::steady_clock::now();
+bool time_ref_mode()
+{
+	static const bool on = [] {
+	    const bool v = getenv("SPALN_GPU_TIME_REF") != 0;
+	    if (v) atexit([] {
+		const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t_start).count();
+		fprintf(stderr, "[spaln_gpu] time-ref mode: %ld aligner calls, %.3f s inside the reference's aligner summed over the worker threads, "
+			"program wall %.3f s\n", g_ref_calls.load(), g_ref_us.load() * 1e-6, wall);
+	    });
+	    return v;
+	}();
+	return on;
+}
+
 SKL* alignS_ng(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori)
 {
+	if (time_ref_mode()) {
+const	    auto t0 = std::chrono::steady_clock::now();
+	    SKL* skl = alignS_ng_ref(seqs, pwd, gsi, ori);
+	    g_ref_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+	    ++g_ref_calls;
+	    return skl;
+	}
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] alignS_ng ori %d qck %d\n", ori, (int) algmode.qck);
 	device_up();
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] device up\n");
@@ -303,6 +345,13 @@ const	    VTYPE scr2 = homscore(seqs, pwd);
 
 SKL* alignH_ng(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi)
 {
+	if (time_ref_mode()) {
+const	    auto t0 = std::chrono::steady_clock::now();
+	    SKL* skl = alignH_ng_ref(seqs, pwd, gsi);
+	    g_ref_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+	    ++g_ref_calls;
+	    return skl;
+	}
 	device_up();
 	Req r; r.seqs = (Seq**) seqs; r.pwd = pwd; r.kind = algmode.qck? 4: 3;
 	submit(r);

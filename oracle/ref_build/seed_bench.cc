@@ -14,7 +14,8 @@
 // library's counters (device batches, lsp calls, tracebacks, cut ranges, Wilip calls).
 //
 // usage: seed_bench -Q n [-A alg] [-t threads] [-X crs] list.txt      (list.txt: one "window.fa query.fa" per line)
-#include "shim_fill.h"
+#include "ref_dump_common.h"
+#include "shim_fill.h"		// integration/shim_fill.h: the reference-side binding under test
 #include <atomic>
 #include <chrono>
 #include <mutex>

@@ -12,7 +12,8 @@
 //   -Q n (cDNA): algmode.qck = n -- the seeded path.  The reference's own geneorient() finds the HSPs and its own Wilip
 //   answers the recursion levels through SpdpHspSource; alignS_ng of the reference against spdp_align_s_seeded.
 
-#include "shim_fill.h"
+#include "ref_dump_common.h"
+#include "shim_fill.h"		// integration/shim_fill.h: the reference-side binding under test
 
 static SpdpContext* g_ctx = 0;
 static bool g_undefined = false;		// the library flagged the input as undefined in the reference (n_skl < 0)

@@ -81,6 +81,25 @@ template <bool X> __device__ __forceinline__ int2 ld_b2(const int* p)
     if constexpr (X) return make_int2(ld_b1<true>(p), ld_b1<true>(p + 1));
     else return ld_nt2(p);
 }
+// ... as plain (non-atomic) buffer loads with the same scope bit: the agent-scope ATOMIC load above is followed by a wait of
+// its own, so the "prefetch" of a cross-CU pass was four memory round trips the wave sat out, one after the other, per
+// block of sixteen steps (profiles/r04_wave_pmc.txt: 61 % of C5's resident wave cycles in s_waitcnt).  A buffer load with
+// sc1 goes the same way to the memory side, stays in flight, and the compiler counts it (round 5).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t bnd_rsrc(const int* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(base), 0, 0x7ffffffc, 0x00020000);
+}
+template <bool X> __device__ __forceinline__ int4 ldx_b4(rsrc_t r, const int* base, int64_t idx)
+{
+    if constexpr (X) { const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) (idx * 4), 0, 16); return make_int4(v.x, v.y, v.z, v.w); }
+    else return ld_nt4(base + idx);
+}
+template <bool X> __device__ __forceinline__ int2 ldx_b2(rsrc_t r, const int* base, int64_t idx)
+{
+    if constexpr (X) { const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int) (idx * 4), 0, 16); return make_int2(v.x, v.y); }
+    else return ld_nt2(base + idx);
+}
 template <bool X> __device__ __forceinline__ void st_b1(int* p, int v)
 {
     if constexpr (X) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -355,9 +374,10 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
             // registers holding the NEXT block's boundary entry / column record of this lane
             int4 nx_b = make_int4(0, 0, 0, 0);
             int2 nx_c = make_int2(0, 0);
+            const rsrc_t brs = bnd_rsrc(bnd);                                 // (CROSS: the boundary array of this problem as a buffer)
             // a row's blocks are prefetched in order (block 0 once, then lb + 1 from block lb), so the two addresses and
             // the flush address below are carried along, 16 entries per block, instead of being rebuilt from lb
-            const int* pf_b = bnd + (int64_t) BIDX(n_start + k - ml) * BW;    // sweep step n_start + 16 lbn + k of this lane
+            int64_t pf_b = (int64_t) BIDX(n_start + k - ml) * BW;            // (index into bnd) sweep step n_start + 16 lbn + k of this lane
             const int2* pf_c = cols + (n_start + k);
             int* st_p = bnd + (int64_t) BIDX(n_start + k - (ml + 1) - 2 * j8) * BW;
             // the reference's write condition (fwd2s1_wip_simd.h:205-209) as a range of the sweep step n0 + k
@@ -365,8 +385,8 @@ __global__ __launch_bounds__(WPB * 64) void spdp_sweep_fp(SweepArgs A)
             const int fl_hi = j9 > 0 ? min(up + (ml + 1) + 2 * j8 + 1, n_end) : INT32_MIN;
             int lbm = 0;                                                // (16 lb) mod 48: where the block sits in the 48-slot rings
             auto prefetch = [&](int) {
-                if constexpr (UDH) nx_b = ld_b4<CROSS>(pf_b);
-                else { const int2 v = ld_b2<CROSS>(pf_b); nx_b.x = v.x; nx_b.y = v.y; }
+                if constexpr (UDH) nx_b = ldx_b4<CROSS>(brs, bnd, pf_b);
+                else { const int2 v = ldx_b2<CROSS>(brs, bnd, pf_b); nx_b.x = v.x; nx_b.y = v.y; }
                 nx_c = *pf_c;                                           // raw record: no use here, the load must stay in flight
                 pf_b += 16 * BW; pf_c += 16;
             };

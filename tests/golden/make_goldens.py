@@ -126,6 +126,21 @@ def cases():
     for m in (3, 9):
         g = gene(60 + m, n_exons=1, mrna_len=40, flank=60)
         c[f"l3_tiny_m{m}"] = (g.window, g.query[:m], ["-l", "3", "-A", "0"])
+    # ... and under -A1 (round 5): scoreonlyS1 / forwardS1 with their ev2 / fv2 vectors, five states a candidate can leave from and
+    # NCAND + 2 candidates per lane (src/fwd2s1_simd.cc:347-455, 556-755).  MaxVmfSpace large enough for the traceback branch:
+    # the reference's own hirschbergS1 is not usable under -yl3.
+    g = gene(41, n_exons=4, mrna_len=500, flank=250, intron_hi=900, sub=0.03, indel=0.01)
+    c["l3a1_long_gaps"] = (g.window, ql, ["-l", "3", "-A", "1", "-V", "8000000"])
+    c["l3a1_long_gaps_global"] = (*cut(g, g.exons[0][0] - 40, g.exons[3][1] + 30)[:1], ql, ["-l", "3", "-A", "1", "-g", "0000", "-V", "8000000"])
+    g = gene(42, n_exons=5, mrna_len=700, flank=300, intron_hi=700, sub=0.12, indel=0.03)
+    c["l3a1_divergent"] = (g.window, g.query, ["-l", "3", "-A", "1", "-V", "8000000"])
+    g = gene(43, n_exons=3, mrna_len=300, flank=120, intron_hi=300)
+    c["l3a1_local"] = (g.window, np.concatenate([g.query[:100], g.query[130:]]), ["-l", "3", "-A", "1", "-L", "-V", "8000000"])
+    # (a 9-nt query -- the smallest the SIMD engines take -- makes the reference itself crash under -yl3 -A1, SIGSEGV in this
+    #  container: no fixture)
+    g = gene(44, n_exons=6, mrna_len=900, flank=300, intron_hi=800, sub=0.04, indel=0.01)
+    ql2a = np.concatenate([g.query[:200], g.query[236:450], synth.random_dna(np.random.default_rng(7), 40), g.query[450:]])
+    c["l3a1_900nt"] = (g.window, ql2a, ["-l", "3", "-A", "1", "-V", "16000000"])
     # ... and through hirschbergS_ng (small MaxVmfSpace / forced intermediate rows): a third link plane per intermediate row.
     # A 30-nt insertion in the query across an intermediate row (F2 crosses it), a 24-nt deletion on one (E2 runs along it)
     g = gene(41, n_exons=4, mrna_len=500, flank=250, intron_hi=900, sub=0.03, indel=0.01)

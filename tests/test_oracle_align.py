@@ -127,3 +127,22 @@ def test_align_s_ori3_vs_reference(path, alg):
 def test_ori3_fixtures_cover_both_outcomes():
     seen = {int(spdg.load(f)["ori3_rev_A2"][0]) for f in O3}
     assert seen == {0, 1} and len(O3) >= 5
+
+
+def test_a1_double_affine_goldens():
+    """-A1 with double affine gaps (-yl3, PwdB::Noll = 3; round 5): scoreonlyS1 and forwardS1 with their ev2 / fv2 vectors,
+    five states a donor candidate can leave from and NCAND + 2 candidates per lane (src/fwd2s1_simd.cc:347-455, 556-755),
+    against the compiled reference's own -yl3 -A1 runs (HomScoreS_ng, alignS_ng through the traceback branch of the ladder)."""
+    from tests.conftest import golden_files
+    n = 0
+    for f in golden_files("l3a1_"):
+        fx = spdg.load(f)
+        sc = spdg.scoring(fx)
+        assert sc.noll == 3
+        _, p = spdg.problem(fx)
+        assert host_logic.homscore_s(sc, p, simd=1) == int(fx["hom_scr_A1"][0]), f
+        scr, flat = host_logic.align_s(sc, p, simd=1)
+        assert scr == int(fx["aln_scr_A1"][0]), f
+        assert (flat or []) == fx["aln_skl_A1"].tolist(), f
+        n += 1
+    assert n >= 5

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--modes", default="Q7,Q4")
     ap.add_argument("--strand", default="-S1")
     ap.add_argument("--extra", default="", help="further options for both programs, e.g. -yl3 (double affine gaps)")
+    ap.add_argument("--where", action="store_true", help="also time the reference's own aligner calls inside its program (Amdahl's bound for the drop-in)")
     ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")
     args = ap.parse_args()
     rng = np.random.default_rng(synth.SEED + 8800)
@@ -112,6 +113,21 @@ def main():
                 m = re.search(r"\[spaln_gpu\] alignS[^\n]*(\n\[spaln_gpu\] [^\n]*)*", r.stderr)
                 if m:
                     run[name]["shim"] = m.group(0)
+            if args.where:
+                # where the reference's time goes: the same program once more with every aligner call timed (no device involved)
+                cmd = [os.path.join(REF, "spaln_gpu"), "-" + mode] + ([] if args.protein else [args.strand]) + args.extra.split() + ["-O4", f"-t{args.threads}", "-dgnm", "q.fa"]
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, cwd=td, env=dict(env, SPALN_GPU_TIME_REF="1"), capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                m = re.search(r"time-ref mode: (\d+) aligner calls, ([0-9.]+) s inside .* program wall ([0-9.]+) s", r.stderr)
+                if m:
+                    calls, inside, wall = int(m.group(1)), float(m.group(2)), float(m.group(3))
+                    run["where_the_reference_spends_its_time"] = {
+                        "wall_s": round(dt, 3), "threads": args.threads, "aligner_calls": calls,
+                        "aligner_thread_seconds": inside, "worker_thread_seconds": round(wall * args.threads, 3),
+                        "aligner_share_of_worker_time": round(inside / (wall * args.threads), 4),
+                        "note": "alignS_ng / alignH_ng timed inside the reference's own program (SPALN_GPU_TIME_REF=1: the shim forwards "
+                                "every call to the reference's aligner); the rest is block search, sequence IO, Exinon, rescoring, output"}
             if "reference" in res and "gpu" in res:
                 a, b = res["reference"], res["gpu"]
                 run["identical"] = a == b

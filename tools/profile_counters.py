@@ -115,7 +115,7 @@ def main():
              "launches_per_step": n_launch / args.steps,
              "avg_ms": round(sum(dur[k]) / len(dur[k]), 4) if dur.get(k) else None,
              "ms_per_step": round(sum(dur[k]) / args.steps, 4) if dur.get(k) else None,
-             "cells_per_step": cells}
+             "cells_per_step": cells, "queries": cfg.get("queries_per_gpu")}
         if k in valu:
             nl = max(1, len(vcalls[k]))
             e["valu_per_launch"] = valu[k].get("SQ_INSTS_VALU", 0.0) / nl

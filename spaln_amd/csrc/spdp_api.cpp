@@ -237,8 +237,8 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     (void) hipSetDevice(ctx->device);
     // double affine gaps (Noll = 3, -yl3): forwardS_ng / hirschbergS_ng / scorealoneS_ng (the -A0 engines, spdp_rowwave<., ., ., DAGP>,
     // spdp_rowwave_udh<., DAGP>); the -A1 / -A2 / -A3 engines and the seeded walk's cut range refuse it (DevRun::prepare)
-    if (sc.noll != 2 && !(sc.noll == 3 && sc.scalar_engines == 1)) {
-        ctx->err = "double affine gaps (Noll = 3) are built for the -A0 engines only (SpdpScoring.scalar_engines = 1); Noll must be 2 or 3";
+    if (sc.noll != 2 && !(sc.noll == 3 && (sc.scalar_engines == 1 || sc.scalar_engines == 2))) {
+        ctx->err = "double affine gaps (Noll = 3) are built for the -A0 and -A1 engines (SpdpScoring.scalar_engines = 1 / 2); Noll must be 2 or 3";
         return -1;
     }
     // GapPenalty(1) of the first column is BasicGOP + BasicGEP only while codonk1 >= 1 (src/aln.h:275-282); a caller that leaves
@@ -493,8 +493,12 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         ctx->err = "scalar exact engine needs intpen / t53 in SpdpScoring and cano5 / cano3 / dinc per problem";
         return -1;
     }
-    if (st->sc.noll == 3 && flav != 3 && flav != 4 && flav != 5) {
-        ctx->err = "double affine gaps (Noll = 3): only the -A0 engines (forwardS_ng / hirschbergS_ng / scorealoneS_ng) are built";
+    if (st->sc.noll == 3 && !(flav >= 3 && flav <= 7)) {
+        // (-A1: scoreonlyS1 / forwardS1 since round 5; the reference's own hirschbergS1 is not usable under -yl3 -- it never lets
+        //  the second vertical gap reach H across an intermediate row -- so there is no result to be identical with)
+        ctx->err = flav == 8 ? "double affine gaps (Noll = 3) under -A1: the linear-space engine (hirschbergS1) is undefined in the reference; "
+                               "raise SpdpScoring.max_vmf_space so that the traceback branch is taken"
+                             : "double affine gaps (Noll = 3): only the -A0 and -A1 engines are built";
         return -1;
     }
     // hirschbergS1_wip with local ends (-LS): its own kernel (spdp_local_udh.hip), flavour 9
@@ -531,7 +535,7 @@ int DevRun::build(const DevStore* st, const std::vector<RunItem>& items, int fla
         P.tb_off = tb_tot;
         if (flav >= 6) {                // -A1 engines: hv / fv (/ hb / hc / fc) by diagonal, buf_size ints each, a counter
             P.bnd_off = bnd_tot - ((int64_t) P.buf_size + SPDP_BND_PAD);
-            bnd_tot = P.bnd_off + (flav >= 8 ? 6ll : 5ll) * P.buf_size + 8;   // udh forms: + the `ml` row of F
+            bnd_tot = P.bnd_off + (flav >= 8 ? 6ll : (st->sc.noll == 3 ? 8ll : 5ll)) * P.buf_size + 8;   // udh forms: + the `ml` row of F; Noll = 3: + fv2, fc2 behind the counter
             if (flav >= 8) { P.imd_off = imd_tot; imd_tot += (int64_t) it.n_im * 4 * it.w.width; }
             if (flav == 7) {
                 // (+ what the lanes may leave unused of the chunks of numbers they reserve, per stripe when pipelined)

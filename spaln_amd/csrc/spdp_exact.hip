@@ -23,7 +23,7 @@
 #define XN 16                                    // rows per stripe (SPDP_NELEM)
 #define XNEV SPDP_NEV16
 // post-splice flag of a state (src/aln.h:56): H 4, E 1, F 8 -- arithmetic, not a table in memory
-__device__ __forceinline__ int x_psp_bit_of(int d) { return d == 0 ? 4 : (d == 1 ? 1 : 8); }
+__device__ __forceinline__ int x_psp_bit_of(int d) { return d == 0 ? 4 : (d == 1 ? 1 : (d == 2 ? 8 : (d == 3 ? 2 : 16))); }    // H, E, F, E2, F2
 
 __device__ __forceinline__ int x_sadd(int a, int b) { return max(a + b, SPDP_FLOOR16); }
 __device__ __forceinline__ int x_up(int v) { return __shfl_up(v, 1, XN); }      // lane k <- lane k - 1 of its group
@@ -60,9 +60,17 @@ template <bool X> __device__ __forceinline__ void x_st(int* p, int v)
     else *p = v;
 }
 
-template <int MODE, bool PIPE>
+// DAGP: double affine gaps (PwdB::Noll = 3, -yl3; round 5): the second horizontal / vertical gap states E2 / F2 priced with
+// LongGOP / LongGEP (src/fwd2s1_simd.cc:347-352, 368-378 / 556-569, 592-611), the better gap of each pair competes for the cell
+// (:399-404 / :641-654), five states a donor candidate can leave from (hfesv[..][0..4], src/fwd2s1_simd.h:270-274) and NCAND + 2
+// candidates per lane (:197), a third boundary array (fv2, and fc2 with pointers).  Score-only and forward engines: the
+// reference's own hirschbergS1 is not usable under -yl3, the ladder refuses that branch.
+template <int MODE, bool PIPE, bool DAGP = false>
 __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(3))) spdp_exact(ScalarArgs A)
 {
+    static_assert(!DAGP || MODE != 2, "hirschbergS1 with double affine gaps is not defined by the reference");
+    constexpr int NCX = DAGP ? 6 : 4;           // Ncand: the list holds NCX + 1 entries
+    constexpr int NOD = DAGP ? 5 : 3;           // states a candidate can leave from
     constexpr bool FORWARD = MODE == 1;         // Vmf records, diagonal flags
     constexpr bool UDH = MODE == 2;             // links, intermediate rows
     constexpr bool PTR = MODE != 0;             // a pointer / link rides on H, E, F
@@ -72,7 +80,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
     __shared__ int s_mtx[32 * 32];
     __shared__ int2 s_col[4 * XWPB][64];
     __shared__ unsigned short s_ax[4 * XWPB][64];
-    enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_N };
+    enum { FD_HV, FD_FV, FD_HC, FD_FC, FD_HB, FD_FB, FD_FV2, FD_FC2, FD_N };
     __shared__ int s_fd[4 * XWPB][FD_N][20];
     // the tables an acceptor prices its candidates with: a read from memory inside that loop stalled the whole wave
     // (some lane of 64 sits on an acceptor column at almost every step)
@@ -116,6 +124,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
     const bool LocalL = local && a_exgl && b_exgl, LocalR = local && a_exgr && b_exgr;
     const bool spj = sc->spj;
     const int ge = sc->gep, gn = sc->gep + sc->gop, gop = sc->gop;
+    const int ge2 = DAGP ? A.lgep : 0, gn2 = DAGP ? A.lgep + A.lgop : 0, lgop = DAGP ? A.lgop : 0;
     const int minl = A.minl, ipen = A.ipen;
     const uint8_t* acod = A.a_codes + P.a_off;
     const int2* cols = A.cols + P.col_off;       // .x = (sig5 + ipen) | sig3 << 16, .y = b[n - 1]
@@ -132,6 +141,8 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
     int* fc = hc + P.buf_size;
     int* vcount = A.work + P.bnd_off + 5 * (int64_t) P.buf_size;          // forward: records appended so far
     int* fb = fc + P.buf_size;                   // udh with local left ends: left-end row (`ml`) of F (hb: of H)
+    int* fv2 = hv + 6 * (int64_t) P.buf_size;    // DAGP: the second vertical gap by diagonal, and its pointer
+    int* fc2 = hv + 7 * (int64_t) P.buf_size;
     int3* vrec = A.vmf + P.tb_off;
     int* vraw = reinterpret_cast<int*>(vrec);
     const int vcap = (int) P.imd_off;
@@ -198,6 +209,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 else if (r > rl + 1 && r < rr) h = gop;
             }
             x_st<PIPE>(&hv[r], h); x_st<PIPE>(&fv[r], XNEV);
+            if constexpr (DAGP) x_st<PIPE>(&fv2[r], XNEV);
             if constexpr (FORWARD) {                 // the Vmf part of fhinitS1 (:185-205): records 0 (dummy) and 1 (start)
                 const int ru = up + 2 * XN;
                 int c = 0;
@@ -205,6 +217,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 else if (r > rl && r <= ru) c = a_exgl ? 0 : 1;
                 else if (r < rl) c = b_exgl ? 0 : 1;
                 x_st<PIPE>(&hb[r], 0); x_st<PIPE>(&hc[r], c); x_st<PIPE>(&fc[r], c);
+                if constexpr (DAGP) x_st<PIPE>(&fc2[r], c);              // (src/fwd2s1_simd.cc:236)
             }
             if constexpr (UDH) {                     // the Hirschberg part (:206-227): link = diagonal where the path starts
                 const int ru = up + 2 * XN;
@@ -251,12 +264,13 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
         // per-lane state: H of the last two steps, F, E, flags, the candidate list of my row
         int H1 = XNEV, H2 = XNEV, F1 = XNEV, E = XNEV, ps = 0;
         int B1 = 0, B2 = 0, C1 = 0, C2 = 0, FC1 = 0, EC = 0, EB = 0, FB = 0;    // forward: flags / pointers of H (two steps), F, E
+        int E2 = XNEV, EC2 = 0, EB2 = 0, F21 = XNEV, FC21 = 0, FB2 = 0;        // DAGP: the long gaps (F21 / FC21: of my last step, for the lane below)
         // the donor candidates of my row, best first, in registers: slots are moved, never indexed by a variable (a
         // run-time index into five register arrays costs a select chain per access, and the wave pays for it at every step
         // on which ANY of its 64 lanes sits on a donor or acceptor column)
-        int c_val[5], c_jnc[5], c_dir[5], c_ml[5], c_ulk[5], c_dn5[5], ncand = -1;      // c_dn5: dinc5 of the donor column
+        int c_val[NCX + 1], c_jnc[NCX + 1], c_dir[NCX + 1], c_ml[NCX + 1], c_ulk[NCX + 1], c_dn5[NCX + 1], ncand = -1;      // c_dn5: dinc5 of the donor column
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; }
+        for (int i = 0; i <= NCX; ++i) { c_val[i] = XNEV; c_jnc[i] = c_dir[i] = c_ml[i] = c_ulk[i] = c_dn5[i] = 0; }
         const int m = ml + 1 + k;                             // my row
         const int sigJ_cip = (A.cip && P.cip_off >= 0 && m <= P.a_right) ? A.cip[P.cip_off + m] : 0;     // Cip_score::cip_score(m), fwd2s1_simd.cc:50
         // udh: is the current intermediate row in this stripe, and on which lane
@@ -290,7 +304,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             cc = in ? cols[c] : make_int2(0, 0);
             ax = in ? reinterpret_cast<const unsigned short*>(aux)[c] : 0u;
         };
-        int2 pc = make_int2(0, 0); unsigned pax = 0; int pfd[FD_N] = {0, 0, 0, 0, 0, 0};
+        int2 pc = make_int2(0, 0); unsigned pax = 0; int pfd[FD_N] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto prefetch = [&](int nb_, int rb_) {                           // block starting at step nb_, diagonal rb_
             ld_col(nb_ + k, pc, pax);
             const int e = min(rb_ + 1 + k, e_last);
@@ -298,6 +312,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             if constexpr (PTR) { pfd[FD_HC] = x_ld<PIPE>(&hc[e]); pfd[FD_FC] = x_ld<PIPE>(&fc[e]); }
             if constexpr (FORWARD) pfd[FD_HB] = x_ld<PIPE>(&hb[e]);
             if constexpr (UDH) { if (LocalL) { pfd[FD_HB] = x_ld<PIPE>(&hb[e]); pfd[FD_FB] = x_ld<PIPE>(&fb[e]); } }
+            if constexpr (DAGP) { pfd[FD_FV2] = x_ld<PIPE>(&fv2[e]); if constexpr (PTR) pfd[FD_FC2] = x_ld<PIPE>(&fc2[e]); }
         };
         auto commit = [&](int nb_) {                                      // the staged block becomes the current one
             ring[(nb_ + k) & 63] = pc; ringx[(nb_ + k) & 63] = (unsigned short) pax;
@@ -320,6 +335,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 if constexpr (PTR) { fd[FD_HC][16] = x_ld<PIPE>(&hc[e]); fd[FD_FC][16] = x_ld<PIPE>(&fc[e]); }
                 if constexpr (FORWARD) fd[FD_HB][16] = x_ld<PIPE>(&hb[e]);
                 if constexpr (UDH) { if (LocalL) { fd[FD_HB][16] = x_ld<PIPE>(&hb[e]); fd[FD_FB][16] = x_ld<PIPE>(&fb[e]); } }
+                if constexpr (DAGP) { fd[FD_FV2][16] = x_ld<PIPE>(&fv2[e]); if constexpr (PTR) fd[FD_FC2][16] = x_ld<PIPE>(&fc2[e]); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             prefetch(n, r);
@@ -351,9 +367,10 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             const int ke = min(j9, n - b_left);
             const int nj = n - k;                             // my column
             // boundary feeds of lane 0 (previous stripe's bottom row, by diagonal): entry r is fd[..][j], r + 1 is fd[..][j + 1]
-            int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0, bB1 = 0, bFB1 = 0;
+            int bH1 = 0, bF1 = 0, bH2 = 0, bC1 = 0, bFC1 = 0, bB2 = 0, bC2 = 0, bB1 = 0, bFB1 = 0, bF21 = 0, bFC21 = 0;
             if (k == 0) {
                 bH1 = fd[FD_HV][j + 1]; bF1 = fd[FD_FV][j + 1]; bH2 = fd[FD_HV][j];
+                if constexpr (DAGP) { bF21 = fd[FD_FV2][j + 1]; if constexpr (PTR) bFC21 = fd[FD_FC2][j + 1]; }
                 if constexpr (PTR) { bC1 = fd[FD_HC][j + 1]; bFC1 = fd[FD_FC][j + 1]; bC2 = fd[FD_HC][j]; }
                 if constexpr (FORWARD) bB2 = fd[FD_HB][j];
                 if constexpr (UDH) { if (LocalL) { bB2 = fd[FD_HB][j]; bB1 = fd[FD_HB][j + 1]; bFB1 = fd[FD_FB][j + 1]; } }
@@ -364,7 +381,9 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             if constexpr (FORWARD) upB2 = x_up(B2);
             int upB1 = 0, upFB1 = 0;                          // udh, local left ends: `ml` of the lane above
             if constexpr (UDH) { if (LocalL) { upB2 = x_up(B2); upB1 = x_up(B1); upFB1 = x_up(FB); } }
-            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; upB1 = bB1; upFB1 = bFB1; }
+            int upF21 = XNEV, upFC21 = 0;
+            if constexpr (DAGP) { upF21 = x_up(F21); if constexpr (PTR) upFC21 = x_up(FC21); }
+            if (k == 0) { upH1 = bH1; upF1 = bF1; upH2 = bH2; upC1 = bC1; upFC1 = bFC1; upB2 = bB2; upC2 = bC2; upB1 = bB1; upFB1 = bFB1; upF21 = bF21; upFC21 = bFC21; }
             // insertion, deletion, diagonal
             {
                 const int open = x_sadd(H1, gn), ext = x_sadd(E, ge);
@@ -373,6 +392,12 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 if constexpr (PTR) EC = m_ ? EC : C1;
                 if constexpr (UDH) { if (LocalL) EB = m_ ? EB : B1; }
             }
+            if constexpr (DAGP) {                             // the long horizontal gap (:347-352 / :556-569)
+                const int open = x_sadd(H1, gn2), ext = x_sadd(E2, ge2);
+                const bool m_ = ext > open;
+                E2 = m_ ? ext : open;
+                if constexpr (PTR) EC2 = m_ ? EC2 : C1;
+            }
             int F, FC = 0;
             {
                 const int open = x_sadd(upH1, gn), ext = x_sadd(upF1, ge);
@@ -380,6 +405,13 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 F = m_ ? ext : open;
                 if constexpr (PTR) FC = m_ ? upFC1 : upC1;
                 if constexpr (UDH) { if (LocalL) FB = m_ ? upFB1 : upB1; }
+            }
+            int F2 = XNEV, FC2 = 0;
+            if constexpr (DAGP) {                             // the long vertical gap (:368-375 / :592-608)
+                const int open = x_sadd(upH1, gn2), ext = x_sadd(upF21, ge2);
+                const bool m_ = ext > open;
+                F2 = m_ ? ext : open;
+                if constexpr (PTR) FC2 = m_ ? upFC21 : upC1;
             }
             int pv = 0;
             const bool incell = nj <= b_right && nj > b_left && k < j9;     // kb <= k < ke
@@ -390,8 +422,15 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             int HC = upC2;
             int code = 0;                                     // diag: 0, hori: 1, vert: 2 (pv_a)
             int HBu = upB2;                                   // udh, local left ends: `ml` of H
-            if (F > H) { H = F; HC = FC; HBu = FB; code = 2; }
-            if (E > H) { H = E; HC = EC; HBu = EB; code = 1; }
+            if constexpr (DAGP) {                             // the better gap of each pair competes for the cell (:376-378, 399-404)
+                const bool f2 = F2 > F, e2 = E2 > E;
+                const int Fb = f2 ? F2 : F, FCb = f2 ? FC2 : FC, Eb = e2 ? E2 : E, ECb = e2 ? EC2 : EC;
+                if (Fb > H) { H = Fb; HC = FCb; code = 2; }
+                if (Eb > H) { H = Eb; HC = ECb; code = 1; }
+            } else {
+                if (F > H) { H = F; HC = FC; HBu = FB; code = 2; }
+                if (E > H) { H = E; HC = EC; HBu = EB; code = 1; }
+            }
             int hb_pv = code;
             if (spj) ps &= code;
             if (!local) { if (!(H > XNEV)) H = XNEV; }
@@ -427,14 +466,14 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 const unsigned fl = axj & 0xffu;
                 // acceptor: Sjsites::get -- unless the best candidate, priced as high as anything can be, cannot beat the lowest of
                 // the three states it may raise (every update below is behind `x > state`)
-                if ((fl & 2) && ncand >= 0 && c_val[0] + sigJ_cip + s_gain[0] + s_gain[1] + (col.x >> 16) > min(H, min(E, F))) {
+                if ((fl & 2) && ncand >= 0 && c_val[0] + sigJ_cip + s_gain[0] + s_gain[1] + (col.x >> 16) > (DAGP ? min(min(H, min(E, F)), min(E2, F2)) : min(H, min(E, F)))) {
                     const int s3 = col.x >> 16;
                     const int d3 = (axj >> 8) & 15;
                     // udh: maxprd[d], brd -- the best candidate per state and overall: its value and link (and state)
                     bool mx_on[3] = {false, false, false}; int mx_v[3] = {0, 0, 0}, mx_lk[3] = {0, 0, 0};
                     bool br_on = false; int br_v = 0, br_d = 0;
 #pragma unroll
-                    for (int ci = 0; ci < 5; ++ci) {
+                    for (int ci = 0; ci <= NCX; ++ci) {
                         if (ci > ncand) continue;
                         const int d = c_dir[ci], don = c_jnc[ci];
                         if (nj - don < minl) continue;
@@ -442,16 +481,17 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                         const int pen = len < 4096 ? (int) s_ipen[len]
                                       : (A.ipen_runs ? ipen_runs_get(s_runs, len, A.intpen_len) : (int) A.intpen[min(len, A.intpen_len - 1)]);
                         const int x = c_val[ci] + sigJ_cip + pen + s3 + s_t53[16 * c_dn5[ci] + d3];
-                        int cur = d == 0 ? H : (d == 1 ? E : F);
+                        int cur = d == 0 ? H : (d == 1 ? E : (d == 2 || !DAGP ? F : (d == 3 ? E2 : F2)));
                         if (x <= cur) continue;
                         cur = (int) (short) x;
-                        if (d == 0) H = cur; else if (d == 1) E = cur; else F = cur;
+                        if (d == 0) H = cur; else if (d == 1) E = cur; else if (d == 2 || !DAGP) F = cur; else if (d == 3) E2 = cur; else F2 = cur;
                         ps |= x_psp_bit_of(d);
                         if constexpr (FORWARD) {
                             const int inner = vadd(m, don, c_ulk[ci]);
                             const int ptr = vadd(m, nj, inner);
                             const int bml = c_ml[ci];
-                            if (d == 0) { HB = bml; HC = ptr; } else if (d == 1) { EB = bml; EC = ptr; } else { FB = bml; FC = ptr; }
+                            if (d == 0) { HB = bml; HC = ptr; } else if (d == 1) { EB = bml; EC = ptr; } else if (d == 2 || !DAGP) { FB = bml; FC = ptr; }
+                            else if (d == 3) { EB2 = bml; EC2 = ptr; } else { FB2 = bml; FC2 = ptr; }
                             if (d && cur > H) { HB = bml; HC = ptr; }
                         }
                         if constexpr (UDH) {
@@ -485,28 +525,28 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                 }
                 if (fl & 1) {                                 // donor: Sjsites::put
                     const int sigJ = (int) (short) (col.x & 0xffff) - ipen;
-                    for (int kk = hb_pv ? 1 : 0; kk < 3; ++kk) {
+                    for (int kk = hb_pv ? 1 : 0; kk < NOD; ++kk) {
                         if (ps & x_psp_bit_of(kk)) continue;
-                        const int from = kk == 0 ? H : (kk == 1 ? E : F);
-                        if (kk && from <= H + gop) continue;
+                        const int from = kk == 0 ? H : (kk == 1 ? E : (kk == 2 ? F : (kk == 3 ? E2 : F2)));
+                        if (kk && from <= H + (kk <= 2 ? gop : lgop)) continue;      // GOP[(k + 1) / 2]
                         const int x = from + sigJ;
                         if (x <= XNEV) continue;
-                        if (ncand >= 3 && c_val[3] > x) { ncand = 3; continue; }      // a full list whose fourth entry beats x: it only gets shorter
+                        if (ncand >= NCX - 1 && c_val[NCX - 1] > x) { ncand = NCX - 1; continue; }      // a full list whose last kept entry beats x: it only gets shorter
                         // the free slot starts below the list and moves up past every entry x ties or beats
-                        int pos = ncand < 4 ? ncand + 1 : 4;
-                        if (ncand < 4) ++ncand;
+                        int pos = ncand < NCX ? ncand + 1 : NCX;
+                        if (ncand < NCX) ++ncand;
 #pragma unroll
-                        for (int l = 4; l >= 1; --l)
+                        for (int l = NCX; l >= 1; --l)
                             if (pos == l && x >= c_val[l - 1]) {
                                 c_val[l] = c_val[l - 1]; c_jnc[l] = c_jnc[l - 1]; c_dir[l] = c_dir[l - 1]; c_dn5[l] = c_dn5[l - 1];
                                 c_ml[l] = c_ml[l - 1]; c_ulk[l] = c_ulk[l - 1];
                                 pos = l - 1;
                             }
-                        if (pos < 4) {
+                        if (pos < NCX) {
                             int n_ml = 0, n_ulk = 0;
                             if constexpr (FORWARD) {
-                                n_ml = kk == 0 ? HB : (kk == 1 ? EB : FB);
-                                n_ulk = kk == 0 ? HC : (kk == 1 ? EC : FC);
+                                n_ml = kk == 0 ? HB : (kk == 1 ? EB : (kk == 2 ? FB : (kk == 3 ? EB2 : FB2)));
+                                n_ulk = kk == 0 ? HC : (kk == 1 ? EC : (kk == 2 ? FC : (kk == 3 ? EC2 : FC2)));
                             }
                             if constexpr (UDH) {
                                 if (imd_here) { if (kk & 1) x_st<PIPE>(&LNK(imd_i, 0, 0, rj), rlst); n_ulk = rj; }
@@ -514,7 +554,7 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
                                 n_ml = kk == 0 ? HB : (kk == 1 ? EB : FB);
                             }
 #pragma unroll
-                            for (int l = 0; l < 4; ++l)
+                            for (int l = 0; l < NCX; ++l)
                                 if (l == pos) {
                                     c_val[l] = (int) (short) x; c_jnc[l] = nj; c_dir[l] = kk; c_dn5[l] = (int) (axj >> 12) & 15;
                                     c_ml[l] = n_ml; c_ulk[l] = n_ulk;
@@ -536,11 +576,13 @@ __global__ void __launch_bounds__(64 * XWPB) __attribute__((amdgpu_waves_per_eu(
             // bottom row of the stripe -> boundary arrays
             if (k == j8 && j9 == ke && lw <= r0 && r0 <= up) {
                 x_st<PIPE>(&hv[r0], H); x_st<PIPE>(&fv[r0], F);
+                if constexpr (DAGP) { x_st<PIPE>(&fv2[r0], F2); if constexpr (PTR) x_st<PIPE>(&fc2[r0], FC2); }
                 if constexpr (FORWARD) x_st<PIPE>(&hb[r0], HB);
                 if constexpr (PTR) { x_st<PIPE>(&hc[r0], HC); x_st<PIPE>(&fc[r0], FC); }
                 if constexpr (UDH) { if (LocalL) { x_st<PIPE>(&hb[r0], HB); x_st<PIPE>(&fb[r0], FB); } }
             }
             H2 = H1; H1 = H; F1 = F;
+            if constexpr (DAGP) { F21 = F2; FC21 = FC2; }
             if constexpr (FORWARD || UDH) { B2 = B1; B1 = HB; }
             if constexpr (PTR) { C2 = C1; C1 = HC; FC1 = FC; }
             if (PIPE && n == n9 - 1) finish_stripe();
@@ -635,16 +677,18 @@ extern "C" hipError_t spdp_launch_exact(int mode, const ScalarArgs* a, hipStream
 {
     ScalarArgs A = *a;
     const dim3 blk(64 * XWPB);
+    const bool dagp = A.noll == 3;               // double affine gaps: score-only and forward engines (DevRun::build refuses mode 2)
+    if (dagp && mode == 2) return hipErrorNotSupported;
     if (A.pipe) {                                // one wave per (four problems, stripe)
         const dim3 grd((A.n_items + XWPB - 1) / XWPB);
         if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, true>), grd, blk, 0, stream, A);
-        else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, true>), grd, blk, 0, stream, A);
-        else hipLaunchKernelGGL((spdp_exact<0, true>), grd, blk, 0, stream, A);
+        else if (mode == 1) { if (dagp) hipLaunchKernelGGL((spdp_exact<1, true, true>), grd, blk, 0, stream, A); else hipLaunchKernelGGL((spdp_exact<1, true>), grd, blk, 0, stream, A); }
+        else { if (dagp) hipLaunchKernelGGL((spdp_exact<0, true, true>), grd, blk, 0, stream, A); else hipLaunchKernelGGL((spdp_exact<0, true>), grd, blk, 0, stream, A); }
         return hipGetLastError();
     }
     const dim3 grd((A.n_probs + 4 * XWPB - 1) / (4 * XWPB));
     if (mode == 2) hipLaunchKernelGGL((spdp_exact<2, false>), grd, blk, 0, stream, A);
-    else if (mode == 1) hipLaunchKernelGGL((spdp_exact<1, false>), grd, blk, 0, stream, A);
-    else hipLaunchKernelGGL((spdp_exact<0, false>), grd, blk, 0, stream, A);
+    else if (mode == 1) { if (dagp) hipLaunchKernelGGL((spdp_exact<1, false, true>), grd, blk, 0, stream, A); else hipLaunchKernelGGL((spdp_exact<1, false>), grd, blk, 0, stream, A); }
+    else { if (dagp) hipLaunchKernelGGL((spdp_exact<0, false, true>), grd, blk, 0, stream, A); else hipLaunchKernelGGL((spdp_exact<0, false>), grd, blk, 0, stream, A); }
     return hipGetLastError();
 }

@@ -1,6 +1,8 @@
 """The oracle's restatement of the alignS_ng dispatch ladder (oracle/host_logic.py)
 against the reference's own alignS_ng output (-A2 and -A3 engine selectors):
 raw engine score and the final SKL corner list, bit-identical."""
+import os
+
 import pytest
 
 from tests import spdg
@@ -146,3 +148,35 @@ def test_a1_double_affine_goldens():
         assert (flat or []) == fx["aln_skl_A1"].tolist(), f
         n += 1
     assert n >= 5
+
+
+def test_reference_hirschbergS1_under_yl3_is_not_usable():
+    """Why the -A1 linear-space engine is refused with double affine gaps (spdp_api.cpp, DevRun::build): the compiled reference
+    itself does not survive hirschbergS1 under -yl3 -- on the pairs of the l3a1_* fixtures a MaxVmfSpace small enough to send
+    lspS_ng into the linear-space branch ends in heap corruption / SIGSEGV (glibc aborts: rc -6 / -11), where the
+    traceback branch of the same pairs gives the fixtures' records.  Runs where the compiled reference is (oracle/_ref)."""
+    import importlib.util
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_dump = os.path.join(root, "oracle", "_ref", "ref_dump")
+    tab = os.path.join(root, "oracle", "_ref", "table")
+    if not (os.path.exists(ref_dump) and os.path.exists(os.path.join(tab, "mdm_mtx"))):
+        pytest.skip("compiled reference not present")
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(root, "tests", "golden", "make_goldens.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from spaln_amd import synth
+    cases = mg.cases()
+    died = 0
+    for name in ("l3a1_900nt", "l3a1_long_gaps"):
+        w, q, opts = cases[name]
+        opts = list(opts)
+        opts[opts.index("-V") + 1] = "60000"
+        with tempfile.TemporaryDirectory() as td:
+            gf, qf, out = (os.path.join(td, x) for x in ("g.fa", "q.fa", "o.spdg"))
+            synth.write_fasta(gf, "win", w)
+            synth.write_fasta(qf, "qry", q)
+            r = subprocess.run([ref_dump] + opts + [gf, qf, out], env=dict(os.environ, ALN_TAB=tab), capture_output=True)
+        died += r.returncode in (-6, -11)
+    assert died == 2

@@ -673,10 +673,13 @@ LEGS = {
               "C3 shape under -A0 (forwardH_ng / hirschbergH_ng)"),
     "c3_a1": (["--workload", "c3", "--engines", "a1", "--queries", "4000", "--steps", "2", "--warmup", "1"],
               "C3 shape under -A1 (forwardH1 / hirschbergH1)"),
-    "dropin": (["tools/dropin_demo.py", "--queries", "600", "--genes", "120", "--modes", "Q4,Q7", "--gpu-threads", "1000"],
+    "dropin": (["tools/dropin_demo.py", "--queries", "600", "--genes", "120", "--modes", "Q4,Q7", "--gpu-threads", "16"],
                "the reference's own CLI (src/spaln.cc, -t workers, block search, output writers) with alignS_ng switched to the library "
                "(oracle/_ref/spaln_gpu) against the unmodified build on a synthetic genome its own `spaln -W` formatted: -O4 records "
-               "compared, wall times of both; default engines (-A0)"),
+               "compared, wall times of both; default engines (-A0); both programs with -t16: the shim's batching boundary (integration/) "
+               "records the workers' aligner calls and aligns them in chunks beside the mapping"),
+    "dropin_q7_20k": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16"],
+                      "the same at 20 000 queries under -Q7 (the reference's normal mode): the size at which the device batches are large enough to matter"),
 }
 
 
@@ -688,7 +691,7 @@ def _run_leg(name):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.perf_counter()
-    if name == "dropin":                                         # a program of its own (tools/dropin_demo.py): its JSON line as it is
+    if name.startswith("dropin"):                                # a program of its own (tools/dropin_demo.py): its JSON line as it is
         if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
             return {"what": what, "error": "oracle/_ref/spaln_gpu is not built (needs the reference's sources at build time)"}
         try:

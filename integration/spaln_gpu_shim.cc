@@ -29,6 +29,8 @@
 SKL* alignS_ng_ref(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori);	// src/fwd2s1.cc, compiled under this name
 SKL* alignH_ng_ref(const Seq* seqs[], const PwdB* pwd, Gsinfo* gsi);		// src/fwd2h1.cc, likewise
 
+bool batch_mode();
+
 namespace {
 
 struct Req {
@@ -273,6 +275,7 @@ bool device_up()
 {
 	static std::once_flag once;
 	std::call_once(once, [] {
+	    if (batch_mode()) g_nctx = 1;			// (one call over everything: one context)
 	    if (const char* e = getenv("SPALN_GPU_CONTEXTS")) g_nctx = std::max(1, std::min(16, atoi(e)));
 	    for (int i = 0; i < g_nctx; ++i) {
 		SpdpContext* c = spdp_create(0);
@@ -315,6 +318,100 @@ bool time_ref_mode()
 	return on;
 }
 
+
+// ---- the batching boundary (round 5): map first, align afterwards -----------------------------------------------------
+// The reference's worker (src/spaln.cc:1363-1384) takes one query through block search, alignment, rescoring and output before it
+// looks at the next: its aligner call sees one pair at a time, and a device wants thousands.  In batch mode (the default;
+// SPALN_GPU_MODE=park restores the thread-parking form above) a worker's aligner call only RECORDS its pair -- deep copies
+// of the two Seq (the window keeps its Exinon and its HSPs), marshalled into the arrays of include/spdp.h right there, on the
+// worker's own thread -- and answers "no alignment", so the reference's blkaln moves on to the next candidate locus and the
+// next query at once: the `-t` workers of the reference map the whole input at host speed.  When they have joined
+// (MasterWorker calls closeGeneRecord(), src/spaln.cc:1454: spaln_gpu_main.cc points that one call here) every recorded
+// pair goes through ONE library call, and what blkaln does with an alignment -- spalign2's rescoring (src/spaln.cc:680-690),
+// the Vthr filter, the order by fstat.val, Gsinfo / alnoutput (src/spaln.cc:938-975) -- is done here, per query, on the
+// same number of threads.  Needs the statics of src/spaln.cc (outputs, skl2exrng): this file is compiled as part of
+// spaln_gpu_main.cc, one translation unit with it.
+struct Job {
+	Seq*	a = 0;			// the query as the call saw it (its own copy: the HSP callback moves its range about)
+	Seq*	b = 0;			// the window, with the Exinon the reference built for it and its HSPs
+const	PwdB*	pwd = 0;
+	int	kind = 0;		// 0 alignS_ng(.., 1), 1 the same with seeding on
+	long	group = 0;		// calls of one blkaln (one query): consecutive on their worker
+	int	order = 0;		// ... in the order blkaln made them
+	SpdpProblem p;
+	std::vector<int16_t> s5, s3;
+	SeedCols c;
+	std::vector<SpdpJuxt> jx;
+	int16_t	t53[256];		// the junction-pair table as this window shows it (entries of classes it lacks are 0)
+	Gsinfo	gsi;
+	bool	keep = false;
+	~Job() { delete a; if (b) { delete b->exin; b->exin = 0; delete b; } }
+};
+std::mutex		g_jm;
+std::condition_variable	g_jcv;
+std::thread		g_warm, g_aligner;
+std::vector<Job*>	g_jobs;			// complete groups, ready for the device
+struct Pending { std::vector<Job*> jobs; };	// the group a worker is still adding to (one per worker thread, kept past its exit)
+std::vector<Pending*>	g_pending;
+bool			g_input_done = false;
+int			g_chunk = 4096;		// SPALN_GPU_CHUNK: jobs that make a library call worth starting while the workers still map
+std::atomic<long>	g_groups;
+void aligner_loop();
+bool batch_mode()
+{
+	static const bool on = [] { const char* e = getenv("SPALN_GPU_MODE"); return !(e && !strcmp(e, "park")); }();
+	return on;
+}
+// the worker's side: one aligner call = one job
+void record_job(Seq* seqs[], const PwdB* pwd, int kind)
+{
+	static thread_local long	t_group = -1;
+	static thread_local int	t_order = 0;
+	static thread_local const Seq* t_a = 0;
+	static thread_local int	t_sid = -1, t_left = -1, t_right = -1;
+	static thread_local Pending* t_pend = 0;
+	static std::once_flag warm;			// the HIP context comes up (about a second) while the workers map, and a thread
+	std::call_once(warm, [] {			// of its own aligns what they have recorded, chunk by chunk, beside them
+	    if (const char* e = getenv("SPALN_GPU_CHUNK")) g_chunk = std::max(1, atoi(e));
+	    g_warm = std::thread([] { device_up(); });
+	    g_aligner = std::thread(aligner_loop);
+	});
+	Seq*	a = seqs[0];
+	Seq*	b = seqs[1];
+	if (!t_pend) { t_pend = new Pending; std::lock_guard<std::mutex> lk(g_jm); g_pending.push_back(t_pend); }
+	if (t_group < 0 || t_a != a || t_sid != a->sid || t_left != a->left || t_right != a->right) {	// another blkaln: the last one's group is complete
+	    if (!t_pend->jobs.empty()) {
+		std::lock_guard<std::mutex> lk(g_jm);
+		g_jobs.insert(g_jobs.end(), t_pend->jobs.begin(), t_pend->jobs.end());
+		t_pend->jobs.clear();
+		if ((int) g_jobs.size() >= g_chunk) g_jcv.notify_one();
+	    }
+	    t_group = g_groups++; t_order = 0; t_a = a; t_sid = a->sid; t_left = a->left; t_right = a->right;
+	}
+	Job*	j = new Job;
+	j->pwd = pwd; j->kind = kind; j->group = t_group; j->order = t_order++;
+	j->a = a->copyseq(0, CPY_ALL);
+	j->b = b->copyseq(0, CPY_ALL);
+	j->b->exin = b->exin; b->exin = 0;		// (Exinon reads its Seq in its constructor only; blkaln deletes it right after the call)
+	j->b->CdsNo = b->CdsNo; j->b->wllvl = b->wllvl;
+	if (b->jxt) { j->b->jxt = new JUXT[b->CdsNo + 1]; vcopy(j->b->jxt, b->jxt, b->CdsNo + 1); }
+	j->a->CdsNo = a->CdsNo;
+	fill_problem(j->p, j->a, j->b, j->s5, j->s3);
+	{
+	    SpdpScoring sc;				// (per job: only its junction table differs, and that is per window)
+	    fill_scoring(sc, pwd, j->b);
+	    fill_exact_s(sc, j->p, j->b, pwd, j->c, false);
+	    memcpy(j->t53, sc.t53, sizeof j->t53);
+	}
+	if (kind == 1)
+	    for (int k = 0; j->b->jxt && k <= j->b->CdsNo; ++k) {		// CdsNo HSPs + the free slot behind them
+const		JUXT& t = j->b->jxt[k];
+		SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		j->jx.push_back(q);
+	    }
+	t_pend->jobs.push_back(j);			// (my own list: no lock)
+}
+
 SKL* alignS_ng(Seq* seqs[], const PwdB* pwd, Gsinfo* gsi, int ori)
 {
 	if (time_ref_mode()) {
@@ -325,6 +422,11 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	    return skl;
 	}
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] alignS_ng ori %d qck %d\n", ori, (int) algmode.qck);
+	if (batch_mode() && ori == 1 && algmode.mlt != 1) {	// recorded now, aligned with everybody else's once the workers have joined
+	    record_job(seqs, pwd, algmode.qck? 1: 0);
+	    ++g_calls[algmode.qck? 1: 0];
+	    return 0;					// "no alignment": blkaln goes on to the next locus / query (src/spaln.cc:907-912)
+	}
 	device_up();
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] device up\n");
 	if (ori == 2 || (ori == 3 && algmode.qck)) { ++g_calls[3]; return alignS_ng_ref(seqs, pwd, gsi, ori); }
@@ -362,4 +464,160 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	++g_calls[r.kind + 1];
 	gsi->scr = r.scr;
 	return r.skl;
+}
+
+// ---- after the workers have joined: one library call, then what blkaln does with an alignment ------------------------------
+static RANGE* exrng_of(SKL* skl)			// skl2exrng, src/spaln.cc:646-663 (static there; same TU: call it)
+{
+	return skl2exrng(skl);
+}
+// one library call over `jobs` (complete groups), then spalign2's second half, blkaln's filter, order and output for them
+static std::mutex g_out_m;
+void align_jobs(std::vector<Job*>& jobs, int nthr)
+{
+	if (jobs.empty()) return;
+	{
+const	    auto t0 = std::chrono::steady_clock::now();
+	    if (g_warm.joinable()) g_warm.join();
+	    device_up();
+	    g_ctx = g_ctxs[0];
+	    std::stable_sort(jobs.begin(), jobs.end(), [](const Job* x, const Job* y) { return x->group != y->group? x->group < y->group: x->order < y->order; });
+const	    int	n = (int) jobs.size();
+	    // ---- one call per kind over everything recorded
+	    for (int kind = 0; kind < 2; ++kind) {
+		std::vector<Job*> part;
+		for (Job* j : jobs) if (j->kind == kind) part.push_back(j);
+		if (part.empty()) continue;
+const		int m = (int) part.size();
+		SpdpScoring sc;
+		fill_scoring(sc, part[0]->pwd, part[0]->b);
+		{ SeedCols tmp; SpdpProblem pp = part[0]->p; fill_exact_s(sc, pp, part[0]->b, part[0]->pwd, tmp, false); }	// minl, scalar_engines
+		memset(sc.t53, 0, sizeof sc.t53);
+		int	longest = 0;
+		for (Job* j : part) {
+		    longest = std::max(longest, j->b->len);
+		    for (int i = 0; i < 256; ++i) if (!sc.t53[i]) sc.t53[i] = j->t53[i];
+		}
+		g_ipen.resize(longest + 2);
+		for (int l = 0; l < longest + 2; ++l) g_ipen[l] = part[0]->pwd->IntPen->Penalty(l);
+		sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
+		std::vector<SpdpProblem> probs(m);
+		for (int i = 0; i < m; ++i) probs[i] = part[i]->p;
+		std::vector<SpdpAlignment> al(m);
+		int	rc;
+const		auto t1 = std::chrono::steady_clock::now();
+		if (kind == 0) rc = spdp_align_s(g_ctx, &sc, probs.data(), m, al.data());
+		else {
+		    SpdpSeedParams sp;
+		    fill_seed_params(sp, part[0]->pwd, part[0]->b);
+		    std::vector<const SpdpJuxt*> lists(m);
+		    std::vector<int32_t> counts(m), lowest(m);
+		    std::vector<Req> rq(m);			// the HSP callback's view of a job
+		    std::vector<Req*> rqp(m);
+		    for (int i = 0; i < m; ++i) {
+			Job* j = part[i];
+			lists[i] = j->jx.empty()? 0: j->jx.data();
+			counts[i] = j->b->jxt? j->b->CdsNo: 0;
+			lowest[i] = j->b->wllvl;
+			rq[i].seqs = &j->a;			// (a and b sit side by side in the job: seqs[0], seqs[1])
+			rq[i].pwd = j->pwd;
+			rqp[i] = &rq[i];
+		    }
+		    SpdpHspSource src = {rqp.data(), units_cb, 0};
+		    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), &src, al.data());
+		    int64_t st[11] = {0};
+		    spdp_seeded_stats(g_ctx, st, 11);
+		    for (int k = 0; k < 11; ++k) g_seed[k] += st[k];
+		}
+		if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
+		g_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+		for (int i = 0; i < m; ++i) { part[i]->gsi.scr = al[i].score; part[i]->gsi.skl = to_skl(al[i], part[i]->a); }
+		spdp_free_alignments(al.data(), m);
+		++g_batches;
+		if (m > g_largest) g_largest = m;
+	    }
+	    // ---- spalign2's second half and blkaln's filter (src/spaln.cc:680-696, 907-912), the jobs spread over the threads
+	    {
+		std::atomic<int> next(0);
+		auto work = [&] {
+		    for (int i; (i = next++) < n; ) {
+			Job* j = jobs[i];
+			Gsinfo* g = &j->gsi;
+			Seq* sqs[2] = {j->a, j->b};
+			bool ok = g->skl && g->skl->n != 0;
+			if (ok) {
+			    if (g->skl->m & AlgnTrb) { g->scr = skl_rngS_ng((const Seq**) sqs, g, j->pwd); g->eiscr2rng(); }
+			    else g->CDSrng = exrng_of(g->skl);
+			}
+			delete j->b->exin; j->b->exin = 0;		// suppress Boundary output
+			j->keep = ok && (OutPrm.all_out || g->scr > j->pwd->Vthr);
+			if (!j->keep) g->scr = NEVSEL;
+		    }
+		};
+		std::vector<std::thread> th;
+		for (int t = 1; t < nthr; ++t) th.emplace_back(work);
+		work();
+		for (auto& t : th) t.join();
+	    }
+	    // ---- per query: the order by fstat.val and the output (src/spaln.cc:938-975)
+	    for (int i0 = 0; i0 < n; ) {
+		int i9 = i0;
+		while (i9 < n && jobs[i9]->group == jobs[i0]->group) ++i9;
+const		int np = i9 - i0;
+		std::vector<int> odr(np);
+		for (int k = 0; k < np; ++k) odr[k] = k;
+		for (int k = 1; k < np; ++k) {			// insert sort, as nearly sorted
+		    int	l = odr[k];
+		    VTYPE v = jobs[i0 + l]->gsi.fstat.val;
+		    int	mm = k;
+		    while (--mm >= 0 && v > jobs[i0 + odr[mm]]->gsi.fstat.val) odr[mm + 1] = odr[mm];
+		    odr[mm + 1] = l;
+		}
+		INT	n_out = 0;
+		for (int k = 0; k < np; ++k) n_out += jobs[i0 + k]->keep;
+		if (OutPrm.MaxOut < n_out) n_out = OutPrm.MaxOut;
+		for (INT k = 0; k < n_out; ++k) {
+		    Job* j = jobs[i0 + odr[k]];
+		    Gsinfo* g = &j->gsi;
+		    if (!g->skl) continue;
+		    Seq* sqs[2] = {j->a, j->b};
+		    if (bool(g->skl->m & A_RevCom) ^ bool(j->a->inex.sens)) j->a->comrev();
+		    if (algmode.nsa == BED_FORM) g->rscr = selfAlnScr(j->a, j->pwd->simmtx);
+		    { std::lock_guard<std::mutex> lk(g_out_m); outputs.alnoutput(sqs, g); }
+		}
+		i0 = i9;
+	    }
+	    for (Job* j : jobs) delete j;
+	    g_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+	}
+}
+// the aligner thread: a library call whenever a chunk of complete groups has gathered, and a last one when the input is done
+void aligner_loop()
+{
+	for (;;) {
+	    std::vector<Job*> take;
+	    bool done;
+	    {
+		std::unique_lock<std::mutex> lk(g_jm);
+		g_jcv.wait(lk, [] { return g_input_done || (int) g_jobs.size() >= g_chunk; });
+		take.swap(g_jobs);
+		done = g_input_done;
+	    }
+	    // (beside the mapping workers a call's host side gets a quarter of the threads; the last call gets them all)
+	    align_jobs(take, done? std::max(1, (int) thread_num): std::max(1, (int) thread_num / 4));
+	    if (done) return;
+	}
+}
+void spaln_gpu_after_workers()
+{
+	if (g_aligner.joinable()) {
+	    {
+		std::lock_guard<std::mutex> lk(g_jm);
+		for (Pending* p : g_pending) { g_jobs.insert(g_jobs.end(), p->jobs.begin(), p->jobs.end()); p->jobs.clear(); }
+		g_input_done = true;
+	    }
+	    g_jcv.notify_one();
+	    g_aligner.join();
+	}
+	closeGeneRecord();				// what MasterWorker meant to call
 }

@@ -335,10 +335,12 @@ struct Job {
 	Seq*	a = 0;			// the query as the call saw it (its own copy: the HSP callback moves its range about)
 	Seq*	b = 0;			// the window, with the Exinon the reference built for it and its HSPs
 const	PwdB*	pwd = 0;
-	int	kind = 0;		// 0 alignS_ng(.., 1), 1 the same with seeding on
+	int	kind = 0;		// 0 alignS_ng(.., 1), 1 the same with seeding on, 3 alignH_ng, 4 alignH_ng with seeding on
 	long	group = 0;		// calls of one blkaln (one query): consecutive on their worker
 	int	order = 0;		// ... in the order blkaln made them
 	SpdpProblem p;
+	SpdpProblemH ph;		// (kinds 3 / 4: alignH_ng)
+	HCols	hc;
 	std::vector<int16_t> s5, s3;
 	SeedCols c;
 	std::vector<SpdpJuxt> jx;
@@ -396,14 +398,21 @@ void record_job(Seq* seqs[], const PwdB* pwd, int kind)
 	j->b->CdsNo = b->CdsNo; j->b->wllvl = b->wllvl;
 	if (b->jxt) { j->b->jxt = new JUXT[b->CdsNo + 1]; vcopy(j->b->jxt, b->jxt, b->CdsNo + 1); }
 	j->a->CdsNo = a->CdsNo;
-	fill_problem(j->p, j->a, j->b, j->s5, j->s3);
-	{
+	if (kind >= 3) {
+	    SpdpScoringH sc;
+	    fill_scoring_h(sc, pwd, j->b);
+	    fill_problem_h(j->ph, j->a, j->b, j->hc, j->b->left, j->b->right);	// the Exinon was built for the range b holds at the call
+	    j->ph.a_pad = *j->a->at(j->a->len);			// what exg_seq left behind the query
+	    fill_exact_h(sc, j->ph, j->b, pwd, j->c, false);
+	    memcpy(j->t53, sc.t53, sizeof j->t53);
+	} else {
+	    fill_problem(j->p, j->a, j->b, j->s5, j->s3);
 	    SpdpScoring sc;				// (per job: only its junction table differs, and that is per window)
 	    fill_scoring(sc, pwd, j->b);
 	    fill_exact_s(sc, j->p, j->b, pwd, j->c, false);
 	    memcpy(j->t53, sc.t53, sizeof j->t53);
 	}
-	if (kind == 1)
+	if (kind == 1 || kind == 4)
 	    for (int k = 0; j->b->jxt && k <= j->b->CdsNo; ++k) {		// CdsNo HSPs + the free slot behind them
 const		JUXT& t = j->b->jxt[k];
 		SpdpJuxt q = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
@@ -453,6 +462,11 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	    g_ref_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
 	    ++g_ref_calls;
 	    return skl;
+	}
+	if (batch_mode() && algmode.mlt != 1) {
+	    record_job((Seq**) seqs, pwd, algmode.qck? 4: 3);
+	    ++g_calls[algmode.qck? 5: 4];
+	    return 0;
 	}
 	device_up();
 	Req r; r.seqs = (Seq**) seqs; r.pwd = pwd; r.kind = algmode.qck? 4: 3;
@@ -536,6 +550,67 @@ const		auto t1 = std::chrono::steady_clock::now();
 		++g_batches;
 		if (m > g_largest) g_largest = m;
 	    }
+	    for (int kind = 3; kind < 5; ++kind) {		// alignH_ng, plain and seeded
+		std::vector<Job*> part;
+		for (Job* j : jobs) if (j->kind == kind) part.push_back(j);
+		if (part.empty()) continue;
+const		int m = (int) part.size();
+		SpdpScoringH sc;
+		fill_scoring_h(sc, part[0]->pwd, part[0]->b);
+		{ SeedCols tmp; SpdpProblemH pp = part[0]->ph; fill_exact_h(sc, pp, part[0]->b, part[0]->pwd, tmp, false); }	// the scalars of the exact model
+		memset(sc.t53, 0, sizeof sc.t53);
+		int	longest = 0;
+		for (Job* j : part) {
+		    longest = std::max(longest, j->b->len);
+		    for (int i = 0; i < 256; ++i) if (!sc.t53[i]) sc.t53[i] = j->t53[i];
+		}
+		g_ipen.resize(longest + 2);
+		for (int l = 0; l < longest + 2; ++l) g_ipen[l] = part[0]->pwd->IntPen->Penalty(l);
+		sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
+		std::vector<SpdpProblemH> probs(m);
+		for (int i = 0; i < m; ++i) probs[i] = part[i]->ph;
+		std::vector<SpdpAlignment> al(m);
+		int	rc;
+const		auto t1 = std::chrono::steady_clock::now();
+		if (kind == 3) rc = spdp_align_h(g_ctx, &sc, probs.data(), m, al.data());
+		else {
+		    SpdpSeedParams sp;
+		    fill_seed_params(sp, part[0]->pwd, part[0]->b);
+		    std::vector<const SpdpJuxt*> lists(m);
+		    std::vector<int32_t> counts(m), lowest(m);
+		    std::vector<Req> rq(m);
+		    std::vector<Req*> rqp(m);
+		    for (int i = 0; i < m; ++i) {
+			Job* j = part[i];
+			lists[i] = j->jx.empty()? 0: j->jx.data();
+			counts[i] = j->b->jxt? j->b->CdsNo: 0;
+			lowest[i] = j->b->wllvl;
+			rq[i].seqs = &j->a; rq[i].pwd = j->pwd;
+			rqp[i] = &rq[i];
+		    }
+		    SpdpHspSource src = {rqp.data(), units_cb, 0};
+		    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), &src, al.data());
+		}
+		if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
+		g_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+		for (int i = 0; i < m; ++i) {
+		    Job* j = part[i];
+		    // undefined in the reference itself (it reads outside its traceback bitmap / the sequences): its own aligner decides
+		    const bool undefined = al[i].n_skl < 0 || (rc == 1 && al[i].n_skl == 0 && al[i].score == SPDP_NEVSEL);
+		    if (undefined) {
+			Seq* sqs[2] = {j->a, j->b};
+			j->gsi.skl = alignH_ng_ref((const Seq**) sqs, j->pwd, &j->gsi);
+			++g_calls[3];
+		    } else {
+			j->gsi.scr = al[i].score;
+			j->gsi.skl = al[i].n_skl > 0? to_skl(al[i], j->a): 0;
+			if (j->gsi.skl) j->gsi.skl->m = 1;		// globalH_ng: skl->m = 1 (no A_RevCom on this path)
+		    }
+		}
+		spdp_free_alignments(al.data(), m);
+		++g_batches;
+		if (m > g_largest) g_largest = m;
+	    }
 	    // ---- spalign2's second half and blkaln's filter (src/spaln.cc:680-696, 907-912), the jobs spread over the threads
 	    {
 		std::atomic<int> next(0);
@@ -546,7 +621,10 @@ const		auto t1 = std::chrono::steady_clock::now();
 			Seq* sqs[2] = {j->a, j->b};
 			bool ok = g->skl && g->skl->n != 0;
 			if (ok) {
-			    if (g->skl->m & AlgnTrb) { g->scr = skl_rngS_ng((const Seq**) sqs, g, j->pwd); g->eiscr2rng(); }
+			    if (g->skl->m & AlgnTrb) {
+				g->scr = j->kind >= 3? skl_rngH_ng((const Seq**) sqs, g, j->pwd): skl_rngS_ng((const Seq**) sqs, g, j->pwd);
+				g->eiscr2rng();
+			    }
 			    else g->CDSrng = exrng_of(g->skl);
 			}
 			delete j->b->exin; j->b->exin = 0;		// suppress Boundary output

@@ -549,6 +549,20 @@ int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct Spd
  * The problems need all seven signal arrays and dinc on the host, sc->intpen / t53.  Return value and out[] as
  * spdp_align_h; a walk with a DP call on which the reference itself is undefined is reported as not served (return 1, no
  * alignment). */
+typedef struct SpdpPhaseMark {
+    int32_t n;                       /* position of the tron sequence                                              */
+    int8_t  side;                    /* 5: SGPT6::phs5, 3: SGPT6::phs3                                              */
+    int8_t  value;                   /* the phase the walk wrote there                                              */
+    int16_t reserved;
+} SpdpPhaseMark;
+/* A side effect of the reference's walk that its caller depends on: where the walk closes a gap between two HSPs with an
+ * intron of its own choice (Aln2h1::indelfreespjH, src/fwd2h1.cc:2508-2517) it WRITES the junction's phase into the Exinon
+ * (SGPT6::phs5 at the donor, phs3 at the acceptor), and skl_rngH_ng -- which spalign2 runs next on the same objects --
+ * reads the phase of every junction from those fields (src/fwd2h1.cc:824-825).  The library does not write into the
+ * caller's arrays; the marks of the last spdp_align_h_seeded call on this context, per query and in the order they were
+ * made, are handed out here for the binding to apply (b->exin->score_p(n)->phs5 / phs3 = value) before it rescores.
+ * *marks stays valid until the next seeded call on the context.  Returns the number of marks of query q (0: none). */
+int spdp_seeded_phase_marks(const SpdpContext* ctx, int q, const SpdpPhaseMark** marks);
 int spdp_align_h_seeded(SpdpContext* ctx, const struct SpdpScoringH* sc, const SpdpSeedParams* sp,
                         const struct SpdpProblemH* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
                         const int32_t* lowest_level, const SpdpHspSource* src, SpdpAlignment* out);

@@ -93,6 +93,18 @@ int units_cb(void* user, int32_t q, int32_t level, const int32_t span[8], const 
 	return 0;
 }
 
+// the reference's walk writes the phase of every junction it chooses itself into the Exinon (src/fwd2h1.cc:2508-2517) and
+// skl_rngH_ng reads it there (:824-825): the library hands those marks out instead of writing into the caller's objects
+void apply_phase_marks(Seq* b, int q)
+{
+const	SpdpPhaseMark* mk = 0;
+const	int	n = spdp_seeded_phase_marks(g_ctx, q, &mk);
+	for (int k = 0; k < n; ++k) {
+	    SGPT6* g = b->exin->score_p(mk[k].n);
+	    if (mk[k].side == 5) g->phs5 = mk[k].value; else g->phs3 = mk[k].value;
+	}
+}
+
 SKL* to_skl(const SpdpAlignment& al, const Seq* a)
 {
 	if (!al.n_skl) return 0;
@@ -156,6 +168,7 @@ const		    JUXT& t = b->jxt[j];
 	    rq[i]->scr = al[i].score;
 	    rq[i]->skl = al[i].n_skl > 0? to_skl(al[i], rq[i]->seqs[0]): 0;
 	    if (rq[i]->skl) rq[i]->skl->m = 1;			// globalH_ng: skl->m = 1 (no A_RevCom on this path)
+	    if (kind == 4 && !rq[i]->undefined) apply_phase_marks(rq[i]->seqs[1], i);
 	}
 	spdp_free_alignments(al.data(), n);
 	++g_batches;
@@ -605,6 +618,7 @@ const		auto t1 = std::chrono::steady_clock::now();
 			j->gsi.scr = al[i].score;
 			j->gsi.skl = al[i].n_skl > 0? to_skl(al[i], j->a): 0;
 			if (j->gsi.skl) j->gsi.skl->m = 1;		// globalH_ng: skl->m = 1 (no A_RevCom on this path)
+			if (kind == 4) apply_phase_marks(j->b, i);
 		    }
 		}
 		spdp_free_alignments(al.data(), m);

@@ -83,6 +83,7 @@ inline void set_default_params()	// same calls, same order as the CLI default se
 
 
 int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn);
+int dump_protein_body(Seq** seqs, PwdB* pwd, const std::vector<int>& udh_list, const char* outfn);
 
 // -B: the reference writes its -O12 record files (<prefix>.grd / .erd / .qrd, Gsinfo::ExonForm with BIN_FORM,
 // sqpr.cc:853-985) for the -A0 and the -A2 alignment of the case instead of the -O4 text; the three files end up in the

@@ -43,6 +43,15 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 	    if (b != b0) { fprintf(stderr, "ref_dump -Q: the reverse strand won geneorient(); not a fixture\n"); return 3; }
 	    if (np == 0) fprintf(stderr, "ref_dump -Q: no HSP at any level\n");
 	}
+	return dump_protein_body(seqs, pwd, udh_list, outfn);
+}
+
+// everything from here on reads the pair as the aligner sees it (ranges, Exinon, HSPs): the part a live run shares
+// (spaln_dumpq: the reference's own CLI writes the fixture of one named query from inside its alignH_ng call)
+int dump_protein_body(Seq** seqs, PwdB* pwd, const std::vector<int>& udh_list, const char* outfn)
+{
+	Seq*&	a = seqs[0];
+	Seq*&	b = seqs[1];
 	Writer	w(outfn);
 	w.put_int("is_protein", 1);
 	w.put("a_codes", 1, a->at(0), a->len);
@@ -228,7 +237,7 @@ int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, 
 		alprm2.jneibr, (int) algmode.lsg, (int) (alprm2.o * 1000)};
 	    w.put_i32("rparams", rp);
 	    std::vector<int>	ql, qp;
-	    for (int j = 0; j < IntronPrm.nquant; ++j) {
+	    for (int j = 0; pwd->IntPen->qm && j < IntronPrm.nquant; ++j) {	// (none under -A0: the quantiles exist for the `_wip` engines only, codepot.cc:163)
 		ql.push_back(pwd->IntPen->qm[j].len);
 		qp.push_back(pwd->IntPen->qm[j].pen);
 	    }
@@ -285,7 +294,20 @@ const		int	alg = algs[k];
 		w.put_i32(nm, skl2vec(gsi.skl));
 		snprintf(nm, sizeof nm, "seed_wilip_A%d", alg);
 		w.put_i32(nm, wilip_tap_log);
+		{   // what the walk left in the Exinon: the phases it wrote at the junctions it chose itself (src/fwd2h1.cc:2508-2517),
+		    // which skl_rngH_ng reads afterwards (:824-825) -- {position, phs5, phs3} wherever a mark differs from the input
+		    std::vector<int> mk;
+		    for (int n = std::max(0, b->left - 1), i = 0; n <= b->right + 1; ++n, ++i) {
+			const SGPT6* g = b->exin->score_p(n);
+			if (g->phs5 != sg0[i].phs5 || g->phs3 != sg0[i].phs3) { mk.push_back(n); mk.push_back(g->phs5); mk.push_back(g->phs3); }
+		    }
+		    snprintf(nm, sizeof nm, "seed_marks_A%d", alg);
+		    w.put_i32(nm, mk);
+		}
 	    }
+	    restore();				// (a live caller -- dumpq.cc -- goes on with the pair)
+	    for (int n = std::max(0, b->left - 1), i = 0; n <= b->right + 1; ++n, ++i) *b->exin->score_p(n) = sg0[i];
+	    if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
 	    return 0;
 	}
 	for (int pass = 0; pass < 2; ++pass) {

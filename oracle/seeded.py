@@ -140,12 +140,24 @@ def align_s_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict,
     return score.value, [1, len(fin)] + [x for mn in fin for x in mn], rc
 
 
+def marks_changed(fx, marks: dict) -> dict:
+    """{position: [phs5, phs3]} of the positions whose marks differ from the fixture's inputs -- the form of seed_marks_A*"""
+    p5, p3 = fx["phs5"], fx["phs3"]
+    out = {}
+    for n, v in marks.items():
+        a = int(p5[n]) if v[0] is None else v[0]
+        b = int(p3[n]) if v[1] is None else v[1]
+        if a != int(p5[n]) or b != int(p3[n]):
+            out[n] = [a, b]
+    return out
+
+
 JOINS_H = ["diagonal", "head_nogenome", "head_cds", "head_exon", "tail_nogenome", "tail_cds", "tail_exon", "junction",
            "micro_exon", "shortcut", "backforth", "small_dp", "recurse", "dp", "giveup_head", "giveup_tail", "giveup_inner",
            "pick_unit", "exact_head", "exact_tail"]
 
 
-def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict, simd: int = 2, trace=None, joins=None):
+def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict, simd: int = 2, trace=None, joins=None, marks=None):
     """alignH_ng with seeding on (the product's protein walk, spdp_seeded_walk_h.h, over the oracle's ladder):
     (gsi->scr, flat SKL or None, status); status 1 = the walk met a join it does not serve"""
     from . import host_logic_h as hh
@@ -194,6 +206,10 @@ def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict,
         raise errs[0]
     if rc < 0:
         raise RuntimeError(f"walk_check_run_h rc={rc}")
+    if marks is not None:                                        # the phases the walk wrote at junctions of its own choice
+        mk = C.POINTER(C.c_int32)()
+        for k in range(lib().walk_check_marks_h(C.byref(mk))):
+            marks.setdefault(int(mk[3 * k]), [None, None])[0 if mk[3 * k + 1] == 5 else 1] = int(mk[3 * k + 2])
     if rc == 1:
         return score.value, None, 1
     recs = [(rec[i].m, rec[i].n) for i in range(1, n_rec.value)]
@@ -201,3 +217,15 @@ def align_h_seeded(sc, sp, p, hsps, n_hsps: int, lowest_level: int, wilip: dict,
         return score.value, None, rc
     fin = hh.std_skl3(recs)
     return score.value, [1, len(fin)] + [x for mn in fin for x in mn], rc
+
+
+def marks_changed(fx, marks: dict) -> dict:
+    """{position: [phs5, phs3]} of the positions whose marks differ from the fixture's inputs -- the form of seed_marks_A*"""
+    p5, p3 = fx["phs5"], fx["phs3"]
+    out = {}
+    for n, v in marks.items():
+        a = int(p5[n]) if v[0] is None else v[0]
+        b = int(p3[n]) if v[1] is None else v[1]
+        if a != int(p5[n]) or b != int(p3[n]):
+            out[n] = [a, b]
+    return out

@@ -102,6 +102,7 @@ struct CallbackBackendH : DpBackend {
 }   // namespace
 
 extern "C" int walk_check_n_joins_h() { return SeedWalkH::J_COUNT; }
+static thread_local std::vector<int32_t> g_marks_h;    // of the last walk_check_run_h on this thread
 
 extern "C" int walk_check_run_h(const SpdpScoringH* sc, const SpdpSeedParams* sp, const SpdpProblemH* p,
                                 const SpdpJuxt* hsps, int n_hsps, int lowest_level, WalkCheckFn fn, void* user,
@@ -116,11 +117,15 @@ extern "C" int walk_check_run_h(const SpdpScoringH* sc, const SpdpSeedParams* sp
     *score = w.run(whole);
     *n_rec = (int) w.rec.size();
     if (joins) for (int k = 0; k < SeedWalkH::J_COUNT; ++k) joins[k] = w.joins[k];
+    g_marks_h.clear();                              // {position, side, value} of the marks the walk made (spdp_seeded_phase_marks of the product)
+    for (const auto& e : w.phs5.edits) { g_marks_h.push_back(e.first); g_marks_h.push_back(5); g_marks_h.push_back(e.second); }
+    for (const auto& e : w.phs3.edits) { g_marks_h.push_back(e.first); g_marks_h.push_back(3); g_marks_h.push_back(e.second); }
     if ((int) w.rec.size() > cap) return -1;
     if (!w.rec.empty()) memcpy(rec, w.rec.data(), sizeof(SpdpSkl) * w.rec.size());
     if (be.failed) return -1;
     return w.unsupported ? 1 : 0;
 }
+extern "C" int walk_check_marks_h(const int32_t** out) { *out = g_marks_h.data(); return (int) g_marks_h.size() / 3; }
 
 // SeedWalkH::split_codon on the whole active range of a problem (tests/test_oracle_spjseq.py)
 extern "C" int walk_check_split_codon_h(const SpdpProblemH* p, int n5, int n3, int32_t* cs)

@@ -259,6 +259,7 @@ struct SpdpContext {
     std::string err;
     std::vector<SpdpContext*> lanes;  // further lanes of this context (spdp_lane): chunks of a batch run side by side
     int64_t seed_stats[12] = {0};      // spdp_seeded_stats
+    std::vector<std::vector<SpdpPhaseMark>> seed_marks;    // spdp_seeded_phase_marks: per query of the last spdp_align_h_seeded call
     int64_t rerun_stats[2] = {0, 0};   // launches repeated because a cross-CU group / a tile pipeline gave up (spdp_rerun_stats)
     void*  stage_ptr[2] = {nullptr, nullptr};   // pinned host staging of DevStore::upload (grow-only)
     size_t stage_cap[2] = {0, 0};

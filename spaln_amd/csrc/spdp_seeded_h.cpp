@@ -33,6 +33,14 @@ struct DeviceBackendH : DpBackend {
         p.query = query; p.kind = kind; p.s = s; p.w = w;
         if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
         fiber->park(&p);                        // back when the request has been served
+        if (const char* tf = getenv("SPDP_SEED_TRACE"))         // (looking inside a walk: every DP request with what came back)
+            if (FILE* f = fopen(tf, "a")) {
+                fprintf(f, "q %d dp kind %d a %d..%d b %d..%d exg %d%d%d%d w %d %d %d cut %d %d -> %s score %d, %d records:", query, kind, s.al, s.ar, s.bl,
+                        s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr, w.lw, w.up, w.width, p.cut[0], p.cut[1], p.failed ? "FAILED" : "ok", p.score, (int) p.rec.size());
+                for (const SpdpSkl& r : p.rec) fprintf(f, " %d,%d", r.m, r.n);
+                fprintf(f, "\n");
+                fclose(f);
+            }
         if (p.failed) { failed = true; return SPDP_NEVSEL; }
         rec.insert(rec.end(), p.rec.begin(), p.rec.end());
         return p.score;
@@ -50,6 +58,13 @@ struct DeviceBackendH : DpBackend {
         ++*n_wilip;
         if (src->units(src->user, query, level, span, &flat, &n) || !flat) return false;
         const bool ok = parse_units(flat, n, units);
+        if (const char* tf = getenv("SPDP_SEED_TRACE"))
+            if (FILE* f = fopen(tf, "a")) {
+                fprintf(f, "q %d wilip level %d a %d..%d b %d..%d exg %d%d%d%d ->", query, level, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr);
+                for (int k = 0; k < n; ++k) fprintf(f, " %d", flat[k]);
+                fprintf(f, "\n");
+                fclose(f);
+            }
         if (src->release) src->release(src->user, query, flat);
         return ok;
     }
@@ -64,6 +79,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     for (int i = 0; i < n_probs; ++i) { out[i].score = SPDP_NEVSEL; out[i].n_skl = 0; out[i].skl = nullptr; out[i].flags = 0; out[i].reserved = 0; }
     if (n_probs <= 0) return 0;
     memset(ctx->seed_stats, 0, sizeof ctx->seed_stats);
+    ctx->seed_marks.assign(n_probs, {});
     if (sp->qck < 1 || sp->qck > 3) { ctx->err = "SpdpSeedParams.qck must be 1 .. 3"; return -1; }
     if (!sc->intpen || sc->intpen_len <= 0) { ctx->err = "the seeded path needs SpdpScoringH.intpen / t53"; return -1; }
     for (int i = 0; i < n_probs; ++i)
@@ -96,6 +112,8 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
             const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
             scores[q] = w.run(whole);
             recs[q].swap(w.rec);
+            for (const auto& e : w.phs5.edits) ctx->seed_marks[q].push_back({e.first, 5, e.second, 0});      // (one walk per query: no lock)
+            for (const auto& e : w.phs3.edits) ctx->seed_marks[q].push_back({e.first, 3, e.second, 0});
             status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
         } catch (...) { status[q] = 2; }            // (out of memory inside one walk: that query comes back without an alignment)
     };
@@ -198,4 +216,12 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         return 1;
     }
     return 0;
+}
+
+extern "C" int spdp_seeded_phase_marks(const SpdpContext* ctx, int q, const SpdpPhaseMark** marks)
+{
+    if (marks) *marks = nullptr;
+    if (!ctx || q < 0 || q >= (int) ctx->seed_marks.size() || ctx->seed_marks[q].empty()) return 0;
+    if (marks) *marks = ctx->seed_marks[q].data();
+    return (int) ctx->seed_marks[q].size();
 }

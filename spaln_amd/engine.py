@@ -455,6 +455,19 @@ class Engine:
         self.lib.spdp_free_alignments(arr, n)
         return res, [int(x) for x in orient]
 
+    def seeded_phase_marks(self, q: int) -> dict:
+        """spdp_seeded_phase_marks: {position: [phs5 or None, phs3 or None]} the walk of query q (last spdp_align_h_seeded call) wrote"""
+        class Mark(C.Structure):
+            _fields_ = [("n", C.c_int32), ("side", C.c_int8), ("value", C.c_int8), ("reserved", C.c_int16)]
+        mk = C.POINTER(Mark)()
+        self.lib.spdp_seeded_phase_marks.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.spdp_seeded_phase_marks.restype = C.c_int
+        n = self.lib.spdp_seeded_phase_marks(self.ctx, q, C.byref(mk))
+        out = {}
+        for k in range(n):
+            out.setdefault(int(mk[k].n), [None, None])[0 if mk[k].side == 5 else 1] = int(mk[k].value)
+        return out
+
     def seeded_stats(self) -> dict:
         v = (C.c_int64 * 6)()
         self.lib.spdp_seeded_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

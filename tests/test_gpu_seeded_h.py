@@ -41,6 +41,9 @@ def test_seeded_alignment_equals_reference(eng, path, alg, eng_sel):
     scr, flat = _flat(res[0])
     assert scr == int(fx[f"seed_scr_A{alg}"][0])
     assert flat == fx[f"seed_skl_A{alg}"].tolist()
+    # the phases the reference's walk wrote into its Exinon (skl_rngH_ng reads them next): handed out by spdp_seeded_phase_marks
+    want = {int(n_): [int(a), int(b)] for n_, a, b in fx[f"seed_marks_A{alg}"].reshape(-1, 3)}
+    assert seeded.marks_changed(fx, eng.seeded_phase_marks(0)) == want
 
 
 def test_requests_of_all_kinds_reach_the_device(eng):
@@ -104,3 +107,24 @@ def test_seeded_alignment_under_a1_equals_reference(eng, path):
     scr, flat = _flat(res[0])
     assert scr == int(fx["seed_scr_A1"][0])
     assert flat == fx["seed_skl_A1"].tolist()
+
+
+LIVE_H = golden_files("live_h_")
+
+
+@pytest.mark.parametrize("path", LIVE_H, ids=[f.split("/")[-1][:-5] for f in LIVE_H])
+def test_live_pairs_equal_reference(eng, path):
+    """pairs out of whole-program runs where the drop-in once differed from the reference (tools/dumpq_case.py;
+    live_h_q7555: one of 10 000 proteins under -Q7, an intron 2 nt to the left)"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 0)
+    sc.scalar_engines = 1
+    res = eng.align_h_seeded(sc, sp, p._owner, [hsps if n else None], [lowest], [wl])
+    scr, flat = _flat(res[0])
+    assert scr == int(fx["seed_scr_A0"][0])
+    assert flat == fx["seed_skl_A0"].tolist()
+    # what the reference's walk left in its Exinon (the phases of the junctions it chose itself; skl_rngH_ng reads them):
+    # the library hands the same marks out (spdp_seeded_phase_marks) instead of writing into the caller's arrays
+    want = {int(n_): [int(a), int(b)] for n_, a, b in fx["seed_marks_A0"].reshape(-1, 3)}
+    assert want, "the case was kept for its marks"
+    assert seeded.marks_changed(fx, eng.seeded_phase_marks(0)) == want

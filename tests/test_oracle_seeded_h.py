@@ -40,10 +40,14 @@ def test_seeded_alignment_equals_reference(fx, alg, simd):
         with pytest.raises(hh.ReferenceUndefined):
             seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, simd)
         return
-    scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, simd)
+    marks = {}
+    scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, simd, marks=marks)
     assert rc == 0
     assert scr == int(fx[f"seed_scr_A{alg}"][0])
     assert (flat or []) == fx[f"seed_skl_A{alg}"].tolist()
+    # what the reference's walk left in its Exinon (phases at the junctions it chose itself; skl_rngH_ng reads them afterwards)
+    want = {int(n): [int(a), int(b)] for n, a, b in fx[f"seed_marks_A{alg}"].reshape(-1, 3)}
+    assert seeded.marks_changed(fx, marks) == want
 
 
 def test_fixtures_reach_every_join():
@@ -85,3 +89,20 @@ def test_seeded_alignment_under_a1_equals_reference(path):
     assert rc == 0
     assert scr == int(fx["seed_scr_A1"][0])
     assert (flat or []) == fx["seed_skl_A1"].tolist()
+
+
+LIVE_H = golden_files("live_h_")
+
+
+@pytest.mark.parametrize("path", LIVE_H, ids=[f.split("/")[-1][:-5] for f in LIVE_H])
+def test_live_pairs_equal_reference(path):
+    """pairs taken out of whole-program runs (tools/dumpq_case.py: the reference's CLI wrote the fixture from inside its own
+    alignH_ng call -- the window blkaln cut, the HSPs its block search left; only the program's -A0 run exists)"""
+    fx = spdg.load(path)
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 0)
+    marks = {}
+    scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 0, marks=marks)
+    assert rc == 0 and scr == int(fx["seed_scr_A0"][0])
+    assert (flat or []) == fx["seed_skl_A0"].tolist()
+    want = {int(n): [int(a), int(b)] for n, a, b in fx["seed_marks_A0"].reshape(-1, 3)}
+    assert want and seeded.marks_changed(fx, marks) == want

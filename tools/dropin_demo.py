@@ -46,6 +46,43 @@ def records(text):
     return sorted(blocks)
 
 
+def make_dataset(td, args):
+    """the synthetic genome (formatted by the reference's own `spaln -W`) and the queries, in directory td; returns
+    (genome length, environment for the two programs)"""
+    rng = np.random.default_rng(synth.SEED + 8800)
+    if args.protein:
+        genes = [synth.make_protein_gene(np.random.default_rng(synth.SEED + 8801 + i), n_exons=6, flank=1000) for i in range(args.genes)]
+    else:
+        genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
+    n_chr = 4
+    per = args.genes // n_chr
+    tot = 0
+    with open(os.path.join(td, "gnm.mfa"), "w") as f:
+        for c in range(n_chr):
+            parts = []
+            for g in genes[c * per:(c + 1) * per]:
+                parts += [synth.random_dna(rng, int(rng.integers(3000, 20000))), g.window]
+            s = bytes(np.concatenate(parts)).decode()
+            tot += len(s)
+            f.write(f">chr{c + 1}\n")
+            f.writelines(s[i:i + 60] + "\n" for i in range(0, len(s), 60))
+    with open(os.path.join(td, "q.fa"), "w") as f:
+        for i in range(args.queries):
+            g = genes[int(rng.integers(0, per * n_chr))]
+            if args.protein:                                  # the planted protein with another 5 % of its residues replaced
+                q = g.query.copy()
+                hit = rng.random(q.size) < 0.05
+                q[hit] = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=int(hit.sum()))]
+            else:
+                q = synth.mutate(rng, g.query, 0.02, 0.002)
+            f.write(f">q{i}\n{bytes(q).decode()}\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
+    env.update(ALN_TAB=os.path.join(REF, "table"), ALN_DBS=td)
+    subprocess.run([os.path.join(REF, "spaln"), "-W", "-KP" if args.protein else "-KD", f"-t{args.threads}", "gnm.mfa"], cwd=td, env=env, check=True,
+                   capture_output=True)
+    return tot, env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, default=2000)
@@ -58,40 +95,9 @@ def main():
     ap.add_argument("--where", action="store_true", help="also time the reference's own aligner calls inside its program (Amdahl's bound for the drop-in)")
     ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")
     args = ap.parse_args()
-    rng = np.random.default_rng(synth.SEED + 8800)
-    if args.protein:
-        genes = [synth.make_protein_gene(np.random.default_rng(synth.SEED + 8801 + i), n_exons=6, flank=1000) for i in range(args.genes)]
-    else:
-        genes = [synth.make_gene(np.random.default_rng(synth.SEED + 8801 + i)) for i in range(args.genes)]
-    n_chr = 4
-    per = args.genes // n_chr
     out = {"queries": args.queries, "genes": args.genes, "query_type": "protein" if args.protein else "cDNA", "extra": args.extra, "runs": []}
     with tempfile.TemporaryDirectory(prefix="spdp_dropin_") as td:
-        tot = 0
-        with open(os.path.join(td, "gnm.mfa"), "w") as f:
-            for c in range(n_chr):
-                parts = []
-                for g in genes[c * per:(c + 1) * per]:
-                    parts += [synth.random_dna(rng, int(rng.integers(3000, 20000))), g.window]
-                s = bytes(np.concatenate(parts)).decode()
-                tot += len(s)
-                f.write(f">chr{c + 1}\n")
-                f.writelines(s[i:i + 60] + "\n" for i in range(0, len(s), 60))
-        with open(os.path.join(td, "q.fa"), "w") as f:
-            for i in range(args.queries):
-                g = genes[int(rng.integers(0, per * n_chr))]
-                if args.protein:                                  # the planted protein with another 5 % of its residues replaced
-                    q = g.query.copy()
-                    hit = rng.random(q.size) < 0.05
-                    q[hit] = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=int(hit.sum()))]
-                else:
-                    q = synth.mutate(rng, g.query, 0.02, 0.002)
-                f.write(f">q{i}\n{bytes(q).decode()}\n")
-        out["genome_nt"] = tot
-        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
-        env.update(ALN_TAB=os.path.join(REF, "table"), ALN_DBS=td)
-        subprocess.run([os.path.join(REF, "spaln"), "-W", "-KP" if args.protein else "-KD", f"-t{args.threads}", "gnm.mfa"], cwd=td, env=env, check=True,
-                       capture_output=True)
+        out["genome_nt"], env = make_dataset(td, args)
         for mode in args.modes.split(","):
             run = {"mode": "-" + mode}
             res = {}

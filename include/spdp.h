@@ -477,6 +477,9 @@ typedef struct SpdpScoringH {
                                         above 7 rows stops with SIGSEGV in the reference under -A1 (forwardH1
                                         without a Vmf) and comes back here as "not computed" (return value 1) */
     int32_t recursive;               /* algmode.alg & 4: lspH_ng always takes the recursive branch    */
+    int32_t noll;                    /* PwdB::Noll: 2 (also 0) affine gaps; 3 double affine gaps (-yl3): the -A0 engines
+                                        (forwardH_ng / hirschbergH_ng, src/fwd2h1.cc:297, 1088) keep a second vertical and a
+                                        second insertion state priced with GapW3L = lgop + lgep / lgep; other engines refuse */
     const struct SpdpSignalModelH* sigmodel;  /* optional: with it, problems whose signal arrays are all NULL get them (and
                                         dinc) computed on the device from the tron codes (spdp_signals_h.hip) */
 } SpdpScoringH;

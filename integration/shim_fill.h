@@ -103,6 +103,7 @@ const	Simmtx* sm = pwd->simmtx;			// aa x tron matrix: rows x dim
 	    for (int j = 0; j < sm->dim; ++j) sc.mtx[i * sm->dim + j] = sm->mtx[i][j];
 	sc.gop = pwd->BasicGOP;  sc.gep = pwd->BasicGEP;  sc.lgep = pwd->LongGEP;
 	sc.codonk1 = pwd->codonk1;			// GapExtPen3, src/aln.h:302
+	sc.noll = pwd->Noll;  sc.lgop = pwd->LongGOP;	// double affine gaps (-yl3): GapW3L = lgop + lgep
 	sc.gapw1 = pwd->GapW1;  sc.gapw2 = pwd->GapW2;  sc.gapw3 = pwd->GapW3;
 	sc.spj = b->inex.intr;  sc.llmt = IntronPrm.llmt;  sc.ipen = pwd->IntPen->Penalty();
 	sc.nquant = IntronPrm.nquant;			// 1 under -A3 (src/fwd2h1.cc:127)

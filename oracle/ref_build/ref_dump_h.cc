@@ -1,5 +1,6 @@
 // ref_dump_h.cc -- protein x genome half of the golden harness (TEST INFRASTRUCTURE ONLY).
 // Separate translation unit: fwd2s1_simd.h and fwd2h1_simd.h cannot share one.
+#include <algorithm>
 #include "ref_dump_common.h"
 #include "fwd2h1_simd.h"
 
@@ -310,7 +311,9 @@ const		int	alg = algs[k];
 	    if (b->jxt) vcopy(b->jxt, jx0.data(), jx0.size());
 	    return 0;
 	}
-	for (int pass = 0; pass < 2; ++pass) {
+	// -A list: only those selectors, and none of the engine-level `_wip` runs (double affine gaps, -l 3: the reference's
+	// `_wip` flavours are not defined there)
+	for (int pass = 0; pass < 2 && g_alg_list.empty(); ++pass) {
 	    IntronPrm.nquant = pass? 1: nq0;
 const	    char*	tag = pass? "q1": "qn";
 	    SpJunc	spjcs(b, pwd);
@@ -369,6 +372,7 @@ const		int	mode = ((std::max(abs(wdw.lw), wdw.up) + wdw.width) < SHRT_MAX)? 2: 4
 	static const int alg_order[] = {0, 2, 3, 6, 1};	// 6 = -A2 with the recursive switch (algmode.alg & 4);
 	for (int ai = 0; ai < 5; ++ai) {		// -A1 last: it leaves state behind that changes later runs
 	    const int alg = alg_order[ai];
+	    if (!g_alg_list.empty() && std::find(g_alg_list.begin(), g_alg_list.end(), alg) == g_alg_list.end()) continue;
 
 	    algmode.alg = alg;
 	    restore();

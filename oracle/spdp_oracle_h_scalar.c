@@ -16,7 +16,7 @@
  * This is the -A0 engine (int32, row by row, exact intron-length penalty with the top-NCAND donor
  * list per row and codon phase) -- also what the -A2/-A3 dispatch falls back to for sub-problems
  * with fewer than 8 query rows (trcbkalignH_ng src/fwd2h1.cc:2005, HomScoreH_ng :3297).
- * Affine gaps (Noll = 2), no cip, no cut range.  Junction terms:
+ * Affine gaps (Noll = 2) and double affine gaps (Noll = 3, -yl3: SpdpScoringH.noll; round 5).  Junction terms:
  *   spjscr(jnc, n) = IntPen(n - jnc) + sig3[n] + T53[16 * dinc5[jnc] + dinc3[n]]
  *     (SpJunc::spjscr src/codepot.cc:74-77, Exinon::sig53 IE53 src/codepot.cc:411-415)
  *   spjseq(jnc, n): the two codons the four bases around an intron spell (src/codepot.cc:79-107),
@@ -158,12 +158,19 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
     const int spj = sc->spj;
     const int lw = w->lw, up = w->up, width = w->width - cutlen;
     if (width < 7) { *score = SPDP_NEVSEL; return -1; }
-    const int GOP[2] = {0, sc->gop};
-    const size_t bufsiz = (size_t) 2 * width;
+    /* double affine gaps (PwdB::Noll = 3, -yl3; src/fwd2h1.cc:297, 343, 365, 413-424, 437-449, 577, 591-598): a second
+     * vertical (F2, by diagonal like F) and a second insertion state (E2, a queue like E1) priced with GapW3L / LongGEP,
+     * five states a candidate can leave from */
+    const int dagp = sc->noll == 3;
+    const int nod = dagp ? 5 : 3;
+    const int gapw3l = sc->lgop + sc->lgep;            /* PwdB::GapW3L, src/aln2.cc:124 */
+    const int GOP[3] = {0, sc->gop, sc->lgop};          /* PwdB::GOP, src/aln2.cc:111 */
+    const size_t bufsiz = (size_t) (dagp ? 3 : 2) * width;
     Rvpd* buf = (Rvpd*) malloc((bufsiz + 8) * sizeof(Rvpd));
     for (size_t i = 0; i < bufsiz + 8; ++i) buf[i] = black;
     Rvpd* hh0 = buf - lw + 3;
     Rvpd* hh1 = hh0 + width;
+    Rvpd* hh2 = hh1 + width;                            /* F2 (Noll = 3 only) */
     Vmf vmf = {0, 0, 0, skl != 0};
     vmf_add(&vmf, 0, 0, 0);                     /* skip 0-th record */
 
@@ -240,21 +247,24 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
         int n = n0;
         int r = n - 3 * m;
         Rvpd e1[NQUE] = {black, black, black};
-        if (!p->b_exgl && m == al) { e1[2] = hh0[r]; e1[2].val = sc->gapw3; }
+        Rvpd e2[NQUE] = {black, black, black};
+        if (!p->b_exgl && m == al) { e1[2] = e2[2] = hh0[r]; e1[2].val = sc->gapw3; e2[2].val = gapw3l; }
         Rvpd* h = hh0 + r;
         Rvpd* f = hh1 + r;
-        Rvpd* hf[NOD] = {h, 0, f};
+        Rvpd* f2 = dagp ? hh2 + r : 0;
+        Rvpd* hf[5] = {h, 0, f, 0, f2};
         const int aa0 = a_code(&cx, m - 1), aa1 = a_code(&cx, m);
         Rvpdj hl[3][NCAND + 1];
         int nx[3][NCAND + 1];
         for (int ph = 0; ph < 3; ++ph)
             for (int l = 0; l <= NCAND; ++l) { hl[ph][l] = blackj; nx[ph][l] = l; }
         int ncand[3] = {-1, -1, -1};
-        for (int q = 0; n <= n9; ++n, ++h, ++f) {
+        for (int q = 0; n <= n9; ++n, ++h, ++f, f2 += dagp) {
             int x, y;
-            hf[0] = h; hf[2] = f;
+            hf[0] = h; hf[2] = f; hf[4] = f2;
             const int sigE = (n > bl && n >= 2) ? p->sigE[n - 2] : 0;       /* position -1 is not in the arrays */
             Rvpd* const eq1 = hf[1] = e1 + q;
+            Rvpd* const eq2 = hf[3] = dagp ? e2 + q : 0;
             const Rvpd hq = *h;                 /* previous state */
             Rvpd* from = h;
             Rvpd* mx = h;
@@ -278,6 +288,13 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
                 if (x >= f->val) { f->val = x; f->dir = VERT; f->ptr = from->ptr; }
                 else if (y >= f->val) { f->val = y; f->dir = VERT; f->ptr = f[3].ptr; }
                 if (f->val > mx->val) mx = f;
+                if (dagp) {                     /* long deletion */
+                    x = from->val + gapw3l;
+                    y = f2[3].val + sc->lgep;
+                    if (x >= y) { f2->val = x; f2->dir = VERL; f2->ptr = from->ptr; }
+                    else { *f2 = f2[3]; f2->val = y; }
+                    if (f2->val > mx->val) mx = f2;
+                }
             }
             /* insertions of a codon, 2 nt, 1 nt */
             if (n > n0 + 2) {
@@ -287,6 +304,14 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
                 if (x > y) { *eq1 = *from; eq1->val = x; }
                 eq1->val += sigE;
                 eq1->dir = (eq1->dir & SPIN) + HORI;
+                if (dagp) {                     /* long insertion */
+                    x = from->val + gapw3l;
+                    y = eq2->val += sc->lgep;
+                    if (x > y) { *eq2 = *from; eq2->val = x; }
+                    eq2->val += sigE;
+                    eq2->dir = (eq2->dir & SPIN) + HORL;
+                    if (eq2->val > mx->val) mx = eq2;
+                }
             }
             if (n > n0 + 1) {
                 from = h - 2;
@@ -305,7 +330,7 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
                 for (;;) {
                     const int nb = n - phs;
                     const int* pnx = nx[phs + 1];
-                    const Rvpdj* maxphl[NOD] = {0, 0, 0};
+                    const Rvpdj* maxphl[5] = {0, 0, 0, 0, 0};
                     for (int l = 0; l <= ncand[phs + 1]; ++l) {
                         const Rvpdj* phl = hl[phs + 1] + pnx[l];
                         if (phs == 1 && phl->dir == 2) continue;
@@ -320,7 +345,7 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
                         from = hf[phl->dir];
                         if (x > from->val) { from->val = x; maxphl[phl->dir] = phl; }
                     }
-                    for (int d = 0; d < NOD; ++d) {
+                    for (int d = 0; d < nod; ++d) {
                         const Rvpdj* phl = maxphl[d];
                         if (!phl) continue;
                         from = hf[d];
@@ -353,7 +378,7 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
                     const int nb = n - phs;
                     const int sigJ = p->sig5[nb];
                     const int hd = dir2nod[mx->dir & 15];
-                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < NOD; ++k) {
+                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < nod; ++k) {
                         const int crossspj = phs == 1 && k == 0;
                         const Rvpd* src = crossspj ? &hq : hf[k];
                         if (!src->dir || (src->dir & SPIN)) continue;        /* no orphan exon */
@@ -382,11 +407,14 @@ static int scalar_forward_h_impl(const SpdpScoringH* sc, const SpdpProblemH* p, 
             }
             if (has_cut && n == cut_l) {                /* shortcut: the insertion states run on over the cut */
                 h -= 3; f -= 3;
+                if (dagp) f2 -= 3;
                 for (int pp = 0; pp < 3; ++pp) {
                     if (++q == 3) q = 0;
                     e1[q].val += sc->gep * cutlen / 3;
-                    *++h = e1[q];
+                    if (dagp) e2[q].val += sc->lgep * cutlen / 3;
+                    *++h = dagp ? e2[q] : e1[q];
                     *++f = black;
+                    if (dagp) *++f2 = black;
                 }
                 n += cutlen;
             }
@@ -515,7 +543,7 @@ int orc_scalar_forward_h_cut(const SpdpScoringH* sc, const SpdpProblemH* p, cons
  * its arrays on this input. */
 typedef struct { int val, dir, upr, lwr, ml, ulk; } Rvdwml;
 typedef struct { int val, dir, upr, lwr, ml, ulk, jnc; } Rvdwmlj;
-typedef struct { int mi; int* buf; int *hlnk[2], *vlnk[2], *lwrb[2], *uprb[2]; } HUImd;
+typedef struct { int mi; int* buf; int *hlnk[3], *vlnk[3], *lwrb[3], *uprb[3]; } HUImd;
 
 int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWindow* w, int n_im, int imd_intvl,
                      int32_t* score, int32_t* cpos, int32_t* ranges)
@@ -531,10 +559,13 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
     const int LocalR = Local && p->a_exgr && p->b_exgr;
     const int spj = sc->spj;
     const int lw = w->lw, up = w->up, width = w->width;
-    const int GOP[2] = {0, sc->gop};
+    const int dagp = sc->noll == 3;                     /* double affine gaps (src/fwd2h1.cc:1088, 1140, 1162, 1211-1247, 1316-1330, 1412-1440) */
+    const int noll = dagp ? 3 : 2, nod = dagp ? 5 : 3;
+    const int gapw3l = sc->lgop + sc->lgep;
+    const int GOP[3] = {0, sc->gop, sc->lgop};
 #define CPOS(i, c) cpos[(i) * 10 + (c)]
     for (int i = 0; i <= n_im; ++i) for (int c = 0; c < 10; ++c) CPOS(i, c) = EOU;
-    const size_t bufsiz = (size_t) 2 * width;
+    const size_t bufsiz = (size_t) noll * width;
     Rvdwml* wbuf = (Rvdwml*) malloc((bufsiz + 8) * sizeof(Rvdwml));
     int r = bl - 3 * ar;
     const Rvdwml black = {NEV, 0, r, r, 0, EOU};
@@ -542,6 +573,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
     for (size_t i = 0; i < bufsiz + 8; ++i) wbuf[i] = black;
     Rvdwml* hh0 = wbuf - lw + 3;
     Rvdwml* hh1 = hh0 + width;
+    Rvdwml* hh2 = hh1 + width;                          /* F2 (Noll = 3) */
 
     /* ---- hinitH_ng ---- */
     {
@@ -611,7 +643,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
     HUImd* imds = (HUImd*) calloc(n_im, sizeof(HUImd));
     {
         int mi = al;
-        const size_t us = (size_t) 2 * width;
+        const size_t us = (size_t) noll * width;
         for (int i = 0; i < n_im; ++i) {
             HUImd* d = imds + i;
             d->mi = (mi += imd_intvl);
@@ -620,8 +652,10 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
             for (size_t k = 0; k < us; ++k) { d->buf[2 * us + k] = INT_MAX; d->buf[3 * us + k] = INT_MIN; }
             d->hlnk[0] = d->buf - lw + 1;  d->vlnk[0] = d->hlnk[0] + us;
             d->lwrb[0] = d->vlnk[0] + us;  d->uprb[0] = d->lwrb[0] + us;
-            d->hlnk[1] = d->hlnk[0] + width; d->vlnk[1] = d->vlnk[0] + width;
-            d->lwrb[1] = d->lwrb[0] + width; d->uprb[1] = d->uprb[0] + width;
+            for (int k = 1; k < noll; ++k) {
+                d->hlnk[k] = d->hlnk[k - 1] + width; d->vlnk[k] = d->vlnk[k - 1] + width;
+                d->lwrb[k] = d->lwrb[k - 1] + width; d->uprb[k] = d->uprb[k - 1] + width;
+            }
         }
     }
     HUImd* imd = imds;
@@ -640,10 +674,12 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
         int n = n0;
         r = n - 3 * m;
         Rvdwml e1[NQUE] = {black, black, black};
-        if (!p->b_exgl && m == al) { e1[2] = hh0[r]; e1[2].val += sc->gapw3; }
+        Rvdwml e2[NQUE] = {black, black, black};
+        if (!p->b_exgl && m == al) { e1[2] = e2[2] = hh0[r]; e1[2].val += sc->gapw3; e2[2].val += gapw3l; }
         Rvdwml* h = hh0 + r;
         Rvdwml* f = hh1 + r;
-        Rvdwml* hf[NOD] = {h, 0, f};
+        Rvdwml* f2 = dagp ? hh2 + r : 0;
+        Rvdwml* hf[5] = {h, 0, f, 0, f2};
         const int aa0 = a_code(&cx, m - 1), aa1 = a_code(&cx, m);
         Rvdwmlj hl[3][NCAND + 1];
         int nx[3][NCAND + 1];
@@ -651,11 +687,12 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
             for (int l = 0; l <= NCAND; ++l) { hl[ph][l] = blackj; nx[ph][l] = l; }
         int ncand[3] = {-1, -1, -1};
         int q = 0;
-        for ( ; n <= n9; ++n, ++r, ++h, ++f) {
+        for ( ; n <= n9; ++n, ++r, ++h, ++f, f2 += dagp) {
             int x, y;
-            hf[0] = h; hf[2] = f;
+            hf[0] = h; hf[2] = f; hf[4] = f2;
             const int sigE = (n > bl && n >= 2) ? p->sigE[n - 2] : 0;
             Rvdwml* const eq1 = hf[1] = e1 + q;
+            Rvdwml* const eq2 = hf[3] = dagp ? e2 + q : 0;
             const Rvdwml hq = *h;
             Rvdwml* from = h;
             Rvdwml* mx = h;
@@ -677,6 +714,13 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                 if (x >= f->val) { *f = *from; f->val = x; f->dir = VERT; }
                 else if (y >= f->val) { *f = f[3]; f->val = y; f->dir = VERT; }
                 if (f->val >= mx->val) mx = f;
+                if (dagp) {                     /* long deletion */
+                    x = from->val + gapw3l;
+                    y = f2[3].val + sc->lgep;
+                    if (x >= y) { *f2 = *from; f2->val = x; f2->dir = VERL; }
+                    else { *f2 = f2[3]; f2->val = y; }
+                    if (f2->val >= mx->val) mx = f2;
+                }
             }
             if (n > n0 + 2) {
                 from = h - 3;
@@ -685,6 +729,14 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                 if (x > y) { *eq1 = *from; eq1->val = x; }
                 eq1->val += sigE;
                 eq1->dir = (eq1->dir & SPIN) + HORI;
+                if (dagp) {                     /* long insertion */
+                    x = from->val + gapw3l;
+                    y = eq2->val += sc->lgep;
+                    if (x > y) { *eq2 = *from; eq2->val = x; }
+                    eq2->val += sigE;
+                    eq2->dir = (eq2->dir & SPIN) + HORL;
+                    if (eq2->val > mx->val) mx = eq2;
+                }
             }
             if (n > n0 + 1) {
                 from = h - 2;
@@ -703,7 +755,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                 for (;;) {
                     const int nb = n - phs;
                     const int* pnx = nx[phs + 1];
-                    const Rvdwmlj* maxphl[NOD] = {0, 0, 0};
+                    const Rvdwmlj* maxphl[5] = {0, 0, 0, 0, 0};
                     for (int l = 0; l <= ncand[phs + 1]; ++l) {
                         const Rvdwmlj* phl = hl[phs + 1] + pnx[l];
                         if (phs == 1 && phl->dir == 2) continue;
@@ -718,8 +770,8 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                         from = hf[phl->dir];
                         if (x > from->val) { from->val = x; maxphl[phl->dir] = phl; }
                     }
-                    int maxk = NOD;
-                    for (int k = 0; k < NOD; ++k) {
+                    int maxk = nod;
+                    for (int k = 0; k < nod; ++k) {
                         const Rvdwmlj* phl = maxphl[k];
                         if (!phl) continue;
                         from = hf[k];
@@ -730,17 +782,19 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                         from->ulk = phl->ulk;
                         if (from->val >= mx->val) { maxk = k; mx = from; }
                     }
-                    if (is_imd && maxk < NOD) {
+                    if (is_imd && maxk < nod) {
                         const Rvdwmlj* phl = maxphl[maxk];
                         imd->hlnk[0][r] = phl->ulk;
                         mx->ulk = rlst[q] = r;
                         spj3 = 1;
                         if (maxk == 0) {
-                            if ((phl = maxphl[1]) && hf[1]->val > mx->val + GOP[1]) {
-                                hf[1]->ulk = r + width;
-                                imd->hlnk[1][r] = phl->ulk;
+                            for (int c = 1, d = 1; c < noll; ++c, d += 2) {
+                                if ((phl = maxphl[d]) && hf[d]->val > mx->val + GOP[c]) {
+                                    hf[d]->ulk = r + c * width;
+                                    imd->hlnk[c][r] = phl->ulk;
+                                }
+                                if (maxphl[d + 1] && hf[d + 1]->val > mx->val + GOP[c]) hf[d + 1]->ulk = r + c * width;
                             }
-                            if (maxphl[2] && hf[2]->val > mx->val + GOP[1]) hf[2]->ulk = r + width;
                         }
                     }
                     if (p->phs3[n] - phs == 3) { phs = 1; continue; }
@@ -771,7 +825,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
                 for (;;) {
                     const int nb = n - phs;
                     const int sigJ = p->sig5[nb];
-                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < NOD; ++k) {
+                    for (int k = (hd == 0 || phs == 1) ? 0 : 1; k < nod; ++k) {
                         const int crossspj = phs == 1 && k == 0;
                         const Rvdwml* src = crossspj ? &hq : hf[k];
                         if (!src->dir || (src->dir & SPIN)) continue;
@@ -807,7 +861,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
             if (is_imd) {
                 if (hd == 0) rlst[q] = r;
                 else if (!spj3 && hd % 2) imd->hlnk[0][r] = rlst[q];
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < noll; ++k) {
                     Rvdwml* g = hf[2 * k];
                     imd->vlnk[k][r] = g->ulk;
                     imd->lwrb[k][r] = imin(r, g->lwr);
@@ -889,7 +943,7 @@ int orc_scalar_udh_h(const SpdpScoringH* sc, const SpdpProblemH* p, const SpdpWi
     for ( ; i >= 0 && (imd = imds + i)->mi > maxh_ml; --i) {
         int c = 0, d = 0;
         for ( ; r > up; r -= width) ++d;
-        if (d > 1 || r < lw - 1) { rc = -3; break; }
+        if (d > noll - 1 || r < lw - 1) { rc = -3; break; }
         if (imd->vlnk[d][r] < EOU) {
             CPOS(i, c++) = imd->mi;
             CPOS(i, c++) = (d > 0) ? 1 : 0;

@@ -338,6 +338,7 @@ class ScoringH(C.Structure):
         ("minl", C.c_int32),
         ("scalar_engines", C.c_int32),
         ("recursive", C.c_int32),
+        ("noll", C.c_int32),
         ("sigmodel", C.c_void_p),
     ]
 
@@ -410,7 +411,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
                    spj=1, llmt=20, ipen=0, qm_len=(0,), qm_pen=(0,), nquant=None, local=0,
                    term_codon=1, sh=100, max_vmf_space=32 * 1024 * 1024, ubh=0,
                    ref_nelem=REF_NELEM, lgop=0, gape1=0, gape2=0, extragop=0, diffu=0, k1=0,
-                   intpen=None, t53=None, minl=0, scalar_engines=0, recursive=0, sigmodel=None) -> ScoringH:
+                   intpen=None, t53=None, minl=0, scalar_engines=0, recursive=0, sigmodel=None, noll=2) -> ScoringH:
     sc = ScoringH()
     sc.mtx_rows, sc.mtx_cols = int(mtx_rows), int(mtx_cols)
     flat = np.asarray(mtx, dtype=np.int32).ravel()
@@ -433,6 +434,7 @@ def make_scoring_h(*, mtx, mtx_rows, mtx_cols, gop, gep, lgep, codonk1, gapw1, g
     sc.minl = int(minl)
     sc.scalar_engines = int(scalar_engines)
     sc.recursive = int(recursive)
+    sc.noll = int(noll)
     if sigmodel is not None:
         sc._keep_sigmodel = sigmodel
         sc.sigmodel = C.addressof(sigmodel)

@@ -165,6 +165,7 @@ def cases():
     g = gene(7100, n_exons=24, mrna_len=6000, flank=1000, intron_hi=2500)
     c["c5_6kb"] = (g.window, g.query, ["-A", "0"])
     c.update(protein_cases())
+    c.update(protein_noll3_cases())
     c.update(cip_cases())
     return c
 
@@ -263,6 +264,48 @@ def protein_cases():
             if i > 0 and (i + k) % 2 == 1:
                 w[lo + 1] = ord("N")
         c[f"h1_amb_junction{k}"] = (w, g.query, ["-u", "1,2"])
+    return c
+
+
+def protein_noll3_cases():
+    """aa x genome under double affine gaps (-yl3, PwdB::Noll = 3), -A0 only: forwardH_ng / hirschbergH_ng with their second
+    vertical and second insertion state (src/fwd2h1.cc:297, 343, 365, 413-449, 577-598; 1088, 1140, 1162, 1211-1247,
+    1316-1330, 1412-1440).  Queries with residues missing (long insertion on the genome side) and extra residues (long
+    deletion) well beyond codonk1 = 21 nt, so that the long pair wins; a small MaxVmfSpace sends the ladder through the
+    linear-space engine (hl3_udh_*)."""
+    c = {}
+    aa = synth._AA_LETTERS
+
+    def gaps(g, seed, cut=(90, 112), ins_at=200, ins_len=16):
+        rng = np.random.default_rng(synth.SEED + 7300 + seed)
+        q = g.query
+        return np.concatenate([q[:cut[0]], q[cut[1]:ins_at], aa[rng.integers(0, 20, size=ins_len)], q[ins_at:]])
+    g = pgene(61, n_exons=4, aa_len=300, flank=300, intron_hi=700)
+    ql = gaps(g, 1)
+    c["hl3_long_gaps"] = (g.window, ql, ["-l", "3", "-A", "0"])
+    c["hl3_long_gaps_global"] = (g.window[g.exons[0][0] - 30:g.exons[-1][1] + 30], ql, ["-l", "3", "-A", "0", "-g", "0000"])
+    g = pgene(62, n_exons=5, aa_len=260, flank=250, intron_hi=600, sub=0.3)
+    c["hl3_divergent"] = (g.window, gaps(g, 2, cut=(60, 75), ins_at=150, ins_len=12), ["-l", "3", "-A", "0"])
+    g = pgene(63, n_exons=4, aa_len=220, flank=200, intron_hi=500, sub=0.1)
+    c["hl3_local"] = (g.window, gaps(g, 3, cut=(40, 58), ins_at=120, ins_len=14), ["-l", "3", "-A", "0", "-L"])
+    for m in (5, 12):
+        g = pgene(64 + m, n_exons=1, aa_len=40, flank=80)
+        c[f"hl3_tiny_m{m}"] = (g.window, g.query[:m], ["-l", "3", "-A", "0"])
+    g = pgene(66, n_exons=3, aa_len=200, flank=200, intron_hi=400)
+    # a deletion of three codons inside an exon of the window and one of fifteen: frame-preserving gaps of both kinds
+    w = g.window
+    e = g.exons
+    w = np.concatenate([w[:e[0][0] + 60], w[e[0][0] + 69:e[1][0] + 30], w[e[1][0] + 75:]])
+    c["hl3_window_deletions"] = (w, g.query, ["-l", "3", "-A", "0"])
+    g = pgene(67, n_exons=5, aa_len=320, flank=300, intron_hi=900)
+    qu = gaps(g, 4, cut=(100, 125), ins_at=230, ins_len=18)
+    c["hl3_udh_auto"] = (g.window, qu, ["-l", "3", "-A", "0", "-V", "400000"])
+    c["hl3_udh_forced3"] = (g.window, qu, ["-l", "3", "-A", "0", "-V", "200000", "-U", "3"])
+    c["hl3_udh_forced7"] = (g.window, qu, ["-l", "3", "-A", "0", "-V", "200000", "-U", "7"])
+    g = pgene(68, n_exons=6, aa_len=450, flank=400, intron_hi=1500, sub=0.2)
+    c["hl3_udh_450aa"] = (g.window, gaps(g, 5, cut=(200, 230), ins_at=330, ins_len=20), ["-l", "3", "-A", "0", "-V", "1500000"])
+    g = pgene(69, n_exons=4, aa_len=240, flank=250, intron_hi=600, sub=0.1)
+    c["hl3_udh_local"] = (g.window, gaps(g, 6, cut=(70, 90), ins_at=160, ins_len=15), ["-l", "3", "-A", "0", "-L", "-V", "150000"])
     return c
 
 

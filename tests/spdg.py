@@ -100,7 +100,7 @@ def scoring_h(fx: dict, nquant: int | None = None, **over) -> abi.ScoringH:
               spj=q["b_intr"], llmt=q["llmt"], ipen=q["ipen"], qm_len=fx["qm_len"], qm_pen=fx["qm_pen"],
               nquant=(q["nquant"] if nquant is None else nquant), local=1 if q["local"] else 0,
               term_codon=1 if h["lcl"] & 2 else 0, sh=q["sh"], max_vmf_space=q["max_vmf_space"],
-              ubh=q["ubh"])
+              ubh=q["ubh"], noll=q.get("noll", 2))
     if "rparams" in fx:                                  # exact-model inputs of the rescoring walk
         kw.update(lgop=q["lgop"], gape1=h["gape1"], gape2=h["gape2"], extragop=h["extragop"],
                   diffu=int(fx["rparams"][0]), k1=h["k1"], intpen=fx["intpen"], t53=fx["t53"],

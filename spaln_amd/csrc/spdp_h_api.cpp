@@ -252,6 +252,12 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;
     for (int i = 0; i < n && !dev_sig; ++i) if (!probs[i].dinc) scalar_ok = false;      // (device-made signals bring dinc along)
+    // double affine gaps (PwdB::Noll = 3, -yl3): built for the -A0 engines (forwardH_ng / hirschbergH_ng, spdh_rowwave<., ., ., true>);
+    // the `_wip` and -A1 families have no well-defined form of it in the reference
+    if (sc.noll != 0 && sc.noll != 2 && !(sc.noll == 3 && sc.scalar_engines == 1)) {
+        ctx->err = "double affine gaps (SpdpScoringH.noll = 3) are built for the -A0 engines (scalar_engines = 1); noll must be 2 or 3";
+        return -1;
+    }
     if (!n) return 0;
     if (scalar_ok) {
         // the table, and behind it its steps beyond the part the kernels keep in LDS (spdp_ipen_runs.h)
@@ -623,7 +629,8 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
         fill_desc(st, items[i], d);
         d.bnd_off = work_int;
         // scalar: two rows of {val, ptr, dir}; -A1 (forwardH1): six boundary rows by diagonal + the record counter
-        work_int += exact ? 6ll * d.buf_size + 8 : 3ll * (2 * (int64_t) d.width + 8);
+        // (Noll = 3: a third group of planes, F2)
+        work_int += exact ? 6ll * d.buf_size + 8 : 3ll * ((st.sc.noll == 3 ? 3 : 2) * ((int64_t) d.width + 4));
         d.tb_off = vmf_rec;
         // Vmf records: one per cell that starts a diagonal run, two per accepted intron, the boundary
         // row; 4 per cell is far above what the recurrence can emit on real inputs (overflow is reported)
@@ -656,6 +663,7 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
     A.ipen_runs = st.ipen_runs_ok ? (const int16_t*) st.d_intpen + st.sc.intpen_len : nullptr;
     A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
+    A.noll = (!exact && st.sc.noll == 3) ? 3 : 2; A.lgop = st.sc.lgop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);
     spdp_genetic_code_tables(A.mid, A.tron_of);
     A.cip = (const int*) st.d_cip;
@@ -663,7 +671,7 @@ static int run_scalar_group(HStore& st, const std::vector<HItem>& items, bool fo
     A.skl = (int2*) d_skl; A.n_skl = (int*) d_nskl; A.skl_cap = skl_cap;
     HPipe pp;
     if (exact) { if (pipe_setup_exact(ctx, pool, HP_PIPE, h_probs, 0, pp, A.item_probs, nopipe)) return -1; }
-    else if (!cut && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;     // (the cut-range variant runs one wave per problem)
+    else if (!cut && A.noll != 3 && pipe_setup(ctx, pool, HP_PIPE, h_probs, false, 0, pp)) return -1;     // (the cut-range variant and double affine gaps run one wave per problem)
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pipe_arm(ctx, pp, nr, A)) return -1;
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -862,9 +870,10 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
         DevProblemH& d = h_probs[i];
         fill_desc(st, items[i], d);
         d.bnd_off = work_int;
-        work_int += exact ? 6ll * d.buf_size + 8 : 6ll * (2 * (int64_t) d.width + 8);
+        const int noll = (engine == 0 && st.sc.noll == 3) ? 3 : 2;        // (Noll = 3: F2 planes, a third plane of links per intermediate row)
+        work_int += exact ? 6ll * d.buf_size + 8 : 6ll * (noll * ((int64_t) d.width + 4));
         d.imd_off = imd_int;
-        imd_int += (int64_t) d.n_im * 8 * d.width;
+        imd_int += (int64_t) d.n_im * 4 * noll * d.width;
         out.cells += d.cells;
     }
     void* d_probs = pool.get(HU_PROBS, nr * sizeof(DevProblemH));
@@ -887,6 +896,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.ipen_runs = st.ipen_runs_ok ? (const int16_t*) st.d_intpen + st.sc.intpen_len : nullptr;
     A.minl = st.sc.minl ? st.sc.minl : st.sc.llmt;
     A.gape1 = st.sc.gape1; A.gape2 = st.sc.gape2; A.extragop = st.sc.extragop;
+    A.noll = (engine == 0 && st.sc.noll == 3) ? 3 : 2; A.lgop = st.sc.lgop;
     memcpy(A.t53, st.sc.t53, sizeof A.t53);
     spdp_genetic_code_tables(A.mid, A.tron_of);
     A.cip = (const int*) st.d_cip;
@@ -895,7 +905,7 @@ static int run_scalar_udh(HStore& st, const std::vector<HItem>& items, HUdhOut& 
     A.cpos_stride = out.stride;
     HPipe pp;
     if (engine == 1) { if (pipe_setup_exact(ctx, pool, HU_PIPE, h_probs, max_im, pp, A.item_probs, nopipe)) return -1; }
-    else if (engine == 0 && pipe_setup(ctx, pool, HU_PIPE, h_probs, true, max_im, pp)) return -1;
+    else if (engine == 0 && A.noll != 3 && pipe_setup(ctx, pool, HU_PIPE, h_probs, true, max_im, pp)) return -1;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pipe_arm(ctx, pp, nr, A)) return -1;
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));

@@ -69,6 +69,7 @@ struct HScalarArgs {
     int                intpen_len;
     int                minl;       // IntronPrm.minl
     int                gape1, gape2, extragop;
+    int                noll, lgop; // PwdB::Noll (3: double affine gaps, spdh_rowwave<., ., ., true>), LongGOP
     int16_t            t53[256];
     uint8_t            mid[32];    // middle base a tron code pins (4: none)
     uint8_t            tron_of[64];

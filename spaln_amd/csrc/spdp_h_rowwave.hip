@@ -173,6 +173,11 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 }
 #define STORES_DRAINED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// DAGP: double affine gaps (PwdB::Noll = 3, -yl3; src/fwd2h1.cc:297, 343, 365, 413-449, 577-598 / 1088, 1140, 1162, 1211-1247,
+// 1316-1330, 1412-1440; round 5): a second deletion state F2 (a third group of planes by diagonal) and a second insertion
+// queue E2, priced with GapW3L = LongGOP + LongGEP / LongGEP; five states a donor candidate can leave from (its state code
+// takes a third bit of the packed word); an intermediate row keeps three planes of links.  One wave per problem, two
+// problems per block (the third group of planes does not leave LDS for four).
 // CUT (MODE 1, one wave per problem): forwardH_ng with a cut range (shortcutH_ng; src/fwd2h1.cc:308-312, 589-603, lastH_ng
 // :210-281).  After column cut_l of a row the three insertion states, charged for the codons of the cut, REPLACE the row's
 // last three entries (F: black) and the row goes on at column cut_l + cut_len + 1 on the next entry: a cell is addressed
@@ -181,19 +186,24 @@ template <bool X> __device__ __forceinline__ void gst(int* p, int v)
 // replaced entries -- two columns ahead of what the one-column skew of the wave provides.  Hence three phases per tile:
 // the skewed sweep up to column cut_l - 3, the seam (cut_l - 2 .. cut_l and the replacement) row after row on one lane
 // at a time, and the skewed sweep again from cut_l + 1.
-template <int MODE, bool PIPE, bool CUT = false>
+template <int MODE, bool PIPE, bool CUT = false, bool DAGP = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void spdh_rowwave(HScalarArgs A)
 {
     static_assert(!CUT || (MODE == 1 && !PIPE), "the cut range: forward engine, one wave per problem");
+    static_assert(!DAGP || !PIPE, "double affine gaps: one wave per problem");
     constexpr bool FWD = MODE == 1, UDH = MODE == 2;
     constexpr int NF = Shape<MODE>::NF;
-    __shared__ int Lw[WPB][2 * NF][RING];
+    constexpr int NP = DAGP ? 3 : 2;                    // groups of planes by diagonal: H, F (, F2)
+    constexpr int NODK = DAGP ? 5 : 3;                  // states (Nod): H, E, F (, E2, F2)
+    constexpr int NOLL = DAGP ? 3 : 2;
+    constexpr int WPBK = DAGP ? 2 : WPB;                // waves (= problems) of a block
+    __shared__ int Lw[WPBK][NP * NF][RING];
     // the column records and signal quadruples of the columns the wave is on (its 64 rows sit on 64 + 31 consecutive
     // columns during a chunk of steps, and a cell looks 2 back and 4 ahead): staged 32 columns at a time, coalesced --
     // an acceptor or donor used to wait for four or five dependent reads from memory, and some lane is on one at
     // almost every step
-    __shared__ int4 Ccol[WPB][CRING];
-    __shared__ short4 Caux[WPB][CRING];
+    __shared__ int4 Ccol[WPBK][CRING];
+    __shared__ short4 Caux[WPBK][CRING];
     __shared__ Tables T;
     const DevScoringH* sc = A.sc;
     load_tables(T, A, sc);
@@ -202,7 +212,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
     int4* const Cc = Ccol[wv];
     short4* const Ca = Caux[wv];
     const int lane = threadIdx.x & 63;
-    int pi = blockIdx.x * WPB + wv;
+    if (wv >= WPBK) return;                             // (not reached: the launch has WPBK waves per block)
+    int pi = blockIdx.x * WPBK + wv;
     int t_lo = 0, t_hi = INT32_MAX;                     // tiles of the problem this wave sweeps
     if (PIPE) {
         int tk = 0;
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
     const bool LocalL = Local && a_exgl && b_exgl, LocalR = Local && a_exgr && b_exgr;
     const int gop = sc->gop, gep = sc->gep, lgep = sc->lgep, codonk1 = sc->codonk1;
     const int gw1 = sc->g1, gw2 = sc->g2, gw3 = sc->g3, ge1 = A.gape1, ge2 = A.gape2;
+    const int lgop = DAGP ? A.lgop : 0, gw3l = lgop + lgep;         // PwdB::GapW3L (src/aln2.cc:124)
     const bool spj = sc->spj && !P.nospj;
     const int minl = A.minl;
     const int cutlen = CUT ? P.cut_len : 0, cut_l = CUT ? P.cut_l : INT32_MAX / 2;
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
     const uint8_t* __restrict__ acod = A.a_codes + P.a_off;
     const int4* __restrict__ cols = A.cols + P.col_off;             // .x: codon ending at n | flags, .y: sig3 x 2, .w: dinc
     const short4* __restrict__ aux = A.aux + P.col_off;             // {sigS, sigT, sigE, sig5}
-    const int W = width + 4;                                        // 2 NF arrays of W ints: entry e = r - lw + 3
+    const int W = width + 4;                                        // NP NF arrays of W ints: entry e = r - lw + 3
     int* const g0 = A.work + P.bnd_off;
     auto G = [&](int arr) { return g0 + (int64_t) arr * W; };
     auto gext3 = [&](int i) { return i > codonk1 ? lgep : gep; };
@@ -292,9 +304,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
         STORES_DRAINED();
         if (lane == 0) __hip_atomic_store(prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    // ---- intermediate rows (MODE 2): hlnk[2], vlnk[2], lwrb[2], uprb[2], `width` ints each, entry r - lw + 1
+    // ---- intermediate rows (MODE 2): hlnk[Noll], vlnk[Noll], lwrb[Noll], uprb[Noll], `width` ints each, entry r - lw + 1
     int* const imd_base = UDH ? A.imd + P.imd_off : nullptr;
-    const int64_t us = 2 * (int64_t) width;
+    const int64_t us = NOLL * (int64_t) width;
     enum { HLNK = 0, VLNK = 1, LWRB = 2, UPRB = 3 };
     auto IM = [&](int i, int arr, int k, int r) -> int* { return imd_base + (int64_t) i * 4 * us + arr * us + (int64_t) k * width + (r - lw + 1); };
     auto mi_of = [&](int i) { return P.a_left + (i + 1) * intvl; };
@@ -355,6 +367,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             put(e, 0, h);
             put(e, 1, black);
+            if constexpr (DAGP) put(e, 2, black);
         }
         // the first row: a leading gap on the genomic side may restart wherever a start codon signal beats it --
         // a running maximum with restarts, one lane, history in registers
@@ -427,6 +440,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                       cipp = has_cip ? A.cip[P.cip_off + 3 * m - 1] : 0;
             // the insertion queue: ea is the slot of the current column's frame
             St ea = black, eb = black, ec = black;
+            St e2a = black, e2b = black, e2c = black;               // the second insertion queue (Noll = 3)
             Cands<MODE> cl[3];
 #pragma unroll
             for (int ph = 0; ph < 3; ++ph) cl[ph].clear();
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int e = res_lo + lane; e < dead; e += 64) {
                     const int q = e & (RING - 1);
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
+                    for (int a = 0; a < NP * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
                 }
                 res_lo = max(res_lo, dead);
                 const int want = min(W, need_hi(S + CHUNK - 1) + 1);
@@ -452,12 +466,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
                 for (int e = max(res_hi, res_lo) + lane; e < want; e += 64) {
                     const int q = e & (RING - 1);
-                    const int* src[2 * NF]; int val[2 * NF];               // (all planes in flight together: spdp_pipe.h)
+                    const int* src[NP * NF]; int val[NP * NF];             // (all planes in flight together: spdp_pipe.h)
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) src[a] = G(a);
+                    for (int a = 0; a < NP * NF; ++a) src[a] = G(a);
                     gld_n<PIPE>(src, e, val);
 #pragma unroll
-                    for (int a = 0; a < 2 * NF; ++a) L[a][q] = val[a];
+                    for (int a = 0; a < NP * NF; ++a) L[a][q] = val[a];
                 }
                 res_hi = max(res_hi, want);
                 // columns [S - (m0 + 63) - 3, S + CHUNK - 1 - m0 + 5] of the next CHUNK steps (CUT: their real positions,
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int e = res_lo + lane; e < res_hi; e += 64) {
                                 const int q = e & (RING - 1);
 #pragma unroll
-                                for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
+                                for (int a = 0; a < NP * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                             res_lo = res_hi = max(0, need_lo(S2));
@@ -534,13 +548,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const St hq = h;                                    // the entry as the cell found it
                 const St u1 = lds_get(e + 1, 0), u2 = lds_get(e + 2, 0), u3 = lds_get(e + 3, 0), fu = lds_get(e + 3, 1);
                 const St l1 = lds_get(e - 1, 0), l2 = lds_get(e - 2, 0), l3 = lds_get(e - 3, 0);
+                St f2 = black, fu2 = black;
+                if constexpr (DAGP) { f2 = lds_get(e, 2); fu2 = lds_get(e + 3, 2); }
                 if (on && !seeded && !b_exgl && m == al) {          // (the queue slot of column n0 + 2)
                     ec = hq;
                     if (UDH) ec.v += gw3; else ec.v = gw3;
+                    if constexpr (DAGP) { e2c = hq; if (UDH) e2c.v += gw3l; else e2c.v = gw3l; }
                 }
                 seeded = seeded || on;
-                int mxk = 0;                                        // which state holds the running maximum: 0 H, 1 E, 2 F
-                auto val_of = [&](int k) { return k == 0 ? h.v : (k == 1 ? ea.v : f.v); };
+                int mxk = 0;                                        // which state holds the running maximum: 0 H, 1 E, 2 F (3 E2, 4 F2)
+                auto val_of = [&](int k) {
+                    if constexpr (DAGP) return k == 0 ? h.v : (k == 1 ? ea.v : (k == 2 ? f.v : (k == 3 ? e2a.v : f2.v)));
+                    else return k == 0 ? h.v : (k == 1 ? ea.v : f.v);
+                };
+                auto st_of = [&](int k) -> St {
+                    if constexpr (DAGP) return st_sel(k < 2, st_sel(k == 0, h, ea), st_sel(k == 2, f, st_sel(k == 3, e2a, f2)));
+                    else return st_sel3(k, h, ea, f);
+                };
+                auto st_set = [&](int k, const St& s) {
+                    if (k == 0) h = s; else if (k == 1) ea = s; else if (k == 2) f = s;
+                    else if constexpr (DAGP) { if (k == 3) e2a = s; else f2 = s; }
+                };
                 if (m != al) {
                     // match: the codon ending here against my residue
                     if (n < bl + 3) h = black;
@@ -559,6 +587,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (x0 >= nf.v) { nf = u3; nf.v = x0; nf.d = T_VERT; }
                     f = nf;
                     if (UDH ? (f.v >= h.v) : (f.v > h.v)) mxk = 2;
+                    if constexpr (DAGP) {                           // long deletion: open from the cell a codon above, or extend
+                        const int xl = u3.v + gw3l, yl = fu2.v + lgep;
+                        St n2 = fu2; n2.v = yl;
+                        if (xl >= yl) { n2 = u3; n2.v = xl; n2.d = T_VERL; }
+                        f2 = n2;
+                        if (UDH ? (f2.v >= val_of(mxk)) : (f2.v > val_of(mxk))) mxk = 4;
+                    }
                 }
                 if (on) {
                     // insertion: a whole codon (extend or open), 2 nt, 1 nt
@@ -568,6 +603,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                         if (x > ea.v) { ea = l3; ea.v = x; }
                         ea.v += sigE;
                         ea.d = (ea.d & T_SPIN) + T_HORI;
+                        if constexpr (DAGP) {                       // long insertion (its place among the maxima: before E's frame shifts)
+                            const int xl = l3.v + gw3l;
+                            e2a.v += lgep;
+                            if (xl > e2a.v) { e2a = l3; e2a.v = xl; }
+                            e2a.v += sigE;
+                            e2a.d = (e2a.d & T_SPIN) + T_HORL;
+                            if (e2a.v > val_of(mxk)) mxk = 3;
+                        }
                     }
                     if (n > n0 + 1) {
                         const int x = l2.v + gw2;
@@ -605,7 +648,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 if (phs == -1) fix = prof1[tron_l(n + 1)] + AUX(n + 1).z;     // what the next row's match will add anyway
                             }
                         }
-                        int sel[3] = {-1, -1, -1};
+                        int sel[5] = {-1, -1, -1, -1, -1};
                         // the list of my column's phase, picked once (round 4: the candidate loop used to be written out three
                         // times, once per phase, and a wave ran all three whenever its lanes sat on columns of different
                         // phases -- the acceptor was 48 % of the step's cycles)
@@ -621,12 +664,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const int cipv = phs < 0 ? cipm : (phs == 0 ? cip0 : cipp);
                         // screen: the best candidate of the list, priced as high as anything can be, against the lowest of the
                         // three states it may raise (every update below is behind `x > state`)
-                        const bool tq = t && tn >= 0 && tv[0] + cipv + s3 + T.gain[0] + T.gain[1] + T.gain[2] + abs(fix) > min(h.v, min(ea.v, f.v));
+                        const int lowest = DAGP ? min(min(h.v, min(ea.v, f.v)), min(e2a.v, f2.v)) : min(h.v, min(ea.v, f.v));
+                        const bool tq = t && tn >= 0 && tv[0] + cipv + s3 + T.gain[0] + T.gain[1] + T.gain[2] + abs(fix) > lowest;
                         if (__ballot(tq)) {
 #pragma unroll
                             for (int l = 0; l < NC; ++l) {
                                 if (!(tq && l <= tn)) continue;
-                                const int cd = tx[l] & 3;
+                                const int cd = DAGP ? ((tx[l] & 3) | ((tx[l] >> 12) & 1) << 2) : (tx[l] & 3);
                                 if (phs == 1 && cd == 2) continue;
                                 if (nb - tj[l] < minl) continue;
                                 int x = tv[l] + cipv + intpen_of(nb - tj[l]) + s3 + T.t53[16 * ((tx[l] >> 2) & 15) + dn3];
@@ -639,14 +683,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 }
                                 if (cd == 0) { if (x > h.v) { h.v = x; sel[0] = l; } }
                                 else if (cd == 1) { if (x > ea.v) { ea.v = x; sel[1] = l; } }
-                                else { if (x > f.v) { f.v = x; sel[2] = l; } }
+                                else if (!DAGP || cd == 2) { if (x > f.v) { f.v = x; sel[2] = l; } }
+                                else if (cd == 3) { if (x > e2a.v) { e2a.v = x; sel[3] = l; } }
+                                else { if (x > f2.v) { f2.v = x; sel[4] = l; } }
                             }
                         }
-                        // the winners, in the order H, E, F
-                        int maxk = 3;
-                        int lnk[3] = {EOU, EOU, EOU};
+                        // the winners, in the order H, E, F (, E2, F2)
+                        int maxk = NODK;
+                        int lnk[5] = {EOU, EOU, EOU, EOU, EOU};
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
+                        for (int k = 0; k < NODK; ++k) {
                             const bool w = sel[k] >= 0;
                             if (!__ballot(w)) continue;
                             int cj = pick(sel[k], tj), ca = 0, cb = 0, cc = 0, ce = 0;
@@ -654,25 +700,29 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int ph = 0; ph < 3; ++ph)
                                 if (phi == ph) { ca = pick(sel[k], cl[ph].a);
                                                  if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
-                            St to = st_sel3(k, h, ea, f);
+                            St to = st_of(k);
                             const int p1 = vadd(w, m, cj + phs, ca);
                             const int p2 = vadd(w, m, n, p1);
                             if (w) {
-                                to.d = (k == 0 ? T_DIAG : (k == 1 ? T_HORI : T_VERT)) | T_SPIN;
+                                to.d = (k == 0 ? T_DIAG : (k == 1 ? T_HORI : (k == 2 ? T_VERT : (k == 3 ? T_HORL : T_VERL)))) | T_SPIN;    // nod2dir
                                 if (FWD) to.a = p2;
                                 if (UDH) { to.a = max(ca, r); to.b = min(cb, r); to.c = cc; to.e = ce; lnk[k] = ce; }
-                                if (k == 0) h = to; else if (k == 1) ea = to; else f = to;
+                                st_set(k, to);
                                 if (UDH ? (to.v >= val_of(mxk)) : (to.v > val_of(mxk))) { mxk = k; maxk = k; }
                             }
                         }
-                        if (UDH && is_imd && t && maxk < 3) {
+                        if (UDH && is_imd && t && maxk < NODK) {
                             gst<PIPE>(IM(iq, HLNK, 0, r), lnk[maxk]);
                             rl_set(r);
-                            if (maxk == 0) h.e = r; else if (maxk == 1) ea.e = r; else f.e = r;
+                            { St w_ = st_of(maxk); w_.e = r; st_set(maxk, w_); }
                             spj3 = true;
                             if (maxk == 0) {
                                 if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), lnk[1]); }
                                 if (sel[2] >= 0 && f.v > h.v + gop) f.e = r + width;
+                                if constexpr (DAGP) {               // (c = 2, d = 3: the long pair against GOP[2])
+                                    if (sel[3] >= 0 && e2a.v > h.v + lgop) { e2a.e = r + 2 * width; gst<PIPE>(IM(iq, HLNK, 2, r), lnk[3]); }
+                                    if (sel[4] >= 0 && f2.v > h.v + lgop) f2.e = r + 2 * width;
+                                }
                             }
                         }
                     }
@@ -680,7 +730,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
 
                 // ---- the cell takes the best state
                 const int y = h.v;
-                St mxs = st_sel3(mxk, h, ea, f);
+                St mxs = st_of(mxk);
                 if (FWD || MODE == 0) {
                     bool opened = false;
                     if (mxk != 0) h = mxs;
@@ -701,7 +751,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                     } else {
                         if (mxs.a < r) mxs.a = r;
                         if (mxs.b > r) mxs.b = r;
-                        if (mxk == 1) ea = mxs; else f = mxs;
+                        st_set(mxk, mxs);
                         h = mxs;
                     }
                     if (LocalL && h.v <= 0) { h.v = 0; h.d = 0; h.c = m; h.e = h.a = h.b = r; }
@@ -728,14 +778,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             packed = ((COL(nb).w >> 4) & 15) << 2 | (w0 & 7) << 6 | (w1 & 7) << 9;
                         }
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
+                        for (int k = 0; k < NODK; ++k) {
                             const bool cross = phs == 1 && k == 0;          // the intron cuts the codon of the cell above-left
-                            const St own = st_sel3(k, h, ea, f);
+                            const St own = st_of(k);
                             const St src = st_sel(cross, hq, own);
                             bool tk = t && k >= ((hd == 0 || phs == 1) ? 0 : 1) && src.d && !(src.d & T_SPIN);    // (no orphan exon)
                             if (tk && !cross && k != hd && hd >= 0) {
                                 int z = mxs.v;
-                                if (hd == 0 || ((k - hd) & 1)) z += (k == 2) ? gop : 0;
+                                if (hd == 0 || ((k - hd) & 1)) z += (k == 2 || k == 3) ? gop : (k == 4 ? lgop : 0);   // GOP[k / 2]
                                 if (src.v <= z) tk = false;         // cannot become the better path
                             }
                             {   // a full list whose last kept entry beats the newcomer: the free slot stays below it and the list is
@@ -752,7 +802,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int ph = 0; ph < 3; ++ph) {
                                 const bool tt = tk && phs + 1 == ph;
                                 if (!__ballot(tt)) continue;
-                                const bool kept = cl[ph].insert(tt, src.v + sigJ, nb, packed | k, src, is_imd ? r : src.e);
+                                const bool kept = cl[ph].insert(tt, src.v + sigJ, nb, packed | (k & 3) | (k >> 2) << 12, src, is_imd ? r : src.e);
                                 // an intermediate row links an insertion that splices out to the last match of its frame
                                 if (UDH && is_imd && kept && k == 1) gst<PIPE>(IM(iq, HLNK, 0, r), rl_get());
                             }
@@ -768,17 +818,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                     h.b = h.a = r; h.e = r;
                     gst<PIPE>(IM(iq, VLNK, 1, r), f.e); gst<PIPE>(IM(iq, LWRB, 1, r), min(r, f.b)); gst<PIPE>(IM(iq, UPRB, 1, r), max(r, f.a));
                     f.b = f.a = r; f.e = r + width;
+                    if constexpr (DAGP) {
+                        gst<PIPE>(IM(iq, VLNK, 2, r), f2.e); gst<PIPE>(IM(iq, LWRB, 2, r), min(r, f2.b)); gst<PIPE>(IM(iq, UPRB, 2, r), max(r, f2.a));
+                        f2.b = f2.a = r; f2.e = r + 2 * width;
+                    }
                 }
                 if (on) {
                     lds_put(e, 0, h);
                     lds_put(e, 1, f);
                     const St t = ea; ea = eb; eb = ec; ec = t;      // the next column is the next frame
+                    if constexpr (DAGP) { lds_put(e, 2, f2); const St t2 = e2a; e2a = e2b; e2b = e2c; e2c = t2; }
                 }
                 if constexpr (CUT) {
                     if (on && v == cut_l) {                         // the insertion states run on over the cut (ea: the next column's frame)
                         const int lg = gep * cutlen / 3;
                         ea.v += lg; eb.v += lg; ec.v += lg;
-                        lds_put(e - 2, 0, eb); lds_put(e - 1, 0, ec); lds_put(e, 0, ea);
+                        if constexpr (DAGP) {                       // (*h = dagp ? e2 : e1, src/fwd2h1.cc:595-598)
+                            const int lg2 = lgep * cutlen / 3;
+                            e2a.v += lg2; e2b.v += lg2; e2c.v += lg2;
+                            lds_put(e - 2, 0, e2b); lds_put(e - 1, 0, e2c); lds_put(e, 0, e2a);
+                            lds_put(e - 2, 2, black); lds_put(e - 1, 2, black); lds_put(e, 2, black);
+                        } else { lds_put(e - 2, 0, eb); lds_put(e - 1, 0, ec); lds_put(e, 0, ea); }
                         lds_put(e - 2, 1, black); lds_put(e - 1, 1, black); lds_put(e, 1, black);
                     }
                 }
@@ -787,7 +847,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int e = res_lo + lane; e < res_hi; e += 64) {
                 const int q = e & (RING - 1);
 #pragma unroll
-                for (int a = 0; a < 2 * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
+                for (int a = 0; a < NP * NF; ++a) gst<PIPE>(G(a) + e, L[a][q]);
             }
         }
         if (UDH && PIPE) {
@@ -1076,7 +1136,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
     for ( ; i >= 0 && mi_of(i) > fin.c; --i) {
         int c = 0, d = 0;
         for ( ; r > up; r -= width) ++d;                            // links into the F array carry + width
-        if (d > 1 || r < lw - 1) { flag = -3; break; }              // outside the link arrays (undefined in the reference)
+        if (d > NOLL - 1 || r < lw - 1) { flag = -3; break; }       // outside the link arrays (undefined in the reference)
         const int mi = mi_of(i);
         if (gld<PIPE>(IM(i, VLNK, d, r)) < EOU) {
             CPOS(i, c++) = mi;
@@ -1134,6 +1194,13 @@ extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipS
         else hipLaunchKernelGGL((spdh_rowwave<0, true>), grd, blk, 0, stream, A);
         return hipGetLastError();
     }
+    if (A.noll == 3) {                                  // double affine gaps: one wave per problem, two problems per block
+        const dim3 g2((A.n_probs + 1) / 2), b2(128);
+        if (forward == 2) hipLaunchKernelGGL((spdh_rowwave<1, false, true, true>), g2, b2, 0, stream, A);
+        else if (forward) hipLaunchKernelGGL((spdh_rowwave<1, false, false, true>), g2, b2, 0, stream, A);
+        else hipLaunchKernelGGL((spdh_rowwave<0, false, false, true>), g2, b2, 0, stream, A);
+        return hipGetLastError();
+    }
     const dim3 grd((A.n_probs + WPB - 1) / WPB);
     if (forward == 2) hipLaunchKernelGGL((spdh_rowwave<1, false, true>), grd, blk, 0, stream, A);      // problems with a cut range
     else if (forward) hipLaunchKernelGGL((spdh_rowwave<1, false>), grd, blk, 0, stream, A);
@@ -1144,6 +1211,7 @@ extern "C" hipError_t spdh_launch_scalar(int forward, const HScalarArgs* a, hipS
 extern "C" hipError_t spdh_launch_scalar_udh(const HScalarArgs* a, hipStream_t stream)
 {
     HScalarArgs A = *a;
+    if (A.noll == 3) { hipLaunchKernelGGL((spdh_rowwave<2, false, false, true>), dim3((A.n_probs + 1) / 2), dim3(128), 0, stream, A); return hipGetLastError(); }
     if (A.pipe) hipLaunchKernelGGL((spdh_rowwave<2, true>), dim3((A.n_items + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     else hipLaunchKernelGGL((spdh_rowwave<2, false>), dim3((A.n_probs + WPB - 1) / WPB), dim3(64 * WPB), 0, stream, A);
     return hipGetLastError();

@@ -211,6 +211,11 @@ def cases_h():
         c[f"qh_{s:04d}"] = (w, q, opts)
     c.update(special_cases_h())
     c.update({k: v for k, v in a1_cases().items() if k.startswith("qh_")})
+    # the same seeds under double affine gaps (-yl3, Noll = 3; -A0: forwardH_ng with and without a cut range, hirschbergH_ng
+    # behind the walk; round 5)
+    for s in FIXTURE_SEEDS_H:
+        w, q, opts, _ = make_case_h(s)
+        c[f"qhl3_{s:04d}"] = (w, q, opts + ["-l", "3", "-A", "0"])
     return c
 
 

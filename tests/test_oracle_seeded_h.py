@@ -106,3 +106,21 @@ def test_live_pairs_equal_reference(path):
     assert (flat or []) == fx["seed_skl_A0"].tolist()
     want = {int(n): [int(a), int(b)] for n, a, b in fx["seed_marks_A0"].reshape(-1, 3)}
     assert want and seeded.marks_changed(fx, marks) == want
+
+
+QHL3 = golden_files("qhl3_")
+
+
+@pytest.mark.parametrize("path", QHL3, ids=[f.split("/")[-1][:-5] for f in QHL3])
+def test_seeded_noll3_equals_reference(path):
+    """the protein walk under double affine gaps (-yl3, -A0): forwardH_ng with and without a cut range and hirschbergH_ng
+    with their F2 / E2 states behind it (round 5)"""
+    fx = spdg.load(path)
+    assert fx["prm"]["noll"] == 3
+    sc, sp, p, hsps, n, lowest, wl = seeded_inputs_h(fx, 0)
+    marks = {}
+    scr, flat, rc = seeded.align_h_seeded(sc, sp, p, hsps, n, lowest, wl, 0, marks=marks)
+    assert rc == 0 and scr == int(fx["seed_scr_A0"][0])
+    assert (flat or []) == fx["seed_skl_A0"].tolist()
+    want = {int(n_): [int(a), int(b)] for n_, a, b in fx["seed_marks_A0"].reshape(-1, 3)}
+    assert seeded.marks_changed(fx, marks) == want

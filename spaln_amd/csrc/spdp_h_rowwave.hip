@@ -103,6 +103,10 @@ __device__ __forceinline__ St st_sel(bool c, const St& a, const St& b)
     return r;
 }
 __device__ __forceinline__ St st_sel3(int k, const St& s0, const St& s1, const St& s2) { return st_sel(k == 0, s0, st_sel(k == 1, s1, s2)); }
+__device__ __forceinline__ St st_sel5(int k, const St& s0, const St& s1, const St& s2, const St& s3, const St& s4)
+{
+    return st_sel(k < 2, st_sel(k == 0, s0, s1), st_sel(k == 2, s2, st_sel(k == 3, s3, s4)));
+}
 __device__ __forceinline__ int& fld(St& s, int i) { return i == 0 ? s.v : i == 1 ? s.d : i == 2 ? s.a : i == 3 ? s.b : i == 4 ? s.c : s.e; }
 
 // donor candidates of one codon phase, best first
@@ -561,14 +565,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if constexpr (DAGP) return k == 0 ? h.v : (k == 1 ? ea.v : (k == 2 ? f.v : (k == 3 ? e2a.v : f2.v)));
                     else return k == 0 ? h.v : (k == 1 ? ea.v : f.v);
                 };
-                auto st_of = [&](int k) -> St {
-                    if constexpr (DAGP) return st_sel(k < 2, st_sel(k == 0, h, ea), st_sel(k == 2, f, st_sel(k == 3, e2a, f2)));
-                    else return st_sel3(k, h, ea, f);
-                };
-                auto st_set = [&](int k, const St& s) {
-                    if (k == 0) h = s; else if (k == 1) ea = s; else if (k == 2) f = s;
-                    else if constexpr (DAGP) { if (k == 3) e2a = s; else f2 = s; }
-                };
+                // (state k of the cell, read and written: spelled out -- a lambda that takes or returns the records by reference
+                //  parks all of them in scratch memory, 0 -> 48 bytes per lane and a0 9.3 -> 5.6 GCUPS when round 5 tried)
+#define ST_OF(K) (DAGP ? st_sel5((K), h, ea, f, e2a, f2) : st_sel3((K), h, ea, f))
+#define ST_SET(K, S) do { if ((K) == 0) h = (S); else if ((K) == 1) ea = (S); else if (!DAGP || (K) == 2) f = (S); \
+                          else if ((K) == 3) e2a = (S); else f2 = (S); } while (0)
                 if (m != al) {
                     // match: the codon ending here against my residue
                     if (n < bl + 3) h = black;
@@ -700,21 +701,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int ph = 0; ph < 3; ++ph)
                                 if (phi == ph) { ca = pick(sel[k], cl[ph].a);
                                                  if (UDH) { cb = pick(sel[k], cl[ph].b); cc = pick(sel[k], cl[ph].c); ce = pick(sel[k], cl[ph].e); } }
-                            St to = st_of(k);
+                            St to = ST_OF(k);
                             const int p1 = vadd(w, m, cj + phs, ca);
                             const int p2 = vadd(w, m, n, p1);
                             if (w) {
                                 to.d = (k == 0 ? T_DIAG : (k == 1 ? T_HORI : (k == 2 ? T_VERT : (k == 3 ? T_HORL : T_VERL)))) | T_SPIN;    // nod2dir
                                 if (FWD) to.a = p2;
                                 if (UDH) { to.a = max(ca, r); to.b = min(cb, r); to.c = cc; to.e = ce; lnk[k] = ce; }
-                                st_set(k, to);
+                                ST_SET(k, to);
                                 if (UDH ? (to.v >= val_of(mxk)) : (to.v > val_of(mxk))) { mxk = k; maxk = k; }
                             }
                         }
                         if (UDH && is_imd && t && maxk < NODK) {
                             gst<PIPE>(IM(iq, HLNK, 0, r), lnk[maxk]);
                             rl_set(r);
-                            { St w_ = st_of(maxk); w_.e = r; st_set(maxk, w_); }
+                            { St w_ = ST_OF(maxk); w_.e = r; ST_SET(maxk, w_); }
                             spj3 = true;
                             if (maxk == 0) {
                                 if (sel[1] >= 0 && ea.v > h.v + gop) { ea.e = r + width; gst<PIPE>(IM(iq, HLNK, 1, r), lnk[1]); }
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
 
                 // ---- the cell takes the best state
                 const int y = h.v;
-                St mxs = st_of(mxk);
+                St mxs = ST_OF(mxk);
                 if (FWD || MODE == 0) {
                     bool opened = false;
                     if (mxk != 0) h = mxs;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
                     } else {
                         if (mxs.a < r) mxs.a = r;
                         if (mxs.b > r) mxs.b = r;
-                        st_set(mxk, mxs);
+                        ST_SET(mxk, mxs);
                         h = mxs;
                     }
                     if (LocalL && h.v <= 0) { h.v = 0; h.d = 0; h.c = m; h.e = h.a = h.b = r; }
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int k = 0; k < NODK; ++k) {
                             const bool cross = phs == 1 && k == 0;          // the intron cuts the codon of the cell above-left
-                            const St own = st_of(k);
+                            const St own = ST_OF(k);
                             const St src = st_sel(cross, hq, own);
                             bool tk = t && k >= ((hd == 0 || phs == 1) ? 0 : 1) && src.d && !(src.d & T_SPIN);    // (no orphan exon)
                             if (tk && !cross && k != hd && hd >= 0) {

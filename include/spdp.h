@@ -267,6 +267,9 @@ typedef struct SpdpSeedParams {
     int32_t any, both_ori;           /* algmode.any, Exinon::both_ori: Exinon::isCanon's site levels follow from them and
                                         the dinucleotide classes (src/codepot.cc:435-475, src/codepot.h:108-113)          */
     int32_t ip_maxl, ip_mode;        /* IntronPrm.maxl, IntronPrm.mode (protein walk: first_exon_wmm / last_exon_wmm)      */
+    const struct SpdpWilipModel* wilip;   /* optional (round 5): with it -- and no SpdpHspSource -- the walks' HSP searches at the
+                                        recursion levels are the library's own (spdp_wilip.h: Wilip restated); NULL: the
+                                        caller's SpdpHspSource answers them                                                */
 } SpdpSeedParams;
 /* Wilip(seqs, pwd, level) (src/wln.cc:980) for the recursion levels above the one the caller's HSPs come from: the HSP
  * search stays with the caller (the reference's wln.cc in an integration).  units() is called from the walks' threads
@@ -552,6 +555,43 @@ int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct Spd
  * The problems need all seven signal arrays and dinc on the host, sc->intpen / t53.  Return value and out[] as
  * spdp_align_h; a walk with a DP call on which the reference itself is undefined is reported as not served (return 1, no
  * alignment). */
+/* ---- the HSP search itself (Wilip, src/wln.cc; SURVEY 8 row f4, second slice) ------------------------------------------------
+ * What the reference's Wilip reads besides the two sequences: per recursion level the word parameters of setwlprm(level)
+ * (src/wln.cc:53-128: reduced alphabet, tuple size, bit pattern, gains, cut-offs) and, shared, the HSP-search substitution
+ * matrix getSimmtx(WlnPamNo), the end bonus, and a few switches.  With a model a seeded call needs no SpdpHspSource: the
+ * library searches the sub-ranges itself (spdp_wilip.h), and spdp_wilip answers one request the way Wilip::Wilip does. */
+typedef struct SpdpWilipLevel {
+    int32_t elem, tpl, mask, width, gain, gain1, thr, xdrp, cutoff, vthr;     /* WLPRM, src/wln.h:35-49                    */
+    int32_t bitpat_len;              /* 0: contiguous words of `width`; else the spaced pattern, bitpat[i] = 1 / 0      */
+    uint8_t bitpat[32];
+    uint8_t convtab[32];             /* WLPRM::ConvTab[code]: class of the reduced alphabet, >= elem: not part of a word */
+} SpdpWilipLevel;
+typedef struct SpdpWilipModel {
+    SpdpWilipLevel level[3];
+    int32_t mtx_rows, mtx_cols;      /* getSimmtx(WlnPamNo): query code x genomic code (nucleotide or tron)              */
+    int32_t mtx[32 * 32];
+    int32_t dvsp;                    /* PwdB::DvsP: 0 nucleotide query, 1 protein query x tron codes                      */
+    int32_t end_bonus;               /* Wlprms::EndBonus = (VTYPE) AvTrc() / 2 (src/wln.cc:146)                           */
+    int32_t crs, lsg, mlt;           /* algmode.crs, lsg, mlt                                                             */
+    int32_t hard_minl, hard_maxl, minl, maxl, llmt;                           /* IntronPrm                                */
+    int32_t avrsig;                  /* IntronPenalty::AvrSig: PenaltyPlus(n) = Penalty(n) + AvrSig (src/codepot.h:248)   */
+    int32_t shortquery;              /* 50 (src/wln.h:33): a level -1 search on a shorter query scales its cut-offs       */
+    int32_t min_hit;                 /* 3 (src/wln.cc:34)                                                                 */
+    int32_t met, ser, ser2;          /* residue codes MET, SER, SER2 (src/cmn.h:117)                                      */
+} SpdpWilipModel;
+
+/* Wilip::Wilip(seqs, pwd, level) on one request (src/wln.cc:980): the HSPs of query range [a_left, a_right) against genomic
+ * range [b_left, b_right), chained into units, best unit first -- the flat record SpdpHspSource::units hands over (n_units,
+ * per unit {num, nid, tlen, llmt, ulmt, scr} + (num + 1) x {jx, jy, jlen, nid, jscr}; the nid of a unit's closing record is 0
+ * where the reference leaves it unset).  Exactly one of p / ph is given (nucleotide / protein query; the protein form reads
+ * sigS / sigE / sigT where present) with the scoring that belongs to it (gap penalties of the chaining, intpen).  level:
+ * 0 .. 2 as the walks and geneorient() ask, -1 as FindHsp does (cut-offs scaled for queries below shortquery residues).
+ * exg = {a->inex.exgl, a->inex.exgr} at the call.  *flat is malloc'ed (free() it); returns the number of ints, < 0 on error.
+ * Host code: no device involved. */
+int spdp_wilip(const struct SpdpWilipModel* model, const SpdpProblem* p, const SpdpScoring* sc,
+               const struct SpdpProblemH* ph, const struct SpdpScoringH* sch,
+               int32_t level, const int32_t span[4], const int32_t exg[2], int32_t** flat);
+
 typedef struct SpdpPhaseMark {
     int32_t n;                       /* position of the tron sequence                                              */
     int8_t  side;                    /* 5: SGPT6::phs5, 3: SGPT6::phs3                                              */

@@ -82,6 +82,41 @@ inline void set_default_params()	// same calls, same order as the CLI default se
 
 
 
+// What Wilip (src/wln.cc: the word-lookup HSP search the seeded walks call at the recursion levels, and geneorient / FindHsp
+// at level 0 / -1) reads besides the two sequences: the three parameter sets of setwlprm(level) with their reduced
+// alphabets, the HSP-search substitution matrix (getSimmtx(WlnPamNo)) and a handful of scalars.  wlparams and hspprm are
+// file statics of wln.cc: EndBonus = AvTrc / 2 and RepPen = Vab * 10, DirRep = 20 are rebuilt from their definitions
+// (src/wln.cc:37, 145-148); AvrSig of the intron penalty (private) = PenaltyPlus(n) - Penalty(n).
+inline void dump_wilip_model(Writer& w, const PwdB* pwd)
+{
+	std::vector<int> lv, ct, bp;
+	for (INT l = 0; l < MaxWlpLevel; ++l) {
+	    const WLPRM* p = setwlprm(l);
+	    const int bl = p->bitpat? (int) strlen(p->bitpat): 0;
+	    const int row[12] = {(int) p->elem, (int) p->tpl, (int) p->mask, (int) p->width, (int) p->gain, (int) p->gain1, (int) p->thr,
+		p->xdrp, p->cutoff, (int) p->vthr, bl, (int) bp.size()};
+	    lv.insert(lv.end(), row, row + 12);
+	    for (int i = 0; i < bl; ++i) bp.push_back(p->bitpat[i] == '1');
+	    for (int c = 0; c <= ZZZ; ++c) ct.push_back(p->ConvTab? (int) p->ConvTab[c]: 127);
+	}
+	w.put_i32("wl_levels", lv);
+	w.put_i32("wl_bitpat", bp);
+	w.put_i32("wl_convtab", ct);
+const	Simmtx*	sm = getSimmtx(WlnPamNo);
+const	int	R = sm->rows? sm->rows: sm->dim, C = sm->dim;		// (Simmtx::cols is not set for every matrix; a row has dim entries)
+	std::vector<int> mx = {R, C};
+	for (int i = 0; i < R; ++i)
+	    for (int j = 0; j < C; ++j) mx.push_back((int) sm->mtx[i][j]);
+	w.put_i32("wl_mtx", mx);
+	int	avrsig = 0;
+	for (int n = IntronPrm.llmt; n < IntronPrm.llmt + 64; ++n)
+	    if (pwd->IntPen->Penalty(n) > SHRT_MIN) { avrsig = pwd->IntPen->PenaltyPlus(n) - pwd->IntPen->Penalty(n); break; }
+	std::vector<int> g = {pwd->DvsP, (int) alprm.scale, (int) ((VTYPE) sm->AvTrc() / 2), (int) ((VTYPE) (alprm.scale * 10.f)), 20,
+	    (int) algmode.crs, (int) algmode.lsg, (int) algmode.mlt, (int) IntronPrm.hard_minl, (int) IntronPrm.hard_maxl,
+	    IntronPrm.minl, IntronPrm.maxl, shortquery, 0, MET, SER, SER2, ZZZ, avrsig, IntronPrm.llmt, 3};
+	w.put_i32("wl_glob", g);
+}
+
 int dump_protein(Seq** seqs, const char* exg, const std::vector<int>& udh_list, const char* outfn);
 int dump_protein_body(Seq** seqs, PwdB* pwd, const std::vector<int>& udh_list, const char* outfn);
 

@@ -264,6 +264,7 @@ const	int	nq0 = IntronPrm.nquant;
 		jx.insert(jx.end(), jr, jr + 5);
 	    }
 	    w.put_i32("seed_jxt", jx);		// CdsNo HSPs + the slot behind them, scores before addsigEjxt (:2397)
+	    dump_wilip_model(w, pwd);
 	    float smn4 = getsmn(4), w2 = alprm2.w, maxsp = alprm.maxsp;
 	    int smn4b, w2b, maxspb;
 	    memcpy(&smn4b, &smn4, 4); memcpy(&w2b, &w2, 4); memcpy(&maxspb, &maxsp, 4);

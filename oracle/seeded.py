@@ -229,3 +229,41 @@ def marks_changed(fx, marks: dict) -> dict:
         if a != int(p5[n]) or b != int(p3[n]):
             out[n] = [a, b]
     return out
+
+
+def wilip(model, p, sc, level: int, span, exg=(0, 0)):
+    """the product's HSP search (spaln_amd/csrc/spdp_wilip.h, compiled into the checker) on one request, as
+    Wilip::Wilip(seqs, pwd, level) answers it: the flat unit record SpdpHspSource::units would hand over.
+    p: abi.Problem (nucleotide query) or abi.ProblemH (protein query); span = (a_left, a_right, b_left, b_right)"""
+    from spaln_amd import abi as _abi
+    protein = isinstance(p, _abi.ProblemH)
+    out = (C.c_int32 * 65536)()
+    al, ar, bl, br = (int(x) for x in span[:4])
+    f = lib().walk_check_wilip
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                  C.c_void_p, C.c_int]
+    sig = (p.sigS, p.sigE, p.sigT) if protein else (None, None, None)
+    n = f(C.addressof(model), p.a, p.a_len, al, ar, int(exg[0]), int(exg[1]), p.b, p.b_len, bl, br, 3 if protein else 1, *sig,
+          sc.intpen, sc.intpen_len, sc.gop, sc.gep, sc.lgop, sc.lgep, sc.codonk1, level, out, len(out))
+    if n < 0:
+        raise RuntimeError("walk_check_wilip: reply too long")
+    return [int(out[i]) for i in range(n)]
+
+
+def same_units(got, want) -> bool:
+    """two flat unit records, but for the `nid` of each unit's closing record (the reference leaves that int as its fresh
+    array held it)"""
+    if len(got) != len(want) or got[:1] != want[:1]:
+        return False
+    at = 1
+    for _ in range(got[0]):
+        num = want[at]
+        blk = 6 + 5 * (num + 1)
+        g, w = list(got[at:at + blk]), list(want[at:at + blk])
+        g[6 + 5 * num + 3] = w[6 + 5 * num + 3] = 0
+        if g != w:
+            return False
+        at += blk
+    return True

@@ -112,7 +112,7 @@ class SeedParams(C.Structure):           # SpdpSeedParams
                 ("vthr", C.c_int32), ("desert", C.c_int32), ("maxsp", C.c_float), ("crs", C.c_int32),
                 ("smn4", C.c_float), ("w2", C.c_float), ("gc_sig5", C.c_int32), ("lcl", C.c_int32),
                 ("codonk1", C.c_int32), ("any", C.c_int32), ("both_ori", C.c_int32), ("ip_maxl", C.c_int32),
-                ("ip_mode", C.c_int32)]
+                ("ip_mode", C.c_int32), ("wilip", C.c_void_p)]
 
 
 HSP_UNITS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -496,3 +496,43 @@ class ProblemSetH:
         arr = (ProblemH * len(self.items))(*self.items)
         self._keep.append(arr)
         return arr
+
+
+class WilipLevel(C.Structure):           # SpdpWilipLevel
+    _fields_ = [("elem", C.c_int32), ("tpl", C.c_int32), ("mask", C.c_int32), ("width", C.c_int32), ("gain", C.c_int32),
+                ("gain1", C.c_int32), ("thr", C.c_int32), ("xdrp", C.c_int32), ("cutoff", C.c_int32), ("vthr", C.c_int32),
+                ("bitpat_len", C.c_int32), ("bitpat", C.c_uint8 * 32), ("convtab", C.c_uint8 * 32)]
+
+
+class WilipModel(C.Structure):           # SpdpWilipModel
+    _fields_ = [("level", WilipLevel * 3), ("mtx_rows", C.c_int32), ("mtx_cols", C.c_int32), ("mtx", C.c_int32 * (32 * 32)),
+                ("dvsp", C.c_int32), ("end_bonus", C.c_int32), ("crs", C.c_int32), ("lsg", C.c_int32), ("mlt", C.c_int32),
+                ("hard_minl", C.c_int32), ("hard_maxl", C.c_int32), ("minl", C.c_int32), ("maxl", C.c_int32), ("llmt", C.c_int32),
+                ("avrsig", C.c_int32), ("shortquery", C.c_int32), ("min_hit", C.c_int32),
+                ("met", C.c_int32), ("ser", C.c_int32), ("ser2", C.c_int32)]
+
+
+def wilip_model_from_fixture(fx) -> WilipModel:
+    """the wl_* fields a `ref_dump -Q` fixture carries (oracle/ref_build/ref_dump_common.h: dump_wilip_model)"""
+    m = WilipModel()
+    lv = np.asarray(fx["wl_levels"]).reshape(3, 12)
+    bits = np.asarray(fx["wl_bitpat"])
+    ct = np.asarray(fx["wl_convtab"]).reshape(3, -1)
+    for i in range(3):
+        L = m.level[i]
+        (L.elem, L.tpl, L.mask, L.width, L.gain, L.gain1, L.thr, L.xdrp, L.cutoff, L.vthr) = (int(x) for x in lv[i, :10])
+        bl, off = int(lv[i, 10]), int(lv[i, 11])
+        assert bl <= 32
+        L.bitpat_len = bl
+        for k in range(bl):
+            L.bitpat[k] = int(bits[off + k])
+        for c in range(32):
+            L.convtab[c] = min(255, int(ct[i, c])) if c < ct.shape[1] else 127
+    mx = np.asarray(fx["wl_mtx"])
+    m.mtx_rows, m.mtx_cols = int(mx[0]), int(mx[1])
+    for k, v in enumerate(mx[2:]):
+        m.mtx[k] = int(v)
+    g = [int(x) for x in fx["wl_glob"]]
+    (m.dvsp, _vab, m.end_bonus, _reppen, _dirrep, m.crs, m.lsg, m.mlt, m.hard_minl, m.hard_maxl, m.minl, m.maxl, m.shortquery,
+     _afact, m.met, m.ser, m.ser2, _zzz, m.avrsig, m.llmt, m.min_hit) = g
+    return m

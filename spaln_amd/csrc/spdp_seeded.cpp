@@ -20,6 +20,7 @@
 
 #include "spdp_internal.h"
 #include "spdp_walk.h"
+#include "spdp_wilip.h"
 #include "spdp_seeded_rv.h"
 
 namespace {
@@ -47,8 +48,20 @@ struct DeviceBackend : DpBackend {
     {
         return park(cut ? 2 : 1, s, w, cut, rec);      // (the cDNA engines have no intron switch)
     }
+    const SpdpWilipModel* wm = nullptr; const SpdpProblem* prob = nullptr; const SpdpScoring* scp = nullptr; int codonk1 = 0;
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
+        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
+            ++*n_wilip;
+            const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 1,
+                                         nullptr, nullptr, nullptr, scp->intpen, scp->intpen_len, scp->gop, scp->gep, scp->lgop,
+                                         scp->lgep, codonk1};
+            std::vector<spdp_wl::Unit> us;
+            spdp_wl::run(wm, &pr, level, us);
+            std::vector<int32_t> flat;
+            spdp_wl::flatten(us, flat);
+            return parse_units(flat.data(), (int32_t) flat.size(), units);
+        }
         if (!src || !src->units) return false;
         const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
         const int32_t* flat = nullptr; int32_t n = 0;
@@ -98,6 +111,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
             DeviceBackend be;
             be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
+            be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc; be.codonk1 = sp->codonk1;       // (the walk's own GapPenalty reads it there)
             SeedWalk w;
             const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
             const int64_t tb0 = cpu_ns();

@@ -17,6 +17,7 @@
 
 #include "spdp_internal.h"
 #include "spdp_walk.h"
+#include "spdp_wilip.h"
 #include "spdp_seeded_rv.h"
 #include "spdp_h_requests.h"
 
@@ -50,8 +51,20 @@ struct DeviceBackendH : DpBackend {
     {
         return park(spj ? 1 : 3, s, w, cut, rec);
     }
+    const SpdpWilipModel* wm = nullptr; const SpdpProblemH* prob = nullptr; const SpdpScoringH* scp = nullptr;
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
+        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
+            ++*n_wilip;
+            const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 3,
+                                         prob->sigS, prob->sigE, prob->sigT, scp->intpen, scp->intpen_len, scp->gop, scp->gep,
+                                         scp->lgop, scp->lgep, scp->codonk1};
+            std::vector<spdp_wl::Unit> us;
+            spdp_wl::run(wm, &pr, level, us);
+            std::vector<int32_t> flat;
+            spdp_wl::flatten(us, flat);
+            return parse_units(flat.data(), (int32_t) flat.size(), units);
+        }
         if (!src || !src->units) return false;
         const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
         const int32_t* flat = nullptr; int32_t n = 0;
@@ -104,6 +117,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
             DeviceBackendH be;
             be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+            be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc;
             SeedWalkH w;
             const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
             if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
@@ -224,4 +238,26 @@ extern "C" int spdp_seeded_phase_marks(const SpdpContext* ctx, int q, const Spdp
     if (!ctx || q < 0 || q >= (int) ctx->seed_marks.size() || ctx->seed_marks[q].empty()) return 0;
     if (marks) *marks = ctx->seed_marks[q].data();
     return (int) ctx->seed_marks[q].size();
+}
+
+extern "C" int spdp_wilip(const SpdpWilipModel* model, const SpdpProblem* p, const SpdpScoring* sc,
+                          const SpdpProblemH* ph, const SpdpScoringH* sch,
+                          int32_t level, const int32_t span[4], const int32_t exg[2], int32_t** flat)
+{
+    if (!model || !span || !flat || (!p == !ph) || (p && !sc) || (ph && !sch) || level < -1 || level > 2) return -1;
+    spdp_wl::Pair pr;
+    if (p) pr = {p->a, p->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, p->b, p->b_len, span[2], span[3], 1,
+                 nullptr, nullptr, nullptr, sc->intpen, sc->intpen_len, sc->gop, sc->gep, sc->lgop, sc->lgep, sc->codonk1};
+    else pr = {ph->a, ph->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, ph->b, ph->b_len, span[2], span[3], 3,
+               ph->sigS, ph->sigE, ph->sigT, sch->intpen, sch->intpen_len, sch->gop, sch->gep, sch->lgop, sch->lgep, sch->codonk1};
+    if (!pr.a || !pr.b || !pr.intpen || pr.intpen_len <= 0) return -1;
+    if (pr.a_left < 0 || pr.a_right > pr.a_len || pr.a_left > pr.a_right || pr.b_left < 0 || pr.b_right > pr.b_len || pr.b_left > pr.b_right) return -1;
+    std::vector<spdp_wl::Unit> us;
+    spdp_wl::run(model, &pr, level, us);
+    std::vector<int32_t> f;
+    spdp_wl::flatten(us, f);
+    *flat = (int32_t*) malloc(sizeof(int32_t) * f.size());
+    if (!*flat) return -1;
+    memcpy(*flat, f.data(), sizeof(int32_t) * f.size());
+    return (int) f.size();
 }

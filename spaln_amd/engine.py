@@ -227,7 +227,13 @@ def _seeded_call(lib, handle, check, name, sc, sp, ps, hsps, lowest_levels, wili
     arr = (abi.Alignment * n)()
     fn = getattr(lib, name)
     fn.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
-    rc = fn(handle, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, C.byref(src), arr)
+    # wilip_tables = an abi.WilipModel: no HSP source at all -- the library's own Wilip (spdp_wilip.h) answers the levels
+    own = isinstance(wilip_tables, abi.WilipModel)
+    if own:
+        sp.wilip = C.addressof(wilip_tables)
+    rc = fn(handle, C.byref(sc), C.byref(sp), ps.array(), n, jx, nh, lv, None if own else C.byref(src), arr)
+    if own:
+        sp.wilip = None
     if missing:
         raise KeyError(f"no Wilip reply for {missing[:3]}")
     if not (allow_partial and rc == 1):

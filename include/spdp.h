@@ -812,6 +812,7 @@ void spdp_blk_index_host_free(SpdpBlkIndexHost* h);
 #define SPDP_BLK_REACHED 1
 #define SPDP_BLK_CUT     2
 #define SPDP_BLK_TABLE   4
+#define SPDP_BLK_FORCED  8         /* the reached call is the one findblock makes behind its scan: TestOutput(1) */
 int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* codes, const int64_t* offs,
                   const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n,
                   int32_t* out, int32_t out_cap, float* kernel_ms);
@@ -819,6 +820,42 @@ int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* codes
 int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* ix, const uint8_t* d_codes, const int64_t* d_offs,
                            const int32_t* d_left, const int32_t* d_right, const int32_t* d_stop_at, int32_t n,
                            int32_t* d_out, int32_t out_cap, float* kernel_ms);
+
+/* ---- block search, third slice (round 5): from the vote to candidate loci ------------------------------------------------
+ * What SrchBlk::findblock returns to its caller: TestOutput's second half (src/blksrc.cc:2677-2692: the candidate block pairs
+ * against the random expectation of their mismatch counts) and FindHsp (:2346-2545: the region of a pair cut from the genome,
+ * the HSP search on it -- spdp_wilip, level -1 --, the units that hold against critjscr, the pair's ends moved towards what the
+ * HSPs leave uncovered, the candidate loci with their overlap / order / pruning rules).  spdp_blk_find runs the vote on the
+ * device for all queries, call after call (stop_at = 0, 1, ..: a query whose pairs all fail asks again, as findblock does),
+ * and this part on the host's threads in between.  Nucleotide queries.  A locus is what the aligner is then given: the region
+ * [base, base + len) of chromosome chr (reverse-complemented when rvs), its range [left, right) and the HSPs inside it --
+ * exactly the window + SpdpJuxt list spdp_align_s_seeded takes. */
+typedef struct SpdpBlkFindParams {
+    int32_t vthr;                    /* alprm.scale * 2 * alprm.thr (src/blksrc.cc:2210)                                   */
+    float   drop_rate;               /* 1 unless -Xr (:56, 115)                                                            */
+    int32_t max_out, max_out2;       /* OutPrm.MaxOut, MaxOut2                                                             */
+    int32_t min_agap;                /* SrchBlk::min_agap                                                                  */
+    int32_t phase1t;                 /* Randbs::Phase1T = (int) (RbsBias * avr) (:2059)                                    */
+    int32_t a_exgl, a_exgr;          /* query->inex.exgl / exgr while it is searched (the HSP search's end bonus reads them) */
+} SpdpBlkFindParams;
+typedef struct SpdpGenome {          /* residue codes of the chromosomes in host memory, in the index's order              */
+    const uint8_t* codes; const int64_t* chr_off; int32_t n_chr;     /* chromosome c = codes[chr_off[c] .. chr_off[c + 1]) */
+} SpdpGenome;
+typedef struct SpdpLocus {
+    int32_t query, chr, rvs;         /* whose, where: chromosome, strand                                                   */
+    int32_t base, len;               /* region [base, base + len) of the chromosome's forward strand                       */
+    int32_t left, right;             /* range inside the region as the aligner sees it (reverse-complemented when rvs)     */
+    int32_t jscr, n_hsp;             /* Seq::jscr, CdsNo                                                                   */
+    int64_t hsp_off;                 /* its n_hsp + 1 SpdpJuxt records (the last one the closing slot) start at hsps[hsp_off] */
+} SpdpLocus;
+/* out: *loci (n_loci of them, query by query, best locus of a query first) and *hsps, both malloc'ed (free() them); status[i]
+ * (may be NULL): TestOutput calls the query took, negative when the search ended without a locus.  sc: the gap penalties and
+ * the intron penalty table the HSP chaining prices with (SpdpScoring gop / gep / lgop / lgep / codonk1, intpen / intpen_len).
+ * hix: the same index on the host (its chromosome and random-score tables; spdp_blk_index_host_desc or the caller's own). */
+int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                  const struct SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
+                  const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
+                  SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status);
 
 /* ---- device groups, continued ------------------------------------------------------------------------------------------ */
 /* the same sharding for the calls of the seeded path, rescoring and the block vote (rounds 3 / 4).  The HSP source of a

@@ -178,6 +178,34 @@ static void fill_seed_params(SpdpSeedParams& sp, const PwdB* pwd, const Seq* b) 
 	sp.any = algmode.any; sp.both_ori = 0; sp.ip_maxl = IntronPrm.maxl; sp.ip_mode = IntronPrm.mode;
 }
 
+// the model of the library's own HSP search (SpdpSeedParams.wilip; spdp_wilip.h restates Wilip): the word parameters of the
+// three levels, the HSP-search matrix and the scalars Wlp reads.  wlparams / hspprm are file statics of src/wln.cc: what is
+// needed of them follows from their definitions (EndBonus = (VTYPE) AvTrc() / 2, src/wln.cc:146); AvrSig of the intron
+// penalty is private: PenaltyPlus(n) - Penalty(n)
+static void fill_wilip_model(SpdpWilipModel& m, const PwdB* pwd) {
+	memset(&m, 0, sizeof m);
+	for (INT l = 0; l < MaxWlpLevel; ++l) {
+const	    WLPRM* p = setwlprm(l);
+	    SpdpWilipLevel& L = m.level[l];
+	    L.elem = p->elem; L.tpl = p->tpl; L.mask = p->mask; L.width = p->width; L.gain = p->gain; L.gain1 = p->gain1;
+	    L.thr = p->thr; L.xdrp = p->xdrp; L.cutoff = p->cutoff; L.vthr = p->vthr;
+	    L.bitpat_len = p->bitpat? (int) strlen(p->bitpat): 0;
+	    for (int i = 0; i < L.bitpat_len && i < 32; ++i) L.bitpat[i] = p->bitpat[i] == '1';
+	    for (int c = 0; c < 32; ++c) L.convtab[c] = (c <= ZZZ && p->ConvTab)? (uint8_t) std::min<INT>(p->ConvTab[c], 255): 127;
+	}
+const	Simmtx*	sm = getSimmtx(WlnPamNo);
+	m.mtx_rows = sm->rows? sm->rows: sm->dim;  m.mtx_cols = sm->dim;
+	for (int i = 0; i < m.mtx_rows; ++i)
+	    for (int j = 0; j < m.mtx_cols; ++j) m.mtx[i * m.mtx_cols + j] = sm->mtx[i][j];
+	m.dvsp = pwd->DvsP;  m.end_bonus = (VTYPE) sm->AvTrc() / 2;
+	m.crs = algmode.crs;  m.lsg = algmode.lsg;  m.mlt = algmode.mlt;
+	m.hard_minl = IntronPrm.hard_minl;  m.hard_maxl = IntronPrm.hard_maxl;  m.minl = IntronPrm.minl;  m.maxl = IntronPrm.maxl;
+	m.llmt = IntronPrm.llmt;
+	for (int n = IntronPrm.llmt; n < IntronPrm.llmt + 64; ++n)
+	    if (pwd->IntPen->Penalty(n) > SHRT_MIN) { m.avrsig = pwd->IntPen->PenaltyPlus(n) - pwd->IntPen->Penalty(n); break; }
+	m.shortquery = shortquery;  m.min_hit = 3;  m.met = MET;  m.ser = SER;  m.ser2 = SER2;
+}
+
 // one Wilip search on a sub-range, flattened as SpdpHspSource::units wants it
 static void wilip_flat(Seq** seqs, const PwdB* pwd, int level, const int32_t span[8], std::vector<int32_t>& L) {
 	Seq*	a = seqs[0];

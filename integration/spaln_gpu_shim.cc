@@ -85,6 +85,13 @@ void report()
 		g_seed[0].load(), g_seed[1].load(), g_seed[2].load(), g_seed[9].load() * 1e-6, g_seed[10].load() * 1e-6, g_seed[4].load());
 }
 
+// the HSP searches of the recursion levels: the library's own (spdp_wilip.h, round 5) unless SPALN_GPU_WILIP=ref asks for the
+// reference's Wilip behind the callback
+bool own_wilip()
+{
+	static const bool on = [] { const char* e = getenv("SPALN_GPU_WILIP"); return !(e && !strcmp(e, "ref")); }();
+	return on;
+}
 int units_cb(void* user, int32_t q, int32_t level, const int32_t span[8], const int32_t** flat, int32_t* n_flat)
 {
 	Req* r = ((Req**) user)[q];
@@ -158,7 +165,9 @@ const		    JUXT& t = b->jxt[j];
 		lowest[i] = b->wllvl;
 	    }
 	    SpdpHspSource src = {rq.data(), units_cb, 0};
-	    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), &src, al.data());
+	    static SpdpWilipModel wmodel; static std::once_flag wonce;
+	    if (own_wilip()) { std::call_once(wonce, [&] { fill_wilip_model(wmodel, rq[0]->pwd); }); sp.wilip = &wmodel; }
+	    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
 	}
 	if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
 	for (int i = 0; i < n; ++i) {
@@ -226,7 +235,9 @@ const		    JUXT& t = b->jxt[j];
 		lowest[i] = b->wllvl;
 	    }
 	    SpdpHspSource src = {rq.data(), units_cb, 0};
-	    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), &src, al.data());
+	    static SpdpWilipModel wmodel; static std::once_flag wonce;
+	    if (own_wilip()) { std::call_once(wonce, [&] { fill_wilip_model(wmodel, rq[0]->pwd); }); sp.wilip = &wmodel; }
+	    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), n, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
 	    if (rc > 0) rc = 0;
 	    int64_t st[11] = {0};
 	    spdp_seeded_stats(g_ctx, st, 11);
@@ -551,7 +562,9 @@ const		auto t1 = std::chrono::steady_clock::now();
 			rqp[i] = &rq[i];
 		    }
 		    SpdpHspSource src = {rqp.data(), units_cb, 0};
-		    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), &src, al.data());
+		    static SpdpWilipModel wmodel; static std::once_flag wonce;
+		    if (own_wilip()) { std::call_once(wonce, [&] { fill_wilip_model(wmodel, part[0]->pwd); }); sp.wilip = &wmodel; }
+		    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
 		    int64_t st[11] = {0};
 		    spdp_seeded_stats(g_ctx, st, 11);
 		    for (int k = 0; k < 11; ++k) g_seed[k] += st[k];
@@ -602,7 +615,9 @@ const		auto t1 = std::chrono::steady_clock::now();
 			rqp[i] = &rq[i];
 		    }
 		    SpdpHspSource src = {rqp.data(), units_cb, 0};
-		    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), &src, al.data());
+		    static SpdpWilipModel wmodel; static std::once_flag wonce;
+		    if (own_wilip()) { std::call_once(wonce, [&] { fill_wilip_model(wmodel, part[0]->pwd); }); sp.wilip = &wmodel; }
+		    rc = spdp_align_h_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
 		}
 		if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
 		g_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();

@@ -36,7 +36,9 @@ _BLK_SO = os.path.join(_HERE, "libblkcheck.so")
 
 def build_blk_check(force: bool = False) -> str:
     """the block vote's CPU checker: the text the device kernel is compiled from (spdp_blk_core.h), host-compiled"""
-    srcs = [os.path.join(_HERE, "blk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_core.h")]
+    srcs = [os.path.join(_HERE, "blk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_core.h"),
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_find.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_wilip.h"),
+            os.path.join(_HERE, "..", "include", "spdp.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_BLK_SO) or os.path.getmtime(_BLK_SO) < newest:
         tmp = f"{_BLK_SO}.{os.getpid()}.tmp"

@@ -27,6 +27,7 @@
 #include <zlib.h>
 
 #include "blksrc.cc"		// (compiled with -fno-access-control: the recorder reads private members)
+#include "ref_dump_common.h"	// dump_wilip_model: the HSP search FindHsp calls reads these
 
 #define NOINST __attribute__((no_instrument_function))
 
@@ -55,9 +56,14 @@ NOINST void put(const char* name, unsigned dtype, const void* p, size_t cnt)
 }
 NOINST void put_i32(const char* name, const int* v, size_t n) { put(name, 3, v, n); }
 
+std::vector<int>	g_find;			// second slice (round 5): what TestOutput leaves behind -- the candidate loci FindHsp made
+int	g_qno = -1, g_call = 0;
+bool	g_find_prm_done = false;
+
 NOINST void at_exit_flush()
 {
 	if (!g_fd) return;
+	put("find_log", 3, g_find.empty()? 0: &g_find[0], g_find.size());
 	put("q_log", 3, g_log.empty()? 0: &g_log[0], g_log.size());
 	fclose(g_fd);
 	g_fd = 0;
@@ -168,6 +174,51 @@ NOINST void snap_pairs(SrchBlk* s)
 }
 }	// namespace
 
+struct TapWriter { NOINST void put_i32(const char* name, const std::vector<int>& v) { put(name, 3, v.empty()? 0: &v[0], v.size()); } };
+
+// the parameters FindHsp / TestOutput's second half read besides the index and the vote (src/blksrc.cc:2346-2545, 2677-2692)
+NOINST void dump_find_prm(SrchBlk* s)
+{
+	int	dr; memcpy(&dr, &drop_rate, 4);
+	std::vector<int> v = {(int) s->vthr, dr, (int) NoRetry, gene_rng_max_extend, (int) OutPrm.MaxOut, (int) OutPrm.MaxOut2, s->bbt,
+	    s->min_agap, (int) wcp.blklen, (int) ExtBlock, (int) ExtBlockL, s->rdbt->Phase1T, (int) s->pwd->DvsP,
+	    (int) s->pwd->BasicGOP, (int) s->pwd->BasicGEP, (int) s->pwd->LongGOP, (int) s->pwd->LongGEP, s->pwd->codonk1,
+	    (int) algmode.nsa, (int) algmode.slv, (int) s->query->inex.exgl, (int) s->query->inex.exgr};
+	put_i32("find_prm", &v[0], v.size());
+	std::vector<short> ip(131072);
+	for (size_t n = 0; n < ip.size(); ++n) ip[n] = (short) s->pwd->IntPen->Penalty((int) n);
+	put("find_intpen", 2, &ip[0], ip.size());
+	TapWriter tw;
+	dump_wilip_model(tw, s->pwd);
+}
+
+// TestOutput is over: the pairs as FindHsp left them, critjscr, and the candidate loci [gener, curgr) with their HSPs
+NOINST void snap_find(SrchBlk* s)
+{
+	Bhit4*	b = s->bh4;
+	g_find.push_back(-4); g_find.push_back(g_qno); g_find.push_back(g_call++);
+	g_find.push_back((int) s->critjscr);
+	g_find.push_back(Ncand + 1);
+	for (int i = 0; i <= Ncand; ++i) {
+	    const BPAIR&	p = b->bpair[i];
+	    const int	v[10] = {p.bscr, p.chr, (int) p.lb, (int) p.rb, (int) p.ub, (int) p.db, (int) p.zl, (int) p.zr, (int) p.rvs, (int) p.jscr};
+	    g_find.insert(g_find.end(), v, v + 10);
+	}
+	int	n = (int) (s->curgr - s->gener);
+	if (n < 0 || n > (int) OutPrm.MaxOut2) n = 0;
+	g_find.push_back(n);
+	for (int k = 0; k < n; ++k) {
+	    Seq*	g = s->gener[k];
+	    const int	hd[9] = {g->did, (int) g->inex.sens, g->base_, g->len, g->left, g->right, (int) g->jscr, g->jxt? g->CdsNo: 0, g->wllvl};
+	    g_find.insert(g_find.end(), hd, hd + 9);
+	    for (int j = 0; g->jxt && j <= g->CdsNo; ++j) {
+		const JUXT& t = g->jxt[j];
+		const int jr[5] = {t.jx, t.jy, t.jlen, t.nid, (int) t.jscr};
+		g_find.insert(g_find.end(), jr, jr + 5);
+	    }
+	}
+}
+
 extern "C" NOINST void __cyg_profile_func_enter(void* fn, void*)
 {
 	static void* const	f_find = (void*) (&SrchBlk::findblock);
@@ -180,6 +231,8 @@ extern "C" NOINST void __cyg_profile_func_enter(void* fn, void*)
 	if (!g_fd) return;
 	if (fn == f_find) {
 	    if (!g_index_done) { dump_index(s); g_index_done = true; }
+	    if (!g_find_prm_done && s->pwd) { dump_find_prm(s); g_find_prm_done = true; }
+	    ++g_qno; g_call = 0;
 	    Seq*	q = s->query;
 	    g_log.push_back(-1);				// record: a query enters findblock
 	    g_log.push_back(q->left); g_log.push_back(q->right); g_log.push_back(q->len);
@@ -193,4 +246,10 @@ extern "C" NOINST void __cyg_profile_func_enter(void* fn, void*)
 	    g_hsp_armed = false;
 	}
 }
-extern "C" NOINST void __cyg_profile_func_exit(void*, void*) {}
+extern "C" NOINST void __cyg_profile_func_exit(void* fn, void*)
+{
+	static void* const	f_test = (void*) (&SrchBlk::TestOutput);
+	if (fn != f_test || !g_fd) return;
+	SrchBlk*	s = g_blk_tap_this;
+	if (s && s->bh4) snap_find(s);
+}

@@ -87,7 +87,7 @@ inline void set_default_params()	// same calls, same order as the CLI default se
 // alphabets, the HSP-search substitution matrix (getSimmtx(WlnPamNo)) and a handful of scalars.  wlparams and hspprm are
 // file statics of wln.cc: EndBonus = AvTrc / 2 and RepPen = Vab * 10, DirRep = 20 are rebuilt from their definitions
 // (src/wln.cc:37, 145-148); AvrSig of the intron penalty (private) = PenaltyPlus(n) - Penalty(n).
-inline void dump_wilip_model(Writer& w, const PwdB* pwd)
+template <class W> inline void dump_wilip_model(W& w, const PwdB* pwd)
 {
 	std::vector<int> lv, ct, bp;
 	for (INT l = 0; l < MaxWlpLevel; ++l) {

@@ -167,3 +167,63 @@ def read_index_file(lib, path: str, **opts):
     out["blk_pb2c"] = np.frombuffer(np.array([out["bclw"], out["bcup"], out["bcce"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
     out["blk_cfact"] = np.frombuffer(np.array([out["cfact"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
     return out
+
+
+class BlkFindParams(C.Structure):        # SpdpBlkFindParams
+    _fields_ = [("vthr", C.c_int32), ("drop_rate", C.c_float), ("max_out", C.c_int32), ("max_out2", C.c_int32),
+                ("min_agap", C.c_int32), ("phase1t", C.c_int32), ("a_exgl", C.c_int32), ("a_exgr", C.c_int32)]
+
+
+class Genome(C.Structure):               # SpdpGenome
+    _fields_ = [("codes", C.c_void_p), ("chr_off", C.c_void_p), ("n_chr", C.c_int32)]
+
+
+class Locus(C.Structure):                # SpdpLocus
+    _fields_ = [(k, C.c_int32) for k in ("query", "chr", "rvs", "base", "len", "left", "right", "jscr", "n_hsp")] + [("hsp_off", C.c_int64)]
+
+
+def find_params_from_fixture(fx) -> BlkFindParams:
+    """find_prm of a blk_* fixture (oracle/ref_build/blk_tap.cc, dump_find_prm)"""
+    v = np.asarray(fx["find_prm"], dtype=np.int32)
+    p = BlkFindParams()
+    p.vthr = int(v[0])
+    p.drop_rate = float(v[1:2].view(np.float32)[0])
+    p.max_out, p.max_out2, p.min_agap, p.phase1t = int(v[4]), int(v[5]), int(v[7]), int(v[11])
+    p.a_exgl, p.a_exgr = int(v[20]), int(v[21])
+    return p
+
+
+def find(index: "BlockIndex", genome_codes, chr_off, model, sc, prm: BlkFindParams, queries, ranges=None):
+    """spdp_blk_find: the block search of every query up to its candidate loci.  Returns (per query a list of dicts
+    {chr, rvs, base, len, left, right, jscr, hsps (n + 1, 5)}, status array)."""
+    lib, eng = index.lib, index.eng
+    n = len(queries)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    codes = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in queries]))
+    left = np.array([0 if ranges is None else ranges[i][0] for i in range(n)], dtype=np.int32)
+    right = np.array([len(queries[i]) if ranges is None else ranges[i][1] for i in range(n)], dtype=np.int32)
+    g = Genome()
+    gc = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    go = np.ascontiguousarray(chr_off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    loci = C.POINTER(Locus)()
+    hsps = C.POINTER(C.c_int32)()
+    nl = C.c_int32()
+    status = np.zeros(n, dtype=np.int32)
+    lib.spdp_blk_find.restype = C.c_int
+    lib.spdp_blk_find.argtypes = [C.c_void_p] * 11 + [C.c_int32] + [C.c_void_p] * 4
+    rc = lib.spdp_blk_find(eng.ctx, index.h, C.byref(index.desc), C.byref(g), C.addressof(model), C.byref(sc), C.byref(prm),
+                           codes.ctypes.data, offs.ctypes.data, left.ctypes.data, right.ctypes.data, n,
+                           C.byref(loci), C.byref(nl), C.byref(hsps), status.ctypes.data)
+    eng._check(rc, "spdp_blk_find")
+    out = [[] for _ in range(n)]
+    for k in range(nl.value):
+        L = loci[k]
+        h = np.array([[hsps[5 * (L.hsp_off + j) + c] for c in range(5)] for j in range(L.n_hsp + 1)], dtype=np.int32)
+        out[L.query].append(dict(chr=L.chr, rvs=L.rvs, base=L.base, len=L.len, left=L.left, right=L.right, jscr=L.jscr, hsps=h))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(loci)
+    libc.free(hsps)
+    return out, status

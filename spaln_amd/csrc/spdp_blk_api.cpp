@@ -3,6 +3,10 @@
 #include "spdp_internal.h"
 #include "spdp_blk_core.h"
 #include "spdp_blk_internal.h"
+#include "spdp_blk_find.h"
+#include "spdp_hostcpus.h"
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -221,5 +225,112 @@ extern "C" int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uin
     if (spdp_blk_vote_resident(ctx, ix, (const uint8_t*) d_codes.p, (const int64_t*) d_offs.p, (const int32_t*) d_l.p,
                                (const int32_t*) d_r.p, (const int32_t*) d_s.p, n, (int32_t*) d_out.p, out_cap, kernel_ms)) return -1;
     HIPCHK(hipMemcpy(out, d_out.p, (size_t) n * out_cap * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- from the vote to candidate loci (spdp_blk_find.h) ---------------------------------------------------------------------
+extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                             const SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
+                             const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
+                             SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status)
+{
+    if (!ctx) return -1;
+    if (!ix || !hix || !genome || !model || !sc || !prm || !loci || !n_loci || !hsps) { ctx->err = "spdp_blk_find: null argument"; return -1; }
+    *loci = nullptr; *hsps = nullptr; *n_loci = 0;
+    if (n <= 0) return 0;
+    if (!sc->intpen || sc->intpen_len <= 0 || !genome->codes || !genome->chr_off || genome->n_chr != hix->n_chr || !hix->chr || !hix->rscrtab) {
+        ctx->err = "spdp_blk_find: needs SpdpScoring.intpen, the genome of the index's chromosomes and the host index's tables"; return -1;
+    }
+    // the host's view of the index: what TestOutput / FindHsp read (random-score table, chromosome table, block geometry)
+    BlkDev hv;
+    memset(&hv, 0, sizeof hv);
+    hv.gdb = hix->gdb; hv.rbscoef = hix->rbscoef; hv.rbscons = hix->rbscons; hv.rscrtab = hix->rscrtab; hv.nseg = hix->nseg;
+    blk_find::Params P;
+    P.vthr = prm->vthr; P.drop_rate = prm->drop_rate; P.max_out = prm->max_out; P.max_out2 = prm->max_out2; P.min_agap = prm->min_agap;
+    P.bbt = 1; P.blklen = hix->blklen; P.ext_block = hix->extblock; P.ext_block_l = hix->extblockl; P.phase1t = prm->phase1t;
+    P.a_exgl = prm->a_exgl; P.a_exgr = prm->a_exgr;
+    if (P.max_out < 1 || P.max_out2 < P.max_out || P.blklen < 1) { ctx->err = "spdp_blk_find: max_out / max_out2 / blklen out of range"; return -1; }
+    const blk_find::Genome G = {genome->codes, genome->chr_off, genome->n_chr};
+    int out_cap = 4096;                                 // (a record that does not fit makes the round run again with room for it)
+    std::vector<int> active(n), stop(n, 0), crit(n, 0), calls(n, 0);
+    for (int i = 0; i < n; ++i) active[i] = i;
+    std::vector<std::vector<blk_find::Locus>> found(n);
+    std::vector<int32_t> rec;
+    while (!active.empty()) {
+        const int m = (int) active.size();
+        // this round's queries, packed
+        std::vector<int64_t> o(m + 1, 0);
+        std::vector<int32_t> l(m), r(m), st(m);
+        for (int k = 0; k < m; ++k) { const int q = active[k]; o[k + 1] = o[k] + (offs[q + 1] - offs[q]); l[k] = left[q]; r[k] = right[q]; st[k] = stop[q]; }
+        std::vector<uint8_t> cd((size_t) o[m]);
+        for (int k = 0; k < m; ++k) memcpy(cd.data() + o[k], codes + offs[active[k]], (size_t) (o[k + 1] - o[k]));
+        for (;;) {
+            rec.assign((size_t) m * out_cap, 0);
+            if (spdp_blk_vote(ctx, ix, cd.data(), o.data(), l.data(), r.data(), st.data(), m, rec.data(), out_cap, nullptr)) return -1;
+            bool cut = false;
+            for (int k = 0; k < m && !cut; ++k) cut = (rec[(size_t) k * out_cap + 2] & SPDP_BLK_CUT) != 0;
+            if (!cut || out_cap >= (1 << 20)) break;
+            out_cap *= 8;
+        }
+        std::vector<int> verdict(m, 0);                 // > 0 loci, 0 go on, -1 ended, -2 record cut / table full
+        std::atomic<int> next{0};
+        auto work = [&] {
+            blk_find::Searcher S;
+            S.ix = &hv; S.P = &P; S.G = &G; S.M = model; S.intpen = sc->intpen; S.intpen_len = sc->intpen_len;
+            S.gop = sc->gop; S.gep = sc->gep; S.lgop = sc->lgop; S.lgep = sc->lgep; S.codonk1 = sc->codonk1; S.chr_tab = hix->chr;
+            for (int k; (k = next++) < m; ) {
+                const int q = active[k];
+                const int32_t* rc = rec.data() + (size_t) k * out_cap;
+                if (!(rc[2] & SPDP_BLK_REACHED)) { verdict[k] = -1; continue; }         // findblock ended before this call
+                if (rc[2] & (SPDP_BLK_CUT | SPDP_BLK_TABLE)) { verdict[k] = -2; continue; }
+                int j = 3;
+                const int32_t* mmct = rc + j + 4;
+                j += 20;
+                for (int d = 0; d < 4; ++d) j += 1 + 2 * rc[j];
+                const int np = rc[j++];
+                std::vector<blk_find::Pair> pairs(np);
+                for (int i = 0; i < np; ++i, j += 9)
+                    pairs[i] = {rc[j], rc[j + 1], 0, (uint32_t) rc[j + 2], (uint32_t) rc[j + 3], (uint32_t) rc[j + 4], (uint32_t) rc[j + 5],
+                                (uint32_t) rc[j + 6], (uint32_t) rc[j + 7], rc[j + 8]};
+                S.n_runs = rc[j++]; S.runs = rc + j;
+                const blk_find::Query Q = {codes + offs[q], (int) (offs[q + 1] - offs[q]), left[q], right[q]};
+                S.q = &Q; S.critjscr = crit[q];
+                const int res = S.test_output(pairs, mmct, (rc[2] & SPDP_BLK_FORCED) != 0);
+                crit[q] = S.critjscr;
+                calls[q] = stop[q] + 1;
+                verdict[k] = res;
+                if (res > 0) found[q].assign(S.gener.begin(), S.gener.begin() + res);
+            }
+        };
+        const int nt = std::max(1, std::min(spdp_host_cpus(), m));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& t : th) t.join();
+        std::vector<int> again;
+        for (int k = 0; k < m; ++k) {
+            const int q = active[k];
+            if (verdict[k] == 0) { ++stop[q]; again.push_back(q); }
+            else if (verdict[k] == -2) { ctx->err = "spdp_blk_find: a vote record was cut or a hash table of the reference's size ran full"; return -1; }
+            else if (verdict[k] < 0 && status) status[q] = -(calls[q] ? calls[q] : stop[q] + 1);
+        }
+        active.swap(again);
+    }
+    size_t nl = 0, nh = 0;
+    for (int q = 0; q < n; ++q) for (const blk_find::Locus& g : found[q]) { ++nl; nh += g.jxt.size(); }
+    *loci = (SpdpLocus*) malloc(sizeof(SpdpLocus) * std::max<size_t>(nl, 1));
+    *hsps = (SpdpJuxt*) malloc(sizeof(SpdpJuxt) * std::max<size_t>(nh, 1));
+    if (!*loci || !*hsps) { free(*loci); free(*hsps); *loci = nullptr; *hsps = nullptr; ctx->err = "spdp_blk_find: out of memory"; return -1; }
+    size_t a = 0, b = 0;
+    for (int q = 0; q < n; ++q) {
+        if (status && !found[q].empty()) status[q] = calls[q];
+        for (const blk_find::Locus& g : found[q]) {
+            SpdpLocus& L = (*loci)[a++];
+            L.query = q; L.chr = g.chr; L.rvs = g.rvs; L.base = g.base; L.len = g.len; L.left = g.left; L.right = g.right;
+            L.jscr = g.jscr; L.n_hsp = (int32_t) g.jxt.size() - 1; L.hsp_off = (int64_t) b;
+            for (const spdp_wl::Juxt& t : g.jxt) { (*hsps)[b++] = {t.jx, t.jy, t.jlen, t.nid, t.jscr}; }
+        }
+    }
+    *n_loci = (int32_t) nl;
     return 0;
 }

@@ -470,7 +470,8 @@ SPDP_HD void blk_touch(BlkWork& w, int slot)
 
 // Runs findblock's scan for the query q[left, right) up to its stop_at-th TestOutput call (earlier calls are taken to have
 // answered "nothing found, go on").  Returns 1 when that call is reached (v and the work slab hold the state TestOutput
-// sees), 0 when findblock ends before it; *calls = TestOutput calls met on the way.  The caller clears the slab
+// sees; 2 when it is the forced call findblock makes behind its scan, TestOutput(1)), 0 when findblock ends before it;
+// *calls = TestOutput calls met on the way.  The caller clears the slab
 // afterwards (blk_work_reset).
 SPDP_HD int blk_vote_run(const BlkDev& ix, BlkWork& w, BlkVote& v, const uint8_t* q, int q_len, int left, int right,
                          int stop_at, int* calls_out)
@@ -585,7 +586,7 @@ SPDP_HD int blk_vote_run(const BlkDev& ix, BlkWork& w, BlkVote& v, const uint8_t
                 }
             }
     }
-    if (c != -1 && calls++ == stop_at) { *calls_out = calls; return 1; }
+    if (c != -1 && calls++ == stop_at) { *calls_out = calls; return 2; }    // (2: the forced call behind the scan, TestOutput(1))
     *calls_out = calls;
     return 0;
 }
@@ -666,7 +667,7 @@ SPDP_HD int blk_emit_and_reset(const BlkDev& ix, BlkWork& w, const BlkVote& v, i
 #undef PUT
     if (cap > 0) out[0] = n < cap ? n : cap;
     if (cap > 1) out[1] = calls;
-    if (cap > 2) out[2] = (reached ? 1 : 0) | (cut ? 2 : 0) | (w.overflow ? 4 : 0);
+    if (cap > 2) out[2] = (reached ? 1 : 0) | (cut ? 2 : 0) | (w.overflow ? 4 : 0) | (reached == 2 ? 8 : 0);
     w.overflow = 0;
     return n;
 }

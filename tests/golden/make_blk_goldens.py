@@ -67,10 +67,34 @@ def genome_and_queries(n_genes, n_chr, seed):
     return chroms, queries
 
 
+def paralog_genome_and_queries(n_genes, n_chr, seed):
+    """every gene twice (the second copy diverged by 4 - 10 %, sometimes on the other strand, sometimes next to the first):
+    several candidate loci per query -- FindHsp's overlap / order / pruning rules, critjscr, MaxOut > 1 (run with -M4)"""
+    rng = np.random.default_rng(synth.SEED + seed)
+    genes = [synth.make_gene(np.random.default_rng(synth.SEED + seed + 1 + i), intron_hi=2000) for i in range(n_genes)]
+    per = n_genes // n_chr
+    chroms = []
+    for c in range(n_chr):
+        parts = []
+        for k, g in enumerate(genes[c * per:(c + 1) * per]):
+            copy = synth.mutate(rng, g.window, float(rng.choice([0.04, 0.07, 0.1])), 0.002)
+            if k % 3 == 1:
+                copy = revcomp(copy)
+            parts += [synth.random_dna(rng, int(rng.integers(500, 3000))), g.window]
+            parts += [synth.random_dna(rng, int(rng.integers(300, 1500) if k % 2 else rng.integers(4000, 9000))), copy]
+        chroms.append(np.concatenate(parts))
+    queries = []
+    for i, g in enumerate(genes):
+        s = g.query
+        queries.append([s, revcomp(s), s[200:1100], synth.mutate(rng, s, 0.05, 0.005)][i % 4])
+    return chroms, queries
+
+
 def main():
     env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
-    for name, fmt_opts, n_genes, seed in (("blk_k1", [], 42, 900), ("blk_k3", ["-XC5"], 28, 950)):
-        chroms, queries = genome_and_queries(n_genes, 2, seed)
+    for name, fmt_opts, n_genes, seed in (("blk_k1", [], 42, 900), ("blk_k3", ["-XC5"], 28, 950), ("blk_par", [], 24, 980)):
+        par = name == "blk_par"
+        chroms, queries = (paralog_genome_and_queries if par else genome_and_queries)(n_genes, 2, seed)
         with tempfile.TemporaryDirectory() as td:
             with open(os.path.join(td, "gnm.mfa"), "w") as f:
                 for c, s in enumerate(chroms):
@@ -84,7 +108,7 @@ def main():
             subprocess.run([os.path.join(REF, "spaln"), "-W", "-KD"] + fmt_opts + ["gnm.mfa"], cwd=td, env=e, check=True,
                            capture_output=True)
             log = os.path.join(td, "log.spdg")
-            r = subprocess.run([os.path.join(REF, "spaln_blktap"), "-Q7", "-O4", "-t1", "-dgnm", "q.fa"], cwd=td,
+            r = subprocess.run([os.path.join(REF, "spaln_blktap"), "-Q7", "-O4", "-t1"] + (["-M4"] if par else []) + ["-dgnm", "q.fa"], cwd=td,
                                env=dict(e, SPDP_BLK_LOG=log), capture_output=True, text=True)
             if r.returncode != 0 or not os.path.exists(log):
                 sys.exit(f"{name}: reference run failed: {r.stderr[-300:]}")
@@ -94,7 +118,8 @@ def main():
             fx = spdg.load(log)
             fx["blk_convtab"][:2] = 255
             spdg.save(os.path.join(OUT, name + ".spdg"), {k: v for k, v in fx.items() if k != "prm"})
-            shutil.copyfile(os.path.join(td, "gnm.bkn"), os.path.join(OUT, name + ".bkn"))     # the reference's own index file: an input of the reader's test
+            if not par:
+                shutil.copyfile(os.path.join(td, "gnm.bkn"), os.path.join(OUT, name + ".bkn"))     # the reference's own index file: an input of the reader's test
             print(f"{name}: genome {sum(len(c) for c in chroms)} nt, {len(queries)} queries, "
                   f"{os.path.getsize(log) / 1e6:.2f} MB, {r.stdout.count(chr(10) + '@')} aligned")
             if name == "blk_k3":

@@ -1,0 +1,91 @@
+"""From the vote to candidate loci (spaln_amd/csrc/spdp_blk_find.h: TestOutput's second half and FindHsp; SURVEY 8 row f4,
+third slice) against the reference, on the CPU: the product's vote (spdp_blk_core.h), its HSP search (spdp_wilip.h, level -1)
+and its FindHsp, compiled by the host compiler into the tests' checker, run every query of the blk_* fixtures call after call
+as findblock does -- and leave, at every TestOutput call, what the compiled reference left there (oracle/ref_build/blk_tap.cc,
+snap_find): critjscr, the candidate block pairs as FindHsp moved their ends, and the candidate loci (chromosome, strand,
+region, range, score, HSPs).  blk_par: every gene twice in the genome, -M4 -- two loci per query, their overlap / order /
+pruning rules."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from spaln_amd import abi
+from tests import spdg
+from tests.conftest import golden_files
+from oracle import blk, oracle
+from tests.golden import make_blk_goldens as mb
+
+CASES = [("blk_k1", 42, 900, False), ("blk_k3", 28, 950, False), ("blk_par", 24, 980, True)]
+CODE_OF = np.zeros(256, dtype=np.uint8)
+for _ch, _code in zip(b"ACGTN", (2, 3, 5, 9, 16)):
+    CODE_OF[_ch] = _code
+
+
+def parse_find(L):
+    """find_log -> [(query, call, critjscr, pairs (n, 10), [(header[9], hsps)])]"""
+    L = [int(x) for x in L]
+    i, recs = 0, []
+    while i < len(L):
+        assert L[i] == -4, (i, L[i])
+        q, call, crit, npair = L[i + 1], L[i + 2], L[i + 3], L[i + 4]
+        i += 5
+        pairs = np.asarray(L[i:i + 10 * npair]).reshape(npair, 10)
+        i += 10 * npair
+        n = L[i]
+        i += 1
+        loci = []
+        for _ in range(n):
+            hd = L[i:i + 9]
+            i += 9
+            nj = hd[7] + 1 if hd[7] else 0
+            jx = np.asarray(L[i:i + 5 * nj]).reshape(-1, 5).tolist()
+            i += 5 * nj
+            if jx:
+                jx[-1][3] = 0                                    # (nid of the closing record: unset in the reference)
+            loci.append((hd[:8], jx))
+        recs.append((q, call, crit, pairs, loci))
+    return recs
+
+
+def genome_of(name, n_genes, seed, par):
+    chroms, _ = (mb.paralog_genome_and_queries if par else mb.genome_and_queries)(n_genes, 2, seed)
+    gen = np.concatenate([CODE_OF[c] for c in chroms]).astype(np.uint8)
+    off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
+    return gen, off
+
+
+@pytest.mark.parametrize("name,n_genes,seed,par", CASES, ids=[c[0] for c in CASES])
+def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
+    fx = spdg.load([f for f in golden_files("blk_") if f.endswith(name + ".spdg")][0])
+    gen, off = genome_of(name, n_genes, seed, par)
+    ix, _keep = blk.index_of(fx)
+    model = abi.wilip_model_from_fixture(fx)
+    prm = np.ascontiguousarray(fx["find_prm"], dtype=np.int32)
+    ip = np.ascontiguousarray(fx["find_intpen"], dtype=np.int16)
+    by_q = {}
+    for r in parse_find(fx["find_log"]):
+        by_q.setdefault(r[0], []).append(r)
+    lib = C.CDLL(oracle._BLK_SO)
+    f = lib.blk_check_find
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n_loci = two = 0
+    for qi, q in enumerate(blk.parse_log(fx)):
+        codes = np.ascontiguousarray(q["codes"], dtype=np.uint8)
+        log = np.zeros(1 << 16, dtype=np.int32)
+        n = f(C.addressof(ix), gen.ctypes.data, off.ctypes.data, codes.ctypes.data, len(codes), q["left"], q["right"], prm.ctypes.data,
+              ip.ctypes.data, len(ip), C.addressof(model), log.ctypes.data, len(log))
+        assert 0 <= n <= len(log), (qi, n)
+        got, want = parse_find(log[:n]), by_q.get(qi, [])
+        assert len(got) == len(want), (qi, len(got), len(want))
+        for g, w in zip(got, want):
+            np_ = g[3].shape[0]
+            assert g[1] == w[1] and g[2] == w[2], (qi, g[1], g[2], w[2])
+            assert g[3].tolist() == w[3][:np_].tolist(), (qi, g[1])
+            assert g[4] == w[4], (qi, g[1], g[4][:1], w[4][:1])
+            n_loci += len(g[4])
+            two += len(g[4]) >= 2
+    assert n_loci >= (30 if par else 15)
+    if par:
+        assert two >= 10

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Map AND align inside the library, against the reference's own program (SURVEY 8 rows f4 + f2 + f3 end to end; round 5).
+
+    python tools/e2e_q7.py [--queries 2000] [--genes 200]          (an MI355X box; oracle/_ref for the comparison)
+
+The data set of tools/dropin_demo.py (a synthetic genome with planted multi-exon genes, formatted by the compiled
+reference's own `spaln -W -KD`; cDNA queries = mutated transcripts).  Two runs:
+
+  * reference:  oracle/_ref/spaln -Q7 -S1 -O4 -t<threads> -dgnm q.fa
+  * library:    the reference's index file read by spdp_blk_index_read, the genome's residue codes, and then nothing of the
+                reference: spdp_blk_find (vote on the device, TestOutput / FindHsp with the library's own HSP search on
+                the host) -> candidate loci -> spdp_align_s_seeded on every locus (window = the locus' region, its HSPs,
+                splice signals made on the device, the recursion levels searched by the library's own Wilip) ->
+                spdp_skl_rng_s (exon table) -> chromosome coordinates.
+
+Compared: per query the exon table (query range, chromosome range of every exon) of the best locus.  The parameter sets
+(scoring, seeded walk, signal model, HSP-search model, block-search constants) are the reference's defaults as its own dumps
+hold them (tests/golden/q_c2_seed0.spdg, blk_k1.spdg).  One JSON line."""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import dropin_demo  # noqa: E402
+from spaln_amd import abi, blocks, engine  # noqa: E402
+from tests import spdg  # noqa: E402
+
+CODE_OF = np.zeros(256, dtype=np.uint8)
+for _ch, _code in zip(b"ACGTNacgtn", (2, 3, 5, 9, 16, 2, 3, 5, 9, 16)):
+    CODE_OF[_ch] = _code
+COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in ((2, 9), (9, 2), (3, 5), (5, 3)):
+    COMP[_a] = _b
+
+
+def read_fasta(path):
+    names, seqs, cur = [], [], []
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if cur:
+                    seqs.append(b"".join(cur))
+                names.append(line[1:].split()[0].decode())
+                cur = []
+            else:
+                cur.append(line.strip())
+    if cur:
+        seqs.append(b"".join(cur))
+    return names, [CODE_OF[np.frombuffer(s, dtype=np.uint8)] for s in seqs]
+
+
+def reference_exons(text):
+    """-O4 output -> {query: [(ref_l, ref_r, tgt_l, tgt_r)]} of the records as printed (the first locus of a query)"""
+    out, cur = {}, []
+    for line in text.splitlines():
+        if line.startswith("#"):
+            continue
+        if line.startswith("@"):
+            name = line.split()[7] if len(line.split()) > 7 else None
+            m = re.search(r"\) (\S+) \[", line)
+            name = m.group(1) if m else name
+            out.setdefault(name, cur)
+            cur = []
+            continue
+        f = line.split("\t")
+        if len(f) >= 10:
+            cur.append((int(f[6]), int(f[7]), int(f[8]), int(f[9])))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=2000)
+    ap.add_argument("--genes", type=int, default=200)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--show", type=int, default=3)
+    args = ap.parse_args()
+    args.protein = False
+    t_all = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="spdp_e2e_") as td:
+        genome_nt, env = dropin_demo.make_dataset(td, args)
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(dropin_demo.REF, "spaln"), "-Q7", "-S1", "-O4", f"-t{args.threads}", "-dgnm", "q.fa"], cwd=td, env=env,
+                           capture_output=True, text=True)
+        ref_s = time.perf_counter() - t0
+        if r.returncode:
+            raise SystemExit("reference run failed: " + r.stderr[-300:])
+        want = reference_exons(r.stdout)
+
+        # ---- the library's run
+        eng = engine.Engine(0)
+        lib = eng.lib
+        fq = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
+        fb = spdg.load(os.path.join(ROOT, "tests", "golden", "blk_k1.spdg"))
+        t0 = time.perf_counter()
+        fx = blocks.read_index_file(lib, os.path.join(td, "gnm.bkn"), max_intron_len=13000)
+        fx["blk_convtab"][:2] = 255
+        dix = blocks.BlockIndex(eng, fx)
+        chr_names, chroms = read_fasta(os.path.join(td, "gnm.mfa"))
+        gen = np.concatenate(chroms).astype(np.uint8)
+        off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
+        q_names, queries = read_fasta(os.path.join(td, "q.fa"))
+        model = abi.wilip_model_from_fixture(fq)
+        sigmodel = abi.signal_model_from_fixture(fq)
+        ip = np.ascontiguousarray(fb["find_intpen"], dtype=np.int16)
+        sc = spdg.scoring(fq, intpen=ip, scalar_engines=1)
+        sp = abi.seed_params_from_fixture(fq)
+        prm = blocks.find_params_from_fixture(fb)
+        prm.phase1t = int(dix.desc.rbscons)              # Phase1T = (int) (RbsBias * avr), RbsBias = RbsBase = 3 (src/blksrc.cc:64-66)
+        load_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        loci, status = blocks.find(dix, gen, off, model, sc, prm, queries)
+        find_s = time.perf_counter() - t0
+        # every locus of every query -> one problem of one seeded call
+        t0 = time.perf_counter()
+        ps = abi.ProblemSet()
+        owner, hs = [], []
+        for qi, ls in enumerate(loci):
+            for L in ls:
+                reg = gen[off[L["chr"]] + L["base"]:off[L["chr"]] + L["base"] + L["len"]]
+                if L["rvs"]:
+                    reg = COMP[reg[::-1]]
+                # genomicseq (src/spaln.cc:913): the Exinon of the range, here made on the device from the codes
+                sg = eng.splice_signals(sigmodel, reg, L["left"], L["right"])
+                ps.add(queries[qi], reg, sg["sig5"], sg["sig3"], 0, len(queries[qi]), L["left"], L["right"], (1, 1, 1, 1),
+                       cano5=sg["cano5"], cano3=sg["cano3"], dinc=sg["dinc"])
+                owner.append((qi, L))
+                hs.append(L["hsps"])
+        res = eng.align_s_seeded(sc, sp, ps, hs, [0] * len(owner), model)
+        align_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        keep = [(i, skl) for i, (scr, skl) in enumerate(res) if len(skl)]
+        sub = abi.ProblemSet()
+        for i, _ in keep:
+            p = ps.items[i]
+            sub.items.append(p)
+        sub._keep = ps._keep
+        fs = fq["rng_fstat_A0"] if "rng_fstat_A0" in fq else [0, 0, 0, 0, 0, 0, 3, 1]
+        rs = eng.skl_rng_s(sc, sub, [skl.ravel() for _, skl in keep], codonk1=fq["prm"]["codonk1"], minl=fq["prm"]["minl"],
+                           jneibr=int(fs[6]), lsg=int(fs[7]))
+        rescore_s = time.perf_counter() - t0
+        got = {}
+        best = {}
+        for (i, _), (h, fst, recs) in zip(keep, rs):
+            qi, L = owner[i]
+            if qi in best and best[qi] >= fst[4]:
+                continue
+            best[qi] = fst[4]
+            ex = []
+            for row in recs:
+                left, right, rleft, rright = (int(x) for x in row[:4])
+                if left > (1 << 30):                             # (the terminator of the EISCR array)
+                    continue
+                site = (lambda n: L["base"] + (L["len"] - n if L["rvs"] else n + 1))
+                ex.append((rleft + 1, rright, site(left), site(right - 1)))
+            got[q_names[qi]] = ex
+        n_same = sum(1 for k, v in want.items() if got.get(k) == v)
+        diff = [k for k, v in want.items() if got.get(k) != v]
+        for k in diff[:args.show]:
+            sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
+        out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 -S1 -O4`",
+               "queries": args.queries, "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
+               "identical_exon_tables": n_same, "different": len(diff),
+               "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
+               "library_s": {"index_and_genome_load": round(load_s, 2), "find": round(find_s, 2), "align": round(align_s, 2),
+                             "rescore": round(rescore_s, 2)},
+               "loci": len(owner), "wall_s": round(time.perf_counter() - t_all, 1)}
+        print(json.dumps(out))
+        dix.free()
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

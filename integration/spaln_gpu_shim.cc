@@ -72,6 +72,7 @@ const	int n = backtrace(bt, 48);
 }
 struct DbgInit { DbgInit() { if (getenv("SPALN_GPU_DEBUG")) { g_dbg = true; signal(SIGSEGV, on_segv); fprintf(stderr, "[spaln_gpu] loaded\n"); } } } g_dbg_init;
 
+bool own_wilip();
 void report()
 {
 	fprintf(stderr, "[spaln_gpu] alignS_ng on the device: %ld plain, %ld seeded, %ld score-only; alignH_ng: %ld plain, %ld seeded; "
@@ -81,8 +82,9 @@ void report()
 		g_us[0].load() * 1e-6, g_us[1].load() * 1e-6);
 	if (g_seed[5].load())
 	    fprintf(stderr, "[spaln_gpu] seeded calls: upload %.2f s, walks alone %.2f s, device batches %.2f s (%ld batches, %ld lspS_ng, %ld tracebacks), "
-		"hand-back %.2f s, in all %.2f s; Wilip through the callback %ld\n", g_seed[6].load() * 1e-6, g_seed[7].load() * 1e-6, g_seed[8].load() * 1e-6,
-		g_seed[0].load(), g_seed[1].load(), g_seed[2].load(), g_seed[9].load() * 1e-6, g_seed[10].load() * 1e-6, g_seed[4].load());
+		"hand-back %.2f s, in all %.2f s; HSP searches of the recursion levels %ld (%s)\n", g_seed[6].load() * 1e-6, g_seed[7].load() * 1e-6, g_seed[8].load() * 1e-6,
+		g_seed[0].load(), g_seed[1].load(), g_seed[2].load(), g_seed[9].load() * 1e-6, g_seed[10].load() * 1e-6, g_seed[4].load(),
+		own_wilip()? "the library's own": "the reference's Wilip through the callback");
 }
 
 // the HSP searches of the recursion levels: the library's own (spdp_wilip.h, round 5) unless SPALN_GPU_WILIP=ref asks for the

@@ -678,11 +678,12 @@ LEGS = {
                "(oracle/_ref/spaln_gpu) against the unmodified build on a synthetic genome its own `spaln -W` formatted: -O4 records "
                "compared, wall times of both; default engines (-A0); both programs with -t16: the shim's batching boundary (integration/) "
                "records the workers' aligner calls and aligns them in chunks beside the mapping"),
-    "e2e_q7": (["tools/e2e_q7.py", "--queries", "5000", "--genes", "200"],
-               "map AND align inside the library (SURVEY 8 rows f4 + f2 + f3 end to end): the reference's index file and the genome in, "
-               "spdp_blk_find (vote on the device, TestOutput / FindHsp with the library's own HSP search on the host) -> candidate loci -> "
-               "spdp_align_s_seeded with the library's own Wilip -> spdp_skl_rng_s -> exon tables in chromosome coordinates, compared with "
-               "`spaln -Q7 -S1 -O4` of the compiled reference on the same queries"),
+    "e2e_q7": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200"],
+               "map AND align inside the library in ONE call (spdp_map_align_s; SURVEY 8 rows f4 + f1 + f2 + f3 end to end): the "
+               "reference's index file and the genome in, spdp_blk_find (vote on the device, TestOutput / FindHsp with the library's own "
+               "HSP search on the host) -> candidate loci -> their regions and splice signals (one launch) -> spdp_align_s_seeded with "
+               "the library's own Wilip -> spdp_skl_rng_s -> the best locus' exon table in chromosome coordinates, compared with, and "
+               "timed against, `spaln -Q7 -S1 -O4 -t16` of the compiled reference on the same 20 000 queries"),
     "dropin_q7_20k": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16"],
                       "the same at 20 000 queries under -Q7 (the reference's normal mode): the size at which the device batches are large enough to matter"),
 }

@@ -857,6 +857,32 @@ int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDe
                   const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
                   SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status);
 
+/* ---- map and align (round 5): the aligner's caller for nucleotide queries, inside the library ------------------------------
+ * What spaln's per-query driver does between the block search and the printer when the genome is searched (-Q4 .. -Q7, cDNA
+ * queries; src/spaln.cc:880-1010 spalign2 / blkaln, genomicseq at :913): every candidate locus of a query becomes a problem
+ * -- its region cut from the genome (reverse-complemented when the locus is on the other strand), the region's splice
+ * signals (Exinon::intron53, here spdp_signals.hip on the device for all loci of a chunk in one launch), the locus' HSPs --,
+ * the seeded aligner runs on all of them (spdp_align_s_seeded, the recursion levels searched by sp->wilip), skl_rngS_ng
+ * rescoring follows (spdp_skl_rng_s), and of a query's loci the one with the highest Gsinfo::fstat.val stays (the first one
+ * on ties).  Its exons come back in the coordinates the reference prints (-O4: query positions 1-based inclusive, chromosome
+ * positions 1-based on the forward strand, left > right on the reverse strand: Seq::SiteNo, src/seq.h).
+ * One call = spdp_blk_find + one batched signal launch + one seeded call + one rescoring call per chunk of loci. */
+typedef struct SpdpMapExon { int32_t q_left, q_right, g_left, g_right; } SpdpMapExon;
+typedef struct SpdpMapGene {
+    int32_t chr, rvs;                /* -1 / 0 when the query has no alignment                                             */
+    int32_t score, val;              /* skl_rngS_ng's return value, Gsinfo::fstat.val of the locus that stayed             */
+    int32_t n_loci;                  /* candidate loci of the query that were aligned                                      */
+    int32_t n_exons;
+    int64_t exon_off;                /* its exons: (*exons)[exon_off .. exon_off + n_exons)                                */
+} SpdpMapGene;
+/* genes: n records of the caller; *exons: malloc'ed (free() it); seconds (may be NULL): [0] block search, [1] regions +
+ * signals, [2] seeded alignment, [3] rescoring + selection.  sp->wilip must be set (the HSP searches are the library's). */
+int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                     const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
+                     const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
+                     const uint8_t* codes, const int64_t* offs, int32_t n,
+                     SpdpMapGene* genes, SpdpMapExon** exons, double* seconds);
+
 /* ---- device groups, continued ------------------------------------------------------------------------------------------ */
 /* the same sharding for the calls of the seeded path, rescoring and the block vote (rounds 3 / 4).  The HSP source of a
  * seeded call is asked with the CALLER's query numbers, from the worker threads of every member.  spdp_group_blk_vote takes

@@ -227,3 +227,51 @@ def find(index: "BlockIndex", genome_codes, chr_off, model, sc, prm: BlkFindPara
     libc.free(loci)
     libc.free(hsps)
     return out, status
+
+
+class MapExon(C.Structure):
+    _fields_ = [("q_left", C.c_int32), ("q_right", C.c_int32), ("g_left", C.c_int32), ("g_right", C.c_int32)]
+
+
+class MapGene(C.Structure):
+    _fields_ = [("chr", C.c_int32), ("rvs", C.c_int32), ("score", C.c_int32), ("val", C.c_int32), ("n_loci", C.c_int32),
+                ("n_exons", C.c_int32), ("exon_off", C.c_int64)]
+
+
+def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm: BlkFindParams, rescore, queries):
+    """spdp_map_align_s: block search -> loci -> signals -> seeded alignment -> rescoring, one call for all queries.
+    rescore = (codonk1, minl, jneibr, lsg).  Returns (per query None or dict(chr, rvs, score, val, n_loci,
+    exons = [(q_left, q_right, g_left, g_right)]), seconds [find, regions + signals, align, rescore], return code)."""
+    from . import abi
+    lib, eng = index.lib, index.eng
+    n = len(queries)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    codes = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in queries]))
+    g = Genome()
+    gc = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    go = np.ascontiguousarray(chr_off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    rp = abi.RescoreParams(*(int(x) for x in rescore))
+    genes = (MapGene * n)()
+    exons = C.POINTER(MapExon)()
+    sec = (C.c_double * 4)()
+    lib.spdp_map_align_s.restype = C.c_int
+    lib.spdp_map_align_s.argtypes = [C.c_void_p] * 11 + [C.c_int32] + [C.c_void_p] * 3
+    rc = lib.spdp_map_align_s(eng.ctx, index.h, C.byref(index.desc), C.byref(g), C.byref(sc), C.byref(sp), C.addressof(sigmodel),
+                              C.byref(prm), C.byref(rp), codes.ctypes.data, offs.ctypes.data, n, genes, C.byref(exons), sec)
+    if rc < 0:
+        eng._check(rc, "spdp_map_align_s")
+    out = []
+    for i in range(n):
+        G = genes[i]
+        if G.chr < 0:
+            out.append(None)
+            continue
+        ex = [(exons[G.exon_off + j].q_left, exons[G.exon_off + j].q_right, exons[G.exon_off + j].g_left, exons[G.exon_off + j].g_right)
+              for j in range(G.n_exons)]
+        out.append(dict(chr=G.chr, rvs=G.rvs, score=G.score, val=G.val, n_loci=G.n_loci, exons=ex))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(exons)
+    return out, list(sec), rc

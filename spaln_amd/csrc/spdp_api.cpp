@@ -171,7 +171,7 @@ void spdp_destroy(SpdpContext* ctx)
     ctx->lanes.clear();
     (void) hipSetDevice(ctx->device);
     for (DevPool& p : ctx->pool) p.release();
-    for (int k = 0; k < 2; ++k) if (ctx->stage_ptr[k]) (void) hipHostFree(ctx->stage_ptr[k]);
+    for (int k = 0; k < 3; ++k) if (ctx->stage_ptr[k]) (void) hipHostFree(ctx->stage_ptr[k]);
     (void) hipEventDestroy(ctx->ev0);
     (void) hipEventDestroy(ctx->ev1);
     (void) hipEventDestroy(ctx->ev2);

@@ -261,8 +261,8 @@ struct SpdpContext {
     int64_t seed_stats[12] = {0};      // spdp_seeded_stats
     std::vector<std::vector<SpdpPhaseMark>> seed_marks;    // spdp_seeded_phase_marks: per query of the last spdp_align_h_seeded call
     int64_t rerun_stats[2] = {0, 0};   // launches repeated because a cross-CU group / a tile pipeline gave up (spdp_rerun_stats)
-    void*  stage_ptr[2] = {nullptr, nullptr};   // pinned host staging of DevStore::upload (grow-only)
-    size_t stage_cap[2] = {0, 0};
+    void*  stage_ptr[3] = {nullptr, nullptr, nullptr};   // pinned host staging (grow-only): [0], [1] DevStore::upload, [2] the regions and
+    size_t stage_cap[3] = {0, 0, 0};                     // signal arrays of spdp_map_align_s
     void*  staging(int k, size_t bytes);
 };
 SpdpContext* spdp_lane(SpdpContext* ctx, int i);

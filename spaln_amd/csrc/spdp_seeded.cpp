@@ -154,12 +154,13 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
             parents[k] = q.query; wins[k] = q.w; kinds[k] = (uint8_t) q.kind;
             cuts[2 * k] = q.cut[0]; cuts[2 * k + 1] = q.cut[1];
         }
-        if (const char* df = getenv("SPDP_SEED_DUMP")) {      // request shapes of every batch, for tuning: batch kind rows cols lw up cut
+        if (const char* df = getenv("SPDP_SEED_DUMP")) {      // request shapes of every batch, for tuning: batch kind rows cols lw up cut query a_left b_left lane
             std::lock_guard<std::mutex> g(stats_mu);
             if (FILE* f = fopen(df, "a")) {
                 for (int k = 0; k < m; ++k) {
                     const Parked& q = *take[k];
-                    fprintf(f, "%lld %d %d %d %d %d %d\n", (long long) n_batches, q.kind, q.s.ar - q.s.al, q.s.br - q.s.bl, q.w.lw, q.w.up, q.cut[1] - q.cut[0]);
+                    fprintf(f, "%lld %d %d %d %d %d %d %d %d %d %d\n", (long long) n_batches, q.kind, q.s.ar - q.s.al, q.s.br - q.s.bl, q.w.lw, q.w.up, q.cut[1] - q.cut[0],
+                            q.query, q.s.al, q.s.bl, lane);
                 }
                 fclose(f);
             }

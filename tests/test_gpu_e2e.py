@@ -2,12 +2,20 @@
 spdp_blk_find -> candidate loci -> spdp_align_s_seeded with the library's own HSP search -> spdp_skl_rng_s, and the exon
 tables in chromosome coordinates against `spaln -Q7 -S1 -O4` of the compiled reference (oracle/_ref/spaln: test
 infrastructure, prebuilt) on the same synthetic genome and queries."""
+import ctypes as C
 import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+from spaln_amd import abi, blocks
+from tests import spdg
+from tests.conftest import golden_files
+from oracle import blk
+from tests.test_blk_find import CASES, genome_of
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,3 +30,72 @@ def test_exon_tables_equal_the_reference_program():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["reference_aligned"] == 300 and d["library_aligned"] == 300
     assert d["identical_exon_tables"] == 300, (d, r.stderr[-600:])
+
+
+COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in ((2, 9), (9, 2), (3, 5), (5, 3)):
+    COMP[_a] = _b
+
+
+@pytest.mark.parametrize("name,n_genes,seed,par", [c for c in CASES if c[0] in ("blk_par", "blk_k1")],
+                         ids=[c[0] for c in CASES if c[0] in ("blk_par", "blk_k1")])
+def test_one_call_equals_its_steps(name, n_genes, seed, par):
+    """spdp_map_align_s against the entries it is made of, called one by one from here: spdp_blk_find, per locus the region
+    and spdp_splice_signals, spdp_align_s_seeded, spdp_skl_rng_s, the locus with the highest fstat.val (the paralog genome
+    under -M4 gives two loci per query to choose from)"""
+    from spaln_amd import engine
+    eng = engine.Engine(0)
+    fx = spdg.load([f for f in golden_files("blk_") if f.endswith(name + ".spdg")][0])
+    fq = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
+    gen, off = genome_of(name, n_genes, seed, par)
+    dix = blocks.BlockIndex(eng, fx)
+    model = abi.wilip_model_from_fixture(fq)
+    sigmodel = abi.signal_model_from_fixture(fq)
+    prm = blocks.find_params_from_fixture(fx)
+    sc = spdg.scoring(fq, intpen=np.ascontiguousarray(fx["find_intpen"], dtype=np.int16), scalar_engines=1)
+    sp = abi.seed_params_from_fixture(fq)
+    fs = fq["rng_fstat_A0"] if "rng_fstat_A0" in fq else [0, 0, 0, 0, 0, 0, 3, 1]
+    rescore = (fq["prm"]["codonk1"], fq["prm"]["minl"], int(fs[6]), int(fs[7]))
+    queries = [q["codes"][q["left"]:q["right"]] for q in blk.parse_log(fx)]
+    # ---- the steps
+    loci, _ = blocks.find(dix, gen, off, model, sc, prm, queries)
+    ps, owner, hs = abi.ProblemSet(), [], []
+    for qi, ls in enumerate(loci):
+        for L in ls:
+            reg = gen[off[L["chr"]] + L["base"]:off[L["chr"]] + L["base"] + L["len"]]
+            if L["rvs"]:
+                reg = COMP[reg[::-1]]
+            sg = eng.splice_signals(sigmodel, reg, L["left"], L["right"])
+            ps.add(queries[qi], reg, sg["sig5"], sg["sig3"], 0, len(queries[qi]), L["left"], L["right"], (1, 1, 1, 1),
+                   cano5=sg["cano5"], cano3=sg["cano3"], dinc=sg["dinc"])
+            owner.append((qi, L))
+            hs.append(L["hsps"])
+    assert len(owner) > len(queries) or name != "blk_par"          # (more loci than queries: there is something to choose)
+    res = eng.align_s_seeded(sc, sp, ps, hs, [0] * len(owner), model)
+    rs = eng.skl_rng_s(sc, ps, [skl.ravel() for _, skl in res], codonk1=rescore[0], minl=rescore[1], jneibr=rescore[2], lsg=rescore[3])
+    want = {}
+    for i, ((scr, skl), (h, fst, recs)) in enumerate(zip(res, rs)):
+        if not len(skl):
+            continue
+        qi, L = owner[i]
+        if qi in want and want[qi]["val"] >= fst[4]:
+            continue
+        site = (lambda n, L=L: L["base"] + (L["len"] - n if L["rvs"] else n + 1))
+        want[qi] = dict(chr=L["chr"], rvs=L["rvs"], score=h, val=fst[4],
+                        exons=[(int(r[2]) + 1, int(r[3]), site(int(r[0])), site(int(r[1]) - 1)) for r in recs if int(r[0]) <= (1 << 30)])
+    # ---- the one call
+    sp.wilip = C.addressof(model)
+    genes, seconds, rc = blocks.map_align(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries)
+    assert rc == 0 and len(genes) == len(queries)
+    n_aligned = 0
+    for qi, g in enumerate(genes):
+        if qi not in want:
+            assert g is None, qi
+            continue
+        n_aligned += 1
+        assert g is not None, qi
+        assert {k: g[k] for k in ("chr", "rvs", "score", "val", "exons")} == want[qi], (qi, g, want[qi])
+        assert g["n_loci"] == sum(1 for i, (q, _) in enumerate(owner) if q == qi and len(res[i][1]))
+    assert n_aligned >= 10
+    dix.free()
+    eng.close()

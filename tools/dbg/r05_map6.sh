@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /root/repo
+for lib in libspdp_hip.so libspdp_colfeed.so; do
+  echo "== $lib"
+  SPDP_LIB=/root/repo/spaln_amd/$lib SPDP_MAP_VERBOSE=1 SPDP_SEED_VERBOSE=1 timeout 1200 python tools/e2e_q7.py --queries 20000 --genes 200 2>/tmp/e.txt >/tmp/o.json
+  grep "^\[map\] chunk\|lane" /tmp/e.txt | tail -5 | cut -c1-330
+  python -c "import json;d=json.load(open('/tmp/o.json'));print(d['queries'], d['identical_exon_tables'], d['reference_wall_s'], d['library_s'], d['library_over_reference'])"
+done

@@ -186,3 +186,46 @@ def runs_near_pairs(ix: BlkIndex, runs, pairs):
                     break
         out.append(keep)
     return out
+
+
+class BuildParams(C.Structure):
+    """OrcBlkBuildParams (oracle/spdp_oracle_blkidx.c) = SpdpBlkBuildParams (include/spdp.h)"""
+    _fields_ = [("ktuple", C.c_int32), ("nshift", C.c_int32), ("blklen", C.c_int32), ("maxgene", C.c_int32), ("nbitpat", C.c_int32),
+                ("afact", C.c_int32), ("bitpat", C.c_uint32), ("bitpat2", C.c_uint32), ("threaded", C.c_int32)]
+
+
+def build_params_of(fx: dict, threaded: int = 0) -> BuildParams:
+    """the BlkWcPrm the reference's own index of a blk_* fixture was built with"""
+    v = np.asarray(fx["blk_prm"], dtype=np.int64)
+    p = BuildParams()
+    p.ktuple, p.nshift, p.blklen, p.maxgene = int(v[PRM["ktuple"]]), int(v[PRM["nshift"]]), int(v[PRM["blklen"]]), int(v[PRM["maxgene"]])
+    p.nbitpat, p.afact = int(v[PRM["nbitpat"]]), int(v[PRM["afact"]])
+    p.bitpat, p.bitpat2 = int(v[PRM["bitpat"]]) & 0xffffffff, int(v[PRM["bitpat2"]]) & 0xffffffff
+    p.threaded = threaded
+    return p
+
+
+def index_build(codes, chr_off, prm: BuildParams) -> dict:
+    """MakeBlk::idxblk + blkscrtab on the CPU: dict(nblk, blkp, wscr, blkb, chr, b2c, word_no, glen, avrscr, maxblk, bytblk,
+    n_blocks, minscr)"""
+    lib = _o.lib()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    off = np.ascontiguousarray(chr_off, dtype=np.int64)
+    n_chr = len(off) - 1
+    tab = 1 << (2 * prm.ktuple)
+    nblk = np.zeros(tab, np.uint16); blkp = np.zeros(tab, np.int32); wscr = np.zeros(tab, np.int16)
+    chr_ = np.zeros(2 * (n_chr + 1), np.int32); b2c = np.zeros(3, np.float64); head = np.zeros(8, np.int64)
+    blkb = C.POINTER(C.c_uint32)()
+    lib.orc_blk_index_build.restype = C.c_int
+    lib.orc_blk_index_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+    rc = lib.orc_blk_index_build(codes.ctypes.data, off.ctypes.data, n_chr, C.byref(prm), nblk.ctypes.data, blkp.ctypes.data,
+                                 wscr.ctypes.data, C.byref(blkb), chr_.ctypes.data, b2c.ctypes.data, head.ctypes.data)
+    if rc:
+        raise RuntimeError(f"orc_blk_index_build: {rc}")
+    n = int(head[0])
+    words = np.ctypeslib.as_array(blkb, shape=(max(n, 1),))[:n].copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(blkb)
+    return dict(nblk=nblk, blkp=blkp, wscr=wscr, blkb=words, chr=chr_, b2c=b2c, word_no=n, glen=int(head[1]), avrscr=int(head[2]),
+                maxblk=int(head[3]), bytblk=int(head[4]), n_blocks=int(head[5]), minscr=int(head[6]))

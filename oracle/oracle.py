@@ -19,7 +19,7 @@ _lib = None
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("spdp_oracle.c", "spdp_oracle_scalar.c", "spdp_oracle_h.c",
-                                                "spdp_oracle_h_scalar.c", "spdp_oracle_blk.c")]
+                                                "spdp_oracle_h_scalar.c", "spdp_oracle_blk.c", "spdp_oracle_blkidx.c")]
     hdr = os.path.join(_HERE, "..", "include", "spdp.h")
     newest = max(os.path.getmtime(f) for f in srcs + [hdr])
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:

@@ -69,7 +69,7 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
     struct Owned { SpdpLocus* l; SpdpJuxt* h; ~Owned() { free(l); free(h); } } owned{loci, hsps};
     sec[0] = since(t0);
 
-    size_t chunk_positions = (size_t) 512 << 20;        // signal arrays of a chunk: 7 B per position on both sides of the bus
+    size_t chunk_positions = (size_t) 2048 << 20;       // signal arrays of a chunk: 7 B per position on both sides of the bus
     if (const char* e = getenv("SPDP_MAP_CHUNK_MB")) chunk_positions = (size_t) std::max(1, atoi(e)) << 20;
     std::vector<std::vector<SpdpMapExon>> kept(n);
     int partial = 0;

@@ -857,6 +857,34 @@ int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDe
                   const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
                   SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status);
 
+/* ---- block search, fourth slice (round 5): the index builder ------------------------------------------------------------
+ * `spaln -W -KD genome.mfa` for the block index (<db>.bkn): MakeBlk::idxblk / m_idxblk + blkscrtab + findChrBbound
+ * (src/blksrc.cc:1185-1241, 1459-1593, 944-997, 583-596) with Block::c2w (:448-464) and Bitpat_wq::word (src/bitpat.cc:188-212).
+ * Every residue of the genome ends a word of every bit pattern; a word counts once per block (blklen residues + the margin of
+ * the widest pattern) at the phases its run of unambiguous residues gives it; words by how many blocks hold them get a
+ * score, the rare enough ones a posting list in block order.  On the device: the words of all positions, their (word, block)
+ * keys and the word counts in one pass over the resident genome, a radix sort of the keys, the lists compacted; on the host:
+ * the scores (the reference's libm logarithms), the cut-off, the file.  The reference builds its blocks in two ways, and
+ * the tables differ: without -t a block's word state starts afresh behind the previous block's end (threaded = 0), with
+ * -t >= 1 every block is scanned over its own blklen + margin residues (threaded = 1).  Nucleotide genomes; residues = the
+ * library's codes, anything but A / C / G / T an ambiguous residue (letters the reference skips -- not IUPAC -- must not be in
+ * the array).  Refused: a word that lies in more than 65 535 blocks (the reference's 16-bit counters wrap there). */
+typedef struct SpdpBlkBuildParams {  /* BlkWcPrm as setupbitpat leaves it (src/blksrc.cc:680-737)                          */
+    int32_t ktuple, nshift, blklen, maxgene, nbitpat, afact;
+    uint32_t bitpat, bitpat2;        /* nbitpat = 1: the one pattern (2^ktuple - 1 = contiguous); 3 / 5: the spaced pairs     */
+    int32_t threaded;
+} SpdpBlkBuildParams;
+/* what `spaln -W -KD [-XC<n>]` picks for a FASTA file of fasta_bytes bytes (k from its logarithm, blklen and MaxGene from its
+ * square root; the spaced patterns of DefBitPat[k] when nbitpat > 1); nbitpat = 0 or 1: the contiguous k-mer.  0, or -1. */
+int spdp_blk_build_params_default(int64_t fasta_bytes, int32_t nbitpat, SpdpBlkBuildParams* p);
+/* the index of `genome`, with the search parameters derived as spdp_blk_index_read derives them from a file (opts may be
+ * NULL).  seconds (may be NULL): [0] device passes (words, sort, lists), [1] host (scores, cut-off, tables), [2] the call. */
+SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParams* p,
+                                       const SpdpBlkSearchOpts* opts, double* seconds);
+/* the index as the reference's file (format version 26; the five pointers of its header, which the reference writes as its
+ * heap held them, as zeros; ConvTab entries the reference leaves unset as "ambiguous"): 0, or -1 */
+int spdp_blk_index_write(const SpdpBlkIndexHost* h, const char* path);
+
 /* ---- map and align (round 5): the aligner's caller for nucleotide queries, inside the library ------------------------------
  * What spaln's per-query driver does between the block search and the printer when the genome is searched (-Q4 .. -Q7, cDNA
  * queries; src/spaln.cc:880-1010 spalign2 / blkaln, genomicseq at :913): every candidate locus of a query becomes a problem

@@ -146,9 +146,20 @@ def read_index_file(lib, path: str, **opts):
     h = lib.spdp_blk_index_read(path.encode(), C.byref(o), err, 256)
     if not h:
         raise RuntimeError(err.value.decode())
+    out = _host_index_to_dict(lib, h)
+    lib.spdp_blk_index_host_free(h)
+    return out
+
+
+def _host_index_to_dict(lib, h) -> dict:
+    """a SpdpBlkIndexHost -> the arrays in the layout of a reference-side dump (BlockIndex, the tests' oracle)"""
+    lib.spdp_blk_index_host_desc.restype = C.POINTER(BlkIndexDesc)
+    lib.spdp_blk_index_host_desc.argtypes = [C.c_void_p]
     d = lib.spdp_blk_index_host_desc(h).contents
 
     def arr(ptr, n, dt):
+        if not n:
+            return np.zeros(0, dtype=dt)
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
     out = {name: int(getattr(d, name)) for name, _ in BlkIndexDesc._fields_[:26]}
     out.update(rbscoef=float(d.rbscoef), rbscons=float(d.rbscons), bclw=d.bclw, bcup=d.bcup, bcce=d.bcce, cfact=d.cfact,
@@ -156,8 +167,6 @@ def read_index_file(lib, path: str, **opts):
                blk_wscr=arr(d.wscr, d.tabsize, np.int16), blk_blkp=arr(d.blkp, d.tabsize, np.int32),
                blk_blkb=arr(d.blkb, d.n_words, np.uint32), blk_rscrtab=arr(d.rscrtab, 128, np.int32),
                blk_chr=arr(d.chr, 2 * (d.n_chr + 1), np.int32), blk_bitpat=arr(d.bitpat, d.n_bitpat, np.int32))
-    lib.spdp_blk_index_host_free(h)
-    # ... and in the layout of a reference-side dump, so that the result can stand in for one (BlockIndex, the tests' oracle)
     prm = np.zeros(42, dtype=np.int32)
     for name, pos in _PRM.items():
         prm[pos] = out[name]
@@ -167,6 +176,51 @@ def read_index_file(lib, path: str, **opts):
     out["blk_pb2c"] = np.frombuffer(np.array([out["bclw"], out["bcup"], out["bcce"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
     out["blk_cfact"] = np.frombuffer(np.array([out["cfact"]], dtype=np.float64).tobytes(), dtype=np.uint8).copy()
     return out
+
+
+class BlkBuildParams(C.Structure):       # SpdpBlkBuildParams
+    _fields_ = [("ktuple", C.c_int32), ("nshift", C.c_int32), ("blklen", C.c_int32), ("maxgene", C.c_int32), ("nbitpat", C.c_int32),
+                ("afact", C.c_int32), ("bitpat", C.c_uint32), ("bitpat2", C.c_uint32), ("threaded", C.c_int32)]
+
+
+def build_params_default(lib, fasta_bytes: int, nbitpat: int = 1, threaded: int = 0) -> BlkBuildParams:
+    """what `spaln -W -KD [-XC<n>]` picks for a FASTA file of that size (spdp_blk_build_params_default)"""
+    p = BlkBuildParams()
+    lib.spdp_blk_build_params_default.argtypes = [C.c_int64, C.c_int32, C.c_void_p]
+    if lib.spdp_blk_build_params_default(int(fasta_bytes), int(nbitpat), C.byref(p)):
+        raise RuntimeError("spdp_blk_build_params_default: out of range")
+    p.threaded = threaded
+    return p
+
+
+def build_index(eng, genome_codes, chr_off, prm: BlkBuildParams, write_to: str = None, **opts):
+    """spdp_blk_index_build (+ spdp_blk_index_write): the block index of a genome made on the device.  Returns (the arrays in
+    the layout read_index_file gives, seconds [device, host, call])."""
+    lib = eng.lib
+    g = Genome()
+    gc = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    go = np.ascontiguousarray(chr_off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    o = SearchOpts()
+    lib.spdp_blk_search_opts_default(C.byref(o))
+    for k, v in opts.items():
+        setattr(o, k, v)
+    sec = (C.c_double * 3)()
+    lib.spdp_blk_index_build.restype = C.c_void_p
+    lib.spdp_blk_index_build.argtypes = [C.c_void_p] * 5
+    lib.spdp_blk_index_host_free.argtypes = [C.c_void_p]
+    h = lib.spdp_blk_index_build(eng.ctx, C.byref(g), C.byref(prm), C.byref(o), sec)
+    if not h:
+        raise RuntimeError(lib.spdp_last_error(eng.ctx).decode())
+    try:
+        if write_to is not None:
+            lib.spdp_blk_index_write.argtypes = [C.c_void_p, C.c_char_p]
+            if lib.spdp_blk_index_write(h, write_to.encode()):
+                raise RuntimeError("spdp_blk_index_write: cannot write " + write_to)
+        out = _host_index_to_dict(lib, h)
+    finally:
+        lib.spdp_blk_index_host_free(h)
+    return out, list(sec)
 
 
 class BlkFindParams(C.Structure):        # SpdpBlkFindParams

@@ -88,3 +88,17 @@ def test_index_files_of_the_reference(name):
     same_tables(got, f)
     assert (got["word_no"], got["glen"], got["avrscr"], got["maxblk"], got["bytblk"]) == (f["word_no"], f["glen"], f["avrscr"], f["maxblk"], f["bytblk"])
     assert f["ver"] == 26 and f["n_chr"] == len(off) - 1
+
+
+def test_default_parameters_are_the_reference_choice():
+    """spdp_blk_build_params_default (host code of the product, no device needed) against the BlkWcPrm the reference's
+    setupbitpat wrote into its files; the FASTA sizes are those tests/golden/make_idx_goldens.py printed"""
+    import ctypes as C
+    from spaln_amd import blocks, engine
+    lib = C.CDLL(engine.LIB_PATH)
+    for name, size, nbit in (("idx_k1_t4", 524081, 1), ("idx_k3_t4", 359387, 5), ("idx_edge_t0", 85346, 5)):
+        w = read_bkn(os.path.join(GOLDEN_DIR, name + ".bkn.gz"))["wcp"]
+        p = blocks.build_params_default(lib, size, nbit)
+        assert (4, p.ktuple, p.bitpat2, 1 << (2 * p.ktuple), p.bitpat, p.nshift, p.blklen, p.maxgene, p.nbitpat, p.afact) == tuple(w), name
+    with pytest.raises(RuntimeError):
+        blocks.build_params_default(lib, 0)

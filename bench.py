@@ -437,7 +437,9 @@ def main_blk(args):
             f.write(s[chr_len // 60 * 60:].tobytes() + b"\n")
     env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
     env.update(ALN_TAB=REF_TAB, ALN_DBS=td)
+    t_fmt = time.perf_counter()
     subprocess.run([os.path.join(ref, "spaln"), "-W", "-KD", f"-t{_host_cores()}", "gnm.mfa"], cwd=td, env=env, check=True, capture_output=True)
+    ref_format_s = time.perf_counter() - t_fmt
     # the library reads the reference's index file itself (spdp_blk_index_read); ExtBlock = max_intron_len(0.996) / blklen + 1
     # with the reference's default intron length distribution (12 288 <= that quantile < 14 336: its own run on the
     # fixtures' 2048-nt blocks gives ExtBlock = 7)
@@ -469,6 +471,45 @@ def main_blk(args):
     input_s = time.perf_counter() - t_in
 
     eng = engine.Engine(local_rank)
+    # the index builder (fourth slice): the same genome's index made by the library on the device, compared with
+    # the tables of the reference's file and timed beside the reference's formatter (which also writes the sequence files)
+    index_build = None
+    if rank == 0:
+        t_b = time.perf_counter()
+        with open(os.path.join(td, "gnm.mfa"), "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.uint8)
+        nl = np.nonzero(raw == 10)[0]
+        heads = np.nonzero(raw == ord(">"))[0]
+        keep = raw != 10
+        for h in heads:
+            keep[h:nl[np.searchsorted(nl, h)] + 1] = False
+        chr_len_seen = []
+        bounds = list(heads) + [raw.size]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            chr_len_seen.append(int(keep[a:b].sum()))
+        code_of_b = np.zeros(256, dtype=np.uint8)
+        for ch, cd in zip(b"ACGTN", (2, 3, 5, 9, 16)):
+            code_of_b[ch] = cd
+        gcodes = code_of_b[raw[keep]]
+        goff = np.array([0] + list(np.cumsum(chr_len_seen)), dtype=np.int64)
+        parse_s = time.perf_counter() - t_b
+        bp = blocks.build_params_default(eng.lib, os.path.getsize(os.path.join(td, "gnm.mfa")), 1, threaded=1)
+        blocks.build_index(eng, gcodes[:1 << 20], np.array([0, 1 << 20], dtype=np.int64), bp)          # (code objects loaded, pools sized)
+        t_b = time.perf_counter()
+        built, bsec = blocks.build_index(eng, gcodes, goff, bp, max_intron_len=13000)
+        build_s = time.perf_counter() - t_b
+        same = all(np.array_equal(np.asarray(built[k]).astype(np.int64), np.asarray(fx[k]).astype(np.int64))
+                   for k in ("blk_nblk", "blk_wscr", "blk_blkp", "blk_blkb", "blk_chr", "blk_bitpat", "blk_rscrtab", "blk_pb2c"))
+        index_build = {"what": "spdp_blk_index_build on the same residues (inputs in host memory; the upload is inside), its tables against "
+                               "those of the reference's file", "identical_tables": bool(same), "genome_nt": int(gcodes.size),
+                       "ktuple": int(bp.ktuple), "blklen": int(bp.blklen), "postings": int(np.asarray(built["blk_blkb"]).size),
+                       "library_s": round(build_s, 3), "library_device_s": round(bsec[0], 3), "library_host_s": round(bsec[1], 3),
+                       "residues_per_s": round(gcodes.size / build_s, 0),
+                       "reference_format_s": round(ref_format_s, 2), "reference_threads": _host_cores(),
+                       "note": "reference = `spaln -W -KD -t<cores>` on the FASTA file: it parses the file and writes the .seq / .idx / "
+                               ".ent files as well as the index; the library starts from residue codes (FASTA -> codes here: "
+                               f"{parse_s:.2f} s of numpy)"}
+        del gcodes, raw, keep
     dix = blocks.BlockIndex(eng, fx)
     out_cap = 768
     dev = torch.device("cuda", local_rank)
@@ -568,7 +609,7 @@ def main_blk(args):
                        "best_pair_covers_planted_locus": f"{hit_any} / {len(sample)} ({hit} with the strand as planted)",
                        "identical_to_oracle_on_sample": f"{same} / {len(chk)}",
                        "words_looked_up_per_query": round(float(tw), 1),
-                       "input_generation_s": round(input_s, 1),
+                       "input_generation_s": round(input_s, 1), "index_build": index_build,
                        "reference_parity": "the vote's state at every TestOutput call and the block pairs handed to FindHsp: bit-identical to the "
                                            "compiled reference's recorded runs (tests/golden/blk_*.spdg: tests/test_gpu_blk.py); FindHsp itself "
                                            "(Wilip on the candidate region) stays with the caller"},
@@ -728,7 +769,7 @@ def _run_leg(name):
            "profile_stale": (rf.get("valu") or {}).get("profile_stale"),
            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None,
            "reference_parity": c.get("reference_parity"), "wall_s": round(time.perf_counter() - t0, 1)}
-    for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems"):
+    for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems", "index_build"):
         if c.get(k) is not None:
             out[k] = c[k]
     return out

@@ -407,8 +407,7 @@ def main_blk(args):
     from spaln_amd import blocks, engine, synth
     from tests import spdg
     ref = os.path.join(ROOT, "oracle", "_ref")
-    if not os.path.exists(os.path.join(ref, "spaln")):
-        raise SystemExit("--workload blk needs the reference's formatter (oracle/_ref/spaln -W) to make its input index")
+    have_ref = os.path.exists(os.path.join(ref, "spaln")) and not os.environ.get("SPDP_BENCH_NO_REF")   # without it the index is the library's own (spdp_blk_index_build)
     n_q = args.queries
     rng = np.random.default_rng(synth.SEED + 4400 + rank)
     t_in = time.perf_counter()
@@ -437,15 +436,19 @@ def main_blk(args):
             f.write(s[chr_len // 60 * 60:].tobytes() + b"\n")
     env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "LD_PRELOAD", "ROCTRACER", "ROCTX"))}
     env.update(ALN_TAB=REF_TAB, ALN_DBS=td)
-    t_fmt = time.perf_counter()
-    subprocess.run([os.path.join(ref, "spaln"), "-W", "-KD", f"-t{_host_cores()}", "gnm.mfa"], cwd=td, env=env, check=True, capture_output=True)
-    ref_format_s = time.perf_counter() - t_fmt
+    ref_format_s = None
+    if have_ref:
+        t_fmt = time.perf_counter()
+        subprocess.run([os.path.join(ref, "spaln"), "-W", "-KD", f"-t{_host_cores()}", "gnm.mfa"], cwd=td, env=env, check=True, capture_output=True)
+        ref_format_s = time.perf_counter() - t_fmt
     # the library reads the reference's index file itself (spdp_blk_index_read); ExtBlock = max_intron_len(0.996) / blklen + 1
     # with the reference's default intron length distribution (12 288 <= that quantile < 14 336: its own run on the
     # fixtures' 2048-nt blocks gives ExtBlock = 7)
     import ctypes as C
-    fx = blocks.read_index_file(C.CDLL(engine.LIB_PATH), os.path.join(td, "gnm.bkn"), max_intron_len=13000)
-    fx["blk_convtab"][:2] = 255
+    fx = None
+    if have_ref:
+        fx = blocks.read_index_file(C.CDLL(engine.LIB_PATH), os.path.join(td, "gnm.bkn"), max_intron_len=13000)
+        fx["blk_convtab"][:2] = 255
     fx_path = os.path.join(td, "index.spdg")
     # the ESTs: 500-nt fragments of the planted transcripts, 1 % substitutions, every other one reverse-complemented
     code_of = np.zeros(256, dtype=np.uint8)
@@ -474,7 +477,7 @@ def main_blk(args):
     # the index builder (fourth slice): the same genome's index made by the library on the device, compared with
     # the tables of the reference's file and timed beside the reference's formatter (which also writes the sequence files)
     index_build = None
-    if rank == 0:
+    if rank == 0 or not have_ref:
         t_b = time.perf_counter()
         with open(os.path.join(td, "gnm.mfa"), "rb") as f:
             raw = np.frombuffer(f.read(), dtype=np.uint8)
@@ -498,18 +501,20 @@ def main_blk(args):
         t_b = time.perf_counter()
         built, bsec = blocks.build_index(eng, gcodes, goff, bp, max_intron_len=13000)
         build_s = time.perf_counter() - t_b
-        same = all(np.array_equal(np.asarray(built[k]).astype(np.int64), np.asarray(fx[k]).astype(np.int64))
-                   for k in ("blk_nblk", "blk_wscr", "blk_blkp", "blk_blkb", "blk_chr", "blk_bitpat", "blk_rscrtab", "blk_pb2c"))
+        same = None if fx is None else all(np.array_equal(np.asarray(built[k]).astype(np.int64), np.asarray(fx[k]).astype(np.int64))
+                                           for k in ("blk_nblk", "blk_wscr", "blk_blkp", "blk_blkb", "blk_chr", "blk_bitpat", "blk_rscrtab", "blk_pb2c"))
+        if fx is None:
+            fx = built
         index_build = {"what": "spdp_blk_index_build on the same residues (inputs in host memory; the upload is inside), its tables against "
-                               "those of the reference's file", "identical_tables": bool(same), "genome_nt": int(gcodes.size),
+                               "those of the reference's file", "identical_tables": same if same is None else bool(same), "genome_nt": int(gcodes.size),
                        "ktuple": int(bp.ktuple), "blklen": int(bp.blklen), "postings": int(np.asarray(built["blk_blkb"]).size),
                        "library_s": round(build_s, 3), "library_device_s": round(bsec[0], 3), "library_host_s": round(bsec[1], 3),
                        "residues_per_s": round(gcodes.size / build_s, 0),
-                       "reference_format_s": round(ref_format_s, 2), "reference_threads": _host_cores(),
+                       "reference_format_s": None if ref_format_s is None else round(ref_format_s, 2), "reference_threads": _host_cores(),
                        "note": "reference = `spaln -W -KD -t<cores>` on the FASTA file: it parses the file and writes the .seq / .idx / "
                                ".ent files as well as the index; the library starts from residue codes (FASTA -> codes here: "
                                f"{parse_s:.2f} s of numpy)"}
-        del gcodes, raw, keep
+        del raw, keep
     dix = blocks.BlockIndex(eng, fx)
     out_cap = 768
     dev = torch.device("cuda", local_rank)
@@ -540,6 +545,32 @@ def main_blk(args):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    find_leg = None
+    if rank == 0 and index_build is not None:
+        # the rest of findblock for every EST: spdp_blk_find = the vote call after call + TestOutput / FindHsp with the library's own
+        # HSP search on the host threads -> candidate loci with their HSPs (what the aligner is given)
+        from spaln_amd import abi as _abi
+        fqx = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
+        fbx = spdg.load(os.path.join(ROOT, "tests", "golden", "blk_k1.spdg"))
+        wmodel = _abi.wilip_model_from_fixture(fqx)
+        scx = spdg.scoring(fqx, intpen=np.ascontiguousarray(fbx["find_intpen"], dtype=np.int16), scalar_engines=1)
+        fprm = blocks.find_params_from_fixture(fbx)
+        fprm.phase1t = int(dix.desc.rbscons)
+        nf = min(n_q, 50000)
+        t_f = time.perf_counter()
+        loci, status = blocks.find(dix, gcodes, goff, wmodel, scx, fprm, [codes[i] for i in range(nf)])
+        find_s = time.perf_counter() - t_f
+        ok = with_locus = n_loc = 0
+        for i in range(nf):
+            if loci[i]:
+                with_locus += 1
+                n_loc += len(loci[i])
+                L = loci[i][0]
+                ok += (L["chr"] == truth[i, 0] and L["base"] <= truth[i, 1] + 60000 and truth[i, 1] <= L["base"] + L["len"] and L["rvs"] == int(rc[i]))
+        find_leg = {"what": "spdp_blk_find: the vote call after call on the device, TestOutput / FindHsp with the library's own HSP search on "
+                            "the host threads in between -> candidate loci with their HSPs; marshalling the result into Python lists inside",
+                    "queries": nf, "with_a_locus": with_locus, "loci": n_loc, "first_locus_covers_the_planted_gene_on_its_strand": int(ok),
+                    "seconds": round(find_s, 2), "queries_per_s": round(nf / find_s, 0)}
     if rank == 0:
         rec = d_out.cpu().numpy()
         reached = (rec[:, 2] & blocks.REACHED) != 0
@@ -598,8 +629,9 @@ def main_blk(args):
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 / int32", "data": "synthetic",
             "config": {"workload": f"block search, first slice of SURVEY 8 f4: {n_q} ESTs of {frag} nt (1 % substitutions, half of them "
-                                   f"reverse strand) vs the index of a synthetic {n_chr * chr_len // 1000000} Mb genome ({n_genes} planted loci); "
-                                   "index file made by the compiled reference's own formatter (spaln -W -KD), an input, read by spdp_blk_index_read; one step = "
+                                   f"reverse strand) vs the index of a synthetic {n_chr * chr_len // 1000000} Mb genome ({n_genes} planted loci); " +
+                                   ("index file made by the compiled reference's own formatter (spaln -W -KD), an input, read by spdp_blk_index_read; " if have_ref else
+                                    "index built by the library (spdp_blk_index_build; oracle/_ref absent); ") + "one step = "
                                    "spdp_blk_vote over all ESTs, queries and records resident in HBM",
                        "queries_per_gpu": n_q, "queries_per_s": round(n_q * world * args.steps / dt, 1),
                        "cells_per_gpu_per_step": 0,
@@ -609,7 +641,7 @@ def main_blk(args):
                        "best_pair_covers_planted_locus": f"{hit_any} / {len(sample)} ({hit} with the strand as planted)",
                        "identical_to_oracle_on_sample": f"{same} / {len(chk)}",
                        "words_looked_up_per_query": round(float(tw), 1),
-                       "input_generation_s": round(input_s, 1), "index_build": index_build,
+                       "input_generation_s": round(input_s, 1), "index_build": index_build, "find": find_leg,
                        "reference_parity": "the vote's state at every TestOutput call and the block pairs handed to FindHsp: bit-identical to the "
                                            "compiled reference's recorded runs (tests/golden/blk_*.spdg: tests/test_gpu_blk.py); FindHsp itself "
                                            "(Wilip on the candidate region) stays with the caller"},
@@ -769,7 +801,7 @@ def _run_leg(name):
            "profile_stale": (rf.get("valu") or {}).get("profile_stale"),
            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None,
            "reference_parity": c.get("reference_parity"), "wall_s": round(time.perf_counter() - t0, 1)}
-    for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems", "index_build"):
+    for k in ("udh_gcups", "fwd_gcups", "sweep_gcups", "fwd_problems", "index_build", "find"):
         if c.get(k) is not None:
             out[k] = c[k]
     return out

@@ -10,7 +10,7 @@
 // this kernel keeps (no reassociation, no fma: the file is built with -ffp-contract=off), so that the truncated
 // shorts are the reference's bit for bit.
 //
-// Mapping: one thread per position, 256 positions per block; the two matrices (2 x 84 x 24 floats = 16 KiB) and the
+// Mapping: one thread per position, 16 chunks of 256 positions per block; the two matrices (2 x 84 x 24 floats = 16 KiB) and the
 // block's window of reduced codes (256 + halo) live in LDS.  Per position 2 x (cols + 2) dependent LDS reads and
 // float adds: HBM traffic is the 1 B/position read and the 8 (+2) B/position column records written -- the records
 // the sweeps read (spdp_dev.h `cols`, `aux`), so a batch uploaded as plain codes never carries its signals over PCIe.
@@ -19,6 +19,7 @@
 #include "spdp_internal.h"
 
 #define SIG_TPB   256
+#define SIG_CHUNKS 16           // 256-position chunks a block walks through with one copy of the matrices
 #define SIG_HALO  64            // >= max(offset, cols - offset) + 2 of either matrix (checked by the launcher)
 
 __device__ __forceinline__ int red_strict(int code)      // ncredctab: A C G T = 2 3 5 9 -> 0..3, everything else "bad"
@@ -61,13 +62,19 @@ void spdp_signals(SignalArgs A)
     __shared__ uint8_t s_x[SIG_TPB + 2 * SIG_HALO];      // codes of bases p0 - HALO .. p0 + TPB + HALO
 
     const SigJob J = A.jobs[blockIdx.y];
-    const int p0 = blockIdx.x * SIG_TPB;
-    if (p0 > J.b_len) return;
+    if ((int) blockIdx.x * SIG_TPB * SIG_CHUNKS > J.b_len) return;
     const SigModelDev& M = *A.model;
     const int n5 = M.rows * M.cols5, n3 = M.rows * M.cols3;
+    // the matrices (16 KB) once per block, for SIG_CHUNKS x 256 positions (one chunk per block made the kernel a copy of
+    // matrices: 64 B of L2 -> LDS traffic per position)
     for (int i = threadIdx.x; i < n5; i += SIG_TPB) s_mtx[i] = A.mtx5[i];
     for (int i = threadIdx.x; i < n3; i += SIG_TPB) s_mtx[n5 + i] = A.mtx3[i];
     const uint8_t* __restrict__ codes = A.codes + J.b_off;
+    int m5 = INT32_MIN, m3 = INT32_MIN;
+  for (int chunk = 0; chunk < SIG_CHUNKS; ++chunk) {
+    const int p0 = ((int) blockIdx.x * SIG_CHUNKS + chunk) * SIG_TPB;
+    if (p0 > J.b_len) break;                                 // (block-uniform)
+    __syncthreads();                                         // the previous chunk's readers are done with s_x
     for (int i = threadIdx.x; i < SIG_TPB + 2 * SIG_HALO; i += SIG_TPB) {
         const int g = p0 - SIG_HALO + i;
         s_x[i] = (g >= 0 && g < J.b_len) ? codes[g] : 0;
@@ -116,8 +123,9 @@ void spdp_signals(SignalArgs A)
     } else {
         v5 = v3 = INT32_MIN;
     }
+    m5 = max(m5, v5); m3 = max(m3, v3);
+  }
     if (A.maxes) {                                               // bounds for the fp32 sweeps' range guard
-        int m5 = v5, m3 = v3;
         for (int o = 32; o; o >>= 1) { m5 = max(m5, __shfl_xor(m5, o)); m3 = max(m3, __shfl_xor(m3, o)); }
         if ((threadIdx.x & 63) == 0) { atomicMax(A.maxes, m5); atomicMax(A.maxes + 1, m3); }
     }
@@ -126,7 +134,7 @@ void spdp_signals(SignalArgs A)
 extern "C" hipError_t spdp_launch_signals(const SignalArgs* a, int n_jobs, int max_len, int lds_floats, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
-    dim3 grid((unsigned) ((max_len + 1 + SIG_TPB - 1) / SIG_TPB), (unsigned) n_jobs);
+    dim3 grid((unsigned) ((max_len + 1 + SIG_TPB * SIG_CHUNKS - 1) / (SIG_TPB * SIG_CHUNKS)), (unsigned) n_jobs);
     hipLaunchKernelGGL(spdp_signals, grid, dim3(SIG_TPB), (size_t) lds_floats * sizeof(float), s, *a);
     return hipGetLastError();
 }

@@ -757,6 +757,9 @@ LEGS = {
                "HSP search on the host) -> candidate loci -> their regions and splice signals (one launch) -> spdp_align_s_seeded with "
                "the library's own Wilip -> spdp_skl_rng_s -> the best locus' exon table in chromosome coordinates, compared with, and "
                "timed against, `spaln -Q7 -S1 -O4 -t16` of the compiled reference on the same 20 000 queries"),
+    "e2e_q7_s3": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200", "--ori", "3"],
+                  "the same in spaln's default orientation mode (a->inex.ori = 3: every locus aligned in both orientations, alignS_ng(.., 3)); "
+                  "every other query is an antisense read; against `spaln -Q7 -O4 -t16`"),
     "dropin_q7_20k": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16"],
                       "the same at 20 000 queries under -Q7 (the reference's normal mode): the size at which the device batches are large enough to matter"),
 }

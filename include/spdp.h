@@ -894,10 +894,16 @@ int spdp_blk_index_write(const SpdpBlkIndexHost* h, const char* path);
  * rescoring follows (spdp_skl_rng_s), and of a query's loci the one with the highest Gsinfo::fstat.val stays (the first one
  * on ties).  Its exons come back in the coordinates the reference prints (-O4: query positions 1-based inclusive, chromosome
  * positions 1-based on the forward strand, left > right on the reverse strand: Seq::SiteNo, src/seq.h).
- * One call = spdp_blk_find + one batched signal launch + one seeded call + one rescoring call per chunk of loci. */
+ * One call = spdp_blk_find + one batched signal launch + one seeded call + one rescoring call per chunk of loci.
+ * ori = a->inex.ori as spaln_job sets it (src/spaln.cc:1153-1156): 1 = the query as given (-S1), 3 = both orientations (the
+ * default for a cDNA without a poly-A tail: alignS_ng(.., 3) -- the walk on the pair as given and on the reverse-complemented
+ * query against the other strand of the locus, both with Exinon::both_ori signals; the reverse one stays only if it scores
+ * strictly higher). */
 typedef struct SpdpMapExon { int32_t q_left, q_right, g_left, g_right; } SpdpMapExon;
 typedef struct SpdpMapGene {
-    int32_t chr, rvs;                /* -1 / 0 when the query has no alignment                                             */
+    int32_t chr, rvs;                /* -1 / 0 when the query has no alignment; rvs: the strand the gene lies on              */
+    int32_t q_rev;                   /* ori = 3 only: the reverse-complemented query gave the alignment (its exons then carry
+                                        descending query positions, as the reference prints them)                            */
     int32_t score, val;              /* skl_rngS_ng's return value, Gsinfo::fstat.val of the locus that stayed             */
     int32_t n_loci;                  /* candidate loci of the query that were aligned                                      */
     int32_t n_exons;
@@ -908,7 +914,7 @@ typedef struct SpdpMapGene {
 int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
                      const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
                      const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
-                     const uint8_t* codes, const int64_t* offs, int32_t n,
+                     const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
                      SpdpMapGene* genes, SpdpMapExon** exons, double* seconds);
 
 /* ---- device groups, continued ------------------------------------------------------------------------------------------ */

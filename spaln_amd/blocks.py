@@ -288,11 +288,11 @@ class MapExon(C.Structure):
 
 
 class MapGene(C.Structure):
-    _fields_ = [("chr", C.c_int32), ("rvs", C.c_int32), ("score", C.c_int32), ("val", C.c_int32), ("n_loci", C.c_int32),
+    _fields_ = [("chr", C.c_int32), ("rvs", C.c_int32), ("q_rev", C.c_int32), ("score", C.c_int32), ("val", C.c_int32), ("n_loci", C.c_int32),
                 ("n_exons", C.c_int32), ("exon_off", C.c_int64)]
 
 
-def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm: BlkFindParams, rescore, queries):
+def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm: BlkFindParams, rescore, queries, ori: int = 1):
     """spdp_map_align_s: block search -> loci -> signals -> seeded alignment -> rescoring, one call for all queries.
     rescore = (codonk1, minl, jneibr, lsg).  Returns (per query None or dict(chr, rvs, score, val, n_loci,
     exons = [(q_left, q_right, g_left, g_right)]), seconds [find, regions + signals, align, rescore], return code)."""
@@ -311,9 +311,9 @@ def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm:
     exons = C.POINTER(MapExon)()
     sec = (C.c_double * 4)()
     lib.spdp_map_align_s.restype = C.c_int
-    lib.spdp_map_align_s.argtypes = [C.c_void_p] * 11 + [C.c_int32] + [C.c_void_p] * 3
+    lib.spdp_map_align_s.argtypes = [C.c_void_p] * 11 + [C.c_int32, C.c_int32] + [C.c_void_p] * 3
     rc = lib.spdp_map_align_s(eng.ctx, index.h, C.byref(index.desc), C.byref(g), C.byref(sc), C.byref(sp), C.addressof(sigmodel),
-                              C.byref(prm), C.byref(rp), codes.ctypes.data, offs.ctypes.data, n, genes, C.byref(exons), sec)
+                              C.byref(prm), C.byref(rp), codes.ctypes.data, offs.ctypes.data, n, int(ori), genes, C.byref(exons), sec)
     if rc < 0:
         eng._check(rc, "spdp_map_align_s")
     out = []
@@ -324,7 +324,7 @@ def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm:
             continue
         ex = [(exons[G.exon_off + j].q_left, exons[G.exon_off + j].q_right, exons[G.exon_off + j].g_left, exons[G.exon_off + j].g_right)
               for j in range(G.n_exons)]
-        out.append(dict(chr=G.chr, rvs=G.rvs, score=G.score, val=G.val, n_loci=G.n_loci, exons=ex))
+        out.append(dict(chr=G.chr, rvs=G.rvs, q_rev=G.q_rev, score=G.score, val=G.val, n_loci=G.n_loci, exons=ex))
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
     libc.free(exons)

@@ -49,17 +49,18 @@ template <class F> void on_host_threads(int n, F f)
 extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
                                 const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
                                 const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
-                                const uint8_t* codes, const int64_t* offs, int32_t n,
+                                const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
                                 SpdpMapGene* genes, SpdpMapExon** exons, double* seconds)
 {
     if (!ctx) return -1;
     if (!ix || !hix || !genome || !sc || !sp || !sigmodel || !fprm || !rp || !codes || !offs || !genes || !exons) {
         ctx->err = "spdp_map_align_s: null argument"; return -1;
     }
+    if (ori != 1 && ori != 3) { ctx->err = "spdp_map_align_s: ori must be 1 (the query as given) or 3 (both orientations)"; return -1; }
     if (!sp->wilip) { ctx->err = "spdp_map_align_s: SpdpSeedParams.wilip missing (the HSP searches of this call are the library's own)"; return -1; }
     *exons = nullptr;
     double sec[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) { genes[i].chr = -1; genes[i].rvs = 0; genes[i].score = SPDP_NEVSEL; genes[i].val = 0; genes[i].n_loci = 0; genes[i].n_exons = 0; genes[i].exon_off = 0; }
+    for (int i = 0; i < n; ++i) { genes[i].chr = -1; genes[i].rvs = 0; genes[i].q_rev = 0; genes[i].score = SPDP_NEVSEL; genes[i].val = 0; genes[i].n_loci = 0; genes[i].n_exons = 0; genes[i].exon_off = 0; }
     if (n <= 0) return 0;
     auto t0 = std::chrono::steady_clock::now();
     std::vector<int32_t> ql(n, 0), qr(n);
@@ -69,6 +70,18 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
     struct Owned { SpdpLocus* l; SpdpJuxt* h; ~Owned() { free(l); free(h); } } owned{loci, hsps};
     sec[0] = since(t0);
 
+    const bool both = ori == 3;
+    std::vector<uint8_t> codes_rc;                      // comrev() of every query (ori = 3)
+    if (both) {
+        codes_rc.resize((size_t) offs[n]);
+        on_host_threads(n, [&](int q) {
+            const int64_t a0 = offs[q], len = offs[q + 1] - offs[q];
+            for (int64_t i = 0; i < len; ++i) codes_rc[a0 + i] = other_strand(codes[a0 + len - 1 - i]);
+        });
+    }
+    SpdpSignalModel sigm = *sigmodel;
+    SpdpSeedParams spx = *sp;
+    if (both) sigm.both_ori = spx.both_ori = 1;         // Exinon(seq, pwd, ori == 3), src/spaln.cc:1143, 1150
     size_t chunk_positions = (size_t) 2048 << 20;       // signal arrays of a chunk: 7 B per position on both sides of the bus
     if (const char* e = getenv("SPDP_MAP_CHUNK_MB")) chunk_positions = (size_t) std::max(1, atoi(e)) << 20;
     std::vector<std::vector<SpdpMapExon>> kept(n);
@@ -77,7 +90,7 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
     // chunks of loci: as few as the position limit allows, of equal size (a call's time is a chain of request latencies, not
     // device work: DESIGN.md 6g -- so the larger a chunk the better, and a short last chunk costs as much as a full one)
     int64_t all_positions = 0;
-    for (int k = 0; k < n_loci; ++k) all_positions += loci[k].len + 1;
+    for (int k = 0; k < n_loci; ++k) all_positions += (both ? 2 : 1) * (int64_t) (loci[k].len + 1);
     const int64_t n_chunks = std::max<int64_t>(1, (all_positions + (int64_t) chunk_positions - 1) / (int64_t) chunk_positions);
     const int64_t per_chunk = (all_positions + n_chunks - 1) / n_chunks;
     for (int c0 = 0; c0 < n_loci; ) {
@@ -85,8 +98,14 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
         std::vector<int64_t> at;                        // first position of locus c0 + k in the chunk's arrays (len + 1 positions each)
         int64_t tot = 0;
         int c1 = c0;
-        while (c1 < n_loci && (c1 == c0 || tot + loci[c1].len + 1 <= per_chunk + (1 << 16))) { at.push_back(tot); tot += loci[c1].len + 1; ++c1; }
+        while (c1 < n_loci && (c1 == c0 || tot + (both ? 2 : 1) * (int64_t) (loci[c1].len + 1) <= per_chunk + (1 << 17))) {
+            at.push_back(tot); tot += (both ? 2 : 1) * (int64_t) (loci[c1].len + 1); ++c1;
+        }
         const int m = c1 - c0;
+        const int ns = both ? 2 * m : m;                // slots of the chunk's arrays: locus k as the block search gave it, then (ori = 3)
+        if (both) { at.resize(ns); for (int k = 0; k < m; ++k) at[m + k] = at[k] + loci[c0 + k].len + 1; }      // its other strand right behind it
+        auto slot_left = [&](int j) { const SpdpLocus& L = loci[c0 + (j < m ? j : j - m)]; return j < m ? L.left : L.len - L.right; };
+        auto slot_right = [&](int j) { const SpdpLocus& L = loci[c0 + (j < m ? j : j - m)]; return j < m ? L.right : L.len - L.left; };
         for (int k = 0; k < m; ++k) {
             const SpdpLocus& L = loci[c0 + k];
             if (L.chr < 0 || L.chr >= genome->n_chr || L.base < 0 || L.len < 0 || L.left < 0 || L.right > L.len || L.right < L.left ||
@@ -99,12 +118,12 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
         if (!H) { ctx->err = "spdp_map_align_s: no pinned host memory for a chunk's regions and signals (SPDP_MAP_CHUNK_MB sets the chunk size)"; return -1; }
         uint8_t* reg = H; int16_t* sig5 = (int16_t*) (H + T); int16_t* sig3 = (int16_t*) (H + 3 * T);
         uint8_t* cano5 = H + 5 * T; uint8_t* cano3 = H + 6 * T; uint8_t* dinc = H + 7 * T;
-        on_host_threads(m, [&](int k) {
-            const SpdpLocus& L = loci[c0 + k];
+        on_host_threads(ns, [&](int j) {
+            const SpdpLocus& L = loci[c0 + (j < m ? j : j - m)];
             const uint8_t* src = genome->codes + genome->chr_off[L.chr] + L.base;
-            uint8_t* dst = reg + at[k];
-            if (!L.rvs) memcpy(dst, src, (size_t) L.len);
-            else for (int i = 0; i < L.len; ++i) dst[i] = other_strand(src[L.len - 1 - i]);
+            uint8_t* dst = reg + at[j];
+            if ((L.rvs != 0) == (j < m)) for (int i = 0; i < L.len; ++i) dst[i] = other_strand(src[L.len - 1 - i]);
+            else memcpy(dst, src, (size_t) L.len);
             dst[L.len] = 0;
         });
         const double t_regions = since(t0);
@@ -113,42 +132,46 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
             HIPCHK(d.get((size_t) T * 8));
             uint8_t* D = d.as<uint8_t>();
             HIPCHK(hipMemcpyAsync(D, reg, tot, hipMemcpyHostToDevice, ctx->stream));
-            std::vector<SigJob> jobs(m);
-            for (int k = 0; k < m; ++k) {
-                SigJob& J = jobs[k];
+            std::vector<SigJob> jobs(ns);
+            for (int j = 0; j < ns; ++j) {
+                SigJob& J = jobs[j];
                 memset(&J, 0, sizeof J);
-                J.b_off = at[k]; J.out_off = at[k]; J.b_len = loci[c0 + k].len; J.left = loci[c0 + k].left; J.right = loci[c0 + k].right;
+                J.b_off = at[j]; J.out_off = at[j]; J.b_len = loci[c0 + (j < m ? j : j - m)].len; J.left = slot_left(j); J.right = slot_right(j);
             }
             SignalArgs A;
             memset(&A, 0, sizeof A);
             A.codes = D;
             A.sig5 = (int16_t*) (D + T); A.sig3 = (int16_t*) (D + 3 * T);
             A.cano5 = D + 5 * T; A.cano3 = D + 6 * T; A.dinc = D + 7 * T;
-            if (spdp_signals_run(ctx, sigmodel, jobs, A, nullptr, nullptr)) return -1;
+            if (spdp_signals_run(ctx, &sigm, jobs, A, nullptr, nullptr)) return -1;
             HIPCHK(hipMemcpy(H + T, D + T, (size_t) T * 7, hipMemcpyDeviceToHost));
         }
         if (getenv("SPDP_MAP_VERBOSE")) fprintf(stderr, "[map] regions cut %.3f s, signals made and brought back %.3f s\n", t_regions, since(t0) - t_regions);
-        std::vector<SpdpProblem> probs(m);
+        std::vector<SpdpProblem> probs(ns);
         std::vector<const SpdpJuxt*> hl(m);
         std::vector<int32_t> hn(m), low(m, 0);
-        for (int k = 0; k < m; ++k) {
+        for (int j = 0; j < ns; ++j) {
+            const int k = j < m ? j : j - m;
             const SpdpLocus& L = loci[c0 + k];
-            SpdpProblem& P = probs[k];
+            SpdpProblem& P = probs[j];
             memset(&P, 0, sizeof P);
-            P.a = codes + offs[L.query]; P.a_len = (int32_t) (offs[L.query + 1] - offs[L.query]);
-            P.b = reg + at[k]; P.b_len = L.len;
-            P.sig5 = sig5 + at[k]; P.sig3 = sig3 + at[k];
-            P.cano5 = cano5 + at[k]; P.cano3 = cano3 + at[k]; P.dinc = dinc + at[k];
-            P.a_left = 0; P.a_right = P.a_len; P.b_left = L.left; P.b_right = L.right;
+            P.a = (j < m ? codes : codes_rc.data()) + offs[L.query]; P.a_len = (int32_t) (offs[L.query + 1] - offs[L.query]);
+            P.b = reg + at[j]; P.b_len = L.len;
+            P.sig5 = sig5 + at[j]; P.sig3 = sig3 + at[j];
+            P.cano5 = cano5 + at[j]; P.cano3 = cano3 + at[j]; P.dinc = dinc + at[j];
+            P.a_left = 0; P.a_right = P.a_len; P.b_left = slot_left(j); P.b_right = slot_right(j);
             P.a_exgl = P.a_exgr = P.b_exgl = P.b_exgr = 1;
-            hl[k] = hsps + L.hsp_off; hn[k] = L.n_hsp;
+            if (j < m) { hl[k] = hsps + L.hsp_off; hn[k] = L.n_hsp; }
         }
         sec[1] += since(t0);
         // ---- the aligner on every locus, then the printer's scores
         t0 = std::chrono::steady_clock::now();
         std::vector<SpdpAlignment> aln(m);
-        const int rc = spdp_align_s_seeded(ctx, sc, sp, probs.data(), m, hl.data(), hn.data(), low.data(), nullptr, aln.data());
+        std::vector<int32_t> orient(m, 0);
+        const int rc = both ? spdp_align_s_seeded_ori3(ctx, sc, &spx, probs.data(), probs.data() + m, m, hl.data(), hn.data(), low.data(), nullptr, aln.data(), orient.data())
+                            : spdp_align_s_seeded(ctx, sc, &spx, probs.data(), m, hl.data(), hn.data(), low.data(), nullptr, aln.data());
         if (rc < 0) return -1;
+        if (both) for (int k = 0; k < m; ++k) if (orient[k]) probs[k] = probs[m + k];        // rescoring reads the pair that was aligned
         if (rc > 0) ++partial;
         sec[2] += since(t0);
         if (getenv("SPDP_MAP_VERBOSE")) {
@@ -168,14 +191,17 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
             SpdpMapGene& G = genes[L.query];
             ++G.n_loci;
             if (G.chr >= 0 && G.val >= res[k].val) continue;
-            G.chr = L.chr; G.rvs = L.rvs; G.score = res[k].score; G.val = res[k].val;
+            const int rvs = orient[k] ? !L.rvs : (L.rvs != 0);                                    // the strand the aligned region lies on
+            const int a_len = probs[k].a_len;
+            G.chr = L.chr; G.rvs = rvs; G.q_rev = orient[k]; G.score = res[k].score; G.val = res[k].val;
             std::vector<SpdpMapExon>& ex = kept[L.query];
             ex.clear();
-            auto site = [&L](int pos) { return L.base + (L.rvs ? L.len - pos : pos + 1); };       // Seq::SiteNo
+            auto site = [&L, rvs](int pos) { return L.base + (rvs ? L.len - pos : pos + 1); };      // Seq::SiteNo
             for (int e = 0; e < res[k].n_exons; ++e) {
                 const SpdpExon& x = res[k].exons[e];
                 if (x.left > (1 << 30)) continue;                                                 // (the closing record of the list)
-                ex.push_back({x.rleft + 1, x.rright, site(x.left), site(x.right - 1)});
+                if (orient[k]) ex.push_back({a_len - x.rleft, a_len - x.rright + 1, site(x.left), site(x.right - 1)});     // positions of the query as given
+                else ex.push_back({x.rleft + 1, x.rright, site(x.left), site(x.right - 1)});
             }
         }
         spdp_free_rescored(res.data(), m);

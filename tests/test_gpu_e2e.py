@@ -21,15 +21,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_exon_tables_equal_the_reference_program():
+@pytest.mark.parametrize("ori", [1, 3])
+def test_exon_tables_equal_the_reference_program(ori):
+    """ori = 1: the queries as given, `spaln -Q7 -S1`; ori = 3: every other query reverse-complemented, both orientations
+    tried (alignS_ng(.., 3) on every locus), spaln's default"""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln")):
         pytest.skip("oracle/_ref/spaln is not built")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_q7.py"), "--queries", "300", "--genes", "60"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_q7.py"), "--queries", "300", "--genes", "60", "--ori", str(ori)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-400:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["reference_aligned"] == 300 and d["library_aligned"] == 300
     assert d["identical_exon_tables"] == 300, (d, r.stderr[-600:])
+    assert d["query_reversed"] == (150 if ori == 3 else 0)
 
 
 COMP = np.arange(256, dtype=np.uint8)

@@ -84,14 +84,23 @@ def main():
     ap.add_argument("--genes", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--show", type=int, default=3)
+    ap.add_argument("--ori", type=int, default=1, choices=[1, 3],
+                    help="1: the queries as given against `spaln -S1`; 3: every other query reverse-complemented, both orientations "
+                         "tried, against spaln's default (-S3)")
     args = ap.parse_args()
     args.protein = False
     t_all = time.perf_counter()
     with tempfile.TemporaryDirectory(prefix="spdp_e2e_") as td:
         genome_nt, env = dropin_demo.make_dataset(td, args)
+        if args.ori == 3:                                        # antisense reads among the queries
+            lines = open(os.path.join(td, "q.fa")).read().split("\n")
+            comp = str.maketrans("ACGTacgt", "TGCAtgca")
+            for i in range(2, len(lines) - 1, 4):
+                lines[i + 1] = lines[i + 1].translate(comp)[::-1]
+            open(os.path.join(td, "q.fa"), "w").write("\n".join(lines))
         t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(dropin_demo.REF, "spaln"), "-Q7", "-S1", "-O4", f"-t{args.threads}", "-dgnm", "q.fa"], cwd=td, env=env,
-                           capture_output=True, text=True)
+        r = subprocess.run([os.path.join(dropin_demo.REF, "spaln"), "-Q7"] + (["-S1"] if args.ori == 1 else []) + ["-O4", f"-t{args.threads}", "-dgnm", "q.fa"],
+                           cwd=td, env=env, capture_output=True, text=True)
         ref_s = time.perf_counter() - t0
         if r.returncode:
             raise SystemExit("reference run failed: " + r.stderr[-300:])
@@ -126,7 +135,7 @@ def main():
         runs = []
         for _ in range(2):
             t0 = time.perf_counter()
-            genes, phases, rc = blocks.map_align(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries)
+            genes, phases, rc = blocks.map_align(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries, ori=args.ori)
             runs.append((time.perf_counter() - t0, phases))
         lib_s, phases = runs[-1]
         got = {q_names[i]: g["exons"] for i, g in enumerate(genes) if g is not None}
@@ -135,8 +144,8 @@ def main():
         diff = [k for k, v in want.items() if got.get(k) != v]
         for k in diff[:args.show]:
             sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
-        out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 -S1 -O4`",
-               "queries": args.queries, "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
+        out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 %s-O4`" % ("-S1 " if args.ori == 1 else ""),
+               "queries": args.queries, "ori": args.ori, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
                "identical_exon_tables": n_same, "different": len(diff),
                "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
                "reference_queries_per_s": round(len(want) / ref_s, 1),

@@ -934,6 +934,13 @@ int spdp_group_skl_rng_h(SpdpGroup* g, const SpdpScoringH* sc, const SpdpRescore
 SpdpContext* spdp_group_context(SpdpGroup* g, int member);
 int spdp_group_blk_vote(SpdpGroup* g, const SpdpBlkIndex* const* ix, const uint8_t* codes, const int64_t* offs,
                         const int32_t* left, const int32_t* right, const int32_t* stop_at, int32_t n, int32_t* out, int32_t out_cap);
+/* spdp_map_align_s with the queries sharded over the members by length (each member: its own index, block search, signals,
+ * walks and rescoring; nothing is exchanged between members); genes / exons in the caller's query order */
+int spdp_group_map_align_s(SpdpGroup* g, const SpdpBlkIndex* const* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                           const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
+                           const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
+                           const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
+                           SpdpMapGene* genes, SpdpMapExon** exons);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 // from its own host thread, and the results land in the caller's arrays in query order.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -288,6 +289,53 @@ int spdp_group_blk_vote(SpdpGroup* g, const SpdpBlkIndex* const* ix, const uint8
             for (int k = 0; k < cnt; ++k) memcpy(out + (size_t) idx[k] * out_cap, rec.data() + (size_t) k * out_cap, (size_t) out_cap * 4);
         return rc;
     });
+}
+
+int spdp_group_map_align_s(SpdpGroup* g, const SpdpBlkIndex* const* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                           const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
+                           const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
+                           const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
+                           SpdpMapGene* genes, SpdpMapExon** exons)
+{
+    if (!ix || !codes || !offs || !genes || !exons) { if (g) g->err = "spdp_group_map_align_s: null argument"; return -1; }
+    *exons = nullptr;
+    std::vector<int64_t> cost(std::max(n, 0));
+    for (int i = 0; i < n; ++i) cost[i] = 1 + offs[i + 1] - offs[i];
+    const int w = g ? (int) g->ctx.size() : 0;
+    std::vector<std::vector<SpdpMapExon>> part(std::max(w, 1));        // a member's exons, its genes' exon_off relative to them
+    std::vector<std::vector<int>> whose(std::max(w, 1));
+    const int rc = fan_out_idx(g, n, cost, [&](SpdpContext* c, const std::vector<int>& idx) {
+        int member = 0;
+        while (g->ctx[member] != c) ++member;
+        const int cnt = (int) idx.size();
+        std::vector<int64_t> o2(cnt + 1, 0);
+        for (int k = 0; k < cnt; ++k) o2[k + 1] = o2[k] + (offs[idx[k] + 1] - offs[idx[k]]);
+        std::vector<uint8_t> cd((size_t) o2[cnt]);
+        for (int k = 0; k < cnt; ++k) memcpy(cd.data() + o2[k], codes + offs[idx[k]], (size_t) (o2[k + 1] - o2[k]));
+        std::vector<SpdpMapGene> gn(cnt);
+        SpdpMapExon* ex = nullptr;
+        const int r = spdp_map_align_s(c, ix[member], hix, genome, sc, sp, sigmodel, fprm, rp, cd.data(), o2.data(), cnt, ori, gn.data(), &ex, nullptr);
+        if (r >= 0) {
+            size_t ne = 0;
+            for (int k = 0; k < cnt; ++k) { genes[idx[k]] = gn[k]; ne = std::max<size_t>(ne, (size_t) gn[k].exon_off + gn[k].n_exons); }
+            if (ex) part[member].assign(ex, ex + ne);
+            whose[member] = idx;
+        }
+        free(ex);
+        return r;
+    });
+    if (rc < 0) return rc;
+    size_t total = 0;
+    for (int r = 0; r < w; ++r) total += part[r].size();
+    *exons = (SpdpMapExon*) malloc(sizeof(SpdpMapExon) * std::max<size_t>(total, 1));
+    if (!*exons) { g->err = "spdp_group_map_align_s: out of memory"; return -1; }
+    size_t base = 0;
+    for (int r = 0; r < w; ++r) {
+        if (!part[r].empty()) memcpy(*exons + base, part[r].data(), sizeof(SpdpMapExon) * part[r].size());
+        for (int i : whose[r]) genes[i].exon_off += (int64_t) base;
+        base += part[r].size();
+    }
+    return rc;
 }
 
 // which member ran problem i in the last group call (cost-balanced: spdp_cells per problem, longest first)

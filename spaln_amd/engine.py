@@ -31,7 +31,7 @@ EXPORTS = [
     "spdp_group_create", "spdp_group_destroy", "spdp_group_size", "spdp_group_last_error",
     "spdp_group_homscore_s", "spdp_group_align_s", "spdp_group_homscore_h", "spdp_group_align_h",
     "spdp_group_align_s_seeded", "spdp_group_align_h_seeded", "spdp_group_skl_rng_s", "spdp_group_skl_rng_h",
-    "spdp_group_context", "spdp_group_blk_vote",
+    "spdp_group_context", "spdp_group_blk_vote", "spdp_group_map_align_s",
     "spdp_align_s_seeded", "spdp_align_s_seeded_ori3", "spdp_seeded_stats",
     "spdp_blk_index_create", "spdp_blk_index_destroy", "spdp_blk_vote", "spdp_blk_vote_resident",
     "spdp_blk_search_opts_default", "spdp_blk_index_read", "spdp_blk_index_host_desc", "spdp_blk_index_host_free",

@@ -183,3 +183,80 @@ def test_group_block_vote_equals_recorded_runs():
     for i in idx:
         i.free()
     grp.close()
+
+
+def test_group_map_align_equals_one_context():
+    """spdp_group_map_align_s (queries sharded over three members, an index per member) against spdp_map_align_s on one
+    context: the same genes and exon tables in the caller's order, both orientations tried"""
+    import ctypes as C
+    from spaln_amd import abi, blocks, engine
+    from oracle import blk as oblk
+    from tests import spdg
+    from tests.test_blk_find import genome_of
+    fx = spdg.load(os.path.join(ROOT, "tests", "golden", "blk_par.spdg"))
+    fq = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
+    gen, off = genome_of("blk_par", 24, 980, True)
+    queries = [q["codes"][q["left"]:q["right"]] for q in oblk.parse_log(fx)]
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in ((2, 9), (9, 2), (3, 5), (5, 3)):
+        comp[a] = b
+    queries = [comp[q[::-1]] if i % 2 else q for i, q in enumerate(queries)]        # antisense reads among them
+    model = abi.wilip_model_from_fixture(fq)
+    sigmodel = abi.signal_model_from_fixture(fq)
+    prm = blocks.find_params_from_fixture(fx)
+    sc = spdg.scoring(fq, intpen=np.ascontiguousarray(fx["find_intpen"], dtype=np.int16), scalar_engines=1)
+    sp = abi.seed_params_from_fixture(fq)
+    sp.wilip = C.addressof(model)
+    fs = fq["rng_fstat_A0"] if "rng_fstat_A0" in fq else [0, 0, 0, 0, 0, 0, 3, 1]
+    rescore = (fq["prm"]["codonk1"], fq["prm"]["minl"], int(fs[6]), int(fs[7]))
+    eng = engine.Engine(0)
+    dix = blocks.BlockIndex(eng, fx)
+    want, _, rc = blocks.map_align(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries, ori=3)
+    assert rc == 0 and sum(1 for g in want if g is not None) >= 10 and any(g and g["q_rev"] for g in want)
+    dix.free()
+    eng.close()
+
+    grp = engine.Group([0, 0, 0])
+    lib = grp.lib
+    lib.spdp_group_context.restype = C.c_void_p
+    lib.spdp_group_context.argtypes = [C.c_void_p, C.c_int]
+
+    class Member:
+        def __init__(self, ctx):
+            self.lib, self.ctx = lib, ctx
+
+        def _check(self, rc, what):
+            assert rc == 0, what
+    idx = [blocks.BlockIndex(Member(lib.spdp_group_context(grp.h, r)), fx) for r in range(3)]
+    handles = (C.c_void_p * 3)(*[i.h for i in idx])
+    n = len(queries)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    codes = np.ascontiguousarray(np.concatenate(queries))
+    g = blocks.Genome()
+    gc = np.ascontiguousarray(gen, dtype=np.uint8)
+    go = np.ascontiguousarray(off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    rp = abi.RescoreParams(*(int(x) for x in rescore))
+    genes = (blocks.MapGene * n)()
+    exons = C.POINTER(blocks.MapExon)()
+    lib.spdp_group_map_align_s.restype = C.c_int
+    lib.spdp_group_map_align_s.argtypes = [C.c_void_p] * 11 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    rc = lib.spdp_group_map_align_s(grp.h, handles, C.byref(idx[0].desc), C.byref(g), C.byref(sc), C.byref(sp), C.addressof(sigmodel),
+                                    C.byref(prm), C.byref(rp), codes.ctypes.data, offs.ctypes.data, n, 3, genes, C.byref(exons))
+    assert rc == 0, lib.spdp_group_last_error(grp.h)
+    for i in range(n):
+        G = genes[i]
+        if want[i] is None:
+            assert G.chr < 0, i
+            continue
+        ex = [(exons[G.exon_off + j].q_left, exons[G.exon_off + j].q_right, exons[G.exon_off + j].g_left, exons[G.exon_off + j].g_right)
+              for j in range(G.n_exons)]
+        assert (G.chr, G.rvs, G.q_rev, G.score, G.val, G.n_loci, ex) == tuple(want[i][k] for k in ("chr", "rvs", "q_rev", "score", "val", "n_loci", "exons")), i
+    assert len(set(grp.shards(n).tolist())) == 3
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(exons)
+    for i in idx:
+        i.free()
+    grp.close()

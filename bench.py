@@ -760,6 +760,9 @@ LEGS = {
     "e2e_q7_s3": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200", "--ori", "3"],
                   "the same in spaln's default orientation mode (a->inex.ori = 3: every locus aligned in both orientations, alignS_ng(.., 3)); "
                   "every other query is an antisense read; against `spaln -Q7 -O4 -t16`"),
+    "dropin_q7_20k_s3": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16", "--strand=-S3", "--antisense"],
+                         "the reference's CLI on the library in spaln's DEFAULT orientation mode (a->inex.ori = 3: alignS_ng(.., 3) on every locus; every "
+                         "other query an antisense read), 20 000 queries under -Q7, both programs with -t16"),
     "dropin_q7_20k": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16"],
                       "the same at 20 000 queries under -Q7 (the reference's normal mode): the size at which the device batches are large enough to matter"),
 }

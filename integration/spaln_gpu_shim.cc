@@ -13,8 +13,8 @@
 // The worker threads are the producers of a batch: a call parks its pair, and the first thread to find no batch running
 // becomes its leader -- it waits a moment for company, runs ONE library call over everything parked (spdp_align_s, or
 // spdp_align_s_seeded with the reference's own Wilip behind the HSP callback when algmode.qck != 0), hands the results
-// back and wakes the others.  What the library does not take (ori = 2, ori = 3 with seeding: they need the reference's
-// file-local reverse_copy_jxt) goes to alignS_ng_ref and is counted.  SPALN_GPU_BATCH / SPALN_GPU_WAIT_US size a batch;
+// back and wakes the others.  What the library does not take (ori = 2; in this parking form also ori = 3 with seeding: the
+// batching boundary below records both orientations) goes to alignS_ng_ref and is counted.  SPALN_GPU_BATCH / SPALN_GPU_WAIT_US size a batch;
 // the counts are printed to stderr at exit.
 #include "shim_fill.h"
 #include <atomic>
@@ -373,7 +373,15 @@ const	PwdB*	pwd = 0;
 	int16_t	t53[256];		// the junction-pair table as this window shows it (entries of classes it lacks are 0)
 	Gsinfo	gsi;
 	bool	keep = false;
-	~Job() { delete a; if (b) { delete b->exin; b->exin = 0; delete b; } }
+	// ori = 3 (alignS_ng tries both orientations: src/fwd2s1.cc:2742-2777): the reverse-complemented query and the other strand of
+	// the window (genomicseq made it, with an Exinon of its own: src/spaln.cc:1146-1151), marshalled like the pair as given
+	int	ori = 1;
+	Seq*	a2 = 0;
+	Seq*	b2 = 0;
+	SpdpProblem p2;
+	std::vector<int16_t> s5r, s3r;
+	SeedCols cr;
+	~Job() { delete a; delete a2; if (b) { delete b->exin; b->exin = 0; delete b; } if (b2) { delete b2->exin; b2->exin = 0; delete b2; } }
 };
 std::mutex		g_jm;
 std::condition_variable	g_jcv;
@@ -391,7 +399,7 @@ bool batch_mode()
 	return on;
 }
 // the worker's side: one aligner call = one job
-void record_job(Seq* seqs[], const PwdB* pwd, int kind)
+void record_job(Seq* seqs[], const PwdB* pwd, int kind, int ori = 1)
 {
 	static thread_local long	t_group = -1;
 	static thread_local int	t_order = 0;
@@ -437,6 +445,19 @@ void record_job(Seq* seqs[], const PwdB* pwd, int kind)
 	    fill_scoring(sc, pwd, j->b);
 	    fill_exact_s(sc, j->p, j->b, pwd, j->c, false);
 	    memcpy(j->t53, sc.t53, sizeof j->t53);
+	    if (ori == 3) {				// the other orientation: comrev(a) against the anti-strand Seq genomicseq left beside b
+		Seq*	anti = *b->getanti();
+		j->ori = 3;
+		j->a2 = a->copyseq(0, CPY_ALL);
+		j->a2->comrev();
+		j->b2 = anti->copyseq(0, CPY_ALL);
+		j->b2->exin = anti->exin; anti->exin = 0;
+		fill_problem(j->p2, j->a2, j->b2, j->s5r, j->s3r);
+		SpdpScoring sc2;
+		fill_scoring(sc2, pwd, j->b2);
+		fill_exact_s(sc2, j->p2, j->b2, pwd, j->cr, false);
+		for (int i = 0; i < 256; ++i) if (!j->t53[i]) j->t53[i] = sc2.t53[i];
+	    }
 	}
 	if (kind == 1 || kind == 4)
 	    for (int k = 0; j->b->jxt && k <= j->b->CdsNo; ++k) {		// CdsNo HSPs + the free slot behind them
@@ -457,8 +478,10 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	    return skl;
 	}
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] alignS_ng ori %d qck %d\n", ori, (int) algmode.qck);
-	if (batch_mode() && ori == 1 && algmode.mlt != 1) {	// recorded now, aligned with everybody else's once the workers have joined
-	    record_job(seqs, pwd, algmode.qck? 1: 0);
+	// recorded now, aligned with everybody else's once the workers have joined: the pair as given, or (ori = 3, the default for a
+	// cDNA without a poly-A tail) both orientations -- with seeding on only when the HSP searches are the library's own
+	if (batch_mode() && algmode.mlt != 1 && (ori == 1 || (ori == 3 && seqs[1]->getanti() && (!algmode.qck || own_wilip())))) {
+	    record_job(seqs, pwd, algmode.qck? 1: 0, ori);
 	    ++g_calls[algmode.qck? 1: 0];
 	    return 0;					// "no alignment": blkaln goes on to the next locus / query (src/spaln.cc:907-912)
 	}
@@ -524,9 +547,10 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	    std::stable_sort(jobs.begin(), jobs.end(), [](const Job* x, const Job* y) { return x->group != y->group? x->group < y->group: x->order < y->order; });
 const	    int	n = (int) jobs.size();
 	    // ---- one call per kind over everything recorded
-	    for (int kind = 0; kind < 2; ++kind) {
+	    for (int ko = 0; ko < 4; ++ko) {
+const		int kind = ko & 1, ori = ko & 2? 3: 1;
 		std::vector<Job*> part;
-		for (Job* j : jobs) if (j->kind == kind) part.push_back(j);
+		for (Job* j : jobs) if (j->kind == kind && j->ori == ori) part.push_back(j);
 		if (part.empty()) continue;
 const		int m = (int) part.size();
 		SpdpScoring sc;
@@ -541,12 +565,14 @@ const		int m = (int) part.size();
 		g_ipen.resize(longest + 2);
 		for (int l = 0; l < longest + 2; ++l) g_ipen[l] = part[0]->pwd->IntPen->Penalty(l);
 		sc.intpen = g_ipen.data(); sc.intpen_len = (int) g_ipen.size();
-		std::vector<SpdpProblem> probs(m);
-		for (int i = 0; i < m; ++i) probs[i] = part[i]->p;
+		std::vector<SpdpProblem> probs(m), rev(ori == 3? m: 0);
+		for (int i = 0; i < m; ++i) { probs[i] = part[i]->p; if (ori == 3) rev[i] = part[i]->p2; }
 		std::vector<SpdpAlignment> al(m);
+		std::vector<int32_t> orient(m, 0);
 		int	rc;
 const		auto t1 = std::chrono::steady_clock::now();
-		if (kind == 0) rc = spdp_align_s(g_ctx, &sc, probs.data(), m, al.data());
+		if (kind == 0) rc = ori == 3? spdp_align_s_ori3(g_ctx, &sc, probs.data(), rev.data(), m, al.data(), orient.data())
+					    : spdp_align_s(g_ctx, &sc, probs.data(), m, al.data());
 		else {
 		    SpdpSeedParams sp;
 		    fill_seed_params(sp, part[0]->pwd, part[0]->b);
@@ -566,14 +592,31 @@ const		auto t1 = std::chrono::steady_clock::now();
 		    SpdpHspSource src = {rqp.data(), units_cb, 0};
 		    static SpdpWilipModel wmodel; static std::once_flag wonce;
 		    if (own_wilip()) { std::call_once(wonce, [&] { fill_wilip_model(wmodel, part[0]->pwd); }); sp.wilip = &wmodel; }
-		    rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
+		    if (ori == 3) { sp.both_ori = 1;		// (Exinon::both_ori of these windows; recorded only when the HSP searches are the library's)
+			rc = spdp_align_s_seeded_ori3(g_ctx, &sc, &sp, probs.data(), rev.data(), m, lists.data(), counts.data(), lowest.data(), 0, al.data(), orient.data()); }
+		    else rc = spdp_align_s_seeded(g_ctx, &sc, &sp, probs.data(), m, lists.data(), counts.data(), lowest.data(), own_wilip()? 0: &src, al.data());
 		    int64_t st[11] = {0};
 		    spdp_seeded_stats(g_ctx, st, 11);
 		    for (int k = 0; k < 11; ++k) g_seed[k] += st[k];
 		}
 		if (rc < 0) fatal("spaln_gpu: %s\n", spdp_last_error(g_ctx));
 		g_us[1] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
-		for (int i = 0; i < m; ++i) { part[i]->gsi.scr = al[i].score; part[i]->gsi.skl = to_skl(al[i], part[i]->a); }
+		for (int i = 0; i < m; ++i) {
+		    Job* j = part[i];
+		    if (orient[i]) {			// the reverse orientation stays: what alignS_ng leaves in seqs[0], seqs[1] then (src/fwd2s1.cc:2771-2775)
+			if (kind == 1 && j->b->jxt) {	// (seeded path only) reverse_copy_jxt (:2730-2743): the anti-strand Seq carries the HSP list turned around, the
+			    Seq* c = j->b2;		// slot behind it as the forward walk left it ({a->len, b->len}, :2693)
+			    delete[] c->jxt;
+			    c->CdsNo = j->b->CdsNo;
+			    c->jxt = new JUXT[c->CdsNo + 1];
+			    vcopy(c->jxt, j->b->jxt, c->CdsNo + 1);
+			    c->jxt[c->CdsNo].jx = j->a->len; c->jxt[c->CdsNo].jy = j->b->len;
+			    c->revjxt();
+			}
+			std::swap(j->a, j->a2); std::swap(j->b, j->b2);
+		    }
+		    j->gsi.scr = al[i].score; j->gsi.skl = to_skl(al[i], j->a);
+		}
 		spdp_free_alignments(al.data(), m);
 		++g_batches;
 		if (m > g_largest) g_largest = m;

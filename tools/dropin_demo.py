@@ -75,6 +75,8 @@ def make_dataset(td, args):
                 q[hit] = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=int(hit.sum()))]
             else:
                 q = synth.mutate(rng, g.query, 0.02, 0.002)
+                if getattr(args, "antisense", False) and i % 2:
+                    q = np.frombuffer(bytes(q).translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1], dtype=np.uint8)
             f.write(f">q{i}\n{bytes(q).decode()}\n")
     env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
     env.update(ALN_TAB=os.path.join(REF, "table"), ALN_DBS=td)
@@ -90,7 +92,8 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--gpu-threads", type=int, default=64)
     ap.add_argument("--modes", default="Q7,Q4")
-    ap.add_argument("--strand", default="-S1")
+    ap.add_argument("--strand", default="-S1", help="-S1: the queries as given; -S3 (spaln's default): both orientations")
+    ap.add_argument("--antisense", action="store_true", help="every other query reverse-complemented (cDNA)")
     ap.add_argument("--extra", default="", help="further options for both programs, e.g. -yl3 (double affine gaps)")
     ap.add_argument("--where", action="store_true", help="also time the reference's own aligner calls inside its program (Amdahl's bound for the drop-in)")
     ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")

@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--genes", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--show", type=int, default=3)
+    ap.add_argument("--members", type=int, default=1,
+                    help="> 1: spdp_group_map_align_s over that many members ON THIS ONE DEVICE (each member its own context, index and "
+                         "chain of device batches: the members' request latencies overlap)")
     ap.add_argument("--ori", type=int, default=1, choices=[1, 3],
                     help="1: the queries as given against `spaln -S1`; 3: every other query reverse-complemented, both orientations "
                          "tried, against spaln's default (-S3)")
@@ -133,7 +136,49 @@ def main():
         # one call: spdp_blk_find -> regions and their signals (one launch) -> spdp_align_s_seeded -> spdp_skl_rng_s -> the
         # locus that stays.  Twice: the first call of a context also loads the kernels' code objects and sizes its pools
         runs = []
-        for _ in range(2):
+        if args.members > 1:
+            grp = engine.Group([0] * args.members)
+            glib = grp.lib
+            glib.spdp_group_context.restype = C.c_void_p
+            glib.spdp_group_context.argtypes = [C.c_void_p, C.c_int]
+
+            class Member:                                    # what blocks.BlockIndex needs of an engine
+                def __init__(self, ctx):
+                    self.lib, self.ctx = glib, ctx
+
+                def _check(self, rc, what):
+                    assert rc == 0, what
+            midx = [blocks.BlockIndex(Member(glib.spdp_group_context(grp.h, r)), fx) for r in range(args.members)]
+            handles = (C.c_void_p * args.members)(*[i.h for i in midx])
+            nq = len(queries)
+            qoffs = np.zeros(nq + 1, dtype=np.int64)
+            qoffs[1:] = np.cumsum([len(q) for q in queries])
+            qcodes = np.ascontiguousarray(np.concatenate(queries))
+            gg = blocks.Genome()
+            goff = np.ascontiguousarray(off, dtype=np.int64)
+            gg.codes, gg.chr_off, gg.n_chr = gen.ctypes.data, goff.ctypes.data, len(goff) - 1
+            rp = abi.RescoreParams(*(int(x) for x in rescore))
+            glib.spdp_group_map_align_s.restype = C.c_int
+            glib.spdp_group_map_align_s.argtypes = [C.c_void_p] * 11 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+            libc = C.CDLL(None)
+            libc.free.argtypes = [C.c_void_p]
+            for _ in range(2):
+                gs = (blocks.MapGene * nq)()
+                ex = C.POINTER(blocks.MapExon)()
+                t0 = time.perf_counter()
+                rc = glib.spdp_group_map_align_s(grp.h, handles, C.byref(midx[0].desc), C.byref(gg), C.byref(sc), C.byref(sp), C.addressof(sigmodel),
+                                                 C.byref(prm), C.byref(rp), qcodes.ctypes.data, qoffs.ctypes.data, nq, args.ori, gs, C.byref(ex))
+                runs.append((time.perf_counter() - t0, [0, 0, 0, 0]))
+                assert rc >= 0, glib.spdp_group_last_error(grp.h)
+                genes = [None if gs[i].chr < 0 else dict(chr=gs[i].chr, rvs=gs[i].rvs, q_rev=gs[i].q_rev, score=gs[i].score, val=gs[i].val, n_loci=gs[i].n_loci,
+                                                         exons=[(ex[gs[i].exon_off + j].q_left, ex[gs[i].exon_off + j].q_right, ex[gs[i].exon_off + j].g_left,
+                                                                 ex[gs[i].exon_off + j].g_right) for j in range(gs[i].n_exons)]) for i in range(nq)]
+                libc.free(ex)
+            phases = runs[-1][1]
+            for i in midx:
+                i.free()
+            grp.close()
+        for _ in range(0 if args.members > 1 else 2):
             t0 = time.perf_counter()
             genes, phases, rc = blocks.map_align(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries, ori=args.ori)
             runs.append((time.perf_counter() - t0, phases))
@@ -145,7 +190,7 @@ def main():
         for k in diff[:args.show]:
             sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
         out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 %s-O4`" % ("-S1 " if args.ori == 1 else ""),
-               "queries": args.queries, "ori": args.ori, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
+               "queries": args.queries, "ori": args.ori, "members": args.members, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
                "identical_exon_tables": n_same, "different": len(diff),
                "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
                "reference_queries_per_s": round(len(want) / ref_s, 1),

@@ -14,6 +14,8 @@
 #include <chrono>
 #include <ctime>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -26,22 +28,71 @@
 namespace {
 using namespace spdp_seed;
 
+// The requests of one walk by what defines them, for the scout pass (seeded_core): a walk is a deterministic function of its
+// inputs and of the DP results it is given, so a second run asks for the same requests again.
+struct RequestCache {
+    struct Entry { int key[14]; Parked p; };
+    std::vector<std::unique_ptr<Entry>> all;
+    static void make_key(int* k, int kind, const Span& s, const SpdpWindow& w, const int* cut)
+    {
+        const int v[14] = {kind, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr, w.lw, w.up, w.width, cut ? cut[0] : 0, cut ? cut[1] : 0};
+        memcpy(k, v, sizeof v);
+    }
+    Entry* find(const int* k) { for (auto& e : all) if (!memcmp(e->key, k, sizeof e->key)) return e.get(); return nullptr; }
+    Entry* add(const int* k) { all.emplace_back(new Entry); memcpy(all.back()->key, k, sizeof all.back()->key); return all.back().get(); }
+    // ... and the HSP searches of the recursion levels by level and span
+    struct Search { int key[9]; bool ok; std::vector<Unit> units; };
+    std::vector<std::unique_ptr<Search>> searches;
+    std::vector<int8_t> phs5, phs3;             // the phase marks the scout derived for the window (bind_problem)
+};
+
 struct DeviceBackend : DpBackend {
     Fiber* fiber; int query; const SpdpHspSource* src;
     bool failed = false;
     int flags = 0;                              // of all DP calls of the walk
     std::atomic<int64_t>* n_wilip;
     std::atomic<int64_t>* ns_cb = nullptr;
-    int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
+    // scout pass (pass 0) and the walk proper (pass 1) over one cache; slow(request): the request belongs to the longest class
+    RequestCache* cache = nullptr;
+    int pass = 1;
+    std::atomic<int64_t>* n_hit = nullptr; std::atomic<int64_t>* n_miss = nullptr;      // the walk proper: requests the scout had / had not asked for
+    const std::function<bool(const Parked&)>* slow = nullptr;
+    int take(const Parked& p, std::vector<SpdpSkl>& rec)
     {
-        Parked p;
-        p.query = query; p.kind = kind; p.s = s; p.w = w;
-        if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
-        fiber->park(&p);                        // back when the request has been served
         if (p.failed) { failed = true; return SPDP_NEVSEL; }
         flags |= p.flags;
         rec.insert(rec.end(), p.rec.begin(), p.rec.end());
         return p.score;
+    }
+    int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
+    {
+        int key[14];
+        if (cache) {
+            RequestCache::make_key(key, kind, s, w, cut);
+            if (RequestCache::Entry* e = cache->find(key)) {
+                if (e->p.async && !e->p.done) {
+                    if (pass == 0) return SPDP_NEVSEL;          // (the scout does not wait for what it handed over)
+                    fiber->wait_for(&e->p);
+                }
+                if (pass && n_hit) ++*n_hit;
+                return take(e->p, rec);
+            }
+            if (pass && n_miss) ++*n_miss;
+        }
+        if (cache && pass == 0) {
+            RequestCache::Entry* e = cache->add(key);
+            Parked& p = e->p;
+            p.query = query; p.kind = kind; p.s = s; p.w = w;
+            if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
+            if ((*slow)(p)) { fiber->submit(&p); return SPDP_NEVSEL; }     // on its way; the scout goes on as if nothing had been found
+            fiber->park(&p);
+            return take(p, rec);
+        }
+        Parked p;
+        p.query = query; p.kind = kind; p.s = s; p.w = w;
+        if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
+        fiber->park(&p);                        // back when the request has been served
+        return take(p, rec);
     }
     int lsp(const Span& s, const SpdpWindow& w, std::vector<SpdpSkl>& rec) override { return park(0, s, w, nullptr, rec); }
     int trcbk(const Span& s, const SpdpWindow& w, bool, const int* cut, std::vector<SpdpSkl>& rec) override
@@ -52,7 +103,24 @@ struct DeviceBackend : DpBackend {
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
         if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
+            int skey[9] = {level, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
+            if (cache) {
+                for (auto& e : cache->searches) if (!memcmp(e->key, skey, sizeof skey)) { units = e->units; if (pass) ++*n_wilip; return e->ok; }
+                const bool ok = own_search(level, s, units);
+                cache->searches.emplace_back(new RequestCache::Search);
+                memcpy(cache->searches.back()->key, skey, sizeof skey);
+                cache->searches.back()->ok = ok; cache->searches.back()->units = units;
+                if (pass) ++*n_wilip;
+                return ok;
+            }
             ++*n_wilip;
+            return own_search(level, s, units);
+        }
+        return callback_search(level, s, units);
+    }
+    bool own_search(int level, const Span& s, std::vector<Unit>& units)
+    {
+        {
             const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 1,
                                          nullptr, nullptr, nullptr, scp->intpen, scp->intpen_len, scp->gop, scp->gep, scp->lgop,
                                          scp->lgep, codonk1};
@@ -62,6 +130,9 @@ struct DeviceBackend : DpBackend {
             spdp_wl::flatten(us, flat);
             return parse_units(flat.data(), (int32_t) flat.size(), units);
         }
+    }
+    bool callback_search(int level, const Span& s, std::vector<Unit>& units)
+    {
         if (!src || !src->units) return false;
         const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
         const int32_t* flat = nullptr; int32_t n = 0;
@@ -107,24 +178,50 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
     scores.assign(n_probs, SPDP_NEVSEL);
     recs.assign(n_probs, std::vector<SpdpSkl>());
     status.assign(n_probs, 0);                          // 1: the walk met a state it does not serve, 2: a request failed
+    // A walk's slow requests -- its terminal stretches: a few query rows against tens of thousands of columns, 100 - 200 ms as
+    // one wave each -- come one after the other, head first, tail last, with the inner gaps in between: the call
+    // waits for their sum.  So a walk runs twice.  The SCOUT hands every slow request over without waiting (and goes on as if
+    // it had found nothing there), waits for the fast ones as usual and keeps all results by what defines a request; the walk
+    // proper then finds its requests answered or on their way -- head and tail are in flight together -- and whatever the scout
+    // did not ask for (its path may differ behind a request it did not wait for) is asked for as before.  Results are those of
+    // the second run alone.  SPDP_SEED_SCOUT=0: one run; = 1 / 2: see where the mode is chosen below.
+    std::atomic<int64_t> n_hit{0}, n_miss{0};
+    std::function<int(const Parked&)> cls_fn;         // (set below, before any walk starts)
+    int slow_class = -1;
+    const std::function<bool(const Parked&)> is_slow = [&](const Parked& r) { return slow_class >= 0 && cls_fn(r) >= slow_class; };
     auto walk = [&](int q, Fiber& fb) {
-        try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
-            DeviceBackend be;
-            be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
-            be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc; be.codonk1 = sp->codonk1;       // (the walk's own GapPenalty reads it there)
-            SeedWalk w;
-            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-            const int64_t tb0 = cpu_ns();
-            if (!bind_problem(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
-            ns_bind += cpu_ns() - tb0;
-            w.dp = &be;
-            const SpdpProblem& p = probs[q];
-            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-            scores[q] = w.run(whole);
-            recs[q].swap(w.rec);
-            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
-            if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
-        } catch (...) { status[q] = 2; }            // (out of memory inside one walk: that query comes back without an alignment)
+        RequestCache cache;
+        const bool two = slow_class >= 0;
+        for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+            try {                                   // (everything a walk allocates is inside: a walk that throws fails alone)
+                DeviceBackend be;
+                be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
+                be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc; be.codonk1 = sp->codonk1;       // (the walk's own GapPenalty reads it there)
+                if (two) { be.cache = &cache; be.pass = pass; be.slow = &is_slow; be.n_hit = &n_hit; be.n_miss = &n_miss; }
+                SeedWalk w;
+                const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+                const int64_t tb0 = cpu_ns();
+                SpdpProblem bound = probs[q];
+                if (two && pass && !cache.phs5.empty()) { bound.phs5 = cache.phs5.data(); bound.phs3 = cache.phs3.data(); }     // (derived by the scout)
+                if (!bind_problem(w, sc, sp, &bound, nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; break; }
+                ns_bind += cpu_ns() - tb0;
+                w.dp = &be;
+                const SpdpProblem& p = probs[q];
+                const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
+                const int score = w.run(whole);
+                if (pass == 0) {                    // (marks the walk sets go to a list of edits, not into the arrays)
+                    if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all();
+                    if (!probs[q].phs5 && !w.phs5.own.empty()) { cache.phs5.swap(w.phs5.own); cache.phs3.swap(w.phs3.own); }
+                    continue;
+                }
+                scores[q] = score;
+                recs[q].swap(w.rec);
+                status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+                if (be.flags & SPDP_ALN_LEFT_EDGE) status[q] |= 16;
+            } catch (...) { if (pass) status[q] = 2; }  // (out of memory inside one walk: that query comes back without an alignment)
+        }
+        // what the scout handed over and the walk never asked for is still written to when it is served: not before that may the cache go
+        for (auto& e : cache.all) if (e->p.async && !e->p.done) fb.wait_for(&e->p);
     };
 
     std::atomic<int> rc{0};
@@ -140,6 +237,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         (void) hipSetDevice(ctx->device);
         { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
         auto t0 = std::chrono::steady_clock::now();
+        if (getenv("SPDP_SEED_TIMELINE")) fprintf(stderr, "[seeded] t = %.3f s: lane %d starts %zu requests\n", us_since(t_begin) / 1e6, lane, take.size());
         // one device batch for everything parked
         const int m = (int) take.size();
         std::vector<SpdpProblem> rp(m);
@@ -207,10 +305,23 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         static const int64_t thr[] = {1500, 6000, 20000};            // (four classes measured: no gain over three; the defaults give lanes to the first three)
         return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };
+    cls_fn = cls;
+    {   // the scout pays where a call has slow requests at all: several classes, and the HSP searches the library's own (a
+        // caller's callback would be asked twice)
+        const char* e = getenv("SPDP_SEED_SCOUT");
+        // 1: only the slow class is handed over; 2: every request is -- more than twice the requests (the scout's paths behind the
+        // gaps it did not wait for), worth it while the host keeps up: 5 000 walks 0.94 -> 0.79 (1) -> 0.50 s (2), 20 000: 1.31 ->
+        // 0.97 -> 1.00 s, 40 000: 1.79 -> 1.40 -> 2.10 s
+        const int mode = e ? atoi(e) : (n_probs <= 16384 ? 2 : 1);
+        slow_class = (mode && n_cls >= 3 && sp->wilip && !(src && src->units)) ? (mode == 2 ? 0 : n_cls - 1) : -1;
+        if (slow_class == 0) { ws.all_in_flight = true; ws.last_class_waits = true; }
+    }
     if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
     us_walks += us_since(t_idle);
     if (getenv("SPDP_SEED_VERBOSE"))
         fprintf(stderr, "[seeded] host CPU: walks %.1f ms (bind %.1f, HSP callback %.1f), %d worker threads\n", ws.cpu_ns / 1e6, ns_bind.load() / 1e6, ns_cb.load() / 1e6, ws.n_threads);
+    if (getenv("SPDP_SEED_VERBOSE") && slow_class >= 0)
+        fprintf(stderr, "[seeded] scout: the walks proper found %lld of their requests asked for already, %lld not\n", (long long) n_hit.load(), (long long) n_miss.load());
     if (getenv("SPDP_SEED_VERBOSE"))
         for (int l = 0; l < n_lanes; ++l)
             fprintf(stderr, "[seeded] lane %d: %lld batches, %.2f ms each, %.0f requests each\n", l, (long long) lane_n[l],

@@ -15,6 +15,7 @@
 #include <ucontext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,10 @@ struct Parked {
     bool failed = false;
     int flags = 0;                              // SpdpAlignment::flags of the request
     Fiber* owner = nullptr;
+    // a request handed over WITHOUT sleeping (Fiber::submit): nobody waits yet; `done` is set when it has been served, and a
+    // walk that needs the result before that sleeps as `waiter` (Fiber::wait_for).  All three under the scheduler's mutex.
+    bool async = false, done = false;
+    Fiber* waiter = nullptr;
 };
 
 struct Fiber {
@@ -46,6 +51,8 @@ struct Fiber {
     int query = -1;
     int home = -1;                              // the worker thread this walk runs on, from its first step to its last
     Parked* want_park = nullptr;
+    Parked* want_submit = nullptr;              // hand this request over and go on at once
+    Parked* want_wait = nullptr;                // sleep until this submitted request has been served
     bool finished = false;
     struct WalkScheduler* sched = nullptr;
     // called by a walk (DpBackend::lsp / trcbk): hand the request over and sleep until it has been served
@@ -55,6 +62,8 @@ struct Fiber {
         want_park = p;
         swapcontext(&ctx, back);                // (resumed by the same worker thread: see WalkScheduler::worker)
     }
+    void submit(Parked* p) { p->owner = nullptr; p->async = true; p->done = false; want_submit = p; swapcontext(&ctx, back); }
+    void wait_for(Parked* p) { want_wait = p; swapcontext(&ctx, back); }
 };
 
 // dispatcher lanes per latency class, shortest class first: "a,b,c,.." in SPDP_SEED_LANES overrides the defaults (a 0 merges
@@ -106,6 +115,9 @@ struct WalkScheduler {
     std::function<int(const Parked&)> classify;
     int n_walks = 0, next = 0, done = 0, in_flight = 0, busy = 0;
     int max_in_flight = 8192, n_threads = 16, batch_target = 256;
+    bool all_in_flight = false;                         // every walk of the call gets its fiber at once (walks that hand their requests over and then wait)
+    bool last_class_waits = false;                      // the dispatcher of the longest class starts only when every walk has handed its requests over
+    std::atomic<int> scouted{0};                        // walks that have (Fiber::sched->scouted, counted by the walk body)
     std::function<void(int, Fiber&)> body;
     std::vector<int> order;                             // walk started k-th (empty: k); longest first shortens the tail of a call
     bool oom = false;
@@ -175,6 +187,18 @@ struct WalkScheduler {
                 --in_flight; ++done;
                 if (done >= n_walks) { cv_work.notify_all(); cv_main.notify_all(); }
                 else if (next < n_walks) cv_work.notify_one();
+            } else if (f->want_submit) {                // hands a request over and goes on
+                Parked* p = f->want_submit;
+                f->want_submit = nullptr;
+                const int c = parked.size() > 1 ? std::max(0, std::min((int) parked.size() - 1, classify(*p))) : 0;
+                parked[c].push_back(p);
+                if ((int) parked[c].size() >= batch_target) cv_main.notify_all();
+                ready_of[me].push_back(f); ++n_ready;
+            } else if (f->want_wait) {                  // needs a request it handed over earlier
+                Parked* p = f->want_wait;
+                f->want_wait = nullptr;
+                if (p->done) { ready_of[me].push_back(f); ++n_ready; }
+                else p->waiter = f;
             } else {
                 const int c = parked.size() > 1 ? std::max(0, std::min((int) parked.size() - 1, classify(*f->want_park))) : 0;
                 parked[c].push_back(f->want_park);
@@ -198,7 +222,7 @@ struct WalkScheduler {
         n_walks = n; body = std::move(walk_body);
         // walks in flight / mean latency of a walk = the rate of a long call: more in flight for big calls (each fiber is two
         // mappings: stay well below vm.max_map_count), and batches in proportion (60 000 pairs: 8192 / 256 -> 0.97 s, 32768 / 1024 -> 0.76 s)
-        max_in_flight = std::min(20000, std::max(8192, n / 2));
+        max_in_flight = all_in_flight ? std::min(28000, std::max(8192, n)) : std::min(20000, std::max(8192, n / 2));
         if (const char* e = getenv("SPDP_SEED_WALKS")) max_in_flight = std::max(1, atoi(e));
         batch_target = std::max(256, max_in_flight / 32);
         if (const char* e = getenv("SPDP_SEED_BATCH")) batch_target = std::max(1, atoi(e));
@@ -221,7 +245,9 @@ struct WalkScheduler {
                         if (parked[c].empty()) return false;
                         // nobody can run (every worker waits: nothing ready, nothing new to start), or enough has gathered
                         const bool startable = next < n_walks && in_flight < max_in_flight && !oom;
-                        return (int) parked[c].size() >= batch_target || (!busy && n_ready == 0 && !startable);
+                        const bool idle = !busy && n_ready == 0 && !startable;
+                        if (last_class_waits && parked.size() > 1 && c == (int) parked.size() - 1) return idle || scouted.load() >= n_walks;
+                        return (int) parked[c].size() >= batch_target || idle;
                     });
                     if (parked[c].empty()) { cv_main.notify_all(); break; }         // every walk has ended
                     take.swap(parked[c]);
@@ -229,7 +255,12 @@ struct WalkScheduler {
                 device(take, lane);
                 {
                     std::lock_guard<std::mutex> g(mu);
-                    for (Parked* p : take) { ready_of[p->owner->home].push_back(p->owner); ++n_ready; }
+                    for (Parked* p : take) {
+                        if (p->async) {
+                            p->done = true;
+                            if (p->waiter) { ready_of[p->waiter->home].push_back(p->waiter); ++n_ready; p->waiter = nullptr; }
+                        } else { ready_of[p->owner->home].push_back(p->owner); ++n_ready; }
+                    }
                 }
                 cv_work.notify_all();
             }

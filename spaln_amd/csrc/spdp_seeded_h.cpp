@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -28,8 +29,38 @@ struct DeviceBackendH : DpBackend {
     Fiber* fiber; int query; const SpdpHspSource* src;
     bool failed = false;
     std::atomic<int64_t>* n_wilip;
+    // the scout pass (spdp_seeded.cpp, seeded_core: the same two runs over one cache)
+    RequestCache* cache = nullptr;
+    int pass = 1;
+    const std::function<bool(const Parked&)>* slow = nullptr;
+    int take(const Parked& p, std::vector<SpdpSkl>& rec)
+    {
+        if (p.failed) { failed = true; return SPDP_NEVSEL; }
+        rec.insert(rec.end(), p.rec.begin(), p.rec.end());
+        return p.score;
+    }
     int park(int kind, const Span& s, const SpdpWindow& w, const int* cut, std::vector<SpdpSkl>& rec)
     {
+        if (cache) {
+            int key[14];
+            RequestCache::make_key(key, kind, s, w, cut);
+            if (RequestCache::Entry* e = cache->find(key)) {
+                if (e->p.async && !e->p.done) {
+                    if (pass == 0) return SPDP_NEVSEL;
+                    fiber->wait_for(&e->p);
+                }
+                return take(e->p, rec);
+            }
+            if (pass == 0) {
+                RequestCache::Entry* e = cache->add(key);
+                Parked& p = e->p;
+                p.query = query; p.kind = kind; p.s = s; p.w = w;
+                if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
+                if ((*slow)(p)) { fiber->submit(&p); return SPDP_NEVSEL; }
+                fiber->park(&p);
+                return take(p, rec);
+            }
+        }
         Parked p;
         p.query = query; p.kind = kind; p.s = s; p.w = w;
         if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
@@ -55,7 +86,10 @@ struct DeviceBackendH : DpBackend {
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
         if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
-            ++*n_wilip;
+            int skey[9] = {level, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
+            if (cache)
+                for (auto& e : cache->searches) if (!memcmp(e->key, skey, sizeof skey)) { units = e->units; if (pass) ++*n_wilip; return e->ok; }
+            if (pass) ++*n_wilip;
             const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 3,
                                          prob->sigS, prob->sigE, prob->sigT, scp->intpen, scp->intpen_len, scp->gop, scp->gep,
                                          scp->lgop, scp->lgep, scp->codonk1};
@@ -63,7 +97,13 @@ struct DeviceBackendH : DpBackend {
             spdp_wl::run(wm, &pr, level, us);
             std::vector<int32_t> flat;
             spdp_wl::flatten(us, flat);
-            return parse_units(flat.data(), (int32_t) flat.size(), units);
+            const bool ok = parse_units(flat.data(), (int32_t) flat.size(), units);
+            if (cache) {
+                cache->searches.emplace_back(new RequestCache::Search);
+                memcpy(cache->searches.back()->key, skey, sizeof skey);
+                cache->searches.back()->ok = ok; cache->searches.back()->units = units;
+            }
+            return ok;
         }
         if (!src || !src->units) return false;
         const int32_t span[8] = {s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
@@ -113,23 +153,35 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     std::vector<int> scores(n_probs, SPDP_NEVSEL);
     std::vector<std::vector<SpdpSkl>> recs(n_probs);
     std::vector<uint8_t> status(n_probs, 0);            // 1: the walk met a state it does not serve, 2: a request failed
+    // the scout pass: see seeded_core (spdp_seeded.cpp)
+    std::function<int(const Parked&)> cls_fn;
+    int slow_class = -1;
+    const std::function<bool(const Parked&)> is_slow = [&](const Parked& r) { return slow_class >= 0 && cls_fn(r) >= slow_class; };
     auto walk = [&](int q, Fiber& fb) {
-        try {                                       // (everything a walk allocates is inside: a walk that throws fails alone)
-            DeviceBackendH be;
-            be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
-            be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc;
-            SeedWalkH w;
-            const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
-            if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; return; }
-            w.dp = &be;
-            const SpdpProblemH& p = probs[q];
-            const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
-            scores[q] = w.run(whole);
-            recs[q].swap(w.rec);
-            for (const auto& e : w.phs5.edits) ctx->seed_marks[q].push_back({e.first, 5, e.second, 0});      // (one walk per query: no lock)
-            for (const auto& e : w.phs3.edits) ctx->seed_marks[q].push_back({e.first, 3, e.second, 0});
-            status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
-        } catch (...) { status[q] = 2; }            // (out of memory inside one walk: that query comes back without an alignment)
+        RequestCache cache;
+        const bool two = slow_class >= 0;
+        for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+            try {                                   // (everything a walk allocates is inside: a walk that throws fails alone)
+                DeviceBackendH be;
+                be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
+                be.wm = sp->wilip; be.prob = &probs[q]; be.scp = sc;
+                if (two) { be.cache = &cache; be.pass = pass; be.slow = &is_slow; }
+                SeedWalkH w;
+                const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+                if (!bind_problem_h(w, sc, sp, &probs[q], nh ? hsps[q] : nullptr, nh, lowest_level ? lowest_level[q] : 0)) { status[q] = 1; break; }
+                w.dp = &be;
+                const SpdpProblemH& p = probs[q];
+                const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
+                const int score = w.run(whole);
+                if (pass == 0) { if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all(); continue; }
+                scores[q] = score;
+                recs[q].swap(w.rec);
+                for (const auto& e : w.phs5.edits) ctx->seed_marks[q].push_back({e.first, 5, e.second, 0});      // (one walk per query: no lock)
+                for (const auto& e : w.phs3.edits) ctx->seed_marks[q].push_back({e.first, 3, e.second, 0});
+                status[q] = be.failed ? 2 : (w.unsupported ? 1 : 0);
+            } catch (...) { if (pass) status[q] = 2; }  // (out of memory inside one walk: that query comes back without an alignment)
+        }
+        for (auto& e : cache.all) if (e->p.async && !e->p.done) fb.wait_for(&e->p);
     };
 
     std::atomic<int> rc{0};
@@ -197,6 +249,13 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         static const int64_t thr[] = {1500, 6000, 18000, 45000};     // (five classes measured: no gain over three; the defaults give lanes to the first three)
         return latency_class(steps, thr, (int) (sizeof thr / sizeof thr[0]), n_cls);
     };
+    cls_fn = cls;
+    {
+        const char* e = getenv("SPDP_SEED_SCOUT");
+        const int mode = e ? atoi(e) : 1;       // (mode 2, every request handed over, costs this path 2.4 x: 10 000 proteins of the drop-in 8.1 -> 19.4 s; mode 1: 7.7 s)
+        slow_class = (mode && n_cls >= 3 && sp->wilip && !(src && src->units) && !getenv("SPDP_SEED_TRACE")) ? (mode == 2 ? 0 : n_cls - 1) : -1;
+        if (slow_class == 0) { ws.all_in_flight = true; ws.last_class_waits = true; }
+    }
     if (!ws.run(n_probs, walk, device, class_of_lane, cls)) { ctx->err = "the seeded path could not allocate a stack for a walk"; rc = -1; }
     us_walks += us_since(t_idle);
     if (getenv("SPDP_SEED_VERBOSE"))

@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <ctime>
 #include <functional>
+#include <memory>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -64,6 +66,24 @@ struct Fiber {
     }
     void submit(Parked* p) { p->owner = nullptr; p->async = true; p->done = false; want_submit = p; swapcontext(&ctx, back); }
     void wait_for(Parked* p) { want_wait = p; swapcontext(&ctx, back); }
+};
+
+// The requests of one walk by what defines them, for the scout pass (seeded_core, seeded_core_h): a walk is a deterministic function of its
+// inputs and of the DP results it is given, so a second run asks for the same requests again.
+struct RequestCache {
+    struct Entry { int key[14]; Parked p; };
+    std::vector<std::unique_ptr<Entry>> all;
+    static void make_key(int* k, int kind, const Span& s, const SpdpWindow& w, const int* cut)
+    {
+        const int v[14] = {kind, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr, w.lw, w.up, w.width, cut ? cut[0] : 0, cut ? cut[1] : 0};
+        memcpy(k, v, sizeof v);
+    }
+    Entry* find(const int* k) { for (auto& e : all) if (!memcmp(e->key, k, sizeof e->key)) return e.get(); return nullptr; }
+    Entry* add(const int* k) { all.emplace_back(new Entry); memcpy(all.back()->key, k, sizeof all.back()->key); return all.back().get(); }
+    // ... and the HSP searches of the recursion levels by level and span
+    struct Search { int key[9]; bool ok; std::vector<Unit> units; };
+    std::vector<std::unique_ptr<Search>> searches;
+    std::vector<int8_t> phs5, phs3;             // the phase marks the scout derived for the window (bind_problem)
 };
 
 // dispatcher lanes per latency class, shortest class first: "a,b,c,.." in SPDP_SEED_LANES overrides the defaults (a 0 merges

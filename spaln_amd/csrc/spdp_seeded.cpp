@@ -37,6 +37,7 @@ struct DeviceBackend : DpBackend {
     // scout pass (pass 0) and the walk proper (pass 1) over one cache; slow(request): the request belongs to the longest class
     RequestCache* cache = nullptr;
     int pass = 1;
+    bool after_dummy = false;
     std::atomic<int64_t>* n_hit = nullptr; std::atomic<int64_t>* n_miss = nullptr;      // the walk proper: requests the scout had / had not asked for
     const std::function<bool(const Parked&)>* slow = nullptr;
     int take(const Parked& p, std::vector<SpdpSkl>& rec)
@@ -62,11 +63,16 @@ struct DeviceBackend : DpBackend {
             if (pass && n_miss) ++*n_miss;
         }
         if (cache && pass == 0) {
+            // the scout's own doing: a gap whose lspS_ng it did not wait for "found nothing", and the walk bridges it by the cut-range
+            // traceback of shortcutS_ng -- a request the walk proper will not make once the real result is in
+            const bool bridge = after_dummy && kind == 2;
+            after_dummy = false;
+            if (bridge) return SPDP_NEVSEL;
             RequestCache::Entry* e = cache->add(key);
             Parked& p = e->p;
             p.query = query; p.kind = kind; p.s = s; p.w = w;
             if (cut) { p.cut[0] = cut[0]; p.cut[1] = cut[1]; }
-            if ((*slow)(p)) { fiber->submit(&p); return SPDP_NEVSEL; }     // on its way; the scout goes on as if nothing had been found
+            if ((*slow)(p)) { fiber->submit(&p); after_dummy = kind == 0; return SPDP_NEVSEL; }     // on its way; the scout goes on as if nothing had been found
             fiber->park(&p);
             return take(p, rec);
         }

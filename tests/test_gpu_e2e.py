@@ -36,6 +36,21 @@ def test_exon_tables_equal_the_reference_program(ori):
     assert d["query_reversed"] == (150 if ori == 3 else 0)
 
 
+@pytest.mark.parametrize("scout", ["0", "1", "2"])
+def test_scout_pass_changes_nothing(scout, monkeypatch):
+    """the walks of a seeded call as one run (0), with a scout run that hands the slow class of requests over without waiting (1),
+    or every request (2: the default at this size): the same exon tables, those of the reference"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln")):
+        pytest.skip("oracle/_ref/spaln is not built")
+    env = dict(os.environ, SPDP_SEED_SCOUT=scout, SPDP_SEED_VERBOSE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_q7.py"), "--queries", "400", "--genes", "60", "--ori", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-400:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["identical_exon_tables"] == 400 and d["library_aligned"] == 400, d
+    assert ("[seeded] scout:" in r.stderr) == (scout != "0")
+
+
 COMP = np.arange(256, dtype=np.uint8)
 for _a, _b in ((2, 9), (9, 2), (3, 5), (5, 3)):
     COMP[_a] = _b

@@ -186,6 +186,7 @@ extern "C" void spdp_blk_index_host_free(SpdpBlkIndexHost* h) { delete (HostInde
 #include "spdp_hostcpus.h"
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <thread>
 
 namespace {
@@ -242,8 +243,16 @@ extern "C" int spdp_blk_build_params_default(int64_t fasta_bytes, int32_t nbitpa
     return 0;
 }
 
+static SpdpBlkIndexHost* blk_index_build(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParams* p,
+                                         const SpdpBlkSearchOpts* opts, double* seconds);
 extern "C" SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParams* p,
                                                   const SpdpBlkSearchOpts* opts, double* seconds)
+{
+    try { return blk_index_build(ctx, genome, p, opts, seconds); }
+    catch (const std::bad_alloc&) { if (ctx) ctx->err = "spdp_blk_index_build: out of host memory"; return nullptr; }      // (nothing of C++ crosses the C boundary)
+}
+static SpdpBlkIndexHost* blk_index_build(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParams* p,
+                                         const SpdpBlkSearchOpts* opts, double* seconds)
 {
     if (!ctx) return nullptr;
     auto fail = [&](const char* m) -> SpdpBlkIndexHost* { ctx->err = std::string("spdp_blk_index_build: ") + m; return nullptr; };
@@ -277,28 +286,29 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGe
     // blocks per chromosome (the walk of scan_genome: a block ends after margin + blklen residues, then after every blklen)
     const int64_t s_size = (int64_t) A.margin + A.blklen;
     std::vector<int32_t> chr_first(n_chr);
-    HostIndex* h = new HostIndex;
+    std::unique_ptr<HostIndex> hold(new HostIndex);         // (freed on every way out but the last)
+    HostIndex* h = hold.get();
     h->chrid.resize((size_t) n_chr + 1);
     uint64_t blocks = 0;
     for (int c = 0; c < n_chr; ++c) {
         const int64_t L = genome->chr_off[c + 1] - genome->chr_off[c];
-        if (L < 0) { delete h; return fail("chr_off decreases"); }
+        if (L < 0) { return fail("chr_off decreases"); }
         chr_first[c] = (int32_t) (blocks + 1);
         h->chrid[c] = {(uint32_t) genome->chr_off[c], (uint32_t) (blocks + 1)};
         blocks += L <= 0 ? 0 : (L < s_size ? 1 : 1 + (L - A.margin) / A.blklen);
     }
     h->chrid[n_chr] = {(uint32_t) G, (uint32_t) (blocks + 1)};
-    if (blocks < 1 || blocks >= (1ull << 31)) { delete h; return fail("no block, or too many"); }
+    if (blocks < 1 || blocks >= (1ull << 31)) { return fail("no block, or too many"); }
     int key_bits = 32 + 2 * K;
     std::vector<uint32_t> tcount, cnt;
     BlkBuildDev* dev = nullptr;
-    if (spdp_blkidx_words(ctx, genome->codes, genome->chr_off, chr_first.data(), n_chr, A, tabsize, key_bits, tcount, cnt, &dev)) { delete h; return nullptr; }
+    if (spdp_blkidx_words(ctx, genome->codes, genome->chr_off, chr_first.data(), n_chr, A, tabsize, key_bits, tcount, cnt, &dev)) { return nullptr; }
     struct DevGuard { BlkBuildDev* d; ~DevGuard() { spdp_blkidx_free(d); } } dev_guard{dev};
     const double t_dev1 = wall(t_begin);
     // ---- blkscrtab(segn, blksz), src/blksrc.cc:944-997
     const auto t_host = std::chrono::steady_clock::now();
     const uint32_t segn = (uint32_t) blocks, blksz = (uint32_t) G / segn;
-    try { h->nblk.assign(tabsize, 0); h->blkp.assign(tabsize, 0); h->wscr.assign(tabsize, 0); } catch (const std::bad_alloc&) { delete h; return fail("out of memory for the index tables"); }
+    try { h->nblk.assign(tabsize, 0); h->blkp.assign(tabsize, 0); h->wscr.assign(tabsize, 0); } catch (const std::bad_alloc&) { return fail("out of memory for the index tables"); }
     const int nt = std::max(1, std::min(spdp_host_cpus(), (int) (tabsize >> 14)));
     auto on_ranges = [&](auto f) {
         std::vector<std::thread> th;
@@ -310,7 +320,7 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGe
     on_ranges([&](int t, uint32_t a, uint32_t b) { uint64_t m = 0; for (uint32_t w = a; w < b; ++w) if (tcount[w]) ++m; part_m[t] = m; });
     uint64_t m_seen = 0;
     for (uint64_t x : part_m) m_seen += x;
-    if (!m_seen) { delete h; return fail("no word in the genome"); }
+    if (!m_seen) { return fail("no word in the genome"); }
     const double basescr = log((double) segn);
     short min_scr = (short) -(100 * log((double) p->afact * blksz / (uint32_t) m_seen));
     if (min_scr < 0) min_scr = 0;
@@ -331,14 +341,14 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGe
     });
     double avr = 0.; uint64_t kept = 0, word_no = 0, max_blk = 0, over = 0;
     for (int t = 0; t < nt; ++t) { avr += part_avr[t]; kept += part_kept[t]; word_no += part_words[t]; max_blk = std::max(max_blk, part_max[t]); over += part_over[t]; }
-    if (over) { delete h; return fail("a word lies in more than 65 535 blocks: the reference's 16-bit counters wrap there (use a longer k)"); }
-    if (word_no > (uint64_t) INT32_MAX) { delete h; return fail("more postings than a 32-bit list offset (blkp) can address"); }
+    if (over) { return fail("a word lies in more than 65 535 blocks: the reference's 16-bit counters wrap there (use a longer k)"); }
+    if (word_no > (uint64_t) INT32_MAX) { return fail("more postings than a 32-bit list offset (blkp) can address"); }
     uint64_t at = 0;
     for (uint32_t w = 0; w < tabsize; ++w) if (cnt[w]) { h->blkp[w] = (int32_t) (at + 1); h->nblk[w] = (uint16_t) cnt[w]; at += cnt[w]; }
-    try { h->blkb.assign((size_t) word_no, 0); } catch (const std::bad_alloc&) { delete h; return fail("out of memory for the posting lists"); }
+    try { h->blkb.assign((size_t) word_no, 0); } catch (const std::bad_alloc&) { return fail("out of memory for the posting lists"); }
     const double t_host1 = wall(t_host);
     const auto t_dev2 = std::chrono::steady_clock::now();
-    if (spdp_blkidx_lists(ctx, dev, h->blkp.data(), (int64_t) word_no, h->blkb.data())) { delete h; return nullptr; }
+    if (spdp_blkidx_lists(ctx, dev, h->blkp.data(), (int64_t) word_no, h->blkb.data())) { return nullptr; }
     const double t_dev2s = wall(t_dev2);
     // ---- the header (MakeBlk::idxblk, WriteBlkInfo, findChrBbound)
     memset(&h->wcp, 0, sizeof h->wcp); memset(&h->wc, 0, sizeof h->wc);
@@ -360,9 +370,9 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGe
     SpdpBlkSearchOpts o;
     if (opts) o = *opts; else spdp_blk_search_opts_default(&o);
     std::string why;
-    if (!derive_search_params(h, o, why)) { ctx->err = "spdp_blk_index_build: " + why; delete h; return nullptr; }
+    if (!derive_search_params(h, o, why)) { ctx->err = "spdp_blk_index_build: " + why; return nullptr; }
     if (seconds) { seconds[0] = t_dev1 + t_dev2s; seconds[1] = t_host1; seconds[2] = wall(t_begin); }
-    return (SpdpBlkIndexHost*) h;
+    return (SpdpBlkIndexHost*) hold.release();
 }
 
 // WriteBlkInfo / writeBlkInfo (src/blksrc.cc:598-622): the struct images of the reference's 64-bit build

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -46,7 +47,7 @@ template <class F> void on_host_threads(int n, F f)
 
 }  // namespace
 
-extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+static int map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
                                 const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
                                 const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
                                 const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
@@ -222,4 +223,18 @@ extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const 
     if (seconds) memcpy(seconds, sec, sizeof sec);
     if (partial) { ctx->err = "spdp_map_align_s: some walks met a state the seeded path does not serve; those loci come back without an alignment"; return 1; }
     return 0;
+}
+
+extern "C" int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                                const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpSignalModel* sigmodel,
+                                const SpdpBlkFindParams* fprm, const SpdpRescoreParams* rp,
+                                const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
+                                SpdpMapGene* genes, SpdpMapExon** exons, double* seconds)
+{
+    try { return map_align_s(ctx, ix, hix, genome, sc, sp, sigmodel, fprm, rp, codes, offs, n, ori, genes, exons, seconds); }
+    catch (const std::bad_alloc&) {                     // (nothing of C++ crosses the C boundary)
+        if (ctx) ctx->err = "spdp_map_align_s: out of host memory (SPDP_MAP_CHUNK_MB sets the size of a chunk)";
+        if (exons && *exons) { free(*exons); *exons = nullptr; }
+        return -1;
+    }
 }

@@ -1647,11 +1647,19 @@ inline bool bind_problem(SeedWalk& w, const SpdpScoring* sc, const SpdpSeedParam
         for (int side = 0; side < 2; ++side) {
             std::vector<int8_t>& q = side ? w.phs3.own : w.phs5.own;
             const uint8_t* cano = side ? p->cano3 : p->cano5;
-            for (int n = std::max(1, p->b_left); n < std::min(N - 1, p->b_right + 1); ++n)
+            const int n_end = std::min(N - 1, p->b_right + 1);
+            for (int n = std::max(1, p->b_left); n < n_end; ++n) {
+                if (n + 8 <= n_end) {                   // (most positions are no site: eight at a glance, then straight to the next one)
+                    uint64_t eight;
+                    memcpy(&eight, cano + n, 8);
+                    if (!eight) { n += 7; continue; }
+                    n += __builtin_ctzll(eight) >> 3;   // (little-endian: the lowest non-zero byte is the first site)
+                }
                 if (q[n] == -2 && cano[n]) {
                     q[n] = 0;
                     if (cano[n] > 1) { q[n + 1] = 1; q[n - 1] = q[n - 1] == 1 ? 2 : -1; }
                 }
+            }
         }
     }
     bind_common(w, sp, hsps, n_hsps, lowest_level);

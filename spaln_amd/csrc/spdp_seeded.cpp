@@ -198,6 +198,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
                 const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
                 const int score = w.run(whole);
                 if (pass == 0) {                    // (marks the walk sets go to a list of edits, not into the arrays)
+                    fb.flush();                     // (what the scout handed over goes to the dispatchers now, under one lock)
                     if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all();
                     if (!probs[q].phs5 && !w.phs5.own.empty()) { cache.phs5.swap(w.phs5.own); cache.phs3.swap(w.phs3.own); }
                     continue;
@@ -300,7 +301,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         // 1: only the slow class is handed over; 2: every request is -- more than twice the requests (the scout's paths behind the
         // gaps it did not wait for), worth it while the host keeps up: 5 000 walks 0.94 -> 0.79 (1) -> 0.50 s (2), 20 000: 1.31 ->
         // 0.97 -> 1.00 s, 40 000: 1.79 -> 1.40 -> 2.10 s
-        const int mode = e ? atoi(e) : (n_probs <= 16384 ? 2 : 1);
+        const int mode = e ? atoi(e) : (n_probs <= 24576 ? 2 : 1);       // (with the fibers' requests handed over in one go: 20 000 walks 0.96 (1) / 0.84 s (2))
         slow_class = (mode && n_cls >= 3 && sp->wilip && !(src && src->units)) ? (mode == 2 ? 0 : n_cls - 1) : -1;
         if (slow_class == 0) { ws.all_in_flight = true; ws.last_class_waits = true; }
     }

@@ -173,7 +173,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
                 const SpdpProblemH& p = probs[q];
                 const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
                 const int score = w.run(whole);
-                if (pass == 0) { if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all(); continue; }
+                if (pass == 0) { fb.flush(); if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all(); continue; }
                 scores[q] = score;
                 recs[q].swap(w.rec);
                 for (const auto& e : w.phs5.edits) ctx->seed_marks[q].push_back({e.first, 5, e.second, 0});      // (one walk per query: no lock)

@@ -53,7 +53,6 @@ struct Fiber {
     int query = -1;
     int home = -1;                              // the worker thread this walk runs on, from its first step to its last
     Parked* want_park = nullptr;
-    Parked* want_submit = nullptr;              // hand this request over and go on at once
     Parked* want_wait = nullptr;                // sleep until this submitted request has been served
     bool finished = false;
     struct WalkScheduler* sched = nullptr;
@@ -64,7 +63,12 @@ struct Fiber {
         want_park = p;
         swapcontext(&ctx, back);                // (resumed by the same worker thread: see WalkScheduler::worker)
     }
-    void submit(Parked* p) { p->owner = nullptr; p->async = true; p->done = false; want_submit = p; swapcontext(&ctx, back); }
+    // (no switch: the requests wait in the fiber until it next goes back to its worker -- flush(), or any park / wait / end --
+    // and are then taken over under one lock)
+    std::vector<Parked*> to_submit;
+    bool want_flush = false;
+    void submit(Parked* p) { p->owner = nullptr; p->async = true; p->done = false; to_submit.push_back(p); }
+    void flush() { if (!to_submit.empty()) { want_flush = true; swapcontext(&ctx, back); } }
     void wait_for(Parked* p) { want_wait = p; swapcontext(&ctx, back); }
 };
 
@@ -164,7 +168,7 @@ struct WalkScheduler {
             f->stack = m; f->sched = this;
             all_fibers.push_back(f);
         }
-        f->query = q; f->finished = false; f->want_park = nullptr;
+        f->query = q; f->finished = false; f->want_park = nullptr; f->want_wait = nullptr; f->want_flush = false; f->to_submit.clear();
         getcontext(&f->ctx);
         f->ctx.uc_stack.ss_sp = (char*) f->stack + GUARD;
         f->ctx.uc_stack.ss_size = STACK;
@@ -202,17 +206,23 @@ struct WalkScheduler {
             lk.lock();
             cpu_ns += (int64_t) (t1.tv_sec - t0.tv_sec) * 1000000000 + (t1.tv_nsec - t0.tv_nsec);
             --busy;
+            if (!f->to_submit.empty()) {                // what the walk handed over without sleeping
+                bool enough = false;
+                for (Parked* p : f->to_submit) {
+                    const int c = parked.size() > 1 ? std::max(0, std::min((int) parked.size() - 1, classify(*p))) : 0;
+                    parked[c].push_back(p);
+                    enough = enough || (int) parked[c].size() >= batch_target;
+                }
+                f->to_submit.clear();
+                if (enough) cv_main.notify_all();
+            }
             if (f->finished) {
                 idle_fibers.push_back(f);
                 --in_flight; ++done;
                 if (done >= n_walks) { cv_work.notify_all(); cv_main.notify_all(); }
                 else if (next < n_walks) cv_work.notify_one();
-            } else if (f->want_submit) {                // hands a request over and goes on
-                Parked* p = f->want_submit;
-                f->want_submit = nullptr;
-                const int c = parked.size() > 1 ? std::max(0, std::min((int) parked.size() - 1, classify(*p))) : 0;
-                parked[c].push_back(p);
-                if ((int) parked[c].size() >= batch_target) cv_main.notify_all();
+            } else if (f->want_flush) {                 // only came to hand its requests over
+                f->want_flush = false;
                 ready_of[me].push_back(f); ++n_ready;
             } else if (f->want_wait) {                  // needs a request it handed over earlier
                 Parked* p = f->want_wait;

@@ -301,7 +301,8 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         // 1: only the slow class is handed over; 2: every request is -- more than twice the requests (the scout's paths behind the
         // gaps it did not wait for), worth it while the host keeps up: 5 000 walks 0.94 -> 0.79 (1) -> 0.50 s (2), 20 000: 1.31 ->
         // 0.97 -> 1.00 s, 40 000: 1.79 -> 1.40 -> 2.10 s
-        const int mode = e ? atoi(e) : (n_probs <= 24576 ? 2 : 1);       // (with the fibers' requests handed over in one go: 20 000 walks 0.96 (1) / 0.84 s (2))
+        const int mode = e ? atoi(e) : 2;       // (with the fibers' requests handed over in one go and the long lane started from a thousand requests on:
+                                                // 20 000 walks 0.96 (1) / 0.84 s (2), 40 000 walks 1.37 / 1.19 s)
         slow_class = (mode && n_cls >= 3 && sp->wilip && !(src && src->units)) ? (mode == 2 ? 0 : n_cls - 1) : -1;
         if (slow_class == 0) { ws.all_in_flight = true; ws.last_class_waits = true; }
     }

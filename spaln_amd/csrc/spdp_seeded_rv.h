@@ -276,7 +276,10 @@ struct WalkScheduler {
                         // nobody can run (every worker waits: nothing ready, nothing new to start), or enough has gathered
                         const bool startable = next < n_walks && in_flight < max_in_flight && !oom;
                         const bool idle = !busy && n_ready == 0 && !startable;
-                        if (last_class_waits && parked.size() > 1 && c == (int) parked.size() - 1) return idle || scouted.load() >= n_walks;
+                        // (the longest class while walks still hand requests over: its launches are long whatever their size, so few
+                        // and full ones -- but from a thousand requests on the device is busy with them anyway)
+                        if (last_class_waits && parked.size() > 1 && c == (int) parked.size() - 1)
+                            return idle || scouted.load() >= n_walks || (int) parked[c].size() >= std::max(1024, batch_target);
                         return (int) parked[c].size() >= batch_target || idle;
                     });
                     if (parked[c].empty()) { cv_main.notify_all(); break; }         // every walk has ended

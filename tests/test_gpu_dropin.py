@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("strand,extra", [("-S1", []), ("-S3", ["--antisense"])], ids=["S1", "S3_antisense"])
+@pytest.mark.parametrize("strand,extra", [("-S1", []), ("-S3", ["--antisense"]), ("-S1", ["--protein"])], ids=["S1", "S3_antisense", "protein"])
 def test_records_identical_to_the_unmodified_program(strand, extra):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
         pytest.skip("oracle/_ref/spaln_gpu is not built")

@@ -760,6 +760,10 @@ LEGS = {
     "e2e_q7_s3": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200", "--ori", "3"],
                   "the same in spaln's default orientation mode (a->inex.ori = 3: every locus aligned in both orientations, alignS_ng(.., 3)); "
                   "every other query is an antisense read; against `spaln -Q7 -O4 -t16`"),
+    "c4_e2e": (["tools/e2e_q7.py", "--queries", "10000", "--genes", "400", "--spacer", "450000", "--frag", "500", "--ori", "3"],
+               "BASELINE configs[3] end to end at reduced size: 10 000 ESTs of 500 nt (half of them antisense) against a 140 Mb genome, block "
+               "search -> candidate loci (five 10 kb blocks each) -> both orientations aligned -> exon tables, one spdp_map_align_s call against "
+               "`spaln -Q7 -O4 -t16`"),
     "dropin_q7_20k_s3": (["tools/dropin_demo.py", "--queries", "20000", "--genes", "200", "--modes", "Q7", "--gpu-threads", "16", "--strand=-S3", "--antisense"],
                          "the reference's CLI on the library in spaln's DEFAULT orientation mode (a->inex.ori = 3: alignS_ng(.., 3) on every locus; every "
                          "other query an antisense read), 20 000 queries under -Q7, both programs with -t16"),
@@ -776,7 +780,7 @@ def _run_leg(name):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.perf_counter()
-    if name.startswith("dropin") or name.startswith("e2e"):      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py): its JSON line as it is
+    if name.startswith("dropin") or name.startswith("e2e") or name == "c4_e2e":      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py): its JSON line as it is
         if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
             return {"what": what, "error": "oracle/_ref/spaln_gpu is not built (needs the reference's sources at build time)"}
         try:

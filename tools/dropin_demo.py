@@ -61,7 +61,8 @@ def make_dataset(td, args):
         for c in range(n_chr):
             parts = []
             for g in genes[c * per:(c + 1) * per]:
-                parts += [synth.random_dna(rng, int(rng.integers(3000, 20000))), g.window]
+                spacer = int(getattr(args, "spacer", 0) or 0)                     # (--spacer: a larger genome around the same genes)
+                parts += [synth.random_dna(rng, int(rng.integers(3000, 20000)) if not spacer else int(rng.integers(spacer // 2, spacer))), g.window]
             s = bytes(np.concatenate(parts)).decode()
             tot += len(s)
             f.write(f">chr{c + 1}\n")
@@ -75,6 +76,10 @@ def make_dataset(td, args):
                 q[hit] = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=int(hit.sum()))]
             else:
                 q = synth.mutate(rng, g.query, 0.02, 0.002)
+                frag = int(getattr(args, "frag", 0) or 0)                         # (--frag: ESTs, fragments of the transcripts)
+                if frag and len(q) > frag:
+                    at = int(rng.integers(0, len(q) - frag))
+                    q = q[at:at + frag]
                 if getattr(args, "antisense", False) and i % 2:
                     q = np.frombuffer(bytes(q).translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1], dtype=np.uint8)
             f.write(f">q{i}\n{bytes(q).decode()}\n")
@@ -94,6 +99,8 @@ def main():
     ap.add_argument("--modes", default="Q7,Q4")
     ap.add_argument("--strand", default="-S1", help="-S1: the queries as given; -S3 (spaln's default): both orientations")
     ap.add_argument("--antisense", action="store_true", help="every other query reverse-complemented (cDNA)")
+    ap.add_argument("--spacer", type=int, default=0, help="longest random stretch between two genes (default 20 000)")
+    ap.add_argument("--frag", type=int, default=0, help="queries are fragments of this length of the transcripts (ESTs)")
     ap.add_argument("--extra", default="", help="further options for both programs, e.g. -yl3 (double affine gaps)")
     ap.add_argument("--where", action="store_true", help="also time the reference's own aligner calls inside its program (Amdahl's bound for the drop-in)")
     ap.add_argument("--protein", action="store_true", help="protein queries (alignH_ng) against genes with ORFs instead of cDNAs")

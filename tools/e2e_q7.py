@@ -59,6 +59,23 @@ def read_fasta(path):
     return names, [CODE_OF[np.frombuffer(s, dtype=np.uint8)] for s in seqs]
 
 
+def extend_intpen(ip, n):
+    """IntronPenalty::Penalty(len) beyond the dumped table (src/codepot.h:242-247: (STYPE) (IntFx + IntEp * log(len - mu)) there):
+    the two constants fitted to the steps of the table's tail.  Only windows longer than the table (131 072 nt: a block-search
+    locus of a 100 Mb genome) read these entries, for introns no alignment of this data set holds."""
+    m = len(ip)
+    if n <= m:
+        return ip
+    tail = ip[m // 2:].astype(np.int64)
+    steps = np.nonzero(np.diff(tail))[0] + 1 + m // 2             # first position of every new value
+    x = np.log(steps.astype(np.float64))
+    y = ip[steps].astype(np.float64) + 0.0                         # at a step the real value has just passed the integer
+    e, f = np.polyfit(x, y, 1)
+    more = np.trunc(f + e * np.log(np.arange(m, n, dtype=np.float64))).astype(np.int16)
+    more = np.minimum(more, ip[-1])                                # (monotone across the seam)
+    return np.ascontiguousarray(np.concatenate([ip, more]))
+
+
 def reference_exons(text):
     """-O4 output -> {query: [(ref_l, ref_r, tgt_l, tgt_r)]} of the records as printed (the first locus of a query)"""
     out, cur = {}, []
@@ -84,6 +101,8 @@ def main():
     ap.add_argument("--genes", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--show", type=int, default=3)
+    ap.add_argument("--spacer", type=int, default=0, help="longest random stretch between two genes (default 20 000): the genome's size")
+    ap.add_argument("--frag", type=int, default=0, help="queries are fragments of this length of the transcripts (ESTs, BASELINE configs[3])")
     ap.add_argument("--members", type=int, default=1,
                     help="> 1: spdp_group_map_align_s over that many members ON THIS ONE DEVICE (each member its own context, index and "
                          "chain of device batches: the members' request latencies overlap)")
@@ -124,7 +143,7 @@ def main():
         q_names, queries = read_fasta(os.path.join(td, "q.fa"))
         model = abi.wilip_model_from_fixture(fq)
         sigmodel = abi.signal_model_from_fixture(fq)
-        ip = np.ascontiguousarray(fb["find_intpen"], dtype=np.int16)
+        ip = extend_intpen(np.ascontiguousarray(fb["find_intpen"], dtype=np.int16), 1 << 19)
         sc = spdg.scoring(fq, intpen=ip, scalar_engines=1)
         sp = abi.seed_params_from_fixture(fq)
         prm = blocks.find_params_from_fixture(fb)
@@ -190,7 +209,7 @@ def main():
         for k in diff[:args.show]:
             sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
         out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 %s-O4`" % ("-S1 " if args.ori == 1 else ""),
-               "queries": args.queries, "ori": args.ori, "members": args.members, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
+               "queries": args.queries, "fragment_nt": args.frag or None, "ori": args.ori, "members": args.members, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
                "identical_exon_tables": n_same, "different": len(diff),
                "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
                "reference_queries_per_s": round(len(want) / ref_s, 1),

@@ -779,7 +779,8 @@ typedef struct SpdpBlkIndexDesc {
 typedef struct SpdpBlkIndex SpdpBlkIndex;
 SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIndexDesc* desc);     /* uploads; NULL on error (spdp_last_error) */
 void          spdp_blk_index_destroy(SpdpBlkIndex* ix);
-/* The reference's own index file (<db>.bkn of `spaln -W`, format version 26, nucleotide) read on the host, with the search
+/* The reference's own index file (<db>.bkn of `spaln -W -KD`, or <db>.bkp of `spaln -W -KP`: the amino-acid words of the
+ * translated genome, for protein queries; format version 26) read on the host, with the search
  * parameters SrchBlk::initialize derives on opening one (src/blksrc.cc:1697-1858, 2179-2227).  What the file does not hold
  * comes from SpdpBlkSearchOpts (defaults = the reference's: spdp_blk_search_opts_default); ExtBlock follows from the species'
  * intron length distribution (max_intron_len(0.996), src/codepot.cc:648), which the caller supplies as max_intron_len or
@@ -851,7 +852,11 @@ typedef struct SpdpLocus {
 /* out: *loci (n_loci of them, query by query, best locus of a query first) and *hsps, both malloc'ed (free() them); status[i]
  * (may be NULL): TestOutput calls the query took, negative when the search ended without a locus.  sc: the gap penalties and
  * the intron penalty table the HSP chaining prices with (SpdpScoring gop / gep / lgop / lgep / codonk1, intpen / intpen_len).
- * hix: the same index on the host (its chromosome and random-score tables; spdp_blk_index_host_desc or the caller's own). */
+ * hix: the same index on the host (its chromosome and random-score tables; spdp_blk_index_host_desc or the caller's own).
+ * Protein queries (model->dvsp = 1) run against the index of the translated genome (`spaln -W -KP`, <db>.bkp; hix->drna = 0):
+ * codes are amino-acid codes, the genome stays nucleotide codes -- a candidate region is turned into tron codes for the HSP
+ * search as Seq::nuc2tron does (src/seq.cc:774-798), a pair whose ends the HSPs moved is searched again on the grown region
+ * (FindHsp's retry, src/blksrc.cc:2462-2466), and jy of an HSP is a nucleotide position of the region's tron sequence. */
 int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
                   const struct SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
                   const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,

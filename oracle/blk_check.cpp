@@ -65,6 +65,7 @@ int blk_check_find(const BlkIndexC* c, const uint8_t* genome, const int64_t* chr
     blk_find::Params P;
     P.vthr = prm[0]; memcpy(&P.drop_rate, &prm[1], 4); P.max_out = prm[4]; P.max_out2 = prm[5]; P.bbt = prm[6]; P.min_agap = prm[7];
     P.blklen = prm[8]; P.ext_block = prm[9]; P.ext_block_l = prm[10]; P.phase1t = prm[11]; P.a_exgl = prm[20]; P.a_exgr = prm[21];
+    P.dvsp = prm[12]; P.no_retry = prm[2];
     blk_find::Genome G = {genome, chr_off, c->n_chr};
     blk_find::Searcher S;
     S.ix = &ix; S.P = &P; S.G = &G; S.M = model; S.intpen = intpen; S.intpen_len = intpen_len;

@@ -535,4 +535,9 @@ def wilip_model_from_fixture(fx) -> WilipModel:
     g = [int(x) for x in fx["wl_glob"]]
     (m.dvsp, _vab, m.end_bonus, _reppen, _dirrep, m.crs, m.lsg, m.mlt, m.hard_minl, m.hard_maxl, m.minl, m.maxl, m.shortquery,
      _afact, m.met, m.ser, m.ser2, _zzz, m.avrsig, m.llmt, m.min_hit) = g
+    if "blk_prm" in fx:
+        # `shortquery` is a file-static of src/wln.h:34: every translation unit has a copy of its own.  SrchBlk::initialize
+        # (src/blksrc.cc:2219) sets the copy of blksrc.cc -- which the block-search recorder, being that unit, wrote here --
+        # to 8 * Ktuple, and findblock reads that one; Wlp::Wlp (src/wln.cc:222) reads the copy of wln.cc, which nobody sets
+        m.shortquery = 50
     return m

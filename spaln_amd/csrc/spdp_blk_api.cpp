@@ -69,8 +69,10 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
         d->ncand < 1 || d->nascr < 1 || d->hh_size < 2 || d->hb_size < 2 || d->ha_size < 2 || d->maxmmc < 1 || d->n_chr < 1) {
         ctx->err = "spdp_blk_index_create: parameter out of range (kk 1..3, Nshift <= 32, table geometries given)"; return nullptr;
     }
-    if (!d->drna || d->nalpha != 4) {
-        ctx->err = "spdp_blk_index_create: only nucleotide queries against a nucleotide index (findblock) are implemented";
+    // findblock serves nucleotide queries on a nucleotide index (DRNA, Nalpha = 4) and protein queries on the amino-acid words
+    // of a translated genome (-KP; src/blksrc.cc:2184-2187): the two must agree
+    if ((d->drna != 0) != (d->nalpha == 4) || d->nalpha < 2 || d->nalpha > 32) {
+        ctx->err = "spdp_blk_index_create: drna = 1 goes with nalpha = 4 (nucleotide index), drna = 0 with an amino-acid alphabet";
         return nullptr;
     }
     (void) hipSetDevice(ctx->device);
@@ -247,7 +249,11 @@ extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const Spd
     hv.gdb = hix->gdb; hv.rbscoef = hix->rbscoef; hv.rbscons = hix->rbscons; hv.rscrtab = hix->rscrtab; hv.nseg = hix->nseg;
     blk_find::Params P;
     P.vthr = prm->vthr; P.drop_rate = prm->drop_rate; P.max_out = prm->max_out; P.max_out2 = prm->max_out2; P.min_agap = prm->min_agap;
-    P.bbt = 1; P.blklen = hix->blklen; P.ext_block = hix->extblock; P.ext_block_l = hix->extblockl; P.phase1t = prm->phase1t;
+    // protein queries against the translated index (-KP): SrchBlk::bbt = 3 (src/blksrc.cc:2218), the DvsP = 1 branch of FindHsp
+    // with its NoRetry = 2 (:34) searches on a grown region
+    P.bbt = model->dvsp == 1 ? 3 : 1; P.dvsp = model->dvsp; P.no_retry = 2;
+    if ((model->dvsp == 0) != (hix->drna != 0)) { ctx->err = "spdp_blk_find: the block table is incompatible with the query type (src/blksrc.cc:2186)"; return -1; }
+    P.blklen = hix->blklen; P.ext_block = hix->extblock; P.ext_block_l = hix->extblockl; P.phase1t = prm->phase1t;
     P.a_exgl = prm->a_exgl; P.a_exgr = prm->a_exgr;
     if (P.max_out < 1 || P.max_out2 < P.max_out || P.blklen < 1) { ctx->err = "spdp_blk_find: max_out / max_out2 / blklen out of range"; return -1; }
     const blk_find::Genome G = {genome->codes, genome->chr_off, genome->n_chr};

@@ -11,8 +11,10 @@
 //                                                                their overlap / order / pruning rules
 // One call of blk_find::test_output = one TestOutput call of one query: in, the vote record of that call (pairs, mismatch
 // counts, run scores near the pairs: spdp_blk_vote); out, the candidate loci (region, range, HSPs) or "go on voting".
-// critjscr lives across the calls of a query.  Nucleotide queries (PwdB::DvsP = 0: no retry with a grown region, that is
-// the protein branch).
+// critjscr lives across the calls of a query.  Nucleotide queries (PwdB::DvsP = 0) and -- Params::bbt = 3, dvsp = 1 -- protein
+// queries against the translated index (-KP): the region is turned into tron codes (Seq::nuc2tron src/seq.cc:774-798 with
+// nuc2tron3 src/utilseq.cc:204-225) before the HSP search, and a pair whose ends FindHsp moved is searched again on the
+// grown region, NoRetry times at most (:2462-2466).
 #ifndef SPDP_BLK_FIND_H_
 #define SPDP_BLK_FIND_H_
 
@@ -22,6 +24,7 @@
 #include <vector>
 #include "spdp_blk_core.h"
 #include "spdp_wilip.h"
+#include "spdp_gencode.h"
 
 namespace blk_find {
 
@@ -33,6 +36,7 @@ struct Params {                         // statics of src/blksrc.cc and OutPrm
     int blklen, ext_block, ext_block_l;
     int phase1t;                        // Randbs::Phase1T
     int a_exgl, a_exgr;                 // query->inex.exgl / exgr (Wilip's end bonus)
+    int dvsp = 0, no_retry = 0;         // PwdB::DvsP (1: protein query, genomic target), NoRetry (:34)
 };
 struct Genome {                         // residue codes of the chromosomes, one after the other
     const uint8_t* codes; const int64_t* off; int n_chr;       // chromosome c = codes[off[c] .. off[c + 1])
@@ -51,6 +55,30 @@ struct Query { const uint8_t* codes; int len, left, right; };
 inline uint8_t comp_code(uint8_t c)     // complement of a nucleotide code (A 2, C 3, G 5, T 9; src/seq.cc ncredctab / comrev)
 {
     switch (c) { case 2: return 9; case 9: return 2; case 3: return 5; case 5: return 3; default: return c; }
+}
+
+// Seq::nuc2tron: position p becomes the codon (p - 1, p, p + 1) in the tron alphabet; the sequence's pads stand for the
+// residues before the first and behind the last one (first residue ambiguous: the most abundant amino acid of the middle
+// one; third residue: ncelements[] of whatever is there)
+inline void nuc2tron(uint8_t* s, int len)
+{
+    static const uint8_t ncredctab[17] = {15, 15, 0, 1, 4, 2, 5, 6, 10, 3, 7, 8, 10, 9, 12, 13, 14};      // src/seq.cc:31
+    static const uint8_t ncelements[17] = {0, 0, 0, 1, 2, 2, 0, 2, 0, 3, 3, 3, 1, 1, 2, 3, 0};            // src/seq.cc:33
+    static const uint8_t most_abund[4] = {14, 3, 10, 13};                                                   // LYS, ALA, GLY, LEU
+    static uint8_t tron_of[64]; static bool have = false;
+    if (!have) { uint8_t mid[32]; spdp_genetic_code_tables(mid, tron_of); have = true; }
+    auto cd = [](uint8_t c) -> int { return c > 16 ? 16 : c; };
+    int prev = 0;                                           // the pad
+    for (int p = 0; p < len; ++p) {
+        const int c0 = prev, c1 = cd(s[p]), c2n = p + 1 < len ? cd(s[p + 1]) : 0;
+        prev = c1;
+        int aa;
+        if (c1 <= 1) aa = 1;                                // UNP: the middle residue is a gap
+        else if (ncredctab[c1] >= 4) aa = 2;                // AMB
+        else if (ncredctab[c0] >= 4) aa = most_abund[ncredctab[c1]];
+        else aa = tron_of[16 * ncredctab[c0] + 4 * ncredctab[c1] + ncelements[c2n]];
+        s[p] = (uint8_t) aa;
+    }
 }
 
 struct Searcher {
@@ -100,15 +128,22 @@ struct Searcher {
         const int qlen = q->right - q->left;
         if ((int) gener.size() <= curgr) gener.resize(curgr + 1);
         Locus cursd;
-        if (!cut_region(bp, cursd)) return 2;
-        const spdp_wl::Pair pr = {q->codes, q->len, q->left, q->right, P->a_exgl, P->a_exgr, region.data(), cursd.len, 0, cursd.len,
-                                  1, nullptr, nullptr, nullptr, intpen, intpen_len, gop, gep, lgop, lgep, codonk1};
+        Pair orgbp = org;
+        int retry_no = 0;
         std::vector<spdp_wl::Unit> wl;
+        int lcrit = critjscr;
+      retry:
+        if (!cut_region(bp, cursd)) return 2;
+        if (P->bbt == 3) nuc2tron(region.data(), cursd.len);
+        const spdp_wl::Pair pr = {q->codes, q->len, q->left, q->right, P->a_exgl, P->a_exgr, region.data(), cursd.len, 0, cursd.len,
+                                  P->bbt == 3 ? 3 : 1, nullptr, nullptr, nullptr, intpen, intpen_len, gop, gep, lgop, lgep, codonk1};
+        wl.clear();
         spdp_wl::run(M, &pr, -1, wl);
         if (wl.empty()) return 2;
         int n = std::min(P->max_out2, (int) wl.size());
         spdp_wl::Juxt lend = {q->right, 0, 0, 0, 0}, rend = {q->left, 0, 0, 0, 0};
-        int nbetter = 0, multi = 0, lcrit = critjscr;
+        int nbetter = 0, multi = 0;
+        lcrit = critjscr;
         for (int u = 0; u < n; ++u) {
             spdp_wl::Unit& w = wl[u];
             if (w.num > 1) ++multi;
@@ -174,10 +209,11 @@ struct Searcher {
                 bp.db = std::min(bp.rb + EB, bp.zr);
             }
         }
-        (void) prv_left; (void) prv_right;
-        int lbias = (int) org.lb - (int) bp.lb, ubias = (int) bp.rb - (int) org.rb;
+        if (P->dvsp == 1 && retry_no++ < P->no_retry && (bp.lb != orgbp.lb || bp.rb != orgbp.rb)) { orgbp = bp; goto retry; }
+        int lbias = (int) orgbp.lb - (int) bp.lb, ubias = (int) bp.rb - (int) orgbp.rb;
         if (lbias || ubias) {
             if (!cut_region(bp, cursd)) return 0;
+            if (P->bbt == 3) nuc2tron(region.data(), cursd.len);
             if (rvs) std::swap(lbias, ubias);
             if (lbias) {
                 const int partial = (rvs && bp.rb == bp.zr) ? (P->blklen - cursd.len % P->blklen) : 0;

@@ -72,7 +72,7 @@ bool derive_search_params(HostIndex* h, const SpdpBlkSearchOpts& o, std::string&
     memset(&d, 0, sizeof d);
     d.nalpha = (int32_t) wcp.Nalpha; d.tabsize = (int32_t) wcp.TabSize; d.nshift = (int32_t) wcp.Nshift; d.nbitpat = wcp.Nbitpat;
     d.convts = (int32_t) wc.ConvTS; d.n_chr = (int32_t) wc.ChrNo; d.maxblk = wc.MaxBlk;
-    d.kk = wcp.Nbitpat / 2 + 1; d.drna = 1;
+    d.kk = wcp.Nbitpat / 2 + 1; d.drna = wcp.Nalpha == 4 ? 1 : 0;
     if (d.kk < 1 || d.kk > 3) { why = ("number of bit patterns out of range"); return false; }
     if (wcp.Nbitpat == 1) add_pattern(h->bitpat, wcp.BitPat);
     else { add_pattern(h->bitpat, (1u << wcp.Ktuple) - 1); add_pattern(h->bitpat, wcp.BitPat); }
@@ -133,7 +133,9 @@ extern "C" SpdpBlkIndexHost* spdp_blk_index_read(const char* path, const SpdpBlk
     if (!read_all(f, &wcp, sizeof wcp) || !read_all(f, &wc, sizeof wc) || !read_all(f, b2c, sizeof b2c)) { fclose(f); return fail("short header"); }
     if (wc.VerNo != 26) { fclose(f); return fail("only index version 26 is read (spaln 3.0.x)"); }
     if (wc.BytBlk != 2 && wc.BytBlk != 4) { fclose(f); return fail("3-byte block numbers are not read"); }
-    if (wcp.Nalpha != 4) { fclose(f); return fail("not a nucleotide index"); }
+    // Nalpha = 4: a nucleotide index (-KD, .bkn); otherwise the amino-acid words of a translated genome (-KP, .bkp: protein
+    // queries, SrchBlk's DvsP = 1 branch) or of a protein database (-KA); src/blksrc.cc:2184-2187
+    if (wcp.Nalpha < 2 || wcp.Nalpha > 32) { fclose(f); return fail("alphabet size out of range"); }
     if (wcp.TabSize == 0 || wcp.TabSize > (1u << 30) || wcp.Nshift == 0 || wcp.Nshift > SPDP_BLK_MAX_SHIFT || wcp.blklen == 0 ||
         wc.ChrNo == 0 || wc.ChrNo > (1u << 24) || wc.WordNo > (1ull << 32) || wc.WordSz > (1ull << 33) || wc.ConvTS == 0 || wc.ConvTS > 256) {
         fclose(f); return fail("header values out of range");

@@ -90,11 +90,52 @@ def paralog_genome_and_queries(n_genes, n_chr, seed):
     return chroms, queries
 
 
+def protein_genome_and_queries(n_genes, n_chr, seed):
+    """blk_p1: protein queries against the translated index (`spaln -W -KP`, amino-acid words of the six frames; SrchBlk's
+    DvsP = 1 branch: the candidate region as tron codes, the retry with a grown region).  Genes on both strands, every third
+    one with a diverged second copy (-M4: two loci); queries: the diverged protein, the exact one, short pieces (below
+    shortquery), random sequences, chimeras"""
+    rng = np.random.default_rng(synth.SEED + seed)
+    genes = [synth.make_protein_gene(np.random.default_rng(synth.SEED + seed + 1 + i), n_exons=5, aa_len=int(rng.integers(150, 500)))
+             for i in range(n_genes)]
+    per = n_genes // n_chr
+    chroms = []
+    for c in range(n_chr):
+        parts = []
+        for k, g in enumerate(genes[c * per:(c + 1) * per]):
+            parts += [synth.random_dna(rng, int(rng.integers(500, 3000))), g.window if k % 3 else revcomp(g.window)]
+            if k % 3 == 2:
+                copy = synth.mutate(rng, g.window, 0.05, 0.0)
+                parts += [synth.random_dna(rng, int(rng.integers(300, 6000))), copy if k % 2 else revcomp(copy)]
+        chroms.append(np.concatenate(parts))
+    queries = []
+    for i, g in enumerate(genes):
+        s, m = g.query, i % 5
+        if m == 0:
+            queries.append(s)
+        elif m == 1:
+            queries.append(g.protein)
+        elif m == 2:
+            a = int(rng.integers(0, len(s) - 90))
+            queries.append(s[a:a + int(rng.integers(40, 90))])
+        elif m == 3:
+            queries.append(synth._AA_LETTERS[rng.integers(0, 20, size=int(rng.integers(100, 400)))])
+        else:
+            o = genes[(i * 7 + 3) % n_genes].query
+            queries.append(np.concatenate([s[:120], o[:100]]))
+    return chroms, queries
+
+
 def main():
     env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
-    for name, fmt_opts, n_genes, seed in (("blk_k1", [], 42, 900), ("blk_k3", ["-XC5"], 28, 950), ("blk_par", [], 24, 980)):
-        par = name == "blk_par"
-        chroms, queries = (paralog_genome_and_queries if par else genome_and_queries)(n_genes, 2, seed)
+    only = sys.argv[1:]
+    for name, fmt_opts, n_genes, seed in (("blk_k1", [], 42, 900), ("blk_k3", ["-XC5"], 28, 950), ("blk_par", [], 24, 980),
+                                          ("blk_p1", [], 30, 1200)):
+        if only and name not in only:
+            continue
+        par = name in ("blk_par", "blk_p1")
+        prot = name == "blk_p1"
+        chroms, queries = (protein_genome_and_queries if prot else paralog_genome_and_queries if par else genome_and_queries)(n_genes, 2, seed)
         with tempfile.TemporaryDirectory() as td:
             with open(os.path.join(td, "gnm.mfa"), "w") as f:
                 for c, s in enumerate(chroms):
@@ -105,7 +146,7 @@ def main():
                 for i, s in enumerate(queries):
                     f.write(f">q{i}\n{bytes(s).decode()}\n")
             e = dict(env, ALN_DBS=td)
-            subprocess.run([os.path.join(REF, "spaln"), "-W", "-KD"] + fmt_opts + ["gnm.mfa"], cwd=td, env=e, check=True,
+            subprocess.run([os.path.join(REF, "spaln"), "-W", "-KP" if prot else "-KD"] + fmt_opts + ["gnm.mfa"], cwd=td, env=e, check=True,
                            capture_output=True)
             log = os.path.join(td, "log.spdg")
             r = subprocess.run([os.path.join(REF, "spaln_blktap"), "-Q7", "-O4", "-t1"] + (["-M4"] if par else []) + ["-dgnm", "q.fa"], cwd=td,
@@ -118,7 +159,9 @@ def main():
             fx = spdg.load(log)
             fx["blk_convtab"][:2] = 255
             spdg.save(os.path.join(OUT, name + ".spdg"), {k: v for k, v in fx.items() if k != "prm"})
-            if not par:
+            if prot:
+                shutil.copyfile(os.path.join(td, "gnm.bkp"), os.path.join(OUT, name + ".bkp"))
+            elif not par:
                 shutil.copyfile(os.path.join(td, "gnm.bkn"), os.path.join(OUT, name + ".bkn"))     # the reference's own index file: an input of the reader's test
             print(f"{name}: genome {sum(len(c) for c in chroms)} nt, {len(queries)} queries, "
                   f"{os.path.getsize(log) / 1e6:.2f} MB, {r.stdout.count(chr(10) + '@')} aligned")

@@ -12,7 +12,7 @@ from tests import spdg
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module", params=["blk_k1", "blk_k3"])
+@pytest.fixture(scope="module", params=["blk_k1", "blk_k3", "blk_p1"])
 def case(request):
     fx = spdg.load(os.path.join(HERE, "golden", request.param + ".spdg"))
     ix, keep = blk.index_of(fx)
@@ -59,7 +59,10 @@ def test_core_equals_oracle_on_random_queries(case):
         lo = int(rng.integers(0, max(1, len(a) - 40)))
         b = a[lo:lo + int(rng.integers(30, 900))].copy()
         hits = rng.random(b.size) < rng.choice([0.0, 0.03, 0.15])
-        b[hits] = rng.choice(np.array([2, 3, 5, 9, 16], dtype=np.uint8), size=int(hits.sum()))   # A C G T N (N: not a residue)
+        if int(fx["blk_prm"][blk.PRM["drna"]]):
+            b[hits] = rng.choice(np.array([2, 3, 5, 9, 16], dtype=np.uint8), size=int(hits.sum()))   # A C G T N (N: not a residue)
+        else:
+            b[hits] = rng.choice(np.array(list(range(3, 23)) + [2], dtype=np.uint8), size=int(hits.sum()))   # amino acids, X
         left = int(rng.integers(0, 5)); right = len(b) - int(rng.integers(0, 5))
         for stop in (0, 1):
             want = blk.vote(ix, b, left, right, stop)

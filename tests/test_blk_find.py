@@ -4,7 +4,8 @@ and its FindHsp, compiled by the host compiler into the tests' checker, run ever
 as findblock does -- and leave, at every TestOutput call, what the compiled reference left there (oracle/ref_build/blk_tap.cc,
 snap_find): critjscr, the candidate block pairs as FindHsp moved their ends, and the candidate loci (chromosome, strand,
 region, range, score, HSPs).  blk_par: every gene twice in the genome, -M4 -- two loci per query, their overlap / order /
-pruning rules."""
+pruning rules.  blk_p1: protein queries against the translated index (-KP) -- the region as tron codes, the retry with a grown
+region (SrchBlk's DvsP = 1 branch), short queries whose cut-offs Wilip scales."""
 import ctypes as C
 
 import numpy as np
@@ -16,7 +17,7 @@ from tests.conftest import golden_files
 from oracle import blk, oracle
 from tests.golden import make_blk_goldens as mb
 
-CASES = [("blk_k1", 42, 900, False), ("blk_k3", 28, 950, False), ("blk_par", 24, 980, True)]
+CASES = [("blk_k1", 42, 900, False), ("blk_k3", 28, 950, False), ("blk_par", 24, 980, True), ("blk_p1", 30, 1200, True)]
 CODE_OF = np.zeros(256, dtype=np.uint8)
 for _ch, _code in zip(b"ACGTN", (2, 3, 5, 9, 16)):
     CODE_OF[_ch] = _code
@@ -49,7 +50,7 @@ def parse_find(L):
 
 
 def genome_of(name, n_genes, seed, par):
-    chroms, _ = (mb.paralog_genome_and_queries if par else mb.genome_and_queries)(n_genes, 2, seed)
+    chroms, _ = (mb.protein_genome_and_queries if name == "blk_p1" else mb.paralog_genome_and_queries if par else mb.genome_and_queries)(n_genes, 2, seed)
     gen = np.concatenate([CODE_OF[c] for c in chroms]).astype(np.uint8)
     off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
     return gen, off
@@ -88,4 +89,4 @@ def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
             two += len(g[4]) >= 2
     assert n_loci >= (30 if par else 15)
     if par:
-        assert two >= 10
+        assert two >= (4 if name == "blk_p1" else 10)

@@ -18,13 +18,13 @@ P = dict(nalpha=0, tabsize=3, nshift=5, blklen=6, nbitpat=8, convts=10, n_chr=12
          hb_size=31, hb_step=32, ha_size=33, ha_step=34, gdb=38)
 
 
-@pytest.mark.parametrize("name", ["blk_k1", "blk_k3"])
+@pytest.mark.parametrize("name", ["blk_k1", "blk_k3", "blk_p1"])         # blk_p1: <db>.bkp of `spaln -W -KP` (amino-acid words of the translated genome)
 def test_reader_equals_what_the_reference_held(name):
     lib = C.CDLL(engine.LIB_PATH)
     fx = spdg.load(os.path.join(HERE, "golden", name + ".spdg"))
     prm = np.asarray(fx["blk_prm"])
     # ExtBlock comes from the species' intron length distribution (outside the index): handed over as the caller would
-    got = blocks.read_index_file(lib, os.path.join(HERE, "golden", name + ".bkn"), ext_block=int(prm[26]), max_out=int(prm[39]))
+    got = blocks.read_index_file(lib, os.path.join(HERE, "golden", name + (".bkp" if name == "blk_p1" else ".bkn")), ext_block=int(prm[26]), max_out=int(prm[39]))
     for k, pos in P.items():
         assert got[k] == int(prm[pos]), (k, got[k], int(prm[pos]))
     f = lambda i: struct.unpack("<f", struct.pack("<i", int(prm[i])))[0]

@@ -19,7 +19,7 @@ def eng():
     e.close()
 
 
-@pytest.fixture(scope="module", params=["blk_k1", "blk_k3"])
+@pytest.fixture(scope="module", params=["blk_k1", "blk_k3", "blk_p1"])      # blk_p1: protein queries, the translated index (-KP)
 def case(request, eng):
     fx = spdg.load(os.path.join(HERE, "golden", request.param + ".spdg"))
     ix, keep = oblk.index_of(fx)
@@ -65,8 +65,10 @@ def test_device_equals_recorded_reference_runs(case):
 
 
 def test_findblock_end_is_reported(case):
-    _, ix, _, qs, dix = case
+    fx, ix, _, qs, dix = case
     sel = [q for q in qs if len(q["calls"]) == ix.minsigpr + 1]
+    if not sel and not int(fx["blk_prm"][oblk.PRM["drna"]]):
+        pytest.skip("no query of the protein fixture runs out of TestOutput calls")
     assert sel
     out, _ = dix.vote([q["codes"] for q in sel], [(q["left"], q["right"]) for q in sel], [len(q["calls"]) for q in sel])
     for i in range(len(sel)):
@@ -76,7 +78,8 @@ def test_findblock_end_is_reported(case):
 
 def test_device_equals_oracle_on_a_random_batch(case):
     """2000 fragments (exact, mutated, with Ns, pure noise), more queries than lanes of a small launch reuse their slabs"""
-    _, ix, _, qs, dix = case
+    fx, ix, _, qs, dix = case
+    letters = np.array([2, 3, 5, 9, 16] if int(fx["blk_prm"][oblk.PRM["drna"]]) else list(range(3, 23)) + [2], dtype=np.uint8)
     rng = np.random.default_rng(99)
     pool = [q["codes"] for q in qs]
     queries, ranges = [], []
@@ -85,7 +88,7 @@ def test_device_equals_oracle_on_a_random_batch(case):
         lo = int(rng.integers(0, max(1, len(a) - 40)))
         b = a[lo:lo + int(rng.integers(30, 700))].copy()
         hits = rng.random(b.size) < rng.choice([0.0, 0.02, 0.2, 1.0])
-        b[hits] = rng.choice(np.array([2, 3, 5, 9, 16], dtype=np.uint8), size=int(hits.sum()))
+        b[hits] = rng.choice(letters, size=int(hits.sum()))
         queries.append(b); ranges.append((int(rng.integers(0, 4)), len(b) - int(rng.integers(0, 4))))
     for stop in (0, 2):
         os.environ["SPDP_BLK_WAVES_PER_CU"] = "1" if stop else "16"
@@ -101,7 +104,7 @@ def test_device_equals_oracle_on_a_random_batch(case):
             w = oblk.split_recorded(want[0], want[1]); w["pairs"] = want[1][2:].reshape(-1, 9)
             assert same(got, w, exact_pairs=True), (i, stop)
             n += 1
-        assert n > 300
+        assert n > (300 if int(fx["blk_prm"][oblk.PRM["drna"]]) else 150)       # (fewer protein fragments reach a TestOutput call)
     os.environ.pop("SPDP_BLK_WAVES_PER_CU", None)
 
 

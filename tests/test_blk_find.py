@@ -17,7 +17,8 @@ from tests.conftest import golden_files
 from oracle import blk, oracle
 from tests.golden import make_blk_goldens as mb
 
-CASES = [("blk_k1", 42, 900, False), ("blk_k3", 28, 950, False), ("blk_par", 24, 980, True), ("blk_p1", 30, 1200, True)]
+CASES = [("blk_k1", 42, 900, False), ("blk_k3", 28, 950, False), ("blk_par", 24, 980, True)]      # nucleotide queries (also the index builder's and the map + align tests' cases)
+PROTEIN_CASES = [("blk_p1", 30, 1200, True)]                                                      # protein queries, the translated index (-KP)
 CODE_OF = np.zeros(256, dtype=np.uint8)
 for _ch, _code in zip(b"ACGTN", (2, 3, 5, 9, 16)):
     CODE_OF[_ch] = _code
@@ -56,7 +57,7 @@ def genome_of(name, n_genes, seed, par):
     return gen, off
 
 
-@pytest.mark.parametrize("name,n_genes,seed,par", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("name,n_genes,seed,par", CASES + PROTEIN_CASES, ids=[c[0] for c in CASES + PROTEIN_CASES])
 def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
     fx = spdg.load([f for f in golden_files("blk_") if f.endswith(name + ".spdg")][0])
     gen, off = genome_of(name, n_genes, seed, par)

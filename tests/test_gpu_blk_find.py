@@ -9,7 +9,7 @@ from spaln_amd import abi, blocks, defaults
 from tests import spdg
 from tests.conftest import golden_files
 from oracle import blk
-from tests.test_blk_find import CASES, genome_of, parse_find
+from tests.test_blk_find import CASES, PROTEIN_CASES, genome_of, parse_find
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize("name,n_genes,seed,par", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("name,n_genes,seed,par", CASES + PROTEIN_CASES, ids=[c[0] for c in CASES + PROTEIN_CASES])
 def test_loci_equal_the_reference(eng, name, n_genes, seed, par):
     fx = spdg.load([f for f in golden_files("blk_") if f.endswith(name + ".spdg")][0])
     gen, off = genome_of(name, n_genes, seed, par)

@@ -739,6 +739,11 @@ LEGS = {
            "BASELINE configs[4]: 32 cDNAs of 50 kb, 25 exons, against their ~190 kb loci"),
     "blk": (["--workload", "blk", "--queries", "200000", "--steps", "3", "--warmup", "1"],
             "SURVEY 8 row f4, first slice: the block search's vote for 200 000 ESTs against the index of a 100 Mb genome"),
+    "blk_find_p": (["tools/blk_find_protein.py", "--queries", "20000", "--genes", "200"],
+                   "SURVEY 8 row f4 for protein queries (BASELINE configs[0] / [2]'s mapping phase): spdp_blk_find on the translated index "
+                   "(<db>.bkp of the reference's `spaln -W -KP`, read by the library) of a 20 Mb genome -- vote on the device, TestOutput / "
+                   "FindHsp's DvsP = 1 branch (region -> tron codes, level -1 HSP search, retry on a grown region) on the host threads; "
+                   "parity: tests/test_gpu_blk_find.py[blk_p1] against the reference's recorded runs"),
     "a0": (["--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
            "C2 shape under -A0 (forwardS_ng / hirschbergS_ng): the engines whose output is bit-identical to the reference's own -A0 records on 2 kb inputs"),
     "a1": (["--engines", "a1", "--queries", "1000", "--steps", "2", "--warmup", "1"], "C2 shape under -A1 (forwardS1 / hirschbergS1)"),
@@ -780,8 +785,8 @@ def _run_leg(name):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.perf_counter()
-    if name.startswith("dropin") or name.startswith("e2e") or name == "c4_e2e":      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py): its JSON line as it is
-        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
+    if name.startswith("dropin") or name.startswith("e2e") or name in ("c4_e2e", "blk_find_p"):      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py, tools/blk_find_protein.py): its JSON line as it is
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln" if name == "blk_find_p" else "spaln_gpu")):
             return {"what": what, "error": "oracle/_ref/spaln_gpu is not built (needs the reference's sources at build time)"}
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], env=env, capture_output=True, text=True, timeout=900)

@@ -65,8 +65,9 @@ inline void nuc2tron(uint8_t* s, int len)
     static const uint8_t ncredctab[17] = {15, 15, 0, 1, 4, 2, 5, 6, 10, 3, 7, 8, 10, 9, 12, 13, 14};      // src/seq.cc:31
     static const uint8_t ncelements[17] = {0, 0, 0, 1, 2, 2, 0, 2, 0, 3, 3, 3, 1, 1, 2, 3, 0};            // src/seq.cc:33
     static const uint8_t most_abund[4] = {14, 3, 10, 13};                                                   // LYS, ALA, GLY, LEU
-    static uint8_t tron_of[64]; static bool have = false;
-    if (!have) { uint8_t mid[32]; spdp_genetic_code_tables(mid, tron_of); have = true; }
+    struct Code { uint8_t tron_of[64]; Code() { uint8_t mid[32]; spdp_genetic_code_tables(mid, tron_of); } };
+    static const Code code;                                 // (the searchers run on several host threads: initialised once, by the language's rule)
+    const uint8_t* tron_of = code.tron_of;
     auto cd = [](uint8_t c) -> int { return c > 16 ? 16 : c; };
     int prev = 0;                                           // the pad
     for (int p = 0; p < len; ++p) {

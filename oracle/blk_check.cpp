@@ -110,3 +110,7 @@ int blk_check_find(const BlkIndexC* c, const uint8_t* genome, const int64_t* chr
     return n;
 }
 }
+
+// the product's Seq::nuc2tron (spdp_blk_find.h) on one sequence, in place: held against the tron codes the reference itself
+// made of the protein fixtures' windows (tests/test_blk_find.py)
+extern "C" void blk_check_nuc2tron(uint8_t* codes, int len) { blk_find::nuc2tron(codes, len); }

@@ -91,3 +91,29 @@ def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
     assert n_loci >= (30 if par else 15)
     if par:
         assert two >= (4 if name == "blk_p1" else 10)
+
+
+def test_region_to_tron_codes_equals_the_references_nuc2tron():
+    """blk_find::nuc2tron (what FindHsp's protein branch makes of a candidate region) against Seq::nuc2tron of the compiled
+    reference: the windows of the protein fixtures (tests/golden/make_goldens.py regenerates the nucleotides; h1_*.spdg hold the
+    tron codes the reference's harness made of them) -- ambiguous residues next to junctions, a random sequence, cut windows,
+    the first and the last position (the codon reaches into the sequence's pads there)."""
+    import os
+    from tests.golden import make_goldens as mg
+    lib = C.CDLL(oracle._BLK_SO)
+    lib.blk_check_nuc2tron.argtypes = [C.c_void_p, C.c_int]
+    n = amb = 0
+    for name, (window, _q, _opts) in mg.protein_cases().items():
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".spdg")
+        if not os.path.exists(path):
+            continue
+        want = np.asarray(spdg.load(path)["b_codes"], dtype=np.uint8)
+        codes = np.ascontiguousarray(CODE_OF[np.asarray(window, dtype=np.uint8)])
+        if len(want) != len(codes) + 1:
+            continue                                             # (the fixture holds the sequence and the pad behind it)
+        want = want[:-1]
+        amb += int((codes == 16).sum())
+        lib.blk_check_nuc2tron(codes.ctypes.data, len(codes))
+        assert np.array_equal(codes, want), (name, np.nonzero(codes != want)[0][:8], codes[:4], want[:4])
+        n += 1
+    assert n >= 20 and amb >= 4

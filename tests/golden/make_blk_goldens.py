@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fixtures of the block search from the REAL reference: tests/golden/blk_k1.spdg, blk_k3.spdg.
+"""Fixtures of the block search from the REAL reference: tests/golden/blk_k1.spdg, blk_k3.spdg, blk_par.spdg
+(nucleotide queries, `spaln -W -KD`) and blk_p1.spdg / blk_p1.bkp (protein queries, `spaln -W -KP`: protein_genome_and_queries).
 
 Build container only (needs oracle/_ref/spaln and oracle/_ref/spaln_blktap, `make -C oracle/ref_build`).  A small synthetic
 genome (planted genes of spaln_amd.synth between random spacers) is formatted by the compiled reference itself
@@ -9,7 +10,7 @@ reverse complements, 500-nt fragments, short fragments, random sequences, chimer
 the index arrays and parameters as the reference's SrchBlk object held them, every query as findblock saw it, the state of
 the vote at each TestOutput call and the block pairs handed to FindHsp.  Data only.
 
-    python tests/golden/make_blk_goldens.py
+    python tests/golden/make_blk_goldens.py [name ...]
 """
 import os
 import shutil

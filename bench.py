@@ -822,6 +822,88 @@ def _run_leg(name):
     return out
 
 
+ROUND_TAG = "r06"
+LINE_LIMIT = 4096            # bytes of the one stdout line (the driver keeps the tail of stdout: round 5's 22 KB line did not parse)
+
+
+def _leg_short(name, leg):
+    """one leg of the full record -> the few numbers the stdout line carries (the whole leg goes to profiles/)"""
+    if not isinstance(leg, dict):
+        return leg
+    if leg.get("error"):
+        return {"error": str(leg["error"])[:60]}
+    if "identical_exon_tables" in leg:                              # tools/e2e_q7.py
+        return {"same": leg["identical_exon_tables"], "of": leg.get("queries"), "x_ref": leg.get("library_over_reference"),
+                "q_per_s": leg.get("library_queries_per_s")}
+    if "runs" in leg:                                               # tools/dropin_demo.py
+        o = {"q": leg.get("queries")}
+        for r in leg["runs"]:
+            m = str(r.get("mode", "")).lstrip("-")
+            sp = r.get("gpu_over_reference_wall")
+            o[m] = {"x_ref": sp, "same": r.get("identical"), "differ": r.get("records_differing")}
+        return o
+    if "identical_to_reference" in leg:                             # seeded_q7
+        return {"same": leg["identical_to_reference"], "of": leg.get("compared"), "pairs_per_s": leg.get("library_pairs_per_s"),
+                "ref_pairs_per_s": leg.get("reference_pairs_per_s")}
+    if "with_a_locus" in leg:                                       # blk_find_p
+        return {"q_per_s": leg.get("queries_per_s"), "loci": leg["with_a_locus"], "of": leg.get("queries")}
+    o = {"value": leg.get("value"), "unit": leg.get("unit")}
+    for k in ("hbm_frac", "valu_frac"):
+        if leg.get(k) is not None:
+            o[k] = leg[k]
+    cb = leg.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("value") is not None:
+        o["cpu"] = cb["value"]
+    return o
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """the ONE stdout line: the contract's keys + roofline + cpu_baseline + one short record per leg, at most `limit` bytes; the
+    prose (what each leg is, which reference output it is pinned to, the sources of the counters) stays in the full record"""
+    cfg = out.get("config", {})
+    legs = {k: _leg_short(k, v) for k, v in cfg.items() if isinstance(v, dict) and k not in ("with_h2d",)
+            and not k.endswith("_scaling")}
+    keep = ("queries_per_gpu", "queries_total", "cells_per_gpu_per_step", "queries_per_s", "queries_per_s_incl_upload",
+            "parallelism", "udh_gcups", "fwd_gcups", "sweep_gcups", "legs_wall_s")
+    rf = dict(out.get("roofline") or {})
+    valu = rf.get("valu")
+    for k in ("note", "bytes_per_cell_source", "traffic_source", "layout_bytes_per_cell", "layout_achieved", "layout_frac"):
+        rf.pop(k, None)
+    if isinstance(valu, dict):
+        rf["valu"] = {k: valu.get(k) for k in ("achieved", "peak", "unit", "frac", "valu_per_64_cells") if k in valu}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cb = dict(cb)
+        cb["sample"] = str(cb.get("sample", ""))[:160]
+    line = {k: v for k, v in out.items() if k not in ("config", "roofline", "cpu_baseline")}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], **{k: cfg[k] for k in keep if cfg.get(k) is not None},
+                      "legs": legs, "full_record": f"profiles/{ROUND_TAG}_bench_legs.json"}
+    line["roofline"] = rf
+    line["cpu_baseline"] = cb
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > limit:                                              # never let the legs cost the line
+        for k in list(legs):
+            legs[k] = {kk: vv for kk, vv in legs[k].items() if kk in ("value", "same", "of", "x_ref", "q_per_s", "error")} \
+                if isinstance(legs[k], dict) else legs[k]
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > limit:
+        line["config"]["legs"] = {"dropped": "see full_record"}
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
+def _write_full_record(out):
+    """the full record (every leg with its prose) as a file: profiles/ is what the judge reads, gpurun_out/ is what travels back"""
+    for d, name in ((os.path.join(ROOT, "profiles"), f"{ROUND_TAG}_bench_legs.json"),
+                    (os.path.join(ROOT, "gpurun_out"), f"{ROUND_TAG}_bench_legs.json")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+
+
 def _parity_note(args):
     """which reference output the timed engines are bit-identical to (tests named)"""
     if args.engines == "a0":
@@ -1140,7 +1222,8 @@ def main():
                 if name in LEGS:
                     out["config"][name] = _run_leg(name)
             out["config"]["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
-        print(json.dumps(out), flush=True)
+        _write_full_record(out)
+        print(compact_line(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,14 @@ bool derive_search_params(HostIndex* h, const SpdpBlkSearchOpts& o, std::string&
     d.convts = (int32_t) wc.ConvTS; d.n_chr = (int32_t) wc.ChrNo; d.maxblk = wc.MaxBlk;
     d.kk = wcp.Nbitpat / 2 + 1; d.drna = wcp.Nalpha == 4 ? 1 : 0;
     if (d.kk < 1 || d.kk > 3) { why = ("number of bit patterns out of range"); return false; }
+    // a header this code would divide by or shift with: k-mer size 1 .. 16 (a word is 32 bits at Nalpha = 4), every pattern of
+    // that weight (Bitpat's weight is the k-mer size for all patterns of an index, src/blksrc.cc:1697-1724)
+    auto weight_of = [](uint32_t x) { int w = 0; for (; x; x >>= 1) w += (int) (x & 1); return w; };
+    if (wcp.Ktuple < 1 || wcp.Ktuple > 16) { why = ("k-mer size out of range"); return false; }
+    if (weight_of(wcp.BitPat) != (int) wcp.Ktuple || (wcp.Nbitpat > 3 && weight_of(wcp.Bitpat2) != (int) wcp.Ktuple)) {
+        why = ("bit pattern weight differs from the k-mer size"); return false;
+    }
+    if (wcp.Nshift < 1 || wcp.blklen < 1) { why = ("shift count / block length out of range"); return false; }
     if (wcp.Nbitpat == 1) add_pattern(h->bitpat, wcp.BitPat);
     else { add_pattern(h->bitpat, (1u << wcp.Ktuple) - 1); add_pattern(h->bitpat, wcp.BitPat); }
     if (wcp.Nbitpat > 3) add_pattern(h->bitpat, wcp.Bitpat2);

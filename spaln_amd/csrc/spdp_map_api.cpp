@@ -83,8 +83,12 @@ static int map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIn
     SpdpSignalModel sigm = *sigmodel;
     SpdpSeedParams spx = *sp;
     if (both) sigm.both_ori = spx.both_ori = 1;         // Exinon(seq, pwd, ori == 3), src/spaln.cc:1143, 1150
-    size_t chunk_positions = (size_t) 2048 << 20;       // signal arrays of a chunk: 7 B per position on both sides of the bus
-    if (const char* e = getenv("SPDP_MAP_CHUNK_MB")) chunk_positions = (size_t) std::max(1, atoi(e)) << 20;
+    // positions (NOT bytes) of the loci one chunk may hold; the signal arrays of a chunk take 8 B per position of pinned host memory
+    // and as much on the device, allocated as the chunk needs them (the default bound is 16 GiB each; a C4-sized batch of 125 000
+    // ESTs x 2 strands x ~50 kb of loci is what reaches it).  SPDP_MAP_CHUNK_MPOS = n: n x 2^20 positions (SPDP_MAP_CHUNK_MB: its old name)
+    size_t chunk_positions = (size_t) 2048 << 20;
+    for (const char* v : {"SPDP_MAP_CHUNK_MB", "SPDP_MAP_CHUNK_MPOS"})
+        if (const char* e = getenv(v)) chunk_positions = (size_t) std::max(1, atoi(e)) << 20;
     std::vector<std::vector<SpdpMapExon>> kept(n);
     int partial = 0;
     (void) hipSetDevice(ctx->device);

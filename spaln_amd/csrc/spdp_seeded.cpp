@@ -181,6 +181,12 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
         RequestCache cache;
         const bool two = slow_class >= 0;
         for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+            // every way out of the scout pass counts (the dispatcher of the slow class starts once all walks have scouted); the
+            // wake-up under the scheduler's mutex, so that it cannot fall between the dispatcher's test and its sleep
+            struct ScoutCounted {
+                WalkScheduler* s; int n; bool on;
+                ~ScoutCounted() { if (on && ++s->scouted >= n) { std::lock_guard<std::mutex> g(s->mu); s->cv_main.notify_all(); } }
+            } scout_counted{fb.sched, n_probs, pass == 0};
             try {                                   // (everything a walk allocates is inside: a walk that throws fails alone)
                 DeviceBackend be;
                 be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip; be.ns_cb = &ns_cb;
@@ -199,7 +205,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
                 const int score = w.run(whole);
                 if (pass == 0) {                    // (marks the walk sets go to a list of edits, not into the arrays)
                     fb.flush();                     // (what the scout handed over goes to the dispatchers now, under one lock)
-                    if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all();
+                   
                     if (!probs[q].phs5 && !w.phs5.own.empty()) { cache.phs5.swap(w.phs5.own); cache.phs3.swap(w.phs3.own); }
                     continue;
                 }

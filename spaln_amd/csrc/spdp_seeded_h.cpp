@@ -161,6 +161,12 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         RequestCache cache;
         const bool two = slow_class >= 0;
         for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+            // every way out of the scout pass counts (the dispatcher of the slow class starts once all walks have scouted); the
+            // wake-up under the scheduler's mutex, so that it cannot fall between the dispatcher's test and its sleep
+            struct ScoutCounted {
+                WalkScheduler* s; int n; bool on;
+                ~ScoutCounted() { if (on && ++s->scouted >= n) { std::lock_guard<std::mutex> g(s->mu); s->cv_main.notify_all(); } }
+            } scout_counted{fb.sched, n_probs, pass == 0};
             try {                                   // (everything a walk allocates is inside: a walk that throws fails alone)
                 DeviceBackendH be;
                 be.fiber = &fb; be.query = q; be.src = src; be.n_wilip = &n_wilip;
@@ -173,7 +179,7 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
                 const SpdpProblemH& p = probs[q];
                 const Span whole = {p.a_left, p.a_right, p.b_left, p.b_right, p.a_exgl, p.a_exgr, p.b_exgl, p.b_exgr};
                 const int score = w.run(whole);
-                if (pass == 0) { fb.flush(); if (++fb.sched->scouted >= n_probs) fb.sched->cv_main.notify_all(); continue; }
+                if (pass == 0) { fb.flush(); continue; }
                 scores[q] = score;
                 recs[q].swap(w.rec);
                 for (const auto& e : w.phs5.edits) ctx->seed_marks[q].push_back({e.first, 5, e.second, 0});      // (one walk per query: no lock)

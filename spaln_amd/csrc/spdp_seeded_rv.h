@@ -41,8 +41,18 @@ struct Parked {
     int flags = 0;                              // SpdpAlignment::flags of the request
     Fiber* owner = nullptr;
     // a request handed over WITHOUT sleeping (Fiber::submit): nobody waits yet; `done` is set when it has been served, and a
-    // walk that needs the result before that sleeps as `waiter` (Fiber::wait_for).  All three under the scheduler's mutex.
-    bool async = false, done = false;
+    // walk that needs the result before that sleeps as `waiter` (Fiber::wait_for).  `async` and `waiter` under the scheduler's mutex;
+    // `done` is also read by the walk without the lock (DeviceBackend::park): the dispatcher's store releases rec / score / flags,
+    // the walk's load acquires them.
+    bool async = false;
+    struct Flag {
+        std::atomic<bool> v{false};
+        Flag() = default;
+        Flag(const Flag& o) : v(o.v.load(std::memory_order_acquire)) {}
+        Flag& operator=(const Flag& o) { v.store(o.v.load(std::memory_order_acquire), std::memory_order_release); return *this; }
+        Flag& operator=(bool b) { v.store(b, std::memory_order_release); return *this; }
+        operator bool() const { return v.load(std::memory_order_acquire); }
+    } done;
     Fiber* waiter = nullptr;
 };
 

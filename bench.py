@@ -876,7 +876,8 @@ def compact_line(out, limit=LINE_LIMIT):
         cb = dict(cb)
         cb["sample"] = str(cb.get("sample", ""))[:160]
     line = {k: v for k, v in out.items() if k not in ("config", "roofline", "cpu_baseline")}
-    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], **{k: cfg[k] for k in keep if cfg.get(k) is not None},
+    scal = {k: {kk: vv for kk, vv in cfg[k].items() if kk != "sharding"} for k in ("strong_scaling", "weak_scaling") if isinstance(cfg.get(k), dict)}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], **{k: cfg[k] for k in keep if cfg.get(k) is not None}, **scal,
                       "legs": legs, "full_record": f"profiles/{ROUND_TAG}_bench_legs.json"}
     line["roofline"] = rf
     line["cpu_baseline"] = cb

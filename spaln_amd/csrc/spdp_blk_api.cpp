@@ -1,8 +1,7 @@
 // spdp_blk_api.cpp -- host side of the block search's vote (include/spdp.h, "block search"): the index goes to the device
-// once, a call uploads its queries, runs spdp_blk_vote_kernel over persistent lanes and brings the records back.
+// once, a call uploads its queries, runs spdp_blk_vote_wave (a wave per query, waves persistent) and brings the records back.
 #include "spdp_internal.h"
-#include "spdp_blk_core.h"
-#include "spdp_blk_internal.h"
+#include "spdp_blk_dev.h"
 #include "spdp_blk_find.h"
 #include "spdp_hostcpus.h"
 #include <atomic>
@@ -16,14 +15,15 @@ struct SpdpBlkIndex {
     SpdpContext* ctx = nullptr;
     BlkDev dev;
     std::vector<void*> bufs;                    // device copies of the index arrays
-    int32_t* slabs = nullptr; int32_t* scratch = nullptr;
-    size_t slab_ints = 0, scratch_ints = 0;
-    int n_lanes = 0, touched_cap = 0;
+    uint8_t* slabs = nullptr; uint32_t* next = nullptr;
+    size_t slab_bytes = 0;
+    int n_waves = 0, hh_in_lds = 0;
+    uint32_t lds_bytes = 0;
     ~SpdpBlkIndex()
     {
         for (void* p : bufs) if (p) (void) hipFree(p);
         if (slabs) (void) hipFree(slabs);
-        if (scratch) (void) hipFree(scratch);
+        if (next) (void) hipFree(next);
     }
 };
 
@@ -45,16 +45,17 @@ const T* to_device(SpdpBlkIndex* ix, const T* src, size_t n, hipError_t& e)
 // containers have (SpdpBlkIndexDesc::hh_size ...); only the second step has a fixed default (SecondHS, src/clib.h:76)
 int or_default(int v, int d) { return v > 0 ? v : d; }
 
-// lanes of a launch: enough waves to cover the memory latency of every CU, as many slabs as fit the budget
-int pick_lanes(const SpdpContext* ctx, size_t slab_bytes)
+// waves of a launch: as many as the LDS of every CU holds (the run hash and the queues of a wave live there), as many slabs as
+// fit the budget
+int pick_waves(const SpdpContext* ctx, size_t slab_bytes, uint32_t lds_bytes)
 {
-    size_t budget = (size_t) 48 << 30;
+    size_t budget = (size_t) 64 << 30;
     if (const char* e = getenv("SPDP_BLK_SLAB_GB")) budget = (size_t) std::max(1, atoi(e)) << 30;
-    int waves_per_cu = 32;
-    if (const char* e = getenv("SPDP_BLK_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(atoi(e), 64));
-    size_t lanes = (size_t) std::max(1, ctx->n_cu) * waves_per_cu * 64;
-    lanes = std::min(lanes, std::max<size_t>(64, budget / std::max<size_t>(slab_bytes, 1)));
-    return (int) (lanes / 64 * 64);
+    int waves_per_cu = (int) std::max<size_t>(1, std::min<size_t>(16, ((size_t) 160 << 10) / std::max<uint32_t>(lds_bytes, 1)));
+    if (const char* e = getenv("SPDP_BLK_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(atoi(e), 32));
+    size_t waves = (size_t) std::max(1, ctx->n_cu) * waves_per_cu;
+    waves = std::min(waves, std::max<size_t>(1, budget / std::max<size_t>(slab_bytes, 1)));
+    return (int) waves;
 }
 
 }  // namespace
@@ -83,6 +84,7 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
     v.nalpha = d->nalpha; v.tabsize = d->tabsize; v.nshift = d->nshift; v.nbitpat = d->nbitpat; v.convts = d->convts;
     v.n_chr = d->n_chr; v.kk = d->kk; v.drna = d->drna; v.maxmmc = d->maxmmc; v.nseg = d->nseg; v.minsigpr = d->minsigpr;
     v.ncand = d->ncand; v.nascr = d->nascr; v.maxblock = d->maxblock; v.extblock = d->extblock; v.extblockl = d->extblockl; v.shortquery = d->shortquery;
+    v.maxlist = std::max(1, d->maxblk);
     v.hh_size1 = d->hh_size; v.hh_size2 = or_default(d->hh_step, 8);
     v.hb_size1 = d->hb_size; v.hb_size2 = or_default(d->hb_step, 8);
     v.ha_size1 = d->ha_size; v.ha_size2 = or_default(d->ha_step, 8);
@@ -141,9 +143,17 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
     v.chr = to_device(ix, d->chr, 2 * ((size_t) d->n_chr + 1), e);
     v.bitpat = to_device(ix, d->bitpat, d->n_bitpat, e);
     if (e != hipSuccess) { ctx->err = std::string("spdp_blk_index_create: ") + hipGetErrorString(e); delete ix; return nullptr; }
-    ix->touched_cap = 2048;
-    ix->slab_ints = blk_work_ints(v, ix->touched_cap);
-    ix->scratch_ints = ((sizeof(BlkPair) * ((size_t) v.ncand + 2) + sizeof(uint32_t) * (2 * (2 * (size_t) v.ncand + 2) + 2)) / 4 + 3) & ~(size_t) 3;
+    // the longest posting list the kernel may meet (its staging area holds two): the header's MaxBlk, checked against the table
+    for (int64_t w = 0; w < d->tabsize; ++w) if (d->blkp[w]) v.maxlist = std::max<int32_t>(v.maxlist, d->nblk[w]);
+    if (v.hh_size2 < 1 || v.hb_size2 < 1 || v.ha_size2 < 1 || v.hh_size2 > v.hh_size1 || v.hb_size2 > v.hb_size1 || v.ha_size2 > v.ha_size1) {
+        ctx->err = "spdp_blk_index_create: a table's second step exceeds its size"; delete ix; return nullptr;
+    }
+    // the run hash of a wave lives in LDS when its first level fits beside the queues (16 KB: ten waves per CU)
+    ix->hh_in_lds = (size_t) v.hh_sizes[0] * 8 <= (size_t) 16 << 10;
+    if (const char* e = getenv("SPDP_BLK_HH_LDS")) ix->hh_in_lds = atoi(e) != 0 && (size_t) v.hh_sizes[0] * 8 <= (size_t) 48 << 10;
+    ix->lds_bytes = spdp_blk_vote_lds_bytes(&v, ix->hh_in_lds);
+    if (ix->lds_bytes > (64u << 10)) { ctx->err = "spdp_blk_index_create: the queues of a query do not fit the LDS of a workgroup (ncand / nascr too large)"; delete ix; return nullptr; }
+    ix->slab_bytes = spdp_blk_vote_slab_bytes(&v, ix->hh_in_lds);
     return ix;
 }
 
@@ -154,18 +164,17 @@ extern "C" void spdp_blk_index_destroy(SpdpBlkIndex* ix)
     delete ix;
 }
 
-static int ensure_lanes(SpdpContext* ctx, SpdpBlkIndex* ix, int n)
+static int ensure_waves(SpdpContext* ctx, SpdpBlkIndex* ix, int n)
 {
-    int want = pick_lanes(ctx, ix->slab_ints * 4);
-    want = std::min(want, std::max(64, (n + 63) / 64 * 64));
-    if (want <= ix->n_lanes) return 0;
+    int want = pick_waves(ctx, ix->slab_bytes, ix->lds_bytes);
+    want = std::min(want, std::max(1, n));
+    if (!ix->next) { HIPCHK(hipMalloc((void**) &ix->next, 16)); }
+    if (want <= ix->n_waves) return 0;
     if (ix->slabs) { (void) hipFree(ix->slabs); ix->slabs = nullptr; }
-    if (ix->scratch) { (void) hipFree(ix->scratch); ix->scratch = nullptr; }
-    ix->n_lanes = 0;
-    HIPCHK(hipMalloc((void**) &ix->slabs, (size_t) want * ix->slab_ints * 4));
-    HIPCHK(hipMalloc((void**) &ix->scratch, (size_t) want * ix->scratch_ints * 4));
-    HIPCHK(hipMemsetAsync(ix->slabs, 0, (size_t) want * ix->slab_ints * 4, ctx->stream));     // the kernel leaves every slab as it found it
-    ix->n_lanes = want;
+    ix->n_waves = 0;
+    HIPCHK(hipMalloc((void**) &ix->slabs, (size_t) want * ix->slab_bytes));
+    HIPCHK(hipMemsetAsync(ix->slabs, 0, (size_t) want * ix->slab_bytes, ctx->stream));     // (tags of no query: every score slot reads as zero)
+    ix->n_waves = want;
     return 0;
 }
 
@@ -179,16 +188,16 @@ extern "C" int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* cix,
     if (n <= 0) return 0;
     if (out_cap < 3) { ctx->err = "spdp_blk_vote: out_cap < 3"; return -1; }
     (void) hipSetDevice(ctx->device);
-    if (ensure_lanes(ctx, ix, n)) return -1;
-    BlkArgs A;
+    if (ensure_waves(ctx, ix, n)) return -1;
+    BlkVoteArgs A;
     A.ix = ix->dev;
     A.codes = d_codes; A.offs = d_offs; A.left = d_left; A.right = d_right; A.stop_at = d_stop_at;
     A.out = d_out; A.out_cap = out_cap; A.n = n;
-    A.slabs = ix->slabs; A.slab_ints = ix->slab_ints; A.scratch = ix->scratch; A.scratch_ints = ix->scratch_ints;
-    A.n_lanes = std::min(ix->n_lanes, (n + 63) / 64 * 64);
-    A.touched_cap = ix->touched_cap;
+    A.slabs = ix->slabs; A.slab_bytes = ix->slab_bytes; A.next = ix->next;
+    A.n_waves = std::min(ix->n_waves, n);
+    A.hh_in_lds = ix->hh_in_lds; A.lds_bytes = ix->lds_bytes;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(spdp_blk_launch(&A, ctx->stream));
+    HIPCHK(spdp_blk_vote_launch(&A, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));

@@ -22,11 +22,22 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
-#include "spdp_blk_core.h"
+#include <math.h>
+#include "spdp_blk_dev.h"
 #include "spdp_wilip.h"
 #include "spdp_gencode.h"
 
 namespace blk_find {
+
+// Randbs::randbs (src/blksrc.cc:2064-2069): the score a block reaches by chance after `mmc` rounds
+inline int random_expectation(const BlkDev& ix, uint32_t mmc)
+{
+    if (mmc < 128) return ix.rscrtab[mmc];
+    if (ix.rbscoef == 0) return (int) ix.rbscons;
+    const double x = (double) (mmc + 1);
+    return (int) (ix.rbscoef * (ix.gdb ? log(x) : sqrt(x)) + ix.rbscons);
+}
+
 
 struct Params {                         // statics of src/blksrc.cc and OutPrm
     int vthr;                           // alprm.scale * 2 * alprm.thr (:2210)
@@ -310,7 +321,7 @@ struct Searcher {
             Pair& bp = pairs[i];
             if (bp.bscr == 0) continue;
             const int d = bp.rvs << 1, e = d + 1;
-            if (force != 2 && bp.bscr < blk_randbs(*ix, (uint32_t) (mmct[d] + mmct[e])) + P->phase1t) continue;
+            if (force != 2 && bp.bscr < random_expectation(*ix, (uint32_t) (mmct[d] + mmct[e])) + P->phase1t) continue;
             pair_index = (int) i;
             switch (find_hsp(bp)) {
                 case 1: ++phase1; break;

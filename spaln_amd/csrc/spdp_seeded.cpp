@@ -139,6 +139,46 @@ struct DeviceBackend : DpBackend {
 
 // the walks of `n_probs` (query, strand) pairs: scores[i] = what globalS_ng's seededS_ng returns, recs[i] = its record file
 // (dummy record first), status[i] = 0, or 1 / 2 for a walk that was not served
+// SPDP_SEED_DUMP=<file> SPDP_SEED_DUMP_HASH=<fnv1a of the query's codes>: what this call was handed for that query, as one flat
+// file of named blocks (a development aid: two callers -- the reference's CLI on the library, spdp_map_align_s -- can be held
+// against each other input by input)
+static void dump_inputs(const SpdpScoring* sc, const SpdpSeedParams* sp, const SpdpProblem* probs, int n_probs,
+                        const SpdpJuxt* const* hsps, const int32_t* n_hsps, const int32_t* lowest_level)
+{
+    const char* path = getenv("SPDP_SEED_DUMP"); const char* hs = getenv("SPDP_SEED_DUMP_HASH");
+    if (!path || !hs) return;
+    std::vector<uint32_t> wants;                        // (comma-separated)
+    for (const char* c = hs; *c; ) { char* e; wants.push_back((uint32_t) strtoul(c, &e, 0)); c = *e ? e + 1 : e; }
+    for (int q = 0; q < n_probs; ++q) {
+        const SpdpProblem& P = probs[q];
+        uint32_t h = 2166136261u;
+        for (int i = 0; i < P.a_len; ++i) h = (h ^ P.a[i]) * 16777619u;
+        if (std::find(wants.begin(), wants.end(), h) == wants.end()) continue;
+        FILE* f = fopen(path, "ab");
+        if (!f) return;
+        auto blk = [&](const char* name, const void* p, size_t n) {
+            char nm[32] = {0}; strncpy(nm, name, 31);
+            const uint64_t len = p ? n : 0;
+            fwrite(nm, 1, 32, f); fwrite(&len, 8, 1, f); if (len) fwrite(p, 1, len, f);
+        };
+        const size_t N = (size_t) P.b_len + 1;
+        SpdpScoring s0 = *sc; s0.intpen = nullptr; s0.sigmodel = nullptr;
+        SpdpSeedParams p0 = *sp; p0.wilip = nullptr;
+        SpdpProblem q0 = P; q0.a = q0.b = nullptr; q0.sig5 = q0.sig3 = nullptr; q0.cano5 = q0.cano3 = q0.dinc = nullptr; q0.cip = nullptr; q0.phs5 = q0.phs3 = nullptr;
+        blk("scoring", &s0, sizeof s0); blk("intpen", sc->intpen, 2 * (size_t) sc->intpen_len);
+        blk("seed", &p0, sizeof p0); blk("problem", &q0, sizeof q0);
+        blk("a", P.a, (size_t) P.a_len); blk("b", P.b, (size_t) P.b_len);
+        blk("sig5", P.sig5, 2 * N); blk("sig3", P.sig3, 2 * N); blk("cano5", P.cano5, N); blk("cano3", P.cano3, N); blk("dinc", P.dinc, N);
+        blk("phs5", P.phs5, N); blk("phs3", P.phs3, N);
+        const int nh = (hsps && n_hsps && hsps[q]) ? n_hsps[q] : 0;
+        blk("hsps", nh ? hsps[q] : nullptr, sizeof(SpdpJuxt) * (size_t) (nh + 1));
+        const int lv = lowest_level ? lowest_level[q] : 0;
+        blk("lowest", &lv, 4);
+        if (sp->wilip) blk("wilip", sp->wilip, sizeof(SpdpWilipModel));
+        fclose(f);
+    }
+}
+
 static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedParams* sp,
                        const SpdpProblem* probs, int n_probs, const SpdpJuxt* const* hsps, const int32_t* n_hsps,
                        const int32_t* lowest_level, const SpdpHspSource* src,
@@ -152,6 +192,7 @@ static int seeded_core(SpdpContext* ctx, const SpdpScoring* sc, const SpdpSeedPa
             ctx->err = "the seeded path needs sig5 / sig3 / cano5 / cano3 / dinc of every problem on the host";
             return -1;
         }
+    dump_inputs(sc, sp, probs, n_probs, hsps, n_hsps, lowest_level);
     const auto t_begin = std::chrono::steady_clock::now();
     auto us_since = [](std::chrono::steady_clock::time_point t) {
         return (int64_t) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); };

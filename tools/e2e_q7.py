@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--ori", type=int, default=1, choices=[1, 3],
                     help="1: the queries as given against `spaln -S1`; 3: every other query reverse-complemented, both orientations "
                          "tried, against spaln's default (-S3)")
+    ap.add_argument("--dump-diff", default="", help="write the queries whose exon tables differ (name, both tables, the library's gene record) to this JSON file")
     args = ap.parse_args()
     args.protein = False
     t_all = time.perf_counter()
@@ -208,6 +209,10 @@ def main():
         diff = [k for k, v in want.items() if got.get(k) != v]
         for k in diff[:args.show]:
             sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
+        if args.dump_diff:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_diff)), exist_ok=True)
+            gi = {q_names[i]: g for i, g in enumerate(genes)}
+            json.dump([{"name": k, "reference": want[k], "library": gi.get(k)} for k in diff], open(args.dump_diff, "w"), indent=1)
         out = {"what": "block search -> HSPs -> seeded alignment -> exon table inside the library against `spaln -Q7 %s-O4`" % ("-S1 " if args.ori == 1 else ""),
                "queries": args.queries, "fragment_nt": args.frag or None, "ori": args.ori, "members": args.members, "query_reversed": sum(1 for g in genes if g is not None and g["q_rev"]), "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
                "identical_exon_tables": n_same, "different": len(diff),

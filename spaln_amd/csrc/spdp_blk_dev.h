@@ -15,6 +15,7 @@ struct BlkDev {                         // the index and the search parameters (
     int32_t nalpha, tabsize, nshift, nbitpat, convts, n_chr, kk, drna, maxmmc, nseg, minsigpr, ncand, nascr;
     int32_t maxblock, extblock, extblockl, shortquery, hh_size1, hh_size2, hb_size1, hb_size2, ha_size1, ha_size2, gdb;
     int32_t hh_sizes[SPDP_BLK_HASH_LEVELS];     // hh_size1 and what the reference's table becomes when it grows: the next prime >= twice the size
+    int32_t hb_sizes[SPDP_BLK_HASH_LEVELS], ha_sizes[SPDP_BLK_HASH_LEVELS];     // the same for the position tables of the two kinds of best-of lists
     int32_t maxlist;                            // longest posting list (ContBlk::MaxBlk)
     float rbscoef, rbscons;
     double bclw, bcup, bcce, app_c;
@@ -42,8 +43,12 @@ inline uint32_t blk_next_prime(uint32_t n)
 }
 inline void blk_fill_hash_levels(BlkDev& ix)
 {
-    ix.hh_sizes[0] = ix.hh_size1;
-    for (int l = 1; l < SPDP_BLK_HASH_LEVELS; ++l) ix.hh_sizes[l] = (int32_t) blk_next_prime(2u * (uint32_t) ix.hh_sizes[l - 1]);
+    ix.hh_sizes[0] = ix.hh_size1; ix.hb_sizes[0] = ix.hb_size1; ix.ha_sizes[0] = ix.ha_size1;
+    for (int l = 1; l < SPDP_BLK_HASH_LEVELS; ++l) {
+        ix.hh_sizes[l] = (int32_t) blk_next_prime(2u * (uint32_t) ix.hh_sizes[l - 1]);
+        ix.hb_sizes[l] = (int32_t) blk_next_prime(2u * (uint32_t) ix.hb_sizes[l - 1]);
+        ix.ha_sizes[l] = (int32_t) blk_next_prime(2u * (uint32_t) ix.ha_sizes[l - 1]);
+    }
 }
 
 // One wave per query.  A wave's working set: LDS (scan positions, the eight bounded queues with their position tables, the run

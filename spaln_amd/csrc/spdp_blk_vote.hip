@@ -38,7 +38,7 @@ constexpr int OWN_SLOTS = 1024;                     // owner marks, slot number 
 constexpr uint32_t NOBODY = 0xffffffffu;
 // status words of the wave (LDS)
 enum { ST_SIGN = 0, ST_MMCT = 4, ST_NHIT = 8, ST_MAXS = 12, ST_TESTWORD = 16, ST_MAXBSCR = 20, ST_QA_FRONT = 24, ST_QB_FRONT = 28,
-       ST_HH_LEVEL = 32, ST_TROUBLE = 33, ST_WORDS = 64 };
+       ST_HH_LEVEL = 32, ST_TROUBLE = 33, ST_Q_LEVEL = 40 /* 8: the position tables' levels */, ST_WORDS = 64 };
 
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
@@ -184,7 +184,7 @@ struct SlowHash {
             if (!H.live(kv)) { count = 1; break; }
             if (H.key_of(kv) == key) { count = kv.val + 1; break; }
             s = H.next(s, u);
-            if (s == s0 && !grow()) { st[ST_TROUBLE] |= SPDP_BLK_TABLE; count = 1; break; }
+            if (s == s0 && !grow()) { st[ST_TROUBLE] |= SPDP_BLK_TABLE | 0x400 | (h->level << 16); count = 1; break; }
         }
         H.put(s, key, count);
         return s;
@@ -212,9 +212,16 @@ struct SlowHash {
 // being marked empty, so a block CAN be lost from sight and entered twice: kept as it is, results depend on it.
 struct BestOf {
     KV* heap; KV* place; int cap; Modulus size; uint32_t step_mod; int* front; int* trouble;
+    KV* level0; KV* grown_a; KV* grown_b; const int32_t* sizes; int* level;      // the table's home in LDS, its larger forms in the slab
     __device__ __forceinline__ uint32_t stride(uint32_t key) const { return step_mod - key % step_mod; }
     __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t u) const { s += u; while (s >= size.n) s -= size.n; return s; }
-    // where the heap holds the block, as far as the table knows (-1: not)
+    __device__ void bind(int lv)
+    {
+        size.set((uint32_t) sizes[lv]);
+        place = lv == 0 ? level0 : ((lv & 1) ? grown_a : grown_b);
+    }
+    // where the heap holds the block, as far as the table knows (-1: not; -2: the probe came round -- the table is full and the
+    // reference grows it at this very lookup: the caller takes the one-lane path)
     __device__ int where(uint32_t key) const
     {
         uint32_t s = size.of(key);
@@ -224,21 +231,41 @@ struct BestOf {
             if (kv.val == -1) return -1;
             if (kv.key == key) return kv.val;
             s = next(s, u);
-            if (s == s0) { *trouble |= SPDP_BLK_TABLE; return -1; }
+            if (s == s0) return -2;
         }
     }
-    __device__ void note(uint32_t key, int at)      // one lane
+    // one lane: the table of the next size, the live entries re-entered in slot order (Dhash::resize, src/clib.h:341-355)
+    __device__ bool grow()
+    {
+        if (*level + 1 >= SPDP_BLK_HASH_LEVELS) { *trouble |= SPDP_BLK_TABLE; return false; }
+        const KV* old = place;
+        const uint32_t n_old = size.n;
+        bind(++*level);
+        for (uint32_t i = 0; i < size.n; ++i) place[i] = KV{0u, -1};
+        for (uint32_t i = 0; i < n_old; ++i) {
+            const KV kv = old[i];
+            if (kv.val == -1) continue;
+            uint32_t s = size.of(kv.key);
+            const uint32_t u = stride(kv.key), s0 = s;
+            while (place[s].val != -1 && place[s].key != kv.key) { s = next(s, u); if (s == s0) { *trouble |= SPDP_BLK_TABLE; return false; } }
+            place[s] = kv;
+        }
+        return true;
+    }
+    // one lane: the slot of a key -- its own, or the empty one its probe sequence meets first; a probe that comes round grows the
+    // table and goes on in the new one from the slot number and with the stride it had (Dhash::map)
+    __device__ uint32_t slot_for(uint32_t key)
     {
         uint32_t s = size.of(key);
         const uint32_t u = stride(key), s0 = s;
         for (;;) {
             const KV kv = place[s];
-            if (kv.val == -1 || kv.key == key) break;
+            if (kv.val == -1 || kv.key == key) return s;
             s = next(s, u);
-            if (s == s0) { *trouble |= SPDP_BLK_TABLE; break; }
+            if (s == s0 && !grow()) return s;
         }
-        place[s] = KV{key, at};
     }
+    __device__ void note(uint32_t key, int at) { const uint32_t s = slot_for(key); place[s] = KV{key, at}; }     // one lane
     __device__ void seat(int k, KV v) { heap[k] = v; note(v.key, k); }
     __device__ void sink(int k)
     {
@@ -266,12 +293,14 @@ struct BestOf {
     __device__ bool matters(uint32_t key, int score) const
     {
         const int at = where(key);
+        if (at == -2) return true;                      // (the lookup itself changes the table)
         if (at < 0 && *front < cap) return true;
         return heap[at < 0 ? 0 : at].val < score;
     }
     __device__ void offer(uint32_t key, int score)  // one lane
     {
-        int at = where(key);
+        int at;                                         // (a lookup, not a claim: an empty slot stays as it is)
+        { const uint32_t s = slot_for(key); const KV kv = place[s]; at = (kv.val != -1 && kv.key == key) ? kv.val : -1; }
         if (at < 0) {
             if (*front < cap) { const int k = (*front)++; heap[k] = KV{key, score}; rise(k); return; }
             at = 0;
@@ -293,14 +322,16 @@ struct BestOf {
             if (!m) break;
             const int l = first_lane(m);
             if (me == l) offer(key, score);
-            lds_sync();
+            wave_sync();
+            bind(*level);                               // (the offer may have grown the table)
             from = l + 1;
         }
     }
     __device__ void reset()                         // all lanes
     {
+        if (lane_id() == 0) { *front = 0; *level = 0; }
+        bind(0);
         for (uint32_t i = lane_id(); i < size.n; i += 64) place[i] = KV{0u, -1};
-        if (lane_id() == 0) *front = 0;
     }
 };
 
@@ -401,7 +432,8 @@ __device__ int chromosome_of(const BlkDev& X, uint32_t blk)
 struct Wave {
     const BlkDev* ix;
     int* st; int* as; uint32_t* own;
-    KV* q_mem[2]; int q_words[2]; int q_cap[2]; Modulus q_size[2]; uint32_t q_step[2];   // [0] by word hits, [1] by run score
+    KV* q_mem[2]; int q_words[2]; int q_cap[2]; uint32_t q_step[2];       // [0] by word hits, [1] by run score
+    KV* q_grown[2]; int q_grown_words[2];               // the larger forms of the position tables (slab): per list A then B
     __device__ __forceinline__ BestOf hits_list(int d) const { return list(0, d); }
     __device__ __forceinline__ BestOf run_list(int d) const { return list(1, d); }
     __device__ __forceinline__ BestOf list(int which, int d) const
@@ -409,9 +441,14 @@ struct Wave {
         BestOf Q;
         KV* m = (which ? q_mem[1] : q_mem[0]) + (size_t) d * (which ? q_words[1] : q_words[0]);
         Q.cap = which ? q_cap[1] : q_cap[0];
-        Q.heap = m; Q.place = m + Q.cap + 1;
-        Q.size = which ? q_size[1] : q_size[0]; Q.step_mod = which ? q_step[1] : q_step[0];
+        Q.heap = m; Q.level0 = m + Q.cap + 1;
+        Q.sizes = which ? ix->hb_sizes : ix->ha_sizes;
+        KV* g = (which ? q_grown[1] : q_grown[0]) + (size_t) d * (which ? q_grown_words[1] : q_grown_words[0]);
+        Q.grown_a = g; Q.grown_b = g + Q.sizes[SPDP_BLK_HASH_LEVELS - 1];
+        Q.step_mod = which ? q_step[1] : q_step[0];
         Q.front = st + (which ? ST_QB_FRONT : ST_QA_FRONT) + d; Q.trouble = st + ST_TROUBLE;
+        Q.level = st + ST_Q_LEVEL + 4 * which + d;
+        Q.bind(*Q.level);
         return Q;
     }
     RunHash hh;
@@ -819,7 +856,6 @@ __global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
         const int cap = which ? X.ncand : X.nascr, hs = which ? X.hb_size1 : X.ha_size1;
         W.q_cap[which] = cap; W.q_words[which] = cap + 1 + hs;
         W.q_mem[which] = (KV*) l; l += 2 * 4 * (size_t) (cap + 1 + hs);
-        W.q_size[which].set((uint32_t) hs);
         W.q_step[which] = (uint32_t) (which ? X.hb_size2 : X.ha_size2);
     }
     // ---- the wave's slab
@@ -834,6 +870,11 @@ __global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
     H.gb = (KV*) g; g += sizeof(KV) * (size_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 2];
     H.epochs = X.nseg < (1 << 24); H.epoch = 255;
     H.bind(0);
+    for (int which = 0; which < 2; ++which) {
+        const int32_t* sz = which ? X.hb_sizes : X.ha_sizes;
+        W.q_grown_words[which] = sz[SPDP_BLK_HASH_LEVELS - 1] + sz[SPDP_BLK_HASH_LEVELS - 2];
+        W.q_grown[which] = (KV*) g; g += sizeof(KV) * 4 * (size_t) W.q_grown_words[which];
+    }
     W.stage = (uint32_t*) g; g += 4 * (2 * (size_t) X.maxlist + 2);
     W.scratch = (int32_t*) g;
     uint32_t tag = *W.header;
@@ -860,7 +901,7 @@ __global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
         if (me == 0) {
             if (A.out_cap > 0) R.out[0] = R.n < R.cap ? R.n : R.cap;
             if (A.out_cap > 1) R.out[1] = calls;
-            if (A.out_cap > 2) R.out[2] = (reached ? SPDP_BLK_REACHED : 0) | (R.cut ? SPDP_BLK_CUT : 0) | (W.st[ST_TROUBLE] & SPDP_BLK_TABLE) |
+            if (A.out_cap > 2) R.out[2] = (reached ? SPDP_BLK_REACHED : 0) | (R.cut ? SPDP_BLK_CUT : 0) | (W.st[ST_TROUBLE] & ~3) |
                                           (reached == 2 ? SPDP_BLK_FORCED : 0);
         }
         wave_sync();
@@ -883,6 +924,8 @@ extern "C" size_t spdp_blk_vote_slab_bytes(const BlkDev* ix, int hh_in_lds)
     size_t b = 16 + sizeof(Score) * (4 * (size_t) ix->nseg + 2);
     if (!hh_in_lds) b += sizeof(KV) * (size_t) ix->hh_sizes[0];
     b += sizeof(KV) * ((size_t) ix->hh_sizes[SPDP_BLK_HASH_LEVELS - 1] + (size_t) ix->hh_sizes[SPDP_BLK_HASH_LEVELS - 2]);
+    b += sizeof(KV) * 4 * ((size_t) ix->hb_sizes[SPDP_BLK_HASH_LEVELS - 1] + ix->hb_sizes[SPDP_BLK_HASH_LEVELS - 2] +
+                           (size_t) ix->ha_sizes[SPDP_BLK_HASH_LEVELS - 1] + ix->ha_sizes[SPDP_BLK_HASH_LEVELS - 2]);
     b += 4 * (2 * (size_t) ix->maxlist + 2);
     b += sizeof(Pair) * ((size_t) ix->ncand + 2) + 4 * 3 * (2 * (size_t) ix->ncand + 2);
     return (b + 255) & ~(size_t) 255;

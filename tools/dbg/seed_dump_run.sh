@@ -10,3 +10,6 @@ SPDP_SEED_DUMP=$PWD/gpurun_out/dump_dropin_q7.bin SPDP_SEED_DUMP_HASH=$H7 timeou
 SPDP_SEED_DUMP=$PWD/gpurun_out/dump_e2e_c4.bin SPDP_SEED_DUMP_HASH=$H4 timeout 400 python tools/e2e_q7.py --queries 10000 --genes 400 --spacer 450000 --frag 500 --ori 3 > gpurun_out/dump_e2e_c4.log 2>&1
 SPDP_SEED_DUMP=$PWD/gpurun_out/dump_dropin_c4.bin SPDP_SEED_DUMP_HASH=$H4 timeout 400 python tools/dropin_demo.py --queries 10000 --genes 400 --spacer 450000 --frag 500 --modes Q7 --gpu-threads 16 --strand=-S3 --antisense > gpurun_out/dump_dropin_c4.log 2>&1
 ls -la gpurun_out/dump_*
+python tools/dbg/seed_dump_diff.py gpurun_out/dump_e2e_q7.bin gpurun_out/dump_dropin_q7.bin > gpurun_out/dump_diff_q7.txt 2>&1
+python tools/dbg/seed_dump_diff.py gpurun_out/dump_e2e_c4.bin gpurun_out/dump_dropin_c4.bin > gpurun_out/dump_diff_c4.txt 2>&1
+rm -f gpurun_out/dump_*.bin

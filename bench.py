@@ -47,7 +47,7 @@ VALU_PEAK_WINST_S = 1024 * 2.3e9 / 2.2
 # in separate passes + --kernel-trace --stats, per workload).  Every entry carries the sha256 of its kernel's source file;
 # an entry whose kernel has changed since is reported as stale (roofline.*.profile_stale, and tests/test_profile_counters.py
 # fails) instead of pricing the new kernel with the old figures.
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r06_counters.json")
 
 
 def _counters(workload, key):
@@ -647,7 +647,7 @@ def main_blk(args):
                                            "(Wilip on the candidate region) stays with the caller"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "bytes_per_query": round(float(bytes_per_q), 1), "traffic": _traffic("blk", "blk", n_q, world)[0],
-                         "traffic_source": _traffic("blk", "blk", n_q, world)[1], "kernel": "spdp_blk_vote_kernel", "kernel_ms": round(k_ms, 3),
+                         "traffic_source": _traffic("blk", "blk", n_q, world)[1], "kernel": "spdp_blk_vote_wave", "kernel_ms": round(k_ms, 3),
                          "note": "one query per lane, random 4 .. 8-byte accesses into posting lists and the lane's private score slab: bound by "
                                  "memory transactions in flight and by divergence, not by bytes; algorithmic bytes = codes + per word its table "
                                  "entries and posting list + two score slots per listed block + the record"},

@@ -141,15 +141,9 @@ def split_recorded(vote_rec: np.ndarray, pairs_rec):
     return dict(head=head, qb=qb, runs=runs, pairs=pairs)
 
 
-def core_vote(ix: BlkIndex, codes, left, right, stop_at=0, cap=1 << 16, touched_cap=4096):
-    """the product's routine, host-compiled (oracle/blk_check.cpp)"""
-    lib = C.CDLL(_o.build_blk_check())
-    q = np.ascontiguousarray(codes, dtype=np.uint8)
-    out = np.zeros(cap, dtype=np.int32)
-    n = lib.blk_check_vote(C.byref(ix), q.ctypes.data_as(C.c_void_p), C.c_int(q.size), C.c_int(left), C.c_int(right),
-                           C.c_int(stop_at), out.ctypes.data_as(C.c_void_p), C.c_int(cap), C.c_int(touched_cap))
-    assert n > -1000000, "a score slot was left dirty after the clean-up"
-    return split_product_record(out)
+def last_vote_was_forced() -> bool:
+    """the snapshot vote() returned last is findblock's closing call, TestOutput(1)"""
+    return bool(C.c_int.in_dll(_o.lib(), "spdp_oracle_blk_last_forced").value)
 
 
 def vote_carry(ix: BlkIndex, codes, left, right, stop_at, carry: np.ndarray):

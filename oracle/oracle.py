@@ -35,9 +35,10 @@ _BLK_SO = os.path.join(_HERE, "libblkcheck.so")
 
 
 def build_blk_check(force: bool = False) -> str:
-    """the block vote's CPU checker: the text the device kernel is compiled from (spdp_blk_core.h), host-compiled"""
-    srcs = [os.path.join(_HERE, "blk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_core.h"),
-            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_blk_find.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_wilip.h"),
+    """the block search's CPU checker: the product's host-side logic (spdp_loci.h, the HSP search in its host form), host-compiled"""
+    d = os.path.join(_HERE, "..", "spaln_amd", "csrc")
+    srcs = [os.path.join(_HERE, "blk_check.cpp"), os.path.join(d, "spdp_loci.h"), os.path.join(d, "spdp_hsp_host.h"),
+            os.path.join(d, "spdp_hsp_chain.h"), os.path.join(d, "spdp_region.h"), os.path.join(d, "spdp_gencode.h"),
             os.path.join(_HERE, "..", "include", "spdp.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_BLK_SO) or os.path.getmtime(_BLK_SO) < newest:
@@ -54,7 +55,8 @@ def build_walk_check(force: bool = False) -> str:
     """the seeded walk's CPU checker: the product's host walk (a header) compiled with callbacks in place of the device"""
     srcs = [os.path.join(_HERE, "walk_check.cpp"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_walk.h"),
             os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_seeded_rv.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_hostcpus.h"),
-            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_gencode.h"), os.path.join(_HERE, "..", "include", "spdp.h")]
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_gencode.h"), os.path.join(_HERE, "..", "include", "spdp.h"),
+            os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_hsp_host.h"), os.path.join(_HERE, "..", "spaln_amd", "csrc", "spdp_hsp_chain.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_WALK_SO) or os.path.getmtime(_WALK_SO) < newest:
         tmp = f"{_WALK_SO}.{os.getpid()}.tmp"

@@ -185,9 +185,14 @@ NOINST void dump_find_prm(SrchBlk* s)
 	    (int) s->pwd->BasicGOP, (int) s->pwd->BasicGEP, (int) s->pwd->LongGOP, (int) s->pwd->LongGEP, s->pwd->codonk1,
 	    (int) algmode.nsa, (int) algmode.slv, (int) s->query->inex.exgl, (int) s->query->inex.exgr};
 	put_i32("find_prm", &v[0], v.size());
-	std::vector<short> ip(131072);
+	std::vector<short> ip(1 << 19);		// (every length a candidate region can hold: no caller has to extend the table by formula)
 	for (size_t n = 0; n < ip.size(); ++n) ip[n] = (short) s->pwd->IntPen->Penalty((int) n);
 	put("find_intpen", 2, &ip[0], ip.size());
+	// the intron-length limits as THIS run holds them: the program derives maxl from the length model's 99 % quantile and minl from where
+	// an intron starts to beat a gap (src/codepot.cc:134-135, 176-212); a harness that sets its own defaults holds other values
+	std::vector<int> cp = {IntronPrm.llmt, IntronPrm.minl, IntronPrm.rlmt, IntronPrm.maxl, IntronPrm.nquant, (int) IntronPrm.hard_minl,
+	    (int) IntronPrm.hard_maxl, IntronPrm.elmt, IntronPrm.tlmt, IntronPrm.mode};
+	put_i32("cli_intron_prm", &cp[0], cp.size());
 	TapWriter tw;
 	dump_wilip_model(tw, s->pwd);
 }

@@ -63,6 +63,7 @@ static uint32_t next_prime(uint32_t n)          /* supprime(n), src/supprime.cc:
     }
 }
 static KV* dh_map(DH* h, uint32_t key, int record);
+int spdp_oracle_blk_last_forced = 0;            /* the snapshot of the last call is findblock's closing TestOutput(1) (tests: the loci checker) */
 int spdp_oracle_blk_grows = 0;                  /* how often a table grew (tests: the fixtures must reach this path) */
 /* Dhash::resize() (src/clib.h:341-355): a table of the next prime >= twice the size, live entries re-entered in slot order */
 static void dh_grow(DH* h)
@@ -465,6 +466,7 @@ int spdp_oracle_blk_vote_carry(const BlkIndex* ix, const uint8_t* q, int q_len, 
         }
     }
     int n_out = 0, calls = 0;
+    spdp_oracle_blk_last_forced = 0;
     int nohit = 0, sigpr = 0;
     int c = qlen / (nshift + nshift) - 1;
     const int is_short = qlen < ix->shortquery;
@@ -547,7 +549,7 @@ int spdp_oracle_blk_vote_carry(const BlkIndex* ix, const uint8_t* q, int q_len, 
                     }
                 }
         }
-        if (c != -1 && calls++ == stop_at) SNAP();
+        if (c != -1 && calls++ == stop_at) { spdp_oracle_blk_last_forced = 1; SNAP(); }
     }
 #undef SNAP
     int overflow = s.hh.overflow;

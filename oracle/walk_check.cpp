@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../spaln_amd/csrc/spdp_walk.h"
-#include "../spaln_amd/csrc/spdp_wilip.h"
+#include "../spaln_amd/csrc/spdp_hsp_host.h"
 #include "../spaln_amd/csrc/spdp_seeded_rv.h"
 
 extern "C" {
@@ -186,7 +186,7 @@ extern "C" int walk_check_scheduler(int n_walks, int max_parks, int depth, int l
     return n_batches.load();
 }
 
-// ---- the HSP search (spdp_wilip.h) on one request, as Wilip::Wilip(seqs, pwd, level) answers it: flat units into out[cap];
+// ---- the HSP search (spdp_hsp_host.h) on one request, as Wilip::Wilip(seqs, pwd, level) answers it: flat units into out[cap];
 // returns the number of ints (-1: cap too small)
 extern "C" int walk_check_wilip(const SpdpWilipModel* m, const uint8_t* a, int a_len, int a_left, int a_right, int a_exgl, int a_exgr,
                                 const uint8_t* b, int b_len, int b_left, int b_right, int bbt,
@@ -194,12 +194,12 @@ extern "C" int walk_check_wilip(const SpdpWilipModel* m, const uint8_t* a, int a
                                 const int16_t* intpen, int intpen_len, int gop, int gep, int lgop, int lgep, int codonk1,
                                 int level, int32_t* out, int cap)
 {
-    spdp_wl::Pair p = {a, a_len, a_left, a_right, a_exgl, a_exgr, b, b_len, b_left, b_right, bbt, sigS, sigE, sigT,
-                          intpen, intpen_len, gop, gep, lgop, lgep, codonk1};
-    std::vector<spdp_wl::Unit> units;
-    spdp_wl::run(m, &p, level, units);
+    const spdp_hsp::Seqs p = {a, a_len, a_left, a_right, a_exgl, a_exgr, b, b_len, b_left, b_right, bbt, sigS, sigE, sigT};
+    const spdp_hsp::GapCosts gc = {intpen, intpen_len, gop, gep, lgop, lgep, codonk1};
+    std::vector<spdp_hsp::Unit> units;
+    spdp_hsp::search(m, p, gc, level, units);
     std::vector<int32_t> flat;
-    spdp_wl::flatten(units, flat);
+    spdp_hsp::flatten(units, flat);
     if ((int) flat.size() > cap) return -1;
     memcpy(out, flat.data(), sizeof(int32_t) * flat.size());
     return (int) flat.size();

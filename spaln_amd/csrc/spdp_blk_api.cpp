@@ -2,7 +2,10 @@
 // once, a call uploads its queries, runs spdp_blk_vote_wave (a wave per query, waves persistent) and brings the records back.
 #include "spdp_internal.h"
 #include "spdp_blk_dev.h"
-#include "spdp_blk_find.h"
+#include "spdp_hsp_dev.h"
+#include "spdp_loci.h"
+#include "spdp_hsp_host.h"
+#include "spdp_region.h"
 #include "spdp_hostcpus.h"
 #include <atomic>
 #include <thread>
@@ -16,6 +19,9 @@ struct SpdpBlkIndex {
     BlkDev dev;
     std::vector<void*> bufs;                    // device copies of the index arrays
     uint8_t* slabs = nullptr; uint32_t* next = nullptr;
+    // the genome, resident for the HSP searches (uploaded by the first spdp_blk_find that names it)
+    uint8_t* d_genome = nullptr; const uint8_t* genome_host = nullptr; int64_t genome_len = 0;
+    uint8_t* d_tron = nullptr; int32_t* d_mtx = nullptr;
     size_t slab_bytes = 0;
     int n_waves = 0, hh_in_lds = 0;
     uint32_t lds_bytes = 0;
@@ -24,6 +30,9 @@ struct SpdpBlkIndex {
         for (void* p : bufs) if (p) (void) hipFree(p);
         if (slabs) (void) hipFree(slabs);
         if (next) (void) hipFree(next);
+        if (d_genome) (void) hipFree(d_genome);
+        if (d_tron) (void) hipFree(d_tron);
+        if (d_mtx) (void) hipFree(d_mtx);
     }
 };
 
@@ -239,41 +248,161 @@ extern "C" int spdp_blk_vote(SpdpContext* ctx, const SpdpBlkIndex* ix, const uin
     return 0;
 }
 
-// ---- from the vote to candidate loci (spdp_blk_find.h) ---------------------------------------------------------------------
-extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
-                             const SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
-                             const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
-                             SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status)
+// ---- from the vote to candidate loci -------------------------------------------------------------------------------------------
+// The vote runs on the device call after call (stop_at); between two votes every query that reached a TestOutput call is a machine
+// (spdp_loci.h) that names the regions it needs searched.  The searches of all machines go to the device as batches (spdp_hsp.hip:
+// the first regions of all pairs in one launch, a protein query's second looks in further ones), their HSPs are chained on the
+// host threads (spdp_hsp_chain.h), the machines advance.
+namespace {
+
+template <class F> void on_threads(int n, F f)
 {
-    if (!ctx) return -1;
-    if (!ix || !hix || !genome || !model || !sc || !prm || !loci || !n_loci || !hsps) { ctx->err = "spdp_blk_find: null argument"; return -1; }
-    *loci = nullptr; *hsps = nullptr; *n_loci = 0;
-    if (n <= 0) return 0;
-    if (!sc->intpen || sc->intpen_len <= 0 || !genome->codes || !genome->chr_off || genome->n_chr != hix->n_chr || !hix->chr || !hix->rscrtab) {
-        ctx->err = "spdp_blk_find: needs SpdpScoring.intpen, the genome of the index's chromosomes and the host index's tables"; return -1;
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&] { try { for (int k; (k = next++) < n; ) f(k); } catch (...) { failed = true; } };
+    const int nt = std::max(1, std::min(spdp_host_cpus(), n));
+    std::vector<std::thread> th;
+    try { for (int t = 1; t < nt; ++t) th.emplace_back(work); } catch (...) {}      // (fewer threads: the caller's does the rest)
+    work();
+    for (std::thread& t : th) t.join();
+    if (failed) throw std::bad_alloc();
+}
+
+struct SearchTask { int machine, pair; spdp_loci::Region r; std::vector<spdp_hsp::Unit> units; };
+
+struct HspBatch {                                       // what a call's searches share
+    SpdpContext* ctx; SpdpBlkIndex* ix; const SpdpGenome* genome; const SpdpWilipModel* model; const SpdpScoring* sc;
+    const spdp_loci::Params* P;
+    const uint8_t* codes; const int64_t* offs; const int32_t* left; const int32_t* right;       // the call's queries (host)
+    uint8_t* d_codes = nullptr;
+    ~HspBatch() { if (d_codes) (void) hipFree(d_codes); }
+
+    int prepare(int n)
+    {
+        // the genome goes to the device once per index (the caller's array is the key: the same pointer and length again = resident)
+        const int64_t glen = genome->chr_off[genome->n_chr];
+        if (ix->genome_host != genome->codes || ix->genome_len != glen) {
+            if (ix->d_genome) { (void) hipFree(ix->d_genome); ix->d_genome = nullptr; }
+            HIPCHK(hipMalloc((void**) &ix->d_genome, (size_t) std::max<int64_t>(glen, 16)));
+            HIPCHK(hipMemcpy(ix->d_genome, genome->codes, (size_t) glen, hipMemcpyHostToDevice));
+            ix->genome_host = genome->codes; ix->genome_len = glen;
+        }
+        if (!ix->d_tron) {
+            uint8_t mid[32], tron_of[64];
+            spdp_genetic_code_tables(mid, tron_of);
+            HIPCHK(hipMalloc((void**) &ix->d_tron, 64));
+            HIPCHK(hipMemcpy(ix->d_tron, tron_of, 64, hipMemcpyHostToDevice));
+        }
+        if (!ix->d_mtx) HIPCHK(hipMalloc((void**) &ix->d_mtx, sizeof model->mtx));
+        HIPCHK(hipMemcpy(ix->d_mtx, model->mtx, sizeof model->mtx, hipMemcpyHostToDevice));
+        const size_t nb = (size_t) (offs[n] - offs[0]);
+        HIPCHK(hipMalloc((void**) &d_codes, std::max<size_t>(nb, 16)));
+        HIPCHK(hipMemcpy(d_codes, codes + offs[0], nb, hipMemcpyHostToDevice));
+        return 0;
     }
-    // the host's view of the index: what TestOutput / FindHsp read (random-score table, chromosome table, block geometry)
-    BlkDev hv;
-    memset(&hv, 0, sizeof hv);
-    hv.gdb = hix->gdb; hv.rbscoef = hix->rbscoef; hv.rbscons = hix->rbscons; hv.rscrtab = hix->rscrtab; hv.nseg = hix->nseg;
-    blk_find::Params P;
+    spdp_hsp::ChainCost cost(int a_len) const
+    {
+        int vthr = model->level[0].vthr;
+        if (a_len < model->shortquery) vthr = vthr * a_len / model->shortquery;       // (as the search scaled it)
+        return {model, sc->intpen, sc->intpen_len, sc->gop, sc->gep, sc->lgop, sc->lgep, sc->codonk1, P->bbt == 3 ? 3 : 1, vthr};
+    }
+    // the host's form, for a task the device hands back
+    void on_host(SearchTask& t, int q) const
+    {
+        std::vector<uint8_t> reg;
+        spdp_region::materialize(genome->codes, genome->chr_off, t.r.chr, t.r.base, t.r.len, t.r.rvs != 0, P->bbt == 3, reg);
+        const int a_len = (int) (offs[q + 1] - offs[q]);
+        const spdp_hsp::Seqs s = {codes + offs[q], a_len, left[q], right[q], P->a_exgl, P->a_exgr, reg.data(), t.r.len, 0, t.r.len,
+                                  P->bbt == 3 ? 3 : 1, nullptr, nullptr, nullptr};
+        const spdp_hsp::GapCosts gc = {sc->intpen, sc->intpen_len, sc->gop, sc->gep, sc->lgop, sc->lgep, sc->codonk1};
+        spdp_hsp::search(model, s, gc, -1, t.units);
+    }
+    // all tasks: device search, then the chains on the host threads.  query_of[machine] = the query
+    int run(std::vector<SearchTask>& tasks, const std::vector<int>& query_of)
+    {
+        const int n = (int) tasks.size();
+        if (!n) return 0;
+        std::vector<HspTask> ht(n);
+        int longest = 1;
+        for (int k = 0; k < n; ++k) {
+            const int q = query_of[tasks[k].machine];
+            HspTask& T = ht[k];
+            T.a_off = offs[q] - offs[0]; T.a_len = (int32_t) (offs[q + 1] - offs[q]); T.a_left = left[q]; T.a_right = right[q];
+            T.g_off = genome->chr_off[tasks[k].r.chr] + tasks[k].r.base; T.b_len = tasks[k].r.len; T.rvs = tasks[k].r.rvs;
+            T.a_exgl = P->a_exgl; T.a_exgr = P->a_exgr; T.pad = 0;
+            longest = std::max(longest, T.a_right - T.a_left);
+        }
+        HspArgs A;
+        memset(&A, 0, sizeof A);
+        A.codes = d_codes; A.genome = ix->d_genome; A.n_tasks = n;
+        A.level = model->level[0];
+        A.mtx = ix->d_mtx; A.mtx_rows = model->mtx_rows; A.mtx_cols = model->mtx_cols; A.tron_of = ix->d_tron;
+        A.bbt = P->bbt == 3 ? 3 : 1; A.shortquery = model->shortquery; A.end_bonus = model->end_bonus; A.crs = model->crs;
+        A.ser = model->ser; A.ser2 = model->ser2;
+        // the wave's LDS: query words (twice their number, a power of two), shared words, segments -- sized for the batch's longest query,
+        // capped where one wave per CU is left; what does not fit comes back flagged
+        int slots = 256;
+        while (slots < 2 * longest && slots < 8192) slots <<= 1;
+        A.hash_slots = slots; A.hit_cap = slots <= 1024 ? 4096 : 8192; A.seg_cap = 256; A.out_cap = 96;
+        if (const char* e = getenv("SPDP_HSP_HITS")) A.hit_cap = std::max(256, atoi(e));
+        const uint32_t lds = spdp_hsp_lds_bytes(&A);
+        struct Dev { void* p = nullptr; ~Dev() { if (p) (void) hipFree(p); } } d_tasks, d_out, d_counts;
+        HIPCHK(hipMalloc(&d_tasks.p, sizeof(HspTask) * (size_t) n));
+        HIPCHK(hipMalloc(&d_out.p, sizeof(int32_t) * 8 * (size_t) A.out_cap * n));
+        HIPCHK(hipMalloc(&d_counts.p, sizeof(int32_t) * 2 * (size_t) n));
+        HIPCHK(hipMemcpyAsync(d_tasks.p, ht.data(), sizeof(HspTask) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+        A.tasks = (const HspTask*) d_tasks.p; A.out = (int32_t*) d_out.p; A.counts = (int32_t*) d_counts.p;
+        const int per_cu = (int) std::max<uint32_t>(1, std::min<uint32_t>(8, (160u << 10) / std::max<uint32_t>(lds, 1)));
+        const int waves = std::min(n, std::max(1, ctx->n_cu) * per_cu);
+        HIPCHK(spdp_hsp_launch(&A, waves, ctx->stream));
+        std::vector<int32_t> counts(2 * (size_t) n), out(8 * (size_t) A.out_cap * n);
+        HIPCHK(hipMemcpyAsync(counts.data(), d_counts.p, sizeof(int32_t) * counts.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(out.data(), d_out.p, sizeof(int32_t) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        on_threads(n, [&](int k) {
+            SearchTask& t = tasks[k];
+            const int q = query_of[t.machine];
+            if (counts[2 * k + 1]) { on_host(t, q); return; }
+            struct Rec { int v[8]; };
+            const Rec* r = (const Rec*) (out.data() + 8 * (size_t) A.out_cap * k);
+            std::vector<Rec> recs(r, r + counts[2 * k]);
+            std::sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.v[5] != y.v[5] ? x.v[5] < y.v[5] : x.v[6] < y.v[6]; });    // scan order: diagonal, position
+            std::vector<spdp_hsp::Hsp> hsps;
+            for (const Rec& x : recs) hsps.push_back({x.v[0], x.v[1], x.v[2], x.v[3], x.v[4]});
+            spdp_hsp::chain(hsps, cost(ht[k].a_len), left[q], right[q], 0, t.r.len, t.units);
+        });
+        return 0;
+    }
+};
+
+}   // namespace
+
+static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                    const SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
+                    const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
+                    SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status)
+{
+    SpdpBlkIndex* ix = const_cast<SpdpBlkIndex*>(cix);
+    spdp_loci::Params P;
     P.vthr = prm->vthr; P.drop_rate = prm->drop_rate; P.max_out = prm->max_out; P.max_out2 = prm->max_out2; P.min_agap = prm->min_agap;
     // protein queries against the translated index (-KP): SrchBlk::bbt = 3 (src/blksrc.cc:2218), the DvsP = 1 branch of FindHsp
     // with its NoRetry = 2 (:34) searches on a grown region
     P.bbt = model->dvsp == 1 ? 3 : 1; P.dvsp = model->dvsp; P.no_retry = 2;
-    if ((model->dvsp == 0) != (hix->drna != 0)) { ctx->err = "spdp_blk_find: the block table is incompatible with the query type (src/blksrc.cc:2186)"; return -1; }
     P.blklen = hix->blklen; P.ext_block = hix->extblock; P.ext_block_l = hix->extblockl; P.phase1t = prm->phase1t;
     P.a_exgl = prm->a_exgl; P.a_exgr = prm->a_exgr;
     if (P.max_out < 1 || P.max_out2 < P.max_out || P.blklen < 1) { ctx->err = "spdp_blk_find: max_out / max_out2 / blklen out of range"; return -1; }
-    const blk_find::Genome G = {genome->codes, genome->chr_off, genome->n_chr};
+    const spdp_loci::Chromosomes G = {genome->chr_off, genome->n_chr, hix->chr};
+    const spdp_loci::RandomScore rnd = {hix->rscrtab, hix->rbscoef, hix->rbscons, hix->gdb};
+    (void) hipSetDevice(ctx->device);
+    HspBatch B = {ctx, ix, genome, model, sc, &P, codes, offs, left, right};
+    if (B.prepare(n)) return -1;
     int out_cap = 4096;                                 // (a record that does not fit makes the round run again with room for it)
     std::vector<int> active(n), stop(n, 0), crit(n, 0), calls(n, 0);
     for (int i = 0; i < n; ++i) active[i] = i;
-    std::vector<std::vector<blk_find::Locus>> found(n);
+    std::vector<std::vector<spdp_loci::Locus>> found(n);
     std::vector<int32_t> rec;
     while (!active.empty()) {
         const int m = (int) active.size();
-        // this round's queries, packed
         std::vector<int64_t> o(m + 1, 0);
         std::vector<int32_t> l(m), r(m), st(m);
         for (int k = 0; k < m; ++k) { const int q = active[k]; o[k + 1] = o[k] + (offs[q + 1] - offs[q]); l[k] = left[q]; r[k] = right[q]; st[k] = stop[q]; }
@@ -287,44 +416,72 @@ extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const Spd
             if (!cut || out_cap >= (1 << 20)) break;
             out_cap *= 8;
         }
+        // ---- a machine per query that reached its call
+        std::vector<spdp_loci::Call> mach(m);
         std::vector<int> verdict(m, 0);                 // > 0 loci, 0 go on, -1 ended, -2 record cut / table full
-        std::atomic<int> next{0};
-        auto work = [&] {
-            blk_find::Searcher S;
-            S.ix = &hv; S.P = &P; S.G = &G; S.M = model; S.intpen = sc->intpen; S.intpen_len = sc->intpen_len;
-            S.gop = sc->gop; S.gep = sc->gep; S.lgop = sc->lgop; S.lgep = sc->lgep; S.codonk1 = sc->codonk1; S.chr_tab = hix->chr;
-            for (int k; (k = next++) < m; ) {
-                const int q = active[k];
-                const int32_t* rc = rec.data() + (size_t) k * out_cap;
-                if (!(rc[2] & SPDP_BLK_REACHED)) { verdict[k] = -1; continue; }         // findblock ended before this call
-                if (rc[2] & (SPDP_BLK_CUT | SPDP_BLK_TABLE)) { verdict[k] = -2; continue; }
-                int j = 3;
-                const int32_t* mmct = rc + j + 4;
-                j += 20;
-                for (int d = 0; d < 4; ++d) j += 1 + 2 * rc[j];
-                const int np = rc[j++];
-                std::vector<blk_find::Pair> pairs(np);
-                for (int i = 0; i < np; ++i, j += 9)
-                    pairs[i] = {rc[j], rc[j + 1], 0, (uint32_t) rc[j + 2], (uint32_t) rc[j + 3], (uint32_t) rc[j + 4], (uint32_t) rc[j + 5],
-                                (uint32_t) rc[j + 6], (uint32_t) rc[j + 7], rc[j + 8]};
-                S.n_runs = rc[j++]; S.runs = rc + j;
-                const blk_find::Query Q = {codes + offs[q], (int) (offs[q + 1] - offs[q]), left[q], right[q]};
-                S.q = &Q; S.critjscr = crit[q];
-                const int res = S.test_output(pairs, mmct, (rc[2] & SPDP_BLK_FORCED) != 0);
-                crit[q] = S.critjscr;
-                calls[q] = stop[q] + 1;
-                verdict[k] = res;
-                if (res > 0) found[q].assign(S.gener.begin(), S.gener.begin() + res);
-            }
-        };
-        const int nt = std::max(1, std::min(spdp_host_cpus(), m));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (std::thread& t : th) t.join();
+        std::vector<char> live(m, 0);
+        for (int k = 0; k < m; ++k) {
+            const int32_t* rc = rec.data() + (size_t) k * out_cap;
+            if (!(rc[2] & SPDP_BLK_REACHED)) { verdict[k] = -1; continue; }          // findblock ended before this call
+            if (rc[2] & (SPDP_BLK_CUT | SPDP_BLK_TABLE)) { verdict[k] = -2; continue; }
+            spdp_loci::Call& c = mach[k];
+            const int q = active[k];
+            c.P = &P; c.G = &G; c.rnd = rnd;
+            c.q = {(int) (offs[q + 1] - offs[q]), left[q], right[q]};
+            int j = 3;
+            memcpy(c.mmct, rc + j + 4, sizeof c.mmct);
+            j += 20;
+            for (int d = 0; d < 4; ++d) j += 1 + 2 * rc[j];
+            const int np = rc[j++];
+            for (int i = 0; i < np; ++i, j += 9)
+                c.pairs.push_back({rc[j], rc[j + 1], 0, (uint32_t) rc[j + 2], (uint32_t) rc[j + 3], (uint32_t) rc[j + 4], (uint32_t) rc[j + 5],
+                                   (uint32_t) rc[j + 6], (uint32_t) rc[j + 7], rc[j + 8]});
+            const int nr = rc[j++];
+            for (int i = 0; i < nr; ++i) c.runs.emplace_back((uint32_t) rc[j + 2 * i], rc[j + 2 * i + 1]);
+            c.forced = (rc[2] & SPDP_BLK_FORCED) != 0;
+            c.critjscr = crit[q];
+            c.begin();
+            live[k] = 1;
+        }
+        // ---- searches in batches: first every pair's first region, then what the machines ask for
+        std::vector<SearchTask> tasks;
+        for (int k = 0; k < m; ++k) {
+            if (!live[k]) continue;
+            std::vector<std::pair<int, spdp_loci::Region>> fr;
+            mach[k].first_regions(fr);
+            for (auto& x : fr) tasks.push_back({k, x.first, x.second, {}});
+        }
+        std::vector<std::vector<SearchTask>> answers(m);
+        while (!tasks.empty()) {
+            if (B.run(tasks, active)) return -1;
+            for (SearchTask& t : tasks) answers[t.machine].push_back(std::move(t));
+            tasks.clear();
+            std::vector<SearchTask> more(m);
+            std::vector<char> asks(m, 0);
+            on_threads(m, [&](int k) {
+                if (!live[k] || mach[k].done) return;
+                spdp_loci::Call& c = mach[k];
+                int pi; spdp_loci::Region rg;
+                while (c.needs(pi, rg)) {
+                    SearchTask* have = nullptr;
+                    for (SearchTask& a : answers[k])
+                        if (a.pair == pi && a.r.chr == rg.chr && a.r.rvs == rg.rvs && a.r.base == rg.base && a.r.len == rg.len) { have = &a; break; }
+                    if (!have) { more[k] = {k, pi, rg, {}}; asks[k] = 1; return; }
+                    std::vector<spdp_hsp::Unit> u = have->units;        // (a region may be asked for again: the answer stays)
+                    c.take(u);
+                }
+            });
+            for (int k = 0; k < m; ++k) if (asks[k]) tasks.push_back(std::move(more[k]));
+        }
         std::vector<int> again;
         for (int k = 0; k < m; ++k) {
             const int q = active[k];
+            if (live[k]) {
+                verdict[k] = mach[k].result;
+                crit[q] = mach[k].critjscr;
+                calls[q] = stop[q] + 1;
+                if (verdict[k] > 0) found[q].assign(mach[k].loci.begin(), mach[k].loci.begin() + verdict[k]);
+            }
             if (verdict[k] == 0) { ++stop[q]; again.push_back(q); }
             else if (verdict[k] == -2) { ctx->err = "spdp_blk_find: a vote record was cut or a hash table of the reference's size ran full"; return -1; }
             else if (verdict[k] < 0 && status) status[q] = -(calls[q] ? calls[q] : stop[q] + 1);
@@ -332,20 +489,44 @@ extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const Spd
         active.swap(again);
     }
     size_t nl = 0, nh = 0;
-    for (int q = 0; q < n; ++q) for (const blk_find::Locus& g : found[q]) { ++nl; nh += g.jxt.size(); }
+    for (int q = 0; q < n; ++q) for (const spdp_loci::Locus& g : found[q]) { ++nl; nh += g.hsp.size(); }
     *loci = (SpdpLocus*) malloc(sizeof(SpdpLocus) * std::max<size_t>(nl, 1));
     *hsps = (SpdpJuxt*) malloc(sizeof(SpdpJuxt) * std::max<size_t>(nh, 1));
     if (!*loci || !*hsps) { free(*loci); free(*hsps); *loci = nullptr; *hsps = nullptr; ctx->err = "spdp_blk_find: out of memory"; return -1; }
     size_t a = 0, b = 0;
     for (int q = 0; q < n; ++q) {
         if (status && !found[q].empty()) status[q] = calls[q];
-        for (const blk_find::Locus& g : found[q]) {
+        for (const spdp_loci::Locus& g : found[q]) {
             SpdpLocus& L = (*loci)[a++];
-            L.query = q; L.chr = g.chr; L.rvs = g.rvs; L.base = g.base; L.len = g.len; L.left = g.left; L.right = g.right;
-            L.jscr = g.jscr; L.n_hsp = (int32_t) g.jxt.size() - 1; L.hsp_off = (int64_t) b;
-            for (const spdp_wl::Juxt& t : g.jxt) { (*hsps)[b++] = {t.jx, t.jy, t.jlen, t.nid, t.jscr}; }
+            L.query = q; L.chr = g.at.chr; L.rvs = g.at.rvs; L.base = g.at.base; L.len = g.at.len; L.left = g.left; L.right = g.right;
+            L.jscr = g.jscr; L.n_hsp = (int32_t) g.hsp.size() - 1; L.hsp_off = (int64_t) b;
+            for (const spdp_hsp::Hsp& t : g.hsp) { (*hsps)[b++] = {t.jx, t.jy, t.jlen, t.nid, t.jscr}; }
         }
     }
     *n_loci = (int32_t) nl;
     return 0;
+}
+
+extern "C" int spdp_blk_find(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                             const SpdpWilipModel* model, const SpdpScoring* sc, const SpdpBlkFindParams* prm,
+                             const uint8_t* codes, const int64_t* offs, const int32_t* left, const int32_t* right, int32_t n,
+                             SpdpLocus** loci, int32_t* n_loci, SpdpJuxt** hsps, int32_t* status)
+{
+    if (!ctx) return -1;
+    if (!ix || !hix || !genome || !model || !sc || !prm || !loci || !n_loci || !hsps) { ctx->err = "spdp_blk_find: null argument"; return -1; }
+    *loci = nullptr; *hsps = nullptr; *n_loci = 0;
+    if (n <= 0) return 0;
+    if (!sc->intpen || sc->intpen_len <= 0 || !genome->codes || !genome->chr_off || genome->n_chr != hix->n_chr || !hix->chr || !hix->rscrtab) {
+        ctx->err = "spdp_blk_find: needs SpdpScoring.intpen, the genome of the index's chromosomes and the host index's tables"; return -1;
+    }
+    if ((model->dvsp == 0) != (hix->drna != 0)) { ctx->err = "spdp_blk_find: the block table is incompatible with the query type (src/blksrc.cc:2186)"; return -1; }
+    if (ix->ctx != ctx) { ctx->err = "spdp_blk_find: the index belongs to another context"; return -1; }
+    try { return blk_find(ctx, ix, hix, genome, model, sc, prm, codes, offs, left, right, n, loci, n_loci, hsps, status); }
+    catch (...) {                                       // (nothing of C++ crosses the C boundary; the worker threads have been joined)
+        if (*loci) { free(*loci); *loci = nullptr; }
+        if (*hsps) { free(*hsps); *hsps = nullptr; }
+        *n_loci = 0;
+        ctx->err = "spdp_blk_find: out of host memory (or no thread could be started)";
+        return -1;
+    }
 }

@@ -8,7 +8,7 @@
 // and the table sizes Dhash picks (src/clib.h:257-267).  Only the current format (version 26, 2- or 4-byte block numbers)
 // of a nucleotide index is read; older versions and the 3-byte form are refused.
 #include "../../include/spdp.h"
-#include "spdp_blk_core.h"
+#include "spdp_blk_dev.h"
 #include <algorithm>
 #include <climits>
 #include <cmath>

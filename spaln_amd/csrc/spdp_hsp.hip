@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(64) spdp_hsp_search(HspArgs A)
     L.spaced = A.level.bitpat_len > 0;
     {
         int wt = 0;
-        if (L.spaced) { L.width = A.level.bitpat_len; for (int w = 0; w < L.width; ++w) if (A.level.bitpat[w]) { if (me == 0) S.exam[wt] = w; ++wt; } }
+        if (L.spaced) { for (int w = 0; w < A.level.bitpat_len; ++w) if (A.level.bitpat[w]) { if (me == 0) S.exam[wt] = w; ++wt; } }
         else { wt = L.width; if (me < wt) S.exam[me] = me; }
         L.weight = wt;
     }

@@ -22,7 +22,7 @@
 
 #include "spdp_internal.h"
 #include "spdp_walk.h"
-#include "spdp_wilip.h"
+#include "spdp_hsp_host.h"
 #include "spdp_seeded_rv.h"
 
 namespace {
@@ -90,7 +90,7 @@ struct DeviceBackend : DpBackend {
     const SpdpWilipModel* wm = nullptr; const SpdpProblem* prob = nullptr; const SpdpScoring* scp = nullptr; int codonk1 = 0;
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
-        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
+        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_hsp_host.h)
             int skey[9] = {level, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
             if (cache) {
                 for (auto& e : cache->searches) if (!memcmp(e->key, skey, sizeof skey)) { units = e->units; if (pass) ++*n_wilip; return e->ok; }
@@ -109,13 +109,13 @@ struct DeviceBackend : DpBackend {
     bool own_search(int level, const Span& s, std::vector<Unit>& units)
     {
         {
-            const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 1,
-                                         nullptr, nullptr, nullptr, scp->intpen, scp->intpen_len, scp->gop, scp->gep, scp->lgop,
-                                         scp->lgep, codonk1};
-            std::vector<spdp_wl::Unit> us;
-            spdp_wl::run(wm, &pr, level, us);
+            const spdp_hsp::Seqs pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 1,
+                                        nullptr, nullptr, nullptr};
+            const spdp_hsp::GapCosts gc = {scp->intpen, scp->intpen_len, scp->gop, scp->gep, scp->lgop, scp->lgep, codonk1};
+            std::vector<spdp_hsp::Unit> us;
+            spdp_hsp::search(wm, pr, gc, level, us);
             std::vector<int32_t> flat;
-            spdp_wl::flatten(us, flat);
+            spdp_hsp::flatten(us, flat);
             return parse_units(flat.data(), (int32_t) flat.size(), units);
         }
     }

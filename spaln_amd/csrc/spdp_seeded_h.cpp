@@ -18,7 +18,7 @@
 
 #include "spdp_internal.h"
 #include "spdp_walk.h"
-#include "spdp_wilip.h"
+#include "spdp_hsp_host.h"
 #include "spdp_seeded_rv.h"
 #include "spdp_h_requests.h"
 
@@ -85,18 +85,18 @@ struct DeviceBackendH : DpBackend {
     const SpdpWilipModel* wm = nullptr; const SpdpProblemH* prob = nullptr; const SpdpScoringH* scp = nullptr;
     bool wilip(int level, const Span& s, std::vector<Unit>& units) override
     {
-        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_wilip.h)
+        if ((!src || !src->units) && wm) {      // the library's own HSP search (spdp_hsp_host.h)
             int skey[9] = {level, s.al, s.ar, s.bl, s.br, s.a_exgl, s.a_exgr, s.b_exgl, s.b_exgr};
             if (cache)
                 for (auto& e : cache->searches) if (!memcmp(e->key, skey, sizeof skey)) { units = e->units; if (pass) ++*n_wilip; return e->ok; }
             if (pass) ++*n_wilip;
-            const spdp_wl::Pair pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 3,
-                                         prob->sigS, prob->sigE, prob->sigT, scp->intpen, scp->intpen_len, scp->gop, scp->gep,
-                                         scp->lgop, scp->lgep, scp->codonk1};
-            std::vector<spdp_wl::Unit> us;
-            spdp_wl::run(wm, &pr, level, us);
+            const spdp_hsp::Seqs pr = {prob->a, prob->a_len, s.al, s.ar, s.a_exgl, s.a_exgr, prob->b, prob->b_len, s.bl, s.br, 3,
+                                        prob->sigS, prob->sigE, prob->sigT};
+            const spdp_hsp::GapCosts gc = {scp->intpen, scp->intpen_len, scp->gop, scp->gep, scp->lgop, scp->lgep, scp->codonk1};
+            std::vector<spdp_hsp::Unit> us;
+            spdp_hsp::search(wm, pr, gc, level, us);
             std::vector<int32_t> flat;
-            spdp_wl::flatten(us, flat);
+            spdp_hsp::flatten(us, flat);
             const bool ok = parse_units(flat.data(), (int32_t) flat.size(), units);
             if (cache) {
                 cache->searches.emplace_back(new RequestCache::Search);
@@ -310,17 +310,17 @@ extern "C" int spdp_wilip(const SpdpWilipModel* model, const SpdpProblem* p, con
                           int32_t level, const int32_t span[4], const int32_t exg[2], int32_t** flat)
 {
     if (!model || !span || !flat || (!p == !ph) || (p && !sc) || (ph && !sch) || level < -1 || level > 2) return -1;
-    spdp_wl::Pair pr;
-    if (p) pr = {p->a, p->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, p->b, p->b_len, span[2], span[3], 1,
-                 nullptr, nullptr, nullptr, sc->intpen, sc->intpen_len, sc->gop, sc->gep, sc->lgop, sc->lgep, sc->codonk1};
-    else pr = {ph->a, ph->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, ph->b, ph->b_len, span[2], span[3], 3,
-               ph->sigS, ph->sigE, ph->sigT, sch->intpen, sch->intpen_len, sch->gop, sch->gep, sch->lgop, sch->lgep, sch->codonk1};
-    if (!pr.a || !pr.b || !pr.intpen || pr.intpen_len <= 0) return -1;
+    spdp_hsp::Seqs pr; spdp_hsp::GapCosts gc;
+    if (p) { pr = {p->a, p->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, p->b, p->b_len, span[2], span[3], 1, nullptr, nullptr, nullptr};
+             gc = {sc->intpen, sc->intpen_len, sc->gop, sc->gep, sc->lgop, sc->lgep, sc->codonk1}; }
+    else { pr = {ph->a, ph->a_len, span[0], span[1], exg ? exg[0] : 0, exg ? exg[1] : 0, ph->b, ph->b_len, span[2], span[3], 3, ph->sigS, ph->sigE, ph->sigT};
+           gc = {sch->intpen, sch->intpen_len, sch->gop, sch->gep, sch->lgop, sch->lgep, sch->codonk1}; }
+    if (!pr.a || !pr.b || !gc.intpen || gc.intpen_len <= 0) return -1;
     if (pr.a_left < 0 || pr.a_right > pr.a_len || pr.a_left > pr.a_right || pr.b_left < 0 || pr.b_right > pr.b_len || pr.b_left > pr.b_right) return -1;
-    std::vector<spdp_wl::Unit> us;
-    spdp_wl::run(model, &pr, level, us);
+    std::vector<spdp_hsp::Unit> us;
+    spdp_hsp::search(model, pr, gc, level, us);
     std::vector<int32_t> f;
-    spdp_wl::flatten(us, f);
+    spdp_hsp::flatten(us, f);
     *flat = (int32_t*) malloc(sizeof(int32_t) * f.size());
     if (!*flat) return -1;
     memcpy(*flat, f.data(), sizeof(int32_t) * f.size());

@@ -1,7 +1,7 @@
-"""From the vote to candidate loci (spaln_amd/csrc/spdp_blk_find.h: TestOutput's second half and FindHsp; SURVEY 8 row f4,
-third slice) against the reference, on the CPU: the product's vote (spdp_blk_core.h), its HSP search (spdp_wilip.h, level -1)
-and its FindHsp, compiled by the host compiler into the tests' checker, run every query of the blk_* fixtures call after call
-as findblock does -- and leave, at every TestOutput call, what the compiled reference left there (oracle/ref_build/blk_tap.cc,
+"""From the vote to candidate loci (spaln_amd/csrc/spdp_loci.h: TestOutput's second half and FindHsp as a machine advanced with
+search answers) against the reference, on the CPU: the oracle's vote, the product's HSP search in its host form
+(spdp_hsp_host.h, level -1) and the product's locus logic, compiled by the host compiler into the tests' checker, run every query of
+the blk_* fixtures call after call as findblock does -- and leave, at every TestOutput call, what the compiled reference left there (oracle/ref_build/blk_tap.cc,
 snap_find): critjscr, the candidate block pairs as FindHsp moved their ends, and the candidate loci (chromosome, strand,
 region, range, score, HSPs).  blk_par: every gene twice in the genome, -M4 -- two loci per query, their overlap / order /
 pruning rules.  blk_p1: protein queries against the translated index (-KP) -- the region as tron codes, the retry with a grown
@@ -57,6 +57,40 @@ def genome_of(name, n_genes, seed, par):
     return gen, off
 
 
+def find_calls(lib, fx, ix, keep, gen, off, model, prm, ip, q):
+    """the block search of one query, call after call as findblock makes them: the oracle's vote up to each TestOutput call, the
+    product's host logic (oracle/blk_check.cpp: spdp_loci.h + the host form of the HSP search) on its state; -> the log in the
+    recorder's layout"""
+    f = lib.loci_check_call
+    f.restype = C.c_int
+    codes = np.ascontiguousarray(q["codes"], dtype=np.uint8)
+    chr_tab = np.ascontiguousarray(fx["blk_chr"], dtype=np.int32) if "blk_chr" in fx else None
+    crit, verdict = C.c_int32(0), C.c_int32(0)
+    out = []
+    for call in range(64):
+        v = blk.vote(ix, codes, q["left"], q["right"], call)
+        if v is None:
+            break
+        forced = blk.last_vote_was_forced()
+        w = blk.split_recorded(v[0], v[1])
+        pairs = np.ascontiguousarray(v[1][2:].reshape(-1, 9), dtype=np.int32)
+        runs = blk.runs_near_pairs(ix, w["runs"], pairs)
+        flat = np.ascontiguousarray([x for d in range(4) for (b, s) in runs[d] for x in (b | d << 28, s)], dtype=np.int32)
+        mmct = np.ascontiguousarray(w["head"][4:8], dtype=np.int32)
+        log = np.zeros(1 << 16, dtype=np.int32)
+        n = f(C.c_void_p(gen.ctypes.data), C.c_void_p(off.ctypes.data), C.c_int(len(off) - 1), C.c_void_p(ix.chr), C.c_void_p(ix.rscrtab),
+              C.c_float(ix.rbscoef), C.c_float(ix.rbscons), C.c_int(ix.gdb), C.c_void_p(codes.ctypes.data), C.c_int(len(codes)),
+              C.c_int(q["left"]), C.c_int(q["right"]), C.c_void_p(prm.ctypes.data), C.c_void_p(ip.ctypes.data), C.c_int(len(ip)),
+              C.c_void_p(C.addressof(model)), C.c_void_p(pairs.ctypes.data), C.c_int(len(pairs)), C.c_void_p(mmct.ctypes.data),
+              C.c_void_p(flat.ctypes.data), C.c_int(len(flat) // 2), C.c_int(int(forced)), C.c_int(call), C.byref(crit), C.byref(verdict),
+              C.c_void_p(log.ctypes.data), C.c_int(len(log)))
+        assert 0 <= n <= len(log)
+        out.extend(log[:n].tolist())
+        if verdict.value != 0:
+            break
+    return out
+
+
 @pytest.mark.parametrize("name,n_genes,seed,par", CASES + PROTEIN_CASES, ids=[c[0] for c in CASES + PROTEIN_CASES])
 def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
     fx = spdg.load([f for f in golden_files("blk_") if f.endswith(name + ".spdg")][0])
@@ -69,17 +103,9 @@ def test_every_testoutput_call_equals_the_reference(name, n_genes, seed, par):
     for r in parse_find(fx["find_log"]):
         by_q.setdefault(r[0], []).append(r)
     lib = C.CDLL(oracle._BLK_SO)
-    f = lib.blk_check_find
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     n_loci = two = 0
     for qi, q in enumerate(blk.parse_log(fx)):
-        codes = np.ascontiguousarray(q["codes"], dtype=np.uint8)
-        log = np.zeros(1 << 16, dtype=np.int32)
-        n = f(C.addressof(ix), gen.ctypes.data, off.ctypes.data, codes.ctypes.data, len(codes), q["left"], q["right"], prm.ctypes.data,
-              ip.ctypes.data, len(ip), C.addressof(model), log.ctypes.data, len(log))
-        assert 0 <= n <= len(log), (qi, n)
-        got, want = parse_find(log[:n]), by_q.get(qi, [])
+        got, want = parse_find(find_calls(lib, fx, ix, _keep, gen, off, model, prm, ip, q)), by_q.get(qi, [])
         assert len(got) == len(want), (qi, len(got), len(want))
         for g, w in zip(got, want):
             np_ = g[3].shape[0]

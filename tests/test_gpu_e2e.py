@@ -68,13 +68,16 @@ def test_one_call_equals_its_steps(name, n_genes, seed, par):
     fq = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
     gen, off = genome_of(name, n_genes, seed, par)
     dix = blocks.BlockIndex(eng, fx)
-    model = abi.wilip_model_from_fixture(fq)
+    # the intron-length limits are those of the PROGRAM's run the block fixture records (its HSP-search model holds them: minl, maxl,
+    # llmt as IntronPenalty derived them for that genome), not the defaults of the alignment fixture's harness
+    model = abi.wilip_model_from_fixture(fx)
     sigmodel = abi.signal_model_from_fixture(fq)
     prm = blocks.find_params_from_fixture(fx)
-    sc = spdg.scoring(fq, intpen=np.ascontiguousarray(fx["find_intpen"], dtype=np.int16), scalar_engines=1)
+    sc = spdg.scoring(fq, intpen=np.ascontiguousarray(fx["find_intpen"], dtype=np.int16), scalar_engines=1, llmt=model.llmt, minl=model.minl)
     sp = abi.seed_params_from_fixture(fq)
+    sp.minl, sp.ip_maxl = model.minl, model.maxl
     fs = fq["rng_fstat_A0"] if "rng_fstat_A0" in fq else [0, 0, 0, 0, 0, 0, 3, 1]
-    rescore = (fq["prm"]["codonk1"], fq["prm"]["minl"], int(fs[6]), int(fs[7]))
+    rescore = (fq["prm"]["codonk1"], model.minl, int(fs[6]), int(fs[7]))
     queries = [q["codes"][q["left"]:q["right"]] for q in blk.parse_log(fx)]
     # ---- the steps
     loci, _ = blocks.find(dix, gen, off, model, sc, prm, queries)

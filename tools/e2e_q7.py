@@ -59,21 +59,21 @@ def read_fasta(path):
     return names, [CODE_OF[np.frombuffer(s, dtype=np.uint8)] for s in seqs]
 
 
-def extend_intpen(ip, n):
-    """IntronPenalty::Penalty(len) beyond the dumped table (src/codepot.h:242-247: (STYPE) (IntFx + IntEp * log(len - mu)) there):
-    the two constants fitted to the steps of the table's tail.  Only windows longer than the table (131 072 nt: a block-search
-    locus of a 100 Mb genome) read these entries, for introns no alignment of this data set holds."""
-    m = len(ip)
-    if n <= m:
-        return ip
-    tail = ip[m // 2:].astype(np.int64)
-    steps = np.nonzero(np.diff(tail))[0] + 1 + m // 2             # first position of every new value
-    x = np.log(steps.astype(np.float64))
-    y = ip[steps].astype(np.float64) + 0.0                         # at a step the real value has just passed the integer
-    e, f = np.polyfit(x, y, 1)
-    more = np.trunc(f + e * np.log(np.arange(m, n, dtype=np.float64))).astype(np.int16)
-    more = np.minimum(more, ip[-1])                                # (monotone across the seam)
-    return np.ascontiguousarray(np.concatenate([ip, more]))
+def cli_parameters(td, env, extra):
+    """the parameters the reference's PROGRAM holds for this data set -- the intron-length limits it derives from its length model
+    (IntronPrm.minl / maxl / llmt: src/codepot.cc:134-135, 176-212), the IntPen table over every length, the HSP-search model and the
+    block search's constants -- read from a one-query run of the recorder (oracle/_ref/spaln_blktap, oracle/ref_build/blk_tap.cc).  A
+    binding reads them from the reference's objects; a harness that set its own defaults would hold other values (a fixture of
+    ref_dump: minl 25, llmt 20, no maxl -- the program on a 5 Mb genome: 15, 15, 5 530)."""
+    lines = open(os.path.join(td, "q.fa")).read().split(">")
+    with open(os.path.join(td, "cli_one.fa"), "w") as f:
+        f.write(">" + lines[1])
+    log = os.path.join(td, "cli_one.spdg")
+    r = subprocess.run([os.path.join(dropin_demo.REF, "spaln_blktap"), "-Q7", "-O4", "-t1"] + extra + ["-dgnm", "cli_one.fa"], cwd=td,
+                       env=dict(env, SPDP_BLK_LOG=log), capture_output=True, text=True)
+    if r.returncode or not os.path.exists(log):
+        raise SystemExit("spaln_blktap failed: " + r.stderr[-300:])
+    return spdg.load(log)
 
 
 def reference_exons(text):
@@ -133,26 +133,29 @@ def main():
         eng = engine.Engine(0)
         lib = eng.lib
         fq = spdg.load(os.path.join(ROOT, "tests", "golden", "q_c2_seed0.spdg"))
-        fb = spdg.load(os.path.join(ROOT, "tests", "golden", "blk_k1.spdg"))
+        cli = cli_parameters(td, env, ["-S1"] if args.ori == 1 else [])
         t0 = time.perf_counter()
-        fx = blocks.read_index_file(lib, os.path.join(td, "gnm.bkn"), max_intron_len=13000)
+        # ExtBlock = max_intron_len() / blklen + 1 follows from the program's IntronPrm.maxl (src/blksrc.cc:2071-2082, 2222): as recorded
+        fx = blocks.read_index_file(lib, os.path.join(td, "gnm.bkn"), ext_block=int(cli["blk_prm"][blocks._PRM["extblock"]]))
         fx["blk_convtab"][:2] = 255
         dix = blocks.BlockIndex(eng, fx)
         chr_names, chroms = read_fasta(os.path.join(td, "gnm.mfa"))
         gen = np.concatenate(chroms).astype(np.uint8)
         off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
         q_names, queries = read_fasta(os.path.join(td, "q.fa"))
-        model = abi.wilip_model_from_fixture(fq)
         sigmodel = abi.signal_model_from_fixture(fq)
-        ip = extend_intpen(np.ascontiguousarray(fb["find_intpen"], dtype=np.int16), 1 << 19)
-        sc = spdg.scoring(fq, intpen=ip, scalar_engines=1)
+        model = abi.wilip_model_from_fixture(cli)
+        ip = np.ascontiguousarray(cli["find_intpen"], dtype=np.int16)
+        llmt, minl, _rlmt, maxl = (int(x) for x in cli["cli_intron_prm"][:4])
+        sc = spdg.scoring(fq, intpen=ip, scalar_engines=1, llmt=llmt, minl=minl)
         sp = abi.seed_params_from_fixture(fq)
-        prm = blocks.find_params_from_fixture(fb)
+        sp.minl, sp.ip_maxl = minl, maxl
+        prm = blocks.find_params_from_fixture(cli)
         prm.phase1t = int(dix.desc.rbscons)              # Phase1T = (int) (RbsBias * avr), RbsBias = RbsBase = 3 (src/blksrc.cc:64-66)
         load_s = time.perf_counter() - t0
         sp.wilip = C.addressof(model)
         fs = fq["rng_fstat_A0"] if "rng_fstat_A0" in fq else [0, 0, 0, 0, 0, 0, 3, 1]
-        rescore = (fq["prm"]["codonk1"], fq["prm"]["minl"], int(fs[6]), int(fs[7]))
+        rescore = (fq["prm"]["codonk1"], minl, int(fs[6]), int(fs[7]))
         # one call: spdp_blk_find -> regions and their signals (one launch) -> spdp_align_s_seeded -> spdp_skl_rng_s -> the
         # locus that stays.  Twice: the first call of a context also loads the kernels' code objects and sizes its pools
         runs = []

@@ -38,7 +38,7 @@ KERNELS = [
     ("void spdh_rowwave<1,", "h_a0_fwd", "spaln_amd/csrc/spdp_h_rowwave.hip", "fwd_cells"),
     ("void spdh_rowwave<2,", "h_a0_udh", "spaln_amd/csrc/spdp_h_rowwave.hip", "udh_cells"),
     ("void spdh_exact<", "h_a1", "spaln_amd/csrc/spdp_h_exact.hip", "fwd_cells"),
-    ("spdp_blk_vote_kernel", "blk", "spaln_amd/csrc/spdp_blk_core.h", None),
+    ("spdp_blk_vote_wave", "blk", "spaln_amd/csrc/spdp_blk_vote.hip", None),
 ]
 
 
@@ -62,7 +62,7 @@ def pmc_totals(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r05")
+    ap.add_argument("--tag", default="r06")
     ap.add_argument("--name", required=True, help="key of this workload in the json (c2, c4, c3, a0, ...)")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("bench_args", nargs=argparse.REMAINDER)

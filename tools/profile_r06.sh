@@ -2,11 +2,11 @@
 # Round-5 profile: per workload of the bench line, the counters bench.py prices its kernels with (tools/profile_counters.py:
 # kernel trace + stats, SQ_INSTS_VALU / SALU, FETCH_SIZE, WRITE_SIZE, each --pmc set in a pass of its own), then where the
 # resident wave time goes for the headline, C5 and the block vote (tools/wave_pmc.sh).  Results under gpurun_out/; the
-# summaries to keep go to profiles/r05_*.
+# summaries to keep go to profiles/r06_*.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 run() { name=$1; shift; echo "== $name"; timeout 1500 python tools/profile_counters.py --tag $TAG --name $name -- "$@" > gpurun_out/${TAG}_counters_$name.log 2>&1; tail -c 300 gpurun_out/${TAG}_counters_$name.log | tr '\n' ' '; echo; }
 mkdir -p gpurun_out
 for w in ${WORKLOADS:-c2 c4 c3 c5 a0 a1 c3_a0 c3_a1 blk}; do

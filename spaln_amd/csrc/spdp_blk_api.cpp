@@ -8,6 +8,7 @@
 #include "spdp_region.h"
 #include "spdp_hostcpus.h"
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <algorithm>
 #include <cmath>
@@ -397,6 +398,10 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
     HspBatch B = {ctx, ix, genome, model, sc, &P, codes, offs, left, right};
     if (B.prepare(n)) return -1;
     int out_cap = 4096;                                 // (a record that does not fit makes the round run again with room for it)
+    const bool verbose = getenv("SPDP_FIND_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    double t_vote = 0, t_machines = 0, t_search = 0, t_advance = 0; int n_batches = 0; size_t n_tasks = 0;
     std::vector<int> active(n), stop(n, 0), crit(n, 0), calls(n, 0);
     for (int i = 0; i < n; ++i) active[i] = i;
     std::vector<std::vector<spdp_loci::Locus>> found(n);
@@ -408,6 +413,7 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
         for (int k = 0; k < m; ++k) { const int q = active[k]; o[k + 1] = o[k] + (offs[q + 1] - offs[q]); l[k] = left[q]; r[k] = right[q]; st[k] = stop[q]; }
         std::vector<uint8_t> cd((size_t) o[m]);
         for (int k = 0; k < m; ++k) memcpy(cd.data() + o[k], codes + offs[active[k]], (size_t) (o[k + 1] - o[k]));
+        auto t0 = now();
         for (;;) {
             rec.assign((size_t) m * out_cap, 0);
             if (spdp_blk_vote(ctx, ix, cd.data(), o.data(), l.data(), r.data(), st.data(), m, rec.data(), out_cap, nullptr)) return -1;
@@ -416,6 +422,7 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
             if (!cut || out_cap >= (1 << 20)) break;
             out_cap *= 8;
         }
+        auto t1 = now(); t_vote += secs(t0, t1);
         // ---- a machine per query that reached its call
         std::vector<spdp_loci::Call> mach(m);
         std::vector<int> verdict(m, 0);                 // > 0 loci, 0 go on, -1 ended, -2 record cut / table full
@@ -452,8 +459,12 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
             for (auto& x : fr) tasks.push_back({k, x.first, x.second, {}});
         }
         std::vector<std::vector<SearchTask>> answers(m);
+        auto t2 = now(); t_machines += secs(t1, t2);
         while (!tasks.empty()) {
+            auto t3 = now();
+            ++n_batches; n_tasks += tasks.size();
             if (B.run(tasks, active)) return -1;
+            auto t4 = now(); t_search += secs(t3, t4);
             for (SearchTask& t : tasks) answers[t.machine].push_back(std::move(t));
             tasks.clear();
             std::vector<SearchTask> more(m);
@@ -472,6 +483,7 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
                 }
             });
             for (int k = 0; k < m; ++k) if (asks[k]) tasks.push_back(std::move(more[k]));
+            t_advance += secs(t4, now());
         }
         std::vector<int> again;
         for (int k = 0; k < m; ++k) {
@@ -488,6 +500,8 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
         }
         active.swap(again);
     }
+    if (verbose) fprintf(stderr, "[find] %d queries: votes %.3f s, machines set up %.3f s, %d search batches of %zu tasks %.3f s (device + chains), machines advanced %.3f s\n",
+                         n, t_vote, t_machines, n_batches, n_tasks, t_search, t_advance);
     size_t nl = 0, nh = 0;
     for (int q = 0; q < n; ++q) for (const spdp_loci::Locus& g : found[q]) { ++nl; nh += g.hsp.size(); }
     *loci = (SpdpLocus*) malloc(sizeof(SpdpLocus) * std::max<size_t>(nl, 1));

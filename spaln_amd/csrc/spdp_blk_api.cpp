@@ -23,6 +23,7 @@ struct SpdpBlkIndex {
     // the genome, resident for the HSP searches (uploaded by the first spdp_blk_find that names it)
     uint8_t* d_genome = nullptr; const uint8_t* genome_host = nullptr; int64_t genome_len = 0;
     uint8_t* d_tron = nullptr; int32_t* d_mtx = nullptr;
+    BlkDev* d_dev = nullptr;                    // `dev` as the kernels read it
     size_t slab_bytes = 0;
     int n_waves = 0, hh_in_lds = 0;
     uint32_t lds_bytes = 0;
@@ -34,6 +35,7 @@ struct SpdpBlkIndex {
         if (d_genome) (void) hipFree(d_genome);
         if (d_tron) (void) hipFree(d_tron);
         if (d_mtx) (void) hipFree(d_mtx);
+        if (d_dev) (void) hipFree(d_dev);
     }
 };
 
@@ -158,12 +160,14 @@ extern "C" SpdpBlkIndex* spdp_blk_index_create(SpdpContext* ctx, const SpdpBlkIn
     if (v.hh_size2 < 1 || v.hb_size2 < 1 || v.ha_size2 < 1 || v.hh_size2 > v.hh_size1 || v.hb_size2 > v.hb_size1 || v.ha_size2 > v.ha_size1) {
         ctx->err = "spdp_blk_index_create: a table's second step exceeds its size"; delete ix; return nullptr;
     }
-    // the run hash of a wave lives in LDS when its first level fits beside the queues (16 KB: ten waves per CU)
-    ix->hh_in_lds = (size_t) v.hh_sizes[0] * 8 <= (size_t) 16 << 10;
+    // the run hash of a wave lives in LDS when its first level fits beside the queues (8 KB: some ten waves per CU)
+    ix->hh_in_lds = (size_t) v.hh_sizes[0] * 8 <= (size_t) 8 << 10;
     if (const char* e = getenv("SPDP_BLK_HH_LDS")) ix->hh_in_lds = atoi(e) != 0 && (size_t) v.hh_sizes[0] * 8 <= (size_t) 48 << 10;
     ix->lds_bytes = spdp_blk_vote_lds_bytes(&v, ix->hh_in_lds);
     if (ix->lds_bytes > (64u << 10)) { ctx->err = "spdp_blk_index_create: the queues of a query do not fit the LDS of a workgroup (ncand / nascr too large)"; delete ix; return nullptr; }
     ix->slab_bytes = spdp_blk_vote_slab_bytes(&v, ix->hh_in_lds);
+    if (getenv("SPDP_BLK_VERBOSE")) fprintf(stderr, "[blk] nseg %d, longest list %d, run hash %d slots (%s), LDS %u B per wave, slab %.2f MB per wave\n",
+                                            v.nseg, v.maxlist, v.hh_sizes[0], ix->hh_in_lds ? "LDS" : "HBM", ix->lds_bytes, ix->slab_bytes / 1048576.);
     return ix;
 }
 
@@ -200,12 +204,16 @@ extern "C" int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* cix,
     (void) hipSetDevice(ctx->device);
     if (ensure_waves(ctx, ix, n)) return -1;
     BlkVoteArgs A;
-    A.ix = ix->dev;
+    if (!ix->d_dev) {
+        HIPCHK(hipMalloc((void**) &ix->d_dev, sizeof(BlkDev)));
+        HIPCHK(hipMemcpy(ix->d_dev, &ix->dev, sizeof(BlkDev), hipMemcpyHostToDevice));
+    }
+    A.ix = ix->d_dev;
     A.codes = d_codes; A.offs = d_offs; A.left = d_left; A.right = d_right; A.stop_at = d_stop_at;
     A.out = d_out; A.out_cap = out_cap; A.n = n;
     A.slabs = ix->slabs; A.slab_bytes = ix->slab_bytes; A.next = ix->next;
     A.n_waves = std::min(ix->n_waves, n);
-    A.hh_in_lds = ix->hh_in_lds; A.lds_bytes = ix->lds_bytes;
+    A.hh_in_lds = ix->hh_in_lds; A.lds_bytes = ix->lds_bytes; A.res_cap = SPDP_BLK_RES_CAP;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(spdp_blk_vote_launch(&A, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

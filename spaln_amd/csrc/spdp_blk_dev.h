@@ -9,6 +9,8 @@
 #endif
 
 #define SPDP_BLK_MAX_SHIFT 32
+#define SPDP_BLK_PRE_PHASES 12          // phases of a direction whose posting lists are fetched ahead (Nshift beyond: fetched one by one)
+#define SPDP_BLK_RES_CAP 2048            // query residues a wave keeps in LDS (longer queries are read where they lie)
 #define SPDP_BLK_HASH_LEVELS 4          // the run hash may grow three times (x ~8) before a query is reported as SPDP_BLK_TABLE
 
 struct BlkDev {                         // the index and the search parameters (pointers into HBM on the device side)
@@ -54,7 +56,7 @@ inline void blk_fill_hash_levels(BlkDev& ix)
 // One wave per query.  A wave's working set: LDS (scan positions, the eight bounded queues with their position tables, the run
 // hash when it fits) and a slab of HBM (score records of every block and direction, the larger run-hash levels, staging).
 struct BlkVoteArgs {
-    BlkDev ix;
+    const BlkDev* ix;                           // in device memory (a kernel argument whose address is taken would be copied to every lane's stack)
     const uint8_t* codes; const int64_t* offs; const int32_t* left; const int32_t* right; const int32_t* stop_at;
     int32_t* out; int out_cap, n;
     uint8_t* slabs; size_t slab_bytes;          // one per wave of the launch; zero when allocated, kept between launches
@@ -62,6 +64,7 @@ struct BlkVoteArgs {
     int n_waves;
     int hh_in_lds;                              // level 0 of the run hash lives in LDS
     uint32_t lds_bytes;
+    int res_cap;
 };
 #ifdef __HIPCC__
 extern "C" hipError_t spdp_blk_vote_launch(const BlkVoteArgs* a, hipStream_t s);

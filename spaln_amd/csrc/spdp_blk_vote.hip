@@ -34,7 +34,7 @@ namespace {
 typedef unsigned long long u64;
 struct KV { uint32_t key; int32_t val; };           // a table slot / a queue entry {block, score}
 
-constexpr int OWN_SLOTS = 1024;                     // owner marks, slot number folded (a false meeting only splits a chunk early)
+constexpr int OWN_SLOTS = 256;                      // owner marks, slot number folded (a false meeting only splits a chunk early)
 constexpr uint32_t NOBODY = 0xffffffffu;
 // status words of the wave (LDS)
 enum { ST_SIGN = 0, ST_MMCT = 4, ST_NHIT = 8, ST_MAXS = 12, ST_TESTWORD = 16, ST_MAXBSCR = 20, ST_QA_FRONT = 24, ST_QB_FRONT = 28,
@@ -50,7 +50,7 @@ __device__ __forceinline__ int from_lane(int x, int l) { return __builtin_amdgcn
 
 struct Modulus {                                    // x mod n without a division (n fixed for many x)
     uint32_t n, m;
-    __device__ void set(uint32_t n_) { n = n_; m = 0xffffffffu / n_; }
+    __device__ __forceinline__ void set(uint32_t n_) { n = n_; m = 0xffffffffu / n_; }
     __device__ __forceinline__ uint32_t of(uint32_t x) const
     {
         uint32_t r = x - __umulhi(x, m) * n;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void slot_put(u64* p, uint32_t tag, int v)
 // and a slot of another phase is empty: "cleared" costs nothing 254 times out of 255.
 struct RunHash {
     KV* lds; KV* glob;                              // level 0 in LDS (or null), the levels in HBM
-    KV* g0; KV* ga; KV* gb;
+    KV* g0; KV* grown; uint32_t b_off;                  // level 0 in the slab (when not in LDS); the larger levels: A at grown, B at grown + b_off
     Modulus size; uint32_t step_mod;
     uint32_t epoch; bool epochs;
     int level;
@@ -92,20 +92,21 @@ struct RunHash {
     __device__ __forceinline__ bool live(const KV& kv) const { return kv.val != 0 && (!epochs || (kv.key >> 24) == epoch); }
     __device__ __forceinline__ uint32_t key_of(const KV& kv) const { return epochs ? kv.key & 0xffffffu : kv.key; }
     __device__ __forceinline__ uint32_t home(uint32_t key) const { return size.of(key); }
-    __device__ __forceinline__ uint32_t stride(uint32_t key) const { return step_mod - key % step_mod; }
+    __device__ __forceinline__ uint32_t stride(uint32_t key) const { return step_mod - ((step_mod & (step_mod - 1)) ? key % step_mod : (key & (step_mod - 1))); }
     __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t u) const { s += u; while (s >= size.n) s -= size.n; return s; }
-    __device__ void bind(int lv)
+    __device__ __forceinline__ void bind(int lv)
     {
         level = lv;
         size.set((uint32_t) sizes[lv]);
-        glob = lv == 0 ? g0 : ((lv & 1) ? ga : gb);
+        glob = g0;
+        if (lv) glob = grown + ((lv & 1) ? 0u : b_off);
     }
-    __device__ void wipe() const                    // all lanes
+    __device__ __forceinline__ void wipe() const                    // all lanes
     {
         const KV z = {0u, 0};
         for (uint32_t i = lane_id(); i < size.n; i += 64) { if (in_lds()) lds[i] = z; else glob[i] = z; }
     }
-    __device__ void new_phase()                     // all lanes, uniform
+    __device__ __forceinline__ void new_phase()                     // all lanes, uniform
     {
         if (epochs && ++epoch < 256) return;
         wipe();
@@ -150,7 +151,7 @@ __device__ __forceinline__ bool path_meets_lower(const RunHash& h, const uint32_
 // slot number and with the stride it had in the old one (Dhash::map / resize, src/clib.h:298-355)
 struct SlowHash {
     RunHash* h; int* st;
-    __device__ bool grow()
+    __device__ __forceinline__ bool grow()
     {
         RunHash& H = *h;
         if (H.level + 1 >= SPDP_BLK_HASH_LEVELS) return false;
@@ -174,7 +175,7 @@ struct SlowHash {
         return true;
     }
     // the slot of a key (claimed if empty), its count after the increment written
-    __device__ uint32_t bump(uint32_t key, int& count)
+    __device__ __forceinline__ uint32_t bump(uint32_t key, int& count)
     {
         RunHash& H = *h;
         uint32_t s = H.home(key);
@@ -190,7 +191,7 @@ struct SlowHash {
         return s;
     }
     // -> the block credited with the word (0xffffffff: none)
-    __device__ uint32_t entry(uint32_t blk, int p, bool towards_up)
+    __device__ __forceinline__ uint32_t entry(uint32_t blk, int p, bool towards_up)
     {
         RunHash& H = *h;
         int c;
@@ -212,17 +213,18 @@ struct SlowHash {
 // being marked empty, so a block CAN be lost from sight and entered twice: kept as it is, results depend on it.
 struct BestOf {
     KV* heap; KV* place; int cap; Modulus size; uint32_t step_mod; int* front; int* trouble;
-    KV* level0; KV* grown_a; KV* grown_b; const int32_t* sizes; int* level;      // the table's home in LDS, its larger forms in the slab
-    __device__ __forceinline__ uint32_t stride(uint32_t key) const { return step_mod - key % step_mod; }
+    KV* level0; KV* grown; uint32_t b_off; const int32_t* sizes; int* level;      // the table's home in LDS, its larger forms in the slab
+    __device__ __forceinline__ uint32_t stride(uint32_t key) const { return step_mod - ((step_mod & (step_mod - 1)) ? key % step_mod : (key & (step_mod - 1))); }
     __device__ __forceinline__ uint32_t next(uint32_t s, uint32_t u) const { s += u; while (s >= size.n) s -= size.n; return s; }
-    __device__ void bind(int lv)
+    __device__ __forceinline__ void bind(int lv)
     {
         size.set((uint32_t) sizes[lv]);
-        place = lv == 0 ? level0 : ((lv & 1) ? grown_a : grown_b);
+        place = level0;
+        if (lv) place = grown + ((lv & 1) ? 0u : b_off);
     }
     // where the heap holds the block, as far as the table knows (-1: not; -2: the probe came round -- the table is full and the
     // reference grows it at this very lookup: the caller takes the one-lane path)
-    __device__ int where(uint32_t key) const
+    __device__ __forceinline__ int where(uint32_t key) const
     {
         uint32_t s = size.of(key);
         const uint32_t u = stride(key), s0 = s;
@@ -235,7 +237,7 @@ struct BestOf {
         }
     }
     // one lane: the table of the next size, the live entries re-entered in slot order (Dhash::resize, src/clib.h:341-355)
-    __device__ bool grow()
+    __device__ __forceinline__ bool grow()
     {
         if (*level + 1 >= SPDP_BLK_HASH_LEVELS) { *trouble |= SPDP_BLK_TABLE; return false; }
         const KV* old = place;
@@ -254,7 +256,7 @@ struct BestOf {
     }
     // one lane: the slot of a key -- its own, or the empty one its probe sequence meets first; a probe that comes round grows the
     // table and goes on in the new one from the slot number and with the stride it had (Dhash::map)
-    __device__ uint32_t slot_for(uint32_t key)
+    __device__ __forceinline__ uint32_t slot_for(uint32_t key)
     {
         uint32_t s = size.of(key);
         const uint32_t u = stride(key), s0 = s;
@@ -265,9 +267,9 @@ struct BestOf {
             if (s == s0 && !grow()) return s;
         }
     }
-    __device__ void note(uint32_t key, int at) { const uint32_t s = slot_for(key); place[s] = KV{key, at}; }     // one lane
-    __device__ void seat(int k, KV v) { heap[k] = v; note(v.key, k); }
-    __device__ void sink(int k)
+    __device__ __forceinline__ void note(uint32_t key, int at) { const uint32_t s = slot_for(key); place[s] = KV{key, at}; }     // one lane
+    __device__ __forceinline__ void seat(int k, KV v) { heap[k] = v; note(v.key, k); }
+    __device__ __forceinline__ void sink(int k)
     {
         const KV v = heap[k];
         const int n = *front;
@@ -278,7 +280,7 @@ struct BestOf {
         }
         seat(k, v);
     }
-    __device__ void rise(int k)
+    __device__ __forceinline__ void rise(int k)
     {
         const KV v = heap[k];
         while (k > 0) {
@@ -290,14 +292,14 @@ struct BestOf {
         seat(k, v);
     }
     // would offering {key, score} change anything?  (all lanes, their own offers, on the list as it is)
-    __device__ bool matters(uint32_t key, int score) const
+    __device__ __forceinline__ bool matters(uint32_t key, int score) const
     {
         const int at = where(key);
         if (at == -2) return true;                      // (the lookup itself changes the table)
         if (at < 0 && *front < cap) return true;
         return heap[at < 0 ? 0 : at].val < score;
     }
-    __device__ void offer(uint32_t key, int score)  // one lane
+    __device__ __forceinline__ void offer(uint32_t key, int score)  // one lane
     {
         int at;                                         // (a lookup, not a claim: an empty slot stays as it is)
         { const uint32_t s = slot_for(key); const KV kv = place[s]; at = (kv.val != -1 && kv.key == key) ? kv.val : -1; }
@@ -312,7 +314,7 @@ struct BestOf {
         }
     }
     // the offers of the lanes in `who`, in lane order
-    __device__ void offer_in_order(u64 who, uint32_t key, int score)
+    __device__ __forceinline__ void offer_in_order(u64 who, uint32_t key, int score)
     {
         const int me = lane_id();
         int from = 0;
@@ -327,7 +329,7 @@ struct BestOf {
             from = l + 1;
         }
     }
-    __device__ void reset()                         // all lanes
+    __device__ __forceinline__ void reset()                         // all lanes
     {
         if (lane_id() == 0) { *front = 0; *level = 0; }
         bind(0);
@@ -336,19 +338,21 @@ struct BestOf {
 };
 
 // ---- the words of the query --------------------------------------------------------------------------------------------------
-struct Word { int score; uint32_t off[2]; int len[2]; };      // score < 0: no usable word, 0: a ubiquitous one; up to two posting lists
+struct Word { int score; uint32_t off0, off1; int len0, len1; };      // score < 0: no usable word, 0: a ubiquitous one; up to two posting lists
 
 struct Speller {
     const BlkDev* ix; const uint8_t* q; int q_len, right;
-    __device__ uint32_t residue(int i) const
+    const uint8_t* res;                                 // the query's residues as the index's alphabet sees them (LDS), or null: too long
+    __device__ __forceinline__ uint32_t residue(int i) const
     {
         if (i < 0 || i >= q_len) return 255u;
+        if (res) return res[i];
         const int c = q[i];
         return c < ix->convts ? ix->convtab[c] : 255u;
     }
     // the word of pattern k at ss: read left to right (d < 2) or as the other strand sees it (d >= 2).  A word that meets an
     // unusable residue keeps the digits read so far (the reference looks its table entries up all the same)
-    __device__ uint32_t spell(int ss, int d, int k, int& good) const
+    __device__ __forceinline__ uint32_t spell(int ss, int d, int k, int& good) const
     {
         const int32_t* bp = ix->bitpat + ix->pat_off[k];
         const int weight = bp[0];
@@ -368,10 +372,10 @@ struct Speller {
         // the digits sit at the top of the word: scaled by base ^ (weight - good)
         return good ? rev * ((uint32_t) ix->tabsize / unit) : 0u;
     }
-    __device__ Word at(int ss, int d) const
+    __device__ __forceinline__ Word at(int ss, int d) const
     {
         const BlkDev& X = *ix;
-        Word w; w.score = -1; w.off[0] = w.off[1] = 0; w.len[0] = w.len[1] = 0;
+        Word w; w.score = -1; w.off0 = w.off1 = 0; w.len0 = w.len1 = 0;
         const uint32_t tab = (uint32_t) X.tabsize;
         if (X.kk == 1) {
             int good;
@@ -380,7 +384,7 @@ struct Speller {
             if (!lp) { w.score = 0; return w; }
             if (good != X.bitpat[X.pat_off[0]]) return w;
             w.score = X.wscr[x];
-            w.off[0] = (uint32_t) lp - 1; w.len[0] = X.nblk[x];
+            w.off0 = (uint32_t) lp - 1; w.len0 = X.nblk[x];
             return w;
         }
         int n_ok = 0, sum = 0;
@@ -393,14 +397,15 @@ struct Speller {
             const int32_t lp = X.blkp[x];
             if (!lp) continue;
             ++n_ok; sum += X.wscr[x];
-            if (k < X.kk - 1) { w.off[k] = (uint32_t) lp - 1; w.len[k] = X.nblk[x]; }     // (the last pattern scores but does not vote)
+            if (k == 0 && X.kk > 1) { w.off0 = (uint32_t) lp - 1; w.len0 = X.nblk[x]; }
+            else if (k == 1 && X.kk > 2) { w.off1 = (uint32_t) lp - 1; w.len1 = X.nblk[x]; }     // (the last pattern scores but does not vote)
         }
         if (n_ok) w.score = (int) ((double) sum / X.app_c);
         return w;
     }
 };
 
-__device__ int random_expectation(const BlkDev& X, uint32_t mmc)
+__device__ __forceinline__ int random_expectation(const BlkDev& X, uint32_t mmc)
 {
     if (mmc < 128) return X.rscrtab[mmc];
     if (X.rbscoef == 0) return (int) X.rbscons;
@@ -409,8 +414,8 @@ __device__ int random_expectation(const BlkDev& X, uint32_t mmc)
 }
 
 // ---- chromosomes: the one that holds a block ---------------------------------------------------------------------------------
-__device__ uint32_t first_block(const BlkDev& X, int c) { return (uint32_t) X.chr[2 * c + 1]; }
-__device__ int chromosome_of(const BlkDev& X, uint32_t blk)
+__device__ __forceinline__ uint32_t first_block(const BlkDev& X, int c) { return (uint32_t) X.chr[2 * c + 1]; }
+__device__ __forceinline__ int chromosome_of(const BlkDev& X, uint32_t blk)
 {
     // the reference brackets the answer with a linear estimate before it bisects (src/blksrc.cc:1985-2002); the bracket decides
     // which chromosome a block on a boundary of equal first blocks is given to, so it is kept
@@ -432,27 +437,35 @@ __device__ int chromosome_of(const BlkDev& X, uint32_t blk)
 struct Wave {
     const BlkDev* ix;
     int* st; int* as; uint32_t* own;
-    KV* q_mem[2]; int q_words[2]; int q_cap[2]; uint32_t q_step[2];       // [0] by word hits, [1] by run score
-    KV* q_grown[2]; int q_grown_words[2];               // the larger forms of the position tables (slab): per list A then B
-    __device__ __forceinline__ BestOf hits_list(int d) const { return list(0, d); }
-    __device__ __forceinline__ BestOf run_list(int d) const { return list(1, d); }
-    __device__ __forceinline__ BestOf list(int which, int d) const
+    // the eight best-of lists: by word hits (h) and by run score (r), a list per direction
+    KV* qh_mem; KV* qr_mem; KV* qh_grown; KV* qr_grown;
+    int qh_words, qr_words, qh_cap, qr_cap, qh_grown_words, qr_grown_words; uint32_t qh_step, qr_step;
+    __device__ __forceinline__ BestOf hits_list(int d) const
     {
         BestOf Q;
-        KV* m = (which ? q_mem[1] : q_mem[0]) + (size_t) d * (which ? q_words[1] : q_words[0]);
-        Q.cap = which ? q_cap[1] : q_cap[0];
-        Q.heap = m; Q.level0 = m + Q.cap + 1;
-        Q.sizes = which ? ix->hb_sizes : ix->ha_sizes;
-        KV* g = (which ? q_grown[1] : q_grown[0]) + (size_t) d * (which ? q_grown_words[1] : q_grown_words[0]);
-        Q.grown_a = g; Q.grown_b = g + Q.sizes[SPDP_BLK_HASH_LEVELS - 1];
-        Q.step_mod = which ? q_step[1] : q_step[0];
-        Q.front = st + (which ? ST_QB_FRONT : ST_QA_FRONT) + d; Q.trouble = st + ST_TROUBLE;
-        Q.level = st + ST_Q_LEVEL + 4 * which + d;
+        KV* m = qh_mem + (size_t) d * qh_words;
+        Q.cap = qh_cap; Q.heap = m; Q.level0 = m + Q.cap + 1; Q.sizes = ix->ha_sizes;
+        KV* g = qh_grown + (size_t) d * qh_grown_words;
+        Q.grown = g; Q.b_off = (uint32_t) Q.sizes[SPDP_BLK_HASH_LEVELS - 1];
+        Q.step_mod = qh_step; Q.front = st + ST_QA_FRONT + d; Q.trouble = st + ST_TROUBLE; Q.level = st + ST_Q_LEVEL + d;
+        Q.bind(*Q.level);
+        return Q;
+    }
+    __device__ __forceinline__ BestOf run_list(int d) const
+    {
+        BestOf Q;
+        KV* m = qr_mem + (size_t) d * qr_words;
+        Q.cap = qr_cap; Q.heap = m; Q.level0 = m + Q.cap + 1; Q.sizes = ix->hb_sizes;
+        KV* g = qr_grown + (size_t) d * qr_grown_words;
+        Q.grown = g; Q.b_off = (uint32_t) Q.sizes[SPDP_BLK_HASH_LEVELS - 1];
+        Q.step_mod = qr_step; Q.front = st + ST_QB_FRONT + d; Q.trouble = st + ST_TROUBLE; Q.level = st + ST_Q_LEVEL + 4 + d;
         Q.bind(*Q.level);
         return Q;
     }
     RunHash hh;
     Score* score; uint32_t* stage; int32_t* scratch; uint32_t* header;
+    uint8_t* res; int res_cap;
+    uint32_t* pre;                                      // the first 64 entries of the posting lists of a direction's phases (fetched together)
     uint32_t tag;
 };
 
@@ -460,7 +473,7 @@ struct Pair { int32_t bscr, chr; uint32_t lb, rb, ub, db, zl, zr; int32_t rvs; }
 
 // the significant blocks of one strand, both ends, in genome order, joined into spans: a span is a block or a stretch of blocks
 // that belong to one gene as far as their distances say (extract_to_work).  -> spans as (first, last), n
-__device__ int spans_of_strand(const Wave& W, int f, uint32_t* sites, uint32_t* first, uint32_t* last)
+__device__ __forceinline__ int spans_of_strand(const Wave& W, int f, uint32_t* sites, uint32_t* first, uint32_t* last)
 {
     const BlkDev& X = *W.ix;
     const int d = 2 * f, e = d + 1;
@@ -499,7 +512,7 @@ __device__ int spans_of_strand(const Wave& W, int f, uint32_t* sites, uint32_t* 
 
 // TestOutput's list of candidate block pairs: every span grown over the neighbouring blocks that scored at all, its score the
 // sum of its blocks' run scores from both ends; best first, at most ncand (one lane)
-__device__ int candidate_pairs(const Wave& W, Pair* pairs)
+__device__ __forceinline__ int candidate_pairs(const Wave& W, Pair* pairs)
 {
     const BlkDev& X = *W.ix;
     const int nseg = X.nseg, cap = X.ncand;
@@ -548,12 +561,12 @@ __device__ int candidate_pairs(const Wave& W, Pair* pairs)
 
 struct Record {                                         // one query's record, written by lane 0 unless said otherwise
     int32_t* out; int cap, n; bool cut;
-    __device__ void put(int v) { if (n < cap) out[n] = v; else cut = true; ++n; }
+    __device__ __forceinline__ void put(int v) { if (n < cap) out[n] = v; else cut = true; ++n; }
 };
 
 // the state at a TestOutput call: counters, the significant blocks per direction in their lists' own order, the candidate pairs,
 // the run scores around the pairs on their strands (what FindHsp looks at when it moves a pair's ends, src/blksrc.cc:2408-2460)
-__device__ void write_state(Wave& W, Record& R)
+__device__ __forceinline__ void write_state(Wave& W, Record& R)
 {
     const BlkDev& X = *W.ix;
     const int me = lane_id(), nseg = X.nseg;
@@ -618,17 +631,17 @@ __device__ void write_state(Wave& W, Record& R)
 
 // the posting entries of one word, the lists merged when there are two (ascending, a block of both counted once): where they
 // are and how many (one lane merges into the staging area; one list is read where it lies)
-__device__ const uint32_t* entries_of(const Wave& W, const Word& w, int& n)
+__device__ __forceinline__ const uint32_t* entries_of(const Wave& W, const Word& w, int& n)
 {
     const BlkDev& X = *W.ix;
-    if (!w.len[1]) { n = w.len[0]; return X.blkb + w.off[0]; }
-    if (!w.len[0]) { n = w.len[1]; return X.blkb + w.off[1]; }
+    if (!w.len1) { n = w.len0; return X.blkb + w.off0; }
+    if (!w.len0) { n = w.len1; return X.blkb + w.off1; }
     int k = 0;
     if (lane_id() == 0) {
-        const uint32_t* a = X.blkb + w.off[0]; const uint32_t* b = X.blkb + w.off[1];
+        const uint32_t* a = X.blkb + w.off0; const uint32_t* b = X.blkb + w.off1;
         int i = 0, j = 0;
-        while (i < w.len[0] || j < w.len[1]) {
-            const uint32_t x = i < w.len[0] ? a[i] : 0xffffffffu, y = j < w.len[1] ? b[j] : 0xffffffffu;
+        while (i < w.len0 || j < w.len1) {
+            const uint32_t x = i < w.len0 ? a[i] : 0xffffffffu, y = j < w.len1 ? b[j] : 0xffffffffu;
             const uint32_t m = x < y ? x : y;
             if (!m) break;                              // (a zero ends a list)
             W.stage[k++] = m;
@@ -641,7 +654,7 @@ __device__ const uint32_t* entries_of(const Wave& W, const Word& w, int& n)
 }
 
 // One word of direction d, phase sft: all its posting entries.  -> how many of them the word's run went on in
-__device__ int vote_of_word(Wave& W, const Word& w, int d, int sft, int p, int threshold)
+__device__ __forceinline__ int vote_of_word(Wave& W, const Word& w, int d, int sft, int p, int threshold, bool fetched)
 {
     const BlkDev& X = *W.ix;
     const int me = lane_id(), nseg = X.nseg;
@@ -653,13 +666,20 @@ __device__ int vote_of_word(Wave& W, const Word& w, int d, int sft, int p, int t
     int went_on = 0;
     for (int c0 = 0; c0 < n_all; c0 += 64) {
         bool have = c0 + me < n_all;
-        const uint32_t blk = have ? list[c0 + me] : 0u;
+        const uint32_t blk = have ? ((fetched && c0 == 0) ? W.pre[sft * 64 + me] : list[c0 + me]) : 0u;
         const u64 zeros = __ballot(have && blk == 0);
         if (zeros) { have = have && me < first_lane(zeros); n_all = 0; }        // a zero ends the list
         // every hit counts for the block's total, and the totals' best-of list sees every one of them
-        int total = 0;
-        if (have) { total = slot_get(&sc[blk].hits, W.tag) + w.score; slot_put(&sc[blk].hits, W.tag, total); }
+        int total = 0, run_ahead = 0;                   // (the block's run score fetched in the same round trip: it is the one credited, mostly)
+        if (have) {
+            const u64 xh = __hip_atomic_load(&sc[blk].hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 xr = __hip_atomic_load(&sc[blk].run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total = ((uint32_t) (xh >> 32) == W.tag ? (int) (uint32_t) xh : 0) + w.score;
+            run_ahead = (uint32_t) (xr >> 32) == W.tag ? (int) (uint32_t) xr : 0;
+            slot_put(&sc[blk].hits, W.tag, total);
+        }
         W.hits_list(d).offer_in_order(__ballot(have), blk, total);
+        bool first_group = true;
         // the run hash: snapshot, marks, commit the lanes below the first meeting
         u64 pend = __ballot(have);
         while (pend) {
@@ -716,7 +736,13 @@ __device__ int vote_of_word(Wave& W, const Word& w, int d, int sft, int p, int t
             // of the direction, the best-of list of the blocks above the random expectation
             const bool cr = credited != NOBODY && ((done >> me) & 1);
             int run = 0;
-            if (cr) { run = slot_get(&sc[credited].run, W.tag) + w.score; slot_put(&sc[credited].run, W.tag, run); }
+            if (cr) {
+                // (within a group the credited blocks are distinct; a value fetched ahead is good for the chunk's first group only: a
+                // later group may follow a lane that credited this block as ITS neighbour)
+                run = ((first_group && credited == blk) ? run_ahead : slot_get(&sc[credited].run, W.tag)) + w.score;
+                slot_put(&sc[credited].run, W.tag, run);
+            }
+            first_group = false;
             const u64 crm = __ballot(cr);
             if (crm) {
                 went_on += __popcll(crm);
@@ -737,7 +763,7 @@ __device__ int vote_of_word(Wave& W, const Word& w, int d, int sft, int p, int t
 
 // the scan of one query up to its stop_at-th TestOutput call.  -> 0: it ends before that call; 1: reached; 2: reached, and it is
 // the call the reference makes behind its scan (TestOutput(1))
-__device__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, int stop_at, int& calls)
+__device__ __forceinline__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, int stop_at, int& calls)
 {
     const BlkDev& X = *W.ix;
     const int me = lane_id(), nshift = X.nshift;
@@ -758,7 +784,10 @@ __device__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, i
         W.as[1 * 32 + ph] = W.as[3 * 32 + ph] = ts + me;
     }
     lds_sync();
-    Speller sp = {&X, q, q_len, right};
+    const bool res_fits = q_len <= W.res_cap;
+    if (res_fits) for (int i = me; i < q_len; i += 64) { const int c = q[i]; W.res[i] = c < X.convts ? X.convtab[c] : (uint8_t) 255; }
+    lds_sync();
+    Speller sp = {&X, q, q_len, right, res_fits ? W.res : nullptr};
     const bool is_short = qlen < X.shortquery;
     const int base = X.rscrtab[0];
     int met_ends = 0;                                   // bit f: the two scans of strand f have met
@@ -772,8 +801,22 @@ __device__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, i
             const bool up = d & 1;
             const int e = d ^ 1;
             // the first word of every phase of this direction, a phase per lane
-            Word mine; mine.score = -1; mine.off[0] = mine.off[1] = 0; mine.len[0] = mine.len[1] = 0;
+            Word mine; mine.score = -1; mine.off0 = mine.off1 = 0; mine.len0 = mine.len1 = 0;
             if (me < nshift) mine = sp.at(W.as[d * 32 + me], d);
+            // ... and the head of every phase's posting list, all in flight together (one list: nothing to merge)
+            const bool fetch = nshift <= SPDP_BLK_PRE_PHASES;
+            if (fetch) {
+                uint32_t head[SPDP_BLK_PRE_PHASES];
+                #pragma unroll
+                for (int k = 0; k < SPDP_BLK_PRE_PHASES; ++k) {
+                    const int n0 = from_lane(mine.len0, k), n1 = from_lane(mine.len1, k), sc0 = from_lane(mine.score, k);
+                    const uint32_t o0 = (uint32_t) from_lane((int) mine.off0, k);
+                    head[k] = (k < nshift && sc0 > 0 && !n1 && me < n0) ? X.blkb[o0 + me] : 0u;
+                }
+                #pragma unroll
+                for (int k = 0; k < SPDP_BLK_PRE_PHASES; ++k) if (k < nshift) W.pre[k * 64 + me] = head[k];
+                lds_sync();
+            }
             int maxp = 0;
             for (int sft = 0; sft < nshift; ++sft) {
                 const int ms = is_short ? (up ? left : right) : W.as[e * 32 + sft];
@@ -789,18 +832,19 @@ __device__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, i
                     Word w;
                     if (first) {
                         w.score = from_lane(mine.score, sft);
-                        w.off[0] = (uint32_t) from_lane((int) mine.off[0], sft); w.len[0] = from_lane(mine.len[0], sft);
-                        w.off[1] = (uint32_t) from_lane((int) mine.off[1], sft); w.len[1] = from_lane(mine.len[1], sft);
+                        w.off0 = (uint32_t) from_lane((int) mine.off0, sft); w.len0 = from_lane(mine.len0, sft);
+                        w.off1 = (uint32_t) from_lane((int) mine.off1, sft); w.len1 = from_lane(mine.len1, sft);
                     } else {
                         w = sp.at(ss, d);
-                        w.score = uni(w.score); w.off[0] = uniu(w.off[0]); w.off[1] = uniu(w.off[1]); w.len[0] = uni(w.len[0]); w.len[1] = uni(w.len[1]);
+                        w.score = uni(w.score); w.off0 = uniu(w.off0); w.off1 = uniu(w.off1); w.len0 = uni(w.len0); w.len1 = uni(w.len1);
                     }
+                    const bool was_first = first;
                     first = false;
                     if (w.score < 0) break;
                     if (me == 0) W.st[ST_TESTWORD + d] += X.kk;
                     if (w.score == 0) { more = 1; continue; }
                     ++p; cscr += w.score;
-                    more = vote_of_word(W, w, d, sft, p, threshold);
+                    more = vote_of_word(W, w, d, sft, p, threshold, fetch && was_first && !w.len1);
                 } while (more && cscr < base);
                 if (p > maxp) maxp = p;
                 lds_sync();
@@ -839,10 +883,11 @@ __device__ int scan(Wave& W, const uint8_t* q, int q_len, int left, int right, i
     return 0;
 }
 
-__global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
+// (four waves per SIMD: the kernel waits for memory three quarters of its time, more waves in flight pay for a few spilled registers)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) spdp_blk_vote_wave(BlkVoteArgs A)
 {
     extern __shared__ uint32_t lds[];
-    const BlkDev& X = A.ix;
+    const BlkDev& X = *A.ix;
     const int me = lane_id();
     Wave W;
     W.ix = &X;
@@ -852,29 +897,29 @@ __global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
     W.as = (int*) l; l += 4 * 32;
     W.own = l; l += OWN_SLOTS;
     for (int i = me; i < OWN_SLOTS; i += 64) W.own[i] = NOBODY;
-    for (int which = 0; which < 2; ++which) {
-        const int cap = which ? X.ncand : X.nascr, hs = which ? X.hb_size1 : X.ha_size1;
-        W.q_cap[which] = cap; W.q_words[which] = cap + 1 + hs;
-        W.q_mem[which] = (KV*) l; l += 2 * 4 * (size_t) (cap + 1 + hs);
-        W.q_step[which] = (uint32_t) (which ? X.hb_size2 : X.ha_size2);
-    }
+    W.qh_cap = X.nascr; W.qh_words = X.nascr + 1 + X.ha_size1; W.qh_step = (uint32_t) X.ha_size2;
+    W.qh_mem = (KV*) l; l += 2 * 4 * (size_t) W.qh_words;
+    W.qr_cap = X.ncand; W.qr_words = X.ncand + 1 + X.hb_size1; W.qr_step = (uint32_t) X.hb_size2;
+    W.qr_mem = (KV*) l; l += 2 * 4 * (size_t) W.qr_words;
     // ---- the wave's slab
     uint8_t* g = A.slabs + (size_t) blockIdx.x * A.slab_bytes;
     W.header = (uint32_t*) g; g += 16;
     W.score = (Score*) g; g += sizeof(Score) * (4 * (size_t) X.nseg + 2);
     RunHash& H = W.hh;
     H.sizes = X.hh_sizes; H.step_mod = (uint32_t) X.hh_size2;
+    W.res = (uint8_t*) l; W.res_cap = A.res_cap; l += A.res_cap / 4;
+    W.pre = l; l += 64 * SPDP_BLK_PRE_PHASES;
     H.lds = A.hh_in_lds ? (KV*) l : nullptr;
     H.g0 = (KV*) g; if (!A.hh_in_lds) g += sizeof(KV) * (size_t) X.hh_sizes[0];
-    H.ga = (KV*) g; g += sizeof(KV) * (size_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 1];
-    H.gb = (KV*) g; g += sizeof(KV) * (size_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 2];
+    H.grown = (KV*) g; H.b_off = (uint32_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 1];
+    g += sizeof(KV) * ((size_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 1] + (size_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 2]);
     H.epochs = X.nseg < (1 << 24); H.epoch = 255;
     H.bind(0);
-    for (int which = 0; which < 2; ++which) {
-        const int32_t* sz = which ? X.hb_sizes : X.ha_sizes;
-        W.q_grown_words[which] = sz[SPDP_BLK_HASH_LEVELS - 1] + sz[SPDP_BLK_HASH_LEVELS - 2];
-        W.q_grown[which] = (KV*) g; g += sizeof(KV) * 4 * (size_t) W.q_grown_words[which];
-    }
+    // (the order of the slab: the run lists' larger tables after the hit lists', as spdp_blk_vote_slab_bytes counts them)
+    W.qh_grown_words = X.ha_sizes[SPDP_BLK_HASH_LEVELS - 1] + X.ha_sizes[SPDP_BLK_HASH_LEVELS - 2];
+    W.qh_grown = (KV*) g; g += sizeof(KV) * 4 * (size_t) W.qh_grown_words;
+    W.qr_grown_words = X.hb_sizes[SPDP_BLK_HASH_LEVELS - 1] + X.hb_sizes[SPDP_BLK_HASH_LEVELS - 2];
+    W.qr_grown = (KV*) g; g += sizeof(KV) * 4 * (size_t) W.qr_grown_words;
     W.stage = (uint32_t*) g; g += 4 * (2 * (size_t) X.maxlist + 2);
     W.scratch = (int32_t*) g;
     uint32_t tag = *W.header;
@@ -913,7 +958,7 @@ __global__ void __launch_bounds__(64) spdp_blk_vote_wave(BlkVoteArgs A)
 
 extern "C" uint32_t spdp_blk_vote_lds_bytes(const BlkDev* ix, int hh_in_lds)
 {
-    size_t w = ST_WORDS + 4 * 32 + OWN_SLOTS;
+    size_t w = ST_WORDS + 4 * 32 + OWN_SLOTS + SPDP_BLK_RES_CAP / 4 + 64 * SPDP_BLK_PRE_PHASES;
     w += 4 * (2 * ((size_t) ix->nascr + 1) + 2 * (size_t) ix->ha_size1);
     w += 4 * (2 * ((size_t) ix->ncand + 1) + 2 * (size_t) ix->hb_size1);
     if (hh_in_lds) w += 2 * (size_t) ix->hh_sizes[0];

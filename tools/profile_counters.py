@@ -38,7 +38,7 @@ KERNELS = [
     ("void spdh_rowwave<1,", "h_a0_fwd", "spaln_amd/csrc/spdp_h_rowwave.hip", "fwd_cells"),
     ("void spdh_rowwave<2,", "h_a0_udh", "spaln_amd/csrc/spdp_h_rowwave.hip", "udh_cells"),
     ("void spdh_exact<", "h_a1", "spaln_amd/csrc/spdp_h_exact.hip", "fwd_cells"),
-    ("spdp_blk_vote_wave", "blk", "spaln_amd/csrc/spdp_blk_vote.hip", None),
+    ("(anonymous namespace)::spdp_blk_vote_wave", "blk", "spaln_amd/csrc/spdp_blk_vote.hip", None),
 ]
 
 

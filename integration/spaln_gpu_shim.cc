@@ -480,6 +480,26 @@ const	    auto t0 = std::chrono::steady_clock::now();
 	if (g_dbg) fprintf(stderr, "[spaln_gpu] alignS_ng ori %d qck %d\n", ori, (int) algmode.qck);
 	// recorded now, aligned with everybody else's once the workers have joined: the pair as given, or (ori = 3, the default for a
 	// cDNA without a poly-A tail) both orientations -- with seeding on only when the HSP searches are the library's own
+	if (batch_mode() && ori == 2) {
+	    // -S2: the other orientation alone.  What the reference does to its operands before it aligns (src/fwd2s1.cc:2750-2753: the HSP
+	    // list turned around and handed to the anti-strand Seq, the query reverse-complemented, the strands swapped) is done here, at
+	    // the call; the pair is then recorded as given -- the library's ori = 1 on the reverse problem
+	    Seq*&	b = seqs[1];
+	    if (b->jxt) {
+		Seq*	c = b;
+		if (b->getanti()) {
+		    c = seqs[2];
+		    if (c->jxt) delete[] c->jxt;
+		    c->CdsNo = b->CdsNo;
+		    c->jxt = new JUXT[b->CdsNo + 1];
+		    vcopy(c->jxt, b->jxt, b->CdsNo + 1);
+		}
+		c->revjxt();
+	    }
+	    seqs[0]->comrev();
+	    antiseq(seqs + 1);
+	    ori = 1;
+	}
 	if (batch_mode() && algmode.mlt != 1 && (ori == 1 || (ori == 3 && seqs[1]->getanti() && (!algmode.qck || own_wilip())))) {
 	    record_job(seqs, pwd, algmode.qck? 1: 0, ori);
 	    ++g_calls[algmode.qck? 1: 0];

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("strand,extra", [("-S1", []), ("-S3", ["--antisense"]), ("-S1", ["--protein"])], ids=["S1", "S3_antisense", "protein"])
+@pytest.mark.parametrize("strand,extra", [("-S1", []), ("-S3", ["--antisense"]), ("-S2", ["--antisense"]), ("-S1", ["--protein"])],
+                         ids=["S1", "S3_antisense", "S2_antisense", "protein"])
 def test_records_identical_to_the_unmodified_program(strand, extra):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_gpu")):
         pytest.skip("oracle/_ref/spaln_gpu is not built")
@@ -22,6 +23,9 @@ def test_records_identical_to_the_unmodified_program(strand, extra):
     assert r.returncode == 0, r.stderr[-400:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     for run in d["runs"]:
-        assert run["reference"]["aligned"] == 200 and run["gpu"]["aligned"] == 200, run["mode"]
+        if strand != "-S2":                             # (-S2 aligns the other orientation alone: the sense half of the reads finds little)
+            assert run["reference"]["aligned"] == 200 and run["gpu"]["aligned"] == 200, run["mode"]
+        else:
+            assert run["reference"]["aligned"] == run["gpu"]["aligned"] >= 90, run["mode"]
         assert run["identical"] and run["records_differing"] == 0, (run["mode"], run["gpu"].get("shim", "")[:300])
         assert "left to the reference: 0" in run["gpu"].get("shim", ""), run["gpu"].get("shim", "")[:200]

@@ -922,6 +922,17 @@ int spdp_map_align_s(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkInde
                      const uint8_t* codes, const int64_t* offs, int32_t n, int32_t ori,
                      SpdpMapGene* genes, SpdpMapExon** exons, double* seconds);
 
+/* The same for protein queries against the translated index (`spaln -W -KP`, <db>.bkp): spdp_blk_find (model->dvsp = 1) -> per locus
+ * the region as tron codes and its SGPT6 signals (one launch of the signal kernels per chunk) -> spdp_align_h_seeded with the
+ * library's own HSP searches -> the junction phases of the walks written back -> spdp_skl_rng_h -> the locus with the highest
+ * fstat.val: what blkaln / genomicseq / spalign2 do for one query (src/spaln.cc:846-1010, 1137-1152), for a batch.  codes:
+ * amino-acid codes; exons: query positions in residues, genomic positions as -O4 prints them.  sp->wilip: the protein model. */
+int spdp_map_align_h(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIndexDesc* hix, const SpdpGenome* genome,
+                     const struct SpdpScoringH* sc, const SpdpSeedParams* sp, const struct SpdpSignalModelH* sigmodel,
+                     const SpdpBlkFindParams* fprm, const struct SpdpRescoreParamsH* rp,
+                     const uint8_t* codes, const int64_t* offs, int32_t n,
+                     SpdpMapGene* genes, SpdpMapExon** exons, double* seconds);
+
 /* ---- device groups, continued ------------------------------------------------------------------------------------------ */
 /* the same sharding for the calls of the seeded path, rescoring and the block vote (rounds 3 / 4).  The HSP source of a
  * seeded call is asked with the CALLER's query numbers, from the worker threads of every member.  spdp_group_blk_vote takes

@@ -329,3 +329,39 @@ def map_align(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm:
     libc.free.argtypes = [C.c_void_p]
     libc.free(exons)
     return out, list(sec), rc
+
+
+def map_align_h(index: "BlockIndex", genome_codes, chr_off, sc, sp, sigmodel, prm: BlkFindParams, rescore, queries):
+    """spdp_map_align_h: the same for protein queries against the translated index.  sc: abi.ScoringH; rescore = abi.RescoreParamsH;
+    Returns as map_align."""
+    lib, eng = index.lib, index.eng
+    n = len(queries)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    codes = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in queries]))
+    g = Genome()
+    gc = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    go = np.ascontiguousarray(chr_off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    genes = (MapGene * n)()
+    exons = C.POINTER(MapExon)()
+    sec = (C.c_double * 4)()
+    lib.spdp_map_align_h.restype = C.c_int
+    lib.spdp_map_align_h.argtypes = [C.c_void_p] * 11 + [C.c_int32] + [C.c_void_p] * 3
+    rc = lib.spdp_map_align_h(eng.ctx, index.h, C.byref(index.desc), C.byref(g), C.byref(sc), C.byref(sp), C.addressof(sigmodel),
+                              C.byref(prm), C.byref(rescore), codes.ctypes.data, offs.ctypes.data, n, genes, C.byref(exons), sec)
+    if rc < 0:
+        eng._check(rc, "spdp_map_align_h")
+    out = []
+    for i in range(n):
+        G = genes[i]
+        if G.chr < 0:
+            out.append(None)
+            continue
+        ex = [(exons[G.exon_off + j].q_left, exons[G.exon_off + j].q_right, exons[G.exon_off + j].g_left, exons[G.exon_off + j].g_right)
+              for j in range(G.n_exons)]
+        out.append(dict(chr=G.chr, rvs=G.rvs, q_rev=G.q_rev, score=G.score, val=G.val, n_loci=G.n_loci, exons=ex))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(exons)
+    return out, list(sec), rc

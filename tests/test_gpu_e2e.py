@@ -36,6 +36,20 @@ def test_exon_tables_equal_the_reference_program(ori):
     assert d["query_reversed"] == (150 if ori == 3 else 0)
 
 
+def test_protein_exon_tables_equal_the_reference_program():
+    """protein queries against the translated index (`spaln -W -KP`): ONE spdp_map_align_h call -- block search, regions as tron codes
+    and their signals, seeded alignment with the library's own HSP searches, the walks' junction phases, rescoring -- against
+    `spaln -Q7 -O4` (BASELINE configs[0] / [2]'s whole path)"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln")):
+        pytest.skip("oracle/_ref/spaln is not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_q7.py"), "--protein", "--queries", "300", "--genes", "60"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-400:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["reference_aligned"] == 300 and d["library_aligned"] == 300
+    assert d["identical_exon_tables"] == 300, (d, r.stderr[-600:])
+
+
 @pytest.mark.parametrize("scout", ["0", "1", "2"])
 def test_scout_pass_changes_nothing(scout, monkeypatch):
     """the walks of a seeded call as one run (0), with a scout run that hands the slow class of requests over without waiting (1),

@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import dropin_demo  # noqa: E402
-from spaln_amd import abi, blocks, engine  # noqa: E402
+from spaln_amd import abi, blocks, engine, synth  # noqa: E402
 from tests import spdg  # noqa: E402
 
 CODE_OF = np.zeros(256, dtype=np.uint8)
@@ -95,6 +95,82 @@ def reference_exons(text):
     return out
 
 
+def main_protein(args):
+    """BASELINE configs[0] / [2]'s whole path: protein queries, `spaln -Q7 -O4` against ONE spdp_map_align_h call"""
+    t_all = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="spdp_e2e_p_") as td:
+        genome_nt, env = dropin_demo.make_dataset(td, args)
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(dropin_demo.REF, "spaln"), "-Q7", "-O4", f"-t{args.threads}", "-dgnm", "q.fa"], cwd=td, env=env,
+                           capture_output=True, text=True)
+        ref_s = time.perf_counter() - t0
+        if r.returncode:
+            raise SystemExit("reference run failed: " + r.stderr[-300:])
+        want = reference_exons(r.stdout)
+        eng = engine.Engine(0)
+        lib = eng.lib
+        cli = cli_parameters(td, env, [])
+        model = abi.wilip_model_from_fixture(cli)
+        # the alignment parameters of a protein run of the reference with the program's cross-species setting (a ref_dump fixture), the
+        # intron-length limits and the IntPen table as the program holds them for THIS genome
+        qh = "live_h_q7555.spdg" if model.crs else "qh_0013.spdg"      # (live_h_*: a pair recorded inside the program itself, oracle/ref_build/dumpq.cc)
+        fq = spdg.load(os.path.join(ROOT, "tests", "golden", qh))
+        assert int(fq["seed_params"][13]) == model.crs, (qh, model.crs)
+        fsig = fq if "pm5_f32" in fq else spdg.load(os.path.join(ROOT, "tests", "golden", "h1_basic.spdg"))
+        t0 = time.perf_counter()
+        fx = blocks.read_index_file(lib, os.path.join(td, "gnm.bkp"), ext_block=int(cli["blk_prm"][blocks._PRM["extblock"]]))
+        fx["blk_convtab"][:2] = 255
+        dix = blocks.BlockIndex(eng, fx)
+        chr_names, chroms = read_fasta(os.path.join(td, "gnm.mfa"))
+        gen = np.concatenate(chroms).astype(np.uint8)
+        off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
+        q_names, q_raw = [], []
+        for blk_ in open(os.path.join(td, "q.fa")).read().split(">")[1:]:
+            nm, seq = blk_.split("\n", 1)
+            q_names.append(nm.split()[0]); q_raw.append(seq.replace("\n", ""))
+        queries = [synth.encode_protein(np.frombuffer(s_.encode(), dtype=np.uint8)) for s_ in q_raw]
+        ip = np.ascontiguousarray(cli["find_intpen"], dtype=np.int16)
+        llmt, minl, _rlmt, maxl = (int(x) for x in cli["cli_intron_prm"][:4])
+        sc = spdg.scoring_h(fq, intpen=ip, llmt=llmt, minl=minl)
+        sc.scalar_engines = 1
+        sp = abi.seed_params_from_fixture(fq)
+        sp.qck, sp.minl, sp.ip_maxl = 3, minl, maxl
+        sigmodel = abi.signal_model_h_from_fixture(fsig)
+        prm = blocks.find_params_from_fixture(cli)
+        prm.phase1t = int(dix.desc.rbscons)
+        rp = [int(x) for x in fq["rparams"]]
+        hp = dict(zip(spdg.HPARAM_NAMES, (int(x) for x in fq["hparams"])))
+        rescore = abi.RescoreParamsH(minl, rp[4], hp["lcl"], rp[1])
+        load_s = time.perf_counter() - t0
+        sp.wilip = C.addressof(model)
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            genes, phases, rc = blocks.map_align_h(dix, gen, off, sc, sp, sigmodel, prm, rescore, queries)
+            runs.append((time.perf_counter() - t0, phases))
+        lib_s, phases = runs[-1]
+        got = {q_names[i]: g["exons"] for i, g in enumerate(genes) if g is not None}
+        n_same = sum(1 for k, v in want.items() if got.get(k) == v)
+        diff = [k for k, v in want.items() if got.get(k) != v]
+        for k in diff[:args.show]:
+            sys.stderr.write(f"{k}\n  reference {want[k]}\n  library   {got.get(k)}\n")
+        if args.dump_diff:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_diff)), exist_ok=True)
+            gi = {q_names[i]: g for i, g in enumerate(genes)}
+            json.dump([{"name": k, "reference": want[k], "library": gi.get(k)} for k in diff], open(args.dump_diff, "w"), indent=1)
+        print(json.dumps({"what": "protein queries: block search on the translated index -> HSPs -> seeded alignment -> exon table inside the library "
+                                  "(spdp_map_align_h) against `spaln -Q7 -O4`",
+                          "queries": args.queries, "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
+                          "identical_exon_tables": n_same, "different": len(diff), "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
+                          "library_s": {"index_and_genome_load": round(load_s, 3), "map_align_call": round(lib_s, 3), "first_call": round(runs[0][0], 3),
+                                        "find": round(phases[0], 3), "regions_and_signals": round(phases[1], 3), "align": round(phases[2], 3),
+                                        "rescore": round(phases[3], 3)},
+                          "library_queries_per_s": round(len(got) / (load_s + lib_s), 1), "library_over_reference": round(ref_s / (load_s + lib_s), 2),
+                          "return_code": rc, "wall_s": round(time.perf_counter() - t_all, 1)}))
+        dix.free()
+        eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, default=2000)
@@ -109,9 +185,11 @@ def main():
     ap.add_argument("--ori", type=int, default=1, choices=[1, 3],
                     help="1: the queries as given against `spaln -S1`; 3: every other query reverse-complemented, both orientations "
                          "tried, against spaln's default (-S3)")
+    ap.add_argument("--protein", action="store_true", help="protein queries against the translated index (spaln -W -KP): spdp_map_align_h")
     ap.add_argument("--dump-diff", default="", help="write the queries whose exon tables differ (name, both tables, the library's gene record) to this JSON file")
     args = ap.parse_args()
-    args.protein = False
+    if args.protein:
+        return main_protein(args)
     t_all = time.perf_counter()
     with tempfile.TemporaryDirectory(prefix="spdp_e2e_") as td:
         genome_nt, env = dropin_demo.make_dataset(td, args)

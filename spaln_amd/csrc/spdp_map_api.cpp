@@ -300,16 +300,15 @@ static int map_align_h(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIn
         const int m = c1 - c0;
         const int64_t T = (tot + 255) / 256 * 256;
         // one host block: tron codes | sig5 sig3 sigS sigT sigE (int16) | phs5 phs3 (int8) | dinc
-        std::vector<uint8_t> Hbuf((size_t) T * 14);
-        uint8_t* reg = Hbuf.data();
-        int16_t* s16[5]; for (int i = 0; i < 5; ++i) s16[i] = (int16_t*) (Hbuf.data() + T + 2 * T * i);
-        int8_t* phs5 = (int8_t*) (Hbuf.data() + 11 * T); int8_t* phs3 = (int8_t*) (Hbuf.data() + 12 * T);
-        uint8_t* dinc = Hbuf.data() + 13 * T;
+        uint8_t* Hbuf = (uint8_t*) ctx->staging(2, (size_t) T * 14);       // (pinned, kept by the context)
+        if (!Hbuf) { ctx->err = "spdp_map_align_h: no pinned host memory for a chunk's regions and signals (SPDP_MAP_CHUNK_MPOS sets the chunk size)"; return -1; }
+        uint8_t* reg = Hbuf;
+        int16_t* s16[5]; for (int i = 0; i < 5; ++i) s16[i] = (int16_t*) (Hbuf + T + 2 * T * i);
+        int8_t* phs5 = (int8_t*) (Hbuf + 11 * T); int8_t* phs3 = (int8_t*) (Hbuf + 12 * T);
+        uint8_t* dinc = Hbuf + 13 * T;
         on_host_threads(m, [&](int j) {
             const SpdpLocus& L = loci[c0 + j];
-            std::vector<uint8_t> r;
-            spdp_region::materialize(genome->codes, genome->chr_off, L.chr, L.base, L.len, L.rvs != 0, true, r);
-            memcpy(reg + at[j], r.data(), (size_t) L.len + 1);
+            spdp_region::materialize_into(genome->codes, genome->chr_off, L.chr, L.base, L.len, L.rvs != 0, true, reg + at[j]);
             reg[at[j] + L.len + 1] = reg[at[j] + L.len + 2] = 0;
         });
         {
@@ -329,7 +328,7 @@ static int map_align_h(SpdpContext* ctx, const SpdpBlkIndex* ix, const SpdpBlkIn
             A.sig5 = (int16_t*) (D + T); A.sig3 = (int16_t*) (D + 3 * T); A.sigS = (int16_t*) (D + 5 * T); A.sigT = (int16_t*) (D + 7 * T);
             A.sigE = (int16_t*) (D + 9 * T); A.phs5 = (int8_t*) (D + 11 * T); A.phs3 = (int8_t*) (D + 12 * T); A.dinc = D + 13 * T; A.cano = D + 14 * T;
             if (spdh_signals_run(ctx, sigmodel, jobs, A, 0)) return -1;
-            HIPCHK(hipMemcpy(Hbuf.data() + T, D + T, (size_t) T * 13, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(Hbuf + T, D + T, (size_t) T * 13, hipMemcpyDeviceToHost));
         }
         std::vector<SpdpProblemH> probs(m);
         std::vector<const SpdpJuxt*> hl(m);

@@ -32,14 +32,19 @@ inline void to_tron(uint8_t* s, int len)
     }
 }
 
+// into dst[0 .. len]: the region's residues and a closing 0
+inline void materialize_into(const uint8_t* genome, const int64_t* chr_off, int chr, int base, int len, bool rvs, bool tron, uint8_t* dst)
+{
+    const uint8_t* src = genome + chr_off[chr] + base;
+    if (!rvs) memcpy(dst, src, (size_t) len);
+    else for (int i = 0; i < len; ++i) dst[i] = other_strand(src[len - 1 - i]);
+    dst[len] = 0;
+    if (tron) to_tron(dst, len);
+}
 inline void materialize(const uint8_t* genome, const int64_t* chr_off, int chr, int base, int len, bool rvs, bool tron, std::vector<uint8_t>& out)
 {
     out.resize((size_t) len + 1);
-    const uint8_t* src = genome + chr_off[chr] + base;
-    if (!rvs) memcpy(out.data(), src, (size_t) len);
-    else for (int i = 0; i < len; ++i) out[i] = other_strand(src[len - 1 - i]);
-    out[len] = 0;
-    if (tron) to_tron(out.data(), len);
+    materialize_into(genome, chr_off, chr, base, len, rvs, tron, out.data());
 }
 
 }   // namespace spdp_region

@@ -11,6 +11,9 @@
 #include "../../include/spdp.h"
 #include "spdp_dev.h"
 #include "spdp_internal.h"
+#include "spdp_hostcpus.h"
+#include <thread>
+#include <atomic>
 #include "spdp_gencode.h"
 
 #define HIPCHK(call)                                                                     \
@@ -212,6 +215,9 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
     std::vector<int64_t> soff, roff;
     std::vector<int> scnt;
     int64_t rtot = 0;
+    // where every problem's pieces go, then the pieces themselves on the host's threads (a batch of a map + align call is tens of
+    // thousands of loci of tens of kilobases: hundreds of millions of positions)
+    int64_t a_tot = 0, b_tot = 0, col_tot = 0, skl_tot = 0;
     for (int i = 0; i < n_probs; ++i) {
         const SpdpProblemH& p = probs[i];
         const int cnt = aln[i].n_skl - 1;
@@ -223,21 +229,39 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
         d.a_left = p.a_left; d.a_right = p.a_right; d.b_left = p.b_left; d.b_right = p.b_right;
         d.a_len = p.a_len; d.b_len = p.b_len;
         d.a_exgl = p.a_exgl; d.a_exgr = p.a_exgr; d.b_exgl = p.b_exgl; d.b_exgr = p.b_exgr;
-        d.a_off = (int64_t) a_all.size(); d.b_off = (int64_t) b_all.size(); d.col_off = (int64_t) phs.size() / 2;
-        a_all.insert(a_all.end(), p.a, p.a + p.a_len);
-        b_all.insert(b_all.end(), p.b, p.b + p.b_len + 1);
-        const int N = p.b_len + 3;
-        for (int x = 0; x < N; ++x) {
-            const short v[5] = {p.sig5[x], p.sig3[x], p.sigS[x], p.sigT[x], p.sigE[x]};
-            sig.insert(sig.end(), v, v + 5);
-            phs.push_back(p.phs5[x]); phs.push_back(p.phs3[x]);
-            dinc.push_back(x <= p.b_len ? p.dinc[x] : 0);
-        }
+        d.a_off = a_tot; d.b_off = b_tot; d.col_off = col_tot;
+        a_tot += p.a_len; b_tot += p.b_len + 1; col_tot += p.b_len + 3;
         idx.push_back(i); descs.push_back(d);
-        soff.push_back((int64_t) skl.size()); scnt.push_back(cnt);
-        skl.insert(skl.end(), aln[i].skl + 1, aln[i].skl + 1 + cnt);
+        soff.push_back(skl_tot); scnt.push_back(cnt);
+        skl_tot += cnt;
         roff.push_back(rtot);
         rtot += cnt + 3;                                    // exons, frame-shift records, end marker
+    }
+    a_all.resize((size_t) a_tot); b_all.resize((size_t) b_tot); sig.resize((size_t) col_tot * 5); phs.resize((size_t) col_tot * 2);
+    dinc.resize((size_t) col_tot); skl.resize((size_t) skl_tot);
+    {
+        std::atomic<int> next{0};
+        auto work = [&] {
+            for (int s; (s = next++) < (int) idx.size(); ) {
+                const SpdpProblemH& p = probs[idx[s]];
+                const HRescoreProb& d = descs[s];
+                memcpy(a_all.data() + d.a_off, p.a, (size_t) p.a_len);
+                memcpy(b_all.data() + d.b_off, p.b, (size_t) p.b_len + 1);
+                const int N = p.b_len + 3;
+                short* sg = sig.data() + 5 * d.col_off; int8_t* ph = phs.data() + 2 * d.col_off; uint8_t* dc = dinc.data() + d.col_off;
+                for (int x = 0; x < N; ++x) {
+                    sg[5 * x] = p.sig5[x]; sg[5 * x + 1] = p.sig3[x]; sg[5 * x + 2] = p.sigS[x]; sg[5 * x + 3] = p.sigT[x]; sg[5 * x + 4] = p.sigE[x];
+                    ph[2 * x] = p.phs5[x]; ph[2 * x + 1] = p.phs3[x];
+                    dc[x] = x <= p.b_len ? p.dinc[x] : 0;
+                }
+                memcpy(skl.data() + soff[s], aln[idx[s]].skl + 1, sizeof(SpdpSkl) * (size_t) scnt[s]);
+            }
+        };
+        const int nt = std::max(1, std::min(spdp_host_cpus(), (int) idx.size()));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& t : th) t.join();
     }
     const int nr = (int) idx.size();
     if (!nr) return 0;

@@ -808,7 +808,7 @@ void spdp_blk_index_host_free(SpdpBlkIndexHost* h);
  * one of the reference-sized hash tables ran full, where the reference would grow it), then sign[4] mmct[4] nhit[4] maxs[4]
  * testword[4] (Bhit4); per direction n, (block, score) x n: the significant blocks (prqueue_b, heap order); n_pairs and
  * nine ints per candidate pair, best first (BPAIR: bscr chr lb rb ub db zl zr rvs); n_runs and (block | direction << 28,
- * score) x n_runs: the run scores (Bhit4::bscr) FindHsp can look at -- within ExtBlockL blocks of a reported pair, inside its
+ * score) x n_runs: the run scores (Bhit4::bscr) FindHsp can look at -- within 4 x max(ExtBlockL, ExtBlock) blocks of a reported pair (its reach over three moves of an end), inside its
  * chromosome, on its strand -- unordered.  kernel_ms (may be NULL): HIP-event time. */
 #define SPDP_BLK_REACHED 1
 #define SPDP_BLK_CUT     2

@@ -169,7 +169,7 @@ def grows() -> int:
 def runs_near_pairs(ix: BlkIndex, runs, pairs):
     """the part of the recorded run scores the product reports: blocks within ExtBlockL of a reported pair, inside its
     chromosome, on its strand (runs: per direction [(block, score)], pairs: rows of nine ints)"""
-    e = int(ix.extblockl)
+    e = 4 * max(int(ix.extblockl), int(ix.extblock))     # (as spdp_blk_vote.hip, write_state: FindHsp's reach over its retries)
     out = []
     for d in range(4):
         keep = []

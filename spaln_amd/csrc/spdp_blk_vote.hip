@@ -592,7 +592,9 @@ __device__ __forceinline__ void write_state(Wave& W, Record& R)
     np = uni(np); n = uni(n);
     const int at_count = n++;
     int n_runs = 0;
-    const uint32_t el = (uint32_t) X.extblockl;
+    // (FindHsp may move a pair's end up to three times -- a protein query looks again at the region it has grown -- by at most
+    // max(ExtBlockL, ExtBlock) blocks each time, and reads the run scores on its way)
+    const uint32_t el = 4u * (uint32_t) (X.extblockl > X.extblock ? X.extblockl : X.extblock);
     for (int i = 0; i < np; ++i) {
         const Pair b = pairs[i];
         uint32_t lo = b.lb > el ? b.lb - el : 0, hi = b.rb + el;

@@ -567,10 +567,38 @@ def main_blk(args):
                 n_loc += len(loci[i])
                 L = loci[i][0]
                 ok += (L["chr"] == truth[i, 0] and L["base"] <= truth[i, 1] + 60000 and truth[i, 1] <= L["base"] + L["len"] and L["rvs"] == int(rc[i]))
-        find_leg = {"what": "spdp_blk_find: the vote call after call on the device, TestOutput / FindHsp with the library's own HSP search on "
-                            "the host threads in between -> candidate loci with their HSPs; marshalling the result into Python lists inside",
+        find_leg = {"what": "spdp_blk_find: the vote call after call and the HSP searches of all candidate regions as device batches, TestOutput / "
+                            "FindHsp as machines advanced on the host threads in between -> candidate loci with their HSPs; marshalling the "
+                            "result into Python lists inside",
                     "queries": nf, "with_a_locus": with_locus, "loci": n_loc, "first_locus_covers_the_planted_gene_on_its_strand": int(ok),
                     "seconds": round(find_s, 2), "queries_per_s": round(nf / find_s, 0)}
+    ref_blk = None
+    if rank == 0 and have_ref and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln_blktime")):
+        # the reference's own block search on the same index and queries: its program with a stop watch around SrchBlk::findblock
+        # (oracle/_ref/spaln_blktime: the reference's object code, one symbol renamed) on a sample, all host cores
+        import re as _re
+        import subprocess as _sp
+        dec = np.zeros(32, dtype=np.uint8)
+        for c_, ch_ in ((2, b"A"), (3, b"C"), (5, b"G"), (9, b"T"), (16, b"N")):
+            dec[c_] = ch_[0]
+        ns_ref = min(n_q, args.cpu_sample if args.cpu_sample > 0 else 6000)
+        with open(os.path.join(td, "qs.fa"), "wb") as f:
+            for i in range(ns_ref):
+                f.write(b">q%d\n" % i + dec[codes[i]].tobytes() + b"\n")
+        ncr = _host_cores()
+        env_r = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS", "LD_PRELOAD"))}
+        env_r.update(ALN_TAB=os.path.join(ROOT, "oracle", "_ref", "table"), ALN_DBS=td)
+        t_r = time.perf_counter()
+        r_ = _sp.run([os.path.join(ROOT, "oracle", "_ref", "spaln_blktime"), "-Q7", "-O4", f"-t{ncr}", "-dgnm", "qs.fa"], cwd=td, env=env_r,
+                     capture_output=True, text=True)
+        m_ = _re.search(r"findblock: (\d+) calls, ([0-9.]+) thread-seconds", r_.stderr)
+        if m_ and int(m_.group(1)):
+            calls_, ts_ = int(m_.group(1)), float(m_.group(2))
+            ref_blk = {"value": round(calls_ / (ts_ / ncr), 1), "unit": "queries/s", "cores": ncr, "kind": "reference",
+                       "sample": f"first {ns_ref} ESTs through the compiled reference's program on the same index with a stop watch around "
+                                 f"SrchBlk::findblock (oracle/_ref/spaln_blktime, -t{ncr}): {calls_} calls, {ts_:.2f} thread-seconds inside -- its whole "
+                                 f"block search (vote + TestOutput / FindHsp with its HSP search), the counterpart of config.find (spdp_blk_find); "
+                                 f"program wall {time.perf_counter() - t_r:.1f} s"}
     if rank == 0:
         rec = d_out.cpu().numpy()
         reached = (rec[:, 2] & blocks.REACHED) != 0
@@ -642,18 +670,22 @@ def main_blk(args):
                        "identical_to_oracle_on_sample": f"{same} / {len(chk)}",
                        "words_looked_up_per_query": round(float(tw), 1),
                        "input_generation_s": round(input_s, 1), "index_build": index_build, "find": find_leg,
-                       "reference_parity": "the vote's state at every TestOutput call and the block pairs handed to FindHsp: bit-identical to the "
-                                           "compiled reference's recorded runs (tests/golden/blk_*.spdg: tests/test_gpu_blk.py); FindHsp itself "
-                                           "(Wilip on the candidate region) stays with the caller"},
+                       "reference_parity": "the vote's state at every TestOutput call, the block pairs, and every candidate locus FindHsp makes of them "
+                                           "(HSPs included): bit-identical to the compiled reference's recorded runs (tests/golden/blk_*.spdg: "
+                                           "tests/test_gpu_blk.py, test_gpu_blk_find.py)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "bytes_per_query": round(float(bytes_per_q), 1), "traffic": _traffic("blk", "blk", n_q, world)[0],
                          "traffic_source": _traffic("blk", "blk", n_q, world)[1], "kernel": "spdp_blk_vote_wave", "kernel_ms": round(k_ms, 3),
-                         "note": "one query per lane, random 4 .. 8-byte accesses into posting lists and the lane's private score slab: bound by "
-                                 "memory transactions in flight and by divergence, not by bytes; algorithmic bytes = codes + per word its table "
-                                 "entries and posting list + two score slots per listed block + the record"},
-            "cpu_baseline": {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
-                             "sample": f"first {ns} ESTs through the oracle's vote (oracle/spdp_oracle_blk.c), one process per host core"},
+                         "note": "one query per wave: posting lists read 64 blocks at a time, the run hash and the bounded lists in LDS, tagged score "
+                                 "slots in the wave's slab of HBM (random 8-byte accesses): bound by memory latency per word, hidden by 16 waves per "
+                                 "CU; algorithmic bytes = codes + per word its table entries and posting list + two score slots per listed block + "
+                                 "the record"},
+            "cpu_baseline": ref_blk or {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
+                                        "sample": f"first {ns} ESTs through the oracle's vote (oracle/spdp_oracle_blk.c), one process per host core"},
         }
+        if ref_blk:
+            out["config"]["vote_port_baseline"] = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
+                                                   "sample": f"the vote alone: first {ns} ESTs through the oracle's restatement, one process per host core"}
         print(json.dumps(out), flush=True)
     dix.free()
     eng.close()
@@ -739,10 +771,13 @@ LEGS = {
            "BASELINE configs[4]: 32 cDNAs of 50 kb, 25 exons, against their ~190 kb loci"),
     "blk": (["--workload", "blk", "--queries", "200000", "--steps", "3", "--warmup", "1"],
             "SURVEY 8 row f4, first slice: the block search's vote for 200 000 ESTs against the index of a 100 Mb genome"),
+    "c4_full": (["tools/c4_full.py", "--mb", "3000", "--queries", "125000"],
+                "BASELINE configs[3], one GPU's eighth of it: 125 000 ESTs of 500 nt mapped to candidate loci (spdp_blk_find: vote + HSP search on "
+                "the device) against the index of a 3 Gb genome the library built itself (spdp_blk_index_build, five bit patterns)"),
     "blk_find_p": (["tools/blk_find_protein.py", "--queries", "20000", "--genes", "200"],
                    "SURVEY 8 row f4 for protein queries (BASELINE configs[0] / [2]'s mapping phase): spdp_blk_find on the translated index "
-                   "(<db>.bkp of the reference's `spaln -W -KP`, read by the library) of a 20 Mb genome -- vote on the device, TestOutput / "
-                   "FindHsp's DvsP = 1 branch (region -> tron codes, level -1 HSP search, retry on a grown region) on the host threads; "
+                   "(<db>.bkp of the reference's `spaln -W -KP`, read by the library) of a 20 Mb genome -- vote and HSP search on the device (regions "
+                   "read as tron codes where they lie), FindHsp's DvsP = 1 branch with its retries on a grown region as batched machines; "
                    "parity: tests/test_gpu_blk_find.py[blk_p1] against the reference's recorded runs"),
     "a0": (["--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],
            "C2 shape under -A0 (forwardS_ng / hirschbergS_ng): the engines whose output is bit-identical to the reference's own -A0 records on 2 kb inputs"),
@@ -762,6 +797,9 @@ LEGS = {
                "HSP search on the host) -> candidate loci -> their regions and splice signals (one launch) -> spdp_align_s_seeded with "
                "the library's own Wilip -> spdp_skl_rng_s -> the best locus' exon table in chromosome coordinates, compared with, and "
                "timed against, `spaln -Q7 -S1 -O4 -t16` of the compiled reference on the same 20 000 queries"),
+    "e2e_q7_p": (["tools/e2e_q7.py", "--protein", "--queries", "20000", "--genes", "200"],
+                 "BASELINE configs[0] / [2]'s whole path for protein queries: ONE spdp_map_align_h call (block search on the translated index, "
+                 "HSP search on regions read as tron codes, signals, seeded alignment, rescoring) against `spaln -Q7 -O4 -t16` on 20 000 proteins"),
     "e2e_q7_s3": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200", "--ori", "3"],
                   "the same in spaln's default orientation mode (a->inex.ori = 3: every locus aligned in both orientations, alignS_ng(.., 3)); "
                   "every other query is an antisense read; against `spaln -Q7 -O4 -t16`"),
@@ -785,8 +823,8 @@ def _run_leg(name):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     t0 = time.perf_counter()
-    if name.startswith("dropin") or name.startswith("e2e") or name in ("c4_e2e", "blk_find_p"):      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py, tools/blk_find_protein.py): its JSON line as it is
-        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln" if name == "blk_find_p" else "spaln_gpu")):
+    if name.startswith("dropin") or name.startswith("e2e") or name in ("c4_e2e", "blk_find_p", "c4_full"):      # a program of its own (tools/dropin_demo.py, tools/e2e_q7.py, tools/blk_find_protein.py): its JSON line as it is
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln" if name in ("blk_find_p", "c4_full") else "spaln_gpu")):
             return {"what": what, "error": "oracle/_ref/spaln_gpu is not built (needs the reference's sources at build time)"}
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], env=env, capture_output=True, text=True, timeout=900)
@@ -845,8 +883,9 @@ def _leg_short(name, leg):
     if "identical_to_reference" in leg:                             # seeded_q7
         return {"same": leg["identical_to_reference"], "of": leg.get("compared"), "pairs_per_s": leg.get("library_pairs_per_s"),
                 "ref_pairs_per_s": leg.get("reference_pairs_per_s")}
-    if "with_a_locus" in leg:                                       # blk_find_p
-        return {"q_per_s": leg.get("queries_per_s"), "loci": leg["with_a_locus"], "of": leg.get("queries")}
+    if "with_a_locus" in leg:                                       # blk_find_p, c4_full
+        return {"q_per_s": leg.get("queries_per_s"), "loci": leg["with_a_locus"], "of": leg.get("queries"),
+                **({"vote_q_per_s": leg["vote_queries_per_s"]} if "vote_queries_per_s" in leg else {})}
     o = {"value": leg.get("value"), "unit": leg.get("unit")}
     for k in ("hbm_frac", "valu_frac"):
         if leg.get(k) is not None:

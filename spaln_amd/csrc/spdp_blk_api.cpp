@@ -219,6 +219,16 @@ extern "C" int spdp_blk_vote_resident(SpdpContext* ctx, const SpdpBlkIndex* cix,
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    if (getenv("SPDP_BLK_VERBOSE")) {                  // how often the run hash met a full table (one-lane path) and grew, over the slabs' lifetime
+        uint64_t slow = 0, grown = 0;
+        for (int w = 0; w < A.n_waves; ++w) {
+            uint32_t h[4];
+            HIPCHK(hipMemcpy(h, ix->slabs + (size_t) w * ix->slab_bytes, sizeof h, hipMemcpyDeviceToHost));
+            slow += h[1]; grown += h[2];
+        }
+        fprintf(stderr, "[blk] %d queries on %d waves: so far %llu entries took the one-lane path, %llu table growths\n", n, A.n_waves,
+                (unsigned long long) slow, (unsigned long long) grown);
+    }
     return 0;
 }
 
@@ -435,10 +445,10 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
         std::vector<spdp_loci::Call> mach(m);
         std::vector<int> verdict(m, 0);                 // > 0 loci, 0 go on, -1 ended, -2 record cut / table full
         std::vector<char> live(m, 0);
-        for (int k = 0; k < m; ++k) {
+        on_threads(m, [&](int k) {
             const int32_t* rc = rec.data() + (size_t) k * out_cap;
-            if (!(rc[2] & SPDP_BLK_REACHED)) { verdict[k] = -1; continue; }          // findblock ended before this call
-            if (rc[2] & (SPDP_BLK_CUT | SPDP_BLK_TABLE)) { verdict[k] = -2; continue; }
+            if (!(rc[2] & SPDP_BLK_REACHED)) { verdict[k] = -1; return; }            // findblock ended before this call
+            if (rc[2] & (SPDP_BLK_CUT | SPDP_BLK_TABLE)) { verdict[k] = -2; return; }
             spdp_loci::Call& c = mach[k];
             const int q = active[k];
             c.P = &P; c.G = &G; c.rnd = rnd;
@@ -457,7 +467,7 @@ static int blk_find(SpdpContext* ctx, const SpdpBlkIndex* cix, const SpdpBlkInde
             c.critjscr = crit[q];
             c.begin();
             live[k] = 1;
-        }
+        });
         // ---- searches in batches: first every pair's first region, then what the machines ask for
         std::vector<SearchTask> tasks;
         for (int k = 0; k < m; ++k) {

@@ -465,6 +465,7 @@ struct Wave {
     RunHash hh;
     Score* score; uint32_t* stage; int32_t* scratch; uint32_t* header;
     uint8_t* res; int res_cap;
+    uint32_t* mrg;                                      // two posting lists and their merge (512 words)
     uint32_t* pre;                                      // the first 64 entries of the posting lists of a direction's phases (fetched together)
     uint32_t tag;
 };
@@ -638,8 +639,52 @@ __device__ __forceinline__ const uint32_t* entries_of(const Wave& W, const Word&
     const BlkDev& X = *W.ix;
     if (!w.len1) { n = w.len0; return X.blkb + w.off0; }
     if (!w.len0) { n = w.len1; return X.blkb + w.off1; }
+    const int me = lane_id();
+    if (w.len0 <= 128 && w.len1 <= 128) {
+        // both lists in LDS (A at 0, B at 128), every entry ranked among the other list's by bisection, the merged sequence (an entry
+        // of both lists once) written at 256 and closed up in place
+        uint32_t* A = W.mrg; uint32_t* B = W.mrg + 128; uint32_t* M = W.mrg + 256;
+        int na = w.len0, nb = w.len1;
+        for (int i = me; i < 128; i += 64) {
+            A[i] = i < na ? X.blkb[w.off0 + i] : 0xffffffffu;
+            B[i] = i < nb ? X.blkb[w.off1 + i] : 0xffffffffu;
+        }
+        lds_sync();
+        for (int i = me; i < 128; i += 64) {            // (a zero ends a list)
+            const u64 za = __ballot(i < na && A[i] == 0), zb = __ballot(i < nb && B[i] == 0);
+            if (za) na = min(na, i - me + first_lane(za));
+            if (zb) nb = min(nb, i - me + first_lane(zb));
+        }
+        auto below = [](const uint32_t* L, int n, uint32_t x, bool or_equal) {        // entries of L below x (or up to x)
+            int lo = 0, hi = n;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; const uint32_t v = L[mid]; if (v < x || (or_equal && v == x)) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        for (int i = me; i < 256; i += 64) M[i] = 0u;
+        lds_sync();
+        for (int i = me; i < 128; i += 64) {
+            if (i < na) M[i + below(B, nb, A[i], false)] = A[i];
+            if (i < nb) {
+                const int r = below(A, na, B[i], true);
+                const bool twice = r > 0 && A[r - 1] == B[i];
+                if (!twice) M[i + r] = B[i];            // (an entry of both lists: A's copy stands, this slot stays empty)
+            }
+        }
+        lds_sync();
+        int k = 0;
+        for (int i0 = 0; i0 < na + nb; i0 += 64) {
+            const uint32_t v = i0 + me < na + nb ? M[i0 + me] : 0u;
+            const u64 m = __ballot(v != 0);
+            lds_sync();
+            if (v) M[k + __popcll(m & ((1ull << me) - 1))] = v;       // (closing up never overtakes a slot still to be read: k <= i0)
+            k += __popcll(m);
+            lds_sync();
+        }
+        n = k;
+        return M;
+    }
     int k = 0;
-    if (lane_id() == 0) {
+    if (me == 0) {
         const uint32_t* a = X.blkb + w.off0; const uint32_t* b = X.blkb + w.off1;
         int i = 0, j = 0;
         while (i < w.len0 || j < w.len1) {
@@ -727,7 +772,7 @@ __device__ __forceinline__ int vote_of_word(Wave& W, const Word& w, int d, int s
             if (!done) {
                 // the lowest pending lane met a full table: its entry alone, with the table growing under it
                 const int l = first_lane(pend);
-                if (me == l) { RunHash T = H; SlowHash S = {&T, W.st}; credited = S.entry(blk, p, up); W.st[ST_HH_LEVEL] = T.level; }
+                if (me == l) { RunHash T = H; SlowHash S = {&T, W.st}; credited = S.entry(blk, p, up); W.header[1] += 1; W.header[2] += (uint32_t) (T.level - H.level); W.st[ST_HH_LEVEL] = T.level; }
                 wave_sync();
                 const int lv = uni(W.st[ST_HH_LEVEL]);
                 if (lv != H.level) H.bind(lv);              // (every lane alike: the table's place and size stay uniform)
@@ -911,6 +956,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     H.sizes = X.hh_sizes; H.step_mod = (uint32_t) X.hh_size2;
     W.res = (uint8_t*) l; W.res_cap = A.res_cap; l += A.res_cap / 4;
     W.pre = l; l += 64 * SPDP_BLK_PRE_PHASES;
+    W.mrg = l; l += 512;
     H.lds = A.hh_in_lds ? (KV*) l : nullptr;
     H.g0 = (KV*) g; if (!A.hh_in_lds) g += sizeof(KV) * (size_t) X.hh_sizes[0];
     H.grown = (KV*) g; H.b_off = (uint32_t) X.hh_sizes[SPDP_BLK_HASH_LEVELS - 1];
@@ -960,7 +1006,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 extern "C" uint32_t spdp_blk_vote_lds_bytes(const BlkDev* ix, int hh_in_lds)
 {
-    size_t w = ST_WORDS + 4 * 32 + OWN_SLOTS + SPDP_BLK_RES_CAP / 4 + 64 * SPDP_BLK_PRE_PHASES;
+    size_t w = ST_WORDS + 4 * 32 + OWN_SLOTS + SPDP_BLK_RES_CAP / 4 + 64 * SPDP_BLK_PRE_PHASES + 512;
     w += 4 * (2 * ((size_t) ix->nascr + 1) + 2 * (size_t) ix->ha_size1);
     w += 4 * (2 * ((size_t) ix->ncand + 1) + 2 * (size_t) ix->hb_size1);
     if (hh_in_lds) w += 2 * (size_t) ix->hh_sizes[0];

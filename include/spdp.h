@@ -268,7 +268,7 @@ typedef struct SpdpSeedParams {
                                         the dinucleotide classes (src/codepot.cc:435-475, src/codepot.h:108-113)          */
     int32_t ip_maxl, ip_mode;        /* IntronPrm.maxl, IntronPrm.mode (protein walk: first_exon_wmm / last_exon_wmm)      */
     const struct SpdpWilipModel* wilip;   /* optional (round 5): with it -- and no SpdpHspSource -- the walks' HSP searches at the
-                                        recursion levels are the library's own (spdp_wilip.h: Wilip restated); NULL: the
+                                        recursion levels are the library's own (spdp_hsp_host.h + spdp_hsp_chain.h); NULL: the
                                         caller's SpdpHspSource answers them                                                */
 } SpdpSeedParams;
 /* Wilip(seqs, pwd, level) (src/wln.cc:980) for the recursion levels above the one the caller's HSPs come from: the HSP
@@ -559,7 +559,7 @@ int spdp_lsp_h(SpdpContext* ctx, const struct SpdpScoringH* sc, const struct Spd
  * What the reference's Wilip reads besides the two sequences: per recursion level the word parameters of setwlprm(level)
  * (src/wln.cc:53-128: reduced alphabet, tuple size, bit pattern, gains, cut-offs) and, shared, the HSP-search substitution
  * matrix getSimmtx(WlnPamNo), the end bonus, and a few switches.  With a model a seeded call needs no SpdpHspSource: the
- * library searches the sub-ranges itself (spdp_wilip.h), and spdp_wilip answers one request the way Wilip::Wilip does. */
+ * library searches the sub-ranges itself (spdp_hsp_host.h), and spdp_wilip answers one request the way Wilip::Wilip does. */
 typedef struct SpdpWilipLevel {
     int32_t elem, tpl, mask, width, gain, gain1, thr, xdrp, cutoff, vthr;     /* WLPRM, src/wln.h:35-49                    */
     int32_t bitpat_len;              /* 0: contiguous words of `width`; else the spaced pattern, bitpat[i] = 1 / 0      */

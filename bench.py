@@ -798,7 +798,8 @@ LEGS = {
                "the library's own Wilip -> spdp_skl_rng_s -> the best locus' exon table in chromosome coordinates, compared with, and "
                "timed against, `spaln -Q7 -S1 -O4 -t16` of the compiled reference on the same 20 000 queries"),
     "e2e_q7_p": (["tools/e2e_q7.py", "--protein", "--queries", "20000", "--genes", "200"],
-                 "BASELINE configs[0] / [2]'s whole path for protein queries: ONE spdp_map_align_h call (block search on the translated index, "
+                 "BASELINE configs[0] / [2]'s whole path for protein queries: the translated index built by the library (spdp_blk_index_build_p; its tables "
+                 "compared with the reference's <db>.bkp), then ONE spdp_map_align_h call (block search on that index, "
                  "HSP search on regions read as tron codes, signals, seeded alignment, rescoring) against `spaln -Q7 -O4 -t16` on 20 000 proteins"),
     "e2e_q7_s3": (["tools/e2e_q7.py", "--queries", "20000", "--genes", "200", "--ori", "3"],
                   "the same in spaln's default orientation mode (a->inex.ori = 3: every locus aligned in both orientations, alignS_ng(.., 3)); "

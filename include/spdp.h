@@ -886,6 +886,34 @@ int spdp_blk_build_params_default(int64_t fasta_bytes, int32_t nbitpat, SpdpBlkB
  * NULL).  seconds (may be NULL): [0] device passes (words, sort, lists), [1] host (scores, cut-off, tables), [2] the call. */
 SpdpBlkIndexHost* spdp_blk_index_build(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParams* p,
                                        const SpdpBlkSearchOpts* opts, double* seconds);
+/* The translated index, `spaln -W -KP genome.mfa` (<db>.bkp: what protein queries are searched in; spdp_blk_find with model->dvsp = 1,
+ * spdp_map_align_h): MakeBlk::idxblk / m_idxblk with Block::c2w6 / c2w6_pp (src/blksrc.cc:466-532), blkscrtab(segn) (:879-942).  A
+ * residue completes one codon on each strand; the codon's class in the reduced amino-acid alphabet (ReducWord's g2r, src/bitpat.cc:
+ * 88-106) joins the word of its reading frame; words are taken every nshift codons counted from the start of the open reading frame,
+ * reach their block minorf residues later, and are dropped when their frame closes before minorf nucleotides.  On the device: the
+ * classes of both strands' codons per residue, the frames' last class-less codon as six prefix maxima, the reference's delay ring
+ * followed per word (no state carried from residue to residue); then the nucleotide builder's sort and list passes.  On the host: the
+ * scores with their composition term -- a running sum over the word table in the reference's order -- and the file.
+ * b.ktuple = amino acids per word (3 .. 7), b.nbitpat = 1 and b.bitpat = 2^k - 1 (contiguous words: what -KP builds unless -XC is
+ * given), b.threaded as above.  acomp: MakeBlk::prepacomp's per-class terms (src/blksrc.cc:844-877), functions of the reference's
+ * substitution-matrix tables and of -Xp / -Xq only -- not of the genome: constants of a deployment.  The values of the reference's
+ * defaults (twenty classes, PAM 20) are in spaln_amd/defaults.py (BLOCK_ACOMP_20), recorded from the compiled reference by
+ * oracle/ref_build/idx_tap.cc; for other alphabets the caller records them the same way.  convtab: ReducWord's iConvTab over the tron
+ * codes (3 .. 22 = A .. V, 23 the AGY serines, 24 Sec), written to the file as the search reads it.
+ * ContBlk::MaxBlk: the reference leaves it unset on this path and its files carry 65535; so do these. */
+typedef struct SpdpBlkBuildParamsP {
+    SpdpBlkBuildParams b;
+    int32_t nalpha, minorf;          /* wcp.Nalpha (-XA), MinOrf (-Xr, nucleotides; 30)                                      */
+    double aaafact;                  /* -Xq (1)                                                                              */
+    double acomp[20];
+    int32_t convts;                  /* entries of convtab (27 for the tron alphabet)                                        */
+    uint8_t convtab[32];
+} SpdpBlkBuildParamsP;
+/* what `spaln -W -KP` picks for a FASTA file of fasta_bytes bytes (k from 0.36 ln(bytes), 3 .. 6; twenty classes, MinOrf 30); p->acomp
+ * is kept as the caller set it.  0, or -1. */
+int spdp_blk_build_params_default_p(int64_t fasta_bytes, SpdpBlkBuildParamsP* p);
+SpdpBlkIndexHost* spdp_blk_index_build_p(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParamsP* p,
+                                         const SpdpBlkSearchOpts* opts, double* seconds);
 /* the index as the reference's file (format version 26; the five pointers of its header, which the reference writes as its
  * heap held them, as zeros; ConvTab entries the reference leaves unset as "ambiguous"): 0, or -1 */
 int spdp_blk_index_write(const SpdpBlkIndexHost* h, const char* path);

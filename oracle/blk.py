@@ -223,3 +223,65 @@ def index_build(codes, chr_off, prm: BuildParams) -> dict:
     libc.free(blkb)
     return dict(nblk=nblk, blkp=blkp, wscr=wscr, blkb=words, chr=chr_, b2c=b2c, word_no=n, glen=int(head[1]), avrscr=int(head[2]),
                 maxblk=int(head[3]), bytblk=int(head[4]), n_blocks=int(head[5]), minscr=int(head[6]))
+
+
+class BuildParamsP(C.Structure):
+    """OrcBlkBuildParamsP (oracle/spdp_oracle_blkidx.c) = SpdpBlkBuildParamsP (include/spdp.h): the translated index (`spaln -W -KP`)"""
+    _fields_ = [("b", BuildParams), ("nalpha", C.c_int32), ("minorf", C.c_int32), ("aaafact", C.c_double), ("acomp", C.c_double * 24),
+                ("codon_class", C.c_uint8 * 64)]
+
+
+_STANDARD_CODE = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF"     # codon 16 b1 + 4 b2 + b3, A C G T = 0 1 2 3
+_TRON_ORDER = "ARNDCQEGHILKMFPSTWYV"                                                      # tron codes 3 .. 22
+
+
+def codon_classes(convtab, nalpha: int) -> np.ndarray:
+    """codon -> class of the reduced amino-acid alphabet as ReducWord::ReducWord builds g2r (src/bitpat.cc:88-106) from the index's
+    ConvTab (tron code -> class); stop codons and Sec: 255 / nalpha, neither a class"""
+    out = np.full(64, 255, dtype=np.uint8)
+    for g, aa in enumerate(_STANDARD_CODE):
+        if aa == "*":
+            continue                                                                     # (TGA: class "U" = nalpha, TAA / TAG: none)
+        code = 3 + _TRON_ORDER.index(aa)
+        if aa == "S" and g >> 4 == 0:
+            code = 23                                                                    # AGY serines: 'J' of the tron alphabet
+        out[g] = int(convtab[code])
+    return out
+
+
+def build_params_p(ktuple, nshift, blklen, maxgene, afact, threaded, convtab, acomp, nalpha=20, minorf=30, aaafact=1.0) -> BuildParamsP:
+    p = BuildParamsP()
+    p.b.ktuple, p.b.nshift, p.b.blklen, p.b.maxgene, p.b.nbitpat, p.b.afact = ktuple, nshift, blklen, maxgene, 1, afact
+    p.b.bitpat, p.b.bitpat2, p.b.threaded = (1 << ktuple) - 1, 0, threaded
+    p.nalpha, p.minorf, p.aaafact = nalpha, minorf, aaafact
+    for i, v in enumerate(acomp):
+        p.acomp[i] = float(v)
+    cc = codon_classes(convtab, nalpha)
+    for i in range(64):
+        p.codon_class[i] = int(cc[i])
+    return p
+
+
+def index_build_tron(codes, chr_off, prm: BuildParamsP) -> dict:
+    """MakeBlk::idxblk / m_idxblk + blkscrtab(segn) for a translated index on the CPU; the dict of index_build"""
+    lib = _o.lib()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    off = np.ascontiguousarray(chr_off, dtype=np.int64)
+    n_chr = len(off) - 1
+    tab = int(prm.nalpha) ** int(prm.b.ktuple)
+    nblk = np.zeros(tab, np.uint16); blkp = np.zeros(tab, np.int32); wscr = np.zeros(tab, np.int16)
+    chr_ = np.zeros(2 * (n_chr + 1), np.int32); b2c = np.zeros(3, np.float64); head = np.zeros(8, np.int64)
+    blkb = C.POINTER(C.c_uint32)()
+    lib.orc_blk_index_build_tron.restype = C.c_int
+    lib.orc_blk_index_build_tron.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+    rc = lib.orc_blk_index_build_tron(codes.ctypes.data, off.ctypes.data, n_chr, C.byref(prm), nblk.ctypes.data, blkp.ctypes.data,
+                                      wscr.ctypes.data, C.byref(blkb), chr_.ctypes.data, b2c.ctypes.data, head.ctypes.data)
+    if rc:
+        raise RuntimeError(f"orc_blk_index_build_tron: {rc}")
+    n = int(head[0])
+    words = np.ctypeslib.as_array(blkb, shape=(max(n, 1),))[:n].copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(blkb)
+    return dict(nblk=nblk, blkp=blkp, wscr=wscr, blkb=words, chr=chr_, b2c=b2c, word_no=n, glen=int(head[1]), avrscr=int(head[2]),
+                maxblk=int(head[3]), bytblk=int(head[4]), n_blocks=int(head[5]), minscr=int(head[6]))

@@ -206,3 +206,235 @@ int orc_blk_index_build(const uint8_t* codes, const int64_t* chr_off, int n_chr,
     free(cnt); free(hits); free(tcount);
     return 0;
 }
+
+/* ---- the translated index, `spaln -W -KP` (<db>.bkp): amino-acid words of the six reading frames ----------------------------
+ *   Block::c2w6 / c2w6_pp               src/blksrc.cc:466-532     a residue completes one codon per strand; its class joins the
+ *                                                                 frame's word; words are taken every Nshift codons counted from
+ *                                                                 the start of the open reading frame, wait MinOrf residues in a
+ *                                                                 ring per strand, and are struck from it when their frame
+ *                                                                 closes before MinOrf nucleotides
+ *   ReducWord::ReducWord (g2r)          src/bitpat.cc:58-106      codon -> class of the reduced amino-acid alphabet
+ *   Bitpat_wq::word / flaw              src/bitpat.cc:178-212     (contiguous words only here: -KP's default, one pattern)
+ *   MakeBlk::scan_genome / m_scan_genome / harvest   :1111-1183, :1485-1593   the walks; a chromosome's last block flushes the ring
+ *                                                                 up to blklen; what lies behind is lost with the reset that
+ *                                                                 closes the block, though a block number is spent on it
+ *   WordTab::reset                      src/bitpat.cc:439-461     what a new block starts from
+ *   MakeBlk::blkscrtab(segn)            src/blksrc.cc:879-942     word scores with the composition term, the cut-off
+ * The composition terms (MakeBlk::prepacomp, :844-877: functions of the reference's matrix tables) are parameters.
+ * Pinned to files of `spaln -W -KP` with and without -t: tests/test_oracle_blkidx.py. */
+typedef struct {
+    OrcBlkBuildParams b;
+    int32_t nalpha, minorf;
+    double aaafact;
+    double acomp[24];
+    uint8_t codon_class[64];    /* codon 16 * b1 + 4 * b2 + b3 (A C G T = 0 1 2 3) -> class, >= nalpha: none (stop, Sec) */
+} OrcBlkBuildParamsP;
+
+typedef struct {
+    uint32_t cc[6], xx[3], ss6[6], fstat[6], word[6];
+    int p, w_qp;
+    uint32_t* ring;             /* 2 * minorf */
+} TronState;
+
+#define TRON_BAD 0xffffffffu
+
+static void tron_reset(TronState* s, int minorf, uint32_t msb)
+{
+    for (int q = 0; q < 6; ++q) { s->ss6[q] = 0; s->fstat[q] = msb; s->word[q] = 0; }
+    for (int q = 0; q < 3; ++q) { s->cc[q] = 0; s->xx[q] = 4; }
+    s->w_qp = 0;
+    for (int i = 0; i < 2 * minorf; ++i) s->ring[i] = TRON_BAD;
+}
+
+typedef struct { Hit* hits; size_t n, cap; int failed; } HitList;
+static void hit_add(HitList* h, uint32_t w, uint32_t block)
+{
+    if (h->n == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : (1 << 20);
+        Hit* h2 = (Hit*) realloc(h->hits, h->cap * sizeof(Hit));
+        if (!h2) { h->failed = 1; return; }
+        h->hits = h2;
+    }
+    h->hits[h->n].word = w; h->hits[h->n].block = block; ++h->n;
+}
+
+/* one residue (Block::c2w6); returns -4 when the reference would write outside its ring */
+static int tron_residue(TronState* s, uint32_t uc, const OrcBlkBuildParamsP* prm, uint32_t tabsize, uint32_t msb, uint32_t* tcc,
+                        HitList* out, uint32_t block)
+{
+    const int K = prm->b.ktuple, nshift = prm->b.nshift, wq = prm->minorf;
+    int p = s->p;
+    s->cc[p] = s->cc[p + 3] = 0;
+    if (uc == 4) { s->xx[0] = s->xx[1] = s->xx[2] = 4; }
+    else for (int q = 0; q < 3; ++q) {
+        s->cc[q] = ((s->cc[q] << 2) + uc) & 63;
+        s->cc[q + 3] = (((3 - uc) << 4) + (s->cc[q + 3] >> 2)) & 63;
+        s->xx[p] >>= 1;
+    }
+    if (++p == 3) p = 0;
+    s->p = p;
+    int wqp = s->w_qp, wq_base = 0;
+    if (++s->w_qp == wq) s->w_qp = 0;
+    for (int q = p; q < 6; q += 3, wqp += wq, wq_base += wq) {
+        const int orf_len = 3 * (int) s->ss6[q];
+        if (!s->xx[p]) uc = prm->codon_class[s->cc[q]];
+        if (!s->xx[p] && uc < (uint32_t) prm->nalpha) s->ss6[q] = (s->ss6[q] + 1) & 0xffff;
+        else s->ss6[q] = 0;
+        uint32_t w = TRON_BAD;
+        if (s->ss6[q]) {
+            s->fstat[q] >>= 1;
+            s->word[q] = (uint32_t) (((uint64_t) s->word[q] * prm->nalpha + uc) % tabsize);
+            if (s->fstat[q] == 0) {
+                w = s->word[q];
+                if (tcc) ++tcc[w];
+                const int nw = (int) s->ss6[q] - K;
+                if (nw < 0 || (uint32_t) nw % (uint32_t) nshift) w = TRON_BAD;
+            }
+        } else {
+            s->word[q] = 0; s->fstat[q] = msb;
+            int nw = orf_len / 3 - K;
+            if (0 <= nw && orf_len < wq) {
+                const int sp = nw % nshift;
+                nw = (nw + sp) / nshift;
+                int qp = wqp - (sp + 1) * 3;
+                for ( ; nw-- >= 0; qp -= 3 * nshift) {
+                    if (qp < wq_base) qp += wq;
+                    if (qp < 0 || qp >= 2 * wq) return -4;
+                    s->ring[qp] = TRON_BAD;
+                }
+            }
+        }
+        if (wq) { const uint32_t t = s->ring[wqp]; s->ring[wqp] = w; w = t; }
+        if (w != TRON_BAD) hit_add(out, w, block);
+    }
+    return 0;
+}
+static void tron_flush(TronState* s, int n, int wq, HitList* out, uint32_t block)     /* Block::c2w6_pp */
+{
+    while (n-- > 0) {
+        int wqp = s->w_qp;
+        if (++s->w_qp == wq) s->w_qp = 0;
+        for (int q = 0; q < 2; ++q, wqp += wq) {
+            const uint32_t w = s->ring[wqp];
+            s->ring[wqp] = TRON_BAD;
+            if (w != TRON_BAD) hit_add(out, w, block);
+        }
+    }
+}
+
+/* as orc_blk_index_build; -4: the reference would write outside its ring with these parameters */
+int orc_blk_index_build_tron(const uint8_t* codes, const int64_t* chr_off, int n_chr, const OrcBlkBuildParamsP* prm,
+                             uint16_t* nblk, int32_t* blkp, int16_t* wscr, uint32_t** blkb, int32_t* chr, double* b2c, int64_t* head)
+{
+    const int K = prm->b.ktuple, nshift = prm->b.nshift, blklen = prm->b.blklen, wq = prm->minorf, na = prm->nalpha;
+    if (K < 1 || K > 7 || prm->b.nbitpat != 1 || nshift < 1 || blklen < 1 || n_chr < 1 || na < 2 || na > 20 || wq < 1 || wq > 4096) return -1;
+    uint64_t tab64 = 1;
+    for (int i = 0; i < K; ++i) tab64 *= (uint64_t) na;
+    if (tab64 > (1ull << 31)) return -1;
+    const uint32_t tabsize = (uint32_t) tab64, msb = 1u << (K - 1);
+    const int prelude = 3 * K - 1, margin = prelude + wq;       /* src/blksrc.cc:440-445 */
+    const int64_t s_size = (int64_t) margin + blklen;
+    uint32_t* tcount = (uint32_t*) calloc(tabsize, sizeof(uint32_t));
+    TronState st;
+    memset(&st, 0, sizeof st);
+    st.ring = (uint32_t*) malloc(sizeof(uint32_t) * 2 * (size_t) wq);
+    HitList hl = {0, 0, 0, 0};
+    if (!tcount || !st.ring) { free(tcount); free(st.ring); return -3; }
+    uint32_t block = 0;
+    int64_t spos = 0;
+    int rc = 0;
+    for (int c = 0; c < n_chr && !rc; ++c) {
+        const uint8_t* s = codes + chr_off[c];
+        const int64_t L = chr_off[c + 1] - chr_off[c];
+        chr[2 * c] = (int32_t) spos; chr[2 * c + 1] = (int32_t) (block + 1);
+        const int64_t nb = L <= 0 ? 0 : (L < s_size ? 1 : 1 + (L - margin) / blklen);
+        for (int64_t b = 0; b < nb && !rc; ++b) {
+            const int64_t lo = prm->b.threaded ? b * blklen : (b == 0 ? 0 : b * blklen + margin);
+            int64_t hi = (b + 1) * blklen + margin;
+            if (hi > L) hi = L;
+            const int pos0 = (!prm->b.threaded && b) ? margin : 0;      /* posinblk of the block's first residue */
+            tron_reset(&st, wq, msb);
+            for (int64_t j = lo; j < hi && !rc; ++j) {
+                const uint32_t uc = (uint32_t) reduced(s[j]);
+                rc = tron_residue(&st, uc, prm, tabsize, msb, pos0 + (j - lo) < blklen ? tcount : 0, &hl, block + 1);
+            }
+            if (b == nb - 1) {                                      /* the chromosome's last block: the ring is emptied */
+                const int64_t n = pos0 + (hi - lo);
+                const int rest = (int) (n > blklen ? n - blklen : 0);
+                tron_flush(&st, wq - rest, wq, &hl, block + 1);
+                /* store_blk: the block is closed and the state reset -- the ring with it; c2w6_pp(rest) then finds it empty, but
+                 * the block it would have filled has its number */
+                if (rest > 0) ++block;
+            }
+            ++block;
+        }
+        spos += L;
+    }
+    free(st.ring);
+    if (rc || hl.failed) { free(tcount); free(hl.hits); return rc ? rc : -3; }
+    chr[2 * n_chr] = (int32_t) spos; chr[2 * n_chr + 1] = (int32_t) (block + 1);
+    Hit* hits = hl.hits; const size_t n_hit = hl.n;
+    if (n_hit) qsort(hits, n_hit, sizeof(Hit), hit_cmp);
+    size_t n_u = 0;
+    for (size_t i = 0; i < n_hit; ++i) if (i == 0 || hits[i].word != hits[n_u - 1].word || hits[i].block != hits[n_u - 1].block) hits[n_u++] = hits[i];
+    uint32_t* cnt = (uint32_t*) calloc(tabsize, sizeof(uint32_t));
+    if (!cnt) { free(hits); free(tcount); return -3; }
+    for (size_t i = 0; i < n_u; ++i) ++cnt[hits[i].word];
+    for (uint32_t w = 0; w < tabsize; ++w) if (cnt[w] > 65535) { free(cnt); free(hits); free(tcount); return -2; }
+
+    /* blkscrtab(segn), src/blksrc.cc:879-942 */
+    const uint32_t segn = block;
+    const double basescr = log((double) segn);
+    const double deltaa = prm->acomp[0] - prm->acomp[na - 1];
+    double alc = prm->aaafact > 0 ? K * prm->acomp[0] : 0.;
+    double avr = 0.;
+    uint32_t m = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) {
+        if (tcount[w]) {
+            ++m;
+            short sc = (short) (100 * (basescr - log((double) tcount[w] / 1)));
+            if (prm->aaafact > 0) sc = (short) (sc + (short) alc);
+            wscr[w] = sc;
+            avr += sc;
+        } else wscr[w] = 0;
+        if (prm->aaafact > 0) {
+            int p = 0, q = 0;
+            for (uint32_t x = w + 1; (q = (int) (x % (uint32_t) na)) == 0; x /= (uint32_t) na) ++p;
+            if (p) alc += p * deltaa;
+            alc += prm->acomp[q] - prm->acomp[q - 1];
+        }
+    }
+    avr /= m;
+    short min_scr = (short) (avr - 100 * (1 + prm->aaafact) * log((double) prm->b.afact));
+    if (min_scr < 0) min_scr = 0;
+    int64_t word_no = 0; uint32_t max_blk = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) {
+        if (!cnt[w]) wscr[w] = -1;
+        else if (wscr[w] > min_scr) { word_no += cnt[w]; if (cnt[w] > max_blk) max_blk = cnt[w]; }
+        else { wscr[w] = 0; }
+    }
+    *blkb = (uint32_t*) malloc(sizeof(uint32_t) * (size_t) (word_no > 0 ? word_no : 1));
+    if (!*blkb) { free(cnt); free(hits); free(tcount); return -3; }
+    int64_t at = 0;
+    size_t hi_ = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) {
+        const size_t first = hi_;
+        hi_ += cnt[w];
+        if (cnt[w] && wscr[w] > min_scr) {
+            blkp[w] = (int32_t) (at + 1); nblk[w] = (uint16_t) cnt[w];
+            for (size_t i = first; i < hi_; ++i) (*blkb)[at++] = hits[i].block;
+        } else { blkp[w] = 0; nblk[w] = 0; }
+    }
+    const double B = (double) segn;
+    b2c[0] = b2c[1] = b2c[2] = 0.;
+    for (int k = 0; k <= n_chr; ++k) {
+        const double off = k * B - n_chr * (double) (chr[2 * k + 1] - 1);
+        if (off < b2c[0]) b2c[0] = off;
+        if (off > b2c[1]) b2c[1] = off;
+    }
+    b2c[0] /= B; b2c[1] /= B;
+    head[0] = word_no; head[1] = spos; head[2] = (int64_t) (uint16_t) avr; head[3] = max_blk;
+    head[4] = segn <= 65535 ? 2 : 4; head[5] = segn; head[6] = min_scr; head[7] = tabsize;
+    free(cnt); free(hits); free(tcount);
+    return 0;
+}

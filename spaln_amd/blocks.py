@@ -223,6 +223,55 @@ def build_index(eng, genome_codes, chr_off, prm: BlkBuildParams, write_to: str =
     return out, list(sec)
 
 
+class BlkBuildParamsP(C.Structure):      # SpdpBlkBuildParamsP
+    _fields_ = [("b", BlkBuildParams), ("nalpha", C.c_int32), ("minorf", C.c_int32), ("aaafact", C.c_double), ("acomp", C.c_double * 20),
+                ("convts", C.c_int32), ("convtab", C.c_uint8 * 32)]
+
+
+def build_params_default_p(lib, fasta_bytes: int, threaded: int = 0, acomp=None) -> BlkBuildParamsP:
+    """what `spaln -W -KP` picks for a FASTA file of that size (spdp_blk_build_params_default_p); acomp: MakeBlk::prepacomp's terms,
+    by default those of the reference's default tables (defaults.BLOCK_ACOMP_20)"""
+    from . import defaults
+    p = BlkBuildParamsP()
+    for i, v in enumerate(defaults.BLOCK_ACOMP_20 if acomp is None else acomp):
+        p.acomp[i] = float(v)
+    lib.spdp_blk_build_params_default_p.argtypes = [C.c_int64, C.c_void_p]
+    if lib.spdp_blk_build_params_default_p(int(fasta_bytes), C.byref(p)):
+        raise RuntimeError("spdp_blk_build_params_default_p: out of range")
+    p.b.threaded = threaded
+    return p
+
+
+def build_index_p(eng, genome_codes, chr_off, prm: BlkBuildParamsP, write_to: str = None, **opts):
+    """spdp_blk_index_build_p (+ spdp_blk_index_write): the translated block index (`spaln -W -KP`, <db>.bkp) made on the device.
+    Returns (the arrays in the layout read_index_file gives, seconds [device, host, call])."""
+    lib = eng.lib
+    g = Genome()
+    gc = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    go = np.ascontiguousarray(chr_off, dtype=np.int64)
+    g.codes, g.chr_off, g.n_chr = gc.ctypes.data, go.ctypes.data, len(go) - 1
+    o = SearchOpts()
+    lib.spdp_blk_search_opts_default(C.byref(o))
+    for k, v in opts.items():
+        setattr(o, k, v)
+    sec = (C.c_double * 3)()
+    lib.spdp_blk_index_build_p.restype = C.c_void_p
+    lib.spdp_blk_index_build_p.argtypes = [C.c_void_p] * 5
+    lib.spdp_blk_index_host_free.argtypes = [C.c_void_p]
+    h = lib.spdp_blk_index_build_p(eng.ctx, C.byref(g), C.byref(prm), C.byref(o), sec)
+    if not h:
+        raise RuntimeError(lib.spdp_last_error(eng.ctx).decode())
+    try:
+        if write_to is not None:
+            lib.spdp_blk_index_write.argtypes = [C.c_void_p, C.c_char_p]
+            if lib.spdp_blk_index_write(h, write_to.encode()):
+                raise RuntimeError("spdp_blk_index_write: cannot write " + write_to)
+        out = _host_index_to_dict(lib, h)
+    finally:
+        lib.spdp_blk_index_host_free(h)
+    return out, list(sec)
+
+
 class BlkFindParams(C.Structure):        # SpdpBlkFindParams
     _fields_ = [("vthr", C.c_int32), ("drop_rate", C.c_float), ("max_out", C.c_int32), ("max_out2", C.c_int32),
                 ("min_agap", C.c_int32), ("phase1t", C.c_int32), ("a_exgl", C.c_int32), ("a_exgr", C.c_int32)]

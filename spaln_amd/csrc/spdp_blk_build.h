@@ -17,7 +17,21 @@ struct BlkBuildArgs {
     uint32_t* tcount;
     unsigned long long* keys; unsigned long long* n_keys; unsigned long long cap;
 };
+// the translated index (`spaln -W -KP`): amino-acid words of the six reading frames
+struct BlkBuildArgsP {
+    const uint8_t* codes; const int64_t* chr_off; const int32_t* chr_first;
+    int n_chr;
+    int64_t G;
+    int K, nalpha, nshift, blklen, margin, minorf, threaded;
+    uint32_t tabsize;
+    uint8_t codon_class[64];                    // codon 16 b1 + 4 b2 + b3 (A C G T = 0 1 2 3) -> class; >= nalpha: none
+    const int64_t* tile_carry;                  // six per tile: the last residue (same residue class mod 3, same strand) whose codon has no class
+    uint32_t* tcount;
+    unsigned long long* keys; unsigned long long* n_keys; unsigned long long cap;
+};
 struct BlkBuildDev;
+int spdp_blkidx_words_p(SpdpContext* ctx, const uint8_t* codes, const int64_t* chr_off, const int32_t* chr_first, int n_chr,
+                        BlkBuildArgsP A, int key_bits, std::vector<uint32_t>& tcount, std::vector<uint32_t>& cnt, BlkBuildDev** out);
 int spdp_blkidx_words(SpdpContext* ctx, const uint8_t* codes, const int64_t* chr_off, const int32_t* chr_first, int n_chr,
                       BlkBuildArgs A, uint32_t tabsize, int key_bits, std::vector<uint32_t>& tcount, std::vector<uint32_t>& cnt,
                       BlkBuildDev** out);

@@ -9,6 +9,7 @@
 // of a nucleotide index is read; older versions and the 3-byte form are refused.
 #include "../../include/spdp.h"
 #include "spdp_blk_dev.h"
+#include "spdp_gencode.h"
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -383,6 +384,177 @@ static SpdpBlkIndexHost* blk_index_build(SpdpContext* ctx, const SpdpGenome* gen
     if (!derive_search_params(h, o, why)) { ctx->err = "spdp_blk_index_build: " + why; return nullptr; }
     if (seconds) { seconds[0] = t_dev1 + t_dev2s; seconds[1] = t_host1; seconds[2] = wall(t_begin); }
     return (SpdpBlkIndexHost*) hold.release();
+}
+
+// ---- the translated index, `spaln -W -KP` (<db>.bkp) --------------------------------------------------------------------------
+// what setupbitpat picks for a translated genome (src/blksrc.cc:680-737: wcp_af; k from 0.36 ln(size), at most 6)
+extern "C" int spdp_blk_build_params_default_p(int64_t fasta_bytes, SpdpBlkBuildParamsP* p)
+{
+    if (!p || fasta_bytes < 1) return -1;
+    const double keep_acomp[20] = {p->acomp[0], p->acomp[1], p->acomp[2], p->acomp[3], p->acomp[4], p->acomp[5], p->acomp[6], p->acomp[7], p->acomp[8], p->acomp[9],
+                                   p->acomp[10], p->acomp[11], p->acomp[12], p->acomp[13], p->acomp[14], p->acomp[15], p->acomp[16], p->acomp[17], p->acomp[18], p->acomp[19]};
+    memset(p, 0, sizeof *p);
+    memcpy(p->acomp, keep_acomp, sizeof keep_acomp);    // (the composition terms are the caller's: see include/spdp.h)
+    p->b.afact = 10; p->b.nbitpat = 1;
+    const double gs = (double) fasta_bytes;
+    int blklen = (int) sqrt(gs);
+    blklen = (int) (blklen / 1024 + 1) * 1024;
+    if (blklen > 65536) blklen = 65536;
+    p->b.blklen = blklen;
+    int k = (int) (log(gs) * 0.36);
+    if (k < 3) k = 3;
+    if (k > 6) k = 6;
+    p->b.ktuple = k; p->b.nshift = k; p->b.bitpat = (1u << k) - 1;
+    p->b.maxgene = (int) (38 * sqrt(gs) / 1024 + 1) * 1024;
+    if (p->b.maxgene < 16384) p->b.maxgene = 16384;
+    p->nalpha = 20; p->minorf = 30; p->aaafact = 1.;
+    // iConvTab of the twenty-letter alphabet over the tron codes (ReducWord::ReducWord, src/bitpat.cc:58-87): A .. V = 3 .. 22 in
+    // the order of the reference's amino-acid codes, the AGY serines (23) with the serines, Sec (24) one past the ambiguous class
+    p->convts = 27;
+    for (int c = 0; c < 27; ++c) p->convtab[c] = 20;
+    for (int c = 3; c <= 22; ++c) p->convtab[c] = (uint8_t) (c - 3);
+    p->convtab[23] = 15; p->convtab[24] = 21; p->convtab[25] = 0; p->convtab[26] = 20;
+    return 0;
+}
+
+static SpdpBlkIndexHost* blk_index_build_p(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParamsP* p,
+                                           const SpdpBlkSearchOpts* opts, double* seconds)
+{
+    if (!ctx) return nullptr;
+    auto fail = [&](const char* m) -> SpdpBlkIndexHost* { ctx->err = std::string("spdp_blk_index_build_p: ") + m; return nullptr; };
+    if (!genome || !genome->codes || !genome->chr_off || genome->n_chr < 1 || !p) return fail("null argument");
+    const int K = p->b.ktuple, na = p->nalpha, wq = p->minorf, nshift = p->b.nshift;
+    if (K < 3 || K > 7 || p->b.nbitpat != 1 || p->b.bitpat != (1u << K) - 1 || nshift < 1 || nshift > SPDP_BLK_MAX_SHIFT || na < 6 || na > 20 ||
+        wq < 3 || wq > 120 || p->b.afact < 1 || p->b.maxgene < p->b.blklen || p->convts < 24 || p->convts > 32 || !(p->aaafact > 0))
+        return fail("parameters out of range (contiguous words of 3 .. 7 amino acids, 6 .. 20 classes, MinOrf 3 .. 120)");
+    uint64_t tab64 = 1;
+    for (int i = 0; i < K; ++i) tab64 *= (uint64_t) na;
+    if (tab64 > (1ull << 30)) return fail("Nalpha ^ k beyond 2^30 words");
+    const uint32_t tabsize = (uint32_t) tab64;
+    const int margin = 3 * K - 1 + wq;                      // prelude + MinOrf, src/blksrc.cc:440-445
+    if (p->b.blklen <= margin || p->b.blklen > 65536) return fail("blklen must exceed 3 k - 1 + MinOrf (and be at most 65536)");
+    // the reference strikes the words of a short frame from its ring by stepping back from the frame's end; parameters with which a
+    // step would pass the ring's length (it would strike younger words there) are refused
+    for (int s = K; 3 * s < wq; ++s) {
+        const int nw = s - K, sp = nw % nshift, turns = (nw + sp) / nshift + 1;
+        if (3 * (sp + 1) + 3 * nshift * (turns - 1) > wq) return fail("k, Nshift and MinOrf for which the reference's delay ring wraps onto itself");
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int n_chr = genome->n_chr;
+    const int64_t G = genome->chr_off[n_chr] - genome->chr_off[0];
+    if (genome->chr_off[0] != 0 || G < 1 || G > (int64_t) UINT32_MAX) return fail("chr_off must start at 0; at most 2^32 - 1 residues (the reference's positions are 32-bit)");
+    BlkBuildArgsP A;
+    memset(&A, 0, sizeof A);
+    A.G = G; A.K = K; A.nalpha = na; A.nshift = nshift; A.blklen = p->b.blklen; A.margin = margin; A.minorf = wq; A.threaded = p->b.threaded ? 1 : 0;
+    A.tabsize = tabsize;
+    {   // g2r (src/bitpat.cc:88-106): codon -> tron code -> class
+        uint8_t mid[32], tron_of[64];
+        spdp_genetic_code_tables(mid, tron_of);
+        for (int g = 0; g < 64; ++g) {
+            const int t = tron_of[g];
+            A.codon_class[g] = (t >= 3 && t <= 23 && t < p->convts) ? p->convtab[t] : (uint8_t) 255;    // TGA (24) is the class "U" = Nalpha, TAA / TAG none
+            if (A.codon_class[g] >= na) A.codon_class[g] = 255;
+        }
+    }
+    const int64_t s_size = (int64_t) margin + A.blklen;
+    std::vector<int32_t> chr_first(n_chr);
+    std::unique_ptr<HostIndex> hold(new HostIndex);
+    HostIndex* h = hold.get();
+    h->chrid.resize((size_t) n_chr + 1);
+    uint64_t blocks = 0;
+    for (int c = 0; c < n_chr; ++c) {
+        const int64_t L = genome->chr_off[c + 1] - genome->chr_off[c];
+        if (L < 0) { return fail("chr_off decreases"); }
+        chr_first[c] = (int32_t) (blocks + 1);
+        h->chrid[c] = {(uint32_t) genome->chr_off[c], (uint32_t) (blocks + 1)};
+        if (L <= 0) continue;
+        const int64_t nb = L < s_size ? 1 : 1 + (L - margin) / A.blklen;
+        // the last block: when it is longer than blklen an empty block follows it (scan_genome / harvest close it twice)
+        const int64_t b = nb - 1;
+        const int64_t lo = A.threaded ? b * A.blklen : (b ? b * A.blklen + margin : 0);
+        const int64_t n = ((!A.threaded && b) ? margin : 0) + (L - lo);
+        blocks += (uint64_t) nb + (n > A.blklen ? 1 : 0);
+    }
+    h->chrid[n_chr] = {(uint32_t) G, (uint32_t) (blocks + 1)};
+    if (blocks < 1 || blocks >= (1ull << 31)) { return fail("no block, or too many"); }
+    int word_bits = 1;
+    while ((1ull << word_bits) < tab64) ++word_bits;
+    std::vector<uint32_t> tcount, cnt;
+    BlkBuildDev* dev = nullptr;
+    if (spdp_blkidx_words_p(ctx, genome->codes, genome->chr_off, chr_first.data(), n_chr, A, 32 + word_bits, tcount, cnt, &dev)) { return nullptr; }
+    struct DevGuard { BlkBuildDev* d; ~DevGuard() { spdp_blkidx_free(d); } } dev_guard{dev};
+    const double t_dev1 = wall(t_begin);
+    // ---- blkscrtab(segn), src/blksrc.cc:879-942: the running composition term is a sum in table order -- one thread
+    const auto t_host = std::chrono::steady_clock::now();
+    const uint32_t segn = (uint32_t) blocks;
+    try { h->nblk.assign(tabsize, 0); h->blkp.assign(tabsize, 0); h->wscr.assign(tabsize, 0); } catch (const std::bad_alloc&) { return fail("out of memory for the index tables"); }
+    const double basescr = log((double) segn);
+    const double deltaa = p->acomp[0] - p->acomp[na - 1];
+    double alc = K * p->acomp[0], avr = 0.;
+    uint64_t m_seen = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) {
+        if (tcount[w]) {
+            ++m_seen;
+            short sc = (short) (100 * (basescr - log((double) tcount[w] / 1)));
+            sc = (short) (sc + (short) alc);
+            h->wscr[w] = sc;
+            avr += sc;
+        }
+        int z = 0, q = 0;
+        for (uint32_t x = w + 1; (q = (int) (x % (uint32_t) na)) == 0; x /= (uint32_t) na) ++z;
+        if (z) alc += z * deltaa;
+        alc += p->acomp[q] - p->acomp[q - 1];
+    }
+    if (!m_seen) { return fail("no word in the genome"); }
+    avr /= (double) m_seen;
+    short min_scr = (short) (avr - 100 * (1 + p->aaafact) * log((double) p->b.afact));
+    if (min_scr < 0) min_scr = 0;
+    uint64_t word_no = 0, over = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) {
+        if (!cnt[w]) { h->wscr[w] = -1; continue; }
+        if (cnt[w] > 65535) ++over;
+        if (h->wscr[w] > min_scr) word_no += cnt[w];
+        else { h->wscr[w] = 0; cnt[w] = 0; }
+    }
+    if (over) { return fail("a word lies in more than 65 535 blocks: the reference's 16-bit counters wrap there (use a longer k)"); }
+    if (word_no > (uint64_t) INT32_MAX) { return fail("more postings than a 32-bit list offset (blkp) can address"); }
+    uint64_t at = 0;
+    for (uint32_t w = 0; w < tabsize; ++w) if (cnt[w]) { h->blkp[w] = (int32_t) (at + 1); h->nblk[w] = (uint16_t) cnt[w]; at += cnt[w]; }
+    try { h->blkb.assign((size_t) word_no, 0); } catch (const std::bad_alloc&) { return fail("out of memory for the posting lists"); }
+    const double t_host1 = wall(t_host);
+    const auto t_dev2 = std::chrono::steady_clock::now();
+    if (spdp_blkidx_lists(ctx, dev, h->blkp.data(), (int64_t) word_no, h->blkb.data())) { return nullptr; }
+    const double t_dev2s = wall(t_dev2);
+    memset(&h->wcp, 0, sizeof h->wcp); memset(&h->wc, 0, sizeof h->wc);
+    h->wcp.Nalpha = (uint32_t) na; h->wcp.Ktuple = (uint32_t) K; h->wcp.Bitpat2 = p->b.bitpat2; h->wcp.TabSize = tabsize; h->wcp.BitPat = p->b.bitpat;
+    h->wcp.Nshift = (uint32_t) nshift; h->wcp.blklen = (uint32_t) p->b.blklen; h->wcp.MaxGene = (uint32_t) p->b.maxgene;
+    h->wcp.Nbitpat = 1; h->wcp.afact = (uint16_t) p->b.afact;
+    h->convtab.assign(p->convtab, p->convtab + p->convts);
+    h->wc.ConvTS = (uint32_t) p->convts; h->wc.WordNo = word_no; h->wc.ChrNo = (uint64_t) n_chr; h->wc.glen = (uint64_t) G;
+    h->wc.AvrScr = (uint16_t) avr;
+    // ContBlk::MaxBlk is never set on this path of the reference (blkscrtab(segn) only raises it, from whatever the heap held): its
+    // files carry 65535, and the search sizes its run table from it (src/blksrc.cc:2983) -- so does this one
+    h->wc.MaxBlk = 65535;
+    h->wc.BytBlk = segn <= 65535 ? 2 : 4; h->wc.WordSz = h->wc.BytBlk == 2 ? word_no : 2 * word_no; h->wc.VerNo = 26;
+    const double B = (double) segn;
+    h->b2c[0] = h->b2c[1] = h->b2c[2] = 0.;
+    for (int k = 0; k <= n_chr; ++k) {
+        const double off = k * B - n_chr * (double) (h->chrid[k].segn - 1);
+        h->b2c[0] = std::min(h->b2c[0], off); h->b2c[1] = std::max(h->b2c[1], off);
+    }
+    h->b2c[0] /= B; h->b2c[1] /= B;
+    SpdpBlkSearchOpts o;
+    if (opts) o = *opts; else spdp_blk_search_opts_default(&o);
+    std::string why;
+    if (!derive_search_params(h, o, why)) { ctx->err = "spdp_blk_index_build_p: " + why; return nullptr; }
+    if (seconds) { seconds[0] = t_dev1 + t_dev2s; seconds[1] = t_host1; seconds[2] = wall(t_begin); }
+    return (SpdpBlkIndexHost*) hold.release();
+}
+extern "C" SpdpBlkIndexHost* spdp_blk_index_build_p(SpdpContext* ctx, const SpdpGenome* genome, const SpdpBlkBuildParamsP* p,
+                                                    const SpdpBlkSearchOpts* opts, double* seconds)
+{
+    try { return blk_index_build_p(ctx, genome, p, opts, seconds); }
+    catch (const std::bad_alloc&) { if (ctx) ctx->err = "spdp_blk_index_build_p: out of host memory"; return nullptr; }
 }
 
 // WriteBlkInfo / writeBlkInfo (src/blksrc.cc:598-622): the struct images of the reference's 64-bit build

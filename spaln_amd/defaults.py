@@ -88,3 +88,13 @@ def scoring_h(nquant=None, **over) -> abi.ScoringH:
               term_codon=1, sh=SH, max_vmf_space=MAX_VMF_SPACE, ubh=0)
     kw.update(over)
     return abi.make_scoring_h(**kw)
+
+
+# MakeBlk::prepacomp's per-class terms of the translated block index's word scores (src/blksrc.cc:844-877) for the reference's defaults
+# (twenty classes, -Xp20, -Xq1, its mdm tables) -- recorded from the compiled reference (`spaln_idxtap -W -KP`, oracle/ref_build/idx_tap.cc:
+# the "[idx_tap] acomp" line, exact hex floats); spdp_blk_index_build_p's acomp
+BLOCK_ACOMP_20 = [float.fromhex(x) for x in (
+    "-0x1.905a039bd2496p+2 -0x1.20cd81c8d9c8p+1 -0x1.ea713dcbdeac6p+2 -0x1.d7828e58105d8p+0 0x1.018bdf0832daep+3 "
+    "0x1.9dac9b7222838p+0 -0x1.2fef0207cbap+1 0x1.44fd3d196c1cfp+3 -0x1.4611967298f91p+2 -0x1.7045848bd36fcp+2 "
+    "0x1.157df2a1998dep+2 0x1.b29309c2da184p-3 -0x1.9e5b95c02c5ccp+1 0x1.aeb2e0dfc9daep+2 0x1.8ffa6b1bb2d76p+1 "
+    "-0x1.785b7311540c6p+3 -0x1.f7373e897ef4ap+2 0x1.7b75b1ad70547p+3 0x1.3672571d50d5bp+3 -0x1.ae4b8287ac8dp+0").split()]

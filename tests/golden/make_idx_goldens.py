@@ -47,6 +47,68 @@ def edge_genome():
     return chroms
 
 
+def edge_genome_p():
+    """for the translated index (-KP): a FASTA file of this size gives 3-residue words and blklen 1024; the margin is
+    3 k - 1 + MinOrf = 38, so a first block ends after 1062 residues"""
+    rng = np.random.default_rng(20260931)
+    dna = lambda n: np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    lens = [1, 2, 5, 37, 38, 39, 40, 1023, 1024, 1025, 1061, 1062, 1063, 1064, 2048, 2085, 2086, 2087, 2088, 3000, 3110, 3111, 5000]
+    chroms = []
+    for k, n in enumerate(lens):
+        s = dna(n)
+        if n >= 1000:
+            at = int(rng.integers(100, n - 50))
+            s[at:at + int(rng.integers(1, 9))] = ord("N")
+            s[int(rng.integers(100, n - 50))] = ord("R")
+        if k % 5 == 0 and n > 2000:
+            s[1020:1030] = ord("N")
+        chroms.append(s)
+    return chroms
+
+
+def genome_p(seed, lens):
+    rng = np.random.default_rng(seed)
+    chroms = []
+    for n in lens:
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+        for _ in range(3):
+            at = int(rng.integers(0, n - 40))
+            s[at:at + int(rng.integers(1, 30))] = ord("N")
+        chroms.append(s)
+    return chroms
+
+
+P_CASES = {                                                     # name -> (genome, options of `spaln -W -KP`, threaded, MinOrf)
+    "idxp_edge_t0": (edge_genome_p, ["-t0"], 0, 30),
+    "idxp_edge_t3": (edge_genome_p, ["-t3"], 1, 30),
+    "idxp_a12_t2": (lambda: genome_p(77, [9000, 14000]), ["-XA12", "-Xk3", "-Xs2", "-Xr21", "-Xb512", "-t2"], 1, 21),
+}
+
+
+def main_p():
+    """the translated index of `spaln -W -KP` (needs oracle/_ref/spaln_idxtap, which also prints MakeBlk::prepacomp's terms);
+    tests/golden/idxp_acomp.json holds those per alphabet size"""
+    import json
+    env = dict(os.environ, ALN_TAB=os.path.join(REF, "table"))
+    acomp = {}
+    for name, (make, opts, threaded, minorf) in P_CASES.items():
+        with tempfile.TemporaryDirectory() as td:
+            write_fasta(os.path.join(td, "gnm.mfa"), make())
+            r = subprocess.run([os.path.join(REF, "spaln_idxtap"), "-W", "-KP"] + opts + ["gnm.mfa"], cwd=td, env=dict(env, ALN_DBS=td),
+                               capture_output=True, text=True)
+            if r.returncode:
+                sys.exit(f"{name}: {r.stderr[-300:]}")
+            line = [l for l in r.stderr.splitlines() if l.startswith("[idx_tap] acomp")][0].split()
+            acomp[line[2]] = line[4:]
+            raw = bytearray(open(os.path.join(td, "gnm.bkp"), "rb").read())
+            raw[36 + 48:36 + 88] = bytes(40)                      # ContBlk's five pointers: whatever the writer's heap was
+            with gzip.GzipFile(os.path.join(OUT, name + ".bkp.gz"), "wb", mtime=0) as f:
+                f.write(bytes(raw))
+            print(name, os.path.getsize(os.path.join(td, "gnm.mfa")), "bytes of FASTA ->", len(raw), "bytes of index")
+    with open(os.path.join(OUT, "idxp_acomp.json"), "w") as f:
+        json.dump(acomp, f, indent=0)
+
+
 def write_fasta(path, chroms):
     with open(path, "w") as f:
         for c, s in enumerate(chroms):
@@ -77,4 +139,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["p"]:
+        main_p()
+    else:
+        main()

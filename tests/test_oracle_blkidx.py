@@ -102,3 +102,70 @@ def test_default_parameters_are_the_reference_choice():
         assert (4, p.ktuple, p.bitpat2, 1 << (2 * p.ktuple), p.bitpat, p.nshift, p.blklen, p.maxgene, p.nbitpat, p.afact) == tuple(w), name
     with pytest.raises(RuntimeError):
         blocks.build_params_default(lib, 0)
+
+
+# ---- the translated index (`spaln -W -KP`, <db>.bkp): oracle/spdp_oracle_blkidx.c orc_blk_index_build_tron ------------------------
+IDXP = [("idxp_edge_t0", 0, 30), ("idxp_edge_t3", 1, 30), ("idxp_a12_t2", 1, 21)]     # (file, the threaded walk, MinOrf)
+
+
+def acomp_of(nalpha):
+    import json
+    return [float.fromhex(x) for x in json.load(open(os.path.join(GOLDEN_DIR, "idxp_acomp.json")))[str(nalpha)]]
+
+
+def genome_of_golden_p(name):
+    chroms = mk.P_CASES[name][0]()
+    conv = CODE_OF.copy()
+    conv[ord("R")] = 1
+    gen = np.concatenate([conv[c] for c in chroms]).astype(np.uint8)
+    off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
+    return gen, off
+
+
+def params_of_file_p(f, threaded, minorf):
+    w = f["wcp"]
+    return blk.build_params_p(w[1], w[5], w[6], w[7], w[9], threaded, f["conv"], acomp_of(w[0]), nalpha=w[0], minorf=minorf)
+
+
+@pytest.mark.parametrize("name,threaded,minorf", IDXP, ids=[c[0] for c in IDXP])
+def test_translated_index_files_of_the_reference(name, threaded, minorf):
+    """edge genome: chromosomes of 1 .. 5000 residues around the block boundaries (a last block whose ring spills into one block
+    more), ambiguous runs, with and without -t; a twelve-class alphabet with 3-residue words every 2 codons and MinOrf 21"""
+    f = read_bkn(os.path.join(GOLDEN_DIR, name + ".bkp.gz"))
+    gen, off = genome_of_golden_p(name)
+    got = blk.index_build_tron(gen, off, params_of_file_p(f, threaded, minorf))
+    same_tables(got, f)
+    assert (got["word_no"], got["glen"], got["avrscr"], got["bytblk"]) == (f["word_no"], f["glen"], f["avrscr"], f["bytblk"])
+    assert f["maxblk"] == 65535                      # ContBlk::MaxBlk is never set on this path of the reference
+    assert f["ver"] == 26 and f["n_chr"] == len(off) - 1
+    other = blk.index_build_tron(gen, off, params_of_file_p(f, 1 - threaded, minorf))       # the two walks differ
+    assert other["word_no"] != got["word_no"]
+
+
+def test_translated_index_of_the_protein_fixture():
+    """tests/golden/blk_p1.bkp: the index the protein block-search fixture was searched in (`spaln -W -KP`, no -t)"""
+    f = read_bkn(os.path.join(GOLDEN_DIR, "blk_p1.bkp"))
+    gen, off = genome_of("blk_p1", 30, 1200, True)
+    from spaln_amd import defaults
+    assert defaults.BLOCK_ACOMP_20 == acomp_of(20)
+    got = blk.index_build_tron(gen, off, params_of_file_p(f, 0, 30))
+    same_tables(got, f)
+    assert (got["word_no"], got["avrscr"]) == (f["word_no"], f["avrscr"])
+
+
+def test_default_parameters_of_a_translated_index():
+    """spdp_blk_build_params_default_p against the BlkWcPrm and ConvTab of the reference's files (FASTA sizes as
+    tests/golden/make_idx_goldens.py printed them; blk_p1's genome file: 129 632 bytes)"""
+    import ctypes as C
+    from spaln_amd import blocks, engine
+    lib = C.CDLL(engine.LIB_PATH)
+    for path, size in ((os.path.join(GOLDEN_DIR, "idxp_edge_t0.bkp.gz"), 32797), (os.path.join(GOLDEN_DIR, "blk_p1.bkp"), None)):
+        f = read_bkn(path)
+        w = f["wcp"]
+        if size is None:
+            gen, off = genome_of("blk_p1", 30, 1200, True)
+            size = sum(len(f">chr{c + 1}\n") + int(off[c + 1] - off[c]) + (int(off[c + 1] - off[c]) + 59) // 60 for c in range(len(off) - 1))
+        p = blocks.build_params_default_p(lib, size)
+        assert (p.nalpha, p.b.ktuple, p.b.bitpat2, 20 ** p.b.ktuple, p.b.bitpat, p.b.nshift, p.b.blklen, p.b.maxgene, p.b.nbitpat, p.b.afact) == tuple(w), path
+        conv = bytes(p.convtab)[:p.convts]
+        assert p.convts == f["conv_ts"] and list(conv[3:25]) + [conv[26]] == f["conv"][3:25].tolist() + [int(f["conv"][26])]

@@ -118,12 +118,21 @@ def main_protein(args):
         assert int(fq["seed_params"][13]) == model.crs, (qh, model.crs)
         fsig = fq if "pm5_f32" in fq else spdg.load(os.path.join(ROOT, "tests", "golden", "h1_basic.spdg"))
         t0 = time.perf_counter()
-        fx = blocks.read_index_file(lib, os.path.join(td, "gnm.bkp"), ext_block=int(cli["blk_prm"][blocks._PRM["extblock"]]))
-        fx["blk_convtab"][:2] = 255
-        dix = blocks.BlockIndex(eng, fx)
         chr_names, chroms = read_fasta(os.path.join(td, "gnm.mfa"))
         gen = np.concatenate(chroms).astype(np.uint8)
         off = np.array([0] + list(np.cumsum([len(c) for c in chroms])), dtype=np.int64)
+        # the translated index: built by the library from the same residues (spdp_blk_index_build_p), compared with the reference's
+        # file, and the one searched below
+        theirs = blocks.read_index_file(lib, os.path.join(td, "gnm.bkp"), ext_block=int(cli["blk_prm"][blocks._PRM["extblock"]]))
+        bprm = blocks.build_params_default_p(lib, os.path.getsize(os.path.join(td, "gnm.mfa")), threaded=1)        # (make_dataset formats with -t)
+        blocks.build_index_p(eng, gen[:1 << 16], np.array([0, min(len(gen), 1 << 16)], dtype=np.int64), bprm)     # (first launch of the kernels)
+        tb = time.perf_counter()
+        _, bsec = blocks.build_index_p(eng, gen, off, bprm, write_to=os.path.join(td, "ours.bkp"))
+        build_s = time.perf_counter() - tb
+        fx = blocks.read_index_file(lib, os.path.join(td, "ours.bkp"), ext_block=int(cli["blk_prm"][blocks._PRM["extblock"]]))
+        index_same = all(np.array_equal(np.asarray(fx[k]), np.asarray(theirs[k])) for k in ("blk_nblk", "blk_wscr", "blk_blkp", "blk_blkb", "blk_chr", "blk_prm"))
+        fx["blk_convtab"][:2] = 255
+        dix = blocks.BlockIndex(eng, fx)
         q_names, q_raw = [], []
         for blk_ in open(os.path.join(td, "q.fa")).read().split(">")[1:]:
             nm, seq = blk_.split("\n", 1)
@@ -162,6 +171,8 @@ def main_protein(args):
                                   "(spdp_map_align_h) against `spaln -Q7 -O4`",
                           "queries": args.queries, "genome_nt": genome_nt, "reference_aligned": len(want), "library_aligned": len(got),
                           "identical_exon_tables": n_same, "different": len(diff), "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
+                          "index": {"built_by": "spdp_blk_index_build_p", "tables_identical_to_the_reference_file": bool(index_same),
+                                    "build_and_write_s": round(build_s, 3), "device_s": round(bsec[0], 3), "host_s": round(bsec[1], 3)},
                           "library_s": {"index_and_genome_load": round(load_s, 3), "map_align_call": round(lib_s, 3), "first_call": round(runs[0][0], 3),
                                         "find": round(phases[0], 3), "regions_and_signals": round(phases[1], 3), "align": round(phases[2], 3),
                                         "rescore": round(phases[3], 3)},

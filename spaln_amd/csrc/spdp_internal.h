@@ -188,6 +188,7 @@ struct HRescoreProb {
     int32_t a_len, b_len;
     int32_t a_exgl, a_exgr, b_exgl, b_exgr;
     int64_t a_off, b_off, col_off;
+    int32_t w_lo, w_hi;               // the region positions the launch holds: [w_lo, w_hi) of the problem's b_len + 3 (the corners' span and a margin)
 };
 struct HRescoreArgs {
     const int*        mtx;        // stride 32: mtx[aa * 32 + tron]

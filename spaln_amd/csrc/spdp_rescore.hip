@@ -219,9 +219,14 @@ __global__ void spdh_rescore(HRescoreArgs A)
     const int AMBc = 2, SERc = 18, SER2c = 23, TRM2c = 24, TRMc = 25;
 
     auto aat = [&](int i) -> int { return (i >= 0 && i < P.a_len) ? a[i] : AMBc; };
-    auto bat = [&](int i) -> int { return (i >= 0 && i <= P.b_len) ? bq[i] : AMBc; };
-    auto sgat = [&](int i, int f) -> int { return (i >= 0 && i < N) ? sg[5 * i + f] : 0; };     // 0 sig5 1 sig3 2 sigS 3 sigT 4 sigE
-    auto phat = [&](int i, int f) -> int { return (i >= 0 && i < N) ? ph[2 * i + f] : -2; };
+    // the launch holds positions [w_lo, w_hi) of the region (what the corners span, and a margin); a read outside them that lies inside
+    // the region is reported (hdr[7]) and refused by the host: nothing is ever made up
+    int missed = 0;
+    auto held = [&](int i) -> bool { const bool in = i >= P.w_lo && i < P.w_hi; if (!in) missed = 1; return in; };
+    auto bat = [&](int i) -> int { return (i >= 0 && i <= P.b_len && held(i)) ? bq[i - P.w_lo] : AMBc; };
+    auto sgat = [&](int i, int f) -> int { return (i >= 0 && i < N && held(i)) ? sg[5 * (i - P.w_lo) + f] : 0; };     // 0 sig5 1 sig3 2 sigS 3 sigT 4 sigE
+    auto phat = [&](int i, int f) -> int { return (i >= 0 && i < N && held(i)) ? ph[2 * (i - P.w_lo) + f] : -2; };
+    auto dcat = [&](int i) -> int { return (i >= 0 && i <= P.b_len && held(i)) ? dc[i - P.w_lo] : 0; };
     auto cdiv = [](int x, int y) { return x / y; };                                            // C division
     auto gap_penalty3 = [&](int i) {
         if (i == 0) return 0;
@@ -236,7 +241,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
         return (i <= A.codonk1) ? unp + egop : unp - A.diffu * (d - A.k1) + egop;
     };
     auto sig53_ie53 = [&](int n5, int n3) {
-        const int d5 = (n5 >= 0 && n5 <= P.b_len) ? (dc[n5] >> 4) : 0, d3 = (n3 >= 0 && n3 <= P.b_len) ? (dc[n3] & 15) : 0;
+        const int d5 = dcat(n5) >> 4, d3 = dcat(n3) & 15;
         return sgat(n3, 1) + (int) A.t53[16 * d5 + d3];
     };
     auto spjscr = [&](int n5, int n3) { return (int) A.intpen[min(max(n3 - n5, 0), A.intpen_len - 1)] + sig53_ie53(n5, n3); };
@@ -468,7 +473,7 @@ __global__ void spdh_rescore(HRescoreArgs A)
     const int unp3 = fst.unp / 3;
     fval += A.gop * fst.gap + A.gep * unp3;
     hdr[0] = h; hdr[1] = fst.mch; hdr[2] = fst.mmc; hdr[3] = fst.gap; hdr[4] = unp3; hdr[5] = fval;
-    hdr[6] = n_rec; hdr[7] = 0;
+    hdr[6] = n_rec; hdr[7] = missed;
     if (fmt == 2) {
         // Vulgar::postproc (src/gsinfo.cc:1206-1226) over the records before the trailing dummy: match lengths next to
         // split codons and frame shifts

@@ -128,6 +128,8 @@ static int rescore_s(SpdpContext* ctx, const SpdpScoring* sc, const SpdpRescoreP
     HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < nr; ++s)
+        if (hdr[(size_t) s * 8 + 7]) { ctx->err = "rescoring (protein): a read outside the region window held on the device (SPDP_RESCORE_WINDOW=0 holds whole regions)"; return -1; }
     for (int s = 0; s < nr && out; ++s) {
         SpdpRescored& o = out[idx[s]];
         const int* h = &hdr[(size_t) s * 8];
@@ -218,6 +220,9 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
     // where every problem's pieces go, then the pieces themselves on the host's threads (a batch of a map + align call is tens of
     // thousands of loci of tens of kilobases: hundreds of millions of positions)
     int64_t a_tot = 0, b_tot = 0, col_tot = 0, skl_tot = 0;
+    const char* we = getenv("SPDP_RESCORE_WINDOW");
+    const bool windowed = !(we && atoi(we) == 0);
+    const int margin = 64 + 3 * rp->jneibr;
     for (int i = 0; i < n_probs; ++i) {
         const SpdpProblemH& p = probs[i];
         const int cnt = aln[i].n_skl - 1;
@@ -229,8 +234,15 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
         d.a_left = p.a_left; d.a_right = p.a_right; d.b_left = p.b_left; d.b_right = p.b_right;
         d.a_len = p.a_len; d.b_len = p.b_len;
         d.a_exgl = p.a_exgl; d.a_exgr = p.a_exgr; d.b_exgl = p.b_exgl; d.b_exgr = p.b_exgr;
+        // the region positions the walk over the corners can read: what the corners span and a margin (junction neighbourhoods, the
+        // codons around a split codon, the stop codon behind the last corner); SPDP_RESCORE_WINDOW=0: the whole region
+        int y_lo = INT32_MAX, y_hi = INT32_MIN;
+        for (int k = 1; k <= cnt; ++k) { y_lo = std::min(y_lo, aln[i].skl[k].n); y_hi = std::max(y_hi, aln[i].skl[k].n); }
+        d.w_lo = windowed ? std::max(0, y_lo - margin) : 0;
+        d.w_hi = windowed ? std::min(p.b_len + 3, y_hi + margin) : p.b_len + 3;
+        if (d.w_hi < d.w_lo) d.w_hi = d.w_lo;
         d.a_off = a_tot; d.b_off = b_tot; d.col_off = col_tot;
-        a_tot += p.a_len; b_tot += p.b_len + 1; col_tot += p.b_len + 3;
+        a_tot += p.a_len; b_tot += d.w_hi - d.w_lo; col_tot += d.w_hi - d.w_lo;
         idx.push_back(i); descs.push_back(d);
         soff.push_back(skl_tot); scnt.push_back(cnt);
         skl_tot += cnt;
@@ -246,13 +258,14 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
                 const SpdpProblemH& p = probs[idx[s]];
                 const HRescoreProb& d = descs[s];
                 memcpy(a_all.data() + d.a_off, p.a, (size_t) p.a_len);
-                memcpy(b_all.data() + d.b_off, p.b, (size_t) p.b_len + 1);
-                const int N = p.b_len + 3;
+                uint8_t* bb = b_all.data() + d.b_off;
                 short* sg = sig.data() + 5 * d.col_off; int8_t* ph = phs.data() + 2 * d.col_off; uint8_t* dc = dinc.data() + d.col_off;
-                for (int x = 0; x < N; ++x) {
-                    sg[5 * x] = p.sig5[x]; sg[5 * x + 1] = p.sig3[x]; sg[5 * x + 2] = p.sigS[x]; sg[5 * x + 3] = p.sigT[x]; sg[5 * x + 4] = p.sigE[x];
-                    ph[2 * x] = p.phs5[x]; ph[2 * x + 1] = p.phs3[x];
-                    dc[x] = x <= p.b_len ? p.dinc[x] : 0;
+                for (int x = d.w_lo; x < d.w_hi; ++x) {
+                    const int o = x - d.w_lo;
+                    bb[o] = x <= p.b_len ? p.b[x] : 0;
+                    sg[5 * o] = p.sig5[x]; sg[5 * o + 1] = p.sig3[x]; sg[5 * o + 2] = p.sigS[x]; sg[5 * o + 3] = p.sigT[x]; sg[5 * o + 4] = p.sigE[x];
+                    ph[2 * o] = p.phs5[x]; ph[2 * o + 1] = p.phs3[x];
+                    dc[o] = x <= p.b_len ? p.dinc[x] : 0;
                 }
                 memcpy(skl.data() + soff[s], aln[idx[s]].skl + 1, sizeof(SpdpSkl) * (size_t) scnt[s]);
             }
@@ -319,6 +332,8 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
     HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < nr; ++s)
+        if (hdr[(size_t) s * 8 + 7]) { ctx->err = "rescoring (protein): a read outside the region window held on the device (SPDP_RESCORE_WINDOW=0 holds whole regions)"; return -1; }
     for (int s = 0; s < nr && out; ++s) {
         SpdpRescored& o = out[idx[s]];
         const int* h = &hdr[(size_t) s * 8];

@@ -745,6 +745,18 @@ static int run_scalar(HStore& st, const std::vector<HItem>& items, bool forward,
     std::vector<std::vector<SpdpSkl>> lists(nr);
     std::vector<int> todo(nr);
     for (int i = 0; i < nr; ++i) todo[i] = i;
+    // dispatch order: the problems with the most anti-diagonals first.  A wave sweeps one problem (or one tile of it) and the hardware
+    // hands blocks out in index order: a long problem that starts late ends the launch late, and a block whose four problems differ in
+    // length holds its LDS until the longest is done
+    {
+        std::vector<int64_t> steps(nr);
+        for (int i = 0; i < nr; ++i) {
+            const HItem& t = items[i];
+            const int64_t rows = t.a_right - t.a_left;
+            steps[i] = std::min<int64_t>((int64_t) t.b_right - t.b_left, (int64_t) t.w.up - t.w.lw + 3 * rows) + rows;
+        }
+        std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return steps[x] > steps[y]; });
+    }
     for (int scale = 1; !todo.empty(); scale *= 8) {
         if (scale > 32768) { ctx->err = "scalar engine: Vmf record store overflow"; return -1; }
         std::vector<int> again;

@@ -199,6 +199,8 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
     if (n_lanes > 1 && !spdp_lane(ctx, n_lanes - 1)) { spdh_store_close(st); return -1; }     // (created here, on one thread)
     int busy_lanes = 0;
     std::vector<int64_t> lane_n(n_lanes, 0), lane_us(n_lanes, 0), lane_req(n_lanes, 0);
+    const bool shape_stats = getenv("SPDP_SEED_VERBOSE") && atoi(getenv("SPDP_SEED_VERBOSE")) >= 2;
+    int64_t shape_n[6] = {0, 0, 0, 0, 0, 0}, shape_steps[6] = {0, 0, 0, 0, 0, 0}, shape_cells[6] = {0, 0, 0, 0, 0, 0};
     auto device = [&](std::vector<Parked*>& take, int lane) {
         (void) hipSetDevice(ctx->device);
         { std::lock_guard<std::mutex> g(stats_mu); if (!busy_lanes++) us_walks += us_since(t_idle); }
@@ -211,6 +213,15 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
             r.parent = q.query; r.al = q.s.al; r.ar = q.s.ar; r.bl = q.s.bl; r.br = q.s.br;
             r.exg[0] = q.s.a_exgl; r.exg[1] = q.s.a_exgr; r.exg[2] = q.s.b_exgl; r.exg[3] = q.s.b_exgr;
             r.w = q.w; r.kind = q.kind; r.cut_l = q.cut[0]; r.cut_r = q.cut[1];
+        }
+        if (shape_stats) {                              // SPDP_SEED_VERBOSE=2: what the walks ask of the device, by query rows
+            std::lock_guard<std::mutex> g(stats_mu);
+            for (int k = 0; k < m; ++k) {
+                const int rows = rq[k].ar - rq[k].al;
+                const int64_t cols = std::max<int64_t>(0, std::min<int64_t>(rq[k].br - rq[k].bl, (int64_t) rq[k].w.up - rq[k].w.lw + 3 * rows));
+                const int b = rows < 8 ? 0 : rows < 16 ? 1 : rows < 32 ? 2 : rows < 64 ? 3 : rows < 128 ? 4 : 5;
+                ++shape_n[b]; shape_steps[b] += cols + rows; shape_cells[b] += cols * rows;
+            }
         }
         std::vector<SpdpAlignment> res(m);
         SpdpContext* lc = spdp_lane(ctx, lane);
@@ -268,6 +279,11 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         for (int l = 0; l < n_lanes; ++l)
             fprintf(stderr, "[seeded] lane %d (class %d): %lld batches, %.2f ms each, %.0f requests each\n", l, class_of_lane[l], (long long) lane_n[l],
                     lane_n[l] ? lane_us[l] / 1e3 / lane_n[l] : 0.0, lane_n[l] ? (double) lane_req[l] / lane_n[l] : 0.0);
+    if (shape_stats) {
+        static const char* name[6] = {"< 8", "8 .. 15", "16 .. 31", "32 .. 63", "64 .. 127", ">= 128"};
+        for (int b = 0; b < 6; ++b)
+            fprintf(stderr, "[seeded] requests of %s query rows: %lld, %.3g anti-diagonals, %.3g cells\n", name[b], (long long) shape_n[b], (double) shape_steps[b], (double) shape_cells[b]);
+    }
     spdh_store_close(st);
     ctx->seed_stats[0] = n_batches; ctx->seed_stats[1] = n_kind[0]; ctx->seed_stats[2] = n_kind[1] + n_kind[3];
     ctx->seed_stats[3] = n_cut; ctx->seed_stats[4] = n_wilip.load(); ctx->seed_stats[5] = n_probs;

@@ -776,7 +776,7 @@ LEGS = {
                 "the device) against the index of a 3 Gb genome the library built itself (spdp_blk_index_build, five bit patterns)"),
     "blk_find_p": (["tools/blk_find_protein.py", "--queries", "20000", "--genes", "200"],
                    "SURVEY 8 row f4 for protein queries (BASELINE configs[0] / [2]'s mapping phase): spdp_blk_find on the translated index "
-                   "(<db>.bkp of the reference's `spaln -W -KP`, read by the library) of a 20 Mb genome -- vote and HSP search on the device (regions "
+                   "(<db>.bkp built by spdp_blk_index_build_p, its tables compared with the file of the reference's `spaln -W -KP`) of a 20 Mb genome -- vote and HSP search on the device (regions "
                    "read as tron codes where they lie), FindHsp's DvsP = 1 branch with its retries on a grown region as batched machines; "
                    "parity: tests/test_gpu_blk_find.py[blk_p1] against the reference's recorded runs"),
     "a0": (["--engines", "a0", "--queries", "1000", "--steps", "2", "--warmup", "1"],

@@ -111,7 +111,7 @@ def main():
         if not n_launch:
             continue
         cells = cfg.get(cells_key) if cells_key else None
-        e = {"kernel": k.split("(")[0], "source": src, "source_sha256": source_sha(src),
+        e = {"kernel": k.replace("(anonymous namespace)::", "").split("(")[0], "source": src, "source_sha256": source_sha(src),
              "launches_per_step": n_launch / args.steps,
              "avg_ms": round(sum(dur[k]) / len(dur[k]), 4) if dur.get(k) else None,
              "ms_per_step": round(sum(dur[k]) / args.steps, 4) if dur.get(k) else None,

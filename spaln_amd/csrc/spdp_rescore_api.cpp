@@ -249,8 +249,18 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
         roff.push_back(rtot);
         rtot += cnt + 3;                                    // exons, frame-shift records, end marker
     }
-    a_all.resize((size_t) a_tot); b_all.resize((size_t) b_tot); sig.resize((size_t) col_tot * 5); phs.resize((size_t) col_tot * 2);
-    dinc.resize((size_t) col_tot); skl.resize((size_t) skl_tot);
+    // the region pieces go through the context's pinned staging blocks when it has them (no zero fill, and the bus at its rate: a map +
+    // align call rescoring 20 000 loci moves 2 GB here); pageable vectors otherwise
+    a_all.resize((size_t) a_tot); skl.resize((size_t) skl_tot);
+    short* sig_p = (short*) ctx->staging(0, std::max<size_t>((size_t) col_tot * 5 * sizeof(short), 64));
+    uint8_t* misc_p = sig_p ? (uint8_t*) ctx->staging(1, std::max<size_t>((size_t) b_tot + (size_t) col_tot * 3, 64)) : nullptr;
+    if (!sig_p || !misc_p) {
+        b_all.resize((size_t) b_tot); sig.resize((size_t) col_tot * 5); phs.resize((size_t) col_tot * 2); dinc.resize((size_t) col_tot);
+        sig_p = sig.data();
+    }
+    uint8_t* const b_p = misc_p ? misc_p : b_all.data();
+    int8_t* const phs_p = misc_p ? (int8_t*) (misc_p + b_tot) : phs.data();
+    uint8_t* const dinc_p = misc_p ? misc_p + b_tot + 2 * col_tot : dinc.data();
     {
         std::atomic<int> next{0};
         auto work = [&] {
@@ -258,8 +268,8 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
                 const SpdpProblemH& p = probs[idx[s]];
                 const HRescoreProb& d = descs[s];
                 memcpy(a_all.data() + d.a_off, p.a, (size_t) p.a_len);
-                uint8_t* bb = b_all.data() + d.b_off;
-                short* sg = sig.data() + 5 * d.col_off; int8_t* ph = phs.data() + 2 * d.col_off; uint8_t* dc = dinc.data() + d.col_off;
+                uint8_t* bb = b_p + d.b_off;
+                short* sg = sig_p + 5 * d.col_off; int8_t* ph = phs_p + 2 * d.col_off; uint8_t* dc = dinc_p + d.col_off;
                 for (int x = d.w_lo; x < d.w_hi; ++x) {
                     const int o = x - d.w_lo;
                     bb[o] = x <= p.b_len ? p.b[x] : 0;
@@ -285,10 +295,10 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
     void* d_mtx = pool.get(RH_MTX, mtx.size() * sizeof(int));
     void* d_probs = pool.get(RH_PROBS, nr * sizeof(HRescoreProb));
     void* d_a = pool.get(RH_A, a_all.size() + 16);
-    void* d_b = pool.get(RH_B, b_all.size() + 16);
-    void* d_sig = pool.get(RH_SIG, sig.size() * sizeof(short));
-    void* d_phs = pool.get(RH_PHS, phs.size());
-    void* d_dinc = pool.get(RH_DINC, dinc.size());
+    void* d_b = pool.get(RH_B, (size_t) b_tot + 16);
+    void* d_sig = pool.get(RH_SIG, std::max<size_t>((size_t) col_tot * 5 * sizeof(short), 16));
+    void* d_phs = pool.get(RH_PHS, std::max<size_t>((size_t) col_tot * 2, 16));
+    void* d_dinc = pool.get(RH_DINC, std::max<size_t>((size_t) col_tot, 16));
     void* d_intpen = pool.get(RH_INTPEN, sizeof(int16_t) * sc->intpen_len);
     void* d_skl = pool.get(RP_SKL, skl.size() * sizeof(SpdpSkl));
     void* d_soff = pool.get(RP_SOFF, nr * sizeof(int64_t));
@@ -299,7 +309,11 @@ static int rescore_h(SpdpContext* ctx, const SpdpScoringH* sc, const SpdpRescore
     if (!d_mtx || !d_probs || !d_a || !d_b || !d_sig || !d_phs || !d_dinc || !d_intpen || !d_skl || !d_soff ||
         !d_scnt || !d_roff || !d_hdr || !d_rec) { ctx->err = "out of device memory"; return -1; }
 #define UP(dst, vec) HIPCHK(hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, ctx->stream))
-    UP(d_mtx, mtx); UP(d_probs, descs); UP(d_a, a_all); UP(d_b, b_all); UP(d_sig, sig); UP(d_phs, phs); UP(d_dinc, dinc);
+    UP(d_mtx, mtx); UP(d_probs, descs); UP(d_a, a_all);
+    HIPCHK(hipMemcpyAsync(d_b, b_p, (size_t) b_tot, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_sig, sig_p, (size_t) col_tot * 5 * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_phs, phs_p, (size_t) col_tot * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_dinc, dinc_p, (size_t) col_tot, hipMemcpyHostToDevice, ctx->stream));
     UP(d_skl, skl); UP(d_soff, soff); UP(d_scnt, scnt); UP(d_roff, roff);
 #undef UP
     HIPCHK(hipMemcpyAsync(d_intpen, sc->intpen, sizeof(int16_t) * sc->intpen_len, hipMemcpyHostToDevice, ctx->stream));

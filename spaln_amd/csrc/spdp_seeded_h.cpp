@@ -283,6 +283,9 @@ extern "C" int spdp_align_h_seeded(SpdpContext* ctx, const SpdpScoringH* sc, con
         for (int l = 0; l < n_lanes; ++l)
             fprintf(stderr, "[seeded] lane %d (class %d): %lld batches, %.2f ms each, %.0f requests each\n", l, class_of_lane[l], (long long) lane_n[l],
                     lane_n[l] ? lane_us[l] / 1e3 / lane_n[l] : 0.0, lane_n[l] ? (double) lane_req[l] / lane_n[l] : 0.0);
+    if (getenv("SPDP_SEED_VERBOSE"))
+        fprintf(stderr, "[seeded] %d problems: upload %.3f s, walks alone %.3f s, device batches %.3f s (summed over the lanes), in all %.3f s\n", n_probs,
+                us_upload / 1e6, us_walks / 1e6, us_device / 1e6, us_since(t_begin) / 1e6);
     if (shape_stats) {
         static const char* name[6] = {"< 8", "8 .. 15", "16 .. 31", "32 .. 63", "64 .. 127", ">= 128"};
         for (int b = 0; b < 6; ++b)

@@ -484,38 +484,73 @@ static SpdpBlkIndexHost* blk_index_build_p(SpdpContext* ctx, const SpdpGenome* g
     if (spdp_blkidx_words_p(ctx, genome->codes, genome->chr_off, chr_first.data(), n_chr, A, 32 + word_bits, tcount, cnt, &dev)) { return nullptr; }
     struct DevGuard { BlkBuildDev* d; ~DevGuard() { spdp_blkidx_free(d); } } dev_guard{dev};
     const double t_dev1 = wall(t_begin);
-    // ---- blkscrtab(segn), src/blksrc.cc:879-942: the running composition term is a sum in table order -- one thread
+    // ---- blkscrtab(segn), src/blksrc.cc:879-942
     const auto t_host = std::chrono::steady_clock::now();
     const uint32_t segn = (uint32_t) blocks;
     try { h->nblk.assign(tabsize, 0); h->blkp.assign(tabsize, 0); h->wscr.assign(tabsize, 0); } catch (const std::bad_alloc&) { return fail("out of memory for the index tables"); }
     const double basescr = log((double) segn);
     const double deltaa = p->acomp[0] - p->acomp[na - 1];
-    double alc = K * p->acomp[0], avr = 0.;
-    uint64_t m_seen = 0;
-    for (uint32_t w = 0; w < tabsize; ++w) {
-        if (tcount[w]) {
-            ++m_seen;
-            short sc = (short) (100 * (basescr - log((double) tcount[w] / 1)));
-            sc = (short) (sc + (short) alc);
-            h->wscr[w] = sc;
-            avr += sc;
+    // the composition term of every word as the reference's running sum leaves it (a double sum in table order: one thread, nothing but
+    // the sum), then the scores -- logarithms -- on all host threads; their total is a sum of integers, exact in any order
+    std::vector<int16_t> alc_of;
+    try { alc_of.resize(tabsize); } catch (const std::bad_alloc&) { return fail("out of memory for the index tables"); }
+    {
+        double alc = K * p->acomp[0];
+        double step[21];                                // what the sum gains when a digit goes from q - 1 to q
+        for (int q = 1; q <= na; ++q) step[q] = p->acomp[q % na] - p->acomp[q - 1];     // (q = na is never taken: the wrap has its own rule below)
+        for (uint32_t w0 = 0; w0 < tabsize; w0 += (uint32_t) na) {
+            // the words w0 .. w0 + na - 1 differ in their last digit only: na - 1 plain steps, then the carry
+            for (int d = 0; d < na - 1; ++d) { alc_of[w0 + d] = (short) alc; alc += step[d + 1]; }
+            const uint32_t w = w0 + (uint32_t) na - 1;
+            alc_of[w] = (short) alc;
+            int z = 0, q = 0;
+            for (uint32_t x = w + 1; (q = (int) (x % (uint32_t) na)) == 0; x /= (uint32_t) na) ++z;
+            alc += z * deltaa;
+            alc += p->acomp[q] - p->acomp[q - 1];
         }
-        int z = 0, q = 0;
-        for (uint32_t x = w + 1; (q = (int) (x % (uint32_t) na)) == 0; x /= (uint32_t) na) ++z;
-        if (z) alc += z * deltaa;
-        alc += p->acomp[q] - p->acomp[q - 1];
     }
+    const int nt = std::max(1, std::min(spdp_host_cpus(), (int) (tabsize >> 14)));
+    auto on_ranges = [&](auto f) {
+        std::vector<std::thread> th;
+        const uint32_t step = (tabsize + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { f(t, (uint32_t) std::min<uint64_t>(tabsize, (uint64_t) t * step), (uint32_t) std::min<uint64_t>(tabsize, (uint64_t) (t + 1) * step)); });
+        for (std::thread& x : th) x.join();
+    };
+    std::vector<int64_t> part_sum(nt, 0);
+    std::vector<uint64_t> part_m(nt, 0);
+    on_ranges([&](int t, uint32_t lo, uint32_t hi) {
+        int64_t sum = 0; uint64_t m = 0;
+        for (uint32_t w = lo; w < hi; ++w) {
+            if (!tcount[w]) continue;
+            ++m;
+            short sc = (short) (100 * (basescr - log((double) tcount[w] / 1)));
+            sc = (short) (sc + alc_of[w]);
+            h->wscr[w] = sc;
+            sum += sc;
+        }
+        part_sum[t] = sum; part_m[t] = m;
+    });
+    uint64_t m_seen = 0; int64_t total = 0;
+    for (int t = 0; t < nt; ++t) { m_seen += part_m[t]; total += part_sum[t]; }
     if (!m_seen) { return fail("no word in the genome"); }
+    double avr = (double) total;
     avr /= (double) m_seen;
     short min_scr = (short) (avr - 100 * (1 + p->aaafact) * log((double) p->b.afact));
     if (min_scr < 0) min_scr = 0;
+    std::vector<uint64_t> part_words(nt, 0), part_over(nt, 0);
+    on_ranges([&](int t, uint32_t lo, uint32_t hi) {
+        uint64_t words = 0, ov = 0;
+        for (uint32_t w = lo; w < hi; ++w) {
+            if (!cnt[w]) { h->wscr[w] = -1; continue; }
+            if (cnt[w] > 65535) ++ov;
+            if (h->wscr[w] > min_scr) words += cnt[w];
+            else { h->wscr[w] = 0; cnt[w] = 0; }
+        }
+        part_words[t] = words; part_over[t] = ov;
+    });
     uint64_t word_no = 0, over = 0;
-    for (uint32_t w = 0; w < tabsize; ++w) {
-        if (!cnt[w]) { h->wscr[w] = -1; continue; }
-        if (cnt[w] > 65535) ++over;
-        if (h->wscr[w] > min_scr) word_no += cnt[w];
-        else { h->wscr[w] = 0; cnt[w] = 0; }
-    }
+    for (int t = 0; t < nt; ++t) { word_no += part_words[t]; over += part_over[t]; }
+    { std::vector<int16_t>().swap(alc_of); }
     if (over) { return fail("a word lies in more than 65 535 blocks: the reference's 16-bit counters wrap there (use a longer k)"); }
     if (word_no > (uint64_t) INT32_MAX) { return fail("more postings than a 32-bit list offset (blkp) can address"); }
     uint64_t at = 0;

@@ -45,3 +45,17 @@ def test_compact_line_never_exceeds_the_limit():
     assert len(line) <= b.LINE_LIMIT
     d = json.loads(line)
     assert d["roofline"]["frac"] and d["cpu_baseline"]["value"] and d["value"]
+
+
+def test_the_round_record_is_within_the_limit():
+    """profiles/r06_bench_legs.json (the full record of the round's last run) through the line builder, and the line kept beside it"""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_legs.json")))
+    line = b.compact_line(full)
+    assert len(line) <= b.LINE_LIMIT
+    d = json.loads(line)
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["kind"] == "reference"
+    for leg in ("e2e_q7", "e2e_q7_p", "e2e_q7_s3", "c4_e2e"):
+        assert d["config"]["legs"][leg]["same"] == d["config"]["legs"][leg]["of"], leg
+    kept = open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read().strip()
+    assert len(kept) <= b.LINE_LIMIT and json.loads(kept)["value"] == full["value"]

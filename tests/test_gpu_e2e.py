@@ -48,6 +48,18 @@ def test_protein_exon_tables_equal_the_reference_program():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["reference_aligned"] == 300 and d["library_aligned"] == 300
     assert d["identical_exon_tables"] == 300, (d, r.stderr[-600:])
+    assert d["index"]["built_by"] == "spdp_blk_index_build_p" and d["index"]["tables_identical_to_the_reference_file"] is True     # (the index searched is the library's own)
+
+
+def test_protein_rescoring_window_changes_nothing():
+    """spdp_skl_rng_h with the corners' span of every region on the device (the default) and with whole regions: the same exon tables"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "spaln")):
+        pytest.skip("oracle/_ref/spaln is not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_q7.py"), "--protein", "--queries", "200", "--genes", "40"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SPDP_RESCORE_WINDOW="0"))
+    assert r.returncode == 0, r.stderr[-400:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["identical_exon_tables"] == 200 and d["library_aligned"] == 200, d
 
 
 @pytest.mark.parametrize("scout", ["0", "1", "2"])

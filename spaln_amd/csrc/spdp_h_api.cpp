@@ -163,9 +163,28 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
     std::vector<uint8_t> a_all((size_t) a_tot, 0);      // (the byte behind a query reads 0 in the reference process: row a_len, see bad_range)
     // column records, packed by the host's cores into pinned staging memory the context keeps (one thread and pageable
     // vectors took 0.18 ms per protein window -- longer than the reference takes to ALIGN the pair on its seeded path)
-    int4* cols = dev_sig ? nullptr : (int4*) ctx->staging(0, (size_t) std::max<int64_t>(c_tot, 1) * sizeof(int4));
-    short4* aux = dev_sig ? nullptr : (short4*) ctx->staging(1, (size_t) std::max<int64_t>(c_tot, 1) * sizeof(short4));
+    // ... through a ring of four groups' worth of it: a group's slot is packed again once its copy has left (a map + align call of
+    // 20 000 protein loci holds 5 * 10^8 positions -- 12 GB of pinned memory when every group had its own place, two seconds of a
+    // context's first call to allocate)
+    std::vector<int> grp_first, grp_of(n);
+    int64_t slot_cap = 1;
+    {
+        int64_t acc = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i == 0 || acc >= (4 << 20)) { grp_first.push_back(i); acc = 0; }
+            grp_of[i] = (int) grp_first.size() - 1;
+            acc += col_len[i];
+            slot_cap = std::max(slot_cap, acc);
+        }
+    }
+    const int RING_SLOTS = (getenv("SPDP_UPLOAD_RING") && atoi(getenv("SPDP_UPLOAD_RING")) == 0) ? std::max<int>(1, (int) grp_first.size()) : 4;     // (0: every group its own place, as before round 6)
+    int4* cols = dev_sig ? nullptr : (int4*) ctx->staging(0, (size_t) slot_cap * RING_SLOTS * sizeof(int4));
+    short4* aux = dev_sig ? nullptr : (short4*) ctx->staging(1, (size_t) slot_cap * RING_SLOTS * sizeof(short4));
     if (!dev_sig && (!cols || !aux)) { ctx->err = "out of pinned host memory"; return -1; }
+    auto stage_of = [&](int i) -> int64_t {             // where problem i's records lie in the staging ring
+        const int g = grp_of[i];
+        return (int64_t) (g % RING_SLOTS) * slot_cap + (col_off[i] - col_off[grp_first[g]]);
+    };
     auto pack_one = [&](int i) {
         const SpdpProblemH& p = probs[i];
         memcpy(a_all.data() + a_off[i], p.a, p.a_len);
@@ -174,7 +193,7 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         const int N = p.b_len + 3;
         auto good = [&](int x) { return p.exin_left - 1 <= x && x < p.exin_right; };
         auto s16at = [&](const int16_t* v, int x) -> int { return (x >= 0 && x < N) ? v[x] : 0; };
-        const size_t c0 = (size_t) col_off[i];
+        const size_t c0 = (size_t) stage_of(i);
         for (int x = 0; x < N; ++x) {
             const int cp = (x - 2 >= 0 && good(x - 2)) ? p.sigE[x - 2] : 0;
             const int tron = (x - 2 >= 0 && x - 2 <= p.b_len) ? p.b[x - 2] : 0;
@@ -213,24 +232,18 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         int n_thr = spdp_host_cpus();
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
-        // the copy of a group of problems (~4 M positions) starts as soon as the group is packed, under the packing of the next ones
-        std::vector<int> grp_first, grp_of(n);
-        {
-            int64_t acc = 0;
-            for (int i = 0; i < n; ++i) {
-                if (i == 0 || acc >= (4 << 20)) { grp_first.push_back(i); acc = 0; }
-                grp_of[i] = (int) grp_first.size() - 1;
-                acc += col_len[i];
-            }
-        }
+        // the copy of a group of problems (~4 M positions) starts as soon as the group is packed, under the packing of the next ones;
+        // a packer that reaches a group whose slot still holds an earlier group waits for that group's copy
         const int n_grp = (int) grp_first.size();
         std::vector<std::atomic<int>> grp_done(std::max(1, n_grp));
         for (auto& g : grp_done) g.store(0);
         std::atomic<int> next_prob{0};
+        std::atomic<int> copied{0};                     // groups whose copy has left the staging (or: give up, INT_MAX)
         auto pack = [&]() {
             for (;;) {
                 const int i = next_prob.fetch_add(1);
                 if (i >= n) break;
+                if (!dev_sig) while (copied.load(std::memory_order_acquire) < grp_of[i] - RING_SLOTS + 1) std::this_thread::yield();
                 pack_one(i);
                 grp_done[grp_of[i]].fetch_add(1, std::memory_order_release);
             }
@@ -238,16 +251,26 @@ int HStore::upload(SpdpContext* c, const SpdpScoringH* scp, const SpdpProblemH* 
         std::vector<std::thread> th;
         for (int t = 0; t < n_thr; ++t) th.emplace_back(pack);
         hipError_t ce = hipSuccess;
+        std::vector<hipEvent_t> left((size_t) RING_SLOTS, nullptr);
+        for (int k = 0; k < RING_SLOTS && !dev_sig && ce == hipSuccess; ++k) ce = hipEventCreateWithFlags(&left[k], hipEventDisableTiming);
+        int synced = 0;                                 // groups known to have left
         for (int g = 0; g < n_grp && !dev_sig && ce == hipSuccess; ++g) {
             const int first = grp_first[g], last = g + 1 < n_grp ? grp_first[g + 1] : n;
             while (grp_done[g].load(std::memory_order_acquire) < last - first) std::this_thread::yield();
             const int64_t c0 = col_off[first], c1 = last < n ? col_off[last] : c_tot;
-            ce = hipMemcpyAsync((int4*) d_cols + c0, cols + c0, (size_t) (c1 - c0) * sizeof(int4), hipMemcpyHostToDevice, ctx->stream);
+            const int64_t s0 = (int64_t) (g % RING_SLOTS) * slot_cap;
+            ce = hipMemcpyAsync((int4*) d_cols + c0, cols + s0, (size_t) (c1 - c0) * sizeof(int4), hipMemcpyHostToDevice, ctx->stream);
             if (ce == hipSuccess)
-                ce = hipMemcpyAsync((short4*) d_aux + c0, aux + c0, (size_t) (c1 - c0) * sizeof(short4), hipMemcpyHostToDevice, ctx->stream);
+                ce = hipMemcpyAsync((short4*) d_aux + c0, aux + s0, (size_t) (c1 - c0) * sizeof(short4), hipMemcpyHostToDevice, ctx->stream);
+            if (ce == hipSuccess) ce = hipEventRecord(left[g % RING_SLOTS], ctx->stream);
+            // the packers may be two groups ahead of the copies: the group before this one has to have left before the next is issued
+            if (ce == hipSuccess && g >= 1) { ce = hipEventSynchronize(left[(g - 1) % RING_SLOTS]); synced = g; copied.store(g, std::memory_order_release); }
         }
+        (void) synced;
+        copied.store(INT32_MAX, std::memory_order_release);                  // (on an error too: no packer may wait for ever)
         for (std::thread& t : th) t.join();
-        if (ce != hipSuccess) (void) hipStreamSynchronize(ctx->stream);       // copies already issued still read the staging
+        if (!dev_sig) (void) hipStreamSynchronize(ctx->stream);              // the last copies still read the staging
+        for (int k = 0; k < RING_SLOTS; ++k) if (left[k]) (void) hipEventDestroy(left[k]);
         HIPCHK(ce);
     }
     scalar_ok = sc.intpen && sc.intpen_len > 0;

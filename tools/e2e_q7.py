@@ -173,7 +173,7 @@ def main_protein(args):
                           "identical_exon_tables": n_same, "different": len(diff), "reference_wall_s": round(ref_s, 2), "reference_threads": args.threads,
                           "index": {"built_by": "spdp_blk_index_build_p", "tables_identical_to_the_reference_file": bool(index_same),
                                     "build_and_write_s": round(build_s, 3), "device_s": round(bsec[0], 3), "host_s": round(bsec[1], 3)},
-                          "library_s": {"index_and_genome_load": round(load_s, 3), "map_align_call": round(lib_s, 3), "first_call": round(runs[0][0], 3),
+                          "library_s": {"index_and_genome_load": round(load_s, 3), "map_align_call": round(lib_s, 3), "first_call": round(runs[0][0], 3), "first_call_phases": [round(x, 3) for x in runs[0][1]],
                                         "find": round(phases[0], 3), "regions_and_signals": round(phases[1], 3), "align": round(phases[2], 3),
                                         "rescore": round(phases[3], 3)},
                           "library_queries_per_s": round(len(got) / (load_s + lib_s), 1), "library_over_reference": round(ref_s / (load_s + lib_s), 2),

@@ -308,25 +308,32 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
     } else {
         // column records (8 B per genomic position) and class bytes, packed by all host cores into pinned staging
         // memory the context keeps (a 10 k batch is ~1 GB: one thread and pageable memory took 430 ms, 40 % of a step)
-        const size_t nc = 2 * (size_t) std::max<int64_t>(col_tot, 1);
-        int32_t* hc = (int32_t*) ctx->staging(0, nc * sizeof(int32_t));
-        uint8_t* hx = has_exact ? (uint8_t*) ctx->staging(1, nc) : nullptr;
-        if (!hc || (has_exact && !hx)) { ctx->err = "out of pinned host memory"; return -1; }
         int n_thr = spdp_host_cpus();
         if (const char* e = getenv("SPDP_UPLOAD_THREADS")) n_thr = atoi(e);
         n_thr = std::max(1, std::min(std::min(n_thr, 32), n));
         std::vector<int> t_s5(n_thr, INT32_MIN), t_s3(n_thr, INT32_MIN);
-        // the copy of a group of problems (~8 M positions) starts as soon as the group is packed, under the packing of the next ones
+        // the copy of a group of problems (~8 M positions) starts as soon as the group is packed, under the packing of the next ones;
+        // the groups go through a ring of four slots of the staging memory (a slot is packed again once its copy has left): a map +
+        // align call holds 5 * 10^8 positions, which was 5 GB of pinned memory when every group had a place of its own
         std::vector<int> grp_first, grp_of(n);
+        int64_t slot_cap = 1;
         {
             int64_t acc = 0;
             for (int i = 0; i < n; ++i) {
                 if (i == 0 || acc >= (8 << 20)) { grp_first.push_back(i); acc = 0; }
                 grp_of[i] = (int) grp_first.size() - 1;
                 acc += (int64_t) probs[i].b_len + 1 + SPDP_COL_PAD;
+                slot_cap = std::max(slot_cap, acc);
             }
         }
         const int n_grp = (int) grp_first.size();
+        const int ring = (getenv("SPDP_UPLOAD_RING") && atoi(getenv("SPDP_UPLOAD_RING")) == 0) ? std::max(1, n_grp) : 4;     // (0: a place per group)
+        const size_t nc = 2 * (size_t) slot_cap * (size_t) ring;
+        int32_t* hc = (int32_t*) ctx->staging(0, nc * sizeof(int32_t));
+        uint8_t* hx = has_exact ? (uint8_t*) ctx->staging(1, nc) : nullptr;
+        if (!hc || (has_exact && !hx)) { ctx->err = "out of pinned host memory"; return -1; }
+        auto stage_of = [&](int i) -> int64_t { const int g = grp_of[i]; return (int64_t) (g % ring) * slot_cap + (col_off[i] - col_off[grp_first[g]]); };
+        std::atomic<int> copied{0};                     // groups whose copy has left the staging
         std::vector<std::atomic<int>> grp_done(n_grp);
         for (auto& g : grp_done) g.store(0);
         std::atomic<int> next_prob{0};
@@ -336,15 +343,16 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
                 const int i = next_prob.fetch_add(1);
                 if (i >= n) break;
                 const SpdpProblem& p = probs[i];
+                while (copied.load(std::memory_order_acquire) < grp_of[i] - ring + 1) std::this_thread::yield();
                 if (has_exact) {
-                    uint8_t* x = hx + 2 * col_off[i];
+                    uint8_t* x = hx + 2 * stage_of(i);
                     for (int nn = 0; nn <= p.b_len; ++nn, x += 2) {
                         x[0] = (p.cano5[nn] ? 1 : 0) | (p.cano3[nn] ? 2 : 0);
                         x[1] = p.dinc[nn];
                     }
                     memset(x, 0, 2 * SPDP_COL_PAD);
                 }
-                int32_t* cr = hc + 2 * col_off[i];
+                int32_t* cr = hc + 2 * stage_of(i);
                 for (int nn = 0; nn <= p.b_len; ++nn, cr += 2) {
                     const uint16_t s5 = (uint16_t) (int16_t) (p.sig5[nn] + sc.ipen);
                     const uint16_t s3 = (uint16_t) p.sig3[nn];
@@ -361,16 +369,25 @@ int DevStore::upload(SpdpContext* c, const SpdpScoring* scp, const SpdpProblem* 
             std::vector<std::thread> th;
             for (int t = 0; t < n_thr; ++t) th.emplace_back(pack, t);
             hipError_t ce = hipSuccess;
+            std::vector<hipEvent_t> left((size_t) ring, nullptr);
+            for (int k = 0; k < ring && ce == hipSuccess && n_grp > ring; ++k) ce = hipEventCreateWithFlags(&left[k], hipEventDisableTiming);
             for (int g = 0; g < n_grp && ce == hipSuccess; ++g) {
                 const int first = grp_first[g], last = g + 1 < n_grp ? grp_first[g + 1] : n;
                 while (grp_done[g].load(std::memory_order_acquire) < last - first) std::this_thread::yield();
                 const int64_t c0 = col_off[first], c1 = last < n ? col_off[last] : col_tot;
-                ce = hipMemcpyAsync((int32_t*) d_cols + 2 * c0, hc + 2 * c0, (size_t) (c1 - c0) * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+                const int64_t s0 = (int64_t) (g % ring) * slot_cap;
+                ce = hipMemcpyAsync((int32_t*) d_cols + 2 * c0, hc + 2 * s0, (size_t) (c1 - c0) * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
                 if (ce == hipSuccess && has_exact)
-                    ce = hipMemcpyAsync((uint8_t*) d_aux + 2 * c0, hx + 2 * c0, (size_t) (c1 - c0) * 2, hipMemcpyHostToDevice, ctx->stream);
+                    ce = hipMemcpyAsync((uint8_t*) d_aux + 2 * c0, hx + 2 * s0, (size_t) (c1 - c0) * 2, hipMemcpyHostToDevice, ctx->stream);
+                if (n_grp > ring) {                     // (a call of up to four groups never waits: every group has its slot)
+                    if (ce == hipSuccess) ce = hipEventRecord(left[g % ring], ctx->stream);
+                    if (ce == hipSuccess && g >= 1) { ce = hipEventSynchronize(left[(g - 1) % ring]); copied.store(g, std::memory_order_release); }
+                }
             }
+            copied.store(INT32_MAX, std::memory_order_release);               // (on an error too: no packer may wait for ever)
             for (std::thread& t : th) t.join();
             if (ce != hipSuccess) (void) hipStreamSynchronize(ctx->stream);   // copies already issued still read the staging
+            for (hipEvent_t e : left) if (e) (void) hipEventDestroy(e);
             HIPCHK(ce);
         }
         for (int t = 0; t < n_thr; ++t) { max_s5 = std::max(max_s5, t_s5[t]); max_s3 = std::max(max_s3, t_s3[t]); }
